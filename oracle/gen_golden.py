@@ -1,0 +1,94 @@
+"""oracle/gen_golden.py -- TEST INFRASTRUCTURE. Not part of the product path.
+
+Generates tests/golden/*.npz by running the REAL mcmcf90 reference (oracle/_ref/mcxref,
+compiled from /root/reference by oracle/Makefile; flang -O2 + MKL) on the pinned Philox
+stream.  Runs only in the dev container (the reference does not travel); the committed
+fixtures are data only: the inputs of each run and what MCMC_writechains
+(MCMC_aux.F90:17-85) wrote for it.
+
+    python oracle/gen_golden.py          # rewrites tests/golden/
+
+Each fixture holds: cfg_* (namelist values), problem arrays, and from the reference
+    runlen    int32  the repeat-count column of chain.mat  (= the accept-index sequence)
+    rows_head / rows_tail   first / last 16 accepted rows (theta)
+    ss_head / ss_tail       matching sschain values
+    s2_head / s2_tail       s2chain (if updatesigma)
+    chaincmat, chainmean    mcmccovf.dat / mcmcmean.dat
+    rng_n     number of uniforms the reference drew
+"""
+import os
+import sys
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import pyoracle as po, refrun as rr  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+XDATA = np.arange(11.0)
+YDATA = np.array([9.33, 9.40, 8.99, 7.06, 7.13, 6.69, 4.69, 4.24, 4.77, 3.86, 4.02])   # testcases/data.dat:2-12
+
+
+def corr_gauss(d, rho=0.5):
+    S = rho ** np.abs(np.subtract.outer(np.arange(d), np.arange(d)))
+    return np.linalg.inv(S)
+
+
+def cases():
+    """name -> (cfg kwargs, Problem kwargs, chain_id).  Mirrors BASELINE.json configs 1-4 at oracle-sized nsimu."""
+    c = {}
+    c["c1_expdata_dram"] = (dict(nsimu=10000, adaptint=100, burnintime=1000, doburnin=1, greedy=1, drscale=2.0,
+                                 updatesigma=1, N0=1.0, S02=0.0, scalelimit=0.3),
+                            dict(kind="expdata", npar=2, par0=[10, 0.1], cmat0=[[0.2, 0], [0, 0.001]], sigma2=0.5,
+                                 nobs=11, xdata=XDATA, ydata=YDATA, lo=[0, 0]), 0)
+    c["c1_shipped_nml"] = (dict(nsimu=1000, adaptint=200, burnintime=1000, doburnin=1, drscale=0.0,
+                                updatesigma=1, N0=1.0, S02=0.0),
+                           dict(kind="expdata", npar=2, par0=[10, 0.1], cmat0=[[0.2, 0], [0, 0.001]], sigma2=0.5,
+                                nobs=11, xdata=XDATA, ydata=YDATA, lo=[0, 0]), 0)
+    c["c1_priors_ap"] = (dict(nsimu=5000, adaptint=100, adapthist=300, updatesigma=1, drscale=3.0),
+                         dict(kind="expdata", npar=2, par0=[10, 0.1], cmat0=[[0.2, 0], [0, 0.001]], sigma2=0.5,
+                              nobs=11, xdata=XDATA, ydata=YDATA, lo=[0, 0], pri_mu=[9.0, 0.1], pri_sig=[2.0, 0.0]), 2)
+    d = 10
+    c["c2_gauss10_am"] = (dict(nsimu=3000, adaptint=100, updatesigma=0),
+                          dict(kind="gauss", npar=d, par0=np.zeros(d), cmat0=0.01 * np.eye(d), mu=np.zeros(d),
+                               lam=np.eye(d)), 0)
+    c["c2_gauss10_am_initcmatn"] = (dict(nsimu=3000, adaptint=100, updatesigma=0, initcmatn=50, adaptend=2000),
+                                    dict(kind="gauss", npar=d, par0=np.zeros(d), cmat0=0.01 * np.eye(d),
+                                         mu=np.zeros(d), lam=np.eye(d)), 5)
+    d = 20
+    c["c3_banana20_dram"] = (dict(nsimu=3000, adaptint=100, updatesigma=0, drscale=2.0),
+                             dict(kind="banana", npar=d, par0=np.zeros(d), cmat0=0.01 * np.eye(d), b=0.1), 3)
+    d = 50
+    c["c4_gauss50_ram"] = (dict(nsimu=3000, method="ram", updatesigma=0),
+                           dict(kind="gauss", npar=d, par0=np.zeros(d), cmat0=0.01 * np.eye(d), mu=np.zeros(d),
+                                lam=corr_gauss(d)), 7)
+    c["c4_gauss50_am"] = (dict(nsimu=2000, adaptint=100, updatesigma=0),
+                          dict(kind="gauss", npar=d, par0=np.zeros(d), cmat0=0.01 * np.eye(d), mu=np.zeros(d),
+                               lam=corr_gauss(d)), 11)
+    return c
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    for name, (ckw, pkw, chain_id) in cases().items():
+        cfg = po.make_cfg(**ckw)
+        prob = po.Problem(**pkw)
+        r = rr.run_reference(cfg, prob, chain_id=chain_id)
+        k = 16
+        out = {"chain_id": chain_id, "rng_n": r.rng_n, "chainind": r.chainind,
+               "runlen": r.chain[:, -1].astype(np.int32),
+               "rows_head": r.chain[:k, :-1], "rows_tail": r.chain[-k:, :-1],
+               "ss_head": r.sschain[:k, 0], "ss_tail": r.sschain[-k:, 0],
+               "chaincmat": r.chaincmat, "chainmean": r.chainmean}
+        if cfg.updatesigma:
+            out["s2_head"], out["s2_tail"] = r.s2chain[:k], r.s2chain[-k:]
+        for f, _ in po.Cfg._fields_:
+            out["cfg_" + f] = getattr(cfg, f)
+        for kk, v in pkw.items():
+            out["prob_" + kk] = np.asarray(v)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        print("%-28s chainind=%d rng_n=%d" % (name, r.chainind, r.rng_n))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,108 @@
+/*
+ * oracle/mcx_oracle.h -- TEST INFRASTRUCTURE. Not part of the product path.
+ *
+ * Plain-C restatement of the mcmcf90 sampling hot path (MCMC_run / MCMC_run_ram,
+ * MCMC_adapt, MCMC_DRAM step primitives, mcmcrand, covmat, LINPACK dchud/dchdd)
+ * for ONE chain, exactly as the Fortran reference runs it.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+ *
+ * Pinned against: the real reference compiled from /root/reference
+ * (oracle/Makefile -> oracle/_ref/) driven by the same Philox stream
+ * (oracle/ref/rng_interpose.c); fixtures in tests/golden/ (oracle/gen_golden.py).
+ */
+#ifndef MCX_ORACLE_H
+#define MCX_ORACLE_H
+#include <stdint.h>
+#include "mcx_rng.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MCXO_METHOD_DRAM = 0, MCXO_METHOD_RAM = 1, MCXO_METHOD_SCAM = 2, MCXO_METHOD_ER = 3 };
+enum { MCXO_TARGET_GAUSS = 0, MCXO_TARGET_BANANA = 1, MCXO_TARGET_EXPDATA = 2 };
+
+/* namelist /mcmc/ numeric control variables (mcmcinit.F90:74-82), defaults :184-230 */
+typedef struct mcxo_cfg {
+    int nsimu, doadapt, doburnin, adaptint, adapthist, badaptint, adaptend, initcmatn;
+    int burnintime, greedy, updatesigma, method;
+    double scalelimit, scalefactor, drscale, N0, S02, condmax, alphatarget, nuparam;
+    /* derived by mcxo_cfg_check (mcmcinit.F90:235-368) */
+    int dodr, doscam, usesvd;
+} mcxo_cfg;
+
+void mcxo_cfg_defaults(mcxo_cfg *c);
+int  mcxo_cfg_check(mcxo_cfg *c);   /* 0 ok, <0 = the reference would stop */
+
+/* Built-in targets: the "user" ssfunction / priorfun / checkbounds of the runs.
+ * The same definitions (same operation order) are compiled into the reference
+ * driver (oracle/ref/user_target.c) and into the HIP engine. */
+typedef struct mcxo_target {
+    int kind, npar;
+    const double *mu;      /* gauss: mean[npar] */
+    const double *lam;     /* gauss: precision, row-major lam[i*npar+j] */
+    double banana_b;       /* banana: twist */
+    int ndata;             /* expdata: y = th1*exp(-th2*x) */
+    const double *xdata, *ydata;
+    const double *lo, *hi;            /* box bounds, in-bounds iff lo<th<hi; NULL = none */
+    const double *pri_mu, *pri_sig;   /* default Gaussian priors, sig<=0 = flat; NULL = none */
+} mcxo_target;
+
+double mcxo_ssfun(const mcxo_target *t, const double *theta);
+double mcxo_priorfun(const mcxo_target *t, const double *theta);
+int    mcxo_checkbounds(const mcxo_target *t, const double *theta);
+
+/* One chain, all module-level state of mcmcmod (mcmc.F90:28-60) */
+typedef struct mcxo_chain {
+    mcxo_cfg cfg;
+    mcxo_target tgt;
+    mcxo_rng rng;
+    int npar;
+    double *par0, *cmat0;                 /* cmat0 col-major npar x npar */
+    double sigma2, S02; int nobs;         /* nycol = 1 */
+    double *R, *R2, *iC;                  /* col-major npar x npar, upper used */
+    double *chaincmat, *chainmean; double chainwsum;
+    double *chain;                        /* row-major [nsimu][npar+1], last col = repeat count */
+    double *sschain;                      /* [nsimu][2] */
+    double *s2chain;                      /* [nsimu] (row simuind-1) */
+    uint8_t *accepted;                    /* [nsimu], accepted[i-1] = 1 if iteration i moved */
+    double *alpha_trace;                  /* [nsimu] alpha12 of each iteration (diagnostic) */
+    int simuind, chainind;
+    int stayed, bndstayed, draccepted, drtries;
+    uint64_t nprop;                       /* proposals evaluated (stage 1 + stage 2) */
+    /* function-static state of MCMC_adapt (MCMC_adapt.F90:15,19) */
+    int ad_istart, ad_istartind, ad_lastind, ad_lastfreq;
+    int info_last;                        /* last info of calculate_R */
+    int ram_downdate_fail;                /* reference would STOP (matutils.F90:719-722) */
+    /* run state */
+    double *oldpar; double ss1, sspri1, alpha12;
+} mcxo_chain;
+
+mcxo_chain *mcxo_chain_create(const mcxo_cfg *cfg, const mcxo_target *tgt, const double *par0,
+                              const double *cmat0, double sigma2, int nobs,
+                              uint32_t seed, uint32_t chain_id);
+void mcxo_chain_free(mcxo_chain *c);
+/* MCMC_init tail + first row of MCMC_run*, then iterations 2..nsimu (or up to upto) */
+int mcxo_chain_run(mcxo_chain *c, int upto);
+
+/* numerics exposed for known-answer tests */
+double mcxo_normal(mcxo_rng *g);
+double mcxo_gamma(mcxo_rng *g, double a, double b);
+void mcxo_trmv_ut(int n, const double *R, double *x);          /* x <- R'x, R upper col-major */
+int  mcxo_potrf_u(int n, double *A);                            /* LAPACK dpotf2 'U' */
+int  mcxo_potri_u(int n, double *A);                            /* dtrti2 + dlauu2 'U' */
+void mcxo_rotg(double *da, double *db, double *c, double *s);
+double mcxo_nrm2(int n, const double *x);
+void mcxo_chud(int p, double *R, const double *x, double *c, double *s);
+int  mcxo_chdd(int p, double *R, const double *x, double *c, double *s);
+void mcxo_covmat(int n, int p, const double *x, int ldx, const double *w, int nw,
+                 double *cmat, double *xmean, double *wsum, int update);
+int  mcxo_calculate_R(mcxo_chain *c, double *cmat);
+double mcxo_log(double x);
+double mcxo_exp(double x);
+double mcxo_alpha(double ss1, double pri1, double ss2, double pri2, double sigma2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,70 @@
+/*
+ * oracle/mcx_targets.h -- TEST INFRASTRUCTURE. Not part of the product path.
+ *
+ * The "user" side of the runs: ssfunction (-2 log likelihood), the default
+ * Gaussian priorfun (priorfun.f90:96-100) and a box checkbounds.  These are
+ * user code in mcmcf90 (link-time callbacks, external_inc.h:4-33), so their
+ * arithmetic is ours to define; one definition is shared by the oracle and by
+ * the driver linked to the real reference (oracle/ref/user_target.c), and the HIP
+ * engine restates it on the device.
+ *
+ *   gauss   : testcases/mcmcrun4.F90:47 pattern, ss = (th-mu)' Lam (th-mu)
+ *   banana  : ss = th1^2/100 + (th2 + b th1^2 - 100 b)^2 + sum_{k>=3} th_k^2
+ *   expdata : testcases/mcmcrun.F90:89,104 pattern, ss = sum (y - th1 exp(-th2 x))^2
+ */
+#ifndef MCX_ORACLE_TARGETS_H
+#define MCX_ORACLE_TARGETS_H
+#include "mcx_math.h"
+
+static inline double mcxt_ss_gauss(int d, const double *th, const double *mu, const double *lam)
+{
+    /* y_i = sum_j lam(i,j) v_j (ascending j, fma chain); ss = sum_i y_i v_i (ascending i, fma chain) */
+    double ss = 0.0;
+    for (int i = 0; i < d; ++i) {
+        const double *row = lam + (long)i * d;
+        double y = row[0] * (th[0] - mu[0]);
+        for (int j = 1; j < d; ++j) y = fma(row[j], th[j] - mu[j], y);
+        double vi = th[i] - mu[i];
+        ss = (i == 0) ? y * vi : fma(y, vi, ss);
+    }
+    return ss;
+}
+
+static inline double mcxt_ss_banana(int d, const double *th, double b)
+{
+    double t1 = th[0] * th[0];
+    double q = fma(b, t1, th[1]) - 100.0 * b;
+    double ss = fma(q, q, t1 / 100.0);
+    for (int k = 2; k < d; ++k) ss = fma(th[k], th[k], ss);
+    return ss;
+}
+
+static inline double mcxt_ss_expdata(const double *th, int n, const double *x, const double *y)
+{
+    double ss = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double r = y[i] - th[0] * mcxm_exp(-(th[1] * x[i]));
+        ss = fma(r, r, ss);
+    }
+    return ss;
+}
+
+/* priorfun.f90:96-100: sum(((theta-mu)/sig)**2, mask=sig>0); library Fortran, no fma */
+static inline double mcxt_prior(int d, const double *th, const double *pmu, const double *psig)
+{
+    double p = 0.0;
+    if (!pmu || !psig) return 0.0;
+    for (int i = 0; i < d; ++i)
+        if (psig[i] > 0.0) { double t = (th[i] - pmu[i]) / psig[i]; p = p + t * t; }
+    return p;
+}
+
+static inline int mcxt_inbounds(int d, const double *th, const double *lo, const double *hi)
+{
+    for (int i = 0; i < d; ++i) {
+        if (lo && !(th[i] > lo[i])) return 0;
+        if (hi && !(th[i] < hi[i])) return 0;
+    }
+    return 1;
+}
+#endif

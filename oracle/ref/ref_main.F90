@@ -1,0 +1,46 @@
+!!! oracle/ref/ref_main.F90 -- TEST INFRASTRUCTURE. Not part of the product path.
+!!!
+!!! Driver program linked against the real mcmcf90 library built from
+!!! /root/reference (oracle/Makefile).  Same shape as the reference's own example
+!!! programs (testcases/mcmcrun.F90:48-52, mcmcrun4.F90:5-15): a main that calls
+!!! mcmc_main() plus the user callbacks ssfunction and checkbounds
+!!! (external_inc.h:12-33), which forward to oracle/ref/user_target.c.
+program mcxref
+  implicit none
+  call mcmc_main()
+end program mcxref
+
+function ssfunction(theta,npar,ny) result(ss)
+  use iso_c_binding
+  implicit none
+  integer(4) :: npar, ny
+  real(8) :: theta(npar)
+  real(8) :: ss(ny)
+  interface
+     function mcxref_ss(theta,npar) bind(C,name='mcxref_ss') result(v)
+       use iso_c_binding
+       real(c_double) :: theta(*)
+       integer(c_int), value :: npar
+       real(c_double) :: v
+     end function mcxref_ss
+  end interface
+  ss(1) = mcxref_ss(theta,npar)
+end function ssfunction
+
+function checkbounds(theta)
+  use iso_c_binding
+  implicit none
+  real(8) :: theta(:)
+  logical :: checkbounds
+  real(8) :: t(size(theta))
+  interface
+     function mcxref_inbounds(theta,npar) bind(C,name='mcxref_inbounds') result(v)
+       use iso_c_binding
+       real(c_double) :: theta(*)
+       integer(c_int), value :: npar
+       integer(c_int) :: v
+     end function mcxref_inbounds
+  end interface
+  t = theta
+  checkbounds = (mcxref_inbounds(t,size(t)) /= 0)
+end function checkbounds

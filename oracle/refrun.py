@@ -1,0 +1,136 @@
+"""oracle/refrun.py -- TEST INFRASTRUCTURE. Not part of the product path.
+
+Runs the REAL mcmcf90 reference (oracle/_ref/mcxref, built by oracle/Makefile from
+/root/reference) in a scratch directory on a Problem/config pair and parses what
+MCMC_writechains (MCMC_aux.F90:17-85) leaves behind.  The uniform stream is the
+pinned Philox stream (oracle/ref/rng_interpose.c), keyed by (seed, chain_id).
+"""
+import os
+import shutil
+import struct
+import subprocess
+import tempfile
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+EXE = os.path.join(_HERE, "_ref", "mcxref")
+METHOD_NAMES = {0: "dram", 1: "ram", 2: "scam", 3: "er"}
+TARGET_IDS = {"gauss": 0, "banana": 1, "expdata": 2}
+
+
+def available():
+    return os.path.exists(EXE)
+
+
+def read_mat4(path):
+    """MAT-v4 file written by matfiles.F90:66-126: 5 x int32 header, name, column-major doubles."""
+    with open(path, "rb") as f:
+        raw = f.read()
+    out, off = {}, 0
+    while off < len(raw):
+        mopt, mrows, ncols, imagf, namlen = struct.unpack_from("<5i", raw, off)
+        off += 20
+        name = raw[off:off + namlen].split(b"\0")[0].decode()
+        off += namlen
+        assert mopt == 0 and imagf == 0, (mopt, imagf)
+        a = np.frombuffer(raw, dtype="<f8", count=mrows * ncols, offset=off).reshape(ncols, mrows).T.copy()
+        off += 8 * mrows * ncols
+        out[name] = a
+    return out
+
+
+def _fdbl(v):
+    """Fortran double-precision literal with 17 significant digits."""
+    t = "%.17g" % float(v)
+    return t.replace("e", "d") if "e" in t else t + "d0"
+
+
+def _hex(v):
+    return " ".join(float(x).hex() for x in np.asarray(v, dtype=np.float64).ravel())
+
+
+def _dat(path, a):
+    a = np.atleast_2d(np.asarray(a, dtype=np.float64))
+    with open(path, "w") as f:
+        for row in a:
+            f.write(" ".join(repr(float(x)) for x in row) + "\n")
+
+
+def write_inputs(d, cfg, prob, extra_nml=""):
+    fields = ["nsimu", "doadapt", "doburnin", "adaptint", "adapthist", "badaptint", "adaptend", "initcmatn",
+              "burnintime", "greedy", "updatesigma"]
+    dfields = ["scalelimit", "scalefactor", "drscale", "N0", "S02", "condmax", "alphatarget", "nuparam"]
+    with open(os.path.join(d, "mcmcinit.nml"), "w") as f:
+        f.write("&mcmc\n")
+        f.write(" method = '%s'\n" % METHOD_NAMES[cfg.method])
+        for k in fields:
+            f.write(" %s = %d\n" % (k, getattr(cfg, k)))
+        for k in dfields:
+            f.write(" %s = %s\n" % (k, _fdbl(getattr(cfg, k))))
+        f.write(" verbosity = 0\n printint = 100000000\n")
+        f.write(" chainfile = 'chain.mat'\n ssfile = 'sschain.mat'\n s2file = 's2chain.mat'\n")
+        if prob.pri_mu is not None:
+            f.write(" priorsfile = 'priors.dat'\n")
+        f.write(extra_nml)
+        f.write("/\n")
+    _dat(os.path.join(d, "mcmcpar.dat"), prob.par0.reshape(1, -1))
+    _dat(os.path.join(d, "mcmccov.dat"), prob.cmat0)
+    _dat(os.path.join(d, "mcmcsigma2.dat"), np.array([[prob.sigma2], [float(prob.nobs)]]))
+    if prob.pri_mu is not None:
+        _dat(os.path.join(d, "priors.dat"), np.vstack([prob.pri_mu, prob.pri_sig]))
+    with open(os.path.join(d, "mcxtarget.txt"), "w") as f:
+        f.write("%d %d\n" % (TARGET_IDS[prob.kind], prob.npar))
+        if prob.kind == "gauss":
+            f.write(_hex(prob.mu) + "\n" + _hex(prob.lam) + "\n")
+        elif prob.kind == "banana":
+            f.write(_hex([prob.b]) + "\n")
+        else:
+            f.write("%d\n" % len(prob.xdata) + _hex(prob.xdata) + "\n" + _hex(prob.ydata) + "\n")
+        if prob.lo is not None or prob.hi is not None:
+            lo = prob.lo if prob.lo is not None else np.full(prob.npar, -np.inf)
+            hi = prob.hi if prob.hi is not None else np.full(prob.npar, np.inf)
+            f.write("%d\n" % prob.npar + _hex(lo) + "\n" + _hex(hi) + "\n")
+        else:
+            f.write("0\n")
+
+
+class RefResult:
+    pass
+
+
+def run_reference(cfg, prob, seed=0x6D636D63, chain_id=0, keep=False, timeout=600):
+    if not available():
+        raise RuntimeError("oracle/_ref/mcxref not built (make -C oracle ref)")
+    d = tempfile.mkdtemp(prefix="mcxref_")
+    try:
+        write_inputs(d, cfg, prob)
+        env = dict(os.environ, MCX_SEED=str(seed), MCX_CHAIN=str(chain_id), MKL_NUM_THREADS="1",
+                   MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1", MCX_RNG_LOG=os.path.join(d, "rng.log"))
+        p = subprocess.run([EXE], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+        r = RefResult()
+        r.stdout = p.stdout.decode(errors="replace")
+        r.returncode = p.returncode
+        if not os.path.exists(os.path.join(d, "chain.mat")):
+            raise RuntimeError("reference run produced no chain:\n" + r.stdout[-2000:])
+        r.chain = read_mat4(os.path.join(d, "chain.mat"))["chain"]
+        r.sschain = read_mat4(os.path.join(d, "sschain.mat"))["sschain"]
+        r.s2chain = read_mat4(os.path.join(d, "s2chain.mat"))["s2chain"][:, 0] if cfg.updatesigma else None
+        r.chaincmat = np.loadtxt(os.path.join(d, "mcmccovf.dat"), ndmin=2)
+        r.chainmean = np.loadtxt(os.path.join(d, "mcmcmean.dat"), ndmin=1)
+        r.rng_n = int(open(os.path.join(d, "rng.log")).read().split()[-1])
+        r.chainind = r.chain.shape[0]
+        return r
+    finally:
+        if keep:
+            print("kept", d)
+        else:
+            shutil.rmtree(d, ignore_errors=True)
+
+
+def accepted_from_chain(chain, nsimu):
+    """Expand the run-length column (MCMC_aux.F90:167-175) to the per-iteration accept flags."""
+    cnt = chain[:, -1].astype(np.int64)
+    acc = np.zeros(int(cnt.sum()), dtype=np.uint8)
+    acc[np.concatenate([[0], np.cumsum(cnt)[:-1]])] = 1
+    assert len(acc) == nsimu, (len(acc), nsimu)
+    return acc
