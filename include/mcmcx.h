@@ -1,0 +1,124 @@
+/*
+ * include/mcmcx.h -- C ABI of the MI355X-native adaptive-Metropolis engine (libmcmcx.so).
+ *
+ * This is the drop-in boundary for mcmcf90's sampling hot path.  A Fortran host
+ * (mcmcf90_amd/fortran/mcmcx_mod.F90: module mcmcmod + subroutine mcmc_main, same
+ * names as mcmc.F90:12 / mcmc_main.F90:12) binds these entry points through
+ * ISO_C_BINDING; tests and bench.py bind them through ctypes.  Plain pointers and
+ * sizes only, all host memory unless a name says "dev".  Every function returns
+ * 0 on success, <0 on a fatal error (the reference would `stop`: doerror,
+ * matutils.F90:764-789), >0 for a warning; mcmcx_last_error() returns the text.
+ *
+ * What each entry point replaces in the reference:
+ *
+ *   mcmcx_create            MCMC_init_namelist + check_mcmcinit_parameters   mcmcinit.F90:184-230, 235-368
+ *   mcmcx_set_par0          MCMC_setpar0_vec                                 MCMC_init.F90:168-183
+ *   mcmcx_set_cmat0         MCMC_setcmat0_mat                                MCMC_init.F90:201-218
+ *   mcmcx_set_sigma2nobs    MCMC_setsigma2nobs_vec                           MCMC_init.F90:295-323
+ *   mcmcx_set_target_*      the user's ssfunction (device-resident form)     external_inc.h:12-19
+ *   mcmcx_set_bounds        the user's checkbounds (box form)                external_inc.h:29-32
+ *   mcmcx_set_priors        default priorfun + priorsfile                    priorfun.f90:31-103
+ *   mcmcx_init              MCMC_init tail: first MCMC_calculate_R, counters MCMC_init.F90:81-160
+ *   mcmcx_run               MCMC_run / MCMC_run_ram loop, MCMC_adapt,        MCMC_run.F90:41-107,
+ *                           MCMC_adapt_ram, MCMC_savechain                   MCMC_run_ram.F90:45-81, MCMC_adapt.F90:12-174
+ *   mcmcx_get_chain         chain / sschain / s2chain module arrays          mcmc.F90:31-33, MCMC_aux.F90:167-185
+ *   mcmcx_get_chaincov      chaincmat / chainmean / chainwsum                mcmc.F90:38-40
+ *   mcmcx_get_counters      stayed, bndstayed, draccepted, drtries           mcmc.F90:46-55
+ *
+ * N independent chains run at once; chain c draws from the Philox4x32-10 stream
+ * keyed (seed, chain_id0 + c) and, in the default "replicas" mode, is the
+ * reference's single chain to the last bit of its accept/reject sequence.
+ */
+#ifndef MCMCX_H
+#define MCMCX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCMCX_METHOD_DRAM 0   /* method = 'dram' (AM / DRAM), mcmc_main.F90:35-36 */
+#define MCMCX_METHOD_RAM  1   /* method = 'ram',              mcmc_main.F90:33-34 */
+#define MCMCX_METHOD_SCAM 2   /* not yet on the device: mcmcx_create fails */
+#define MCMCX_METHOD_ER   3   /* not yet on the device: mcmcx_create fails */
+
+#define MCMCX_DEFAULT_SEED 0x6D636D63u
+
+/* Numeric members of namelist /mcmc/ (mcmcinit.F90:74-82) plus the multi-chain extensions. */
+typedef struct mcmcx_config {
+    int32_t npar;          /* d */
+    int32_t nchains;       /* N independent chains on this device */
+    int32_t method;
+    int32_t nsimu;
+    int32_t doadapt, doburnin, adaptint, adapthist, badaptint, adaptend, initcmatn;
+    int32_t burnintime, greedy, updatesigma;
+    double  scalelimit, scalefactor, drscale, N0, S02, condmax, alphatarget, nuparam;
+    uint32_t seed;         /* Philox key word 0 */
+    uint32_t chain_id0;    /* Philox key word 1 of chain 0 (rank offset when sharded) */
+    int32_t record_accept; /* keep the wavefront accept ballots of every iteration */
+    int32_t record_chain;  /* keep every accepted row (the reference's chain/sschain/s2chain) */
+    int32_t device;        /* HIP device ordinal */
+    int32_t reserved;
+} mcmcx_config;
+
+typedef struct mcmcx_engine *mcmcx_handle;
+
+void mcmcx_config_defaults(mcmcx_config *cfg);                 /* mcmcinit.F90:184-230 */
+int  mcmcx_create(const mcmcx_config *cfg, mcmcx_handle *out);
+int  mcmcx_destroy(mcmcx_handle h);
+const char *mcmcx_last_error(void);
+const char *mcmcx_version(void);
+
+int mcmcx_set_par0(mcmcx_handle h, const double *par0, int32_t npar);
+int mcmcx_set_cmat0(mcmcx_handle h, const double *cmat0_colmajor, int32_t npar);
+int mcmcx_set_sigma2nobs(mcmcx_handle h, const double *sigma2, const int32_t *nobs, int32_t nycol);
+int mcmcx_set_target_gauss(mcmcx_handle h, const double *mu, const double *lam_rowmajor);
+int mcmcx_set_target_banana(mcmcx_handle h, double b);
+int mcmcx_set_target_expdata(mcmcx_handle h, int32_t ndata, const double *x, const double *y);
+int mcmcx_set_bounds(mcmcx_handle h, const double *lo, const double *hi);       /* NULL = unbounded side */
+int mcmcx_set_priors(mcmcx_handle h, const double *mu, const double *sig);      /* sig <= 0: flat */
+int mcmcx_set_stream(mcmcx_handle h, void *hip_stream);
+
+int mcmcx_init(mcmcx_handle h);
+int mcmcx_run(mcmcx_handle h, int32_t upto);                   /* iterations simuind+1 .. upto */
+int mcmcx_sync(mcmcx_handle h);
+
+int32_t mcmcx_simuind(mcmcx_handle h);
+/* counters[0..7] = stayed, bndstayed, draccepted, drtries, chainind, status, 0, 0 of one chain */
+int mcmcx_get_counters(mcmcx_handle h, int32_t chain, int32_t *counters8);
+/* sums over all chains: stayed, bndstayed, draccepted, drtries, proposals (stage 1 + stage 2) */
+int mcmcx_get_totals(mcmcx_handle h, int64_t *totals5);
+int mcmcx_get_theta(mcmcx_handle h, double *theta_rowmajor /* [nchains][npar] */);
+/* per chain: ss1, sspri1, sigma2, alpha12 */
+int mcmcx_get_scalars(mcmcx_handle h, double *out /* [nchains][4] */);
+/* per chain: uniforms drawn, polar cache flag, cached deviate */
+int mcmcx_get_rng(mcmcx_handle h, int32_t chain, uint64_t *n, int32_t *saved, double *saved_y);
+int mcmcx_get_R(mcmcx_handle h, int32_t chain, double *R_colmajor);
+int mcmcx_get_chaincov(mcmcx_handle h, int32_t chain, double *cmat_colmajor, double *mean, double *wsum);
+/* accept flags of iterations 1..simuind for one chain (needs record_accept or record_chain) */
+int mcmcx_get_accepted(mcmcx_handle h, int32_t chain, uint8_t *accepted);
+/* raw wavefront ballots: masks[(it-1)*ntiles + tile], bit l = chain tile*64+l moved at iteration it */
+int mcmcx_get_accept_masks(mcmcx_handle h, uint64_t *masks, int32_t *ntiles);
+/* run-length compressed chain of one chain, like chain(1:chainind,:) / sschain / s2chain
+ * (needs record_chain).  chain: [nrows][npar+1] row-major; ss: [nrows][2]; s2: [simuind] */
+int mcmcx_get_chain(mcmcx_handle h, int32_t chain, double *chain_out, double *ss_out, double *s2_out,
+                    int32_t *nrows);
+/* pooled moments of the current states of all chains of this device (shifted by par0):
+ * out = [count, sum_j (th-par0)_j (npar), sum (th-par0)_j (th-par0)_k j<=k (npar(npar+1)/2)] */
+int mcmcx_pooled_moments(mcmcx_handle h, double *out);
+int32_t mcmcx_pooled_moments_len(mcmcx_handle h);
+
+/* device time of the step kernel over all launches since the last reset, measured with HIP
+ * events on the engine's stream; launches = number of step-kernel launches, steps = iterations */
+int mcmcx_kernel_time(mcmcx_handle h, double *ms, int64_t *launches, int64_t *steps, int reset);
+
+/* Test probes of the device primitives (no reference counterpart; used by tests/ only).
+ * op: 0 log, 1 exp, 2 sqrt, 3 a/b, 4 fma(a,b,a), 5 drotg digest.  kind: 0 uniform, 1 normal, 2 gamma(a,b). */
+int mcmcx_debug_math(int32_t op, int32_t n, const double *a, const double *b, double *out);
+int mcmcx_debug_rng(uint32_t seed, uint32_t chain_id, int32_t kind, int32_t n, double a, double b, double *out,
+                    uint64_t *nused);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

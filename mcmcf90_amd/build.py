@@ -1,0 +1,38 @@
+"""Build the HIP engine in-tree: mcmcf90_amd/libmcmcx.so (gfx950 only).
+
+    python -m mcmcf90_amd.build [--force]
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = [os.path.join(HERE, "csrc", f) for f in ("mcx_api.hip", "mcx_kernels.hpp", "mcx_device.hpp")]
+HDR = os.path.join(os.path.dirname(HERE), "include", "mcmcx.h")
+LIB = os.path.join(HERE, "libmcmcx.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -ffp-contract=off: the kernels spell out every fma themselves
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+         "-Wno-unused-value"]
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(s) > t for s in SRC + [HDR])
+
+
+def build(force=False, verbose=False):
+    if not force and not stale():
+        return LIB
+    cmd = [HIPCC] + FLAGS + ["-o", LIB, SRC[0]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    print(LIB)

@@ -1,0 +1,723 @@
+// mcx_api.hip -- host side of libmcmcx.so: the C ABI of include/mcmcx.h.
+//
+// Owns the device state of N chains, cuts the iteration range into launches of the
+// step kernel separated by the adaptation ticks of MCMC_adapt (MCMC_adapt.F90:40-46),
+// and decodes the device history back into the reference's chain/sschain/s2chain
+// form.  No CPU fallback: every numerical step of the sampler runs in the HIP kernels
+// of mcx_kernels.hpp; without a GPU every entry point that needs one fails.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include "../../include/mcmcx.h"
+#include "mcx_kernels.hpp"
+
+using namespace mcx;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIPCHK(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(-100, std::string(#call) + ": " + hipGetErrorString(e_));                 \
+    } while (0)
+
+struct mcmcx_engine {
+    mcmcx_config cfg;
+    int d = 0, P = 0, ntiles = 0, nlanes = 0;
+    int dodr = 0, usesvd = 0;
+    bool inited = false;
+    int simuind = 0;
+    // host copies of the problem
+    std::vector<double> par0, cmat0;                 // cmat0 col-major d*d
+    double sigma2 = 1.0; int nobs = 1; bool sigma2ok = false;
+    int tkind = -1; std::vector<double> tmu, tlam, tx, ty, tlo, thi, tpmu, tpsig; double tb = 0.1;
+    bool has_lo = false, has_hi = false, has_pri = false;
+    double S02eff = 0.0;
+    // device
+    hipStream_t stream = nullptr; bool own_stream = false;
+    EngineDev E{};
+    std::vector<void *> allocs;
+    double *d_ramscale = nullptr, *d_moments = nullptr;
+    int wcap = 0;
+    // timing of the step kernel
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double ms_total = 0.0; long long launches = 0, steps = 0;
+};
+
+template <typename T>
+static int dev_alloc(mcmcx_engine *h, T **p, size_t n, bool zero = true)
+{
+    void *q = nullptr;
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail(-101, "hipMalloc of " + std::to_string(bytes) + " bytes: " + hipGetErrorString(e));
+    if (zero) { e = hipMemsetAsync(q, 0, bytes, h->stream); if (e != hipSuccess) return fail(-101, hipGetErrorString(e)); }
+    h->allocs.push_back(q);
+    *p = (T *)q;
+    return 0;
+}
+
+template <typename T>
+static int dev_upload(mcmcx_engine *h, const T **p, const std::vector<T> &v)
+{
+    T *q = nullptr;
+    int rc = dev_alloc(h, &q, v.size(), false);
+    if (rc) return rc;
+    if (!v.empty()) {
+        hipError_t e = hipMemcpy(q, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail(-102, hipGetErrorString(e));
+    }
+    *p = q;
+    return 0;
+}
+
+// ------------------------------------------------------------------ kernel dispatch on the register-array size
+#define MCX_DISPATCH(h, CALL)                                                                     \
+    do {                                                                                          \
+        int d_ = (h)->d;                                                                          \
+        if (d_ <= 2) { CALL(2); } else if (d_ <= 4) { CALL(4); } else if (d_ <= 8) { CALL(8); }   \
+        else if (d_ <= 10) { CALL(10); } else if (d_ <= 16) { CALL(16); } else if (d_ <= 20) { CALL(20); } \
+        else if (d_ <= 32) { CALL(32); } else if (d_ <= 50) { CALL(50); } else { CALL(64); }      \
+    } while (0)
+static const int MCX_MAX_NPAR = 64;
+
+// dpotf2('U') + scaling on the host for the shared initial factor: same operation sequence as the
+// device's calculate_R (MCMC_calculate_R at MCMC_init.F90:109).  cm: col-major d*d, Rp: packed upper.
+static int host_initial_R(int d, const std::vector<double> &cm, std::vector<double> &Rp, std::vector<double> &Cp)
+{
+    int P = d * (d + 1) / 2;
+    std::vector<double> A(P);
+    for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) A[j * (j + 1) / 2 + i] = cm[(size_t)i + (size_t)j * d];
+    Cp = A;
+    for (int j = 0; j < d; ++j) {
+        double *colj = &A[j * (j + 1) / 2];
+        double dot = 0.0;
+        for (int i = 0; i < j; ++i) dot = std::fma(colj[i], colj[i], dot);
+        double ajj = colj[j] - dot;
+        if (!(ajj > 0.0)) return j + 1;
+        double rj = std::sqrt(ajj);
+        colj[j] = rj;
+        double rinv = 1.0 / rj;
+        for (int k = j + 1; k < d; ++k) {
+            double *colk = &A[k * (k + 1) / 2];
+            double t = 0.0;
+            for (int i = 0; i < j; ++i) t = std::fma(colk[i], colj[i], t);
+            colk[j] = (colk[j] - t) * rinv;
+        }
+    }
+    double sq = std::sqrt((double)d);
+    Rp.resize(P);
+    for (int e = 0; e < P; ++e) Rp[e] = A[e] * 2.4 / sq;
+    return 0;
+}
+
+template <int D> static void launch_init(mcmcx_engine *h)
+{ hipLaunchKernelGGL(init_kernel<D>, dim3(h->ntiles), dim3(64), 0, h->stream, h->E); }
+template <int D> static void launch_step(mcmcx_engine *h, int it0, int it1)
+{ hipLaunchKernelGGL(step_kernel<D>, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it0, it1, h->d_ramscale + it0); }
+template <int D> static void launch_adapt(mcmcx_engine *h, int it, int mode)
+{ hipLaunchKernelGGL(adapt_kernel<D>, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it, mode); }
+
+// Which branch of MCMC_adapt fires at iteration `it` (0 = none).  MCMC_adapt.F90:42-46, 60-61, 105.
+static int adapt_mode(const mcmcx_config &c, int it)
+{
+    if (c.method != MCMCX_METHOD_DRAM) return 0;
+    if (c.doadapt == 0 && c.doburnin == 0) return 0;
+    if (c.adaptend > 0 && it > c.adaptend) return 0;
+    bool m1 = (c.adaptint != 0) && (it % c.adaptint == 0);
+    bool m2 = (c.badaptint != 0) && (it % c.badaptint == 0);
+    if (!m1 && !m2) return 0;
+    if (it < c.burnintime && c.doburnin != 0 && m2) return AD_BURN;
+    if (it >= c.burnintime + c.adaptint + c.adapthist && c.doadapt != 0)
+        return AD_AM | ((it == c.burnintime + c.adaptint + c.adapthist) ? AD_FIRST : 0);
+    return 0;
+}
+
+// ------------------------------------------------------------------ getters
+template <typename T>
+static int fetch(mcmcx_engine *h, const T *dev, size_t n, std::vector<T> &out)
+{
+    out.resize(n);
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out.data(), dev, n * sizeof(T), hipMemcpyDeviceToHost));
+    return 0;
+}
+// gather element k of one chain from a tile-interleaved array
+template <typename T>
+static int fetch_chain_vec(mcmcx_engine *h, const T *dev, int K, int chain, std::vector<T> &out)
+{
+    int tile = chain / 64, lane = chain % 64;
+    std::vector<T> tmp;
+    int rc = fetch(h, dev + (size_t)tile * K * 64, (size_t)K * 64, tmp);
+    if (rc) return rc;
+    out.resize(K);
+    for (int k = 0; k < K; ++k) out[k] = tmp[(size_t)k * 64 + lane];
+    return 0;
+}
+static int check_chain(mcmcx_engine *h, int chain)
+{
+    if (!h) return fail(-1, "null handle");
+    if (!h->inited) return fail(-40, "we have not inited");
+    if (chain < 0 || chain >= h->cfg.nchains) return fail(-41, "chain index out of range");
+    return 0;
+}
+
+static void unpack_upper(int d, const std::vector<double> &p, double *colmajor, bool symmetric)
+{
+    for (int j = 0; j < d; ++j)
+        for (int i = 0; i < d; ++i) {
+            double v = 0.0;
+            if (i <= j) v = p[j * (j + 1) / 2 + i];
+            else if (symmetric) v = p[i * (i + 1) / 2 + j];
+            colmajor[(size_t)i + (size_t)j * d] = v;
+        }
+}
+
+// ------------------------------------------------------------------ C ABI
+extern "C" {
+
+const char *mcmcx_last_error(void) { return g_err.c_str(); }
+const char *mcmcx_version(void) { return "mcmcx 0.1 (gfx950)"; }
+
+void mcmcx_config_defaults(mcmcx_config *c)                      // mcmcinit.F90:184-230
+{
+    memset(c, 0, sizeof *c);
+    c->npar = 0; c->nchains = 1; c->method = MCMCX_METHOD_DRAM;
+    c->nsimu = 0; c->doadapt = 1; c->doburnin = 0; c->burnintime = 0; c->badaptint = -1;
+    c->greedy = 0; c->scalelimit = 0.05; c->scalefactor = 2.5; c->drscale = 0.0;
+    c->adaptint = 100; c->adapthist = 0; c->adaptend = 0; c->initcmatn = 0;
+    c->N0 = 1.0; c->S02 = 0.0; c->updatesigma = 1; c->condmax = 0.0;
+    c->alphatarget = 0.234; c->nuparam = 0.7;
+    c->seed = MCMCX_DEFAULT_SEED; c->chain_id0 = 0; c->record_accept = 0; c->record_chain = 0; c->device = 0;
+}
+
+int mcmcx_create(const mcmcx_config *cfg_in, mcmcx_handle *out)
+{
+    if (!cfg_in || !out) return fail(-1, "mcmcx_create: null argument");
+    mcmcx_config c = *cfg_in;
+    // check_mcmcinit_parameters, mcmcinit.F90:235-368
+    if (c.adapthist < 0) c.adapthist = 0;
+    if (c.adaptint < 0) { c.adaptint = 0; c.doadapt = 0; }
+    if (c.burnintime < 0) c.burnintime = 0;
+    if (c.badaptint <= 0) c.badaptint = c.adaptint;
+    if (c.badaptint == 0) c.doburnin = 0;
+    if (c.initcmatn < 0) c.initcmatn = 0;
+    if (c.scalelimit < 0.0 || c.scalelimit > 0.5)
+        return fail(-2, "ERROR: Scalelimit control variable should be between [0,0.5]");
+    if (c.scalefactor < 0.0) c.scalefactor = 1.0;
+    if (c.method == MCMCX_METHOD_SCAM || c.method == MCMCX_METHOD_ER)
+        return fail(-3, "method 'scam'/'er' is not available in the device engine yet");
+    if (c.method != MCMCX_METHOD_DRAM && c.method != MCMCX_METHOD_RAM) return fail(-3, "unknown method");
+    if (c.method == MCMCX_METHOD_RAM) c.drscale = 0.0;
+    if (c.nsimu < 1) return fail(-4, "nsimu <= 0 stopping");                         // mcmc_main.F90:22-25
+    if (c.npar < 1 || c.npar > MCX_MAX_NPAR) return fail(-5, "npar must be in 1.." + std::to_string(MCX_MAX_NPAR));
+    if (c.nchains < 1) return fail(-5, "nchains must be >= 1");
+    if (c.condmax > 0.0) return fail(-6, "condmax > 0 (SVD proposal) is not available in the device engine yet");
+    if (c.drscale > 0.0) return fail(-6, "drscale > 0 (delayed rejection) is not available in the device engine yet");
+    if (c.doadapt && c.method == MCMCX_METHOD_DRAM) {
+        if (c.adaptint == 0) return fail(-7, "doadapt with adaptint = 0");
+        if (c.adapthist > 1) return fail(-6, "adapthist > 1 (AP window) is not available in the device engine yet");
+        if (c.greedy != 0 && c.doburnin != 0) return fail(-6, "greedy burn-in adaptation is not available in the device engine yet");
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1) return fail(-10, "no HIP device: the mcmcx engine has no CPU fallback");
+    if (c.device < 0 || c.device >= ndev) return fail(-10, "bad device ordinal");
+    HIPCHK(hipSetDevice(c.device));
+    mcmcx_engine *h = new mcmcx_engine();
+    h->cfg = c; h->d = c.npar; h->P = c.npar * (c.npar + 1) / 2;
+    h->ntiles = (c.nchains + 63) / 64; h->nlanes = h->ntiles * 64;
+    h->dodr = 0; h->usesvd = 0;
+    e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; return fail(-100, hipGetErrorString(e)); }
+    h->own_stream = true;
+    *out = h;
+    return 0;
+}
+
+int mcmcx_destroy(mcmcx_handle h)
+{
+    if (!h) return 0;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto &p : h->pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (void *p : h->allocs) (void)hipFree(p);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+int mcmcx_set_stream(mcmcx_handle h, void *s)
+{
+    if (!h) return fail(-1, "null handle");
+    if (h->inited) return fail(-1, "mcmcx_set_stream after mcmcx_init");
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    h->stream = (hipStream_t)s; h->own_stream = false;
+    return 0;
+}
+
+int mcmcx_set_par0(mcmcx_handle h, const double *p, int32_t n)
+{
+    if (!h || !p) return fail(-1, "null argument");
+    if (n != h->d) return fail(-20, "par0 and npar dont match");                     // MCMC_init.F90:173
+    h->par0.assign(p, p + n);
+    return 0;
+}
+int mcmcx_set_cmat0(mcmcx_handle h, const double *c, int32_t n)
+{
+    if (!h || !c) return fail(-1, "null argument");
+    if (n != h->d) return fail(-20, "cmat0 and npar dont match");                    // MCMC_init.F90:207
+    h->cmat0.assign(c, c + (size_t)n * n);
+    return 0;
+}
+int mcmcx_set_sigma2nobs(mcmcx_handle h, const double *s2, const int32_t *nobs, int32_t nycol)
+{
+    if (!h || !s2 || !nobs) return fail(-1, "null argument");
+    if (nycol != 1) return fail(-21, "the device engine supports nycol = 1 only");
+    h->sigma2 = s2[0]; h->nobs = nobs[0]; h->sigma2ok = true;
+    return 0;
+}
+int mcmcx_set_target_gauss(mcmcx_handle h, const double *mu, const double *lam)
+{
+    if (!h || !mu || !lam) return fail(-1, "null argument");
+    h->tkind = TGT_GAUSS; h->tmu.assign(mu, mu + h->d); h->tlam.assign(lam, lam + (size_t)h->d * h->d);
+    return 0;
+}
+int mcmcx_set_target_banana(mcmcx_handle h, double b)
+{
+    if (!h) return fail(-1, "null handle");
+    if (h->d < 2) return fail(-22, "banana target needs npar >= 2");
+    h->tkind = TGT_BANANA; h->tb = b;
+    return 0;
+}
+int mcmcx_set_target_expdata(mcmcx_handle h, int32_t n, const double *x, const double *y)
+{
+    if (!h || !x || !y || n < 1) return fail(-1, "bad argument");
+    if (h->d != 2) return fail(-22, "expdata target needs npar = 2");
+    h->tkind = TGT_EXPDATA; h->tx.assign(x, x + n); h->ty.assign(y, y + n);
+    return 0;
+}
+int mcmcx_set_bounds(mcmcx_handle h, const double *lo, const double *hi)
+{
+    if (!h) return fail(-1, "null handle");
+    h->has_lo = lo != nullptr; h->has_hi = hi != nullptr;
+    if (lo) h->tlo.assign(lo, lo + h->d);
+    if (hi) h->thi.assign(hi, hi + h->d);
+    return 0;
+}
+int mcmcx_set_priors(mcmcx_handle h, const double *mu, const double *sig)
+{
+    if (!h || !mu || !sig) return fail(-1, "null argument");
+    h->has_pri = true; h->tpmu.assign(mu, mu + h->d); h->tpsig.assign(sig, sig + h->d);
+    return 0;
+}
+
+int mcmcx_init(mcmcx_handle h)
+{
+    if (!h) return fail(-1, "null handle");
+    if (h->inited) return fail(1, "Warning(mcmcinit): allready inited");            // MCMC_init.F90:24-27
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const mcmcx_config &c = h->cfg;
+    const int d = h->d, P = h->P, T = h->ntiles;
+    if ((int)h->par0.size() != d) return fail(-30, "user initialization error: par0 not set");
+    if (h->cmat0.empty()) {                                                           // MCMC_initcmat0: identity
+        h->cmat0.assign((size_t)d * d, 0.0);
+        for (int i = 0; i < d; ++i) h->cmat0[(size_t)i * d + i] = 1.0;
+    }
+    if (!h->sigma2ok) { h->sigma2 = 1.0; h->nobs = 1; }                               // MCMC_init.F90:52-59
+    if (h->tkind < 0) return fail(-31, "no target: the device engine needs mcmcx_set_target_*");
+    std::vector<double> Rp, Cp;
+    int info = host_initial_R(d, h->cmat0, Rp, Cp);
+    if (info != 0) return fail(-32, "could not factor the initial covariance");      // MCMC_init.F90:110
+    h->S02eff = (c.S02 <= 0.0) ? h->sigma2 : c.S02;                                   // MCMC_init.F90:114-116
+    double shape = c.N0 / 2.0 + (double)h->nobs / 2.0;
+    if (c.updatesigma && shape < 1.0) return fail(-33, "updatesigma with gamma shape < 1 is not available in the device engine");
+
+    EngineDev &E = h->E;
+    E.d = d; E.P = P; E.ntiles = T;
+    E.method = (c.method == MCMCX_METHOD_RAM) ? M_RAM : M_DRAM;
+    E.dodr = 0; E.updatesigma = c.updatesigma; E.doadapt = c.doadapt; E.doburnin = c.doburnin; E.burnintime = c.burnintime;
+    E.gam_shape = shape; E.N0S02 = c.N0 * h->S02eff;
+    E.alphatarget = c.alphatarget; E.drscale = c.drscale; E.scalelimit = c.scalelimit; E.scalefactor = c.scalefactor;
+    E.k0 = c.seed; E.chain_id0 = c.chain_id0;
+    // target
+    E.tgt.kind = h->tkind; E.tgt.b = h->tb; E.tgt.ndata = (int)h->tx.size();
+    E.tgt.mu = E.tgt.lam = E.tgt.x = E.tgt.y = E.tgt.lo = E.tgt.hi = E.tgt.pmu = E.tgt.psig = nullptr;
+    int rc;
+    if (h->tkind == TGT_GAUSS) { if ((rc = dev_upload(h, &E.tgt.mu, h->tmu))) return rc; if ((rc = dev_upload(h, &E.tgt.lam, h->tlam))) return rc; }
+    if (h->tkind == TGT_EXPDATA) { if ((rc = dev_upload(h, &E.tgt.x, h->tx))) return rc; if ((rc = dev_upload(h, &E.tgt.y, h->ty))) return rc; }
+    if (h->has_lo && (rc = dev_upload(h, &E.tgt.lo, h->tlo))) return rc;
+    if (h->has_hi && (rc = dev_upload(h, &E.tgt.hi, h->thi))) return rc;
+    if (h->has_pri) { if ((rc = dev_upload(h, &E.tgt.pmu, h->tpmu))) return rc; if ((rc = dev_upload(h, &E.tgt.psig, h->tpsig))) return rc; }
+    if ((rc = dev_upload(h, &E.par0, h->par0))) return rc;
+    if ((rc = dev_upload(h, &E.cmat0p, Cp))) return rc;
+
+    // state
+    const size_t L = (size_t)T * 64;
+    if ((rc = dev_alloc(h, &E.theta, L * d))) return rc;
+    if ((rc = dev_alloc(h, &E.cand, L * d))) return rc;
+    if ((rc = dev_alloc(h, &E.scal, L * NSCAL))) return rc;
+    if ((rc = dev_alloc(h, &E.ictr, L * NICTR))) return rc;
+    if ((rc = dev_alloc(h, &E.rngn, L))) return rc;
+    if ((rc = dev_alloc(h, &E.R, L * P, false))) return rc;
+    if ((rc = dev_alloc(h, &E.basetheta, L * d))) return rc;
+    E.R2 = E.iC = nullptr;
+    const bool am = (E.method == M_DRAM) && (c.doadapt != 0 || c.doburnin != 0);
+    E.cmat = E.mean = E.Rtmp = nullptr; E.rowlist = nullptr;
+    // history ring
+    const bool need_hist = am || c.record_chain;
+    h->wcap = 0; E.hist = E.s2hist = nullptr; E.wacc = nullptr; E.record_s2 = 0;
+    if (need_hist) {
+        long long wc = c.record_chain ? (long long)c.nsimu + 1
+                                      : (long long)c.burnintime + c.adaptint + c.adapthist + 2;
+        if (wc > (long long)c.nsimu + 1) wc = (long long)c.nsimu + 1;
+        h->wcap = (int)wc;
+        if ((rc = dev_alloc(h, &E.hist, L * (size_t)h->wcap * (d + 1), false))) return rc;
+        if ((rc = dev_alloc(h, &E.wacc, (size_t)T * h->wcap))) return rc;
+        if (c.record_chain && c.updatesigma) { E.record_s2 = 1; if ((rc = dev_alloc(h, &E.s2hist, L * (size_t)h->wcap))) return rc; }
+    }
+    E.wcap = h->wcap > 0 ? h->wcap : 1;
+    if (am) {
+        if ((rc = dev_alloc(h, &E.cmat, L * P))) return rc;
+        if ((rc = dev_alloc(h, &E.mean, L * d))) return rc;
+        if ((rc = dev_alloc(h, &E.Rtmp, L * P))) return rc;
+        if ((rc = dev_alloc(h, &E.rowlist, L * (size_t)(h->wcap + 1)))) return rc;
+    }
+    E.accmask = nullptr;
+    if (c.record_accept && (rc = dev_alloc(h, &E.accmask, (size_t)c.nsimu * T))) return rc;
+    // 1/simuind**nuparam, computed like the reference: real(simuind) is default REAL (MCMC_run_ram.F90:166)
+    {
+        std::vector<double> rs((size_t)c.nsimu + 2, 0.0);
+        for (int it = 1; it <= c.nsimu; ++it) rs[it] = 1.0 / std::pow((double)(float)it, c.nuparam);
+        const double *p = nullptr;
+        if ((rc = dev_upload(h, &p, rs))) return rc;
+        h->d_ramscale = const_cast<double *>(p);
+    }
+    if ((rc = dev_alloc(h, &h->d_moments, (size_t)T * (1 + d + P)))) return rc;
+
+    // fill theta = par0, R = R(cmat0), chaincmat = cmat0, chainmean = par0, scalars
+    {
+        std::vector<double> th(L * d), Rv(L * P), sc(L * NSCAL, 0.0);
+        std::vector<uint32_t> ic(L * NICTR, 0u);
+        for (int t = 0; t < T; ++t) {
+            for (int k = 0; k < d; ++k) for (int l = 0; l < 64; ++l) th[((size_t)t * d + k) * 64 + l] = h->par0[k];
+            for (int e = 0; e < P; ++e) for (int l = 0; l < 64; ++l) Rv[((size_t)t * P + e) * 64 + l] = Rp[e];
+            for (int l = 0; l < 64; ++l) {
+                sc[((size_t)t * NSCAL + S_SIGMA2) * 64 + l] = h->sigma2;
+                sc[((size_t)t * NSCAL + S_WSUM) * 64 + l] = (double)c.initcmatn;
+                ic[((size_t)t * NICTR + I_CHAININD) * 64 + l] = 1;
+                ic[((size_t)t * NICTR + I_CURCOUNT) * 64 + l] = 1;
+                ic[((size_t)t * NICTR + I_BASECNT) * 64 + l] = 1;
+                ic[((size_t)t * NICTR + I_WINSTART) * 64 + l] = 2;
+            }
+        }
+        HIPCHK(hipMemcpyAsync(E.theta, th.data(), th.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(E.R, Rv.data(), Rv.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(E.scal, sc.data(), sc.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(E.ictr, ic.data(), ic.size() * 4, hipMemcpyHostToDevice, h->stream));
+        if (am) {
+            std::vector<double> cv(L * P), mv(L * d);
+            for (int t = 0; t < T; ++t) {
+                for (int e = 0; e < P; ++e) for (int l = 0; l < 64; ++l) cv[((size_t)t * P + e) * 64 + l] = Cp[e];
+                for (int k = 0; k < d; ++k) for (int l = 0; l < 64; ++l) mv[((size_t)t * d + k) * 64 + l] = h->par0[k];
+            }
+            HIPCHK(hipMemcpyAsync(E.cmat, cv.data(), cv.size() * 8, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(E.mean, mv.data(), mv.size() * 8, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+#define CALL_INIT(DD) launch_init<DD>(h)
+    MCX_DISPATCH(h, CALL_INIT);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->simuind = 1;
+    h->inited = true;
+    return 0;
+}
+
+int mcmcx_run(mcmcx_handle h, int32_t upto)
+{
+    if (!h) return fail(-1, "null handle");
+    if (!h->inited) return fail(-40, "we have not inited");                           // MCMC_run.F90:22
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const mcmcx_config &c = h->cfg;
+    if (upto > c.nsimu) upto = c.nsimu;
+    const int maxseg = (c.method == MCMCX_METHOD_RAM) ? 4096 : 1 << 30;
+    int it = h->simuind + 1;
+    while (it <= upto) {
+        int end = it, mode = 0;
+        for (;; ++end) {                                    // extend the launch up to the next tick
+            mode = adapt_mode(c, end);
+            if (mode != 0 || end == upto || end - it + 1 >= maxseg) break;
+        }
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, h->stream));
+#define CALL_STEP(DD) launch_step<DD>(h, it, end)
+        MCX_DISPATCH(h, CALL_STEP);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(e1, h->stream));
+        h->pending.emplace_back(e0, e1);
+        h->launches += 1; h->steps += (end - it + 1);
+        if (mode != 0) {
+#define CALL_ADAPT(DD) launch_adapt<DD>(h, end, mode)
+            MCX_DISPATCH(h, CALL_ADAPT);
+            HIPCHK(hipGetLastError());
+        }
+        it = end + 1;
+        if (h->pending.size() > 4096) { int rc = mcmcx_sync(h); if (rc) return rc; }
+    }
+    h->simuind = std::max(h->simuind, (int)upto);
+    return 0;
+}
+
+int mcmcx_sync(mcmcx_handle h)
+{
+    if (!h) return fail(-1, "null handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (auto &p : h->pending) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));
+        h->ms_total += ms;
+        (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second);
+    }
+    h->pending.clear();
+    return 0;
+}
+
+int mcmcx_kernel_time(mcmcx_handle h, double *ms, int64_t *launches, int64_t *steps, int reset)
+{
+    int rc = mcmcx_sync(h);
+    if (rc) return rc;
+    if (ms) *ms = h->ms_total;
+    if (launches) *launches = h->launches;
+    if (steps) *steps = h->steps;
+    if (reset) { h->ms_total = 0.0; h->launches = 0; h->steps = 0; }
+    return 0;
+}
+
+int32_t mcmcx_simuind(mcmcx_handle h) { return h ? h->simuind : -1; }
+
+int mcmcx_get_counters(mcmcx_handle h, int32_t chain, int32_t *out)
+{
+    int rc = check_chain(h, chain); if (rc) return rc;
+    std::vector<uint32_t> v;
+    if ((rc = fetch_chain_vec(h, h->E.ictr, NICTR, chain, v))) return rc;
+    out[0] = (int32_t)v[I_STAYED]; out[1] = (int32_t)v[I_BNDSTAYED]; out[2] = (int32_t)v[I_DRACC]; out[3] = (int32_t)v[I_DRTRIES];
+    out[4] = (int32_t)v[I_CHAININD]; out[5] = (int32_t)v[I_STATUS]; out[6] = (int32_t)v[I_INFO]; out[7] = (int32_t)v[I_CURCOUNT];
+    return 0;
+}
+
+int mcmcx_get_totals(mcmcx_handle h, int64_t *t5)
+{
+    if (!h || !h->inited) return fail(-40, "we have not inited");
+    std::vector<uint32_t> v;
+    int rc = fetch(h, h->E.ictr, (size_t)h->nlanes * NICTR, v); if (rc) return rc;
+    for (int i = 0; i < 5; ++i) t5[i] = 0;
+    for (int c = 0; c < h->cfg.nchains; ++c) {
+        int t = c / 64, l = c % 64;
+        auto at = [&](int k) { return (int64_t)v[((size_t)t * NICTR + k) * 64 + l]; };
+        t5[0] += at(I_STAYED); t5[1] += at(I_BNDSTAYED); t5[2] += at(I_DRACC); t5[3] += at(I_DRTRIES);
+    }
+    t5[4] = (int64_t)h->cfg.nchains * (int64_t)(h->simuind - 1) + t5[3];
+    return 0;
+}
+
+int mcmcx_get_theta(mcmcx_handle h, double *out)
+{
+    if (!h || !h->inited) return fail(-40, "we have not inited");
+    std::vector<double> v;
+    int rc = fetch(h, h->E.theta, (size_t)h->nlanes * h->d, v); if (rc) return rc;
+    for (int c = 0; c < h->cfg.nchains; ++c)
+        for (int k = 0; k < h->d; ++k) out[(size_t)c * h->d + k] = v[((size_t)(c / 64) * h->d + k) * 64 + (c % 64)];
+    return 0;
+}
+
+int mcmcx_get_scalars(mcmcx_handle h, double *out)
+{
+    if (!h || !h->inited) return fail(-40, "we have not inited");
+    std::vector<double> v;
+    int rc = fetch(h, h->E.scal, (size_t)h->nlanes * NSCAL, v); if (rc) return rc;
+    const int idx[4] = {S_SS1, S_PRI1, S_SIGMA2, S_ALPHA12};
+    for (int c = 0; c < h->cfg.nchains; ++c)
+        for (int k = 0; k < 4; ++k) out[(size_t)c * 4 + k] = v[((size_t)(c / 64) * NSCAL + idx[k]) * 64 + (c % 64)];
+    return 0;
+}
+
+int mcmcx_get_rng(mcmcx_handle h, int32_t chain, uint64_t *n, int32_t *saved, double *saved_y)
+{
+    int rc = check_chain(h, chain); if (rc) return rc;
+    std::vector<uint64_t> vn; std::vector<uint32_t> vi; std::vector<double> vs;
+    if ((rc = fetch_chain_vec(h, h->E.rngn, 1, chain, vn))) return rc;
+    if ((rc = fetch_chain_vec(h, h->E.ictr, NICTR, chain, vi))) return rc;
+    if ((rc = fetch_chain_vec(h, h->E.scal, NSCAL, chain, vs))) return rc;
+    if (n) *n = vn[0];
+    if (saved) *saved = (int32_t)vi[I_SAVED];
+    if (saved_y) *saved_y = vs[S_SAVEDY];
+    return 0;
+}
+
+int mcmcx_get_R(mcmcx_handle h, int32_t chain, double *R)
+{
+    int rc = check_chain(h, chain); if (rc) return rc;
+    std::vector<double> p;
+    if ((rc = fetch_chain_vec(h, h->E.R, h->P, chain, p))) return rc;
+    unpack_upper(h->d, p, R, false);
+    return 0;
+}
+
+int mcmcx_get_chaincov(mcmcx_handle h, int32_t chain, double *cmat, double *mean, double *wsum)
+{
+    int rc = check_chain(h, chain); if (rc) return rc;
+    std::vector<double> s;
+    if ((rc = fetch_chain_vec(h, h->E.scal, NSCAL, chain, s))) return rc;
+    if (wsum) *wsum = s[S_WSUM];
+    if (!h->E.cmat) {                                   // no AM state on the device: chaincmat = cmat0, chainmean = par0
+        if (cmat) memcpy(cmat, h->cmat0.data(), sizeof(double) * (size_t)h->d * h->d);
+        if (mean) memcpy(mean, h->par0.data(), sizeof(double) * (size_t)h->d);
+        return 0;
+    }
+    std::vector<double> p, m;
+    if ((rc = fetch_chain_vec(h, h->E.cmat, h->P, chain, p))) return rc;
+    if ((rc = fetch_chain_vec(h, h->E.mean, h->d, chain, m))) return rc;
+    if (cmat) unpack_upper(h->d, p, cmat, true);
+    if (mean) memcpy(mean, m.data(), sizeof(double) * (size_t)h->d);
+    return 0;
+}
+
+int mcmcx_get_accept_masks(mcmcx_handle h, uint64_t *masks, int32_t *ntiles)
+{
+    if (!h || !h->inited) return fail(-40, "we have not inited");
+    if (ntiles) *ntiles = h->ntiles;
+    if (!h->E.accmask) return fail(-42, "record_accept was not requested");
+    if (!masks) return 0;
+    std::vector<uint64_t> v;
+    int rc = fetch(h, h->E.accmask, (size_t)h->simuind * h->ntiles, v); if (rc) return rc;
+    memcpy(masks, v.data(), v.size() * 8);
+    return 0;
+}
+
+int mcmcx_get_accepted(mcmcx_handle h, int32_t chain, uint8_t *acc)
+{
+    int rc = check_chain(h, chain); if (rc) return rc;
+    const int tile = chain / 64, lane = chain % 64;
+    if (h->E.accmask) {
+        std::vector<uint64_t> v;
+        if ((rc = fetch(h, h->E.accmask, (size_t)h->simuind * h->ntiles, v))) return rc;
+        for (int it = 1; it <= h->simuind; ++it) acc[it - 1] = (uint8_t)((v[(size_t)(it - 1) * h->ntiles + tile] >> lane) & 1ull);
+        return 0;
+    }
+    if (h->cfg.record_chain && h->E.wacc) {
+        std::vector<uint64_t> v;
+        if ((rc = fetch(h, h->E.wacc + (size_t)tile * h->wcap, (size_t)h->wcap, v))) return rc;
+        for (int it = 1; it <= h->simuind; ++it) acc[it - 1] = (uint8_t)((v[it % h->wcap] >> lane) & 1ull);
+        return 0;
+    }
+    return fail(-42, "record_accept / record_chain was not requested");
+}
+
+int mcmcx_get_chain(mcmcx_handle h, int32_t chain, double *chain_out, double *ss_out, double *s2_out, int32_t *nrows)
+{
+    int rc = check_chain(h, chain); if (rc) return rc;
+    if (!h->cfg.record_chain || !h->E.hist) return fail(-42, "record_chain was not requested");
+    const int tile = chain / 64, lane = chain % 64, d = h->d, W = h->wcap;
+    std::vector<uint64_t> m;
+    if ((rc = fetch(h, h->E.wacc + (size_t)tile * W, (size_t)W, m))) return rc;
+    std::vector<double> hv;
+    if ((rc = fetch(h, h->E.hist + (size_t)tile * W * (d + 1) * 64, (size_t)W * (d + 1) * 64, hv))) return rc;
+    int row = -1;
+    for (int it = 1; it <= h->simuind; ++it) {
+        if ((m[it] >> lane) & 1ull) {
+            ++row;
+            if (chain_out) {
+                for (int k = 0; k < d; ++k) chain_out[(size_t)row * (d + 1) + k] = hv[((size_t)it * (d + 1) + k) * 64 + lane];
+                chain_out[(size_t)row * (d + 1) + d] = 1.0;
+            }
+            if (ss_out) { ss_out[(size_t)row * 2] = hv[((size_t)it * (d + 1) + d) * 64 + lane]; ss_out[(size_t)row * 2 + 1] = 1.0; }
+        } else {
+            if (chain_out) chain_out[(size_t)row * (d + 1) + d] += 1.0;
+            if (ss_out) ss_out[(size_t)row * 2 + 1] += 1.0;
+        }
+    }
+    if (nrows) *nrows = row + 1;
+    if (s2_out && h->E.s2hist) {
+        std::vector<double> sv;
+        if ((rc = fetch(h, h->E.s2hist + (size_t)tile * W * 64, (size_t)W * 64, sv))) return rc;
+        for (int it = 1; it <= h->simuind; ++it) s2_out[it - 1] = sv[(size_t)it * 64 + lane];
+    }
+    return 0;
+}
+
+int32_t mcmcx_pooled_moments_len(mcmcx_handle h) { return h ? 1 + h->d + h->P : -1; }
+
+int mcmcx_pooled_moments(mcmcx_handle h, double *out)
+{
+    if (!h || !h->inited) return fail(-40, "we have not inited");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int len = 1 + h->d + h->P, T = h->ntiles;
+    hipLaunchKernelGGL(moments_kernel, dim3(T), dim3(64), 0, h->stream, h->E, h->d_moments, h->cfg.nchains);
+    HIPCHK(hipGetLastError());
+    std::vector<double> v;
+    int rc = fetch(h, h->d_moments, (size_t)T * len, v); if (rc) return rc;
+    // fixed pairwise tree over tiles (adjacent pairs first), so the result does not depend on how
+    // the tiles are later grouped onto GPUs as long as each GPU owns a power-of-two aligned block
+    int n = T;
+    std::vector<double> cur = v;
+    while (n > 1) {
+        int half = (n + 1) / 2;
+        std::vector<double> nxt((size_t)half * len);
+        for (int i = 0; i < half; ++i)
+            for (int k = 0; k < len; ++k) {
+                double a = cur[(size_t)(2 * i) * len + k];
+                nxt[(size_t)i * len + k] = (2 * i + 1 < n) ? a + cur[(size_t)(2 * i + 1) * len + k] : a;
+            }
+        cur.swap(nxt); n = half;
+    }
+    memcpy(out, cur.data(), sizeof(double) * len);
+    return 0;
+}
+
+
+// ------------------------------------------------------------------ debug probes (tests only)
+int mcmcx_debug_math(int32_t op, int32_t n, const double *a, const double *b, double *out)
+{
+    if (n < 1 || !a || !out) return fail(-1, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(-10, "no HIP device: the mcmcx engine has no CPU fallback");
+    double *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIPCHK(hipMalloc((void **)&da, (size_t)n * 8)); HIPCHK(hipMalloc((void **)&dout, (size_t)n * 8));
+    HIPCHK(hipMemcpy(da, a, (size_t)n * 8, hipMemcpyHostToDevice));
+    if (b) { HIPCHK(hipMalloc((void **)&db, (size_t)n * 8)); HIPCHK(hipMemcpy(db, b, (size_t)n * 8, hipMemcpyHostToDevice)); }
+    hipLaunchKernelGGL(debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, op, n, da, db, dout);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(dout); if (db) (void)hipFree(db);
+    return 0;
+}
+
+int mcmcx_debug_rng(uint32_t seed, uint32_t chain_id, int32_t kind, int32_t n, double a, double b, double *out, uint64_t *nused)
+{
+    if (n < 1 || !out) return fail(-1, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(-10, "no HIP device: the mcmcx engine has no CPU fallback");
+    double *dout = nullptr; uint64_t *dn = nullptr;
+    HIPCHK(hipMalloc((void **)&dout, (size_t)n * 8)); HIPCHK(hipMalloc((void **)&dn, 8));
+    hipLaunchKernelGGL(debug_rng_kernel, dim3(1), dim3(64), 0, 0, seed, chain_id, kind, n, a, b, dout, dn);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (nused) HIPCHK(hipMemcpy(nused, dn, 8, hipMemcpyDeviceToHost));
+    (void)hipFree(dout); (void)hipFree(dn);
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,194 @@
+"""Host-side mirror of mcmcf90's user surface on top of the C ABI.
+
+`McmcConfig` carries the numeric members of namelist /mcmc/ (mcmcinit.F90:74-82) with the reference's
+defaults (:184-230); `Engine` follows the call sequence of a reference driver program:
+MCMC_setpar0 / MCMC_setcmat0 / MCMC_setsigma2nobs (MCMC_init.F90:168-347, testcases/mcmcrun3.F90:18-23),
+then mcmc_main() = init + run (mcmc_main.F90:12-44), then the chain/sschain/s2chain arrays.
+Every call goes through libmcmcx.so; nothing is computed in Python.
+"""
+import ctypes as C
+import numpy as np
+from . import _lib
+
+METHODS = {"dram": 0, "ram": 1, "scam": 2, "er": 3}
+
+
+class McmcError(RuntimeError):
+    pass
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def make_config(npar, nchains=1, **kw):
+    c = _lib.Config()
+    _lib.load().mcmcx_config_defaults(C.byref(c))
+    c.npar, c.nchains = int(npar), int(nchains)
+    for k, v in kw.items():
+        if k == "method" and isinstance(v, str):
+            v = METHODS[v]
+        if not hasattr(c, k):
+            raise KeyError(k)
+        setattr(c, k, v)
+    return c
+
+
+class Engine:
+    def __init__(self, cfg):
+        self.L = _lib.load()
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        self._chk(self.L.mcmcx_create(C.byref(cfg), C.byref(self.h)))
+        self.npar, self.nchains, self.nsimu = cfg.npar, cfg.nchains, cfg.nsimu
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise McmcError(self.L.mcmcx_last_error().decode())
+        return rc
+
+    def close(self):
+        if self.h:
+            self.L.mcmcx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- MCMC_setpar0 / MCMC_setcmat0 / MCMC_setsigma2nobs
+    def setpar0(self, par0):
+        a = _f64(par0)
+        self._chk(self.L.mcmcx_set_par0(self.h, _dp(a), a.size))
+
+    def setcmat0(self, cmat0):
+        a = np.asfortranarray(np.asarray(cmat0, dtype=np.float64))
+        self._chk(self.L.mcmcx_set_cmat0(self.h, a.ctypes.data_as(C.POINTER(C.c_double)), a.shape[0]))
+
+    def setsigma2nobs(self, sigma2, nobs):
+        s = _f64([sigma2]); n = np.asarray([nobs], dtype=np.int32)
+        self._chk(self.L.mcmcx_set_sigma2nobs(self.h, _dp(s), n.ctypes.data_as(C.POINTER(C.c_int32)), 1))
+
+    # --- the device-resident user callbacks
+    def set_target(self, kind, mu=None, lam=None, b=0.1, xdata=None, ydata=None):
+        if kind == "gauss":
+            self._chk(self.L.mcmcx_set_target_gauss(self.h, _dp(_f64(mu)), _dp(_f64(lam))))
+        elif kind == "banana":
+            self._chk(self.L.mcmcx_set_target_banana(self.h, float(b)))
+        elif kind == "expdata":
+            x, y = _f64(xdata), _f64(ydata)
+            self._chk(self.L.mcmcx_set_target_expdata(self.h, x.size, _dp(x), _dp(y)))
+        else:
+            raise KeyError(kind)
+
+    def set_bounds(self, lo=None, hi=None):
+        lo = _f64(lo) if lo is not None else None
+        hi = _f64(hi) if hi is not None else None
+        self._chk(self.L.mcmcx_set_bounds(self.h, _dp(lo), _dp(hi)))
+
+    def set_priors(self, mu, sig):
+        self._chk(self.L.mcmcx_set_priors(self.h, _dp(_f64(mu)), _dp(_f64(sig))))
+
+    # --- mcmc_main
+    def init(self):
+        self._chk(self.L.mcmcx_init(self.h))
+
+    def run(self, upto=None):
+        self._chk(self.L.mcmcx_run(self.h, self.nsimu if upto is None else int(upto)))
+
+    def sync(self):
+        self._chk(self.L.mcmcx_sync(self.h))
+
+    @property
+    def simuind(self):
+        return self.L.mcmcx_simuind(self.h)
+
+    # --- results
+    def counters(self, chain=0):
+        a = np.zeros(8, dtype=np.int32)
+        self._chk(self.L.mcmcx_get_counters(self.h, chain, a.ctypes.data_as(C.POINTER(C.c_int32))))
+        return dict(stayed=int(a[0]), bndstayed=int(a[1]), draccepted=int(a[2]), drtries=int(a[3]),
+                    chainind=int(a[4]), status=int(a[5]), info=int(a[6]), curcount=int(a[7]))
+
+    def totals(self):
+        a = np.zeros(5, dtype=np.int64)
+        self._chk(self.L.mcmcx_get_totals(self.h, a.ctypes.data_as(C.POINTER(C.c_int64))))
+        return dict(stayed=int(a[0]), bndstayed=int(a[1]), draccepted=int(a[2]), drtries=int(a[3]), proposals=int(a[4]))
+
+    def theta(self):
+        a = np.zeros((self.nchains, self.npar))
+        self._chk(self.L.mcmcx_get_theta(self.h, _dp(a)))
+        return a
+
+    def scalars(self):
+        a = np.zeros((self.nchains, 4))
+        self._chk(self.L.mcmcx_get_scalars(self.h, _dp(a)))
+        return a          # ss1, sspri1, sigma2, alpha12
+
+    def rng(self, chain=0):
+        n, s, y = C.c_uint64(), C.c_int32(), C.c_double()
+        self._chk(self.L.mcmcx_get_rng(self.h, chain, C.byref(n), C.byref(s), C.byref(y)))
+        return n.value, s.value, y.value
+
+    def R(self, chain=0):
+        a = np.zeros((self.npar, self.npar), order="F")
+        self._chk(self.L.mcmcx_get_R(self.h, chain, a.ctypes.data_as(C.POINTER(C.c_double))))
+        return np.array(a)
+
+    def chaincov(self, chain=0):
+        a = np.zeros((self.npar, self.npar), order="F"); m = np.zeros(self.npar); w = C.c_double()
+        self._chk(self.L.mcmcx_get_chaincov(self.h, chain, a.ctypes.data_as(C.POINTER(C.c_double)), _dp(m), C.byref(w)))
+        return np.array(a), m, w.value
+
+    def accepted(self, chain=0):
+        a = np.zeros(self.simuind, dtype=np.uint8)
+        self._chk(self.L.mcmcx_get_accepted(self.h, chain, a.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return a
+
+    def accept_masks(self):
+        nt = C.c_int32()
+        self._chk(self.L.mcmcx_get_accept_masks(self.h, None, C.byref(nt)))
+        a = np.zeros((self.simuind, nt.value), dtype=np.uint64)
+        self._chk(self.L.mcmcx_get_accept_masks(self.h, a.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(nt)))
+        return a
+
+    def chain(self, chain=0):
+        n = self.simuind
+        ch = np.zeros((n, self.npar + 1)); ss = np.zeros((n, 2)); s2 = np.zeros(n); nr = C.c_int32()
+        self._chk(self.L.mcmcx_get_chain(self.h, chain, _dp(ch), _dp(ss), _dp(s2), C.byref(nr)))
+        return ch[:nr.value], ss[:nr.value], s2
+
+    def pooled_moments(self):
+        n = self.L.mcmcx_pooled_moments_len(self.h)
+        a = np.zeros(n)
+        self._chk(self.L.mcmcx_pooled_moments(self.h, _dp(a)))
+        return a
+
+    def kernel_time(self, reset=False):
+        ms, nl, ns = C.c_double(), C.c_int64(), C.c_int64()
+        self._chk(self.L.mcmcx_kernel_time(self.h, C.byref(ms), C.byref(nl), C.byref(ns), int(reset)))
+        return ms.value, nl.value, ns.value
+
+
+def engine_from_problem(cfg_kw, prob_kw, nchains=1, **extra):
+    """Build an Engine from the same (cfg, problem) dictionaries the oracle / golden fixtures use."""
+    pk = dict(prob_kw)
+    npar = int(pk["npar"])
+    cfg = make_config(npar, nchains, **cfg_kw, **extra)
+    e = Engine(cfg)
+    e.setpar0(pk["par0"])
+    e.setcmat0(np.asarray(pk["cmat0"], dtype=np.float64).reshape(npar, npar))
+    e.setsigma2nobs(float(pk.get("sigma2", 1.0)), int(pk.get("nobs", 1)))
+    e.set_target(str(pk["kind"]), mu=pk.get("mu"), lam=pk.get("lam"), b=float(pk.get("b", 0.1)),
+                 xdata=pk.get("xdata"), ydata=pk.get("ydata"))
+    if pk.get("lo") is not None or pk.get("hi") is not None:
+        e.set_bounds(pk.get("lo"), pk.get("hi"))
+    if pk.get("pri_mu") is not None:
+        e.set_priors(pk["pri_mu"], pk["pri_sig"])
+    return e
