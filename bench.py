@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- MH proposals/sec of the MI355X engine on BASELINE.json's headline workload.
+
+Workload "C4": correlated Gaussian target d=50 (Sigma_ij = 0.5^|i-j|, Lambda dense), method='ram'
+(MCMC_run_ram + MCMC_adapt_ram with a per-chain Cholesky factor), 131072 chains per GPU (the 8-GPU
+configuration of BASELINE.json is 1 048 576 chains = 131072 x 8: weak scaling), pooled
+empirical-moment reduction of all chains every `--its-per-step` iterations (all-reduce over RCCL
+when N > 1).  One bench "step" = --its-per-step MH iterations of every chain + that reduction.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the engine's
+stream around every step-kernel launch of the timed region (mcmcx_kernel_time); `cpu_baseline`
+times the real Fortran reference (oracle/_ref, kind "reference") or the C oracle (kind "port")
+on one host core on the same target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def corr_gauss_precision(d, rho=0.5):
+    S = rho ** np.abs(np.subtract.outer(np.arange(d), np.arange(d)))
+    return np.linalg.inv(S)
+
+
+def alg_bytes_per_proposal(d, method):
+    """Algorithmic HBM bytes per proposal:
+    theta read + write (16 d) + ss/prior read/write (32); per-chain Cholesky factor, packed
+    upper triangle: RAM reads it once and writes it once per iteration (8 d (d+1)), AM only reads
+    it (4 d (d+1))."""
+    base = 16 * d + 32
+    tri = d * (d + 1) // 2 * 8
+    return base + (2 * tri if method == "ram" else tri)
+
+
+def cpu_baseline(d, lam, target_seconds=12.0):
+    """One chain of the same workload on one host core."""
+    from oracle import pyoracle as po, refrun as rr
+    prob = po.Problem("gauss", d, np.zeros(d), 0.01 * np.eye(d), mu=np.zeros(d), lam=lam)
+    out = {"cores": 1, "unit": "proposals/s"}
+    # the C oracle, in process (no file output)
+    n_port = 100000
+    cfg = po.make_cfg(nsimu=n_port, method="ram", updatesigma=0)
+    t0 = time.perf_counter(); po.run_chain(cfg, prob); t_port = time.perf_counter() - t0
+    port_rate = (n_port - 1) / t_port
+    if rr.available():
+        try:
+            nsimu = int(min(1500000, max(20000, port_rate * target_seconds * 0.6)))
+            cfg = po.make_cfg(nsimu=nsimu, method="ram", updatesigma=0)
+            t0 = time.perf_counter(); rr.run_reference(cfg, prob, timeout=300); t_ref = time.perf_counter() - t0
+            out.update(value=(nsimu - 1) / t_ref, kind="reference",
+                       sample="mcmcf90 Fortran reference (flang -O2 + MKL, oracle/_ref/mcxref), 1 chain, d=%d RAM, "
+                              "nsimu=%d, wall time of the whole program incl. namelist/file I/O = %.2f s" % (d, nsimu, t_ref),
+                       port_value=port_rate)
+            return out
+        except Exception as ex:                      # reference binary present but not runnable here
+            out["reference_error"] = str(ex)[:200]
+    out.update(value=port_rate, kind="port",
+               sample="C oracle (oracle/mcx_oracle.c, gcc -O2), 1 chain, d=%d RAM, nsimu=%d, %.2f s" % (d, n_port, t_port))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--chains-per-gpu", type=int, default=131072)
+    ap.add_argument("--its-per-step", type=int, default=100)
+    ap.add_argument("--npar", type=int, default=50)
+    ap.add_argument("--method", default="ram", choices=["ram", "dram"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from mcmcf90_amd import engine_from_problem
+    d, n_local, ips = a.npar, a.chains_per_gpu, a.its_per_step
+    lam = corr_gauss_precision(d)
+    nsimu = 1 + (a.warmup + a.steps) * ips
+    ckw = dict(nsimu=nsimu, method=a.method, updatesigma=0, adaptint=ips)
+    pkw = dict(kind="gauss", npar=d, par0=np.zeros(d), cmat0=0.01 * np.eye(d), mu=np.zeros(d), lam=lam)
+    eng = engine_from_problem(ckw, pkw, nchains=n_local, chain_id0=rank * n_local, device=local_rank)
+    eng.init()
+    mom_len = 1 + d + d * (d + 1) // 2
+    pooled = torch.zeros(mom_len, dtype=torch.float64, device=dev)
+
+    def one_step(k):
+        eng.run(1 + (k + 1) * ips)
+        m = eng.pooled_moments()                       # fixed-tree sum over this GPU's chains
+        pooled.copy_(torch.from_numpy(m))
+        if world > 1:
+            dist.all_reduce(pooled)                    # RCCL over xGMI: 1+d+d(d+1)/2 doubles
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(a.warmup):
+        one_step(k)
+    fence()
+    eng.kernel_time(reset=True)
+    t0 = time.perf_counter()
+    for k in range(a.warmup, a.warmup + a.steps):
+        one_step(k)
+    fence()
+    dt = time.perf_counter() - t0
+    kms, klaunch, ksteps = eng.kernel_time()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        proposals = float(world) * n_local * ips * a.steps
+        value = proposals / dt
+        balg = alg_bytes_per_proposal(d, a.method)
+        per_launch_bytes = balg * n_local * (ksteps / max(klaunch, 1))
+        avg_launch_s = kms / 1e3 / max(klaunch, 1)
+        achieved = per_launch_bytes / avg_launch_s / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                key = "%s_d%d" % (a.method, d)
+                if key in tj:                      # measured HBM bytes per proposal (rocprofv3 --pmc, see profiles/)
+                    traffic = tj[key]["hbm_bytes_per_proposal"] * n_local * (ksteps / max(klaunch, 1))
+            except Exception:
+                traffic = None
+        cnt = float(pooled[0].item())
+        mean = (pooled[1:1 + d] / cnt).cpu().numpy()
+        line = {
+            "metric": "MH proposals/sec (whole node), d=50 Gaussian target",
+            "value": value, "unit": "proposals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C4: correlated Gaussian d=%d (Sigma=0.5^|i-j|), method=%s, per-chain Cholesky "
+                                   "factor, %d chains/GPU, pooled moments all-reduce every %d iterations"
+                                   % (d, a.method, n_local, ips),
+                       "chains_per_gpu": n_local, "its_per_step": ips, "npar": d, "method": a.method,
+                       "parallelism": "chains sharded over %d GPU(s)" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "mcx::step_kernel<%d>" % d, "alg_bytes_per_proposal": balg,
+                         "launches": int(klaunch), "avg_launch_ms": avg_launch_s * 1e3,
+                         "kernel_share_of_wall": kms / 1e3 / dt},
+            "pooled_check": {"chains": cnt, "max_abs_mean": float(np.max(np.abs(mean)))},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(d, lam)
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
