@@ -90,26 +90,27 @@ static const int MCX_MAX_NPAR = 64;
 
 // dpotf2('U') + scaling on the host for the shared initial factor: same operation sequence as the
 // device's calculate_R (MCMC_calculate_R at MCMC_init.F90:109).  cm: col-major d*d, Rp: packed upper.
+static inline int h_rowstart(int i, int d) { return i * d - (i * (i - 1)) / 2; }
+static inline int h_pidx(int i, int j, int d) { return h_rowstart(i, d) + (j - i); }
+
 static int host_initial_R(int d, const std::vector<double> &cm, std::vector<double> &Rp, std::vector<double> &Cp)
 {
     int P = d * (d + 1) / 2;
     std::vector<double> A(P);
-    for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) A[j * (j + 1) / 2 + i] = cm[(size_t)i + (size_t)j * d];
+    for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) A[h_pidx(i, j, d)] = cm[(size_t)i + (size_t)j * d];
     Cp = A;
     for (int j = 0; j < d; ++j) {
-        double *colj = &A[j * (j + 1) / 2];
         double dot = 0.0;
-        for (int i = 0; i < j; ++i) dot = std::fma(colj[i], colj[i], dot);
-        double ajj = colj[j] - dot;
+        for (int i = 0; i < j; ++i) dot = std::fma(A[h_pidx(i, j, d)], A[h_pidx(i, j, d)], dot);
+        double ajj = A[h_pidx(j, j, d)] - dot;
         if (!(ajj > 0.0)) return j + 1;
         double rj = std::sqrt(ajj);
-        colj[j] = rj;
+        A[h_pidx(j, j, d)] = rj;
         double rinv = 1.0 / rj;
         for (int k = j + 1; k < d; ++k) {
-            double *colk = &A[k * (k + 1) / 2];
             double t = 0.0;
-            for (int i = 0; i < j; ++i) t = std::fma(colk[i], colj[i], t);
-            colk[j] = (colk[j] - t) * rinv;
+            for (int i = 0; i < j; ++i) t = std::fma(A[h_pidx(i, k, d)], A[h_pidx(i, j, d)], t);
+            A[h_pidx(j, k, d)] = (A[h_pidx(j, k, d)] - t) * rinv;
         }
     }
     double sq = std::sqrt((double)d);
@@ -175,8 +176,8 @@ static void unpack_upper(int d, const std::vector<double> &p, double *colmajor, 
     for (int j = 0; j < d; ++j)
         for (int i = 0; i < d; ++i) {
             double v = 0.0;
-            if (i <= j) v = p[j * (j + 1) / 2 + i];
-            else if (symmetric) v = p[i * (i + 1) / 2 + j];
+            if (i <= j) v = p[h_pidx(i, j, d)];
+            else if (symmetric) v = p[h_pidx(j, i, d)];
             colmajor[(size_t)i + (size_t)j * d] = v;
         }
 }
@@ -364,6 +365,8 @@ int mcmcx_init(mcmcx_handle h)
     const size_t L = (size_t)T * 64;
     if ((rc = dev_alloc(h, &E.theta, L * d))) return rc;
     if ((rc = dev_alloc(h, &E.cand, L * d))) return rc;
+    if ((rc = dev_alloc(h, &E.zs, L * d))) return rc;
+    if ((rc = dev_alloc(h, &E.cs, L * 2 * d))) return rc;
     if ((rc = dev_alloc(h, &E.scal, L * NSCAL))) return rc;
     if ((rc = dev_alloc(h, &E.ictr, L * NICTR))) return rc;
     if ((rc = dev_alloc(h, &E.rngn, L))) return rc;

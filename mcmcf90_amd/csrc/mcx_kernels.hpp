@@ -5,8 +5,9 @@
 //     element k of chain (tile, lane)  ->  base[(tile*K + k)*64 + lane],
 // i.e. parameter-major inside a tile, so every wave access is one contiguous
 // 512-byte segment and a tile's whole Cholesky factor is one sequential stream.
-// Per-lane d-vectors live in VGPR arrays with compile-time indices: O(d^2) loops
-// are written "runtime outer index, unrolled + guarded inner index".
+// One per-lane d-vector lives in a VGPR array with compile-time indices; the O(d^2) loops are
+// "runtime row index, unrolled column index" with the row's elements loaded 8 at a time, so a
+// wave always has several independent 512-byte loads in flight.
 #pragma once
 #include "mcx_device.hpp"
 
@@ -42,7 +43,7 @@ struct EngineDev {
     double alphatarget, drscale, scalelimit, scalefactor;
     DevTarget tgt;
     // state, tile-interleaved
-    double *theta, *cand, *scal, *R, *R2, *iC, *Rtmp;
+    double *theta, *cand, *zs, *cs, *scal, *R, *R2, *iC, *Rtmp;   // cand/zs [d], cs [2d]: per-chain scratch vectors
     double *cmat, *mean, *basetheta;
     const double *cmat0p, *par0;    // packed upper cmat0 [P], par0 [d] (shared by all chains)
     uint32_t *ictr;
@@ -58,31 +59,68 @@ struct EngineDev {
 
 #define TIDX(base, tile, K, k, lane) ((base)[((size_t)(tile) * (size_t)(K) + (size_t)(k)) * 64 + (lane)])
 
-MCX_DEV int pk(int i, int j) { return j * (j + 1) / 2 + i; }     // packed upper, column-major, i <= j
+// Packed upper triangle, ROW-major: element (i,j), i <= j, sits at rowstart(i) + (j - i).
+// Every sweep of the factor (proposal, update, downdate) walks whole rows, forwards or backwards,
+// so a tile's factor is one sequential HBM stream of 512-byte wave segments.
+MCX_DEV int rowstart(int i, int d) { return i * d - (i * (i - 1)) / 2; }
+MCX_DEV int pidx(int i, int j, int d) { return rowstart(i, d) + (j - i); }
+
+constexpr int CH = 8;     // row elements loaded per batch (8 x 512 B in flight per wave and batch)
+
+// Visit row i of a packed factor: the elements j0..j0+CH-1 of each chunk that reaches the row are
+// loaded together (clamped addresses, unconditional), then f(j, r, valid, interior) runs per element
+// with a compile-time j.  interior == true: the whole chunk is strictly right of the diagonal and
+// inside d, so the body needs no predication.
+template <int D, typename F>
+MCX_DEV void sweep_row(int i, int d, const double *rowp, F &&f)
+{
+    constexpr int NCH = (D + CH - 1) / CH;
+    const int m = d - 1 - i;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int j0 = c * CH;
+        if (j0 + CH - 1 >= i && j0 < d) {
+            double r[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                int o = j0 + u - i; o = o < 0 ? 0 : o; o = o > m ? m : o;
+                r[u] = rowp[(size_t)o * 64];
+            }
+            if (j0 > i && j0 + CH <= d) {
+#pragma unroll
+                for (int u = 0; u < CH; ++u) if (j0 + u < D) f(j0 + u, r[u], true, true);
+            } else {
+#pragma unroll
+                for (int u = 0; u < CH; ++u) if (j0 + u < D) f(j0 + u, r[u], (j0 + u >= i) && (j0 + u < d), false);
+            }
+        }
+    }
+}
 
 // ---------------------------------------------------------------- targets (user ssfunction / priorfun / checkbounds)
+// th[] holds the candidate on entry and (th - mu) on exit for the Gaussian target; cand_t is the
+// same candidate in global scratch (element stride 64), used for the few runtime-indexed reads.
 template <int D>
-MCX_DEV double target_ss(const DevTarget &t, int d, const double (&th)[D], double (&v)[D],
-                         const double *cand_t /* tile base + lane, element stride 64 */)
+MCX_DEV double target_ss(const DevTarget &t, int d, double (&th)[D], const double *cand_t)
 {
     double ss = 0.0;
     if (t.kind == TGT_GAUSS) {
         // ss = (th-mu)' Lam (th-mu): y_i = sum_j lam(i,j) v_j ascending (fma chain), ss = sum_i y_i v_i (fma chain)
 #pragma unroll
-        for (int j = 0; j < D; ++j) if (j < d) v[j] = th[j] - t.mu[j];
+        for (int j = 0; j < D; ++j) if (j < d) th[j] = th[j] - t.mu[j];
         for (int i = 0; i < d; ++i) {
             const double *__restrict__ row = t.lam + (size_t)i * d;
             double y = 0.0;
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                if (j < d) { if (j == 0) y = row[0] * v[0]; else y = dfma(row[j], v[j], y); }
+                if (j < d) { if (j == 0) y = row[0] * th[0]; else y = dfma(row[j], th[j], y); }
             }
             double vi = cand_t[(size_t)i * 64] - t.mu[i];
             if (i == 0) ss = y * vi; else ss = dfma(y, vi, ss);
         }
     } else if (t.kind == TGT_BANANA) {
         double t1 = th[0] * th[0];
-        double q = dfma(t.b, t1, (D > 1) ? th[D > 1 ? 1 : 0] : 0.0) - 100.0 * t.b;
+        double q = dfma(t.b, t1, th[D > 1 ? 1 : 0]) - 100.0 * t.b;
         ss = dfma(q, q, t1 / 100.0);
 #pragma unroll
         for (int k = 2; k < D; ++k) if (k < d) ss = dfma(th[k], th[k], ss);
@@ -120,20 +158,21 @@ MCX_DEV bool target_inbounds(const DevTarget &t, int d, const double (&th)[D])
     return ok;
 }
 
-// ---------------------------------------------------------------- normals into LDS (mcmcrand.F90:60-83,166-190)
-// Each lane appends accepted polar pairs to its own column of zbuf until it has d deviates; the
-// wave loops until every participating lane is done.  The cached second deviate is honoured.
-MCX_DEV void gen_normals(Rng &g, double *zbuf /* LDS [D][64] */, int lane, int d, bool participate)
+// ---------------------------------------------------------------- normals (mcmcrand.F90:60-83,166-190)
+// Each lane appends accepted polar pairs to its own column of zs (global scratch, element stride 64)
+// until it has d deviates; the wave loops until every participating lane is done.  The cached
+// second deviate of normal_bm is honoured and left behind when d is odd.
+MCX_DEV void gen_normals(Rng &g, double *zs_t, int d, bool participate)
 {
     int k = 0;
-    if (participate && g.saved && d > 0) { zbuf[0 * 64 + lane] = g.saved_y; g.saved = 0; k = 1; }
+    if (participate && g.saved && d > 0) { zs_t[0] = g.saved_y; g.saved = 0; k = 1; }
     bool need = participate && (k < d);
     while (__any(need)) {
         if (need) {
             double a, b;
             if (polar_try(g, a, b)) {
-                zbuf[k * 64 + lane] = a; ++k;
-                if (k < d) { zbuf[k * 64 + lane] = b; ++k; }
+                zs_t[(size_t)k * 64] = a; ++k;
+                if (k < d) { zs_t[(size_t)k * 64] = b; ++k; }
                 else { g.saved_y = b; g.saved = 1; }
             }
             need = (k < d);
@@ -141,88 +180,102 @@ MCX_DEV void gen_normals(Rng &g, double *zbuf /* LDS [D][64] */, int lane, int d
     }
 }
 
-// ---------------------------------------------------------------- proposal: cand = theta + R'z  (MCMC_DRAM.F90:20-31)
-// dtrmv('U','T','N') in netlib order (matutils.F90:108-109): column j = d-1..0, temp = z_j R(j,j),
-// then i = j-1..0 as an fma chain.  R packed upper, column j contiguous.
+// ---------------------------------------------------------------- proposal: P = R'z  (MCMC_DRAM.F90:20-31)
+// dtrmv('U','T','N') (matutils.F90:108-109) in netlib accumulation order: p_j = z_j R(j,j), then
+// + R(i,j) z_i for i = j-1..0 as an fma chain -- which is what a sweep over rows i = d-1..0 produces.
 template <int D>
-MCX_DEV void propose(const double *Rt, const double *theta_t, double *cand_t, const double (&z)[D], int d, bool act)
+MCX_DEV void trmv_rows(const double *Rt, const double *zs_t, int d, double (&P)[D])
 {
-    for (int j = d - 1; j >= 0; --j) {
-        const double *col = Rt + (size_t)(j * (j + 1) / 2) * 64;
-        double temp = 0.0;
-        if (act) {
-#pragma unroll
-            for (int i = D - 1; i >= 0; --i) {
-                if (i == j) temp = z[i] * col[(size_t)i * 64];
-                else if (i < j) temp = dfma(col[(size_t)i * 64], z[i], temp);
+    for (int i = d - 1; i >= 0; --i) {
+        const double zi = zs_t[(size_t)i * 64];
+        const double *rowp = Rt + (size_t)rowstart(i, d) * 64;
+        sweep_row<D>(i, d, rowp, [&](int j, double r, bool valid, bool interior) {
+            if (interior) P[j] = dfma(r, zi, P[j]);
+            else {
+                double nv = (j == i) ? zi * r : dfma(r, zi, P[j]);
+                P[j] = valid ? nv : P[j];
             }
-            cand_t[(size_t)j * 64] = theta_t[(size_t)j * 64] + temp;
-        }
+        });
     }
 }
 
 // ---------------------------------------------------------------- RAM rank-1 adaptation (MCMC_run_ram.F90:104-179)
-// a >= 0: cholupdate = DCHUD (dchud.f:122-139); a < 0: choldowndate = DCHDD (dchdd.f:141-179).
-// c[] and s[] are the rotation vectors; x_j = z_j / sum(z^2) * |a| is formed on the fly from zbuf.
+// a >= 0: cholupdate = DCHUD (dchud.f:122-139); a < 0: choldowndate = DCHDD (dchdd.f:141-179), both
+// restated row by row (same operations on every element, in the same order per column).
+// X is the one per-lane register array; cs_t is global scratch for the downdate's rotations.
 template <int D>
-MCX_DEV void ram_update(double *Rt, const double *zbuf, int lane, int d, double a, bool act,
-                        double (&c)[D], double (&s)[D], uint32_t &status)
+MCX_DEV void ram_update(double *Rt, const double *zs_t, double *cs_t, int d, double a, bool act,
+                        double (&X)[D], uint32_t &status)
 {
     double su = 0.0;
-    for (int k = 0; k < d; ++k) { double zk = zbuf[k * 64 + lane]; su = su + zk * zk; }
-    bool up = act && (a >= 0.0);
-    bool down = act && !(a >= 0.0);
+#pragma unroll
+    for (int k = 0; k < D; ++k) if (k < d) { X[k] = zs_t[(size_t)k * 64]; }
+#pragma unroll
+    for (int k = 0; k < D; ++k) if (k < d) { su = su + X[k] * X[k]; }
+    const bool up = act && (a >= 0.0);
+    const bool down = act && !(a >= 0.0);
     if (__any(up)) {
         if (up) {
-            double pc = 0.0, ps = 0.0;           // rotation of the previous column, committed lazily
-            for (int j = 0; j < d; ++j) {
-                double *col = Rt + (size_t)(j * (j + 1) / 2) * 64;
-                double xj = zbuf[j * 64 + lane] / su * a;
 #pragma unroll
-                for (int i = 0; i < D; ++i) {
-                    if (i < j) {
-                        if (i == j - 1) { c[i] = pc; s[i] = ps; }
-                        double rij = col[(size_t)i * 64];
-                        double t = c[i] * rij + s[i] * xj;
-                        xj = c[i] * xj - s[i] * rij;
-                        col[(size_t)i * 64] = t;
+            for (int k = 0; k < D; ++k) if (k < d) X[k] = X[k] / su * a;          // x = u/sum(u**2) * a
+            double xdiag = X[0];
+            for (int i = 0; i < d; ++i) {
+                double *rowp = Rt + (size_t)rowstart(i, d) * 64;
+                double r, c, s;
+                d_rotg(rowp[0], xdiag, r, c, s);
+                rowp[0] = r;
+                sweep_row<D>(i, d, rowp, [&](int j, double rij, bool valid, bool interior) {
+                    if (interior) {
+                        double t = c * rij + s * X[j];
+                        X[j] = c * X[j] - s * rij;
+                        rowp[(size_t)(j - i) * 64] = t;
+                        if ((j % CH) == 0) xdiag = (j == i + 1) ? X[j] : xdiag;
+                    } else {
+                        const bool off = valid && (j > i);
+                        double t = c * rij + s * X[j];
+                        double nx = c * X[j] - s * rij;
+                        X[j] = off ? nx : X[j];
+                        if (off) rowp[(size_t)(j - i) * 64] = t;
+                        xdiag = (off && j == i + 1) ? X[j] : xdiag;
                     }
-                }
-                double r;
-                d_rotg(col[(size_t)j * 64], xj, r, pc, ps);
-                col[(size_t)j * 64] = r;
+                });
             }
         }
     }
     if (__any(down)) {
         if (down) {
-            // solve R' a = x  (dchdd.f:141-148), s[] holds the solution
-            double pend = 0.0;
-            for (int j = 0; j < d; ++j) {
-                const double *col = Rt + (size_t)(j * (j + 1) / 2) * 64;
-                double xj = -(zbuf[j * 64 + lane] / su * a);
-                double dot = 0.0;
+            // solve R'a = x, x = -u/sum(u**2)*a (dchdd.f:141-148); slot j of X is the running dot of column j
+            // until row j, then the solution s_j
+            const double fac = a;
+            double accdiag = 0.0;
 #pragma unroll
-                for (int i = 0; i < D; ++i) {
-                    if (i < j) {
-                        if (i == j - 1) s[i] = pend;
-                        dot = dfma(col[(size_t)i * 64], s[i], dot);
+            for (int k = 0; k < D; ++k) if (k < d) X[k] = 0.0;
+            for (int i = 0; i < d; ++i) {
+                const double *rowp = Rt + (size_t)rowstart(i, d) * 64;
+                double xi = -(zs_t[(size_t)i * 64] / su * fac);
+                double si = xi - accdiag;
+                si = si / rowp[0];
+                sweep_row<D>(i, d, rowp, [&](int j, double rij, bool valid, bool interior) {
+                    if (interior) {
+                        X[j] = dfma(rij, si, X[j]);
+                        if ((j % CH) == 0) accdiag = (j == i + 1) ? X[j] : accdiag;
+                    } else {
+                        const bool off = valid && (j > i);
+                        double na = dfma(rij, si, X[j]);
+                        X[j] = off ? na : ((valid && j == i) ? si : X[j]);
+                        accdiag = (off && j == i + 1) ? X[j] : accdiag;
                     }
-                }
-                double sj = xj - dot;
-                pend = sj / col[(size_t)j * 64];
+                });
             }
-#pragma unroll
-            for (int i = 0; i < D; ++i) if (i == d - 1) s[i] = pend;
-            // norm = dnrm2(p, s) classic scale/ssq form (dchdd.f:149)
+            // norm = dnrm2(p, s), classic scale/ssq form (dchdd.f:149)
             double norm;
-            if (d == 1) norm = fabs(s[0]);
+            if (d == 1) norm = fabs(X[0]);
             else {
                 double scale = 0.0, ssq = 1.0;
 #pragma unroll
-                for (int i = 0; i < D; ++i) {
-                    if (i < d && s[i] != 0.0) {
-                        double ax = fabs(s[i]);
+                for (int k = 0; k < D; ++k) {
+                    if (k < d && X[k] != 0.0) {
+                        double ax = fabs(X[k]);
                         if (scale < ax) { double q = scale / ax; ssq = 1.0 + ssq * (q * q); scale = ax; }
                         else { double q = ax / scale; ssq = ssq + q * q; }
                     }
@@ -234,27 +287,29 @@ MCX_DEV void ram_update(double *Rt, const double *zbuf, int lane, int d, double 
             } else {
                 double alpha = sqrt(1.0 - norm * norm);
 #pragma unroll
-                for (int i = D - 1; i >= 0; --i) {
-                    if (i < d) {
-                        double scale = alpha + fabs(s[i]);
-                        double aa = alpha / scale, bb = s[i] / scale;
+                for (int k = D - 1; k >= 0; --k) {   // dchdd.f:158-167
+                    if (k < d) {
+                        double scale = alpha + fabs(X[k]);
+                        double aa = alpha / scale, bb = X[k] / scale;
                         double nn = sqrt(aa * aa + bb * bb);
-                        c[i] = aa / nn; s[i] = bb / nn;
+                        cs_t[(size_t)(2 * k) * 64] = aa / nn;
+                        cs_t[(size_t)(2 * k + 1) * 64] = bb / nn;
                         alpha = scale * nn;
                     }
                 }
-                for (int j = 0; j < d; ++j) {
-                    double *col = Rt + (size_t)(j * (j + 1) / 2) * 64;
-                    double xx = 0.0;
 #pragma unroll
-                    for (int i = D - 1; i >= 0; --i) {
-                        if (i <= j) {
-                            double rij = col[(size_t)i * 64];
-                            double t = c[i] * xx + s[i] * rij;
-                            col[(size_t)i * 64] = c[i] * rij - s[i] * xx;
-                            xx = t;
-                        }
-                    }
+                for (int k = 0; k < D; ++k) if (k < d) X[k] = 0.0;          // xx of every column
+                double cn = cs_t[(size_t)(2 * (d - 1)) * 64], sn = cs_t[(size_t)(2 * (d - 1) + 1) * 64];
+                for (int i = d - 1; i >= 0; --i) {   // dchdd.f:171-179, rows d-1..0
+                    double *rowp = Rt + (size_t)rowstart(i, d) * 64;
+                    const double ci = cn, si = sn;
+                    if (i > 0) { cn = cs_t[(size_t)(2 * (i - 1)) * 64]; sn = cs_t[(size_t)(2 * (i - 1) + 1) * 64]; }
+                    sweep_row<D>(i, d, rowp, [&](int j, double rij, bool valid, bool interior) {
+                        double t = ci * X[j] + si * rij;
+                        double nr = ci * rij - si * X[j];
+                        if (interior) { rowp[(size_t)(j - i) * 64] = nr; X[j] = t; }
+                        else { if (valid) rowp[(size_t)(j - i) * 64] = nr; X[j] = valid ? t : X[j]; }
+                    });
                 }
             }
         }
@@ -267,11 +322,12 @@ MCX_DEV void ram_update(double *Rt, const double *zbuf, int lane, int d, double 
 template <int D>
 __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ ramscale)
 {
-    __shared__ double zbuf[D * 64];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
     const double *theta_t = E.theta + (size_t)tile * d * 64 + lane;
     double *theta_w = E.theta + (size_t)tile * d * 64 + lane;
     double *cand_t = E.cand + (size_t)tile * d * 64 + lane;
+    double *zs_t = E.zs + (size_t)tile * d * 64 + lane;
+    double *cs_t = E.cs + (size_t)tile * 2 * d * 64 + lane;
     double *Rt = E.R + (size_t)tile * E.P * 64 + lane;
 
     Rng g;
@@ -285,20 +341,20 @@ __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1,
     uint32_t chainind = TIDX(E.ictr, tile, NICTR, I_CHAININD, lane), curcount = TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane);
     uint32_t status = TIDX(E.ictr, tile, NICTR, I_STATUS, lane);
 
-    double A[D], B[D];
+    double V[D];
 
     for (int it = it0; it <= it1; ++it) {
         // ---- newpar = MCMC_propose(oldpar, R)
-        gen_normals(g, zbuf, lane, d, true);
+        gen_normals(g, zs_t, d, true);
 #pragma unroll
-        for (int k = 0; k < D; ++k) if (k < d) A[k] = zbuf[k * 64 + lane];
-        propose<D>(Rt, theta_t, cand_t, A, d, true);
+        for (int k = 0; k < D; ++k) V[k] = 0.0;
+        trmv_rows<D>(Rt, zs_t, d, V);
 #pragma unroll
-        for (int k = 0; k < D; ++k) if (k < d) B[k] = cand_t[(size_t)k * 64];
+        for (int k = 0; k < D; ++k) if (k < d) { V[k] = theta_t[(size_t)k * 64] + V[k]; cand_t[(size_t)k * 64] = V[k]; }
         // ---- bounds, prior, ss, alpha, reject
-        bool inb = target_inbounds<D>(E.tgt, d, B);
-        double pri2 = target_prior<D>(E.tgt, d, B);
-        double ss2 = target_ss<D>(E.tgt, d, B, A, cand_t);
+        bool inb = target_inbounds<D>(E.tgt, d, V);
+        double pri2 = target_prior<D>(E.tgt, d, V);
+        double ss2 = target_ss<D>(E.tgt, d, V, cand_t);
         bool reject;
         if (!inb) {
             bnd += 1; reject = true;
@@ -310,27 +366,30 @@ __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1,
             else if (alpha12 > 0.0) { double u = rng_uniform(g); if (u <= alpha12) reject = false; }
         }
         if (reject) { stayed += 1; curcount += 1; }
-        else {
-            ss1 = ss2; pri1 = pri2;
-#pragma unroll
-            for (int k = 0; k < D; ++k) if (k < d) theta_w[(size_t)k * 64] = B[k];
-            chainind += 1; curcount = 1;
-        }
+        else { ss1 = ss2; pri1 = pri2; chainind += 1; curcount = 1; }
         // ---- MCMC_updatesigma2 (MCMC_DRAM.F90:192-206)
         if (E.updatesigma) {
             double gm = rng_gamma(g, E.gam_shape, 2.0 / (E.N0S02 + ss1));
             sigma2 = 1.0 / gm;
         }
-        // ---- MCMC_savechain (MCMC_aux.F90:167-185): accept ballot + accepted row into the history ring
+        // ---- oldpar = newpar; MCMC_savechain (MCMC_aux.F90:167-185): accept ballot + accepted row into the ring
         unsigned long long ballot = __ballot(!reject);
         const int slot = it % E.wcap;
-        if (E.hist) {
-            if (!reject) {
-                double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64 + lane;
+        if (ballot != 0ull) {
 #pragma unroll
-                for (int k = 0; k < D; ++k) if (k < d) h[(size_t)k * 64] = B[k];
-                h[(size_t)d * 64] = ss1;
+            for (int k = 0; k < D; ++k) if (k < d) V[k] = cand_t[(size_t)k * 64];
+            if (!reject) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) if (k < d) theta_w[(size_t)k * 64] = V[k];
+                if (E.hist) {
+                    double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64 + lane;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) if (k < d) h[(size_t)k * 64] = V[k];
+                    h[(size_t)d * 64] = ss1;
+                }
             }
+        }
+        if (E.hist) {
             if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ballot;
             if (E.record_s2) E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = sigma2;
         }
@@ -338,7 +397,7 @@ __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1,
         // ---- MCMC_adapt_ram
         if (E.method == M_RAM && E.doadapt != 0 && !(it < E.burnintime && E.doburnin != 0)) {
             double a = ramscale[it - it0] * (alpha12 - E.alphatarget);
-            ram_update<D>(Rt, zbuf, lane, d, a, true, A, B, status);
+            ram_update<D>(Rt, zs_t, cs_t, d, a, true, V, status);
         }
     }
 
@@ -359,56 +418,53 @@ __global__ __launch_bounds__(64) void init_kernel(EngineDev E)
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
     double *theta_t = E.theta + (size_t)tile * d * 64 + lane;
     double *cand_t = E.cand + (size_t)tile * d * 64 + lane;
-    double A[D], B[D];
+    double V[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) if (k < d) { B[k] = theta_t[(size_t)k * 64]; cand_t[(size_t)k * 64] = B[k]; }
-    double pri1 = target_prior<D>(E.tgt, d, B);
-    double ss1 = target_ss<D>(E.tgt, d, B, A, cand_t);
+    for (int k = 0; k < D; ++k) if (k < d) { V[k] = theta_t[(size_t)k * 64]; cand_t[(size_t)k * 64] = V[k]; }
+    double pri1 = target_prior<D>(E.tgt, d, V);
+    double ss1 = target_ss<D>(E.tgt, d, V, cand_t);
     TIDX(E.scal, tile, NSCAL, S_SS1, lane) = ss1; TIDX(E.scal, tile, NSCAL, S_PRI1, lane) = pri1;
     // row 1 of the chain: iteration 1 counts as accepted
     const int slot = 1 % E.wcap;
     if (E.hist) {
         double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64 + lane;
-#pragma unroll
-        for (int k = 0; k < D; ++k) if (k < d) h[(size_t)k * 64] = B[k];
+        for (int k = 0; k < d; ++k) h[(size_t)k * 64] = theta_t[(size_t)k * 64];
         h[(size_t)d * 64] = ss1;
         if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ~0ull;
         if (E.record_s2) E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = TIDX(E.scal, tile, NSCAL, S_SIGMA2, lane);
     }
     if (E.accmask && lane == 0) E.accmask[tile] = ~0ull;
-#pragma unroll
-    for (int k = 0; k < D; ++k) if (k < d) TIDX(E.basetheta, tile, d, k, lane) = B[k];
+    for (int k = 0; k < d; ++k) TIDX(E.basetheta, tile, d, k, lane) = theta_t[(size_t)k * 64];
 }
 
 // ---------------------------------------------------------------- MCMC_adapt (MCMC_adapt.F90:12-174) at a tick
-// mode bits chosen by the host from (simuind, namelist): see Engine::run.
+// mode bits chosen by the host from (simuind, namelist): see mcmcx_run.
 enum { AD_BURN = 1, AD_AM = 2, AD_FIRST = 4 };
 
-// dpotf2('U') on the packed matrix in Rtmp (holds C on entry), then commit R = R0*2.4/sqrt(d)
-// (MCMC_calculate_R, MCMC_adapt.F90:181-230, Cholesky path).  Returns info.
+// dpotf2('U') on the packed matrix in Ct (holds C on entry, the factor on exit), then commit
+// R = R0*2.4/sqrt(d) (MCMC_calculate_R, MCMC_adapt.F90:181-230, Cholesky path).  Returns info.
 template <int D>
-MCX_DEV int calculate_R(double *Ct /* Rtmp tile base + lane */, double *Rt, int d, int P, bool act, double (&A)[D])
+MCX_DEV int calculate_R(double *Ct, double *Rt, int d, int P, bool act, double (&A)[D])
 {
     int info = 0;
     for (int j = 0; j < d; ++j) {
-        double *colj = Ct + (size_t)(j * (j + 1) / 2) * 64;
         double dot = 0.0;
 #pragma unroll
-        for (int i = 0; i < D; ++i) if (i < j) { A[i] = colj[(size_t)i * 64]; dot = dfma(A[i], A[i], dot); }
-        double ajj = colj[(size_t)j * 64] - dot;
+        for (int i = 0; i < D; ++i) if (i < j) { A[i] = Ct[(size_t)pidx(i, j, d) * 64]; dot = dfma(A[i], A[i], dot); }
+        double *rowj = Ct + (size_t)rowstart(j, d) * 64;
+        double ajj = rowj[0] - dot;
         bool ok = (ajj > 0.0);
         if (act && info == 0 && !ok) { info = j + 1; }
         bool go = act && info == 0;
         double rj = sqrt(ajj);
-        if (go) colj[(size_t)j * 64] = rj;
+        if (go) rowj[0] = rj;
         double rinv = 1.0 / rj;
         for (int k = j + 1; k < d; ++k) {
-            double *colk = Ct + (size_t)(k * (k + 1) / 2) * 64;
             if (go) {
                 double t = 0.0;
 #pragma unroll
-                for (int i = 0; i < D; ++i) if (i < j) t = dfma(colk[(size_t)i * 64], A[i], t);
-                colk[(size_t)j * 64] = (colk[(size_t)j * 64] - t) * rinv;
+                for (int i = 0; i < D; ++i) if (i < j) t = dfma(Ct[(size_t)pidx(i, k, d) * 64], A[i], t);
+                rowj[(size_t)(k - j) * 64] = (rowj[(size_t)(k - j) * 64] - t) * rinv;
             }
         }
     }
@@ -450,14 +506,12 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
         } else {
             // lastind = chainind: the covariance window restarts at the current row (lastfreq is NOT touched)
             docalc = true;
-#pragma unroll
-            for (int k = 0; k < D; ++k) if (k < d) base_t[(size_t)k * 64] = theta_t[(size_t)k * 64];
+            for (int k = 0; k < d; ++k) base_t[(size_t)k * 64] = theta_t[(size_t)k * 64];
             basecnt = curcount; winstart = (uint32_t)(it + 1);
         }
     } else if (mode & AD_AM) {                                        // MCMC_adapt.F90:105-159, adapthist <= 1
         docalc = true;
         if (mode & AD_FIRST) {
-            wsum = TIDX(E.scal, tile, NSCAL, S_WSUM, lane);           // = initcmatn (set at init, untouched so far)
             for (int e = 0; e < P; ++e) Ct[(size_t)e * 64] = E.cmat0p[e];
             for (int k = 0; k < d; ++k) mean_t[(size_t)k * 64] = E.par0[k];
         }
@@ -479,7 +533,6 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
             rows[(size_t)nr * 64] = (uint64_t)slot_prev | ((uint64_t)wr << 32);
             ++nr;
         }
-        // maximum row count over the wave
         int nrmax = nr;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { int other = __shfl_xor(nrmax, o); nrmax = other > nrmax ? other : nrmax; }
@@ -497,15 +550,15 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
                     for (int k = 0; k < D; ++k) if (k < d) { A[k] = src[(size_t)k * 64] - mean_t[(size_t)k * 64]; dl_t[(size_t)k * 64] = A[k]; }
                     double f1 = w3 / (wsum + w3 - 1.0);
                     double f2 = wsum / (wsum + w3);
-                    for (int b = 0; b < d; ++b) {
-                        double db = dl_t[(size_t)b * 64];
-                        double *colb = Ct + (size_t)(b * (b + 1) / 2) * 64;
+                    for (int a = 0; a < d; ++a) {             // row a of the upper triangle: elements (a, b >= a)
+                        double da = dl_t[(size_t)a * 64];
+                        double *rowa = Ct + (size_t)rowstart(a, d) * 64;
 #pragma unroll
-                        for (int a = 0; a < D; ++a) {
-                            if (a <= b) {
-                                double o = A[a] * db;
-                                double cab = colb[(size_t)a * 64];
-                                colb[(size_t)a * 64] = cab + f1 * (f2 * o - cab);
+                        for (int b = 0; b < D; ++b) {
+                            if (b >= a && b < d) {
+                                double o = da * A[b];
+                                double cab = rowa[(size_t)(b - a) * 64];
+                                rowa[(size_t)(b - a) * 64] = cab + f1 * (f2 * o - cab);
                             }
                         }
                     }
@@ -544,13 +597,13 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
                 if (act) {
 #pragma unroll
                     for (int k = 0; k < D; ++k) if (k < d) { A[k] = src[(size_t)k * 64] - B[k]; dl_t[(size_t)k * 64] = A[k]; }
-                    // cmat(i,j), j <= i: sum_r (x_ri - m_i) * ((x_rj - m_j) * w_r); stored at packed (j,i)
-                    for (int i = 0; i < d; ++i) {
-                        double xa = dl_t[(size_t)i * 64];
-                        double *coli = Ct + (size_t)(i * (i + 1) / 2) * 64;
+                    // reference: cmat(i,j), j <= i = sum_r (x_ri - m_i) * ((x_rj - m_j) * w_r); kept at packed (j,i)
+                    for (int j = 0; j < d; ++j) {
+                        double xb = dl_t[(size_t)j * 64] * w;
+                        double *rowj = Ct + (size_t)rowstart(j, d) * 64;
 #pragma unroll
-                        for (int j = 0; j < D; ++j) {
-                            if (j <= i) { double xb = A[j] * w; coli[(size_t)j * 64] = coli[(size_t)j * 64] + xa * xb; }
+                        for (int i = 0; i < D; ++i) {
+                            if (i >= j && i < d) rowj[(size_t)(i - j) * 64] = rowj[(size_t)(i - j) * 64] + A[i] * xb;
                         }
                     }
                 }
@@ -562,8 +615,7 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
         }
         // lastfreq = count of the current row; lastind = chainind -> window restarts here
         lastfreq = curcount;
-#pragma unroll
-        for (int k = 0; k < D; ++k) if (k < d) base_t[(size_t)k * 64] = theta_t[(size_t)k * 64];
+        for (int k = 0; k < d; ++k) base_t[(size_t)k * 64] = theta_t[(size_t)k * 64];
         basecnt = curcount; winstart = (uint32_t)(it + 1);
     }
 
@@ -582,8 +634,9 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
 }
 
 // ---------------------------------------------------------------- pooled moments of the current states
-// out[tile][1 + d + P] partial sums over the 64 lanes of a tile by an xor-butterfly (fixed pairwise tree);
-// the host (or an RCCL all-reduce across GPUs) finishes the sum.
+// out[tile][1 + d + d(d+1)/2]: partial sums over the 64 lanes of a tile by an xor-butterfly (a fixed
+// pairwise tree: adjacent lanes first); the host finishes the tree over tiles, RCCL over GPUs.
+// Second moments are indexed j(j+1)/2 + i for i <= j.
 __global__ __launch_bounds__(64) void moments_kernel(EngineDev E, double *out, int nchains)
 {
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d, P = E.P;
@@ -604,11 +657,10 @@ __global__ __launch_bounds__(64) void moments_kernel(EngineDev E, double *out, i
         for (int i = 0; i <= j; ++i) {
             double vi = act ? (theta_t[(size_t)i * 64] - E.par0[i]) : 0.0;
             double s2 = wsum64(vi * vj);
-            if (lane == 0) o[1 + d + pk(i, j)] = s2;
+            if (lane == 0) o[1 + d + j * (j + 1) / 2 + i] = s2;
         }
     }
 }
-
 
 // ---------------------------------------------------------------- debug probes of the device primitives
 // (tests/test_gpu_primitives.py compares them bit for bit with the oracle)
