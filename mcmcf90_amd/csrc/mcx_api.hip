@@ -78,15 +78,7 @@ static int dev_upload(mcmcx_engine *h, const T **p, const std::vector<T> &v)
     return 0;
 }
 
-// ------------------------------------------------------------------ kernel dispatch on the register-array size
-#define MCX_DISPATCH(h, CALL)                                                                     \
-    do {                                                                                          \
-        int d_ = (h)->d;                                                                          \
-        if (d_ <= 2) { CALL(2); } else if (d_ <= 4) { CALL(4); } else if (d_ <= 8) { CALL(8); }   \
-        else if (d_ <= 10) { CALL(10); } else if (d_ <= 16) { CALL(16); } else if (d_ <= 20) { CALL(20); } \
-        else if (d_ <= 32) { CALL(32); } else if (d_ <= 50) { CALL(50); } else { CALL(64); }      \
-    } while (0)
-static const int MCX_MAX_NPAR = 64;
+static const int MCX_MAX_NPAR = 256;      // d*512 B of LDS per wave: 160 KiB/CU holds d <= 320
 
 // dpotf2('U') + scaling on the host for the shared initial factor: same operation sequence as the
 // device's calculate_R (MCMC_calculate_R at MCMC_init.F90:109).  cm: col-major d*d, Rp: packed upper.
@@ -119,12 +111,13 @@ static int host_initial_R(int d, const std::vector<double> &cm, std::vector<doub
     return 0;
 }
 
-template <int D> static void launch_init(mcmcx_engine *h)
-{ hipLaunchKernelGGL(init_kernel<D>, dim3(h->ntiles), dim3(64), 0, h->stream, h->E); }
-template <int D> static void launch_step(mcmcx_engine *h, int it0, int it1)
-{ hipLaunchKernelGGL(step_kernel<D>, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it0, it1, h->d_ramscale + it0); }
-template <int D> static void launch_adapt(mcmcx_engine *h, int it, int mode)
-{ hipLaunchKernelGGL(adapt_kernel<D>, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it, mode); }
+static size_t lds_bytes(const mcmcx_engine *h) { return (size_t)h->d * 64 * sizeof(double); }
+static void launch_init(mcmcx_engine *h)
+{ hipLaunchKernelGGL(init_kernel, dim3(h->ntiles), dim3(64), lds_bytes(h), h->stream, h->E); }
+static void launch_step(mcmcx_engine *h, int it0, int it1)
+{ hipLaunchKernelGGL(step_kernel, dim3(h->ntiles), dim3(64), lds_bytes(h), h->stream, h->E, it0, it1, h->d_ramscale + it0); }
+static void launch_adapt(mcmcx_engine *h, int it, int mode)
+{ hipLaunchKernelGGL(adapt_kernel, dim3(h->ntiles), dim3(64), lds_bytes(h), h->stream, h->E, it, mode); }
 
 // Which branch of MCMC_adapt fires at iteration `it` (0 = none).  MCMC_adapt.F90:42-46, 60-61, 105.
 static int adapt_mode(const mcmcx_config &c, int it)
@@ -438,8 +431,7 @@ int mcmcx_init(mcmcx_handle h)
         }
         HIPCHK(hipStreamSynchronize(h->stream));
     }
-#define CALL_INIT(DD) launch_init<DD>(h)
-    MCX_DISPATCH(h, CALL_INIT);
+    launch_init(h);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     h->simuind = 1;
@@ -465,15 +457,13 @@ int mcmcx_run(mcmcx_handle h, int32_t upto)
         hipEvent_t e0, e1;
         HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
         HIPCHK(hipEventRecord(e0, h->stream));
-#define CALL_STEP(DD) launch_step<DD>(h, it, end)
-        MCX_DISPATCH(h, CALL_STEP);
+        launch_step(h, it, end);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(e1, h->stream));
         h->pending.emplace_back(e0, e1);
         h->launches += 1; h->steps += (end - it + 1);
         if (mode != 0) {
-#define CALL_ADAPT(DD) launch_adapt<DD>(h, end, mode)
-            MCX_DISPATCH(h, CALL_ADAPT);
+            launch_adapt(h, end, mode);
             HIPCHK(hipGetLastError());
         }
         it = end + 1;

@@ -5,9 +5,9 @@
 //     element k of chain (tile, lane)  ->  base[(tile*K + k)*64 + lane],
 // i.e. parameter-major inside a tile, so every wave access is one contiguous
 // 512-byte segment and a tile's whole Cholesky factor is one sequential stream.
-// One per-lane d-vector lives in a VGPR array with compile-time indices; the O(d^2) loops are
-// "runtime row index, unrolled column index" with the row's elements loaded 8 at a time, so a
-// wave always has several independent 512-byte loads in flight.
+// The one per-lane d-vector a wave needs (proposal, rotation work vector, ...) lives in LDS as
+// X[j][lane]; the O(d^2) loops are plain row sweeps with the row's elements loaded 8 at a time, so
+// a wave always has several independent 512-byte loads in flight.  Nothing is templated on d.
 #pragma once
 #include "mcx_device.hpp"
 
@@ -65,96 +65,73 @@ struct EngineDev {
 MCX_DEV int rowstart(int i, int d) { return i * d - (i * (i - 1)) / 2; }
 MCX_DEV int pidx(int i, int j, int d) { return rowstart(i, d) + (j - i); }
 
-constexpr int CH = 8;     // row elements loaded per batch (8 x 512 B in flight per wave and batch)
+constexpr int CH = 8;     // row elements loaded per batch: 8 independent 512-byte wave loads in flight
 
-// Visit row i of a packed factor: the elements j0..j0+CH-1 of each chunk that reaches the row are
-// loaded together (clamped addresses, unconditional), then f(j, r, valid, interior) runs per element
-// with a compile-time j.  interior == true: the whole chunk is strictly right of the diagonal and
-// inside d, so the body needs no predication.
-template <int D, typename F>
-MCX_DEV void sweep_row(int i, int d, const double *rowp, F &&f)
-{
-    constexpr int NCH = (D + CH - 1) / CH;
-    const int m = d - 1 - i;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int j0 = c * CH;
-        if (j0 + CH - 1 >= i && j0 < d) {
-            double r[CH];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                int o = j0 + u - i; o = o < 0 ? 0 : o; o = o > m ? m : o;
-                r[u] = rowp[(size_t)o * 64];
-            }
-            if (j0 > i && j0 + CH <= d) {
-#pragma unroll
-                for (int u = 0; u < CH; ++u) if (j0 + u < D) f(j0 + u, r[u], true, true);
-            } else {
-#pragma unroll
-                for (int u = 0; u < CH; ++u) if (j0 + u < D) f(j0 + u, r[u], (j0 + u >= i) && (j0 + u < d), false);
-            }
-        }
-    }
-}
+// The one per-lane d-vector of a wave lives in LDS as X[j*64 + lane] (conflict-free ds_read/write_b64).
+#define XL(j) X[(j) * 64 + lane]
+// element k of a tile-interleaved global vector whose tile base is `p` (uniform pointer)
+#define GV(p, k) (p)[(size_t)(k) * 64 + lane]
 
 // ---------------------------------------------------------------- targets (user ssfunction / priorfun / checkbounds)
-// th[] holds the candidate on entry and (th - mu) on exit for the Gaussian target; cand_t is the
-// same candidate in global scratch (element stride 64), used for the few runtime-indexed reads.
-template <int D>
-MCX_DEV double target_ss(const DevTarget &t, int d, double (&th)[D], const double *cand_t)
+// X holds the candidate on entry; the Gaussian target overwrites it with (theta - mu).
+MCX_DEV double target_ss(const DevTarget &t, int d, double *X, int lane, const double *cand_t)
 {
     double ss = 0.0;
     if (t.kind == TGT_GAUSS) {
         // ss = (th-mu)' Lam (th-mu): y_i = sum_j lam(i,j) v_j ascending (fma chain), ss = sum_i y_i v_i (fma chain)
-#pragma unroll
-        for (int j = 0; j < D; ++j) if (j < d) th[j] = th[j] - t.mu[j];
-        for (int i = 0; i < d; ++i) {
-            const double *__restrict__ row = t.lam + (size_t)i * d;
-            double y = 0.0;
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-                if (j < d) { if (j == 0) y = row[0] * th[0]; else y = dfma(row[j], th[j], y); }
+        for (int j = 0; j < d; ++j) XL(j) = XL(j) - t.mu[j];
+        int i = 0;
+        for (; i + 4 <= d; i += 4) {               // four rows per pass over v: one LDS read feeds four chains
+            const double *__restrict__ r0 = t.lam + (size_t)i * d, *__restrict__ r1 = r0 + d, *__restrict__ r2 = r1 + d, *__restrict__ r3 = r2 + d;
+            double v0 = XL(0);
+            double y0 = r0[0] * v0, y1 = r1[0] * v0, y2 = r2[0] * v0, y3 = r3[0] * v0;
+            for (int j = 1; j < d; ++j) {
+                double v = XL(j);
+                y0 = dfma(r0[j], v, y0); y1 = dfma(r1[j], v, y1); y2 = dfma(r2[j], v, y2); y3 = dfma(r3[j], v, y3);
             }
-            double vi = cand_t[(size_t)i * 64] - t.mu[i];
-            if (i == 0) ss = y * vi; else ss = dfma(y, vi, ss);
+            if (i == 0) ss = y0 * XL(0); else ss = dfma(y0, XL(i), ss);
+            ss = dfma(y1, XL(i + 1), ss); ss = dfma(y2, XL(i + 2), ss); ss = dfma(y3, XL(i + 3), ss);
+        }
+        for (; i < d; ++i) {
+            const double *__restrict__ row = t.lam + (size_t)i * d;
+            double y = row[0] * XL(0);
+            for (int j = 1; j < d; ++j) y = dfma(row[j], XL(j), y);
+            if (i == 0) ss = y * XL(0); else ss = dfma(y, XL(i), ss);
         }
     } else if (t.kind == TGT_BANANA) {
-        double t1 = th[0] * th[0];
-        double q = dfma(t.b, t1, th[D > 1 ? 1 : 0]) - 100.0 * t.b;
+        double th0 = XL(0), th1 = XL(1);
+        double t1 = th0 * th0;
+        double q = dfma(t.b, t1, th1) - 100.0 * t.b;
         ss = dfma(q, q, t1 / 100.0);
-#pragma unroll
-        for (int k = 2; k < D; ++k) if (k < d) ss = dfma(th[k], th[k], ss);
+        for (int k = 2; k < d; ++k) { double v = XL(k); ss = dfma(v, v, ss); }
     } else {
+        double th0 = XL(0), th1 = XL(1);
         for (int i = 0; i < t.ndata; ++i) {
-            double r = t.y[i] - th[0] * d_exp(-(th[D > 1 ? 1 : 0] * t.x[i]));
+            double r = t.y[i] - th0 * d_exp(-(th1 * t.x[i]));
             ss = dfma(r, r, ss);
         }
     }
+    (void)cand_t;
     return ss;
 }
 
-template <int D>
-MCX_DEV double target_prior(const DevTarget &t, int d, const double (&th)[D])
+MCX_DEV double target_prior(const DevTarget &t, int d, const double *X, int lane)
 {
     double p = 0.0;
     if (t.pmu) {
-#pragma unroll
-        for (int i = 0; i < D; ++i)
-            if (i < d) { double sg = t.psig[i]; if (sg > 0.0) { double q = (th[i] - t.pmu[i]) / sg; p = p + q * q; } }
+        for (int i = 0; i < d; ++i) {
+            double sg = t.psig[i];
+            if (sg > 0.0) { double q = (XL(i) - t.pmu[i]) / sg; p = p + q * q; }
+        }
     }
     return p;
 }
 
-template <int D>
-MCX_DEV bool target_inbounds(const DevTarget &t, int d, const double (&th)[D])
+MCX_DEV bool target_inbounds(const DevTarget &t, int d, const double *X, int lane)
 {
     bool ok = true;
-#pragma unroll
-    for (int i = 0; i < D; ++i)
-        if (i < d) {
-            if (t.lo) ok = ok && (th[i] > t.lo[i]);
-            if (t.hi) ok = ok && (th[i] < t.hi[i]);
-        }
+    if (t.lo) for (int i = 0; i < d; ++i) ok = ok && (XL(i) > t.lo[i]);
+    if (t.hi) for (int i = 0; i < d; ++i) ok = ok && (XL(i) < t.hi[i]);
     return ok;
 }
 
@@ -162,17 +139,17 @@ MCX_DEV bool target_inbounds(const DevTarget &t, int d, const double (&th)[D])
 // Each lane appends accepted polar pairs to its own column of zs (global scratch, element stride 64)
 // until it has d deviates; the wave loops until every participating lane is done.  The cached
 // second deviate of normal_bm is honoured and left behind when d is odd.
-MCX_DEV void gen_normals(Rng &g, double *zs_t, int d, bool participate)
+MCX_DEV void gen_normals(Rng &g, double *zs_t, int lane, int d, bool participate)
 {
     int k = 0;
-    if (participate && g.saved && d > 0) { zs_t[0] = g.saved_y; g.saved = 0; k = 1; }
+    if (participate && g.saved && d > 0) { GV(zs_t, 0) = g.saved_y; g.saved = 0; k = 1; }
     bool need = participate && (k < d);
     while (__any(need)) {
         if (need) {
             double a, b;
             if (polar_try(g, a, b)) {
-                zs_t[(size_t)k * 64] = a; ++k;
-                if (k < d) { zs_t[(size_t)k * 64] = b; ++k; }
+                GV(zs_t, k) = a; ++k;
+                if (k < d) { GV(zs_t, k) = b; ++k; }
                 else { g.saved_y = b; g.saved = 1; }
             }
             need = (k < d);
@@ -180,102 +157,101 @@ MCX_DEV void gen_normals(Rng &g, double *zs_t, int d, bool participate)
     }
 }
 
-// ---------------------------------------------------------------- proposal: P = R'z  (MCMC_DRAM.F90:20-31)
+// ---------------------------------------------------------------- proposal: X = R'z  (MCMC_DRAM.F90:20-31)
 // dtrmv('U','T','N') (matutils.F90:108-109) in netlib accumulation order: p_j = z_j R(j,j), then
 // + R(i,j) z_i for i = j-1..0 as an fma chain -- which is what a sweep over rows i = d-1..0 produces.
-template <int D>
-MCX_DEV void trmv_rows(const double *Rt, const double *zs_t, int d, double (&P)[D])
+MCX_DEV void trmv_rows(const double *Rt, const double *zs_t, int lane, int d, double *X)
 {
     for (int i = d - 1; i >= 0; --i) {
-        const double zi = zs_t[(size_t)i * 64];
-        const double *rowp = Rt + (size_t)rowstart(i, d) * 64;
-        sweep_row<D>(i, d, rowp, [&](int j, double r, bool valid, bool interior) {
-            if (interior) P[j] = dfma(r, zi, P[j]);
-            else {
-                double nv = (j == i) ? zi * r : dfma(r, zi, P[j]);
-                P[j] = valid ? nv : P[j];
-            }
-        });
+        const double zi = GV(zs_t, i);
+        const double *rowp = Rt + (size_t)rowstart(i, d) * 64;       // element (i, i+k) at rowp[k]
+        const int n = d - i;
+        double rd = GV(rowp, 0);
+        int k = 1;
+        for (; k + CH <= n; k += CH) {
+            double r[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) r[u] = GV(rowp, k + u);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) XL(i + k + u) = dfma(r[u], zi, XL(i + k + u));
+        }
+        for (; k < n; ++k) XL(i + k) = dfma(GV(rowp, k), zi, XL(i + k));
+        XL(i) = zi * rd;
     }
 }
 
 // ---------------------------------------------------------------- RAM rank-1 adaptation (MCMC_run_ram.F90:104-179)
 // a >= 0: cholupdate = DCHUD (dchud.f:122-139); a < 0: choldowndate = DCHDD (dchdd.f:141-179), both
 // restated row by row (same operations on every element, in the same order per column).
-// X is the one per-lane register array; cs_t is global scratch for the downdate's rotations.
-template <int D>
-MCX_DEV void ram_update(double *Rt, const double *zs_t, double *cs_t, int d, double a, bool act,
-                        double (&X)[D], uint32_t &status)
+MCX_DEV void ram_update(double *Rt, const double *zs_t, double *cs_t, int lane, int d, double a, bool act,
+                        double *X, uint32_t &status)
 {
     double su = 0.0;
-#pragma unroll
-    for (int k = 0; k < D; ++k) if (k < d) { X[k] = zs_t[(size_t)k * 64]; }
-#pragma unroll
-    for (int k = 0; k < D; ++k) if (k < d) { su = su + X[k] * X[k]; }
+    for (int k = 0; k < d; ++k) { double zk = GV(zs_t, k); su = su + zk * zk; }
     const bool up = act && (a >= 0.0);
     const bool down = act && !(a >= 0.0);
     if (__any(up)) {
         if (up) {
-#pragma unroll
-            for (int k = 0; k < D; ++k) if (k < d) X[k] = X[k] / su * a;          // x = u/sum(u**2) * a
-            double xdiag = X[0];
+            for (int k = 0; k < d; ++k) XL(k) = GV(zs_t, k) / su * a;          // x = u/sum(u**2) * a
             for (int i = 0; i < d; ++i) {
                 double *rowp = Rt + (size_t)rowstart(i, d) * 64;
+                const int n = d - i;
                 double r, c, s;
-                d_rotg(rowp[0], xdiag, r, c, s);
-                rowp[0] = r;
-                sweep_row<D>(i, d, rowp, [&](int j, double rij, bool valid, bool interior) {
-                    if (interior) {
-                        double t = c * rij + s * X[j];
-                        X[j] = c * X[j] - s * rij;
-                        rowp[(size_t)(j - i) * 64] = t;
-                        if ((j % CH) == 0) xdiag = (j == i + 1) ? X[j] : xdiag;
-                    } else {
-                        const bool off = valid && (j > i);
-                        double t = c * rij + s * X[j];
-                        double nx = c * X[j] - s * rij;
-                        X[j] = off ? nx : X[j];
-                        if (off) rowp[(size_t)(j - i) * 64] = t;
-                        xdiag = (off && j == i + 1) ? X[j] : xdiag;
+                d_rotg(GV(rowp, 0), XL(i), r, c, s);
+                GV(rowp, 0) = r;
+                int k = 1;
+                for (; k + CH <= n; k += CH) {
+                    double rr[CH];
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) rr[u] = GV(rowp, k + u);
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) {
+                        double xj = XL(i + k + u);
+                        double t = c * rr[u] + s * xj;
+                        XL(i + k + u) = c * xj - s * rr[u];
+                        GV(rowp, k + u) = t;
                     }
-                });
+                }
+                for (; k < n; ++k) {
+                    double rij = GV(rowp, k), xj = XL(i + k);
+                    double t = c * rij + s * xj;
+                    XL(i + k) = c * xj - s * rij;
+                    GV(rowp, k) = t;
+                }
             }
         }
     }
     if (__any(down)) {
         if (down) {
-            // solve R'a = x, x = -u/sum(u**2)*a (dchdd.f:141-148); slot j of X is the running dot of column j
-            // until row j, then the solution s_j
-            const double fac = a;
-            double accdiag = 0.0;
-#pragma unroll
-            for (int k = 0; k < D; ++k) if (k < d) X[k] = 0.0;
+            // solve R'a = x, x = -u/sum(u**2)*a (dchdd.f:141-148): X[j] is the running dot of column j until
+            // row j, then the solution s_j
+            for (int k = 0; k < d; ++k) XL(k) = 0.0;
             for (int i = 0; i < d; ++i) {
                 const double *rowp = Rt + (size_t)rowstart(i, d) * 64;
-                double xi = -(zs_t[(size_t)i * 64] / su * fac);
-                double si = xi - accdiag;
-                si = si / rowp[0];
-                sweep_row<D>(i, d, rowp, [&](int j, double rij, bool valid, bool interior) {
-                    if (interior) {
-                        X[j] = dfma(rij, si, X[j]);
-                        if ((j % CH) == 0) accdiag = (j == i + 1) ? X[j] : accdiag;
-                    } else {
-                        const bool off = valid && (j > i);
-                        double na = dfma(rij, si, X[j]);
-                        X[j] = off ? na : ((valid && j == i) ? si : X[j]);
-                        accdiag = (off && j == i + 1) ? X[j] : accdiag;
-                    }
-                });
+                const int n = d - i;
+                double xi = -(GV(zs_t, i) / su * a);
+                double si = xi - XL(i);
+                si = si / GV(rowp, 0);
+                XL(i) = si;
+                int k = 1;
+                for (; k + CH <= n; k += CH) {
+                    double rr[CH];
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) rr[u] = GV(rowp, k + u);
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) XL(i + k + u) = dfma(rr[u], si, XL(i + k + u));
+                }
+                for (; k < n; ++k) XL(i + k) = dfma(GV(rowp, k), si, XL(i + k));
             }
             // norm = dnrm2(p, s), classic scale/ssq form (dchdd.f:149)
             double norm;
-            if (d == 1) norm = fabs(X[0]);
+            if (d == 1) norm = fabs(XL(0));
             else {
                 double scale = 0.0, ssq = 1.0;
-#pragma unroll
-                for (int k = 0; k < D; ++k) {
-                    if (k < d && X[k] != 0.0) {
-                        double ax = fabs(X[k]);
+                for (int k = 0; k < d; ++k) {
+                    double xk = XL(k);
+                    if (xk != 0.0) {
+                        double ax = fabs(xk);
                         if (scale < ax) { double q = scale / ax; ssq = 1.0 + ssq * (q * q); scale = ax; }
                         else { double q = ax / scale; ssq = ssq + q * q; }
                     }
@@ -286,30 +262,39 @@ MCX_DEV void ram_update(double *Rt, const double *zs_t, double *cs_t, int d, dou
                 status |= ST_RAM_DOWNDATE_FAIL;      // INFO = -1: R untouched (the reference stops here)
             } else {
                 double alpha = sqrt(1.0 - norm * norm);
-#pragma unroll
-                for (int k = D - 1; k >= 0; --k) {   // dchdd.f:158-167
-                    if (k < d) {
-                        double scale = alpha + fabs(X[k]);
-                        double aa = alpha / scale, bb = X[k] / scale;
-                        double nn = sqrt(aa * aa + bb * bb);
-                        cs_t[(size_t)(2 * k) * 64] = aa / nn;
-                        cs_t[(size_t)(2 * k + 1) * 64] = bb / nn;
-                        alpha = scale * nn;
-                    }
+                for (int k = d - 1; k >= 0; --k) {   // dchdd.f:158-167
+                    double sk = XL(k);
+                    double scale = alpha + fabs(sk);
+                    double aa = alpha / scale, bb = sk / scale;
+                    double nn = sqrt(aa * aa + bb * bb);
+                    GV(cs_t, 2 * k) = aa / nn;
+                    GV(cs_t, 2 * k + 1) = bb / nn;
+                    alpha = scale * nn;
+                    XL(k) = 0.0;                     // becomes xx of column k
                 }
-#pragma unroll
-                for (int k = 0; k < D; ++k) if (k < d) X[k] = 0.0;          // xx of every column
-                double cn = cs_t[(size_t)(2 * (d - 1)) * 64], sn = cs_t[(size_t)(2 * (d - 1) + 1) * 64];
                 for (int i = d - 1; i >= 0; --i) {   // dchdd.f:171-179, rows d-1..0
                     double *rowp = Rt + (size_t)rowstart(i, d) * 64;
-                    const double ci = cn, si = sn;
-                    if (i > 0) { cn = cs_t[(size_t)(2 * (i - 1)) * 64]; sn = cs_t[(size_t)(2 * (i - 1) + 1) * 64]; }
-                    sweep_row<D>(i, d, rowp, [&](int j, double rij, bool valid, bool interior) {
-                        double t = ci * X[j] + si * rij;
-                        double nr = ci * rij - si * X[j];
-                        if (interior) { rowp[(size_t)(j - i) * 64] = nr; X[j] = t; }
-                        else { if (valid) rowp[(size_t)(j - i) * 64] = nr; X[j] = valid ? t : X[j]; }
-                    });
+                    const int n = d - i;
+                    const double ci = GV(cs_t, 2 * i), si = GV(cs_t, 2 * i + 1);
+                    int k = 0;
+                    for (; k + CH <= n; k += CH) {
+                        double rr[CH];
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) rr[u] = GV(rowp, k + u);
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) {
+                            double xx = XL(i + k + u);
+                            double t = ci * xx + si * rr[u];
+                            GV(rowp, k + u) = ci * rr[u] - si * xx;
+                            XL(i + k + u) = t;
+                        }
+                    }
+                    for (; k < n; ++k) {
+                        double rij = GV(rowp, k), xx = XL(i + k);
+                        double t = ci * xx + si * rij;
+                        GV(rowp, k) = ci * rij - si * xx;
+                        XL(i + k) = t;
+                    }
                 }
             }
         }
@@ -318,17 +303,16 @@ MCX_DEV void ram_update(double *Rt, const double *zs_t, double *cs_t, int d, dou
 
 // ---------------------------------------------------------------- the step kernel
 // Iterations it0..it1 (absolute simuind) of MCMC_run (MCMC_run.F90:41-107, no DR stage here)
-// or MCMC_run_ram (MCMC_run_ram.F90:45-81) for one tile of 64 chains.
-template <int D>
+// or MCMC_run_ram (MCMC_run_ram.F90:45-81) for one tile of 64 chains.  Dynamic LDS: d*64 doubles.
 __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ ramscale)
 {
+    extern __shared__ double X[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
-    const double *theta_t = E.theta + (size_t)tile * d * 64 + lane;
-    double *theta_w = E.theta + (size_t)tile * d * 64 + lane;
-    double *cand_t = E.cand + (size_t)tile * d * 64 + lane;
-    double *zs_t = E.zs + (size_t)tile * d * 64 + lane;
-    double *cs_t = E.cs + (size_t)tile * 2 * d * 64 + lane;
-    double *Rt = E.R + (size_t)tile * E.P * 64 + lane;
+    double *theta_t = E.theta + (size_t)tile * d * 64;
+    double *cand_t = E.cand + (size_t)tile * d * 64;
+    double *zs_t = E.zs + (size_t)tile * d * 64;
+    double *cs_t = E.cs + (size_t)tile * 2 * d * 64;
+    double *Rt = E.R + (size_t)tile * E.P * 64;
 
     Rng g;
     g.k0 = E.k0; g.k1 = E.chain_id0 + (uint32_t)(tile * 64 + lane);
@@ -341,20 +325,15 @@ __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1,
     uint32_t chainind = TIDX(E.ictr, tile, NICTR, I_CHAININD, lane), curcount = TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane);
     uint32_t status = TIDX(E.ictr, tile, NICTR, I_STATUS, lane);
 
-    double V[D];
-
     for (int it = it0; it <= it1; ++it) {
         // ---- newpar = MCMC_propose(oldpar, R)
-        gen_normals(g, zs_t, d, true);
-#pragma unroll
-        for (int k = 0; k < D; ++k) V[k] = 0.0;
-        trmv_rows<D>(Rt, zs_t, d, V);
-#pragma unroll
-        for (int k = 0; k < D; ++k) if (k < d) { V[k] = theta_t[(size_t)k * 64] + V[k]; cand_t[(size_t)k * 64] = V[k]; }
+        gen_normals(g, zs_t, lane, d, true);
+        trmv_rows(Rt, zs_t, lane, d, X);
+        for (int k = 0; k < d; ++k) { double v = GV(theta_t, k) + XL(k); XL(k) = v; GV(cand_t, k) = v; }
         // ---- bounds, prior, ss, alpha, reject
-        bool inb = target_inbounds<D>(E.tgt, d, V);
-        double pri2 = target_prior<D>(E.tgt, d, V);
-        double ss2 = target_ss<D>(E.tgt, d, V, cand_t);
+        bool inb = target_inbounds(E.tgt, d, X, lane);
+        double pri2 = target_prior(E.tgt, d, X, lane);
+        double ss2 = target_ss(E.tgt, d, X, lane, cand_t);
         bool reject;
         if (!inb) {
             bnd += 1; reject = true;
@@ -375,19 +354,14 @@ __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1,
         // ---- oldpar = newpar; MCMC_savechain (MCMC_aux.F90:167-185): accept ballot + accepted row into the ring
         unsigned long long ballot = __ballot(!reject);
         const int slot = it % E.wcap;
-        if (ballot != 0ull) {
-#pragma unroll
-            for (int k = 0; k < D; ++k) if (k < d) V[k] = cand_t[(size_t)k * 64];
-            if (!reject) {
-#pragma unroll
-                for (int k = 0; k < D; ++k) if (k < d) theta_w[(size_t)k * 64] = V[k];
-                if (E.hist) {
-                    double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64 + lane;
-#pragma unroll
-                    for (int k = 0; k < D; ++k) if (k < d) h[(size_t)k * 64] = V[k];
-                    h[(size_t)d * 64] = ss1;
-                }
+        if (!reject) {
+            double *h = E.hist ? E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64 : nullptr;
+            for (int k = 0; k < d; ++k) {
+                double v = GV(cand_t, k);
+                GV(theta_t, k) = v;
+                if (h) GV(h, k) = v;
             }
+            if (h) GV(h, d) = ss1;
         }
         if (E.hist) {
             if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ballot;
@@ -397,7 +371,7 @@ __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1,
         // ---- MCMC_adapt_ram
         if (E.method == M_RAM && E.doadapt != 0 && !(it < E.burnintime && E.doburnin != 0)) {
             double a = ramscale[it - it0] * (alpha12 - E.alphatarget);
-            ram_update<D>(Rt, zs_t, cs_t, d, a, true, V, status);
+            ram_update(Rt, zs_t, cs_t, lane, d, a, true, X, status);
         }
     }
 
@@ -412,29 +386,27 @@ __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1,
 }
 
 // ---------------------------------------------------------------- first point (MCMC_run.F90:33-39)
-template <int D>
 __global__ __launch_bounds__(64) void init_kernel(EngineDev E)
 {
+    extern __shared__ double X[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
-    double *theta_t = E.theta + (size_t)tile * d * 64 + lane;
-    double *cand_t = E.cand + (size_t)tile * d * 64 + lane;
-    double V[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) if (k < d) { V[k] = theta_t[(size_t)k * 64]; cand_t[(size_t)k * 64] = V[k]; }
-    double pri1 = target_prior<D>(E.tgt, d, V);
-    double ss1 = target_ss<D>(E.tgt, d, V, cand_t);
+    double *theta_t = E.theta + (size_t)tile * d * 64;
+    double *cand_t = E.cand + (size_t)tile * d * 64;
+    for (int k = 0; k < d; ++k) { double v = GV(theta_t, k); XL(k) = v; GV(cand_t, k) = v; }
+    double pri1 = target_prior(E.tgt, d, X, lane);
+    double ss1 = target_ss(E.tgt, d, X, lane, cand_t);
     TIDX(E.scal, tile, NSCAL, S_SS1, lane) = ss1; TIDX(E.scal, tile, NSCAL, S_PRI1, lane) = pri1;
     // row 1 of the chain: iteration 1 counts as accepted
     const int slot = 1 % E.wcap;
     if (E.hist) {
-        double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64 + lane;
-        for (int k = 0; k < d; ++k) h[(size_t)k * 64] = theta_t[(size_t)k * 64];
-        h[(size_t)d * 64] = ss1;
+        double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64;
+        for (int k = 0; k < d; ++k) GV(h, k) = GV(theta_t, k);
+        GV(h, d) = ss1;
         if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ~0ull;
         if (E.record_s2) E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = TIDX(E.scal, tile, NSCAL, S_SIGMA2, lane);
     }
     if (E.accmask && lane == 0) E.accmask[tile] = ~0ull;
-    for (int k = 0; k < d; ++k) TIDX(E.basetheta, tile, d, k, lane) = theta_t[(size_t)k * 64];
+    for (int k = 0; k < d; ++k) TIDX(E.basetheta, tile, d, k, lane) = GV(theta_t, k);
 }
 
 // ---------------------------------------------------------------- MCMC_adapt (MCMC_adapt.F90:12-174) at a tick
@@ -443,77 +415,74 @@ enum { AD_BURN = 1, AD_AM = 2, AD_FIRST = 4 };
 
 // dpotf2('U') on the packed matrix in Ct (holds C on entry, the factor on exit), then commit
 // R = R0*2.4/sqrt(d) (MCMC_calculate_R, MCMC_adapt.F90:181-230, Cholesky path).  Returns info.
-template <int D>
-MCX_DEV int calculate_R(double *Ct, double *Rt, int d, int P, bool act, double (&A)[D])
+// X (LDS) holds column j above the diagonal while row j is formed.
+MCX_DEV int calculate_R(double *Ct, double *Rt, int lane, int d, int P, bool act, double *X)
 {
     int info = 0;
     for (int j = 0; j < d; ++j) {
         double dot = 0.0;
-#pragma unroll
-        for (int i = 0; i < D; ++i) if (i < j) { A[i] = Ct[(size_t)pidx(i, j, d) * 64]; dot = dfma(A[i], A[i], dot); }
+        for (int i = 0; i < j; ++i) { double v = GV(Ct, pidx(i, j, d)); XL(i) = v; dot = dfma(v, v, dot); }
         double *rowj = Ct + (size_t)rowstart(j, d) * 64;
-        double ajj = rowj[0] - dot;
+        double ajj = GV(rowj, 0) - dot;
         bool ok = (ajj > 0.0);
         if (act && info == 0 && !ok) { info = j + 1; }
         bool go = act && info == 0;
         double rj = sqrt(ajj);
-        if (go) rowj[0] = rj;
+        if (go) GV(rowj, 0) = rj;
         double rinv = 1.0 / rj;
         for (int k = j + 1; k < d; ++k) {
             if (go) {
                 double t = 0.0;
-#pragma unroll
-                for (int i = 0; i < D; ++i) if (i < j) t = dfma(Ct[(size_t)pidx(i, k, d) * 64], A[i], t);
-                rowj[(size_t)(k - j) * 64] = (rowj[(size_t)(k - j) * 64] - t) * rinv;
+                for (int i = 0; i < j; ++i) t = dfma(GV(Ct, pidx(i, k, d)), XL(i), t);
+                GV(rowj, k - j) = (GV(rowj, k - j) - t) * rinv;
             }
         }
     }
     if (act && info == 0) {
         double sq = sqrt((double)d);
-        for (int e = 0; e < P; ++e) Rt[(size_t)e * 64] = Ct[(size_t)e * 64] * 2.4 / sq;
+        for (int e = 0; e < P; ++e) GV(Rt, e) = GV(Ct, e) * 2.4 / sq;
     }
     return info;
 }
 
-template <int D>
 __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode)
 {
+    extern __shared__ double X[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d, P = E.P;
-    double *Rt = E.R + (size_t)tile * P * 64 + lane;
-    double *Ct = E.cmat + (size_t)tile * P * 64 + lane;
-    double *Tt = E.Rtmp + (size_t)tile * P * 64 + lane;
-    double *mean_t = E.mean + (size_t)tile * d * 64 + lane;
-    double *base_t = E.basetheta + (size_t)tile * d * 64 + lane;
-    double *theta_t = E.theta + (size_t)tile * d * 64 + lane;
-    double *dl_t = E.cand + (size_t)tile * d * 64 + lane;            // scratch for the centred row
-    uint64_t *rows = E.rowlist + (size_t)tile * (E.wcap + 1) * 64 + lane;
+    double *Rt = E.R + (size_t)tile * P * 64;
+    double *Ct = E.cmat + (size_t)tile * P * 64;
+    double *Tt = E.Rtmp + (size_t)tile * P * 64;
+    double *mean_t = E.mean + (size_t)tile * d * 64;
+    double *base_t = E.basetheta + (size_t)tile * d * 64;
+    double *theta_t = E.theta + (size_t)tile * d * 64;
+    double *m2_t = E.cand + (size_t)tile * d * 64;                 // scratch: xmean2 of the batch branch
+    uint64_t *rows = E.rowlist + (size_t)tile * (E.wcap + 1) * 64;
     uint32_t stayed = TIDX(E.ictr, tile, NICTR, I_STAYED, lane);
     uint32_t curcount = TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane);
     uint32_t lastfreq = TIDX(E.ictr, tile, NICTR, I_LASTFREQ, lane);
     uint32_t basecnt = TIDX(E.ictr, tile, NICTR, I_BASECNT, lane);
     uint32_t winstart = TIDX(E.ictr, tile, NICTR, I_WINSTART, lane);
     double wsum = TIDX(E.scal, tile, NSCAL, S_WSUM, lane);
-    double A[D], B[D];
     bool docalc = false;          // lanes that go on to MCMC_calculate_R
 
     if (mode & AD_BURN) {                                             // MCMC_adapt.F90:60-102
         double staypc = (double)stayed / (double)it;
         double sf = E.scalefactor;
         if (staypc > 1.0 - E.scalelimit) {
-            for (int e = 0; e < P; ++e) Rt[(size_t)e * 64] = Rt[(size_t)e * 64] / sf;
+            for (int e = 0; e < P; ++e) GV(Rt, e) = GV(Rt, e) / sf;
         } else if (staypc < E.scalelimit) {
-            for (int e = 0; e < P; ++e) Rt[(size_t)e * 64] = Rt[(size_t)e * 64] * sf;
+            for (int e = 0; e < P; ++e) GV(Rt, e) = GV(Rt, e) * sf;
         } else {
             // lastind = chainind: the covariance window restarts at the current row (lastfreq is NOT touched)
             docalc = true;
-            for (int k = 0; k < d; ++k) base_t[(size_t)k * 64] = theta_t[(size_t)k * 64];
+            for (int k = 0; k < d; ++k) GV(base_t, k) = GV(theta_t, k);
             basecnt = curcount; winstart = (uint32_t)(it + 1);
         }
     } else if (mode & AD_AM) {                                        // MCMC_adapt.F90:105-159, adapthist <= 1
         docalc = true;
         if (mode & AD_FIRST) {
-            for (int e = 0; e < P; ++e) Ct[(size_t)e * 64] = E.cmat0p[e];
-            for (int k = 0; k < d; ++k) mean_t[(size_t)k * 64] = E.par0[k];
+            for (int e = 0; e < P; ++e) GV(Ct, e) = E.cmat0p[e];
+            for (int k = 0; k < d; ++k) GV(mean_t, k) = E.par0[k];
         }
         // ---- phase 1: rows of chain(lastind:chainind) and their weights, from the accept ballots
         int nr = 0;
@@ -525,103 +494,100 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
                 unsigned long long m = E.wacc[(size_t)tile * E.wcap + slot];
                 if ((m >> lane) & 1ull) {
                     uint32_t wr = (nr == 0) ? (w - lastfreq) : w;
-                    rows[(size_t)nr * 64] = (uint64_t)slot_prev | ((uint64_t)wr << 32);
+                    GV(rows, nr) = (uint64_t)slot_prev | ((uint64_t)wr << 32);
                     ++nr; slot_prev = (uint32_t)slot; w = 1;
                 } else w += 1;
             }
             uint32_t wr = (nr == 0) ? (w - lastfreq) : w;
-            rows[(size_t)nr * 64] = (uint64_t)slot_prev | ((uint64_t)wr << 32);
+            GV(rows, nr) = (uint64_t)slot_prev | ((uint64_t)wr << 32);
             ++nr;
         }
         int nrmax = nr;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { int other = __shfl_xor(nrmax, o); nrmax = other > nrmax ? other : nrmax; }
+        const double *hist_t = E.hist + (size_t)tile * E.wcap * (size_t)(d + 1) * 64;
 
         if (wsum > 0.0) {
             // ---- covmat(update=.true.): weighted Welford, one row at a time (matutils.F90:283-310)
             for (int r = 0; r < nrmax; ++r) {
                 bool act = r < nr;
-                uint64_t e = act ? rows[(size_t)r * 64] : 0ull;
+                uint64_t e = act ? GV(rows, r) : 0ull;
                 uint32_t slot = (uint32_t)e; double w3 = (double)(uint32_t)(e >> 32);
-                const double *src = (slot == 0xffffffffu) ? base_t
-                    : E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64 + lane;
                 if (act) {
-#pragma unroll
-                    for (int k = 0; k < D; ++k) if (k < d) { A[k] = src[(size_t)k * 64] - mean_t[(size_t)k * 64]; dl_t[(size_t)k * 64] = A[k]; }
+                    const bool isbase = (slot == 0xffffffffu);
+                    const size_t so = isbase ? 0 : (size_t)slot * (size_t)(d + 1) * 64;
+                    for (int k = 0; k < d; ++k) {
+                        double xv = isbase ? GV(base_t, k) : hist_t[so + (size_t)k * 64 + lane];
+                        XL(k) = xv - GV(mean_t, k);
+                    }
                     double f1 = w3 / (wsum + w3 - 1.0);
                     double f2 = wsum / (wsum + w3);
                     for (int a = 0; a < d; ++a) {             // row a of the upper triangle: elements (a, b >= a)
-                        double da = dl_t[(size_t)a * 64];
+                        double da = XL(a);
                         double *rowa = Ct + (size_t)rowstart(a, d) * 64;
-#pragma unroll
-                        for (int b = 0; b < D; ++b) {
-                            if (b >= a && b < d) {
-                                double o = da * A[b];
-                                double cab = rowa[(size_t)(b - a) * 64];
-                                rowa[(size_t)(b - a) * 64] = cab + f1 * (f2 * o - cab);
-                            }
+                        for (int b = a; b < d; ++b) {
+                            double o = da * XL(b);
+                            double cab = GV(rowa, b - a);
+                            GV(rowa, b - a) = cab + f1 * (f2 * o - cab);
                         }
                     }
                     double f3 = w3 / (wsum + w3);
-#pragma unroll
-                    for (int k = 0; k < D; ++k) if (k < d) mean_t[(size_t)k * 64] = mean_t[(size_t)k * 64] + f3 * A[k];
+                    for (int k = 0; k < d; ++k) GV(mean_t, k) = GV(mean_t, k) + f3 * XL(k);
                     wsum = w3 + wsum;
                 }
             }
         } else {
             // ---- covmat batch branch (matutils.F90:311-338): wsum == 0 on entry
             double wsum2 = 0.0;
-            for (int r = 0; r < nr; ++r) wsum2 = wsum2 + (double)(uint32_t)(rows[(size_t)r * 64] >> 32);
-#pragma unroll
-            for (int k = 0; k < D; ++k) B[k] = 0.0;
+            for (int r = 0; r < nr; ++r) wsum2 = wsum2 + (double)(uint32_t)(GV(rows, r) >> 32);
+            for (int k = 0; k < d; ++k) GV(m2_t, k) = 0.0;
             for (int r = 0; r < nrmax; ++r) {
                 bool act = r < nr;
-                uint64_t e = act ? rows[(size_t)r * 64] : 0ull;
+                uint64_t e = act ? GV(rows, r) : 0ull;
                 uint32_t slot = (uint32_t)e; double w = (double)(uint32_t)(e >> 32);
-                const double *src = (slot == 0xffffffffu) ? base_t
-                    : E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64 + lane;
                 if (act) {
-#pragma unroll
-                    for (int k = 0; k < D; ++k) if (k < d) B[k] = B[k] + src[(size_t)k * 64] * w;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < D; ++k) if (k < d) B[k] = B[k] / wsum2;          // xmean2
-            for (int e = 0; e < P; ++e) Ct[(size_t)e * 64] = 0.0;
-            for (int r = 0; r < nrmax; ++r) {
-                bool act = r < nr;
-                uint64_t e = act ? rows[(size_t)r * 64] : 0ull;
-                uint32_t slot = (uint32_t)e; double w = (double)(uint32_t)(e >> 32);
-                const double *src = (slot == 0xffffffffu) ? base_t
-                    : E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64 + lane;
-                if (act) {
-#pragma unroll
-                    for (int k = 0; k < D; ++k) if (k < d) { A[k] = src[(size_t)k * 64] - B[k]; dl_t[(size_t)k * 64] = A[k]; }
-                    // reference: cmat(i,j), j <= i = sum_r (x_ri - m_i) * ((x_rj - m_j) * w_r); kept at packed (j,i)
-                    for (int j = 0; j < d; ++j) {
-                        double xb = dl_t[(size_t)j * 64] * w;
-                        double *rowj = Ct + (size_t)rowstart(j, d) * 64;
-#pragma unroll
-                        for (int i = 0; i < D; ++i) {
-                            if (i >= j && i < d) rowj[(size_t)(i - j) * 64] = rowj[(size_t)(i - j) * 64] + A[i] * xb;
-                        }
+                    const bool isbase = (slot == 0xffffffffu);
+                    const size_t so = isbase ? 0 : (size_t)slot * (size_t)(d + 1) * 64;
+                    for (int k = 0; k < d; ++k) {
+                        double xv = isbase ? GV(base_t, k) : hist_t[so + (size_t)k * 64 + lane];
+                        GV(m2_t, k) = GV(m2_t, k) + xv * w;
                     }
                 }
             }
-            for (int e = 0; e < P; ++e) Ct[(size_t)e * 64] = Ct[(size_t)e * 64] / (wsum2 - 1.0);
-#pragma unroll
-            for (int k = 0; k < D; ++k) if (k < d) mean_t[(size_t)k * 64] = B[k];
+            for (int k = 0; k < d; ++k) GV(m2_t, k) = GV(m2_t, k) / wsum2;          // xmean2
+            for (int e = 0; e < P; ++e) GV(Ct, e) = 0.0;
+            for (int r = 0; r < nrmax; ++r) {
+                bool act = r < nr;
+                uint64_t e = act ? GV(rows, r) : 0ull;
+                uint32_t slot = (uint32_t)e; double w = (double)(uint32_t)(e >> 32);
+                if (act) {
+                    const bool isbase = (slot == 0xffffffffu);
+                    const size_t so = isbase ? 0 : (size_t)slot * (size_t)(d + 1) * 64;
+                    for (int k = 0; k < d; ++k) {
+                        double xv = isbase ? GV(base_t, k) : hist_t[so + (size_t)k * 64 + lane];
+                        XL(k) = xv - GV(m2_t, k);
+                    }
+                    // reference: cmat(i,j), j <= i = sum_r (x_ri - m_i) * ((x_rj - m_j) * w_r); kept at packed (j,i)
+                    for (int j = 0; j < d; ++j) {
+                        double xb = XL(j) * w;
+                        double *rowj = Ct + (size_t)rowstart(j, d) * 64;
+                        for (int i = j; i < d; ++i) GV(rowj, i - j) = GV(rowj, i - j) + XL(i) * xb;
+                    }
+                }
+            }
+            for (int e = 0; e < P; ++e) GV(Ct, e) = GV(Ct, e) / (wsum2 - 1.0);
+            for (int k = 0; k < d; ++k) GV(mean_t, k) = GV(m2_t, k);
             wsum = wsum2;
         }
         // lastfreq = count of the current row; lastind = chainind -> window restarts here
         lastfreq = curcount;
-        for (int k = 0; k < d; ++k) base_t[(size_t)k * 64] = theta_t[(size_t)k * 64];
+        for (int k = 0; k < d; ++k) GV(base_t, k) = GV(theta_t, k);
         basecnt = curcount; winstart = (uint32_t)(it + 1);
     }
 
     if (__any(docalc)) {
-        if (docalc) for (int e = 0; e < P; ++e) Tt[(size_t)e * 64] = Ct[(size_t)e * 64];
-        int info = calculate_R<D>(Tt, Rt, d, P, docalc, A);
+        if (docalc) for (int e = 0; e < P; ++e) GV(Tt, e) = GV(Ct, e);
+        int info = calculate_R(Tt, Rt, lane, d, P, docalc, X);
         if (docalc) {
             TIDX(E.ictr, tile, NICTR, I_INFO, lane) = (uint32_t)info;
             if (info != 0) TIDX(E.ictr, tile, NICTR, I_STATUS, lane) |= ST_CHOL_FAIL;   // warning, old R kept (:168-171)
@@ -640,7 +606,7 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
 __global__ __launch_bounds__(64) void moments_kernel(EngineDev E, double *out, int nchains)
 {
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d, P = E.P;
-    const double *theta_t = E.theta + (size_t)tile * d * 64 + lane;
+    const double *theta_t = E.theta + (size_t)tile * d * 64;
     const bool act = (tile * 64 + lane) < nchains;
     double *o = out + (size_t)tile * (1 + d + P);
     auto wsum64 = [](double v) {
@@ -651,11 +617,11 @@ __global__ __launch_bounds__(64) void moments_kernel(EngineDev E, double *out, i
     double cnt = wsum64(act ? 1.0 : 0.0);
     if (lane == 0) o[0] = cnt;
     for (int j = 0; j < d; ++j) {
-        double vj = act ? (theta_t[(size_t)j * 64] - E.par0[j]) : 0.0;
+        double vj = act ? (GV(theta_t, j) - E.par0[j]) : 0.0;
         double s1 = wsum64(vj);
         if (lane == 0) o[1 + j] = s1;
         for (int i = 0; i <= j; ++i) {
-            double vi = act ? (theta_t[(size_t)i * 64] - E.par0[i]) : 0.0;
+            double vi = act ? (GV(theta_t, i) - E.par0[i]) : 0.0;
             double s2 = wsum64(vi * vj);
             if (lane == 0) o[1 + d + j * (j + 1) / 2 + i] = s2;
         }
