@@ -113,9 +113,9 @@ def main():
 
     def one_step(k):
         eng.run(1 + (k + 1) * ips)
-        m = eng.pooled_moments()                       # fixed-tree sum over this GPU's chains
-        pooled.copy_(torch.from_numpy(m))
+        eng.pooled_moments_dev(pooled.data_ptr())      # fixed-tree sum over this GPU's chains, stays in HBM
         if world > 1:
+            eng.sync()                                 # engine stream -> torch stream hand-off
             dist.all_reduce(pooled)                    # RCCL over xGMI: 1+d+d(d+1)/2 doubles
 
     def fence():

@@ -107,6 +107,9 @@ int mcmcx_get_chain(mcmcx_handle h, int32_t chain, double *chain_out, double *ss
  * out = [count, sum_j (th-par0)_j (npar), sum (th-par0)_j (th-par0)_k j<=k (npar(npar+1)/2)] */
 int mcmcx_pooled_moments(mcmcx_handle h, double *out);
 int32_t mcmcx_pooled_moments_len(mcmcx_handle h);
+/* same, written to a device buffer of the caller (the operand of an RCCL all-reduce); asynchronous on
+ * the engine's stream */
+int mcmcx_pooled_moments_dev(mcmcx_handle h, void *dev_out);
 
 /* device time of the step kernel over all launches since the last reset, measured with HIP
  * events on the engine's stream; launches = number of step-kernel launches, steps = iterations */

@@ -55,6 +55,7 @@ SYMBOLS = {
     "mcmcx_get_accept_masks": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), _IP]),
     "mcmcx_get_chain": (C.c_int, [C.c_void_p, C.c_int32, _DP, _DP, _DP, _IP]),
     "mcmcx_pooled_moments": (C.c_int, [C.c_void_p, _DP]),
+    "mcmcx_pooled_moments_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mcmcx_pooled_moments_len": (C.c_int32, [C.c_void_p]),
     "mcmcx_debug_math": (C.c_int, [C.c_int32, C.c_int32, _DP, _DP, _DP]),
     "mcmcx_debug_rng": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_double, C.c_double, _DP,

@@ -653,34 +653,37 @@ int mcmcx_get_chain(mcmcx_handle h, int32_t chain, double *chain_out, double *ss
 
 int32_t mcmcx_pooled_moments_len(mcmcx_handle h) { return h ? 1 + h->d + h->P : -1; }
 
-int mcmcx_pooled_moments(mcmcx_handle h, double *out)
+static int pooled_moments_launch(mcmcx_engine *h, double *dev_dst)
 {
     if (!h || !h->inited) return fail(-40, "we have not inited");
     HIPCHK(hipSetDevice(h->cfg.device));
     const int len = 1 + h->d + h->P, T = h->ntiles;
     hipLaunchKernelGGL(moments_kernel, dim3(T), dim3(64), 0, h->stream, h->E, h->d_moments, h->cfg.nchains);
+    hipLaunchKernelGGL(moments_tree_kernel, dim3((len + 255) / 256), dim3(256), 0, h->stream, h->d_moments, T, len, dev_dst);
     HIPCHK(hipGetLastError());
-    std::vector<double> v;
-    int rc = fetch(h, h->d_moments, (size_t)T * len, v); if (rc) return rc;
-    // fixed pairwise tree over tiles (adjacent pairs first), so the result does not depend on how
-    // the tiles are later grouped onto GPUs as long as each GPU owns a power-of-two aligned block
-    int n = T;
-    std::vector<double> cur = v;
-    while (n > 1) {
-        int half = (n + 1) / 2;
-        std::vector<double> nxt((size_t)half * len);
-        for (int i = 0; i < half; ++i)
-            for (int k = 0; k < len; ++k) {
-                double a = cur[(size_t)(2 * i) * len + k];
-                nxt[(size_t)i * len + k] = (2 * i + 1 < n) ? a + cur[(size_t)(2 * i + 1) * len + k] : a;
-            }
-        cur.swap(nxt); n = half;
-    }
-    memcpy(out, cur.data(), sizeof(double) * len);
     return 0;
 }
 
+int mcmcx_pooled_moments(mcmcx_handle h, double *out)
+{
+    int rc = pooled_moments_launch(h, nullptr); if (rc) return rc;
+    std::vector<double> v;
+    if ((rc = fetch(h, h->d_moments, (size_t)(1 + h->d + h->P), v))) return rc;
+    memcpy(out, v.data(), sizeof(double) * v.size());
+    return 0;
+}
 
+/* same, result left in device memory at dev_out (e.g. the buffer an RCCL all-reduce works on);
+ * asynchronous on the engine's stream: call mcmcx_sync before another stream reads it */
+int mcmcx_pooled_moments_dev(mcmcx_handle h, void *dev_out)
+{
+    if (!dev_out) return fail(-1, "null argument");
+    return pooled_moments_launch(h, (double *)dev_out);
+}
+
+} // extern "C"
+
+extern "C" {
 // ------------------------------------------------------------------ debug probes (tests only)
 int mcmcx_debug_math(int32_t op, int32_t n, const double *a, const double *b, double *out)
 {

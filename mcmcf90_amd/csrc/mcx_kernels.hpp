@@ -65,12 +65,52 @@ struct EngineDev {
 MCX_DEV int rowstart(int i, int d) { return i * d - (i * (i - 1)) / 2; }
 MCX_DEV int pidx(int i, int j, int d) { return rowstart(i, d) + (j - i); }
 
-constexpr int CH = 8;     // row elements loaded per batch: 8 independent 512-byte wave loads in flight
+constexpr int CH = 8;     // row elements per batch; two batches (2 x 8 x 512 B) are in flight per wave
 
 // The one per-lane d-vector of a wave lives in LDS as X[j*64 + lane] (conflict-free ds_read/write_b64).
 #define XL(j) X[(j) * 64 + lane]
 // element k of a tile-interleaved global vector whose tile base is `p` (uniform pointer)
 #define GV(p, k) (p)[(size_t)(k) * 64 + lane]
+
+// Software-pipelined sweep over elements k0..n-1 of one packed row (rowp[k], element stride 64):
+// the next batch of CH elements is requested before the current one is consumed, and the
+// ragged last batch is loaded with clamped addresses, so no load of a row is ever issued alone.
+// f(k, r) is called for k ascending.
+MCX_DEV void load_batch(double (&r)[CH], const double *rowp, int lane, int k, int n)
+{
+#pragma unroll
+    for (int u = 0; u < CH; ++u) { int kk = k + u; kk = kk < n ? kk : n - 1; r[u] = GV(rowp, kk); }
+}
+template <typename F>
+MCX_DEV void sweep(const double *rowp, int lane, int k0, int n, F &&f)
+{
+    double ra[CH], rb[CH];
+    int k = k0;
+    if (k < n) load_batch(ra, rowp, lane, k, n);
+    while (k < n) {
+        int k2 = k + CH;
+        if (k2 < n) load_batch(rb, rowp, lane, k2, n);
+        if (k2 <= n) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) f(k + u, ra[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) if (k + u < n) f(k + u, ra[u]);
+        }
+        k = k2;
+        if (k >= n) break;
+        int k3 = k + CH;
+        if (k3 < n) load_batch(ra, rowp, lane, k3, n);
+        if (k3 <= n) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) f(k + u, rb[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) if (k + u < n) f(k + u, rb[u]);
+        }
+        k = k3;
+    }
+}
 
 // ---------------------------------------------------------------- targets (user ssfunction / priorfun / checkbounds)
 // X holds the candidate on entry; the Gaussian target overwrites it with (theta - mu).
@@ -167,15 +207,7 @@ MCX_DEV void trmv_rows(const double *Rt, const double *zs_t, int lane, int d, do
         const double *rowp = Rt + (size_t)rowstart(i, d) * 64;       // element (i, i+k) at rowp[k]
         const int n = d - i;
         double rd = GV(rowp, 0);
-        int k = 1;
-        for (; k + CH <= n; k += CH) {
-            double r[CH];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) r[u] = GV(rowp, k + u);
-#pragma unroll
-            for (int u = 0; u < CH; ++u) XL(i + k + u) = dfma(r[u], zi, XL(i + k + u));
-        }
-        for (; k < n; ++k) XL(i + k) = dfma(GV(rowp, k), zi, XL(i + k));
+        sweep(rowp, lane, 1, n, [&](int k, double r) { XL(i + k) = dfma(r, zi, XL(i + k)); });
         XL(i) = zi * rd;
     }
 }
@@ -199,25 +231,12 @@ MCX_DEV void ram_update(double *Rt, const double *zs_t, double *cs_t, int lane, 
                 double r, c, s;
                 d_rotg(GV(rowp, 0), XL(i), r, c, s);
                 GV(rowp, 0) = r;
-                int k = 1;
-                for (; k + CH <= n; k += CH) {
-                    double rr[CH];
-#pragma unroll
-                    for (int u = 0; u < CH; ++u) rr[u] = GV(rowp, k + u);
-#pragma unroll
-                    for (int u = 0; u < CH; ++u) {
-                        double xj = XL(i + k + u);
-                        double t = c * rr[u] + s * xj;
-                        XL(i + k + u) = c * xj - s * rr[u];
-                        GV(rowp, k + u) = t;
-                    }
-                }
-                for (; k < n; ++k) {
-                    double rij = GV(rowp, k), xj = XL(i + k);
+                sweep(rowp, lane, 1, n, [&](int k, double rij) {
+                    double xj = XL(i + k);
                     double t = c * rij + s * xj;
                     XL(i + k) = c * xj - s * rij;
                     GV(rowp, k) = t;
-                }
+                });
             }
         }
     }
@@ -233,15 +252,7 @@ MCX_DEV void ram_update(double *Rt, const double *zs_t, double *cs_t, int lane, 
                 double si = xi - XL(i);
                 si = si / GV(rowp, 0);
                 XL(i) = si;
-                int k = 1;
-                for (; k + CH <= n; k += CH) {
-                    double rr[CH];
-#pragma unroll
-                    for (int u = 0; u < CH; ++u) rr[u] = GV(rowp, k + u);
-#pragma unroll
-                    for (int u = 0; u < CH; ++u) XL(i + k + u) = dfma(rr[u], si, XL(i + k + u));
-                }
-                for (; k < n; ++k) XL(i + k) = dfma(GV(rowp, k), si, XL(i + k));
+                sweep(rowp, lane, 1, n, [&](int k, double rij) { XL(i + k) = dfma(rij, si, XL(i + k)); });
             }
             // norm = dnrm2(p, s), classic scale/ssq form (dchdd.f:149)
             double norm;
@@ -276,25 +287,12 @@ MCX_DEV void ram_update(double *Rt, const double *zs_t, double *cs_t, int lane, 
                     double *rowp = Rt + (size_t)rowstart(i, d) * 64;
                     const int n = d - i;
                     const double ci = GV(cs_t, 2 * i), si = GV(cs_t, 2 * i + 1);
-                    int k = 0;
-                    for (; k + CH <= n; k += CH) {
-                        double rr[CH];
-#pragma unroll
-                        for (int u = 0; u < CH; ++u) rr[u] = GV(rowp, k + u);
-#pragma unroll
-                        for (int u = 0; u < CH; ++u) {
-                            double xx = XL(i + k + u);
-                            double t = ci * xx + si * rr[u];
-                            GV(rowp, k + u) = ci * rr[u] - si * xx;
-                            XL(i + k + u) = t;
-                        }
-                    }
-                    for (; k < n; ++k) {
-                        double rij = GV(rowp, k), xx = XL(i + k);
+                    sweep(rowp, lane, 0, n, [&](int k, double rij) {
+                        double xx = XL(i + k);
                         double t = ci * xx + si * rij;
                         GV(rowp, k) = ci * rij - si * xx;
                         XL(i + k) = t;
-                    }
+                    });
                 }
             }
         }
@@ -626,6 +624,19 @@ __global__ __launch_bounds__(64) void moments_kernel(EngineDev E, double *out, i
             if (lane == 0) o[1 + d + j * (j + 1) / 2 + i] = s2;
         }
     }
+}
+
+// Finish the pooled sum over tiles in the same fixed pairwise tree (adjacent tiles first), one
+// thread per moment: v[0..len) of tile 0 holds the result.  Deterministic and independent of how
+// tiles are later grouped onto GPUs, as long as every GPU owns a power-of-two aligned block.
+__global__ void moments_tree_kernel(double *v, int ntiles, int len, double *dst)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= len) return;
+    for (int s = 1; s < ntiles; s <<= 1)
+        for (int t = 0; t + s < ntiles; t += 2 * s)
+            v[(size_t)t * len + k] = v[(size_t)t * len + k] + v[(size_t)(t + s) * len + k];
+    if (dst) dst[k] = v[k];
 }
 
 // ---------------------------------------------------------------- debug probes of the device primitives

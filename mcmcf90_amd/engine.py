@@ -170,6 +170,10 @@ class Engine:
         self._chk(self.L.mcmcx_pooled_moments(self.h, _dp(a)))
         return a
 
+    def pooled_moments_dev(self, dev_ptr):
+        """Pooled moments straight into device memory (e.g. a torch tensor's data_ptr()); async on the engine stream."""
+        self._chk(self.L.mcmcx_pooled_moments_dev(self.h, C.c_void_p(int(dev_ptr))))
+
     def kernel_time(self, reset=False):
         ms, nl, ns = C.c_double(), C.c_int64(), C.c_int64()
         self._chk(self.L.mcmcx_kernel_time(self.h, C.byref(ms), C.byref(nl), C.byref(ns), int(reset)))
