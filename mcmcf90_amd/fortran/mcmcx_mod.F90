@@ -1,0 +1,656 @@
+!!! mcmcx_mod.F90 -- Fortran host side of the MI355X engine: the same user surface as mcmcf90.
+!!!
+!!! An existing driver program keeps its source:
+!!!
+!!!     use mcmcmod, only : MCMC_setpar0, MCMC_setcmat0, MCMC_setsigma2nobs
+!!!     call MCMC_setpar0(5, 0.0d0); call MCMC_setcmat0(0.1d0)      ! testcases/mcmcrun4.F90:11-12
+!!!     call mcmc_main()                                            ! testcases/mcmcrun.F90:51
+!!!
+!!! and is linked with  mcmcx_mod.o  -L<repo>/mcmcf90_amd -lmcmcx  instead of  -lmcmcrun.
+!!!
+!!!   module mcmcmod      same name and generic setters as mcmc.F90:12,62-71 / MCMC_init.F90:168-347;
+!!!                       public chain, sschain, s2chain, npar, nycol, sigma2, simuind, chainind
+!!!                       (mcmc.F90:28-52); namelist /mcmc/ with the reference's variable list
+!!!                       (mcmcinit.F90:74-82) and defaults (:184-230), read with real namelist I/O
+!!!                       from mcmcinit.nml, else the file named in mcmcnml.txt (:101-117)
+!!!   mcmc_main()         external subroutine, no arguments (mcmc_main.F90:12-44): init, run, write
+!!!
+!!! The sampling itself runs in libmcmcx.so (HIP) through the bind(C) interfaces below
+!!! (include/mcmcx.h).  A GPU cannot call a host ssfunction, so the likelihood is selected from the
+!!! device-resident targets, either by MCMC_settarget_* calls before mcmc_main or by an extra
+!!! namelist group in the same file (ignored by the reference, which reads only &mcmc):
+!!!
+!!!     &mcmcx  devtarget='gauss'  nchains=65536  mufile='mcmctest_mu.dat' lamfile='mcmctest_lam.dat' /
+!!!
+!!! Input files follow initialize.F90:41-119 (parfile, cov0file, sigma2file; whitespace/comma
+!!! separated numbers, lines starting with # % ! are comments, matutils.F90:1019-1021); outputs follow
+!!! MCMC_writechains (MCMC_aux.F90:25-69) in ASCII for chain 0.
+module mcmcmod
+  use iso_c_binding
+  implicit none
+  public
+
+  integer, parameter :: dbl = kind(1.0d0)
+  integer, parameter :: ik4 = c_int32_t
+  character(len=*), parameter :: Mcmc_Code_Version = 'mcmcx 0.1 (MI355X engine behind the mcmcf90 1.2.8 surface)'
+
+  !! namelist /mcmc/ variables, mcmcinit.F90:20-62
+  integer, save :: nsimu, doadapt, doburnin, adaptint, adapthist, initcmatn, burnintime, badaptint
+  integer, save :: adaptend, greedy, svddim, sstype, filepars, printint, updatesigma, usrfunlen, dumpint
+  integer, save :: verbosity
+  real(kind=dbl), save :: scalelimit, scalefactor, drscale, condmax, condmaxini, N0, S02, sstrans
+  real(kind=dbl), save :: alphatarget, nuparam
+  character(len=256), save :: chainfile, s2file, ssfile, priorsfile, cov0file, covffile, covnfile
+  character(len=256), save :: meanfile, nmlffile, parfile, parffile, sigma2file, sigma2ffile
+  character(len=10), save :: method
+  namelist /mcmc/ nsimu, doadapt, doburnin, adaptint, adapthist, &
+       scalelimit, scalefactor, drscale, &
+       badaptint, adaptend, initcmatn, N0, S02, &
+       filepars, burnintime, greedy, printint, updatesigma, &
+       usrfunlen, chainfile, s2file, ssfile, svddim, condmax, &
+       cov0file, covffile, covnfile, meanfile, &
+       nmlffile, parfile, parffile, sigma2file, sigma2ffile, &
+       condmaxini, sstype, sstrans, dumpint, priorsfile, verbosity, &
+       method, alphatarget, nuparam
+
+  !! engine extension group &mcmcx (same file)
+  character(len=16), save :: devtarget = 'none'
+  integer, save :: nchains = 1, seed = 1835232611     ! 0x6D636D63
+  real(kind=dbl), save :: banana_b = 0.1_dbl
+  character(len=256), save :: mufile = 'mcmctest_mu.dat', lamfile = 'mcmctest_lam.dat'
+  character(len=256), save :: datafile = 'data.dat', lowerfile = '', upperfile = ''
+  namelist /mcmcx/ devtarget, nchains, seed, banana_b, mufile, lamfile, datafile, lowerfile, upperfile
+
+  !! public state, mcmc.F90:28-52
+  integer, save :: npar = 0, nycol = 1, simuind = 0, chainind = 0, MCMC_running = 0
+  real(kind=dbl), allocatable, save :: chain(:,:), sschain(:,:), s2chain(:,:), sigma2(:)
+  real(kind=dbl), allocatable, save :: chaincmat(:,:), chainmean(:)
+  real(kind=dbl), save :: chainwsum = 0.0_dbl
+  integer, allocatable, save :: nobs(:)
+  integer, save :: stayed = 0, bndstayed = 0, draccepted = 0, drtries = 0
+
+  !! set by the MCMC_set* calls
+  real(kind=dbl), allocatable, save, private :: par0(:), cmat0(:,:)
+  real(kind=dbl), allocatable, save, private :: tmu(:), tlam(:,:), tx(:), ty(:), tlo(:), thi(:), pmu(:), psig(:)
+  logical, save, private :: par0ok = .false., cmat0ok = .false., sigma2ok = .false., nparok = .false.
+  logical, save, private :: has_lo = .false., has_hi = .false.
+  type(c_ptr), save, private :: handle = c_null_ptr
+
+  interface MCMC_setpar0
+     module procedure MCMC_setpar0_vec, MCMC_setpar0_n, MCMC_setpar0_file
+  end interface
+  interface MCMC_setcmat0
+     module procedure MCMC_setcmat0_mat, MCMC_setcmat0_pct, MCMC_setcmat0_std, MCMC_setcmat0_file
+  end interface
+  interface MCMC_setsigma2nobs
+     module procedure MCMC_setsigma2nobs_sca, MCMC_setsigma2nobs_vec
+  end interface
+
+  !! plain-C mirror of mcmcx_config (include/mcmcx.h)
+  type, bind(C) :: mcmcx_config
+     integer(c_int32_t) :: npar, nchains, method, nsimu
+     integer(c_int32_t) :: doadapt, doburnin, adaptint, adapthist, badaptint, adaptend, initcmatn
+     integer(c_int32_t) :: burnintime, greedy, updatesigma
+     real(c_double) :: scalelimit, scalefactor, drscale, N0, S02, condmax, alphatarget, nuparam
+     integer(c_int32_t) :: seed, chain_id0, record_accept, record_chain, device, reserved
+  end type mcmcx_config
+
+  interface
+     subroutine mcmcx_config_defaults(cfg) bind(C, name='mcmcx_config_defaults')
+       import :: mcmcx_config
+       type(mcmcx_config), intent(inout) :: cfg
+     end subroutine
+     function mcmcx_create(cfg, h) bind(C, name='mcmcx_create') result(rc)
+       import :: mcmcx_config, c_ptr, c_int
+       type(mcmcx_config), intent(in) :: cfg
+       type(c_ptr), intent(out) :: h
+       integer(c_int) :: rc
+     end function
+     function mcmcx_destroy(h) bind(C, name='mcmcx_destroy') result(rc)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: h
+       integer(c_int) :: rc
+     end function
+     function mcmcx_last_error() bind(C, name='mcmcx_last_error') result(p)
+       import :: c_ptr
+       type(c_ptr) :: p
+     end function
+     function mcmcx_set_par0(h, p, n) bind(C, name='mcmcx_set_par0') result(rc)
+       import :: c_ptr, c_int, c_double, c_int32_t
+       type(c_ptr), value :: h
+       real(c_double), intent(in) :: p(*)
+       integer(c_int32_t), value :: n
+       integer(c_int) :: rc
+     end function
+     function mcmcx_set_cmat0(h, c, n) bind(C, name='mcmcx_set_cmat0') result(rc)
+       import :: c_ptr, c_int, c_double, c_int32_t
+       type(c_ptr), value :: h
+       real(c_double), intent(in) :: c(*)
+       integer(c_int32_t), value :: n
+       integer(c_int) :: rc
+     end function
+     function mcmcx_set_sigma2nobs(h, s2, nobs, ny) bind(C, name='mcmcx_set_sigma2nobs') result(rc)
+       import :: c_ptr, c_int, c_double, c_int32_t
+       type(c_ptr), value :: h
+       real(c_double), intent(in) :: s2(*)
+       integer(c_int32_t), intent(in) :: nobs(*)
+       integer(c_int32_t), value :: ny
+       integer(c_int) :: rc
+     end function
+     function mcmcx_set_target_gauss(h, mu, lam) bind(C, name='mcmcx_set_target_gauss') result(rc)
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h
+       real(c_double), intent(in) :: mu(*), lam(*)
+       integer(c_int) :: rc
+     end function
+     function mcmcx_set_target_banana(h, b) bind(C, name='mcmcx_set_target_banana') result(rc)
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h
+       real(c_double), value :: b
+       integer(c_int) :: rc
+     end function
+     function mcmcx_set_target_expdata(h, n, x, y) bind(C, name='mcmcx_set_target_expdata') result(rc)
+       import :: c_ptr, c_int, c_double, c_int32_t
+       type(c_ptr), value :: h
+       integer(c_int32_t), value :: n
+       real(c_double), intent(in) :: x(*), y(*)
+       integer(c_int) :: rc
+     end function
+     function mcmcx_set_bounds(h, lo, hi) bind(C, name='mcmcx_set_bounds') result(rc)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: h, lo, hi
+       integer(c_int) :: rc
+     end function
+     function mcmcx_set_priors(h, mu, sig) bind(C, name='mcmcx_set_priors') result(rc)
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h
+       real(c_double), intent(in) :: mu(*), sig(*)
+       integer(c_int) :: rc
+     end function
+     function mcmcx_init(h) bind(C, name='mcmcx_init') result(rc)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: h
+       integer(c_int) :: rc
+     end function
+     function mcmcx_run(h, upto) bind(C, name='mcmcx_run') result(rc)
+       import :: c_ptr, c_int, c_int32_t
+       type(c_ptr), value :: h
+       integer(c_int32_t), value :: upto
+       integer(c_int) :: rc
+     end function
+     function mcmcx_sync(h) bind(C, name='mcmcx_sync') result(rc)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: h
+       integer(c_int) :: rc
+     end function
+     function mcmcx_get_counters(h, chain, c8) bind(C, name='mcmcx_get_counters') result(rc)
+       import :: c_ptr, c_int, c_int32_t
+       type(c_ptr), value :: h
+       integer(c_int32_t), value :: chain
+       integer(c_int32_t), intent(out) :: c8(8)
+       integer(c_int) :: rc
+     end function
+     function mcmcx_get_chain(h, chain, ch, ss, s2, nrows) bind(C, name='mcmcx_get_chain') result(rc)
+       import :: c_ptr, c_int, c_int32_t, c_double
+       type(c_ptr), value :: h
+       integer(c_int32_t), value :: chain
+       real(c_double), intent(out) :: ch(*), ss(*), s2(*)
+       integer(c_int32_t), intent(out) :: nrows
+       integer(c_int) :: rc
+     end function
+     function mcmcx_get_chaincov(h, chain, cm, mean, wsum) bind(C, name='mcmcx_get_chaincov') result(rc)
+       import :: c_ptr, c_int, c_int32_t, c_double
+       type(c_ptr), value :: h
+       integer(c_int32_t), value :: chain
+       real(c_double), intent(out) :: cm(*), mean(*), wsum
+       integer(c_int) :: rc
+     end function
+     function mcmcx_get_scalars(h, out) bind(C, name='mcmcx_get_scalars') result(rc)
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h
+       real(c_double), intent(out) :: out(*)
+       integer(c_int) :: rc
+     end function
+  end interface
+
+contains
+
+  !! doerror, matutils.F90:764-789: message + stop
+  subroutine doerror(msg)
+    character(len=*), intent(in) :: msg
+    write(*,*) 'ERROR: ', trim(msg)
+    stop 1
+  end subroutine doerror
+
+  subroutine chk(rc)
+    integer(c_int), intent(in) :: rc
+    character(kind=c_char), pointer :: s(:)
+    character(len=512) :: msg
+    integer :: i
+    if (rc >= 0) return
+    call c_f_pointer(mcmcx_last_error(), s, [512])
+    msg = ''
+    do i = 1, 512
+       if (s(i) == c_null_char) exit
+       msg(i:i) = s(i)
+    end do
+    call doerror(msg)
+  end subroutine chk
+
+  !! MCMC_init_namelist, mcmcinit.F90:184-230
+  subroutine MCMC_init_namelist()
+    nsimu = 0; doadapt = 1; doburnin = 0; burnintime = 0; badaptint = -1; greedy = 0
+    scalelimit = 0.05_dbl; scalefactor = 2.5_dbl; drscale = 0.0_dbl; adaptint = 100; adapthist = 0
+    adaptend = 0; initcmatn = 0; N0 = 1.0_dbl; S02 = 0.0_dbl; filepars = 1; printint = 500
+    updatesigma = 1; usrfunlen = 0; dumpint = 0
+    chainfile = 'chain.dat'; s2file = 's2chain.dat'; ssfile = 'sschain.dat'; priorsfile = ''
+    cov0file = 'mcmccov.dat'; covffile = 'mcmccovf.dat'; covnfile = ''; meanfile = 'mcmcmean.dat'
+    nmlffile = ''; parfile = 'mcmcpar.dat'; parffile = 'mcmcparf.dat'
+    sigma2file = 'mcmcsigma2.dat'; sigma2ffile = 'mcmcsigma2f.dat'
+    svddim = 0; condmax = 0.0_dbl; condmaxini = 1.0e15_dbl; sstype = 0; sstrans = -1.0_dbl
+    verbosity = 1; method = 'dram'; alphatarget = 0.234_dbl; nuparam = 0.7_dbl
+  end subroutine MCMC_init_namelist
+
+  !! read_mcmcinit_namelist, mcmcinit.F90:86-142
+  subroutine read_mcmcinit_namelist(status)
+    integer, intent(out) :: status
+    integer :: fstat
+    character(len=256) :: nmlfile
+    logical :: fexist
+    status = 0
+    call MCMC_init_namelist()
+    inquire(file='mcmcinit.nml', exist=fexist)
+    if (fexist) then
+       nmlfile = 'mcmcinit.nml'
+    else
+       inquire(file='mcmcnml.txt', exist=fexist)
+       nmlfile = 'mcmcinit.nml'
+       if (fexist) then
+          open(unit=10, file='mcmcnml.txt', status='old', iostat=fstat)
+          read(10,*) nmlfile
+          close(10)
+          if (len_trim(nmlfile) == 0) nmlfile = 'mcmcinit.nml'
+       end if
+    end if
+    open(unit=10, file=nmlfile, status='old', iostat=fstat)
+    if (fstat /= 0) then
+       write(*,*) 'File ', trim(nmlfile), ' not found, no MCMC run'
+       status = -1
+       return
+    end if
+    read(10, nml=mcmc, iostat=fstat)
+    if (fstat /= 0) then
+       write(*,*) 'Error reading mcmc namelist from file ', trim(nmlfile)
+       write(*,*) ' status:', fstat
+       write(*,*) 'No mcmc run'
+       close(10)
+       status = -2
+       return
+    end if
+    rewind(10)
+    read(10, nml=mcmcx, iostat=fstat)      ! optional engine group; absent -> defaults / MCMC_settarget_*
+    close(10)
+    if (verbosity > 0) write(*,*) 'note: using nmlfile ', trim(nmlfile)
+  end subroutine read_mcmcinit_namelist
+
+  !! ---------------------------------------------------------------- setters, MCMC_init.F90:168-347
+  subroutine MCMC_setpar0_vec(par)
+    real(kind=dbl), intent(in) :: par(:)
+    if (nparok .and. npar /= size(par)) call doerror('par0 and npar dont match')
+    npar = size(par)
+    if (allocated(par0)) deallocate(par0)
+    allocate(par0(npar)); par0 = par
+    nparok = .true.; par0ok = .true.
+  end subroutine MCMC_setpar0_vec
+  subroutine MCMC_setpar0_n(n, par)
+    integer, intent(in) :: n
+    real(kind=dbl), intent(in) :: par
+    real(kind=dbl) :: v(n)
+    v = par
+    call MCMC_setpar0_vec(v)
+  end subroutine MCMC_setpar0_n
+  subroutine MCMC_setpar0_file(file)
+    character(len=*), intent(in) :: file
+    real(kind=dbl), allocatable :: v(:)
+    integer :: nr, nc, stat
+    call loadnumbers(file, v, nr, nc, stat)
+    if (stat /= 0) call doerror('Error reading file '//trim(file))
+    call MCMC_setpar0_vec(v)
+  end subroutine MCMC_setpar0_file
+  subroutine MCMC_setcmat0_mat(cmat)
+    real(kind=dbl), intent(in) :: cmat(:,:)
+    if (nparok .and. npar /= size(cmat,1)) call doerror('cmat0 and npar dont match')
+    if (size(cmat,2) /= size(cmat,1)) call doerror('cmat0 must be square')
+    npar = size(cmat,1)
+    if (allocated(cmat0)) deallocate(cmat0)
+    allocate(cmat0(npar,npar)); cmat0 = cmat
+    nparok = .true.; cmat0ok = .true.
+  end subroutine MCMC_setcmat0_mat
+  subroutine MCMC_setcmat0_pct(pct)                       ! MCMC_init.F90:240-262
+    real(kind=dbl), intent(in) :: pct
+    integer :: i
+    if (.not.nparok .or. .not.par0ok) call doerror('par0 not defined when calling setcmat0')
+    if (allocated(cmat0)) deallocate(cmat0)
+    allocate(cmat0(npar,npar)); cmat0 = 0.0_dbl
+    do i = 1, npar
+       if (par0(i) /= 0.0_dbl) then
+          cmat0(i,i) = abs(pct*par0(i))**2
+       else
+          cmat0(i,i) = abs(pct)**2
+       end if
+    end do
+    cmat0ok = .true.
+  end subroutine MCMC_setcmat0_pct
+  subroutine MCMC_setcmat0_std(std)
+    real(kind=dbl), intent(in) :: std(:)
+    integer :: i
+    if (.not.nparok) call doerror('npar not defined when calling setcmat0')
+    if (size(std) /= npar) call doerror('std size does not macth when calling setcmat0')
+    if (allocated(cmat0)) deallocate(cmat0)
+    allocate(cmat0(npar,npar)); cmat0 = 0.0_dbl
+    do i = 1, npar
+       cmat0(i,i) = std(i)**2
+    end do
+    cmat0ok = .true.
+  end subroutine MCMC_setcmat0_std
+  subroutine MCMC_setcmat0_file(file)
+    character(len=*), intent(in) :: file
+    real(kind=dbl), allocatable :: v(:)
+    integer :: nr, nc, stat
+    call loadnumbers(file, v, nr, nc, stat)
+    if (stat /= 0 .or. nr /= nc) call doerror('Error reading file '//trim(file))
+    call MCMC_setcmat0_mat(transpose(reshape(v, (/nc, nr/))))
+  end subroutine MCMC_setcmat0_file
+  subroutine MCMC_setsigma2nobs_vec(sig2, n)
+    real(kind=dbl), intent(in) :: sig2(:)
+    integer, intent(in) :: n(:)
+    if (size(sig2) /= size(n)) call doerror('sig2 and nobs sizes')
+    nycol = size(sig2)
+    if (allocated(sigma2)) deallocate(sigma2)
+    if (allocated(nobs)) deallocate(nobs)
+    allocate(sigma2(nycol), nobs(nycol))
+    sigma2 = sig2; nobs = n
+    sigma2ok = .true.
+  end subroutine MCMC_setsigma2nobs_vec
+  subroutine MCMC_setsigma2nobs_sca(sig2, n)
+    real(kind=dbl), intent(in) :: sig2
+    integer, intent(in) :: n
+    call MCMC_setsigma2nobs_vec((/sig2/), (/n/))
+  end subroutine MCMC_setsigma2nobs_sca
+
+  !! ---------------------------------------------------------------- device-resident user callbacks
+  subroutine MCMC_settarget_gauss(mu, lam)              ! ss = (theta-mu)' lam (theta-mu), testcases/mcmcrun4.F90:47
+    real(kind=dbl), intent(in) :: mu(:), lam(:,:)
+    if (allocated(tmu)) deallocate(tmu, tlam)
+    allocate(tmu(size(mu)), tlam(size(lam,1), size(lam,2)))
+    tmu = mu; tlam = lam; devtarget = 'gauss'
+  end subroutine MCMC_settarget_gauss
+  subroutine MCMC_settarget_banana(b)
+    real(kind=dbl), intent(in) :: b
+    banana_b = b; devtarget = 'banana'
+  end subroutine MCMC_settarget_banana
+  subroutine MCMC_settarget_expdata(x, y)               ! ss = sum((y - th1*exp(-th2*x))**2), testcases/mcmcrun.F90:89,104
+    real(kind=dbl), intent(in) :: x(:), y(:)
+    if (allocated(tx)) deallocate(tx, ty)
+    allocate(tx(size(x)), ty(size(y)))
+    tx = x; ty = y; devtarget = 'expdata'
+  end subroutine MCMC_settarget_expdata
+  subroutine MCMC_setbounds(lo, hi)                     ! box form of checkbounds, external_inc.h:29-32
+    real(kind=dbl), intent(in), optional :: lo(:), hi(:)
+    if (present(lo)) then
+       if (allocated(tlo)) deallocate(tlo)
+       allocate(tlo(size(lo))); tlo = lo; has_lo = .true.
+    end if
+    if (present(hi)) then
+       if (allocated(thi)) deallocate(thi)
+       allocate(thi(size(hi))); thi = hi; has_hi = .true.
+    end if
+  end subroutine MCMC_setbounds
+  subroutine MCMC_setnchains(n)
+    integer, intent(in) :: n
+    nchains = n
+  end subroutine MCMC_setnchains
+
+  !! ---------------------------------------------------------------- ASCII numbers: matutils.F90:1019-1056 rules
+  subroutine loadnumbers(file, v, nrows, ncols, stat)
+    character(len=*), intent(in) :: file
+    real(kind=dbl), allocatable, intent(out) :: v(:)
+    integer, intent(out) :: nrows, ncols, stat
+    character(len=8192) :: line
+    real(kind=dbl) :: tmp(4096)
+    real(kind=dbl), allocatable :: buf(:), nb(:)
+    integer :: u, ios, n, i, k, ntot
+    character(len=1) :: c
+    stat = 0; nrows = 0; ncols = 0; ntot = 0
+    allocate(buf(1024))
+    open(newunit=u, file=file, status='old', iostat=ios)
+    if (ios /= 0) then
+       stat = -1; allocate(v(0)); return
+    end if
+    do
+       read(u, '(A)', iostat=ios) line
+       if (ios /= 0) exit
+       line = adjustl(line)
+       if (len_trim(line) == 0) cycle
+       c = line(1:1)
+       if (c == '#' .or. c == '%' .or. c == '!' .or. c == 'C' .or. c == 'c') cycle
+       do i = 1, len_trim(line)
+          if (line(i:i) == ',' .or. line(i:i) == ';' .or. line(i:i) == achar(9)) line(i:i) = ' '
+       end do
+       n = 0
+       do k = 1, 4096                               ! count the numbers on this line
+          read(line, *, iostat=ios) tmp(1:k)
+          if (ios /= 0) exit
+          n = k
+       end do
+       if (n == 0) cycle
+       if (ntot + n > size(buf)) then
+          allocate(nb(2*size(buf) + n)); nb(1:ntot) = buf(1:ntot); call move_alloc(nb, buf)
+       end if
+       buf(ntot+1:ntot+n) = tmp(1:n)
+       ntot = ntot + n
+       nrows = nrows + 1
+       if (nrows == 1) ncols = n
+    end do
+    close(u)
+    allocate(v(ntot)); v = buf(1:ntot)
+    if (nrows > 0 .and. ncols*nrows /= ntot) ncols = ntot / nrows
+  end subroutine loadnumbers
+
+  subroutine writenumbers(file, a)
+    character(len=*), intent(in) :: file
+    real(kind=dbl), intent(in) :: a(:,:)
+    integer :: u, i
+    open(newunit=u, file=file, status='replace')
+    do i = 1, size(a,1)
+       write(u, '(*(ES24.16E3,1X))') a(i,:)
+    end do
+    close(u)
+  end subroutine writenumbers
+
+  !! ---------------------------------------------------------------- the default `initialize`, initialize.F90:41-119
+  subroutine initialize_from_files()
+    real(kind=dbl), allocatable :: v(:)
+    integer :: nr, nc, stat
+    if (.not.par0ok) then
+       call loadnumbers(parfile, v, nr, nc, stat)
+       if (stat /= 0 .or. size(v) < 1) call doerror('Error reading file, '//trim(parfile))
+       call MCMC_setpar0_vec(v)
+    end if
+    if (.not.cmat0ok) then
+       call loadnumbers(cov0file, v, nr, nc, stat)
+       if (stat /= 0 .or. nr /= npar .or. nc /= npar) call doerror('Error reading file mcmccov.dat')
+       call MCMC_setcmat0_mat(transpose(reshape(v, (/nc, nr/))))
+    end if
+    if (.not.sigma2ok) then
+       call loadnumbers(sigma2file, v, nr, nc, stat)
+       if (stat /= 0) then
+          call MCMC_setsigma2nobs_sca(1.0_dbl, 1)
+       else
+          if (size(v) < 2) call doerror('error in mcmcsigma2.dat (obs: new format 4.8.2006)')
+          call MCMC_setsigma2nobs_sca(v(1), int(v(2)))
+       end if
+    end if
+  end subroutine initialize_from_files
+
+  subroutine load_target_from_files()
+    real(kind=dbl), allocatable :: v(:), w(:)
+    integer :: nr, nc, stat
+    select case (trim(devtarget))
+    case ('gauss')
+       if (.not.allocated(tmu)) then
+          call loadnumbers(mufile, v, nr, nc, stat)
+          if (stat /= 0 .or. size(v) /= npar) call doerror('error in sizes: '//trim(mufile))
+          call loadnumbers(lamfile, w, nr, nc, stat)
+          if (stat /= 0 .or. size(w) /= npar*npar) call doerror('error in sizes: '//trim(lamfile))
+          call MCMC_settarget_gauss(v, transpose(reshape(w, (/npar, npar/))))
+       end if
+    case ('expdata')
+       if (.not.allocated(tx)) then
+          call loadnumbers(datafile, v, nr, nc, stat)
+          if (stat /= 0 .or. nc /= 2) call doerror('error reading '//trim(datafile))
+          call MCMC_settarget_expdata(v(1::2), v(2::2))
+       end if
+    case ('banana')
+    case default
+       call doerror('no device target selected: put devtarget= in an &mcmcx group or call MCMC_settarget_* ' // &
+            '(host ssfunction callbacks are not available in the device engine)')
+    end select
+    if (len_trim(lowerfile) > 0 .and. .not.has_lo) then
+       call loadnumbers(lowerfile, v, nr, nc, stat)
+       if (stat /= 0 .or. size(v) /= npar) call doerror('error reading '//trim(lowerfile))
+       call MCMC_setbounds(lo=v)
+    end if
+    if (len_trim(upperfile) > 0 .and. .not.has_hi) then
+       call loadnumbers(upperfile, v, nr, nc, stat)
+       if (stat /= 0 .or. size(v) /= npar) call doerror('error reading '//trim(upperfile))
+       call MCMC_setbounds(hi=v)
+    end if
+    if (len_trim(priorsfile) > 0) then                ! priorfun.f90:52-80: two rows, mu and sigma
+       call loadnumbers(priorsfile, v, nr, nc, stat)
+       if (stat /= 0 .or. size(v) /= 2*npar) call doerror('priors.dat should have  2*npar elements')
+       allocate(pmu(npar), psig(npar)); pmu = v(1:npar); psig = v(npar+1:2*npar)
+    end if
+  end subroutine load_target_from_files
+
+  !! ---------------------------------------------------------------- MCMC_init + MCMC_run* + results
+  subroutine MCMC_engine_run()
+    type(mcmcx_config) :: cfg
+    integer(c_int32_t) :: c8(8), nrows, nob(1)
+    real(kind=dbl), allocatable :: ch(:), ss(:), s2(:), cm(:), sc(:)
+    real(kind=dbl), target, allocatable :: lo(:), hi(:)
+    real(kind=dbl) :: lamrow(npar*npar)
+    type(c_ptr) :: plo, phi
+    integer :: i, j
+    call mcmcx_config_defaults(cfg)
+    cfg%npar = npar; cfg%nchains = nchains; cfg%nsimu = nsimu
+    select case (trim(method))
+    case ('ram');  cfg%method = 1
+    case ('scam'); cfg%method = 2
+    case ('er');   cfg%method = 3
+    case default;  cfg%method = 0
+    end select
+    cfg%doadapt = doadapt; cfg%doburnin = doburnin; cfg%adaptint = adaptint; cfg%adapthist = adapthist
+    cfg%badaptint = badaptint; cfg%adaptend = adaptend; cfg%initcmatn = initcmatn
+    cfg%burnintime = burnintime; cfg%greedy = greedy; cfg%updatesigma = updatesigma
+    cfg%scalelimit = scalelimit; cfg%scalefactor = scalefactor; cfg%drscale = drscale
+    cfg%N0 = N0; cfg%S02 = S02; cfg%condmax = condmax; cfg%alphatarget = alphatarget; cfg%nuparam = nuparam
+    cfg%seed = seed; cfg%chain_id0 = 0; cfg%record_accept = 0; cfg%record_chain = 1; cfg%device = 0
+    call chk(mcmcx_create(cfg, handle))
+    call chk(mcmcx_set_par0(handle, par0, int(npar, c_int32_t)))
+    call chk(mcmcx_set_cmat0(handle, cmat0, int(npar, c_int32_t)))
+    nob(1) = nobs(1)
+    call chk(mcmcx_set_sigma2nobs(handle, sigma2, nob, 1_c_int32_t))
+    select case (trim(devtarget))
+    case ('gauss')
+       do i = 1, npar                                  ! row-major lam(i,j) for the C side
+          do j = 1, npar
+             lamrow((i-1)*npar + j) = tlam(i,j)
+          end do
+       end do
+       call chk(mcmcx_set_target_gauss(handle, tmu, lamrow))
+    case ('banana')
+       call chk(mcmcx_set_target_banana(handle, banana_b))
+    case ('expdata')
+       call chk(mcmcx_set_target_expdata(handle, int(size(tx), c_int32_t), tx, ty))
+    end select
+    plo = c_null_ptr; phi = c_null_ptr
+    if (has_lo) then
+       allocate(lo(npar)); lo = tlo; plo = c_loc(lo)
+    end if
+    if (has_hi) then
+       allocate(hi(npar)); hi = thi; phi = c_loc(hi)
+    end if
+    if (has_lo .or. has_hi) call chk(mcmcx_set_bounds(handle, plo, phi))
+    if (allocated(pmu)) call chk(mcmcx_set_priors(handle, pmu, psig))
+    call chk(mcmcx_init(handle))
+    MCMC_running = 1
+    call chk(mcmcx_run(handle, int(nsimu, c_int32_t)))
+    call chk(mcmcx_sync(handle))
+    MCMC_running = 0
+    simuind = nsimu
+    !! chain 0 in the reference's arrays
+    allocate(ch(nsimu*(npar+1)), ss(nsimu*2), s2(nsimu), cm(npar*npar), sc(4*nchains))
+    call chk(mcmcx_get_chain(handle, 0_c_int32_t, ch, ss, s2, nrows))
+    chainind = nrows
+    if (allocated(chain)) deallocate(chain, sschain)
+    allocate(chain(nsimu, npar+1), sschain(nsimu, 2))
+    chain = 0.0_dbl; sschain = 0.0_dbl
+    do i = 1, chainind
+       chain(i,:) = ch((i-1)*(npar+1)+1 : i*(npar+1))
+       sschain(i,:) = ss((i-1)*2+1 : i*2)
+    end do
+    if (updatesigma /= 0) then
+       if (allocated(s2chain)) deallocate(s2chain)
+       allocate(s2chain(nsimu,1)); s2chain(:,1) = s2
+    end if
+    if (allocated(chaincmat)) deallocate(chaincmat, chainmean)
+    allocate(chaincmat(npar,npar), chainmean(npar))
+    call chk(mcmcx_get_chaincov(handle, 0_c_int32_t, cm, chainmean, chainwsum))
+    chaincmat = reshape(cm, (/npar, npar/))
+    call chk(mcmcx_get_counters(handle, 0_c_int32_t, c8))
+    stayed = c8(1); bndstayed = c8(2); draccepted = c8(3); drtries = c8(4)
+    call chk(mcmcx_get_scalars(handle, sc))
+    sigma2(1) = sc(3)
+  end subroutine MCMC_engine_run
+
+  !! MCMC_writechains, MCMC_aux.F90:17-85 (ASCII branch)
+  subroutine MCMC_writechains()
+    call writenumbers(chainfile, chain(1:chainind,:))
+    call writenumbers(ssfile, sschain(1:chainind,:))
+    if (updatesigma /= 0) call writenumbers(s2file, s2chain(1:simuind,:))
+    call writenumbers(covffile, chaincmat)
+    call writenumbers(meanfile, reshape(chainmean, (/npar, 1/)))
+    call writenumbers(parffile, chain(chainind:chainind, 1:npar))
+    if (updatesigma /= 0) call writenumbers(sigma2ffile, &
+         reshape((/s2chain(simuind,1), dble(nobs(1))/), (/2, 1/)))
+    if (verbosity > 0) write(*,*) 'note: saved results in ', trim(chainfile), ' and ', trim(ssfile), '.'
+  end subroutine MCMC_writechains
+
+  subroutine MCMC_cleanup()
+    integer(c_int) :: rc
+    rc = mcmcx_destroy(handle)
+    handle = c_null_ptr
+    nparok = .false.; par0ok = .false.; cmat0ok = .false.; sigma2ok = .false.
+  end subroutine MCMC_cleanup
+
+end module mcmcmod
+
+!!! mcmc_main, mcmc_main.F90:12-44: external, no arguments
+subroutine mcmc_main()
+  use mcmcmod
+  implicit none
+  integer :: status
+  write(*,*) 'MCMC code version: ', Mcmc_Code_Version
+  call read_mcmcinit_namelist(status)
+  if (status /= 0) call doerror('error in mcmcinit namelist')          ! MCMC_init.F90:35
+  if (nsimu <= 0) then
+     write(*,*) 'nsimu <= 0 stopping'
+     stop
+  end if
+  call initialize_from_files()
+  call load_target_from_files()
+  call MCMC_engine_run()
+  call MCMC_writechains()
+  call MCMC_cleanup()
+end subroutine mcmc_main

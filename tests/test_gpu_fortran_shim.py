@@ -1,0 +1,74 @@
+"""The drop-in boundary end to end: a Fortran driver program shaped like the reference's
+testcases/mcmcrun.F90 (`call mcmc_main()`), linked against the ISO_C_BINDING shim
+(mcmcf90_amd/fortran/mcmcx_mod.F90) + libmcmcx.so, reads the reference's own shipped namelist
+(testcases/mcmcinit.nml values) and .dat inputs and must write the chain the real reference wrote
+(fixture c1_shipped_nml): identical run-length column, theta to BLAS/libm rounding."""
+import os
+import subprocess
+import tempfile
+import numpy as np
+import pytest
+from golden_util import load
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FDIR = os.path.join(ROOT, "mcmcf90_amd", "fortran")
+
+NML = """!! Run time parameters for the mcmc run (values of the reference's testcases/mcmcinit.nml)
+&mcmc
+ method = 'dram'
+ nsimu       = 1000
+ verbosity   = 1
+ doadapt     = 1
+ adaptint    = 200
+ burnintime  = 1000
+ doburnin    = 1
+ drscale     = 0
+ printint    = 100
+ updatesigma = 1
+ N0          = 1
+ S02         = 0
+ chainfile   = 'chain.dat'
+ ssfile      = 'sschain.dat'
+ s2file      = 's2chain.dat'
+/
+&mcmcx
+ devtarget = 'expdata'
+ datafile  = 'data.dat'
+ lowerfile = 'lower.dat'
+ nchains   = 64
+/
+"""
+
+
+def test_fortran_driver_reproduces_reference_chain(oracle):
+    exe = os.path.join(FDIR, "demo_main")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", FDIR])
+    z, cfg, prob = load("c1_shipped_nml", oracle)
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "mcmcinit.nml"), "w").write(NML)
+        with open(os.path.join(d, "data.dat"), "w") as f:
+            f.write("% example data set\n")
+            for x, y in zip(z["prob_xdata"], z["prob_ydata"]):
+                f.write("  %g   %.2f\n" % (x, y))
+        open(os.path.join(d, "mcmcpar.dat"), "w").write("10 0.1 \n")
+        open(os.path.join(d, "mcmccov.dat"), "w").write("0.2 0 \n0 0.001 \n")
+        open(os.path.join(d, "mcmcsigma2.dat"), "w").write("0.5\n11\n")
+        open(os.path.join(d, "lower.dat"), "w").write("0 0\n")
+        p = subprocess.run([exe], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        out = p.stdout.decode(errors="replace")
+        assert p.returncode == 0, out
+        chain = np.loadtxt(os.path.join(d, "chain.dat"), ndmin=2)
+        s2 = np.loadtxt(os.path.join(d, "s2chain.dat"), ndmin=1)
+        ss = np.loadtxt(os.path.join(d, "sschain.dat"), ndmin=2)
+    np.testing.assert_array_equal(chain[:, -1].astype(np.int32), z["runlen"])
+    k = z["rows_head"].shape[0]
+    np.testing.assert_allclose(chain[:k, :-1], z["rows_head"], rtol=1e-9)
+    np.testing.assert_allclose(chain[-k:, :-1], z["rows_tail"], rtol=1e-9)
+    np.testing.assert_allclose(s2[-k:], z["s2_tail"], rtol=1e-9)
+    np.testing.assert_allclose(ss[-k:, 0], z["ss_tail"], rtol=1e-9)
+    # and bit for bit against the oracle (ES24.16 round-trips a double)
+    o = oracle.run_chain(cfg, prob, chain_id=0)
+    np.testing.assert_array_equal(chain, o.chain)
+    np.testing.assert_array_equal(s2, o.s2chain)
