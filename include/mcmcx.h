@@ -95,6 +95,8 @@ int mcmcx_get_scalars(mcmcx_handle h, double *out /* [nchains][4] */);
 int mcmcx_get_rng(mcmcx_handle h, int32_t chain, uint64_t *n, int32_t *saved, double *saved_y);
 int mcmcx_get_R(mcmcx_handle h, int32_t chain, double *R_colmajor);
 int mcmcx_get_chaincov(mcmcx_handle h, int32_t chain, double *cmat_colmajor, double *mean, double *wsum);
+/* delayed-rejection state of one chain: R2 = R/drscale and the upper triangle of iC (mcmc.F90:36) */
+int mcmcx_get_dr(mcmcx_handle h, int32_t chain, double *R2_colmajor, double *iC_colmajor);
 /* accept flags of iterations 1..simuind for one chain (needs record_accept or record_chain) */
 int mcmcx_get_accepted(mcmcx_handle h, int32_t chain, uint8_t *accepted);
 /* raw wavefront ballots: masks[(it-1)*ntiles + tile], bit l = chain tile*64+l moved at iteration it */

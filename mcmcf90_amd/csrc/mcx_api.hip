@@ -111,7 +111,44 @@ static int host_initial_R(int d, const std::vector<double> &cm, std::vector<doub
     return 0;
 }
 
-static size_t lds_bytes(const mcmcx_engine *h) { return (size_t)h->d * 64 * sizeof(double); }
+// dpotri('U') on the packed factor (dtrti2 + dlauu2), same operation sequence as the device's potri_packed
+static int host_potri(int d, std::vector<double> &A)
+{
+    for (int j = 0; j < d; ++j) if (A[h_pidx(j, j, d)] == 0.0) return j + 1;
+    std::vector<double> x(d);
+    for (int j = 0; j < d; ++j) {
+        double ajj = 1.0 / A[h_pidx(j, j, d)];
+        A[h_pidx(j, j, d)] = ajj; ajj = -ajj;
+        for (int i = 0; i < j; ++i) x[i] = A[h_pidx(i, j, d)];
+        for (int jj = 0; jj < j; ++jj) {
+            double temp = x[jj];
+            if (temp != 0.0) {
+                for (int i = 0; i < jj; ++i) x[i] = std::fma(temp, A[h_pidx(i, jj, d)], x[i]);
+                x[jj] = temp * A[h_pidx(jj, jj, d)];
+            }
+        }
+        for (int i = 0; i < j; ++i) A[h_pidx(i, j, d)] = ajj * x[i];
+    }
+    for (int i = 0; i < d; ++i) {
+        double aii = A[h_pidx(i, i, d)];
+        if (i < d - 1) {
+            double dot = 0.0;
+            for (int k = i; k < d; ++k) dot = std::fma(A[h_pidx(i, k, d)], A[h_pidx(i, k, d)], dot);
+            A[h_pidx(i, i, d)] = dot;
+            for (int r = 0; r < i; ++r) x[r] = aii * A[h_pidx(r, i, d)];
+            for (int k = i + 1; k < d; ++k) {
+                double temp = A[h_pidx(i, k, d)];
+                if (temp != 0.0) for (int r = 0; r < i; ++r) x[r] = std::fma(temp, A[h_pidx(r, k, d)], x[r]);
+            }
+            for (int r = 0; r < i; ++r) A[h_pidx(r, i, d)] = x[r];
+        } else {
+            for (int r = 0; r <= i; ++r) A[h_pidx(r, i, d)] = aii * A[h_pidx(r, i, d)];
+        }
+    }
+    return 0;
+}
+
+static size_t lds_bytes(const mcmcx_engine *h) { return (size_t)h->d * 64 * sizeof(double) * (h->dodr ? 2 : 1); }
 static void launch_init(mcmcx_engine *h)
 { hipLaunchKernelGGL(init_kernel, dim3(h->ntiles), dim3(64), lds_bytes(h), h->stream, h->E); }
 static void launch_step(mcmcx_engine *h, int it0, int it1)
@@ -215,7 +252,6 @@ int mcmcx_create(const mcmcx_config *cfg_in, mcmcx_handle *out)
     if (c.npar < 1 || c.npar > MCX_MAX_NPAR) return fail(-5, "npar must be in 1.." + std::to_string(MCX_MAX_NPAR));
     if (c.nchains < 1) return fail(-5, "nchains must be >= 1");
     if (c.condmax > 0.0) return fail(-6, "condmax > 0 (SVD proposal) is not available in the device engine yet");
-    if (c.drscale > 0.0) return fail(-6, "drscale > 0 (delayed rejection) is not available in the device engine yet");
     if (c.doadapt && c.method == MCMCX_METHOD_DRAM) {
         if (c.adaptint == 0) return fail(-7, "doadapt with adaptint = 0");
         if (c.adapthist > 1) return fail(-6, "adapthist > 1 (AP window) is not available in the device engine yet");
@@ -229,7 +265,7 @@ int mcmcx_create(const mcmcx_config *cfg_in, mcmcx_handle *out)
     mcmcx_engine *h = new mcmcx_engine();
     h->cfg = c; h->d = c.npar; h->P = c.npar * (c.npar + 1) / 2;
     h->ntiles = (c.nchains + 63) / 64; h->nlanes = h->ntiles * 64;
-    h->dodr = 0; h->usesvd = 0;
+    h->dodr = (c.drscale > 0.0) ? 1 : 0; h->usesvd = 0;
     e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(-100, hipGetErrorString(e)); }
     h->own_stream = true;
@@ -338,7 +374,7 @@ int mcmcx_init(mcmcx_handle h)
     EngineDev &E = h->E;
     E.d = d; E.P = P; E.ntiles = T;
     E.method = (c.method == MCMCX_METHOD_RAM) ? M_RAM : M_DRAM;
-    E.dodr = 0; E.updatesigma = c.updatesigma; E.doadapt = c.doadapt; E.doburnin = c.doburnin; E.burnintime = c.burnintime;
+    E.dodr = h->dodr; E.updatesigma = c.updatesigma; E.doadapt = c.doadapt; E.doburnin = c.doburnin; E.burnintime = c.burnintime;
     E.gam_shape = shape; E.N0S02 = c.N0 * h->S02eff;
     E.alphatarget = c.alphatarget; E.drscale = c.drscale; E.scalelimit = c.scalelimit; E.scalefactor = c.scalefactor;
     E.k0 = c.seed; E.chain_id0 = c.chain_id0;
@@ -366,6 +402,10 @@ int mcmcx_init(mcmcx_handle h)
     if ((rc = dev_alloc(h, &E.R, L * P, false))) return rc;
     if ((rc = dev_alloc(h, &E.basetheta, L * d))) return rc;
     E.R2 = E.iC = nullptr;
+    if (h->dodr) {
+        if ((rc = dev_alloc(h, &E.R2, L * P, false))) return rc;
+        if ((rc = dev_alloc(h, &E.iC, L * P, false))) return rc;
+    }
     const bool am = (E.method == M_DRAM) && (c.doadapt != 0 || c.doburnin != 0);
     E.cmat = E.mean = E.Rtmp = nullptr; E.rowlist = nullptr;
     // history ring
@@ -419,6 +459,19 @@ int mcmcx_init(mcmcx_handle h)
         HIPCHK(hipMemcpyAsync(E.R, Rv.data(), Rv.size() * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(E.scal, sc.data(), sc.size() * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(E.ictr, ic.data(), ic.size() * 4, hipMemcpyHostToDevice, h->stream));
+        if (h->dodr) {                                   // iC = dpotri(R), R2 = R/drscale, MCMC_adapt.F90:216-225
+            std::vector<double> iCp = Rp, R2p(P);
+            if (host_potri(d, iCp) != 0) return fail(-34, "ERROR: cannot invert cmat");
+            for (int e = 0; e < P; ++e) R2p[e] = Rp[e] / c.drscale;
+            std::vector<double> v2(L * P), vi(L * P);
+            for (int t = 0; t < T; ++t)
+                for (int e = 0; e < P; ++e) for (int l = 0; l < 64; ++l) {
+                    v2[((size_t)t * P + e) * 64 + l] = R2p[e]; vi[((size_t)t * P + e) * 64 + l] = iCp[e];
+                }
+            HIPCHK(hipMemcpyAsync(E.R2, v2.data(), v2.size() * 8, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(E.iC, vi.data(), vi.size() * 8, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
         if (am) {
             std::vector<double> cv(L * P), mv(L * d);
             for (int t = 0; t < T; ++t) {
@@ -566,6 +619,16 @@ int mcmcx_get_R(mcmcx_handle h, int32_t chain, double *R)
     std::vector<double> p;
     if ((rc = fetch_chain_vec(h, h->E.R, h->P, chain, p))) return rc;
     unpack_upper(h->d, p, R, false);
+    return 0;
+}
+
+int mcmcx_get_dr(mcmcx_handle h, int32_t chain, double *R2, double *iC)
+{
+    int rc = check_chain(h, chain); if (rc) return rc;
+    if (!h->dodr) return fail(-43, "drscale = 0: no delayed-rejection state");
+    std::vector<double> p;
+    if (R2) { if ((rc = fetch_chain_vec(h, h->E.R2, h->P, chain, p))) return rc; unpack_upper(h->d, p, R2, false); }
+    if (iC) { if ((rc = fetch_chain_vec(h, h->E.iC, h->P, chain, p))) return rc; unpack_upper(h->d, p, iC, false); }
     return 0;
 }
 

@@ -23,7 +23,7 @@ enum { I_SAVED = 0, I_STAYED, I_BNDSTAYED, I_DRACC, I_DRTRIES, I_CHAININD, I_CUR
        I_LASTFREQ, I_BASECNT, I_WINSTART, I_INFO, NICTR };
 
 // status bits
-enum { ST_RAM_DOWNDATE_FAIL = 1, ST_CHOL_FAIL = 2 };
+enum { ST_RAM_DOWNDATE_FAIL = 1, ST_CHOL_FAIL = 2, ST_POTRI_FAIL = 4 };
 
 struct DevTarget {
     int kind;
@@ -299,6 +299,29 @@ MCX_DEV void ram_update(double *Rt, const double *zs_t, double *cs_t, int lane, 
     }
 }
 
+// ---------------------------------------------------------------- delayed rejection (MCMC_run.F90:65-91)
+// q = dx' iC dx with iC symmetric, upper triangle packed by rows (dsymv 'U' + sum, MCMC_DRAM.F90:180-182,
+// matutils.F90:180): y_i = sum_j S(i,j) dx_j ascending j as an fma chain, q = sum_i y_i dx_i.
+// One sweep over the rows: row i finishes y_i and feeds S(i,j) dx_i into y_j for j > i.
+// X holds dx, Y the running y; both per-lane LDS vectors.
+MCX_DEV double quadform_sym(const double *St, int lane, int d, const double *X, double *Y)
+{
+    double q = 0.0;
+    for (int i = 0; i < d; ++i) {
+        const double *rowp = St + (size_t)rowstart(i, d) * 64;
+        const int n = d - i;
+        const double dxi = XL(i);
+        double sii = GV(rowp, 0);
+        double yi = (i == 0) ? sii * dxi : dfma(sii, dxi, Y[i * 64 + lane]);
+        sweep(rowp, lane, 1, n, [&](int k, double sij) {
+            yi = dfma(sij, XL(i + k), yi);
+            Y[(i + k) * 64 + lane] = (i == 0) ? sij * dxi : dfma(sij, dxi, Y[(i + k) * 64 + lane]);
+        });
+        q = q + yi * dxi;
+    }
+    return q;
+}
+
 // ---------------------------------------------------------------- the step kernel
 // Iterations it0..it1 (absolute simuind) of MCMC_run (MCMC_run.F90:41-107, no DR stage here)
 // or MCMC_run_ram (MCMC_run_ram.F90:45-81) for one tile of 64 chains.  Dynamic LDS: d*64 doubles.
@@ -311,6 +334,8 @@ __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1,
     double *zs_t = E.zs + (size_t)tile * d * 64;
     double *cs_t = E.cs + (size_t)tile * 2 * d * 64;
     double *Rt = E.R + (size_t)tile * E.P * 64;
+    double *Y = X + (size_t)d * 64;                       // second LDS vector, only allocated when dodr
+    double *c2_t = cs_t;                                  // DR: second-stage candidate (cs is RAM-only scratch)
 
     Rng g;
     g.k0 = E.k0; g.k1 = E.chain_id0 + (uint32_t)(tile * 64 + lane);
@@ -322,6 +347,7 @@ __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1,
     uint32_t stayed = TIDX(E.ictr, tile, NICTR, I_STAYED, lane), bnd = TIDX(E.ictr, tile, NICTR, I_BNDSTAYED, lane);
     uint32_t chainind = TIDX(E.ictr, tile, NICTR, I_CHAININD, lane), curcount = TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane);
     uint32_t status = TIDX(E.ictr, tile, NICTR, I_STATUS, lane);
+    uint32_t dracc = TIDX(E.ictr, tile, NICTR, I_DRACC, lane), drtries = TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane);
 
     for (int it = it0; it <= it1; ++it) {
         // ---- newpar = MCMC_propose(oldpar, R)
@@ -334,13 +360,47 @@ __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1,
         double ss2 = target_ss(E.tgt, d, X, lane, cand_t);
         bool reject;
         if (!inb) {
-            bnd += 1; reject = true;
+            if (!E.dodr) bnd += 1;                        // MCMC_run.F90:49
+            reject = true;
             if (E.method != M_RAM) alpha12 = 0.0;        // RAM leaves alpha12 stale: MCMC_run_ram.F90:52-54
         } else {
             alpha12 = d_alpha(ss1, pri1, ss2, pri2, sigma2);
             reject = true;                                // MCMC_reject, MCMC_DRAM.F90:140-155
             if (alpha12 >= 1.0) reject = false;
             else if (alpha12 > 0.0) { double u = rng_uniform(g); if (u <= alpha12) reject = false; }
+        }
+        // ---- second stage: one delayed-rejection try with R2 = R/drscale (MCMC_run.F90:65-91)
+        bool dr_moved = false;
+        if (E.dodr && __any(reject)) {
+            const bool m = reject;
+            if (m) drtries += 1;
+            gen_normals(g, zs_t, lane, d, m);
+            if (m) {
+                trmv_rows(E.R2 + (size_t)tile * E.P * 64, zs_t, lane, d, X);
+                for (int k = 0; k < d; ++k) { double v = GV(theta_t, k) + XL(k); XL(k) = v; GV(c2_t, k) = v; }
+                bool inb2 = target_inbounds(E.tgt, d, X, lane);
+                if (!inb2) bnd += 1;
+                else {
+                    double pri3 = target_prior(E.tgt, d, X, lane);
+                    double ss3 = target_ss(E.tgt, d, X, lane, c2_t);
+                    // MCMC_DR_alpha13, MCMC_DRAM.F90:162-186
+                    double alpha32;
+                    if (alpha12 == 0.0) alpha32 = 0.0;
+                    else alpha32 = min1(d_exp(-0.5 * ((ss2 - ss3) / sigma2 + (pri2 - pri3))));
+                    double l2 = -0.5 * ((ss3 - ss1) / sigma2 + (pri3 - pri1));
+                    const double *iCt = E.iC + (size_t)tile * E.P * 64;
+                    for (int k = 0; k < d; ++k) XL(k) = GV(c2_t, k) - GV(cand_t, k);
+                    double qa = quadform_sym(iCt, lane, d, X, Y);
+                    for (int k = 0; k < d; ++k) XL(k) = GV(theta_t, k) - GV(cand_t, k);
+                    double qb = quadform_sym(iCt, lane, d, X, Y);
+                    double q1 = -0.5 * (qa - qb);
+                    double alpha13 = min1(d_exp(l2 + q1) * (1.0 - alpha32) / (1.0 - alpha12));
+                    bool rej2 = true;
+                    if (alpha13 >= 1.0) rej2 = false;
+                    else if (alpha13 > 0.0) { double u = rng_uniform(g); if (u <= alpha13) rej2 = false; }
+                    if (!rej2) { dracc += 1; reject = false; dr_moved = true; ss2 = ss3; pri2 = pri3; }
+                }
+            }
         }
         if (reject) { stayed += 1; curcount += 1; }
         else { ss1 = ss2; pri1 = pri2; chainind += 1; curcount = 1; }
@@ -354,8 +414,9 @@ __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1,
         const int slot = it % E.wcap;
         if (!reject) {
             double *h = E.hist ? E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64 : nullptr;
+            const double *src = dr_moved ? c2_t : cand_t;     // newpar = newpar2 when the DR try was accepted
             for (int k = 0; k < d; ++k) {
-                double v = GV(cand_t, k);
+                double v = GV(src, k);
                 GV(theta_t, k) = v;
                 if (h) GV(h, k) = v;
             }
@@ -381,6 +442,7 @@ __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1,
     TIDX(E.ictr, tile, NICTR, I_STAYED, lane) = stayed; TIDX(E.ictr, tile, NICTR, I_BNDSTAYED, lane) = bnd;
     TIDX(E.ictr, tile, NICTR, I_CHAININD, lane) = chainind; TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane) = curcount;
     TIDX(E.ictr, tile, NICTR, I_STATUS, lane) = status;
+    TIDX(E.ictr, tile, NICTR, I_DRACC, lane) = dracc; TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane) = drtries;
 }
 
 // ---------------------------------------------------------------- first point (MCMC_run.F90:33-39)
@@ -443,6 +505,52 @@ MCX_DEV int calculate_R(double *Ct, double *Rt, int lane, int d, int P, bool act
     return info;
 }
 
+// dpotri('U') on a packed upper factor, in place: dtrti2('U','N') then dlauu2('U') (MCMC_adapt.F90:217-224).
+// On exit A holds the upper triangle of inv(R'R).  X (LDS) carries one column above the diagonal.
+MCX_DEV int potri_packed(double *At, int lane, int d, bool act, double *X)
+{
+    int info = 0;
+    for (int j = 0; j < d; ++j) if (act && info == 0 && GV(At, pidx(j, j, d)) == 0.0) info = j + 1;
+    const bool go = act && info == 0;
+    if (__any(go)) {
+        if (go) {
+            for (int j = 0; j < d; ++j) {                    // dtrti2
+                double ajj = 1.0 / GV(At, pidx(j, j, d));
+                GV(At, pidx(j, j, d)) = ajj;
+                ajj = -ajj;
+                for (int i = 0; i < j; ++i) XL(i) = GV(At, pidx(i, j, d));
+                for (int jj = 0; jj < j; ++jj) {             // dtrmv('U','N','N') with the inverted leading block
+                    double temp = XL(jj);
+                    if (temp != 0.0) {
+                        for (int i = 0; i < jj; ++i) XL(i) = dfma(temp, GV(At, pidx(i, jj, d)), XL(i));
+                        XL(jj) = temp * GV(At, pidx(jj, jj, d));
+                    }
+                }
+                for (int i = 0; i < j; ++i) GV(At, pidx(i, j, d)) = ajj * XL(i);
+            }
+            for (int i = 0; i < d; ++i) {                    // dlauu2
+                double *rowi = At + (size_t)rowstart(i, d) * 64;
+                double aii = GV(rowi, 0);
+                if (i < d - 1) {
+                    double dot = 0.0;
+                    for (int k = 0; k < d - i; ++k) { double v = GV(rowi, k); dot = dfma(v, v, dot); }
+                    GV(rowi, 0) = dot;
+                    for (int r = 0; r < i; ++r) XL(r) = aii * GV(At, pidx(r, i, d));
+                    for (int k = i + 1; k < d; ++k) {
+                        double temp = GV(rowi, k - i);
+                        if (temp != 0.0)
+                            for (int r = 0; r < i; ++r) XL(r) = dfma(temp, GV(At, pidx(r, k, d)), XL(r));
+                    }
+                    for (int r = 0; r < i; ++r) GV(At, pidx(r, i, d)) = XL(r);
+                } else {
+                    for (int r = 0; r <= i; ++r) GV(At, pidx(r, i, d)) = aii * GV(At, pidx(r, i, d));
+                }
+            }
+        }
+    }
+    return info;
+}
+
 __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode)
 {
     extern __shared__ double X[];
@@ -468,8 +576,16 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
         double sf = E.scalefactor;
         if (staypc > 1.0 - E.scalelimit) {
             for (int e = 0; e < P; ++e) GV(Rt, e) = GV(Rt, e) / sf;
+            if (E.dodr) {
+                double *R2t = E.R2 + (size_t)tile * P * 64, *iCt = E.iC + (size_t)tile * P * 64;
+                for (int e = 0; e < P; ++e) { GV(R2t, e) = GV(R2t, e) / sf; GV(iCt, e) = GV(iCt, e) * sf * sf; }
+            }
         } else if (staypc < E.scalelimit) {
             for (int e = 0; e < P; ++e) GV(Rt, e) = GV(Rt, e) * sf;
+            if (E.dodr) {
+                double *R2t = E.R2 + (size_t)tile * P * 64, *iCt = E.iC + (size_t)tile * P * 64;
+                for (int e = 0; e < P; ++e) { GV(R2t, e) = GV(R2t, e) * sf; GV(iCt, e) = GV(iCt, e) / sf / sf; }
+            }
         } else {
             // lastind = chainind: the covariance window restarts at the current row (lastfreq is NOT touched)
             docalc = true;
@@ -589,6 +705,14 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
         if (docalc) {
             TIDX(E.ictr, tile, NICTR, I_INFO, lane) = (uint32_t)info;
             if (info != 0) TIDX(E.ictr, tile, NICTR, I_STATUS, lane) |= ST_CHOL_FAIL;   // warning, old R kept (:168-171)
+        }
+        if (E.dodr) {                                       // iC = dpotri(R), R2 = R/drscale (:216-225)
+            const bool ok = docalc && info == 0;
+            double *R2t = E.R2 + (size_t)tile * P * 64, *iCt = E.iC + (size_t)tile * P * 64;
+            if (ok) for (int e = 0; e < P; ++e) GV(iCt, e) = GV(Rt, e);
+            int info2 = potri_packed(iCt, lane, d, ok, X);
+            if (ok && info2 != 0) TIDX(E.ictr, tile, NICTR, I_STATUS, lane) |= ST_POTRI_FAIL;  // the reference stops
+            if (ok) for (int e = 0; e < P; ++e) GV(R2t, e) = GV(Rt, e) / E.drscale;
         }
     }
     TIDX(E.ictr, tile, NICTR, I_LASTFREQ, lane) = lastfreq;

@@ -141,6 +141,12 @@ class Engine:
         self._chk(self.L.mcmcx_get_R(self.h, chain, a.ctypes.data_as(C.POINTER(C.c_double))))
         return np.array(a)
 
+    def dr_state(self, chain=0):
+        r2 = np.zeros((self.npar, self.npar), order="F"); ic = np.zeros((self.npar, self.npar), order="F")
+        dp = C.POINTER(C.c_double)
+        self._chk(self.L.mcmcx_get_dr(self.h, chain, r2.ctypes.data_as(dp), ic.ctypes.data_as(dp)))
+        return np.array(r2), np.array(ic)
+
     def chaincov(self, chain=0):
         a = np.zeros((self.npar, self.npar), order="F"); m = np.zeros(self.npar); w = C.c_double()
         self._chk(self.L.mcmcx_get_chaincov(self.h, chain, a.ctypes.data_as(C.POINTER(C.c_double)), _dp(m), C.byref(w)))

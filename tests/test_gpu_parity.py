@@ -9,8 +9,9 @@ from golden_util import names, load, accepted_from_runlen, GOLDEN
 
 pytestmark = pytest.mark.gpu
 
-# fixtures whose namelist the device engine supports today (no DR / AP / greedy)
-SUPPORTED = ["c1_shipped_nml", "c2_gauss10_am", "c2_gauss10_am_initcmatn", "c4_gauss50_ram", "c4_gauss50_am"]
+# fixtures whose namelist the device engine supports today (no AP window / greedy burn-in)
+SUPPORTED = ["c1_shipped_nml", "c2_gauss10_am", "c2_gauss10_am_initcmatn", "c3_banana20_dram", "c4_gauss50_ram",
+             "c4_gauss50_am"]
 
 
 def _kw(z):
@@ -60,6 +61,11 @@ def test_engine_matches_oracle_and_reference(oracle, name):
         assert (n, saved) == (o.rng_n, o.rng_saved)
         cnt = e.counters(c)
         assert (cnt["stayed"], cnt["bndstayed"], cnt["chainind"]) == (o.stayed, o.bndstayed, o.chainind)
+        assert (cnt["draccepted"], cnt["drtries"]) == (o.draccepted, o.drtries)
+        if cfg.dodr:
+            r2, ic = e.dr_state(c)
+            np.testing.assert_array_equal(_bits(np.triu(r2)), _bits(np.triu(o.R2)))
+            np.testing.assert_array_equal(_bits(np.triu(ic)), _bits(np.triu(o.iC)))
         np.testing.assert_array_equal(_bits(np.triu(e.R(c))), _bits(np.triu(o.R)))
         cm, mean, wsum = e.chaincov(c)
         np.testing.assert_array_equal(_bits(np.triu(cm)), _bits(np.triu(o.chaincmat)))
