@@ -148,11 +148,12 @@ static int host_potri(int d, std::vector<double> &A)
     return 0;
 }
 
-static size_t lds_bytes(const mcmcx_engine *h) { return (size_t)h->d * 64 * sizeof(double) * (h->dodr ? 2 : 1); }
+static size_t lds_bytes(const mcmcx_engine *h) { return (size_t)h->d * 64 * sizeof(double) * 2; }   // adapt / DR work vectors
+static size_t lds_step(const mcmcx_engine *h) { return h->dodr ? lds_bytes(h) : 0; }
 static void launch_init(mcmcx_engine *h)
-{ hipLaunchKernelGGL(init_kernel, dim3(h->ntiles), dim3(64), lds_bytes(h), h->stream, h->E); }
+{ hipLaunchKernelGGL(init_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E); }
 static void launch_step(mcmcx_engine *h, int it0, int it1)
-{ hipLaunchKernelGGL(step_kernel, dim3(h->ntiles), dim3(64), lds_bytes(h), h->stream, h->E, it0, it1, h->d_ramscale + it0); }
+{ hipLaunchKernelGGL(step_kernel, dim3(h->ntiles), dim3(64), lds_step(h), h->stream, h->E, it0, it1, h->d_ramscale + it0); }
 static void launch_adapt(mcmcx_engine *h, int it, int mode)
 { hipLaunchKernelGGL(adapt_kernel, dim3(h->ntiles), dim3(64), lds_bytes(h), h->stream, h->E, it, mode); }
 
@@ -382,7 +383,14 @@ int mcmcx_init(mcmcx_handle h)
     E.tgt.kind = h->tkind; E.tgt.b = h->tb; E.tgt.ndata = (int)h->tx.size();
     E.tgt.mu = E.tgt.lam = E.tgt.x = E.tgt.y = E.tgt.lo = E.tgt.hi = E.tgt.pmu = E.tgt.psig = nullptr;
     int rc;
-    if (h->tkind == TGT_GAUSS) { if ((rc = dev_upload(h, &E.tgt.mu, h->tmu))) return rc; if ((rc = dev_upload(h, &E.tgt.lam, h->tlam))) return rc; }
+    E.tgt.lamT = nullptr;
+    if (h->tkind == TGT_GAUSS) {
+        if ((rc = dev_upload(h, &E.tgt.mu, h->tmu))) return rc;
+        if ((rc = dev_upload(h, &E.tgt.lam, h->tlam))) return rc;
+        std::vector<double> lt((size_t)d * d + 64, 0.0);           // transpose, padded for the 16-wide panel reads
+        for (int i = 0; i < d; ++i) for (int j = 0; j < d; ++j) lt[(size_t)j * d + i] = h->tlam[(size_t)i * d + j];
+        if ((rc = dev_upload(h, &E.tgt.lamT, lt))) return rc;
+    }
     if (h->tkind == TGT_EXPDATA) { if ((rc = dev_upload(h, &E.tgt.x, h->tx))) return rc; if ((rc = dev_upload(h, &E.tgt.y, h->ty))) return rc; }
     if (h->has_lo && (rc = dev_upload(h, &E.tgt.lo, h->tlo))) return rc;
     if (h->has_hi && (rc = dev_upload(h, &E.tgt.hi, h->thi))) return rc;
@@ -394,7 +402,7 @@ int mcmcx_init(mcmcx_handle h)
     const size_t L = (size_t)T * 64;
     if ((rc = dev_alloc(h, &E.theta, L * d))) return rc;
     if ((rc = dev_alloc(h, &E.cand, L * d))) return rc;
-    if ((rc = dev_alloc(h, &E.zs, L * d))) return rc;
+    if ((rc = dev_alloc(h, &E.zs, L * 2 * d))) return rc;
     if ((rc = dev_alloc(h, &E.cs, L * 2 * d))) return rc;
     if ((rc = dev_alloc(h, &E.scal, L * NSCAL))) return rc;
     if ((rc = dev_alloc(h, &E.ictr, L * NICTR))) return rc;

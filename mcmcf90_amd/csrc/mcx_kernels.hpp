@@ -5,9 +5,11 @@
 //     element k of chain (tile, lane)  ->  base[(tile*K + k)*64 + lane],
 // i.e. parameter-major inside a tile, so every wave access is one contiguous
 // 512-byte segment and a tile's whole Cholesky factor is one sequential stream.
-// The one per-lane d-vector a wave needs (proposal, rotation work vector, ...) lives in LDS as
-// X[j][lane]; the O(d^2) loops are plain row sweeps with the row's elements loaded 8 at a time, so
-// a wave always has several independent 512-byte loads in flight.  Nothing is templated on d.
+// The O(d^2) sweeps over a chain's packed factor are left-looking COLUMN PANELS: 16 columns of
+// per-lane state (rotation work values, proposal accumulators) live in registers with compile-time
+// indices, every row contributes one contiguous 16 x 512-byte segment, and the few O(d) vectors
+// (normals, rotations, candidate) sit in per-chain global scratch.  No LDS on the hot path, nothing
+// templated on d.
 #pragma once
 #include "mcx_device.hpp"
 
@@ -27,7 +29,7 @@ enum { ST_RAM_DOWNDATE_FAIL = 1, ST_CHOL_FAIL = 2, ST_POTRI_FAIL = 4 };
 
 struct DevTarget {
     int kind;
-    const double *mu, *lam;     // gauss: mean[d], precision row-major [d*d]
+    const double *mu, *lam, *lamT;   // gauss: mean[d], precision row-major [d*d] and its transpose (padded)
     double b;                   // banana
     int ndata;                  // expdata
     const double *x, *y;
@@ -113,65 +115,89 @@ MCX_DEV void sweep(const double *rowp, int lane, int k0, int n, F &&f)
 }
 
 // ---------------------------------------------------------------- targets (user ssfunction / priorfun / checkbounds)
-// X holds the candidate on entry; the Gaussian target overwrites it with (theta - mu).
-MCX_DEV double target_ss(const DevTarget &t, int d, double *X, int lane, const double *cand_t)
+// The candidate is read from a per-chain global scratch vector c_t (element stride 64); the
+// Gaussian target works on 16x16 register panels: y[16] (rows) x v[16] (columns), precision matrix
+// through scalar loads of its transpose (lamT[j*d + i] = lam(i,j), padded by PW doubles).
+constexpr int PW = 16;    // panel width: columns (or rows) of per-lane state held in registers
+
+MCX_DEV double target_ss(const DevTarget &t, int d, int lane, const double *c_t)
 {
     double ss = 0.0;
     if (t.kind == TGT_GAUSS) {
         // ss = (th-mu)' Lam (th-mu): y_i = sum_j lam(i,j) v_j ascending (fma chain), ss = sum_i y_i v_i (fma chain)
-        for (int j = 0; j < d; ++j) XL(j) = XL(j) - t.mu[j];
-        int i = 0;
-        for (; i + 4 <= d; i += 4) {               // four rows per pass over v: one LDS read feeds four chains
-            const double *__restrict__ r0 = t.lam + (size_t)i * d, *__restrict__ r1 = r0 + d, *__restrict__ r2 = r1 + d, *__restrict__ r3 = r2 + d;
-            double v0 = XL(0);
-            double y0 = r0[0] * v0, y1 = r1[0] * v0, y2 = r2[0] * v0, y3 = r3[0] * v0;
-            for (int j = 1; j < d; ++j) {
-                double v = XL(j);
-                y0 = dfma(r0[j], v, y0); y1 = dfma(r1[j], v, y1); y2 = dfma(r2[j], v, y2); y3 = dfma(r3[j], v, y3);
+        for (int I0 = 0; I0 < d; I0 += PW) {
+            const int nr = (d - I0) < PW ? (d - I0) : PW;
+            double y[PW];
+#pragma unroll
+            for (int u = 0; u < PW; ++u) y[u] = 0.0;
+            for (int J0 = 0; J0 < d; J0 += PW) {
+                const int nc = (d - J0) < PW ? (d - J0) : PW;
+                double v[PW];
+#pragma unroll
+                for (int w = 0; w < PW; ++w) { int j = J0 + (w < nc ? w : nc - 1); v[w] = GV(c_t, j) - t.mu[j]; }
+#pragma unroll
+                for (int w = 0; w < PW; ++w) {
+                    if (w < nc) {
+                        const double *__restrict__ lrow = t.lamT + (size_t)(J0 + w) * d + I0;
+                        if (J0 == 0 && w == 0) {
+#pragma unroll
+                            for (int u = 0; u < PW; ++u) y[u] = lrow[u] * v[0];
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < PW; ++u) y[u] = dfma(lrow[u], v[w], y[u]);
+                        }
+                    }
+                }
             }
-            if (i == 0) ss = y0 * XL(0); else ss = dfma(y0, XL(i), ss);
-            ss = dfma(y1, XL(i + 1), ss); ss = dfma(y2, XL(i + 2), ss); ss = dfma(y3, XL(i + 3), ss);
-        }
-        for (; i < d; ++i) {
-            const double *__restrict__ row = t.lam + (size_t)i * d;
-            double y = row[0] * XL(0);
-            for (int j = 1; j < d; ++j) y = dfma(row[j], XL(j), y);
-            if (i == 0) ss = y * XL(0); else ss = dfma(y, XL(i), ss);
+            double vi[PW];
+#pragma unroll
+            for (int u = 0; u < PW; ++u) { int i = I0 + (u < nr ? u : nr - 1); vi[u] = GV(c_t, i) - t.mu[i]; }
+#pragma unroll
+            for (int u = 0; u < PW; ++u) {
+                if (u < nr) { if (I0 == 0 && u == 0) ss = y[0] * vi[0]; else ss = dfma(y[u], vi[u], ss); }
+            }
         }
     } else if (t.kind == TGT_BANANA) {
-        double th0 = XL(0), th1 = XL(1);
+        double th0 = GV(c_t, 0), th1 = GV(c_t, 1);
         double t1 = th0 * th0;
         double q = dfma(t.b, t1, th1) - 100.0 * t.b;
         ss = dfma(q, q, t1 / 100.0);
-        for (int k = 2; k < d; ++k) { double v = XL(k); ss = dfma(v, v, ss); }
+#pragma unroll 4
+        for (int k = 2; k < d; ++k) { double v = GV(c_t, k); ss = dfma(v, v, ss); }
     } else {
-        double th0 = XL(0), th1 = XL(1);
+        double th0 = GV(c_t, 0), th1 = GV(c_t, 1);
         for (int i = 0; i < t.ndata; ++i) {
             double r = t.y[i] - th0 * d_exp(-(th1 * t.x[i]));
             ss = dfma(r, r, ss);
         }
     }
-    (void)cand_t;
     return ss;
 }
 
-MCX_DEV double target_prior(const DevTarget &t, int d, const double *X, int lane)
+MCX_DEV double target_prior(const DevTarget &t, int d, int lane, const double *c_t)
 {
     double p = 0.0;
     if (t.pmu) {
+#pragma unroll 4
         for (int i = 0; i < d; ++i) {
-            double sg = t.psig[i];
-            if (sg > 0.0) { double q = (XL(i) - t.pmu[i]) / sg; p = p + q * q; }
+            double sg = t.psig[i], th = GV(c_t, i);
+            if (sg > 0.0) { double q = (th - t.pmu[i]) / sg; p = p + q * q; }
         }
     }
     return p;
 }
 
-MCX_DEV bool target_inbounds(const DevTarget &t, int d, const double *X, int lane)
+MCX_DEV bool target_inbounds(const DevTarget &t, int d, int lane, const double *c_t)
 {
     bool ok = true;
-    if (t.lo) for (int i = 0; i < d; ++i) ok = ok && (XL(i) > t.lo[i]);
-    if (t.hi) for (int i = 0; i < d; ++i) ok = ok && (XL(i) < t.hi[i]);
+    if (t.lo || t.hi) {
+#pragma unroll 4
+        for (int i = 0; i < d; ++i) {
+            double th = GV(c_t, i);
+            if (t.lo) ok = ok && (th > t.lo[i]);
+            if (t.hi) ok = ok && (th < t.hi[i]);
+        }
+    }
     return ok;
 }
 
@@ -197,70 +223,159 @@ MCX_DEV void gen_normals(Rng &g, double *zs_t, int lane, int d, bool participate
     }
 }
 
-// ---------------------------------------------------------------- proposal: X = R'z  (MCMC_DRAM.F90:20-31)
-// dtrmv('U','T','N') (matutils.F90:108-109) in netlib accumulation order: p_j = z_j R(j,j), then
-// + R(i,j) z_i for i = j-1..0 as an fma chain -- which is what a sweep over rows i = d-1..0 produces.
-MCX_DEV void trmv_rows(const double *Rt, const double *zs_t, int lane, int d, double *X)
+// ---------------------------------------------------------------- proposal: P = R'z  (MCMC_DRAM.F90:20-31)
+// dtrmv('U','T','N') (matutils.F90:108-109): p_j = sum_{i<=j} R(i,j) z_i, each dot product ascending in i
+// as one fma chain from 0.  Column panels of PW accumulators in registers; every row contributes one
+// contiguous PW x 512-byte segment, so the factor is read exactly once.
+MCX_DEV void trmv_panels(const double *Rt, const double *z_t, double *P_t, int lane, int d, bool act)
 {
-    for (int i = d - 1; i >= 0; --i) {
-        const double zi = GV(zs_t, i);
-        const double *rowp = Rt + (size_t)rowstart(i, d) * 64;       // element (i, i+k) at rowp[k]
-        const int n = d - i;
-        double rd = GV(rowp, 0);
-        sweep(rowp, lane, 1, n, [&](int k, double r) { XL(i + k) = dfma(r, zi, XL(i + k)); });
-        XL(i) = zi * rd;
+    for (int J0 = 0; J0 < d; J0 += PW) {
+        const int nw = (d - J0) < PW ? (d - J0) : PW;
+        double P[PW];
+#pragma unroll
+        for (int u = 0; u < PW; ++u) P[u] = 0.0;
+        if (act) {
+#pragma unroll 2
+            for (int i = 0; i < J0; ++i) {                               // rows above the diagonal block
+                const double zi = GV(z_t, i);
+                const double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
+                double r[PW];
+#pragma unroll
+                for (int u = 0; u < PW; ++u) r[u] = GV(seg, u < nw ? u : nw - 1);
+#pragma unroll
+                for (int u = 0; u < PW; ++u) P[u] = dfma(r[u], zi, P[u]);
+            }
+            for (int i = J0; i < J0 + nw; ++i) {                         // diagonal block: elements u >= ui
+                const double zi = GV(z_t, i);
+                const double *seg = Rt + (size_t)rowstart(i, d) * 64;
+                const int ui = i - J0, m = d - 1 - i;
+                double r[PW];
+#pragma unroll
+                for (int u = 0; u < PW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = GV(seg, k); }
+#pragma unroll
+                for (int u = 0; u < PW; ++u) { double nv = dfma(r[u], zi, P[u]); P[u] = (u >= ui) ? nv : P[u]; }
+            }
+#pragma unroll
+            for (int u = 0; u < PW; ++u) if (u < nw) GV(P_t, J0 + u) = P[u];
+        }
     }
 }
 
 // ---------------------------------------------------------------- RAM rank-1 adaptation (MCMC_run_ram.F90:104-179)
-// a >= 0: cholupdate = DCHUD (dchud.f:122-139); a < 0: choldowndate = DCHDD (dchdd.f:141-179), both
-// restated row by row (same operations on every element, in the same order per column).
-MCX_DEV void ram_update(double *Rt, const double *zs_t, double *cs_t, int lane, int d, double a, bool act,
-                        double *X, uint32_t &status)
+// a >= 0: cholupdate = DCHUD (dchud.f:122-139); a < 0: choldowndate = DCHDD (dchdd.f:141-179), restated
+// left-looking by column panels: the PW columns' work values sit in registers, the rotations of the
+// rows above come back from a per-chain scratch vector cs_t = (c_0, s_0, c_1, s_1, ...).  Every element
+// sees the same operations in the same order as in LINPACK's column loops.
+// When `fuse` is set the update sweep also accumulates the NEXT proposal P = R_new' z_next (ascending
+// rows = the pinned dtrmv order) into P_t, so update lanes read and write the factor once per
+// iteration.  Returns true for lanes whose P_t is valid.
+MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, double *cs_t, double *P_t,
+                        int lane, int d, double a, bool act, bool fuse, uint32_t &status)
 {
     double su = 0.0;
-    for (int k = 0; k < d; ++k) { double zk = GV(zs_t, k); su = su + zk * zk; }
+#pragma unroll 4
+    for (int k = 0; k < d; ++k) { double zk = GV(zc_t, k); su = su + zk * zk; }
     const bool up = act && (a >= 0.0);
     const bool down = act && !(a >= 0.0);
     if (__any(up)) {
         if (up) {
-            for (int k = 0; k < d; ++k) XL(k) = GV(zs_t, k) / su * a;          // x = u/sum(u**2) * a
-            for (int i = 0; i < d; ++i) {
-                double *rowp = Rt + (size_t)rowstart(i, d) * 64;
-                const int n = d - i;
-                double r, c, s;
-                d_rotg(GV(rowp, 0), XL(i), r, c, s);
-                GV(rowp, 0) = r;
-                sweep(rowp, lane, 1, n, [&](int k, double rij) {
-                    double xj = XL(i + k);
-                    double t = c * rij + s * xj;
-                    XL(i + k) = c * xj - s * rij;
-                    GV(rowp, k) = t;
-                });
+            for (int J0 = 0; J0 < d; J0 += PW) {
+                const int nw = (d - J0) < PW ? (d - J0) : PW;
+                double x[PW], P[PW];
+#pragma unroll
+                for (int u = 0; u < PW; ++u) { x[u] = GV(zc_t, J0 + (u < nw ? u : nw - 1)) / su * a; P[u] = 0.0; }   // x = u/sum(u**2)*a
+#pragma unroll 2
+                for (int i = 0; i < J0; ++i) {                           // rotations of the rows above
+                    const double c = GV(cs_t, 2 * i), sn = GV(cs_t, 2 * i + 1);
+                    const double zi = fuse ? GV(zn_t, i) : 0.0;
+                    double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
+                    double r[PW];
+#pragma unroll
+                    for (int u = 0; u < PW; ++u) r[u] = GV(seg, u < nw ? u : nw - 1);
+#pragma unroll
+                    for (int u = 0; u < PW; ++u) {
+                        double t = c * r[u] + sn * x[u];
+                        x[u] = c * x[u] - sn * r[u];
+                        if (u < nw) GV(seg, u) = t;
+                        P[u] = dfma(t, zi, P[u]);
+                    }
+                }
+                for (int i = J0; i < J0 + nw; ++i) {                     // diagonal block
+                    double *seg = Rt + (size_t)rowstart(i, d) * 64;
+                    const int ui = i - J0, m = d - 1 - i;
+                    const double zi = fuse ? GV(zn_t, i) : 0.0;
+                    double r[PW];
+#pragma unroll
+                    for (int u = 0; u < PW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = GV(seg, k); }
+                    double xi = x[0];
+#pragma unroll
+                    for (int u = 1; u < PW; ++u) xi = (u == ui) ? x[u] : xi;
+                    double rr, c, sn;
+                    d_rotg(GV(seg, 0), xi, rr, c, sn);
+                    GV(seg, 0) = rr;
+                    GV(cs_t, 2 * i) = c; GV(cs_t, 2 * i + 1) = sn;
+#pragma unroll
+                    for (int u = 0; u < PW; ++u) {
+                        const bool off = (u > ui) && (u < nw);
+                        double t = c * r[u] + sn * x[u];
+                        double nx = c * x[u] - sn * r[u];
+                        x[u] = off ? nx : x[u];
+                        if (off) GV(seg, u - ui) = t;
+                        double tp = (u == ui) ? rr : t;
+                        double np = dfma(tp, zi, P[u]);
+                        P[u] = (u >= ui && u < nw) ? np : P[u];
+                    }
+                }
+                if (fuse) {
+#pragma unroll
+                    for (int u = 0; u < PW; ++u) if (u < nw) GV(P_t, J0 + u) = P[u];
+                }
             }
         }
     }
     if (__any(down)) {
         if (down) {
-            // solve R'a = x, x = -u/sum(u**2)*a (dchdd.f:141-148): X[j] is the running dot of column j until
-            // row j, then the solution s_j
-            for (int k = 0; k < d; ++k) XL(k) = 0.0;
-            for (int i = 0; i < d; ++i) {
-                const double *rowp = Rt + (size_t)rowstart(i, d) * 64;
-                const int n = d - i;
-                double xi = -(GV(zs_t, i) / su * a);
-                double si = xi - XL(i);
-                si = si / GV(rowp, 0);
-                XL(i) = si;
-                sweep(rowp, lane, 1, n, [&](int k, double rij) { XL(i + k) = dfma(rij, si, XL(i + k)); });
+            // solve R'a = x, x = -u/sum(u**2)*a (dchdd.f:141-148); the solution goes to cs_t[2i+1]
+            for (int J0 = 0; J0 < d; J0 += PW) {
+                const int nw = (d - J0) < PW ? (d - J0) : PW;
+                double acc[PW];
+#pragma unroll
+                for (int u = 0; u < PW; ++u) acc[u] = 0.0;
+#pragma unroll 2
+                for (int i = 0; i < J0; ++i) {
+                    const double si = GV(cs_t, 2 * i + 1);
+                    const double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
+                    double r[PW];
+#pragma unroll
+                    for (int u = 0; u < PW; ++u) r[u] = GV(seg, u < nw ? u : nw - 1);
+#pragma unroll
+                    for (int u = 0; u < PW; ++u) acc[u] = dfma(r[u], si, acc[u]);
+                }
+                for (int i = J0; i < J0 + nw; ++i) {
+                    const double *seg = Rt + (size_t)rowstart(i, d) * 64;
+                    const int ui = i - J0, m = d - 1 - i;
+                    double r[PW];
+#pragma unroll
+                    for (int u = 0; u < PW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = GV(seg, k); }
+                    double ai = acc[0];
+#pragma unroll
+                    for (int u = 1; u < PW; ++u) ai = (u == ui) ? acc[u] : ai;
+                    double xi = -(GV(zc_t, i) / su * a);
+                    double si = xi - ai;
+                    si = si / GV(seg, 0);
+                    GV(cs_t, 2 * i + 1) = si;
+#pragma unroll
+                    for (int u = 0; u < PW; ++u) { double na = dfma(r[u], si, acc[u]); acc[u] = (u > ui) ? na : acc[u]; }
+                }
             }
             // norm = dnrm2(p, s), classic scale/ssq form (dchdd.f:149)
             double norm;
-            if (d == 1) norm = fabs(XL(0));
+            if (d == 1) norm = fabs(GV(cs_t, 1));
             else {
                 double scale = 0.0, ssq = 1.0;
+#pragma unroll 4
                 for (int k = 0; k < d; ++k) {
-                    double xk = XL(k);
+                    double xk = GV(cs_t, 2 * k + 1);
                     if (xk != 0.0) {
                         double ax = fabs(xk);
                         if (scale < ax) { double q = scale / ax; ssq = 1.0 + ssq * (q * q); scale = ax; }
@@ -273,30 +388,56 @@ MCX_DEV void ram_update(double *Rt, const double *zs_t, double *cs_t, int lane, 
                 status |= ST_RAM_DOWNDATE_FAIL;      // INFO = -1: R untouched (the reference stops here)
             } else {
                 double alpha = sqrt(1.0 - norm * norm);
+#pragma unroll 2
                 for (int k = d - 1; k >= 0; --k) {   // dchdd.f:158-167
-                    double sk = XL(k);
+                    double sk = GV(cs_t, 2 * k + 1);
                     double scale = alpha + fabs(sk);
                     double aa = alpha / scale, bb = sk / scale;
                     double nn = sqrt(aa * aa + bb * bb);
                     GV(cs_t, 2 * k) = aa / nn;
                     GV(cs_t, 2 * k + 1) = bb / nn;
                     alpha = scale * nn;
-                    XL(k) = 0.0;                     // becomes xx of column k
                 }
-                for (int i = d - 1; i >= 0; --i) {   // dchdd.f:171-179, rows d-1..0
-                    double *rowp = Rt + (size_t)rowstart(i, d) * 64;
-                    const int n = d - i;
-                    const double ci = GV(cs_t, 2 * i), si = GV(cs_t, 2 * i + 1);
-                    sweep(rowp, lane, 0, n, [&](int k, double rij) {
-                        double xx = XL(i + k);
-                        double t = ci * xx + si * rij;
-                        GV(rowp, k) = ci * rij - si * xx;
-                        XL(i + k) = t;
-                    });
+                for (int J0 = 0; J0 < d; J0 += PW) {  // dchdd.f:171-179, each column from its diagonal up
+                    const int nw = (d - J0) < PW ? (d - J0) : PW;
+                    double xx[PW];
+#pragma unroll
+                    for (int u = 0; u < PW; ++u) xx[u] = 0.0;
+                    for (int i = J0 + nw - 1; i >= J0; --i) {            // diagonal block, rows descending
+                        double *seg = Rt + (size_t)rowstart(i, d) * 64;
+                        const int ui = i - J0, m = d - 1 - i;
+                        const double ci = GV(cs_t, 2 * i), si = GV(cs_t, 2 * i + 1);
+                        double r[PW];
+#pragma unroll
+                        for (int u = 0; u < PW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = GV(seg, k); }
+#pragma unroll
+                        for (int u = 0; u < PW; ++u) {
+                            const bool on = (u >= ui) && (u < nw);
+                            double t = ci * xx[u] + si * r[u];
+                            double nr = ci * r[u] - si * xx[u];
+                            if (on) GV(seg, u - ui) = nr;
+                            xx[u] = on ? t : xx[u];
+                        }
+                    }
+#pragma unroll 2
+                    for (int i = J0 - 1; i >= 0; --i) {                  // rows above, descending
+                        double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
+                        const double ci = GV(cs_t, 2 * i), si = GV(cs_t, 2 * i + 1);
+                        double r[PW];
+#pragma unroll
+                        for (int u = 0; u < PW; ++u) r[u] = GV(seg, u < nw ? u : nw - 1);
+#pragma unroll
+                        for (int u = 0; u < PW; ++u) {
+                            double t = ci * xx[u] + si * r[u];
+                            if (u < nw) GV(seg, u) = ci * r[u] - si * xx[u];
+                            xx[u] = t;
+                        }
+                    }
                 }
             }
         }
     }
+    return up && fuse;
 }
 
 // ---------------------------------------------------------------- delayed rejection (MCMC_run.F90:65-91)
@@ -323,19 +464,20 @@ MCX_DEV double quadform_sym(const double *St, int lane, int d, const double *X, 
 }
 
 // ---------------------------------------------------------------- the step kernel
-// Iterations it0..it1 (absolute simuind) of MCMC_run (MCMC_run.F90:41-107, no DR stage here)
-// or MCMC_run_ram (MCMC_run_ram.F90:45-81) for one tile of 64 chains.  Dynamic LDS: d*64 doubles.
+// Iterations it0..it1 (absolute simuind) of MCMC_run (MCMC_run.F90:41-107) or MCMC_run_ram
+// (MCMC_run_ram.F90:45-81) for one tile of 64 chains.  LDS is used only by the delayed-rejection
+// quadratic forms (2*d*64 doubles when dodr, none otherwise).
 __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ ramscale)
 {
     extern __shared__ double X[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
     double *theta_t = E.theta + (size_t)tile * d * 64;
-    double *cand_t = E.cand + (size_t)tile * d * 64;
-    double *zs_t = E.zs + (size_t)tile * d * 64;
-    double *cs_t = E.cs + (size_t)tile * 2 * d * 64;
+    double *cand_t = E.cand + (size_t)tile * d * 64;           // proposal vector P, then candidate theta + P
+    double *zs_t = E.zs + (size_t)tile * 2 * d * 64;           // two normal vectors: this iteration's and the next one's
+    double *cs_t = E.cs + (size_t)tile * 2 * d * 64;           // RAM: rotations; DR: second-stage candidate
     double *Rt = E.R + (size_t)tile * E.P * 64;
-    double *Y = X + (size_t)d * 64;                       // second LDS vector, only allocated when dodr
-    double *c2_t = cs_t;                                  // DR: second-stage candidate (cs is RAM-only scratch)
+    double *Y = X + (size_t)d * 64;
+    double *c2_t = cs_t;
 
     Rng g;
     g.k0 = E.k0; g.k1 = E.chain_id0 + (uint32_t)(tile * 64 + lane);
@@ -349,15 +491,20 @@ __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1,
     uint32_t status = TIDX(E.ictr, tile, NICTR, I_STATUS, lane);
     uint32_t dracc = TIDX(E.ictr, tile, NICTR, I_DRACC, lane), drtries = TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane);
 
+    bool have_p = false;                          // lanes whose proposal vector is already in cand_t
+    gen_normals(g, zs_t + (size_t)(it0 & 1) * d * 64, lane, d, true);
+
     for (int it = it0; it <= it1; ++it) {
+        double *zc_t = zs_t + (size_t)(it & 1) * d * 64;          // z of this iteration
+        double *zn_t = zs_t + (size_t)((it + 1) & 1) * d * 64;    // z of the next one
         // ---- newpar = MCMC_propose(oldpar, R)
-        gen_normals(g, zs_t, lane, d, true);
-        trmv_rows(Rt, zs_t, lane, d, X);
-        for (int k = 0; k < d; ++k) { double v = GV(theta_t, k) + XL(k); XL(k) = v; GV(cand_t, k) = v; }
+        if (__any(!have_p)) trmv_panels(Rt, zc_t, cand_t, lane, d, !have_p);
+#pragma unroll 4
+        for (int k = 0; k < d; ++k) GV(cand_t, k) = GV(theta_t, k) + GV(cand_t, k);
         // ---- bounds, prior, ss, alpha, reject
-        bool inb = target_inbounds(E.tgt, d, X, lane);
-        double pri2 = target_prior(E.tgt, d, X, lane);
-        double ss2 = target_ss(E.tgt, d, X, lane, cand_t);
+        bool inb = target_inbounds(E.tgt, d, lane, cand_t);
+        double pri2 = target_prior(E.tgt, d, lane, cand_t);
+        double ss2 = target_ss(E.tgt, d, lane, cand_t);
         bool reject;
         if (!inb) {
             if (!E.dodr) bnd += 1;                        // MCMC_run.F90:49
@@ -374,15 +521,17 @@ __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1,
         if (E.dodr && __any(reject)) {
             const bool m = reject;
             if (m) drtries += 1;
-            gen_normals(g, zs_t, lane, d, m);
+            double *z2_t = zn_t;                          // stage-2 normals: the "next" buffer is still free
+            gen_normals(g, z2_t, lane, d, m);
+            trmv_panels(E.R2 + (size_t)tile * E.P * 64, z2_t, c2_t, lane, d, m);
             if (m) {
-                trmv_rows(E.R2 + (size_t)tile * E.P * 64, zs_t, lane, d, X);
-                for (int k = 0; k < d; ++k) { double v = GV(theta_t, k) + XL(k); XL(k) = v; GV(c2_t, k) = v; }
-                bool inb2 = target_inbounds(E.tgt, d, X, lane);
+#pragma unroll 4
+                for (int k = 0; k < d; ++k) GV(c2_t, k) = GV(theta_t, k) + GV(c2_t, k);
+                bool inb2 = target_inbounds(E.tgt, d, lane, c2_t);
                 if (!inb2) bnd += 1;
                 else {
-                    double pri3 = target_prior(E.tgt, d, X, lane);
-                    double ss3 = target_ss(E.tgt, d, X, lane, c2_t);
+                    double pri3 = target_prior(E.tgt, d, lane, c2_t);
+                    double ss3 = target_ss(E.tgt, d, lane, c2_t);
                     // MCMC_DR_alpha13, MCMC_DRAM.F90:162-186
                     double alpha32;
                     if (alpha12 == 0.0) alpha32 = 0.0;
@@ -415,6 +564,7 @@ __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1,
         if (!reject) {
             double *h = E.hist ? E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64 : nullptr;
             const double *src = dr_moved ? c2_t : cand_t;     // newpar = newpar2 when the DR try was accepted
+#pragma unroll 4
             for (int k = 0; k < d; ++k) {
                 double v = GV(src, k);
                 GV(theta_t, k) = v;
@@ -427,10 +577,14 @@ __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1,
             if (E.record_s2) E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = sigma2;
         }
         if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
+        // ---- the next iteration's normals: nothing else draws between here and its MCMC_propose
+        const bool pre = (it < it1);
+        if (pre) gen_normals(g, zn_t, lane, d, true);
         // ---- MCMC_adapt_ram
+        have_p = false;
         if (E.method == M_RAM && E.doadapt != 0 && !(it < E.burnintime && E.doburnin != 0)) {
             double a = ramscale[it - it0] * (alpha12 - E.alphatarget);
-            ram_update(Rt, zs_t, cs_t, lane, d, a, true, X, status);
+            have_p = ram_update(Rt, zc_t, zn_t, cs_t, cand_t, lane, d, a, true, pre, status);
         }
     }
 
@@ -448,13 +602,10 @@ __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1,
 // ---------------------------------------------------------------- first point (MCMC_run.F90:33-39)
 __global__ __launch_bounds__(64) void init_kernel(EngineDev E)
 {
-    extern __shared__ double X[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
     double *theta_t = E.theta + (size_t)tile * d * 64;
-    double *cand_t = E.cand + (size_t)tile * d * 64;
-    for (int k = 0; k < d; ++k) { double v = GV(theta_t, k); XL(k) = v; GV(cand_t, k) = v; }
-    double pri1 = target_prior(E.tgt, d, X, lane);
-    double ss1 = target_ss(E.tgt, d, X, lane, cand_t);
+    double pri1 = target_prior(E.tgt, d, lane, theta_t);
+    double ss1 = target_ss(E.tgt, d, lane, theta_t);
     TIDX(E.scal, tile, NSCAL, S_SS1, lane) = ss1; TIDX(E.scal, tile, NSCAL, S_PRI1, lane) = pri1;
     // row 1 of the chain: iteration 1 counts as accepted
     const int slot = 1 % E.wcap;

@@ -11,8 +11,9 @@
  *  - BLAS/LAPACK are NOT vendored by the reference and are unpinned ("any
  *    implementation", testcases/Makefile:11, INSTALL.txt:14-15).  We pin them as
  *    the netlib reference algorithms (BLAS 3.8.0 level-1/2, LAPACK unblocked
- *    dpotf2/dtrti2/dlauu2, classic drotg/dnrm2) in netlib loop order, with each
- *    dot-product / axpy accumulation done as an fma() chain;
+ *    dpotf2/dtrti2/dlauu2, classic drotg/dnrm2) with each dot-product / axpy accumulation done
+ *    as an fma() chain, in netlib loop order except dtrmv('U','T'), whose dot products run
+ *    ascending (see mcxo_trmv_ut);
  *  - libm log/exp are pinned in mcx_math.h.
  *
  * Parity status: pinned against the real reference compiled from /root/reference
@@ -136,12 +137,16 @@ double mcxo_gamma(mcxo_rng *g, double a, double b)
 
 #define A_(M, i, j, n) (M)[(size_t)(i) + (size_t)(j) * (size_t)(n)]
 
-/* dtrmv('U','T','N'), matutils.F90:108-109: x <- R'x; netlib: j = n..1, temp = x(j)*a(j,j), i = j-1..1 */
+/* dtrmv('U','T','N'), matutils.F90:108-109: x <- R'x, i.e. p_j = sum_{i<=j} R(i,j) x_i.  The reference
+ * leaves the BLAS unpinned, so the accumulation order inside each dot product is ours to fix: ascending
+ * i as one fma chain from 0 (netlib's reference loop runs i = j..1; MKL, which the reference build here
+ * links, is blocked).  Ascending order is what lets the device accumulate the NEXT proposal while
+ * DCHUD streams the freshly updated rows 1..p of the factor. */
 void mcxo_trmv_ut(int n, const double *R, double *x)
 {
     for (int j = n - 1; j >= 0; --j) {
-        double temp = x[j] * A_(R, j, j, n);
-        for (int i = j - 1; i >= 0; --i) temp = fma(A_(R, i, j, n), x[i], temp);
+        double temp = 0.0;
+        for (int i = 0; i <= j; ++i) temp = fma(A_(R, i, j, n), x[i], temp);
         x[j] = temp;
     }
 }
