@@ -153,7 +153,13 @@ static size_t lds_step(const mcmcx_engine *h) { return h->dodr ? lds_bytes(h) : 
 static void launch_init(mcmcx_engine *h)
 { hipLaunchKernelGGL(init_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E); }
 static void launch_step(mcmcx_engine *h, int it0, int it1)
-{ hipLaunchKernelGGL(step_kernel, dim3(h->ntiles), dim3(64), lds_step(h), h->stream, h->E, it0, it1, h->d_ramscale + it0); }
+{
+    const dim3 g(h->ntiles), b(64);
+    const double *rs = h->d_ramscale + it0;
+    if (h->E.method == M_RAM) hipLaunchKernelGGL((step_kernel<true, false>), g, b, 0, h->stream, h->E, it0, it1, rs);
+    else if (h->dodr) hipLaunchKernelGGL((step_kernel<false, true>), g, b, lds_step(h), h->stream, h->E, it0, it1, rs);
+    else hipLaunchKernelGGL((step_kernel<false, false>), g, b, 0, h->stream, h->E, it0, it1, rs);
+}
 static void launch_adapt(mcmcx_engine *h, int it, int mode)
 { hipLaunchKernelGGL(adapt_kernel, dim3(h->ntiles), dim3(64), lds_bytes(h), h->stream, h->E, it, mode); }
 

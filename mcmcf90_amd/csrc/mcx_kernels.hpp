@@ -118,7 +118,7 @@ MCX_DEV void sweep(const double *rowp, int lane, int k0, int n, F &&f)
 // The candidate is read from a per-chain global scratch vector c_t (element stride 64); the
 // Gaussian target works on 16x16 register panels: y[16] (rows) x v[16] (columns), precision matrix
 // through scalar loads of its transpose (lamT[j*d + i] = lam(i,j), padded by PW doubles).
-constexpr int PW = 16;    // panel width: columns (or rows) of per-lane state held in registers
+constexpr int PW = 8;     // panel width: columns (or rows) of per-lane state held in registers
 
 MCX_DEV double target_ss(const DevTarget &t, int d, int lane, const double *c_t)
 {
@@ -467,7 +467,8 @@ MCX_DEV double quadform_sym(const double *St, int lane, int d, const double *X, 
 // Iterations it0..it1 (absolute simuind) of MCMC_run (MCMC_run.F90:41-107) or MCMC_run_ram
 // (MCMC_run_ram.F90:45-81) for one tile of 64 chains.  LDS is used only by the delayed-rejection
 // quadratic forms (2*d*64 doubles when dodr, none otherwise).
-__global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ ramscale)
+template <bool RAM, bool DR>
+__global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ ramscale)
 {
     extern __shared__ double X[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
@@ -507,9 +508,9 @@ __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1,
         double ss2 = target_ss(E.tgt, d, lane, cand_t);
         bool reject;
         if (!inb) {
-            if (!E.dodr) bnd += 1;                        // MCMC_run.F90:49
+            if (!DR) bnd += 1;                            // MCMC_run.F90:49
             reject = true;
-            if (E.method != M_RAM) alpha12 = 0.0;        // RAM leaves alpha12 stale: MCMC_run_ram.F90:52-54
+            if (!RAM) alpha12 = 0.0;                      // RAM leaves alpha12 stale: MCMC_run_ram.F90:52-54
         } else {
             alpha12 = d_alpha(ss1, pri1, ss2, pri2, sigma2);
             reject = true;                                // MCMC_reject, MCMC_DRAM.F90:140-155
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1,
         }
         // ---- second stage: one delayed-rejection try with R2 = R/drscale (MCMC_run.F90:65-91)
         bool dr_moved = false;
-        if (E.dodr && __any(reject)) {
+        if (DR && __any(reject)) {
             const bool m = reject;
             if (m) drtries += 1;
             double *z2_t = zn_t;                          // stage-2 normals: the "next" buffer is still free
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(64) void step_kernel(EngineDev E, int it0, int it1,
         if (pre) gen_normals(g, zn_t, lane, d, true);
         // ---- MCMC_adapt_ram
         have_p = false;
-        if (E.method == M_RAM && E.doadapt != 0 && !(it < E.burnintime && E.doburnin != 0)) {
+        if (RAM && E.doadapt != 0 && !(it < E.burnintime && E.doburnin != 0)) {
             double a = ramscale[it - it0] * (alpha12 - E.alphatarget);
             have_p = ram_update(Rt, zc_t, zn_t, cs_t, cand_t, lane, d, a, true, pre, status);
         }
