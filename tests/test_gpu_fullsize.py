@@ -1,0 +1,80 @@
+"""BASELINE.json's configurations at their full chain counts, checked through size-independent
+properties: (1) a few chains picked from the whole range are still bit-identical to the oracle run with
+the same stream, (2) every chain's counters are consistent with its accept ballots, (3) pooled posterior
+moments agree with the analytic target within Monte-Carlo error, (4) no chain raised a status flag."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def _check_chains_vs_oracle(oracle, e, ckw, pkw, chains):
+    cfg = oracle.make_cfg(**ckw)
+    prob = oracle.Problem(**pkw)
+    th = e.theta()
+    for c in chains:
+        o = oracle.run_chain(cfg, prob, chain_id=c)
+        assert o.rc == 0
+        np.testing.assert_array_equal(_bits(th[c]), _bits(o.theta))
+        cnt = e.counters(c)
+        assert (cnt["stayed"], cnt["bndstayed"], cnt["chainind"], cnt["draccepted"], cnt["drtries"]) == \
+               (o.stayed, o.bndstayed, o.chainind, o.draccepted, o.drtries)
+        assert e.rng(c)[0] == o.rng_n
+        np.testing.assert_array_equal(_bits(np.triu(e.R(c))), _bits(np.triu(o.R)))
+
+
+def test_c2_gauss10_am_65536_chains(oracle):
+    from mcmcf90_amd import engine_from_problem
+    from mcmcf90_amd import dist as mdist
+    d, n, nsimu = 10, 65536, 5000
+    ckw = dict(nsimu=nsimu, adaptint=100, updatesigma=0)
+    pkw = dict(kind="gauss", npar=d, par0=np.zeros(d), cmat0=0.01 * np.eye(d), mu=np.zeros(d), lam=np.eye(d))
+    e = engine_from_problem(ckw, pkw, nchains=n, record_accept=1)
+    e.init(); e.run()
+    _check_chains_vs_oracle(oracle, e, ckw, pkw, [0, 1, 4097, 65535])
+    tot = e.totals()
+    masks = e.accept_masks()                                  # [nsimu][ntiles] wave ballots
+    pop = int(np.unpackbits(masks.view(np.uint8)).sum())
+    assert pop == n * nsimu - tot["stayed"]                   # accepted (incl. row 1) + stayed = nsimu per chain
+    assert tot["proposals"] == n * (nsimu - 1)
+    mean, cov = mdist.finalize_moments(e.pooled_moments(), d, np.zeros(d))
+    assert np.max(np.abs(mean)) < 0.03                        # N(0, I): se = 1/sqrt(65536) = 0.004
+    assert np.max(np.abs(cov - np.eye(d))) < 0.05
+    acc = 1.0 - tot["stayed"] / (n * (nsimu - 1.0))
+    assert 0.15 < acc < 0.45                                  # AM at d=10 settles near 0.25-0.3
+    e.close()
+
+
+def test_c3_banana20_dram_262144_chains(oracle):
+    from mcmcf90_amd import engine_from_problem
+    d, n, nsimu = 20, 262144, 600
+    ckw = dict(nsimu=nsimu, adaptint=100, updatesigma=0, drscale=2.0)
+    pkw = dict(kind="banana", npar=d, par0=np.zeros(d), cmat0=0.01 * np.eye(d), b=0.1)
+    e = engine_from_problem(ckw, pkw, nchains=n)
+    e.init(); e.run()
+    _check_chains_vs_oracle(oracle, e, ckw, pkw, [0, 131071, 262143])
+    tot = e.totals()
+    assert tot["proposals"] == n * (nsimu - 1) + tot["drtries"]
+    assert 0 < tot["draccepted"] < tot["drtries"] <= tot["proposals"]
+    assert tot["stayed"] + tot["draccepted"] <= n * (nsimu - 1)
+    e.close()
+
+
+def test_c4_gauss50_ram_131072_chains(oracle):
+    from mcmcf90_amd import engine_from_problem
+    d, n, nsimu = 50, 131072, 400
+    S = 0.5 ** np.abs(np.subtract.outer(np.arange(d), np.arange(d)))
+    ckw = dict(nsimu=nsimu, method="ram", updatesigma=0)
+    pkw = dict(kind="gauss", npar=d, par0=np.zeros(d), cmat0=0.01 * np.eye(d), mu=np.zeros(d), lam=np.linalg.inv(S))
+    e = engine_from_problem(ckw, pkw, nchains=n)
+    e.init(); e.run(137); e.run()                             # a launch boundary in the middle of the run
+    _check_chains_vs_oracle(oracle, e, ckw, pkw, [0, 77, 65536, 131071])
+    for c in (0, 131071):
+        assert e.counters(c)["status"] == 0                   # no failed downdate
+    R = e.R(5)
+    assert np.all(np.diag(R) > 0) and np.allclose(np.tril(R, -1), 0)
+    e.close()
