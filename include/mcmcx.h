@@ -75,6 +75,15 @@ int mcmcx_set_sigma2nobs(mcmcx_handle h, const double *sigma2, const int32_t *no
 int mcmcx_set_target_gauss(mcmcx_handle h, const double *mu, const double *lam_rowmajor);
 int mcmcx_set_target_banana(mcmcx_handle h, double b);
 int mcmcx_set_target_expdata(mcmcx_handle h, int32_t ndata, const double *x, const double *y);
+/* Host-callback target: the user's own ssfunction / priorfun / checkbounds (external_inc.h:4-33) behind plain C
+ * signatures (the Fortran shim adapts the array-result / assumed-shape ABIs).  The engine calls them from the
+ * thread that calls mcmcx_run, one chain after the other, at the points the reference does (MCMC_run.F90:47,55-56,
+ * 69,74-75); the candidates make a D2H/H2D round trip per stage, so this is the plumbing path, not the fast one.
+ * priorfun / checkbounds may be NULL (flat prior, no bounds = the library defaults). */
+typedef void    (*mcmcx_ssfun_t)(const double *theta, int32_t npar, int32_t ny, double *ss_out, void *user);
+typedef double  (*mcmcx_priorfun_t)(const double *theta, int32_t npar, void *user);
+typedef int32_t (*mcmcx_checkbounds_t)(const double *theta, int32_t npar, void *user);
+int mcmcx_set_target_host(mcmcx_handle h, mcmcx_ssfun_t ss, mcmcx_priorfun_t pri, mcmcx_checkbounds_t cb, void *user);
 int mcmcx_set_bounds(mcmcx_handle h, const double *lo, const double *hi);       /* NULL = unbounded side */
 int mcmcx_set_priors(mcmcx_handle h, const double *mu, const double *sig);      /* sig <= 0: flat */
 int mcmcx_set_stream(mcmcx_handle h, void *hip_stream);

@@ -64,6 +64,11 @@ SYMBOLS = {
     "mcmcx_kernel_time": (C.c_int, [C.c_void_p, _DP, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]),
 }
 
+SSFUN_T = C.CFUNCTYPE(None, _DP, C.c_int32, C.c_int32, _DP, C.c_void_p)
+PRIORFUN_T = C.CFUNCTYPE(C.c_double, _DP, C.c_int32, C.c_void_p)
+CHECKBOUNDS_T = C.CFUNCTYPE(C.c_int32, _DP, C.c_int32, C.c_void_p)
+SYMBOLS["mcmcx_set_target_host"] = (C.c_int, [C.c_void_p, SSFUN_T, PRIORFUN_T, CHECKBOUNDS_T, C.c_void_p])
+
 _lib = None
 
 

@@ -39,6 +39,8 @@ struct mcmcx_engine {
     double sigma2 = 1.0; int nobs = 1; bool sigma2ok = false;
     int tkind = -1; std::vector<double> tmu, tlam, tx, ty, tlo, thi, tpmu, tpsig; double tb = 0.1;
     bool has_lo = false, has_hi = false, has_pri = false;
+    mcmcx_ssfun_t h_ss = nullptr; mcmcx_priorfun_t h_pri = nullptr; mcmcx_checkbounds_t h_cb = nullptr; void *h_user = nullptr;
+    std::vector<double> h_cand, h_ev;
     double S02eff = 0.0;
     // device
     hipStream_t stream = nullptr; bool own_stream = false;
@@ -219,6 +221,56 @@ static void unpack_upper(int d, const std::vector<double> &p, double *colmajor, 
         }
 }
 
+// Host-callback evaluation of one candidate vector per chain, in chain order, from the calling thread
+// (the reference's callbacks keep SAVEd state and are not thread-safe: testcases/mcmcrun.F90:69-70).
+// src: tile-interleaved device vector [T][stride][64]; only chains with want != 0 (hx slot) are evaluated.
+static int host_eval(mcmcx_engine *h, const double *dev_src, int stride_k, bool use_stage2_flag)
+{
+    const int d = h->d, T = h->ntiles;
+    const size_t L = (size_t)T * 64;
+    h->h_cand.resize(L * stride_k);
+    h->h_ev.assign(L * NHE, 0.0);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->h_cand.data(), dev_src, h->h_cand.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> hx;
+    if (use_stage2_flag) { hx.resize(L * NHX); HIPCHK(hipMemcpy(hx.data(), h->E.hx, hx.size() * 8, hipMemcpyDeviceToHost)); }
+    std::vector<double> th(d);
+    for (int c = 0; c < h->cfg.nchains; ++c) {
+        const int t = c / 64, l = c % 64;
+        if (use_stage2_flag && hx[((size_t)t * NHX + HX_STAGE2) * 64 + l] == 0.0) continue;
+        for (int k = 0; k < d; ++k) th[k] = h->h_cand[((size_t)t * stride_k + k) * 64 + l];
+        int inb = h->h_cb ? h->h_cb(th.data(), d, h->h_user) : 1;                    // checkbounds0.f90: .true.
+        double pri = 0.0, ss = 0.0;
+        if (inb) {                                                                   // MCMC_run.F90:54-56: prior first
+            pri = h->h_pri ? h->h_pri(th.data(), d, h->h_user) : 0.0;
+            h->h_ss(th.data(), d, 1, &ss, h->h_user);
+        }
+        h->h_ev[((size_t)t * NHE + HE_INB) * 64 + l] = inb ? 1.0 : 0.0;
+        h->h_ev[((size_t)t * NHE + HE_PRI) * 64 + l] = pri;
+        h->h_ev[((size_t)t * NHE + HE_SS) * 64 + l] = ss;
+    }
+    HIPCHK(hipMemcpy(h->E.hev, h->h_ev.data(), h->h_ev.size() * 8, hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int host_iteration(mcmcx_engine *h, int it)
+{
+    const dim3 g(h->ntiles), b(64);
+    const double *rs = h->d_ramscale + it;
+    const size_t lds = (size_t)h->d * 64 * sizeof(double) * 2;
+    hipLaunchKernelGGL((host_phase_kernel<0>), g, b, 0, h->stream, h->E, it, rs);
+    HIPCHK(hipGetLastError());
+    int rc = host_eval(h, h->E.cand, h->d, false); if (rc) return rc;
+    hipLaunchKernelGGL((host_phase_kernel<1>), g, b, 0, h->stream, h->E, it, rs);
+    HIPCHK(hipGetLastError());
+    if (h->dodr) {
+        rc = host_eval(h, h->E.cs, 2 * h->d, true); if (rc) return rc;
+        hipLaunchKernelGGL((host_phase_kernel<2>), g, b, lds, h->stream, h->E, it, rs);
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------ C ABI
 extern "C" {
 
@@ -342,6 +394,13 @@ int mcmcx_set_target_expdata(mcmcx_handle h, int32_t n, const double *x, const d
     h->tkind = TGT_EXPDATA; h->tx.assign(x, x + n); h->ty.assign(y, y + n);
     return 0;
 }
+int mcmcx_set_target_host(mcmcx_handle h, mcmcx_ssfun_t ss, mcmcx_priorfun_t pri, mcmcx_checkbounds_t cb, void *user)
+{
+    if (!h || !ss) return fail(-1, "mcmcx_set_target_host: ssfunction is required");     // ssfunction0.f90:10-14
+    h->tkind = TGT_HOST; h->h_ss = ss; h->h_pri = pri; h->h_cb = cb; h->h_user = user;
+    return 0;
+}
+
 int mcmcx_set_bounds(mcmcx_handle h, const double *lo, const double *hi)
 {
     if (!h) return fail(-1, "null handle");
@@ -441,6 +500,11 @@ int mcmcx_init(mcmcx_handle h)
         if ((rc = dev_alloc(h, &E.Rtmp, L * P))) return rc;
         if ((rc = dev_alloc(h, &E.rowlist, L * (size_t)(h->wcap + 1)))) return rc;
     }
+    E.hev = E.hx = nullptr;
+    if (h->tkind == TGT_HOST) {
+        if ((rc = dev_alloc(h, &E.hev, L * NHE))) return rc;
+        if ((rc = dev_alloc(h, &E.hx, L * NHX))) return rc;
+    }
     E.accmask = nullptr;
     if (c.record_accept && (rc = dev_alloc(h, &E.accmask, (size_t)c.nsimu * T))) return rc;
     // 1/simuind**nuparam, computed like the reference: real(simuind) is default REAL (MCMC_run_ram.F90:166)
@@ -498,6 +562,10 @@ int mcmcx_init(mcmcx_handle h)
         }
         HIPCHK(hipStreamSynchronize(h->stream));
     }
+    if (h->tkind == TGT_HOST) {                         // first point: sspri1, ss1 from the host callbacks (MCMC_run.F90:35-36)
+        int rc2 = host_eval(h, E.theta, d, false);
+        if (rc2) return rc2;
+    }
     launch_init(h);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -521,14 +589,18 @@ int mcmcx_run(mcmcx_handle h, int32_t upto)
             mode = adapt_mode(c, end);
             if (mode != 0 || end == upto || end - it + 1 >= maxseg) break;
         }
-        hipEvent_t e0, e1;
-        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-        HIPCHK(hipEventRecord(e0, h->stream));
-        launch_step(h, it, end);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(e1, h->stream));
-        h->pending.emplace_back(e0, e1);
-        h->launches += 1; h->steps += (end - it + 1);
+        if (h->tkind == TGT_HOST) {
+            for (int i2 = it; i2 <= end; ++i2) { int rc = host_iteration(h, i2); if (rc) return rc; }
+        } else {
+            hipEvent_t e0, e1;
+            HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+            HIPCHK(hipEventRecord(e0, h->stream));
+            launch_step(h, it, end);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(e1, h->stream));
+            h->pending.emplace_back(e0, e1);
+            h->launches += 1; h->steps += (end - it + 1);
+        }
         if (mode != 0) {
             launch_adapt(h, end, mode);
             HIPCHK(hipGetLastError());

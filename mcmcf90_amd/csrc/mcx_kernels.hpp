@@ -15,7 +15,7 @@
 
 namespace mcx {
 
-enum { TGT_GAUSS = 0, TGT_BANANA = 1, TGT_EXPDATA = 2 };
+enum { TGT_GAUSS = 0, TGT_BANANA = 1, TGT_EXPDATA = 2, TGT_HOST = 3 };
 enum { M_DRAM = 0, M_RAM = 1 };
 
 // per-chain scalar slots (doubles)
@@ -57,6 +57,8 @@ struct EngineDev {
     uint64_t *wacc;             // [tile*wcap + slot]
     uint64_t *accmask;          // [(it-1)*ntiles + tile] or nullptr
     uint64_t *rowlist;          // [(tile*(wcap+1) + r)*64 + lane]  (slot | weight<<32)
+    // host-callback targets: per-chain evaluation results (inbounds, prior, ss) and state carried between phases
+    double *hev, *hx;
 };
 
 #define TIDX(base, tile, K, k, lane) ((base)[((size_t)(tile) * (size_t)(K) + (size_t)(k)) * 64 + (lane)])
@@ -600,13 +602,162 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
     TIDX(E.ictr, tile, NICTR, I_DRACC, lane) = dracc; TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane) = drtries;
 }
 
+// ---------------------------------------------------------------- host-callback targets
+// When ssfunction / priorfun / checkbounds are host functions of the user (external_inc.h:4-33) one
+// iteration is cut where the reference calls them (MCMC_run.F90:47,55-56,69,74-75): phase 0 proposes,
+// the host evaluates the candidates of all chains in chain order, phase 1 decides (and proposes the DR
+// try), the host evaluates again, phase 2 decides the DR try and finishes the iteration.  Same device
+// functions as step_kernel; per-lane state round-trips through HBM between phases.
+enum { HX_SS2 = 0, HX_PRI2, HX_REJECT, HX_STAGE2, HX_DRMOVED, NHX };
+enum { HE_INB = 0, HE_PRI, HE_SS, NHE };
+
+struct LaneState {
+    Rng g;
+    double ss1, pri1, sigma2, alpha12;
+    uint32_t stayed, bnd, chainind, curcount, status, dracc, drtries;
+};
+MCX_DEV void lane_load(const EngineDev &E, int tile, int lane, LaneState &L)
+{
+    L.g.k0 = E.k0; L.g.k1 = E.chain_id0 + (uint32_t)(tile * 64 + lane);
+    L.g.n = TIDX(E.rngn, tile, 1, 0, lane); L.g.cblk = 0; L.g.c2 = 0; L.g.c3 = 0;
+    L.g.saved = (int)TIDX(E.ictr, tile, NICTR, I_SAVED, lane);
+    L.g.saved_y = TIDX(E.scal, tile, NSCAL, S_SAVEDY, lane);
+    L.ss1 = TIDX(E.scal, tile, NSCAL, S_SS1, lane); L.pri1 = TIDX(E.scal, tile, NSCAL, S_PRI1, lane);
+    L.sigma2 = TIDX(E.scal, tile, NSCAL, S_SIGMA2, lane); L.alpha12 = TIDX(E.scal, tile, NSCAL, S_ALPHA12, lane);
+    L.stayed = TIDX(E.ictr, tile, NICTR, I_STAYED, lane); L.bnd = TIDX(E.ictr, tile, NICTR, I_BNDSTAYED, lane);
+    L.chainind = TIDX(E.ictr, tile, NICTR, I_CHAININD, lane); L.curcount = TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane);
+    L.status = TIDX(E.ictr, tile, NICTR, I_STATUS, lane);
+    L.dracc = TIDX(E.ictr, tile, NICTR, I_DRACC, lane); L.drtries = TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane);
+}
+MCX_DEV void lane_store(const EngineDev &E, int tile, int lane, const LaneState &L)
+{
+    TIDX(E.rngn, tile, 1, 0, lane) = L.g.n;
+    TIDX(E.ictr, tile, NICTR, I_SAVED, lane) = (uint32_t)L.g.saved;
+    TIDX(E.scal, tile, NSCAL, S_SAVEDY, lane) = L.g.saved_y;
+    TIDX(E.scal, tile, NSCAL, S_SS1, lane) = L.ss1; TIDX(E.scal, tile, NSCAL, S_PRI1, lane) = L.pri1;
+    TIDX(E.scal, tile, NSCAL, S_SIGMA2, lane) = L.sigma2; TIDX(E.scal, tile, NSCAL, S_ALPHA12, lane) = L.alpha12;
+    TIDX(E.ictr, tile, NICTR, I_STAYED, lane) = L.stayed; TIDX(E.ictr, tile, NICTR, I_BNDSTAYED, lane) = L.bnd;
+    TIDX(E.ictr, tile, NICTR, I_CHAININD, lane) = L.chainind; TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane) = L.curcount;
+    TIDX(E.ictr, tile, NICTR, I_STATUS, lane) = L.status;
+    TIDX(E.ictr, tile, NICTR, I_DRACC, lane) = L.dracc; TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane) = L.drtries;
+}
+
+// end of an iteration: MCMC_run.F90:93-105 / MCMC_run_ram.F90:66-78
+MCX_DEV void host_finish(const EngineDev &E, int tile, int lane, int it, LaneState &L, bool reject, bool dr_moved,
+                         double ss2, double pri2, const double *ramscale)
+{
+    const int d = E.d;
+    double *theta_t = E.theta + (size_t)tile * d * 64;
+    double *cand_t = E.cand + (size_t)tile * d * 64;
+    double *zs_t = E.zs + (size_t)tile * 2 * d * 64;
+    double *cs_t = E.cs + (size_t)tile * 2 * d * 64;
+    if (reject) { L.stayed += 1; L.curcount += 1; }
+    else { L.ss1 = ss2; L.pri1 = pri2; L.chainind += 1; L.curcount = 1; }
+    if (E.updatesigma) {
+        double gm = rng_gamma(L.g, E.gam_shape, 2.0 / (E.N0S02 + L.ss1));
+        L.sigma2 = 1.0 / gm;
+    }
+    unsigned long long ballot = __ballot(!reject);
+    const int slot = it % E.wcap;
+    if (!reject) {
+        double *h = E.hist ? E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64 : nullptr;
+        const double *src = dr_moved ? cs_t : cand_t;
+        for (int k = 0; k < d; ++k) { double v = GV(src, k); GV(theta_t, k) = v; if (h) GV(h, k) = v; }
+        if (h) GV(h, d) = L.ss1;
+    }
+    if (E.hist) {
+        if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ballot;
+        if (E.record_s2) E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = L.sigma2;
+    }
+    if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
+    if (E.method == M_RAM && E.doadapt != 0 && !(it < E.burnintime && E.doburnin != 0)) {
+        double a = ramscale[0] * (L.alpha12 - E.alphatarget);
+        ram_update(E.R + (size_t)tile * E.P * 64, zs_t, zs_t, cs_t, cand_t, lane, d, a, true, false, L.status);
+    }
+}
+
+template <int PHASE>
+__global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, const double *__restrict__ ramscale)
+{
+    extern __shared__ double X[];
+    const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
+    double *theta_t = E.theta + (size_t)tile * d * 64;
+    double *cand_t = E.cand + (size_t)tile * d * 64;
+    double *zs_t = E.zs + (size_t)tile * 2 * d * 64;           // host mode: first half = stage-1 z, second half = stage-2 z
+    double *c2_t = E.cs + (size_t)tile * 2 * d * 64;
+    double *hev = E.hev + (size_t)tile * NHE * 64;
+    double *hx = E.hx + (size_t)tile * NHX * 64;
+    double *Y = X + (size_t)d * 64;
+    LaneState L;
+    lane_load(E, tile, lane, L);
+    if (PHASE == 0) {                                             // newpar = MCMC_propose(oldpar, R)
+        gen_normals(L.g, zs_t, lane, d, true);
+        trmv_panels(E.R + (size_t)tile * E.P * 64, zs_t, cand_t, lane, d, true);
+        for (int k = 0; k < d; ++k) GV(cand_t, k) = GV(theta_t, k) + GV(cand_t, k);
+    } else if (PHASE == 1) {
+        const bool inb = GV(hev, HE_INB) != 0.0;
+        const double pri2 = GV(hev, HE_PRI), ss2 = GV(hev, HE_SS);
+        bool reject;
+        if (!inb) {
+            if (!E.dodr) L.bnd += 1;
+            reject = true;
+            if (E.method != M_RAM) L.alpha12 = 0.0;
+        } else {
+            L.alpha12 = d_alpha(L.ss1, L.pri1, ss2, pri2, L.sigma2);
+            reject = true;
+            if (L.alpha12 >= 1.0) reject = false;
+            else if (L.alpha12 > 0.0) { double u = rng_uniform(L.g); if (u <= L.alpha12) reject = false; }
+        }
+        if (E.dodr) {
+            const bool m = reject;
+            if (m) L.drtries += 1;
+            gen_normals(L.g, zs_t + (size_t)d * 64, lane, d, m);
+            trmv_panels(E.R2 + (size_t)tile * E.P * 64, zs_t + (size_t)d * 64, c2_t, lane, d, m);
+            if (m) for (int k = 0; k < d; ++k) GV(c2_t, k) = GV(theta_t, k) + GV(c2_t, k);
+            GV(hx, HX_SS2) = ss2; GV(hx, HX_PRI2) = pri2;
+            GV(hx, HX_REJECT) = reject ? 1.0 : 0.0; GV(hx, HX_STAGE2) = m ? 1.0 : 0.0;
+        } else {
+            host_finish(E, tile, lane, it, L, reject, false, ss2, pri2, ramscale);
+        }
+    } else {                                                      // PHASE 2: decide the DR try, finish
+        bool reject = GV(hx, HX_REJECT) != 0.0;
+        double ss2 = GV(hx, HX_SS2), pri2 = GV(hx, HX_PRI2);
+        bool dr_moved = false;
+        if (GV(hx, HX_STAGE2) != 0.0) {
+            const bool inb2 = GV(hev, HE_INB) != 0.0;
+            if (!inb2) L.bnd += 1;
+            else {
+                const double pri3 = GV(hev, HE_PRI), ss3 = GV(hev, HE_SS);
+                double alpha32;
+                if (L.alpha12 == 0.0) alpha32 = 0.0;
+                else alpha32 = min1(d_exp(-0.5 * ((ss2 - ss3) / L.sigma2 + (pri2 - pri3))));
+                double l2 = -0.5 * ((ss3 - L.ss1) / L.sigma2 + (pri3 - L.pri1));
+                const double *iCt = E.iC + (size_t)tile * E.P * 64;
+                for (int k = 0; k < d; ++k) XL(k) = GV(c2_t, k) - GV(cand_t, k);
+                double qa = quadform_sym(iCt, lane, d, X, Y);
+                for (int k = 0; k < d; ++k) XL(k) = GV(theta_t, k) - GV(cand_t, k);
+                double qb = quadform_sym(iCt, lane, d, X, Y);
+                double q1 = -0.5 * (qa - qb);
+                double alpha13 = min1(d_exp(l2 + q1) * (1.0 - alpha32) / (1.0 - L.alpha12));
+                bool rej2 = true;
+                if (alpha13 >= 1.0) rej2 = false;
+                else if (alpha13 > 0.0) { double u = rng_uniform(L.g); if (u <= alpha13) rej2 = false; }
+                if (!rej2) { L.dracc += 1; reject = false; dr_moved = true; ss2 = ss3; pri2 = pri3; }
+            }
+        }
+        host_finish(E, tile, lane, it, L, reject, dr_moved, ss2, pri2, ramscale);
+    }
+    lane_store(E, tile, lane, L);
+}
+
 // ---------------------------------------------------------------- first point (MCMC_run.F90:33-39)
 __global__ __launch_bounds__(64) void init_kernel(EngineDev E)
 {
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
     double *theta_t = E.theta + (size_t)tile * d * 64;
-    double pri1 = target_prior(E.tgt, d, lane, theta_t);
-    double ss1 = target_ss(E.tgt, d, lane, theta_t);
+    double pri1, ss1;
+    if (E.tgt.kind == TGT_HOST) { const double *hev = E.hev + (size_t)tile * NHE * 64; pri1 = GV(hev, HE_PRI); ss1 = GV(hev, HE_SS); }
+    else { pri1 = target_prior(E.tgt, d, lane, theta_t); ss1 = target_ss(E.tgt, d, lane, theta_t); }
     TIDX(E.scal, tile, NSCAL, S_SS1, lane) = ss1; TIDX(E.scal, tile, NSCAL, S_PRI1, lane) = pri1;
     // row 1 of the chain: iteration 1 counts as accepted
     const int slot = 1 % E.wcap;

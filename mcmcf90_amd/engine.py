@@ -87,6 +87,24 @@ class Engine:
         else:
             raise KeyError(kind)
 
+    def set_target_host(self, ssfun, priorfun=None, checkbounds=None):
+        """User callbacks on the host, like the reference's link-time ssfunction / priorfun / checkbounds:
+        ssfun(theta) -> float, priorfun(theta) -> float, checkbounds(theta) -> bool, theta a numpy vector."""
+        n = self.npar
+
+        def _ss(th, npar, ny, out, user):
+            out[0] = float(ssfun(np.ctypeslib.as_array(th, shape=(n,)).copy()))
+
+        def _pri(th, npar, user):
+            return float(priorfun(np.ctypeslib.as_array(th, shape=(n,)).copy()))
+
+        def _cb(th, npar, user):
+            return 1 if checkbounds(np.ctypeslib.as_array(th, shape=(n,)).copy()) else 0
+
+        self._cb_keep = (_lib.SSFUN_T(_ss), _lib.PRIORFUN_T(_pri) if priorfun else _lib.PRIORFUN_T(),
+                         _lib.CHECKBOUNDS_T(_cb) if checkbounds else _lib.CHECKBOUNDS_T())
+        self._chk(self.L.mcmcx_set_target_host(self.h, self._cb_keep[0], self._cb_keep[1], self._cb_keep[2], None))
+
     def set_bounds(self, lo=None, hi=None):
         lo = _f64(lo) if lo is not None else None
         hi = _f64(hi) if hi is not None else None

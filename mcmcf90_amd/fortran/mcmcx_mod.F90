@@ -16,9 +16,11 @@
 !!!   mcmc_main()         external subroutine, no arguments (mcmc_main.F90:12-44): init, run, write
 !!!
 !!! The sampling itself runs in libmcmcx.so (HIP) through the bind(C) interfaces below
-!!! (include/mcmcx.h).  A GPU cannot call a host ssfunction, so the likelihood is selected from the
-!!! device-resident targets, either by MCMC_settarget_* calls before mcmc_main or by an extra
-!!! namelist group in the same file (ignored by the reference, which reads only &mcmc):
+!!! (include/mcmcx.h).  By default the user's link-time ssfunction / priorfun / checkbounds are called on
+!!! the host exactly where the reference calls them (candidates make a D2H/H2D round trip: the plumbing
+!!! path).  The fast path keeps the likelihood on the GPU: pick a device-resident target by
+!!! MCMC_settarget_* calls before mcmc_main or by an extra namelist group in the same file (ignored by
+!!! the reference, which reads only &mcmc):
 !!!
 !!!     &mcmcx  devtarget='gauss'  nchains=65536  mufile='mcmctest_mu.dat' lamfile='mcmctest_lam.dat' /
 !!!
@@ -54,7 +56,7 @@ module mcmcmod
        method, alphatarget, nuparam
 
   !! engine extension group &mcmcx (same file)
-  character(len=16), save :: devtarget = 'none'
+  character(len=16), save :: devtarget = 'host'       ! 'host' = the user's link-time ssfunction/priorfun/checkbounds
   integer, save :: nchains = 1, seed = 1835232611     ! 0x6D636D63
   real(kind=dbl), save :: banana_b = 0.1_dbl
   character(len=256), save :: mufile = 'mcmctest_mu.dat', lamfile = 'mcmctest_lam.dat'
@@ -154,6 +156,12 @@ module mcmcmod
        type(c_ptr), value :: h
        integer(c_int32_t), value :: n
        real(c_double), intent(in) :: x(*), y(*)
+       integer(c_int) :: rc
+     end function
+     function mcmcx_set_target_host(h, ss, pri, cb, user) bind(C, name='mcmcx_set_target_host') result(rc)
+       import :: c_ptr, c_funptr, c_int
+       type(c_ptr), value :: h, user
+       type(c_funptr), value :: ss, pri, cb
        integer(c_int) :: rc
      end function
      function mcmcx_set_bounds(h, lo, hi) bind(C, name='mcmcx_set_bounds') result(rc)
@@ -411,6 +419,58 @@ contains
     nchains = n
   end subroutine MCMC_setnchains
 
+  !! ---------------------------------------------------------------- adapters for the user's link-time callbacks
+  !! (external_inc.h:4-33: array-valued result and assumed-shape dummies need the Fortran compiler's own ABI,
+  !! so the C engine calls these bind(C) wrappers, which call the user's functions)
+  subroutine mcx_ss_adapter(theta, n, ny, ss_out, user) bind(C)
+    real(c_double), intent(in) :: theta(*)
+    integer(c_int32_t), value :: n, ny
+    real(c_double), intent(out) :: ss_out(*)
+    type(c_ptr), value :: user
+    integer(kind=4) :: n4, ny4
+    interface
+       function ssfunction(theta,npar,ny)
+         integer*4 npar, ny
+         real*8 theta(npar)
+         real*8 ssfunction(ny)
+       end function ssfunction
+    end interface
+    n4 = n; ny4 = ny
+    ss_out(1:ny) = ssfunction(theta(1:n), n4, ny4)
+  end subroutine mcx_ss_adapter
+  function mcx_prior_adapter(theta, n, user) bind(C) result(p)
+    real(c_double), intent(in) :: theta(*)
+    integer(c_int32_t), value :: n
+    type(c_ptr), value :: user
+    real(c_double) :: p
+    integer(kind=4) :: n4
+    interface
+       function priorfun(theta,len)
+         real*8 priorfun
+         integer*4 len
+         real*8 theta(len)
+       end function priorfun
+    end interface
+    n4 = n
+    p = priorfun(theta(1:n), n4)
+  end function mcx_prior_adapter
+  function mcx_bounds_adapter(theta, n, user) bind(C) result(ok)
+    real(c_double), intent(in) :: theta(*)
+    integer(c_int32_t), value :: n
+    type(c_ptr), value :: user
+    integer(c_int32_t) :: ok
+    real(kind=dbl) :: t(n)
+    interface
+       function checkbounds(theta)
+         real*8 theta(:)
+         logical checkbounds
+       end function checkbounds
+    end interface
+    t = theta(1:n)
+    ok = 0
+    if (checkbounds(t)) ok = 1
+  end function mcx_bounds_adapter
+
   !! ---------------------------------------------------------------- ASCII numbers: matutils.F90:1019-1056 rules
   subroutine loadnumbers(file, v, nrows, ncols, stat)
     character(len=*), intent(in) :: file
@@ -512,9 +572,9 @@ contains
           call MCMC_settarget_expdata(v(1::2), v(2::2))
        end if
     case ('banana')
+    case ('host')
     case default
-       call doerror('no device target selected: put devtarget= in an &mcmcx group or call MCMC_settarget_* ' // &
-            '(host ssfunction callbacks are not available in the device engine)')
+       call doerror('unknown devtarget in &mcmcx: '//trim(devtarget))
     end select
     if (len_trim(lowerfile) > 0 .and. .not.has_lo) then
        call loadnumbers(lowerfile, v, nr, nc, stat)
@@ -526,7 +586,7 @@ contains
        if (stat /= 0 .or. size(v) /= npar) call doerror('error reading '//trim(upperfile))
        call MCMC_setbounds(hi=v)
     end if
-    if (len_trim(priorsfile) > 0) then                ! priorfun.f90:52-80: two rows, mu and sigma
+    if (len_trim(priorsfile) > 0 .and. trim(devtarget) /= 'host') then    ! priorfun.f90:52-80: two rows, mu and sigma
        call loadnumbers(priorsfile, v, nr, nc, stat)
        if (stat /= 0 .or. size(v) /= 2*npar) call doerror('priors.dat should have  2*npar elements')
        allocate(pmu(npar), psig(npar)); pmu = v(1:npar); psig = v(npar+1:2*npar)
@@ -573,6 +633,9 @@ contains
        call chk(mcmcx_set_target_banana(handle, banana_b))
     case ('expdata')
        call chk(mcmcx_set_target_expdata(handle, int(size(tx), c_int32_t), tx, ty))
+    case ('host')
+       call chk(mcmcx_set_target_host(handle, c_funloc(mcx_ss_adapter), c_funloc(mcx_prior_adapter), &
+            c_funloc(mcx_bounds_adapter), c_null_ptr))
     end select
     plo = c_null_ptr; phi = c_null_ptr
     if (has_lo) then

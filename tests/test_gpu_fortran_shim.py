@@ -72,3 +72,31 @@ def test_fortran_driver_reproduces_reference_chain(oracle):
     o = oracle.run_chain(cfg, prob, chain_id=0)
     np.testing.assert_array_equal(chain, o.chain)
     np.testing.assert_array_equal(s2, o.s2chain)
+
+
+def test_unmodified_user_program_with_fortran_callbacks(oracle):
+    """demo_user.F90 is a complete mcmcf90-style user program (own Fortran ssfunction reading data.dat, own
+    checkbounds) with the reference's shipped namelist and NO engine-specific input: the shim routes the
+    callbacks through the host-callback path.  The user's ssfunction uses the Fortran runtime's exp, so it is
+    compared with the real reference's chain at the libm rounding level; the accept sequence is identical."""
+    exe = os.path.join(FDIR, "demo_user")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", FDIR])
+    z, cfg, prob = load("c1_shipped_nml", oracle)
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "mcmcinit.nml"), "w").write(NML.split("&mcmcx")[0])
+        with open(os.path.join(d, "data.dat"), "w") as f:
+            f.write("% example data set\n")
+            for x, y in zip(z["prob_xdata"], z["prob_ydata"]):
+                f.write("  %g   %.2f\n" % (x, y))
+        open(os.path.join(d, "mcmcpar.dat"), "w").write("10 0.1 \n")
+        open(os.path.join(d, "mcmccov.dat"), "w").write("0.2 0 \n0 0.001 \n")
+        open(os.path.join(d, "mcmcsigma2.dat"), "w").write("0.5\n11\n")
+        p = subprocess.run([exe], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert p.returncode == 0, p.stdout.decode(errors="replace")
+        chain = np.loadtxt(os.path.join(d, "chain.dat"), ndmin=2)
+        s2 = np.loadtxt(os.path.join(d, "s2chain.dat"), ndmin=1)
+    np.testing.assert_array_equal(chain[:, -1].astype(np.int32), z["runlen"])
+    k = z["rows_head"].shape[0]
+    np.testing.assert_allclose(chain[-k:, :-1], z["rows_tail"], rtol=1e-9)
+    np.testing.assert_allclose(s2[-k:], z["s2_tail"], rtol=1e-9)
