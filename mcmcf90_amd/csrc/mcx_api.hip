@@ -313,8 +313,6 @@ int mcmcx_create(const mcmcx_config *cfg_in, mcmcx_handle *out)
     if (c.condmax > 0.0) return fail(-6, "condmax > 0 (SVD proposal) is not available in the device engine yet");
     if (c.doadapt && c.method == MCMCX_METHOD_DRAM) {
         if (c.adaptint == 0) return fail(-7, "doadapt with adaptint = 0");
-        if (c.adapthist > 1) return fail(-6, "adapthist > 1 (AP window) is not available in the device engine yet");
-        if (c.greedy != 0 && c.doburnin != 0) return fail(-6, "greedy burn-in adaptation is not available in the device engine yet");
     }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -440,6 +438,7 @@ int mcmcx_init(mcmcx_handle h)
     EngineDev &E = h->E;
     E.d = d; E.P = P; E.ntiles = T;
     E.method = (c.method == MCMCX_METHOD_RAM) ? M_RAM : M_DRAM;
+    E.greedy = c.greedy; E.adapthist = c.adapthist; E.initcmatn = (double)c.initcmatn;
     E.dodr = h->dodr; E.updatesigma = c.updatesigma; E.doadapt = c.doadapt; E.doburnin = c.doburnin; E.burnintime = c.burnintime;
     E.gam_shape = shape; E.N0S02 = c.N0 * h->S02eff;
     E.alphatarget = c.alphatarget; E.drscale = c.drscale; E.scalelimit = c.scalelimit; E.scalefactor = c.scalefactor;
@@ -485,7 +484,8 @@ int mcmcx_init(mcmcx_handle h)
     const bool need_hist = am || c.record_chain;
     h->wcap = 0; E.hist = E.s2hist = nullptr; E.wacc = nullptr; E.record_s2 = 0;
     if (need_hist) {
-        long long wc = c.record_chain ? (long long)c.nsimu + 1
+        // AP windows (adapthist > 1) may reach back to an arbitrarily old row: keep everything
+        long long wc = (c.record_chain || (am && c.adapthist > 1)) ? (long long)c.nsimu + 1
                                       : (long long)c.burnintime + c.adaptint + c.adapthist + 2;
         if (wc > (long long)c.nsimu + 1) wc = (long long)c.nsimu + 1;
         h->wcap = (int)wc;

@@ -39,7 +39,8 @@ struct DevTarget {
 
 struct EngineDev {
     int d, P, ntiles;
-    int method, dodr, updatesigma, doadapt, doburnin, burnintime;
+    int method, dodr, updatesigma, doadapt, doburnin, burnintime, greedy, adapthist;
+    double initcmatn;
     double gam_shape;           // N0/2 + nobs/2           (MCMC_DRAM.F90:201)
     double N0S02;               // N0*S02
     double alphatarget, drscale, scalelimit, scalefactor;
@@ -854,6 +855,98 @@ MCX_DEV int potri_packed(double *At, int lane, int d, bool act, double *X)
     return info;
 }
 
+// covmat (matutils.F90:232-341) over the nr rows listed in `rows` (ring slot | weight << 32; slot 0xffffffff =
+// the window's base row in basetheta) for one chain per lane.  update && wsum > 0: weighted Welford, one row
+// at a time (:283-310); otherwise the two-pass batch branch (:311-338), which overwrites cmat, mean and wsum.
+MCX_DEV void covmat_rows(const EngineDev &E, int tile, int lane, const uint64_t *rows, int nr, bool act, bool update,
+                         double *Ct, double *mean_t, const double *base_t, double *m2_t, double &wsum, double *X)
+{
+    const int d = E.d, P = E.P;
+    int nrmax = act ? nr : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { int other = __shfl_xor(nrmax, o); nrmax = other > nrmax ? other : nrmax; }
+    const double *hist_t = E.hist + (size_t)tile * E.wcap * (size_t)(d + 1) * 64;
+    const bool upd = act && update && (wsum > 0.0);
+    const bool bat = act && !upd;
+    if (__any(upd)) {
+        for (int r = 0; r < nrmax; ++r) {
+            const bool on = upd && r < nr;
+            uint64_t e = on ? GV(rows, r) : 0ull;
+            uint32_t slot = (uint32_t)e; double w3 = (double)(uint32_t)(e >> 32);
+            if (on) {
+                const bool isbase = (slot == 0xffffffffu);
+                const size_t so = isbase ? 0 : (size_t)slot * (size_t)(d + 1) * 64;
+                for (int k = 0; k < d; ++k) {
+                    double xv = isbase ? GV(base_t, k) : hist_t[so + (size_t)k * 64 + lane];
+                    XL(k) = xv - GV(mean_t, k);
+                }
+                double f1 = w3 / (wsum + w3 - 1.0);
+                double f2 = wsum / (wsum + w3);
+                for (int a = 0; a < d; ++a) {             // row a of the upper triangle: elements (a, b >= a)
+                    double da = XL(a);
+                    double *rowa = Ct + (size_t)rowstart(a, d) * 64;
+                    for (int b = a; b < d; ++b) {
+                        double o = da * XL(b);
+                        double cab = GV(rowa, b - a);
+                        GV(rowa, b - a) = cab + f1 * (f2 * o - cab);
+                    }
+                }
+                double f3 = w3 / (wsum + w3);
+                for (int k = 0; k < d; ++k) GV(mean_t, k) = GV(mean_t, k) + f3 * XL(k);
+                wsum = w3 + wsum;
+            }
+        }
+    }
+    if (__any(bat)) {
+        double wsum2 = 0.0;
+        if (bat) {
+            for (int r = 0; r < nr; ++r) wsum2 = wsum2 + (double)(uint32_t)(GV(rows, r) >> 32);
+            for (int k = 0; k < d; ++k) GV(m2_t, k) = 0.0;
+        }
+        for (int r = 0; r < nrmax; ++r) {
+            const bool on = bat && r < nr;
+            uint64_t e = on ? GV(rows, r) : 0ull;
+            uint32_t slot = (uint32_t)e; double w = (double)(uint32_t)(e >> 32);
+            if (on) {
+                const bool isbase = (slot == 0xffffffffu);
+                const size_t so = isbase ? 0 : (size_t)slot * (size_t)(d + 1) * 64;
+                for (int k = 0; k < d; ++k) {
+                    double xv = isbase ? GV(base_t, k) : hist_t[so + (size_t)k * 64 + lane];
+                    GV(m2_t, k) = GV(m2_t, k) + xv * w;
+                }
+            }
+        }
+        if (bat) {
+            for (int k = 0; k < d; ++k) GV(m2_t, k) = GV(m2_t, k) / wsum2;          // xmean2
+            for (int e = 0; e < P; ++e) GV(Ct, e) = 0.0;
+        }
+        for (int r = 0; r < nrmax; ++r) {
+            const bool on = bat && r < nr;
+            uint64_t e = on ? GV(rows, r) : 0ull;
+            uint32_t slot = (uint32_t)e; double w = (double)(uint32_t)(e >> 32);
+            if (on) {
+                const bool isbase = (slot == 0xffffffffu);
+                const size_t so = isbase ? 0 : (size_t)slot * (size_t)(d + 1) * 64;
+                for (int k = 0; k < d; ++k) {
+                    double xv = isbase ? GV(base_t, k) : hist_t[so + (size_t)k * 64 + lane];
+                    XL(k) = xv - GV(m2_t, k);
+                }
+                // reference: cmat(i,j), j <= i = sum_r (x_ri - m_i) * ((x_rj - m_j) * w_r); kept at packed (j,i)
+                for (int j = 0; j < d; ++j) {
+                    double xb = XL(j) * w;
+                    double *rowj = Ct + (size_t)rowstart(j, d) * 64;
+                    for (int i = j; i < d; ++i) GV(rowj, i - j) = GV(rowj, i - j) + XL(i) * xb;
+                }
+            }
+        }
+        if (bat) {
+            for (int e = 0; e < P; ++e) GV(Ct, e) = GV(Ct, e) / (wsum2 - 1.0);
+            for (int k = 0; k < d; ++k) GV(mean_t, k) = GV(m2_t, k);
+            wsum = wsum2;
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode)
 {
     extern __shared__ double X[];
@@ -877,6 +970,7 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
     if (mode & AD_BURN) {                                             // MCMC_adapt.F90:60-102
         double staypc = (double)stayed / (double)it;
         double sf = E.scalefactor;
+        bool greedy_lane = false;
         if (staypc > 1.0 - E.scalelimit) {
             for (int e = 0; e < P; ++e) GV(Rt, e) = GV(Rt, e) / sf;
             if (E.dodr) {
@@ -890,20 +984,70 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
                 for (int e = 0; e < P; ++e) { GV(R2t, e) = GV(R2t, e) * sf; GV(iCt, e) = GV(iCt, e) / sf / sf; }
             }
         } else {
-            // lastind = chainind: the covariance window restarts at the current row (lastfreq is NOT touched)
             docalc = true;
+            greedy_lane = (E.greedy != 0);
+        }
+        if (E.greedy != 0) {                                          // :83-101 greedy: restart from cmat0 over chain(1:chainind), unit weights
+            int nr = 0;
+            if (greedy_lane) {
+                wsum = E.initcmatn;
+                for (int e = 0; e < P; ++e) GV(Ct, e) = E.cmat0p[e];
+                for (int k = 0; k < d; ++k) GV(mean_t, k) = E.par0[k];
+                for (int t = 1; t <= it; ++t) {
+                    const int slot = t % E.wcap;
+                    unsigned long long m = E.wacc[(size_t)tile * E.wcap + slot];
+                    if ((m >> lane) & 1ull) { GV(rows, nr) = (uint64_t)(uint32_t)slot | (1ull << 32); ++nr; }
+                }
+            }
+            covmat_rows(E, tile, lane, rows, nr, greedy_lane, true, Ct, mean_t, base_t, m2_t, wsum, X);
+            if (greedy_lane) lastfreq = curcount;
+        }
+        if (docalc) {
+            // lastind = chainind: the covariance window restarts at the current row (lastfreq only touched by greedy)
             for (int k = 0; k < d; ++k) GV(base_t, k) = GV(theta_t, k);
             basecnt = curcount; winstart = (uint32_t)(it + 1);
         }
-    } else if (mode & AD_AM) {                                        // MCMC_adapt.F90:105-159, adapthist <= 1
+    } else if (mode & AD_AM) {                                        // MCMC_adapt.F90:105-159
         docalc = true;
         if (mode & AD_FIRST) {
+            wsum = E.initcmatn;
             for (int e = 0; e < P; ++e) GV(Ct, e) = E.cmat0p[e];
             for (int k = 0; k < d; ++k) GV(mean_t, k) = E.par0[k];
         }
-        // ---- phase 1: rows of chain(lastind:chainind) and their weights, from the accept ballots
         int nr = 0;
-        {
+        if (E.adapthist > 1) {
+            // AP (:116-136): rows back from chainind until the repeat counts cover adapthist iterations; the oldest
+            // row's weight is cut so that the weights sum to adapthist; batch recompute (update = .false.)
+            int histsum = (int)curcount;
+            int t = it;                                   // walk back over the ballots to the accepting iterations
+            // find the iteration that accepted the current row
+            int nback = 0;
+            uint32_t w = curcount;
+            // first pass: count rows needed (newest first), remember the oldest one's count
+            int tt = it - (int)curcount + 1;              // iteration at which the current row was accepted
+            GV(rows, 0) = (uint64_t)(uint32_t)(tt % E.wcap) | ((uint64_t)w << 32);
+            nback = 1;
+            while (histsum < E.adapthist && tt > 1) {
+                int t2 = tt - 1, cnt = 1;                 // previous row: accepted at the last set ballot before tt
+                while (t2 > 1 && !((E.wacc[(size_t)tile * E.wcap + (t2 % E.wcap)] >> lane) & 1ull)) { --t2; ++cnt; }
+                histsum += cnt;
+                GV(rows, nback) = (uint64_t)(uint32_t)(t2 % E.wcap) | ((uint64_t)(uint32_t)cnt << 32);
+                ++nback; tt = t2;
+            }
+            (void)t;
+            // oldest row's weight: newfreq - histsum + adapthist
+            {
+                uint64_t e = GV(rows, nback - 1);
+                int newfreq = (int)(uint32_t)(e >> 32);
+                int wadj = newfreq - histsum + E.adapthist;
+                GV(rows, nback - 1) = (e & 0xffffffffull) | ((uint64_t)(uint32_t)wadj << 32);
+            }
+            // reverse into chain order (oldest first)
+            for (int a = 0, b2 = nback - 1; a < b2; ++a, --b2) { uint64_t ta = GV(rows, a); GV(rows, a) = GV(rows, b2); GV(rows, b2) = ta; }
+            nr = nback;
+            covmat_rows(E, tile, lane, rows, nr, true, false, Ct, mean_t, base_t, m2_t, wsum, X);
+        } else {
+            // AM (:138-157): rows of chain(lastind:chainind) and their weights, from the accept ballots
             uint32_t w = basecnt;                 // count of the base row when the window started
             uint32_t slot_prev = 0xffffffffu;     // base row lives in basetheta
             for (int t = (int)winstart; t <= it; ++t) {
@@ -918,88 +1062,12 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
             uint32_t wr = (nr == 0) ? (w - lastfreq) : w;
             GV(rows, nr) = (uint64_t)slot_prev | ((uint64_t)wr << 32);
             ++nr;
+            covmat_rows(E, tile, lane, rows, nr, true, true, Ct, mean_t, base_t, m2_t, wsum, X);
+            // lastfreq = count of the current row; lastind = chainind -> window restarts here
+            lastfreq = curcount;
+            for (int k = 0; k < d; ++k) GV(base_t, k) = GV(theta_t, k);
+            basecnt = curcount; winstart = (uint32_t)(it + 1);
         }
-        int nrmax = nr;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { int other = __shfl_xor(nrmax, o); nrmax = other > nrmax ? other : nrmax; }
-        const double *hist_t = E.hist + (size_t)tile * E.wcap * (size_t)(d + 1) * 64;
-
-        if (wsum > 0.0) {
-            // ---- covmat(update=.true.): weighted Welford, one row at a time (matutils.F90:283-310)
-            for (int r = 0; r < nrmax; ++r) {
-                bool act = r < nr;
-                uint64_t e = act ? GV(rows, r) : 0ull;
-                uint32_t slot = (uint32_t)e; double w3 = (double)(uint32_t)(e >> 32);
-                if (act) {
-                    const bool isbase = (slot == 0xffffffffu);
-                    const size_t so = isbase ? 0 : (size_t)slot * (size_t)(d + 1) * 64;
-                    for (int k = 0; k < d; ++k) {
-                        double xv = isbase ? GV(base_t, k) : hist_t[so + (size_t)k * 64 + lane];
-                        XL(k) = xv - GV(mean_t, k);
-                    }
-                    double f1 = w3 / (wsum + w3 - 1.0);
-                    double f2 = wsum / (wsum + w3);
-                    for (int a = 0; a < d; ++a) {             // row a of the upper triangle: elements (a, b >= a)
-                        double da = XL(a);
-                        double *rowa = Ct + (size_t)rowstart(a, d) * 64;
-                        for (int b = a; b < d; ++b) {
-                            double o = da * XL(b);
-                            double cab = GV(rowa, b - a);
-                            GV(rowa, b - a) = cab + f1 * (f2 * o - cab);
-                        }
-                    }
-                    double f3 = w3 / (wsum + w3);
-                    for (int k = 0; k < d; ++k) GV(mean_t, k) = GV(mean_t, k) + f3 * XL(k);
-                    wsum = w3 + wsum;
-                }
-            }
-        } else {
-            // ---- covmat batch branch (matutils.F90:311-338): wsum == 0 on entry
-            double wsum2 = 0.0;
-            for (int r = 0; r < nr; ++r) wsum2 = wsum2 + (double)(uint32_t)(GV(rows, r) >> 32);
-            for (int k = 0; k < d; ++k) GV(m2_t, k) = 0.0;
-            for (int r = 0; r < nrmax; ++r) {
-                bool act = r < nr;
-                uint64_t e = act ? GV(rows, r) : 0ull;
-                uint32_t slot = (uint32_t)e; double w = (double)(uint32_t)(e >> 32);
-                if (act) {
-                    const bool isbase = (slot == 0xffffffffu);
-                    const size_t so = isbase ? 0 : (size_t)slot * (size_t)(d + 1) * 64;
-                    for (int k = 0; k < d; ++k) {
-                        double xv = isbase ? GV(base_t, k) : hist_t[so + (size_t)k * 64 + lane];
-                        GV(m2_t, k) = GV(m2_t, k) + xv * w;
-                    }
-                }
-            }
-            for (int k = 0; k < d; ++k) GV(m2_t, k) = GV(m2_t, k) / wsum2;          // xmean2
-            for (int e = 0; e < P; ++e) GV(Ct, e) = 0.0;
-            for (int r = 0; r < nrmax; ++r) {
-                bool act = r < nr;
-                uint64_t e = act ? GV(rows, r) : 0ull;
-                uint32_t slot = (uint32_t)e; double w = (double)(uint32_t)(e >> 32);
-                if (act) {
-                    const bool isbase = (slot == 0xffffffffu);
-                    const size_t so = isbase ? 0 : (size_t)slot * (size_t)(d + 1) * 64;
-                    for (int k = 0; k < d; ++k) {
-                        double xv = isbase ? GV(base_t, k) : hist_t[so + (size_t)k * 64 + lane];
-                        XL(k) = xv - GV(m2_t, k);
-                    }
-                    // reference: cmat(i,j), j <= i = sum_r (x_ri - m_i) * ((x_rj - m_j) * w_r); kept at packed (j,i)
-                    for (int j = 0; j < d; ++j) {
-                        double xb = XL(j) * w;
-                        double *rowj = Ct + (size_t)rowstart(j, d) * 64;
-                        for (int i = j; i < d; ++i) GV(rowj, i - j) = GV(rowj, i - j) + XL(i) * xb;
-                    }
-                }
-            }
-            for (int e = 0; e < P; ++e) GV(Ct, e) = GV(Ct, e) / (wsum2 - 1.0);
-            for (int k = 0; k < d; ++k) GV(mean_t, k) = GV(m2_t, k);
-            wsum = wsum2;
-        }
-        // lastfreq = count of the current row; lastind = chainind -> window restarts here
-        lastfreq = curcount;
-        for (int k = 0; k < d; ++k) GV(base_t, k) = GV(theta_t, k);
-        basecnt = curcount; winstart = (uint32_t)(it + 1);
     }
 
     if (__any(docalc)) {

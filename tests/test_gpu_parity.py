@@ -9,9 +9,9 @@ from golden_util import names, load, accepted_from_runlen, GOLDEN
 
 pytestmark = pytest.mark.gpu
 
-# fixtures whose namelist the device engine supports today (no AP window / greedy burn-in)
-SUPPORTED = ["c1_shipped_nml", "c2_gauss10_am", "c2_gauss10_am_initcmatn", "c3_banana20_dram", "c4_gauss50_ram",
-             "c4_gauss50_am"]
+# every fixture: AM, DRAM, RAM, burn-in scaling, greedy burn-in, AP window, priors, bounds, sigma2 update
+SUPPORTED = ["c1_shipped_nml", "c1_expdata_dram", "c1_priors_ap", "c2_gauss10_am", "c2_gauss10_am_initcmatn",
+             "c3_banana20_dram", "c4_gauss50_ram", "c4_gauss50_am"]
 
 
 def _kw(z):
