@@ -76,6 +76,10 @@ constexpr int CH = 8;     // row elements per batch; two batches (2 x 8 x 512 B)
 #define XL(j) X[(j) * 64 + lane]
 // element k of a tile-interleaved global vector whose tile base is `p` (uniform pointer)
 #define GV(p, k) (p)[(size_t)(k) * 64 + lane]
+// streaming (non-temporal) access for the factor, which is touched once per iteration and should not evict
+// the small per-chain scratch vectors from L2 / Infinity Cache
+#define LDNT(p, k) __builtin_nontemporal_load(&(p)[(size_t)(k) * 64 + lane])
+#define STNT(p, k, v) __builtin_nontemporal_store((v), &(p)[(size_t)(k) * 64 + lane])
 
 // Software-pipelined sweep over elements k0..n-1 of one packed row (rowp[k], element stride 64):
 // the next batch of CH elements is requested before the current one is consumed, and the
@@ -244,7 +248,7 @@ MCX_DEV void trmv_panels(const double *Rt, const double *z_t, double *P_t, int l
                 const double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
                 double r[PW];
 #pragma unroll
-                for (int u = 0; u < PW; ++u) r[u] = GV(seg, u < nw ? u : nw - 1);
+                for (int u = 0; u < PW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
 #pragma unroll
                 for (int u = 0; u < PW; ++u) P[u] = dfma(r[u], zi, P[u]);
             }
@@ -254,7 +258,7 @@ MCX_DEV void trmv_panels(const double *Rt, const double *z_t, double *P_t, int l
                 const int ui = i - J0, m = d - 1 - i;
                 double r[PW];
 #pragma unroll
-                for (int u = 0; u < PW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = GV(seg, k); }
+                for (int u = 0; u < PW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
 #pragma unroll
                 for (int u = 0; u < PW; ++u) { double nv = dfma(r[u], zi, P[u]); P[u] = (u >= ui) ? nv : P[u]; }
             }
@@ -294,12 +298,12 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                     double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
                     double r[PW];
 #pragma unroll
-                    for (int u = 0; u < PW; ++u) r[u] = GV(seg, u < nw ? u : nw - 1);
+                    for (int u = 0; u < PW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
 #pragma unroll
                     for (int u = 0; u < PW; ++u) {
                         double t = c * r[u] + sn * x[u];
                         x[u] = c * x[u] - sn * r[u];
-                        if (u < nw) GV(seg, u) = t;
+                        if (u < nw) STNT(seg, u, t);
                         P[u] = dfma(t, zi, P[u]);
                     }
                 }
@@ -309,7 +313,7 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                     const double zi = fuse ? GV(zn_t, i) : 0.0;
                     double r[PW];
 #pragma unroll
-                    for (int u = 0; u < PW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = GV(seg, k); }
+                    for (int u = 0; u < PW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
                     double xi = x[0];
 #pragma unroll
                     for (int u = 1; u < PW; ++u) xi = (u == ui) ? x[u] : xi;
@@ -323,7 +327,7 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                         double t = c * r[u] + sn * x[u];
                         double nx = c * x[u] - sn * r[u];
                         x[u] = off ? nx : x[u];
-                        if (off) GV(seg, u - ui) = t;
+                        if (off) STNT(seg, u - ui, t);
                         double tp = (u == ui) ? rr : t;
                         double np = dfma(tp, zi, P[u]);
                         P[u] = (u >= ui && u < nw) ? np : P[u];
@@ -350,7 +354,7 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                     const double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
                     double r[PW];
 #pragma unroll
-                    for (int u = 0; u < PW; ++u) r[u] = GV(seg, u < nw ? u : nw - 1);
+                    for (int u = 0; u < PW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
 #pragma unroll
                     for (int u = 0; u < PW; ++u) acc[u] = dfma(r[u], si, acc[u]);
                 }
@@ -359,7 +363,7 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                     const int ui = i - J0, m = d - 1 - i;
                     double r[PW];
 #pragma unroll
-                    for (int u = 0; u < PW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = GV(seg, k); }
+                    for (int u = 0; u < PW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
                     double ai = acc[0];
 #pragma unroll
                     for (int u = 1; u < PW; ++u) ai = (u == ui) ? acc[u] : ai;
@@ -412,13 +416,13 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                         const double ci = GV(cs_t, 2 * i), si = GV(cs_t, 2 * i + 1);
                         double r[PW];
 #pragma unroll
-                        for (int u = 0; u < PW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = GV(seg, k); }
+                        for (int u = 0; u < PW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
 #pragma unroll
                         for (int u = 0; u < PW; ++u) {
                             const bool on = (u >= ui) && (u < nw);
                             double t = ci * xx[u] + si * r[u];
                             double nr = ci * r[u] - si * xx[u];
-                            if (on) GV(seg, u - ui) = nr;
+                            if (on) STNT(seg, u - ui, nr);
                             xx[u] = on ? t : xx[u];
                         }
                     }
@@ -428,11 +432,11 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                         const double ci = GV(cs_t, 2 * i), si = GV(cs_t, 2 * i + 1);
                         double r[PW];
 #pragma unroll
-                        for (int u = 0; u < PW; ++u) r[u] = GV(seg, u < nw ? u : nw - 1);
+                        for (int u = 0; u < PW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
 #pragma unroll
                         for (int u = 0; u < PW; ++u) {
                             double t = ci * xx[u] + si * r[u];
-                            if (u < nw) GV(seg, u) = ci * r[u] - si * xx[u];
+                            if (u < nw) STNT(seg, u, ci * r[u] - si * xx[u]);
                             xx[u] = t;
                         }
                     }
