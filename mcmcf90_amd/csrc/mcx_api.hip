@@ -163,7 +163,7 @@ static void launch_step(mcmcx_engine *h, int it0, int it1)
     else hipLaunchKernelGGL((step_kernel<false, false>), g, b, 0, h->stream, h->E, it0, it1, rs);
 }
 static void launch_adapt(mcmcx_engine *h, int it, int mode)
-{ hipLaunchKernelGGL(adapt_kernel, dim3(h->ntiles), dim3(64), lds_bytes(h), h->stream, h->E, it, mode); }
+{ hipLaunchKernelGGL(adapt_kernel, dim3(h->ntiles), dim3(64), lds_bytes(h) / 2, h->stream, h->E, it, mode); }   // one d-vector
 
 // Which branch of MCMC_adapt fires at iteration `it` (0 = none).  MCMC_adapt.F90:42-46, 60-61, 105.
 static int adapt_mode(const mcmcx_config &c, int it)

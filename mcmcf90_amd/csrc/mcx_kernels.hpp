@@ -789,7 +789,13 @@ MCX_DEV int calculate_R(double *Ct, double *Rt, int lane, int d, int P, bool act
     int info = 0;
     for (int j = 0; j < d; ++j) {
         double dot = 0.0;
-        for (int i = 0; i < j; ++i) { double v = GV(Ct, pidx(i, j, d)); XL(i) = v; dot = dfma(v, v, dot); }
+        for (int i0 = 0; i0 < j; i0 += CH) {
+            double v[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) { int i = (i0 + u < j) ? i0 + u : j - 1; v[u] = GV(Ct, pidx(i, j, d)); }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) if (i0 + u < j) { XL(i0 + u) = v[u]; dot = dfma(v[u], v[u], dot); }
+        }
         double *rowj = Ct + (size_t)rowstart(j, d) * 64;
         double ajj = GV(rowj, 0) - dot;
         bool ok = (ajj > 0.0);
@@ -801,7 +807,13 @@ MCX_DEV int calculate_R(double *Ct, double *Rt, int lane, int d, int P, bool act
         for (int k = j + 1; k < d; ++k) {
             if (go) {
                 double t = 0.0;
-                for (int i = 0; i < j; ++i) t = dfma(GV(Ct, pidx(i, k, d)), XL(i), t);
+                for (int i0 = 0; i0 < j; i0 += CH) {
+                    double v[CH];
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) { int i = (i0 + u < j) ? i0 + u : j - 1; v[u] = GV(Ct, pidx(i, k, d)); }
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) if (i0 + u < j) t = dfma(v[u], XL(i0 + u), t);
+                }
                 GV(rowj, k - j) = (GV(rowj, k - j) - t) * rinv;
             }
         }
@@ -889,10 +901,18 @@ MCX_DEV void covmat_rows(const EngineDev &E, int tile, int lane, const uint64_t 
                 for (int a = 0; a < d; ++a) {             // row a of the upper triangle: elements (a, b >= a)
                     double da = XL(a);
                     double *rowa = Ct + (size_t)rowstart(a, d) * 64;
-                    for (int b = a; b < d; ++b) {
-                        double o = da * XL(b);
-                        double cab = GV(rowa, b - a);
-                        GV(rowa, b - a) = cab + f1 * (f2 * o - cab);
+                    const int n = d - a;
+                    for (int k0 = 0; k0 < n; k0 += CH) {  // CH elements per batch: loads first, then the updates
+                        double cab[CH];
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) cab[u] = GV(rowa, (k0 + u < n) ? k0 + u : n - 1);
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) {
+                            if (k0 + u < n) {
+                                double o = da * XL(a + k0 + u);
+                                GV(rowa, k0 + u) = cab[u] + f1 * (f2 * o - cab[u]);
+                            }
+                        }
                     }
                 }
                 double f3 = w3 / (wsum + w3);
@@ -939,7 +959,14 @@ MCX_DEV void covmat_rows(const EngineDev &E, int tile, int lane, const uint64_t 
                 for (int j = 0; j < d; ++j) {
                     double xb = XL(j) * w;
                     double *rowj = Ct + (size_t)rowstart(j, d) * 64;
-                    for (int i = j; i < d; ++i) GV(rowj, i - j) = GV(rowj, i - j) + XL(i) * xb;
+                    const int n = d - j;
+                    for (int k0 = 0; k0 < n; k0 += CH) {
+                        double cji[CH];
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) cji[u] = GV(rowj, (k0 + u < n) ? k0 + u : n - 1);
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) if (k0 + u < n) GV(rowj, k0 + u) = cji[u] + XL(j + k0 + u) * xb;
+                    }
                 }
             }
         }
@@ -948,6 +975,110 @@ MCX_DEV void covmat_rows(const EngineDev &E, int tile, int lane, const uint64_t 
             for (int k = 0; k < d; ++k) GV(mean_t, k) = GV(m2_t, k);
             wsum = wsum2;
         }
+    }
+}
+
+// The steady-state form of the same Welford update (matutils.F90:283-310), blocked: an 8x8 block of the
+// upper triangle of cmat stays in registers while the window's iterations t0..t1 stream by, so cmat is read
+// and written once per adaptation instead of once per accepted row.  Row r of the reference's
+// chain(lastind:chainind) is "the state between two set ballot bits"; its weight (the repeat count) is known
+// when the next accept arrives, which is when the row is folded in.  Every component's running mean obeys its
+// own recurrence, so recomputing delta = x - mean inside each block repeats the reference's operations exactly.
+//   have_base/count0/adj0 : the window's base row (basetheta), its count at window start, and the amount
+//                           (lastfreq) taken off the first folded weight          (AM: MCMC_adapt.F90:140-147)
+//   unit                  : every row has weight 1 and there is no base row       (greedy: MCMC_adapt.F90:91)
+MCX_DEV void covmat_window_blocked(const EngineDev &E, int tile, int lane, bool act, int t0lane, int t1, bool unit,
+                                   uint32_t count0, uint32_t adj0, double *Ct, double *mean_t, const double *base_t,
+                                   double *mnew_t, double &wsum)
+{
+    const int d = E.d;
+    int t0 = act ? t0lane : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { int other = __shfl_xor(t0, o); t0 = other < t0 ? other : t0; }
+    if (t0 == 0x7fffffff) return;
+    const double *hist_t = E.hist + (size_t)tile * E.wcap * (size_t)(d + 1) * 64;
+    const unsigned long long *wacc_t = (const unsigned long long *)E.wacc + (size_t)tile * E.wcap;
+    double Wend = wsum;
+    for (int a0 = 0; a0 < d; a0 += 8) {
+        for (int b0 = a0; b0 < d; b0 += 8) {
+            double C[8][8], ma[8], mb[8], xa[8], xb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int a = (a0 + u < d) ? a0 + u : d - 1;
+                ma[u] = GV(mean_t, a);
+                const int b = (b0 + u < d) ? b0 + u : d - 1;
+                mb[u] = GV(mean_t, b);
+                xa[u] = unit ? 0.0 : GV(base_t, a);
+                xb[u] = unit ? 0.0 : GV(base_t, b);
+#pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    int bb = (b0 + v < d) ? b0 + v : d - 1;
+                    bb = bb < a ? a : bb;
+                    C[u][v] = GV(Ct, pidx(a, bb, d));
+                }
+            }
+            double W = wsum;
+            bool have = act && !unit;
+            uint32_t cnt = count0, adj = adj0;
+            auto fold = [&](bool on, double w3) {
+                const double f1 = w3 / (W + w3 - 1.0), f2 = W / (W + w3), f3 = w3 / (W + w3);
+                double da[8], db[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { da[u] = xa[u] - ma[u]; db[u] = xb[u] - mb[u]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) {
+                        double o = da[u] * db[v];
+                        double nc = C[u][v] + f1 * (f2 * o - C[u][v]);
+                        C[u][v] = on ? nc : C[u][v];
+                    }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    double na = ma[u] + f3 * da[u], nb = mb[u] + f3 * db[u];
+                    ma[u] = on ? na : ma[u]; mb[u] = on ? nb : mb[u];
+                }
+                W = on ? (w3 + W) : W;
+            };
+            for (int t = t0; t <= t1; ++t) {
+                const int slot = t % E.wcap;
+                const bool inwin = act && (t >= t0lane);
+                const bool acc = inwin && ((wacc_t[slot] >> lane) & 1ull);
+                if (__any(acc)) {
+                    const bool fl = acc && have;
+                    if (__any(fl)) fold(fl, unit ? 1.0 : (double)(cnt - adj));
+                    if (acc) {
+                        const size_t so = (size_t)slot * (size_t)(d + 1) * 64;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int a = (a0 + u < d) ? a0 + u : d - 1, b = (b0 + u < d) ? b0 + u : d - 1;
+                            xa[u] = hist_t[so + (size_t)a * 64 + lane];
+                            xb[u] = hist_t[so + (size_t)b * 64 + lane];
+                        }
+                        if (have) adj = 0;
+                        have = true; cnt = 1;
+                    }
+                }
+                if (inwin && !acc) cnt += 1;
+            }
+            if (__any(have)) fold(have, unit ? 1.0 : (double)(cnt - adj));
+            // write the block back (upper triangle only) and, from the diagonal blocks, the means
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int a = a0 + u;
+#pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    const int b = b0 + v;
+                    if (act && a < d && b < d && b >= a) GV(Ct, pidx(a, b, d)) = C[u][v];
+                }
+                if (act && a0 == b0 && a < d) GV(mnew_t, a) = ma[u];     // the other blocks still need the old means
+            }
+            Wend = W;
+        }
+    }
+    if (act) {
+        for (int k = 0; k < d; ++k) GV(mean_t, k) = GV(mnew_t, k);
+        wsum = Wend;
     }
 }
 
@@ -1003,7 +1134,11 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
                     if ((m >> lane) & 1ull) { GV(rows, nr) = (uint64_t)(uint32_t)slot | (1ull << 32); ++nr; }
                 }
             }
-            covmat_rows(E, tile, lane, rows, nr, greedy_lane, true, Ct, mean_t, base_t, m2_t, wsum, X);
+            {
+                const bool steady = greedy_lane && wsum > 0.0;
+                covmat_window_blocked(E, tile, lane, steady, 1, it, true, 0u, 0u, Ct, mean_t, base_t, m2_t, wsum);
+                covmat_rows(E, tile, lane, rows, nr, greedy_lane && !steady, true, Ct, mean_t, base_t, m2_t, wsum, X);
+            }
             if (greedy_lane) lastfreq = curcount;
         }
         if (docalc) {
@@ -1066,7 +1201,11 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
             uint32_t wr = (nr == 0) ? (w - lastfreq) : w;
             GV(rows, nr) = (uint64_t)slot_prev | ((uint64_t)wr << 32);
             ++nr;
-            covmat_rows(E, tile, lane, rows, nr, true, true, Ct, mean_t, base_t, m2_t, wsum, X);
+            // steady state (chainwsum > 0): blocked Welford straight from the ballots; the row list is only
+            // needed by the one-off batch branch
+            const bool steady = wsum > 0.0;
+            covmat_window_blocked(E, tile, lane, steady, (int)winstart, it, false, basecnt, lastfreq, Ct, mean_t, base_t, m2_t, wsum);
+            covmat_rows(E, tile, lane, rows, nr, !steady, true, Ct, mean_t, base_t, m2_t, wsum, X);
             // lastfreq = count of the current row; lastind = chainind -> window restarts here
             lastfreq = curcount;
             for (int k = 0; k < d; ++k) GV(base_t, k) = GV(theta_t, k);
