@@ -42,6 +42,8 @@ def alg_bytes_per_proposal(d, method):
     it (4 d (d+1))."""
     base = 16 * d + 32
     tri = d * (d + 1) // 2 * 8
+    if method == "pooled":
+        return base                                   # the shared factor lives in the scalar cache
     return base + (2 * tri if method == "ram" else tri)
 
 
@@ -81,6 +83,7 @@ def main():
     ap.add_argument("--its-per-step", type=int, default=100)
     ap.add_argument("--npar", type=int, default=50)
     ap.add_argument("--method", default="ram", choices=["ram", "dram"])
+    ap.add_argument("--pooled", action="store_true", help="pooled AM: one shared factor from the all-reduced pooled covariance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -106,10 +109,20 @@ def main():
     nsimu = 1 + (a.warmup + a.steps) * ips
     ckw = dict(nsimu=nsimu, method=a.method, updatesigma=0, adaptint=ips)
     pkw = dict(kind="gauss", npar=d, par0=np.zeros(d), cmat0=0.01 * np.eye(d), mu=np.zeros(d), lam=lam)
-    eng = engine_from_problem(ckw, pkw, nchains=n_local, chain_id0=rank * n_local, device=local_rank)
-    eng.init()
+    if a.pooled:
+        a.method = "dram"
+        ckw = dict(nsimu=nsimu, method="dram", updatesigma=0, adaptint=ips)
+    eng = engine_from_problem(ckw, pkw, nchains=n_local, chain_id0=rank * n_local, device=local_rank,
+                              pooled=1 if a.pooled else 0)
     mom_len = 1 + d + d * (d + 1) // 2
     pooled = torch.zeros(mom_len, dtype=torch.float64, device=dev)
+    xbuf = torch.zeros(mom_len, dtype=torch.float64, device=dev)
+    if a.pooled and world > 1:
+        def _xchg():                                   # called by the engine at every adaptation tick
+            dist.all_reduce(xbuf)
+            torch.cuda.synchronize()
+        eng.set_exchange(_xchg, xbuf.data_ptr())
+    eng.init()
 
     def one_step(k):
         eng.run(1 + (k + 1) * ips)
@@ -143,7 +156,7 @@ def main():
     if rank == 0:
         proposals = float(world) * n_local * ips * a.steps
         value = proposals / dt
-        balg = alg_bytes_per_proposal(d, a.method)
+        balg = alg_bytes_per_proposal(d, "pooled" if a.pooled else a.method)
         per_launch_bytes = balg * n_local * (ksteps / max(klaunch, 1))
         avg_launch_s = kms / 1e3 / max(klaunch, 1)
         achieved = per_launch_bytes / avg_launch_s / 1e9
@@ -166,7 +179,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C4: correlated Gaussian d=%d (Sigma=0.5^|i-j|), method=%s, per-chain Cholesky "
                                    "factor, %d chains/GPU, pooled moments all-reduce every %d iterations"
-                                   % (d, a.method, n_local, ips),
+                                   % (d, a.method + (" pooled (shared factor)" if a.pooled else ""), n_local, ips),
                        "chains_per_gpu": n_local, "its_per_step": ips, "npar": d, "method": a.method,
                        "parallelism": "chains sharded over %d GPU(s)" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

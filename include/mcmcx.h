@@ -58,7 +58,8 @@ typedef struct mcmcx_config {
     int32_t record_accept; /* keep the wavefront accept ballots of every iteration */
     int32_t record_chain;  /* keep every accepted row (the reference's chain/sschain/s2chain) */
     int32_t device;        /* HIP device ordinal */
-    int32_t reserved;
+    int32_t pooled;        /* 1: one proposal factor shared by all chains, adapted from the pooled empirical
+                            * covariance of the current states (multi-chain extension; 0 = the reference's per-chain AM) */
 } mcmcx_config;
 
 typedef struct mcmcx_engine *mcmcx_handle;
@@ -121,6 +122,15 @@ int32_t mcmcx_pooled_moments_len(mcmcx_handle h);
 /* same, written to a device buffer of the caller (the operand of an RCCL all-reduce); asynchronous on
  * the engine's stream */
 int mcmcx_pooled_moments_dev(mcmcx_handle h, void *dev_out);
+
+/* Pooled mode across several GPUs: at every adaptation tick the engine writes its local moment vector
+ * (mcmcx_pooled_moments_len doubles) to dev_buf, synchronises its stream and calls fn(user); fn must sum dev_buf
+ * over all ranks in place (an RCCL all-reduce) and return after the result is visible.  Without a hook the local
+ * moments are used (single GPU). */
+typedef void (*mcmcx_exchange_t)(void *user);
+int mcmcx_set_exchange(mcmcx_handle h, mcmcx_exchange_t fn, void *user, void *dev_buf);
+/* pooled proposal state: chaincmat, chainmean, chainwsum and the shared factor R (column-major d x d) */
+int mcmcx_get_pooled(mcmcx_handle h, double *cmat_colmajor, double *mean, double *wsum, double *R_colmajor);
 
 /* device time of the step kernel over all launches since the last reset, measured with HIP
  * events on the engine's stream; launches = number of step-kernel launches, steps = iterations */

@@ -21,7 +21,7 @@ class Config(C.Structure):
                [(n, C.c_double) for n in
                 ("scalelimit", "scalefactor", "drscale", "N0", "S02", "condmax", "alphatarget", "nuparam")] + \
                [("seed", C.c_uint32), ("chain_id0", C.c_uint32), ("record_accept", C.c_int32),
-                ("record_chain", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32)]
+                ("record_chain", C.c_int32), ("device", C.c_int32), ("pooled", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/mcmcx.h declares
@@ -67,6 +67,9 @@ SYMBOLS = {
 SSFUN_T = C.CFUNCTYPE(None, _DP, C.c_int32, C.c_int32, _DP, C.c_void_p)
 PRIORFUN_T = C.CFUNCTYPE(C.c_double, _DP, C.c_int32, C.c_void_p)
 CHECKBOUNDS_T = C.CFUNCTYPE(C.c_int32, _DP, C.c_int32, C.c_void_p)
+EXCHANGE_T = C.CFUNCTYPE(None, C.c_void_p)
+SYMBOLS["mcmcx_set_exchange"] = (C.c_int, [C.c_void_p, EXCHANGE_T, C.c_void_p, C.c_void_p])
+SYMBOLS["mcmcx_get_pooled"] = (C.c_int, [C.c_void_p, _DP, _DP, _DP, _DP])
 SYMBOLS["mcmcx_set_target_host"] = (C.c_int, [C.c_void_p, SSFUN_T, PRIORFUN_T, CHECKBOUNDS_T, C.c_void_p])
 
 _lib = None

@@ -41,6 +41,9 @@ struct mcmcx_engine {
     bool has_lo = false, has_hi = false, has_pri = false;
     mcmcx_ssfun_t h_ss = nullptr; mcmcx_priorfun_t h_pri = nullptr; mcmcx_checkbounds_t h_cb = nullptr; void *h_user = nullptr;
     std::vector<double> h_cand, h_ev;
+    // pooled mode
+    int pooled = 0; double pool_W = 0.0; std::vector<double> pool_mean, pool_C, pool_R;   // packed upper, row-major
+    double *d_sharedR = nullptr; mcmcx_exchange_t xfn = nullptr; void *xuser = nullptr; double *xbuf = nullptr;
     double S02eff = 0.0;
     // device
     hipStream_t stream = nullptr; bool own_stream = false;
@@ -158,9 +161,10 @@ static void launch_step(mcmcx_engine *h, int it0, int it1)
 {
     const dim3 g(h->ntiles), b(64);
     const double *rs = h->d_ramscale + it0;
-    if (h->E.method == M_RAM) hipLaunchKernelGGL((step_kernel<true, false>), g, b, 0, h->stream, h->E, it0, it1, rs);
-    else if (h->dodr) hipLaunchKernelGGL((step_kernel<false, true>), g, b, lds_step(h), h->stream, h->E, it0, it1, rs);
-    else hipLaunchKernelGGL((step_kernel<false, false>), g, b, 0, h->stream, h->E, it0, it1, rs);
+    if (h->E.method == M_RAM) hipLaunchKernelGGL((step_kernel<true, false, false>), g, b, 0, h->stream, h->E, it0, it1, rs);
+    else if (h->dodr) hipLaunchKernelGGL((step_kernel<false, true, false>), g, b, lds_step(h), h->stream, h->E, it0, it1, rs);
+    else if (h->pooled) hipLaunchKernelGGL((step_kernel<false, false, true>), g, b, 0, h->stream, h->E, it0, it1, rs);
+    else hipLaunchKernelGGL((step_kernel<false, false, false>), g, b, 0, h->stream, h->E, it0, it1, rs);
 }
 static void launch_adapt(mcmcx_engine *h, int it, int mode)
 { hipLaunchKernelGGL(adapt_kernel, dim3(h->ntiles), dim3(64), lds_bytes(h) / 2, h->stream, h->E, it, mode); }   // one d-vector
@@ -219,6 +223,63 @@ static void unpack_upper(int d, const std::vector<double> &p, double *colmajor, 
             else if (symmetric) v = p[h_pidx(j, i, d)];
             colmajor[(size_t)i + (size_t)j * d] = v;
         }
+}
+
+static int pooled_moments_launch(mcmcx_engine *h, double *dev_dst);
+
+// Pooled adaptation tick (the multi-chain form of MCMC_adapt.F90:105-170): the N current states are a batch of
+// N unit-weight rows.  Their mean/covariance come from the device-reduced moment vector (all-reduced over
+// ranks by the exchange hook), are merged into (chaincmat, chainmean, chainwsum) by the pairwise-update formula
+// -- or taken as they are when chainwsum == 0, like covmat's batch branch -- and the shared factor is
+// R = chol(chaincmat) * 2.4/sqrt(d).  Every operation below is restated in tests/test_gpu_pooled.py.
+static int pooled_adapt(mcmcx_engine *h, int it)
+{
+    const mcmcx_config &c = h->cfg;
+    const int d = h->d, P = h->P, len = 1 + d + P;
+    double *dst = h->xbuf ? h->xbuf : h->d_moments + (size_t)h->ntiles * len;      // tail of the moments workspace
+    int rc = pooled_moments_launch(h, dst); if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->xfn) h->xfn(h->xuser);
+    std::vector<double> v(len);
+    HIPCHK(hipMemcpy(v.data(), dst, (size_t)len * 8, hipMemcpyDeviceToHost));
+    if (it == c.burnintime + c.adaptint + c.adapthist) {                            // first time: MCMC_adapt.F90:108-114
+        h->pool_W = (double)c.initcmatn;
+        for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) h->pool_C[h_pidx(i, j, d)] = h->cmat0[(size_t)i + (size_t)j * d];
+        h->pool_mean = h->par0;
+    }
+    const double n = v[0];
+    std::vector<double> m1(d), mb(d), Cb(P);
+    for (int j = 0; j < d; ++j) { m1[j] = v[1 + j] / n; mb[j] = h->par0[j] + m1[j]; }
+    for (int j = 0; j < d; ++j)
+        for (int i = 0; i <= j; ++i) {
+            double s2 = v[1 + d + j * (j + 1) / 2 + i];
+            Cb[h_pidx(i, j, d)] = (s2 - n * m1[i] * m1[j]) / (n - 1.0);
+        }
+    if (!(h->pool_W > 0.0)) {
+        h->pool_C = Cb; h->pool_mean = mb; h->pool_W = n;
+    } else {
+        const double W = h->pool_W, Wn = W + n;
+        std::vector<double> dl(d);
+        for (int j = 0; j < d; ++j) dl[j] = mb[j] - h->pool_mean[j];
+        const double f = W * n / Wn;
+        for (int j = 0; j < d; ++j)
+            for (int i = 0; i <= j; ++i) {
+                const int e = h_pidx(i, j, d);
+                h->pool_C[e] = ((W - 1.0) * h->pool_C[e] + (n - 1.0) * Cb[e] + f * dl[i] * dl[j]) / (Wn - 1.0);
+            }
+        const double g = n / Wn;
+        for (int j = 0; j < d; ++j) h->pool_mean[j] = h->pool_mean[j] + g * dl[j];
+        h->pool_W = Wn;
+    }
+    // MCMC_calculate_R: dpotf2 + 2.4/sqrt(d); on failure keep the old factor (MCMC_adapt.F90:168-171)
+    std::vector<double> cm((size_t)d * d, 0.0), Rp, Cp;
+    for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) cm[(size_t)i + (size_t)j * d] = h->pool_C[h_pidx(i, j, d)];
+    if (host_initial_R(d, cm, Rp, Cp) == 0) {
+        h->pool_R = Rp;
+        HIPCHK(hipMemcpyAsync(h->d_sharedR, h->pool_R.data(), (size_t)P * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return 0;
 }
 
 // Host-callback evaluation of one candidate vector per chain, in chain order, from the calling thread
@@ -314,6 +375,10 @@ int mcmcx_create(const mcmcx_config *cfg_in, mcmcx_handle *out)
     if (c.doadapt && c.method == MCMCX_METHOD_DRAM) {
         if (c.adaptint == 0) return fail(-7, "doadapt with adaptint = 0");
     }
+    if (c.pooled) {
+        if (c.method != MCMCX_METHOD_DRAM || c.drscale > 0.0 || c.doburnin != 0 || c.adapthist > 1 || c.greedy != 0)
+            return fail(-8, "pooled mode supports method='dram' with doburnin=0, drscale=0, adapthist<=1");
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev < 1) return fail(-10, "no HIP device: the mcmcx engine has no CPU fallback");
@@ -322,7 +387,7 @@ int mcmcx_create(const mcmcx_config *cfg_in, mcmcx_handle *out)
     mcmcx_engine *h = new mcmcx_engine();
     h->cfg = c; h->d = c.npar; h->P = c.npar * (c.npar + 1) / 2;
     h->ntiles = (c.nchains + 63) / 64; h->nlanes = h->ntiles * 64;
-    h->dodr = (c.drscale > 0.0) ? 1 : 0; h->usesvd = 0;
+    h->dodr = (c.drscale > 0.0) ? 1 : 0; h->usesvd = 0; h->pooled = c.pooled ? 1 : 0;
     e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(-100, hipGetErrorString(e)); }
     h->own_stream = true;
@@ -478,7 +543,7 @@ int mcmcx_init(mcmcx_handle h)
         if ((rc = dev_alloc(h, &E.R2, L * P, false))) return rc;
         if ((rc = dev_alloc(h, &E.iC, L * P, false))) return rc;
     }
-    const bool am = (E.method == M_DRAM) && (c.doadapt != 0 || c.doburnin != 0);
+    const bool am = (E.method == M_DRAM) && (c.doadapt != 0 || c.doburnin != 0) && !h->pooled;
     E.cmat = E.mean = E.Rtmp = nullptr; E.rowlist = nullptr;
     // history ring
     const bool need_hist = am || c.record_chain;
@@ -500,6 +565,14 @@ int mcmcx_init(mcmcx_handle h)
         if ((rc = dev_alloc(h, &E.Rtmp, L * P))) return rc;
         if ((rc = dev_alloc(h, &E.rowlist, L * (size_t)(h->wcap + 1)))) return rc;
     }
+    E.sharedR = nullptr;
+    if (h->pooled) {
+        if (h->tkind == TGT_HOST) return fail(-8, "pooled mode needs a device-resident target");
+        if ((rc = dev_alloc(h, &h->d_sharedR, (size_t)P, false))) return rc;
+        HIPCHK(hipMemcpy(h->d_sharedR, Rp.data(), (size_t)P * 8, hipMemcpyHostToDevice));
+        E.sharedR = h->d_sharedR;
+        h->pool_R = Rp; h->pool_C = Cp; h->pool_mean = h->par0; h->pool_W = (double)c.initcmatn;
+    }
     E.hev = E.hx = nullptr;
     if (h->tkind == TGT_HOST) {
         if ((rc = dev_alloc(h, &E.hev, L * NHE))) return rc;
@@ -515,7 +588,7 @@ int mcmcx_init(mcmcx_handle h)
         if ((rc = dev_upload(h, &p, rs))) return rc;
         h->d_ramscale = const_cast<double *>(p);
     }
-    if ((rc = dev_alloc(h, &h->d_moments, (size_t)T * (1 + d + P)))) return rc;
+    if ((rc = dev_alloc(h, &h->d_moments, (size_t)(T + 1) * (1 + d + P)))) return rc;
 
     // fill theta = par0, R = R(cmat0), chaincmat = cmat0, chainmean = par0, scalars
     {
@@ -602,8 +675,8 @@ int mcmcx_run(mcmcx_handle h, int32_t upto)
             h->launches += 1; h->steps += (end - it + 1);
         }
         if (mode != 0) {
-            launch_adapt(h, end, mode);
-            HIPCHK(hipGetLastError());
+            if (h->pooled) { if (mode & AD_AM) { int rc = pooled_adapt(h, end); if (rc) return rc; } }
+            else { launch_adapt(h, end, mode); HIPCHK(hipGetLastError()); }
         }
         it = end + 1;
         if (h->pending.size() > 4096) { int rc = mcmcx_sync(h); if (rc) return rc; }
@@ -803,7 +876,7 @@ int mcmcx_get_chain(mcmcx_handle h, int32_t chain, double *chain_out, double *ss
 int32_t mcmcx_pooled_moments_len(mcmcx_handle h) { return h ? 1 + h->d + h->P : -1; }
 
 static int pooled_moments_launch(mcmcx_engine *h, double *dev_dst)
-{
+{   // (declared above)
     if (!h || !h->inited) return fail(-40, "we have not inited");
     HIPCHK(hipSetDevice(h->cfg.device));
     const int len = 1 + h->d + h->P, T = h->ntiles;
@@ -819,6 +892,25 @@ int mcmcx_pooled_moments(mcmcx_handle h, double *out)
     std::vector<double> v;
     if ((rc = fetch(h, h->d_moments, (size_t)(1 + h->d + h->P), v))) return rc;
     memcpy(out, v.data(), sizeof(double) * v.size());
+    return 0;
+}
+
+int mcmcx_set_exchange(mcmcx_handle h, mcmcx_exchange_t fn, void *user, void *dev_buf)
+{
+    if (!h) return fail(-1, "null handle");
+    if (fn && !dev_buf) return fail(-1, "mcmcx_set_exchange: dev_buf is required");
+    h->xfn = fn; h->xuser = user; h->xbuf = (double *)dev_buf;
+    return 0;
+}
+
+int mcmcx_get_pooled(mcmcx_handle h, double *cmat, double *mean, double *wsum, double *R)
+{
+    if (!h || !h->inited) return fail(-40, "we have not inited");
+    if (!h->pooled) return fail(-44, "not in pooled mode");
+    if (cmat) unpack_upper(h->d, h->pool_C, cmat, true);
+    if (mean) memcpy(mean, h->pool_mean.data(), sizeof(double) * (size_t)h->d);
+    if (wsum) *wsum = h->pool_W;
+    if (R) unpack_upper(h->d, h->pool_R, R, false);
     return 0;
 }
 

@@ -58,6 +58,7 @@ struct EngineDev {
     uint64_t *wacc;             // [tile*wcap + slot]
     uint64_t *accmask;          // [(it-1)*ntiles + tile] or nullptr
     uint64_t *rowlist;          // [(tile*(wcap+1) + r)*64 + lane]  (slot | weight<<32)
+    const double *sharedR;      // pooled mode: the one packed factor all chains propose with
     // host-callback targets: per-chain evaluation results (inbounds, prior, ss) and state carried between phases
     double *hev, *hx;
 };
@@ -268,6 +269,38 @@ MCX_DEV void trmv_panels(const double *Rt, const double *z_t, double *P_t, int l
     }
 }
 
+// Same product with ONE factor shared by every chain (pooled mode): the factor is wave-uniform, so its
+// elements come through the scalar cache (s_load) and the only vector traffic is the chain's own z and P.
+MCX_DEV void trmv_shared(const double *__restrict__ Rs, const double *z_t, double *P_t, int lane, int d)
+{
+    for (int J0 = 0; J0 < d; J0 += PW) {
+        const int nw = (d - J0) < PW ? (d - J0) : PW;
+        double P[PW];
+#pragma unroll
+        for (int u = 0; u < PW; ++u) P[u] = 0.0;
+#pragma unroll 2
+        for (int i = 0; i < J0; ++i) {
+            const double zi = GV(z_t, i);
+            const double *__restrict__ seg = Rs + (size_t)(rowstart(i, d) + J0 - i);
+#pragma unroll
+            for (int u = 0; u < PW; ++u) P[u] = dfma(seg[u < nw ? u : nw - 1], zi, P[u]);
+        }
+        for (int i = J0; i < J0 + nw; ++i) {
+            const double zi = GV(z_t, i);
+            const double *__restrict__ seg = Rs + (size_t)rowstart(i, d);
+            const int ui = i - J0, m = d - 1 - i;
+#pragma unroll
+            for (int u = 0; u < PW; ++u) {
+                int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k;
+                double nv = dfma(seg[k], zi, P[u]);
+                P[u] = (u >= ui) ? nv : P[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PW; ++u) if (u < nw) GV(P_t, J0 + u) = P[u];
+    }
+}
+
 // ---------------------------------------------------------------- RAM rank-1 adaptation (MCMC_run_ram.F90:104-179)
 // a >= 0: cholupdate = DCHUD (dchud.f:122-139); a < 0: choldowndate = DCHDD (dchdd.f:141-179), restated
 // left-looking by column panels: the PW columns' work values sit in registers, the rotations of the
@@ -474,7 +507,7 @@ MCX_DEV double quadform_sym(const double *St, int lane, int d, const double *X, 
 // Iterations it0..it1 (absolute simuind) of MCMC_run (MCMC_run.F90:41-107) or MCMC_run_ram
 // (MCMC_run_ram.F90:45-81) for one tile of 64 chains.  LDS is used only by the delayed-rejection
 // quadratic forms (2*d*64 doubles when dodr, none otherwise).
-template <bool RAM, bool DR>
+template <bool RAM, bool DR, bool POOLED>
 __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ ramscale)
 {
     extern __shared__ double X[];
@@ -506,7 +539,8 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
         double *zc_t = zs_t + (size_t)(it & 1) * d * 64;          // z of this iteration
         double *zn_t = zs_t + (size_t)((it + 1) & 1) * d * 64;    // z of the next one
         // ---- newpar = MCMC_propose(oldpar, R)
-        if (__any(!have_p)) trmv_panels(Rt, zc_t, cand_t, lane, d, !have_p);
+        if (POOLED) trmv_shared(E.sharedR, zc_t, cand_t, lane, d);
+        else if (__any(!have_p)) trmv_panels(Rt, zc_t, cand_t, lane, d, !have_p);
 #pragma unroll 4
         for (int k = 0; k < d; ++k) GV(cand_t, k) = GV(theta_t, k) + GV(cand_t, k);
         // ---- bounds, prior, ss, alpha, reject

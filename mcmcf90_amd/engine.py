@@ -198,6 +198,18 @@ class Engine:
         """Pooled moments straight into device memory (e.g. a torch tensor's data_ptr()); async on the engine stream."""
         self._chk(self.L.mcmcx_pooled_moments_dev(self.h, C.c_void_p(int(dev_ptr))))
 
+    def set_exchange(self, fn, dev_ptr):
+        """Pooled mode over several GPUs: fn() must all-reduce (sum) the device buffer at dev_ptr in place."""
+        self._xkeep = _lib.EXCHANGE_T(lambda user: fn())
+        self._chk(self.L.mcmcx_set_exchange(self.h, self._xkeep, None, C.c_void_p(int(dev_ptr))))
+
+    def pooled(self):
+        n = self.npar
+        cm = np.zeros((n, n), order="F"); R = np.zeros((n, n), order="F"); m = np.zeros(n); w = C.c_double()
+        dp = C.POINTER(C.c_double)
+        self._chk(self.L.mcmcx_get_pooled(self.h, cm.ctypes.data_as(dp), _dp(m), C.byref(w), R.ctypes.data_as(dp)))
+        return np.array(cm), m, w.value, np.array(R)
+
     def kernel_time(self, reset=False):
         ms, nl, ns = C.c_double(), C.c_int64(), C.c_int64()
         self._chk(self.L.mcmcx_kernel_time(self.h, C.byref(ms), C.byref(nl), C.byref(ns), int(reset)))

@@ -58,10 +58,11 @@ module mcmcmod
   !! engine extension group &mcmcx (same file)
   character(len=16), save :: devtarget = 'host'       ! 'host' = the user's link-time ssfunction/priorfun/checkbounds
   integer, save :: nchains = 1, seed = 1835232611     ! 0x6D636D63
+  integer, save :: pooled = 0                          ! 1: one shared proposal factor from the pooled covariance
   real(kind=dbl), save :: banana_b = 0.1_dbl
   character(len=256), save :: mufile = 'mcmctest_mu.dat', lamfile = 'mcmctest_lam.dat'
   character(len=256), save :: datafile = 'data.dat', lowerfile = '', upperfile = ''
-  namelist /mcmcx/ devtarget, nchains, seed, banana_b, mufile, lamfile, datafile, lowerfile, upperfile
+  namelist /mcmcx/ devtarget, nchains, seed, pooled, banana_b, mufile, lamfile, datafile, lowerfile, upperfile
 
   !! public state, mcmc.F90:28-52
   integer, save :: npar = 0, nycol = 1, simuind = 0, chainind = 0, MCMC_running = 0
@@ -94,7 +95,7 @@ module mcmcmod
      integer(c_int32_t) :: doadapt, doburnin, adaptint, adapthist, badaptint, adaptend, initcmatn
      integer(c_int32_t) :: burnintime, greedy, updatesigma
      real(c_double) :: scalelimit, scalefactor, drscale, N0, S02, condmax, alphatarget, nuparam
-     integer(c_int32_t) :: seed, chain_id0, record_accept, record_chain, device, reserved
+     integer(c_int32_t) :: seed, chain_id0, record_accept, record_chain, device, pooled
   end type mcmcx_config
 
   interface
@@ -615,7 +616,7 @@ contains
     cfg%burnintime = burnintime; cfg%greedy = greedy; cfg%updatesigma = updatesigma
     cfg%scalelimit = scalelimit; cfg%scalefactor = scalefactor; cfg%drscale = drscale
     cfg%N0 = N0; cfg%S02 = S02; cfg%condmax = condmax; cfg%alphatarget = alphatarget; cfg%nuparam = nuparam
-    cfg%seed = seed; cfg%chain_id0 = 0; cfg%record_accept = 0; cfg%record_chain = 1; cfg%device = 0
+    cfg%seed = seed; cfg%chain_id0 = 0; cfg%record_accept = 0; cfg%record_chain = 1; cfg%device = 0; cfg%pooled = pooled
     call chk(mcmcx_create(cfg, handle))
     call chk(mcmcx_set_par0(handle, par0, int(npar, c_int32_t)))
     call chk(mcmcx_set_cmat0(handle, cmat0, int(npar, c_int32_t)))

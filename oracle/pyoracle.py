@@ -190,3 +190,41 @@ def run_chain(cfg, prob, seed=0x6D636D63, chain_id=0, upto=None):
         return r
     finally:
         L.mcxo_chain_free(ch)
+
+
+class LiveChain:
+    """An oracle chain kept alive between segments, whose proposal factor can be replaced from outside
+    (used to restate the engine's pooled mode, where adaptation happens across chains)."""
+
+    def __init__(self, cfg, prob, seed=0x6D636D63, chain_id=0):
+        L = lib()
+        self.cfg, self.prob, self.n = cfg, prob, prob.npar
+        self._tgt = prob.ctarget()
+        cm = np.asfortranarray(prob.cmat0)
+        self.ch = L.mcxo_chain_create(C.byref(cfg), C.byref(self._tgt), _dp(prob.par0), cm.ctypes.data_as(_DP),
+                                      prob.sigma2, prob.nobs, seed, chain_id)
+        if not self.ch:
+            raise RuntimeError("could not factor the initial covariance")
+
+    def run(self, upto):
+        rc = lib().mcxo_chain_run(self.ch, upto)
+        assert rc == 0, rc
+
+    def set_R(self, R):
+        """R[i, j] upper triangular -> the chain's column-major factor."""
+        view = np.ctypeslib.as_array(self.ch.contents.R, shape=(self.n, self.n))      # view[j, i] = R(i, j)
+        view[:, :] = np.asarray(R, dtype=np.float64).T
+
+    @property
+    def theta(self):
+        return np.ctypeslib.as_array(self.ch.contents.oldpar, shape=(self.n,)).copy()
+
+    @property
+    def accepted(self):
+        c = self.ch.contents
+        return np.ctypeslib.as_array(c.accepted, shape=(self.cfg.nsimu,))[:c.simuind].copy()
+
+    def close(self):
+        if self.ch:
+            lib().mcxo_chain_free(self.ch)
+            self.ch = None

@@ -9,6 +9,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch bundles its own HIP runtime under the same soname as /opt/rocm's: whichever is loaded first serves the
+    # whole process.  Let torch initialise first (as bench.py does) so tests may use torch.cuda next to libmcmcx.so.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

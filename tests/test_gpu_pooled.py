@@ -1,0 +1,165 @@
+"""Pooled mode (the multi-chain extension named in BASELINE.json's north_star): all chains propose with ONE
+factor, adapted every adaptint iterations from the pooled empirical covariance of the current states.  The
+oracle side restates it with the single-chain C oracle (adaptation off, factor replaced from outside) plus the
+moment tree / merge / Cholesky written out in Python floats in the engine's operation order: the states,
+accept masks and the shared factor must agree bit for bit.  A second test splits the chains over two engines
+that exchange their moment vectors through the exchange hook (the RCCL all-reduce of the multi-GPU run)."""
+import ctypes as C
+import math
+import threading
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def _tree(v):
+    """Pairwise tree, adjacent partners first (the xor-butterfly inside a tile, then the tile tree)."""
+    v = list(v)
+    while len(v) > 1:
+        v = [v[i] + v[i + 1] if i + 1 < len(v) else v[i] for i in range(0, len(v), 2)]
+    return v[0]
+
+
+def _pooled_moments(theta, par0, nchains):
+    n, d = theta.shape
+    T = (nchains + 63) // 64
+    x = np.zeros((T * 64, d))
+    x[:n] = theta - par0
+    act = np.zeros(T * 64); act[:n] = 1.0
+    cnt = _tree([_tree(act[t * 64:(t + 1) * 64]) for t in range(T)])
+    s1 = [_tree([_tree(x[t * 64:(t + 1) * 64, j]) for t in range(T)]) for j in range(d)]
+    s2 = {}
+    for j in range(d):
+        for i in range(j + 1):
+            p = x[:, i] * x[:, j]
+            s2[(i, j)] = _tree([_tree(p[t * 64:(t + 1) * 64]) for t in range(T)])
+    return cnt, s1, s2
+
+
+def _merge_and_factor(oracle, state, cnt, s1, s2, par0, d, first, cmat0, initcmatn):
+    """pooled_adapt of mcx_api.hip in Python floats."""
+    if first:
+        state["W"] = float(initcmatn); state["C"] = {(i, j): float(cmat0[i, j]) for j in range(d) for i in range(j + 1)}
+        state["mean"] = [float(v) for v in par0]
+    n = cnt
+    m1 = [s1[j] / n for j in range(d)]
+    mb = [float(par0[j]) + m1[j] for j in range(d)]
+    Cb = {(i, j): (s2[(i, j)] - n * m1[i] * m1[j]) / (n - 1.0) for j in range(d) for i in range(j + 1)}
+    if not state["W"] > 0.0:
+        state["C"], state["mean"], state["W"] = Cb, mb, n
+    else:
+        W = state["W"]; Wn = W + n
+        dl = [mb[j] - state["mean"][j] for j in range(d)]
+        f = W * n / Wn
+        state["C"] = {(i, j): ((W - 1.0) * state["C"][(i, j)] + (n - 1.0) * Cb[(i, j)] + f * dl[i] * dl[j]) / (Wn - 1.0)
+                      for j in range(d) for i in range(j + 1)}
+        g = n / Wn
+        state["mean"] = [state["mean"][j] + g * dl[j] for j in range(d)]
+        state["W"] = Wn
+    A = np.zeros((d, d), order="F")
+    for (i, j), v in state["C"].items():
+        A[i, j] = v; A[j, i] = v
+    info = oracle.lib().mcxo_potrf_u(d, A.ctypes.data_as(C.POINTER(C.c_double)))
+    if info == 0:
+        sq = math.sqrt(float(d))
+        state["R"] = np.array([[A[i, j] * 2.4 / sq if i <= j else 0.0 for j in range(d)] for i in range(d)])
+    return state
+
+
+def _setup(oracle, d, nsimu):
+    ckw = dict(nsimu=nsimu, adaptint=100, updatesigma=0)
+    S = 0.6 ** np.abs(np.subtract.outer(np.arange(d), np.arange(d)))
+    pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.5), cmat0=0.02 * np.eye(d), mu=np.linspace(-1, 1, d),
+               lam=np.linalg.inv(S))
+    return ckw, pkw
+
+
+def test_pooled_mode_matches_restatement(oracle):
+    from mcmcf90_amd import engine_from_problem
+    d, N, nsimu = 6, 150, 330
+    ckw, pkw = _setup(oracle, d, nsimu)
+    e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
+    e.init(); e.run()
+    # ---- restatement
+    cfg = oracle.make_cfg(**dict(ckw, doadapt=0))
+    prob = oracle.Problem(**pkw)
+    chains = [oracle.LiveChain(cfg, prob, chain_id=c) for c in range(N)]
+    state = {}
+    par0, cmat0 = np.asarray(pkw["par0"], float), np.asarray(pkw["cmat0"], float)
+    for tick in (100, 200, 300, nsimu):
+        for ch in chains:
+            ch.run(tick)
+        if tick % 100 == 0 and tick < nsimu:
+            theta = np.array([ch.theta for ch in chains])
+            cnt, s1, s2 = _pooled_moments(theta, par0, N)
+            state = _merge_and_factor(oracle, state, cnt, s1, s2, par0, d, tick == 100, cmat0, 0)
+            for ch in chains:
+                ch.set_R(state["R"])
+    theta = np.array([ch.theta for ch in chains])
+    np.testing.assert_array_equal(_bits(e.theta()), _bits(theta))
+    for c in (0, 63, 64, 149):
+        np.testing.assert_array_equal(e.accepted(c), chains[c].accepted)
+    cm, mean, W, R = e.pooled()
+    assert W == state["W"] == 3 * N
+    np.testing.assert_array_equal(_bits(np.triu(R)), _bits(np.triu(state["R"])))
+    np.testing.assert_array_equal(_bits(mean), _bits(np.array(state["mean"])))
+    for ch in chains:
+        ch.close()
+    e.close()
+
+
+def test_pooled_mode_two_shards_with_exchange_hook(oracle):
+    """256 chains on one engine == 2 x 128 chains on two engines whose moment vectors are summed by the exchange
+    hook (what the RCCL all-reduce does on a multi-GPU node): identical states and identical shared factor."""
+    import torch
+    from mcmcf90_amd import engine_from_problem
+    d, nsimu = 6, 260
+    ckw, pkw = _setup(oracle, d, nsimu)
+    one = engine_from_problem(ckw, pkw, nchains=256, pooled=1)
+    one.init(); one.run()
+    ref_theta = one.theta(); _, _, _, ref_R = one.pooled()
+    one.close()
+
+    mlen = 1 + d + d * (d + 1) // 2
+    bufs = [torch.zeros(mlen, dtype=torch.float64, device="cuda") for _ in range(2)]
+    engs = [engine_from_problem(ckw, pkw, nchains=128, chain_id0=128 * r, pooled=1) for r in range(2)]
+    barrier = threading.Barrier(2)
+
+    def make_hook(r):
+        def hook():                      # the all-reduce: both ranks meet, rank 0 leaves the sum in both buffers
+            torch.cuda.synchronize()
+            barrier.wait()
+            if r == 0:
+                tot = bufs[0] + bufs[1]
+                bufs[0].copy_(tot); bufs[1].copy_(tot)
+                torch.cuda.synchronize()
+            barrier.wait()
+        return hook
+
+    errs = []
+
+    def rank(r):
+        try:
+            engs[r].set_exchange(make_hook(r), bufs[r].data_ptr())
+            engs[r].init()
+            engs[r].run()                # ctypes drops the GIL inside mcmcx_run; the hook re-enters Python
+        except Exception as ex:          # noqa: BLE001
+            errs.append(ex)
+            barrier.abort()
+
+    ts = [threading.Thread(target=rank, args=(r,)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not errs, errs
+    th = np.vstack([e.theta() for e in engs])
+    np.testing.assert_array_equal(_bits(th), _bits(ref_theta))
+    for e in engs:
+        np.testing.assert_array_equal(_bits(np.triu(e.pooled()[3])), _bits(np.triu(ref_R)))
+        e.close()
