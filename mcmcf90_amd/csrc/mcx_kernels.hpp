@@ -128,7 +128,8 @@ MCX_DEV void sweep(const double *rowp, int lane, int k0, int n, F &&f)
 // through scalar loads of its transpose (lamT[j*d + i] = lam(i,j), padded by PW doubles).
 constexpr int PW = 8;     // panel width: columns (or rows) of per-lane state held in registers
 
-MCX_DEV double target_ss(const DevTarget &t, int d, int lane, const double *c_t)
+MCX_DEV double target_ss(const DevTarget &t, int d, int lane, const double *c_t,
+                         const double *__restrict__ g_mu, const double *__restrict__ g_lamT)
 {
     double ss = 0.0;
     if (t.kind == TGT_GAUSS) {
@@ -142,11 +143,11 @@ MCX_DEV double target_ss(const DevTarget &t, int d, int lane, const double *c_t)
                 const int nc = (d - J0) < PW ? (d - J0) : PW;
                 double v[PW];
 #pragma unroll
-                for (int w = 0; w < PW; ++w) { int j = J0 + (w < nc ? w : nc - 1); v[w] = GV(c_t, j) - t.mu[j]; }
+                for (int w = 0; w < PW; ++w) { int j = J0 + (w < nc ? w : nc - 1); v[w] = GV(c_t, j) - g_mu[j]; }
 #pragma unroll
                 for (int w = 0; w < PW; ++w) {
                     if (w < nc) {
-                        const double *__restrict__ lrow = t.lamT + (size_t)(J0 + w) * d + I0;
+                        const double *__restrict__ lrow = g_lamT + (size_t)(J0 + w) * d + I0;
                         if (J0 == 0 && w == 0) {
 #pragma unroll
                             for (int u = 0; u < PW; ++u) y[u] = lrow[u] * v[0];
@@ -159,7 +160,7 @@ MCX_DEV double target_ss(const DevTarget &t, int d, int lane, const double *c_t)
             }
             double vi[PW];
 #pragma unroll
-            for (int u = 0; u < PW; ++u) { int i = I0 + (u < nr ? u : nr - 1); vi[u] = GV(c_t, i) - t.mu[i]; }
+            for (int u = 0; u < PW; ++u) { int i = I0 + (u < nr ? u : nr - 1); vi[u] = GV(c_t, i) - g_mu[i]; }
 #pragma unroll
             for (int u = 0; u < PW; ++u) {
                 if (u < nr) { if (I0 == 0 && u == 0) ss = y[0] * vi[0]; else ss = dfma(y[u], vi[u], ss); }
@@ -508,7 +509,9 @@ MCX_DEV double quadform_sym(const double *St, int lane, int d, const double *X, 
 // (MCMC_run_ram.F90:45-81) for one tile of 64 chains.  LDS is used only by the delayed-rejection
 // quadratic forms (2*d*64 doubles when dodr, none otherwise).
 template <bool RAM, bool DR, bool POOLED>
-__global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ ramscale)
+__global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
+                                                     const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
+                                                     const double *__restrict__ g_sharedR)
 {
     extern __shared__ double X[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
@@ -539,14 +542,14 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
         double *zc_t = zs_t + (size_t)(it & 1) * d * 64;          // z of this iteration
         double *zn_t = zs_t + (size_t)((it + 1) & 1) * d * 64;    // z of the next one
         // ---- newpar = MCMC_propose(oldpar, R)
-        if (POOLED) trmv_shared(E.sharedR, zc_t, cand_t, lane, d);
+        if (POOLED) trmv_shared(g_sharedR, zc_t, cand_t, lane, d);
         else if (__any(!have_p)) trmv_panels(Rt, zc_t, cand_t, lane, d, !have_p);
 #pragma unroll 4
         for (int k = 0; k < d; ++k) GV(cand_t, k) = GV(theta_t, k) + GV(cand_t, k);
         // ---- bounds, prior, ss, alpha, reject
         bool inb = target_inbounds(E.tgt, d, lane, cand_t);
         double pri2 = target_prior(E.tgt, d, lane, cand_t);
-        double ss2 = target_ss(E.tgt, d, lane, cand_t);
+        double ss2 = target_ss(E.tgt, d, lane, cand_t, g_mu, g_lamT);
         bool reject;
         if (!inb) {
             if (!DR) bnd += 1;                            // MCMC_run.F90:49
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
                 if (!inb2) bnd += 1;
                 else {
                     double pri3 = target_prior(E.tgt, d, lane, c2_t);
-                    double ss3 = target_ss(E.tgt, d, lane, c2_t);
+                    double ss3 = target_ss(E.tgt, d, lane, c2_t, g_mu, g_lamT);
                     // MCMC_DR_alpha13, MCMC_DRAM.F90:162-186
                     double alpha32;
                     if (alpha12 == 0.0) alpha32 = 0.0;
@@ -796,7 +799,7 @@ __global__ __launch_bounds__(64) void init_kernel(EngineDev E)
     double *theta_t = E.theta + (size_t)tile * d * 64;
     double pri1, ss1;
     if (E.tgt.kind == TGT_HOST) { const double *hev = E.hev + (size_t)tile * NHE * 64; pri1 = GV(hev, HE_PRI); ss1 = GV(hev, HE_SS); }
-    else { pri1 = target_prior(E.tgt, d, lane, theta_t); ss1 = target_ss(E.tgt, d, lane, theta_t); }
+    else { pri1 = target_prior(E.tgt, d, lane, theta_t); ss1 = target_ss(E.tgt, d, lane, theta_t, E.tgt.mu, E.tgt.lamT); }
     TIDX(E.scal, tile, NSCAL, S_SS1, lane) = ss1; TIDX(E.scal, tile, NSCAL, S_PRI1, lane) = pri1;
     // row 1 of the chain: iteration 1 counts as accepted
     const int slot = 1 % E.wcap;
