@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--method", default="ram", choices=["ram", "dram"])
     ap.add_argument("--pooled", action="store_true", help="pooled AM: one shared factor from the all-reduced pooled covariance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--one-gpu-dryrun", action="store_true",
+                    help="debug: all ranks share GPU 0 and reduce over gloo (checks the N>1 control path on a 1-GPU box)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -97,11 +99,24 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    if a.one_gpu_dryrun:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.one_gpu_dryrun:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def all_reduce_dev(t, op=None):
+        """Sum a device tensor over ranks: RCCL in place, or (dry run) through a host copy over gloo."""
+        kw = {} if op is None else {"op": op}
+        if a.one_gpu_dryrun:
+            h = t.cpu(); dist.all_reduce(h, **kw); t.copy_(h)
+        else:
+            dist.all_reduce(t, **kw)
 
     from mcmcf90_amd import engine_from_problem
     d, n_local, ips = a.npar, a.chains_per_gpu, a.its_per_step
@@ -119,7 +134,7 @@ def main():
     xbuf = torch.zeros(mom_len, dtype=torch.float64, device=dev)
     if a.pooled and world > 1:
         def _xchg():                                   # called by the engine at every adaptation tick
-            dist.all_reduce(xbuf)
+            all_reduce_dev(xbuf)
             torch.cuda.synchronize()
         eng.set_exchange(_xchg, xbuf.data_ptr())
     eng.init()
@@ -129,7 +144,7 @@ def main():
         eng.pooled_moments_dev(pooled.data_ptr())      # fixed-tree sum over this GPU's chains, stays in HBM
         if world > 1:
             eng.sync()                                 # engine stream -> torch stream hand-off
-            dist.all_reduce(pooled)                    # RCCL over xGMI: 1+d+d(d+1)/2 doubles
+            all_reduce_dev(pooled)                     # RCCL over xGMI: 1+d+d(d+1)/2 doubles
 
     def fence():
         eng.sync()
@@ -150,7 +165,7 @@ def main():
     kms, klaunch, ksteps = eng.kernel_time()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce_dev(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     if rank == 0:

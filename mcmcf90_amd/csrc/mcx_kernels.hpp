@@ -128,12 +128,63 @@ MCX_DEV void sweep(const double *rowp, int lane, int k0, int n, F &&f)
 // through scalar loads of its transpose (lamT[j*d + i] = lam(i,j), padded by PW doubles).
 constexpr int PW = 8;     // panel width: columns (or rows) of per-lane state held in registers
 
+// WIDE: keep every row accumulator in registers and read the candidate once (pays when the kernel is
+// bandwidth-bound: RAM); otherwise one row panel at a time (fewer registers: pooled / AM / DR kernels).
+template <bool WIDE>
 MCX_DEV double target_ss(const DevTarget &t, int d, int lane, const double *c_t,
                          const double *__restrict__ g_mu, const double *__restrict__ g_lamT)
 {
     double ss = 0.0;
-    if (t.kind == TGT_GAUSS) {
-        // ss = (th-mu)' Lam (th-mu): y_i = sum_j lam(i,j) v_j ascending (fma chain), ss = sum_i y_i v_i (fma chain)
+    if (WIDE && t.kind == TGT_GAUSS && d <= 8 * PW) {
+        // ss = (th-mu)' Lam (th-mu): y_i = sum_j lam(i,j) v_j ascending (fma chain), ss = sum_i y_i v_i (fma chain).
+        // All row accumulators (up to 8 panels of PW) stay in registers while the columns stream by once, so
+        // the candidate is read once instead of once per row panel.
+        constexpr int NPM = 8;
+        double y[NPM][PW];
+#pragma unroll
+        for (int p = 0; p < NPM; ++p)
+#pragma unroll
+            for (int u = 0; u < PW; ++u) y[p][u] = 0.0;
+        const int np = (d + PW - 1) / PW;
+        for (int J0 = 0; J0 < d; J0 += PW) {
+            const int nc = (d - J0) < PW ? (d - J0) : PW;
+            double v[PW];
+#pragma unroll
+            for (int w = 0; w < PW; ++w) { int j = J0 + (w < nc ? w : nc - 1); v[w] = GV(c_t, j) - g_mu[j]; }
+#pragma unroll
+            for (int w = 0; w < PW; ++w) {
+                if (w < nc) {
+                    const double *__restrict__ lcol = g_lamT + (size_t)(J0 + w) * d;     // lam(0..d-1, J0+w)
+#pragma unroll
+                    for (int p = 0; p < NPM; ++p) {
+                        if (p < np) {
+                            if (J0 == 0 && w == 0) {
+#pragma unroll
+                                for (int u = 0; u < PW; ++u) y[p][u] = lcol[p * PW + u] * v[0];
+                            } else {
+#pragma unroll
+                                for (int u = 0; u < PW; ++u) y[p][u] = dfma(lcol[p * PW + u], v[w], y[p][u]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NPM; ++p) {
+            if (p < np) {
+                const int I0 = p * PW;
+                const int nr = (d - I0) < PW ? (d - I0) : PW;
+                double vi[PW];
+#pragma unroll
+                for (int u = 0; u < PW; ++u) { int i = I0 + (u < nr ? u : nr - 1); vi[u] = GV(c_t, i) - g_mu[i]; }
+#pragma unroll
+                for (int u = 0; u < PW; ++u) {
+                    if (u < nr) { if (p == 0 && u == 0) ss = y[0][0] * vi[0]; else ss = dfma(y[p][u], vi[u], ss); }
+                }
+            }
+        }
+    } else if (t.kind == TGT_GAUSS) {
         for (int I0 = 0; I0 < d; I0 += PW) {
             const int nr = (d - I0) < PW ? (d - I0) : PW;
             double y[PW];
@@ -549,7 +600,7 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
         // ---- bounds, prior, ss, alpha, reject
         bool inb = target_inbounds(E.tgt, d, lane, cand_t);
         double pri2 = target_prior(E.tgt, d, lane, cand_t);
-        double ss2 = target_ss(E.tgt, d, lane, cand_t, g_mu, g_lamT);
+        double ss2 = target_ss<RAM>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
         bool reject;
         if (!inb) {
             if (!DR) bnd += 1;                            // MCMC_run.F90:49
@@ -576,7 +627,7 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
                 if (!inb2) bnd += 1;
                 else {
                     double pri3 = target_prior(E.tgt, d, lane, c2_t);
-                    double ss3 = target_ss(E.tgt, d, lane, c2_t, g_mu, g_lamT);
+                    double ss3 = target_ss<false>(E.tgt, d, lane, c2_t, g_mu, g_lamT);
                     // MCMC_DR_alpha13, MCMC_DRAM.F90:162-186
                     double alpha32;
                     if (alpha12 == 0.0) alpha32 = 0.0;
@@ -799,7 +850,7 @@ __global__ __launch_bounds__(64) void init_kernel(EngineDev E)
     double *theta_t = E.theta + (size_t)tile * d * 64;
     double pri1, ss1;
     if (E.tgt.kind == TGT_HOST) { const double *hev = E.hev + (size_t)tile * NHE * 64; pri1 = GV(hev, HE_PRI); ss1 = GV(hev, HE_SS); }
-    else { pri1 = target_prior(E.tgt, d, lane, theta_t); ss1 = target_ss(E.tgt, d, lane, theta_t, E.tgt.mu, E.tgt.lamT); }
+    else { pri1 = target_prior(E.tgt, d, lane, theta_t); ss1 = target_ss<false>(E.tgt, d, lane, theta_t, E.tgt.mu, E.tgt.lamT); }
     TIDX(E.scal, tile, NSCAL, S_SS1, lane) = ss1; TIDX(E.scal, tile, NSCAL, S_PRI1, lane) = pri1;
     // row 1 of the chain: iteration 1 counts as accepted
     const int slot = 1 % E.wcap;
