@@ -265,29 +265,33 @@ MCX_DEV bool target_inbounds(const DevTarget &t, int d, int lane, const double *
 // Each lane appends accepted polar pairs to its own column of zs (global scratch, element stride 64)
 // until it has d deviates; the wave loops until every participating lane is done.  The cached
 // second deviate of normal_bm is honoured and left behind when d is odd.
-MCX_DEV void gen_normals(Rng &g, double *zs_t, int lane, int d, bool participate)
+// Returns sum(z**2) accumulated in element order (the `sum(u**2)` of MCMC_run_ram.F90:166), so the RAM
+// update does not have to read the vector again.
+MCX_DEV double gen_normals(Rng &g, double *zs_t, int lane, int d, bool participate)
 {
     int k = 0;
-    if (participate && g.saved && d > 0) { GV(zs_t, 0) = g.saved_y; g.saved = 0; k = 1; }
+    double su = 0.0;
+    if (participate && g.saved && d > 0) { GV(zs_t, 0) = g.saved_y; su = su + g.saved_y * g.saved_y; g.saved = 0; k = 1; }
     bool need = participate && (k < d);
     while (__any(need)) {
         if (need) {
             double a, b;
             if (polar_try(g, a, b)) {
-                GV(zs_t, k) = a; ++k;
-                if (k < d) { GV(zs_t, k) = b; ++k; }
+                GV(zs_t, k) = a; su = su + a * a; ++k;
+                if (k < d) { GV(zs_t, k) = b; su = su + b * b; ++k; }
                 else { g.saved_y = b; g.saved = 1; }
             }
             need = (k < d);
         }
     }
+    return su;
 }
 
 // ---------------------------------------------------------------- proposal: P = R'z  (MCMC_DRAM.F90:20-31)
 // dtrmv('U','T','N') (matutils.F90:108-109): p_j = sum_{i<=j} R(i,j) z_i, each dot product ascending in i
 // as one fma chain from 0.  Column panels of PW accumulators in registers; every row contributes one
 // contiguous PW x 512-byte segment, so the factor is read exactly once.
-MCX_DEV void trmv_panels(const double *Rt, const double *z_t, double *P_t, int lane, int d, bool act)
+MCX_DEV void trmv_panels(const double *Rt, const double *z_t, double *P_t, const double *theta_t, int lane, int d, bool act)
 {
     for (int J0 = 0; J0 < d; J0 += PW) {
         const int nw = (d - J0) < PW ? (d - J0) : PW;
@@ -316,14 +320,14 @@ MCX_DEV void trmv_panels(const double *Rt, const double *z_t, double *P_t, int l
                 for (int u = 0; u < PW; ++u) { double nv = dfma(r[u], zi, P[u]); P[u] = (u >= ui) ? nv : P[u]; }
             }
 #pragma unroll
-            for (int u = 0; u < PW; ++u) if (u < nw) GV(P_t, J0 + u) = P[u];
+            for (int u = 0; u < PW; ++u) if (u < nw) GV(P_t, J0 + u) = GV(theta_t, J0 + u) + P[u];   // newpar = oldpar + R'z
         }
     }
 }
 
 // Same product with ONE factor shared by every chain (pooled mode): the factor is wave-uniform, so its
 // elements come through the scalar cache (s_load) and the only vector traffic is the chain's own z and P.
-MCX_DEV void trmv_shared(const double *__restrict__ Rs, const double *z_t, double *P_t, int lane, int d)
+MCX_DEV void trmv_shared(const double *__restrict__ Rs, const double *z_t, double *P_t, const double *theta_t, int lane, int d)
 {
     for (int J0 = 0; J0 < d; J0 += PW) {
         const int nw = (d - J0) < PW ? (d - J0) : PW;
@@ -349,7 +353,7 @@ MCX_DEV void trmv_shared(const double *__restrict__ Rs, const double *z_t, doubl
             }
         }
 #pragma unroll
-        for (int u = 0; u < PW; ++u) if (u < nw) GV(P_t, J0 + u) = P[u];
+        for (int u = 0; u < PW; ++u) if (u < nw) GV(P_t, J0 + u) = GV(theta_t, J0 + u) + P[u];
     }
 }
 
@@ -362,11 +366,8 @@ MCX_DEV void trmv_shared(const double *__restrict__ Rs, const double *z_t, doubl
 // rows = the pinned dtrmv order) into P_t, so update lanes read and write the factor once per
 // iteration.  Returns true for lanes whose P_t is valid.
 MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, double *cs_t, double *P_t,
-                        int lane, int d, double a, bool act, bool fuse, uint32_t &status)
+                        const double *theta_t, int lane, int d, double a, double su, bool act, bool fuse, uint32_t &status)
 {
-    double su = 0.0;
-#pragma unroll 4
-    for (int k = 0; k < d; ++k) { double zk = GV(zc_t, k); su = su + zk * zk; }
     const bool up = act && (a >= 0.0);
     const bool down = act && !(a >= 0.0);
     if (__any(up)) {
@@ -418,9 +419,9 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                         P[u] = (u >= ui && u < nw) ? np : P[u];
                     }
                 }
-                if (fuse) {
+                if (fuse) {                              // next candidate = theta + R_new' z_next (MCMC_DRAM.F90:29)
 #pragma unroll
-                    for (int u = 0; u < PW; ++u) if (u < nw) GV(P_t, J0 + u) = P[u];
+                    for (int u = 0; u < PW; ++u) if (u < nw) GV(P_t, J0 + u) = GV(theta_t, J0 + u) + P[u];
                 }
             }
         }
@@ -586,17 +587,15 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
     uint32_t status = TIDX(E.ictr, tile, NICTR, I_STATUS, lane);
     uint32_t dracc = TIDX(E.ictr, tile, NICTR, I_DRACC, lane), drtries = TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane);
 
-    bool have_p = false;                          // lanes whose proposal vector is already in cand_t
-    gen_normals(g, zs_t + (size_t)(it0 & 1) * d * 64, lane, d, true);
+    bool have_p = false;                          // lanes whose candidate is already in cand_t
+    double su_c = gen_normals(g, zs_t + (size_t)(it0 & 1) * d * 64, lane, d, true), su_n = 0.0;
 
     for (int it = it0; it <= it1; ++it) {
         double *zc_t = zs_t + (size_t)(it & 1) * d * 64;          // z of this iteration
         double *zn_t = zs_t + (size_t)((it + 1) & 1) * d * 64;    // z of the next one
         // ---- newpar = MCMC_propose(oldpar, R)
-        if (POOLED) trmv_shared(g_sharedR, zc_t, cand_t, lane, d);
-        else if (__any(!have_p)) trmv_panels(Rt, zc_t, cand_t, lane, d, !have_p);
-#pragma unroll 4
-        for (int k = 0; k < d; ++k) GV(cand_t, k) = GV(theta_t, k) + GV(cand_t, k);
+        if (POOLED) trmv_shared(g_sharedR, zc_t, cand_t, theta_t, lane, d);
+        else if (__any(!have_p)) trmv_panels(Rt, zc_t, cand_t, theta_t, lane, d, !have_p);
         // ---- bounds, prior, ss, alpha, reject
         bool inb = target_inbounds(E.tgt, d, lane, cand_t);
         double pri2 = target_prior(E.tgt, d, lane, cand_t);
@@ -619,10 +618,8 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
             if (m) drtries += 1;
             double *z2_t = zn_t;                          // stage-2 normals: the "next" buffer is still free
             gen_normals(g, z2_t, lane, d, m);
-            trmv_panels(E.R2 + (size_t)tile * E.P * 64, z2_t, c2_t, lane, d, m);
+            trmv_panels(E.R2 + (size_t)tile * E.P * 64, z2_t, c2_t, theta_t, lane, d, m);
             if (m) {
-#pragma unroll 4
-                for (int k = 0; k < d; ++k) GV(c2_t, k) = GV(theta_t, k) + GV(c2_t, k);
                 bool inb2 = target_inbounds(E.tgt, d, lane, c2_t);
                 if (!inb2) bnd += 1;
                 else {
@@ -675,13 +672,14 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
         if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
         // ---- the next iteration's normals: nothing else draws between here and its MCMC_propose
         const bool pre = (it < it1);
-        if (pre) gen_normals(g, zn_t, lane, d, true);
+        if (pre) su_n = gen_normals(g, zn_t, lane, d, true);
         // ---- MCMC_adapt_ram
         have_p = false;
         if (RAM && E.doadapt != 0 && !(it < E.burnintime && E.doburnin != 0)) {
             double a = ramscale[it - it0] * (alpha12 - E.alphatarget);
-            have_p = ram_update(Rt, zc_t, zn_t, cs_t, cand_t, lane, d, a, true, pre, status);
+            have_p = ram_update(Rt, zc_t, zn_t, cs_t, cand_t, theta_t, lane, d, a, su_c, true, pre, status);
         }
+        su_c = su_n;
     }
 
     TIDX(E.rngn, tile, 1, 0, lane) = g.n;
@@ -701,7 +699,7 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
 // the host evaluates the candidates of all chains in chain order, phase 1 decides (and proposes the DR
 // try), the host evaluates again, phase 2 decides the DR try and finishes the iteration.  Same device
 // functions as step_kernel; per-lane state round-trips through HBM between phases.
-enum { HX_SS2 = 0, HX_PRI2, HX_REJECT, HX_STAGE2, HX_DRMOVED, NHX };
+enum { HX_SS2 = 0, HX_PRI2, HX_REJECT, HX_STAGE2, HX_DRMOVED, HX_SU, NHX };
 enum { HE_INB = 0, HE_PRI, HE_SS, NHE };
 
 struct LaneState {
@@ -765,7 +763,8 @@ MCX_DEV void host_finish(const EngineDev &E, int tile, int lane, int it, LaneSta
     if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
     if (E.method == M_RAM && E.doadapt != 0 && !(it < E.burnintime && E.doburnin != 0)) {
         double a = ramscale[0] * (L.alpha12 - E.alphatarget);
-        ram_update(E.R + (size_t)tile * E.P * 64, zs_t, zs_t, cs_t, cand_t, lane, d, a, true, false, L.status);
+        const double *hx = E.hx + (size_t)tile * NHX * 64;
+        ram_update(E.R + (size_t)tile * E.P * 64, zs_t, zs_t, cs_t, cand_t, theta_t, lane, d, a, GV(hx, HX_SU), true, false, L.status);
     }
 }
 
@@ -784,9 +783,9 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
     LaneState L;
     lane_load(E, tile, lane, L);
     if (PHASE == 0) {                                             // newpar = MCMC_propose(oldpar, R)
-        gen_normals(L.g, zs_t, lane, d, true);
-        trmv_panels(E.R + (size_t)tile * E.P * 64, zs_t, cand_t, lane, d, true);
-        for (int k = 0; k < d; ++k) GV(cand_t, k) = GV(theta_t, k) + GV(cand_t, k);
+        double su = gen_normals(L.g, zs_t, lane, d, true);
+        GV(hx, HX_SU) = su;
+        trmv_panels(E.R + (size_t)tile * E.P * 64, zs_t, cand_t, theta_t, lane, d, true);
     } else if (PHASE == 1) {
         const bool inb = GV(hev, HE_INB) != 0.0;
         const double pri2 = GV(hev, HE_PRI), ss2 = GV(hev, HE_SS);
@@ -805,8 +804,7 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
             const bool m = reject;
             if (m) L.drtries += 1;
             gen_normals(L.g, zs_t + (size_t)d * 64, lane, d, m);
-            trmv_panels(E.R2 + (size_t)tile * E.P * 64, zs_t + (size_t)d * 64, c2_t, lane, d, m);
-            if (m) for (int k = 0; k < d; ++k) GV(c2_t, k) = GV(theta_t, k) + GV(c2_t, k);
+            trmv_panels(E.R2 + (size_t)tile * E.P * 64, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d, m);
             GV(hx, HX_SS2) = ss2; GV(hx, HX_PRI2) = pri2;
             GV(hx, HX_REJECT) = reject ? 1.0 : 0.0; GV(hx, HX_STAGE2) = m ? 1.0 : 0.0;
         } else {
