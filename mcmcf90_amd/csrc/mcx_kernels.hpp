@@ -365,8 +365,12 @@ MCX_DEV void trmv_shared(const double *__restrict__ Rs, const double *z_t, doubl
 // When `fuse` is set the update sweep also accumulates the NEXT proposal P = R_new' z_next (ascending
 // rows = the pinned dtrmv order) into P_t, so update lanes read and write the factor once per
 // iteration.  Returns true for lanes whose P_t is valid.
+// Rotations (c_i, s_i) of the first NLC rows are kept in LDS (lc), the rest in global scratch: row i's rotation is
+// re-read by every later panel, and the early rows are the ones re-read most often.
+constexpr int NLC = 19;     // 19 rows x 2 doubles x 64 lanes = 19 456 B per wave: 8 waves fill the CU's 160 KiB
 MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, double *cs_t, double *P_t,
-                        const double *theta_t, int lane, int d, double a, double su, bool act, bool fuse, uint32_t &status)
+                        const double *theta_t, int lane, int d, double a, double su, bool act, bool fuse, uint32_t &status,
+                        double *lc)
 {
     const bool up = act && (a >= 0.0);
     const bool down = act && !(a >= 0.0);
@@ -379,7 +383,9 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                 for (int u = 0; u < PW; ++u) { x[u] = GV(zc_t, J0 + (u < nw ? u : nw - 1)) / su * a; P[u] = 0.0; }   // x = u/sum(u**2)*a
 #pragma unroll 2
                 for (int i = 0; i < J0; ++i) {                           // rotations of the rows above
-                    const double c = GV(cs_t, 2 * i), sn = GV(cs_t, 2 * i + 1);
+                    const bool inl = lc && i < NLC;
+                    const double c = inl ? lc[(2 * i) * 64 + lane] : GV(cs_t, 2 * i);
+                    const double sn = inl ? lc[(2 * i + 1) * 64 + lane] : GV(cs_t, 2 * i + 1);
                     const double zi = fuse ? GV(zn_t, i) : 0.0;
                     double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
                     double r[PW];
@@ -406,7 +412,8 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                     double rr, c, sn;
                     d_rotg(GV(seg, 0), xi, rr, c, sn);
                     GV(seg, 0) = rr;
-                    GV(cs_t, 2 * i) = c; GV(cs_t, 2 * i + 1) = sn;
+                    if (lc && i < NLC) { lc[(2 * i) * 64 + lane] = c; lc[(2 * i + 1) * 64 + lane] = sn; }
+                    else { GV(cs_t, 2 * i) = c; GV(cs_t, 2 * i + 1) = sn; }
 #pragma unroll
                     for (int u = 0; u < PW; ++u) {
                         const bool off = (u > ui) && (u < nw);
@@ -677,7 +684,7 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
         have_p = false;
         if (RAM && E.doadapt != 0 && !(it < E.burnintime && E.doburnin != 0)) {
             double a = ramscale[it - it0] * (alpha12 - E.alphatarget);
-            have_p = ram_update(Rt, zc_t, zn_t, cs_t, cand_t, theta_t, lane, d, a, su_c, true, pre, status);
+            have_p = ram_update(Rt, zc_t, zn_t, cs_t, cand_t, theta_t, lane, d, a, su_c, true, pre, status, RAM ? X : nullptr);
         }
         su_c = su_n;
     }
@@ -764,7 +771,7 @@ MCX_DEV void host_finish(const EngineDev &E, int tile, int lane, int it, LaneSta
     if (E.method == M_RAM && E.doadapt != 0 && !(it < E.burnintime && E.doburnin != 0)) {
         double a = ramscale[0] * (L.alpha12 - E.alphatarget);
         const double *hx = E.hx + (size_t)tile * NHX * 64;
-        ram_update(E.R + (size_t)tile * E.P * 64, zs_t, zs_t, cs_t, cand_t, theta_t, lane, d, a, GV(hx, HX_SU), true, false, L.status);
+        ram_update(E.R + (size_t)tile * E.P * 64, zs_t, zs_t, cs_t, cand_t, theta_t, lane, d, a, GV(hx, HX_SU), true, false, L.status, nullptr);
     }
 }
 
