@@ -65,6 +65,21 @@ def cases():
     c["c4_gauss50_am"] = (dict(nsimu=2000, adaptint=100, updatesigma=0),
                           dict(kind="gauss", npar=d, par0=np.zeros(d), cmat0=0.01 * np.eye(d), mu=np.zeros(d),
                                lam=corr_gauss(d)), 11)
+    # --- edge cases
+    c["e1_expdata_ram_bounds_s2"] = (dict(nsimu=3000, method="ram", updatesigma=1, N0=1.0, S02=0.0),       # RAM + out-of-bounds
+                                     dict(kind="expdata", npar=2, par0=[10, 0.1], cmat0=[[4.0, 0], [0, 0.05]],   # proposals: stale alpha12
+                                          sigma2=0.5, nobs=11, xdata=XDATA, ydata=YDATA, lo=[0, 0]), 9)         # (MCMC_run_ram.F90:52-54)
+    c["e2_gauss1_am"] = (dict(nsimu=1500, adaptint=50, updatesigma=0),                                      # npar = 1
+                         dict(kind="gauss", npar=1, par0=[3.0], cmat0=[[0.5]], mu=[1.0], lam=[[2.0]]), 13)
+    c["e3_gauss3_ram_burnin"] = (dict(nsimu=1200, method="ram", updatesigma=0, doburnin=1, burnintime=300,    # RAM idle during burn-in
+                                      alphatarget=0.4, nuparam=0.6),
+                                 dict(kind="gauss", npar=3, par0=[1.0, -1.0, 0.5], cmat0=np.diag([2.0, 1.0, 3.0]),
+                                      mu=[0.0, 0.0, 0.0], lam=[[2.0, 0.3, 0.0], [0.3, 1.0, -0.2], [0.0, -0.2, 0.5]]), 17)
+    c["e4_banana9_dram_noadapt"] = (dict(nsimu=800, doadapt=0, updatesigma=0, drscale=3.0),                 # DR without adaptation, odd npar
+                                    dict(kind="banana", npar=9, par0=np.zeros(9), cmat0=0.5 * np.eye(9), b=0.03), 19)
+    c["e5_gauss17_am_short"] = (dict(nsimu=99, adaptint=100, updatesigma=0),                                # never reaches an adaptation; odd npar
+                                dict(kind="gauss", npar=17, par0=np.linspace(-1, 1, 17), cmat0=0.05 * np.eye(17),
+                                     mu=np.zeros(17), lam=corr_gauss(17, 0.3)), 23)
     return c
 
 

@@ -551,7 +551,10 @@ static int adapt_ram(mcxo_chain *c, int simuind, const double *u, double alpha, 
     } else {
         for (int i = 0; i < n; ++i) x[i] = -(u[i] / su * a);
         int info = mcxo_chdd(n, c->R, x, cc, ss);
-        if (info != 0) { c->ram_downdate_fail = simuind; return -3000; }   /* matutils.F90:719-722 stop */
+        if (info != 0) {                                                    /* matutils.F90:719-722 stop */
+            if (!c->ram_downdate_fail) c->ram_downdate_fail = simuind;
+            if (!c->continue_on_downdate_fail) return -3000;
+        }
     }
     return 0;
 }

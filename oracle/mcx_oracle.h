@@ -76,6 +76,9 @@ typedef struct mcxo_chain {
     int ram_downdate_fail;                /* reference would STOP (matutils.F90:719-722) */
     /* run state */
     double *oldpar; double ss1, sspri1, alpha12;
+    /* 0: stop at a failed downdate like the reference (matutils.F90:719-722); 1: record it and go on with R
+     * untouched, which is what the multi-chain engine does (one bad chain must not end a million-chain run) */
+    int continue_on_downdate_fail;
 } mcxo_chain;
 
 mcxo_chain *mcxo_chain_create(const mcxo_cfg *cfg, const mcxo_target *tgt, const double *par0,

@@ -52,7 +52,8 @@ class Chain(C.Structure):
                 ("nprop", C.c_uint64),
                 ("ad_istart", C.c_int), ("ad_istartind", C.c_int), ("ad_lastind", C.c_int), ("ad_lastfreq", C.c_int),
                 ("info_last", C.c_int), ("ram_downdate_fail", C.c_int),
-                ("oldpar", _DP), ("ss1", C.c_double), ("sspri1", C.c_double), ("alpha12", C.c_double)]
+                ("oldpar", _DP), ("ss1", C.c_double), ("sspri1", C.c_double), ("alpha12", C.c_double),
+                ("continue_on_downdate_fail", C.c_int)]
 
 
 _lib = None
@@ -152,7 +153,7 @@ class Result:
     pass
 
 
-def run_chain(cfg, prob, seed=0x6D636D63, chain_id=0, upto=None):
+def run_chain(cfg, prob, seed=0x6D636D63, chain_id=0, upto=None, continue_on_downdate_fail=False):
     """Run one chain through the oracle; returns the reference-visible outputs."""
     L = lib()
     tgt = prob.ctarget()
@@ -162,6 +163,7 @@ def run_chain(cfg, prob, seed=0x6D636D63, chain_id=0, upto=None):
     if not ch:
         raise RuntimeError("could not factor the initial covariance")
     try:
+        ch.contents.continue_on_downdate_fail = 1 if continue_on_downdate_fail else 0
         rc = L.mcxo_chain_run(ch, cfg.nsimu if upto is None else upto)
         c = ch.contents
         n, ns = prob.npar, c.simuind

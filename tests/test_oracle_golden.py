@@ -25,8 +25,9 @@ def test_oracle_matches_reference_fixture(oracle, name):
     np.testing.assert_allclose(o.sschain[:k, 0], z["ss_head"], rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(o.sschain[-k:, 0], z["ss_tail"], rtol=1e-7, atol=1e-9)
     if "s2_head" in z.files:
-        np.testing.assert_allclose(o.s2chain[:k], z["s2_head"], rtol=1e-9)
-        np.testing.assert_allclose(o.s2chain[-k:], z["s2_tail"], rtol=1e-9)
+        ks = z["s2_head"].shape[0]
+        np.testing.assert_allclose(o.s2chain[:ks], z["s2_head"], rtol=1e-7)
+        np.testing.assert_allclose(o.s2chain[-ks:], z["s2_tail"], rtol=1e-7)
     cs = np.max(np.abs(z["chaincmat"]))
     assert np.max(np.abs(o.chaincmat - z["chaincmat"])) / cs < 1e-9
     np.testing.assert_allclose(o.chainmean, z["chainmean"], rtol=1e-9, atol=1e-9 * np.abs(z["chainmean"]).max() + 1e-12)
