@@ -510,12 +510,11 @@ int mcmcx_init(mcmcx_handle h)
     E.k0 = c.seed; E.chain_id0 = c.chain_id0;
     // target
     E.tgt.kind = h->tkind; E.tgt.b = h->tb; E.tgt.ndata = (int)h->tx.size();
-    E.tgt.mu = E.tgt.lam = E.tgt.x = E.tgt.y = E.tgt.lo = E.tgt.hi = E.tgt.pmu = E.tgt.psig = nullptr;
+    E.tgt.mu = E.tgt.x = E.tgt.y = E.tgt.lo = E.tgt.hi = E.tgt.pmu = E.tgt.psig = nullptr;
     int rc;
     E.tgt.lamT = nullptr;
     if (h->tkind == TGT_GAUSS) {
         if ((rc = dev_upload(h, &E.tgt.mu, h->tmu))) return rc;
-        if ((rc = dev_upload(h, &E.tgt.lam, h->tlam))) return rc;
         std::vector<double> lt((size_t)d * d + 64, 0.0);           // transpose, padded for the 16-wide panel reads
         for (int i = 0; i < d; ++i) for (int j = 0; j < d; ++j) lt[(size_t)j * d + i] = h->tlam[(size_t)i * d + j];
         if ((rc = dev_upload(h, &E.tgt.lamT, lt))) return rc;

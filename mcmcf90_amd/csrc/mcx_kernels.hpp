@@ -5,11 +5,11 @@
 //     element k of chain (tile, lane)  ->  base[(tile*K + k)*64 + lane],
 // i.e. parameter-major inside a tile, so every wave access is one contiguous
 // 512-byte segment and a tile's whole Cholesky factor is one sequential stream.
-// The O(d^2) sweeps over a chain's packed factor are left-looking COLUMN PANELS: 16 columns of
+// The O(d^2) sweeps over a chain's packed factor are left-looking COLUMN PANELS: PW = 8 columns of
 // per-lane state (rotation work values, proposal accumulators) live in registers with compile-time
-// indices, every row contributes one contiguous 16 x 512-byte segment, and the few O(d) vectors
-// (normals, rotations, candidate) sit in per-chain global scratch.  No LDS on the hot path, nothing
-// templated on d.
+// indices, every row contributes one contiguous PW x 512-byte segment (streamed non-temporally), and
+// the few O(d) vectors (normals, rotations, candidate) sit in per-chain global scratch, with the most
+// re-read rotations cached in LDS.  Nothing is templated on d (d <= 256).
 #pragma once
 #include "mcx_device.hpp"
 
@@ -29,7 +29,7 @@ enum { ST_RAM_DOWNDATE_FAIL = 1, ST_CHOL_FAIL = 2, ST_POTRI_FAIL = 4 };
 
 struct DevTarget {
     int kind;
-    const double *mu, *lam, *lamT;   // gauss: mean[d], precision row-major [d*d] and its transpose (padded)
+    const double *mu, *lamT;    // gauss: mean[d] and the precision matrix transposed, lamT[j*d+i] = lam(i,j) (padded)
     double b;                   // banana
     int ndata;                  // expdata
     const double *x, *y;
