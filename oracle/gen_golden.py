@@ -80,6 +80,18 @@ def cases():
     c["e5_gauss17_am_short"] = (dict(nsimu=99, adaptint=100, updatesigma=0),                                # never reaches an adaptation; odd npar
                                 dict(kind="gauss", npar=17, par0=np.linspace(-1, 1, 17), cmat0=0.05 * np.eye(17),
                                      mu=np.zeros(17), lam=corr_gauss(17, 0.3)), 23)
+    # --- SVD paths: the reference is linked with the pinned Jacobi dgesvd (oracle/ref/dgesvd_shim.c), see mcx_svd.h
+    d = 6
+    Sg = 0.6 ** np.abs(np.subtract.outer(np.arange(d), np.arange(d))) * np.outer(np.logspace(0, 1.5, d), np.logspace(0, 1.5, d))
+    g6 = dict(kind="gauss", npar=d, par0=np.zeros(d), cmat0=0.05 * np.eye(d), mu=np.linspace(-1, 1, d), lam=np.linalg.inv(Sg))
+    c["s1_gauss6_scam"] = (dict(nsimu=1500, method="scam", adaptint=100, updatesigma=0), g6, 31)
+    c["s2_gauss6_dram_svd"] = (dict(nsimu=2000, adaptint=100, updatesigma=0, condmax=1e10), g6, 32)
+    c["s3_gauss6_dram_svd_dr"] = (dict(nsimu=2000, adaptint=100, updatesigma=0, condmax=1e10, drscale=2.0), g6, 33)
+    c["s4_expdata_scam_s2"] = (dict(nsimu=2000, method="scam", adaptint=100, updatesigma=1),
+                               dict(kind="expdata", npar=2, par0=[10, 0.1], cmat0=[[0.2, 0], [0, 0.001]], sigma2=0.5,
+                                    nobs=11, xdata=XDATA, ydata=YDATA, lo=[0, 0]), 34)
+    c["s5_banana20_scam"] = (dict(nsimu=400, method="scam", adaptint=100, updatesigma=0),
+                             dict(kind="banana", npar=20, par0=np.zeros(20), cmat0=0.01 * np.eye(20), b=0.1), 35)
     return c
 
 
@@ -88,9 +100,9 @@ def main():
     for name, (ckw, pkw, chain_id) in cases().items():
         cfg = po.make_cfg(**ckw)
         prob = po.Problem(**pkw)
-        r = rr.run_reference(cfg, prob, chain_id=chain_id)
+        r = rr.run_reference(cfg, prob, chain_id=chain_id, pinned_svd=bool(cfg.usesvd))
         k = 16
-        out = {"chain_id": chain_id, "rng_n": r.rng_n, "chainind": r.chainind,
+        out = {"chain_id": chain_id, "rng_n": r.rng_n, "chainind": r.chainind, "pinned_svd": int(bool(cfg.usesvd)),
                "runlen": r.chain[:, -1].astype(np.int32),
                "rows_head": r.chain[:k, :-1], "rows_tail": r.chain[-k:, :-1],
                "ss_head": r.sschain[:k, 0], "ss_tail": r.sschain[-k:, 0],

@@ -29,6 +29,7 @@
 #include "mcx_oracle.h"
 #include "mcx_math.h"
 #include "mcx_targets.h"
+#include "mcx_svd.h"
 
 double mcxo_log(double x) { return mcxm_log(x); }
 double mcxo_exp(double x) { return mcxm_exp(x); }
@@ -211,6 +212,27 @@ int mcxo_potri_u(int n, double *A)
         }
     }
     return 0;
+}
+
+int mcxo_symsvd(int n, double *G, double *V, double *s) { return mcxs_symsvd(n, G, V, s); }
+
+/* dgemv (matutils.F90:161, matmulx), alpha = 1, beta = 0, netlib 3.8.0 loop order with fma accumulation:
+ * 'N': y = 0; for j: temp = x(j); y(i) += temp*a(i,j).   'T': y(j) = sum_i a(i,j) x(i), i ascending. */
+void mcxo_gemv(int trans, int n, const double *A, const double *x, double *y)
+{
+    if (!trans) {
+        for (int i = 0; i < n; ++i) y[i] = 0.0;
+        for (int j = 0; j < n; ++j) {
+            double temp = x[j];
+            for (int i = 0; i < n; ++i) y[i] = fma(temp, A_(A, i, j, n), y[i]);
+        }
+    } else {
+        for (int j = 0; j < n; ++j) {
+            double temp = 0.0;
+            for (int i = 0; i < n; ++i) temp = fma(A_(A, i, j, n), x[i], temp);
+            y[j] = temp;
+        }
+    }
 }
 
 /* classic netlib drotg (BLAS 3.8.0); dchud.f:138 only uses r (into da), c, s */
@@ -416,7 +438,12 @@ static void propose(mcxo_chain *c, const double *oldpar, const double *R, double
     double *z = newpar;
     for (int i = 0; i < n; ++i) z[i] = mcxo_normal(&c->rng);
     if (zout) memcpy(zout, z, sizeof(double) * (size_t)n);
-    mcxo_trmv_ut(n, R, z);
+    if (c->cfg.usesvd) {                               /* matmulx(R, z): full dgemv 'N' (MCMC_DRAM.F90:27) */
+        double *y = (double *)malloc(sizeof(double) * (size_t)n);
+        mcxo_gemv(0, n, R, z, y);
+        memcpy(z, y, sizeof(double) * (size_t)n);
+        free(y);
+    } else mcxo_trmv_ut(n, R, z);
     for (int i = 0; i < n; ++i) newpar[i] = oldpar[i] + z[i];
 }
 
@@ -438,20 +465,71 @@ static void savechain(mcxo_chain *c, const double *par, double ss, int reject)
 
 /* ------------------------------------------------------------------ adaptation: MCMC_adapt.F90 */
 
-/* MCMC_calculate_R, MCMC_adapt.F90:181-230 (Cholesky path) */
+/* covtor_svd (matutils.F90:378-453) / scam_svd (:583-653): dgesvd('A','N') of the covariance, singular values
+ * floored at s(1)/condmax.  scam: R = U, std = sqrt(s).  otherwise R = U diag(sqrt(s)).
+ * returns info: 0, -1 (values were floored), n (s(1) == 0). */
+static int svd_factor(int n, const double *cmat, double condmax, int scam, double *R0, double *std)
+{
+    double *G = (double *)malloc(sizeof(double) * (size_t)n * n * 2 + sizeof(double) * n);
+    double *V = G + (size_t)n * n, *sv = V + (size_t)n * n;
+    memcpy(G, cmat, sizeof(double) * (size_t)n * n);
+    mcxs_symsvd(n, G, V, sv);
+    int info = 0;
+    if (sv[0] == 0.0) { free(G); return n; }
+    double tol = sv[0] / condmax;
+    if (sv[n - 1] <= tol) {
+        for (int i = 0; i < n; ++i) if (sv[i] < tol) sv[i] = tol;
+        info = -1;
+    }
+    if (scam) {
+        memcpy(R0, V, sizeof(double) * (size_t)n * n);
+        for (int i = 0; i < n; ++i) std[i] = sqrt(sv[i]);
+    } else {
+        for (int i = 0; i < n; ++i) {
+            double sq = sqrt(sv[i]);
+            for (int k = 0; k < n; ++k) A_(R0, k, i, n) = sq * A_(V, k, i, n);        /* dscal */
+        }
+    }
+    free(G);
+    return info;
+}
+
+/* MCMC_calculate_R, MCMC_adapt.F90:181-230 */
 int mcxo_calculate_R(mcxo_chain *c, double *cmat)
 {
     int n = c->npar;
-    if (c->cfg.doscam || c->cfg.usesvd) return -1000;   /* SVD paths: not restated yet */
     double *R0 = (double *)malloc(sizeof(double) * (size_t)n * n);
-    memcpy(R0, cmat, sizeof(double) * (size_t)n * n);
-    int info = mcxo_potrf_u(n, R0);
+    int info = 0;
+    if (c->cfg.doscam) {                                           /* :189-200 */
+        info = svd_factor(n, cmat, c->cfg.condmax, 1, R0, c->qcovstd);
+        if (info > 0) { free(R0); c->info_last = info; return info; }
+        info = 0;
+        memcpy(c->R, R0, sizeof(double) * (size_t)n * n);
+        free(R0);
+        c->info_last = 0;
+        return 0;
+    }
+    if (c->cfg.usesvd) {                                           /* :204-209 */
+        info = svd_factor(n, cmat, c->cfg.condmax, 0, R0, NULL);
+        if (info == -1) {                                          /* cmat = matmul(R0, transpose(R0)) */
+            for (int j = 0; j < n; ++j)
+                for (int i = 0; i < n; ++i) {
+                    double acc = 0.0;
+                    for (int k = 0; k < n; ++k) acc = fma(A_(R0, i, k, n), A_(R0, j, k, n), acc);
+                    A_(cmat, i, j, n) = acc;
+                }
+            info = 0;
+        }
+    } else {
+        memcpy(R0, cmat, sizeof(double) * (size_t)n * n);
+        info = mcxo_potrf_u(n, R0);
+    }
     if (info == 0) {
         double sq = sqrt((double)n);
         for (size_t k = 0; k < (size_t)n * n; ++k) c->R[k] = R0[k] * 2.4 / sq;
         if (c->cfg.dodr) {
             memcpy(c->iC, c->R, sizeof(double) * (size_t)n * n);
-            int info2 = mcxo_potri_u(n, c->iC);
+            int info2 = mcxo_potri_u(n, c->iC);                    /* on the upper triangle of R, also when R is U sqrt(s) */
             if (info2 != 0) { free(R0); return -2000 - info2; }       /* reference stops, :220-223 */
             for (size_t k = 0; k < (size_t)n * n; ++k) c->R2[k] = c->R[k] / c->cfg.drscale;
         }
@@ -579,6 +657,7 @@ mcxo_chain *mcxo_chain_create(const mcxo_cfg *cfg, const mcxo_target *tgt, const
     c->accepted = (uint8_t *)calloc(ns, 1);
     c->alpha_trace = (double *)calloc(ns, sizeof(double));
     c->oldpar = (double *)malloc(sizeof(double) * n);
+    c->qcovstd = (double *)calloc((size_t)n, sizeof(double));
     c->ad_istart = 1; c->ad_istartind = 1; c->ad_lastind = 1; c->ad_lastfreq = 0;
     /* MCMC_init.F90:99-116 */
     memcpy(c->chaincmat, cmat0, sizeof(double) * nn);
@@ -597,7 +676,7 @@ void mcxo_chain_free(mcxo_chain *c)
 {
     if (!c) return;
     free(c->par0); free(c->cmat0); free(c->R); free(c->R2); free(c->iC); free(c->chaincmat); free(c->chainmean);
-    free(c->chain); free(c->sschain); free(c->s2chain); free(c->accepted); free(c->alpha_trace); free(c->oldpar);
+    free(c->chain); free(c->sschain); free(c->s2chain); free(c->accepted); free(c->alpha_trace); free(c->oldpar); free(c->qcovstd);
     free(c);
 }
 
@@ -607,7 +686,7 @@ int mcxo_chain_run(mcxo_chain *c, int upto)
 {
     const mcxo_cfg *g = &c->cfg;
     int n = c->npar;
-    if (g->method == MCXO_METHOD_SCAM || g->method == MCXO_METHOD_ER) return -1000;
+    if (g->method == MCXO_METHOD_ER) return -1000;
     if (upto > g->nsimu) upto = g->nsimu;
     double *newpar = (double *)malloc(sizeof(double) * (size_t)n * 6);
     double *newpar2 = newpar + n, *z = newpar + 2 * n, *work = newpar + 3 * n;
@@ -625,6 +704,35 @@ int mcxo_chain_run(mcxo_chain *c, int upto)
         c->simuind = i;
         int reject, inb;
         double ss2 = 0, pri2 = 0, ss3 = 0, pri3 = 0;
+        if (g->method == MCXO_METHOD_SCAM) {                        /* MCMC_run_scam.F90:38-88 */
+            int rejall = 1;
+            double *rot = work;                                      /* work has 3n doubles */
+            for (int j = 0; j < n; ++j) {
+                /* MCMC_propose_sc (:94-117): rotate, perturb component j, rotate back */
+                mcxo_gemv(1, n, c->R, c->oldpar, rot);
+                double zj = mcxo_normal(&c->rng) * c->qcovstd[j];
+                rot[j] = rot[j] + zj;
+                mcxo_gemv(0, n, c->R, rot, newpar);
+                c->nprop++;
+                inb = mcxo_checkbounds(&c->tgt, newpar);
+                if (!inb) { if (!g->dodr) c->bndstayed++; ss2 = DBL_MAX; c->alpha12 = 0.0; reject = 1; }
+                else {
+                    pri2 = mcxo_priorfun(&c->tgt, newpar); ss2 = mcxo_ssfun(&c->tgt, newpar);
+                    c->alpha12 = mcxo_alpha(c->ss1, c->sspri1, ss2, pri2, c->sigma2);
+                    reject = mcmc_reject(c, c->alpha12);
+                }
+                if (!reject) { c->ss1 = ss2; c->sspri1 = pri2; memcpy(c->oldpar, newpar, sizeof(double) * n); rejall = 0; }
+            }
+            reject = rejall;
+            c->alpha_trace[i - 1] = c->alpha12;
+            if (reject) c->stayed++;
+            c->accepted[i - 1] = (uint8_t)!reject;
+            updatesigma2(c, c->ss1);
+            savechain(c, c->oldpar, c->ss1, reject);
+            rc = adapt(c, i);
+            if (rc != 0) break;
+            continue;
+        }
         if (g->method == MCXO_METHOD_RAM) {
             propose(c, c->oldpar, c->R, newpar, z);
             c->nprop++;

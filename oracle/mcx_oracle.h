@@ -79,6 +79,7 @@ typedef struct mcxo_chain {
     /* 0: stop at a failed downdate like the reference (matutils.F90:719-722); 1: record it and go on with R
      * untouched, which is what the multi-chain engine does (one bad chain must not end a million-chain run) */
     int continue_on_downdate_fail;
+    double *qcovstd;                      /* SCAM: sqrt of the singular values (mcmc.F90:37) */
 } mcxo_chain;
 
 mcxo_chain *mcxo_chain_create(const mcxo_cfg *cfg, const mcxo_target *tgt, const double *par0,
@@ -101,6 +102,8 @@ int  mcxo_chdd(int p, double *R, const double *x, double *c, double *s);
 void mcxo_covmat(int n, int p, const double *x, int ldx, const double *w, int nw,
                  double *cmat, double *xmean, double *wsum, int update);
 int  mcxo_calculate_R(mcxo_chain *c, double *cmat);
+int  mcxo_symsvd(int n, double *G, double *V, double *s);      /* pinned dgesvd('A','N') of a PSD matrix, mcx_svd.h */
+void mcxo_gemv(int trans, int n, const double *A, const double *x, double *y);   /* y = A x or A'x, netlib dgemv order */
 double mcxo_log(double x);
 double mcxo_exp(double x);
 double mcxo_alpha(double ss1, double pri1, double ss2, double pri2, double sigma2);

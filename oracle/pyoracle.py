@@ -53,7 +53,7 @@ class Chain(C.Structure):
                 ("ad_istart", C.c_int), ("ad_istartind", C.c_int), ("ad_lastind", C.c_int), ("ad_lastfreq", C.c_int),
                 ("info_last", C.c_int), ("ram_downdate_fail", C.c_int),
                 ("oldpar", _DP), ("ss1", C.c_double), ("sspri1", C.c_double), ("alpha12", C.c_double),
-                ("continue_on_downdate_fail", C.c_int)]
+                ("continue_on_downdate_fail", C.c_int), ("qcovstd", _DP)]
 
 
 _lib = None
@@ -89,6 +89,9 @@ def lib():
         L.mcxo_chud.argtypes = [C.c_int, _DP, _DP, _DP, _DP]
         L.mcxo_chdd.argtypes = [C.c_int, _DP, _DP, _DP, _DP]
         L.mcxo_chdd.restype = C.c_int
+        L.mcxo_symsvd.argtypes = [C.c_int, _DP, _DP, _DP]
+        L.mcxo_symsvd.restype = C.c_int
+        L.mcxo_gemv.argtypes = [C.c_int, C.c_int, _DP, _DP, _DP]
         L.mcxo_covmat.argtypes = [C.c_int, C.c_int, _DP, C.c_int, _DP, C.c_int, _DP, _DP, _DP, C.c_int]
         L.mcxo_alpha.argtypes = [C.c_double] * 5
         L.mcxo_alpha.restype = C.c_double
@@ -181,6 +184,7 @@ def run_chain(cfg, prob, seed=0x6D636D63, chain_id=0, upto=None, continue_on_dow
         r.chaincmat = np.ctypeslib.as_array(c.chaincmat, shape=(n, n)).T.copy()
         r.chainmean = np.ctypeslib.as_array(c.chainmean, shape=(n,)).copy()
         r.chainwsum = c.chainwsum
+        r.qcovstd = np.ctypeslib.as_array(c.qcovstd, shape=(n,)).copy()
         r.sigma2 = c.sigma2
         r.theta = np.ctypeslib.as_array(c.oldpar, shape=(n,)).copy()
         r.ss1, r.sspri1 = c.ss1, c.sspri1

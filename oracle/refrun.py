@@ -14,6 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 EXE = os.path.join(_HERE, "_ref", "mcxref")
+EXE_SVD = os.path.join(_HERE, "_ref", "mcxref_svd")      # same program, dgesvd = the pinned Jacobi routine
 METHOD_NAMES = {0: "dram", 1: "ram", 2: "scam", 3: "er"}
 TARGET_IDS = {"gauss": 0, "banana": 1, "expdata": 2}
 
@@ -98,7 +99,7 @@ class RefResult:
     pass
 
 
-def run_reference(cfg, prob, seed=0x6D636D63, chain_id=0, keep=False, timeout=600):
+def run_reference(cfg, prob, seed=0x6D636D63, chain_id=0, keep=False, timeout=600, pinned_svd=False):
     if not available():
         raise RuntimeError("oracle/_ref/mcxref not built (make -C oracle ref)")
     d = tempfile.mkdtemp(prefix="mcxref_")
@@ -106,7 +107,7 @@ def run_reference(cfg, prob, seed=0x6D636D63, chain_id=0, keep=False, timeout=60
         write_inputs(d, cfg, prob)
         env = dict(os.environ, MCX_SEED=str(seed), MCX_CHAIN=str(chain_id), MKL_NUM_THREADS="1",
                    MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1", MCX_RNG_LOG=os.path.join(d, "rng.log"))
-        p = subprocess.run([EXE], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+        p = subprocess.run([EXE_SVD if pinned_svd else EXE], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
         r = RefResult()
         r.stdout = p.stdout.decode(errors="replace")
         r.returncode = p.returncode
