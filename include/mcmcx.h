@@ -39,7 +39,7 @@ extern "C" {
 
 #define MCMCX_METHOD_DRAM 0   /* method = 'dram' (AM / DRAM), mcmc_main.F90:35-36 */
 #define MCMCX_METHOD_RAM  1   /* method = 'ram',              mcmc_main.F90:33-34 */
-#define MCMCX_METHOD_SCAM 2   /* not yet on the device: mcmcx_create fails */
+#define MCMCX_METHOD_SCAM 2   /* method = 'scam',             mcmc_main.F90:29-30 */
 #define MCMCX_METHOD_ER   3   /* not yet on the device: mcmcx_create fails */
 
 #define MCMCX_DEFAULT_SEED 0x6D636D63u
@@ -103,7 +103,8 @@ int mcmcx_get_theta(mcmcx_handle h, double *theta_rowmajor /* [nchains][npar] */
 int mcmcx_get_scalars(mcmcx_handle h, double *out /* [nchains][4] */);
 /* per chain: uniforms drawn, polar cache flag, cached deviate */
 int mcmcx_get_rng(mcmcx_handle h, int32_t chain, uint64_t *n, int32_t *saved, double *saved_y);
-int mcmcx_get_R(mcmcx_handle h, int32_t chain, double *R_colmajor);
+int mcmcx_get_R(mcmcx_handle h, int32_t chain, double *R_colmajor);    /* upper triangular, or the full SVD factor when condmax > 0 */
+int mcmcx_get_qcovstd(mcmcx_handle h, int32_t chain, double *std);      /* SCAM: qcovstd (mcmc.F90:37) */
 int mcmcx_get_chaincov(mcmcx_handle h, int32_t chain, double *cmat_colmajor, double *mean, double *wsum);
 /* delayed-rejection state of one chain: R2 = R/drscale and the upper triangle of iC (mcmc.F90:36) */
 int mcmcx_get_dr(mcmcx_handle h, int32_t chain, double *R2_colmajor, double *iC_colmajor);

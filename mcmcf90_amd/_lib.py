@@ -50,6 +50,7 @@ SYMBOLS = {
     "mcmcx_get_scalars": (C.c_int, [C.c_void_p, _DP]),
     "mcmcx_get_rng": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64), _IP, _DP]),
     "mcmcx_get_R": (C.c_int, [C.c_void_p, C.c_int32, _DP]),
+    "mcmcx_get_qcovstd": (C.c_int, [C.c_void_p, C.c_int32, _DP]),
     "mcmcx_get_dr": (C.c_int, [C.c_void_p, C.c_int32, _DP, _DP]),
     "mcmcx_get_chaincov": (C.c_int, [C.c_void_p, C.c_int32, _DP, _DP, _DP]),
     "mcmcx_get_accepted": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint8)]),

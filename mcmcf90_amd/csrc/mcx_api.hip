@@ -116,6 +116,61 @@ static int host_initial_R(int d, const std::vector<double> &cm, std::vector<doub
     return 0;
 }
 
+// The pinned dgesvd('A','N') of a symmetric PSD matrix (one-sided Jacobi), same operation sequence as the device's
+// symsvd_dev; used for the shared initial factor.  G, V column-major n*n.
+static void host_symsvd(int n, std::vector<double> &G, std::vector<double> &V, std::vector<double> &sv)
+{
+    V.assign((size_t)n * n, 0.0); sv.assign(n, 0.0);
+    for (int j = 0; j < n; ++j) V[(size_t)j * n + j] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                double *gp = &G[(size_t)p * n], *gq = &G[(size_t)q * n];
+                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+                for (int k = 0; k < n; ++k) { alpha = std::fma(gp[k], gp[k], alpha); beta = std::fma(gq[k], gq[k], beta); gamma = std::fma(gp[k], gq[k], gamma); }
+                if (gamma == 0.0) continue;
+                if (std::fabs(gamma) <= 1e-15 * std::sqrt(alpha * beta)) continue;
+                rotated = true;
+                double zeta = (beta - alpha) / (2.0 * gamma);
+                double t = std::copysign(1.0, zeta) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
+                for (int k = 0; k < n; ++k) { double a = gp[k], b = gq[k]; gp[k] = c * a - sn * b; gq[k] = sn * a + c * b; }
+                double *vp = &V[(size_t)p * n], *vq = &V[(size_t)q * n];
+                for (int k = 0; k < n; ++k) { double a = vp[k], b = vq[k]; vp[k] = c * a - sn * b; vq[k] = sn * a + c * b; }
+            }
+        if (!rotated) break;
+    }
+    for (int j = 0; j < n; ++j) { double a = 0.0; for (int k = 0; k < n; ++k) a = std::fma(G[(size_t)j * n + k], G[(size_t)j * n + k], a); sv[j] = std::sqrt(a); }
+    for (int i = 0; i < n - 1; ++i) {
+        int m = i;
+        for (int j = i + 1; j < n; ++j) if (sv[j] > sv[m]) m = j;
+        if (m != i) { std::swap(sv[i], sv[m]); for (int k = 0; k < n; ++k) std::swap(V[(size_t)i * n + k], V[(size_t)m * n + k]); }
+    }
+}
+
+// MCMC_calculate_R, SVD branches, for the shared initial covariance (MCMC_init.F90:109): returns 0 or an error code.
+// Rfull: column-major d*d factor (U for scam, U sqrt(s) 2.4/sqrt(d) otherwise); std: sqrt(s) (scam)
+static int host_initial_svd(int d, const std::vector<double> &cm, double condmax, bool scam,
+                            std::vector<double> &Rfull, std::vector<double> &std)
+{
+    std::vector<double> G((size_t)d * d), V, sv;
+    for (int j = 0; j < d; ++j) for (int i = 0; i < d; ++i) G[(size_t)j * d + i] = (i <= j) ? cm[(size_t)i + (size_t)j * d] : cm[(size_t)j + (size_t)i * d];
+    host_symsvd(d, G, V, sv);
+    if (sv[0] == 0.0) return d;
+    const double tol = sv[0] / condmax;
+    if (sv[d - 1] <= tol) for (int i = 0; i < d; ++i) if (sv[i] < tol) sv[i] = tol;
+    Rfull.resize((size_t)d * d); std.assign(d, 0.0);
+    if (scam) {
+        Rfull = V;
+        for (int i = 0; i < d; ++i) std[i] = std::sqrt(sv[i]);
+    } else {
+        const double sqd = std::sqrt((double)d);
+        for (int i = 0; i < d; ++i) { double sq = std::sqrt(sv[i]); for (int k = 0; k < d; ++k) Rfull[(size_t)i * d + k] = (sq * V[(size_t)i * d + k]) * 2.4 / sqd; }
+    }
+    return 0;
+}
+
 // dpotri('U') on the packed factor (dtrti2 + dlauu2), same operation sequence as the device's potri_packed
 static int host_potri(int d, std::vector<double> &A)
 {
@@ -166,13 +221,15 @@ static void launch_step(mcmcx_engine *h, int it0, int it1)
     else if (h->pooled) hipLaunchKernelGGL((step_kernel<false, false, true>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else hipLaunchKernelGGL((step_kernel<false, false, false>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
 }
+static void launch_scam(mcmcx_engine *h, int it0, int it1)
+{ hipLaunchKernelGGL(scam_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT); }
 static void launch_adapt(mcmcx_engine *h, int it, int mode)
 { hipLaunchKernelGGL(adapt_kernel, dim3(h->ntiles), dim3(64), lds_bytes(h) / 2, h->stream, h->E, it, mode); }   // one d-vector
 
 // Which branch of MCMC_adapt fires at iteration `it` (0 = none).  MCMC_adapt.F90:42-46, 60-61, 105.
 static int adapt_mode(const mcmcx_config &c, int it)
 {
-    if (c.method != MCMCX_METHOD_DRAM) return 0;
+    if (c.method == MCMCX_METHOD_RAM) return 0;
     if (c.doadapt == 0 && c.doburnin == 0) return 0;
     if (c.adaptend > 0 && it > c.adaptend) return 0;
     bool m1 = (c.adaptint != 0) && (it % c.adaptint == 0);
@@ -364,20 +421,24 @@ int mcmcx_create(const mcmcx_config *cfg_in, mcmcx_handle *out)
     if (c.scalelimit < 0.0 || c.scalelimit > 0.5)
         return fail(-2, "ERROR: Scalelimit control variable should be between [0,0.5]");
     if (c.scalefactor < 0.0) c.scalefactor = 1.0;
-    if (c.method == MCMCX_METHOD_SCAM || c.method == MCMCX_METHOD_ER)
-        return fail(-3, "method 'scam'/'er' is not available in the device engine yet");
-    if (c.method != MCMCX_METHOD_DRAM && c.method != MCMCX_METHOD_RAM) return fail(-3, "unknown method");
+    if (c.method == MCMCX_METHOD_ER)
+        return fail(-3, "method 'er' is not available in the device engine yet");
+    if (c.method != MCMCX_METHOD_DRAM && c.method != MCMCX_METHOD_RAM && c.method != MCMCX_METHOD_SCAM) return fail(-3, "unknown method");
+    if (c.method == MCMCX_METHOD_SCAM) {                                             // mcmcinit.F90:321-330
+        if (c.condmax <= 0.0) c.condmax = 1.0e15;
+        c.doburnin = 0; c.drscale = 0.0;
+    }
     if (c.method == MCMCX_METHOD_RAM) c.drscale = 0.0;
+    if (c.method == MCMCX_METHOD_RAM && c.condmax > 0.0) return fail(-6, "method='ram' with condmax > 0 is not available in the device engine");
     if (c.nsimu < 1) return fail(-4, "nsimu <= 0 stopping");                         // mcmc_main.F90:22-25
     if (c.npar < 1 || c.npar > MCX_MAX_NPAR) return fail(-5, "npar must be in 1.." + std::to_string(MCX_MAX_NPAR));
     if (c.nchains < 1) return fail(-5, "nchains must be >= 1");
-    if (c.condmax > 0.0) return fail(-6, "condmax > 0 (SVD proposal) is not available in the device engine yet");
-    if (c.doadapt && c.method == MCMCX_METHOD_DRAM) {
+    if (c.doadapt && c.method != MCMCX_METHOD_RAM) {
         if (c.adaptint == 0) return fail(-7, "doadapt with adaptint = 0");
     }
     if (c.pooled) {
-        if (c.method != MCMCX_METHOD_DRAM || c.drscale > 0.0 || c.doburnin != 0 || c.adapthist > 1 || c.greedy != 0)
-            return fail(-8, "pooled mode supports method='dram' with doburnin=0, drscale=0, adapthist<=1");
+        if (c.method != MCMCX_METHOD_DRAM || c.drscale > 0.0 || c.doburnin != 0 || c.adapthist > 1 || c.greedy != 0 || c.condmax > 0.0)
+            return fail(-8, "pooled mode supports method='dram' with doburnin=0, drscale=0, adapthist<=1, condmax=0");
     }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -387,7 +448,7 @@ int mcmcx_create(const mcmcx_config *cfg_in, mcmcx_handle *out)
     mcmcx_engine *h = new mcmcx_engine();
     h->cfg = c; h->d = c.npar; h->P = c.npar * (c.npar + 1) / 2;
     h->ntiles = (c.nchains + 63) / 64; h->nlanes = h->ntiles * 64;
-    h->dodr = (c.drscale > 0.0) ? 1 : 0; h->usesvd = 0; h->pooled = c.pooled ? 1 : 0;
+    h->dodr = (c.drscale > 0.0) ? 1 : 0; h->usesvd = (c.condmax > 0.0) ? 1 : 0; h->pooled = c.pooled ? 1 : 0;
     e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(-100, hipGetErrorString(e)); }
     h->own_stream = true;
@@ -493,8 +554,13 @@ int mcmcx_init(mcmcx_handle h)
     }
     if (!h->sigma2ok) { h->sigma2 = 1.0; h->nobs = 1; }                               // MCMC_init.F90:52-59
     if (h->tkind < 0) return fail(-31, "no target: the device engine needs mcmcx_set_target_*");
-    std::vector<double> Rp, Cp;
+    if (h->tkind == TGT_HOST && h->usesvd) return fail(-31, "host-callback targets are not available with condmax > 0 / method='scam'");
+    std::vector<double> Rp, Cp, Rfull, qstd0;
     int info = host_initial_R(d, h->cmat0, Rp, Cp);
+    if (h->usesvd) {                                                                  // Cp (packed cmat0) is still needed
+        if (info != 0) { Rp.assign(P, 0.0); info = 0; }
+        info = host_initial_svd(d, h->cmat0, c.condmax, c.method == MCMCX_METHOD_SCAM, Rfull, qstd0);
+    }
     if (info != 0) return fail(-32, "could not factor the initial covariance");      // MCMC_init.F90:110
     h->S02eff = (c.S02 <= 0.0) ? h->sigma2 : c.S02;                                   // MCMC_init.F90:114-116
     double shape = c.N0 / 2.0 + (double)h->nobs / 2.0;
@@ -503,6 +569,8 @@ int mcmcx_init(mcmcx_handle h)
     EngineDev &E = h->E;
     E.d = d; E.P = P; E.ntiles = T;
     E.method = (c.method == MCMCX_METHOD_RAM) ? M_RAM : M_DRAM;
+    E.usesvd = h->usesvd; E.doscam = (c.method == MCMCX_METHOD_SCAM) ? 1 : 0; E.condmax = c.condmax;
+    E.Rf = E.R2f = E.qstd = E.Gw = E.Vw = nullptr;
     E.greedy = c.greedy; E.adapthist = c.adapthist; E.initcmatn = (double)c.initcmatn;
     E.dodr = h->dodr; E.updatesigma = c.updatesigma; E.doadapt = c.doadapt; E.doburnin = c.doburnin; E.burnintime = c.burnintime;
     E.gam_shape = shape; E.N0S02 = c.N0 * h->S02eff;
@@ -537,12 +605,31 @@ int mcmcx_init(mcmcx_handle h)
     if ((rc = dev_alloc(h, &E.rngn, L))) return rc;
     if ((rc = dev_alloc(h, &E.R, L * P, false))) return rc;
     if ((rc = dev_alloc(h, &E.basetheta, L * d))) return rc;
+    if (h->usesvd) {
+        const size_t DD = (size_t)d * d;
+        if ((rc = dev_alloc(h, &E.Rf, L * DD, false))) return rc;
+        if ((rc = dev_alloc(h, &E.Gw, L * DD))) return rc;
+        if ((rc = dev_alloc(h, &E.Vw, L * DD))) return rc;
+        if ((rc = dev_alloc(h, &E.qstd, L * d))) return rc;
+        if (h->dodr && (rc = dev_alloc(h, &E.R2f, L * DD, false))) return rc;
+        std::vector<double> rf(L * DD), qs(L * d);
+        for (int t = 0; t < T; ++t) {
+            for (size_t e = 0; e < DD; ++e) for (int l = 0; l < 64; ++l) rf[((size_t)t * DD + e) * 64 + l] = Rfull[e];
+            for (int k = 0; k < d; ++k) for (int l = 0; l < 64; ++l) qs[((size_t)t * d + k) * 64 + l] = qstd0[k];
+        }
+        HIPCHK(hipMemcpy(E.Rf, rf.data(), rf.size() * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(E.qstd, qs.data(), qs.size() * 8, hipMemcpyHostToDevice));
+        if (h->dodr) {
+            for (auto &v : rf) v = v / c.drscale;
+            HIPCHK(hipMemcpy(E.R2f, rf.data(), rf.size() * 8, hipMemcpyHostToDevice));
+        }
+    }
     E.R2 = E.iC = nullptr;
     if (h->dodr) {
         if ((rc = dev_alloc(h, &E.R2, L * P, false))) return rc;
         if ((rc = dev_alloc(h, &E.iC, L * P, false))) return rc;
     }
-    const bool am = (E.method == M_DRAM) && (c.doadapt != 0 || c.doburnin != 0) && !h->pooled;
+    const bool am = (c.method != MCMCX_METHOD_RAM) && (c.doadapt != 0 || c.doburnin != 0) && !h->pooled;
     E.cmat = E.mean = E.Rtmp = nullptr; E.rowlist = nullptr;
     // history ring
     const bool need_hist = am || c.record_chain;
@@ -611,6 +698,7 @@ int mcmcx_init(mcmcx_handle h)
         HIPCHK(hipMemcpyAsync(E.ictr, ic.data(), ic.size() * 4, hipMemcpyHostToDevice, h->stream));
         if (h->dodr) {                                   // iC = dpotri(R), R2 = R/drscale, MCMC_adapt.F90:216-225
             std::vector<double> iCp = Rp, R2p(P);
+            if (h->usesvd) for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) iCp[h_pidx(i, j, d)] = Rfull[(size_t)j * d + i];
             if (host_potri(d, iCp) != 0) return fail(-34, "ERROR: cannot invert cmat");
             for (int e = 0; e < P; ++e) R2p[e] = Rp[e] / c.drscale;
             std::vector<double> v2(L * P), vi(L * P);
@@ -667,7 +755,7 @@ int mcmcx_run(mcmcx_handle h, int32_t upto)
             hipEvent_t e0, e1;
             HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
             HIPCHK(hipEventRecord(e0, h->stream));
-            launch_step(h, it, end);
+            if (h->cfg.method == MCMCX_METHOD_SCAM) launch_scam(h, it, end); else launch_step(h, it, end);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(e1, h->stream));
             h->pending.emplace_back(e0, e1);
@@ -775,8 +863,23 @@ int mcmcx_get_R(mcmcx_handle h, int32_t chain, double *R)
 {
     int rc = check_chain(h, chain); if (rc) return rc;
     std::vector<double> p;
+    if (h->usesvd) {                                     // full column-major factor
+        if ((rc = fetch_chain_vec(h, h->E.Rf, h->d * h->d, chain, p))) return rc;
+        memcpy(R, p.data(), sizeof(double) * p.size());
+        return 0;
+    }
     if ((rc = fetch_chain_vec(h, h->E.R, h->P, chain, p))) return rc;
     unpack_upper(h->d, p, R, false);
+    return 0;
+}
+
+int mcmcx_get_qcovstd(mcmcx_handle h, int32_t chain, double *std)
+{
+    int rc = check_chain(h, chain); if (rc) return rc;
+    if (!h->E.qstd) return fail(-45, "no SVD state (condmax = 0)");
+    std::vector<double> p;
+    if ((rc = fetch_chain_vec(h, h->E.qstd, h->d, chain, p))) return rc;
+    memcpy(std, p.data(), sizeof(double) * p.size());
     return 0;
 }
 
@@ -785,7 +888,8 @@ int mcmcx_get_dr(mcmcx_handle h, int32_t chain, double *R2, double *iC)
     int rc = check_chain(h, chain); if (rc) return rc;
     if (!h->dodr) return fail(-43, "drscale = 0: no delayed-rejection state");
     std::vector<double> p;
-    if (R2) { if ((rc = fetch_chain_vec(h, h->E.R2, h->P, chain, p))) return rc; unpack_upper(h->d, p, R2, false); }
+    if (R2 && h->usesvd) { if ((rc = fetch_chain_vec(h, h->E.R2f, h->d * h->d, chain, p))) return rc; memcpy(R2, p.data(), sizeof(double) * p.size()); }
+    else if (R2) { if ((rc = fetch_chain_vec(h, h->E.R2, h->P, chain, p))) return rc; unpack_upper(h->d, p, R2, false); }
     if (iC) { if ((rc = fetch_chain_vec(h, h->E.iC, h->P, chain, p))) return rc; unpack_upper(h->d, p, iC, false); }
     return 0;
 }

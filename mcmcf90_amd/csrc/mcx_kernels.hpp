@@ -59,6 +59,9 @@ struct EngineDev {
     uint64_t *accmask;          // [(it-1)*ntiles + tile] or nullptr
     uint64_t *rowlist;          // [(tile*(wcap+1) + r)*64 + lane]  (slot | weight<<32)
     const double *sharedR;      // pooled mode: the one packed factor all chains propose with
+    // SVD paths (condmax > 0 / method='scam'): full column-major d x d factors per chain, element (i,j) at j*d+i
+    int usesvd, doscam; double condmax;
+    double *Rf, *R2f, *qstd, *Gw, *Vw;
     // host-callback targets: per-chain evaluation results (inbounds, prior, ss) and state carried between phases
     double *hev, *hx;
 };
@@ -321,6 +324,115 @@ MCX_DEV void trmv_panels(const double *Rt, const double *z_t, double *P_t, const
             }
 #pragma unroll
             for (int u = 0; u < PW; ++u) if (u < nw) GV(P_t, J0 + u) = GV(theta_t, J0 + u) + P[u];   // newpar = oldpar + R'z
+        }
+    }
+}
+
+// ---------------------------------------------------------------- full-matrix products for the SVD paths
+// y = M x (dgemv 'N', matutils.F90:161): y = 0, then column by column y_i += x_j M(i,j) -- each y_i is an fma chain
+// ascending in j.  Row panels of PW accumulators in registers; out_t = (add_t ? add_t : 0) + y.
+MCX_DEV void gemvN_panels(const double *Mt, const double *x_t, double *out_t, const double *add_t, int lane, int d, bool act)
+{
+    for (int I0 = 0; I0 < d; I0 += PW) {
+        const int nr = (d - I0) < PW ? (d - I0) : PW;
+        double y[PW];
+#pragma unroll
+        for (int u = 0; u < PW; ++u) y[u] = 0.0;
+        if (act) {
+#pragma unroll 2
+            for (int j = 0; j < d; ++j) {
+                const double xj = GV(x_t, j);
+                const double *seg = Mt + ((size_t)j * d + I0) * 64;
+                double r[PW];
+#pragma unroll
+                for (int u = 0; u < PW; ++u) r[u] = GV(seg, u < nr ? u : nr - 1);
+#pragma unroll
+                for (int u = 0; u < PW; ++u) y[u] = dfma(xj, r[u], y[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < PW; ++u) if (u < nr) GV(out_t, I0 + u) = add_t ? (GV(add_t, I0 + u) + y[u]) : y[u];
+        }
+    }
+}
+// y = M'x (dgemv 'T'): y_k = sum_i M(i,k) x_i, i ascending, one fma chain per column.
+MCX_DEV void gemvT_panels(const double *Mt, const double *x_t, double *out_t, int lane, int d)
+{
+    for (int K0 = 0; K0 < d; K0 += PW) {
+        const int nc = (d - K0) < PW ? (d - K0) : PW;
+        double t[PW];
+#pragma unroll
+        for (int u = 0; u < PW; ++u) t[u] = 0.0;
+        for (int i = 0; i < d; ++i) {
+            const double xi = GV(x_t, i);
+            double r[PW];
+#pragma unroll
+            for (int u = 0; u < PW; ++u) r[u] = GV(Mt, (size_t)(K0 + (u < nc ? u : nc - 1)) * d + i);
+#pragma unroll
+            for (int u = 0; u < PW; ++u) t[u] = dfma(r[u], xi, t[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < PW; ++u) if (u < nc) GV(out_t, K0 + u) = t[u];
+    }
+}
+
+// The pinned dgesvd('A','N') of a symmetric PSD matrix: one-sided Jacobi, row-cyclic, operation for operation the
+// routine of oracle/mcx_svd.h (see there).  Gt: in the matrix (column-major d*d per chain), destroyed; Vt: out
+// the singular vectors; sv_t: out singular values, descending.  Lanes converge independently; a converged lane
+// keeps re-deriving "no rotation" from unchanged data, which is the same as having left the loop.
+MCX_DEV void symsvd_dev(double *Gt, double *Vt, double *sv_t, int lane, int d, bool act)
+{
+    for (int j = 0; j < d; ++j) for (int i = 0; i < d; ++i) if (act) GV(Vt, (size_t)j * d + i) = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < d - 1; ++p) {
+            for (int q = p + 1; q < d; ++q) {
+                double *gp = Gt + (size_t)p * d * 64, *gq = Gt + (size_t)q * d * 64;
+                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll 4
+                for (int k = 0; k < d; ++k) {
+                    double a = GV(gp, k), b = GV(gq, k);
+                    alpha = dfma(a, a, alpha); beta = dfma(b, b, beta); gamma = dfma(a, b, gamma);
+                }
+                bool rot = act && (gamma != 0.0) && !(fabs(gamma) <= 1e-15 * sqrt(alpha * beta));
+                if (__any(rot)) {
+                    if (rot) {
+                        rotated = true;
+                        double zeta = (beta - alpha) / (2.0 * gamma);
+                        double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                        double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+#pragma unroll 4
+                        for (int k = 0; k < d; ++k) {
+                            double a = GV(gp, k), b = GV(gq, k);
+                            GV(gp, k) = c * a - sn * b; GV(gq, k) = sn * a + c * b;
+                        }
+                        double *vp = Vt + (size_t)p * d * 64, *vq = Vt + (size_t)q * d * 64;
+#pragma unroll 4
+                        for (int k = 0; k < d; ++k) {
+                            double a = GV(vp, k), b = GV(vq, k);
+                            GV(vp, k) = c * a - sn * b; GV(vq, k) = sn * a + c * b;
+                        }
+                    }
+                }
+            }
+        }
+        if (!__any(rotated)) break;
+    }
+    if (act) {
+        for (int j = 0; j < d; ++j) {
+            const double *gj = Gt + (size_t)j * d * 64;
+            double a = 0.0;
+            for (int k = 0; k < d; ++k) { double g = GV(gj, k); a = dfma(g, g, a); }
+            GV(sv_t, j) = sqrt(a);
+        }
+        for (int i = 0; i < d - 1; ++i) {                     // descending order, first maximum wins
+            int m = i; double sm = GV(sv_t, i);
+            for (int j = i + 1; j < d; ++j) { double sj = GV(sv_t, j); if (sj > sm) { m = j; sm = sj; } }
+            if (m != i) {
+                double ts = GV(sv_t, i); GV(sv_t, i) = GV(sv_t, m); GV(sv_t, m) = ts;
+                for (int k = 0; k < d; ++k) {
+                    double tv = GV(Vt, (size_t)i * d + k); GV(Vt, (size_t)i * d + k) = GV(Vt, (size_t)m * d + k); GV(Vt, (size_t)m * d + k) = tv;
+                }
+            }
         }
     }
 }
@@ -602,6 +714,7 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
         double *zn_t = zs_t + (size_t)((it + 1) & 1) * d * 64;    // z of the next one
         // ---- newpar = MCMC_propose(oldpar, R)
         if (POOLED) trmv_shared(g_sharedR, zc_t, cand_t, theta_t, lane, d);
+        else if (E.usesvd) gemvN_panels(E.Rf + (size_t)tile * d * d * 64, zc_t, cand_t, theta_t, lane, d, true);   // matmulx(R,z)
         else if (__any(!have_p)) trmv_panels(Rt, zc_t, cand_t, theta_t, lane, d, !have_p);
         // ---- bounds, prior, ss, alpha, reject
         bool inb = target_inbounds(E.tgt, d, lane, cand_t);
@@ -625,7 +738,8 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
             if (m) drtries += 1;
             double *z2_t = zn_t;                          // stage-2 normals: the "next" buffer is still free
             gen_normals(g, z2_t, lane, d, m);
-            trmv_panels(E.R2 + (size_t)tile * E.P * 64, z2_t, c2_t, theta_t, lane, d, m);
+            if (E.usesvd) gemvN_panels(E.R2f + (size_t)tile * d * d * 64, z2_t, c2_t, theta_t, lane, d, m);
+            else trmv_panels(E.R2 + (size_t)tile * E.P * 64, z2_t, c2_t, theta_t, lane, d, m);
             if (m) {
                 bool inb2 = target_inbounds(E.tgt, d, lane, c2_t);
                 if (!inb2) bnd += 1;
@@ -738,6 +852,66 @@ MCX_DEV void lane_store(const EngineDev &E, int tile, int lane, const LaneState 
     TIDX(E.ictr, tile, NICTR, I_CHAININD, lane) = L.chainind; TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane) = L.curcount;
     TIDX(E.ictr, tile, NICTR, I_STATUS, lane) = L.status;
     TIDX(E.ictr, tile, NICTR, I_DRACC, lane) = L.dracc; TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane) = L.drtries;
+}
+
+// ---------------------------------------------------------------- MCMC_run_scam (MCMC_run_scam.F90:38-88)
+// One outer iteration = d componentwise Metropolis sub-steps in the rotated basis: rot = U'theta (dgemv 'T'),
+// rot_j += N(0,1) std_j, theta' = U rot (dgemv 'N'), full ss evaluation, alpha, reject (MCMC_propose_sc :94-117).
+// One chain row per outer iteration.  U (full d x d per chain) is streamed twice per sub-step.
+__global__ __launch_bounds__(64, 2) void scam_kernel(EngineDev E, int it0, int it1,
+                                                     const double *__restrict__ g_mu, const double *__restrict__ g_lamT)
+{
+    const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
+    double *theta_t = E.theta + (size_t)tile * d * 64;
+    double *cand_t = E.cand + (size_t)tile * d * 64;
+    double *rot_t = E.cs + (size_t)tile * 2 * d * 64;
+    const double *Ut = E.Rf + (size_t)tile * d * d * 64;
+    const double *std_t = E.qstd + (size_t)tile * d * 64;
+    LaneState L;
+    lane_load(E, tile, lane, L);
+    for (int it = it0; it <= it1; ++it) {
+        bool rejall = true;
+        for (int j = 0; j < d; ++j) {
+            gemvT_panels(Ut, theta_t, rot_t, lane, d);
+            const double zj = rng_normal(L.g) * GV(std_t, j);
+            GV(rot_t, j) = GV(rot_t, j) + zj;
+            gemvN_panels(Ut, rot_t, cand_t, nullptr, lane, d, true);
+            bool inb = target_inbounds(E.tgt, d, lane, cand_t);
+            double pri2 = target_prior(E.tgt, d, lane, cand_t);
+            double ss2 = target_ss<false>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
+            bool reject;
+            if (!inb) { L.bnd += 1; L.alpha12 = 0.0; reject = true; }
+            else {
+                L.alpha12 = d_alpha(L.ss1, L.pri1, ss2, pri2, L.sigma2);
+                reject = true;
+                if (L.alpha12 >= 1.0) reject = false;
+                else if (L.alpha12 > 0.0) { double u = rng_uniform(L.g); if (u <= L.alpha12) reject = false; }
+            }
+            if (!reject) {
+                L.ss1 = ss2; L.pri1 = pri2; rejall = false;
+                for (int k = 0; k < d; ++k) GV(theta_t, k) = GV(cand_t, k);
+            }
+        }
+        if (rejall) { L.stayed += 1; L.curcount += 1; }
+        else { L.chainind += 1; L.curcount = 1; }
+        if (E.updatesigma) {
+            double gm = rng_gamma(L.g, E.gam_shape, 2.0 / (E.N0S02 + L.ss1));
+            L.sigma2 = 1.0 / gm;
+        }
+        unsigned long long ballot = __ballot(!rejall);
+        const int slot = it % E.wcap;
+        if (E.hist) {
+            if (!rejall) {
+                double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64;
+                for (int k = 0; k < d; ++k) GV(h, k) = GV(theta_t, k);
+                GV(h, d) = L.ss1;
+            }
+            if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ballot;
+            if (E.record_s2) E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = L.sigma2;
+        }
+        if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
+    }
+    lane_store(E, tile, lane, L);
 }
 
 // end of an iteration: MCMC_run.F90:93-105 / MCMC_run_ram.F90:66-78
@@ -1306,7 +1480,58 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
         }
     }
 
-    if (__any(docalc)) {
+    if (E.usesvd) {
+        // MCMC_calculate_R, SVD branches (MCMC_adapt.F90:189-209): covtor_svd / scam_svd (matutils.F90:378-453, 583-653)
+        double *Gt = E.Gw + (size_t)tile * d * d * 64, *Vt = E.Vw + (size_t)tile * d * d * 64;
+        double *Rft = E.Rf + (size_t)tile * d * d * 64;
+        double *sv_t = E.cs + (size_t)tile * 2 * d * 64;
+        if (__any(docalc)) {
+            if (docalc) for (int j = 0; j < d; ++j) for (int i = 0; i < d; ++i)
+                GV(Gt, (size_t)j * d + i) = (i <= j) ? GV(Ct, pidx(i, j, d)) : GV(Ct, pidx(j, i, d));
+            symsvd_dev(Gt, Vt, sv_t, lane, d, docalc);
+            if (docalc) {
+                int info = 0;
+                const double s0 = GV(sv_t, 0);
+                if (s0 == 0.0) { info = d; TIDX(E.ictr, tile, NICTR, I_STATUS, lane) |= ST_CHOL_FAIL; }
+                else {
+                    const double tol = s0 / E.condmax;
+                    bool floored = false;
+                    if (GV(sv_t, d - 1) <= tol) {
+                        floored = true;
+                        for (int i = 0; i < d; ++i) if (GV(sv_t, i) < tol) GV(sv_t, i) = tol;
+                    }
+                    if (E.doscam) {                                   // R = U, qcovstd = sqrt(s)
+                        for (int e = 0; e < d * d; ++e) GV(Rft, e) = GV(Vt, e);
+                        double *std_t = E.qstd + (size_t)tile * d * 64;
+                        for (int i = 0; i < d; ++i) GV(std_t, i) = sqrt(GV(sv_t, i));
+                    } else {                                          // R0 = U diag(sqrt(s)); R = R0*2.4/sqrt(d)
+                        for (int i = 0; i < d; ++i) {
+                            const double sq = sqrt(GV(sv_t, i));
+                            for (int k = 0; k < d; ++k) GV(Vt, (size_t)i * d + k) = sq * GV(Vt, (size_t)i * d + k);
+                        }
+                        if (floored) {                                // cmat = matmul(R0, transpose(R0))
+                            for (int j = 0; j < d; ++j)
+                                for (int i = 0; i <= j; ++i) {
+                                    double acc = 0.0;
+                                    for (int k = 0; k < d; ++k) acc = dfma(GV(Vt, (size_t)k * d + i), GV(Vt, (size_t)k * d + j), acc);
+                                    GV(Ct, pidx(i, j, d)) = acc;
+                                }
+                        }
+                        const double sqd = sqrt((double)d);
+                        for (int e = 0; e < d * d; ++e) GV(Rft, e) = GV(Vt, e) * 2.4 / sqd;
+                        if (E.dodr) {                                 // iC = dpotri('u', R): on R's upper triangle; R2 = R/drscale
+                            double *iCt = E.iC + (size_t)tile * P * 64, *R2ft = E.R2f + (size_t)tile * d * d * 64;
+                            for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) GV(iCt, pidx(i, j, d)) = GV(Rft, (size_t)j * d + i);
+                            int info2 = potri_packed(iCt, lane, d, true, X);
+                            if (info2 != 0) TIDX(E.ictr, tile, NICTR, I_STATUS, lane) |= ST_POTRI_FAIL;
+                            for (int e = 0; e < d * d; ++e) GV(R2ft, e) = GV(Rft, e) / E.drscale;
+                        }
+                    }
+                }
+                TIDX(E.ictr, tile, NICTR, I_INFO, lane) = (uint32_t)info;
+            }
+        }
+    } else if (__any(docalc)) {
         if (docalc) for (int e = 0; e < P; ++e) GV(Tt, e) = GV(Ct, e);
         int info = calculate_R(Tt, Rt, lane, d, P, docalc, X);
         if (docalc) {

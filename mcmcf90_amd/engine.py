@@ -159,6 +159,11 @@ class Engine:
         self._chk(self.L.mcmcx_get_R(self.h, chain, a.ctypes.data_as(C.POINTER(C.c_double))))
         return np.array(a)
 
+    def qcovstd(self, chain=0):
+        a = np.zeros(self.npar)
+        self._chk(self.L.mcmcx_get_qcovstd(self.h, chain, _dp(a)))
+        return a
+
     def dr_state(self, chain=0):
         r2 = np.zeros((self.npar, self.npar), order="F"); ic = np.zeros((self.npar, self.npar), order="F")
         dp = C.POINTER(C.c_double)

@@ -65,9 +65,17 @@ def test_engine_matches_oracle_and_reference(oracle, name):
         assert (cnt["draccepted"], cnt["drtries"]) == (o.draccepted, o.drtries)
         if cfg.dodr:
             r2, ic = e.dr_state(c)
-            np.testing.assert_array_equal(_bits(np.triu(r2)), _bits(np.triu(o.R2)))
+            if cfg.usesvd:
+                np.testing.assert_array_equal(_bits(r2), _bits(o.R2))
+            else:
+                np.testing.assert_array_equal(_bits(np.triu(r2)), _bits(np.triu(o.R2)))
             np.testing.assert_array_equal(_bits(np.triu(ic)), _bits(np.triu(o.iC)))
-        np.testing.assert_array_equal(_bits(np.triu(e.R(c))), _bits(np.triu(o.R)))
+        if cfg.usesvd:                                   # full factor U sqrt(s) 2.4/sqrt(d), or U for scam
+            np.testing.assert_array_equal(_bits(e.R(c)), _bits(o.R))
+            if cfg.doscam:
+                np.testing.assert_array_equal(_bits(e.qcovstd(c)), _bits(o.qcovstd))
+        else:
+            np.testing.assert_array_equal(_bits(np.triu(e.R(c))), _bits(np.triu(o.R)))
         cm, mean, wsum = e.chaincov(c)
         np.testing.assert_array_equal(_bits(np.triu(cm)), _bits(np.triu(o.chaincmat)))
         np.testing.assert_array_equal(_bits(mean), _bits(o.chainmean))
@@ -98,7 +106,7 @@ def test_incremental_runs_equal_one_shot(oracle):
 def test_unsupported_and_bad_configs_fail_loudly():
     from mcmcf90_amd import make_config, Engine, McmcError
     with pytest.raises(McmcError):
-        Engine(make_config(2, 1, nsimu=10, method="scam"))
+        Engine(make_config(2, 1, nsimu=10, method="er"))
     with pytest.raises(McmcError):
         Engine(make_config(2, 1, nsimu=10, scalelimit=0.9))          # mcmcinit.F90:260-263
     with pytest.raises(McmcError):
