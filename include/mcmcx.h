@@ -40,7 +40,7 @@ extern "C" {
 #define MCMCX_METHOD_DRAM 0   /* method = 'dram' (AM / DRAM), mcmc_main.F90:35-36 */
 #define MCMCX_METHOD_RAM  1   /* method = 'ram',              mcmc_main.F90:33-34 */
 #define MCMCX_METHOD_SCAM 2   /* method = 'scam',             mcmc_main.F90:29-30 */
-#define MCMCX_METHOD_ER   3   /* not yet on the device: mcmcx_create fails */
+#define MCMCX_METHOD_ER   3   /* method = 'er',               mcmc_main.F90:31-32 */
 
 #define MCMCX_DEFAULT_SEED 0x6D636D63u
 
@@ -94,7 +94,8 @@ int mcmcx_run(mcmcx_handle h, int32_t upto);                   /* iterations sim
 int mcmcx_sync(mcmcx_handle h);
 
 int32_t mcmcx_simuind(mcmcx_handle h);
-/* counters[0..7] = stayed, bndstayed, draccepted, drtries, chainind, status, 0, 0 of one chain */
+/* counters[0..7] = stayed, bndstayed, draccepted, drtries, chainind, status bits, erstayed, run length of the
+ * current row, of one chain */
 int mcmcx_get_counters(mcmcx_handle h, int32_t chain, int32_t *counters8);
 /* sums over all chains: stayed, bndstayed, draccepted, drtries, proposals (stage 1 + stage 2) */
 int mcmcx_get_totals(mcmcx_handle h, int64_t *totals5);

@@ -421,9 +421,9 @@ int mcmcx_create(const mcmcx_config *cfg_in, mcmcx_handle *out)
     if (c.scalelimit < 0.0 || c.scalelimit > 0.5)
         return fail(-2, "ERROR: Scalelimit control variable should be between [0,0.5]");
     if (c.scalefactor < 0.0) c.scalefactor = 1.0;
-    if (c.method == MCMCX_METHOD_ER)
-        return fail(-3, "method 'er' is not available in the device engine yet");
-    if (c.method != MCMCX_METHOD_DRAM && c.method != MCMCX_METHOD_RAM && c.method != MCMCX_METHOD_SCAM) return fail(-3, "unknown method");
+    if (c.method != MCMCX_METHOD_DRAM && c.method != MCMCX_METHOD_RAM && c.method != MCMCX_METHOD_SCAM &&
+        c.method != MCMCX_METHOD_ER) return fail(-3, "unknown method");
+    if (c.method == MCMCX_METHOD_ER) c.drscale = 0.0;                                // 'no dr with er', MCMC_run_er.F90:26-29
     if (c.method == MCMCX_METHOD_SCAM) {                                             // mcmcinit.F90:321-330
         if (c.condmax <= 0.0) c.condmax = 1.0e15;
         c.doburnin = 0; c.drscale = 0.0;
@@ -554,6 +554,7 @@ int mcmcx_init(mcmcx_handle h)
     }
     if (!h->sigma2ok) { h->sigma2 = 1.0; h->nobs = 1; }                               // MCMC_init.F90:52-59
     if (h->tkind < 0) return fail(-31, "no target: the device engine needs mcmcx_set_target_*");
+    if (h->tkind == TGT_HOST && c.method == MCMCX_METHOD_ER) return fail(-31, "host-callback targets are not available with method='er'");
     if (h->tkind == TGT_HOST && h->usesvd) return fail(-31, "host-callback targets are not available with condmax > 0 / method='scam'");
     std::vector<double> Rp, Cp, Rfull, qstd0;
     int info = host_initial_R(d, h->cmat0, Rp, Cp);
@@ -568,7 +569,7 @@ int mcmcx_init(mcmcx_handle h)
 
     EngineDev &E = h->E;
     E.d = d; E.P = P; E.ntiles = T;
-    E.method = (c.method == MCMCX_METHOD_RAM) ? M_RAM : M_DRAM;
+    E.method = (c.method == MCMCX_METHOD_RAM) ? M_RAM : (c.method == MCMCX_METHOD_ER ? M_ER : M_DRAM);
     E.usesvd = h->usesvd; E.doscam = (c.method == MCMCX_METHOD_SCAM) ? 1 : 0; E.condmax = c.condmax;
     E.Rf = E.R2f = E.qstd = E.Gw = E.Vw = nullptr;
     E.greedy = c.greedy; E.adapthist = c.adapthist; E.initcmatn = (double)c.initcmatn;
@@ -806,7 +807,7 @@ int mcmcx_get_counters(mcmcx_handle h, int32_t chain, int32_t *out)
     std::vector<uint32_t> v;
     if ((rc = fetch_chain_vec(h, h->E.ictr, NICTR, chain, v))) return rc;
     out[0] = (int32_t)v[I_STAYED]; out[1] = (int32_t)v[I_BNDSTAYED]; out[2] = (int32_t)v[I_DRACC]; out[3] = (int32_t)v[I_DRTRIES];
-    out[4] = (int32_t)v[I_CHAININD]; out[5] = (int32_t)v[I_STATUS]; out[6] = (int32_t)v[I_INFO]; out[7] = (int32_t)v[I_CURCOUNT];
+    out[4] = (int32_t)v[I_CHAININD]; out[5] = (int32_t)v[I_STATUS]; out[6] = (int32_t)v[I_ERSTAYED]; out[7] = (int32_t)v[I_CURCOUNT];
     return 0;
 }
 

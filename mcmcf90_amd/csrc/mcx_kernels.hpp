@@ -16,13 +16,13 @@
 namespace mcx {
 
 enum { TGT_GAUSS = 0, TGT_BANANA = 1, TGT_EXPDATA = 2, TGT_HOST = 3 };
-enum { M_DRAM = 0, M_RAM = 1 };
+enum { M_DRAM = 0, M_RAM = 1, M_ER = 3 };
 
 // per-chain scalar slots (doubles)
 enum { S_SS1 = 0, S_PRI1, S_SIGMA2, S_ALPHA12, S_SAVEDY, S_WSUM, NSCAL };
 // per-chain integer slots (u32)
 enum { I_SAVED = 0, I_STAYED, I_BNDSTAYED, I_DRACC, I_DRTRIES, I_CHAININD, I_CURCOUNT, I_STATUS,
-       I_LASTFREQ, I_BASECNT, I_WINSTART, I_INFO, NICTR };
+       I_LASTFREQ, I_BASECNT, I_WINSTART, I_INFO, I_ERSTAYED, NICTR };
 
 // status bits
 enum { ST_RAM_DOWNDATE_FAIL = 1, ST_CHOL_FAIL = 2, ST_POTRI_FAIL = 4 };
@@ -705,6 +705,7 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
     uint32_t chainind = TIDX(E.ictr, tile, NICTR, I_CHAININD, lane), curcount = TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane);
     uint32_t status = TIDX(E.ictr, tile, NICTR, I_STATUS, lane);
     uint32_t dracc = TIDX(E.ictr, tile, NICTR, I_DRACC, lane), drtries = TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane);
+    uint32_t erstayed = TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane);
 
     bool have_p = false;                          // lanes whose candidate is already in cand_t
     double su_c = gen_normals(g, zs_t + (size_t)(it0 & 1) * d * 64, lane, d, true), su_n = 0.0;
@@ -721,7 +722,15 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
         double pri2 = target_prior(E.tgt, d, lane, cand_t);
         double ss2 = target_ss<RAM>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
         bool reject;
-        if (!inb) {
+        if (!RAM && !DR && E.method == M_ER) {            // early rejection, MCMC_run_er.F90:60-89
+            if (!inb) { bnd += 1; reject = true; }
+            else {
+                double u = rng_uniform(g);                // MCMC_sscrit, MCMC_DRAM.F90:124-135: always drawn
+                double sscrit = -2.0 * d_log(u) + ss1 / sigma2 + pri1;
+                if (pri2 >= sscrit) { reject = true; erstayed += 1; }
+                else { sscrit = sigma2 * (sscrit - pri2); reject = (ss2 >= sscrit); }
+            }
+        } else if (!inb) {
             if (!DR) bnd += 1;                            // MCMC_run.F90:49
             reject = true;
             if (!RAM) alpha12 = 0.0;                      // RAM leaves alpha12 stale: MCMC_run_ram.F90:52-54
@@ -812,6 +821,7 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
     TIDX(E.ictr, tile, NICTR, I_CHAININD, lane) = chainind; TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane) = curcount;
     TIDX(E.ictr, tile, NICTR, I_STATUS, lane) = status;
     TIDX(E.ictr, tile, NICTR, I_DRACC, lane) = dracc; TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane) = drtries;
+    TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane) = erstayed;
 }
 
 // ---------------------------------------------------------------- host-callback targets

@@ -132,7 +132,7 @@ class Engine:
         a = np.zeros(8, dtype=np.int32)
         self._chk(self.L.mcmcx_get_counters(self.h, chain, a.ctypes.data_as(C.POINTER(C.c_int32))))
         return dict(stayed=int(a[0]), bndstayed=int(a[1]), draccepted=int(a[2]), drtries=int(a[3]),
-                    chainind=int(a[4]), status=int(a[5]), info=int(a[6]), curcount=int(a[7]))
+                    chainind=int(a[4]), status=int(a[5]), erstayed=int(a[6]), curcount=int(a[7]))
 
     def totals(self):
         a = np.zeros(5, dtype=np.int64)

@@ -80,6 +80,12 @@ def cases():
     c["e5_gauss17_am_short"] = (dict(nsimu=99, adaptint=100, updatesigma=0),                                # never reaches an adaptation; odd npar
                                 dict(kind="gauss", npar=17, par0=np.linspace(-1, 1, 17), cmat0=0.05 * np.eye(17),
                                      mu=np.zeros(17), lam=corr_gauss(17, 0.3)), 23)
+    c["e6_expdata_er_priors"] = (dict(nsimu=3000, method="er", adaptint=100, updatesigma=1),               # early rejection
+                                 dict(kind="expdata", npar=2, par0=[10, 0.1], cmat0=[[0.2, 0], [0, 0.001]], sigma2=0.5,
+                                      nobs=11, xdata=XDATA, ydata=YDATA, lo=[0, 0], pri_mu=[9.0, 0.1], pri_sig=[0.5, 0.02]), 41)
+    c["e7_gauss10_er"] = (dict(nsimu=2000, method="er", adaptint=100, updatesigma=0),
+                          dict(kind="gauss", npar=10, par0=np.zeros(10), cmat0=0.01 * np.eye(10), mu=np.zeros(10),
+                               lam=np.eye(10)), 42)
     # --- SVD paths: the reference is linked with the pinned Jacobi dgesvd (oracle/ref/dgesvd_shim.c), see mcx_svd.h
     d = 6
     Sg = 0.6 ** np.abs(np.subtract.outer(np.arange(d), np.arange(d))) * np.outer(np.logspace(0, 1.5, d), np.logspace(0, 1.5, d))

@@ -64,6 +64,7 @@ int mcxo_cfg_check(mcxo_cfg *c)
         c->doburnin = 0; c->drscale = 0.0;
     } else c->doscam = 0;
     if (c->method == MCXO_METHOD_RAM) c->drscale = 0.0;
+    if (c->method == MCXO_METHOD_ER) c->drscale = 0.0;          /* 'no dr with er', MCMC_run_er.F90:26-29 */
     c->dodr = (c->drscale > 0.0);
     c->usesvd = (c->condmax > 0.0);
     return 0;
@@ -686,7 +687,6 @@ int mcxo_chain_run(mcxo_chain *c, int upto)
 {
     const mcxo_cfg *g = &c->cfg;
     int n = c->npar;
-    if (g->method == MCXO_METHOD_ER) return -1000;
     if (upto > g->nsimu) upto = g->nsimu;
     double *newpar = (double *)malloc(sizeof(double) * (size_t)n * 6);
     double *newpar2 = newpar + n, *z = newpar + 2 * n, *work = newpar + 3 * n;
@@ -726,6 +726,32 @@ int mcxo_chain_run(mcxo_chain *c, int upto)
             reject = rejall;
             c->alpha_trace[i - 1] = c->alpha12;
             if (reject) c->stayed++;
+            c->accepted[i - 1] = (uint8_t)!reject;
+            updatesigma2(c, c->ss1);
+            savechain(c, c->oldpar, c->ss1, reject);
+            rc = adapt(c, i);
+            if (rc != 0) break;
+            continue;
+        }
+        if (g->method == MCXO_METHOD_ER) {                          /* MCMC_run_er.F90:46-104 */
+            propose(c, c->oldpar, c->R, newpar, NULL);
+            c->nprop++;
+            inb = mcxo_checkbounds(&c->tgt, newpar);
+            if (!inb) { c->bndstayed++; reject = 1; }
+            else {
+                double u = mcxo_uniform(&c->rng);                    /* MCMC_sscrit, MCMC_DRAM.F90:124-135 */
+                double sscrit = -2.0 * mcxm_log(u) + c->ss1 / c->sigma2 + c->sspri1;
+                pri2 = mcxo_priorfun(&c->tgt, newpar);
+                if (pri2 >= sscrit) { reject = 1; c->erstayed++; }
+                else {
+                    sscrit = c->sigma2 * (sscrit - pri2);
+                    ss2 = mcxo_ssfun(&c->tgt, newpar);               /* default ssfunction_er: no early exit */
+                    reject = (ss2 >= sscrit) ? 1 : 0;
+                }
+            }
+            c->alpha_trace[i - 1] = c->alpha12;
+            if (reject) c->stayed++;
+            else { c->ss1 = ss2; c->sspri1 = pri2; memcpy(c->oldpar, newpar, sizeof(double) * n); }
             c->accepted[i - 1] = (uint8_t)!reject;
             updatesigma2(c, c->ss1);
             savechain(c, c->oldpar, c->ss1, reject);

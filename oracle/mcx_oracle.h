@@ -80,6 +80,7 @@ typedef struct mcxo_chain {
      * untouched, which is what the multi-chain engine does (one bad chain must not end a million-chain run) */
     int continue_on_downdate_fail;
     double *qcovstd;                      /* SCAM: sqrt of the singular values (mcmc.F90:37) */
+    int erstayed;                         /* early rejection on the prior (mcmc.F90:48) */
 } mcxo_chain;
 
 mcxo_chain *mcxo_chain_create(const mcxo_cfg *cfg, const mcxo_target *tgt, const double *par0,

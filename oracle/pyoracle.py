@@ -53,7 +53,7 @@ class Chain(C.Structure):
                 ("ad_istart", C.c_int), ("ad_istartind", C.c_int), ("ad_lastind", C.c_int), ("ad_lastfreq", C.c_int),
                 ("info_last", C.c_int), ("ram_downdate_fail", C.c_int),
                 ("oldpar", _DP), ("ss1", C.c_double), ("sspri1", C.c_double), ("alpha12", C.c_double),
-                ("continue_on_downdate_fail", C.c_int), ("qcovstd", _DP)]
+                ("continue_on_downdate_fail", C.c_int), ("qcovstd", _DP), ("erstayed", C.c_int)]
 
 
 _lib = None
@@ -190,6 +190,7 @@ def run_chain(cfg, prob, seed=0x6D636D63, chain_id=0, upto=None, continue_on_dow
         r.ss1, r.sspri1 = c.ss1, c.sspri1
         r.stayed, r.bndstayed, r.draccepted, r.drtries = c.stayed, c.bndstayed, c.draccepted, c.drtries
         r.nprop = c.nprop
+        r.erstayed = c.erstayed
         r.rng_n = c.rng.n
         r.rng_saved, r.rng_saved_y = c.rng.saved, c.rng.saved_y
         r.ram_downdate_fail = c.ram_downdate_fail

@@ -62,7 +62,7 @@ def test_engine_matches_oracle_and_reference(oracle, name):
         assert (n, saved) == (o.rng_n, o.rng_saved)
         cnt = e.counters(c)
         assert (cnt["stayed"], cnt["bndstayed"], cnt["chainind"]) == (o.stayed, o.bndstayed, o.chainind)
-        assert (cnt["draccepted"], cnt["drtries"]) == (o.draccepted, o.drtries)
+        assert (cnt["draccepted"], cnt["drtries"], cnt["erstayed"]) == (o.draccepted, o.drtries, o.erstayed)
         if cfg.dodr:
             r2, ic = e.dr_state(c)
             if cfg.usesvd:
@@ -106,7 +106,7 @@ def test_incremental_runs_equal_one_shot(oracle):
 def test_unsupported_and_bad_configs_fail_loudly():
     from mcmcf90_amd import make_config, Engine, McmcError
     with pytest.raises(McmcError):
-        Engine(make_config(2, 1, nsimu=10, method="er"))
+        Engine(make_config(2, 1, nsimu=10, method=7))
     with pytest.raises(McmcError):
         Engine(make_config(2, 1, nsimu=10, scalelimit=0.9))          # mcmcinit.F90:260-263
     with pytest.raises(McmcError):
