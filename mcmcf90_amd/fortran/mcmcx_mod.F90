@@ -678,17 +678,65 @@ contains
     sigma2(1) = sc(3)
   end subroutine MCMC_engine_run
 
-  !! MCMC_writechains, MCMC_aux.F90:17-85 (ASCII branch)
+  !! MAT-v4 file like writemat4_mat (matfiles.F90:66-126): 5 x int32 header (type 0, mrows, ncols, imagf 0, namelen),
+  !! the name with a trailing NUL, the data column by column as 8-byte reals
+  subroutine writemat4(file, a, aname)
+    character(len=*), intent(in) :: file, aname
+    real(kind=dbl), intent(in) :: a(:,:)
+    integer :: u
+    open(newunit=u, file=file, status='replace', form='unformatted', access='stream')
+    write(u) 0_4, int(size(a,1),4), int(size(a,2),4), 0_4, int(len_trim(aname)+1,4)
+    write(u) trim(aname)//achar(0)
+    write(u) a
+    close(u)
+  end subroutine writemat4
+
+  logical function ismat(file)
+    character(len=*), intent(in) :: file
+    integer :: n
+    n = len_trim(file)
+    ismat = .false.
+    if (n >= 4) ismat = (file(n-3:n) == '.mat')
+  end function ismat
+
+  !! MCMC_writechains, MCMC_aux.F90:17-85
   subroutine MCMC_writechains()
-    call writenumbers(chainfile, chain(1:chainind,:))
-    call writenumbers(ssfile, sschain(1:chainind,:))
-    if (updatesigma /= 0) call writenumbers(s2file, s2chain(1:simuind,:))
+    integer :: u
+    if (ismat(chainfile)) then
+       call writemat4(chainfile, chain(1:chainind,:), 'chain')
+    else
+       call writenumbers(chainfile, chain(1:chainind,:))
+    end if
+    if (ismat(ssfile)) then
+       call writemat4(ssfile, sschain(1:chainind,:), 'sschain')
+    else
+       call writenumbers(ssfile, sschain(1:chainind,:))
+    end if
+    if (updatesigma /= 0) then
+       if (ismat(s2file)) then
+          call writemat4(s2file, s2chain(1:simuind,:), 's2chain')
+       else
+          call writenumbers(s2file, s2chain(1:simuind,:))
+       end if
+    end if
+    if (len_trim(covnfile) > 0) then                    ! MCMC_aux.F90:48-52
+       initcmatn = int(chainwsum)
+       call writenumbers(covnfile, reshape((/dble(initcmatn)/), (/1,1/)))
+    end if
     call writenumbers(covffile, chaincmat)
     call writenumbers(meanfile, reshape(chainmean, (/npar, 1/)))
     call writenumbers(parffile, chain(chainind:chainind, 1:npar))
     if (updatesigma /= 0) call writenumbers(sigma2ffile, &
          reshape((/s2chain(simuind,1), dble(nobs(1))/), (/2, 1/)))
     if (verbosity > 0) write(*,*) 'note: saved results in ', trim(chainfile), ' and ', trim(ssfile), '.'
+    !! restart namelist, MCMC_aux.F90:78-83
+    initcmatn = initcmatn + simuind
+    burnintime = 0
+    if (len_trim(nmlffile) > 0) then
+       open(newunit=u, file=nmlffile, status='replace', delim='APOSTROPHE')
+       write(u, nml=mcmc)
+       close(u)
+    end if
   end subroutine MCMC_writechains
 
   subroutine MCMC_cleanup()

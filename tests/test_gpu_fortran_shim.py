@@ -100,3 +100,36 @@ def test_unmodified_user_program_with_fortran_callbacks(oracle):
     k = z["rows_head"].shape[0]
     np.testing.assert_allclose(chain[-k:, :-1], z["rows_tail"], rtol=1e-9)
     np.testing.assert_allclose(s2[-k:], z["s2_tail"], rtol=1e-9)
+
+
+def test_mat4_output_and_restart_namelist(oracle):
+    """chainfile='chain.mat' selects the MAT-v4 writer (MCMC_aux.F90:25-29, matfiles.F90:66-126) and nmlffile the restart
+    namelist with initcmatn += nsimu, burnintime = 0 (MCMC_aux.F90:78-83)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle.refrun import read_mat4
+    exe = os.path.join(FDIR, "demo_main")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", FDIR])
+    z, cfg, prob = load("c1_shipped_nml", oracle)
+    nml = NML.replace("chainfile   = 'chain.dat'", "chainfile   = 'chain.mat'").replace("s2file      = 's2chain.dat'", "s2file = 's2chain.mat'\n nmlffile = 'mcmcinitf.nml'\n covnfile = 'mcmccovn.dat'")
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "mcmcinit.nml"), "w").write(nml)
+        with open(os.path.join(d, "data.dat"), "w") as f:
+            for x, y in zip(z["prob_xdata"], z["prob_ydata"]):
+                f.write("  %g   %.2f\n" % (x, y))
+        open(os.path.join(d, "mcmcpar.dat"), "w").write("10 0.1 \n")
+        open(os.path.join(d, "mcmccov.dat"), "w").write("0.2 0 \n0 0.001 \n")
+        open(os.path.join(d, "mcmcsigma2.dat"), "w").write("0.5\n11\n")
+        open(os.path.join(d, "lower.dat"), "w").write("0 0\n")
+        p = subprocess.run([exe], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert p.returncode == 0, p.stdout.decode(errors="replace")
+        chain = read_mat4(os.path.join(d, "chain.mat"))["chain"]
+        s2 = read_mat4(os.path.join(d, "s2chain.mat"))["s2chain"][:, 0]
+        restart = open(os.path.join(d, "mcmcinitf.nml")).read().upper()
+    o = oracle.run_chain(cfg, prob, chain_id=0)
+    np.testing.assert_array_equal(chain, o.chain)
+    np.testing.assert_array_equal(s2, o.s2chain)
+    np.testing.assert_array_equal(chain[:, -1].astype(np.int32), z["runlen"])
+    import re
+    assert re.search(r"INITCMATN\s*=\s*1000", restart) and re.search(r"BURNINTIME\s*=\s*0\b", restart)
