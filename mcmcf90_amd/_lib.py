@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIBPATH = os.path.join(HERE, "libmcmcx.so")
+LIBPATH = os.environ.get("MCMCX_LIBRARY") or os.path.join(HERE, "libmcmcx.so")      # override: profiling / debug builds
 
 _DP = C.POINTER(C.c_double)
 _IP = C.POINTER(C.c_int32)

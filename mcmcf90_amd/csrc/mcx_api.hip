@@ -43,6 +43,8 @@ struct mcmcx_engine {
     std::vector<double> h_cand, h_ev;
     // pooled mode
     int pooled = 0; double pool_W = 0.0; std::vector<double> pool_mean, pool_C, pool_R;   // packed upper, row-major
+    std::vector<double> pool_U, pool_std;             // pooled SCAM: the shared rotation (column-major) and qcovstd
+    double *d_sharedU = nullptr;                      // [U col-major | pad | U row-major | pad | std]
     double *d_sharedR = nullptr; mcmcx_exchange_t xfn = nullptr; void *xuser = nullptr; double *xbuf = nullptr;
     double S02eff = 0.0;
     // device
@@ -221,8 +223,29 @@ static void launch_step(mcmcx_engine *h, int it0, int it1)
     else if (h->pooled) hipLaunchKernelGGL((step_kernel<false, false, true>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else hipLaunchKernelGGL((step_kernel<false, false, false>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
 }
+static size_t shared_u_stride(const mcmcx_engine *h) { return (size_t)((h->d + 3) & ~3) * h->d + PWS; }     // d4 rows (pad rows zero) + slack
+static int upload_shared_u(mcmcx_engine *h)
+{
+    const int d = h->d; const size_t st = shared_u_stride(h);
+    std::vector<double> b(2 * st + d, 0.0);
+    for (int j = 0; j < d; ++j) for (int i = 0; i < d; ++i) { b[(size_t)j * d + i] = h->pool_U[(size_t)j * d + i]; b[st + (size_t)i * d + j] = h->pool_U[(size_t)j * d + i]; }
+    for (int i = 0; i < d; ++i) b[2 * st + i] = h->pool_std[i];
+    HIPCHK(hipMemcpyAsync(h->d_sharedU, b.data(), b.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
 static void launch_scam(mcmcx_engine *h, int it0, int it1)
-{ hipLaunchKernelGGL(scam_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT); }
+{
+    if (h->pooled) {
+        const size_t st = shared_u_stride(h);
+        const int nt = (h->d + 15) / 16;                   // 16-output tiles; 4 chain-group waves + up to 12 whole-tile waves
+        int nw = 4 + std::min(12, nt & ~3); if (const char *e = getenv("MCMCX_SCAM_NW")) nw = atoi(e);
+        hipLaunchKernelGGL(scam_pooled_kernel, dim3(h->ntiles), dim3(64 * nw), ((size_t)((h->d + 3) & ~3) * 64 + 128) * sizeof(double), h->stream, h->E, it0, it1,
+                           h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedU, h->d_sharedU + st, h->d_sharedU + 2 * st);
+        return;
+    }
+    hipLaunchKernelGGL(scam_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
+}
 static void launch_adapt(mcmcx_engine *h, int it, int mode)
 { hipLaunchKernelGGL(adapt_kernel, dim3(h->ntiles), dim3(64), lds_bytes(h) / 2, h->stream, h->E, it, mode); }   // one d-vector
 
@@ -331,6 +354,11 @@ static int pooled_adapt(mcmcx_engine *h, int it)
     // MCMC_calculate_R: dpotf2 + 2.4/sqrt(d); on failure keep the old factor (MCMC_adapt.F90:168-171)
     std::vector<double> cm((size_t)d * d, 0.0), Rp, Cp;
     for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) cm[(size_t)i + (size_t)j * d] = h->pool_C[h_pidx(i, j, d)];
+    if (c.method == MCMCX_METHOD_SCAM) {                // scam_svd of the pooled covariance, MCMC_adapt.F90:189-200
+        std::vector<double> U, sd;
+        if (host_initial_svd(d, cm, c.condmax, true, U, sd) == 0) { h->pool_U = U; h->pool_std = sd; return upload_shared_u(h); }
+        return 0;
+    }
     if (host_initial_R(d, cm, Rp, Cp) == 0) {
         h->pool_R = Rp;
         HIPCHK(hipMemcpyAsync(h->d_sharedR, h->pool_R.data(), (size_t)P * 8, hipMemcpyHostToDevice, h->stream));
@@ -437,8 +465,9 @@ int mcmcx_create(const mcmcx_config *cfg_in, mcmcx_handle *out)
         if (c.adaptint == 0) return fail(-7, "doadapt with adaptint = 0");
     }
     if (c.pooled) {
-        if (c.method != MCMCX_METHOD_DRAM || c.drscale > 0.0 || c.doburnin != 0 || c.adapthist > 1 || c.greedy != 0 || c.condmax > 0.0)
-            return fail(-8, "pooled mode supports method='dram' with doburnin=0, drscale=0, adapthist<=1, condmax=0");
+        const bool scam = (c.method == MCMCX_METHOD_SCAM);
+        if ((c.method != MCMCX_METHOD_DRAM && !scam) || c.drscale > 0.0 || c.doburnin != 0 || c.adapthist > 1 || c.greedy != 0 || (!scam && c.condmax > 0.0))
+            return fail(-8, "pooled mode supports method='dram' (condmax=0) or 'scam', with doburnin=0, drscale=0, adapthist<=1, greedy=0");
     }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -584,7 +613,7 @@ int mcmcx_init(mcmcx_handle h)
     E.tgt.lamT = nullptr;
     if (h->tkind == TGT_GAUSS) {
         if ((rc = dev_upload(h, &E.tgt.mu, h->tmu))) return rc;
-        std::vector<double> lt((size_t)d * d + 64, 0.0);           // transpose, padded for the 16-wide panel reads
+        std::vector<double> lt((size_t)(d + 4) * d + 64, 0.0);     // transpose; zero pad rows + slack for the panel / MFMA tile reads
         for (int i = 0; i < d; ++i) for (int j = 0; j < d; ++j) lt[(size_t)j * d + i] = h->tlam[(size_t)i * d + j];
         if ((rc = dev_upload(h, &E.tgt.lamT, lt))) return rc;
     }
@@ -604,9 +633,14 @@ int mcmcx_init(mcmcx_handle h)
     if ((rc = dev_alloc(h, &E.scal, L * NSCAL))) return rc;
     if ((rc = dev_alloc(h, &E.ictr, L * NICTR))) return rc;
     if ((rc = dev_alloc(h, &E.rngn, L))) return rc;
-    if ((rc = dev_alloc(h, &E.R, L * P, false))) return rc;
+    E.R = nullptr;
+    if (!h->pooled && (rc = dev_alloc(h, &E.R, L * P, false))) return rc;          // pooled: one shared factor instead
     if ((rc = dev_alloc(h, &E.basetheta, L * d))) return rc;
-    if (h->usesvd) {
+    if (h->usesvd && h->pooled) {                       // pooled SCAM: one rotation for every chain
+        if ((rc = dev_alloc(h, &h->d_sharedU, 2 * shared_u_stride(h) + d, false))) return rc;
+        h->pool_U = Rfull; h->pool_std = qstd0;
+        if ((rc = upload_shared_u(h))) return rc;
+    } else if (h->usesvd) {
         const size_t DD = (size_t)d * d;
         if ((rc = dev_alloc(h, &E.Rf, L * DD, false))) return rc;
         if ((rc = dev_alloc(h, &E.Gw, L * DD))) return rc;
@@ -655,6 +689,7 @@ int mcmcx_init(mcmcx_handle h)
     E.sharedR = nullptr;
     if (h->pooled) {
         if (h->tkind == TGT_HOST) return fail(-8, "pooled mode needs a device-resident target");
+        if ((size_t)(d + 3) * 64 * sizeof(double) > 160 * 1024 - 2048 && c.method == MCMCX_METHOD_SCAM) return fail(-8, "pooled scam: npar too large for the LDS input vector");
         if ((rc = dev_alloc(h, &h->d_sharedR, (size_t)P, false))) return rc;
         HIPCHK(hipMemcpy(h->d_sharedR, Rp.data(), (size_t)P * 8, hipMemcpyHostToDevice));
         E.sharedR = h->d_sharedR;
@@ -679,11 +714,11 @@ int mcmcx_init(mcmcx_handle h)
 
     // fill theta = par0, R = R(cmat0), chaincmat = cmat0, chainmean = par0, scalars
     {
-        std::vector<double> th(L * d), Rv(L * P), sc(L * NSCAL, 0.0);
+        std::vector<double> th(L * d), Rv(h->pooled ? 0 : L * P), sc(L * NSCAL, 0.0);
         std::vector<uint32_t> ic(L * NICTR, 0u);
         for (int t = 0; t < T; ++t) {
             for (int k = 0; k < d; ++k) for (int l = 0; l < 64; ++l) th[((size_t)t * d + k) * 64 + l] = h->par0[k];
-            for (int e = 0; e < P; ++e) for (int l = 0; l < 64; ++l) Rv[((size_t)t * P + e) * 64 + l] = Rp[e];
+            if (!h->pooled) for (int e = 0; e < P; ++e) for (int l = 0; l < 64; ++l) Rv[((size_t)t * P + e) * 64 + l] = Rp[e];
             for (int l = 0; l < 64; ++l) {
                 sc[((size_t)t * NSCAL + S_SIGMA2) * 64 + l] = h->sigma2;
                 sc[((size_t)t * NSCAL + S_WSUM) * 64 + l] = (double)c.initcmatn;
@@ -694,7 +729,7 @@ int mcmcx_init(mcmcx_handle h)
             }
         }
         HIPCHK(hipMemcpyAsync(E.theta, th.data(), th.size() * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(E.R, Rv.data(), Rv.size() * 8, hipMemcpyHostToDevice, h->stream));
+        if (!h->pooled) HIPCHK(hipMemcpyAsync(E.R, Rv.data(), Rv.size() * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(E.scal, sc.data(), sc.size() * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(E.ictr, ic.data(), ic.size() * 4, hipMemcpyHostToDevice, h->stream));
         if (h->dodr) {                                   // iC = dpotri(R), R2 = R/drscale, MCMC_adapt.F90:216-225
@@ -864,6 +899,8 @@ int mcmcx_get_R(mcmcx_handle h, int32_t chain, double *R)
 {
     int rc = check_chain(h, chain); if (rc) return rc;
     std::vector<double> p;
+    if (h->pooled && h->usesvd) { memcpy(R, h->pool_U.data(), sizeof(double) * h->pool_U.size()); return 0; }
+    if (h->pooled) { unpack_upper(h->d, h->pool_R, R, false); return 0; }
     if (h->usesvd) {                                     // full column-major factor
         if ((rc = fetch_chain_vec(h, h->E.Rf, h->d * h->d, chain, p))) return rc;
         memcpy(R, p.data(), sizeof(double) * p.size());
@@ -877,6 +914,7 @@ int mcmcx_get_R(mcmcx_handle h, int32_t chain, double *R)
 int mcmcx_get_qcovstd(mcmcx_handle h, int32_t chain, double *std)
 {
     int rc = check_chain(h, chain); if (rc) return rc;
+    if (h->pooled && h->usesvd) { memcpy(std, h->pool_std.data(), sizeof(double) * h->pool_std.size()); return 0; }
     if (!h->E.qstd) return fail(-45, "no SVD state (condmax = 0)");
     std::vector<double> p;
     if ((rc = fetch_chain_vec(h, h->E.qstd, h->d, chain, p))) return rc;
@@ -1014,7 +1052,8 @@ int mcmcx_get_pooled(mcmcx_handle h, double *cmat, double *mean, double *wsum, d
     if (cmat) unpack_upper(h->d, h->pool_C, cmat, true);
     if (mean) memcpy(mean, h->pool_mean.data(), sizeof(double) * (size_t)h->d);
     if (wsum) *wsum = h->pool_W;
-    if (R) unpack_upper(h->d, h->pool_R, R, false);
+    if (R && h->usesvd) memcpy(R, h->pool_U.data(), sizeof(double) * h->pool_U.size());    // scam: the rotation U, column-major
+    else if (R) unpack_upper(h->d, h->pool_R, R, false);
     return 0;
 }
 

@@ -924,6 +924,201 @@ __global__ __launch_bounds__(64, 2) void scam_kernel(EngineDev E, int it0, int i
     lane_store(E, tile, lane, L);
 }
 
+// ---------------------------------------------------------------- pooled SCAM: one rotation shared by all chains
+// out_o = sum_s M[s*d + o] X[s] for every output o and the 64 chains of a tile, s ascending, one fma chain per
+// (output, chain) -- the order of gemvT_panels / gemvN_panels / the Gaussian ss rows -- on the matrix cores:
+// v_mfma_f64_16x16x4_f64 accumulates its four products as an ascending fma chain (checked bit for bit on gfx950,
+// tools/mfma_f64_probe.hip), so D = A B + D repeated over blocks of four s IS that chain.  A = M' (16 outputs x
+// 4 s, straight from the shared table, L2-resident), B = X (4 s x 16 chains, from the workgroup's LDS vector).
+// X has d4 = 4*ceil(d/4) rows, the pad rows zero; M has d4 rows (pad rows zero) and PWS doubles of slack.
+//
+// Work split over the nw waves of a workgroup (wave w runs on SIMD w mod 4): the first 4*(nt/4) output tiles go
+// whole (four accumulators = the four 16-chain groups) to the nw-4 "tile waves" round robin; each of the nt mod 4
+// leftover tiles is cut into its four chain groups, one for each of the last four waves -- so every SIMD gets the
+// same number of MFMAs.  With nw == 4 there are no tile waves and everything goes by chain group.
+constexpr int PWS = 16;
+typedef double mcx_d4 __attribute__((ext_vector_type(4)));
+template <int NG>   // NG = 4: a whole tile; NG = 1: chain group g0 only
+MCX_DEV void mfma_tile(const double *__restrict__ M, const double *X, double *out_t, int lane, int d, int d4, int o0, int g0)
+{
+    const int li = lane & 15, lk = lane >> 4;
+    mcx_d4 c[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) c[g] = mcx_d4{0.0, 0.0, 0.0, 0.0};
+    const double *__restrict__ ap = M + (size_t)lk * d + o0 + li;
+    const double *xp = X + lk * 64 + li + 16 * g0;
+    int s0 = 0;
+    for (; s0 + 16 <= d4; s0 += 16) {                   // four k-blocks per trip: the four A loads go out together
+        double a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = ap[(size_t)(s0 + 4 * u) * d];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double *xq = xp + (s0 + 4 * u) * 64;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) c[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], xq[16 * g], c[g], 0, 0, 0);
+        }
+    }
+    for (; s0 < d4; s0 += 4) {
+        const double a = ap[(size_t)s0 * d];
+        const double *xq = xp + s0 * 64;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) c[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xq[16 * g], c[g], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                       // C/D: row = (lane>>4) + 4r, col = lane&15
+        const int o = o0 + lk + 4 * r;
+        if (o < d) {
+            double *op = out_t + (size_t)o * 64 + li + 16 * g0;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) op[16 * g] = c[g][r];
+        }
+    }
+}
+MCX_DEV void mfma_gemv(const double *__restrict__ M, const double *X, double *out_t, int lane, int d, int d4, int w, int nw)
+{
+    const int nt = (d + 15) >> 4, ntw = nw - 4;
+    const int nfull = ntw > 0 ? (nt & ~3) : 0;
+    if (w < ntw) { for (int t = w; t < nfull; t += ntw) mfma_tile<4>(M, X, out_t, lane, d, d4, t * 16, 0); }
+    else { for (int t = nfull; t < nt; ++t) mfma_tile<1>(M, X, out_t, lane, d, d4, t * 16, w - ntw); }
+}
+
+// X[k] = f(k, src[k]) (or dst[k] = src[k]) for the rows k = w, w+nw, ... < d of a tile-interleaved vector, 16 loads in
+// flight per wave
+template <typename F>
+MCX_DEV void rows_apply(const double *src_t, int lane, int d, int w, int nw, F &&f)
+{
+    for (int k0 = w; k0 < d; k0 += 16 * nw) {
+        double r[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { int k = k0 + u * nw; r[u] = GV(src_t, k < d ? k : k0); }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { int k = k0 + u * nw; if (k < d) f(k, r[u]); }
+    }
+}
+
+// MCMC_run_scam with ONE rotation U (and one qcovstd) for every chain of the node (pooled mode).  A workgroup is nw
+// waves that share one tile of 64 chains: lane l of every wave is chain l.  The three matrix-vector products of a
+// sub-step (rot = U'theta, theta' = U rot, y = Lam (theta'-mu)) run on the matrix cores (mfma_gemv), their input
+// vector in LDS; the last wave also carries the per-chain scalar state and does the O(1)/O(d) work of the sub-step
+// (random numbers, prior, bounds, the final ss chain, alpha, accept) and hands the normal deviate and the accept flag
+// of each chain to the other waves through LDS.  Arithmetic per chain is operation for operation that of scam_kernel.
+__global__ __launch_bounds__(1024, 1) void scam_pooled_kernel(EngineDev E, int it0, int it1,
+                                                             const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
+                                                             const double *__restrict__ g_U, const double *__restrict__ g_UT,
+                                                             const double *__restrict__ g_std)
+{
+    extern __shared__ double X[];
+    const int lane = threadIdx.x & 63, tile = blockIdx.x, d = E.d;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = (int)(blockDim.x >> 6);
+    const int d4 = (d + 3) & ~3;
+    double *zb = X + (size_t)d4 * 64, *fl = zb + 64;                          // per chain: the deviate, the accept flag
+    const bool sc = (w == nw - 1);                                              // the scalar wave
+    for (int k = d + w; k < d4; k += nw) XL(k) = 0.0;                           // pad rows of the LDS vector stay zero
+    double *theta_t = E.theta + (size_t)tile * d * 64;
+    double *cand_t = E.cand + (size_t)tile * d * 64;
+    double *rot_t = E.cs + (size_t)tile * 2 * d * 64;
+    double *y_t = rot_t + (size_t)d * 64;
+    LaneState L;
+    if (sc) lane_load(E, tile, lane, L);
+#ifdef MCX_PHASE_PROF
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = wall_clock64();
+#define PH(i) { unsigned long long tn = wall_clock64(); ph[i] += tn - tq; tq = tn; }
+#else
+#define PH(i)
+#endif
+    for (int it = it0; it <= it1; ++it) {
+        bool rejall = true;
+        for (int j = 0; j < d; ++j) {
+            rows_apply(theta_t, lane, d, w, nw, [lane](int k, double v) { XL(k) = v; });
+            if (sc) zb[lane] = rng_normal(L.g) * g_std[j];
+            PH(0)
+            __syncthreads();
+            PH(3)
+            mfma_gemv(g_UT, X, rot_t, lane, d, d4, w, nw);                      // rot = U'theta
+            PH(1)
+            __syncthreads();
+            PH(3)
+            const double zj = zb[lane];
+            rows_apply(rot_t, lane, d, w, nw, [lane, j, zj](int k, double v) { XL(k) = (k == j) ? v + zj : v; });
+            PH(0)
+            __syncthreads();
+            PH(3)
+            mfma_gemv(g_U, X, cand_t, lane, d, d4, w, nw);                      // theta' = U rot
+            PH(1)
+            __syncthreads();
+            PH(3)
+            bool inb = true; double pri2 = 0.0, ss2 = 0.0;
+            if (sc) { inb = target_inbounds(E.tgt, d, lane, cand_t); pri2 = target_prior(E.tgt, d, lane, cand_t); }
+            if (E.tgt.kind == TGT_GAUSS) {
+                rows_apply(cand_t, lane, d, w, nw, [lane, g_mu](int k, double v) { XL(k) = v - g_mu[k]; });
+                PH(0)
+                __syncthreads();
+                PH(3)
+                mfma_gemv(g_lamT, X, y_t, lane, d, d4, w, nw);                  // y = Lam v
+                PH(1)
+                __syncthreads();
+                PH(3)
+                if (sc) {
+                    for (int i0 = 0; i0 < d; i0 += 16) {                        // 16 rows of y in flight
+                        double yv[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) { int i = i0 + u; yv[u] = GV(y_t, i < d ? i : d - 1); }
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) { int i = i0 + u; if (i < d) ss2 = (i == 0) ? yv[0] * XL(0) : dfma(yv[u], XL(i), ss2); }
+                    }
+                }
+                PH(4)
+            } else if (sc) ss2 = target_ss<false>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
+            if (sc) {
+                bool reject;
+                if (!inb) { L.bnd += 1; L.alpha12 = 0.0; reject = true; }
+                else {
+                    L.alpha12 = d_alpha(L.ss1, L.pri1, ss2, pri2, L.sigma2);
+                    reject = true;
+                    if (L.alpha12 >= 1.0) reject = false;
+                    else if (L.alpha12 > 0.0) { double u = rng_uniform(L.g); if (u <= L.alpha12) reject = false; }
+                }
+                if (!reject) { L.ss1 = ss2; L.pri1 = pri2; rejall = false; }
+                fl[lane] = reject ? 0.0 : 1.0;
+            }
+            PH(5)
+            __syncthreads();
+            PH(3)
+            const bool acc = fl[lane] != 0.0;
+            if (__any(acc)) rows_apply(cand_t, lane, d, w, nw, [theta_t, lane, acc](int k, double v) { if (acc) GV(theta_t, k) = v; });
+            PH(6)
+            // no barrier: the next sub-step's fill reads, in every wave, exactly the theta rows that wave just wrote
+        }
+        __syncthreads();
+        if (sc) {
+            if (rejall) { L.stayed += 1; L.curcount += 1; }
+            else { L.chainind += 1; L.curcount = 1; }
+            if (E.updatesigma) {
+                double gm = rng_gamma(L.g, E.gam_shape, 2.0 / (E.N0S02 + L.ss1));
+                L.sigma2 = 1.0 / gm;
+            }
+            unsigned long long ballot = __ballot(!rejall);
+            const int slot = it % E.wcap;
+            if (E.hist) {
+                if (!rejall) {
+                    double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64;
+                    for (int k = 0; k < d; ++k) GV(h, k) = GV(theta_t, k);
+                    GV(h, d) = L.ss1;
+                }
+                if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ballot;
+                if (E.record_s2) E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = L.sigma2;
+            }
+            if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
+        }
+    }
+    if (sc) lane_store(E, tile, lane, L);
+#ifdef MCX_PHASE_PROF
+    if (tile == 0 && lane == 0 && (w == 0 || w == nw - 1)) printf("wave %d x10ns: fill %llu gemv %llu barrier %llu sschain %llu alpha %llu copy %llu\n", w, ph[0], ph[1], ph[3], ph[4], ph[5], ph[6]);
+#endif
+#undef PH
+}
+
 // end of an iteration: MCMC_run.F90:93-105 / MCMC_run_ram.F90:66-78
 MCX_DEV void host_finish(const EngineDev &E, int tile, int lane, int it, LaneState &L, bool reject, bool dr_moved,
                          double ss2, double pri2, const double *ramscale)

@@ -222,6 +222,10 @@ class LiveChain:
         view = np.ctypeslib.as_array(self.ch.contents.R, shape=(self.n, self.n))      # view[j, i] = R(i, j)
         view[:, :] = np.asarray(R, dtype=np.float64).T
 
+    def set_qcovstd(self, std):
+        """SCAM: the proposal standard deviations along the rotated axes."""
+        np.ctypeslib.as_array(self.ch.contents.qcovstd, shape=(self.n,))[:] = np.asarray(std, dtype=np.float64)
+
     @property
     def theta(self):
         return np.ctypeslib.as_array(self.ch.contents.oldpar, shape=(self.n,)).copy()

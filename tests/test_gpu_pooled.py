@@ -163,3 +163,63 @@ def test_pooled_mode_two_shards_with_exchange_hook(oracle):
     for e in engs:
         np.testing.assert_array_equal(_bits(np.triu(e.pooled()[3])), _bits(np.triu(ref_R)))
         e.close()
+
+
+def _scam_factor(oracle, state, d, condmax):
+    """host_initial_svd(scam) of mcx_api.hip: pinned Jacobi SVD of the pooled covariance, singular-value floor, sqrt."""
+    G = np.zeros((d, d), order="F")
+    for (i, j), v in state["C"].items():
+        G[i, j] = v; G[j, i] = v
+    V = np.zeros((d, d), order="F"); sv = np.zeros(d)
+    DP = C.POINTER(C.c_double)
+    oracle.lib().mcxo_symsvd(d, G.ctypes.data_as(DP), V.ctypes.data_as(DP), sv.ctypes.data_as(DP))
+    if sv[0] == 0.0:
+        return state
+    tol = sv[0] / condmax
+    if sv[d - 1] <= tol:
+        sv = np.where(sv < tol, tol, sv)
+    state["U"] = np.array(V)                       # U[i, j] = V(i, j)
+    state["std"] = np.array([math.sqrt(v) for v in sv])
+    return state
+
+
+@pytest.mark.parametrize("kind", ["gauss", "banana"])
+def test_pooled_scam_matches_restatement(oracle, kind):
+    """method='scam' with pooled=1: one rotation U / qcovstd for all chains, re-derived at every tick from the pooled
+    covariance (scam_pooled_kernel: four waves per tile, U through the scalar cache)."""
+    from mcmcf90_amd import engine_from_problem
+    d, N, nsimu = 7, 150, 230
+    ckw = dict(nsimu=nsimu, adaptint=100, updatesigma=0, method="scam")
+    if kind == "gauss":
+        S = 0.6 ** np.abs(np.subtract.outer(np.arange(d), np.arange(d)))
+        pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.5), cmat0=0.02 * np.eye(d), mu=np.linspace(-1, 1, d), lam=np.linalg.inv(S))
+    else:
+        pkw = dict(kind="banana", npar=d, par0=np.zeros(d), cmat0=0.05 * np.eye(d), b=0.1)
+    e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
+    e.init(); e.run()
+    cfg = oracle.make_cfg(**dict(ckw, doadapt=0))
+    prob = oracle.Problem(**pkw)
+    chains = [oracle.LiveChain(cfg, prob, chain_id=c) for c in range(N)]
+    state = {}
+    par0, cmat0 = np.asarray(pkw["par0"], float), np.asarray(pkw["cmat0"], float)
+    for tick in (100, 200, nsimu):
+        for ch in chains:
+            ch.run(tick)
+        if tick % 100 == 0 and tick < nsimu:
+            theta = np.array([ch.theta for ch in chains])
+            cnt, s1, s2 = _pooled_moments(theta, par0, N)
+            state = _merge_and_factor(oracle, state, cnt, s1, s2, par0, d, tick == 100, cmat0, 0)
+            state = _scam_factor(oracle, state, d, cfg.condmax)
+            for ch in chains:
+                ch.set_R(state["U"]); ch.set_qcovstd(state["std"])
+    theta = np.array([ch.theta for ch in chains])
+    np.testing.assert_array_equal(_bits(e.theta()), _bits(theta))
+    for c in (0, 63, 64, 149):
+        np.testing.assert_array_equal(e.accepted(c), chains[c].accepted)
+    cm, mean, W, U = e.pooled()
+    assert W == 2 * N
+    np.testing.assert_array_equal(_bits(U), _bits(state["U"]))
+    np.testing.assert_array_equal(_bits(e.qcovstd(0)), _bits(state["std"]))
+    for ch in chains:
+        ch.close()
+    e.close()
