@@ -138,8 +138,9 @@ MCX_DEV double target_ss(const DevTarget &t, int d, int lane, const double *c_t,
                          const double *__restrict__ g_mu, const double *__restrict__ g_lamT)
 {
     double ss = 0.0;
+    // Gaussian: ss = v' Lam v in the order of mcxt_ss_gauss (oracle/mcx_targets.h): y_i = fma chain over j from 0; per
+    // block of 16 rows four partial chains q_k over the rows 16t + k + 4r; ss = running sum of the q_k.
     if (WIDE && t.kind == TGT_GAUSS && d <= 8 * PW) {
-        // ss = (th-mu)' Lam (th-mu): y_i = sum_j lam(i,j) v_j ascending (fma chain), ss = sum_i y_i v_i (fma chain).
         // All row accumulators (up to 8 panels of PW) stay in registers while the columns stream by once, so
         // the candidate is read once instead of once per row panel.
         constexpr int NPM = 8;
@@ -161,64 +162,72 @@ MCX_DEV double target_ss(const DevTarget &t, int d, int lane, const double *c_t,
 #pragma unroll
                     for (int p = 0; p < NPM; ++p) {
                         if (p < np) {
-                            if (J0 == 0 && w == 0) {
 #pragma unroll
-                                for (int u = 0; u < PW; ++u) y[p][u] = lcol[p * PW + u] * v[0];
-                            } else {
-#pragma unroll
-                                for (int u = 0; u < PW; ++u) y[p][u] = dfma(lcol[p * PW + u], v[w], y[p][u]);
-                            }
+                            for (int u = 0; u < PW; ++u) y[p][u] = dfma(lcol[p * PW + u], v[w], y[p][u]);
                         }
                     }
                 }
             }
         }
 #pragma unroll
-        for (int p = 0; p < NPM; ++p) {
-            if (p < np) {
-                const int I0 = p * PW;
-                const int nr = (d - I0) < PW ? (d - I0) : PW;
-                double vi[PW];
+        for (int tb = 0; tb < NPM / 2; ++tb) {
+            if (2 * tb < np) {
+                double q[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int u = 0; u < PW; ++u) { int i = I0 + (u < nr ? u : nr - 1); vi[u] = GV(c_t, i) - g_mu[i]; }
+                for (int h = 0; h < 2; ++h) {
+                    const int p = 2 * tb + h;
+                    if (p < np) {
+                        const int I0 = p * PW;
+                        const int nr = (d - I0) < PW ? (d - I0) : PW;
+                        double vi[PW];
 #pragma unroll
-                for (int u = 0; u < PW; ++u) {
-                    if (u < nr) { if (p == 0 && u == 0) ss = y[0][0] * vi[0]; else ss = dfma(y[p][u], vi[u], ss); }
+                        for (int u = 0; u < PW; ++u) { int i = I0 + (u < nr ? u : nr - 1); vi[u] = GV(c_t, i) - g_mu[i]; }
+#pragma unroll
+                        for (int u = 0; u < PW; ++u) {
+                            if (u < nr) { if (h == 0 && u < 4) q[u & 3] = y[p][u] * vi[u]; else q[u & 3] = dfma(y[p][u], vi[u], q[u & 3]); }
+                        }
+                    }
                 }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (16 * tb + k < d) ss = (tb == 0 && k == 0) ? q[0] : ss + q[k];
             }
         }
     } else if (t.kind == TGT_GAUSS) {
-        for (int I0 = 0; I0 < d; I0 += PW) {
-            const int nr = (d - I0) < PW ? (d - I0) : PW;
-            double y[PW];
+        for (int B0 = 0; B0 < d; B0 += 16) {
+            double q[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int u = 0; u < PW; ++u) y[u] = 0.0;
-            for (int J0 = 0; J0 < d; J0 += PW) {
-                const int nc = (d - J0) < PW ? (d - J0) : PW;
-                double v[PW];
+            for (int h = 0; h < 2; ++h) {
+                const int I0 = B0 + PW * h;
+                if (I0 < d) {
+                    const int nr = (d - I0) < PW ? (d - I0) : PW;
+                    double y[PW];
 #pragma unroll
-                for (int w = 0; w < PW; ++w) { int j = J0 + (w < nc ? w : nc - 1); v[w] = GV(c_t, j) - g_mu[j]; }
+                    for (int u = 0; u < PW; ++u) y[u] = 0.0;
+                    for (int J0 = 0; J0 < d; J0 += PW) {
+                        const int nc = (d - J0) < PW ? (d - J0) : PW;
+                        double v[PW];
 #pragma unroll
-                for (int w = 0; w < PW; ++w) {
-                    if (w < nc) {
-                        const double *__restrict__ lrow = g_lamT + (size_t)(J0 + w) * d + I0;
-                        if (J0 == 0 && w == 0) {
+                        for (int w = 0; w < PW; ++w) { int j = J0 + (w < nc ? w : nc - 1); v[w] = GV(c_t, j) - g_mu[j]; }
 #pragma unroll
-                            for (int u = 0; u < PW; ++u) y[u] = lrow[u] * v[0];
-                        } else {
+                        for (int w = 0; w < PW; ++w) {
+                            if (w < nc) {
+                                const double *__restrict__ lrow = g_lamT + (size_t)(J0 + w) * d + I0;
 #pragma unroll
-                            for (int u = 0; u < PW; ++u) y[u] = dfma(lrow[u], v[w], y[u]);
+                                for (int u = 0; u < PW; ++u) y[u] = dfma(lrow[u], v[w], y[u]);
+                            }
                         }
+                    }
+                    double vi[PW];
+#pragma unroll
+                    for (int u = 0; u < PW; ++u) { int i = I0 + (u < nr ? u : nr - 1); vi[u] = GV(c_t, i) - g_mu[i]; }
+#pragma unroll
+                    for (int u = 0; u < PW; ++u) {
+                        if (u < nr) { if (h == 0 && u < 4) q[u & 3] = y[u] * vi[u]; else q[u & 3] = dfma(y[u], vi[u], q[u & 3]); }
                     }
                 }
             }
-            double vi[PW];
 #pragma unroll
-            for (int u = 0; u < PW; ++u) { int i = I0 + (u < nr ? u : nr - 1); vi[u] = GV(c_t, i) - g_mu[i]; }
-#pragma unroll
-            for (int u = 0; u < PW; ++u) {
-                if (u < nr) { if (I0 == 0 && u == 0) ss = y[0] * vi[0]; else ss = dfma(y[u], vi[u], ss); }
-            }
+            for (int k = 0; k < 4; ++k) if (B0 + k < d) ss = (B0 == 0 && k == 0) ? q[0] : ss + q[k];
         }
     } else if (t.kind == TGT_BANANA) {
         double th0 = GV(c_t, 0), th1 = GV(c_t, 1);
@@ -1060,12 +1069,14 @@ __global__ __launch_bounds__(1024, 1) void scam_pooled_kernel(EngineDev E, int i
                 __syncthreads();
                 PH(3)
                 if (sc) {
-                    for (int i0 = 0; i0 < d; i0 += 16) {                        // 16 rows of y in flight
-                        double yv[16];
+                    for (int i0 = 0; i0 < d; i0 += 16) {                        // one block of 16 rows of y in flight
+                        double yv[16], q[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                         for (int u = 0; u < 16; ++u) { int i = i0 + u; yv[u] = GV(y_t, i < d ? i : d - 1); }
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) { int i = i0 + u; if (i < d) ss2 = (i == 0) ? yv[0] * XL(0) : dfma(yv[u], XL(i), ss2); }
+                        for (int u = 0; u < 16; ++u) { int i = i0 + u; if (i < d) q[u & 3] = (u < 4) ? yv[u] * XL(i) : dfma(yv[u], XL(i), q[u & 3]); }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (i0 + k < d) ss2 = (i0 == 0 && k == 0) ? q[0] : ss2 + q[k];
                     }
                 }
                 PH(4)

@@ -18,15 +18,28 @@
 
 static inline double mcxt_ss_gauss(int d, const double *th, const double *mu, const double *lam)
 {
-    /* y_i = sum_j lam(i,j) v_j (ascending j, fma chain); ss = sum_i y_i v_i (ascending i, fma chain) */
+    /* ss = v' Lam v, v = th - mu.  The target is build-defined (it is not part of mcmcf90), so is its operation order:
+     *   y_i = sum_j lam(i,j) v_j          one fma chain ascending in j, from 0;
+     *   rows in blocks of 16; in block t four interleaved partial chains q_k, k = 0..3, over the rows
+     *   16t + k + 4r, r = 0..3: q_k = y_i v_i for r = 0, then fma(y_i, v_i, q_k);
+     *   ss = q_0 of block 0, then ss = ss + q_k, k ascending inside a block, blocks ascending.
+     * This is the order in which a 16x16 f64 matrix-core tile leaves y in registers (each q_k is lane-local), and it
+     * costs a lane-per-chain kernel nothing. */
     double ss = 0.0;
-    for (int i = 0; i < d; ++i) {
-        const double *row = lam + (long)i * d;
-        double y = row[0] * (th[0] - mu[0]);
-        for (int j = 1; j < d; ++j) y = fma(row[j], th[j] - mu[j], y);
-        double vi = th[i] - mu[i];
-        ss = (i == 0) ? y * vi : fma(y, vi, ss);
-    }
+    for (int t0 = 0; t0 < d; t0 += 16)
+        for (int k = 0; k < 4 && t0 + k < d; ++k) {
+            double q = 0.0;
+            for (int r = 0; r < 4; ++r) {
+                const int i = t0 + k + 4 * r;
+                if (i >= d) break;
+                const double *row = lam + (long)i * d;
+                double y = 0.0;
+                for (int j = 0; j < d; ++j) y = fma(row[j], th[j] - mu[j], y);
+                const double vi = th[i] - mu[i];
+                q = (r == 0) ? y * vi : fma(y, vi, q);
+            }
+            ss = (t0 == 0 && k == 0) ? q : ss + q;
+        }
     return ss;
 }
 
