@@ -224,6 +224,7 @@ static void launch_step(mcmcx_engine *h, int it0, int it1)
     else hipLaunchKernelGGL((step_kernel<false, false, false>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
 }
 static size_t shared_u_stride(const mcmcx_engine *h) { return (size_t)((h->d + 3) & ~3) * h->d + PWS; }     // d4 rows (pad rows zero) + slack
+static size_t scam_pooled_lds(int d) { return ((size_t)((d + 15) / 16) * (16 + 4) * 64 + 128) * sizeof(double); }     // X [16 nt][64], Q [4 nt][64], zb, fl
 static int upload_shared_u(mcmcx_engine *h)
 {
     const int d = h->d; const size_t st = shared_u_stride(h);
@@ -238,9 +239,9 @@ static void launch_scam(mcmcx_engine *h, int it0, int it1)
 {
     if (h->pooled) {
         const size_t st = shared_u_stride(h);
-        const int nt = (h->d + 15) / 16;                   // 16-output tiles; 4 chain-group waves + up to 12 whole-tile waves
-        int nw = 4 + std::min(12, nt & ~3); if (const char *e = getenv("MCMCX_SCAM_NW")) nw = atoi(e);
-        hipLaunchKernelGGL(scam_pooled_kernel, dim3(h->ntiles), dim3(64 * nw), ((size_t)((h->d + 3) & ~3) * 64 + 128) * sizeof(double), h->stream, h->E, it0, it1,
+        const int nt = (h->d + 15) / 16;                   // 16-row output blocks: min(12, 4*(nt/4)) block waves + 4 chain-group waves
+        const int nw = 4 + std::min(12, nt & ~3);
+        hipLaunchKernelGGL(scam_pooled_kernel, dim3(h->ntiles), dim3(64 * nw), scam_pooled_lds(h->d), h->stream, h->E, it0, it1,
                            h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedU, h->d_sharedU + st, h->d_sharedU + 2 * st);
         return;
     }
@@ -689,7 +690,7 @@ int mcmcx_init(mcmcx_handle h)
     E.sharedR = nullptr;
     if (h->pooled) {
         if (h->tkind == TGT_HOST) return fail(-8, "pooled mode needs a device-resident target");
-        if ((size_t)(d + 3) * 64 * sizeof(double) > 160 * 1024 - 2048 && c.method == MCMCX_METHOD_SCAM) return fail(-8, "pooled scam: npar too large for the LDS input vector");
+        if (c.method == MCMCX_METHOD_SCAM && scam_pooled_lds(d) > 160 * 1024) return fail(-8, "pooled scam: npar > 240 does not fit the 160 KiB of LDS");
         if ((rc = dev_alloc(h, &h->d_sharedR, (size_t)P, false))) return rc;
         HIPCHK(hipMemcpy(h->d_sharedR, Rp.data(), (size_t)P * 8, hipMemcpyHostToDevice));
         E.sharedR = h->d_sharedR;

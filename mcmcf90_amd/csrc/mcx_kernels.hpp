@@ -934,154 +934,168 @@ __global__ __launch_bounds__(64, 2) void scam_kernel(EngineDev E, int it0, int i
 }
 
 // ---------------------------------------------------------------- pooled SCAM: one rotation shared by all chains
-// out_o = sum_s M[s*d + o] X[s] for every output o and the 64 chains of a tile, s ascending, one fma chain per
-// (output, chain) -- the order of gemvT_panels / gemvN_panels / the Gaussian ss rows -- on the matrix cores:
-// v_mfma_f64_16x16x4_f64 accumulates its four products as an ascending fma chain (checked bit for bit on gfx950,
-// tools/mfma_f64_probe.hip), so D = A B + D repeated over blocks of four s IS that chain.  A = M' (16 outputs x
-// 4 s, straight from the shared table, L2-resident), B = X (4 s x 16 chains, from the workgroup's LDS vector).
-// X has d4 = 4*ceil(d/4) rows, the pad rows zero; M has d4 rows (pad rows zero) and PWS doubles of slack.
+// MCMC_run_scam with ONE rotation U (and one qcovstd) for every chain of the node (pooled mode), on the matrix cores.
 //
-// Work split over the nw waves of a workgroup (wave w runs on SIMD w mod 4): the first 4*(nt/4) output tiles go
-// whole (four accumulators = the four 16-chain groups) to the nw-4 "tile waves" round robin; each of the nt mod 4
-// leftover tiles is cut into its four chain groups, one for each of the last four waves -- so every SIMD gets the
-// same number of MFMAs.  With nw == 4 there are no tile waves and everything goes by chain group.
+// out(o, c) = sum_s M[s*d + o] X(s, c) for every output row o and chain c of a tile, s ascending, one fma chain per
+// (o, c) -- the order of gemvT_panels / gemvN_panels / the Gaussian y rows.  v_mfma_f64_16x16x4_f64 accumulates its
+// four products as an ascending fma chain (checked bit for bit on gfx950, tools/mfma_f64_probe.hip), so D = A B + D
+// repeated over blocks of four s IS that chain.  A = M' (16 outputs x 4 s, from the shared table, L2-resident),
+// B = X (4 s x 16 chains, from the workgroup's LDS vector; d4 = 4*ceil(d/4) rows, the pad rows zero; M has d4 rows,
+// pad rows zero, and PWS doubles of slack).
+//
+// A workgroup is nw waves that share one tile of 64 chains.  Every wave owns four 16x16 (output block x chain group)
+// result tiles -- "slots" -- and keeps them in registers in the MFMA C layout (row = 16*block + (lane>>4) + 4r,
+// chain = 16*group + (lane&15)): a block wave (w < ntw) owns output block w for all four chain groups (one A, four
+// B per k-block), each of the last four waves owns chain group w-ntw of the leftover blocks ntw.. (one B, up to four
+// A) -- so every SIMD (wave mod 4) runs the same number of MFMAs.  The products of a sub-step chain through LDS only:
+// theta -> X -> rot (registers) -> X -> theta' (registers, kept for the accept) -> X = theta'-mu -> y (registers) ->
+// per-lane partial chains q of ss (mcxt_ss_gauss's order is exactly this layout) -> LDS; the last wave carries the
+// per-chain scalar state, sums the q, does prior / bounds / alpha / accept and hands the normal deviate and the accept
+// flag of each chain to the others through LDS.  Arithmetic per chain is operation for operation that of scam_kernel.
 constexpr int PWS = 16;
 typedef double mcx_d4 __attribute__((ext_vector_type(4)));
-template <int NG>   // NG = 4: a whole tile; NG = 1: chain group g0 only
-MCX_DEV void mfma_tile(const double *__restrict__ M, const double *X, double *out_t, int lane, int d, int d4, int o0, int g0)
+
+template <bool BW, int NS>   // BW: block wave (blk0 = its block, slot = chain group); else group wave (slot s = block blk0+s, s < NS)
+MCX_DEV void mfma_slots(const double *__restrict__ M, const double *X, int lane, int d, int d4, int blk0, int grp, mcx_d4 (&c)[4])
 {
     const int li = lane & 15, lk = lane >> 4;
-    mcx_d4 c[NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) c[g] = mcx_d4{0.0, 0.0, 0.0, 0.0};
-    const double *__restrict__ ap = M + (size_t)lk * d + o0 + li;
-    const double *xp = X + lk * 64 + li + 16 * g0;
+    for (int s = 0; s < 4; ++s) c[s] = mcx_d4{0.0, 0.0, 0.0, 0.0};
+    const double *__restrict__ ap = M + (size_t)lk * d + 16 * blk0 + li;
+    const double *xp = X + lk * 64 + li + (BW ? 0 : 16 * grp);
     int s0 = 0;
-    for (; s0 + 16 <= d4; s0 += 16) {                   // four k-blocks per trip: the four A loads go out together
-        double a[4];
+    if (BW) {
+        for (; s0 + 16 <= d4; s0 += 16) {               // four k-blocks per trip: the four A loads go out together
+            double a[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] = ap[(size_t)(s0 + 4 * u) * d];
+            for (int u = 0; u < 4; ++u) a[u] = ap[(size_t)(s0 + 4 * u) * d];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const double *xq = xp + (s0 + 4 * u) * 64;
+            for (int u = 0; u < 4; ++u) {
+                const double *xq = xp + (s0 + 4 * u) * 64;
 #pragma unroll
-            for (int g = 0; g < NG; ++g) c[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], xq[16 * g], c[g], 0, 0, 0);
+                for (int g = 0; g < 4; ++g) c[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], xq[16 * g], c[g], 0, 0, 0);
+            }
+        }
+        for (; s0 < d4; s0 += 4) {
+            const double a = ap[(size_t)s0 * d];
+            const double *xq = xp + s0 * 64;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) c[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xq[16 * g], c[g], 0, 0, 0);
+        }
+    } else {
+        for (; s0 + 8 <= d4; s0 += 8) {                 // two k-blocks per trip, up to four A each
+            double a[2][NS > 0 ? NS : 1], bq[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) a[u][s] = ap[(size_t)(s0 + 4 * u) * d + 16 * s];
+                bq[u] = xp[(s0 + 4 * u) * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) c[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][s], bq[u], c[s], 0, 0, 0);
+        }
+        for (; s0 < d4; s0 += 4) {
+            const double bq = xp[s0 * 64];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) c[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[(size_t)s0 * d + 16 * s], bq, c[s], 0, 0, 0);
         }
     }
-    for (; s0 < d4; s0 += 4) {
-        const double a = ap[(size_t)s0 * d];
-        const double *xq = xp + s0 * 64;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) c[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xq[16 * g], c[g], 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {                       // C/D: row = (lane>>4) + 4r, col = lane&15
-        const int o = o0 + lk + 4 * r;
-        if (o < d) {
-            double *op = out_t + (size_t)o * 64 + li + 16 * g0;
-#pragma unroll
-            for (int g = 0; g < NG; ++g) op[16 * g] = c[g][r];
-        }
-    }
 }
-MCX_DEV void mfma_gemv(const double *__restrict__ M, const double *X, double *out_t, int lane, int d, int d4, int w, int nw)
+// Element (slot s, register r) of a lane: output row o = 16*block + (lane>>4) + 4r, chain c = 16*group + (lane&15); its
+// offset o*64 + c in a tile-interleaved vector (and in X) is e0 + (BW ? 16 s : 1024 s) + 256 r.  X has 16*nt rows, so
+// every element has an LDS home; rows >= d are written as zeros (the k loop reads the rows < d4 only).
+template <bool BW, int NS>
+MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, int lane, int w, int nw, int blk0, int grp,
+                              const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
+                              const double *__restrict__ g_U, const double *__restrict__ g_UT, const double *__restrict__ g_std)
 {
-    const int nt = (d + 15) >> 4, ntw = nw - 4;
-    const int nfull = ntw > 0 ? (nt & ~3) : 0;
-    if (w < ntw) { for (int t = w; t < nfull; t += ntw) mfma_tile<4>(M, X, out_t, lane, d, d4, t * 16, 0); }
-    else { for (int t = nfull; t < nt; ++t) mfma_tile<1>(M, X, out_t, lane, d, d4, t * 16, w - ntw); }
-}
-
-// X[k] = f(k, src[k]) (or dst[k] = src[k]) for the rows k = w, w+nw, ... < d of a tile-interleaved vector, 16 loads in
-// flight per wave
-template <typename F>
-MCX_DEV void rows_apply(const double *src_t, int lane, int d, int w, int nw, F &&f)
-{
-    for (int k0 = w; k0 < d; k0 += 16 * nw) {
-        double r[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) { int k = k0 + u * nw; r[u] = GV(src_t, k < d ? k : k0); }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) { int k = k0 + u * nw; if (k < d) f(k, r[u]); }
-    }
-}
-
-// MCMC_run_scam with ONE rotation U (and one qcovstd) for every chain of the node (pooled mode).  A workgroup is nw
-// waves that share one tile of 64 chains: lane l of every wave is chain l.  The three matrix-vector products of a
-// sub-step (rot = U'theta, theta' = U rot, y = Lam (theta'-mu)) run on the matrix cores (mfma_gemv), their input
-// vector in LDS; the last wave also carries the per-chain scalar state and does the O(1)/O(d) work of the sub-step
-// (random numbers, prior, bounds, the final ss chain, alpha, accept) and hands the normal deviate and the accept flag
-// of each chain to the other waves through LDS.  Arithmetic per chain is operation for operation that of scam_kernel.
-__global__ __launch_bounds__(1024, 1) void scam_pooled_kernel(EngineDev E, int it0, int it1,
-                                                             const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
-                                                             const double *__restrict__ g_U, const double *__restrict__ g_UT,
-                                                             const double *__restrict__ g_std)
-{
-    extern __shared__ double X[];
-    const int lane = threadIdx.x & 63, tile = blockIdx.x, d = E.d;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = (int)(blockDim.x >> 6);
-    const int d4 = (d + 3) & ~3;
-    double *zb = X + (size_t)d4 * 64, *fl = zb + 64;                          // per chain: the deviate, the accept flag
+    const int tile = blockIdx.x, d = E.d, d4 = (d + 3) & ~3, nt = (d + 15) >> 4, li = lane & 15, lk = lane >> 4;
+    double *Q = X + (size_t)nt * 16 * 64;                                       // [4*nt][64] partial ss chains
+    double *zb = Q + (size_t)nt * 4 * 64, *fl = zb + 64;                      // per chain: the deviate, the accept flag
     const bool sc = (w == nw - 1);                                              // the scalar wave
-    for (int k = d + w; k < d4; k += nw) XL(k) = 0.0;                           // pad rows of the LDS vector stay zero
+    const bool gauss = (E.tgt.kind == TGT_GAUSS);
+    const bool cand_global = !gauss || E.tgt.pmu || E.tgt.lo || E.tgt.hi;       // prior / bounds / other targets read theta' per chain
+    constexpr int nsl = NS;
+    const int e0 = (16 * blk0 + lk) * 64 + (BW ? 0 : 16 * grp) + li, o0 = 16 * blk0 + lk, c0 = (BW ? 0 : 16 * grp) + li;
+#define EOFF(s, r) (e0 + (BW ? 16 : 1024) * (s) + 256 * (r))
+#define EROW(s, r) (o0 + (BW ? 0 : 16) * (s) + 4 * (r))
+#define ECH(s) (c0 + (BW ? 16 : 0) * (s))
     double *theta_t = E.theta + (size_t)tile * d * 64;
     double *cand_t = E.cand + (size_t)tile * d * 64;
-    double *rot_t = E.cs + (size_t)tile * 2 * d * 64;
-    double *y_t = rot_t + (size_t)d * 64;
     LaneState L;
     if (sc) lane_load(E, tile, lane, L);
-#ifdef MCX_PHASE_PROF
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = wall_clock64();
-#define PH(i) { unsigned long long tn = wall_clock64(); ph[i] += tn - tq; tq = tn; }
-#else
-#define PH(i)
-#endif
+    mcx_d4 cand[4], cc[4];
     for (int it = it0; it <= it1; ++it) {
         bool rejall = true;
         for (int j = 0; j < d; ++j) {
-            rows_apply(theta_t, lane, d, w, nw, [lane](int k, double v) { XL(k) = v; });
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {                                       // X = theta
+                if (s < nsl) {
+                    double th[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) th[r] = theta_t[EROW(s, r) < d ? EOFF(s, r) : e0];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) X[EOFF(s, r)] = EROW(s, r) < d ? th[r] : 0.0;
+                }
+            }
             if (sc) zb[lane] = rng_normal(L.g) * g_std[j];
-            PH(0)
             __syncthreads();
-            PH(3)
-            mfma_gemv(g_UT, X, rot_t, lane, d, d4, w, nw);                      // rot = U'theta
-            PH(1)
+            mfma_slots<BW, NS>(g_UT, X, lane, d, d4, blk0, grp, cc);           // rot = U'theta
             __syncthreads();
-            PH(3)
-            const double zj = zb[lane];
-            rows_apply(rot_t, lane, d, w, nw, [lane, j, zj](int k, double v) { XL(k) = (k == j) ? v + zj : v; });
-            PH(0)
-            __syncthreads();
-            PH(3)
-            mfma_gemv(g_U, X, cand_t, lane, d, d4, w, nw);                      // theta' = U rot
-            PH(1)
-            __syncthreads();
-            PH(3)
-            bool inb = true; double pri2 = 0.0, ss2 = 0.0;
-            if (sc) { inb = target_inbounds(E.tgt, d, lane, cand_t); pri2 = target_prior(E.tgt, d, lane, cand_t); }
-            if (E.tgt.kind == TGT_GAUSS) {
-                rows_apply(cand_t, lane, d, w, nw, [lane, g_mu](int k, double v) { XL(k) = v - g_mu[k]; });
-                PH(0)
-                __syncthreads();
-                PH(3)
-                mfma_gemv(g_lamT, X, y_t, lane, d, d4, w, nw);                  // y = Lam v
-                PH(1)
-                __syncthreads();
-                PH(3)
-                if (sc) {
-                    for (int i0 = 0; i0 < d; i0 += 16) {                        // one block of 16 rows of y in flight
-                        double yv[16], q[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) { int i = i0 + u; yv[u] = GV(y_t, i < d ? i : d - 1); }
+            for (int s = 0; s < 4; ++s) {
+                if (s < nsl) {
+                    const double zj = zb[ECH(s)];
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) { int i = i0 + u; if (i < d) q[u & 3] = (u < 4) ? yv[u] * XL(i) : dfma(yv[u], XL(i), q[u & 3]); }
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) if (i0 + k < d) ss2 = (i0 == 0 && k == 0) ? q[0] : ss2 + q[k];
+                    for (int r = 0; r < 4; ++r) {
+                        const int o = EROW(s, r);
+                        double v = cc[s][r];
+                        if (o == j) v = v + zj;
+                        X[EOFF(s, r)] = o < d ? v : 0.0;
                     }
                 }
-                PH(4)
-            } else if (sc) ss2 = target_ss<false>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
+            }
+            __syncthreads();
+            mfma_slots<BW, NS>(g_U, X, lane, d, d4, blk0, grp, cand);          // theta' = U rot
+            if (cand_global) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (s < nsl) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (EROW(s, r) < d) cand_t[EOFF(s, r)] = cand[s][r];
+                    }
+            }
+            __syncthreads();
+            if (gauss) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (s < nsl) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const int o = EROW(s, r); X[EOFF(s, r)] = o < d ? cand[s][r] - g_mu[o < d ? o : 0] : 0.0; }
+                    }
+                __syncthreads();
+                mfma_slots<BW, NS>(g_lamT, X, lane, d, d4, blk0, grp, cc);     // y = Lam v
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {                                   // q_(block, lane>>4) = chain over r of y v
+                    if (s < nsl) {
+                        double q = cc[s][0] * X[EOFF(s, 0)];
+#pragma unroll
+                        for (int r = 1; r < 4; ++r) { const double t = dfma(cc[s][r], X[EOFF(s, r)], q); q = EROW(s, r) < d ? t : q; }
+                        if (EROW(s, 0) < d) Q[(size_t)(EROW(s, 0) >> 4) * 256 + (EROW(s, 0) & 3) * 64 + ECH(s)] = q;
+                    }
+                }
+                __syncthreads();
+            }
             if (sc) {
+                bool inb = true; double pri2 = 0.0, ss2 = 0.0;
+                if (cand_global) { inb = target_inbounds(E.tgt, d, lane, cand_t); pri2 = target_prior(E.tgt, d, lane, cand_t); }
+                if (gauss) {
+                    ss2 = Q[lane];
+#pragma unroll 4
+                    for (int e = 1; e < 4 * nt; ++e) if (16 * (e >> 2) + (e & 3) < d) ss2 = ss2 + Q[(size_t)e * 64 + lane];
+                } else ss2 = target_ss<false>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
                 bool reject;
                 if (!inb) { L.bnd += 1; L.alpha12 = 0.0; reject = true; }
                 else {
@@ -1093,13 +1107,15 @@ __global__ __launch_bounds__(1024, 1) void scam_pooled_kernel(EngineDev E, int i
                 if (!reject) { L.ss1 = ss2; L.pri1 = pri2; rejall = false; }
                 fl[lane] = reject ? 0.0 : 1.0;
             }
-            PH(5)
             __syncthreads();
-            PH(3)
-            const bool acc = fl[lane] != 0.0;
-            if (__any(acc)) rows_apply(cand_t, lane, d, w, nw, [theta_t, lane, acc](int k, double v) { if (acc) GV(theta_t, k) = v; });
-            PH(6)
-            // no barrier: the next sub-step's fill reads, in every wave, exactly the theta rows that wave just wrote
+            // accepted chains: theta = theta' (each lane its own elements; the next sub-step reloads exactly those)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (s < nsl) {
+                    const bool acc = fl[ECH(s)] != 0.0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (acc && EROW(s, r) < d) theta_t[EOFF(s, r)] = cand[s][r];
+                }
         }
         __syncthreads();
         if (sc) {
@@ -1124,10 +1140,28 @@ __global__ __launch_bounds__(1024, 1) void scam_pooled_kernel(EngineDev E, int i
         }
     }
     if (sc) lane_store(E, tile, lane, L);
-#ifdef MCX_PHASE_PROF
-    if (tile == 0 && lane == 0 && (w == 0 || w == nw - 1)) printf("wave %d x10ns: fill %llu gemv %llu barrier %llu sschain %llu alpha %llu copy %llu\n", w, ph[0], ph[1], ph[3], ph[4], ph[5], ph[6]);
-#endif
-#undef PH
+#undef EOFF
+#undef EROW
+#undef ECH
+}
+
+__global__ __launch_bounds__(1024, 1) void scam_pooled_kernel(EngineDev E, int it0, int it1,
+                                                             const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
+                                                             const double *__restrict__ g_U, const double *__restrict__ g_UT,
+                                                             const double *__restrict__ g_std)
+{
+    extern __shared__ double X[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = (int)(blockDim.x >> 6);
+    const int nt = (E.d + 15) >> 4, ntw = nw - 4;                               // ntw block waves own blocks 0..ntw-1
+    if (w < ntw) scam_pooled_body<true, 4>(E, it0, it1, X, lane, w, nw, w, 0, g_mu, g_lamT, g_U, g_UT, g_std);
+    else switch (nt - ntw) {
+        case 0: scam_pooled_body<false, 0>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
+        case 1: scam_pooled_body<false, 1>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
+        case 2: scam_pooled_body<false, 2>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
+        case 3: scam_pooled_body<false, 3>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
+        default: scam_pooled_body<false, 4>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
+    }
 }
 
 // end of an iteration: MCMC_run.F90:93-105 / MCMC_run_ram.F90:66-78
