@@ -858,7 +858,8 @@ int mcmcx_get_totals(mcmcx_handle h, int64_t *t5)
         auto at = [&](int k) { return (int64_t)v[((size_t)t * NICTR + k) * 64 + l]; };
         t5[0] += at(I_STAYED); t5[1] += at(I_BNDSTAYED); t5[2] += at(I_DRACC); t5[3] += at(I_DRTRIES);
     }
-    t5[4] = (int64_t)h->cfg.nchains * (int64_t)(h->simuind - 1) + t5[3];
+    // proposals evaluated: one per iteration (d componentwise ones with method='scam') + the delayed-rejection tries
+    t5[4] = (int64_t)h->cfg.nchains * (int64_t)(h->simuind - 1) * (h->cfg.method == MCMCX_METHOD_SCAM ? h->d : 1) + t5[3];
     return 0;
 }
 

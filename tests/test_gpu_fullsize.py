@@ -78,3 +78,59 @@ def test_c4_gauss50_ram_131072_chains(oracle):
     R = e.R(5)
     assert np.all(np.diag(R) > 0) and np.allclose(np.tril(R, -1), 0)
     e.close()
+
+
+def test_c5_illcond200_scam_pooled_65536_chains(oracle):
+    """BASELINE config 5 at full size in the pooled mode (one rotation for all chains, scam_pooled_kernel on the f64
+    matrix cores).  (1) up to the first tick every chain is the single-chain oracle with adaptation off; (2) the shared
+    rotation is an orthogonal eigenbasis of the pooled covariance of the states at the tick; (3) carried on with the
+    engine's U / qcovstd, the oracle chains stay bit-identical to the engine to the end."""
+    from mcmcf90_amd import engine_from_problem
+    from mcmcf90_amd.workloads import problem
+    n, nsimu, tick = 65536, 16, 10
+    ckw, pkw, _ = problem("c5", nsimu, adaptint=tick)
+    d = pkw["npar"]
+    e = engine_from_problem(ckw, pkw, nchains=n, pooled=1)
+    e.init(); e.run(tick)
+    cfg = oracle.make_cfg(**dict(ckw, doadapt=0))
+    prob = oracle.Problem(**pkw)
+    picks = [0, 4097, 65535]
+    live = {c: oracle.LiveChain(cfg, prob, chain_id=c) for c in picks}
+    th = e.theta()
+    for c in picks:
+        live[c].run(tick)
+        np.testing.assert_array_equal(_bits(th[c]), _bits(live[c].theta))
+    cm, mean, W, U = e.pooled()
+    std = e.qcovstd(0)
+    assert W == n
+    np.testing.assert_allclose(mean, th.mean(axis=0), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(cm, np.cov(th.T), rtol=1e-9, atol=1e-18)
+    np.testing.assert_allclose(U.T @ U, np.eye(d), atol=1e-12)
+    floor = std[0] ** 2 / cfg.condmax
+    np.testing.assert_allclose((U * np.maximum(std ** 2, floor)) @ U.T, cm, rtol=0, atol=1e-10 * std[0] ** 2)
+    assert np.all(np.diff(std) <= 0)
+    e.run()
+    th = e.theta()
+    for c in picks:
+        live[c].set_R(U); live[c].set_qcovstd(std)
+        live[c].run(nsimu)
+        np.testing.assert_array_equal(_bits(th[c]), _bits(live[c].theta))
+        live[c].close()
+    tot = e.totals()
+    assert tot["proposals"] == n * (nsimu - 1) * d
+    e.close()
+
+
+def test_c5_illcond200_scam_replicas_small(oracle):
+    """The same target with per-chain rotations (the reference's semantics), a few chains up to the first tick."""
+    from mcmcf90_amd import engine_from_problem
+    from mcmcf90_amd.workloads import problem
+    ckw, pkw, _ = problem("c5", 4, adaptint=100)
+    e = engine_from_problem(ckw, pkw, nchains=70)
+    e.init(); e.run()
+    cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
+    th = e.theta()
+    for c in (0, 69):
+        o = oracle.run_chain(cfg, prob, chain_id=c)
+        np.testing.assert_array_equal(_bits(th[c]), _bits(o.theta))
+    e.close()
