@@ -223,3 +223,50 @@ def test_pooled_scam_matches_restatement(oracle, kind):
     for ch in chains:
         ch.close()
     e.close()
+
+
+@pytest.mark.parametrize("d,extras", [(40, "s2"), (64, ""), (70, "bounds"), (100, "priors"), (130, "")])
+def test_pooled_scam_wave_layouts(oracle, d, extras):
+    """Every split of scam_pooled_kernel's output blocks over its waves: d=40 three leftover blocks and no block wave,
+    64 four block waves and nothing left over, 70 / 100 four block waves + one / three leftover blocks, 130 eight + one;
+    with the sigma2 update, box bounds and Gaussian priors (which make theta' round-trip through global memory)."""
+    from mcmcf90_amd import engine_from_problem
+    N, nsimu, tick = 70, 8, 3
+    rng = np.random.default_rng(d)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    lam = A @ A.T + np.diag(np.linspace(0.5, 3.0, d))
+    ckw = dict(nsimu=nsimu, adaptint=tick, updatesigma=1 if extras == "s2" else 0, method="scam")
+    pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.1), cmat0=0.01 * np.eye(d), mu=np.linspace(-0.5, 0.5, d), lam=lam)
+    if extras == "s2":
+        pkw.update(sigma2=0.7, nobs=30)
+    if extras == "bounds":
+        pkw.update(lo=np.full(d, -0.2), hi=np.full(d, 0.45))
+    if extras == "priors":
+        pkw.update(pri_mu=np.zeros(d), pri_sig=np.where(np.arange(d) % 3 == 0, 0.0, 0.5))
+    e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
+    e.init(); e.run()
+    cfg = oracle.make_cfg(**dict(ckw, doadapt=0))
+    prob = oracle.Problem(**pkw)
+    chains = [oracle.LiveChain(cfg, prob, chain_id=c) for c in range(N)]
+    state = {}
+    par0, cmat0 = np.asarray(pkw["par0"], float), np.asarray(pkw["cmat0"], float)
+    for t in (3, 6, nsimu):
+        for ch in chains:
+            ch.run(t)
+        if t < nsimu:
+            theta = np.array([ch.theta for ch in chains])
+            cnt, s1, s2 = _pooled_moments(theta, par0, N)
+            state = _merge_and_factor(oracle, state, cnt, s1, s2, par0, d, t == 3, cmat0, 0)
+            state = _scam_factor(oracle, state, d, cfg.condmax)
+            for ch in chains:
+                ch.set_R(state["U"]); ch.set_qcovstd(state["std"])
+    theta = np.array([ch.theta for ch in chains])
+    np.testing.assert_array_equal(_bits(e.theta()), _bits(theta))
+    for c in (0, 63, 64, 69):
+        np.testing.assert_array_equal(e.accepted(c), chains[c].accepted)
+    if extras == "bounds":
+        assert sum(e.counters(c)["bndstayed"] for c in range(N)) > 0
+    np.testing.assert_array_equal(_bits(e.pooled()[3]), _bits(state["U"]))
+    for ch in chains:
+        ch.close()
+    e.close()
