@@ -248,7 +248,7 @@ static void launch_scam(mcmcx_engine *h, int it0, int it1)
     hipLaunchKernelGGL(scam_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
 }
 static void launch_adapt(mcmcx_engine *h, int it, int mode)
-{ hipLaunchKernelGGL(adapt_kernel, dim3(h->ntiles), dim3(64), lds_bytes(h) / 2, h->stream, h->E, it, mode); }   // one d-vector
+{ hipLaunchKernelGGL(adapt_kernel, dim3(h->ntiles), dim3(64), std::max(lds_bytes(h) / 2, (size_t)44 * 64 * sizeof(double)), h->stream, h->E, it, mode); }   // one d-vector / the Cholesky's diagonal block
 
 // Which branch of MCMC_adapt fires at iteration `it` (0 = none).  MCMC_adapt.F90:42-46, 60-61, 105.
 static int adapt_mode(const mcmcx_config &c, int it)

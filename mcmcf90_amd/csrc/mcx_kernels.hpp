@@ -1298,49 +1298,91 @@ __global__ __launch_bounds__(64) void init_kernel(EngineDev E)
 // mode bits chosen by the host from (simuind, namelist): see mcmcx_run.
 enum { AD_BURN = 1, AD_AM = 2, AD_FIRST = 4 };
 
-// dpotf2('U') on the packed matrix in Ct (holds C on entry, the factor on exit), then commit
-// R = R0*2.4/sqrt(d) (MCMC_calculate_R, MCMC_adapt.F90:181-230, Cholesky path).  Returns info.
-// X (LDS) holds column j above the diagonal while row j is formed.
-MCX_DEV int calculate_R(double *Ct, double *Rt, int lane, int d, int P, bool act, double *X)
+// MCMC_calculate_R, Cholesky branch (MCMC_adapt.F90:211-215): R = dpotf2('U', cmat) * 2.4/sqrt(d).
+// dpotf2 computes R(j,k) = (A(j,k) - sum_{i<j} R(i,j) R(i,k)) / R(j,j) with every sum an fma chain ascending in i
+// from 0.  Same chains here, but formed for an 8 x 8 block of (j,k) at a time: the 64 accumulators stay in registers
+// while the finished rows i < J0 stream by once per block (16 loads per 64 fma instead of 1 per fma), then the rows
+// of the block row itself are folded in -- from registers on the diagonal block, whose finished rows and 1/R(j,j) are
+// parked in LDS for the blocks to its right.  At: cmat (read), Tt: the factor (written, and read back as rows i < J0),
+// Rt: scaled copy on success.  X: 44 LDS vectors.  Returns LAPACK's info (0, or j+1 at the first non-positive pivot).
+constexpr int BT = 8;
+#define MCX_DLI(a, b) ((a) * (17 - (a)) / 2 + ((b) - (a)))
+MCX_DEV int calculate_R(const double *At, double *Tt, double *Rt, int lane, int d, int P, bool act, double *X)
 {
     int info = 0;
-    for (int j = 0; j < d; ++j) {
-        double dot = 0.0;
-        for (int i0 = 0; i0 < j; i0 += CH) {
-            double v[CH];
+    for (int J0 = 0; J0 < d; J0 += BT) {
+        const int nr = (d - J0) < BT ? (d - J0) : BT;
+        for (int K0 = J0; K0 < d; K0 += BT) {
+            const int nc = (d - K0) < BT ? (d - K0) : BT;
+            const bool diag = (K0 == J0);
+            double T[BT][BT];
 #pragma unroll
-            for (int u = 0; u < CH; ++u) { int i = (i0 + u < j) ? i0 + u : j - 1; v[u] = GV(Ct, pidx(i, j, d)); }
+            for (int a = 0; a < BT; ++a)
 #pragma unroll
-            for (int u = 0; u < CH; ++u) if (i0 + u < j) { XL(i0 + u) = v[u]; dot = dfma(v[u], v[u], dot); }
-        }
-        double *rowj = Ct + (size_t)rowstart(j, d) * 64;
-        double ajj = GV(rowj, 0) - dot;
-        bool ok = (ajj > 0.0);
-        if (act && info == 0 && !ok) { info = j + 1; }
-        bool go = act && info == 0;
-        double rj = sqrt(ajj);
-        if (go) GV(rowj, 0) = rj;
-        double rinv = 1.0 / rj;
-        for (int k = j + 1; k < d; ++k) {
-            if (go) {
-                double t = 0.0;
-                for (int i0 = 0; i0 < j; i0 += CH) {
-                    double v[CH];
+                for (int b = 0; b < BT; ++b) T[a][b] = 0.0;
+#pragma unroll 2
+            for (int i = 0; i < J0; ++i) {
+                const double *rowi = Tt + (size_t)rowstart(i, d) * 64;             // element (i,k) at rowi[k - i]
+                double rj[BT], rk[BT];
 #pragma unroll
-                    for (int u = 0; u < CH; ++u) { int i = (i0 + u < j) ? i0 + u : j - 1; v[u] = GV(Ct, pidx(i, k, d)); }
+                for (int a = 0; a < BT; ++a) rj[a] = GV(rowi, J0 - i + (a < nr ? a : nr - 1));
 #pragma unroll
-                    for (int u = 0; u < CH; ++u) if (i0 + u < j) t = dfma(v[u], XL(i0 + u), t);
+                for (int b = 0; b < BT; ++b) rk[b] = GV(rowi, K0 - i + (b < nc ? b : nc - 1));
+#pragma unroll
+                for (int a = 0; a < BT; ++a)
+#pragma unroll
+                    for (int b = 0; b < BT; ++b) T[a][b] = dfma(rj[a], rk[b], T[a][b]);
+            }
+#pragma unroll
+            for (int a = 0; a < BT; ++a) {
+                if (a < nr) {
+                    const int j = J0 + a;
+                    const double *arow = At + (size_t)rowstart(j, d) * 64;
+                    double *trow = Tt + (size_t)rowstart(j, d) * 64;
+                    double av[BT];
+#pragma unroll
+                    for (int b = 0; b < BT; ++b) { int k = K0 + (b < nc ? b : nc - 1); av[b] = GV(arow, (k >= j ? k : j) - j); }
+                    if (diag) {
+#pragma unroll
+                        for (int a2 = 0; a2 < a; ++a2)
+#pragma unroll
+                            for (int b = a; b < BT; ++b) T[a][b] = dfma(T[a2][a], T[a2][b], T[a][b]);
+                        const double ajj = av[a] - T[a][a];
+                        if (act && info == 0 && !(ajj > 0.0)) info = j + 1;
+                        const double rjj = sqrt(ajj), rinv = 1.0 / rjj;
+                        T[a][a] = rjj;
+#pragma unroll
+                        for (int b = a + 1; b < BT; ++b) T[a][b] = (av[b] - T[a][b]) * rinv;
+#pragma unroll
+                        for (int b = a; b < BT; ++b) {
+                            if (b < nc) { GV(trow, K0 + b - j) = T[a][b]; X[MCX_DLI(a, b) * 64 + lane] = T[a][b]; }
+                        }
+                        X[(36 + a) * 64 + lane] = rinv;
+                    } else {
+#pragma unroll
+                        for (int a2 = 0; a2 < a; ++a2) {
+                            const double dl = X[MCX_DLI(a2, a) * 64 + lane];
+#pragma unroll
+                            for (int b = 0; b < BT; ++b) T[a][b] = dfma(dl, T[a2][b], T[a][b]);
+                        }
+                        const double rinv = X[(36 + a) * 64 + lane];
+#pragma unroll
+                        for (int b = 0; b < BT; ++b) {
+                            T[a][b] = (av[b] - T[a][b]) * rinv;
+                            if (b < nc) GV(trow, K0 + b - j) = T[a][b];
+                        }
+                    }
                 }
-                GV(rowj, k - j) = (GV(rowj, k - j) - t) * rinv;
             }
         }
     }
     if (act && info == 0) {
         double sq = sqrt((double)d);
-        for (int e = 0; e < P; ++e) GV(Rt, e) = GV(Ct, e) * 2.4 / sq;
+        for (int e = 0; e < P; ++e) GV(Rt, e) = GV(Tt, e) * 2.4 / sq;
     }
     return info;
 }
+#undef MCX_DLI
 
 // dpotri('U') on a packed upper factor, in place: dtrti2('U','N') then dlauu2('U') (MCMC_adapt.F90:217-224).
 // On exit A holds the upper triangle of inv(R'R).  X (LDS) carries one column above the diagonal.
@@ -1782,8 +1824,7 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
             }
         }
     } else if (__any(docalc)) {
-        if (docalc) for (int e = 0; e < P; ++e) GV(Tt, e) = GV(Ct, e);
-        int info = calculate_R(Tt, Rt, lane, d, P, docalc, X);
+        int info = calculate_R(Ct, Tt, Rt, lane, d, P, docalc, X);
         if (docalc) {
             TIDX(E.ictr, tile, NICTR, I_INFO, lane) = (uint32_t)info;
             if (info != 0) TIDX(E.ictr, tile, NICTR, I_STATUS, lane) |= ST_CHOL_FAIL;   // warning, old R kept (:168-171)
