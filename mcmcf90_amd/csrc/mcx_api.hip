@@ -223,6 +223,22 @@ static void launch_step(mcmcx_engine *h, int it0, int it1)
     else if (h->pooled) hipLaunchKernelGGL((step_kernel<false, false, true>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else hipLaunchKernelGGL((step_kernel<false, false, false>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
 }
+// every chain's copy of a K-vector, filled on the device
+static int dev_bcast(mcmcx_engine *h, double *dst, const std::vector<double> &v)
+{
+    double *tmp = nullptr;
+    HIPCHK(hipMalloc(&tmp, v.size() * sizeof(double)));
+    hipError_t e = hipMemcpy(tmp, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const unsigned gy = (unsigned)std::min<size_t>(v.size(), 64);
+        hipLaunchKernelGGL(bcast_kernel, dim3(h->ntiles, gy), dim3(64), 0, h->stream, dst, tmp, v.size());
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(-100, hipGetErrorString(e));
+    return 0;
+}
 static size_t shared_u_stride(const mcmcx_engine *h) { return (size_t)((h->d + 3) & ~3) * h->d + PWS; }     // d4 rows (pad rows zero) + slack
 static size_t scam_pooled_lds(int d) { return ((size_t)((d + 15) / 16) * (16 + 4) * 64 + 128) * sizeof(double); }     // X [16 nt][64], Q [4 nt][64], zb, fl
 static int upload_shared_u(mcmcx_engine *h)
@@ -248,7 +264,10 @@ static void launch_scam(mcmcx_engine *h, int it0, int it1)
     hipLaunchKernelGGL(scam_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
 }
 static void launch_adapt(mcmcx_engine *h, int it, int mode)
-{ hipLaunchKernelGGL(adapt_kernel, dim3(h->ntiles), dim3(64), std::max(lds_bytes(h) / 2, (size_t)44 * 64 * sizeof(double)), h->stream, h->E, it, mode); }   // one d-vector / the Cholesky's diagonal block
+{
+    const size_t lds = std::max(lds_bytes(h) / 2, (size_t)44 * 64 * sizeof(double));    // one d-vector / the Cholesky's diagonal block
+    hipLaunchKernelGGL(adapt_kernel, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode);
+}
 
 // Which branch of MCMC_adapt fires at iteration `it` (0 = none).  MCMC_adapt.F90:42-46, 60-61, 105.
 static int adapt_mode(const mcmcx_config &c, int it)
@@ -648,16 +667,12 @@ int mcmcx_init(mcmcx_handle h)
         if ((rc = dev_alloc(h, &E.Vw, L * DD))) return rc;
         if ((rc = dev_alloc(h, &E.qstd, L * d))) return rc;
         if (h->dodr && (rc = dev_alloc(h, &E.R2f, L * DD, false))) return rc;
-        std::vector<double> rf(L * DD), qs(L * d);
-        for (int t = 0; t < T; ++t) {
-            for (size_t e = 0; e < DD; ++e) for (int l = 0; l < 64; ++l) rf[((size_t)t * DD + e) * 64 + l] = Rfull[e];
-            for (int k = 0; k < d; ++k) for (int l = 0; l < 64; ++l) qs[((size_t)t * d + k) * 64 + l] = qstd0[k];
-        }
-        HIPCHK(hipMemcpy(E.Rf, rf.data(), rf.size() * 8, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(E.qstd, qs.data(), qs.size() * 8, hipMemcpyHostToDevice));
+        if ((rc = dev_bcast(h, E.Rf, Rfull))) return rc;
+        if ((rc = dev_bcast(h, E.qstd, qstd0))) return rc;
         if (h->dodr) {
-            for (auto &v : rf) v = v / c.drscale;
-            HIPCHK(hipMemcpy(E.R2f, rf.data(), rf.size() * 8, hipMemcpyHostToDevice));
+            std::vector<double> r2 = Rfull;
+            for (auto &v : r2) v = v / c.drscale;
+            if ((rc = dev_bcast(h, E.R2f, r2))) return rc;
         }
     }
     E.R2 = E.iC = nullptr;
@@ -715,11 +730,9 @@ int mcmcx_init(mcmcx_handle h)
 
     // fill theta = par0, R = R(cmat0), chaincmat = cmat0, chainmean = par0, scalars
     {
-        std::vector<double> th(L * d), Rv(h->pooled ? 0 : L * P), sc(L * NSCAL, 0.0);
+        std::vector<double> sc(L * NSCAL, 0.0);
         std::vector<uint32_t> ic(L * NICTR, 0u);
-        for (int t = 0; t < T; ++t) {
-            for (int k = 0; k < d; ++k) for (int l = 0; l < 64; ++l) th[((size_t)t * d + k) * 64 + l] = h->par0[k];
-            if (!h->pooled) for (int e = 0; e < P; ++e) for (int l = 0; l < 64; ++l) Rv[((size_t)t * P + e) * 64 + l] = Rp[e];
+        for (int t = 0; t < T; ++t)
             for (int l = 0; l < 64; ++l) {
                 sc[((size_t)t * NSCAL + S_SIGMA2) * 64 + l] = h->sigma2;
                 sc[((size_t)t * NSCAL + S_WSUM) * 64 + l] = (double)c.initcmatn;
@@ -728,36 +741,23 @@ int mcmcx_init(mcmcx_handle h)
                 ic[((size_t)t * NICTR + I_BASECNT) * 64 + l] = 1;
                 ic[((size_t)t * NICTR + I_WINSTART) * 64 + l] = 2;
             }
-        }
-        HIPCHK(hipMemcpyAsync(E.theta, th.data(), th.size() * 8, hipMemcpyHostToDevice, h->stream));
-        if (!h->pooled) HIPCHK(hipMemcpyAsync(E.R, Rv.data(), Rv.size() * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(E.scal, sc.data(), sc.size() * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(E.ictr, ic.data(), ic.size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if ((rc = dev_bcast(h, E.theta, h->par0))) return rc;
+        if (!h->pooled && (rc = dev_bcast(h, E.R, Rp))) return rc;
         if (h->dodr) {                                   // iC = dpotri(R), R2 = R/drscale, MCMC_adapt.F90:216-225
             std::vector<double> iCp = Rp, R2p(P);
             if (h->usesvd) for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) iCp[h_pidx(i, j, d)] = Rfull[(size_t)j * d + i];
             if (host_potri(d, iCp) != 0) return fail(-34, "ERROR: cannot invert cmat");
             for (int e = 0; e < P; ++e) R2p[e] = Rp[e] / c.drscale;
-            std::vector<double> v2(L * P), vi(L * P);
-            for (int t = 0; t < T; ++t)
-                for (int e = 0; e < P; ++e) for (int l = 0; l < 64; ++l) {
-                    v2[((size_t)t * P + e) * 64 + l] = R2p[e]; vi[((size_t)t * P + e) * 64 + l] = iCp[e];
-                }
-            HIPCHK(hipMemcpyAsync(E.R2, v2.data(), v2.size() * 8, hipMemcpyHostToDevice, h->stream));
-            HIPCHK(hipMemcpyAsync(E.iC, vi.data(), vi.size() * 8, hipMemcpyHostToDevice, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
+            if ((rc = dev_bcast(h, E.R2, R2p))) return rc;
+            if ((rc = dev_bcast(h, E.iC, iCp))) return rc;
         }
         if (am) {
-            std::vector<double> cv(L * P), mv(L * d);
-            for (int t = 0; t < T; ++t) {
-                for (int e = 0; e < P; ++e) for (int l = 0; l < 64; ++l) cv[((size_t)t * P + e) * 64 + l] = Cp[e];
-                for (int k = 0; k < d; ++k) for (int l = 0; l < 64; ++l) mv[((size_t)t * d + k) * 64 + l] = h->par0[k];
-            }
-            HIPCHK(hipMemcpyAsync(E.cmat, cv.data(), cv.size() * 8, hipMemcpyHostToDevice, h->stream));
-            HIPCHK(hipMemcpyAsync(E.mean, mv.data(), mv.size() * 8, hipMemcpyHostToDevice, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
+            if ((rc = dev_bcast(h, E.cmat, Cp))) return rc;
+            if ((rc = dev_bcast(h, E.mean, h->par0))) return rc;
         }
-        HIPCHK(hipStreamSynchronize(h->stream));
     }
     if (h->tkind == TGT_HOST) {                         // first point: sspri1, ss1 from the host callbacks (MCMC_run.F90:35-36)
         int rc2 = host_eval(h, E.theta, d, false);

@@ -1273,6 +1273,13 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
 }
 
 // ---------------------------------------------------------------- first point (MCMC_run.F90:33-39)
+// dst[(tile*K + e)*64 + lane] = src[e]: every chain starts from the same K-vector (par0, R(cmat0), ...)
+__global__ __launch_bounds__(64) void bcast_kernel(double *dst, const double *__restrict__ src, size_t K)
+{
+    double *o = dst + (size_t)blockIdx.x * K * 64;
+    for (size_t e = blockIdx.y; e < K; e += gridDim.y) o[e * 64 + threadIdx.x] = src[e];
+}
+
 __global__ __launch_bounds__(64) void init_kernel(EngineDev E)
 {
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
@@ -1599,26 +1606,35 @@ MCX_DEV void covmat_window_blocked(const EngineDev &E, int tile, int lane, bool 
                 }
                 W = on ? (w3 + W) : W;
             };
-            for (int t = t0; t <= t1; ++t) {
-                const int slot = t % E.wcap;
-                const bool inwin = act && (t >= t0lane);
-                const bool acc = inwin && ((wacc_t[slot] >> lane) & 1ull);
-                if (__any(acc)) {
-                    const bool fl = acc && have;
-                    if (__any(fl)) fold(fl, unit ? 1.0 : (double)(cnt - adj));
-                    if (acc) {
-                        const size_t so = (size_t)slot * (size_t)(d + 1) * 64;
+            // The accept ballots of 64 iterations at a time sit in one register per lane (one coalesced load) and are
+            // handed out by v_readlane: the loop's control flow never waits on a dependent global load.
+            for (int tc = t0; tc <= t1; tc += 64) {
+                const int tl = tc + lane;
+                const unsigned long long mine = (tl <= t1) ? wacc_t[tl % E.wcap] : 0ull;
+                const int nq = (t1 - tc + 1) < 64 ? (t1 - tc + 1) : 64;
+                for (int q = 0; q < nq; ++q) {
+                    const int t = tc + q, slot = t % E.wcap;
+                    const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), q) << 32)
+                                                 | (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mine, q);
+                    const bool inwin = act && (t >= t0lane);
+                    const bool acc = inwin && ((m >> lane) & 1ull);
+                    if (__any(acc)) {
+                        const bool fl = acc && have;
+                        if (__any(fl)) fold(fl, unit ? 1.0 : (double)(cnt - adj));
+                        if (acc) {
+                            const size_t so = (size_t)slot * (size_t)(d + 1) * 64;
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int a = (a0 + u < d) ? a0 + u : d - 1, b = (b0 + u < d) ? b0 + u : d - 1;
-                            xa[u] = hist_t[so + (size_t)a * 64 + lane];
-                            xb[u] = hist_t[so + (size_t)b * 64 + lane];
+                            for (int u = 0; u < 8; ++u) {
+                                const int a = (a0 + u < d) ? a0 + u : d - 1, b = (b0 + u < d) ? b0 + u : d - 1;
+                                xa[u] = hist_t[so + (size_t)a * 64 + lane];
+                                xb[u] = hist_t[so + (size_t)b * 64 + lane];
+                            }
+                            if (have) adj = 0;
+                            have = true; cnt = 1;
                         }
-                        if (have) adj = 0;
-                        have = true; cnt = 1;
                     }
+                    if (inwin && !acc) cnt += 1;
                 }
-                if (inwin && !acc) cnt += 1;
             }
             if (__any(have)) fold(have, unit ? 1.0 : (double)(cnt - adj));
             // write the block back (upper triangle only) and, from the diagonal blocks, the means
