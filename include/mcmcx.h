@@ -90,8 +90,18 @@ int mcmcx_set_priors(mcmcx_handle h, const double *mu, const double *sig);      
 int mcmcx_set_stream(mcmcx_handle h, void *hip_stream);
 
 int mcmcx_init(mcmcx_handle h);
-int mcmcx_run(mcmcx_handle h, int32_t upto);                   /* iterations simuind+1 .. upto */
+/* iterations simuind+1 .. upto.  Returns MCMCX_INTERRUPTED (> 0) when a signal caught by
+ * mcmcx_install_signal_handlers arrived: the run stopped at a launch boundary, mcmcx_simuind() says where, and
+ * every getter is valid for the iterations done (the reference saves the chain "upto simuind" and stops,
+ * MCMC_signal_handler.F90:95-107) */
+int mcmcx_run(mcmcx_handle h, int32_t upto);
 int mcmcx_sync(mcmcx_handle h);
+#define MCMCX_INTERRUPTED 2
+/* SIGHUP, SIGINT, SIGTERM, SIGTSTP, SIGUSR1, SIGUSR2 (the set of signalqq.c:57-62) raise a flag that mcmcx_run
+ * polls between kernel launches; mcmcx_interrupted() reads it, mcmcx_clear_interrupt() resets it */
+int mcmcx_install_signal_handlers(void);
+int mcmcx_interrupted(void);
+void mcmcx_clear_interrupt(void);
 
 int32_t mcmcx_simuind(mcmcx_handle h);
 /* counters[0..7] = stayed, bndstayed, draccepted, drtries, chainind, status bits, erstayed, run length of the

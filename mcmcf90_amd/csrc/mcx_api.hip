@@ -6,6 +6,7 @@
 // form.  No CPU fallback: every numerical step of the sampler runs in the HIP kernels
 // of mcx_kernels.hpp; without a GPU every entry point that needs one fails.
 #include <hip/hip_runtime.h>
+#include <csignal>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -771,6 +772,23 @@ int mcmcx_init(mcmcx_handle h)
     return 0;
 }
 
+static volatile sig_atomic_t g_interrupt = 0;
+static bool g_sig_installed = false;       // then mcmcx_run waits for each launch, so that a signal is seen at the next boundary
+static void on_signal(int) { g_interrupt = 1; }
+int mcmcx_install_signal_handlers(void)
+{
+    struct sigaction act;
+    memset(&act, 0, sizeof(act));
+    act.sa_handler = on_signal;
+    sigemptyset(&act.sa_mask);
+    const int sigs[] = {SIGHUP, SIGINT, SIGTERM, SIGTSTP, SIGUSR1, SIGUSR2};
+    for (int sg : sigs) if (sigaction(sg, &act, nullptr) != 0) return fail(-1, "sigaction failed");
+    g_sig_installed = true;
+    return 0;
+}
+int mcmcx_interrupted(void) { return g_interrupt ? 1 : 0; }
+void mcmcx_clear_interrupt(void) { g_interrupt = 0; }
+
 int mcmcx_run(mcmcx_handle h, int32_t upto)
 {
     if (!h) return fail(-1, "null handle");
@@ -781,6 +799,11 @@ int mcmcx_run(mcmcx_handle h, int32_t upto)
     const int maxseg = (c.method == MCMCX_METHOD_RAM) ? 4096 : 1 << 30;
     int it = h->simuind + 1;
     while (it <= upto) {
+        if (g_interrupt) {                                  // a caught signal: stop at this launch boundary
+            int rc = mcmcx_sync(h); if (rc) return rc;
+            h->simuind = it - 1;
+            return MCMCX_INTERRUPTED;
+        }
         int end = it, mode = 0;
         for (;; ++end) {                                    // extend the launch up to the next tick
             mode = adapt_mode(c, end);
@@ -803,6 +826,7 @@ int mcmcx_run(mcmcx_handle h, int32_t upto)
             else { launch_adapt(h, end, mode); HIPCHK(hipGetLastError()); }
         }
         it = end + 1;
+        if (g_sig_installed) { HIPCHK(hipStreamSynchronize(h->stream)); h->simuind = std::max(h->simuind, end); }
         if (h->pending.size() > 4096) { int rc = mcmcx_sync(h); if (rc) return rc; }
     }
     h->simuind = std::max(h->simuind, (int)upto);
@@ -836,6 +860,8 @@ int mcmcx_kernel_time(mcmcx_handle h, double *ms, int64_t *launches, int64_t *st
 }
 
 int32_t mcmcx_simuind(mcmcx_handle h) { return h ? h->simuind : -1; }
+
+
 
 int mcmcx_get_counters(mcmcx_handle h, int32_t chain, int32_t *out)
 {

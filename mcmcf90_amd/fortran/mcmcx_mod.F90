@@ -29,11 +29,11 @@
 !!! MCMC_writechains (MCMC_aux.F90:25-69) in ASCII for chain 0.
 module mcmcmod
   use iso_c_binding
+  use mcmcprec
+  use matutils
   implicit none
   public
 
-  integer, parameter :: dbl = kind(1.0d0)
-  integer, parameter :: ik4 = c_int32_t
   character(len=*), parameter :: Mcmc_Code_Version = 'mcmcx 0.1 (MI355X engine behind the mcmcf90 1.2.8 surface)'
 
   !! namelist /mcmc/ variables, mcmcinit.F90:20-62
@@ -76,7 +76,8 @@ module mcmcmod
   real(kind=dbl), allocatable, save, private :: par0(:), cmat0(:,:)
   real(kind=dbl), allocatable, save, private :: tmu(:), tlam(:,:), tx(:), ty(:), tlo(:), thi(:), pmu(:), psig(:)
   logical, save, private :: par0ok = .false., cmat0ok = .false., sigma2ok = .false., nparok = .false.
-  logical, save, private :: has_lo = .false., has_hi = .false.
+  logical, save, private :: has_lo = .false., has_hi = .false., interrupted = .false.
+  character(len=32), save, private :: seedfile_used = ''
   type(c_ptr), save, private :: handle = c_null_ptr
 
   interface MCMC_setpar0
@@ -214,6 +215,21 @@ module mcmcmod
        real(c_double), intent(out) :: cm(*), mean(*), wsum
        integer(c_int) :: rc
      end function
+     function mcmcx_get_theta(h, out) bind(C, name='mcmcx_get_theta') result(rc)
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h
+       real(c_double), intent(out) :: out(*)
+       integer(c_int) :: rc
+     end function
+     function mcmcx_simuind(h) bind(C, name='mcmcx_simuind') result(n)
+       import :: c_ptr, c_int32_t
+       type(c_ptr), value :: h
+       integer(c_int32_t) :: n
+     end function
+     function mcmcx_install_signal_handlers() bind(C, name='mcmcx_install_signal_handlers') result(rc)
+       import :: c_int
+       integer(c_int) :: rc
+     end function
      function mcmcx_get_scalars(h, out) bind(C, name='mcmcx_get_scalars') result(rc)
        import :: c_ptr, c_int, c_double
        type(c_ptr), value :: h
@@ -223,13 +239,6 @@ module mcmcmod
   end interface
 
 contains
-
-  !! doerror, matutils.F90:764-789: message + stop
-  subroutine doerror(msg)
-    character(len=*), intent(in) :: msg
-    write(*,*) 'ERROR: ', trim(msg)
-    stop 1
-  end subroutine doerror
 
   subroutine chk(rc)
     integer(c_int), intent(in) :: rc
@@ -472,87 +481,47 @@ contains
     if (checkbounds(t)) ok = 1
   end function mcx_bounds_adapter
 
-  !! ---------------------------------------------------------------- ASCII numbers: matutils.F90:1019-1056 rules
-  subroutine loadnumbers(file, v, nrows, ncols, stat)
-    character(len=*), intent(in) :: file
-    real(kind=dbl), allocatable, intent(out) :: v(:)
-    integer, intent(out) :: nrows, ncols, stat
-    character(len=8192) :: line
-    real(kind=dbl) :: tmp(4096)
-    real(kind=dbl), allocatable :: buf(:), nb(:)
-    integer :: u, ios, n, i, k, ntot
-    character(len=1) :: c
-    stat = 0; nrows = 0; ncols = 0; ntot = 0
-    allocate(buf(1024))
-    open(newunit=u, file=file, status='old', iostat=ios)
-    if (ios /= 0) then
-       stat = -1; allocate(v(0)); return
-    end if
-    do
-       read(u, '(A)', iostat=ios) line
-       if (ios /= 0) exit
-       line = adjustl(line)
-       if (len_trim(line) == 0) cycle
-       c = line(1:1)
-       if (c == '#' .or. c == '%' .or. c == '!' .or. c == 'C' .or. c == 'c') cycle
-       do i = 1, len_trim(line)
-          if (line(i:i) == ',' .or. line(i:i) == ';' .or. line(i:i) == achar(9)) line(i:i) = ' '
-       end do
-       n = 0
-       do k = 1, 4096                               ! count the numbers on this line
-          read(line, *, iostat=ios) tmp(1:k)
-          if (ios /= 0) exit
-          n = k
-       end do
-       if (n == 0) cycle
-       if (ntot + n > size(buf)) then
-          allocate(nb(2*size(buf) + n)); nb(1:ntot) = buf(1:ntot); call move_alloc(nb, buf)
+  !! ---------------------------------------------------------------- initial values, MCMC_init.F90:44-70
+  !! After MCMC_setpar0 the missing pieces get the reference's defaults (cmat0 = MCMC_initcmat0: unit matrix;
+  !! sigma2 = 1, nobs = 1); otherwise the link-time `initialize` (external_inc.h:35-43; default = files,
+  !! defaults/initialize0.F90, overridable like in libmcmcrun.a) allocates and fills everything.
+  subroutine MCMC_initial_values()
+    real(kind=dbl), allocatable :: p0(:), c0(:,:), s2(:)
+    integer, allocatable :: nob(:)
+    integer :: np, i
+    interface
+       subroutine initialize(par0,npar,cmat0,initcmatn,sigma2,nobs,nycol)
+         use mcmcprec
+         implicit none
+         integer, intent(inout) :: npar, initcmatn, nycol
+         real(kind=dbl), intent(inout), allocatable :: par0(:), cmat0(:,:)
+         real(kind=dbl), intent(inout), allocatable :: sigma2(:)
+         integer, intent(inout), allocatable :: nobs(:)
+       end subroutine initialize
+    end interface
+    if (nparok) then
+       if (verbosity > 0) write(*,*) 'note: user init for par0'
+       if (.not.par0ok) call doerror('user initialization error')
+       if (.not.cmat0ok) then
+          allocate(c0(npar,npar)); c0 = 0.0_dbl
+          do i = 1, npar
+             c0(i,i) = 1.0_dbl
+          end do
+          call MCMC_setcmat0_mat(c0)
        end if
-       buf(ntot+1:ntot+n) = tmp(1:n)
-       ntot = ntot + n
-       nrows = nrows + 1
-       if (nrows == 1) ncols = n
-    end do
-    close(u)
-    allocate(v(ntot)); v = buf(1:ntot)
-    if (nrows > 0 .and. ncols*nrows /= ntot) ncols = ntot / nrows
-  end subroutine loadnumbers
-
-  subroutine writenumbers(file, a)
-    character(len=*), intent(in) :: file
-    real(kind=dbl), intent(in) :: a(:,:)
-    integer :: u, i
-    open(newunit=u, file=file, status='replace')
-    do i = 1, size(a,1)
-       write(u, '(*(ES24.16E3,1X))') a(i,:)
-    end do
-    close(u)
-  end subroutine writenumbers
-
-  !! ---------------------------------------------------------------- the default `initialize`, initialize.F90:41-119
-  subroutine initialize_from_files()
-    real(kind=dbl), allocatable :: v(:)
-    integer :: nr, nc, stat
-    if (.not.par0ok) then
-       call loadnumbers(parfile, v, nr, nc, stat)
-       if (stat /= 0 .or. size(v) < 1) call doerror('Error reading file, '//trim(parfile))
-       call MCMC_setpar0_vec(v)
+       if (.not.sigma2ok) call MCMC_setsigma2nobs_sca(1.0_dbl, 1)
+    else
+       np = npar
+       call initialize(p0, np, c0, initcmatn, s2, nob, nycol)
+       if (.not.allocated(p0) .or. .not.allocated(c0) .or. .not.allocated(s2) .or. .not.allocated(nob)) &
+            call doerror('initialize did not allocate par0, cmat0, sigma2, nobs')
+       if (nycol /= 1) call doerror('nycol > 1 is not available in the device engine')
+       call MCMC_setpar0_vec(p0)
+       if (size(c0,1) /= npar .or. size(c0,2) /= npar) call doerror('initialize: cmat0 is not npar x npar')
+       call MCMC_setcmat0_mat(c0)
+       call MCMC_setsigma2nobs_sca(s2(1), nob(1))
     end if
-    if (.not.cmat0ok) then
-       call loadnumbers(cov0file, v, nr, nc, stat)
-       if (stat /= 0 .or. nr /= npar .or. nc /= npar) call doerror('Error reading file mcmccov.dat')
-       call MCMC_setcmat0_mat(transpose(reshape(v, (/nc, nr/))))
-    end if
-    if (.not.sigma2ok) then
-       call loadnumbers(sigma2file, v, nr, nc, stat)
-       if (stat /= 0) then
-          call MCMC_setsigma2nobs_sca(1.0_dbl, 1)
-       else
-          if (size(v) < 2) call doerror('error in mcmcsigma2.dat (obs: new format 4.8.2006)')
-          call MCMC_setsigma2nobs_sca(v(1), int(v(2)))
-       end if
-    end if
-  end subroutine initialize_from_files
+  end subroutine MCMC_initial_values
 
   subroutine load_target_from_files()
     real(kind=dbl), allocatable :: v(:), w(:)
@@ -602,7 +571,19 @@ contains
     real(kind=dbl), target, allocatable :: lo(:), hi(:)
     real(kind=dbl) :: lamrow(npar*npar)
     type(c_ptr) :: plo, phi
-    integer :: i, j
+    real(kind=dbl), allocatable :: th(:)
+    integer :: i, j, upto
+    integer(c_int) :: rc
+    interface
+       subroutine dump_init()
+       end subroutine dump_init
+       subroutine dump(oldpar)
+         use mcmcprec
+         real(kind=dbl), intent(in) :: oldpar(:)
+       end subroutine dump
+    end interface
+    call chk(mcmcx_install_signal_handlers())           ! signal_handler_init, MCMC_signal_handler.F90:21-60
+    call read_seed_file()
     call mcmcx_config_defaults(cfg)
     cfg%npar = npar; cfg%nchains = nchains; cfg%nsimu = nsimu
     select case (trim(method))
@@ -648,11 +629,35 @@ contains
     if (has_lo .or. has_hi) call chk(mcmcx_set_bounds(handle, plo, phi))
     if (allocated(pmu)) call chk(mcmcx_set_priors(handle, pmu, psig))
     call chk(mcmcx_init(handle))
+    call dump_init()                                    ! MCMC_dump_init, MCMC_run.F90:38
     MCMC_running = 1
-    call chk(mcmcx_run(handle, int(nsimu, c_int32_t)))
+    interrupted = .false.
+    upto = 1
+    do while (upto < nsimu)
+       !! MCMC_dump(oldpar) (MCMC_run.F90:102): with dumpint > 0 the run is cut every dumpint iterations and the
+       !! user's dump sees the current point of chain 1 (the reference calls it at every iteration)
+       if (dumpint > 0) then
+          upto = min(nsimu, (upto / dumpint + 1) * dumpint)
+       else
+          upto = nsimu
+       end if
+       rc = mcmcx_run(handle, int(upto, c_int32_t))
+       call chk(rc)
+       if (rc == 2) then                                ! MCMCX_INTERRUPTED: cc_handler, MCMC_signal_handler.F90:95-107
+          interrupted = .true.
+          exit
+       end if
+       if (dumpint > 0) then
+          allocate(th(npar*nchains))
+          call chk(mcmcx_get_theta(handle, th))
+          call dump(th(1:npar))
+          deallocate(th)
+       end if
+    end do
     call chk(mcmcx_sync(handle))
     MCMC_running = 0
-    simuind = nsimu
+    simuind = mcmcx_simuind(handle)
+    if (interrupted) write(*,*) 'Saving chain upto ', simuind
     !! chain 0 in the reference's arrays
     allocate(ch(nsimu*(npar+1)), ss(nsimu*2), s2(nsimu), cm(npar*npar), sc(4*nchains))
     call chk(mcmcx_get_chain(handle, 0_c_int32_t, ch, ss, s2, nrows))
@@ -666,7 +671,7 @@ contains
     end do
     if (updatesigma /= 0) then
        if (allocated(s2chain)) deallocate(s2chain)
-       allocate(s2chain(nsimu,1)); s2chain(:,1) = s2
+       allocate(s2chain(nsimu,1)); s2chain = 0.0_dbl; s2chain(1:simuind,1) = s2(1:simuind)
     end if
     if (allocated(chaincmat)) deallocate(chaincmat, chainmean)
     allocate(chaincmat(npar,npar), chainmean(npar))
@@ -739,8 +744,55 @@ contains
     end if
   end subroutine MCMC_writechains
 
+  !! the stream's key lives in the reference's seed file (mcmcrand.F90:28-40, 214-238): an integer there replaces
+  !! the &mcmcx seed, and the end of job (random_eoj, :317-342) leaves the next run's key, so reruns are
+  !! reproducible and successive runs continue with fresh streams
+  subroutine read_seed_file()
+    integer :: u, ios, v
+    logical :: ex
+    seedfile_used = ''
+    inquire(file='gfortran_seed.dat', exist=ex)
+    if (ex) then
+       seedfile_used = 'gfortran_seed.dat'
+    else
+       inquire(file='random_seed.dat', exist=ex)
+       if (ex) seedfile_used = 'random_seed.dat'
+    end if
+    if (len_trim(seedfile_used) == 0) return
+    open(newunit=u, file=seedfile_used, status='old', iostat=ios)
+    if (ios /= 0) return
+    read(u, *, iostat=ios) v
+    close(u)
+    if (ios == 0) then
+       seed = v
+       if (verbosity > 0) write(*,*) 'note: read the seed from '//trim(seedfile_used)
+    end if
+  end subroutine read_seed_file
+
+  subroutine write_seed_file()
+    integer :: u, ios
+    integer(kind=8) :: nx
+    if (len_trim(seedfile_used) == 0) return
+    nx = mod(int(seed, 8) * 6364136223846793005_8 + 1442695040888963407_8 + int(simuind, 8), 2147483647_8)
+    if (nx < 0) nx = -nx
+    open(newunit=u, file=seedfile_used, status='replace', iostat=ios)
+    if (ios /= 0) return
+    write(u, *) int(nx)
+    close(u)
+  end subroutine write_seed_file
+
+  logical function was_interrupted()
+    was_interrupted = interrupted
+  end function was_interrupted
+
   subroutine MCMC_cleanup()
     integer(c_int) :: rc
+    interface
+       subroutine dump_end()
+       end subroutine dump_end
+    end interface
+    call write_seed_file()                              ! random_eoj, MCMC_aux.F90:115
+    call dump_end()                                     ! MCMC_dump_end, MCMC_aux.F90:116
     rc = mcmcx_destroy(handle)
     handle = c_null_ptr
     nparok = .false.; par0ok = .false.; cmat0ok = .false.; sigma2ok = .false.
@@ -760,9 +812,10 @@ subroutine mcmc_main()
      write(*,*) 'nsimu <= 0 stopping'
      stop
   end if
-  call initialize_from_files()
+  call MCMC_initial_values()
   call load_target_from_files()
   call MCMC_engine_run()
   call MCMC_writechains()
   call MCMC_cleanup()
+  if (was_interrupted()) stop 'Coltrol-c interrupt'      ! [sic] MCMC_signal_handler.F90:105
 end subroutine mcmc_main

@@ -56,3 +56,28 @@ def test_shim_rejects_bad_namelist():
         out = p.stdout.decode(errors="replace")
     assert "Error reading mcmc namelist" in out and "No mcmc run" in out      # mcmcinit.F90:129-137
     assert p.returncode != 0
+
+
+def test_reference_example_programs_link_unmodified():
+    """The reference's own testcases/mcmcrun{,2,3,4}.F90 (use mcmcprec / matutils / mcmcmod, external ssfunction,
+    checkbounds, a user `initialize`) compile and link without a change against libmcmcxf.a + libmcmcx.so
+    (oracle/Makefile, target testcases); without a GPU the program must stop loudly, never sample on the CPU."""
+    import shutil, subprocess, tempfile
+    if not os.path.isdir("/root/reference/testcases"):
+        pytest.skip("/root/reference is only in the dev container")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "mcmcf90_amd", "fortran")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "testcases"])
+    for t in ("tc_mcmcrun", "tc_mcmcrun2", "tc_mcmcrun3", "tc_mcmcrun4"):
+        assert os.path.exists(os.path.join(root, "oracle", "_ref", t))
+    import torch
+    if torch.cuda.is_available():
+        return
+    with tempfile.TemporaryDirectory() as d:
+        for f in ("mcmcinit.nml", "data.dat", "mcmcpar.dat", "mcmccov.dat", "mcmcsigma2.dat"):
+            shutil.copy(os.path.join("/root/reference/testcases", f), d)
+        p = subprocess.run([os.path.join(root, "oracle", "_ref", "tc_mcmcrun")], cwd=d, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=120)
+        out = p.stdout.decode(errors="replace")
+        assert p.returncode != 0 and "no HIP device" in out, out
+        assert not os.path.exists(os.path.join(d, "chain.dat"))

@@ -133,3 +133,129 @@ def test_mat4_output_and_restart_namelist(oracle):
     np.testing.assert_array_equal(chain[:, -1].astype(np.int32), z["runlen"])
     import re
     assert re.search(r"INITCMATN\s*=\s*1000", restart) and re.search(r"BURNINTIME\s*=\s*0\b", restart)
+
+
+def _write_inputs(d, z, nml):
+    open(os.path.join(d, "mcmcinit.nml"), "w").write(nml)
+    with open(os.path.join(d, "data.dat"), "w") as f:
+        f.write("% example data set\n")
+        for x, y in zip(z["prob_xdata"], z["prob_ydata"]):
+            f.write("  %g   %.2f\n" % (x, y))
+    open(os.path.join(d, "mcmcpar.dat"), "w").write("10 0.1 \n")
+    open(os.path.join(d, "mcmccov.dat"), "w").write("0.2 0 \n0 0.001 \n")
+    open(os.path.join(d, "mcmcsigma2.dat"), "w").write("0.5\n11\n")
+
+
+@pytest.mark.parametrize("prog", ["tc_mcmcrun", "tc_mcmcrun2", "tc_mcmcrun3"])
+def test_reference_example_programs_run_unmodified(oracle, prog):
+    """oracle/_ref/tc_* are the reference's OWN example programs (testcases/mcmcrun.F90: file-based initialize;
+    mcmcrun2.F90: user-supplied `initialize` with allocatable dummies; mcmcrun3.F90: MCMC_setpar0 / _setcmat0 /
+    _setsigma2nobs before mcmc_main), compiled from /root/reference without a change and linked against the
+    engine's shim instead of libmcmcrun.a (oracle/Makefile, target testcases).  With the reference's shipped namelist
+    and input files all three must write the chain the real reference wrote (fixture c1_shipped_nml)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", prog)
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/%s was not built (needs /root/reference in the dev container)" % prog)
+    z, cfg, prob = load("c1_shipped_nml", oracle)
+    with tempfile.TemporaryDirectory() as d:
+        _write_inputs(d, z, NML.split("&mcmcx")[0])
+        p = subprocess.run([exe], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert p.returncode == 0, p.stdout.decode(errors="replace")
+        chain = np.loadtxt(os.path.join(d, "chain.dat"), ndmin=2)
+        s2 = np.loadtxt(os.path.join(d, "s2chain.dat"), ndmin=1)
+    np.testing.assert_array_equal(chain[:, -1].astype(np.int32), z["runlen"])
+    k = z["rows_head"].shape[0]
+    np.testing.assert_allclose(chain[:k, :-1], z["rows_head"], rtol=1e-9)
+    np.testing.assert_allclose(chain[-k:, :-1], z["rows_tail"], rtol=1e-9)
+    np.testing.assert_allclose(s2[-k:], z["s2_tail"], rtol=1e-9)
+
+
+def test_user_initialize_and_dump_hooks(oracle):
+    """demo_hooks.F90 overrides the optional link-time hooks: its `initialize` supplies par0 / cmat0 / sigma2 / nobs
+    without any input file, and dump_init / dump / dump_end trace the chain every dumpint iterations."""
+    exe = os.path.join(FDIR, "demo_hooks")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", FDIR])
+    z, cfg, prob = load("c1_shipped_nml", oracle)
+    nml = NML.split("&mcmcx")[0].replace("&mcmc", "&mcmc\n dumpint = 250", 1)
+    with tempfile.TemporaryDirectory() as d:
+        _write_inputs(d, z, nml)
+        for f in ("mcmcpar.dat", "mcmccov.dat", "mcmcsigma2.dat"):
+            os.remove(os.path.join(d, f))                         # the user's initialize needs none of them
+        p = subprocess.run([exe], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert p.returncode == 0, p.stdout.decode(errors="replace")
+        chain = np.loadtxt(os.path.join(d, "chain.dat"), ndmin=2)
+        trace = open(os.path.join(d, "dump_trace.dat")).read().splitlines()
+    np.testing.assert_array_equal(chain[:, -1].astype(np.int32), z["runlen"])
+    assert trace[0] == "# dump_init" and trace[-1] == "# dump_end"
+    rows = np.array([[float(v) for v in ln.split()] for ln in trace[1:-1]])
+    assert rows.shape == (4, 2)                                   # iterations 250, 500, 750, 1000
+    np.testing.assert_array_equal(rows[-1], chain[-1, :2])        # the last dump is the last row of the chain
+    starts = np.cumsum(chain[:, -1]) - chain[:, -1] + 1           # iteration at which each row was accepted
+    for it, r in zip((250, 500, 750), rows):
+        np.testing.assert_array_equal(r, chain[np.searchsorted(starts, it, side="right") - 1, :2])
+
+
+def test_seed_file_and_signal(oracle):
+    """gfortran_seed.dat holds the stream key (mcmcrand.F90:214-238) and is rewritten at the end of the job (:317-342);
+    SIGUSR1 during the run saves the chain "upto simuind" and stops (MCMC_signal_handler.F90:95-107)."""
+    import signal, time
+    exe = os.path.join(FDIR, "demo_main")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", FDIR])
+    z, cfg, prob = load("c1_shipped_nml", oracle)
+    chains = []
+    with tempfile.TemporaryDirectory() as d:
+        _write_inputs(d, z, NML)
+        open(os.path.join(d, "lower.dat"), "w").write("0 0\n")
+        for rep in range(3):
+            if rep < 2:
+                open(os.path.join(d, "gfortran_seed.dat"), "w").write(" 424242\n")
+            p = subprocess.run([exe], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+            assert p.returncode == 0, p.stdout.decode(errors="replace")
+            chains.append(np.loadtxt(os.path.join(d, "chain.dat"), ndmin=2))
+            nxt = int(open(os.path.join(d, "gfortran_seed.dat")).read().split()[0])
+            assert nxt != 424242
+    assert np.array_equal(chains[0], chains[1])                   # same key, same chain
+    assert not np.array_equal(chains[0][:50], chains[2][:50])     # the rewritten key starts a new stream
+    assert not np.array_equal(chains[0][:, -1].astype(np.int32), z["runlen"])   # and 424242 is not the default key
+    # signal: a long run, interrupted
+    with tempfile.TemporaryDirectory() as d:
+        _write_inputs(d, z, NML.replace("nsimu       = 1000", "nsimu       = 2000000").replace("adaptint    = 200", "adaptint    = 1000"))
+        open(os.path.join(d, "lower.dat"), "w").write("0 0\n")
+        p = subprocess.Popen([exe], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        time.sleep(4.0)
+        p.send_signal(signal.SIGUSR1)
+        out, _ = p.communicate(timeout=600)
+        text = out.decode(errors="replace")
+        assert "Saving chain upto" in text, text[-2000:]
+        upto = int(text.split("Saving chain upto")[1].split()[0])
+        chain = np.loadtxt(os.path.join(d, "chain.dat"), ndmin=2)
+        assert 1 <= upto < 2000000 and int(chain[:, -1].sum()) == upto
+
+
+def test_reference_gaussian_example_mcmcrun4():
+    """testcases/mcmcrun4.F90 unmodified: MCMC_setpar0(5, 0.0), MCMC_setcmat0(0.1), the user's dense Gaussian
+    ssfunction reading mcmctest_mu.dat / mcmctest_lam.dat (files the reference does not ship).  The likelihood runs in
+    the user's Fortran, so the check is statistical: the chain must sample N(mu, inv(lam))."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "tc_mcmcrun4")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/tc_mcmcrun4 was not built (needs /root/reference in the dev container)")
+    d5 = 5
+    S = 0.5 ** np.abs(np.subtract.outer(np.arange(d5), np.arange(d5))) * 0.25
+    mu = np.linspace(-1.0, 1.0, d5)
+    nml = NML.split("&mcmcx")[0].replace("nsimu       = 1000", "nsimu       = 40000").replace("burnintime  = 1000", "burnintime  = 0") \
+        .replace("doburnin    = 1", "doburnin    = 0").replace("updatesigma = 1", "updatesigma = 0").replace("adaptint    = 200", "adaptint    = 100")
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "mcmcinit.nml"), "w").write(nml)
+        np.savetxt(os.path.join(d, "mcmctest_mu.dat"), mu[None, :])
+        np.savetxt(os.path.join(d, "mcmctest_lam.dat"), np.linalg.inv(S))
+        p = subprocess.run([exe], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, p.stdout.decode(errors="replace")
+        chain = np.loadtxt(os.path.join(d, "chain.dat"), ndmin=2)
+    w = chain[:, -1]
+    assert int(w.sum()) == 40000
+    th = np.repeat(chain[:, :-1], w.astype(int), axis=0)[5000:]
+    assert np.max(np.abs(th.mean(axis=0) - mu)) < 0.08
+    assert np.max(np.abs(np.cov(th.T) - S)) < 0.08
+    assert 0.1 < len(chain) / 40000.0 < 0.6
