@@ -98,6 +98,15 @@ def cases():
                                     nobs=11, xdata=XDATA, ydata=YDATA, lo=[0, 0]), 34)
     c["s5_banana20_scam"] = (dict(nsimu=400, method="scam", adaptint=100, updatesigma=0),
                              dict(kind="banana", npar=20, par0=np.zeros(20), cmat0=0.01 * np.eye(20), b=0.1), 35)
+    # --- BASELINE config 5 at its own dimension (SURVEY.md section 8c asks for "d=200 SCAM 50 its").  Past an adaptation
+    # the d=200 trajectory is not a function of the inputs alone: the new rotation is the singular basis of a covariance
+    # with many nearly equal small singular values, and 1e-16 differences in the states (MKL's dgemv order, glibc's log
+    # in the normal deviates) turn that basis by O(1) -- the reference linked to another BLAS would not reproduce
+    # itself either.  So the fixture pins what is well posed: 250 iterations x 200 componentwise proposals with the
+    # initial rotation, and the covariance / mean the adaptation at the last iteration sees.
+    from mcmcf90_amd.workloads import problem
+    ckw, pkw, _ = problem("c5", 250, adaptint=250)
+    c["c5_illcond200_scam"] = (ckw, pkw, 51)
     return c
 
 
