@@ -85,6 +85,10 @@ typedef void    (*mcmcx_ssfun_t)(const double *theta, int32_t npar, int32_t ny, 
 typedef double  (*mcmcx_priorfun_t)(const double *theta, int32_t npar, void *user);
 typedef int32_t (*mcmcx_checkbounds_t)(const double *theta, int32_t npar, void *user);
 int mcmcx_set_target_host(mcmcx_handle h, mcmcx_ssfun_t ss, mcmcx_priorfun_t pri, mcmcx_checkbounds_t cb, void *user);
+/* method='er' with host callbacks: the user's ssfunction_er(theta,npar,ny,sscrit) (external_inc.h:16-20), which may
+ * stop summing once it passes sscrit; NULL (default) = ssfunction, like ssfunction_er0.f90.  Same `user` pointer. */
+typedef void (*mcmcx_ssfun_er_t)(const double *theta, int32_t npar, int32_t ny, double sscrit, double *ss_out, void *user);
+int mcmcx_set_target_host_er(mcmcx_handle h, mcmcx_ssfun_er_t ss_er);
 int mcmcx_set_bounds(mcmcx_handle h, const double *lo, const double *hi);       /* NULL = unbounded side */
 int mcmcx_set_priors(mcmcx_handle h, const double *mu, const double *sig);      /* sig <= 0: flat */
 int mcmcx_set_stream(mcmcx_handle h, void *hip_stream);

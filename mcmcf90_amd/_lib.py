@@ -71,6 +71,8 @@ CHECKBOUNDS_T = C.CFUNCTYPE(C.c_int32, _DP, C.c_int32, C.c_void_p)
 EXCHANGE_T = C.CFUNCTYPE(None, C.c_void_p)
 SYMBOLS["mcmcx_set_exchange"] = (C.c_int, [C.c_void_p, EXCHANGE_T, C.c_void_p, C.c_void_p])
 SYMBOLS["mcmcx_get_pooled"] = (C.c_int, [C.c_void_p, _DP, _DP, _DP, _DP])
+SSFUN_ER_T = C.CFUNCTYPE(None, _DP, C.c_int32, C.c_int32, C.c_double, _DP, C.c_void_p)
+SYMBOLS["mcmcx_set_target_host_er"] = (C.c_int, [C.c_void_p, SSFUN_ER_T])
 SYMBOLS["mcmcx_install_signal_handlers"] = (C.c_int, [])
 SYMBOLS["mcmcx_interrupted"] = (C.c_int, [])
 SYMBOLS["mcmcx_clear_interrupt"] = (None, [])

@@ -40,7 +40,7 @@ struct mcmcx_engine {
     double sigma2 = 1.0; int nobs = 1; bool sigma2ok = false;
     int tkind = -1; std::vector<double> tmu, tlam, tx, ty, tlo, thi, tpmu, tpsig; double tb = 0.1;
     bool has_lo = false, has_hi = false, has_pri = false;
-    mcmcx_ssfun_t h_ss = nullptr; mcmcx_priorfun_t h_pri = nullptr; mcmcx_checkbounds_t h_cb = nullptr; void *h_user = nullptr;
+    mcmcx_ssfun_t h_ss = nullptr; mcmcx_ssfun_er_t h_ss_er = nullptr; mcmcx_priorfun_t h_pri = nullptr; mcmcx_checkbounds_t h_cb = nullptr; void *h_user = nullptr;
     std::vector<double> h_cand, h_ev;
     // pooled mode
     int pooled = 0; double pool_W = 0.0; std::vector<double> pool_mean, pool_C, pool_R;   // packed upper, row-major
@@ -391,7 +391,9 @@ static int pooled_adapt(mcmcx_engine *h, int it)
 // Host-callback evaluation of one candidate vector per chain, in chain order, from the calling thread
 // (the reference's callbacks keep SAVEd state and are not thread-safe: testcases/mcmcrun.F90:69-70).
 // src: tile-interleaved device vector [T][stride][64]; only chains with want != 0 (hx slot) are evaluated.
-static int host_eval(mcmcx_engine *h, const double *dev_src, int stride_k, bool use_stage2_flag)
+// what: 0 = checkbounds, priorfun, ssfunction (MCMC_run.F90:47-56); 1 = checkbounds and priorfun only, 2 = ssfunction_er
+// with each chain's threshold (the two halves of an early-rejection iteration, MCMC_run_er.F90:54-76)
+static int host_eval(mcmcx_engine *h, const double *dev_src, int stride_k, bool use_stage2_flag, int what = 0)
 {
     const int d = h->d, T = h->ntiles;
     const size_t L = (size_t)T * 64;
@@ -406,11 +408,18 @@ static int host_eval(mcmcx_engine *h, const double *dev_src, int stride_k, bool 
         const int t = c / 64, l = c % 64;
         if (use_stage2_flag && hx[((size_t)t * NHX + HX_STAGE2) * 64 + l] == 0.0) continue;
         for (int k = 0; k < d; ++k) th[k] = h->h_cand[((size_t)t * stride_k + k) * 64 + l];
-        int inb = h->h_cb ? h->h_cb(th.data(), d, h->h_user) : 1;                    // checkbounds0.f90: .true.
+        int inb = 1;
         double pri = 0.0, ss = 0.0;
-        if (inb) {                                                                   // MCMC_run.F90:54-56: prior first
-            pri = h->h_pri ? h->h_pri(th.data(), d, h->h_user) : 0.0;
-            h->h_ss(th.data(), d, 1, &ss, h->h_user);
+        if (what == 2) {                                                             // MCMC_ssfunction_er(newpar, sscrit)
+            const double crit = hx[((size_t)t * NHX + HX_CRIT) * 64 + l];
+            if (h->h_ss_er) h->h_ss_er(th.data(), d, 1, crit, &ss, h->h_user);
+            else h->h_ss(th.data(), d, 1, &ss, h->h_user);                           // ssfunction_er0.f90: no er for ss
+        } else {
+            inb = h->h_cb ? h->h_cb(th.data(), d, h->h_user) : 1;                    // checkbounds0.f90: .true.
+            if (inb) {                                                               // MCMC_run.F90:54-56: prior first
+                pri = h->h_pri ? h->h_pri(th.data(), d, h->h_user) : 0.0;
+                if (what == 0) h->h_ss(th.data(), d, 1, &ss, h->h_user);
+            }
         }
         h->h_ev[((size_t)t * NHE + HE_INB) * 64 + l] = inb ? 1.0 : 0.0;
         h->h_ev[((size_t)t * NHE + HE_PRI) * 64 + l] = pri;
@@ -427,6 +436,15 @@ static int host_iteration(mcmcx_engine *h, int it)
     const size_t lds = (size_t)h->d * 64 * sizeof(double) * 2;
     hipLaunchKernelGGL((host_phase_kernel<0>), g, b, 0, h->stream, h->E, it, rs);
     HIPCHK(hipGetLastError());
+    if (h->cfg.method == MCMCX_METHOD_ER) {             // MCMC_run_er: the threshold is drawn between priorfun and ssfunction_er
+        int rc = host_eval(h, h->E.cand, h->d, false, 1); if (rc) return rc;
+        hipLaunchKernelGGL((host_phase_kernel<3>), g, b, 0, h->stream, h->E, it, rs);
+        HIPCHK(hipGetLastError());
+        rc = host_eval(h, h->E.cand, h->d, true, 2); if (rc) return rc;
+        hipLaunchKernelGGL((host_phase_kernel<4>), g, b, 0, h->stream, h->E, it, rs);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     int rc = host_eval(h, h->E.cand, h->d, false); if (rc) return rc;
     hipLaunchKernelGGL((host_phase_kernel<1>), g, b, 0, h->stream, h->E, it, rs);
     HIPCHK(hipGetLastError());
@@ -575,6 +593,14 @@ int mcmcx_set_target_host(mcmcx_handle h, mcmcx_ssfun_t ss, mcmcx_priorfun_t pri
     return 0;
 }
 
+int mcmcx_set_target_host_er(mcmcx_handle h, mcmcx_ssfun_er_t ss_er)
+{
+    if (!h) return fail(-1, "null handle");
+    if (h->inited) return fail(-20, "set the target before mcmcx_init");
+    h->h_ss_er = ss_er;
+    return 0;
+}
+
 int mcmcx_set_bounds(mcmcx_handle h, const double *lo, const double *hi)
 {
     if (!h) return fail(-1, "null handle");
@@ -604,7 +630,6 @@ int mcmcx_init(mcmcx_handle h)
     }
     if (!h->sigma2ok) { h->sigma2 = 1.0; h->nobs = 1; }                               // MCMC_init.F90:52-59
     if (h->tkind < 0) return fail(-31, "no target: the device engine needs mcmcx_set_target_*");
-    if (h->tkind == TGT_HOST && c.method == MCMCX_METHOD_ER) return fail(-31, "host-callback targets are not available with method='er'");
     if (h->tkind == TGT_HOST && h->usesvd) return fail(-31, "host-callback targets are not available with condmax > 0 / method='scam'");
     std::vector<double> Rp, Cp, Rfull, qstd0;
     int info = host_initial_R(d, h->cmat0, Rp, Cp);

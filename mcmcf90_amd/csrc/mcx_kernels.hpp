@@ -839,7 +839,7 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
 // the host evaluates the candidates of all chains in chain order, phase 1 decides (and proposes the DR
 // try), the host evaluates again, phase 2 decides the DR try and finishes the iteration.  Same device
 // functions as step_kernel; per-lane state round-trips through HBM between phases.
-enum { HX_SS2 = 0, HX_PRI2, HX_REJECT, HX_STAGE2, HX_DRMOVED, HX_SU, NHX };
+enum { HX_SS2 = 0, HX_PRI2, HX_REJECT, HX_STAGE2, HX_DRMOVED, HX_SU, HX_CRIT, NHX };
 enum { HE_INB = 0, HE_PRI, HE_SS, NHE };
 
 struct LaneState {
@@ -1241,6 +1241,27 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
         } else {
             host_finish(E, tile, lane, it, L, reject, false, ss2, pri2, ramscale);
         }
+    } else if (PHASE == 3) {                                      // early rejection, first half (MCMC_run_er.F90:54-70)
+        // the host has evaluated checkbounds and priorfun; draw the threshold, test the prior, leave sscrit for ssfunction_er
+        const bool inb = GV(hev, HE_INB) != 0.0;
+        const double pri2 = GV(hev, HE_PRI);
+        bool reject = false, need = false;
+        double crit = 0.0;
+        if (!inb) { L.bnd += 1; reject = true; }
+        else {
+            double u = rng_uniform(L.g);                          // MCMC_sscrit, MCMC_DRAM.F90:124-135: always drawn
+            double sscrit = -2.0 * d_log(u) + L.ss1 / L.sigma2 + L.pri1;
+            if (pri2 >= sscrit) { reject = true; TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane) += 1; }
+            else { crit = L.sigma2 * (sscrit - pri2); need = true; }
+        }
+        GV(hx, HX_PRI2) = pri2; GV(hx, HX_CRIT) = crit;
+        GV(hx, HX_REJECT) = reject ? 1.0 : 0.0; GV(hx, HX_STAGE2) = need ? 1.0 : 0.0;
+    } else if (PHASE == 4) {                                      // early rejection, second half (:71-101)
+        bool reject = GV(hx, HX_REJECT) != 0.0;
+        const double pri2 = GV(hx, HX_PRI2);
+        double ss2 = 0.0;
+        if (GV(hx, HX_STAGE2) != 0.0) { ss2 = GV(hev, HE_SS); reject = (ss2 >= GV(hx, HX_CRIT)); }
+        host_finish(E, tile, lane, it, L, reject, false, ss2, pri2, ramscale);
     } else {                                                      // PHASE 2: decide the DR try, finish
         bool reject = GV(hx, HX_REJECT) != 0.0;
         double ss2 = GV(hx, HX_SS2), pri2 = GV(hx, HX_PRI2);

@@ -87,9 +87,10 @@ class Engine:
         else:
             raise KeyError(kind)
 
-    def set_target_host(self, ssfun, priorfun=None, checkbounds=None):
+    def set_target_host(self, ssfun, priorfun=None, checkbounds=None, ssfun_er=None):
         """User callbacks on the host, like the reference's link-time ssfunction / priorfun / checkbounds:
-        ssfun(theta) -> float, priorfun(theta) -> float, checkbounds(theta) -> bool, theta a numpy vector."""
+        ssfun(theta) -> float, priorfun(theta) -> float, checkbounds(theta) -> bool, theta a numpy vector;
+        ssfun_er(theta, sscrit) -> float is the early-rejection form used by method='er' (default: ssfun)."""
         n = self.npar
 
         def _ss(th, npar, ny, out, user):
@@ -104,6 +105,11 @@ class Engine:
         self._cb_keep = (_lib.SSFUN_T(_ss), _lib.PRIORFUN_T(_pri) if priorfun else _lib.PRIORFUN_T(),
                          _lib.CHECKBOUNDS_T(_cb) if checkbounds else _lib.CHECKBOUNDS_T())
         self._chk(self.L.mcmcx_set_target_host(self.h, self._cb_keep[0], self._cb_keep[1], self._cb_keep[2], None))
+        if ssfun_er is not None:
+            def _ss_er(th, npar, ny, crit, out, user):
+                out[0] = float(ssfun_er(np.ctypeslib.as_array(th, shape=(n,)).copy(), crit))
+            self._er_keep = _lib.SSFUN_ER_T(_ss_er)
+            self._chk(self.L.mcmcx_set_target_host_er(self.h, self._er_keep))
 
     def set_bounds(self, lo=None, hi=None):
         lo = _f64(lo) if lo is not None else None

@@ -166,6 +166,12 @@ module mcmcmod
        type(c_funptr), value :: ss, pri, cb
        integer(c_int) :: rc
      end function
+     function mcmcx_set_target_host_er(h, ss_er) bind(C, name='mcmcx_set_target_host_er') result(rc)
+       import :: c_ptr, c_funptr, c_int
+       type(c_ptr), value :: h
+       type(c_funptr), value :: ss_er
+       integer(c_int) :: rc
+     end function
      function mcmcx_set_bounds(h, lo, hi) bind(C, name='mcmcx_set_bounds') result(rc)
        import :: c_ptr, c_int
        type(c_ptr), value :: h, lo, hi
@@ -448,6 +454,24 @@ contains
     n4 = n; ny4 = ny
     ss_out(1:ny) = ssfunction(theta(1:n), n4, ny4)
   end subroutine mcx_ss_adapter
+  subroutine mcx_ss_er_adapter(theta, n, ny, sscrit, ss_out, user) bind(C)
+    real(c_double), intent(in) :: theta(*)
+    integer(c_int32_t), value :: n, ny
+    real(c_double), value :: sscrit
+    real(c_double), intent(out) :: ss_out(*)
+    type(c_ptr), value :: user
+    integer(kind=4) :: n4, ny4
+    real(kind=8) :: crit
+    interface
+       function ssfunction_er(theta,npar,ny,sscrit)
+         integer*4 npar, ny
+         real*8 theta(npar), sscrit
+         real*8 ssfunction_er(ny)
+       end function ssfunction_er
+    end interface
+    n4 = n; ny4 = ny; crit = sscrit
+    ss_out(1:ny) = ssfunction_er(theta(1:n), n4, ny4, crit)
+  end subroutine mcx_ss_er_adapter
   function mcx_prior_adapter(theta, n, user) bind(C) result(p)
     real(c_double), intent(in) :: theta(*)
     integer(c_int32_t), value :: n
@@ -618,6 +642,7 @@ contains
     case ('host')
        call chk(mcmcx_set_target_host(handle, c_funloc(mcx_ss_adapter), c_funloc(mcx_prior_adapter), &
             c_funloc(mcx_bounds_adapter), c_null_ptr))
+       call chk(mcmcx_set_target_host_er(handle, c_funloc(mcx_ss_er_adapter)))     ! used by method = 'er' only
     end select
     plo = c_null_ptr; phi = c_null_ptr
     if (has_lo) then

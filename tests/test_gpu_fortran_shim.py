@@ -259,3 +259,31 @@ def test_reference_gaussian_example_mcmcrun4():
     assert np.max(np.abs(th.mean(axis=0) - mu)) < 0.08
     assert np.max(np.abs(np.cov(th.T) - S)) < 0.08
     assert 0.1 < len(chain) / 40000.0 < 0.6
+
+
+def test_user_program_with_method_er(oracle):
+    """The unmodified user program (own Fortran ssfunction / checkbounds, the library's default ssfunction_er and
+    priorfun with a priorsfile) with method = 'er' in the namelist: fixture e6_expdata_er_priors' accept sequence."""
+    exe = os.path.join(FDIR, "demo_user")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", FDIR])
+    z, cfg, prob = load("e6_expdata_er_priors", oracle)
+    nml = """&mcmc
+ method = 'er'
+ nsimu = %d
+ adaptint = %d
+ updatesigma = 1
+ priorsfile = 'priors.dat'
+/
+""" % (cfg.nsimu, cfg.adaptint)
+    with tempfile.TemporaryDirectory() as d:
+        _write_inputs(d, z, nml)
+        np.savetxt(os.path.join(d, "priors.dat"), np.vstack([z["prob_pri_mu"], z["prob_pri_sig"]]))
+        open(os.path.join(d, "gfortran_seed.dat"), "w").write(" 1835232611\n")
+        p = subprocess.run([exe], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert p.returncode == 0, p.stdout.decode(errors="replace")
+        chain = np.loadtxt(os.path.join(d, "chain.dat"), ndmin=2)
+    # the fixture's stream is chain id 41 of the default key; the shim's chain 0 has another stream: compare with the oracle
+    o = oracle.run_chain(cfg, prob, chain_id=0)
+    np.testing.assert_array_equal(chain[:, -1].astype(np.int32), o.chain[:, -1].astype(np.int32))
+    np.testing.assert_allclose(chain[:, :-1], o.chain[:, :-1], rtol=1e-9)

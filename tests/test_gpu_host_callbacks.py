@@ -74,3 +74,58 @@ def test_host_callbacks_equal_device_target(oracle, name, nsimu):
     if not cfg.dodr:
         assert calls["ss"] == tot["proposals"] + nch - tot["bndstayed"]
     e.close()
+
+
+@pytest.mark.parametrize("early", [False, True])
+def test_host_callbacks_early_rejection(oracle, early):
+    """method='er' through the host callbacks (MCMC_run_er.F90:54-101): checkbounds and priorfun first, the threshold
+    drawn on the device, then ssfunction_er with each chain's own sscrit.  `early`: a user function that really stops
+    summing once it is past sscrit -- the decisions, hence the chain, are the same."""
+    from mcmcf90_amd import Engine, make_config
+    z, cfg, prob = load("e6_expdata_er_priors", oracle)
+    ckw, pkw = _kw(z)
+    ckw["nsimu"] = 600
+    cfg = oracle.make_cfg(**ckw)
+    L = oracle.lib()
+    tgt = prob.ctarget()
+    L.mcxo_ssfun.restype = C.c_double; L.mcxo_priorfun.restype = C.c_double; L.mcxo_checkbounds.restype = C.c_int
+    dp = C.POINTER(C.c_double)
+    x, y = np.asarray(pkw["xdata"], float), np.asarray(pkw["ydata"], float)
+    stopped = {"n": 0}
+
+    def ssfun(th):
+        return L.mcxo_ssfun(C.byref(tgt), th.ctypes.data_as(dp))
+
+    def ssfun_er(th, crit):
+        if not early:
+            return ssfun(th)
+        full = ssfun(th)
+        if full < crit:
+            return full                                            # accepted proposals must carry the exact ss
+        part = 0.0
+        for xi, yi in zip(x, y):                                    # a rejected one may stop at the first partial sum past sscrit
+            part += (yi - th[0] * np.exp(-th[1] * xi)) ** 2
+            if part >= crit:
+                stopped["n"] += 1
+                return part
+        return full
+
+    npar, nch = int(pkw["npar"]), 3
+    e = Engine(make_config(npar, nch, record_chain=1, chain_id0=40, **ckw))
+    e.setpar0(pkw["par0"]); e.setcmat0(np.asarray(pkw["cmat0"], dtype=float).reshape(npar, npar))
+    e.setsigma2nobs(float(pkw.get("sigma2", 1.0)), int(pkw.get("nobs", 1)))
+    e.set_target_host(ssfun, lambda th: L.mcxo_priorfun(C.byref(tgt), th.ctypes.data_as(dp)),
+                      lambda th: bool(L.mcxo_checkbounds(C.byref(tgt), th.ctypes.data_as(dp))), ssfun_er=ssfun_er)
+    e.init(); e.run()
+    for c in range(nch):
+        o = oracle.run_chain(cfg, prob, chain_id=40 + c)
+        ch, ss, s2 = e.chain(c)
+        np.testing.assert_array_equal(_bits(ch), _bits(o.chain))
+        np.testing.assert_array_equal(_bits(ss), _bits(o.sschain))
+        np.testing.assert_array_equal(_bits(s2), _bits(o.s2chain))
+        cnt = e.counters(c)
+        assert (cnt["stayed"], cnt["bndstayed"], cnt["erstayed"]) == (o.stayed, o.bndstayed, o.erstayed)
+        assert e.rng(c)[0] == o.rng_n
+    if early:
+        assert stopped["n"] > 0
+    e.close()
