@@ -1043,17 +1043,31 @@ int mcmcx_get_chain(mcmcx_handle h, int32_t chain, double *chain_out, double *ss
     const int tile = chain / 64, lane = chain % 64, d = h->d, W = h->wcap;
     std::vector<uint64_t> m;
     if ((rc = fetch(h, h->E.wacc + (size_t)tile * W, (size_t)W, m))) return rc;
+    // this chain's lane of the history ring, gathered on the device: hv[slot*(d+1) + k]
+    auto gather = [&](const double *src, size_t n, std::vector<double> &dst) -> int {
+        double *tmp = nullptr;
+        HIPCHK(hipMalloc(&tmp, n * sizeof(double)));
+        hipLaunchKernelGGL(gather_lane_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, h->stream, src, tmp, n, lane);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        dst.resize(n);
+        if (e == hipSuccess) e = hipMemcpy(dst.data(), tmp, n * sizeof(double), hipMemcpyDeviceToHost);
+        (void)hipFree(tmp);
+        if (e != hipSuccess) return fail(-100, hipGetErrorString(e));
+        return 0;
+    };
     std::vector<double> hv;
-    if ((rc = fetch(h, h->E.hist + (size_t)tile * W * (d + 1) * 64, (size_t)W * (d + 1) * 64, hv))) return rc;
+    if ((rc = gather(h->E.hist + (size_t)tile * W * (d + 1) * 64, (size_t)W * (d + 1), hv))) return rc;
     int row = -1;
     for (int it = 1; it <= h->simuind; ++it) {
-        if ((m[it] >> lane) & 1ull) {
+        const size_t so = (size_t)(it % W) * (d + 1);
+        if ((m[it % W] >> lane) & 1ull) {
             ++row;
             if (chain_out) {
-                for (int k = 0; k < d; ++k) chain_out[(size_t)row * (d + 1) + k] = hv[((size_t)it * (d + 1) + k) * 64 + lane];
+                for (int k = 0; k < d; ++k) chain_out[(size_t)row * (d + 1) + k] = hv[so + k];
                 chain_out[(size_t)row * (d + 1) + d] = 1.0;
             }
-            if (ss_out) { ss_out[(size_t)row * 2] = hv[((size_t)it * (d + 1) + d) * 64 + lane]; ss_out[(size_t)row * 2 + 1] = 1.0; }
+            if (ss_out) { ss_out[(size_t)row * 2] = hv[so + d]; ss_out[(size_t)row * 2 + 1] = 1.0; }
         } else {
             if (chain_out) chain_out[(size_t)row * (d + 1) + d] += 1.0;
             if (ss_out) ss_out[(size_t)row * 2 + 1] += 1.0;
@@ -1062,8 +1076,8 @@ int mcmcx_get_chain(mcmcx_handle h, int32_t chain, double *chain_out, double *ss
     if (nrows) *nrows = row + 1;
     if (s2_out && h->E.s2hist) {
         std::vector<double> sv;
-        if ((rc = fetch(h, h->E.s2hist + (size_t)tile * W * 64, (size_t)W * 64, sv))) return rc;
-        for (int it = 1; it <= h->simuind; ++it) s2_out[it - 1] = sv[(size_t)it * 64 + lane];
+        if ((rc = gather(h->E.s2hist + (size_t)tile * W * 64, (size_t)W, sv))) return rc;
+        for (int it = 1; it <= h->simuind; ++it) s2_out[it - 1] = sv[(size_t)(it % W)];
     }
     return 0;
 }

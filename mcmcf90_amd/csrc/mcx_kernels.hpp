@@ -1881,6 +1881,13 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
     TIDX(E.scal, tile, NSCAL, S_WSUM, lane) = wsum;
 }
 
+// one chain's lane of a tile-interleaved array: out[e] = src[e*64 + lane], e < n (mcmcx_get_chain copies a single
+// chain's history to the host, not the other 63 of its tile)
+__global__ __launch_bounds__(256) void gather_lane_kernel(const double *__restrict__ src, double *out, size_t n, int lane)
+{
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) out[e] = src[e * 64 + lane];
+}
+
 // ---------------------------------------------------------------- pooled moments of the current states
 // out[tile][1 + d + d(d+1)/2]: partial sums over the 64 lanes of a tile by an xor-butterfly (a fixed
 // pairwise tree: adjacent lanes first); the host finishes the tree over tiles, RCCL over GPUs.
