@@ -630,6 +630,7 @@ int mcmcx_init(mcmcx_handle h)
     }
     if (!h->sigma2ok) { h->sigma2 = 1.0; h->nobs = 1; }                               // MCMC_init.F90:52-59
     if (h->tkind < 0) return fail(-31, "no target: the device engine needs mcmcx_set_target_*");
+    if (h->dodr && lds_bytes(h) > 160 * 1024) return fail(-35, "delayed rejection keeps two npar-vectors per chain in LDS: npar <= 160 with drscale > 0");
     if (h->tkind == TGT_HOST && h->usesvd) return fail(-31, "host-callback targets are not available with condmax > 0 / method='scam'");
     std::vector<double> Rp, Cp, Rfull, qstd0;
     int info = host_initial_R(d, h->cmat0, Rp, Cp);

@@ -174,3 +174,36 @@ def test_pooled_moments_and_shard_invariance(oracle):
     mean, cov = mdist.finalize_moments(m_all, d, np.zeros(d))
     np.testing.assert_allclose(mean, th_all.mean(axis=0), rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(cov, np.cov(th_all.T), rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("method,d,extra", [("dram", 256, {}), ("ram", 256, {}), ("dram", 150, {"drscale": 2.0}), ("dram", 1, {"drscale": 3.0})])
+def test_extreme_dimensions(oracle, method, d, extra):
+    """npar at the engine's limits: 256 (AM and RAM; one adaptation tick), the largest delayed-rejection size whose two
+    work vectors fit the LDS, and npar = 1 with DR."""
+    from mcmcf90_amd import engine_from_problem
+    rng = np.random.default_rng(d)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    lam = A @ A.T + np.eye(d)
+    ckw = dict(nsimu=45, adaptint=20, updatesigma=0, method=method, **extra)
+    pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.05), cmat0=(0.3 / d) * np.eye(d), mu=np.zeros(d), lam=lam)
+    e = engine_from_problem(ckw, pkw, nchains=66, record_accept=1)
+    e.init(); e.run()
+    cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
+    th = e.theta()
+    for c in (0, 65):
+        o = oracle.run_chain(cfg, prob, chain_id=c, continue_on_downdate_fail=True)
+        np.testing.assert_array_equal(e.accepted(c), o.accepted)
+        np.testing.assert_array_equal(_bits(th[c]), _bits(o.theta))
+        np.testing.assert_array_equal(_bits(np.triu(e.R(c))), _bits(np.triu(o.R)))
+    e.close()
+
+
+def test_sizes_beyond_the_limits_fail_loudly():
+    from mcmcf90_amd import make_config, Engine, McmcError
+    with pytest.raises(McmcError):
+        Engine(make_config(257, 1, nsimu=10))
+    e = Engine(make_config(200, 1, nsimu=10, drscale=2.0))          # DR keeps two npar-vectors per chain in LDS
+    e.setpar0(np.zeros(200)); e.set_target("banana", b=0.1)
+    with pytest.raises(McmcError):
+        e.init()
+    e.close()
