@@ -596,7 +596,7 @@ contains
     real(kind=dbl) :: lamrow(npar*npar)
     type(c_ptr) :: plo, phi
     real(kind=dbl), allocatable :: th(:)
-    integer :: i, j, upto
+    integer :: i, j, upto, nxt
     integer(c_int) :: rc
     interface
        subroutine dump_init()
@@ -659,24 +659,29 @@ contains
     interrupted = .false.
     upto = 1
     do while (upto < nsimu)
-       !! MCMC_dump(oldpar) (MCMC_run.F90:102): with dumpint > 0 the run is cut every dumpint iterations and the
-       !! user's dump sees the current point of chain 1 (the reference calls it at every iteration)
-       if (dumpint > 0) then
-          upto = min(nsimu, (upto / dumpint + 1) * dumpint)
-       else
-          upto = nsimu
-       end if
+       !! The run is cut where the host has something to do: every printint iterations the progress line of
+       !! MCMC_adapt.F90:22-37 (chain 1's counters), every dumpint iterations MCMC_dump(oldpar) (MCMC_run.F90:102: the
+       !! user's dump sees the current point of chain 1; the reference calls it at every iteration)
+       nxt = nsimu
+       if (dumpint > 0) nxt = min(nxt, (upto / dumpint + 1) * dumpint)
+       if (printint > 0) nxt = min(nxt, (upto / printint + 1) * printint)
+       upto = nxt
        rc = mcmcx_run(handle, int(upto, c_int32_t))
        call chk(rc)
        if (rc == 2) then                                ! MCMCX_INTERRUPTED: cc_handler, MCMC_signal_handler.F90:95-107
           interrupted = .true.
           exit
        end if
+       if (printint > 0) then
+          if (mod(upto, printint) == 0) call progress_line(upto)
+       end if
        if (dumpint > 0) then
-          allocate(th(npar*nchains))
-          call chk(mcmcx_get_theta(handle, th))
-          call dump(th(1:npar))
-          deallocate(th)
+          if (mod(upto, dumpint) == 0 .or. upto == nsimu) then
+             allocate(th(npar*nchains))
+             call chk(mcmcx_get_theta(handle, th))
+             call dump(th(1:npar))
+             deallocate(th)
+          end if
        end if
     end do
     call chk(mcmcx_sync(handle))
@@ -707,6 +712,27 @@ contains
     call chk(mcmcx_get_scalars(handle, sc))
     sigma2(1) = sc(3)
   end subroutine MCMC_engine_run
+
+  !! the progress line of MCMC_adapt.F90:22-37 / MCMC_run_ram.F90:118-122, from chain 1's counters
+  subroutine progress_line(it)
+    integer, intent(in) :: it
+    integer(c_int32_t) :: c8(8)
+    call chk(mcmcx_get_counters(handle, 0_c_int32_t, c8))
+    if (drscale > 0.0_dbl .and. trim(method) == 'dram') then
+       write(*,'(A,I10,A,F5.1,A,F5.1,A,F5.1,A)') ' simu i =', it, &
+            ', stayed % = ', real(c8(1))/real(it)*100.0, &
+            ' /', (1.0-real(c8(3))/real(max(c8(4),1)))*100.0, &
+            '  [', real(c8(2))/real(it)*100.0, ']'
+    else if (c8(7) > 0) then
+       write(*,'(A,I10,A,F5.1,A,F5.1,A)') ' simu i =', it, &
+            ', stayed % = ', real(c8(1))/real(it)*100.0, &
+            '  [', real(c8(7))/real(it)*100.0, '](er)'
+    else
+       write(*,'(A,I10,A,F5.1,A,F5.1,A)') ' simu i =', it, &
+            ', stayed % = ', real(c8(1))/real(it)*100.0, &
+            '  [', real(c8(2))/real(it)*100.0, ']'
+    end if
+  end subroutine progress_line
 
   !! MAT-v4 file like writemat4_mat (matfiles.F90:66-126): 5 x int32 header (type 0, mrows, ncols, imagf 0, namelen),
   !! the name with a trailing NUL, the data column by column as 8-byte reals

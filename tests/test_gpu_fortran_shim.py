@@ -187,6 +187,11 @@ def test_user_initialize_and_dump_hooks(oracle):
         chain = np.loadtxt(os.path.join(d, "chain.dat"), ndmin=2)
         trace = open(os.path.join(d, "dump_trace.dat")).read().splitlines()
     np.testing.assert_array_equal(chain[:, -1].astype(np.int32), z["runlen"])
+    # the progress line of MCMC_adapt.F90:22-37 every printint = 100 iterations, with chain 1's stayed / bounds shares
+    lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith(" simu i =")]
+    assert len(lines) == 10
+    stayed_at_1000 = 1000 - len(chain)
+    assert "%5.1f" % (stayed_at_1000 / 1000.0 * 100.0) in lines[-1] and lines[-1].split()[3] == "1000,"
     assert trace[0] == "# dump_init" and trace[-1] == "# dump_end"
     rows = np.array([[float(v) for v in ln.split()] for ln in trace[1:-1]])
     assert rows.shape == (4, 2)                                   # iterations 250, 500, 750, 1000
