@@ -68,6 +68,7 @@ module mcmcmod
   integer, save :: npar = 0, nycol = 1, simuind = 0, chainind = 0, MCMC_running = 0
   real(kind=dbl), allocatable, save :: chain(:,:), sschain(:,:), s2chain(:,:), sigma2(:)
   real(kind=dbl), allocatable, save :: chaincmat(:,:), chainmean(:)
+  real(kind=dbl), allocatable, save :: laststates(:,:), pooledmean(:), pooledcov(:,:)   ! nchains > 1 (engine extension)
   real(kind=dbl), save :: chainwsum = 0.0_dbl
   integer, allocatable, save :: nobs(:)
   integer, save :: stayed = 0, bndstayed = 0, draccepted = 0, drtries = 0
@@ -222,6 +223,12 @@ module mcmcmod
        integer(c_int) :: rc
      end function
      function mcmcx_get_theta(h, out) bind(C, name='mcmcx_get_theta') result(rc)
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h
+       real(c_double), intent(out) :: out(*)
+       integer(c_int) :: rc
+     end function
+     function mcmcx_pooled_moments(h, out) bind(C, name='mcmcx_pooled_moments') result(rc)
        import :: c_ptr, c_int, c_double
        type(c_ptr), value :: h
        real(c_double), intent(out) :: out(*)
@@ -595,7 +602,7 @@ contains
     real(kind=dbl), target, allocatable :: lo(:), hi(:)
     real(kind=dbl) :: lamrow(npar*npar)
     type(c_ptr) :: plo, phi
-    real(kind=dbl), allocatable :: th(:)
+    real(kind=dbl), allocatable :: th(:), pm(:)
     integer :: i, j, upto, nxt
     integer(c_int) :: rc
     interface
@@ -711,6 +718,26 @@ contains
     stayed = c8(1); bndstayed = c8(2); draccepted = c8(3); drtries = c8(4)
     call chk(mcmcx_get_scalars(handle, sc))
     sigma2(1) = sc(3)
+    !! several chains: what the reference has no counterpart for -- the last state of every chain and the moments of
+    !! those states over all chains (about par0: count, sum, upper second moments)
+    if (nchains > 1) then
+       allocate(th(npar*nchains), pm(1 + npar + npar*(npar+1)/2))
+       call chk(mcmcx_get_theta(handle, th))
+       if (allocated(laststates)) deallocate(laststates, pooledmean, pooledcov)
+       allocate(laststates(nchains, npar), pooledmean(npar), pooledcov(npar, npar))
+       laststates = transpose(reshape(th, (/npar, nchains/)))
+       call chk(mcmcx_pooled_moments(handle, pm))
+       do j = 1, npar
+          pooledmean(j) = pm(1 + j) / pm(1)
+       end do
+       do j = 1, npar
+          do i = 1, j
+             pooledcov(i,j) = (pm(1 + npar + j*(j-1)/2 + i) - pm(1) * pooledmean(i) * pooledmean(j)) / (pm(1) - 1.0_dbl)
+             pooledcov(j,i) = pooledcov(i,j)
+          end do
+       end do
+       pooledmean = pooledmean + par0
+    end if
   end subroutine MCMC_engine_run
 
   !! the progress line of MCMC_adapt.F90:22-37 / MCMC_run_ram.F90:118-122, from chain 1's counters
@@ -784,6 +811,11 @@ contains
     call writenumbers(parffile, chain(chainind:chainind, 1:npar))
     if (updatesigma /= 0) call writenumbers(sigma2ffile, &
          reshape((/s2chain(simuind,1), dble(nobs(1))/), (/2, 1/)))
+    if (nchains > 1) then                               ! engine extension: all chains' last states, pooled mean / covariance
+       call writenumbers('mcmclaststates.dat', laststates)
+       call writenumbers('mcmcpooledmean.dat', reshape(pooledmean, (/npar, 1/)))
+       call writenumbers('mcmcpooledcov.dat', pooledcov)
+    end if
     if (verbosity > 0) write(*,*) 'note: saved results in ', trim(chainfile), ' and ', trim(ssfile), '.'
     !! restart namelist, MCMC_aux.F90:78-83
     initcmatn = initcmatn + simuind

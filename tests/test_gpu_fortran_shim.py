@@ -62,6 +62,13 @@ def test_fortran_driver_reproduces_reference_chain(oracle):
         chain = np.loadtxt(os.path.join(d, "chain.dat"), ndmin=2)
         s2 = np.loadtxt(os.path.join(d, "s2chain.dat"), ndmin=1)
         ss = np.loadtxt(os.path.join(d, "sschain.dat"), ndmin=2)
+        last = np.loadtxt(os.path.join(d, "mcmclaststates.dat"), ndmin=2)        # nchains = 64: engine extension files
+        pmean = np.loadtxt(os.path.join(d, "mcmcpooledmean.dat"), ndmin=1)
+        pcov = np.loadtxt(os.path.join(d, "mcmcpooledcov.dat"), ndmin=2)
+    assert last.shape == (64, 2)
+    np.testing.assert_array_equal(last[0], chain[-1, :2])
+    np.testing.assert_allclose(pmean, last.mean(axis=0), rtol=1e-12)
+    np.testing.assert_allclose(pcov, np.cov(last.T), rtol=1e-9)
     np.testing.assert_array_equal(chain[:, -1].astype(np.int32), z["runlen"])
     k = z["rows_head"].shape[0]
     np.testing.assert_allclose(chain[:k, :-1], z["rows_head"], rtol=1e-9)
