@@ -46,6 +46,7 @@ struct mcmcx_engine {
     int pooled = 0; double pool_W = 0.0; std::vector<double> pool_mean, pool_C, pool_R;   // packed upper, row-major
     std::vector<double> pool_U, pool_std;             // pooled SCAM: the shared rotation (column-major) and qcovstd
     double *d_sharedU = nullptr;                      // [U col-major | pad | U row-major | pad | std]
+    double *d_sharedRT = nullptr;                     // pooled AM on the matrix cores: dense R, M[s*d + o] = R(s,o), zero below the diagonal and in the pad rows
     double *d_sharedR = nullptr; mcmcx_exchange_t xfn = nullptr; void *xuser = nullptr; double *xbuf = nullptr;
     double S02eff = 0.0;
     // device
@@ -211,6 +212,20 @@ static int host_potri(int d, std::vector<double> &A)
     return 0;
 }
 
+// LDS of pooled_mfma_kernel: the tile's vector [d4][64] (+ the products [16 nt][64] when they need more than one pass)
+// and the partial ss chains [4 nt][64]
+static size_t pooled_mfma_lds(int d)
+{
+    const size_t d4 = (size_t)((d + 3) & ~3), nt = (size_t)((d + 15) / 16);
+    const size_t rows = (nt <= 4 ? std::max(d4, 16 * nt) : d4 + 16 * nt) + 4 * nt;
+    return rows * 64 * sizeof(double);
+}
+static bool pooled_use_mfma(const mcmcx_engine *h)
+{
+    if (!h->pooled || h->cfg.method != MCMCX_METHOD_DRAM) return false;
+    if (const char *e = getenv("MCMCX_POOLED_SCALAR")) if (atoi(e)) return false;      // A/B switch for tests: the lane-per-chain kernel
+    return pooled_mfma_lds(h->d) <= 160 * 1024;
+}
 static size_t lds_bytes(const mcmcx_engine *h) { return (size_t)h->d * 64 * sizeof(double) * 2; }   // adapt / DR work vectors
 static size_t lds_step(const mcmcx_engine *h) { return h->dodr ? lds_bytes(h) : 0; }
 static void launch_init(mcmcx_engine *h)
@@ -221,6 +236,7 @@ static void launch_step(mcmcx_engine *h, int it0, int it1)
     const double *rs = h->d_ramscale + it0;
     if (h->E.method == M_RAM) hipLaunchKernelGGL((step_kernel<true, false, false>), g, b, (size_t)NLC * 2 * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->dodr) hipLaunchKernelGGL((step_kernel<false, true, false>), g, b, lds_step(h), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
+    else if (pooled_use_mfma(h)) hipLaunchKernelGGL(pooled_mfma_kernel, g, b, pooled_mfma_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedRT);
     else if (h->pooled) hipLaunchKernelGGL((step_kernel<false, false, true>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else hipLaunchKernelGGL((step_kernel<false, false, false>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
 }
@@ -238,6 +254,15 @@ static int dev_bcast(mcmcx_engine *h, double *dst, const std::vector<double> &v)
     }
     (void)hipFree(tmp);
     if (e != hipSuccess) return fail(-100, hipGetErrorString(e));
+    return 0;
+}
+static int upload_shared_rt(mcmcx_engine *h)
+{
+    const int d = h->d, d4 = (d + 3) & ~3;
+    std::vector<double> m((size_t)d4 * d + PWS, 0.0);
+    for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) m[(size_t)i * d + j] = h->pool_R[h_pidx(i, j, d)];
+    HIPCHK(hipMemcpyAsync(h->d_sharedRT, m.data(), m.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
 static size_t shared_u_stride(const mcmcx_engine *h) { return (size_t)((h->d + 3) & ~3) * h->d + PWS; }     // d4 rows (pad rows zero) + slack
@@ -384,6 +409,7 @@ static int pooled_adapt(mcmcx_engine *h, int it)
         h->pool_R = Rp;
         HIPCHK(hipMemcpyAsync(h->d_sharedR, h->pool_R.data(), (size_t)P * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->d_sharedRT) return upload_shared_rt(h);
     }
     return 0;
 }
@@ -737,6 +763,10 @@ int mcmcx_init(mcmcx_handle h)
         HIPCHK(hipMemcpy(h->d_sharedR, Rp.data(), (size_t)P * 8, hipMemcpyHostToDevice));
         E.sharedR = h->d_sharedR;
         h->pool_R = Rp; h->pool_C = Cp; h->pool_mean = h->par0; h->pool_W = (double)c.initcmatn;
+        if (c.method == MCMCX_METHOD_DRAM) {
+            if ((rc = dev_alloc(h, &h->d_sharedRT, (size_t)((d + 3) & ~3) * d + PWS, false))) return rc;
+            if ((rc = upload_shared_rt(h))) return rc;
+        }
     }
     E.hev = E.hx = nullptr;
     if (h->tkind == TGT_HOST) {

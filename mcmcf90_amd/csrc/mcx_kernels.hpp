@@ -1164,6 +1164,146 @@ __global__ __launch_bounds__(1024, 1) void scam_pooled_kernel(EngineDev E, int i
     }
 }
 
+// ---------------------------------------------------------------- pooled AM on the matrix cores
+// One wave = one tile of 64 chains, lane = chain for everything sequential (random numbers, prior, alpha, accept);
+// the two products with tables shared by all chains -- the proposal P = R'z (R the one pooled factor, dense d x d
+// with its lower triangle zero: M[s*d + o] = R(s,o)) and the Gaussian target's y = Lam v -- run as MFMA tiles like in
+// scam_pooled_kernel: B = the wave's own 64 chains' vector in LDS, A from the shared table, NB = 4 output blocks x
+// 4 chain groups = 16 accumulators per pass.  Rows s beyond an output block's last column are zero in R and are
+// skipped (exact: they would add 0*z).  The results come back to lane = chain order through LDS (P) or as the
+// lane-local partial chains of ss (y).  Same arithmetic per chain as step_kernel<false,false,true>.
+template <bool TRI>
+MCX_DEV void mfma_wave_product(const double *__restrict__ M, const double *X, int lane, int d, int d4, int ob0, int nb,
+                               mcx_d4 (&c)[4][4])
+{
+    const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) c[b][g] = mcx_d4{0.0, 0.0, 0.0, 0.0};
+    int kmax = d4;
+    if (TRI) { const int last = 16 * (ob0 + nb); kmax = last < d4 ? last : d4; }
+    const double *__restrict__ ap = M + (size_t)lk * d + 16 * ob0 + li;
+    const double *xp = X + lk * 64 + li;
+    for (int s0 = 0; s0 < kmax; s0 += 4) {
+        double a[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) a[b] = ap[(size_t)s0 * d + 16 * (b < nb ? b : 0)];
+        const double *xq = xp + s0 * 64;
+        const double b0 = xq[0], b1 = xq[16], b2 = xq[32], b3 = xq[48];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (b < nb && (!TRI || s0 < 16 * (ob0 + b + 1))) {
+                c[b][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[b], b0, c[b][0], 0, 0, 0);
+                c[b][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[b], b1, c[b][1], 0, 0, 0);
+                c[b][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[b], b2, c[b][2], 0, 0, 0);
+                c[b][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[b], b3, c[b][3], 0, 0, 0);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void pooled_mfma_kernel(EngineDev E, int it0, int it1,
+                                                         const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
+                                                         const double *__restrict__ g_RT)
+{
+    extern __shared__ double X[];
+    const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
+    const int d4 = (d + 3) & ~3, nt = (d + 15) >> 4, li = lane & 15, lk = lane >> 4;
+    const bool single = (nt <= 4);                                  // one pass: the outputs may overwrite the input vector
+    double *T = single ? X : X + (size_t)d4 * 64;                  // [16 nt][64] products in (row, chain) order
+    double *Q = T + (size_t)nt * 16 * 64;                          // [4 nt][64] partial ss chains
+    double *theta_t = E.theta + (size_t)tile * d * 64;
+    double *cand_t = E.cand + (size_t)tile * d * 64;
+    const bool gauss = (E.tgt.kind == TGT_GAUSS);
+    LaneState L;
+    lane_load(E, tile, lane, L);
+    mcx_d4 c[4][4];
+    for (int it = it0; it <= it1; ++it) {
+        // ---- newpar = MCMC_propose(oldpar, R): z straight into the LDS vector, P = R'z on the matrix cores
+        gen_normals(L.g, X, lane, d, true);
+        for (int k = d; k < d4; ++k) XL(k) = 0.0;
+        for (int ob0 = 0; ob0 < nt; ob0 += 4) {
+            const int nb = (nt - ob0) < 4 ? (nt - ob0) : 4;
+            mfma_wave_product<true>(g_RT, X, lane, d, d4, ob0, nb, c);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (b < nb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        double *o = T + (size_t)(16 * (ob0 + b) + lk + 4 * r) * 64 + li;
+                        o[0] = c[b][0][r]; o[16] = c[b][1][r]; o[32] = c[b][2][r]; o[48] = c[b][3][r];
+                    }
+                }
+        }
+        // ---- candidate (lane = chain), and v = theta' - mu back into the LDS vector for the target
+#pragma unroll 4
+        for (int k = 0; k < d; ++k) {
+            const double cnd = GV(theta_t, k) + T[(size_t)k * 64 + lane];
+            GV(cand_t, k) = cnd;
+            if (gauss) XL(k) = cnd - g_mu[k];
+        }
+        bool inb = target_inbounds(E.tgt, d, lane, cand_t);
+        double pri2 = target_prior(E.tgt, d, lane, cand_t);
+        double ss2 = 0.0;
+        if (gauss) {
+            for (int k = d; k < d4; ++k) XL(k) = 0.0;
+            for (int ob0 = 0; ob0 < nt; ob0 += 4) {
+                const int nb = (nt - ob0) < 4 ? (nt - ob0) : 4;
+                mfma_wave_product<false>(g_lamT, X, lane, d, d4, ob0, nb, c);       // y = Lam v
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (b < nb) {
+                        const int o0 = 16 * (ob0 + b) + lk;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {                               // q = chain over r of y v (mcxt_ss_gauss)
+                            double q = c[b][g][0] * X[(size_t)o0 * 64 + 16 * g + li];
+#pragma unroll
+                            for (int r = 1; r < 4; ++r) {
+                                const int o = o0 + 4 * r;
+                                const double t = dfma(c[b][g][r], X[(size_t)(o < d4 ? o : 0) * 64 + 16 * g + li], q);
+                                q = (o < d) ? t : q;
+                            }
+                            if (o0 < d) Q[(size_t)(4 * (ob0 + b) + lk) * 64 + 16 * g + li] = q;
+                        }
+                    }
+            }
+            ss2 = Q[lane];
+#pragma unroll 4
+            for (int e = 1; e < 4 * nt; ++e) if (16 * (e >> 2) + (e & 3) < d) ss2 = ss2 + Q[(size_t)e * 64 + lane];
+        } else ss2 = target_ss<false>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
+        // ---- alpha, reject (MCMC_run.F90:47-63), as in step_kernel
+        bool reject;
+        if (!inb) { L.bnd += 1; reject = true; L.alpha12 = 0.0; }
+        else {
+            L.alpha12 = d_alpha(L.ss1, L.pri1, ss2, pri2, L.sigma2);
+            reject = true;
+            if (L.alpha12 >= 1.0) reject = false;
+            else if (L.alpha12 > 0.0) { double u = rng_uniform(L.g); if (u <= L.alpha12) reject = false; }
+        }
+        if (reject) { L.stayed += 1; L.curcount += 1; }
+        else { L.ss1 = ss2; L.pri1 = pri2; L.chainind += 1; L.curcount = 1; }
+        if (E.updatesigma) {
+            double gm = rng_gamma(L.g, E.gam_shape, 2.0 / (E.N0S02 + L.ss1));
+            L.sigma2 = 1.0 / gm;
+        }
+        unsigned long long ballot = __ballot(!reject);
+        const int slot = it % E.wcap;
+        if (!reject) {
+            double *h = E.hist ? E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64 : nullptr;
+#pragma unroll 4
+            for (int k = 0; k < d; ++k) { double v = GV(cand_t, k); GV(theta_t, k) = v; if (h) GV(h, k) = v; }
+            if (h) GV(h, d) = L.ss1;
+        }
+        if (E.hist) {
+            if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ballot;
+            if (E.record_s2) E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = L.sigma2;
+        }
+        if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
+    }
+    lane_store(E, tile, lane, L);
+}
+
 // end of an iteration: MCMC_run.F90:93-105 / MCMC_run_ram.F90:66-78
 MCX_DEV void host_finish(const EngineDev &E, int tile, int lane, int it, LaneState &L, bool reject, bool dr_moved,
                          double ss2, double pri2, const double *ramscale)

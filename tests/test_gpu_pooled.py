@@ -270,3 +270,43 @@ def test_pooled_scam_wave_layouts(oracle, d, extras):
     for ch in chains:
         ch.close()
     e.close()
+
+
+@pytest.mark.parametrize("d", [50, 70])
+def test_pooled_am_matrix_core_kernel_sizes(oracle, d, monkeypatch):
+    """pooled_mfma_kernel at d = 50 (one pass of four output blocks, the bench's size) and d = 70 (two passes, products
+    parked in a second LDS buffer): bit for bit the lane-per-chain kernel (MCMCX_POOLED_SCALAR=1) and the restatement."""
+    from mcmcf90_amd import engine_from_problem
+    N, nsimu, tick = 2 * d + 10, 9, 4           # more chains than parameters, or the pooled covariance is singular
+    rng = np.random.default_rng(d)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    lam = A @ A.T + np.diag(np.linspace(0.5, 3.0, d))
+    ckw = dict(nsimu=nsimu, adaptint=tick, updatesigma=0)
+    pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.1), cmat0=(0.5 / d) * np.eye(d), mu=np.linspace(-0.5, 0.5, d), lam=lam)
+    e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
+    e.init(); e.run()
+    monkeypatch.setenv("MCMCX_POOLED_SCALAR", "1")
+    e2 = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
+    e2.init(); e2.run()
+    np.testing.assert_array_equal(_bits(e.theta()), _bits(e2.theta()))
+    np.testing.assert_array_equal(e.accept_masks(), e2.accept_masks())
+    e2.close()
+    cfg = oracle.make_cfg(**dict(ckw, doadapt=0))
+    prob = oracle.Problem(**pkw)
+    chains = [oracle.LiveChain(cfg, prob, chain_id=c) for c in range(N)]
+    state = {}
+    par0, cmat0 = np.asarray(pkw["par0"], float), np.asarray(pkw["cmat0"], float)
+    for t in (4, 8, nsimu):
+        for ch in chains:
+            ch.run(t)
+        if t < nsimu:
+            theta = np.array([ch.theta for ch in chains])
+            cnt, s1, s2 = _pooled_moments(theta, par0, N)
+            state = _merge_and_factor(oracle, state, cnt, s1, s2, par0, d, t == 4, cmat0, 0)
+            for ch in chains:
+                ch.set_R(state["R"])
+    theta = np.array([ch.theta for ch in chains])
+    np.testing.assert_array_equal(_bits(e.theta()), _bits(theta))
+    for ch in chains:
+        ch.close()
+    e.close()
