@@ -1,4 +1,10 @@
-"""Scratch: SCAM at d=200 (BASELINE config 5) on the device vs the oracle, small chain count."""
+"""Timing probe for method='scam' on BASELINE config 5's target (not a test, not the bench):
+
+    python tools/scam_probe.py [d=200] [nchains=128] [nsimu=12] [adaptint=5] [pooled=0]
+
+prints init / run time and componentwise proposals per second; in the per-chain mode it also checks chain 1 against
+the oracle.  With MCMCX_LIBRARY pointing at a -DMCX_PHASE_PROF build the kernels print
+their phase timers."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,16 +13,7 @@ from mcmcf90_amd import engine_from_problem
 from oracle import pyoracle as po
 
 
-def c5_precision(d=200, seed=5):
-    rng = np.random.default_rng(seed)
-    Q = np.eye(d)
-    for _ in range(8):
-        v = rng.standard_normal(d); v /= np.linalg.norm(v)
-        Q = Q - 2.0 * np.outer(Q @ v, v)
-    ev = 10.0 ** np.linspace(0, 6, d)
-    L = (Q * ev) @ Q.T
-    return 0.5 * (L + L.T)
-
+from mcmcf90_amd.workloads import illcond_gauss_precision as c5_precision
 
 d = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 nch = int(sys.argv[2]) if len(sys.argv) > 2 else 128
