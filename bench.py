@@ -219,6 +219,9 @@ def main():
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "kernel": "mcx::scam_kernel" if method == "scam" else "mcx::step_kernel", "alg_bytes_per_proposal": balg}
         roof.update(launches=int(klaunch), avg_launch_ms=avg_launch_s * 1e3, kernel_share_of_wall=kms / 1e3 / dt)
+        if roof["bound"] == "hbm" and (a.pooled or d <= 20):
+            roof["note"] = ("the chip's HBM roof is quoted for uniformity; this configuration is bound by the per-chain random "
+                            "numbers (Philox + polar + pinned log/sqrt on the VALU), see DESIGN.md section 5")
         mode = method + (" pooled (one shared factor)" if a.pooled else ", per-chain factor")
         cnt = float(pooled[0].item())
         mean = (pooled[1:1 + d] / cnt).cpu().numpy()
