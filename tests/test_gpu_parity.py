@@ -49,6 +49,11 @@ def test_engine_matches_oracle_and_reference(oracle, name):
     k = z["rows_head"].shape[0]
     scale = np.maximum(np.abs(z["rows_tail"]).max(axis=0), 1e-3)
     assert np.max(np.abs(ch[-z["rows_tail"].shape[0]:, :-1] - z["rows_tail"]) / scale) < 1e-7
+    # posterior moments the reference wrote (mcmccovf.dat, mcmcmean.dat): north_star asks for 1e-6 relative
+    cmf, meanf, _ = e.chaincov(off)
+    assert np.max(np.abs(np.triu(cmf) - np.triu(z["chaincmat"]))) / np.max(np.abs(z["chaincmat"])) < 1e-6
+    assert np.max(np.abs(meanf - z["chainmean"])) / max(np.max(np.abs(z["chainmean"])), 1e-300) < 1e-6 \
+        or np.max(np.abs(meanf - z["chainmean"])) < 1e-9 * np.sqrt(np.max(np.abs(z["chaincmat"])))
     # --- against the oracle, several chains incl. the ragged tile: bit for bit
     for c in (0, off, 63, 64, 129):
         o = oracle.run_chain(cfg, prob, chain_id=(cid - off) + c, continue_on_downdate_fail=True)
