@@ -1027,6 +1027,12 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
     LaneState L;
     if (sc) lane_load(E, tile, lane, L);
     mcx_d4 cand[4], cc[4];
+#ifdef MCX_PHASE_PROF
+    unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tq = wall_clock64();
+#define PH(i) { unsigned long long tn = wall_clock64(); ph[i] += tn - tq; tq = tn; }
+#else
+#define PH(i)
+#endif
     for (int it = it0; it <= it1; ++it) {
         bool rejall = true;
         for (int j = 0; j < d; ++j) {
@@ -1041,9 +1047,13 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
                 }
             }
             if (sc) zb[lane] = rng_normal(L.g) * g_std[j];
+            PH(0)
             __syncthreads();
+            PH(1)
             mfma_slots<BW, NS>(g_UT, X, lane, d, d4, blk0, grp, cc);           // rot = U'theta
+            PH(2)
             __syncthreads();
+            PH(1)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if (s < nsl) {
@@ -1057,8 +1067,11 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
                     }
                 }
             }
+            PH(3)
             __syncthreads();
+            PH(1)
             mfma_slots<BW, NS>(g_U, X, lane, d, d4, blk0, grp, cand);          // theta' = U rot
+            PH(2)
             if (cand_global) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
@@ -1075,8 +1088,11 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { const int o = EROW(s, r); X[EOFF(s, r)] = o < d ? cand[s][r] - g_mu[o < d ? o : 0] : 0.0; }
                     }
+                PH(3)
                 __syncthreads();
+                PH(1)
                 mfma_slots<BW, NS>(g_lamT, X, lane, d, d4, blk0, grp, cc);     // y = Lam v
+                PH(2)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {                                   // q_(block, lane>>4) = chain over r of y v
                     if (s < nsl) {
@@ -1086,7 +1102,9 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
                         if (EROW(s, 0) < d) Q[(size_t)(EROW(s, 0) >> 4) * 256 + (EROW(s, 0) & 3) * 64 + ECH(s)] = q;
                     }
                 }
+                PH(4)
                 __syncthreads();
+                PH(1)
             }
             if (sc) {
                 bool inb = true; double pri2 = 0.0, ss2 = 0.0;
@@ -1107,7 +1125,9 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
                 if (!reject) { L.ss1 = ss2; L.pri1 = pri2; rejall = false; }
                 fl[lane] = reject ? 0.0 : 1.0;
             }
+            PH(5)
             __syncthreads();
+            PH(1)
             // accepted chains: theta = theta' (each lane its own elements; the next sub-step reloads exactly those)
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -1140,6 +1160,11 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
         }
     }
     if (sc) lane_store(E, tile, lane, L);
+#ifdef MCX_PHASE_PROF
+    PH(6)
+    if (tile == 0 && lane == 0 && (w == 0 || sc)) printf("wave %d x10ns: theta+fill %llu barriers %llu mfma %llu fills %llu q %llu scalar %llu accept %llu\n", w, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
+#endif
+#undef PH
 #undef EOFF
 #undef EROW
 #undef ECH
