@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "_build", "libmcxoracle.so")
+_LIB = os.environ.get("MCX_ORACLE_LIB") or os.path.join(_HERE, "_build", "libmcxoracle.so")   # override: the sanitizer build
 
 METHODS = {"dram": 0, "ram": 1, "scam": 2, "er": 3}
 TARGETS = {"gauss": 0, "banana": 1, "expdata": 2}
