@@ -120,6 +120,10 @@ class Engine:
         self._chk(self.L.mcmcx_set_priors(self.h, _dp(_f64(mu)), _dp(_f64(sig))))
 
     # --- mcmc_main
+    def set_stream(self, hip_stream):
+        """Run on the caller's HIP stream (e.g. torch.cuda.Stream().cuda_stream) instead of the engine's own; before init."""
+        self._chk(self.L.mcmcx_set_stream(self.h, C.c_void_p(int(hip_stream))))
+
     def init(self):
         self._chk(self.L.mcmcx_init(self.h))
 

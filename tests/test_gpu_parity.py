@@ -212,3 +212,22 @@ def test_sizes_beyond_the_limits_fail_loudly():
     with pytest.raises(McmcError):
         e.init()
     e.close()
+
+
+def test_caller_supplied_stream(oracle):
+    """mcmcx_set_stream: the engine enqueues on the host program's stream (ordering with the caller's own kernels and
+    copies); same chain as on its private stream."""
+    import torch
+    from mcmcf90_amd import engine_from_problem
+    z, cfg, prob = load("c2_gauss10_am", oracle)
+    ckw, pkw = _kw(z)
+    ckw["nsimu"] = 350
+    ref = engine_from_problem(ckw, pkw, nchains=70)
+    ref.init(); ref.run()
+    st = torch.cuda.Stream()
+    e = engine_from_problem(ckw, pkw, nchains=70)
+    e.set_stream(st.cuda_stream)
+    e.init(); e.run(); e.sync()
+    st.synchronize()
+    np.testing.assert_array_equal(_bits(e.theta()), _bits(ref.theta()))
+    e.close(); ref.close()
