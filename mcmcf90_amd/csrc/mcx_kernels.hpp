@@ -1867,17 +1867,23 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
         double staypc = (double)stayed / (double)it;
         double sf = E.scalefactor;
         bool greedy_lane = false;
+        // the factor in use: packed Cholesky factor, or the full d x d SVD factor with condmax > 0
+        double *Ft = E.usesvd ? E.Rf + (size_t)tile * d * d * 64 : Rt;
+        double *F2t = !E.dodr ? nullptr : (E.usesvd ? E.R2f + (size_t)tile * d * d * 64 : E.R2 + (size_t)tile * P * 64);
+        const int nf = E.usesvd ? d * d : P;
         if (staypc > 1.0 - E.scalelimit) {
-            for (int e = 0; e < P; ++e) GV(Rt, e) = GV(Rt, e) / sf;
+            for (int e = 0; e < nf; ++e) GV(Ft, e) = GV(Ft, e) / sf;
             if (E.dodr) {
-                double *R2t = E.R2 + (size_t)tile * P * 64, *iCt = E.iC + (size_t)tile * P * 64;
-                for (int e = 0; e < P; ++e) { GV(R2t, e) = GV(R2t, e) / sf; GV(iCt, e) = GV(iCt, e) * sf * sf; }
+                double *iCt = E.iC + (size_t)tile * P * 64;
+                for (int e = 0; e < nf; ++e) GV(F2t, e) = GV(F2t, e) / sf;
+                for (int e = 0; e < P; ++e) GV(iCt, e) = GV(iCt, e) * sf * sf;
             }
         } else if (staypc < E.scalelimit) {
-            for (int e = 0; e < P; ++e) GV(Rt, e) = GV(Rt, e) * sf;
+            for (int e = 0; e < nf; ++e) GV(Ft, e) = GV(Ft, e) * sf;
             if (E.dodr) {
-                double *R2t = E.R2 + (size_t)tile * P * 64, *iCt = E.iC + (size_t)tile * P * 64;
-                for (int e = 0; e < P; ++e) { GV(R2t, e) = GV(R2t, e) * sf; GV(iCt, e) = GV(iCt, e) / sf / sf; }
+                double *iCt = E.iC + (size_t)tile * P * 64;
+                for (int e = 0; e < nf; ++e) GV(F2t, e) = GV(F2t, e) * sf;
+                for (int e = 0; e < P; ++e) GV(iCt, e) = GV(iCt, e) / sf / sf;
             }
         } else {
             docalc = true;

@@ -1,0 +1,99 @@
+"""Randomised configurations: the engine against the oracle, bit for bit, over the namelist's option space at small
+sizes -- method x delayed rejection x burn-in scaling x greedy x AP window x adaptend x initcmatn x sigma2 update x
+bounds x priors x SVD factor (condmax) x target, with seeds fixed so a failure reproduces."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def _draw(seed):
+    r = np.random.default_rng(1000 + seed)
+    method = r.choice(["dram", "dram", "ram", "scam", "er"])
+    d = int(r.integers(1, 13))
+    kind = r.choice(["gauss", "gauss", "banana", "expdata"])
+    if kind == "banana" and d < 2:
+        d = 2
+    if kind == "expdata":
+        d = 2
+    nsimu = int(r.integers(60, 260))
+    ckw = dict(nsimu=nsimu, method=str(method), adaptint=int(r.choice([7, 20, 50])), updatesigma=int(r.integers(0, 2)))
+    if method == "dram":
+        if r.random() < 0.5:
+            ckw["drscale"] = float(r.choice([2.0, 3.0, 5.0]))
+        if r.random() < 0.4:
+            ckw.update(doburnin=1, burnintime=int(r.integers(20, 120)), scalelimit=float(r.choice([0.05, 0.3])),
+                       greedy=int(r.integers(0, 2)))
+        if r.random() < 0.25:
+            ckw["adapthist"] = int(r.choice([30, 80]))
+        if r.random() < 0.3:
+            ckw["condmax"] = float(r.choice([1e8, 1e12]))
+    if method in ("dram", "er") and r.random() < 0.3:
+        ckw["adaptend"] = int(nsimu * 0.6)
+    if r.random() < 0.3:
+        ckw["initcmatn"] = int(r.integers(1, 60))
+    if method == "ram":
+        ckw.update(alphatarget=float(r.choice([0.234, 0.4])), nuparam=float(r.choice([0.6, 0.7, 0.9])))
+        if r.random() < 0.3:
+            ckw.update(doburnin=1, burnintime=int(r.integers(10, 60)))
+    if kind == "gauss":
+        A = r.standard_normal((d, d)) / np.sqrt(d)
+        pkw = dict(kind="gauss", npar=d, par0=r.standard_normal(d) * 0.3, cmat0=np.diag(r.uniform(0.05, 0.6, d)),
+                   mu=r.standard_normal(d) * 0.2, lam=A @ A.T + np.diag(r.uniform(0.5, 2.0, d)))
+    elif kind == "banana":
+        pkw = dict(kind="banana", npar=d, par0=np.zeros(d), cmat0=float(r.uniform(0.05, 0.5)) * np.eye(d), b=float(r.choice([0.03, 0.1])))
+    else:
+        x = np.arange(11.0)
+        y = 9.0 * np.exp(-0.1 * x) + r.standard_normal(11) * 0.3
+        pkw = dict(kind="expdata", npar=2, par0=[9.0, 0.12], cmat0=[[0.2, 0], [0, 0.001]], xdata=x, ydata=y, lo=[0, 0])
+    if ckw["updatesigma"]:
+        pkw.update(sigma2=float(r.uniform(0.3, 1.5)), nobs=int(r.integers(5, 40)))
+        ckw.update(N0=float(r.choice([1.0, 4.0])), S02=float(r.choice([0.0, 0.8])))
+    if kind != "expdata" and r.random() < 0.3:
+        pkw.update(lo=np.full(d, -1.5), hi=np.full(d, 1.8))
+    if r.random() < 0.3:
+        pkw.update(pri_mu=np.zeros(d), pri_sig=np.where(r.random(d) < 0.5, 0.0, 1.0))
+    return ckw, pkw
+
+
+@pytest.mark.parametrize("seed", range(300))
+def test_random_configuration(oracle, seed):
+    from mcmcf90_amd import engine_from_problem
+    ckw, pkw = _draw(seed)
+    cfg = oracle.make_cfg(**ckw)
+    prob = oracle.Problem(**pkw)
+    from mcmcf90_amd import McmcError
+    e = engine_from_problem(ckw, pkw, nchains=67, chain_id0=3 * seed, record_accept=1, record_chain=1)
+    try:
+        oracle.run_chain(oracle.make_cfg(**dict(ckw, nsimu=2)), prob, chain_id=3 * seed)
+    except RuntimeError:                                      # the reference stops in MCMC_init (e.g. dpotri of an SVD factor
+        with pytest.raises(McmcError):                        # whose upper triangle is singular): so must the engine
+            e.init()
+        e.close()
+        return
+    e.init(); e.run()
+    for c in (0, 63, 66):
+        o = oracle.run_chain(cfg, prob, chain_id=3 * seed + c, continue_on_downdate_fail=True)
+        assert o.rc == 0, (ckw, o.rc)
+        np.testing.assert_array_equal(e.accepted(c), o.accepted, err_msg=str(ckw))
+        ch, ss, s2 = e.chain(c)
+        np.testing.assert_array_equal(_bits(ch), _bits(o.chain), err_msg=str(ckw))
+        if cfg.updatesigma:
+            np.testing.assert_array_equal(_bits(s2), _bits(o.s2chain), err_msg=str(ckw))
+        cnt = e.counters(c)
+        assert (cnt["stayed"], cnt["bndstayed"], cnt["draccepted"], cnt["drtries"], cnt["erstayed"]) == \
+               (o.stayed, o.bndstayed, o.draccepted, o.drtries, o.erstayed), ckw
+        assert e.rng(c)[0] == o.rng_n, ckw
+        if cfg.usesvd:
+            np.testing.assert_array_equal(_bits(e.R(c)), _bits(o.R), err_msg=str(ckw))
+        else:
+            np.testing.assert_array_equal(_bits(np.triu(e.R(c))), _bits(np.triu(o.R)), err_msg=str(ckw))
+        cm, mean, wsum = e.chaincov(c)
+        if cfg.method != 1:                                   # RAM never touches chaincmat
+            np.testing.assert_array_equal(_bits(np.triu(cm)), _bits(np.triu(o.chaincmat)), err_msg=str(ckw))
+            assert wsum == o.chainwsum, ckw
+    e.close()
