@@ -97,3 +97,89 @@ def test_random_configuration(oracle, seed):
             np.testing.assert_array_equal(_bits(np.triu(cm)), _bits(np.triu(o.chaincmat)), err_msg=str(ckw))
             assert wsum == o.chainwsum, ckw
     e.close()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_configuration_in_pieces(oracle, seed):
+    """mcmcx_run(upto) called in random pieces (launch boundaries anywhere relative to the adaptation ticks) ends in the
+    same state as one call, for random configurations."""
+    from mcmcf90_amd import engine_from_problem, McmcError
+    ckw, pkw = _draw(5000 + seed)
+    r = np.random.default_rng(seed)
+    e1 = engine_from_problem(ckw, pkw, nchains=65, record_accept=1)
+    try:
+        e1.init()
+    except McmcError:
+        e1.close()
+        return
+    e1.run()
+    e2 = engine_from_problem(ckw, pkw, nchains=65, record_accept=1)
+    e2.init()
+    cuts = sorted(set(int(v) for v in r.integers(2, ckw["nsimu"], size=6))) + [ckw["nsimu"]]
+    for upto in cuts:
+        e2.run(upto)
+    np.testing.assert_array_equal(e1.accept_masks(), e2.accept_masks(), err_msg=str((ckw, cuts)))
+    np.testing.assert_array_equal(_bits(e1.theta()), _bits(e2.theta()), err_msg=str((ckw, cuts)))
+    e1.close(); e2.close()
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_configuration_host_callbacks(oracle, seed):
+    """The same option space through the host-callback path (the user's ssfunction / priorfun / checkbounds /
+    ssfunction_er): identical to the device-resident target."""
+    import ctypes as C
+    from mcmcf90_amd import Engine, make_config, engine_from_problem, McmcError
+    ckw, pkw = _draw(9000 + seed)
+    if ckw["method"] == "scam" or ckw.get("condmax", 0.0) > 0.0:
+        pytest.skip("host callbacks are not available with the SVD paths")
+    ckw["nsimu"] = min(ckw["nsimu"], 120)
+    prob = oracle.Problem(**pkw)
+    L = oracle.lib()
+    tgt = prob.ctarget()
+    L.mcxo_ssfun.restype = C.c_double; L.mcxo_priorfun.restype = C.c_double; L.mcxo_checkbounds.restype = C.c_int
+    dp = C.POINTER(C.c_double)
+    ref = engine_from_problem(ckw, pkw, nchains=3, chain_id0=7, record_accept=1)
+    try:
+        ref.init()
+    except McmcError:
+        ref.close()
+        return
+    ref.run()
+    npar = int(pkw["npar"])
+    e = Engine(make_config(npar, 3, chain_id0=7, record_accept=1, **ckw))
+    e.setpar0(pkw["par0"]); e.setcmat0(np.asarray(pkw["cmat0"], dtype=float).reshape(npar, npar))
+    e.setsigma2nobs(float(pkw.get("sigma2", 1.0)), int(pkw.get("nobs", 1)))
+    e.set_target_host(lambda th: L.mcxo_ssfun(C.byref(tgt), th.ctypes.data_as(dp)),
+                      lambda th: L.mcxo_priorfun(C.byref(tgt), th.ctypes.data_as(dp)),
+                      lambda th: bool(L.mcxo_checkbounds(C.byref(tgt), th.ctypes.data_as(dp))))
+    e.init(); e.run()
+    np.testing.assert_array_equal(_bits(e.theta()), _bits(ref.theta()), err_msg=str(ckw))
+    for c in range(3):                                        # (the ballots' bits of the tile's unused lanes differ: no callbacks there)
+        np.testing.assert_array_equal(e.accepted(c), ref.accepted(c), err_msg=str(ckw))
+        assert e.rng(c)[0] == ref.rng(c)[0], ckw
+    e.close(); ref.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configuration_larger_npar(oracle, seed):
+    """npar 13..48 (several register panels / blocks of the factor, ragged last panels), Gaussian target."""
+    from mcmcf90_amd import engine_from_problem
+    r = np.random.default_rng(7000 + seed)
+    d = int(r.integers(13, 49))
+    method = str(r.choice(["dram", "ram", "dram", "er"]))
+    ckw = dict(nsimu=int(r.integers(50, 130)), method=method, adaptint=int(r.choice([15, 40])), updatesigma=0)
+    if method == "dram" and r.random() < 0.5:
+        ckw["drscale"] = 2.0
+    A = r.standard_normal((d, d)) / np.sqrt(d)
+    pkw = dict(kind="gauss", npar=d, par0=r.standard_normal(d) * 0.1, cmat0=np.diag(r.uniform(0.2, 1.0, d)) / d,
+               mu=np.zeros(d), lam=A @ A.T + np.eye(d))
+    cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
+    e = engine_from_problem(ckw, pkw, nchains=66, chain_id0=seed, record_accept=1)
+    e.init(); e.run()
+    th = e.theta()
+    for c in (0, 65):
+        o = oracle.run_chain(cfg, prob, chain_id=seed + c, continue_on_downdate_fail=True)
+        np.testing.assert_array_equal(e.accepted(c), o.accepted, err_msg=str(ckw))
+        np.testing.assert_array_equal(_bits(th[c]), _bits(o.theta), err_msg=str(ckw))
+        np.testing.assert_array_equal(_bits(np.triu(e.R(c))), _bits(np.triu(o.R)), err_msg=str(ckw))
+    e.close()
