@@ -1,0 +1,67 @@
+"""The oracle against the REAL reference on randomised configurations (dev container only: needs oracle/_ref/mcxref,
+built from /root/reference; skipped on the GPU box).  Same generator as tests/test_gpu_fuzz.py, so the option space the
+device is checked on against the oracle is the one the oracle is checked on against mcmcf90 itself: identical
+run-length column (accept sequence), identical number of uniforms drawn, states to BLAS/libm rounding."""
+import importlib.util
+import os
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_spec = importlib.util.spec_from_file_location("gpu_fuzz_gen", os.path.join(HERE, "test_gpu_fuzz.py"))
+_gen = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_gen)
+
+
+def _well_posed(oracle, cfg, prob, seed):
+    """Condition number of chaincmat at every iteration where MCMC_adapt may factor it."""
+    n = prob.npar
+    lc = oracle.LiveChain(cfg, prob, chain_id=seed)
+    ok = True
+    step = max(1, min(cfg.adaptint, cfg.badaptint if cfg.badaptint > 0 else cfg.adaptint))
+    for it in range(step, cfg.nsimu + 1, step):
+        lc.run(it)
+        cm = np.ctypeslib.as_array(lc.ch.contents.chaincmat, shape=(n, n)).copy()
+        cm = np.triu(cm) + np.triu(cm, 1).T
+        if not np.isfinite(cm).all():                          # e.g. a one-row window: covmat divides by wsum - 1 = 0
+            ok = False
+            break
+        ev = np.linalg.eigvalsh(cm)
+        if ev[-1] <= 0 or ev[0] < 1e-6 * ev[-1]:
+            ok = False
+            break
+        # the SVD paths also need distinct singular values: inside a cluster the basis is arbitrary
+        if cfg.usesvd and n > 1 and np.min(np.diff(ev)) < 1e-6 * ev[-1]:
+            ok = False
+            break
+    lc.close()
+    return ok
+
+
+@pytest.mark.parametrize("seed", range(400))
+def test_oracle_equals_reference_on_random_configuration(oracle, seed):
+    from oracle import refrun as rr
+    if not rr.available():
+        pytest.skip("oracle/_ref/mcxref not built (needs /root/reference)")
+    ckw, pkw = _gen._draw(seed)
+    cfg = oracle.make_cfg(**ckw)
+    prob = oracle.Problem(**pkw)
+    try:
+        o = oracle.run_chain(cfg, prob, chain_id=seed)
+    except RuntimeError:
+        with pytest.raises(Exception):                        # the reference stops in MCMC_init too
+            rr.run_reference(cfg, prob, chain_id=seed, pinned_svd=bool(cfg.usesvd))
+        return
+    if o.ram_downdate_fail:
+        pytest.skip("failed RAM downdate: the reference stops there")
+    if cfg.method != 1 and not _well_posed(oracle, cfg, prob, seed):
+        pytest.skip("a covariance handed to the factorisation is numerically singular (fewer distinct rows than parameters) or, "
+                    "on the SVD paths, has clustered singular values: what LAPACK returns for it is rounding noise, the "
+                    "reference linked to another LAPACK would differ from itself")
+    r = rr.run_reference(cfg, prob, chain_id=seed, pinned_svd=bool(cfg.usesvd))
+    np.testing.assert_array_equal(r.chain[:, -1].astype(np.int64), o.chain[:, -1].astype(np.int64), err_msg=str(ckw))
+    assert r.rng_n == o.rng_n, ckw
+    scale = np.maximum(np.abs(o.chain[:, :-1]).max(axis=0), 1e-3)
+    assert np.max(np.abs(r.chain[:, :-1] - o.chain[:, :-1]) / scale) < 1e-7, ckw
+    if cfg.updatesigma:
+        np.testing.assert_allclose(r.s2chain, o.s2chain, rtol=1e-7)
