@@ -183,3 +183,37 @@ def test_random_configuration_larger_npar(oracle, seed):
         np.testing.assert_array_equal(_bits(th[c]), _bits(o.theta), err_msg=str(ckw))
         np.testing.assert_array_equal(_bits(np.triu(e.R(c))), _bits(np.triu(o.R)), err_msg=str(ckw))
     e.close()
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_pooled_am_matrix_core_kernel_equals_lane_kernel(seed, monkeypatch):
+    """pooled_mfma_kernel (products as MFMA tiles) == the lane-per-chain pooled kernel, for random sizes (one to three
+    passes of output blocks, ragged last block and k-block), targets, bounds, priors and the sigma2 update."""
+    from mcmcf90_amd import engine_from_problem
+    r = np.random.default_rng(11000 + seed)
+    d = int(r.choice([1, 2, 3, 5, 16, 17, 31, 48, 50, 63, 64, 65, 80, 97, 130]))
+    kind = str(r.choice(["gauss", "gauss", "banana"])) if d >= 2 else "gauss"
+    n = int(r.choice([65, 130, 200]))
+    ckw = dict(nsimu=int(r.integers(20, 60)), adaptint=int(r.choice([8, 15])), updatesigma=int(r.integers(0, 2)))
+    if kind == "gauss":
+        A = r.standard_normal((d, d)) / np.sqrt(d)
+        pkw = dict(kind="gauss", npar=d, par0=r.standard_normal(d) * 0.1, cmat0=np.diag(r.uniform(0.2, 1.0, d)) / d,
+                   mu=r.standard_normal(d) * 0.1, lam=A @ A.T + np.eye(d))
+    else:
+        pkw = dict(kind="banana", npar=d, par0=np.zeros(d), cmat0=(0.3 / d) * np.eye(d), b=0.05)
+    if ckw["updatesigma"]:
+        pkw.update(sigma2=0.8, nobs=20)
+    if r.random() < 0.4:
+        pkw.update(lo=np.full(d, -1.0), hi=np.full(d, 1.2))
+    if r.random() < 0.4:
+        pkw.update(pri_mu=np.zeros(d), pri_sig=np.where(r.random(d) < 0.5, 0.0, 1.0))
+    e = engine_from_problem(ckw, pkw, nchains=n, pooled=1, record_accept=1)
+    e.init(); e.run()
+    monkeypatch.setenv("MCMCX_POOLED_SCALAR", "1")
+    e2 = engine_from_problem(ckw, pkw, nchains=n, pooled=1, record_accept=1)
+    e2.init(); e2.run()
+    np.testing.assert_array_equal(e.accept_masks(), e2.accept_masks(), err_msg=str((d, kind, n, ckw)))
+    np.testing.assert_array_equal(_bits(e.theta()), _bits(e2.theta()), err_msg=str((d, kind, n, ckw)))
+    np.testing.assert_array_equal(_bits(e.scalars()), _bits(e2.scalars()), err_msg=str((d, kind, n, ckw)))
+    np.testing.assert_array_equal(_bits(e.pooled()[3]), _bits(e2.pooled()[3]))
+    e.close(); e2.close()
