@@ -217,3 +217,38 @@ def test_pooled_am_matrix_core_kernel_equals_lane_kernel(seed, monkeypatch):
     np.testing.assert_array_equal(_bits(e.scalars()), _bits(e2.scalars()), err_msg=str((d, kind, n, ckw)))
     np.testing.assert_array_equal(_bits(e.pooled()[3]), _bits(e2.pooled()[3]))
     e.close(); e2.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_pooled_scam_substeps_equal_lane_kernel(seed):
+    """Without adaptation the pooled SCAM (one rotation, MFMA tiles, up to 16 waves per tile) and the per-chain SCAM
+    kernel (lane per chain, every chain its own copy of the same initial rotation) must produce the same chains:
+    random sizes over every block / group wave split, targets, bounds, priors, sigma2 update."""
+    from mcmcf90_amd import engine_from_problem
+    r = np.random.default_rng(13000 + seed)
+    d = int(r.choice([2, 3, 7, 15, 16, 17, 33, 48, 63, 64, 65, 81, 100, 113, 129]))
+    kind = str(r.choice(["gauss", "gauss", "banana"]))
+    n = int(r.choice([65, 130]))
+    ckw = dict(nsimu=int(r.integers(4, 9)), method="scam", doadapt=0, updatesigma=int(r.integers(0, 2)))
+    if kind == "gauss":
+        A = r.standard_normal((d, d)) / np.sqrt(d)
+        pkw = dict(kind="gauss", npar=d, par0=r.standard_normal(d) * 0.1, cmat0=np.diag(r.uniform(0.2, 1.0, d)) / d,
+                   mu=r.standard_normal(d) * 0.1, lam=A @ A.T + np.eye(d))
+    else:
+        pkw = dict(kind="banana", npar=d, par0=np.zeros(d), cmat0=np.diag(r.uniform(0.2, 0.4, d)) / d, b=0.05)
+    if ckw["updatesigma"]:
+        pkw.update(sigma2=0.8, nobs=20)
+    if r.random() < 0.4:
+        pkw.update(lo=np.full(d, -1.0), hi=np.full(d, 1.2))
+    if r.random() < 0.4:
+        pkw.update(pri_mu=np.zeros(d), pri_sig=np.where(r.random(d) < 0.5, 0.0, 1.0))
+    e = engine_from_problem(ckw, pkw, nchains=n, pooled=1, record_accept=1)
+    e.init(); e.run()
+    e2 = engine_from_problem(ckw, pkw, nchains=n, pooled=0, record_accept=1)
+    e2.init(); e2.run()
+    np.testing.assert_array_equal(e.accept_masks(), e2.accept_masks(), err_msg=str((d, kind, n, ckw)))
+    np.testing.assert_array_equal(_bits(e.theta()), _bits(e2.theta()), err_msg=str((d, kind, n, ckw)))
+    np.testing.assert_array_equal(_bits(e.scalars()), _bits(e2.scalars()), err_msg=str((d, kind, n, ckw)))
+    for c in (0, n - 1):
+        assert e.rng(c)[0] == e2.rng(c)[0]
+    e.close(); e2.close()
