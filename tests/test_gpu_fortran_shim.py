@@ -299,3 +299,41 @@ def test_user_program_with_method_er(oracle):
     o = oracle.run_chain(cfg, prob, chain_id=0)
     np.testing.assert_array_equal(chain[:, -1].astype(np.int32), o.chain[:, -1].astype(np.int32))
     np.testing.assert_allclose(chain[:, :-1], o.chain[:, :-1], rtol=1e-9)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_namelists_through_the_shim(oracle, seed):
+    """Random values for the namelist's numeric control variables, written as mcmcinit.nml, through the Fortran shim
+    (demo_main, device-resident expdata target): chain.dat must be the oracle's chain for the same settings -- checks
+    the namelist -> mcmcx_config mapping variable by variable."""
+    exe = os.path.join(FDIR, "demo_main")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", FDIR])
+    z, _, _ = load("c1_shipped_nml", oracle)
+    r = np.random.default_rng(21000 + seed)
+    method = str(r.choice(["dram", "dram", "ram", "er", "scam"]))
+    ckw = dict(nsimu=int(r.integers(300, 900)), method=method, adaptint=int(r.choice([50, 100])), updatesigma=int(r.integers(0, 2)),
+               N0=float(r.choice([1.0, 3.0])), S02=float(r.choice([0.0, 0.6])), initcmatn=int(r.choice([0, 25])))
+    if method == "dram":
+        ckw.update(drscale=float(r.choice([0.0, 2.0])), doburnin=int(r.integers(0, 2)), burnintime=int(r.choice([0, 150])),
+                   scalelimit=float(r.choice([0.05, 0.3])), scalefactor=float(r.choice([2.5, 1.5])), greedy=int(r.integers(0, 2)),
+                   adapthist=int(r.choice([0, 120])), adaptend=int(r.choice([0, 250])), badaptint=int(r.choice([-1, 30])))
+    if method == "ram":
+        ckw.update(alphatarget=float(r.choice([0.234, 0.35])), nuparam=float(r.choice([0.7, 0.55])))
+    if method == "scam":
+        ckw.update(condmax=float(r.choice([0.0, 1e12])))
+    pkw = dict(kind="expdata", npar=2, par0=[10, 0.1], cmat0=[[0.2, 0], [0, 0.001]], sigma2=0.5, nobs=11,
+               xdata=z["prob_xdata"], ydata=z["prob_ydata"], lo=[0, 0])
+    nml = "&mcmc\n" + "".join(" %s = %s\n" % (k, ("'%s'" % v) if isinstance(v, str) else repr(v)) for k, v in ckw.items()) + \
+          " printint = 0\n/\n&mcmcx\n devtarget = 'expdata'\n datafile = 'data.dat'\n lowerfile = 'lower.dat'\n nchains = 3\n/\n"
+    with tempfile.TemporaryDirectory() as d:
+        _write_inputs(d, z, nml)
+        open(os.path.join(d, "lower.dat"), "w").write("0 0\n")
+        p = subprocess.run([exe], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert p.returncode == 0, p.stdout.decode(errors="replace")
+        chain = np.loadtxt(os.path.join(d, "chain.dat"), ndmin=2)
+        cov = np.loadtxt(os.path.join(d, "mcmccovf.dat"), ndmin=2)
+    o = oracle.run_chain(oracle.make_cfg(**ckw), oracle.Problem(**pkw), chain_id=0, continue_on_downdate_fail=True)
+    np.testing.assert_array_equal(chain, o.chain, err_msg=nml)
+    if method != "ram":
+        np.testing.assert_array_equal(np.triu(cov), np.triu(o.chaincmat), err_msg=nml)
