@@ -460,23 +460,35 @@ static int host_iteration(mcmcx_engine *h, int it)
     const dim3 g(h->ntiles), b(64);
     const double *rs = h->d_ramscale + it;
     const size_t lds = (size_t)h->d * 64 * sizeof(double) * 2;
-    hipLaunchKernelGGL((host_phase_kernel<0>), g, b, 0, h->stream, h->E, it, rs);
+    if (h->cfg.method == MCMCX_METHOD_SCAM) {           // MCMC_run_scam: npar componentwise proposals, each evaluated by the host
+        for (int j = 0; j < h->d; ++j) {
+            hipLaunchKernelGGL((host_phase_kernel<5>), g, b, 0, h->stream, h->E, it, rs, j);
+            HIPCHK(hipGetLastError());
+            int rc = host_eval(h, h->E.cand, h->d, false); if (rc) return rc;
+            hipLaunchKernelGGL((host_phase_kernel<6>), g, b, 0, h->stream, h->E, it, rs, j);
+            HIPCHK(hipGetLastError());
+        }
+        hipLaunchKernelGGL((host_phase_kernel<7>), g, b, 0, h->stream, h->E, it, rs, 0);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    hipLaunchKernelGGL((host_phase_kernel<0>), g, b, 0, h->stream, h->E, it, rs, 0);
     HIPCHK(hipGetLastError());
     if (h->cfg.method == MCMCX_METHOD_ER) {             // MCMC_run_er: the threshold is drawn between priorfun and ssfunction_er
         int rc = host_eval(h, h->E.cand, h->d, false, 1); if (rc) return rc;
-        hipLaunchKernelGGL((host_phase_kernel<3>), g, b, 0, h->stream, h->E, it, rs);
+        hipLaunchKernelGGL((host_phase_kernel<3>), g, b, 0, h->stream, h->E, it, rs, 0);
         HIPCHK(hipGetLastError());
         rc = host_eval(h, h->E.cand, h->d, true, 2); if (rc) return rc;
-        hipLaunchKernelGGL((host_phase_kernel<4>), g, b, 0, h->stream, h->E, it, rs);
+        hipLaunchKernelGGL((host_phase_kernel<4>), g, b, 0, h->stream, h->E, it, rs, 0);
         HIPCHK(hipGetLastError());
         return 0;
     }
     int rc = host_eval(h, h->E.cand, h->d, false); if (rc) return rc;
-    hipLaunchKernelGGL((host_phase_kernel<1>), g, b, 0, h->stream, h->E, it, rs);
+    hipLaunchKernelGGL((host_phase_kernel<1>), g, b, 0, h->stream, h->E, it, rs, 0);
     HIPCHK(hipGetLastError());
     if (h->dodr) {
         rc = host_eval(h, h->E.cs, 2 * h->d, true); if (rc) return rc;
-        hipLaunchKernelGGL((host_phase_kernel<2>), g, b, lds, h->stream, h->E, it, rs);
+        hipLaunchKernelGGL((host_phase_kernel<2>), g, b, lds, h->stream, h->E, it, rs, 0);
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -657,7 +669,6 @@ int mcmcx_init(mcmcx_handle h)
     if (!h->sigma2ok) { h->sigma2 = 1.0; h->nobs = 1; }                               // MCMC_init.F90:52-59
     if (h->tkind < 0) return fail(-31, "no target: the device engine needs mcmcx_set_target_*");
     if (h->dodr && lds_bytes(h) > 160 * 1024) return fail(-35, "delayed rejection keeps two npar-vectors per chain in LDS: npar <= 160 with drscale > 0");
-    if (h->tkind == TGT_HOST && h->usesvd) return fail(-31, "host-callback targets are not available with condmax > 0 / method='scam'");
     std::vector<double> Rp, Cp, Rfull, qstd0;
     int info = host_initial_R(d, h->cmat0, Rp, Cp);
     if (h->usesvd) {                                                                  // Cp (packed cmat0) is still needed

@@ -839,7 +839,7 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
 // the host evaluates the candidates of all chains in chain order, phase 1 decides (and proposes the DR
 // try), the host evaluates again, phase 2 decides the DR try and finishes the iteration.  Same device
 // functions as step_kernel; per-lane state round-trips through HBM between phases.
-enum { HX_SS2 = 0, HX_PRI2, HX_REJECT, HX_STAGE2, HX_DRMOVED, HX_SU, HX_CRIT, NHX };
+enum { HX_SS2 = 0, HX_PRI2, HX_REJECT, HX_STAGE2, HX_DRMOVED, HX_SU, HX_CRIT, HX_MOVED, NHX };
 enum { HE_INB = 0, HE_PRI, HE_SS, NHE };
 
 struct LaneState {
@@ -1365,7 +1365,7 @@ MCX_DEV void host_finish(const EngineDev &E, int tile, int lane, int it, LaneSta
 }
 
 template <int PHASE>
-__global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, const double *__restrict__ ramscale)
+__global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, const double *__restrict__ ramscale, int aux)
 {
     extern __shared__ double X[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
@@ -1381,7 +1381,8 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
     if (PHASE == 0) {                                             // newpar = MCMC_propose(oldpar, R)
         double su = gen_normals(L.g, zs_t, lane, d, true);
         GV(hx, HX_SU) = su;
-        trmv_panels(E.R + (size_t)tile * E.P * 64, zs_t, cand_t, theta_t, lane, d, true);
+        if (E.usesvd) gemvN_panels(E.Rf + (size_t)tile * d * d * 64, zs_t, cand_t, theta_t, lane, d, true);    // matmulx(R,z)
+        else trmv_panels(E.R + (size_t)tile * E.P * 64, zs_t, cand_t, theta_t, lane, d, true);
     } else if (PHASE == 1) {
         const bool inb = GV(hev, HE_INB) != 0.0;
         const double pri2 = GV(hev, HE_PRI), ss2 = GV(hev, HE_SS);
@@ -1400,12 +1401,57 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
             const bool m = reject;
             if (m) L.drtries += 1;
             gen_normals(L.g, zs_t + (size_t)d * 64, lane, d, m);
-            trmv_panels(E.R2 + (size_t)tile * E.P * 64, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d, m);
+            if (E.usesvd) gemvN_panels(E.R2f + (size_t)tile * d * d * 64, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d, m);
+            else trmv_panels(E.R2 + (size_t)tile * E.P * 64, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d, m);
             GV(hx, HX_SS2) = ss2; GV(hx, HX_PRI2) = pri2;
             GV(hx, HX_REJECT) = reject ? 1.0 : 0.0; GV(hx, HX_STAGE2) = m ? 1.0 : 0.0;
         } else {
             host_finish(E, tile, lane, it, L, reject, false, ss2, pri2, ramscale);
         }
+    } else if (PHASE == 5) {                                      // SCAM sub-step aux: propose (MCMC_run_scam.F90:94-117)
+        const int j = aux;
+        double *rot_t = c2_t;
+        const double *Ut = E.Rf + (size_t)tile * d * d * 64;
+        if (j == 0) GV(hx, HX_MOVED) = 0.0;
+        gemvT_panels(Ut, theta_t, rot_t, lane, d);
+        const double zj = rng_normal(L.g) * TIDX(E.qstd, tile, d, j, lane);
+        GV(rot_t, j) = GV(rot_t, j) + zj;
+        gemvN_panels(Ut, rot_t, cand_t, nullptr, lane, d, true);
+    } else if (PHASE == 6) {                                      // SCAM sub-step: decide with the host's bounds / prior / ss
+        const bool inb = GV(hev, HE_INB) != 0.0;
+        const double pri2 = GV(hev, HE_PRI), ss2 = GV(hev, HE_SS);
+        bool reject;
+        if (!inb) { L.bnd += 1; L.alpha12 = 0.0; reject = true; }
+        else {
+            L.alpha12 = d_alpha(L.ss1, L.pri1, ss2, pri2, L.sigma2);
+            reject = true;
+            if (L.alpha12 >= 1.0) reject = false;
+            else if (L.alpha12 > 0.0) { double u = rng_uniform(L.g); if (u <= L.alpha12) reject = false; }
+        }
+        if (!reject) {
+            L.ss1 = ss2; L.pri1 = pri2; GV(hx, HX_MOVED) = 1.0;
+            for (int k = 0; k < d; ++k) GV(theta_t, k) = GV(cand_t, k);
+        }
+    } else if (PHASE == 7) {                                      // SCAM: end of the outer iteration (one chain row)
+        const bool rejall = GV(hx, HX_MOVED) == 0.0;
+        if (rejall) { L.stayed += 1; L.curcount += 1; }
+        else { L.chainind += 1; L.curcount = 1; }
+        if (E.updatesigma) {
+            double gm = rng_gamma(L.g, E.gam_shape, 2.0 / (E.N0S02 + L.ss1));
+            L.sigma2 = 1.0 / gm;
+        }
+        unsigned long long ballot = __ballot(!rejall);
+        const int slot = it % E.wcap;
+        if (E.hist) {
+            if (!rejall) {
+                double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64;
+                for (int k = 0; k < d; ++k) GV(h, k) = GV(theta_t, k);
+                GV(h, d) = L.ss1;
+            }
+            if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ballot;
+            if (E.record_s2) E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = L.sigma2;
+        }
+        if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
     } else if (PHASE == 3) {                                      // early rejection, first half (MCMC_run_er.F90:54-70)
         // the host has evaluated checkbounds and priorfun; draw the threshold, test the prior, leave sscrit for ssfunction_er
         const bool inb = GV(hev, HE_INB) != 0.0;

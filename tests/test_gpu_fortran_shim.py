@@ -337,3 +337,28 @@ def test_random_namelists_through_the_shim(oracle, seed):
     np.testing.assert_array_equal(chain, o.chain, err_msg=nml)
     if method != "ram":
         np.testing.assert_array_equal(np.triu(cov), np.triu(o.chaincmat), err_msg=nml)
+
+
+@pytest.mark.parametrize("method,extra", [("scam", ""), ("dram", " condmax = 1e10\n drscale = 2.0\n")])
+def test_user_program_with_the_svd_paths(oracle, method, extra):
+    """The unmodified user program (its own Fortran ssfunction / checkbounds on the host) with method = 'scam', and with
+    the SVD proposal factor (condmax > 0) plus delayed rejection: every componentwise proposal / every DR stage makes its
+    round trip to the user's functions, and the chain is the oracle's."""
+    exe = os.path.join(FDIR, "demo_user")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", FDIR])
+    z, _, _ = load("s4_expdata_scam_s2", oracle)
+    ckw = dict(nsimu=400, method=method, adaptint=100, updatesigma=1)
+    if method == "dram":
+        ckw.update(condmax=1e10, drscale=2.0)
+    pkw = dict(kind="expdata", npar=2, par0=[10, 0.1], cmat0=[[0.2, 0], [0, 0.001]], sigma2=0.5, nobs=11,
+               xdata=z["prob_xdata"], ydata=z["prob_ydata"], lo=[0, 0])
+    nml = "&mcmc\n method = '%s'\n nsimu = 400\n adaptint = 100\n updatesigma = 1\n%s/\n" % (method, extra)
+    with tempfile.TemporaryDirectory() as d:
+        _write_inputs(d, z, nml)
+        p = subprocess.run([exe], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, p.stdout.decode(errors="replace")
+        chain = np.loadtxt(os.path.join(d, "chain.dat"), ndmin=2)
+    o = oracle.run_chain(oracle.make_cfg(**ckw), oracle.Problem(**pkw), chain_id=0)
+    np.testing.assert_array_equal(chain[:, -1].astype(np.int32), o.chain[:, -1].astype(np.int32))
+    np.testing.assert_allclose(chain[:, :-1], o.chain[:, :-1], rtol=1e-8)

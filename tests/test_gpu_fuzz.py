@@ -123,16 +123,14 @@ def test_random_configuration_in_pieces(oracle, seed):
     e1.close(); e2.close()
 
 
-@pytest.mark.parametrize("seed", range(30))
+@pytest.mark.parametrize("seed", range(60))
 def test_random_configuration_host_callbacks(oracle, seed):
     """The same option space through the host-callback path (the user's ssfunction / priorfun / checkbounds /
     ssfunction_er): identical to the device-resident target."""
     import ctypes as C
     from mcmcf90_amd import Engine, make_config, engine_from_problem, McmcError
     ckw, pkw = _draw(9000 + seed)
-    if ckw["method"] == "scam" or ckw.get("condmax", 0.0) > 0.0:
-        pytest.skip("host callbacks are not available with the SVD paths")
-    ckw["nsimu"] = min(ckw["nsimu"], 120)
+    ckw["nsimu"] = min(ckw["nsimu"], 120 if ckw["method"] != "scam" else 40)
     prob = oracle.Problem(**pkw)
     L = oracle.lib()
     tgt = prob.ctarget()
