@@ -54,7 +54,7 @@ def alg_bytes_per_proposal(d, method):
     return base + (2 * tri if method == "ram" else tri)
 
 
-def cpu_baseline(ckw, pkw, per_it, label, target_seconds=12.0):
+def cpu_baseline(wl, ckw, pkw, per_it, label, target_seconds=12.0):
     """One chain of the same workload on one host core (the reference adapts its single chain on its own history)."""
     from oracle import pyoracle as po, refrun as rr
     prob = po.Problem(**pkw)
@@ -72,6 +72,7 @@ def cpu_baseline(ckw, pkw, per_it, label, target_seconds=12.0):
             cfg = po.make_cfg(**dict(ckw, nsimu=nsimu))
             t0 = time.perf_counter(); r = rr.run_reference(cfg, prob, timeout=300, pinned_svd=bool(cfg.usesvd)); t_ref = time.perf_counter() - t0
             o2 = po.run_chain(cfg, prob)             # same stream: its delayed-rejection count is the reference's
+            out["all_cores"] = cpu_all_cores(wl, ckw, per_it, port_rate)
             out.update(value=((nsimu - 1) * per_it + o2.drtries) / t_ref, kind="reference",
                        sample="mcmcf90 Fortran reference (flang -O2 + MKL, oracle/_ref/mcxref), 1 chain, %s, "
                               "nsimu=%d, wall time of the whole program incl. namelist/file I/O = %.2f s" % (label, nsimu, t_ref),
@@ -79,9 +80,40 @@ def cpu_baseline(ckw, pkw, per_it, label, target_seconds=12.0):
             return out
         except Exception as ex:                      # reference binary present but not runnable here
             out["reference_error"] = str(ex)[:200]
+    out["all_cores"] = cpu_all_cores(wl, ckw, per_it, port_rate)
     out.update(value=port_rate, kind="port",
                sample="C oracle (oracle/mcx_oracle.c, gcc -O2), 1 chain, %s, nsimu=%d, %.2f s" % (label, n_port, t_port))
     return out
+
+
+def cpu_all_cores(wl, ckw, per_it, port_rate, seconds=4.0):
+    """every host core runs one independent chain of the C restatement, each in a process of its
+    own (the reference is one chain per process; the port is what spreads over the cores without N copies of its file I/O)."""
+    import subprocess
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    avail = cores
+    cores = min(cores, 32)                            # bounded: the default bench run must stay within minutes
+    n = int(max(50, port_rate / per_it * seconds))
+    cmd = [sys.executable, "-m", "oracle.portrun", wl, str(n), str(ckw.get("adaptint", 100))]
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen(cmd + [str(1000 + c), ckw.get("method", "dram")], cwd=ROOT, stdout=subprocess.PIPE) for c in range(cores)]
+    tries = 0
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=90)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            return {"error": "the host did not finish %d port chains in 90 s (CPU quota?)" % cores}
+        if p.returncode != 0:
+            return {"error": "oracle.portrun failed"}
+        tries += int(out.decode().split()[-1])
+    dt = time.perf_counter() - t0
+    return {"value": (cores * (n - 1) * per_it + tries) / dt, "unit": "proposals/s", "cores": cores, "kind": "port",
+            "sample": "C oracle, %d independent chains, one process each (host CPUs in the affinity mask: %d, processes capped at 32), nsimu=%d each, %.2f s incl. process start" % (cores, avail, n, dt)}
 
 
 def main():
@@ -239,7 +271,7 @@ def main():
             "pooled_check": {"chains": cnt, "max_abs_mean": float(np.max(np.abs(mean)))},
         }
         if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(ckw, pkw, per_it, "d=%d %s" % (d, method))
+            line["cpu_baseline"] = cpu_baseline(wl, ckw, pkw, per_it, "d=%d %s" % (d, method))
         print(json.dumps(line), flush=True)
     eng.close()
     if world > 1:
