@@ -2,6 +2,7 @@
 import os
 import re
 import subprocess
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -35,3 +36,28 @@ def test_no_gpu_means_loud_failure_not_fallback():
         L.mcmcx_destroy(h)
         pytest.skip("a GPU is present")
     assert rc < 0 and b"no HIP device" in L.mcmcx_last_error()
+
+
+def test_header_is_plain_c_and_the_c_example_links():
+    """include/mcmcx.h must be usable from C (the reference's host language side binds a C ABI): compile the example
+    driver as pedantic C99 against it and link it with libmcmcx.so."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "c_driver")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"),
+           os.path.join(root, "examples", "c_driver.c"), "-L" + os.path.join(root, "mcmcf90_amd"), "-lmcmcx",
+           "-Wl,-rpath," + os.path.join(root, "mcmcf90_amd"), "-o", exe]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert p.returncode == 0, p.stdout.decode()
+
+
+@pytest.mark.gpu
+def test_c_example_runs():
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "c_driver")
+    if not os.path.exists(exe):
+        test_header_is_plain_c_and_the_c_example_links()
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and "simuind 2000" in out and "pooled mean over 256 chains" in out, out
