@@ -348,13 +348,13 @@ MCX_DEV void gemvN_panels(const double *Mt, const double *x_t, double *out_t, co
 #pragma unroll
         for (int u = 0; u < PW; ++u) y[u] = 0.0;
         if (act) {
-#pragma unroll 2
-            for (int j = 0; j < d; ++j) {
+#pragma unroll 4
+            for (int j = 0; j < d; ++j) {                          // the matrix is streamed (non-temporal), x stays cached
                 const double xj = GV(x_t, j);
                 const double *seg = Mt + ((size_t)j * d + I0) * 64;
                 double r[PW];
 #pragma unroll
-                for (int u = 0; u < PW; ++u) r[u] = GV(seg, u < nr ? u : nr - 1);
+                for (int u = 0; u < PW; ++u) r[u] = LDNT(seg, u < nr ? u : nr - 1);
 #pragma unroll
                 for (int u = 0; u < PW; ++u) y[u] = dfma(xj, r[u], y[u]);
             }
@@ -371,11 +371,12 @@ MCX_DEV void gemvT_panels(const double *Mt, const double *x_t, double *out_t, in
         double t[PW];
 #pragma unroll
         for (int u = 0; u < PW; ++u) t[u] = 0.0;
+#pragma unroll 4
         for (int i = 0; i < d; ++i) {
             const double xi = GV(x_t, i);
             double r[PW];
 #pragma unroll
-            for (int u = 0; u < PW; ++u) r[u] = GV(Mt, (size_t)(K0 + (u < nc ? u : nc - 1)) * d + i);
+            for (int u = 0; u < PW; ++u) r[u] = LDNT(Mt, (size_t)(K0 + (u < nc ? u : nc - 1)) * d + i);
 #pragma unroll
             for (int u = 0; u < PW; ++u) t[u] = dfma(r[u], xi, t[u]);
         }
