@@ -128,7 +128,8 @@ int mcmcx_get_accepted(mcmcx_handle h, int32_t chain, uint8_t *accepted);
 /* raw wavefront ballots: masks[(it-1)*ntiles + tile], bit l = chain tile*64+l moved at iteration it */
 int mcmcx_get_accept_masks(mcmcx_handle h, uint64_t *masks, int32_t *ntiles);
 /* run-length compressed chain of one chain, like chain(1:chainind,:) / sschain / s2chain
- * (needs record_chain).  chain: [nrows][npar+1] row-major; ss: [nrows][2]; s2: [simuind] */
+ * (needs record_chain).  chain: [nrows][npar+1] row-major; ss: [nrows][nycol+1] (ss per column, repeat count);
+ * s2: [simuind][nycol] */
 int mcmcx_get_chain(mcmcx_handle h, int32_t chain, double *chain_out, double *ss_out, double *s2_out,
                     int32_t *nrows);
 /* pooled moments of the current states of all chains of this device (shifted by par0):

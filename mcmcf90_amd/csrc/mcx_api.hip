@@ -38,6 +38,7 @@ struct mcmcx_engine {
     // host copies of the problem
     std::vector<double> par0, cmat0;                 // cmat0 col-major d*d
     double sigma2 = 1.0; int nobs = 1; bool sigma2ok = false;
+    int ny = 1; std::vector<double> sigma2v; std::vector<int> nobsv;      // nycol columns (host callbacks only when > 1)
     int tkind = -1; std::vector<double> tmu, tlam, tx, ty, tlo, thi, tpmu, tpsig; double tb = 0.1;
     bool has_lo = false, has_hi = false, has_pri = false;
     mcmcx_ssfun_t h_ss = nullptr; mcmcx_ssfun_er_t h_ss_er = nullptr; mcmcx_priorfun_t h_pri = nullptr; mcmcx_checkbounds_t h_cb = nullptr; void *h_user = nullptr;
@@ -424,7 +425,9 @@ static int host_eval(mcmcx_engine *h, const double *dev_src, int stride_k, bool 
     const int d = h->d, T = h->ntiles;
     const size_t L = (size_t)T * 64;
     h->h_cand.resize(L * stride_k);
-    h->h_ev.assign(L * NHE, 0.0);
+    const int ny = h->ny, nhe = NHE - 1 + ny;
+    h->h_ev.assign(L * nhe, 0.0);
+    std::vector<double> ssc(ny, 0.0);
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(h->h_cand.data(), dev_src, h->h_cand.size() * 8, hipMemcpyDeviceToHost));
     std::vector<double> hx;
@@ -435,21 +438,22 @@ static int host_eval(mcmcx_engine *h, const double *dev_src, int stride_k, bool 
         if (use_stage2_flag && hx[((size_t)t * NHX + HX_STAGE2) * 64 + l] == 0.0) continue;
         for (int k = 0; k < d; ++k) th[k] = h->h_cand[((size_t)t * stride_k + k) * 64 + l];
         int inb = 1;
-        double pri = 0.0, ss = 0.0;
+        double pri = 0.0;
+        std::fill(ssc.begin(), ssc.end(), 0.0);
         if (what == 2) {                                                             // MCMC_ssfunction_er(newpar, sscrit)
             const double crit = hx[((size_t)t * NHX + HX_CRIT) * 64 + l];
-            if (h->h_ss_er) h->h_ss_er(th.data(), d, 1, crit, &ss, h->h_user);
-            else h->h_ss(th.data(), d, 1, &ss, h->h_user);                           // ssfunction_er0.f90: no er for ss
+            if (h->h_ss_er) h->h_ss_er(th.data(), d, ny, crit, ssc.data(), h->h_user);
+            else h->h_ss(th.data(), d, ny, ssc.data(), h->h_user);                   // ssfunction_er0.f90: no er for ss
         } else {
             inb = h->h_cb ? h->h_cb(th.data(), d, h->h_user) : 1;                    // checkbounds0.f90: .true.
             if (inb) {                                                               // MCMC_run.F90:54-56: prior first
                 pri = h->h_pri ? h->h_pri(th.data(), d, h->h_user) : 0.0;
-                if (what == 0) h->h_ss(th.data(), d, 1, &ss, h->h_user);
+                if (what == 0) h->h_ss(th.data(), d, ny, ssc.data(), h->h_user);
             }
         }
-        h->h_ev[((size_t)t * NHE + HE_INB) * 64 + l] = inb ? 1.0 : 0.0;
-        h->h_ev[((size_t)t * NHE + HE_PRI) * 64 + l] = pri;
-        h->h_ev[((size_t)t * NHE + HE_SS) * 64 + l] = ss;
+        h->h_ev[((size_t)t * nhe + HE_INB) * 64 + l] = inb ? 1.0 : 0.0;
+        h->h_ev[((size_t)t * nhe + HE_PRI) * 64 + l] = pri;
+        for (int j = 0; j < ny; ++j) h->h_ev[((size_t)t * nhe + HE_SS + j) * 64 + l] = ssc[j];
     }
     HIPCHK(hipMemcpy(h->E.hev, h->h_ev.data(), h->h_ev.size() * 8, hipMemcpyHostToDevice));
     return 0;
@@ -600,7 +604,9 @@ int mcmcx_set_cmat0(mcmcx_handle h, const double *c, int32_t n)
 int mcmcx_set_sigma2nobs(mcmcx_handle h, const double *s2, const int32_t *nobs, int32_t nycol)
 {
     if (!h || !s2 || !nobs) return fail(-1, "null argument");
-    if (nycol != 1) return fail(-21, "the device engine supports nycol = 1 only");
+    if (nycol < 1 || nycol > 8) return fail(-21, "nycol must be in 1..8");
+    if (h->inited) return fail(-20, "set sigma2 / nobs before mcmcx_init");
+    h->ny = nycol; h->sigma2v.assign(s2, s2 + nycol); h->nobsv.assign(nobs, nobs + nycol);
     h->sigma2 = s2[0]; h->nobs = nobs[0]; h->sigma2ok = true;
     return 0;
 }
@@ -666,7 +672,11 @@ int mcmcx_init(mcmcx_handle h)
         h->cmat0.assign((size_t)d * d, 0.0);
         for (int i = 0; i < d; ++i) h->cmat0[(size_t)i * d + i] = 1.0;
     }
-    if (!h->sigma2ok) { h->sigma2 = 1.0; h->nobs = 1; }                               // MCMC_init.F90:52-59
+    if (!h->sigma2ok) { h->sigma2 = 1.0; h->nobs = 1; h->ny = 1; }                    // MCMC_init.F90:52-59
+    if (h->ny == 1) { h->sigma2v.assign(1, h->sigma2); h->nobsv.assign(1, h->nobs); }
+    const int ny = h->ny;
+    if (ny > 1 && h->tkind != TGT_HOST) return fail(-36, "nycol > 1 needs the host-callback target (the built-in targets have one response column)");
+    if (ny > 1 && h->pooled) return fail(-36, "nycol > 1 is not available in pooled mode");
     if (h->tkind < 0) return fail(-31, "no target: the device engine needs mcmcx_set_target_*");
     if (h->dodr && lds_bytes(h) > 160 * 1024) return fail(-35, "delayed rejection keeps two npar-vectors per chain in LDS: npar <= 160 with drscale > 0");
     std::vector<double> Rp, Cp, Rfull, qstd0;
@@ -688,6 +698,9 @@ int mcmcx_init(mcmcx_handle h)
     E.greedy = c.greedy; E.adapthist = c.adapthist; E.initcmatn = (double)c.initcmatn;
     E.dodr = h->dodr; E.updatesigma = c.updatesigma; E.doadapt = c.doadapt; E.doburnin = c.doburnin; E.burnintime = c.burnintime;
     E.gam_shape = shape; E.N0S02 = c.N0 * h->S02eff;
+    if (c.updatesigma) for (int j = 0; j < ny; ++j) if (c.N0 / 2.0 + (double)h->nobsv[j] / 2.0 < 1.0)
+        return fail(-33, "updatesigma with gamma shape < 1 is not available in the device engine");
+    E.ny = ny; E.hs = d + ny; E.ssv = E.s2v = E.ss2v = nullptr; E.gshapev = nullptr;
     E.alphatarget = c.alphatarget; E.drscale = c.drscale; E.scalelimit = c.scalelimit; E.scalefactor = c.scalefactor;
     E.k0 = c.seed; E.chain_id0 = c.chain_id0;
     // target
@@ -755,9 +768,9 @@ int mcmcx_init(mcmcx_handle h)
                                       : (long long)c.burnintime + c.adaptint + c.adapthist + 2;
         if (wc > (long long)c.nsimu + 1) wc = (long long)c.nsimu + 1;
         h->wcap = (int)wc;
-        if ((rc = dev_alloc(h, &E.hist, L * (size_t)h->wcap * (d + 1), false))) return rc;
+        if ((rc = dev_alloc(h, &E.hist, L * (size_t)h->wcap * (d + ny), false))) return rc;
         if ((rc = dev_alloc(h, &E.wacc, (size_t)T * h->wcap))) return rc;
-        if (c.record_chain && c.updatesigma) { E.record_s2 = 1; if ((rc = dev_alloc(h, &E.s2hist, L * (size_t)h->wcap))) return rc; }
+        if (c.record_chain && c.updatesigma) { E.record_s2 = 1; if ((rc = dev_alloc(h, &E.s2hist, L * (size_t)h->wcap * ny))) return rc; }
     }
     E.wcap = h->wcap > 0 ? h->wcap : 1;
     if (am) {
@@ -781,7 +794,16 @@ int mcmcx_init(mcmcx_handle h)
     }
     E.hev = E.hx = nullptr;
     if (h->tkind == TGT_HOST) {
-        if ((rc = dev_alloc(h, &E.hev, L * NHE))) return rc;
+        if ((rc = dev_alloc(h, &E.hev, L * (NHE - 1 + ny)))) return rc;
+        if (ny > 1) {
+            if ((rc = dev_alloc(h, &E.ssv, L * ny))) return rc;
+            if ((rc = dev_alloc(h, &E.s2v, L * ny))) return rc;
+            if ((rc = dev_alloc(h, &E.ss2v, L * ny))) return rc;
+            if ((rc = dev_bcast(h, E.s2v, h->sigma2v))) return rc;
+            std::vector<double> gs(ny);
+            for (int j = 0; j < ny; ++j) gs[j] = c.N0 / 2.0 + (double)h->nobsv[j] / 2.0;
+            if ((rc = dev_upload(h, &E.gshapev, gs))) return rc;
+        }
         if ((rc = dev_alloc(h, &E.hx, L * NHX))) return rc;
     }
     E.accmask = nullptr;
@@ -1099,27 +1121,28 @@ int mcmcx_get_chain(mcmcx_handle h, int32_t chain, double *chain_out, double *ss
         return 0;
     };
     std::vector<double> hv;
-    if ((rc = gather(h->E.hist + (size_t)tile * W * (d + 1) * 64, (size_t)W * (d + 1), hv))) return rc;
+    const int ny = h->ny, hs = d + ny;                  // history row: theta, ss per column
+    if ((rc = gather(h->E.hist + (size_t)tile * W * hs * 64, (size_t)W * hs, hv))) return rc;
     int row = -1;
     for (int it = 1; it <= h->simuind; ++it) {
-        const size_t so = (size_t)(it % W) * (d + 1);
+        const size_t so = (size_t)(it % W) * hs;
         if ((m[it % W] >> lane) & 1ull) {
             ++row;
             if (chain_out) {
                 for (int k = 0; k < d; ++k) chain_out[(size_t)row * (d + 1) + k] = hv[so + k];
                 chain_out[(size_t)row * (d + 1) + d] = 1.0;
             }
-            if (ss_out) { ss_out[(size_t)row * 2] = hv[so + d]; ss_out[(size_t)row * 2 + 1] = 1.0; }
+            if (ss_out) { for (int j = 0; j < ny; ++j) ss_out[(size_t)row * (ny + 1) + j] = hv[so + d + j]; ss_out[(size_t)row * (ny + 1) + ny] = 1.0; }
         } else {
             if (chain_out) chain_out[(size_t)row * (d + 1) + d] += 1.0;
-            if (ss_out) ss_out[(size_t)row * 2 + 1] += 1.0;
+            if (ss_out) ss_out[(size_t)row * (ny + 1) + ny] += 1.0;
         }
     }
     if (nrows) *nrows = row + 1;
     if (s2_out && h->E.s2hist) {
         std::vector<double> sv;
-        if ((rc = gather(h->E.s2hist + (size_t)tile * W * 64, (size_t)W, sv))) return rc;
-        for (int it = 1; it <= h->simuind; ++it) s2_out[it - 1] = sv[(size_t)(it % W)];
+        if ((rc = gather(h->E.s2hist + (size_t)tile * W * ny * 64, (size_t)W * ny, sv))) return rc;
+        for (int it = 1; it <= h->simuind; ++it) for (int j = 0; j < ny; ++j) s2_out[(size_t)(it - 1) * ny + j] = sv[(size_t)(it % W) * ny + j];
     }
     return 0;
 }

@@ -64,6 +64,12 @@ struct EngineDev {
     double *Rf, *R2f, *qstd, *Gw, *Vw;
     // host-callback targets: per-chain evaluation results (inbounds, prior, ss) and state carried between phases
     double *hev, *hx;
+    // response columns (nycol, mcmc.F90:30-33): ny > 1 only with host callbacks.  hs = d + ny doubles per history row
+    // (theta, then ss per column); hev holds ny ss values per chain; per-chain vectors ssv (current ss), s2v (sigma2),
+    // ss2v (first-stage ss kept for the DR formulas), gshapev[ny] = N0/2 + nobs(j)/2 (shared)
+    int ny, hs;
+    double *ssv, *s2v, *ss2v;
+    const double *gshapev;
 };
 
 #define TIDX(base, tile, K, k, lane) ((base)[((size_t)(tile) * (size_t)(K) + (size_t)(k)) * 64 + (lane)])
@@ -795,7 +801,7 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
         unsigned long long ballot = __ballot(!reject);
         const int slot = it % E.wcap;
         if (!reject) {
-            double *h = E.hist ? E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64 : nullptr;
+            double *h = E.hist ? E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64 : nullptr;
             const double *src = dr_moved ? c2_t : cand_t;     // newpar = newpar2 when the DR try was accepted
 #pragma unroll 4
             for (int k = 0; k < d; ++k) {
@@ -922,7 +928,7 @@ __global__ __launch_bounds__(64, 2) void scam_kernel(EngineDev E, int it0, int i
         const int slot = it % E.wcap;
         if (E.hist) {
             if (!rejall) {
-                double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64;
+                double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64;
                 for (int k = 0; k < d; ++k) GV(h, k) = GV(theta_t, k);
                 GV(h, d) = L.ss1;
             }
@@ -1150,7 +1156,7 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
             const int slot = it % E.wcap;
             if (E.hist) {
                 if (!rejall) {
-                    double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64;
+                    double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64;
                     for (int k = 0; k < d; ++k) GV(h, k) = GV(theta_t, k);
                     GV(h, d) = L.ss1;
                 }
@@ -1316,7 +1322,7 @@ __global__ __launch_bounds__(64) void pooled_mfma_kernel(EngineDev E, int it0, i
         unsigned long long ballot = __ballot(!reject);
         const int slot = it % E.wcap;
         if (!reject) {
-            double *h = E.hist ? E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64 : nullptr;
+            double *h = E.hist ? E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64 : nullptr;
 #pragma unroll 4
             for (int k = 0; k < d; ++k) { double v = GV(cand_t, k); GV(theta_t, k) = v; if (h) GV(h, k) = v; }
             if (h) GV(h, d) = L.ss1;
@@ -1330,32 +1336,67 @@ __global__ __launch_bounds__(64) void pooled_mfma_kernel(EngineDev E, int it0, i
     lane_store(E, tile, lane, L);
 }
 
-// end of an iteration: MCMC_run.F90:93-105 / MCMC_run_ram.F90:66-78
-MCX_DEV void host_finish(const EngineDev &E, int tile, int lane, int it, LaneState &L, bool reject, bool dr_moved,
-                         double ss2, double pri2, const double *ramscale)
+// ---------------------------------------------------------------- nycol > 1: sums over the response columns
+// sum((a - b)/sigma2) and friends reduce from 0 in column order, like the reference's array expressions
+// (MCMC_DRAM.F90:111, 129, 176-179); a, b, s2 are per-chain vectors (element j at GV(p, j)).
+MCX_DEV double colsum_diff(const double *a, const double *b, const double *s2, int ny, int lane)
 {
-    const int d = E.d;
+    double s = 0.0;
+    for (int j = 0; j < ny; ++j) s = s + (GV(a, j) - GV(b, j)) / GV(s2, j);
+    return s;
+}
+MCX_DEV double d_alpha_cols(const double *ss1, double pri1, const double *ss2, double pri2, const double *s2, int ny, int lane)
+{
+    double tst = -0.5 * (colsum_diff(ss2, ss1, s2, ny, lane) + (pri2 - pri1));
+    double a;
+    if (tst >= 0.0) a = 1.0;
+    else if (tst < -708.39641853226408) a = 0.0;
+    else a = d_exp(tst);
+    return a;
+}
+
+// end of an iteration: MCMC_run.F90:93-105 / MCMC_run_ram.F90:66-78
+// ss2cols: with nycol > 1 the accepted point's ss per column (a per-chain vector); nullptr = the scalar ss2
+MCX_DEV void host_finish(const EngineDev &E, int tile, int lane, int it, LaneState &L, bool reject, bool dr_moved,
+                         double ss2, double pri2, const double *ramscale, const double *ss2cols = nullptr)
+{
+    const int d = E.d, ny = E.ny;
+    double *ssv = ny > 1 ? E.ssv + (size_t)tile * ny * 64 : nullptr, *s2v = ny > 1 ? E.s2v + (size_t)tile * ny * 64 : nullptr;
     double *theta_t = E.theta + (size_t)tile * d * 64;
     double *cand_t = E.cand + (size_t)tile * d * 64;
     double *zs_t = E.zs + (size_t)tile * 2 * d * 64;
     double *cs_t = E.cs + (size_t)tile * 2 * d * 64;
     if (reject) { L.stayed += 1; L.curcount += 1; }
-    else { L.ss1 = ss2; L.pri1 = pri2; L.chainind += 1; L.curcount = 1; }
-    if (E.updatesigma) {
-        double gm = rng_gamma(L.g, E.gam_shape, 2.0 / (E.N0S02 + L.ss1));
-        L.sigma2 = 1.0 / gm;
+    else {
+        if (ny > 1) { for (int j = 0; j < ny; ++j) GV(ssv, j) = GV(ss2cols, j); ss2 = GV(ssv, 0); }
+        L.ss1 = ss2; L.pri1 = pri2; L.chainind += 1; L.curcount = 1;
+    }
+    if (E.updatesigma) {                                // MCMC_updatesigma2: one gamma draw per column, in column order
+        if (ny > 1) {
+            for (int j = 0; j < ny; ++j) {
+                double gm = rng_gamma(L.g, E.gshapev[j], 2.0 / (E.N0S02 + GV(ssv, j)));
+                GV(s2v, j) = 1.0 / gm;
+            }
+            L.sigma2 = GV(s2v, 0);
+        } else {
+            double gm = rng_gamma(L.g, E.gam_shape, 2.0 / (E.N0S02 + L.ss1));
+            L.sigma2 = 1.0 / gm;
+        }
     }
     unsigned long long ballot = __ballot(!reject);
     const int slot = it % E.wcap;
     if (!reject) {
-        double *h = E.hist ? E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64 : nullptr;
+        double *h = E.hist ? E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64 : nullptr;
         const double *src = dr_moved ? cs_t : cand_t;
         for (int k = 0; k < d; ++k) { double v = GV(src, k); GV(theta_t, k) = v; if (h) GV(h, k) = v; }
-        if (h) GV(h, d) = L.ss1;
+        if (h) { GV(h, d) = L.ss1; for (int j = 1; j < ny; ++j) GV(h, d + j) = GV(ssv, j); }
     }
     if (E.hist) {
         if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ballot;
-        if (E.record_s2) E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = L.sigma2;
+        if (E.record_s2) {
+            if (ny > 1) { for (int j = 0; j < ny; ++j) E.s2hist[(((size_t)tile * E.wcap + slot) * ny + j) * 64 + lane] = GV(s2v, j); }
+            else E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = L.sigma2;
+        }
     }
     if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
     if (E.method == M_RAM && E.doadapt != 0 && !(it < E.burnintime && E.doburnin != 0)) {
@@ -1374,9 +1415,13 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
     double *cand_t = E.cand + (size_t)tile * d * 64;
     double *zs_t = E.zs + (size_t)tile * 2 * d * 64;           // host mode: first half = stage-1 z, second half = stage-2 z
     double *c2_t = E.cs + (size_t)tile * 2 * d * 64;
-    double *hev = E.hev + (size_t)tile * NHE * 64;
+    const int ny = E.ny;
+    double *hev = E.hev + (size_t)tile * (NHE - 1 + ny) * 64;    // inbounds, prior, ss per column
     double *hx = E.hx + (size_t)tile * NHX * 64;
     double *Y = X + (size_t)d * 64;
+    double *ssv = ny > 1 ? E.ssv + (size_t)tile * ny * 64 : nullptr, *s2v = ny > 1 ? E.s2v + (size_t)tile * ny * 64 : nullptr;
+    double *ss2v = ny > 1 ? E.ss2v + (size_t)tile * ny * 64 : nullptr;
+    const double *sshev = hev + (size_t)HE_SS * 64;              // the host's ss columns of the point just evaluated
     LaneState L;
     lane_load(E, tile, lane, L);
     if (PHASE == 0) {                                             // newpar = MCMC_propose(oldpar, R)
@@ -1393,7 +1438,7 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
             reject = true;
             if (E.method != M_RAM) L.alpha12 = 0.0;
         } else {
-            L.alpha12 = d_alpha(L.ss1, L.pri1, ss2, pri2, L.sigma2);
+            L.alpha12 = ny > 1 ? d_alpha_cols(ssv, L.pri1, sshev, pri2, s2v, ny, lane) : d_alpha(L.ss1, L.pri1, ss2, pri2, L.sigma2);
             reject = true;
             if (L.alpha12 >= 1.0) reject = false;
             else if (L.alpha12 > 0.0) { double u = rng_uniform(L.g); if (u <= L.alpha12) reject = false; }
@@ -1401,13 +1446,14 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
         if (E.dodr) {
             const bool m = reject;
             if (m) L.drtries += 1;
+            for (int j = 0; j < (ny > 1 ? ny : 0); ++j) GV(ss2v, j) = GV(sshev, j);
             gen_normals(L.g, zs_t + (size_t)d * 64, lane, d, m);
             if (E.usesvd) gemvN_panels(E.R2f + (size_t)tile * d * d * 64, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d, m);
             else trmv_panels(E.R2 + (size_t)tile * E.P * 64, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d, m);
             GV(hx, HX_SS2) = ss2; GV(hx, HX_PRI2) = pri2;
             GV(hx, HX_REJECT) = reject ? 1.0 : 0.0; GV(hx, HX_STAGE2) = m ? 1.0 : 0.0;
         } else {
-            host_finish(E, tile, lane, it, L, reject, false, ss2, pri2, ramscale);
+            host_finish(E, tile, lane, it, L, reject, false, ss2, pri2, ramscale, sshev);
         }
     } else if (PHASE == 5) {                                      // SCAM sub-step aux: propose (MCMC_run_scam.F90:94-117)
         const int j = aux;
@@ -1424,12 +1470,13 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
         bool reject;
         if (!inb) { L.bnd += 1; L.alpha12 = 0.0; reject = true; }
         else {
-            L.alpha12 = d_alpha(L.ss1, L.pri1, ss2, pri2, L.sigma2);
+            L.alpha12 = ny > 1 ? d_alpha_cols(ssv, L.pri1, sshev, pri2, s2v, ny, lane) : d_alpha(L.ss1, L.pri1, ss2, pri2, L.sigma2);
             reject = true;
             if (L.alpha12 >= 1.0) reject = false;
             else if (L.alpha12 > 0.0) { double u = rng_uniform(L.g); if (u <= L.alpha12) reject = false; }
         }
         if (!reject) {
+            for (int j = 0; j < (ny > 1 ? ny : 0); ++j) GV(ssv, j) = GV(sshev, j);
             L.ss1 = ss2; L.pri1 = pri2; GV(hx, HX_MOVED) = 1.0;
             for (int k = 0; k < d; ++k) GV(theta_t, k) = GV(cand_t, k);
         }
@@ -1438,19 +1485,28 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
         if (rejall) { L.stayed += 1; L.curcount += 1; }
         else { L.chainind += 1; L.curcount = 1; }
         if (E.updatesigma) {
-            double gm = rng_gamma(L.g, E.gam_shape, 2.0 / (E.N0S02 + L.ss1));
-            L.sigma2 = 1.0 / gm;
+            if (ny > 1) {
+                for (int j = 0; j < ny; ++j) { double gm = rng_gamma(L.g, E.gshapev[j], 2.0 / (E.N0S02 + GV(ssv, j))); GV(s2v, j) = 1.0 / gm; }
+                L.sigma2 = GV(s2v, 0);
+            } else {
+                double gm = rng_gamma(L.g, E.gam_shape, 2.0 / (E.N0S02 + L.ss1));
+                L.sigma2 = 1.0 / gm;
+            }
         }
         unsigned long long ballot = __ballot(!rejall);
         const int slot = it % E.wcap;
         if (E.hist) {
             if (!rejall) {
-                double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64;
+                double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64;
                 for (int k = 0; k < d; ++k) GV(h, k) = GV(theta_t, k);
                 GV(h, d) = L.ss1;
+                for (int j = 1; j < ny; ++j) GV(h, d + j) = GV(ssv, j);
             }
             if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ballot;
-            if (E.record_s2) E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = L.sigma2;
+            if (E.record_s2) {
+                if (ny > 1) { for (int j = 0; j < ny; ++j) E.s2hist[(((size_t)tile * E.wcap + slot) * ny + j) * 64 + lane] = GV(s2v, j); }
+                else E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = L.sigma2;
+            }
         }
         if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
     } else if (PHASE == 3) {                                      // early rejection, first half (MCMC_run_er.F90:54-70)
@@ -1462,9 +1518,11 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
         if (!inb) { L.bnd += 1; reject = true; }
         else {
             double u = rng_uniform(L.g);                          // MCMC_sscrit, MCMC_DRAM.F90:124-135: always drawn
-            double sscrit = -2.0 * d_log(u) + L.ss1 / L.sigma2 + L.pri1;
+            double s1 = L.ss1 / L.sigma2;
+            if (ny > 1) { s1 = 0.0; for (int j = 0; j < ny; ++j) s1 = s1 + GV(ssv, j) / GV(s2v, j); }      // sum(ss1/sigma2)
+            double sscrit = -2.0 * d_log(u) + s1 + L.pri1;
             if (pri2 >= sscrit) { reject = true; TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane) += 1; }
-            else { crit = L.sigma2 * (sscrit - pri2); need = true; }
+            else { crit = L.sigma2 * (sscrit - pri2); need = true; }    // sigma2(1): MCMC_run_er.F90:72
         }
         GV(hx, HX_PRI2) = pri2; GV(hx, HX_CRIT) = crit;
         GV(hx, HX_REJECT) = reject ? 1.0 : 0.0; GV(hx, HX_STAGE2) = need ? 1.0 : 0.0;
@@ -1472,8 +1530,13 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
         bool reject = GV(hx, HX_REJECT) != 0.0;
         const double pri2 = GV(hx, HX_PRI2);
         double ss2 = 0.0;
-        if (GV(hx, HX_STAGE2) != 0.0) { ss2 = GV(hev, HE_SS); reject = (ss2 >= GV(hx, HX_CRIT)); }
-        host_finish(E, tile, lane, it, L, reject, false, ss2, pri2, ramscale);
+        if (GV(hx, HX_STAGE2) != 0.0) {
+            ss2 = GV(hev, HE_SS);
+            double tot = ss2;
+            if (ny > 1) { tot = 0.0; for (int j = 0; j < ny; ++j) tot = tot + GV(sshev, j); }                 // sum(ss2)
+            reject = (tot >= GV(hx, HX_CRIT));
+        }
+        host_finish(E, tile, lane, it, L, reject, false, ss2, pri2, ramscale, sshev);
     } else {                                                      // PHASE 2: decide the DR try, finish
         bool reject = GV(hx, HX_REJECT) != 0.0;
         double ss2 = GV(hx, HX_SS2), pri2 = GV(hx, HX_PRI2);
@@ -1483,10 +1546,16 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
             if (!inb2) L.bnd += 1;
             else {
                 const double pri3 = GV(hev, HE_PRI), ss3 = GV(hev, HE_SS);
-                double alpha32;
-                if (L.alpha12 == 0.0) alpha32 = 0.0;
-                else alpha32 = min1(d_exp(-0.5 * ((ss2 - ss3) / L.sigma2 + (pri2 - pri3))));
-                double l2 = -0.5 * ((ss3 - L.ss1) / L.sigma2 + (pri3 - L.pri1));
+                double alpha32, l2;
+                if (ny > 1) {
+                    if (L.alpha12 == 0.0) alpha32 = 0.0;
+                    else alpha32 = min1(d_exp(-0.5 * (colsum_diff(ss2v, sshev, s2v, ny, lane) + (pri2 - pri3))));
+                    l2 = -0.5 * (colsum_diff(sshev, ssv, s2v, ny, lane) + (pri3 - L.pri1));
+                } else {
+                    if (L.alpha12 == 0.0) alpha32 = 0.0;
+                    else alpha32 = min1(d_exp(-0.5 * ((ss2 - ss3) / L.sigma2 + (pri2 - pri3))));
+                    l2 = -0.5 * ((ss3 - L.ss1) / L.sigma2 + (pri3 - L.pri1));
+                }
                 const double *iCt = E.iC + (size_t)tile * E.P * 64;
                 for (int k = 0; k < d; ++k) XL(k) = GV(c2_t, k) - GV(cand_t, k);
                 double qa = quadform_sym(iCt, lane, d, X, Y);
@@ -1500,7 +1569,7 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
                 if (!rej2) { L.dracc += 1; reject = false; dr_moved = true; ss2 = ss3; pri2 = pri3; }
             }
         }
-        host_finish(E, tile, lane, it, L, reject, dr_moved, ss2, pri2, ramscale);
+        host_finish(E, tile, lane, it, L, reject, dr_moved, ss2, pri2, ramscale, dr_moved ? sshev : ss2v);
     }
     lane_store(E, tile, lane, L);
 }
@@ -1518,17 +1587,26 @@ __global__ __launch_bounds__(64) void init_kernel(EngineDev E)
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
     double *theta_t = E.theta + (size_t)tile * d * 64;
     double pri1, ss1;
-    if (E.tgt.kind == TGT_HOST) { const double *hev = E.hev + (size_t)tile * NHE * 64; pri1 = GV(hev, HE_PRI); ss1 = GV(hev, HE_SS); }
+    const int ny = E.ny;
+    if (E.tgt.kind == TGT_HOST) {
+        const double *hev = E.hev + (size_t)tile * (NHE - 1 + ny) * 64;
+        pri1 = GV(hev, HE_PRI); ss1 = GV(hev, HE_SS);
+        for (int j = 0; j < (ny > 1 ? ny : 0); ++j) TIDX(E.ssv, tile, ny, j, lane) = GV(hev, HE_SS + j);
+    }
     else { pri1 = target_prior(E.tgt, d, lane, theta_t); ss1 = target_ss<false>(E.tgt, d, lane, theta_t, E.tgt.mu, E.tgt.lamT); }
     TIDX(E.scal, tile, NSCAL, S_SS1, lane) = ss1; TIDX(E.scal, tile, NSCAL, S_PRI1, lane) = pri1;
     // row 1 of the chain: iteration 1 counts as accepted
     const int slot = 1 % E.wcap;
     if (E.hist) {
-        double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)(d + 1) * 64;
+        double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64;
         for (int k = 0; k < d; ++k) GV(h, k) = GV(theta_t, k);
         GV(h, d) = ss1;
+        for (int j = 1; j < ny; ++j) GV(h, d + j) = TIDX(E.ssv, tile, ny, j, lane);
         if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ~0ull;
-        if (E.record_s2) E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = TIDX(E.scal, tile, NSCAL, S_SIGMA2, lane);
+        if (E.record_s2) {
+            if (ny > 1) { for (int j = 0; j < ny; ++j) E.s2hist[(((size_t)tile * E.wcap + slot) * ny + j) * 64 + lane] = TIDX(E.s2v, tile, ny, j, lane); }
+            else E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = TIDX(E.scal, tile, NSCAL, S_SIGMA2, lane);
+        }
     }
     if (E.accmask && lane == 0) E.accmask[tile] = ~0ull;
     for (int k = 0; k < d; ++k) TIDX(E.basetheta, tile, d, k, lane) = GV(theta_t, k);
@@ -1680,7 +1758,7 @@ MCX_DEV void covmat_rows(const EngineDev &E, int tile, int lane, const uint64_t 
     int nrmax = act ? nr : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { int other = __shfl_xor(nrmax, o); nrmax = other > nrmax ? other : nrmax; }
-    const double *hist_t = E.hist + (size_t)tile * E.wcap * (size_t)(d + 1) * 64;
+    const double *hist_t = E.hist + (size_t)tile * E.wcap * (size_t)E.hs * 64;
     const bool upd = act && update && (wsum > 0.0);
     const bool bat = act && !upd;
     if (__any(upd)) {
@@ -1690,7 +1768,7 @@ MCX_DEV void covmat_rows(const EngineDev &E, int tile, int lane, const uint64_t 
             uint32_t slot = (uint32_t)e; double w3 = (double)(uint32_t)(e >> 32);
             if (on) {
                 const bool isbase = (slot == 0xffffffffu);
-                const size_t so = isbase ? 0 : (size_t)slot * (size_t)(d + 1) * 64;
+                const size_t so = isbase ? 0 : (size_t)slot * (size_t)E.hs * 64;
                 for (int k = 0; k < d; ++k) {
                     double xv = isbase ? GV(base_t, k) : hist_t[so + (size_t)k * 64 + lane];
                     XL(k) = xv - GV(mean_t, k);
@@ -1732,7 +1810,7 @@ MCX_DEV void covmat_rows(const EngineDev &E, int tile, int lane, const uint64_t 
             uint32_t slot = (uint32_t)e; double w = (double)(uint32_t)(e >> 32);
             if (on) {
                 const bool isbase = (slot == 0xffffffffu);
-                const size_t so = isbase ? 0 : (size_t)slot * (size_t)(d + 1) * 64;
+                const size_t so = isbase ? 0 : (size_t)slot * (size_t)E.hs * 64;
                 for (int k = 0; k < d; ++k) {
                     double xv = isbase ? GV(base_t, k) : hist_t[so + (size_t)k * 64 + lane];
                     GV(m2_t, k) = GV(m2_t, k) + xv * w;
@@ -1749,7 +1827,7 @@ MCX_DEV void covmat_rows(const EngineDev &E, int tile, int lane, const uint64_t 
             uint32_t slot = (uint32_t)e; double w = (double)(uint32_t)(e >> 32);
             if (on) {
                 const bool isbase = (slot == 0xffffffffu);
-                const size_t so = isbase ? 0 : (size_t)slot * (size_t)(d + 1) * 64;
+                const size_t so = isbase ? 0 : (size_t)slot * (size_t)E.hs * 64;
                 for (int k = 0; k < d; ++k) {
                     double xv = isbase ? GV(base_t, k) : hist_t[so + (size_t)k * 64 + lane];
                     XL(k) = xv - GV(m2_t, k);
@@ -1795,7 +1873,7 @@ MCX_DEV void covmat_window_blocked(const EngineDev &E, int tile, int lane, bool 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { int other = __shfl_xor(t0, o); t0 = other < t0 ? other : t0; }
     if (t0 == 0x7fffffff) return;
-    const double *hist_t = E.hist + (size_t)tile * E.wcap * (size_t)(d + 1) * 64;
+    const double *hist_t = E.hist + (size_t)tile * E.wcap * (size_t)E.hs * 64;
     const unsigned long long *wacc_t = (const unsigned long long *)E.wacc + (size_t)tile * E.wcap;
     double Wend = wsum;
     for (int a0 = 0; a0 < d; a0 += 8) {
@@ -1855,7 +1933,7 @@ MCX_DEV void covmat_window_blocked(const EngineDev &E, int tile, int lane, bool 
                         const bool fl = acc && have;
                         if (__any(fl)) fold(fl, unit ? 1.0 : (double)(cnt - adj));
                         if (acc) {
-                            const size_t so = (size_t)slot * (size_t)(d + 1) * 64;
+                            const size_t so = (size_t)slot * (size_t)E.hs * 64;
 #pragma unroll
                             for (int u = 0; u < 8; ++u) {
                                 const int a = (a0 + u < d) ? a0 + u : d - 1, b = (b0 + u < d) ? b0 + u : d - 1;

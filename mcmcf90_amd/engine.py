@@ -72,8 +72,11 @@ class Engine:
         self._chk(self.L.mcmcx_set_cmat0(self.h, a.ctypes.data_as(C.POINTER(C.c_double)), a.shape[0]))
 
     def setsigma2nobs(self, sigma2, nobs):
-        s = _f64([sigma2]); n = np.asarray([nobs], dtype=np.int32)
-        self._chk(self.L.mcmcx_set_sigma2nobs(self.h, _dp(s), n.ctypes.data_as(C.POINTER(C.c_int32)), 1))
+        """Scalars, or vectors of length nycol (one error variance per response column of ssfunction)."""
+        s = _f64(np.atleast_1d(sigma2)); n = np.ascontiguousarray(np.atleast_1d(nobs), dtype=np.int32)
+        assert len(s) == len(n)
+        self.nycol = len(s)
+        self._chk(self.L.mcmcx_set_sigma2nobs(self.h, _dp(s), n.ctypes.data_as(C.POINTER(C.c_int32)), len(s)))
 
     # --- the device-resident user callbacks
     def set_target(self, kind, mu=None, lam=None, b=0.1, xdata=None, ydata=None):
@@ -94,7 +97,9 @@ class Engine:
         n = self.npar
 
         def _ss(th, npar, ny, out, user):
-            out[0] = float(ssfun(np.ctypeslib.as_array(th, shape=(n,)).copy()))
+            v = np.atleast_1d(ssfun(np.ctypeslib.as_array(th, shape=(n,)).copy()))
+            for j in range(ny):
+                out[j] = float(v[j])
 
         def _pri(th, npar, user):
             return float(priorfun(np.ctypeslib.as_array(th, shape=(n,)).copy()))
@@ -107,7 +112,9 @@ class Engine:
         self._chk(self.L.mcmcx_set_target_host(self.h, self._cb_keep[0], self._cb_keep[1], self._cb_keep[2], None))
         if ssfun_er is not None:
             def _ss_er(th, npar, ny, crit, out, user):
-                out[0] = float(ssfun_er(np.ctypeslib.as_array(th, shape=(n,)).copy(), crit))
+                v = np.atleast_1d(ssfun_er(np.ctypeslib.as_array(th, shape=(n,)).copy(), crit))
+                for j in range(ny):
+                    out[j] = float(v[j])
             self._er_keep = _lib.SSFUN_ER_T(_ss_er)
             self._chk(self.L.mcmcx_set_target_host_er(self.h, self._er_keep))
 
@@ -198,10 +205,10 @@ class Engine:
         return a
 
     def chain(self, chain=0):
-        n = self.simuind
-        ch = np.zeros((n, self.npar + 1)); ss = np.zeros((n, 2)); s2 = np.zeros(n); nr = C.c_int32()
+        n, ny = self.simuind, getattr(self, "nycol", 1)
+        ch = np.zeros((n, self.npar + 1)); ss = np.zeros((n, ny + 1)); s2 = np.zeros((n, ny)); nr = C.c_int32()
         self._chk(self.L.mcmcx_get_chain(self.h, chain, _dp(ch), _dp(ss), _dp(s2), C.byref(nr)))
-        return ch[:nr.value], ss[:nr.value], s2
+        return ch[:nr.value], ss[:nr.value], (s2[:, 0] if ny == 1 else s2)
 
     def pooled_moments(self):
         n = self.L.mcmcx_pooled_moments_len(self.h)

@@ -81,6 +81,11 @@ double mcxo_ssfun(const mcxo_target *t, const double *th)
     }
     return NAN;
 }
+void mcxo_ssfun_cols(const mcxo_target *t, const double *th, double *ss)
+{
+    if (t->ny > 1) mcxt_ss_expdata_cols(th, t->ndata, t->xdata, t->ydata, t->ny, ss);    /* the one multi-column target */
+    else ss[0] = mcxo_ssfun(t, th);
+}
 double mcxo_priorfun(const mcxo_target *t, const double *th) { return mcxt_prior(t->npar, th, t->pri_mu, t->pri_sig); }
 int mcxo_checkbounds(const mcxo_target *t, const double *th) { return mcxt_inbounds(t->npar, th, t->lo, t->hi); }
 
@@ -410,15 +415,32 @@ static double quadform_sym_upper(int n, const double *S, const double *x)
     return q;
 }
 
-/* MCMC_DR_alpha13, MCMC_DRAM.F90:162-186 */
-static double dr_alpha13(mcxo_chain *c, const double *oldpar, double ss1, double pri1,
-                         const double *newpar, double ss2, double pri2, double alpha12,
-                         const double *newpar2, double ss3, double pri3)
+/* sum((a - b)/sigma2) and sum(a/sigma2) over the response columns, the way the reference's array expressions reduce
+ * (from 0, ascending); with one column 0 + x = x */
+static double colsum_diff(const mcxo_chain *c, const double *a, const double *b)
 {
-    int n = c->npar; double s2 = c->sigma2, alpha32;
+    double s = 0.0;
+    for (int j = 0; j < c->ny; ++j) s = s + (a[j] - b[j]) / c->sigma2v[j];
+    return s;
+}
+/* MCMC_alpha, MCMC_DRAM.F90:100-118, vector form */
+static double alpha_cols(const mcxo_chain *c, const double *ss1, double pri1, const double *ss2, double pri2)
+{
+    double tst = -0.5 * (colsum_diff(c, ss2, ss1) + (pri2 - pri1));
+    if (tst >= 0.0) return 1.0;
+    if (tst < MCX_LOG_REALMIN) return 0.0;
+    return mcxm_exp(tst);
+}
+
+/* MCMC_DR_alpha13, MCMC_DRAM.F90:162-186 */
+static double dr_alpha13(mcxo_chain *c, const double *oldpar, const double *ss1, double pri1,
+                         const double *newpar, const double *ss2, double pri2, double alpha12,
+                         const double *newpar2, const double *ss3, double pri3)
+{
+    int n = c->npar; double alpha32;
     if (alpha12 == 0.0) alpha32 = 0.0;
-    else { double tst32 = -0.5 * ((ss2 - ss3) / s2 + (pri2 - pri3)); alpha32 = min1(mcxm_exp(tst32)); }
-    double l2 = -0.5 * ((ss3 - ss1) / s2 + (pri3 - pri1));
+    else { double tst32 = -0.5 * (colsum_diff(c, ss2, ss3) + (pri2 - pri3)); alpha32 = min1(mcxm_exp(tst32)); }
+    double l2 = -0.5 * (colsum_diff(c, ss3, ss1) + (pri3 - pri1));
     double *d1 = (double *)malloc(sizeof(double) * 2 * (size_t)n), *d2 = d1 + n;
     for (int i = 0; i < n; ++i) { d1[i] = newpar2[i] - newpar[i]; d2[i] = oldpar[i] - newpar[i]; }
     double q1 = -0.5 * (quadform_sym_upper(n, c->iC, d1) - quadform_sym_upper(n, c->iC, d2));
@@ -427,11 +449,14 @@ static double dr_alpha13(mcxo_chain *c, const double *oldpar, double ss1, double
 }
 
 /* MCMC_updatesigma2, MCMC_DRAM.F90:192-206 */
-static void updatesigma2(mcxo_chain *c, double ss)
+static void updatesigma2(mcxo_chain *c, const double *ss)
 {
     if (c->cfg.updatesigma != 0) {
-        double g = mcxo_gamma(&c->rng, c->cfg.N0 / 2.0 + (double)c->nobs / 2.0, 2.0 / (c->cfg.N0 * c->S02 + ss));
-        c->sigma2 = 1.0 / g;
+        for (int j = 0; j < c->ny; ++j) {
+            double g = mcxo_gamma(&c->rng, c->cfg.N0 / 2.0 + (double)c->nobsv[j] / 2.0, 2.0 / (c->cfg.N0 * c->S02 + ss[j]));
+            c->sigma2v[j] = 1.0 / g;
+        }
+        c->sigma2 = c->sigma2v[0];
     }
 }
 
@@ -452,19 +477,19 @@ static void propose(mcxo_chain *c, const double *oldpar, const double *R, double
 }
 
 /* MCMC_savechain 'memory' mode, MCMC_aux.F90:167-185 */
-static void savechain(mcxo_chain *c, const double *par, double ss, int reject)
+static void savechain(mcxo_chain *c, const double *par, const double *ss, int reject)
 {
-    int nc = c->npar + 1;
+    int nc = c->npar + 1, ny = c->ny;
     if (reject) c->chain[(size_t)(c->chainind - 1) * nc + c->npar] += 1.0;
     else {
         c->chainind += 1;
         double *row = c->chain + (size_t)(c->chainind - 1) * nc;
         memcpy(row, par, sizeof(double) * (size_t)c->npar);
         row[c->npar] = 1.0;
-        c->sschain[(size_t)(c->chainind - 1) * 2] = ss;
+        for (int j = 0; j < ny; ++j) c->sschain[(size_t)(c->chainind - 1) * (ny + 1) + j] = ss[j];
     }
-    c->sschain[(size_t)(c->chainind - 1) * 2 + 1] = c->chain[(size_t)(c->chainind - 1) * nc + c->npar];
-    if (c->cfg.updatesigma != 0) c->s2chain[c->simuind - 1] = c->sigma2;
+    c->sschain[(size_t)(c->chainind - 1) * (ny + 1) + ny] = c->chain[(size_t)(c->chainind - 1) * nc + c->npar];
+    if (c->cfg.updatesigma != 0) for (int j = 0; j < ny; ++j) c->s2chain[(size_t)(c->simuind - 1) * ny + j] = c->sigma2v[j];
 }
 
 /* ------------------------------------------------------------------ adaptation: MCMC_adapt.F90 */
@@ -646,7 +671,19 @@ static int adapt_ram(mcxo_chain *c, int simuind, const double *u, double alpha, 
 mcxo_chain *mcxo_chain_create(const mcxo_cfg *cfg, const mcxo_target *tgt, const double *par0,
                               const double *cmat0, double sigma2, int nobs, uint32_t seed, uint32_t chain_id)
 {
+    return mcxo_chain_create_ny(cfg, tgt, par0, cmat0, &sigma2, &nobs, 1, seed, chain_id);
+}
+
+mcxo_chain *mcxo_chain_create_ny(const mcxo_cfg *cfg, const mcxo_target *tgt, const double *par0,
+                                 const double *cmat0, const double *sigma2v, const int *nobsv, int ny,
+                                 uint32_t seed, uint32_t chain_id)
+{
+    if (ny < 1 || ny > MCXO_NYMAX) return NULL;
+    if ((tgt->ny > 1 ? tgt->ny : 1) != ny) return NULL;
+    const double sigma2 = sigma2v[0]; const int nobs = nobsv[0];
     mcxo_chain *c = (mcxo_chain *)calloc(1, sizeof *c);
+    c->ny = ny;
+    for (int j = 0; j < ny; ++j) { c->sigma2v[j] = sigma2v[j]; c->nobsv[j] = nobsv[j]; }
     int n = tgt->npar; size_t nn = (size_t)n * n, ns = (size_t)(cfg->nsimu > 0 ? cfg->nsimu : 1);
     c->cfg = *cfg; c->tgt = *tgt; c->npar = n;
     mcxo_rng_init(&c->rng, seed, chain_id);
@@ -656,8 +693,8 @@ mcxo_chain *mcxo_chain_create(const mcxo_cfg *cfg, const mcxo_target *tgt, const
     c->R = (double *)calloc(nn, sizeof(double)); c->R2 = (double *)calloc(nn, sizeof(double)); c->iC = (double *)calloc(nn, sizeof(double));
     c->chaincmat = (double *)malloc(sizeof(double) * nn); c->chainmean = (double *)malloc(sizeof(double) * n);
     c->chain = (double *)calloc(ns * (size_t)(n + 1), sizeof(double));
-    c->sschain = (double *)calloc(ns * 2, sizeof(double));
-    c->s2chain = (double *)calloc(ns, sizeof(double));
+    c->sschain = (double *)calloc(ns * (size_t)(ny + 1), sizeof(double));
+    c->s2chain = (double *)calloc(ns * (size_t)ny, sizeof(double));
     c->accepted = (uint8_t *)calloc(ns, 1);
     c->alpha_trace = (double *)calloc(ns, sizeof(double));
     c->oldpar = (double *)malloc(sizeof(double) * n);
@@ -694,19 +731,23 @@ int mcxo_chain_run(mcxo_chain *c, int upto)
     double *newpar = (double *)malloc(sizeof(double) * (size_t)n * 6);
     double *newpar2 = newpar + n, *z = newpar + 2 * n, *work = newpar + 3 * n;
     int rc = 0;
+    const int ny = c->ny;
+    double ss2v[MCXO_NYMAX], ss3v[MCXO_NYMAX];
+#define SS1_TAKE(src) do { for (int j_ = 0; j_ < ny; ++j_) c->ss1v[j_] = (src)[j_]; c->ss1 = c->ss1v[0]; } while (0)
     if (c->chainind == 0) {
         memcpy(c->oldpar, c->par0, sizeof(double) * n);
         c->sspri1 = mcxo_priorfun(&c->tgt, c->oldpar);
-        c->ss1 = mcxo_ssfun(&c->tgt, c->oldpar);
+        mcxo_ssfun_cols(&c->tgt, c->oldpar, c->ss1v); c->ss1 = c->ss1v[0];
         c->simuind = 1;
-        savechain(c, c->oldpar, c->ss1, 0);
+        savechain(c, c->oldpar, c->ss1v, 0);
         c->accepted[0] = 1;
         c->alpha12 = 0.0;
     }
     for (int i = c->simuind + 1; i <= upto; ++i) {
         c->simuind = i;
         int reject, inb;
-        double ss2 = 0, pri2 = 0, ss3 = 0, pri3 = 0;
+        double pri2 = 0, pri3 = 0;
+        for (int j_ = 0; j_ < ny; ++j_) { ss2v[j_] = 0.0; ss3v[j_] = 0.0; }
         if (g->method == MCXO_METHOD_SCAM) {                        /* MCMC_run_scam.F90:38-88 */
             int rejall = 1;
             double *rot = work;                                      /* work has 3n doubles */
@@ -718,20 +759,20 @@ int mcxo_chain_run(mcxo_chain *c, int upto)
                 mcxo_gemv(0, n, c->R, rot, newpar);
                 c->nprop++;
                 inb = mcxo_checkbounds(&c->tgt, newpar);
-                if (!inb) { if (!g->dodr) c->bndstayed++; ss2 = DBL_MAX; c->alpha12 = 0.0; reject = 1; }
+                if (!inb) { if (!g->dodr) c->bndstayed++; c->alpha12 = 0.0; reject = 1; }
                 else {
-                    pri2 = mcxo_priorfun(&c->tgt, newpar); ss2 = mcxo_ssfun(&c->tgt, newpar);
-                    c->alpha12 = mcxo_alpha(c->ss1, c->sspri1, ss2, pri2, c->sigma2);
+                    pri2 = mcxo_priorfun(&c->tgt, newpar); mcxo_ssfun_cols(&c->tgt, newpar, ss2v);
+                    c->alpha12 = alpha_cols(c, c->ss1v, c->sspri1, ss2v, pri2);
                     reject = mcmc_reject(c, c->alpha12);
                 }
-                if (!reject) { c->ss1 = ss2; c->sspri1 = pri2; memcpy(c->oldpar, newpar, sizeof(double) * n); rejall = 0; }
+                if (!reject) { SS1_TAKE(ss2v); c->sspri1 = pri2; memcpy(c->oldpar, newpar, sizeof(double) * n); rejall = 0; }
             }
             reject = rejall;
             c->alpha_trace[i - 1] = c->alpha12;
             if (reject) c->stayed++;
             c->accepted[i - 1] = (uint8_t)!reject;
-            updatesigma2(c, c->ss1);
-            savechain(c, c->oldpar, c->ss1, reject);
+            updatesigma2(c, c->ss1v);
+            savechain(c, c->oldpar, c->ss1v, reject);
             rc = adapt(c, i);
             if (rc != 0) break;
             continue;
@@ -743,21 +784,25 @@ int mcxo_chain_run(mcxo_chain *c, int upto)
             if (!inb) { c->bndstayed++; reject = 1; }
             else {
                 double u = mcxo_uniform(&c->rng);                    /* MCMC_sscrit, MCMC_DRAM.F90:124-135 */
-                double sscrit = -2.0 * mcxm_log(u) + c->ss1 / c->sigma2 + c->sspri1;
+                double s1 = 0.0;                                     /* sum(ss1/sigma2) */
+                for (int j_ = 0; j_ < ny; ++j_) s1 = s1 + c->ss1v[j_] / c->sigma2v[j_];
+                double sscrit = -2.0 * mcxm_log(u) + s1 + c->sspri1;
                 pri2 = mcxo_priorfun(&c->tgt, newpar);
                 if (pri2 >= sscrit) { reject = 1; c->erstayed++; }
                 else {
-                    sscrit = c->sigma2 * (sscrit - pri2);
-                    ss2 = mcxo_ssfun(&c->tgt, newpar);               /* default ssfunction_er: no early exit */
-                    reject = (ss2 >= sscrit) ? 1 : 0;
+                    sscrit = c->sigma2v[0] * (sscrit - pri2);       /* MCMC_run_er.F90:72 "problem here if nycol > 1" */
+                    mcxo_ssfun_cols(&c->tgt, newpar, ss2v);          /* default ssfunction_er: no early exit */
+                    double s2 = 0.0;                                 /* sum(ss2) */
+                    for (int j_ = 0; j_ < ny; ++j_) s2 = s2 + ss2v[j_];
+                    reject = (s2 >= sscrit) ? 1 : 0;
                 }
             }
             c->alpha_trace[i - 1] = c->alpha12;
             if (reject) c->stayed++;
-            else { c->ss1 = ss2; c->sspri1 = pri2; memcpy(c->oldpar, newpar, sizeof(double) * n); }
+            else { SS1_TAKE(ss2v); c->sspri1 = pri2; memcpy(c->oldpar, newpar, sizeof(double) * n); }
             c->accepted[i - 1] = (uint8_t)!reject;
-            updatesigma2(c, c->ss1);
-            savechain(c, c->oldpar, c->ss1, reject);
+            updatesigma2(c, c->ss1v);
+            savechain(c, c->oldpar, c->ss1v, reject);
             rc = adapt(c, i);
             if (rc != 0) break;
             continue;
@@ -768,8 +813,8 @@ int mcxo_chain_run(mcxo_chain *c, int upto)
             inb = mcxo_checkbounds(&c->tgt, newpar);
             if (!inb) { c->bndstayed++; reject = 1; }              /* alpha12 left stale: MCMC_run_ram.F90:52-54 */
             else {
-                pri2 = mcxo_priorfun(&c->tgt, newpar); ss2 = mcxo_ssfun(&c->tgt, newpar);
-                c->alpha12 = mcxo_alpha(c->ss1, c->sspri1, ss2, pri2, c->sigma2);
+                pri2 = mcxo_priorfun(&c->tgt, newpar); mcxo_ssfun_cols(&c->tgt, newpar, ss2v);
+                c->alpha12 = alpha_cols(c, c->ss1v, c->sspri1, ss2v, pri2);
                 reject = mcmc_reject(c, c->alpha12);
             }
         } else {
@@ -778,10 +823,11 @@ int mcxo_chain_run(mcxo_chain *c, int upto)
             inb = mcxo_checkbounds(&c->tgt, newpar);
             if (!inb) {
                 if (!g->dodr) c->bndstayed++;
-                ss2 = DBL_MAX; pri2 = DBL_MAX; c->alpha12 = 0.0; reject = 1;
+                for (int j_ = 0; j_ < ny; ++j_) ss2v[j_] = DBL_MAX;
+                pri2 = DBL_MAX; c->alpha12 = 0.0; reject = 1;
             } else {
-                pri2 = mcxo_priorfun(&c->tgt, newpar); ss2 = mcxo_ssfun(&c->tgt, newpar);
-                c->alpha12 = mcxo_alpha(c->ss1, c->sspri1, ss2, pri2, c->sigma2);
+                pri2 = mcxo_priorfun(&c->tgt, newpar); mcxo_ssfun_cols(&c->tgt, newpar, ss2v);
+                c->alpha12 = alpha_cols(c, c->ss1v, c->sspri1, ss2v, pri2);
                 reject = mcmc_reject(c, c->alpha12);
             }
             if (reject && g->dodr) {                                /* MCMC_run.F90:65-91 */
@@ -791,19 +837,19 @@ int mcxo_chain_run(mcxo_chain *c, int upto)
                 inb = mcxo_checkbounds(&c->tgt, newpar2);
                 if (!inb) { c->bndstayed++; reject = 1; }
                 else {
-                    pri3 = mcxo_priorfun(&c->tgt, newpar2); ss3 = mcxo_ssfun(&c->tgt, newpar2);
-                    double a13 = dr_alpha13(c, c->oldpar, c->ss1, c->sspri1, newpar, ss2, pri2, c->alpha12, newpar2, ss3, pri3);
+                    pri3 = mcxo_priorfun(&c->tgt, newpar2); mcxo_ssfun_cols(&c->tgt, newpar2, ss3v);
+                    double a13 = dr_alpha13(c, c->oldpar, c->ss1v, c->sspri1, newpar, ss2v, pri2, c->alpha12, newpar2, ss3v, pri3);
                     reject = mcmc_reject(c, a13);
-                    if (!reject) { c->draccepted++; memcpy(newpar, newpar2, sizeof(double) * n); ss2 = ss3; pri2 = pri3; }
+                    if (!reject) { c->draccepted++; memcpy(newpar, newpar2, sizeof(double) * n); for (int j_ = 0; j_ < ny; ++j_) ss2v[j_] = ss3v[j_]; pri2 = pri3; }
                 }
             }
         }
         c->alpha_trace[i - 1] = c->alpha12;
         if (reject) c->stayed++;
-        else { c->ss1 = ss2; c->sspri1 = pri2; memcpy(c->oldpar, newpar, sizeof(double) * n); }
+        else { SS1_TAKE(ss2v); c->sspri1 = pri2; memcpy(c->oldpar, newpar, sizeof(double) * n); }
         c->accepted[i - 1] = (uint8_t)!reject;
-        updatesigma2(c, c->ss1);
-        savechain(c, c->oldpar, c->ss1, reject);
+        updatesigma2(c, c->ss1v);
+        savechain(c, c->oldpar, c->ss1v, reject);
         if (g->method == MCXO_METHOD_RAM) rc = adapt_ram(c, i, z, c->alpha12, work);
         else rc = adapt(c, i);
         if (rc != 0) break;

@@ -46,9 +46,12 @@ typedef struct mcxo_target {
     const double *xdata, *ydata;
     const double *lo, *hi;            /* box bounds, in-bounds iff lo<th<hi; NULL = none */
     const double *pri_mu, *pri_sig;   /* default Gaussian priors, sig<=0 = flat; NULL = none */
+    int ny;                           /* response columns of ssfunction (nycol); 0 or 1 = one; > 1: expdata only, ydata ny x ndata */
 } mcxo_target;
 
-double mcxo_ssfun(const mcxo_target *t, const double *theta);
+#define MCXO_NYMAX 8
+double mcxo_ssfun(const mcxo_target *t, const double *theta);               /* column 0 */
+void   mcxo_ssfun_cols(const mcxo_target *t, const double *theta, double *ss); /* all ny columns */
 double mcxo_priorfun(const mcxo_target *t, const double *theta);
 int    mcxo_checkbounds(const mcxo_target *t, const double *theta);
 
@@ -81,11 +84,19 @@ typedef struct mcxo_chain {
     int continue_on_downdate_fail;
     double *qcovstd;                      /* SCAM: sqrt of the singular values (mcmc.F90:37) */
     int erstayed;                         /* early rejection on the prior (mcmc.F90:48) */
+    /* nycol columns (mcmc.F90:30-33: sigma2(:), nobs(:); ss vectors): the scalars ss1 / sigma2 / nobs above mirror column 0;
+     * sschain is [nsimu][ny+1] (ss columns, then the repeat count), s2chain [nsimu][ny] */
+    int ny;
+    double ss1v[MCXO_NYMAX], sigma2v[MCXO_NYMAX];
+    int nobsv[MCXO_NYMAX];
 } mcxo_chain;
 
 mcxo_chain *mcxo_chain_create(const mcxo_cfg *cfg, const mcxo_target *tgt, const double *par0,
                               const double *cmat0, double sigma2, int nobs,
                               uint32_t seed, uint32_t chain_id);
+mcxo_chain *mcxo_chain_create_ny(const mcxo_cfg *cfg, const mcxo_target *tgt, const double *par0,
+                                 const double *cmat0, const double *sigma2, const int *nobs, int ny,
+                                 uint32_t seed, uint32_t chain_id);
 void mcxo_chain_free(mcxo_chain *c);
 /* MCMC_init tail + first row of MCMC_run*, then iterations 2..nsimu (or up to upto) */
 int mcxo_chain_run(mcxo_chain *c, int upto);

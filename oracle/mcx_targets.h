@@ -62,6 +62,20 @@ static inline double mcxt_ss_expdata(const double *th, int n, const double *x, c
     return ss;
 }
 
+/* ny response columns (nycol > 1, MCMC_DRAM.F90:100-118: one sigma2 per column): column j is th0 * exp(-th(1+j) x)
+ * against y + j*n, so npar = 1 + ny; column 0 alone is mcxt_ss_expdata */
+static inline void mcxt_ss_expdata_cols(const double *th, int n, const double *x, const double *y, int ny, double *ss)
+{
+    for (int j = 0; j < ny; ++j) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double r = y[(long)j * n + i] - th[0] * mcxm_exp(-(th[1 + j] * x[i]));
+            s = fma(r, r, s);
+        }
+        ss[j] = s;
+    }
+}
+
 /* priorfun.f90:96-100: sum(((theta-mu)/sig)**2, mask=sig>0); library Fortran, no fma */
 static inline double mcxt_prior(int d, const double *th, const double *pmu, const double *psig)
 {

@@ -34,7 +34,7 @@ _DP = C.POINTER(C.c_double)
 class Target(C.Structure):
     _fields_ = [("kind", C.c_int), ("npar", C.c_int), ("mu", _DP), ("lam", _DP), ("banana_b", C.c_double),
                 ("ndata", C.c_int), ("xdata", _DP), ("ydata", _DP), ("lo", _DP), ("hi", _DP),
-                ("pri_mu", _DP), ("pri_sig", _DP)]
+                ("pri_mu", _DP), ("pri_sig", _DP), ("ny", C.c_int)]
 
 
 class Rng(C.Structure):
@@ -53,7 +53,8 @@ class Chain(C.Structure):
                 ("ad_istart", C.c_int), ("ad_istartind", C.c_int), ("ad_lastind", C.c_int), ("ad_lastfreq", C.c_int),
                 ("info_last", C.c_int), ("ram_downdate_fail", C.c_int),
                 ("oldpar", _DP), ("ss1", C.c_double), ("sspri1", C.c_double), ("alpha12", C.c_double),
-                ("continue_on_downdate_fail", C.c_int), ("qcovstd", _DP), ("erstayed", C.c_int)]
+                ("continue_on_downdate_fail", C.c_int), ("qcovstd", _DP), ("erstayed", C.c_int),
+                ("ny", C.c_int), ("ss1v", C.c_double * 8), ("sigma2v", C.c_double * 8), ("nobsv", C.c_int * 8)]
 
 
 _lib = None
@@ -71,6 +72,10 @@ def lib():
         L.mcxo_chain_create.restype = C.POINTER(Chain)
         L.mcxo_chain_create.argtypes = [C.POINTER(Cfg), C.POINTER(Target), _DP, _DP, C.c_double, C.c_int,
                                         C.c_uint32, C.c_uint32]
+        L.mcxo_chain_create_ny.restype = C.POINTER(Chain)
+        L.mcxo_chain_create_ny.argtypes = [C.POINTER(Cfg), C.POINTER(Target), _DP, _DP, _DP, C.POINTER(C.c_int), C.c_int,
+                                           C.c_uint32, C.c_uint32]
+        L.mcxo_ssfun_cols.argtypes = [C.POINTER(Target), _DP, _DP]
         L.mcxo_chain_free.argtypes = [C.POINTER(Chain)]
         L.mcxo_chain_run.argtypes = [C.POINTER(Chain), C.c_int]
         L.mcxo_chain_run.restype = C.c_int
@@ -131,7 +136,12 @@ class Problem:
         self.kind, self.npar = kind, int(npar)
         self.par0 = f64(par0).reshape(npar)
         self.cmat0 = f64(cmat0).reshape(npar, npar)
-        self.sigma2, self.nobs = float(sigma2), int(nobs)
+        # nycol > 1 (expdata with ydata [ny][ndata], npar = 1 + ny): sigma2 and nobs are vectors of length ny
+        self.sigma2v = f64(np.atleast_1d(sigma2))
+        self.nobsv = np.ascontiguousarray(np.atleast_1d(nobs), dtype=np.int32)
+        self.ny = len(self.sigma2v)
+        assert len(self.nobsv) == self.ny
+        self.sigma2, self.nobs = float(self.sigma2v[0]), int(self.nobsv[0])
         self.mu = f64(mu) if mu is not None else None
         self.lam = f64(lam) if lam is not None else None      # row-major lam[i, j]
         self.b = float(b)
@@ -149,6 +159,9 @@ class Problem:
         t.ndata = 0 if self.xdata is None else len(self.xdata)
         t.xdata, t.ydata = _dp(self.xdata), _dp(self.ydata)
         t.lo, t.hi, t.pri_mu, t.pri_sig = _dp(self.lo), _dp(self.hi), _dp(self.pri_mu), _dp(self.pri_sig)
+        t.ny = self.ny
+        if self.ny > 1:
+            assert self.kind == "expdata" and self.ydata.size == self.ny * t.ndata and self.npar == 1 + self.ny
         return t
 
 
@@ -161,8 +174,8 @@ def run_chain(cfg, prob, seed=0x6D636D63, chain_id=0, upto=None, continue_on_dow
     L = lib()
     tgt = prob.ctarget()
     cm = np.asfortranarray(prob.cmat0)            # column-major like the reference
-    ch = L.mcxo_chain_create(C.byref(cfg), C.byref(tgt), _dp(prob.par0), cm.ctypes.data_as(_DP),
-                             prob.sigma2, prob.nobs, seed, chain_id)
+    ch = L.mcxo_chain_create_ny(C.byref(cfg), C.byref(tgt), _dp(prob.par0), cm.ctypes.data_as(_DP),
+                                _dp(prob.sigma2v), prob.nobsv.ctypes.data_as(C.POINTER(C.c_int)), prob.ny, seed, chain_id)
     if not ch:
         raise RuntimeError("could not factor the initial covariance")
     try:
@@ -174,8 +187,11 @@ def run_chain(cfg, prob, seed=0x6D636D63, chain_id=0, upto=None, continue_on_dow
         r.rc = rc
         r.simuind, r.chainind = c.simuind, c.chainind
         r.chain = np.ctypeslib.as_array(c.chain, shape=(cfg.nsimu, n + 1))[:c.chainind].copy()
-        r.sschain = np.ctypeslib.as_array(c.sschain, shape=(cfg.nsimu, 2))[:c.chainind].copy()
-        r.s2chain = np.ctypeslib.as_array(c.s2chain, shape=(cfg.nsimu,))[:ns].copy()
+        ny = prob.ny
+        r.sschain = np.ctypeslib.as_array(c.sschain, shape=(cfg.nsimu, ny + 1))[:c.chainind].copy()
+        r.s2chain = np.ctypeslib.as_array(c.s2chain, shape=(cfg.nsimu, ny))[:ns].copy()
+        if ny == 1:
+            r.s2chain = r.s2chain[:, 0]
         r.accepted = np.ctypeslib.as_array(c.accepted, shape=(cfg.nsimu,))[:ns].copy()
         r.alpha = np.ctypeslib.as_array(c.alpha_trace, shape=(cfg.nsimu,))[:ns].copy()
         r.R = np.ctypeslib.as_array(c.R, shape=(n, n)).T.copy()            # -> R[i, j]
@@ -186,6 +202,7 @@ def run_chain(cfg, prob, seed=0x6D636D63, chain_id=0, upto=None, continue_on_dow
         r.chainwsum = c.chainwsum
         r.qcovstd = np.ctypeslib.as_array(c.qcovstd, shape=(n,)).copy()
         r.sigma2 = c.sigma2
+        r.sigma2v = np.array(c.sigma2v[:ny]); r.ss1v = np.array(c.ss1v[:ny])
         r.theta = np.ctypeslib.as_array(c.oldpar, shape=(n,)).copy()
         r.ss1, r.sspri1 = c.ss1, c.sspri1
         r.stayed, r.bndstayed, r.draccepted, r.drtries = c.stayed, c.bndstayed, c.draccepted, c.drtries

@@ -17,14 +17,13 @@ function ssfunction(theta,npar,ny) result(ss)
   real(8) :: theta(npar)
   real(8) :: ss(ny)
   interface
-     function mcxref_ss(theta,npar) bind(C,name='mcxref_ss') result(v)
+     subroutine mcxref_ss_cols(theta,npar,ny,ss) bind(C,name='mcxref_ss_cols')
        use iso_c_binding
-       real(c_double) :: theta(*)
-       integer(c_int), value :: npar
-       real(c_double) :: v
-     end function mcxref_ss
+       real(c_double) :: theta(*), ss(*)
+       integer(c_int), value :: npar, ny
+     end subroutine mcxref_ss_cols
   end interface
-  ss(1) = mcxref_ss(theta,npar)
+  call mcxref_ss_cols(theta,npar,ny,ss)
 end function ssfunction
 
 function checkbounds(theta)

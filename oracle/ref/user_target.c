@@ -13,6 +13,7 @@
  *   gauss  : mu[npar], lam[npar*npar] row-major
  *   banana : b
  *   expdata: ndata, x[ndata], y[ndata]
+ *   expdata with several response columns (kind 3): ny, ndata, x[ndata], y[ny*ndata] column after column
  *   nbounds (0 or npar) then lo[npar], hi[npar]
  * Numbers are C99 hex floats (exact).
  */
@@ -20,8 +21,10 @@
 #include <stdlib.h>
 #include "../mcx_targets.h"
 
-static int g_loaded = 0, g_kind, g_npar, g_ndata, g_nb;
+static int g_loaded = 0, g_kind, g_npar, g_ndata, g_nb, g_ny = 1;
 static double *g_mu, *g_lam, g_b, *g_x, *g_y, *g_lo, *g_hi;
+
+double mcxref_ss(const double *theta, int npar);
 
 static double rd(FILE *f)
 {
@@ -44,10 +47,20 @@ static void load(void)
     if (g_kind == 0) { g_mu = rdv(f, g_npar); g_lam = rdv(f, g_npar * g_npar); }
     else if (g_kind == 1) g_b = rd(f);
     else if (g_kind == 2) { g_ndata = (int)rd(f); g_x = rdv(f, g_ndata); g_y = rdv(f, g_ndata); }
+    else if (g_kind == 3) { g_ny = (int)rd(f); g_ndata = (int)rd(f); g_x = rdv(f, g_ndata); g_y = rdv(f, g_ny * g_ndata); }
     g_nb = (int)rd(f);
     if (g_nb > 0) { g_lo = rdv(f, g_nb); g_hi = rdv(f, g_nb); }
     fclose(f);
     g_loaded = 1;
+}
+
+/* ssfunction(theta, npar, ny): ny values */
+void mcxref_ss_cols(const double *theta, int npar, int ny, double *ss)
+{
+    load();
+    if (npar != g_npar || ny != g_ny) { fprintf(stderr, "user_target: npar / ny mismatch\n"); exit(2); }
+    if (g_kind == 3) mcxt_ss_expdata_cols(theta, g_ndata, g_x, g_y, g_ny, ss);
+    else ss[0] = mcxref_ss(theta, npar);
 }
 
 double mcxref_ss(const double *theta, int npar)

@@ -76,15 +76,20 @@ def write_inputs(d, cfg, prob, extra_nml=""):
         f.write("/\n")
     _dat(os.path.join(d, "mcmcpar.dat"), prob.par0.reshape(1, -1))
     _dat(os.path.join(d, "mcmccov.dat"), prob.cmat0)
-    _dat(os.path.join(d, "mcmcsigma2.dat"), np.array([[prob.sigma2], [float(prob.nobs)]]))
+    ny = getattr(prob, "ny", 1)
+    _dat(os.path.join(d, "mcmcsigma2.dat"), np.vstack([prob.sigma2v, prob.nobsv.astype(np.float64)]))     # 2 x nycol
+    if ny > 1:
+        _dat(os.path.join(d, "mcmcnycol.dat"), np.array([[float(ny)]]))                               # initialize.F90:52-58
     if prob.pri_mu is not None:
         _dat(os.path.join(d, "priors.dat"), np.vstack([prob.pri_mu, prob.pri_sig]))
     with open(os.path.join(d, "mcxtarget.txt"), "w") as f:
-        f.write("%d %d\n" % (TARGET_IDS[prob.kind], prob.npar))
+        f.write("%d %d\n" % (3 if ny > 1 else TARGET_IDS[prob.kind], prob.npar))
         if prob.kind == "gauss":
             f.write(_hex(prob.mu) + "\n" + _hex(prob.lam) + "\n")
         elif prob.kind == "banana":
             f.write(_hex([prob.b]) + "\n")
+        elif ny > 1:
+            f.write("%d %d\n" % (ny, len(prob.xdata)) + _hex(prob.xdata) + "\n" + _hex(prob.ydata) + "\n")
         else:
             f.write("%d\n" % len(prob.xdata) + _hex(prob.xdata) + "\n" + _hex(prob.ydata) + "\n")
         if prob.lo is not None or prob.hi is not None:
@@ -115,7 +120,9 @@ def run_reference(cfg, prob, seed=0x6D636D63, chain_id=0, keep=False, timeout=60
             raise RuntimeError("reference run produced no chain:\n" + r.stdout[-2000:])
         r.chain = read_mat4(os.path.join(d, "chain.mat"))["chain"]
         r.sschain = read_mat4(os.path.join(d, "sschain.mat"))["sschain"]
-        r.s2chain = read_mat4(os.path.join(d, "s2chain.mat"))["s2chain"][:, 0] if cfg.updatesigma else None
+        r.s2chain = read_mat4(os.path.join(d, "s2chain.mat"))["s2chain"] if cfg.updatesigma else None
+        if r.s2chain is not None and r.s2chain.shape[1] == 1:
+            r.s2chain = r.s2chain[:, 0]
         r.chaincmat = np.loadtxt(os.path.join(d, "mcmccovf.dat"), ndmin=2)
         r.chainmean = np.loadtxt(os.path.join(d, "mcmcmean.dat"), ndmin=1)
         r.rng_n = int(open(os.path.join(d, "rng.log")).read().split()[-1])
