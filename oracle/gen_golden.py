@@ -98,6 +98,18 @@ def cases():
                                     nobs=11, xdata=XDATA, ydata=YDATA, lo=[0, 0]), 34)
     c["s5_banana20_scam"] = (dict(nsimu=400, method="scam", adaptint=100, updatesigma=0),
                              dict(kind="banana", npar=20, par0=np.zeros(20), cmat0=0.01 * np.eye(20), b=0.1), 35)
+    # --- nycol = 2: ssfunction returns one ss per response column, one sigma2 / nobs per column (MCMC_DRAM.F90:100-118,
+    # 124-135, 162-186, 192-206; sschain has nycol+1 columns, s2chain nycol)
+    Y2 = np.vstack([YDATA, 9.0 * np.exp(-0.25 * XDATA) + 0.2 * np.cos(2.0 * XDATA)])
+    m = dict(kind="expdata", npar=3, par0=[9.0, 0.1, 0.2], cmat0=np.diag([0.02, 0.0001, 0.0002]), sigma2=[0.5, 0.3], nobs=[11, 13],
+             xdata=XDATA, ydata=Y2, lo=[0, 0, 0])
+    c["m1_expdata2_dram_dr_s2"] = (dict(nsimu=4000, adaptint=100, updatesigma=1, drscale=2.0, N0=1.0, S02=0.0), m, 51)
+    c["m2_expdata2_er_s2"] = (dict(nsimu=3000, method="er", adaptint=100, updatesigma=1), m, 52)
+    c["m3_expdata2_scam_s2"] = (dict(nsimu=1500, method="scam", adaptint=100, updatesigma=1), m, 53)
+    c["m4_expdata2_ram"] = (dict(nsimu=2500, method="ram", updatesigma=0, N0=1.0, S02=0.0),
+                            dict(m, cmat0=np.diag([0.5, 0.005, 0.01]), sigma2=[0.5, 0.5]), 59)
+    c["m5_expdata2_burnin_greedy_priors"] = (dict(nsimu=3000, adaptint=100, updatesigma=1, doburnin=1, burnintime=500, greedy=1, scalelimit=0.3),
+                                              dict(m, pri_mu=[9.0, 0.1, 0.2], pri_sig=[1.0, 0.0, 0.1]), 55)
     # --- BASELINE config 5 at its own dimension (SURVEY.md section 8c asks for "d=200 SCAM 50 its").  Past an adaptation
     # the d=200 trajectory is not a function of the inputs alone: the new rotation is the singular basis of a covariance
     # with many nearly equal small singular values, and 1e-16 differences in the states (MKL's dgemv order, glibc's log
@@ -124,6 +136,8 @@ def main():
                "chaincmat": r.chaincmat, "chainmean": r.chainmean}
         if cfg.updatesigma:
             out["s2_head"], out["s2_tail"] = r.s2chain[:k], r.s2chain[-k:]
+        if r.sschain.shape[1] > 2:                       # nycol > 1: every ss column
+            out["ss_head"], out["ss_tail"] = r.sschain[:k, :-1], r.sschain[-k:, :-1]
         for f, _ in po.Cfg._fields_:
             out["cfg_" + f] = getattr(cfg, f)
         for kk, v in pkw.items():

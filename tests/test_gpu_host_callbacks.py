@@ -129,3 +129,61 @@ def test_host_callbacks_early_rejection(oracle, early):
     if early:
         assert stopped["n"] > 0
     e.close()
+
+
+@pytest.mark.parametrize("name", ["m1_expdata2_dram_dr_s2", "m2_expdata2_er_s2", "m3_expdata2_scam_s2", "m4_expdata2_ram",
+                                  "m5_expdata2_burnin_greedy_priors"])
+def test_two_response_columns(oracle, name):
+    """nycol = 2: the user's ssfunction returns one ss per response column, sigma2 / nobs are vectors, MCMC_alpha and the
+    DR / ER formulas sum over the columns, the sigma2 update draws one gamma per column, sschain has three columns and
+    s2chain two.  Fixtures from the real reference; the engine through the host callbacks against fixture and oracle."""
+    from mcmcf90_amd import Engine, make_config
+    from golden_util import accepted_from_runlen
+    z, cfg, prob = load(name, oracle)
+    ckw, pkw = _kw(z)
+    L = oracle.lib()
+    tgt = prob.ctarget()
+    L.mcxo_priorfun.restype = C.c_double; L.mcxo_checkbounds.restype = C.c_int
+    dp = C.POINTER(C.c_double)
+
+    def ssfun(th):
+        out = np.zeros(2)
+        L.mcxo_ssfun_cols(C.byref(tgt), th.ctypes.data_as(dp), out.ctypes.data_as(dp))
+        return out
+
+    cid = int(z["chain_id"])
+    npar, nch = 3, 3
+    e = Engine(make_config(npar, nch, record_chain=1, record_accept=1, chain_id0=cid - 1, **ckw))
+    e.setpar0(pkw["par0"]); e.setcmat0(np.asarray(pkw["cmat0"], dtype=float).reshape(npar, npar))
+    e.setsigma2nobs(pkw["sigma2"], pkw["nobs"])
+    e.set_target_host(ssfun, lambda th: L.mcxo_priorfun(C.byref(tgt), th.ctypes.data_as(dp)),
+                      lambda th: bool(L.mcxo_checkbounds(C.byref(tgt), th.ctypes.data_as(dp))))
+    e.init(); e.run()
+    # the fixture's chain is engine chain 1
+    np.testing.assert_array_equal(e.accepted(1), accepted_from_runlen(z["runlen"]))
+    ch, ss, s2 = e.chain(1)
+    assert ss.shape[1] == 3 and (not cfg.updatesigma or s2.shape[1] == 2)
+    k = z["rows_head"].shape[0]
+    np.testing.assert_allclose(ch[-k:, :-1], z["rows_tail"], rtol=1e-7)
+    np.testing.assert_allclose(ss[-k:, :-1], z["ss_tail"], rtol=1e-7)
+    if cfg.updatesigma:
+        np.testing.assert_allclose(s2[-k:], z["s2_tail"], rtol=1e-7)
+    assert e.rng(1)[0] == int(z["rng_n"])
+    for c in range(nch):
+        o = oracle.run_chain(cfg, prob, chain_id=cid - 1 + c, continue_on_downdate_fail=True)
+        chc, ssc, s2c = e.chain(c)
+        np.testing.assert_array_equal(_bits(chc), _bits(o.chain))
+        np.testing.assert_array_equal(_bits(ssc), _bits(o.sschain))
+        if cfg.updatesigma:
+            np.testing.assert_array_equal(_bits(s2c), _bits(o.s2chain))
+        assert e.rng(c)[0] == o.rng_n
+    e.close()
+
+
+def test_two_columns_need_the_host_target():
+    from mcmcf90_amd import Engine, make_config, McmcError
+    e = Engine(make_config(2, 1, nsimu=10))
+    e.setpar0([1.0, 1.0]); e.setsigma2nobs([1.0, 1.0], [5, 5]); e.set_target("banana", b=0.1)
+    with pytest.raises(McmcError):
+        e.init()
+    e.close()
