@@ -225,8 +225,8 @@ class LiveChain:
         self.cfg, self.prob, self.n = cfg, prob, prob.npar
         self._tgt = prob.ctarget()
         cm = np.asfortranarray(prob.cmat0)
-        self.ch = L.mcxo_chain_create(C.byref(cfg), C.byref(self._tgt), _dp(prob.par0), cm.ctypes.data_as(_DP),
-                                      prob.sigma2, prob.nobs, seed, chain_id)
+        self.ch = L.mcxo_chain_create_ny(C.byref(cfg), C.byref(self._tgt), _dp(prob.par0), cm.ctypes.data_as(_DP),
+                                         _dp(prob.sigma2v), prob.nobsv.ctypes.data_as(C.POINTER(C.c_int)), prob.ny, seed, chain_id)
         if not self.ch:
             raise RuntimeError("could not factor the initial covariance")
 

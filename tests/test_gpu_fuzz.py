@@ -250,3 +250,68 @@ def test_pooled_scam_substeps_equal_lane_kernel(seed):
     for c in (0, n - 1):
         assert e.rng(c)[0] == e2.rng(c)[0]
     e.close(); e2.close()
+
+
+def _draw_cols(seed):
+    """Random configuration with nycol = 2 or 3 response columns (model column j: th0 exp(-th(1+j) x), npar = 1 + nycol)."""
+    r = np.random.default_rng(31000 + seed)
+    ny = int(r.choice([2, 3]))
+    method = str(r.choice(["dram", "dram", "er", "scam", "ram"]))
+    nsimu = int(r.integers(80, 300)) if method != "scam" else int(r.integers(40, 100))
+    ckw = dict(nsimu=nsimu, method=method, adaptint=int(r.choice([20, 50])), updatesigma=int(r.integers(0, 2)),
+               N0=float(r.choice([1.0, 4.0])), S02=float(r.choice([0.0, 0.8])))
+    if method == "dram":
+        if r.random() < 0.5:
+            ckw["drscale"] = float(r.choice([2.0, 3.0]))
+        if r.random() < 0.4:
+            ckw.update(doburnin=1, burnintime=int(r.integers(20, 120)), scalelimit=float(r.choice([0.05, 0.3])), greedy=int(r.integers(0, 2)))
+        if r.random() < 0.25:
+            ckw["adapthist"] = 60
+    x = np.arange(11.0)
+    rates = np.array([0.1, 0.25, 0.18])[:ny]
+    Y = np.vstack([9.0 * np.exp(-k * x) + r.standard_normal(11) * 0.3 for k in rates])
+    npar = 1 + ny
+    scale = 10.0 if method == "ram" else 1.0
+    pkw = dict(kind="expdata", npar=npar, par0=np.concatenate([[9.0], rates]), cmat0=scale * np.diag([0.02] + [0.0002] * ny),
+               sigma2=r.uniform(0.3, 1.0, ny), nobs=r.integers(8, 20, ny), xdata=x, ydata=Y, lo=np.zeros(npar))
+    if r.random() < 0.3:
+        pkw.update(pri_mu=np.concatenate([[9.0], rates]), pri_sig=np.concatenate([[1.0], np.where(r.random(ny) < 0.5, 0.0, 0.1)]))
+    return ckw, pkw
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_configuration_response_columns(oracle, seed):
+    """nycol = 2 or 3 through the host callbacks against the oracle, bit for bit."""
+    import ctypes as C
+    from mcmcf90_amd import Engine, make_config, McmcError
+    ckw, pkw = _draw_cols(seed)
+    cfg = oracle.make_cfg(**ckw)
+    prob = oracle.Problem(**pkw)
+    L = oracle.lib()
+    tgt = prob.ctarget()
+    L.mcxo_priorfun.restype = C.c_double; L.mcxo_checkbounds.restype = C.c_int
+    dp = C.POINTER(C.c_double)
+    ny, npar = prob.ny, prob.npar
+
+    def ssfun(th):
+        out = np.zeros(ny)
+        L.mcxo_ssfun_cols(C.byref(tgt), th.ctypes.data_as(dp), out.ctypes.data_as(dp))
+        return out
+
+    e = Engine(make_config(npar, 3, record_chain=1, chain_id0=2 * seed, **ckw))
+    e.setpar0(prob.par0); e.setcmat0(prob.cmat0); e.setsigma2nobs(prob.sigma2v, prob.nobsv)
+    e.set_target_host(ssfun, lambda th: L.mcxo_priorfun(C.byref(tgt), th.ctypes.data_as(dp)),
+                      lambda th: bool(L.mcxo_checkbounds(C.byref(tgt), th.ctypes.data_as(dp))))
+    e.init(); e.run()
+    for c in range(3):
+        o = oracle.run_chain(cfg, prob, chain_id=2 * seed + c, continue_on_downdate_fail=True)
+        ch, ss, s2 = e.chain(c)
+        np.testing.assert_array_equal(_bits(ch), _bits(o.chain), err_msg=str(ckw))
+        np.testing.assert_array_equal(_bits(ss), _bits(o.sschain), err_msg=str(ckw))
+        if cfg.updatesigma:
+            np.testing.assert_array_equal(_bits(s2), _bits(o.s2chain), err_msg=str(ckw))
+        assert e.rng(c)[0] == o.rng_n, ckw
+        cnt = e.counters(c)
+        assert (cnt["stayed"], cnt["bndstayed"], cnt["draccepted"], cnt["drtries"], cnt["erstayed"]) == \
+               (o.stayed, o.bndstayed, o.draccepted, o.drtries, o.erstayed), ckw
+    e.close()

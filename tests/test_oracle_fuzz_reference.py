@@ -65,3 +65,27 @@ def test_oracle_equals_reference_on_random_configuration(oracle, seed):
     assert np.max(np.abs(r.chain[:, :-1] - o.chain[:, :-1]) / scale) < 1e-7, ckw
     if cfg.updatesigma:
         np.testing.assert_allclose(r.s2chain, o.s2chain, rtol=1e-7)
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_oracle_equals_reference_with_response_columns(oracle, seed):
+    """nycol = 2 or 3 (vector-valued ssfunction, one sigma2 per column): the oracle against the real reference."""
+    from oracle import refrun as rr
+    if not rr.available():
+        pytest.skip("oracle/_ref/mcxref not built (needs /root/reference)")
+    ckw, pkw = _gen._draw_cols(seed)
+    cfg = oracle.make_cfg(**ckw)
+    prob = oracle.Problem(**pkw)
+    o = oracle.run_chain(cfg, prob, chain_id=seed)
+    if o.ram_downdate_fail:
+        pytest.skip("failed RAM downdate: the reference stops there")
+    if cfg.method != 1 and not _well_posed(oracle, cfg, prob, seed):
+        pytest.skip("ill-posed covariance (see above)")
+    r = rr.run_reference(cfg, prob, chain_id=seed, pinned_svd=bool(cfg.usesvd))
+    np.testing.assert_array_equal(r.chain[:, -1].astype(np.int64), o.chain[:, -1].astype(np.int64), err_msg=str(ckw))
+    assert r.rng_n == o.rng_n, ckw
+    assert r.sschain.shape == o.sschain.shape
+    np.testing.assert_allclose(r.sschain[:, :-1], o.sschain[:, :-1], rtol=1e-7)
+    if cfg.updatesigma:
+        assert r.s2chain.shape == o.s2chain.shape
+        np.testing.assert_allclose(r.s2chain, o.s2chain, rtol=1e-7)
