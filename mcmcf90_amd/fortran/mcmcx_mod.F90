@@ -546,11 +546,11 @@ contains
        call initialize(p0, np, c0, initcmatn, s2, nob, nycol)
        if (.not.allocated(p0) .or. .not.allocated(c0) .or. .not.allocated(s2) .or. .not.allocated(nob)) &
             call doerror('initialize did not allocate par0, cmat0, sigma2, nobs')
-       if (nycol /= 1) call doerror('nycol > 1 is not available in the device engine')
+       if (size(s2) /= nycol .or. size(nob) /= nycol) call doerror('initialize: sigma2 / nobs are not of length nycol')
        call MCMC_setpar0_vec(p0)
        if (size(c0,1) /= npar .or. size(c0,2) /= npar) call doerror('initialize: cmat0 is not npar x npar')
        call MCMC_setcmat0_mat(c0)
-       call MCMC_setsigma2nobs_sca(s2(1), nob(1))
+       call MCMC_setsigma2nobs_vec(s2, nob)
     end if
   end subroutine MCMC_initial_values
 
@@ -597,7 +597,8 @@ contains
   !! ---------------------------------------------------------------- MCMC_init + MCMC_run* + results
   subroutine MCMC_engine_run()
     type(mcmcx_config) :: cfg
-    integer(c_int32_t) :: c8(8), nrows, nob(1)
+    integer(c_int32_t) :: c8(8), nrows
+    integer(c_int32_t), allocatable :: nob(:)
     real(kind=dbl), allocatable :: ch(:), ss(:), s2(:), cm(:), sc(:)
     real(kind=dbl), target, allocatable :: lo(:), hi(:)
     real(kind=dbl) :: lamrow(npar*npar)
@@ -632,8 +633,8 @@ contains
     call chk(mcmcx_create(cfg, handle))
     call chk(mcmcx_set_par0(handle, par0, int(npar, c_int32_t)))
     call chk(mcmcx_set_cmat0(handle, cmat0, int(npar, c_int32_t)))
-    nob(1) = nobs(1)
-    call chk(mcmcx_set_sigma2nobs(handle, sigma2, nob, 1_c_int32_t))
+    allocate(nob(nycol)); nob = nobs                    ! nycol response columns: one sigma2 / nobs each (host callbacks when > 1)
+    call chk(mcmcx_set_sigma2nobs(handle, sigma2, nob, int(nycol, c_int32_t)))
     select case (trim(devtarget))
     case ('gauss')
        do i = 1, npar                                  ! row-major lam(i,j) for the C side
@@ -696,19 +697,22 @@ contains
     simuind = mcmcx_simuind(handle)
     if (interrupted) write(*,*) 'Saving chain upto ', simuind
     !! chain 0 in the reference's arrays
-    allocate(ch(nsimu*(npar+1)), ss(nsimu*2), s2(nsimu), cm(npar*npar), sc(4*nchains))
+    allocate(ch(nsimu*(npar+1)), ss(nsimu*(nycol+1)), s2(nsimu*nycol), cm(npar*npar), sc(4*nchains))
     call chk(mcmcx_get_chain(handle, 0_c_int32_t, ch, ss, s2, nrows))
     chainind = nrows
     if (allocated(chain)) deallocate(chain, sschain)
-    allocate(chain(nsimu, npar+1), sschain(nsimu, 2))
+    allocate(chain(nsimu, npar+1), sschain(nsimu, nycol+1))             ! MCMC_init.F90:126-131
     chain = 0.0_dbl; sschain = 0.0_dbl
     do i = 1, chainind
        chain(i,:) = ch((i-1)*(npar+1)+1 : i*(npar+1))
-       sschain(i,:) = ss((i-1)*2+1 : i*2)
+       sschain(i,:) = ss((i-1)*(nycol+1)+1 : i*(nycol+1))
     end do
     if (updatesigma /= 0) then
        if (allocated(s2chain)) deallocate(s2chain)
-       allocate(s2chain(nsimu,1)); s2chain = 0.0_dbl; s2chain(1:simuind,1) = s2(1:simuind)
+       allocate(s2chain(nsimu,nycol)); s2chain = 0.0_dbl                ! MCMC_init.F90:119-122
+       do i = 1, simuind
+          s2chain(i,:) = s2((i-1)*nycol+1 : i*nycol)
+       end do
     end if
     if (allocated(chaincmat)) deallocate(chaincmat, chainmean)
     allocate(chaincmat(npar,npar), chainmean(npar))
@@ -718,6 +722,7 @@ contains
     stayed = c8(1); bndstayed = c8(2); draccepted = c8(3); drtries = c8(4)
     call chk(mcmcx_get_scalars(handle, sc))
     sigma2(1) = sc(3)
+    if (updatesigma /= 0 .and. simuind >= 1) sigma2 = s2chain(simuind,:)
     !! several chains: what the reference has no counterpart for -- the last state of every chain and the moments of
     !! those states over all chains (about par0: count, sum, upper second moments)
     if (nchains > 1) then
@@ -809,8 +814,8 @@ contains
     call writenumbers(covffile, chaincmat)
     call writenumbers(meanfile, reshape(chainmean, (/npar, 1/)))
     call writenumbers(parffile, chain(chainind:chainind, 1:npar))
-    if (updatesigma /= 0) call writenumbers(sigma2ffile, &
-         reshape((/s2chain(simuind,1), dble(nobs(1))/), (/2, 1/)))
+    if (updatesigma /= 0) call writenumbers(sigma2ffile, &                 ! MCMC_aux.F90:58-62: row 1 sigma2, row 2 nobs
+         transpose(reshape((/s2chain(simuind,1:nycol), dble(nobs)/), (/nycol, 2/))))
     if (nchains > 1) then                               ! engine extension: all chains' last states, pooled mean / covariance
        call writenumbers('mcmclaststates.dat', laststates)
        call writenumbers('mcmcpooledmean.dat', reshape(pooledmean, (/npar, 1/)))

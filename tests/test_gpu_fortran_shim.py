@@ -362,3 +362,42 @@ def test_user_program_with_the_svd_paths(oracle, method, extra):
     o = oracle.run_chain(oracle.make_cfg(**ckw), oracle.Problem(**pkw), chain_id=0)
     np.testing.assert_array_equal(chain[:, -1].astype(np.int32), o.chain[:, -1].astype(np.int32))
     np.testing.assert_allclose(chain[:, :-1], o.chain[:, :-1], rtol=1e-8)
+
+
+def test_user_program_with_two_response_columns(oracle):
+    """demo_cols.F90: nycol = 2 from MCMC_setsigma2nobs((/s1, s2/), (/n1, n2/)), the user's ssfunction returns ss(1:2);
+    chain / sschain (three columns) / s2chain (two columns) / mcmcsigma2f.dat (2 x 2) against the oracle on fixture m1's problem."""
+    exe = os.path.join(FDIR, "demo_cols")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", FDIR])
+    z, cfg, prob = load("m1_expdata2_dram_dr_s2", oracle)
+    nml = """&mcmc
+ nsimu = %d
+ adaptint = %d
+ updatesigma = 1
+ drscale = 2.0
+ N0 = 1
+ S02 = 0
+ printint = 0
+/
+""" % (cfg.nsimu, cfg.adaptint)
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "mcmcinit.nml"), "w").write(nml)
+        x, Y = z["prob_xdata"], z["prob_ydata"]
+        with open(os.path.join(d, "data2.dat"), "w") as f:
+            f.write("% x y1 y2\n")
+            for i in range(len(x)):
+                f.write("  %r   %r   %r\n" % (float(x[i]), float(Y[0, i]), float(Y[1, i])))
+        p = subprocess.run([exe], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, p.stdout.decode(errors="replace")
+        chain = np.loadtxt(os.path.join(d, "chain.dat"), ndmin=2)
+        ss = np.loadtxt(os.path.join(d, "sschain.dat"), ndmin=2)
+        s2 = np.loadtxt(os.path.join(d, "s2chain.dat"), ndmin=2)
+        sf = np.loadtxt(os.path.join(d, "mcmcsigma2f.dat"), ndmin=2)
+    o = oracle.run_chain(cfg, prob, chain_id=0)
+    np.testing.assert_array_equal(chain[:, -1].astype(np.int32), o.chain[:, -1].astype(np.int32))
+    np.testing.assert_allclose(chain[:, :-1], o.chain[:, :-1], rtol=1e-8)
+    assert ss.shape == o.sschain.shape == (len(chain), 3) and s2.shape == o.s2chain.shape == (cfg.nsimu, 2)
+    np.testing.assert_allclose(ss, o.sschain, rtol=1e-8)
+    np.testing.assert_allclose(s2, o.s2chain, rtol=1e-8)
+    np.testing.assert_allclose(sf, np.vstack([o.s2chain[-1], [11.0, 13.0]]), rtol=1e-8)
