@@ -736,7 +736,7 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
         // ---- bounds, prior, ss, alpha, reject
         bool inb = target_inbounds(E.tgt, d, lane, cand_t);
         double pri2 = target_prior(E.tgt, d, lane, cand_t);
-        double ss2 = target_ss<RAM>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
+        double ss2 = target_ss<(RAM || (!DR && !POOLED))>(E.tgt, d, lane, cand_t, g_mu, g_lamT);   // wide (candidate read once) where registers allow
         bool reject;
         if (!RAM && !DR && E.method == M_ER) {            // early rejection, MCMC_run_er.F90:60-89
             if (!inb) { bnd += 1; reject = true; }
