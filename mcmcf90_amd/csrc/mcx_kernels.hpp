@@ -695,10 +695,10 @@ MCX_DEV double quadform_sym(const double *St, int lane, int d, const double *X, 
 // Iterations it0..it1 (absolute simuind) of MCMC_run (MCMC_run.F90:41-107) or MCMC_run_ram
 // (MCMC_run_ram.F90:45-81) for one tile of 64 chains.  LDS is used only by the delayed-rejection
 // quadratic forms (2*d*64 doubles when dodr, none otherwise).
-template <bool RAM, bool DR, bool POOLED>
-__global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
-                                                     const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
-                                                     const double *__restrict__ g_sharedR)
+template <bool RAM, bool DR, bool POOLED, bool WIDE_T = (RAM || (!DR && !POOLED))>
+MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__restrict__ ramscale,
+                       const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
+                       const double *__restrict__ g_sharedR)
 {
     extern __shared__ double X[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
         // ---- bounds, prior, ss, alpha, reject
         bool inb = target_inbounds(E.tgt, d, lane, cand_t);
         double pri2 = target_prior(E.tgt, d, lane, cand_t);
-        double ss2 = target_ss<(RAM || (!DR && !POOLED))>(E.tgt, d, lane, cand_t, g_mu, g_lamT);   // wide (candidate read once) where registers allow
+        double ss2 = target_ss<WIDE_T>(E.tgt, d, lane, cand_t, g_mu, g_lamT);   // wide (candidate read once) where registers allow
         bool reject;
         if (!RAM && !DR && E.method == M_ER) {            // early rejection, MCMC_run_er.F90:60-89
             if (!inb) { bnd += 1; reject = true; }
@@ -839,6 +839,12 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
     TIDX(E.ictr, tile, NICTR, I_DRACC, lane) = dracc; TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane) = drtries;
     TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane) = erstayed;
 }
+
+template <bool RAM, bool DR, bool POOLED>
+__global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
+                                                     const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
+                                                     const double *__restrict__ g_sharedR)
+{ step_body<RAM, DR, POOLED>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
 
 // ---------------------------------------------------------------- host-callback targets
 // When ssfunction / priorfun / checkbounds are host functions of the user (external_inc.h:4-33) one
