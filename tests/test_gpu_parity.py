@@ -232,3 +232,21 @@ def test_caller_supplied_stream(oracle):
     st.synchronize()
     np.testing.assert_array_equal(_bits(e.theta()), _bits(ref.theta()))
     e.close(); ref.close()
+
+
+def test_engines_release_their_device_memory(oracle):
+    """Create / run / destroy in a loop: device memory returns to where it was (allocations are owned by the handle)."""
+    import torch
+    from mcmcf90_amd import engine_from_problem
+    z, cfg, prob = load("c3_banana20_dram", oracle)
+    ckw, pkw = _kw(z)
+    ckw["nsimu"] = 120
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(25):
+        e = engine_from_problem(ckw, pkw, nchains=4096, record_chain=1)
+        e.init(); e.run(); e.sync()
+        e.close()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 * 1024 * 1024, (free0, free1)
