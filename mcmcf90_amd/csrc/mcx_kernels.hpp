@@ -10,6 +10,15 @@
 // indices, every row contributes one contiguous PW x 512-byte segment (streamed non-temporally), and
 // the few O(d) vectors (normals, rotations, candidate) sit in per-chain global scratch, with the most
 // re-read rotations cached in LDS.  Nothing is templated on d (d <= 256).
+//
+// Kernels in this file:
+//   step_kernel<RAM,DR,POOLED>   MCMC_run / MCMC_run_ram / MCMC_run_er iterations, lane per chain (the headline kernel)
+//   scam_kernel                  MCMC_run_scam, lane per chain, per-chain rotation
+//   scam_pooled_kernel           SCAM with one pooled rotation: up to 16 waves per tile, products as f64 MFMA tiles
+//   pooled_mfma_kernel           pooled AM: lane per chain, the two shared-table products as f64 MFMA tiles
+//   host_phase_kernel<0..7>      the iteration cut at the user's host callbacks (DRAM/DR, RAM, ER, SCAM; nycol columns)
+//   adapt_kernel                 MCMC_adapt at a tick: covariance update, Cholesky / SVD factor, DR inverse
+//   init_kernel, bcast_kernel, gather_lane_kernel, moments_kernel, moments_tree_kernel, debug kernels
 #pragma once
 #include "mcx_device.hpp"
 
