@@ -133,12 +133,11 @@ static double gammar_mt(mcxo_rng *g, double a, double b)
 }
 double mcxo_gamma(mcxo_rng *g, double a, double b)
 {
-    if (a < 1.0) {                                    /* mcmcrand.F90:136-146: bb = bb*u**(1/aa); aa = aa+1 (the reference
-                                                         warns that this branch "is not correct" and never takes it in a run;
-                                                         the device engine refuses updatesigma with shape < 1) */
+    if (a < 1.0) {                                    /* random_gamma, mcmcrand.F90:102-105 (the route MCMC_DRAM.F90:201 takes):
+                                                         u first, then gammar_mt(1+a, b) * u**(1/a).  The device engine
+                                                         refuses updatesigma with shape < 1. */
         double u = mcxo_uniform(g);
-        b = b * pow(u, 1.0 / a);
-        a = a + 1.0;
+        return gammar_mt(g, 1.0 + a, b) * pow(u, 1.0 / a);
     }
     return gammar_mt(g, a, b);
 }

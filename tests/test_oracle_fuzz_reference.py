@@ -89,3 +89,22 @@ def test_oracle_equals_reference_with_response_columns(oracle, seed):
     if cfg.updatesigma:
         assert r.s2chain.shape == o.s2chain.shape
         np.testing.assert_allclose(r.s2chain, o.s2chain, rtol=1e-7)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_oracle_equals_reference_with_gamma_shape_below_one(oracle, seed):
+    """N0/2 + nobs/2 < 1: random_gamma's u**(1/a) branch (mcmcrand.F90:102-105), which the reference warns about and the
+    device engine refuses; the oracle still has to consume the stream the way the reference does."""
+    from oracle import refrun as rr
+    if not rr.available():
+        pytest.skip("oracle/_ref/mcxref not built (needs /root/reference)")
+    x = np.linspace(0, 5, 9)
+    y = 2 * np.exp(-0.5 * x)
+    cfg = oracle.make_cfg(nsimu=300, method="dram" if seed % 2 else "scam", adaptint=50, updatesigma=1, N0=0.5, S02=0.8)
+    prob = oracle.Problem("expdata", 2, par0=np.array([2.0, 0.5]), cmat0=np.diag([0.01, 0.01]), sigma2=0.5, nobs=1,
+                          xdata=x, ydata=y)
+    o = oracle.run_chain(cfg, prob, chain_id=seed)
+    r = rr.run_reference(cfg, prob, chain_id=seed)
+    np.testing.assert_array_equal(r.chain[:, -1].astype(np.int64), o.chain[:, -1].astype(np.int64))
+    assert r.rng_n == o.rng_n
+    np.testing.assert_allclose(r.s2chain, o.s2chain, rtol=1e-12)
