@@ -235,7 +235,8 @@ static void launch_step(mcmcx_engine *h, int it0, int it1)
 {
     const dim3 g(h->ntiles), b(64);
     const double *rs = h->d_ramscale + it0;
-    if (h->E.method == M_RAM) hipLaunchKernelGGL((step_kernel<true, false, false>), g, b, (size_t)NLC * 2 * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
+    if (h->E.method == M_RAM && h->usesvd) hipLaunchKernelGGL(step_kernel_ram_fullr, g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
+    else if (h->E.method == M_RAM) hipLaunchKernelGGL((step_kernel<true, false, false>), g, b, (size_t)NLC * 2 * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->dodr) hipLaunchKernelGGL((step_kernel<false, true, false>), g, b, lds_step(h), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (pooled_use_mfma(h)) hipLaunchKernelGGL(pooled_mfma_kernel, g, b, pooled_mfma_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedRT);
     else if (h->pooled) hipLaunchKernelGGL((step_kernel<false, false, true>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
@@ -538,7 +539,6 @@ int mcmcx_create(const mcmcx_config *cfg_in, mcmcx_handle *out)
         c.doburnin = 0; c.drscale = 0.0;
     }
     if (c.method == MCMCX_METHOD_RAM) c.drscale = 0.0;
-    if (c.method == MCMCX_METHOD_RAM && c.condmax > 0.0) return fail(-6, "method='ram' with condmax > 0 is not available in the device engine");
     if (c.nsimu < 1) return fail(-4, "nsimu <= 0 stopping");                         // mcmc_main.F90:22-25
     if (c.npar < 1 || c.npar > MCX_MAX_NPAR) return fail(-5, "npar must be in 1.." + std::to_string(MCX_MAX_NPAR));
     if (c.nchains < 1) return fail(-5, "nchains must be >= 1");
@@ -740,8 +740,10 @@ int mcmcx_init(mcmcx_handle h)
     } else if (h->usesvd) {
         const size_t DD = (size_t)d * d;
         if ((rc = dev_alloc(h, &E.Rf, L * DD, false))) return rc;
-        if ((rc = dev_alloc(h, &E.Gw, L * DD))) return rc;
-        if ((rc = dev_alloc(h, &E.Vw, L * DD))) return rc;
+        if (c.method != MCMCX_METHOD_RAM) {                 // work space of the adaptation's SVD; RAM never refactors
+            if ((rc = dev_alloc(h, &E.Gw, L * DD))) return rc;
+            if ((rc = dev_alloc(h, &E.Vw, L * DD))) return rc;
+        }
         if ((rc = dev_alloc(h, &E.qstd, L * d))) return rc;
         if (h->dodr && (rc = dev_alloc(h, &E.R2f, L * DD, false))) return rc;
         if ((rc = dev_bcast(h, E.Rf, Rfull))) return rc;

@@ -13,6 +13,7 @@
 //
 // Kernels in this file:
 //   step_kernel<RAM,DR,POOLED>   MCMC_run / MCMC_run_ram / MCMC_run_er iterations, lane per chain (the headline kernel)
+//   step_kernel_ram_fullr        method='ram' with condmax > 0: rank-one adaptation of the full SVD factor
 //   scam_kernel                  MCMC_run_scam, lane per chain, per-chain rotation
 //   scam_pooled_kernel           SCAM with one pooled rotation: up to 16 waves per tile, products as f64 MFMA tiles
 //   pooled_mfma_kernel           pooled AM: lane per chain, the two shared-table products as f64 MFMA tiles
@@ -677,6 +678,75 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
     return up && fuse;
 }
 
+// The same adaptation on a FULL column-major factor (condmax > 0: R is the d x d SVD factor U sqrt(s) 2.4/sqrt(d) of
+// covtor, and MCMC_adapt_ram hands it to dchud / dchdd as it is, MCMC_run_ram.F90:168-172).  LINPACK only touches
+// R(i,j), i <= j; the proposal matmulx(R,u) (MCMC_run_ram.F90:96-97) goes on using the whole matrix.  Plain column
+// loops, the arithmetic of ram_update element for element; not fused, not tuned (the combination is a curiosity of the
+// reference, kept so that every namelist it accepts runs).
+#define RF(i, j) Rf_t[((size_t)(j) * d + (i)) * 64 + lane]
+MCX_DEV void ram_update_full(double *Rf_t, const double *zc_t, double *cs_t, int lane, int d, double a, double su, bool act,
+                             uint32_t &status)
+{
+    if (!act) return;
+    if (a >= 0.0) {                                              // dchud.f:122-139
+        for (int j = 0; j < d; ++j) {
+            double xj = GV(zc_t, j) / su * a;
+            for (int i = 0; i < j; ++i) {
+                const double c = GV(cs_t, 2 * i), sn = GV(cs_t, 2 * i + 1), r = RF(i, j);
+                double t = c * r + sn * xj;
+                xj = c * xj - sn * r;
+                RF(i, j) = t;
+            }
+            double rr, c, sn;
+            d_rotg(RF(j, j), xj, rr, c, sn);
+            RF(j, j) = rr; GV(cs_t, 2 * j) = c; GV(cs_t, 2 * j + 1) = sn;
+        }
+        return;
+    }
+    for (int j = 0; j < d; ++j) {                                // dchdd.f:141-148: R'a = x, x = -u/sum(u**2)*a
+        double acc = 0.0;
+        for (int i = 0; i < j; ++i) acc = dfma(RF(i, j), GV(cs_t, 2 * i + 1), acc);
+        double xj = -(GV(zc_t, j) / su * a);
+        double sj = xj - acc;
+        GV(cs_t, 2 * j + 1) = sj / RF(j, j);
+    }
+    double norm;                                                 // dnrm2, dchdd.f:149
+    if (d == 1) norm = fabs(GV(cs_t, 1));
+    else {
+        double scale = 0.0, ssq = 1.0;
+        for (int k = 0; k < d; ++k) {
+            double xk = GV(cs_t, 2 * k + 1);
+            if (xk != 0.0) {
+                double ax = fabs(xk);
+                if (scale < ax) { double q = scale / ax; ssq = 1.0 + ssq * (q * q); scale = ax; }
+                else { double q = ax / scale; ssq = ssq + q * q; }
+            }
+        }
+        norm = scale * sqrt(ssq);
+    }
+    if (!(norm < 1.0)) { status |= ST_RAM_DOWNDATE_FAIL; return; }
+    double alpha = sqrt(1.0 - norm * norm);
+    for (int k = d - 1; k >= 0; --k) {                           // dchdd.f:158-167
+        double sk = GV(cs_t, 2 * k + 1);
+        double scale = alpha + fabs(sk);
+        double aa = alpha / scale, bb = sk / scale;
+        double nn = sqrt(aa * aa + bb * bb);
+        GV(cs_t, 2 * k) = aa / nn;
+        GV(cs_t, 2 * k + 1) = bb / nn;
+        alpha = scale * nn;
+    }
+    for (int j = 0; j < d; ++j) {                                // dchdd.f:171-179
+        double xx = 0.0;
+        for (int i = j; i >= 0; --i) {
+            const double ci = GV(cs_t, 2 * i), si = GV(cs_t, 2 * i + 1), r = RF(i, j);
+            double t = ci * xx + si * r;
+            RF(i, j) = ci * r - si * xx;
+            xx = t;
+        }
+    }
+}
+#undef RF
+
 // ---------------------------------------------------------------- delayed rejection (MCMC_run.F90:65-91)
 // q = dx' iC dx with iC symmetric, upper triangle packed by rows (dsymv 'U' + sum, MCMC_DRAM.F90:180-182,
 // matutils.F90:180): y_i = sum_j S(i,j) dx_j ascending j as an fma chain, q = sum_i y_i dx_i.
@@ -704,7 +774,7 @@ MCX_DEV double quadform_sym(const double *St, int lane, int d, const double *X, 
 // Iterations it0..it1 (absolute simuind) of MCMC_run (MCMC_run.F90:41-107) or MCMC_run_ram
 // (MCMC_run_ram.F90:45-81) for one tile of 64 chains.  LDS is used only by the delayed-rejection
 // quadratic forms (2*d*64 doubles when dodr, none otherwise).
-template <bool RAM, bool DR, bool POOLED, bool WIDE_T = (RAM || (!DR && !POOLED))>
+template <bool RAM, bool DR, bool POOLED, bool WIDE_T = (RAM || (!DR && !POOLED)), bool FULLR = false>
 MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__restrict__ ramscale,
                        const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
                        const double *__restrict__ g_sharedR)
@@ -832,7 +902,8 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
         have_p = false;
         if (RAM && E.doadapt != 0 && !(it < E.burnintime && E.doburnin != 0)) {
             double a = ramscale[it - it0] * (alpha12 - E.alphatarget);
-            have_p = ram_update(Rt, zc_t, zn_t, cs_t, cand_t, theta_t, lane, d, a, su_c, true, pre, status, RAM ? X : nullptr);
+            if (FULLR) ram_update_full(E.Rf + (size_t)tile * d * d * 64, zc_t, cs_t, lane, d, a, su_c, true, status);   // condmax > 0
+            else have_p = ram_update(Rt, zc_t, zn_t, cs_t, cand_t, theta_t, lane, d, a, su_c, true, pre, status, RAM ? X : nullptr);
         }
         su_c = su_n;
     }
@@ -854,6 +925,13 @@ __global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int i
                                                      const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
                                                      const double *__restrict__ g_sharedR)
 { step_body<RAM, DR, POOLED>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
+
+// method='ram' with condmax > 0: the factor is the full SVD one (E.Rf), proposals are matmulx(R,u), the rank-one
+// adaptation runs on its upper triangle (ram_update_full)
+__global__ __launch_bounds__(64, 2) void step_kernel_ram_fullr(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
+                                                               const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
+                                                               const double *__restrict__ g_sharedR)
+{ step_body<true, false, false, false, true>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
 
 // ---------------------------------------------------------------- host-callback targets
 // When ssfunction / priorfun / checkbounds are host functions of the user (external_inc.h:4-33) one
@@ -1417,7 +1495,8 @@ MCX_DEV void host_finish(const EngineDev &E, int tile, int lane, int it, LaneSta
     if (E.method == M_RAM && E.doadapt != 0 && !(it < E.burnintime && E.doburnin != 0)) {
         double a = ramscale[0] * (L.alpha12 - E.alphatarget);
         const double *hx = E.hx + (size_t)tile * NHX * 64;
-        ram_update(E.R + (size_t)tile * E.P * 64, zs_t, zs_t, cs_t, cand_t, theta_t, lane, d, a, GV(hx, HX_SU), true, false, L.status, nullptr);
+        if (E.usesvd) ram_update_full(E.Rf + (size_t)tile * d * d * 64, zs_t, cs_t, lane, d, a, GV(hx, HX_SU), true, L.status);
+        else ram_update(E.R + (size_t)tile * E.P * 64, zs_t, zs_t, cs_t, cand_t, theta_t, lane, d, a, GV(hx, HX_SU), true, false, L.status, nullptr);
     }
 }
 

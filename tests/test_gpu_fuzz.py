@@ -60,10 +60,8 @@ def _draw(seed):
     return ckw, pkw
 
 
-@pytest.mark.parametrize("seed", range(300))
-def test_random_configuration(oracle, seed):
+def _check_against_oracle(oracle, ckw, pkw, seed):
     from mcmcf90_amd import engine_from_problem
-    ckw, pkw = _draw(seed)
     cfg = oracle.make_cfg(**ckw)
     prob = oracle.Problem(**pkw)
     from mcmcf90_amd import McmcError
@@ -99,6 +97,36 @@ def test_random_configuration(oracle, seed):
     e.close()
 
 
+@pytest.mark.parametrize("seed", range(300))
+def test_random_configuration(oracle, seed):
+    ckw, pkw = _draw(seed)
+    _check_against_oracle(oracle, ckw, pkw, seed)
+
+
+def _draw_ram_svd(seed):
+    """method='ram' with condmax > 0: the factor is covtor's full SVD factor, proposals are matmulx(R,u) and
+    cholupdate / choldowndate work on its upper triangle (MCMC_run_ram.F90:96-97, 168-172)."""
+    ckw, pkw = _draw(20000 + seed)
+    r = np.random.default_rng(21000 + seed)
+    for k in ("drscale", "greedy", "adapthist", "adaptend", "scalelimit", "doburnin", "burnintime"):
+        ckw.pop(k, None)
+    ckw.update(method="ram", condmax=float(r.choice([1e8, 1e12])), alphatarget=float(r.choice([0.234, 0.4])),
+               nuparam=float(r.choice([0.6, 0.7, 0.9])))
+    if r.random() < 0.3:
+        ckw.update(doburnin=1, burnintime=int(r.integers(10, 60)))
+    d = int(pkw["npar"])
+    if pkw["kind"] != "expdata" and d > 1:                    # a dense initial covariance: a factor with a full lower triangle
+        A = r.standard_normal((d, d)) / np.sqrt(d)
+        pkw["cmat0"] = (A @ A.T + np.eye(d)) * float(r.uniform(0.02, 0.2))
+    return ckw, pkw
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_configuration_ram_with_svd_factor(oracle, seed):
+    ckw, pkw = _draw_ram_svd(seed)
+    _check_against_oracle(oracle, ckw, pkw, seed)
+
+
 @pytest.mark.parametrize("seed", range(40))
 def test_random_configuration_in_pieces(oracle, seed):
     """mcmcx_run(upto) called in random pieces (launch boundaries anywhere relative to the adaptation ticks) ends in the
@@ -127,9 +155,19 @@ def test_random_configuration_in_pieces(oracle, seed):
 def test_random_configuration_host_callbacks(oracle, seed):
     """The same option space through the host-callback path (the user's ssfunction / priorfun / checkbounds /
     ssfunction_er): identical to the device-resident target."""
+    ckw, pkw = _draw(9000 + seed)
+    _check_host_callbacks(oracle, ckw, pkw)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_configuration_ram_with_svd_factor_host_callbacks(oracle, seed):
+    ckw, pkw = _draw_ram_svd(500 + seed)
+    _check_host_callbacks(oracle, ckw, pkw)
+
+
+def _check_host_callbacks(oracle, ckw, pkw):
     import ctypes as C
     from mcmcf90_amd import Engine, make_config, engine_from_problem, McmcError
-    ckw, pkw = _draw(9000 + seed)
     ckw["nsimu"] = min(ckw["nsimu"], 120 if ckw["method"] != "scam" else 40)
     prob = oracle.Problem(**pkw)
     L = oracle.lib()

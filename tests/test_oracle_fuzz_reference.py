@@ -108,3 +108,30 @@ def test_oracle_equals_reference_with_gamma_shape_below_one(oracle, seed):
     np.testing.assert_array_equal(r.chain[:, -1].astype(np.int64), o.chain[:, -1].astype(np.int64))
     assert r.rng_n == o.rng_n
     np.testing.assert_allclose(r.s2chain, o.s2chain, rtol=1e-12)
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_oracle_equals_reference_ram_with_svd_factor(oracle, seed):
+    """method='ram' with condmax > 0 (MCMC_run_ram.F90:96-97, 168-172: the full SVD factor goes through matmulx and
+    dchud / dchdd as it is).  Most draws end in a failed downdate, where the reference stops; the rest must agree."""
+    from oracle import refrun as rr
+    if not rr.available():
+        pytest.skip("oracle/_ref/mcxref not built (needs /root/reference)")
+    ckw, pkw = _gen._draw_ram_svd(seed)
+    cfg = oracle.make_cfg(**ckw)
+    prob = oracle.Problem(**pkw)
+    try:
+        o = oracle.run_chain(cfg, prob, chain_id=seed)
+    except RuntimeError:
+        with pytest.raises(Exception):
+            rr.run_reference(cfg, prob, chain_id=seed, pinned_svd=True)
+        return
+    if o.ram_downdate_fail:
+        pytest.skip("failed RAM downdate: the reference stops there")
+    r = rr.run_reference(cfg, prob, chain_id=seed, pinned_svd=True)
+    np.testing.assert_array_equal(r.chain[:, -1].astype(np.int64), o.chain[:, -1].astype(np.int64), err_msg=str(ckw))
+    assert r.rng_n == o.rng_n, ckw
+    scale = np.maximum(np.abs(o.chain[:, :-1]).max(axis=0), 1e-3)
+    assert np.max(np.abs(r.chain[:, :-1] - o.chain[:, :-1]) / scale) < 1e-7, ckw
+    if cfg.updatesigma:
+        np.testing.assert_allclose(r.s2chain, o.s2chain, rtol=1e-7)
