@@ -76,6 +76,11 @@ int mcmcx_set_sigma2nobs(mcmcx_handle h, const double *sigma2, const int32_t *no
 int mcmcx_set_target_gauss(mcmcx_handle h, const double *mu, const double *lam_rowmajor);
 int mcmcx_set_target_banana(mcmcx_handle h, double b);
 int mcmcx_set_target_expdata(mcmcx_handle h, int32_t ndata, const double *x, const double *y);
+/* The same model with nycol response columns (a vector-valued ssfunction, external_inc.h:4-9; one sigma2 per column,
+ * MCMC_DRAM.F90:100-118, 192-206): ss_j = sum_i (y_j(i) - theta_1 exp(-theta_{1+j} x_i))**2, npar = 1 + nycol,
+ * y = [nycol][ndata].  Device-resident; the iteration is cut at the evaluations like the host-callback path (several
+ * short launches per iteration, no host round trip).  Give the nycol sigma2 / nobs with mcmcx_set_sigma2nobs. */
+int mcmcx_set_target_expdata_cols(mcmcx_handle h, int32_t ndata, int32_t nycol, const double *x, const double *y);
 /* Host-callback target: the user's own ssfunction / priorfun / checkbounds (external_inc.h:4-33) behind plain C
  * signatures (the Fortran shim adapts the array-result / assumed-shape ABIs).  The engine calls them from the
  * thread that calls mcmcx_run, one chain after the other, at the points the reference does (MCMC_run.F90:47,55-56,

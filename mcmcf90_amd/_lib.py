@@ -37,6 +37,7 @@ SYMBOLS = {
     "mcmcx_set_target_gauss": (C.c_int, [C.c_void_p, _DP, _DP]),
     "mcmcx_set_target_banana": (C.c_int, [C.c_void_p, C.c_double]),
     "mcmcx_set_target_expdata": (C.c_int, [C.c_void_p, C.c_int32, _DP, _DP]),
+    "mcmcx_set_target_expdata_cols": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _DP, _DP]),
     "mcmcx_set_bounds": (C.c_int, [C.c_void_p, _DP, _DP]),
     "mcmcx_set_priors": (C.c_int, [C.c_void_p, _DP, _DP]),
     "mcmcx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -39,7 +39,7 @@ struct mcmcx_engine {
     std::vector<double> par0, cmat0;                 // cmat0 col-major d*d
     double sigma2 = 1.0; int nobs = 1; bool sigma2ok = false;
     int ny = 1; std::vector<double> sigma2v; std::vector<int> nobsv;      // nycol columns (host callbacks only when > 1)
-    int tkind = -1; std::vector<double> tmu, tlam, tx, ty, tlo, thi, tpmu, tpsig; double tb = 0.1;
+    int tkind = -1, tncols = 1; std::vector<double> tmu, tlam, tx, ty, tlo, thi, tpmu, tpsig; double tb = 0.1;
     bool has_lo = false, has_hi = false, has_pri = false;
     mcmcx_ssfun_t h_ss = nullptr; mcmcx_ssfun_er_t h_ss_er = nullptr; mcmcx_priorfun_t h_pri = nullptr; mcmcx_checkbounds_t h_cb = nullptr; void *h_user = nullptr;
     std::vector<double> h_cand, h_ev;
@@ -227,6 +227,7 @@ static bool pooled_use_mfma(const mcmcx_engine *h)
     if (const char *e = getenv("MCMCX_POOLED_SCALAR")) if (atoi(e)) return false;      // A/B switch for tests: the lane-per-chain kernel
     return pooled_mfma_lds(h->d) <= 160 * 1024;
 }
+static bool phased(const mcmcx_engine *h) { return h->tkind == TGT_HOST || h->tkind == TGT_EXPCOLS; }   // iteration cut at the evaluations
 static size_t lds_bytes(const mcmcx_engine *h) { return (size_t)h->d * 64 * sizeof(double) * 2; }   // adapt / DR work vectors
 static size_t lds_step(const mcmcx_engine *h) { return h->dodr ? lds_bytes(h) : 0; }
 static void launch_init(mcmcx_engine *h)
@@ -424,6 +425,11 @@ static int pooled_adapt(mcmcx_engine *h, int it)
 static int host_eval(mcmcx_engine *h, const double *dev_src, int stride_k, bool use_stage2_flag, int what = 0)
 {
     const int d = h->d, T = h->ntiles;
+    if (h->tkind == TGT_EXPCOLS) {                      // device-resident response-column target: no host round trip
+        hipLaunchKernelGGL(dev_eval_kernel, dim3(T), dim3(64), 0, h->stream, h->E, dev_src, stride_k, use_stage2_flag ? 1 : 0, what);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     const size_t L = (size_t)T * 64;
     h->h_cand.resize(L * stride_k);
     const int ny = h->ny, nhe = NHE - 1 + ny;
@@ -630,6 +636,14 @@ int mcmcx_set_target_expdata(mcmcx_handle h, int32_t n, const double *x, const d
     h->tkind = TGT_EXPDATA; h->tx.assign(x, x + n); h->ty.assign(y, y + n);
     return 0;
 }
+int mcmcx_set_target_expdata_cols(mcmcx_handle h, int32_t n, int32_t nycol, const double *x, const double *y)
+{
+    if (!h || !x || !y || n < 1) return fail(-1, "bad argument");
+    if (nycol < 1 || nycol > 8) return fail(-21, "nycol must be in 1..8");
+    if (h->d != 1 + nycol) return fail(-22, "response-column target needs npar = 1 + nycol");
+    h->tkind = TGT_EXPCOLS; h->tncols = nycol; h->tx.assign(x, x + n); h->ty.assign(y, y + (size_t)n * nycol);
+    return 0;
+}
 int mcmcx_set_target_host(mcmcx_handle h, mcmcx_ssfun_t ss, mcmcx_priorfun_t pri, mcmcx_checkbounds_t cb, void *user)
 {
     if (!h || !ss) return fail(-1, "mcmcx_set_target_host: ssfunction is required");     // ssfunction0.f90:10-14
@@ -675,7 +689,8 @@ int mcmcx_init(mcmcx_handle h)
     if (!h->sigma2ok) { h->sigma2 = 1.0; h->nobs = 1; h->ny = 1; }                    // MCMC_init.F90:52-59
     if (h->ny == 1) { h->sigma2v.assign(1, h->sigma2); h->nobsv.assign(1, h->nobs); }
     const int ny = h->ny;
-    if (ny > 1 && h->tkind != TGT_HOST) return fail(-36, "nycol > 1 needs the host-callback target (the built-in targets have one response column)");
+    if (ny > 1 && !phased(h)) return fail(-36, "nycol > 1 needs the host-callback or the response-column target (the other built-in targets have one column)");
+    if (h->tkind == TGT_EXPCOLS && h->tncols != ny) return fail(-36, "response-column target: mcmcx_set_sigma2nobs must give one sigma2 / nobs per column");
     if (ny > 1 && h->pooled) return fail(-36, "nycol > 1 is not available in pooled mode");
     if (h->tkind < 0) return fail(-31, "no target: the device engine needs mcmcx_set_target_*");
     if (h->dodr && lds_bytes(h) > 160 * 1024) return fail(-35, "delayed rejection keeps two npar-vectors per chain in LDS: npar <= 160 with drscale > 0");
@@ -704,7 +719,8 @@ int mcmcx_init(mcmcx_handle h)
     E.alphatarget = c.alphatarget; E.drscale = c.drscale; E.scalelimit = c.scalelimit; E.scalefactor = c.scalefactor;
     E.k0 = c.seed; E.chain_id0 = c.chain_id0;
     // target
-    E.tgt.kind = h->tkind; E.tgt.b = h->tb; E.tgt.ndata = (int)h->tx.size();
+    E.tgt.kind = phased(h) ? (int)TGT_HOST : h->tkind;   // the kernels know one phase-cut mode; who evaluates is the host's business
+    E.tgt.b = h->tb; E.tgt.ndata = (int)h->tx.size(); E.tgt.ncols = h->tncols;
     E.tgt.mu = E.tgt.x = E.tgt.y = E.tgt.lo = E.tgt.hi = E.tgt.pmu = E.tgt.psig = nullptr;
     int rc;
     E.tgt.lamT = nullptr;
@@ -714,7 +730,7 @@ int mcmcx_init(mcmcx_handle h)
         for (int i = 0; i < d; ++i) for (int j = 0; j < d; ++j) lt[(size_t)j * d + i] = h->tlam[(size_t)i * d + j];
         if ((rc = dev_upload(h, &E.tgt.lamT, lt))) return rc;
     }
-    if (h->tkind == TGT_EXPDATA) { if ((rc = dev_upload(h, &E.tgt.x, h->tx))) return rc; if ((rc = dev_upload(h, &E.tgt.y, h->ty))) return rc; }
+    if (h->tkind == TGT_EXPDATA || h->tkind == TGT_EXPCOLS) { if ((rc = dev_upload(h, &E.tgt.x, h->tx))) return rc; if ((rc = dev_upload(h, &E.tgt.y, h->ty))) return rc; }
     if (h->has_lo && (rc = dev_upload(h, &E.tgt.lo, h->tlo))) return rc;
     if (h->has_hi && (rc = dev_upload(h, &E.tgt.hi, h->thi))) return rc;
     if (h->has_pri) { if ((rc = dev_upload(h, &E.tgt.pmu, h->tpmu))) return rc; if ((rc = dev_upload(h, &E.tgt.psig, h->tpsig))) return rc; }
@@ -783,7 +799,7 @@ int mcmcx_init(mcmcx_handle h)
     }
     E.sharedR = nullptr;
     if (h->pooled) {
-        if (h->tkind == TGT_HOST) return fail(-8, "pooled mode needs a device-resident target");
+        if (phased(h)) return fail(-8, "pooled mode needs one of the single-launch device targets (gauss, banana, expdata)");
         if (c.method == MCMCX_METHOD_SCAM && scam_pooled_lds(d) > 160 * 1024) return fail(-8, "pooled scam: npar > 240 does not fit the 160 KiB of LDS");
         if ((rc = dev_alloc(h, &h->d_sharedR, (size_t)P, false))) return rc;
         HIPCHK(hipMemcpy(h->d_sharedR, Rp.data(), (size_t)P * 8, hipMemcpyHostToDevice));
@@ -795,7 +811,7 @@ int mcmcx_init(mcmcx_handle h)
         }
     }
     E.hev = E.hx = nullptr;
-    if (h->tkind == TGT_HOST) {
+    if (phased(h)) {
         if ((rc = dev_alloc(h, &E.hev, L * (NHE - 1 + ny)))) return rc;
         if (ny > 1) {
             if ((rc = dev_alloc(h, &E.ssv, L * ny))) return rc;
@@ -851,7 +867,7 @@ int mcmcx_init(mcmcx_handle h)
             if ((rc = dev_bcast(h, E.mean, h->par0))) return rc;
         }
     }
-    if (h->tkind == TGT_HOST) {                         // first point: sspri1, ss1 from the host callbacks (MCMC_run.F90:35-36)
+    if (phased(h)) {                                    // first point: sspri1, ss1 from the callbacks (MCMC_run.F90:35-36)
         int rc2 = host_eval(h, E.theta, d, false);
         if (rc2) return rc2;
     }
@@ -900,7 +916,7 @@ int mcmcx_run(mcmcx_handle h, int32_t upto)
             mode = adapt_mode(c, end);
             if (mode != 0 || end == upto || end - it + 1 >= maxseg) break;
         }
-        if (h->tkind == TGT_HOST) {
+        if (phased(h)) {
             for (int i2 = it; i2 <= end; ++i2) { int rc = host_iteration(h, i2); if (rc) return rc; }
         } else {
             hipEvent_t e0, e1;

@@ -18,6 +18,7 @@
 //   scam_pooled_kernel           SCAM with one pooled rotation: up to 16 waves per tile, products as f64 MFMA tiles
 //   pooled_mfma_kernel           pooled AM: lane per chain, the two shared-table products as f64 MFMA tiles
 //   host_phase_kernel<0..7>      the iteration cut at the user's host callbacks (DRAM/DR, RAM, ER, SCAM; nycol columns)
+//   dev_eval_kernel              the evaluation between the phases on the device (response-column target)
 //   adapt_kernel                 MCMC_adapt at a tick: covariance update, Cholesky / SVD factor, DR inverse
 //   init_kernel, bcast_kernel, gather_lane_kernel, moments_kernel, moments_tree_kernel, debug kernels
 #pragma once
@@ -25,7 +26,7 @@
 
 namespace mcx {
 
-enum { TGT_GAUSS = 0, TGT_BANANA = 1, TGT_EXPDATA = 2, TGT_HOST = 3 };
+enum { TGT_GAUSS = 0, TGT_BANANA = 1, TGT_EXPDATA = 2, TGT_HOST = 3, TGT_EXPCOLS = 4 };   // EXPCOLS: host side only (the device sees TGT_HOST + dev_eval_kernel)
 enum { M_DRAM = 0, M_RAM = 1, M_ER = 3 };
 
 // per-chain scalar slots (doubles)
@@ -42,7 +43,8 @@ struct DevTarget {
     const double *mu, *lamT;    // gauss: mean[d] and the precision matrix transposed, lamT[j*d+i] = lam(i,j) (padded)
     double b;                   // banana
     int ndata;                  // expdata
-    const double *x, *y;
+    const double *x, *y;        // y: [ncols][ndata] for the response-column target
+    int ncols;
     const double *lo, *hi;      // box bounds or nullptr
     const double *pmu, *psig;   // Gaussian priors or nullptr
 };
@@ -1498,6 +1500,42 @@ MCX_DEV void host_finish(const EngineDev &E, int tile, int lane, int it, LaneSta
         if (E.usesvd) ram_update_full(E.Rf + (size_t)tile * d * d * 64, zs_t, cs_t, lane, d, a, GV(hx, HX_SU), true, L.status);
         else ram_update(E.R + (size_t)tile * E.P * 64, zs_t, zs_t, cs_t, cand_t, theta_t, lane, d, a, GV(hx, HX_SU), true, false, L.status, nullptr);
     }
+}
+
+// Device-resident evaluation for the phase-cut iteration: fills hev (inbounds, prior, ss per response column) the way
+// host_eval does from the user's host callbacks, for the built-in response-column target
+//   ss_j(theta) = sum_i (y_j(i) - theta_1 exp(-theta_{1+j} x_i))**2,  j = 1..nycol  (oracle/mcx_targets.h: mcxt_ss_expdata_cols)
+// with the library's box bounds and Gaussian priors.  what: 0 = checkbounds, priorfun, ssfunction; 1 = checkbounds and
+// priorfun; 2 = ssfunction alone (ssfunction_er0.f90: the default ssfunction_er is ssfunction).
+__global__ __launch_bounds__(64) void dev_eval_kernel(EngineDev E, const double *__restrict__ src, int stride_k, int use_stage2, int what)
+{
+    const int lane = threadIdx.x, tile = blockIdx.x, d = E.d, ny = E.ny;
+    const double *c_t = src + (size_t)tile * stride_k * 64;
+    double *hev = E.hev + (size_t)tile * (NHE - 1 + ny) * 64;
+    const double *hx = E.hx + (size_t)tile * NHX * 64;
+    bool inb = true;
+    double pri = 0.0;
+    const bool skip = use_stage2 && GV(hx, HX_STAGE2) == 0.0;
+    if (!skip && what != 2) {
+        inb = target_inbounds(E.tgt, d, lane, c_t);
+        if (inb) pri = target_prior(E.tgt, d, lane, c_t);          // MCMC_run.F90:54-56: prior first
+    }
+    const bool doss = !skip && ((what == 0 && inb) || what == 2);
+    const double th0 = GV(c_t, 0);
+    for (int j = 0; j < ny; ++j) {
+        double ss = 0.0;
+        if (doss) {
+            const double thj = GV(c_t, 1 + j);
+            const double *yj = E.tgt.y + (size_t)j * E.tgt.ndata;
+            for (int i = 0; i < E.tgt.ndata; ++i) {
+                double r = yj[i] - th0 * d_exp(-(thj * E.tgt.x[i]));
+                ss = dfma(r, r, ss);
+            }
+        }
+        GV(hev, HE_SS + j) = ss;
+    }
+    GV(hev, HE_INB) = (inb && !skip) ? 1.0 : 0.0;
+    GV(hev, HE_PRI) = pri;
 }
 
 template <int PHASE>

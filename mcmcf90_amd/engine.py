@@ -85,8 +85,11 @@ class Engine:
         elif kind == "banana":
             self._chk(self.L.mcmcx_set_target_banana(self.h, float(b)))
         elif kind == "expdata":
-            x, y = _f64(xdata), _f64(ydata)
-            self._chk(self.L.mcmcx_set_target_expdata(self.h, x.size, _dp(x), _dp(y)))
+            x, y = _f64(xdata), np.ascontiguousarray(np.asarray(ydata, dtype=np.float64))
+            if y.ndim == 2:                                   # response columns: y[nycol][ndata]
+                self._chk(self.L.mcmcx_set_target_expdata_cols(self.h, x.size, y.shape[0], _dp(x), _dp(y.ravel())))
+            else:
+                self._chk(self.L.mcmcx_set_target_expdata(self.h, x.size, _dp(x), _dp(y)))
         else:
             raise KeyError(kind)
 
@@ -246,7 +249,7 @@ def engine_from_problem(cfg_kw, prob_kw, nchains=1, **extra):
     e = Engine(cfg)
     e.setpar0(pk["par0"])
     e.setcmat0(np.asarray(pk["cmat0"], dtype=np.float64).reshape(npar, npar))
-    e.setsigma2nobs(float(pk.get("sigma2", 1.0)), int(pk.get("nobs", 1)))
+    e.setsigma2nobs(pk.get("sigma2", 1.0), pk.get("nobs", 1))
     e.set_target(str(pk["kind"]), mu=pk.get("mu"), lam=pk.get("lam"), b=float(pk.get("b", 0.1)),
                  xdata=pk.get("xdata"), ydata=pk.get("ydata"))
     if pk.get("lo") is not None or pk.get("hi") is not None:

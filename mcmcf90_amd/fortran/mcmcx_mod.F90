@@ -161,6 +161,13 @@ module mcmcmod
        real(c_double), intent(in) :: x(*), y(*)
        integer(c_int) :: rc
      end function
+     function mcmcx_set_target_expdata_cols(h, n, ny, x, y) bind(C, name='mcmcx_set_target_expdata_cols') result(rc)
+       import :: c_ptr, c_int, c_double, c_int32_t
+       type(c_ptr), value :: h
+       integer(c_int32_t), value :: n, ny
+       real(c_double), intent(in) :: x(*), y(*)
+       integer(c_int) :: rc
+     end function
      function mcmcx_set_target_host(h, ss, pri, cb, user) bind(C, name='mcmcx_set_target_host') result(rc)
        import :: c_ptr, c_funptr, c_int
        type(c_ptr), value :: h, user
@@ -426,6 +433,12 @@ contains
     allocate(tx(size(x)), ty(size(y)))
     tx = x; ty = y; devtarget = 'expdata'
   end subroutine MCMC_settarget_expdata
+  subroutine MCMC_settarget_expdata_cols(x, y)          ! nycol columns: ss(j) = sum((y(:,j) - th1*exp(-th(1+j)*x))**2)
+    real(kind=dbl), intent(in) :: x(:), y(:,:)
+    if (allocated(tx)) deallocate(tx, ty)
+    allocate(tx(size(x)), ty(size(y)))
+    tx = x; ty = reshape(y, (/size(y)/)); devtarget = 'expcols'
+  end subroutine MCMC_settarget_expdata_cols
   subroutine MCMC_setbounds(lo, hi)                     ! box form of checkbounds, external_inc.h:29-32
     real(kind=dbl), intent(in), optional :: lo(:), hi(:)
     if (present(lo)) then
@@ -555,7 +568,7 @@ contains
   end subroutine MCMC_initial_values
 
   subroutine load_target_from_files()
-    real(kind=dbl), allocatable :: v(:), w(:)
+    real(kind=dbl), allocatable :: v(:), w(:), a2(:,:)
     integer :: nr, nc, stat
     select case (trim(devtarget))
     case ('gauss')
@@ -571,6 +584,14 @@ contains
           call loadnumbers(datafile, v, nr, nc, stat)
           if (stat /= 0 .or. nc /= 2) call doerror('error reading '//trim(datafile))
           call MCMC_settarget_expdata(v(1::2), v(2::2))
+       end if
+    case ('expcols')                                   ! datafile rows: x, y_1 .. y_nycol
+       if (.not.allocated(tx)) then
+          call loadnumbers(datafile, v, nr, nc, stat)
+          if (stat /= 0 .or. nc < 2) call doerror('error reading '//trim(datafile))
+          allocate(a2(nc, nr)); a2 = reshape(v, (/nc, nr/))          ! a2(column, row)
+          call MCMC_settarget_expdata_cols(a2(1,:), transpose(a2(2:nc,:)))
+          deallocate(a2)
        end if
     case ('banana')
     case ('host')
@@ -647,6 +668,9 @@ contains
        call chk(mcmcx_set_target_banana(handle, banana_b))
     case ('expdata')
        call chk(mcmcx_set_target_expdata(handle, int(size(tx), c_int32_t), tx, ty))
+    case ('expcols')
+       if (size(ty) /= size(tx)*nycol) call doerror('devtarget expcols: the data file needs 1 + nycol columns')
+       call chk(mcmcx_set_target_expdata_cols(handle, int(size(tx), c_int32_t), int(nycol, c_int32_t), tx, ty))
     case ('host')
        call chk(mcmcx_set_target_host(handle, c_funloc(mcx_ss_adapter), c_funloc(mcx_prior_adapter), &
             c_funloc(mcx_bounds_adapter), c_null_ptr))

@@ -401,3 +401,49 @@ def test_user_program_with_two_response_columns(oracle):
     np.testing.assert_allclose(ss, o.sschain, rtol=1e-8)
     np.testing.assert_allclose(s2, o.s2chain, rtol=1e-8)
     np.testing.assert_allclose(sf, np.vstack([o.s2chain[-1], [11.0, 13.0]]), rtol=1e-8)
+
+
+def test_two_response_columns_with_the_device_resident_target(oracle):
+    """The same two-column problem with `&mcmcx devtarget = 'expcols'`: the response-column model evaluated on the
+    device (dev_eval_kernel between the phase kernels), 96 chains; chain 1's files against the oracle."""
+    exe = os.path.join(FDIR, "demo_cols")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", FDIR])
+    z, cfg, prob = load("m1_expdata2_dram_dr_s2", oracle)
+    nml = """&mcmc
+ nsimu = %d
+ adaptint = %d
+ updatesigma = 1
+ drscale = 2.0
+ N0 = 1
+ S02 = 0
+ printint = 0
+/
+&mcmcx
+ devtarget = 'expcols'
+ datafile = 'data2.dat'
+ lowerfile = 'lower.dat'
+ nchains = 96
+/
+""" % (cfg.nsimu, cfg.adaptint)
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "mcmcinit.nml"), "w").write(nml)
+        open(os.path.join(d, "lower.dat"), "w").write("0.0 0.0 0.0\n")
+        x, Y = z["prob_xdata"], z["prob_ydata"]
+        with open(os.path.join(d, "data2.dat"), "w") as f:
+            for i in range(len(x)):
+                f.write("  %r   %r   %r\n" % (float(x[i]), float(Y[0, i]), float(Y[1, i])))
+        p = subprocess.run([exe], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, p.stdout.decode(errors="replace")
+        chain = np.loadtxt(os.path.join(d, "chain.dat"), ndmin=2)
+        ss = np.loadtxt(os.path.join(d, "sschain.dat"), ndmin=2)
+        s2 = np.loadtxt(os.path.join(d, "s2chain.dat"), ndmin=2)
+        last = np.loadtxt(os.path.join(d, "mcmclaststates.dat"), ndmin=2)
+    o = oracle.run_chain(cfg, prob, chain_id=0)
+    np.testing.assert_array_equal(chain[:, -1].astype(np.int32), o.chain[:, -1].astype(np.int32))
+    np.testing.assert_allclose(chain[:, :-1], o.chain[:, :-1], rtol=1e-13)
+    np.testing.assert_allclose(ss, o.sschain, rtol=1e-13)
+    np.testing.assert_allclose(s2, o.s2chain, rtol=1e-13)
+    assert last.shape == (96, 3)
+    o95 = oracle.run_chain(cfg, prob, chain_id=95)
+    np.testing.assert_allclose(last[95], o95.theta, rtol=1e-13)

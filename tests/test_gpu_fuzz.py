@@ -353,3 +353,27 @@ def test_random_configuration_response_columns(oracle, seed):
         assert (cnt["stayed"], cnt["bndstayed"], cnt["draccepted"], cnt["drtries"], cnt["erstayed"]) == \
                (o.stayed, o.bndstayed, o.draccepted, o.drtries, o.erstayed), ckw
     e.close()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_configuration_response_columns_device_target(oracle, seed):
+    """nycol = 2 or 3 with the device-resident response-column target (mcmcx_set_target_expdata_cols: the phase kernels
+    with dev_eval_kernel between them, no host round trip) against the oracle, bit for bit."""
+    from mcmcf90_amd import engine_from_problem
+    ckw, pkw = _draw_cols(seed)
+    cfg = oracle.make_cfg(**ckw)
+    prob = oracle.Problem(**pkw)
+    e = engine_from_problem(ckw, pkw, nchains=67, record_chain=1, chain_id0=2 * seed)
+    e.init(); e.run()
+    for c in (0, 1, 66):
+        o = oracle.run_chain(cfg, prob, chain_id=2 * seed + c, continue_on_downdate_fail=True)
+        ch, ss, s2 = e.chain(c)
+        np.testing.assert_array_equal(_bits(ch), _bits(o.chain), err_msg=str(ckw))
+        np.testing.assert_array_equal(_bits(ss), _bits(o.sschain), err_msg=str(ckw))
+        if cfg.updatesigma:
+            np.testing.assert_array_equal(_bits(s2), _bits(o.s2chain), err_msg=str(ckw))
+        assert e.rng(c)[0] == o.rng_n, ckw
+        cnt = e.counters(c)
+        assert (cnt["stayed"], cnt["bndstayed"], cnt["draccepted"], cnt["drtries"], cnt["erstayed"]) == \
+               (o.stayed, o.bndstayed, o.draccepted, o.drtries, o.erstayed), ckw
+    e.close()
