@@ -703,7 +703,6 @@ int mcmcx_init(mcmcx_handle h)
     if (info != 0) return fail(-32, "could not factor the initial covariance");      // MCMC_init.F90:110
     h->S02eff = (c.S02 <= 0.0) ? h->sigma2 : c.S02;                                   // MCMC_init.F90:114-116
     double shape = c.N0 / 2.0 + (double)h->nobs / 2.0;
-    if (c.updatesigma && shape < 1.0) return fail(-33, "updatesigma with gamma shape < 1 is not available in the device engine");
 
     EngineDev &E = h->E;
     E.d = d; E.P = P; E.ntiles = T;
@@ -713,8 +712,6 @@ int mcmcx_init(mcmcx_handle h)
     E.greedy = c.greedy; E.adapthist = c.adapthist; E.initcmatn = (double)c.initcmatn;
     E.dodr = h->dodr; E.updatesigma = c.updatesigma; E.doadapt = c.doadapt; E.doburnin = c.doburnin; E.burnintime = c.burnintime;
     E.gam_shape = shape; E.N0S02 = c.N0 * h->S02eff;
-    if (c.updatesigma) for (int j = 0; j < ny; ++j) if (c.N0 / 2.0 + (double)h->nobsv[j] / 2.0 < 1.0)
-        return fail(-33, "updatesigma with gamma shape < 1 is not available in the device engine");
     E.ny = ny; E.hs = d + ny; E.ssv = E.s2v = E.ss2v = nullptr; E.gshapev = nullptr;
     E.alphatarget = c.alphatarget; E.drscale = c.drscale; E.scalelimit = c.scalelimit; E.scalefactor = c.scalefactor;
     E.k0 = c.seed; E.chain_id0 = c.chain_id0;

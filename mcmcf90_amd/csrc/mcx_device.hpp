@@ -209,9 +209,13 @@ MCX_DEV double rng_normal(Rng &g)
     return a;
 }
 
-// random_gamma / gammar_mt for shape a >= 1 (mcmcrand.F90:86-162); a < 1 is rejected at init.
+// random_gamma / gammar_mt (mcmcrand.F90:86-162).  a < 1 (:102-105): u first, then gammar_mt(1+a, b) * u**(1/a), with
+// u**e pinned as exp(e log u) (oracle/mcx_math.h).
 MCX_DEV double rng_gamma(Rng &g, double a, double b)
 {
+    double boost = 1.0;
+    const bool small = a < 1.0;
+    if (small) { double u0 = rng_uniform(g); boost = d_exp((1.0 / a) * d_log(u0)); a = 1.0 + a; }
     double d = a - 1.0 / 3.0;
     double c = 1.0 / sqrt(9.0 * d);
     double x, v, u;
@@ -223,7 +227,8 @@ MCX_DEV double rng_gamma(Rng &g, double a, double b)
         if (u < 1.0 - 0.0331 * (x2 * x2)) break;
         if (d_log(u) < 0.5 * x2 + d * (1.0 - v + d_log(v))) break;
     }
-    return b * d * v;
+    const double y = b * d * v;
+    return small ? y * boost : y;
 }
 
 // ---------------------------------------------------------------- small BLAS pieces (pinned netlib forms)

@@ -14,6 +14,10 @@
  * tests/test_oracle_math.py measures it against the host libm.
  *
  * sqrt() and '/' are IEEE correctly-rounded on both sides and need no pinning.
+ *
+ * u**e (mcmcrand.F90:105, 138: the shape < 1 branch of the gamma sampler, u uniform in [0,1)) is pinned as
+ * exp(e * log(u)) on the two functions above: within |e log u| ulp of libm's pow (< 1e-13 relative for the shapes a
+ * run can produce), exactly reproducible on the device.
  */
 #ifndef MCX_ORACLE_MATH_H
 #define MCX_ORACLE_MATH_H
@@ -124,5 +128,7 @@ static inline double mcxm_exp(double x)
         return y * twom1000;
     }
 }
+
+static inline double mcxm_powu(double u, double e) { return mcxm_exp(e * mcxm_log(u)); }
 
 #endif

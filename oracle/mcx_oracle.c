@@ -115,7 +115,7 @@ static double gammar_mt(mcxo_rng *g, double a, double b)
     double aa = a, bb = b;
     if (aa < 1.0) {                                   /* :136-146 (prints a warning in the reference) */
         double u = mcxo_uniform(g);
-        bb = bb * pow(u, 1.0 / aa);
+        bb = bb * mcxm_powu(u, 1.0 / aa);
         aa = aa + 1.0;
     }
     double d = aa - 1.0 / 3.0;
@@ -134,10 +134,10 @@ static double gammar_mt(mcxo_rng *g, double a, double b)
 double mcxo_gamma(mcxo_rng *g, double a, double b)
 {
     if (a < 1.0) {                                    /* random_gamma, mcmcrand.F90:102-105 (the route MCMC_DRAM.F90:201 takes):
-                                                         u first, then gammar_mt(1+a, b) * u**(1/a).  The device engine
-                                                         refuses updatesigma with shape < 1. */
+                                                         u first, then gammar_mt(1+a, b) * u**(1/a); u**e pinned in
+                                                         mcx_math.h */
         double u = mcxo_uniform(g);
-        return gammar_mt(g, 1.0 + a, b) * pow(u, 1.0 / a);
+        return gammar_mt(g, 1.0 + a, b) * mcxm_powu(u, 1.0 / a);
     }
     return gammar_mt(g, a, b);
 }

@@ -377,3 +377,33 @@ def test_random_configuration_response_columns_device_target(oracle, seed):
         assert (cnt["stayed"], cnt["bndstayed"], cnt["draccepted"], cnt["drtries"], cnt["erstayed"]) == \
                (o.stayed, o.bndstayed, o.draccepted, o.drtries, o.erstayed), ckw
     e.close()
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_configuration_gamma_shape_below_one(oracle, seed):
+    """updatesigma with N0/2 + nobs/2 < 1: random_gamma's boost branch, gammar_mt(1+a, b) * u**(1/a) (mcmcrand.F90:102-105)."""
+    ckw, pkw = _draw(40000 + seed)
+    r = np.random.default_rng(41000 + seed)
+    ckw.update(updatesigma=1, N0=float(r.choice([0.2, 0.5, 0.9])), S02=float(r.choice([0.0, 0.8])))
+    pkw.update(sigma2=float(r.uniform(0.3, 1.5)), nobs=1)
+    _check_against_oracle(oracle, ckw, pkw, seed)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_response_columns_gamma_shape_below_one_in_one_column(oracle, seed):
+    from mcmcf90_amd import engine_from_problem
+    ckw, pkw = _draw_cols(600 + seed)
+    ckw.update(updatesigma=1, N0=0.5)
+    nobs = np.asarray(pkw["nobs"]).copy(); nobs[0] = 1
+    pkw["nobs"] = nobs
+    cfg = oracle.make_cfg(**ckw)
+    prob = oracle.Problem(**pkw)
+    e = engine_from_problem(ckw, pkw, nchains=5, record_chain=1, chain_id0=seed)
+    e.init(); e.run()
+    for c in (0, 4):
+        o = oracle.run_chain(cfg, prob, chain_id=seed + c, continue_on_downdate_fail=True)
+        ch, ss, s2 = e.chain(c)
+        np.testing.assert_array_equal(_bits(ch), _bits(o.chain), err_msg=str(ckw))
+        np.testing.assert_array_equal(_bits(s2), _bits(o.s2chain), err_msg=str(ckw))
+        assert e.rng(c)[0] == o.rng_n, ckw
+    e.close()
