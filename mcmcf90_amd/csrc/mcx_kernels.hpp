@@ -410,37 +410,77 @@ MCX_DEV void gemvT_panels(const double *Mt, const double *x_t, double *out_t, in
 MCX_DEV void symsvd_dev(double *Gt, double *Vt, double *sv_t, int lane, int d, bool act)
 {
     for (int j = 0; j < d; ++j) for (int i = 0; i < d; ++i) if (act) GV(Vt, (size_t)j * d + i) = (i == j) ? 1.0 : 0.0;
+    // One pass over k per pair: the rotation of (g_p, g_q) and (v_p, v_q) and, on the fly, the three dot products of
+    // the NEXT pair (p, q+1), which see g_p as this rotation leaves it.  Every chain of operations is the one of
+    // oracle/mcx_svd.h (same operands, same order); only the loops are merged, so that a pair costs one latency-bound
+    // sweep over the columns instead of three.  A pair nobody in the wave rotates leaves g_p alone: alpha carries over
+    // (the same fma chain over the same data), beta and gamma of the next pair take one read of g_p and g_{q+1}.
     for (int sweep = 0; sweep < 60; ++sweep) {
         bool rotated = false;
         for (int p = 0; p < d - 1; ++p) {
-            for (int q = p + 1; q < d; ++q) {
-                double *gp = Gt + (size_t)p * d * 64, *gq = Gt + (size_t)q * d * 64;
-                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+            double *gp = Gt + (size_t)p * d * 64, *vp = Vt + (size_t)p * d * 64;
+            double alpha = 0.0, beta = 0.0, gamma = 0.0;
+            {
+                const double *gq = gp + (size_t)d * 64;
 #pragma unroll 4
                 for (int k = 0; k < d; ++k) {
                     double a = GV(gp, k), b = GV(gq, k);
                     alpha = dfma(a, a, alpha); beta = dfma(b, b, beta); gamma = dfma(a, b, gamma);
                 }
-                bool rot = act && (gamma != 0.0) && !(fabs(gamma) <= 1e-15 * sqrt(alpha * beta));
+            }
+            for (int q = p + 1; q < d; ++q) {
+                double *gq = Gt + (size_t)q * d * 64, *vq = Vt + (size_t)q * d * 64;
+                const bool more = q + 1 < d;
+                const double *gn = more ? gq + (size_t)d * 64 : gq;          // column q+1 (unused when !more)
+                const bool rot = act && (gamma != 0.0) && !(fabs(gamma) <= 1e-15 * sqrt(alpha * beta));
+                double na = 0.0, nb = 0.0, ng = 0.0;
                 if (__any(rot)) {
+                    double c = 1.0, sn = 0.0;
                     if (rot) {
                         rotated = true;
                         double zeta = (beta - alpha) / (2.0 * gamma);
                         double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                        double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
-#pragma unroll 4
-                        for (int k = 0; k < d; ++k) {
-                            double a = GV(gp, k), b = GV(gq, k);
-                            GV(gp, k) = c * a - sn * b; GV(gq, k) = sn * a + c * b;
+                        c = 1.0 / sqrt(1.0 + t * t); sn = c * t;
+                    }
+                    // blocks of SB rows, the next block's fifteen loads issued before this block's stores: the
+                    // columns alias as far as the compiler can tell, so without this every row would wait for its own loads
+                    constexpr int SB = 8;
+                    double A[SB], B[SB], Ee[SB], VA[SB], VB[SB];
+#pragma unroll
+                    for (int u = 0; u < SB; ++u) {
+                        const int k = u < d ? u : d - 1;
+                        A[u] = GV(gp, k); B[u] = GV(gq, k); Ee[u] = GV(gn, k); VA[u] = GV(vp, k); VB[u] = GV(vq, k);
+                    }
+                    for (int k0 = 0; k0 < d; k0 += SB) {
+                        double A2[SB], B2[SB], E2[SB], VA2[SB], VB2[SB];
+#pragma unroll
+                        for (int u = 0; u < SB; ++u) {
+                            int k = k0 + SB + u; k = k < d ? k : d - 1;
+                            A2[u] = GV(gp, k); B2[u] = GV(gq, k); E2[u] = GV(gn, k); VA2[u] = GV(vp, k); VB2[u] = GV(vq, k);
                         }
-                        double *vp = Vt + (size_t)p * d * 64, *vq = Vt + (size_t)q * d * 64;
-#pragma unroll 4
-                        for (int k = 0; k < d; ++k) {
-                            double a = GV(vp, k), b = GV(vq, k);
-                            GV(vp, k) = c * a - sn * b; GV(vq, k) = sn * a + c * b;
+#pragma unroll
+                        for (int u = 0; u < SB; ++u) {
+                            const int k = k0 + u;
+                            if (k < d) {
+                                const double a = A[u], b = B[u], e = Ee[u], va = VA[u], vb = VB[u];
+                                const double ra = c * a - sn * b, rb = sn * a + c * b;
+                                const double aa = rot ? ra : a;
+                                if (rot) { GV(gp, k) = ra; GV(gq, k) = rb; GV(vp, k) = c * va - sn * vb; GV(vq, k) = sn * va + c * vb; }
+                                na = dfma(aa, aa, na); nb = dfma(e, e, nb); ng = dfma(aa, e, ng);
+                            }
                         }
+#pragma unroll
+                        for (int u = 0; u < SB; ++u) { A[u] = A2[u]; B[u] = B2[u]; Ee[u] = E2[u]; VA[u] = VA2[u]; VB[u] = VB2[u]; }
+                    }
+                } else if (more) {
+                    na = alpha;
+#pragma unroll 8
+                    for (int k = 0; k < d; ++k) {
+                        const double a = GV(gp, k), e = GV(gn, k);
+                        nb = dfma(e, e, nb); ng = dfma(a, e, ng);
                     }
                 }
+                alpha = na; beta = nb; gamma = ng;
             }
         }
         if (!__any(rotated)) break;
