@@ -159,55 +159,58 @@ MCX_DEV double target_ss(const DevTarget &t, int d, int lane, const double *c_t,
     // Gaussian: ss = v' Lam v in the order of mcxt_ss_gauss (oracle/mcx_targets.h): y_i = fma chain over j from 0; per
     // block of 16 rows four partial chains q_k over the rows 16t + k + 4r; ss = running sum of the q_k.
     if (WIDE && t.kind == TGT_GAUSS && d <= 8 * PW) {
-        // All row accumulators (up to 8 panels of PW) stay in registers while the columns stream by once, so
-        // the candidate is read once instead of once per row panel.
-        constexpr int NPM = 8;
-        double y[NPM][PW];
-#pragma unroll
-        for (int p = 0; p < NPM; ++p)
-#pragma unroll
-            for (int u = 0; u < PW; ++u) y[p][u] = 0.0;
+        // Row accumulators of NPM panels of PW (32 rows) stay in registers while the columns stream by, so the candidate
+        // is read once per 32 rows instead of once per row panel (all 64 rows at once spills).
+        constexpr int NPM = 4;
         const int np = (d + PW - 1) / PW;
-        for (int J0 = 0; J0 < d; J0 += PW) {
-            const int nc = (d - J0) < PW ? (d - J0) : PW;
-            double v[PW];
+        for (int G0 = 0; G0 < np; G0 += NPM) {
+            double y[NPM][PW];
 #pragma unroll
-            for (int w = 0; w < PW; ++w) { int j = J0 + (w < nc ? w : nc - 1); v[w] = GV(c_t, j) - g_mu[j]; }
+            for (int p = 0; p < NPM; ++p)
 #pragma unroll
-            for (int w = 0; w < PW; ++w) {
-                if (w < nc) {
-                    const double *__restrict__ lcol = g_lamT + (size_t)(J0 + w) * d;     // lam(0..d-1, J0+w)
+                for (int u = 0; u < PW; ++u) y[p][u] = 0.0;
+            for (int J0 = 0; J0 < d; J0 += PW) {
+                const int nc = (d - J0) < PW ? (d - J0) : PW;
+                double v[PW];
 #pragma unroll
-                    for (int p = 0; p < NPM; ++p) {
-                        if (p < np) {
+                for (int w = 0; w < PW; ++w) { int j = J0 + (w < nc ? w : nc - 1); v[w] = GV(c_t, j) - g_mu[j]; }
 #pragma unroll
-                            for (int u = 0; u < PW; ++u) y[p][u] = dfma(lcol[p * PW + u], v[w], y[p][u]);
+                for (int w = 0; w < PW; ++w) {
+                    if (w < nc) {
+                        const double *__restrict__ lcol = g_lamT + (size_t)(J0 + w) * d + (size_t)G0 * PW;     // lam(32 G0/4 .., J0+w)
+#pragma unroll
+                        for (int p = 0; p < NPM; ++p) {
+                            if (G0 + p < np) {
+#pragma unroll
+                                for (int u = 0; u < PW; ++u) y[p][u] = dfma(lcol[p * PW + u], v[w], y[p][u]);
+                            }
                         }
                     }
                 }
             }
-        }
 #pragma unroll
-        for (int tb = 0; tb < NPM / 2; ++tb) {
-            if (2 * tb < np) {
-                double q[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int tb = 0; tb < NPM / 2; ++tb) {
+                if (G0 + 2 * tb < np) {
+                    double q[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int p = 2 * tb + h;
-                    if (p < np) {
-                        const int I0 = p * PW;
-                        const int nr = (d - I0) < PW ? (d - I0) : PW;
-                        double vi[PW];
+                    for (int h = 0; h < 2; ++h) {
+                        const int p = 2 * tb + h;
+                        if (G0 + p < np) {
+                            const int I0 = (G0 + p) * PW;
+                            const int nr = (d - I0) < PW ? (d - I0) : PW;
+                            double vi[PW];
 #pragma unroll
-                        for (int u = 0; u < PW; ++u) { int i = I0 + (u < nr ? u : nr - 1); vi[u] = GV(c_t, i) - g_mu[i]; }
+                            for (int u = 0; u < PW; ++u) { int i = I0 + (u < nr ? u : nr - 1); vi[u] = GV(c_t, i) - g_mu[i]; }
 #pragma unroll
-                        for (int u = 0; u < PW; ++u) {
-                            if (u < nr) { if (h == 0 && u < 4) q[u & 3] = y[p][u] * vi[u]; else q[u & 3] = dfma(y[p][u], vi[u], q[u & 3]); }
+                            for (int u = 0; u < PW; ++u) {
+                                if (u < nr) { if (h == 0 && u < 4) q[u & 3] = y[p][u] * vi[u]; else q[u & 3] = dfma(y[p][u], vi[u], q[u & 3]); }
+                            }
                         }
                     }
-                }
+                    const int B0 = (G0 + 2 * tb) * PW;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) if (16 * tb + k < d) ss = (tb == 0 && k == 0) ? q[0] : ss + q[k];
+                    for (int k = 0; k < 4; ++k) if (B0 + k < d) ss = (B0 == 0 && k == 0) ? q[0] : ss + q[k];
+                }
             }
         }
     } else if (t.kind == TGT_GAUSS) {
