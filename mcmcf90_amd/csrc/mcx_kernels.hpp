@@ -148,6 +148,14 @@ MCX_DEV void sweep(const double *rowp, int lane, int k0, int n, F &&f)
 // Gaussian target works on 16x16 register panels: y[16] (rows) x v[16] (columns), precision matrix
 // through scalar loads of its transpose (lamT[j*d + i] = lam(i,j), padded by PW doubles).
 constexpr int PW = 8;     // panel width: columns (or rows) of per-lane state held in registers
+#ifndef MCX_RW
+#define MCX_RW 10
+#endif
+#ifndef MCX_TW
+#define MCX_TW 10
+#endif
+constexpr int RW = MCX_RW;  // panel width of the RAM sweep (d = 50: five full panels)
+constexpr int TW = MCX_TW;  // panel width of the per-chain triangular product
 
 // WIDE: keep every row accumulator in registers and read the candidate once (pays when the kernel is
 // bandwidth-bound: RAM); otherwise one row panel at a time (fewer registers: pooled / AM / DR kernels).
@@ -326,34 +334,34 @@ MCX_DEV double gen_normals(Rng &g, double *zs_t, int lane, int d, bool participa
 // contiguous PW x 512-byte segment, so the factor is read exactly once.
 MCX_DEV void trmv_panels(const double *Rt, const double *z_t, double *P_t, const double *theta_t, int lane, int d, bool act)
 {
-    for (int J0 = 0; J0 < d; J0 += PW) {
-        const int nw = (d - J0) < PW ? (d - J0) : PW;
-        double P[PW];
+    for (int J0 = 0; J0 < d; J0 += TW) {
+        const int nw = (d - J0) < TW ? (d - J0) : TW;
+        double P[TW];
 #pragma unroll
-        for (int u = 0; u < PW; ++u) P[u] = 0.0;
+        for (int u = 0; u < TW; ++u) P[u] = 0.0;
         if (act) {
 #pragma unroll 2
             for (int i = 0; i < J0; ++i) {                               // rows above the diagonal block
                 const double zi = GV(z_t, i);
                 const double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
-                double r[PW];
+                double r[TW];
 #pragma unroll
-                for (int u = 0; u < PW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
+                for (int u = 0; u < TW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
 #pragma unroll
-                for (int u = 0; u < PW; ++u) P[u] = dfma(r[u], zi, P[u]);
+                for (int u = 0; u < TW; ++u) P[u] = dfma(r[u], zi, P[u]);
             }
             for (int i = J0; i < J0 + nw; ++i) {                         // diagonal block: elements u >= ui
                 const double zi = GV(z_t, i);
                 const double *seg = Rt + (size_t)rowstart(i, d) * 64;
                 const int ui = i - J0, m = d - 1 - i;
-                double r[PW];
+                double r[TW];
 #pragma unroll
-                for (int u = 0; u < PW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
+                for (int u = 0; u < TW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
 #pragma unroll
-                for (int u = 0; u < PW; ++u) { double nv = dfma(r[u], zi, P[u]); P[u] = (u >= ui) ? nv : P[u]; }
+                for (int u = 0; u < TW; ++u) { double nv = dfma(r[u], zi, P[u]); P[u] = (u >= ui) ? nv : P[u]; }
             }
 #pragma unroll
-            for (int u = 0; u < PW; ++u) if (u < nw) GV(P_t, J0 + u) = GV(theta_t, J0 + u) + P[u];   // newpar = oldpar + R'z
+            for (int u = 0; u < TW; ++u) if (u < nw) GV(P_t, J0 + u) = GV(theta_t, J0 + u) + P[u];   // newpar = oldpar + R'z
         }
     }
 }
@@ -559,11 +567,11 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
     const bool down = act && !(a >= 0.0);
     if (__any(up)) {
         if (up) {
-            for (int J0 = 0; J0 < d; J0 += PW) {
-                const int nw = (d - J0) < PW ? (d - J0) : PW;
-                double x[PW], P[PW];
+            for (int J0 = 0; J0 < d; J0 += RW) {
+                const int nw = (d - J0) < RW ? (d - J0) : RW;
+                double x[RW], P[RW];
 #pragma unroll
-                for (int u = 0; u < PW; ++u) { x[u] = GV(zc_t, J0 + (u < nw ? u : nw - 1)) / su * a; P[u] = 0.0; }   // x = u/sum(u**2)*a
+                for (int u = 0; u < RW; ++u) { x[u] = GV(zc_t, J0 + (u < nw ? u : nw - 1)) / su * a; P[u] = 0.0; }   // x = u/sum(u**2)*a
 #pragma unroll 2
                 for (int i = 0; i < J0; ++i) {                           // rotations of the rows above
                     const bool inl = lc && i < NLC;
@@ -571,11 +579,11 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                     const double sn = inl ? lc[(2 * i + 1) * 64 + lane] : GV(cs_t, 2 * i + 1);
                     const double zi = fuse ? GV(zn_t, i) : 0.0;
                     double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
-                    double r[PW];
+                    double r[RW];
 #pragma unroll
-                    for (int u = 0; u < PW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
+                    for (int u = 0; u < RW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
 #pragma unroll
-                    for (int u = 0; u < PW; ++u) {
+                    for (int u = 0; u < RW; ++u) {
                         double t = c * r[u] + sn * x[u];
                         x[u] = c * x[u] - sn * r[u];
                         if (u < nw) STNT(seg, u, t);
@@ -586,19 +594,19 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                     double *seg = Rt + (size_t)rowstart(i, d) * 64;
                     const int ui = i - J0, m = d - 1 - i;
                     const double zi = fuse ? GV(zn_t, i) : 0.0;
-                    double r[PW];
+                    double r[RW];
 #pragma unroll
-                    for (int u = 0; u < PW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
+                    for (int u = 0; u < RW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
                     double xi = x[0];
 #pragma unroll
-                    for (int u = 1; u < PW; ++u) xi = (u == ui) ? x[u] : xi;
+                    for (int u = 1; u < RW; ++u) xi = (u == ui) ? x[u] : xi;
                     double rr, c, sn;
                     d_rotg(GV(seg, 0), xi, rr, c, sn);
                     GV(seg, 0) = rr;
                     if (lc && i < NLC) { lc[(2 * i) * 64 + lane] = c; lc[(2 * i + 1) * 64 + lane] = sn; }
                     else { GV(cs_t, 2 * i) = c; GV(cs_t, 2 * i + 1) = sn; }
 #pragma unroll
-                    for (int u = 0; u < PW; ++u) {
+                    for (int u = 0; u < RW; ++u) {
                         const bool off = (u > ui) && (u < nw);
                         double t = c * r[u] + sn * x[u];
                         double nx = c * x[u] - sn * r[u];
@@ -611,7 +619,7 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                 }
                 if (fuse) {                              // next candidate = theta + R_new' z_next (MCMC_DRAM.F90:29)
 #pragma unroll
-                    for (int u = 0; u < PW; ++u) if (u < nw) GV(P_t, J0 + u) = GV(theta_t, J0 + u) + P[u];
+                    for (int u = 0; u < RW; ++u) if (u < nw) GV(P_t, J0 + u) = GV(theta_t, J0 + u) + P[u];
                 }
             }
         }
@@ -619,36 +627,36 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
     if (__any(down)) {
         if (down) {
             // solve R'a = x, x = -u/sum(u**2)*a (dchdd.f:141-148); the solution goes to cs_t[2i+1]
-            for (int J0 = 0; J0 < d; J0 += PW) {
-                const int nw = (d - J0) < PW ? (d - J0) : PW;
-                double acc[PW];
+            for (int J0 = 0; J0 < d; J0 += RW) {
+                const int nw = (d - J0) < RW ? (d - J0) : RW;
+                double acc[RW];
 #pragma unroll
-                for (int u = 0; u < PW; ++u) acc[u] = 0.0;
+                for (int u = 0; u < RW; ++u) acc[u] = 0.0;
 #pragma unroll 2
                 for (int i = 0; i < J0; ++i) {
                     const double si = GV(cs_t, 2 * i + 1);
                     const double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
-                    double r[PW];
+                    double r[RW];
 #pragma unroll
-                    for (int u = 0; u < PW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
+                    for (int u = 0; u < RW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
 #pragma unroll
-                    for (int u = 0; u < PW; ++u) acc[u] = dfma(r[u], si, acc[u]);
+                    for (int u = 0; u < RW; ++u) acc[u] = dfma(r[u], si, acc[u]);
                 }
                 for (int i = J0; i < J0 + nw; ++i) {
                     const double *seg = Rt + (size_t)rowstart(i, d) * 64;
                     const int ui = i - J0, m = d - 1 - i;
-                    double r[PW];
+                    double r[RW];
 #pragma unroll
-                    for (int u = 0; u < PW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
+                    for (int u = 0; u < RW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
                     double ai = acc[0];
 #pragma unroll
-                    for (int u = 1; u < PW; ++u) ai = (u == ui) ? acc[u] : ai;
+                    for (int u = 1; u < RW; ++u) ai = (u == ui) ? acc[u] : ai;
                     double xi = -(GV(zc_t, i) / su * a);
                     double si = xi - ai;
                     si = si / GV(seg, 0);
                     GV(cs_t, 2 * i + 1) = si;
 #pragma unroll
-                    for (int u = 0; u < PW; ++u) { double na = dfma(r[u], si, acc[u]); acc[u] = (u > ui) ? na : acc[u]; }
+                    for (int u = 0; u < RW; ++u) { double na = dfma(r[u], si, acc[u]); acc[u] = (u > ui) ? na : acc[u]; }
                 }
             }
             // norm = dnrm2(p, s), classic scale/ssq form (dchdd.f:149)
@@ -681,20 +689,20 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                     GV(cs_t, 2 * k + 1) = bb / nn;
                     alpha = scale * nn;
                 }
-                for (int J0 = 0; J0 < d; J0 += PW) {  // dchdd.f:171-179, each column from its diagonal up
-                    const int nw = (d - J0) < PW ? (d - J0) : PW;
-                    double xx[PW];
+                for (int J0 = 0; J0 < d; J0 += RW) {  // dchdd.f:171-179, each column from its diagonal up
+                    const int nw = (d - J0) < RW ? (d - J0) : RW;
+                    double xx[RW];
 #pragma unroll
-                    for (int u = 0; u < PW; ++u) xx[u] = 0.0;
+                    for (int u = 0; u < RW; ++u) xx[u] = 0.0;
                     for (int i = J0 + nw - 1; i >= J0; --i) {            // diagonal block, rows descending
                         double *seg = Rt + (size_t)rowstart(i, d) * 64;
                         const int ui = i - J0, m = d - 1 - i;
                         const double ci = GV(cs_t, 2 * i), si = GV(cs_t, 2 * i + 1);
-                        double r[PW];
+                        double r[RW];
 #pragma unroll
-                        for (int u = 0; u < PW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
+                        for (int u = 0; u < RW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
 #pragma unroll
-                        for (int u = 0; u < PW; ++u) {
+                        for (int u = 0; u < RW; ++u) {
                             const bool on = (u >= ui) && (u < nw);
                             double t = ci * xx[u] + si * r[u];
                             double nr = ci * r[u] - si * xx[u];
@@ -706,11 +714,11 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                     for (int i = J0 - 1; i >= 0; --i) {                  // rows above, descending
                         double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
                         const double ci = GV(cs_t, 2 * i), si = GV(cs_t, 2 * i + 1);
-                        double r[PW];
+                        double r[RW];
 #pragma unroll
-                        for (int u = 0; u < PW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
+                        for (int u = 0; u < RW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
 #pragma unroll
-                        for (int u = 0; u < PW; ++u) {
+                        for (int u = 0; u < RW; ++u) {
                             double t = ci * xx[u] + si * r[u];
                             if (u < nw) STNT(seg, u, ci * r[u] - si * xx[u]);
                             xx[u] = t;
