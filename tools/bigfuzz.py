@@ -1,0 +1,35 @@
+"""One-off extended fuzz (GPU box): the generators of tests/test_gpu_fuzz.py over seeds outside the test suite's range --
+the base option space, method='ram' with condmax > 0, and updatesigma with gamma shape < 1 -- device vs oracle, bit for
+bit.  python tools/bigfuzz.py [first_seed=300] [last_seed=2300]   (round 1: 3167 configurations, 0 failures)"""
+import importlib.util, sys, os, time, traceback
+import numpy as np
+sys.path.insert(0, os.getcwd())
+spec = importlib.util.spec_from_file_location("g", "tests/test_gpu_fuzz.py"); g = importlib.util.module_from_spec(spec); spec.loader.exec_module(g)
+from oracle import pyoracle as po; po.build()
+import torch; torch.cuda.init()
+bad = []
+t0 = time.time()
+n = 0
+A = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 2300
+for seed in range(A, B):
+    for name, draw in (("base", g._draw), ("ramsvd", g._draw_ram_svd)):
+        if name == "ramsvd" and seed % 4: continue
+        try:
+            ckw, pkw = draw(seed)
+            g._check_against_oracle(po, ckw, pkw, seed); n += 1
+        except Exception as e:
+            bad.append((name, seed, repr(e)[:200]))
+    if seed % 3 == 0:
+        try:
+            ckw, pkw = g._draw(40000 + seed)
+            r = np.random.default_rng(41000 + seed)
+            ckw.update(updatesigma=1, N0=float(r.choice([0.2, 0.5, 0.9])), S02=float(r.choice([0.0, 0.8])))
+            pkw.update(sigma2=float(r.uniform(0.3, 1.5)), nobs=1)
+            g._check_against_oracle(po, ckw, pkw, seed); n += 1
+        except Exception as e:
+            bad.append(("gamma", seed, repr(e)[:200]))
+    if time.time() - t0 > 1500: 
+        print("time limit at seed", seed); break
+print("configs checked", n, "failures", len(bad))
+for b in bad[:20]: print(b)
