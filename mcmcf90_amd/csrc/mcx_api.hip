@@ -1170,7 +1170,12 @@ static int pooled_moments_launch(mcmcx_engine *h, double *dev_dst)
     HIPCHK(hipSetDevice(h->cfg.device));
     const int len = 1 + h->d + h->P, T = h->ntiles;
     hipLaunchKernelGGL(moments_kernel, dim3(T), dim3(64), 0, h->stream, h->E, h->d_moments, h->cfg.nchains);
-    hipLaunchKernelGGL(moments_tree_kernel, dim3((len + 255) / 256), dim3(256), 0, h->stream, h->d_moments, T, len, dev_dst);
+    for (long long stride = 1;; stride *= 64) {                            // six levels of the fixed pairwise tree per launch
+        const long long groups = (T + 64 * stride - 1) / (64 * stride);
+        hipLaunchKernelGGL(moments_tree_kernel, dim3((len + 255) / 256, (unsigned)groups), dim3(256), 0, h->stream, h->d_moments, T, len,
+                           (int)stride, dev_dst);
+        if (groups == 1) break;
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }

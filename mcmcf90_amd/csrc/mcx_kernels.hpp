@@ -2396,17 +2396,31 @@ __global__ __launch_bounds__(64) void moments_kernel(EngineDev E, double *out, i
     }
 }
 
-// Finish the pooled sum over tiles in the same fixed pairwise tree (adjacent tiles first), one
-// thread per moment: v[0..len) of tile 0 holds the result.  Deterministic and independent of how
-// tiles are later grouped onto GPUs, as long as every GPU owns a power-of-two aligned block.
-__global__ void moments_tree_kernel(double *v, int ntiles, int len, double *dst)
+// Finish the pooled sum over tiles in the same fixed pairwise tree (adjacent tiles first):
+//     for s = 1, 2, 4, ...: for t = 0, 2s, 4s, ... with t + s < ntiles: v[t] += v[t + s]
+// v[0..len) of tile 0 ends up holding the result.  Deterministic and independent of how tiles are later grouped onto
+// GPUs, as long as every GPU owns a power-of-two aligned block.  One launch runs six levels of the tree: thread
+// (group g, moment k) loads the 64 partial sums v[(64 g + i) stride], i < 64, adds them up in registers in tree order
+// and stores the result where the tree leaves it, v[64 g stride]; the host repeats with stride 64, 4096, ... until one
+// group is left.  Loads are coalesced along k and independent of each other.
+__global__ __launch_bounds__(256) void moments_tree_kernel(double *v, int ntiles, int len, int stride, double *dst)
 {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const long long t0 = (long long)blockIdx.y * 64 * stride;
     if (k >= len) return;
-    for (int s = 1; s < ntiles; s <<= 1)
-        for (int t = 0; t + s < ntiles; t += 2 * s)
-            v[(size_t)t * len + k] = v[(size_t)t * len + k] + v[(size_t)(t + s) * len + k];
-    if (dst) dst[k] = v[k];
+    double a[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const long long t = t0 + (long long)i * stride;
+        a[i] = (t < ntiles) ? v[(size_t)t * len + k] : 0.0;
+    }
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1)
+#pragma unroll
+        for (int i = 0; i + s < 64; i += 2 * s)
+            if (t0 + (long long)(i + s) * stride < ntiles) a[i] = a[i] + a[i + s];
+    v[(size_t)t0 * len + k] = a[0];
+    if (dst && gridDim.y == 1) dst[k] = a[0];
 }
 
 // ---------------------------------------------------------------- debug probes of the device primitives
