@@ -33,7 +33,7 @@ enum { M_DRAM = 0, M_RAM = 1, M_ER = 3 };
 enum { S_SS1 = 0, S_PRI1, S_SIGMA2, S_ALPHA12, S_SAVEDY, S_WSUM, NSCAL };
 // per-chain integer slots (u32)
 enum { I_SAVED = 0, I_STAYED, I_BNDSTAYED, I_DRACC, I_DRTRIES, I_CHAININD, I_CURCOUNT, I_STATUS,
-       I_LASTFREQ, I_BASECNT, I_WINSTART, I_INFO, I_ERSTAYED, NICTR };
+       I_LASTFREQ, I_BASECNT, I_WINSTART, I_INFO, I_ERSTAYED, I_PDESC, NICTR };   // I_PDESC: 1 after a successful RAM downdate
 
 // status bits
 enum { ST_RAM_DOWNDATE_FAIL = 1, ST_CHOL_FAIL = 2, ST_POTRI_FAIL = 4 };
@@ -332,36 +332,77 @@ MCX_DEV double gen_normals(Rng &g, double *zs_t, int lane, int d, bool participa
 // dtrmv('U','T','N') (matutils.F90:108-109): p_j = sum_{i<=j} R(i,j) z_i, each dot product ascending in i
 // as one fma chain from 0.  Column panels of PW accumulators in registers; every row contributes one
 // contiguous PW x 512-byte segment, so the factor is read exactly once.
-MCX_DEV void trmv_panels(const double *Rt, const double *z_t, double *P_t, const double *theta_t, int lane, int d, bool act)
+MCX_DEV void trmv_panels(const double *Rt, const double *z_t, double *P_t, const double *theta_t, int lane, int d, bool act,
+                         bool desc = false)
 {
-    for (int J0 = 0; J0 < d; J0 += TW) {
-        const int nw = (d - J0) < TW ? (d - J0) : TW;
-        double P[TW];
+    const bool asc = act && !desc, dsc = act && desc;
+    if (__any(asc)) {
+        for (int J0 = 0; J0 < d; J0 += TW) {
+            const int nw = (d - J0) < TW ? (d - J0) : TW;
+            double P[TW];
 #pragma unroll
-        for (int u = 0; u < TW; ++u) P[u] = 0.0;
-        if (act) {
+            for (int u = 0; u < TW; ++u) P[u] = 0.0;
+            if (asc) {
 #pragma unroll 2
-            for (int i = 0; i < J0; ++i) {                               // rows above the diagonal block
-                const double zi = GV(z_t, i);
-                const double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
-                double r[TW];
+                for (int i = 0; i < J0; ++i) {                               // rows above the diagonal block
+                    const double zi = GV(z_t, i);
+                    const double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
+                    double r[TW];
 #pragma unroll
-                for (int u = 0; u < TW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
+                    for (int u = 0; u < TW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
 #pragma unroll
-                for (int u = 0; u < TW; ++u) P[u] = dfma(r[u], zi, P[u]);
+                    for (int u = 0; u < TW; ++u) P[u] = dfma(r[u], zi, P[u]);
+                }
+                for (int i = J0; i < J0 + nw; ++i) {                         // diagonal block: elements u >= ui
+                    const double zi = GV(z_t, i);
+                    const double *seg = Rt + (size_t)rowstart(i, d) * 64;
+                    const int ui = i - J0, m = d - 1 - i;
+                    double r[TW];
+#pragma unroll
+                    for (int u = 0; u < TW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
+#pragma unroll
+                    for (int u = 0; u < TW; ++u) { double nv = dfma(r[u], zi, P[u]); P[u] = (u >= ui) ? nv : P[u]; }
+                }
+#pragma unroll
+                for (int u = 0; u < TW; ++u) if (u < nw) GV(P_t, J0 + u) = GV(theta_t, J0 + u) + P[u];   // newpar = oldpar + R'z
             }
-            for (int i = J0; i < J0 + nw; ++i) {                         // diagonal block: elements u >= ui
-                const double zi = GV(z_t, i);
-                const double *seg = Rt + (size_t)rowstart(i, d) * 64;
-                const int ui = i - J0, m = d - 1 - i;
-                double r[TW];
+        }
+    }
+    // The proposal that follows a successful Cholesky downdate accumulates from the diagonal up (mcxo_trmv_ut_desc): this
+    // standalone form serves the cases where ram_update could not fuse it (first iteration of a launch, host callbacks).
+    if (__any(dsc)) {
+        for (int J0 = 0; J0 < d; J0 += TW) {
+            const int nw = (d - J0) < TW ? (d - J0) : TW;
+            double P[TW];
 #pragma unroll
-                for (int u = 0; u < TW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
+            for (int u = 0; u < TW; ++u) P[u] = 0.0;
+            if (dsc) {
+                for (int i = J0 + nw - 1; i >= J0; --i) {                    // diagonal block, rows descending
+                    const double zi = GV(z_t, i);
+                    const double *seg = Rt + (size_t)rowstart(i, d) * 64;
+                    const int ui = i - J0, m = d - 1 - i;
+                    double r[TW];
 #pragma unroll
-                for (int u = 0; u < TW; ++u) { double nv = dfma(r[u], zi, P[u]); P[u] = (u >= ui) ? nv : P[u]; }
+                    for (int u = 0; u < TW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
+#pragma unroll
+                    for (int u = 0; u < TW; ++u) {
+                        const double nv = (u == ui) ? r[u] * zi : dfma(r[u], zi, P[u]);
+                        P[u] = (u >= ui) ? nv : P[u];
+                    }
+                }
+#pragma unroll 2
+                for (int i = J0 - 1; i >= 0; --i) {                          // rows above, descending
+                    const double zi = GV(z_t, i);
+                    const double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
+                    double r[TW];
+#pragma unroll
+                    for (int u = 0; u < TW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
+#pragma unroll
+                    for (int u = 0; u < TW; ++u) P[u] = dfma(r[u], zi, P[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < TW; ++u) if (u < nw) GV(P_t, J0 + u) = GV(theta_t, J0 + u) + P[u];
             }
-#pragma unroll
-            for (int u = 0; u < TW; ++u) if (u < nw) GV(P_t, J0 + u) = GV(theta_t, J0 + u) + P[u];   // newpar = oldpar + R'z
         }
     }
 }
@@ -553,112 +594,99 @@ MCX_DEV void trmv_shared(const double *__restrict__ Rs, const double *z_t, doubl
 // left-looking by column panels: the PW columns' work values sit in registers, the rotations of the
 // rows above come back from a per-chain scratch vector cs_t = (c_0, s_0, c_1, s_1, ...).  Every element
 // sees the same operations in the same order as in LINPACK's column loops.
-// When `fuse` is set the update sweep also accumulates the NEXT proposal P = R_new' z_next (ascending
-// rows = the pinned dtrmv order) into P_t, so update lanes read and write the factor once per
-// iteration.  Returns true for lanes whose P_t is valid.
+// When `fuse` is set the sweeps also accumulate the NEXT proposal P = R_new' z_next into P_t -- update lanes with
+// ascending rows, downdate lanes from the diagonal up (the two pinned dtrmv orders; pdesc says
+// which one a lane's next proposal uses) -- so a wave reads and writes the factor once for its update lanes and once
+// more for its downdate lanes.  Returns true for lanes whose P_t is valid.
 // Rotations (c_i, s_i) of the first NLC rows are kept in LDS (lc), the rest in global scratch: row i's rotation is
 // re-read by every later panel, and the early rows are the ones re-read most often.
 constexpr int NLC = 19;     // 19 rows x 2 doubles x 64 lanes = 19 456 B per wave: 8 waves fill the CU's 160 KiB
 MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, double *cs_t, double *P_t,
                         const double *theta_t, int lane, int d, double a, double su, bool act, bool fuse, uint32_t &status,
-                        double *lc)
+                        double *lc, bool &pdesc)
 {
     const bool up = act && (a >= 0.0);
     const bool down = act && !(a >= 0.0);
-    if (__any(up)) {
-        if (up) {
+    // ---- pass A, rows ascending, one read of the factor for both kinds of lanes: update lanes rotate (DCHUD), write and
+    // accumulate the next proposal; downdate lanes run the forward substitution R'a = x of DCHDD (dchdd.f:141-148, x =
+    // -u/sum(u**2)*a), whose solution goes to cs_t[2i+1].  xa = DCHUD's work vector x, or the substitution's partial sums.
+    if (__any(act)) {
+        if (act) {
             for (int J0 = 0; J0 < d; J0 += RW) {
                 const int nw = (d - J0) < RW ? (d - J0) : RW;
-                double x[RW], P[RW];
+                double xa[RW], P[RW];
 #pragma unroll
-                for (int u = 0; u < RW; ++u) { x[u] = GV(zc_t, J0 + (u < nw ? u : nw - 1)) / su * a; P[u] = 0.0; }   // x = u/sum(u**2)*a
+                for (int u = 0; u < RW; ++u) { xa[u] = up ? GV(zc_t, J0 + (u < nw ? u : nw - 1)) / su * a : 0.0; P[u] = 0.0; }   // x = u/sum(u**2)*a
 #pragma unroll 2
-                for (int i = 0; i < J0; ++i) {                           // rotations of the rows above
-                    const bool inl = lc && i < NLC;
-                    const double c = inl ? lc[(2 * i) * 64 + lane] : GV(cs_t, 2 * i);
-                    const double sn = inl ? lc[(2 * i + 1) * 64 + lane] : GV(cs_t, 2 * i + 1);
-                    const double zi = fuse ? GV(zn_t, i) : 0.0;
+                for (int i = 0; i < J0; ++i) {                           // rows above the diagonal block
                     double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
                     double r[RW];
 #pragma unroll
                     for (int u = 0; u < RW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
+                    if (up) {
+                        const bool inl = lc && i < NLC;
+                        const double c = inl ? lc[(2 * i) * 64 + lane] : GV(cs_t, 2 * i);
+                        const double sn = inl ? lc[(2 * i + 1) * 64 + lane] : GV(cs_t, 2 * i + 1);
+                        const double zi = fuse ? GV(zn_t, i) : 0.0;
 #pragma unroll
-                    for (int u = 0; u < RW; ++u) {
-                        double t = c * r[u] + sn * x[u];
-                        x[u] = c * x[u] - sn * r[u];
-                        if (u < nw) STNT(seg, u, t);
-                        P[u] = dfma(t, zi, P[u]);
+                        for (int u = 0; u < RW; ++u) {
+                            double t = c * r[u] + sn * xa[u];
+                            xa[u] = c * xa[u] - sn * r[u];
+                            if (u < nw) STNT(seg, u, t);
+                            P[u] = dfma(t, zi, P[u]);
+                        }
+                    } else {
+                        const double si = GV(cs_t, 2 * i + 1);
+#pragma unroll
+                        for (int u = 0; u < RW; ++u) xa[u] = dfma(r[u], si, xa[u]);
                     }
                 }
                 for (int i = J0; i < J0 + nw; ++i) {                     // diagonal block
                     double *seg = Rt + (size_t)rowstart(i, d) * 64;
                     const int ui = i - J0, m = d - 1 - i;
-                    const double zi = fuse ? GV(zn_t, i) : 0.0;
                     double r[RW];
 #pragma unroll
                     for (int u = 0; u < RW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
-                    double xi = x[0];
+                    double xi = xa[0];
 #pragma unroll
-                    for (int u = 1; u < RW; ++u) xi = (u == ui) ? x[u] : xi;
-                    double rr, c, sn;
-                    d_rotg(GV(seg, 0), xi, rr, c, sn);
-                    GV(seg, 0) = rr;
-                    if (lc && i < NLC) { lc[(2 * i) * 64 + lane] = c; lc[(2 * i + 1) * 64 + lane] = sn; }
-                    else { GV(cs_t, 2 * i) = c; GV(cs_t, 2 * i + 1) = sn; }
+                    for (int u = 1; u < RW; ++u) xi = (u == ui) ? xa[u] : xi;
+                    if (up) {
+                        const double zi = fuse ? GV(zn_t, i) : 0.0;
+                        double rr, c, sn;
+                        d_rotg(GV(seg, 0), xi, rr, c, sn);
+                        GV(seg, 0) = rr;
+                        if (lc && i < NLC) { lc[(2 * i) * 64 + lane] = c; lc[(2 * i + 1) * 64 + lane] = sn; }
+                        else { GV(cs_t, 2 * i) = c; GV(cs_t, 2 * i + 1) = sn; }
 #pragma unroll
-                    for (int u = 0; u < RW; ++u) {
-                        const bool off = (u > ui) && (u < nw);
-                        double t = c * r[u] + sn * x[u];
-                        double nx = c * x[u] - sn * r[u];
-                        x[u] = off ? nx : x[u];
-                        if (off) STNT(seg, u - ui, t);
-                        double tp = (u == ui) ? rr : t;
-                        double np = dfma(tp, zi, P[u]);
-                        P[u] = (u >= ui && u < nw) ? np : P[u];
+                        for (int u = 0; u < RW; ++u) {
+                            const bool off = (u > ui) && (u < nw);
+                            double t = c * r[u] + sn * xa[u];
+                            double nx = c * xa[u] - sn * r[u];
+                            xa[u] = off ? nx : xa[u];
+                            if (off) STNT(seg, u - ui, t);
+                            double tp = (u == ui) ? rr : t;
+                            double np = dfma(tp, zi, P[u]);
+                            P[u] = (u >= ui && u < nw) ? np : P[u];
+                        }
+                    } else {
+                        double si = -(GV(zc_t, i) / su * a) - xi;
+                        si = si / GV(seg, 0);
+                        GV(cs_t, 2 * i + 1) = si;
+#pragma unroll
+                        for (int u = 0; u < RW; ++u) { double na = dfma(r[u], si, xa[u]); xa[u] = (u > ui) ? na : xa[u]; }
                     }
                 }
-                if (fuse) {                              // next candidate = theta + R_new' z_next (MCMC_DRAM.F90:29)
+                if (up && fuse) {                        // next candidate = theta + R_new' z_next (MCMC_DRAM.F90:29)
 #pragma unroll
                     for (int u = 0; u < RW; ++u) if (u < nw) GV(P_t, J0 + u) = GV(theta_t, J0 + u) + P[u];
                 }
             }
         }
     }
+    if (up) pdesc = false;
+    bool down_ok = false;
     if (__any(down)) {
         if (down) {
-            // solve R'a = x, x = -u/sum(u**2)*a (dchdd.f:141-148); the solution goes to cs_t[2i+1]
-            for (int J0 = 0; J0 < d; J0 += RW) {
-                const int nw = (d - J0) < RW ? (d - J0) : RW;
-                double acc[RW];
-#pragma unroll
-                for (int u = 0; u < RW; ++u) acc[u] = 0.0;
-#pragma unroll 2
-                for (int i = 0; i < J0; ++i) {
-                    const double si = GV(cs_t, 2 * i + 1);
-                    const double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
-                    double r[RW];
-#pragma unroll
-                    for (int u = 0; u < RW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
-#pragma unroll
-                    for (int u = 0; u < RW; ++u) acc[u] = dfma(r[u], si, acc[u]);
-                }
-                for (int i = J0; i < J0 + nw; ++i) {
-                    const double *seg = Rt + (size_t)rowstart(i, d) * 64;
-                    const int ui = i - J0, m = d - 1 - i;
-                    double r[RW];
-#pragma unroll
-                    for (int u = 0; u < RW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
-                    double ai = acc[0];
-#pragma unroll
-                    for (int u = 1; u < RW; ++u) ai = (u == ui) ? acc[u] : ai;
-                    double xi = -(GV(zc_t, i) / su * a);
-                    double si = xi - ai;
-                    si = si / GV(seg, 0);
-                    GV(cs_t, 2 * i + 1) = si;
-#pragma unroll
-                    for (int u = 0; u < RW; ++u) { double na = dfma(r[u], si, acc[u]); acc[u] = (u > ui) ? na : acc[u]; }
-                }
-            }
             // norm = dnrm2(p, s), classic scale/ssq form (dchdd.f:149)
             double norm;
             if (d == 1) norm = fabs(GV(cs_t, 1));
@@ -677,7 +705,10 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
             }
             if (!(norm < 1.0)) {
                 status |= ST_RAM_DOWNDATE_FAIL;      // INFO = -1: R untouched (the reference stops here)
+                pdesc = false;
             } else {
+                down_ok = true;
+                pdesc = true;
                 double alpha = sqrt(1.0 - norm * norm);
 #pragma unroll 2
                 for (int k = d - 1; k >= 0; --k) {   // dchdd.f:158-167
@@ -689,15 +720,18 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                     GV(cs_t, 2 * k + 1) = bb / nn;
                     alpha = scale * nn;
                 }
-                for (int J0 = 0; J0 < d; J0 += RW) {  // dchdd.f:171-179, each column from its diagonal up
+                // ---- pass B (dchdd.f:171-179): each column from its diagonal up; the next proposal accumulates in that
+                // same order (mcxo_trmv_ut_desc), so downdate lanes, too, read and write the factor once more and are done
+                for (int J0 = 0; J0 < d; J0 += RW) {
                     const int nw = (d - J0) < RW ? (d - J0) : RW;
-                    double xx[RW];
+                    double xx[RW], P[RW];
 #pragma unroll
-                    for (int u = 0; u < RW; ++u) xx[u] = 0.0;
+                    for (int u = 0; u < RW; ++u) { xx[u] = 0.0; P[u] = 0.0; }
                     for (int i = J0 + nw - 1; i >= J0; --i) {            // diagonal block, rows descending
                         double *seg = Rt + (size_t)rowstart(i, d) * 64;
                         const int ui = i - J0, m = d - 1 - i;
                         const double ci = GV(cs_t, 2 * i), si = GV(cs_t, 2 * i + 1);
+                        const double zi = fuse ? GV(zn_t, i) : 0.0;
                         double r[RW];
 #pragma unroll
                         for (int u = 0; u < RW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
@@ -708,27 +742,36 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                             double nr = ci * r[u] - si * xx[u];
                             if (on) STNT(seg, u - ui, nr);
                             xx[u] = on ? t : xx[u];
+                            const double np = (u == ui) ? nr * zi : dfma(nr, zi, P[u]);
+                            P[u] = on ? np : P[u];
                         }
                     }
 #pragma unroll 2
                     for (int i = J0 - 1; i >= 0; --i) {                  // rows above, descending
                         double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
                         const double ci = GV(cs_t, 2 * i), si = GV(cs_t, 2 * i + 1);
+                        const double zi = fuse ? GV(zn_t, i) : 0.0;
                         double r[RW];
 #pragma unroll
                         for (int u = 0; u < RW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
 #pragma unroll
                         for (int u = 0; u < RW; ++u) {
                             double t = ci * xx[u] + si * r[u];
-                            if (u < nw) STNT(seg, u, ci * r[u] - si * xx[u]);
+                            const double nr = ci * r[u] - si * xx[u];
+                            if (u < nw) STNT(seg, u, nr);
                             xx[u] = t;
+                            P[u] = dfma(nr, zi, P[u]);
                         }
+                    }
+                    if (fuse) {
+#pragma unroll
+                        for (int u = 0; u < RW; ++u) if (u < nw) GV(P_t, J0 + u) = GV(theta_t, J0 + u) + P[u];
                     }
                 }
             }
         }
     }
-    return up && fuse;
+    return (up || down_ok) && fuse;
 }
 
 // The same adaptation on a FULL column-major factor (condmax > 0: R is the d x d SVD factor U sqrt(s) 2.4/sqrt(d) of
@@ -854,6 +897,7 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
     uint32_t status = TIDX(E.ictr, tile, NICTR, I_STATUS, lane);
     uint32_t dracc = TIDX(E.ictr, tile, NICTR, I_DRACC, lane), drtries = TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane);
     uint32_t erstayed = TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane);
+    bool pdesc = RAM && TIDX(E.ictr, tile, NICTR, I_PDESC, lane) != 0u;   // the next proposal's dtrmv order (after a downdate: diagonal first)
 
     bool have_p = false;                          // lanes whose candidate is already in cand_t
     double su_c = gen_normals(g, zs_t + (size_t)(it0 & 1) * d * 64, lane, d, true), su_n = 0.0;
@@ -864,7 +908,7 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
         // ---- newpar = MCMC_propose(oldpar, R)
         if (POOLED) trmv_shared(g_sharedR, zc_t, cand_t, theta_t, lane, d);
         else if (E.usesvd) gemvN_panels(E.Rf + (size_t)tile * d * d * 64, zc_t, cand_t, theta_t, lane, d, true);   // matmulx(R,z)
-        else if (__any(!have_p)) trmv_panels(Rt, zc_t, cand_t, theta_t, lane, d, !have_p);
+        else if (__any(!have_p)) trmv_panels(Rt, zc_t, cand_t, theta_t, lane, d, !have_p, RAM && pdesc);
         // ---- bounds, prior, ss, alpha, reject
         bool inb = target_inbounds(E.tgt, d, lane, cand_t);
         double pri2 = target_prior(E.tgt, d, lane, cand_t);
@@ -956,7 +1000,7 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
         if (RAM && E.doadapt != 0 && !(it < E.burnintime && E.doburnin != 0)) {
             double a = ramscale[it - it0] * (alpha12 - E.alphatarget);
             if (FULLR) ram_update_full(E.Rf + (size_t)tile * d * d * 64, zc_t, cs_t, lane, d, a, su_c, true, status);   // condmax > 0
-            else have_p = ram_update(Rt, zc_t, zn_t, cs_t, cand_t, theta_t, lane, d, a, su_c, true, pre, status, RAM ? X : nullptr);
+            else have_p = ram_update(Rt, zc_t, zn_t, cs_t, cand_t, theta_t, lane, d, a, su_c, true, pre, status, RAM ? X : nullptr, pdesc);
         }
         su_c = su_n;
     }
@@ -971,6 +1015,7 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
     TIDX(E.ictr, tile, NICTR, I_STATUS, lane) = status;
     TIDX(E.ictr, tile, NICTR, I_DRACC, lane) = dracc; TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane) = drtries;
     TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane) = erstayed;
+    if (RAM) TIDX(E.ictr, tile, NICTR, I_PDESC, lane) = pdesc ? 1u : 0u;
 }
 
 template <bool RAM, bool DR, bool POOLED>
@@ -998,7 +1043,7 @@ enum { HE_INB = 0, HE_PRI, HE_SS, NHE };
 struct LaneState {
     Rng g;
     double ss1, pri1, sigma2, alpha12;
-    uint32_t stayed, bnd, chainind, curcount, status, dracc, drtries;
+    uint32_t stayed, bnd, chainind, curcount, status, dracc, drtries, pdesc;
 };
 MCX_DEV void lane_load(const EngineDev &E, int tile, int lane, LaneState &L)
 {
@@ -1012,6 +1057,7 @@ MCX_DEV void lane_load(const EngineDev &E, int tile, int lane, LaneState &L)
     L.chainind = TIDX(E.ictr, tile, NICTR, I_CHAININD, lane); L.curcount = TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane);
     L.status = TIDX(E.ictr, tile, NICTR, I_STATUS, lane);
     L.dracc = TIDX(E.ictr, tile, NICTR, I_DRACC, lane); L.drtries = TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane);
+    L.pdesc = TIDX(E.ictr, tile, NICTR, I_PDESC, lane);
 }
 MCX_DEV void lane_store(const EngineDev &E, int tile, int lane, const LaneState &L)
 {
@@ -1024,6 +1070,7 @@ MCX_DEV void lane_store(const EngineDev &E, int tile, int lane, const LaneState 
     TIDX(E.ictr, tile, NICTR, I_CHAININD, lane) = L.chainind; TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane) = L.curcount;
     TIDX(E.ictr, tile, NICTR, I_STATUS, lane) = L.status;
     TIDX(E.ictr, tile, NICTR, I_DRACC, lane) = L.dracc; TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane) = L.drtries;
+    TIDX(E.ictr, tile, NICTR, I_PDESC, lane) = L.pdesc;
 }
 
 // ---------------------------------------------------------------- MCMC_run_scam (MCMC_run_scam.F90:38-88)
@@ -1549,7 +1596,7 @@ MCX_DEV void host_finish(const EngineDev &E, int tile, int lane, int it, LaneSta
         double a = ramscale[0] * (L.alpha12 - E.alphatarget);
         const double *hx = E.hx + (size_t)tile * NHX * 64;
         if (E.usesvd) ram_update_full(E.Rf + (size_t)tile * d * d * 64, zs_t, cs_t, lane, d, a, GV(hx, HX_SU), true, L.status);
-        else ram_update(E.R + (size_t)tile * E.P * 64, zs_t, zs_t, cs_t, cand_t, theta_t, lane, d, a, GV(hx, HX_SU), true, false, L.status, nullptr);
+        else { bool pd = L.pdesc != 0u; ram_update(E.R + (size_t)tile * E.P * 64, zs_t, zs_t, cs_t, cand_t, theta_t, lane, d, a, GV(hx, HX_SU), true, false, L.status, nullptr, pd); L.pdesc = pd ? 1u : 0u; }
     }
 }
 
@@ -1611,7 +1658,7 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
         double su = gen_normals(L.g, zs_t, lane, d, true);
         GV(hx, HX_SU) = su;
         if (E.usesvd) gemvN_panels(E.Rf + (size_t)tile * d * d * 64, zs_t, cand_t, theta_t, lane, d, true);    // matmulx(R,z)
-        else trmv_panels(E.R + (size_t)tile * E.P * 64, zs_t, cand_t, theta_t, lane, d, true);
+        else trmv_panels(E.R + (size_t)tile * E.P * 64, zs_t, cand_t, theta_t, lane, d, true, E.method == M_RAM && L.pdesc != 0u);
     } else if (PHASE == 1) {
         const bool inb = GV(hev, HE_INB) != 0.0;
         const double pri2 = GV(hev, HE_PRI), ss2 = GV(hev, HE_SS);

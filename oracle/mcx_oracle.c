@@ -160,6 +160,19 @@ void mcxo_trmv_ut(int n, const double *R, double *x)
     }
 }
 
+/* The same product in netlib dtrmv's own order (temp = x(j) a(j,j); temp += a(i,j) x(i), i = j-1..1), as an fma chain.
+ * Used for the one proposal that follows a successful Cholesky downdate of MCMC_adapt_ram: DCHDD finishes every
+ * column from its diagonal upwards, so this is the order in which the device can accumulate the next proposal while
+ * the downdated factor streams out. */
+void mcxo_trmv_ut_desc(int n, const double *R, double *x)
+{
+    for (int j = n - 1; j >= 0; --j) {
+        double temp = A_(R, j, j, n) * x[j];
+        for (int i = j - 1; i >= 0; --i) temp = fma(A_(R, i, j, n), x[i], temp);
+        x[j] = temp;
+    }
+}
+
 /* dpotf2('U'): A = U'U, upper triangle overwritten, lower untouched (matutils.F90:363 via dpotrf) */
 int mcxo_potrf_u(int n, double *A)
 {
@@ -471,7 +484,8 @@ static void propose(mcxo_chain *c, const double *oldpar, const double *R, double
         mcxo_gemv(0, n, R, z, y);
         memcpy(z, y, sizeof(double) * (size_t)n);
         free(y);
-    } else mcxo_trmv_ut(n, R, z);
+    } else if (c->trmv_desc && R == c->R) mcxo_trmv_ut_desc(n, R, z);
+    else mcxo_trmv_ut(n, R, z);
     for (int i = 0; i < n; ++i) newpar[i] = oldpar[i] + z[i];
 }
 
@@ -654,9 +668,11 @@ static int adapt_ram(mcxo_chain *c, int simuind, const double *u, double alpha, 
     if (a >= 0.0) {
         for (int i = 0; i < n; ++i) x[i] = u[i] / su * a;
         mcxo_chud(n, c->R, x, cc, ss);
+        c->trmv_desc = 0;
     } else {
         for (int i = 0; i < n; ++i) x[i] = -(u[i] / su * a);
         int info = mcxo_chdd(n, c->R, x, cc, ss);
+        c->trmv_desc = (info == 0 && !c->cfg.usesvd);
         if (info != 0) {                                                    /* matutils.F90:719-722 stop */
             if (!c->ram_downdate_fail) c->ram_downdate_fail = simuind;
             if (!c->continue_on_downdate_fail) return -3000;

@@ -89,6 +89,9 @@ typedef struct mcxo_chain {
     int ny;
     double ss1v[MCXO_NYMAX], sigma2v[MCXO_NYMAX];
     int nobsv[MCXO_NYMAX];
+    /* 1 after a successful Cholesky downdate of MCMC_adapt_ram: the next proposal's R'z accumulates from the diagonal
+     * up (mcxo_trmv_ut_desc), which is the order DCHDD leaves the columns in; otherwise ascending (mcxo_trmv_ut) */
+    int trmv_desc;
 } mcxo_chain;
 
 mcxo_chain *mcxo_chain_create(const mcxo_cfg *cfg, const mcxo_target *tgt, const double *par0,
@@ -104,7 +107,8 @@ int mcxo_chain_run(mcxo_chain *c, int upto);
 /* numerics exposed for known-answer tests */
 double mcxo_normal(mcxo_rng *g);
 double mcxo_gamma(mcxo_rng *g, double a, double b);
-void mcxo_trmv_ut(int n, const double *R, double *x);          /* x <- R'x, R upper col-major */
+void mcxo_trmv_ut(int n, const double *R, double *x);          /* x <- R'x, R upper col-major; dot products ascending */
+void mcxo_trmv_ut_desc(int n, const double *R, double *x);     /* the same with netlib's own order: diagonal first, rows descending */
 int  mcxo_potrf_u(int n, double *A);                            /* LAPACK dpotf2 'U' */
 int  mcxo_potri_u(int n, double *A);                            /* dtrti2 + dlauu2 'U' */
 void mcxo_rotg(double *da, double *db, double *c, double *s);

@@ -54,7 +54,8 @@ class Chain(C.Structure):
                 ("info_last", C.c_int), ("ram_downdate_fail", C.c_int),
                 ("oldpar", _DP), ("ss1", C.c_double), ("sspri1", C.c_double), ("alpha12", C.c_double),
                 ("continue_on_downdate_fail", C.c_int), ("qcovstd", _DP), ("erstayed", C.c_int),
-                ("ny", C.c_int), ("ss1v", C.c_double * 8), ("sigma2v", C.c_double * 8), ("nobsv", C.c_int * 8)]
+                ("ny", C.c_int), ("ss1v", C.c_double * 8), ("sigma2v", C.c_double * 8), ("nobsv", C.c_int * 8),
+                ("trmv_desc", C.c_int)]
 
 
 _lib = None
