@@ -127,6 +127,9 @@ def main():
     ap.add_argument("--method", default=None, choices=["ram", "dram"], help="c4 only: per-chain RAM (default) or AM")
     ap.add_argument("--pooled", action="store_true", help="one shared factor from the all-reduced pooled covariance (c5: the default)")
     ap.add_argument("--replicas", action="store_true", help="c5: per-chain rotations (the reference's semantics) instead of the pooled one")
+    ap.add_argument("--start", default="default", choices=["default", "target"],
+                    help="c4: 'target' starts from cmat0 = Sigma, i.e. at RAM's target acceptance rate, where most iterations are "
+                         "Cholesky downdates (default: cmat0 = 0.01 I, 86 %% accepted, RAM adapts by updates)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--one-gpu-dryrun", action="store_true",
                     help="debug: all ranks share GPU 0 and reduce over gloo (checks the N>1 control path on a 1-GPU box)")
@@ -169,6 +172,8 @@ def main():
     nsimu = 1 + (a.warmup + a.steps) * ips
     ckw, pkw, per_it = problem(wl, nsimu, adaptint=max(ips, 100))
     d = pkw["npar"]
+    if wl == "c4" and a.start == "target":
+        pkw = dict(pkw, cmat0=np.linalg.inv(np.asarray(pkw["lam"], dtype=float)))
     if wl == "c4" and a.method == "dram":
         ckw = dict(ckw, method="dram")
     if wl == "c5":
@@ -254,6 +259,10 @@ def main():
         if roof["bound"] == "hbm" and (a.pooled or d <= 20):
             roof["note"] = ("the chip's HBM roof is quoted for uniformity; this configuration is bound by the per-chain random "
                             "numbers (Philox + polar + pinned log/sqrt on the VALU), see DESIGN.md section 5")
+        if method == "ram":
+            stay = float(tot["stayed"]) / (float(n_local) * (nsimu - 1))
+            roof["note"] = ("accepted fraction on this rank %.2f (start: %s); RAM updates the factor after alpha >= alphatarget (one "
+                            "read+write sweep) and downdates it otherwise (two sweeps): DESIGN.md section 10 item 5" % (1.0 - stay, a.start))
         mode = method + (" pooled (one shared factor)" if a.pooled else ", per-chain factor")
         cnt = float(pooled[0].item())
         mean = (pooled[1:1 + d] / cnt).cpu().numpy()
