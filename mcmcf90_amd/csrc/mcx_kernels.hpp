@@ -611,6 +611,8 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
 {
     const bool up = act && (a >= 0.0);
     const bool down = act && !(a >= 0.0);
+    // per-chain scratch pair k (rotation c_k, s_k; for a downdate lane first the substitution's a_k): rows < NLC in LDS
+#define CS_(k, w) (*((lc && (k) < NLC) ? &lc[(2 * (k) + (w)) * 64 + lane] : &cs_t[(size_t)(2 * (k) + (w)) * 64 + lane]))
     // ---- pass A, rows ascending, one read of the factor for both kinds of lanes: update lanes rotate (DCHUD), write and
     // accumulate the next proposal; downdate lanes run the forward substitution R'a = x of DCHDD (dchdd.f:141-148, x =
     // -u/sum(u**2)*a), whose solution goes to cs_t[2i+1].  xa = DCHUD's work vector x, or the substitution's partial sums.
@@ -640,7 +642,7 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                             P[u] = dfma(t, zi, P[u]);
                         }
                     } else {
-                        const double si = GV(cs_t, 2 * i + 1);
+                        const double si = CS_(i, 1);
 #pragma unroll
                         for (int u = 0; u < RW; ++u) xa[u] = dfma(r[u], si, xa[u]);
                     }
@@ -675,7 +677,7 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                     } else {
                         double si = -(GV(zc_t, i) / su * a) - xi;
                         si = si / GV(seg, 0);
-                        GV(cs_t, 2 * i + 1) = si;
+                        CS_(i, 1) = si;
 #pragma unroll
                         for (int u = 0; u < RW; ++u) { double na = dfma(r[u], si, xa[u]); xa[u] = (u > ui) ? na : xa[u]; }
                     }
@@ -693,12 +695,12 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
         if (down) {
             // norm = dnrm2(p, s), classic scale/ssq form (dchdd.f:149)
             double norm;
-            if (d == 1) norm = fabs(GV(cs_t, 1));
+            if (d == 1) norm = fabs(CS_(0, 1));
             else {
                 double scale = 0.0, ssq = 1.0;
 #pragma unroll 4
                 for (int k = 0; k < d; ++k) {
-                    double xk = GV(cs_t, 2 * k + 1);
+                    double xk = CS_(k, 1);
                     if (xk != 0.0) {
                         double ax = fabs(xk);
                         if (scale < ax) { double q = scale / ax; ssq = 1.0 + ssq * (q * q); scale = ax; }
@@ -716,12 +718,12 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                 double alpha = sqrt(1.0 - norm * norm);
 #pragma unroll 2
                 for (int k = d - 1; k >= 0; --k) {   // dchdd.f:158-167
-                    double sk = GV(cs_t, 2 * k + 1);
+                    double sk = CS_(k, 1);
                     double scale = alpha + fabs(sk);
                     double aa = alpha / scale, bb = sk / scale;
                     double nn = sqrt(aa * aa + bb * bb);
-                    GV(cs_t, 2 * k) = aa / nn;
-                    GV(cs_t, 2 * k + 1) = bb / nn;
+                    CS_(k, 0) = aa / nn;
+                    CS_(k, 1) = bb / nn;
                     alpha = scale * nn;
                 }
                 // ---- pass B (dchdd.f:171-179): each column from its diagonal up; the next proposal accumulates in that
@@ -734,7 +736,7 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                     for (int i = J0 + nw - 1; i >= J0; --i) {            // diagonal block, rows descending
                         double *seg = Rt + (size_t)rowstart(i, d) * 64;
                         const int ui = i - J0, m = d - 1 - i;
-                        const double ci = GV(cs_t, 2 * i), si = GV(cs_t, 2 * i + 1);
+                        const double ci = CS_(i, 0), si = CS_(i, 1);
                         const double zi = fuse ? GV(zn_t, i) : 0.0;
                         double r[RW];
 #pragma unroll
@@ -753,7 +755,7 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
 #pragma unroll 2
                     for (int i = J0 - 1; i >= 0; --i) {                  // rows above, descending
                         double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
-                        const double ci = GV(cs_t, 2 * i), si = GV(cs_t, 2 * i + 1);
+                        const double ci = CS_(i, 0), si = CS_(i, 1);
                         const double zi = fuse ? GV(zn_t, i) : 0.0;
                         double r[RW];
 #pragma unroll
@@ -776,6 +778,7 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
         }
     }
     return (up || down_ok) && fuse;
+#undef CS_
 }
 
 // The same adaptation on a FULL column-major factor (condmax > 0: R is the d x d SVD factor U sqrt(s) 2.4/sqrt(d) of
