@@ -88,6 +88,7 @@ def lib():
         L.mcxo_gamma.argtypes = [C.POINTER(Rng), C.c_double, C.c_double]
         L.mcxo_gamma.restype = C.c_double
         L.mcxo_trmv_ut.argtypes = [C.c_int, _DP, _DP]
+        L.mcxo_trmv_ut_desc.argtypes = [C.c_int, _DP, _DP]
         L.mcxo_potrf_u.argtypes = [C.c_int, _DP]
         L.mcxo_potrf_u.restype = C.c_int
         L.mcxo_potri_u.argtypes = [C.c_int, _DP]

@@ -110,6 +110,11 @@ def test_trmv_chud_chdd(oracle, n):
     z = rng.standard_normal(n); x = z.copy()
     L.mcxo_trmv_ut(n, _dp(R), _dp(x))
     np.testing.assert_allclose(x, R.T @ z, rtol=1e-13, atol=1e-13)
+    xd = z.copy()                                                    # the post-downdate order: diagonal first, rows descending
+    L.mcxo_trmv_ut_desc(n, _dp(R), _dp(xd))
+    np.testing.assert_allclose(xd, R.T @ z, rtol=1e-13, atol=1e-13)
+    ref = np.array([np.sum((R[:j + 1, j] * z[:j + 1])[::-1].cumsum()[-1:]) for j in range(n)])
+    np.testing.assert_allclose(xd, ref, rtol=1e-13, atol=1e-13)
     v = rng.standard_normal(n) * 0.3
     c = np.zeros(n); s = np.zeros(n)
     R1 = R.copy(order="F")
