@@ -407,3 +407,34 @@ def test_response_columns_gamma_shape_below_one_in_one_column(oracle, seed):
         np.testing.assert_array_equal(_bits(s2), _bits(o.s2chain), err_msg=str(ckw))
         assert e.rng(c)[0] == o.rng_n, ckw
     e.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_ram_at_target_acceptance_in_pieces(oracle, seed):
+    """RAM started at its target acceptance rate (cmat0 = the target's covariance: most iterations are Cholesky
+    downdates, after which the proposal accumulates from the diagonal up), mcmcx_run cut at random iterations so that
+    the per-chain order flag crosses launch boundaries; three chains against the oracle, bit for bit."""
+    from mcmcf90_amd import engine_from_problem
+    r = np.random.default_rng(777 + seed)
+    d = int(r.integers(3, 24))
+    A = r.standard_normal((d, d)) / np.sqrt(d)
+    lam = A @ A.T + np.eye(d)
+    ckw = dict(nsimu=int(r.integers(150, 400)), method="ram", updatesigma=0, alphatarget=0.234, nuparam=float(r.choice([0.6, 0.7])))
+    pkw = dict(kind="gauss", npar=d, par0=np.zeros(d), cmat0=np.linalg.inv(lam), mu=np.zeros(d), lam=lam)
+    cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
+    e = engine_from_problem(ckw, pkw, nchains=70, chain_id0=seed, record_accept=1)
+    e.init()
+    cuts = sorted(set(int(v) for v in r.integers(2, ckw["nsimu"], size=7))) + [ckw["nsimu"]]
+    for upto in cuts:
+        e.run(upto)
+    th = e.theta()
+    ndown = 0
+    for c in (0, 64, 69):
+        o = oracle.run_chain(cfg, prob, chain_id=seed + c, continue_on_downdate_fail=True)
+        np.testing.assert_array_equal(e.accepted(c), o.accepted, err_msg=str((ckw, cuts)))
+        np.testing.assert_array_equal(_bits(th[c]), _bits(o.theta), err_msg=str((ckw, cuts)))
+        np.testing.assert_array_equal(_bits(np.triu(e.R(c))), _bits(np.triu(o.R)), err_msg=str((ckw, cuts)))
+        assert e.rng(c)[0] == o.rng_n
+        ndown += int((~o.accepted.astype(bool)).sum())
+    assert ndown > 0.4 * 3 * ckw["nsimu"]                       # the regime the test is about: mostly rejections
+    e.close()
