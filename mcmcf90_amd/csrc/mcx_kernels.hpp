@@ -2427,27 +2427,45 @@ __global__ __launch_bounds__(256) void gather_lane_kernel(const double *__restri
 // Second moments are indexed j(j+1)/2 + i for i <= j.
 __global__ __launch_bounds__(64) void moments_kernel(EngineDev E, double *out, int nchains)
 {
+    // Each lane produces its chain's terms in a fixed order (count, first moments, second moments by rows of the lower
+    // triangle); 64 terms at a time are transposed through LDS, and lane k then adds term k of the 64 chains in the
+    // butterfly's tree order (lane pairs first) -- the sums v_l + v_{l^1}, (..) + (..)_{l^2}, ... a xor-butterfly leaves in
+    // lane 0 -- in registers.
+    __shared__ double T[64 * 65];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d, P = E.P;
     const double *theta_t = E.theta + (size_t)tile * d * 64;
     const bool act = (tile * 64 + lane) < nchains;
     double *o = out + (size_t)tile * (1 + d + P);
-    auto wsum64 = [](double v) {
+    int m = 0;                                          // terms produced so far
+    auto flush = [&](int base, int n) {                 // terms base .. base+n-1 sit in T[0..n-1][*]
+        __syncthreads();
+        if (lane < n) {
+            double a[64];
 #pragma unroll
-        for (int s = 1; s < 64; s <<= 1) v = v + __shfl_xor(v, s);
-        return v;
+            for (int l = 0; l < 64; ++l) a[l] = T[lane * 65 + l];
+#pragma unroll
+            for (int s2 = 1; s2 < 64; s2 <<= 1)
+#pragma unroll
+                for (int l = 0; l + s2 < 64; l += 2 * s2) a[l] = a[l] + a[l + s2];
+            o[base + lane] = a[0];
+        }
+        __syncthreads();
     };
-    double cnt = wsum64(act ? 1.0 : 0.0);
-    if (lane == 0) o[0] = cnt;
+    auto put = [&](double v) {
+        T[(m & 63) * 65 + lane] = v;
+        ++m;
+        if ((m & 63) == 0) flush(m - 64, 64);
+    };
+    put(act ? 1.0 : 0.0);
+    for (int j = 0; j < d; ++j) put(act ? (GV(theta_t, j) - E.par0[j]) : 0.0);
     for (int j = 0; j < d; ++j) {
-        double vj = act ? (GV(theta_t, j) - E.par0[j]) : 0.0;
-        double s1 = wsum64(vj);
-        if (lane == 0) o[1 + j] = s1;
+        const double vj = act ? (GV(theta_t, j) - E.par0[j]) : 0.0;
         for (int i = 0; i <= j; ++i) {
-            double vi = act ? (GV(theta_t, i) - E.par0[i]) : 0.0;
-            double s2 = wsum64(vi * vj);
-            if (lane == 0) o[1 + d + j * (j + 1) / 2 + i] = s2;
+            const double vi = act ? (GV(theta_t, i) - E.par0[i]) : 0.0;
+            put(vi * vj);
         }
     }
+    if (m & 63) flush(m & ~63, m & 63);
 }
 
 // Finish the pooled sum over tiles in the same fixed pairwise tree (adjacent tiles first):
