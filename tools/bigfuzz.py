@@ -1,6 +1,6 @@
 """One-off extended fuzz (GPU box): the generators of tests/test_gpu_fuzz.py over seeds outside the test suite's range --
-the base option space, method='ram' with condmax > 0, and updatesigma with gamma shape < 1 -- device vs oracle, bit for
-bit.  python tools/bigfuzz.py [first_seed=300] [last_seed=2300]   (round 1: 3167 configurations, 0 failures)"""
+the base option space, method='ram' with condmax > 0, updatesigma with gamma shape < 1, the device-resident response
+columns and runs cut into pieces -- device vs oracle, bit for bit.  python tools/bigfuzz.py [first_seed=300] [last_seed=2300]   (round 1: 3167 configurations, 0 failures)"""
 import importlib.util, sys, os, time, traceback
 import numpy as np
 sys.path.insert(0, os.getcwd())
@@ -29,6 +29,12 @@ for seed in range(A, B):
             g._check_against_oracle(po, ckw, pkw, seed); n += 1
         except Exception as e:
             bad.append(("gamma", seed, repr(e)[:200]))
+    if seed % 5 == 0:
+        for fn in (g.test_random_configuration_response_columns_device_target, g.test_random_configuration_in_pieces):
+            try:
+                fn(po, 100000 + seed); n += 1
+            except Exception as e:
+                bad.append((fn.__name__, seed, repr(e)[:200]))
     if time.time() - t0 > 1500: 
         print("time limit at seed", seed); break
 print("configs checked", n, "failures", len(bad))
