@@ -262,7 +262,7 @@ def main():
         if method == "ram":
             stay = float(tot["stayed"]) / (float(n_local) * (nsimu - 1))
             roof["note"] = ("accepted fraction on this rank %.2f (start: %s); RAM updates the factor after alpha >= alphatarget (one "
-                            "read+write sweep) and downdates it otherwise (two sweeps): DESIGN.md section 10 item 5" % (1.0 - stay, a.start))
+                            "read+write sweep) and downdates it otherwise (two sweeps): DESIGN.md section 10 item 6" % (1.0 - stay, a.start))
         mode = method + (" pooled (one shared factor)" if a.pooled else ", per-chain factor")
         cnt = float(pooled[0].item())
         mean = (pooled[1:1 + d] / cnt).cpu().numpy()

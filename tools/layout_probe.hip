@@ -1,4 +1,4 @@
-// Scratch probe for the RAM factor's layout (DESIGN.md section 10, item 5): one read + one write sweep over a per-chain
+// Scratch probe for the RAM factor's layout (DESIGN.md section 10, item 6): one read + one write sweep over a per-chain
 // packed factor of P doubles, panels of 10 elements, lane = chain, a fraction of the lanes storing.
 //   layout 0: element e of a lane at (e*64 + lane)          -- a row segment of the tile is 512 contiguous bytes
 //   layout 1: element e at ((e>>3)*64 + lane)*8 + (e&7)     -- a lane's 8 consecutive elements are one 64-byte sector
