@@ -4,13 +4,20 @@
 Workload "C4": correlated Gaussian target d=50 (Sigma_ij = 0.5^|i-j|, Lambda dense), method='ram'
 (MCMC_run_ram + MCMC_adapt_ram with a per-chain Cholesky factor), 131072 chains per GPU (the 8-GPU
 configuration of BASELINE.json is 1 048 576 chains = 131072 x 8: weak scaling), pooled
-empirical-moment reduction of all chains every `--its-per-step` iterations (all-reduce over RCCL
-when N > 1).  One bench "step" = --its-per-step MH iterations of every chain + that reduction.
+empirical-moment reduction over all chains of all GPUs every `--its-per-step` iterations (RCCL
+all-gather + fixed tree inside libmcmcx.so when N > 1).  One bench "step" = --its-per-step MH
+iterations of every chain + that reduction.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8                   # starts 8 ranks itself, one process per GPU
     python bench.py --workload c5              # the other BASELINE configurations: c2, c3, c5 (see WORKLOADS)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W      # the same ranks under torchrun
+
+One process per GPU.  Under torchrun the ranks come from RANK / LOCAL_RANK / WORLD_SIZE; without it
+`--gpus N` spawns the N rank processes itself (before anything touches a GPU) and fails if they cannot
+all start.  The ranks meet in libmcmcx.so's communicator (RCCL; the ncclUniqueId travels through a POSIX
+shm segment), which also carries the barrier and the max-over-ranks of the timing: torch is not imported.
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the engine's
 stream around every step-kernel launch of the timed region (mcmcx_kernel_time); `cpu_baseline`
@@ -18,10 +25,13 @@ times the real Fortran reference (oracle/_ref, kind "reference") or the C oracle
 on one host core on the same target.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
+import uuid
 
 import numpy as np
 
@@ -30,6 +40,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 FP64_MFMA_PEAK_TF = 78.6       # MI355X FP64 matrix (= FP64 vector) spec peak; tools/mfma_f64_probe.hip measures 77.6
+# vector-instruction issue roof: 256 CUs x 4 SIMDs, one wave64 VALU instruction per SIMD every 4 cycles at 2.4 GHz
+# (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost': v_fma 4 cyc for one wave's stream on one SIMD)
+VALU_ISSUE_PEAK_GIPS = 256 * 4 * 2.4 / 4.0 * 64 / 64      # 614.4 G wave-instructions/s
 
 WORKLOADS = {   # BASELINE.json configs 2-5; the headline metric is quoted on c4
     "c2": "C2: isotropic Gaussian d=10, AM (method=dram, drscale=0)",
@@ -40,18 +53,44 @@ WORKLOADS = {   # BASELINE.json configs 2-5; the headline
 DEFAULT_CHAINS = {"c2": 65536, "c3": 262144, "c4": 131072, "c5": 65536}
 
 
-def alg_bytes_per_proposal(d, method):
+def alg_bytes_per_proposal(d, method, down_frac=0.0):
     """Algorithmic HBM bytes per proposal:
     theta read + write (16 d) + ss/prior read/write (32); per-chain Cholesky factor, packed
     upper triangle: RAM reads it once and writes it once per iteration (8 d (d+1)), AM / DRAM only read
-    it (4 d (d+1)); per-chain SCAM streams its rotation twice per componentwise proposal (16 d^2)."""
+    it (4 d (d+1)); per-chain SCAM streams its rotation twice per componentwise proposal (16 d^2).
+    A RAM downdate (dchdd.f:141-179) is two dependent sweeps -- the forward substitution, then rotations generated
+    from its LAST element backwards -- so it reads the factor twice: `down_frac` of the proposals add one read."""
     base = 16 * d + 32
     tri = d * (d + 1) // 2 * 8
     if method == "pooled":
         return base                                   # the shared factor lives in the scalar cache
     if method == "scam":
         return base + 16 * d * d
-    return base + (2 * tri if method == "ram" else tri)
+    if method == "ram":
+        return base + 2 * tri + int(round(down_frac * tri))
+    return base + tri
+
+
+def kernels_sha():
+    h = hashlib.sha256()
+    for f in ("mcx_kernels.hpp", "mcx_device.hpp"):
+        with open(os.path.join(ROOT, "mcmcf90_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def measured_counters(key):
+    """PMC results of profiles/traffic.json for this configuration -- only when they were collected with the kernel
+    source that is running now (the file records the sha of csrc/mcx_kernels.hpp + mcx_device.hpp)."""
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(tfile))
+        e = tj.get(key)
+        if e and e.get("kernels_sha") == kernels_sha():
+            return e
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(wl, ckw, pkw, per_it, label, target_seconds=12.0):
@@ -68,15 +107,23 @@ def cpu_baseline(wl, ckw, pkw, per_it, label, target_seconds=12.0):
     port_rate = ((n_port - 1) * per_it + o.drtries) / t_port
     if rr.available():
         try:
-            nsimu = int(min(1500000, max(n0, port_rate / per_it * target_seconds * 0.6)))
-            cfg = po.make_cfg(**dict(ckw, nsimu=nsimu))
-            t0 = time.perf_counter(); r = rr.run_reference(cfg, prob, timeout=300, pinned_svd=bool(cfg.usesvd)); t_ref = time.perf_counter() - t0
-            o2 = po.run_chain(cfg, prob)             # same stream: its delayed-rejection count is the reference's
+            # the sampling loop alone: two runs of the reference program, nsimu = n and n/4, in a tmpfs scratch
+            # directory; the difference removes process start, namelist / input files and MCMC_init
+            n2 = int(min(1000000, max(4 * n0, port_rate / per_it * target_seconds * 0.5)))
+            n1 = max(n0, n2 // 4)
+            runs = []
+            for n in (n1, n2):
+                cfg = po.make_cfg(**dict(ckw, nsimu=n))
+                r = rr.run_reference(cfg, prob, timeout=300, pinned_svd=bool(cfg.usesvd), timing_only=True)
+                o2 = po.run_chain(cfg, prob)             # same stream: its delayed-rejection count is the reference's
+                runs.append(((n - 1) * per_it + o2.drtries, r.seconds, r.scratch))
+            (p1, t1, _), (p2, t2, scratch) = runs
             out["all_cores"] = cpu_all_cores(wl, ckw, per_it, port_rate)
-            out.update(value=((nsimu - 1) * per_it + o2.drtries) / t_ref, kind="reference",
-                       sample="mcmcf90 Fortran reference (flang -O2 + MKL, oracle/_ref/mcxref), 1 chain, %s, "
-                              "nsimu=%d, wall time of the whole program incl. namelist/file I/O = %.2f s" % (label, nsimu, t_ref),
-                       port_value=port_rate)
+            out.update(value=(p2 - p1) / (t2 - t1), kind="reference",
+                       sample="mcmcf90 Fortran reference (flang -O2 + MKL, oracle/_ref/mcxref), 1 chain, %s: sampling loop "
+                              "only = (proposals(nsimu=%d) - proposals(nsimu=%d)) / (%.2f s - %.2f s) of the whole program, "
+                              "outputs on %s" % (label, n2, n1, t2, t1, scratch),
+                       whole_program_value=p2 / t2, port_value=port_rate)
             return out
         except Exception as ex:                      # reference binary present but not runnable here
             out["reference_error"] = str(ex)[:200]
@@ -89,7 +136,6 @@ def cpu_baseline(wl, ckw, pkw, per_it, label, target_seconds=12.0):
 def cpu_all_cores(wl, ckw, per_it, port_rate, seconds=4.0):
     """every host core runs one independent chain of the C restatement, each in a process of its
     own (the reference is one chain per process; the port is what spreads over the cores without N copies of its file I/O)."""
-    import subprocess
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -116,6 +162,33 @@ def cpu_all_cores(wl, ckw, per_it, port_rate, seconds=4.0):
             "sample": "C oracle, %d independent chains, one process each (host CPUs in the affinity mask: %d, processes capped at 32), nsimu=%d each, %.2f s incl. process start" % (cores, avail, n, dt)}
 
 
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` without a launcher: start the N rank processes (one per GPU) ourselves.  This parent never
+    touches a GPU; rank 0's JSON line goes straight to our stdout.  Any rank failing fails the run."""
+    key = "b%s" % uuid.uuid4().hex[:16]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MCMCX_COMM_KEY=key)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.05)
+        for p in list(alive):
+            r = p.poll()
+            if r is None:
+                continue
+            alive.remove(p)
+            if r != 0 and rc == 0:
+                rc = r
+                for q in alive:                                    # exactly the children we started
+                    q.terminate()
+    if rc != 0:
+        sys.stderr.write("bench.py: a rank exited with code %d -- %d ranks could not be formed / run\n" % (rc, n))
+    return 1 if rc != 0 else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,40 +205,29 @@ def main():
                          "Cholesky downdates (default: cmat0 = 0.01 I, 86 %% accepted, RAM adapts by updates)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--one-gpu-dryrun", action="store_true",
-                    help="debug: all ranks share GPU 0 and reduce over gloo (checks the N>1 control path on a 1-GPU box)")
+                    help="debug: all ranks share GPU 0 and exchange through the host transport (checks the N>1 path on a 1-GPU box)")
+    ap.add_argument("--dump-moments", default=None, help="debug: rank 0 writes the final pooled moment vector (float64) to this file")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ:
+        if a.gpus < 1:
+            raise SystemExit("--gpus must be >= 1")
+        if a.gpus > 1:
+            sys.exit(spawn_ranks(a.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: one rank per GPU" % (a.gpus, world))
 
-    import torch
-    import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
-    if a.one_gpu_dryrun:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.one_gpu_dryrun:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    def all_reduce_dev(t, op=None):
-        """Sum a device tensor over ranks: RCCL in place, or (dry run) through a host copy over gloo."""
-        kw = {} if op is None else {"op": op}
-        if a.one_gpu_dryrun:
-            h = t.cpu(); dist.all_reduce(h, **kw); t.copy_(h)
-        else:
-            dist.all_reduce(t, **kw)
-
-    from mcmcf90_amd import engine_from_problem
+    from mcmcf90_amd import engine_from_problem, Comm
     from mcmcf90_amd.workloads import problem
+    dev = 0 if a.one_gpu_dryrun else local_rank
+    comm = None
+    if world > 1:
+        key = os.environ.get("MCMCX_COMM_KEY") or "t%s_%s_%d" % (os.environ.get("TORCHELASTIC_RUN_ID", "x"),
+                                                                 os.environ.get("MASTER_PORT", "0"), os.getppid())
+        comm = Comm(key, rank, world, dev, backend="host" if a.one_gpu_dryrun else "rccl")    # raises unless all ranks arrive
     wl = a.workload
     n_local = a.chains_per_gpu or DEFAULT_CHAINS[wl]
     ips = a.its_per_step or (10 if wl == "c5" else 100)       # c5: one iteration is d = 200 componentwise proposals
@@ -181,31 +243,19 @@ def main():
     elif a.pooled:
         ckw = dict(ckw, method="dram", drscale=0.0)
     method = ckw.get("method", "dram")
-    eng = engine_from_problem(ckw, pkw, nchains=n_local, chain_id0=rank * n_local, device=local_rank,
-                              pooled=1 if a.pooled else 0)
-    mom_len = 1 + d + d * (d + 1) // 2
-    pooled = torch.zeros(mom_len, dtype=torch.float64, device=dev)
-    xbuf = torch.zeros(mom_len, dtype=torch.float64, device=dev)
-    if a.pooled and world > 1:
-        def _xchg():                                   # called by the engine at every adaptation tick
-            all_reduce_dev(xbuf)
-            torch.cuda.synchronize()
-        eng.set_exchange(_xchg, xbuf.data_ptr())
+    eng = engine_from_problem(ckw, pkw, nchains=n_local, chain_id0=rank * n_local, device=dev,
+                              pooled=1 if a.pooled else 0, comm=comm)
     eng.init()
 
     def one_step(k):
         eng.run(1 + (k + 1) * ips)
-        eng.pooled_moments_dev(pooled.data_ptr())      # fixed-tree sum over this GPU's chains, stays in HBM
-        if world > 1:
-            eng.sync()                                 # engine stream -> torch stream hand-off
-            all_reduce_dev(pooled)                     # RCCL over xGMI: 1+d+d(d+1)/2 doubles
+        eng.allreduce_moments(fetch=False)             # local fixed tree -> RCCL all-gather -> tree over ranks; stays in HBM
 
     def fence():
-        eng.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+        eng.sync()                                     # everything this rank queued, the gathers included
+        if comm is not None:
+            comm.barrier()
+            eng.sync()
 
     for k in range(a.warmup):
         one_step(k)
@@ -217,22 +267,22 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     kms, klaunch, ksteps = eng.kernel_time()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        all_reduce_dev(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
     tot = eng.totals()
-    tries = torch.tensor([float(tot["drtries"])], dtype=torch.float64, device=dev)   # delayed-rejection proposals of this rank (whole run)
-    if world > 1:
-        all_reduce_dev(tries)
+    red = np.array([dt, kms]), np.array([float(tot["drtries"]), float(tot["stayed"]), float(tot["downdates"])])
+    if comm is not None:
+        red = comm.allreduce(red[0], op="max"), comm.allreduce(red[1], op="sum")
+    dt, kms = float(red[0][0]), float(red[0][1])                                    # slowest rank
+    tries, stayed_all, downs_all = (float(x) for x in red[1])
+    pooled = eng.allreduce_moments(fetch=True)                                      # collective: every rank
     if rank == 0:
         base = float(world) * n_local * ips * per_it
-        dr_per_it = float(tries.item()) / (a.warmup + a.steps) / ips                # stage-2 proposals per iteration, all ranks
+        dr_per_it = tries / (a.warmup + a.steps) / ips                              # stage-2 proposals per iteration, all ranks
         proposals = (base + dr_per_it * ips) * a.steps
         value = proposals / dt
         per_launch_prop = proposals / world / max(klaunch, 1)                        # proposals one launch of one GPU evaluates
         avg_launch_s = kms / 1e3 / max(klaunch, 1)
+        ckey = "%s_%s%s" % (wl, "pooled" if a.pooled else method, "_target" if a.start == "target" else "")
+        pmc = measured_counters(ckey)
         if wl == "c5" and a.pooled:                   # shared rotation: three d x d products per proposal on the f64 matrix cores
             flop = 6.0 * d * d
             achieved = flop * per_launch_prop / avg_launch_s / 1e12
@@ -240,51 +290,60 @@ def main():
                     "frac": achieved / FP64_MFMA_PEAK_TF, "traffic": None, "kernel": "mcx::scam_pooled_kernel",
                     "alg_flop_per_proposal": flop}
         else:
-            balg = alg_bytes_per_proposal(d, "pooled" if a.pooled else method)
+            down_frac = downs_all / (float(world) * n_local * (nsimu - 1)) if method == "ram" else 0.0
+            balg = alg_bytes_per_proposal(d, "pooled" if a.pooled else method, down_frac)
             achieved = balg * per_launch_prop / avg_launch_s / 1e9
-            traffic = None
-            tfile = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tfile):
-                try:
-                    tj = json.load(open(tfile))
-                    key = "%s_d%d" % (method, d)
-                    if key in tj and not a.pooled:   # measured HBM bytes per proposal (rocprofv3 --pmc, see profiles/)
-                        traffic = tj[key]["hbm_bytes_per_proposal"] * per_launch_prop
-                except Exception:
-                    traffic = None
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "kernel": "mcx::scam_kernel" if method == "scam" else "mcx::step_kernel", "alg_bytes_per_proposal": balg}
+                    "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": pmc["hbm_bytes_per_proposal"] * per_launch_prop if pmc and "hbm_bytes_per_proposal" in pmc else None,
+                    "kernel": "mcx::scam_kernel" if method == "scam" else ("mcx::pooled_mfma_kernel" if a.pooled else "mcx::step_kernel"),
+                    "alg_bytes_per_proposal": balg}
+            if method == "ram":
+                roof["downdate_fraction"] = down_frac
+        if pmc:
+            roof["traffic_measured_at"] = {"kernels_sha": pmc["kernels_sha"], "profile": pmc.get("profile")}
+            if "valu_insts_per_proposal" in pmc:      # second roof: vector-instruction issue, from an SQ counter pass
+                ips_ach = pmc["valu_insts_per_proposal"] / 64.0 * per_launch_prop / avg_launch_s / 1e9   # wave-instructions/s
+                roof["issue"] = {"achieved": ips_ach, "peak": VALU_ISSUE_PEAK_GIPS, "unit": "G wave-instr/s",
+                                 "frac": ips_ach / VALU_ISSUE_PEAK_GIPS,
+                                 "valu_insts_per_proposal": pmc["valu_insts_per_proposal"],
+                                 "valu_busy": pmc.get("valu_busy")}
+                if roof["issue"]["frac"] > roof["frac"]:
+                    roof["bound_by"] = "valu-issue"
         roof.update(launches=int(klaunch), avg_launch_ms=avg_launch_s * 1e3, kernel_share_of_wall=kms / 1e3 / dt)
         if roof["bound"] == "hbm" and (a.pooled or d <= 20):
             roof["note"] = ("the chip's HBM roof is quoted for uniformity; this configuration is bound by the per-chain random "
                             "numbers (Philox + polar + pinned log/sqrt on the VALU), see DESIGN.md section 5")
         if method == "ram":
-            stay = float(tot["stayed"]) / (float(n_local) * (nsimu - 1))
-            roof["note"] = ("accepted fraction on this rank %.2f (start: %s); RAM updates the factor after alpha >= alphatarget (one "
+            stay = stayed_all / (float(world) * n_local * (nsimu - 1))
+            roof["note"] = ("accepted fraction %.2f (start: %s); RAM updates the factor after alpha >= alphatarget (one "
                             "read+write sweep) and downdates it otherwise (two sweeps): DESIGN.md section 10 item 6" % (1.0 - stay, a.start))
         mode = method + (" pooled (one shared factor)" if a.pooled else ", per-chain factor")
-        cnt = float(pooled[0].item())
-        mean = (pooled[1:1 + d] / cnt).cpu().numpy()
+        cnt = float(pooled[0])
+        mean = pooled[1:1 + d] / cnt
         line = {
             "metric": "MH proposals/sec (whole node), d=50 Gaussian target" if wl == "c4" else "MH proposals/sec (whole node), " + WORKLOADS[wl],
             "value": value, "unit": "proposals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s, method=%s, %d chains/GPU, pooled moments all-reduce every %d iterations"
-                                   % (WORKLOADS[wl], mode, n_local, ips),
+            "config": {"workload": "%s, method=%s, %d chains/GPU, pooled moments of all %d chains combined every %d iterations (%s)"
+                                   % (WORKLOADS[wl], mode, n_local, world * n_local, ips,
+                                      "one GPU" if world == 1 else ("host transport, ranks share GPU 0" if a.one_gpu_dryrun else "RCCL all-gather + fixed tree")),
                        "chains_per_gpu": n_local, "its_per_step": ips, "npar": d, "method": method,
                        "proposals_per_iteration": per_it + dr_per_it / (float(world) * n_local),
-                       "parallelism": "chains sharded over %d GPU(s)" % world},
+                       "parallelism": "chains sharded over %d GPU(s), one process each" % world},
             "roofline": roof,
             "pooled_check": {"chains": cnt, "max_abs_mean": float(np.max(np.abs(mean)))},
         }
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(wl, ckw, pkw, per_it, "d=%d %s" % (d, method))
+        if a.dump_moments:
+            np.asarray(pooled, dtype=np.float64).tofile(a.dump_moments)
         print(json.dumps(line), flush=True)
     eng.close()
-    if world > 1:
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 if __name__ == "__main__":

@@ -116,8 +116,14 @@ int32_t mcmcx_simuind(mcmcx_handle h);
 /* counters[0..7] = stayed, bndstayed, draccepted, drtries, chainind, status bits, erstayed, run length of the
  * current row, of one chain */
 int mcmcx_get_counters(mcmcx_handle h, int32_t chain, int32_t *counters8);
-/* sums over all chains: stayed, bndstayed, draccepted, drtries, proposals (stage 1 + stage 2) */
-int mcmcx_get_totals(mcmcx_handle h, int64_t *totals5);
+/* over all chains: sums of stayed, bndstayed, draccepted, drtries, proposals (stage 1 + stage 2), RAM iterations that
+ * were Cholesky downdates (a < 0, MCMC_run_ram.F90:168-172); [6] = the OR of every chain's status bits
+ * (MCMCX_ST_*: where the reference would have stopped -- matutils.F90:719-722, MCMC_adapt.F90:221 -- or kept its old
+ * factor, MCMC_adapt.F90:168-171) */
+#define MCMCX_ST_RAM_DOWNDATE_FAIL 1
+#define MCMCX_ST_CHOL_FAIL 2
+#define MCMCX_ST_POTRI_FAIL 4
+int mcmcx_get_totals(mcmcx_handle h, int64_t *totals7);
 int mcmcx_get_theta(mcmcx_handle h, double *theta_rowmajor /* [nchains][npar] */);
 /* per chain: ss1, sspri1, sigma2, alpha12 */
 int mcmcx_get_scalars(mcmcx_handle h, double *out /* [nchains][4] */);
@@ -153,6 +159,35 @@ typedef void (*mcmcx_exchange_t)(void *user);
 int mcmcx_set_exchange(mcmcx_handle h, mcmcx_exchange_t fn, void *user, void *dev_buf);
 /* pooled proposal state: chaincmat, chainmean, chainwsum and the shared factor R (column-major d x d) */
 int mcmcx_get_pooled(mcmcx_handle h, double *cmat_colmajor, double *mean, double *wsum, double *R_colmajor);
+
+/* ---- several GPUs of one node (no counterpart in the single-chain reference).  Chains are
+ * sharded by rank (cfg.chain_id0 = rank * nchains keys the streams, so results do not depend on the GPU count); the
+ * one exchange is the pooled moment vector, combined over RCCL (all-gather + a fixed pairwise tree over the ranks:
+ * bit-identical on 1, 2, 4, 8 GPUs).  Attach a communicator before mcmcx_init; in pooled mode every adaptation tick
+ * then uses the moments of ALL ranks.
+ *   one process per GPU:   mcmcx_comm_create(key, rank, nranks, device, MCMCX_COMM_RCCL, &c) on every rank with the
+ *                          same `key` (names a POSIX shm segment that carries the ncclUniqueId: one node, no MPI);
+ *   one process, N GPUs:   mcmcx_comm_create_all(N, NULL, comms) (ncclCommInitAll), one engine per comms[i],
+ *                          mcmcx_run_all / mcmcx_allreduce_moments_all drive them together.
+ * MCMCX_COMM_HOST stages the gather through the shm segment instead of RCCL: for ranks that share one GPU. */
+typedef struct mcmcx_comm *mcmcx_comm_t;
+#define MCMCX_COMM_RCCL 0
+#define MCMCX_COMM_HOST 1
+int mcmcx_comm_create(const char *key, int32_t rank, int32_t nranks, int32_t device, int32_t backend, mcmcx_comm_t *out);
+int mcmcx_comm_create_all(int32_t ndev, const int32_t *devices /* NULL: 0..ndev-1 */, mcmcx_comm_t *out /* [ndev] */);
+int mcmcx_comm_destroy(mcmcx_comm_t c);
+int32_t mcmcx_comm_rank(mcmcx_comm_t c);
+int32_t mcmcx_comm_size(mcmcx_comm_t c);
+int mcmcx_comm_barrier(mcmcx_comm_t c);
+/* sum (op 0) / maximum (op 1) of n <= 512 host doubles over the ranks, in place (ncclAllReduce) */
+int mcmcx_comm_allreduce_host(mcmcx_comm_t c, double *inout, int32_t n, int32_t op);
+int mcmcx_set_comm(mcmcx_handle h, mcmcx_comm_t c);
+/* pooled moments (layout of mcmcx_pooled_moments) of the chains of ALL ranks; collective: every rank calls it.
+ * host_out may be NULL: the result stays on the device and the call is asynchronous on the engine's stream. */
+int mcmcx_allreduce_moments(mcmcx_handle h, double *host_out);
+int mcmcx_allreduce_moments_all(mcmcx_handle *hs, int32_t n, double *host_out);
+/* mcmcx_run for the n engines of a one-process node, one host thread each */
+int mcmcx_run_all(mcmcx_handle *hs, int32_t n, int32_t upto);
 
 /* device time of the step kernel over all launches since the last reset, measured with HIP
  * events on the engine's stream; launches = number of step-kernel launches, steps = iterations */

@@ -79,6 +79,19 @@ SYMBOLS["mcmcx_interrupted"] = (C.c_int, [])
 SYMBOLS["mcmcx_clear_interrupt"] = (None, [])
 SYMBOLS["mcmcx_set_target_host"] = (C.c_int, [C.c_void_p, SSFUN_T, PRIORFUN_T, CHECKBOUNDS_T, C.c_void_p])
 
+_HP = C.POINTER(C.c_void_p)
+SYMBOLS["mcmcx_comm_create"] = (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _HP])
+SYMBOLS["mcmcx_comm_create_all"] = (C.c_int, [C.c_int32, _IP, _HP])
+SYMBOLS["mcmcx_comm_destroy"] = (C.c_int, [C.c_void_p])
+SYMBOLS["mcmcx_comm_rank"] = (C.c_int32, [C.c_void_p])
+SYMBOLS["mcmcx_comm_size"] = (C.c_int32, [C.c_void_p])
+SYMBOLS["mcmcx_comm_barrier"] = (C.c_int, [C.c_void_p])
+SYMBOLS["mcmcx_comm_allreduce_host"] = (C.c_int, [C.c_void_p, _DP, C.c_int32, C.c_int32])
+SYMBOLS["mcmcx_set_comm"] = (C.c_int, [C.c_void_p, C.c_void_p])
+SYMBOLS["mcmcx_allreduce_moments"] = (C.c_int, [C.c_void_p, _DP])
+SYMBOLS["mcmcx_allreduce_moments_all"] = (C.c_int, [_HP, C.c_int32, _DP])
+SYMBOLS["mcmcx_run_all"] = (C.c_int, [_HP, C.c_int32, C.c_int32])
+
 _lib = None
 
 

@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, "csrc", f) for f in ("mcx_api.hip", "mcx_kernels.hpp", "mcx_device.hpp")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("mcx_api.hip", "mcx_kernels.hpp", "mcx_device.hpp", "mcx_comm.hpp")]
 HDR = os.path.join(os.path.dirname(HERE), "include", "mcmcx.h")
 LIB = os.path.join(HERE, "libmcmcx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -26,7 +26,7 @@ def stale():
 def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
-    cmd = [HIPCC] + FLAGS + ["-o", LIB, SRC[0]]
+    cmd = [HIPCC] + FLAGS + ["-o", LIB, SRC[0], "-L/opt/rocm/lib", "-lrccl", "-lrt", "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -49,6 +49,8 @@ struct mcmcx_engine {
     double *d_sharedU = nullptr;                      // [U col-major | pad | U row-major | pad | std]
     double *d_sharedRT = nullptr;                     // pooled AM on the matrix cores: dense R, M[s*d + o] = R(s,o), zero below the diagonal and in the pad rows
     double *d_sharedR = nullptr; mcmcx_exchange_t xfn = nullptr; void *xuser = nullptr; double *xbuf = nullptr;
+    struct mcmcx_comm *comm = nullptr;                // the node's communicator (mcx_comm.hpp); nullptr = this GPU alone
+    double *d_gather = nullptr, *d_pooled = nullptr;  // [nranks][len] per-rank moment vectors, [len] their tree sum
     double S02eff = 0.0;
     // device
     hipStream_t stream = nullptr; bool own_stream = false;
@@ -355,6 +357,23 @@ static void unpack_upper(int d, const std::vector<double> &p, double *colmajor, 
 }
 
 static int pooled_moments_launch(mcmcx_engine *h, double *dev_dst);
+#include "mcx_comm.hpp"
+
+// Pooled moments of the chains of ALL ranks, left in h->d_pooled (asynchronous on the engine's stream): local tree ->
+// slot `rank` of d_gather -> all-gather over the communicator -> the same pairwise tree over the ranks.
+static int allreduce_moments_enqueue(mcmcx_engine *h, int stage /* 0 all, 1 local part, 2 gather, 3 tree */)
+{
+    const int len = 1 + h->d + h->P;
+    const int nr = h->comm ? h->comm->nranks : 1, rk = h->comm ? h->comm->rank : 0;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (stage == 0 || stage == 1) { int rc = pooled_moments_launch(h, h->d_gather + (size_t)rk * len); if (rc) return rc; }
+    if ((stage == 0 || stage == 2) && h->comm) { int rc = comm_allgather(h->comm, h->d_gather, len, h->stream); if (rc) return rc; }
+    if (stage == 0 || stage == 3) {
+        hipLaunchKernelGGL(moments_tree_kernel, dim3((len + 255) / 256, 1), dim3(256), 0, h->stream, h->d_gather, nr, len, 1, h->d_pooled);
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
 
 // Pooled adaptation tick (the multi-chain form of MCMC_adapt.F90:105-170): the N current states are a batch of
 // N unit-weight rows.  Their mean/covariance come from the device-reduced moment vector (all-reduced over
@@ -365,12 +384,21 @@ static int pooled_adapt(mcmcx_engine *h, int it)
 {
     const mcmcx_config &c = h->cfg;
     const int d = h->d, P = h->P, len = 1 + d + P;
-    double *dst = h->xbuf ? h->xbuf : h->d_moments + (size_t)h->ntiles * len;      // tail of the moments workspace
-    int rc = pooled_moments_launch(h, dst); if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
-    if (h->xfn) h->xfn(h->xuser);
     std::vector<double> v(len);
-    HIPCHK(hipMemcpy(v.data(), dst, (size_t)len * 8, hipMemcpyDeviceToHost));
+    if (h->comm && !h->xfn) {                                                       // RCCL all-gather + fixed tree over the ranks
+        int rc = allreduce_moments_enqueue(h, 0); if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(v.data(), h->d_pooled, (size_t)len * 8, hipMemcpyDeviceToHost));
+    } else {
+        double *dst = h->xbuf ? h->xbuf : h->d_moments + (size_t)h->ntiles * len;  // tail of the moments workspace
+        int rc = pooled_moments_launch(h, dst); if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->xfn) h->xfn(h->xuser);                                               // the caller's own exchange
+        HIPCHK(hipMemcpy(v.data(), dst, (size_t)len * 8, hipMemcpyDeviceToHost));
+    }
+    // the vector has been through an exchange: refuse to merge garbage (it would poison pool_C for the rest of the run)
+    if (!(v[0] >= 2.0) || !std::isfinite(v[0])) return fail(-46, "pooled adaptation needs at least 2 chains over all ranks (count = " + std::to_string(v[0]) + ")");
+    for (int k = 1; k < len; ++k) if (!std::isfinite(v[k])) return fail(-46, "pooled adaptation: non-finite pooled moments at iteration " + std::to_string(it));
     if (it == c.burnintime + c.adaptint + c.adapthist) {                            // first time: MCMC_adapt.F90:108-114
         h->pool_W = (double)c.initcmatn;
         for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) h->pool_C[h_pidx(i, j, d)] = h->cmat0[(size_t)i + (size_t)j * d];
@@ -796,6 +824,7 @@ int mcmcx_init(mcmcx_handle h)
     }
     E.sharedR = nullptr;
     if (h->pooled) {
+        if ((long long)c.nchains * (h->comm ? h->comm->nranks : 1) < 2) return fail(-8, "pooled mode needs at least 2 chains over all ranks");
         if (phased(h)) return fail(-8, "pooled mode needs one of the single-launch device targets (gauss, banana, expdata)");
         if (c.method == MCMCX_METHOD_SCAM && scam_pooled_lds(d) > 160 * 1024) return fail(-8, "pooled scam: npar > 240 does not fit the 160 KiB of LDS");
         if ((rc = dev_alloc(h, &h->d_sharedR, (size_t)P, false))) return rc;
@@ -832,6 +861,8 @@ int mcmcx_init(mcmcx_handle h)
         h->d_ramscale = const_cast<double *>(p);
     }
     if ((rc = dev_alloc(h, &h->d_moments, (size_t)(T + 1) * (1 + d + P)))) return rc;
+    if ((rc = dev_alloc(h, &h->d_gather, (size_t)(h->comm ? h->comm->nranks : 1) * (1 + d + P)))) return rc;
+    if ((rc = dev_alloc(h, &h->d_pooled, (size_t)(1 + d + P)))) return rc;
 
     // fill theta = par0, R = R(cmat0), chaincmat = cmat0, chainmean = par0, scalars
     {
@@ -977,19 +1008,20 @@ int mcmcx_get_counters(mcmcx_handle h, int32_t chain, int32_t *out)
     return 0;
 }
 
-int mcmcx_get_totals(mcmcx_handle h, int64_t *t5)
+int mcmcx_get_totals(mcmcx_handle h, int64_t *t7)
 {
     if (!h || !h->inited) return fail(-40, "we have not inited");
     std::vector<uint32_t> v;
     int rc = fetch(h, h->E.ictr, (size_t)h->nlanes * NICTR, v); if (rc) return rc;
-    for (int i = 0; i < 5; ++i) t5[i] = 0;
+    for (int i = 0; i < 7; ++i) t7[i] = 0;
     for (int c = 0; c < h->cfg.nchains; ++c) {
         int t = c / 64, l = c % 64;
         auto at = [&](int k) { return (int64_t)v[((size_t)t * NICTR + k) * 64 + l]; };
-        t5[0] += at(I_STAYED); t5[1] += at(I_BNDSTAYED); t5[2] += at(I_DRACC); t5[3] += at(I_DRTRIES);
+        t7[0] += at(I_STAYED); t7[1] += at(I_BNDSTAYED); t7[2] += at(I_DRACC); t7[3] += at(I_DRTRIES);
+        t7[5] += at(I_DOWNS); t7[6] |= at(I_STATUS);
     }
     // proposals evaluated: one per iteration (d componentwise ones with method='scam') + the delayed-rejection tries
-    t5[4] = (int64_t)h->cfg.nchains * (int64_t)(h->simuind - 1) * (h->cfg.method == MCMCX_METHOD_SCAM ? h->d : 1) + t5[3];
+    t7[4] = (int64_t)h->cfg.nchains * (int64_t)(h->simuind - 1) * (h->cfg.method == MCMCX_METHOD_SCAM ? h->d : 1) + t7[3];
     return 0;
 }
 
@@ -1215,6 +1247,70 @@ int mcmcx_pooled_moments_dev(mcmcx_handle h, void *dev_out)
 {
     if (!dev_out) return fail(-1, "null argument");
     return pooled_moments_launch(h, (double *)dev_out);
+}
+
+// ------------------------------------------------------------------ the node: several GPUs, one communicator
+int mcmcx_set_comm(mcmcx_handle h, mcmcx_comm_t c)
+{
+    if (!h) return fail(-1, "null handle");
+    if (h->inited) return fail(-1, "mcmcx_set_comm after mcmcx_init");
+    if (c && c->device != h->cfg.device) return fail(-1, "mcmcx_set_comm: the communicator lives on device " + std::to_string(c->device) + ", the engine on " + std::to_string(h->cfg.device));
+    h->comm = c;
+    return 0;
+}
+
+int mcmcx_allreduce_moments(mcmcx_handle h, double *host_out)
+{
+    if (!h || !h->inited) return fail(-40, "we have not inited");
+    if (h->comm && h->comm->single_process && h->comm->nranks > 1)
+        return fail(-1, "mcmcx_allreduce_moments: this communicator drives several GPUs from one process; use mcmcx_allreduce_moments_all");
+    int rc = allreduce_moments_enqueue(h, 0); if (rc) return rc;
+    if (host_out) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(host_out, h->d_pooled, (size_t)(1 + h->d + h->P) * 8, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+int mcmcx_allreduce_moments_all(mcmcx_handle *hs, int32_t n, double *host_out)
+{
+    if (!hs || n < 1) return fail(-1, "bad argument");
+    for (int i = 0; i < n; ++i) if (!hs[i] || !hs[i]->inited) return fail(-40, "we have not inited");
+    int rc;
+    for (int i = 0; i < n; ++i) if ((rc = allreduce_moments_enqueue(hs[i], 1))) return rc;
+    NCCLCHK(ncclGroupStart());                                  // one thread, several devices: the gathers go out as a group
+    for (int i = 0; i < n; ++i) if ((rc = allreduce_moments_enqueue(hs[i], 2))) { (void)ncclGroupEnd(); return rc; }
+    NCCLCHK(ncclGroupEnd());
+    for (int i = 0; i < n; ++i) if ((rc = allreduce_moments_enqueue(hs[i], 3))) return rc;
+    if (host_out) {
+        HIPCHK(hipSetDevice(hs[0]->cfg.device));
+        HIPCHK(hipStreamSynchronize(hs[0]->stream));
+        HIPCHK(hipMemcpy(host_out, hs[0]->d_pooled, (size_t)(1 + hs[0]->d + hs[0]->P) * 8, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+// mcmcx_run on n engines at once, one host thread per engine (each GPU has its own stream; in pooled mode the threads
+// meet in the all-gather of every adaptation tick).  User host callbacks are not thread-safe: engines with
+// a host target run one after the other on the calling thread instead.
+int mcmcx_run_all(mcmcx_handle *hs, int32_t n, int32_t upto)
+{
+    if (!hs || n < 1) return fail(-1, "bad argument");
+    bool serial = (n == 1);
+    for (int i = 0; i < n; ++i) { if (!hs[i]) return fail(-1, "null handle"); if (phased(hs[i]) && hs[i]->tkind == TGT_HOST) serial = true; }
+    if (serial) {
+        int worst = 0;
+        for (int i = 0; i < n; ++i) { int rc = mcmcx_run(hs[i], upto); if (rc < 0) return rc; worst = std::max(worst, rc); }
+        return worst;
+    }
+    std::vector<int> rcs(n, 0); std::vector<std::string> errs(n);
+    std::vector<std::thread> th;
+    for (int i = 1; i < n; ++i) th.emplace_back([&, i]() { rcs[i] = mcmcx_run(hs[i], upto); if (rcs[i] < 0) errs[i] = g_err; });
+    rcs[0] = mcmcx_run(hs[0], upto); if (rcs[0] < 0) errs[0] = g_err;
+    for (auto &t : th) t.join();
+    int worst = 0;
+    for (int i = 0; i < n; ++i) { if (rcs[i] < 0) return fail(rcs[i], "engine " + std::to_string(i) + ": " + errs[i]); worst = std::max(worst, rcs[i]); }
+    return worst;
 }
 
 } // extern "C"

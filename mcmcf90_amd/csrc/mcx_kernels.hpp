@@ -33,7 +33,7 @@ enum { M_DRAM = 0, M_RAM = 1, M_ER = 3 };
 enum { S_SS1 = 0, S_PRI1, S_SIGMA2, S_ALPHA12, S_SAVEDY, S_WSUM, NSCAL };
 // per-chain integer slots (u32)
 enum { I_SAVED = 0, I_STAYED, I_BNDSTAYED, I_DRACC, I_DRTRIES, I_CHAININD, I_CURCOUNT, I_STATUS,
-       I_LASTFREQ, I_BASECNT, I_WINSTART, I_INFO, I_ERSTAYED, I_PDESC, NICTR };   // I_PDESC: 1 after a successful RAM downdate
+       I_LASTFREQ, I_BASECNT, I_WINSTART, I_INFO, I_ERSTAYED, I_PDESC, I_DOWNS, NICTR };   // I_PDESC: 1 after a successful RAM downdate; I_DOWNS: RAM iterations with a < 0 (choldowndate)
 
 // status bits
 enum { ST_RAM_DOWNDATE_FAIL = 1, ST_CHOL_FAIL = 2, ST_POTRI_FAIL = 4 };
@@ -905,6 +905,7 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
     uint32_t dracc = TIDX(E.ictr, tile, NICTR, I_DRACC, lane), drtries = TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane);
     uint32_t erstayed = TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane);
     bool pdesc = RAM && TIDX(E.ictr, tile, NICTR, I_PDESC, lane) != 0u;   // the next proposal's dtrmv order (after a downdate: diagonal first)
+    uint32_t downs = RAM ? TIDX(E.ictr, tile, NICTR, I_DOWNS, lane) : 0u;
 
     bool have_p = false;                          // lanes whose candidate is already in cand_t
     double su_c = gen_normals(g, zs_t + (size_t)(it0 & 1) * d * 64, lane, d, true), su_n = 0.0;
@@ -1006,6 +1007,7 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
         have_p = false;
         if (RAM && E.doadapt != 0 && !(it < E.burnintime && E.doburnin != 0)) {
             double a = ramscale[it - it0] * (alpha12 - E.alphatarget);
+            downs += (a >= 0.0) ? 0u : 1u;
             if (FULLR) ram_update_full(E.Rf + (size_t)tile * d * d * 64, zc_t, cs_t, lane, d, a, su_c, true, status);   // condmax > 0
             else have_p = ram_update(Rt, zc_t, zn_t, cs_t, cand_t, theta_t, lane, d, a, su_c, true, pre, status, RAM ? X : nullptr, pdesc);
         }
@@ -1022,7 +1024,7 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
     TIDX(E.ictr, tile, NICTR, I_STATUS, lane) = status;
     TIDX(E.ictr, tile, NICTR, I_DRACC, lane) = dracc; TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane) = drtries;
     TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane) = erstayed;
-    if (RAM) TIDX(E.ictr, tile, NICTR, I_PDESC, lane) = pdesc ? 1u : 0u;
+    if (RAM) { TIDX(E.ictr, tile, NICTR, I_PDESC, lane) = pdesc ? 1u : 0u; TIDX(E.ictr, tile, NICTR, I_DOWNS, lane) = downs; }
 }
 
 template <bool RAM, bool DR, bool POOLED>
@@ -1601,6 +1603,7 @@ MCX_DEV void host_finish(const EngineDev &E, int tile, int lane, int it, LaneSta
     if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
     if (E.method == M_RAM && E.doadapt != 0 && !(it < E.burnintime && E.doburnin != 0)) {
         double a = ramscale[0] * (L.alpha12 - E.alphatarget);
+        if (!(a >= 0.0)) TIDX(E.ictr, tile, NICTR, I_DOWNS, lane) += 1u;
         const double *hx = E.hx + (size_t)tile * NHX * 64;
         if (E.usesvd) ram_update_full(E.Rf + (size_t)tile * d * d * 64, zs_t, cs_t, lane, d, a, GV(hx, HX_SU), true, L.status);
         else { bool pd = L.pdesc != 0u; ram_update(E.R + (size_t)tile * E.P * 64, zs_t, zs_t, cs_t, cand_t, theta_t, lane, d, a, GV(hx, HX_SU), true, false, L.status, nullptr, pd); L.pdesc = pd ? 1u : 0u; }

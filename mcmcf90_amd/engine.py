@@ -38,6 +38,38 @@ def make_config(npar, nchains=1, **kw):
     return c
 
 
+class Comm:
+    """The node's communicator (include/mcmcx.h, "several GPUs of one node"): one process per GPU, RCCL underneath
+    (backend "rccl"), or the host-staged transport for ranks that share one GPU (backend "host")."""
+    BACKENDS = {"rccl": 0, "host": 1}
+
+    def __init__(self, key, rank, nranks, device, backend="rccl"):
+        self.L = _lib.load()
+        self.h = C.c_void_p()
+        rc = self.L.mcmcx_comm_create(str(key).encode(), int(rank), int(nranks), int(device), self.BACKENDS[backend], C.byref(self.h))
+        if rc < 0:
+            raise McmcError(self.L.mcmcx_last_error().decode())
+        self.rank, self.size = int(rank), int(nranks)
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise McmcError(self.L.mcmcx_last_error().decode())
+
+    def barrier(self):
+        self._chk(self.L.mcmcx_comm_barrier(self.h))
+
+    def allreduce(self, values, op="sum"):
+        """Sum / maximum of a few host doubles over the ranks."""
+        a = np.ascontiguousarray(np.atleast_1d(values), dtype=np.float64).copy()
+        self._chk(self.L.mcmcx_comm_allreduce_host(self.h, _dp(a), a.size, 1 if op == "max" else 0))
+        return a
+
+    def close(self):
+        if self.h:
+            self.L.mcmcx_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+
 class Engine:
     def __init__(self, cfg):
         self.L = _lib.load()
@@ -155,9 +187,10 @@ class Engine:
                     chainind=int(a[4]), status=int(a[5]), erstayed=int(a[6]), curcount=int(a[7]))
 
     def totals(self):
-        a = np.zeros(5, dtype=np.int64)
+        a = np.zeros(7, dtype=np.int64)
         self._chk(self.L.mcmcx_get_totals(self.h, a.ctypes.data_as(C.POINTER(C.c_int64))))
-        return dict(stayed=int(a[0]), bndstayed=int(a[1]), draccepted=int(a[2]), drtries=int(a[3]), proposals=int(a[4]))
+        return dict(stayed=int(a[0]), bndstayed=int(a[1]), draccepted=int(a[2]), drtries=int(a[3]), proposals=int(a[4]),
+                    downdates=int(a[5]), status=int(a[6]))
 
     def theta(self):
         a = np.zeros((self.nchains, self.npar))
@@ -223,6 +256,20 @@ class Engine:
         """Pooled moments straight into device memory (e.g. a torch tensor's data_ptr()); async on the engine stream."""
         self._chk(self.L.mcmcx_pooled_moments_dev(self.h, C.c_void_p(int(dev_ptr))))
 
+    def set_comm(self, comm):
+        """Attach the node's communicator (before init): pooled-mode ticks and allreduce_moments span all ranks."""
+        self._comm = comm
+        self._chk(self.L.mcmcx_set_comm(self.h, comm.h if comm is not None else None))
+
+    def allreduce_moments(self, fetch=True):
+        """Pooled moments of the chains of ALL ranks (collective).  fetch=False leaves them on the device (async)."""
+        if not fetch:
+            self._chk(self.L.mcmcx_allreduce_moments(self.h, None))
+            return None
+        a = np.zeros(self.L.mcmcx_pooled_moments_len(self.h))
+        self._chk(self.L.mcmcx_allreduce_moments(self.h, _dp(a)))
+        return a
+
     def set_exchange(self, fn, dev_ptr):
         """Pooled mode over several GPUs: fn() must all-reduce (sum) the device buffer at dev_ptr in place."""
         self._xkeep = _lib.EXCHANGE_T(lambda user: fn())
@@ -245,8 +292,12 @@ def engine_from_problem(cfg_kw, prob_kw, nchains=1, **extra):
     """Build an Engine from the same (cfg, problem) dictionaries the oracle / golden fixtures use."""
     pk = dict(prob_kw)
     npar = int(pk["npar"])
+    extra = dict(extra)
+    comm = extra.pop("comm", None)
     cfg = make_config(npar, nchains, **cfg_kw, **extra)
     e = Engine(cfg)
+    if comm is not None:
+        e.set_comm(comm)
     e.setpar0(pk["par0"])
     e.setcmat0(np.asarray(pk["cmat0"], dtype=np.float64).reshape(npar, npar))
     e.setsigma2nobs(pk.get("sigma2", 1.0), pk.get("nobs", 1))

@@ -104,20 +104,29 @@ class RefResult:
     pass
 
 
-def run_reference(cfg, prob, seed=0x6D636D63, chain_id=0, keep=False, timeout=600, pinned_svd=False):
+def run_reference(cfg, prob, seed=0x6D636D63, chain_id=0, keep=False, timeout=600, pinned_svd=False, timing_only=False):
+    """timing_only: run in a tmpfs scratch directory when there is one, time the reference process alone (r.seconds)
+    and do not parse its output files (bench.py's cpu_baseline leg)."""
     if not available():
         raise RuntimeError("oracle/_ref/mcxref not built (make -C oracle ref)")
-    d = tempfile.mkdtemp(prefix="mcxref_")
+    import time
+    shm = "/dev/shm" if (timing_only and os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK)) else None
+    d = tempfile.mkdtemp(prefix="mcxref_", dir=shm)
     try:
         write_inputs(d, cfg, prob)
         env = dict(os.environ, MCX_SEED=str(seed), MCX_CHAIN=str(chain_id), MKL_NUM_THREADS="1",
                    MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1", MCX_RNG_LOG=os.path.join(d, "rng.log"))
+        t0 = time.perf_counter()
         p = subprocess.run([EXE_SVD if pinned_svd else EXE], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
         r = RefResult()
+        r.seconds = time.perf_counter() - t0
+        r.scratch = "tmpfs" if shm else "disk"
         r.stdout = p.stdout.decode(errors="replace")
         r.returncode = p.returncode
         if not os.path.exists(os.path.join(d, "chain.mat")):
             raise RuntimeError("reference run produced no chain:\n" + r.stdout[-2000:])
+        if timing_only:
+            return r
         r.chain = read_mat4(os.path.join(d, "chain.mat"))["chain"]
         r.sschain = read_mat4(os.path.join(d, "sschain.mat"))["sschain"]
         r.s2chain = read_mat4(os.path.join(d, "s2chain.mat"))["s2chain"] if cfg.updatesigma else None

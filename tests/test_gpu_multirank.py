@@ -1,0 +1,109 @@
+"""N > 1 through the engine, on the one GPU of the test box: bench.py starts two rank
+processes that share GPU 0 and exchange through libmcmcx.so's host transport (RCCL refuses two ranks on one device);
+everything else -- sharding by chain_id0, the local fixed tree, the gather, the tree over ranks, the pooled-mode
+adaptation from the moments of ALL ranks -- is the code an 8-GPU run executes.  Fixed-tree claim of DESIGN.md
+section 7: the pooled moments of 2 ranks x n chains are bit-identical to 1 rank x 2n chains."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, tmp_path, name):
+    dump = str(tmp_path / (name + ".f64"))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MCMCX_COMM_KEY")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--dump-moments", dump] + args,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()
+    return json.loads(lines[0]), np.fromfile(dump, dtype=np.float64)
+
+
+@pytest.mark.parametrize("extra", [[], ["--pooled"], ["--workload", "c2"], ["--workload", "c5", "--chains-per-gpu", "128", "--its-per-step", "2"]],
+                         ids=["c4_ram", "c4_pooled_am", "c2_am", "c5_pooled_scam"])
+def test_two_ranks_equal_one_rank_with_twice_the_chains(tmp_path, extra):
+    n = 2048
+    common = ["--steps", "2", "--warmup", "1"] + extra
+    if "--chains-per-gpu" in extra:
+        n = int(extra[extra.index("--chains-per-gpu") + 1])
+        common = [a for i, a in enumerate(common) if a != "--chains-per-gpu" and (i == 0 or common[i - 1] != "--chains-per-gpu")]
+    two, m2 = _bench(common + ["--gpus", "2", "--one-gpu-dryrun", "--chains-per-gpu", str(n)], tmp_path, "two")
+    one, m1 = _bench(common + ["--gpus", "1", "--chains-per-gpu", str(2 * n)], tmp_path, "one")
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["pooled_check"]["chains"] == 2 * n == one["pooled_check"]["chains"]
+    assert two["config"]["chains_per_gpu"] == n
+    assert m2.shape == m1.shape and m2[0] == 2 * n
+    assert np.array_equal(m2.view(np.uint64), m1.view(np.uint64)), "pooled moments of 2 ranks differ from 1 rank with twice the chains"
+    # whole-job rate: both ranks' proposals over the slowest rank's time
+    assert two["value"] > 0 and two["roofline"]["launches"] == one["roofline"]["launches"]
+
+
+def test_two_ranks_cannot_form_on_one_gpu_without_the_dry_run(tmp_path):
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    n = ctypes.c_int(0)
+    hip.hipGetDeviceCount(ctypes.byref(n))
+    if n.value >= 2:
+        pytest.skip("two GPUs are present")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MCMCX_COMM_KEY")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--chains-per-gpu", "64",
+                        "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+
+
+def test_rccl_communicator_of_one_rank(tmp_path):
+    """The RCCL transport itself (ncclGetUniqueId through the shm bootstrap, ncclCommInitRank, ncclAllReduce for the
+    host scalars, the engine's all-gather + tree) with the one rank a one-GPU box can form: results equal the
+    communicator-less engine bit for bit."""
+    import uuid
+    from mcmcf90_amd import Comm, engine_from_problem
+    from mcmcf90_amd.workloads import problem
+    comm = Comm("t" + uuid.uuid4().hex[:12], 0, 1, 0, backend="rccl")
+    assert comm.allreduce(np.array([3.0, -1.5]), op="sum").tolist() == [3.0, -1.5]
+    assert comm.allreduce(np.array([3.0, -1.5]), op="max").tolist() == [3.0, -1.5]
+    comm.barrier()
+    ckw, pkw, _ = problem("c2", 301)
+    ckw = dict(ckw, drscale=0.0)
+    res = []
+    for c in (comm, None):
+        e = engine_from_problem(ckw, pkw, nchains=256, pooled=1, comm=c)
+        e.init(); e.run()
+        res.append((e.allreduce_moments(), e.pooled_moments(), e.theta()))
+        e.close()
+    comm.close()
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    assert np.array_equal(res[0][0].view(np.uint64), res[0][1].view(np.uint64))      # one rank: all-reduced == local
+
+
+def test_one_process_node_api_with_one_gpu():
+    """mcmcx_comm_create_all / mcmcx_run_all / mcmcx_allreduce_moments_all (what the Fortran shim's `ngpus` drives) with
+    the one device of the box: ncclCommInitAll(1), the threaded run and the grouped gather are exercised."""
+    import ctypes as C
+    from mcmcf90_amd import _lib, engine_from_problem
+    from mcmcf90_amd.workloads import problem
+    L = _lib.load()
+    comms = (C.c_void_p * 1)()
+    assert L.mcmcx_comm_create_all(1, None, comms) == 0, L.mcmcx_last_error()
+    ckw, pkw, _ = problem("c2", 201)
+
+    class _C:                                    # duck-typed Comm for Engine.set_comm
+        h = C.c_void_p(comms[0])
+    e = engine_from_problem(ckw, pkw, nchains=128, pooled=1, comm=_C())
+    e.init()
+    hs = (C.c_void_p * 1)(e.h)
+    assert L.mcmcx_run_all(hs, 1, 201) == 0, L.mcmcx_last_error()
+    out = np.zeros(L.mcmcx_pooled_moments_len(e.h))
+    assert L.mcmcx_allreduce_moments_all(hs, 1, out.ctypes.data_as(C.POINTER(C.c_double))) == 0, L.mcmcx_last_error()
+    assert np.array_equal(out.view(np.uint64), e.pooled_moments().view(np.uint64)) and out[0] == 128
+    assert e.simuind == 201
+    e.close()
+    L.mcmcx_comm_destroy(comms[0])
