@@ -112,6 +112,7 @@ def cpu_baseline(wl, ckw, pkw, per_it, label, target_seconds=12.0):
             n2 = int(min(1000000, max(4 * n0, port_rate / per_it * target_seconds * 0.5)))
             n1 = max(n0, n2 // 4)
             runs = []
+            rr.run_reference(po.make_cfg(**dict(ckw, nsimu=n0)), prob, timeout=300, pinned_svd=bool(cfgp.usesvd), timing_only=True)   # page the binary + MKL in
             for n in (n1, n2):
                 cfg = po.make_cfg(**dict(ckw, nsimu=n))
                 r = rr.run_reference(cfg, prob, timeout=300, pinned_svd=bool(cfg.usesvd), timing_only=True)

@@ -806,9 +806,12 @@ int mcmcx_init(mcmcx_handle h)
     const bool need_hist = am || c.record_chain;
     h->wcap = 0; E.hist = E.s2hist = nullptr; E.wacc = nullptr; E.record_s2 = 0;
     if (need_hist) {
-        // AP windows (adapthist > 1) may reach back to an arbitrarily old row: keep everything
+        // AP windows (adapthist > 1) may reach back to an arbitrarily old row: keep everything.  Otherwise the longest
+        // window is the first AM one, rows 2 .. T1 with T1 the first multiple of adaptint / badaptint that is
+        // >= burnintime + adaptint + adapthist (MCMC_adapt.F90:42-46,105): up to adaptint - 1 iterations past that
+        // threshold when it is not a multiple itself (burn-in ticks only rescale and never restart the window)
         long long wc = (c.record_chain || (am && c.adapthist > 1)) ? (long long)c.nsimu + 1
-                                      : (long long)c.burnintime + c.adaptint + c.adapthist + 2;
+                                      : (long long)c.burnintime + 2LL * c.adaptint + c.adapthist + 2;
         if (wc > (long long)c.nsimu + 1) wc = (long long)c.nsimu + 1;
         h->wcap = (int)wc;
         if ((rc = dev_alloc(h, &E.hist, L * (size_t)h->wcap * (d + ny), false))) return rc;

@@ -62,7 +62,8 @@ module mcmcmod
   real(kind=dbl), save :: banana_b = 0.1_dbl
   character(len=256), save :: mufile = 'mcmctest_mu.dat', lamfile = 'mcmctest_lam.dat'
   character(len=256), save :: datafile = 'data.dat', lowerfile = '', upperfile = ''
-  namelist /mcmcx/ devtarget, nchains, seed, pooled, banana_b, mufile, lamfile, datafile, lowerfile, upperfile
+  integer, save :: ngpus = 1                           ! GPUs of this node: nchains/ngpus chains each, one RCCL communicator
+  namelist /mcmcx/ devtarget, nchains, seed, pooled, banana_b, mufile, lamfile, datafile, lowerfile, upperfile, ngpus
 
   !! public state, mcmc.F90:28-52
   integer, save :: npar = 0, nycol = 1, simuind = 0, chainind = 0, MCMC_running = 0
@@ -79,7 +80,8 @@ module mcmcmod
   logical, save, private :: par0ok = .false., cmat0ok = .false., sigma2ok = .false., nparok = .false.
   logical, save, private :: has_lo = .false., has_hi = .false., interrupted = .false.
   character(len=32), save, private :: seedfile_used = ''
-  type(c_ptr), save, private :: handle = c_null_ptr
+  type(c_ptr), save, private :: handle = c_null_ptr                  ! the engine of GPU 0 (= handles(1)): chain 1 lives there
+  type(c_ptr), allocatable, save, private :: handles(:), comms(:)    ! one engine + one communicator rank per GPU
 
   interface MCMC_setpar0
      module procedure MCMC_setpar0_vec, MCMC_setpar0_n, MCMC_setpar0_file
@@ -253,6 +255,42 @@ module mcmcmod
      function mcmcx_get_scalars(h, out) bind(C, name='mcmcx_get_scalars') result(rc)
        import :: c_ptr, c_int, c_double
        type(c_ptr), value :: h
+       real(c_double), intent(out) :: out(*)
+       integer(c_int) :: rc
+     end function
+     function mcmcx_get_totals(h, t7) bind(C, name='mcmcx_get_totals') result(rc)
+       import :: c_ptr, c_int, c_int64_t
+       type(c_ptr), value :: h
+       integer(c_int64_t), intent(out) :: t7(7)
+       integer(c_int) :: rc
+     end function
+     function mcmcx_comm_create_all(ndev, devices, out) bind(C, name='mcmcx_comm_create_all') result(rc)
+       import :: c_ptr, c_int, c_int32_t
+       integer(c_int32_t), value :: ndev
+       type(c_ptr), value :: devices
+       type(c_ptr), intent(out) :: out(*)
+       integer(c_int) :: rc
+     end function
+     function mcmcx_comm_destroy(c) bind(C, name='mcmcx_comm_destroy') result(rc)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: c
+       integer(c_int) :: rc
+     end function
+     function mcmcx_set_comm(h, c) bind(C, name='mcmcx_set_comm') result(rc)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: h, c
+       integer(c_int) :: rc
+     end function
+     function mcmcx_run_all(hs, n, upto) bind(C, name='mcmcx_run_all') result(rc)
+       import :: c_ptr, c_int, c_int32_t
+       type(c_ptr), intent(in) :: hs(*)
+       integer(c_int32_t), value :: n, upto
+       integer(c_int) :: rc
+     end function
+     function mcmcx_allreduce_moments_all(hs, n, out) bind(C, name='mcmcx_allreduce_moments_all') result(rc)
+       import :: c_ptr, c_int, c_int32_t, c_double
+       type(c_ptr), intent(in) :: hs(*)
+       integer(c_int32_t), value :: n
        real(c_double), intent(out) :: out(*)
        integer(c_int) :: rc
      end function
@@ -619,13 +657,14 @@ contains
   subroutine MCMC_engine_run()
     type(mcmcx_config) :: cfg
     integer(c_int32_t) :: c8(8), nrows
+    integer(c_int64_t) :: t7(7)
     integer(c_int32_t), allocatable :: nob(:)
     real(kind=dbl), allocatable :: ch(:), ss(:), s2(:), cm(:), sc(:)
     real(kind=dbl), target, allocatable :: lo(:), hi(:)
     real(kind=dbl) :: lamrow(npar*npar)
     type(c_ptr) :: plo, phi
     real(kind=dbl), allocatable :: th(:), pm(:)
-    integer :: i, j, upto, nxt
+    integer :: i, j, g, upto, nxt, nloc, stbits
     integer(c_int) :: rc
     interface
        subroutine dump_init()
@@ -637,8 +676,16 @@ contains
     end interface
     call chk(mcmcx_install_signal_handlers())           ! signal_handler_init, MCMC_signal_handler.F90:21-60
     call read_seed_file()
+    !! &mcmcx ngpus = G: the nchains chains are split into G contiguous blocks, one engine per GPU, chain c keyed
+    !! (seed, c) whatever G is; the GPUs meet in one RCCL communicator for the pooled moments (SURVEY 8e)
+    if (ngpus < 1) ngpus = 1
+    if (mod(nchains, ngpus) /= 0) call doerror('&mcmcx: nchains must be a multiple of ngpus')
+    nloc = nchains / ngpus
+    allocate(handles(ngpus), comms(ngpus))
+    handles = c_null_ptr; comms = c_null_ptr
+    if (ngpus > 1) call chk(mcmcx_comm_create_all(int(ngpus, c_int32_t), c_null_ptr, comms))
     call mcmcx_config_defaults(cfg)
-    cfg%npar = npar; cfg%nchains = nchains; cfg%nsimu = nsimu
+    cfg%npar = npar; cfg%nchains = nloc; cfg%nsimu = nsimu
     select case (trim(method))
     case ('ram');  cfg%method = 1
     case ('scam'); cfg%method = 2
@@ -650,32 +697,15 @@ contains
     cfg%burnintime = burnintime; cfg%greedy = greedy; cfg%updatesigma = updatesigma
     cfg%scalelimit = scalelimit; cfg%scalefactor = scalefactor; cfg%drscale = drscale
     cfg%N0 = N0; cfg%S02 = S02; cfg%condmax = condmax; cfg%alphatarget = alphatarget; cfg%nuparam = nuparam
-    cfg%seed = seed; cfg%chain_id0 = 0; cfg%record_accept = 0; cfg%record_chain = 1; cfg%device = 0; cfg%pooled = pooled
-    call chk(mcmcx_create(cfg, handle))
-    call chk(mcmcx_set_par0(handle, par0, int(npar, c_int32_t)))
-    call chk(mcmcx_set_cmat0(handle, cmat0, int(npar, c_int32_t)))
+    cfg%seed = seed; cfg%record_accept = 0; cfg%pooled = pooled
     allocate(nob(nycol)); nob = nobs                    ! nycol response columns: one sigma2 / nobs each (host callbacks when > 1)
-    call chk(mcmcx_set_sigma2nobs(handle, sigma2, nob, int(nycol, c_int32_t)))
-    select case (trim(devtarget))
-    case ('gauss')
+    if (trim(devtarget) == 'gauss') then
        do i = 1, npar                                  ! row-major lam(i,j) for the C side
           do j = 1, npar
              lamrow((i-1)*npar + j) = tlam(i,j)
           end do
        end do
-       call chk(mcmcx_set_target_gauss(handle, tmu, lamrow))
-    case ('banana')
-       call chk(mcmcx_set_target_banana(handle, banana_b))
-    case ('expdata')
-       call chk(mcmcx_set_target_expdata(handle, int(size(tx), c_int32_t), tx, ty))
-    case ('expcols')
-       if (size(ty) /= size(tx)*nycol) call doerror('devtarget expcols: the data file needs 1 + nycol columns')
-       call chk(mcmcx_set_target_expdata_cols(handle, int(size(tx), c_int32_t), int(nycol, c_int32_t), tx, ty))
-    case ('host')
-       call chk(mcmcx_set_target_host(handle, c_funloc(mcx_ss_adapter), c_funloc(mcx_prior_adapter), &
-            c_funloc(mcx_bounds_adapter), c_null_ptr))
-       call chk(mcmcx_set_target_host_er(handle, c_funloc(mcx_ss_er_adapter)))     ! used by method = 'er' only
-    end select
+    end if
     plo = c_null_ptr; phi = c_null_ptr
     if (has_lo) then
        allocate(lo(npar)); lo = tlo; plo = c_loc(lo)
@@ -683,9 +713,35 @@ contains
     if (has_hi) then
        allocate(hi(npar)); hi = thi; phi = c_loc(hi)
     end if
-    if (has_lo .or. has_hi) call chk(mcmcx_set_bounds(handle, plo, phi))
-    if (allocated(pmu)) call chk(mcmcx_set_priors(handle, pmu, psig))
-    call chk(mcmcx_init(handle))
+    do g = 1, ngpus
+       cfg%device = g - 1; cfg%chain_id0 = (g - 1) * nloc
+       cfg%record_chain = merge(1, 0, g == 1)           ! the reference's chain arrays hold chain 1, which lives on GPU 0
+       call chk(mcmcx_create(cfg, handles(g)))
+       handle = handles(g)
+       if (ngpus > 1) call chk(mcmcx_set_comm(handle, comms(g)))
+       call chk(mcmcx_set_par0(handle, par0, int(npar, c_int32_t)))
+       call chk(mcmcx_set_cmat0(handle, cmat0, int(npar, c_int32_t)))
+       call chk(mcmcx_set_sigma2nobs(handle, sigma2, nob, int(nycol, c_int32_t)))
+       select case (trim(devtarget))
+       case ('gauss')
+          call chk(mcmcx_set_target_gauss(handle, tmu, lamrow))
+       case ('banana')
+          call chk(mcmcx_set_target_banana(handle, banana_b))
+       case ('expdata')
+          call chk(mcmcx_set_target_expdata(handle, int(size(tx), c_int32_t), tx, ty))
+       case ('expcols')
+          if (size(ty) /= size(tx)*nycol) call doerror('devtarget expcols: the data file needs 1 + nycol columns')
+          call chk(mcmcx_set_target_expdata_cols(handle, int(size(tx), c_int32_t), int(nycol, c_int32_t), tx, ty))
+       case ('host')
+          call chk(mcmcx_set_target_host(handle, c_funloc(mcx_ss_adapter), c_funloc(mcx_prior_adapter), &
+               c_funloc(mcx_bounds_adapter), c_null_ptr))
+          call chk(mcmcx_set_target_host_er(handle, c_funloc(mcx_ss_er_adapter)))     ! used by method = 'er' only
+       end select
+       if (has_lo .or. has_hi) call chk(mcmcx_set_bounds(handle, plo, phi))
+       if (allocated(pmu)) call chk(mcmcx_set_priors(handle, pmu, psig))
+       call chk(mcmcx_init(handle))
+    end do
+    handle = handles(1)
     call dump_init()                                    ! MCMC_dump_init, MCMC_run.F90:38
     MCMC_running = 1
     interrupted = .false.
@@ -698,7 +754,7 @@ contains
        if (dumpint > 0) nxt = min(nxt, (upto / dumpint + 1) * dumpint)
        if (printint > 0) nxt = min(nxt, (upto / printint + 1) * printint)
        upto = nxt
-       rc = mcmcx_run(handle, int(upto, c_int32_t))
+       rc = mcmcx_run_all(handles, int(ngpus, c_int32_t), int(upto, c_int32_t))
        call chk(rc)
        if (rc == 2) then                                ! MCMCX_INTERRUPTED: cc_handler, MCMC_signal_handler.F90:95-107
           interrupted = .true.
@@ -709,19 +765,21 @@ contains
        end if
        if (dumpint > 0) then
           if (mod(upto, dumpint) == 0 .or. upto == nsimu) then
-             allocate(th(npar*nchains))
+             allocate(th(npar*nloc))
              call chk(mcmcx_get_theta(handle, th))
              call dump(th(1:npar))
              deallocate(th)
           end if
        end if
     end do
-    call chk(mcmcx_sync(handle))
+    do g = 1, ngpus
+       call chk(mcmcx_sync(handles(g)))
+    end do
     MCMC_running = 0
     simuind = mcmcx_simuind(handle)
     if (interrupted) write(*,*) 'Saving chain upto ', simuind
     !! chain 0 in the reference's arrays
-    allocate(ch(nsimu*(npar+1)), ss(nsimu*(nycol+1)), s2(nsimu*nycol), cm(npar*npar), sc(4*nchains))
+    allocate(ch(nsimu*(npar+1)), ss(nsimu*(nycol+1)), s2(nsimu*nycol), cm(npar*npar), sc(4*nloc))
     call chk(mcmcx_get_chain(handle, 0_c_int32_t, ch, ss, s2, nrows))
     chainind = nrows
     if (allocated(chain)) deallocate(chain, sschain)
@@ -749,13 +807,32 @@ contains
     if (updatesigma /= 0 .and. simuind >= 1) sigma2 = s2chain(simuind,:)
     !! several chains: what the reference has no counterpart for -- the last state of every chain and the moments of
     !! those states over all chains (about par0: count, sum, upper second moments)
+    !! where the reference would have stopped or warned (the engine records it per chain and carries on): a failed
+    !! choldowndate stops (matutils.F90:719-722), so does a covariance that cannot be inverted for DR
+    !! (MCMC_adapt.F90:221-224); a failed Cholesky / SVD keeps the old factor with a warning (MCMC_adapt.F90:168-171)
+    stbits = 0
+    do g = 1, ngpus
+       call chk(mcmcx_get_totals(handles(g), t7))
+       stbits = ior(stbits, int(t7(7)))
+    end do
+    if (iand(stbits, 2) /= 0) write(*,*) 'Warning: error in Chol/SVD, not adapting (some chain and tick)'
+    if (iand(c8(6), 1) /= 0) call doerror('error in coldowndate, info: -1')
+    if (iand(c8(6), 4) /= 0) call doerror('ERROR: cannot invert cmat')
+    if (iand(stbits, 1) /= 0) write(*,*) 'Warning: choldowndate failed (info = -1) in some chain other than chain 1; its factor was left unchanged'
+    if (iand(stbits, 4) /= 0) write(*,*) 'Warning: cannot invert cmat in some chain other than chain 1'
     if (nchains > 1) then
-       allocate(th(npar*nchains), pm(1 + npar + npar*(npar+1)/2))
-       call chk(mcmcx_get_theta(handle, th))
+       allocate(th(npar*nloc), pm(1 + npar + npar*(npar+1)/2))
        if (allocated(laststates)) deallocate(laststates, pooledmean, pooledcov)
        allocate(laststates(nchains, npar), pooledmean(npar), pooledcov(npar, npar))
-       laststates = transpose(reshape(th, (/npar, nchains/)))
-       call chk(mcmcx_pooled_moments(handle, pm))
+       do g = 1, ngpus
+          call chk(mcmcx_get_theta(handles(g), th))
+          laststates((g-1)*nloc+1 : g*nloc, :) = transpose(reshape(th, (/npar, nloc/)))
+       end do
+       if (ngpus > 1) then
+          call chk(mcmcx_allreduce_moments_all(handles, int(ngpus, c_int32_t), pm))      ! RCCL: all GPUs' chains
+       else
+          call chk(mcmcx_pooled_moments(handle, pm))
+       end if
        do j = 1, npar
           pooledmean(j) = pm(1 + j) / pm(1)
        end do
@@ -899,13 +976,20 @@ contains
 
   subroutine MCMC_cleanup()
     integer(c_int) :: rc
+    integer :: g
     interface
        subroutine dump_end()
        end subroutine dump_end
     end interface
     call write_seed_file()                              ! random_eoj, MCMC_aux.F90:115
     call dump_end()                                     ! MCMC_dump_end, MCMC_aux.F90:116
-    rc = mcmcx_destroy(handle)
+    if (allocated(handles)) then
+       do g = 1, size(handles)
+          rc = mcmcx_destroy(handles(g))
+          if (c_associated(comms(g))) rc = mcmcx_comm_destroy(comms(g))
+       end do
+       deallocate(handles, comms)
+    end if
     handle = c_null_ptr
     nparok = .false.; par0ok = .false.; cmat0ok = .false.; sigma2ok = .false.
   end subroutine MCMC_cleanup
@@ -931,3 +1015,14 @@ subroutine mcmc_main()
   call MCMC_cleanup()
   if (was_interrupted()) stop 'Coltrol-c interrupt'      ! [sic] MCMC_signal_handler.F90:105
 end subroutine mcmc_main
+
+!!! mcmc_main_one, mcmc_main.F90:49-70: consecutive one-step invocations through MCMC_run1's file protocol
+!!! (MCMC_run1.F90:62-107,229-252: one evaluation per program run, state carried in files).  A GPU engine has nothing
+!!! to offer one iteration at a time on one chain: the entry point exists so that programs link, and stops with a
+!!! message -- use mcmc_main.
+subroutine mcmc_main_one()
+  use mcmcmod
+  implicit none
+  write(*,*) 'MCMC code version: ', Mcmc_Code_Version
+  call doerror('mcmc_main_one (the one-iteration-per-invocation file protocol of MCMC_run1) is not supported by the mcmcx engine; call mcmc_main')
+end subroutine mcmc_main_one

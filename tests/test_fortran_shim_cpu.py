@@ -29,7 +29,7 @@ def test_shim_builds_and_reads_inputs():
     build.build()
     subprocess.check_call(["make", "-s", "-C", FDIR])
     syms = subprocess.check_output(["nm", os.path.join(FDIR, "libmcmcxf.a")]).decode()
-    for sym in ("mcmc_main_", "ssfunction_", "checkbounds_", "priorfun_", "mcx_ss_adapter"):
+    for sym in ("mcmc_main_", "mcmc_main_one_", "ssfunction_", "checkbounds_", "priorfun_", "mcx_ss_adapter"):     # mcmc_main.F90:12,49
         assert sym in syms, sym
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "mcmcinit.nml"), "w").write(NML)

@@ -447,3 +447,35 @@ def test_two_response_columns_with_the_device_resident_target(oracle):
     assert last.shape == (96, 3)
     o95 = oracle.run_chain(cfg, prob, chain_id=95)
     np.testing.assert_allclose(last[95], o95.theta, rtol=1e-13)
+
+
+def test_ngpus_namelist_variable():
+    """&mcmcx ngpus: one engine per GPU under one RCCL communicator (mcmcx_comm_create_all / mcmcx_run_all).  The test
+    box has one GPU: ngpus = 1 must equal the default run, ngpus = 2 must stop with the engine's message instead of
+    quietly running on one device."""
+    exe = os.path.join(FDIR, "demo_main")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", FDIR])
+    import ctypes
+    n = ctypes.c_int(0)
+    ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(n))
+    nml = "&mcmc\n method = 'dram'\n nsimu = 300\n updatesigma = 0\n verbosity = 0\n/\n&mcmcx\n devtarget = 'banana'\n nchains = 128\n ngpus = %d\n pooled = %d\n/\n"
+    res = {}
+    for ng, pooled in ((1, 0), (2, 0), (2, 1)):
+        with tempfile.TemporaryDirectory() as d:
+            open(os.path.join(d, "mcmcinit.nml"), "w").write(nml % (ng, pooled))
+            open(os.path.join(d, "mcmcpar.dat"), "w").write("0 0 0 0\n")
+            open(os.path.join(d, "mcmccov.dat"), "w").write("1 0 0 0\n0 1 0 0\n0 0 1 0\n0 0 0 1\n")
+            p = subprocess.run([exe], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+            out = p.stdout.decode(errors="replace")
+            if ng > n.value:
+                assert p.returncode != 0 and "HIP device(s) are visible" in out, out
+                assert not os.path.exists(os.path.join(d, "chain.dat"))
+                continue
+            assert p.returncode == 0, out
+            res[(ng, pooled)] = (np.loadtxt(os.path.join(d, "chain.dat"), ndmin=2), np.loadtxt(os.path.join(d, "mcmclaststates.dat"), ndmin=2),
+                                 np.loadtxt(os.path.join(d, "mcmcpooledcov.dat"), ndmin=2))
+    assert res[(1, 0)][1].shape == (128, 4)
+    if (2, 0) in res:                                   # a multi-GPU box: the chains do not depend on the GPU count
+        for a, b in zip(res[(1, 0)], res[(2, 0)]):
+            np.testing.assert_array_equal(a, b)

@@ -250,3 +250,35 @@ def test_engines_release_their_device_memory(oracle):
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 64 * 1024 * 1024, (free0, free1)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(burnintime=50, adaptint=100, doburnin=0),                  # first AM tick at 200, not at the threshold 150
+    dict(burnintime=130, adaptint=100, doburnin=1, badaptint=40),   # burn-in ticks only rescale; first AM tick at 240 (threshold 230)
+    dict(burnintime=37, adaptint=64, adapthist=1, doburnin=0),      # adapthist = 1: threshold 102, tick at 128
+    dict(burnintime=0, adaptint=100, doburnin=0),                   # aligned (the case every fixture has)
+], ids=["burn50", "burn130_b40", "hist1", "aligned"])
+@pytest.mark.parametrize("dr", [0.0, 2.0], ids=["am", "dram"])
+def test_history_ring_without_record_chain(oracle, kw, dr):
+    """record_chain = 0 (what bench.py runs): the history ring only holds the adaptation window.  Its size must cover
+    the FIRST window, which is longer than burnintime + adaptint + adapthist whenever that threshold is not a multiple
+    of adaptint: final state, factor and covariance bit for bit against the oracle."""
+    from mcmcf90_amd import engine_from_problem
+    d = 6
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((d, d)); lam = A @ A.T + d * np.eye(d)
+    ckw = dict(nsimu=700, updatesigma=0, drscale=dr, **kw)
+    pkw = dict(kind="gauss", npar=d, par0=np.zeros(d), cmat0=0.05 * np.eye(d), mu=np.zeros(d), lam=lam)
+    e = engine_from_problem(ckw, pkw, nchains=70, record_accept=1, record_chain=0)
+    e.init(); e.run()
+    th = e.theta()
+    for c in (0, 5, 64, 69):
+        o = oracle.run_chain(oracle.make_cfg(**ckw), oracle.Problem(**pkw), chain_id=c)
+        np.testing.assert_array_equal(e.accepted(c), o.accepted)
+        np.testing.assert_array_equal(_bits(th[c]), _bits(o.theta))
+        np.testing.assert_array_equal(_bits(np.triu(e.R(c))), _bits(np.triu(o.R)))
+        cm, mean, wsum = e.chaincov(c)
+        np.testing.assert_array_equal(_bits(np.triu(cm)), _bits(np.triu(o.chaincmat)))
+        np.testing.assert_array_equal(_bits(mean), _bits(o.chainmean))
+        assert wsum == o.chainwsum
+    e.close()
