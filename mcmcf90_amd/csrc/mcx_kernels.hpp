@@ -605,6 +605,12 @@ MCX_DEV void trmv_shared(const double *__restrict__ Rs, const double *z_t, doubl
 // Rotations (c_i, s_i) of the first NLC rows are kept in LDS (lc), the rest in global scratch: row i's rotation is
 // re-read by every later panel, and the early rows are the ones re-read most often.
 constexpr int NLC = 19;     // 19 rows x 2 doubles x 64 lanes = 19 456 B per wave: 8 waves fill the CU's 160 KiB
+// MIXED: the wave holds update AND downdate lanes (RAM near its target acceptance rate).  Stores that cover part of a
+// 512-byte row segment are slow whichever lanes they are (tools/layout_probe2.hip: read all + write 22 % of the lanes
+// takes longer than read all + write all), so in such a wave every lane stores in both sweeps -- the lanes a sweep does
+// not concern store the value they loaded -- and each sweep writes whole segments.  A wave of one kind (the bench's
+// default start: no downdates) takes the other instantiation, whose update sweep stores from inside its own branch.
+template <bool MIXED>
 MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, double *cs_t, double *P_t,
                         const double *theta_t, int lane, int d, double a, double su, bool act, bool fuse, uint32_t &status,
                         double *lc, bool &pdesc)
@@ -623,28 +629,69 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                 double xa[RW], P[RW];
 #pragma unroll
                 for (int u = 0; u < RW; ++u) { xa[u] = up ? GV(zc_t, J0 + (u < nw ? u : nw - 1)) / su * a : 0.0; P[u] = 0.0; }   // x = u/sum(u**2)*a
-#pragma unroll 2
-                for (int i = 0; i < J0; ++i) {                           // rows above the diagonal block
-                    double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
-                    double r[RW];
+if (MIXED) {
+                    // next row's loads before this row's stores (see sweep B)
+                    // (c, s) of an update lane or the substitution's a_i of a downdate lane, and z_next: one row ahead as well
+                    double rn[RW], cn = 0.0, sn_ = 0.0, zn_ = 0.0;
+                    if (J0 > 0) {
+                        const double *sg = Rt + (size_t)J0 * 64;
 #pragma unroll
-                    for (int u = 0; u < RW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
-                    if (up) {
-                        const bool inl = lc && i < NLC;
-                        const double c = inl ? lc[(2 * i) * 64 + lane] : GV(cs_t, 2 * i);
-                        const double sn = inl ? lc[(2 * i + 1) * 64 + lane] : GV(cs_t, 2 * i + 1);
-                        const double zi = fuse ? GV(zn_t, i) : 0.0;
+                        for (int u = 0; u < RW; ++u) rn[u] = LDNT(sg, u < nw ? u : nw - 1);
+                        sn_ = CS_(0, 1);
+                        if (up) { cn = CS_(0, 0); zn_ = fuse ? GV(zn_t, 0) : 0.0; }
+                    }
+                    for (int i = 0; i < J0; ++i) {                       // rows above the diagonal block
+                        double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
+                        double r[RW];
 #pragma unroll
-                        for (int u = 0; u < RW; ++u) {
-                            double t = c * r[u] + sn * xa[u];
-                            xa[u] = c * xa[u] - sn * r[u];
-                            if (u < nw) STNT(seg, u, t);
-                            P[u] = dfma(t, zi, P[u]);
+                        for (int u = 0; u < RW; ++u) r[u] = rn[u];
+                        const double c = cn, sn = sn_, zi = zn_;
+                        if (i + 1 < J0) {
+                            const double *sg = Rt + (size_t)(rowstart(i + 1, d) + J0 - (i + 1)) * 64;
+#pragma unroll
+                            for (int u = 0; u < RW; ++u) rn[u] = LDNT(sg, u < nw ? u : nw - 1);
+                            sn_ = CS_(i + 1, 1);
+                            if (up) { cn = CS_(i + 1, 0); zn_ = fuse ? GV(zn_t, i + 1) : 0.0; }
                         }
-                    } else {
-                        const double si = CS_(i, 1);
+                        if (up) {
 #pragma unroll
-                        for (int u = 0; u < RW; ++u) xa[u] = dfma(r[u], si, xa[u]);
+                            for (int u = 0; u < RW; ++u) {
+                                double t = c * r[u] + sn * xa[u];
+                                xa[u] = c * xa[u] - sn * r[u];
+                                r[u] = t;
+                                P[u] = dfma(t, zi, P[u]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < RW; ++u) xa[u] = dfma(r[u], sn, xa[u]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < RW; ++u) if (u < nw) STNT(seg, u, r[u]);
+                    }
+                } else {
+#pragma unroll 2
+                    for (int i = 0; i < J0; ++i) {                       // rows above the diagonal block
+                        double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
+                        double r[RW];
+#pragma unroll
+                        for (int u = 0; u < RW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
+                        if (up) {
+                            const bool inl = lc && i < NLC;
+                            const double c = inl ? lc[(2 * i) * 64 + lane] : GV(cs_t, 2 * i);
+                            const double sn = inl ? lc[(2 * i + 1) * 64 + lane] : GV(cs_t, 2 * i + 1);
+                            const double zi = fuse ? GV(zn_t, i) : 0.0;
+#pragma unroll
+                            for (int u = 0; u < RW; ++u) {
+                                double t = c * r[u] + sn * xa[u];
+                                xa[u] = c * xa[u] - sn * r[u];
+                                if (u < nw) STNT(seg, u, t);
+                                P[u] = dfma(t, zi, P[u]);
+                            }
+                        } else {
+                            const double si = CS_(i, 1);
+#pragma unroll
+                            for (int u = 0; u < RW; ++u) xa[u] = dfma(r[u], si, xa[u]);
+                        }
                     }
                 }
                 for (int i = J0; i < J0 + nw; ++i) {                     // diagonal block
@@ -669,7 +716,8 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                             double t = c * r[u] + sn * xa[u];
                             double nx = c * xa[u] - sn * r[u];
                             xa[u] = off ? nx : xa[u];
-                            if (off) STNT(seg, u - ui, t);
+                            if (!MIXED) { if (off) STNT(seg, u - ui, t); }
+                            else r[u] = off ? t : r[u];
                             double tp = (u == ui) ? rr : t;
                             double np = dfma(tp, zi, P[u]);
                             P[u] = (u >= ui && u < nw) ? np : P[u];
@@ -680,6 +728,10 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                         CS_(i, 1) = si;
 #pragma unroll
                         for (int u = 0; u < RW; ++u) { double na = dfma(r[u], si, xa[u]); xa[u] = (u > ui) ? na : xa[u]; }
+                    }
+                    if (MIXED) {                                         // the off-diagonal part of the row, every lane
+#pragma unroll
+                        for (int u = 0; u < RW; ++u) if ((u > ui) && (u < nw)) STNT(seg, u - ui, r[u]);
                     }
                 }
                 if (up && fuse) {                        // next candidate = theta + R_new' z_next (MCMC_DRAM.F90:29)
@@ -726,8 +778,14 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                     CS_(k, 1) = bb / nn;
                     alpha = scale * nn;
                 }
-                // ---- pass B (dchdd.f:171-179): each column from its diagonal up; the next proposal accumulates in that
-                // same order (mcxo_trmv_ut_desc), so downdate lanes, too, read and write the factor once more and are done
+            }
+        }
+        // ---- pass B (dchdd.f:171-179): each column from its diagonal up; the next proposal accumulates in that
+        // same order (mcxo_trmv_ut_desc), so downdate lanes, too, read and write the factor once more and are done.
+        // MIXED: every lane of the wave loads and stores (whole segments); only the downdate lanes change the values.
+        const bool touch = MIXED ? act : down_ok;
+        if (__any(down_ok)) {
+            if (touch) {
                 for (int J0 = 0; J0 < d; J0 += RW) {
                     const int nw = (d - J0) < RW ? (d - J0) : RW;
                     double xx[RW], P[RW];
@@ -736,40 +794,85 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                     for (int i = J0 + nw - 1; i >= J0; --i) {            // diagonal block, rows descending
                         double *seg = Rt + (size_t)rowstart(i, d) * 64;
                         const int ui = i - J0, m = d - 1 - i;
-                        const double ci = CS_(i, 0), si = CS_(i, 1);
-                        const double zi = fuse ? GV(zn_t, i) : 0.0;
                         double r[RW];
 #pragma unroll
                         for (int u = 0; u < RW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDB(seg, k); }
+                        if (!MIXED || down_ok) {
+                            const double ci = CS_(i, 0), si = CS_(i, 1);
+                            const double zi = fuse ? GV(zn_t, i) : 0.0;
 #pragma unroll
-                        for (int u = 0; u < RW; ++u) {
-                            const bool on = (u >= ui) && (u < nw);
-                            double t = ci * xx[u] + si * r[u];
-                            double nr = ci * r[u] - si * xx[u];
-                            if (on) STB(seg, u - ui, nr);
-                            xx[u] = on ? t : xx[u];
-                            const double np = (u == ui) ? nr * zi : dfma(nr, zi, P[u]);
-                            P[u] = on ? np : P[u];
+                            for (int u = 0; u < RW; ++u) {
+                                const bool on = (u >= ui) && (u < nw);
+                                double t = ci * xx[u] + si * r[u];
+                                double nr = ci * r[u] - si * xx[u];
+                                if (!MIXED) { if (on) STB(seg, u - ui, nr); }
+                                else r[u] = on ? nr : r[u];
+                                xx[u] = on ? t : xx[u];
+                                const double np = (u == ui) ? nr * zi : dfma(nr, zi, P[u]);
+                                P[u] = on ? np : P[u];
+                            }
+                        }
+                        if (MIXED) {
+#pragma unroll
+                            for (int u = 0; u < RW; ++u) if ((u >= ui) && (u < nw)) STB(seg, u - ui, r[u]);
                         }
                     }
+if (MIXED) {
+                        // The next row's loads go out before this row's stores: vmcnt retires in order, so a load issued
+                        // after a store cannot be waited for without waiting for that store's acknowledgement -- which
+                        // would put the store latency on every row's critical path.
+                        double rn[RW], cn = 0.0, sn_ = 0.0, zn_ = 0.0;
+                        if (J0 > 0) {
+                            const double *sg = Rt + (size_t)(rowstart(J0 - 1, d) + 1) * 64;
+#pragma unroll
+                            for (int u = 0; u < RW; ++u) rn[u] = LDB(sg, u < nw ? u : nw - 1);
+                            if (down_ok) { cn = CS_(J0 - 1, 0); sn_ = CS_(J0 - 1, 1); zn_ = fuse ? GV(zn_t, J0 - 1) : 0.0; }
+                        }
+                        for (int i = J0 - 1; i >= 0; --i) {              // rows above, descending
+                            double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
+                            double r[RW];
+#pragma unroll
+                            for (int u = 0; u < RW; ++u) r[u] = rn[u];
+                            const double ci = cn, si = sn_, zi = zn_;
+                            if (i > 0) {
+                                const double *sg = Rt + (size_t)(rowstart(i - 1, d) + J0 - (i - 1)) * 64;
+#pragma unroll
+                                for (int u = 0; u < RW; ++u) rn[u] = LDB(sg, u < nw ? u : nw - 1);
+                                if (down_ok) { cn = CS_(i - 1, 0); sn_ = CS_(i - 1, 1); zn_ = fuse ? GV(zn_t, i - 1) : 0.0; }
+                            }
+                            if (down_ok) {
+#pragma unroll
+                                for (int u = 0; u < RW; ++u) {
+                                    double t = ci * xx[u] + si * r[u];
+                                    const double nr = ci * r[u] - si * xx[u];
+                                    r[u] = nr;
+                                    xx[u] = t;
+                                    P[u] = dfma(nr, zi, P[u]);
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < RW; ++u) if (u < nw) STB(seg, u, r[u]);
+                        }
+                    } else {
 #pragma unroll 2
-                    for (int i = J0 - 1; i >= 0; --i) {                  // rows above, descending
-                        double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
-                        const double ci = CS_(i, 0), si = CS_(i, 1);
-                        const double zi = fuse ? GV(zn_t, i) : 0.0;
-                        double r[RW];
+                        for (int i = J0 - 1; i >= 0; --i) {              // rows above, descending
+                            double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
+                            const double ci = CS_(i, 0), si = CS_(i, 1);
+                            const double zi = fuse ? GV(zn_t, i) : 0.0;
+                            double r[RW];
 #pragma unroll
-                        for (int u = 0; u < RW; ++u) r[u] = LDB(seg, u < nw ? u : nw - 1);
+                            for (int u = 0; u < RW; ++u) r[u] = LDB(seg, u < nw ? u : nw - 1);
 #pragma unroll
-                        for (int u = 0; u < RW; ++u) {
-                            double t = ci * xx[u] + si * r[u];
-                            const double nr = ci * r[u] - si * xx[u];
-                            if (u < nw) STB(seg, u, nr);
-                            xx[u] = t;
-                            P[u] = dfma(nr, zi, P[u]);
+                            for (int u = 0; u < RW; ++u) {
+                                double t = ci * xx[u] + si * r[u];
+                                const double nr = ci * r[u] - si * xx[u];
+                                if (u < nw) STB(seg, u, nr);
+                                xx[u] = t;
+                                P[u] = dfma(nr, zi, P[u]);
+                            }
                         }
                     }
-                    if (fuse) {
+                    if (fuse && down_ok) {
 #pragma unroll
                         for (int u = 0; u < RW; ++u) if (u < nw) GV(P_t, J0 + u) = GV(theta_t, J0 + u) + P[u];
                     }
@@ -1009,7 +1112,9 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
             double a = ramscale[it - it0] * (alpha12 - E.alphatarget);
             downs += (a >= 0.0) ? 0u : 1u;
             if (FULLR) ram_update_full(E.Rf + (size_t)tile * d * d * 64, zc_t, cs_t, lane, d, a, su_c, true, status);   // condmax > 0
-            else have_p = ram_update(Rt, zc_t, zn_t, cs_t, cand_t, theta_t, lane, d, a, su_c, true, pre, status, RAM ? X : nullptr, pdesc);
+            else if (__any(!(a >= 0.0)))                  // a wave with downdate lanes: whole-segment stores in both sweeps
+                have_p = ram_update<true>(Rt, zc_t, zn_t, cs_t, cand_t, theta_t, lane, d, a, su_c, true, pre, status, RAM ? X : nullptr, pdesc);
+            else have_p = ram_update<false>(Rt, zc_t, zn_t, cs_t, cand_t, theta_t, lane, d, a, su_c, true, pre, status, RAM ? X : nullptr, pdesc);
         }
         su_c = su_n;
     }
@@ -1606,7 +1711,7 @@ MCX_DEV void host_finish(const EngineDev &E, int tile, int lane, int it, LaneSta
         if (!(a >= 0.0)) TIDX(E.ictr, tile, NICTR, I_DOWNS, lane) += 1u;
         const double *hx = E.hx + (size_t)tile * NHX * 64;
         if (E.usesvd) ram_update_full(E.Rf + (size_t)tile * d * d * 64, zs_t, cs_t, lane, d, a, GV(hx, HX_SU), true, L.status);
-        else { bool pd = L.pdesc != 0u; ram_update(E.R + (size_t)tile * E.P * 64, zs_t, zs_t, cs_t, cand_t, theta_t, lane, d, a, GV(hx, HX_SU), true, false, L.status, nullptr, pd); L.pdesc = pd ? 1u : 0u; }
+        else { bool pd = L.pdesc != 0u; ram_update<false>(E.R + (size_t)tile * E.P * 64, zs_t, zs_t, cs_t, cand_t, theta_t, lane, d, a, GV(hx, HX_SU), true, false, L.status, nullptr, pd); L.pdesc = pd ? 1u : 0u; }
     }
 }
 
