@@ -297,7 +297,11 @@ static void launch_scam(mcmcx_engine *h, int it0, int it1)
 static void launch_adapt(mcmcx_engine *h, int it, int mode)
 {
     const size_t lds = std::max(lds_bytes(h) / 2, (size_t)44 * 64 * sizeof(double));    // one d-vector / the Cholesky's diagonal block
-    hipLaunchKernelGGL(adapt_kernel, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode);
+    const int nb = (h->d + 7) / 8, nblk = nb * (nb + 1) / 2;
+    hipLaunchKernelGGL(adapt_pre_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it, mode);
+    if (!((mode & AD_AM) && h->cfg.adapthist > 1))                        // the AP window is a batch recompute: no blocked update
+        hipLaunchKernelGGL(adapt_cov_kernel, dim3((unsigned)(8 * ((h->ntiles + 7) / 8) * nblk)), dim3(64), 0, h->stream, h->E, it, mode, nblk);
+    hipLaunchKernelGGL(adapt_post_kernel, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode);
 }
 
 // Which branch of MCMC_adapt fires at iteration `it` (0 = none).  MCMC_adapt.F90:42-46, 60-61, 105.

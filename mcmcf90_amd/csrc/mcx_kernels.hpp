@@ -30,10 +30,10 @@ enum { TGT_GAUSS = 0, TGT_BANANA = 1, TGT_EXPDATA = 2, TGT_HOST = 3, TGT_EXPCOLS
 enum { M_DRAM = 0, M_RAM = 1, M_ER = 3 };
 
 // per-chain scalar slots (doubles)
-enum { S_SS1 = 0, S_PRI1, S_SIGMA2, S_ALPHA12, S_SAVEDY, S_WSUM, NSCAL };
+enum { S_SS1 = 0, S_PRI1, S_SIGMA2, S_ALPHA12, S_SAVEDY, S_WSUM, S_WNEW, NSCAL };   // S_WNEW: chainwsum after the blocked covariance update (adapt_cov_kernel -> adapt_post_kernel)
 // per-chain integer slots (u32)
 enum { I_SAVED = 0, I_STAYED, I_BNDSTAYED, I_DRACC, I_DRTRIES, I_CHAININD, I_CURCOUNT, I_STATUS,
-       I_LASTFREQ, I_BASECNT, I_WINSTART, I_INFO, I_ERSTAYED, I_PDESC, I_DOWNS, NICTR };   // I_PDESC: 1 after a successful RAM downdate; I_DOWNS: RAM iterations with a < 0 (choldowndate)
+       I_LASTFREQ, I_BASECNT, I_WINSTART, I_INFO, I_ERSTAYED, I_PDESC, I_DOWNS, I_ADFLAGS, I_NR, NICTR };   // I_PDESC: 1 after a successful RAM downdate; I_DOWNS: RAM iterations with a < 0 (choldowndate)
 
 // status bits
 enum { ST_RAM_DOWNDATE_FAIL = 1, ST_CHOL_FAIL = 2, ST_POTRI_FAIL = 4 };
@@ -2210,8 +2210,8 @@ MCX_DEV void covmat_rows(const EngineDev &E, int tile, int lane, const uint64_t 
 //                           (lastfreq) taken off the first folded weight          (AM: MCMC_adapt.F90:140-147)
 //   unit                  : every row has weight 1 and there is no base row       (greedy: MCMC_adapt.F90:91)
 MCX_DEV void covmat_window_blocked(const EngineDev &E, int tile, int lane, bool act, int t0lane, int t1, bool unit,
-                                   uint32_t count0, uint32_t adj0, double *Ct, double *mean_t, const double *base_t,
-                                   double *mnew_t, double &wsum)
+                                   uint32_t count0, uint32_t adj0, double *Ct, const double *mean_t, const double *base_t,
+                                   double *mnew_t, double wsum, int a0, int b0, double &Wend)
 {
     const int d = E.d;
     int t0 = act ? t0lane : 0x7fffffff;
@@ -2220,9 +2220,9 @@ MCX_DEV void covmat_window_blocked(const EngineDev &E, int tile, int lane, bool 
     if (t0 == 0x7fffffff) return;
     const double *hist_t = E.hist + (size_t)tile * E.wcap * (size_t)E.hs * 64;
     const unsigned long long *wacc_t = (const unsigned long long *)E.wacc + (size_t)tile * E.wcap;
-    double Wend = wsum;
-    for (int a0 = 0; a0 < d; a0 += 8) {
-        for (int b0 = a0; b0 < d; b0 += 8) {
+    Wend = wsum;
+    {
+        {
             double C[8][8], ma[8], mb[8], xa[8], xb[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -2242,28 +2242,28 @@ MCX_DEV void covmat_window_blocked(const EngineDev &E, int tile, int lane, bool 
             double W = wsum;
             bool have = act && !unit;
             uint32_t cnt = count0, adj = adj0;
+            // One Welford step for the lanes `on` (exec-masked: the other lanes' registers are left alone).  xa / xb turn
+            // into the deltas in place: an `on` lane's row has been consumed and is replaced right after.
             auto fold = [&](bool on, double w3) {
-                const double f1 = w3 / (W + w3 - 1.0), f2 = W / (W + w3), f3 = w3 / (W + w3);
-                double da[8], db[8];
+                if (on) {
+                    const double f1 = w3 / (W + w3 - 1.0), f2 = W / (W + w3), f3 = w3 / (W + w3);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { da[u] = xa[u] - ma[u]; db[u] = xb[u] - mb[u]; }
+                    for (int u = 0; u < 8; ++u) { xa[u] = xa[u] - ma[u]; xb[u] = xb[u] - mb[u]; }
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                    for (int u = 0; u < 8; ++u)
 #pragma unroll
-                    for (int v = 0; v < 8; ++v) {
-                        double o = da[u] * db[v];
-                        double nc = C[u][v] + f1 * (f2 * o - C[u][v]);
-                        C[u][v] = on ? nc : C[u][v];
-                    }
+                        for (int v = 0; v < 8; ++v) {
+                            double o = xa[u] * xb[v];
+                            C[u][v] = C[u][v] + f1 * (f2 * o - C[u][v]);
+                        }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    double na = ma[u] + f3 * da[u], nb = mb[u] + f3 * db[u];
-                    ma[u] = on ? na : ma[u]; mb[u] = on ? nb : mb[u];
+                    for (int u = 0; u < 8; ++u) { ma[u] = ma[u] + f3 * xa[u]; mb[u] = mb[u] + f3 * xb[u]; }
+                    W = w3 + W;
                 }
-                W = on ? (w3 + W) : W;
             };
             // The accept ballots of 64 iterations at a time sit in one register per lane (one coalesced load) and are
-            // handed out by v_readlane: the loop's control flow never waits on a dependent global load.
+            // handed out by v_readlane: the loop's control flow never waits on a dependent global load.  The new row's
+            // loads go out BEFORE the fold of the row it replaces, so their latency hides behind that arithmetic.
             for (int tc = t0; tc <= t1; tc += 64) {
                 const int tl = tc + lane;
                 const unsigned long long mine = (tl <= t1) ? wacc_t[tl % E.wcap] : 0ull;
@@ -2275,16 +2275,21 @@ MCX_DEV void covmat_window_blocked(const EngineDev &E, int tile, int lane, bool 
                     const bool inwin = act && (t >= t0lane);
                     const bool acc = inwin && ((m >> lane) & 1ull);
                     if (__any(acc)) {
-                        const bool fl = acc && have;
-                        if (__any(fl)) fold(fl, unit ? 1.0 : (double)(cnt - adj));
+                        double xan[8], xbn[8];
                         if (acc) {
                             const size_t so = (size_t)slot * (size_t)E.hs * 64;
 #pragma unroll
                             for (int u = 0; u < 8; ++u) {
                                 const int a = (a0 + u < d) ? a0 + u : d - 1, b = (b0 + u < d) ? b0 + u : d - 1;
-                                xa[u] = hist_t[so + (size_t)a * 64 + lane];
-                                xb[u] = hist_t[so + (size_t)b * 64 + lane];
+                                xan[u] = hist_t[so + (size_t)a * 64 + lane];
+                                xbn[u] = hist_t[so + (size_t)b * 64 + lane];
                             }
+                        }
+                        const bool fl = acc && have;
+                        if (__any(fl)) fold(fl, unit ? 1.0 : (double)(cnt - adj));
+                        if (acc) {
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) { xa[u] = xan[u]; xb[u] = xbn[u]; }
                             if (have) adj = 0;
                             have = true; cnt = 1;
                         }
@@ -2307,23 +2312,24 @@ MCX_DEV void covmat_window_blocked(const EngineDev &E, int tile, int lane, bool 
             Wend = W;
         }
     }
-    if (act) {
-        for (int k = 0; k < d; ++k) GV(mean_t, k) = GV(mnew_t, k);
-        wsum = Wend;
-    }
 }
 
-__global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode)
+// One MCMC_adapt tick is three launches.  adapt_pre_kernel (one wave per tile) runs the schedule's branch up to the
+// covariance update: burn-in scaling, the greedy / first-tick restarts, the list of window rows.  adapt_cov_kernel
+// runs the steady-state Welford update with ONE 8 x 8 block of chaincmat per wave: the nb(nb+1)/2 blocks of a tile
+// are separate workgroups that walk the same window of the history ring at about the same time, laid out over the
+// grid so that they land on the same XCD (workgroups go round-robin over the 8 XCDs) -- the window is fetched from HBM
+// once and served to the other blocks by that XCD's L2, where one wave per tile used to stream it from HBM once per
+// block.  adapt_post_kernel (one wave per tile) finishes: the one-off batch branches, the window restart and
+// MCMC_calculate_R.  Every element of chaincmat / chainmean sees the operations of the single-kernel form.
+enum { ADF_DOCALC = 1, ADF_GREEDY = 2, ADF_STEADY = 4 };
+
+__global__ __launch_bounds__(64) void adapt_pre_kernel(EngineDev E, int it, int mode)
 {
-    extern __shared__ double X[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d, P = E.P;
     double *Rt = E.R + (size_t)tile * P * 64;
     double *Ct = E.cmat + (size_t)tile * P * 64;
-    double *Tt = E.Rtmp + (size_t)tile * P * 64;
     double *mean_t = E.mean + (size_t)tile * d * 64;
-    double *base_t = E.basetheta + (size_t)tile * d * 64;
-    double *theta_t = E.theta + (size_t)tile * d * 64;
-    double *m2_t = E.cand + (size_t)tile * d * 64;                 // scratch: xmean2 of the batch branch
     uint64_t *rows = E.rowlist + (size_t)tile * (E.wcap + 1) * 64;
     uint32_t stayed = TIDX(E.ictr, tile, NICTR, I_STAYED, lane);
     uint32_t curcount = TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane);
@@ -2331,7 +2337,8 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
     uint32_t basecnt = TIDX(E.ictr, tile, NICTR, I_BASECNT, lane);
     uint32_t winstart = TIDX(E.ictr, tile, NICTR, I_WINSTART, lane);
     double wsum = TIDX(E.scal, tile, NSCAL, S_WSUM, lane);
-    bool docalc = false;          // lanes that go on to MCMC_calculate_R
+    uint32_t flags = 0;
+    int nr = 0;
 
     if (mode & AD_BURN) {                                             // MCMC_adapt.F90:60-102
         double staypc = (double)stayed / (double)it;
@@ -2356,50 +2363,35 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
                 for (int e = 0; e < P; ++e) GV(iCt, e) = GV(iCt, e) / sf / sf;
             }
         } else {
-            docalc = true;
+            flags |= ADF_DOCALC;
             greedy_lane = (E.greedy != 0);
         }
-        if (E.greedy != 0) {                                          // :83-101 greedy: restart from cmat0 over chain(1:chainind), unit weights
-            int nr = 0;
-            if (greedy_lane) {
-                wsum = E.initcmatn;
-                for (int e = 0; e < P; ++e) GV(Ct, e) = E.cmat0p[e];
-                for (int k = 0; k < d; ++k) GV(mean_t, k) = E.par0[k];
-                for (int t = 1; t <= it; ++t) {
+        if (E.greedy != 0 && greedy_lane) {                           // :83-101 greedy: restart from cmat0 over chain(1:chainind), unit weights
+            flags |= ADF_GREEDY;
+            wsum = E.initcmatn;
+            for (int e = 0; e < P; ++e) GV(Ct, e) = E.cmat0p[e];
+            for (int k = 0; k < d; ++k) GV(mean_t, k) = E.par0[k];
+            if (wsum > 0.0) flags |= ADF_STEADY;
+            else
+                for (int t = 1; t <= it; ++t) {                       // row list of the one-off batch branch
                     const int slot = t % E.wcap;
                     unsigned long long m = E.wacc[(size_t)tile * E.wcap + slot];
                     if ((m >> lane) & 1ull) { GV(rows, nr) = (uint64_t)(uint32_t)slot | (1ull << 32); ++nr; }
                 }
-            }
-            {
-                const bool steady = greedy_lane && wsum > 0.0;
-                covmat_window_blocked(E, tile, lane, steady, 1, it, true, 0u, 0u, Ct, mean_t, base_t, m2_t, wsum);
-                covmat_rows(E, tile, lane, rows, nr, greedy_lane && !steady, true, Ct, mean_t, base_t, m2_t, wsum, X);
-            }
-            if (greedy_lane) lastfreq = curcount;
-        }
-        if (docalc) {
-            // lastind = chainind: the covariance window restarts at the current row (lastfreq only touched by greedy)
-            for (int k = 0; k < d; ++k) GV(base_t, k) = GV(theta_t, k);
-            basecnt = curcount; winstart = (uint32_t)(it + 1);
         }
     } else if (mode & AD_AM) {                                        // MCMC_adapt.F90:105-159
-        docalc = true;
+        flags |= ADF_DOCALC;
         if (mode & AD_FIRST) {
             wsum = E.initcmatn;
             for (int e = 0; e < P; ++e) GV(Ct, e) = E.cmat0p[e];
             for (int k = 0; k < d; ++k) GV(mean_t, k) = E.par0[k];
         }
-        int nr = 0;
         if (E.adapthist > 1) {
             // AP (:116-136): rows back from chainind until the repeat counts cover adapthist iterations; the oldest
             // row's weight is cut so that the weights sum to adapthist; batch recompute (update = .false.)
             int histsum = (int)curcount;
-            int t = it;                                   // walk back over the ballots to the accepting iterations
-            // find the iteration that accepted the current row
             int nback = 0;
             uint32_t w = curcount;
-            // first pass: count rows needed (newest first), remember the oldest one's count
             int tt = it - (int)curcount + 1;              // iteration at which the current row was accepted
             GV(rows, 0) = (uint64_t)(uint32_t)(tt % E.wcap) | ((uint64_t)w << 32);
             nback = 1;
@@ -2410,9 +2402,7 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
                 GV(rows, nback) = (uint64_t)(uint32_t)(t2 % E.wcap) | ((uint64_t)(uint32_t)cnt << 32);
                 ++nback; tt = t2;
             }
-            (void)t;
-            // oldest row's weight: newfreq - histsum + adapthist
-            {
+            {                                             // oldest row's weight: newfreq - histsum + adapthist
                 uint64_t e = GV(rows, nback - 1);
                 int newfreq = (int)(uint32_t)(e >> 32);
                 int wadj = newfreq - histsum + E.adapthist;
@@ -2421,9 +2411,10 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
             // reverse into chain order (oldest first)
             for (int a = 0, b2 = nback - 1; a < b2; ++a, --b2) { uint64_t ta = GV(rows, a); GV(rows, a) = GV(rows, b2); GV(rows, b2) = ta; }
             nr = nback;
-            covmat_rows(E, tile, lane, rows, nr, true, false, Ct, mean_t, base_t, m2_t, wsum, X);
+        } else if (wsum > 0.0) {
+            flags |= ADF_STEADY;                          // steady state (chainwsum > 0): blocked Welford straight from the ballots
         } else {
-            // AM (:138-157): rows of chain(lastind:chainind) and their weights, from the accept ballots
+            // AM (:138-157), one-off batch branch: rows of chain(lastind:chainind) and their weights, from the accept ballots
             uint32_t w = basecnt;                 // count of the base row when the window started
             uint32_t slot_prev = 0xffffffffu;     // base row lives in basetheta
             for (int t = (int)winstart; t <= it; ++t) {
@@ -2438,10 +2429,80 @@ __global__ __launch_bounds__(64) void adapt_kernel(EngineDev E, int it, int mode
             uint32_t wr = (nr == 0) ? (w - lastfreq) : w;
             GV(rows, nr) = (uint64_t)slot_prev | ((uint64_t)wr << 32);
             ++nr;
-            // steady state (chainwsum > 0): blocked Welford straight from the ballots; the row list is only
-            // needed by the one-off batch branch
-            const bool steady = wsum > 0.0;
-            covmat_window_blocked(E, tile, lane, steady, (int)winstart, it, false, basecnt, lastfreq, Ct, mean_t, base_t, m2_t, wsum);
+        }
+    }
+    TIDX(E.ictr, tile, NICTR, I_ADFLAGS, lane) = flags;
+    TIDX(E.ictr, tile, NICTR, I_NR, lane) = (uint32_t)nr;
+    TIDX(E.scal, tile, NSCAL, S_WSUM, lane) = wsum;
+    TIDX(E.scal, tile, NSCAL, S_WNEW, lane) = wsum;
+}
+
+// grid: 8 * ceil(ntiles / 8) * nblk workgroups of one wave; workgroup w runs on XCD w % 8, so
+// tile = (w / 8 / nblk) * 8 + w % 8, block = (w / 8) % nblk keeps a tile's blocks on one XCD and next to each other in time
+__global__ __launch_bounds__(64, 2) void adapt_cov_kernel(EngineDev E, int it, int mode, int nblk)
+{
+    const int lane = threadIdx.x, d = E.d, P = E.P;
+    const int w = blockIdx.x, j = w >> 3;
+    const int tile = (j / nblk) * 8 + (w & 7);
+    int blk = j % nblk;
+    if (tile >= E.ntiles) return;
+    const uint32_t flags = TIDX(E.ictr, tile, NICTR, I_ADFLAGS, lane);
+    const bool steady = (flags & ADF_STEADY) != 0;
+    if (!__any(steady)) return;
+    int a0 = 0, nb = (d + 7) / 8;
+    while (blk >= nb - a0) { blk -= nb - a0; ++a0; }                 // block rows a0 hold nb - a0 blocks
+    const int b0 = (a0 + blk) * 8;
+    a0 *= 8;
+    double *Ct = E.cmat + (size_t)tile * P * 64;
+    const double *mean_t = E.mean + (size_t)tile * d * 64;
+    const double *base_t = E.basetheta + (size_t)tile * d * 64;
+    double *mnew_t = E.cand + (size_t)tile * d * 64;
+    const bool unit = (mode & AD_BURN) != 0;                          // greedy restart: rows 1..it, unit weights, no base row
+    const uint32_t basecnt = TIDX(E.ictr, tile, NICTR, I_BASECNT, lane), lastfreq = TIDX(E.ictr, tile, NICTR, I_LASTFREQ, lane);
+    const int winstart = (int)TIDX(E.ictr, tile, NICTR, I_WINSTART, lane);
+    const double wsum = TIDX(E.scal, tile, NSCAL, S_WSUM, lane);
+    double Wend = wsum;
+    covmat_window_blocked(E, tile, lane, steady, unit ? 1 : winstart, it, unit, unit ? 0u : basecnt, unit ? 0u : lastfreq,
+                          Ct, mean_t, base_t, mnew_t, wsum, a0, b0, Wend);
+    if (a0 == 0 && b0 == 0 && steady) TIDX(E.scal, tile, NSCAL, S_WNEW, lane) = Wend;
+}
+
+__global__ __launch_bounds__(64) void adapt_post_kernel(EngineDev E, int it, int mode)
+{
+    extern __shared__ double X[];
+    const int lane = threadIdx.x, tile = blockIdx.x, d = E.d, P = E.P;
+    double *Rt = E.R + (size_t)tile * P * 64;
+    double *Ct = E.cmat + (size_t)tile * P * 64;
+    double *Tt = E.Rtmp + (size_t)tile * P * 64;
+    double *mean_t = E.mean + (size_t)tile * d * 64;
+    double *base_t = E.basetheta + (size_t)tile * d * 64;
+    double *theta_t = E.theta + (size_t)tile * d * 64;
+    double *m2_t = E.cand + (size_t)tile * d * 64;                 // the blocked update's new means; then scratch (xmean2 of the batch branch)
+    uint64_t *rows = E.rowlist + (size_t)tile * (E.wcap + 1) * 64;
+    uint32_t curcount = TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane);
+    uint32_t lastfreq = TIDX(E.ictr, tile, NICTR, I_LASTFREQ, lane);
+    uint32_t basecnt = TIDX(E.ictr, tile, NICTR, I_BASECNT, lane);
+    uint32_t winstart = TIDX(E.ictr, tile, NICTR, I_WINSTART, lane);
+    const uint32_t flags = TIDX(E.ictr, tile, NICTR, I_ADFLAGS, lane);
+    const int nr = (int)TIDX(E.ictr, tile, NICTR, I_NR, lane);
+    const bool docalc = (flags & ADF_DOCALC) != 0, steady = (flags & ADF_STEADY) != 0, greedy_lane = (flags & ADF_GREEDY) != 0;
+    double wsum = TIDX(E.scal, tile, NSCAL, steady ? S_WNEW : S_WSUM, lane);
+    if (steady) for (int k = 0; k < d; ++k) GV(mean_t, k) = GV(m2_t, k);
+
+    if (mode & AD_BURN) {
+        if (E.greedy != 0) {
+            covmat_rows(E, tile, lane, rows, nr, greedy_lane && !steady, true, Ct, mean_t, base_t, m2_t, wsum, X);
+            if (greedy_lane) lastfreq = curcount;
+        }
+        if (docalc) {
+            // lastind = chainind: the covariance window restarts at the current row (lastfreq only touched by greedy)
+            for (int k = 0; k < d; ++k) GV(base_t, k) = GV(theta_t, k);
+            basecnt = curcount; winstart = (uint32_t)(it + 1);
+        }
+    } else if (mode & AD_AM) {
+        if (E.adapthist > 1) {
+            covmat_rows(E, tile, lane, rows, nr, true, false, Ct, mean_t, base_t, m2_t, wsum, X);
+        } else {
             covmat_rows(E, tile, lane, rows, nr, !steady, true, Ct, mean_t, base_t, m2_t, wsum, X);
             // lastfreq = count of the current row; lastind = chainind -> window restarts here
             lastfreq = curcount;
