@@ -15,6 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 EXE = os.path.join(_HERE, "_ref", "mcxref")
 EXE_SVD = os.path.join(_HERE, "_ref", "mcxref_svd")      # same program, dgesvd = the pinned Jacobi routine
+EXE_MKLLOG = os.path.join(_HERE, "_ref", "mcxref_mkllog")  # same program, MKL's dgesvd, every call logged (ref/dgesvd_logger.c)
 METHOD_NAMES = {0: "dram", 1: "ram", 2: "scam", 3: "er"}
 TARGET_IDS = {"gauss": 0, "banana": 1, "expdata": 2}
 
@@ -104,7 +105,22 @@ class RefResult:
     pass
 
 
-def run_reference(cfg, prob, seed=0x6D636D63, chain_id=0, keep=False, timeout=600, pinned_svd=False, timing_only=False):
+def read_svd_log(path):
+    """[(info, s[n], U[n, n])] of every dgesvd call logged by ref/dgesvd_logger.c"""
+    calls = []
+    if not os.path.exists(path):
+        return calls
+    raw = open(path, "rb").read()
+    off = 0
+    while off < len(raw):
+        n, info = struct.unpack_from("<2i", raw, off); off += 8
+        sv = np.frombuffer(raw, dtype="<f8", count=n, offset=off).copy(); off += 8 * n
+        U = np.frombuffer(raw, dtype="<f8", count=n * n, offset=off).reshape(n, n).T.copy(); off += 8 * n * n
+        calls.append((info, sv, U))
+    return calls
+
+
+def run_reference(cfg, prob, seed=0x6D636D63, chain_id=0, keep=False, timeout=600, pinned_svd=False, timing_only=False, svd_log=False):
     """timing_only: run in a tmpfs scratch directory when there is one, time the reference process alone (r.seconds)
     and do not parse its output files (bench.py's cpu_baseline leg)."""
     if not available():
@@ -117,8 +133,13 @@ def run_reference(cfg, prob, seed=0x6D636D63, chain_id=0, keep=False, timeout=60
         env = dict(os.environ, MCX_SEED=str(seed), MCX_CHAIN=str(chain_id), MKL_NUM_THREADS="1",
                    MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1", MCX_RNG_LOG=os.path.join(d, "rng.log"))
         t0 = time.perf_counter()
-        p = subprocess.run([EXE_SVD if pinned_svd else EXE], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+        if svd_log:
+            env["MCX_SVD_LOG"] = os.path.join(d, "svd.log")
+        exe = EXE_MKLLOG if svd_log else (EXE_SVD if pinned_svd else EXE)
+        p = subprocess.run([exe], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
         r = RefResult()
+        if svd_log:
+            r.svd_calls = read_svd_log(env["MCX_SVD_LOG"])
         r.seconds = time.perf_counter() - t0
         r.scratch = "tmpfs" if shm else "disk"
         r.stdout = p.stdout.decode(errors="replace")

@@ -196,19 +196,35 @@ def _check_host_callbacks(oracle, ckw, pkw):
     e.close(); ref.close()
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(72))
 def test_random_configuration_larger_npar(oracle, seed):
-    """npar 13..48 (several register panels / blocks of the factor, ragged last panels), Gaussian target."""
+    """npar 13..64: two to seven column panels of the RAM sweeps (panel width 10), several 8 x 8 blocks of the
+    covariance update and of the Cholesky factorisation, ragged last panels.  RAM is drawn half of the time, half of
+    those started at the target's own covariance -- waves that mix update and downdate lanes (whole-segment stores,
+    pipelined sweeps) -- with burn-in, bounds, priors and the sigma2 update mixed in."""
     from mcmcf90_amd import engine_from_problem
     r = np.random.default_rng(7000 + seed)
-    d = int(r.integers(13, 49))
-    method = str(r.choice(["dram", "ram", "dram", "er"]))
-    ckw = dict(nsimu=int(r.integers(50, 130)), method=method, adaptint=int(r.choice([15, 40])), updatesigma=0)
+    d = int(r.integers(13, 65))
+    method = str(r.choice(["ram", "ram", "dram", "er"]))
+    ckw = dict(nsimu=int(r.integers(50, 130)), method=method, adaptint=int(r.choice([15, 40])), updatesigma=int(r.random() < 0.3))
     if method == "dram" and r.random() < 0.5:
         ckw["drscale"] = 2.0
+    if method == "dram" and r.random() < 0.3:
+        ckw.update(doburnin=1, burnintime=int(r.integers(20, 60)), greedy=int(r.integers(0, 2)), scalelimit=0.3)
+    if method == "ram":
+        ckw.update(alphatarget=float(r.choice([0.234, 0.4])), nuparam=float(r.choice([0.6, 0.7, 0.9])))
     A = r.standard_normal((d, d)) / np.sqrt(d)
-    pkw = dict(kind="gauss", npar=d, par0=r.standard_normal(d) * 0.1, cmat0=np.diag(r.uniform(0.2, 1.0, d)) / d,
-               mu=np.zeros(d), lam=A @ A.T + np.eye(d))
+    lam = A @ A.T + np.eye(d)
+    cmat0 = np.diag(r.uniform(0.2, 1.0, d)) / d
+    if method == "ram" and r.random() < 0.5:
+        cmat0 = np.linalg.inv(lam)                 # at the target acceptance rate: most iterations downdate
+    pkw = dict(kind="gauss", npar=d, par0=r.standard_normal(d) * 0.1, cmat0=cmat0, mu=np.zeros(d), lam=lam)
+    if ckw["updatesigma"]:
+        pkw.update(sigma2=float(r.uniform(0.5, 1.5)), nobs=int(r.integers(5, 40)))
+    if r.random() < 0.25:
+        pkw.update(lo=np.full(d, -2.5), hi=np.full(d, 2.5))
+    if r.random() < 0.25:
+        pkw.update(pri_mu=np.zeros(d), pri_sig=np.where(r.random(d) < 0.5, 0.0, 2.0))
     cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
     e = engine_from_problem(ckw, pkw, nchains=66, chain_id0=seed, record_accept=1)
     e.init(); e.run()
@@ -218,6 +234,11 @@ def test_random_configuration_larger_npar(oracle, seed):
         np.testing.assert_array_equal(e.accepted(c), o.accepted, err_msg=str(ckw))
         np.testing.assert_array_equal(_bits(th[c]), _bits(o.theta), err_msg=str(ckw))
         np.testing.assert_array_equal(_bits(np.triu(e.R(c))), _bits(np.triu(o.R)), err_msg=str(ckw))
+        assert e.rng(c)[0] == o.rng_n, ckw
+        assert bool(e.counters(c)["status"] & 1) == (o.ram_downdate_fail != 0), ckw
+        if method != "ram":
+            cm, mean, wsum = e.chaincov(c)
+            np.testing.assert_array_equal(_bits(np.triu(cm)), _bits(np.triu(o.chaincmat)), err_msg=str(ckw))
     e.close()
 
 

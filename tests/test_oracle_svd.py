@@ -70,3 +70,55 @@ def test_scam_posterior_does_not_depend_on_the_lapack_linked(oracle):
     for m, c, _ in out:
         np.testing.assert_allclose(m, prob.mu, atol=0.12)
         np.testing.assert_allclose(c, S, atol=0.45)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_scam_against_the_mkl_linked_reference_with_its_own_factors(oracle, seed):
+    """MCMC_run_scam (MCMC_run_scam.F90:38-138) pinned independently of the Jacobi routine: the reference runs with MKL's
+    dgesvd, every call logged (oracle/_ref/mcxref_mkllog); the oracle takes the rotation U and sqrt(s) of each call
+    (scam_svd's floor applied, matutils.F90:633-645) in place of its own SVD at the same adaptation.  Everything else
+    -- the rotations U'theta / U rot, the componentwise proposals, alpha, the accept decisions, the covariance the next
+    adaptation sees -- must then reproduce the MKL-linked chain: identical run-length column and stream position."""
+    from oracle import refrun as rr
+    if not (rr.available() and os.path.exists(rr.EXE_MKLLOG)):
+        pytest.skip("oracle/_ref/mcxref_mkllog not built here")
+    r0 = np.random.default_rng(500 + seed)
+    d = int(r0.integers(2, 9))
+    A = r0.standard_normal((d, d)) / np.sqrt(d)
+    S = A @ A.T + np.diag(r0.uniform(0.05, 2.0, d))
+    adaptint = int(r0.choice([20, 50]))
+    nsimu = int(r0.integers(150, 400))
+    updatesigma = int(r0.integers(0, 2))
+    kw = dict(nsimu=nsimu, method="scam", adaptint=adaptint, updatesigma=updatesigma)
+    pkw = dict(sigma2=0.7, nobs=12) if updatesigma else {}
+    prob = oracle.Problem("gauss", d, r0.standard_normal(d) * 0.2, np.diag(r0.uniform(0.05, 0.4, d)), mu=r0.standard_normal(d) * 0.3,
+                          lam=np.linalg.inv(S), **pkw)
+    cfg = oracle.make_cfg(**kw)
+    ref = rr.run_reference(cfg, prob, chain_id=seed, svd_log=True)
+    ticks = [it for it in range(adaptint, nsimu + 1, adaptint) if it >= cfg.burnintime + adaptint + cfg.adapthist]
+    assert len(ref.svd_calls) == 1 + len(ticks), (len(ref.svd_calls), ticks)
+
+    def factors(call):
+        info, sv, U = call
+        sv = sv.copy()
+        tol = sv[0] / cfg.condmax
+        if sv[-1] <= tol:
+            sv[sv < tol] = tol
+        return U, np.sqrt(sv)
+
+    lc = oracle.LiveChain(cfg, prob, chain_id=seed)
+    U, sd = factors(ref.svd_calls[0])
+    lc.set_R(U); lc.set_qcovstd(sd)                        # MCMC_init's first MCMC_calculate_R
+    for k, it in enumerate(ticks):
+        lc.run(it)                                         # the tick at `it` ran the oracle's own SVD: replace its result
+        U, sd = factors(ref.svd_calls[1 + k])
+        lc.set_R(U); lc.set_qcovstd(sd)
+    lc.run(nsimu)
+    acc = lc.accepted
+    c = lc.ch.contents
+    assert c.rng.n == ref.rng_n
+    np.testing.assert_array_equal(acc, rr.accepted_from_chain(ref.chain, nsimu))
+    ch = np.ctypeslib.as_array(c.chain, shape=(nsimu, d + 1))[:c.chainind]
+    scale = np.maximum(np.abs(ref.chain[:, :-1]).max(axis=0), 1e-3)
+    assert np.max(np.abs(ch[:, :-1] - ref.chain[:, :-1]) / scale) < 1e-7
+    lc.close()
