@@ -90,6 +90,19 @@ typedef void    (*mcmcx_ssfun_t)(const double *theta, int32_t npar, int32_t ny, 
 typedef double  (*mcmcx_priorfun_t)(const double *theta, int32_t npar, void *user);
 typedef int32_t (*mcmcx_checkbounds_t)(const double *theta, int32_t npar, void *user);
 int mcmcx_set_target_host(mcmcx_handle h, mcmcx_ssfun_t ss, mcmcx_priorfun_t pri, mcmcx_checkbounds_t cb, void *user);
+/* Batched form of the same (opt-in; external_inc.h:12-19 has no counterpart): ss_batch evaluates n candidates in one
+ * call -- theta[n][npar] row-major (= Fortran theta(npar,n)), ss[n][ny] -- and, with nthreads > 1, is called from that
+ * many threads at once on disjoint slices, so it must be re-entrant (the very first evaluation, at mcmcx_init, is made
+ * from the calling thread alone, so load-on-first-call code is safe).  Bounds and prior stay per chain on the calling
+ * thread, before the batch.  (method = 'er' with mcmcx_set_target_host_er keeps the per-chain path.) */
+typedef void (*mcmcx_ssfun_batch_t)(const double *theta, int32_t npar, int32_t n, int32_t ny, double *ss_out, void *user);
+int mcmcx_set_target_host_batch(mcmcx_handle h, mcmcx_ssfun_batch_t ss_batch, mcmcx_priorfun_t pri, mcmcx_checkbounds_t cb,
+                                void *user, int32_t nthreads);
+/* The user's ssfunction / priorfun / checkbounds as DEVICE code: a code object (hipcc --genco) whose kernel
+ * `kernel_name` was defined with MCMCX_DEFINE_TARGET (include/mcmcx_target.h).  The engine launches it where the
+ * reference calls the functions; candidates and results never leave HBM.  userdata (nbytes, may be NULL) is copied
+ * to the device and handed to the functions. */
+int mcmcx_set_target_module(mcmcx_handle h, const char *code_object_path, const char *kernel_name, const void *userdata, int64_t nbytes);
 /* method='er' with host callbacks: the user's ssfunction_er(theta,npar,ny,sscrit) (external_inc.h:16-20), which may
  * stop summing once it passes sscrit; NULL (default) = ssfunction, like ssfunction_er0.f90.  Same `user` pointer. */
 typedef void (*mcmcx_ssfun_er_t)(const double *theta, int32_t npar, int32_t ny, double sscrit, double *ss_out, void *user);

@@ -79,6 +79,9 @@ SYMBOLS["mcmcx_interrupted"] = (C.c_int, [])
 SYMBOLS["mcmcx_clear_interrupt"] = (None, [])
 SYMBOLS["mcmcx_set_target_host"] = (C.c_int, [C.c_void_p, SSFUN_T, PRIORFUN_T, CHECKBOUNDS_T, C.c_void_p])
 
+SSFUN_BATCH_T = C.CFUNCTYPE(None, _DP, C.c_int32, C.c_int32, C.c_int32, _DP, C.c_void_p)
+SYMBOLS["mcmcx_set_target_host_batch"] = (C.c_int, [C.c_void_p, SSFUN_BATCH_T, PRIORFUN_T, CHECKBOUNDS_T, C.c_void_p, C.c_int32])
+SYMBOLS["mcmcx_set_target_module"] = (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_int64])
 _HP = C.POINTER(C.c_void_p)
 SYMBOLS["mcmcx_comm_create"] = (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _HP])
 SYMBOLS["mcmcx_comm_create_all"] = (C.c_int, [C.c_int32, _IP, _HP])

@@ -15,9 +15,12 @@
 #include <vector>
 #include <algorithm>
 #include "../../include/mcmcx.h"
+#include "../../include/mcmcx_target.h"
 #include "mcx_kernels.hpp"
 
 using namespace mcx;
+static_assert(MCMCX_HE_INB == HE_INB && MCMCX_HE_PRI == HE_PRI && MCMCX_HE_SS == HE_SS && MCMCX_HX_STAGE2 == HX_STAGE2 && MCMCX_HX_CRIT == HX_CRIT,
+              "include/mcmcx_target.h and mcx_kernels.hpp disagree about the phase-state slots");
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -42,6 +45,9 @@ struct mcmcx_engine {
     int tkind = -1, tncols = 1; std::vector<double> tmu, tlam, tx, ty, tlo, thi, tpmu, tpsig; double tb = 0.1;
     bool has_lo = false, has_hi = false, has_pri = false;
     mcmcx_ssfun_t h_ss = nullptr; mcmcx_ssfun_er_t h_ss_er = nullptr; mcmcx_priorfun_t h_pri = nullptr; mcmcx_checkbounds_t h_cb = nullptr; void *h_user = nullptr;
+    mcmcx_ssfun_batch_t h_ss_batch = nullptr; int h_threads = 1;      // batched form of the user's ssfunction (opt-in)
+    hipModule_t mod = nullptr; hipFunction_t mod_fn = nullptr; void *d_moddata = nullptr;   // user target module (include/mcmcx_target.h)
+    std::vector<double> h_bth, h_bss; std::vector<int> h_bidx;
     std::vector<double> h_cand, h_ev;
     // pooled mode
     int pooled = 0; double pool_W = 0.0; std::vector<double> pool_mean, pool_C, pool_R;   // packed upper, row-major
@@ -229,7 +235,7 @@ static bool pooled_use_mfma(const mcmcx_engine *h)
     if (const char *e = getenv("MCMCX_POOLED_SCALAR")) if (atoi(e)) return false;      // A/B switch for tests: the lane-per-chain kernel
     return pooled_mfma_lds(h->d) <= 160 * 1024;
 }
-static bool phased(const mcmcx_engine *h) { return h->tkind == TGT_HOST || h->tkind == TGT_EXPCOLS; }   // iteration cut at the evaluations
+static bool phased(const mcmcx_engine *h) { return h->tkind == TGT_HOST || h->tkind == TGT_EXPCOLS || h->tkind == TGT_MODULE; }   // iteration cut at the evaluations
 static size_t lds_bytes(const mcmcx_engine *h) { return (size_t)h->d * 64 * sizeof(double) * 2; }   // adapt / DR work vectors
 static size_t lds_step(const mcmcx_engine *h) { return h->dodr ? lds_bytes(h) : 0; }
 static void launch_init(mcmcx_engine *h)
@@ -462,6 +468,16 @@ static int host_eval(mcmcx_engine *h, const double *dev_src, int stride_k, bool 
         HIPCHK(hipGetLastError());
         return 0;
     }
+    if (h->tkind == TGT_MODULE) {                       // the user's own device code, loaded from a code object
+        mcmcx_target_args a;
+        a.src = dev_src; a.hev = h->E.hev; a.hx = h->E.hx; a.userdata = h->d_moddata;
+        a.stride_k = stride_k; a.npar = d; a.ny = h->ny; a.nhe = NHE - 1 + h->ny; a.nhx = NHX; a.nchains = h->cfg.nchains;
+        a.use_stage2 = use_stage2_flag ? 1 : 0; a.what = what;
+        size_t asz = sizeof(a);
+        void *cfgv[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+        HIPCHK(hipModuleLaunchKernel(h->mod_fn, (unsigned)T, 1, 1, 64, 1, 1, 0, h->stream, nullptr, cfgv));
+        return 0;
+    }
     const size_t L = (size_t)T * 64;
     h->h_cand.resize(L * stride_k);
     const int ny = h->ny, nhe = NHE - 1 + ny;
@@ -472,6 +488,44 @@ static int host_eval(mcmcx_engine *h, const double *dev_src, int stride_k, bool 
     std::vector<double> hx;
     if (use_stage2_flag) { hx.resize(L * NHX); HIPCHK(hipMemcpy(hx.data(), h->E.hx, hx.size() * 8, hipMemcpyDeviceToHost)); }
     std::vector<double> th(d);
+    if (h->h_ss_batch && !(what == 2 && h->h_ss_er)) {
+        // Batched form (opt-in): bounds and prior per chain on this thread, in chain order; then ONE call of the user's
+        // ssfunction_batch per worker thread over the chains that need the sum of squares.
+        h->h_bidx.clear(); h->h_bth.clear();
+        for (int c = 0; c < h->cfg.nchains; ++c) {
+            const int t = c / 64, l = c % 64;
+            if (use_stage2_flag && hx[((size_t)t * NHX + HX_STAGE2) * 64 + l] == 0.0) continue;
+            for (int k = 0; k < d; ++k) th[k] = h->h_cand[((size_t)t * stride_k + k) * 64 + l];
+            int inb = 1; double pri = 0.0;
+            if (what != 2) {
+                inb = h->h_cb ? h->h_cb(th.data(), d, h->h_user) : 1;
+                if (inb) pri = h->h_pri ? h->h_pri(th.data(), d, h->h_user) : 0.0;
+            }
+            h->h_ev[((size_t)t * nhe + HE_INB) * 64 + l] = inb ? 1.0 : 0.0;
+            h->h_ev[((size_t)t * nhe + HE_PRI) * 64 + l] = pri;
+            if ((what == 0 && inb) || what == 2) { h->h_bidx.push_back(c); h->h_bth.insert(h->h_bth.end(), th.begin(), th.end()); }
+        }
+        const int n = (int)h->h_bidx.size();
+        h->h_bss.assign((size_t)n * ny, 0.0);
+        // the first evaluation (MCMC_init's starting point) stays on the calling thread: user code commonly loads its
+        // data on first call (testcases/mcmcrun.F90:69-70) -- after that concurrent calls only read it
+        const int nt = h->inited ? std::max(1, std::min(h->h_threads, n)) : 1;
+        if (nt <= 1) { if (n > 0) h->h_ss_batch(h->h_bth.data(), d, n, ny, h->h_bss.data(), h->h_user); }
+        else {
+            std::vector<std::thread> pool;
+            for (int w = 0; w < nt; ++w) {
+                const int lo = (int)((long long)n * w / nt), hi = (int)((long long)n * (w + 1) / nt);
+                if (hi > lo) pool.emplace_back([=]() { h->h_ss_batch(h->h_bth.data() + (size_t)lo * d, d, hi - lo, ny, h->h_bss.data() + (size_t)lo * ny, h->h_user); });
+            }
+            for (auto &t : pool) t.join();
+        }
+        for (int i = 0; i < n; ++i) {
+            const int c = h->h_bidx[i], t = c / 64, l = c % 64;
+            for (int j = 0; j < ny; ++j) h->h_ev[((size_t)t * nhe + HE_SS + j) * 64 + l] = h->h_bss[(size_t)i * ny + j];
+        }
+        HIPCHK(hipMemcpy(h->E.hev, h->h_ev.data(), h->h_ev.size() * 8, hipMemcpyHostToDevice));
+        return 0;
+    }
     for (int c = 0; c < h->cfg.nchains; ++c) {
         const int t = c / 64, l = c % 64;
         if (use_stage2_flag && hx[((size_t)t * NHX + HX_STAGE2) * 64 + l] == 0.0) continue;
@@ -612,6 +666,7 @@ int mcmcx_destroy(mcmcx_handle h)
     for (auto &p : h->pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (void *p : h->allocs) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->mod) (void)hipModuleUnload(h->mod);
     delete h;
     return 0;
 }
@@ -679,7 +734,42 @@ int mcmcx_set_target_expdata_cols(mcmcx_handle h, int32_t n, int32_t nycol, cons
 int mcmcx_set_target_host(mcmcx_handle h, mcmcx_ssfun_t ss, mcmcx_priorfun_t pri, mcmcx_checkbounds_t cb, void *user)
 {
     if (!h || !ss) return fail(-1, "mcmcx_set_target_host: ssfunction is required");     // ssfunction0.f90:10-14
-    h->tkind = TGT_HOST; h->h_ss = ss; h->h_pri = pri; h->h_cb = cb; h->h_user = user;
+    h->tkind = TGT_HOST; h->h_ss = ss; h->h_ss_batch = nullptr; h->h_pri = pri; h->h_cb = cb; h->h_user = user;
+    return 0;
+}
+
+int mcmcx_set_target_host_batch(mcmcx_handle h, mcmcx_ssfun_batch_t ss_batch, mcmcx_priorfun_t pri, mcmcx_checkbounds_t cb, void *user, int32_t nthreads)
+{
+    if (!h || !ss_batch) return fail(-1, "mcmcx_set_target_host_batch: ssfunction_batch is required");
+    if (h->inited) return fail(-20, "set the target before mcmcx_init");
+    h->tkind = TGT_HOST; h->h_ss_batch = ss_batch; h->h_ss = nullptr; h->h_pri = pri; h->h_cb = cb; h->h_user = user;
+    h->h_threads = nthreads < 1 ? 1 : nthreads;
+    return 0;
+}
+
+int mcmcx_set_target_module(mcmcx_handle h, const char *code_object_path, const char *kernel_name, const void *userdata, int64_t nbytes)
+{
+    if (!h || !code_object_path || !kernel_name) return fail(-1, "mcmcx_set_target_module: null argument");
+    if (h->inited) return fail(-20, "set the target before mcmcx_init");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    hipError_t e = hipModuleLoad(&h->mod, code_object_path);
+    if (e != hipSuccess) return fail(-37, std::string("cannot load the target module ") + code_object_path + ": " + hipGetErrorString(e));
+    e = hipModuleGetFunction(&h->mod_fn, h->mod, kernel_name);
+    if (e != hipSuccess) return fail(-37, std::string("target module: no kernel named ") + kernel_name + " (define it with MCMCX_DEFINE_TARGET, include/mcmcx_target.h)");
+    for (const char *suffix : {"_abi", "_max_npar"}) {
+        hipDeviceptr_t p = nullptr; size_t sz = 0; int v = 0;
+        e = hipModuleGetGlobal(&p, &sz, h->mod, (std::string(kernel_name) + suffix).c_str());
+        if (e != hipSuccess || sz != sizeof(int)) return fail(-37, std::string("target module: ") + kernel_name + suffix + " is missing (not built with MCMCX_DEFINE_TARGET?)");
+        HIPCHK(hipMemcpy(&v, p, sizeof(int), hipMemcpyDeviceToHost));
+        if (suffix[1] == 'a' && v != MCMCX_TARGET_ABI) return fail(-37, "target module: built against another mcmcx_target.h (abi " + std::to_string(v) + ")");
+        if (suffix[1] == 'm' && h->d > v) return fail(-37, "target module: npar = " + std::to_string(h->d) + " but the module was compiled with MCMCX_TARGET_MAX_NPAR = " + std::to_string(v));
+    }
+    if (userdata && nbytes > 0) {
+        HIPCHK(hipMalloc(&h->d_moddata, (size_t)nbytes));
+        h->allocs.push_back(h->d_moddata);
+        HIPCHK(hipMemcpy(h->d_moddata, userdata, (size_t)nbytes, hipMemcpyHostToDevice));
+    }
+    h->tkind = TGT_MODULE;
     return 0;
 }
 

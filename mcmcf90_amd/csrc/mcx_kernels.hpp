@@ -26,7 +26,7 @@
 
 namespace mcx {
 
-enum { TGT_GAUSS = 0, TGT_BANANA = 1, TGT_EXPDATA = 2, TGT_HOST = 3, TGT_EXPCOLS = 4 };   // EXPCOLS: host side only (the device sees TGT_HOST + dev_eval_kernel)
+enum { TGT_GAUSS = 0, TGT_BANANA = 1, TGT_EXPDATA = 2, TGT_HOST = 3, TGT_EXPCOLS = 4, TGT_MODULE = 5 };   // EXPCOLS / MODULE: host side only (the device sees TGT_HOST + an evaluation kernel between the phases)
 enum { M_DRAM = 0, M_RAM = 1, M_ER = 3 };
 
 // per-chain scalar slots (doubles)

@@ -153,6 +153,33 @@ class Engine:
             self._er_keep = _lib.SSFUN_ER_T(_ss_er)
             self._chk(self.L.mcmcx_set_target_host_er(self.h, self._er_keep))
 
+    def set_target_host_batch(self, ssfun_batch, priorfun=None, checkbounds=None, nthreads=1):
+        """Batched user callback: ssfun_batch(theta[n, npar]) -> ss[n] or ss[n, ny], called once per stage (or from
+        `nthreads` threads on disjoint slices)."""
+        n = self.npar
+
+        def _ssb(th, npar, nb, ny, out, user):
+            a = np.ctypeslib.as_array(th, shape=(nb, n)).copy()
+            v = np.asarray(ssfun_batch(a), dtype=np.float64).reshape(nb, ny)
+            np.ctypeslib.as_array(out, shape=(nb, ny))[:, :] = v
+
+        def _pri(th, npar, user):
+            return float(priorfun(np.ctypeslib.as_array(th, shape=(n,)).copy()))
+
+        def _cb(th, npar, user):
+            return 1 if checkbounds(np.ctypeslib.as_array(th, shape=(n,)).copy()) else 0
+
+        self._cbb_keep = (_lib.SSFUN_BATCH_T(_ssb), _lib.PRIORFUN_T(_pri) if priorfun else _lib.PRIORFUN_T(),
+                          _lib.CHECKBOUNDS_T(_cb) if checkbounds else _lib.CHECKBOUNDS_T())
+        self._chk(self.L.mcmcx_set_target_host_batch(self.h, self._cbb_keep[0], self._cbb_keep[1], self._cbb_keep[2], None, int(nthreads)))
+
+    def set_target_module(self, code_object, kernel_name, userdata=None):
+        """The user's ssfunction / priorfun / checkbounds as device code (include/mcmcx_target.h): `code_object` is the
+        hipcc --genco output, userdata a bytes-like object or a float64 array copied to the device."""
+        buf = None if userdata is None else np.ascontiguousarray(userdata)
+        self._chk(self.L.mcmcx_set_target_module(self.h, str(code_object).encode(), str(kernel_name).encode(),
+                                                 None if buf is None else buf.ctypes.data_as(C.c_void_p), 0 if buf is None else buf.nbytes))
+
     def set_bounds(self, lo=None, hi=None):
         lo = _f64(lo) if lo is not None else None
         hi = _f64(hi) if hi is not None else None

@@ -63,7 +63,15 @@ module mcmcmod
   character(len=256), save :: mufile = 'mcmctest_mu.dat', lamfile = 'mcmctest_lam.dat'
   character(len=256), save :: datafile = 'data.dat', lowerfile = '', upperfile = ''
   integer, save :: ngpus = 1                           ! GPUs of this node: nchains/ngpus chains each, one RCCL communicator
-  namelist /mcmcx/ devtarget, nchains, seed, pooled, banana_b, mufile, lamfile, datafile, lowerfile, upperfile, ngpus
+  !! the user's own functions faster than one host call per chain:
+  !!   hostbatch = 1: ssfunction_batch(theta(npar,n), npar, n, ny, ss(ny,n)) once per stage (default member: a loop over
+  !!                  ssfunction), from hostthreads threads on disjoint column blocks when hostthreads > 1
+  !!   devtarget = 'module': device code built with include/mcmcx_target.h -- modulefile (hipcc --genco output),
+  !!                  modulekernel (the MCMCX_DEFINE_TARGET name), moduledatafile (numbers handed to the functions)
+  integer, save :: hostbatch = 0, hostthreads = 1
+  character(len=256), save :: modulefile = '', modulekernel = 'user_target', moduledatafile = ''
+  namelist /mcmcx/ devtarget, nchains, seed, pooled, banana_b, mufile, lamfile, datafile, lowerfile, upperfile, ngpus, &
+       hostbatch, hostthreads, modulefile, modulekernel, moduledatafile
 
   !! public state, mcmc.F90:28-52
   integer, save :: npar = 0, nycol = 1, simuind = 0, chainind = 0, MCMC_running = 0
@@ -76,7 +84,7 @@ module mcmcmod
 
   !! set by the MCMC_set* calls
   real(kind=dbl), allocatable, save, private :: par0(:), cmat0(:,:)
-  real(kind=dbl), allocatable, save, private :: tmu(:), tlam(:,:), tx(:), ty(:), tlo(:), thi(:), pmu(:), psig(:)
+  real(kind=dbl), allocatable, save, private :: tmu(:), tlam(:,:), tx(:), ty(:), tlo(:), thi(:), pmu(:), psig(:), moddata(:)
   logical, save, private :: par0ok = .false., cmat0ok = .false., sigma2ok = .false., nparok = .false.
   logical, save, private :: has_lo = .false., has_hi = .false., interrupted = .false.
   character(len=32), save, private :: seedfile_used = ''
@@ -256,6 +264,21 @@ module mcmcmod
        import :: c_ptr, c_int, c_double
        type(c_ptr), value :: h
        real(c_double), intent(out) :: out(*)
+       integer(c_int) :: rc
+     end function
+     function mcmcx_set_target_host_batch(h, ssb, pri, cb, user, nthreads) bind(C, name='mcmcx_set_target_host_batch') result(rc)
+       import :: c_ptr, c_funptr, c_int, c_int32_t
+       type(c_ptr), value :: h, user
+       type(c_funptr), value :: ssb, pri, cb
+       integer(c_int32_t), value :: nthreads
+       integer(c_int) :: rc
+     end function
+     function mcmcx_set_target_module(h, path, kname, udata, nbytes) bind(C, name='mcmcx_set_target_module') result(rc)
+       import :: c_ptr, c_char, c_int, c_int64_t, c_double
+       type(c_ptr), value :: h
+       character(kind=c_char), intent(in) :: path(*), kname(*)
+       real(c_double), intent(in) :: udata(*)
+       integer(c_int64_t), value :: nbytes
        integer(c_int) :: rc
      end function
      function mcmcx_get_totals(h, t7) bind(C, name='mcmcx_get_totals') result(rc)
@@ -512,6 +535,22 @@ contains
     n4 = n; ny4 = ny
     ss_out(1:ny) = ssfunction(theta(1:n), n4, ny4)
   end subroutine mcx_ss_adapter
+  subroutine mcx_ss_batch_adapter(theta, n, nb, ny, ss_out, user) bind(C)
+    real(c_double), intent(in) :: theta(*)
+    integer(c_int32_t), value :: n, nb, ny
+    real(c_double), intent(out) :: ss_out(*)
+    type(c_ptr), value :: user
+    integer(kind=4) :: n4, nb4, ny4
+    interface
+       subroutine ssfunction_batch(theta,npar,n,ny,ss)
+         integer*4 npar, n, ny
+         real*8 theta(npar,n)
+         real*8 ss(ny,n)
+       end subroutine ssfunction_batch
+    end interface
+    n4 = n; nb4 = nb; ny4 = ny
+    call ssfunction_batch(theta, n4, nb4, ny4, ss_out)
+  end subroutine mcx_ss_batch_adapter
   subroutine mcx_ss_er_adapter(theta, n, ny, sscrit, ss_out, user) bind(C)
     real(c_double), intent(in) :: theta(*)
     integer(c_int32_t), value :: n, ny
@@ -633,6 +672,12 @@ contains
        end if
     case ('banana')
     case ('host')
+    case ('module')                                    ! the numbers the user's device functions get as `data`
+       if (len_trim(moduledatafile) > 0 .and. .not.allocated(moddata)) then
+          call loadnumbers(moduledatafile, v, nr, nc, stat)
+          if (stat /= 0) call doerror('error reading '//trim(moduledatafile))
+          allocate(moddata(size(v))); moddata = v
+       end if
     case default
        call doerror('unknown devtarget in &mcmcx: '//trim(devtarget))
     end select
@@ -646,7 +691,7 @@ contains
        if (stat /= 0 .or. size(v) /= npar) call doerror('error reading '//trim(upperfile))
        call MCMC_setbounds(hi=v)
     end if
-    if (len_trim(priorsfile) > 0 .and. trim(devtarget) /= 'host') then    ! priorfun.f90:52-80: two rows, mu and sigma
+    if (len_trim(priorsfile) > 0 .and. trim(devtarget) /= 'host' .and. trim(devtarget) /= 'module') then    ! priorfun.f90:52-80: two rows, mu and sigma
        call loadnumbers(priorsfile, v, nr, nc, stat)
        if (stat /= 0 .or. size(v) /= 2*npar) call doerror('priors.dat should have  2*npar elements')
        allocate(pmu(npar), psig(npar)); pmu = v(1:npar); psig = v(npar+1:2*npar)
@@ -733,9 +778,21 @@ contains
           if (size(ty) /= size(tx)*nycol) call doerror('devtarget expcols: the data file needs 1 + nycol columns')
           call chk(mcmcx_set_target_expdata_cols(handle, int(size(tx), c_int32_t), int(nycol, c_int32_t), tx, ty))
        case ('host')
-          call chk(mcmcx_set_target_host(handle, c_funloc(mcx_ss_adapter), c_funloc(mcx_prior_adapter), &
-               c_funloc(mcx_bounds_adapter), c_null_ptr))
-          call chk(mcmcx_set_target_host_er(handle, c_funloc(mcx_ss_er_adapter)))     ! used by method = 'er' only
+          if (hostbatch /= 0) then
+             call chk(mcmcx_set_target_host_batch(handle, c_funloc(mcx_ss_batch_adapter), c_funloc(mcx_prior_adapter), &
+                  c_funloc(mcx_bounds_adapter), c_null_ptr, int(hostthreads, c_int32_t)))
+          else
+             call chk(mcmcx_set_target_host(handle, c_funloc(mcx_ss_adapter), c_funloc(mcx_prior_adapter), &
+                  c_funloc(mcx_bounds_adapter), c_null_ptr))
+             call chk(mcmcx_set_target_host_er(handle, c_funloc(mcx_ss_er_adapter)))     ! used by method = 'er' only
+          end if
+       case ('module')
+          if (len_trim(modulefile) == 0) call doerror('devtarget module: &mcmcx modulefile is not set')
+          if (.not. allocated(moddata)) then
+             allocate(moddata(1)); moddata = 0.0_dbl
+          end if
+          call chk(mcmcx_set_target_module(handle, trim(modulefile)//c_null_char, trim(modulekernel)//c_null_char, &
+               moddata, int(8*size(moddata), c_int64_t)))
        end select
        if (has_lo .or. has_hi) call chk(mcmcx_set_bounds(handle, plo, phi))
        if (allocated(pmu)) call chk(mcmcx_set_priors(handle, pmu, psig))
