@@ -242,7 +242,9 @@ def main():
     if wl == "c5":
         a.pooled = not a.replicas
     elif a.pooled:
-        ckw = dict(ckw, method="dram", drscale=0.0)
+        ckw = dict(ckw, drscale=0.0)                   # c4 keeps method='ram' (pooled RAM); c2 / c3: pooled AM without DR
+        if wl == "c4" and a.method == "dram":
+            ckw = dict(ckw, method="dram")
     method = ckw.get("method", "dram")
     eng = engine_from_problem(ckw, pkw, nchains=n_local, chain_id0=rank * n_local, device=dev,
                               pooled=1 if a.pooled else 0, comm=comm)

@@ -50,6 +50,7 @@ struct mcmcx_engine {
     std::vector<double> h_bth, h_bss; std::vector<int> h_bidx;
     std::vector<double> h_cand, h_ev;
     // pooled mode
+    int pool_status = 0; double pool_alpha = 0.0;       // pooled RAM: skipped ticks, mean acceptance of the last tick
     int pooled = 0; double pool_W = 0.0; std::vector<double> pool_mean, pool_C, pool_R;   // packed upper, row-major
     std::vector<double> pool_U, pool_std;             // pooled SCAM: the shared rotation (column-major) and qcovstd
     double *d_sharedU = nullptr;                      // [U col-major | pad | U row-major | pad | std]
@@ -231,7 +232,7 @@ static size_t pooled_mfma_lds(int d)
 }
 static bool pooled_use_mfma(const mcmcx_engine *h)
 {
-    if (!h->pooled || h->cfg.method != MCMCX_METHOD_DRAM) return false;
+    if (!h->pooled || (h->cfg.method != MCMCX_METHOD_DRAM && h->cfg.method != MCMCX_METHOD_RAM)) return false;
     if (const char *e = getenv("MCMCX_POOLED_SCALAR")) if (atoi(e)) return false;      // A/B switch for tests: the lane-per-chain kernel
     return pooled_mfma_lds(h->d) <= 160 * 1024;
 }
@@ -244,11 +245,11 @@ static void launch_step(mcmcx_engine *h, int it0, int it1)
 {
     const dim3 g(h->ntiles), b(64);
     const double *rs = h->d_ramscale + it0;
-    if (h->E.method == M_RAM && h->usesvd) hipLaunchKernelGGL(step_kernel_ram_fullr, g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
+    if (pooled_use_mfma(h)) hipLaunchKernelGGL(pooled_mfma_kernel, g, b, pooled_mfma_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedRT);
+    else if (h->pooled) hipLaunchKernelGGL((step_kernel<false, false, true>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
+    else if (h->E.method == M_RAM && h->usesvd) hipLaunchKernelGGL(step_kernel_ram_fullr, g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->E.method == M_RAM) hipLaunchKernelGGL((step_kernel<true, false, false>), g, b, (size_t)NLC * 2 * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->dodr) hipLaunchKernelGGL((step_kernel<false, true, false>), g, b, lds_step(h), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
-    else if (pooled_use_mfma(h)) hipLaunchKernelGGL(pooled_mfma_kernel, g, b, pooled_mfma_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedRT);
-    else if (h->pooled) hipLaunchKernelGGL((step_kernel<false, false, true>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else hipLaunchKernelGGL((step_kernel<false, false, false>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
 }
 // every chain's copy of a K-vector, filled on the device
@@ -325,6 +326,16 @@ static int adapt_mode(const mcmcx_config &c, int it)
     return 0;
 }
 
+// pooled RAM: every adaptint iterations once the burn-in is over (MCMC_run_ram.F90:123-131), up to adaptend
+static bool pooled_ram_due(const mcmcx_engine *h, int it)
+{
+    const mcmcx_config &c = h->cfg;
+    if (!h->pooled || c.method != MCMCX_METHOD_RAM || c.doadapt == 0 || c.adaptint <= 0) return false;
+    if (it < c.burnintime && c.doburnin != 0) return false;
+    if (c.adaptend > 0 && it > c.adaptend) return false;
+    return it % c.adaptint == 0;
+}
+
 // ------------------------------------------------------------------ getters
 template <typename T>
 static int fetch(mcmcx_engine *h, const T *dev, size_t n, std::vector<T> &out)
@@ -366,17 +377,18 @@ static void unpack_upper(int d, const std::vector<double> &p, double *colmajor, 
         }
 }
 
-static int pooled_moments_launch(mcmcx_engine *h, double *dev_dst);
+static int pooled_moments_launch(mcmcx_engine *h, double *dev_dst, int kind = 0, int it = 0);
+static int pooled_vec_len(const mcmcx_engine *h, int kind);
 #include "mcx_comm.hpp"
 
 // Pooled moments of the chains of ALL ranks, left in h->d_pooled (asynchronous on the engine's stream): local tree ->
 // slot `rank` of d_gather -> all-gather over the communicator -> the same pairwise tree over the ranks.
-static int allreduce_moments_enqueue(mcmcx_engine *h, int stage /* 0 all, 1 local part, 2 gather, 3 tree */)
+static int allreduce_moments_enqueue(mcmcx_engine *h, int stage /* 0 all, 1 local part, 2 gather, 3 tree */, int kind = 0, int it = 0)
 {
-    const int len = 1 + h->d + h->P;
+    const int len = pooled_vec_len(h, kind);
     const int nr = h->comm ? h->comm->nranks : 1, rk = h->comm ? h->comm->rank : 0;
     HIPCHK(hipSetDevice(h->cfg.device));
-    if (stage == 0 || stage == 1) { int rc = pooled_moments_launch(h, h->d_gather + (size_t)rk * len); if (rc) return rc; }
+    if (stage == 0 || stage == 1) { int rc = pooled_moments_launch(h, h->d_gather + (size_t)rk * len, kind, it); if (rc) return rc; }
     if ((stage == 0 || stage == 2) && h->comm) { int rc = comm_allgather(h->comm, h->d_gather, len, h->stream); if (rc) return rc; }
     if (stage == 0 || stage == 3) {
         hipLaunchKernelGGL(moments_tree_kernel, dim3((len + 255) / 256, 1), dim3(256), 0, h->stream, h->d_gather, nr, len, 1, h->d_pooled);
@@ -385,35 +397,61 @@ static int allreduce_moments_enqueue(mcmcx_engine *h, int stage /* 0 all, 1 loca
     return 0;
 }
 
-// Pooled adaptation tick (the multi-chain form of MCMC_adapt.F90:105-170): the N current states are a batch of
-// N unit-weight rows.  Their mean/covariance come from the device-reduced moment vector (all-reduced over
-// ranks by the exchange hook), are merged into (chaincmat, chainmean, chainwsum) by the pairwise-update formula
-// -- or taken as they are when chainwsum == 0, like covmat's batch branch -- and the shared factor is
-// R = chol(chaincmat) * 2.4/sqrt(d).  Every operation below is restated in tests/test_gpu_pooled.py.
-static int pooled_adapt(mcmcx_engine *h, int it)
+// The pooled statistic vector of `kind` over the chains of ALL ranks, on the host.  With a communicator: local tree ->
+// all-gather -> tree over ranks; with the caller's exchange hook (kind 0 only): the hook sums the device buffer.
+static int pooled_reduce(mcmcx_engine *h, int kind, int it, std::vector<double> &v)
 {
-    const mcmcx_config &c = h->cfg;
-    const int d = h->d, P = h->P, len = 1 + d + P;
-    std::vector<double> v(len);
-    if (h->comm && !h->xfn) {                                                       // RCCL all-gather + fixed tree over the ranks
-        int rc = allreduce_moments_enqueue(h, 0); if (rc) return rc;
+    const int len = pooled_vec_len(h, kind);
+    v.assign(len, 0.0);
+    if (h->xfn && kind != 0) return fail(-8, "pooled burn-in scaling and the pooled RAM variant exchange through a communicator (mcmcx_set_comm), not through the mcmcx_set_exchange hook");
+    if (!h->xfn) {
+        int rc = allreduce_moments_enqueue(h, 0, kind, it); if (rc) return rc;
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipMemcpy(v.data(), h->d_pooled, (size_t)len * 8, hipMemcpyDeviceToHost));
     } else {
         double *dst = h->xbuf ? h->xbuf : h->d_moments + (size_t)h->ntiles * len;  // tail of the moments workspace
-        int rc = pooled_moments_launch(h, dst); if (rc) return rc;
+        int rc = pooled_moments_launch(h, dst, kind, it); if (rc) return rc;
         HIPCHK(hipStreamSynchronize(h->stream));
-        if (h->xfn) h->xfn(h->xuser);                                               // the caller's own exchange
+        h->xfn(h->xuser);                                                            // the caller's own exchange
         HIPCHK(hipMemcpy(v.data(), dst, (size_t)len * 8, hipMemcpyDeviceToHost));
     }
-    // the vector has been through an exchange: refuse to merge garbage (it would poison pool_C for the rest of the run)
+    // the vector has been through an exchange: refuse to merge garbage (it would poison the pooled state for the rest of the run)
     if (!(v[0] >= 2.0) || !std::isfinite(v[0])) return fail(-46, "pooled adaptation needs at least 2 chains over all ranks (count = " + std::to_string(v[0]) + ")");
-    for (int k = 1; k < len; ++k) if (!std::isfinite(v[k])) return fail(-46, "pooled adaptation: non-finite pooled moments at iteration " + std::to_string(it));
-    if (it == c.burnintime + c.adaptint + c.adapthist) {                            // first time: MCMC_adapt.F90:108-114
-        h->pool_W = (double)c.initcmatn;
-        for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) h->pool_C[h_pidx(i, j, d)] = h->cmat0[(size_t)i + (size_t)j * d];
-        h->pool_mean = h->par0;
+    for (int k = 1; k < len; ++k) if (!std::isfinite(v[k])) return fail(-46, "pooled adaptation: non-finite pooled statistic at iteration " + std::to_string(it));
+    return 0;
+}
+
+static int pooled_upload_R(mcmcx_engine *h)
+{
+    HIPCHK(hipMemcpyAsync(h->d_sharedR, h->pool_R.data(), (size_t)h->P * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->d_sharedRT) return upload_shared_rt(h);
+    return 0;
+}
+
+// chaincmat -> the shared proposal factor (MCMC_calculate_R): dpotf2 + 2.4/sqrt(d), or the pinned SVD for scam; on
+// failure the old factor stays (MCMC_adapt.F90:168-171)
+static int pooled_factor(mcmcx_engine *h)
+{
+    const mcmcx_config &c = h->cfg;
+    const int d = h->d;
+    std::vector<double> cm((size_t)d * d, 0.0), Rp, Cp;
+    for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) cm[(size_t)i + (size_t)j * d] = h->pool_C[h_pidx(i, j, d)];
+    if (c.method == MCMCX_METHOD_SCAM) {                // scam_svd of the pooled covariance, MCMC_adapt.F90:189-200
+        std::vector<double> U, sd;
+        if (host_initial_svd(d, cm, c.condmax, true, U, sd) == 0) { h->pool_U = U; h->pool_std = sd; return upload_shared_u(h); }
+        return 0;
     }
+    if (host_initial_R(d, cm, Rp, Cp) == 0) { h->pool_R = Rp; return pooled_upload_R(h); }
+    return 0;
+}
+
+// merge the batch of n unit-weight rows (moments v about par0) into (chaincmat, chainmean, chainwsum): covmat's
+// weighted update for a whole batch at once, or its batch branch when there is nothing to update (wsum = 0) or when
+// `replace` (the AP window: covmat(..., update = .false.), MCMC_adapt.F90:131-133)
+static void pooled_merge(mcmcx_engine *h, const std::vector<double> &v, bool replace)
+{
+    const int d = h->d, P = h->P;
     const double n = v[0];
     std::vector<double> m1(d), mb(d), Cb(P);
     for (int j = 0; j < d; ++j) { m1[j] = v[1 + j] / n; mb[j] = h->par0[j] + m1[j]; }
@@ -422,7 +460,7 @@ static int pooled_adapt(mcmcx_engine *h, int it)
             double s2 = v[1 + d + j * (j + 1) / 2 + i];
             Cb[h_pidx(i, j, d)] = (s2 - n * m1[i] * m1[j]) / (n - 1.0);
         }
-    if (!(h->pool_W > 0.0)) {
+    if (replace || !(h->pool_W > 0.0)) {
         h->pool_C = Cb; h->pool_mean = mb; h->pool_W = n;
     } else {
         const double W = h->pool_W, Wn = W + n;
@@ -438,21 +476,83 @@ static int pooled_adapt(mcmcx_engine *h, int it)
         for (int j = 0; j < d; ++j) h->pool_mean[j] = h->pool_mean[j] + g * dl[j];
         h->pool_W = Wn;
     }
-    // MCMC_calculate_R: dpotf2 + 2.4/sqrt(d); on failure keep the old factor (MCMC_adapt.F90:168-171)
-    std::vector<double> cm((size_t)d * d, 0.0), Rp, Cp;
-    for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) cm[(size_t)i + (size_t)j * d] = h->pool_C[h_pidx(i, j, d)];
-    if (c.method == MCMCX_METHOD_SCAM) {                // scam_svd of the pooled covariance, MCMC_adapt.F90:189-200
-        std::vector<double> U, sd;
-        if (host_initial_svd(d, cm, c.condmax, true, U, sd) == 0) { h->pool_U = U; h->pool_std = sd; return upload_shared_u(h); }
-        return 0;
+}
+
+static void pooled_restart(mcmcx_engine *h)             // chainwsum = initcmatn, chaincmat = cmat0, chainmean = par0
+{
+    const int d = h->d;
+    h->pool_W = (double)h->cfg.initcmatn;
+    for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) h->pool_C[h_pidx(i, j, d)] = h->cmat0[(size_t)i + (size_t)j * d];
+    h->pool_mean = h->par0;
+}
+
+// Pooled tick: the multi-chain form of MCMC_adapt (MCMC_adapt.F90:60-170).  The N current states of all ranks are a
+// batch of N unit-weight rows; `stayed` is summed over the chains.  Every operation below is restated in
+// tests/test_gpu_pooled.py.
+//   burn-in tick (:60-102): pooled rejection rate sum(stayed) / (N it) against scalelimit -> the shared factor is scaled
+//       down / up; in between, greedy restarts from cmat0 and merges the batch, otherwise chaincmat stays, and the
+//       factor is recomputed from chaincmat either way (which is what undoes earlier scalings in the reference too)
+//   AM tick (:105-159): first time restart from cmat0; merge the batch; AP (adapthist > 1): the batch replaces the
+//       covariance instead (the window of the single chain becomes the snapshot of the population)
+static int pooled_tick(mcmcx_engine *h, int it, int mode)
+{
+    const mcmcx_config &c = h->cfg;
+    std::vector<double> v;
+    if (mode & AD_BURN) {
+        int rc = pooled_reduce(h, 1, it, v); if (rc) return rc;
+        const double staypc = v[pooled_vec_len(h, 1) - 1] / (v[0] * (double)it);
+        const double sf = c.scalefactor;
+        if (staypc > 1.0 - c.scalelimit || staypc < c.scalelimit) {
+            const bool down = staypc > 1.0 - c.scalelimit;
+            for (auto &r : h->pool_R) r = down ? r / sf : r * sf;
+            return pooled_upload_R(h);
+        }
+        if (c.greedy != 0) { pooled_restart(h); pooled_merge(h, v, false); }
+        return pooled_factor(h);
     }
-    if (host_initial_R(d, cm, Rp, Cp) == 0) {
-        h->pool_R = Rp;
-        HIPCHK(hipMemcpyAsync(h->d_sharedR, h->pool_R.data(), (size_t)P * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        if (h->d_sharedRT) return upload_shared_rt(h);
+    int rc = pooled_reduce(h, 0, it, v); if (rc) return rc;
+    if (it == c.burnintime + c.adaptint + c.adapthist) pooled_restart(h);           // first time: MCMC_adapt.F90:108-114
+    pooled_merge(h, v, c.adapthist > 1);
+    return pooled_factor(h);
+}
+
+// Pooled RAM tick (the multi-chain form of MCMC_adapt_ram, MCMC_run_ram.F90:104-179): every adaptint iterations the
+// rank-one statistics of that iteration, one per chain, are averaged over all chains of all ranks and applied to the
+// Gram matrix of the shared factor at once:   R'R  <-  R'R + (1/N) sum_c sign(a_c) x_c x_c',
+// x_c = u_c / sum(u_c**2) * a_c,  a_c = (alpha_c - alphatarget) / it**nuparam  -- N Cholesky up/downdates of weight 1/N
+// folded into one refactorisation.  A Gram matrix that stops being positive definite keeps the old factor (the
+// single-chain code stops on a failed downdate; here one bad tick is skipped and flagged).
+static int pooled_ram_tick(mcmcx_engine *h, int it)
+{
+    const int d = h->d, P = h->P;
+    std::vector<double> v;
+    int rc = pooled_reduce(h, 2, it, v); if (rc) return rc;
+    const double n = v[0];
+    std::vector<double> S(P), A;
+    for (int j = 0; j < d; ++j)
+        for (int i = 0; i <= j; ++i) {
+            double acc = 0.0;
+            for (int k = 0; k <= i; ++k) acc = std::fma(h->pool_R[h_pidx(k, i, d)], h->pool_R[h_pidx(k, j, d)], acc);
+            S[h_pidx(i, j, d)] = acc + v[2 + j * (j + 1) / 2 + i] / n;
+        }
+    A = S;
+    for (int j = 0; j < d; ++j) {                       // dpotf2('U'), the order of host_initial_R
+        double dot = 0.0;
+        for (int i = 0; i < j; ++i) dot = std::fma(A[h_pidx(i, j, d)], A[h_pidx(i, j, d)], dot);
+        double ajj = A[h_pidx(j, j, d)] - dot;
+        if (!(ajj > 0.0)) { h->pool_status |= ST_CHOL_FAIL; return 0; }
+        double rj = std::sqrt(ajj);
+        A[h_pidx(j, j, d)] = rj;
+        double rinv = 1.0 / rj;
+        for (int k = j + 1; k < d; ++k) {
+            double t = 0.0;
+            for (int i = 0; i < j; ++i) t = std::fma(A[h_pidx(i, k, d)], A[h_pidx(i, j, d)], t);
+            A[h_pidx(j, k, d)] = (A[h_pidx(j, k, d)] - t) * rinv;
+        }
     }
-    return 0;
+    h->pool_R = A;
+    h->pool_alpha = v[1] / n;
+    return pooled_upload_R(h);
 }
 
 // Host-callback evaluation of one candidate vector per chain, in chain order, from the calling thread
@@ -639,8 +739,9 @@ int mcmcx_create(const mcmcx_config *cfg_in, mcmcx_handle *out)
     }
     if (c.pooled) {
         const bool scam = (c.method == MCMCX_METHOD_SCAM);
-        if ((c.method != MCMCX_METHOD_DRAM && !scam) || c.drscale > 0.0 || c.doburnin != 0 || c.adapthist > 1 || c.greedy != 0 || (!scam && c.condmax > 0.0))
-            return fail(-8, "pooled mode supports method='dram' (condmax=0) or 'scam', with doburnin=0, drscale=0, adapthist<=1, greedy=0");
+        if (c.method == MCMCX_METHOD_ER) return fail(-8, "pooled mode: method = 'er' is not available (use 'dram', 'ram' or 'scam')");
+        if (c.drscale > 0.0) return fail(-8, "pooled mode: delayed rejection keeps a per-chain inverse covariance; drscale must be 0");
+        if (!scam && c.condmax > 0.0) return fail(-8, "pooled mode: the SVD proposal factor (condmax > 0) is only available with method = 'scam'");
     }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -828,7 +929,7 @@ int mcmcx_init(mcmcx_handle h)
 
     EngineDev &E = h->E;
     E.d = d; E.P = P; E.ntiles = T;
-    E.method = (c.method == MCMCX_METHOD_RAM) ? M_RAM : (c.method == MCMCX_METHOD_ER ? M_ER : M_DRAM);
+    E.method = (c.method == MCMCX_METHOD_RAM && !h->pooled) ? M_RAM : (c.method == MCMCX_METHOD_ER ? M_ER : M_DRAM);   // pooled RAM adapts on the host side: the kernels see a plain Metropolis step
     E.usesvd = h->usesvd; E.doscam = (c.method == MCMCX_METHOD_SCAM) ? 1 : 0; E.condmax = c.condmax;
     E.Rf = E.R2f = E.qstd = E.Gw = E.Vw = nullptr;
     E.greedy = c.greedy; E.adapthist = c.adapthist; E.initcmatn = (double)c.initcmatn;
@@ -928,7 +1029,7 @@ int mcmcx_init(mcmcx_handle h)
         HIPCHK(hipMemcpy(h->d_sharedR, Rp.data(), (size_t)P * 8, hipMemcpyHostToDevice));
         E.sharedR = h->d_sharedR;
         h->pool_R = Rp; h->pool_C = Cp; h->pool_mean = h->par0; h->pool_W = (double)c.initcmatn;
-        if (c.method == MCMCX_METHOD_DRAM) {
+        if (c.method == MCMCX_METHOD_DRAM || c.method == MCMCX_METHOD_RAM) {
             if ((rc = dev_alloc(h, &h->d_sharedRT, (size_t)((d + 3) & ~3) * d + PWS, false))) return rc;
             if ((rc = upload_shared_rt(h))) return rc;
         }
@@ -957,9 +1058,9 @@ int mcmcx_init(mcmcx_handle h)
         if ((rc = dev_upload(h, &p, rs))) return rc;
         h->d_ramscale = const_cast<double *>(p);
     }
-    if ((rc = dev_alloc(h, &h->d_moments, (size_t)(T + 1) * (1 + d + P)))) return rc;
-    if ((rc = dev_alloc(h, &h->d_gather, (size_t)(h->comm ? h->comm->nranks : 1) * (1 + d + P)))) return rc;
-    if ((rc = dev_alloc(h, &h->d_pooled, (size_t)(1 + d + P)))) return rc;
+    if ((rc = dev_alloc(h, &h->d_moments, (size_t)(T + 1) * (2 + d + P)))) return rc;                         // longest pooled vector: 2 + d + P
+    if ((rc = dev_alloc(h, &h->d_gather, (size_t)(h->comm ? h->comm->nranks : 1) * (2 + d + P)))) return rc;
+    if ((rc = dev_alloc(h, &h->d_pooled, (size_t)(2 + d + P)))) return rc;
 
     // fill theta = par0, R = R(cmat0), chaincmat = cmat0, chainmean = par0, scalars
     {
@@ -1028,7 +1129,7 @@ int mcmcx_run(mcmcx_handle h, int32_t upto)
     HIPCHK(hipSetDevice(h->cfg.device));
     const mcmcx_config &c = h->cfg;
     if (upto > c.nsimu) upto = c.nsimu;
-    const int maxseg = (c.method == MCMCX_METHOD_RAM) ? 4096 : 1 << 30;
+    const int maxseg = (c.method == MCMCX_METHOD_RAM && !h->pooled) ? 4096 : 1 << 30;
     int it = h->simuind + 1;
     while (it <= upto) {
         if (g_interrupt) {                                  // a caught signal: stop at this launch boundary
@@ -1037,9 +1138,11 @@ int mcmcx_run(mcmcx_handle h, int32_t upto)
             return MCMCX_INTERRUPTED;
         }
         int end = it, mode = 0;
+        bool ramtick = false;
         for (;; ++end) {                                    // extend the launch up to the next tick
             mode = adapt_mode(c, end);
-            if (mode != 0 || end == upto || end - it + 1 >= maxseg) break;
+            ramtick = pooled_ram_due(h, end);
+            if (mode != 0 || ramtick || end == upto || end - it + 1 >= maxseg) break;
         }
         if (phased(h)) {
             for (int i2 = it; i2 <= end; ++i2) { int rc = host_iteration(h, i2); if (rc) return rc; }
@@ -1054,9 +1157,10 @@ int mcmcx_run(mcmcx_handle h, int32_t upto)
             h->launches += 1; h->steps += (end - it + 1);
         }
         if (mode != 0) {
-            if (h->pooled) { if (mode & AD_AM) { int rc = pooled_adapt(h, end); if (rc) return rc; } }
+            if (h->pooled) { int rc = pooled_tick(h, end, mode); if (rc) return rc; }
             else { launch_adapt(h, end, mode); HIPCHK(hipGetLastError()); }
         }
+        if (ramtick) { int rc = pooled_ram_tick(h, end); if (rc) return rc; }
         it = end + 1;
         if (g_sig_installed) { HIPCHK(hipStreamSynchronize(h->stream)); h->simuind = std::max(h->simuind, end); }
         if (h->pending.size() > 4096) { int rc = mcmcx_sync(h); if (rc) return rc; }
@@ -1117,6 +1221,7 @@ int mcmcx_get_totals(mcmcx_handle h, int64_t *t7)
         t7[0] += at(I_STAYED); t7[1] += at(I_BNDSTAYED); t7[2] += at(I_DRACC); t7[3] += at(I_DRTRIES);
         t7[5] += at(I_DOWNS); t7[6] |= at(I_STATUS);
     }
+    t7[6] |= h->pool_status;                            // pooled RAM: a tick whose Gram matrix was not positive definite was skipped
     // proposals evaluated: one per iteration (d componentwise ones with method='scam') + the delayed-rejection tries
     t7[4] = (int64_t)h->cfg.nchains * (int64_t)(h->simuind - 1) * (h->cfg.method == MCMCX_METHOD_SCAM ? h->d : 1) + t7[3];
     return 0;
@@ -1293,12 +1398,15 @@ int mcmcx_get_chain(mcmcx_handle h, int32_t chain, double *chain_out, double *ss
 
 int32_t mcmcx_pooled_moments_len(mcmcx_handle h) { return h ? 1 + h->d + h->P : -1; }
 
-static int pooled_moments_launch(mcmcx_engine *h, double *dev_dst)
+static int pooled_vec_len(const mcmcx_engine *h, int kind) { return kind == 2 ? 2 + h->P : 1 + h->d + h->P + (kind == 1 ? 1 : 0); }
+
+static int pooled_moments_launch(mcmcx_engine *h, double *dev_dst, int kind, int it)
 {   // (declared above)
     if (!h || !h->inited) return fail(-40, "we have not inited");
     HIPCHK(hipSetDevice(h->cfg.device));
-    const int len = 1 + h->d + h->P, T = h->ntiles;
-    hipLaunchKernelGGL(moments_kernel, dim3(T), dim3(64), 0, h->stream, h->E, h->d_moments, h->cfg.nchains);
+    const int len = pooled_vec_len(h, kind), T = h->ntiles;
+    const double rs = (kind == 2) ? 1.0 / std::pow((double)(float)it, h->cfg.nuparam) : 0.0;      // like d_ramscale (MCMC_run_ram.F90:166)
+    hipLaunchKernelGGL(moments_kernel, dim3(T), dim3(64), 0, h->stream, h->E, h->d_moments, h->cfg.nchains, kind, it, rs);
     for (long long stride = 1;; stride *= 64) {                            // six levels of the fixed pairwise tree per launch
         const long long groups = (T + 64 * stride - 1) / (64 * stride);
         hipLaunchKernelGGL(moments_tree_kernel, dim3((len + 255) / 256, (unsigned)groups), dim3(256), 0, h->stream, h->d_moments, T, len,
@@ -1311,7 +1419,7 @@ static int pooled_moments_launch(mcmcx_engine *h, double *dev_dst)
 
 int mcmcx_pooled_moments(mcmcx_handle h, double *out)
 {
-    int rc = pooled_moments_launch(h, nullptr); if (rc) return rc;
+    int rc = pooled_moments_launch(h, nullptr, 0, 0); if (rc) return rc;
     std::vector<double> v;
     if ((rc = fetch(h, h->d_moments, (size_t)(1 + h->d + h->P), v))) return rc;
     memcpy(out, v.data(), sizeof(double) * v.size());
@@ -1343,7 +1451,7 @@ int mcmcx_get_pooled(mcmcx_handle h, double *cmat, double *mean, double *wsum, d
 int mcmcx_pooled_moments_dev(mcmcx_handle h, void *dev_out)
 {
     if (!dev_out) return fail(-1, "null argument");
-    return pooled_moments_launch(h, (double *)dev_out);
+    return pooled_moments_launch(h, (double *)dev_out, 0, 0);
 }
 
 // ------------------------------------------------------------------ the node: several GPUs, one communicator

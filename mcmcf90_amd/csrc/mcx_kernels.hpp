@@ -1561,6 +1561,10 @@ __global__ __launch_bounds__(64) void pooled_mfma_kernel(EngineDev E, int it0, i
     for (int it = it0; it <= it1; ++it) {
         // ---- newpar = MCMC_propose(oldpar, R): z straight into the LDS vector, P = R'z on the matrix cores
         gen_normals(L.g, X, lane, d, true);
+        if (it == it1) {                                               // the launch's last normals stay readable (pooled RAM statistic)
+            double *zk = E.zs + ((size_t)tile * 2 + (it & 1)) * d * 64;
+            for (int k = 0; k < d; ++k) GV(zk, k) = XL(k);
+        }
         for (int k = d; k < d4; ++k) XL(k) = 0.0;
         for (int ob0 = 0; ob0 < nt; ob0 += 4) {
             const int nb = (nt - ob0) < 4 ? (nt - ob0) : 4;
@@ -2594,7 +2598,11 @@ __global__ __launch_bounds__(256) void gather_lane_kernel(const double *__restri
 // out[tile][1 + d + d(d+1)/2]: partial sums over the 64 lanes of a tile by an xor-butterfly (a fixed
 // pairwise tree: adjacent lanes first); the host finishes the tree over tiles, RCCL over GPUs.
 // Second moments are indexed j(j+1)/2 + i for i <= j.
-__global__ __launch_bounds__(64) void moments_kernel(EngineDev E, double *out, int nchains)
+// kind 0: [count, sum_j x_j, sum x_i x_j (i <= j)], x = theta - par0                       (1 + d + P terms)
+// kind 1: the same followed by sum_c stayed_c (the pooled rejection count of a burn-in tick)  (2 + d + P)
+// kind 2: the pooled RAM statistic of iteration `it` (MCMC_run_ram.F90:166-172 summed over chains): [count, sum alpha,
+//         sum_c sign(a_c) x_c x_c'], x_c = u_c / sum(u_c**2) * a_c, a_c = rs (alpha_c - alphatarget)     (2 + P)
+__global__ __launch_bounds__(64) void moments_kernel(EngineDev E, double *out, int nchains, int kind, int it, double rs)
 {
     // Each lane produces its chain's terms in a fixed order (count, first moments, second moments by rows of the lower
     // triangle); 64 terms at a time are transposed through LDS, and lane k then adds term k of the 64 chains in the
@@ -2604,7 +2612,8 @@ __global__ __launch_bounds__(64) void moments_kernel(EngineDev E, double *out, i
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d, P = E.P;
     const double *theta_t = E.theta + (size_t)tile * d * 64;
     const bool act = (tile * 64 + lane) < nchains;
-    double *o = out + (size_t)tile * (1 + d + P);
+    const int len = (kind == 2) ? 2 + P : (1 + d + P + (kind == 1 ? 1 : 0));
+    double *o = out + (size_t)tile * len;
     int m = 0;                                          // terms produced so far
     auto flush = [&](int base, int n) {                 // terms base .. base+n-1 sit in T[0..n-1][*]
         __syncthreads();
@@ -2626,13 +2635,31 @@ __global__ __launch_bounds__(64) void moments_kernel(EngineDev E, double *out, i
         if ((m & 63) == 0) flush(m - 64, 64);
     };
     put(act ? 1.0 : 0.0);
-    for (int j = 0; j < d; ++j) put(act ? (GV(theta_t, j) - E.par0[j]) : 0.0);
-    for (int j = 0; j < d; ++j) {
-        const double vj = act ? (GV(theta_t, j) - E.par0[j]) : 0.0;
-        for (int i = 0; i <= j; ++i) {
-            const double vi = act ? (GV(theta_t, i) - E.par0[i]) : 0.0;
-            put(vi * vj);
+    if (kind == 2) {
+        const double *z_t = E.zs + ((size_t)tile * 2 + (it & 1)) * d * 64;    // the normals iteration `it` proposed with
+        const double alpha = TIDX(E.scal, tile, NSCAL, S_ALPHA12, lane);
+        const double a = rs * (alpha - E.alphatarget);
+        double su = 0.0;
+        for (int k = 0; k < d; ++k) { const double z = GV(z_t, k); su = su + z * z; }
+        put(act ? alpha : 0.0);
+        for (int j = 0; j < d; ++j) {
+            const double xj = GV(z_t, j) / su * a;
+            for (int i = 0; i <= j; ++i) {
+                const double xi = GV(z_t, i) / su * a;
+                const double t = xi * xj;
+                put(act ? ((a >= 0.0) ? t : -t) : 0.0);
+            }
         }
+    } else {
+        for (int j = 0; j < d; ++j) put(act ? (GV(theta_t, j) - E.par0[j]) : 0.0);
+        for (int j = 0; j < d; ++j) {
+            const double vj = act ? (GV(theta_t, j) - E.par0[j]) : 0.0;
+            for (int i = 0; i <= j; ++i) {
+                const double vi = act ? (GV(theta_t, i) - E.par0[i]) : 0.0;
+                put(vi * vj);
+            }
+        }
+        if (kind == 1) put(act ? (double)TIDX(E.ictr, tile, NICTR, I_STAYED, lane) : 0.0);
     }
     if (m & 63) flush(m & ~63, m & 63);
 }

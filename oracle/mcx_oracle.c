@@ -479,6 +479,7 @@ static void propose(mcxo_chain *c, const double *oldpar, const double *R, double
     double *z = newpar;
     for (int i = 0; i < n; ++i) z[i] = mcxo_normal(&c->rng);
     if (zout) memcpy(zout, z, sizeof(double) * (size_t)n);
+    if (R == c->R && c->last_u) memcpy(c->last_u, z, sizeof(double) * (size_t)n);
     if (c->cfg.usesvd) {                               /* matmulx(R, z): full dgemv 'N' (MCMC_DRAM.F90:27) */
         double *y = (double *)malloc(sizeof(double) * (size_t)n);
         mcxo_gemv(0, n, R, z, y);
@@ -714,6 +715,7 @@ mcxo_chain *mcxo_chain_create_ny(const mcxo_cfg *cfg, const mcxo_target *tgt, co
     c->alpha_trace = (double *)calloc(ns, sizeof(double));
     c->oldpar = (double *)malloc(sizeof(double) * n);
     c->qcovstd = (double *)calloc((size_t)n, sizeof(double));
+    c->last_u = (double *)calloc((size_t)n, sizeof(double));
     c->ad_istart = 1; c->ad_istartind = 1; c->ad_lastind = 1; c->ad_lastfreq = 0;
     /* MCMC_init.F90:99-116 */
     memcpy(c->chaincmat, cmat0, sizeof(double) * nn);
@@ -732,7 +734,7 @@ void mcxo_chain_free(mcxo_chain *c)
 {
     if (!c) return;
     free(c->par0); free(c->cmat0); free(c->R); free(c->R2); free(c->iC); free(c->chaincmat); free(c->chainmean);
-    free(c->chain); free(c->sschain); free(c->s2chain); free(c->accepted); free(c->alpha_trace); free(c->oldpar); free(c->qcovstd);
+    free(c->chain); free(c->sschain); free(c->s2chain); free(c->accepted); free(c->alpha_trace); free(c->oldpar); free(c->qcovstd); free(c->last_u);
     free(c);
 }
 

@@ -92,6 +92,9 @@ typedef struct mcxo_chain {
     /* 1 after a successful Cholesky downdate of MCMC_adapt_ram: the next proposal's R'z accumulates from the diagonal
      * up (mcxo_trmv_ut_desc), which is the order DCHDD leaves the columns in; otherwise ascending (mcxo_trmv_ut) */
     int trmv_desc;
+    /* the normal deviates of the latest first-stage proposal (MCMC_propose's u): what a pooled RAM tick of the engine
+     * reads back; test restatements only (tests/test_gpu_pooled.py) */
+    double *last_u;
 } mcxo_chain;
 
 mcxo_chain *mcxo_chain_create(const mcxo_cfg *cfg, const mcxo_target *tgt, const double *par0,

@@ -55,7 +55,7 @@ class Chain(C.Structure):
                 ("oldpar", _DP), ("ss1", C.c_double), ("sspri1", C.c_double), ("alpha12", C.c_double),
                 ("continue_on_downdate_fail", C.c_int), ("qcovstd", _DP), ("erstayed", C.c_int),
                 ("ny", C.c_int), ("ss1v", C.c_double * 8), ("sigma2v", C.c_double * 8), ("nobsv", C.c_int * 8),
-                ("trmv_desc", C.c_int)]
+                ("trmv_desc", C.c_int), ("last_u", _DP)]
 
 
 _lib = None
@@ -248,6 +248,19 @@ class LiveChain:
     @property
     def theta(self):
         return np.ctypeslib.as_array(self.ch.contents.oldpar, shape=(self.n,)).copy()
+
+    @property
+    def last_u(self):
+        """normal deviates of the latest first-stage proposal"""
+        return np.ctypeslib.as_array(self.ch.contents.last_u, shape=(self.n,)).copy()
+
+    @property
+    def alpha12(self):
+        return float(self.ch.contents.alpha12)
+
+    @property
+    def stayed(self):
+        return int(self.ch.contents.stayed)
 
     @property
     def accepted(self):

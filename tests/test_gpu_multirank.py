@@ -26,8 +26,9 @@ def _bench(args, tmp_path, name):
     return json.loads(lines[0]), np.fromfile(dump, dtype=np.float64)
 
 
-@pytest.mark.parametrize("extra", [[], ["--pooled"], ["--workload", "c2"], ["--workload", "c5", "--chains-per-gpu", "128", "--its-per-step", "2"]],
-                         ids=["c4_ram", "c4_pooled_am", "c2_am", "c5_pooled_scam"])
+@pytest.mark.parametrize("extra", [[], ["--pooled"], ["--pooled", "--method", "dram"], ["--workload", "c2"],
+                                   ["--workload", "c5", "--chains-per-gpu", "128", "--its-per-step", "2"]],
+                         ids=["c4_ram", "c4_pooled_ram", "c4_pooled_am", "c2_am", "c5_pooled_scam"])
 def test_two_ranks_equal_one_rank_with_twice_the_chains(tmp_path, extra):
     n = 2048
     common = ["--steps", "2", "--warmup", "1"] + extra

@@ -17,6 +17,15 @@ def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
+_libm = C.CDLL("libm.so.6")
+_libm.fma.restype = C.c_double
+_libm.fma.argtypes = [C.c_double, C.c_double, C.c_double]
+
+
+def _fma(a, b, c):
+    return _libm.fma(float(a), float(b), float(c))
+
+
 def _tree(v):
     """Pairwise tree, adjacent partners first (the xor-butterfly inside a tile, then the tile tree)."""
     v = list(v)
@@ -307,6 +316,194 @@ def test_pooled_am_matrix_core_kernel_sizes(oracle, d, monkeypatch):
                 ch.set_R(state["R"])
     theta = np.array([ch.theta for ch in chains])
     np.testing.assert_array_equal(_bits(e.theta()), _bits(theta))
+    for ch in chains:
+        ch.close()
+    e.close()
+
+
+# ---------------------------------------------------------------- pooled burn-in scaling / greedy / AP / RAM
+def _init_state(oracle, d, par0, cmat0, initcmatn):
+    st = {"W": float(initcmatn), "C": {(i, j): float(cmat0[i, j]) for j in range(d) for i in range(j + 1)},
+          "mean": [float(v) for v in par0]}
+    return _factor(oracle, st, d)
+
+
+def _factor(oracle, st, d):
+    """pooled_factor: dpotf2 + 2.4/sqrt(d); the old factor stays when the covariance is not positive definite"""
+    A = np.zeros((d, d), order="F")
+    for (i, j), v in st["C"].items():
+        A[i, j] = v; A[j, i] = v
+    if oracle.lib().mcxo_potrf_u(d, A.ctypes.data_as(C.POINTER(C.c_double))) == 0:
+        sq = math.sqrt(float(d))
+        st["R"] = np.array([[A[i, j] * 2.4 / sq if i <= j else 0.0 for j in range(d)] for i in range(d)])
+    return st
+
+
+def _merge(st, cnt, s1, s2, par0, d, replace):
+    """pooled_merge of mcx_api.hip in Python floats"""
+    n = cnt
+    m1 = [s1[j] / n for j in range(d)]
+    mb = [float(par0[j]) + m1[j] for j in range(d)]
+    Cb = {(i, j): (s2[(i, j)] - n * m1[i] * m1[j]) / (n - 1.0) for j in range(d) for i in range(j + 1)}
+    if replace or not st["W"] > 0.0:
+        st["C"], st["mean"], st["W"] = Cb, mb, n
+    else:
+        W = st["W"]; Wn = W + n
+        dl = [mb[j] - st["mean"][j] for j in range(d)]
+        f = W * n / Wn
+        st["C"] = {(i, j): ((W - 1.0) * st["C"][(i, j)] + (n - 1.0) * Cb[(i, j)] + f * dl[i] * dl[j]) / (Wn - 1.0)
+                   for j in range(d) for i in range(j + 1)}
+        g = n / Wn
+        st["mean"] = [st["mean"][j] + g * dl[j] for j in range(d)]
+        st["W"] = Wn
+    return st
+
+
+def _restate_pooled(oracle, ckw, pkw, N, nranks=1):
+    """The engine's pooled_tick, tick by tick, on N single-chain oracles that never adapt on their own."""
+    d = int(pkw["npar"])
+    cfg = oracle.make_cfg(**ckw)
+    plain = oracle.make_cfg(**dict(ckw, doadapt=0, doburnin=0, method="dram"))
+    prob = oracle.Problem(**pkw)
+    chains = [oracle.LiveChain(plain, prob, chain_id=c) for c in range(N)]
+    par0, cmat0 = np.asarray(pkw["par0"], float), np.asarray(pkw["cmat0"], float).reshape(d, d)
+    st = _init_state(oracle, d, par0, cmat0, cfg.initcmatn)
+    badapt = cfg.badaptint if cfg.badaptint > 0 else cfg.adaptint
+    log = []
+    for it in range(2, cfg.nsimu + 1):
+        m1 = cfg.adaptint != 0 and it % cfg.adaptint == 0
+        m2 = badapt != 0 and it % badapt == 0
+        if not (m1 or m2) or (cfg.adaptend > 0 and it > cfg.adaptend):
+            continue
+        burn = it < cfg.burnintime and cfg.doburnin != 0 and m2
+        am = (not burn) and it >= cfg.burnintime + cfg.adaptint + cfg.adapthist and cfg.doadapt != 0
+        if not (burn or am):
+            continue
+        for ch in chains:
+            ch.run(it)
+        theta = np.array([ch.theta for ch in chains])
+        cnt, s1, s2 = _pooled_moments(theta, par0, N)
+        if burn:
+            stayed = float(sum(ch.stayed for ch in chains))
+            staypc = stayed / (cnt * float(it))
+            sf = cfg.scalefactor
+            if staypc > 1.0 - cfg.scalelimit:
+                st["R"] = st["R"] / sf; log.append((it, "down"))
+            elif staypc < cfg.scalelimit:
+                st["R"] = st["R"] * sf; log.append((it, "up"))
+            else:
+                if cfg.greedy:
+                    st.update(W=float(cfg.initcmatn), C={(i, j): float(cmat0[i, j]) for j in range(d) for i in range(j + 1)},
+                              mean=[float(v) for v in par0])
+                    st = _merge(st, cnt, s1, s2, par0, d, False)
+                st = _factor(oracle, st, d); log.append((it, "greedy" if cfg.greedy else "refactor"))
+        else:
+            if it == cfg.burnintime + cfg.adaptint + cfg.adapthist:
+                st.update(W=float(cfg.initcmatn), C={(i, j): float(cmat0[i, j]) for j in range(d) for i in range(j + 1)},
+                          mean=[float(v) for v in par0])
+            st = _merge(st, cnt, s1, s2, par0, d, cfg.adapthist > 1)
+            st = _factor(oracle, st, d); log.append((it, "ap" if cfg.adapthist > 1 else "am"))
+        for ch in chains:
+            ch.set_R(st["R"])
+    for ch in chains:
+        ch.run(cfg.nsimu)
+    return chains, st, log
+
+
+@pytest.mark.parametrize("name,extra,c0", [
+    ("scale_up", dict(doburnin=1, burnintime=260, badaptint=50, scalelimit=0.3), 1e-4),       # nearly everything accepted
+    ("scale_down", dict(doburnin=1, burnintime=260, badaptint=50, scalelimit=0.3), 40.0),     # nearly everything rejected
+    ("refactor", dict(doburnin=1, burnintime=260, badaptint=50, scalelimit=0.05), 0.05),
+    ("greedy", dict(doburnin=1, burnintime=260, badaptint=50, scalelimit=0.05, greedy=1, initcmatn=7), 0.05),
+    ("ap", dict(adapthist=60), 0.05),
+    ("adaptend", dict(adaptend=150), 0.05),
+])
+def test_pooled_burnin_greedy_ap_match_restatement(oracle, name, extra, c0):
+    from mcmcf90_amd import engine_from_problem
+    d, N, nsimu = 5, 130, 420
+    ckw = dict(nsimu=nsimu, adaptint=100, updatesigma=0, **extra)
+    S = 0.5 ** np.abs(np.subtract.outer(np.arange(d), np.arange(d)))
+    pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.3), cmat0=c0 * np.eye(d), mu=np.linspace(-1, 1, d), lam=np.linalg.inv(S))
+    e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
+    e.init(); e.run()
+    chains, st, log = _restate_pooled(oracle, ckw, pkw, N)
+    kinds = {k for _, k in log}
+    want = {"scale_up": "up", "scale_down": "down", "refactor": "refactor", "greedy": "greedy", "ap": "ap", "adaptend": "am"}[name]
+    assert want in kinds, log                                   # the branch the case is about was taken
+    theta = np.array([ch.theta for ch in chains])
+    np.testing.assert_array_equal(_bits(e.theta()), _bits(theta), err_msg=str(log))
+    for c in (0, 63, 64, N - 1):
+        np.testing.assert_array_equal(e.accepted(c), chains[c].accepted)
+    cm, mean, W, R = e.pooled()
+    assert W == st["W"]
+    np.testing.assert_array_equal(_bits(np.triu(R)), _bits(np.triu(st["R"])))
+    np.testing.assert_array_equal(_bits(mean), _bits(np.array(st["mean"])))
+    for ch in chains:
+        ch.close()
+    e.close()
+
+
+@pytest.mark.parametrize("d,N,mfma", [(6, 150, 0), (6, 150, 1), (50, 200, 1)])
+def test_pooled_ram_matches_restatement(oracle, d, N, mfma, monkeypatch):
+    """method = 'ram', pooled = 1: one factor for all chains; every adaptint iterations the chains' rank-one RAM
+    statistics sign(a) x x' (MCMC_run_ram.F90:166-172) of that iteration are averaged over all chains and folded into
+    the Gram matrix of the shared factor, which is refactored (pooled_ram_tick)."""
+    from mcmcf90_amd import engine_from_problem
+    if not mfma:
+        monkeypatch.setenv("MCMCX_POOLED_SCALAR", "1")
+    nsimu, adaptint, nu, target = 130, 20, 0.7, 0.234
+    ckw = dict(nsimu=nsimu, method="ram", adaptint=adaptint, updatesigma=0, nuparam=nu, alphatarget=target)
+    rng = np.random.default_rng(d)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.2), cmat0=(0.5 / d) * np.eye(d), mu=np.zeros(d), lam=A @ A.T + np.eye(d))
+    e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
+    e.init(); e.run()
+    plain = oracle.make_cfg(**dict(ckw, doadapt=0, method="dram"))
+    prob = oracle.Problem(**pkw)
+    chains = [oracle.LiveChain(plain, prob, chain_id=c) for c in range(N)]
+    st = _init_state(oracle, d, np.asarray(pkw["par0"], float), np.asarray(pkw["cmat0"], float), 0)
+    R = st["R"]
+    T = (N + 63) // 64
+
+    def tree_over_chains(vals):
+        v = np.zeros(T * 64); v[:N] = vals
+        return _tree([_tree(v[t * 64:(t + 1) * 64]) for t in range(T)])
+
+    for it in range(adaptint, nsimu + 1, adaptint):
+        for ch in chains:
+            ch.run(it)
+        rs = 1.0 / math.pow(float(np.float32(it)), nu)
+        X = np.zeros((N, d)); sgn = np.zeros(N)
+        for c, ch in enumerate(chains):
+            u = ch.last_u
+            su = 0.0
+            for k in range(d):
+                su = su + u[k] * u[k]
+            a = rs * (ch.alpha12 - target)
+            X[c] = [u[k] / su * a for k in range(d)]
+            sgn[c] = 1.0 if a >= 0.0 else -1.0
+        cnt = tree_over_chains(np.ones(N))
+        S = np.zeros((d, d))
+        for j in range(d):
+            for i in range(j + 1):
+                acc = 0.0
+                for k in range(i + 1):
+                    acc = _fma(R[k, i], R[k, j], acc)
+                S[i, j] = acc + tree_over_chains(sgn * (X[:, i] * X[:, j])) / cnt
+                S[j, i] = S[i, j]
+        Af = np.asfortranarray(S.copy())
+        if oracle.lib().mcxo_potrf_u(d, Af.ctypes.data_as(C.POINTER(C.c_double))) == 0:
+            R = np.triu(np.array(Af))
+        for ch in chains:
+            ch.set_R(R)
+    for ch in chains:
+        ch.run(nsimu)
+    theta = np.array([ch.theta for ch in chains])
+    np.testing.assert_array_equal(_bits(e.theta()), _bits(theta))
+    for c in (0, 63, 64, N - 1):
+        np.testing.assert_array_equal(e.accepted(c), chains[c].accepted)
+    np.testing.assert_array_equal(_bits(np.triu(e.pooled()[3])), _bits(R))
+    assert not np.array_equal(R, st["R"])                       # the factor did adapt
     for ch in chains:
         ch.close()
     e.close()
