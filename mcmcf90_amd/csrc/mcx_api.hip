@@ -1147,12 +1147,20 @@ int mcmcx_run(mcmcx_handle h, int32_t upto)
         if (phased(h)) {
             for (int i2 = it; i2 <= end; ++i2) { int rc = host_iteration(h, i2); if (rc) return rc; }
         } else {
-            hipEvent_t e0, e1;
-            HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-            HIPCHK(hipEventRecord(e0, h->stream));
-            if (h->cfg.method == MCMCX_METHOD_SCAM) launch_scam(h, it, end); else launch_step(h, it, end);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(e1, h->stream));
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            hipError_t er = hipEventCreate(&e0);
+            if (er == hipSuccess) er = hipEventCreate(&e1);
+            if (er == hipSuccess) er = hipEventRecord(e0, h->stream);
+            if (er == hipSuccess) {
+                if (h->cfg.method == MCMCX_METHOD_SCAM) launch_scam(h, it, end); else launch_step(h, it, end);
+                er = hipGetLastError();
+            }
+            if (er == hipSuccess) er = hipEventRecord(e1, h->stream);
+            if (er != hipSuccess) {                       // nothing is left behind on the error path
+                if (e0) (void)hipEventDestroy(e0);
+                if (e1) (void)hipEventDestroy(e1);
+                return fail(-100, std::string("step launch: ") + hipGetErrorString(er));
+            }
             h->pending.emplace_back(e0, e1);
             h->launches += 1; h->steps += (end - it + 1);
         }
@@ -1359,7 +1367,7 @@ int mcmcx_get_chain(mcmcx_handle h, int32_t chain, double *chain_out, double *ss
     // this chain's lane of the history ring, gathered on the device: hv[slot*(d+1) + k]
     auto gather = [&](const double *src, size_t n, std::vector<double> &dst) -> int {
         double *tmp = nullptr;
-        HIPCHK(hipMalloc(&tmp, n * sizeof(double)));
+        HIPCHK(hipMalloc(&tmp, n * sizeof(double)));       // (freed on every path below)
         hipLaunchKernelGGL(gather_lane_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, h->stream, src, tmp, n, lane);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -1522,19 +1530,25 @@ int mcmcx_run_all(mcmcx_handle *hs, int32_t n, int32_t upto)
 
 extern "C" {
 // ------------------------------------------------------------------ debug probes (tests only)
+struct DevBufs {                                       // hipFree on every exit path
+    std::vector<void *> p;
+    template <typename T> hipError_t alloc(T **q, size_t bytes) { void *v = nullptr; hipError_t e = hipMalloc(&v, bytes); if (e == hipSuccess) p.push_back(v); *q = (T *)v; return e; }
+    ~DevBufs() { for (void *v : p) (void)hipFree(v); }
+};
+
 int mcmcx_debug_math(int32_t op, int32_t n, const double *a, const double *b, double *out)
 {
     if (n < 1 || !a || !out) return fail(-1, "bad argument");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(-10, "no HIP device: the mcmcx engine has no CPU fallback");
+    DevBufs g;
     double *da = nullptr, *db = nullptr, *dout = nullptr;
-    HIPCHK(hipMalloc((void **)&da, (size_t)n * 8)); HIPCHK(hipMalloc((void **)&dout, (size_t)n * 8));
+    HIPCHK(g.alloc(&da, (size_t)n * 8)); HIPCHK(g.alloc(&dout, (size_t)n * 8));
     HIPCHK(hipMemcpy(da, a, (size_t)n * 8, hipMemcpyHostToDevice));
-    if (b) { HIPCHK(hipMalloc((void **)&db, (size_t)n * 8)); HIPCHK(hipMemcpy(db, b, (size_t)n * 8, hipMemcpyHostToDevice)); }
+    if (b) { HIPCHK(g.alloc(&db, (size_t)n * 8)); HIPCHK(hipMemcpy(db, b, (size_t)n * 8, hipMemcpyHostToDevice)); }
     hipLaunchKernelGGL(debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, op, n, da, db, dout);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(da); (void)hipFree(dout); if (db) (void)hipFree(db);
     return 0;
 }
 
@@ -1543,13 +1557,13 @@ int mcmcx_debug_rng(uint32_t seed, uint32_t chain_id, int32_t kind, int32_t n, d
     if (n < 1 || !out) return fail(-1, "bad argument");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(-10, "no HIP device: the mcmcx engine has no CPU fallback");
+    DevBufs g;
     double *dout = nullptr; uint64_t *dn = nullptr;
-    HIPCHK(hipMalloc((void **)&dout, (size_t)n * 8)); HIPCHK(hipMalloc((void **)&dn, 8));
+    HIPCHK(g.alloc(&dout, (size_t)n * 8)); HIPCHK(g.alloc(&dn, 8));
     hipLaunchKernelGGL(debug_rng_kernel, dim3(1), dim3(64), 0, 0, seed, chain_id, kind, n, a, b, dout, dn);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost));
     if (nused) HIPCHK(hipMemcpy(nused, dn, 8, hipMemcpyDeviceToHost));
-    (void)hipFree(dout); (void)hipFree(dn);
     return 0;
 }
 

@@ -108,3 +108,23 @@ def test_one_process_node_api_with_one_gpu():
     assert e.simuind == 201
     e.close()
     L.mcmcx_comm_destroy(comms[0])
+
+
+def test_two_ranks_under_torchrun(tmp_path):
+    """The driver's launch line (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`): ranks from
+    RANK / LOCAL_RANK / WORLD_SIZE, communicator key from the launcher's port and pid.  Two ranks on the one GPU
+    (dry run), equal to the self-launched form."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MCMCX_COMM_KEY")}
+    dump = str(tmp_path / "tr.f64")
+    args = ["--gpus", "2", "--one-gpu-dryrun", "--steps", "2", "--warmup", "1", "--chains-per-gpu", "1024", "--no-cpu-baseline"]
+    port = 29600 + os.getpid() % 300
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args + ["--dump-moments", dump],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["pooled_check"]["chains"] == 2048
+    own, m_own = _bench(args, tmp_path, "own")
+    assert np.array_equal(np.fromfile(dump, dtype=np.float64).view(np.uint64), m_own.view(np.uint64))
