@@ -70,6 +70,12 @@ struct mcmcx_engine {
     double ms_total = 0.0; long long launches = 0, steps = 0;
 };
 
+struct DevBufs {                                       // hipFree on every exit path
+    std::vector<void *> p;
+    template <typename T> hipError_t alloc(T **q, size_t bytes) { void *v = nullptr; hipError_t e = hipMalloc(&v, bytes); if (e == hipSuccess) p.push_back(v); *q = (T *)v; return e; }
+    ~DevBufs() { for (void *v : p) (void)hipFree(v); }
+};
+
 template <typename T>
 static int dev_alloc(mcmcx_engine *h, T **p, size_t n, bool zero = true)
 {
@@ -1530,12 +1536,6 @@ int mcmcx_run_all(mcmcx_handle *hs, int32_t n, int32_t upto)
 
 extern "C" {
 // ------------------------------------------------------------------ debug probes (tests only)
-struct DevBufs {                                       // hipFree on every exit path
-    std::vector<void *> p;
-    template <typename T> hipError_t alloc(T **q, size_t bytes) { void *v = nullptr; hipError_t e = hipMalloc(&v, bytes); if (e == hipSuccess) p.push_back(v); *q = (T *)v; return e; }
-    ~DevBufs() { for (void *v : p) (void)hipFree(v); }
-};
-
 int mcmcx_debug_math(int32_t op, int32_t n, const double *a, const double *b, double *out)
 {
     if (n < 1 || !a || !out) return fail(-1, "bad argument");
