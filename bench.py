@@ -221,9 +221,18 @@ def main():
     if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: one rank per GPU" % (a.gpus, world))
 
-    from mcmcf90_amd import engine_from_problem, Comm
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
+    from mcmcf90_amd import engine_from_problem, Comm, _lib
     from mcmcf90_amd.workloads import problem
+    ndev = _lib.load().mcmcx_device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
     dev = 0 if a.one_gpu_dryrun else local_rank
+    if dev >= ndev:
+        if ndev == 1 and world > 1 and not a.one_gpu_dryrun and any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")):
+            dev = 0                                   # the launcher gave every rank its own single visible GPU
+        else:
+            raise SystemExit("rank %d: local rank %d but %d HIP device(s) visible -- %d ranks need %d GPUs (or --one-gpu-dryrun)" % (rank, local_rank, ndev, world, world))
     comm = None
     if world > 1:
         key = os.environ.get("MCMCX_COMM_KEY") or "t%s_%s_%d" % (os.environ.get("TORCHELASTIC_RUN_ID", "x"),

@@ -69,6 +69,7 @@ int  mcmcx_create(const mcmcx_config *cfg, mcmcx_handle *out);
 int  mcmcx_destroy(mcmcx_handle h);
 const char *mcmcx_last_error(void);
 const char *mcmcx_version(void);
+int32_t mcmcx_device_count(void);                              /* HIP devices visible to this process (0: none -- nothing will run) */
 
 int mcmcx_set_par0(mcmcx_handle h, const double *par0, int32_t npar);
 int mcmcx_set_cmat0(mcmcx_handle h, const double *cmat0_colmajor, int32_t npar);

@@ -31,6 +31,7 @@ SYMBOLS = {
     "mcmcx_destroy": (C.c_int, [C.c_void_p]),
     "mcmcx_last_error": (C.c_char_p, []),
     "mcmcx_version": (C.c_char_p, []),
+    "mcmcx_device_count": (C.c_int32, []),
     "mcmcx_set_par0": (C.c_int, [C.c_void_p, _DP, C.c_int32]),
     "mcmcx_set_cmat0": (C.c_int, [C.c_void_p, _DP, C.c_int32]),
     "mcmcx_set_sigma2nobs": (C.c_int, [C.c_void_p, _DP, _IP, C.c_int32]),

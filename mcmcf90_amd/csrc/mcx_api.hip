@@ -701,7 +701,8 @@ static int host_iteration(mcmcx_engine *h, int it)
 extern "C" {
 
 const char *mcmcx_last_error(void) { return g_err.c_str(); }
-const char *mcmcx_version(void) { return "mcmcx 0.1 (gfx950)"; }
+const char *mcmcx_version(void) { return "mcmcx 0.2 (gfx950)"; }
+int32_t mcmcx_device_count(void) { int n = 0; return (hipGetDeviceCount(&n) == hipSuccess) ? n : 0; }
 
 void mcmcx_config_defaults(mcmcx_config *c)                      // mcmcinit.F90:184-230
 {
