@@ -53,6 +53,7 @@ struct mcmcx_engine {
     int pool_status = 0; double pool_alpha = 0.0;       // pooled RAM: skipped ticks, mean acceptance of the last tick
     int pooled = 0; double pool_W = 0.0; std::vector<double> pool_mean, pool_C, pool_R;   // packed upper, row-major
     std::vector<double> pool_U, pool_std;             // pooled SCAM: the shared rotation (column-major) and qcovstd
+    std::vector<double> pool_Rf;                      // pooled AM with condmax > 0: covtor_svd's full factor U sqrt(s) 2.4/sqrt(d), column-major
     double *d_sharedU = nullptr;                      // [U col-major | pad | U row-major | pad | std]
     double *d_sharedRT = nullptr;                     // pooled AM on the matrix cores: dense R, M[s*d + o] = R(s,o), zero below the diagonal and in the pad rows
     double *d_sharedR = nullptr; mcmcx_exchange_t xfn = nullptr; void *xuser = nullptr; double *xbuf = nullptr;
@@ -172,21 +173,32 @@ static void host_symsvd(int n, std::vector<double> &G, std::vector<double> &V, s
 // MCMC_calculate_R, SVD branches, for the shared initial covariance (MCMC_init.F90:109): returns 0 or an error code.
 // Rfull: column-major d*d factor (U for scam, U sqrt(s) 2.4/sqrt(d) otherwise); std: sqrt(s) (scam)
 static int host_initial_svd(int d, const std::vector<double> &cm, double condmax, bool scam,
-                            std::vector<double> &Rfull, std::vector<double> &std)
+                            std::vector<double> &Rfull, std::vector<double> &std, std::vector<double> *floored_cm = nullptr)
 {
     std::vector<double> G((size_t)d * d), V, sv;
     for (int j = 0; j < d; ++j) for (int i = 0; i < d; ++i) G[(size_t)j * d + i] = (i <= j) ? cm[(size_t)i + (size_t)j * d] : cm[(size_t)j + (size_t)i * d];
     host_symsvd(d, G, V, sv);
     if (sv[0] == 0.0) return d;
     const double tol = sv[0] / condmax;
-    if (sv[d - 1] <= tol) for (int i = 0; i < d; ++i) if (sv[i] < tol) sv[i] = tol;
+    bool floored = false;
+    if (sv[d - 1] <= tol) { floored = true; for (int i = 0; i < d; ++i) if (sv[i] < tol) sv[i] = tol; }
     Rfull.resize((size_t)d * d); std.assign(d, 0.0);
     if (scam) {
         Rfull = V;
         for (int i = 0; i < d; ++i) std[i] = std::sqrt(sv[i]);
     } else {
         const double sqd = std::sqrt((double)d);
-        for (int i = 0; i < d; ++i) { double sq = std::sqrt(sv[i]); for (int k = 0; k < d; ++k) Rfull[(size_t)i * d + k] = (sq * V[(size_t)i * d + k]) * 2.4 / sqd; }
+        for (int i = 0; i < d; ++i) { double sq = std::sqrt(sv[i]); for (int k = 0; k < d; ++k) V[(size_t)i * d + k] = sq * V[(size_t)i * d + k]; }   // R0 = U diag(sqrt(s))
+        if (floored && floored_cm) {                    // covtor_svd info = -1: cmat = matmul(R0, transpose(R0)), matutils.F90:441-446
+            floored_cm->assign((size_t)d * d, 0.0);
+            for (int j = 0; j < d; ++j)
+                for (int i = 0; i <= j; ++i) {
+                    double acc = 0.0;
+                    for (int k = 0; k < d; ++k) acc = std::fma(V[(size_t)k * d + i], V[(size_t)k * d + j], acc);
+                    (*floored_cm)[(size_t)i + (size_t)j * d] = acc;
+                }
+        }
+        for (size_t e = 0; e < (size_t)d * d; ++e) Rfull[e] = V[e] * 2.4 / sqd;
     }
     return 0;
 }
@@ -279,6 +291,15 @@ static int upload_shared_rt(mcmcx_engine *h)
     const int d = h->d, d4 = (d + 3) & ~3;
     std::vector<double> m((size_t)d4 * d + PWS, 0.0);
     for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) m[(size_t)i * d + j] = h->pool_R[h_pidx(i, j, d)];
+    HIPCHK(hipMemcpyAsync(h->d_sharedRT, m.data(), m.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+static int upload_shared_rf(mcmcx_engine *h)            // dense M[s*d + o] = Rf(o, s): the column-major factor as it stands, pad rows zero
+{
+    const int d = h->d, d4 = (d + 3) & ~3;
+    std::vector<double> m((size_t)d4 * d + PWS, 0.0);
+    memcpy(m.data(), h->pool_Rf.data(), (size_t)d * d * 8);
     HIPCHK(hipMemcpyAsync(h->d_sharedRT, m.data(), m.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
@@ -429,6 +450,7 @@ static int pooled_reduce(mcmcx_engine *h, int kind, int it, std::vector<double> 
 
 static int pooled_upload_R(mcmcx_engine *h)
 {
+    if (h->usesvd) return upload_shared_rf(h);
     HIPCHK(hipMemcpyAsync(h->d_sharedR, h->pool_R.data(), (size_t)h->P * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->d_sharedRT) return upload_shared_rt(h);
@@ -446,6 +468,15 @@ static int pooled_factor(mcmcx_engine *h)
     if (c.method == MCMCX_METHOD_SCAM) {                // scam_svd of the pooled covariance, MCMC_adapt.F90:189-200
         std::vector<double> U, sd;
         if (host_initial_svd(d, cm, c.condmax, true, U, sd) == 0) { h->pool_U = U; h->pool_std = sd; return upload_shared_u(h); }
+        return 0;
+    }
+    if (h->usesvd) {                                    // covtor_svd of the pooled covariance, MCMC_adapt.F90:203-209
+        std::vector<double> Rf, sd, fc;
+        if (host_initial_svd(d, cm, c.condmax, false, Rf, sd, &fc) == 0) {
+            h->pool_Rf = Rf;
+            if (!fc.empty()) for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) h->pool_C[h_pidx(i, j, d)] = fc[(size_t)i + (size_t)j * d];
+            return pooled_upload_R(h);
+        }
         return 0;
     }
     if (host_initial_R(d, cm, Rp, Cp) == 0) { h->pool_R = Rp; return pooled_upload_R(h); }
@@ -510,7 +541,7 @@ static int pooled_tick(mcmcx_engine *h, int it, int mode)
         const double sf = c.scalefactor;
         if (staypc > 1.0 - c.scalelimit || staypc < c.scalelimit) {
             const bool down = staypc > 1.0 - c.scalelimit;
-            for (auto &r : h->pool_R) r = down ? r / sf : r * sf;
+            for (auto &r : (h->usesvd ? h->pool_Rf : h->pool_R)) r = down ? r / sf : r * sf;
             return pooled_upload_R(h);
         }
         if (c.greedy != 0) { pooled_restart(h); pooled_merge(h, v, false); }
@@ -748,7 +779,7 @@ int mcmcx_create(const mcmcx_config *cfg_in, mcmcx_handle *out)
         const bool scam = (c.method == MCMCX_METHOD_SCAM);
         if (c.method == MCMCX_METHOD_ER) return fail(-8, "pooled mode: method = 'er' is not available (use 'dram', 'ram' or 'scam')");
         if (c.drscale > 0.0) return fail(-8, "pooled mode: delayed rejection keeps a per-chain inverse covariance; drscale must be 0");
-        if (!scam && c.condmax > 0.0) return fail(-8, "pooled mode: the SVD proposal factor (condmax > 0) is only available with method = 'scam'");
+        if (c.method == MCMCX_METHOD_RAM && c.condmax > 0.0) return fail(-8, "pooled mode: method = 'ram' with condmax > 0 is not available");
     }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -976,10 +1007,12 @@ int mcmcx_init(mcmcx_handle h)
     E.R = nullptr;
     if (!h->pooled && (rc = dev_alloc(h, &E.R, L * P, false))) return rc;          // pooled: one shared factor instead
     if ((rc = dev_alloc(h, &E.basetheta, L * d))) return rc;
-    if (h->usesvd && h->pooled) {                       // pooled SCAM: one rotation for every chain
+    if (h->usesvd && h->pooled && c.method == MCMCX_METHOD_SCAM) {     // pooled SCAM: one rotation for every chain
         if ((rc = dev_alloc(h, &h->d_sharedU, 2 * shared_u_stride(h) + d, false))) return rc;
         h->pool_U = Rfull; h->pool_std = qstd0;
         if ((rc = upload_shared_u(h))) return rc;
+    } else if (h->usesvd && h->pooled) {                // pooled AM with the SVD factor: one full matrix for every chain (below)
+        h->pool_Rf = Rfull;
     } else if (h->usesvd) {
         const size_t DD = (size_t)d * d;
         if ((rc = dev_alloc(h, &E.Rf, L * DD, false))) return rc;
@@ -1038,7 +1071,8 @@ int mcmcx_init(mcmcx_handle h)
         h->pool_R = Rp; h->pool_C = Cp; h->pool_mean = h->par0; h->pool_W = (double)c.initcmatn;
         if (c.method == MCMCX_METHOD_DRAM || c.method == MCMCX_METHOD_RAM) {
             if ((rc = dev_alloc(h, &h->d_sharedRT, (size_t)((d + 3) & ~3) * d + PWS, false))) return rc;
-            if ((rc = upload_shared_rt(h))) return rc;
+            if ((rc = h->usesvd ? upload_shared_rf(h) : upload_shared_rt(h))) return rc;
+            if (h->usesvd) E.sharedR = h->d_sharedRT;   // the lane-per-chain kernel reads the full matrix through the scalar cache
         }
     }
     E.hev = E.hx = nullptr;
@@ -1280,7 +1314,7 @@ int mcmcx_get_R(mcmcx_handle h, int32_t chain, double *R)
 {
     int rc = check_chain(h, chain); if (rc) return rc;
     std::vector<double> p;
-    if (h->pooled && h->usesvd) { memcpy(R, h->pool_U.data(), sizeof(double) * h->pool_U.size()); return 0; }
+    if (h->pooled && h->usesvd) { const auto &M = h->cfg.method == MCMCX_METHOD_SCAM ? h->pool_U : h->pool_Rf; memcpy(R, M.data(), sizeof(double) * M.size()); return 0; }
     if (h->pooled) { unpack_upper(h->d, h->pool_R, R, false); return 0; }
     if (h->usesvd) {                                     // full column-major factor
         if ((rc = fetch_chain_vec(h, h->E.Rf, h->d * h->d, chain, p))) return rc;
@@ -1295,7 +1329,7 @@ int mcmcx_get_R(mcmcx_handle h, int32_t chain, double *R)
 int mcmcx_get_qcovstd(mcmcx_handle h, int32_t chain, double *std)
 {
     int rc = check_chain(h, chain); if (rc) return rc;
-    if (h->pooled && h->usesvd) { memcpy(std, h->pool_std.data(), sizeof(double) * h->pool_std.size()); return 0; }
+    if (h->pooled && h->usesvd && h->cfg.method == MCMCX_METHOD_SCAM) { memcpy(std, h->pool_std.data(), sizeof(double) * h->pool_std.size()); return 0; }
     if (!h->E.qstd) return fail(-45, "no SVD state (condmax = 0)");
     std::vector<double> p;
     if ((rc = fetch_chain_vec(h, h->E.qstd, h->d, chain, p))) return rc;
@@ -1456,7 +1490,7 @@ int mcmcx_get_pooled(mcmcx_handle h, double *cmat, double *mean, double *wsum, d
     if (cmat) unpack_upper(h->d, h->pool_C, cmat, true);
     if (mean) memcpy(mean, h->pool_mean.data(), sizeof(double) * (size_t)h->d);
     if (wsum) *wsum = h->pool_W;
-    if (R && h->usesvd) memcpy(R, h->pool_U.data(), sizeof(double) * h->pool_U.size());    // scam: the rotation U, column-major
+    if (R && h->usesvd) { const auto &M = h->cfg.method == MCMCX_METHOD_SCAM ? h->pool_U : h->pool_Rf; memcpy(R, M.data(), sizeof(double) * M.size()); }   // scam: the rotation U; condmax > 0: the full SVD factor; column-major
     else if (R) unpack_upper(h->d, h->pool_R, R, false);
     return 0;
 }

@@ -593,6 +593,27 @@ MCX_DEV void trmv_shared(const double *__restrict__ Rs, const double *z_t, doubl
     }
 }
 
+// matmulx(R, z) with ONE full factor shared by every chain (pooled mode with condmax > 0): M[j*d + i] = R(i,j) (column-major,
+// padded by PWS doubles), y_i an fma chain ascending in j like gemvN_panels; the matrix comes through the scalar cache.
+MCX_DEV void gemvN_shared(const double *__restrict__ M, const double *z_t, double *out_t, const double *theta_t, int lane, int d)
+{
+    for (int I0 = 0; I0 < d; I0 += PW) {
+        const int nr = (d - I0) < PW ? (d - I0) : PW;
+        double y[PW];
+#pragma unroll
+        for (int u = 0; u < PW; ++u) y[u] = 0.0;
+#pragma unroll 2
+        for (int j = 0; j < d; ++j) {
+            const double zj = GV(z_t, j);
+            const double *__restrict__ col = M + (size_t)j * d + I0;
+#pragma unroll
+            for (int u = 0; u < PW; ++u) y[u] = dfma(zj, col[u < nr ? u : nr - 1], y[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < PW; ++u) if (u < nr) GV(out_t, I0 + u) = GV(theta_t, I0 + u) + y[u];
+    }
+}
+
 // ---------------------------------------------------------------- RAM rank-1 adaptation (MCMC_run_ram.F90:104-179)
 // a >= 0: cholupdate = DCHUD (dchud.f:122-139); a < 0: choldowndate = DCHDD (dchdd.f:141-179), restated
 // left-looking by column panels: the PW columns' work values sit in registers, the rotations of the
@@ -1017,7 +1038,7 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
         double *zc_t = zs_t + (size_t)(it & 1) * d * 64;          // z of this iteration
         double *zn_t = zs_t + (size_t)((it + 1) & 1) * d * 64;    // z of the next one
         // ---- newpar = MCMC_propose(oldpar, R)
-        if (POOLED) trmv_shared(g_sharedR, zc_t, cand_t, theta_t, lane, d);
+        if (POOLED) { if (E.usesvd) gemvN_shared(g_sharedR, zc_t, cand_t, theta_t, lane, d); else trmv_shared(g_sharedR, zc_t, cand_t, theta_t, lane, d); }
         else if (E.usesvd) gemvN_panels(E.Rf + (size_t)tile * d * d * 64, zc_t, cand_t, theta_t, lane, d, true);   // matmulx(R,z)
         else if (__any(!have_p)) trmv_panels(Rt, zc_t, cand_t, theta_t, lane, d, !have_p, RAM && pdesc);
         // ---- bounds, prior, ss, alpha, reject
@@ -1568,7 +1589,8 @@ __global__ __launch_bounds__(64) void pooled_mfma_kernel(EngineDev E, int it0, i
         for (int k = d; k < d4; ++k) XL(k) = 0.0;
         for (int ob0 = 0; ob0 < nt; ob0 += 4) {
             const int nb = (nt - ob0) < 4 ? (nt - ob0) : 4;
-            mfma_wave_product<true>(g_RT, X, lane, d, d4, ob0, nb, c);
+            if (E.usesvd) mfma_wave_product<false>(g_RT, X, lane, d, d4, ob0, nb, c);        // the full SVD factor (condmax > 0)
+            else mfma_wave_product<true>(g_RT, X, lane, d, d4, ob0, nb, c);
 #pragma unroll
             for (int b = 0; b < 4; ++b)
                 if (b < nb) {

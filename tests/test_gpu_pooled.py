@@ -507,3 +507,101 @@ def test_pooled_ram_matches_restatement(oracle, d, N, mfma, monkeypatch):
     for ch in chains:
         ch.close()
     e.close()
+
+
+@pytest.mark.parametrize("mfma,condmax,burn", [(1, 1e8, 0), (0, 1e8, 0), (1, 40.0, 0), (0, 40.0, 1)])
+def test_pooled_am_with_svd_factor_matches_restatement(oracle, mfma, condmax, burn, monkeypatch):
+    """pooled = 1 with condmax > 0 (method dram): the shared factor is covtor_svd's full matrix U sqrt(s) 2.4/sqrt(d)
+    (matutils.F90:378-453) of the pooled covariance, proposals are matmulx(R, z); condmax = 40 makes the singular-value
+    floor bite, after which the covariance itself is replaced by R0 R0' (info = -1 branch)."""
+    from mcmcf90_amd import engine_from_problem
+    if not mfma:
+        monkeypatch.setenv("MCMCX_POOLED_SCALAR", "1")
+    d, N, nsimu = 6, 140, 330
+    ckw = dict(nsimu=nsimu, adaptint=100, updatesigma=0, condmax=condmax)
+    if burn:
+        ckw.update(doburnin=1, burnintime=160, badaptint=40, scalelimit=0.3)
+    lam = np.diag(10.0 ** np.linspace(-1.5, 1.5, d))            # posterior variances over three decades
+    pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.1), cmat0=(1e-4 if burn else 0.02) * np.eye(d), mu=np.zeros(d), lam=lam)
+    e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
+    e.init(); e.run()
+    cfg = oracle.make_cfg(**ckw)
+    plain = oracle.make_cfg(**dict(ckw, doadapt=0, doburnin=0))
+    prob = oracle.Problem(**pkw)
+    chains = [oracle.LiveChain(plain, prob, chain_id=c) for c in range(N)]
+    par0, cmat0 = np.asarray(pkw["par0"], float), np.asarray(pkw["cmat0"], float)
+    DP = C.POINTER(C.c_double)
+    floored_ticks = []
+
+    def svd_factor(st, it):
+        G = np.zeros((d, d), order="F")
+        for (i, j), v in st["C"].items():
+            G[i, j] = v; G[j, i] = v
+        V = np.zeros((d, d), order="F"); sv = np.zeros(d)
+        oracle.lib().mcxo_symsvd(d, G.ctypes.data_as(DP), V.ctypes.data_as(DP), sv.ctypes.data_as(DP))
+        if sv[0] == 0.0:
+            return st
+        tol = sv[0] / condmax
+        floored = bool(sv[d - 1] <= tol)
+        if floored:
+            sv = np.where(sv < tol, tol, sv); floored_ticks.append(it)
+        R0 = np.array([[math.sqrt(sv[i]) * V[k, i] for i in range(d)] for k in range(d)])       # R0[k, i] = U(k,i) sqrt(s_i)
+        if floored:
+            newC = {}
+            for j in range(d):
+                for i in range(j + 1):
+                    acc = 0.0
+                    for k in range(d):
+                        acc = _fma(R0[i, k], R0[j, k], acc)
+                    newC[(i, j)] = acc
+            st["C"] = newC
+        sqd = math.sqrt(float(d))
+        st["R"] = np.array([[R0[i, j] * 2.4 / sqd for j in range(d)] for i in range(d)])
+        return st
+
+    st = {"W": 0.0, "C": {(i, j): float(cmat0[i, j]) for j in range(d) for i in range(j + 1)}, "mean": [float(v) for v in par0]}
+    C0 = dict(st["C"])
+    st = svd_factor(st, 0); st["C"] = C0                        # MCMC_init's factor; cmat0 itself stays
+    badapt = cfg.badaptint if cfg.badaptint > 0 else cfg.adaptint
+    for it in range(2, nsimu + 1):
+        m1, m2 = it % cfg.adaptint == 0, it % badapt == 0
+        burn_tick = it < cfg.burnintime and cfg.doburnin != 0 and m2
+        am_tick = (not burn_tick) and (m1 or m2) and it >= cfg.burnintime + cfg.adaptint + cfg.adapthist
+        if not (burn_tick or am_tick):
+            continue
+        for ch in chains:
+            ch.run(it)
+        theta = np.array([ch.theta for ch in chains])
+        cnt, s1, s2 = _pooled_moments(theta, par0, N)
+        if burn_tick:
+            staypc = float(sum(ch.stayed for ch in chains)) / (cnt * float(it))
+            if staypc > 1.0 - cfg.scalelimit:
+                st["R"] = st["R"] / cfg.scalefactor
+            elif staypc < cfg.scalelimit:
+                st["R"] = st["R"] * cfg.scalefactor
+            else:
+                st = svd_factor(st, it)
+        else:
+            if it == cfg.burnintime + cfg.adaptint + cfg.adapthist:
+                st.update(W=float(cfg.initcmatn), C={(i, j): float(cmat0[i, j]) for j in range(d) for i in range(j + 1)}, mean=[float(v) for v in par0])
+            st = _merge(st, cnt, s1, s2, par0, d, False)
+            st = svd_factor(st, it)
+        for ch in chains:
+            ch.set_R(st["R"])
+    for ch in chains:
+        ch.run(nsimu)
+    if condmax < 100:
+        assert floored_ticks, "the floor never bit: the case does not test what it is about"
+    theta = np.array([ch.theta for ch in chains])
+    np.testing.assert_array_equal(_bits(e.theta()), _bits(theta))
+    for c in (0, 63, 64, N - 1):
+        np.testing.assert_array_equal(e.accepted(c), chains[c].accepted)
+    cm, mean, W, R = e.pooled()
+    np.testing.assert_array_equal(_bits(R), _bits(st["R"]))
+    Cst = np.zeros((d, d))
+    for (i, j), v in st["C"].items():
+        Cst[i, j] = v; Cst[j, i] = v
+    np.testing.assert_array_equal(_bits(np.triu(cm)), _bits(np.triu(Cst)))
+    for ch in chains:
+        ch.close()
+    e.close()
