@@ -65,6 +65,7 @@ struct mcmcx_engine {
     EngineDev E{};
     std::vector<void *> allocs;
     double *d_ramscale = nullptr, *d_moments = nullptr;
+    double *d_Gc = nullptr, *d_Vc = nullptr, *d_svc = nullptr; uint8_t *d_need = nullptr; int svd_b = 0;    // blocked SVD of the adaptation (large npar)
     int wcap = 0;
     // timing of the step kernel
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -328,6 +329,22 @@ static void launch_scam(mcmcx_engine *h, int it0, int it1)
     }
     hipLaunchKernelGGL(scam_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
 }
+// LDS of svd_blocked_kernel for block width b: four blocks of b columns (odd stride) + the rotation slots
+static size_t svd_lds(int d, int b) { const int LS = ((d + 1) & ~1) + (((d + 1) & 2) ? 0 : 2); return ((size_t)4 * b * LS + 64) * sizeof(double) + 32 * sizeof(int); }
+// block width of the blocked SVD: two workgroups per CU hide each other's dot-product latency
+static int svd_block_width(int d)
+{
+    if (const char *e = getenv("MCMCX_SVD_BLOCK")) { int b = atoi(e); if (b >= 2 && b <= 32 && svd_lds(d, b) <= 150 * 1024) return b; }
+    int b = 32;
+    while (b > 2 && svd_lds(d, b) > 75 * 1024) --b;
+    return b;
+}
+static bool svd_blocked(const mcmcx_engine *h)
+{
+    if (!h->usesvd || h->pooled || h->cfg.method == MCMCX_METHOD_RAM) return false;
+    if (const char *e = getenv("MCMCX_SVD_LANE")) if (atoi(e)) return false;          // A/B switch for tests: one lane per chain
+    return h->d >= 48;
+}
 static void launch_adapt(mcmcx_engine *h, int it, int mode)
 {
     const size_t lds = std::max(lds_bytes(h) / 2, (size_t)44 * 64 * sizeof(double));    // one d-vector / the Cholesky's diagonal block
@@ -335,7 +352,19 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
     hipLaunchKernelGGL(adapt_pre_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it, mode);
     if (!((mode & AD_AM) && h->cfg.adapthist > 1))                        // the AP window is a batch recompute: no blocked update
         hipLaunchKernelGGL(adapt_cov_kernel, dim3((unsigned)(8 * ((h->ntiles + 7) / 8) * nblk)), dim3(64), 0, h->stream, h->E, it, mode, nblk);
-    hipLaunchKernelGGL(adapt_post_kernel, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode);
+    if (!h->d_Gc) {
+        hipLaunchKernelGGL(adapt_post_kernel, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr);
+        return;
+    }
+    // large npar with an SVD factor: the factorisation runs one workgroup per chain on chain-major copies
+    const size_t DD = (size_t)h->d * h->d;
+    const dim3 tg((unsigned)((DD + 63) / 64), (unsigned)h->ntiles), tg1((unsigned)((h->d + 63) / 64), (unsigned)h->ntiles);
+    hipLaunchKernelGGL(adapt_post_kernel, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 1, h->d_need);
+    hipLaunchKernelGGL(tile2chain_kernel, tg, dim3(256), 0, h->stream, h->E.Gw, h->d_Gc, DD, DD, h->d_need);
+    hipLaunchKernelGGL(svd_blocked_kernel, dim3(h->nlanes), dim3(256), svd_lds(h->d, h->svd_b), h->stream, h->d_Gc, h->d_Vc, h->d_svc, h->d_need, h->nlanes, h->d, h->svd_b);
+    hipLaunchKernelGGL(chain2tile_kernel, tg, dim3(256), 0, h->stream, h->d_Gc, h->E.Vw, DD, DD, h->d_need);
+    hipLaunchKernelGGL(chain2tile_kernel, tg1, dim3(256), 0, h->stream, h->d_svc, h->E.cs, (size_t)h->d, (size_t)2 * h->d, h->d_need);
+    hipLaunchKernelGGL(adapt_post_kernel, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 2, h->d_need);
 }
 
 // Which branch of MCMC_adapt fires at iteration `it` (0 = none).  MCMC_adapt.F90:42-46, 60-61, 105.
@@ -1019,6 +1048,13 @@ int mcmcx_init(mcmcx_handle h)
         if (c.method != MCMCX_METHOD_RAM) {                 // work space of the adaptation's SVD; RAM never refactors
             if ((rc = dev_alloc(h, &E.Gw, L * DD))) return rc;
             if ((rc = dev_alloc(h, &E.Vw, L * DD))) return rc;
+            if (svd_blocked(h) && (c.doadapt != 0 || c.doburnin != 0)) {      // chain-major copies for svd_blocked_kernel
+                h->svd_b = svd_block_width(d);
+                if ((rc = dev_alloc(h, &h->d_Gc, L * DD, false))) return rc;
+                if ((rc = dev_alloc(h, &h->d_Vc, L * DD, false))) return rc;
+                if ((rc = dev_alloc(h, &h->d_svc, L * d, false))) return rc;
+                if ((rc = dev_alloc(h, &h->d_need, L))) return rc;
+            }
         }
         if ((rc = dev_alloc(h, &E.qstd, L * d))) return rc;
         if (h->dodr && (rc = dev_alloc(h, &E.R2f, L * DD, false))) return rc;

@@ -1289,6 +1289,7 @@ __global__ __launch_bounds__(64, 2) void scam_kernel(EngineDev E, int it0, int i
 // flag of each chain to the others through LDS.  Arithmetic per chain is operation for operation that of scam_kernel.
 constexpr int PWS = 16;
 typedef double mcx_d4 __attribute__((ext_vector_type(4)));
+typedef double mcx_d2 __attribute__((ext_vector_type(2)));
 
 template <bool BW, int NS>   // BW: block wave (blk0 = its block, slot = chain group); else group wave (slot s = block blk0+s, s < NS)
 MCX_DEV void mfma_slots(const double *__restrict__ M, const double *X, int lane, int d, int d4, int blk0, int grp, mcx_d4 (&c)[4])
@@ -2493,7 +2494,10 @@ __global__ __launch_bounds__(64, 2) void adapt_cov_kernel(EngineDev E, int it, i
     if (a0 == 0 && b0 == 0 && steady) TIDX(E.scal, tile, NSCAL, S_WNEW, lane) = Wend;
 }
 
-__global__ __launch_bounds__(64) void adapt_post_kernel(EngineDev E, int it, int mode)
+// phase 0: the whole tick.  With the blocked SVD (large npar, below) the tick is cut around the factorisation:
+// phase 1 = everything up to and including the symmetric matrix in Gw (and the per-chain `need` flags),
+// phase 2 = everything after the SVD (which has left the singular vectors in Vw and the singular values in cs).
+__global__ __launch_bounds__(64) void adapt_post_kernel(EngineDev E, int it, int mode, int phase, uint8_t *need)
 {
     extern __shared__ double X[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d, P = E.P;
@@ -2512,7 +2516,8 @@ __global__ __launch_bounds__(64) void adapt_post_kernel(EngineDev E, int it, int
     const uint32_t flags = TIDX(E.ictr, tile, NICTR, I_ADFLAGS, lane);
     const int nr = (int)TIDX(E.ictr, tile, NICTR, I_NR, lane);
     const bool docalc = (flags & ADF_DOCALC) != 0, steady = (flags & ADF_STEADY) != 0, greedy_lane = (flags & ADF_GREEDY) != 0;
-    double wsum = TIDX(E.scal, tile, NSCAL, steady ? S_WNEW : S_WSUM, lane);
+    double wsum = TIDX(E.scal, tile, NSCAL, (steady && phase != 2) ? S_WNEW : S_WSUM, lane);
+    if (phase != 2) {
     if (steady) for (int k = 0; k < d; ++k) GV(mean_t, k) = GV(m2_t, k);
 
     if (mode & AD_BURN) {
@@ -2537,15 +2542,22 @@ __global__ __launch_bounds__(64) void adapt_post_kernel(EngineDev E, int it, int
         }
     }
 
+    TIDX(E.ictr, tile, NICTR, I_LASTFREQ, lane) = lastfreq;
+    TIDX(E.ictr, tile, NICTR, I_BASECNT, lane) = basecnt;
+    TIDX(E.ictr, tile, NICTR, I_WINSTART, lane) = winstart;
+    TIDX(E.scal, tile, NSCAL, S_WSUM, lane) = wsum;
+    }
     if (E.usesvd) {
         // MCMC_calculate_R, SVD branches (MCMC_adapt.F90:189-209): covtor_svd / scam_svd (matutils.F90:378-453, 583-653)
         double *Gt = E.Gw + (size_t)tile * d * d * 64, *Vt = E.Vw + (size_t)tile * d * d * 64;
         double *Rft = E.Rf + (size_t)tile * d * d * 64;
         double *sv_t = E.cs + (size_t)tile * 2 * d * 64;
+        if (phase == 1) need[tile * 64 + lane] = docalc ? 1 : 0;
         if (__any(docalc)) {
-            if (docalc) for (int j = 0; j < d; ++j) for (int i = 0; i < d; ++i)
+            if (phase != 2 && docalc) for (int j = 0; j < d; ++j) for (int i = 0; i < d; ++i)
                 GV(Gt, (size_t)j * d + i) = (i <= j) ? GV(Ct, pidx(i, j, d)) : GV(Ct, pidx(j, i, d));
-            symsvd_dev(Gt, Vt, sv_t, lane, d, docalc);
+            if (phase == 1) return;
+            if (phase == 0) symsvd_dev(Gt, Vt, sv_t, lane, d, docalc);
             if (docalc) {
                 int info = 0;
                 const double s0 = GV(sv_t, 0);
@@ -2603,10 +2615,189 @@ __global__ __launch_bounds__(64) void adapt_post_kernel(EngineDev E, int it, int
             if (ok) for (int e = 0; e < P; ++e) GV(R2t, e) = GV(Rt, e) / E.drscale;
         }
     }
-    TIDX(E.ictr, tile, NICTR, I_LASTFREQ, lane) = lastfreq;
-    TIDX(E.ictr, tile, NICTR, I_BASECNT, lane) = basecnt;
-    TIDX(E.ictr, tile, NICTR, I_WINSTART, lane) = winstart;
-    TIDX(E.scal, tile, NSCAL, S_WSUM, lane) = wsum;
+}
+
+// ---------------------------------------------------------------- blocked one-sided Jacobi SVD, one workgroup per chain
+// The pinned routine (oracle/mcx_svd.h; symsvd_dev above runs it one lane per chain) streams four columns per pair from
+// HBM: 640 kB of G and V per chain at npar = 200, ~26 sweeps x 19900 pairs.  A pair (p,q) only touches columns p and q,
+// so any order of the pairs that keeps "(p,q) after (p,q-1) and after (p-1,q)" (and (p,p+1) after (p-1,p)) produces the
+// same bits.  This kernel uses that freedom: column blocks of b, block pairs (I,J) in row-major order, the 2b columns
+// of G and of V of a block pair in LDS, and inside a block pair the pairs on one anti-diagonal p + q = const at a
+// time -- they are independent.  A step: (A) up to b threads each run one pair's three dot products (sequential fma
+// chains over the rows, exactly the routine's) and derive its rotation; (B) all 256 threads apply the step's
+// rotations to the rows of G and V.  The rows cannot be spread over lanes in (A) -- that would change the summation
+// order -- which is why (A) dominates.  Storage is chain-major here (a chain's column = 8 d contiguous bytes);
+// tile2chain_kernel / chain2tile_kernel convert from and to the engine's tile-interleaved layout through LDS.
+__global__ __launch_bounds__(256) void svd_blocked_kernel(double *Gc, double *Vc, double *svc, const uint8_t *need, int nlanes, int d, int b)
+{
+    extern __shared__ double S[];
+    __shared__ int s_rot, s_perm[256];
+    __shared__ double s_sv[256];
+    const int chain = blockIdx.x, tid = threadIdx.x;
+    if (chain >= nlanes || !need[chain]) return;
+    double *G = Gc + (size_t)chain * d * d, *V = Vc + (size_t)chain * d * d;
+    const int LS = ((d + 1) & ~1) + (((d + 1) & 2) ? 0 : 2);   // column stride: even (16-byte vector accesses) and = 2 mod 4 (16 lanes on 16 columns: 64 banks)
+    double *GI = S, *GJ = GI + (size_t)b * LS, *VI = GJ + (size_t)b * LS, *VJ = VI + (size_t)b * LS;
+    double *slot_c = VJ + (size_t)b * LS, *slot_s = slot_c + 32;
+    int *slot_m = (int *)(slot_s + 32);                        // partner column of pair-lane l in this step, or -1
+    for (int e = tid; e < d * d; e += 256) V[e] = (e % (d + 1) == 0) ? 1.0 : 0.0;
+    const int nb = (d + b - 1) / b;
+    // phase A: four lanes per pair (b <= 32 pairs: waves 0 and 1), lane r of a quad runs ONE of the three chains --
+    // r = 0: alpha = sum g_p g_p, 1: beta = sum g_q g_q, 2: gamma = sum g_p g_q -- so a step's dot products cost one fma per
+    // row instead of three; the quad's lane 0 collects them by shuffles and derives the rotation.
+    const int ql = tid >> 2, qr = tid & 3;                     // pair-lane of this thread's quad, chain index
+    const int rl = tid & 31, rk0 = tid >> 5;                   // phase B: pair-lane rl, row pairs 2 rk0, 2 rk0 + 16, ...
+    __syncthreads();
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        if (tid == 0) s_rot = 0;
+        __syncthreads();
+        for (int I = 0; I < nb; ++I) {
+            const int I0 = I * b, wI = (d - I0) < b ? (d - I0) : b;
+            for (int e = tid; e < wI * d; e += 256) { const int c = e / d, k = e - c * d; GI[c * LS + k] = G[(size_t)(I0 + c) * d + k]; VI[c * LS + k] = V[(size_t)(I0 + c) * d + k]; }
+            for (int J = I; J < nb; ++J) {
+                const int J0 = J * b, wJ = (d - J0) < b ? (d - J0) : b;
+                const bool diag = (J == I);
+                if (!diag)
+                    for (int e = tid; e < wJ * d; e += 256) { const int c = e / d, k = e - c * d; GJ[c * LS + k] = G[(size_t)(J0 + c) * d + k]; VJ[c * LS + k] = V[(size_t)(J0 + c) * d + k]; }
+                __syncthreads();
+                double *Gq = diag ? GI : GJ, *Vq = diag ? VI : VJ;
+                const int nsteps = diag ? (2 * wI - 3) : (wI + wJ - 1);        // diag: pairs l < m at step l + m - 1
+                for (int t = 0; t < nsteps; ++t) {
+                    // ---- (A) one pair per quad: alpha, beta, gamma and the rotation
+                    if (tid < 128) {                           // waves 0 and 1 (whole waves: the shuffles below need their quads)
+                        const int l = ql, m = diag ? (t + 1 - l) : (t - l);
+                        const bool valid = (l < wI) && (diag ? (m > l && m < wI) : (m >= 0 && m < wJ));
+                        double acc = 0.0;
+                        if (valid && qr < 3) {
+                            const double *x = (qr == 1) ? Gq + (size_t)m * LS : GI + (size_t)l * LS;
+                            const double *y = (qr == 0) ? GI + (size_t)l * LS : Gq + (size_t)m * LS;
+                            // 16-byte LDS reads in groups of eight rows, the next group in flight while the chain works through
+                            // this one; the loop control is scalar (no per-element predicates in the chain's way)
+                            const mcx_d2 *X2 = (const mcx_d2 *)x, *Y2 = (const mcx_d2 *)y;
+                            const int ng = d >> 3;
+                            mcx_d2 xa[4], ya[4], xb[4], yb[4];
+#define MCX_SVD_LD(xv, yv, g) { _Pragma("unroll") for (int u = 0; u < 4; ++u) { xv[u] = X2[4 * (g) + u]; yv[u] = Y2[4 * (g) + u]; } }
+#define MCX_SVD_FM(xv, yv) { _Pragma("unroll") for (int u = 0; u < 4; ++u) { acc = dfma(xv[u].x, yv[u].x, acc); acc = dfma(xv[u].y, yv[u].y, acc); } }
+                            int g = 0;
+                            if (ng > 0) MCX_SVD_LD(xa, ya, 0)
+                            while (g < ng) {
+                                if (g + 1 < ng) MCX_SVD_LD(xb, yb, g + 1)
+                                MCX_SVD_FM(xa, ya)
+                                ++g;
+                                if (g < ng) {
+                                    if (g + 1 < ng) MCX_SVD_LD(xa, ya, g + 1)
+                                    MCX_SVD_FM(xb, yb)
+                                    ++g;
+                                }
+                            }
+#undef MCX_SVD_LD
+#undef MCX_SVD_FM
+                            for (int k = 8 * ng; k < d; ++k) acc = dfma(x[k], y[k], acc);
+                        }
+                        const int q0 = tid & 60 & 63;
+                        const double alpha = __shfl(acc, q0, 64), beta = __shfl(acc, q0 | 1, 64), gamma = __shfl(acc, q0 | 2, 64);
+                        if (qr == 0 && l < b) {
+                            int mm = -1;
+                            if (valid && (gamma != 0.0) && !(fabs(gamma) <= 1e-15 * sqrt(alpha * beta))) {
+                                const double zeta = (beta - alpha) / (2.0 * gamma);
+                                const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                                const double c = 1.0 / sqrt(1.0 + tt * tt);
+                                slot_c[l] = c; slot_s[l] = c * tt;
+                                mm = m;
+                                s_rot = 1;
+                            }
+                            slot_m[l] = mm;
+                        }
+                    }
+                    __syncthreads();
+                    // ---- (B) the step's rotations, rows spread over the threads (two adjacent rows per trip)
+                    if (rl < wI) {
+                        const int m = slot_m[rl];
+                        if (m >= 0) {
+                            const double c = slot_c[rl], sn = slot_s[rl];
+                            double *gp = GI + (size_t)rl * LS, *gq = Gq + (size_t)m * LS, *vp = VI + (size_t)rl * LS, *vq = Vq + (size_t)m * LS;
+                            // 16-byte accesses (rows k, k + 1), four trips' loads in flight before the first result is needed
+                            for (int k0 = 2 * rk0; k0 + 1 < d; k0 += 64) {
+                                mcx_d2 a[4], bq[4], va[4], vb[4];
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const int k = k0 + 16 * u;
+                                    if (k + 1 < d) { a[u] = *(mcx_d2 *)(gp + k); bq[u] = *(mcx_d2 *)(gq + k); va[u] = *(mcx_d2 *)(vp + k); vb[u] = *(mcx_d2 *)(vq + k); }
+                                }
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const int k = k0 + 16 * u;
+                                    if (k + 1 < d) {
+                                        mcx_d2 na, nb2, nva, nvb;
+                                        na.x = c * a[u].x - sn * bq[u].x; na.y = c * a[u].y - sn * bq[u].y; nb2.x = sn * a[u].x + c * bq[u].x; nb2.y = sn * a[u].y + c * bq[u].y;
+                                        nva.x = c * va[u].x - sn * vb[u].x; nva.y = c * va[u].y - sn * vb[u].y; nvb.x = sn * va[u].x + c * vb[u].x; nvb.y = sn * va[u].y + c * vb[u].y;
+                                        *(mcx_d2 *)(gp + k) = na; *(mcx_d2 *)(gq + k) = nb2; *(mcx_d2 *)(vp + k) = nva; *(mcx_d2 *)(vq + k) = nvb;
+                                    }
+                                }
+                            }
+                            if ((d & 1) && rk0 == 0) {                            // the odd last row
+                                const int k = d - 1;
+                                const double a0 = gp[k], b0 = gq[k], va0 = vp[k], vb0 = vq[k];
+                                gp[k] = c * a0 - sn * b0; gq[k] = sn * a0 + c * b0;
+                                vp[k] = c * va0 - sn * vb0; vq[k] = sn * va0 + c * vb0;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+                if (!diag)
+                    for (int e = tid; e < wJ * d; e += 256) { const int c = e / d, k = e - c * d; G[(size_t)(J0 + c) * d + k] = GJ[c * LS + k]; V[(size_t)(J0 + c) * d + k] = VJ[c * LS + k]; }
+                __syncthreads();
+            }
+            for (int e = tid; e < wI * d; e += 256) { const int c = e / d, k = e - c * d; G[(size_t)(I0 + c) * d + k] = GI[c * LS + k]; V[(size_t)(I0 + c) * d + k] = VI[c * LS + k]; }
+            __syncthreads();
+        }
+        if (!s_rot) break;
+        __syncthreads();
+    }
+    // ---- singular values = column norms (fma chain over the rows), sorted descending (first maximum wins), V's columns with them
+    if (tid < d) {
+        const double *gj = G + (size_t)tid * d;
+        double a = 0.0;
+        for (int k = 0; k < d; ++k) a = dfma(gj[k], gj[k], a);
+        s_sv[tid] = sqrt(a); s_perm[tid] = tid;
+    }
+    __syncthreads();
+    if (tid == 0)
+        for (int i = 0; i < d - 1; ++i) {
+            int m = i; double sm = s_sv[i];
+            for (int j = i + 1; j < d; ++j) if (s_sv[j] > sm) { m = j; sm = s_sv[j]; }
+            if (m != i) { double ts = s_sv[i]; s_sv[i] = s_sv[m]; s_sv[m] = ts; int tp = s_perm[i]; s_perm[i] = s_perm[m]; s_perm[m] = tp; }
+        }
+    __syncthreads();
+    if (tid < d) svc[(size_t)chain * d + tid] = s_sv[tid];
+    for (int e = tid; e < d * d; e += 256) { const int j = e / d, k = e - j * d; G[e] = V[(size_t)s_perm[j] * d + k]; }     // sorted vectors over G
+}
+
+// tile-interleaved [tile][K][64 lanes]  <->  chain-major [chain][K], 64 x 64 blocks through LDS (both sides coalesced)
+__global__ __launch_bounds__(256) void tile2chain_kernel(const double *__restrict__ src, double *__restrict__ dst, size_t K, size_t Kt, const uint8_t *need)
+{
+    __shared__ double T[64][65];
+    const int tile = blockIdx.y, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const size_t k0 = (size_t)blockIdx.x * 64;
+    bool any = false;
+    for (int l = 0; l < 64; ++l) any = any || need[tile * 64 + l];
+    if (!any) return;
+    for (int r = ty; r < 64; r += 4) if (k0 + r < K) T[r][tx] = src[((size_t)tile * Kt + k0 + r) * 64 + tx];          // element k0+r, lane tx (Kt: elements per tile on the interleaved side)
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4) if (k0 + tx < K && need[tile * 64 + c]) dst[((size_t)tile * 64 + c) * K + k0 + tx] = T[tx][c];
+}
+__global__ __launch_bounds__(256) void chain2tile_kernel(const double *__restrict__ src, double *__restrict__ dst, size_t K, size_t Kt, const uint8_t *need)
+{
+    __shared__ double T[64][65];
+    const int tile = blockIdx.y, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const size_t k0 = (size_t)blockIdx.x * 64;
+    bool any = false;
+    for (int l = 0; l < 64; ++l) any = any || need[tile * 64 + l];
+    if (!any) return;
+    for (int c = ty; c < 64; c += 4) if (k0 + tx < K && need[tile * 64 + c]) T[tx][c] = src[((size_t)tile * 64 + c) * K + k0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) if (k0 + r < K && need[tile * 64 + tx]) dst[((size_t)tile * Kt + k0 + r) * 64 + tx] = T[r][tx];
 }
 
 // one chain's lane of a tile-interleaved array: out[e] = src[e*64 + lane], e < n (mcmcx_get_chain copies a single

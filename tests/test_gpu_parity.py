@@ -282,3 +282,38 @@ def test_history_ring_without_record_chain(oracle, kw, dr):
         np.testing.assert_array_equal(_bits(mean), _bits(o.chainmean))
         assert wsum == o.chainwsum
     e.close()
+
+
+@pytest.mark.parametrize("d,method,extra", [(48, "scam", {}), (70, "scam", {}), (64, "dram", dict(condmax=1e6)), (100, "dram", dict(condmax=50.0, drscale=2.0))])
+def test_blocked_svd_equals_lane_svd_and_oracle(oracle, d, method, extra, monkeypatch):
+    """npar >= 48 with an SVD factor: MCMC_adapt's factorisation runs svd_blocked_kernel (a workgroup per chain, block
+    pairs of columns in LDS, the pinned routine's pairs in a reordered but equivalent sequence).  Bit for bit the
+    one-lane-per-chain routine (MCMCX_SVD_LANE=1) -- factor, singular values, states after several adaptations, a ragged
+    tile, lanes that skip a tick (adaptend) -- and the oracle on two chains."""
+    from mcmcf90_amd import engine_from_problem
+    rng = np.random.default_rng(d)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    lam = A @ A.T + np.diag(10.0 ** np.linspace(-1, 2, d))
+    nsimu = 45 if method == "scam" else 160
+    ckw = dict(nsimu=nsimu, method=method, adaptint=14 if method == "scam" else 50, updatesigma=0, **extra)
+    pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.05), cmat0=(0.3 / d) * np.eye(d), mu=np.zeros(d), lam=lam)
+    res = []
+    for lane_path in (0, 1):
+        if lane_path:
+            monkeypatch.setenv("MCMCX_SVD_LANE", "1")
+        e = engine_from_problem(ckw, pkw, nchains=70, chain_id0=5, record_accept=1)
+        e.init(); e.run()
+        res.append((e.theta(), e.accept_masks(), [e.R(c) for c in (0, 63, 64, 69)],
+                    [e.qcovstd(c) for c in (0, 69)], [e.chaincov(c)[0] for c in (0, 69)], [e.rng(c)[0] for c in (0, 69)]))
+        e.close()
+    a, b = res
+    assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1])
+    for x, y in zip(a[2] + a[3] + a[4], b[2] + b[3] + b[4]):
+        np.testing.assert_array_equal(_bits(x), _bits(y))
+    assert a[5] == b[5]
+    cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
+    for i, c in enumerate((0, 69)):
+        o = oracle.run_chain(cfg, prob, chain_id=5 + c)
+        np.testing.assert_array_equal(_bits(a[0][c]), _bits(o.theta))
+        np.testing.assert_array_equal(_bits(a[2][0 if c == 0 else 3]), _bits(o.R))
+        assert a[5][i] == o.rng_n
