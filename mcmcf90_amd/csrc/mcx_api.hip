@@ -65,7 +65,7 @@ struct mcmcx_engine {
     EngineDev E{};
     std::vector<void *> allocs;
     double *d_ramscale = nullptr, *d_moments = nullptr;
-    double *d_Gc = nullptr, *d_Vc = nullptr, *d_svc = nullptr; uint8_t *d_need = nullptr; int svd_b = 0;    // blocked SVD of the adaptation (large npar)
+    double *d_Gc = nullptr, *d_Vc = nullptr, *d_svc = nullptr; uint8_t *d_need = nullptr, *d_state = nullptr; int *d_anyrot = nullptr; int svd_b = 0;    // blocked SVD of the adaptation (large npar)
     int wcap = 0;
     // timing of the step kernel
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -330,13 +330,13 @@ static void launch_scam(mcmcx_engine *h, int it0, int it1)
     hipLaunchKernelGGL(scam_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
 }
 // LDS of svd_blocked_kernel for block width b: four blocks of b columns (odd stride) + the rotation slots
-static size_t svd_lds(int d, int b) { const int LS = ((d + 1) & ~1) + (((d + 1) & 2) ? 0 : 2); return ((size_t)4 * b * LS + 64) * sizeof(double) + 32 * sizeof(int); }
+static size_t svd_lds(int d, int b) { const int LS = ((d + 1) & ~1) + (((d + 1) & 2) ? 0 : 2); return ((size_t)2 * b * LS + 64) * sizeof(double) + 32 * sizeof(int); }   // two blocks of b columns + the rotation slots
 // block width of the blocked SVD: two workgroups per CU hide each other's dot-product latency
 static int svd_block_width(int d)
 {
     if (const char *e = getenv("MCMCX_SVD_BLOCK")) { int b = atoi(e); if (b >= 2 && b <= 32 && svd_lds(d, b) <= 150 * 1024) return b; }
     int b = 32;
-    while (b > 2 && svd_lds(d, b) > 75 * 1024) --b;
+    while (b > 2 && svd_lds(d, b) > 78 * 1024) --b;
     return b;
 }
 static bool svd_blocked(const mcmcx_engine *h)
@@ -356,12 +356,23 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
         hipLaunchKernelGGL(adapt_post_kernel, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr);
         return;
     }
-    // large npar with an SVD factor: the factorisation runs one workgroup per chain on chain-major copies
+    // large npar with an SVD factor: the factorisation runs one workgroup per chain on chain-major copies, one launch
+    // pair per Jacobi sweep (the rotation log lives in Gw, which is free between tile2chain and the next tick)
     const size_t DD = (size_t)h->d * h->d;
     const dim3 tg((unsigned)((DD + 63) / 64), (unsigned)h->ntiles), tg1((unsigned)((h->d + 63) / 64), (unsigned)h->ntiles);
+    const size_t lsv = svd_lds(h->d, h->svd_b);
     hipLaunchKernelGGL(adapt_post_kernel, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 1, h->d_need);
     hipLaunchKernelGGL(tile2chain_kernel, tg, dim3(256), 0, h->stream, h->E.Gw, h->d_Gc, DD, DD, h->d_need);
-    hipLaunchKernelGGL(svd_blocked_kernel, dim3(h->nlanes), dim3(256), svd_lds(h->d, h->svd_b), h->stream, h->d_Gc, h->d_Vc, h->d_svc, h->d_need, h->nlanes, h->d, h->svd_b);
+    hipLaunchKernelGGL(svd_init_kernel, dim3(h->nlanes), dim3(256), 0, h->stream, h->d_Vc, h->d_state, h->d_need, h->nlanes, h->d);
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        (void)hipMemsetAsync(h->d_anyrot, 0, sizeof(int), h->stream);
+        hipLaunchKernelGGL(svd_sweep_kernel, dim3(h->nlanes), dim3(256), lsv, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d, h->svd_b);
+        hipLaunchKernelGGL(svd_applyv_kernel, dim3(h->nlanes), dim3(256), lsv, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d, h->svd_b);
+        int any = 0;
+        if (hipMemcpyAsync(&any, h->d_anyrot, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) break;   // (reported by the caller's hipGetLastError)
+        if (!any) break;
+    }
+    hipLaunchKernelGGL(svd_finish_kernel, dim3(h->nlanes), dim3(256), 0, h->stream, h->d_Gc, h->d_Vc, h->d_svc, h->d_state, h->nlanes, h->d);
     hipLaunchKernelGGL(chain2tile_kernel, tg, dim3(256), 0, h->stream, h->d_Gc, h->E.Vw, DD, DD, h->d_need);
     hipLaunchKernelGGL(chain2tile_kernel, tg1, dim3(256), 0, h->stream, h->d_svc, h->E.cs, (size_t)h->d, (size_t)2 * h->d, h->d_need);
     hipLaunchKernelGGL(adapt_post_kernel, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 2, h->d_need);
@@ -1054,6 +1065,8 @@ int mcmcx_init(mcmcx_handle h)
                 if ((rc = dev_alloc(h, &h->d_Vc, L * DD, false))) return rc;
                 if ((rc = dev_alloc(h, &h->d_svc, L * d, false))) return rc;
                 if ((rc = dev_alloc(h, &h->d_need, L))) return rc;
+                if ((rc = dev_alloc(h, &h->d_state, L))) return rc;
+                if ((rc = dev_alloc(h, &h->d_anyrot, 1))) return rc;
             }
         }
         if ((rc = dev_alloc(h, &E.qstd, L * d))) return rc;

@@ -2619,143 +2619,234 @@ __global__ __launch_bounds__(64) void adapt_post_kernel(EngineDev E, int it, int
 
 // ---------------------------------------------------------------- blocked one-sided Jacobi SVD, one workgroup per chain
 // The pinned routine (oracle/mcx_svd.h; symsvd_dev above runs it one lane per chain) streams four columns per pair from
-// HBM: 640 kB of G and V per chain at npar = 200, ~26 sweeps x 19900 pairs.  A pair (p,q) only touches columns p and q,
-// so any order of the pairs that keeps "(p,q) after (p,q-1) and after (p-1,q)" (and (p,p+1) after (p-1,p)) produces the
-// same bits.  This kernel uses that freedom: column blocks of b, block pairs (I,J) in row-major order, the 2b columns
-// of G and of V of a block pair in LDS, and inside a block pair the pairs on one anti-diagonal p + q = const at a
-// time -- they are independent.  A step: (A) up to b threads each run one pair's three dot products (sequential fma
-// chains over the rows, exactly the routine's) and derive its rotation; (B) all 256 threads apply the step's
-// rotations to the rows of G and V.  The rows cannot be spread over lanes in (A) -- that would change the summation
-// order -- which is why (A) dominates.  Storage is chain-major here (a chain's column = 8 d contiguous bytes);
-// tile2chain_kernel / chain2tile_kernel convert from and to the engine's tile-interleaved layout through LDS.
-__global__ __launch_bounds__(256) void svd_blocked_kernel(double *Gc, double *Vc, double *svc, const uint8_t *need, int nlanes, int d, int b)
+// HBM: 640 kB of G and V per chain at npar = 200, ~10-26 sweeps x 19900 pairs.  A pair (p,q) only touches columns p
+// and q, so any order of the pairs that keeps "(p,q) after (p,q-1) and after (p-1,q)" (and (p,p+1) after (p-1,p))
+// produces the same bits.  The kernels below use that freedom: column blocks of b, block pairs (I,J) in row-major
+// order with their 2b columns of G in LDS, and inside a block pair the pairs on one anti-diagonal p + q = const at a
+// time -- they are independent.  A step of svd_sweep_kernel: (A) the three dot products of each of the step's pairs
+// (sequential fma chains over the rows, exactly the routine's; one lane per chain, so a quad per pair) and its
+// rotation; (B) all 256 threads apply the step's rotations to the rows of G.  The rows cannot be spread over lanes in
+// (A) -- that would change the summation order -- which is why (A) dominates and why V is kept OUT of the sweep: V
+// never feeds back into the rotations, so the sweep only logs (c, s) per pair and svd_applyv_kernel replays the log
+// on V afterwards, row-parallel and barrier-free (a wave owns its rows).  Half the LDS per block = twice the pairs per
+// step.  One launch of each per sweep; the host stops when no chain rotated (mcx_api.hip: launch_adapt).
+// Storage is chain-major here (a chain's column = 8 d contiguous bytes); tile2chain_kernel / chain2tile_kernel
+// convert from and to the engine's tile-interleaved layout through LDS.
+MCX_DEV int svd_ls(int d) { return ((d + 1) & ~1) + (((d + 1) & 2) ? 0 : 2); }   // LDS column stride: even (16-byte accesses), = 2 mod 4 (16 lanes on 16 columns: 64 banks)
+MCX_DEV size_t svd_pair_index(int p, int q, int d) { return (size_t)p * d - (size_t)p * (p + 1) / 2 + (size_t)(q - p - 1); }
+
+// state[chain]: 0 = not part of this factorisation, 1 = sweeping, 2 = converged (its last sweep rotated nothing)
+__global__ __launch_bounds__(256) void svd_init_kernel(double *Vc, uint8_t *state, const uint8_t *need, int nlanes, int d)
+{
+    const int chain = blockIdx.x, tid = threadIdx.x;
+    if (chain >= nlanes) return;
+    if (tid == 0) state[chain] = need[chain] ? 1 : 0;
+    if (!need[chain]) return;
+    double *V = Vc + (size_t)chain * d * d;
+    for (int e = tid; e < d * d; e += 256) V[e] = (e % (d + 1) == 0) ? 1.0 : 0.0;
+}
+
+__global__ __launch_bounds__(256) void svd_sweep_kernel(double *Gc, mcx_d2 *rot, uint8_t *state, int *any_rotated, int nlanes, int d, int b)
 {
     extern __shared__ double S[];
-    __shared__ int s_rot, s_perm[256];
-    __shared__ double s_sv[256];
+    __shared__ int s_rot;
     const int chain = blockIdx.x, tid = threadIdx.x;
-    if (chain >= nlanes || !need[chain]) return;
-    double *G = Gc + (size_t)chain * d * d, *V = Vc + (size_t)chain * d * d;
-    const int LS = ((d + 1) & ~1) + (((d + 1) & 2) ? 0 : 2);   // column stride: even (16-byte vector accesses) and = 2 mod 4 (16 lanes on 16 columns: 64 banks)
-    double *GI = S, *GJ = GI + (size_t)b * LS, *VI = GJ + (size_t)b * LS, *VJ = VI + (size_t)b * LS;
-    double *slot_c = VJ + (size_t)b * LS, *slot_s = slot_c + 32;
+    if (chain >= nlanes || state[chain] != 1) return;
+    double *G = Gc + (size_t)chain * d * d;
+    mcx_d2 *log = rot + (size_t)chain * ((size_t)d * (d - 1) / 2);
+    const int LS = svd_ls(d);
+    double *GI = S, *GJ = GI + (size_t)b * LS;
+    double *slot_c = GJ + (size_t)b * LS, *slot_s = slot_c + 32;
     int *slot_m = (int *)(slot_s + 32);                        // partner column of pair-lane l in this step, or -1
-    for (int e = tid; e < d * d; e += 256) V[e] = (e % (d + 1) == 0) ? 1.0 : 0.0;
     const int nb = (d + b - 1) / b;
     // phase A: four lanes per pair (b <= 32 pairs: waves 0 and 1), lane r of a quad runs ONE of the three chains --
     // r = 0: alpha = sum g_p g_p, 1: beta = sum g_q g_q, 2: gamma = sum g_p g_q -- so a step's dot products cost one fma per
     // row instead of three; the quad's lane 0 collects them by shuffles and derives the rotation.
     const int ql = tid >> 2, qr = tid & 3;                     // pair-lane of this thread's quad, chain index
     const int rl = tid & 31, rk0 = tid >> 5;                   // phase B: pair-lane rl, row pairs 2 rk0, 2 rk0 + 16, ...
+    if (tid == 0) s_rot = 0;
     __syncthreads();
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        if (tid == 0) s_rot = 0;
-        __syncthreads();
-        for (int I = 0; I < nb; ++I) {
-            const int I0 = I * b, wI = (d - I0) < b ? (d - I0) : b;
-            for (int e = tid; e < wI * d; e += 256) { const int c = e / d, k = e - c * d; GI[c * LS + k] = G[(size_t)(I0 + c) * d + k]; VI[c * LS + k] = V[(size_t)(I0 + c) * d + k]; }
-            for (int J = I; J < nb; ++J) {
-                const int J0 = J * b, wJ = (d - J0) < b ? (d - J0) : b;
-                const bool diag = (J == I);
-                if (!diag)
-                    for (int e = tid; e < wJ * d; e += 256) { const int c = e / d, k = e - c * d; GJ[c * LS + k] = G[(size_t)(J0 + c) * d + k]; VJ[c * LS + k] = V[(size_t)(J0 + c) * d + k]; }
-                __syncthreads();
-                double *Gq = diag ? GI : GJ, *Vq = diag ? VI : VJ;
-                const int nsteps = diag ? (2 * wI - 3) : (wI + wJ - 1);        // diag: pairs l < m at step l + m - 1
-                for (int t = 0; t < nsteps; ++t) {
-                    // ---- (A) one pair per quad: alpha, beta, gamma and the rotation
-                    if (tid < 128) {                           // waves 0 and 1 (whole waves: the shuffles below need their quads)
-                        const int l = ql, m = diag ? (t + 1 - l) : (t - l);
-                        const bool valid = (l < wI) && (diag ? (m > l && m < wI) : (m >= 0 && m < wJ));
-                        double acc = 0.0;
-                        if (valid && qr < 3) {
-                            const double *x = (qr == 1) ? Gq + (size_t)m * LS : GI + (size_t)l * LS;
-                            const double *y = (qr == 0) ? GI + (size_t)l * LS : Gq + (size_t)m * LS;
-                            // 16-byte LDS reads in groups of eight rows, the next group in flight while the chain works through
-                            // this one; the loop control is scalar (no per-element predicates in the chain's way)
-                            const mcx_d2 *X2 = (const mcx_d2 *)x, *Y2 = (const mcx_d2 *)y;
-                            const int ng = d >> 3;
-                            mcx_d2 xa[4], ya[4], xb[4], yb[4];
+    for (int I = 0; I < nb; ++I) {
+        const int I0 = I * b, wI = (d - I0) < b ? (d - I0) : b;
+        for (int e = tid; e < wI * d; e += 256) { const int c = e / d, k = e - c * d; GI[c * LS + k] = G[(size_t)(I0 + c) * d + k]; }
+        for (int J = I; J < nb; ++J) {
+            const int J0 = J * b, wJ = (d - J0) < b ? (d - J0) : b;
+            const bool diag = (J == I);
+            if (!diag)
+                for (int e = tid; e < wJ * d; e += 256) { const int c = e / d, k = e - c * d; GJ[c * LS + k] = G[(size_t)(J0 + c) * d + k]; }
+            __syncthreads();
+            double *Gq = diag ? GI : GJ;
+            const int nsteps = diag ? (2 * wI - 3) : (wI + wJ - 1);            // diag: pairs l < m at step l + m - 1
+            for (int t = 0; t < nsteps; ++t) {
+                // ---- (A) one pair per quad: alpha, beta, gamma and the rotation
+                if (tid < 128) {                               // waves 0 and 1 (whole waves: the shuffles below need their quads)
+                    const int l = ql, m = diag ? (t + 1 - l) : (t - l);
+                    const bool valid = (l < wI) && (diag ? (m > l && m < wI) : (m >= 0 && m < wJ));
+                    double acc = 0.0;
+                    if (valid && qr < 3) {
+                        const double *x = (qr == 1) ? Gq + (size_t)m * LS : GI + (size_t)l * LS;
+                        const double *y = (qr == 0) ? GI + (size_t)l * LS : Gq + (size_t)m * LS;
+                        // 16-byte LDS reads in groups of eight rows, the next group in flight while the chain works through
+                        // this one; the loop control is scalar (no per-element predicates in the chain's way)
+                        const mcx_d2 *X2 = (const mcx_d2 *)x, *Y2 = (const mcx_d2 *)y;
+                        const int ng = d >> 3;
+                        mcx_d2 xa[4], ya[4], xb[4], yb[4];
 #define MCX_SVD_LD(xv, yv, g) { _Pragma("unroll") for (int u = 0; u < 4; ++u) { xv[u] = X2[4 * (g) + u]; yv[u] = Y2[4 * (g) + u]; } }
 #define MCX_SVD_FM(xv, yv) { _Pragma("unroll") for (int u = 0; u < 4; ++u) { acc = dfma(xv[u].x, yv[u].x, acc); acc = dfma(xv[u].y, yv[u].y, acc); } }
-                            int g = 0;
-                            if (ng > 0) MCX_SVD_LD(xa, ya, 0)
-                            while (g < ng) {
-                                if (g + 1 < ng) MCX_SVD_LD(xb, yb, g + 1)
-                                MCX_SVD_FM(xa, ya)
+                        int g = 0;
+                        if (ng > 0) MCX_SVD_LD(xa, ya, 0)
+                        while (g < ng) {
+                            if (g + 1 < ng) MCX_SVD_LD(xb, yb, g + 1)
+                            MCX_SVD_FM(xa, ya)
+                            ++g;
+                            if (g < ng) {
+                                if (g + 1 < ng) MCX_SVD_LD(xa, ya, g + 1)
+                                MCX_SVD_FM(xb, yb)
                                 ++g;
-                                if (g < ng) {
-                                    if (g + 1 < ng) MCX_SVD_LD(xa, ya, g + 1)
-                                    MCX_SVD_FM(xb, yb)
-                                    ++g;
-                                }
                             }
+                        }
 #undef MCX_SVD_LD
 #undef MCX_SVD_FM
-                            for (int k = 8 * ng; k < d; ++k) acc = dfma(x[k], y[k], acc);
-                        }
-                        const int q0 = tid & 60 & 63;
-                        const double alpha = __shfl(acc, q0, 64), beta = __shfl(acc, q0 | 1, 64), gamma = __shfl(acc, q0 | 2, 64);
-                        if (qr == 0 && l < b) {
-                            int mm = -1;
-                            if (valid && (gamma != 0.0) && !(fabs(gamma) <= 1e-15 * sqrt(alpha * beta))) {
+                        for (int k = 8 * ng; k < d; ++k) acc = dfma(x[k], y[k], acc);
+                    }
+                    const int q0 = tid & 60 & 63;
+                    const double alpha = __shfl(acc, q0, 64), beta = __shfl(acc, q0 | 1, 64), gamma = __shfl(acc, q0 | 2, 64);
+                    if (qr == 0 && l < b) {
+                        int mm = -1;
+                        if (valid) {
+                            mcx_d2 cs; cs.x = 1.0; cs.y = 0.0;                 // the identity: what svd_applyv_kernel skips
+                            if ((gamma != 0.0) && !(fabs(gamma) <= 1e-15 * sqrt(alpha * beta))) {
                                 const double zeta = (beta - alpha) / (2.0 * gamma);
                                 const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                                 const double c = 1.0 / sqrt(1.0 + tt * tt);
-                                slot_c[l] = c; slot_s[l] = c * tt;
+                                cs.x = c; cs.y = c * tt;
+                                slot_c[l] = cs.x; slot_s[l] = cs.y;
                                 mm = m;
                                 s_rot = 1;
                             }
-                            slot_m[l] = mm;
+                            log[svd_pair_index(I0 + l, (diag ? I0 : J0) + m, d)] = cs;
                         }
+                        slot_m[l] = mm;
                     }
-                    __syncthreads();
-                    // ---- (B) the step's rotations, rows spread over the threads (two adjacent rows per trip)
-                    if (rl < wI) {
-                        const int m = slot_m[rl];
-                        if (m >= 0) {
-                            const double c = slot_c[rl], sn = slot_s[rl];
-                            double *gp = GI + (size_t)rl * LS, *gq = Gq + (size_t)m * LS, *vp = VI + (size_t)rl * LS, *vq = Vq + (size_t)m * LS;
-                            // 16-byte accesses (rows k, k + 1), four trips' loads in flight before the first result is needed
-                            for (int k0 = 2 * rk0; k0 + 1 < d; k0 += 64) {
-                                mcx_d2 a[4], bq[4], va[4], vb[4];
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) {
-                                    const int k = k0 + 16 * u;
-                                    if (k + 1 < d) { a[u] = *(mcx_d2 *)(gp + k); bq[u] = *(mcx_d2 *)(gq + k); va[u] = *(mcx_d2 *)(vp + k); vb[u] = *(mcx_d2 *)(vq + k); }
-                                }
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) {
-                                    const int k = k0 + 16 * u;
-                                    if (k + 1 < d) {
-                                        mcx_d2 na, nb2, nva, nvb;
-                                        na.x = c * a[u].x - sn * bq[u].x; na.y = c * a[u].y - sn * bq[u].y; nb2.x = sn * a[u].x + c * bq[u].x; nb2.y = sn * a[u].y + c * bq[u].y;
-                                        nva.x = c * va[u].x - sn * vb[u].x; nva.y = c * va[u].y - sn * vb[u].y; nvb.x = sn * va[u].x + c * vb[u].x; nvb.y = sn * va[u].y + c * vb[u].y;
-                                        *(mcx_d2 *)(gp + k) = na; *(mcx_d2 *)(gq + k) = nb2; *(mcx_d2 *)(vp + k) = nva; *(mcx_d2 *)(vq + k) = nvb;
-                                    }
-                                }
-                            }
-                            if ((d & 1) && rk0 == 0) {                            // the odd last row
-                                const int k = d - 1;
-                                const double a0 = gp[k], b0 = gq[k], va0 = vp[k], vb0 = vq[k];
-                                gp[k] = c * a0 - sn * b0; gq[k] = sn * a0 + c * b0;
-                                vp[k] = c * va0 - sn * vb0; vq[k] = sn * va0 + c * vb0;
-                            }
-                        }
-                    }
-                    __syncthreads();
                 }
-                if (!diag)
-                    for (int e = tid; e < wJ * d; e += 256) { const int c = e / d, k = e - c * d; G[(size_t)(J0 + c) * d + k] = GJ[c * LS + k]; V[(size_t)(J0 + c) * d + k] = VJ[c * LS + k]; }
+                __syncthreads();
+                // ---- (B) the step's rotations of G, rows spread over the threads (two adjacent rows per 16-byte access)
+                if (rl < wI) {
+                    const int m = slot_m[rl];
+                    if (m >= 0) {
+                        const double c = slot_c[rl], sn = slot_s[rl];
+                        double *gp = GI + (size_t)rl * LS, *gq = Gq + (size_t)m * LS;
+                        for (int k0 = 2 * rk0; k0 + 1 < d; k0 += 64) {
+                            mcx_d2 a[4], bq[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) { const int k = k0 + 16 * u; if (k + 1 < d) { a[u] = *(mcx_d2 *)(gp + k); bq[u] = *(mcx_d2 *)(gq + k); } }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int k = k0 + 16 * u;
+                                if (k + 1 < d) {
+                                    mcx_d2 na, nb2;
+                                    na.x = c * a[u].x - sn * bq[u].x; na.y = c * a[u].y - sn * bq[u].y; nb2.x = sn * a[u].x + c * bq[u].x; nb2.y = sn * a[u].y + c * bq[u].y;
+                                    *(mcx_d2 *)(gp + k) = na; *(mcx_d2 *)(gq + k) = nb2;
+                                }
+                            }
+                        }
+                        if ((d & 1) && rk0 == 0) {                              // the odd last row
+                            const int k = d - 1;
+                            const double a0 = gp[k], b0 = gq[k];
+                            gp[k] = c * a0 - sn * b0; gq[k] = sn * a0 + c * b0;
+                        }
+                    }
+                }
                 __syncthreads();
             }
-            for (int e = tid; e < wI * d; e += 256) { const int c = e / d, k = e - c * d; G[(size_t)(I0 + c) * d + k] = GI[c * LS + k]; V[(size_t)(I0 + c) * d + k] = VI[c * LS + k]; }
+            if (!diag)
+                for (int e = tid; e < wJ * d; e += 256) { const int c = e / d, k = e - c * d; G[(size_t)(J0 + c) * d + k] = GJ[c * LS + k]; }
             __syncthreads();
         }
-        if (!s_rot) break;
+        for (int e = tid; e < wI * d; e += 256) { const int c = e / d, k = e - c * d; G[(size_t)(I0 + c) * d + k] = GI[c * LS + k]; }
         __syncthreads();
     }
-    // ---- singular values = column norms (fma chain over the rows), sorted descending (first maximum wins), V's columns with them
+    if (tid == 0) { if (s_rot) *any_rotated = 1; else state[chain] = 2; }
+}
+
+// Replays one sweep's rotations on V, same block pairs, same steps.  Thread (rl, rk0) owns rows 2 rk0 + 16 i (+1) of the
+// columns it meets, and the 32 pair-lanes of one row group sit in ONE wave: within a wave the LDS accesses of consecutive
+// steps are ordered, so no barrier is needed between steps.  Chains whose sweep rotated nothing (state 2) are skipped.
+__global__ __launch_bounds__(256) void svd_applyv_kernel(double *Vc, const mcx_d2 *rot, const uint8_t *state, int nlanes, int d, int b)
+{
+    extern __shared__ double S[];
+    const int chain = blockIdx.x, tid = threadIdx.x;
+    if (chain >= nlanes || state[chain] != 1) return;
+    double *V = Vc + (size_t)chain * d * d;
+    const mcx_d2 *log = rot + (size_t)chain * ((size_t)d * (d - 1) / 2);
+    const int LS = svd_ls(d);
+    double *VI = S, *VJ = VI + (size_t)b * LS;
+    const int nb = (d + b - 1) / b;
+    const int rl = tid & 31, rk0 = tid >> 5;
+    for (int I = 0; I < nb; ++I) {
+        const int I0 = I * b, wI = (d - I0) < b ? (d - I0) : b;
+        for (int e = tid; e < wI * d; e += 256) { const int c = e / d, k = e - c * d; VI[c * LS + k] = V[(size_t)(I0 + c) * d + k]; }
+        for (int J = I; J < nb; ++J) {
+            const int J0 = J * b, wJ = (d - J0) < b ? (d - J0) : b;
+            const bool diag = (J == I);
+            if (!diag)
+                for (int e = tid; e < wJ * d; e += 256) { const int c = e / d, k = e - c * d; VJ[c * LS + k] = V[(size_t)(J0 + c) * d + k]; }
+            __syncthreads();
+            double *Vq = diag ? VI : VJ;
+            const int nsteps = diag ? (2 * wI - 3) : (wI + wJ - 1);
+            if (rl < wI)
+                for (int t = 0; t < nsteps; ++t) {
+                    // step t reads what other lanes of THIS wave wrote in step t - 1: keep the compiler from moving LDS
+                    // accesses across the step boundary (the hardware runs a wave's LDS operations in order)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const int m = diag ? (t + 1 - rl) : (t - rl);
+                    const bool valid = diag ? (m > rl && m < wI) : (m >= 0 && m < wJ);
+                    if (!valid) continue;
+                    const mcx_d2 cs = log[svd_pair_index(I0 + rl, (diag ? I0 : J0) + m, d)];
+                    if (cs.x == 1.0 && cs.y == 0.0) continue;
+                    const double c = cs.x, sn = cs.y;
+                    double *vp = VI + (size_t)rl * LS, *vq = Vq + (size_t)m * LS;
+                    for (int k0 = 2 * rk0; k0 + 1 < d; k0 += 64) {
+                        mcx_d2 va[4], vb[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const int k = k0 + 16 * u; if (k + 1 < d) { va[u] = *(mcx_d2 *)(vp + k); vb[u] = *(mcx_d2 *)(vq + k); } }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int k = k0 + 16 * u;
+                            if (k + 1 < d) {
+                                mcx_d2 nva, nvb;
+                                nva.x = c * va[u].x - sn * vb[u].x; nva.y = c * va[u].y - sn * vb[u].y; nvb.x = sn * va[u].x + c * vb[u].x; nvb.y = sn * va[u].y + c * vb[u].y;
+                                *(mcx_d2 *)(vp + k) = nva; *(mcx_d2 *)(vq + k) = nvb;
+                            }
+                        }
+                    }
+                    if ((d & 1) && rk0 == 0) {
+                        const int k = d - 1;
+                        const double va0 = vp[k], vb0 = vq[k];
+                        vp[k] = c * va0 - sn * vb0; vq[k] = sn * va0 + c * vb0;
+                    }
+                }
+            __syncthreads();
+            if (!diag)
+                for (int e = tid; e < wJ * d; e += 256) { const int c = e / d, k = e - c * d; V[(size_t)(J0 + c) * d + k] = VJ[c * LS + k]; }
+            __syncthreads();
+        }
+        for (int e = tid; e < wI * d; e += 256) { const int c = e / d, k = e - c * d; V[(size_t)(I0 + c) * d + k] = VI[c * LS + k]; }
+        __syncthreads();
+    }
+}
+
+// singular values = column norms of G (fma chain over the rows), sorted descending (first maximum wins), V's columns
+// with them; the sorted vectors are left in G's place
+__global__ __launch_bounds__(256) void svd_finish_kernel(double *Gc, const double *Vc, double *svc, const uint8_t *state, int nlanes, int d)
+{
+    __shared__ int s_perm[256];
+    __shared__ double s_sv[256];
+    const int chain = blockIdx.x, tid = threadIdx.x;
+    if (chain >= nlanes || state[chain] == 0) return;
+    double *G = Gc + (size_t)chain * d * d;
+    const double *V = Vc + (size_t)chain * d * d;
     if (tid < d) {
         const double *gj = G + (size_t)tid * d;
         double a = 0.0;
@@ -2771,7 +2862,7 @@ __global__ __launch_bounds__(256) void svd_blocked_kernel(double *Gc, double *Vc
         }
     __syncthreads();
     if (tid < d) svc[(size_t)chain * d + tid] = s_sv[tid];
-    for (int e = tid; e < d * d; e += 256) { const int j = e / d, k = e - j * d; G[e] = V[(size_t)s_perm[j] * d + k]; }     // sorted vectors over G
+    for (int e = tid; e < d * d; e += 256) { const int j = e / d, k = e - j * d; G[e] = V[(size_t)s_perm[j] * d + k]; }
 }
 
 // tile-interleaved [tile][K][64 lanes]  <->  chain-major [chain][K], 64 x 64 blocks through LDS (both sides coalesced)
