@@ -128,3 +128,45 @@ def test_two_ranks_under_torchrun(tmp_path):
     assert line["n_gpus"] == 2 and line["pooled_check"]["chains"] == 2048
     own, m_own = _bench(args, tmp_path, "own")
     assert np.array_equal(np.fromfile(dump, dtype=np.float64).view(np.uint64), m_own.view(np.uint64))
+
+
+@pytest.mark.parametrize("nranks", [4, 8])
+def test_tree_over_ranks_equals_tree_over_tiles(tmp_path, nranks):
+    """The claim behind all-gather + tree: for power-of-two shards the pairwise tree over ranks
+    continues the pairwise tree over tiles, so N ranks x n chains give the bits of 1 rank x N n chains.  Two ranks
+    cannot tell a tree from a ring (a + b = b + a); four and eight can."""
+    n = 512
+    common = ["--steps", "2", "--warmup", "1", "--pooled", "--method", "dram"]     # pooled AM: the moments feed back into every proposal
+    many, mN = _bench(common + ["--gpus", str(nranks), "--one-gpu-dryrun", "--chains-per-gpu", str(n)], tmp_path, "many")
+    one, m1 = _bench(common + ["--gpus", "1", "--chains-per-gpu", str(nranks * n)], tmp_path, "one")
+    assert many["n_gpus"] == nranks and many["pooled_check"]["chains"] == nranks * n
+    assert np.array_equal(mN.view(np.uint64), m1.view(np.uint64))
+
+
+def test_rocm_rccl_without_torch(tmp_path):
+    """bench.py's ranks never import torch, so their librccl / libamdhip64 are /opt/rocm's (pytest's own process has
+    torch's copies loaded first).  The same transport calls in a torch-free child: unique id through the shm bootstrap,
+    ncclCommInitRank, ncclAllReduce, the engine's all-gather + tree."""
+    code = r"""
+import sys, uuid, numpy as np
+sys.path.insert(0, %r)
+assert "torch" not in sys.modules
+from mcmcf90_amd import Comm, engine_from_problem
+from mcmcf90_amd.workloads import problem
+c = Comm("t" + uuid.uuid4().hex[:12], 0, 1, 0, backend="rccl")
+assert c.allreduce(np.array([2.5, -1.0]), op="sum").tolist() == [2.5, -1.0]
+c.barrier()
+ckw, pkw, _ = problem("c2", 201)
+e = engine_from_problem(dict(ckw, drscale=0.0), pkw, nchains=128, pooled=1, comm=c)
+e.init(); e.run()
+a, b = e.allreduce_moments(), e.pooled_moments()
+assert np.array_equal(a.view(np.uint64), b.view(np.uint64)) and a[0] == 128
+e.close(); c.close()
+assert "torch" not in sys.modules
+maps = open("/proc/self/maps").read()
+print("RCCL_FROM", [l.split()[-1] for l in maps.splitlines() if "librccl" in l][0])
+""" % ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MCMCX_COMM_KEY")}
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    assert "RCCL_FROM /opt/rocm" in p.stdout.decode(), p.stdout.decode()
