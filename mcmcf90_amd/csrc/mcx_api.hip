@@ -246,7 +246,7 @@ static int host_potri(int d, std::vector<double> &A)
 static size_t pooled_mfma_lds(int d)
 {
     const size_t d4 = (size_t)((d + 3) & ~3), nt = (size_t)((d + 15) / 16);
-    const size_t rows = (nt <= 4 ? std::max(d4, 16 * nt) : d4 + 16 * nt) + 4 * nt;
+    const size_t rows = (nt <= 4) ? std::max(d4, 4 * nt) : d4 + 16 * nt + 4 * nt;   // single pass: products and ss chains reuse the vector's rows
     return rows * 64 * sizeof(double);
 }
 static bool pooled_use_mfma(const mcmcx_engine *h)

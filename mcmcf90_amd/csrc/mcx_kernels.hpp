@@ -1572,8 +1572,10 @@ __global__ __launch_bounds__(64) void pooled_mfma_kernel(EngineDev E, int it0, i
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
     const int d4 = (d + 3) & ~3, nt = (d + 15) >> 4, li = lane & 15, lk = lane >> 4;
     const bool single = (nt <= 4);                                  // one pass: the outputs may overwrite the input vector
+    // single pass: the products (rows < d4 only) overwrite the vector they came from, and the partial ss chains go over
+    // its first 4 nt rows once y = Lam v is in registers -- 512 d4 bytes of LDS per wave (26 KiB at d = 50: six waves per CU)
     double *T = single ? X : X + (size_t)d4 * 64;                  // [16 nt][64] products in (row, chain) order
-    double *Q = T + (size_t)nt * 16 * 64;                          // [4 nt][64] partial ss chains
+    double *Q = single ? X : T + (size_t)nt * 16 * 64;             // [4 nt][64] partial ss chains
     double *theta_t = E.theta + (size_t)tile * d * 64;
     double *cand_t = E.cand + (size_t)tile * d * 64;
     const bool gauss = (E.tgt.kind == TGT_GAUSS);
@@ -1597,8 +1599,11 @@ __global__ __launch_bounds__(64) void pooled_mfma_kernel(EngineDev E, int it0, i
                 if (b < nb) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        double *o = T + (size_t)(16 * (ob0 + b) + lk + 4 * r) * 64 + li;
-                        o[0] = c[b][0][r]; o[16] = c[b][1][r]; o[32] = c[b][2][r]; o[48] = c[b][3][r];
+                        const int row = 16 * (ob0 + b) + lk + 4 * r;
+                        if (row < d4) {                                 // rows >= d are never read
+                            double *o = T + (size_t)row * 64 + li;
+                            o[0] = c[b][0][r]; o[16] = c[b][1][r]; o[32] = c[b][2][r]; o[48] = c[b][3][r];
+                        }
                     }
                 }
         }
