@@ -315,7 +315,7 @@ def main():
                 # what the tile-interleaved layout can reach at best: update and downdate lanes share every 64-byte sector,
                 # so an iteration in which a wave holds both kinds moves the factor twice in each direction (2R + 2W)
                 tri = d * (d + 1) // 2 * 8
-                roof["alg_bytes_2r2w_per_proposal"] = 16 * d + 32 + int(round(tri * (2.0 + 2.0 * min(1.0, down_frac / 0.5))))
+                roof["alg_bytes_2r2w_per_proposal"] = 16 * d + 32 + int(round(tri * (2.0 + 2.0 * (1.0 - (1.0 - down_frac) ** 64))))   # share of waves with a downdate lane
         if pmc:
             roof["traffic_measured_at"] = {"kernels_sha": pmc["kernels_sha"], "profile": pmc.get("profile")}
             if "valu_insts_per_proposal" in pmc:      # second roof: vector-instruction issue, from an SQ counter pass
