@@ -1,7 +1,7 @@
-"""Host-side helpers for the multi-GPU form of the path: how chains are sharded over ranks and how the
-pooled empirical moments are combined.  No device code here: the per-GPU partial comes from
-`Engine.pooled_moments[_dev]` (libmcmcx.so); the exchange is a torch.distributed all-reduce (RCCL on GPUs, gloo in the
-CPU tests)."""
+"""Host-side arithmetic around the pooled moment vector [count, sum (d), upper second moments (d(d+1)/2)] of the
+multi-GPU form of the path: how chains are sharded over ranks (the rule bench.py and the Fortran shim's `ngpus` follow)
+and how mean / covariance come out of the vector.  The exchange itself is in libmcmcx.so (csrc/mcx_comm.hpp:
+mcmcx_comm_create / mcmcx_allreduce_moments, RCCL); nothing here touches a device."""
 import numpy as np
 
 
@@ -16,14 +16,6 @@ def shard(nchains_total, rank, world):
 
 def moments_len(d):
     return 1 + d + d * (d + 1) // 2
-
-
-def allreduce_moments(vec, dist=None):
-    """Sum the per-rank pooled moment vectors [count, sum (d), second moments (d(d+1)/2)].  `vec` is a torch
-    tensor (on the GPU for RCCL, on the CPU for gloo); in place."""
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(vec)
-    return vec
 
 
 def finalize_moments(vec, d, shift):

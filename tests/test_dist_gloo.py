@@ -1,5 +1,7 @@
-"""The N>1 host path on CPU: two gloo ranks shard the chains, all-reduce their pooled moment vectors and
-finalize the same mean/covariance a single process gets from all chains."""
+"""The sharding rule and the moment-vector arithmetic on CPU: two gloo ranks take their blocks of chains, sum their pooled
+moment vectors and finalize the same mean/covariance a single process gets from all chains.  (The product's own
+exchange -- libmcmcx.so's communicator -- is covered by tests/test_comm_cpu.py without a GPU and by
+tests/test_gpu_multirank.py with one.)"""
 import os
 import sys
 import numpy as np
@@ -35,7 +37,7 @@ def _worker(rank, world, port, q):
     n, c0 = mdist.shard(ntot, rank, world)
     assert (n, c0) == (ntot // world, rank * (ntot // world))
     v = torch.from_numpy(_local_moments(theta[c0:c0 + n] - shift))
-    mdist.allreduce_moments(v, dist)
+    dist.all_reduce(v)                                     # (on a GPU node: mcmcx_allreduce_moments, RCCL, inside libmcmcx.so)
     mean, cov = mdist.finalize_moments(v.numpy(), d, shift)
     if rank == 0:
         q.put((mean, cov, theta))
