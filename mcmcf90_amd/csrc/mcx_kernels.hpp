@@ -336,6 +336,10 @@ MCX_DEV double gen_normals(Rng &g, double *zs_t, int lane, int d, bool participa
 // dtrmv('U','T','N') (matutils.F90:108-109): p_j = sum_{i<=j} R(i,j) z_i, each dot product ascending in i
 // as one fma chain from 0.  Column panels of PW accumulators in registers; every row contributes one
 // contiguous PW x 512-byte segment, so the factor is read exactly once.
+// PIPE: the AM / DRAM step kernels, where this product is the iteration's only pass over the factor and memory latency is
+// what it waits for: three rows' loads in flight above the diagonal block, two inside it.  The RAM kernel runs it once per
+// launch (later proposals come fused out of the update sweep) and keeps the plain form: its registers are spoken for.
+template <bool PIPE>
 MCX_DEV void trmv_panels(const double *Rt, const double *z_t, double *P_t, const double *theta_t, int lane, int d, bool act,
                          bool desc = false)
 {
@@ -347,25 +351,43 @@ MCX_DEV void trmv_panels(const double *Rt, const double *z_t, double *P_t, const
 #pragma unroll
             for (int u = 0; u < TW; ++u) P[u] = 0.0;
             if (asc) {
-#pragma unroll 2
-                for (int i = 0; i < J0; ++i) {                               // rows above the diagonal block
-                    const double zi = GV(z_t, i);
-                    const double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
-                    double r[TW];
+                // rows above the diagonal block, two rows' loads in flight: left to itself the compiler keeps four loads
+                // outstanding (it sinks each load next to its fma), and a lane-per-chain wave then waits out the HBM
+                // latency once per row; the accumulation order of every P[u] is unchanged (rows ascending)
+                constexpr int NB = PIPE ? 3 : 1;                               // rows in flight
+                double rr[NB][TW], zz[NB];
+#define MCX_TRMV_LD(rv, zv, i_) { zv = GV(z_t, (i_)); const double *seg_ = Rt + (size_t)(rowstart((i_), d) + J0 - (i_)) * 64; \
+                                  _Pragma("unroll") for (int u = 0; u < TW; ++u) rv[u] = LDNT(seg_, u < nw ? u : nw - 1); }
+#define MCX_TRMV_FM(rv, zv) { _Pragma("unroll") for (int u = 0; u < TW; ++u) P[u] = dfma(rv[u], zv, P[u]); }
 #pragma unroll
-                    for (int u = 0; u < TW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
+                for (int s_ = 0; s_ < NB - 1; ++s_) if (s_ < J0) MCX_TRMV_LD(rr[s_], zz[s_], s_)
+                for (int i = 0; i < J0; i += NB) {
 #pragma unroll
-                    for (int u = 0; u < TW; ++u) P[u] = dfma(r[u], zi, P[u]);
+                    for (int s_ = 0; s_ < NB; ++s_) {
+                        if (i + s_ + NB - 1 < J0) MCX_TRMV_LD(rr[(s_ + NB - 1) % NB], zz[(s_ + NB - 1) % NB], i + s_ + NB - 1)
+                        if (i + s_ < J0) MCX_TRMV_FM(rr[s_], zz[s_])
+                    }
                 }
-                for (int i = J0; i < J0 + nw; ++i) {                         // diagonal block: elements u >= ui
-                    const double zi = GV(z_t, i);
-                    const double *seg = Rt + (size_t)rowstart(i, d) * 64;
-                    const int ui = i - J0, m = d - 1 - i;
-                    double r[TW];
-#pragma unroll
-                    for (int u = 0; u < TW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
-#pragma unroll
-                    for (int u = 0; u < TW; ++u) { double nv = dfma(r[u], zi, P[u]); P[u] = (u >= ui) ? nv : P[u]; }
+#undef MCX_TRMV_LD
+#undef MCX_TRMV_FM
+                {                                                            // diagonal block: elements u >= ui; the next row's loads in flight
+                    double da[TW], db[TW], za = 0.0, zb = 0.0;
+#define MCX_TRMV_LDD(rv, zv, i_) { zv = GV(z_t, (i_)); const double *seg_ = Rt + (size_t)rowstart((i_), d) * 64; const int ui_ = (i_) - J0, m_ = d - 1 - (i_); \
+                                   _Pragma("unroll") for (int u = 0; u < TW; ++u) { int k = u - ui_; k = k < 0 ? 0 : k; k = k > m_ ? m_ : k; rv[u] = LDNT(seg_, k); } }
+#define MCX_TRMV_FMD(rv, zv, i_) { const int ui_ = (i_) - J0; _Pragma("unroll") for (int u = 0; u < TW; ++u) { double nv = dfma(rv[u], zv, P[u]); P[u] = (u >= ui_) ? nv : P[u]; } }
+                    if (PIPE) {
+                        MCX_TRMV_LDD(da, za, J0)
+                        for (int i = J0; i < J0 + nw; i += 2) {
+                            if (i + 1 < J0 + nw) MCX_TRMV_LDD(db, zb, i + 1)
+                            MCX_TRMV_FMD(da, za, i)
+                            if (i + 2 < J0 + nw) MCX_TRMV_LDD(da, za, i + 2)
+                            if (i + 1 < J0 + nw) MCX_TRMV_FMD(db, zb, i + 1)
+                        }
+                    } else {
+                        for (int i = J0; i < J0 + nw; ++i) { MCX_TRMV_LDD(da, za, i) MCX_TRMV_FMD(da, za, i) }
+                    }
+#undef MCX_TRMV_LDD
+#undef MCX_TRMV_FMD
                 }
 #pragma unroll
                 for (int u = 0; u < TW; ++u) if (u < nw) GV(P_t, J0 + u) = GV(theta_t, J0 + u) + P[u];   // newpar = oldpar + R'z
@@ -1040,7 +1062,7 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
         // ---- newpar = MCMC_propose(oldpar, R)
         if (POOLED) { if (E.usesvd) gemvN_shared(g_sharedR, zc_t, cand_t, theta_t, lane, d); else trmv_shared(g_sharedR, zc_t, cand_t, theta_t, lane, d); }
         else if (E.usesvd) gemvN_panels(E.Rf + (size_t)tile * d * d * 64, zc_t, cand_t, theta_t, lane, d, true);   // matmulx(R,z)
-        else if (__any(!have_p)) trmv_panels(Rt, zc_t, cand_t, theta_t, lane, d, !have_p, RAM && pdesc);
+        else if (__any(!have_p)) trmv_panels<!RAM>(Rt, zc_t, cand_t, theta_t, lane, d, !have_p, RAM && pdesc);
         // ---- bounds, prior, ss, alpha, reject
         bool inb = target_inbounds(E.tgt, d, lane, cand_t);
         double pri2 = target_prior(E.tgt, d, lane, cand_t);
@@ -1072,7 +1094,7 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
             double *z2_t = zn_t;                          // stage-2 normals: the "next" buffer is still free
             gen_normals(g, z2_t, lane, d, m);
             if (E.usesvd) gemvN_panels(E.R2f + (size_t)tile * d * d * 64, z2_t, c2_t, theta_t, lane, d, m);
-            else trmv_panels(E.R2 + (size_t)tile * E.P * 64, z2_t, c2_t, theta_t, lane, d, m);
+            else trmv_panels<true>(E.R2 + (size_t)tile * E.P * 64, z2_t, c2_t, theta_t, lane, d, m);
             if (m) {
                 bool inb2 = target_inbounds(E.tgt, d, lane, c2_t);
                 if (!inb2) bnd += 1;
@@ -1153,11 +1175,17 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
     if (RAM) { TIDX(E.ictr, tile, NICTR, I_PDESC, lane) = pdesc ? 1u : 0u; TIDX(E.ictr, tile, NICTR, I_DOWNS, lane) = downs; }
 }
 
+#ifndef MCX_AM_WAVES
+#define MCX_AM_WAVES 2
+#endif
+#ifndef MCX_AM_WIDE
+#define MCX_AM_WIDE true
+#endif
 template <bool RAM, bool DR, bool POOLED>
-__global__ __launch_bounds__(64, 2) void step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
+__global__ __launch_bounds__(64, (RAM || DR || POOLED) ? 2 : MCX_AM_WAVES) void step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
                                                      const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
                                                      const double *__restrict__ g_sharedR)
-{ step_body<RAM, DR, POOLED>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
+{ step_body<RAM, DR, POOLED, (RAM || (!DR && !POOLED && MCX_AM_WIDE))>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
 
 // method='ram' with condmax > 0: the factor is the full SVD one (E.Rf), proposals are matmulx(R,u), the rank-one
 // adaptation runs on its upper triangle (ram_update_full)
@@ -1805,7 +1833,7 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
         double su = gen_normals(L.g, zs_t, lane, d, true);
         GV(hx, HX_SU) = su;
         if (E.usesvd) gemvN_panels(E.Rf + (size_t)tile * d * d * 64, zs_t, cand_t, theta_t, lane, d, true);    // matmulx(R,z)
-        else trmv_panels(E.R + (size_t)tile * E.P * 64, zs_t, cand_t, theta_t, lane, d, true, E.method == M_RAM && L.pdesc != 0u);
+        else trmv_panels<false>(E.R + (size_t)tile * E.P * 64, zs_t, cand_t, theta_t, lane, d, true, E.method == M_RAM && L.pdesc != 0u);
     } else if (PHASE == 1) {
         const bool inb = GV(hev, HE_INB) != 0.0;
         const double pri2 = GV(hev, HE_PRI), ss2 = GV(hev, HE_SS);
@@ -1826,7 +1854,7 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
             for (int j = 0; j < (ny > 1 ? ny : 0); ++j) GV(ss2v, j) = GV(sshev, j);
             gen_normals(L.g, zs_t + (size_t)d * 64, lane, d, m);
             if (E.usesvd) gemvN_panels(E.R2f + (size_t)tile * d * d * 64, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d, m);
-            else trmv_panels(E.R2 + (size_t)tile * E.P * 64, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d, m);
+            else trmv_panels<false>(E.R2 + (size_t)tile * E.P * 64, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d, m);
             GV(hx, HX_SS2) = ss2; GV(hx, HX_PRI2) = pri2;
             GV(hx, HX_REJECT) = reject ? 1.0 : 0.0; GV(hx, HX_STAGE2) = m ? 1.0 : 0.0;
         } else {
