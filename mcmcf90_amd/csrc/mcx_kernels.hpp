@@ -436,46 +436,73 @@ MCX_DEV void trmv_panels(const double *Rt, const double *z_t, double *P_t, const
 // ---------------------------------------------------------------- full-matrix products for the SVD paths
 // y = M x (dgemv 'N', matutils.F90:161): y = 0, then column by column y_i += x_j M(i,j) -- each y_i is an fma chain
 // ascending in j.  Row panels of PW accumulators in registers; out_t = (add_t ? add_t : 0) + y.
+// PIPE (the per-chain SCAM kernel, which does nothing but stream its rotation): four columns' loads in flight -- left to
+// itself the compiler sinks every load next to its fma and keeps ~4 outstanding.  The step kernels (SVD proposal factor)
+// keep the plain form: their registers are spoken for.
+template <bool PIPE = false>
 MCX_DEV void gemvN_panels(const double *Mt, const double *x_t, double *out_t, const double *add_t, int lane, int d, bool act)
 {
+#ifndef MCX_GEMV_NB
+#define MCX_GEMV_NB 4
+#endif
+    constexpr int NB = PIPE ? MCX_GEMV_NB : 1;
     for (int I0 = 0; I0 < d; I0 += PW) {
         const int nr = (d - I0) < PW ? (d - I0) : PW;
         double y[PW];
 #pragma unroll
         for (int u = 0; u < PW; ++u) y[u] = 0.0;
         if (act) {
-#pragma unroll 4
-            for (int j = 0; j < d; ++j) {                          // the matrix is streamed (non-temporal), x stays cached
-                const double xj = GV(x_t, j);
-                const double *seg = Mt + ((size_t)j * d + I0) * 64;
-                double r[PW];
+            double rr[NB][PW], xx[NB];                             // the matrix is streamed (non-temporal), x stays cached
+#define MCX_GEMV_LD(s_, j_) { xx[s_] = GV(x_t, (j_)); const double *seg_ = Mt + ((size_t)(j_) * d + I0) * 64; \
+                              _Pragma("unroll") for (int u = 0; u < PW; ++u) rr[s_][u] = LDNT(seg_, u < nr ? u : nr - 1); }
 #pragma unroll
-                for (int u = 0; u < PW; ++u) r[u] = LDNT(seg, u < nr ? u : nr - 1);
+            for (int s = 0; s < NB - 1; ++s) if (s < d) MCX_GEMV_LD(s, s)
+#pragma unroll (NB == 1 ? 4 : 1)
+            for (int j = 0; j < d; j += NB) {
 #pragma unroll
-                for (int u = 0; u < PW; ++u) y[u] = dfma(xj, r[u], y[u]);
+                for (int s = 0; s < NB; ++s) {
+                    if (j + s + NB - 1 < d) MCX_GEMV_LD((s + NB - 1) % NB, j + s + NB - 1)
+                    if (j + s < d) {
+#pragma unroll
+                        for (int u = 0; u < PW; ++u) y[u] = dfma(xx[s], rr[s][u], y[u]);
+                    }
+                }
             }
+#undef MCX_GEMV_LD
 #pragma unroll
             for (int u = 0; u < PW; ++u) if (u < nr) GV(out_t, I0 + u) = add_t ? (GV(add_t, I0 + u) + y[u]) : y[u];
         }
     }
 }
 // y = M'x (dgemv 'T'): y_k = sum_i M(i,k) x_i, i ascending, one fma chain per column.
+template <bool PIPE = false>
 MCX_DEV void gemvT_panels(const double *Mt, const double *x_t, double *out_t, int lane, int d)
 {
+#ifndef MCX_GEMV_NB
+#define MCX_GEMV_NB 4
+#endif
+    constexpr int NB = PIPE ? MCX_GEMV_NB : 1;
     for (int K0 = 0; K0 < d; K0 += PW) {
         const int nc = (d - K0) < PW ? (d - K0) : PW;
         double t[PW];
 #pragma unroll
         for (int u = 0; u < PW; ++u) t[u] = 0.0;
-#pragma unroll 4
-        for (int i = 0; i < d; ++i) {
-            const double xi = GV(x_t, i);
-            double r[PW];
+        double rr[NB][PW], xx[NB];
+#define MCX_GEMV_LD(s_, i_) { xx[s_] = GV(x_t, (i_)); _Pragma("unroll") for (int u = 0; u < PW; ++u) rr[s_][u] = LDNT(Mt, (size_t)(K0 + (u < nc ? u : nc - 1)) * d + (i_)); }
 #pragma unroll
-            for (int u = 0; u < PW; ++u) r[u] = LDNT(Mt, (size_t)(K0 + (u < nc ? u : nc - 1)) * d + i);
+        for (int s = 0; s < NB - 1; ++s) if (s < d) MCX_GEMV_LD(s, s)
+#pragma unroll (NB == 1 ? 4 : 1)
+        for (int i = 0; i < d; i += NB) {
 #pragma unroll
-            for (int u = 0; u < PW; ++u) t[u] = dfma(r[u], xi, t[u]);
+            for (int s = 0; s < NB; ++s) {
+                if (i + s + NB - 1 < d) MCX_GEMV_LD((s + NB - 1) % NB, i + s + NB - 1)
+                if (i + s < d) {
+#pragma unroll
+                    for (int u = 0; u < PW; ++u) t[u] = dfma(rr[s][u], xx[s], t[u]);
+                }
+            }
         }
+#undef MCX_GEMV_LD
 #pragma unroll
         for (int u = 0; u < PW; ++u) if (u < nc) GV(out_t, K0 + u) = t[u];
     }
@@ -1240,7 +1267,10 @@ MCX_DEV void lane_store(const EngineDev &E, int tile, int lane, const LaneState 
 // One outer iteration = d componentwise Metropolis sub-steps in the rotated basis: rot = U'theta (dgemv 'T'),
 // rot_j += N(0,1) std_j, theta' = U rot (dgemv 'N'), full ss evaluation, alpha, reject (MCMC_propose_sc :94-117).
 // One chain row per outer iteration.  U (full d x d per chain) is streamed twice per sub-step.
-__global__ __launch_bounds__(64, 2) void scam_kernel(EngineDev E, int it0, int it1,
+#ifndef MCX_SCAM_WAVES
+#define MCX_SCAM_WAVES 2
+#endif
+__global__ __launch_bounds__(64, MCX_SCAM_WAVES) void scam_kernel(EngineDev E, int it0, int it1,
                                                      const double *__restrict__ g_mu, const double *__restrict__ g_lamT)
 {
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
@@ -1254,10 +1284,10 @@ __global__ __launch_bounds__(64, 2) void scam_kernel(EngineDev E, int it0, int i
     for (int it = it0; it <= it1; ++it) {
         bool rejall = true;
         for (int j = 0; j < d; ++j) {
-            gemvT_panels(Ut, theta_t, rot_t, lane, d);
+            gemvT_panels<true>(Ut, theta_t, rot_t, lane, d);
             const double zj = rng_normal(L.g) * GV(std_t, j);
             GV(rot_t, j) = GV(rot_t, j) + zj;
-            gemvN_panels(Ut, rot_t, cand_t, nullptr, lane, d, true);
+            gemvN_panels<true>(Ut, rot_t, cand_t, nullptr, lane, d, true);
             bool inb = target_inbounds(E.tgt, d, lane, cand_t);
             double pri2 = target_prior(E.tgt, d, lane, cand_t);
             double ss2 = target_ss<false>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
