@@ -54,6 +54,8 @@ struct mcmcx_engine {
     int pooled = 0; double pool_W = 0.0; std::vector<double> pool_mean, pool_C, pool_R;   // packed upper, row-major
     std::vector<double> pool_U, pool_std;             // pooled SCAM: the shared rotation (column-major) and qcovstd
     std::vector<double> pool_Rf;                      // pooled AM with condmax > 0: covtor_svd's full factor U sqrt(s) 2.4/sqrt(d), column-major
+    std::vector<double> pool_R2, pool_iC;             // pooled mode with delayed rejection: R / drscale (packed, or full with condmax > 0) and dpotri(R) (packed)
+    double *d_sharedR2 = nullptr, *d_sharediC = nullptr;
     double *d_sharedU = nullptr;                      // [U col-major | pad | U row-major | pad | std]
     double *d_sharedRT = nullptr;                     // pooled AM on the matrix cores: dense R, M[s*d + o] = R(s,o), zero below the diagonal and in the pad rows
     double *d_sharedR = nullptr; mcmcx_exchange_t xfn = nullptr; void *xuser = nullptr; double *xbuf = nullptr;
@@ -251,7 +253,7 @@ static size_t pooled_mfma_lds(int d)
 }
 static bool pooled_use_mfma(const mcmcx_engine *h)
 {
-    if (!h->pooled || (h->cfg.method != MCMCX_METHOD_DRAM && h->cfg.method != MCMCX_METHOD_RAM)) return false;
+    if (!h->pooled || h->dodr || (h->cfg.method != MCMCX_METHOD_DRAM && h->cfg.method != MCMCX_METHOD_RAM)) return false;   // DR and ER: the lane-per-chain kernel
     if (const char *e = getenv("MCMCX_POOLED_SCALAR")) if (atoi(e)) return false;      // A/B switch for tests: the lane-per-chain kernel
     return pooled_mfma_lds(h->d) <= 160 * 1024;
 }
@@ -265,6 +267,7 @@ static void launch_step(mcmcx_engine *h, int it0, int it1)
     const dim3 g(h->ntiles), b(64);
     const double *rs = h->d_ramscale + it0;
     if (pooled_use_mfma(h)) hipLaunchKernelGGL(pooled_mfma_kernel, g, b, pooled_mfma_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedRT);
+    else if (h->pooled && h->dodr) hipLaunchKernelGGL(step_kernel_pooled_dr, g, b, lds_step(h), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR, h->d_sharedR2, h->d_sharediC);
     else if (h->pooled) hipLaunchKernelGGL((step_kernel<false, false, true>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->E.method == M_RAM && h->usesvd) hipLaunchKernelGGL(step_kernel_ram_fullr, g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->E.method == M_RAM) hipLaunchKernelGGL((step_kernel<true, false, false>), g, b, (size_t)NLC * 2 * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
@@ -488,6 +491,31 @@ static int pooled_reduce(mcmcx_engine *h, int kind, int it, std::vector<double> 
     return 0;
 }
 
+// Delayed rejection in pooled mode (MCMC_adapt.F90:216-225 once for all chains): R2 = R / drscale, iC = dpotri('U', R) on
+// the upper triangle of the factor as it stands.  fresh: a new factor (recompute both); otherwise the burn-in scaling
+// has already been applied to the tables themselves, as MCMC_adapt.F90:66-78 does.
+static int pooled_upload_dr(mcmcx_engine *h, bool fresh)
+{
+    if (!h->dodr) return 0;
+    const int d = h->d, P = h->P;
+    if (fresh) {
+        std::vector<double> iC(P);
+        if (h->usesvd) {
+            h->pool_R2 = h->pool_Rf;
+            for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) iC[h_pidx(i, j, d)] = h->pool_Rf[(size_t)j * d + i];
+        } else { h->pool_R2 = h->pool_R; iC = h->pool_R; }
+        for (auto &v : h->pool_R2) v = v / h->cfg.drscale;
+        if (host_potri(d, iC) != 0) h->pool_status |= ST_POTRI_FAIL;          // the reference stops ("cannot invert cmat"); the old iC stays
+        else h->pool_iC = iC;
+    }
+    std::vector<double> r2 = h->pool_R2;
+    if (h->usesvd) r2.resize((size_t)((d + 3) & ~3) * d + PWS, 0.0);
+    HIPCHK(hipMemcpyAsync(h->d_sharedR2, r2.data(), r2.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_sharediC, h->pool_iC.data(), (size_t)P * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 static int pooled_upload_R(mcmcx_engine *h)
 {
     if (h->usesvd) return upload_shared_rf(h);
@@ -515,11 +543,12 @@ static int pooled_factor(mcmcx_engine *h)
         if (host_initial_svd(d, cm, c.condmax, false, Rf, sd, &fc) == 0) {
             h->pool_Rf = Rf;
             if (!fc.empty()) for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) h->pool_C[h_pidx(i, j, d)] = fc[(size_t)i + (size_t)j * d];
-            return pooled_upload_R(h);
+            int rc = pooled_upload_R(h);
+            return rc ? rc : pooled_upload_dr(h, true);
         }
         return 0;
     }
-    if (host_initial_R(d, cm, Rp, Cp) == 0) { h->pool_R = Rp; return pooled_upload_R(h); }
+    if (host_initial_R(d, cm, Rp, Cp) == 0) { h->pool_R = Rp; int rc = pooled_upload_R(h); return rc ? rc : pooled_upload_dr(h, true); }
     return 0;
 }
 
@@ -582,7 +611,12 @@ static int pooled_tick(mcmcx_engine *h, int it, int mode)
         if (staypc > 1.0 - c.scalelimit || staypc < c.scalelimit) {
             const bool down = staypc > 1.0 - c.scalelimit;
             for (auto &r : (h->usesvd ? h->pool_Rf : h->pool_R)) r = down ? r / sf : r * sf;
-            return pooled_upload_R(h);
+            if (h->dodr) {                                  // R2 and iC are scaled themselves (MCMC_adapt.F90:66-78), not recomputed
+                for (auto &r : h->pool_R2) r = down ? r / sf : r * sf;
+                for (auto &r : h->pool_iC) r = down ? r * sf * sf : r / sf / sf;
+            }
+            int rc2 = pooled_upload_R(h);
+            return rc2 ? rc2 : pooled_upload_dr(h, false);
         }
         if (c.greedy != 0) { pooled_restart(h); pooled_merge(h, v, false); }
         return pooled_factor(h);
@@ -817,8 +851,6 @@ int mcmcx_create(const mcmcx_config *cfg_in, mcmcx_handle *out)
     }
     if (c.pooled) {
         const bool scam = (c.method == MCMCX_METHOD_SCAM);
-        if (c.method == MCMCX_METHOD_ER) return fail(-8, "pooled mode: method = 'er' is not available (use 'dram', 'ram' or 'scam')");
-        if (c.drscale > 0.0) return fail(-8, "pooled mode: delayed rejection keeps a per-chain inverse covariance; drscale must be 0");
         if (c.method == MCMCX_METHOD_RAM && c.condmax > 0.0) return fail(-8, "pooled mode: method = 'ram' with condmax > 0 is not available");
     }
     int ndev = 0;
@@ -1080,7 +1112,7 @@ int mcmcx_init(mcmcx_handle h)
         }
     }
     E.R2 = E.iC = nullptr;
-    if (h->dodr) {
+    if (h->dodr && !h->pooled) {                        // pooled: one R2 and one iC for every chain (below)
         if ((rc = dev_alloc(h, &E.R2, L * P, false))) return rc;
         if ((rc = dev_alloc(h, &E.iC, L * P, false))) return rc;
     }
@@ -1175,8 +1207,16 @@ int mcmcx_init(mcmcx_handle h)
             if (h->usesvd) for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) iCp[h_pidx(i, j, d)] = Rfull[(size_t)j * d + i];
             if (host_potri(d, iCp) != 0) return fail(-34, "ERROR: cannot invert cmat");
             for (int e = 0; e < P; ++e) R2p[e] = Rp[e] / c.drscale;
+            if (h->pooled) {
+                h->pool_iC = iCp;
+                if (h->usesvd) { h->pool_R2 = Rfull; for (auto &v : h->pool_R2) v = v / c.drscale; } else h->pool_R2 = R2p;
+                if ((rc = dev_alloc(h, &h->d_sharedR2, h->usesvd ? (size_t)((d + 3) & ~3) * d + PWS : (size_t)P, false))) return rc;
+                if ((rc = dev_alloc(h, &h->d_sharediC, (size_t)P, false))) return rc;
+                if ((rc = pooled_upload_dr(h, false))) return rc;
+            } else {
             if ((rc = dev_bcast(h, E.R2, R2p))) return rc;
             if ((rc = dev_bcast(h, E.iC, iCp))) return rc;
+            }
         }
         if (am) {
             if ((rc = dev_bcast(h, E.cmat, Cp))) return rc;
@@ -1391,6 +1431,12 @@ int mcmcx_get_dr(mcmcx_handle h, int32_t chain, double *R2, double *iC)
     int rc = check_chain(h, chain); if (rc) return rc;
     if (!h->dodr) return fail(-43, "drscale = 0: no delayed-rejection state");
     std::vector<double> p;
+    if (h->pooled) {                                    // one pair of tables for every chain
+        if (R2 && h->usesvd) memcpy(R2, h->pool_R2.data(), sizeof(double) * h->pool_R2.size());
+        else if (R2) unpack_upper(h->d, h->pool_R2, R2, false);
+        if (iC) unpack_upper(h->d, h->pool_iC, iC, false);
+        return 0;
+    }
     if (R2 && h->usesvd) { if ((rc = fetch_chain_vec(h, h->E.R2f, h->d * h->d, chain, p))) return rc; memcpy(R2, p.data(), sizeof(double) * p.size()); }
     else if (R2) { if ((rc = fetch_chain_vec(h, h->E.R2, h->P, chain, p))) return rc; unpack_upper(h->d, p, R2, false); }
     if (iC) { if ((rc = fetch_chain_vec(h, h->E.iC, h->P, chain, p))) return rc; unpack_upper(h->d, p, iC, false); }

@@ -1046,6 +1046,27 @@ MCX_DEV double quadform_sym(const double *St, int lane, int d, const double *X, 
     return q;
 }
 
+// the same quadratic form with ONE inverse covariance for every chain (pooled mode with delayed rejection): Ss is the
+// packed upper triangle by rows, wave-uniform, read through the scalar cache; per element the operations of quadform_sym
+MCX_DEV double quadform_sym_shared(const double *__restrict__ Ss, int lane, int d, const double *X, double *Y)
+{
+    double q = 0.0;
+    for (int i = 0; i < d; ++i) {
+        const double *__restrict__ rowp = Ss + rowstart(i, d);
+        const int n = d - i;
+        const double dxi = XL(i);
+        const double sii = rowp[0];
+        double yi = (i == 0) ? sii * dxi : dfma(sii, dxi, Y[i * 64 + lane]);
+        for (int k = 1; k < n; ++k) {
+            const double sij = rowp[k];
+            yi = dfma(sij, XL(i + k), yi);
+            Y[(i + k) * 64 + lane] = (i == 0) ? sij * dxi : dfma(sij, dxi, Y[(i + k) * 64 + lane]);
+        }
+        q = q + yi * dxi;
+    }
+    return q;
+}
+
 // ---------------------------------------------------------------- the step kernel
 // Iterations it0..it1 (absolute simuind) of MCMC_run (MCMC_run.F90:41-107) or MCMC_run_ram
 // (MCMC_run_ram.F90:45-81) for one tile of 64 chains.  LDS is used only by the delayed-rejection
@@ -1053,7 +1074,8 @@ MCX_DEV double quadform_sym(const double *St, int lane, int d, const double *X, 
 template <bool RAM, bool DR, bool POOLED, bool WIDE_T = (RAM || (!DR && !POOLED)), bool FULLR = false>
 MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__restrict__ ramscale,
                        const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
-                       const double *__restrict__ g_sharedR)
+                       const double *__restrict__ g_sharedR, const double *__restrict__ g_sharedR2 = nullptr,
+                       const double *__restrict__ g_sharediC = nullptr)
 {
     extern __shared__ double X[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
@@ -1120,7 +1142,10 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
             if (m) drtries += 1;
             double *z2_t = zn_t;                          // stage-2 normals: the "next" buffer is still free
             gen_normals(g, z2_t, lane, d, m);
-            if (E.usesvd) gemvN_panels(E.R2f + (size_t)tile * d * d * 64, z2_t, c2_t, theta_t, lane, d, m);
+            if (POOLED) {                                 // one R2 for every chain; lanes that did not draw compute on stale normals and are not looked at
+                if (E.usesvd) gemvN_shared(g_sharedR2, z2_t, c2_t, theta_t, lane, d); else trmv_shared(g_sharedR2, z2_t, c2_t, theta_t, lane, d);
+            }
+            else if (E.usesvd) gemvN_panels(E.R2f + (size_t)tile * d * d * 64, z2_t, c2_t, theta_t, lane, d, m);
             else trmv_panels<true>(E.R2 + (size_t)tile * E.P * 64, z2_t, c2_t, theta_t, lane, d, m);
             if (m) {
                 bool inb2 = target_inbounds(E.tgt, d, lane, c2_t);
@@ -1133,11 +1158,11 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
                     if (alpha12 == 0.0) alpha32 = 0.0;
                     else alpha32 = min1(d_exp(-0.5 * ((ss2 - ss3) / sigma2 + (pri2 - pri3))));
                     double l2 = -0.5 * ((ss3 - ss1) / sigma2 + (pri3 - pri1));
-                    const double *iCt = E.iC + (size_t)tile * E.P * 64;
+                    const double *iCt = POOLED ? nullptr : E.iC + (size_t)tile * E.P * 64;
                     for (int k = 0; k < d; ++k) XL(k) = GV(c2_t, k) - GV(cand_t, k);
-                    double qa = quadform_sym(iCt, lane, d, X, Y);
+                    double qa = POOLED ? quadform_sym_shared(g_sharediC, lane, d, X, Y) : quadform_sym(iCt, lane, d, X, Y);
                     for (int k = 0; k < d; ++k) XL(k) = GV(theta_t, k) - GV(cand_t, k);
-                    double qb = quadform_sym(iCt, lane, d, X, Y);
+                    double qb = POOLED ? quadform_sym_shared(g_sharediC, lane, d, X, Y) : quadform_sym(iCt, lane, d, X, Y);
                     double q1 = -0.5 * (qa - qb);
                     double alpha13 = min1(d_exp(l2 + q1) * (1.0 - alpha32) / (1.0 - alpha12));
                     bool rej2 = true;
@@ -1213,6 +1238,14 @@ __global__ __launch_bounds__(64, (RAM || DR || POOLED) ? 2 : MCX_AM_WAVES) void 
                                                      const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
                                                      const double *__restrict__ g_sharedR)
 { step_body<RAM, DR, POOLED, (RAM || (!DR && !POOLED && MCX_AM_WIDE))>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
+
+// pooled mode with delayed rejection: the shared factor, its second-stage copy R2 = R / drscale and the shared inverse
+// covariance iC = dpotri(R) all come through the scalar cache (the host recomputes the three at every pooled tick)
+__global__ __launch_bounds__(64, 2) void step_kernel_pooled_dr(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
+                                                               const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
+                                                               const double *__restrict__ g_sharedR, const double *__restrict__ g_sharedR2,
+                                                               const double *__restrict__ g_sharediC)
+{ step_body<false, true, true, false>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR, g_sharedR2, g_sharediC); }
 
 // method='ram' with condmax > 0: the factor is the full SVD one (E.Rf), proposals are matmulx(R,u), the rank-one
 // adaptation runs on its upper triangle (ram_update_full)

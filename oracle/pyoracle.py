@@ -241,6 +241,13 @@ class LiveChain:
         view = np.ctypeslib.as_array(self.ch.contents.R, shape=(self.n, self.n))      # view[j, i] = R(i, j)
         view[:, :] = np.asarray(R, dtype=np.float64).T
 
+    def set_dr(self, R2, iC):
+        """delayed rejection: the second-stage factor R2[i, j] and the inverse covariance iC[i, j] (upper triangles)."""
+        v2 = np.ctypeslib.as_array(self.ch.contents.R2, shape=(self.n, self.n))
+        v2[:, :] = np.asarray(R2, dtype=np.float64).T
+        vi = np.ctypeslib.as_array(self.ch.contents.iC, shape=(self.n, self.n))
+        vi[:, :] = np.asarray(iC, dtype=np.float64).T
+
     def set_qcovstd(self, std):
         """SCAM: the proposal standard deviations along the rotated axes."""
         np.ctypeslib.as_array(self.ch.contents.qcovstd, shape=(self.n,))[:] = np.asarray(std, dtype=np.float64)
@@ -261,6 +268,18 @@ class LiveChain:
     @property
     def stayed(self):
         return int(self.ch.contents.stayed)
+
+    @property
+    def drtries(self):
+        return int(self.ch.contents.drtries)
+
+    @property
+    def draccepted(self):
+        return int(self.ch.contents.draccepted)
+
+    @property
+    def erstayed(self):
+        return int(self.ch.contents.erstayed)
 
     @property
     def accepted(self):

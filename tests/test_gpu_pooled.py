@@ -322,9 +322,9 @@ def test_pooled_am_matrix_core_kernel_sizes(oracle, d, monkeypatch):
 
 
 # ---------------------------------------------------------------- pooled burn-in scaling / greedy / AP / RAM
-def _init_state(oracle, d, par0, cmat0, initcmatn):
+def _init_state(oracle, d, par0, cmat0, initcmatn, drscale=0.0):
     st = {"W": float(initcmatn), "C": {(i, j): float(cmat0[i, j]) for j in range(d) for i in range(j + 1)},
-          "mean": [float(v) for v in par0]}
+          "mean": [float(v) for v in par0], "drscale": float(drscale)}
     return _factor(oracle, st, d)
 
 
@@ -336,6 +336,11 @@ def _factor(oracle, st, d):
     if oracle.lib().mcxo_potrf_u(d, A.ctypes.data_as(C.POINTER(C.c_double))) == 0:
         sq = math.sqrt(float(d))
         st["R"] = np.array([[A[i, j] * 2.4 / sq if i <= j else 0.0 for j in range(d)] for i in range(d)])
+        if st.get("drscale", 0.0) > 0.0:                 # pooled_upload_dr: R2 = R / drscale, iC = dpotri('U', R)
+            st["R2"] = st["R"] / st["drscale"]
+            B = np.asfortranarray(st["R"].copy())
+            assert oracle.lib().mcxo_potri_u(d, B.ctypes.data_as(C.POINTER(C.c_double))) == 0
+            st["iC"] = np.triu(B)
     return st
 
 
@@ -363,11 +368,12 @@ def _restate_pooled(oracle, ckw, pkw, N, nranks=1):
     """The engine's pooled_tick, tick by tick, on N single-chain oracles that never adapt on their own."""
     d = int(pkw["npar"])
     cfg = oracle.make_cfg(**ckw)
-    plain = oracle.make_cfg(**dict(ckw, doadapt=0, doburnin=0, method="dram"))
+    plain = oracle.make_cfg(**dict(ckw, doadapt=0, doburnin=0, method="er" if ckw.get("method") == "er" else "dram"))
     prob = oracle.Problem(**pkw)
     chains = [oracle.LiveChain(plain, prob, chain_id=c) for c in range(N)]
     par0, cmat0 = np.asarray(pkw["par0"], float), np.asarray(pkw["cmat0"], float).reshape(d, d)
-    st = _init_state(oracle, d, par0, cmat0, cfg.initcmatn)
+    dr = cfg.drscale if cfg.drscale > 0.0 and ckw.get("method") != "er" else 0.0
+    st = _init_state(oracle, d, par0, cmat0, cfg.initcmatn, dr)
     badapt = cfg.badaptint if cfg.badaptint > 0 else cfg.adaptint
     log = []
     for it in range(2, cfg.nsimu + 1):
@@ -389,8 +395,10 @@ def _restate_pooled(oracle, ckw, pkw, N, nranks=1):
             sf = cfg.scalefactor
             if staypc > 1.0 - cfg.scalelimit:
                 st["R"] = st["R"] / sf; log.append((it, "down"))
+                if dr > 0.0: st["R2"] = st["R2"] / sf; st["iC"] = st["iC"] * sf * sf
             elif staypc < cfg.scalelimit:
                 st["R"] = st["R"] * sf; log.append((it, "up"))
+                if dr > 0.0: st["R2"] = st["R2"] * sf; st["iC"] = st["iC"] / sf / sf
             else:
                 if cfg.greedy:
                     st.update(W=float(cfg.initcmatn), C={(i, j): float(cmat0[i, j]) for j in range(d) for i in range(j + 1)},
@@ -405,6 +413,7 @@ def _restate_pooled(oracle, ckw, pkw, N, nranks=1):
             st = _factor(oracle, st, d); log.append((it, "ap" if cfg.adapthist > 1 else "am"))
         for ch in chains:
             ch.set_R(st["R"])
+            if dr > 0.0: ch.set_dr(st["R2"], st["iC"])
     for ch in chains:
         ch.run(cfg.nsimu)
     return chains, st, log
@@ -438,6 +447,54 @@ def test_pooled_burnin_greedy_ap_match_restatement(oracle, name, extra, c0):
     assert W == st["W"]
     np.testing.assert_array_equal(_bits(np.triu(R)), _bits(np.triu(st["R"])))
     np.testing.assert_array_equal(_bits(mean), _bits(np.array(st["mean"])))
+    for ch in chains:
+        ch.close()
+    e.close()
+
+
+@pytest.mark.parametrize("name,extra,c0,kind", [
+    ("dr_am", dict(drscale=2.0), 0.3, "gauss"),                                                          # second stage with the shared R2, iC
+    ("dr_banana", dict(drscale=3.0), 1.0, "banana"),
+    ("dr_scale_down", dict(drscale=2.0, doburnin=1, burnintime=260, badaptint=50, scalelimit=0.3), 400.0, "gauss"),   # R2 / sf, iC * sf * sf
+    ("dr_scale_up", dict(drscale=2.0, doburnin=1, burnintime=260, badaptint=50, scalelimit=0.3), 1e-6, "gauss"),
+    ("dr_updatesigma", dict(drscale=2.0, updatesigma=1), 0.3, "gauss"),
+    ("er", dict(method="er"), 0.05, "gauss"),                                                            # MCMC_run_er with the shared factor
+    ("er_updatesigma", dict(method="er", updatesigma=1), 0.05, "gauss"),
+])
+def test_pooled_delayed_rejection_and_er_match_restatement(oracle, name, extra, c0, kind):
+    """pooled = 1 with drscale > 0 (one R2 = R / drscale and one iC = dpotri(R) for every chain, recomputed at each pooled
+    tick, scaled in place by the burn-in branch as MCMC_adapt.F90:66-78 does) and with method = 'er'."""
+    from mcmcf90_amd import engine_from_problem
+    d, N, nsimu = 5, 130, 420
+    ckw = dict(dict(nsimu=nsimu, adaptint=100, updatesigma=0), **extra)
+    S = 0.5 ** np.abs(np.subtract.outer(np.arange(d), np.arange(d)))
+    if kind == "gauss":
+        pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.3), cmat0=c0 * np.eye(d), mu=np.linspace(-1, 1, d), lam=np.linalg.inv(S))
+    else:
+        pkw = dict(kind="banana", npar=d, par0=np.zeros(d), cmat0=c0 * np.eye(d), b=0.1)
+    e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
+    e.init(); e.run()
+    chains, st, log = _restate_pooled(oracle, ckw, pkw, N)
+    kinds = {k for _, k in log}
+    if "scale_down" in name: assert "down" in kinds, log
+    if "scale_up" in name: assert "up" in kinds, log
+    theta = np.array([ch.theta for ch in chains])
+    np.testing.assert_array_equal(_bits(e.theta()), _bits(theta), err_msg=str(log))
+    for c in (0, 63, 64, N - 1):
+        np.testing.assert_array_equal(e.accepted(c), chains[c].accepted)
+    cm, mean, W, R = e.pooled()
+    np.testing.assert_array_equal(_bits(np.triu(R)), _bits(np.triu(st["R"])))
+    tot = e.totals()
+    if "dr" in name:
+        R2, iC = e.dr_state(0)
+        np.testing.assert_array_equal(_bits(np.triu(R2)), _bits(np.triu(st["R2"])))
+        np.testing.assert_array_equal(_bits(np.triu(iC)), _bits(np.triu(st["iC"])))
+        assert tot["drtries"] == sum(ch.drtries for ch in chains) and tot["drtries"] > 0
+        assert tot["draccepted"] == sum(ch.draccepted for ch in chains) and tot["draccepted"] > 0
+    else:
+        for c in (0, 63, 64, N - 1):
+            assert e.counters(c)["erstayed"] == chains[c].erstayed
+    assert tot["stayed"] == sum(ch.stayed for ch in chains)
     for ch in chains:
         ch.close()
     e.close()
@@ -509,8 +566,9 @@ def test_pooled_ram_matches_restatement(oracle, d, N, mfma, monkeypatch):
     e.close()
 
 
-@pytest.mark.parametrize("mfma,condmax,burn", [(1, 1e8, 0), (0, 1e8, 0), (1, 40.0, 0), (0, 40.0, 1)])
-def test_pooled_am_with_svd_factor_matches_restatement(oracle, mfma, condmax, burn, monkeypatch):
+@pytest.mark.parametrize("mfma,condmax,burn,drscale", [(1, 1e8, 0, 0.0), (0, 1e8, 0, 0.0), (1, 40.0, 0, 0.0), (0, 40.0, 1, 0.0),
+                                                       (0, 1e8, 0, 2.0), (0, 40.0, 1, 2.0)])     # + delayed rejection: R2 full, iC from R's upper triangle
+def test_pooled_am_with_svd_factor_matches_restatement(oracle, mfma, condmax, burn, drscale, monkeypatch):
     """pooled = 1 with condmax > 0 (method dram): the shared factor is covtor_svd's full matrix U sqrt(s) 2.4/sqrt(d)
     (matutils.F90:378-453) of the pooled covariance, proposals are matmulx(R, z); condmax = 40 makes the singular-value
     floor bite, after which the covariance itself is replaced by R0 R0' (info = -1 branch)."""
@@ -518,7 +576,7 @@ def test_pooled_am_with_svd_factor_matches_restatement(oracle, mfma, condmax, bu
     if not mfma:
         monkeypatch.setenv("MCMCX_POOLED_SCALAR", "1")
     d, N, nsimu = 6, 140, 330
-    ckw = dict(nsimu=nsimu, adaptint=100, updatesigma=0, condmax=condmax)
+    ckw = dict(nsimu=nsimu, adaptint=100, updatesigma=0, condmax=condmax, drscale=drscale)
     if burn:
         ckw.update(doburnin=1, burnintime=160, badaptint=40, scalelimit=0.3)
     lam = np.diag(10.0 ** np.linspace(-1.5, 1.5, d))            # posterior variances over three decades
@@ -557,6 +615,11 @@ def test_pooled_am_with_svd_factor_matches_restatement(oracle, mfma, condmax, bu
             st["C"] = newC
         sqd = math.sqrt(float(d))
         st["R"] = np.array([[R0[i, j] * 2.4 / sqd for j in range(d)] for i in range(d)])
+        if drscale > 0.0:
+            st["R2"] = st["R"] / drscale
+            B = np.asfortranarray(np.triu(st["R"]))
+            assert oracle.lib().mcxo_potri_u(d, B.ctypes.data_as(DP)) == 0
+            st["iC"] = np.triu(B)
         return st
 
     st = {"W": 0.0, "C": {(i, j): float(cmat0[i, j]) for j in range(d) for i in range(j + 1)}, "mean": [float(v) for v in par0]}
@@ -575,10 +638,13 @@ def test_pooled_am_with_svd_factor_matches_restatement(oracle, mfma, condmax, bu
         cnt, s1, s2 = _pooled_moments(theta, par0, N)
         if burn_tick:
             staypc = float(sum(ch.stayed for ch in chains)) / (cnt * float(it))
+            sf = cfg.scalefactor
             if staypc > 1.0 - cfg.scalelimit:
-                st["R"] = st["R"] / cfg.scalefactor
+                st["R"] = st["R"] / sf
+                if drscale > 0.0: st["R2"] = st["R2"] / sf; st["iC"] = st["iC"] * sf * sf
             elif staypc < cfg.scalelimit:
-                st["R"] = st["R"] * cfg.scalefactor
+                st["R"] = st["R"] * sf
+                if drscale > 0.0: st["R2"] = st["R2"] * sf; st["iC"] = st["iC"] / sf / sf
             else:
                 st = svd_factor(st, it)
         else:
@@ -588,8 +654,14 @@ def test_pooled_am_with_svd_factor_matches_restatement(oracle, mfma, condmax, bu
             st = svd_factor(st, it)
         for ch in chains:
             ch.set_R(st["R"])
+            if drscale > 0.0: ch.set_dr(st["R2"], st["iC"])
     for ch in chains:
         ch.run(nsimu)
+    if drscale > 0.0:
+        R2, iC = e.dr_state(0)
+        np.testing.assert_array_equal(_bits(R2), _bits(st["R2"]))
+        np.testing.assert_array_equal(_bits(np.triu(iC)), _bits(np.triu(st["iC"])))
+        assert e.totals()["drtries"] == sum(ch.drtries for ch in chains) > 0
     if condmax < 100:
         assert floored_ticks, "the floor never bit: the case does not test what it is about"
     theta = np.array([ch.theta for ch in chains])
