@@ -24,6 +24,7 @@
  *   mcmcx_get_chain         chain / sschain / s2chain module arrays          mcmc.F90:31-33, MCMC_aux.F90:167-185
  *   mcmcx_get_chaincov      chaincmat / chainmean / chainwsum                mcmc.F90:38-40
  *   mcmcx_get_counters      stayed, bndstayed, draccepted, drtries           mcmc.F90:46-55
+ *   mcmcx_run1_*            the arithmetic of one MCMC_run1 / MCMC_run1_er call  MCMC_run1.F90:131-199, MCMC_run1_er.F90:122-182
  *
  * N independent chains run at once; chain c draws from the Philox4x32-10 stream
  * keyed (seed, chain_id0 + c) and, in the default "replicas" mode, is the
@@ -119,6 +120,25 @@ int mcmcx_init(mcmcx_handle h);
  * MCMC_signal_handler.F90:95-107) */
 int mcmcx_run(mcmcx_handle h, int32_t upto);
 int mcmcx_sync(mcmcx_handle h);
+
+/* ---- MCMC_run1 / MCMC_run1_er (mcmc_main_one, mcmc_main.F90:49-70): one evaluation of ssfunction per program
+ * invocation, the chain's state carried in files between invocations (MCMC_run1.F90:14-29).  The file protocol is the
+ * host's (the Fortran shim's mcmc_main_one); what is arithmetic in one invocation runs here, on the factors of
+ * mcmcx_init (R, R2 = R/drscale, iC) and the chain's stream.  mcmcx_set_target_external declares that EVERY
+ * evaluation of ssfunction / priorfun / checkbounds is the caller's -- mcmcx_init evaluates nothing, mcmcx_run refuses.
+ * All chains at once; vectors are row-major per chain ([nchains][npar], [nchains][nycol], [nchains]).
+ *   mcmcx_run1_decide   alpha = MCMC_alpha(oldpar1 -> newpar) in stage 1 (MCMC_run1.F90:141), or
+ *                       MCMC_DR_alpha13(oldpar2, oldpar1, newpar) in stage 2 with drscale > 0 (:137-139; oldpar2 =
+ *                       the current point, oldpar1 = the rejected first try); then reject = MCMC_reject(alpha) (:143).
+ *                       The stage-2 arguments may be NULL in stage 1.
+ *   mcmcx_run1_propose  newpar = MCMC_propose(from, R) (stage 1) or (from, R2) (stage 2 with drscale > 0) (:185-189)
+ *   mcmcx_run1_sscrit   sscrit = MCMC_sscrit(ssprev1, sspri1) = -2 log u + sum(ss/sigma2) + pri  (MCMC_run1_er.F90:168) */
+int mcmcx_set_target_external(mcmcx_handle h);
+int mcmcx_run1_decide(mcmcx_handle h, int32_t drstage, const double *oldpar2, const double *ssprev2, const double *sspri2,
+                      const double *oldpar1, const double *ssprev1, const double *sspri1, const double *alpha12,
+                      const double *newpar, const double *ss, const double *sspri, double *alpha_out, int32_t *reject_out);
+int mcmcx_run1_propose(mcmcx_handle h, int32_t stage, const double *from, double *newpar_out);
+int mcmcx_run1_sscrit(mcmcx_handle h, const double *ssprev1, const double *sspri1, double *sscrit_out);
 #define MCMCX_INTERRUPTED 2
 /* SIGHUP, SIGINT, SIGTERM, SIGTSTP, SIGUSR1, SIGUSR2 (the set of signalqq.c:57-62) raise a flag that mcmcx_run
  * polls between kernel launches; mcmcx_interrupted() reads it, mcmcx_clear_interrupt() resets it */

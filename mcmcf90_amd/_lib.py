@@ -95,6 +95,11 @@ SYMBOLS["mcmcx_set_comm"] = (C.c_int, [C.c_void_p, C.c_void_p])
 SYMBOLS["mcmcx_allreduce_moments"] = (C.c_int, [C.c_void_p, _DP])
 SYMBOLS["mcmcx_allreduce_moments_all"] = (C.c_int, [_HP, C.c_int32, _DP])
 SYMBOLS["mcmcx_run_all"] = (C.c_int, [_HP, C.c_int32, C.c_int32])
+# MCMC_run1 / MCMC_run1_er: the arithmetic of one invocation (the caller evaluates the target)
+SYMBOLS["mcmcx_set_target_external"] = (C.c_int, [C.c_void_p])
+SYMBOLS["mcmcx_run1_decide"] = (C.c_int, [C.c_void_p, C.c_int32, _DP, _DP, _DP, _DP, _DP, _DP, _DP, _DP, _DP, _DP, _DP, _IP])
+SYMBOLS["mcmcx_run1_propose"] = (C.c_int, [C.c_void_p, C.c_int32, _DP, _DP])
+SYMBOLS["mcmcx_run1_sscrit"] = (C.c_int, [C.c_void_p, _DP, _DP, _DP])
 
 _lib = None
 

@@ -69,6 +69,7 @@ struct mcmcx_engine {
     double *d_ramscale = nullptr, *d_moments = nullptr;
     double *d_Gc = nullptr, *d_Vc = nullptr, *d_svc = nullptr; uint8_t *d_need = nullptr, *d_state = nullptr; int *d_anyrot = nullptr; int svd_b = 0;    // blocked SVD of the adaptation (large npar)
     int wcap = 0;
+    bool external = false; double *d_r1 = nullptr; std::vector<double> h_r1;      // MCMC_run1: the caller evaluates; exchange vectors of run1_kernel
     // timing of the step kernel
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double ms_total = 0.0; long long launches = 0, steps = 0;
@@ -802,6 +803,42 @@ static int host_iteration(mcmcx_engine *h, int it)
     return 0;
 }
 
+// ---- MCMC_run1 / MCMC_run1_er: the arithmetic of one invocation (run1_kernel), all chains at once, vectors row-major per chain
+static int run1_check(mcmcx_engine *h)
+{
+    if (!h) return fail(-1, "null handle");
+    if (!h->inited) return fail(-40, "we have not inited");                           // MCMC_run1.F90:55
+    if (!h->external) return fail(-42, "mcmcx_run1_*: needs mcmcx_set_target_external (the caller evaluates ssfunction / priorfun / checkbounds)");
+    return 0;
+}
+static void run1_put(mcmcx_engine *h, int slot0, int K, const double *src /* [nchains][K] or nullptr */)
+{
+    const int n1 = 3 * h->d + 3 * h->ny + NR1;
+    for (int c = 0; c < h->cfg.nchains; ++c) {
+        const int t = c / 64, l = c % 64;
+        for (int k = 0; k < K; ++k) h->h_r1[((size_t)t * n1 + slot0 + k) * 64 + l] = src ? src[(size_t)c * K + k] : 0.0;
+    }
+}
+static void run1_get(mcmcx_engine *h, int slot0, int K, double *dst)
+{
+    const int n1 = 3 * h->d + 3 * h->ny + NR1;
+    for (int c = 0; c < h->cfg.nchains; ++c) {
+        const int t = c / 64, l = c % 64;
+        for (int k = 0; k < K; ++k) dst[(size_t)c * K + k] = h->h_r1[((size_t)t * n1 + slot0 + k) * 64 + l];
+    }
+}
+template <int MODE>
+static int run1_launch(mcmcx_engine *h, int drstage)
+{
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipMemcpyAsync(h->d_r1, h->h_r1.data(), h->h_r1.size() * 8, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL((run1_kernel<MODE>), dim3(h->ntiles), dim3(64), MODE == 0 ? lds_bytes(h) : 0, h->stream, h->E, h->d_r1, drstage);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h->h_r1.data(), h->d_r1, h->h_r1.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 // ------------------------------------------------------------------ C ABI
 extern "C" {
 
@@ -955,6 +992,15 @@ int mcmcx_set_target_host_batch(mcmcx_handle h, mcmcx_ssfun_batch_t ss_batch, mc
     if (h->inited) return fail(-20, "set the target before mcmcx_init");
     h->tkind = TGT_HOST; h->h_ss_batch = ss_batch; h->h_ss = nullptr; h->h_pri = pri; h->h_cb = cb; h->h_user = user;
     h->h_threads = nthreads < 1 ? 1 : nthreads;
+    return 0;
+}
+
+int mcmcx_set_target_external(mcmcx_handle h)
+{
+    if (!h) return fail(-1, "null handle");
+    if (h->inited) return fail(-2, "mcmcx_set_target_external after mcmcx_init");
+    h->tkind = TGT_HOST; h->h_ss = nullptr; h->h_ss_batch = nullptr; h->h_pri = nullptr; h->h_cb = nullptr; h->h_user = nullptr;
+    h->external = true;
     return 0;
 }
 
@@ -1223,7 +1269,10 @@ int mcmcx_init(mcmcx_handle h)
             if ((rc = dev_bcast(h, E.mean, h->par0))) return rc;
         }
     }
-    if (phased(h)) {                                    // first point: sspri1, ss1 from the callbacks (MCMC_run.F90:35-36)
+    if (h->external) {                                  // MCMC_run1: every evaluation is the caller's, the first one included
+        if (h->pooled) return fail(-8, "mcmcx_set_target_external: not in pooled mode");
+        if ((rc = dev_alloc(h, &h->d_r1, L * (size_t)(3 * d + 3 * ny + NR1)))) return rc;
+    } else if (phased(h)) {                             // first point: sspri1, ss1 from the callbacks (MCMC_run.F90:35-36)
         int rc2 = host_eval(h, E.theta, d, false);
         if (rc2) return rc2;
     }
@@ -1256,6 +1305,7 @@ int mcmcx_run(mcmcx_handle h, int32_t upto)
 {
     if (!h) return fail(-1, "null handle");
     if (!h->inited) return fail(-40, "we have not inited");                           // MCMC_run.F90:22
+    if (h->external) return fail(-41, "mcmcx_run: the target is external (mcmcx_set_target_external): drive the chain with mcmcx_run1_*");
     HIPCHK(hipSetDevice(h->cfg.device));
     const mcmcx_config &c = h->cfg;
     if (upto > c.nsimu) upto = c.nsimu;
@@ -1304,6 +1354,53 @@ int mcmcx_run(mcmcx_handle h, int32_t upto)
         if (h->pending.size() > 4096) { int rc = mcmcx_sync(h); if (rc) return rc; }
     }
     h->simuind = std::max(h->simuind, (int)upto);
+    return 0;
+}
+
+int mcmcx_run1_decide(mcmcx_handle h, int32_t drstage, const double *oldpar2, const double *ssprev2, const double *sspri2,
+                      const double *oldpar1, const double *ssprev1, const double *sspri1, const double *alpha12,
+                      const double *newpar, const double *ss, const double *sspri, double *alpha_out, int32_t *reject_out)
+{
+    int rc = run1_check(h); if (rc) return rc;
+    if (!oldpar1 || !ssprev1 || !sspri1 || !newpar || !ss || !sspri || !alpha_out || !reject_out) return fail(-1, "mcmcx_run1_decide: null argument");
+    const bool dr2 = drstage > 1 && h->dodr;
+    if (dr2 && (!oldpar2 || !ssprev2 || !sspri2 || !alpha12)) return fail(-1, "mcmcx_run1_decide: the second stage needs oldpar2, ssprev2, sspri2, alpha12");
+    const int d = h->d, ny = h->ny, n = h->cfg.nchains, s0 = 3 * d + 3 * ny;
+    h->h_r1.assign((size_t)h->ntiles * 64 * (s0 + NR1), 0.0);
+    run1_put(h, 0, d, dr2 ? oldpar2 : nullptr); run1_put(h, d, d, oldpar1); run1_put(h, 2 * d, d, newpar);
+    run1_put(h, 3 * d, ny, dr2 ? ssprev2 : nullptr); run1_put(h, 3 * d + ny, ny, ssprev1); run1_put(h, 3 * d + 2 * ny, ny, ss);
+    run1_put(h, s0 + R1_PRI2, 1, dr2 ? sspri2 : nullptr); run1_put(h, s0 + R1_PRI1, 1, sspri1); run1_put(h, s0 + R1_PRI, 1, sspri);
+    run1_put(h, s0 + R1_A12, 1, dr2 ? alpha12 : nullptr);
+    if ((rc = run1_launch<0>(h, drstage))) return rc;
+    run1_get(h, s0 + R1_ALPHA, 1, alpha_out);
+    std::vector<double> rj(n);
+    run1_get(h, s0 + R1_REJECT, 1, rj.data());
+    for (int c = 0; c < n; ++c) reject_out[c] = rj[c] != 0.0 ? 1 : 0;
+    return 0;
+}
+
+int mcmcx_run1_propose(mcmcx_handle h, int32_t stage, const double *from, double *newpar_out)
+{
+    int rc = run1_check(h); if (rc) return rc;
+    if (!from || !newpar_out) return fail(-1, "mcmcx_run1_propose: null argument");
+    const int d = h->d, ny = h->ny;
+    h->h_r1.assign((size_t)h->ntiles * 64 * (3 * d + 3 * ny + NR1), 0.0);
+    run1_put(h, 0, d, from);
+    if (stage > 1 && h->dodr) rc = run1_launch<2>(h, 2); else rc = run1_launch<1>(h, 1);
+    if (rc) return rc;
+    run1_get(h, 2 * d, d, newpar_out);
+    return 0;
+}
+
+int mcmcx_run1_sscrit(mcmcx_handle h, const double *ssprev1, const double *sspri1, double *sscrit_out)
+{
+    int rc = run1_check(h); if (rc) return rc;
+    if (!ssprev1 || !sspri1 || !sscrit_out) return fail(-1, "mcmcx_run1_sscrit: null argument");
+    const int d = h->d, ny = h->ny, s0 = 3 * d + 3 * ny;
+    h->h_r1.assign((size_t)h->ntiles * 64 * (s0 + NR1), 0.0);
+    run1_put(h, 3 * d + ny, ny, ssprev1); run1_put(h, s0 + R1_PRI1, 1, sspri1);
+    if ((rc = run1_launch<3>(h, 1))) return rc;
+    run1_get(h, s0 + R1_CRIT, 1, sscrit_out);
     return 0;
 }
 

@@ -2042,6 +2042,75 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
     lane_store(E, tile, lane, L);
 }
 
+// ---------------------------------------------------------------- MCMC_run1 / MCMC_run1_er: one evaluation per invocation
+// The reference's file protocol (MCMC_run1.F90:31-256, MCMC_run1_er.F90:28-234) keeps the chain's state in files between
+// program runs; what is arithmetic in it -- the acceptance probability of the point just evaluated, MCMC_reject's draw,
+// the next proposal, early rejection's threshold -- runs here, on the engine's factors (R, R2, iC of mcmcx_init) and
+// the chain's stream.  The caller's vectors travel in r1, tile-interleaved like everything else:
+//   [0,d) the current point (oldpar2; `from` of a proposal)   [d,2d) oldpar1   [2d,3d) newpar (a proposal's result)
+//   then ny each: ssprev2, ssprev1, ss;  then the scalars below.
+enum { R1_PRI2 = 0, R1_PRI1, R1_PRI, R1_A12, R1_ALPHA, R1_REJECT, R1_CRIT, R1_SPARE, NR1 };
+MCX_DEV int r1_len(int d, int ny) { return 3 * d + 3 * ny + NR1; }
+// MODE 0: alpha = MCMC_alpha(oldpar1 -> newpar) (drstage 1, MCMC_run1.F90:141) or MCMC_DR_alpha13(oldpar2, oldpar1,
+//         newpar) (drstage 2, :137-139), then MCMC_reject(alpha) (:143)
+// MODE 1 / 2: newpar = MCMC_propose(from, R) / (from, R2)  (:185-189)
+// MODE 3: sscrit = MCMC_sscrit(ssprev1, sspri1) (MCMC_run1_er.F90:168; MCMC_DRAM.F90:124-135)
+template <int MODE>
+__global__ __launch_bounds__(64) void run1_kernel(EngineDev E, double *r1, int drstage)
+{
+    extern __shared__ double X[];
+    const int lane = threadIdx.x, tile = blockIdx.x, d = E.d, ny = E.ny;
+    double *b = r1 + (size_t)tile * r1_len(d, ny) * 64;
+    double *cur_t = b, *old1_t = b + (size_t)d * 64, *new_t = b + (size_t)2 * d * 64;
+    double *ssp2 = b + (size_t)3 * d * 64, *ssp1 = ssp2 + (size_t)ny * 64, *ssn = ssp1 + (size_t)ny * 64;
+    double *sc = ssn + (size_t)ny * 64;
+    const double *s2v = ny > 1 ? E.s2v + (size_t)tile * ny * 64 : nullptr;
+    double *zs_t = E.zs + (size_t)tile * 2 * d * 64;
+    double *Y = X + (size_t)d * 64;
+    LaneState L;
+    lane_load(E, tile, lane, L);
+    if (MODE == 0) {
+        const double pri1 = GV(sc, R1_PRI1), pri = GV(sc, R1_PRI);
+        double alpha;
+        if (drstage > 1 && E.dodr) {                      // MCMC_DR_alpha13, MCMC_DRAM.F90:162-186: 1 = oldpar2, 2 = oldpar1, 3 = newpar
+            const double pri2c = GV(sc, R1_PRI2), alpha12 = GV(sc, R1_A12);
+            double alpha32, l2;
+            if (ny > 1) {
+                if (alpha12 == 0.0) alpha32 = 0.0;
+                else alpha32 = min1(d_exp(-0.5 * (colsum_diff(ssp1, ssn, s2v, ny, lane) + (pri1 - pri))));
+                l2 = -0.5 * (colsum_diff(ssn, ssp2, s2v, ny, lane) + (pri - pri2c));
+            } else {
+                if (alpha12 == 0.0) alpha32 = 0.0;
+                else alpha32 = min1(d_exp(-0.5 * ((GV(ssp1, 0) - GV(ssn, 0)) / L.sigma2 + (pri1 - pri))));
+                l2 = -0.5 * ((GV(ssn, 0) - GV(ssp2, 0)) / L.sigma2 + (pri - pri2c));
+            }
+            const double *iCt = E.iC + (size_t)tile * E.P * 64;
+            for (int k = 0; k < d; ++k) XL(k) = GV(new_t, k) - GV(old1_t, k);
+            double qa = quadform_sym(iCt, lane, d, X, Y);
+            for (int k = 0; k < d; ++k) XL(k) = GV(cur_t, k) - GV(old1_t, k);
+            double qb = quadform_sym(iCt, lane, d, X, Y);
+            double q1 = -0.5 * (qa - qb);
+            alpha = min1(d_exp(l2 + q1) * (1.0 - alpha32) / (1.0 - alpha12));
+        } else {
+            alpha = ny > 1 ? d_alpha_cols(ssp1, pri1, ssn, pri, s2v, ny, lane) : d_alpha(GV(ssp1, 0), pri1, GV(ssn, 0), pri, L.sigma2);
+        }
+        bool reject = true;                               // MCMC_reject, MCMC_DRAM.F90:140-155
+        if (alpha >= 1.0) reject = false;
+        else if (alpha > 0.0) { double u = rng_uniform(L.g); if (u <= alpha) reject = false; }
+        GV(sc, R1_ALPHA) = alpha; GV(sc, R1_REJECT) = reject ? 1.0 : 0.0;
+    } else if (MODE == 1 || MODE == 2) {
+        gen_normals(L.g, zs_t, lane, d, true);
+        if (E.usesvd) gemvN_panels((MODE == 2 ? E.R2f : E.Rf) + (size_t)tile * d * d * 64, zs_t, new_t, cur_t, lane, d, true);   // matmulx(R,z)
+        else trmv_panels<false>((MODE == 2 ? E.R2 : E.R) + (size_t)tile * E.P * 64, zs_t, new_t, cur_t, lane, d, true);
+    } else {
+        double u = rng_uniform(L.g);
+        double s1 = GV(ssp1, 0) / L.sigma2;
+        if (ny > 1) { s1 = 0.0; for (int j = 0; j < ny; ++j) s1 = s1 + GV(ssp1, j) / GV(s2v, j); }           // sum(ss1/sigma2)
+        GV(sc, R1_CRIT) = -2.0 * d_log(u) + s1 + GV(sc, R1_PRI1);
+    }
+    lane_store(E, tile, lane, L);
+}
+
 // ---------------------------------------------------------------- first point (MCMC_run.F90:33-39)
 // dst[(tile*K + e)*64 + lane] = src[e]: every chain starts from the same K-vector (par0, R(cmat0), ...)
 __global__ __launch_bounds__(64) void bcast_kernel(double *dst, const double *__restrict__ src, size_t K)

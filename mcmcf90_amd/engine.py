@@ -188,6 +188,34 @@ class Engine:
     def set_priors(self, mu, sig):
         self._chk(self.L.mcmcx_set_priors(self.h, _dp(_f64(mu)), _dp(_f64(sig))))
 
+    # --- mcmc_main_one: MCMC_run1 / MCMC_run1_er, the arithmetic of one invocation (MCMC_run1.F90:131-199); all chains at once
+    def set_target_external(self):
+        """Every evaluation of ssfunction / priorfun / checkbounds is the caller's: init evaluates nothing, run refuses."""
+        self._chk(self.L.mcmcx_set_target_external(self.h))
+
+    def _rows(self, a, k):
+        return None if a is None else np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64).reshape(-1, k), (self.nchains, k)))
+
+    def run1_decide(self, drstage, oldpar1, ssprev1, sspri1, newpar, ss, sspri, oldpar2=None, ssprev2=None, sspri2=None, alpha12=None):
+        """(alpha[nchains], reject[nchains]): MCMC_alpha(oldpar1 -> newpar) in stage 1, MCMC_DR_alpha13(oldpar2, oldpar1, newpar)
+        in stage 2 with drscale > 0, then MCMC_reject.  Vectors [nchains][npar] / [nchains][nycol] / [nchains] (or one row for all)."""
+        n, ny = self.npar, getattr(self, "nycol", 1)
+        A = [self._rows(oldpar2, n), self._rows(ssprev2, ny), self._rows(sspri2, 1), self._rows(oldpar1, n), self._rows(ssprev1, ny),
+             self._rows(sspri1, 1), self._rows(alpha12, 1), self._rows(newpar, n), self._rows(ss, ny), self._rows(sspri, 1)]
+        alpha = np.zeros(self.nchains); rej = np.zeros(self.nchains, dtype=np.int32)
+        self._chk(self.L.mcmcx_run1_decide(self.h, int(drstage), *[_dp(a) for a in A], _dp(alpha), rej.ctypes.data_as(C.POINTER(C.c_int32))))
+        return alpha, rej.astype(bool)
+
+    def run1_propose(self, stage, from_):
+        out = np.zeros((self.nchains, self.npar))
+        self._chk(self.L.mcmcx_run1_propose(self.h, int(stage), _dp(self._rows(from_, self.npar)), _dp(out)))
+        return out
+
+    def run1_sscrit(self, ssprev1, sspri1):
+        out = np.zeros(self.nchains)
+        self._chk(self.L.mcmcx_run1_sscrit(self.h, _dp(self._rows(ssprev1, getattr(self, "nycol", 1))), _dp(self._rows(sspri1, 1)), _dp(out)))
+        return out
+
     # --- mcmc_main
     def set_stream(self, hip_stream):
         """Run on the caller's HIP stream (e.g. torch.cuda.Stream().cuda_stream) instead of the engine's own; before init."""
@@ -321,6 +349,7 @@ def engine_from_problem(cfg_kw, prob_kw, nchains=1, **extra):
     npar = int(pk["npar"])
     extra = dict(extra)
     comm = extra.pop("comm", None)
+    external = extra.pop("external", False)          # MCMC_run1: the caller evaluates the target
     cfg = make_config(npar, nchains, **cfg_kw, **extra)
     e = Engine(cfg)
     if comm is not None:
@@ -328,6 +357,9 @@ def engine_from_problem(cfg_kw, prob_kw, nchains=1, **extra):
     e.setpar0(pk["par0"])
     e.setcmat0(np.asarray(pk["cmat0"], dtype=np.float64).reshape(npar, npar))
     e.setsigma2nobs(pk.get("sigma2", 1.0), pk.get("nobs", 1))
+    if external:
+        e.set_target_external()
+        return e
     e.set_target(str(pk["kind"]), mu=pk.get("mu"), lam=pk.get("lam"), b=float(pk.get("b", 0.1)),
                  xdata=pk.get("xdata"), ydata=pk.get("ydata"))
     if pk.get("lo") is not None or pk.get("hi") is not None:

@@ -317,6 +317,37 @@ module mcmcmod
        real(c_double), intent(out) :: out(*)
        integer(c_int) :: rc
      end function
+     function mcmcx_set_target_external(h) bind(C, name='mcmcx_set_target_external') result(rc)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: h
+       integer(c_int) :: rc
+     end function
+     function mcmcx_run1_decide(h, drstage, oldpar2, ssprev2, sspri2, oldpar1, ssprev1, sspri1, alpha12, newpar, ss, sspri, &
+          alpha, reject) bind(C, name='mcmcx_run1_decide') result(rc)
+       import :: c_ptr, c_int, c_int32_t, c_double
+       type(c_ptr), value :: h
+       integer(c_int32_t), value :: drstage
+       real(c_double), intent(in) :: oldpar2(*), ssprev2(*), sspri2(*), oldpar1(*), ssprev1(*), sspri1(*), alpha12(*)
+       real(c_double), intent(in) :: newpar(*), ss(*), sspri(*)
+       real(c_double), intent(out) :: alpha(*)
+       integer(c_int32_t), intent(out) :: reject(*)
+       integer(c_int) :: rc
+     end function
+     function mcmcx_run1_propose(h, stage, from, newpar) bind(C, name='mcmcx_run1_propose') result(rc)
+       import :: c_ptr, c_int, c_int32_t, c_double
+       type(c_ptr), value :: h
+       integer(c_int32_t), value :: stage
+       real(c_double), intent(in) :: from(*)
+       real(c_double), intent(out) :: newpar(*)
+       integer(c_int) :: rc
+     end function
+     function mcmcx_run1_sscrit(h, ssprev1, sspri1, crit) bind(C, name='mcmcx_run1_sscrit') result(rc)
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h
+       real(c_double), intent(in) :: ssprev1(*), sspri1(*)
+       real(c_double), intent(out) :: crit(*)
+       integer(c_int) :: rc
+     end function
   end interface
 
 contains
@@ -903,6 +934,337 @@ contains
     end if
   end subroutine MCMC_engine_run
 
+  !! ---------------------------------------------------------------- mcmc_main_one: MCMC_run1 / MCMC_run1_er
+  !! One evaluation of ssfunction per program invocation; the chain's state lives in files between invocations
+  !! (MCMC_run1.F90:14-29).  The files, the namelist /mcmcrun/ and the user's callbacks are the host's; the arithmetic
+  !! of an invocation -- MCMC_alpha / MCMC_DR_alpha13, MCMC_reject, MCMC_propose, MCMC_sscrit -- runs in the engine
+  !! (mcmcx_run1_*), one chain, on the factors of mcmcx_init (MCMC_init.F90:81-160: R, R2, iC of cmat0).
+  subroutine MCMC_engine_create_one()
+    type(mcmcx_config) :: cfg
+    integer(c_int32_t), allocatable :: nob(:)
+    call chk(mcmcx_install_signal_handlers())
+    call read_seed_file()
+    allocate(handles(1), comms(1))
+    handles = c_null_ptr; comms = c_null_ptr
+    call mcmcx_config_defaults(cfg)
+    cfg%npar = npar; cfg%nchains = 1; cfg%nsimu = nsimu
+    select case (trim(method))
+    case ('ram');  cfg%method = 1
+    case ('scam'); cfg%method = 2
+    case ('er');   cfg%method = 3
+    case default;  cfg%method = 0
+    end select
+    cfg%doadapt = doadapt; cfg%doburnin = doburnin; cfg%adaptint = adaptint; cfg%adapthist = adapthist
+    cfg%badaptint = badaptint; cfg%adaptend = adaptend; cfg%initcmatn = initcmatn
+    cfg%burnintime = burnintime; cfg%greedy = greedy; cfg%updatesigma = 0
+    cfg%scalelimit = scalelimit; cfg%scalefactor = scalefactor; cfg%drscale = drscale
+    cfg%N0 = N0; cfg%S02 = S02; cfg%condmax = condmax; cfg%alphatarget = alphatarget; cfg%nuparam = nuparam
+    cfg%seed = seed; cfg%record_accept = 0; cfg%record_chain = 0; cfg%pooled = 0; cfg%device = 0; cfg%chain_id0 = 0
+    allocate(nob(nycol)); nob = nobs
+    call chk(mcmcx_create(cfg, handles(1)))
+    handle = handles(1)
+    call chk(mcmcx_set_par0(handle, par0, int(npar, c_int32_t)))
+    call chk(mcmcx_set_cmat0(handle, cmat0, int(npar, c_int32_t)))
+    call chk(mcmcx_set_sigma2nobs(handle, sigma2, nob, int(nycol, c_int32_t)))
+    call chk(mcmcx_set_target_external(handle))          ! every evaluation is made here, by the user's functions
+    call chk(mcmcx_init(handle))
+    if (allocated(chaincmat)) deallocate(chaincmat, chainmean)
+    allocate(chaincmat(npar,npar), chainmean(npar))
+    chaincmat = cmat0; chainmean = par0; chainwsum = dble(initcmatn)      ! MCMC_init.F90:99-102
+    if (allocated(chain)) deallocate(chain, sschain)
+    allocate(chain(nsimu, npar+1), sschain(nsimu, nycol+1))
+    chain = 0.0_dbl; sschain = 0.0_dbl
+    stayed = 0; bndstayed = 0; draccepted = 0; drtries = 0; chainind = 0; simuind = 1
+  end subroutine MCMC_engine_create_one
+
+  subroutine touch_file(file)
+    character(len=*), intent(in) :: file
+    integer :: u, ios
+    open(newunit=u, file=file, status='replace', iostat=ios)
+    if (ios == 0) close(u)
+  end subroutine touch_file
+  subroutine remove_file(file)
+    character(len=*), intent(in) :: file
+    integer :: u, ios
+    logical :: ex
+    inquire(file=file, exist=ex)
+    if (.not. ex) return
+    open(newunit=u, file=file, status='old', iostat=ios)
+    if (ios == 0) close(u, status='delete')
+  end subroutine remove_file
+
+  !! MCMC_adapt(1) at the end of an invocation (MCMC_run1.F90:223): with simuind = 1 the schedule of
+  !! MCMC_adapt.F90:42-46 fires only for adaptint = 1 or badaptint = 1, on a "chain" of one row
+  subroutine run1_adapt_guard()
+    integer :: bad
+    bad = badaptint
+    if (bad <= 0) bad = adaptint
+    if ((doadapt /= 0 .or. doburnin /= 0) .and. (adaptint == 1 .or. bad == 1)) &
+         call doerror('mcmc_main_one: adaptint = 1 / badaptint = 1 (adaptation from a one-row chain) is not supported')
+  end subroutine run1_adapt_guard
+
+  !! MCMC_run1, MCMC_run1.F90:31-256
+  subroutine MCMC_run1()
+    use mcmcrun1
+    real(kind=dbl) :: ss(nycol), newpar(npar), sspri(1), alpha(1), a12(1)
+    real(kind=dbl) :: oldpar1(npar), oldpar2(npar), ssprev1(nycol), ssprev2(nycol), sspri1(1), sspri2(1), pad(npar)
+    integer(c_int32_t) :: rej(1)
+    logical :: reject, inbounds, dodr
+    integer :: fstat
+    integer(kind=4) :: n4, ny4
+    interface
+       function ssfunction(theta,npar,ny)
+         integer*4 npar, ny
+         real*8 theta(npar)
+         real*8 ssfunction(ny)
+       end function ssfunction
+       function priorfun(theta,len)
+         real*8 priorfun
+         integer*4 len
+         real*8 theta(len)
+       end function priorfun
+       function checkbounds(theta)
+         real*8 theta(:)
+         logical checkbounds
+       end function checkbounds
+    end interface
+    n4 = npar; ny4 = nycol
+    dodr = (drscale > 0.0_dbl) .and. trim(method) /= 'ram' .and. trim(method) /= 'scam'      ! mcmcinit.F90:303-322
+    if (updatesigma == 1) then
+       write(*,*) 'Warning: do not use updatesigma in ER!'
+       updatesigma = 0
+    end if
+    call run1_adapt_guard()
+    call read_mcmcrun_namelist()
+    reject = .false.
+    if (isimu == 1) then
+       if (verbosity >= 0) write(*,*) 'first simulation'
+       newpar = par0; oldpar1 = par0; oldpar2 = par0
+       sspri(1) = priorfun(newpar, n4)
+       ss = ssfunction(newpar, n4, ny4)
+       ieval = ieval + 1
+       if (verbosity >= 0) write(*,*) 'ss1 = ', real(ss), ' sspri1 = ', real(sspri(1))
+       ssprev1 = ss; ssprev2 = ss
+       isimu = isimu + 1
+       nrej = 1
+       call readdata(meanfile, par0, stat=fstat, uselock=.true.)            ! MCMC_run1.F90:86: continuing an older run
+       if (fstat == 0 .and. verbosity > 0) write(*,*) 'note: read ', trim(meanfile), ' for the chain mean'
+    else
+       if (drstage > 1 .and. dodr) then
+          call readdata('mcmcoldpar2.dat', oldpar2)
+          call readdata('mcmcoldpar1.dat', oldpar1)
+          call readdata('mcmcssprev2.dat', ssprev2)
+          call readdata('mcmcssprev1.dat', ssprev1)
+       else
+          call readdata('mcmcparf.dat', oldpar1)
+          call readdata('mcmcssprev1.dat', ssprev1)
+          !! the reference leaves oldpar2 / ssprev2 unset here (locals, MCMC_run1.F90:44-45): set before use after an accept,
+          !! but after a reject without DR its next proposal starts from whatever the stack holds; stated as what the
+          !! protocol means, the last accepted point
+          oldpar2 = oldpar1; ssprev2 = ssprev1
+       end if
+       call readdata(meanfile, par0, uselock=.true.)                        ! MCMC_run1.F90:108: the point to evaluate
+       simuind = isimu
+       newpar = par0
+       sspri(1) = priorfun(newpar, n4)
+       ss = ssfunction(newpar, n4, ny4)
+       ieval = ieval + 1
+       if (verbosity >= 0) write(*,*) 'isimu:', isimu, ' drstage:', drstage
+       if (verbosity >= 0) write(*,*) 'oldpar1:', real(oldpar1), ' ssprev1:', real(ssprev1)
+       !! MCMC_run1.F90:126,133: the old priors are recomputed -- from the ss vectors, as the reference writes it
+       !! (MCMC_priorfun(ssprev1)); here the first nycol entries of an npar-vector, the rest zero
+       pad = 0.0_dbl; pad(1:min(npar,nycol)) = ssprev1(1:min(npar,nycol))
+       sspri1(1) = priorfun(pad, n4)
+       sspri2(1) = 0.0_dbl
+       a12(1) = alpha12
+       if (drstage > 1 .and. dodr) then
+          pad = 0.0_dbl; pad(1:min(npar,nycol)) = ssprev2(1:min(npar,nycol))
+          sspri2(1) = priorfun(pad, n4)
+       end if
+       call chk(mcmcx_run1_decide(handle, int(drstage, c_int32_t), oldpar2, ssprev2, sspri2, oldpar1, ssprev1, sspri1, a12, &
+            newpar, ss, sspri, alpha, rej))
+       reject = (rej(1) /= 0)
+       if (reject) then                                                      ! MCMC_run1.F90:145-172
+          if (dodr) then
+             if (drstage == 1) then
+                drstage = 2
+                ssprev2 = ssprev1; ssprev1 = ss
+                oldpar2 = oldpar1; oldpar1 = newpar
+                alpha12 = alpha(1)
+             else
+                isimu = isimu + 1
+                drstage = 1
+                ssprev1 = ssprev2; oldpar1 = oldpar2
+             end if
+          else
+             isimu = isimu + 1
+             drstage = 1
+          end if
+       else
+          drstage = 1
+          isimu = isimu + 1
+          nrej = 1
+          oldpar1 = newpar; ssprev1 = ss
+          alpha12 = alpha(1)
+          ssprev2 = ssprev1; oldpar2 = oldpar1
+       end if
+       if (verbosity >= 0) write(*,*) 'newpar:', real(newpar), 'ssnew:', real(ss), ' ', .not.reject, ' ', real(alpha(1))
+    end if
+    !! the next value: proposed until one falls inside the bounds (MCMC_run1.F90:180-212)
+    inbounds = .false.
+    nrej = 1
+    do while (.not. inbounds)
+       if (drstage > 1 .and. dodr) then
+          call chk(mcmcx_run1_propose(handle, 2_c_int32_t, oldpar2, newpar))
+       else
+          call chk(mcmcx_run1_propose(handle, 1_c_int32_t, oldpar2, newpar))
+       end if
+       inbounds = checkbounds(newpar)
+       if (.not. inbounds) then
+          if (drstage == 1 .and. dodr) then
+             drstage = 2
+             oldpar1 = newpar
+             ssprev1 = huge(ssprev1)
+             alpha12 = 0.0_dbl
+             if (verbosity >= 0) write(*,*) 'outbound, stage 1, par:', real(newpar)
+          else
+             drstage = 1
+             isimu = isimu + 1
+             nrej = nrej + 1
+             oldpar1 = oldpar2; ssprev1 = ssprev2
+             if (verbosity >= 0) write(*,*) 'outbound, rej:', nrej, 'par:', real(newpar)
+          end if
+       end if
+    end do
+    chain(1,1:npar) = oldpar2; sschain(1,1:nycol) = ssprev2
+    chain(1,npar+1) = dble(nrej); sschain(1,nycol+1) = dble(nrej)
+    chainind = 1; simuind = 1
+    call write_mcmcrun_namelist()
+    call writedata('mcmcparnew.dat', reshape(newpar, (/1, npar/)))
+    call writedata('mcmcssprev1.dat', ssprev1)
+    if (dodr) call writedata('mcmcoldpar2.dat', oldpar2)
+    if (dodr) call writedata('mcmcoldpar1.dat', oldpar1)
+    if (dodr) call writedata('mcmcssprev2.dat', ssprev2)
+    if (reject) then
+       call remove_file('mcmc_accepted'); call touch_file('mcmc_rejected')
+    else
+       call remove_file('mcmc_rejected'); call touch_file('mcmc_accepted')
+    end if
+    if (ieval >= nsimu) call touch_file('mcmc_run_done')
+  end subroutine MCMC_run1
+
+  !! MCMC_run1_er, MCMC_run1_er.F90:28-234: early rejection -- the threshold for the next point is drawn with the proposal
+  subroutine MCMC_run1_er()
+    use mcmcrun1
+    real(kind=dbl) :: ss(nycol), newpar(npar), sspri, alpha
+    real(kind=dbl) :: oldpar1(npar), ssprev1(nycol), sspri1(1), pad(npar), crit(1)
+    logical :: reject, inbounds
+    integer :: fstat
+    integer(kind=4) :: n4, ny4
+    interface
+       function ssfunction(theta,npar,ny)
+         integer*4 npar, ny
+         real*8 theta(npar)
+         real*8 ssfunction(ny)
+       end function ssfunction
+       function priorfun(theta,len)
+         real*8 priorfun
+         integer*4 len
+         real*8 theta(len)
+       end function priorfun
+       function checkbounds(theta)
+         real*8 theta(:)
+         logical checkbounds
+       end function checkbounds
+    end interface
+    n4 = npar; ny4 = nycol
+    alpha = 0.0_dbl; sspri1 = 0.0_dbl
+    drstage = 1
+    if (updatesigma == 1) then
+       write(*,*) 'Warning: do not use updatesigma in ER!'
+       updatesigma = 0
+    end if
+    call run1_adapt_guard()
+    call read_mcmcrun_namelist()
+    drstage = 1
+    reject = .false.
+    if (isimu == 1) then
+       if (verbosity >= 0) write(*,*) 'first simulation'
+       if (verbosity >= 0) write(*,*) 'Early rejection version'
+       newpar = par0; oldpar1 = par0
+       sspri = priorfun(newpar, n4)
+       ss = ssfunction(newpar, n4, ny4)
+       ieval = ieval + 1
+       if (verbosity >= 0) write(*,*) 'ss1 = ', real(ss), ' sspri1 = ', real(sspri)
+       ssprev1 = ss
+       sspri1(1) = sspri                          ! unset in the reference's first invocation (MCMC_run1_er.F90:43); the prior of the point just evaluated
+       isimu = isimu + 1
+       nrej = 1
+       call readdata(meanfile, par0, stat=fstat, uselock=.true.)
+       if (fstat == 0 .and. verbosity > 0) write(*,*) 'note: read ', trim(meanfile), ' for the chain mean'
+    else
+       call readdata('mcmcparf.dat', oldpar1)
+       call readdata('mcmcssprev1.dat', ssprev1)
+       call readdata(meanfile, par0, uselock=.true.)
+       simuind = isimu
+       newpar = par0
+       sspri = priorfun(newpar, n4)
+       ss = ssfunction(newpar, n4, ny4)
+       ieval = ieval + 1
+       if (verbosity >= 0) write(*,*) 'isimu:', isimu
+       if (verbosity >= 0) write(*,*) 'oldpar1:', real(oldpar1), ' ssprev1:', real(ssprev1), ' sscrit', real(sscrit)
+       pad = 0.0_dbl; pad(1:min(npar,nycol)) = ssprev1(1:min(npar,nycol))
+       sspri1(1) = priorfun(pad, n4)                                         ! MCMC_run1_er.F90:126, as written there
+       reject = (sum(ss/sigma2) >= sscrit)                                   ! :131-137
+       if (reject) then
+          isimu = isimu + 1
+       else
+          isimu = isimu + 1
+          nrej = 1
+          oldpar1 = newpar; ssprev1 = ss
+          alpha12 = alpha
+          sspri1(1) = sspri
+       end if
+       if (verbosity >= 0) write(*,*) 'newpar:', real(newpar), 'ssnew:', real(ss), ' ', .not.reject, ' ', real(alpha)
+    end if
+    inbounds = .false.
+    nrej = 1
+    do while (.not. inbounds)                                                ! :162-190
+       call chk(mcmcx_run1_propose(handle, 1_c_int32_t, oldpar1, newpar))
+       inbounds = checkbounds(newpar)
+       if (.not. inbounds) then
+          isimu = isimu + 1
+          nrej = nrej + 1
+          if (verbosity >= 0) write(*,*) 'outbound, rej:', nrej, 'par:', real(newpar)
+       else
+          sspri = priorfun(newpar, n4)
+          call chk(mcmcx_run1_sscrit(handle, ssprev1, sspri1, crit))
+          sscrit = crit(1)
+          if (sspri >= sscrit) then
+             inbounds = .false.
+             isimu = isimu + 1
+             nrej = nrej + 1
+             if (verbosity >= 0) write(*,*) 'er, rej by prior:', nrej, 'par:', real(newpar)
+          else
+             sscrit = sscrit - sspri
+          end if
+       end if
+    end do
+    chain(1,1:npar) = oldpar1; sschain(1,1:nycol) = ssprev1
+    chain(1,npar+1) = dble(nrej); sschain(1,nycol+1) = dble(nrej)
+    chainind = 1; simuind = 1
+    call write_mcmcrun_namelist()
+    call writedata('mcmcparnew.dat', reshape(newpar, (/1, npar/)))
+    call writedata('mcmcssprev1.dat', ssprev1)
+    call writedata('mcmcsscrit.dat', sscrit)
+    if (reject) then
+       call remove_file('mcmc_accepted'); call touch_file('mcmc_rejected')
+    else
+       call remove_file('mcmc_rejected'); call touch_file('mcmc_accepted')
+    end if
+    if (ieval >= nsimu) call touch_file('mcmc_run_done')
+  end subroutine MCMC_run1_er
+
   !! the progress line of MCMC_adapt.F90:22-37 / MCMC_run_ram.F90:118-122, from chain 1's counters
   subroutine progress_line(it)
     integer, intent(in) :: it
@@ -1073,13 +1435,30 @@ subroutine mcmc_main()
   if (was_interrupted()) stop 'Coltrol-c interrupt'      ! [sic] MCMC_signal_handler.F90:105
 end subroutine mcmc_main
 
-!!! mcmc_main_one, mcmc_main.F90:49-70: consecutive one-step invocations through MCMC_run1's file protocol
-!!! (MCMC_run1.F90:62-107,229-252: one evaluation per program run, state carried in files).  A GPU engine has nothing
-!!! to offer one iteration at a time on one chain: the entry point exists so that programs link, and stops with a
-!!! message -- use mcmc_main.
+!!! mcmc_main_one, mcmc_main.F90:49-70: consecutive one-evaluation invocations through the file protocol of MCMC_run1 /
+!!! MCMC_run1_er (state in mcmcrun.nml and the mcmc*.dat files between program runs).  Same sequence as the reference:
+!!! MCMC_init, one MCMC_run1[_er], MCMC_writechains, MCMC_cleanup.
 subroutine mcmc_main_one()
   use mcmcmod
   implicit none
+  integer :: status
   write(*,*) 'MCMC code version: ', Mcmc_Code_Version
-  call doerror('mcmc_main_one (the one-iteration-per-invocation file protocol of MCMC_run1) is not supported by the mcmcx engine; call mcmc_main')
+  call read_mcmcinit_namelist(status)
+  if (status /= 0) call doerror('error in mcmcinit namelist')
+  if (nsimu <= 0) stop 'nsimu <= 0'
+  call MCMC_initial_values()
+  if (trim(method) == 'er') then                         ! MCMC_run1_er.F90:62-66, before the engine takes sigma2
+     if (any(abs(sigma2 - 1.0_dbl) > 1.0e-6_dbl)) then
+        write(*,*) 'Warning: in ER sigma2 should be exactly 1'
+        sigma2 = 1.0_dbl
+     end if
+  end if
+  call MCMC_engine_create_one()
+  if (trim(method) == 'er') then
+     call MCMC_run1_er()
+  else
+     call MCMC_run1()
+  end if
+  call MCMC_writechains()
+  call MCMC_cleanup()
 end subroutine mcmc_main_one

@@ -738,6 +738,38 @@ void mcxo_chain_free(mcxo_chain *c)
     free(c);
 }
 
+/* ------------------------------------------------------------------ MCMC_run1 / MCMC_run1_er: the arithmetic of one invocation
+ * The one-evaluation-per-invocation protocol (MCMC_run1.F90:31-256, MCMC_run1_er.F90:28-234) keeps its state in files; its
+ * state machine is restated in oracle/run1.py, the three pieces of arithmetic here, on a freshly created chain (MCMC_init:
+ * R, R2, iC of cmat0; the stream of this invocation). */
+/* MCMC_run1.F90:131-143: alpha = MCMC_DR_alpha13(oldpar2, .., oldpar1, .., alpha12, newpar, ..) in DR stage 2, else
+ * MCMC_alpha(oldpar1 -> newpar); returns reject = MCMC_reject(alpha) */
+int mcxo_run1_decide(mcxo_chain *c, int drstage, const double *oldpar2, const double *ssprev2, double sspri2,
+                     const double *oldpar1, const double *ssprev1, double sspri1, double alpha12,
+                     const double *newpar, const double *ss, double sspri, double *alpha_out)
+{
+    double alpha;
+    if (drstage > 1 && c->cfg.dodr)
+        alpha = dr_alpha13(c, oldpar2, ssprev2, sspri2, oldpar1, ssprev1, sspri1, alpha12, newpar, ss, sspri);
+    else
+        alpha = alpha_cols(c, ssprev1, sspri1, ss, sspri);
+    *alpha_out = alpha;
+    return mcmc_reject(c, alpha);
+}
+/* MCMC_run1.F90:185-189: newpar = MCMC_propose(from, R2) in DR stage 2, else (from, R) */
+void mcxo_run1_propose(mcxo_chain *c, int stage, const double *from, double *newpar)
+{
+    propose(c, from, (stage > 1 && c->cfg.dodr) ? c->R2 : c->R, newpar, NULL);
+}
+/* MCMC_sscrit, MCMC_DRAM.F90:124-135 (called at MCMC_run1_er.F90:168) */
+double mcxo_run1_sscrit(mcxo_chain *c, const double *ssprev1, double sspri1)
+{
+    double u = mcxo_uniform(&c->rng);
+    double s1 = 0.0;
+    for (int j = 0; j < c->ny; ++j) s1 = s1 + ssprev1[j] / c->sigma2v[j];
+    return -2.0 * mcxm_log(u) + s1 + sspri1;
+}
+
 /* MCMC_run (MCMC_run.F90:12-114) and MCMC_run_ram (MCMC_run_ram.F90:13-83).
  * First call does the pre-loop part; continues from simuind+1 up to `upto` (<= nsimu). */
 int mcxo_chain_run(mcxo_chain *c, int upto)

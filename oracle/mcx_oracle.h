@@ -107,6 +107,13 @@ void mcxo_chain_free(mcxo_chain *c);
 /* MCMC_init tail + first row of MCMC_run*, then iterations 2..nsimu (or up to upto) */
 int mcxo_chain_run(mcxo_chain *c, int upto);
 
+/* MCMC_run1 / MCMC_run1_er, the arithmetic of one invocation (state machine: oracle/run1.py) */
+int mcxo_run1_decide(mcxo_chain *c, int drstage, const double *oldpar2, const double *ssprev2, double sspri2,
+                     const double *oldpar1, const double *ssprev1, double sspri1, double alpha12,
+                     const double *newpar, const double *ss, double sspri, double *alpha_out);
+void mcxo_run1_propose(mcxo_chain *c, int stage, const double *from, double *newpar);
+double mcxo_run1_sscrit(mcxo_chain *c, const double *ssprev1, double sspri1);
+
 /* numerics exposed for known-answer tests */
 double mcxo_normal(mcxo_rng *g);
 double mcxo_gamma(mcxo_rng *g, double a, double b);

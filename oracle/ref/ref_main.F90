@@ -7,7 +7,11 @@
 !!! (external_inc.h:12-33), which forward to oracle/ref/user_target.c.
 program mcxref
   implicit none
+#ifdef MCX_MAIN_ONE
+  call mcmc_main_one()      ! one evaluation per invocation: MCMC_run1 / MCMC_run1_er (mcmc_main.F90:49-70)
+#else
   call mcmc_main()
+#endif
 end program mcxref
 
 function ssfunction(theta,npar,ny) result(ss)

@@ -172,3 +172,66 @@ def accepted_from_chain(chain, nsimu):
     acc[np.concatenate([[0], np.cumsum(cnt)[:-1]])] = 1
     assert len(acc) == nsimu, (len(acc), nsimu)
     return acc
+
+
+# ---------------------------------------------------------------- mcmc_main_one: one invocation at a time
+EXE_ONE = os.path.join(_HERE, "_ref", "mcxref_one")     # same callbacks, main program calls mcmc_main_one (MCMC_run1[_er])
+
+
+def _nums(path):
+    return np.array([float(t) for t in open(path).read().split()], dtype=np.float64)
+
+
+def read_run1_files(d):
+    """what one invocation of mcmc_main_one leaves in directory d, in the dict layout of oracle/run1.py"""
+    import re
+    txt = open(os.path.join(d, "mcmcrun.nml")).read().upper().replace("\n", " ")
+    f = {}
+    for k, conv in (("DRSTAGE", int), ("ISIMU", int), ("IEVAL", int), ("NREJ", int), ("ALPHA12", float), ("SSCRIT", float)):
+        m = re.search(k + r"\s*=\s*([-+0-9.EDed]+)", txt)
+        f[k.lower()] = conv(m.group(1).replace("D", "E").rstrip(",")) if conv is float else int(m.group(1).rstrip(",").rstrip("."))
+    for key, name in (("mean", "mcmcmean.dat"), ("parf", "mcmcparf.dat"), ("oldpar1", "mcmcoldpar1.dat"), ("oldpar2", "mcmcoldpar2.dat"),
+                      ("ssprev1", "mcmcssprev1.dat"), ("ssprev2", "mcmcssprev2.dat"), ("parnew", "mcmcparnew.dat"),
+                      ("sscritfile", "mcmcsscrit.dat")):
+        p = os.path.join(d, name)
+        f[key] = _nums(p) if os.path.exists(p) else None
+    if f["sscritfile"] is not None:
+        f["sscritfile"] = float(f["sscritfile"][0])
+    acc, rej = os.path.exists(os.path.join(d, "mcmc_accepted")), os.path.exists(os.path.join(d, "mcmc_rejected"))
+    assert acc != rej, "exactly one of mcmc_accepted / mcmc_rejected must exist"
+    f["accepted"] = acc
+    f["done"] = os.path.exists(os.path.join(d, "mcmc_run_done"))
+    return f
+
+
+def run_program_one(exe, cfg, prob, seeds, extra_nml="", seedfile=False, keep=False):
+    """Drive a mcmc_main_one program (the reference's mcxref_one, or the same user program linked against the engine's
+    shim) through len(seeds) invocations the way the protocol's driver script would: mcmcrun.nml initialised once
+    (init_mcmcrun_namelist), then run, copy mcmcparnew.dat over mcmcpar.dat, run again.  Invocation k draws from the
+    stream keyed (seeds[k], 0): through MCX_SEED for the interposed reference, through the seed file for the shim.
+    Returns the list of files dicts."""
+    d = tempfile.mkdtemp(prefix="mcxone_")
+    out = []
+    try:
+        write_inputs(d, cfg, prob, extra_nml=extra_nml)
+        with open(os.path.join(d, "mcmcrun.nml"), "w") as f:
+            f.write("&mcmcrun\n drstage = 1, isimu = 1, ieval = 0, nrej = 0, alpha12 = 0.0, sscrit = -1.0\n/\n")
+        for s in seeds:
+            env = dict(os.environ, MCX_SEED=str(s), MCX_CHAIN="0", MKL_NUM_THREADS="1", MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1")
+            if seedfile:
+                open(os.path.join(d, "gfortran_seed.dat"), "w").write("%d\n" % s)
+            p = subprocess.run([exe], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+            if p.returncode != 0 or not os.path.exists(os.path.join(d, "mcmcparnew.dat")):
+                raise RuntimeError("mcmc_main_one failed:\n" + p.stdout.decode(errors="replace")[-3000:])
+            f = read_run1_files(d)
+            f["stdout"] = p.stdout.decode(errors="replace")
+            f["chainrow"] = (read_mat4(os.path.join(d, "chain.mat"))["chain"] if os.path.exists(os.path.join(d, "chain.mat"))
+                             else np.loadtxt(os.path.join(d, "chain.dat"), ndmin=2))[0]
+            out.append(f)
+            shutil.copy(os.path.join(d, "mcmcparnew.dat"), os.path.join(d, "mcmcpar.dat"))
+        return out
+    finally:
+        if keep:
+            print("kept", d)
+        else:
+            shutil.rmtree(d, ignore_errors=True)
