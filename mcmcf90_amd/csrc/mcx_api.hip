@@ -143,6 +143,7 @@ static int host_initial_R(int d, const std::vector<double> &cm, std::vector<doub
 
 // The pinned dgesvd('A','N') of a symmetric PSD matrix (one-sided Jacobi), same operation sequence as the device's
 // symsvd_dev; used for the shared initial factor.  G, V column-major n*n.
+static inline double h_tree8(const double *p) { return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])); }
 static void host_symsvd(int n, std::vector<double> &G, std::vector<double> &V, std::vector<double> &sv)
 {
     V.assign((size_t)n * n, 0.0); sv.assign(n, 0.0);
@@ -152,8 +153,10 @@ static void host_symsvd(int n, std::vector<double> &G, std::vector<double> &V, s
         for (int p = 0; p < n - 1; ++p)
             for (int q = p + 1; q < n; ++q) {
                 double *gp = &G[(size_t)p * n], *gq = &G[(size_t)q * n];
-                double alpha = 0.0, beta = 0.0, gamma = 0.0;
-                for (int k = 0; k < n; ++k) { alpha = std::fma(gp[k], gp[k], alpha); beta = std::fma(gq[k], gq[k], beta); gamma = std::fma(gp[k], gq[k], gamma); }
+                // the routine's dot products: eight partial fma chains by row index mod 8, added pairwise (oracle/mcx_svd.h)
+                double pa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int k = 0; k < n; ++k) { const int j = k & 7; pa[j] = std::fma(gp[k], gp[k], pa[j]); pb[j] = std::fma(gq[k], gq[k], pb[j]); pg[j] = std::fma(gp[k], gq[k], pg[j]); }
+                const double alpha = h_tree8(pa), beta = h_tree8(pb), gamma = h_tree8(pg);
                 if (gamma == 0.0) continue;
                 if (std::fabs(gamma) <= 1e-15 * std::sqrt(alpha * beta)) continue;
                 rotated = true;
@@ -166,7 +169,11 @@ static void host_symsvd(int n, std::vector<double> &G, std::vector<double> &V, s
             }
         if (!rotated) break;
     }
-    for (int j = 0; j < n; ++j) { double a = 0.0; for (int k = 0; k < n; ++k) a = std::fma(G[(size_t)j * n + k], G[(size_t)j * n + k], a); sv[j] = std::sqrt(a); }
+    for (int j = 0; j < n; ++j) {
+        double pa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < n; ++k) pa[k & 7] = std::fma(G[(size_t)j * n + k], G[(size_t)j * n + k], pa[k & 7]);
+        sv[j] = std::sqrt(h_tree8(pa));
+    }
     for (int i = 0; i < n - 1; ++i) {
         int m = i;
         for (int j = i + 1; j < n; ++j) if (sv[j] > sv[m]) m = j;

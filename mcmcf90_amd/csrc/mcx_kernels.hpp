@@ -508,6 +508,9 @@ MCX_DEV void gemvT_panels(const double *Mt, const double *x_t, double *out_t, in
     }
 }
 
+// The routine's dot products (oracle/mcx_svd.h): eight partial fma chains over the rows k = j, j + 8, ... and the pairwise tree
+MCX_DEV double svd_tree8(const double (&p)[8]) { return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])); }
+
 // The pinned dgesvd('A','N') of a symmetric PSD matrix: one-sided Jacobi, row-cyclic, operation for operation the
 // routine of oracle/mcx_svd.h (see there).  Gt: in the matrix (column-major d*d per chain), destroyed; Vt: out
 // the singular vectors; sv_t: out singular values, descending.  Lanes converge independently; a converged lane
@@ -524,14 +527,22 @@ MCX_DEV void symsvd_dev(double *Gt, double *Vt, double *sv_t, int lane, int d, b
         bool rotated = false;
         for (int p = 0; p < d - 1; ++p) {
             double *gp = Gt + (size_t)p * d * 64, *vp = Vt + (size_t)p * d * 64;
-            double alpha = 0.0, beta = 0.0, gamma = 0.0;
+            double alpha, beta, gamma;
             {
                 const double *gq = gp + (size_t)d * 64;
-#pragma unroll 4
-                for (int k = 0; k < d; ++k) {
-                    double a = GV(gp, k), b = GV(gq, k);
-                    alpha = dfma(a, a, alpha); beta = dfma(b, b, beta); gamma = dfma(a, b, gamma);
+                double pa[8], pb[8], pg[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { pa[u] = 0.0; pb[u] = 0.0; pg[u] = 0.0; }
+                for (int k0 = 0; k0 < d; k0 += 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (k0 + u < d) {
+                            double a = GV(gp, k0 + u), b = GV(gq, k0 + u);
+                            pa[u] = dfma(a, a, pa[u]); pb[u] = dfma(b, b, pb[u]); pg[u] = dfma(a, b, pg[u]);
+                        }
+                    }
                 }
+                alpha = svd_tree8(pa); beta = svd_tree8(pb); gamma = svd_tree8(pg);
             }
             for (int q = p + 1; q < d; ++q) {
                 double *gq = Gt + (size_t)q * d * 64, *vq = Vt + (size_t)q * d * 64;
@@ -539,6 +550,9 @@ MCX_DEV void symsvd_dev(double *Gt, double *Vt, double *sv_t, int lane, int d, b
                 const double *gn = more ? gq + (size_t)d * 64 : gq;          // column q+1 (unused when !more)
                 const bool rot = act && (gamma != 0.0) && !(fabs(gamma) <= 1e-15 * sqrt(alpha * beta));
                 double na = 0.0, nb = 0.0, ng = 0.0;
+                double pa[8], pb[8], pg[8];                      // partial chains by row index mod 8 (SB = 8 rows per block below)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { pa[u] = 0.0; pb[u] = 0.0; pg[u] = 0.0; }
                 if (__any(rot)) {
                     double c = 1.0, sn = 0.0;
                     if (rot) {
@@ -571,19 +585,25 @@ MCX_DEV void symsvd_dev(double *Gt, double *Vt, double *sv_t, int lane, int d, b
                                 const double ra = c * a - sn * b, rb = sn * a + c * b;
                                 const double aa = rot ? ra : a;
                                 if (rot) { GV(gp, k) = ra; GV(gq, k) = rb; GV(vp, k) = c * va - sn * vb; GV(vq, k) = sn * va + c * vb; }
-                                na = dfma(aa, aa, na); nb = dfma(e, e, nb); ng = dfma(aa, e, ng);
+                                pa[u] = dfma(aa, aa, pa[u]); pb[u] = dfma(e, e, pb[u]); pg[u] = dfma(aa, e, pg[u]);
                             }
                         }
 #pragma unroll
                         for (int u = 0; u < SB; ++u) { A[u] = A2[u]; B[u] = B2[u]; Ee[u] = E2[u]; VA[u] = VA2[u]; VB[u] = VB2[u]; }
                     }
+                    na = svd_tree8(pa); nb = svd_tree8(pb); ng = svd_tree8(pg);
                 } else if (more) {
                     na = alpha;
-#pragma unroll 8
-                    for (int k = 0; k < d; ++k) {
-                        const double a = GV(gp, k), e = GV(gn, k);
-                        nb = dfma(e, e, nb); ng = dfma(a, e, ng);
+                    for (int k0 = 0; k0 < d; k0 += 8) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            if (k0 + u < d) {
+                                const double a = GV(gp, k0 + u), e = GV(gn, k0 + u);
+                                pb[u] = dfma(e, e, pb[u]); pg[u] = dfma(a, e, pg[u]);
+                            }
+                        }
                     }
+                    nb = svd_tree8(pb); ng = svd_tree8(pg);
                 }
                 alpha = na; beta = nb; gamma = ng;
             }
@@ -593,9 +613,14 @@ MCX_DEV void symsvd_dev(double *Gt, double *Vt, double *sv_t, int lane, int d, b
     if (act) {
         for (int j = 0; j < d; ++j) {
             const double *gj = Gt + (size_t)j * d * 64;
-            double a = 0.0;
-            for (int k = 0; k < d; ++k) { double g = GV(gj, k); a = dfma(g, g, a); }
-            GV(sv_t, j) = sqrt(a);
+            double pa[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pa[u] = 0.0;
+            for (int k0 = 0; k0 < d; k0 += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (k0 + u < d) { double g = GV(gj, k0 + u); pa[u] = dfma(g, g, pa[u]); }
+            }
+            GV(sv_t, j) = sqrt(svd_tree8(pa));
         }
         for (int i = 0; i < d - 1; ++i) {                     // descending order, first maximum wins
             int m = i; double sm = GV(sv_t, i);
@@ -2824,10 +2849,11 @@ __global__ __launch_bounds__(256) void svd_sweep_kernel(double *Gc, mcx_d2 *rot,
     double *slot_c = GJ + (size_t)b * LS, *slot_s = slot_c + 32;
     int *slot_m = (int *)(slot_s + 32);                        // partner column of pair-lane l in this step, or -1
     const int nb = (d + b - 1) / b;
-    // phase A: four lanes per pair (b <= 32 pairs: waves 0 and 1), lane r of a quad runs ONE of the three chains --
-    // r = 0: alpha = sum g_p g_p, 1: beta = sum g_q g_q, 2: gamma = sum g_p g_q -- so a step's dot products cost one fma per
-    // row instead of three; the quad's lane 0 collects them by shuffles and derives the rotation.
-    const int ql = tid >> 2, qr = tid & 3;                     // pair-lane of this thread's quad, chain index
+    // phase A: EIGHT lanes per pair (b <= 32 pairs: all four waves); lane j of an octet runs the three partial chains of
+    // the routine's dot products over the rows k = j, j + 8, ... -- alpha = sum g_p g_p, beta = sum g_q g_q, gamma = sum g_p g_q --
+    // and an xor-butterfly over the octet adds them in the routine's pairwise order (a + b = b + a bit for bit, so every
+    // lane ends up with the tree's value); the octet's lane 0 derives the rotation.
+    const int ol = tid >> 3, oj = tid & 7;                     // pair-lane of this thread's octet, partial chain
     const int rl = tid & 31, rk0 = tid >> 5;                   // phase B: pair-lane rl, row pairs 2 rk0, 2 rk0 + 16, ...
     if (tid == 0) s_rot = 0;
     __syncthreads();
@@ -2843,40 +2869,32 @@ __global__ __launch_bounds__(256) void svd_sweep_kernel(double *Gc, mcx_d2 *rot,
             double *Gq = diag ? GI : GJ;
             const int nsteps = diag ? (2 * wI - 3) : (wI + wJ - 1);            // diag: pairs l < m at step l + m - 1
             for (int t = 0; t < nsteps; ++t) {
-                // ---- (A) one pair per quad: alpha, beta, gamma and the rotation
-                if (tid < 128) {                               // waves 0 and 1 (whole waves: the shuffles below need their quads)
-                    const int l = ql, m = diag ? (t + 1 - l) : (t - l);
+                // ---- (A) one pair per octet: alpha, beta, gamma and the rotation
+                {
+                    const int l = ol, m = diag ? (t + 1 - l) : (t - l);
                     const bool valid = (l < wI) && (diag ? (m > l && m < wI) : (m >= 0 && m < wJ));
-                    double acc = 0.0;
-                    if (valid && qr < 3) {
-                        const double *x = (qr == 1) ? Gq + (size_t)m * LS : GI + (size_t)l * LS;
-                        const double *y = (qr == 0) ? GI + (size_t)l * LS : Gq + (size_t)m * LS;
-                        // 16-byte LDS reads in groups of eight rows, the next group in flight while the chain works through
-                        // this one; the loop control is scalar (no per-element predicates in the chain's way)
-                        const mcx_d2 *X2 = (const mcx_d2 *)x, *Y2 = (const mcx_d2 *)y;
-                        const int ng = d >> 3;
-                        mcx_d2 xa[4], ya[4], xb[4], yb[4];
-#define MCX_SVD_LD(xv, yv, g) { _Pragma("unroll") for (int u = 0; u < 4; ++u) { xv[u] = X2[4 * (g) + u]; yv[u] = Y2[4 * (g) + u]; } }
-#define MCX_SVD_FM(xv, yv) { _Pragma("unroll") for (int u = 0; u < 4; ++u) { acc = dfma(xv[u].x, yv[u].x, acc); acc = dfma(xv[u].y, yv[u].y, acc); } }
-                        int g = 0;
-                        if (ng > 0) MCX_SVD_LD(xa, ya, 0)
-                        while (g < ng) {
-                            if (g + 1 < ng) MCX_SVD_LD(xb, yb, g + 1)
-                            MCX_SVD_FM(xa, ya)
-                            ++g;
-                            if (g < ng) {
-                                if (g + 1 < ng) MCX_SVD_LD(xa, ya, g + 1)
-                                MCX_SVD_FM(xb, yb)
-                                ++g;
-                            }
+                    double alpha = 0.0, beta = 0.0, gamma = 0.0;
+                    if (valid) {
+                        const double *x = GI + (size_t)l * LS, *y = Gq + (size_t)m * LS;
+                        // rows oj, oj + 8, ...: four rows' LDS reads in flight while the chains work through the previous four
+                        int k = oj;
+                        for (; k + 24 < d; k += 32) {
+                            const double x0 = x[k], y0 = y[k], x1 = x[k + 8], y1 = y[k + 8], x2 = x[k + 16], y2 = y[k + 16], x3 = x[k + 24], y3 = y[k + 24];
+                            alpha = dfma(x0, x0, alpha); beta = dfma(y0, y0, beta); gamma = dfma(x0, y0, gamma);
+                            alpha = dfma(x1, x1, alpha); beta = dfma(y1, y1, beta); gamma = dfma(x1, y1, gamma);
+                            alpha = dfma(x2, x2, alpha); beta = dfma(y2, y2, beta); gamma = dfma(x2, y2, gamma);
+                            alpha = dfma(x3, x3, alpha); beta = dfma(y3, y3, beta); gamma = dfma(x3, y3, gamma);
                         }
-#undef MCX_SVD_LD
-#undef MCX_SVD_FM
-                        for (int k = 8 * ng; k < d; ++k) acc = dfma(x[k], y[k], acc);
+                        for (; k < d; k += 8) {
+                            const double x0 = x[k], y0 = y[k];
+                            alpha = dfma(x0, x0, alpha); beta = dfma(y0, y0, beta); gamma = dfma(x0, y0, gamma);
+                        }
                     }
-                    const int q0 = tid & 60 & 63;
-                    const double alpha = __shfl(acc, q0, 64), beta = __shfl(acc, q0 | 1, 64), gamma = __shfl(acc, q0 | 2, 64);
-                    if (qr == 0 && l < b) {
+#pragma unroll
+                    for (int o = 1; o < 8; o <<= 1) {
+                        alpha = alpha + __shfl_xor(alpha, o, 64); beta = beta + __shfl_xor(beta, o, 64); gamma = gamma + __shfl_xor(gamma, o, 64);
+                    }
+                    if (oj == 0 && l < b) {
                         int mm = -1;
                         if (valid) {
                             mcx_d2 cs; cs.x = 1.0; cs.y = 0.0;                 // the identity: what svd_applyv_kernel skips
@@ -3002,7 +3020,7 @@ __global__ __launch_bounds__(256) void svd_applyv_kernel(double *Vc, const mcx_d
     }
 }
 
-// singular values = column norms of G (fma chain over the rows), sorted descending (first maximum wins), V's columns
+// singular values = column norms of G (the routine's eight partial chains over the rows), sorted descending (first maximum wins), V's columns
 // with them; the sorted vectors are left in G's place
 __global__ __launch_bounds__(256) void svd_finish_kernel(double *Gc, const double *Vc, double *svc, const uint8_t *state, int nlanes, int d)
 {
@@ -3014,9 +3032,14 @@ __global__ __launch_bounds__(256) void svd_finish_kernel(double *Gc, const doubl
     const double *V = Vc + (size_t)chain * d * d;
     if (tid < d) {
         const double *gj = G + (size_t)tid * d;
-        double a = 0.0;
-        for (int k = 0; k < d; ++k) a = dfma(gj[k], gj[k], a);
-        s_sv[tid] = sqrt(a); s_perm[tid] = tid;
+        double pa[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pa[u] = 0.0;
+        for (int k0 = 0; k0 < d; k0 += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (k0 + u < d) pa[u] = dfma(gj[k0 + u], gj[k0 + u], pa[u]);
+        }
+        s_sv[tid] = sqrt(svd_tree8(pa)); s_perm[tid] = tid;
     }
     __syncthreads();
     if (tid == 0)
