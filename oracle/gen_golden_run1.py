@@ -42,7 +42,14 @@ def cases():
     # no delayed rejection: the reference proposes from an unset local after its first rejection (MCMC_run1.F90:44-45,
     # 185-189), so only the invocations before that rejection are pinned (`valid`)
     c["dram_nodr_gauss5"] = (dict(nsimu=40, drscale=0.0, updatesigma=0), g, 12, 5000)
-    # the SVD factor: MCMC_propose = matmulx(R, z) (MCMC_DRAM.F90:27); dgesvd answered by the pinned Jacobi routine
+    # the SVD factor: MCMC_propose = matmulx(R, z) (MCMC_DRAM.F90:27), iC = dpotri on the factor's upper triangle; dgesvd
+    # answered by the pinned Jacobi routine (oracle/_ref/mcxref_one_svd)
+    c["dram_dr_svd_gauss5"] = (dict(nsimu=30, drscale=2.0, updatesigma=0, condmax=1e8), dict(g, cmat0=0.02 * (A @ A.T / d + np.eye(d))), 30, 6000)
+    # two response columns (mcmcnycol.dat, one sigma2 per column): the sums over columns in MCMC_alpha / MCMC_DR_alpha13
+    y2 = np.vstack([YDATA, 0.8 * YDATA + 0.3])
+    c["dram_dr_expcols2"] = (dict(nsimu=30, drscale=2.0, updatesigma=0),
+                             dict(kind="expdata", npar=3, par0=[10, 0.1, 0.1], cmat0=np.diag([0.2, 0.001, 0.001]), sigma2=[0.5, 0.8], nobs=[11, 11],
+                                  xdata=XDATA, ydata=y2, lo=[0, 0, 0]), 30, 7000)
     return c
 
 
@@ -52,7 +59,7 @@ def main():
         cfg = po.make_cfg(**ckw)
         prob = po.Problem(**pkw)
         seeds = [seed0 + k for k in range(K)]
-        ref = rr.run_program_one(rr.EXE_ONE, cfg, prob, seeds)
+        ref = rr.run_program_one(rr.EXE_ONE_SVD if cfg.usesvd else rr.EXE_ONE, cfg, prob, seeds)
         valid = K
         if not cfg.dodr and cfg.method != po.METHODS["er"]:
             rej = [k for k in range(1, K) if not ref[k]["accepted"]]

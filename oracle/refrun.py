@@ -176,6 +176,7 @@ def accepted_from_chain(chain, nsimu):
 
 # ---------------------------------------------------------------- mcmc_main_one: one invocation at a time
 EXE_ONE = os.path.join(_HERE, "_ref", "mcxref_one")     # same callbacks, main program calls mcmc_main_one (MCMC_run1[_er])
+EXE_ONE_SVD = os.path.join(_HERE, "_ref", "mcxref_one_svd")   # ... with dgesvd = the pinned Jacobi routine (condmax > 0)
 
 
 def _nums(path):
