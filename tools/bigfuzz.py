@@ -35,7 +35,9 @@ for seed in range(A, B):
                 fn(po, 100000 + seed); n += 1
             except Exception as e:
                 bad.append((fn.__name__, seed, repr(e)[:200]))
-    if time.time() - t0 > 1500: 
+    if seed % 50 == 0:
+        print("seed", seed, "checked", n, "failures", len(bad), "%.0f s" % (time.time() - t0), flush=True)
+    if time.time() - t0 > float(os.environ.get("BIGFUZZ_SECONDS", "1500")): 
         print("time limit at seed", seed); break
 print("configs checked", n, "failures", len(bad))
 for b in bad[:20]: print(b)
