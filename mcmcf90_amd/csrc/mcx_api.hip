@@ -280,7 +280,7 @@ static void launch_step(mcmcx_engine *h, int it0, int it1)
     else if (h->E.method == M_RAM && h->usesvd) hipLaunchKernelGGL(step_kernel_ram_fullr, g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->E.method == M_RAM) hipLaunchKernelGGL((step_kernel<true, false, false>), g, b, (size_t)NLC * 2 * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->dodr) hipLaunchKernelGGL((step_kernel<false, true, false>), g, b, lds_step(h), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
-    else hipLaunchKernelGGL((step_kernel<false, false, false>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
+    else hipLaunchKernelGGL((step_kernel<false, false, false>), g, b, h->E.lds_scratch ? (size_t)4 * h->d * 64 * sizeof(double) : 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
 }
 // every chain's copy of a K-vector, filled on the device
 static int dev_bcast(mcmcx_engine *h, double *dst, const std::vector<double> &v)
@@ -1101,6 +1101,17 @@ int mcmcx_init(mcmcx_handle h)
     E.ny = ny; E.hs = d + ny; E.ssv = E.s2v = E.ss2v = nullptr; E.gshapev = nullptr;
     E.alphatarget = c.alphatarget; E.drscale = c.drscale; E.scalelimit = c.scalelimit; E.scalefactor = c.scalefactor;
     E.k0 = c.seed; E.chain_id0 = c.chain_id0;
+    {   // plain AM / Metropolis / ER step kernel: state and scratch vectors in LDS (4 d x 512 bytes per wave) when that costs no
+        // occupancy -- eight waves per CU still fit (npar <= 10), or all tiles are resident at once anyway (few chains)
+        const char *ev = getenv("MCMCX_LDS_SCRATCH");                      // A/B switch: 0 = off
+        const size_t per_wave = (size_t)4 * d * 64 * sizeof(double);
+        const int per_cu = (int)((size_t)160 * 1024 / per_wave);
+        hipDeviceProp_t prop;
+        int cus = 256;
+        if (hipGetDeviceProperties(&prop, c.device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        const bool fits = per_cu >= 8 || (per_cu >= 1 && (long long)T <= (long long)per_cu * cus);
+        E.lds_scratch = (!h->pooled && !h->dodr && c.method != MCMCX_METHOD_RAM && c.method != MCMCX_METHOD_SCAM && fits && !(ev && atoi(ev) == 0)) ? 1 : 0;
+    }
     // target
     E.tgt.kind = phased(h) ? (int)TGT_HOST : h->tkind;   // the kernels know one phase-cut mode; who evaluates is the host's business
     E.tgt.b = h->tb; E.tgt.ndata = (int)h->tx.size(); E.tgt.ncols = h->tncols;

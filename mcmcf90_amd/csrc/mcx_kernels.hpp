@@ -82,6 +82,9 @@ struct EngineDev {
     int ny, hs;
     double *ssv, *s2v, *ss2v;
     const double *gshapev;
+    // small npar, plain AM step kernel: the state vector and the per-chain scratch vectors (theta, candidate, two normal vectors)
+    // live in LDS for the launch -- their store -> load chains are what an iteration waits for when the factor is small
+    int lds_scratch;
 };
 
 #define TIDX(base, tile, K, k, lane) ((base)[((size_t)(tile) * (size_t)(K) + (size_t)(k)) * 64 + (lane)])
@@ -306,26 +309,75 @@ MCX_DEV bool target_inbounds(const DevTarget &t, int d, int lane, const double *
     return ok;
 }
 
+#ifndef MCX_RNG_NB
+#define MCX_RNG_NB 2      // polar attempts computed side by side in the kernels that wait for the generator (AM, DRAM, pooled); 4 loses at config 2 (d = 10: a vector is ~11 attempts)
+#endif
 // ---------------------------------------------------------------- normals (mcmcrand.F90:60-83,166-190)
 // Each lane appends accepted polar pairs to its own column of zs (global scratch, element stride 64)
 // until it has d deviates; the wave loops until every participating lane is done.  The cached
 // second deviate of normal_bm is honoured and left behind when d is odd.
 // Returns sum(z**2) accumulated in element order (the `sum(u**2)` of MCMC_run_ram.F90:166), so the RAM
 // update does not have to read the vector again.
+template <int NB = 1>
 MCX_DEV double gen_normals(Rng &g, double *zs_t, int lane, int d, bool participate)
 {
     int k = 0;
     double su = 0.0;
     if (participate && g.saved && d > 0) { GV(zs_t, 0) = g.saved_y; su = su + g.saved_y * g.saved_y; g.saved = 0; k = 1; }
     bool need = participate && (k < d);
-    while (__any(need)) {
-        if (need) {
-            double a, b;
-            if (polar_try(g, a, b)) {
-                GV(zs_t, k) = a; su = su + a * a; ++k;
-                if (k < d) { GV(zs_t, k) = b; su = su + b * b; ++k; }
-                else { g.saved_y = b; g.saved = 1; }
+    if (NB == 1) {
+        while (__any(need)) {
+            if (need) {
+                double a, b;
+                if (polar_try(g, a, b)) {
+                    GV(zs_t, k) = a; su = su + a * a; ++k;
+                    if (k < d) { GV(zs_t, k) = b; su = su + b * b; ++k; }
+                    else { g.saved_y = b; g.saved = 1; }
+                }
+                need = (k < d);
             }
+        }
+        return su;
+    }
+    // NB attempts per trip, side by side: the Philox blocks, the polar tests and the log / sqrt / division of NB consecutive
+    // attempts of the lane's stream are independent of one another, and a kernel that waits for their dependent chains (one
+    // wave per SIMD at config 2's size) gets NB chains in flight instead of one.  They are CONSUMED in order, and only as
+    // many as the lane needs: an attempt past the one that completes the vector is dropped with its uniforms undrawn, so
+    // the stream position, the deviates and the order of the sum are those of the one-at-a-time loop.
+    while (__any(need)) {
+        const uint64_t b0 = g.n >> 1;
+        const bool odd = (g.n & 1) != 0;
+        uint32_t w[NB + 1][4];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) philox4x32_10((uint32_t)(b0 + j), (uint32_t)((b0 + j) >> 32), g.k0, g.k1, w[j][0], w[j][1], w[j][2], w[j][3]);
+        if (__any(need && odd)) philox4x32_10((uint32_t)(b0 + NB), (uint32_t)((b0 + NB) >> 32), g.k0, g.k1, w[NB][0], w[NB][1], w[NB][2], w[NB][3]);
+        else { w[NB][0] = w[NB][1] = w[NB][2] = w[NB][3] = 0u; }
+        double za[NB], zb[NB];
+        bool ok[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            // uniforms 2 (n/2 + j) and the next one (random_number(x), x(2): mcmcrand.F90:177)
+            double x1 = odd ? bits_to_uniform(w[j][2], w[j][3]) : bits_to_uniform(w[j][0], w[j][1]);
+            double x2 = odd ? bits_to_uniform(w[j + 1][0], w[j + 1][1]) : bits_to_uniform(w[j][2], w[j][3]);
+            x1 = 2.0 * x1 - 1.0; x2 = 2.0 * x2 - 1.0;
+            const double xx = x1 * x1 + x2 * x2;
+            ok[j] = (xx < 1.0) && (xx != 0.0);
+            const double z = sqrt(-2.0 * d_log(ok[j] ? xx : 0.5) / (ok[j] ? xx : 0.5));
+            zb[j] = z * x1; za[j] = z * x2;
+        }
+        if (need) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (k < d) {
+                    g.n += 2;
+                    if (ok[j]) {
+                        GV(zs_t, k) = za[j]; su = su + za[j] * za[j]; ++k;
+                        if (k < d) { GV(zs_t, k) = zb[j]; su = su + zb[j] * zb[j]; ++k; }
+                        else { g.saved_y = zb[j]; g.saved = 1; }
+                    }
+                }
+            }
+            g.cblk = 0;                                   // the half-used block (n odd) is recomputed by the next single draw
             need = (k < d);
         }
     }
@@ -1104,10 +1156,13 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
 {
     extern __shared__ double X[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
-    double *theta_t = E.theta + (size_t)tile * d * 64;
-    double *cand_t = E.cand + (size_t)tile * d * 64;           // proposal vector P, then candidate theta + P
-    double *zs_t = E.zs + (size_t)tile * 2 * d * 64;           // two normal vectors: this iteration's and the next one's
+    const bool ldsv = !RAM && !DR && !POOLED && E.lds_scratch != 0;     // launched with 4 d x 512 bytes of LDS
+    double *theta_g = E.theta + (size_t)tile * d * 64;
+    double *theta_t = ldsv ? X : theta_g;
+    double *cand_t = ldsv ? X + (size_t)d * 64 : E.cand + (size_t)tile * d * 64;           // proposal vector P, then candidate theta + P
+    double *zs_t = ldsv ? X + (size_t)2 * d * 64 : E.zs + (size_t)tile * 2 * d * 64;       // two normal vectors: this iteration's and the next one's
     double *cs_t = E.cs + (size_t)tile * 2 * d * 64;           // RAM: rotations; DR: second-stage candidate
+    if (ldsv) for (int k = 0; k < d; ++k) GV(theta_t, k) = GV(theta_g, k);
     double *Rt = E.R + (size_t)tile * E.P * 64;
     double *Y = X + (size_t)d * 64;
     double *c2_t = cs_t;
@@ -1128,7 +1183,7 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
     uint32_t downs = RAM ? TIDX(E.ictr, tile, NICTR, I_DOWNS, lane) : 0u;
 
     bool have_p = false;                          // lanes whose candidate is already in cand_t
-    double su_c = gen_normals(g, zs_t + (size_t)(it0 & 1) * d * 64, lane, d, true), su_n = 0.0;
+    double su_c = gen_normals<RAM ? 1 : MCX_RNG_NB>(g, zs_t + (size_t)(it0 & 1) * d * 64, lane, d, true), su_n = 0.0;
 
     for (int it = it0; it <= it1; ++it) {
         double *zc_t = zs_t + (size_t)(it & 1) * d * 64;          // z of this iteration
@@ -1166,7 +1221,7 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
             const bool m = reject;
             if (m) drtries += 1;
             double *z2_t = zn_t;                          // stage-2 normals: the "next" buffer is still free
-            gen_normals(g, z2_t, lane, d, m);
+            gen_normals<RAM ? 1 : MCX_RNG_NB>(g, z2_t, lane, d, m);
             if (POOLED) {                                 // one R2 for every chain; lanes that did not draw compute on stale normals and are not looked at
                 if (E.usesvd) gemvN_shared(g_sharedR2, z2_t, c2_t, theta_t, lane, d); else trmv_shared(g_sharedR2, z2_t, c2_t, theta_t, lane, d);
             }
@@ -1225,7 +1280,7 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
         if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
         // ---- the next iteration's normals: nothing else draws between here and its MCMC_propose
         const bool pre = (it < it1);
-        if (pre) su_n = gen_normals(g, zn_t, lane, d, true);
+        if (pre) su_n = gen_normals<RAM ? 1 : MCX_RNG_NB>(g, zn_t, lane, d, true);
         // ---- MCMC_adapt_ram
         have_p = false;
         if (RAM && E.doadapt != 0 && !(it < E.burnintime && E.doburnin != 0)) {
@@ -1250,6 +1305,7 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
     TIDX(E.ictr, tile, NICTR, I_DRACC, lane) = dracc; TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane) = drtries;
     TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane) = erstayed;
     if (RAM) { TIDX(E.ictr, tile, NICTR, I_PDESC, lane) = pdesc ? 1u : 0u; TIDX(E.ictr, tile, NICTR, I_DOWNS, lane) = downs; }
+    if (ldsv) for (int k = 0; k < d; ++k) GV(theta_g, k) = GV(theta_t, k);
 }
 
 #ifndef MCX_AM_WAVES
@@ -1700,7 +1756,7 @@ __global__ __launch_bounds__(64) void pooled_mfma_kernel(EngineDev E, int it0, i
     mcx_d4 c[4][4];
     for (int it = it0; it <= it1; ++it) {
         // ---- newpar = MCMC_propose(oldpar, R): z straight into the LDS vector, P = R'z on the matrix cores
-        gen_normals(L.g, X, lane, d, true);
+        gen_normals<MCX_RNG_NB>(L.g, X, lane, d, true);
         if (it == it1) {                                               // the launch's last normals stay readable (pooled RAM statistic)
             double *zk = E.zs + ((size_t)tile * 2 + (it & 1)) * d * 64;
             for (int k = 0; k < d; ++k) GV(zk, k) = XL(k);
