@@ -280,7 +280,8 @@ static void launch_step(mcmcx_engine *h, int it0, int it1)
     else if (h->E.method == M_RAM && h->usesvd) hipLaunchKernelGGL(step_kernel_ram_fullr, g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->E.method == M_RAM) hipLaunchKernelGGL((step_kernel<true, false, false>), g, b, (size_t)NLC * 2 * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->dodr) hipLaunchKernelGGL((step_kernel<false, true, false>), g, b, lds_step(h), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
-    else hipLaunchKernelGGL((step_kernel<false, false, false>), g, b, h->E.lds_scratch ? (size_t)4 * h->d * 64 * sizeof(double) : 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
+    else if (h->E.lds_scratch) hipLaunchKernelGGL(step_kernel_ldsv, g, b, (size_t)4 * h->d * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
+    else hipLaunchKernelGGL((step_kernel<false, false, false>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
 }
 // every chain's copy of a K-vector, filled on the device
 static int dev_bcast(mcmcx_engine *h, double *dst, const std::vector<double> &v)

@@ -150,6 +150,26 @@ MCX_DEV void sweep(const double *rowp, int lane, int k0, int n, F &&f)
     }
 }
 
+// The same sweep handing over a whole batch at a time: f(k, r, m) sees elements k..k+m-1 (m <= CH) in r[0..m-1], k ascending.
+template <typename F>
+MCX_DEV void sweep_batches(const double *rowp, int lane, int k0, int n, F &&f)
+{
+    double ra[CH], rb[CH];
+    int k = k0;
+    if (k < n) load_batch(ra, rowp, lane, k, n);
+    while (k < n) {
+        int k2 = k + CH;
+        if (k2 < n) load_batch(rb, rowp, lane, k2, n);
+        f(k, ra, (k2 <= n) ? CH : n - k);
+        k = k2;
+        if (k >= n) break;
+        int k3 = k + CH;
+        if (k3 < n) load_batch(ra, rowp, lane, k3, n);
+        f(k, rb, (k3 <= n) ? CH : n - k);
+        k = k3;
+    }
+}
+
 // ---------------------------------------------------------------- targets (user ssfunction / priorfun / checkbounds)
 // The candidate is read from a per-chain global scratch vector c_t (element stride 64); the
 // Gaussian target works on 16x16 register panels: y[16] (rows) x v[16] (columns), precision matrix
@@ -1114,9 +1134,17 @@ MCX_DEV double quadform_sym(const double *St, int lane, int d, const double *X, 
         const double dxi = XL(i);
         double sii = GV(rowp, 0);
         double yi = (i == 0) ? sii * dxi : dfma(sii, dxi, Y[i * 64 + lane]);
-        sweep(rowp, lane, 1, n, [&](int k, double sij) {
-            yi = dfma(sij, XL(i + k), yi);
-            Y[(i + k) * 64 + lane] = (i == 0) ? sij * dxi : dfma(sij, dxi, Y[(i + k) * 64 + lane]);
+        // a batch of row elements at a time: the batch's dx and y values are read together, then the chain of y_i and the
+        // independent updates of y_{i+k} -- element by element every update's LDS store stands between the next element's
+        // loads and the ones before it (the compiler must assume the two vectors overlap), a round trip per element
+        sweep_batches(rowp, lane, 1, n, [&](int k, const double (&sij)[CH], int m) {
+            double xs[CH], ys[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) { const int kk = i + k + (u < m ? u : m - 1); xs[u] = XL(kk); ys[u] = (i == 0) ? 0.0 : Y[kk * 64 + lane]; }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) if (u < m) yi = dfma(sij[u], xs[u], yi);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) if (u < m) Y[(i + k + u) * 64 + lane] = (i == 0) ? sij[u] * dxi : dfma(sij[u], dxi, ys[u]);
         });
         q = q + yi * dxi;
     }
@@ -1148,7 +1176,7 @@ MCX_DEV double quadform_sym_shared(const double *__restrict__ Ss, int lane, int 
 // Iterations it0..it1 (absolute simuind) of MCMC_run (MCMC_run.F90:41-107) or MCMC_run_ram
 // (MCMC_run_ram.F90:45-81) for one tile of 64 chains.  LDS is used only by the delayed-rejection
 // quadratic forms (2*d*64 doubles when dodr, none otherwise).
-template <bool RAM, bool DR, bool POOLED, bool WIDE_T = (RAM || (!DR && !POOLED)), bool FULLR = false>
+template <bool RAM, bool DR, bool POOLED, bool WIDE_T = (RAM || (!DR && !POOLED)), bool FULLR = false, bool LDSV = false>
 MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__restrict__ ramscale,
                        const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
                        const double *__restrict__ g_sharedR, const double *__restrict__ g_sharedR2 = nullptr,
@@ -1156,7 +1184,8 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
 {
     extern __shared__ double X[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
-    const bool ldsv = !RAM && !DR && !POOLED && E.lds_scratch != 0;     // launched with 4 d x 512 bytes of LDS
+    constexpr bool ldsv = LDSV && !RAM && !DR && !POOLED;                // step_kernel_ldsv: launched with 4 d x 512 bytes of LDS (a compile-time
+                                                                        // choice, so that the vectors' accesses are ds_read / ds_write, not flat)
     double *theta_g = E.theta + (size_t)tile * d * 64;
     double *theta_t = ldsv ? X : theta_g;
     double *cand_t = ldsv ? X + (size_t)d * 64 : E.cand + (size_t)tile * d * 64;           // proposal vector P, then candidate theta + P
@@ -1319,6 +1348,11 @@ __global__ __launch_bounds__(64, (RAM || DR || POOLED) ? 2 : MCX_AM_WAVES) void 
                                                      const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
                                                      const double *__restrict__ g_sharedR)
 { step_body<RAM, DR, POOLED, (RAM || (!DR && !POOLED && MCX_AM_WIDE))>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
+// the plain AM / Metropolis / ER step with the state vector, the candidate and the two normal vectors in LDS (EngineDev::lds_scratch)
+__global__ __launch_bounds__(64, MCX_AM_WAVES) void step_kernel_ldsv(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
+                                                     const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
+                                                     const double *__restrict__ g_sharedR)
+{ step_body<false, false, false, MCX_AM_WIDE, false, true>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
 
 // pooled mode with delayed rejection: the shared factor, its second-stage copy R2 = R / drscale and the shared inverse
 // covariance iC = dpotri(R) all come through the scalar cache (the host recomputes the three at every pooled tick)
@@ -2322,6 +2356,22 @@ MCX_DEV int calculate_R(const double *At, double *Tt, double *Rt, int lane, int 
 
 // dpotri('U') on a packed upper factor, in place: dtrti2('U','N') then dlauu2('U') (MCMC_adapt.F90:217-224).
 // On exit A holds the upper triangle of inv(R'R).  X (LDS) carries one column above the diagonal.
+// X += temp * column(k) over the rows r < n, four rows at a time: the column's loads and X's go out together, then the four
+// independent fmas (each element's own chain is unchanged) -- the plain loop is a load-fma-store round trip per row, because
+// the compiler must assume the vector and the matrix overlap
+MCX_DEV void potri_axpy_col(double *X, const double *At, int lane, int d, int n, int k, double temp)
+{
+    constexpr int NB = 4;                               // eight at a time is slower again (4.2 vs 3.9 ms at config 3: registers)
+    int r = 0;
+    for (; r + NB <= n; r += NB) {
+        double a[NB], x[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) { a[u] = GV(At, pidx(r + u, k, d)); x[u] = XL(r + u); }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) XL(r + u) = dfma(temp, a[u], x[u]);
+    }
+    for (; r < n; ++r) XL(r) = dfma(temp, GV(At, pidx(r, k, d)), XL(r));
+}
 MCX_DEV int potri_packed(double *At, int lane, int d, bool act, double *X)
 {
     int info = 0;
@@ -2337,7 +2387,7 @@ MCX_DEV int potri_packed(double *At, int lane, int d, bool act, double *X)
                 for (int jj = 0; jj < j; ++jj) {             // dtrmv('U','N','N') with the inverted leading block
                     double temp = XL(jj);
                     if (temp != 0.0) {
-                        for (int i = 0; i < jj; ++i) XL(i) = dfma(temp, GV(At, pidx(i, jj, d)), XL(i));
+                        potri_axpy_col(X, At, lane, d, jj, jj, temp);
                         XL(jj) = temp * GV(At, pidx(jj, jj, d));
                     }
                 }
@@ -2353,8 +2403,7 @@ MCX_DEV int potri_packed(double *At, int lane, int d, bool act, double *X)
                     for (int r = 0; r < i; ++r) XL(r) = aii * GV(At, pidx(r, i, d));
                     for (int k = i + 1; k < d; ++k) {
                         double temp = GV(rowi, k - i);
-                        if (temp != 0.0)
-                            for (int r = 0; r < i; ++r) XL(r) = dfma(temp, GV(At, pidx(r, k, d)), XL(r));
+                        if (temp != 0.0) potri_axpy_col(X, At, lane, d, i, k, temp);
                     }
                     for (int r = 0; r < i; ++r) GV(At, pidx(r, i, d)) = XL(r);
                 } else {
