@@ -150,6 +150,38 @@ MCX_DEV void sweep(const double *rowp, int lane, int k0, int n, F &&f)
     }
 }
 
+// dst[k] = src[k] (and h[k] when h is given), k < d, eight elements' loads in flight: written element by element a copy waits
+// for each load before its store and cannot issue the next load before that store (the compiler must assume that the vectors
+// overlap) -- npar cache round trips in a row at every accepted move
+MCX_DEV void copy_vec(double *dst, const double *src, double *h, int lane, int d)
+{
+    int k = 0;
+    for (; k + 8 <= d; k += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = GV(src, k + u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { GV(dst, k + u) = v[u]; if (h) GV(h, k + u) = v[u]; }
+    }
+    for (; k < d; ++k) { const double v = GV(src, k); GV(dst, k) = v; if (h) GV(h, k) = v; }
+}
+
+// dst[e] = f(src[e]), e < n, eight loads in flight (dst may be src): the element-by-element loop is a load-op-store round trip per
+// element for the same reason as in copy_vec
+template <typename F>
+MCX_DEV void map_vec(double *dst, const double *src, int lane, int n, F &&f)
+{
+    int e = 0;
+    for (; e + 8 <= n; e += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = GV(src, e + u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) GV(dst, e + u) = f(v[u]);
+    }
+    for (; e < n; ++e) GV(dst, e) = f(GV(src, e));
+}
+
 // The same sweep handing over a whole batch at a time: f(k, r, m) sees elements k..k+m-1 (m <= CH) in r[0..m-1], k ascending.
 template <typename F>
 MCX_DEV void sweep_batches(const double *rowp, int lane, int k0, int n, F &&f)
@@ -461,8 +493,11 @@ MCX_DEV void trmv_panels(const double *Rt, const double *z_t, double *P_t, const
 #undef MCX_TRMV_LDD
 #undef MCX_TRMV_FMD
                 }
+                double th[TW];                           // the state's loads before the candidate's stores (see copy_vec)
 #pragma unroll
-                for (int u = 0; u < TW; ++u) if (u < nw) GV(P_t, J0 + u) = GV(theta_t, J0 + u) + P[u];   // newpar = oldpar + R'z
+                for (int u = 0; u < TW; ++u) th[u] = GV(theta_t, J0 + (u < nw ? u : nw - 1));
+#pragma unroll
+                for (int u = 0; u < TW; ++u) if (u < nw) GV(P_t, J0 + u) = th[u] + P[u];   // newpar = oldpar + R'z
             }
         }
     }
@@ -498,8 +533,11 @@ MCX_DEV void trmv_panels(const double *Rt, const double *z_t, double *P_t, const
 #pragma unroll
                     for (int u = 0; u < TW; ++u) P[u] = dfma(r[u], zi, P[u]);
                 }
+                double th[TW];
 #pragma unroll
-                for (int u = 0; u < TW; ++u) if (u < nw) GV(P_t, J0 + u) = GV(theta_t, J0 + u) + P[u];
+                for (int u = 0; u < TW; ++u) th[u] = GV(theta_t, J0 + (u < nw ? u : nw - 1));
+#pragma unroll
+                for (int u = 0; u < TW; ++u) if (u < nw) GV(P_t, J0 + u) = th[u] + P[u];
             }
         }
     }
@@ -734,8 +772,11 @@ MCX_DEV void trmv_shared(const double *__restrict__ Rs, const double *z_t, doubl
                 P[u] = (u >= ui) ? nv : P[u];
             }
         }
+        double th[PW];
 #pragma unroll
-        for (int u = 0; u < PW; ++u) if (u < nw) GV(P_t, J0 + u) = GV(theta_t, J0 + u) + P[u];
+        for (int u = 0; u < PW; ++u) th[u] = GV(theta_t, J0 + (u < nw ? u : nw - 1));
+#pragma unroll
+        for (int u = 0; u < PW; ++u) if (u < nw) GV(P_t, J0 + u) = th[u] + P[u];
     }
 }
 
@@ -755,8 +796,11 @@ MCX_DEV void gemvN_shared(const double *__restrict__ M, const double *z_t, doubl
 #pragma unroll
             for (int u = 0; u < PW; ++u) y[u] = dfma(zj, col[u < nr ? u : nr - 1], y[u]);
         }
+        double th[PW];
 #pragma unroll
-        for (int u = 0; u < PW; ++u) if (u < nr) GV(out_t, I0 + u) = GV(theta_t, I0 + u) + y[u];
+        for (int u = 0; u < PW; ++u) th[u] = GV(theta_t, I0 + (u < nr ? u : nr - 1));
+#pragma unroll
+        for (int u = 0; u < PW; ++u) if (u < nr) GV(out_t, I0 + u) = th[u] + y[u];
     }
 }
 
@@ -902,8 +946,11 @@ if (MIXED) {
                     }
                 }
                 if (up && fuse) {                        // next candidate = theta + R_new' z_next (MCMC_DRAM.F90:29)
+                    double th[RW];                       // the state's loads before the candidate's stores (see copy_vec)
 #pragma unroll
-                    for (int u = 0; u < RW; ++u) if (u < nw) GV(P_t, J0 + u) = GV(theta_t, J0 + u) + P[u];
+                    for (int u = 0; u < RW; ++u) th[u] = GV(theta_t, J0 + (u < nw ? u : nw - 1));
+#pragma unroll
+                    for (int u = 0; u < RW; ++u) if (u < nw) GV(P_t, J0 + u) = th[u] + P[u];
                 }
             }
         }
@@ -1040,8 +1087,11 @@ if (MIXED) {
                         }
                     }
                     if (fuse && down_ok) {
+                        double th[RW];
 #pragma unroll
-                        for (int u = 0; u < RW; ++u) if (u < nw) GV(P_t, J0 + u) = GV(theta_t, J0 + u) + P[u];
+                        for (int u = 0; u < RW; ++u) th[u] = GV(theta_t, J0 + (u < nw ? u : nw - 1));
+#pragma unroll
+                        for (int u = 0; u < RW; ++u) if (u < nw) GV(P_t, J0 + u) = th[u] + P[u];
                     }
                 }
             }
@@ -1294,12 +1344,7 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
         if (!reject) {
             double *h = E.hist ? E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64 : nullptr;
             const double *src = dr_moved ? c2_t : cand_t;     // newpar = newpar2 when the DR try was accepted
-#pragma unroll 4
-            for (int k = 0; k < d; ++k) {
-                double v = GV(src, k);
-                GV(theta_t, k) = v;
-                if (h) GV(h, k) = v;
-            }
+            copy_vec(theta_t, src, h, lane, d);
             if (h) GV(h, d) = ss1;
         }
         if (E.hist) {
@@ -1449,7 +1494,7 @@ __global__ __launch_bounds__(64, MCX_SCAM_WAVES) void scam_kernel(EngineDev E, i
             }
             if (!reject) {
                 L.ss1 = ss2; L.pri1 = pri2; rejall = false;
-                for (int k = 0; k < d; ++k) GV(theta_t, k) = GV(cand_t, k);
+                copy_vec(theta_t, cand_t, nullptr, lane, d);
             }
         }
         if (rejall) { L.stayed += 1; L.curcount += 1; }
@@ -1814,11 +1859,18 @@ __global__ __launch_bounds__(64) void pooled_mfma_kernel(EngineDev E, int it0, i
                 }
         }
         // ---- candidate (lane = chain), and v = theta' - mu back into the LDS vector for the target
-#pragma unroll 4
-        for (int k = 0; k < d; ++k) {
-            const double cnd = GV(theta_t, k) + T[(size_t)k * 64 + lane];
-            GV(cand_t, k) = cnd;
-            if (gauss) XL(k) = cnd - g_mu[k];
+        for (int k0 = 0; k0 < d; k0 += 8) {              // eight state elements' loads before the eight stores (see copy_vec)
+            double th[8], tv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int k = (k0 + u < d) ? k0 + u : d - 1; th[u] = GV(theta_t, k); tv[u] = T[(size_t)k * 64 + lane]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (k0 + u < d) {
+                    const double cnd = th[u] + tv[u];
+                    GV(cand_t, k0 + u) = cnd;
+                    if (gauss) XL(k0 + u) = cnd - g_mu[k0 + u];
+                }
+            }
         }
         bool inb = target_inbounds(E.tgt, d, lane, cand_t);
         double pri2 = target_prior(E.tgt, d, lane, cand_t);
@@ -1868,8 +1920,7 @@ __global__ __launch_bounds__(64) void pooled_mfma_kernel(EngineDev E, int it0, i
         const int slot = it % E.wcap;
         if (!reject) {
             double *h = E.hist ? E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64 : nullptr;
-#pragma unroll 4
-            for (int k = 0; k < d; ++k) { double v = GV(cand_t, k); GV(theta_t, k) = v; if (h) GV(h, k) = v; }
+            copy_vec(theta_t, cand_t, h, lane, d);
             if (h) GV(h, d) = L.ss1;
         }
         if (E.hist) {
@@ -1933,7 +1984,7 @@ MCX_DEV void host_finish(const EngineDev &E, int tile, int lane, int it, LaneSta
     if (!reject) {
         double *h = E.hist ? E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64 : nullptr;
         const double *src = dr_moved ? cs_t : cand_t;
-        for (int k = 0; k < d; ++k) { double v = GV(src, k); GV(theta_t, k) = v; if (h) GV(h, k) = v; }
+        copy_vec(theta_t, src, h, lane, d);
         if (h) { GV(h, d) = L.ss1; for (int j = 1; j < ny; ++j) GV(h, d + j) = GV(ssv, j); }
     }
     if (E.hist) {
@@ -2061,7 +2112,7 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
         if (!reject) {
             for (int j = 0; j < (ny > 1 ? ny : 0); ++j) GV(ssv, j) = GV(sshev, j);
             L.ss1 = ss2; L.pri1 = pri2; GV(hx, HX_MOVED) = 1.0;
-            for (int k = 0; k < d; ++k) GV(theta_t, k) = GV(cand_t, k);
+            copy_vec(theta_t, cand_t, nullptr, lane, d);
         }
     } else if (PHASE == 7) {                                      // SCAM: end of the outer iteration (one chain row)
         const bool rejall = GV(hx, HX_MOVED) == 0.0;
@@ -2348,7 +2399,7 @@ MCX_DEV int calculate_R(const double *At, double *Tt, double *Rt, int lane, int 
     }
     if (act && info == 0) {
         double sq = sqrt((double)d);
-        for (int e = 0; e < P; ++e) GV(Rt, e) = GV(Tt, e) * 2.4 / sq;
+        map_vec(Rt, Tt, lane, P, [&](double v) { return v * 2.4 / sq; });
     }
     return info;
 }
@@ -2515,8 +2566,8 @@ MCX_DEV void covmat_rows(const EngineDev &E, int tile, int lane, const uint64_t 
             }
         }
         if (bat) {
-            for (int e = 0; e < P; ++e) GV(Ct, e) = GV(Ct, e) / (wsum2 - 1.0);
-            for (int k = 0; k < d; ++k) GV(mean_t, k) = GV(m2_t, k);
+            map_vec(Ct, Ct, lane, P, [&](double v) { return v / (wsum2 - 1.0); });
+            copy_vec(mean_t, m2_t, nullptr, lane, d);
             wsum = wsum2;
         }
     }
@@ -2671,18 +2722,18 @@ __global__ __launch_bounds__(64) void adapt_pre_kernel(EngineDev E, int it, int 
         double *F2t = !E.dodr ? nullptr : (E.usesvd ? E.R2f + (size_t)tile * d * d * 64 : E.R2 + (size_t)tile * P * 64);
         const int nf = E.usesvd ? d * d : P;
         if (staypc > 1.0 - E.scalelimit) {
-            for (int e = 0; e < nf; ++e) GV(Ft, e) = GV(Ft, e) / sf;
+            map_vec(Ft, Ft, lane, nf, [&](double v) { return v / sf; });
             if (E.dodr) {
                 double *iCt = E.iC + (size_t)tile * P * 64;
-                for (int e = 0; e < nf; ++e) GV(F2t, e) = GV(F2t, e) / sf;
-                for (int e = 0; e < P; ++e) GV(iCt, e) = GV(iCt, e) * sf * sf;
+                map_vec(F2t, F2t, lane, nf, [&](double v) { return v / sf; });
+                map_vec(iCt, iCt, lane, P, [&](double v) { return v * sf * sf; });
             }
         } else if (staypc < E.scalelimit) {
-            for (int e = 0; e < nf; ++e) GV(Ft, e) = GV(Ft, e) * sf;
+            map_vec(Ft, Ft, lane, nf, [&](double v) { return v * sf; });
             if (E.dodr) {
                 double *iCt = E.iC + (size_t)tile * P * 64;
-                for (int e = 0; e < nf; ++e) GV(F2t, e) = GV(F2t, e) * sf;
-                for (int e = 0; e < P; ++e) GV(iCt, e) = GV(iCt, e) / sf / sf;
+                map_vec(F2t, F2t, lane, nf, [&](double v) { return v * sf; });
+                map_vec(iCt, iCt, lane, P, [&](double v) { return v / sf / sf; });
             }
         } else {
             flags |= ADF_DOCALC;
@@ -2813,7 +2864,7 @@ __global__ __launch_bounds__(64) void adapt_post_kernel(EngineDev E, int it, int
     const bool docalc = (flags & ADF_DOCALC) != 0, steady = (flags & ADF_STEADY) != 0, greedy_lane = (flags & ADF_GREEDY) != 0;
     double wsum = TIDX(E.scal, tile, NSCAL, (steady && phase != 2) ? S_WNEW : S_WSUM, lane);
     if (phase != 2) {
-    if (steady) for (int k = 0; k < d; ++k) GV(mean_t, k) = GV(m2_t, k);
+    if (steady) copy_vec(mean_t, m2_t, nullptr, lane, d);
 
     if (mode & AD_BURN) {
         if (E.greedy != 0) {
@@ -2822,7 +2873,7 @@ __global__ __launch_bounds__(64) void adapt_post_kernel(EngineDev E, int it, int
         }
         if (docalc) {
             // lastind = chainind: the covariance window restarts at the current row (lastfreq only touched by greedy)
-            for (int k = 0; k < d; ++k) GV(base_t, k) = GV(theta_t, k);
+            copy_vec(base_t, theta_t, nullptr, lane, d);
             basecnt = curcount; winstart = (uint32_t)(it + 1);
         }
     } else if (mode & AD_AM) {
@@ -2832,7 +2883,7 @@ __global__ __launch_bounds__(64) void adapt_post_kernel(EngineDev E, int it, int
             covmat_rows(E, tile, lane, rows, nr, !steady, true, Ct, mean_t, base_t, m2_t, wsum, X);
             // lastfreq = count of the current row; lastind = chainind -> window restarts here
             lastfreq = curcount;
-            for (int k = 0; k < d; ++k) GV(base_t, k) = GV(theta_t, k);
+            copy_vec(base_t, theta_t, nullptr, lane, d);
             basecnt = curcount; winstart = (uint32_t)(it + 1);
         }
     }
@@ -2865,7 +2916,7 @@ __global__ __launch_bounds__(64) void adapt_post_kernel(EngineDev E, int it, int
                         for (int i = 0; i < d; ++i) if (GV(sv_t, i) < tol) GV(sv_t, i) = tol;
                     }
                     if (E.doscam) {                                   // R = U, qcovstd = sqrt(s)
-                        for (int e = 0; e < d * d; ++e) GV(Rft, e) = GV(Vt, e);
+                        copy_vec(Rft, Vt, nullptr, lane, d * d);
                         double *std_t = E.qstd + (size_t)tile * d * 64;
                         for (int i = 0; i < d; ++i) GV(std_t, i) = sqrt(GV(sv_t, i));
                     } else {                                          // R0 = U diag(sqrt(s)); R = R0*2.4/sqrt(d)
@@ -2882,13 +2933,13 @@ __global__ __launch_bounds__(64) void adapt_post_kernel(EngineDev E, int it, int
                                 }
                         }
                         const double sqd = sqrt((double)d);
-                        for (int e = 0; e < d * d; ++e) GV(Rft, e) = GV(Vt, e) * 2.4 / sqd;
+                        map_vec(Rft, Vt, lane, d * d, [&](double v) { return v * 2.4 / sqd; });
                         if (E.dodr) {                                 // iC = dpotri('u', R): on R's upper triangle; R2 = R/drscale
                             double *iCt = E.iC + (size_t)tile * P * 64, *R2ft = E.R2f + (size_t)tile * d * d * 64;
                             for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) GV(iCt, pidx(i, j, d)) = GV(Rft, (size_t)j * d + i);
                             int info2 = potri_packed(iCt, lane, d, true, X);
                             if (info2 != 0) TIDX(E.ictr, tile, NICTR, I_STATUS, lane) |= ST_POTRI_FAIL;
-                            for (int e = 0; e < d * d; ++e) GV(R2ft, e) = GV(Rft, e) / E.drscale;
+                            map_vec(R2ft, Rft, lane, d * d, [&](double v) { return v / E.drscale; });
                         }
                     }
                 }
@@ -2904,10 +2955,10 @@ __global__ __launch_bounds__(64) void adapt_post_kernel(EngineDev E, int it, int
         if (E.dodr) {                                       // iC = dpotri(R), R2 = R/drscale (:216-225)
             const bool ok = docalc && info == 0;
             double *R2t = E.R2 + (size_t)tile * P * 64, *iCt = E.iC + (size_t)tile * P * 64;
-            if (ok) for (int e = 0; e < P; ++e) GV(iCt, e) = GV(Rt, e);
+            if (ok) copy_vec(iCt, Rt, nullptr, lane, P);
             int info2 = potri_packed(iCt, lane, d, ok, X);
             if (ok && info2 != 0) TIDX(E.ictr, tile, NICTR, I_STATUS, lane) |= ST_POTRI_FAIL;  // the reference stops
-            if (ok) for (int e = 0; e < P; ++e) GV(R2t, e) = GV(Rt, e) / E.drscale;
+            if (ok) map_vec(R2t, Rt, lane, P, [&](double v) { return v / E.drscale; });
         }
     }
 }
