@@ -362,8 +362,17 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
     const size_t lds = std::max(lds_bytes(h) / 2, (size_t)44 * 64 * sizeof(double));    // one d-vector / the Cholesky's diagonal block
     const int nb = (h->d + 7) / 8, nblk = nb * (nb + 1) / 2;
     hipLaunchKernelGGL(adapt_pre_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it, mode);
-    if (!((mode & AD_AM) && h->cfg.adapthist > 1))                        // the AP window is a batch recompute: no blocked update
-        hipLaunchKernelGGL(adapt_cov_kernel, dim3((unsigned)(8 * ((h->ntiles + 7) / 8) * nblk)), dim3(64), 0, h->stream, h->E, it, mode, nblk);
+    if (!((mode & AD_AM) && h->cfg.adapthist > 1)) {                      // the AP window is a batch recompute: no blocked update
+        // blocks of ten (triangular on the diagonal): fewer elements and fewer repeats of the per-fold overhead than the 8 x 8 cover
+        if (!(getenv("MCMCX_COV_TD") && atoi(getenv("MCMCX_COV_TD")) == 0)) {
+            const int n10 = (h->d + TD - 1) / TD, noff = n10 * (n10 - 1) / 2;
+            const unsigned g8 = (unsigned)(8 * ((h->ntiles + 7) / 8));
+            hipLaunchKernelGGL(adapt_cov_diag_kernel, dim3(g8 * n10), dim3(64), 0, h->stream, h->E, it, mode, n10);
+            if (noff > 0) hipLaunchKernelGGL(adapt_cov_off_kernel, dim3(g8 * noff), dim3(64), 0, h->stream, h->E, it, mode, noff);
+        }
+        else
+            hipLaunchKernelGGL(adapt_cov_kernel, dim3((unsigned)(8 * ((h->ntiles + 7) / 8) * nblk)), dim3(64), 0, h->stream, h->E, it, mode, nblk);
+    }
     if (!h->d_Gc) {
         hipLaunchKernelGGL(adapt_post_kernel, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr);
         return;

@@ -2840,6 +2840,123 @@ __global__ __launch_bounds__(64, 2) void adapt_cov_kernel(EngineDev E, int it, i
     if (a0 == 0 && b0 == 0 && steady) TIDX(E.scal, tile, NSCAL, S_WNEW, lane) = Wend;
 }
 
+// The same update in blocks of TD = 10 (the BASELINE dimensions 10, 20, 50 are whole numbers of them): a DIAGONAL block is
+// its upper triangle, 55 elements, an off-diagonal one 100 -- the 8 x 8 blocks above cover a 10 x 10 matrix with three waves
+// and 192 elements of which 55 are wanted, a 50 x 50 one with 28 waves and 1792 of which 1275 are; and fewer, larger blocks
+// repeat the per-fold overhead (the three divisions, the deltas, the row's loads) less often.  Operation for operation the
+// walk of covmat_window_blocked (deltas, o = delta_u delta_v, C += f1 (f2 o - C), means).  DIAG: launched with two waves per
+// SIMD; the off-diagonal form holds 100 accumulators and runs one wave per SIMD (its hundred independent chains keep the
+// VALU busy without a second wave).  Grid as for adapt_cov_kernel: workgroup w -> XCD w % 8, tile = (w / 8 / nblk) * 8 + w % 8.
+constexpr int TD = 10;
+template <bool DIAG>
+MCX_DEV void covmat_window_td(const EngineDev &E, int it, int mode, int nblk)
+{
+    const int lane = threadIdx.x, d = E.d, P = E.P;
+    const int w = blockIdx.x, j = w >> 3;
+    const int tile = (j / nblk) * 8 + (w & 7);
+    int blk = j % nblk;
+    if (tile >= E.ntiles) return;
+    const uint32_t flags = TIDX(E.ictr, tile, NICTR, I_ADFLAGS, lane);
+    const bool act = (flags & ADF_STEADY) != 0;
+    if (!__any(act)) return;
+    const int nb = (d + TD - 1) / TD;
+    int a0 = 0, b0 = 0;
+    if (DIAG) { a0 = b0 = blk * TD; }
+    else { int ar = 0; while (blk >= nb - 1 - ar) { blk -= nb - 1 - ar; ++ar; } a0 = ar * TD; b0 = (ar + 1 + blk) * TD; }   // block row ar holds nb - 1 - ar off-diagonal blocks
+    double *Ct = E.cmat + (size_t)tile * P * 64;
+    const double *mean_t = E.mean + (size_t)tile * d * 64;
+    const double *base_t = E.basetheta + (size_t)tile * d * 64;
+    double *mnew_t = E.cand + (size_t)tile * d * 64;
+    const bool unit = (mode & AD_BURN) != 0;                          // greedy restart: rows 1..it, unit weights, no base row
+    const uint32_t count0 = unit ? 0u : TIDX(E.ictr, tile, NICTR, I_BASECNT, lane), adj0 = unit ? 0u : TIDX(E.ictr, tile, NICTR, I_LASTFREQ, lane);
+    const int t0lane = unit ? 1 : (int)TIDX(E.ictr, tile, NICTR, I_WINSTART, lane), t1 = it;
+    const double wsum = TIDX(E.scal, tile, NSCAL, S_WSUM, lane);
+    int t0 = act ? t0lane : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { int other = __shfl_xor(t0, o); t0 = other < t0 ? other : t0; }
+    if (t0 == 0x7fffffff) return;
+    const double *hist_t = E.hist + (size_t)tile * E.wcap * (size_t)E.hs * 64;
+    const unsigned long long *wacc_t = (const unsigned long long *)E.wacc + (size_t)tile * E.wcap;
+    constexpr int NBV = DIAG ? 1 : TD;                 // the b-side vectors exist for off-diagonal blocks only
+    double C[TD][TD], ma[TD], xa[TD], mb[NBV], xb[NBV];
+#pragma unroll
+    for (int u = 0; u < TD; ++u) {
+        const int a = (a0 + u < d) ? a0 + u : d - 1;
+        ma[u] = GV(mean_t, a);
+        xa[u] = unit ? 0.0 : GV(base_t, a);
+        if (!DIAG) { const int b = (b0 + u < d) ? b0 + u : d - 1; mb[u] = GV(mean_t, b); xb[u] = unit ? 0.0 : GV(base_t, b); }
+#pragma unroll
+        for (int v = (DIAG ? u : 0); v < TD; ++v) {
+            int bb = (b0 + v < d) ? b0 + v : d - 1;
+            bb = bb < a ? a : bb;
+            C[u][v] = GV(Ct, pidx(a, bb, d));
+        }
+    }
+    double W = wsum;
+    bool have = act && !unit;
+    uint32_t cnt = count0, adj = adj0;
+    auto fold = [&](bool on, double w3) {
+        if (on) {
+            const double f1 = w3 / (W + w3 - 1.0), f2 = W / (W + w3), f3 = w3 / (W + w3);
+#pragma unroll
+            for (int u = 0; u < TD; ++u) { xa[u] = xa[u] - ma[u]; if (!DIAG) xb[u] = xb[u] - mb[u]; }
+#pragma unroll
+            for (int u = 0; u < TD; ++u)
+#pragma unroll
+                for (int v = (DIAG ? u : 0); v < TD; ++v) {
+                    double o = xa[u] * (DIAG ? xa[v] : xb[v]);
+                    C[u][v] = C[u][v] + f1 * (f2 * o - C[u][v]);
+                }
+#pragma unroll
+            for (int u = 0; u < TD; ++u) { ma[u] = ma[u] + f3 * xa[u]; if (!DIAG) mb[u] = mb[u] + f3 * xb[u]; }
+            W = w3 + W;
+        }
+    };
+    for (int tc = t0; tc <= t1; tc += 64) {
+        const int tl = tc + lane;
+        const unsigned long long mine = (tl <= t1) ? wacc_t[tl % E.wcap] : 0ull;
+        const int nq = (t1 - tc + 1) < 64 ? (t1 - tc + 1) : 64;
+        for (int q = 0; q < nq; ++q) {
+            const int t = tc + q, slot = t % E.wcap;
+            const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), q) << 32)
+                                         | (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mine, q);
+            const bool inwin = act && (t >= t0lane);
+            const bool acc = inwin && ((m >> lane) & 1ull);
+            if (__any(acc)) {
+                double xan[TD], xbn[NBV];
+                if (acc) {
+                    const size_t so = (size_t)slot * (size_t)E.hs * 64;
+#pragma unroll
+                    for (int u = 0; u < TD; ++u) {
+                        xan[u] = hist_t[so + (size_t)((a0 + u < d) ? a0 + u : d - 1) * 64 + lane];
+                        if (!DIAG) xbn[u] = hist_t[so + (size_t)((b0 + u < d) ? b0 + u : d - 1) * 64 + lane];
+                    }
+                }
+                const bool fl = acc && have;
+                if (__any(fl)) fold(fl, unit ? 1.0 : (double)(cnt - adj));
+                if (acc) {
+#pragma unroll
+                    for (int u = 0; u < TD; ++u) { xa[u] = xan[u]; if (!DIAG) xb[u] = xbn[u]; }
+                    if (have) adj = 0;
+                    have = true; cnt = 1;
+                }
+            }
+            if (inwin && !acc) cnt += 1;
+        }
+    }
+    if (__any(have)) fold(have, unit ? 1.0 : (double)(cnt - adj));
+#pragma unroll
+    for (int u = 0; u < TD; ++u) {
+        const int a = a0 + u;
+#pragma unroll
+        for (int v = (DIAG ? u : 0); v < TD; ++v) { const int b = b0 + v; if (act && a < d && b < d) GV(Ct, pidx(a, b, d)) = C[u][v]; }
+        if (DIAG && act && a < d) GV(mnew_t, a) = ma[u];     // the other blocks still need the old means
+    }
+    if (DIAG && a0 == 0 && act) TIDX(E.scal, tile, NSCAL, S_WNEW, lane) = W;
+}
+__global__ __launch_bounds__(64, 2) void adapt_cov_diag_kernel(EngineDev E, int it, int mode, int nblk) { covmat_window_td<true>(E, it, mode, nblk); }
+__global__ __launch_bounds__(64, 1) void adapt_cov_off_kernel(EngineDev E, int it, int mode, int nblk) { covmat_window_td<false>(E, it, mode, nblk); }
+
 // phase 0: the whole tick.  With the blocked SVD (large npar, below) the tick is cut around the factorisation:
 // phase 1 = everything up to and including the symmetric matrix in Gw (and the per-chain `need` flags),
 // phase 2 = everything after the SVD (which has left the singular vectors in Vw and the singular values in cs).
