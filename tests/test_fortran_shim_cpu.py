@@ -81,3 +81,32 @@ def test_reference_example_programs_link_unmodified():
         out = p.stdout.decode(errors="replace")
         assert p.returncode != 0 and "no HIP device" in out, out
         assert not os.path.exists(os.path.join(d, "chain.dat"))
+
+
+@pytest.mark.skipif(not os.path.exists(FLANG), reason="flang not available")
+def test_mcmc_main_one_without_a_gpu_stops_loudly_and_leaves_the_protocol_files_alone(oracle):
+    """mcmc_main_one (MCMC_run1's one-evaluation-per-invocation protocol) goes through the engine like mcmc_main: without a
+    GPU it stops with the engine's message -- no host-side fallback decides or proposes anything, mcmcrun.nml stays as the
+    driver script left it and no mcmcparnew.dat appears.  (With a GPU: tests/test_gpu_run1.py.)"""
+    import numpy as np
+    import torch
+    from oracle import refrun
+    exe = os.path.join(ROOT, "oracle", "_ref", "one_shim")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/one_shim not built (make -C oracle testcases)")
+    syms = subprocess.check_output(["nm", os.path.join(FDIR, "libmcmcxf.a")]).decode()
+    for sym in ("mcmc_main_one_", "_QMmcmcrun1Pinit_mcmcrun_namelist", "_QMmcmcrun1Pwrite_mcmcrun_namelist"):      # mcmc_main.F90:49, mcmcrun1.F90:27,64
+        assert sym in syms, sym
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by tests/test_gpu_run1.py")
+    cfg = oracle.make_cfg(nsimu=5, drscale=2.0, updatesigma=0)
+    prob = oracle.Problem(kind="gauss", npar=2, par0=[0.1, 0.2], cmat0=0.1 * np.eye(2), mu=np.zeros(2), lam=np.eye(2))
+    with tempfile.TemporaryDirectory() as d:
+        refrun.write_inputs(d, cfg, prob)
+        nml = "&mcmcrun\n drstage = 1, isimu = 1, ieval = 0, nrej = 0, alpha12 = 0.0, sscrit = -1.0\n/\n"
+        open(os.path.join(d, "mcmcrun.nml"), "w").write(nml)
+        p = subprocess.run([exe], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+        out = p.stdout.decode(errors="replace")
+        assert p.returncode != 0 and "no HIP device" in out, out
+        assert open(os.path.join(d, "mcmcrun.nml")).read() == nml
+        assert not os.path.exists(os.path.join(d, "mcmcparnew.dat"))
