@@ -18,18 +18,23 @@ One process per GPU.  Under torchrun the ranks come from RANK / LOCAL_RANK / WOR
 `--gpus N` spawns the N rank processes itself (before anything touches a GPU) and fails if they cannot
 all start.  The ranks meet in libmcmcx.so's communicator (RCCL; the ncclUniqueId travels through a POSIX
 shm segment), which also carries the barrier and the max-over-ranks of the timing: torch is not imported.
+Every rank prints its device (name, PCI bus id) and its place in the communicator to stderr once, runs RCCL
+with NCCL_DEBUG=WARN, and arms a watchdog around the communicator's formation (--comm-timeout): a rank that
+cannot join ends the run with a non-zero exit code instead of hanging it.
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the engine's
 stream around every step-kernel launch of the timed region (mcmcx_kernel_time); `cpu_baseline`
 times the real Fortran reference (oracle/_ref, kind "reference") or the C oracle (kind "port")
-on one host core on the same target.
+on one host core and on all of them on the same target; `other_configs` (N = 1 only) holds a short run of
+each of the other BASELINE configurations in the same process, after the headline's timed region.
 """
 import argparse
-import hashlib
 import json
 import os
 import subprocess
 import sys
+import tempfile
+import threading
 import time
 import uuid
 
@@ -72,16 +77,23 @@ def alg_bytes_per_proposal(d, method, down_frac=0.0):
 
 
 def kernels_sha():
-    h = hashlib.sha256()
-    for f in ("mcx_kernels.hpp", "mcx_device.hpp"):
-        with open(os.path.join(ROOT, "mcmcf90_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+    from mcmcf90_amd.build import source_sha
+    return source_sha()
+
+
+def ab_switches():
+    """Environment switches that select another kernel path or another library build than the profiled one
+    (mcx_api.hip's A/B switches, tools/build_variant.sh): with any of them set the stored PMC figures do not describe
+    what is being timed."""
+    return sorted(k for k in os.environ if k.startswith("MCMCX_") and k not in ("MCMCX_COMM_KEY",))
 
 
 def measured_counters(key):
-    """PMC results of profiles/traffic.json for this configuration -- only when they were collected with the kernel
-    source that is running now (the file records the sha of csrc/mcx_kernels.hpp + mcx_device.hpp)."""
+    """PMC results of profiles/traffic.json for this configuration -- only when they were collected with the engine
+    sources that are running now (the file records the sha of csrc/*: kernels, device functions, host orchestration and
+    communicator) and no A/B switch is active."""
+    if ab_switches():
+        return None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         tj = json.load(open(tfile))
@@ -93,10 +105,95 @@ def measured_counters(key):
     return None
 
 
-def cpu_baseline(wl, ckw, pkw, per_it, label, target_seconds=12.0):
-    """One chain of the same workload on one host core (the reference adapts its single chain on its own history)."""
+# ------------------------------------------------------------------ the CPU baseline (rank 0, N = 1): reference + port
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cgroup_cpu_quota():
+    """CPUs the container may use at once (cgroup v2 cpu.max / v1 cpu.cfs_quota_us), or None when unlimited / unknown."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except Exception:
+        return None
+
+
+def reference_all_cores(ckw, pkw, per_it, rate_it, cores):
+    """SURVEY section 8(d)(ii) / north_star: the REFERENCE on the node's own host cores -- one process of oracle/_ref/mcxref
+    per CPU of the affinity mask, each an independent chain (its own Philox stream) in its own tmpfs directory.  Sampling
+    loop only, by the same two-nsimu difference as the one-core figure: all processes run nsimu = n1 together, then all run
+    nsimu = n2; rate = cores x (proposals(n2) - proposals(n1)) / (wall(n2) - wall(n1))."""
     from oracle import pyoracle as po, refrun as rr
     prob = po.Problem(**pkw)
+    d = prob.npar
+    cap = int(48e6 / (16.0 * (d + 2)))                  # chain array + its .mat file: <= ~48 MB per process
+    n2 = int(max(16, min(cap, rate_it * 1.5)))
+    n1 = max(8, n2 // 4)
+    def batch(n):
+        cfg = po.make_cfg(**dict(ckw, nsimu=n))
+        r = rr.run_reference_many(cfg, prob, nprocs=cores, chain_id0=1000, timeout=240, pinned_svd=bool(cfg.usesvd))
+        tries = 0
+        if cfg.dodr:                                    # same streams: the port's delayed-rejection count is the reference's
+            tries = sum(po.run_chain(cfg, prob, chain_id=1000 + c).drtries for c in range(min(cores, 4))) / float(min(cores, 4)) * cores
+        return cores * (n - 1) * per_it + tries, r
+
+    batch(n1)                                           # untimed: binary, MKL, tmpfs paged in and every (virtual) core awake
+    res = [batch(n1), batch(n2)]
+    again = batch(n1)                                   # the short batch once more: the less disturbed of the two counts
+    if again[1]["wall"] < res[0][1]["wall"]:
+        res[0] = again
+    (p1, r1), (p2, r2) = res
+    dt = r2["wall"] - r1["wall"]
+    if not dt > 0:
+        raise RuntimeError("reference all-cores: wall(n2) <= wall(n1) (%.2f, %.2f)" % (r2["wall"], r1["wall"]))
+    quota = cgroup_cpu_quota()
+    return {"value": (p2 - p1) / dt, "unit": "proposals/s", "cores": cores, "kind": "reference",
+            "effective_parallelism": r2["cpu_seconds"] / r2["wall"],
+            "cgroup_cpu_quota": quota,
+            "sample": "mcmcf90 Fortran reference (flang -O2 + MKL, oracle/_ref/mcxref), %d processes = the CPUs of the affinity mask, "
+                      "one independent chain each, own %s directory: sampling loop only = %d x (proposals(nsimu=%d) - proposals(nsimu=%d)) / "
+                      "(%.2f s - %.2f s wall of the whole batch); CPU seconds used / wall = %.1f"
+                      % (cores, r2["scratch"], cores, n2, n1, r2["wall"], r1["wall"], r2["cpu_seconds"] / r2["wall"])}
+
+
+def port_all_cores(wl, ckw, per_it, port_rate, cores, seconds=0.6):
+    """The C restatement, one process per CPU of the affinity mask (kept beside the reference figure)."""
+    n = int(max(50, port_rate / per_it * seconds))
+    cmd = [sys.executable, "-m", "oracle.portrun", wl, str(n), str(ckw.get("adaptint", 100))]
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen(cmd + [str(1000 + c), ckw.get("method", "dram")], cwd=ROOT, stdout=subprocess.PIPE) for c in range(cores)]
+    tries = 0
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=120)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            return {"error": "the host did not finish %d port chains in 120 s (CPU quota?)" % cores}
+        if p.returncode != 0:
+            return {"error": "oracle.portrun failed"}
+        tries += int(out.decode().split()[-1])
+    dt = time.perf_counter() - t0
+    return {"value": (cores * (n - 1) * per_it + tries) / dt, "unit": "proposals/s", "cores": cores, "kind": "port",
+            "sample": "C oracle, %d independent chains, one process each, nsimu=%d each, %.2f s incl. process start (python + ctypes)" % (cores, n, dt)}
+
+
+def cpu_baseline(wl, ckw, pkw, per_it, label, target_seconds=12.0, all_cores=True):
+    """One chain of the same workload on one host core (the reference adapts its single chain on its own history), then
+    one chain per host core."""
+    from oracle import pyoracle as po, refrun as rr
+    prob = po.Problem(**pkw)
+    cores = host_cores()
     out = {"cores": 1, "unit": "proposals/s"}
     # the C oracle, in process (no file output): a short run sizes the reference run
     n0 = 2000 if per_it == 1 else 12
@@ -119,75 +216,237 @@ def cpu_baseline(wl, ckw, pkw, per_it, label, target_seconds=12.0):
                 o2 = po.run_chain(cfg, prob)             # same stream: its delayed-rejection count is the reference's
                 runs.append(((n - 1) * per_it + o2.drtries, r.seconds, r.scratch))
             (p1, t1, _), (p2, t2, scratch) = runs
-            out["all_cores"] = cpu_all_cores(wl, ckw, per_it, port_rate)
-            out.update(value=(p2 - p1) / (t2 - t1), kind="reference",
+            value = (p2 - p1) / (t2 - t1)
+            out.update(value=value, kind="reference",
                        sample="mcmcf90 Fortran reference (flang -O2 + MKL, oracle/_ref/mcxref), 1 chain, %s: sampling loop "
                               "only = (proposals(nsimu=%d) - proposals(nsimu=%d)) / (%.2f s - %.2f s) of the whole program, "
                               "outputs on %s" % (label, n2, n1, t2, t1, scratch),
                        whole_program_value=p2 / t2, port_value=port_rate)
+            if all_cores:
+                try:
+                    out["all_cores"] = reference_all_cores(ckw, pkw, per_it, value / (per_it + o2.drtries / max(n2 - 1.0, 1.0)), cores)
+                except Exception as ex:
+                    out["all_cores"] = {"error": str(ex)[:300], "kind": "reference", "cores": cores}
+                out["all_cores_port"] = port_all_cores(wl, ckw, per_it, port_rate, cores)
             return out
         except Exception as ex:                      # reference binary present but not runnable here
             out["reference_error"] = str(ex)[:200]
-    out["all_cores"] = cpu_all_cores(wl, ckw, per_it, port_rate)
+    if all_cores:
+        out["all_cores"] = port_all_cores(wl, ckw, per_it, port_rate, cores, seconds=3.0)
     out.update(value=port_rate, kind="port",
                sample="C oracle (oracle/mcx_oracle.c, gcc -O2), 1 chain, %s, nsimu=%d, %.2f s" % (label, n_port, t_port))
     return out
 
 
-def cpu_all_cores(wl, ckw, per_it, port_rate, seconds=4.0):
-    """every host core runs one independent chain of the C restatement, each in a process of its
-    own (the reference is one chain per process; the port is what spreads over the cores without N copies of its file I/O)."""
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    avail = cores
-    cores = min(cores, 32)                            # bounded: the default bench run must stay within minutes
-    n = int(max(50, port_rate / per_it * seconds))
-    cmd = [sys.executable, "-m", "oracle.portrun", wl, str(n), str(ckw.get("adaptint", 100))]
-    t0 = time.perf_counter()
-    procs = [subprocess.Popen(cmd + [str(1000 + c), ckw.get("method", "dram")], cwd=ROOT, stdout=subprocess.PIPE) for c in range(cores)]
-    tries = 0
-    for p in procs:
-        try:
-            out, _ = p.communicate(timeout=90)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            return {"error": "the host did not finish %d port chains in 90 s (CPU quota?)" % cores}
-        if p.returncode != 0:
-            return {"error": "oracle.portrun failed"}
-        tries += int(out.decode().split()[-1])
-    dt = time.perf_counter() - t0
-    return {"value": (cores * (n - 1) * per_it + tries) / dt, "unit": "proposals/s", "cores": cores, "kind": "port",
-            "sample": "C oracle, %d independent chains, one process each (host CPUs in the affinity mask: %d, processes capped at 32), nsimu=%d each, %.2f s incl. process start" % (cores, avail, n, dt)}
-
-
-def spawn_ranks(n, argv):
+# ------------------------------------------------------------------ ranks
+def spawn_ranks(n, argv, comm_timeout):
     """`bench.py --gpus N` without a launcher: start the N rank processes (one per GPU) ourselves.  This parent never
-    touches a GPU; rank 0's JSON line goes straight to our stdout.  Any rank failing fails the run."""
+    touches a GPU; rank 0's JSON line goes straight to our stdout, every rank's stderr (its device line, RCCL's
+    NCCL_DEBUG=WARN output) into a file of its own that is printed when the run fails.  Any rank failing -- or the ranks not
+    having formed their communicator within comm_timeout seconds -- ends the run: the children we started are terminated
+    and the exit code is non-zero."""
     key = "b%s" % uuid.uuid4().hex[:16]
-    procs = []
+    logdir = tempfile.mkdtemp(prefix="mcmcx_bench_")
+    procs, logs = [], []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MCMCX_COMM_KEY=key)
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MCMCX_COMM_KEY=key, MCMCX_BENCH_LOGDIR=logdir)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this driver
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+        env.setdefault("NCCL_DEBUG", "WARN")
+        lf = open(os.path.join(logdir, "rank%d.stderr" % r), "wb")
+        logs.append(lf)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stderr=lf))
     rc = 0
+    why = ""
     alive = list(procs)
+    t0 = time.time()
+    formed = False
     while alive:
         time.sleep(0.05)
+        if not formed:
+            formed = all(os.path.exists(os.path.join(logdir, "rank%d.formed" % r)) for r in range(n))
+            if not formed and time.time() - t0 > comm_timeout and rc == 0:
+                rc, why = 3, "the %d ranks had not formed their communicator after %.0f s" % (n, comm_timeout)
+                for q in alive:
+                    q.terminate()
         for p in list(alive):
             r = p.poll()
             if r is None:
                 continue
             alive.remove(p)
             if r != 0 and rc == 0:
-                rc = r
+                rc, why = r, "rank %d exited with code %d" % (procs.index(p), r)
                 for q in alive:                                    # exactly the children we started
                     q.terminate()
+    for lf in logs:
+        lf.close()
+    for r in range(n):
+        try:
+            txt = open(os.path.join(logdir, "rank%d.stderr" % r), "rb").read().decode(errors="replace")
+        except OSError:
+            txt = ""
+        if rc != 0 or os.environ.get("MCMCX_BENCH_VERBOSE"):
+            sys.stderr.write("---- rank %d stderr ----\n%s\n" % (r, txt[-6000:]))
+        else:                                                      # success: the device lines only
+            sys.stderr.write("".join(l + "\n" for l in txt.splitlines() if l.startswith("bench.py rank")))
     if rc != 0:
-        sys.stderr.write("bench.py: a rank exited with code %d -- %d ranks could not be formed / run\n" % (rc, n))
+        sys.stderr.write("bench.py: %s -- %d ranks could not be formed / run\n" % (why, n))
+    import shutil
+    shutil.rmtree(logdir, ignore_errors=True)
     return 1 if rc != 0 else 0
+
+
+class Watchdog:
+    """Ends THIS process (exit code 3, after a message) if disarm() is not called within `seconds`: around the
+    communicator's formation, where a missing peer would otherwise hold ncclCommInitRank forever."""
+
+    def __init__(self, seconds, what):
+        self.ev = threading.Event()
+        self.t = threading.Thread(target=self._run, args=(seconds, what), daemon=True)
+        self.t.start()
+
+    def _run(self, seconds, what):
+        if not self.ev.wait(seconds):
+            sys.stderr.write("bench.py rank %s: %s did not complete within %.0f s -- giving up (exit 3)\n" % (os.environ.get("RANK", "0"), what, seconds))
+            sys.stderr.flush()
+            os._exit(3)
+
+    def disarm(self):
+        self.ev.set()
+
+
+# ------------------------------------------------------------------ one configuration
+def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_per_step=0, method_opt=None, pooled=False,
+               replicas=False, start="default", transport="one GPU"):
+    """Time `steps` bench steps of configuration `wl` (after `warmup` untimed ones) on this rank's GPU; returns the pieces
+    of the JSON line on rank 0 (None elsewhere) and the pooled moment vector."""
+    from mcmcf90_amd import engine_from_problem
+    from mcmcf90_amd.workloads import problem
+    n_local = chains_per_gpu or DEFAULT_CHAINS[wl]
+    ips = its_per_step or (10 if wl == "c5" else 100)       # c5: one iteration is d = 200 componentwise proposals
+    nsimu = 1 + (warmup + steps) * ips
+    ckw, pkw, per_it = problem(wl, nsimu, adaptint=max(ips, 100))
+    d = pkw["npar"]
+    if wl == "c4" and start == "target":
+        pkw = dict(pkw, cmat0=np.linalg.inv(np.asarray(pkw["lam"], dtype=float)))
+    if wl == "c4" and method_opt == "dram":
+        ckw = dict(ckw, method="dram")
+    if wl == "c5":
+        pooled = not replicas
+    elif pooled:
+        ckw = dict(ckw, drscale=0.0)                   # c4 keeps method='ram' (pooled RAM); c2 / c3: pooled AM without DR
+        if wl == "c4" and method_opt == "dram":
+            ckw = dict(ckw, method="dram")
+    method = ckw.get("method", "dram")
+    eng = engine_from_problem(ckw, pkw, nchains=n_local, chain_id0=rank * n_local, device=dev,
+                              pooled=1 if pooled else 0, comm=comm)
+    eng.init()
+
+    def one_step(k):
+        eng.run(1 + (k + 1) * ips)
+        eng.allreduce_moments(fetch=False)             # local fixed tree -> RCCL all-gather -> tree over ranks; stays in HBM
+
+    def fence():
+        eng.sync()                                     # everything this rank queued, the gathers included
+        if comm is not None:
+            comm.barrier()
+            eng.sync()
+
+    for k in range(warmup):
+        one_step(k)
+    fence()
+    eng.kernel_time(reset=True)
+    t0 = time.perf_counter()
+    for k in range(warmup, warmup + steps):
+        one_step(k)
+    fence()
+    dt = time.perf_counter() - t0
+    kms, klaunch, ksteps = eng.kernel_time()
+    tot = eng.totals()
+    red = np.array([dt, kms]), np.array([float(tot["drtries"]), float(tot["stayed"]), float(tot["downdates"])])
+    if comm is not None:
+        red = comm.allreduce(red[0], op="max"), comm.allreduce(red[1], op="sum")
+    dt, kms = float(red[0][0]), float(red[0][1])                                    # slowest rank
+    tries, stayed_all, downs_all = (float(x) for x in red[1])
+    pooled_vec = eng.allreduce_moments(fetch=True)                                  # collective: every rank
+    eng.close()
+    if rank != 0:
+        return None, pooled_vec
+    base = float(world) * n_local * ips * per_it
+    dr_per_it = tries / (warmup + steps) / ips                                  # stage-2 proposals per iteration, all ranks
+    proposals = (base + dr_per_it * ips) * steps
+    value = proposals / dt
+    per_launch_prop = proposals / world / max(klaunch, 1)                        # proposals one launch of one GPU evaluates
+    avg_launch_s = kms / 1e3 / max(klaunch, 1)
+    ckey = "%s_%s%s" % (wl, "pooled" if pooled else method, "_target" if start == "target" else "")
+    pmc = measured_counters(ckey)
+    if wl == "c5" and pooled:                   # shared rotation: three d x d products per proposal on the f64 matrix cores
+        flop = 6.0 * d * d
+        achieved = flop * per_launch_prop / avg_launch_s / 1e12
+        roof = {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": achieved / FP64_MFMA_PEAK_TF,
+                "traffic": pmc["hbm_bytes_per_proposal"] * per_launch_prop if pmc and "hbm_bytes_per_proposal" in pmc else None,
+                "kernel": "mcx::scam_pooled_kernel", "alg_flop_per_proposal": flop}
+    else:
+        down_frac = downs_all / (float(world) * n_local * (nsimu - 1)) if method == "ram" else 0.0
+        balg = alg_bytes_per_proposal(d, "pooled" if pooled else method, down_frac)
+        achieved = balg * per_launch_prop / avg_launch_s / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": pmc["hbm_bytes_per_proposal"] * per_launch_prop if pmc and "hbm_bytes_per_proposal" in pmc else None,
+                "kernel": "mcx::scam_kernel" if method == "scam" else ("mcx::pooled_mfma_kernel" if pooled else "mcx::step_kernel"),
+                "alg_bytes_per_proposal": balg}
+        if method == "ram":
+            roof["downdate_fraction"] = down_frac
+            # what the tile-interleaved layout can reach at best: update and downdate lanes share every 64-byte sector,
+            # so an iteration in which a wave holds both kinds moves the factor twice in each direction (2R + 2W)
+            tri = d * (d + 1) // 2 * 8
+            roof["alg_bytes_2r2w_per_proposal"] = 16 * d + 32 + int(round(tri * (2.0 + 2.0 * (1.0 - (1.0 - down_frac) ** 64))))   # share of waves with a downdate lane
+    if pmc:
+        roof["traffic_measured_at"] = {"kernels_sha": pmc["kernels_sha"], "profile": pmc.get("profile")}
+        if "valu_insts_per_proposal" in pmc:      # second roof (SURVEY 8d): vector-instruction issue, from an SQ counter pass
+            ips_ach = pmc["valu_insts_per_proposal"] / 64.0 * per_launch_prop / avg_launch_s / 1e9   # wave-instructions/s
+            roof["issue"] = {"achieved": ips_ach, "peak": VALU_ISSUE_PEAK_GIPS, "unit": "G wave-instr/s",
+                             "frac": ips_ach / VALU_ISSUE_PEAK_GIPS,
+                             "valu_insts_per_proposal": pmc["valu_insts_per_proposal"],
+                             "valu_busy": pmc.get("valu_busy")}
+            if roof["issue"]["frac"] > roof["frac"]:
+                roof["bound_by"] = "valu-issue"
+    elif ab_switches():
+        roof["traffic_note"] = "PMC figures withheld: A/B switches active (%s)" % ", ".join(ab_switches())
+    roof.update(launches=int(klaunch), avg_launch_ms=avg_launch_s * 1e3, kernel_share_of_wall=kms / 1e3 / dt)
+    if roof["bound"] == "hbm" and (pooled or d <= 20):
+        roof["note"] = ("the chip's HBM roof is quoted for uniformity; this configuration is bound by the per-chain random "
+                        "numbers (Philox + polar + pinned log/sqrt on the VALU), see DESIGN.md section 5")
+    if method == "ram":
+        stay = stayed_all / (float(world) * n_local * (nsimu - 1))
+        roof["note"] = ("accepted fraction %.2f (start: %s); RAM updates the factor after alpha >= alphatarget (one "
+                        "read+write sweep) and downdates it otherwise (two sweeps): DESIGN.md section 10 item 6" % (1.0 - stay, start))
+    mode = method + (" pooled (one shared factor)" if pooled else ", per-chain factor")
+    cnt = float(pooled_vec[0])
+    mean = pooled_vec[1:1 + d] / cnt
+    res = {
+        "metric": "MH proposals/sec (whole node), d=50 Gaussian target" if wl == "c4" else "MH proposals/sec (whole node), " + WORKLOADS[wl],
+        "value": value, "ms_per_step": dt / steps * 1e3,
+        "config": {"workload": "%s, method=%s, %d chains/GPU, pooled moments of all %d chains combined every %d iterations (%s)"
+                               % (WORKLOADS[wl], mode, n_local, world * n_local, ips, transport),
+                   "chains_per_gpu": n_local, "its_per_step": ips, "npar": d, "method": method,
+                   "proposals_per_iteration": per_it + dr_per_it / (float(world) * n_local),
+                   "parallelism": "chains sharded over %d GPU(s), one process each" % world},
+        "roofline": roof,
+        "pooled_check": {"chains": cnt, "max_abs_mean": float(np.max(np.abs(mean)))},
+        "_cpu": (wl, ckw, pkw, per_it, "d=%d %s" % (d, method)),
+    }
+    return res, pooled_vec
+
+
+# the other BASELINE configurations, run briefly after the headline in the same process (N = 1): (key, run_config arguments)
+OTHER_CONFIGS = [
+    ("c2", dict(wl="c2", steps=3, warmup=1)),
+    ("c3", dict(wl="c3", steps=3, warmup=1)),
+    ("c4_target", dict(wl="c4", steps=3, warmup=1, start="target")),
+    ("c4_pooled", dict(wl="c4", steps=3, warmup=1, pooled=True)),
+    ("c5_pooled", dict(wl="c5", steps=2, warmup=1)),
+]
 
 
 def main():
@@ -205,6 +464,9 @@ def main():
                     help="c4: 'target' starts from cmat0 = Sigma, i.e. at RAM's target acceptance rate, where most iterations are "
                          "Cholesky downdates (default: cmat0 = 0.01 I, 86 %% accepted, RAM adapts by updates)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the other BASELINE configurations after the headline")
+    ap.add_argument("--comm-timeout", type=float, default=float(os.environ.get("MCMCX_COMM_TIMEOUT", "240")),
+                    help="seconds the ranks may take to form their communicator before the run is given up")
     ap.add_argument("--one-gpu-dryrun", action="store_true",
                     help="debug: all ranks share GPU 0 and exchange through the host transport (checks the N>1 path on a 1-GPU box)")
     ap.add_argument("--dump-moments", default=None, help="debug: rank 0 writes the final pooled moment vector (float64) to this file")
@@ -214,7 +476,7 @@ def main():
         if a.gpus < 1:
             raise SystemExit("--gpus must be >= 1")
         if a.gpus > 1:
-            sys.exit(spawn_ranks(a.gpus, sys.argv[1:]))
+            sys.exit(spawn_ranks(a.gpus, sys.argv[1:], a.comm_timeout))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -222,9 +484,11 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: one rank per GPU" % (a.gpus, world))
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
-    from mcmcf90_amd import engine_from_problem, Comm, _lib
-    from mcmcf90_amd.workloads import problem
-    ndev = _lib.load().mcmcx_device_count()
+    if world > 1:
+        os.environ.setdefault("NCCL_DEBUG", "WARN")                # RCCL's own diagnostics on stderr, should the formation fail
+    from mcmcf90_amd import Comm, _lib
+    L = _lib.load()
+    ndev = L.mcmcx_device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
     dev = 0 if a.one_gpu_dryrun else local_rank
@@ -233,130 +497,65 @@ def main():
             dev = 0                                   # the launcher gave every rank its own single visible GPU
         else:
             raise SystemExit("rank %d: local rank %d but %d HIP device(s) visible -- %d ranks need %d GPUs (or --one-gpu-dryrun)" % (rank, local_rank, ndev, world, world))
+    import ctypes
+    info = ctypes.create_string_buffer(256)
+    L.mcmcx_device_info(dev, info, 256)
     comm = None
+    rccl_ranks = 1
     if world > 1:
         key = os.environ.get("MCMCX_COMM_KEY") or "t%s_%s_%d" % (os.environ.get("TORCHELASTIC_RUN_ID", "x"),
                                                                  os.environ.get("MASTER_PORT", "0"), os.getppid())
+        wd = Watchdog(a.comm_timeout, "forming the %d-rank communicator (%s)" % (world, "host transport" if a.one_gpu_dryrun else "ncclCommInitRank"))
         comm = Comm(key, rank, world, dev, backend="host" if a.one_gpu_dryrun else "rccl")    # raises unless all ranks arrive
-    wl = a.workload
-    n_local = a.chains_per_gpu or DEFAULT_CHAINS[wl]
-    ips = a.its_per_step or (10 if wl == "c5" else 100)       # c5: one iteration is d = 200 componentwise proposals
-    nsimu = 1 + (a.warmup + a.steps) * ips
-    ckw, pkw, per_it = problem(wl, nsimu, adaptint=max(ips, 100))
-    d = pkw["npar"]
-    if wl == "c4" and a.start == "target":
-        pkw = dict(pkw, cmat0=np.linalg.inv(np.asarray(pkw["lam"], dtype=float)))
-    if wl == "c4" and a.method == "dram":
-        ckw = dict(ckw, method="dram")
-    if wl == "c5":
-        a.pooled = not a.replicas
-    elif a.pooled:
-        ckw = dict(ckw, drscale=0.0)                   # c4 keeps method='ram' (pooled RAM); c2 / c3: pooled AM without DR
-        if wl == "c4" and a.method == "dram":
-            ckw = dict(ckw, method="dram")
-    method = ckw.get("method", "dram")
-    eng = engine_from_problem(ckw, pkw, nchains=n_local, chain_id0=rank * n_local, device=dev,
-                              pooled=1 if a.pooled else 0, comm=comm)
-    eng.init()
-
-    def one_step(k):
-        eng.run(1 + (k + 1) * ips)
-        eng.allreduce_moments(fetch=False)             # local fixed tree -> RCCL all-gather -> tree over ranks; stays in HBM
-
-    def fence():
-        eng.sync()                                     # everything this rank queued, the gathers included
-        if comm is not None:
-            comm.barrier()
-            eng.sync()
-
-    for k in range(a.warmup):
-        one_step(k)
-    fence()
-    eng.kernel_time(reset=True)
-    t0 = time.perf_counter()
-    for k in range(a.warmup, a.warmup + a.steps):
-        one_step(k)
-    fence()
-    dt = time.perf_counter() - t0
-    kms, klaunch, ksteps = eng.kernel_time()
-    tot = eng.totals()
-    red = np.array([dt, kms]), np.array([float(tot["drtries"]), float(tot["stayed"]), float(tot["downdates"])])
-    if comm is not None:
-        red = comm.allreduce(red[0], op="max"), comm.allreduce(red[1], op="sum")
-    dt, kms = float(red[0][0]), float(red[0][1])                                    # slowest rank
-    tries, stayed_all, downs_all = (float(x) for x in red[1])
-    pooled = eng.allreduce_moments(fetch=True)                                      # collective: every rank
+        comm.barrier()
+        wd.disarm()
+        rccl_ranks = int(L.mcmcx_comm_size(comm.h))
+        if rccl_ranks != world or int(L.mcmcx_comm_rank(comm.h)) != rank:
+            raise SystemExit("rank %d: the communicator reports rank %d of %d, expected %d of %d" % (rank, L.mcmcx_comm_rank(comm.h), rccl_ranks, rank, world))
+        ld = os.environ.get("MCMCX_BENCH_LOGDIR")
+        if ld:
+            open(os.path.join(ld, "rank%d.formed" % rank), "w").close()
+    sys.stderr.write("bench.py rank %d/%d: HIP device %d of %d visible [%s], communicator %s\n"
+                     % (rank, world, dev, ndev, info.value.decode(errors="replace"),
+                        "none (one GPU)" if comm is None else "%s rank %d of %d" % ("host-staged" if a.one_gpu_dryrun else "RCCL", rank, rccl_ranks)))
+    sys.stderr.flush()
+    transport = "one GPU" if world == 1 else ("host transport, ranks share GPU 0" if a.one_gpu_dryrun else "RCCL all-gather + fixed tree")
+    res, pooled_vec = run_config(a.workload, a.steps, a.warmup, rank, world, dev, comm, chains_per_gpu=a.chains_per_gpu,
+                                 its_per_step=a.its_per_step, method_opt=a.method, pooled=a.pooled, replicas=a.replicas,
+                                 start=a.start, transport=transport)
     if rank == 0:
-        base = float(world) * n_local * ips * per_it
-        dr_per_it = tries / (a.warmup + a.steps) / ips                              # stage-2 proposals per iteration, all ranks
-        proposals = (base + dr_per_it * ips) * a.steps
-        value = proposals / dt
-        per_launch_prop = proposals / world / max(klaunch, 1)                        # proposals one launch of one GPU evaluates
-        avg_launch_s = kms / 1e3 / max(klaunch, 1)
-        ckey = "%s_%s%s" % (wl, "pooled" if a.pooled else method, "_target" if a.start == "target" else "")
-        pmc = measured_counters(ckey)
-        if wl == "c5" and a.pooled:                   # shared rotation: three d x d products per proposal on the f64 matrix cores
-            flop = 6.0 * d * d
-            achieved = flop * per_launch_prop / avg_launch_s / 1e12
-            roof = {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": achieved / FP64_MFMA_PEAK_TF, "traffic": None, "kernel": "mcx::scam_pooled_kernel",
-                    "alg_flop_per_proposal": flop}
-        else:
-            down_frac = downs_all / (float(world) * n_local * (nsimu - 1)) if method == "ram" else 0.0
-            balg = alg_bytes_per_proposal(d, "pooled" if a.pooled else method, down_frac)
-            achieved = balg * per_launch_prop / avg_launch_s / 1e9
-            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": pmc["hbm_bytes_per_proposal"] * per_launch_prop if pmc and "hbm_bytes_per_proposal" in pmc else None,
-                    "kernel": "mcx::scam_kernel" if method == "scam" else ("mcx::pooled_mfma_kernel" if a.pooled else "mcx::step_kernel"),
-                    "alg_bytes_per_proposal": balg}
-            if method == "ram":
-                roof["downdate_fraction"] = down_frac
-                # what the tile-interleaved layout can reach at best: update and downdate lanes share every 64-byte sector,
-                # so an iteration in which a wave holds both kinds moves the factor twice in each direction (2R + 2W)
-                tri = d * (d + 1) // 2 * 8
-                roof["alg_bytes_2r2w_per_proposal"] = 16 * d + 32 + int(round(tri * (2.0 + 2.0 * (1.0 - (1.0 - down_frac) ** 64))))   # share of waves with a downdate lane
-        if pmc:
-            roof["traffic_measured_at"] = {"kernels_sha": pmc["kernels_sha"], "profile": pmc.get("profile")}
-            if "valu_insts_per_proposal" in pmc:      # second roof: vector-instruction issue, from an SQ counter pass
-                ips_ach = pmc["valu_insts_per_proposal"] / 64.0 * per_launch_prop / avg_launch_s / 1e9   # wave-instructions/s
-                roof["issue"] = {"achieved": ips_ach, "peak": VALU_ISSUE_PEAK_GIPS, "unit": "G wave-instr/s",
-                                 "frac": ips_ach / VALU_ISSUE_PEAK_GIPS,
-                                 "valu_insts_per_proposal": pmc["valu_insts_per_proposal"],
-                                 "valu_busy": pmc.get("valu_busy")}
-                if roof["issue"]["frac"] > roof["frac"]:
-                    roof["bound_by"] = "valu-issue"
-        roof.update(launches=int(klaunch), avg_launch_ms=avg_launch_s * 1e3, kernel_share_of_wall=kms / 1e3 / dt)
-        if roof["bound"] == "hbm" and (a.pooled or d <= 20):
-            roof["note"] = ("the chip's HBM roof is quoted for uniformity; this configuration is bound by the per-chain random "
-                            "numbers (Philox + polar + pinned log/sqrt on the VALU), see DESIGN.md section 5")
-        if method == "ram":
-            stay = stayed_all / (float(world) * n_local * (nsimu - 1))
-            roof["note"] = ("accepted fraction %.2f (start: %s); RAM updates the factor after alpha >= alphatarget (one "
-                            "read+write sweep) and downdates it otherwise (two sweeps): DESIGN.md section 10 item 6" % (1.0 - stay, a.start))
-        mode = method + (" pooled (one shared factor)" if a.pooled else ", per-chain factor")
-        cnt = float(pooled[0])
-        mean = pooled[1:1 + d] / cnt
+        cpu_args = res.pop("_cpu")
         line = {
-            "metric": "MH proposals/sec (whole node), d=50 Gaussian target" if wl == "c4" else "MH proposals/sec (whole node), " + WORKLOADS[wl],
-            "value": value, "unit": "proposals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": res["metric"], "value": res["value"], "unit": "proposals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s, method=%s, %d chains/GPU, pooled moments of all %d chains combined every %d iterations (%s)"
-                                   % (WORKLOADS[wl], mode, n_local, world * n_local, ips,
-                                      "one GPU" if world == 1 else ("host transport, ranks share GPU 0" if a.one_gpu_dryrun else "RCCL all-gather + fixed tree")),
-                       "chains_per_gpu": n_local, "its_per_step": ips, "npar": d, "method": method,
-                       "proposals_per_iteration": per_it + dr_per_it / (float(world) * n_local),
-                       "parallelism": "chains sharded over %d GPU(s), one process each" % world},
-            "roofline": roof,
-            "pooled_check": {"chains": cnt, "max_abs_mean": float(np.max(np.abs(mean)))},
+            "config": res["config"], "roofline": res["roofline"], "pooled_check": res["pooled_check"],
+            "rccl_ranks": rccl_ranks if (world > 1 and not a.one_gpu_dryrun) else (1 if world == 1 else 0),
+            "engine_sha": kernels_sha(),
         }
+        if world == 1 and not a.no_other_configs and a.workload == "c4" and not (a.pooled or a.method or a.start != "default" or a.chains_per_gpu or a.its_per_step):
+            # the other BASELINE configurations, briefly, in this same process (builder-independent numbers for all of them)
+            others = {}
+            for key, kw in OTHER_CONFIGS:
+                try:
+                    t0 = time.perf_counter()
+                    r, _ = run_config(rank=0, world=1, dev=dev, comm=None, **kw)
+                    rf = r["roofline"]
+                    others[key] = {"value": r["value"], "unit": "proposals/s", "ms_per_step": r["ms_per_step"], "steps": kw["steps"],
+                                   "bound": rf["bound"], "roofline_frac": rf["frac"], "achieved": rf["achieved"], "roofline_unit": rf["unit"],
+                                   "issue_frac": rf.get("issue", {}).get("frac"), "kernel": rf["kernel"],
+                                   "avg_launch_ms": rf["avg_launch_ms"], "kernel_share_of_wall": rf["kernel_share_of_wall"],
+                                   "alg_per_proposal": rf.get("alg_bytes_per_proposal", rf.get("alg_flop_per_proposal")),
+                                   "workload": r["config"]["workload"], "proposals_per_iteration": r["config"]["proposals_per_iteration"],
+                                   "wall_s_incl_init": time.perf_counter() - t0}
+                except Exception as ex:
+                    others[key] = {"error": str(ex)[:300]}
+            line["other_configs"] = others
         if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(wl, ckw, pkw, per_it, "d=%d %s" % (d, method))
+            line["cpu_baseline"] = cpu_baseline(*cpu_args)
         if a.dump_moments:
-            np.asarray(pooled, dtype=np.float64).tofile(a.dump_moments)
+            np.asarray(pooled_vec, dtype=np.float64).tofile(a.dump_moments)
         print(json.dumps(line), flush=True)
-    eng.close()
     if comm is not None:
         comm.barrier()
         comm.close()

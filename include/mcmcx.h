@@ -71,6 +71,7 @@ int  mcmcx_destroy(mcmcx_handle h);
 const char *mcmcx_last_error(void);
 const char *mcmcx_version(void);
 int32_t mcmcx_device_count(void);                              /* HIP devices visible to this process (0: none -- nothing will run) */
+int mcmcx_device_info(int32_t device, char *buf, int32_t len); /* "name arch, pci bus id, CUs, memory" of one of them (diagnostics) */
 
 int mcmcx_set_par0(mcmcx_handle h, const double *par0, int32_t npar);
 int mcmcx_set_cmat0(mcmcx_handle h, const double *cmat0_colmajor, int32_t npar);
@@ -232,6 +233,9 @@ int mcmcx_kernel_time(mcmcx_handle h, double *ms, int64_t *launches, int64_t *st
 int mcmcx_debug_math(int32_t op, int32_t n, const double *a, const double *b, double *out);
 int mcmcx_debug_rng(uint32_t seed, uint32_t chain_id, int32_t kind, int32_t n, double a, double b, double *out,
                     uint64_t *nused);
+/* every chain's SVD proposal factor (per-chain mode, condmax > 0) replaced by R (column-major d x d; scam: the rotation)
+ * and qcovstd (scam; NULL = keep): a test feeds the factors an external dgesvd returned at an adaptation */
+int mcmcx_debug_set_factor(mcmcx_handle h, const double *R_colmajor, const double *qcovstd);
 
 #ifdef __cplusplus
 }

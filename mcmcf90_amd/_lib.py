@@ -32,6 +32,7 @@ SYMBOLS = {
     "mcmcx_last_error": (C.c_char_p, []),
     "mcmcx_version": (C.c_char_p, []),
     "mcmcx_device_count": (C.c_int32, []),
+    "mcmcx_device_info": (C.c_int, [C.c_int32, C.c_char_p, C.c_int32]),
     "mcmcx_set_par0": (C.c_int, [C.c_void_p, _DP, C.c_int32]),
     "mcmcx_set_cmat0": (C.c_int, [C.c_void_p, _DP, C.c_int32]),
     "mcmcx_set_sigma2nobs": (C.c_int, [C.c_void_p, _DP, _IP, C.c_int32]),
@@ -64,6 +65,7 @@ SYMBOLS = {
     "mcmcx_debug_math": (C.c_int, [C.c_int32, C.c_int32, _DP, _DP, _DP]),
     "mcmcx_debug_rng": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_double, C.c_double, _DP,
                                   C.POINTER(C.c_uint64)]),
+    "mcmcx_debug_set_factor": (C.c_int, [C.c_void_p, _DP, _DP]),
     "mcmcx_kernel_time": (C.c_int, [C.c_void_p, _DP, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]),
 }
 

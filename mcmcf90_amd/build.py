@@ -16,6 +16,17 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared"
          "-Wno-unused-value", "-Wno-cuda-compat"]
 
 
+def source_sha():
+    """sha of everything that decides which instructions run: kernels, device functions, host orchestration (kernel choice,
+    LDS sizes, launch geometry) and the communicator.  bench.py and tools/ key the stored PMC figures on it."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SRC):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def stale():
     if not os.path.exists(LIB):
         return True

@@ -339,7 +339,20 @@ static void launch_scam(mcmcx_engine *h, int it0, int it1)
                            h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedU, h->d_sharedU + st, h->d_sharedU + 2 * st);
         return;
     }
-    hipLaunchKernelGGL(scam_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
+    // few tiles: several waves per tile (scam_mw_kernel), so that a sub-step is not bound by the latency of one wave's loads
+    // while most of the chip idles -- as many waves as keep the chip's ~2048 resident-wave slots busy, at most 8 (sixteen
+    // waves of 128 registers spill the products' panels)
+    int nw = 1;
+    while (nw < 8 && (long long)h->ntiles * nw * 2 <= 2048) nw *= 2;
+    if (const char *e = getenv("MCMCX_SCAM_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) nw = v; }   // A/B switch for tests
+    const size_t lds = (size_t)(4 * ((h->d + 15) / 16) + 2) * 64 * sizeof(double);
+    const dim3 g(h->ntiles);
+    switch (nw) {
+    case 8: hipLaunchKernelGGL(scam_mw_kernel<8>, g, dim3(512), lds, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT); break;
+    case 4: hipLaunchKernelGGL(scam_mw_kernel<4>, g, dim3(256), lds, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT); break;
+    case 2: hipLaunchKernelGGL(scam_mw_kernel<2>, g, dim3(128), lds, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT); break;
+    default: hipLaunchKernelGGL(scam_kernel, g, dim3(64), 0, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
+    }
 }
 // LDS of svd_blocked_kernel for block width b: four blocks of b columns (odd stride) + the rotation slots
 static size_t svd_lds(int d, int b) { const int LS = ((d + 1) & ~1) + (((d + 1) & 2) ? 0 : 2); return ((size_t)2 * b * LS + 64) * sizeof(double) + 32 * sizeof(int); }   // two blocks of b columns + the rotation slots
@@ -862,6 +875,17 @@ extern "C" {
 const char *mcmcx_last_error(void) { return g_err.c_str(); }
 const char *mcmcx_version(void) { return "mcmcx 0.2 (gfx950)"; }
 int32_t mcmcx_device_count(void) { int n = 0; return (hipGetDeviceCount(&n) == hipSuccess) ? n : 0; }
+int mcmcx_device_info(int32_t device, char *buf, int32_t len)
+{
+    if (!buf || len < 2) return fail(-1, "mcmcx_device_info: bad argument");
+    hipDeviceProp_t prop;
+    char bus[64] = "?";
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) { snprintf(buf, (size_t)len, "device %d: %s", device, hipGetErrorString(e)); return fail(-10, buf); }
+    (void)hipDeviceGetPCIBusId(bus, (int)sizeof bus, device);
+    snprintf(buf, (size_t)len, "%s %s, pci %s, %d CUs, %.0f GiB", prop.name, prop.gcnArchName, bus, prop.multiProcessorCount, (double)prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
+    return 0;
+}
 
 void mcmcx_config_defaults(mcmcx_config *c)                      // mcmcinit.F90:184-230
 {
@@ -1804,6 +1828,21 @@ int mcmcx_debug_math(int32_t op, int32_t n, const double *a, const double *b, do
     hipLaunchKernelGGL(debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, op, n, da, db, dout);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// Replace the SVD proposal factor of EVERY chain (per-chain mode, condmax > 0): R column-major d x d (scam: the rotation U),
+// qcovstd (scam; may be NULL).  Lets a test feed the factors an external LAPACK returned at an adaptation
+// (tests/test_gpu_parity.py: the MKL-linked reference's logged dgesvd results at d = 200).
+int mcmcx_debug_set_factor(mcmcx_handle h, const double *R_colmajor, const double *qcovstd)
+{
+    if (!h || !h->inited || !R_colmajor) return fail(-1, "mcmcx_debug_set_factor: bad argument");
+    if (!h->usesvd || h->pooled || !h->E.Rf) return fail(-45, "mcmcx_debug_set_factor: per-chain SVD factor only (condmax > 0, not pooled)");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<double> r(R_colmajor, R_colmajor + (size_t)h->d * h->d);
+    int rc = dev_bcast(h, h->E.Rf, r); if (rc) return rc;
+    if (qcovstd && h->E.qstd) { std::vector<double> q(qcovstd, qcovstd + h->d); if ((rc = dev_bcast(h, h->E.qstd, q))) return rc; }
     return 0;
 }
 

@@ -216,6 +216,46 @@ constexpr int PW = 8;     // panel width: columns (or rows) of per-lane state he
 constexpr int RW = MCX_RW;  // panel width of the RAM sweep (d = 50: five full panels)
 constexpr int TW = MCX_TW;  // panel width of the per-chain triangular product
 
+// One block of 16 rows of the Gaussian target (mcxt_ss_gauss, oracle/mcx_targets.h): y_i = sum_j lam(i,j) v_j as fma chains
+// ascending in j, and the block's four partial chains q_k over the rows B0 + k + 4r.  ss is the running sum of the q_k over
+// the blocks in order; blocks are independent of one another (a workgroup's waves share them in scam_mw_kernel).
+MCX_DEV void gauss_block_q(int d, int lane, const double *c_t, const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
+                           int B0, double (&q)[4])
+{
+    q[0] = q[1] = q[2] = q[3] = 0.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int I0 = B0 + PW * h;
+        if (I0 < d) {
+            const int nr = (d - I0) < PW ? (d - I0) : PW;
+            double y[PW];
+#pragma unroll
+            for (int u = 0; u < PW; ++u) y[u] = 0.0;
+            for (int J0 = 0; J0 < d; J0 += PW) {
+                const int nc = (d - J0) < PW ? (d - J0) : PW;
+                double v[PW];
+#pragma unroll
+                for (int w = 0; w < PW; ++w) { int j = J0 + (w < nc ? w : nc - 1); v[w] = GV(c_t, j) - g_mu[j]; }
+#pragma unroll
+                for (int w = 0; w < PW; ++w) {
+                    if (w < nc) {
+                        const double *__restrict__ lrow = g_lamT + (size_t)(J0 + w) * d + I0;
+#pragma unroll
+                        for (int u = 0; u < PW; ++u) y[u] = dfma(lrow[u], v[w], y[u]);
+                    }
+                }
+            }
+            double vi[PW];
+#pragma unroll
+            for (int u = 0; u < PW; ++u) { int i = I0 + (u < nr ? u : nr - 1); vi[u] = GV(c_t, i) - g_mu[i]; }
+#pragma unroll
+            for (int u = 0; u < PW; ++u) {
+                if (u < nr) { if (h == 0 && u < 4) q[u & 3] = y[u] * vi[u]; else q[u & 3] = dfma(y[u], vi[u], q[u & 3]); }
+            }
+        }
+    }
+}
+
 // WIDE: keep every row accumulator in registers and read the candidate once (pays when the kernel is
 // bandwidth-bound: RAM); otherwise one row panel at a time (fewer registers: pooled / AM / DR kernels).
 template <bool WIDE>
@@ -282,38 +322,8 @@ MCX_DEV double target_ss(const DevTarget &t, int d, int lane, const double *c_t,
         }
     } else if (t.kind == TGT_GAUSS) {
         for (int B0 = 0; B0 < d; B0 += 16) {
-            double q[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int I0 = B0 + PW * h;
-                if (I0 < d) {
-                    const int nr = (d - I0) < PW ? (d - I0) : PW;
-                    double y[PW];
-#pragma unroll
-                    for (int u = 0; u < PW; ++u) y[u] = 0.0;
-                    for (int J0 = 0; J0 < d; J0 += PW) {
-                        const int nc = (d - J0) < PW ? (d - J0) : PW;
-                        double v[PW];
-#pragma unroll
-                        for (int w = 0; w < PW; ++w) { int j = J0 + (w < nc ? w : nc - 1); v[w] = GV(c_t, j) - g_mu[j]; }
-#pragma unroll
-                        for (int w = 0; w < PW; ++w) {
-                            if (w < nc) {
-                                const double *__restrict__ lrow = g_lamT + (size_t)(J0 + w) * d + I0;
-#pragma unroll
-                                for (int u = 0; u < PW; ++u) y[u] = dfma(lrow[u], v[w], y[u]);
-                            }
-                        }
-                    }
-                    double vi[PW];
-#pragma unroll
-                    for (int u = 0; u < PW; ++u) { int i = I0 + (u < nr ? u : nr - 1); vi[u] = GV(c_t, i) - g_mu[i]; }
-#pragma unroll
-                    for (int u = 0; u < PW; ++u) {
-                        if (u < nr) { if (h == 0 && u < 4) q[u & 3] = y[u] * vi[u]; else q[u & 3] = dfma(y[u], vi[u], q[u & 3]); }
-                    }
-                }
-            }
+            double q[4];
+            gauss_block_q(d, lane, c_t, g_mu, g_lamT, B0, q);
 #pragma unroll
             for (int k = 0; k < 4; ++k) if (B0 + k < d) ss = (B0 == 0 && k == 0) ? q[0] : ss + q[k];
         }
@@ -549,14 +559,15 @@ MCX_DEV void trmv_panels(const double *Rt, const double *z_t, double *P_t, const
 // PIPE (the per-chain SCAM kernel, which does nothing but stream its rotation): four columns' loads in flight -- left to
 // itself the compiler sinks every load next to its fma and keeps ~4 outstanding.  The step kernels (SVD proposal factor)
 // keep the plain form: their registers are spoken for.
-template <bool PIPE = false>
-MCX_DEV void gemvN_panels(const double *Mt, const double *x_t, double *out_t, const double *add_t, int lane, int d, bool act)
+template <bool PIPE = false, int NBO = 0>       // NBO: rows in flight, when not the default of PIPE
+MCX_DEV void gemvN_panels(const double *Mt, const double *x_t, double *out_t, const double *add_t, int lane, int d, bool act,
+                          int p0 = 0, int pstep = 1)                 // panels p0, p0 + pstep, ...: a workgroup's waves share the rows
 {
 #ifndef MCX_GEMV_NB
 #define MCX_GEMV_NB 4
 #endif
-    constexpr int NB = PIPE ? MCX_GEMV_NB : 1;
-    for (int I0 = 0; I0 < d; I0 += PW) {
+    constexpr int NB = NBO ? NBO : (PIPE ? MCX_GEMV_NB : 1);
+    for (int I0 = p0 * PW; I0 < d; I0 += pstep * PW) {
         const int nr = (d - I0) < PW ? (d - I0) : PW;
         double y[PW];
 #pragma unroll
@@ -585,14 +596,14 @@ MCX_DEV void gemvN_panels(const double *Mt, const double *x_t, double *out_t, co
     }
 }
 // y = M'x (dgemv 'T'): y_k = sum_i M(i,k) x_i, i ascending, one fma chain per column.
-template <bool PIPE = false>
-MCX_DEV void gemvT_panels(const double *Mt, const double *x_t, double *out_t, int lane, int d)
+template <bool PIPE = false, int NBO = 0>
+MCX_DEV void gemvT_panels(const double *Mt, const double *x_t, double *out_t, int lane, int d, int p0 = 0, int pstep = 1)
 {
 #ifndef MCX_GEMV_NB
 #define MCX_GEMV_NB 4
 #endif
-    constexpr int NB = PIPE ? MCX_GEMV_NB : 1;
-    for (int K0 = 0; K0 < d; K0 += PW) {
+    constexpr int NB = NBO ? NBO : (PIPE ? MCX_GEMV_NB : 1);
+    for (int K0 = p0 * PW; K0 < d; K0 += pstep * PW) {
         const int nc = (d - K0) < PW ? (d - K0) : PW;
         double t[PW];
 #pragma unroll
@@ -1517,6 +1528,100 @@ __global__ __launch_bounds__(64, MCX_SCAM_WAVES) void scam_kernel(EngineDev E, i
         if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
     }
     lane_store(E, tile, lane, L);
+}
+
+// The same iteration with NW waves per tile (a workgroup of 64 NW threads; lane = chain, wave = a share of the work): for
+// chain counts that leave most of the chip idle at one wave per tile (the reference's own use is ONE chain), where a
+// sub-step is bound by the latency of one wave's loads -- 2 d^2 x 512 bytes streamed with ~16 kB in flight.  Every output
+// element of the two products is its own fma chain (gemvT: one per column, gemvN: one per row), and the Gaussian target's
+// blocks of 16 rows are independent up to the running sum of their q_k, so the waves share panels / blocks without
+// changing one operation; wave 0 owns the per-chain scalar state (stream, ss1, counters), draws, decides, and hands the
+// deviate and the accept flag to the others through LDS.  Vectors stay in the per-chain global scratch (the workgroup's
+// waves run on one CU and meet at workgroup barriers).  lds: [16 nblk][64] partial chains, [64] deviates, [64] flags.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void scam_mw_kernel(EngineDev E, int it0, int it1,
+                                                          const double *__restrict__ g_mu, const double *__restrict__ g_lamT)
+{
+    extern __shared__ double lds_mw[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tile = blockIdx.x, d = E.d;
+    const int nblk = (d + 15) / 16;
+    double *Q = lds_mw, *zl = lds_mw + (size_t)4 * nblk * 64, *fl = zl + 64;
+    double *theta_t = E.theta + (size_t)tile * d * 64;
+    double *cand_t = E.cand + (size_t)tile * d * 64;
+    double *rot_t = E.cs + (size_t)tile * 2 * d * 64;
+    const double *Ut = E.Rf + (size_t)tile * d * d * 64;
+    const double *std_t = E.qstd + (size_t)tile * d * 64;
+    const bool gauss = (E.tgt.kind == TGT_GAUSS);
+    LaneState L;
+    if (w == 0) lane_load(E, tile, lane, L);
+    for (int it = it0; it <= it1; ++it) {
+        bool rejall = true;
+        for (int j = 0; j < d; ++j) {
+            if (w == 0) zl[lane] = rng_normal(L.g) * GV(std_t, j);           // the sub-step's first draw (MCMC_run_scam.F90:108)
+            gemvT_panels<true, (NW >= 8 ? 2 : 0)>(Ut, theta_t, rot_t, lane, d, w, NW);      // many waves: fewer rows in flight each (registers)
+            __syncthreads();
+            if (w == (j / PW) % NW) GV(rot_t, j) = GV(rot_t, j) + zl[lane];  // by the wave that wrote rot_j
+            __syncthreads();
+            gemvN_panels<true, (NW >= 8 ? 2 : 0)>(Ut, rot_t, cand_t, nullptr, lane, d, true, w, NW);
+            __syncthreads();
+            if (gauss) {
+                for (int b = w; b < nblk; b += NW) {
+                    double q[4];
+                    gauss_block_q(d, lane, cand_t, g_mu, g_lamT, 16 * b, q);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) Q[(size_t)(4 * b + k) * 64 + lane] = q[k];
+                }
+                __syncthreads();
+            }
+            if (w == 0) {
+                bool inb = target_inbounds(E.tgt, d, lane, cand_t);
+                double pri2 = target_prior(E.tgt, d, lane, cand_t);
+                double ss2 = 0.0;
+                if (gauss) { for (int e = 0; e < 4 * nblk; ++e) if (16 * (e >> 2) + (e & 3) < d) ss2 = (e == 0) ? Q[lane] : ss2 + Q[(size_t)e * 64 + lane]; }
+                else ss2 = target_ss<false>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
+                bool reject;
+                if (!inb) { L.bnd += 1; L.alpha12 = 0.0; reject = true; }
+                else {
+                    L.alpha12 = d_alpha(L.ss1, L.pri1, ss2, pri2, L.sigma2);
+                    reject = true;
+                    if (L.alpha12 >= 1.0) reject = false;
+                    else if (L.alpha12 > 0.0) { double u = rng_uniform(L.g); if (u <= L.alpha12) reject = false; }
+                }
+                if (!reject) { L.ss1 = ss2; L.pri1 = pri2; rejall = false; }
+                fl[lane] = reject ? 0.0 : 1.0;
+            }
+            __syncthreads();
+            if (fl[lane] != 0.0) for (int K0 = w * PW; K0 < d; K0 += NW * PW) {
+                double v[PW];
+#pragma unroll
+                for (int u = 0; u < PW; ++u) v[u] = GV(cand_t, K0 + (K0 + u < d ? u : 0));
+#pragma unroll
+                for (int u = 0; u < PW; ++u) if (K0 + u < d) GV(theta_t, K0 + u) = v[u];
+            }
+            __syncthreads();
+        }
+        if (w == 0) {
+            if (rejall) { L.stayed += 1; L.curcount += 1; }
+            else { L.chainind += 1; L.curcount = 1; }
+            if (E.updatesigma) {
+                double gm = rng_gamma(L.g, E.gam_shape, 2.0 / (E.N0S02 + L.ss1));
+                L.sigma2 = 1.0 / gm;
+            }
+            unsigned long long ballot = __ballot(!rejall);
+            const int slot = it % E.wcap;
+            if (E.hist) {
+                if (!rejall) {
+                    double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64;
+                    copy_vec(h, theta_t, nullptr, lane, d);
+                    GV(h, d) = L.ss1;
+                }
+                if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ballot;
+                if (E.record_s2) E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = L.sigma2;
+            }
+            if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
+        }
+    }
+    if (w == 0) lane_store(E, tile, lane, L);
 }
 
 // ---------------------------------------------------------------- pooled SCAM: one rotation shared by all chains

@@ -337,6 +337,12 @@ class Engine:
         self._chk(self.L.mcmcx_get_pooled(self.h, cm.ctypes.data_as(dp), _dp(m), C.byref(w), R.ctypes.data_as(dp)))
         return np.array(cm), m, w.value, np.array(R)
 
+    def debug_set_factor(self, R, qcovstd=None):
+        """Test probe: every chain's SVD proposal factor replaced by R[i, j] (scam: the rotation U) and qcovstd."""
+        a = np.asfortranarray(np.asarray(R, dtype=np.float64))
+        q = None if qcovstd is None else _f64(qcovstd)
+        self._chk(self.L.mcmcx_debug_set_factor(self.h, a.ctypes.data_as(C.POINTER(C.c_double)), _dp(q)))
+
     def kernel_time(self, reset=False):
         ms, nl, ns = C.c_double(), C.c_int64(), C.c_int64()
         self._chk(self.L.mcmcx_kernel_time(self.h, C.byref(ms), C.byref(nl), C.byref(ns), int(reset)))

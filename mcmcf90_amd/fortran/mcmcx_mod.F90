@@ -63,6 +63,7 @@ module mcmcmod
   character(len=256), save :: mufile = 'mcmctest_mu.dat', lamfile = 'mcmctest_lam.dat'
   character(len=256), save :: datafile = 'data.dat', lowerfile = '', upperfile = ''
   integer, save :: ngpus = 1                           ! GPUs of this node: nchains/ngpus chains each, one RCCL communicator
+  integer, save :: usecomm = 0                         ! 1: form the RCCL communicator for ngpus = 1 too (the N-GPU code path on one GPU)
   !! the user's own functions faster than one host call per chain:
   !!   hostbatch = 1: ssfunction_batch(theta(npar,n), npar, n, ny, ss(ny,n)) once per stage (default member: a loop over
   !!                  ssfunction), from hostthreads threads on disjoint column blocks when hostthreads > 1
@@ -71,7 +72,7 @@ module mcmcmod
   integer, save :: hostbatch = 0, hostthreads = 1
   character(len=256), save :: modulefile = '', modulekernel = 'user_target', moduledatafile = ''
   namelist /mcmcx/ devtarget, nchains, seed, pooled, banana_b, mufile, lamfile, datafile, lowerfile, upperfile, ngpus, &
-       hostbatch, hostthreads, modulefile, modulekernel, moduledatafile
+       hostbatch, hostthreads, modulefile, modulekernel, moduledatafile, usecomm
 
   !! public state, mcmc.F90:28-52
   integer, save :: npar = 0, nycol = 1, simuind = 0, chainind = 0, MCMC_running = 0
@@ -759,7 +760,7 @@ contains
     nloc = nchains / ngpus
     allocate(handles(ngpus), comms(ngpus))
     handles = c_null_ptr; comms = c_null_ptr
-    if (ngpus > 1) call chk(mcmcx_comm_create_all(int(ngpus, c_int32_t), c_null_ptr, comms))
+    if (ngpus > 1 .or. usecomm /= 0) call chk(mcmcx_comm_create_all(int(ngpus, c_int32_t), c_null_ptr, comms))
     call mcmcx_config_defaults(cfg)
     cfg%npar = npar; cfg%nchains = nloc; cfg%nsimu = nsimu
     select case (trim(method))
@@ -794,7 +795,7 @@ contains
        cfg%record_chain = merge(1, 0, g == 1)           ! the reference's chain arrays hold chain 1, which lives on GPU 0
        call chk(mcmcx_create(cfg, handles(g)))
        handle = handles(g)
-       if (ngpus > 1) call chk(mcmcx_set_comm(handle, comms(g)))
+       if (ngpus > 1 .or. usecomm /= 0) call chk(mcmcx_set_comm(handle, comms(g)))
        call chk(mcmcx_set_par0(handle, par0, int(npar, c_int32_t)))
        call chk(mcmcx_set_cmat0(handle, cmat0, int(npar, c_int32_t)))
        call chk(mcmcx_set_sigma2nobs(handle, sigma2, nob, int(nycol, c_int32_t)))
@@ -916,7 +917,7 @@ contains
           call chk(mcmcx_get_theta(handles(g), th))
           laststates((g-1)*nloc+1 : g*nloc, :) = transpose(reshape(th, (/npar, nloc/)))
        end do
-       if (ngpus > 1) then
+       if (ngpus > 1 .or. usecomm /= 0) then
           call chk(mcmcx_allreduce_moments_all(handles, int(ngpus, c_int32_t), pm))      ! RCCL: all GPUs' chains
        else
           call chk(mcmcx_pooled_moments(handle, pm))

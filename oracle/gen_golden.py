@@ -15,6 +15,7 @@ Each fixture holds: cfg_* (namelist values), problem arrays, and from the refere
     s2_head / s2_tail       s2chain (if updatesigma)
     chaincmat, chainmean    mcmccovf.dat / mcmcmean.dat
     rng_n     number of uniforms the reference drew
+    svd_s, svd_U, svd_ticks, rows_at_ticks   (c5 only) what MKL's dgesvd returned at MCMC_init and at each adaptation
 """
 import os
 import sys
@@ -110,30 +111,52 @@ def cases():
                             dict(m, cmat0=np.diag([0.5, 0.005, 0.01]), sigma2=[0.5, 0.5]), 59)
     c["m5_expdata2_burnin_greedy_priors"] = (dict(nsimu=3000, adaptint=100, updatesigma=1, doburnin=1, burnintime=500, greedy=1, scalelimit=0.3),
                                               dict(m, pri_mu=[9.0, 0.1, 0.2], pri_sig=[1.0, 0.0, 0.1]), 55)
-    # --- BASELINE config 5 at its own dimension (SURVEY.md section 8c asks for "d=200 SCAM 50 its").  Past an adaptation
-    # the d=200 trajectory is not a function of the inputs alone: the new rotation is the singular basis of a covariance
-    # with many nearly equal small singular values, and 1e-16 differences in the states (MKL's dgemv order, glibc's log
-    # in the normal deviates) turn that basis by O(1) -- the reference linked to another BLAS would not reproduce
-    # itself either.  So the fixture pins what is well posed: 250 iterations x 200 componentwise proposals with the
-    # initial rotation, and the covariance / mean the adaptation at the last iteration sees.
+    # --- BASELINE config 5 at its own dimension (SURVEY.md section 8c asks for "d=200 SCAM 50 its"), through TWO
+    # adaptations (iterations 100 and 200).  Past an adaptation the d=200 trajectory is not a function of the inputs alone:
+    # the covariance of <= 200 rows has rank < 200, the rotation in its null space is whatever the LAPACK linked makes of
+    # rounding noise, and the reference linked to another BLAS would not reproduce itself either.  So this fixture comes
+    # from the reference with MKL's own dgesvd, every call logged (oracle/_ref/mcxref_mkllog, ref/dgesvd_logger.c), and
+    # holds what those calls returned (svd_s, svd_U): a checker that takes the logged factors at the same adaptations must
+    # reproduce the reference's 250 iterations x 200 componentwise proposals decision by decision
+    # (tests/test_oracle_golden.py, tests/test_gpu_parity.py), which pins MCMC_run_scam.F90:38-138 and the covariance
+    # MCMC_adapt hands to scam_svd (MCMC_adapt.F90:138-157, matutils.F90:583-653) independently of any SVD routine.
     from mcmcf90_amd.workloads import problem
-    ckw, pkw, _ = problem("c5", 250, adaptint=250)
+    ckw, pkw, _ = problem("c5", 250, adaptint=100)
     c["c5_illcond200_scam"] = (ckw, pkw, 51)
     return c
 
 
+MKL_LOGGED = {"c5_illcond200_scam"}       # fixtures made with MKL's dgesvd + the call log instead of the pinned routine
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    only = set(sys.argv[1:])                 # python oracle/gen_golden.py [name ...]: regenerate these fixtures only
     for name, (ckw, pkw, chain_id) in cases().items():
+        if only and name not in only:
+            continue
         cfg = po.make_cfg(**ckw)
         prob = po.Problem(**pkw)
-        r = rr.run_reference(cfg, prob, chain_id=chain_id, pinned_svd=bool(cfg.usesvd))
+        logged = name in MKL_LOGGED
+        r = rr.run_reference(cfg, prob, chain_id=chain_id, pinned_svd=bool(cfg.usesvd) and not logged, svd_log=logged)
         k = 16
-        out = {"chain_id": chain_id, "rng_n": r.rng_n, "chainind": r.chainind, "pinned_svd": int(bool(cfg.usesvd)),
+        out = {"chain_id": chain_id, "rng_n": r.rng_n, "chainind": r.chainind, "pinned_svd": int(bool(cfg.usesvd) and not logged),
                "runlen": r.chain[:, -1].astype(np.int32),
                "rows_head": r.chain[:k, :-1], "rows_tail": r.chain[-k:, :-1],
                "ss_head": r.sschain[:k, 0], "ss_tail": r.sschain[-k:, 0],
                "chaincmat": r.chaincmat, "chainmean": r.chainmean}
+        if logged:
+            # what every dgesvd call returned: [0] MCMC_init's MCMC_calculate_R (cmat0 = 1e-6 I: U = I exactly, not stored),
+            # [1..] the adaptations.  Also the rows the chain stood on at the adaptations (scam writes one row per iteration).
+            assert all(info == 0 for info, _, _ in r.svd_calls)
+            assert np.array_equal(r.svd_calls[0][2], np.eye(prob.npar))
+            out["mkl_logged"] = 1
+            out["svd_s"] = np.array([sv for _, sv, _ in r.svd_calls])
+            out["svd_U"] = np.array([U for _, _, U in r.svd_calls[1:]])
+            ticks = [it for it in range(cfg.adaptint, cfg.nsimu + 1, cfg.adaptint)]
+            out["svd_ticks"] = np.array(ticks[:len(r.svd_calls) - 1], dtype=np.int32)
+            assert r.chainind == cfg.nsimu                      # one row per iteration: row it-1 is the state after iteration it
+            out["rows_at_ticks"] = r.chain[[t - 1 for t in out["svd_ticks"]], :-1]
         if cfg.updatesigma:
             out["s2_head"], out["s2_tail"] = r.s2chain[:k], r.s2chain[-k:]
         if r.sschain.shape[1] > 2:                       # nycol > 1: every ss column

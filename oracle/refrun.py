@@ -165,6 +165,64 @@ def run_reference(cfg, prob, seed=0x6D636D63, chain_id=0, keep=False, timeout=60
             shutil.rmtree(d, ignore_errors=True)
 
 
+def run_reference_many(cfg, prob, nprocs, seed=0x6D636D63, chain_id0=0, timeout=300, pinned_svd=False):
+    """nprocs processes of the reference at once (bench.py's all-cores leg): process c runs the chain keyed
+    (seed, chain_id0 + c) in its own scratch directory (tmpfs when there is one).  Timing only: returns
+    {"wall": seconds from the first start to the last exit, "cpu_seconds": user + system time of all of them, "scratch"}."""
+    if not available():
+        raise RuntimeError("oracle/_ref/mcxref not built (make -C oracle ref)")
+    import time
+    shm = "/dev/shm" if (os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK)) else None
+    top = tempfile.mkdtemp(prefix="mcxrefN_", dir=shm)
+    exe = EXE_SVD if pinned_svd else EXE
+    procs = []
+    try:
+        dirs = []
+        for c in range(nprocs):
+            d = os.path.join(top, "p%d" % c)
+            os.mkdir(d)
+            if c == 0:
+                write_inputs(d, cfg, prob)
+            else:
+                for f in os.listdir(dirs[0]):
+                    os.link(os.path.join(dirs[0], f), os.path.join(d, f))       # inputs are read-only: hard links, no copies
+            dirs.append(d)
+        base = dict(os.environ, MCX_SEED=str(seed), MKL_NUM_THREADS="1", MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1")
+        t0 = time.perf_counter()
+        for c, d in enumerate(dirs):
+            procs.append(subprocess.Popen([exe], cwd=d, env=dict(base, MCX_CHAIN=str(chain_id0 + c)),
+                                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
+        cpu = 0.0
+        left = {p.pid: p for p in procs}
+        while left:
+            if time.perf_counter() - t0 > timeout:
+                raise RuntimeError("%d of %d reference processes still running after %d s" % (len(left), nprocs, timeout))
+            pid, status, ru = os.wait4(-1, os.WNOHANG)
+            if pid == 0:
+                time.sleep(0.002)
+                continue
+            p = left.pop(pid, None)
+            if p is None:
+                continue                                   # some other child of the caller
+            p.returncode = os.waitstatus_to_exitcode(status) if hasattr(os, "waitstatus_to_exitcode") else (status >> 8)
+            cpu += ru.ru_utime + ru.ru_stime
+            if p.returncode != 0:
+                raise RuntimeError("a reference process exited with code %d" % p.returncode)
+        wall = time.perf_counter() - t0
+        for d in dirs:
+            if not os.path.exists(os.path.join(d, "chain.mat")):
+                raise RuntimeError("a reference process produced no chain")
+        return {"wall": wall, "cpu_seconds": cpu, "scratch": "tmpfs" if shm else "disk"}
+    finally:
+        for p in procs:
+            if p.returncode is None:
+                try:
+                    p.kill()
+                except OSError:
+                    pass
+        shutil.rmtree(top, ignore_errors=True)
+
+
 def accepted_from_chain(chain, nsimu):
     """Expand the run-length column (MCMC_aux.F90:167-175) to the per-iteration accept flags."""
     cnt = chain[:, -1].astype(np.int64)

@@ -31,3 +31,19 @@ def accepted_from_runlen(runlen):
     acc = np.zeros(int(cnt.sum()), dtype=np.uint8)
     acc[np.concatenate([[0], np.cumsum(cnt)[:-1]])] = 1
     return acc
+
+
+def logged_factors(z, cfg):
+    """A fixture made with MKL's dgesvd and its call log (oracle/gen_golden.py, MKL_LOGGED): [(iteration, U, qcovstd)] with
+    iteration 0 = MCMC_init's MCMC_calculate_R, then one entry per adaptation; scam_svd's floor applied to the logged
+    singular values (matutils.F90:633-645)."""
+    n = z["svd_s"].shape[1]
+    out = []
+    for k, sv in enumerate(z["svd_s"]):
+        sv = sv.copy()
+        tol = sv[0] / cfg.condmax
+        if sv[-1] <= tol:
+            sv[sv < tol] = tol
+        U = np.eye(n) if k == 0 else z["svd_U"][k - 1]
+        out.append((0 if k == 0 else int(z["svd_ticks"][k - 1]), U, np.sqrt(sv)))
+    return out

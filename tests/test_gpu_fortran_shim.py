@@ -464,11 +464,11 @@ def test_ngpus_namelist_variable():
     import ctypes
     n = ctypes.c_int(0)
     ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(n))
-    nml = "&mcmc\n method = 'dram'\n nsimu = 300\n updatesigma = 0\n verbosity = 0\n/\n&mcmcx\n devtarget = 'banana'\n nchains = 128\n ngpus = %d\n pooled = %d\n/\n"
+    nml = "&mcmc\n method = 'dram'\n nsimu = 300\n updatesigma = 0\n verbosity = 0\n/\n&mcmcx\n devtarget = 'banana'\n nchains = 128\n ngpus = %d\n pooled = %d\n usecomm = %d\n/\n"
     res = {}
-    for ng, pooled in ((1, 0), (2, 0), (2, 1)):
+    for ng, pooled, usecomm in ((1, 0, 0), (2, 0, 0), (2, 1, 0), (1, 1, 0), (1, 1, 1), (1, 0, 1)):
         with tempfile.TemporaryDirectory() as d:
-            open(os.path.join(d, "mcmcinit.nml"), "w").write(nml % (ng, pooled))
+            open(os.path.join(d, "mcmcinit.nml"), "w").write(nml % (ng, pooled, usecomm))
             open(os.path.join(d, "mcmcpar.dat"), "w").write("0 0 0 0\n")
             open(os.path.join(d, "mcmccov.dat"), "w").write("1 0 0 0\n0 1 0 0\n0 0 1 0\n0 0 0 1\n")
             p = subprocess.run([exe], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
@@ -478,12 +478,18 @@ def test_ngpus_namelist_variable():
                 assert not os.path.exists(os.path.join(d, "chain.dat"))
                 continue
             assert p.returncode == 0, out
-            res[(ng, pooled)] = (np.loadtxt(os.path.join(d, "chain.dat"), ndmin=2), np.loadtxt(os.path.join(d, "mcmclaststates.dat"), ndmin=2),
-                                 np.loadtxt(os.path.join(d, "mcmcpooledcov.dat"), ndmin=2))
-    assert res[(1, 0)][1].shape == (128, 4)
-    if (2, 0) in res:                                   # a multi-GPU box: the chains do not depend on the GPU count
-        for a, b in zip(res[(1, 0)], res[(2, 0)]):
+            res[(ng, pooled, usecomm)] = (np.loadtxt(os.path.join(d, "chain.dat"), ndmin=2), np.loadtxt(os.path.join(d, "mcmclaststates.dat"), ndmin=2),
+                                          np.loadtxt(os.path.join(d, "mcmcpooledcov.dat"), ndmin=2))
+    assert res[(1, 0, 0)][1].shape == (128, 4)
+    if (2, 0, 0) in res:                                # a multi-GPU box: the chains do not depend on the GPU count
+        for a, b in zip(res[(1, 0, 0)], res[(2, 0, 0)]):
             np.testing.assert_array_equal(a, b)
+    # usecomm = 1: the N-GPU code path end to end on the one GPU -- ncclCommInitAll(1), mcmcx_set_comm, mcmcx_run_all with the
+    # pooled ticks' all-gathers on the communicator, mcmcx_allreduce_moments_all -- must reproduce the run without it
+    for pooled in (0, 1):
+        for a, b in zip(res[(1, pooled, 0)], res[(1, pooled, 1)]):
+            np.testing.assert_array_equal(a, b)
+    assert not np.array_equal(res[(1, 0, 0)][1], res[(1, 1, 0)][1])          # (the pooled run is a different run)
 
 
 def test_user_program_batched_and_module_targets(oracle, tmp_path):

@@ -109,6 +109,16 @@ def test_c5_illcond200_scam_pooled_65536_chains(oracle):
     floor = std[0] ** 2 / cfg.condmax
     np.testing.assert_allclose((U * np.maximum(std ** 2, floor)) @ U.T, cm, rtol=0, atol=1e-10 * std[0] ** 2)
     assert np.all(np.diff(std) <= 0)
+    # ... and bit for bit the oracle's pinned SVD (scam_svd, matutils.F90:583-653: dgesvd + the condmax floor) of that covariance
+    import ctypes as C
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    G = np.asfortranarray(cm.copy()); V = np.zeros((d, d), order="F"); sv = np.zeros(d)
+    oracle.lib().mcxo_symsvd(d, dp(G), dp(V), dp(sv))
+    tol = sv[0] / cfg.condmax
+    if sv[-1] <= tol:
+        sv[sv < tol] = tol
+    np.testing.assert_array_equal(_bits(U), _bits(V))
+    np.testing.assert_array_equal(_bits(std), _bits(np.sqrt(sv)))
     e.run()
     th = e.theta()
     for c in picks:
@@ -121,16 +131,31 @@ def test_c5_illcond200_scam_pooled_65536_chains(oracle):
     e.close()
 
 
-def test_c5_illcond200_scam_replicas_small(oracle):
-    """The same target with per-chain rotations (the reference's semantics), a few chains up to the first tick."""
+@pytest.mark.parametrize("lane_svd", [0, 1], ids=["blocked_svd", "lane_svd"])
+def test_c5_illcond200_scam_replicas_two_ticks(oracle, lane_svd, monkeypatch):
+    """BASELINE config 5's target with per-chain rotations (the reference's semantics) THROUGH two adaptations: 70 chains
+    (a ragged second tile), adaptint = 10, 25 iterations = 5000 componentwise proposals per chain, the adaptation's pinned
+    SVD in both device forms (a workgroup per chain through LDS -- thirteen column blocks and eight-lane partial chains of
+    25 rows at d = 200 -- and one lane per chain) against oracle.run_chain: state, rotation, qcovstd, covariance, stream
+    position, bit for bit."""
     from mcmcf90_amd import engine_from_problem
     from mcmcf90_amd.workloads import problem
-    ckw, pkw, _ = problem("c5", 4, adaptint=100)
-    e = engine_from_problem(ckw, pkw, nchains=70)
+    if lane_svd:
+        monkeypatch.setenv("MCMCX_SVD_LANE", "1")
+    ckw, pkw, _ = problem("c5", 25, adaptint=10)
+    e = engine_from_problem(ckw, pkw, nchains=70, record_accept=1)
     e.init(); e.run()
     cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
     th = e.theta()
-    for c in (0, 69):
+    for c in (0, 63, 69):
         o = oracle.run_chain(cfg, prob, chain_id=c)
+        np.testing.assert_array_equal(e.accepted(c), o.accepted)
         np.testing.assert_array_equal(_bits(th[c]), _bits(o.theta))
+        np.testing.assert_array_equal(_bits(e.R(c)), _bits(o.R))
+        np.testing.assert_array_equal(_bits(e.qcovstd(c)), _bits(o.qcovstd))
+        cm, mean, wsum = e.chaincov(c)
+        np.testing.assert_array_equal(_bits(np.triu(cm)), _bits(np.triu(o.chaincmat)))
+        np.testing.assert_array_equal(_bits(mean), _bits(o.chainmean))
+        assert e.rng(c)[0] == o.rng_n
+    assert e.totals()["proposals"] == 70 * 24 * 200
     e.close()

@@ -95,28 +95,60 @@ def test_engine_matches_oracle_and_reference(oracle, name):
     e.close()
 
 
-def test_c5_fixture_first_iterations(oracle):
-    """BASELINE config 5's fixture (d=200 SCAM from the real reference): its first 24 iterations = 4800 componentwise
-    proposals on the device, against the fixture's head rows and, bit for bit, against the oracle."""
+def test_c5_fixture_all_iterations_with_the_logged_factors(oracle):
+    """BASELINE config 5's fixture (d=200 SCAM, the MKL-linked reference through the adaptations at iterations 100 and
+    200): ALL 250 iterations = 50000 componentwise proposals per chain on the device.  At each adaptation the engine runs
+    its own tick (covariance update + the pinned SVD) and the test then replaces the factor by what MKL's dgesvd returned
+    to the reference there (mcmcx_debug_set_factor) -- past an adaptation the rotation is not a function of the inputs
+    alone (rank-deficient covariance), see oracle/gen_golden.py.  Chain 1 (the fixture's stream) against the reference:
+    run-length column, stream position, the rows at the adaptations and at both ends; three chains incl. the ragged tile
+    bit for bit against the oracle fed the same factors."""
     from mcmcf90_amd import engine_from_problem
+    from golden_util import logged_factors
     z, cfg, prob = load("c5_illcond200_scam", oracle)
     ckw, pkw = _kw(z)
-    n = 24
-    ckw["nsimu"] = n
     cid = int(z["chain_id"])
+    picks = (0, 1, 65)
     e = engine_from_problem(ckw, pkw, nchains=66, chain_id0=cid - 1, record_accept=1, record_chain=1)
-    e.init(); e.run()
-    np.testing.assert_array_equal(e.accepted(1), accepted_from_runlen(z["runlen"])[:n])
+    e.init()
+    live = {c: oracle.LiveChain(cfg, prob, chain_id=cid - 1 + c) for c in picks}
+    scale = np.maximum(np.abs(z["rows_tail"]).max(axis=0), 1e-3)
+    for k, (it, U, sd) in enumerate(logged_factors(z, cfg)):
+        if it > 0:
+            e.run(it)
+            th = e.theta()
+            assert np.max(np.abs(th[1] - z["rows_at_ticks"][k - 1]) / scale) < 1e-7
+            for c in picks:
+                live[c].run(it)
+                np.testing.assert_array_equal(_bits(th[c]), _bits(live[c].theta))
+            # the tick's own products, before they are replaced: covariance, and the pinned SVD of it (blocked form at d=200)
+            o = live[1].ch.contents
+            cm, mean, wsum = e.chaincov(1)
+            np.testing.assert_array_equal(_bits(np.triu(cm)), _bits(np.triu(np.ctypeslib.as_array(o.chaincmat, shape=(200, 200)).T)))
+            np.testing.assert_array_equal(_bits(e.R(1)), _bits(np.ctypeslib.as_array(o.R, shape=(200, 200)).T))
+            np.testing.assert_array_equal(_bits(e.qcovstd(1)), _bits(np.ctypeslib.as_array(o.qcovstd, shape=(200,))))
+        e.debug_set_factor(U, sd)
+        for c in picks:
+            live[c].set_R(U); live[c].set_qcovstd(sd)
+    e.run()
+    assert e.simuind == cfg.nsimu
+    np.testing.assert_array_equal(e.accepted(1), accepted_from_runlen(z["runlen"]))
     ch, ss, s2 = e.chain(1)
+    np.testing.assert_array_equal(ch[:, -1].astype(np.int32), z["runlen"])
+    assert e.rng(1)[0] == int(z["rng_n"])
     k = z["rows_head"].shape[0]
-    np.testing.assert_allclose(ch[:k, :-1], z["rows_head"], rtol=0, atol=1e-9 * np.abs(z["rows_head"]).max())
-    cfg_n = oracle.make_cfg(**ckw)
-    for c in (0, 1, 65):
-        o = oracle.run_chain(cfg_n, prob, chain_id=cid - 1 + c)
+    assert np.max(np.abs(ch[:k, :-1] - z["rows_head"]) / scale) < 1e-7
+    assert np.max(np.abs(ch[-k:, :-1] - z["rows_tail"]) / scale) < 1e-7
+    np.testing.assert_allclose(ss[-k:, 0], z["ss_tail"], rtol=1e-7, atol=1e-9)
+    cmf, meanf, _ = e.chaincov(1)
+    assert np.max(np.abs(np.triu(cmf) - np.triu(z["chaincmat"]))) / np.max(np.abs(z["chaincmat"])) < 1e-6
+    for c in picks:
+        live[c].run(cfg.nsimu)
+        o = live[c].ch.contents
         chc, ssc, _ = e.chain(c)
-        np.testing.assert_array_equal(_bits(chc), _bits(o.chain))
-        np.testing.assert_array_equal(_bits(ssc), _bits(o.sschain))
-        assert e.rng(c)[0] == o.rng_n
+        np.testing.assert_array_equal(_bits(chc), _bits(np.ctypeslib.as_array(o.chain, shape=(cfg.nsimu, 201))[:o.chainind]))
+        assert e.rng(c)[0] == o.rng.n
+        live[c].close()
     e.close()
 
 
@@ -284,21 +316,29 @@ def test_history_ring_without_record_chain(oracle, kw, dr):
     e.close()
 
 
-@pytest.mark.parametrize("d,method,extra", [(48, "scam", {}), (70, "scam", {}), (64, "dram", dict(condmax=1e6)), (100, "dram", dict(condmax=50.0, drscale=2.0))])
+@pytest.mark.parametrize("d,method,extra", [(48, "scam", {}), (70, "scam", {}), (64, "dram", dict(condmax=1e6)), (100, "dram", dict(condmax=50.0, drscale=2.0)),
+                                            (128, "scam", {}), (200, "dram", dict(condmax=1e6)), (200, "scam", {}), (256, "scam", {})])
 def test_blocked_svd_equals_lane_svd_and_oracle(oracle, d, method, extra, monkeypatch):
     """npar >= 48 with an SVD factor: MCMC_adapt's factorisation runs svd_blocked_kernel (a workgroup per chain, block
     pairs of columns in LDS, the pinned routine's pairs in a reordered but equivalent sequence).  Bit for bit the
-    one-lane-per-chain routine (MCMCX_SVD_LANE=1) -- factor, singular values, states after several adaptations, a ragged
-    tile, lanes that skip a tick (adaptend) -- and the oracle on two chains."""
+    one-lane-per-chain routine (MCMCX_SVD_LANE=1; up to npar = 128) -- factor, singular values, states after several
+    adaptations, a ragged tile -- and the oracle on two chains, up to the engine's largest npar (256: other block counts
+    and partial-chain lengths than 200)."""
     from mcmcf90_amd import engine_from_problem
     rng = np.random.default_rng(d)
     A = rng.standard_normal((d, d)) / np.sqrt(d)
     lam = A @ A.T + np.diag(10.0 ** np.linspace(-1, 2, d))
     nsimu = 45 if method == "scam" else 160
-    ckw = dict(nsimu=nsimu, method=method, adaptint=14 if method == "scam" else 50, updatesigma=0, **extra)
+    adaptint = 14 if method == "scam" else 50
+    if d >= 128:                                          # two adaptations: a lane-per-chain SVD of this size takes ~10-25 s
+        adaptint = 9 if method == "scam" else 40
+        nsimu = 2 * adaptint + 3
+    ckw = dict(nsimu=nsimu, method=method, adaptint=adaptint, updatesigma=0, **extra)
     pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.05), cmat0=(0.3 / d) * np.eye(d), mu=np.zeros(d), lam=lam)
     res = []
-    for lane_path in (0, 1):
+    # (the lane-per-chain form is the production path below npar = 48 only; at 200 it is compared with the oracle in
+    #  test_gpu_fullsize.py::test_c5_illcond200_scam_replicas_two_ticks, and takes 10-25 s per adaptation up here)
+    for lane_path in ((0, 1) if d <= 128 else (0,)):
         if lane_path:
             monkeypatch.setenv("MCMCX_SVD_LANE", "1")
         e = engine_from_problem(ckw, pkw, nchains=70, chain_id0=5, record_accept=1)
@@ -306,7 +346,7 @@ def test_blocked_svd_equals_lane_svd_and_oracle(oracle, d, method, extra, monkey
         res.append((e.theta(), e.accept_masks(), [e.R(c) for c in (0, 63, 64, 69)],
                     [e.qcovstd(c) for c in (0, 69)], [e.chaincov(c)[0] for c in (0, 69)], [e.rng(c)[0] for c in (0, 69)]))
         e.close()
-    a, b = res
+    a, b = res[0], res[-1]
     assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1])
     for x, y in zip(a[2] + a[3] + a[4], b[2] + b[3] + b[4]):
         np.testing.assert_array_equal(_bits(x), _bits(y))
@@ -317,3 +357,43 @@ def test_blocked_svd_equals_lane_svd_and_oracle(oracle, d, method, extra, monkey
         np.testing.assert_array_equal(_bits(a[0][c]), _bits(o.theta))
         np.testing.assert_array_equal(_bits(a[2][0 if c == 0 else 3]), _bits(o.R))
         assert a[5][i] == o.rng_n
+
+
+@pytest.mark.parametrize("nw", [1, 2, 4, 8])
+@pytest.mark.parametrize("kind,d", [("gauss", 37), ("banana", 20), ("expdata", 2)])
+def test_scam_waves_per_tile(oracle, nw, kind, d, monkeypatch):
+    """Per-chain SCAM with 1, 2, 4, 8 waves per tile (scam_kernel / scam_mw_kernel: the waves share the panels of the two
+    rotations and the Gaussian target's row blocks): the same chain bit for bit, whatever the split -- ragged panels
+    (d = 37: five panels, three row blocks), fewer panels than waves (d = 2), bounds, the sigma2 update, an adaptation."""
+    from mcmcf90_amd import engine_from_problem
+    monkeypatch.setenv("MCMCX_SCAM_WAVES", str(nw))
+    rng = np.random.default_rng(d)
+    if kind == "gauss":
+        A = rng.standard_normal((d, d)) / np.sqrt(d)
+        pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.05), cmat0=(0.3 / d) * np.eye(d), mu=np.linspace(-1, 1, d), lam=A @ A.T + np.eye(d))
+        ckw = dict(nsimu=33, method="scam", adaptint=15, updatesigma=0)
+    elif kind == "banana":
+        pkw = dict(kind="banana", npar=d, par0=np.zeros(d), cmat0=0.01 * np.eye(d), b=0.1)
+        ckw = dict(nsimu=60, method="scam", adaptint=25, updatesigma=0)
+    else:
+        z, _, _ = load("s4_expdata_scam_s2", oracle)
+        ckw, pkw = _kw(z)
+        ckw["nsimu"] = 250
+    e = engine_from_problem(ckw, pkw, nchains=70, chain_id0=3, record_accept=1, record_chain=1)
+    e.init(); e.run()
+    cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
+    th = e.theta()
+    for c in (0, 64, 69):
+        o = oracle.run_chain(cfg, prob, chain_id=3 + c)
+        np.testing.assert_array_equal(e.accepted(c), o.accepted)
+        np.testing.assert_array_equal(_bits(th[c]), _bits(o.theta))
+        chc, ssc, s2c = e.chain(c)
+        np.testing.assert_array_equal(_bits(chc), _bits(o.chain))
+        np.testing.assert_array_equal(_bits(ssc), _bits(o.sschain))
+        if cfg.updatesigma:
+            np.testing.assert_array_equal(_bits(s2c), _bits(o.s2chain))
+        np.testing.assert_array_equal(_bits(e.R(c)), _bits(o.R))
+        cnt = e.counters(c)
+        assert (cnt["stayed"], cnt["bndstayed"], cnt["chainind"]) == (o.stayed, o.bndstayed, o.chainind)
+        assert e.rng(c)[0] == o.rng_n
+    e.close()

@@ -12,6 +12,8 @@ RTOL = 1e-7      # relative to the column scale; observed <= 5e-9
 @pytest.mark.parametrize("name", names())
 def test_oracle_matches_reference_fixture(oracle, name):
     z, cfg, prob = load(name, oracle)
+    if "mkl_logged" in z.files:
+        pytest.skip("made with MKL's dgesvd: test_c5_fixture_through_two_adaptations_with_the_logged_factors")
     o = oracle.run_chain(cfg, prob, chain_id=int(z["chain_id"]))
     assert o.rc == 0
     assert o.rng_n == int(z["rng_n"])                       # same stream consumption
@@ -32,6 +34,39 @@ def test_oracle_matches_reference_fixture(oracle, name):
     cs = np.max(np.abs(z["chaincmat"]))
     assert np.max(np.abs(o.chaincmat - z["chaincmat"])) / cs < 1e-9
     np.testing.assert_allclose(o.chainmean, z["chainmean"], rtol=1e-9, atol=1e-9 * np.abs(z["chainmean"]).max() + 1e-12)
+
+
+def test_c5_fixture_through_two_adaptations_with_the_logged_factors(oracle):
+    """BASELINE config 5 (d=200 SCAM) from the MKL-linked reference, through the adaptations at iterations 100 and 200.
+    The oracle takes the rotation and singular values MKL's dgesvd returned at MCMC_init and at both adaptations in place
+    of its own SVD; everything else -- MCMC_run_scam.F90:38-138 (250 x 200 componentwise proposals: rotations, alpha, the
+    uniforms drawn) and the covariance MCMC_adapt builds for the next scam_svd -- must reproduce the reference: identical
+    run-length column and stream position, every stored row to rounding level."""
+    from golden_util import logged_factors
+    z, cfg, prob = load("c5_illcond200_scam", oracle)
+    assert cfg.adaptint == 100 and len(z["svd_ticks"]) == 2
+    lc = oracle.LiveChain(cfg, prob, chain_id=int(z["chain_id"]))
+    scale = np.maximum(np.abs(z["rows_tail"]).max(axis=0), 1e-3)
+    for k, (it, U, sd) in enumerate(logged_factors(z, cfg)):
+        if it > 0:
+            lc.run(it)                                     # the tick at `it` ran the oracle's own SVD: replace its result
+            assert np.max(np.abs(lc.theta - z["rows_at_ticks"][k - 1]) / scale) < RTOL
+        lc.set_R(U); lc.set_qcovstd(sd)
+    lc.run(cfg.nsimu)
+    c = lc.ch.contents
+    assert c.rng.n == int(z["rng_n"])
+    assert c.chainind == int(z["chainind"])
+    n = prob.npar
+    ch = np.ctypeslib.as_array(c.chain, shape=(cfg.nsimu, n + 1))[:c.chainind]
+    np.testing.assert_array_equal(ch[:, -1].astype(np.int32), z["runlen"])
+    k = z["rows_head"].shape[0]
+    assert np.max(np.abs(ch[:k, :-1] - z["rows_head"]) / scale) < RTOL
+    assert np.max(np.abs(ch[-k:, :-1] - z["rows_tail"]) / scale) < RTOL
+    cm = np.ctypeslib.as_array(c.chaincmat, shape=(n, n)).T
+    assert np.max(np.abs(cm - z["chaincmat"])) / np.max(np.abs(z["chaincmat"])) < 1e-9
+    mean = np.ctypeslib.as_array(c.chainmean, shape=(n,))
+    np.testing.assert_allclose(mean, z["chainmean"], rtol=1e-9, atol=1e-9 * np.abs(z["chainmean"]).max() + 1e-12)
+    lc.close()
 
 
 def test_incremental_run_equals_one_shot(oracle):

@@ -8,11 +8,8 @@ import hashlib, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def sha():
-    h = hashlib.sha256()
-    for f in ("mcx_kernels.hpp", "mcx_device.hpp"):
-        h.update(open(os.path.join(ROOT, "mcmcf90_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:16]
+sys.path.insert(0, ROOT)
+from mcmcf90_amd.build import source_sha as sha  # noqa: E402
 
 
 dest, tags = sys.argv[1], sys.argv[2:]

@@ -12,11 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = ("step_kernel", "scam_pooled_kernel", "scam_kernel", "pooled_mfma_kernel")
 
 
-def kernels_sha():
-    h = hashlib.sha256()
-    for f in ("mcx_kernels.hpp", "mcx_device.hpp"):
-        h.update(open(os.path.join(ROOT, "mcmcf90_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:16]
+sys.path.insert(0, ROOT)
+from mcmcf90_amd.build import source_sha as kernels_sha  # noqa: E402
 
 
 def bench_line(tag):
