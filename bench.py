@@ -295,6 +295,17 @@ def spawn_ranks(n, argv, comm_timeout):
     return 1 if rc != 0 else 0
 
 
+def launcher_key():
+    """Key of the communicator's bootstrap segment under a launcher (torchrun): the same on every rank of this run, never
+    the same for two runs -- the launcher's pid and its start time (field 22 of /proc/<pid>/stat) beside run id and port."""
+    ppid = os.getppid()
+    try:
+        start = open("/proc/%d/stat" % ppid).read().rsplit(")", 1)[1].split()[19]
+    except Exception:
+        start = "0"
+    return "t%s_%s_%d_%s" % (os.environ.get("TORCHELASTIC_RUN_ID", "x"), os.environ.get("MASTER_PORT", "0"), ppid, start)
+
+
 class Watchdog:
     """Ends THIS process (exit code 3, after a message) if disarm() is not called within `seconds`: around the
     communicator's formation, where a missing peer would otherwise hold ncclCommInitRank forever."""
@@ -503,8 +514,7 @@ def main():
     comm = None
     rccl_ranks = 1
     if world > 1:
-        key = os.environ.get("MCMCX_COMM_KEY") or "t%s_%s_%d" % (os.environ.get("TORCHELASTIC_RUN_ID", "x"),
-                                                                 os.environ.get("MASTER_PORT", "0"), os.getppid())
+        key = os.environ.get("MCMCX_COMM_KEY") or launcher_key()
         wd = Watchdog(a.comm_timeout, "forming the %d-rank communicator (%s)" % (world, "host transport" if a.one_gpu_dryrun else "ncclCommInitRank"))
         comm = Comm(key, rank, world, dev, backend="host" if a.one_gpu_dryrun else "rccl")    # raises unless all ranks arrive
         comm.barrier()

@@ -118,7 +118,9 @@ int mcmcx_init(mcmcx_handle h);
 /* iterations simuind+1 .. upto.  Returns MCMCX_INTERRUPTED (> 0) when a signal caught by
  * mcmcx_install_signal_handlers arrived: the run stopped at a launch boundary, mcmcx_simuind() says where, and
  * every getter is valid for the iterations done (the reference saves the chain "upto simuind" and stops,
- * MCMC_signal_handler.F90:95-107) */
+ * MCMC_signal_handler.F90:95-107).  In pooled mode with a communicator of several ranks the run is left only at an
+ * adaptation tick, by agreement of all ranks (every rank's stop flag travels with the pooled vector), so that no rank
+ * is left waiting in a collective; a rank that fails marks the communicator and its peers' waits give up (< 0). */
 int mcmcx_run(mcmcx_handle h, int32_t upto);
 int mcmcx_sync(mcmcx_handle h);
 
@@ -158,7 +160,8 @@ int mcmcx_get_counters(mcmcx_handle h, int32_t chain, int32_t *counters8);
 #define MCMCX_ST_RAM_DOWNDATE_FAIL 1
 #define MCMCX_ST_CHOL_FAIL 2
 #define MCMCX_ST_POTRI_FAIL 4
-int mcmcx_get_totals(mcmcx_handle h, int64_t *totals7);
+int mcmcx_get_totals(mcmcx_handle h, int64_t *totals7);      /* writes SEVEN values (five before library version 0.2) */
+int mcmcx_get_totals_n(mcmcx_handle h, int64_t *totals, int32_t n);   /* the first n of them: the caller states its buffer */
 int mcmcx_get_theta(mcmcx_handle h, double *theta_rowmajor /* [nchains][npar] */);
 /* per chain: ss1, sspri1, sigma2, alpha12 */
 int mcmcx_get_scalars(mcmcx_handle h, double *out /* [nchains][4] */);

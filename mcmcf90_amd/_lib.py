@@ -49,6 +49,7 @@ SYMBOLS = {
     "mcmcx_simuind": (C.c_int32, [C.c_void_p]),
     "mcmcx_get_counters": (C.c_int, [C.c_void_p, C.c_int32, _IP]),
     "mcmcx_get_totals": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "mcmcx_get_totals_n": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
     "mcmcx_get_theta": (C.c_int, [C.c_void_p, _DP]),
     "mcmcx_get_scalars": (C.c_int, [C.c_void_p, _DP]),
     "mcmcx_get_rng": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64), _IP, _DP]),

@@ -60,7 +60,8 @@ struct mcmcx_engine {
     double *d_sharedRT = nullptr;                     // pooled AM on the matrix cores: dense R, M[s*d + o] = R(s,o), zero below the diagonal and in the pad rows
     double *d_sharedR = nullptr; mcmcx_exchange_t xfn = nullptr; void *xuser = nullptr; double *xbuf = nullptr;
     struct mcmcx_comm *comm = nullptr;                // the node's communicator (mcx_comm.hpp); nullptr = this GPU alone
-    double *d_gather = nullptr, *d_pooled = nullptr;  // [nranks][len] per-rank moment vectors, [len] their tree sum
+    double *d_gather = nullptr, *d_pooled = nullptr;  // [nranks][len + 1] per-rank moment vectors (+ the rank's stop flag), [len + 1] their tree sum
+    double h_flag = 0.0;                              // this rank's stop flag of the exchange being enqueued (1 = a caught signal)
     double S02eff = 0.0;
     // device
     hipStream_t stream = nullptr; bool own_stream = false;
@@ -478,37 +479,52 @@ static void unpack_upper(int d, const std::vector<double> &p, double *colmajor, 
         }
 }
 
+static volatile sig_atomic_t g_interrupt = 0;
+static bool g_sig_installed = false;       // then mcmcx_run waits for each launch, so that a signal is seen at the next boundary
+static void on_signal(int) { g_interrupt = 1; }
+
 static int pooled_moments_launch(mcmcx_engine *h, double *dev_dst, int kind = 0, int it = 0);
 static int pooled_vec_len(const mcmcx_engine *h, int kind);
 #include "mcx_comm.hpp"
 
 // Pooled moments of the chains of ALL ranks, left in h->d_pooled (asynchronous on the engine's stream): local tree ->
-// slot `rank` of d_gather -> all-gather over the communicator -> the same pairwise tree over the ranks.
-static int allreduce_moments_enqueue(mcmcx_engine *h, int stage /* 0 all, 1 local part, 2 gather, 3 tree */, int kind = 0, int it = 0)
+// slot `rank` of d_gather -> all-gather over the communicator -> the same pairwise tree over the ranks.  Every rank's
+// slot carries one more element behind the vector, the rank's STOP FLAG (1 = a signal was caught here): its sum over the
+// ranks comes back with the moments, so the decision to leave a run that has collectives ahead is taken by all ranks at
+// the same tick (a rank that returned alone would leave its peers waiting in the next gather).
+static int allreduce_moments_enqueue(mcmcx_engine *h, int stage /* 0 all, 1 local part, 2 gather, 3 tree */, int kind = 0, int it = 0, double flag = 0.0)
 {
-    const int len = pooled_vec_len(h, kind);
+    const int len = pooled_vec_len(h, kind), st = len + 1;
     const int nr = h->comm ? h->comm->nranks : 1, rk = h->comm ? h->comm->rank : 0;
     HIPCHK(hipSetDevice(h->cfg.device));
-    if (stage == 0 || stage == 1) { int rc = pooled_moments_launch(h, h->d_gather + (size_t)rk * len, kind, it); if (rc) return rc; }
-    if ((stage == 0 || stage == 2) && h->comm) { int rc = comm_allgather(h->comm, h->d_gather, len, h->stream); if (rc) return rc; }
+    if (stage == 0 || stage == 1) {
+        int rc = pooled_moments_launch(h, h->d_gather + (size_t)rk * st, kind, it); if (rc) return rc;
+        h->h_flag = flag;
+        HIPCHK(hipMemcpyAsync(h->d_gather + (size_t)rk * st + len, &h->h_flag, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    if ((stage == 0 || stage == 2) && h->comm) { int rc = comm_allgather(h->comm, h->d_gather, st, h->stream); if (rc) return rc; }
     if (stage == 0 || stage == 3) {
-        hipLaunchKernelGGL(moments_tree_kernel, dim3((len + 255) / 256, 1), dim3(256), 0, h->stream, h->d_gather, nr, len, 1, h->d_pooled);
+        hipLaunchKernelGGL(moments_tree_kernel, dim3((st + 255) / 256, 1), dim3(256), 0, h->stream, h->d_gather, nr, st, 1, h->d_pooled);
         HIPCHK(hipGetLastError());
     }
     return 0;
 }
 
+// several ranks meet in this engine's ticks: its run may only be left at a tick, by agreement (the stop flag above)
+static bool collective_run(const mcmcx_engine *h) { return h->pooled && h->comm && h->comm->nranks > 1 && !h->xfn; }
+
 // The pooled statistic vector of `kind` over the chains of ALL ranks, on the host.  With a communicator: local tree ->
 // all-gather -> tree over ranks; with the caller's exchange hook (kind 0 only): the hook sums the device buffer.
+// Returns MCMCX_INTERRUPTED (> 0) when some rank raised its stop flag: every rank gets the same answer at the same tick.
 static int pooled_reduce(mcmcx_engine *h, int kind, int it, std::vector<double> &v)
 {
     const int len = pooled_vec_len(h, kind);
-    v.assign(len, 0.0);
+    v.assign(len + 1, 0.0);
     if (h->xfn && kind != 0) return fail(-8, "pooled burn-in scaling and the pooled RAM variant exchange through a communicator (mcmcx_set_comm), not through the mcmcx_set_exchange hook");
     if (!h->xfn) {
-        int rc = allreduce_moments_enqueue(h, 0, kind, it); if (rc) return rc;
-        HIPCHK(hipStreamSynchronize(h->stream));
-        HIPCHK(hipMemcpy(v.data(), h->d_pooled, (size_t)len * 8, hipMemcpyDeviceToHost));
+        int rc = allreduce_moments_enqueue(h, 0, kind, it, (collective_run(h) && g_interrupt) ? 1.0 : 0.0); if (rc) return rc;
+        if ((rc = comm_wait_stream(h->comm, h->stream))) return rc;
+        HIPCHK(hipMemcpy(v.data(), h->d_pooled, (size_t)(len + 1) * 8, hipMemcpyDeviceToHost));
     } else {
         double *dst = h->xbuf ? h->xbuf : h->d_moments + (size_t)h->ntiles * len;  // tail of the moments workspace
         int rc = pooled_moments_launch(h, dst, kind, it); if (rc) return rc;
@@ -516,6 +532,9 @@ static int pooled_reduce(mcmcx_engine *h, int kind, int it, std::vector<double> 
         h->xfn(h->xuser);                                                            // the caller's own exchange
         HIPCHK(hipMemcpy(v.data(), dst, (size_t)len * 8, hipMemcpyDeviceToHost));
     }
+    const double stop = v[len];
+    v.resize(len);
+    if (collective_run(h) && stop != 0.0) return MCMCX_INTERRUPTED;
     // the vector has been through an exchange: refuse to merge garbage (it would poison the pooled state for the rest of the run)
     if (!(v[0] >= 2.0) || !std::isfinite(v[0])) return fail(-46, "pooled adaptation needs at least 2 chains over all ranks (count = " + std::to_string(v[0]) + ")");
     for (int k = 1; k < len; ++k) if (!std::isfinite(v[k])) return fail(-46, "pooled adaptation: non-finite pooled statistic at iteration " + std::to_string(it));
@@ -873,7 +892,7 @@ static int run1_launch(mcmcx_engine *h, int drstage)
 extern "C" {
 
 const char *mcmcx_last_error(void) { return g_err.c_str(); }
-const char *mcmcx_version(void) { return "mcmcx 0.2 (gfx950)"; }
+const char *mcmcx_version(void) { return "mcmcx 0.3 (gfx950)"; }
 int32_t mcmcx_device_count(void) { int n = 0; return (hipGetDeviceCount(&n) == hipSuccess) ? n : 0; }
 int mcmcx_device_info(int32_t device, char *buf, int32_t len)
 {
@@ -1279,8 +1298,8 @@ int mcmcx_init(mcmcx_handle h)
         h->d_ramscale = const_cast<double *>(p);
     }
     if ((rc = dev_alloc(h, &h->d_moments, (size_t)(T + 1) * (2 + d + P)))) return rc;                         // longest pooled vector: 2 + d + P
-    if ((rc = dev_alloc(h, &h->d_gather, (size_t)(h->comm ? h->comm->nranks : 1) * (2 + d + P)))) return rc;
-    if ((rc = dev_alloc(h, &h->d_pooled, (size_t)(2 + d + P)))) return rc;
+    if ((rc = dev_alloc(h, &h->d_gather, (size_t)(h->comm ? h->comm->nranks : 1) * (3 + d + P)))) return rc;   // longest vector + the stop flag
+    if ((rc = dev_alloc(h, &h->d_pooled, (size_t)(3 + d + P)))) return rc;
 
     // fill theta = par0, R = R(cmat0), chaincmat = cmat0, chainmean = par0, scalars
     {
@@ -1336,9 +1355,6 @@ int mcmcx_init(mcmcx_handle h)
     return 0;
 }
 
-static volatile sig_atomic_t g_interrupt = 0;
-static bool g_sig_installed = false;       // then mcmcx_run waits for each launch, so that a signal is seen at the next boundary
-static void on_signal(int) { g_interrupt = 1; }
 int mcmcx_install_signal_handlers(void)
 {
     struct sigaction act;
@@ -1353,7 +1369,16 @@ int mcmcx_install_signal_handlers(void)
 int mcmcx_interrupted(void) { return g_interrupt ? 1 : 0; }
 void mcmcx_clear_interrupt(void) { g_interrupt = 0; }
 
+static int run_impl(mcmcx_handle h, int32_t upto);
 int mcmcx_run(mcmcx_handle h, int32_t upto)
+{
+    const int rc = run_impl(h, upto);
+    // Several ranks meet in this engine's ticks: one that fails must not leave the others waiting in the next gather --
+    // the communicator is marked failed, which the peers' waits poll (comm_wait_stream, shm_barrier)
+    if (rc < 0 && h && h->inited && collective_run(h)) comm_mark_failed(h->comm);
+    return rc;
+}
+static int run_impl(mcmcx_handle h, int32_t upto)
 {
     if (!h) return fail(-1, "null handle");
     if (!h->inited) return fail(-40, "we have not inited");                           // MCMC_run.F90:22
@@ -1363,8 +1388,13 @@ int mcmcx_run(mcmcx_handle h, int32_t upto)
     if (upto > c.nsimu) upto = c.nsimu;
     const int maxseg = (c.method == MCMCX_METHOD_RAM && !h->pooled) ? 4096 : 1 << 30;
     int it = h->simuind + 1;
+    // Several ranks that meet in this engine's ticks (pooled mode with a communicator): a rank that left the loop alone --
+    // on a signal it happened to see first, or on an error of its own -- would leave its peers waiting in the next gather.
+    // So a signal only raises this rank's stop flag in the exchanged vector and the run is left at the tick where every
+    // rank reads the summed flag (pooled_reduce); an error marks the communicator failed (mcmcx_run).
+    const bool coll = collective_run(h);
     while (it <= upto) {
-        if (g_interrupt) {                                  // a caught signal: stop at this launch boundary
+        if (g_interrupt && !coll) {                         // a caught signal: stop at this launch boundary
             int rc = mcmcx_sync(h); if (rc) return rc;
             h->simuind = it - 1;
             return MCMCX_INTERRUPTED;
@@ -1396,11 +1426,18 @@ int mcmcx_run(mcmcx_handle h, int32_t upto)
             h->pending.emplace_back(e0, e1);
             h->launches += 1; h->steps += (end - it + 1);
         }
+        int trc = 0;
         if (mode != 0) {
-            if (h->pooled) { int rc = pooled_tick(h, end, mode); if (rc) return rc; }
+            if (h->pooled) trc = pooled_tick(h, end, mode);
             else { launch_adapt(h, end, mode); HIPCHK(hipGetLastError()); }
         }
-        if (ramtick) { int rc = pooled_ram_tick(h, end); if (rc) return rc; }
+        if (ramtick && trc == 0) trc = pooled_ram_tick(h, end);
+        if (trc == MCMCX_INTERRUPTED) {                     // every rank read the same summed stop flag at this tick: leave together,
+            int rc = mcmcx_sync(h); if (rc) return rc;           // after iteration `end`, its adaptation not applied
+            h->simuind = end;
+            return MCMCX_INTERRUPTED;
+        }
+        if (trc) return trc;
         it = end + 1;
         if (g_sig_installed) { HIPCHK(hipStreamSynchronize(h->stream)); h->simuind = std::max(h->simuind, end); }
         if (h->pending.size() > 4096) { int rc = mcmcx_sync(h); if (rc) return rc; }
@@ -1493,6 +1530,15 @@ int mcmcx_get_counters(mcmcx_handle h, int32_t chain, int32_t *out)
     if ((rc = fetch_chain_vec(h, h->E.ictr, NICTR, chain, v))) return rc;
     out[0] = (int32_t)v[I_STAYED]; out[1] = (int32_t)v[I_BNDSTAYED]; out[2] = (int32_t)v[I_DRACC]; out[3] = (int32_t)v[I_DRTRIES];
     out[4] = (int32_t)v[I_CHAININD]; out[5] = (int32_t)v[I_STATUS]; out[6] = (int32_t)v[I_ERSTAYED]; out[7] = (int32_t)v[I_CURCOUNT];
+    return 0;
+}
+
+int mcmcx_get_totals_n(mcmcx_handle h, int64_t *out, int32_t n)
+{
+    if (!out || n < 1) return fail(-1, "mcmcx_get_totals_n: bad argument");
+    int64_t t7[7];
+    int rc = mcmcx_get_totals(h, t7); if (rc) return rc;
+    for (int i = 0; i < n; ++i) out[i] = i < 7 ? t7[i] : 0;
     return 0;
 }
 

@@ -57,6 +57,32 @@ struct mcmcx_comm {
     std::vector<double> hbuf;
 };
 
+// An engine of this process failed inside a run whose ranks meet in collectives (mcmcx_run): the waits of its peers --
+// other threads of a one-process node (mcmcx_run_all), other processes through the segment's `failed` word -- poll this
+// and abort their side of the communicator instead of waiting for a gather that will never complete.
+static std::atomic<int> g_peer_failed{0};
+static void comm_mark_failed(mcmcx_comm *c)
+{
+    g_peer_failed.store(1);
+    if (c && c->hdr) c->hdr->failed.store(1);
+}
+// wait for `stream` (which may hold a collective) without outliving a failed peer
+static int comm_wait_stream(mcmcx_comm *c, hipStream_t stream)
+{
+    if (!c || c->nranks == 1) { HIPCHK(hipStreamSynchronize(stream)); return 0; }
+    for (int spins = 0;; ++spins) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) return fail(-100, std::string("hipStreamQuery: ") + hipGetErrorString(e));
+        if (g_peer_failed.load(std::memory_order_relaxed) || (c->hdr && c->hdr->failed.load(std::memory_order_relaxed))) {
+            if (c->nccl) { (void)ncclCommAbort(c->nccl); c->nccl = nullptr; }     // frees this rank's pending collective
+            return fail(-111, "mcmcx_comm: another rank failed; this rank's collective was aborted (rank " + std::to_string(c->rank) + ")");
+        }
+        if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        else std::this_thread::yield();
+    }
+}
+
 static int shm_barrier(mcmcx_comm *c, double timeout_s = 300.0)
 {
     mcx_shm_header *h = c->hdr;
@@ -92,33 +118,49 @@ static int shm_attach(mcmcx_comm *c, const char *key)
         if (c->shm_fd < 0) return fail(-112, "mcmcx_comm: shm_open(" + c->shm_name + ") failed");
         if (ftruncate(c->shm_fd, (off_t)c->shm_bytes) != 0) return fail(-112, "mcmcx_comm: ftruncate failed");
     } else {
-        for (;;) {                                                          // wait for rank 0 to create and size it
-            c->shm_fd = shm_open(c->shm_name.c_str(), O_RDWR, 0600);
-            if (c->shm_fd >= 0) {
-                struct stat st;
-                if (fstat(c->shm_fd, &st) == 0 && (size_t)st.st_size >= c->shm_bytes) break;
-                close(c->shm_fd); c->shm_fd = -1;
+        // A segment of the same name left by an earlier run (same key) may still be there until this run's rank 0 unlinks it.
+        // Rank 0 clears `magic` once a communicator has formed (mcmcx_comm_create), so a left-over segment of a run that got
+        // that far never looks ready; and a rank that sits on a segment rank 0 has meanwhile unlinked (st_nlink == 0) lets go
+        // of it and opens the name again.  What remains is a run killed DURING its formation whose key recurs: callers make
+        // keys unique per run (bench.py: a uuid, or the launcher's pid + start time).
+        for (;;) {
+            for (;;) {                                                      // wait for rank 0 to create and size it
+                c->shm_fd = shm_open(c->shm_name.c_str(), O_RDWR, 0600);
+                if (c->shm_fd >= 0) {
+                    struct stat st;
+                    if (fstat(c->shm_fd, &st) == 0 && (size_t)st.st_size >= c->shm_bytes && st.st_nlink > 0) break;
+                    close(c->shm_fd); c->shm_fd = -1;
+                }
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 300.0)
+                    return fail(-112, "mcmcx_comm: rank 0 never created " + c->shm_name);
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
             }
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 300.0)
-                return fail(-112, "mcmcx_comm: rank 0 never created " + c->shm_name);
-            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            void *q = mmap(nullptr, c->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, c->shm_fd, 0);
+            if (q == MAP_FAILED) return fail(-112, "mcmcx_comm: mmap failed");
+            mcx_shm_header *hq = (mcx_shm_header *)q;
+            bool stale = false;
+            while (hq->magic.load(std::memory_order_acquire) != MCX_SHM_MAGIC) {
+                struct stat st;
+                if (fstat(c->shm_fd, &st) != 0 || st.st_nlink == 0) { stale = true; break; }   // unlinked under us: not this run's segment
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 300.0)
+                    return fail(-112, "mcmcx_comm: the segment was never initialised");
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            }
+            if (!stale) {
+                c->hdr = hq;
+                c->slots = (double *)((char *)q + sizeof(mcx_shm_header));
+                if (c->hdr->nranks != c->nranks) return fail(-112, "mcmcx_comm: ranks disagree about the world size");
+                return 0;
+            }
+            munmap(q, c->shm_bytes); close(c->shm_fd); c->shm_fd = -1;
         }
     }
     void *p = mmap(nullptr, c->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, c->shm_fd, 0);
     if (p == MAP_FAILED) return fail(-112, "mcmcx_comm: mmap failed");
     c->hdr = (mcx_shm_header *)p;
     c->slots = (double *)((char *)p + sizeof(mcx_shm_header));
-    if (c->rank == 0) {
-        c->hdr->arrived.store(0); c->hdr->sense.store(0); c->hdr->failed.store(0); c->hdr->nranks = c->nranks;
-        c->hdr->magic.store(MCX_SHM_MAGIC, std::memory_order_release);
-    } else {
-        while (c->hdr->magic.load(std::memory_order_acquire) != MCX_SHM_MAGIC) {
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 300.0)
-                return fail(-112, "mcmcx_comm: the segment was never initialised");
-            std::this_thread::sleep_for(std::chrono::milliseconds(1));
-        }
-        if (c->hdr->nranks != c->nranks) return fail(-112, "mcmcx_comm: ranks disagree about the world size");
-    }
+    c->hdr->arrived.store(0); c->hdr->sense.store(0); c->hdr->failed.store(0); c->hdr->nranks = c->nranks;
+    c->hdr->magic.store(MCX_SHM_MAGIC, std::memory_order_release);
     return 0;
 }
 
@@ -193,6 +235,8 @@ int mcmcx_comm_create(const char *key, int32_t rank, int32_t nranks, int32_t dev
         if (r != ncclSuccess) { c->hdr->failed.store(1); c->nccl = nullptr; comm_free(c); return fail(-110, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
     }
     if ((rc = shm_barrier(c))) { comm_free(c); return rc; }
+    if (rank == 0) c->hdr->magic.store(0, std::memory_order_release);      // formed: nobody attaches to this segment any more (see shm_attach)
+    g_peer_failed.store(0);
     *out = c;
     return 0;
 }
@@ -209,6 +253,7 @@ int mcmcx_comm_create_all(int32_t ndev_want, const int32_t *devices, mcmcx_comm_
         for (int k = 0; k < i; ++k) if (dl[k] == dl[i]) return fail(-10, "mcmcx_comm_create_all: duplicate device");
     }
     std::vector<ncclComm_t> comms(ndev_want);
+    for (int i = 0; i < ndev_want; ++i) out[i] = nullptr;
     NCCLCHK(ncclCommInitAll(comms.data(), ndev_want, dl.data()));
     for (int i = 0; i < ndev_want; ++i) {
         mcmcx_comm *c = new mcmcx_comm();
@@ -216,9 +261,16 @@ int mcmcx_comm_create_all(int32_t ndev_want, const int32_t *devices, mcmcx_comm_
         hipError_t e = hipSetDevice(dl[i]);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipMalloc((void **)&c->d_scratch, 512 * sizeof(double));
-        if (e != hipSuccess) return fail(-100, hipGetErrorString(e));
+        if (e != hipSuccess) {                                              // nothing half-made is handed back: every rank so far, this one,
+            const std::string msg = hipGetErrorString(e);                   // and the raw communicators of the ranks not reached yet
+            comm_free(c);
+            for (int k = 0; k < i; ++k) { comm_free(out[k]); out[k] = nullptr; }
+            for (int k = i + 1; k < ndev_want; ++k) (void)ncclCommDestroy(comms[k]);
+            return fail(-100, "mcmcx_comm_create_all: device " + std::to_string(dl[i]) + ": " + msg);
+        }
         out[i] = c;
     }
+    g_peer_failed.store(0);
     return 0;
 }
 

@@ -225,7 +225,8 @@ class Engine:
         self._chk(self.L.mcmcx_init(self.h))
 
     def run(self, upto=None):
-        self._chk(self.L.mcmcx_run(self.h, self.nsimu if upto is None else int(upto)))
+        """Returns 0, or 2 (MCMCX_INTERRUPTED) when a caught signal ended the run early (see mcmcx_run)."""
+        return self._chk(self.L.mcmcx_run(self.h, self.nsimu if upto is None else int(upto)))
 
     def sync(self):
         self._chk(self.L.mcmcx_sync(self.h))
@@ -243,7 +244,7 @@ class Engine:
 
     def totals(self):
         a = np.zeros(7, dtype=np.int64)
-        self._chk(self.L.mcmcx_get_totals(self.h, a.ctypes.data_as(C.POINTER(C.c_int64))))
+        self._chk(self.L.mcmcx_get_totals_n(self.h, a.ctypes.data_as(C.POINTER(C.c_int64)), a.size))
         return dict(stayed=int(a[0]), bndstayed=int(a[1]), draccepted=int(a[2]), drtries=int(a[3]), proposals=int(a[4]),
                     downdates=int(a[5]), status=int(a[6]))
 

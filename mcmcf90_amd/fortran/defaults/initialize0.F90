@@ -22,11 +22,11 @@ subroutine initialize(par0,npar,cmat0,initcmatn,sigma2,nobs,nycol)
   if (stat /= 0) nycol = 1
   call loaddata2(parfile, par0)
   npar = size(par0)
-  call loaddata2(cov0file, cmat0, stat)
+  call loaddata2(cov0file, cmat0, stat, uselock=.true.)          ! initialize.F90:77
   if (stat /= 0) call doerror('Error reading file '//trim(cov0file))
   if (size(cmat0,1) /= npar .or. size(cmat0,2) /= npar) call doerror('Error reading file mcmccov.dat')
   if (len_trim(covnfile) > 0) then
-     call loaddata(covnfile, x, stat)
+     call loaddata(covnfile, x, stat, uselock=.true.)            ! initialize.F90:94
      if (stat == 0) initcmatn = int(x)
   end if
   allocate(sigma2(nycol), nobs(nycol))

@@ -3,13 +3,17 @@
 !!! lists (matutils.F90:32-47, 764, 841, 1007, 1338, 1829), written for the engine's shim.
 !!! File format as the reference reads it (matutils.F90:1019-1056): numbers separated by blanks, commas,
 !!! semicolons or tabs, one matrix row per line; blank lines and lines starting with # % ! c C are skipped.
-!!! `uselock` (the reference's .lock protocol) is accepted and ignored.
+!!! Written as the reference writes it (matutils.F90:57, 889-899, 950): every element through the edit descriptor
+!!! G0 -- a matrix row as '(G0,x)' per element and a newline, a vector one '(G0)' per line -- so that, compiled by
+!!! the same compiler, a given double leaves the same bytes.  `uselock` is the reference's lock-file protocol
+!!! (matutils.F90:1544-1680): wait up to 10 s for FILE.lock to disappear, create it, work on FILE, remove it.
 module matutils
   use mcmcprec
   implicit none
   private
   public :: loaddata, loaddata2, readdata, writedata, sizecheck_mat, sizecheck_vec, doerror
-  public :: loadnumbers, writenumbers
+  public :: loadnumbers, lock_acquire, lock_release
+  real, parameter :: lock_timeout = 10.0               ! seconds (matutils.F90:1573)
 
   interface loaddata
      module procedure loaddata_mat, loaddata_vec, loaddata_x, loaddata_int, loaddata_ints
@@ -34,20 +38,70 @@ contains
     stop 1
   end subroutine doerror
 
-  !! all numbers of a text file, row by row; nrows / ncols as found (ncols of the first row)
-  subroutine loadnumbers(file, v, nrows, ncols, stat)
+  !! FILE.lock: wait for another process's lock to go (polling once a second, with the reference's message, for at
+  !! most lock_timeout seconds), then take it.  stat: 0 = taken, -1 = still locked after the timeout, > 0 = the lock file
+  !! could not be created.  (matutils.F90:1585-1629)
+  subroutine lock_acquire(file, stat)
+    character(len=*), intent(in) :: file
+    integer, intent(out) :: stat
+    integer :: t0, t1, rate, u, ios
+    real :: waited
+    logical :: there
+    stat = 0
+    call system_clock(count_rate=rate)
+    call system_clock(count=t0)
+    do
+       inquire(file=trim(file)//'.lock', exist=there)
+       if (.not. there) exit
+       call system_clock(count=t1)
+       waited = real(t1 - t0) / real(rate)
+       if (waited > lock_timeout) then
+          stat = -1
+          return
+       end if
+       write(*,*) 'waiting for lock file ...'//'time left:', lock_timeout - waited
+       call sleep(1)
+    end do
+    open(newunit=u, file=trim(file)//'.lock', status='replace', iostat=ios)
+    if (ios /= 0) then
+       stat = ios
+       return
+    end if
+    close(u)
+  end subroutine lock_acquire
+
+  subroutine lock_release(file)
+    character(len=*), intent(in) :: file
+    integer :: u, ios
+    open(newunit=u, file=trim(file)//'.lock', status='old', iostat=ios)
+    if (ios == 0) close(u, status='delete', iostat=ios)
+  end subroutine lock_release
+
+  !! all numbers of a text file, row by row; nrows / ncols as found (ncols of the first row); uselock: under FILE.lock
+  subroutine loadnumbers(file, v, nrows, ncols, stat, uselock)
     character(len=*), intent(in) :: file
     real(kind=dbl), allocatable, intent(out) :: v(:)
     integer, intent(out) :: nrows, ncols, stat
+    logical, intent(in), optional :: uselock
+    logical :: locked
     character(len=8192) :: line
     real(kind=dbl) :: tmp(4096)
     real(kind=dbl), allocatable :: buf(:), nb(:)
     integer :: u, ios, n, i, k, ntot
     character(len=1) :: c
     stat = 0; nrows = 0; ncols = 0; ntot = 0
+    locked = .false.
+    if (present(uselock)) locked = uselock
+    if (locked) then
+       call lock_acquire(file, ios)
+       if (ios /= 0) then
+          stat = ios; allocate(v(0)); return
+       end if
+    end if
     allocate(buf(1024))
     open(newunit=u, file=file, status='old', iostat=ios)
     if (ios /= 0) then
+       if (locked) call lock_release(file)
        stat = -1; allocate(v(0)); return
     end if
     do
@@ -76,23 +130,10 @@ contains
        if (nrows == 1) ncols = n
     end do
     close(u)
+    if (locked) call lock_release(file)
     allocate(v(ntot)); v = buf(1:ntot)
     if (nrows > 0 .and. ncols*nrows /= ntot) ncols = ntot / nrows
   end subroutine loadnumbers
-
-  subroutine writenumbers(file, a, stat)
-    character(len=*), intent(in) :: file
-    real(kind=dbl), intent(in) :: a(:,:)
-    integer, intent(out), optional :: stat
-    integer :: u, i, ios
-    open(newunit=u, file=file, status='replace', iostat=ios)
-    if (present(stat)) stat = ios
-    if (ios /= 0) return
-    do i = 1, size(a,1)
-       write(u, '(*(ES24.16E3,1X))') a(i,:)
-    end do
-    close(u)
-  end subroutine writenumbers
 
   subroutine failed(file, status)
     character(len=*), intent(in) :: file
@@ -113,7 +154,7 @@ contains
     real(kind=dbl), allocatable :: v(:)
     integer :: nr, nc, st
     if (present(status)) status = 0
-    call loadnumbers(file, v, nr, nc, st)
+    call loadnumbers(file, v, nr, nc, st, uselock)
     if (st /= 0 .or. nr < 1) then
        nullify(xmat); call failed(file, status); return
     end if
@@ -129,7 +170,7 @@ contains
     real(kind=dbl), allocatable :: v(:)
     integer :: nr, nc, st
     if (present(status)) status = 0
-    call loadnumbers(file, v, nr, nc, st)
+    call loadnumbers(file, v, nr, nc, st, uselock)
     if (st /= 0 .or. size(v) < 1) then
        nullify(xvec); call failed(file, status); return
     end if
@@ -146,7 +187,7 @@ contains
     integer :: nr, nc, st
     if (present(status)) status = 0
     x = 0.0_dbl
-    call loadnumbers(file, v, nr, nc, st)
+    call loadnumbers(file, v, nr, nc, st, uselock)
     if (st /= 0 .or. size(v) < 1) then
        call failed(file, status); return
     end if
@@ -209,7 +250,7 @@ contains
     real(kind=dbl), allocatable :: v(:)
     integer :: nr, nc, st
     if (present(stat)) stat = 0
-    call loadnumbers(file, v, nr, nc, st)
+    call loadnumbers(file, v, nr, nc, st, uselock)
     if (st /= 0 .or. size(v) /= size(par)) then
        call failed(file, stat); return
     end if
@@ -224,7 +265,7 @@ contains
     real(kind=dbl), allocatable :: v(:)
     integer :: nr, nc, st
     if (present(stat)) stat = 0
-    call loadnumbers(file, v, nr, nc, st)
+    call loadnumbers(file, v, nr, nc, st, uselock)
     if (st /= 0 .or. nr /= size(xmat,1) .or. nc /= size(xmat,2)) then
        call failed(file, stat); return
     end if
@@ -247,27 +288,89 @@ contains
     call loaddata_x(file, x, stat, uselock)
   end subroutine readdata_x
 
-  !! ---- writedata
+  !! ---- writedata (matutils.F90:841-967): a matrix row by row, every element as '(G0,x)' without advancing, then the end
+  !! of the record; a vector one element per line as '(G0)'.  An empty file name sets stat = -1 and writes nothing; an
+  !! open error is returned in stat when the caller asked for it and stops the program otherwise.
   subroutine writedata_mat(file, xmat, stat, uselock)
     character(len=*), intent(in) :: file
     real(kind=dbl), intent(in) :: xmat(:,:)
     integer, intent(out), optional :: stat
     logical, intent(in), optional :: uselock
-    call writenumbers(file, xmat, stat)
+    integer :: u, i, j, ios
+    logical :: locked
+    if (len_trim(file) == 0) then
+       if (present(stat)) stat = -1
+       return
+    end if
+    if (size(xmat,1) < 1 .or. size(xmat,2) < 1) then
+       write(*,*) 'Error in writedata, empty matrix, file:', trim(file)
+       return
+    end if
+    locked = .false.
+    if (present(uselock)) locked = uselock
+    ios = 0
+    if (locked) call lock_acquire(file, ios)
+    if (ios == 0) then
+       open(newunit=u, file=file, status='replace', iostat=ios)
+       if (ios /= 0 .and. locked) call lock_release(file)
+    end if
+    if (ios /= 0) then
+       if (present(stat)) then
+          stat = ios
+          return
+       end if
+       write(*,*) 'Error opening file ', trim(file)
+       stop
+    end if
+    do i = 1, size(xmat,1)
+       do j = 1, size(xmat,2)
+          write(u, '(G0,x)', iostat=ios, advance='NO') xmat(i,j)
+          if (ios /= 0) then
+             write(*,*) 'Write error on file ', trim(file)
+             stop
+          end if
+       end do
+       write(u, *)
+    end do
+    close(u, iostat=ios)
+    if (locked) call lock_release(file)
+    if (present(stat)) stat = ios
   end subroutine writedata_mat
 
   subroutine writedata_vec(file, xvec, stat)
     character(len=*), intent(in) :: file
     real(kind=dbl), intent(in) :: xvec(:)
     integer, intent(out), optional :: stat
-    call writenumbers(file, reshape(xvec, (/size(xvec), 1/)), stat)
+    integer :: u, i, ios
+    if (len_trim(file) == 0) then
+       if (present(stat)) stat = -1
+       return
+    end if
+    open(newunit=u, file=file, status='replace', iostat=ios)
+    if (ios /= 0) then
+       if (present(stat)) then
+          stat = ios
+          return
+       end if
+       write(*,*) 'Error opening file ', trim(file)
+       stop
+    end if
+    do i = 1, size(xvec)
+       write(u, '(G0)', iostat=ios) xvec(i)
+       if (ios /= 0) then
+          write(*,*) 'Write error on file ', trim(file)
+          stop
+       end if
+    end do
+    close(u)
+    if (present(stat)) stat = ios
   end subroutine writedata_vec
 
   subroutine writedata_scal(file, x, stat)
     character(len=*), intent(in) :: file
     real(kind=dbl), intent(in) :: x
     integer, intent(out), optional :: stat
-    call writenumbers(file, reshape((/x/), (/1, 1/)), stat)
+    call writedata_vec(file, (/x/), stat)
   end subroutine writedata_scal
 
   !! ---- shape checks (matutils.F90:1829-1860): wrong size is fatal

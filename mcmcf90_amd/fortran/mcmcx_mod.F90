@@ -282,10 +282,11 @@ module mcmcmod
        integer(c_int64_t), value :: nbytes
        integer(c_int) :: rc
      end function
-     function mcmcx_get_totals(h, t7) bind(C, name='mcmcx_get_totals') result(rc)
-       import :: c_ptr, c_int, c_int64_t
+     function mcmcx_get_totals_n(h, t, n) bind(C, name='mcmcx_get_totals_n') result(rc)
+       import :: c_ptr, c_int, c_int64_t, c_int32_t
        type(c_ptr), value :: h
-       integer(c_int64_t), intent(out) :: t7(7)
+       integer(c_int64_t), intent(out) :: t(*)
+       integer(c_int32_t), value :: n
        integer(c_int) :: rc
      end function
      function mcmcx_comm_create_all(ndev, devices, out) bind(C, name='mcmcx_comm_create_all') result(rc)
@@ -901,7 +902,7 @@ contains
     !! (MCMC_adapt.F90:221-224); a failed Cholesky / SVD keeps the old factor with a warning (MCMC_adapt.F90:168-171)
     stbits = 0
     do g = 1, ngpus
-       call chk(mcmcx_get_totals(handles(g), t7))
+       call chk(mcmcx_get_totals_n(handles(g), t7, 7_c_int32_t))
        stbits = ior(stbits, int(t7(7)))
     end do
     if (iand(stbits, 2) /= 0) write(*,*) 'Warning: error in Chol/SVD, not adapting (some chain and tick)'
@@ -1314,33 +1315,35 @@ contains
     if (ismat(chainfile)) then
        call writemat4(chainfile, chain(1:chainind,:), 'chain')
     else
-       call writenumbers(chainfile, chain(1:chainind,:))
+       call writedata(chainfile, chain(1:chainind,:))
     end if
     if (ismat(ssfile)) then
        call writemat4(ssfile, sschain(1:chainind,:), 'sschain')
     else
-       call writenumbers(ssfile, sschain(1:chainind,:))
+       call writedata(ssfile, sschain(1:chainind,:))
     end if
     if (updatesigma /= 0) then
        if (ismat(s2file)) then
           call writemat4(s2file, s2chain(1:simuind,:), 's2chain')
        else
-          call writenumbers(s2file, s2chain(1:simuind,:))
+          call writedata(s2file, s2chain(1:simuind,:))
        end if
     end if
-    if (len_trim(covnfile) > 0) then                    ! MCMC_aux.F90:48-52
+    !! the restart files, in the reference's order, shapes and locking (MCMC_aux.F90:46-62): covffile, covnfile and meanfile
+    !! under their lock files; the mean as an npar x 1 matrix, the last point as a vector (one value per line)
+    call writedata(covffile, chaincmat, uselock=.true.)
+    if (len_trim(covnfile) > 0) then
        initcmatn = int(chainwsum)
-       call writenumbers(covnfile, reshape((/dble(initcmatn)/), (/1,1/)))
+       call writedata(covnfile, reshape((/dble(initcmatn)/), (/1,1/)), uselock=.true.)
     end if
-    call writenumbers(covffile, chaincmat)
-    call writenumbers(meanfile, reshape(chainmean, (/npar, 1/)))
-    call writenumbers(parffile, chain(chainind:chainind, 1:npar))
-    if (updatesigma /= 0) call writenumbers(sigma2ffile, &                 ! MCMC_aux.F90:58-62: row 1 sigma2, row 2 nobs
+    call writedata(meanfile, reshape(chainmean, (/npar, 1/)), uselock=.true.)
+    call writedata(parffile, chain(chainind, 1:npar))
+    if (updatesigma /= 0) call writedata(sigma2ffile, &
          transpose(reshape((/s2chain(simuind,1:nycol), dble(nobs)/), (/nycol, 2/))))
     if (nchains > 1) then                               ! engine extension: all chains' last states, pooled mean / covariance
-       call writenumbers('mcmclaststates.dat', laststates)
-       call writenumbers('mcmcpooledmean.dat', reshape(pooledmean, (/npar, 1/)))
-       call writenumbers('mcmcpooledcov.dat', pooledcov)
+       call writedata('mcmclaststates.dat', laststates)
+       call writedata('mcmcpooledmean.dat', reshape(pooledmean, (/npar, 1/)))
+       call writedata('mcmcpooledcov.dat', pooledcov)
     end if
     if (verbosity > 0) write(*,*) 'note: saved results in ', trim(chainfile), ' and ', trim(ssfile), '.'
     !! restart namelist, MCMC_aux.F90:78-83

@@ -89,3 +89,37 @@ def test_bench_world_size_mismatch_is_an_error():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=120, env=env)
     assert p.returncode != 0 and b"WORLD_SIZE" in p.stderr
+
+
+def test_a_left_over_segment_is_not_mistaken_for_this_runs(tmp_path):
+    """ADVICE round 2 (mcx_comm.hpp shm_attach): a segment with the same key left by an earlier run must not capture a
+    non-zero rank that arrives before this run's rank 0.  Rank 0 clears the segment's magic once a communicator has
+    formed, and a rank waiting on a segment that rank 0 has meanwhile unlinked lets go of it and opens the name again."""
+    import time
+    import uuid
+    key = "stale%s" % uuid.uuid4().hex[:10]
+    worker = (
+        "import sys, time; sys.path.insert(0, %r)\n"
+        "from mcmcf90_amd import Comm\n"
+        "rank, delay, keep = int(sys.argv[1]), float(sys.argv[2]), int(sys.argv[3])\n"
+        "time.sleep(delay)\n"
+        "c = Comm(%r, rank, 2, -1, backend='host')\n"
+        "c.barrier(); print('formed', rank, float(c.allreduce([rank + 1.0])[0]), flush=True)\n"
+        "import os\n"
+        "if keep: os._exit(0)\n"          # leave without unlinking: the segment stays behind, like after a crash
+        "c.close()\n") % (ROOT, key)
+
+    def launch(rank, delay, keep):
+        return subprocess.Popen([sys.executable, "-c", worker, str(rank), str(delay), str(keep)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+
+    a = [launch(0, 0.0, 1), launch(1, 0.0, 1)]               # first run: forms, then both ranks vanish without cleaning up
+    outs = [p.communicate(timeout=120)[0].decode() for p in a]
+    assert all("formed" in o and " 3.0" in o for o in outs), outs
+    assert os.path.exists("/dev/shm/mcmcx_" + key)           # the left-over segment
+    t0 = time.time()
+    b = [launch(1, 0.0, 0), launch(0, 1.5, 0)]               # second run, same key: rank 1 arrives 1.5 s BEFORE rank 0
+    outs = [p.communicate(timeout=120)[0].decode() for p in b]
+    assert all(p.returncode == 0 for p in b), outs
+    assert all("formed" in o and " 3.0" in o for o in outs), outs
+    assert time.time() - t0 < 60
+    assert not os.path.exists("/dev/shm/mcmcx_" + key)

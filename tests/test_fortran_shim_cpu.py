@@ -110,3 +110,67 @@ def test_mcmc_main_one_without_a_gpu_stops_loudly_and_leaves_the_protocol_files_
         assert p.returncode != 0 and "no HIP device" in out, out
         assert open(os.path.join(d, "mcmcrun.nml")).read() == nml
         assert not os.path.exists(os.path.join(d, "mcmcparnew.dat"))
+
+
+@pytest.mark.skipif(not os.path.exists(FLANG), reason="flang not available")
+def test_ascii_writers_leave_the_reference_bytes():
+    """the shim's writedata (matrix, vector, scalar; module matutils) against the bytes the REAL
+    reference's writedata wrote for the same doubles (tests/golden/io/writedata.npz, made by oracle/gen_golden_io.py from
+    oracle/_ref/wd_ref): byte for byte -- '(G0,x)' per element and a newline per row (matutils.F90:57, 889-899), '(G0)' per
+    line for vectors (:950) -- and what loaddata reads back under the lock protocol is the doubles, bit for bit."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from oracle.gen_golden_io import run_probe
+    subprocess.check_call(["make", "-s", "-C", FDIR])
+    z = np.load(os.path.join(ROOT, "tests", "golden", "io", "writedata.npz"))
+    r = run_probe(os.path.join(FDIR, "demo_writedata"), z["values"])
+    assert r["mat"] == z["mat"].tobytes()
+    assert r["lock"] == z["mat"].tobytes()
+    assert r["vec"] == z["vec"].tobytes()
+    assert r["scal"] == z["scal"].tobytes()
+    assert not r["leftover"]                                             # every .lock file removed again
+    assert np.array_equal(r["back"].view(np.uint64), z["values"].view(np.uint64))
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "wd_ref")):  # dev container: the reference program itself, now
+        q = run_probe(os.path.join(ROOT, "oracle", "_ref", "wd_ref"), z["values"])
+        assert q["mat"] == r["mat"] and q["vec"] == r["vec"] and q["scal"] == r["scal"]
+
+
+@pytest.mark.skipif(not os.path.exists(FLANG), reason="flang not available")
+def test_lock_file_protocol():
+    """matutils.F90:1544-1680: a writer / reader under `uselock` waits while FILE.lock exists (one message a second), goes
+    on when it disappears, and gives up after 10 s (status -1 to a caller that asked for it); its own lock is gone afterwards."""
+    import struct
+    import threading
+    import time
+    import numpy as np
+    subprocess.check_call(["make", "-s", "-C", FDIR])
+    exe = os.path.join(FDIR, "demo_writedata")
+    a = np.arange(6.0).reshape(2, 3)
+
+    def run(d):
+        with open(os.path.join(d, "wd_in.bin"), "wb") as f:
+            f.write(struct.pack("<2i", *a.shape)); f.write(a.astype("<f8").tobytes())
+        t0 = time.time()
+        p = subprocess.run([exe], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=60)
+        return p, time.time() - t0
+
+    with tempfile.TemporaryDirectory() as d:                            # a lock that goes away after ~2.5 s
+        lock = os.path.join(d, "wd_lock.dat.lock")
+        open(lock, "w").close()
+        t = threading.Timer(2.5, os.remove, args=(lock,)); t.start()
+        p, dt = run(d)
+        t.join()
+        out = p.stdout.decode(errors="replace")
+        assert p.returncode == 0, out
+        assert "waiting for lock file" in out and 2.0 < dt < 9.0
+        assert open(os.path.join(d, "wd_lock.dat")).read() == open(os.path.join(d, "wd_mat.dat")).read()
+        assert not os.path.exists(lock)
+    with tempfile.TemporaryDirectory() as d:                            # a lock that never goes away: timeout, nothing written
+        lock = os.path.join(d, "wd_lock.dat.lock")
+        open(lock, "w").close()
+        p, dt = run(d)
+        out = p.stdout.decode(errors="replace")
+        assert dt > 9.5 and out.count("waiting for lock file") >= 9
+        assert not os.path.exists(os.path.join(d, "wd_lock.dat"))       # writedata(..., stat, uselock) returned stat = -1
+        assert os.path.exists(lock)                                     # someone else's lock is left alone

@@ -170,3 +170,34 @@ print("RCCL_FROM", [l.split()[-1] for l in maps.splitlines() if "librccl" in l][
     p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     assert "RCCL_FROM /opt/rocm" in p.stdout.decode(), p.stdout.decode()
+
+
+def test_a_signal_caught_by_one_rank_stops_all_ranks_at_the_same_tick(tmp_path):
+    """in pooled mode the ranks meet in every tick's gather, so a rank that acted on a signal by itself
+    would leave its peers waiting.  The stop decision is collective: the rank that caught SIGUSR1 only raises its flag in
+    the exchanged vector, and BOTH ranks leave mcmcx_run with MCMCX_INTERRUPTED at the same adaptation tick -- same
+    simuind, same pooled factor (the reference saves the chain "upto simuind" and stops, MCMC_signal_handler.F90:95-107)."""
+    import signal
+    import time
+    import uuid
+    key = "sig%s" % uuid.uuid4().hex[:12]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MCMCX_COMM_KEY")}
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), key, str(r), "2", str(tmp_path)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(2)]
+    try:
+        t0 = time.time()
+        while not all((tmp_path / ("rank%d.ready" % r)).exists() for r in range(2)):
+            assert time.time() - t0 < 240 and all(p.poll() is None for p in procs), [p.stdout.read().decode()[-2000:] for p in procs if p.poll() is not None]
+            time.sleep(0.05)
+        time.sleep(0.5)
+        procs[1].send_signal(signal.SIGUSR1)                 # one rank only
+        outs = [p.communicate(timeout=240)[0].decode(errors="replace") for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode == 0 for p in procs), outs
+    res = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
+    assert res[0]["rc"] == 2 and res[1]["rc"] == 2, res                        # MCMCX_INTERRUPTED on both
+    assert res[0]["simuind"] == res[1]["simuind"] and res[0]["simuind"] % 50 == 0 and 100 < res[0]["simuind"] < 2000000
+    assert res[0]["W"] == res[1]["W"] and res[0]["R00"] == res[1]["R00"]       # the same pooled state on both ranks
