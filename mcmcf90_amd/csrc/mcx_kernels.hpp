@@ -1393,6 +1393,202 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
     if (ldsv) for (int k = 0; k < d; ++k) GV(theta_g, k) = GV(theta_t, k);
 }
 
+// ---------------------------------------------------------------- delayed rejection with per-chain factors
+// MCMC_run with drscale > 0 (MCMC_run.F90:41-107).  step_body<DR> above moves, per iteration, the factor R, its
+// second-stage copy R2, the inverse covariance iC TWICE (one sweep per quadratic form of MCMC_DR_alpha13) and ~2.5 kB of
+// per-chain scratch vectors that L2 cannot hold between a write and the read that follows it (rocprof,
+// profiles/r02_d_final/c3_dram: 9.4 kB per iteration against 3.7 kB of factors at npar = 20).  Here
+//   * the normals and the first-stage candidate live in the wave's two LDS vectors (the ones step_body<DR> keeps for the
+//     quadratic forms); only the second-stage candidate goes through the chain's global scratch;
+//   * the two quadratic forms dx' iC dx of MCMC_DR_alpha13 (MCMC_DRAM.F90:180-182) share ONE sweep over iC
+//     (quadform2_panels): both dx vectors in the two LDS vectors (normals and first-stage candidate are dead by then).
+// Every chain of operations is the one of step_body<DR> (same operands, same order): the results are its bit for bit.
+
+// qa = xa' S xa and qb = xb' S xb, S symmetric with its upper triangle packed by rows, in one sweep over S.
+// Per form the operations of quadform_sym: y_i = sum_j S(i,j) x_j as ONE fma chain ascending in j -- first the column part
+// S(i',i) x_i' (i' < i), then the diagonal, then the row part -- and q = sum_i y_i x_i ascending in i.  Column panels of TQ:
+// the column parts of the panel's y_j accumulate in registers while the rows stream by (rows ascending); a row's own
+// chain y_i runs along the row, across the panels, and waits between two panels in the chain's global scratch (ysa, ysb:
+// npar doubles each, one store and one load per row and panel boundary -- nothing at npar <= TQ); q takes y_i x_i when
+// the last panel completes it, rows ascending.  xa, xb: per-lane LDS vectors.
+constexpr int TQ = 10;
+MCX_DEV void quadform2_panels(const double *St, int lane, int d, const double *Xa, const double *Xb, double *ysa, double *ysb,
+                              double &qa, double &qb)
+{
+    qa = 0.0; qb = 0.0;
+    for (int J0 = 0; J0 < d; J0 += TQ) {
+        const int nw = (d - J0) < TQ ? (d - J0) : TQ;
+        const bool last = J0 + TQ >= d;
+        double Ya[TQ], Yb[TQ], xja[TQ], xjb[TQ];
+#pragma unroll
+        for (int u = 0; u < TQ; ++u) { const int j = J0 + (u < nw ? u : nw - 1); xja[u] = GV(Xa, j); xjb[u] = GV(Xb, j); Ya[u] = 0.0; Yb[u] = 0.0; }
+        // rows above the panel: the row's chain takes the panel's nw elements, the panel's columns take the row's x_i
+        {
+#ifndef MCX_Q2_NB
+#define MCX_Q2_NB 1
+#endif
+            constexpr int NB = MCX_Q2_NB;                          // rows in flight: more than one spills registers (2: 70, 3: 167), and a spill here costs more than the latency it hides (c3: 20.3 / 17.5 / 14.8 ms per launch at 3 / 2 / 1)
+            double rr[NB][TQ], xa_[NB], xb_[NB], ya_[NB], yb_[NB];
+#define MCX_Q2_LD(s_, i_) { const double *seg_ = St + (size_t)(rowstart((i_), d) + J0 - (i_)) * 64; \
+                            _Pragma("unroll") for (int u = 0; u < TQ; ++u) rr[s_][u] = GV(seg_, u < nw ? u : nw - 1); \
+                            xa_[s_] = GV(Xa, (i_)); xb_[s_] = GV(Xb, (i_)); ya_[s_] = GV(ysa, (i_)); yb_[s_] = GV(ysb, (i_)); }
+#define MCX_Q2_FM(s_, i_) { double ya = ya_[s_], yb = yb_[s_]; const double xia = xa_[s_], xib = xb_[s_]; \
+                            _Pragma("unroll") for (int u = 0; u < TQ; ++u) if (u < nw) { ya = dfma(rr[s_][u], xja[u], ya); yb = dfma(rr[s_][u], xjb[u], yb); } \
+                            _Pragma("unroll") for (int u = 0; u < TQ; ++u) { \
+                                Ya[u] = ((i_) == 0) ? rr[s_][u] * xia : dfma(rr[s_][u], xia, Ya[u]); \
+                                Yb[u] = ((i_) == 0) ? rr[s_][u] * xib : dfma(rr[s_][u], xib, Yb[u]); } \
+                            if (last) { qa = qa + ya * xia; qb = qb + yb * xib; } else { GV(ysa, (i_)) = ya; GV(ysb, (i_)) = yb; } }
+#pragma unroll
+            for (int s = 0; s < NB - 1; ++s) if (s < J0) MCX_Q2_LD(s, s)
+            for (int i = 0; i < J0; i += NB) {
+#pragma unroll
+                for (int s = 0; s < NB; ++s) {
+                    if (i + s + NB - 1 < J0) MCX_Q2_LD((s + NB - 1) % NB, i + s + NB - 1)
+                    if (i + s < J0) MCX_Q2_FM(s, i + s)
+                }
+            }
+#undef MCX_Q2_LD
+#undef MCX_Q2_FM
+        }
+        // diagonal block: row i = J0 + ui takes its diagonal element on top of the finished column part, then the rest of its row
+        {
+            double da[TQ], db[TQ];
+#define MCX_Q2_LDD(rv, i_) { const double *seg_ = St + (size_t)rowstart((i_), d) * 64; const int ui_ = (i_) - J0, m_ = d - 1 - (i_); \
+                             _Pragma("unroll") for (int u = 0; u < TQ; ++u) { int k = u - ui_; k = k < 0 ? 0 : k; k = k > m_ ? m_ : k; rv[u] = GV(seg_, k); } }
+#define MCX_Q2_FMD(rv, i_) { const int ui_ = (i_) - J0; double xia = 0.0, xib = 0.0, ya = 0.0, yb = 0.0; \
+                             _Pragma("unroll") for (int u = 0; u < TQ; ++u) if (u == ui_) { xia = xja[u]; xib = xjb[u]; \
+                                 ya = ((i_) == 0) ? rv[u] * xia : dfma(rv[u], xia, Ya[u]); yb = ((i_) == 0) ? rv[u] * xib : dfma(rv[u], xib, Yb[u]); } \
+                             _Pragma("unroll") for (int u = 0; u < TQ; ++u) if (u > ui_ && u < nw) { \
+                                 ya = dfma(rv[u], xja[u], ya); yb = dfma(rv[u], xjb[u], yb); \
+                                 Ya[u] = ((i_) == 0) ? rv[u] * xia : dfma(rv[u], xia, Ya[u]); \
+                                 Yb[u] = ((i_) == 0) ? rv[u] * xib : dfma(rv[u], xib, Yb[u]); } \
+                             if (last) { qa = qa + ya * xia; qb = qb + yb * xib; } else { GV(ysa, (i_)) = ya; GV(ysb, (i_)) = yb; } }
+            MCX_Q2_LDD(da, J0)
+            for (int i = J0; i < J0 + nw; i += 2) {
+                if (i + 1 < J0 + nw) MCX_Q2_LDD(db, i + 1)
+                MCX_Q2_FMD(da, i)
+                if (i + 2 < J0 + nw) MCX_Q2_LDD(da, i + 2)
+                if (i + 1 < J0 + nw) MCX_Q2_FMD(db, i + 1)
+            }
+#undef MCX_Q2_LDD
+#undef MCX_Q2_FMD
+        }
+    }
+}
+
+MCX_DEV void dr_body(const EngineDev &E, int it0, int it1, const double *__restrict__ g_mu, const double *__restrict__ g_lamT)
+{
+    extern __shared__ double X[];
+    const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
+    double *theta_t = E.theta + (size_t)tile * d * 64;
+    double *zb_t = X;                                          // normals of the stage at hand, then dx_a = newpar2 - newpar
+    double *cand_t = X + (size_t)d * 64;                       // first-stage candidate, then dx_b = oldpar - newpar
+    double *c2_t = E.cs + (size_t)tile * 2 * d * 64;           // second-stage candidate (global scratch)
+    double *ysa_t = E.zs + (size_t)tile * 2 * d * 64, *ysb_t = ysa_t + (size_t)d * 64;     // row chains between two panels of iC
+    const double *Rt = E.R + (size_t)tile * E.P * 64;
+
+    Rng g;
+    g.k0 = E.k0; g.k1 = E.chain_id0 + (uint32_t)(tile * 64 + lane);
+    g.n = TIDX(E.rngn, tile, 1, 0, lane); g.cblk = 0; g.c2 = 0; g.c3 = 0;
+    g.saved = (int)TIDX(E.ictr, tile, NICTR, I_SAVED, lane);
+    g.saved_y = TIDX(E.scal, tile, NSCAL, S_SAVEDY, lane);
+    double ss1 = TIDX(E.scal, tile, NSCAL, S_SS1, lane), pri1 = TIDX(E.scal, tile, NSCAL, S_PRI1, lane);
+    double sigma2 = TIDX(E.scal, tile, NSCAL, S_SIGMA2, lane), alpha12 = TIDX(E.scal, tile, NSCAL, S_ALPHA12, lane);
+    uint32_t stayed = TIDX(E.ictr, tile, NICTR, I_STAYED, lane), bnd = TIDX(E.ictr, tile, NICTR, I_BNDSTAYED, lane);
+    uint32_t chainind = TIDX(E.ictr, tile, NICTR, I_CHAININD, lane), curcount = TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane);
+    uint32_t dracc = TIDX(E.ictr, tile, NICTR, I_DRACC, lane), drtries = TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane);
+
+    for (int it = it0; it <= it1; ++it) {
+        // ---- newpar = MCMC_propose(oldpar, R)   (the iteration's first draws: nothing else drew since the last one's end)
+        gen_normals<MCX_RNG_NB>(g, zb_t, lane, d, true);
+        if (E.usesvd) gemvN_panels(E.Rf + (size_t)tile * d * d * 64, zb_t, cand_t, theta_t, lane, d, true);   // matmulx(R,z)
+        else trmv_panels<true>(Rt, zb_t, cand_t, theta_t, lane, d, true);
+        // ---- bounds, prior, ss, alpha, reject
+        bool inb = target_inbounds(E.tgt, d, lane, cand_t);
+        double pri2 = target_prior(E.tgt, d, lane, cand_t);
+        double ss2 = target_ss<false>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
+        bool reject;
+        if (!inb) { reject = true; alpha12 = 0.0; }         // (with DR an out-of-bounds first stage is not counted, MCMC_run.F90:49)
+        else {
+            alpha12 = d_alpha(ss1, pri1, ss2, pri2, sigma2);
+            reject = true;                                  // MCMC_reject, MCMC_DRAM.F90:140-155
+            if (alpha12 >= 1.0) reject = false;
+            else if (alpha12 > 0.0) { double u = rng_uniform(g); if (u <= alpha12) reject = false; }
+        }
+        // ---- second stage: one delayed-rejection try with R2 = R/drscale (MCMC_run.F90:65-91)
+        bool dr_moved = false;
+        if (__any(reject)) {
+            const bool m = reject;
+            if (m) drtries += 1;
+            gen_normals<MCX_RNG_NB>(g, zb_t, lane, d, m);
+            if (E.usesvd) gemvN_panels(E.R2f + (size_t)tile * d * d * 64, zb_t, c2_t, theta_t, lane, d, m);
+            else trmv_panels<true>(E.R2 + (size_t)tile * E.P * 64, zb_t, c2_t, theta_t, lane, d, m);
+            if (m) {
+                bool inb2 = target_inbounds(E.tgt, d, lane, c2_t);
+                if (!inb2) bnd += 1;
+                else {
+                    double pri3 = target_prior(E.tgt, d, lane, c2_t);
+                    double ss3 = target_ss<false>(E.tgt, d, lane, c2_t, g_mu, g_lamT);
+                    // MCMC_DR_alpha13, MCMC_DRAM.F90:162-186
+                    double alpha32;
+                    if (alpha12 == 0.0) alpha32 = 0.0;
+                    else alpha32 = min1(d_exp(-0.5 * ((ss2 - ss3) / sigma2 + (pri2 - pri3))));
+                    double l2 = -0.5 * ((ss3 - ss1) / sigma2 + (pri3 - pri1));
+                    // dx_a = newpar2 - newpar, dx_b = oldpar - newpar take this lane's two LDS vectors (its normals and its
+                    // first-stage candidate are dead from here on)
+                    for (int k0 = 0; k0 < d; k0 += 8) {
+                        double c1[8], c2[8], th[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { const int k = (k0 + u < d) ? k0 + u : d - 1; c1[u] = GV(cand_t, k); c2[u] = GV(c2_t, k); th[u] = GV(theta_t, k); }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) if (k0 + u < d) { GV(zb_t, k0 + u) = c2[u] - c1[u]; GV(cand_t, k0 + u) = th[u] - c1[u]; }
+                    }
+                    double qa, qb;
+                    quadform2_panels(E.iC + (size_t)tile * E.P * 64, lane, d, zb_t, cand_t, ysa_t, ysb_t, qa, qb);
+                    double q1 = -0.5 * (qa - qb);
+                    double alpha13 = min1(d_exp(l2 + q1) * (1.0 - alpha32) / (1.0 - alpha12));
+                    bool rej2 = true;
+                    if (alpha13 >= 1.0) rej2 = false;
+                    else if (alpha13 > 0.0) { double u = rng_uniform(g); if (u <= alpha13) rej2 = false; }
+                    if (!rej2) { dracc += 1; reject = false; dr_moved = true; ss2 = ss3; pri2 = pri3; }
+                }
+            }
+        }
+        if (reject) { stayed += 1; curcount += 1; }
+        else { ss1 = ss2; pri1 = pri2; chainind += 1; curcount = 1; }
+        // ---- MCMC_updatesigma2 (MCMC_DRAM.F90:192-206)
+        if (E.updatesigma) {
+            double gm = rng_gamma(g, E.gam_shape, 2.0 / (E.N0S02 + ss1));
+            sigma2 = 1.0 / gm;
+        }
+        // ---- oldpar = newpar; MCMC_savechain (MCMC_aux.F90:167-185): accept ballot + accepted row into the ring
+        unsigned long long ballot = __ballot(!reject);
+        const int slot = it % E.wcap;
+        if (!reject) {
+            double *h = E.hist ? E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64 : nullptr;
+            if (dr_moved) copy_vec(theta_t, c2_t, h, lane, d);     // newpar = newpar2 when the DR try was accepted (two calls: a source
+            else copy_vec(theta_t, cand_t, h, lane, d);            // that is global or LDS by the lane would mean FLAT accesses)
+            if (h) GV(h, d) = ss1;
+        }
+        if (E.hist) {
+            if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ballot;
+            if (E.record_s2) E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = sigma2;
+        }
+        if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
+    }
+
+    TIDX(E.rngn, tile, 1, 0, lane) = g.n;
+    TIDX(E.ictr, tile, NICTR, I_SAVED, lane) = (uint32_t)g.saved;
+    TIDX(E.scal, tile, NSCAL, S_SAVEDY, lane) = g.saved_y;
+    TIDX(E.scal, tile, NSCAL, S_SS1, lane) = ss1; TIDX(E.scal, tile, NSCAL, S_PRI1, lane) = pri1;
+    TIDX(E.scal, tile, NSCAL, S_SIGMA2, lane) = sigma2; TIDX(E.scal, tile, NSCAL, S_ALPHA12, lane) = alpha12;
+    TIDX(E.ictr, tile, NICTR, I_STAYED, lane) = stayed; TIDX(E.ictr, tile, NICTR, I_BNDSTAYED, lane) = bnd;
+    TIDX(E.ictr, tile, NICTR, I_CHAININD, lane) = chainind; TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane) = curcount;
+    TIDX(E.ictr, tile, NICTR, I_DRACC, lane) = dracc; TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane) = drtries;
+}
+__global__ __launch_bounds__(64, 2) void step_kernel_dr(EngineDev E, int it0, int it1, const double *__restrict__ g_mu, const double *__restrict__ g_lamT)
+{ dr_body(E, it0, it1, g_mu, g_lamT); }
+
 #ifndef MCX_AM_WAVES
 #define MCX_AM_WAVES 2
 #endif
