@@ -1871,16 +1871,20 @@ MCX_DEV void mfma_slots(const double *__restrict__ M, const double *X, int lane,
             for (int g = 0; g < 4; ++g) c[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xq[16 * g], c[g], 0, 0, 0);
         }
     } else {
-        for (; s0 + 8 <= d4; s0 += 8) {                 // two k-blocks per trip, up to four A each
-            double a[2][NS > 0 ? NS : 1], bq[2];
+        // KU k-blocks per trip, up to four A each: a trip waits for its loads once, and a wave with one or two slots has few
+        // MFMAs to put behind them -- with two k-blocks per trip the four group waves were the last at every barrier
+        // (64 us per sub-step against the block waves' 54 at d = 200); eight A loads in flight per trip whatever NS is
+        constexpr int KU = NS <= 1 ? 8 : (NS == 2 ? 4 : 2);
+        for (; s0 + 4 * KU <= d4; s0 += 4 * KU) {
+            double a[KU][NS > 0 ? NS : 1], bq[KU];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < KU; ++u) {
 #pragma unroll
                 for (int s = 0; s < NS; ++s) a[u][s] = ap[(size_t)(s0 + 4 * u) * d + 16 * s];
                 bq[u] = xp[(s0 + 4 * u) * 64];
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < KU; ++u)
 #pragma unroll
                 for (int s = 0; s < NS; ++s) c[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][s], bq[u], c[s], 0, 0, 0);
         }
@@ -1894,7 +1898,8 @@ MCX_DEV void mfma_slots(const double *__restrict__ M, const double *X, int lane,
 // Element (slot s, register r) of a lane: output row o = 16*block + (lane>>4) + 4r, chain c = 16*group + (lane&15); its
 // offset o*64 + c in a tile-interleaved vector (and in X) is e0 + (BW ? 16 s : 1024 s) + 256 r.  X has 16*nt rows, so
 // every element has an LDS home; rows >= d are written as zeros (the k loop reads the rows < d4 only).
-template <bool BW, int NS>
+template <bool BW, int NS, bool SC>   // SC: the scalar wave (the last one).  A template parameter, so that the other fifteen waves carry
+                                      // neither the generator nor the per-chain state: at 128 registers a wave they spilled around their MFMAs
 MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, int lane, int w, int nw, int blk0, int grp,
                               const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
                               const double *__restrict__ g_U, const double *__restrict__ g_UT, const double *__restrict__ g_std)
@@ -1902,7 +1907,7 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
     const int tile = blockIdx.x, d = E.d, d4 = (d + 3) & ~3, nt = (d + 15) >> 4, li = lane & 15, lk = lane >> 4;
     double *Q = X + (size_t)nt * 16 * 64;                                       // [4*nt][64] partial ss chains
     double *zb = Q + (size_t)nt * 4 * 64, *fl = zb + 64;                      // per chain: the deviate, the accept flag
-    const bool sc = (w == nw - 1);                                              // the scalar wave
+    constexpr bool sc = SC;                                                     // the scalar wave
     const bool gauss = (E.tgt.kind == TGT_GAUSS);
     const bool cand_global = !gauss || E.tgt.pmu || E.tgt.lo || E.tgt.hi;       // prior / bounds / other targets read theta' per chain
     constexpr int nsl = NS;
@@ -1914,7 +1919,15 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
     double *cand_t = E.cand + (size_t)tile * d * 64;
     LaneState L;
     if (sc) lane_load(E, tile, lane, L);
-    mcx_d4 cand[4], cc[4];
+    mcx_d4 cand[4], cc[4], th[4];
+    // The chains' state: every lane keeps the elements of its slots in registers across the sub-steps (they are the ones it
+    // fills into X and the ones it replaces on an accept) and writes them back once per iteration.
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (s < nsl) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) th[s][r] = theta_t[EROW(s, r) < d ? EOFF(s, r) : e0];
+        }
 #ifdef MCX_PHASE_PROF
     unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tq = wall_clock64();
 #define PH(i) { unsigned long long tn = wall_clock64(); ph[i] += tn - tq; tq = tn; }
@@ -1927,11 +1940,8 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
 #pragma unroll
             for (int s = 0; s < 4; ++s) {                                       // X = theta
                 if (s < nsl) {
-                    double th[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) th[r] = theta_t[EROW(s, r) < d ? EOFF(s, r) : e0];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) X[EOFF(s, r)] = EROW(s, r) < d ? th[r] : 0.0;
+                    for (int r = 0; r < 4; ++r) X[EOFF(s, r)] = EROW(s, r) < d ? th[s][r] : 0.0;
                 }
             }
             if (sc) zb[lane] = rng_normal(L.g) * g_std[j];
@@ -2022,9 +2032,15 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
                 if (s < nsl) {
                     const bool acc = fl[ECH(s)] != 0.0;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) if (acc && EROW(s, r) < d) theta_t[EOFF(s, r)] = cand[s][r];
+                    for (int r = 0; r < 4; ++r) th[s][r] = acc ? cand[s][r] : th[s][r];
                 }
         }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)                                             // the iteration's state: for the history row below, the
+            if (s < nsl) {                                                      // pooled moments and the next launch
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (EROW(s, r) < d) theta_t[EOFF(s, r)] = th[s][r];
+            }
         __syncthreads();
         if (sc) {
             if (rejall) { L.stayed += 1; L.curcount += 1; }
@@ -2067,13 +2083,20 @@ __global__ __launch_bounds__(1024, 1) void scam_pooled_kernel(EngineDev E, int i
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = (int)(blockDim.x >> 6);
     const int nt = (E.d + 15) >> 4, ntw = nw - 4;                               // ntw block waves own blocks 0..ntw-1
-    if (w < ntw) scam_pooled_body<true, 4>(E, it0, it1, X, lane, w, nw, w, 0, g_mu, g_lamT, g_U, g_UT, g_std);
+    if (w < ntw) scam_pooled_body<true, 4, false>(E, it0, it1, X, lane, w, nw, w, 0, g_mu, g_lamT, g_U, g_UT, g_std);
+    else if (w == nw - 1) switch (nt - ntw) {                                   // the scalar wave
+        case 0: scam_pooled_body<false, 0, true>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
+        case 1: scam_pooled_body<false, 1, true>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
+        case 2: scam_pooled_body<false, 2, true>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
+        case 3: scam_pooled_body<false, 3, true>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
+        default: scam_pooled_body<false, 4, true>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
+    }
     else switch (nt - ntw) {
-        case 0: scam_pooled_body<false, 0>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
-        case 1: scam_pooled_body<false, 1>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
-        case 2: scam_pooled_body<false, 2>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
-        case 3: scam_pooled_body<false, 3>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
-        default: scam_pooled_body<false, 4>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
+        case 0: scam_pooled_body<false, 0, false>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
+        case 1: scam_pooled_body<false, 1, false>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
+        case 2: scam_pooled_body<false, 2, false>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
+        case 3: scam_pooled_body<false, 3, false>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
+        default: scam_pooled_body<false, 4, false>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
     }
 }
 
