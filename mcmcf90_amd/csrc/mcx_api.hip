@@ -185,7 +185,7 @@ static void host_symsvd(int n, std::vector<double> &G, std::vector<double> &V, s
 // MCMC_calculate_R, SVD branches, for the shared initial covariance (MCMC_init.F90:109): returns 0 or an error code.
 // Rfull: column-major d*d factor (U for scam, U sqrt(s) 2.4/sqrt(d) otherwise); std: sqrt(s) (scam)
 static int host_initial_svd(int d, const std::vector<double> &cm, double condmax, bool scam,
-                            std::vector<double> &Rfull, std::vector<double> &std, std::vector<double> *floored_cm = nullptr)
+                            std::vector<double> &Rfull, std::vector<double> &std, std::vector<double> *floored_cm = nullptr, bool scaled = true)
 {
     std::vector<double> G((size_t)d * d), V, sv;
     for (int j = 0; j < d; ++j) for (int i = 0; i < d; ++i) G[(size_t)j * d + i] = (i <= j) ? cm[(size_t)i + (size_t)j * d] : cm[(size_t)j + (size_t)i * d];
@@ -210,7 +210,7 @@ static int host_initial_svd(int d, const std::vector<double> &cm, double condmax
                     (*floored_cm)[(size_t)i + (size_t)j * d] = acc;
                 }
         }
-        for (size_t e = 0; e < (size_t)d * d; ++e) Rfull[e] = V[e] * 2.4 / sqd;
+        for (size_t e = 0; e < (size_t)d * d; ++e) Rfull[e] = scaled ? V[e] * 2.4 / sqd : V[e];
     }
     return 0;
 }
@@ -268,7 +268,8 @@ static bool pooled_use_mfma(const mcmcx_engine *h)
 }
 static bool phased(const mcmcx_engine *h) { return h->tkind == TGT_HOST || h->tkind == TGT_EXPCOLS || h->tkind == TGT_MODULE; }   // iteration cut at the evaluations
 static size_t lds_bytes(const mcmcx_engine *h) { return (size_t)h->d * 64 * sizeof(double) * 2; }   // adapt / DR work vectors
-static size_t lds_step(const mcmcx_engine *h) { return h->dodr ? lds_bytes(h) : 0; }
+static bool dr_fits_lds(const mcmcx_engine *h) { return lds_bytes(h) <= 160 * 1024; }          // npar <= 160
+static size_t lds_step(const mcmcx_engine *h) { return (h->dodr && dr_fits_lds(h)) ? lds_bytes(h) : 0; }
 static void launch_init(mcmcx_engine *h)
 { hipLaunchKernelGGL(init_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E); }
 static void launch_step(mcmcx_engine *h, int it0, int it1)
@@ -280,6 +281,8 @@ static void launch_step(mcmcx_engine *h, int it0, int it1)
     else if (h->pooled) hipLaunchKernelGGL((step_kernel<false, false, true>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->E.method == M_RAM && h->usesvd) hipLaunchKernelGGL(step_kernel_ram_fullr, g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->E.method == M_RAM) hipLaunchKernelGGL((step_kernel<true, false, false>), g, b, (size_t)NLC * 2 * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
+    else if (h->dodr && !dr_fits_lds(h))                  // npar > 160: the second stage's two vectors in global scratch
+        hipLaunchKernelGGL(step_kernel_dr_big, g, b, 0, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
     else if (h->dodr && !(getenv("MCMCX_DR_GENERAL") && atoi(getenv("MCMCX_DR_GENERAL"))))      // (A/B switch for tests: step_body<DR>)
         hipLaunchKernelGGL(step_kernel_dr, g, b, lds_step(h), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
     else if (h->dodr) hipLaunchKernelGGL((step_kernel<false, true, false>), g, b, lds_step(h), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
@@ -691,6 +694,23 @@ static int pooled_ram_tick(mcmcx_engine *h, int it)
     std::vector<double> v;
     int rc = pooled_reduce(h, 2, it, v); if (rc) return rc;
     const double n = v[0];
+    if (h->usesvd) {
+        // condmax > 0: the shared factor is the full matrix Rf of covtor_svd (matutils.F90:378-453), proposals are
+        // matmulx(Rf, z) with covariance Rf Rf'.  The same fold on that Gram matrix, refactored the way this factor is made:
+        // Rf <- U sqrt(s) of Rf Rf' + (1/N) sum_c sign(a_c) x_c x_c', singular values floored at s_1 / condmax (no 2.4/sqrt(d):
+        // the Gram matrix carries the scale already, like the Cholesky form below)
+        std::vector<double> S((size_t)d * d, 0.0), Rf, sd;
+        for (int j = 0; j < d; ++j)
+            for (int i = 0; i <= j; ++i) {
+                double acc = 0.0;
+                for (int k = 0; k < d; ++k) acc = std::fma(h->pool_Rf[(size_t)k * d + i], h->pool_Rf[(size_t)k * d + j], acc);
+                S[(size_t)i + (size_t)j * d] = acc + v[2 + j * (j + 1) / 2 + i] / n;
+            }
+        if (host_initial_svd(d, S, h->cfg.condmax, false, Rf, sd, nullptr, false) != 0) { h->pool_status |= ST_CHOL_FAIL; return 0; }
+        h->pool_Rf = Rf;
+        h->pool_alpha = v[1] / n;
+        return pooled_upload_R(h);
+    }
     std::vector<double> S(P), A;
     for (int j = 0; j < d; ++j)
         for (int i = 0; i <= j; ++i) {
@@ -819,7 +839,7 @@ static int host_iteration(mcmcx_engine *h, int it)
 {
     const dim3 g(h->ntiles), b(64);
     const double *rs = h->d_ramscale + it;
-    const size_t lds = (size_t)h->d * 64 * sizeof(double) * 2;
+    const size_t lds = lds_step(h);
     if (h->cfg.method == MCMCX_METHOD_SCAM) {           // MCMC_run_scam: npar componentwise proposals, each evaluated by the host
         for (int j = 0; j < h->d; ++j) {
             hipLaunchKernelGGL((host_phase_kernel<5>), g, b, 0, h->stream, h->E, it, rs, j);
@@ -883,7 +903,7 @@ static int run1_launch(mcmcx_engine *h, int drstage)
 {
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipMemcpyAsync(h->d_r1, h->h_r1.data(), h->h_r1.size() * 8, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL((run1_kernel<MODE>), dim3(h->ntiles), dim3(64), MODE == 0 ? lds_bytes(h) : 0, h->stream, h->E, h->d_r1, drstage);
+    hipLaunchKernelGGL((run1_kernel<MODE>), dim3(h->ntiles), dim3(64), MODE == 0 ? lds_step(h) : 0, h->stream, h->E, h->d_r1, drstage);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h->h_r1.data(), h->d_r1, h->h_r1.size() * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -947,10 +967,6 @@ int mcmcx_create(const mcmcx_config *cfg_in, mcmcx_handle *out)
     if (c.nchains < 1) return fail(-5, "nchains must be >= 1");
     if (c.doadapt && c.method != MCMCX_METHOD_RAM) {
         if (c.adaptint == 0) return fail(-7, "doadapt with adaptint = 0");
-    }
-    if (c.pooled) {
-        const bool scam = (c.method == MCMCX_METHOD_SCAM);
-        if (c.method == MCMCX_METHOD_RAM && c.condmax > 0.0) return fail(-8, "pooled mode: method = 'ram' with condmax > 0 is not available");
     }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -1134,7 +1150,7 @@ int mcmcx_init(mcmcx_handle h)
     if (h->tkind == TGT_EXPCOLS && h->tncols != ny) return fail(-36, "response-column target: mcmcx_set_sigma2nobs must give one sigma2 / nobs per column");
     if (ny > 1 && h->pooled) return fail(-36, "nycol > 1 is not available in pooled mode");
     if (h->tkind < 0) return fail(-31, "no target: the device engine needs mcmcx_set_target_*");
-    if (h->dodr && lds_bytes(h) > 160 * 1024) return fail(-35, "delayed rejection keeps two npar-vectors per chain in LDS: npar <= 160 with drscale > 0");
+    if (h->dodr && h->pooled && !dr_fits_lds(h)) return fail(-35, "pooled mode with delayed rejection keeps two npar-vectors per chain in LDS: npar <= 160 (per-chain factors have no such limit)");
     std::vector<double> Rp, Cp, Rfull, qstd0;
     int info = host_initial_R(d, h->cmat0, Rp, Cp);
     if (h->usesvd) {                                                                  // Cp (packed cmat0) is still needed
@@ -1156,6 +1172,7 @@ int mcmcx_init(mcmcx_handle h)
     E.ny = ny; E.hs = d + ny; E.ssv = E.s2v = E.ss2v = nullptr; E.gshapev = nullptr;
     E.alphatarget = c.alphatarget; E.drscale = c.drscale; E.scalelimit = c.scalelimit; E.scalefactor = c.scalefactor;
     E.k0 = c.seed; E.chain_id0 = c.chain_id0;
+    E.dr_lds = (h->dodr && dr_fits_lds(h)) ? 1 : 0;
     {   // plain AM / Metropolis / ER step kernel: state and scratch vectors in LDS (4 d x 512 bytes per wave) when that costs no
         // occupancy -- eight waves per CU still fit (npar <= 10), or all tiles are resident at once anyway (few chains)
         const char *ev = getenv("MCMCX_LDS_SCRATCH");                      // A/B switch: 0 = off

@@ -85,6 +85,9 @@ struct EngineDev {
     // small npar, plain AM step kernel: the state vector and the per-chain scratch vectors (theta, candidate, two normal vectors)
     // live in LDS for the launch -- their store -> load chains are what an iteration waits for when the factor is small
     int lds_scratch;
+    // delayed rejection: the two npar-vectors of the second stage live in LDS (1) or, where 2 x npar x 512 bytes do not fit a
+    // CU's 160 KiB (npar > 160), in the chain's global scratch (0)
+    int dr_lds;
 };
 
 #define TIDX(base, tile, K, k, lane) ((base)[((size_t)(tile) * (size_t)(K) + (size_t)(k)) * 64 + (lane)])
@@ -1476,14 +1479,16 @@ MCX_DEV void quadform2_panels(const double *St, int lane, int d, const double *X
     }
 }
 
+template <bool LDSV>      // the two vectors in LDS (a compile-time choice: a pointer that is LDS or global at run time means FLAT accesses)
 MCX_DEV void dr_body(const EngineDev &E, int it0, int it1, const double *__restrict__ g_mu, const double *__restrict__ g_lamT)
 {
     extern __shared__ double X[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
     double *theta_t = E.theta + (size_t)tile * d * 64;
-    double *zb_t = X;                                          // normals of the stage at hand, then dx_a = newpar2 - newpar
-    double *cand_t = X + (size_t)d * 64;                       // first-stage candidate, then dx_b = oldpar - newpar
     double *c2_t = E.cs + (size_t)tile * 2 * d * 64;           // second-stage candidate (global scratch)
+    // normals of the stage at hand, then dx_a = newpar2 - newpar  |  first-stage candidate, then dx_b = oldpar - newpar
+    double *zb_t = LDSV ? X : c2_t + (size_t)d * 64;
+    double *cand_t = LDSV ? X + (size_t)d * 64 : E.cand + (size_t)tile * d * 64;
     double *ysa_t = E.zs + (size_t)tile * 2 * d * 64, *ysb_t = ysa_t + (size_t)d * 64;     // row chains between two panels of iC
     const double *Rt = E.R + (size_t)tile * E.P * 64;
 
@@ -1587,7 +1592,10 @@ MCX_DEV void dr_body(const EngineDev &E, int it0, int it1, const double *__restr
     TIDX(E.ictr, tile, NICTR, I_DRACC, lane) = dracc; TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane) = drtries;
 }
 __global__ __launch_bounds__(64, 2) void step_kernel_dr(EngineDev E, int it0, int it1, const double *__restrict__ g_mu, const double *__restrict__ g_lamT)
-{ dr_body(E, it0, it1, g_mu, g_lamT); }
+{ dr_body<true>(E, it0, it1, g_mu, g_lamT); }
+// npar > 160: the same with the two vectors in global scratch
+__global__ __launch_bounds__(64, 2) void step_kernel_dr_big(EngineDev E, int it0, int it1, const double *__restrict__ g_mu, const double *__restrict__ g_lamT)
+{ dr_body<false>(E, it0, it1, g_mu, g_lamT); }
 
 #ifndef MCX_AM_WAVES
 #define MCX_AM_WAVES 2
@@ -2515,10 +2523,11 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
                     l2 = -0.5 * ((ss3 - L.ss1) / L.sigma2 + (pri3 - L.pri1));
                 }
                 const double *iCt = E.iC + (size_t)tile * E.P * 64;
-                for (int k = 0; k < d; ++k) XL(k) = GV(c2_t, k) - GV(cand_t, k);
-                double qa = quadform_sym(iCt, lane, d, X, Y);
-                for (int k = 0; k < d; ++k) XL(k) = GV(theta_t, k) - GV(cand_t, k);
-                double qb = quadform_sym(iCt, lane, d, X, Y);
+                double *Xq = E.dr_lds ? X : zs_t, *Yq = E.dr_lds ? Y : zs_t + (size_t)d * 64;   // npar > 160: the (dead) normal vectors
+                for (int k = 0; k < d; ++k) GV(Xq, k) = GV(c2_t, k) - GV(cand_t, k);
+                double qa = quadform_sym(iCt, lane, d, Xq, Yq);
+                for (int k = 0; k < d; ++k) GV(Xq, k) = GV(theta_t, k) - GV(cand_t, k);
+                double qb = quadform_sym(iCt, lane, d, Xq, Yq);
                 double q1 = -0.5 * (qa - qb);
                 double alpha13 = min1(d_exp(l2 + q1) * (1.0 - alpha32) / (1.0 - L.alpha12));
                 bool rej2 = true;
@@ -2575,10 +2584,11 @@ __global__ __launch_bounds__(64) void run1_kernel(EngineDev E, double *r1, int d
                 l2 = -0.5 * ((GV(ssn, 0) - GV(ssp2, 0)) / L.sigma2 + (pri - pri2c));
             }
             const double *iCt = E.iC + (size_t)tile * E.P * 64;
-            for (int k = 0; k < d; ++k) XL(k) = GV(new_t, k) - GV(old1_t, k);
-            double qa = quadform_sym(iCt, lane, d, X, Y);
-            for (int k = 0; k < d; ++k) XL(k) = GV(cur_t, k) - GV(old1_t, k);
-            double qb = quadform_sym(iCt, lane, d, X, Y);
+            double *Xq = E.dr_lds ? X : zs_t, *Yq = E.dr_lds ? Y : zs_t + (size_t)d * 64;       // npar > 160: the normal vectors' scratch
+            for (int k = 0; k < d; ++k) GV(Xq, k) = GV(new_t, k) - GV(old1_t, k);
+            double qa = quadform_sym(iCt, lane, d, Xq, Yq);
+            for (int k = 0; k < d; ++k) GV(Xq, k) = GV(cur_t, k) - GV(old1_t, k);
+            double qb = quadform_sym(iCt, lane, d, Xq, Yq);
             double q1 = -0.5 * (qa - qb);
             alpha = min1(d_exp(l2 + q1) * (1.0 - alpha32) / (1.0 - alpha12));
         } else {

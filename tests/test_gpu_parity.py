@@ -214,10 +214,12 @@ def test_pooled_moments_and_shard_invariance(oracle):
     np.testing.assert_allclose(cov, np.cov(th_all.T), rtol=1e-9, atol=1e-12)
 
 
-@pytest.mark.parametrize("method,d,extra", [("dram", 256, {}), ("ram", 256, {}), ("dram", 150, {"drscale": 2.0}), ("dram", 1, {"drscale": 3.0})])
+@pytest.mark.parametrize("method,d,extra", [("dram", 256, {}), ("ram", 256, {}), ("dram", 150, {"drscale": 2.0}), ("dram", 1, {"drscale": 3.0}),
+                                            ("dram", 160, {"drscale": 2.0}), ("dram", 161, {"drscale": 2.0}), ("dram", 256, {"drscale": 2.0})])
 def test_extreme_dimensions(oracle, method, d, extra):
-    """npar at the engine's limits: 256 (AM and RAM; one adaptation tick), the largest delayed-rejection size whose two
-    work vectors fit the LDS, and npar = 1 with DR."""
+    """npar at the engine's limits: 256 (AM and RAM; one adaptation tick), delayed rejection on both sides of the size
+    whose two second-stage vectors still fit the LDS (160: step_kernel_dr; 161 and 256: step_kernel_dr_big, the vectors in
+    global scratch), and npar = 1 with DR."""
     from mcmcf90_amd import engine_from_problem
     rng = np.random.default_rng(d)
     A = rng.standard_normal((d, d)) / np.sqrt(d)
@@ -240,8 +242,8 @@ def test_sizes_beyond_the_limits_fail_loudly():
     from mcmcf90_amd import make_config, Engine, McmcError
     with pytest.raises(McmcError):
         Engine(make_config(257, 1, nsimu=10))
-    e = Engine(make_config(200, 1, nsimu=10, drscale=2.0))          # DR keeps two npar-vectors per chain in LDS
-    e.setpar0(np.zeros(200)); e.set_target("banana", b=0.1)
+    e = Engine(make_config(200, 4, nsimu=10, drscale=2.0, pooled=1))   # the pooled extension keeps its DR vectors in LDS (npar <= 160);
+    e.setpar0(np.zeros(200)); e.set_target("banana", b=0.1)           # per-chain DR has no such limit (test_extreme_dimensions)
     with pytest.raises(McmcError):
         e.init()
     e.close()

@@ -500,26 +500,48 @@ def test_pooled_delayed_rejection_and_er_match_restatement(oracle, name, extra, 
     e.close()
 
 
-@pytest.mark.parametrize("d,N,mfma", [(6, 150, 0), (6, 150, 1), (50, 200, 1)])
-def test_pooled_ram_matches_restatement(oracle, d, N, mfma, monkeypatch):
+@pytest.mark.parametrize("d,N,mfma,condmax", [(6, 150, 0, 0.0), (6, 150, 1, 0.0), (50, 200, 1, 0.0), (6, 150, 0, 1e8), (6, 150, 1, 25.0), (20, 130, 1, 1e8)])
+def test_pooled_ram_matches_restatement(oracle, d, N, mfma, condmax, monkeypatch):
     """method = 'ram', pooled = 1: one factor for all chains; every adaptint iterations the chains' rank-one RAM
     statistics sign(a) x x' (MCMC_run_ram.F90:166-172) of that iteration are averaged over all chains and folded into
-    the Gram matrix of the shared factor, which is refactored (pooled_ram_tick)."""
+    the Gram matrix of the shared factor, which is refactored (pooled_ram_tick).  condmax > 0: the shared factor is
+    covtor_svd's full matrix (matutils.F90:378-453), proposals are matmulx(Rf, z), the Gram matrix is Rf Rf' and the
+    refactorisation goes through the pinned SVD with the singular-value floor (condmax = 25 makes it bite)."""
     from mcmcf90_amd import engine_from_problem
     if not mfma:
         monkeypatch.setenv("MCMCX_POOLED_SCALAR", "1")
     nsimu, adaptint, nu, target = 130, 20, 0.7, 0.234
-    ckw = dict(nsimu=nsimu, method="ram", adaptint=adaptint, updatesigma=0, nuparam=nu, alphatarget=target)
+    ckw = dict(nsimu=nsimu, method="ram", adaptint=adaptint, updatesigma=0, nuparam=nu, alphatarget=target, condmax=condmax)
     rng = np.random.default_rng(d)
     A = rng.standard_normal((d, d)) / np.sqrt(d)
-    pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.2), cmat0=(0.5 / d) * np.eye(d), mu=np.zeros(d), lam=A @ A.T + np.eye(d))
+    cm0 = (0.5 / d) * (np.diag(10.0 ** np.linspace(-3, 0, d)) if 0.0 < condmax < 100.0 else np.eye(d))     # cond 1000 > condmax: the floor bites
+    pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.2), cmat0=cm0, mu=np.zeros(d), lam=A @ A.T + np.eye(d))
     e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
     e.init(); e.run()
     plain = oracle.make_cfg(**dict(ckw, doadapt=0, method="dram"))
     prob = oracle.Problem(**pkw)
     chains = [oracle.LiveChain(plain, prob, chain_id=c) for c in range(N)]
-    st = _init_state(oracle, d, np.asarray(pkw["par0"], float), np.asarray(pkw["cmat0"], float), 0)
-    R = st["R"]
+    DP = C.POINTER(C.c_double)
+    floored = []
+
+    def svd_factor(S, scale):
+        """covtor_svd: U sqrt(s) of the symmetric S with s floored at s_1 / condmax (times 2.4/sqrt(d) for MCMC_init's factor)"""
+        G = np.asfortranarray(S.copy()); V = np.zeros((d, d), order="F"); sv = np.zeros(d)
+        oracle.lib().mcxo_symsvd(d, G.ctypes.data_as(DP), V.ctypes.data_as(DP), sv.ctypes.data_as(DP))
+        tol = sv[0] / condmax
+        if sv[d - 1] <= tol:
+            sv = np.where(sv < tol, tol, sv); floored.append(1)
+        R0 = np.array([[math.sqrt(sv[i]) * V[k, i] for i in range(d)] for k in range(d)])
+        return np.array([[R0[i, j] * 2.4 / math.sqrt(float(d)) for j in range(d)] for i in range(d)]) if scale else R0
+
+    if condmax > 0.0:
+        R = svd_factor(np.asarray(pkw["cmat0"], float), True)
+        for ch in chains:
+            ch.set_R(R)
+        st = {"R": R.copy()}
+    else:
+        st = _init_state(oracle, d, np.asarray(pkw["par0"], float), np.asarray(pkw["cmat0"], float), 0)
+        R = st["R"]
     T = (N + 63) // 64
 
     def tree_over_chains(vals):
@@ -544,13 +566,20 @@ def test_pooled_ram_matches_restatement(oracle, d, N, mfma, monkeypatch):
         for j in range(d):
             for i in range(j + 1):
                 acc = 0.0
-                for k in range(i + 1):
-                    acc = _fma(R[k, i], R[k, j], acc)
+                if condmax > 0.0:                      # proposals Rf z: the Gram matrix is Rf Rf'
+                    for k in range(d):
+                        acc = _fma(R[i, k], R[j, k], acc)
+                else:
+                    for k in range(i + 1):
+                        acc = _fma(R[k, i], R[k, j], acc)
                 S[i, j] = acc + tree_over_chains(sgn * (X[:, i] * X[:, j])) / cnt
                 S[j, i] = S[i, j]
-        Af = np.asfortranarray(S.copy())
-        if oracle.lib().mcxo_potrf_u(d, Af.ctypes.data_as(C.POINTER(C.c_double))) == 0:
-            R = np.triu(np.array(Af))
+        if condmax > 0.0:
+            R = svd_factor(S, False)
+        else:
+            Af = np.asfortranarray(S.copy())
+            if oracle.lib().mcxo_potrf_u(d, Af.ctypes.data_as(C.POINTER(C.c_double))) == 0:
+                R = np.triu(np.array(Af))
         for ch in chains:
             ch.set_R(R)
     for ch in chains:
@@ -559,7 +588,11 @@ def test_pooled_ram_matches_restatement(oracle, d, N, mfma, monkeypatch):
     np.testing.assert_array_equal(_bits(e.theta()), _bits(theta))
     for c in (0, 63, 64, N - 1):
         np.testing.assert_array_equal(e.accepted(c), chains[c].accepted)
-    np.testing.assert_array_equal(_bits(np.triu(e.pooled()[3])), _bits(R))
+    if condmax > 0.0:
+        np.testing.assert_array_equal(_bits(e.pooled()[3]), _bits(R))
+        assert floored or condmax > 100
+    else:
+        np.testing.assert_array_equal(_bits(np.triu(e.pooled()[3])), _bits(R))
     assert not np.array_equal(R, st["R"])                       # the factor did adapt
     for ch in chains:
         ch.close()
