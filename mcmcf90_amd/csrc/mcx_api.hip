@@ -286,6 +286,7 @@ static void launch_step(mcmcx_engine *h, int it0, int it1)
     else if (h->dodr && !(getenv("MCMCX_DR_GENERAL") && atoi(getenv("MCMCX_DR_GENERAL"))))      // (A/B switch for tests: step_body<DR>)
         hipLaunchKernelGGL(step_kernel_dr, g, b, lds_step(h), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
     else if (h->dodr) hipLaunchKernelGGL((step_kernel<false, true, false>), g, b, lds_step(h), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
+    else if (h->E.lds_scratch == 2) hipLaunchKernelGGL(step_kernel_ldsr, g, b, (size_t)(2 * h->d + h->P) * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->E.lds_scratch) hipLaunchKernelGGL(step_kernel_ldsv, g, b, (size_t)4 * h->d * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else hipLaunchKernelGGL((step_kernel<false, false, false>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
 }
@@ -1183,6 +1184,12 @@ int mcmcx_init(mcmcx_handle h)
         if (hipGetDeviceProperties(&prop, c.device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
         const bool fits = per_cu >= 8 || (per_cu >= 1 && (long long)T <= (long long)per_cu * cus);
         E.lds_scratch = (!h->pooled && !h->dodr && c.method != MCMCX_METHOD_RAM && c.method != MCMCX_METHOD_SCAM && fits && !(ev && atoi(ev) == 0)) ? 1 : 0;
+        // ... and the packed factor with it (step_kernel_ldsr) where one column panel covers npar and state + factor of all tiles
+        // are resident at once: (2 npar + npar (npar + 1) / 2) x 512 bytes per wave, 38 KiB at npar = 10 = four waves per CU
+        const size_t per_wave_r = (size_t)(2 * d + P) * 64 * sizeof(double);
+        const int per_cu_r = (int)((size_t)160 * 1024 / per_wave_r);
+        const bool fits_r = per_cu_r >= 8 || (per_cu_r >= 1 && (long long)T <= (long long)per_cu_r * cus);
+        if (E.lds_scratch && !h->usesvd && d <= TW && fits_r && !(ev && atoi(ev) == 1)) E.lds_scratch = 2;     // MCMCX_LDS_SCRATCH=1: the state only (A/B)
     }
     // target
     E.tgt.kind = phased(h) ? (int)TGT_HOST : h->tkind;   // the kernels know one phase-cut mode; who evaluates is the host's business

@@ -1240,7 +1240,7 @@ MCX_DEV double quadform_sym_shared(const double *__restrict__ Ss, int lane, int 
 // Iterations it0..it1 (absolute simuind) of MCMC_run (MCMC_run.F90:41-107) or MCMC_run_ram
 // (MCMC_run_ram.F90:45-81) for one tile of 64 chains.  LDS is used only by the delayed-rejection
 // quadratic forms (2*d*64 doubles when dodr, none otherwise).
-template <bool RAM, bool DR, bool POOLED, bool WIDE_T = (RAM || (!DR && !POOLED)), bool FULLR = false, bool LDSV = false>
+template <bool RAM, bool DR, bool POOLED, bool WIDE_T = (RAM || (!DR && !POOLED)), bool FULLR = false, bool LDSV = false, bool LDSR = false>
 MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__restrict__ ramscale,
                        const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
                        const double *__restrict__ g_sharedR, const double *__restrict__ g_sharedR2 = nullptr,
@@ -1250,13 +1250,18 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
     constexpr bool ldsv = LDSV && !RAM && !DR && !POOLED;                // step_kernel_ldsv: launched with 4 d x 512 bytes of LDS (a compile-time
                                                                         // choice, so that the vectors' accesses are ds_read / ds_write, not flat)
+    // step_kernel_ldsr (npar <= TW): besides the state, the chain's packed factor stays in LDS for the launch -- AM only reads
+    // it between two ticks -- and ONE vector serves as normals, proposal and candidate (a single column panel: the product
+    // has read every normal before it stores anything)
+    constexpr bool ldsr = ldsv && LDSR;
     double *theta_g = E.theta + (size_t)tile * d * 64;
     double *theta_t = ldsv ? X : theta_g;
     double *cand_t = ldsv ? X + (size_t)d * 64 : E.cand + (size_t)tile * d * 64;           // proposal vector P, then candidate theta + P
-    double *zs_t = ldsv ? X + (size_t)2 * d * 64 : E.zs + (size_t)tile * 2 * d * 64;       // two normal vectors: this iteration's and the next one's
+    double *zs_t = ldsr ? cand_t : (ldsv ? X + (size_t)2 * d * 64 : E.zs + (size_t)tile * 2 * d * 64);       // two normal vectors: this iteration's and the next one's
     double *cs_t = E.cs + (size_t)tile * 2 * d * 64;           // RAM: rotations; DR: second-stage candidate
     if (ldsv) for (int k = 0; k < d; ++k) GV(theta_t, k) = GV(theta_g, k);
-    double *Rt = E.R + (size_t)tile * E.P * 64;
+    double *Rt = ldsr ? X + (size_t)2 * d * 64 : E.R + (size_t)tile * E.P * 64;
+    if (ldsr) { const double *Rg = E.R + (size_t)tile * E.P * 64; copy_vec(Rt, Rg, nullptr, lane, E.P); }
     double *Y = X + (size_t)d * 64;
     double *c2_t = cs_t;
 
@@ -1276,11 +1281,11 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
     uint32_t downs = RAM ? TIDX(E.ictr, tile, NICTR, I_DOWNS, lane) : 0u;
 
     bool have_p = false;                          // lanes whose candidate is already in cand_t
-    double su_c = gen_normals<RAM ? 1 : MCX_RNG_NB>(g, zs_t + (size_t)(it0 & 1) * d * 64, lane, d, true), su_n = 0.0;
+    double su_c = gen_normals<RAM ? 1 : MCX_RNG_NB>(g, zs_t + (ldsr ? 0 : (size_t)(it0 & 1) * d * 64), lane, d, true), su_n = 0.0;
 
     for (int it = it0; it <= it1; ++it) {
-        double *zc_t = zs_t + (size_t)(it & 1) * d * 64;          // z of this iteration
-        double *zn_t = zs_t + (size_t)((it + 1) & 1) * d * 64;    // z of the next one
+        double *zc_t = ldsr ? zs_t : zs_t + (size_t)(it & 1) * d * 64;          // z of this iteration
+        double *zn_t = ldsr ? zs_t : zs_t + (size_t)((it + 1) & 1) * d * 64;    // z of the next one
         // ---- newpar = MCMC_propose(oldpar, R)
         if (POOLED) { if (E.usesvd) gemvN_shared(g_sharedR, zc_t, cand_t, theta_t, lane, d); else trmv_shared(g_sharedR, zc_t, cand_t, theta_t, lane, d); }
         else if (E.usesvd) gemvN_panels(E.Rf + (size_t)tile * d * d * 64, zc_t, cand_t, theta_t, lane, d, true);   // matmulx(R,z)
@@ -1613,6 +1618,11 @@ __global__ __launch_bounds__(64, MCX_AM_WAVES) void step_kernel_ldsv(EngineDev E
                                                      const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
                                                      const double *__restrict__ g_sharedR)
 { step_body<false, false, false, MCX_AM_WIDE, false, true>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
+// ... and the chain's packed factor too (npar <= TW; EngineDev::lds_scratch == 2): north_star's "Cholesky factor staged in LDS"
+__global__ __launch_bounds__(64, MCX_AM_WAVES) void step_kernel_ldsr(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
+                                                     const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
+                                                     const double *__restrict__ g_sharedR)
+{ step_body<false, false, false, MCX_AM_WIDE, false, true, true>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
 
 // pooled mode with delayed rejection: the shared factor, its second-stage copy R2 = R / drscale and the shared inverse
 // covariance iC = dpotri(R) all come through the scalar cache (the host recomputes the three at every pooled tick)
