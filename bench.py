@@ -334,7 +334,7 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
     from mcmcf90_amd.workloads import problem
     n_local = chains_per_gpu or DEFAULT_CHAINS[wl]
     ips = its_per_step or (10 if wl == "c5" else 100)       # c5: one iteration is d = 200 componentwise proposals
-    nsimu = 1 + (warmup + steps) * ips
+    nsimu = (warmup + steps) * ips + 1                       # steps end ON the adaptation ticks (iteration k * ips): one launch + one tick each
     ckw, pkw, per_it = problem(wl, nsimu, adaptint=max(ips, 100))
     d = pkw["npar"]
     if wl == "c4" and start == "target":
@@ -353,7 +353,7 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
     eng.init()
 
     def one_step(k):
-        eng.run(1 + (k + 1) * ips)
+        eng.run((k + 1) * ips)                         # iterations k*ips + 1 .. (k+1)*ips (the very first step starts at iteration 2)
         eng.allreduce_moments(fetch=False)             # local fixed tree -> RCCL all-gather -> tree over ranks; stays in HBM
 
     def fence():
@@ -382,9 +382,10 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
     eng.close()
     if rank != 0:
         return None, pooled_vec
-    base = float(world) * n_local * ips * per_it
-    dr_per_it = tries / (warmup + steps) / ips                                  # stage-2 proposals per iteration, all ranks
-    proposals = (base + dr_per_it * ips) * steps
+    its_timed = steps * ips - (1 if warmup == 0 else 0)                         # iteration 1 is the starting point (MCMC_run.F90:35-41)
+    its_all = (warmup + steps) * ips - 1
+    dr_per_it = tries / its_all                                                 # stage-2 proposals per iteration, all ranks
+    proposals = (float(world) * n_local * per_it + dr_per_it) * its_timed
     value = proposals / dt
     per_launch_prop = proposals / world / max(klaunch, 1)                        # proposals one launch of one GPU evaluates
     avg_launch_s = kms / 1e3 / max(klaunch, 1)
@@ -398,7 +399,7 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
                 "traffic": pmc["hbm_bytes_per_proposal"] * per_launch_prop if pmc and "hbm_bytes_per_proposal" in pmc else None,
                 "kernel": "mcx::scam_pooled_kernel", "alg_flop_per_proposal": flop}
     else:
-        down_frac = downs_all / (float(world) * n_local * (nsimu - 1)) if method == "ram" else 0.0
+        down_frac = downs_all / (float(world) * n_local * its_all) if method == "ram" else 0.0
         balg = alg_bytes_per_proposal(d, "pooled" if pooled else method, down_frac)
         achieved = balg * per_launch_prop / avg_launch_s / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -429,7 +430,7 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
         roof["note"] = ("the chip's HBM roof is quoted for uniformity; this configuration is bound by the per-chain random "
                         "numbers (Philox + polar + pinned log/sqrt on the VALU), see DESIGN.md section 5")
     if method == "ram":
-        stay = stayed_all / (float(world) * n_local * (nsimu - 1))
+        stay = stayed_all / (float(world) * n_local * its_all)
         roof["note"] = ("accepted fraction %.2f (start: %s); RAM updates the factor after alpha >= alphatarget (one "
                         "read+write sweep) and downdates it otherwise (two sweeps): DESIGN.md section 10 item 6" % (1.0 - stay, start))
     mode = method + (" pooled (one shared factor)" if pooled else ", per-chain factor")
