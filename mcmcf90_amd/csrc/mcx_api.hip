@@ -325,7 +325,7 @@ static int upload_shared_rf(mcmcx_engine *h)            // dense M[s*d + o] = Rf
     return 0;
 }
 static size_t shared_u_stride(const mcmcx_engine *h) { return (size_t)((h->d + 3) & ~3) * h->d + PWS; }     // d4 rows (pad rows zero) + slack
-static size_t scam_pooled_lds(int d) { return ((size_t)((d + 15) / 16) * (16 + 4) * 64 + 128) * sizeof(double); }     // X [16 nt][64], Q [4 nt][64], zb, fl
+static size_t scam_pooled_lds(int d) { return ((size_t)((d + 15) / 16) * (16 + 4) * 64 + 128 + (size_t)((d + 15) / 16) * 16) * sizeof(double); }     // X [16 nt][64], Q [4 nt][64], zb, fl, mu [16 nt]
 static int upload_shared_u(mcmcx_engine *h)
 {
     const int d = h->d; const size_t st = shared_u_stride(h);

@@ -1925,6 +1925,7 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
     const int tile = blockIdx.x, d = E.d, d4 = (d + 3) & ~3, nt = (d + 15) >> 4, li = lane & 15, lk = lane >> 4;
     double *Q = X + (size_t)nt * 16 * 64;                                       // [4*nt][64] partial ss chains
     double *zb = Q + (size_t)nt * 4 * 64, *fl = zb + 64;                      // per chain: the deviate, the accept flag
+    double *mul = fl + 64;                                                      // the target's mean, [16 nt]: read at every third fill
     constexpr bool sc = SC;                                                     // the scalar wave
     const bool gauss = (E.tgt.kind == TGT_GAUSS);
     const bool cand_global = !gauss || E.tgt.pmu || E.tgt.lo || E.tgt.hi;       // prior / bounds / other targets read theta' per chain
@@ -1937,6 +1938,11 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
     double *cand_t = E.cand + (size_t)tile * d * 64;
     LaneState L;
     if (sc) lane_load(E, tile, lane, L);
+    // The group waves own one or two tile sets whose MFMAs form ONE dependent chain per product; at equal priority the (older)
+    // block waves' sixteen independent MFMAs per trip win the matrix pipe and the chain only runs once they are done -- the
+    // whole workgroup then waits ~2 us per product at the barrier.  Raised priority lets the chain interleave.
+    if (!BW) __builtin_amdgcn_s_setprio(2);
+    if (gauss) { for (int o = w * 64 + lane; o < 16 * nt; o += nw * 64) mul[o] = o < d ? g_mu[o] : 0.0; }
     mcx_d4 cand[4], cc[4], th[4];
     // The chains' state: every lane keeps the elements of its slots in registers across the sub-steps (they are the ones it
     // fills into X and the ones it replaces on an accept) and writes them back once per iteration.
@@ -1947,7 +1953,7 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
             for (int r = 0; r < 4; ++r) th[s][r] = theta_t[EROW(s, r) < d ? EOFF(s, r) : e0];
         }
 #ifdef MCX_PHASE_PROF
-    unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tq = wall_clock64();
+    unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tq = wall_clock64();
 #define PH(i) { unsigned long long tn = wall_clock64(); ph[i] += tn - tq; tq = tn; }
 #else
 #define PH(i)
@@ -1962,14 +1968,16 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
                     for (int r = 0; r < 4; ++r) X[EOFF(s, r)] = EROW(s, r) < d ? th[s][r] : 0.0;
                 }
             }
-            if (sc) zb[lane] = rng_normal(L.g) * g_std[j];
             PH(0)
             __syncthreads();
-            PH(1)
+            PH(7)
+            // the sub-step's deviate is not needed before the second fill: the scalar wave draws it while the first product runs
+            // (its own share of the product is one tile set) instead of holding everybody at the barrier above
+            if (sc) zb[lane] = rng_normal(L.g) * g_std[j];
             mfma_slots<BW, NS>(g_UT, X, lane, d, d4, blk0, grp, cc);           // rot = U'theta
             PH(2)
             __syncthreads();
-            PH(1)
+            PH(8)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if (s < nsl) {
@@ -1985,7 +1993,7 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
             }
             PH(3)
             __syncthreads();
-            PH(1)
+            PH(9)
             mfma_slots<BW, NS>(g_U, X, lane, d, d4, blk0, grp, cand);          // theta' = U rot
             PH(2)
             if (cand_global) {
@@ -2002,11 +2010,11 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
                 for (int s = 0; s < 4; ++s)
                     if (s < nsl) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { const int o = EROW(s, r); X[EOFF(s, r)] = o < d ? cand[s][r] - g_mu[o < d ? o : 0] : 0.0; }
+                        for (int r = 0; r < 4; ++r) { const int o = EROW(s, r); X[EOFF(s, r)] = o < d ? cand[s][r] - mul[o] : 0.0; }
                     }
                 PH(3)
                 __syncthreads();
-                PH(1)
+                PH(10)
                 mfma_slots<BW, NS>(g_lamT, X, lane, d, d4, blk0, grp, cc);     // y = Lam v
                 PH(2)
 #pragma unroll
@@ -2020,7 +2028,7 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
                 }
                 PH(4)
                 __syncthreads();
-                PH(1)
+                PH(11)
             }
             if (sc) {
                 bool inb = true; double pri2 = 0.0, ss2 = 0.0;
@@ -2043,7 +2051,7 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
             }
             PH(5)
             __syncthreads();
-            PH(1)
+            PH(12)
             // accepted chains: theta = theta' (each lane its own elements; the next sub-step reloads exactly those)
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -2084,7 +2092,7 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
     if (sc) lane_store(E, tile, lane, L);
 #ifdef MCX_PHASE_PROF
     PH(6)
-    if (tile == 0 && lane == 0 && (w == 0 || sc)) printf("wave %d x10ns: theta+fill %llu barriers %llu mfma %llu fills %llu q %llu scalar %llu accept %llu\n", w, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
+    if (tile == 0 && lane == 0 && (w == 0 || sc)) printf("wave %d x10ns: theta+fill %llu mfma %llu fills %llu q %llu scalar %llu accept %llu | barrier waits after: fill0 %llu P1 %llu fill1 %llu P2 %llu fill2 %llu P3q %llu scalar %llu\n", w, ph[0], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7], ph[8], ph[9], ph[10], ph[11], ph[12], ph[13]);
 #endif
 #undef PH
 #undef EOFF
