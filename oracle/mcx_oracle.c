@@ -543,6 +543,7 @@ int mcxo_calculate_R(mcxo_chain *c, double *cmat)
     int n = c->npar;
     double *R0 = (double *)malloc(sizeof(double) * (size_t)n * n);
     int info = 0;
+    c->n_calcR += 1; c->svd_floored = 0;
     if (c->cfg.doscam) {                                           /* :189-200 */
         info = svd_factor(n, cmat, c->cfg.condmax, 1, R0, c->qcovstd);
         if (info > 0) { free(R0); c->info_last = info; return info; }
@@ -555,6 +556,7 @@ int mcxo_calculate_R(mcxo_chain *c, double *cmat)
     if (c->cfg.usesvd) {                                           /* :204-209 */
         info = svd_factor(n, cmat, c->cfg.condmax, 0, R0, NULL);
         if (info == -1) {                                          /* cmat = matmul(R0, transpose(R0)) */
+            c->svd_floored = 1;
             for (int j = 0; j < n; ++j)
                 for (int i = 0; i < n; ++i) {
                     double acc = 0.0;

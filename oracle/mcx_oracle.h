@@ -95,6 +95,9 @@ typedef struct mcxo_chain {
     /* the normal deviates of the latest first-stage proposal (MCMC_propose's u): what a pooled RAM tick of the engine
      * reads back; test restatements only (tests/test_gpu_pooled.py) */
     double *last_u;
+    /* bookkeeping for tests that replace the factors of an adaptation from outside (tests/test_oracle_fuzz_reference.py):
+     * calls of MCMC_calculate_R so far, and whether the latest covtor_svd floored its singular values (info = -1) */
+    int n_calcR, svd_floored;
 } mcxo_chain;
 
 mcxo_chain *mcxo_chain_create(const mcxo_cfg *cfg, const mcxo_target *tgt, const double *par0,

@@ -54,6 +54,69 @@ def _scam_against_the_mkl_chain_with_its_logged_factors(oracle, rr, cfg, prob, s
     return True
 
 
+def _svd_dram_against_the_mkl_chain_with_its_logged_factors(oracle, rr, cfg, prob, seed):
+    """The same for method = 'dram' with condmax > 0 (covtor_svd, matutils.F90:378-453): at every MCMC_calculate_R of the
+    oracle (MCMC_init, the AM ticks, the burn-in ticks that fall through to it -- the oracle counts its calls) the factor is
+    rebuilt from what MKL's dgesvd returned to the reference there: singular values floored at s_1 / condmax,
+    R = U sqrt(s) 2.4/sqrt(npar), and with delayed rejection R2 = R / drscale, iC = dpotri('U', R) (MCMC_adapt.F90:204-225).
+    Where the floor bites the covariance itself becomes U s U' -- a function of the covariance that does not depend on the
+    basis chosen inside a cluster -- so the oracle's own replacement stands as long as both agree that it bit.
+    Returns False when the case cannot be checked this way."""
+    import ctypes as C
+    ref = rr.run_reference(cfg, prob, chain_id=seed, svd_log=True)
+    calls = ref.svd_calls
+    if not calls or any(info != 0 or not np.isfinite(sv).all() or not np.isfinite(U).all() or not sv[0] > 0.0 for info, sv, U in calls):
+        return False
+    n = prob.npar
+    DP = C.POINTER(C.c_double)
+    lc = oracle.LiveChain(cfg, prob, chain_id=seed)
+
+    def put(call):
+        info, sv, U = call
+        sv = sv.copy()
+        tol = sv[0] / cfg.condmax
+        floored = bool(sv[-1] <= tol)
+        if floored:
+            sv[sv < tol] = tol
+        if floored != bool(lc.ch.contents.svd_floored):
+            return False
+        R = (U * np.sqrt(sv)) * 2.4 / np.sqrt(float(n))           # R(i,j) = U(i,j) sqrt(s_j) 2.4/sqrt(n)
+        lc.set_R(R)
+        if cfg.dodr:
+            B = np.asfortranarray(R.copy())
+            if oracle.lib().mcxo_potri_u(n, B.ctypes.data_as(DP)) != 0:
+                return False
+            lc.set_dr(R / cfg.drscale, np.array(B))
+        return True
+
+    k = 0
+    ok = lc.ch.contents.n_calcR == 1 and put(calls[0])
+    step = max(1, min(cfg.adaptint, cfg.badaptint if cfg.badaptint > 0 else cfg.adaptint))
+    it = step
+    while ok and it <= cfg.nsimu:
+        before = lc.ch.contents.n_calcR
+        lc.run(it)
+        if lc.ch.contents.n_calcR != before:
+            k += 1
+            ok = lc.ch.contents.n_calcR == before + 1 and k < len(calls) and put(calls[k])
+        it += 1 if step == 1 else (step - it % step if it % step else step)
+    if ok:
+        lc.run(cfg.nsimu)
+        ok = (k + 1 == len(calls))
+    if not ok:
+        lc.close()
+        return False
+    c = lc.ch.contents
+    ch = np.ctypeslib.as_array(c.chain, shape=(cfg.nsimu, n + 1))[:c.chainind].copy()
+    rng_n = c.rng.n
+    lc.close()
+    np.testing.assert_array_equal(ref.chain[:, -1].astype(np.int64), ch[:, -1].astype(np.int64))
+    assert ref.rng_n == rng_n
+    scale = np.maximum(np.abs(ch[:, :-1]).max(axis=0), 1e-3)
+    assert np.max(np.abs(ref.chain[:, :-1] - ch[:, :-1]) / scale) < 1e-7
+    return True
+
+
 def _well_posed(oracle, cfg, prob, seed):
     """Condition number of chaincmat at every iteration where MCMC_adapt may factor it."""
     n = prob.npar
@@ -103,6 +166,9 @@ def test_oracle_equals_reference_on_random_configuration(oracle, seed):
     if cfg.method != 1 and not _well_posed(oracle, cfg, prob, seed):
         if cfg.doscam and os.path.exists(rr.EXE_MKLLOG) and _scam_against_the_mkl_chain_with_its_logged_factors(oracle, rr, cfg, prob, seed):
             return
+        if cfg.usesvd and not cfg.doscam and cfg.method == 0 and os.path.exists(rr.EXE_MKLLOG) and \
+                _svd_dram_against_the_mkl_chain_with_its_logged_factors(oracle, rr, cfg, prob, seed):
+            return
         pytest.skip("a covariance handed to the factorisation is numerically singular (fewer distinct rows than parameters) or, "
                     "on the SVD paths, has clustered singular values: what LAPACK returns for it is rounding noise, the "
                     "reference linked to another LAPACK would differ from itself")
@@ -113,6 +179,12 @@ def test_oracle_equals_reference_on_random_configuration(oracle, seed):
     assert np.max(np.abs(r.chain[:, :-1] - o.chain[:, :-1]) / scale) < 1e-7, ckw
     if cfg.updatesigma:
         np.testing.assert_allclose(r.s2chain, o.s2chain, rtol=1e-7)
+    # the SVD paths a second time, independently of the pinned routine: against the MKL-linked chain with its logged factors
+    if cfg.usesvd and cfg.method in (0, 2) and os.path.exists(rr.EXE_MKLLOG):
+        if cfg.doscam:
+            _scam_against_the_mkl_chain_with_its_logged_factors(oracle, rr, cfg, prob, seed)
+        else:
+            _svd_dram_against_the_mkl_chain_with_its_logged_factors(oracle, rr, cfg, prob, seed)
 
 
 def _prefix_before_failed_downdate(oracle, rr, ckw, cfg, prob, seed, o, pinned_svd=False):
