@@ -327,7 +327,7 @@ class Watchdog:
 
 # ------------------------------------------------------------------ one configuration
 def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_per_step=0, method_opt=None, pooled=False,
-               replicas=False, start="default", transport="one GPU"):
+               replicas=False, start="default", transport="one GPU", scam_fast=False):
     """Time `steps` bench steps of configuration `wl` (after `warmup` untimed ones) on this rank's GPU; returns the pieces
     of the JSON line on rank 0 (None elsewhere) and the pooled moment vector."""
     from mcmcf90_amd import engine_from_problem
@@ -349,7 +349,7 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
             ckw = dict(ckw, method="dram")
     method = ckw.get("method", "dram")
     eng = engine_from_problem(ckw, pkw, nchains=n_local, chain_id0=rank * n_local, device=dev,
-                              pooled=1 if pooled else 0, comm=comm)
+                              pooled=1 if pooled else 0, comm=comm, scam_fast=1 if (scam_fast and wl == "c5") else 0)
     eng.init()
 
     def one_step(k):
@@ -391,8 +391,11 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
     avg_launch_s = kms / 1e3 / max(klaunch, 1)
     ckey = "%s_%s%s" % (wl, "pooled" if pooled else method, "_target" if start == "target" else "")
     pmc = measured_counters(ckey)
-    if wl == "c5" and pooled:                   # shared rotation: three d x d products per proposal on the f64 matrix cores
-        flop = 6.0 * d * d
+    if wl == "c5" and scam_fast:
+        ckey += "_fast"
+        pmc = measured_counters(ckey)
+    if wl == "c5" and (pooled or scam_fast):    # shared rotation: three d x d products per proposal on the f64 matrix cores
+        flop = (2.0 if scam_fast else 6.0) * d * d  # (scam_fast, pooled or per-chain: the target's product only)
         achieved = flop * per_launch_prop / avg_launch_s / 1e12
         roof = {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TF,
@@ -401,6 +404,8 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
     else:
         down_frac = downs_all / (float(world) * n_local * its_all) if method == "ram" else 0.0
         balg = alg_bytes_per_proposal(d, "pooled" if pooled else method, down_frac)
+        if method == "scam" and scam_fast:
+            balg = 16 * d + 32 + 8 * d                   # scam_fast: one column of the rotation per proposal instead of two passes over it
         achieved = balg * per_launch_prop / avg_launch_s / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
@@ -433,7 +438,8 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
         stay = stayed_all / (float(world) * n_local * its_all)
         roof["note"] = ("accepted fraction %.2f (start: %s); RAM updates the factor after alpha >= alphatarget (one "
                         "read+write sweep) and downdates it otherwise (two sweeps): DESIGN.md section 10 item 6" % (1.0 - stay, start))
-    mode = method + (" pooled (one shared factor)" if pooled else ", per-chain factor")
+    mode = method + (" pooled (one shared factor)" if pooled else ", per-chain factor") + \
+        (", scam_fast = 1 (opt-in: proposals as theta + delta U(:,j), not the reference's operation order)" if (scam_fast and wl == "c5") else "")
     cnt = float(pooled_vec[0])
     mean = pooled_vec[1:1 + d] / cnt
     res = {
@@ -458,6 +464,8 @@ OTHER_CONFIGS = [
     ("c4_target", dict(wl="c4", steps=3, warmup=1, start="target")),
     ("c4_pooled", dict(wl="c4", steps=3, warmup=1, pooled=True)),
     ("c5_pooled", dict(wl="c5", steps=2, warmup=1)),
+    ("c5_pooled_scam_fast", dict(wl="c5", steps=2, warmup=1, scam_fast=True)),        # opt-in variants, labelled as such in `workload`
+    ("c5_replicas_scam_fast", dict(wl="c5", steps=2, warmup=1, replicas=True, scam_fast=True)),
 ]
 
 
@@ -472,6 +480,7 @@ def main():
     ap.add_argument("--method", default=None, choices=["ram", "dram"], help="c4 only: per-chain RAM (default) or AM")
     ap.add_argument("--pooled", action="store_true", help="one shared factor from the all-reduced pooled covariance (c5: the default)")
     ap.add_argument("--replicas", action="store_true", help="c5: per-chain rotations (the reference's semantics) instead of the pooled one")
+    ap.add_argument("--scam-fast", action="store_true", help="c5: the opt-in fast componentwise proposal (mcmcx_config::scam_fast); never the default")
     ap.add_argument("--start", default="default", choices=["default", "target"],
                     help="c4: 'target' starts from cmat0 = Sigma, i.e. at RAM's target acceptance rate, where most iterations are "
                          "Cholesky downdates (default: cmat0 = 0.01 I, 86 %% accepted, RAM adapts by updates)")
@@ -533,7 +542,7 @@ def main():
     transport = "one GPU" if world == 1 else ("host transport, ranks share GPU 0" if a.one_gpu_dryrun else "RCCL all-gather + fixed tree")
     res, pooled_vec = run_config(a.workload, a.steps, a.warmup, rank, world, dev, comm, chains_per_gpu=a.chains_per_gpu,
                                  its_per_step=a.its_per_step, method_opt=a.method, pooled=a.pooled, replicas=a.replicas,
-                                 start=a.start, transport=transport)
+                                 start=a.start, transport=transport, scam_fast=a.scam_fast)
     if rank == 0:
         cpu_args = res.pop("_cpu")
         line = {

@@ -61,6 +61,11 @@ typedef struct mcmcx_config {
     int32_t device;        /* HIP device ordinal */
     int32_t pooled;        /* 1: one proposal factor shared by all chains, adapted from the pooled empirical
                             * covariance of the current states (multi-chain extension; 0 = the reference's per-chain AM) */
+    int32_t scam_fast;     /* method = 'scam' only, opt-in (default 0 = the reference's operations): the componentwise proposal
+                            * newpar = U (U'oldpar + delta e_j) (MCMC_run_scam.F90:106-115: two dgemv) is formed as
+                            * newpar = oldpar + delta U(:,j) -- the same point up to the rounding of U U' = I, one column
+                            * of the rotation instead of two passes over it.  Accept sequences and states agree with the
+                            * reference-order form to rounding level, not bit for bit (tests/test_gpu_scam_fast.py). */
 } mcmcx_config;
 
 typedef struct mcmcx_engine *mcmcx_handle;

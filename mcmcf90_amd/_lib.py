@@ -21,7 +21,7 @@ class Config(C.Structure):
                [(n, C.c_double) for n in
                 ("scalelimit", "scalefactor", "drscale", "N0", "S02", "condmax", "alphatarget", "nuparam")] + \
                [("seed", C.c_uint32), ("chain_id0", C.c_uint32), ("record_accept", C.c_int32),
-                ("record_chain", C.c_int32), ("device", C.c_int32), ("pooled", C.c_int32)]
+                ("record_chain", C.c_int32), ("device", C.c_int32), ("pooled", C.c_int32), ("scam_fast", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/mcmcx.h declares

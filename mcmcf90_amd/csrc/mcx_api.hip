@@ -346,6 +346,16 @@ static void launch_scam(mcmcx_engine *h, int it0, int it1)
                            h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedU, h->d_sharedU + st, h->d_sharedU + 2 * st);
         return;
     }
+    // opt-in fast proposals with the Gaussian target: the workgroup-per-tile kernel of the pooled mode with each chain's own
+    // rotation column (g_U = nullptr) -- the target's d x d product on the matrix cores instead of lane by lane
+    if (h->cfg.scam_fast && h->tkind == TGT_GAUSS && !h->has_lo && !h->has_hi && !h->has_pri && scam_pooled_lds(h->d) <= 160 * 1024 &&
+        !(getenv("MCMCX_SCAM_FAST_LANES") && atoi(getenv("MCMCX_SCAM_FAST_LANES")))) {
+        const int nt = (h->d + 15) / 16;
+        const int nwp = 4 + std::min(12, nt & ~3);
+        hipLaunchKernelGGL(scam_pooled_kernel, dim3(h->ntiles), dim3(64 * nwp), scam_pooled_lds(h->d), h->stream, h->E, it0, it1,
+                           h->E.tgt.mu, h->E.tgt.lamT, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr);
+        return;
+    }
     // few tiles: several waves per tile (scam_mw_kernel), so that a sub-step is not bound by the latency of one wave's loads
     // while most of the chip idles -- as many waves as keep the chip's ~2048 resident-wave slots busy, at most 8 (sixteen
     // waves of 128 registers spill the products' panels)
@@ -938,7 +948,7 @@ void mcmcx_config_defaults(mcmcx_config *c)                      // mcmcinit.F90
     c->adaptint = 100; c->adapthist = 0; c->adaptend = 0; c->initcmatn = 0;
     c->N0 = 1.0; c->S02 = 0.0; c->updatesigma = 1; c->condmax = 0.0;
     c->alphatarget = 0.234; c->nuparam = 0.7;
-    c->seed = MCMCX_DEFAULT_SEED; c->chain_id0 = 0; c->record_accept = 0; c->record_chain = 0; c->device = 0;
+    c->seed = MCMCX_DEFAULT_SEED; c->chain_id0 = 0; c->record_accept = 0; c->record_chain = 0; c->device = 0; c->scam_fast = 0;
 }
 
 int mcmcx_create(const mcmcx_config *cfg_in, mcmcx_handle *out)
@@ -963,6 +973,7 @@ int mcmcx_create(const mcmcx_config *cfg_in, mcmcx_handle *out)
         c.doburnin = 0; c.drscale = 0.0;
     }
     if (c.method == MCMCX_METHOD_RAM) c.drscale = 0.0;
+    if (c.method != MCMCX_METHOD_SCAM) c.scam_fast = 0;
     if (c.nsimu < 1) return fail(-4, "nsimu <= 0 stopping");                         // mcmc_main.F90:22-25
     if (c.npar < 1 || c.npar > MCX_MAX_NPAR) return fail(-5, "npar must be in 1.." + std::to_string(MCX_MAX_NPAR));
     if (c.nchains < 1) return fail(-5, "nchains must be >= 1");
@@ -1166,6 +1177,7 @@ int mcmcx_init(mcmcx_handle h)
     E.d = d; E.P = P; E.ntiles = T;
     E.method = (c.method == MCMCX_METHOD_RAM && !h->pooled) ? M_RAM : (c.method == MCMCX_METHOD_ER ? M_ER : M_DRAM);   // pooled RAM adapts on the host side: the kernels see a plain Metropolis step
     E.usesvd = h->usesvd; E.doscam = (c.method == MCMCX_METHOD_SCAM) ? 1 : 0; E.condmax = c.condmax;
+    E.scam_fast = c.scam_fast ? 1 : 0;
     E.Rf = E.R2f = E.qstd = E.Gw = E.Vw = nullptr;
     E.greedy = c.greedy; E.adapthist = c.adapthist; E.initcmatn = (double)c.initcmatn;
     E.dodr = h->dodr; E.updatesigma = c.updatesigma; E.doadapt = c.doadapt; E.doburnin = c.doburnin; E.burnintime = c.burnintime;

@@ -73,6 +73,7 @@ struct EngineDev {
     const double *sharedR;      // pooled mode: the one packed factor all chains propose with
     // SVD paths (condmax > 0 / method='scam'): full column-major d x d factors per chain, element (i,j) at j*d+i
     int usesvd, doscam; double condmax;
+    int scam_fast;                  // opt-in: componentwise proposals as theta + delta U(:,j) (mcmcx_config::scam_fast)
     double *Rf, *R2f, *qstd, *Gw, *Vw;
     // host-callback targets: per-chain evaluation results (inbounds, prior, ss) and state carried between phases
     double *hev, *hx;
@@ -1681,6 +1682,19 @@ MCX_DEV void lane_store(const EngineDev &E, int tile, int lane, const LaneState 
     TIDX(E.ictr, tile, NICTR, I_PDESC, lane) = L.pdesc;
 }
 
+// scam_fast: newpar_k = oldpar_k + delta U(k,j), elements k0, k0 + kstep, ... (one fma each; U column-major per chain)
+MCX_DEV void scam_fast_propose(const double *Ut, const double *theta_t, double *cand_t, int lane, int d, int j, double delta, int p0 = 0, int pstep = 1)
+{
+    const double *col = Ut + (size_t)j * d * 64;
+    for (int K0 = p0 * PW; K0 < d; K0 += pstep * PW) {
+        double u[PW], th[PW];
+#pragma unroll
+        for (int q = 0; q < PW; ++q) { const int k = K0 + q < d ? K0 + q : d - 1; u[q] = LDNT(col, k); th[q] = GV(theta_t, k); }
+#pragma unroll
+        for (int q = 0; q < PW; ++q) if (K0 + q < d) GV(cand_t, K0 + q) = dfma(delta, u[q], th[q]);
+    }
+}
+
 // ---------------------------------------------------------------- MCMC_run_scam (MCMC_run_scam.F90:38-88)
 // One outer iteration = d componentwise Metropolis sub-steps in the rotated basis: rot = U'theta (dgemv 'T'),
 // rot_j += N(0,1) std_j, theta' = U rot (dgemv 'N'), full ss evaluation, alpha, reject (MCMC_propose_sc :94-117).
@@ -1702,10 +1716,15 @@ __global__ __launch_bounds__(64, MCX_SCAM_WAVES) void scam_kernel(EngineDev E, i
     for (int it = it0; it <= it1; ++it) {
         bool rejall = true;
         for (int j = 0; j < d; ++j) {
-            gemvT_panels<true>(Ut, theta_t, rot_t, lane, d);
-            const double zj = rng_normal(L.g) * GV(std_t, j);
-            GV(rot_t, j) = GV(rot_t, j) + zj;
-            gemvN_panels<true>(Ut, rot_t, cand_t, nullptr, lane, d, true);
+            if (E.scam_fast) {
+                const double zj = rng_normal(L.g) * GV(std_t, j);
+                scam_fast_propose(Ut, theta_t, cand_t, lane, d, j, zj);
+            } else {
+                gemvT_panels<true>(Ut, theta_t, rot_t, lane, d);
+                const double zj = rng_normal(L.g) * GV(std_t, j);
+                GV(rot_t, j) = GV(rot_t, j) + zj;
+                gemvN_panels<true>(Ut, rot_t, cand_t, nullptr, lane, d, true);
+            }
             bool inb = target_inbounds(E.tgt, d, lane, cand_t);
             double pri2 = target_prior(E.tgt, d, lane, cand_t);
             double ss2 = target_ss<false>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
@@ -1772,11 +1791,16 @@ __global__ __launch_bounds__(64 * NW) void scam_mw_kernel(EngineDev E, int it0, 
         bool rejall = true;
         for (int j = 0; j < d; ++j) {
             if (w == 0) zl[lane] = rng_normal(L.g) * GV(std_t, j);           // the sub-step's first draw (MCMC_run_scam.F90:108)
-            gemvT_panels<true, (NW >= 8 ? 2 : 0)>(Ut, theta_t, rot_t, lane, d, w, NW);      // many waves: fewer rows in flight each (registers)
-            __syncthreads();
-            if (w == (j / PW) % NW) GV(rot_t, j) = GV(rot_t, j) + zl[lane];  // by the wave that wrote rot_j
-            __syncthreads();
-            gemvN_panels<true, (NW >= 8 ? 2 : 0)>(Ut, rot_t, cand_t, nullptr, lane, d, true, w, NW);
+            if (E.scam_fast) {
+                __syncthreads();
+                scam_fast_propose(Ut, theta_t, cand_t, lane, d, j, zl[lane], w, NW);
+            } else {
+                gemvT_panels<true, (NW >= 8 ? 2 : 0)>(Ut, theta_t, rot_t, lane, d, w, NW);      // many waves: fewer rows in flight each (registers)
+                __syncthreads();
+                if (w == (j / PW) % NW) GV(rot_t, j) = GV(rot_t, j) + zl[lane];  // by the wave that wrote rot_j
+                __syncthreads();
+                gemvN_panels<true, (NW >= 8 ? 2 : 0)>(Ut, rot_t, cand_t, nullptr, lane, d, true, w, NW);
+            }
             __syncthreads();
             if (gauss) {
                 for (int b = w; b < nblk; b += NW) {
@@ -1961,6 +1985,28 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
     for (int it = it0; it <= it1; ++it) {
         bool rejall = true;
         for (int j = 0; j < d; ++j) {
+          if (E.scam_fast) {
+            // opt-in (mcmcx_config::scam_fast): theta' = theta + delta U(:,j) from the registers -- no rotation products at all
+            // (g_U == nullptr: per-chain rotations -- the column comes from the chain's own factor, the target still runs on the
+            //  matrix cores: what the lane-per-chain kernels cannot do for it, they re-read the candidate once per 8 rows)
+            const bool pc = (g_U == nullptr);
+            if (sc) zb[lane] = rng_normal(L.g) * (pc ? TIDX(E.qstd, tile, d, j, lane) : g_std[j]);
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (s < nsl) {
+                    const double zj = zb[ECH(s)];
+                    double uc[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int o = EROW(s, r) < d ? EROW(s, r) : 0;
+                        uc[r] = pc ? __builtin_nontemporal_load(&E.Rf[((size_t)tile * d * d + (size_t)j * d + o) * 64 + ECH(s)]) : g_U[(size_t)j * d + o];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cand[s][r] = EROW(s, r) < d ? dfma(zj, uc[r], th[s][r]) : 0.0;
+                }
+            }
+          } else {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {                                       // X = theta
                 if (s < nsl) {
@@ -1996,6 +2042,7 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
             PH(9)
             mfma_slots<BW, NS>(g_U, X, lane, d, d4, blk0, grp, cand);          // theta' = U rot
             PH(2)
+          }
             if (cand_global) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
@@ -2444,10 +2491,15 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
         double *rot_t = c2_t;
         const double *Ut = E.Rf + (size_t)tile * d * d * 64;
         if (j == 0) GV(hx, HX_MOVED) = 0.0;
-        gemvT_panels(Ut, theta_t, rot_t, lane, d);
-        const double zj = rng_normal(L.g) * TIDX(E.qstd, tile, d, j, lane);
-        GV(rot_t, j) = GV(rot_t, j) + zj;
-        gemvN_panels(Ut, rot_t, cand_t, nullptr, lane, d, true);
+        if (E.scam_fast) {
+            const double zj = rng_normal(L.g) * TIDX(E.qstd, tile, d, j, lane);
+            scam_fast_propose(Ut, theta_t, cand_t, lane, d, j, zj);
+        } else {
+            gemvT_panels(Ut, theta_t, rot_t, lane, d);
+            const double zj = rng_normal(L.g) * TIDX(E.qstd, tile, d, j, lane);
+            GV(rot_t, j) = GV(rot_t, j) + zj;
+            gemvN_panels(Ut, rot_t, cand_t, nullptr, lane, d, true);
+        }
     } else if (PHASE == 6) {                                      // SCAM sub-step: decide with the host's bounds / prior / ss
         const bool inb = GV(hev, HE_INB) != 0.0;
         const double pri2 = GV(hev, HE_PRI), ss2 = GV(hev, HE_SS);

@@ -64,6 +64,7 @@ module mcmcmod
   character(len=256), save :: datafile = 'data.dat', lowerfile = '', upperfile = ''
   integer, save :: ngpus = 1                           ! GPUs of this node: nchains/ngpus chains each, one RCCL communicator
   integer, save :: usecomm = 0                         ! 1: form the RCCL communicator for ngpus = 1 too (the N-GPU code path on one GPU)
+  integer, save :: scamfast = 0                        ! 1 (method = 'scam'): componentwise proposals as oldpar + delta U(:,j) (include/mcmcx.h: scam_fast)
   !! the user's own functions faster than one host call per chain:
   !!   hostbatch = 1: ssfunction_batch(theta(npar,n), npar, n, ny, ss(ny,n)) once per stage (default member: a loop over
   !!                  ssfunction), from hostthreads threads on disjoint column blocks when hostthreads > 1
@@ -72,7 +73,7 @@ module mcmcmod
   integer, save :: hostbatch = 0, hostthreads = 1
   character(len=256), save :: modulefile = '', modulekernel = 'user_target', moduledatafile = ''
   namelist /mcmcx/ devtarget, nchains, seed, pooled, banana_b, mufile, lamfile, datafile, lowerfile, upperfile, ngpus, &
-       hostbatch, hostthreads, modulefile, modulekernel, moduledatafile, usecomm
+       hostbatch, hostthreads, modulefile, modulekernel, moduledatafile, usecomm, scamfast
 
   !! public state, mcmc.F90:28-52
   integer, save :: npar = 0, nycol = 1, simuind = 0, chainind = 0, MCMC_running = 0
@@ -108,7 +109,7 @@ module mcmcmod
      integer(c_int32_t) :: doadapt, doburnin, adaptint, adapthist, badaptint, adaptend, initcmatn
      integer(c_int32_t) :: burnintime, greedy, updatesigma
      real(c_double) :: scalelimit, scalefactor, drscale, N0, S02, condmax, alphatarget, nuparam
-     integer(c_int32_t) :: seed, chain_id0, record_accept, record_chain, device, pooled
+     integer(c_int32_t) :: seed, chain_id0, record_accept, record_chain, device, pooled, scam_fast
   end type mcmcx_config
 
   interface
@@ -775,7 +776,7 @@ contains
     cfg%burnintime = burnintime; cfg%greedy = greedy; cfg%updatesigma = updatesigma
     cfg%scalelimit = scalelimit; cfg%scalefactor = scalefactor; cfg%drscale = drscale
     cfg%N0 = N0; cfg%S02 = S02; cfg%condmax = condmax; cfg%alphatarget = alphatarget; cfg%nuparam = nuparam
-    cfg%seed = seed; cfg%record_accept = 0; cfg%pooled = pooled
+    cfg%seed = seed; cfg%record_accept = 0; cfg%pooled = pooled; cfg%scam_fast = scamfast
     allocate(nob(nycol)); nob = nobs                    ! nycol response columns: one sigma2 / nobs each (host callbacks when > 1)
     if (trim(devtarget) == 'gauss') then
        do i = 1, npar                                  ! row-major lam(i,j) for the C side
