@@ -830,7 +830,13 @@ MCX_DEV void gemvN_shared(const double *__restrict__ M, const double *z_t, doubl
 // more for its downdate lanes.  Returns true for lanes whose P_t is valid.
 // Rotations (c_i, s_i) of the first NLC rows are kept in LDS (lc), the rest in global scratch: row i's rotation is
 // re-read by every later panel, and the early rows are the ones re-read most often.
-constexpr int NLC = 19;     // 19 rows x 2 doubles x 64 lanes = 19 456 B per wave: 8 waves fill the CU's 160 KiB
+#ifndef MCX_NLC
+#define MCX_NLC 19
+#endif
+#ifndef MCX_RAM_WAVES
+#define MCX_RAM_WAVES 2
+#endif
+constexpr int NLC = MCX_NLC;     // 19 rows x 2 doubles x 64 lanes = 19 456 B per wave: 8 waves fill the CU's 160 KiB
 // MIXED: the wave holds update AND downdate lanes (RAM near its target acceptance rate).  Stores that cover part of a
 // 512-byte row segment are slow whichever lanes they are (tools/layout_probe2.hip: read all + write 22 % of the lanes
 // takes longer than read all + write all), so in such a wave every lane stores in both sweeps -- the lanes a sweep does
@@ -1610,7 +1616,7 @@ __global__ __launch_bounds__(64, 2) void step_kernel_dr_big(EngineDev E, int it0
 #define MCX_AM_WIDE true
 #endif
 template <bool RAM, bool DR, bool POOLED>
-__global__ __launch_bounds__(64, (RAM || DR || POOLED) ? 2 : MCX_AM_WAVES) void step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
+__global__ __launch_bounds__(64, RAM ? MCX_RAM_WAVES : (DR || POOLED) ? 2 : MCX_AM_WAVES) void step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
                                                      const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
                                                      const double *__restrict__ g_sharedR)
 { step_body<RAM, DR, POOLED, (RAM || (!DR && !POOLED && MCX_AM_WIDE))>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }

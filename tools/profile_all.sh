@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/profile_all.sh -- run on the GPU box from the repo root: every bench configuration through tools/profile_round.sh
 # (kernel trace + separate PMC passes), summaries under gpurun_out/prof/<tag>/; then
-#   python tools/install_profiles.py rNN_x c4_ram c4_ram_target c2_dram c3_dram c4_dram c4_pooled c5_pooled
+#   python tools/install_profiles.py rNN_x c4_ram c4_ram_target c2_dram c3_dram c4_dram c4_pooled c5_pooled c5_pooled_fast
 cd $GRAFT_REPO_ROOT
 bash tools/profile_round.sh c4_ram > /dev/null 2>&1;                         echo c4_ram done
 bash tools/profile_round.sh c4_ram_target --start target > /dev/null 2>&1;   echo c4_ram_target done
@@ -10,7 +10,8 @@ bash tools/profile_round.sh c3_dram --workload c3 > /dev/null 2>&1;          ech
 bash tools/profile_round.sh c4_dram --method dram > /dev/null 2>&1;          echo c4_dram done
 bash tools/profile_round.sh c4_pooled --pooled > /dev/null 2>&1;             echo c4_pooled done
 bash tools/profile_round.sh c5_pooled --workload c5 > /dev/null 2>&1;        echo c5_pooled done
-for t in c4_ram c4_ram_target c2_dram c3_dram c4_dram c4_pooled c5_pooled; do
+bash tools/profile_round.sh c5_pooled_fast --workload c5 --scam-fast > /dev/null 2>&1;   echo c5_pooled_fast done
+for t in c4_ram c4_ram_target c2_dram c3_dram c4_dram c4_pooled c5_pooled c5_pooled_fast; do
   python3 - <<PY
 import json
 j = json.load(open("gpurun_out/prof/$t/summary.json"))
