@@ -379,6 +379,7 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
     dt, kms = float(red[0][0]), float(red[0][1])                                    # slowest rank
     tries, stayed_all, downs_all = (float(x) for x in red[1])
     pooled_vec = eng.allreduce_moments(fetch=True)                                  # collective: every rank
+    kname = eng.last_kernel()
     eng.close()
     if rank != 0:
         return None, pooled_vec
@@ -400,7 +401,7 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
         roof = {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TF,
                 "traffic": pmc["hbm_bytes_per_proposal"] * per_launch_prop if pmc and "hbm_bytes_per_proposal" in pmc else None,
-                "kernel": "mcx::scam_pooled_kernel", "alg_flop_per_proposal": flop}
+                "kernel": "mcx::" + (kname or "scam_pooled_kernel"), "alg_flop_per_proposal": flop}
     else:
         down_frac = downs_all / (float(world) * n_local * its_all) if method == "ram" else 0.0
         balg = alg_bytes_per_proposal(d, "pooled" if pooled else method, down_frac)
@@ -410,7 +411,7 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc["hbm_bytes_per_proposal"] * per_launch_prop if pmc and "hbm_bytes_per_proposal" in pmc else None,
-                "kernel": "mcx::scam_kernel" if method == "scam" else ("mcx::pooled_mfma_kernel" if pooled else "mcx::step_kernel"),
+                "kernel": "mcx::" + (kname or "step_kernel"),        # as the engine names the kernel it launched
                 "alg_bytes_per_proposal": balg}
         if method == "ram":
             roof["downdate_fraction"] = down_frac

@@ -38,6 +38,7 @@ struct mcmcx_engine {
     int dodr = 0, usesvd = 0;
     bool inited = false;
     int simuind = 0;
+    const char *last_kernel = "";       // name of the sampling kernel launch_step / launch_scam chose last (mcmcx_last_kernel)
     // host copies of the problem
     std::vector<double> par0, cmat0;                 // cmat0 col-major d*d
     double sigma2 = 1.0; int nobs = 1; bool sigma2ok = false;
@@ -272,23 +273,25 @@ static bool dr_fits_lds(const mcmcx_engine *h) { return lds_bytes(h) <= 160 * 10
 static size_t lds_step(const mcmcx_engine *h) { return (h->dodr && dr_fits_lds(h)) ? lds_bytes(h) : 0; }
 static void launch_init(mcmcx_engine *h)
 { hipLaunchKernelGGL(init_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E); }
+// the sampling kernels go through LAUNCHK, which notes the kernel's name for mcmcx_last_kernel (bench.py labels its roofline with it)
+#define LAUNCHK(k, ...) do { h->last_kernel = #k; hipLaunchKernelGGL(k, __VA_ARGS__); } while (0)
 static void launch_step(mcmcx_engine *h, int it0, int it1)
 {
     const dim3 g(h->ntiles), b(64);
     const double *rs = h->d_ramscale + it0;
-    if (pooled_use_mfma(h)) hipLaunchKernelGGL(pooled_mfma_kernel, g, b, pooled_mfma_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedRT);
-    else if (h->pooled && h->dodr) hipLaunchKernelGGL(step_kernel_pooled_dr, g, b, lds_step(h), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR, h->d_sharedR2, h->d_sharediC);
-    else if (h->pooled) hipLaunchKernelGGL((step_kernel<false, false, true>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
-    else if (h->E.method == M_RAM && h->usesvd) hipLaunchKernelGGL(step_kernel_ram_fullr, g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
-    else if (h->E.method == M_RAM) hipLaunchKernelGGL((step_kernel<true, false, false>), g, b, (size_t)NLC * 2 * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
+    if (pooled_use_mfma(h)) LAUNCHK(pooled_mfma_kernel, g, b, pooled_mfma_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedRT);
+    else if (h->pooled && h->dodr) LAUNCHK(step_kernel_pooled_dr, g, b, lds_step(h), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR, h->d_sharedR2, h->d_sharediC);
+    else if (h->pooled) LAUNCHK((step_kernel<false, false, true>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
+    else if (h->E.method == M_RAM && h->usesvd) LAUNCHK(step_kernel_ram_fullr, g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
+    else if (h->E.method == M_RAM) LAUNCHK((step_kernel<true, false, false>), g, b, (size_t)NLC * 2 * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->dodr && !dr_fits_lds(h))                  // npar > 160: the second stage's two vectors in global scratch
-        hipLaunchKernelGGL(step_kernel_dr_big, g, b, 0, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
+        LAUNCHK(step_kernel_dr_big, g, b, 0, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
     else if (h->dodr && !(getenv("MCMCX_DR_GENERAL") && atoi(getenv("MCMCX_DR_GENERAL"))))      // (A/B switch for tests: step_body<DR>)
-        hipLaunchKernelGGL(step_kernel_dr, g, b, lds_step(h), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
-    else if (h->dodr) hipLaunchKernelGGL((step_kernel<false, true, false>), g, b, lds_step(h), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
-    else if (h->E.lds_scratch == 2) hipLaunchKernelGGL(step_kernel_ldsr, g, b, (size_t)(2 * h->d + h->P) * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
-    else if (h->E.lds_scratch) hipLaunchKernelGGL(step_kernel_ldsv, g, b, (size_t)4 * h->d * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
-    else hipLaunchKernelGGL((step_kernel<false, false, false>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
+        LAUNCHK(step_kernel_dr, g, b, lds_step(h), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
+    else if (h->dodr) LAUNCHK((step_kernel<false, true, false>), g, b, lds_step(h), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
+    else if (h->E.lds_scratch == 2) LAUNCHK(step_kernel_ldsr, g, b, (size_t)(2 * h->d + h->P) * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
+    else if (h->E.lds_scratch) LAUNCHK(step_kernel_ldsv, g, b, (size_t)4 * h->d * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
+    else LAUNCHK((step_kernel<false, false, false>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
 }
 // every chain's copy of a K-vector, filled on the device
 static int dev_bcast(mcmcx_engine *h, double *dst, const std::vector<double> &v)
@@ -342,7 +345,7 @@ static void launch_scam(mcmcx_engine *h, int it0, int it1)
         const size_t st = shared_u_stride(h);
         const int nt = (h->d + 15) / 16;                   // 16-row output blocks: min(12, 4*(nt/4)) block waves + 4 chain-group waves
         const int nw = 4 + std::min(12, nt & ~3);
-        hipLaunchKernelGGL(scam_pooled_kernel, dim3(h->ntiles), dim3(64 * nw), scam_pooled_lds(h->d), h->stream, h->E, it0, it1,
+        LAUNCHK(scam_pooled_kernel, dim3(h->ntiles), dim3(64 * nw), scam_pooled_lds(h->d), h->stream, h->E, it0, it1,
                            h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedU, h->d_sharedU + st, h->d_sharedU + 2 * st);
         return;
     }
@@ -352,7 +355,7 @@ static void launch_scam(mcmcx_engine *h, int it0, int it1)
         !(getenv("MCMCX_SCAM_FAST_LANES") && atoi(getenv("MCMCX_SCAM_FAST_LANES")))) {
         const int nt = (h->d + 15) / 16;
         const int nwp = 4 + std::min(12, nt & ~3);
-        hipLaunchKernelGGL(scam_pooled_kernel, dim3(h->ntiles), dim3(64 * nwp), scam_pooled_lds(h->d), h->stream, h->E, it0, it1,
+        LAUNCHK(scam_pooled_kernel, dim3(h->ntiles), dim3(64 * nwp), scam_pooled_lds(h->d), h->stream, h->E, it0, it1,
                            h->E.tgt.mu, h->E.tgt.lamT, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr);
         return;
     }
@@ -365,10 +368,10 @@ static void launch_scam(mcmcx_engine *h, int it0, int it1)
     const size_t lds = (size_t)(4 * ((h->d + 15) / 16) + 2) * 64 * sizeof(double);
     const dim3 g(h->ntiles);
     switch (nw) {
-    case 8: hipLaunchKernelGGL(scam_mw_kernel<8>, g, dim3(512), lds, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT); break;
-    case 4: hipLaunchKernelGGL(scam_mw_kernel<4>, g, dim3(256), lds, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT); break;
-    case 2: hipLaunchKernelGGL(scam_mw_kernel<2>, g, dim3(128), lds, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT); break;
-    default: hipLaunchKernelGGL(scam_kernel, g, dim3(64), 0, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
+    case 8: LAUNCHK(scam_mw_kernel<8>, g, dim3(512), lds, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT); break;
+    case 4: LAUNCHK(scam_mw_kernel<4>, g, dim3(256), lds, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT); break;
+    case 2: LAUNCHK(scam_mw_kernel<2>, g, dim3(128), lds, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT); break;
+    default: LAUNCHK(scam_kernel, g, dim3(64), 0, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
     }
 }
 // LDS of svd_blocked_kernel for block width b: four blocks of b columns (odd stride) + the rotation slots
@@ -389,7 +392,7 @@ static bool svd_blocked(const mcmcx_engine *h)
 }
 static void launch_adapt(mcmcx_engine *h, int it, int mode)
 {
-    const size_t lds = std::max(lds_bytes(h) / 2, (size_t)44 * 64 * sizeof(double));    // one d-vector / the Cholesky's diagonal block
+    const size_t lds = std::max(lds_bytes(h) / 2, (size_t)36 * 64 * sizeof(double));    // one d-vector / the Cholesky's diagonal block (18 kB: eight waves per CU up to npar 36)
     const int nb = (h->d + 7) / 8, nblk = nb * (nb + 1) / 2;
     hipLaunchKernelGGL(adapt_pre_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it, mode);
     if (!((mode & AD_AM) && h->cfg.adapthist > 1)) {                      // the AP window is a batch recompute: no blocked update
@@ -404,7 +407,8 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
             hipLaunchKernelGGL(adapt_cov_kernel, dim3((unsigned)(8 * ((h->ntiles + 7) / 8) * nblk)), dim3(64), 0, h->stream, h->E, it, mode, nblk);
     }
     if (!h->d_Gc) {
-        hipLaunchKernelGGL(adapt_post_kernel, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr);
+        if (h->usesvd) hipLaunchKernelGGL(adapt_post_kernel<true>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr);
+        else hipLaunchKernelGGL(adapt_post_kernel<false>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr);
         return;
     }
     // large npar with an SVD factor: the factorisation runs one workgroup per chain on chain-major copies, one launch
@@ -412,7 +416,7 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
     const size_t DD = (size_t)h->d * h->d;
     const dim3 tg((unsigned)((DD + 63) / 64), (unsigned)h->ntiles), tg1((unsigned)((h->d + 63) / 64), (unsigned)h->ntiles);
     const size_t lsv = svd_lds(h->d, h->svd_b);
-    hipLaunchKernelGGL(adapt_post_kernel, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 1, h->d_need);
+    hipLaunchKernelGGL(adapt_post_kernel<true>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 1, h->d_need);
     hipLaunchKernelGGL(tile2chain_kernel, tg, dim3(256), 0, h->stream, h->E.Gw, h->d_Gc, DD, DD, h->d_need);
     hipLaunchKernelGGL(svd_init_kernel, dim3(h->nlanes), dim3(256), 0, h->stream, h->d_Vc, h->d_state, h->d_need, h->nlanes, h->d);
     for (int sweep = 0; sweep < 60; ++sweep) {
@@ -426,7 +430,7 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
     hipLaunchKernelGGL(svd_finish_kernel, dim3(h->nlanes), dim3(256), 0, h->stream, h->d_Gc, h->d_Vc, h->d_svc, h->d_state, h->nlanes, h->d);
     hipLaunchKernelGGL(chain2tile_kernel, tg, dim3(256), 0, h->stream, h->d_Gc, h->E.Vw, DD, DD, h->d_need);
     hipLaunchKernelGGL(chain2tile_kernel, tg1, dim3(256), 0, h->stream, h->d_svc, h->E.cs, (size_t)h->d, (size_t)2 * h->d, h->d_need);
-    hipLaunchKernelGGL(adapt_post_kernel, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 2, h->d_need);
+    hipLaunchKernelGGL(adapt_post_kernel<true>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 2, h->d_need);
 }
 
 // Which branch of MCMC_adapt fires at iteration `it` (0 = none).  MCMC_adapt.F90:42-46, 60-61, 105.
@@ -938,6 +942,8 @@ int mcmcx_device_info(int32_t device, char *buf, int32_t len)
     snprintf(buf, (size_t)len, "%s %s, pci %s, %d CUs, %.0f GiB", prop.name, prop.gcnArchName, bus, prop.multiProcessorCount, (double)prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
     return 0;
 }
+
+const char *mcmcx_last_kernel(const mcmcx_engine *h) { return h ? h->last_kernel : ""; }
 
 void mcmcx_config_defaults(mcmcx_config *c)                      // mcmcinit.F90:184-230
 {

@@ -2735,9 +2735,9 @@ enum { AD_BURN = 1, AD_AM = 2, AD_FIRST = 4 };
 // while the finished rows i < J0 stream by once per block (16 loads per 64 fma instead of 1 per fma), then the rows
 // of the block row itself are folded in -- from registers on the diagonal block, whose finished rows and 1/R(j,j) are
 // parked in LDS for the blocks to its right.  At: cmat (read), Tt: the factor (written, and read back as rows i < J0),
-// Rt: scaled copy on success.  X: 44 LDS vectors.  Returns LAPACK's info (0, or j+1 at the first non-positive pivot).
+// Rt: scaled copy on success.  X: 36 LDS vectors.  Returns LAPACK's info (0, or j+1 at the first non-positive pivot).
 constexpr int BT = 8;
-#define MCX_DLI(a, b) ((a) * (17 - (a)) / 2 + ((b) - (a)))
+#define MCX_DLI(a, b) ((a) * (15 - (a)) / 2 + ((b) - (a) - 1))   // strictly upper part of the 8 x 8 diagonal block, by rows: 28 entries
 MCX_DEV int calculate_R(const double *At, double *Tt, double *Rt, int lane, int d, int P, bool act, double *X)
 {
     int info = 0;
@@ -2786,9 +2786,9 @@ MCX_DEV int calculate_R(const double *At, double *Tt, double *Rt, int lane, int 
                         for (int b = a + 1; b < BT; ++b) T[a][b] = (av[b] - T[a][b]) * rinv;
 #pragma unroll
                         for (int b = a; b < BT; ++b) {
-                            if (b < nc) { GV(trow, K0 + b - j) = T[a][b]; X[MCX_DLI(a, b) * 64 + lane] = T[a][b]; }
+                            if (b < nc) { GV(trow, K0 + b - j) = T[a][b]; if (b > a) X[MCX_DLI(a, b) * 64 + lane] = T[a][b]; }
                         }
-                        X[(36 + a) * 64 + lane] = rinv;
+                        X[(28 + a) * 64 + lane] = rinv;
                     } else {
 #pragma unroll
                         for (int a2 = 0; a2 < a; ++a2) {
@@ -2796,7 +2796,7 @@ MCX_DEV int calculate_R(const double *At, double *Tt, double *Rt, int lane, int 
 #pragma unroll
                             for (int b = 0; b < BT; ++b) T[a][b] = dfma(dl, T[a2][b], T[a][b]);
                         }
-                        const double rinv = X[(36 + a) * 64 + lane];
+                        const double rinv = X[(28 + a) * 64 + lane];
 #pragma unroll
                         for (int b = 0; b < BT; ++b) {
                             T[a][b] = (av[b] - T[a][b]) * rinv;
@@ -3370,7 +3370,13 @@ __global__ __launch_bounds__(64, 1) void adapt_cov_off_kernel(EngineDev E, int i
 // phase 0: the whole tick.  With the blocked SVD (large npar, below) the tick is cut around the factorisation:
 // phase 1 = everything up to and including the symmetric matrix in Gw (and the per-chain `need` flags),
 // phase 2 = everything after the SVD (which has left the singular vectors in Vw and the singular values in cs).
-__global__ __launch_bounds__(64) void adapt_post_kernel(EngineDev E, int it, int mode, int phase, uint8_t *need)
+// SVD: the instance with the SVD branches of MCMC_calculate_R (condmax > 0, scam); the Cholesky instance keeps to 256 registers
+// (two waves per SIMD: its sweeps wait on loads)
+#ifndef MCX_POST_WAVES
+#define MCX_POST_WAVES 2
+#endif
+template <bool SVD>
+__global__ __launch_bounds__(64, SVD ? 1 : MCX_POST_WAVES) void adapt_post_kernel(EngineDev E, int it, int mode, int phase, uint8_t *need)
 {
     extern __shared__ double X[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d, P = E.P;
@@ -3420,7 +3426,7 @@ __global__ __launch_bounds__(64) void adapt_post_kernel(EngineDev E, int it, int
     TIDX(E.ictr, tile, NICTR, I_WINSTART, lane) = winstart;
     TIDX(E.scal, tile, NSCAL, S_WSUM, lane) = wsum;
     }
-    if (E.usesvd) {
+    if (SVD) {
         // MCMC_calculate_R, SVD branches (MCMC_adapt.F90:189-209): covtor_svd / scam_svd (matutils.F90:378-453, 583-653)
         double *Gt = E.Gw + (size_t)tile * d * d * 64, *Vt = E.Vw + (size_t)tile * d * d * 64;
         double *Rft = E.Rf + (size_t)tile * d * d * 64;

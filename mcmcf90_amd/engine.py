@@ -344,6 +344,10 @@ class Engine:
         q = None if qcovstd is None else _f64(qcovstd)
         self._chk(self.L.mcmcx_debug_set_factor(self.h, a.ctypes.data_as(C.POINTER(C.c_double)), _dp(q)))
 
+    def last_kernel(self):
+        """Name of the sampling kernel the last run() launched (mcmcx_last_kernel)."""
+        return (self.L.mcmcx_last_kernel(self.h) or b"").decode()
+
     def kernel_time(self, reset=False):
         ms, nl, ns = C.c_double(), C.c_int64(), C.c_int64()
         self._chk(self.L.mcmcx_kernel_time(self.h, C.byref(ms), C.byref(nl), C.byref(ns), int(reset)))
