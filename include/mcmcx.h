@@ -77,7 +77,7 @@ const char *mcmcx_last_error(void);
 const char *mcmcx_version(void);
 int32_t mcmcx_device_count(void);                              /* HIP devices visible to this process (0: none -- nothing will run) */
 int mcmcx_device_info(int32_t device, char *buf, int32_t len); /* "name arch, pci bus id, CUs, memory" of one of them (diagnostics) */
-const char *mcmcx_last_kernel(const mcmcx_engine *h);          /* the sampling kernel the last mcmcx_run launched, as spelled in the
+const char *mcmcx_last_kernel(mcmcx_handle h);                /* the sampling kernel the last mcmcx_run launched, as spelled in the
                                                                   source ("step_kernel<true, false, false>", "scam_pooled_kernel", ...);
                                                                   "" before the first run or with host callbacks (diagnostics) */
 

@@ -943,7 +943,7 @@ int mcmcx_device_info(int32_t device, char *buf, int32_t len)
     return 0;
 }
 
-const char *mcmcx_last_kernel(const mcmcx_engine *h) { return h ? h->last_kernel : ""; }
+const char *mcmcx_last_kernel(mcmcx_handle h) { return h ? h->last_kernel : ""; }
 
 void mcmcx_config_defaults(mcmcx_config *c)                      // mcmcinit.F90:184-230
 {
