@@ -375,6 +375,9 @@ MCX_DEV bool target_inbounds(const DevTarget &t, int d, int lane, const double *
     return ok;
 }
 
+#ifndef MCX_POOLED_NB
+#define MCX_POOLED_NB 8      // ... in pooled_mfma_kernel (one wave per SIMD, nothing else to issue while an attempt's chain waits: config 4 pooled 9.25e8 -> 9.65e8 at 8; 1: 9.04, 4: 9.21, 12: 9.55, 16: 8.99)
+#endif
 #ifndef MCX_RNG_NB
 #define MCX_RNG_NB 2      // polar attempts computed side by side in the kernels that wait for the generator (AM, DRAM, pooled); 4 loses at config 2 (d = 10: a vector is ~11 attempts)
 #endif
@@ -833,6 +836,9 @@ MCX_DEV void gemvN_shared(const double *__restrict__ M, const double *z_t, doubl
 #ifndef MCX_NLC
 #define MCX_NLC 19
 #endif
+#ifndef MCX_MIXED_UNROLL
+#define MCX_MIXED_UNROLL 1
+#endif
 #ifndef MCX_RAM_WAVES
 #define MCX_RAM_WAVES 2
 #endif
@@ -872,6 +878,7 @@ if (MIXED) {
                         sn_ = CS_(0, 1);
                         if (up) { cn = CS_(0, 0); zn_ = fuse ? GV(zn_t, 0) : 0.0; }
                     }
+#pragma unroll MCX_MIXED_UNROLL
                     for (int i = 0; i < J0; ++i) {                       // rows above the diagonal block
                         double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
                         double r[RW];
@@ -1063,6 +1070,7 @@ if (MIXED) {
                             for (int u = 0; u < RW; ++u) rn[u] = LDB(sg, u < nw ? u : nw - 1);
                             if (down_ok) { cn = CS_(J0 - 1, 0); sn_ = CS_(J0 - 1, 1); zn_ = fuse ? GV(zn_t, J0 - 1) : 0.0; }
                         }
+#pragma unroll MCX_MIXED_UNROLL
                         for (int i = J0 - 1; i >= 0; --i) {              // rows above, descending
                             double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
                             double r[RW];
@@ -2238,7 +2246,7 @@ __global__ __launch_bounds__(64) void pooled_mfma_kernel(EngineDev E, int it0, i
     mcx_d4 c[4][4];
     for (int it = it0; it <= it1; ++it) {
         // ---- newpar = MCMC_propose(oldpar, R): z straight into the LDS vector, P = R'z on the matrix cores
-        gen_normals<MCX_RNG_NB>(L.g, X, lane, d, true);
+        gen_normals<MCX_POOLED_NB>(L.g, X, lane, d, true);
         if (it == it1) {                                               // the launch's last normals stay readable (pooled RAM statistic)
             double *zk = E.zs + ((size_t)tile * 2 + (it & 1)) * d * 64;
             for (int k = 0; k < d; ++k) GV(zk, k) = XL(k);
