@@ -441,13 +441,23 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
                         "read+write sweep) and downdates it otherwise (two sweeps): DESIGN.md section 10 item 6" % (1.0 - stay, start))
     mode = method + (" pooled (one shared factor)" if pooled else ", per-chain factor") + \
         (", scam_fast = 1 (opt-in: proposals as theta + delta U(:,j), not the reference's operation order)" if (scam_fast and wl == "c5") else "")
+    # what the timed iterations hold besides proposals: the adaptation ticks (every adaptint iterations), the starting regime
+    adaptint = int(ckw.get("adaptint", 100))
+    nticks = sum(1 for it in range(warmup * ips + 1, (warmup + steps) * ips + 1) if it % adaptint == 0) if method != "ram" else 0
+    regime = ""
+    if method != "ram":
+        regime = "; adaptint = %d: %d adaptation tick(s) inside the %d timed iterations" % (adaptint, nticks, steps * ips)
+        if nticks == 0:
+            regime += " (the rate between two adaptations)"
+    elif start == "target":
+        regime = "; cmat0 = the target's covariance: RAM at its target acceptance rate from the start (about half of the lanes downdate)"
     cnt = float(pooled_vec[0])
     mean = pooled_vec[1:1 + d] / cnt
     res = {
         "metric": "MH proposals/sec (whole node), d=50 Gaussian target" if wl == "c4" else "MH proposals/sec (whole node), " + WORKLOADS[wl],
         "value": value, "ms_per_step": dt / steps * 1e3,
-        "config": {"workload": "%s, method=%s, %d chains/GPU, pooled moments of all %d chains combined every %d iterations (%s)"
-                               % (WORKLOADS[wl], mode, n_local, world * n_local, ips, transport),
+        "config": {"workload": "%s, method=%s, %d chains/GPU, pooled moments of all %d chains combined every %d iterations (%s)%s"
+                               % (WORKLOADS[wl], mode, n_local, world * n_local, ips, transport, regime),
                    "chains_per_gpu": n_local, "its_per_step": ips, "npar": d, "method": method,
                    "proposals_per_iteration": per_it + dr_per_it / (float(world) * n_local),
                    "parallelism": "chains sharded over %d GPU(s), one process each" % world},
