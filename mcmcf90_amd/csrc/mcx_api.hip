@@ -943,7 +943,13 @@ int mcmcx_device_info(int32_t device, char *buf, int32_t len)
     return 0;
 }
 
-const char *mcmcx_last_kernel(mcmcx_handle h) { return h ? h->last_kernel : ""; }
+const char *mcmcx_last_kernel(mcmcx_handle h)
+{
+    static thread_local std::string name;
+    name = h ? h->last_kernel : "";
+    if (name.size() >= 2 && name.front() == '(' && name.back() == ')') name = name.substr(1, name.size() - 2);   // template instances are launched as (k<...>)
+    return name.c_str();
+}
 
 void mcmcx_config_defaults(mcmcx_config *c)                      // mcmcinit.F90:184-230
 {
