@@ -470,10 +470,10 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
 
 # the other BASELINE configurations, run briefly after the headline in the same process (N = 1): (key, run_config arguments)
 OTHER_CONFIGS = [
-    ("c2", dict(wl="c2", steps=3, warmup=1)),
+    ("c2", dict(wl="c2", steps=10, warmup=2)),                      # 1.7 ms per step: ten of them
     ("c3", dict(wl="c3", steps=3, warmup=1)),
     ("c4_target", dict(wl="c4", steps=3, warmup=1, start="target")),
-    ("c4_pooled", dict(wl="c4", steps=3, warmup=1, pooled=True)),
+    ("c4_pooled", dict(wl="c4", steps=6, warmup=1, pooled=True)),
     ("c5_pooled", dict(wl="c5", steps=2, warmup=1)),
     ("c5_pooled_scam_fast", dict(wl="c5", steps=2, warmup=1, scam_fast=True)),        # opt-in variants, labelled as such in `workload`
     ("c5_replicas_scam_fast", dict(wl="c5", steps=2, warmup=1, replicas=True, scam_fast=True)),
