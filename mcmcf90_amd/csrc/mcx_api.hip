@@ -395,6 +395,18 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
     const size_t lds = std::max(lds_bytes(h) / 2, (size_t)36 * 64 * sizeof(double));    // one d-vector / the Cholesky's diagonal block (18 kB: eight waves per CU up to npar 36)
     const int nb = (h->d + 7) / 8, nblk = nb * (nb + 1) / 2;
     hipLaunchKernelGGL(adapt_pre_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it, mode);
+    // covmat's batch branch in blocks (adapt_covb_*): the AP window at every adaptation; with initcmatn = 0 the first AM adaptation and
+    // the greedy restarts.  Which lanes take it is the lanes' own business (ADF_BATCH); a tick that cannot hold any skips the launches.
+    const bool td = !(getenv("MCMCX_COV_TD") && atoi(getenv("MCMCX_COV_TD")) == 0);
+    const bool ap = (mode & AD_AM) && h->cfg.adapthist > 1;
+    const int batch_done = (td && !(getenv("MCMCX_COV_BATCH_ROWS") && atoi(getenv("MCMCX_COV_BATCH_ROWS"))) &&      // (A/B switch for tests: covmat_rows)
+                            (ap || (h->cfg.initcmatn == 0 && ((mode & AD_FIRST) || ((mode & AD_BURN) && h->cfg.greedy != 0))))) ? 1 : 0;
+    if (batch_done) {
+        const int n10 = (h->d + TD - 1) / TD, noff = n10 * (n10 - 1) / 2;
+        const unsigned g8 = (unsigned)(8 * ((h->ntiles + 7) / 8));
+        hipLaunchKernelGGL(adapt_covb_diag_kernel, dim3(g8 * n10), dim3(64), 0, h->stream, h->E, it, n10);
+        if (noff > 0) hipLaunchKernelGGL(adapt_covb_off_kernel, dim3(g8 * noff), dim3(64), 0, h->stream, h->E, it, noff);
+    }
     if (!((mode & AD_AM) && h->cfg.adapthist > 1)) {                      // the AP window is a batch recompute: no blocked update
         // blocks of ten (triangular on the diagonal): fewer elements and fewer repeats of the per-fold overhead than the 8 x 8 cover
         if (!(getenv("MCMCX_COV_TD") && atoi(getenv("MCMCX_COV_TD")) == 0)) {
@@ -407,8 +419,8 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
             hipLaunchKernelGGL(adapt_cov_kernel, dim3((unsigned)(8 * ((h->ntiles + 7) / 8) * nblk)), dim3(64), 0, h->stream, h->E, it, mode, nblk);
     }
     if (!h->d_Gc) {
-        if (h->usesvd) hipLaunchKernelGGL(adapt_post_kernel<true>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr);
-        else hipLaunchKernelGGL(adapt_post_kernel<false>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr);
+        if (h->usesvd) hipLaunchKernelGGL(adapt_post_kernel<true>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr, batch_done);
+        else hipLaunchKernelGGL(adapt_post_kernel<false>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr, batch_done);
         return;
     }
     // large npar with an SVD factor: the factorisation runs one workgroup per chain on chain-major copies, one launch
@@ -416,7 +428,7 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
     const size_t DD = (size_t)h->d * h->d;
     const dim3 tg((unsigned)((DD + 63) / 64), (unsigned)h->ntiles), tg1((unsigned)((h->d + 63) / 64), (unsigned)h->ntiles);
     const size_t lsv = svd_lds(h->d, h->svd_b);
-    hipLaunchKernelGGL(adapt_post_kernel<true>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 1, h->d_need);
+    hipLaunchKernelGGL(adapt_post_kernel<true>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 1, h->d_need, batch_done);
     hipLaunchKernelGGL(tile2chain_kernel, tg, dim3(256), 0, h->stream, h->E.Gw, h->d_Gc, DD, DD, h->d_need);
     hipLaunchKernelGGL(svd_init_kernel, dim3(h->nlanes), dim3(256), 0, h->stream, h->d_Vc, h->d_state, h->d_need, h->nlanes, h->d);
     for (int sweep = 0; sweep < 60; ++sweep) {
@@ -430,7 +442,7 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
     hipLaunchKernelGGL(svd_finish_kernel, dim3(h->nlanes), dim3(256), 0, h->stream, h->d_Gc, h->d_Vc, h->d_svc, h->d_state, h->nlanes, h->d);
     hipLaunchKernelGGL(chain2tile_kernel, tg, dim3(256), 0, h->stream, h->d_Gc, h->E.Vw, DD, DD, h->d_need);
     hipLaunchKernelGGL(chain2tile_kernel, tg1, dim3(256), 0, h->stream, h->d_svc, h->E.cs, (size_t)h->d, (size_t)2 * h->d, h->d_need);
-    hipLaunchKernelGGL(adapt_post_kernel<true>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 2, h->d_need);
+    hipLaunchKernelGGL(adapt_post_kernel<true>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 2, h->d_need, batch_done);
 }
 
 // Which branch of MCMC_adapt fires at iteration `it` (0 = none).  MCMC_adapt.F90:42-46, 60-61, 105.

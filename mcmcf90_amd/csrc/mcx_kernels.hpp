@@ -33,7 +33,7 @@ enum { M_DRAM = 0, M_RAM = 1, M_ER = 3 };
 enum { S_SS1 = 0, S_PRI1, S_SIGMA2, S_ALPHA12, S_SAVEDY, S_WSUM, S_WNEW, NSCAL };   // S_WNEW: chainwsum after the blocked covariance update (adapt_cov_kernel -> adapt_post_kernel)
 // per-chain integer slots (u32)
 enum { I_SAVED = 0, I_STAYED, I_BNDSTAYED, I_DRACC, I_DRTRIES, I_CHAININD, I_CURCOUNT, I_STATUS,
-       I_LASTFREQ, I_BASECNT, I_WINSTART, I_INFO, I_ERSTAYED, I_PDESC, I_DOWNS, I_ADFLAGS, I_NR, NICTR };   // I_PDESC: 1 after a successful RAM downdate; I_DOWNS: RAM iterations with a < 0 (choldowndate)
+       I_LASTFREQ, I_BASECNT, I_WINSTART, I_INFO, I_ERSTAYED, I_PDESC, I_DOWNS, I_ADFLAGS, I_NR, I_BSTART, NICTR };   // I_PDESC: 1 after a successful RAM downdate; I_DOWNS: RAM iterations with a < 0 (choldowndate)
 
 // status bits
 enum { ST_RAM_DOWNDATE_FAIL = 1, ST_CHOL_FAIL = 2, ST_POTRI_FAIL = 4 };
@@ -3113,7 +3113,10 @@ MCX_DEV void covmat_window_blocked(const EngineDev &E, int tile, int lane, bool 
 // once and served to the other blocks by that XCD's L2, where one wave per tile used to stream it from HBM once per
 // block.  adapt_post_kernel (one wave per tile) finishes: the one-off batch branches, the window restart and
 // MCMC_calculate_R.  Every element of chaincmat / chainmean sees the operations of the single-kernel form.
-enum { ADF_DOCALC = 1, ADF_GREEDY = 2, ADF_STEADY = 4 };
+enum { ADF_DOCALC = 1, ADF_GREEDY = 2, ADF_STEADY = 4,
+       ADF_BATCH = 8,       // the lane takes covmat's two-pass batch branch over the row list (first AM adaptation with initcmatn = 0, AP window,
+                            // greedy restart with initcmatn = 0); I_BSTART = the first iteration whose ballot belongs to the list
+       ADF_BNOINIT = 16 };  // ... and the list's first row is the one accepted AT I_BSTART (greedy: rows 1..it) instead of a row from before it
 
 __global__ __launch_bounds__(64) void adapt_pre_kernel(EngineDev E, int it, int mode)
 {
@@ -3128,7 +3131,7 @@ __global__ __launch_bounds__(64) void adapt_pre_kernel(EngineDev E, int it, int 
     uint32_t basecnt = TIDX(E.ictr, tile, NICTR, I_BASECNT, lane);
     uint32_t winstart = TIDX(E.ictr, tile, NICTR, I_WINSTART, lane);
     double wsum = TIDX(E.scal, tile, NSCAL, S_WSUM, lane);
-    uint32_t flags = 0;
+    uint32_t flags = 0, bstart = 0;
     int nr = 0;
 
     if (mode & AD_BURN) {                                             // MCMC_adapt.F90:60-102
@@ -3163,12 +3166,14 @@ __global__ __launch_bounds__(64) void adapt_pre_kernel(EngineDev E, int it, int 
             for (int e = 0; e < P; ++e) GV(Ct, e) = E.cmat0p[e];
             for (int k = 0; k < d; ++k) GV(mean_t, k) = E.par0[k];
             if (wsum > 0.0) flags |= ADF_STEADY;
-            else
+            else {
                 for (int t = 1; t <= it; ++t) {                       // row list of the one-off batch branch
                     const int slot = t % E.wcap;
                     unsigned long long m = E.wacc[(size_t)tile * E.wcap + slot];
                     if ((m >> lane) & 1ull) { GV(rows, nr) = (uint64_t)(uint32_t)slot | (1ull << 32); ++nr; }
                 }
+                flags |= ADF_BATCH | ADF_BNOINIT; bstart = 1u;
+            }
         }
     } else if (mode & AD_AM) {                                        // MCMC_adapt.F90:105-159
         flags |= ADF_DOCALC;
@@ -3202,6 +3207,7 @@ __global__ __launch_bounds__(64) void adapt_pre_kernel(EngineDev E, int it, int 
             // reverse into chain order (oldest first)
             for (int a = 0, b2 = nback - 1; a < b2; ++a, --b2) { uint64_t ta = GV(rows, a); GV(rows, a) = GV(rows, b2); GV(rows, b2) = ta; }
             nr = nback;
+            flags |= ADF_BATCH; bstart = (uint32_t)(tt + 1);          // tt: the iteration at which the oldest listed row was accepted
         } else if (wsum > 0.0) {
             flags |= ADF_STEADY;                          // steady state (chainwsum > 0): blocked Welford straight from the ballots
         } else {
@@ -3220,8 +3226,10 @@ __global__ __launch_bounds__(64) void adapt_pre_kernel(EngineDev E, int it, int 
             uint32_t wr = (nr == 0) ? (w - lastfreq) : w;
             GV(rows, nr) = (uint64_t)slot_prev | ((uint64_t)wr << 32);
             ++nr;
+            flags |= ADF_BATCH; bstart = winstart;                    // the list's first row is the window's base row
         }
     }
+    TIDX(E.ictr, tile, NICTR, I_BSTART, lane) = bstart;
     TIDX(E.ictr, tile, NICTR, I_ADFLAGS, lane) = flags;
     TIDX(E.ictr, tile, NICTR, I_NR, lane) = (uint32_t)nr;
     TIDX(E.scal, tile, NSCAL, S_WSUM, lane) = wsum;
@@ -3372,6 +3380,127 @@ MCX_DEV void covmat_window_td(const EngineDev &E, int it, int mode, int nblk)
     }
     if (DIAG && a0 == 0 && act) TIDX(E.scal, tile, NSCAL, S_WNEW, lane) = W;
 }
+// covmat's batch branch (matutils.F90:311-338: weighted mean first, then sum_r (x_ri - m_i) ((x_rj - m_j) w_r), divided by wsum - 1)
+// in the same blocks: the rows of the lane's list (adapt_pre_kernel: ring slot | weight << 32) are the states between set ballot
+// bits from I_BSTART on, so the block walks the window's iterations in lockstep like the steady form -- a row's loads are whole
+// 512-byte segments whichever lanes want them -- and takes each row's WEIGHT from the list when the next accept closes it.  Two
+// walks (means, then products); element for element the operations of covmat_rows' batch branch, which visits cmat once per ROW
+// (84 ms for the first adaptation of 131072 chains at npar = 50, and every adaptation of an AP run).
+template <bool DIAG>
+MCX_DEV void covmat_batch_td(const EngineDev &E, int it, int nblk)
+{
+    const int lane = threadIdx.x, d = E.d, P = E.P;
+    const int w = blockIdx.x, j = w >> 3;
+    const int tile = (j / nblk) * 8 + (w & 7);
+    int blk = j % nblk;
+    if (tile >= E.ntiles) return;
+    const uint32_t flags = TIDX(E.ictr, tile, NICTR, I_ADFLAGS, lane);
+    const bool act = (flags & ADF_BATCH) != 0, noinit = (flags & ADF_BNOINIT) != 0;
+    if (!__any(act)) return;
+    const int nb = (d + TD - 1) / TD;
+    int a0 = 0, b0 = 0;
+    if (DIAG) { a0 = b0 = blk * TD; }
+    else { int ar = 0; while (blk >= nb - 1 - ar) { blk -= nb - 1 - ar; ++ar; } a0 = ar * TD; b0 = (ar + 1 + blk) * TD; }
+    double *Ct = E.cmat + (size_t)tile * P * 64;
+    const double *base_t = E.basetheta + (size_t)tile * d * 64;
+    double *mnew_t = E.cand + (size_t)tile * d * 64;
+    const uint64_t *rows = E.rowlist + (size_t)tile * (E.wcap + 1) * 64;
+    const int t0lane = (int)TIDX(E.ictr, tile, NICTR, I_BSTART, lane), t1 = it;
+    int t0 = act ? t0lane : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { int other = __shfl_xor(t0, o); t0 = other < t0 ? other : t0; }
+    const double *hist_t = E.hist + (size_t)tile * E.wcap * (size_t)E.hs * 64;
+    const unsigned long long *wacc_t = (const unsigned long long *)E.wacc + (size_t)tile * E.wcap;
+    constexpr int NBV = DIAG ? 1 : TD;
+    double C[TD][TD], ma[TD], xa[TD], mb[NBV], xb[NBV];
+    // one walk over the window: fold(on, weight) closes the row in xa / xb for the lanes `on`
+    auto walk = [&](auto &&fold) {
+        bool have = act && !noinit;
+        int idx = have ? 0 : -1;                          // the list entry of the open row
+        if (have) {                                       // the list's first row dates from before the window: the base row, or a ring slot of the lane's own
+            const uint32_t slot = (uint32_t)GV(rows, 0);
+            const bool isbase = (slot == 0xffffffffu);
+            const size_t so = isbase ? 0 : (size_t)slot * (size_t)E.hs * 64;
+#pragma unroll
+            for (int u = 0; u < TD; ++u) {
+                const int a = (a0 + u < d) ? a0 + u : d - 1;
+                xa[u] = isbase ? GV(base_t, a) : hist_t[so + (size_t)a * 64 + lane];
+                if (!DIAG) { const int b = (b0 + u < d) ? b0 + u : d - 1; xb[u] = isbase ? GV(base_t, b) : hist_t[so + (size_t)b * 64 + lane]; }
+            }
+        }
+        for (int tc = t0; tc <= t1; tc += 64) {
+            const int tl = tc + lane;
+            const unsigned long long mine = (tl <= t1) ? wacc_t[tl % E.wcap] : 0ull;
+            const int nq = (t1 - tc + 1) < 64 ? (t1 - tc + 1) : 64;
+            for (int q = 0; q < nq; ++q) {
+                const int t = tc + q, slot = t % E.wcap;
+                const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), q) << 32)
+                                             | (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mine, q);
+                const bool acc = act && (t >= t0lane) && ((m >> lane) & 1ull);
+                if (__any(acc)) {
+                    double xan[TD], xbn[NBV];
+                    if (acc) {
+                        const size_t so = (size_t)slot * (size_t)E.hs * 64;
+#pragma unroll
+                        for (int u = 0; u < TD; ++u) {
+                            xan[u] = hist_t[so + (size_t)((a0 + u < d) ? a0 + u : d - 1) * 64 + lane];
+                            if (!DIAG) xbn[u] = hist_t[so + (size_t)((b0 + u < d) ? b0 + u : d - 1) * 64 + lane];
+                        }
+                    }
+                    const bool fl = acc && have;
+                    if (__any(fl)) fold(fl, fl ? (double)(uint32_t)(GV(rows, idx) >> 32) : 0.0);
+                    if (acc) {
+#pragma unroll
+                        for (int u = 0; u < TD; ++u) { xa[u] = xan[u]; if (!DIAG) xb[u] = xbn[u]; }
+                        have = true; idx += 1;
+                    }
+                }
+            }
+        }
+        if (__any(have)) fold(have, have ? (double)(uint32_t)(GV(rows, idx) >> 32) : 0.0);
+    };
+    // ---- xmean2 = sum_r x_r w_r / sum_r w_r (rows in list order)
+    double wsum2 = 0.0;
+#pragma unroll
+    for (int u = 0; u < TD; ++u) { ma[u] = 0.0; if (!DIAG) mb[u] = 0.0; }
+    walk([&](bool on, double w3) {
+        if (on) {
+#pragma unroll
+            for (int u = 0; u < TD; ++u) { ma[u] = ma[u] + xa[u] * w3; if (!DIAG) mb[u] = mb[u] + xb[u] * w3; }
+            wsum2 = wsum2 + w3;
+        }
+    });
+#pragma unroll
+    for (int u = 0; u < TD; ++u) { ma[u] = ma[u] / wsum2; if (!DIAG) mb[u] = mb[u] / wsum2; }
+    // ---- cmat(j,k), j <= k: sum_r (x_rk - m_k) ((x_rj - m_j) w_r), then / (wsum - 1)
+#pragma unroll
+    for (int u = 0; u < TD; ++u)
+#pragma unroll
+        for (int v = 0; v < TD; ++v) C[u][v] = 0.0;
+    walk([&](bool on, double w3) {
+        if (on) {
+            double da[TD], db[NBV];
+#pragma unroll
+            for (int u = 0; u < TD; ++u) { da[u] = xa[u] - ma[u]; if (!DIAG) db[u] = xb[u] - mb[u]; }
+#pragma unroll
+            for (int u = 0; u < TD; ++u) {
+                const double xw = da[u] * w3;
+#pragma unroll
+                for (int v = (DIAG ? u : 0); v < TD; ++v) C[u][v] = C[u][v] + (DIAG ? da[v] : db[v]) * xw;
+            }
+        }
+    });
+#pragma unroll
+    for (int u = 0; u < TD; ++u) {
+        const int a = a0 + u;
+#pragma unroll
+        for (int v = (DIAG ? u : 0); v < TD; ++v) { const int b = b0 + v; if (act && a < d && b < d) GV(Ct, pidx(a, b, d)) = C[u][v] / (wsum2 - 1.0); }
+        if (DIAG && act && a < d) GV(mnew_t, a) = ma[u];
+    }
+    if (DIAG && a0 == 0 && act) TIDX(E.scal, tile, NSCAL, S_WNEW, lane) = wsum2;
+}
+__global__ __launch_bounds__(64, 2) void adapt_covb_diag_kernel(EngineDev E, int it, int nblk) { covmat_batch_td<true>(E, it, nblk); }
+__global__ __launch_bounds__(64, 1) void adapt_covb_off_kernel(EngineDev E, int it, int nblk) { covmat_batch_td<false>(E, it, nblk); }
 __global__ __launch_bounds__(64, 2) void adapt_cov_diag_kernel(EngineDev E, int it, int mode, int nblk) { covmat_window_td<true>(E, it, mode, nblk); }
 __global__ __launch_bounds__(64, 1) void adapt_cov_off_kernel(EngineDev E, int it, int mode, int nblk) { covmat_window_td<false>(E, it, mode, nblk); }
 
@@ -3384,7 +3513,7 @@ __global__ __launch_bounds__(64, 1) void adapt_cov_off_kernel(EngineDev E, int i
 #define MCX_POST_WAVES 2
 #endif
 template <bool SVD>
-__global__ __launch_bounds__(64, SVD ? 1 : MCX_POST_WAVES) void adapt_post_kernel(EngineDev E, int it, int mode, int phase, uint8_t *need)
+__global__ __launch_bounds__(64, SVD ? 1 : MCX_POST_WAVES) void adapt_post_kernel(EngineDev E, int it, int mode, int phase, uint8_t *need, int batch_done)
 {
     extern __shared__ double X[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d, P = E.P;
@@ -3402,7 +3531,10 @@ __global__ __launch_bounds__(64, SVD ? 1 : MCX_POST_WAVES) void adapt_post_kerne
     uint32_t winstart = TIDX(E.ictr, tile, NICTR, I_WINSTART, lane);
     const uint32_t flags = TIDX(E.ictr, tile, NICTR, I_ADFLAGS, lane);
     const int nr = (int)TIDX(E.ictr, tile, NICTR, I_NR, lane);
-    const bool docalc = (flags & ADF_DOCALC) != 0, steady = (flags & ADF_STEADY) != 0, greedy_lane = (flags & ADF_GREEDY) != 0;
+    const bool docalc = (flags & ADF_DOCALC) != 0, greedy_lane = (flags & ADF_GREEDY) != 0;
+    // lanes whose covariance and mean the blocked kernels have already updated: the steady Welford form, and (batch_done: the
+    // host launched adapt_covb_*) the batch branch over the row list
+    const bool steady = (flags & ADF_STEADY) != 0 || (batch_done != 0 && (flags & ADF_BATCH) != 0);
     double wsum = TIDX(E.scal, tile, NSCAL, (steady && phase != 2) ? S_WNEW : S_WSUM, lane);
     if (phase != 2) {
     if (steady) copy_vec(mean_t, m2_t, nullptr, lane, d);
@@ -3419,7 +3551,7 @@ __global__ __launch_bounds__(64, SVD ? 1 : MCX_POST_WAVES) void adapt_post_kerne
         }
     } else if (mode & AD_AM) {
         if (E.adapthist > 1) {
-            covmat_rows(E, tile, lane, rows, nr, true, false, Ct, mean_t, base_t, m2_t, wsum, X);
+            covmat_rows(E, tile, lane, rows, nr, !steady, false, Ct, mean_t, base_t, m2_t, wsum, X);
         } else {
             covmat_rows(E, tile, lane, rows, nr, !steady, true, Ct, mean_t, base_t, m2_t, wsum, X);
             // lastfreq = count of the current row; lastind = chainind -> window restarts here

@@ -399,3 +399,50 @@ def test_scam_waves_per_tile(oracle, nw, kind, d, monkeypatch):
         assert (cnt["stayed"], cnt["bndstayed"], cnt["chainind"]) == (o.stayed, o.bndstayed, o.chainind)
         assert e.rng(c)[0] == o.rng_n
     e.close()
+
+
+@pytest.mark.parametrize("case", ["am_first", "ap", "greedy", "ap_ragged"])
+def test_batch_branch_in_blocks_equals_row_form_and_oracle(oracle, case, monkeypatch):
+    """covmat's two-pass batch branch (matutils.F90:311-338) -- the first AM adaptation with initcmatn = 0, every adaptation of
+    an AP window (adapthist > 1), the greedy restart of the burn-in -- runs in register blocks (adapt_covb_*); the row-by-row
+    form (covmat_rows, MCMCX_COV_BATCH_ROWS=1) and the oracle must give the same bits: covariance, mean, weight, factor, state."""
+    from mcmcf90_amd import engine_from_problem
+    if case == "am_first":
+        z, _, _ = load("c4_gauss50_am", oracle); ckw, pkw = _kw(z)
+    elif case == "ap":
+        z, _, _ = load("c1_priors_ap", oracle); ckw, pkw = _kw(z)
+    elif case == "greedy":
+        rng = np.random.default_rng(5)
+        d = 13
+        A = rng.standard_normal((d, d)) / np.sqrt(d)
+        pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.3), cmat0=0.05 * np.eye(d), mu=np.zeros(d), lam=A @ A.T + np.eye(d))
+        ckw = dict(nsimu=700, method="dram", drscale=0.0, adaptint=100, doburnin=1, burnintime=400, badaptint=50, greedy=1,
+                   scalelimit=0.05, scalefactor=2.5, updatesigma=0)
+    else:
+        rng = np.random.default_rng(9)
+        d = 37                                                    # four blocks of ten, the last one ragged
+        A = rng.standard_normal((d, d)) / np.sqrt(d)
+        pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.1), cmat0=(0.5 / d) * np.eye(d), mu=np.linspace(-1, 1, d), lam=A @ A.T + np.eye(d))
+        ckw = dict(nsimu=650, method="dram", drscale=0.0, adaptint=100, adapthist=230, updatesigma=0)
+    res = []
+    for rows in (0, 1):
+        if rows:
+            monkeypatch.setenv("MCMCX_COV_BATCH_ROWS", "1")
+        e = engine_from_problem(ckw, pkw, nchains=70, chain_id0=11, record_accept=1)
+        e.init(); e.run()
+        res.append((e.theta().copy(), [e.chaincov(c) for c in (0, 63, 69)], [e.R(c).copy() for c in (0, 63, 69)], [e.rng(c)[0] for c in (0, 63, 69)]))
+        e.close()
+    a, b = res
+    np.testing.assert_array_equal(_bits(a[0]), _bits(b[0]))
+    for (ca, ma, wa, *_), (cb, mb, wb, *_) in zip(a[1], b[1]):
+        np.testing.assert_array_equal(_bits(ca), _bits(cb)); np.testing.assert_array_equal(_bits(ma), _bits(mb)); assert wa == wb
+    for ra, rb in zip(a[2], b[2]):
+        np.testing.assert_array_equal(_bits(ra), _bits(rb))
+    assert a[3] == b[3]
+    cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
+    for i, c in enumerate((0, 63, 69)):
+        o = oracle.run_chain(cfg, prob, chain_id=11 + c)
+        np.testing.assert_array_equal(_bits(a[0][c]), _bits(o.theta))
+        np.testing.assert_array_equal(_bits(np.triu(a[1][i][0])), _bits(np.triu(o.chaincmat)))
+        np.testing.assert_array_equal(_bits(a[1][i][1]), _bits(o.chainmean))
+        assert a[3][i] == o.rng_n
