@@ -271,6 +271,15 @@ static bool phased(const mcmcx_engine *h) { return h->tkind == TGT_HOST || h->tk
 static size_t lds_bytes(const mcmcx_engine *h) { return (size_t)h->d * 64 * sizeof(double) * 2; }   // adapt / DR work vectors
 static bool dr_fits_lds(const mcmcx_engine *h) { return lds_bytes(h) <= 160 * 1024; }          // npar <= 160
 static size_t lds_step(const mcmcx_engine *h) { return (h->dodr && dr_fits_lds(h)) ? lds_bytes(h) : 0; }
+// step_kernel_dr keeps the second stage's two vectors in LDS, step_kernel_dr_big in global scratch.  LDS pays while eight waves
+// still fit a CU (npar <= 20: 6.9e8 against 6.0e8 iterations/s at 20); beyond, the waves it costs are worth more than the bytes
+// it saves (npar 24: 3.1e8 against 4.1e8, 64: 3.2e7 / 4.6e7, 100: 0.8e7 / 1.7e7 -- tools/dr_sweep.py)
+static bool dr_vectors_in_lds(const mcmcx_engine *h)
+{
+    if (!dr_fits_lds(h)) return false;
+    if (const char *e = getenv("MCMCX_DR_BIG")) return atoi(e) == 0;                  // A/B switch for tests: 1 = global scratch, 0 = LDS
+    return lds_bytes(h) * 8 <= 160 * 1024;
+}
 static void launch_init(mcmcx_engine *h)
 { hipLaunchKernelGGL(init_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E); }
 // the sampling kernels go through LAUNCHK, which notes the kernel's name for mcmcx_last_kernel (bench.py labels its roofline with it)
@@ -284,7 +293,7 @@ static void launch_step(mcmcx_engine *h, int it0, int it1)
     else if (h->pooled) LAUNCHK((step_kernel<false, false, true>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->E.method == M_RAM && h->usesvd) LAUNCHK(step_kernel_ram_fullr, g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->E.method == M_RAM) LAUNCHK((step_kernel<true, false, false>), g, b, (size_t)NLC * 2 * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
-    else if (h->dodr && !dr_fits_lds(h))                  // npar > 160: the second stage's two vectors in global scratch
+    else if (h->dodr && !dr_vectors_in_lds(h))            // the second stage's two vectors in global scratch
         LAUNCHK(step_kernel_dr_big, g, b, 0, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
     else if (h->dodr && !(getenv("MCMCX_DR_GENERAL") && atoi(getenv("MCMCX_DR_GENERAL"))))      // (A/B switch for tests: step_body<DR>)
         LAUNCHK(step_kernel_dr, g, b, lds_step(h), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);

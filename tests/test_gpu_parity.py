@@ -216,11 +216,13 @@ def test_pooled_moments_and_shard_invariance(oracle):
 
 @pytest.mark.parametrize("method,d,extra", [("dram", 256, {}), ("ram", 256, {}), ("dram", 150, {"drscale": 2.0}), ("dram", 1, {"drscale": 3.0}),
                                             ("dram", 160, {"drscale": 2.0}), ("dram", 161, {"drscale": 2.0}), ("dram", 256, {"drscale": 2.0})])
-def test_extreme_dimensions(oracle, method, d, extra):
+def test_extreme_dimensions(oracle, method, d, extra, monkeypatch):
     """npar at the engine's limits: 256 (AM and RAM; one adaptation tick), delayed rejection on both sides of the size
-    whose two second-stage vectors still fit the LDS (160: step_kernel_dr; 161 and 256: step_kernel_dr_big, the vectors in
-    global scratch), and npar = 1 with DR."""
+    whose two second-stage vectors still fit the LDS (150, 160: step_kernel_dr, asked for -- above npar 20 the engine would
+    take the other form by itself; 161 and 256: step_kernel_dr_big, the vectors in global scratch), and npar = 1 with DR."""
     from mcmcf90_amd import engine_from_problem
+    if d in (150, 160):
+        monkeypatch.setenv("MCMCX_DR_BIG", "0")
     rng = np.random.default_rng(d)
     A = rng.standard_normal((d, d)) / np.sqrt(d)
     lam = A @ A.T + np.eye(d)
@@ -236,6 +238,34 @@ def test_extreme_dimensions(oracle, method, d, extra):
         np.testing.assert_array_equal(_bits(th[c]), _bits(o.theta))
         np.testing.assert_array_equal(_bits(np.triu(e.R(c))), _bits(np.triu(o.R)))
     e.close()
+
+
+@pytest.mark.parametrize("d", [7, 20, 23, 37, 64])
+def test_delayed_rejection_vectors_in_lds_or_global(oracle, d, monkeypatch):
+    """step_kernel_dr (second-stage vectors in LDS: the engine's choice up to npar 20) and step_kernel_dr_big (in global scratch:
+    its choice above) are the same chain bit for bit, and the oracle's -- both forms at every size, a ragged tile, two adaptations."""
+    from mcmcf90_amd import engine_from_problem
+    rng = np.random.default_rng(100 + d)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    ckw = dict(nsimu=130, adaptint=50, updatesigma=0, drscale=2.0)
+    pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.05), cmat0=(0.5 / d) * np.eye(d), mu=np.linspace(-1, 1, d), lam=A @ A.T + np.eye(d))
+    res = []
+    for big in ("0", "1"):
+        monkeypatch.setenv("MCMCX_DR_BIG", big)
+        e = engine_from_problem(ckw, pkw, nchains=70, chain_id0=2, record_accept=1)
+        e.init(); e.run()
+        assert e.last_kernel() == ("step_kernel_dr_big" if big == "1" else "step_kernel_dr")
+        res.append((e.theta().copy(), e.accept_masks(), [e.R(c).copy() for c in (0, 69)], [e.rng(c)[0] for c in (0, 69)], [e.counters(c)["draccepted"] for c in (0, 69)]))
+        e.close()
+    a, b = res
+    assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1]) and a[3] == b[3] and a[4] == b[4]
+    for x, y in zip(a[2], b[2]):
+        np.testing.assert_array_equal(_bits(x), _bits(y))
+    cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
+    for i, c in enumerate((0, 69)):
+        o = oracle.run_chain(cfg, prob, chain_id=2 + c)
+        np.testing.assert_array_equal(_bits(a[0][c]), _bits(o.theta))
+        assert a[3][i] == o.rng_n
 
 
 def test_sizes_beyond_the_limits_fail_loudly():
