@@ -335,7 +335,18 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
     n_local = chains_per_gpu or DEFAULT_CHAINS[wl]
     ips = its_per_step or (10 if wl == "c5" else 100)       # c5: one iteration is d = 200 componentwise proposals
     nsimu = (warmup + steps) * ips + 1                       # steps end ON the adaptation ticks (iteration k * ips): one launch + one tick each
-    ckw, pkw, per_it = problem(wl, nsimu, adaptint=max(ips, 100))
+    adaptint_ = max(ips, 100)
+    it_end = (warmup + steps) * ips
+    # a configuration whose timed iterations hold no adaptation (c5: ten iterations per step, adaptint 100) runs on to its next one
+    # afterwards, untimed for `value`, so that the line can say what an adaptation costs (N = 1 only)
+    # (not with per-chain rotations at npar = 200: that adaptation is 65536 SVDs -- 7 s on full-rank covariances, 35 s at the first
+    #  adaptation of this line, whose 100 rows leave the 200 x 200 covariance rank-deficient and the pinned routine at its 60-sweep cap;
+    #  tools/svd_tick_probe.py)
+    tick_probe = (world == 1 and it_end // adaptint_ == (warmup * ips) // adaptint_ and not (wl == "c5" and replicas))
+    next_tick = (it_end // adaptint_ + 1) * adaptint_
+    if tick_probe:
+        nsimu = next_tick + 1
+    ckw, pkw, per_it = problem(wl, nsimu, adaptint=adaptint_)
     d = pkw["npar"]
     if wl == "c4" and start == "target":
         pkw = dict(pkw, cmat0=np.linalg.inv(np.asarray(pkw["lam"], dtype=float)))
@@ -380,6 +391,12 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
     tries, stayed_all, downs_all = (float(x) for x in red[1])
     pooled_vec = eng.allreduce_moments(fetch=True)                                  # collective: every rank
     kname = eng.last_kernel()
+    tick_s = None
+    if tick_probe and ckw.get("method", "dram") != "ram":
+        eng.run(next_tick - 1); fence()
+        tt0 = time.perf_counter()
+        eng.run(next_tick); fence()                                                 # one iteration and the adaptation behind it
+        tick_s = max(time.perf_counter() - tt0 - dt / (steps * ips), 0.0)
     eng.close()
     if rank != 0:
         return None, pooled_vec
@@ -449,8 +466,17 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
         regime = "; adaptint = %d: %d adaptation tick(s) inside the %d timed iterations" % (adaptint, nticks, steps * ips)
         if nticks == 0:
             regime += " (the rate between two adaptations)"
+            if wl == "c5" and replicas:
+                regime += "; an adaptation here is one SVD per chain: 7 s for 65536 full-rank covariances, 35 s when adaptint < npar leaves them rank-deficient (not timed in this line)"
     elif start == "target":
         regime = "; cmat0 = the target's covariance: RAM at its target acceptance rate from the start (about half of the lanes downdate)"
+    adaptation = None
+    if tick_s is not None:
+        t_it = dt / (steps * ips)
+        adaptation = {"adaptint": adaptint, "tick_ms": tick_s * 1e3,
+                      "sustained_value": float(world) * n_local * per_it * adaptint / (adaptint * t_it + tick_s),
+                      "note": "`value` is the rate between two adaptations; sustained_value = proposals of adaptint iterations / (their time + one "
+                              "adaptation), the adaptation timed once after the timed region (iteration %d)" % next_tick}
     cnt = float(pooled_vec[0])
     mean = pooled_vec[1:1 + d] / cnt
     res = {
@@ -462,6 +488,7 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
                    "proposals_per_iteration": per_it + dr_per_it / (float(world) * n_local),
                    "parallelism": "chains sharded over %d GPU(s), one process each" % world},
         "roofline": roof,
+        "adaptation": adaptation,
         "pooled_check": {"chains": cnt, "max_abs_mean": float(np.max(np.abs(mean)))},
         "_cpu": (wl, ckw, pkw, per_it, "d=%d %s" % (d, method)),
     }
@@ -561,6 +588,7 @@ def main():
             "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": res["config"], "roofline": res["roofline"], "pooled_check": res["pooled_check"],
+            **({"adaptation": res["adaptation"]} if res.get("adaptation") else {}),
             "rccl_ranks": rccl_ranks if (world > 1 and not a.one_gpu_dryrun) else (1 if world == 1 else 0),
             "engine_sha": kernels_sha(),
         }
@@ -579,6 +607,8 @@ def main():
                                    "alg_per_proposal": rf.get("alg_bytes_per_proposal", rf.get("alg_flop_per_proposal")),
                                    "workload": r["config"]["workload"], "proposals_per_iteration": r["config"]["proposals_per_iteration"],
                                    "wall_s_incl_init": time.perf_counter() - t0}
+                    if r.get("adaptation"):
+                        others[key].update(tick_ms=r["adaptation"]["tick_ms"], sustained_value=r["adaptation"]["sustained_value"])
                 except Exception as ex:
                     others[key] = {"error": str(ex)[:300]}
             line["other_configs"] = others
