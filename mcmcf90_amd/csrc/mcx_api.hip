@@ -49,7 +49,23 @@ struct mcmcx_engine {
     mcmcx_ssfun_batch_t h_ss_batch = nullptr; int h_threads = 1;      // batched form of the user's ssfunction (opt-in)
     hipModule_t mod = nullptr; hipFunction_t mod_fn = nullptr; void *d_moddata = nullptr;   // user target module (include/mcmcx_target.h)
     std::vector<double> h_bth, h_bss; std::vector<int> h_bidx;
-    std::vector<double> h_cand, h_ev;
+    // host side of the callback path: page-locked, so that the candidates come back and the results go out as asynchronous copies
+    // on the engine's stream with ONE synchronisation per stage (pageable buffers cost a staged, blocking copy each way)
+    struct Pinned {
+        double *p = nullptr; size_t cap = 0, n = 0;
+        int resize(size_t m) {
+            n = m;
+            if (m <= cap) return 0;
+            if (p) (void)hipHostFree(p);
+            p = nullptr; cap = 0;
+            if (hipHostMalloc((void **)&p, m * sizeof(double), hipHostMallocDefault) != hipSuccess) return -1;
+            cap = m; return 0;
+        }
+        double &operator[](size_t i) { return p[i]; }
+        double *data() { return p; }
+        size_t size() const { return n; }
+        void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = n = 0; }
+    } h_cand, h_ev, h_hx;
     // pooled mode
     int pool_status = 0; double pool_alpha = 0.0;       // pooled RAM: skipped ticks, mean acceptance of the last tick
     int pooled = 0; double pool_W = 0.0; std::vector<double> pool_mean, pool_C, pool_R;   // packed upper, row-major
@@ -798,14 +814,15 @@ static int host_eval(mcmcx_engine *h, const double *dev_src, int stride_k, bool 
         return 0;
     }
     const size_t L = (size_t)T * 64;
-    h->h_cand.resize(L * stride_k);
     const int ny = h->ny, nhe = NHE - 1 + ny;
-    h->h_ev.assign(L * nhe, 0.0);
+    if (h->h_cand.resize(L * stride_k) || h->h_ev.resize(L * nhe) || (use_stage2_flag && h->h_hx.resize(L * NHX)))
+        return fail(-100, "host callbacks: no page-locked memory for the candidates");
     std::vector<double> ssc(ny, 0.0);
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(h->h_cand.data(), dev_src, h->h_cand.size() * 8, hipMemcpyDeviceToHost));
-    std::vector<double> hx;
-    if (use_stage2_flag) { hx.resize(L * NHX); HIPCHK(hipMemcpy(hx.data(), h->E.hx, hx.size() * 8, hipMemcpyDeviceToHost)); }
+    HIPCHK(hipMemcpyAsync(h->h_cand.data(), dev_src, h->h_cand.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    if (use_stage2_flag) HIPCHK(hipMemcpyAsync(h->h_hx.data(), h->E.hx, h->h_hx.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));             // (also: the previous stage's results have left h_ev)
+    memset(h->h_ev.data(), 0, h->h_ev.size() * sizeof(double));
+    auto &hx = h->h_hx;
     std::vector<double> th(d);
     if (h->h_ss_batch && !(what == 2 && h->h_ss_er)) {
         // Batched form (opt-in): bounds and prior per chain on this thread, in chain order; then ONE call of the user's
@@ -842,7 +859,7 @@ static int host_eval(mcmcx_engine *h, const double *dev_src, int stride_k, bool 
             const int c = h->h_bidx[i], t = c / 64, l = c % 64;
             for (int j = 0; j < ny; ++j) h->h_ev[((size_t)t * nhe + HE_SS + j) * 64 + l] = h->h_bss[(size_t)i * ny + j];
         }
-        HIPCHK(hipMemcpy(h->E.hev, h->h_ev.data(), h->h_ev.size() * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(h->E.hev, h->h_ev.data(), h->h_ev.size() * 8, hipMemcpyHostToDevice, h->stream));
         return 0;
     }
     for (int c = 0; c < h->cfg.nchains; ++c) {
@@ -867,7 +884,7 @@ static int host_eval(mcmcx_engine *h, const double *dev_src, int stride_k, bool 
         h->h_ev[((size_t)t * nhe + HE_PRI) * 64 + l] = pri;
         for (int j = 0; j < ny; ++j) h->h_ev[((size_t)t * nhe + HE_SS + j) * 64 + l] = ssc[j];
     }
-    HIPCHK(hipMemcpy(h->E.hev, h->h_ev.data(), h->h_ev.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(h->E.hev, h->h_ev.data(), h->h_ev.size() * 8, hipMemcpyHostToDevice, h->stream));
     return 0;
 }
 
@@ -1036,6 +1053,7 @@ int mcmcx_destroy(mcmcx_handle h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &p : h->pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (void *p : h->allocs) (void)hipFree(p);
+    h->h_cand.release(); h->h_ev.release(); h->h_hx.release();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     if (h->mod) (void)hipModuleUnload(h->mod);
     delete h;
