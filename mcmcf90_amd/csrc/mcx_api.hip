@@ -364,11 +364,23 @@ static int upload_shared_u(mcmcx_engine *h)
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
+// 13..15 output blocks (npar 193..240): twelve waves of 170 registers (scam_pooled12_kernel) instead of sixteen of 128
+static bool scam_use_12(const mcmcx_engine *h)
+{
+    const int nt = (h->d + 15) / 16;
+    if (const char *e = getenv("MCMCX_SCAM_POOLED_16")) if (atoi(e)) return false;    // A/B switch for tests: the sixteen-wave layout
+    return nt >= 13 && nt <= 15;
+}
 static void launch_scam(mcmcx_engine *h, int it0, int it1)
 {
     if (h->pooled) {
         const size_t st = shared_u_stride(h);
         const int nt = (h->d + 15) / 16;                   // 16-row output blocks: min(12, 4*(nt/4)) block waves + 4 chain-group waves
+        if (scam_use_12(h)) {
+            LAUNCHK(scam_pooled12_kernel, dim3(h->ntiles), dim3(768), scam_pooled_lds(h->d), h->stream, h->E, it0, it1,
+                    h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedU, h->d_sharedU + st, h->d_sharedU + 2 * st);
+            return;
+        }
         const int nw = 4 + std::min(12, nt & ~3);
         LAUNCHK(scam_pooled_kernel, dim3(h->ntiles), dim3(64 * nw), scam_pooled_lds(h->d), h->stream, h->E, it0, it1,
                            h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedU, h->d_sharedU + st, h->d_sharedU + 2 * st);
@@ -379,6 +391,11 @@ static void launch_scam(mcmcx_engine *h, int it0, int it1)
     if (h->cfg.scam_fast && h->tkind == TGT_GAUSS && !h->has_lo && !h->has_hi && !h->has_pri && scam_pooled_lds(h->d) <= 160 * 1024 &&
         !(getenv("MCMCX_SCAM_FAST_LANES") && atoi(getenv("MCMCX_SCAM_FAST_LANES")))) {
         const int nt = (h->d + 15) / 16;
+        if (scam_use_12(h)) {
+            LAUNCHK(scam_pooled12_kernel, dim3(h->ntiles), dim3(768), scam_pooled_lds(h->d), h->stream, h->E, it0, it1,
+                    h->E.tgt.mu, h->E.tgt.lamT, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr);
+            return;
+        }
         const int nwp = 4 + std::min(12, nt & ~3);
         LAUNCHK(scam_pooled_kernel, dim3(h->ntiles), dim3(64 * nwp), scam_pooled_lds(h->d), h->stream, h->E, it0, it1,
                            h->E.tgt.mu, h->E.tgt.lamT, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr);

@@ -1899,25 +1899,28 @@ constexpr int PWS = 16;
 typedef double mcx_d4 __attribute__((ext_vector_type(4)));
 typedef double mcx_d2 __attribute__((ext_vector_type(2)));
 
-template <bool BW, int NS>   // BW: block wave (blk0 = its block, slot = chain group); else group wave (slot s = block blk0+s, s < NS)
-MCX_DEV void mfma_slots(const double *__restrict__ M, const double *X, int lane, int d, int d4, int blk0, int grp, mcx_d4 (&c)[4])
+template <bool BW, int NS, bool XS = false>   // BW: block wave (blk0 = its block, slot = chain group; XS: a fifth slot, group xgrp of block xblk); else group wave (slot s = block blk0+s, s < NS)
+MCX_DEV void mfma_slots(const double *__restrict__ M, const double *X, int lane, int d, int d4, int blk0, int grp, mcx_d4 (&c)[XS ? 5 : 4],
+                        int xblk = 0, int xgrp = 0)
 {
     const int li = lane & 15, lk = lane >> 4;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) c[s] = mcx_d4{0.0, 0.0, 0.0, 0.0};
+    for (int s = 0; s < (XS ? 5 : 4); ++s) c[s] = mcx_d4{0.0, 0.0, 0.0, 0.0};
     const double *__restrict__ ap = M + (size_t)lk * d + 16 * blk0 + li;
     const double *xp = X + lk * 64 + li + (BW ? 0 : 16 * grp);
     int s0 = 0;
     if (BW) {
-        for (; s0 + 16 <= d4; s0 += 16) {               // four k-blocks per trip: the four A loads go out together
-            double a[4];
+        const double *__restrict__ axp = M + (size_t)lk * d + 16 * xblk + li;      // XS: the fifth slot's A operand
+        for (; s0 + 16 <= d4; s0 += 16) {               // four k-blocks per trip: the four (eight) A loads go out together
+            double a[4], ax[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] = ap[(size_t)(s0 + 4 * u) * d];
+            for (int u = 0; u < 4; ++u) { a[u] = ap[(size_t)(s0 + 4 * u) * d]; if (XS) ax[u] = axp[(size_t)(s0 + 4 * u) * d]; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const double *xq = xp + (s0 + 4 * u) * 64;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) c[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], xq[16 * g], c[g], 0, 0, 0);
+                if (XS) c[XS ? 4 : 0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[u], xq[16 * xgrp], c[XS ? 4 : 0], 0, 0, 0);
             }
         }
         for (; s0 < d4; s0 += 4) {
@@ -1925,6 +1928,7 @@ MCX_DEV void mfma_slots(const double *__restrict__ M, const double *X, int lane,
             const double *xq = xp + s0 * 64;
 #pragma unroll
             for (int g = 0; g < 4; ++g) c[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xq[16 * g], c[g], 0, 0, 0);
+            if (XS) c[XS ? 4 : 0] = __builtin_amdgcn_mfma_f64_16x16x4f64(axp[(size_t)s0 * d], xq[16 * xgrp], c[XS ? 4 : 0], 0, 0, 0);
         }
     } else {
         // KU k-blocks per trip, up to four A each: a trip waits for its loads once, and a wave with one or two slots has few
@@ -1954,11 +1958,13 @@ MCX_DEV void mfma_slots(const double *__restrict__ M, const double *X, int lane,
 // Element (slot s, register r) of a lane: output row o = 16*block + (lane>>4) + 4r, chain c = 16*group + (lane&15); its
 // offset o*64 + c in a tile-interleaved vector (and in X) is e0 + (BW ? 16 s : 1024 s) + 256 r.  X has 16*nt rows, so
 // every element has an LDS home; rows >= d are written as zeros (the k loop reads the rows < d4 only).
-template <bool BW, int NS, bool SC>   // SC: the scalar wave (the last one).  A template parameter, so that the other fifteen waves carry
+template <bool BW, int NS, bool SC, bool XS = false>   // SC: the scalar wave (the last one).  A template parameter, so that the other fifteen waves carry
                                       // neither the generator nor the per-chain state: at 128 registers a wave they spilled around their MFMAs
+                                      // XS (scam_pooled12_kernel): a block wave with a FIFTH slot, chain group xgrp of block xblk
 MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, int lane, int w, int nw, int blk0, int grp,
                               const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
-                              const double *__restrict__ g_U, const double *__restrict__ g_UT, const double *__restrict__ g_std)
+                              const double *__restrict__ g_U, const double *__restrict__ g_UT, const double *__restrict__ g_std,
+                              int xblk = 0, int xgrp = 0)
 {
     const int tile = blockIdx.x, d = E.d, d4 = (d + 3) & ~3, nt = (d + 15) >> 4, li = lane & 15, lk = lane >> 4;
     double *Q = X + (size_t)nt * 16 * 64;                                       // [4*nt][64] partial ss chains
@@ -1967,11 +1973,13 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
     constexpr bool sc = SC;                                                     // the scalar wave
     const bool gauss = (E.tgt.kind == TGT_GAUSS);
     const bool cand_global = !gauss || E.tgt.pmu || E.tgt.lo || E.tgt.hi;       // prior / bounds / other targets read theta' per chain
-    constexpr int nsl = NS;
+    static_assert(!XS || (BW && NS == 4), "the fifth slot belongs to a block wave");
+    constexpr int nsl = XS ? 5 : NS, NA = XS ? 5 : 4;
     const int e0 = (16 * blk0 + lk) * 64 + (BW ? 0 : 16 * grp) + li, o0 = 16 * blk0 + lk, c0 = (BW ? 0 : 16 * grp) + li;
-#define EOFF(s, r) (e0 + (BW ? 16 : 1024) * (s) + 256 * (r))
-#define EROW(s, r) (o0 + (BW ? 0 : 16) * (s) + 4 * (r))
-#define ECH(s) (c0 + (BW ? 16 : 0) * (s))
+    const int ex = (16 * xblk + lk) * 64 + 16 * xgrp + li, ox = 16 * xblk + lk, cx = 16 * xgrp + li;      // the fifth slot
+#define EOFF(s, r) ((XS && (s) == 4) ? ex + 256 * (r) : e0 + (BW ? 16 : 1024) * (s) + 256 * (r))
+#define EROW(s, r) ((XS && (s) == 4) ? ox + 4 * (r) : o0 + (BW ? 0 : 16) * (s) + 4 * (r))
+#define ECH(s) ((XS && (s) == 4) ? cx : c0 + (BW ? 16 : 0) * (s))
     double *theta_t = E.theta + (size_t)tile * d * 64;
     double *cand_t = E.cand + (size_t)tile * d * 64;
     LaneState L;
@@ -1981,11 +1989,11 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
     // whole workgroup then waits ~2 us per product at the barrier.  Raised priority lets the chain interleave.
     if (!BW) __builtin_amdgcn_s_setprio(2);
     if (gauss) { for (int o = w * 64 + lane; o < 16 * nt; o += nw * 64) mul[o] = o < d ? g_mu[o] : 0.0; }
-    mcx_d4 cand[4], cc[4], th[4];
+    mcx_d4 cand[NA], cc[NA], th[NA];
     // The chains' state: every lane keeps the elements of its slots in registers across the sub-steps (they are the ones it
     // fills into X and the ones it replaces on an accept) and writes them back once per iteration.
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < NA; ++s)
         if (s < nsl) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) th[s][r] = theta_t[EROW(s, r) < d ? EOFF(s, r) : e0];
@@ -2007,7 +2015,7 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
             if (sc) zb[lane] = rng_normal(L.g) * (pc ? TIDX(E.qstd, tile, d, j, lane) : g_std[j]);
             __syncthreads();
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < NA; ++s) {
                 if (s < nsl) {
                     const double zj = zb[ECH(s)];
                     double uc[4];
@@ -2022,7 +2030,7 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
             }
           } else {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {                                       // X = theta
+            for (int s = 0; s < NA; ++s) {                                       // X = theta
                 if (s < nsl) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) X[EOFF(s, r)] = EROW(s, r) < d ? th[s][r] : 0.0;
@@ -2034,12 +2042,12 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
             // the sub-step's deviate is not needed before the second fill: the scalar wave draws it while the first product runs
             // (its own share of the product is one tile set) instead of holding everybody at the barrier above
             if (sc) zb[lane] = rng_normal(L.g) * g_std[j];
-            mfma_slots<BW, NS>(g_UT, X, lane, d, d4, blk0, grp, cc);           // rot = U'theta
+            mfma_slots<BW, NS, XS>(g_UT, X, lane, d, d4, blk0, grp, cc, xblk, xgrp);           // rot = U'theta
             PH(2)
             __syncthreads();
             PH(8)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < NA; ++s) {
                 if (s < nsl) {
                     const double zj = zb[ECH(s)];
 #pragma unroll
@@ -2054,12 +2062,12 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
             PH(3)
             __syncthreads();
             PH(9)
-            mfma_slots<BW, NS>(g_U, X, lane, d, d4, blk0, grp, cand);          // theta' = U rot
+            mfma_slots<BW, NS, XS>(g_U, X, lane, d, d4, blk0, grp, cand, xblk, xgrp);          // theta' = U rot
             PH(2)
           }
             if (cand_global) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                for (int s = 0; s < NA; ++s)
                     if (s < nsl) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) if (EROW(s, r) < d) cand_t[EOFF(s, r)] = cand[s][r];
@@ -2068,7 +2076,7 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
             __syncthreads();
             if (gauss) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                for (int s = 0; s < NA; ++s)
                     if (s < nsl) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { const int o = EROW(s, r); X[EOFF(s, r)] = o < d ? cand[s][r] - mul[o] : 0.0; }
@@ -2076,10 +2084,10 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
                 PH(3)
                 __syncthreads();
                 PH(10)
-                mfma_slots<BW, NS>(g_lamT, X, lane, d, d4, blk0, grp, cc);     // y = Lam v
+                mfma_slots<BW, NS, XS>(g_lamT, X, lane, d, d4, blk0, grp, cc, xblk, xgrp);     // y = Lam v
                 PH(2)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {                                   // q_(block, lane>>4) = chain over r of y v
+                for (int s = 0; s < NA; ++s) {                                   // q_(block, lane>>4) = chain over r of y v
                     if (s < nsl) {
                         double q = cc[s][0] * X[EOFF(s, 0)];
 #pragma unroll
@@ -2115,7 +2123,7 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
             PH(12)
             // accepted chains: theta = theta' (each lane its own elements; the next sub-step reloads exactly those)
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < NA; ++s)
                 if (s < nsl) {
                     const bool acc = fl[ECH(s)] != 0.0;
 #pragma unroll
@@ -2123,7 +2131,7 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
                 }
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s)                                             // the iteration's state: for the history row below, the
+        for (int s = 0; s < NA; ++s)                                             // the iteration's state: for the history row below, the
             if (s < nsl) {                                                      // pooled moments and the next launch
 #pragma unroll
                 for (int r = 0; r < 4; ++r) if (EROW(s, r) < d) theta_t[EOFF(s, r)] = th[s][r];
@@ -2184,6 +2192,31 @@ __global__ __launch_bounds__(1024, 1) void scam_pooled_kernel(EngineDev E, int i
         case 2: scam_pooled_body<false, 2, false>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
         case 3: scam_pooled_body<false, 3, false>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
         default: scam_pooled_body<false, 4, false>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
+    }
+}
+
+// The same sub-step with TWELVE waves for 13..15 output blocks (npar 193..240): every wave is a block wave (blocks 0..11, four chain
+// groups each), and the slots of the blocks 12.. -- four per block, one chain group each -- ride as a FIFTH slot on the waves 0, 1, 2, ...
+// (wave w: group w % 4 of block 12 + w / 4), so every SIMD (wave mod 4) still runs nt tile sets per product.  Three waves per SIMD have
+// 170 registers each instead of 128: the three 32-register tile sets of a block wave (state, candidate, product) no longer spill around
+// the products.  The last wave carries the per-chain scalar state on top of its block.
+__global__ __launch_bounds__(768, 1) void scam_pooled12_kernel(EngineDev E, int it0, int it1,
+                                                              const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
+                                                              const double *__restrict__ g_U, const double *__restrict__ g_UT,
+                                                              const double *__restrict__ g_std)
+{
+    extern __shared__ double X[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = 12;
+    const int nt = (E.d + 15) >> 4, nx = 4 * (nt - 12);                          // nx extra slots, on the waves 0 .. nx - 1
+    const bool xs = w < nx;
+    const int xblk = 12 + (w >> 2), xgrp = w & 3;
+    if (w == nw - 1) {
+        if (xs) scam_pooled_body<true, 4, true, true>(E, it0, it1, X, lane, w, nw, w, 0, g_mu, g_lamT, g_U, g_UT, g_std, xblk, xgrp);
+        else scam_pooled_body<true, 4, true, false>(E, it0, it1, X, lane, w, nw, w, 0, g_mu, g_lamT, g_U, g_UT, g_std);
+    } else {
+        if (xs) scam_pooled_body<true, 4, false, true>(E, it0, it1, X, lane, w, nw, w, 0, g_mu, g_lamT, g_U, g_UT, g_std, xblk, xgrp);
+        else scam_pooled_body<true, 4, false, false>(E, it0, it1, X, lane, w, nw, w, 0, g_mu, g_lamT, g_U, g_UT, g_std);
     }
 }
 

@@ -234,11 +234,15 @@ def test_pooled_scam_matches_restatement(oracle, kind):
     e.close()
 
 
-@pytest.mark.parametrize("d,extras", [(40, "s2"), (64, ""), (70, "bounds"), (100, "priors"), (130, "")])
-def test_pooled_scam_wave_layouts(oracle, d, extras):
+@pytest.mark.parametrize("d,extras", [(40, "s2"), (64, ""), (70, "bounds"), (100, "priors"), (130, ""), (200, "bounds"), (215, ""), (230, "priors"), (200, "sixteen")])
+def test_pooled_scam_wave_layouts(oracle, d, extras, monkeypatch):
     """Every split of scam_pooled_kernel's output blocks over its waves: d=40 three leftover blocks and no block wave,
     64 four block waves and nothing left over, 70 / 100 four block waves + one / three leftover blocks, 130 eight + one;
-    with the sigma2 update, box bounds and Gaussian priors (which make theta' round-trip through global memory)."""
+    200 / 215 / 230: scam_pooled12_kernel, twelve block waves with four / eight / twelve fifth slots (the last one on the
+    scalar wave, ragged last block), and 200 once more in the sixteen-wave layout; with the sigma2 update, box bounds and
+    Gaussian priors (which make theta' round-trip through global memory)."""
+    if extras == "sixteen":
+        monkeypatch.setenv("MCMCX_SCAM_POOLED_16", "1")
     from mcmcf90_amd import engine_from_problem
     N, nsimu, tick = 70, 8, 3
     rng = np.random.default_rng(d)
