@@ -290,11 +290,13 @@ static size_t lds_step(const mcmcx_engine *h) { return (h->dodr && dr_fits_lds(h
 // step_kernel_dr keeps the second stage's two vectors in LDS, step_kernel_dr_big in global scratch.  LDS pays while eight waves
 // still fit a CU (npar <= 20: 6.9e8 against 6.0e8 iterations/s at 20); beyond, the waves it costs are worth more than the bytes
 // it saves (npar 24: 3.1e8 against 4.1e8, 64: 3.2e7 / 4.6e7, 100: 0.8e7 / 1.7e7 -- tools/dr_sweep.py)
-static bool dr_vectors_in_lds(const mcmcx_engine *h)
+// (the pooled form, whose factors come through the scalar cache, is bound by that latency rather than by waves: LDS down to four
+//  waves per CU -- npar 32: 2.5e8 against 2.2e8, 50: 7.4e7 / 8.1e7, 100: 0.8e7 / 1.3e7 -- tools/pooled_dr_probe.py)
+static bool dr_vectors_in_lds(const mcmcx_engine *h, int min_waves = 8)
 {
     if (!dr_fits_lds(h)) return false;
     if (const char *e = getenv("MCMCX_DR_BIG")) return atoi(e) == 0;                  // A/B switch for tests: 1 = global scratch, 0 = LDS
-    return lds_bytes(h) * 8 <= 160 * 1024;
+    return lds_bytes(h) * (size_t)min_waves <= 160 * 1024;
 }
 static void launch_init(mcmcx_engine *h)
 { hipLaunchKernelGGL(init_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E); }
@@ -305,6 +307,7 @@ static void launch_step(mcmcx_engine *h, int it0, int it1)
     const dim3 g(h->ntiles), b(64);
     const double *rs = h->d_ramscale + it0;
     if (pooled_use_mfma(h)) LAUNCHK(pooled_mfma_kernel, g, b, pooled_mfma_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedRT);
+    else if (h->pooled && h->dodr && !dr_vectors_in_lds(h, 4)) LAUNCHK(step_kernel_pooled_dr_big, g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR, h->d_sharedR2, h->d_sharediC);
     else if (h->pooled && h->dodr) LAUNCHK(step_kernel_pooled_dr, g, b, lds_step(h), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR, h->d_sharedR2, h->d_sharediC);
     else if (h->pooled) LAUNCHK((step_kernel<false, false, true>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->E.method == M_RAM && h->usesvd) LAUNCHK(step_kernel_ram_fullr, g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
@@ -1227,7 +1230,6 @@ int mcmcx_init(mcmcx_handle h)
     if (h->tkind == TGT_EXPCOLS && h->tncols != ny) return fail(-36, "response-column target: mcmcx_set_sigma2nobs must give one sigma2 / nobs per column");
     if (ny > 1 && h->pooled) return fail(-36, "nycol > 1 is not available in pooled mode");
     if (h->tkind < 0) return fail(-31, "no target: the device engine needs mcmcx_set_target_*");
-    if (h->dodr && h->pooled && !dr_fits_lds(h)) return fail(-35, "pooled mode with delayed rejection keeps two npar-vectors per chain in LDS: npar <= 160 (per-chain factors have no such limit)");
     std::vector<double> Rp, Cp, Rfull, qstd0;
     int info = host_initial_R(d, h->cmat0, Rp, Cp);
     if (h->usesvd) {                                                                  // Cp (packed cmat0) is still needed
@@ -1293,6 +1295,8 @@ int mcmcx_init(mcmcx_handle h)
     if ((rc = dev_alloc(h, &E.cand, L * d))) return rc;
     if ((rc = dev_alloc(h, &E.zs, L * 2 * d))) return rc;
     if ((rc = dev_alloc(h, &E.cs, L * 2 * d))) return rc;
+    E.xscr = nullptr;
+    if (h->pooled && h->dodr && (rc = dev_alloc(h, &E.xscr, L * 2 * d))) return rc;      // step_kernel_pooled_dr_big's quadratic-form vectors
     if ((rc = dev_alloc(h, &E.scal, L * NSCAL))) return rc;
     if ((rc = dev_alloc(h, &E.ictr, L * NICTR))) return rc;
     if ((rc = dev_alloc(h, &E.rngn, L))) return rc;

@@ -59,6 +59,7 @@ struct EngineDev {
     DevTarget tgt;
     // state, tile-interleaved
     double *theta, *cand, *zs, *cs, *scal, *R, *R2, *iC, *Rtmp;   // cand/zs [d], cs [2d]: per-chain scratch vectors
+    double *xscr;               // [2d] per chain: the two quadratic-form vectors of pooled delayed rejection when LDS would cost waves (step_kernel_pooled_dr_big)
     double *cmat, *mean, *basetheta;
     const double *cmat0p, *par0;    // packed upper cmat0 [P], par0 [d] (shared by all chains)
     uint32_t *ictr;
@@ -1255,14 +1256,16 @@ MCX_DEV double quadform_sym_shared(const double *__restrict__ Ss, int lane, int 
 // Iterations it0..it1 (absolute simuind) of MCMC_run (MCMC_run.F90:41-107) or MCMC_run_ram
 // (MCMC_run_ram.F90:45-81) for one tile of 64 chains.  LDS is used only by the delayed-rejection
 // quadratic forms (2*d*64 doubles when dodr, none otherwise).
-template <bool RAM, bool DR, bool POOLED, bool WIDE_T = (RAM || (!DR && !POOLED)), bool FULLR = false, bool LDSV = false, bool LDSR = false>
+template <bool RAM, bool DR, bool POOLED, bool WIDE_T = (RAM || (!DR && !POOLED)), bool FULLR = false, bool LDSV = false, bool LDSR = false, bool XG = false>
 MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__restrict__ ramscale,
                        const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
                        const double *__restrict__ g_sharedR, const double *__restrict__ g_sharedR2 = nullptr,
                        const double *__restrict__ g_sharediC = nullptr)
 {
-    extern __shared__ double X[];
+    extern __shared__ double Xlds[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
+    // the delayed-rejection quadratic forms' two vectors: LDS, or (XG, a compile-time choice: no flat accesses) the chain's global scratch
+    double *X = XG ? E.xscr + (size_t)tile * 2 * d * 64 : Xlds;
     constexpr bool ldsv = LDSV && !RAM && !DR && !POOLED;                // step_kernel_ldsv: launched with 4 d x 512 bytes of LDS (a compile-time
                                                                         // choice, so that the vectors' accesses are ds_read / ds_write, not flat)
     // step_kernel_ldsr (npar <= TW): besides the state, the chain's packed factor stays in LDS for the launch -- AM only reads
@@ -1646,6 +1649,13 @@ __global__ __launch_bounds__(64, 2) void step_kernel_pooled_dr(EngineDev E, int 
                                                                const double *__restrict__ g_sharedR, const double *__restrict__ g_sharedR2,
                                                                const double *__restrict__ g_sharediC)
 { step_body<false, true, true, false>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR, g_sharedR2, g_sharediC); }
+// ... with the two quadratic-form vectors in global scratch (EngineDev::xscr): above npar 20 the LDS form costs waves (51 KiB per wave
+// at npar 50: three waves per CU), and above 160 it does not fit at all
+__global__ __launch_bounds__(64, 2) void step_kernel_pooled_dr_big(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
+                                                                   const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
+                                                                   const double *__restrict__ g_sharedR, const double *__restrict__ g_sharedR2,
+                                                                   const double *__restrict__ g_sharediC)
+{ step_body<false, true, true, false, false, false, false, true>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR, g_sharedR2, g_sharediC); }
 
 // method='ram' with condmax > 0: the factor is the full SVD one (E.Rf), proposals are matmulx(R,u), the rank-one
 // adaptation runs on its upper triangle (ram_update_full)

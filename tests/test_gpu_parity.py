@@ -272,10 +272,10 @@ def test_sizes_beyond_the_limits_fail_loudly():
     from mcmcf90_amd import make_config, Engine, McmcError
     with pytest.raises(McmcError):
         Engine(make_config(257, 1, nsimu=10))
-    e = Engine(make_config(200, 4, nsimu=10, drscale=2.0, pooled=1))   # the pooled extension keeps its DR vectors in LDS (npar <= 160);
-    e.setpar0(np.zeros(200)); e.set_target("banana", b=0.1)           # per-chain DR has no such limit (test_extreme_dimensions)
-    with pytest.raises(McmcError):
-        e.init()
+    e = Engine(make_config(200, 4, nsimu=10, drscale=2.0, pooled=1))   # pooled delayed rejection beyond 160 (where its two vectors no longer fit
+    e.setpar0(np.zeros(200)); e.set_target("banana", b=0.1)           # the LDS) runs on global scratch since round 3: no limit of its own
+    e.init(); e.run()
+    assert e.last_kernel() == "step_kernel_pooled_dr_big"
     e.close()
 
 

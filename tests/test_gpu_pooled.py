@@ -439,6 +439,8 @@ def test_pooled_burnin_greedy_ap_match_restatement(oracle, name, extra, c0):
     pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.3), cmat0=c0 * np.eye(d), mu=np.linspace(-1, 1, d), lam=np.linalg.inv(S))
     e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
     e.init(); e.run()
+    if "dr" in name:
+        assert e.last_kernel() == ("step_kernel_pooled_dr" if (d <= 40 and name != "dr_am_global_scratch") else "step_kernel_pooled_dr_big")
     chains, st, log = _restate_pooled(oracle, ckw, pkw, N)
     kinds = {k for _, k in log}
     want = {"scale_up": "up", "scale_down": "down", "refactor": "refactor", "greedy": "greedy", "ap": "ap", "adaptend": "am"}[name]
@@ -464,12 +466,26 @@ def test_pooled_burnin_greedy_ap_match_restatement(oracle, name, extra, c0):
     ("dr_updatesigma", dict(drscale=2.0, updatesigma=1), 0.3, "gauss"),
     ("er", dict(method="er"), 0.05, "gauss"),                                                            # MCMC_run_er with the shared factor
     ("er_updatesigma", dict(method="er", updatesigma=1), 0.05, "gauss"),
+    ("dr_am_global_scratch", dict(drscale=2.0), 0.3, "gauss"),           # npar 5 forced onto step_kernel_pooled_dr_big (MCMCX_DR_BIG=1)
+    ("dr_am_37", dict(drscale=2.0), 0.3, "gauss"),                       # npar 37: still the LDS form (four waves per CU)
+    ("dr_am_57", dict(drscale=2.0), 0.3, "gauss"),                       # npar 57: the engine's own choice of the global-scratch form
+    ("dr_am_170", dict(drscale=2.0), 0.3, "gauss"),                      # npar 170: beyond what the LDS form could hold at all
 ])
-def test_pooled_delayed_rejection_and_er_match_restatement(oracle, name, extra, c0, kind):
+def test_pooled_delayed_rejection_and_er_match_restatement(oracle, name, extra, c0, kind, monkeypatch):
     """pooled = 1 with drscale > 0 (one R2 = R / drscale and one iC = dpotri(R) for every chain, recomputed at each pooled
-    tick, scaled in place by the burn-in branch as MCMC_adapt.F90:66-78 does) and with method = 'er'."""
+    tick, scaled in place by the burn-in branch as MCMC_adapt.F90:66-78 does) and with method = 'er'; the quadratic-form
+    vectors of the second stage in LDS (npar <= 40) or in global scratch."""
     from mcmcf90_amd import engine_from_problem
     d, N, nsimu = 5, 130, 420
+    if name == "dr_am_global_scratch":
+        monkeypatch.setenv("MCMCX_DR_BIG", "1")
+    if name == "dr_am_37":
+        d, N, nsimu = 37, 70, 230
+    if name == "dr_am_57":
+        d, N, nsimu = 57, 70, 230
+    if name == "dr_am_170":
+        d, N, nsimu = 170, 70, 120
+        c0 = 0.3 / d
     ckw = dict(dict(nsimu=nsimu, adaptint=100, updatesigma=0), **extra)
     S = 0.5 ** np.abs(np.subtract.outer(np.arange(d), np.arange(d)))
     if kind == "gauss":
@@ -478,6 +494,8 @@ def test_pooled_delayed_rejection_and_er_match_restatement(oracle, name, extra, 
         pkw = dict(kind="banana", npar=d, par0=np.zeros(d), cmat0=c0 * np.eye(d), b=0.1)
     e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
     e.init(); e.run()
+    if "dr" in name:
+        assert e.last_kernel() == ("step_kernel_pooled_dr" if (d <= 40 and name != "dr_am_global_scratch") else "step_kernel_pooled_dr_big")
     chains, st, log = _restate_pooled(oracle, ckw, pkw, N)
     kinds = {k for _, k in log}
     if "scale_down" in name: assert "down" in kinds, log
@@ -494,7 +512,7 @@ def test_pooled_delayed_rejection_and_er_match_restatement(oracle, name, extra, 
         np.testing.assert_array_equal(_bits(np.triu(R2)), _bits(np.triu(st["R2"])))
         np.testing.assert_array_equal(_bits(np.triu(iC)), _bits(np.triu(st["iC"])))
         assert tot["drtries"] == sum(ch.drtries for ch in chains) and tot["drtries"] > 0
-        assert tot["draccepted"] == sum(ch.draccepted for ch in chains) and tot["draccepted"] > 0
+        assert tot["draccepted"] == sum(ch.draccepted for ch in chains) and (tot["draccepted"] > 0 or d > 100)
     else:
         for c in (0, 63, 64, N - 1):
             assert e.counters(c)["erstayed"] == chains[c].erstayed
