@@ -75,6 +75,7 @@ struct mcmcx_engine {
     double *d_sharedR2 = nullptr, *d_sharediC = nullptr;
     double *d_sharedU = nullptr;                      // [U col-major | pad | U row-major | pad | std]
     double *d_sharedRT = nullptr;                     // pooled AM on the matrix cores: dense R, M[s*d + o] = R(s,o), zero below the diagonal and in the pad rows
+    double *d_sharedR2T = nullptr, *d_sharediCd = nullptr;   // ... with delayed rejection: R2 in the same form, iC dense and symmetric
     double *d_sharedR = nullptr; mcmcx_exchange_t xfn = nullptr; void *xuser = nullptr; double *xbuf = nullptr;
     struct mcmcx_comm *comm = nullptr;                // the node's communicator (mcx_comm.hpp); nullptr = this GPU alone
     double *d_gather = nullptr, *d_pooled = nullptr;  // [nranks][len + 1] per-rank moment vectors (+ the rank's stop flag), [len + 1] their tree sum
@@ -279,7 +280,13 @@ static size_t pooled_mfma_lds(int d)
 }
 static bool pooled_use_mfma(const mcmcx_engine *h)
 {
-    if (!h->pooled || h->dodr || (h->cfg.method != MCMCX_METHOD_DRAM && h->cfg.method != MCMCX_METHOD_RAM)) return false;   // DR and ER: the lane-per-chain kernel
+    if (!h->pooled || (h->cfg.method != MCMCX_METHOD_DRAM && h->cfg.method != MCMCX_METHOD_RAM)) return false;   // ER: the lane-per-chain kernel
+    if (h->dodr) {                                                                                                   // DR: with its dense tables, and above
+        if (h->cfg.method != MCMCX_METHOD_DRAM || !h->d_sharedR2T) return false;                                     // npar 20 (8.3e8 against 8.9e8 iterations/s
+        int dmin = 21;                                                                                               // for the lane kernel with its LDS vectors at 20;
+        if (const char *e = getenv("MCMCX_POOLED_MFMA_DR_MIN")) dmin = atoi(e);                                      // 32: 5.6e8 / 2.5e8, 50: 3.2e8 / 0.8e8)
+        if (h->d < dmin) return false;
+    }
     if (const char *e = getenv("MCMCX_POOLED_SCALAR")) if (atoi(e)) return false;      // A/B switch for tests: the lane-per-chain kernel
     return pooled_mfma_lds(h->d) <= 160 * 1024;
 }
@@ -306,7 +313,8 @@ static void launch_step(mcmcx_engine *h, int it0, int it1)
 {
     const dim3 g(h->ntiles), b(64);
     const double *rs = h->d_ramscale + it0;
-    if (pooled_use_mfma(h)) LAUNCHK(pooled_mfma_kernel, g, b, pooled_mfma_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedRT);
+    if (pooled_use_mfma(h) && h->dodr) LAUNCHK(pooled_mfma_kernel<true>, g, b, pooled_mfma_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedRT, h->d_sharedR2T, h->d_sharediCd);
+    else if (pooled_use_mfma(h)) LAUNCHK(pooled_mfma_kernel<false>, g, b, pooled_mfma_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedRT, (const double *)nullptr, (const double *)nullptr);
     else if (h->pooled && h->dodr && !dr_vectors_in_lds(h, 4)) LAUNCHK(step_kernel_pooled_dr_big, g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR, h->d_sharedR2, h->d_sharediC);
     else if (h->pooled && h->dodr) LAUNCHK(step_kernel_pooled_dr, g, b, lds_step(h), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR, h->d_sharedR2, h->d_sharediC);
     else if (h->pooled) LAUNCHK((step_kernel<false, false, true>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
@@ -637,6 +645,16 @@ static int pooled_upload_dr(mcmcx_engine *h, bool fresh)
     HIPCHK(hipMemcpyAsync(h->d_sharedR2, r2.data(), r2.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_sharediC, h->pool_iC.data(), (size_t)P * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->d_sharedR2T) {                                  // pooled_mfma_kernel<true>: R2 like d_sharedRT (M[s*d + o] = R2(s,o)), iC dense symmetric
+        const int d4 = (d + 3) & ~3;
+        std::vector<double> m((size_t)d4 * d + PWS, 0.0), q((size_t)d4 * d + PWS, 0.0);
+        if (h->usesvd) memcpy(m.data(), h->pool_R2.data(), (size_t)d * d * 8);          // the full factor as it stands: M[s*d + o] = R2f(o, s)
+        else for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) m[(size_t)i * d + j] = h->pool_R2[h_pidx(i, j, d)];
+        for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) { const double v = h->pool_iC[h_pidx(i, j, d)]; q[(size_t)i * d + j] = v; q[(size_t)j * d + i] = v; }
+        HIPCHK(hipMemcpyAsync(h->d_sharedR2T, m.data(), m.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_sharediCd, q.data(), q.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     return 0;
 }
 
@@ -1436,6 +1454,11 @@ int mcmcx_init(mcmcx_handle h)
                 if (h->usesvd) { h->pool_R2 = Rfull; for (auto &v : h->pool_R2) v = v / c.drscale; } else h->pool_R2 = R2p;
                 if ((rc = dev_alloc(h, &h->d_sharedR2, h->usesvd ? (size_t)((d + 3) & ~3) * d + PWS : (size_t)P, false))) return rc;
                 if ((rc = dev_alloc(h, &h->d_sharediC, (size_t)P, false))) return rc;
+                if (c.method == MCMCX_METHOD_DRAM && h->d_sharedRT && pooled_mfma_lds(d) <= 160 * 1024 &&
+                    !(getenv("MCMCX_POOLED_SCALAR") && atoi(getenv("MCMCX_POOLED_SCALAR")))) {          // the second stage on the matrix cores too
+                    if ((rc = dev_alloc(h, &h->d_sharedR2T, (size_t)((d + 3) & ~3) * d + PWS, false))) return rc;
+                    if ((rc = dev_alloc(h, &h->d_sharediCd, (size_t)((d + 3) & ~3) * d + PWS, false))) return rc;
+                }
                 if ((rc = pooled_upload_dr(h, false))) return rc;
             } else {
             if ((rc = dev_bcast(h, E.R2, R2p))) return rc;

@@ -2269,9 +2269,16 @@ MCX_DEV void mfma_wave_product(const double *__restrict__ M, const double *X, in
     }
 }
 
+// DR: delayed rejection's second stage on the same cores (drscale > 0): the stage-2 proposal with the shared R2 = R / drscale
+// (g_R2T, dense like g_RT), the target once more, and the two quadratic forms dx' iC dx of MCMC_DR_alpha13 as y = iC dx
+// products against the dense symmetric table g_iCd, each followed by the chain q = sum_i y_i dx_i ascending in i (lane = chain:
+// y comes back through the LDS vector, dx waits in the chain's global scratch EngineDev::xscr).  Operation for operation
+// step_body<false, true, true> (the lane-per-chain form with the tables through the scalar cache), whose chains these are.
+template <bool DR>
 __global__ __launch_bounds__(64) void pooled_mfma_kernel(EngineDev E, int it0, int it1,
                                                          const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
-                                                         const double *__restrict__ g_RT)
+                                                         const double *__restrict__ g_RT, const double *__restrict__ g_R2T,
+                                                         const double *__restrict__ g_iCd)
 {
     extern __shared__ double X[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
@@ -2283,22 +2290,18 @@ __global__ __launch_bounds__(64) void pooled_mfma_kernel(EngineDev E, int it0, i
     double *Q = single ? X : T + (size_t)nt * 16 * 64;             // [4 nt][64] partial ss chains
     double *theta_t = E.theta + (size_t)tile * d * 64;
     double *cand_t = E.cand + (size_t)tile * d * 64;
+    double *c2_t = E.cs + (size_t)tile * 2 * d * 64;               // DR: the second-stage candidate
+    double *xs_t = DR ? E.xscr + (size_t)tile * 2 * d * 64 : nullptr;   // DR: dx of the quadratic form in flight
     const bool gauss = (E.tgt.kind == TGT_GAUSS);
     LaneState L;
     lane_load(E, tile, lane, L);
     mcx_d4 c[4][4];
-    for (int it = it0; it <= it1; ++it) {
-        // ---- newpar = MCMC_propose(oldpar, R): z straight into the LDS vector, P = R'z on the matrix cores
-        gen_normals<MCX_POOLED_NB>(L.g, X, lane, d, true);
-        if (it == it1) {                                               // the launch's last normals stay readable (pooled RAM statistic)
-            double *zk = E.zs + ((size_t)tile * 2 + (it & 1)) * d * 64;
-            for (int k = 0; k < d; ++k) GV(zk, k) = XL(k);
-        }
-        for (int k = d; k < d4; ++k) XL(k) = 0.0;
+    // out = M' X on the matrix cores, into T in (row, chain) order; tri: M is upper triangular (rows beyond a block's last column are zero)
+    auto product_to_T = [&](const double *__restrict__ M, bool tri) {
         for (int ob0 = 0; ob0 < nt; ob0 += 4) {
             const int nb = (nt - ob0) < 4 ? (nt - ob0) : 4;
-            if (E.usesvd) mfma_wave_product<false>(g_RT, X, lane, d, d4, ob0, nb, c);        // the full SVD factor (condmax > 0)
-            else mfma_wave_product<true>(g_RT, X, lane, d, d4, ob0, nb, c);
+            if (tri) mfma_wave_product<true>(M, X, lane, d, d4, ob0, nb, c);
+            else mfma_wave_product<false>(M, X, lane, d, d4, ob0, nb, c);
 #pragma unroll
             for (int b = 0; b < 4; ++b)
                 if (b < nb) {
@@ -2312,7 +2315,38 @@ __global__ __launch_bounds__(64) void pooled_mfma_kernel(EngineDev E, int it0, i
                     }
                 }
         }
-        // ---- candidate (lane = chain), and v = theta' - mu back into the LDS vector for the target
+    };
+    // ss of the Gaussian target for the vector v = x - mu in X (mcxt_ss_gauss): y = Lam v on the matrix cores, the partial chains
+    // q over r of y v in the lanes that hold them, their sum per chain
+    auto gauss_ss = [&]() -> double {
+        for (int k = d; k < d4; ++k) XL(k) = 0.0;
+        for (int ob0 = 0; ob0 < nt; ob0 += 4) {
+            const int nb = (nt - ob0) < 4 ? (nt - ob0) : 4;
+            mfma_wave_product<false>(g_lamT, X, lane, d, d4, ob0, nb, c);       // y = Lam v
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (b < nb) {
+                    const int o0 = 16 * (ob0 + b) + lk;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {                               // q = chain over r of y v (mcxt_ss_gauss)
+                        double q = c[b][g][0] * X[(size_t)o0 * 64 + 16 * g + li];
+#pragma unroll
+                        for (int r = 1; r < 4; ++r) {
+                            const int o = o0 + 4 * r;
+                            const double t = dfma(c[b][g][r], X[(size_t)(o < d4 ? o : 0) * 64 + 16 * g + li], q);
+                            q = (o < d) ? t : q;
+                        }
+                        if (o0 < d) Q[(size_t)(4 * (ob0 + b) + lk) * 64 + 16 * g + li] = q;
+                    }
+                }
+        }
+        double ss = Q[lane];
+#pragma unroll 4
+        for (int e = 1; e < 4 * nt; ++e) if (16 * (e >> 2) + (e & 3) < d) ss = ss + Q[(size_t)e * 64 + lane];
+        return ss;
+    };
+    // dst = theta + T (lane = chain), and v = dst - mu back into the LDS vector for the Gaussian target
+    auto candidate_from_T = [&](double *dst_t) {
         for (int k0 = 0; k0 < d; k0 += 8) {              // eight state elements' loads before the eight stores (see copy_vec)
             double th[8], tv[8];
 #pragma unroll
@@ -2321,48 +2355,73 @@ __global__ __launch_bounds__(64) void pooled_mfma_kernel(EngineDev E, int it0, i
             for (int u = 0; u < 8; ++u) {
                 if (k0 + u < d) {
                     const double cnd = th[u] + tv[u];
-                    GV(cand_t, k0 + u) = cnd;
+                    GV(dst_t, k0 + u) = cnd;
                     if (gauss) XL(k0 + u) = cnd - g_mu[k0 + u];
                 }
             }
         }
+    };
+    for (int it = it0; it <= it1; ++it) {
+        // ---- newpar = MCMC_propose(oldpar, R): z straight into the LDS vector, P = R'z on the matrix cores
+        gen_normals<MCX_POOLED_NB>(L.g, X, lane, d, true);
+        if (it == it1) {                                               // the launch's last normals stay readable (pooled RAM statistic)
+            double *zk = E.zs + ((size_t)tile * 2 + (it & 1)) * d * 64;
+            for (int k = 0; k < d; ++k) GV(zk, k) = XL(k);
+        }
+        for (int k = d; k < d4; ++k) XL(k) = 0.0;
+        product_to_T(g_RT, !E.usesvd);                                 // (condmax > 0: the full SVD factor)
+        candidate_from_T(cand_t);
         bool inb = target_inbounds(E.tgt, d, lane, cand_t);
         double pri2 = target_prior(E.tgt, d, lane, cand_t);
-        double ss2 = 0.0;
-        if (gauss) {
-            for (int k = d; k < d4; ++k) XL(k) = 0.0;
-            for (int ob0 = 0; ob0 < nt; ob0 += 4) {
-                const int nb = (nt - ob0) < 4 ? (nt - ob0) : 4;
-                mfma_wave_product<false>(g_lamT, X, lane, d, d4, ob0, nb, c);       // y = Lam v
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    if (b < nb) {
-                        const int o0 = 16 * (ob0 + b) + lk;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {                               // q = chain over r of y v (mcxt_ss_gauss)
-                            double q = c[b][g][0] * X[(size_t)o0 * 64 + 16 * g + li];
-#pragma unroll
-                            for (int r = 1; r < 4; ++r) {
-                                const int o = o0 + 4 * r;
-                                const double t = dfma(c[b][g][r], X[(size_t)(o < d4 ? o : 0) * 64 + 16 * g + li], q);
-                                q = (o < d) ? t : q;
-                            }
-                            if (o0 < d) Q[(size_t)(4 * (ob0 + b) + lk) * 64 + 16 * g + li] = q;
-                        }
-                    }
-            }
-            ss2 = Q[lane];
-#pragma unroll 4
-            for (int e = 1; e < 4 * nt; ++e) if (16 * (e >> 2) + (e & 3) < d) ss2 = ss2 + Q[(size_t)e * 64 + lane];
-        } else ss2 = target_ss<false>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
+        double ss2 = gauss ? gauss_ss() : target_ss<false>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
         // ---- alpha, reject (MCMC_run.F90:47-63), as in step_kernel
         bool reject;
-        if (!inb) { L.bnd += 1; reject = true; L.alpha12 = 0.0; }
+        if (!inb) { if (!DR) L.bnd += 1; reject = true; L.alpha12 = 0.0; }
         else {
             L.alpha12 = d_alpha(L.ss1, L.pri1, ss2, pri2, L.sigma2);
             reject = true;
             if (L.alpha12 >= 1.0) reject = false;
             else if (L.alpha12 > 0.0) { double u = rng_uniform(L.g); if (u <= L.alpha12) reject = false; }
+        }
+        // ---- second stage: one delayed-rejection try with R2 = R/drscale (MCMC_run.F90:65-91)
+        bool dr_moved = false;
+        if (DR && __any(reject)) {
+            const bool m = reject;
+            if (m) L.drtries += 1;
+            gen_normals<MCX_POOLED_NB>(L.g, X, lane, d, m);            // lanes that did not draw compute on stale values and are not looked at
+            for (int k = d; k < d4; ++k) XL(k) = 0.0;
+            product_to_T(g_R2T, !E.usesvd);
+            candidate_from_T(c2_t);
+            const bool inb2 = target_inbounds(E.tgt, d, lane, c2_t);
+            const double pri3 = target_prior(E.tgt, d, lane, c2_t);
+            const double ss3 = gauss ? gauss_ss() : target_ss<false>(E.tgt, d, lane, c2_t, g_mu, g_lamT);
+            double qf[2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {                              // qa: dx = newpar2 - newpar, qb: dx = oldpar - newpar (MCMC_DRAM.F90:180-182)
+                const double *a_t = f == 0 ? c2_t : theta_t;
+                for (int k = 0; k < d; ++k) { const double dx = GV(a_t, k) - GV(cand_t, k); XL(k) = dx; GV(xs_t, k) = dx; }
+                for (int k = d; k < d4; ++k) XL(k) = 0.0;
+                product_to_T(g_iCd, false);                            // y = iC dx
+                double q = 0.0;
+                for (int i = 0; i < d; ++i) q = q + T[(size_t)i * 64 + lane] * GV(xs_t, i);
+                qf[f] = q;
+            }
+            if (m) {
+                if (!inb2) L.bnd += 1;
+                else {
+                    // MCMC_DR_alpha13, MCMC_DRAM.F90:162-186
+                    double alpha32;
+                    if (L.alpha12 == 0.0) alpha32 = 0.0;
+                    else alpha32 = min1(d_exp(-0.5 * ((ss2 - ss3) / L.sigma2 + (pri2 - pri3))));
+                    const double l2 = -0.5 * ((ss3 - L.ss1) / L.sigma2 + (pri3 - L.pri1));
+                    const double q1 = -0.5 * (qf[0] - qf[1]);
+                    const double alpha13 = min1(d_exp(l2 + q1) * (1.0 - alpha32) / (1.0 - L.alpha12));
+                    bool rej2 = true;
+                    if (alpha13 >= 1.0) rej2 = false;
+                    else if (alpha13 > 0.0) { double u = rng_uniform(L.g); if (u <= alpha13) rej2 = false; }
+                    if (!rej2) { L.dracc += 1; reject = false; dr_moved = true; ss2 = ss3; pri2 = pri3; }
+                }
+            }
         }
         if (reject) { L.stayed += 1; L.curcount += 1; }
         else { L.ss1 = ss2; L.pri1 = pri2; L.chainind += 1; L.curcount = 1; }
@@ -2374,7 +2433,7 @@ __global__ __launch_bounds__(64) void pooled_mfma_kernel(EngineDev E, int it0, i
         const int slot = it % E.wcap;
         if (!reject) {
             double *h = E.hist ? E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64 : nullptr;
-            copy_vec(theta_t, cand_t, h, lane, d);
+            copy_vec(theta_t, dr_moved ? c2_t : cand_t, h, lane, d);   // newpar = newpar2 when the DR try was accepted
             if (h) GV(h, d) = L.ss1;
         }
         if (E.hist) {

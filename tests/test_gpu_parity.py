@@ -275,7 +275,7 @@ def test_sizes_beyond_the_limits_fail_loudly():
     e = Engine(make_config(200, 4, nsimu=10, drscale=2.0, pooled=1))   # pooled delayed rejection beyond 160 (where its two vectors no longer fit
     e.setpar0(np.zeros(200)); e.set_target("banana", b=0.1)           # the LDS) runs on global scratch since round 3: no limit of its own
     e.init(); e.run()
-    assert e.last_kernel() == "step_kernel_pooled_dr_big"
+    assert e.last_kernel() == "step_kernel_pooled_dr_big"      # (the matrix-core form stops where its LDS does, below npar 200)
     e.close()
 
 

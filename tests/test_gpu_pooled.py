@@ -440,7 +440,8 @@ def test_pooled_burnin_greedy_ap_match_restatement(oracle, name, extra, c0):
     e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
     e.init(); e.run()
     if "dr" in name:
-        assert e.last_kernel() == ("step_kernel_pooled_dr" if (d <= 40 and name != "dr_am_global_scratch") else "step_kernel_pooled_dr_big")
+        assert e.last_kernel() == ("pooled_mfma_kernel<true>" if (not scalar and d <= 140) else        # (its LDS ends at npar ~140)
+                                   "step_kernel_pooled_dr" if (d <= 40 and name != "dr_am_global_scratch") else "step_kernel_pooled_dr_big")
     chains, st, log = _restate_pooled(oracle, ckw, pkw, N)
     kinds = {k for _, k in log}
     want = {"scale_up": "up", "scale_down": "down", "refactor": "refactor", "greedy": "greedy", "ap": "ap", "adaptend": "am"}[name]
@@ -470,13 +471,25 @@ def test_pooled_burnin_greedy_ap_match_restatement(oracle, name, extra, c0):
     ("dr_am_37", dict(drscale=2.0), 0.3, "gauss"),                       # npar 37: still the LDS form (four waves per CU)
     ("dr_am_57", dict(drscale=2.0), 0.3, "gauss"),                       # npar 57: the engine's own choice of the global-scratch form
     ("dr_am_170", dict(drscale=2.0), 0.3, "gauss"),                      # npar 170: beyond what the LDS form could hold at all
+    ("dr_am_130_priors", dict(drscale=2.0), 0.3, "gauss"),               # npar 130: the matrix-core form in two passes, priors and bounds
+    ("dr_banana_24", dict(drscale=3.0), 1.0, "banana"),                  # a non-Gaussian target between the products
 ])
-def test_pooled_delayed_rejection_and_er_match_restatement(oracle, name, extra, c0, kind, monkeypatch):
+@pytest.mark.parametrize("scalar", [0, 1], ids=["matrix_cores", "lane_kernels"])
+def test_pooled_delayed_rejection_and_er_match_restatement(oracle, name, extra, c0, kind, scalar, monkeypatch):
     """pooled = 1 with drscale > 0 (one R2 = R / drscale and one iC = dpotri(R) for every chain, recomputed at each pooled
-    tick, scaled in place by the burn-in branch as MCMC_adapt.F90:66-78 does) and with method = 'er'; the quadratic-form
-    vectors of the second stage in LDS (npar <= 40) or in global scratch."""
+    tick, scaled in place by the burn-in branch as MCMC_adapt.F90:66-78 does) and with method = 'er'.  Delayed rejection on the
+    matrix cores (pooled_mfma_kernel<true>: both stages' proposals, the Gaussian target and the two quadratic forms as products
+    against the shared tables) and in the lane-per-chain kernels, their quadratic-form vectors in LDS (npar <= 40) or global scratch."""
     from mcmcf90_amd import engine_from_problem
     d, N, nsimu = 5, 130, 420
+    if scalar:
+        if "dr" not in name:
+            pytest.skip("early rejection has one pooled kernel")
+        monkeypatch.setenv("MCMCX_POOLED_SCALAR", "1")         # the lane-per-chain kernels (shared tables through the scalar cache)
+    elif name == "dr_am_global_scratch":
+        pytest.skip("a switch of the lane-per-chain kernels")
+    else:
+        monkeypatch.setenv("MCMCX_POOLED_MFMA_DR_MIN", "1")    # the matrix-core form at npar 5 too (the engine's own choice starts at 21)
     if name == "dr_am_global_scratch":
         monkeypatch.setenv("MCMCX_DR_BIG", "1")
     if name == "dr_am_37":
@@ -486,16 +499,24 @@ def test_pooled_delayed_rejection_and_er_match_restatement(oracle, name, extra, 
     if name == "dr_am_170":
         d, N, nsimu = 170, 70, 120
         c0 = 0.3 / d
+    if name == "dr_am_130_priors":
+        d, N, nsimu = 130, 70, 120
+        c0 = 0.3 / d
+    if name == "dr_banana_24":
+        d, N, nsimu = 24, 70, 230
     ckw = dict(dict(nsimu=nsimu, adaptint=100, updatesigma=0), **extra)
     S = 0.5 ** np.abs(np.subtract.outer(np.arange(d), np.arange(d)))
     if kind == "gauss":
         pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.3), cmat0=c0 * np.eye(d), mu=np.linspace(-1, 1, d), lam=np.linalg.inv(S))
+        if "priors" in name:
+            pkw.update(pri_mu=np.zeros(d), pri_sig=np.where(np.arange(d) % 3 == 0, 0.0, 2.0), lo=np.full(d, -3.0), hi=np.full(d, 3.0))
     else:
         pkw = dict(kind="banana", npar=d, par0=np.zeros(d), cmat0=c0 * np.eye(d), b=0.1)
     e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
     e.init(); e.run()
     if "dr" in name:
-        assert e.last_kernel() == ("step_kernel_pooled_dr" if (d <= 40 and name != "dr_am_global_scratch") else "step_kernel_pooled_dr_big")
+        assert e.last_kernel() == ("pooled_mfma_kernel<true>" if (not scalar and d <= 140) else        # (its LDS ends at npar ~140)
+                                   "step_kernel_pooled_dr" if (d <= 40 and name != "dr_am_global_scratch") else "step_kernel_pooled_dr_big")
     chains, st, log = _restate_pooled(oracle, ckw, pkw, N)
     kinds = {k for _, k in log}
     if "scale_down" in name: assert "down" in kinds, log
@@ -622,7 +643,8 @@ def test_pooled_ram_matches_restatement(oracle, d, N, mfma, condmax, monkeypatch
 
 
 @pytest.mark.parametrize("mfma,condmax,burn,drscale", [(1, 1e8, 0, 0.0), (0, 1e8, 0, 0.0), (1, 40.0, 0, 0.0), (0, 40.0, 1, 0.0),
-                                                       (0, 1e8, 0, 2.0), (0, 40.0, 1, 2.0)])     # + delayed rejection: R2 full, iC from R's upper triangle
+                                                       (0, 1e8, 0, 2.0), (0, 40.0, 1, 2.0),      # + delayed rejection: R2 full, iC from R's upper triangle
+                                                       (1, 1e8, 0, 2.0), (1, 40.0, 1, 2.0)])     # ... and its second stage on the matrix cores
 def test_pooled_am_with_svd_factor_matches_restatement(oracle, mfma, condmax, burn, drscale, monkeypatch):
     """pooled = 1 with condmax > 0 (method dram): the shared factor is covtor_svd's full matrix U sqrt(s) 2.4/sqrt(d)
     (matutils.F90:378-453) of the pooled covariance, proposals are matmulx(R, z); condmax = 40 makes the singular-value
@@ -630,6 +652,8 @@ def test_pooled_am_with_svd_factor_matches_restatement(oracle, mfma, condmax, bu
     from mcmcf90_amd import engine_from_problem
     if not mfma:
         monkeypatch.setenv("MCMCX_POOLED_SCALAR", "1")
+    else:
+        monkeypatch.setenv("MCMCX_POOLED_MFMA_DR_MIN", "1")
     d, N, nsimu = 6, 140, 330
     ckw = dict(nsimu=nsimu, adaptint=100, updatesigma=0, condmax=condmax, drscale=drscale)
     if burn:
