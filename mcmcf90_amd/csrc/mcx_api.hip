@@ -280,7 +280,7 @@ static size_t pooled_mfma_lds(int d)
 }
 static bool pooled_use_mfma(const mcmcx_engine *h)
 {
-    if (!h->pooled || (h->cfg.method != MCMCX_METHOD_DRAM && h->cfg.method != MCMCX_METHOD_RAM)) return false;   // ER: the lane-per-chain kernel
+    if (!h->pooled || (h->cfg.method != MCMCX_METHOD_DRAM && h->cfg.method != MCMCX_METHOD_RAM && h->cfg.method != MCMCX_METHOD_ER)) return false;   // (SCAM has its own)
     if (h->dodr) {                                                                                                   // DR: with its dense tables, and above
         if (h->cfg.method != MCMCX_METHOD_DRAM || !h->d_sharedR2T) return false;                                     // npar 20 (8.3e8 against 8.9e8 iterations/s
         int dmin = 21;                                                                                               // for the lane kernel with its LDS vectors at 20;
@@ -1392,7 +1392,7 @@ int mcmcx_init(mcmcx_handle h)
         HIPCHK(hipMemcpy(h->d_sharedR, Rp.data(), (size_t)P * 8, hipMemcpyHostToDevice));
         E.sharedR = h->d_sharedR;
         h->pool_R = Rp; h->pool_C = Cp; h->pool_mean = h->par0; h->pool_W = (double)c.initcmatn;
-        if (c.method == MCMCX_METHOD_DRAM || c.method == MCMCX_METHOD_RAM) {
+        if (c.method == MCMCX_METHOD_DRAM || c.method == MCMCX_METHOD_RAM || c.method == MCMCX_METHOD_ER) {
             if ((rc = dev_alloc(h, &h->d_sharedRT, (size_t)((d + 3) & ~3) * d + PWS, false))) return rc;
             if ((rc = h->usesvd ? upload_shared_rf(h) : upload_shared_rt(h))) return rc;
             if (h->usesvd) E.sharedR = h->d_sharedRT;   // the lane-per-chain kernel reads the full matrix through the scalar cache

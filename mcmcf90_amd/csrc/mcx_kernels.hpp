@@ -2295,6 +2295,7 @@ __global__ __launch_bounds__(64) void pooled_mfma_kernel(EngineDev E, int it0, i
     const bool gauss = (E.tgt.kind == TGT_GAUSS);
     LaneState L;
     lane_load(E, tile, lane, L);
+    uint32_t erstayed = TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane);
     mcx_d4 c[4][4];
     // out = M' X on the matrix cores, into T in (row, chain) order; tri: M is upper triangular (rows beyond a block's last column are zero)
     auto product_to_T = [&](const double *__restrict__ M, bool tri) {
@@ -2376,7 +2377,16 @@ __global__ __launch_bounds__(64) void pooled_mfma_kernel(EngineDev E, int it0, i
         double ss2 = gauss ? gauss_ss() : target_ss<false>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
         // ---- alpha, reject (MCMC_run.F90:47-63), as in step_kernel
         bool reject;
-        if (!inb) { if (!DR) L.bnd += 1; reject = true; L.alpha12 = 0.0; }
+        if (!DR && E.method == M_ER) {                    // early rejection, MCMC_run_er.F90:60-89 (no second stage with it)
+            if (!inb) { L.bnd += 1; reject = true; }
+            else {
+                double u = rng_uniform(L.g);              // MCMC_sscrit, MCMC_DRAM.F90:124-135: always drawn
+                double sscrit = -2.0 * d_log(u) + L.ss1 / L.sigma2 + L.pri1;
+                if (pri2 >= sscrit) { reject = true; erstayed += 1; }
+                else { sscrit = L.sigma2 * (sscrit - pri2); reject = (ss2 >= sscrit); }
+            }
+        }
+        else if (!inb) { if (!DR) L.bnd += 1; reject = true; L.alpha12 = 0.0; }
         else {
             L.alpha12 = d_alpha(L.ss1, L.pri1, ss2, pri2, L.sigma2);
             reject = true;
@@ -2443,6 +2453,7 @@ __global__ __launch_bounds__(64) void pooled_mfma_kernel(EngineDev E, int it0, i
         if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
     }
     lane_store(E, tile, lane, L);
+    TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane) = erstayed;
 }
 
 // ---------------------------------------------------------------- nycol > 1: sums over the response columns

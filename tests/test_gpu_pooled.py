@@ -439,9 +439,6 @@ def test_pooled_burnin_greedy_ap_match_restatement(oracle, name, extra, c0):
     pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.3), cmat0=c0 * np.eye(d), mu=np.linspace(-1, 1, d), lam=np.linalg.inv(S))
     e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
     e.init(); e.run()
-    if "dr" in name:
-        assert e.last_kernel() == ("pooled_mfma_kernel<true>" if (not scalar and d <= 140) else        # (its LDS ends at npar ~140)
-                                   "step_kernel_pooled_dr" if (d <= 40 and name != "dr_am_global_scratch") else "step_kernel_pooled_dr_big")
     chains, st, log = _restate_pooled(oracle, ckw, pkw, N)
     kinds = {k for _, k in log}
     want = {"scale_up": "up", "scale_down": "down", "refactor": "refactor", "greedy": "greedy", "ap": "ap", "adaptend": "am"}[name]
@@ -483,8 +480,6 @@ def test_pooled_delayed_rejection_and_er_match_restatement(oracle, name, extra, 
     from mcmcf90_amd import engine_from_problem
     d, N, nsimu = 5, 130, 420
     if scalar:
-        if "dr" not in name:
-            pytest.skip("early rejection has one pooled kernel")
         monkeypatch.setenv("MCMCX_POOLED_SCALAR", "1")         # the lane-per-chain kernels (shared tables through the scalar cache)
     elif name == "dr_am_global_scratch":
         pytest.skip("a switch of the lane-per-chain kernels")
@@ -517,6 +512,8 @@ def test_pooled_delayed_rejection_and_er_match_restatement(oracle, name, extra, 
     if "dr" in name:
         assert e.last_kernel() == ("pooled_mfma_kernel<true>" if (not scalar and d <= 140) else        # (its LDS ends at npar ~140)
                                    "step_kernel_pooled_dr" if (d <= 40 and name != "dr_am_global_scratch") else "step_kernel_pooled_dr_big")
+    else:
+        assert e.last_kernel() == ("step_kernel<false, false, true>" if scalar else "pooled_mfma_kernel<false>")
     chains, st, log = _restate_pooled(oracle, ckw, pkw, N)
     kinds = {k for _, k in log}
     if "scale_down" in name: assert "down" in kinds, log
