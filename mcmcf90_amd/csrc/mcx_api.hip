@@ -319,6 +319,7 @@ static void launch_step(mcmcx_engine *h, int it0, int it1)
     else if (h->pooled && h->dodr) LAUNCHK(step_kernel_pooled_dr, g, b, lds_step(h), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR, h->d_sharedR2, h->d_sharediC);
     else if (h->pooled) LAUNCHK((step_kernel<false, false, true>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->E.method == M_RAM && h->usesvd) LAUNCHK(step_kernel_ram_fullr, g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
+    else if (h->E.method == M_RAM && h->E.lds_scratch == 3) LAUNCHK(step_kernel_ram_ldsr, g, b, (size_t)(2 * h->d + h->P) * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->E.method == M_RAM) LAUNCHK((step_kernel<true, false, false>), g, b, (size_t)NLC * 2 * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->dodr && !dr_vectors_in_lds(h))            // the second stage's two vectors in global scratch
         LAUNCHK(step_kernel_dr_big, g, b, 0, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
@@ -1287,6 +1288,9 @@ int mcmcx_init(mcmcx_handle h)
         const int per_cu_r = (int)((size_t)160 * 1024 / per_wave_r);
         const bool fits_r = per_cu_r >= 8 || (per_cu_r >= 1 && (long long)T <= (long long)per_cu_r * cus);
         if (E.lds_scratch && !h->usesvd && d <= TW && fits_r && !(ev && atoi(ev) == 1)) E.lds_scratch = 2;     // MCMCX_LDS_SCRATCH=1: the state only (A/B)
+        // method='ram' (per-chain factor, Cholesky form): the factor DCHUD / DCHDD rewrite every iteration, and their rotations, in LDS for
+        // the launch where one column panel covers npar and all tiles are resident at once (step_kernel_ram_ldsr)
+        if (!h->pooled && c.method == MCMCX_METHOD_RAM && !h->usesvd && d <= RW && fits_r && !(ev && atoi(ev) == 0)) E.lds_scratch = 3;
     }
     // target
     E.tgt.kind = phased(h) ? (int)TGT_HOST : h->tkind;   // the kernels know one phase-cut mode; who evaluates is the host's business

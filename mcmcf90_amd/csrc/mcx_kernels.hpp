@@ -1278,8 +1278,11 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
     double *zs_t = ldsr ? cand_t : (ldsv ? X + (size_t)2 * d * 64 : E.zs + (size_t)tile * 2 * d * 64);       // two normal vectors: this iteration's and the next one's
     double *cs_t = E.cs + (size_t)tile * 2 * d * 64;           // RAM: rotations; DR: second-stage candidate
     if (ldsv) for (int k = 0; k < d; ++k) GV(theta_t, k) = GV(theta_g, k);
-    double *Rt = ldsr ? X + (size_t)2 * d * 64 : E.R + (size_t)tile * E.P * 64;
-    if (ldsr) { const double *Rg = E.R + (size_t)tile * E.P * 64; copy_vec(Rt, Rg, nullptr, lane, E.P); }
+    // step_kernel_ram_ldsr (npar <= RW: one column panel): the factor that DCHUD / DCHDD rewrite at every iteration stays in LDS for the
+    // launch, behind the 2 npar vectors of rotations -- north_star's "Cholesky factor staged in LDS" for the rank-one update itself
+    constexpr bool ramr = RAM && LDSR && !FULLR;
+    double *Rt = (ldsr || ramr) ? X + (size_t)2 * d * 64 : E.R + (size_t)tile * E.P * 64;
+    if (ldsr || ramr) { const double *Rg = E.R + (size_t)tile * E.P * 64; copy_vec(Rt, Rg, nullptr, lane, E.P); }
     double *Y = X + (size_t)d * 64;
     double *c2_t = cs_t;
 
@@ -1417,6 +1420,7 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
     TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane) = erstayed;
     if (RAM) { TIDX(E.ictr, tile, NICTR, I_PDESC, lane) = pdesc ? 1u : 0u; TIDX(E.ictr, tile, NICTR, I_DOWNS, lane) = downs; }
     if (ldsv) for (int k = 0; k < d; ++k) GV(theta_g, k) = GV(theta_t, k);
+    if (ramr) { double *Rg = E.R + (size_t)tile * E.P * 64; copy_vec(Rg, Rt, nullptr, lane, E.P); }
 }
 
 // ---------------------------------------------------------------- delayed rejection with per-chain factors
@@ -1641,6 +1645,12 @@ __global__ __launch_bounds__(64, MCX_AM_WAVES) void step_kernel_ldsr(EngineDev E
                                                      const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
                                                      const double *__restrict__ g_sharedR)
 { step_body<false, false, false, MCX_AM_WIDE, false, true, true>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
+
+// method='ram' at npar <= RW with few enough tiles: the factor in LDS for the launch (EngineDev::lds_scratch == 3)
+__global__ __launch_bounds__(64, 2) void step_kernel_ram_ldsr(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
+                                                     const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
+                                                     const double *__restrict__ g_sharedR)
+{ step_body<true, false, false, true, false, false, true>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
 
 // pooled mode with delayed rejection: the shared factor, its second-stage copy R2 = R / drscale and the shared inverse
 // covariance iC = dpotri(R) all come through the scalar cache (the host recomputes the three at every pooled tick)

@@ -476,3 +476,44 @@ def test_batch_branch_in_blocks_equals_row_form_and_oracle(oracle, case, monkeyp
         np.testing.assert_array_equal(_bits(np.triu(a[1][i][0])), _bits(np.triu(o.chaincmat)))
         np.testing.assert_array_equal(_bits(a[1][i][1]), _bits(o.chainmean))
         assert a[3][i] == o.rng_n
+
+
+@pytest.mark.parametrize("d", [1, 3, 7, 10])
+@pytest.mark.parametrize("start", ["default", "target"])
+def test_ram_factor_in_lds(oracle, d, start, monkeypatch):
+    """method='ram' at npar <= 10 (one column panel) with all tiles resident: step_kernel_ram_ldsr keeps the packed factor that
+    DCHUD / DCHDD rewrite at every iteration, and their rotations, in LDS for the launch.  Same chain bit for bit as the
+    global-memory form (MCMCX_LDS_SCRATCH=0) and as the oracle -- update and downdate lanes mixed (start = target: about half of
+    the iterations downdate), bounds, the sigma2 update, several launches."""
+    from mcmcf90_amd import engine_from_problem
+    rng = np.random.default_rng(40 + d)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    lam = A @ A.T + np.eye(d)
+    cm0 = np.linalg.inv(lam) if start == "target" else 0.01 * np.eye(d)
+    ckw = dict(nsimu=260, method="ram", adaptint=100, updatesigma=1 if d == 3 else 0)
+    pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.1), cmat0=cm0, mu=np.linspace(-0.5, 0.5, d), lam=lam)
+    if d == 7:
+        pkw.update(lo=np.full(d, -1.5), hi=np.full(d, 1.5))
+    if d == 3:
+        pkw.update(sigma2=0.9, nobs=20)
+    res = []
+    for off in (0, 1):
+        if off:
+            monkeypatch.setenv("MCMCX_LDS_SCRATCH", "0")
+        e = engine_from_problem(ckw, pkw, nchains=70, chain_id0=4, record_accept=1)
+        e.init(); e.run(90); e.run(91); e.run()
+        assert e.last_kernel() == ("step_kernel<true, false, false>" if off else "step_kernel_ram_ldsr")
+        res.append((e.theta().copy(), e.accept_masks().copy(), [e.R(c).copy() for c in (0, 63, 69)], [e.rng(c)[0] for c in (0, 63, 69)], e.totals()["downdates"]))
+        e.close()
+    a, b = res
+    assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1]) and a[3] == b[3] and a[4] == b[4]
+    for x, y in zip(a[2], b[2]):
+        np.testing.assert_array_equal(_bits(x), _bits(y))
+    if start == "target" and d > 1:
+        assert a[4] > 0                                    # downdates happened: both kinds of lanes were in the waves
+    cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
+    for i, c in enumerate((0, 63, 69)):
+        o = oracle.run_chain(cfg, prob, chain_id=4 + c, continue_on_downdate_fail=True)
+        np.testing.assert_array_equal(_bits(a[0][c]), _bits(o.theta))
+        np.testing.assert_array_equal(_bits(np.triu(a[2][i])), _bits(np.triu(o.R)))
+        assert a[3][i] == o.rng_n

@@ -10,7 +10,7 @@ from mcmcf90_amd.workloads import corr_gauss_precision
 what = sys.argv[1] if len(sys.argv) > 1 else "am"
 dims = [int(x) for x in os.environ.get("SIZES", "4,8,10,11,12,16,20,24,32,40,50,64,80,100,128,160,200,256").split(",")]
 for d in dims:
-    n = 131072 if d <= 64 else (65536 if d <= 128 else 16384)
+    n = int(os.environ.get("CHAINS", "0")) or (131072 if d <= 64 else (65536 if d <= 128 else 16384))
     if what == "scam":
         n = 65536 if d <= 32 else 8192
     nit = 401 if what != "scam" else 41
