@@ -25,8 +25,10 @@ cannot join ends the run with a non-zero exit code instead of hanging it.
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the engine's
 stream around every step-kernel launch of the timed region (mcmcx_kernel_time); `cpu_baseline`
 times the real Fortran reference (oracle/_ref, kind "reference") or the C oracle (kind "port")
-on one host core and on all of them on the same target; `other_configs` (N = 1 only) holds a short run of
-each of the other BASELINE configurations in the same process, after the headline's timed region.
+on one host core and on all of them on the same target; `other_configs` holds, at N = 1, a short run of each of the
+other BASELINE configurations in the same process after the headline's timed region and, at N > 1, a short run of c4 in
+POOLED mode on the same communicator -- the one collective that sits on the critical path (the pooled RAM tick every
+adaptint iterations) -- so that one scaling run also measures that; `device` identifies the box (UUID, PCI id, clocks).
 """
 import argparse
 import json
@@ -55,7 +57,17 @@ WORKLOADS = {   # BASELINE.json configs 2-5; the headline
     "c4": "C4: correlated Gaussian d=50 (Sigma=0.5^|i-j|)",
     "c5": "C5: ill-conditioned Gaussian d=200 (cond 1e6), SCAM componentwise",
 }
-DEFAULT_CHAINS = {"c2": 65536, "c3": 262144, "c4": 131072, "c5": 65536}
+DEFAULT_CHAINS = {"c2": 65536, "c3": 262144, "c4": 1048576, "c5": 65536}
+# BASELINE.json: c4 and c5 are ONE problem "sharded over 8 x MI355X" -- the whole job's chains are divided among the GPUs of a run
+# (strong scaling); c2 and c3 are quoted "on 1 MI355X" and keep their count per GPU (weak scaling)
+STRONG = ("c4", "c5")
+
+
+def default_chains(wl, world):
+    if wl in STRONG:
+        n = DEFAULT_CHAINS[wl] // world
+        return max(64, n - n % 64)
+    return DEFAULT_CHAINS[wl]
 
 
 def alg_bytes_per_proposal(d, method, down_frac=0.0):
@@ -238,6 +250,41 @@ def cpu_baseline(wl, ckw, pkw, per_it, label, target_seconds=12.0, all_cores=Tru
     return out
 
 
+def device_ident(L, dev):
+    """What tells this box from another one of the pool in the JSON line: UUID, PCI bus id, clock limits (HIP) and, where
+    rocm-smi answers, the clocks and the power cap it reports right now (best effort; never fatal)."""
+    import ctypes
+    out = {}
+    try:
+        uuid_hex = ctypes.create_string_buffer(40)
+        v = (ctypes.c_int32 * 5)()
+        if L.mcmcx_device_ident(dev, uuid_hex, 40, v) == 0:
+            out.update(uuid=uuid_hex.value.decode(), sclk_limit_mhz=v[0] / 1e3, mclk_limit_mhz=v[1] / 1e3, mem_bus_bits=int(v[2]), cus=int(v[3]), l2_bytes=int(v[4]))
+        info = ctypes.create_string_buffer(256)
+        L.mcmcx_device_info(dev, info, 256)
+        txt = info.value.decode(errors="replace")
+        out["info"] = txt
+        if "pci " in txt:
+            out["pci"] = txt.split("pci ", 1)[1].split(",")[0]
+    except Exception as ex:
+        out["error"] = str(ex)[:120]
+    try:
+        p = subprocess.run(["/opt/rocm/bin/rocm-smi", "-d", str(dev), "--showclocks", "--showmaxpower", "--showserial", "--json"],
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=20)
+        j = json.loads(p.stdout.decode())
+        card = j.get("card%d" % dev) or (list(j.values())[0] if j else {})
+        keep = {}
+        for k, val in card.items():
+            kl = k.lower()
+            if "sclk" in kl or "mclk" in kl or "fclk" in kl or "power" in kl or "serial" in kl:
+                keep[k] = val
+        if keep:
+            out["rocm_smi"] = keep
+    except Exception:
+        pass
+    return out
+
+
 # ------------------------------------------------------------------ ranks
 def spawn_ranks(n, argv, comm_timeout):
     """`bench.py --gpus N` without a launcher: start the N rank processes (one per GPU) ourselves.  This parent never
@@ -332,7 +379,7 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
     of the JSON line on rank 0 (None elsewhere) and the pooled moment vector."""
     from mcmcf90_amd import engine_from_problem
     from mcmcf90_amd.workloads import problem
-    n_local = chains_per_gpu or DEFAULT_CHAINS[wl]
+    n_local = chains_per_gpu or default_chains(wl, world)
     ips = its_per_step or (10 if wl == "c5" else 100)       # c5: one iteration is d = 200 componentwise proposals
     nsimu = (warmup + steps) * ips + 1                       # steps end ON the adaptation ticks (iteration k * ips): one launch + one tick each
     adaptint_ = max(ips, 100)
@@ -499,11 +546,18 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
 OTHER_CONFIGS = [
     ("c2", dict(wl="c2", steps=10, warmup=2)),                      # 1.7 ms per step: ten of them
     ("c3", dict(wl="c3", steps=3, warmup=1)),
-    ("c4_target", dict(wl="c4", steps=3, warmup=1, start="target")),
+    ("c4_target", dict(wl="c4", steps=3, warmup=1, start="target", chains_per_gpu=131072)),    # one eighth of the chains: 0.14 s per step
     ("c4_pooled", dict(wl="c4", steps=6, warmup=1, pooled=True)),
     ("c5_pooled", dict(wl="c5", steps=2, warmup=1)),
     ("c5_pooled_scam_fast", dict(wl="c5", steps=2, warmup=1, scam_fast=True)),        # opt-in variants, labelled as such in `workload`
     ("c5_replicas_scam_fast", dict(wl="c5", steps=2, warmup=1, replicas=True, scam_fast=True)),
+    # MCMC_run_scam.F90:106-115 as written: per-chain rotations, two dgemv per componentwise proposal (no scam_fast); one iteration per step
+    ("c5_replicas", dict(wl="c5", steps=2, warmup=1, replicas=True, its_per_step=1)),
+]
+# N > 1: the pooled form of the headline configuration on the same communicator -- its RAM tick (the rank-one statistics of all chains
+# of all ranks gathered and folded into the one shared factor every adaptint iterations) is the collective ON the critical path
+OTHER_CONFIGS_MULTI = [
+    ("c4_pooled", dict(wl="c4", steps=6, warmup=1, pooled=True)),
 ]
 
 
@@ -513,7 +567,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS), help="BASELINE.json configuration (default: the headline one)")
-    ap.add_argument("--chains-per-gpu", type=int, default=0, help="default: the configuration's chain count (c4: 131072 = 1048576/8)")
+    ap.add_argument("--chains-per-gpu", type=int, default=0, help="default: c4 / c5: the configuration's chains divided by --gpus (c4: 1048576 / N, strong scaling); c2 / c3: the configuration's count per GPU")
     ap.add_argument("--its-per-step", type=int, default=0, help="MH iterations per bench step (default 100; c5: 10)")
     ap.add_argument("--method", default=None, choices=["ram", "dram"], help="c4 only: per-chain RAM (default) or AM")
     ap.add_argument("--pooled", action="store_true", help="one shared factor from the all-reduced pooled covariance (c5: the default)")
@@ -581,24 +635,32 @@ def main():
     res, pooled_vec = run_config(a.workload, a.steps, a.warmup, rank, world, dev, comm, chains_per_gpu=a.chains_per_gpu,
                                  its_per_step=a.its_per_step, method_opt=a.method, pooled=a.pooled, replicas=a.replicas,
                                  start=a.start, transport=transport, scam_fast=a.scam_fast)
+    plain = a.workload == "c4" and not (a.pooled or a.method or a.start != "default" or a.its_per_step or a.replicas or a.scam_fast)
+    line = None
     if rank == 0:
         cpu_args = res.pop("_cpu")
         line = {
             "metric": res["metric"], "value": res["value"], "unit": "proposals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True,
+            "scaling": "strong" if (a.workload in STRONG and not a.chains_per_gpu) else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": res["config"], "roofline": res["roofline"], "pooled_check": res["pooled_check"],
             **({"adaptation": res["adaptation"]} if res.get("adaptation") else {}),
             "rccl_ranks": rccl_ranks if (world > 1 and not a.one_gpu_dryrun) else (1 if world == 1 else 0),
             "engine_sha": kernels_sha(),
+            "device": device_ident(L, dev),
         }
-        if world == 1 and not a.no_other_configs and a.workload == "c4" and not (a.pooled or a.method or a.start != "default" or a.chains_per_gpu or a.its_per_step):
-            # the other BASELINE configurations, briefly, in this same process (builder-independent numbers for all of them)
-            others = {}
-            for key, kw in OTHER_CONFIGS:
-                try:
-                    t0 = time.perf_counter()
-                    r, _ = run_config(rank=0, world=1, dev=dev, comm=None, **kw)
+    if not a.no_other_configs and plain and (world > 1 or not a.chains_per_gpu):
+        # N = 1: the other BASELINE configurations, briefly, in this same process (builder-independent numbers for all of them);
+        # N > 1: the pooled form of the headline on the same communicator (every rank runs it: its ticks are collective, so an
+        # error there is not swallowed -- a rank that raised alone would leave its peers in the next gather)
+        others = {}
+        for key, kw in (OTHER_CONFIGS if world == 1 else OTHER_CONFIGS_MULTI):
+            try:
+                t0 = time.perf_counter()
+                r, _ = run_config(rank=rank, world=world, dev=dev, comm=comm, transport=transport,
+                                  **dict(kw, **({"chains_per_gpu": a.chains_per_gpu} if (world > 1 and a.chains_per_gpu) else {})))
+                if rank == 0:
                     rf = r["roofline"]
                     others[key] = {"value": r["value"], "unit": "proposals/s", "ms_per_step": r["ms_per_step"], "steps": kw["steps"],
                                    "bound": rf["bound"], "roofline_frac": rf["frac"], "achieved": rf["achieved"], "roofline_unit": rf["unit"],
@@ -606,12 +668,20 @@ def main():
                                    "avg_launch_ms": rf["avg_launch_ms"], "kernel_share_of_wall": rf["kernel_share_of_wall"],
                                    "alg_per_proposal": rf.get("alg_bytes_per_proposal", rf.get("alg_flop_per_proposal")),
                                    "workload": r["config"]["workload"], "proposals_per_iteration": r["config"]["proposals_per_iteration"],
+                                   "chains_per_gpu": r["config"]["chains_per_gpu"], "n_gpus": world,
                                    "wall_s_incl_init": time.perf_counter() - t0}
+                    if world > 1:
+                        others[key]["rccl_ranks"] = line["rccl_ranks"]
+                        others[key]["pooled_check"] = r["pooled_check"]
                     if r.get("adaptation"):
                         others[key].update(tick_ms=r["adaptation"]["tick_ms"], sustained_value=r["adaptation"]["sustained_value"])
-                except Exception as ex:
-                    others[key] = {"error": str(ex)[:300]}
+            except Exception as ex:
+                if world > 1:
+                    raise
+                others[key] = {"error": str(ex)[:300]}
+        if rank == 0:
             line["other_configs"] = others
+    if rank == 0:
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(*cpu_args)
         if a.dump_moments:

@@ -77,6 +77,9 @@ const char *mcmcx_last_error(void);
 const char *mcmcx_version(void);
 int32_t mcmcx_device_count(void);                              /* HIP devices visible to this process (0: none -- nothing will run) */
 int mcmcx_device_info(int32_t device, char *buf, int32_t len); /* "name arch, pci bus id, CUs, memory" of one of them (diagnostics) */
+/* the device's UUID as 32 hex digits (len >= 33) and out5 = {engine clock limit kHz, memory clock limit kHz, memory bus width
+ * in bits, compute units, L2 bytes}: what tells two boxes of a pool apart in a benchmark line (diagnostics) */
+int mcmcx_device_ident(int32_t device, char *uuid_hex, int32_t len, int32_t *out5);
 const char *mcmcx_last_kernel(mcmcx_handle h);                /* the sampling kernel the last mcmcx_run launched, as spelled in the
                                                                   source ("step_kernel<true, false, false>", "scam_pooled_kernel", ...);
                                                                   "" before the first run or with host callbacks (diagnostics) */
@@ -128,7 +131,10 @@ int mcmcx_init(mcmcx_handle h);
  * every getter is valid for the iterations done (the reference saves the chain "upto simuind" and stops,
  * MCMC_signal_handler.F90:95-107).  In pooled mode with a communicator of several ranks the run is left only at an
  * adaptation tick, by agreement of all ranks (every rank's stop flag travels with the pooled vector), so that no rank
- * is left waiting in a collective; a rank that fails marks the communicator and its peers' waits give up (< 0). */
+ * is left waiting in a collective: that tick's adaptation IS applied before the ranks return, so mcmcx_clear_interrupt +
+ * mcmcx_run resumes into the trajectory of an uninterrupted run.  Where no tick lies ahead of the call's `upto`
+ * (doadapt = 0, past adaptend, the tail of a run) nothing collective remains and the rank that caught the signal returns
+ * at its next launch boundary by itself.  A rank that fails marks the communicator and its peers' waits give up (< 0). */
 int mcmcx_run(mcmcx_handle h, int32_t upto);
 int mcmcx_sync(mcmcx_handle h);
 

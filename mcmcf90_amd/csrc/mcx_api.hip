@@ -80,6 +80,7 @@ struct mcmcx_engine {
     struct mcmcx_comm *comm = nullptr;                // the node's communicator (mcx_comm.hpp); nullptr = this GPU alone
     double *d_gather = nullptr, *d_pooled = nullptr;  // [nranks][len + 1] per-rank moment vectors (+ the rank's stop flag), [len + 1] their tree sum
     double h_flag = 0.0;                              // this rank's stop flag of the exchange being enqueued (1 = a caught signal)
+    bool stop_seen = false;                           // the summed stop flag of the tick just applied was non-zero: every rank leaves after this tick
     double S02eff = 0.0;
     // device
     hipStream_t stream = nullptr; bool own_stream = false;
@@ -598,7 +599,9 @@ static bool collective_run(const mcmcx_engine *h) { return h->pooled && h->comm 
 
 // The pooled statistic vector of `kind` over the chains of ALL ranks, on the host.  With a communicator: local tree ->
 // all-gather -> tree over ranks; with the caller's exchange hook (kind 0 only): the hook sums the device buffer.
-// Returns MCMCX_INTERRUPTED (> 0) when some rank raised its stop flag: every rank gets the same answer at the same tick.
+// When some rank raised its stop flag, h->stop_seen is set: every rank reads the same sum at the same tick, APPLIES that tick
+// like any other (all of them hold the same pooled vector) and leaves mcmcx_run behind it -- so a run resumed after
+// mcmcx_clear_interrupt continues exactly like one that was never interrupted.
 static int pooled_reduce(mcmcx_engine *h, int kind, int it, std::vector<double> &v)
 {
     const int len = pooled_vec_len(h, kind);
@@ -617,7 +620,7 @@ static int pooled_reduce(mcmcx_engine *h, int kind, int it, std::vector<double> 
     }
     const double stop = v[len];
     v.resize(len);
-    if (collective_run(h) && stop != 0.0) return MCMCX_INTERRUPTED;
+    if (collective_run(h) && stop != 0.0) h->stop_seen = true;
     // the vector has been through an exchange: refuse to merge garbage (it would poison the pooled state for the rest of the run)
     if (!(v[0] >= 2.0) || !std::isfinite(v[0])) return fail(-46, "pooled adaptation needs at least 2 chains over all ranks (count = " + std::to_string(v[0]) + ")");
     for (int k = 1; k < len; ++k) if (!std::isfinite(v[k])) return fail(-46, "pooled adaptation: non-finite pooled statistic at iteration " + std::to_string(it));
@@ -1014,6 +1017,22 @@ int mcmcx_device_info(int32_t device, char *buf, int32_t len)
     if (e != hipSuccess) { snprintf(buf, (size_t)len, "device %d: %s", device, hipGetErrorString(e)); return fail(-10, buf); }
     (void)hipDeviceGetPCIBusId(bus, (int)sizeof bus, device);
     snprintf(buf, (size_t)len, "%s %s, pci %s, %d CUs, %.0f GiB", prop.name, prop.gcnArchName, bus, prop.multiProcessorCount, (double)prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
+    return 0;
+}
+
+// what identifies the physical device and its clock limits (bench.py puts it in its JSON line: the pool's boxes differ by ~8 %)
+int mcmcx_device_ident(int32_t device, char *uuid_hex, int32_t len, int32_t *out5)
+{
+    if (!uuid_hex || len < 33 || !out5) return fail(-1, "mcmcx_device_ident: bad argument (uuid buffer of >= 33 bytes, five integers)");
+    hipUUID u;
+    HIPCHK(hipDeviceGetUuid(&u, device));
+    for (int i = 0; i < 16; ++i) snprintf(uuid_hex + 2 * i, 3, "%02x", (unsigned)(unsigned char)u.bytes[i]);
+    int v = 0;
+    HIPCHK(hipDeviceGetAttribute(&v, hipDeviceAttributeClockRate, device)); out5[0] = v;                 // kHz, the engine clock's limit
+    HIPCHK(hipDeviceGetAttribute(&v, hipDeviceAttributeMemoryClockRate, device)); out5[1] = v;           // kHz
+    HIPCHK(hipDeviceGetAttribute(&v, hipDeviceAttributeMemoryBusWidth, device)); out5[2] = v;            // bits
+    HIPCHK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device)); out5[3] = v;
+    HIPCHK(hipDeviceGetAttribute(&v, hipDeviceAttributeL2CacheSize, device)); out5[4] = v;
     return 0;
 }
 
@@ -1527,8 +1546,14 @@ static int run_impl(mcmcx_handle h, int32_t upto)
     // So a signal only raises this rank's stop flag in the exchanged vector and the run is left at the tick where every
     // rank reads the summed flag (pooled_reduce); an error marks the communicator failed (mcmcx_run).
     const bool coll = collective_run(h);
+    // ... which needs a tick ahead.  Whether one lies in (it, upto] follows from the configuration alone, the same on every
+    // rank: past the last one (doadapt = 0, iterations beyond adaptend, the tail of a run) no collective is left to strand a
+    // peer in, and a signal is acted on at the next launch boundary like in a run of one rank.
+    int last_tick = 0;
+    if (coll) for (int i2 = upto; i2 >= it; --i2) if (adapt_mode(c, i2) != 0 || pooled_ram_due(h, i2)) { last_tick = i2; break; }
+    h->stop_seen = false;
     while (it <= upto) {
-        if (g_interrupt && !coll) {                         // a caught signal: stop at this launch boundary
+        if (g_interrupt && (!coll || it > last_tick)) {     // a caught signal: stop at this launch boundary
             int rc = mcmcx_sync(h); if (rc) return rc;
             h->simuind = it - 1;
             return MCMCX_INTERRUPTED;
@@ -1566,12 +1591,13 @@ static int run_impl(mcmcx_handle h, int32_t upto)
             else { launch_adapt(h, end, mode); HIPCHK(hipGetLastError()); }
         }
         if (ramtick && trc == 0) trc = pooled_ram_tick(h, end);
-        if (trc == MCMCX_INTERRUPTED) {                     // every rank read the same summed stop flag at this tick: leave together,
-            int rc = mcmcx_sync(h); if (rc) return rc;           // after iteration `end`, its adaptation not applied
+        if (trc) return trc;
+        if (h->stop_seen) {                                 // every rank read the same summed stop flag at this tick: leave together,
+            h->stop_seen = false;                           // after iteration `end` WITH its adaptation applied (a resumed run
+            int rc = mcmcx_sync(h); if (rc) return rc;      // continues at end + 1 like an uninterrupted one)
             h->simuind = end;
             return MCMCX_INTERRUPTED;
         }
-        if (trc) return trc;
         it = end + 1;
         if (g_sig_installed) { HIPCHK(hipStreamSynchronize(h->stream)); h->simuind = std::max(h->simuind, end); }
         if (h->pending.size() > 4096) { int rc = mcmcx_sync(h); if (rc) return rc; }

@@ -201,3 +201,51 @@ def test_a_signal_caught_by_one_rank_stops_all_ranks_at_the_same_tick(tmp_path):
     assert res[0]["rc"] == 2 and res[1]["rc"] == 2, res                        # MCMCX_INTERRUPTED on both
     assert res[0]["simuind"] == res[1]["simuind"] and res[0]["simuind"] % 50 == 0 and 100 < res[0]["simuind"] < 2000000
     assert res[0]["W"] == res[1]["W"] and res[0]["R00"] == res[1]["R00"]       # the same pooled state on both ranks
+
+
+def _workers(tmp_path, mode, signal_rank=None):
+    import signal
+    import time
+    import uuid
+    key = "w%s" % uuid.uuid4().hex[:12]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MCMCX_COMM_KEY")}
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), key, str(r), "2", str(tmp_path), mode],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(2)]
+    try:
+        if signal_rank is not None:
+            t0 = time.time()
+            while not all((tmp_path / ("rank%d.ready" % r)).exists() for r in range(2)):
+                assert time.time() - t0 < 240 and all(p.poll() is None for p in procs), [p.stdout.read().decode()[-2000:] for p in procs if p.poll() is not None]
+                time.sleep(0.05)
+            time.sleep(0.5)
+            procs[signal_rank].send_signal(signal.SIGUSR1)
+        outs = [p.communicate(timeout=400)[0].decode(errors="replace") for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode == 0 for p in procs), outs
+    return [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
+
+
+def test_a_signal_past_the_last_tick_stops_the_rank_that_caught_it(tmp_path):
+    """with no tick ahead (here adaptend = 100) no collective is left in which a peer could be stranded, so the
+    rank that caught the signal leaves at its next launch boundary by itself instead of ignoring the signal until `upto`;
+    its peer, which saw no signal, runs to the end."""
+    res = _workers(tmp_path, "tail", signal_rank=1)
+    assert res[1]["rc"] == 2 and 100 < res[1]["simuind"] < 1200000, res
+    assert res[0]["rc"] == 0 and res[0]["simuind"] == 1200000, res
+
+
+def test_a_run_resumed_after_a_collective_stop_equals_an_uninterrupted_one(tmp_path):
+    """the tick at which the ranks agree to stop is applied before they return, so clearing the flag and
+    calling mcmcx_run again continues the trajectory of a run that was never interrupted, bit for bit."""
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    res = _workers(tmp_path / "a", "resume")
+    ref = _workers(tmp_path / "b", "plain")
+    assert res[0]["stops"] == [150] and res[1]["stops"] == [150], res      # the first tick of mcmcx_run(101..): both ranks, same place
+    assert ref[0]["stops"] == [] and ref[1]["stops"] == []
+    for r in range(2):
+        assert res[r]["rc"] == 0 and res[r]["simuind"] == 1000
+        for k in ("theta_bits", "R_bits", "W", "R00", "theta_sum"):
+            assert res[r][k] == ref[r][k], (r, k, res[r], ref[r])

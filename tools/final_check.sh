@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/final_check.sh -- on the GPU box: the whole GPU suite, the default bench.py (driver style), smoke()
 mkdir -p gpurun_out
-timeout -k 10 800 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_suite.log 2>&1; rc=$?; echo suite rc $rc; tail -3 gpurun_out/gpu_suite.log
+MCMCX_SUITE_BUDGET_STRICT=1 timeout -k 10 800 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_suite.log 2>&1; rc=$?; echo suite rc $rc; tail -3 gpurun_out/gpu_suite.log
 [ $rc -eq 0 ] || exit $rc
 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; rc=$?; echo bench rc $rc
 [ $rc -eq 0 ] || { tail -20 gpurun_out/bench_default.err; exit $rc; }
