@@ -17,6 +17,7 @@
 #include "../../include/mcmcx.h"
 #include "../../include/mcmcx_target.h"
 #include "mcx_kernels.hpp"
+#include "mcx_group.hpp"
 
 using namespace mcx;
 static_assert(MCMCX_HE_INB == HE_INB && MCMCX_HE_PRI == HE_PRI && MCMCX_HE_SS == HE_SS && MCMCX_HX_STAGE2 == HX_STAGE2 && MCMCX_HX_CRIT == HX_CRIT,
@@ -89,6 +90,7 @@ struct mcmcx_engine {
     double *d_ramscale = nullptr, *d_moments = nullptr;
     double *d_Gc = nullptr, *d_Vc = nullptr, *d_svc = nullptr; uint8_t *d_need = nullptr, *d_state = nullptr; int *d_anyrot = nullptr; int svd_b = 0;    // blocked SVD of the adaptation (large npar)
     int wcap = 0;
+    int group_d4 = 0; uint8_t *d_accb = nullptr;         // lane-group step kernel (mcx_group.hpp): npar rounded up to four when it is the one to launch; accept bytes of a launch
     bool external = false; double *d_r1 = nullptr; std::vector<double> h_r1;      // MCMC_run1: the caller evaluates; exchange vectors of run1_kernel
     // timing of the step kernel
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -310,10 +312,47 @@ static void launch_init(mcmcx_engine *h)
 { hipLaunchKernelGGL(init_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E); }
 // the sampling kernels go through LAUNCHK, which notes the kernel's name for mcmcx_last_kernel (bench.py labels its roofline with it)
 #define LAUNCHK(k, ...) do { h->last_kernel = #k; hipLaunchKernelGGL(k, __VA_ARGS__); } while (0)
+// ---- the lane-group step kernel (mcx_group.hpp): four chains per wave, factors in registers
+static const int GROUP_MAXSEG = 256;                  // iterations per launch (one accept byte per chain and iteration in d_accb)
+static const int GROUP_MAX_NPAR = 32;
+// what the kernel covers: MCMC_run with per-chain Cholesky factors (method 'dram', with or without delayed rejection), one of
+// the single-launch device targets, one response column, no sigma2 update
+static bool group_covers(const mcmcx_engine *h)
+{
+    const mcmcx_config &c = h->cfg;
+    return !h->pooled && c.method == MCMCX_METHOD_DRAM && !h->usesvd && !phased(h) && h->ny == 1 && c.updatesigma == 0 &&
+           (h->tkind == TGT_GAUSS || h->tkind == TGT_BANANA || h->tkind == TGT_EXPDATA) && h->d <= GROUP_MAX_NPAR &&
+           !(h->tkind == TGT_BANANA && h->d < 2) && !(h->tkind == TGT_EXPDATA && h->d < 2);
+}
+template <int D4>
+static void launch_group_d4(mcmcx_engine *h, int it0, int it1)
+{
+    const dim3 g(h->ntiles * 16), b(64);
+    if (h->dodr) { h->last_kernel = "group_step_kernel<DR>"; hipLaunchKernelGGL((group_step_kernel<D4, true>), g, b, 0, h->stream, h->E, it0, it1, h->E.tgt.lamT, h->d_accb); }
+    else { h->last_kernel = "group_step_kernel"; hipLaunchKernelGGL((group_step_kernel<D4, false>), g, b, 0, h->stream, h->E, it0, it1, h->E.tgt.lamT, h->d_accb); }
+}
+static void launch_group(mcmcx_engine *h, int it0, int it1)
+{
+    switch (h->group_d4) {
+    case 4: launch_group_d4<4>(h, it0, it1); break;
+    case 8: launch_group_d4<8>(h, it0, it1); break;
+    case 12: launch_group_d4<12>(h, it0, it1); break;
+    case 16: launch_group_d4<16>(h, it0, it1); break;
+    case 20: launch_group_d4<20>(h, it0, it1); break;
+    case 24: launch_group_d4<24>(h, it0, it1); break;
+    case 28: launch_group_d4<28>(h, it0, it1); break;
+    default: launch_group_d4<32>(h, it0, it1); break;
+    }
+    if (h->d_accb) {
+        const long long n = (long long)(it1 - it0 + 1) * h->ntiles;
+        hipLaunchKernelGGL(group_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->E, h->d_accb, it0, it1);
+    }
+}
 static void launch_step(mcmcx_engine *h, int it0, int it1)
 {
     const dim3 g(h->ntiles), b(64);
     const double *rs = h->d_ramscale + it0;
+    if (h->group_d4) { launch_group(h, it0, it1); return; }
     if (pooled_use_mfma(h) && h->dodr) LAUNCHK(pooled_mfma_kernel<true>, g, b, pooled_mfma_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedRT, h->d_sharedR2T, h->d_sharediCd);
     else if (pooled_use_mfma(h)) LAUNCHK(pooled_mfma_kernel<false>, g, b, pooled_mfma_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedRT, (const double *)nullptr, (const double *)nullptr);
     else if (h->pooled && h->dodr && !dr_vectors_in_lds(h, 4)) LAUNCHK(step_kernel_pooled_dr_big, g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR, h->d_sharedR2, h->d_sharediC);
@@ -1437,6 +1476,14 @@ int mcmcx_init(mcmcx_handle h)
     }
     E.accmask = nullptr;
     if (c.record_accept && (rc = dev_alloc(h, &E.accmask, (size_t)c.nsimu * T))) return rc;
+    // the lane-group step kernel where it covers the configuration: MCMCX_GROUP = 1 / 0 forces it on / off (A/B, tests)
+    h->group_d4 = 0;
+    if (group_covers(h)) {
+        const char *ev = getenv("MCMCX_GROUP");
+        const bool on = ev ? atoi(ev) != 0 : false;
+        if (on) h->group_d4 = (d + 3) & ~3;
+        if (h->group_d4 && (E.hist || E.accmask) && (rc = dev_alloc(h, &h->d_accb, L * (size_t)GROUP_MAXSEG))) return rc;
+    }
     // 1/simuind**nuparam, computed like the reference: real(simuind) is default REAL (MCMC_run_ram.F90:166)
     {
         std::vector<double> rs((size_t)c.nsimu + 2, 0.0);
@@ -1539,7 +1586,7 @@ static int run_impl(mcmcx_handle h, int32_t upto)
     HIPCHK(hipSetDevice(h->cfg.device));
     const mcmcx_config &c = h->cfg;
     if (upto > c.nsimu) upto = c.nsimu;
-    const int maxseg = (c.method == MCMCX_METHOD_RAM && !h->pooled) ? 4096 : 1 << 30;
+    const int maxseg = h->group_d4 ? GROUP_MAXSEG : (c.method == MCMCX_METHOD_RAM && !h->pooled) ? 4096 : 1 << 30;
     int it = h->simuind + 1;
     // Several ranks that meet in this engine's ticks (pooled mode with a communicator): a rank that left the loop alone --
     // on a signal it happened to see first, or on an error of its own -- would leave its peers waiting in the next gather.

@@ -1,0 +1,496 @@
+// mcx_group.hpp -- the lane-GROUP-per-chain step kernel (gfx950, wave64): MCMC_run / DRAM with the factors on chip.
+//
+// The lane-per-chain kernels of mcx_kernels.hpp stream every chain's packed factor R (and, with delayed rejection,
+// R2 = R / drscale and iC TWICE) from HBM at every iteration although none of them changes between two adaptations
+// (MCMC_adapt.F90:45-46).  Here one chain belongs to the 16 lanes of one DPP row -- four chains per wave -- and
+//   * lane l of a group OWNS the columns l, l + 16, ... of R and R2 (rows 0..column: MCMC_propose's dtrmv('U','T'),
+//     matutils.F90:108-109, one fma chain per column, rows ascending) and the rows l, l + 16, ... of the symmetric iC
+//     (MCMC_DR_alpha13's dsymv, MCMC_DRAM.F90:180-182, one fma chain per row, columns ascending), all of it in REGISTERS
+//     for the whole launch: an iteration reads no factor from memory at all;
+//   * a vector element x_i that every column / row chain needs comes from lane i mod 16 by `row_newbcast` (the DPP
+//     control the f64 pipe supports: v_fmac_f64_dpp = one instruction per term);
+//   * the polar attempts of normal_bm (mcmcrand.F90:166-190) of one chain run SIXTEEN AT A TIME, attempt a of a round on
+//     lane a: Philox is counter-based, so lane a computes the block that holds the attempt's two uniforms; a prefix count
+//     over the group's accept ballot puts every accepted pair at the place the one-at-a-time loop would have given it,
+//     and the attempts behind the one that completes the vector are dropped with their uniforms undrawn -- stream
+//     position, deviates and the cached second deviate are those of the reference's loop;
+//   * sums that the reference takes in index order across what are now lanes (priorfun, the banana target, the q-sums
+//     of the quadratic forms) run as chains of `row_newbcast` adds / fmas in that order.
+// Every chain of floating-point operations is the one of step_body / dr_body (same operands, same order), so the
+// results are theirs bit for bit (tests/test_gpu_group.py compares the two kernel families and the oracle).
+//
+// Layout of a wave: lane = 16 * row + l16; chain slot = 4 * blockIdx.x + row (tile = slot / 64, lane-in-tile = slot % 64
+// of the tile-interleaved global arrays).  D4 = npar rounded up to a multiple of four (template parameter: the register
+// arrays are sized by it); NS = ceil(D4 / 16) slots per lane; positions npar..D4-1 are padding (zero everywhere).
+#pragma once
+#include "mcx_kernels.hpp"
+#include <type_traits>
+
+namespace mcx {
+
+template <int I, int N, typename F>
+MCX_DEV void sfor(F &&f)
+{
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
+}
+
+// ---------------------------------------------------------------- cross-lane primitives inside a row of 16 lanes
+// value of lane N of the row, through the builtin (32-bit halves): hazards and scheduling are the compiler's
+template <int N>
+MCX_DEV double row_bcast(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + N, 0xf, 0xf, false);     // row_newbcast:N
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// value of lane l16 + N of the same row (garbage past the row's end: callers mask)
+template <int N>
+MCX_DEV double row_down(double x) { return __shfl_down(x, N, 16); }
+
+// The hot sequences are single asm statements: v_fmac_f64_dpp / v_add_f64_dpp / v_mov_b64_dpp with row_newbcast (the one DPP
+// control the f64 pipe takes).  The compiler's hazard recogniser does not look into inline asm, and a DPP operand must not be
+// read within two wait states of the VALU instruction that wrote it (five after a VALU write of EXEC): every statement
+// opens with s_nop 4, and the instructions inside one statement never write a register that a later DPP operand of the same
+// statement reads.
+#define MCX_DPPC(i) " row_newbcast:" #i " row_mask:0xf bank_mask:0xf\n\t"
+#define MCX_GFM(i, r) "v_fmac_f64_dpp %0, %1, %" #r MCX_DPPC(i)
+#define MCX_GFM4(b) MCX_GFM(0, 2) MCX_GFM(1, 3) MCX_GFM(2, 4) MCX_GFM(3, 5)
+#define MCX_GFM8(b) MCX_GFM4(b) MCX_GFM(4, 6) MCX_GFM(5, 7) MCX_GFM(6, 8) MCX_GFM(7, 9)
+#define MCX_GFM12(b) MCX_GFM8(b) MCX_GFM(8, 10) MCX_GFM(9, 11) MCX_GFM(10, 12) MCX_GFM(11, 13)
+#define MCX_GFM16(b) MCX_GFM12(b) MCX_GFM(12, 14) MCX_GFM(13, 15) MCX_GFM(14, 16) MCX_GFM(15, 17)
+#define MCX_R4(r) "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3])
+#define MCX_R8(r) MCX_R4(r), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7])
+#define MCX_R12(r) MCX_R8(r), "v"(r[8]), "v"(r[9]), "v"(r[10]), "v"(r[11])
+#define MCX_R16(r) MCX_R12(r), "v"(r[12]), "v"(r[13]), "v"(r[14]), "v"(r[15])
+// p = fma(r[i], x_i, p) for i = 0..N-1 in that order, x_i = lane i's z
+template <int N>
+MCX_DEV void blk_fmac(double &p, double z, const double *r)
+{
+    static_assert(N == 4 || N == 8 || N == 12 || N == 16, "blocks of four");
+    if constexpr (N == 4) asm("s_nop 4\n\t" MCX_GFM4(0) : "+v"(p) : "v"(z), MCX_R4(r));
+    else if constexpr (N == 8) asm("s_nop 4\n\t" MCX_GFM8(0) : "+v"(p) : "v"(z), MCX_R8(r));
+    else if constexpr (N == 12) asm("s_nop 4\n\t" MCX_GFM12(0) : "+v"(p) : "v"(z), MCX_R12(r));
+    else asm("s_nop 4\n\t" MCX_GFM16(0) : "+v"(p) : "v"(z), MCX_R16(r));
+}
+// two chains over the same coefficients: pa = fma(r[i], xa_i, pa), pb = fma(r[i], xb_i, pb).  (A chain whose first term is a plain
+// product -- quadform_sym's `(i == 0) ? sij * dxi : dfma(...)` -- starts from -0.0: fma(a, b, -0.0) is a * b bit for bit, signed zeros
+// included; of the f64 VALU operations only v_fmac_f64 and the VOP1 forms have a DPP encoding on gfx950.)
+#define MCX_GF2(i, r) "v_fmac_f64_dpp %0, %2, %" #r MCX_DPPC(i) "v_fmac_f64_dpp %1, %3, %" #r MCX_DPPC(i)
+#define MCX_GF2_4 MCX_GF2(0, 4) MCX_GF2(1, 5) MCX_GF2(2, 6) MCX_GF2(3, 7)
+#define MCX_GF2_8 MCX_GF2_4 MCX_GF2(4, 8) MCX_GF2(5, 9) MCX_GF2(6, 10) MCX_GF2(7, 11)
+#define MCX_GF2_12 MCX_GF2_8 MCX_GF2(8, 12) MCX_GF2(9, 13) MCX_GF2(10, 14) MCX_GF2(11, 15)
+#define MCX_GF2_16 MCX_GF2_12 MCX_GF2(12, 16) MCX_GF2(13, 17) MCX_GF2(14, 18) MCX_GF2(15, 19)
+template <int N>
+MCX_DEV void blk_fmac2(double &pa, double &pb, double za, double zb, const double *r)
+{
+    static_assert(N == 4 || N == 8 || N == 12 || N == 16, "blocks of four");
+    if constexpr (N == 4) asm("s_nop 4\n\t" MCX_GF2_4 : "+v"(pa), "+v"(pb) : "v"(za), "v"(zb), MCX_R4(r));
+    else if constexpr (N == 8) asm("s_nop 4\n\t" MCX_GF2_8 : "+v"(pa), "+v"(pb) : "v"(za), "v"(zb), MCX_R8(r));
+    else if constexpr (N == 12) asm("s_nop 4\n\t" MCX_GF2_12 : "+v"(pa), "+v"(pb) : "v"(za), "v"(zb), MCX_R12(r));
+    else asm("s_nop 4\n\t" MCX_GF2_16 : "+v"(pa), "+v"(pb) : "v"(za), "v"(zb), MCX_R16(r));
+}
+// q = q + t_i, i = 0..N-1 in that order (t_i = lane i's t), as q = fma(t_i, 1.0, q): the same rounding of the same sum
+#define MCX_GAD(i) "v_fmac_f64_dpp %0, %1, %2" MCX_DPPC(i)
+#define MCX_GAD4 MCX_GAD(0) MCX_GAD(1) MCX_GAD(2) MCX_GAD(3)
+#define MCX_GAD8 MCX_GAD4 MCX_GAD(4) MCX_GAD(5) MCX_GAD(6) MCX_GAD(7)
+#define MCX_GAD12 MCX_GAD8 MCX_GAD(8) MCX_GAD(9) MCX_GAD(10) MCX_GAD(11)
+#define MCX_GAD16 MCX_GAD12 MCX_GAD(12) MCX_GAD(13) MCX_GAD(14) MCX_GAD(15)
+template <int N>
+MCX_DEV void blk_addchain(double &q, double t)
+{
+    static_assert(N == 4 || N == 8 || N == 12 || N == 16, "blocks of four");
+    const double one = 1.0;
+    if constexpr (N == 4) asm("s_nop 4\n\t" MCX_GAD4 : "+v"(q) : "v"(t), "v"(one));
+    else if constexpr (N == 8) asm("s_nop 4\n\t" MCX_GAD8 : "+v"(q) : "v"(t), "v"(one));
+    else if constexpr (N == 12) asm("s_nop 4\n\t" MCX_GAD12 : "+v"(q) : "v"(t), "v"(one));
+    else asm("s_nop 4\n\t" MCX_GAD16 : "+v"(q) : "v"(t), "v"(one));
+}
+// ss = fma(v_i, v_i, ss), i = 0..N-1 in that order (the banana target's and the data target's sums of squares)
+#define MCX_GSQ(i) "v_mov_b64_dpp %2, %1" MCX_DPPC(i) "v_fmac_f64_dpp %0, %1, %2" MCX_DPPC(i)
+#define MCX_GSQ4 MCX_GSQ(0) MCX_GSQ(1) MCX_GSQ(2) MCX_GSQ(3)
+#define MCX_GSQ8 MCX_GSQ4 MCX_GSQ(4) MCX_GSQ(5) MCX_GSQ(6) MCX_GSQ(7)
+#define MCX_GSQ12 MCX_GSQ8 MCX_GSQ(8) MCX_GSQ(9) MCX_GSQ(10) MCX_GSQ(11)
+#define MCX_GSQ16 MCX_GSQ12 MCX_GSQ(12) MCX_GSQ(13) MCX_GSQ(14) MCX_GSQ(15)
+template <int N>
+MCX_DEV void blk_sqchain(double &ss, double v)
+{
+    static_assert(N == 4 || N == 8 || N == 12 || N == 16, "blocks of four");
+    double tmp;
+    if constexpr (N == 4) asm("s_nop 4\n\t" MCX_GSQ4 : "+v"(ss), "+v"(v), "=&v"(tmp));
+    else if constexpr (N == 8) asm("s_nop 4\n\t" MCX_GSQ8 : "+v"(ss), "+v"(v), "=&v"(tmp));
+    else if constexpr (N == 12) asm("s_nop 4\n\t" MCX_GSQ12 : "+v"(ss), "+v"(v), "=&v"(tmp));
+    else asm("s_nop 4\n\t" MCX_GSQ16 : "+v"(ss), "+v"(v), "=&v"(tmp));
+}
+
+// ---------------------------------------------------------------- shapes
+template <int D4>
+struct GDims {
+    static constexpr int NS = (D4 + 15) / 16;                                          // slots (columns / rows / positions) per lane
+    static constexpr int rows(int s) { return D4 < 16 * (s + 1) ? D4 : 16 * (s + 1); }   // rows of the columns of slot s (upper triangle)
+    static constexpr int off(int s) { int o = 0; for (int q = 0; q < s; ++q) o += rows(q); return o; }
+    static constexpr int NR = off(NS);                                                 // doubles per lane for one triangular factor
+    static constexpr int blk(int t) { return (D4 - 16 * t) < 16 ? (D4 - 16 * t) : 16; }  // positions of block t
+    static constexpr int ZS = D4 + 4;                                                  // LDS doubles per chain (normals + the saved slot)
+};
+
+struct GChain { uint64_t n; int saved; double saved_y; };     // the chain's stream: uniform over its 16 lanes
+
+// ---------------------------------------------------------------- normals: sixteen polar attempts of a chain at a time
+// z[t] <- the chain's next npar deviates (position 16 t + l16; 0 in the padding), through the chain's LDS row.
+template <int D4>
+MCX_DEV void group_normals(uint32_t k0, uint32_t k1, GChain &g, double *zrow, int l16, int row, int d, bool act, double (&z)[GDims<D4>::NS])
+{
+    using G = GDims<D4>;
+    int k = 0;
+    if (act && g.saved) { if (l16 == 0) zrow[0] = g.saved_y; g.saved = 0; k = 1; }     // normal_bm's cached second deviate, mcmcrand.F90:172-175
+    bool need = act && (k < d);
+    bool newsave = false;
+    while (__any(need)) {
+        const uint64_t b = (g.n >> 1) + (uint64_t)l16;
+        const bool odd = (g.n & 1) != 0;
+        uint32_t w0, w1, w2, w3;
+        philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), k0, k1, w0, w1, w2, w3);
+        // n odd (a single uniform was drawn since the last pair): attempt a takes the second half of block b and the first
+        // half of block b + 1 = lane a + 1's block; the row's last lane has no such neighbour and sits the round out
+        const uint32_t nw0 = (uint32_t)__shfl_down((int)w0, 1), nw1 = (uint32_t)__shfl_down((int)w1, 1);
+        double x1 = odd ? bits_to_uniform(w2, w3) : bits_to_uniform(w0, w1);
+        double x2 = odd ? bits_to_uniform(nw0, nw1) : bits_to_uniform(w2, w3);
+        const bool valid = !(odd && l16 == 15);
+        x1 = 2.0 * x1 - 1.0; x2 = 2.0 * x2 - 1.0;
+        const double xx = x1 * x1 + x2 * x2;
+        const bool ok = valid && (xx < 1.0) && (xx != 0.0);
+        const double xs = ok ? xx : 0.5;
+        const double zz = sqrt(-2.0 * d_log(xs) / xs);
+        const double za = zz * x2, zb = zz * x1;                   // this call's deviate, the next call's (mcmcrand.F90:183-186)
+        const uint32_t okm = (uint32_t)(__ballot(ok && need) >> (16 * row)) & 0xffffu;
+        const int pre = __popc(okm & ((1u << l16) - 1u));          // accepted attempts before this one
+        const int m = (d - k + 1) >> 1;                            // pairs the chain still needs
+        const int tot = __popc(okm);
+        const uint32_t mth = (uint32_t)(__ballot(ok && need && pre == m - 1) >> (16 * row)) & 0xffffu;
+        if (ok && need && pre < m) {
+            const int pos = k + 2 * pre;
+            zrow[pos] = za;
+            if (pos + 1 < d) zrow[pos + 1] = zb; else zrow[D4] = zb;
+        }
+        if (need) {
+            if (tot >= m) {
+                g.n += 2ull * (uint64_t)__ffs((int)mth);            // attempts up to and including the m-th accepted one
+                newsave = ((d - k) & 1) != 0;                       // its second deviate is left over
+                k = d; need = false;
+            } else {
+                g.n += odd ? 30ull : 32ull;
+                k += 2 * tot;
+            }
+        }
+    }
+    // (the wave's LDS operations retire in order: its reads below see its writes above)
+    sfor<0, G::NS>([&](auto T) __attribute__((always_inline)) {
+        constexpr int t = decltype(T)::value;
+        const int pos = 16 * t + l16;
+        z[t] = (pos < d) ? zrow[pos] : 0.0;
+    });
+    if (newsave) { g.saved = 1; g.saved_y = zrow[D4]; }
+}
+
+// one uniform for the chains with `take` (MCMC_reject, MCMC_DRAM.F90:150-151); every lane computes the block
+MCX_DEV double group_uniform(uint32_t k0, uint32_t k1, GChain &g, bool take)
+{
+    const uint64_t blk = g.n >> 1;
+    uint32_t x0, x1, x2, x3;
+    philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), k0, k1, x0, x1, x2, x3);
+    const double u = (g.n & 1) ? bits_to_uniform(x2, x3) : bits_to_uniform(x0, x1);
+    if (take) g.n += 1;
+    return u;
+}
+
+// ---------------------------------------------------------------- checkbounds / priorfun / ssfunction on a group's vector
+template <int D4>
+struct GTarget {
+    using G = GDims<D4>;
+    double lo[G::NS], hi[G::NS], pmu[G::NS], psig[G::NS], mu[G::NS];
+    bool has_lo, has_hi, has_pri;
+};
+
+template <int D4>
+MCX_DEV bool group_inbounds(const GTarget<D4> &T, const double (&x)[GDims<D4>::NS], int l16, int row, int d)
+{
+    using G = GDims<D4>;
+    bool bad = false;
+    sfor<0, G::NS>([&](auto S) __attribute__((always_inline)) {
+        constexpr int s = decltype(S)::value;
+        if (16 * s + l16 < d) {
+            if (T.has_lo) bad = bad || !(x[s] > T.lo[s]);
+            if (T.has_hi) bad = bad || !(x[s] < T.hi[s]);
+        }
+    });
+    if (!(T.has_lo || T.has_hi)) return true;
+    return ((uint32_t)(__ballot(bad) >> (16 * row)) & 0xffffu) == 0u;
+}
+
+// priorfun.f90:96-100: sum over the parameters with sigma > 0 of ((theta - mu) / sigma)**2, in index order from 0
+template <int D4>
+MCX_DEV double group_prior(const GTarget<D4> &T, const double (&x)[GDims<D4>::NS], int l16, int d)
+{
+    using G = GDims<D4>;
+    double p = 0.0;
+    if (T.has_pri) {
+        sfor<0, G::NS>([&](auto S) __attribute__((always_inline)) {
+            constexpr int s = decltype(S)::value;
+            double qq = 0.0;
+            if (16 * s + l16 < d && T.psig[s] > 0.0) { const double q = (x[s] - T.pmu[s]) / T.psig[s]; qq = q * q; }
+            blk_addchain<G::blk(s)>(p, qq);          // (adding +0 for the parameters left out changes nothing: p >= +0)
+        });
+    }
+    return p;
+}
+
+template <int D4>
+MCX_DEV double group_ss(const DevTarget &t, const GTarget<D4> &T, const double (&x)[GDims<D4>::NS], int l16, int d,
+                        const double *__restrict__ g_lamT)
+{
+    using G = GDims<D4>;
+    double ss = 0.0;
+    if (t.kind == TGT_BANANA) {                       // target_ss: ss = fma chain over theta_k**2, k ascending from 2
+        const double th0 = row_bcast<0>(x[0]), th1 = row_bcast<1>(x[0]);
+        const double t1 = th0 * th0;
+        const double q = dfma(t.b, t1, th1) - 100.0 * t.b;
+        ss = dfma(q, q, t1 / 100.0);
+        sfor<0, G::NS>([&](auto S) __attribute__((always_inline)) {
+            constexpr int s = decltype(S)::value;
+            const double w = (s == 0 && l16 < 2) ? 0.0 : x[s];        // fma(0, 0, ss) = ss: positions 0, 1 and the padding drop out
+            blk_sqchain<G::blk(s)>(ss, w);
+        });
+    } else if (t.kind == TGT_EXPDATA) {               // ss = fma chain over the residuals, data index ascending
+        const double th0 = row_bcast<0>(x[0]), th1 = row_bcast<1>(x[0]);
+        for (int base = 0; base < t.ndata; base += 16) {
+            const int i = base + l16;
+            double r = 0.0;
+            if (i < t.ndata) r = t.y[i] - th0 * d_exp(-(th1 * t.x[i]));
+            blk_sqchain<16>(ss, r);
+        }
+    } else {                                          // Gaussian: mcxt_ss_gauss (oracle/mcx_targets.h), lane = row of Lam
+        double v[G::NS];
+        sfor<0, G::NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; v[s] = (16 * s + l16 < d) ? x[s] - T.mu[s] : 0.0; });
+        sfor<0, G::NS>([&](auto S) __attribute__((always_inline)) {
+            constexpr int s = decltype(S)::value;
+            const int c = 16 * s + l16;
+            double y = 0.0;
+            sfor<0, G::NS>([&](auto TT) __attribute__((always_inline)) {
+                constexpr int tb = decltype(TT)::value;
+                constexpr int n = G::blk(tb);
+                double lam[n];
+#pragma unroll
+                for (int u = 0; u < n; ++u) { const int j = 16 * tb + u; lam[u] = (c < d && j < d) ? g_lamT[(size_t)j * d + c] : 0.0; }
+                blk_fmac<n>(y, v[tb], lam);
+            });
+            // the block's four partial chains q_k over the rows 16 s + k + 4 r: lane k < 4 collects lanes k + 4, k + 8, k + 12
+            double q = y * v[s];
+            const double y4 = row_down<4>(y), v4 = row_down<4>(v[s]), y8 = row_down<8>(y), v8 = row_down<8>(v[s]), y12 = row_down<12>(y), v12 = row_down<12>(v[s]);
+            if (c + 4 < d) q = dfma(y4, v4, q);
+            if (c + 8 < d) q = dfma(y8, v8, q);
+            if (c + 12 < d) q = dfma(y12, v12, q);
+            const double q0 = row_bcast<0>(q), q1 = row_bcast<1>(q), q2 = row_bcast<2>(q), q3 = row_bcast<3>(q);
+            if (16 * s + 0 < d) ss = (s == 0) ? q0 : ss + q0;
+            if (16 * s + 1 < d) ss = ss + q1;
+            if (16 * s + 2 < d) ss = ss + q2;
+            if (16 * s + 3 < d) ss = ss + q3;
+        });
+    }
+    return ss;
+}
+
+// ---------------------------------------------------------------- the kernel
+// Iterations it0..it1 of MCMC_run (MCMC_run.F90:41-107) for the four chains of a wave: method = 'dram' without (DR = false) or
+// with (true) the delayed-rejection stage, per-chain Cholesky factors, one of the single-launch device targets, nycol = 1,
+// updatesigma = 0.  accb: one byte per chain and iteration of the launch (accepted or not); group_pack_kernel turns them
+// into the tile ballots the adaptation and the chain decoder read.
+template <int D4, bool DR>
+__global__ __launch_bounds__(64, 1) void group_step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ g_lamT, uint8_t *accb)
+{
+    using G = GDims<D4>;
+    constexpr int NS = G::NS;
+    __shared__ double zl[4 * G::ZS];
+    const int lane = threadIdx.x, l16 = lane & 15, row = lane >> 4, d = E.d;
+    const int chain = blockIdx.x * 4 + row, tile = chain >> 6, cl = chain & 63;
+    const size_t nslots = (size_t)E.ntiles * 64;
+    double *zrow = zl + row * G::ZS;
+
+    // ---- factors into registers (once per launch)
+    double Rr[G::NR], R2r[DR ? G::NR : 1], Sr[DR ? NS * D4 : 1];
+    {
+        const double *Rt = E.R + (size_t)tile * E.P * 64;
+        const double *R2t = DR ? E.R2 + (size_t)tile * E.P * 64 : nullptr;
+        const double *iCt = DR ? E.iC + (size_t)tile * E.P * 64 : nullptr;
+        sfor<0, NS>([&](auto S) __attribute__((always_inline)) {
+            constexpr int s = decltype(S)::value;
+            const int c = 16 * s + l16;
+#pragma unroll
+            for (int i = 0; i < G::rows(s); ++i) {
+                const bool in = (c < d) && (i <= c);
+                const size_t e = in ? (size_t)pidx(i, c, d) : 0;
+                const double r = Rt[e * 64 + cl];
+                Rr[G::off(s) + i] = in ? r : 0.0;
+                if constexpr (DR) { const double r2 = R2t[e * 64 + cl]; R2r[G::off(s) + i] = in ? r2 : 0.0; }
+            }
+            if constexpr (DR) {
+#pragma unroll
+                for (int j = 0; j < D4; ++j) {
+                    const bool in = (c < d) && (j < d);
+                    const size_t e = in ? (size_t)((c <= j) ? pidx(c, j, d) : pidx(j, c, d)) : 0;
+                    const double v = iCt[e * 64 + cl];
+                    Sr[s * D4 + j] = in ? v : 0.0;
+                }
+            }
+        });
+    }
+    // ---- the target's per-parameter tables and the state
+    GTarget<D4> T;
+    T.has_lo = E.tgt.lo != nullptr; T.has_hi = E.tgt.hi != nullptr; T.has_pri = E.tgt.pmu != nullptr;
+    double th[NS];
+    sfor<0, NS>([&](auto S) __attribute__((always_inline)) {
+        constexpr int s = decltype(S)::value;
+        const int c = 16 * s + l16, cc = c < d ? c : 0;
+        T.lo[s] = T.has_lo ? E.tgt.lo[cc] : 0.0; T.hi[s] = T.has_hi ? E.tgt.hi[cc] : 0.0;
+        T.pmu[s] = T.has_pri ? E.tgt.pmu[cc] : 0.0; T.psig[s] = T.has_pri ? E.tgt.psig[cc] : 0.0;
+        T.mu[s] = (E.tgt.kind == TGT_GAUSS) ? E.tgt.mu[cc] : 0.0;
+        th[s] = (c < d) ? TIDX(E.theta, tile, d, cc, cl) : 0.0;
+    });
+    GChain g;
+    g.n = TIDX(E.rngn, tile, 1, 0, cl);
+    g.saved = (int)TIDX(E.ictr, tile, NICTR, I_SAVED, cl);
+    g.saved_y = TIDX(E.scal, tile, NSCAL, S_SAVEDY, cl);
+    const uint32_t k0 = E.k0, k1 = E.chain_id0 + (uint32_t)chain;
+    double ss1 = TIDX(E.scal, tile, NSCAL, S_SS1, cl), pri1 = TIDX(E.scal, tile, NSCAL, S_PRI1, cl);
+    const double sigma2 = TIDX(E.scal, tile, NSCAL, S_SIGMA2, cl);
+    double alpha12 = TIDX(E.scal, tile, NSCAL, S_ALPHA12, cl);
+    uint32_t stayed = TIDX(E.ictr, tile, NICTR, I_STAYED, cl), bnd = TIDX(E.ictr, tile, NICTR, I_BNDSTAYED, cl);
+    uint32_t chainind = TIDX(E.ictr, tile, NICTR, I_CHAININD, cl), curcount = TIDX(E.ictr, tile, NICTR, I_CURCOUNT, cl);
+    uint32_t dracc = TIDX(E.ictr, tile, NICTR, I_DRACC, cl), drtries = TIDX(E.ictr, tile, NICTR, I_DRTRIES, cl);
+
+    for (int it = it0; it <= it1; ++it) {
+        // ---- newpar = MCMC_propose(oldpar, R): the iteration's first draws
+        double z[NS], c1[NS];
+        group_normals<D4>(k0, k1, g, zrow, l16, row, d, true, z);
+        sfor<0, NS>([&](auto S) __attribute__((always_inline)) {
+            constexpr int s = decltype(S)::value;
+            double p = 0.0;
+            sfor<0, (G::rows(s) + 15) / 16>([&](auto TT) __attribute__((always_inline)) {
+                constexpr int tb = decltype(TT)::value;
+                constexpr int n = (G::rows(s) - 16 * tb) < 16 ? (G::rows(s) - 16 * tb) : 16;
+                blk_fmac<n>(p, z[tb], &Rr[G::off(s) + 16 * tb]);
+            });
+            c1[s] = th[s] + p;                           // newpar = oldpar + R'z
+        });
+        // ---- bounds, prior, ss, alpha, reject
+        const bool inb = group_inbounds<D4>(T, c1, l16, row, d);
+        double pri2 = group_prior<D4>(T, c1, l16, d);
+        double ss2 = group_ss<D4>(E.tgt, T, c1, l16, d, g_lamT);
+        bool reject = true, takeu = false;
+        if (!inb) { alpha12 = 0.0; if (!DR) bnd += 1; }              // MCMC_run.F90:49 (with DR an out-of-bounds first stage is not counted)
+        else {
+            alpha12 = d_alpha(ss1, pri1, ss2, pri2, sigma2);
+            if (alpha12 >= 1.0) reject = false;                     // MCMC_reject, MCMC_DRAM.F90:140-155
+            else if (alpha12 > 0.0) takeu = true;
+        }
+        if (__any(takeu)) { const double u = group_uniform(k0, k1, g, takeu); if (takeu && u <= alpha12) reject = false; }
+        // ---- second stage: one delayed-rejection try with R2 = R/drscale (MCMC_run.F90:65-91)
+        bool dr_moved = false;
+        double c2[NS];
+        if constexpr (DR) {
+            if (__any(reject)) {
+                const bool m = reject;
+                if (m) drtries += 1;
+                double z2[NS];
+                group_normals<D4>(k0, k1, g, zrow, l16, row, d, m, z2);
+                sfor<0, NS>([&](auto S) __attribute__((always_inline)) {
+                    constexpr int s = decltype(S)::value;
+                    double p = 0.0;
+                    sfor<0, (G::rows(s) + 15) / 16>([&](auto TT) __attribute__((always_inline)) {
+                        constexpr int tb = decltype(TT)::value;
+                        constexpr int n = (G::rows(s) - 16 * tb) < 16 ? (G::rows(s) - 16 * tb) : 16;
+                        blk_fmac<n>(p, z2[tb], &R2r[G::off(s) + 16 * tb]);
+                    });
+                    c2[s] = th[s] + p;
+                });
+                const bool inb2 = group_inbounds<D4>(T, c2, l16, row, d);
+                const double pri3 = group_prior<D4>(T, c2, l16, d);
+                const double ss3 = group_ss<D4>(E.tgt, T, c2, l16, d, g_lamT);
+                // MCMC_DR_alpha13, MCMC_DRAM.F90:162-186: the two quadratic forms dx' iC dx, dx_a = newpar2 - newpar, dx_b = oldpar - newpar
+                double xa[NS], xb[NS], ta[NS], tb_[NS];
+                sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; xa[s] = c2[s] - c1[s]; xb[s] = th[s] - c1[s]; });
+                sfor<0, NS>([&](auto S) __attribute__((always_inline)) {
+                    constexpr int s = decltype(S)::value;
+                    double ya = -0.0, yb = -0.0;                      // first term a plain product (see blk_fmac2)
+                    sfor<0, NS>([&](auto TT) __attribute__((always_inline)) {
+                        constexpr int tb = decltype(TT)::value;
+                        blk_fmac2<G::blk(tb)>(ya, yb, xa[tb], xb[tb], &Sr[s * D4 + 16 * tb]);
+                    });
+                    const bool in = 16 * s + l16 < d;
+                    ta[s] = in ? ya * xa[s] : 0.0; tb_[s] = in ? yb * xb[s] : 0.0;
+                });
+                double qa = 0.0, qb = 0.0;
+                sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; blk_addchain<G::blk(s)>(qa, ta[s]); blk_addchain<G::blk(s)>(qb, tb_[s]); });
+                bool take2 = false, rej2 = true;
+                double alpha13 = 0.0;
+                if (m) {
+                    if (!inb2) bnd += 1;
+                    else {
+                        double alpha32;
+                        if (alpha12 == 0.0) alpha32 = 0.0;
+                        else alpha32 = min1(d_exp(-0.5 * ((ss2 - ss3) / sigma2 + (pri2 - pri3))));
+                        const double l2 = -0.5 * ((ss3 - ss1) / sigma2 + (pri3 - pri1));
+                        const double q1 = -0.5 * (qa - qb);
+                        alpha13 = min1(d_exp(l2 + q1) * (1.0 - alpha32) / (1.0 - alpha12));
+                        if (alpha13 >= 1.0) rej2 = false;
+                        else if (alpha13 > 0.0) take2 = true;
+                    }
+                }
+                if (__any(take2)) { const double u = group_uniform(k0, k1, g, take2); if (take2 && u <= alpha13) rej2 = false; }
+                if (m && inb2 && !rej2) { dracc += 1; reject = false; dr_moved = true; ss2 = ss3; pri2 = pri3; }
+            }
+        }
+        if (reject) { stayed += 1; curcount += 1; }
+        else { ss1 = ss2; pri1 = pri2; chainind += 1; curcount = 1; }
+        // ---- oldpar = newpar; MCMC_savechain (MCMC_aux.F90:167-185): accepted row into the ring, accept byte for the ballots
+        if (!reject) {
+            sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; th[s] = (DR && dr_moved) ? c2[s] : c1[s]; });
+            if (E.hist) {
+                double *h = E.hist + ((size_t)tile * E.wcap + (it % E.wcap)) * (size_t)E.hs * 64;
+                sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = 16 * s + l16; if (c < d) h[(size_t)c * 64 + cl] = th[s]; });
+                if (l16 == 0) h[(size_t)d * 64 + cl] = ss1;
+            }
+        }
+        if (accb && l16 == 0) accb[(size_t)(it - it0) * nslots + chain] = reject ? (uint8_t)0 : (uint8_t)1;
+    }
+
+    sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = 16 * s + l16; if (c < d) TIDX(E.theta, tile, d, c, cl) = th[s]; });
+    if (l16 == 0) {
+        TIDX(E.rngn, tile, 1, 0, cl) = g.n;
+        TIDX(E.ictr, tile, NICTR, I_SAVED, cl) = (uint32_t)g.saved;
+        TIDX(E.scal, tile, NSCAL, S_SAVEDY, cl) = g.saved_y;
+        TIDX(E.scal, tile, NSCAL, S_SS1, cl) = ss1; TIDX(E.scal, tile, NSCAL, S_PRI1, cl) = pri1;
+        TIDX(E.scal, tile, NSCAL, S_ALPHA12, cl) = alpha12;
+        TIDX(E.ictr, tile, NICTR, I_STAYED, cl) = stayed; TIDX(E.ictr, tile, NICTR, I_BNDSTAYED, cl) = bnd;
+        TIDX(E.ictr, tile, NICTR, I_CHAININD, cl) = chainind; TIDX(E.ictr, tile, NICTR, I_CURCOUNT, cl) = curcount;
+        TIDX(E.ictr, tile, NICTR, I_DRACC, cl) = dracc; TIDX(E.ictr, tile, NICTR, I_DRTRIES, cl) = drtries;
+    }
+}
+
+// accept bytes of a launch -> the tile ballots (MCMC_savechain's repeat counts are decoded from them): one thread per
+// (iteration, tile); bit l of a ballot = chain l of the tile accepted
+__global__ void group_pack_kernel(EngineDev E, const uint8_t *accb, int it0, int it1)
+{
+    const long long n = (long long)(it1 - it0 + 1) * E.ntiles;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int i = (int)(idx / E.ntiles), tile = (int)(idx % E.ntiles), it = it0 + i;
+    const uint64_t *p = (const uint64_t *)(accb + ((size_t)i * E.ntiles + tile) * 64);
+    uint64_t m = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) m |= (((p[w] & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56) << (8 * w);
+    if (E.hist) E.wacc[(size_t)tile * E.wcap + (it % E.wcap)] = m;
+    if (E.accmask) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = m;
+}
+
+} // namespace mcx

@@ -1,0 +1,148 @@
+"""The lane-group-per-chain step kernel (mcmcf90_amd/csrc/mcx_group.hpp: four chains per wave, R / R2 / iC in registers, sixteen
+polar attempts of a chain at a time) against the lane-per-chain kernels and the oracle: the same chain bit for bit --
+state, accept ballots, stream position, counters, the decoded chain, the adapted factors and covariance
+(MCMC_run.F90:41-107, MCMC_DRAM.F90:20-31,100-186, mcmcrand.F90:166-190)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def _problem(kind, d, seed, priors=False, bounds=False):
+    rng = np.random.default_rng(seed)
+    pkw = dict(kind=kind, npar=d, par0=np.full(d, 0.05), cmat0=(0.5 / d) * np.eye(d))
+    if kind == "gauss":
+        A = rng.standard_normal((d, d)) / np.sqrt(d)
+        pkw.update(mu=np.linspace(-1, 1, d), lam=A @ A.T + np.eye(d))
+    elif kind == "banana":
+        pkw.update(b=0.1, cmat0=(2.0 / d) * np.eye(d))
+    else:
+        x = np.linspace(0.0, 6.0, 21)
+        y = 1.5 * np.exp(-0.4 * x) + 0.05 * rng.standard_normal(x.size)
+        pkw.update(xdata=x, ydata=y, par0=np.concatenate([[1.0, 0.5], np.zeros(d - 2)])[:d], cmat0=0.01 * np.eye(d))
+    if priors:
+        sig = np.where(np.arange(d) % 3 == 1, -1.0, 2.0)            # every third parameter flat
+        pkw.update(pri_mu=np.full(d, 0.1), pri_sig=sig)
+    if bounds:
+        pkw.update(lo=np.full(d, -1.5), hi=np.full(d, 1.2))
+    return pkw
+
+
+def _run(ckw, pkw, nchains, group, monkeypatch, chains=(0, 1, 5, 69), **ekw):
+    from mcmcf90_amd import engine_from_problem
+    monkeypatch.setenv("MCMCX_GROUP", "1" if group else "0")
+    e = engine_from_problem(ckw, pkw, nchains=nchains, chain_id0=3, record_accept=1, **ekw)
+    e.init(); e.run()
+    k = e.last_kernel()
+    assert k.startswith("group_step_kernel") == bool(group), k
+    chains = [c for c in chains if c < nchains]
+    out = dict(theta=e.theta().copy(), masks=e.accept_masks().copy(), scal=e.scalars().copy(),
+               rng=[e.rng(c) for c in chains], ctr=[e.counters(c) for c in chains], R=[e.R(c).copy() for c in chains])
+    if ckw.get("drscale", 0) > 0:
+        out["dr"] = [e.dr_state(c) for c in chains]
+    if ckw.get("doadapt", 1):
+        out["cov"] = [e.chaincov(c) for c in chains]
+    if ekw.get("record_chain"):
+        out["chain"] = [e.chain(c) for c in chains]
+    e.close()
+    return out, chains
+
+
+def _same(a, b):
+    assert np.array_equal(_bits(a["theta"]), _bits(b["theta"])), "state"
+    assert np.array_equal(a["masks"], b["masks"]), "accept ballots"
+    assert np.array_equal(_bits(a["scal"]), _bits(b["scal"])), "ss1 / pri1 / sigma2 / alpha12"
+    assert a["rng"] == b["rng"] and a["ctr"] == b["ctr"], (a["rng"], b["rng"], a["ctr"], b["ctr"])
+    for x, y in zip(a["R"], b["R"]):
+        np.testing.assert_array_equal(_bits(np.triu(x)), _bits(np.triu(y)))
+    for key in ("dr", "cov", "chain"):
+        if key in a:
+            for x, y in zip(a[key], b[key]):
+                for u, v in zip(x, y):
+                    np.testing.assert_array_equal(_bits(u), _bits(v))
+
+
+CASES = [
+    # kind, npar, delayed rejection, priors, bounds
+    ("banana", 20, 2.0, False, False),           # BASELINE config 3's shape
+    ("banana", 20, 0.0, False, False),
+    ("gauss", 20, 2.0, True, True),
+    ("gauss", 13, 3.0, False, True),             # odd npar: the cached second deviate changes hands every iteration
+    ("gauss", 11, 0.0, True, False),
+    ("gauss", 16, 0.0, False, False),
+    ("gauss", 17, 2.0, False, False),            # one parameter in the second slot
+    ("banana", 5, 2.0, True, True),
+    ("expdata", 2, 2.0, False, False),           # BASELINE config 1's model, device-resident
+    ("expdata", 2, 0.0, True, True),
+    ("gauss", 24, 2.0, False, False),
+    ("gauss", 29, 0.0, False, True),
+    ("gauss", 32, 2.0, True, False),
+    ("banana", 31, 1.5, False, False),
+]
+
+
+@pytest.mark.parametrize("kind,d,drscale,priors,bounds", CASES, ids=["%s%d%s%s%s" % (k, d, "_dr" if s else "", "_pri" if p else "", "_bnd" if b else "") for k, d, s, p, b in CASES])
+def test_group_kernel_equals_lane_kernels_and_oracle(oracle, monkeypatch, kind, d, drscale, priors, bounds):
+    """130 iterations with two adaptations (the factors are re-read from the adaptation's output), 70 chains: a ragged last tile and
+    a last wave with two chains of padding."""
+    ckw = dict(nsimu=130, adaptint=50, updatesigma=0, drscale=drscale)
+    pkw = _problem(kind, d, 40 + d, priors, bounds)
+    g, chains = _run(ckw, pkw, 70, True, monkeypatch)
+    l, _ = _run(ckw, pkw, 70, False, monkeypatch)
+    _same(g, l)
+    cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
+    for i, c in enumerate(chains[:3]):
+        o = oracle.run_chain(cfg, prob, chain_id=3 + c)
+        np.testing.assert_array_equal(_bits(g["theta"][c]), _bits(o.theta))
+        assert g["rng"][i][0] == o.rng_n and g["ctr"][i]["stayed"] == o.stayed
+        np.testing.assert_array_equal(_bits(np.triu(g["R"][i])), _bits(np.triu(o.R)))
+
+
+def test_group_kernel_full_chain_and_burnin(oracle, monkeypatch):
+    """record_chain (every accepted row through the ring, ballots from the accept bytes), burn-in scaling + greedy restart, launches
+    cut at 256 iterations and by mcmcx_run calls of odd lengths."""
+    from mcmcf90_amd import engine_from_problem
+    d = 20
+    ckw = dict(nsimu=700, adaptint=60, updatesigma=0, drscale=2.0, doburnin=1, burnintime=150, badaptint=30, greedy=1, scalelimit=0.1, scalefactor=2.0)
+    pkw = _problem("banana", d, 7)
+    res = []
+    for group in (True, False):
+        monkeypatch.setenv("MCMCX_GROUP", "1" if group else "0")
+        e = engine_from_problem(ckw, pkw, nchains=66, chain_id0=11, record_chain=1, record_accept=1)
+        e.init()
+        for upto in (17, 18, 301, 700):
+            e.run(upto)
+        assert e.last_kernel().startswith("group_step_kernel") == group
+        res.append((e.theta().copy(), e.accept_masks().copy(), [e.chain(c) for c in (0, 65)], [e.rng(c) for c in (0, 65)], [e.chaincov(c) for c in (0, 65)], [e.counters(c) for c in (0, 65)]))
+        e.close()
+    a, b = res
+    assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1]) and a[3] == b[3] and a[5] == b[5]
+    for x, y in zip(a[2] + a[4], b[2] + b[4]):
+        for u, v in zip(x, y):
+            np.testing.assert_array_equal(_bits(u), _bits(v))
+    o = oracle.run_chain(oracle.make_cfg(**ckw), oracle.Problem(**pkw), chain_id=11)
+    np.testing.assert_array_equal(_bits(a[0][0]), _bits(o.theta))
+    assert a[3][0][0] == o.rng_n
+    ch = a[2][0][0]
+    assert ch.shape[0] == o.chain.shape[0] and np.array_equal(_bits(ch), _bits(o.chain))
+
+
+def test_group_kernel_config3_fixture(oracle, monkeypatch):
+    """BASELINE config 3's fixture from the real reference (banana d = 20, DRAM): run-length column and stream position."""
+    from golden_util import load
+    from mcmcf90_amd import engine_from_problem
+    z, cfg, prob = load("c3_banana20_dram", oracle)
+    monkeypatch.setenv("MCMCX_GROUP", "1")
+    ckw = {k[4:]: z[k].item() for k in z.files if k.startswith("cfg_") and k[4:] not in ("dodr", "doscam", "usesvd")}
+    pkw = {k[5:]: (z[k].item() if z[k].ndim == 0 else z[k]) for k in z.files if k.startswith("prob_")}
+    e = engine_from_problem(ckw, pkw, nchains=5, chain_id0=int(z["chain_id"]), record_chain=1)
+    e.init(); e.run()
+    assert e.last_kernel().startswith("group_step_kernel")
+    ch, ss, s2 = e.chain(0)
+    assert np.array_equal(ch[:, -1].astype(np.int64), np.asarray(z["runlen"], dtype=np.int64))
+    assert e.rng(0)[0] == int(z["rng_n"])
+    e.close()
