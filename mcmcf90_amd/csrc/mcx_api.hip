@@ -90,7 +90,7 @@ struct mcmcx_engine {
     double *d_ramscale = nullptr, *d_moments = nullptr;
     double *d_Gc = nullptr, *d_Vc = nullptr, *d_svc = nullptr; uint8_t *d_need = nullptr, *d_state = nullptr; int *d_anyrot = nullptr; int svd_b = 0;    // blocked SVD of the adaptation (large npar)
     int wcap = 0;
-    int group_d4 = 0; uint8_t *d_accb = nullptr;         // lane-group step kernel (mcx_group.hpp): npar rounded up to four when it is the one to launch; accept bytes of a launch
+    int group_d4 = 0, group_drm = 0; bool group_check_due = true; int *d_gflag = nullptr; uint8_t *d_accb = nullptr;         // lane-group step kernel (mcx_group.hpp): npar rounded up to four when it is the one to launch; accept bytes of a launch
     bool external = false; double *d_r1 = nullptr; std::vector<double> h_r1;      // MCMC_run1: the caller evaluates; exchange vectors of run1_kernel
     // timing of the step kernel
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -328,11 +328,24 @@ template <int D4>
 static void launch_group_d4(mcmcx_engine *h, int it0, int it1)
 {
     const dim3 g(h->ntiles * 16), b(64);
-    if (h->dodr) { h->last_kernel = "group_step_kernel<DR>"; hipLaunchKernelGGL((group_step_kernel<D4, true>), g, b, 0, h->stream, h->E, it0, it1, h->E.tgt.lamT, h->d_accb); }
-    else { h->last_kernel = "group_step_kernel"; hipLaunchKernelGGL((group_step_kernel<D4, false>), g, b, 0, h->stream, h->E, it0, it1, h->E.tgt.lamT, h->d_accb); }
+    const double *lam = h->E.tgt.lamT;
+    if (h->group_drm == 0) { h->last_kernel = "group_step_kernel"; hipLaunchKernelGGL((group_step_kernel<D4, 0>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)nullptr, 0); }
+    else if (h->group_drm == 1) { h->last_kernel = "group_step_kernel<DR>"; hipLaunchKernelGGL((group_step_kernel<D4, 1>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)nullptr, 0); }
+    else {
+        // drscale a power of two: the instantiation without R2 runs unless the device flag says that some factor leaves the range in
+        // which R'z / drscale is R2'z bit for bit; the general one is queued behind the same flag and returns at once otherwise
+        h->last_kernel = "group_step_kernel<DR2>";
+        hipLaunchKernelGGL((group_step_kernel<D4, 2>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)h->d_gflag, 0);
+        hipLaunchKernelGGL((group_step_kernel<D4, 1>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)h->d_gflag, 1);
+    }
 }
 static void launch_group(mcmcx_engine *h, int it0, int it1)
 {
+    if (h->group_drm == 2 && h->group_check_due) {       // the factors have been rewritten since the last look
+        (void)hipMemsetAsync(h->d_gflag, 0, sizeof(int), h->stream);
+        hipLaunchKernelGGL(group_check_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, h->d_gflag);
+        h->group_check_due = false;
+    }
     switch (h->group_d4) {
     case 4: launch_group_d4<4>(h, it0, it1); break;
     case 8: launch_group_d4<8>(h, it0, it1); break;
@@ -1483,6 +1496,13 @@ int mcmcx_init(mcmcx_handle h)
         const bool on = ev ? atoi(ev) != 0 : false;
         if (on) h->group_d4 = (d + 3) & ~3;
         if (h->group_d4 && (E.hist || E.accmask) && (rc = dev_alloc(h, &h->d_accb, L * (size_t)GROUP_MAXSEG))) return rc;
+        if (h->group_d4) {
+            int ex = 0;
+            const bool pow2 = h->dodr && c.drscale > 0.0 && std::frexp(c.drscale, &ex) == 0.5 && ex > -64 && ex < 64;
+            h->group_drm = !h->dodr ? 0 : (pow2 && !(getenv("MCMCX_GROUP_DR2") && atoi(getenv("MCMCX_GROUP_DR2")) == 0)) ? 2 : 1;
+            h->group_check_due = true;
+            if (h->group_drm == 2 && (rc = dev_alloc(h, &h->d_gflag, 1))) return rc;
+        }
     }
     // 1/simuind**nuparam, computed like the reference: real(simuind) is default REAL (MCMC_run_ram.F90:166)
     {
@@ -1635,7 +1655,7 @@ static int run_impl(mcmcx_handle h, int32_t upto)
         int trc = 0;
         if (mode != 0) {
             if (h->pooled) trc = pooled_tick(h, end, mode);
-            else { launch_adapt(h, end, mode); HIPCHK(hipGetLastError()); }
+            else { launch_adapt(h, end, mode); h->group_check_due = true; HIPCHK(hipGetLastError()); }
         }
         if (ramtick && trc == 0) trc = pooled_ram_tick(h, end);
         if (trc) return trc;

@@ -205,40 +205,37 @@ MCX_DEV double group_uniform(uint32_t k0, uint32_t k1, GChain &g, bool take)
 }
 
 // ---------------------------------------------------------------- checkbounds / priorfun / ssfunction on a group's vector
+// (the per-parameter tables -- bounds, prior means and sigmas, the Gaussian target's mean -- are read where they are used: they are
+//  shared by all chains and stay in the vector L1; holding them would cost ten registers per slot for the whole launch)
 template <int D4>
-struct GTarget {
-    using G = GDims<D4>;
-    double lo[G::NS], hi[G::NS], pmu[G::NS], psig[G::NS], mu[G::NS];
-    bool has_lo, has_hi, has_pri;
-};
-
-template <int D4>
-MCX_DEV bool group_inbounds(const GTarget<D4> &T, const double (&x)[GDims<D4>::NS], int l16, int row, int d)
+MCX_DEV bool group_inbounds(const DevTarget &t, const double (&x)[GDims<D4>::NS], int l16, int row, int d)
 {
     using G = GDims<D4>;
+    if (!(t.lo || t.hi)) return true;
     bool bad = false;
     sfor<0, G::NS>([&](auto S) __attribute__((always_inline)) {
         constexpr int s = decltype(S)::value;
-        if (16 * s + l16 < d) {
-            if (T.has_lo) bad = bad || !(x[s] > T.lo[s]);
-            if (T.has_hi) bad = bad || !(x[s] < T.hi[s]);
+        const int c = 16 * s + l16;
+        if (c < d) {
+            if (t.lo) bad = bad || !(x[s] > t.lo[c]);
+            if (t.hi) bad = bad || !(x[s] < t.hi[c]);
         }
     });
-    if (!(T.has_lo || T.has_hi)) return true;
     return ((uint32_t)(__ballot(bad) >> (16 * row)) & 0xffffu) == 0u;
 }
 
 // priorfun.f90:96-100: sum over the parameters with sigma > 0 of ((theta - mu) / sigma)**2, in index order from 0
 template <int D4>
-MCX_DEV double group_prior(const GTarget<D4> &T, const double (&x)[GDims<D4>::NS], int l16, int d)
+MCX_DEV double group_prior(const DevTarget &t, const double (&x)[GDims<D4>::NS], int l16, int d)
 {
     using G = GDims<D4>;
     double p = 0.0;
-    if (T.has_pri) {
+    if (t.pmu) {
         sfor<0, G::NS>([&](auto S) __attribute__((always_inline)) {
             constexpr int s = decltype(S)::value;
+            const int c = 16 * s + l16;
             double qq = 0.0;
-            if (16 * s + l16 < d && T.psig[s] > 0.0) { const double q = (x[s] - T.pmu[s]) / T.psig[s]; qq = q * q; }
+            if (c < d) { const double sg = t.psig[c]; if (sg > 0.0) { const double q = (x[s] - t.pmu[c]) / sg; qq = q * q; } }
             blk_addchain<G::blk(s)>(p, qq);          // (adding +0 for the parameters left out changes nothing: p >= +0)
         });
     }
@@ -246,8 +243,7 @@ MCX_DEV double group_prior(const GTarget<D4> &T, const double (&x)[GDims<D4>::NS
 }
 
 template <int D4>
-MCX_DEV double group_ss(const DevTarget &t, const GTarget<D4> &T, const double (&x)[GDims<D4>::NS], int l16, int d,
-                        const double *__restrict__ g_lamT)
+MCX_DEV double group_ss(const DevTarget &t, const double (&x)[GDims<D4>::NS], int l16, int d, const double *__restrict__ g_lamT)
 {
     using G = GDims<D4>;
     double ss = 0.0;
@@ -271,7 +267,7 @@ MCX_DEV double group_ss(const DevTarget &t, const GTarget<D4> &T, const double (
         }
     } else {                                          // Gaussian: mcxt_ss_gauss (oracle/mcx_targets.h), lane = row of Lam
         double v[G::NS];
-        sfor<0, G::NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; v[s] = (16 * s + l16 < d) ? x[s] - T.mu[s] : 0.0; });
+        sfor<0, G::NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = 16 * s + l16; v[s] = (c < d) ? x[s] - t.mu[c] : 0.0; });
         sfor<0, G::NS>([&](auto S) __attribute__((always_inline)) {
             constexpr int s = decltype(S)::value;
             const int c = 16 * s + l16;
@@ -301,23 +297,41 @@ MCX_DEV double group_ss(const DevTarget &t, const GTarget<D4> &T, const double (
 }
 
 // ---------------------------------------------------------------- the kernel
-// Iterations it0..it1 of MCMC_run (MCMC_run.F90:41-107) for the four chains of a wave: method = 'dram' without (DR = false) or
-// with (true) the delayed-rejection stage, per-chain Cholesky factors, one of the single-launch device targets, nycol = 1,
-// updatesigma = 0.  accb: one byte per chain and iteration of the launch (accepted or not); group_pack_kernel turns them
-// into the tile ballots the adaptation and the chain decoder read.
-template <int D4, bool DR>
-__global__ __launch_bounds__(64, 1) void group_step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ g_lamT, uint8_t *accb)
+// Iterations it0..it1 of MCMC_run (MCMC_run.F90:41-107) for the four chains of a wave: method = 'dram', per-chain Cholesky factors,
+// one of the single-launch device targets, nycol = 1, updatesigma = 0.  accb: one byte per chain and iteration of the launch
+// (accepted or not); group_pack_kernel turns them into the tile ballots the adaptation and the chain decoder read.
+// DRM = 0: no delayed rejection.  R in registers; two waves per SIMD.
+// DRM = 1: delayed rejection, any drscale: R, R2 and iC in registers (accumulator registers included); one wave per SIMD.
+// DRM = 2: delayed rejection with drscale a power of two: R2 = R / drscale is then exact element by element, and so is every
+//          product and every partial sum of the second-stage proposal -- R2'z = (R'z) / drscale bit for bit as long as nothing
+//          leaves the normal range, which holds when every nonzero |R(i,j)| lies in [2**-500, 2**500] (group_check_kernel looks
+//          at every chain's factor whenever an adaptation has rewritten it and raises a device flag otherwise; the host queues
+//          this kernel AND the DRM = 1 one behind that flag, and the one it does not select returns at once).  R in registers,
+//          iC as a full symmetric square in LDS (the quadratic forms read it with immediate offsets); two waves per SIMD up to
+//          npar = 20.
+#ifndef MCX_GROUP_WAVES2
+#define MCX_GROUP_WAVES2 2
+#endif
+template <int D4, int DRM>
+__global__ __launch_bounds__(64, DRM == 1 ? 1 : MCX_GROUP_WAVES2) void group_step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ g_lamT, uint8_t *accb,
+                                                                                                   const int *__restrict__ gflag, int want)
 {
     using G = GDims<D4>;
     constexpr int NS = G::NS;
-    __shared__ double zl[4 * G::ZS];
+    constexpr bool DR = DRM != 0;
+    if (gflag && ((*gflag != 0) != (want != 0))) return;          // the other instantiation has this launch (wave-uniform: every wave reads the same word)
+    // LDS: [iC squares of the four chains (DRM = 2)] [the chains' normal rows]: a padding lane's read past its chain's square lands in the
+    // next square or in the normal rows (finite or not, its result is discarded)
+    constexpr int SQ = (DRM == 2) ? D4 * D4 : 0;
+    __shared__ double lds[4 * SQ + 4 * G::ZS];
     const int lane = threadIdx.x, l16 = lane & 15, row = lane >> 4, d = E.d;
     const int chain = blockIdx.x * 4 + row, tile = chain >> 6, cl = chain & 63;
     const size_t nslots = (size_t)E.ntiles * 64;
-    double *zrow = zl + row * G::ZS;
+    double *zrow = lds + 4 * SQ + row * G::ZS;
+    const double *icl = lds + row * SQ;
 
-    // ---- factors into registers (once per launch)
-    double Rr[G::NR], R2r[DR ? G::NR : 1], Sr[DR ? NS * D4 : 1];
+    // ---- factors into registers / LDS (once per launch)
+    double Rr[G::NR], R2r[DRM == 1 ? G::NR : 1], Sr[DRM == 1 ? NS * D4 : 1];
     {
         const double *Rt = E.R + (size_t)tile * E.P * 64;
         const double *R2t = DR ? E.R2 + (size_t)tile * E.P * 64 : nullptr;
@@ -331,9 +345,9 @@ __global__ __launch_bounds__(64, 1) void group_step_kernel(EngineDev E, int it0,
                 const size_t e = in ? (size_t)pidx(i, c, d) : 0;
                 const double r = Rt[e * 64 + cl];
                 Rr[G::off(s) + i] = in ? r : 0.0;
-                if constexpr (DR) { const double r2 = R2t[e * 64 + cl]; R2r[G::off(s) + i] = in ? r2 : 0.0; }
+                if constexpr (DRM == 1) { const double r2 = R2t[e * 64 + cl]; R2r[G::off(s) + i] = in ? r2 : 0.0; }
             }
-            if constexpr (DR) {
+            if constexpr (DRM == 1) {
 #pragma unroll
                 for (int j = 0; j < D4; ++j) {
                     const bool in = (c < d) && (j < d);
@@ -342,18 +356,24 @@ __global__ __launch_bounds__(64, 1) void group_step_kernel(EngineDev E, int it0,
                     Sr[s * D4 + j] = in ? v : 0.0;
                 }
             }
+            if constexpr (DRM == 2) {
+                if (c < D4) {
+#pragma unroll 4
+                    for (int j = 0; j < D4; ++j) {
+                        const bool in = (c < d) && (j < d);
+                        const size_t e = in ? (size_t)((c <= j) ? pidx(c, j, d) : pidx(j, c, d)) : 0;
+                        const double v = iCt[e * 64 + cl];
+                        lds[row * SQ + j * D4 + c] = in ? v : 0.0;
+                    }
+                }
+            }
         });
     }
-    // ---- the target's per-parameter tables and the state
-    GTarget<D4> T;
-    T.has_lo = E.tgt.lo != nullptr; T.has_hi = E.tgt.hi != nullptr; T.has_pri = E.tgt.pmu != nullptr;
+    const double inv2 = (DRM == 2) ? 1.0 / E.drscale : 1.0;   // exact: drscale is a power of two in this instantiation
     double th[NS];
     sfor<0, NS>([&](auto S) __attribute__((always_inline)) {
         constexpr int s = decltype(S)::value;
         const int c = 16 * s + l16, cc = c < d ? c : 0;
-        T.lo[s] = T.has_lo ? E.tgt.lo[cc] : 0.0; T.hi[s] = T.has_hi ? E.tgt.hi[cc] : 0.0;
-        T.pmu[s] = T.has_pri ? E.tgt.pmu[cc] : 0.0; T.psig[s] = T.has_pri ? E.tgt.psig[cc] : 0.0;
-        T.mu[s] = (E.tgt.kind == TGT_GAUSS) ? E.tgt.mu[cc] : 0.0;
         th[s] = (c < d) ? TIDX(E.theta, tile, d, cc, cl) : 0.0;
     });
     GChain g;
@@ -383,9 +403,9 @@ __global__ __launch_bounds__(64, 1) void group_step_kernel(EngineDev E, int it0,
             c1[s] = th[s] + p;                           // newpar = oldpar + R'z
         });
         // ---- bounds, prior, ss, alpha, reject
-        const bool inb = group_inbounds<D4>(T, c1, l16, row, d);
-        double pri2 = group_prior<D4>(T, c1, l16, d);
-        double ss2 = group_ss<D4>(E.tgt, T, c1, l16, d, g_lamT);
+        const bool inb = group_inbounds<D4>(E.tgt, c1, l16, row, d);
+        double pri2 = group_prior<D4>(E.tgt, c1, l16, d);
+        double ss2 = group_ss<D4>(E.tgt, c1, l16, d, g_lamT);
         bool reject = true, takeu = false;
         if (!inb) { alpha12 = 0.0; if (!DR) bnd += 1; }              // MCMC_run.F90:49 (with DR an out-of-bounds first stage is not counted)
         else {
@@ -406,16 +426,19 @@ __global__ __launch_bounds__(64, 1) void group_step_kernel(EngineDev E, int it0,
                 sfor<0, NS>([&](auto S) __attribute__((always_inline)) {
                     constexpr int s = decltype(S)::value;
                     double p = 0.0;
-                    sfor<0, (G::rows(s) + 15) / 16>([&](auto TT) __attribute__((always_inline)) {
-                        constexpr int tb = decltype(TT)::value;
-                        constexpr int n = (G::rows(s) - 16 * tb) < 16 ? (G::rows(s) - 16 * tb) : 16;
-                        blk_fmac<n>(p, z2[tb], &R2r[G::off(s) + 16 * tb]);
-                    });
+                    {
+                        sfor<0, (G::rows(s) + 15) / 16>([&](auto TT) __attribute__((always_inline)) {
+                            constexpr int tb = decltype(TT)::value;
+                            constexpr int n = (G::rows(s) - 16 * tb) < 16 ? (G::rows(s) - 16 * tb) : 16;
+                            blk_fmac<n>(p, z2[tb], (DRM == 1) ? &R2r[(DRM == 1) ? G::off(s) + 16 * tb : 0] : &Rr[G::off(s) + 16 * tb]);
+                        });
+                        if (DRM == 2) p = p * inv2;          // exact (see above)
+                    }
                     c2[s] = th[s] + p;
                 });
-                const bool inb2 = group_inbounds<D4>(T, c2, l16, row, d);
-                const double pri3 = group_prior<D4>(T, c2, l16, d);
-                const double ss3 = group_ss<D4>(E.tgt, T, c2, l16, d, g_lamT);
+                const bool inb2 = group_inbounds<D4>(E.tgt, c2, l16, row, d);
+                const double pri3 = group_prior<D4>(E.tgt, c2, l16, d);
+                const double ss3 = group_ss<D4>(E.tgt, c2, l16, d, g_lamT);
                 // MCMC_DR_alpha13, MCMC_DRAM.F90:162-186: the two quadratic forms dx' iC dx, dx_a = newpar2 - newpar, dx_b = oldpar - newpar
                 double xa[NS], xb[NS], ta[NS], tb_[NS];
                 sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; xa[s] = c2[s] - c1[s]; xb[s] = th[s] - c1[s]; });
@@ -424,7 +447,15 @@ __global__ __launch_bounds__(64, 1) void group_step_kernel(EngineDev E, int it0,
                     double ya = -0.0, yb = -0.0;                      // first term a plain product (see blk_fmac2)
                     sfor<0, NS>([&](auto TT) __attribute__((always_inline)) {
                         constexpr int tb = decltype(TT)::value;
-                        blk_fmac2<G::blk(tb)>(ya, yb, xa[tb], xb[tb], &Sr[s * D4 + 16 * tb]);
+                        constexpr int n = G::blk(tb);
+                        if constexpr (DRM == 1) blk_fmac2<n>(ya, yb, xa[tb], xb[tb], &Sr[(DRM == 1) ? s * D4 + 16 * tb : 0]);
+                        else {
+                            double r[n];
+#pragma unroll
+                            for (int u = 0; u < n; ++u) r[u] = icl[(16 * tb + u) * D4 + 16 * s + l16];
+                            blk_fmac2<n>(ya, yb, xa[tb], xb[tb], r);
+                            __builtin_amdgcn_sched_barrier(0);          // (keeps the next block's LDS reads from piling up in registers)
+                        }
                     });
                     const bool in = 16 * s + l16 < d;
                     ta[s] = in ? ya * xa[s] : 0.0; tb_[s] = in ? yb * xb[s] : 0.0;
@@ -475,6 +506,16 @@ __global__ __launch_bounds__(64, 1) void group_step_kernel(EngineDev E, int it0,
         TIDX(E.ictr, tile, NICTR, I_CHAININD, cl) = chainind; TIDX(E.ictr, tile, NICTR, I_CURCOUNT, cl) = curcount;
         TIDX(E.ictr, tile, NICTR, I_DRACC, cl) = dracc; TIDX(E.ictr, tile, NICTR, I_DRTRIES, cl) = drtries;
     }
+}
+
+// DRM = 2's precondition: *flag |= 1 when some chain's factor holds a nonzero element outside [2**-500, 2**500] (lane = chain)
+__global__ void group_check_kernel(EngineDev E, int *flag)
+{
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    const double *Rt = E.R + (size_t)tile * E.P * 64;
+    bool bad = false;
+    for (int e = 0; e < E.P; ++e) { const double r = GV(Rt, e); const double ar = fabs(r); bad = bad || (r != 0.0 && !(ar >= 0x1.0p-500 && ar <= 0x1.0p500)); }
+    if (__any(bad) && lane == 0) atomicOr(flag, 1);
 }
 
 // accept bytes of a launch -> the tile ballots (MCMC_savechain's repeat counts are decoded from them): one thread per

@@ -102,6 +102,31 @@ def test_group_kernel_equals_lane_kernels_and_oracle(oracle, monkeypatch, kind, 
         np.testing.assert_array_equal(_bits(np.triu(g["R"][i])), _bits(np.triu(o.R)))
 
 
+def test_group_kernel_power_of_two_drscale_and_its_range_check(oracle, monkeypatch):
+    """drscale = 2**k takes the instantiation that forms the second-stage proposal as (R'z) / drscale (exact while every nonzero
+    element of R lies in [2**-500, 2**500]); a factor outside that range raises the device flag and the general instantiation
+    (R2 as stored) runs instead -- both the lane kernels' chain bit for bit.  drscale = 3 always takes the general one."""
+    from mcmcf90_amd import engine_from_problem
+    d = 20
+    for drscale, tiny, kernel in ((4.0, False, "group_step_kernel<DR2>"), (0.5, True, "group_step_kernel<DR2>"), (3.0, False, "group_step_kernel<DR>")):
+        pkw = _problem("gauss", d, 77)
+        if tiny:
+            cm = np.array(pkw["cmat0"]); cm[3, 3] = 1e-304; pkw["cmat0"] = cm          # R(3,3) ~ 5e-153 < 2**-500
+        ckw = dict(nsimu=60, adaptint=50, updatesigma=0, drscale=drscale, doadapt=0 if tiny else 1)
+        res = []
+        for group in (True, False):
+            monkeypatch.setenv("MCMCX_GROUP", "1" if group else "0")
+            e = engine_from_problem(ckw, pkw, nchains=70, chain_id0=5, record_accept=1)
+            e.init(); e.run()
+            if group:
+                assert e.last_kernel() == kernel, e.last_kernel()
+            res.append((e.theta().copy(), e.accept_masks().copy(), [e.rng(c) for c in (0, 69)], [e.counters(c) for c in (0, 69)]))
+            e.close()
+        a, b = res
+        assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3], (drscale, tiny)
+        assert sum(c["drtries"] for c in a[3]) > 0
+
+
 def test_group_kernel_full_chain_and_burnin(oracle, monkeypatch):
     """record_chain (every accepted row through the ring, ballots from the accept bytes), burn-in scaling + greedy restart, launches
     cut at 256 iterations and by mcmcx_run calls of odd lengths."""
