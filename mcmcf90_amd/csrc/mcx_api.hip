@@ -324,20 +324,27 @@ static bool group_covers(const mcmcx_engine *h)
            (h->tkind == TGT_GAUSS || h->tkind == TGT_BANANA || h->tkind == TGT_EXPDATA) && h->d <= GROUP_MAX_NPAR &&
            !(h->tkind == TGT_BANANA && h->d < 2) && !(h->tkind == TGT_EXPDATA && h->d < 2);
 }
-template <int D4>
-static void launch_group_d4(mcmcx_engine *h, int it0, int it1)
+template <int D4, int TK>
+static void launch_group_tk(mcmcx_engine *h, int it0, int it1)
 {
     const dim3 g(h->ntiles * 16), b(64);
     const double *lam = h->E.tgt.lamT;
-    if (h->group_drm == 0) { h->last_kernel = "group_step_kernel"; hipLaunchKernelGGL((group_step_kernel<D4, 0>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)nullptr, 0); }
-    else if (h->group_drm == 1) { h->last_kernel = "group_step_kernel<DR>"; hipLaunchKernelGGL((group_step_kernel<D4, 1>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)nullptr, 0); }
+    if (h->group_drm == 0) { h->last_kernel = "group_step_kernel"; hipLaunchKernelGGL((group_step_kernel<D4, 0, TK>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)nullptr, 0); }
+    else if (h->group_drm == 1) { h->last_kernel = "group_step_kernel<DR>"; hipLaunchKernelGGL((group_step_kernel<D4, 1, -1>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)nullptr, 0); }
     else {
         // drscale a power of two: the instantiation without R2 runs unless the device flag says that some factor leaves the range in
         // which R'z / drscale is R2'z bit for bit; the general one is queued behind the same flag and returns at once otherwise
         h->last_kernel = "group_step_kernel<DR2>";
-        hipLaunchKernelGGL((group_step_kernel<D4, 2>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)h->d_gflag, 0);
-        hipLaunchKernelGGL((group_step_kernel<D4, 1>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)h->d_gflag, 1);
+        hipLaunchKernelGGL((group_step_kernel<D4, 2, TK>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)h->d_gflag, 0);
+        hipLaunchKernelGGL((group_step_kernel<D4, 1, -1>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)h->d_gflag, 1);
     }
+}
+template <int D4>
+static void launch_group_d4(mcmcx_engine *h, int it0, int it1)
+{
+    if (h->tkind == TGT_BANANA) launch_group_tk<D4, TGT_BANANA>(h, it0, it1);
+    else if (h->tkind == TGT_EXPDATA) { if constexpr (D4 == 4) launch_group_tk<D4, TGT_EXPDATA>(h, it0, it1); }   // (that target has two parameters)
+    else launch_group_tk<D4, TGT_GAUSS>(h, it0, it1);
 }
 static void launch_group(mcmcx_engine *h, int it0, int it1)
 {

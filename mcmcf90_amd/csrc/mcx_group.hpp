@@ -134,7 +134,12 @@ struct GDims {
     static constexpr int ZS = D4 + 4;                                                  // LDS doubles per chain (normals + the saved slot)
 };
 
-struct GChain { uint64_t n; int saved; double saved_y; };     // the chain's stream: uniform over its 16 lanes
+struct GChain {                         // the chain's stream: uniform over its 16 lanes ...
+    uint64_t n; int saved; double saved_y;
+    // ... and what the lane still holds of it: the Philox block `cb + l16` of the last round of attempts (cw), which very likely
+    // contains the uniform MCMC_reject draws next (group_uniform)
+    uint64_t cb; uint32_t cw[4];
+};
 
 // ---------------------------------------------------------------- normals: sixteen polar attempts of a chain at a time
 // z[t] <- the chain's next npar deviates (position 16 t + l16; 0 in the padding), through the chain's LDS row.
@@ -151,6 +156,7 @@ MCX_DEV void group_normals(uint32_t k0, uint32_t k1, GChain &g, double *zrow, in
         const bool odd = (g.n & 1) != 0;
         uint32_t w0, w1, w2, w3;
         philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), k0, k1, w0, w1, w2, w3);
+        g.cb = g.n >> 1; g.cw[0] = w0; g.cw[1] = w1; g.cw[2] = w2; g.cw[3] = w3;
         // n odd (a single uniform was drawn since the last pair): attempt a takes the second half of block b and the first
         // half of block b + 1 = lane a + 1's block; the row's last lane has no such neighbour and sits the round out
         const uint32_t nw0 = (uint32_t)__shfl_down((int)w0, 1), nw1 = (uint32_t)__shfl_down((int)w1, 1);
@@ -193,15 +199,25 @@ MCX_DEV void group_normals(uint32_t k0, uint32_t k1, GChain &g, double *zrow, in
     if (newsave) { g.saved = 1; g.saved_y = zrow[D4]; }
 }
 
-// one uniform for the chains with `take` (MCMC_reject, MCMC_DRAM.F90:150-151); every lane computes the block
-MCX_DEV double group_uniform(uint32_t k0, uint32_t k1, GChain &g, bool take)
+// one uniform for the chains with `take` (MCMC_reject, MCMC_DRAM.F90:150-151).  Uniform n sits in block n / 2; the lanes of the
+// chain hold the blocks cb .. cb + 15 of its last round of polar attempts, and the attempts consumed there end right in front of n:
+// the block is lane (n / 2 - cb)'s unless the round used up all sixteen -- then (any chain of the wave) every lane computes it.
+MCX_DEV double group_uniform(uint32_t k0, uint32_t k1, GChain &g, bool take, int row)
 {
     const uint64_t blk = g.n >> 1;
-    uint32_t x0, x1, x2, x3;
-    philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), k0, k1, x0, x1, x2, x3);
-    const double u = (g.n & 1) ? bits_to_uniform(x2, x3) : bits_to_uniform(x0, x1);
+    const uint64_t off = blk - g.cb;
+    const bool have = off < 16ull;
+    const bool odd = (g.n & 1) != 0;
+    const int src = (16 * row + (int)(off & 15ull)) << 2;
+    uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(odd ? g.cw[2] : g.cw[0]));
+    uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(odd ? g.cw[3] : g.cw[1]));
+    if (__any(take && !have)) {
+        uint32_t x0, x1, x2, x3;
+        philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), k0, k1, x0, x1, x2, x3);
+        if (!have) { lo = odd ? x2 : x0; hi = odd ? x3 : x1; }
+    }
     if (take) g.n += 1;
-    return u;
+    return bits_to_uniform(lo, hi);
 }
 
 // ---------------------------------------------------------------- checkbounds / priorfun / ssfunction on a group's vector
@@ -242,12 +258,14 @@ MCX_DEV double group_prior(const DevTarget &t, const double (&x)[GDims<D4>::NS],
     return p;
 }
 
-template <int D4>
+// TK: the target's kind at compile time (TGT_GAUSS / TGT_BANANA / TGT_EXPDATA), or -1 = whichever the engine holds: the three forms
+// together cost a kernel ~100 registers more than its own form alone (the Gaussian one keeps sixteen matrix elements in flight)
+template <int D4, int TK>
 MCX_DEV double group_ss(const DevTarget &t, const double (&x)[GDims<D4>::NS], int l16, int d, const double *__restrict__ g_lamT)
 {
     using G = GDims<D4>;
     double ss = 0.0;
-    if (t.kind == TGT_BANANA) {                       // target_ss: ss = fma chain over theta_k**2, k ascending from 2
+    if (TK == TGT_BANANA || (TK < 0 && t.kind == TGT_BANANA)) {                       // target_ss: ss = fma chain over theta_k**2, k ascending from 2
         const double th0 = row_bcast<0>(x[0]), th1 = row_bcast<1>(x[0]);
         const double t1 = th0 * th0;
         const double q = dfma(t.b, t1, th1) - 100.0 * t.b;
@@ -257,7 +275,7 @@ MCX_DEV double group_ss(const DevTarget &t, const double (&x)[GDims<D4>::NS], in
             const double w = (s == 0 && l16 < 2) ? 0.0 : x[s];        // fma(0, 0, ss) = ss: positions 0, 1 and the padding drop out
             blk_sqchain<G::blk(s)>(ss, w);
         });
-    } else if (t.kind == TGT_EXPDATA) {               // ss = fma chain over the residuals, data index ascending
+    } else if (TK == TGT_EXPDATA || (TK < 0 && t.kind == TGT_EXPDATA)) {               // ss = fma chain over the residuals, data index ascending
         const double th0 = row_bcast<0>(x[0]), th1 = row_bcast<1>(x[0]);
         for (int base = 0; base < t.ndata; base += 16) {
             const int i = base + l16;
@@ -312,7 +330,7 @@ MCX_DEV double group_ss(const DevTarget &t, const double (&x)[GDims<D4>::NS], in
 #ifndef MCX_GROUP_WAVES2
 #define MCX_GROUP_WAVES2 2
 #endif
-template <int D4, int DRM>
+template <int D4, int DRM, int TK>
 __global__ __launch_bounds__(64, DRM == 1 ? 1 : MCX_GROUP_WAVES2) void group_step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ g_lamT, uint8_t *accb,
                                                                                                    const int *__restrict__ gflag, int want)
 {
@@ -323,15 +341,22 @@ __global__ __launch_bounds__(64, DRM == 1 ? 1 : MCX_GROUP_WAVES2) void group_ste
     // LDS: [iC squares of the four chains (DRM = 2)] [the chains' normal rows]: a padding lane's read past its chain's square lands in the
     // next square or in the normal rows (finite or not, its result is discarded)
     constexpr int SQ = (DRM == 2) ? D4 * D4 : 0;
-    __shared__ double lds[4 * SQ + 4 * G::ZS];
+    // ... and (two waves per SIMD: registers are short) the columns of R's LAST, partly filled slot -- npar - 16 (NS - 1) columns of
+    // which only as many lanes hold anything: [row][column] per chain, read back with immediate offsets
+    constexpr int LS = (DRM != 1 && NS > 1 && (D4 % 16) != 0) ? NS - 1 : -1;      // the slot kept in LDS (-1: none)
+    constexpr int LC = (LS >= 0) ? D4 - 16 * LS : 0;                              // its columns
+    constexpr int RL = LC * D4;                                                   // doubles per chain
+    constexpr int NRR = (LS >= 0) ? G::off(LS) : G::NR;                           // doubles of R per lane that stay in registers
+    __shared__ double lds[4 * SQ + 4 * RL + 4 * G::ZS];
     const int lane = threadIdx.x, l16 = lane & 15, row = lane >> 4, d = E.d;
     const int chain = blockIdx.x * 4 + row, tile = chain >> 6, cl = chain & 63;
     const size_t nslots = (size_t)E.ntiles * 64;
-    double *zrow = lds + 4 * SQ + row * G::ZS;
+    double *zrow = lds + 4 * SQ + 4 * RL + row * G::ZS;
     const double *icl = lds + row * SQ;
+    const double *rll = lds + 4 * SQ + row * RL + ((l16 < LC) ? l16 : (LC > 0 ? LC - 1 : 0));     // (lanes past the slot's columns read its last one: finite, discarded)
 
     // ---- factors into registers / LDS (once per launch)
-    double Rr[G::NR], R2r[DRM == 1 ? G::NR : 1], Sr[DRM == 1 ? NS * D4 : 1];
+    double Rr[NRR > 0 ? NRR : 1], R2r[DRM == 1 ? G::NR : 1], Sr[DRM == 1 ? NS * D4 : 1];
     {
         const double *Rt = E.R + (size_t)tile * E.P * 64;
         const double *R2t = DR ? E.R2 + (size_t)tile * E.P * 64 : nullptr;
@@ -344,7 +369,8 @@ __global__ __launch_bounds__(64, DRM == 1 ? 1 : MCX_GROUP_WAVES2) void group_ste
                 const bool in = (c < d) && (i <= c);
                 const size_t e = in ? (size_t)pidx(i, c, d) : 0;
                 const double r = Rt[e * 64 + cl];
-                Rr[G::off(s) + i] = in ? r : 0.0;
+                if constexpr (s == LS) { if (l16 < LC) lds[4 * SQ + row * RL + i * LC + l16] = in ? r : 0.0; }
+                else Rr[G::off(s) + i] = in ? r : 0.0;
                 if constexpr (DRM == 1) { const double r2 = R2t[e * 64 + cl]; R2r[G::off(s) + i] = in ? r2 : 0.0; }
             }
             if constexpr (DRM == 1) {
@@ -380,6 +406,7 @@ __global__ __launch_bounds__(64, DRM == 1 ? 1 : MCX_GROUP_WAVES2) void group_ste
     g.n = TIDX(E.rngn, tile, 1, 0, cl);
     g.saved = (int)TIDX(E.ictr, tile, NICTR, I_SAVED, cl);
     g.saved_y = TIDX(E.scal, tile, NSCAL, S_SAVEDY, cl);
+    g.cb = (g.n >> 1) + (1ull << 62); g.cw[0] = g.cw[1] = g.cw[2] = g.cw[3] = 0u;      // nothing held yet: n / 2 - cb is far from 0..15
     const uint32_t k0 = E.k0, k1 = E.chain_id0 + (uint32_t)chain;
     double ss1 = TIDX(E.scal, tile, NSCAL, S_SS1, cl), pri1 = TIDX(E.scal, tile, NSCAL, S_PRI1, cl);
     const double sigma2 = TIDX(E.scal, tile, NSCAL, S_SIGMA2, cl);
@@ -388,60 +415,61 @@ __global__ __launch_bounds__(64, DRM == 1 ? 1 : MCX_GROUP_WAVES2) void group_ste
     uint32_t chainind = TIDX(E.ictr, tile, NICTR, I_CHAININD, cl), curcount = TIDX(E.ictr, tile, NICTR, I_CURCOUNT, cl);
     uint32_t dracc = TIDX(E.ictr, tile, NICTR, I_DRACC, cl), drtries = TIDX(E.ictr, tile, NICTR, I_DRTRIES, cl);
 
-    for (int it = it0; it <= it1; ++it) {
-        // ---- newpar = MCMC_propose(oldpar, R): the iteration's first draws
-        double z[NS], c1[NS];
-        group_normals<D4>(k0, k1, g, zrow, l16, row, d, true, z);
+    // One pass of the loop below is one STAGE of every chain of the wave -- the first stage of its iteration, or (delayed rejection) the
+    // second one when the first was rejected -- so the four chains of a wave drift apart by whole iterations instead of all of
+    // them sitting through a second stage whenever one of them needs it (MCMC_run.F90:41-107: 1.48 stages per iteration at
+    // BASELINE config 3's acceptance, against two in lockstep).  Both stages are the same code: normals, proposal with R (times
+    // 1 / drscale, or with R2), bounds / prior / ss of the candidate; then MCMC_alpha for a first stage, MCMC_DR_alpha13 for a
+    // second, MCMC_reject for both.  A chain's own sequence of draws and operations is untouched.
+    int it = it0;                                       // the chain's iteration (uniform over its 16 lanes)
+    bool st2 = false;                                   // ... and whether it is at its second stage
+    double c1[NS], ss2s = 0.0, pri2s = 0.0;             // the rejected first-stage candidate with its ss and prior
+    sfor<0, NS>([&](auto S) __attribute__((always_inline)) { c1[decltype(S)::value] = 0.0; });
+    while (__any(it <= it1)) {
+        const bool act = it <= it1;
+        // ---- newpar = MCMC_propose(oldpar, R) / newpar2 = MCMC_propose(oldpar, R2): the stage's first draws
+        double z[NS], cand[NS];
+        group_normals<D4>(k0, k1, g, zrow, l16, row, d, act, z);
+        const bool any2 = DR && __any(act && st2);
         sfor<0, NS>([&](auto S) __attribute__((always_inline)) {
             constexpr int s = decltype(S)::value;
             double p = 0.0;
             sfor<0, (G::rows(s) + 15) / 16>([&](auto TT) __attribute__((always_inline)) {
                 constexpr int tb = decltype(TT)::value;
                 constexpr int n = (G::rows(s) - 16 * tb) < 16 ? (G::rows(s) - 16 * tb) : 16;
-                blk_fmac<n>(p, z[tb], &Rr[G::off(s) + 16 * tb]);
+                if constexpr (s == LS) {
+                    double r[n];
+#pragma unroll
+                    for (int u = 0; u < n; ++u) r[u] = rll[(16 * tb + u) * LC];
+                    blk_fmac<n>(p, z[tb], r);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else blk_fmac<n>(p, z[tb], &Rr[(s == LS) ? 0 : G::off(s) + 16 * tb]);
             });
-            c1[s] = th[s] + p;                           // newpar = oldpar + R'z
+            if constexpr (s == LS) p = (l16 < LC) ? p : 0.0;         // (the padding lanes multiplied somebody else's column)
+            if constexpr (DRM == 2) p = st2 ? p * inv2 : p;          // exact (see above)
+            if constexpr (DRM == 1) {
+                if (any2) {
+                    double p2 = 0.0;
+                    sfor<0, (G::rows(s) + 15) / 16>([&](auto TT) __attribute__((always_inline)) {
+                        constexpr int tb = decltype(TT)::value;
+                        constexpr int n = (G::rows(s) - 16 * tb) < 16 ? (G::rows(s) - 16 * tb) : 16;
+                        blk_fmac<n>(p2, z[tb], &R2r[(DRM == 1) ? G::off(s) + 16 * tb : 0]);
+                    });
+                    p = st2 ? p2 : p;
+                }
+            }
+            cand[s] = th[s] + p;                         // newpar = oldpar + R'z
         });
-        // ---- bounds, prior, ss, alpha, reject
-        const bool inb = group_inbounds<D4>(E.tgt, c1, l16, row, d);
-        double pri2 = group_prior<D4>(E.tgt, c1, l16, d);
-        double ss2 = group_ss<D4>(E.tgt, c1, l16, d, g_lamT);
-        bool reject = true, takeu = false;
-        if (!inb) { alpha12 = 0.0; if (!DR) bnd += 1; }              // MCMC_run.F90:49 (with DR an out-of-bounds first stage is not counted)
-        else {
-            alpha12 = d_alpha(ss1, pri1, ss2, pri2, sigma2);
-            if (alpha12 >= 1.0) reject = false;                     // MCMC_reject, MCMC_DRAM.F90:140-155
-            else if (alpha12 > 0.0) takeu = true;
-        }
-        if (__any(takeu)) { const double u = group_uniform(k0, k1, g, takeu); if (takeu && u <= alpha12) reject = false; }
-        // ---- second stage: one delayed-rejection try with R2 = R/drscale (MCMC_run.F90:65-91)
-        bool dr_moved = false;
-        double c2[NS];
+        // ---- bounds, prior, ss of the candidate
+        const bool inb = group_inbounds<D4>(E.tgt, cand, l16, row, d);
+        const double pri = group_prior<D4>(E.tgt, cand, l16, d);
+        const double ss = group_ss<D4, TK>(E.tgt, cand, l16, d, g_lamT);
+        // ---- second stages: MCMC_DR_alpha13's two quadratic forms dx' iC dx, dx_a = newpar2 - newpar, dx_b = oldpar - newpar (MCMC_DRAM.F90:176-182)
+        double qa = 0.0, qb = 0.0;
         if constexpr (DR) {
-            if (__any(reject)) {
-                const bool m = reject;
-                if (m) drtries += 1;
-                double z2[NS];
-                group_normals<D4>(k0, k1, g, zrow, l16, row, d, m, z2);
-                sfor<0, NS>([&](auto S) __attribute__((always_inline)) {
-                    constexpr int s = decltype(S)::value;
-                    double p = 0.0;
-                    {
-                        sfor<0, (G::rows(s) + 15) / 16>([&](auto TT) __attribute__((always_inline)) {
-                            constexpr int tb = decltype(TT)::value;
-                            constexpr int n = (G::rows(s) - 16 * tb) < 16 ? (G::rows(s) - 16 * tb) : 16;
-                            blk_fmac<n>(p, z2[tb], (DRM == 1) ? &R2r[(DRM == 1) ? G::off(s) + 16 * tb : 0] : &Rr[G::off(s) + 16 * tb]);
-                        });
-                        if (DRM == 2) p = p * inv2;          // exact (see above)
-                    }
-                    c2[s] = th[s] + p;
-                });
-                const bool inb2 = group_inbounds<D4>(E.tgt, c2, l16, row, d);
-                const double pri3 = group_prior<D4>(E.tgt, c2, l16, d);
-                const double ss3 = group_ss<D4>(E.tgt, c2, l16, d, g_lamT);
-                // MCMC_DR_alpha13, MCMC_DRAM.F90:162-186: the two quadratic forms dx' iC dx, dx_a = newpar2 - newpar, dx_b = oldpar - newpar
+            if (any2) {
                 double xa[NS], xb[NS], ta[NS], tb_[NS];
-                sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; xa[s] = c2[s] - c1[s]; xb[s] = th[s] - c1[s]; });
+                sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; xa[s] = cand[s] - c1[s]; xb[s] = th[s] - c1[s]; });
                 sfor<0, NS>([&](auto S) __attribute__((always_inline)) {
                     constexpr int s = decltype(S)::value;
                     double ya = -0.0, yb = -0.0;                      // first term a plain product (see blk_fmac2)
@@ -460,39 +488,62 @@ __global__ __launch_bounds__(64, DRM == 1 ? 1 : MCX_GROUP_WAVES2) void group_ste
                     const bool in = 16 * s + l16 < d;
                     ta[s] = in ? ya * xa[s] : 0.0; tb_[s] = in ? yb * xb[s] : 0.0;
                 });
-                double qa = 0.0, qb = 0.0;
                 sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; blk_addchain<G::blk(s)>(qa, ta[s]); blk_addchain<G::blk(s)>(qb, tb_[s]); });
-                bool take2 = false, rej2 = true;
-                double alpha13 = 0.0;
-                if (m) {
-                    if (!inb2) bnd += 1;
+            }
+        }
+        // ---- MCMC_alpha (MCMC_DRAM.F90:100-118) or MCMC_DR_alpha13 (:162-186), then MCMC_reject (:140-155)
+        bool rej = true, take = false;
+        double alpha = 0.0;
+        {
+            // tst of MCMC_alpha for a first stage, l2 of MCMC_DR_alpha13 for a second: the same expression of the same operands
+            const double tstl = -0.5 * ((ss - ss1) / sigma2 + (pri - pri1));
+            // ONE exponential for both kinds of chains: exp(tst) (MCMC_alpha) or the alpha32 term (MCMC_DR_alpha13); every lane evaluates
+            // it whether its chain needs the value or not (d_exp has no side effects), which takes two divergent calls out of the pass
+            const double a32 = -0.5 * ((ss2s - ss) / sigma2 + (pri2s - pri));
+            const double e1 = d_exp((DR && st2) ? a32 : tstl);
+            if (act) {
+                if (!(DR && st2)) {
+                    if (!inb) { alpha12 = 0.0; if (!DR) bnd += 1; }          // MCMC_run.F90:49 (with DR an out-of-bounds first stage is not counted)
                     else {
-                        double alpha32;
-                        if (alpha12 == 0.0) alpha32 = 0.0;
-                        else alpha32 = min1(d_exp(-0.5 * ((ss2 - ss3) / sigma2 + (pri2 - pri3))));
-                        const double l2 = -0.5 * ((ss3 - ss1) / sigma2 + (pri3 - pri1));
+                        alpha12 = (tstl >= 0.0) ? 1.0 : ((tstl < -708.39641853226408) ? 0.0 : e1);      // d_alpha
+                        if (alpha12 >= 1.0) rej = false;
+                        else if (alpha12 > 0.0) take = true;
+                    }
+                    alpha = alpha12;
+                } else {
+                    if (!inb) bnd += 1;
+                    else {
+                        const double alpha32 = (alpha12 == 0.0) ? 0.0 : min1(e1);
                         const double q1 = -0.5 * (qa - qb);
-                        alpha13 = min1(d_exp(l2 + q1) * (1.0 - alpha32) / (1.0 - alpha12));
-                        if (alpha13 >= 1.0) rej2 = false;
-                        else if (alpha13 > 0.0) take2 = true;
+                        alpha = min1(d_exp(tstl + q1) * (1.0 - alpha32) / (1.0 - alpha12));
+                        if (alpha >= 1.0) rej = false;
+                        else if (alpha > 0.0) take = true;
                     }
                 }
-                if (__any(take2)) { const double u = group_uniform(k0, k1, g, take2); if (take2 && u <= alpha13) rej2 = false; }
-                if (m && inb2 && !rej2) { dracc += 1; reject = false; dr_moved = true; ss2 = ss3; pri2 = pri3; }
             }
         }
-        if (reject) { stayed += 1; curcount += 1; }
-        else { ss1 = ss2; pri1 = pri2; chainind += 1; curcount = 1; }
-        // ---- oldpar = newpar; MCMC_savechain (MCMC_aux.F90:167-185): accepted row into the ring, accept byte for the ballots
-        if (!reject) {
-            sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; th[s] = (DR && dr_moved) ? c2[s] : c1[s]; });
-            if (E.hist) {
-                double *h = E.hist + ((size_t)tile * E.wcap + (it % E.wcap)) * (size_t)E.hs * 64;
-                sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = 16 * s + l16; if (c < d) h[(size_t)c * 64 + cl] = th[s]; });
-                if (l16 == 0) h[(size_t)d * 64 + cl] = ss1;
+        if (__any(take)) { const double u = group_uniform(k0, k1, g, take, row); if (take && u <= alpha) rej = false; }
+        if (act) {
+            if (DR && !st2 && rej) {                     // on to the second stage: one delayed-rejection try (MCMC_run.F90:65-91)
+                st2 = true; drtries += 1; ss2s = ss; pri2s = pri;
+                sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; c1[s] = cand[s]; });
+            } else {                                     // the iteration ends with this stage
+                if (rej) { stayed += 1; curcount += 1; }
+                else {
+                    if (DR && st2) dracc += 1;
+                    ss1 = ss; pri1 = pri; chainind += 1; curcount = 1;
+                    // oldpar = newpar; MCMC_savechain (MCMC_aux.F90:167-185): accepted row into the ring
+                    sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; th[s] = cand[s]; });
+                    if (E.hist) {
+                        double *h = E.hist + ((size_t)tile * E.wcap + (it % E.wcap)) * (size_t)E.hs * 64;
+                        sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = 16 * s + l16; if (c < d) h[(size_t)c * 64 + cl] = th[s]; });
+                        if (l16 == 0) h[(size_t)d * 64 + cl] = ss1;
+                    }
+                }
+                if (accb && l16 == 0) accb[(size_t)(it - it0) * nslots + chain] = rej ? (uint8_t)0 : (uint8_t)1;   // the accept byte for the ballots
+                it += 1; st2 = false;
             }
         }
-        if (accb && l16 == 0) accb[(size_t)(it - it0) * nslots + chain] = reject ? (uint8_t)0 : (uint8_t)1;
     }
 
     sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = 16 * s + l16; if (c < d) TIDX(E.theta, tile, d, c, cl) = th[s]; });

@@ -24,19 +24,23 @@ def bench_line(tag):
 
 
 def counters(tag):
-    """{counter: median over the dominant kernel's dispatches of the per-dispatch sum}"""
-    acc, name = {}, None
+    """{counter: median over the dominant kernel's dispatches of the per-dispatch sum}; the dominant kernel = the sampling kernel
+    whose dispatches sum to the most over the pass (a launch may queue several instantiations of which all but one return at once)"""
+    acc, tot = {}, {}
     for f in glob.glob(os.path.join(out, tag, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             kn = r.get("Kernel_Name", "")
             if not any(k in kn for k in KERNELS):
                 continue
             name = kn.split("(")[0]
-            key = (r["Counter_Name"], r["Dispatch_Id"])
+            key = (name, r["Counter_Name"], r["Dispatch_Id"])
             acc[key] = acc.get(key, 0.0) + float(r["Counter_Value"])
+            tot[name] = tot.get(name, 0.0) + float(r["Counter_Value"])
+    name = max(tot, key=tot.get) if tot else None
     res = {}
-    for (c, _), v in acc.items():
-        res.setdefault(c, []).append(v)
+    for (kn, c, _), v in acc.items():
+        if kn == name:
+            res.setdefault(c, []).append(v)
     return {c: statistics.median(v) for c, v in res.items()}, {c: len(v) for c, v in res.items()}, name
 
 
