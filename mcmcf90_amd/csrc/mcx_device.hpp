@@ -23,7 +23,7 @@ MCX_DEV double add_exp(double y, int32_t k)
 MCX_DEV double dfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 // ---------------------------------------------------------------- log / exp (pinned; see oracle/mcx_math.h)
-MCX_DEV double d_log(double x)
+MCX_DEV double d_log_ref(double x)
 {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
         two54 = 1.80143985094819840000e+16,
@@ -72,7 +72,7 @@ MCX_DEV double d_log(double x)
     }
 }
 
-MCX_DEV double d_exp(double x)
+MCX_DEV double d_exp_ref(double x)
 {
     const double o_threshold = 7.09782712893383973096e+02, u_threshold = -7.45133219101941108420e+02,
         ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
@@ -115,6 +115,99 @@ MCX_DEV double d_exp(double x)
     if (k >= -1021) return add_exp(y, k);
     y = add_exp(y, k + 1000);
     return y * twom1000;
+}
+
+// The same two functions as the kernels call them: value for value d_log_ref / d_exp_ref (tools/math_probe.hip compares them over
+// random bit patterns and dense sweeps; tests/test_gpu_primitives.py against the oracle), with the case distinctions of the common
+// range written as selects.  A wave of 64 chains takes every one of fdlibm's branches at nearly every call -- k = 0 or not, the two
+// forms of the final correction, |x| below or above 1.5 ln 2 -- so the branching form runs all of them one after the other behind
+// exec masks, each with its scalar bookkeeping; here every lane computes the few operations in which the cases differ and picks.
+// Only the rare ranges stay branches (a wave skips them when no lane is there): subnormal / zero / negative / non-finite arguments
+// and |x - 1| < 2**-20 for the logarithm, |x| >= 709.78 and non-finite arguments for the exponential.
+MCX_DEV double d_log(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+        Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+        Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+        Lg7 = 1.479819860511658591e-01;
+#ifdef MCX_MATH_REF
+    return d_log_ref(x);                                                 // (A/B: tools/math_probe.hip)
+#endif
+    int32_t hx = hi32(x);
+    if (hx < 0x00100000 || hx >= 0x7ff00000) return d_log_ref(x);       // subnormal, zero, negative, infinite, NaN
+    int32_t k = (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    int32_t i = (hx + 0x95f64) & 0x100000;
+    x = set_hi32(x, hx | (i ^ 0x3ff00000));
+    k += (i >> 20);
+    const double f = x - 1.0, dk = (double)k;
+    if ((0x000fffff & (2 + hx)) < 3) {                                   // |f| < 2**-20
+        if (f == 0.0) {
+            if (k == 0) return 0.0;
+            return dfma(dk, ln2_hi, dk * ln2_lo);
+        }
+        const double R = (f * f) * dfma(-0.33333333333333333, f, 0.5);
+        if (k == 0) return f - R;
+        return dfma(dk, ln2_hi, -((R - dk * ln2_lo) - f));
+    }
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    i = hx - 0x6147a;
+    const double w = z * z;
+    const int32_t j = 0x6b851 - hx;
+    const double t1 = w * dfma(w, dfma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * dfma(w, dfma(w, dfma(w, Lg7, Lg5), Lg3), Lg1);
+    i |= j;
+    const double R = t2 + t1;
+    const bool A = i > 0;
+    const double hfsq = 0.5 * f * f;
+    const double t = A ? hfsq + R : f - R;
+    const double c = dk * ln2_lo;
+    // k != 0:  A: dk ln2_hi - ((hfsq - (s (hfsq + R) + dk ln2_lo)) - f)      else: dk ln2_hi - ((s (f - R) - dk ln2_lo) - f)
+    const double m = dfma(s, t, A ? c : -c);
+    const double rk = dfma(dk, ln2_hi, -((A ? hfsq - m : m) - f));
+    // k == 0:  A: f - (hfsq - s (hfsq + R))                                    else: f - s (f - R)
+    const double m0 = s * t;
+    const double r0 = f - (A ? hfsq - m0 : m0);
+    return (k == 0) ? r0 : rk;
+}
+
+MCX_DEV double d_exp(double x)
+{
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+        invln2 = 1.44269504088896338700e+00, twom1000 = 9.33263618503218878990e-302,
+        P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+        P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+#ifdef MCX_MATH_REF
+    return d_exp_ref(x);
+#endif
+    uint32_t hx = (uint32_t)hi32(x);
+    const bool neg = (hx >> 31) != 0u;
+    hx &= 0x7fffffff;
+    if (hx >= 0x40862E42) return d_exp_ref(x);                           // |x| >= 709.78, infinite, NaN
+    // |x| > 0.5 ln 2: k = +-1 below 1.5 ln 2 (hi = x -+ ln2HI, lo = +-ln2LO), else k = int(x / ln 2 +- 0.5), hi = x - k ln2HI, lo = k ln2LO --
+    // the first form is the second with k forced (fma(-(+-1), ln2HI, x) rounds x -+ ln2HI once, (+-1) ln2LO is exact); k = 0 otherwise,
+    // for which hi = x, lo = 0 and hi - lo = x
+    const bool big = hx > 0x3fd62e42, mid = hx < 0x3FF0A2B2;
+    int32_t k = (int32_t)(dfma(invln2, x, neg ? -0.5 : 0.5));
+    k = mid ? (neg ? -1 : 1) : k;
+    k = big ? k : 0;
+    const double t = (double)k;
+    const double hi = dfma(-t, ln2HI, x);
+    const double lo = t * ln2LO;
+    const double xr = hi - lo;
+    const double tt = xr * xr;
+    const double c = xr - tt * dfma(tt, dfma(tt, dfma(tt, dfma(tt, P5, P4), P3), P2), P1);
+    // k == 0: 1 - ((x c) / (c - 2) - x);  else y = 1 - ((lo - (x c) / (2 - c)) - hi): one division, a / (-b) = -(a / b) exactly
+    const double q = (xr * c) / (2.0 - c);
+    const double r0 = 1.0 - ((-q) - xr);
+    const double y = 1.0 - ((lo - q) - hi);
+    const bool deep = k < -1021;
+    double ys = add_exp(y, deep ? k + 1000 : k);
+    ys = deep ? ys * twom1000 : ys;
+    double r = (k == 0) ? r0 : ys;
+    r = (!big && hx < 0x3e300000) ? 1.0 + x : r;                         // |x| < 2**-28
+    return r;
 }
 
 // ---------------------------------------------------------------- RNG: Philox4x32-10 stream per lane
