@@ -324,6 +324,23 @@ static bool group_covers(const mcmcx_engine *h)
            (h->tkind == TGT_GAUSS || h->tkind == TGT_BANANA || h->tkind == TGT_EXPDATA) && h->d <= GROUP_MAX_NPAR &&
            !(h->tkind == TGT_BANANA && h->d < 2) && !(h->tkind == TGT_EXPDATA && h->d < 2);
 }
+// ... and where it is the faster one (tools/group_sweep.py, profiles/r04_a/group_sweep.txt: proposals/s of both kernel families over npar,
+// target, delayed rejection and chain count).  Up to 16384 chains always: the chip is not full, a chain's iteration is latency, and
+// sixteen lanes per chain with the factors in registers take 2-4 us where a lane takes 7-160 (4x-35x).  With the chip full, from npar
+// 11 on (below, the lane kernels keep everything in LDS: 0.35-0.9x): 1.3-3.8x for the banana target at every size; for the Gaussian
+// target -- whose group form still spills registers around its matrix-vector product -- 1.0-1.6x up to npar 16, 0.7-0.9x at 17..20,
+// 1.0-2.3x above except without delayed rejection (or a drscale that is no power of two) past npar 28.
+static bool group_wins(const mcmcx_engine *h, int drm)
+{
+    const int d = h->d;
+    if ((long long)h->cfg.nchains <= 16384) return true;
+    if (d <= 10) return false;
+    if (h->tkind != TGT_GAUSS) return true;
+    if (d <= 16) return true;
+    if (d <= 20) return false;
+    if (d <= 28) return true;
+    return drm == 2;
+}
 template <int D4, int TK>
 static void launch_group_tk(mcmcx_engine *h, int it0, int it1)
 {
@@ -1500,13 +1517,14 @@ int mcmcx_init(mcmcx_handle h)
     h->group_d4 = 0;
     if (group_covers(h)) {
         const char *ev = getenv("MCMCX_GROUP");
-        const bool on = ev ? atoi(ev) != 0 : false;
+        int ex = 0;
+        const bool pow2 = h->dodr && c.drscale > 0.0 && std::frexp(c.drscale, &ex) == 0.5 && ex > -64 && ex < 64;
+        const int drm = !h->dodr ? 0 : (pow2 && !(getenv("MCMCX_GROUP_DR2") && atoi(getenv("MCMCX_GROUP_DR2")) == 0)) ? 2 : 1;
+        const bool on = ev ? atoi(ev) != 0 : group_wins(h, drm);
         if (on) h->group_d4 = (d + 3) & ~3;
         if (h->group_d4 && (E.hist || E.accmask) && (rc = dev_alloc(h, &h->d_accb, L * (size_t)GROUP_MAXSEG))) return rc;
         if (h->group_d4) {
-            int ex = 0;
-            const bool pow2 = h->dodr && c.drscale > 0.0 && std::frexp(c.drscale, &ex) == 0.5 && ex > -64 && ex < 64;
-            h->group_drm = !h->dodr ? 0 : (pow2 && !(getenv("MCMCX_GROUP_DR2") && atoi(getenv("MCMCX_GROUP_DR2")) == 0)) ? 2 : 1;
+            h->group_drm = drm;
             h->group_check_due = true;
             if (h->group_drm == 2 && (rc = dev_alloc(h, &h->d_gflag, 1))) return rc;
         }

@@ -60,3 +60,25 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
             terminalreporter.write_line("GPU SUITE OVER BUDGET: %.0f s > %.0f s -- thin the cases marked `slow` (MCMCX_THIN=1) or split them" % (dt, GPU_SUITE_BUDGET_S), red=True)
             if os.environ.get("MCMCX_SUITE_BUDGET_STRICT") == "1":
                 terminalreporter._session.exitstatus = 1
+
+
+# Which sampling-kernel family a GPU test runs.  The engine picks the lane-group kernels (mcx_group.hpp) by itself wherever they cover the
+# configuration and win -- which is everywhere at the chain counts of a test.  The modules below predate them and exercise the
+# lane-per-chain kernels (their LDS / global-scratch / delayed-rejection variants, selected through other switches), so they run with
+# MCMCX_GROUP=0 unless a test asks for "auto" through the `kernels` parameter; tests/test_gpu_group.py compares the two families
+# directly, and the Fortran-shim, run1 and multi-rank modules take whatever the engine picks.
+_LANE_MODULES = ("test_gpu_parity", "test_gpu_primitives", "test_gpu_fullsize", "test_gpu_fuzz", "test_gpu_pooled",
+                 "test_gpu_host_callbacks", "test_gpu_user_module", "test_gpu_scam_fast", "test_cabi_exports")
+
+
+@pytest.fixture(autouse=True)
+def _kernel_family(request, monkeypatch):
+    mod = request.module.__name__.split(".")[-1]
+    fam = None
+    if hasattr(request.node, "callspec"):
+        fam = request.node.callspec.params.get("kernels")
+    if fam == "auto":
+        monkeypatch.delenv("MCMCX_GROUP", raising=False)
+    elif fam == "lane" or mod in _LANE_MODULES:
+        monkeypatch.setenv("MCMCX_GROUP", "0")
+    yield

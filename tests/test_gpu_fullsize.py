@@ -131,6 +131,7 @@ def test_c5_illcond200_scam_pooled_65536_chains(oracle):
     e.close()
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("lane_svd", [0, 1], ids=["blocked_svd", "lane_svd"])
 def test_c5_illcond200_scam_replicas_two_ticks(oracle, lane_svd, monkeypatch):
     """BASELINE config 5's target with per-chain rotations (the reference's semantics) THROUGH two adaptations: 70 chains

@@ -97,8 +97,9 @@ def _check_against_oracle(oracle, ckw, pkw, seed):
     e.close()
 
 
+@pytest.mark.parametrize("kernels", ["lane", "auto"])          # the lane-per-chain kernels / whatever the engine picks (tests/conftest.py)
 @pytest.mark.parametrize("seed", range(300))
-def test_random_configuration(oracle, seed):
+def test_random_configuration(oracle, seed, kernels):
     ckw, pkw = _draw(seed)
     _check_against_oracle(oracle, ckw, pkw, seed)
 
@@ -127,8 +128,9 @@ def test_random_configuration_ram_with_svd_factor(oracle, seed):
     _check_against_oracle(oracle, ckw, pkw, seed)
 
 
+@pytest.mark.parametrize("kernels", ["lane", "auto"])
 @pytest.mark.parametrize("seed", range(40))
-def test_random_configuration_in_pieces(oracle, seed):
+def test_random_configuration_in_pieces(oracle, seed, kernels):
     """mcmcx_run(upto) called in random pieces (launch boundaries anywhere relative to the adaptation ticks) ends in the
     same state as one call, for random configurations."""
     from mcmcf90_amd import engine_from_problem, McmcError
@@ -196,8 +198,9 @@ def _check_host_callbacks(oracle, ckw, pkw):
     e.close(); ref.close()
 
 
+@pytest.mark.parametrize("kernels", ["lane", "auto"])
 @pytest.mark.parametrize("seed", range(72))
-def test_random_configuration_larger_npar(oracle, seed):
+def test_random_configuration_larger_npar(oracle, seed, kernels):
     """npar 13..64: two to seven column panels of the RAM sweeps (panel width 10), several 8 x 8 blocks of the
     covariance update and of the Cholesky factorisation, ragged last panels.  RAM is drawn half of the time, half of
     those started at the target's own covariance -- waves that mix update and downdate lanes (whole-segment stores,

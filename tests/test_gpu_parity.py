@@ -30,8 +30,9 @@ def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
+@pytest.mark.parametrize("kernels", ["lane", "auto"])          # the lane-per-chain kernels / whatever the engine picks (tests/conftest.py)
 @pytest.mark.parametrize("name", SUPPORTED)
-def test_engine_matches_oracle_and_reference(oracle, name):
+def test_engine_matches_oracle_and_reference(oracle, name, kernels):
     from mcmcf90_amd import engine_from_problem
     z, cfg, prob = load(name, oracle)
     ckw, pkw = _kw(z)
@@ -95,6 +96,7 @@ def test_engine_matches_oracle_and_reference(oracle, name):
     e.close()
 
 
+@pytest.mark.slow
 def test_c5_fixture_all_iterations_with_the_logged_factors(oracle):
     """BASELINE config 5's fixture (d=200 SCAM, the MKL-linked reference through the adaptations at iterations 100 and
     200): ALL 250 iterations = 50000 componentwise proposals per chain on the device.  At each adaptation the engine runs

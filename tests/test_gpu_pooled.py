@@ -234,6 +234,7 @@ def test_pooled_scam_matches_restatement(oracle, kind):
     e.close()
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("d,extras", [(40, "s2"), (64, ""), (70, "bounds"), (100, "priors"), (130, ""), (200, "bounds"), (215, ""), (230, "priors"), (200, "sixteen")])
 def test_pooled_scam_wave_layouts(oracle, d, extras, monkeypatch):
     """Every split of scam_pooled_kernel's output blocks over its waves: d=40 three leftover blocks and no block wave,
