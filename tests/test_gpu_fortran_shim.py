@@ -177,6 +177,59 @@ def test_reference_example_programs_run_unmodified(oracle, prog):
     np.testing.assert_allclose(s2[-k:], z["s2_tail"], rtol=1e-9)
 
 
+def test_config1_verbatim_10000_iterations_with_delayed_rejection(oracle):
+    """BASELINE config 1 as written: the reference's UNMODIFIED testcases/mcmcrun.F90:48-122 (oracle/_ref/tc_mcmcrun: its own Fortran
+    ssfunction / modelfunction / checkbounds on the host, file-based initialize, one chain) on the bundled data with DRAM -- nsimu =
+    10000, drscale = 2, greedy burn-in scaling up to iteration 1000, sigma2 update -- linked against the shim instead of libmcmcrun.a.
+    The files it leaves must be the chain the real reference produced with the same namelist (fixture c1_expdata_dram, made by
+    oracle/gen_golden.py): identical run-length column (every accept decision of the 10000 iterations and of the delayed-rejection
+    tries in between), rows, sigma2 chain, and the final covariance / mean files (mcmccovf.dat, mcmcmean.dat) within north_star's
+    1e-6."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "tc_mcmcrun")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/tc_mcmcrun was not built (needs /root/reference in the dev container)")
+    z, cfg, prob = load("c1_expdata_dram", oracle)
+    nml = """&mcmc
+ method = 'dram'
+ nsimu       = %d
+ verbosity   = 0
+ doadapt     = 1
+ adaptint    = %d
+ burnintime  = %d
+ doburnin    = 1
+ greedy      = %d
+ scalelimit  = %g
+ scalefactor = %g
+ drscale     = %g
+ printint    = 1000
+ updatesigma = 1
+ N0          = %g
+ S02         = %g
+ chainfile   = 'chain.dat'
+ ssfile      = 'sschain.dat'
+ s2file      = 's2chain.dat'
+/
+""" % (cfg.nsimu, cfg.adaptint, cfg.burnintime, cfg.greedy, cfg.scalelimit, cfg.scalefactor, cfg.drscale, cfg.N0, cfg.S02)
+    assert cfg.nsimu == 10000 and cfg.drscale == 2.0 and cfg.doburnin == 1 and cfg.greedy == 1
+    with tempfile.TemporaryDirectory() as d:
+        _write_inputs(d, z, nml)
+        p = subprocess.run([exe], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, p.stdout.decode(errors="replace")
+        chain = np.loadtxt(os.path.join(d, "chain.dat"), ndmin=2)
+        s2 = np.loadtxt(os.path.join(d, "s2chain.dat"), ndmin=1)
+        covf = np.loadtxt(os.path.join(d, "mcmccovf.dat"), ndmin=2)
+        meanf = np.loadtxt(os.path.join(d, "mcmcmean.dat"), ndmin=1)
+    assert chain.shape[0] == int(z["chainind"]) and int(chain[:, -1].sum()) == cfg.nsimu
+    np.testing.assert_array_equal(chain[:, -1].astype(np.int32), z["runlen"])
+    k = z["rows_head"].shape[0]
+    np.testing.assert_allclose(chain[:k, :-1], z["rows_head"], rtol=1e-9)
+    np.testing.assert_allclose(chain[-k:, :-1], z["rows_tail"], rtol=1e-9)
+    np.testing.assert_allclose(s2[:k], z["s2_head"], rtol=1e-9)
+    np.testing.assert_allclose(s2[-k:], z["s2_tail"], rtol=1e-9)
+    assert np.max(np.abs(covf - z["chaincmat"])) / np.max(np.abs(z["chaincmat"])) < 1e-6
+    assert np.max(np.abs(meanf.ravel() - z["chainmean"]) / np.abs(z["chainmean"])) < 1e-6
+
+
 def test_user_initialize_and_dump_hooks(oracle):
     """demo_hooks.F90 overrides the optional link-time hooks: its `initialize` supplies par0 / cmat0 / sigma2 / nobs
     without any input file, and dump_init / dump / dump_end trace the chain every dumpint iterations."""
