@@ -1519,7 +1519,8 @@ int mcmcx_init(mcmcx_handle h)
         const char *ev = getenv("MCMCX_GROUP");
         int ex = 0;
         const bool pow2 = h->dodr && c.drscale > 0.0 && std::frexp(c.drscale, &ex) == 0.5 && ex > -64 && ex < 64;
-        const int drm = !h->dodr ? 0 : (pow2 && !(getenv("MCMCX_GROUP_DR2") && atoi(getenv("MCMCX_GROUP_DR2")) == 0)) ? 2 : 1;
+        // (the power-of-two form keeps iC in LDS: above npar 24 that leaves fewer waves per CU than the register form's four)
+        const int drm = !h->dodr ? 0 : (pow2 && d <= 24 && !(getenv("MCMCX_GROUP_DR2") && atoi(getenv("MCMCX_GROUP_DR2")) == 0)) ? 2 : 1;
         const bool on = ev ? atoi(ev) != 0 : group_wins(h, drm);
         if (on) h->group_d4 = (d + 3) & ~3;
         if (h->group_d4 && (E.hist || E.accmask) && (rc = dev_alloc(h, &h->d_accb, L * (size_t)GROUP_MAXSEG))) return rc;

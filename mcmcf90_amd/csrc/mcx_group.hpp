@@ -261,7 +261,7 @@ MCX_DEV double group_prior(const DevTarget &t, const double (&x)[GDims<D4>::NS],
 // TK: the target's kind at compile time (TGT_GAUSS / TGT_BANANA / TGT_EXPDATA), or -1 = whichever the engine holds: the three forms
 // together cost a kernel ~100 registers more than its own form alone (the Gaussian one keeps sixteen matrix elements in flight)
 template <int D4, int TK>
-MCX_DEV double group_ss(const DevTarget &t, const double (&x)[GDims<D4>::NS], int l16, int d, const double *__restrict__ g_lamT)
+MCX_DEV double group_ss(const DevTarget &t, const double (&x)[GDims<D4>::NS], int l16, int d, const double *laml)
 {
     using G = GDims<D4>;
     double ss = 0.0;
@@ -293,11 +293,13 @@ MCX_DEV double group_ss(const DevTarget &t, const double (&x)[GDims<D4>::NS], in
             sfor<0, G::NS>([&](auto TT) __attribute__((always_inline)) {
                 constexpr int tb = decltype(TT)::value;
                 constexpr int n = G::blk(tb);
-                double lam[n];
+                double lam[n];                         // row c of the precision matrix from the wave's LDS copy [j][c] (pitch D4, zero padding)
 #pragma unroll
-                for (int u = 0; u < n; ++u) { const int j = 16 * tb + u; lam[u] = (c < d && j < d) ? g_lamT[(size_t)j * d + c] : 0.0; }
+                for (int u = 0; u < n; ++u) lam[u] = laml[(16 * tb + u) * D4 + ((c < D4) ? c : D4 - 1)];
                 blk_fmac<n>(y, v[tb], lam);
+                __builtin_amdgcn_sched_barrier(0);
             });
+            if (c >= d) y = 0.0;
             // the block's four partial chains q_k over the rows 16 s + k + 4 r: lane k < 4 collects lanes k + 4, k + 8, k + 12
             double q = y * v[s];
             const double y4 = row_down<4>(y), v4 = row_down<4>(v[s]), y8 = row_down<8>(y), v8 = row_down<8>(v[s]), y12 = row_down<12>(y), v12 = row_down<12>(v[s]);
@@ -330,8 +332,11 @@ MCX_DEV double group_ss(const DevTarget &t, const double (&x)[GDims<D4>::NS], in
 #ifndef MCX_GROUP_WAVES2
 #define MCX_GROUP_WAVES2 2
 #endif
+#ifndef MCX_GROUP_GAUSS1
+#define MCX_GROUP_GAUSS1 99      // the Gaussian target from this D4 on: one wave per SIMD (its matrix-vector product spills at 256 registers)
+#endif
 template <int D4, int DRM, int TK>
-__global__ __launch_bounds__(64, DRM == 1 ? 1 : MCX_GROUP_WAVES2) void group_step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ g_lamT, uint8_t *accb,
+__global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 >= MCX_GROUP_GAUSS1)) ? 1 : MCX_GROUP_WAVES2) void group_step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ g_lamT, uint8_t *accb,
                                                                                                    const int *__restrict__ gflag, int want)
 {
     using G = GDims<D4>;
@@ -347,12 +352,19 @@ __global__ __launch_bounds__(64, DRM == 1 ? 1 : MCX_GROUP_WAVES2) void group_ste
     constexpr int LC = (LS >= 0) ? D4 - 16 * LS : 0;                              // its columns
     constexpr int RL = LC * D4;                                                   // doubles per chain
     constexpr int NRR = (LS >= 0) ? G::off(LS) : G::NR;                           // doubles of R per lane that stay in registers
-    __shared__ double lds[4 * SQ + 4 * RL + 4 * G::ZS];
+    constexpr int LQ = (TK == TGT_GAUSS || TK < 0) ? D4 * D4 : 0;                   // the Gaussian target's precision matrix, [j][i] with pitch D4
+    __shared__ double lds[4 * SQ + 4 * RL + 4 * G::ZS + LQ];
     const int lane = threadIdx.x, l16 = lane & 15, row = lane >> 4, d = E.d;
     const int chain = blockIdx.x * 4 + row, tile = chain >> 6, cl = chain & 63;
     const size_t nslots = (size_t)E.ntiles * 64;
     double *zrow = lds + 4 * SQ + 4 * RL + row * G::ZS;
     const double *icl = lds + row * SQ;
+    const double *laml = lds + 4 * SQ + 4 * RL + 4 * G::ZS;
+    if constexpr (LQ > 0) {
+        if (E.tgt.kind == TGT_GAUSS) {
+            for (int e = lane; e < D4 * D4; e += 64) { const int j = e / D4, i = e % D4; lds[4 * SQ + 4 * RL + 4 * G::ZS + e] = (i < d && j < d) ? g_lamT[(size_t)j * d + i] : 0.0; }
+        }
+    }
     const double *rll = lds + 4 * SQ + row * RL + ((l16 < LC) ? l16 : (LC > 0 ? LC - 1 : 0));     // (lanes past the slot's columns read its last one: finite, discarded)
 
     // ---- factors into registers / LDS (once per launch)
@@ -463,7 +475,7 @@ __global__ __launch_bounds__(64, DRM == 1 ? 1 : MCX_GROUP_WAVES2) void group_ste
         // ---- bounds, prior, ss of the candidate
         const bool inb = group_inbounds<D4>(E.tgt, cand, l16, row, d);
         const double pri = group_prior<D4>(E.tgt, cand, l16, d);
-        const double ss = group_ss<D4, TK>(E.tgt, cand, l16, d, g_lamT);
+        const double ss = group_ss<D4, TK>(E.tgt, cand, l16, d, laml);
         // ---- second stages: MCMC_DR_alpha13's two quadratic forms dx' iC dx, dx_a = newpar2 - newpar, dx_b = oldpar - newpar (MCMC_DRAM.F90:176-182)
         double qa = 0.0, qb = 0.0;
         if constexpr (DR) {

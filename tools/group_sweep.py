@@ -8,14 +8,15 @@ from mcmcf90_amd import engine_from_problem
 from mcmcf90_amd.workloads import corr_gauss_precision
 
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+gauss_only = len(sys.argv) > 1 and sys.argv[1] == "gauss"
 CASES = []
-for d in ((12, 20, 32) if quick else (4, 8, 10, 12, 16, 20, 24, 28, 32)):
-    for kind in ("gauss", "banana"):
+for d in ((12, 20, 32) if quick else (18, 20, 24, 28, 32) if gauss_only else (4, 8, 10, 12, 16, 20, 24, 28, 32)):
+    for kind in (("gauss",) if gauss_only else ("gauss", "banana")):
         for drs in (0.0, 2.0, 3.0):
             if quick and drs == 3.0:
                 continue
             CASES.append((kind, d, drs))
-COUNTS = (64, 4096, 262144) if quick else (64, 1024, 16384, 65536, 262144)
+COUNTS = (64, 4096, 262144) if quick else (65536, 262144) if gauss_only else (64, 1024, 16384, 65536, 262144)
 
 def rate(kind, d, drs, n, group):
     os.environ["MCMCX_GROUP"] = "1" if group else "0"
