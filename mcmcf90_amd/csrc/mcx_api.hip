@@ -326,20 +326,13 @@ static bool group_covers(const mcmcx_engine *h)
 }
 // ... and where it is the faster one (tools/group_sweep.py, profiles/r04_a/group_sweep.txt: proposals/s of both kernel families over npar,
 // target, delayed rejection and chain count).  Up to 16384 chains always: the chip is not full, a chain's iteration is latency, and
-// sixteen lanes per chain with the factors in registers take 2-4 us where a lane takes 7-160 (4x-35x).  With the chip full, from npar
-// 11 on (below, the lane kernels keep everything in LDS: 0.35-0.9x): 1.3-3.8x for the banana target at every size; for the Gaussian
-// target -- whose group form still spills registers around its matrix-vector product -- 1.0-1.6x up to npar 16, 0.7-0.9x at 17..20,
-// 1.0-2.3x above except without delayed rejection (or a drscale that is no power of two) past npar 28.
+// sixteen lanes per chain with the factors on chip take 2-5 us where a lane takes 7-160 (4x-33x).  With the chip full, from npar 11
+// on: 1.04-1.3x without delayed rejection up to npar 20 and 1.7-3x above, 1.1-3.7x with it; at npar <= 10 the lane kernels, which keep
+// the factor in LDS there, stay ahead (group: 0.35-0.9x).
 static bool group_wins(const mcmcx_engine *h, int drm)
 {
-    const int d = h->d;
-    if ((long long)h->cfg.nchains <= 16384) return true;
-    if (d <= 10) return false;
-    if (h->tkind != TGT_GAUSS) return true;
-    if (d <= 16) return true;
-    if (d <= 20) return false;
-    if (d <= 28) return true;
-    return drm == 2;
+    (void)drm;
+    return (long long)h->cfg.nchains <= 16384 || h->d >= 11;
 }
 template <int D4, int TK>
 static void launch_group_tk(mcmcx_engine *h, int it0, int it1)
