@@ -314,14 +314,14 @@ static void launch_init(mcmcx_engine *h)
 #define LAUNCHK(k, ...) do { h->last_kernel = #k; hipLaunchKernelGGL(k, __VA_ARGS__); } while (0)
 // ---- the lane-group step kernel (mcx_group.hpp): four chains per wave, factors in registers
 static const int GROUP_MAXSEG = 256;                  // iterations per launch (one accept byte per chain and iteration in d_accb)
-static const int GROUP_MAX_NPAR = 32;
+static const int GROUP_MAX_NPAR = 64, GROUP_MAX_NPAR_DR = 32;      // (with delayed rejection three tables must fit a lane's registers)
 // what the kernel covers: MCMC_run with per-chain Cholesky factors (method 'dram', with or without delayed rejection), one of
-// the single-launch device targets, one response column, no sigma2 update
+// the single-launch device targets, one response column
 static bool group_covers(const mcmcx_engine *h)
 {
     const mcmcx_config &c = h->cfg;
-    return !h->pooled && c.method == MCMCX_METHOD_DRAM && !h->usesvd && !phased(h) && h->ny == 1 && c.updatesigma == 0 &&
-           (h->tkind == TGT_GAUSS || h->tkind == TGT_BANANA || h->tkind == TGT_EXPDATA) && h->d <= GROUP_MAX_NPAR &&
+    return !h->pooled && c.method == MCMCX_METHOD_DRAM && !h->usesvd && !phased(h) && h->ny == 1 &&
+           (h->tkind == TGT_GAUSS || h->tkind == TGT_BANANA || h->tkind == TGT_EXPDATA) && h->d <= (h->dodr ? GROUP_MAX_NPAR_DR : GROUP_MAX_NPAR) &&
            !(h->tkind == TGT_BANANA && h->d < 2) && !(h->tkind == TGT_EXPDATA && h->d < 2);
 }
 // ... and where it is the faster one (tools/group_sweep.py, profiles/r04_a/group_sweep.txt: proposals/s of both kernel families over npar,
@@ -332,7 +332,16 @@ static bool group_covers(const mcmcx_engine *h)
 static bool group_wins(const mcmcx_engine *h, int drm)
 {
     (void)drm;
-    return (long long)h->cfg.nchains <= 16384 || h->d >= 11;
+    const long long n = h->cfg.nchains;
+    if (h->cfg.updatesigma) {
+        // MCMC_updatesigma2's gamma sampler is a serial, data-dependent sequence of draws per chain: a group wave runs it for four chains,
+        // a lane wave for 64 (tools/group_probe2.py: 2.3-12x up to 1024 chains, 0.9-5x at 16384, 0.45-0.8x beyond without delayed
+        // rejection, 1.3-1.6x with it at npar 20)
+        if (n <= 8192) return true;
+        if (n <= 16384) return h->d >= 4;
+        return h->dodr && h->d >= 11;
+    }
+    return n <= 16384 || h->d >= 11;
 }
 template <int D4, int TK>
 static void launch_group_tk(mcmcx_engine *h, int it0, int it1)
@@ -340,6 +349,7 @@ static void launch_group_tk(mcmcx_engine *h, int it0, int it1)
     const dim3 g(h->ntiles * 16), b(64);
     const double *lam = h->E.tgt.lamT;
     if (h->group_drm == 0) { h->last_kernel = "group_step_kernel"; hipLaunchKernelGGL((group_step_kernel<D4, 0, TK>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)nullptr, 0); }
+    else if constexpr (D4 > 32) { return; }               // (group_covers: no delayed rejection above npar 32)
     else if (h->group_drm == 1) { h->last_kernel = "group_step_kernel<DR>"; hipLaunchKernelGGL((group_step_kernel<D4, 1, -1>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)nullptr, 0); }
     else {
         // drscale a power of two: the instantiation without R2 runs unless the device flag says that some factor leaves the range in
@@ -371,7 +381,11 @@ static void launch_group(mcmcx_engine *h, int it0, int it1)
     case 20: launch_group_d4<20>(h, it0, it1); break;
     case 24: launch_group_d4<24>(h, it0, it1); break;
     case 28: launch_group_d4<28>(h, it0, it1); break;
-    default: launch_group_d4<32>(h, it0, it1); break;
+    case 32: launch_group_d4<32>(h, it0, it1); break;
+    case 40: launch_group_d4<40>(h, it0, it1); break;       // (above 32: sizes of eight, no delayed rejection)
+    case 48: launch_group_d4<48>(h, it0, it1); break;
+    case 56: launch_group_d4<56>(h, it0, it1); break;
+    default: launch_group_d4<64>(h, it0, it1); break;
     }
     if (h->d_accb) {
         const long long n = (long long)(it1 - it0 + 1) * h->ntiles;
@@ -1515,7 +1529,7 @@ int mcmcx_init(mcmcx_handle h)
         // (the power-of-two form keeps iC in LDS: above npar 24 that leaves fewer waves per CU than the register form's four)
         const int drm = !h->dodr ? 0 : (pow2 && d <= 24 && !(getenv("MCMCX_GROUP_DR2") && atoi(getenv("MCMCX_GROUP_DR2")) == 0)) ? 2 : 1;
         const bool on = ev ? atoi(ev) != 0 : group_wins(h, drm);
-        if (on) h->group_d4 = (d + 3) & ~3;
+        if (on) h->group_d4 = d <= 32 ? ((d + 3) & ~3) : ((d + 7) & ~7);
         if (h->group_d4 && (E.hist || E.accmask) && (rc = dev_alloc(h, &h->d_accb, L * (size_t)GROUP_MAXSEG))) return rc;
         if (h->group_d4) {
             h->group_drm = drm;

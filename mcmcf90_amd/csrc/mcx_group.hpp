@@ -318,7 +318,7 @@ MCX_DEV double group_ss(const DevTarget &t, const double (&x)[GDims<D4>::NS], in
 
 // ---------------------------------------------------------------- the kernel
 // Iterations it0..it1 of MCMC_run (MCMC_run.F90:41-107) for the four chains of a wave: method = 'dram', per-chain Cholesky factors,
-// one of the single-launch device targets, nycol = 1, updatesigma = 0.  accb: one byte per chain and iteration of the launch
+// one of the single-launch device targets, nycol = 1.  accb: one byte per chain and iteration of the launch
 // (accepted or not); group_pack_kernel turns them into the tile ballots the adaptation and the chain decoder read.
 // DRM = 0: no delayed rejection.  R in registers; two waves per SIMD.
 // DRM = 1: delayed rejection, any drscale: R, R2 and iC in registers (accumulator registers included); one wave per SIMD.
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
     g.cb = (g.n >> 1) + (1ull << 62); g.cw[0] = g.cw[1] = g.cw[2] = g.cw[3] = 0u;      // nothing held yet: n / 2 - cb is far from 0..15
     const uint32_t k0 = E.k0, k1 = E.chain_id0 + (uint32_t)chain;
     double ss1 = TIDX(E.scal, tile, NSCAL, S_SS1, cl), pri1 = TIDX(E.scal, tile, NSCAL, S_PRI1, cl);
-    const double sigma2 = TIDX(E.scal, tile, NSCAL, S_SIGMA2, cl);
+    double sigma2 = TIDX(E.scal, tile, NSCAL, S_SIGMA2, cl);
     double alpha12 = TIDX(E.scal, tile, NSCAL, S_ALPHA12, cl);
     uint32_t stayed = TIDX(E.ictr, tile, NICTR, I_STAYED, cl), bnd = TIDX(E.ictr, tile, NICTR, I_BNDSTAYED, cl);
     uint32_t chainind = TIDX(E.ictr, tile, NICTR, I_CHAININD, cl), curcount = TIDX(E.ictr, tile, NICTR, I_CURCOUNT, cl);
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
             }
         }
         // ---- MCMC_alpha (MCMC_DRAM.F90:100-118) or MCMC_DR_alpha13 (:162-186), then MCMC_reject (:140-155)
-        bool rej = true, take = false;
+        bool rej = true, take = false, fin = false;
         double alpha = 0.0;
         {
             // tst of MCMC_alpha for a first stage, l2 of MCMC_DR_alpha13 for a second: the same expression of the same operands
@@ -553,13 +553,31 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
                     }
                 }
                 if (accb && l16 == 0) accb[(size_t)(it - it0) * nslots + chain] = rej ? (uint8_t)0 : (uint8_t)1;   // the accept byte for the ballots
-                it += 1; st2 = false;
+                fin = true;
             }
+        }
+        // ---- MCMC_updatesigma2 (MCMC_DRAM.F90:192-206) of the chains whose iteration ended: random_gamma's rejection loops draw a
+        // data-dependent number of deviates and uniforms one after the other (mcmcrand.F90:86-162), so every lane of the chain runs the
+        // chain's own sampler on the chain's stream -- sixteen identical copies; the polar cache changes hands through it as in the
+        // reference.  (A wave pays one sampler for four chains here where the lane kernels pay one for 64: few chains, not many.)
+        if (E.updatesigma && __any(fin)) {
+            if (fin) {
+                Rng q;
+                q.k0 = k0; q.k1 = k1; q.n = g.n; q.cblk = 0; q.c2 = 0; q.c3 = 0; q.saved = g.saved; q.saved_y = g.saved_y;
+                const double gm = rng_gamma(q, E.gam_shape, 2.0 / (E.N0S02 + ss1));
+                sigma2 = 1.0 / gm;
+                g.n = q.n; g.saved = q.saved; g.saved_y = q.saved_y;
+            }
+        }
+        if (fin) {
+            if (E.hist && E.record_s2 && l16 == 0) E.s2hist[((size_t)tile * E.wcap + (it % E.wcap)) * 64 + cl] = sigma2;
+            it += 1; st2 = false;
         }
     }
 
     sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = 16 * s + l16; if (c < d) TIDX(E.theta, tile, d, c, cl) = th[s]; });
     if (l16 == 0) {
+        TIDX(E.scal, tile, NSCAL, S_SIGMA2, cl) = sigma2;
         TIDX(E.rngn, tile, 1, 0, cl) = g.n;
         TIDX(E.ictr, tile, NICTR, I_SAVED, cl) = (uint32_t)g.saved;
         TIDX(E.scal, tile, NSCAL, S_SAVEDY, cl) = g.saved_y;

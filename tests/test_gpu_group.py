@@ -82,6 +82,9 @@ CASES = [
     ("gauss", 29, 0.0, False, True),
     ("gauss", 32, 2.0, True, False),
     ("banana", 31, 1.5, False, False),
+    ("gauss", 50, 0.0, False, False),            # BASELINE config 4's target with method = 'dram': four slots, R in registers, one wave per SIMD
+    ("gauss", 37, 0.0, True, True),
+    ("banana", 64, 0.0, False, False),
 ]
 
 
@@ -100,6 +103,34 @@ def test_group_kernel_equals_lane_kernels_and_oracle(oracle, monkeypatch, kind, 
         np.testing.assert_array_equal(_bits(g["theta"][c]), _bits(o.theta))
         assert g["rng"][i][0] == o.rng_n and g["ctr"][i]["stayed"] == o.stayed
         np.testing.assert_array_equal(_bits(np.triu(g["R"][i])), _bits(np.triu(o.R)))
+
+
+@pytest.mark.parametrize("kind,d,drscale", [("expdata", 2, 2.0), ("gauss", 7, 0.0), ("banana", 20, 2.0), ("gauss", 13, 3.0)])
+def test_group_kernel_with_sigma2_update(oracle, monkeypatch, kind, d, drscale):
+    """updatesigma = 1 (MCMC_updatesigma2, MCMC_DRAM.F90:192-206: the gamma sampler's rejection loops on the chain's own stream, between
+    the iteration's accept decision and the next iteration's normals; shape below and above 1): sigma2 chain, state and stream
+    position equal to the lane kernels' and the oracle's."""
+    from mcmcf90_amd import engine_from_problem
+    for N0, nobs in ((1.0, 11), (0.2, 1)):
+        ckw = dict(nsimu=120, adaptint=50, updatesigma=1, drscale=drscale, N0=N0, S02=0.3)
+        pkw = dict(_problem(kind, d, 90 + d), sigma2=0.5, nobs=nobs)
+        res = []
+        for group in (True, False):
+            monkeypatch.setenv("MCMCX_GROUP", "1" if group else "0")
+            e = engine_from_problem(ckw, pkw, nchains=66, chain_id0=9, record_chain=1, record_accept=1)
+            e.init(); e.run()
+            assert e.last_kernel().startswith("group_step_kernel") == group
+            res.append((e.theta().copy(), e.scalars().copy(), e.accept_masks().copy(), [e.rng(c) for c in (0, 65)], [e.chain(c) for c in (0, 65)]))
+            e.close()
+        a, b = res
+        assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(_bits(a[1]), _bits(b[1])) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+        for x, y in zip(a[4], b[4]):
+            for u, v in zip(x, y):
+                np.testing.assert_array_equal(_bits(u), _bits(v))
+        o = oracle.run_chain(oracle.make_cfg(**ckw), oracle.Problem(**pkw), chain_id=9)
+        np.testing.assert_array_equal(_bits(a[4][0][2]), _bits(o.s2chain))
+        np.testing.assert_array_equal(_bits(a[0][0]), _bits(o.theta))
+        assert a[3][0][0] == o.rng_n
 
 
 def test_group_kernel_power_of_two_drscale_and_its_range_check(oracle, monkeypatch):
