@@ -320,7 +320,7 @@ static const int GROUP_MAX_NPAR = 64, GROUP_MAX_NPAR_DR = 32;      // (with dela
 static bool group_covers(const mcmcx_engine *h)
 {
     const mcmcx_config &c = h->cfg;
-    return !h->pooled && c.method == MCMCX_METHOD_DRAM && !h->usesvd && !phased(h) && h->ny == 1 &&
+    return !h->pooled && (c.method == MCMCX_METHOD_DRAM || (c.method == MCMCX_METHOD_ER && !h->dodr)) && !h->usesvd && !phased(h) && h->ny == 1 &&
            (h->tkind == TGT_GAUSS || h->tkind == TGT_BANANA || h->tkind == TGT_EXPDATA) && h->d <= (h->dodr ? GROUP_MAX_NPAR_DR : GROUP_MAX_NPAR) &&
            !(h->tkind == TGT_BANANA && h->d < 2) && !(h->tkind == TGT_EXPDATA && h->d < 2);
 }

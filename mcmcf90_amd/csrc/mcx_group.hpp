@@ -426,6 +426,8 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
     uint32_t stayed = TIDX(E.ictr, tile, NICTR, I_STAYED, cl), bnd = TIDX(E.ictr, tile, NICTR, I_BNDSTAYED, cl);
     uint32_t chainind = TIDX(E.ictr, tile, NICTR, I_CHAININD, cl), curcount = TIDX(E.ictr, tile, NICTR, I_CURCOUNT, cl);
     uint32_t dracc = TIDX(E.ictr, tile, NICTR, I_DRACC, cl), drtries = TIDX(E.ictr, tile, NICTR, I_DRTRIES, cl);
+    uint32_t erstayed = TIDX(E.ictr, tile, NICTR, I_ERSTAYED, cl);
+    const bool er = !DR && E.method == M_ER;           // MCMC_run_er: the threshold is drawn before ss is looked at
 
     // One pass of the loop below is one STAGE of every chain of the wave -- the first stage of its iteration, or (delayed rejection) the
     // second one when the first was rejected -- so the four chains of a wave drift apart by whole iterations instead of all of
@@ -514,7 +516,10 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
             const double a32 = -0.5 * ((ss2s - ss) / sigma2 + (pri2s - pri));
             const double e1 = d_exp((DR && st2) ? a32 : tstl);
             if (act) {
-                if (!(DR && st2)) {
+                if (er) {                                                   // early rejection, MCMC_run_er.F90:60-89: u is always drawn (MCMC_sscrit)
+                    if (!inb) bnd += 1;
+                    else take = true;
+                } else if (!(DR && st2)) {
                     if (!inb) { alpha12 = 0.0; if (!DR) bnd += 1; }          // MCMC_run.F90:49 (with DR an out-of-bounds first stage is not counted)
                     else {
                         alpha12 = (tstl >= 0.0) ? 1.0 : ((tstl < -708.39641853226408) ? 0.0 : e1);      // d_alpha
@@ -534,7 +539,16 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
                 }
             }
         }
-        if (__any(take)) { const double u = group_uniform(k0, k1, g, take, row); if (take && u <= alpha) rej = false; }
+        if (__any(take)) {
+            const double u = group_uniform(k0, k1, g, take, row);
+            if (er) {
+                if (take) {                                                  // sscrit = -2 log u + ss1 / sigma2 + pri1 (MCMC_DRAM.F90:124-135)
+                    double sscrit = -2.0 * d_log(u) + ss1 / sigma2 + pri1;
+                    if (pri >= sscrit) erstayed += 1;                        // rejected on the prior alone
+                    else { sscrit = sigma2 * (sscrit - pri); rej = (ss >= sscrit); }
+                }
+            } else if (take && u <= alpha) rej = false;
+        }
         if (act) {
             if (DR && !st2 && rej) {                     // on to the second stage: one delayed-rejection try (MCMC_run.F90:65-91)
                 st2 = true; drtries += 1; ss2s = ss; pri2s = pri;
@@ -586,6 +600,7 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
         TIDX(E.ictr, tile, NICTR, I_STAYED, cl) = stayed; TIDX(E.ictr, tile, NICTR, I_BNDSTAYED, cl) = bnd;
         TIDX(E.ictr, tile, NICTR, I_CHAININD, cl) = chainind; TIDX(E.ictr, tile, NICTR, I_CURCOUNT, cl) = curcount;
         TIDX(E.ictr, tile, NICTR, I_DRACC, cl) = dracc; TIDX(E.ictr, tile, NICTR, I_DRTRIES, cl) = drtries;
+        TIDX(E.ictr, tile, NICTR, I_ERSTAYED, cl) = erstayed;
     }
 }
 

@@ -133,6 +133,20 @@ def test_group_kernel_with_sigma2_update(oracle, monkeypatch, kind, d, drscale):
         assert a[3][0][0] == o.rng_n
 
 
+@pytest.mark.parametrize("kind,d,priors,bounds", [("gauss", 9, True, True), ("banana", 20, False, False), ("expdata", 2, True, True)])
+def test_group_kernel_early_rejection(oracle, monkeypatch, kind, d, priors, bounds):
+    """method = 'er' (MCMC_run_er.F90:46-104: the threshold u is drawn before ss is looked at; a candidate the prior alone rejects counts in
+    erstayed): the lane kernels' chain and the oracle's."""
+    ckw = dict(nsimu=130, adaptint=50, updatesigma=0, method="er")
+    pkw = _problem(kind, d, 140 + d, priors, bounds)
+    g, chains = _run(ckw, pkw, 70, True, monkeypatch)
+    l, _ = _run(ckw, pkw, 70, False, monkeypatch)
+    _same(g, l)
+    o = oracle.run_chain(oracle.make_cfg(**ckw), oracle.Problem(**pkw), chain_id=3)
+    np.testing.assert_array_equal(_bits(g["theta"][0]), _bits(o.theta))
+    assert g["rng"][0][0] == o.rng_n and g["ctr"][0]["erstayed"] == o.erstayed and g["ctr"][0]["stayed"] == o.stayed
+
+
 def test_group_kernel_power_of_two_drscale_and_its_range_check(oracle, monkeypatch):
     """drscale = 2**k takes the instantiation that forms the second-stage proposal as (R'z) / drscale (exact while every nonzero
     element of R lies in [2**-500, 2**500]); a factor outside that range raises the device flag and the general instantiation
