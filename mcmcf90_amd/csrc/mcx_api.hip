@@ -81,6 +81,7 @@ struct mcmcx_engine {
     struct mcmcx_comm *comm = nullptr;                // the node's communicator (mcx_comm.hpp); nullptr = this GPU alone
     double *d_gather = nullptr, *d_pooled = nullptr;  // [nranks][len + 1] per-rank moment vectors (+ the rank's stop flag), [len + 1] their tree sum
     double h_flag = 0.0;                              // this rank's stop flag of the exchange being enqueued (1 = a caught signal)
+    bool run_entered = false;                         // mcmcx_run is past its argument checks (a failure from here on may strand peers)
     bool stop_seen = false;                           // the summed stop flag of the tick just applied was non-zero: every rank leaves after this tick
     double S02eff = 0.0;
     // device
@@ -1628,7 +1629,10 @@ int mcmcx_run(mcmcx_handle h, int32_t upto)
     const int rc = run_impl(h, upto);
     // Several ranks meet in this engine's ticks: one that fails must not leave the others waiting in the next gather --
     // the communicator is marked failed, which the peers' waits poll (comm_wait_stream, shm_barrier)
-    if (rc < 0 && h && h->inited && collective_run(h)) comm_mark_failed(h->comm);
+    // -- once the run has entered its loop, that is: an argument or state error returned before that (-40 not inited, -41 external
+    // target) strands nobody, and marking the communicator for it would abort peers that have nothing to do with it
+    if (rc < 0 && h && h->inited && h->run_entered && collective_run(h)) comm_mark_failed(h->comm);
+    if (h) h->run_entered = false;
     return rc;
 }
 static int run_impl(mcmcx_handle h, int32_t upto)
@@ -1646,6 +1650,7 @@ static int run_impl(mcmcx_handle h, int32_t upto)
     // So a signal only raises this rank's stop flag in the exchanged vector and the run is left at the tick where every
     // rank reads the summed flag (pooled_reduce); an error marks the communicator failed (mcmcx_run).
     const bool coll = collective_run(h);
+    h->run_entered = true;
     // ... which needs a tick ahead.  Whether one lies in (it, upto] follows from the configuration alone, the same on every
     // rank: past the last one (doadapt = 0, iterations beyond adaptend, the tail of a run) no collective is left to strand a
     // peer in, and a signal is acted on at the next launch boundary like in a run of one rank.

@@ -19,6 +19,7 @@
 #pragma once
 #include <rccl/rccl.h>
 #include <atomic>
+#include <memory>
 #include <chrono>
 #include <thread>
 #include <fcntl.h>
@@ -55,15 +56,18 @@ struct mcmcx_comm {
     std::string shm_name; int shm_fd = -1; size_t shm_bytes = 0; mcx_shm_header *hdr = nullptr; double *slots = nullptr;
     uint32_t local_sense = 0;
     std::vector<double> hbuf;
+    // the communicators of ONE mcmcx_comm_create_all call share this word (one process, a thread per engine): a rank that fails in a run
+    // raises it, the waits of its siblings poll it.  Communicators of one process per rank use the segment's `failed` word.  Either way
+    // the mark belongs to the communicator it concerns: other communicators of the process never see it.
+    std::shared_ptr<std::atomic<int>> group_failed;
 };
 
 // An engine of this process failed inside a run whose ranks meet in collectives (mcmcx_run): the waits of its peers --
 // other threads of a one-process node (mcmcx_run_all), other processes through the segment's `failed` word -- poll this
 // and abort their side of the communicator instead of waiting for a gather that will never complete.
-static std::atomic<int> g_peer_failed{0};
 static void comm_mark_failed(mcmcx_comm *c)
 {
-    g_peer_failed.store(1);
+    if (c && c->group_failed) c->group_failed->store(1);
     if (c && c->hdr) c->hdr->failed.store(1);
 }
 // wait for `stream` (which may hold a collective) without outliving a failed peer
@@ -74,7 +78,7 @@ static int comm_wait_stream(mcmcx_comm *c, hipStream_t stream)
         const hipError_t e = hipStreamQuery(stream);
         if (e == hipSuccess) return 0;
         if (e != hipErrorNotReady) return fail(-100, std::string("hipStreamQuery: ") + hipGetErrorString(e));
-        if (g_peer_failed.load(std::memory_order_relaxed) || (c->hdr && c->hdr->failed.load(std::memory_order_relaxed))) {
+        if ((c->group_failed && c->group_failed->load(std::memory_order_relaxed)) || (c->hdr && c->hdr->failed.load(std::memory_order_relaxed))) {
             if (c->nccl) { (void)ncclCommAbort(c->nccl); c->nccl = nullptr; }     // frees this rank's pending collective
             return fail(-111, "mcmcx_comm: another rank failed; this rank's collective was aborted (rank " + std::to_string(c->rank) + ")");
         }
@@ -236,7 +240,6 @@ int mcmcx_comm_create(const char *key, int32_t rank, int32_t nranks, int32_t dev
     }
     if ((rc = shm_barrier(c))) { comm_free(c); return rc; }
     if (rank == 0) c->hdr->magic.store(0, std::memory_order_release);      // formed: nobody attaches to this segment any more (see shm_attach)
-    g_peer_failed.store(0);
     *out = c;
     return 0;
 }
@@ -253,11 +256,12 @@ int mcmcx_comm_create_all(int32_t ndev_want, const int32_t *devices, mcmcx_comm_
         for (int k = 0; k < i; ++k) if (dl[k] == dl[i]) return fail(-10, "mcmcx_comm_create_all: duplicate device");
     }
     std::vector<ncclComm_t> comms(ndev_want);
+    auto group_failed = std::make_shared<std::atomic<int>>(0);
     for (int i = 0; i < ndev_want; ++i) out[i] = nullptr;
     NCCLCHK(ncclCommInitAll(comms.data(), ndev_want, dl.data()));
     for (int i = 0; i < ndev_want; ++i) {
         mcmcx_comm *c = new mcmcx_comm();
-        c->rank = i; c->nranks = ndev_want; c->device = dl[i]; c->backend = MCMCX_COMM_RCCL; c->single_process = true; c->nccl = comms[i];
+        c->rank = i; c->nranks = ndev_want; c->device = dl[i]; c->backend = MCMCX_COMM_RCCL; c->single_process = true; c->nccl = comms[i]; c->group_failed = group_failed;
         hipError_t e = hipSetDevice(dl[i]);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipMalloc((void **)&c->d_scratch, 512 * sizeof(double));
@@ -270,7 +274,6 @@ int mcmcx_comm_create_all(int32_t ndev_want, const int32_t *devices, mcmcx_comm_
         }
         out[i] = c;
     }
-    g_peer_failed.store(0);
     return 0;
 }
 

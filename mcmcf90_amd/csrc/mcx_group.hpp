@@ -50,9 +50,10 @@ MCX_DEV double row_down(double x) { return __shfl_down(x, N, 16); }
 
 // The hot sequences are single asm statements: v_fmac_f64_dpp / v_add_f64_dpp / v_mov_b64_dpp with row_newbcast (the one DPP
 // control the f64 pipe takes).  The compiler's hazard recogniser does not look into inline asm, and a DPP operand must not be
-// read within two wait states of the VALU instruction that wrote it (five after a VALU write of EXEC): every statement
-// opens with s_nop 4, and the instructions inside one statement never write a register that a later DPP operand of the same
-// statement reads.
+// read within two wait states of the VALU instruction that wrote it: every statement opens with s_nop 1 (two wait states), and the
+// instructions inside one statement never write a register that a later DPP operand of the same statement reads.  (The other DPP
+// hazard -- five wait states after a VALU write of EXEC, i.e. v_cmpx -- does not arise: on gfx9 the compiler forms exec masks with
+// v_cmp + s_and_saveexec, and tests/test_cabi_exports.py::test_group_kernels_hold_no_v_cmpx looks at the shipped code object.)
 #define MCX_DPPC(i) " row_newbcast:" #i " row_mask:0xf bank_mask:0xf\n\t"
 #define MCX_GFM(i, r) "v_fmac_f64_dpp %0, %1, %" #r MCX_DPPC(i)
 #define MCX_GFM4(b) MCX_GFM(0, 2) MCX_GFM(1, 3) MCX_GFM(2, 4) MCX_GFM(3, 5)
@@ -68,10 +69,10 @@ template <int N>
 MCX_DEV void blk_fmac(double &p, double z, const double *r)
 {
     static_assert(N == 4 || N == 8 || N == 12 || N == 16, "blocks of four");
-    if constexpr (N == 4) asm("s_nop 4\n\t" MCX_GFM4(0) : "+v"(p) : "v"(z), MCX_R4(r));
-    else if constexpr (N == 8) asm("s_nop 4\n\t" MCX_GFM8(0) : "+v"(p) : "v"(z), MCX_R8(r));
-    else if constexpr (N == 12) asm("s_nop 4\n\t" MCX_GFM12(0) : "+v"(p) : "v"(z), MCX_R12(r));
-    else asm("s_nop 4\n\t" MCX_GFM16(0) : "+v"(p) : "v"(z), MCX_R16(r));
+    if constexpr (N == 4) asm("s_nop 1\n\t" MCX_GFM4(0) : "+v"(p) : "v"(z), MCX_R4(r));
+    else if constexpr (N == 8) asm("s_nop 1\n\t" MCX_GFM8(0) : "+v"(p) : "v"(z), MCX_R8(r));
+    else if constexpr (N == 12) asm("s_nop 1\n\t" MCX_GFM12(0) : "+v"(p) : "v"(z), MCX_R12(r));
+    else asm("s_nop 1\n\t" MCX_GFM16(0) : "+v"(p) : "v"(z), MCX_R16(r));
 }
 // two chains over the same coefficients: pa = fma(r[i], xa_i, pa), pb = fma(r[i], xb_i, pb).  (A chain whose first term is a plain
 // product -- quadform_sym's `(i == 0) ? sij * dxi : dfma(...)` -- starts from -0.0: fma(a, b, -0.0) is a * b bit for bit, signed zeros
@@ -85,10 +86,10 @@ template <int N>
 MCX_DEV void blk_fmac2(double &pa, double &pb, double za, double zb, const double *r)
 {
     static_assert(N == 4 || N == 8 || N == 12 || N == 16, "blocks of four");
-    if constexpr (N == 4) asm("s_nop 4\n\t" MCX_GF2_4 : "+v"(pa), "+v"(pb) : "v"(za), "v"(zb), MCX_R4(r));
-    else if constexpr (N == 8) asm("s_nop 4\n\t" MCX_GF2_8 : "+v"(pa), "+v"(pb) : "v"(za), "v"(zb), MCX_R8(r));
-    else if constexpr (N == 12) asm("s_nop 4\n\t" MCX_GF2_12 : "+v"(pa), "+v"(pb) : "v"(za), "v"(zb), MCX_R12(r));
-    else asm("s_nop 4\n\t" MCX_GF2_16 : "+v"(pa), "+v"(pb) : "v"(za), "v"(zb), MCX_R16(r));
+    if constexpr (N == 4) asm("s_nop 1\n\t" MCX_GF2_4 : "+v"(pa), "+v"(pb) : "v"(za), "v"(zb), MCX_R4(r));
+    else if constexpr (N == 8) asm("s_nop 1\n\t" MCX_GF2_8 : "+v"(pa), "+v"(pb) : "v"(za), "v"(zb), MCX_R8(r));
+    else if constexpr (N == 12) asm("s_nop 1\n\t" MCX_GF2_12 : "+v"(pa), "+v"(pb) : "v"(za), "v"(zb), MCX_R12(r));
+    else asm("s_nop 1\n\t" MCX_GF2_16 : "+v"(pa), "+v"(pb) : "v"(za), "v"(zb), MCX_R16(r));
 }
 // q = q + t_i, i = 0..N-1 in that order (t_i = lane i's t), as q = fma(t_i, 1.0, q): the same rounding of the same sum
 #define MCX_GAD(i) "v_fmac_f64_dpp %0, %1, %2" MCX_DPPC(i)
@@ -101,10 +102,10 @@ MCX_DEV void blk_addchain(double &q, double t)
 {
     static_assert(N == 4 || N == 8 || N == 12 || N == 16, "blocks of four");
     const double one = 1.0;
-    if constexpr (N == 4) asm("s_nop 4\n\t" MCX_GAD4 : "+v"(q) : "v"(t), "v"(one));
-    else if constexpr (N == 8) asm("s_nop 4\n\t" MCX_GAD8 : "+v"(q) : "v"(t), "v"(one));
-    else if constexpr (N == 12) asm("s_nop 4\n\t" MCX_GAD12 : "+v"(q) : "v"(t), "v"(one));
-    else asm("s_nop 4\n\t" MCX_GAD16 : "+v"(q) : "v"(t), "v"(one));
+    if constexpr (N == 4) asm("s_nop 1\n\t" MCX_GAD4 : "+v"(q) : "v"(t), "v"(one));
+    else if constexpr (N == 8) asm("s_nop 1\n\t" MCX_GAD8 : "+v"(q) : "v"(t), "v"(one));
+    else if constexpr (N == 12) asm("s_nop 1\n\t" MCX_GAD12 : "+v"(q) : "v"(t), "v"(one));
+    else asm("s_nop 1\n\t" MCX_GAD16 : "+v"(q) : "v"(t), "v"(one));
 }
 // ss = fma(v_i, v_i, ss), i = 0..N-1 in that order (the banana target's and the data target's sums of squares)
 #define MCX_GSQ(i) "v_mov_b64_dpp %2, %1" MCX_DPPC(i) "v_fmac_f64_dpp %0, %1, %2" MCX_DPPC(i)
@@ -117,10 +118,10 @@ MCX_DEV void blk_sqchain(double &ss, double v)
 {
     static_assert(N == 4 || N == 8 || N == 12 || N == 16, "blocks of four");
     double tmp;
-    if constexpr (N == 4) asm("s_nop 4\n\t" MCX_GSQ4 : "+v"(ss), "+v"(v), "=&v"(tmp));
-    else if constexpr (N == 8) asm("s_nop 4\n\t" MCX_GSQ8 : "+v"(ss), "+v"(v), "=&v"(tmp));
-    else if constexpr (N == 12) asm("s_nop 4\n\t" MCX_GSQ12 : "+v"(ss), "+v"(v), "=&v"(tmp));
-    else asm("s_nop 4\n\t" MCX_GSQ16 : "+v"(ss), "+v"(v), "=&v"(tmp));
+    if constexpr (N == 4) asm("s_nop 1\n\t" MCX_GSQ4 : "+v"(ss), "+v"(v), "=&v"(tmp));
+    else if constexpr (N == 8) asm("s_nop 1\n\t" MCX_GSQ8 : "+v"(ss), "+v"(v), "=&v"(tmp));
+    else if constexpr (N == 12) asm("s_nop 1\n\t" MCX_GSQ12 : "+v"(ss), "+v"(v), "=&v"(tmp));
+    else asm("s_nop 1\n\t" MCX_GSQ16 : "+v"(ss), "+v"(v), "=&v"(tmp));
 }
 
 // ---------------------------------------------------------------- shapes
@@ -510,10 +511,14 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
         double alpha = 0.0;
         {
             // tst of MCMC_alpha for a first stage, l2 of MCMC_DR_alpha13 for a second: the same expression of the same operands
-            const double tstl = -0.5 * ((ss - ss1) / sigma2 + (pri - pri1));
+            // (x / 1.0 is x: with sigma2 = 1 on every chain of the wave -- no sigma2 update, the reference's default -- the divisions are skipped)
+            const bool s2one = __all(sigma2 == 1.0);
+            double dss = ss - ss1, dss2 = ss2s - ss;
+            if (!s2one) { dss = dss / sigma2; dss2 = dss2 / sigma2; }
+            const double tstl = -0.5 * (dss + (pri - pri1));
             // ONE exponential for both kinds of chains: exp(tst) (MCMC_alpha) or the alpha32 term (MCMC_DR_alpha13); every lane evaluates
             // it whether its chain needs the value or not (d_exp has no side effects), which takes two divergent calls out of the pass
-            const double a32 = -0.5 * ((ss2s - ss) / sigma2 + (pri2s - pri));
+            const double a32 = -0.5 * (dss2 + (pri2s - pri));
             const double e1 = d_exp((DR && st2) ? a32 : tstl);
             if (act) {
                 if (er) {                                                   // early rejection, MCMC_run_er.F90:60-89: u is always drawn (MCMC_sscrit)

@@ -61,3 +61,29 @@ def test_c_example_runs():
     p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     out = p.stdout.decode()
     assert p.returncode == 0 and "simuind 2000" in out and "pooled mean over 256 chains" in out, out
+
+
+def test_group_kernels_hold_no_v_cmpx(tmp_path):
+    """mcx_group.hpp's DPP sequences are inline asm that opens with `s_nop 1`: enough for a DPP operand written by the preceding VALU
+    instruction, not for a VALU write of EXEC (five wait states), which the hazard recogniser cannot see across an asm statement.  On
+    gfx9 the compiler forms exec masks with v_cmp + s_and_saveexec (SALU), never v_cmpx: the shipped code object is checked for it."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "mcmcf90_amd", "libmcmcx.so")
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(lib) and os.path.exists(objdump)):
+        pytest.skip("needs the built library and llvm-objdump")
+    shutil.copy(lib, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", "lib.so"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    co = [f for f in os.listdir(tmp_path) if "amdgcn" in f]
+    assert co, os.listdir(tmp_path)
+    dis = subprocess.run([objdump, "-d", co[0]], cwd=tmp_path, stdout=subprocess.PIPE, check=True).stdout.decode(errors="replace")
+    ingroup, seen, bad = False, 0, []
+    for line in dis.splitlines():
+        if line.endswith(">:"):
+            ingroup = "group_step_kernel" in line
+            seen += ingroup
+        elif ingroup and "v_cmpx" in line:
+            bad.append(line.strip())
+    assert seen >= 10 and not bad, (seen, bad[:3])

@@ -1,5 +1,5 @@
 # tools/c2ab.sh -- run on the GPU box: config 2 (Gaussian d=10, AM) with state + factor in LDS, state only, neither
-cd $GRAFT_REPO_ROOT
+cd "$(dirname "$0")/.." || exit 1
 for v in "MCMCX_X=0" "MCMCX_LDS_SCRATCH=1" "MCMCX_LDS_SCRATCH=0"; do
   echo "== $v"
   env $v python bench.py --workload c2 --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "

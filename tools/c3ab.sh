@@ -1,5 +1,5 @@
 # tools/c3ab.sh -- run on the GPU box: config 3 (banana d=20, DRAM) with the delayed-rejection kernel, build variants of it, and the general step kernel
-cd $GRAFT_REPO_ROOT
+cd "$(dirname "$0")/.." || exit 1
 for v in "MCMCX_X=0" "MCMCX_LIBRARY=$PWD/tools/_build/libmcmcx_q2nb2.so" "MCMCX_LIBRARY=$PWD/tools/_build/libmcmcx_q2nb1.so" "MCMCX_DR_GENERAL=1"; do
   echo "== $v"
   env $v python bench.py --workload c3 --steps 6 --warmup 2 --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "

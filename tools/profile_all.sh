@@ -2,7 +2,7 @@
 # tools/profile_all.sh -- run on the GPU box from the repo root: every bench configuration through tools/profile_round.sh
 # (kernel trace + separate PMC passes), summaries under gpurun_out/prof/<tag>/; then
 #   python tools/install_profiles.py rNN_x c4_ram c4_ram_target c2_dram c3_dram c4_dram c4_pooled c5_pooled c5_pooled_fast
-cd $GRAFT_REPO_ROOT
+cd "$(dirname "$0")/.." || exit 1
 bash tools/profile_round.sh c4_ram > /dev/null 2>&1;                         echo c4_ram done
 bash tools/profile_round.sh c4_ram_target --start target > /dev/null 2>&1;   echo c4_ram_target done
 bash tools/profile_round.sh c2_dram --workload c2 > /dev/null 2>&1;          echo c2 done
