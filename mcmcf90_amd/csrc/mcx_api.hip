@@ -91,7 +91,7 @@ struct mcmcx_engine {
     double *d_ramscale = nullptr, *d_moments = nullptr;
     double *d_Gc = nullptr, *d_Vc = nullptr, *d_svc = nullptr; uint8_t *d_need = nullptr, *d_state = nullptr; int *d_anyrot = nullptr; int svd_b = 0;    // blocked SVD of the adaptation (large npar)
     int wcap = 0;
-    int group_d4 = 0, group_drm = 0; bool group_check_due = true; int *d_gflag = nullptr; uint8_t *d_accb = nullptr;         // lane-group step kernel (mcx_group.hpp): npar rounded up to four when it is the one to launch; accept bytes of a launch
+    int group_d4 = 0, group_drm = 0; bool group_factor = false; bool group_check_due = true; int *d_gflag = nullptr; uint8_t *d_accb = nullptr;         // lane-group step kernel (mcx_group.hpp): npar rounded up to four when it is the one to launch; accept bytes of a launch
     bool external = false; double *d_r1 = nullptr; std::vector<double> h_r1;      // MCMC_run1: the caller evaluates; exchange vectors of run1_kernel
     // timing of the step kernel
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -556,6 +556,12 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
     }
     if (!h->d_Gc) {
         if (h->usesvd) hipLaunchKernelGGL(adapt_post_kernel<true>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr, batch_done);
+        else if (h->group_factor) {
+            // with the lane-group step kernels: the Cholesky factor, its inverse and R2 in the group layout too (mcx_group.hpp)
+            hipLaunchKernelGGL(adapt_post_kernel<false>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 3, (uint8_t *)nullptr, batch_done);
+            const int LD = h->d | 1;
+            hipLaunchKernelGGL(group_factor_kernel, dim3(h->ntiles * 16), dim3(64), (size_t)4 * h->d * LD * sizeof(double), h->stream, h->E);
+        }
         else hipLaunchKernelGGL(adapt_post_kernel<false>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr, batch_done);
         return;
     }
@@ -1533,6 +1539,10 @@ int mcmcx_init(mcmcx_handle h)
         if (on) h->group_d4 = d <= 32 ? ((d + 3) & ~3) : ((d + 7) & ~7);
         if (h->group_d4 && (E.hist || E.accmask) && (rc = dev_alloc(h, &h->d_accb, L * (size_t)GROUP_MAXSEG))) return rc;
         if (h->group_d4) {
+            // the factorisation in the group layout too (group_factor_kernel) where a tick is latency: ~250 us less per tick for one tile at
+            // npar 20 with delayed rejection; with the chip full it is a wash (2.1 ms against adapt_post_kernel's 2.2 at config 3's size)
+            const char *gf = getenv("MCMCX_GROUP_FACTOR");                                          // (0 / 1: A/B, tests)
+            h->group_factor = d <= 32 && (gf ? atoi(gf) != 0 : (long long)c.nchains <= 16384);
             h->group_drm = drm;
             h->group_check_due = true;
             if (h->group_drm == 2 && (rc = dev_alloc(h, &h->d_gflag, 1))) return rc;

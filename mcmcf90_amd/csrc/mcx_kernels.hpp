@@ -3742,7 +3742,7 @@ __global__ __launch_bounds__(64, SVD ? 1 : MCX_POST_WAVES) void adapt_post_kerne
                 TIDX(E.ictr, tile, NICTR, I_INFO, lane) = (uint32_t)info;
             }
         }
-    } else if (__any(docalc)) {
+    } else if (phase != 3 && __any(docalc)) {           // (phase 3: group_factor_kernel has the factorisation)
         int info = calculate_R(Ct, Tt, Rt, lane, d, P, docalc, X);
         if (docalc) {
             TIDX(E.ictr, tile, NICTR, I_INFO, lane) = (uint32_t)info;

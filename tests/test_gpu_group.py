@@ -172,6 +172,33 @@ def test_group_kernel_power_of_two_drscale_and_its_range_check(oracle, monkeypat
         assert sum(c["drtries"] for c in a[3]) > 0
 
 
+@pytest.mark.parametrize("kind,d,drscale", [("gauss", 20, 2.0), ("banana", 31, 3.0), ("gauss", 17, 0.0), ("gauss", 5, 2.0)])
+def test_group_factorisation_kernel(oracle, monkeypatch, kind, d, drscale):
+    """group_factor_kernel (dpotf2 with lanes as columns, dtrti2 / dlauu2 with lanes as rows, the matrix in LDS) against adapt_post_kernel's
+    own factorisation: R, R2, iC and the chain after three adaptations, bit for bit; and against the oracle."""
+    from mcmcf90_amd import engine_from_problem
+    ckw = dict(nsimu=170, adaptint=50, updatesigma=0, drscale=drscale)
+    pkw = _problem(kind, d, 300 + d)
+    res = []
+    for gf in ("1", "0"):
+        monkeypatch.setenv("MCMCX_GROUP", "1"); monkeypatch.setenv("MCMCX_GROUP_FACTOR", gf)
+        e = engine_from_problem(ckw, pkw, nchains=70, chain_id0=4, record_accept=1)
+        e.init(); e.run()
+        res.append((e.theta().copy(), e.accept_masks().copy(), [e.R(c).copy() for c in (0, 69)], [e.dr_state(c) for c in (0, 69)] if drscale else [], [e.counters(c) for c in (0, 69)]))
+        e.close()
+    a, b = res
+    assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1]) and a[4] == b[4]
+    for x, y in zip(a[2], b[2]):
+        np.testing.assert_array_equal(_bits(np.triu(x)), _bits(np.triu(y)))
+    for x, y in zip(a[3], b[3]):
+        for u, v in zip(x, y):
+            np.testing.assert_array_equal(_bits(np.triu(u)), _bits(np.triu(v)))
+    o = oracle.run_chain(oracle.make_cfg(**ckw), oracle.Problem(**pkw), chain_id=4)
+    np.testing.assert_array_equal(_bits(np.triu(a[2][0])), _bits(np.triu(o.R)))
+    if drscale:
+        np.testing.assert_array_equal(_bits(np.triu(a[3][0][1])), _bits(np.triu(o.iC)))
+
+
 def test_group_kernel_full_chain_and_burnin(oracle, monkeypatch):
     """record_chain (every accepted row through the ring, ballots from the accept bytes), burn-in scaling + greedy restart, launches
     cut at 256 iterations and by mcmcx_run calls of odd lengths."""
