@@ -91,7 +91,7 @@ struct mcmcx_engine {
     double *d_ramscale = nullptr, *d_moments = nullptr;
     double *d_Gc = nullptr, *d_Vc = nullptr, *d_svc = nullptr; uint8_t *d_need = nullptr, *d_state = nullptr; int *d_anyrot = nullptr; int svd_b = 0;    // blocked SVD of the adaptation (large npar)
     int wcap = 0;
-    int group_d4 = 0, group_drm = 0; bool group_factor = false; bool group_check_due = true; int *d_gflag = nullptr; uint8_t *d_accb = nullptr;         // lane-group step kernel (mcx_group.hpp): npar rounded up to four when it is the one to launch; accept bytes of a launch
+    int group_d4 = 0, group_drm = 0, group_gw = 16; bool group_factor = false; bool group_check_due = true; int *d_gflag = nullptr; uint8_t *d_accb = nullptr;         // lane-group step kernel (mcx_group.hpp): npar rounded up to four when it is the one to launch; accept bytes of a launch
     bool external = false; double *d_r1 = nullptr; std::vector<double> h_r1;      // MCMC_run1: the caller evaluates; exchange vectors of run1_kernel
     // timing of the step kernel
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -330,42 +330,53 @@ static bool group_covers(const mcmcx_engine *h)
 // sixteen lanes per chain with the factors on chip take 2-5 us where a lane takes 7-160 (4x-33x).  With the chip full, from npar 11
 // on: 1.04-1.3x without delayed rejection up to npar 20 and 1.7-3x above, 1.1-3.7x with it; at npar <= 10 the lane kernels, which keep
 // the factor in LDS there, stay ahead (group: 0.35-0.9x).
-static bool group_wins(const mcmcx_engine *h, int drm)
+// ... and with which group width: four lanes per chain (sixteen chains per wave) for small npar with the chip full, where sixteen lanes
+// would mostly idle (tools/quad_sweep.py, profiles/r04_b/quad_sweep.txt: without delayed rejection 1.3-3.6x the sixteen-lane form at npar
+// <= 16 and 1.1-3.2x the lane kernels up to 131072 chains -- 1.5-1.7x at any count from npar 11 on; with it at npar <= 8)
+static int group_width(const mcmcx_engine *h)
 {
-    (void)drm;
+    if ((long long)h->cfg.nchains <= 16384 || h->d > 16 || h->cfg.updatesigma) return 16;
+    if (!h->dodr) return 4;
+    return h->d <= 8 ? 4 : 16;
+}
+static bool group_wins(const mcmcx_engine *h, int drm, int gw)
+{
     const long long n = h->cfg.nchains;
+    const int d = h->d;
     if (h->cfg.updatesigma) {
         // MCMC_updatesigma2's gamma sampler is a serial, data-dependent sequence of draws per chain: a group wave runs it for four chains,
         // a lane wave for 64 (tools/group_probe2.py: 2.3-12x up to 1024 chains, 0.9-5x at 16384, 0.45-0.8x beyond without delayed
         // rejection, 1.3-1.6x with it at npar 20)
         if (n <= 8192) return true;
-        if (n <= 16384) return h->d >= 4;
-        return h->dodr && h->d >= 11;
+        if (n <= 16384) return d >= 4;
+        return h->dodr && d >= 11;
     }
-    return n <= 16384 || h->d >= 11;
+    if (n <= 16384) return true;
+    if (gw == 4) return h->dodr ? (drm == 2 || n <= 131072) : (d >= 11 || n <= 131072);
+    return d >= 11 || (h->dodr && d >= 9 && n <= 131072);
 }
-template <int D4, int TK>
+template <int GW, int D4, int TK>
 static void launch_group_tk(mcmcx_engine *h, int it0, int it1)
 {
-    const dim3 g(h->ntiles * 16), b(64);
+    const dim3 g(h->ntiles * (GW == 16 ? 16 : 4)), b(64);           // 64 / GW chains per wave
     const double *lam = h->E.tgt.lamT;
-    if (h->group_drm == 0) { h->last_kernel = "group_step_kernel"; hipLaunchKernelGGL((group_step_kernel<D4, 0, TK>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)nullptr, 0); }
+    if (h->group_drm == 0) { h->last_kernel = GW == 16 ? "group_step_kernel" : "group_step_kernel<quad>"; hipLaunchKernelGGL((group_step_kernel<GW, D4, 0, TK>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)nullptr, 0); }
     else if constexpr (D4 > 32) { return; }               // (group_covers: no delayed rejection above npar 32)
-    else if (h->group_drm == 1) { h->last_kernel = "group_step_kernel<DR>"; hipLaunchKernelGGL((group_step_kernel<D4, 1, -1>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)nullptr, 0); }
+    else if (h->group_drm == 1) { h->last_kernel = GW == 16 ? "group_step_kernel<DR>" : "group_step_kernel<quad, DR>"; hipLaunchKernelGGL((group_step_kernel<GW, D4, 1, -1>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)nullptr, 0); }
     else {
         // drscale a power of two: the instantiation without R2 runs unless the device flag says that some factor leaves the range in
         // which R'z / drscale is R2'z bit for bit; the general one is queued behind the same flag and returns at once otherwise
-        h->last_kernel = "group_step_kernel<DR2>";
-        hipLaunchKernelGGL((group_step_kernel<D4, 2, TK>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)h->d_gflag, 0);
-        hipLaunchKernelGGL((group_step_kernel<D4, 1, -1>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)h->d_gflag, 1);
+        h->last_kernel = GW == 16 ? "group_step_kernel<DR2>" : "group_step_kernel<quad, DR2>";
+        hipLaunchKernelGGL((group_step_kernel<GW, D4, 2, TK>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)h->d_gflag, 0);
+        hipLaunchKernelGGL((group_step_kernel<GW, D4, 1, -1>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)h->d_gflag, 1);
     }
 }
-template <int D4>
+template <int GW, int D4>
 static void launch_group_d4(mcmcx_engine *h, int it0, int it1)
 {
-    if (h->tkind == TGT_BANANA) launch_group_tk<D4, TGT_BANANA>(h, it0, it1);
-    else if (h->tkind == TGT_EXPDATA) { if constexpr (D4 == 4) launch_group_tk<D4, TGT_EXPDATA>(h, it0, it1); }   // (that target has two parameters)
-    else launch_group_tk<D4, TGT_GAUSS>(h, it0, it1);
+    if (h->tkind == TGT_BANANA) launch_group_tk<GW, D4, TGT_BANANA>(h, it0, it1);
+    else if (h->tkind == TGT_EXPDATA) { if constexpr (D4 == 4) launch_group_tk<GW, D4, TGT_EXPDATA>(h, it0, it1); }   // (that target has two parameters)
+    else launch_group_tk<GW, D4, TGT_GAUSS>(h, it0, it1);
 }
 static void launch_group(mcmcx_engine *h, int it0, int it1)
 {
@@ -374,19 +385,28 @@ static void launch_group(mcmcx_engine *h, int it0, int it1)
         hipLaunchKernelGGL(group_check_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, h->d_gflag);
         h->group_check_due = false;
     }
-    switch (h->group_d4) {
-    case 4: launch_group_d4<4>(h, it0, it1); break;
-    case 8: launch_group_d4<8>(h, it0, it1); break;
-    case 12: launch_group_d4<12>(h, it0, it1); break;
-    case 16: launch_group_d4<16>(h, it0, it1); break;
-    case 20: launch_group_d4<20>(h, it0, it1); break;
-    case 24: launch_group_d4<24>(h, it0, it1); break;
-    case 28: launch_group_d4<28>(h, it0, it1); break;
-    case 32: launch_group_d4<32>(h, it0, it1); break;
-    case 40: launch_group_d4<40>(h, it0, it1); break;       // (above 32: sizes of eight, no delayed rejection)
-    case 48: launch_group_d4<48>(h, it0, it1); break;
-    case 56: launch_group_d4<56>(h, it0, it1); break;
-    default: launch_group_d4<64>(h, it0, it1); break;
+    if (h->group_gw == 4) {                                  // quads: npar <= 16
+        switch (h->group_d4) {
+        case 4: launch_group_d4<4, 4>(h, it0, it1); break;
+        case 8: launch_group_d4<4, 8>(h, it0, it1); break;
+        case 12: launch_group_d4<4, 12>(h, it0, it1); break;
+        default: launch_group_d4<4, 16>(h, it0, it1); break;
+        }
+    } else {
+        switch (h->group_d4) {
+        case 4: launch_group_d4<16, 4>(h, it0, it1); break;
+        case 8: launch_group_d4<16, 8>(h, it0, it1); break;
+        case 12: launch_group_d4<16, 12>(h, it0, it1); break;
+        case 16: launch_group_d4<16, 16>(h, it0, it1); break;
+        case 20: launch_group_d4<16, 20>(h, it0, it1); break;
+        case 24: launch_group_d4<16, 24>(h, it0, it1); break;
+        case 28: launch_group_d4<16, 28>(h, it0, it1); break;
+        case 32: launch_group_d4<16, 32>(h, it0, it1); break;
+        case 40: launch_group_d4<16, 40>(h, it0, it1); break;       // (above 32: sizes of eight, no delayed rejection)
+        case 48: launch_group_d4<16, 48>(h, it0, it1); break;
+        case 56: launch_group_d4<16, 56>(h, it0, it1); break;
+        default: launch_group_d4<16, 64>(h, it0, it1); break;
+        }
     }
     if (h->d_accb) {
         const long long n = (long long)(it1 - it0 + 1) * h->ntiles;
@@ -1535,14 +1555,17 @@ int mcmcx_init(mcmcx_handle h)
         const bool pow2 = h->dodr && c.drscale > 0.0 && std::frexp(c.drscale, &ex) == 0.5 && ex > -64 && ex < 64;
         // (the power-of-two form keeps iC in LDS: above npar 24 that leaves fewer waves per CU than the register form's four)
         const int drm = !h->dodr ? 0 : (pow2 && d <= 24 && !(getenv("MCMCX_GROUP_DR2") && atoi(getenv("MCMCX_GROUP_DR2")) == 0)) ? 2 : 1;
-        const bool on = ev ? atoi(ev) != 0 : group_wins(h, drm);
+        const char *gwe = getenv("MCMCX_GROUP_GW");                                             // (4 / 16: A/B, tests)
+        const int gw = (d <= 16 && gwe) ? (atoi(gwe) == 4 ? 4 : 16) : group_width(h);
+        const bool on = ev ? atoi(ev) != 0 : group_wins(h, drm, gw);
         if (on) h->group_d4 = d <= 32 ? ((d + 3) & ~3) : ((d + 7) & ~7);
         if (h->group_d4 && (E.hist || E.accmask) && (rc = dev_alloc(h, &h->d_accb, L * (size_t)GROUP_MAXSEG))) return rc;
         if (h->group_d4) {
+            h->group_gw = gw;
             // the factorisation in the group layout too (group_factor_kernel) where a tick is latency: ~250 us less per tick for one tile at
             // npar 20 with delayed rejection; with the chip full it is a wash (2.1 ms against adapt_post_kernel's 2.2 at config 3's size)
             const char *gf = getenv("MCMCX_GROUP_FACTOR");                                          // (0 / 1: A/B, tests)
-            h->group_factor = d <= 32 && (gf ? atoi(gf) != 0 : (long long)c.nchains <= 16384);
+            h->group_factor = d <= 32 && h->group_gw == 16 && (gf ? atoi(gf) != 0 : (long long)c.nchains <= 16384);
             h->group_drm = drm;
             h->group_check_due = true;
             if (h->group_drm == 2 && (rc = dev_alloc(h, &h->d_gflag, 1))) return rc;

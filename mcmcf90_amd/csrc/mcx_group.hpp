@@ -47,6 +47,19 @@ MCX_DEV double row_bcast(double x)
 // value of lane l16 + N of the same row (garbage past the row's end: callers mask)
 template <int N>
 MCX_DEV double row_down(double x) { return __shfl_down(x, N, 16); }
+// GW lanes per chain: 16 (a DPP row) or 4 (a quad: sixteen chains per wave -- small npar with the chip full, where sixteen lanes would
+// mostly idle).  Value of lane N of the group: row_newbcast, or quad_perm [N,N,N,N] on the two halves.
+template <int GW, int N>
+MCX_DEV double grp_bcast(double x)
+{
+    if constexpr (GW == 16) return row_bcast<N>(x);
+    else {
+        int lo = __double2loint(x), hi = __double2hiint(x);
+        lo = __builtin_amdgcn_update_dpp(0, lo, N * 0x55, 0xf, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(0, hi, N * 0x55, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+    }
+}
 
 // The hot sequences are single asm statements: v_fmac_f64_dpp / v_add_f64_dpp / v_mov_b64_dpp with row_newbcast (the one DPP
 // control the f64 pipe takes).  The compiler's hazard recogniser does not look into inline asm, and a DPP operand must not be
@@ -124,15 +137,54 @@ MCX_DEV void blk_sqchain(double &ss, double v)
     else asm("s_nop 1\n\t" MCX_GSQ16 : "+v"(ss), "+v"(v), "=&v"(tmp));
 }
 
+// the same four sequences for either group width: the asm statements above for rows of sixteen, the compiler's own DPP moves (quad_perm
+// has no f64 form) and plain fmas for quads -- same operands, same order
+template <int GW, int N>
+MCX_DEV void gblk_fmac(double &p, double z, const double *r)
+{
+    if constexpr (GW == 16) blk_fmac<N>(p, z, r);
+    else { static_assert(N == 4, "a quad"); p = dfma(r[0], grp_bcast<4, 0>(z), p); p = dfma(r[1], grp_bcast<4, 1>(z), p); p = dfma(r[2], grp_bcast<4, 2>(z), p); p = dfma(r[3], grp_bcast<4, 3>(z), p); }
+}
+template <int GW, int N>
+MCX_DEV void gblk_fmac2(double &pa, double &pb, double za, double zb, const double *r)
+{
+    if constexpr (GW == 16) blk_fmac2<N>(pa, pb, za, zb, r);
+    else {
+        static_assert(N == 4, "a quad");
+        pa = dfma(r[0], grp_bcast<4, 0>(za), pa); pb = dfma(r[0], grp_bcast<4, 0>(zb), pb);
+        pa = dfma(r[1], grp_bcast<4, 1>(za), pa); pb = dfma(r[1], grp_bcast<4, 1>(zb), pb);
+        pa = dfma(r[2], grp_bcast<4, 2>(za), pa); pb = dfma(r[2], grp_bcast<4, 2>(zb), pb);
+        pa = dfma(r[3], grp_bcast<4, 3>(za), pa); pb = dfma(r[3], grp_bcast<4, 3>(zb), pb);
+    }
+}
+template <int GW, int N>
+MCX_DEV void gblk_addchain(double &q, double t)
+{
+    if constexpr (GW == 16) blk_addchain<N>(q, t);
+    else { static_assert(N == 4, "a quad"); q = q + grp_bcast<4, 0>(t); q = q + grp_bcast<4, 1>(t); q = q + grp_bcast<4, 2>(t); q = q + grp_bcast<4, 3>(t); }
+}
+template <int GW, int N>
+MCX_DEV void gblk_sqchain(double &ss, double v)
+{
+    if constexpr (GW == 16) blk_sqchain<N>(ss, v);
+    else {
+        static_assert(N == 4, "a quad");
+        const double v0 = grp_bcast<4, 0>(v), v1 = grp_bcast<4, 1>(v), v2 = grp_bcast<4, 2>(v), v3 = grp_bcast<4, 3>(v);
+        ss = dfma(v0, v0, ss); ss = dfma(v1, v1, ss); ss = dfma(v2, v2, ss); ss = dfma(v3, v3, ss);
+    }
+}
+
 // ---------------------------------------------------------------- shapes
-template <int D4>
+template <int D4, int GW = 16>
 struct GDims {
-    static constexpr int NS = (D4 + 15) / 16;                                          // slots (columns / rows / positions) per lane
-    static constexpr int rows(int s) { return D4 < 16 * (s + 1) ? D4 : 16 * (s + 1); }   // rows of the columns of slot s (upper triangle)
+    static constexpr int NS = (D4 + GW - 1) / GW;                                      // slots (columns / rows / positions) per lane
+    static constexpr int rows(int s) { return D4 < GW * (s + 1) ? D4 : GW * (s + 1); }   // rows of the columns of slot s (upper triangle)
     static constexpr int off(int s) { int o = 0; for (int q = 0; q < s; ++q) o += rows(q); return o; }
     static constexpr int NR = off(NS);                                                 // doubles per lane for one triangular factor
-    static constexpr int blk(int t) { return (D4 - 16 * t) < 16 ? (D4 - 16 * t) : 16; }  // positions of block t
+    static constexpr int blk(int t) { return (D4 - GW * t) < GW ? (D4 - GW * t) : GW; }  // positions of block t
     static constexpr int ZS = D4 + 4;                                                  // LDS doubles per chain (normals + the saved slot)
+    static constexpr int CPW = 64 / GW;                                                // chains per wave
+    static constexpr unsigned GM = (GW == 16) ? 0xffffu : 0xfu;                        // a group's bits of a ballot
 };
 
 struct GChain {                         // the chain's stream: uniform over its 16 lanes ...
@@ -144,10 +196,10 @@ struct GChain {                         // the chain's stream: uniform over its 
 
 // ---------------------------------------------------------------- normals: sixteen polar attempts of a chain at a time
 // z[t] <- the chain's next npar deviates (position 16 t + l16; 0 in the padding), through the chain's LDS row.
-template <int D4>
-MCX_DEV void group_normals(uint32_t k0, uint32_t k1, GChain &g, double *zrow, int l16, int row, int d, bool act, double (&z)[GDims<D4>::NS])
+template <int D4, int GW>
+MCX_DEV void group_normals(uint32_t k0, uint32_t k1, GChain &g, double *zrow, int l16, int row, int d, bool act, double (&z)[GDims<D4, GW>::NS])
 {
-    using G = GDims<D4>;
+    using G = GDims<D4, GW>;
     int k = 0;
     if (act && g.saved) { if (l16 == 0) zrow[0] = g.saved_y; g.saved = 0; k = 1; }     // normal_bm's cached second deviate, mcmcrand.F90:172-175
     bool need = act && (k < d);
@@ -163,18 +215,18 @@ MCX_DEV void group_normals(uint32_t k0, uint32_t k1, GChain &g, double *zrow, in
         const uint32_t nw0 = (uint32_t)__shfl_down((int)w0, 1), nw1 = (uint32_t)__shfl_down((int)w1, 1);
         double x1 = odd ? bits_to_uniform(w2, w3) : bits_to_uniform(w0, w1);
         double x2 = odd ? bits_to_uniform(nw0, nw1) : bits_to_uniform(w2, w3);
-        const bool valid = !(odd && l16 == 15);
+        const bool valid = !(odd && l16 == GW - 1);
         x1 = 2.0 * x1 - 1.0; x2 = 2.0 * x2 - 1.0;
         const double xx = x1 * x1 + x2 * x2;
         const bool ok = valid && (xx < 1.0) && (xx != 0.0);
         const double xs = ok ? xx : 0.5;
         const double zz = sqrt(-2.0 * d_log(xs) / xs);
         const double za = zz * x2, zb = zz * x1;                   // this call's deviate, the next call's (mcmcrand.F90:183-186)
-        const uint32_t okm = (uint32_t)(__ballot(ok && need) >> (16 * row)) & 0xffffu;
+        const uint32_t okm = (uint32_t)(__ballot(ok && need) >> (GW * row)) & G::GM;
         const int pre = __popc(okm & ((1u << l16) - 1u));          // accepted attempts before this one
         const int m = (d - k + 1) >> 1;                            // pairs the chain still needs
         const int tot = __popc(okm);
-        const uint32_t mth = (uint32_t)(__ballot(ok && need && pre == m - 1) >> (16 * row)) & 0xffffu;
+        const uint32_t mth = (uint32_t)(__ballot(ok && need && pre == m - 1) >> (GW * row)) & G::GM;
         if (ok && need && pre < m) {
             const int pos = k + 2 * pre;
             zrow[pos] = za;
@@ -186,7 +238,7 @@ MCX_DEV void group_normals(uint32_t k0, uint32_t k1, GChain &g, double *zrow, in
                 newsave = ((d - k) & 1) != 0;                       // its second deviate is left over
                 k = d; need = false;
             } else {
-                g.n += odd ? 30ull : 32ull;
+                g.n += odd ? 2ull * (GW - 1) : 2ull * GW;
                 k += 2 * tot;
             }
         }
@@ -194,7 +246,7 @@ MCX_DEV void group_normals(uint32_t k0, uint32_t k1, GChain &g, double *zrow, in
     // (the wave's LDS operations retire in order: its reads below see its writes above)
     sfor<0, G::NS>([&](auto T) __attribute__((always_inline)) {
         constexpr int t = decltype(T)::value;
-        const int pos = 16 * t + l16;
+        const int pos = GW * t + l16;
         z[t] = (pos < d) ? zrow[pos] : 0.0;
     });
     if (newsave) { g.saved = 1; g.saved_y = zrow[D4]; }
@@ -203,13 +255,14 @@ MCX_DEV void group_normals(uint32_t k0, uint32_t k1, GChain &g, double *zrow, in
 // one uniform for the chains with `take` (MCMC_reject, MCMC_DRAM.F90:150-151).  Uniform n sits in block n / 2; the lanes of the
 // chain hold the blocks cb .. cb + 15 of its last round of polar attempts, and the attempts consumed there end right in front of n:
 // the block is lane (n / 2 - cb)'s unless the round used up all sixteen -- then (any chain of the wave) every lane computes it.
+template <int GW>
 MCX_DEV double group_uniform(uint32_t k0, uint32_t k1, GChain &g, bool take, int row)
 {
     const uint64_t blk = g.n >> 1;
     const uint64_t off = blk - g.cb;
-    const bool have = off < 16ull;
+    const bool have = off < (uint64_t)GW;
     const bool odd = (g.n & 1) != 0;
-    const int src = (16 * row + (int)(off & 15ull)) << 2;
+    const int src = (GW * row + (int)(off & (uint64_t)(GW - 1))) << 2;
     uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(odd ? g.cw[2] : g.cw[0]));
     uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(odd ? g.cw[3] : g.cw[1]));
     if (__any(take && !have)) {
@@ -224,36 +277,36 @@ MCX_DEV double group_uniform(uint32_t k0, uint32_t k1, GChain &g, bool take, int
 // ---------------------------------------------------------------- checkbounds / priorfun / ssfunction on a group's vector
 // (the per-parameter tables -- bounds, prior means and sigmas, the Gaussian target's mean -- are read where they are used: they are
 //  shared by all chains and stay in the vector L1; holding them would cost ten registers per slot for the whole launch)
-template <int D4>
-MCX_DEV bool group_inbounds(const DevTarget &t, const double (&x)[GDims<D4>::NS], int l16, int row, int d)
+template <int D4, int GW>
+MCX_DEV bool group_inbounds(const DevTarget &t, const double (&x)[GDims<D4, GW>::NS], int l16, int row, int d)
 {
-    using G = GDims<D4>;
+    using G = GDims<D4, GW>;
     if (!(t.lo || t.hi)) return true;
     bool bad = false;
     sfor<0, G::NS>([&](auto S) __attribute__((always_inline)) {
         constexpr int s = decltype(S)::value;
-        const int c = 16 * s + l16;
+        const int c = GW * s + l16;
         if (c < d) {
             if (t.lo) bad = bad || !(x[s] > t.lo[c]);
             if (t.hi) bad = bad || !(x[s] < t.hi[c]);
         }
     });
-    return ((uint32_t)(__ballot(bad) >> (16 * row)) & 0xffffu) == 0u;
+    return ((uint32_t)(__ballot(bad) >> (GW * row)) & G::GM) == 0u;
 }
 
 // priorfun.f90:96-100: sum over the parameters with sigma > 0 of ((theta - mu) / sigma)**2, in index order from 0
-template <int D4>
-MCX_DEV double group_prior(const DevTarget &t, const double (&x)[GDims<D4>::NS], int l16, int d)
+template <int D4, int GW>
+MCX_DEV double group_prior(const DevTarget &t, const double (&x)[GDims<D4, GW>::NS], int l16, int d)
 {
-    using G = GDims<D4>;
+    using G = GDims<D4, GW>;
     double p = 0.0;
     if (t.pmu) {
         sfor<0, G::NS>([&](auto S) __attribute__((always_inline)) {
             constexpr int s = decltype(S)::value;
-            const int c = 16 * s + l16;
+            const int c = GW * s + l16;
             double qq = 0.0;
             if (c < d) { const double sg = t.psig[c]; if (sg > 0.0) { const double q = (x[s] - t.pmu[c]) / sg; qq = q * q; } }
-            blk_addchain<G::blk(s)>(p, qq);          // (adding +0 for the parameters left out changes nothing: p >= +0)
+            gblk_addchain<GW, G::blk(s)>(p, qq);          // (adding +0 for the parameters left out changes nothing: p >= +0)
         });
     }
     return p;
@@ -261,58 +314,80 @@ MCX_DEV double group_prior(const DevTarget &t, const double (&x)[GDims<D4>::NS],
 
 // TK: the target's kind at compile time (TGT_GAUSS / TGT_BANANA / TGT_EXPDATA), or -1 = whichever the engine holds: the three forms
 // together cost a kernel ~100 registers more than its own form alone (the Gaussian one keeps sixteen matrix elements in flight)
-template <int D4, int TK>
-MCX_DEV double group_ss(const DevTarget &t, const double (&x)[GDims<D4>::NS], int l16, int d, const double *laml)
+template <int D4, int TK, int GW>
+MCX_DEV double group_ss(const DevTarget &t, const double (&x)[GDims<D4, GW>::NS], int l16, int d, const double *laml)
 {
-    using G = GDims<D4>;
+    using G = GDims<D4, GW>;
     double ss = 0.0;
     if (TK == TGT_BANANA || (TK < 0 && t.kind == TGT_BANANA)) {                       // target_ss: ss = fma chain over theta_k**2, k ascending from 2
-        const double th0 = row_bcast<0>(x[0]), th1 = row_bcast<1>(x[0]);
+        const double th0 = grp_bcast<GW, 0>(x[0]), th1 = grp_bcast<GW, 1>(x[0]);
         const double t1 = th0 * th0;
         const double q = dfma(t.b, t1, th1) - 100.0 * t.b;
         ss = dfma(q, q, t1 / 100.0);
         sfor<0, G::NS>([&](auto S) __attribute__((always_inline)) {
             constexpr int s = decltype(S)::value;
             const double w = (s == 0 && l16 < 2) ? 0.0 : x[s];        // fma(0, 0, ss) = ss: positions 0, 1 and the padding drop out
-            blk_sqchain<G::blk(s)>(ss, w);
+            gblk_sqchain<GW, G::blk(s)>(ss, w);
         });
     } else if (TK == TGT_EXPDATA || (TK < 0 && t.kind == TGT_EXPDATA)) {               // ss = fma chain over the residuals, data index ascending
-        const double th0 = row_bcast<0>(x[0]), th1 = row_bcast<1>(x[0]);
-        for (int base = 0; base < t.ndata; base += 16) {
+        const double th0 = grp_bcast<GW, 0>(x[0]), th1 = grp_bcast<GW, 1>(x[0]);
+        for (int base = 0; base < t.ndata; base += GW) {
             const int i = base + l16;
             double r = 0.0;
             if (i < t.ndata) r = t.y[i] - th0 * d_exp(-(th1 * t.x[i]));
-            blk_sqchain<16>(ss, r);
+            gblk_sqchain<GW, GW>(ss, r);
         }
     } else {                                          // Gaussian: mcxt_ss_gauss (oracle/mcx_targets.h), lane = row of Lam
-        double v[G::NS];
-        sfor<0, G::NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = 16 * s + l16; v[s] = (c < d) ? x[s] - t.mu[c] : 0.0; });
+        double v[G::NS], y[G::NS];
+        sfor<0, G::NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = GW * s + l16; v[s] = (c < d) ? x[s] - t.mu[c] : 0.0; });
         sfor<0, G::NS>([&](auto S) __attribute__((always_inline)) {
             constexpr int s = decltype(S)::value;
-            const int c = 16 * s + l16;
-            double y = 0.0;
+            const int c = GW * s + l16;
+            double ys = 0.0;
             sfor<0, G::NS>([&](auto TT) __attribute__((always_inline)) {
                 constexpr int tb = decltype(TT)::value;
                 constexpr int n = G::blk(tb);
                 double lam[n];                         // row c of the precision matrix from the wave's LDS copy [j][c] (pitch D4, zero padding)
 #pragma unroll
-                for (int u = 0; u < n; ++u) lam[u] = laml[(16 * tb + u) * D4 + ((c < D4) ? c : D4 - 1)];
-                blk_fmac<n>(y, v[tb], lam);
+                for (int u = 0; u < n; ++u) lam[u] = laml[(GW * tb + u) * D4 + ((c < D4) ? c : D4 - 1)];
+                gblk_fmac<GW, n>(ys, v[tb], lam);
                 __builtin_amdgcn_sched_barrier(0);
             });
-            if (c >= d) y = 0.0;
-            // the block's four partial chains q_k over the rows 16 s + k + 4 r: lane k < 4 collects lanes k + 4, k + 8, k + 12
-            double q = y * v[s];
-            const double y4 = row_down<4>(y), v4 = row_down<4>(v[s]), y8 = row_down<8>(y), v8 = row_down<8>(v[s]), y12 = row_down<12>(y), v12 = row_down<12>(v[s]);
-            if (c + 4 < d) q = dfma(y4, v4, q);
-            if (c + 8 < d) q = dfma(y8, v8, q);
-            if (c + 12 < d) q = dfma(y12, v12, q);
-            const double q0 = row_bcast<0>(q), q1 = row_bcast<1>(q), q2 = row_bcast<2>(q), q3 = row_bcast<3>(q);
-            if (16 * s + 0 < d) ss = (s == 0) ? q0 : ss + q0;
-            if (16 * s + 1 < d) ss = ss + q1;
-            if (16 * s + 2 < d) ss = ss + q2;
-            if (16 * s + 3 < d) ss = ss + q3;
+            y[s] = (c >= d) ? 0.0 : ys;
         });
+        // per block of 16 rows, four partial chains q_k over the rows 16 b + k + 4 r (r = 0..3), summed into ss in the order b, k
+        if constexpr (GW == 16) {
+            sfor<0, G::NS>([&](auto S) __attribute__((always_inline)) {
+                constexpr int s = decltype(S)::value;
+                const int c = 16 * s + l16;
+                // lane k < 4 collects lanes k + 4, k + 8, k + 12
+                double q = y[s] * v[s];
+                const double y4 = row_down<4>(y[s]), v4 = row_down<4>(v[s]), y8 = row_down<8>(y[s]), v8 = row_down<8>(v[s]), y12 = row_down<12>(y[s]), v12 = row_down<12>(v[s]);
+                if (c + 4 < d) q = dfma(y4, v4, q);
+                if (c + 8 < d) q = dfma(y8, v8, q);
+                if (c + 12 < d) q = dfma(y12, v12, q);
+                const double q0 = row_bcast<0>(q), q1 = row_bcast<1>(q), q2 = row_bcast<2>(q), q3 = row_bcast<3>(q);
+                if (16 * s + 0 < d) ss = (s == 0) ? q0 : ss + q0;
+                if (16 * s + 1 < d) ss = ss + q1;
+                if (16 * s + 2 < d) ss = ss + q2;
+                if (16 * s + 3 < d) ss = ss + q3;
+            });
+        } else {
+            // a quad: lane k owns the rows k, k + 4, ...: chain k of block b runs over the lane's own slots 4 b .. 4 b + 3
+            sfor<0, (D4 + 15) / 16>([&](auto B) __attribute__((always_inline)) {
+                constexpr int b = decltype(B)::value;
+                double q = y[4 * b] * v[4 * b];
+                sfor<1, 4>([&](auto R) __attribute__((always_inline)) {
+                    constexpr int r = decltype(R)::value;
+                    if constexpr (4 * b + r < G::NS) { if (16 * b + 4 * r + l16 < d) q = dfma(y[4 * b + r], v[4 * b + r], q); }
+                });
+                const double q0 = grp_bcast<4, 0>(q), q1 = grp_bcast<4, 1>(q), q2 = grp_bcast<4, 2>(q), q3 = grp_bcast<4, 3>(q);
+                if (16 * b + 0 < d) ss = (b == 0) ? q0 : ss + q0;
+                if (16 * b + 1 < d) ss = ss + q1;
+                if (16 * b + 2 < d) ss = ss + q2;
+                if (16 * b + 3 < d) ss = ss + q3;
+            });
+        }
     }
     return ss;
 }
@@ -336,12 +411,15 @@ MCX_DEV double group_ss(const DevTarget &t, const double (&x)[GDims<D4>::NS], in
 #ifndef MCX_GROUP_GAUSS1
 #define MCX_GROUP_GAUSS1 99      // the Gaussian target from this D4 on: one wave per SIMD (its matrix-vector product spills at 256 registers)
 #endif
-template <int D4, int DRM, int TK>
-__global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 >= MCX_GROUP_GAUSS1)) ? 1 : MCX_GROUP_WAVES2) void group_step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ g_lamT, uint8_t *accb,
+#ifndef MCX_GROUP_WAVES4
+#define MCX_GROUP_WAVES4 2       // quads (GW = 4)
+#endif
+template <int GW, int D4, int DRM, int TK>
+__global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 >= MCX_GROUP_GAUSS1)) ? 1 : (GW == 4 ? MCX_GROUP_WAVES4 : MCX_GROUP_WAVES2)) void group_step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ g_lamT, uint8_t *accb,
                                                                                                    const int *__restrict__ gflag, int want)
 {
-    using G = GDims<D4>;
-    constexpr int NS = G::NS;
+    using G = GDims<D4, GW>;
+    constexpr int NS = G::NS, CPW = G::CPW;
     constexpr bool DR = DRM != 0;
     if (gflag && ((*gflag != 0) != (want != 0))) return;          // the other instantiation has this launch (wave-uniform: every wave reads the same word)
     // LDS: [iC squares of the four chains (DRM = 2)] [the chains' normal rows]: a padding lane's read past its chain's square lands in the
@@ -349,24 +427,24 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
     constexpr int SQ = (DRM == 2) ? D4 * D4 : 0;
     // ... and (two waves per SIMD: registers are short) the columns of R's LAST, partly filled slot -- npar - 16 (NS - 1) columns of
     // which only as many lanes hold anything: [row][column] per chain, read back with immediate offsets
-    constexpr int LS = (DRM != 1 && NS > 1 && (D4 % 16) != 0) ? NS - 1 : -1;      // the slot kept in LDS (-1: none)
-    constexpr int LC = (LS >= 0) ? D4 - 16 * LS : 0;                              // its columns
+    constexpr int LS = (DRM != 1 && NS > 1 && (D4 % GW) != 0) ? NS - 1 : -1;      // the slot kept in LDS (-1: none)
+    constexpr int LC = (LS >= 0) ? D4 - GW * LS : 0;                              // its columns
     constexpr int RL = LC * D4;                                                   // doubles per chain
     constexpr int NRR = (LS >= 0) ? G::off(LS) : G::NR;                           // doubles of R per lane that stay in registers
     constexpr int LQ = (TK == TGT_GAUSS || TK < 0) ? D4 * D4 : 0;                   // the Gaussian target's precision matrix, [j][i] with pitch D4
-    __shared__ double lds[4 * SQ + 4 * RL + 4 * G::ZS + LQ];
-    const int lane = threadIdx.x, l16 = lane & 15, row = lane >> 4, d = E.d;
-    const int chain = blockIdx.x * 4 + row, tile = chain >> 6, cl = chain & 63;
+    __shared__ double lds[CPW * SQ + CPW * RL + CPW * G::ZS + LQ];
+    const int lane = threadIdx.x, l16 = lane & (GW - 1), row = lane / GW, d = E.d;          // (l16: the lane's place in its group, row: the group = chain of the wave)
+    const int chain = blockIdx.x * CPW + row, tile = chain >> 6, cl = chain & 63;
     const size_t nslots = (size_t)E.ntiles * 64;
-    double *zrow = lds + 4 * SQ + 4 * RL + row * G::ZS;
+    double *zrow = lds + CPW * SQ + CPW * RL + row * G::ZS;
     const double *icl = lds + row * SQ;
-    const double *laml = lds + 4 * SQ + 4 * RL + 4 * G::ZS;
+    const double *laml = lds + CPW * SQ + CPW * RL + CPW * G::ZS;
     if constexpr (LQ > 0) {
         if (E.tgt.kind == TGT_GAUSS) {
-            for (int e = lane; e < D4 * D4; e += 64) { const int j = e / D4, i = e % D4; lds[4 * SQ + 4 * RL + 4 * G::ZS + e] = (i < d && j < d) ? g_lamT[(size_t)j * d + i] : 0.0; }
+            for (int e = lane; e < D4 * D4; e += 64) { const int j = e / D4, i = e % D4; lds[CPW * SQ + CPW * RL + CPW * G::ZS + e] = (i < d && j < d) ? g_lamT[(size_t)j * d + i] : 0.0; }
         }
     }
-    const double *rll = lds + 4 * SQ + row * RL + ((l16 < LC) ? l16 : (LC > 0 ? LC - 1 : 0));     // (lanes past the slot's columns read its last one: finite, discarded)
+    const double *rll = lds + CPW * SQ + row * RL + ((l16 < LC) ? l16 : (LC > 0 ? LC - 1 : 0));     // (lanes past the slot's columns read its last one: finite, discarded)
 
     // ---- factors into registers / LDS (once per launch)
     double Rr[NRR > 0 ? NRR : 1], R2r[DRM == 1 ? G::NR : 1], Sr[DRM == 1 ? NS * D4 : 1];
@@ -376,13 +454,13 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
         const double *iCt = DR ? E.iC + (size_t)tile * E.P * 64 : nullptr;
         sfor<0, NS>([&](auto S) __attribute__((always_inline)) {
             constexpr int s = decltype(S)::value;
-            const int c = 16 * s + l16;
+            const int c = GW * s + l16;
 #pragma unroll
             for (int i = 0; i < G::rows(s); ++i) {
                 const bool in = (c < d) && (i <= c);
                 const size_t e = in ? (size_t)pidx(i, c, d) : 0;
                 const double r = Rt[e * 64 + cl];
-                if constexpr (s == LS) { if (l16 < LC) lds[4 * SQ + row * RL + i * LC + l16] = in ? r : 0.0; }
+                if constexpr (s == LS) { if (l16 < LC) lds[CPW * SQ + row * RL + i * LC + l16] = in ? r : 0.0; }
                 else Rr[G::off(s) + i] = in ? r : 0.0;
                 if constexpr (DRM == 1) { const double r2 = R2t[e * 64 + cl]; R2r[G::off(s) + i] = in ? r2 : 0.0; }
             }
@@ -412,7 +490,7 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
     double th[NS];
     sfor<0, NS>([&](auto S) __attribute__((always_inline)) {
         constexpr int s = decltype(S)::value;
-        const int c = 16 * s + l16, cc = c < d ? c : 0;
+        const int c = GW * s + l16, cc = c < d ? c : 0;
         th[s] = (c < d) ? TIDX(E.theta, tile, d, cc, cl) : 0.0;
     });
     GChain g;
@@ -444,31 +522,31 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
         const bool act = it <= it1;
         // ---- newpar = MCMC_propose(oldpar, R) / newpar2 = MCMC_propose(oldpar, R2): the stage's first draws
         double z[NS], cand[NS];
-        group_normals<D4>(k0, k1, g, zrow, l16, row, d, act, z);
+        group_normals<D4, GW>(k0, k1, g, zrow, l16, row, d, act, z);
         const bool any2 = DR && __any(act && st2);
         sfor<0, NS>([&](auto S) __attribute__((always_inline)) {
             constexpr int s = decltype(S)::value;
             double p = 0.0;
-            sfor<0, (G::rows(s) + 15) / 16>([&](auto TT) __attribute__((always_inline)) {
+            sfor<0, (G::rows(s) + GW - 1) / GW>([&](auto TT) __attribute__((always_inline)) {
                 constexpr int tb = decltype(TT)::value;
-                constexpr int n = (G::rows(s) - 16 * tb) < 16 ? (G::rows(s) - 16 * tb) : 16;
+                constexpr int n = (G::rows(s) - GW * tb) < GW ? (G::rows(s) - GW * tb) : GW;
                 if constexpr (s == LS) {
                     double r[n];
 #pragma unroll
-                    for (int u = 0; u < n; ++u) r[u] = rll[(16 * tb + u) * LC];
-                    blk_fmac<n>(p, z[tb], r);
+                    for (int u = 0; u < n; ++u) r[u] = rll[(GW * tb + u) * LC];
+                    gblk_fmac<GW, n>(p, z[tb], r);
                     __builtin_amdgcn_sched_barrier(0);
-                } else blk_fmac<n>(p, z[tb], &Rr[(s == LS) ? 0 : G::off(s) + 16 * tb]);
+                } else gblk_fmac<GW, n>(p, z[tb], &Rr[(s == LS) ? 0 : G::off(s) + GW * tb]);
             });
             if constexpr (s == LS) p = (l16 < LC) ? p : 0.0;         // (the padding lanes multiplied somebody else's column)
             if constexpr (DRM == 2) p = st2 ? p * inv2 : p;          // exact (see above)
             if constexpr (DRM == 1) {
                 if (any2) {
                     double p2 = 0.0;
-                    sfor<0, (G::rows(s) + 15) / 16>([&](auto TT) __attribute__((always_inline)) {
+                    sfor<0, (G::rows(s) + GW - 1) / GW>([&](auto TT) __attribute__((always_inline)) {
                         constexpr int tb = decltype(TT)::value;
-                        constexpr int n = (G::rows(s) - 16 * tb) < 16 ? (G::rows(s) - 16 * tb) : 16;
-                        blk_fmac<n>(p2, z[tb], &R2r[(DRM == 1) ? G::off(s) + 16 * tb : 0]);
+                        constexpr int n = (G::rows(s) - GW * tb) < GW ? (G::rows(s) - GW * tb) : GW;
+                        gblk_fmac<GW, n>(p2, z[tb], &R2r[(DRM == 1) ? G::off(s) + GW * tb : 0]);
                     });
                     p = st2 ? p2 : p;
                 }
@@ -476,9 +554,9 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
             cand[s] = th[s] + p;                         // newpar = oldpar + R'z
         });
         // ---- bounds, prior, ss of the candidate
-        const bool inb = group_inbounds<D4>(E.tgt, cand, l16, row, d);
-        const double pri = group_prior<D4>(E.tgt, cand, l16, d);
-        const double ss = group_ss<D4, TK>(E.tgt, cand, l16, d, laml);
+        const bool inb = group_inbounds<D4, GW>(E.tgt, cand, l16, row, d);
+        const double pri = group_prior<D4, GW>(E.tgt, cand, l16, d);
+        const double ss = group_ss<D4, TK, GW>(E.tgt, cand, l16, d, laml);
         // ---- second stages: MCMC_DR_alpha13's two quadratic forms dx' iC dx, dx_a = newpar2 - newpar, dx_b = oldpar - newpar (MCMC_DRAM.F90:176-182)
         double qa = 0.0, qb = 0.0;
         if constexpr (DR) {
@@ -491,19 +569,19 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
                     sfor<0, NS>([&](auto TT) __attribute__((always_inline)) {
                         constexpr int tb = decltype(TT)::value;
                         constexpr int n = G::blk(tb);
-                        if constexpr (DRM == 1) blk_fmac2<n>(ya, yb, xa[tb], xb[tb], &Sr[(DRM == 1) ? s * D4 + 16 * tb : 0]);
+                        if constexpr (DRM == 1) gblk_fmac2<GW, n>(ya, yb, xa[tb], xb[tb], &Sr[(DRM == 1) ? s * D4 + GW * tb : 0]);
                         else {
                             double r[n];
 #pragma unroll
-                            for (int u = 0; u < n; ++u) r[u] = icl[(16 * tb + u) * D4 + 16 * s + l16];
-                            blk_fmac2<n>(ya, yb, xa[tb], xb[tb], r);
+                            for (int u = 0; u < n; ++u) r[u] = icl[(GW * tb + u) * D4 + GW * s + l16];
+                            gblk_fmac2<GW, n>(ya, yb, xa[tb], xb[tb], r);
                             __builtin_amdgcn_sched_barrier(0);          // (keeps the next block's LDS reads from piling up in registers)
                         }
                     });
-                    const bool in = 16 * s + l16 < d;
+                    const bool in = GW * s + l16 < d;
                     ta[s] = in ? ya * xa[s] : 0.0; tb_[s] = in ? yb * xb[s] : 0.0;
                 });
-                sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; blk_addchain<G::blk(s)>(qa, ta[s]); blk_addchain<G::blk(s)>(qb, tb_[s]); });
+                sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; gblk_addchain<GW, G::blk(s)>(qa, ta[s]); gblk_addchain<GW, G::blk(s)>(qb, tb_[s]); });
             }
         }
         // ---- MCMC_alpha (MCMC_DRAM.F90:100-118) or MCMC_DR_alpha13 (:162-186), then MCMC_reject (:140-155)
@@ -545,7 +623,7 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
             }
         }
         if (__any(take)) {
-            const double u = group_uniform(k0, k1, g, take, row);
+            const double u = group_uniform<GW>(k0, k1, g, take, row);
             if (er) {
                 if (take) {                                                  // sscrit = -2 log u + ss1 / sigma2 + pri1 (MCMC_DRAM.F90:124-135)
                     double sscrit = -2.0 * d_log(u) + ss1 / sigma2 + pri1;
@@ -567,7 +645,7 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
                     sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; th[s] = cand[s]; });
                     if (E.hist) {
                         double *h = E.hist + ((size_t)tile * E.wcap + (it % E.wcap)) * (size_t)E.hs * 64;
-                        sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = 16 * s + l16; if (c < d) h[(size_t)c * 64 + cl] = th[s]; });
+                        sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = GW * s + l16; if (c < d) h[(size_t)c * 64 + cl] = th[s]; });
                         if (l16 == 0) h[(size_t)d * 64 + cl] = ss1;
                     }
                 }
@@ -594,7 +672,7 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
         }
     }
 
-    sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = 16 * s + l16; if (c < d) TIDX(E.theta, tile, d, c, cl) = th[s]; });
+    sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = GW * s + l16; if (c < d) TIDX(E.theta, tile, d, c, cl) = th[s]; });
     if (l16 == 0) {
         TIDX(E.scal, tile, NSCAL, S_SIGMA2, cl) = sigma2;
         TIDX(E.rngn, tile, 1, 0, cl) = g.n;

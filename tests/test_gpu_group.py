@@ -32,13 +32,15 @@ def _problem(kind, d, seed, priors=False, bounds=False):
     return pkw
 
 
-def _run(ckw, pkw, nchains, group, monkeypatch, chains=(0, 1, 5, 69), **ekw):
+def _run(ckw, pkw, nchains, group, monkeypatch, chains=(0, 1, 5, 69), gw=16, **ekw):
     from mcmcf90_amd import engine_from_problem
     monkeypatch.setenv("MCMCX_GROUP", "1" if group else "0")
+    monkeypatch.setenv("MCMCX_GROUP_GW", str(gw))
     e = engine_from_problem(ckw, pkw, nchains=nchains, chain_id0=3, record_accept=1, **ekw)
     e.init(); e.run()
     k = e.last_kernel()
     assert k.startswith("group_step_kernel") == bool(group), k
+    assert ("quad" in k) == (bool(group) and gw == 4 and int(pkw["npar"]) <= 16), k
     chains = [c for c in chains if c < nchains]
     out = dict(theta=e.theta().copy(), masks=e.accept_masks().copy(), scal=e.scalars().copy(),
                rng=[e.rng(c) for c in chains], ctr=[e.counters(c) for c in chains], R=[e.R(c).copy() for c in chains])
@@ -131,6 +133,24 @@ def test_group_kernel_with_sigma2_update(oracle, monkeypatch, kind, d, drscale):
         np.testing.assert_array_equal(_bits(a[4][0][2]), _bits(o.s2chain))
         np.testing.assert_array_equal(_bits(a[0][0]), _bits(o.theta))
         assert a[3][0][0] == o.rng_n
+
+
+QUAD_CASES = [c for c in CASES if c[1] <= 16] + [("gauss", 10, 0.0, False, False), ("gauss", 1, 0.0, False, False), ("gauss", 15, 4.0, True, True), ("banana", 16, 3.0, False, False)]
+
+
+@pytest.mark.parametrize("kind,d,drscale,priors,bounds", QUAD_CASES, ids=["%s%d%s%s%s" % (k, d, "_dr" if s else "", "_pri" if p else "", "_bnd" if b else "") for k, d, s, p, b in QUAD_CASES])
+def test_quad_group_kernel_equals_lane_kernels_and_oracle(oracle, monkeypatch, kind, d, drscale, priors, bounds):
+    """The same kernel with FOUR lanes per chain (sixteen chains per wave: small npar with the chip full): npar <= 16, every target,
+    both delayed-rejection instantiations, with the sigma2 update and with early rejection."""
+    for extra in (dict(), dict(updatesigma=1, N0=1.0, S02=0.3), dict(method="er") if not drscale else dict(adaptint=30)):
+        ckw = dict(dict(nsimu=130, adaptint=50, updatesigma=0, drscale=drscale), **extra)
+        pkw = _problem(kind, d, 540 + d, priors, bounds)
+        g, chains = _run(ckw, pkw, 70, True, monkeypatch, gw=4)
+        l, _ = _run(ckw, pkw, 70, False, monkeypatch)
+        _same(g, l)
+        o = oracle.run_chain(oracle.make_cfg(**ckw), oracle.Problem(**pkw), chain_id=3)
+        np.testing.assert_array_equal(_bits(g["theta"][0]), _bits(o.theta))
+        assert g["rng"][0][0] == o.rng_n and g["ctr"][0]["stayed"] == o.stayed
 
 
 @pytest.mark.parametrize("kind,d,priors,bounds", [("gauss", 9, True, True), ("banana", 20, False, False), ("expdata", 2, True, True)])
@@ -243,3 +263,28 @@ def test_group_kernel_config3_fixture(oracle, monkeypatch):
     assert np.array_equal(ch[:, -1].astype(np.int64), np.asarray(z["runlen"], dtype=np.int64))
     assert e.rng(0)[0] == int(z["rng_n"])
     e.close()
+
+
+def test_engine_picks_quads_for_config2_and_groups_for_config3(monkeypatch):
+    """The engine's own choice at BASELINE sizes (no MCMCX_GROUP / MCMCX_GROUP_GW): config 2 (Gaussian d = 10, AM, 65536 chains) on the
+    quad-group kernel, config 3 (banana d = 20, DRAM, here 32768 of its 262144 chains) on the sixteen-lane one -- and every chain's state,
+    stream position and accept ballots equal to the lane-per-chain kernels' after 230 iterations with two adaptations."""
+    from mcmcf90_amd import engine_from_problem
+    from mcmcf90_amd.workloads import problem
+    for wl, n, want in (("c2", 65536, "group_step_kernel<quad>"), ("c3", 32768, "group_step_kernel<DR2>")):
+        ckw, pkw, _ = problem(wl, 231, adaptint=100)
+        res = []
+        for lane in (False, True):
+            monkeypatch.delenv("MCMCX_GROUP_GW", raising=False)
+            if lane:
+                monkeypatch.setenv("MCMCX_GROUP", "0")
+            else:
+                monkeypatch.delenv("MCMCX_GROUP", raising=False)
+            e = engine_from_problem(ckw, pkw, nchains=n, record_accept=1)
+            e.init(); e.run()
+            if not lane:
+                assert e.last_kernel() == want, e.last_kernel()
+            res.append((e.theta().copy(), e.accept_masks().copy(), e.scalars().copy(), [e.rng(c) for c in (0, n // 2 + 3, n - 1)], e.totals()))
+            e.close()
+        a, b = res
+        assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1]) and np.array_equal(_bits(a[2]), _bits(b[2])) and a[3] == b[3] and a[4] == b[4], wl
