@@ -553,6 +553,9 @@ OTHER_CONFIGS = [
     ("c5_replicas_scam_fast", dict(wl="c5", steps=2, warmup=1, replicas=True, scam_fast=True)),
     # MCMC_run_scam.F90:106-115 as written: per-chain rotations, two dgemv per componentwise proposal (no scam_fast); one iteration per step
     ("c5_replicas", dict(wl="c5", steps=2, warmup=1, replicas=True, its_per_step=1)),
+    # the few-chains regime (one tile of 64 chains: an iteration is latency, not throughput): us per iteration incl. the adaptation ticks
+    ("c2_64_chains", dict(wl="c2", steps=5, warmup=1, chains_per_gpu=64)),
+    ("c3_64_chains", dict(wl="c3", steps=5, warmup=1, chains_per_gpu=64)),
 ]
 # N > 1: the pooled form of the headline configuration on the same communicator -- its RAM tick (the rank-one statistics of all chains
 # of all ranks gathered and folded into the one shared factor every adaptint iterations) is the collective ON the critical path
@@ -669,6 +672,7 @@ def main():
                                    "alg_per_proposal": rf.get("alg_bytes_per_proposal", rf.get("alg_flop_per_proposal")),
                                    "workload": r["config"]["workload"], "proposals_per_iteration": r["config"]["proposals_per_iteration"],
                                    "chains_per_gpu": r["config"]["chains_per_gpu"], "n_gpus": world,
+                                   "us_per_iteration": r["ms_per_step"] * 1e3 / r["config"]["its_per_step"],
                                    "wall_s_incl_init": time.perf_counter() - t0}
                     if world > 1:
                         others[key]["rccl_ranks"] = line["rccl_ranks"]

@@ -1,6 +1,8 @@
 """One-off extended fuzz (GPU box): the generators of tests/test_gpu_fuzz.py over seeds outside the test suite's range --
 the base option space, method='ram' with condmax > 0, updatesigma with gamma shape < 1, the device-resident response
-columns and runs cut into pieces -- device vs oracle, bit for bit.  python tools/bigfuzz.py [first_seed=300] [last_seed=2300]   (round 1: 3167 configurations, 0 failures)"""
+columns and runs cut into pieces -- device vs oracle, bit for bit.  python tools/bigfuzz.py [first_seed=300] [last_seed=2300]   (round 1: 3167 configurations, 0 failures).
+The engine picks its kernels (round 4: the lane-group kernels wherever they cover a configuration); MCMCX_GROUP=1 MCMCX_GROUP_GW=4 in the
+environment forces the quad form where it applies, MCMCX_GROUP=0 the lane-per-chain kernels."""
 import importlib.util, sys, os, time, traceback
 import numpy as np
 sys.path.insert(0, os.getcwd())
@@ -32,7 +34,7 @@ for seed in range(A, B):
     if seed % 5 == 0:
         for fn in (g.test_random_configuration_response_columns_device_target, g.test_random_configuration_in_pieces):
             try:
-                fn(po, 100000 + seed); n += 1
+                fn(po, 100000 + seed, "auto") if fn is g.test_random_configuration_in_pieces else fn(po, 100000 + seed); n += 1
             except Exception as e:
                 bad.append((fn.__name__, seed, repr(e)[:200]))
     if seed % 50 == 0:
