@@ -120,6 +120,13 @@ def cases():
     # reproduce the reference's 250 iterations x 200 componentwise proposals decision by decision
     # (tests/test_oracle_golden.py, tests/test_gpu_parity.py), which pins MCMC_run_scam.F90:38-138 and the covariance
     # MCMC_adapt hands to scam_svd (MCMC_adapt.F90:138-157, matutils.F90:583-653) independently of any SVD routine.
+    # --- NaN propagation (the corner round 3 left unpinned): a response value that is not a number makes every ss
+    # NaN.  The reference (flang -O2) then never moves and draws no uniform besides the normals: MCMC_alpha's comparisons are false and
+    # exp(NaN) = NaN, MCMC_reject(NaN) takes neither branch (MCMC_DRAM.F90:147-152), and in MCMC_DR_alpha13 min(1, NaN) = NaN (:178,185) --
+    # had flang's min returned 1, every second stage would be accepted.  Pins the compare-select form of min1() / MCMC_alpha in the oracle.
+    ynan = np.array(YDATA, dtype=float); ynan[4] = np.nan
+    c["e8_nan_target_dr"] = (dict(nsimu=300, adaptint=100, drscale=2.0, updatesigma=0),
+                             dict(kind="expdata", npar=2, par0=[10, 0.1], cmat0=[[0.2, 0], [0, 0.001]], sigma2=0.5, nobs=11, xdata=XDATA, ydata=ynan, lo=[0, 0]), 61)
     from mcmcf90_amd.workloads import problem
     ckw, pkw, _ = problem("c5", 250, adaptint=100)
     c["c5_illcond200_scam"] = (ckw, pkw, 51)

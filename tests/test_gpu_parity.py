@@ -53,7 +53,7 @@ def test_engine_matches_oracle_and_reference(oracle, name, kernels):
     assert np.max(np.abs(ch[-z["rows_tail"].shape[0]:, :-1] - z["rows_tail"]) / scale) < 1e-7
     # posterior moments the reference wrote (mcmccovf.dat, mcmcmean.dat): north_star asks for 1e-6 relative
     cmf, meanf, _ = e.chaincov(off)
-    assert np.max(np.abs(np.triu(cmf) - np.triu(z["chaincmat"]))) / np.max(np.abs(z["chaincmat"])) < 1e-6
+    assert np.max(np.abs(np.triu(cmf) - np.triu(z["chaincmat"]))) / max(np.max(np.abs(z["chaincmat"])), 1e-300) < 1e-6    # (fixture e8: covariance 0)
     assert np.max(np.abs(meanf - z["chainmean"])) / max(np.max(np.abs(z["chainmean"])), 1e-300) < 1e-6 \
         or np.max(np.abs(meanf - z["chainmean"])) < 1e-9 * np.sqrt(np.max(np.abs(z["chaincmat"])))
     # --- against the oracle, several chains incl. the ragged tile: bit for bit
@@ -92,7 +92,7 @@ def test_engine_matches_oracle_and_reference(oracle, name, kernels):
     th = e.theta(); sc = e.scalars()
     o = oracle.run_chain(cfg, prob, chain_id=(cid - off) + 129)
     np.testing.assert_array_equal(_bits(th[129]), _bits(o.theta))
-    assert sc[129, 0] == o.ss1 and sc[129, 2] == o.sigma2
+    assert _bits(sc[129, 0]) == _bits(np.float64(o.ss1)) and sc[129, 2] == o.sigma2       # (bits: fixture e8's ss is NaN)
     e.close()
 
 
@@ -143,7 +143,7 @@ def test_c5_fixture_all_iterations_with_the_logged_factors(oracle):
     assert np.max(np.abs(ch[-k:, :-1] - z["rows_tail"]) / scale) < 1e-7
     np.testing.assert_allclose(ss[-k:, 0], z["ss_tail"], rtol=1e-7, atol=1e-9)
     cmf, meanf, _ = e.chaincov(1)
-    assert np.max(np.abs(np.triu(cmf) - np.triu(z["chaincmat"]))) / np.max(np.abs(z["chaincmat"])) < 1e-6
+    assert np.max(np.abs(np.triu(cmf) - np.triu(z["chaincmat"]))) / max(np.max(np.abs(z["chaincmat"])), 1e-300) < 1e-6    # (fixture e8: covariance 0)
     for c in picks:
         live[c].run(cfg.nsimu)
         o = live[c].ch.contents
