@@ -531,6 +531,7 @@ static void launch_scam(mcmcx_engine *h, int it0, int it1)
     }
 }
 // LDS of svd_blocked_kernel for block width b: four blocks of b columns (odd stride) + the rotation slots
+static int svd_ls_host(int d) { return ((d + 1) & ~1) + (((d + 1) & 2) ? 0 : 2); }
 static size_t svd_lds(int d, int b) { const int LS = ((d + 1) & ~1) + (((d + 1) & 2) ? 0 : 2); return ((size_t)2 * b * LS + 64) * sizeof(double) + 32 * sizeof(int); }   // two blocks of b columns + the rotation slots
 // block width of the blocked SVD: two workgroups per CU hide each other's dot-product latency
 static int svd_block_width(int d)
@@ -590,12 +591,27 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
     const size_t DD = (size_t)h->d * h->d;
     const dim3 tg((unsigned)((DD + 63) / 64), (unsigned)h->ntiles), tg1((unsigned)((h->d + 63) / 64), (unsigned)h->ntiles);
     const size_t lsv = svd_lds(h->d, h->svd_b);
+    const bool svd_reg = !(getenv("MCMCX_SVD_REG") && atoi(getenv("MCMCX_SVD_REG")) == 0);         // (0: A/B, tests -- svd_sweep_kernel)
     hipLaunchKernelGGL(adapt_post_kernel<true>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 1, h->d_need, batch_done);
     hipLaunchKernelGGL(tile2chain_kernel, tg, dim3(256), 0, h->stream, h->E.Gw, h->d_Gc, DD, DD, h->d_need);
     hipLaunchKernelGGL(svd_init_kernel, dim3(h->nlanes), dim3(256), 0, h->stream, h->d_Vc, h->d_state, h->d_need, h->nlanes, h->d);
     for (int sweep = 0; sweep < 60; ++sweep) {
         (void)hipMemsetAsync(h->d_anyrot, 0, sizeof(int), h->stream);
+        if (svd_reg) {                                   // the I block's columns in registers: one block of LDS (round 4)
+            const size_t lsr = ((size_t)h->svd_b * svd_ls_host(h->d) + 64) * sizeof(double);
+            if (h->d <= 64) hipLaunchKernelGGL(svd_sweep_reg_kernel<8>, dim3(h->nlanes), dim3(256), lsr, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d, h->svd_b);
+            else if (h->d <= 128) hipLaunchKernelGGL(svd_sweep_reg_kernel<16>, dim3(h->nlanes), dim3(256), lsr, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d, h->svd_b);
+            else if (h->d <= 208) hipLaunchKernelGGL(svd_sweep_reg_kernel<26>, dim3(h->nlanes), dim3(256), lsr, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d, h->svd_b);
+            else hipLaunchKernelGGL(svd_sweep_reg_kernel<32>, dim3(h->nlanes), dim3(256), lsr, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d, h->svd_b);
+        } else
         hipLaunchKernelGGL(svd_sweep_kernel, dim3(h->nlanes), dim3(256), lsv, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d, h->svd_b);
+        if (svd_reg) {
+            const size_t lsr = ((size_t)h->svd_b * svd_ls_host(h->d) + 64) * sizeof(double);
+            if (h->d <= 64) hipLaunchKernelGGL(svd_applyv_reg_kernel<4>, dim3(h->nlanes), dim3(256), lsr, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d, h->svd_b);
+            else if (h->d <= 128) hipLaunchKernelGGL(svd_applyv_reg_kernel<8>, dim3(h->nlanes), dim3(256), lsr, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d, h->svd_b);
+            else if (h->d <= 208) hipLaunchKernelGGL(svd_applyv_reg_kernel<13>, dim3(h->nlanes), dim3(256), lsr, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d, h->svd_b);
+            else hipLaunchKernelGGL(svd_applyv_reg_kernel<16>, dim3(h->nlanes), dim3(256), lsr, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d, h->svd_b);
+        } else
         hipLaunchKernelGGL(svd_applyv_kernel, dim3(h->nlanes), dim3(256), lsv, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d, h->svd_b);
         int any = 0;
         if (hipMemcpyAsync(&any, h->d_anyrot, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) break;   // (reported by the caller's hipGetLastError)

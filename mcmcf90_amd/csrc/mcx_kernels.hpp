@@ -3907,6 +3907,106 @@ __global__ __launch_bounds__(256) void svd_sweep_kernel(double *Gc, mcx_d2 *rot,
 // Replays one sweep's rotations on V, same block pairs, same steps.  Thread (rl, rk0) owns rows 2 rk0 + 16 i (+1) of the
 // columns it meets, and the 32 pair-lanes of one row group sit in ONE wave: within a wave the LDS accesses of consecutive
 // steps are ordered, so no barrier is needed between steps.  Chains whose sweep rotated nothing (state 2) are skipped.
+// The same sweep with the I block's columns in REGISTERS (round 4).  svd_sweep_kernel moves 9.6 kB through LDS per pair at npar = 200 --
+// phase A reads both columns for the three dot products, phase B reads and writes both for the rotation -- and that traffic, not the
+// arithmetic, is what a sweep takes (2 workgroups x 230 kB per step against 128 B per clock).  Inside a block pair (I,J) the pair-lane l
+// keeps the SAME column I0 + l for every step -- only its partner changes -- so the octet that owns pair-lane l holds that column in
+// registers (lane j of the octet: rows j, j + 8, ..., the routine's eight partial chains) from the end of the diagonal block to the end
+// of the J loop, and a step is ONE phase: read the partner column from LDS, the three chains, the butterfly, the rotation (all eight lanes
+// derive it: same operands), apply it, write the partner back.  3.2 kB of LDS traffic per pair, one barrier per step, one block of LDS
+// per workgroup instead of two.  In the diagonal block a column is first a partner (in LDS) and then, from the step at which its own
+// pairs start, the octet's own (loaded once).  Same pairs in the same order, same chains, same log: bit for bit svd_sweep_kernel's result.
+template <int RL>
+__global__ __launch_bounds__(256) void svd_sweep_reg_kernel(double *Gc, mcx_d2 *rot, uint8_t *state, int *any_rotated, int nlanes, int d, int b)
+{
+    extern __shared__ double S[];
+    __shared__ int s_rot;
+    const int chain = blockIdx.x, tid = threadIdx.x;
+    if (chain >= nlanes || state[chain] != 1) return;
+    double *G = Gc + (size_t)chain * d * d;
+    mcx_d2 *log = rot + (size_t)chain * ((size_t)d * (d - 1) / 2);
+    const int LS = svd_ls(d);
+    double *GY = S;                                            // the partner block: b columns
+    const int nb = (d + b - 1) / b;
+    const int ol = tid >> 3, oj = tid & 7;                     // pair-lane of this thread's octet, partial chain / row residue
+    if (tid == 0) s_rot = 0;
+    double xr[RL];
+    // one step of pair (l = ol, m): y from LDS column m of GY, x in registers
+    auto pair_step = [&](int m, size_t logidx) {
+        double *ycol = GY + (size_t)m * LS;
+        double yr[RL];
+#pragma unroll
+        for (int u = 0; u < RL; ++u) { const int k = oj + 8 * u; yr[u] = (k < d) ? ycol[k] : 0.0; }
+        double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+        for (int u = 0; u < RL; ++u) {
+            if (oj + 8 * u < d) { alpha = dfma(xr[u], xr[u], alpha); beta = dfma(yr[u], yr[u], beta); gamma = dfma(xr[u], yr[u], gamma); }
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            alpha = alpha + __shfl_xor(alpha, o, 64); beta = beta + __shfl_xor(beta, o, 64); gamma = gamma + __shfl_xor(gamma, o, 64);
+        }
+        mcx_d2 cs; cs.x = 1.0; cs.y = 0.0;                     // the identity: what svd_applyv_kernel skips
+        if ((gamma != 0.0) && !(fabs(gamma) <= 1e-15 * sqrt(alpha * beta))) {
+            const double zeta = (beta - alpha) / (2.0 * gamma);
+            const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            const double c = 1.0 / sqrt(1.0 + tt * tt);
+            cs.x = c; cs.y = c * tt;
+            const double sn = cs.y;
+#pragma unroll
+            for (int u = 0; u < RL; ++u) {
+                const int k = oj + 8 * u;
+                if (k < d) { const double a0 = xr[u], b0 = yr[u]; xr[u] = c * a0 - sn * b0; ycol[k] = sn * a0 + c * b0; }
+            }
+            if (oj == 0) s_rot = 1;
+        }
+        if (oj == 0) log[logidx] = cs;
+    };
+    __syncthreads();
+    for (int I = 0; I < nb; ++I) {
+        const int I0 = I * b, wI = (d - I0) < b ? (d - I0) : b;
+        for (int e = tid; e < wI * d; e += 256) { const int c = e / d, k = e - c * d; GY[c * LS + k] = G[(size_t)(I0 + c) * d + k]; }
+        __syncthreads();
+        // ---- the diagonal block: pairs l < m at step l + m - 1; column l becomes its octet's own at its first pair (l, l + 1), step 2 l
+        for (int t = 0; t < 2 * wI - 3; ++t) {
+            const int l = ol, m = t + 1 - l;
+            if (l < wI && m > l && m < wI) {
+                if (m == l + 1) {
+#pragma unroll
+                    for (int u = 0; u < RL; ++u) { const int k = oj + 8 * u; xr[u] = (k < d) ? GY[(size_t)l * LS + k] : 0.0; }
+                }
+                pair_step(m, svd_pair_index(I0 + l, I0 + m, d));
+            }
+            __syncthreads();
+        }
+        // the block's last column never had a pair of its own (and with one column there were no steps at all): into registers now
+        if (ol == wI - 1) {
+#pragma unroll
+            for (int u = 0; u < RL; ++u) { const int k = oj + 8 * u; xr[u] = (k < d) ? GY[(size_t)ol * LS + k] : 0.0; }
+        }
+        __syncthreads();
+        // ---- the blocks to the right: pair (l, m) at step l + m
+        for (int J = I + 1; J < nb; ++J) {
+            const int J0 = J * b, wJ = (d - J0) < b ? (d - J0) : b;
+            for (int e = tid; e < wJ * d; e += 256) { const int c = e / d, k = e - c * d; GY[c * LS + k] = G[(size_t)(J0 + c) * d + k]; }
+            __syncthreads();
+            for (int t = 0; t < wI + wJ - 1; ++t) {
+                const int l = ol, m = t - l;
+                if (l < wI && m >= 0 && m < wJ) pair_step(m, svd_pair_index(I0 + l, J0 + m, d));
+                __syncthreads();
+            }
+            for (int e = tid; e < wJ * d; e += 256) { const int c = e / d, k = e - c * d; G[(size_t)(J0 + c) * d + k] = GY[c * LS + k]; }
+            __syncthreads();
+        }
+        if (ol < wI) {
+#pragma unroll
+            for (int u = 0; u < RL; ++u) { const int k = oj + 8 * u; if (k < d) G[(size_t)(I0 + ol) * d + k] = xr[u]; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { if (s_rot) *any_rotated = 1; else state[chain] = 2; }
+}
+
 __global__ __launch_bounds__(256) void svd_applyv_kernel(double *Vc, const mcx_d2 *rot, const uint8_t *state, int nlanes, int d, int b)
 {
     extern __shared__ double S[];
@@ -3974,6 +4074,97 @@ __global__ __launch_bounds__(256) void svd_applyv_kernel(double *Vc, const mcx_d
 
 // singular values = column norms of G (the routine's eight partial chains over the rows), sorted descending (first maximum wins), V's columns
 // with them; the sorted vectors are left in G's place
+// svd_applyv_kernel with the I block's columns of V in registers (round 4, like svd_sweep_reg_kernel): thread (rl, rk0) keeps its rows
+// (2 rk0, 2 rk0 + 1) + 16 u of column I0 + rl for the whole row of block pairs; only the partner column goes through LDS.  Same rotations
+// in the same order on the same elements.
+template <int RP>         // row PAIRS per thread: 16 RP >= npar
+__global__ __launch_bounds__(256) void svd_applyv_reg_kernel(double *Vc, const mcx_d2 *rot, const uint8_t *state, int nlanes, int d, int b)
+{
+    extern __shared__ double S[];
+    const int chain = blockIdx.x, tid = threadIdx.x;
+    if (chain >= nlanes || state[chain] != 1) return;
+    double *V = Vc + (size_t)chain * d * d;
+    const mcx_d2 *log = rot + (size_t)chain * ((size_t)d * (d - 1) / 2);
+    const int LS = svd_ls(d);
+    double *VY = S;                                            // the partner block: b columns
+    const int nb = (d + b - 1) / b;
+    const int rl = tid & 31, rk0 = tid >> 5;
+    mcx_d2 vr[RP];                                             // rows k = 2 rk0 + 16 u, k + 1 (the odd last row: .x only, by rk0 = 0's extra slot below)
+    double vlast = 0.0;                                        // row d - 1 when d is odd (thread rk0 = 0)
+    auto load_own = [&](const double *col) {
+#pragma unroll
+        for (int u = 0; u < RP; ++u) { const int k = 2 * rk0 + 16 * u; if (k + 1 < d) vr[u] = *(const mcx_d2 *)(col + k); }
+        if ((d & 1) && rk0 == 0) vlast = col[d - 1];
+    };
+    auto pair_step = [&](int m, size_t logidx) {
+        const mcx_d2 cs = log[logidx];
+        if (cs.x == 1.0 && cs.y == 0.0) return;
+        const double c = cs.x, sn = cs.y;
+        double *vq = VY + (size_t)m * LS;
+        mcx_d2 vb[RP];
+#pragma unroll
+        for (int u = 0; u < RP; ++u) { const int k = 2 * rk0 + 16 * u; if (k + 1 < d) vb[u] = *(mcx_d2 *)(vq + k); }
+#pragma unroll
+        for (int u = 0; u < RP; ++u) {
+            const int k = 2 * rk0 + 16 * u;
+            if (k + 1 < d) {
+                mcx_d2 nva, nvb;
+                nva.x = c * vr[u].x - sn * vb[u].x; nva.y = c * vr[u].y - sn * vb[u].y; nvb.x = sn * vr[u].x + c * vb[u].x; nvb.y = sn * vr[u].y + c * vb[u].y;
+                vr[u] = nva; *(mcx_d2 *)(vq + k) = nvb;
+            }
+        }
+        if ((d & 1) && rk0 == 0) {
+            const int k = d - 1;
+            const double va0 = vlast, vb0 = vq[k];
+            vlast = c * va0 - sn * vb0; vq[k] = sn * va0 + c * vb0;
+        }
+    };
+    for (int I = 0; I < nb; ++I) {
+        const int I0 = I * b, wI = (d - I0) < b ? (d - I0) : b;
+        for (int e = tid; e < wI * d; e += 256) { const int c = e / d, k = e - c * d; VY[c * LS + k] = V[(size_t)(I0 + c) * d + k]; }
+        __syncthreads();
+        // the diagonal block: column rl becomes the thread's own at its first pair (rl, rl + 1), step 2 rl (before that it is a partner, in LDS)
+        if (rl < wI)
+            for (int t = 0; t < 2 * wI - 3; ++t) {
+                // step t reads what other lanes of THIS wave wrote in step t - 1: keep the compiler from moving LDS accesses across the
+                // step boundary (the hardware runs a wave's LDS operations in order; the rows of a thread group never leave its wave)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int m = t + 1 - rl;
+                if (!(m > rl && m < wI)) continue;
+                if (m == rl + 1) load_own(VY + (size_t)rl * LS);
+                pair_step(m, svd_pair_index(I0 + rl, I0 + m, d));
+            }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (rl == wI - 1) load_own(VY + (size_t)rl * LS);      // the block's last column never had a pair of its own
+        __syncthreads();
+        for (int J = I + 1; J < nb; ++J) {
+            const int J0 = J * b, wJ = (d - J0) < b ? (d - J0) : b;
+            for (int e = tid; e < wJ * d; e += 256) { const int c = e / d, k = e - c * d; VY[c * LS + k] = V[(size_t)(J0 + c) * d + k]; }
+            __syncthreads();
+            if (rl < wI)
+                for (int t = 0; t < wI + wJ - 1; ++t) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const int m = t - rl;
+                    if (!(m >= 0 && m < wJ)) continue;
+                    pair_step(m, svd_pair_index(I0 + rl, J0 + m, d));
+                }
+            __syncthreads();
+            for (int e = tid; e < wJ * d; e += 256) { const int c = e / d, k = e - c * d; V[(size_t)(J0 + c) * d + k] = VY[c * LS + k]; }
+            __syncthreads();
+        }
+        if (rl < wI) {
+            double *col = V + (size_t)(I0 + rl) * d;
+#pragma unroll
+            for (int u = 0; u < RP; ++u) { const int k = 2 * rk0 + 16 * u; if (k + 1 < d) *(mcx_d2 *)(col + k) = vr[u]; }
+            if ((d & 1) && rk0 == 0) col[d - 1] = vlast;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void svd_finish_kernel(double *Gc, const double *Vc, double *svc, const uint8_t *state, int nlanes, int d)
 {
     __shared__ int s_perm[256];

@@ -372,19 +372,25 @@ def test_blocked_svd_equals_lane_svd_and_oracle(oracle, d, method, extra, monkey
     res = []
     # (the lane-per-chain form is the production path below npar = 48 only; at 200 it is compared with the oracle in
     #  test_gpu_fullsize.py::test_c5_illcond200_scam_replicas_two_ticks, and takes 10-25 s per adaptation up here)
-    for lane_path in ((0, 1) if d <= 128 else (0,)):
-        if lane_path:
+    # paths: the sweep / V replay with the I block's columns in registers (round 4, the default), with both blocks in LDS
+    # (MCMCX_SVD_REG=0), one lane per chain (MCMCX_SVD_LANE=1)
+    for path in (("reg", "lds", "lane") if d <= 128 else ("reg", "lds")):
+        monkeypatch.delenv("MCMCX_SVD_LANE", raising=False); monkeypatch.delenv("MCMCX_SVD_REG", raising=False)
+        if path == "lane":
             monkeypatch.setenv("MCMCX_SVD_LANE", "1")
+        if path == "lds":
+            monkeypatch.setenv("MCMCX_SVD_REG", "0")
         e = engine_from_problem(ckw, pkw, nchains=70, chain_id0=5, record_accept=1)
         e.init(); e.run()
         res.append((e.theta(), e.accept_masks(), [e.R(c) for c in (0, 63, 64, 69)],
                     [e.qcovstd(c) for c in (0, 69)], [e.chaincov(c)[0] for c in (0, 69)], [e.rng(c)[0] for c in (0, 69)]))
         e.close()
-    a, b = res[0], res[-1]
-    assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1])
-    for x, y in zip(a[2] + a[3] + a[4], b[2] + b[3] + b[4]):
-        np.testing.assert_array_equal(_bits(x), _bits(y))
-    assert a[5] == b[5]
+    a = res[0]
+    for b in res[1:]:
+        assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1])
+        for x, y in zip(a[2] + a[3] + a[4], b[2] + b[3] + b[4]):
+            np.testing.assert_array_equal(_bits(x), _bits(y))
+        assert a[5] == b[5]
     cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
     for i, c in enumerate((0, 69)):
         o = oracle.run_chain(cfg, prob, chain_id=5 + c)
