@@ -23,6 +23,7 @@
 //   init_kernel, bcast_kernel, gather_lane_kernel, moments_kernel, moments_tree_kernel, debug kernels
 #pragma once
 #include "mcx_device.hpp"
+#include <type_traits>
 
 namespace mcx {
 
@@ -4007,6 +4008,122 @@ __global__ __launch_bounds__(256) void svd_sweep_reg_kernel(double *Gc, mcx_d2 *
     if (tid == 0) { if (s_rot) *any_rotated = 1; else state[chain] = 2; }
 }
 
+// ... and with every later column STREAMED past the I block (round 4).  In svd_sweep_reg_kernel a block pair (I,J) takes wI + wJ - 1
+// steps for wI wJ pairs: on average half of the pair-lanes have a partner.  The partners of column I0 + l are simply the columns
+// I0 + l + 1 .. npar - 1 in order: pair-lane l meets stream column j (= column I0 + 1 + j) at step l + j, j >= l -- one wavefront over the
+// whole rest of the matrix (the block's own columns are the stream's first wI - 1: pair-lane l takes column I0 + l out of the ring at step
+// 2 l - 1, after its last pair as a partner), every pair-lane busy from its first partner to its last.  Two pairs that share a column keep
+// their order, so do the bits.  A column is needed for wI consecutive steps: it enters a ring of wI + 2 LDS columns one step ahead and
+// leaves it for global memory the step after its last pair.  Each wave holds six octets and sixteen loader lanes: the loaders' global
+// loads (issued one step before they write the ring) and stores run under the wave's own pair arithmetic, and all four SIMDs compute.
+#ifndef MCX_SVDS_WAVES
+#define MCX_SVDS_WAVES 3                                     // waves per SIMD asked for up to npar 208 (RL 26)
+#endif
+#define MCX_SVDS_EPT 4                                       // elements of a column per loader lane: 64 loaders, npar <= 256
+template <int RL>
+__global__ __launch_bounds__(256, (RL <= 26 ? MCX_SVDS_WAVES : 2)) void svd_sweep_stream_kernel(double *Gc, mcx_d2 *rot, uint8_t *state, int *any_rotated, int nlanes, int d, int b)
+{
+    extern __shared__ double S[];
+    __shared__ int s_rot;
+    const int chain = blockIdx.x, tid = threadIdx.x;
+    if (chain >= nlanes || state[chain] != 1) return;
+    double *G = Gc + (size_t)chain * d * d;
+    mcx_d2 *log = rot + (size_t)chain * ((size_t)d * (d - 1) / 2);
+    constexpr int LS = 8 * RL + 2;                             // ring column stride: every octet row 8 u + oj exists (rows >= npar hold zeros: they add
+                                                               // nothing to the three sums and rotate to zero -- no bounds tests in the loop); = 2 mod 4
+    double *GY = S;                                            // the ring: RB columns
+    const int RB = b + 2;
+    const int nb = (d + b - 1) / b;
+    const int wv = tid >> 6, ln = tid & 63;
+    const bool loader = ln >= 48;
+    const int ol = loader ? 64 : wv * 6 + (ln >> 3), oj = ln & 7;   // pair-lane of this thread's octet, partial chain / row residue
+    const int li = wv * 16 + (ln - 48);                        // loader lanes: 0 .. 63
+    if (tid == 0) s_rot = 0;
+    double xr[RL];
+    double stg[MCX_SVDS_EPT];                                  // loaders: the column on its way from global memory to the ring
+    auto pair_step = [&](double *ycol, size_t logidx) __attribute__((always_inline)) {
+        double yr[RL];
+#pragma unroll
+        for (int u = 0; u < RL; ++u) yr[u] = ycol[oj + 8 * u];
+        double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+        for (int u = 0; u < RL; ++u) { alpha = dfma(xr[u], xr[u], alpha); beta = dfma(yr[u], yr[u], beta); gamma = dfma(xr[u], yr[u], gamma); }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            alpha = alpha + __shfl_xor(alpha, o, 64); beta = beta + __shfl_xor(beta, o, 64); gamma = gamma + __shfl_xor(gamma, o, 64);
+        }
+        mcx_d2 cs; cs.x = 1.0; cs.y = 0.0;
+        if ((gamma != 0.0) && !(fabs(gamma) <= 1e-15 * sqrt(alpha * beta))) {
+            const double zeta = (beta - alpha) / (2.0 * gamma);
+            const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            const double c = 1.0 / sqrt(1.0 + tt * tt);
+            cs.x = c; cs.y = c * tt;
+            const double sn = cs.y;
+#pragma unroll
+            for (int u = 0; u < RL; ++u) {
+                const double a0 = xr[u], b0 = yr[u];
+                xr[u] = c * a0 - sn * b0; ycol[oj + 8 * u] = sn * a0 + c * b0;
+            }
+            if (oj == 0) s_rot = 1;
+        }
+        if (oj == 0) log[logidx] = cs;
+    };
+    for (int e = tid; e < RB * LS; e += 256) GY[e] = 0.0;
+    __syncthreads();
+    for (int I = 0; I < nb; ++I) {
+        const int I0 = I * b, wI = (d - I0) < b ? (d - I0) : b;
+        const int nJ = d - I0 - 1;                             // stream columns: j = 0 .. nJ - 1 is column I0 + 1 + j
+        if (ol == 0) {
+#pragma unroll
+            for (int u = 0; u < RL; ++u) { const int k = oj + 8 * u; xr[u] = (k < d) ? G[(size_t)I0 * d + k] : 0.0; }
+        }
+        for (int e = tid; e < 2 * d; e += 256) {                // the ring's first two columns
+            const int c = e / d, k = e - c * d;
+            if (c < nJ) GY[(size_t)c * LS + k] = G[(size_t)(I0 + 1 + c) * d + k];
+        }
+        __syncthreads();
+        const int nsteps = nJ + wI;                            // (the last one only writes the last column back)
+        for (int t = 0; t < nsteps; ++t) {
+            if (loader) {
+                const int cw = t + 1;                          // ring <- stream column cw (its load was issued in the previous step)
+                if (cw >= 2 && cw < nJ) {
+                    double *dst = GY + (size_t)(cw % RB) * LS;
+#pragma unroll
+                    for (int u = 0; u < MCX_SVDS_EPT; ++u) { const int k = li + 64 * u; if (k < d) dst[k] = stg[u]; }
+                }
+                const int cg = t + 2;                          // issue the load of stream column cg
+                if (cg < nJ) {
+                    const double *src = G + (size_t)(I0 + 1 + cg) * d;
+#pragma unroll
+                    for (int u = 0; u < MCX_SVDS_EPT; ++u) { const int k = li + 64 * u; if (k < d) stg[u] = src[k]; }
+                }
+                const int cs = t - wI;                         // stream column cs had its last pair in the previous step
+                if (cs >= wI - 1 && cs < nJ) {
+                    const double *src = GY + (size_t)(cs % RB) * LS;
+                    double *dst = G + (size_t)(I0 + 1 + cs) * d;
+#pragma unroll
+                    for (int u = 0; u < MCX_SVDS_EPT; ++u) { const int k = li + 64 * u; if (k < d) dst[k] = src[k]; }
+                }
+            } else if (ol < wI) {
+                if (t == 2 * ol - 1) {                         // this pair-lane's own column: its last pair as a partner was in step 2 ol - 2
+                    const double *src = GY + (size_t)((ol - 1) % RB) * LS;
+#pragma unroll
+                    for (int u = 0; u < RL; ++u) xr[u] = src[oj + 8 * u];
+                }
+                const int jj = t - ol;
+                if (jj >= ol && jj < nJ) pair_step(GY + (size_t)(jj % RB) * LS, svd_pair_index(I0 + ol, I0 + 1 + jj, d));
+            }
+            __syncthreads();
+        }
+        if (ol < wI) {
+#pragma unroll
+            for (int u = 0; u < RL; ++u) { const int k = oj + 8 * u; if (k < d) G[(size_t)(I0 + ol) * d + k] = xr[u]; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { if (s_rot) *any_rotated = 1; else state[chain] = 2; }
+}
+
 __global__ __launch_bounds__(256) void svd_applyv_kernel(double *Vc, const mcx_d2 *rot, const uint8_t *state, int nlanes, int d, int b)
 {
     extern __shared__ double S[];
@@ -4072,8 +4189,6 @@ __global__ __launch_bounds__(256) void svd_applyv_kernel(double *Vc, const mcx_d
     }
 }
 
-// singular values = column norms of G (the routine's eight partial chains over the rows), sorted descending (first maximum wins), V's columns
-// with them; the sorted vectors are left in G's place
 // svd_applyv_kernel with the I block's columns of V in registers (round 4, like svd_sweep_reg_kernel): thread (rl, rk0) keeps its rows
 // (2 rk0, 2 rk0 + 1) + 16 u of column I0 + rl for the whole row of block pairs; only the partner column goes through LDS.  Same rotations
 // in the same order on the same elements.
@@ -4165,6 +4280,114 @@ __global__ __launch_bounds__(256) void svd_applyv_reg_kernel(double *Vc, const m
     }
 }
 
+// svd_applyv_reg_kernel with V's later columns streamed past the I block like svd_sweep_stream_kernel's: the rotations of a sweep touch
+// the rows of V independently, so each of a chain's four waves (two row groups of 32 lanes: 24 pair-lanes and 8 loader lanes each) is a
+// workgroup of its own, with a ring of b + 2 columns of ITS rows in LDS, and never waits for the others.  A pair-lane reads the next step's
+// (c, s) from the log one step ahead.  blockIdx: the four waves of a chain on one XCD (they read the same log).
+template <int RP>         // row PAIRS per thread: 16 RP >= npar
+__global__ __launch_bounds__(64) void svd_applyv_stream_kernel(double *Vc, const mcx_d2 *rot, const uint8_t *state, int nlanes, int d, int b)
+{
+    extern __shared__ double S[];
+    const int blk = blockIdx.x;
+    const int chain = (blk >> 5) * 8 + (blk & 7), wv = (blk >> 3) & 3;
+    if (chain >= nlanes || state[chain] != 1) return;
+    double *V = Vc + (size_t)chain * d * d;
+    const mcx_d2 *log = rot + (size_t)chain * ((size_t)d * (d - 1) / 2);
+    constexpr int RGS = 2 * RP + 2, SLOT = 4 * RP + 6;          // doubles per row group (its odd last row at 2 RP) and per ring column (SLOT / 2 odd: 16 lanes on 16 columns, 64 banks)
+    const int RB = b + 2;
+    const int nb = (d + b - 1) / b;
+    const int ln = threadIdx.x, rg = ln >> 5, rl = ln & 31, rk0 = 2 * wv + rg;
+    const bool loader = rl >= 24;
+    const int q = rl - 24;
+    const bool oddrow = (d & 1) && rk0 == 0;                    // row d - 1 of an odd npar: row group 0's extra element
+    double *ring = S + rg * RGS;
+    mcx_d2 vr[RP];
+    double vlast = 0.0;
+    double stg[4], stgl = 0.0;                                  // loaders: row pairs u = q, q + 8 of the column on its way to the ring (+ the odd row: lane q = 7)
+    auto g_load = [&](const double *col) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { const int u = q + 8 * h, k = 2 * rk0 + 16 * u; if (u < RP && k + 1 < d) { stg[2 * h] = col[k]; stg[2 * h + 1] = col[k + 1]; } }
+        if (oddrow && q == 7) stgl = col[d - 1];
+    };
+    auto r_write = [&](double *slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { const int u = q + 8 * h, k = 2 * rk0 + 16 * u; if (u < RP && k + 1 < d) { mcx_d2 v; v.x = stg[2 * h]; v.y = stg[2 * h + 1]; *(mcx_d2 *)(slot + 2 * u) = v; } }
+        if (oddrow && q == 7) slot[2 * RP] = stgl;
+    };
+    auto r_store = [&](const double *slot, double *col) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { const int u = q + 8 * h, k = 2 * rk0 + 16 * u; if (u < RP && k + 1 < d) { const mcx_d2 v = *(const mcx_d2 *)(slot + 2 * u); col[k] = v.x; col[k + 1] = v.y; } }
+        if (oddrow && q == 7) col[d - 1] = slot[2 * RP];
+    };
+    auto pair_step = [&](double *vq, const mcx_d2 cs) __attribute__((always_inline)) {
+        if (cs.x == 1.0 && cs.y == 0.0) return;
+        const double c = cs.x, sn = cs.y;
+        mcx_d2 vb[RP];
+#pragma unroll
+        for (int u = 0; u < RP; ++u) vb[u] = *(mcx_d2 *)(vq + 2 * u);   // (row pairs beyond npar: zeros in the ring and in vr, they stay zero)
+#pragma unroll
+        for (int u = 0; u < RP; ++u) {
+            mcx_d2 nva, nvb;
+            nva.x = c * vr[u].x - sn * vb[u].x; nva.y = c * vr[u].y - sn * vb[u].y; nvb.x = sn * vr[u].x + c * vb[u].x; nvb.y = sn * vr[u].y + c * vb[u].y;
+            vr[u] = nva; *(mcx_d2 *)(vq + 2 * u) = nvb;
+        }
+        if (oddrow) { const double va0 = vlast, vb0 = vq[2 * RP]; vlast = c * va0 - sn * vb0; vq[2 * RP] = sn * va0 + c * vb0; }
+    };
+    for (int e = ln; e < RB * SLOT; e += 64) S[e] = 0.0;
+    __syncthreads();
+    for (int I = 0; I < nb; ++I) {
+        const int I0 = I * b, wI = (d - I0) < b ? (d - I0) : b;
+        const int nJ = d - I0 - 1;
+        if (rl == 0) {                                          // the block's first column: straight into registers
+            const double *col = V + (size_t)I0 * d;
+#pragma unroll
+            for (int u = 0; u < RP; ++u) { const int k = 2 * rk0 + 16 * u; vr[u].x = 0.0; vr[u].y = 0.0; if (k + 1 < d) { vr[u].x = col[k]; vr[u].y = col[k + 1]; } }
+            if (oddrow) vlast = col[d - 1];
+        }
+        if (loader)
+            for (int c = 0; c < 2 && c < nJ; ++c) { g_load(V + (size_t)(I0 + 1 + c) * d); r_write(ring + (size_t)c * SLOT); }
+        const size_t base = svd_pair_index(I0 + rl, I0 + 1 + rl, d);   // log entry of this pair-lane's first pair (step 2 rl), the next ones follow it
+        mcx_d2 nxt; nxt.x = 1.0; nxt.y = 0.0;
+        if (rl == 0 && nJ > 0) nxt = log[base];
+        const int nsteps = nJ + wI;
+        for (int t = 0; t < nsteps; ++t) {
+            // a step reads what other lanes of THIS wave wrote in the previous one: keep the compiler from moving LDS accesses across the
+            // step boundary (the hardware runs a wave's LDS operations in order)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (loader) {
+                const int cw = t + 1;
+                if (cw >= 2 && cw < nJ) r_write(ring + (size_t)(cw % RB) * SLOT);
+                const int cg = t + 2;
+                if (cg < nJ) g_load(V + (size_t)(I0 + 1 + cg) * d);
+                const int cs = t - wI;
+                if (cs >= wI - 1 && cs < nJ) r_store(ring + (size_t)(cs % RB) * SLOT, V + (size_t)(I0 + 1 + cs) * d);
+            } else if (rl < wI) {
+                const mcx_d2 cur = nxt;
+                const int jn = t + 1 - rl;                      // the next step's partner
+                if (jn >= rl && jn < nJ) nxt = log[base + (size_t)(jn - rl)];
+                if (t == 2 * rl - 1) {
+                    const double *src = ring + (size_t)((rl - 1) % RB) * SLOT;
+#pragma unroll
+                    for (int u = 0; u < RP; ++u) vr[u] = *(const mcx_d2 *)(src + 2 * u);
+                    if (oddrow) vlast = src[2 * RP];
+                }
+                const int jj = t - rl;
+                if (jj >= rl && jj < nJ) pair_step(ring + (size_t)(jj % RB) * SLOT, cur);
+            }
+        }
+        if (rl < wI) {
+            double *col = V + (size_t)(I0 + rl) * d;
+#pragma unroll
+            for (int u = 0; u < RP; ++u) { const int k = 2 * rk0 + 16 * u; if (k + 1 < d) { col[k] = vr[u].x; col[k + 1] = vr[u].y; } }
+            if (oddrow) col[d - 1] = vlast;
+        }
+        __syncthreads();                                       // (one wave: the next block row's loads follow these stores)
+    }
+}
+
+// singular values = column norms of G (the routine's eight partial chains over the rows), sorted descending (first maximum wins), V's columns
+// with them; the sorted vectors are left in G's place
 __global__ __launch_bounds__(256) void svd_finish_kernel(double *Gc, const double *Vc, double *svc, const uint8_t *state, int nlanes, int d)
 {
     __shared__ int s_perm[256];

@@ -374,8 +374,15 @@ def test_blocked_svd_equals_lane_svd_and_oracle(oracle, d, method, extra, monkey
     #  test_gpu_fullsize.py::test_c5_illcond200_scam_replicas_two_ticks, and takes 10-25 s per adaptation up here)
     # paths: the sweep / V replay with the I block's columns in registers (round 4, the default), with both blocks in LDS
     # (MCMCX_SVD_REG=0), one lane per chain (MCMCX_SVD_LANE=1)
-    for path in (("reg", "lds", "lane") if d <= 128 else ("reg", "lds")):
-        monkeypatch.delenv("MCMCX_SVD_LANE", raising=False); monkeypatch.delenv("MCMCX_SVD_REG", raising=False)
+    # the columns right of the I block streamed past it through an LDS ring (the default; block width 24 and 16), the I block in
+    # registers and block pairs (MCMCX_SVD_STREAM=0), ...
+    for path in (("stream", "stream16", "reg", "lds", "lane") if d <= 128 else ("stream", "stream16", "reg", "lds")):
+        for k in ("MCMCX_SVD_LANE", "MCMCX_SVD_REG", "MCMCX_SVD_STREAM", "MCMCX_SVD_STREAM_B"):
+            monkeypatch.delenv(k, raising=False)
+        if path == "stream16":
+            monkeypatch.setenv("MCMCX_SVD_STREAM_B", "16")
+        if path in ("reg", "lds"):
+            monkeypatch.setenv("MCMCX_SVD_STREAM", "0")
         if path == "lane":
             monkeypatch.setenv("MCMCX_SVD_LANE", "1")
         if path == "lds":
