@@ -386,9 +386,8 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
     it_end = (warmup + steps) * ips
     # a configuration whose timed iterations hold no adaptation (c5: ten iterations per step, adaptint 100) runs on to its next one
     # afterwards, untimed for `value`, so that the line can say what an adaptation costs (N = 1 only)
-    # (not with per-chain rotations at npar = 200: that adaptation is 65536 SVDs -- 7 s on full-rank covariances, 35 s at the first
-    #  adaptation of this line, whose 100 rows leave the 200 x 200 covariance rank-deficient and the pinned routine at its 60-sweep cap;
-    #  tools/svd_tick_probe.py)
+    # (per-chain rotations at npar = 200, where an adaptation is one SVD per chain, time theirs on a second engine below: the first
+    #  adaptation of this line has 100 rows for a 200 x 200 covariance -- rank-deficient, the pinned routine at its 60-sweep cap)
     tick_probe = (world == 1 and it_end // adaptint_ == (warmup * ips) // adaptint_ and not (wl == "c5" and replicas))
     next_tick = (it_end // adaptint_ + 1) * adaptint_
     if tick_probe:
@@ -445,6 +444,25 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
         eng.run(next_tick); fence()                                                 # one iteration and the adaptation behind it
         tick_s = max(time.perf_counter() - tt0 - dt / (steps * ips), 0.0)
     eng.close()
+    tick_note = None
+    if wl == "c5" and replicas and not scam_fast and world == 1 and steps * ips < adaptint_:
+        # per-chain rotations at npar = 200: an adaptation is one SVD per chain.  Timed on a second engine of the same chains whose
+        # covariance is full rank at the tick (initcmatn = npar: cmat0 carries weight; adaptint 10) -- what every adaptation after the
+        # first is; the configuration's own first one (iteration 100 < npar rows: rank-deficient, the pinned routine runs to its
+        # 60-sweep cap) costs about five of these (tools/svd_tick_probe.py, PROBE_INITCMATN=0)
+        ckw2, pkw2, _ = problem(wl, 12, adaptint=10)
+        ckw2 = dict(ckw2, initcmatn=int(pkw2["npar"]))
+        e2 = engine_from_problem(ckw2, pkw2, nchains=n_local, chain_id0=rank * n_local, device=dev, pooled=0, comm=None, scam_fast=0)
+        e2.init(); e2.run(9); e2.sync()
+        tt0 = time.perf_counter(); e2.run(10); e2.sync()
+        tt1 = time.perf_counter(); e2.run(11); e2.sync()
+        tt2 = time.perf_counter()
+        e2.close()
+        tick_s = max((tt1 - tt0) - (tt2 - tt1), 0.0)
+        tick_note = ("`value` is the rate between two adaptations; an adaptation is one 200 x 200 Jacobi SVD per chain, timed on a second "
+                     "engine of the same %d chains with a full-rank covariance at the tick (initcmatn = npar, adaptint 10: iteration 10 with "
+                     "its adaptation minus iteration 11); sustained_value = proposals of adaptint iterations / (their time + one such "
+                     "adaptation)" % n_local)
     if rank != 0:
         return None, pooled_vec
     its_timed = steps * ips - (1 if warmup == 0 else 0)                         # iteration 1 is the starting point (MCMC_run.F90:35-41)
@@ -514,7 +532,7 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
         if nticks == 0:
             regime += " (the rate between two adaptations)"
             if wl == "c5" and replicas:
-                regime += "; an adaptation here is one SVD per chain: 7 s for 65536 full-rank covariances, 35 s when adaptint < npar leaves them rank-deficient (not timed in this line)"
+                regime += "; an adaptation here is one SVD per chain (`adaptation.tick_ms`: full-rank covariances)"
     elif start == "target":
         regime = "; cmat0 = the target's covariance: RAM at its target acceptance rate from the start (about half of the lanes downdate)"
     adaptation = None
@@ -522,8 +540,8 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
         t_it = dt / (steps * ips)
         adaptation = {"adaptint": adaptint, "tick_ms": tick_s * 1e3,
                       "sustained_value": float(world) * n_local * per_it * adaptint / (adaptint * t_it + tick_s),
-                      "note": "`value` is the rate between two adaptations; sustained_value = proposals of adaptint iterations / (their time + one "
-                              "adaptation), the adaptation timed once after the timed region (iteration %d)" % next_tick}
+                      "note": tick_note or ("`value` is the rate between two adaptations; sustained_value = proposals of adaptint iterations / (their time + one "
+                                            "adaptation), the adaptation timed once after the timed region (iteration %d)" % next_tick)}
     cnt = float(pooled_vec[0])
     mean = pooled_vec[1:1 + d] / cnt
     res = {

@@ -350,8 +350,9 @@ def test_history_ring_without_record_chain(oracle, kw, dr):
     e.close()
 
 
-@pytest.mark.parametrize("d,method,extra", [(48, "scam", {}), (70, "scam", {}), (64, "dram", dict(condmax=1e6)), (100, "dram", dict(condmax=50.0, drscale=2.0)),
-                                            (128, "scam", {}), (200, "dram", dict(condmax=1e6)), (200, "scam", {}), (256, "scam", {})])
+@pytest.mark.parametrize("d,method,extra", [(48, "scam", {}), (49, "scam", {}), (70, "scam", {}), (64, "dram", dict(condmax=1e6)), (65, "dram", dict(condmax=1e6)),
+                                            (100, "dram", dict(condmax=50.0, drscale=2.0)), (128, "scam", {}), (129, "scam", {}), (200, "dram", dict(condmax=1e6)),
+                                            (200, "scam", {}), (209, "scam", {}), (255, "scam", {}), (256, "scam", {})])
 def test_blocked_svd_equals_lane_svd_and_oracle(oracle, d, method, extra, monkeypatch):
     """npar >= 48 with an SVD factor: MCMC_adapt's factorisation runs svd_blocked_kernel (a workgroup per chain, block
     pairs of columns in LDS, the pinned routine's pairs in a reordered but equivalent sequence).  Bit for bit the
@@ -376,7 +377,10 @@ def test_blocked_svd_equals_lane_svd_and_oracle(oracle, d, method, extra, monkey
     # (MCMCX_SVD_REG=0), one lane per chain (MCMCX_SVD_LANE=1)
     # the columns right of the I block streamed past it through an LDS ring (the default; block width 24 and 16), the I block in
     # registers and block pairs (MCMCX_SVD_STREAM=0), ...
-    for path in (("stream", "stream16", "reg", "lds", "lane") if d <= 128 else ("stream", "stream16", "reg", "lds")):
+    # (odd npar: the V replay's extra row and unaligned columns; 65 / 129 / 209: one row past a register-count instantiation)
+    paths = ("stream", "stream16", "reg", "lds", "lane") if d <= 100 else ("stream", "reg", "lane") if d == 128 else \
+            ("stream", "stream16", "reg", "lds") if (d == 129 or (d == 200 and method == "dram")) else ("stream", "reg")
+    for path in paths:
         for k in ("MCMCX_SVD_LANE", "MCMCX_SVD_REG", "MCMCX_SVD_STREAM", "MCMCX_SVD_STREAM_B"):
             monkeypatch.delenv(k, raising=False)
         if path == "stream16":
