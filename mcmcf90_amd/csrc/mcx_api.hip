@@ -2079,7 +2079,7 @@ static int pooled_moments_launch(mcmcx_engine *h, double *dev_dst, int kind, int
     HIPCHK(hipSetDevice(h->cfg.device));
     const int len = pooled_vec_len(h, kind), T = h->ntiles;
     const double rs = (kind == 2) ? 1.0 / std::pow((double)(float)it, h->cfg.nuparam) : 0.0;      // like d_ramscale (MCMC_run_ram.F90:166)
-    hipLaunchKernelGGL(moments_kernel, dim3(T), dim3(64), 0, h->stream, h->E, h->d_moments, h->cfg.nchains, kind, it, rs);
+    hipLaunchKernelGGL(moments_kernel, dim3(T), dim3(256), ((size_t)64 * (h->d | 1) + 256) * sizeof(double), h->stream, h->E, h->d_moments, h->cfg.nchains, kind, it, rs);
     for (long long stride = 1;; stride *= 64) {                            // six levels of the fixed pairwise tree per launch
         const long long groups = (T + 64 * stride - 1) / (64 * stride);
         hipLaunchKernelGGL(moments_tree_kernel, dim3((len + 255) / 256, (unsigned)groups), dim3(256), 0, h->stream, h->d_moments, T, len,

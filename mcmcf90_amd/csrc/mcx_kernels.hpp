@@ -107,6 +107,7 @@ constexpr int CH = 8;     // row elements per batch; two batches (2 x 8 x 512 B)
 #define XL(j) X[(j) * 64 + lane]
 // element k of a tile-interleaved global vector whose tile base is `p` (uniform pointer)
 #define GV(p, k) (p)[(size_t)(k) * 64 + lane]
+#define GV2(p, k, c) (p)[(size_t)(k) * 64 + (c)]
 // streaming (non-temporal) access for the factor, which is touched once per iteration and should not evict
 // the small per-chain scratch vectors from L2 / Infinity Cache
 #define LDNT(p, k) __builtin_nontemporal_load(&(p)[(size_t)(k) * 64 + lane])
@@ -4460,66 +4461,79 @@ __global__ __launch_bounds__(256) void gather_lane_kernel(const double *__restri
 // kind 1: the same followed by sum_c stayed_c (the pooled rejection count of a burn-in tick)  (2 + d + P)
 // kind 2: the pooled RAM statistic of iteration `it` (MCMC_run_ram.F90:166-172 summed over chains): [count, sum alpha,
 //         sum_c sign(a_c) x_c x_c'], x_c = u_c / sum(u_c**2) * a_c, a_c = rs (alpha_c - alphatarget)     (2 + P)
-__global__ __launch_bounds__(64) void moments_kernel(EngineDev E, double *out, int nchains, int kind, int it, double rs)
+__global__ __launch_bounds__(256) void moments_kernel(EngineDev E, double *out, int nchains, int kind, int it, double rs)
 {
-    // Each lane produces its chain's terms in a fixed order (count, first moments, second moments by rows of the lower
-    // triangle); 64 terms at a time are transposed through LDS, and lane k then adds term k of the 64 chains in the
-    // butterfly's tree order (lane pairs first) -- the sums v_l + v_{l^1}, (..) + (..)_{l^2}, ... a xor-butterfly leaves in
-    // lane 0 -- in registers.
-    __shared__ double T[64 * 65];
-    const int lane = threadIdx.x, tile = blockIdx.x, d = E.d, P = E.P;
+    // The tile's 64 vectors x_c go to LDS once (chain-major, odd stride); then each of the 256 threads takes terms m, m + 256, ...:
+    // it forms the term's 64 values (one per chain) and adds them in the butterfly's tree order (lane pairs first) -- the sums
+    // v_l + v_{l^1}, (..) + (..)_{l^2}, ... a xor-butterfly leaves in lane 0 -- in registers.  No barrier after the first, every
+    // lane on a term of its own; the old form (one chain per lane, 64 terms at a time transposed through LDS) spent its time
+    // in the latencies of 1300 global loads and 2 x 20 barriers per tile at four waves per CU.
+    extern __shared__ double XS[];                      // x[64][DP]; then count[64], alpha or stayed [64], sign(a) [64], sum(u**2) [64]
+    const int tid = threadIdx.x, tile = blockIdx.x, d = E.d, P = E.P, DP = d | 1;
+    double *sp0 = XS + (size_t)64 * DP, *sp1 = sp0 + 64, *sg = sp1 + 64, *ssu = sg + 64;
     const double *theta_t = E.theta + (size_t)tile * d * 64;
-    const bool act = (tile * 64 + lane) < nchains;
+    const double *z_t = E.zs + ((size_t)tile * 2 + (it & 1)) * d * 64;        // kind 2: the normals iteration `it` proposed with
     const int len = (kind == 2) ? 2 + P : (1 + d + P + (kind == 1 ? 1 : 0));
     double *o = out + (size_t)tile * len;
-    int m = 0;                                          // terms produced so far
-    auto flush = [&](int base, int n) {                 // terms base .. base+n-1 sit in T[0..n-1][*]
-        __syncthreads();
-        if (lane < n) {
-            double a[64];
-#pragma unroll
-            for (int l = 0; l < 64; ++l) a[l] = T[lane * 65 + l];
-#pragma unroll
-            for (int s2 = 1; s2 < 64; s2 <<= 1)
-#pragma unroll
-                for (int l = 0; l + s2 < 64; l += 2 * s2) a[l] = a[l] + a[l + s2];
-            o[base + lane] = a[0];
-        }
-        __syncthreads();
-    };
-    auto put = [&](double v) {
-        T[(m & 63) * 65 + lane] = v;
-        ++m;
-        if ((m & 63) == 0) flush(m - 64, 64);
-    };
-    put(act ? 1.0 : 0.0);
-    if (kind == 2) {
-        const double *z_t = E.zs + ((size_t)tile * 2 + (it & 1)) * d * 64;    // the normals iteration `it` proposed with
-        const double alpha = TIDX(E.scal, tile, NSCAL, S_ALPHA12, lane);
-        const double a = rs * (alpha - E.alphatarget);
-        double su = 0.0;
-        for (int k = 0; k < d; ++k) { const double z = GV(z_t, k); su = su + z * z; }
-        put(act ? alpha : 0.0);
-        for (int j = 0; j < d; ++j) {
-            const double xj = GV(z_t, j) / su * a;
-            for (int i = 0; i <= j; ++i) {
-                const double xi = GV(z_t, i) / su * a;
-                const double t = xi * xj;
-                put(act ? ((a >= 0.0) ? t : -t) : 0.0);
-            }
-        }
-    } else {
-        for (int j = 0; j < d; ++j) put(act ? (GV(theta_t, j) - E.par0[j]) : 0.0);
-        for (int j = 0; j < d; ++j) {
-            const double vj = act ? (GV(theta_t, j) - E.par0[j]) : 0.0;
-            for (int i = 0; i <= j; ++i) {
-                const double vi = act ? (GV(theta_t, i) - E.par0[i]) : 0.0;
-                put(vi * vj);
-            }
-        }
-        if (kind == 1) put(act ? (double)TIDX(E.ictr, tile, NICTR, I_STAYED, lane) : 0.0);
+    const int c0 = tid & 63;
+    const bool act = (tile * 64 + c0) < nchains;
+    if (tid < 64) {
+        sp0[c0] = act ? 1.0 : 0.0;
+        double s1 = 0.0, sgn = 1.0, su = 1.0;
+        if (kind == 2) {
+            const double alpha = TIDX(E.scal, tile, NSCAL, S_ALPHA12, c0);
+            const double a = rs * (alpha - E.alphatarget);
+            su = 0.0;
+            for (int k = 0; k < d; ++k) { const double z = GV2(z_t, k, c0); su = su + z * z; }
+            s1 = act ? alpha : 0.0;
+            sgn = (!act || a >= 0.0) ? 1.0 : -1.0;
+        } else if (kind == 1) s1 = act ? (double)TIDX(E.ictr, tile, NICTR, I_STAYED, c0) : 0.0;
+        sp1[c0] = s1; sg[c0] = sgn; ssu[c0] = su;
     }
-    if (m & 63) flush(m & ~63, m & 63);
+    __syncthreads();
+    if (kind == 2) {
+        const double alpha = TIDX(E.scal, tile, NSCAL, S_ALPHA12, c0);
+        const double a = rs * (alpha - E.alphatarget), su = ssu[c0];
+        for (int k = tid >> 6; k < d; k += 4) XS[(size_t)c0 * DP + k] = act ? GV2(z_t, k, c0) / su * a : 0.0;     // x = u / sum(u**2) * a
+    } else {
+        for (int k = tid >> 6; k < d; k += 4) XS[(size_t)c0 * DP + k] = act ? (GV2(theta_t, k, c0) - E.par0[k]) : 0.0;
+    }
+    __syncthreads();
+    const int pair0 = (kind == 2) ? 2 : 1 + d;          // first second-moment term
+    for (int m = tid; m < len; m += 256) {
+        double a[64];
+        if (m == 0) {
+#pragma unroll
+            for (int l = 0; l < 64; ++l) a[l] = sp0[l];
+        } else if (m < pair0 && kind == 2) {
+#pragma unroll
+            for (int l = 0; l < 64; ++l) a[l] = sp1[l];
+        } else if (m < pair0) {
+#pragma unroll
+            for (int l = 0; l < 64; ++l) a[l] = XS[(size_t)l * DP + (m - 1)];
+        } else if (m >= pair0 + P) {                    // kind 1: the rejection counts
+#pragma unroll
+            for (int l = 0; l < 64; ++l) a[l] = sp1[l];
+        } else {
+            const int q = m - pair0;                    // = j (j + 1) / 2 + i, i <= j
+            int j = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+            while ((j + 1) * (j + 2) / 2 <= q) ++j;
+            while (j * (j + 1) / 2 > q) --j;
+            const int i2 = q - j * (j + 1) / 2;
+            if (kind == 2) {
+#pragma unroll
+                for (int l = 0; l < 64; ++l) { const double t = XS[(size_t)l * DP + i2] * XS[(size_t)l * DP + j]; a[l] = (sg[l] >= 0.0) ? t : -t; }
+            } else {
+#pragma unroll
+                for (int l = 0; l < 64; ++l) a[l] = XS[(size_t)l * DP + i2] * XS[(size_t)l * DP + j];
+            }
+        }
+#pragma unroll
+        for (int s2 = 1; s2 < 64; s2 <<= 1)
+#pragma unroll
+            for (int l = 0; l + s2 < 64; l += 2 * s2) a[l] = a[l] + a[l + s2];
+        o[m] = a[0];
+    }
 }
 
 // Finish the pooled sum over tiles in the same fixed pairwise tree (adjacent tiles first):
