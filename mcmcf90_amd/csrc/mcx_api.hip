@@ -594,12 +594,21 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
     const bool svd_reg = !(getenv("MCMCX_SVD_REG") && atoi(getenv("MCMCX_SVD_REG")) == 0);         // (0: A/B, tests -- svd_sweep_kernel)
     const bool svd_stream = !(getenv("MCMCX_SVD_STREAM") && atoi(getenv("MCMCX_SVD_STREAM")) == 0);   // (0: A/B, tests -- svd_sweep_reg_kernel)
     int svd_sb = 24;                                     // pair-lanes of the streamed sweep: whole waves of octets, one wave of loaders at least
-    if (const char *e = getenv("MCMCX_SVD_STREAM_B")) { const int b = atoi(e); if (b >= 2 && b <= 24) svd_sb = b; }
+    bool svd_s32 = h->d <= 200 && !(getenv("MCMCX_SVD_STREAM32") && atoi(getenv("MCMCX_SVD_STREAM32")) == 0);   // (0, or a block width given: svd_sweep_stream_kernel)
+    bool svd_a32 = !(getenv("MCMCX_SVD_STREAM32") && atoi(getenv("MCMCX_SVD_STREAM32")) == 0);     // the V replay's 32-lane form: any npar
+    if (const char *e = getenv("MCMCX_SVD_STREAM_B")) { const int b = atoi(e); if (b >= 2 && b <= 24) { svd_sb = b; svd_s32 = false; svd_a32 = false; } }
     hipLaunchKernelGGL(adapt_post_kernel<true>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 1, h->d_need, batch_done);
     hipLaunchKernelGGL(tile2chain_kernel, tg, dim3(256), 0, h->stream, h->E.Gw, h->d_Gc, DD, DD, h->d_need);
     hipLaunchKernelGGL(svd_init_kernel, dim3(h->nlanes), dim3(256), 0, h->stream, h->d_Vc, h->d_state, h->d_need, h->nlanes, h->d);
     for (int sweep = 0; sweep < 60; ++sweep) {
         (void)hipMemsetAsync(h->d_anyrot, 0, sizeof(int), h->stream);
+        if (svd_reg && svd_stream && svd_s32) {          // ... all lanes on pairs (npar <= 200), the ring's slots handed over in place
+            const int RLs = h->d <= 64 ? 8 : h->d <= 128 ? 16 : 25;
+            const size_t lss = (size_t)33 * (8 * RLs + 2) * sizeof(double);
+            if (h->d <= 64) hipLaunchKernelGGL(svd_sweep_stream32_kernel<8>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
+            else if (h->d <= 128) hipLaunchKernelGGL(svd_sweep_stream32_kernel<16>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
+            else hipLaunchKernelGGL(svd_sweep_stream32_kernel<25>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
+        } else
         if (svd_reg && svd_stream) {                     // ... and the columns to their right streamed past them through an LDS ring
             const int RLs = h->d <= 64 ? 8 : h->d <= 128 ? 16 : h->d <= 208 ? 26 : 32;
             const size_t lss = (size_t)(svd_sb + 2) * (8 * RLs + 2) * sizeof(double);
@@ -616,6 +625,15 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
             else hipLaunchKernelGGL(svd_sweep_reg_kernel<32>, dim3(h->nlanes), dim3(256), lsr, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d, h->svd_b);
         } else
         hipLaunchKernelGGL(svd_sweep_kernel, dim3(h->nlanes), dim3(256), lsv, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d, h->svd_b);
+        if (svd_reg && svd_stream && svd_a32) {          // all 32 lanes of a row group on pairs
+            const unsigned gv = (unsigned)(32 * ((h->nlanes + 7) / 8));
+            const int RP = h->d <= 64 ? 4 : h->d <= 128 ? 8 : h->d <= 208 ? 13 : 16;
+            const size_t lsv2 = (size_t)33 * (4 * RP + 6) * sizeof(double);
+            if (h->d <= 64) hipLaunchKernelGGL(svd_applyv_stream32_kernel<4>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d);
+            else if (h->d <= 128) hipLaunchKernelGGL(svd_applyv_stream32_kernel<8>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d);
+            else if (h->d <= 208) hipLaunchKernelGGL(svd_applyv_stream32_kernel<13>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d);
+            else hipLaunchKernelGGL(svd_applyv_stream32_kernel<16>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d);
+        } else
         if (svd_reg && svd_stream) {
             const unsigned gv = (unsigned)(32 * ((h->nlanes + 7) / 8));                     // four one-wave workgroups per chain, a chain's on one XCD
             const int RP = h->d <= 64 ? 4 : h->d <= 128 ? 8 : h->d <= 208 ? 13 : 16;

@@ -4131,6 +4131,100 @@ __global__ __launch_bounds__(256, (RL <= 26 ? MCX_SVDS_WAVES : 2)) void svd_swee
     if (tid == 0) { if (s_rot) *any_rotated = 1; else state[chain] = 2; }
 }
 
+// svd_sweep_stream_kernel with ALL lanes on pairs (npar <= 200): 32 pair-lanes, and every thread carries one element of the column
+// entering the ring and of the one leaving it, so no lane is set aside for loading.  The ring is 33 columns of 8 RL + 2 <= 202 doubles
+// (a leaving column hands its slot to the entering one element by element inside one thread): 53 kB, three workgroups per CU as before.
+// 921 steps per sweep at npar 200 instead of 1134, 64 live lanes per wave instead of 48.
+template <int RL>
+__global__ __launch_bounds__(256, MCX_SVDS_WAVES) void svd_sweep_stream32_kernel(double *Gc, mcx_d2 *rot, uint8_t *state, int *any_rotated, int nlanes, int d)
+{
+    extern __shared__ double S[];
+    __shared__ int s_rot;
+    const int chain = blockIdx.x, tid = threadIdx.x;
+    if (chain >= nlanes || state[chain] != 1) return;
+    double *G = Gc + (size_t)chain * d * d;
+    mcx_d2 *log = rot + (size_t)chain * ((size_t)d * (d - 1) / 2);
+    constexpr int LS = 8 * RL + 2;                             // ring column stride: every octet row 8 u + oj exists (rows >= npar hold zeros: they add
+                                                               // nothing to the three sums and rotate to zero -- no bounds tests in the loop); = 2 mod 4
+    double *GY = S;                                            // the ring: RB columns
+    constexpr int b = 32, RB = b + 1;
+    const int nb = (d + b - 1) / b;
+    const int ol = tid >> 3, oj = tid & 7;                     // pair-lane of this thread's octet, partial chain / row residue
+    const bool ld = tid < d;                                   // ... and every thread moves element `tid` of the columns on their way in and out
+    if (tid == 0) s_rot = 0;
+    double xr[RL];
+    double stg = 0.0;                                          // the element on its way from global memory to the ring
+    auto pair_step = [&](double *ycol, size_t logidx) __attribute__((always_inline)) {
+        double yr[RL];
+#pragma unroll
+        for (int u = 0; u < RL; ++u) yr[u] = ycol[oj + 8 * u];
+        double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+        for (int u = 0; u < RL; ++u) { alpha = dfma(xr[u], xr[u], alpha); beta = dfma(yr[u], yr[u], beta); gamma = dfma(xr[u], yr[u], gamma); }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            alpha = alpha + __shfl_xor(alpha, o, 64); beta = beta + __shfl_xor(beta, o, 64); gamma = gamma + __shfl_xor(gamma, o, 64);
+        }
+        mcx_d2 cs; cs.x = 1.0; cs.y = 0.0;
+        if ((gamma != 0.0) && !(fabs(gamma) <= 1e-15 * sqrt(alpha * beta))) {
+            const double zeta = (beta - alpha) / (2.0 * gamma);
+            const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            const double c = 1.0 / sqrt(1.0 + tt * tt);
+            cs.x = c; cs.y = c * tt;
+            const double sn = cs.y;
+#pragma unroll
+            for (int u = 0; u < RL; ++u) {
+                const double a0 = xr[u], b0 = yr[u];
+                xr[u] = c * a0 - sn * b0; ycol[oj + 8 * u] = sn * a0 + c * b0;
+            }
+            if (oj == 0) s_rot = 1;
+        }
+        if (oj == 0) log[logidx] = cs;
+    };
+    for (int e = tid; e < RB * LS; e += 256) GY[e] = 0.0;
+    __syncthreads();
+    for (int I = 0; I < nb; ++I) {
+        const int I0 = I * b, wI = (d - I0) < b ? (d - I0) : b;
+        const int nJ = d - I0 - 1;                             // stream columns: j = 0 .. nJ - 1 is column I0 + 1 + j
+        if (ol == 0) {
+#pragma unroll
+            for (int u = 0; u < RL; ++u) { const int k = oj + 8 * u; xr[u] = (k < d) ? G[(size_t)I0 * d + k] : 0.0; }
+        }
+        for (int e = tid; e < 2 * d; e += 256) {                // the ring's first two columns
+            const int c = e / d, k = e - c * d;
+            if (c < nJ) GY[(size_t)c * LS + k] = G[(size_t)(I0 + 1 + c) * d + k];
+        }
+        __syncthreads();
+        const int nsteps = nJ + wI;                            // (the last one only writes the last column back)
+        for (int t = 0; t < nsteps; ++t) {
+            {
+                // ring slot (t + 1) mod RB changes hands: stream column t - wI (its last pair was in the previous step) leaves it for global
+                // memory and column t + 1 (loaded in the previous step) enters -- element by element in the same thread, so RB = wI + 1 will do
+                const int cs = t - wI, cw = t + 1, cg = t + 2;
+                if (ld && cs >= wI - 1 && cs < nJ) G[(size_t)(I0 + 1 + cs) * d + tid] = GY[(size_t)(cs % RB) * LS + tid];
+                if (ld && cw >= 2 && cw < nJ) GY[(size_t)(cw % RB) * LS + tid] = stg;
+                if (ld && cg < nJ) stg = G[(size_t)(I0 + 1 + cg) * d + tid];
+            }
+            if (ol < wI) {
+                if (t == 2 * ol - 1) {                         // this pair-lane's own column: its last pair as a partner was in step 2 ol - 2
+                    const double *src = GY + (size_t)((ol - 1) % RB) * LS;
+#pragma unroll
+                    for (int u = 0; u < RL; ++u) xr[u] = src[oj + 8 * u];
+                }
+                const int jj = t - ol;
+                if (jj >= ol && jj < nJ) pair_step(GY + (size_t)(jj % RB) * LS, svd_pair_index(I0 + ol, I0 + 1 + jj, d));
+            }
+            __syncthreads();
+        }
+        if (ol < wI) {
+#pragma unroll
+            for (int u = 0; u < RL; ++u) { const int k = oj + 8 * u; if (k < d) G[(size_t)(I0 + ol) * d + k] = xr[u]; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { if (s_rot) *any_rotated = 1; else state[chain] = 2; }
+}
+
 __global__ __launch_bounds__(256) void svd_applyv_kernel(double *Vc, const mcx_d2 *rot, const uint8_t *state, int nlanes, int d, int b)
 {
     extern __shared__ double S[];
@@ -4370,6 +4464,107 @@ __global__ __launch_bounds__(64) void svd_applyv_stream_kernel(double *Vc, const
                 const int cs = t - wI;
                 if (cs >= wI - 1 && cs < nJ) r_store(ring + (size_t)(cs % RB) * SLOT, V + (size_t)(I0 + 1 + cs) * d);
             } else if (rl < wI) {
+                const mcx_d2 cur = nxt;
+                const int jn = t + 1 - rl;                      // the next step's partner
+                if (jn >= rl && jn < nJ) nxt = log[base + (size_t)(jn - rl)];
+                if (t == 2 * rl - 1) {
+                    const double *src = ring + (size_t)((rl - 1) % RB) * SLOT;
+#pragma unroll
+                    for (int u = 0; u < RP; ++u) vr[u] = *(const mcx_d2 *)(src + 2 * u);
+                    if (oddrow) vlast = src[2 * RP];
+                }
+                const int jj = t - rl;
+                if (jj >= rl && jj < nJ) pair_step(ring + (size_t)(jj % RB) * SLOT, cur);
+            }
+        }
+        if (rl < wI) {
+            double *col = V + (size_t)(I0 + rl) * d;
+#pragma unroll
+            for (int u = 0; u < RP; ++u) { const int k = 2 * rk0 + 16 * u; if (k + 1 < d) { col[k] = vr[u].x; col[k + 1] = vr[u].y; } }
+            if (oddrow) col[d - 1] = vlast;
+        }
+        __syncthreads();                                       // (one wave: the next block row's loads follow these stores)
+    }
+}
+
+// svd_applyv_stream_kernel with all 32 lanes of a row group on pairs (like svd_sweep_stream32_kernel; any npar): lane rl < RP also
+// carries row pair rl of the column entering the ring and of the one leaving it; 33 slots.
+template <int RP>         // row PAIRS per thread: 16 RP >= npar
+__global__ __launch_bounds__(64) void svd_applyv_stream32_kernel(double *Vc, const mcx_d2 *rot, const uint8_t *state, int nlanes, int d)
+{
+    extern __shared__ double S[];
+    const int blk = blockIdx.x;
+    const int chain = (blk >> 5) * 8 + (blk & 7), wv = (blk >> 3) & 3;
+    if (chain >= nlanes || state[chain] != 1) return;
+    double *V = Vc + (size_t)chain * d * d;
+    const mcx_d2 *log = rot + (size_t)chain * ((size_t)d * (d - 1) / 2);
+    constexpr int RGS = 2 * RP + 2, SLOT = 4 * RP + 6;          // doubles per row group (its odd last row at 2 RP) and per ring column (SLOT / 2 odd: 16 lanes on 16 columns, 64 banks)
+    constexpr int b = 32, RB = b + 1;
+    const int nb = (d + b - 1) / b;
+    const int ln = threadIdx.x, rg = ln >> 5, rl = ln & 31, rk0 = 2 * wv + rg;
+    const int lu = rl;                                         // ... and row pair `rl` (rl < RP) of the columns on their way in and out
+    const int lk_ = 2 * rk0 + 16 * lu;
+    const bool ld = lu < RP && lk_ + 1 < d;
+    const bool oddrow = (d & 1) && rk0 == 0;                    // row d - 1 of an odd npar: row group 0's extra element
+    double *ring = S + rg * RGS;
+    mcx_d2 vr[RP];
+    double vlast = 0.0;
+    double stg[2] = {0.0, 0.0}, stgl = 0.0;                     // the row pair on its way to the ring (+ the odd row: lane rl = RP)
+    auto g_load = [&](const double *col) __attribute__((always_inline)) {
+        if (ld) { stg[0] = col[lk_]; stg[1] = col[lk_ + 1]; }
+        if (oddrow && lu == RP) stgl = col[d - 1];
+    };
+    auto r_write = [&](double *slot) __attribute__((always_inline)) {
+        if (ld) { mcx_d2 v2; v2.x = stg[0]; v2.y = stg[1]; *(mcx_d2 *)(slot + 2 * lu) = v2; }
+        if (oddrow && lu == RP) slot[2 * RP] = stgl;
+    };
+    auto r_store = [&](const double *slot, double *col) __attribute__((always_inline)) {
+        if (ld) { const mcx_d2 v2 = *(const mcx_d2 *)(slot + 2 * lu); col[lk_] = v2.x; col[lk_ + 1] = v2.y; }
+        if (oddrow && lu == RP) col[d - 1] = slot[2 * RP];
+    };
+    auto pair_step = [&](double *vq, const mcx_d2 cs) __attribute__((always_inline)) {
+        if (cs.x == 1.0 && cs.y == 0.0) return;
+        const double c = cs.x, sn = cs.y;
+        mcx_d2 vb[RP];
+#pragma unroll
+        for (int u = 0; u < RP; ++u) vb[u] = *(mcx_d2 *)(vq + 2 * u);   // (row pairs beyond npar: zeros in the ring and in vr, they stay zero)
+#pragma unroll
+        for (int u = 0; u < RP; ++u) {
+            mcx_d2 nva, nvb;
+            nva.x = c * vr[u].x - sn * vb[u].x; nva.y = c * vr[u].y - sn * vb[u].y; nvb.x = sn * vr[u].x + c * vb[u].x; nvb.y = sn * vr[u].y + c * vb[u].y;
+            vr[u] = nva; *(mcx_d2 *)(vq + 2 * u) = nvb;
+        }
+        if (oddrow) { const double va0 = vlast, vb0 = vq[2 * RP]; vlast = c * va0 - sn * vb0; vq[2 * RP] = sn * va0 + c * vb0; }
+    };
+    for (int e = ln; e < RB * SLOT; e += 64) S[e] = 0.0;
+    __syncthreads();
+    for (int I = 0; I < nb; ++I) {
+        const int I0 = I * b, wI = (d - I0) < b ? (d - I0) : b;
+        const int nJ = d - I0 - 1;
+        if (rl == 0) {                                          // the block's first column: straight into registers
+            const double *col = V + (size_t)I0 * d;
+#pragma unroll
+            for (int u = 0; u < RP; ++u) { const int k = 2 * rk0 + 16 * u; vr[u].x = 0.0; vr[u].y = 0.0; if (k + 1 < d) { vr[u].x = col[k]; vr[u].y = col[k + 1]; } }
+            if (oddrow) vlast = col[d - 1];
+        }
+        for (int c = 0; c < 2 && c < nJ; ++c) { g_load(V + (size_t)(I0 + 1 + c) * d); r_write(ring + (size_t)c * SLOT); }
+        const size_t base = svd_pair_index(I0 + rl, I0 + 1 + rl, d);   // log entry of this pair-lane's first pair (step 2 rl), the next ones follow it
+        mcx_d2 nxt; nxt.x = 1.0; nxt.y = 0.0;
+        if (rl == 0 && nJ > 0) nxt = log[base];
+        const int nsteps = nJ + wI;
+        for (int t = 0; t < nsteps; ++t) {
+            // a step reads what other lanes of THIS wave wrote in the previous one: keep the compiler from moving LDS accesses across the
+            // step boundary (the hardware runs a wave's LDS operations in order)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            {
+                // slot (t + 1) mod RB changes hands, element by element in the lane that moves it: column t - wI out, column t + 1 in
+                const int cs = t - wI, cw = t + 1, cg = t + 2;
+                if (cs >= wI - 1 && cs < nJ) r_store(ring + (size_t)(cs % RB) * SLOT, V + (size_t)(I0 + 1 + cs) * d);
+                if (cw >= 2 && cw < nJ) r_write(ring + (size_t)(cw % RB) * SLOT);
+                if (cg < nJ) g_load(V + (size_t)(I0 + 1 + cg) * d);
+            }
+            if (rl < wI) {
                 const mcx_d2 cur = nxt;
                 const int jn = t + 1 - rl;                      // the next step's partner
                 if (jn >= rl && jn < nJ) nxt = log[base + (size_t)(jn - rl)];

@@ -378,13 +378,16 @@ def test_blocked_svd_equals_lane_svd_and_oracle(oracle, d, method, extra, monkey
     # the columns right of the I block streamed past it through an LDS ring (the default; block width 24 and 16), the I block in
     # registers and block pairs (MCMCX_SVD_STREAM=0), ...
     # (odd npar: the V replay's extra row and unaligned columns; 65 / 129 / 209: one row past a register-count instantiation)
-    paths = ("stream", "stream16", "reg", "lds", "lane") if d <= 100 else ("stream", "reg", "lane") if d == 128 else \
-            ("stream", "stream16", "reg", "lds") if (d == 129 or (d == 200 and method == "dram")) else ("stream", "reg")
+    paths = ("stream", "stream24", "stream16", "reg", "lds", "lane") if d <= 100 else ("stream", "stream24", "lane") if d == 128 else \
+            ("stream", "stream24", "stream16", "reg", "lds") if (d == 129 or (d == 200 and method == "dram")) else \
+            ("stream", "stream24", "reg") if d in (200, 255) else ("stream", "reg")
     for path in paths:
         for k in ("MCMCX_SVD_LANE", "MCMCX_SVD_REG", "MCMCX_SVD_STREAM", "MCMCX_SVD_STREAM_B"):
             monkeypatch.delenv(k, raising=False)
         if path == "stream16":
             monkeypatch.setenv("MCMCX_SVD_STREAM_B", "16")
+        if path == "stream24":                            # (npar <= 200: "stream" is the 32-pair-lane form)
+            monkeypatch.setenv("MCMCX_SVD_STREAM32", "0")
         if path in ("reg", "lds"):
             monkeypatch.setenv("MCMCX_SVD_STREAM", "0")
         if path == "lane":
