@@ -380,7 +380,7 @@ def test_blocked_svd_equals_lane_svd_and_oracle(oracle, d, method, extra, monkey
     # (odd npar: the V replay's extra row and unaligned columns; 65 / 129 / 209: one row past a register-count instantiation)
     paths = ("stream", "stream24", "stream16", "reg", "lds", "lane") if d <= 100 else ("stream", "stream24", "lane") if d == 128 else \
             ("stream", "stream24", "stream16", "reg", "lds") if (d == 129 or (d == 200 and method == "dram")) else \
-            ("stream", "stream24", "reg") if d in (200, 255) else ("stream", "reg")
+            ("stream", "stream24", "reg") if d == 200 else ("stream", "reg")
     for path in paths:
         for k in ("MCMCX_SVD_LANE", "MCMCX_SVD_REG", "MCMCX_SVD_STREAM", "MCMCX_SVD_STREAM_B"):
             monkeypatch.delenv(k, raising=False)
