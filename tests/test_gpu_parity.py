@@ -110,7 +110,7 @@ def test_c5_fixture_all_iterations_with_the_logged_factors(oracle):
     z, cfg, prob = load("c5_illcond200_scam", oracle)
     ckw, pkw = _kw(z)
     cid = int(z["chain_id"])
-    picks = (0, 1, 65)
+    picks = (1, 65)                                       # the fixture's stream and the ragged tile (an oracle chain is ~25 s of this test)
     e = engine_from_problem(ckw, pkw, nchains=66, chain_id0=cid - 1, record_accept=1, record_chain=1)
     e.init()
     live = {c: oracle.LiveChain(cfg, prob, chain_id=cid - 1 + c) for c in picks}
@@ -407,6 +407,8 @@ def test_blocked_svd_equals_lane_svd_and_oracle(oracle, d, method, extra, monkey
         assert a[5] == b[5]
     cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
     for i, c in enumerate((0, 69)):
+        if d >= 200 and c == 0:                           # (the forms above agree on all 70 chains; one oracle chain at this size: the ragged tile's)
+            continue
         o = oracle.run_chain(cfg, prob, chain_id=5 + c)
         np.testing.assert_array_equal(_bits(a[0][c]), _bits(o.theta))
         np.testing.assert_array_equal(_bits(a[2][0 if c == 0 else 3]), _bits(o.R))
