@@ -33,8 +33,23 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
             return fail(-100, std::string(#call) + ": " + hipGetErrorString(e_));                 \
     } while (0)
 
+// The A/B switches of the kernels' variants (tests, tools): read from the environment ONCE per engine, at mcmcx_create and again at
+// mcmcx_init -- never at launch time.  -1 = not set.
+struct mcx_switches {
+    int pooled_mfma_dr_min = -1, pooled_scalar = -1, dr_big = -1, dr_general = -1, scam_pooled_16 = -1, scam_fast_lanes = -1, scam_waves = -1,
+        svd_lane = -1, cov_td = -1, cov_batch_rows = -1, svd_reg = -1, svd_stream = -1, svd_stream32 = -1, svd_stream_b = -1;
+    static int get(const char *name) { const char *e = getenv(name); return e ? atoi(e) : -1; }
+    void read()
+    {
+        pooled_mfma_dr_min = get("MCMCX_POOLED_MFMA_DR_MIN"); pooled_scalar = get("MCMCX_POOLED_SCALAR"); dr_big = get("MCMCX_DR_BIG");
+        dr_general = get("MCMCX_DR_GENERAL"); scam_pooled_16 = get("MCMCX_SCAM_POOLED_16"); scam_fast_lanes = get("MCMCX_SCAM_FAST_LANES");
+        scam_waves = get("MCMCX_SCAM_WAVES"); svd_lane = get("MCMCX_SVD_LANE"); cov_td = get("MCMCX_COV_TD"); cov_batch_rows = get("MCMCX_COV_BATCH_ROWS");
+        svd_reg = get("MCMCX_SVD_REG"); svd_stream = get("MCMCX_SVD_STREAM"); svd_stream32 = get("MCMCX_SVD_STREAM32"); svd_stream_b = get("MCMCX_SVD_STREAM_B");
+    }
+};
 struct mcmcx_engine {
     mcmcx_config cfg;
+    mcx_switches sw;
     int d = 0, P = 0, ntiles = 0, nlanes = 0;
     int dodr = 0, usesvd = 0;
     bool inited = false;
@@ -288,10 +303,10 @@ static bool pooled_use_mfma(const mcmcx_engine *h)
     if (h->dodr) {                                                                                                   // DR: with its dense tables, and above
         if (h->cfg.method != MCMCX_METHOD_DRAM || !h->d_sharedR2T) return false;                                     // npar 20 (8.3e8 against 8.9e8 iterations/s
         int dmin = 21;                                                                                               // for the lane kernel with its LDS vectors at 20;
-        if (const char *e = getenv("MCMCX_POOLED_MFMA_DR_MIN")) dmin = atoi(e);                                      // 32: 5.6e8 / 2.5e8, 50: 3.2e8 / 0.8e8)
+        if (h->sw.pooled_mfma_dr_min >= 0) dmin = h->sw.pooled_mfma_dr_min;                                         // 32: 5.6e8 / 2.5e8, 50: 3.2e8 / 0.8e8)
         if (h->d < dmin) return false;
     }
-    if (const char *e = getenv("MCMCX_POOLED_SCALAR")) if (atoi(e)) return false;      // A/B switch for tests: the lane-per-chain kernel
+    if (h->sw.pooled_scalar > 0) return false;                                         // A/B switch for tests: the lane-per-chain kernel
     return pooled_mfma_lds(h->d) <= 160 * 1024;
 }
 static bool phased(const mcmcx_engine *h) { return h->tkind == TGT_HOST || h->tkind == TGT_EXPCOLS || h->tkind == TGT_MODULE; }   // iteration cut at the evaluations
@@ -306,7 +321,7 @@ static size_t lds_step(const mcmcx_engine *h) { return (h->dodr && dr_fits_lds(h
 static bool dr_vectors_in_lds(const mcmcx_engine *h, int min_waves = 8)
 {
     if (!dr_fits_lds(h)) return false;
-    if (const char *e = getenv("MCMCX_DR_BIG")) return atoi(e) == 0;                  // A/B switch for tests: 1 = global scratch, 0 = LDS
+    if (h->sw.dr_big >= 0) return h->sw.dr_big == 0;                                  // A/B switch for tests: 1 = global scratch, 0 = LDS
     return lds_bytes(h) * (size_t)min_waves <= 160 * 1024;
 }
 static void launch_init(mcmcx_engine *h)
@@ -428,7 +443,7 @@ static void launch_step(mcmcx_engine *h, int it0, int it1)
     else if (h->E.method == M_RAM) LAUNCHK((step_kernel<true, false, false>), g, b, (size_t)NLC * 2 * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->dodr && !dr_vectors_in_lds(h))            // the second stage's two vectors in global scratch
         LAUNCHK(step_kernel_dr_big, g, b, 0, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
-    else if (h->dodr && !(getenv("MCMCX_DR_GENERAL") && atoi(getenv("MCMCX_DR_GENERAL"))))      // (A/B switch for tests: step_body<DR>)
+    else if (h->dodr && !(h->sw.dr_general > 0))                                                // (A/B switch for tests: step_body<DR>)
         LAUNCHK(step_kernel_dr, g, b, lds_step(h), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
     else if (h->dodr) LAUNCHK((step_kernel<false, true, false>), g, b, lds_step(h), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->E.lds_scratch == 2) LAUNCHK(step_kernel_ldsr, g, b, (size_t)(2 * h->d + h->P) * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
@@ -485,7 +500,7 @@ static int upload_shared_u(mcmcx_engine *h)
 static bool scam_use_12(const mcmcx_engine *h)
 {
     const int nt = (h->d + 15) / 16;
-    if (const char *e = getenv("MCMCX_SCAM_POOLED_16")) if (atoi(e)) return false;    // A/B switch for tests: the sixteen-wave layout
+    if (h->sw.scam_pooled_16 > 0) return false;                                       // A/B switch for tests: the sixteen-wave layout
     return nt >= 13 && nt <= 15;
 }
 static void launch_scam(mcmcx_engine *h, int it0, int it1)
@@ -506,7 +521,7 @@ static void launch_scam(mcmcx_engine *h, int it0, int it1)
     // opt-in fast proposals with the Gaussian target: the workgroup-per-tile kernel of the pooled mode with each chain's own
     // rotation column (g_U = nullptr) -- the target's d x d product on the matrix cores instead of lane by lane
     if (h->cfg.scam_fast && h->tkind == TGT_GAUSS && !h->has_lo && !h->has_hi && !h->has_pri && scam_pooled_lds(h->d) <= 160 * 1024 &&
-        !(getenv("MCMCX_SCAM_FAST_LANES") && atoi(getenv("MCMCX_SCAM_FAST_LANES")))) {
+        !(h->sw.scam_fast_lanes > 0)) {
         // (the sixteen-wave layout whatever npar: every lane fetches the column of its own chain's factor per sub-step, and four
         //  waves per SIMD cover that better than three -- 4.62e8 against 4.45e8 proposals/s at npar 200)
         const int nt = (h->d + 15) / 16;
@@ -520,7 +535,7 @@ static void launch_scam(mcmcx_engine *h, int it0, int it1)
     // waves of 128 registers spill the products' panels)
     int nw = 1;
     while (nw < 8 && (long long)h->ntiles * nw * 2 <= 2048) nw *= 2;
-    if (const char *e = getenv("MCMCX_SCAM_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) nw = v; }   // A/B switch for tests
+    { const int v = h->sw.scam_waves; if (v == 1 || v == 2 || v == 4 || v == 8) nw = v; }   // A/B switch for tests
     const size_t lds = (size_t)(4 * ((h->d + 15) / 16) + 2) * 64 * sizeof(double);
     const dim3 g(h->ntiles);
     switch (nw) {
@@ -544,7 +559,7 @@ static int svd_block_width(int d)
 static bool svd_blocked(const mcmcx_engine *h)
 {
     if (!h->usesvd || h->pooled || h->cfg.method == MCMCX_METHOD_RAM) return false;
-    if (const char *e = getenv("MCMCX_SVD_LANE")) if (atoi(e)) return false;          // A/B switch for tests: one lane per chain
+    if (h->sw.svd_lane > 0) return false;                                             // A/B switch for tests: one lane per chain
     return h->d >= 48;
 }
 static void launch_adapt(mcmcx_engine *h, int it, int mode)
@@ -554,9 +569,9 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
     hipLaunchKernelGGL(adapt_pre_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it, mode);
     // covmat's batch branch in blocks (adapt_covb_*): the AP window at every adaptation; with initcmatn = 0 the first AM adaptation and
     // the greedy restarts.  Which lanes take it is the lanes' own business (ADF_BATCH); a tick that cannot hold any skips the launches.
-    const bool td = !(getenv("MCMCX_COV_TD") && atoi(getenv("MCMCX_COV_TD")) == 0);
+    const bool td = h->sw.cov_td != 0;
     const bool ap = (mode & AD_AM) && h->cfg.adapthist > 1;
-    const int batch_done = (td && !(getenv("MCMCX_COV_BATCH_ROWS") && atoi(getenv("MCMCX_COV_BATCH_ROWS"))) &&      // (A/B switch for tests: covmat_rows)
+    const int batch_done = (td && !(h->sw.cov_batch_rows > 0) &&                                                    // (A/B switch for tests: covmat_rows)
                             (ap || (h->cfg.initcmatn == 0 && ((mode & AD_FIRST) || ((mode & AD_BURN) && h->cfg.greedy != 0))))) ? 1 : 0;
     if (batch_done) {
         const int n10 = (h->d + TD - 1) / TD, noff = n10 * (n10 - 1) / 2;
@@ -566,7 +581,7 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
     }
     if (!((mode & AD_AM) && h->cfg.adapthist > 1)) {                      // the AP window is a batch recompute: no blocked update
         // blocks of ten (triangular on the diagonal): fewer elements and fewer repeats of the per-fold overhead than the 8 x 8 cover
-        if (!(getenv("MCMCX_COV_TD") && atoi(getenv("MCMCX_COV_TD")) == 0)) {
+        if (td) {
             const int n10 = (h->d + TD - 1) / TD, noff = n10 * (n10 - 1) / 2;
             const unsigned g8 = (unsigned)(8 * ((h->ntiles + 7) / 8));
             hipLaunchKernelGGL(adapt_cov_diag_kernel, dim3(g8 * n10), dim3(64), 0, h->stream, h->E, it, mode, n10);
@@ -591,12 +606,12 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
     const size_t DD = (size_t)h->d * h->d;
     const dim3 tg((unsigned)((DD + 63) / 64), (unsigned)h->ntiles), tg1((unsigned)((h->d + 63) / 64), (unsigned)h->ntiles);
     const size_t lsv = svd_lds(h->d, h->svd_b);
-    const bool svd_reg = !(getenv("MCMCX_SVD_REG") && atoi(getenv("MCMCX_SVD_REG")) == 0);         // (0: A/B, tests -- svd_sweep_kernel)
-    const bool svd_stream = !(getenv("MCMCX_SVD_STREAM") && atoi(getenv("MCMCX_SVD_STREAM")) == 0);   // (0: A/B, tests -- svd_sweep_reg_kernel)
+    const bool svd_reg = h->sw.svd_reg != 0;                                                       // (0: A/B, tests -- svd_sweep_kernel)
+    const bool svd_stream = h->sw.svd_stream != 0;                                                    // (0: A/B, tests -- svd_sweep_reg_kernel)
     int svd_sb = 24;                                     // pair-lanes of the streamed sweep: whole waves of octets, one wave of loaders at least
-    bool svd_s32 = h->d <= 200 && !(getenv("MCMCX_SVD_STREAM32") && atoi(getenv("MCMCX_SVD_STREAM32")) == 0);   // (0, or a block width given: svd_sweep_stream_kernel)
-    bool svd_a32 = !(getenv("MCMCX_SVD_STREAM32") && atoi(getenv("MCMCX_SVD_STREAM32")) == 0);     // the V replay's 32-lane form: any npar
-    if (const char *e = getenv("MCMCX_SVD_STREAM_B")) { const int b = atoi(e); if (b >= 2 && b <= 24) { svd_sb = b; svd_s32 = false; svd_a32 = false; } }
+    bool svd_s32 = h->d <= 200 && h->sw.svd_stream32 != 0;                                                      // (0, or a block width given: svd_sweep_stream_kernel)
+    bool svd_a32 = h->sw.svd_stream32 != 0;                                                        // the V replay's 32-lane form: any npar
+    { const int b = h->sw.svd_stream_b; if (b >= 2 && b <= 24) { svd_sb = b; svd_s32 = false; svd_a32 = false; } }
     hipLaunchKernelGGL(adapt_post_kernel<true>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 1, h->d_need, batch_done);
     hipLaunchKernelGGL(tile2chain_kernel, tg, dim3(256), 0, h->stream, h->E.Gw, h->d_Gc, DD, DD, h->d_need);
     hipLaunchKernelGGL(svd_init_kernel, dim3(h->nlanes), dim3(256), 0, h->stream, h->d_Vc, h->d_state, h->d_need, h->nlanes, h->d);
@@ -1255,6 +1270,7 @@ int mcmcx_create(const mcmcx_config *cfg_in, mcmcx_handle *out)
     if (c.device < 0 || c.device >= ndev) return fail(-10, "bad device ordinal");
     HIPCHK(hipSetDevice(c.device));
     mcmcx_engine *h = new mcmcx_engine();
+    h->sw.read();
     h->cfg = c; h->d = c.npar; h->P = c.npar * (c.npar + 1) / 2;
     h->ntiles = (c.nchains + 63) / 64; h->nlanes = h->ntiles * 64;
     h->dodr = (c.drscale > 0.0) ? 1 : 0; h->usesvd = (c.condmax > 0.0) ? 1 : 0; h->pooled = c.pooled ? 1 : 0;
@@ -1418,6 +1434,7 @@ int mcmcx_init(mcmcx_handle h)
     if (!h) return fail(-1, "null handle");
     if (h->inited) return fail(1, "Warning(mcmcinit): allready inited");            // MCMC_init.F90:24-27
     HIPCHK(hipSetDevice(h->cfg.device));
+    h->sw.read();                                    // the A/B switches as the environment has them now: fixed for the engine's life
     const mcmcx_config &c = h->cfg;
     const int d = h->d, P = h->P, T = h->ntiles;
     if ((int)h->par0.size() != d) return fail(-30, "user initialization error: par0 not set");
@@ -1666,7 +1683,7 @@ int mcmcx_init(mcmcx_handle h)
                 if ((rc = dev_alloc(h, &h->d_sharedR2, h->usesvd ? (size_t)((d + 3) & ~3) * d + PWS : (size_t)P, false))) return rc;
                 if ((rc = dev_alloc(h, &h->d_sharediC, (size_t)P, false))) return rc;
                 if (c.method == MCMCX_METHOD_DRAM && h->d_sharedRT && pooled_mfma_lds(d) <= 160 * 1024 &&
-                    !(getenv("MCMCX_POOLED_SCALAR") && atoi(getenv("MCMCX_POOLED_SCALAR")))) {          // the second stage on the matrix cores too
+                    !(h->sw.pooled_scalar > 0)) {          // the second stage on the matrix cores too
                     if ((rc = dev_alloc(h, &h->d_sharedR2T, (size_t)((d + 3) & ~3) * d + PWS, false))) return rc;
                     if ((rc = dev_alloc(h, &h->d_sharediCd, (size_t)((d + 3) & ~3) * d + PWS, false))) return rc;
                 }
