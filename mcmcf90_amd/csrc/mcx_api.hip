@@ -37,14 +37,14 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // mcmcx_init -- never at launch time.  -1 = not set.
 struct mcx_switches {
     int pooled_mfma_dr_min = -1, pooled_scalar = -1, dr_big = -1, dr_general = -1, scam_pooled_16 = -1, scam_fast_lanes = -1, scam_waves = -1,
-        svd_lane = -1, cov_td = -1, cov_batch_rows = -1, svd_reg = -1, svd_stream = -1, svd_stream32 = -1, svd_stream_b = -1;
+        svd_lane = -1, cov_td = -1, cov_batch_rows = -1, svd_reg = -1, svd_stream = -1, svd_stream32 = -1, svd_stream_b = -1, ram_wide = -1;
     static int get(const char *name) { const char *e = getenv(name); return e ? atoi(e) : -1; }
     void read()
     {
         pooled_mfma_dr_min = get("MCMCX_POOLED_MFMA_DR_MIN"); pooled_scalar = get("MCMCX_POOLED_SCALAR"); dr_big = get("MCMCX_DR_BIG");
         dr_general = get("MCMCX_DR_GENERAL"); scam_pooled_16 = get("MCMCX_SCAM_POOLED_16"); scam_fast_lanes = get("MCMCX_SCAM_FAST_LANES");
         scam_waves = get("MCMCX_SCAM_WAVES"); svd_lane = get("MCMCX_SVD_LANE"); cov_td = get("MCMCX_COV_TD"); cov_batch_rows = get("MCMCX_COV_BATCH_ROWS");
-        svd_reg = get("MCMCX_SVD_REG"); svd_stream = get("MCMCX_SVD_STREAM"); svd_stream32 = get("MCMCX_SVD_STREAM32"); svd_stream_b = get("MCMCX_SVD_STREAM_B");
+        svd_reg = get("MCMCX_SVD_REG"); svd_stream = get("MCMCX_SVD_STREAM"); svd_stream32 = get("MCMCX_SVD_STREAM32"); svd_stream_b = get("MCMCX_SVD_STREAM_B"); ram_wide = get("MCMCX_RAM_WIDE");
     }
 };
 struct mcmcx_engine {
@@ -440,6 +440,7 @@ static void launch_step(mcmcx_engine *h, int it0, int it1)
     else if (h->pooled) LAUNCHK((step_kernel<false, false, true>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->E.method == M_RAM && h->usesvd) LAUNCHK(step_kernel_ram_fullr, g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->E.method == M_RAM && h->E.lds_scratch == 3) LAUNCHK(step_kernel_ram_ldsr, g, b, (size_t)(2 * h->d + h->P) * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
+    else if (h->E.method == M_RAM && h->d > RAM_SMALL_MAX && h->sw.ram_wide != 0) LAUNCHK(step_kernel_ram_wide, g, b, (size_t)NLC * 2 * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->E.method == M_RAM) LAUNCHK((step_kernel<true, false, false>), g, b, (size_t)NLC * 2 * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
     else if (h->dodr && !dr_vectors_in_lds(h))            // the second stage's two vectors in global scratch
         LAUNCHK(step_kernel_dr_big, g, b, 0, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);

@@ -221,6 +221,15 @@ constexpr int PW = 8;     // panel width: columns (or rows) of per-lane state he
 #define MCX_TW 10
 #endif
 constexpr int RW = MCX_RW;  // panel width of the RAM sweep (d = 50: five full panels)
+// step_kernel_ram_wide (npar > RAM_SMALL_MAX, round 4): column panels up to RW_WIDE wide, as few as that allows and as equal as possible
+// (npar 50: 17 + 17 + 16) -- every panel re-reads the rotations and the next normals of the rows above it.  A kernel of its own: the
+// narrow panels in 17-element register rows, or both widths instantiated in one kernel, cost 11-15 % at npar <= 20 (tools/ram_rw_probe.py);
+// 19 columns spill at two waves per SIMD.
+#ifndef MCX_RW_WIDE
+#define MCX_RW_WIDE 17
+#endif
+constexpr int RW_WIDE = MCX_RW_WIDE, RAM_SMALL_MAX = 20;
+MCX_DEV int ram_panel_width(int d, int rwmax) { const int np = (d + rwmax - 1) / rwmax; return (d + np - 1) / np; }
 constexpr int TW = MCX_TW;  // panel width of the per-chain triangular product
 
 // One block of 16 rows of the Gaussian target (mcxt_ss_gauss, oracle/mcx_targets.h): y_i = sum_j lam(i,j) v_j as fma chains
@@ -851,13 +860,14 @@ constexpr int NLC = MCX_NLC;     // 19 rows x 2 doubles x 64 lanes = 19 456 B pe
 // takes longer than read all + write all), so in such a wave every lane stores in both sweeps -- the lanes a sweep does
 // not concern store the value they loaded -- and each sweep writes whole segments.  A wave of one kind (the bench's
 // default start: no downdates) takes the other instantiation, whose update sweep stores from inside its own branch.
-template <bool MIXED>
+template <bool MIXED, int RWT = RW>
 MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, double *cs_t, double *P_t,
                         const double *theta_t, int lane, int d, double a, double su, bool act, bool fuse, uint32_t &status,
                         double *lc, bool &pdesc)
 {
     const bool up = act && (a >= 0.0);
     const bool down = act && !(a >= 0.0);
+    const int rwe = (RWT == RW) ? RW : ram_panel_width(d, RWT);       // RW: panels of ten (the last one narrower); wide: equal panels
     // per-chain scratch pair k (rotation c_k, s_k; for a downdate lane first the substitution's a_k): rows < NLC in LDS
 #define CS_(k, w) (*((lc && (k) < NLC) ? &lc[(2 * (k) + (w)) * 64 + lane] : &cs_t[(size_t)(2 * (k) + (w)) * 64 + lane]))
     // ---- pass A, rows ascending, one read of the factor for both kinds of lanes: update lanes rotate (DCHUD), write and
@@ -865,39 +875,39 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
     // -u/sum(u**2)*a), whose solution goes to cs_t[2i+1].  xa = DCHUD's work vector x, or the substitution's partial sums.
     if (__any(act)) {
         if (act) {
-            for (int J0 = 0; J0 < d; J0 += RW) {
-                const int nw = (d - J0) < RW ? (d - J0) : RW;
-                double xa[RW], P[RW];
+            for (int J0 = 0; J0 < d; J0 += rwe) {
+                const int nw = (d - J0) < rwe ? (d - J0) : rwe;
+                double xa[RWT], P[RWT];
 #pragma unroll
-                for (int u = 0; u < RW; ++u) { xa[u] = up ? GV(zc_t, J0 + (u < nw ? u : nw - 1)) / su * a : 0.0; P[u] = 0.0; }   // x = u/sum(u**2)*a
+                for (int u = 0; u < RWT; ++u) { xa[u] = up ? GV(zc_t, J0 + (u < nw ? u : nw - 1)) / su * a : 0.0; P[u] = 0.0; }   // x = u/sum(u**2)*a
 if (MIXED) {
                     // next row's loads before this row's stores (see sweep B)
                     // (c, s) of an update lane or the substitution's a_i of a downdate lane, and z_next: one row ahead as well
-                    double rn[RW], cn = 0.0, sn_ = 0.0, zn_ = 0.0;
+                    double rn[RWT], cn = 0.0, sn_ = 0.0, zn_ = 0.0;
                     if (J0 > 0) {
                         const double *sg = Rt + (size_t)J0 * 64;
 #pragma unroll
-                        for (int u = 0; u < RW; ++u) rn[u] = LDNT(sg, u < nw ? u : nw - 1);
+                        for (int u = 0; u < RWT; ++u) rn[u] = LDNT(sg, u < nw ? u : nw - 1);
                         sn_ = CS_(0, 1);
                         if (up) { cn = CS_(0, 0); zn_ = fuse ? GV(zn_t, 0) : 0.0; }
                     }
 #pragma unroll MCX_MIXED_UNROLL
                     for (int i = 0; i < J0; ++i) {                       // rows above the diagonal block
                         double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
-                        double r[RW];
+                        double r[RWT];
 #pragma unroll
-                        for (int u = 0; u < RW; ++u) r[u] = rn[u];
+                        for (int u = 0; u < RWT; ++u) r[u] = rn[u];
                         const double c = cn, sn = sn_, zi = zn_;
                         if (i + 1 < J0) {
                             const double *sg = Rt + (size_t)(rowstart(i + 1, d) + J0 - (i + 1)) * 64;
 #pragma unroll
-                            for (int u = 0; u < RW; ++u) rn[u] = LDNT(sg, u < nw ? u : nw - 1);
+                            for (int u = 0; u < RWT; ++u) rn[u] = LDNT(sg, u < nw ? u : nw - 1);
                             sn_ = CS_(i + 1, 1);
                             if (up) { cn = CS_(i + 1, 0); zn_ = fuse ? GV(zn_t, i + 1) : 0.0; }
                         }
                         if (up) {
 #pragma unroll
-                            for (int u = 0; u < RW; ++u) {
+                            for (int u = 0; u < RWT; ++u) {
                                 double t = c * r[u] + sn * xa[u];
                                 xa[u] = c * xa[u] - sn * r[u];
                                 r[u] = t;
@@ -905,25 +915,25 @@ if (MIXED) {
                             }
                         } else {
 #pragma unroll
-                            for (int u = 0; u < RW; ++u) xa[u] = dfma(r[u], sn, xa[u]);
+                            for (int u = 0; u < RWT; ++u) xa[u] = dfma(r[u], sn, xa[u]);
                         }
 #pragma unroll
-                        for (int u = 0; u < RW; ++u) if (u < nw) STNT(seg, u, r[u]);
+                        for (int u = 0; u < RWT; ++u) if (u < nw) STNT(seg, u, r[u]);
                     }
                 } else {
 #pragma unroll 2
                     for (int i = 0; i < J0; ++i) {                       // rows above the diagonal block
                         double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
-                        double r[RW];
+                        double r[RWT];
 #pragma unroll
-                        for (int u = 0; u < RW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
+                        for (int u = 0; u < RWT; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
                         if (up) {
                             const bool inl = lc && i < NLC;
                             const double c = inl ? lc[(2 * i) * 64 + lane] : GV(cs_t, 2 * i);
                             const double sn = inl ? lc[(2 * i + 1) * 64 + lane] : GV(cs_t, 2 * i + 1);
                             const double zi = fuse ? GV(zn_t, i) : 0.0;
 #pragma unroll
-                            for (int u = 0; u < RW; ++u) {
+                            for (int u = 0; u < RWT; ++u) {
                                 double t = c * r[u] + sn * xa[u];
                                 xa[u] = c * xa[u] - sn * r[u];
                                 if (u < nw) STNT(seg, u, t);
@@ -932,19 +942,19 @@ if (MIXED) {
                         } else {
                             const double si = CS_(i, 1);
 #pragma unroll
-                            for (int u = 0; u < RW; ++u) xa[u] = dfma(r[u], si, xa[u]);
+                            for (int u = 0; u < RWT; ++u) xa[u] = dfma(r[u], si, xa[u]);
                         }
                     }
                 }
                 for (int i = J0; i < J0 + nw; ++i) {                     // diagonal block
                     double *seg = Rt + (size_t)rowstart(i, d) * 64;
                     const int ui = i - J0, m = d - 1 - i;
-                    double r[RW];
+                    double r[RWT];
 #pragma unroll
-                    for (int u = 0; u < RW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
+                    for (int u = 0; u < RWT; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
                     double xi = xa[0];
 #pragma unroll
-                    for (int u = 1; u < RW; ++u) xi = (u == ui) ? xa[u] : xi;
+                    for (int u = 1; u < RWT; ++u) xi = (u == ui) ? xa[u] : xi;
                     if (up) {
                         const double zi = fuse ? GV(zn_t, i) : 0.0;
                         double rr, c, sn;
@@ -953,7 +963,7 @@ if (MIXED) {
                         if (lc && i < NLC) { lc[(2 * i) * 64 + lane] = c; lc[(2 * i + 1) * 64 + lane] = sn; }
                         else { GV(cs_t, 2 * i) = c; GV(cs_t, 2 * i + 1) = sn; }
 #pragma unroll
-                        for (int u = 0; u < RW; ++u) {
+                        for (int u = 0; u < RWT; ++u) {
                             const bool off = (u > ui) && (u < nw);
                             double t = c * r[u] + sn * xa[u];
                             double nx = c * xa[u] - sn * r[u];
@@ -969,19 +979,19 @@ if (MIXED) {
                         si = si / GV(seg, 0);
                         CS_(i, 1) = si;
 #pragma unroll
-                        for (int u = 0; u < RW; ++u) { double na = dfma(r[u], si, xa[u]); xa[u] = (u > ui) ? na : xa[u]; }
+                        for (int u = 0; u < RWT; ++u) { double na = dfma(r[u], si, xa[u]); xa[u] = (u > ui) ? na : xa[u]; }
                     }
                     if (MIXED) {                                         // the off-diagonal part of the row, every lane
 #pragma unroll
-                        for (int u = 0; u < RW; ++u) if ((u > ui) && (u < nw)) STNT(seg, u - ui, r[u]);
+                        for (int u = 0; u < RWT; ++u) if ((u > ui) && (u < nw)) STNT(seg, u - ui, r[u]);
                     }
                 }
                 if (up && fuse) {                        // next candidate = theta + R_new' z_next (MCMC_DRAM.F90:29)
-                    double th[RW];                       // the state's loads before the candidate's stores (see copy_vec)
+                    double th[RWT];                       // the state's loads before the candidate's stores (see copy_vec)
 #pragma unroll
-                    for (int u = 0; u < RW; ++u) th[u] = GV(theta_t, J0 + (u < nw ? u : nw - 1));
+                    for (int u = 0; u < RWT; ++u) th[u] = GV(theta_t, J0 + (u < nw ? u : nw - 1));
 #pragma unroll
-                    for (int u = 0; u < RW; ++u) if (u < nw) GV(P_t, J0 + u) = th[u] + P[u];
+                    for (int u = 0; u < RWT; ++u) if (u < nw) GV(P_t, J0 + u) = th[u] + P[u];
                 }
             }
         }
@@ -1031,22 +1041,22 @@ if (MIXED) {
         const bool touch = MIXED ? act : down_ok;
         if (__any(down_ok)) {
             if (touch) {
-                for (int J0 = 0; J0 < d; J0 += RW) {
-                    const int nw = (d - J0) < RW ? (d - J0) : RW;
-                    double xx[RW], P[RW];
+                for (int J0 = 0; J0 < d; J0 += rwe) {
+                    const int nw = (d - J0) < rwe ? (d - J0) : rwe;
+                    double xx[RWT], P[RWT];
 #pragma unroll
-                    for (int u = 0; u < RW; ++u) { xx[u] = 0.0; P[u] = 0.0; }
+                    for (int u = 0; u < RWT; ++u) { xx[u] = 0.0; P[u] = 0.0; }
                     for (int i = J0 + nw - 1; i >= J0; --i) {            // diagonal block, rows descending
                         double *seg = Rt + (size_t)rowstart(i, d) * 64;
                         const int ui = i - J0, m = d - 1 - i;
-                        double r[RW];
+                        double r[RWT];
 #pragma unroll
-                        for (int u = 0; u < RW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDB(seg, k); }
+                        for (int u = 0; u < RWT; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDB(seg, k); }
                         if (!MIXED || down_ok) {
                             const double ci = CS_(i, 0), si = CS_(i, 1);
                             const double zi = fuse ? GV(zn_t, i) : 0.0;
 #pragma unroll
-                            for (int u = 0; u < RW; ++u) {
+                            for (int u = 0; u < RWT; ++u) {
                                 const bool on = (u >= ui) && (u < nw);
                                 double t = ci * xx[u] + si * r[u];
                                 double nr = ci * r[u] - si * xx[u];
@@ -1059,36 +1069,36 @@ if (MIXED) {
                         }
                         if (MIXED) {
 #pragma unroll
-                            for (int u = 0; u < RW; ++u) if ((u >= ui) && (u < nw)) STB(seg, u - ui, r[u]);
+                            for (int u = 0; u < RWT; ++u) if ((u >= ui) && (u < nw)) STB(seg, u - ui, r[u]);
                         }
                     }
 if (MIXED) {
                         // The next row's loads go out before this row's stores: vmcnt retires in order, so a load issued
                         // after a store cannot be waited for without waiting for that store's acknowledgement -- which
                         // would put the store latency on every row's critical path.
-                        double rn[RW], cn = 0.0, sn_ = 0.0, zn_ = 0.0;
+                        double rn[RWT], cn = 0.0, sn_ = 0.0, zn_ = 0.0;
                         if (J0 > 0) {
                             const double *sg = Rt + (size_t)(rowstart(J0 - 1, d) + 1) * 64;
 #pragma unroll
-                            for (int u = 0; u < RW; ++u) rn[u] = LDB(sg, u < nw ? u : nw - 1);
+                            for (int u = 0; u < RWT; ++u) rn[u] = LDB(sg, u < nw ? u : nw - 1);
                             if (down_ok) { cn = CS_(J0 - 1, 0); sn_ = CS_(J0 - 1, 1); zn_ = fuse ? GV(zn_t, J0 - 1) : 0.0; }
                         }
 #pragma unroll MCX_MIXED_UNROLL
                         for (int i = J0 - 1; i >= 0; --i) {              // rows above, descending
                             double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
-                            double r[RW];
+                            double r[RWT];
 #pragma unroll
-                            for (int u = 0; u < RW; ++u) r[u] = rn[u];
+                            for (int u = 0; u < RWT; ++u) r[u] = rn[u];
                             const double ci = cn, si = sn_, zi = zn_;
                             if (i > 0) {
                                 const double *sg = Rt + (size_t)(rowstart(i - 1, d) + J0 - (i - 1)) * 64;
 #pragma unroll
-                                for (int u = 0; u < RW; ++u) rn[u] = LDB(sg, u < nw ? u : nw - 1);
+                                for (int u = 0; u < RWT; ++u) rn[u] = LDB(sg, u < nw ? u : nw - 1);
                                 if (down_ok) { cn = CS_(i - 1, 0); sn_ = CS_(i - 1, 1); zn_ = fuse ? GV(zn_t, i - 1) : 0.0; }
                             }
                             if (down_ok) {
 #pragma unroll
-                                for (int u = 0; u < RW; ++u) {
+                                for (int u = 0; u < RWT; ++u) {
                                     double t = ci * xx[u] + si * r[u];
                                     const double nr = ci * r[u] - si * xx[u];
                                     r[u] = nr;
@@ -1097,7 +1107,7 @@ if (MIXED) {
                                 }
                             }
 #pragma unroll
-                            for (int u = 0; u < RW; ++u) if (u < nw) STB(seg, u, r[u]);
+                            for (int u = 0; u < RWT; ++u) if (u < nw) STB(seg, u, r[u]);
                         }
                     } else {
 #pragma unroll 2
@@ -1105,11 +1115,11 @@ if (MIXED) {
                             double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
                             const double ci = CS_(i, 0), si = CS_(i, 1);
                             const double zi = fuse ? GV(zn_t, i) : 0.0;
-                            double r[RW];
+                            double r[RWT];
 #pragma unroll
-                            for (int u = 0; u < RW; ++u) r[u] = LDB(seg, u < nw ? u : nw - 1);
+                            for (int u = 0; u < RWT; ++u) r[u] = LDB(seg, u < nw ? u : nw - 1);
 #pragma unroll
-                            for (int u = 0; u < RW; ++u) {
+                            for (int u = 0; u < RWT; ++u) {
                                 double t = ci * xx[u] + si * r[u];
                                 const double nr = ci * r[u] - si * xx[u];
                                 if (u < nw) STB(seg, u, nr);
@@ -1119,11 +1129,11 @@ if (MIXED) {
                         }
                     }
                     if (fuse && down_ok) {
-                        double th[RW];
+                        double th[RWT];
 #pragma unroll
-                        for (int u = 0; u < RW; ++u) th[u] = GV(theta_t, J0 + (u < nw ? u : nw - 1));
+                        for (int u = 0; u < RWT; ++u) th[u] = GV(theta_t, J0 + (u < nw ? u : nw - 1));
 #pragma unroll
-                        for (int u = 0; u < RW; ++u) if (u < nw) GV(P_t, J0 + u) = th[u] + P[u];
+                        for (int u = 0; u < RWT; ++u) if (u < nw) GV(P_t, J0 + u) = th[u] + P[u];
                     }
                 }
             }
@@ -1258,7 +1268,7 @@ MCX_DEV double quadform_sym_shared(const double *__restrict__ Ss, int lane, int 
 // Iterations it0..it1 (absolute simuind) of MCMC_run (MCMC_run.F90:41-107) or MCMC_run_ram
 // (MCMC_run_ram.F90:45-81) for one tile of 64 chains.  LDS is used only by the delayed-rejection
 // quadratic forms (2*d*64 doubles when dodr, none otherwise).
-template <bool RAM, bool DR, bool POOLED, bool WIDE_T = (RAM || (!DR && !POOLED)), bool FULLR = false, bool LDSV = false, bool LDSR = false, bool XG = false>
+template <bool RAM, bool DR, bool POOLED, bool WIDE_T = (RAM || (!DR && !POOLED)), bool FULLR = false, bool LDSV = false, bool LDSR = false, bool XG = false, int RWT = RW>
 MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__restrict__ ramscale,
                        const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
                        const double *__restrict__ g_sharedR, const double *__restrict__ g_sharedR2 = nullptr,
@@ -1404,8 +1414,8 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
             downs += (a >= 0.0) ? 0u : 1u;
             if (FULLR) ram_update_full(E.Rf + (size_t)tile * d * d * 64, zc_t, cs_t, lane, d, a, su_c, true, status);   // condmax > 0
             else if (__any(!(a >= 0.0)))                  // a wave with downdate lanes: whole-segment stores in both sweeps
-                have_p = ram_update<true>(Rt, zc_t, zn_t, cs_t, cand_t, theta_t, lane, d, a, su_c, true, pre, status, RAM ? X : nullptr, pdesc);
-            else have_p = ram_update<false>(Rt, zc_t, zn_t, cs_t, cand_t, theta_t, lane, d, a, su_c, true, pre, status, RAM ? X : nullptr, pdesc);
+                have_p = ram_update<true, RWT>(Rt, zc_t, zn_t, cs_t, cand_t, theta_t, lane, d, a, su_c, true, pre, status, RAM ? X : nullptr, pdesc);
+            else have_p = ram_update<false, RWT>(Rt, zc_t, zn_t, cs_t, cand_t, theta_t, lane, d, a, su_c, true, pre, status, RAM ? X : nullptr, pdesc);
         }
         su_c = su_n;
     }
@@ -1653,6 +1663,12 @@ __global__ __launch_bounds__(64, 2) void step_kernel_ram_ldsr(EngineDev E, int i
                                                      const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
                                                      const double *__restrict__ g_sharedR)
 { step_body<true, false, false, true, false, false, true>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
+
+// method='ram' above npar 20: step_kernel<true, false, false> with the wide column panels (RW_WIDE above)
+__global__ __launch_bounds__(64, MCX_RAM_WAVES) void step_kernel_ram_wide(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
+                                                     const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
+                                                     const double *__restrict__ g_sharedR)
+{ step_body<true, false, false, true, false, false, false, false, RW_WIDE>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
 
 // pooled mode with delayed rejection: the shared factor, its second-stage copy R2 = R / drscale and the shared inverse
 // covariance iC = dpotri(R) all come through the scalar cache (the host recomputes the three at every pooled tick)

@@ -502,6 +502,47 @@ def test_batch_branch_in_blocks_equals_row_form_and_oracle(oracle, case, monkeyp
         assert a[3][i] == o.rng_n
 
 
+@pytest.mark.parametrize("d", [21, 34, 50, 64, 100])
+@pytest.mark.parametrize("start", ["default", "target"])
+def test_ram_wide_panels(oracle, d, start, monkeypatch):
+    """method='ram' above npar 20: step_kernel_ram_wide sweeps the factor in equal column panels up to 17 wide (21: 11 + 10, 34: 17 + 17,
+    50: 17 + 17 + 16, 64: four of 16, 100: six of 17 / 15) instead of panels of ten.  Same chain bit for bit as step_kernel<true, false, false>
+    (MCMCX_RAM_WIDE=0) and as the oracle -- update lanes alone (default start) and update and downdate lanes mixed (start = target), a ragged
+    tile, several launches, the sigma2 update and bounds at one size each."""
+    from mcmcf90_amd import engine_from_problem
+    rng = np.random.default_rng(140 + d)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    lam = A @ A.T + np.eye(d)
+    cm0 = np.linalg.inv(lam) if start == "target" else 0.01 * np.eye(d)
+    ckw = dict(nsimu=130, method="ram", adaptint=100, updatesigma=1 if d == 34 else 0)
+    pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.1), cmat0=cm0, mu=np.linspace(-0.5, 0.5, d), lam=lam)
+    if d == 21:
+        pkw.update(lo=np.full(d, -2.5), hi=np.full(d, 2.5))
+    if d == 34:
+        pkw.update(sigma2=0.9, nobs=20)
+    res = []
+    for narrow in (0, 1):
+        if narrow:
+            monkeypatch.setenv("MCMCX_RAM_WIDE", "0")
+        e = engine_from_problem(ckw, pkw, nchains=70, chain_id0=4, record_accept=1)
+        e.init(); e.run(60); e.run(61); e.run()
+        assert e.last_kernel() == ("step_kernel<true, false, false>" if narrow else "step_kernel_ram_wide")
+        res.append((e.theta().copy(), e.accept_masks().copy(), [e.R(c).copy() for c in (0, 63, 69)], [e.rng(c)[0] for c in (0, 63, 69)], e.totals()["downdates"]))
+        e.close()
+    a, b = res
+    assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1]) and a[3] == b[3] and a[4] == b[4]
+    for x, y in zip(a[2], b[2]):
+        np.testing.assert_array_equal(_bits(x), _bits(y))
+    if start == "target":
+        assert a[4] > 0
+    cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
+    for i, c in enumerate((0, 69)):
+        o = oracle.run_chain(cfg, prob, chain_id=4 + c)
+        np.testing.assert_array_equal(_bits(a[0][c]), _bits(o.theta))
+        np.testing.assert_array_equal(_bits(np.triu(a[2][0 if c == 0 else 2])), _bits(np.triu(o.R)))
+        assert a[3][0 if c == 0 else 2] == o.rng_n
+
+
 @pytest.mark.parametrize("d", [1, 3, 7, 10])
 @pytest.mark.parametrize("start", ["default", "target"])
 def test_ram_factor_in_lds(oracle, d, start, monkeypatch):
