@@ -173,6 +173,20 @@ MCX_DEV void copy_vec(double *dst, const double *src, double *h, int lane, int d
     for (; k < d; ++k) { const double v = GV(src, k); GV(dst, k) = v; if (h) GV(h, k) = v; }
 }
 
+// copy_vec with NL loads in flight and no element-by-element tail (the last batch re-reads its last element): for a wave that has its SIMD
+// almost to itself (pooled_mfma_kernel) every batch is a cache round trip nobody else covers
+template <int NL>
+MCX_DEV void copy_vec_wide(double *dst, const double *src, double *h, int lane, int d)
+{
+    for (int k = 0; k < d; k += NL) {
+        double v[NL];
+#pragma unroll
+        for (int u = 0; u < NL; ++u) v[u] = GV(src, (k + u < d) ? k + u : d - 1);
+#pragma unroll
+        for (int u = 0; u < NL; ++u) if (k + u < d) { GV(dst, k + u) = v[u]; if (h) GV(h, k + u) = v[u]; }
+    }
+}
+
 // dst[e] = f(src[e]), e < n, eight loads in flight (dst may be src): the element-by-element loop is a load-op-store round trip per
 // element for the same reason as in copy_vec
 template <typename F>
@@ -2266,6 +2280,12 @@ __global__ __launch_bounds__(768, 1) void scam_pooled12_kernel(EngineDev E, int 
 // 4 chain groups = 16 accumulators per pass.  Rows s beyond an output block's last column are zero in R and are
 // skipped (exact: they would add 0*z).  The results come back to lane = chain order through LDS (P) or as the
 // lane-local partial chains of ss (y).  Same arithmetic per chain as step_kernel<false,false,true>.
+#ifndef MCX_POOLED_KU
+#define MCX_POOLED_KU 4
+#endif
+#ifndef MCX_POOLED_CB
+#define MCX_POOLED_CB 16
+#endif
 template <bool TRI>
 MCX_DEV void mfma_wave_product(const double *__restrict__ M, const double *X, int lane, int d, int d4, int ob0, int nb,
                                mcx_d4 (&c)[4][4])
@@ -2279,19 +2299,33 @@ MCX_DEV void mfma_wave_product(const double *__restrict__ M, const double *X, in
     if (TRI) { const int last = 16 * (ob0 + nb); kmax = last < d4 ? last : d4; }
     const double *__restrict__ ap = M + (size_t)lk * d + 16 * ob0 + li;
     const double *xp = X + lk * 64 + li;
-    for (int s0 = 0; s0 < kmax; s0 += 4) {
-        double a[4];
+    // KU k-blocks per trip, their 4 KU loads of the shared table first: a trip waits for the L2 once -- one k-block per trip put thirteen
+    // round trips of ~1 us on each product of a wave that has the SIMD almost to itself (round 4: 0.93 -> 0.73 ms per iteration of 1 048 576
+    // chains at npar 50; two k-blocks per trip do almost as well, seven or eight are slower)
+    constexpr int KU = MCX_POOLED_KU;
+    for (int s0 = 0; s0 < kmax; s0 += 4 * KU) {
+        double a[KU][4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) a[b] = ap[(size_t)s0 * d + 16 * (b < nb ? b : 0)];
-        const double *xq = xp + s0 * 64;
-        const double b0 = xq[0], b1 = xq[16], b2 = xq[32], b3 = xq[48];
+        for (int u = 0; u < KU; ++u) {
+            const int s = (s0 + 4 * u < kmax) ? s0 + 4 * u : kmax - 4;          // (a k-block past the end: loaded again, not multiplied)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            if (b < nb && (!TRI || s0 < 16 * (ob0 + b + 1))) {
-                c[b][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[b], b0, c[b][0], 0, 0, 0);
-                c[b][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[b], b1, c[b][1], 0, 0, 0);
-                c[b][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[b], b2, c[b][2], 0, 0, 0);
-                c[b][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[b], b3, c[b][3], 0, 0, 0);
+            for (int b = 0; b < 4; ++b) a[u][b] = ap[(size_t)s * d + 16 * (b < nb ? b : 0)];
+        }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int s = s0 + 4 * u;
+            if (s < kmax) {
+                const double *xq = xp + s * 64;
+                const double b0 = xq[0], b1 = xq[16], b2 = xq[32], b3 = xq[48];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (b < nb && (!TRI || s < 16 * (ob0 + b + 1))) {
+                        c[b][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][b], b0, c[b][0], 0, 0, 0);
+                        c[b][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][b], b1, c[b][1], 0, 0, 0);
+                        c[b][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][b], b2, c[b][2], 0, 0, 0);
+                        c[b][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][b], b3, c[b][3], 0, 0, 0);
+                    }
+                }
             }
         }
     }
@@ -2382,12 +2416,13 @@ __global__ __launch_bounds__(64, DR ? 1 : MCX_POOLED_WAVES) void pooled_mfma_ker
     };
     // dst = theta + T (lane = chain), and v = dst - mu back into the LDS vector for the Gaussian target
     auto candidate_from_T = [&](double *dst_t) {
-        for (int k0 = 0; k0 < d; k0 += 8) {              // eight state elements' loads before the eight stores (see copy_vec)
-            double th[8], tv[8];
+        constexpr int CB = MCX_POOLED_CB;                // state elements' loads before their stores (see copy_vec): sixteen in flight
+        for (int k0 = 0; k0 < d; k0 += CB) {
+            double th[CB], tv[CB];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int k = (k0 + u < d) ? k0 + u : d - 1; th[u] = GV(theta_t, k); tv[u] = T[(size_t)k * 64 + lane]; }
+            for (int u = 0; u < CB; ++u) { const int k = (k0 + u < d) ? k0 + u : d - 1; th[u] = GV(theta_t, k); tv[u] = T[(size_t)k * 64 + lane]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < CB; ++u) {
                 if (k0 + u < d) {
                     const double cnd = th[u] + tv[u];
                     GV(dst_t, k0 + u) = cnd;
@@ -2477,7 +2512,7 @@ __global__ __launch_bounds__(64, DR ? 1 : MCX_POOLED_WAVES) void pooled_mfma_ker
         const int slot = it % E.wcap;
         if (!reject) {
             double *h = E.hist ? E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64 : nullptr;
-            copy_vec(theta_t, dr_moved ? c2_t : cand_t, h, lane, d);   // newpar = newpar2 when the DR try was accepted
+            copy_vec_wide<MCX_POOLED_CB>(theta_t, dr_moved ? c2_t : cand_t, h, lane, d);   // newpar = newpar2 when the DR try was accepted
             if (h) GV(h, d) = L.ss1;
         }
         if (E.hist) {
