@@ -3012,16 +3012,16 @@ MCX_DEV int calculate_R(const double *At, double *Tt, double *Rt, int lane, int 
 // the compiler must assume the vector and the matrix overlap
 MCX_DEV void potri_axpy_col(double *X, const double *At, int lane, int d, int n, int k, double temp)
 {
-    constexpr int NB = 4;                               // eight at a time is slower again (4.2 vs 3.9 ms at config 3: registers)
-    int r = 0;
-    for (; r + NB <= n; r += NB) {
+    // eight rows per trip, the last trip's spare slots re-read row n - 1 and are dropped: a trip is one cache round trip, and dpotri is
+    // ~1700 of them in a row at npar 20 (round 4; four rows per trip plus an element-by-element tail before)
+    constexpr int NB = 8;
+    for (int r = 0; r < n; r += NB) {
         double a[NB], x[NB];
 #pragma unroll
-        for (int u = 0; u < NB; ++u) { a[u] = GV(At, pidx(r + u, k, d)); x[u] = XL(r + u); }
+        for (int u = 0; u < NB; ++u) { const int ru = (r + u < n) ? r + u : n - 1; a[u] = GV(At, pidx(ru, k, d)); x[u] = XL(ru); }
 #pragma unroll
-        for (int u = 0; u < NB; ++u) XL(r + u) = dfma(temp, a[u], x[u]);
+        for (int u = 0; u < NB; ++u) if (r + u < n) XL(r + u) = dfma(temp, a[u], x[u]);
     }
-    for (; r < n; ++r) XL(r) = dfma(temp, GV(At, pidx(r, k, d)), XL(r));
 }
 MCX_DEV int potri_packed(double *At, int lane, int d, bool act, double *X)
 {
@@ -3034,12 +3034,27 @@ MCX_DEV int potri_packed(double *At, int lane, int d, bool act, double *X)
                 double ajj = 1.0 / GV(At, pidx(j, j, d));
                 GV(At, pidx(j, j, d)) = ajj;
                 ajj = -ajj;
-                for (int i = 0; i < j; ++i) XL(i) = GV(At, pidx(i, j, d));
-                for (int jj = 0; jj < j; ++jj) {             // dtrmv('U','N','N') with the inverted leading block
-                    double temp = XL(jj);
-                    if (temp != 0.0) {
-                        potri_axpy_col(X, At, lane, d, jj, jj, temp);
-                        XL(jj) = temp * GV(At, pidx(jj, jj, d));
+                for (int i0 = 0; i0 < j; i0 += 8) {             // (eight loads in flight: element by element every one is a cache round trip)
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = GV(At, pidx((i0 + u < j) ? i0 + u : j - 1, j, d));
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) if (i0 + u < j) XL(i0 + u) = v[u];
+                }
+                for (int j0 = 0; j0 < j; j0 += 8) {          // dtrmv('U','N','N') with the inverted leading block
+                    double dg[8];                            // (its diagonal: eight loads in flight)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) dg[u] = GV(At, pidx((j0 + u < j) ? j0 + u : j - 1, (j0 + u < j) ? j0 + u : j - 1, d));
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int jj = j0 + u;
+                        if (jj < j) {
+                            double temp = XL(jj);
+                            if (temp != 0.0) {
+                                potri_axpy_col(X, At, lane, d, jj, jj, temp);
+                                XL(jj) = temp * dg[u];
+                            }
+                        }
                     }
                 }
                 for (int i = 0; i < j; ++i) GV(At, pidx(i, j, d)) = ajj * XL(i);
@@ -3049,12 +3064,30 @@ MCX_DEV int potri_packed(double *At, int lane, int d, bool act, double *X)
                 double aii = GV(rowi, 0);
                 if (i < d - 1) {
                     double dot = 0.0;
-                    for (int k = 0; k < d - i; ++k) { double v = GV(rowi, k); dot = dfma(v, v, dot); }
+                    for (int k0 = 0; k0 < d - i; k0 += 8) {
+                        double v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = GV(rowi, (k0 + u < d - i) ? k0 + u : d - i - 1);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) if (k0 + u < d - i) dot = dfma(v[u], v[u], dot);
+                    }
                     GV(rowi, 0) = dot;
-                    for (int r = 0; r < i; ++r) XL(r) = aii * GV(At, pidx(r, i, d));
-                    for (int k = i + 1; k < d; ++k) {
-                        double temp = GV(rowi, k - i);
-                        if (temp != 0.0) potri_axpy_col(X, At, lane, d, i, k, temp);
+                    for (int r0 = 0; r0 < i; r0 += 8) {
+                        double v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = GV(At, pidx((r0 + u < i) ? r0 + u : i - 1, i, d));
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) if (r0 + u < i) XL(r0 + u) = aii * v[u];
+                    }
+                    for (int k0 = i + 1; k0 < d; k0 += 8) {
+                        double tv[8];                        // (row i's elements: eight loads in flight)
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) tv[u] = GV(rowi, ((k0 + u < d) ? k0 + u : d - 1) - i);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int k = k0 + u;
+                            if (k < d && tv[u] != 0.0) potri_axpy_col(X, At, lane, d, i, k, tv[u]);
+                        }
                     }
                     for (int r = 0; r < i; ++r) GV(At, pidx(r, i, d)) = XL(r);
                 } else {
