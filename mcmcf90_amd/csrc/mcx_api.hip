@@ -37,14 +37,14 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // mcmcx_init -- never at launch time.  -1 = not set.
 struct mcx_switches {
     int pooled_mfma_dr_min = -1, pooled_scalar = -1, dr_big = -1, dr_general = -1, scam_pooled_16 = -1, scam_fast_lanes = -1, scam_waves = -1,
-        svd_lane = -1, cov_td = -1, cov_batch_rows = -1, svd_reg = -1, svd_stream = -1, svd_stream32 = -1, svd_stream_b = -1, ram_wide = -1;
+        svd_lane = -1, cov_td = -1, cov_batch_rows = -1, svd_reg = -1, svd_stream = -1, svd_stream32 = -1, svd_stream_b = -1, ram_wide = -1, pooled_waves = -1;
     static int get(const char *name) { const char *e = getenv(name); return e ? atoi(e) : -1; }
     void read()
     {
         pooled_mfma_dr_min = get("MCMCX_POOLED_MFMA_DR_MIN"); pooled_scalar = get("MCMCX_POOLED_SCALAR"); dr_big = get("MCMCX_DR_BIG");
         dr_general = get("MCMCX_DR_GENERAL"); scam_pooled_16 = get("MCMCX_SCAM_POOLED_16"); scam_fast_lanes = get("MCMCX_SCAM_FAST_LANES");
         scam_waves = get("MCMCX_SCAM_WAVES"); svd_lane = get("MCMCX_SVD_LANE"); cov_td = get("MCMCX_COV_TD"); cov_batch_rows = get("MCMCX_COV_BATCH_ROWS");
-        svd_reg = get("MCMCX_SVD_REG"); svd_stream = get("MCMCX_SVD_STREAM"); svd_stream32 = get("MCMCX_SVD_STREAM32"); svd_stream_b = get("MCMCX_SVD_STREAM_B"); ram_wide = get("MCMCX_RAM_WIDE");
+        svd_reg = get("MCMCX_SVD_REG"); svd_stream = get("MCMCX_SVD_STREAM"); svd_stream32 = get("MCMCX_SVD_STREAM32"); svd_stream_b = get("MCMCX_SVD_STREAM_B"); ram_wide = get("MCMCX_RAM_WIDE"); pooled_waves = get("MCMCX_POOLED_WAVES");
     }
 };
 struct mcmcx_engine {
@@ -434,6 +434,13 @@ static void launch_step(mcmcx_engine *h, int it0, int it1)
     const double *rs = h->d_ramscale + it0;
     if (h->group_d4) { launch_group(h, it0, it1); return; }
     if (pooled_use_mfma(h) && h->dodr) LAUNCHK(pooled_mfma_kernel<true>, g, b, pooled_mfma_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedRT, h->d_sharedR2T, h->d_sharediCd);
+    // two waves per SIMD (256 registers, some state spilled) pay with more tiles than SIMDs: from two per SIMD where the LDS vector lets eight
+    // waves on a CU (npar <= 39: +25 .. +55 %), from eight where it lets six (npar 50: 0.80 at 2048 tiles, 0.99 at 4096, 1.14 at 16384);
+    // with one tile per SIMD the spills are all they buy (0.83 .. 0.90) -- tools/pooled_waves_probe.py
+    else if (pooled_use_mfma(h) && (h->sw.pooled_waves >= 0 ? h->sw.pooled_waves == 2 : h->ntiles >= (pooled_mfma_lds(h->d) * 8 <= 160 * 1024 ? 2048 : 8192))) {
+        hipLaunchKernelGGL((pooled_mfma_kernel<false, true>), g, b, pooled_mfma_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedRT, (const double *)nullptr, (const double *)nullptr);
+        h->last_kernel = "pooled_mfma_kernel<false>";
+    }
     else if (pooled_use_mfma(h)) LAUNCHK(pooled_mfma_kernel<false>, g, b, pooled_mfma_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedRT, (const double *)nullptr, (const double *)nullptr);
     else if (h->pooled && h->dodr && !dr_vectors_in_lds(h, 4)) LAUNCHK(step_kernel_pooled_dr_big, g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR, h->d_sharedR2, h->d_sharediC);
     else if (h->pooled && h->dodr) LAUNCHK(step_kernel_pooled_dr, g, b, lds_step(h), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR, h->d_sharedR2, h->d_sharediC);

@@ -2336,14 +2336,13 @@ MCX_DEV void mfma_wave_product(const double *__restrict__ M, const double *X, in
 // products against the dense symmetric table g_iCd, each followed by the chain q = sum_i y_i dx_i ascending in i (lane = chain:
 // y comes back through the LDS vector, dx waits in the chain's global scratch EngineDev::xscr).  Operation for operation
 // step_body<false, true, true> (the lane-per-chain form with the tables through the scalar cache), whose chains these are.
-// Without delayed rejection: 256 registers, so that two waves share a SIMD (the LDS vector lets six waves on a CU at npar 50: two SIMDs
-// with two).  The compiler spills ~40 doubles of state around the products to fit, and it is still 4 % faster (round 4; round 2's
-// attempt predates the single-pass LDS layout): 97.1 -> 93.2 ms per 100 iterations of 1 048 576 chains.
-#ifndef MCX_POOLED_WAVES
-#define MCX_POOLED_WAVES 2
-#endif
-template <bool DR>
-__global__ __launch_bounds__(64, DR ? 1 : MCX_POOLED_WAVES) void pooled_mfma_kernel(EngineDev E, int it0, int it1,
+// W2 (without delayed rejection): 256 registers, so that two waves share a SIMD (the LDS vector lets six waves on a CU at npar 50: two SIMDs
+// with two).  The compiler spills ~40 doubles of state around the products to fit, and with more tiles than SIMDs it is still faster (round 4;
+// round 2's attempt predates the single-pass LDS layout): 97.1 -> 93.2 ms per 100 iterations of 1 048 576 chains at npar 50.  With one tile
+// per SIMD or fewer there is nobody to share with and the spills are all it buys (npar 20, 65536 chains: 2.1e9 against 2.6e9 proposals/s):
+// the host takes the 512-register instance there.
+template <bool DR, bool W2 = false>
+__global__ __launch_bounds__(64, (!DR && W2) ? 2 : 1) void pooled_mfma_kernel(EngineDev E, int it0, int it1,
                                                          const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
                                                          const double *__restrict__ g_RT, const double *__restrict__ g_R2T,
                                                          const double *__restrict__ g_iCd)
