@@ -2,8 +2,10 @@
 """bench.py -- MH proposals/sec of the MI355X engine on BASELINE.json's headline workload.
 
 Workload "C4": correlated Gaussian target d=50 (Sigma_ij = 0.5^|i-j|, Lambda dense), method='ram'
-(MCMC_run_ram + MCMC_adapt_ram with a per-chain Cholesky factor), 131072 chains per GPU (the 8-GPU
-configuration of BASELINE.json is 1 048 576 chains = 131072 x 8: weak scaling), pooled
+(MCMC_run_ram + MCMC_adapt_ram with a per-chain Cholesky factor), BASELINE.json's 1 048 576 chains divided among
+the --gpus of the run (strong scaling: all of them on the one GPU at N = 1, 131072 per GPU at N = 8; `--plan` prints
+the sharding of any N without touching a GPU; rounds 1-3 ran 131072 chains per GPU at every N -- the line's
+`config.total_chains` says which problem a number belongs to), pooled
 empirical-moment reduction over all chains of all GPUs every `--its-per-step` iterations (RCCL
 all-gather + fixed tree inside libmcmcx.so when N > 1).  One bench "step" = --its-per-step MH
 iterations of every chain + that reduction.
@@ -68,6 +70,17 @@ def default_chains(wl, world):
         n = DEFAULT_CHAINS[wl] // world
         return max(64, n - n % 64)
     return DEFAULT_CHAINS[wl]
+
+
+def shard_plan(wl, world, chains_per_gpu=0):
+    """What `--gpus world` runs: rank r owns the chains [r n, (r + 1) n) (chain_id0 = r n keys their Philox streams, so the chains are the
+    same whatever the GPU count) -- n the configuration's chains divided by world for c4 / c5 (strong scaling: BASELINE.json
+    quotes them as ONE problem sharded over the node), the configuration's count per GPU for c2 / c3 (weak), or --chains-per-gpu."""
+    n = chains_per_gpu or default_chains(wl, world)
+    return {"workload": wl, "n_gpus": world, "chains_per_gpu": n, "total_chains": n * world,
+            "scaling": "strong" if (wl in STRONG and not chains_per_gpu) else "weak",
+            "ranks": [{"rank": r, "chain_id0": r * n, "chains": n, "device": r} for r in range(world)],
+            "collective": "none on the data path; pooled moments: all-gather of %s doubles per rank + fixed pairwise tree over ranks" % "1 + d + d (d + 1) / 2"}
 
 
 def alg_bytes_per_proposal(d, method, down_frac=0.0):
@@ -549,7 +562,7 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
         "value": value, "ms_per_step": dt / steps * 1e3,
         "config": {"workload": "%s, method=%s, %d chains/GPU, pooled moments of all %d chains combined every %d iterations (%s)%s"
                                % (WORKLOADS[wl], mode, n_local, world * n_local, ips, transport, regime),
-                   "chains_per_gpu": n_local, "its_per_step": ips, "npar": d, "method": method,
+                   "chains_per_gpu": n_local, "total_chains": world * n_local, "its_per_step": ips, "npar": d, "method": method,
                    "proposals_per_iteration": per_it + dr_per_it / (float(world) * n_local),
                    "parallelism": "chains sharded over %d GPU(s), one process each" % world},
         "roofline": roof,
@@ -604,7 +617,12 @@ def main():
     ap.add_argument("--one-gpu-dryrun", action="store_true",
                     help="debug: all ranks share GPU 0 and exchange through the host transport (checks the N>1 path on a 1-GPU box)")
     ap.add_argument("--dump-moments", default=None, help="debug: rank 0 writes the final pooled moment vector (float64) to this file")
+    ap.add_argument("--plan", action="store_true", help="print how --gpus N would shard the configuration (one JSON line: chains and first chain id of "
+                                                        "every rank, scaling mode) and exit; touches no GPU and starts no rank")
     a = ap.parse_args()
+    if a.plan:
+        print(json.dumps(shard_plan(a.workload, a.gpus, a.chains_per_gpu)), flush=True)
+        return
 
     if "WORLD_SIZE" not in os.environ:
         if a.gpus < 1:

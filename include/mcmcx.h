@@ -250,6 +250,10 @@ int mcmcx_kernel_time(mcmcx_handle h, double *ms, int64_t *launches, int64_t *st
 int mcmcx_debug_math(int32_t op, int32_t n, const double *a, const double *b, double *out);
 int mcmcx_debug_rng(uint32_t seed, uint32_t chain_id, int32_t kind, int32_t n, double a, double b, double *out,
                     uint64_t *nused);
+/* The engine's kernel-selection tables (which sampling kernel a configuration runs: launch_step / launch_group / launch_scam of
+ * mcx_api.hip), entry `index` as "family:name" into buf -- the name mcmcx_last_kernel reports after a run.  Returns the number
+ * of entries (index = -1, buf = NULL: count only).  Needs no device.  tests/test_kernel_table.py requires a parity test per entry. */
+int mcmcx_debug_kernel_table(int32_t index, char *buf, int32_t len);
 /* every chain's SVD proposal factor (per-chain mode, condmax > 0) replaced by R (column-major d x d; scam: the rotation)
  * and qcovstd (scam; NULL = keep): a test feeds the factors an external dgesvd returned at an adaptation */
 int mcmcx_debug_set_factor(mcmcx_handle h, const double *R_colmajor, const double *qcovstd);

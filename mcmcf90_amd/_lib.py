@@ -35,6 +35,7 @@ SYMBOLS = {
     "mcmcx_device_info": (C.c_int, [C.c_int32, C.c_char_p, C.c_int32]),
     "mcmcx_device_ident": (C.c_int, [C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]),
     "mcmcx_last_kernel": (C.c_char_p, [C.c_void_p]),
+    "mcmcx_debug_kernel_table": (C.c_int, [C.c_int32, C.c_char_p, C.c_int32]),
     "mcmcx_set_par0": (C.c_int, [C.c_void_p, _DP, C.c_int32]),
     "mcmcx_set_cmat0": (C.c_int, [C.c_void_p, _DP, C.c_int32]),
     "mcmcx_set_sigma2nobs": (C.c_int, [C.c_void_p, _DP, _IP, C.c_int32]),

@@ -37,7 +37,8 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // mcmcx_init -- never at launch time.  -1 = not set.
 struct mcx_switches {
     int pooled_mfma_dr_min = -1, pooled_scalar = -1, dr_big = -1, dr_general = -1, scam_pooled_16 = -1, scam_fast_lanes = -1, scam_waves = -1,
-        svd_lane = -1, cov_td = -1, cov_batch_rows = -1, svd_reg = -1, svd_stream = -1, svd_stream32 = -1, svd_stream_b = -1, ram_wide = -1, pooled_waves = -1;
+        svd_lane = -1, cov_td = -1, cov_batch_rows = -1, svd_reg = -1, svd_stream = -1, svd_stream32 = -1, svd_stream_b = -1, ram_wide = -1, pooled_waves = -1,
+        cols_phased = -1;
     static int get(const char *name) { const char *e = getenv(name); return e ? atoi(e) : -1; }
     void read()
     {
@@ -45,6 +46,7 @@ struct mcx_switches {
         dr_general = get("MCMCX_DR_GENERAL"); scam_pooled_16 = get("MCMCX_SCAM_POOLED_16"); scam_fast_lanes = get("MCMCX_SCAM_FAST_LANES");
         scam_waves = get("MCMCX_SCAM_WAVES"); svd_lane = get("MCMCX_SVD_LANE"); cov_td = get("MCMCX_COV_TD"); cov_batch_rows = get("MCMCX_COV_BATCH_ROWS");
         svd_reg = get("MCMCX_SVD_REG"); svd_stream = get("MCMCX_SVD_STREAM"); svd_stream32 = get("MCMCX_SVD_STREAM32"); svd_stream_b = get("MCMCX_SVD_STREAM_B"); ram_wide = get("MCMCX_RAM_WIDE"); pooled_waves = get("MCMCX_POOLED_WAVES");
+        cols_phased = get("MCMCX_COLS_PHASED");
     }
 };
 struct mcmcx_engine {
@@ -55,6 +57,7 @@ struct mcmcx_engine {
     bool inited = false;
     int simuind = 0;
     const char *last_kernel = "";       // name of the sampling kernel launch_step / launch_scam chose last (mcmcx_last_kernel)
+    std::string launch_err;             // set by a launcher that found no kernel for the configuration: the run fails with it
     // host copies of the problem
     std::vector<double> par0, cmat0;                 // cmat0 col-major d*d
     double sigma2 = 1.0; int nobs = 1; bool sigma2ok = false;
@@ -146,7 +149,11 @@ static int dev_upload(mcmcx_engine *h, const T **p, const std::vector<T> &v)
     return 0;
 }
 
-static const int MCX_MAX_NPAR = 256;      // d*512 B of LDS per wave: 160 KiB/CU holds d <= 320
+// No limit on npar like the reference (MCMC_init.F90:81-102 allocates whatever the namelist says) -- beyond int-sized packed indices.  Up to 256
+// every kernel family applies; above, the forms that keep an npar-vector per lane in LDS give way to global scratch where the 160 KiB end
+// (delayed rejection > 160, the adaptation's work vector > 320, the pooled-moment kernel > 317), the blocked SVD to the lane-per-chain SVD
+// (> 256), the matrix-core pooled kernels to the lane kernels (their own LDS tests): slower, never refused.
+static const int MCX_MAX_NPAR = 8192;     // P = npar (npar + 1) / 2 and 64 P stay far inside int / size_t arithmetic
 
 // dpotf2('U') + scaling on the host for the shared initial factor: same operation sequence as the
 // device's calculate_R (MCMC_calculate_R at MCMC_init.F90:109).  cm: col-major d*d, Rp: packed upper.
@@ -310,6 +317,10 @@ static bool pooled_use_mfma(const mcmcx_engine *h)
     return pooled_mfma_lds(h->d) <= 160 * 1024;
 }
 static bool phased(const mcmcx_engine *h) { return h->tkind == TGT_HOST || h->tkind == TGT_EXPCOLS || h->tkind == TGT_MODULE; }   // iteration cut at the evaluations
+// ... except where the DEVICE evaluates between the phases (the response-column target): the phases fused into one launch per segment
+// (step_kernel_cols); MCMCX_COLS_PHASED=1 keeps the separate launches (A/B, tests)
+static bool fused_cols(const mcmcx_engine *h) { return h->tkind == TGT_EXPCOLS && !(h->sw.cols_phased > 0); }
+static bool phase_cut(const mcmcx_engine *h) { return phased(h) && !fused_cols(h); }
 static size_t lds_bytes(const mcmcx_engine *h) { return (size_t)h->d * 64 * sizeof(double) * 2; }   // adapt / DR work vectors
 static bool dr_fits_lds(const mcmcx_engine *h) { return lds_bytes(h) <= 160 * 1024; }          // npar <= 160
 static size_t lds_step(const mcmcx_engine *h) { return (h->dodr && dr_fits_lds(h)) ? lds_bytes(h) : 0; }
@@ -326,8 +337,22 @@ static bool dr_vectors_in_lds(const mcmcx_engine *h, int min_waves = 8)
 }
 static void launch_init(mcmcx_engine *h)
 { hipLaunchKernelGGL(init_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E); }
-// the sampling kernels go through LAUNCHK, which notes the kernel's name for mcmcx_last_kernel (bench.py labels its roofline with it)
-#define LAUNCHK(k, ...) do { h->last_kernel = #k; hipLaunchKernelGGL(k, __VA_ARGS__); } while (0)
+// ---- which sampling kernel runs: ONE table per launcher, walked in order -- the first entry whose predicate holds is launched and
+// its name noted for mcmcx_last_kernel (bench.py labels its roofline with it).  The tables are exported through
+// mcmcx_debug_kernel_table, so that tests/test_kernel_table.py can list every selectable instance and require a parity test that
+// asserted each of them.  A configuration no entry accepts is an error of the run (launch_err), never a silent no-launch.
+struct KernelEntry {
+    const char *family;                                   // "step" (launch_step), "group" (launch_group), "scam" (launch_scam)
+    const char *name;
+    bool (*when)(const mcmcx_engine *);
+    void (*launch)(mcmcx_engine *, int it0, int it1);
+};
+static void walk_table(mcmcx_engine *h, const KernelEntry *tab, size_t n, int it0, int it1)
+{
+    for (size_t i = 0; i < n; ++i)
+        if (tab[i].when(h)) { h->last_kernel = tab[i].name; tab[i].launch(h, it0, it1); return; }
+    h->launch_err = std::string("no ") + (n ? tab[0].family : "?") + " kernel covers this configuration";
+}
 // ---- the lane-group step kernel (mcx_group.hpp): four chains per wave, factors in registers
 static const int GROUP_MAXSEG = 256;                  // iterations per launch (one accept byte per chain and iteration in d_accb)
 static const int GROUP_MAX_NPAR = 64, GROUP_MAX_NPAR_DR = 32;      // (with delayed rejection three tables must fit a lane's registers)
@@ -370,29 +395,67 @@ static bool group_wins(const mcmcx_engine *h, int drm, int gw)
     if (gw == 4) return h->dodr ? (drm == 2 || n <= 131072) : (d >= 11 || n <= 131072);
     return d >= 11 || (h->dodr && d >= 9 && n <= 131072);
 }
-template <int GW, int D4, int TK>
-static void launch_group_tk(mcmcx_engine *h, int it0, int it1)
+// one instantiation per (group width, npar rounded up, delayed-rejection form, target kind); DRM 0 = none, 1 = the general form (R, R2, iC in
+// registers), 2 = drscale a power of two (no R2; iC in LDS): the instantiation without R2 runs unless the device flag says that some factor
+// leaves the range in which R'z / drscale is R2'z bit for bit; the general one is queued behind the same flag and returns at once otherwise
+template <int GW, int D4, int DRM, int TK>
+static void launch_group_inst(mcmcx_engine *h, int it0, int it1)
 {
     const dim3 g(h->ntiles * (GW == 16 ? 16 : 4)), b(64);           // 64 / GW chains per wave
     const double *lam = h->E.tgt.lamT;
-    if (h->group_drm == 0) { h->last_kernel = GW == 16 ? "group_step_kernel" : "group_step_kernel<quad>"; hipLaunchKernelGGL((group_step_kernel<GW, D4, 0, TK>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)nullptr, 0); }
-    else if constexpr (D4 > 32) { return; }               // (group_covers: no delayed rejection above npar 32)
-    else if (h->group_drm == 1) { h->last_kernel = GW == 16 ? "group_step_kernel<DR>" : "group_step_kernel<quad, DR>"; hipLaunchKernelGGL((group_step_kernel<GW, D4, 1, -1>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)nullptr, 0); }
+    if constexpr (DRM != 0 && D4 > GROUP_MAX_NPAR_DR) h->launch_err = "group kernel: no delayed-rejection instantiation above npar " + std::to_string(GROUP_MAX_NPAR_DR);
+    else if constexpr (TK == TGT_EXPDATA && D4 != 4) h->launch_err = "group kernel: the expdata target has two parameters";
+    else if constexpr (DRM == 0) hipLaunchKernelGGL((group_step_kernel<GW, D4, 0, TK>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)nullptr, 0);
+    else if constexpr (DRM == 1) hipLaunchKernelGGL((group_step_kernel<GW, D4, 1, -1>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)nullptr, 0);
     else {
-        // drscale a power of two: the instantiation without R2 runs unless the device flag says that some factor leaves the range in
-        // which R'z / drscale is R2'z bit for bit; the general one is queued behind the same flag and returns at once otherwise
-        h->last_kernel = GW == 16 ? "group_step_kernel<DR2>" : "group_step_kernel<quad, DR2>";
         hipLaunchKernelGGL((group_step_kernel<GW, D4, 2, TK>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)h->d_gflag, 0);
         hipLaunchKernelGGL((group_step_kernel<GW, D4, 1, -1>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)h->d_gflag, 1);
     }
 }
-template <int GW, int D4>
+template <int GW, int D4, int DRM>
+static void launch_group_tk(mcmcx_engine *h, int it0, int it1)
+{
+    if (h->tkind == TGT_BANANA) launch_group_inst<GW, D4, DRM, TGT_BANANA>(h, it0, it1);
+    else if (h->tkind == TGT_EXPDATA) launch_group_inst<GW, D4, DRM, TGT_EXPDATA>(h, it0, it1);
+    else launch_group_inst<GW, D4, DRM, TGT_GAUSS>(h, it0, it1);
+}
+template <int GW, int DRM>
 static void launch_group_d4(mcmcx_engine *h, int it0, int it1)
 {
-    if (h->tkind == TGT_BANANA) launch_group_tk<GW, D4, TGT_BANANA>(h, it0, it1);
-    else if (h->tkind == TGT_EXPDATA) { if constexpr (D4 == 4) launch_group_tk<GW, D4, TGT_EXPDATA>(h, it0, it1); }   // (that target has two parameters)
-    else launch_group_tk<GW, D4, TGT_GAUSS>(h, it0, it1);
+    if constexpr (GW == 4) {                              // quads: npar <= 16
+        switch (h->group_d4) {
+        case 4: launch_group_tk<4, 4, DRM>(h, it0, it1); break;
+        case 8: launch_group_tk<4, 8, DRM>(h, it0, it1); break;
+        case 12: launch_group_tk<4, 12, DRM>(h, it0, it1); break;
+        case 16: launch_group_tk<4, 16, DRM>(h, it0, it1); break;
+        default: h->launch_err = "group kernel (quads): npar > 16";
+        }
+    } else {
+        switch (h->group_d4) {
+        case 4: launch_group_tk<16, 4, DRM>(h, it0, it1); break;
+        case 8: launch_group_tk<16, 8, DRM>(h, it0, it1); break;
+        case 12: launch_group_tk<16, 12, DRM>(h, it0, it1); break;
+        case 16: launch_group_tk<16, 16, DRM>(h, it0, it1); break;
+        case 20: launch_group_tk<16, 20, DRM>(h, it0, it1); break;
+        case 24: launch_group_tk<16, 24, DRM>(h, it0, it1); break;
+        case 28: launch_group_tk<16, 28, DRM>(h, it0, it1); break;
+        case 32: launch_group_tk<16, 32, DRM>(h, it0, it1); break;
+        case 40: launch_group_tk<16, 40, DRM>(h, it0, it1); break;       // (above 32: sizes of eight, no delayed rejection)
+        case 48: launch_group_tk<16, 48, DRM>(h, it0, it1); break;
+        case 56: launch_group_tk<16, 56, DRM>(h, it0, it1); break;
+        case 64: launch_group_tk<16, 64, DRM>(h, it0, it1); break;
+        default: h->launch_err = "group kernel: npar > 64";
+        }
+    }
 }
+static const KernelEntry GROUP_TABLE[] = {
+    {"group", "group_step_kernel",            [](const mcmcx_engine *h) { return h->group_gw == 16 && h->group_drm == 0; }, launch_group_d4<16, 0>},
+    {"group", "group_step_kernel<DR>",        [](const mcmcx_engine *h) { return h->group_gw == 16 && h->group_drm == 1; }, launch_group_d4<16, 1>},
+    {"group", "group_step_kernel<DR2>",       [](const mcmcx_engine *h) { return h->group_gw == 16 && h->group_drm == 2; }, launch_group_d4<16, 2>},
+    {"group", "group_step_kernel<quad>",      [](const mcmcx_engine *h) { return h->group_gw == 4 && h->group_drm == 0; }, launch_group_d4<4, 0>},
+    {"group", "group_step_kernel<quad, DR>",  [](const mcmcx_engine *h) { return h->group_gw == 4 && h->group_drm == 1; }, launch_group_d4<4, 1>},
+    {"group", "group_step_kernel<quad, DR2>", [](const mcmcx_engine *h) { return h->group_gw == 4 && h->group_drm == 2; }, launch_group_d4<4, 2>},
+};
 static void launch_group(mcmcx_engine *h, int it0, int it1)
 {
     if (h->group_drm == 2 && h->group_check_due) {       // the factors have been rewritten since the last look
@@ -400,63 +463,70 @@ static void launch_group(mcmcx_engine *h, int it0, int it1)
         hipLaunchKernelGGL(group_check_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, h->d_gflag);
         h->group_check_due = false;
     }
-    if (h->group_gw == 4) {                                  // quads: npar <= 16
-        switch (h->group_d4) {
-        case 4: launch_group_d4<4, 4>(h, it0, it1); break;
-        case 8: launch_group_d4<4, 8>(h, it0, it1); break;
-        case 12: launch_group_d4<4, 12>(h, it0, it1); break;
-        default: launch_group_d4<4, 16>(h, it0, it1); break;
-        }
-    } else {
-        switch (h->group_d4) {
-        case 4: launch_group_d4<16, 4>(h, it0, it1); break;
-        case 8: launch_group_d4<16, 8>(h, it0, it1); break;
-        case 12: launch_group_d4<16, 12>(h, it0, it1); break;
-        case 16: launch_group_d4<16, 16>(h, it0, it1); break;
-        case 20: launch_group_d4<16, 20>(h, it0, it1); break;
-        case 24: launch_group_d4<16, 24>(h, it0, it1); break;
-        case 28: launch_group_d4<16, 28>(h, it0, it1); break;
-        case 32: launch_group_d4<16, 32>(h, it0, it1); break;
-        case 40: launch_group_d4<16, 40>(h, it0, it1); break;       // (above 32: sizes of eight, no delayed rejection)
-        case 48: launch_group_d4<16, 48>(h, it0, it1); break;
-        case 56: launch_group_d4<16, 56>(h, it0, it1); break;
-        default: launch_group_d4<16, 64>(h, it0, it1); break;
-        }
-    }
-    if (h->d_accb) {
+    walk_table(h, GROUP_TABLE, sizeof(GROUP_TABLE) / sizeof(GROUP_TABLE[0]), it0, it1);
+    if (h->d_accb && h->launch_err.empty()) {
         const long long n = (long long)(it1 - it0 + 1) * h->ntiles;
         hipLaunchKernelGGL(group_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->E, h->d_accb, it0, it1);
     }
 }
+// pooled_mfma_kernel<false, true>: two waves per SIMD (256 registers, some state spilled) pay with more tiles than SIMDs: from two per SIMD
+// where the LDS vector lets eight waves on a CU (npar <= 39: +25 .. +55 %), from eight where it lets six (npar 50: 0.80 at 2048 tiles, 0.99 at
+// 4096, 1.14 at 16384); with one tile per SIMD the spills are all they buy (0.83 .. 0.90) -- tools/pooled_waves_probe.py
+static bool pooled_two_waves(const mcmcx_engine *h)
+{
+    if (h->sw.pooled_waves >= 0) return h->sw.pooled_waves == 2;                                 // (A/B switch, tests)
+    return h->ntiles >= (pooled_mfma_lds(h->d) * 8 <= 160 * 1024 ? 2048 : 8192);
+}
+#define STEP_ARGS h->stream, h->E, it0, it1
+#define STEP_RS (h->d_ramscale + it0)
+#define STEP_TGT h->E.tgt.mu, h->E.tgt.lamT
+#define G1 dim3(h->ntiles), dim3(64)
+static const KernelEntry STEP_TABLE[] = {
+    // ---- a device target with response columns (nycol >= 1 sums of squares per point): the phases of an iteration in one launch
+    {"step", "step_kernel_cols", fused_cols,
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_cols, G1, lds_step(h), STEP_ARGS, (const double *)h->d_ramscale,
+                                                                (const double *)(h->pooled ? h->E.sharedR : nullptr), (const double *)h->d_sharedR2, (const double *)h->d_sharediC); }},
+    // ---- pooled mode (one shared factor)
+    {"step", "pooled_mfma_kernel<true>", [](const mcmcx_engine *h) { return pooled_use_mfma(h) && h->dodr != 0; },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(pooled_mfma_kernel<true>, G1, pooled_mfma_lds(h->d), STEP_ARGS, STEP_TGT, h->d_sharedRT, h->d_sharedR2T, h->d_sharediCd); }},
+    {"step", "pooled_mfma_kernel<false, true>", [](const mcmcx_engine *h) { return pooled_use_mfma(h) && pooled_two_waves(h); },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((pooled_mfma_kernel<false, true>), G1, pooled_mfma_lds(h->d), STEP_ARGS, STEP_TGT, h->d_sharedRT, (const double *)nullptr, (const double *)nullptr); }},
+    {"step", "pooled_mfma_kernel<false>", [](const mcmcx_engine *h) { return pooled_use_mfma(h); },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(pooled_mfma_kernel<false>, G1, pooled_mfma_lds(h->d), STEP_ARGS, STEP_TGT, h->d_sharedRT, (const double *)nullptr, (const double *)nullptr); }},
+    {"step", "step_kernel_pooled_dr_big", [](const mcmcx_engine *h) { return h->pooled && h->dodr && !dr_vectors_in_lds(h, 4); },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_pooled_dr_big, G1, 0, STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR, h->d_sharedR2, h->d_sharediC); }},
+    {"step", "step_kernel_pooled_dr", [](const mcmcx_engine *h) { return h->pooled && h->dodr; },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_pooled_dr, G1, lds_step(h), STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR, h->d_sharedR2, h->d_sharediC); }},
+    {"step", "step_kernel<false, false, true>", [](const mcmcx_engine *h) { return h->pooled != 0; },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((step_kernel<false, false, true>), G1, 0, STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
+    // ---- method = 'ram', per-chain factors
+    {"step", "step_kernel_ram_fullr", [](const mcmcx_engine *h) { return h->E.method == M_RAM && h->usesvd; },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ram_fullr, G1, 0, STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
+    {"step", "step_kernel_ram_ldsr", [](const mcmcx_engine *h) { return h->E.method == M_RAM && h->E.lds_scratch == 3; },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ram_ldsr, G1, (size_t)(2 * h->d + h->P) * 64 * sizeof(double), STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
+    {"step", "step_kernel_ram_wide", [](const mcmcx_engine *h) { return h->E.method == M_RAM && h->d > RAM_SMALL_MAX && h->sw.ram_wide != 0; },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ram_wide, G1, (size_t)NLC * 2 * 64 * sizeof(double), STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
+    {"step", "step_kernel<true, false, false>", [](const mcmcx_engine *h) { return h->E.method == M_RAM; },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((step_kernel<true, false, false>), G1, (size_t)NLC * 2 * 64 * sizeof(double), STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
+    // ---- delayed rejection, per-chain factors: the second stage's two vectors in global scratch / in LDS / the general step_body<DR> (A/B)
+    {"step", "step_kernel_dr_big", [](const mcmcx_engine *h) { return h->dodr && !dr_vectors_in_lds(h); },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_dr_big, G1, 0, STEP_ARGS, STEP_TGT); }},
+    {"step", "step_kernel_dr", [](const mcmcx_engine *h) { return h->dodr && !(h->sw.dr_general > 0); },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_dr, G1, lds_step(h), STEP_ARGS, STEP_TGT); }},
+    {"step", "step_kernel<false, true, false>", [](const mcmcx_engine *h) { return h->dodr != 0; },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((step_kernel<false, true, false>), G1, lds_step(h), STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
+    // ---- AM / Metropolis / early rejection: state + factor in LDS, state in LDS, nothing in LDS
+    {"step", "step_kernel_ldsr", [](const mcmcx_engine *h) { return h->E.lds_scratch == 2; },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ldsr, G1, (size_t)(2 * h->d + h->P) * 64 * sizeof(double), STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
+    {"step", "step_kernel_ldsv", [](const mcmcx_engine *h) { return h->E.lds_scratch != 0; },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ldsv, G1, (size_t)4 * h->d * 64 * sizeof(double), STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
+    {"step", "step_kernel<false, false, false>", [](const mcmcx_engine *) { return true; },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((step_kernel<false, false, false>), G1, 0, STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
+};
 static void launch_step(mcmcx_engine *h, int it0, int it1)
 {
-    const dim3 g(h->ntiles), b(64);
-    const double *rs = h->d_ramscale + it0;
     if (h->group_d4) { launch_group(h, it0, it1); return; }
-    if (pooled_use_mfma(h) && h->dodr) LAUNCHK(pooled_mfma_kernel<true>, g, b, pooled_mfma_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedRT, h->d_sharedR2T, h->d_sharediCd);
-    // two waves per SIMD (256 registers, some state spilled) pay with more tiles than SIMDs: from two per SIMD where the LDS vector lets eight
-    // waves on a CU (npar <= 39: +25 .. +55 %), from eight where it lets six (npar 50: 0.80 at 2048 tiles, 0.99 at 4096, 1.14 at 16384);
-    // with one tile per SIMD the spills are all they buy (0.83 .. 0.90) -- tools/pooled_waves_probe.py
-    else if (pooled_use_mfma(h) && (h->sw.pooled_waves >= 0 ? h->sw.pooled_waves == 2 : h->ntiles >= (pooled_mfma_lds(h->d) * 8 <= 160 * 1024 ? 2048 : 8192))) {
-        hipLaunchKernelGGL((pooled_mfma_kernel<false, true>), g, b, pooled_mfma_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedRT, (const double *)nullptr, (const double *)nullptr);
-        h->last_kernel = "pooled_mfma_kernel<false>";
-    }
-    else if (pooled_use_mfma(h)) LAUNCHK(pooled_mfma_kernel<false>, g, b, pooled_mfma_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedRT, (const double *)nullptr, (const double *)nullptr);
-    else if (h->pooled && h->dodr && !dr_vectors_in_lds(h, 4)) LAUNCHK(step_kernel_pooled_dr_big, g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR, h->d_sharedR2, h->d_sharediC);
-    else if (h->pooled && h->dodr) LAUNCHK(step_kernel_pooled_dr, g, b, lds_step(h), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR, h->d_sharedR2, h->d_sharediC);
-    else if (h->pooled) LAUNCHK((step_kernel<false, false, true>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
-    else if (h->E.method == M_RAM && h->usesvd) LAUNCHK(step_kernel_ram_fullr, g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
-    else if (h->E.method == M_RAM && h->E.lds_scratch == 3) LAUNCHK(step_kernel_ram_ldsr, g, b, (size_t)(2 * h->d + h->P) * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
-    else if (h->E.method == M_RAM && h->d > RAM_SMALL_MAX && h->sw.ram_wide != 0) LAUNCHK(step_kernel_ram_wide, g, b, (size_t)NLC * 2 * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
-    else if (h->E.method == M_RAM) LAUNCHK((step_kernel<true, false, false>), g, b, (size_t)NLC * 2 * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
-    else if (h->dodr && !dr_vectors_in_lds(h))            // the second stage's two vectors in global scratch
-        LAUNCHK(step_kernel_dr_big, g, b, 0, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
-    else if (h->dodr && !(h->sw.dr_general > 0))                                                // (A/B switch for tests: step_body<DR>)
-        LAUNCHK(step_kernel_dr, g, b, lds_step(h), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
-    else if (h->dodr) LAUNCHK((step_kernel<false, true, false>), g, b, lds_step(h), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
-    else if (h->E.lds_scratch == 2) LAUNCHK(step_kernel_ldsr, g, b, (size_t)(2 * h->d + h->P) * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
-    else if (h->E.lds_scratch) LAUNCHK(step_kernel_ldsv, g, b, (size_t)4 * h->d * 64 * sizeof(double), h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
-    else LAUNCHK((step_kernel<false, false, false>), g, b, 0, h->stream, h->E, it0, it1, rs, h->E.tgt.mu, h->E.tgt.lamT, h->E.sharedR);
+    walk_table(h, STEP_TABLE, sizeof(STEP_TABLE) / sizeof(STEP_TABLE[0]), it0, it1);
 }
 // every chain's copy of a K-vector, filled on the device
 static int dev_bcast(mcmcx_engine *h, double *dst, const std::vector<double> &v)
@@ -511,47 +581,53 @@ static bool scam_use_12(const mcmcx_engine *h)
     if (h->sw.scam_pooled_16 > 0) return false;                                       // A/B switch for tests: the sixteen-wave layout
     return nt >= 13 && nt <= 15;
 }
-static void launch_scam(mcmcx_engine *h, int it0, int it1)
+// opt-in fast proposals with the Gaussian target: the workgroup-per-tile kernel of the pooled mode with each chain's own
+// rotation column (g_U = nullptr) -- the target's d x d product on the matrix cores instead of lane by lane
+static bool scam_fast_tile_kernel(const mcmcx_engine *h)
 {
-    if (h->pooled) {
-        const size_t st = shared_u_stride(h);
-        const int nt = (h->d + 15) / 16;                   // 16-row output blocks: min(12, 4*(nt/4)) block waves + 4 chain-group waves
-        if (scam_use_12(h)) {
-            LAUNCHK(scam_pooled12_kernel, dim3(h->ntiles), dim3(768), scam_pooled_lds(h->d), h->stream, h->E, it0, it1,
-                    h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedU, h->d_sharedU + st, h->d_sharedU + 2 * st);
-            return;
-        }
-        const int nw = 4 + std::min(12, nt & ~3);
-        LAUNCHK(scam_pooled_kernel, dim3(h->ntiles), dim3(64 * nw), scam_pooled_lds(h->d), h->stream, h->E, it0, it1,
-                           h->E.tgt.mu, h->E.tgt.lamT, h->d_sharedU, h->d_sharedU + st, h->d_sharedU + 2 * st);
-        return;
-    }
-    // opt-in fast proposals with the Gaussian target: the workgroup-per-tile kernel of the pooled mode with each chain's own
-    // rotation column (g_U = nullptr) -- the target's d x d product on the matrix cores instead of lane by lane
-    if (h->cfg.scam_fast && h->tkind == TGT_GAUSS && !h->has_lo && !h->has_hi && !h->has_pri && scam_pooled_lds(h->d) <= 160 * 1024 &&
-        !(h->sw.scam_fast_lanes > 0)) {
-        // (the sixteen-wave layout whatever npar: every lane fetches the column of its own chain's factor per sub-step, and four
-        //  waves per SIMD cover that better than three -- 4.62e8 against 4.45e8 proposals/s at npar 200)
-        const int nt = (h->d + 15) / 16;
-        const int nwp = 4 + std::min(12, nt & ~3);
-        LAUNCHK(scam_pooled_kernel, dim3(h->ntiles), dim3(64 * nwp), scam_pooled_lds(h->d), h->stream, h->E, it0, it1,
-                           h->E.tgt.mu, h->E.tgt.lamT, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr);
-        return;
-    }
-    // few tiles: several waves per tile (scam_mw_kernel), so that a sub-step is not bound by the latency of one wave's loads
-    // while most of the chip idles -- as many waves as keep the chip's ~2048 resident-wave slots busy, at most 8 (sixteen
-    // waves of 128 registers spill the products' panels)
+    return h->cfg.scam_fast && h->tkind == TGT_GAUSS && !h->has_lo && !h->has_hi && !h->has_pri && scam_pooled_lds(h->d) <= 160 * 1024 &&
+           !(h->sw.scam_fast_lanes > 0);
+}
+// few tiles: several waves per tile (scam_mw_kernel), so that a sub-step is not bound by the latency of one wave's loads
+// while most of the chip idles -- as many waves as keep the chip's ~2048 resident-wave slots busy, at most 8 (sixteen
+// waves of 128 registers spill the products' panels)
+static size_t scam_mw_lds(const mcmcx_engine *h) { return (size_t)(4 * ((h->d + 15) / 16) + 2) * 64 * sizeof(double); }
+static int scam_tile_waves(const mcmcx_engine *h)
+{
     int nw = 1;
     while (nw < 8 && (long long)h->ntiles * nw * 2 <= 2048) nw *= 2;
     { const int v = h->sw.scam_waves; if (v == 1 || v == 2 || v == 4 || v == 8) nw = v; }   // A/B switch for tests
-    const size_t lds = (size_t)(4 * ((h->d + 15) / 16) + 2) * 64 * sizeof(double);
-    const dim3 g(h->ntiles);
-    switch (nw) {
-    case 8: LAUNCHK(scam_mw_kernel<8>, g, dim3(512), lds, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT); break;
-    case 4: LAUNCHK(scam_mw_kernel<4>, g, dim3(256), lds, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT); break;
-    case 2: LAUNCHK(scam_mw_kernel<2>, g, dim3(128), lds, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT); break;
-    default: LAUNCHK(scam_kernel, g, dim3(64), 0, h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT);
-    }
+    if (scam_mw_lds(h) > 160 * 1024) nw = 1;                                               // (npar > 1200: the one-wave kernel needs no LDS)
+    return nw;
+}
+#define SCAM_POOLED_ARGS scam_pooled_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT
+static const KernelEntry SCAM_TABLE[] = {
+    {"scam", "step_kernel_cols<scam>", [](const mcmcx_engine *h) { return fused_cols(h) && !h->pooled; },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_cols, G1, 0, STEP_ARGS, (const double *)h->d_ramscale, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr); }},
+    // pooled: 16-row output blocks, min(12, 4*(nt/4)) block waves + 4 chain-group waves; twelve waves of 170 registers for 13..15 blocks
+    {"scam", "scam_pooled12_kernel", [](const mcmcx_engine *h) { return h->pooled && scam_use_12(h); },
+     [](mcmcx_engine *h, int it0, int it1) { const size_t st = shared_u_stride(h);
+        hipLaunchKernelGGL(scam_pooled12_kernel, dim3(h->ntiles), dim3(768), SCAM_POOLED_ARGS, h->d_sharedU, h->d_sharedU + st, h->d_sharedU + 2 * st); }},
+    {"scam", "scam_pooled_kernel", [](const mcmcx_engine *h) { return h->pooled != 0; },
+     [](mcmcx_engine *h, int it0, int it1) { const size_t st = shared_u_stride(h); const int nw = 4 + std::min(12, ((h->d + 15) / 16) & ~3);
+        hipLaunchKernelGGL(scam_pooled_kernel, dim3(h->ntiles), dim3(64 * nw), SCAM_POOLED_ARGS, h->d_sharedU, h->d_sharedU + st, h->d_sharedU + 2 * st); }},
+    // (the sixteen-wave layout whatever npar: every lane fetches the column of its own chain's factor per sub-step, and four
+    //  waves per SIMD cover that better than three -- 4.62e8 against 4.45e8 proposals/s at npar 200)
+    {"scam", "scam_pooled_kernel<per-chain>", scam_fast_tile_kernel,
+     [](mcmcx_engine *h, int it0, int it1) { const int nw = 4 + std::min(12, ((h->d + 15) / 16) & ~3);
+        hipLaunchKernelGGL(scam_pooled_kernel, dim3(h->ntiles), dim3(64 * nw), SCAM_POOLED_ARGS, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr); }},
+    {"scam", "scam_mw_kernel<8>", [](const mcmcx_engine *h) { return scam_tile_waves(h) == 8; },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(scam_mw_kernel<8>, dim3(h->ntiles), dim3(512), scam_mw_lds(h), STEP_ARGS, STEP_TGT); }},
+    {"scam", "scam_mw_kernel<4>", [](const mcmcx_engine *h) { return scam_tile_waves(h) == 4; },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(scam_mw_kernel<4>, dim3(h->ntiles), dim3(256), scam_mw_lds(h), STEP_ARGS, STEP_TGT); }},
+    {"scam", "scam_mw_kernel<2>", [](const mcmcx_engine *h) { return scam_tile_waves(h) == 2; },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(scam_mw_kernel<2>, dim3(h->ntiles), dim3(128), scam_mw_lds(h), STEP_ARGS, STEP_TGT); }},
+    {"scam", "scam_kernel", [](const mcmcx_engine *) { return true; },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(scam_kernel, G1, 0, STEP_ARGS, STEP_TGT); }},
+};
+static void launch_scam(mcmcx_engine *h, int it0, int it1)
+{
+    walk_table(h, SCAM_TABLE, sizeof(SCAM_TABLE) / sizeof(SCAM_TABLE[0]), it0, it1);
 }
 // LDS of svd_blocked_kernel for block width b: four blocks of b columns (odd stride) + the rotation slots
 static int svd_ls_host(int d) { return ((d + 1) & ~1) + (((d + 1) & 2) ? 0 : 2); }
@@ -568,7 +644,7 @@ static bool svd_blocked(const mcmcx_engine *h)
 {
     if (!h->usesvd || h->pooled || h->cfg.method == MCMCX_METHOD_RAM) return false;
     if (h->sw.svd_lane > 0) return false;                                             // A/B switch for tests: one lane per chain
-    return h->d >= 48;
+    return h->d >= 48 && h->d <= 256;                                                  // (its rings and row groups are instantiated up to npar 256)
 }
 static void launch_adapt(mcmcx_engine *h, int it, int mode)
 {
@@ -599,6 +675,11 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
             hipLaunchKernelGGL(adapt_cov_kernel, dim3((unsigned)(8 * ((h->ntiles + 7) / 8) * nblk)), dim3(64), 0, h->stream, h->E, it, mode, nblk);
     }
     if (!h->d_Gc) {
+        if (lds > 160 * 1024) {                             // npar > 320: the work vector in global scratch (slower; no limit)
+            if (h->usesvd) hipLaunchKernelGGL((adapt_post_kernel<true, true>), dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr, batch_done);
+            else hipLaunchKernelGGL((adapt_post_kernel<false, true>), dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr, batch_done);
+            return;
+        }
         if (h->usesvd) hipLaunchKernelGGL(adapt_post_kernel<true>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr, batch_done);
         else if (h->group_factor) {
             // with the lane-group step kernels: the Cholesky factor, its inverse and R2 in the group layout too (mcx_group.hpp)
@@ -1455,7 +1536,8 @@ int mcmcx_init(mcmcx_handle h)
     const int ny = h->ny;
     if (ny > 1 && !phased(h)) return fail(-36, "nycol > 1 needs the host-callback or the response-column target (the other built-in targets have one column)");
     if (h->tkind == TGT_EXPCOLS && h->tncols != ny) return fail(-36, "response-column target: mcmcx_set_sigma2nobs must give one sigma2 / nobs per column");
-    if (ny > 1 && h->pooled) return fail(-36, "nycol > 1 is not available in pooled mode");
+    if (ny > 1 && h->pooled && (!fused_cols(h) || c.method == MCMCX_METHOD_SCAM))
+        return fail(-36, "nycol > 1 in pooled mode: the device-resident response-column target only, and not with method = 'scam'");
     if (h->tkind < 0) return fail(-31, "no target: the device engine needs mcmcx_set_target_*");
     std::vector<double> Rp, Cp, Rfull, qstd0;
     int info = host_initial_R(d, h->cmat0, Rp, Cp);
@@ -1526,7 +1608,7 @@ int mcmcx_init(mcmcx_handle h)
     if ((rc = dev_alloc(h, &E.zs, L * 2 * d))) return rc;
     if ((rc = dev_alloc(h, &E.cs, L * 2 * d))) return rc;
     E.xscr = nullptr;
-    if (h->pooled && h->dodr && (rc = dev_alloc(h, &E.xscr, L * 2 * d))) return rc;      // step_kernel_pooled_dr_big's quadratic-form vectors
+    if (((h->pooled && h->dodr) || d > 320) && (rc = dev_alloc(h, &E.xscr, L * 2 * d))) return rc;      // step_kernel_pooled_dr_big's quadratic-form vectors; npar > 320: adapt_post_kernel's work vector
     if ((rc = dev_alloc(h, &E.scal, L * NSCAL))) return rc;
     if ((rc = dev_alloc(h, &E.ictr, L * NICTR))) return rc;
     if ((rc = dev_alloc(h, &E.rngn, L))) return rc;
@@ -1598,7 +1680,8 @@ int mcmcx_init(mcmcx_handle h)
     E.sharedR = nullptr;
     if (h->pooled) {
         if ((long long)c.nchains * (h->comm ? h->comm->nranks : 1) < 2) return fail(-8, "pooled mode needs at least 2 chains over all ranks");
-        if (phased(h)) return fail(-8, "pooled mode needs one of the single-launch device targets (gauss, banana, expdata)");
+        if (phase_cut(h) || (fused_cols(h) && c.method == MCMCX_METHOD_SCAM))
+            return fail(-8, "pooled mode needs one of the single-launch device targets (gauss, banana, expdata, expcols; scam: not expcols)");
         if (c.method == MCMCX_METHOD_SCAM && scam_pooled_lds(d) > 160 * 1024) return fail(-8, "pooled scam: npar > 240 does not fit the 160 KiB of LDS");
         if ((rc = dev_alloc(h, &h->d_sharedR, (size_t)P, false))) return rc;
         HIPCHK(hipMemcpy(h->d_sharedR, Rp.data(), (size_t)P * 8, hipMemcpyHostToDevice));
@@ -1782,7 +1865,7 @@ static int run_impl(mcmcx_handle h, int32_t upto)
             ramtick = pooled_ram_due(h, end);
             if (mode != 0 || ramtick || end == upto || end - it + 1 >= maxseg) break;
         }
-        if (phased(h)) {
+        if (phase_cut(h)) {
             for (int i2 = it; i2 <= end; ++i2) { int rc = host_iteration(h, i2); if (rc) return rc; }
         } else {
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1790,8 +1873,14 @@ static int run_impl(mcmcx_handle h, int32_t upto)
             if (er == hipSuccess) er = hipEventCreate(&e1);
             if (er == hipSuccess) er = hipEventRecord(e0, h->stream);
             if (er == hipSuccess) {
+                h->launch_err.clear();
                 if (h->cfg.method == MCMCX_METHOD_SCAM) launch_scam(h, it, end); else launch_step(h, it, end);
                 er = hipGetLastError();
+            }
+            if (er == hipSuccess && !h->launch_err.empty()) {      // a cover predicate and the dispatch disagree: fail, never skip iterations silently
+                if (e0) (void)hipEventDestroy(e0);
+                if (e1) (void)hipEventDestroy(e1);
+                return fail(-103, "step launch: " + h->launch_err);
             }
             if (er == hipSuccess) er = hipEventRecord(e1, h->stream);
             if (er != hipSuccess) {                       // nothing is left behind on the error path
@@ -2122,7 +2211,9 @@ static int pooled_moments_launch(mcmcx_engine *h, double *dev_dst, int kind, int
     HIPCHK(hipSetDevice(h->cfg.device));
     const int len = pooled_vec_len(h, kind), T = h->ntiles;
     const double rs = (kind == 2) ? 1.0 / std::pow((double)(float)it, h->cfg.nuparam) : 0.0;      // like d_ramscale (MCMC_run_ram.F90:166)
-    hipLaunchKernelGGL(moments_kernel, dim3(T), dim3(256), ((size_t)64 * (h->d | 1) + 256) * sizeof(double), h->stream, h->E, h->d_moments, h->cfg.nchains, kind, it, rs);
+    const size_t mlds = ((size_t)64 * (h->d | 1) + 320) * sizeof(double);
+    if (mlds <= 160 * 1024) hipLaunchKernelGGL(moments_kernel<false>, dim3(T), dim3(256), mlds, h->stream, h->E, h->d_moments, h->cfg.nchains, kind, it, rs);
+    else hipLaunchKernelGGL(moments_kernel<true>, dim3(T), dim3(256), (size_t)320 * sizeof(double), h->stream, h->E, h->d_moments, h->cfg.nchains, kind, it, rs);   // npar > 317
     for (long long stride = 1;; stride *= 64) {                            // six levels of the fixed pairwise tree per launch
         const long long groups = (T + 64 * stride - 1) / (64 * stride);
         hipLaunchKernelGGL(moments_tree_kernel, dim3((len + 255) / 256, (unsigned)groups), dim3(256), 0, h->stream, h->d_moments, T, len,
@@ -2238,6 +2329,21 @@ int mcmcx_run_all(mcmcx_handle *hs, int32_t n, int32_t upto)
 
 extern "C" {
 // ------------------------------------------------------------------ debug probes (tests only)
+// The kernel-selection tables (launch_step / launch_group / launch_scam): entry `index` as "family:name" into buf; returns the number of
+// entries (so index = -1 with buf = NULL just counts).  Needs no device.
+int mcmcx_debug_kernel_table(int32_t index, char *buf, int32_t len)
+{
+    const KernelEntry *tabs[] = {STEP_TABLE, GROUP_TABLE, SCAM_TABLE};
+    const size_t ns[] = {sizeof(STEP_TABLE) / sizeof(STEP_TABLE[0]), sizeof(GROUP_TABLE) / sizeof(GROUP_TABLE[0]), sizeof(SCAM_TABLE) / sizeof(SCAM_TABLE[0])};
+    int total = 0, k = index;
+    for (int t = 0; t < 3; ++t) {
+        if (k >= 0 && k < (int)ns[t] && buf && len > 0) { snprintf(buf, (size_t)len, "%s:%s", tabs[t][k].family, tabs[t][k].name); k = -1 - total - (int)ns[t]; }
+        else if (k >= 0) k -= (int)ns[t];
+        total += (int)ns[t];
+    }
+    return total;
+}
+
 int mcmcx_debug_math(int32_t op, int32_t n, const double *a, const double *b, double *out)
 {
     if (n < 1 || !a || !out) return fail(-1, "bad argument");

@@ -34,7 +34,7 @@
             return fail(-110, std::string(#call) + ": " + ncclGetErrorString(r_));                \
     } while (0)
 
-static const int MCX_SHM_SLOT = 40960;          // doubles per rank in the host segment: >= 1 + d + d(d+1)/2 at d = 256 (33153)
+static const int MCX_SHM_SLOT = 131072;         // doubles per rank in the host segment (1 MiB): >= 3 + d + d(d+1)/2 up to d = 510; longer messages fail loudly (RCCL has no such limit)
 static const int MCX_COMM_MAXRANKS = 64;        // one level of moments_tree_kernel
 
 struct mcx_shm_header {

@@ -28,6 +28,12 @@
 
 namespace mcx {
 
+// Cross-lane exchange through LDS inside ONE wave (every block of this file is a single wave): the hardware retires a wave's LDS
+// operations in order, so a read issued after a write sees it; what has to be said is the COMPILER's order between the write phase and the
+// read phase -- an acquire-release fence at wavefront scope (no instruction) plus the wave barrier (no instruction either).  Without it
+// the order rests on the alias analysis not proving the two index expressions distinct.
+#define MCX_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
 template <int I, int N, typename F>
 MCX_DEV void sfor(F &&f)
 {
@@ -201,6 +207,7 @@ MCX_DEV void group_normals(uint32_t k0, uint32_t k1, GChain &g, double *zrow, in
 {
     using G = GDims<D4, GW>;
     int k = 0;
+    MCX_WAVE_LDS_SYNC();                                         // the previous round's reads of the row are done
     if (act && g.saved) { if (l16 == 0) zrow[0] = g.saved_y; g.saved = 0; k = 1; }     // normal_bm's cached second deviate, mcmcrand.F90:172-175
     bool need = act && (k < d);
     bool newsave = false;
@@ -243,7 +250,7 @@ MCX_DEV void group_normals(uint32_t k0, uint32_t k1, GChain &g, double *zrow, in
             }
         }
     }
-    // (the wave's LDS operations retire in order: its reads below see its writes above)
+    MCX_WAVE_LDS_SYNC();                                         // (the wave's LDS operations retire in order: its reads below see its writes above)
     sfor<0, G::NS>([&](auto T) __attribute__((always_inline)) {
         constexpr int t = decltype(T)::value;
         const int pos = GW * t + l16;
@@ -486,6 +493,7 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
             }
         });
     }
+    MCX_WAVE_LDS_SYNC();                                       // the fills above (Lam, R's last slot, iC) before any lane reads another lane's part
     const double inv2 = (DRM == 2) ? 1.0 / E.drscale : 1.0;   // exact: drscale is a power of two in this instantiation
     double th[NS];
     sfor<0, NS>([&](auto S) __attribute__((always_inline)) {
@@ -726,6 +734,7 @@ __global__ __launch_bounds__(64) void group_factor_kernel(EngineDev E)
     // ---- dpotf2
     int info = 0;
     for (int j = 0; j < d; ++j) {
+        MCX_WAVE_LDS_SYNC();                                 // row j - 1 (other lanes' columns) is written
         double acc0 = 0.0, acc1 = 0.0, accj = 0.0;
 #pragma unroll 4
         for (int i = 0; i < j; ++i) {
@@ -759,6 +768,7 @@ __global__ __launch_bounds__(64) void group_factor_kernel(EngineDev E)
             }
     }
     if (!E.dodr || !__any(ok)) return;
+    MCX_WAVE_LDS_SYNC();
     // ---- iC = dpotri('U', R): dtrti2 then dlauu2, in place on the scaled factor
     int info2 = 0;
     for (int j = 0; j < d; ++j) if (ok && info2 == 0 && M[j * LD + j] == 0.0) info2 = j + 1;
@@ -767,6 +777,7 @@ __global__ __launch_bounds__(64) void group_factor_kernel(EngineDev E)
     const int r0 = l16, r1 = l16 + 16, r0c = k0c, r1c = k1c;
     if (__any(go)) {
         for (int j = 0; j < d; ++j) {                        // dtrti2
+            MCX_WAVE_LDS_SYNC();                             // column j - 1 (other lanes' rows) is written
             const double ajj = 1.0 / M[j * LD + j];
             double x0 = 0.0, x1 = 0.0;
 #pragma unroll 4
@@ -785,6 +796,7 @@ __global__ __launch_bounds__(64) void group_factor_kernel(EngineDev E)
             }
         }
         for (int i = 0; i < d; ++i) {                        // dlauu2
+            MCX_WAVE_LDS_SYNC();
             const double aii = M[i * LD + i];
             if (i < d - 1) {
                 double dot = 0.0;
@@ -812,6 +824,7 @@ __global__ __launch_bounds__(64) void group_factor_kernel(EngineDev E)
             }
         }
     }
+    MCX_WAVE_LDS_SYNC();
     if (ok) {                                                // (a singular factor leaves the copy of R, as potri_packed does)
         double *iCt = E.iC + (size_t)tile * P * 64;
         for (int r = l16; r < d; r += 16) for (int k = r; k < d; ++k) iCt[(size_t)pidx(r, k, d) * 64 + cl] = M[r * LD + k];

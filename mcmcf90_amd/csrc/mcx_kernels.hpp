@@ -2601,9 +2601,9 @@ MCX_DEV void host_finish(const EngineDev &E, int tile, int lane, int it, LaneSta
 //   ss_j(theta) = sum_i (y_j(i) - theta_1 exp(-theta_{1+j} x_i))**2,  j = 1..nycol  (oracle/mcx_targets.h: mcxt_ss_expdata_cols)
 // with the library's box bounds and Gaussian priors.  what: 0 = checkbounds, priorfun, ssfunction; 1 = checkbounds and
 // priorfun; 2 = ssfunction alone (ssfunction_er0.f90: the default ssfunction_er is ssfunction).
-__global__ __launch_bounds__(64) void dev_eval_kernel(EngineDev E, const double *__restrict__ src, int stride_k, int use_stage2, int what)
+MCX_DEV void dev_eval_body(const EngineDev &E, int tile, int lane, const double *src, int stride_k, int use_stage2, int what)
 {
-    const int lane = threadIdx.x, tile = blockIdx.x, d = E.d, ny = E.ny;
+    const int d = E.d, ny = E.ny;
     const double *c_t = src + (size_t)tile * stride_k * 64;
     double *hev = E.hev + (size_t)tile * (NHE - 1 + ny) * 64;
     const double *hx = E.hx + (size_t)tile * NHX * 64;
@@ -2631,12 +2631,15 @@ __global__ __launch_bounds__(64) void dev_eval_kernel(EngineDev E, const double 
     GV(hev, HE_INB) = (inb && !skip) ? 1.0 : 0.0;
     GV(hev, HE_PRI) = pri;
 }
+__global__ __launch_bounds__(64) void dev_eval_kernel(EngineDev E, const double *__restrict__ src, int stride_k, int use_stage2, int what)
+{ dev_eval_body(E, blockIdx.x, threadIdx.x, src, stride_k, use_stage2, what); }
 
+// sR / sR2 / siC: pooled mode's shared factor, second-stage factor and inverse covariance (nullptr: the chain's own)
 template <int PHASE>
-__global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, const double *__restrict__ ramscale, int aux)
+MCX_DEV void host_phase_body(const EngineDev &E, int tile, int lane, int it, const double *__restrict__ ramscale, int aux, double *X,
+                             const double *__restrict__ sR = nullptr, const double *__restrict__ sR2 = nullptr, const double *__restrict__ siC = nullptr)
 {
-    extern __shared__ double X[];
-    const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
+    const int d = E.d;
     double *theta_t = E.theta + (size_t)tile * d * 64;
     double *cand_t = E.cand + (size_t)tile * d * 64;
     double *zs_t = E.zs + (size_t)tile * 2 * d * 64;           // host mode: first half = stage-1 z, second half = stage-2 z
@@ -2653,7 +2656,8 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
     if (PHASE == 0) {                                             // newpar = MCMC_propose(oldpar, R)
         double su = gen_normals(L.g, zs_t, lane, d, true);
         GV(hx, HX_SU) = su;
-        if (E.usesvd) gemvN_panels(E.Rf + (size_t)tile * d * d * 64, zs_t, cand_t, theta_t, lane, d, true);    // matmulx(R,z)
+        if (sR) { if (E.usesvd) gemvN_shared(sR, zs_t, cand_t, theta_t, lane, d); else trmv_shared(sR, zs_t, cand_t, theta_t, lane, d); }
+        else if (E.usesvd) gemvN_panels(E.Rf + (size_t)tile * d * d * 64, zs_t, cand_t, theta_t, lane, d, true);    // matmulx(R,z)
         else trmv_panels<false>(E.R + (size_t)tile * E.P * 64, zs_t, cand_t, theta_t, lane, d, true, E.method == M_RAM && L.pdesc != 0u);
     } else if (PHASE == 1) {
         const bool inb = GV(hev, HE_INB) != 0.0;
@@ -2674,7 +2678,8 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
             if (m) L.drtries += 1;
             for (int j = 0; j < (ny > 1 ? ny : 0); ++j) GV(ss2v, j) = GV(sshev, j);
             gen_normals(L.g, zs_t + (size_t)d * 64, lane, d, m);
-            if (E.usesvd) gemvN_panels(E.R2f + (size_t)tile * d * d * 64, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d, m);
+            if (sR2) { if (E.usesvd) gemvN_shared(sR2, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d); else trmv_shared(sR2, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d); }
+            else if (E.usesvd) gemvN_panels(E.R2f + (size_t)tile * d * d * 64, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d, m);
             else trmv_panels<false>(E.R2 + (size_t)tile * E.P * 64, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d, m);
             GV(hx, HX_SS2) = ss2; GV(hx, HX_PRI2) = pri2;
             GV(hx, HX_REJECT) = reject ? 1.0 : 0.0; GV(hx, HX_STAGE2) = m ? 1.0 : 0.0;
@@ -2787,12 +2792,12 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
                     else alpha32 = min1(d_exp(-0.5 * ((ss2 - ss3) / L.sigma2 + (pri2 - pri3))));
                     l2 = -0.5 * ((ss3 - L.ss1) / L.sigma2 + (pri3 - L.pri1));
                 }
-                const double *iCt = E.iC + (size_t)tile * E.P * 64;
+                const double *iCt = siC ? nullptr : E.iC + (size_t)tile * E.P * 64;
                 double *Xq = E.dr_lds ? X : zs_t, *Yq = E.dr_lds ? Y : zs_t + (size_t)d * 64;   // npar > 160: the (dead) normal vectors
                 for (int k = 0; k < d; ++k) GV(Xq, k) = GV(c2_t, k) - GV(cand_t, k);
-                double qa = quadform_sym(iCt, lane, d, Xq, Yq);
+                double qa = siC ? quadform_sym_shared(siC, lane, d, Xq, Yq) : quadform_sym(iCt, lane, d, Xq, Yq);
                 for (int k = 0; k < d; ++k) GV(Xq, k) = GV(theta_t, k) - GV(cand_t, k);
-                double qb = quadform_sym(iCt, lane, d, Xq, Yq);
+                double qb = siC ? quadform_sym_shared(siC, lane, d, Xq, Yq) : quadform_sym(iCt, lane, d, Xq, Yq);
                 double q1 = -0.5 * (qa - qb);
                 double alpha13 = min1(d_exp(l2 + q1) * (1.0 - alpha32) / (1.0 - L.alpha12));
                 bool rej2 = true;
@@ -2804,6 +2809,60 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
         host_finish(E, tile, lane, it, L, reject, dr_moved, ss2, pri2, ramscale, dr_moved ? sshev : ss2v);
     }
     lane_store(E, tile, lane, L);
+}
+template <int PHASE>
+__global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, const double *__restrict__ ramscale, int aux)
+{
+    extern __shared__ double X[];
+    host_phase_body<PHASE>(E, blockIdx.x, threadIdx.x, it, ramscale, aux, X);
+}
+
+// ---------------------------------------------------------------- nycol > 1 in ONE launch (step_kernel_cols)
+// Iterations it0..it1 of MCMC_run / MCMC_run_ram / MCMC_run_er / MCMC_run_scam for a target the DEVICE evaluates between the phases
+// of an iteration (the response-column target `expcols`: nycol sums of squares per point, one sigma2 per column, sums over the
+// columns in MCMC_alpha, MCMC_sscrit and MCMC_DR_alpha13, one gamma draw per column -- MCMC_DRAM.F90:100-135,162-206): the phase
+// bodies of the host-callback path and dev_eval_body in the order host_iteration launches them, fused into one kernel.  The phases
+// hand their intermediate results over through the chain's own global scratch (hev, hx, cand, ...) exactly as the separate launches
+// do -- every element is written and read back by the same lane, so program order is all the ordering there is to keep -- which makes
+// the fused form the phase form bit for bit (tests/test_gpu_host_callbacks.py, fixtures m1..m5 both ways).  ramscale: the table's
+// base (1 / it**nuparam at index it).  sR / sR2 / siC: pooled mode's shared tables.
+__global__ __launch_bounds__(64) void step_kernel_cols(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
+                                                       const double *__restrict__ sR, const double *__restrict__ sR2, const double *__restrict__ siC)
+{
+    extern __shared__ double X[];
+    const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
+    for (int it = it0; it <= it1; ++it) {
+        const double *rs = ramscale + it;
+        if (E.doscam) {                                 // MCMC_run_scam.F90:94-138: npar componentwise proposals, each with its own evaluation
+            for (int j = 0; j < d; ++j) {
+                host_phase_body<5>(E, tile, lane, it, rs, j, X);
+                dev_eval_body(E, tile, lane, E.cand, d, 0, 0);
+                host_phase_body<6>(E, tile, lane, it, rs, j, X);
+            }
+            host_phase_body<7>(E, tile, lane, it, rs, 0, X);
+            continue;
+        }
+        host_phase_body<0>(E, tile, lane, it, rs, 0, X, sR, sR2, siC);
+        if (E.method == M_ER) {                         // MCMC_run_er.F90:54-101: the threshold is drawn between priorfun and ssfunction
+            dev_eval_body(E, tile, lane, E.cand, d, 0, 1);
+            host_phase_body<3>(E, tile, lane, it, rs, 0, X, sR, sR2, siC);
+            dev_eval_body(E, tile, lane, E.cand, d, 1, 2);
+            host_phase_body<4>(E, tile, lane, it, rs, 0, X, sR, sR2, siC);
+            continue;
+        }
+        dev_eval_body(E, tile, lane, E.cand, d, 0, 0);
+        host_phase_body<1>(E, tile, lane, it, rs, 0, X, sR, sR2, siC);
+        if (E.dodr) {
+            dev_eval_body(E, tile, lane, E.cs, 2 * d, 1, 0);
+            host_phase_body<2>(E, tile, lane, it, rs, 0, X, sR, sR2, siC);
+        }
+    }
+    // pooled method = 'ram': the tick's statistic reads the last iteration's normals where the single-launch kernels leave them,
+    // in the (it & 1) half of the chain's two normal vectors (moments_kernel kind 2); the phases keep stage-1 normals in the first half
+    if (sR && !E.dodr && (it1 & 1)) {
+        double *zs_t = E.zs + (size_t)tile * 2 * d * 64;
+        for (int k = 0; k < d; ++k) GV(zs_t, d + k) = GV(zs_t, k);
+    }
 }
 
 // ---------------------------------------------------------------- MCMC_run1 / MCMC_run1_er: one evaluation per invocation
@@ -3726,11 +3785,14 @@ __global__ __launch_bounds__(64, 1) void adapt_cov_off_kernel(EngineDev E, int i
 #ifndef MCX_POST_WAVES
 #define MCX_POST_WAVES 2
 #endif
-template <bool SVD>
+// XG (npar > 320: one npar-vector per lane no longer fits a CU's LDS): the work vector in the tile's global scratch (EngineDev::xscr) -- a
+// compile-time choice, so that neither form uses flat accesses.  Slower; any npar.
+template <bool SVD, bool XG = false>
 __global__ __launch_bounds__(64, SVD ? 1 : MCX_POST_WAVES) void adapt_post_kernel(EngineDev E, int it, int mode, int phase, uint8_t *need, int batch_done)
 {
-    extern __shared__ double X[];
+    extern __shared__ double Xlds[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d, P = E.P;
+    double *X = XG ? E.xscr + (size_t)tile * 2 * d * 64 : Xlds;
     double *Rt = E.R + (size_t)tile * P * 64;
     double *Ct = E.cmat + (size_t)tile * P * 64;
     double *Tt = E.Rtmp + (size_t)tile * P * 64;
@@ -4745,6 +4807,10 @@ __global__ __launch_bounds__(256) void gather_lane_kernel(const double *__restri
 // kind 1: the same followed by sum_c stayed_c (the pooled rejection count of a burn-in tick)  (2 + d + P)
 // kind 2: the pooled RAM statistic of iteration `it` (MCMC_run_ram.F90:166-172 summed over chains): [count, sum alpha,
 //         sum_c sign(a_c) x_c x_c'], x_c = u_c / sum(u_c**2) * a_c, a_c = rs (alpha_c - alphatarget)     (2 + P)
+// BIG (npar > 318: the tile's 64 vectors no longer fit a CU's LDS): the same terms with every x value formed from global memory where it
+// is used -- the same operations on the same operands, so the same bits; only the four 64-vectors (count, alpha or stayed, sign, sum(u**2))
+// and the chains' a = rs (alpha - alphatarget) stay in LDS.  Slower (each term reads its 2 x 64 values through L2); any npar.
+template <bool BIG>
 __global__ __launch_bounds__(256) void moments_kernel(EngineDev E, double *out, int nchains, int kind, int it, double rs)
 {
     // The tile's 64 vectors x_c go to LDS once (chain-major, odd stride); then each of the 256 threads takes terms m, m + 256, ...:
@@ -4753,8 +4819,8 @@ __global__ __launch_bounds__(256) void moments_kernel(EngineDev E, double *out, 
     // lane on a term of its own; the old form (one chain per lane, 64 terms at a time transposed through LDS) spent its time
     // in the latencies of 1300 global loads and 2 x 20 barriers per tile at four waves per CU.
     extern __shared__ double XS[];                      // x[64][DP]; then count[64], alpha or stayed [64], sign(a) [64], sum(u**2) [64]
-    const int tid = threadIdx.x, tile = blockIdx.x, d = E.d, P = E.P, DP = d | 1;
-    double *sp0 = XS + (size_t)64 * DP, *sp1 = sp0 + 64, *sg = sp1 + 64, *ssu = sg + 64;
+    const int tid = threadIdx.x, tile = blockIdx.x, d = E.d, P = E.P, DP = BIG ? 0 : (d | 1);
+    double *sp0 = XS + (size_t)64 * DP, *sp1 = sp0 + 64, *sg = sp1 + 64, *ssu = sg + 64, *sa = ssu + 64;
     const double *theta_t = E.theta + (size_t)tile * d * 64;
     const double *z_t = E.zs + ((size_t)tile * 2 + (it & 1)) * d * 64;        // kind 2: the normals iteration `it` proposed with
     const int len = (kind == 2) ? 2 + P : (1 + d + P + (kind == 1 ? 1 : 0));
@@ -4773,8 +4839,10 @@ __global__ __launch_bounds__(256) void moments_kernel(EngineDev E, double *out, 
             sgn = (!act || a >= 0.0) ? 1.0 : -1.0;
         } else if (kind == 1) s1 = act ? (double)TIDX(E.ictr, tile, NICTR, I_STAYED, c0) : 0.0;
         sp1[c0] = s1; sg[c0] = sgn; ssu[c0] = su;
+        if (BIG) sa[c0] = (kind == 2) ? rs * (TIDX(E.scal, tile, NSCAL, S_ALPHA12, c0) - E.alphatarget) : 0.0;
     }
     __syncthreads();
+    if (!BIG) {
     if (kind == 2) {
         const double alpha = TIDX(E.scal, tile, NSCAL, S_ALPHA12, c0);
         const double a = rs * (alpha - E.alphatarget), su = ssu[c0];
@@ -4783,6 +4851,13 @@ __global__ __launch_bounds__(256) void moments_kernel(EngineDev E, double *out, 
         for (int k = tid >> 6; k < d; k += 4) XS[(size_t)c0 * DP + k] = act ? (GV2(theta_t, k, c0) - E.par0[k]) : 0.0;
     }
     __syncthreads();
+    }
+    // x value k of chain l of the tile: from the LDS copy, or (BIG) formed here
+    auto xv = [&](int l, int k) -> double {
+        if (!BIG) return XS[(size_t)l * DP + k];
+        if (!(sp0[l] != 0.0)) return 0.0;
+        return (kind == 2) ? GV2(z_t, k, l) / ssu[l] * sa[l] : (GV2(theta_t, k, l) - E.par0[k]);
+    };
     const int pair0 = (kind == 2) ? 2 : 1 + d;          // first second-moment term
     for (int m = tid; m < len; m += 256) {
         double a[64];
@@ -4794,7 +4869,7 @@ __global__ __launch_bounds__(256) void moments_kernel(EngineDev E, double *out, 
             for (int l = 0; l < 64; ++l) a[l] = sp1[l];
         } else if (m < pair0) {
 #pragma unroll
-            for (int l = 0; l < 64; ++l) a[l] = XS[(size_t)l * DP + (m - 1)];
+            for (int l = 0; l < 64; ++l) a[l] = xv(l, m - 1);
         } else if (m >= pair0 + P) {                    // kind 1: the rejection counts
 #pragma unroll
             for (int l = 0; l < 64; ++l) a[l] = sp1[l];
@@ -4806,10 +4881,10 @@ __global__ __launch_bounds__(256) void moments_kernel(EngineDev E, double *out, 
             const int i2 = q - j * (j + 1) / 2;
             if (kind == 2) {
 #pragma unroll
-                for (int l = 0; l < 64; ++l) { const double t = XS[(size_t)l * DP + i2] * XS[(size_t)l * DP + j]; a[l] = (sg[l] >= 0.0) ? t : -t; }
+                for (int l = 0; l < 64; ++l) { const double t = xv(l, i2) * xv(l, j); a[l] = (sg[l] >= 0.0) ? t : -t; }
             } else {
 #pragma unroll
-                for (int l = 0; l < 64; ++l) a[l] = XS[(size_t)l * DP + i2] * XS[(size_t)l * DP + j];
+                for (int l = 0; l < 64; ++l) a[l] = xv(l, i2) * xv(l, j);
             }
         }
 #pragma unroll

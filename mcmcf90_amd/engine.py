@@ -354,6 +354,19 @@ class Engine:
         return ms.value, nl.value, ns.value
 
 
+def kernel_table():
+    """[(family, name), ...]: every entry of the engine's kernel-selection tables (mcmcx_debug_kernel_table); no device needed."""
+    L = _lib.load()
+    n = L.mcmcx_debug_kernel_table(-1, None, 0)
+    out = []
+    for i in range(n):
+        buf = C.create_string_buffer(128)
+        L.mcmcx_debug_kernel_table(i, buf, 128)
+        fam, name = buf.value.decode().split(":", 1)
+        out.append((fam, name))
+    return out
+
+
 def engine_from_problem(cfg_kw, prob_kw, nchains=1, **extra):
     """Build an Engine from the same (cfg, problem) dictionaries the oracle / golden fixtures use."""
     pk = dict(prob_kw)

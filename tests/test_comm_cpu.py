@@ -42,7 +42,7 @@ def _run(world):
 
 
 def test_two_ranks_barrier_and_scalar_allreduce():
-    for world in (2, 4):
+    for world in (2, 4, 8):                                  # eight: the node the scaling bench runs on (one process per rank, device -1: no GPU touched)
         outs = _run(world)
         tri = world * (world + 1) / 2
         for r, o in enumerate(outs):
@@ -89,6 +89,54 @@ def test_bench_world_size_mismatch_is_an_error():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=120, env=env)
     assert p.returncode != 0 and b"WORLD_SIZE" in p.stderr
+
+
+def test_bench_plan_shards_the_headline_over_eight_ranks():
+    """`bench.py --gpus N --plan`: the sharding of BASELINE config 4 for N = 1, 2, 4, 8 without a GPU -- contiguous chain blocks keyed by chain id,
+    the same 1 048 576 chains at every N (strong scaling), c2 / c3 a fixed count per GPU (weak)."""
+    for world in (1, 2, 4, 8):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--plan"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert p.returncode == 0, p.stderr.decode()
+        j = json.loads(p.stdout.decode())
+        assert j["n_gpus"] == world and j["total_chains"] == 1048576 and j["scaling"] == "strong" and j["chains_per_gpu"] == 1048576 // world
+        ids = [(r["rank"], r["chain_id0"], r["chains"]) for r in j["ranks"]]
+        assert ids == [(r, r * (1048576 // world), 1048576 // world) for r in range(world)]
+        assert all(r["chains"] % 64 == 0 for r in j["ranks"])             # whole tiles: the tree over ranks continues the tree over tiles
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--plan", "--workload", "c3"], stdout=subprocess.PIPE, timeout=120)
+    j = json.loads(p.stdout.decode())
+    assert j["scaling"] == "weak" and j["chains_per_gpu"] == 262144 and j["total_chains"] == 8 * 262144
+
+
+def test_eight_ranks_stale_segment_and_a_late_rank_zero():
+    """Eight processes (the node's rank count) on the host transport with device -1: a segment of the same key left behind by an earlier
+    eight-rank run, and this run's rank 0 arriving last -- every rank must still form, reduce and clean up."""
+    import time
+    key = "stale8%s" % uuid.uuid4().hex[:10]
+    worker = (
+        "import sys, time; sys.path.insert(0, %r)\n"
+        "from mcmcf90_amd import Comm\n"
+        "rank, delay, keep = int(sys.argv[1]), float(sys.argv[2]), int(sys.argv[3])\n"
+        "time.sleep(delay)\n"
+        "c = Comm(%r, rank, 8, -1, backend='host')\n"
+        "c.barrier(); print('formed', rank, float(c.allreduce([rank + 1.0])[0]), float(c.allreduce([float(rank)], op='max')[0]), flush=True)\n"
+        "import os\n"
+        "if keep: os._exit(0)\n"
+        "c.close()\n") % (ROOT, key)
+
+    def launch(rank, delay, keep):
+        return subprocess.Popen([sys.executable, "-c", worker, str(rank), str(delay), str(keep)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+
+    a = [launch(r, 0.0, 1) for r in range(8)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in a]
+    assert all("formed" in o and " 36.0 7.0" in o for o in outs), outs
+    assert os.path.exists("/dev/shm/mcmcx_" + key)
+    t0 = time.time()
+    b = [launch(r, 0.0 if r else 1.5, 0) for r in range(8)]      # ranks 1..7 arrive 1.5 s before rank 0
+    outs = [p.communicate(timeout=180)[0].decode() for p in b]
+    assert all(p.returncode == 0 for p in b), outs
+    assert all("formed" in o and " 36.0 7.0" in o for o in outs), outs
+    assert time.time() - t0 < 90
+    assert not os.path.exists("/dev/shm/mcmcx_" + key)
 
 
 def test_a_left_over_segment_is_not_mistaken_for_this_runs(tmp_path):

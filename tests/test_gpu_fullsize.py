@@ -80,6 +80,70 @@ def test_c4_gauss50_ram_131072_chains(oracle):
     e.close()
 
 
+def test_c4_gauss50_ram_1048576_chains(oracle):
+    """BASELINE config 4 as written -- ALL 1 048 576 chains on one GPU, what bench.py times at N = 1 (10.7 GB of per-chain factors, byte
+    offsets past 2**32): 130 iterations with a launch boundary in the middle; chains from both ends and the middle of the range against
+    oracle.run_chain (state, factor, counters, stream position), every chain's counters against the accept ballots, no status flag."""
+    from mcmcf90_amd import engine_from_problem
+    from mcmcf90_amd.workloads import problem
+    n, nsimu = 1048576, 130
+    ckw, pkw, _ = problem("c4", nsimu)
+    e = engine_from_problem(ckw, pkw, nchains=n, record_accept=1)
+    e.init(); e.run(67); e.run()
+    assert e.last_kernel() == "step_kernel_ram_wide", e.last_kernel()
+    _check_chains_vs_oracle(oracle, e, ckw, pkw, [0, 524288, 524289 + 63, 1048575])
+    tot = e.totals()
+    masks = e.accept_masks()                                  # [nsimu][ntiles] wave ballots
+    pop = int(np.unpackbits(masks.view(np.uint8)).sum())
+    assert pop == n * nsimu - tot["stayed"]                   # accepted (incl. row 1) + stayed = nsimu per chain
+    assert tot["proposals"] == n * (nsimu - 1)
+    assert tot["status"] == 0                                 # the OR of all chains' status bits: no failed downdate anywhere
+    e.close()
+
+
+def test_c4_gauss50_pooled_ram_1048576_chains(oracle, monkeypatch):
+    """... and its pooled twin (bench.py's `c4_pooled`: one shared factor, the RAM statistic of all chains folded in every adaptint
+    iterations): at 16384 tiles the engine takes pooled_mfma_kernel<false, true> (two waves per SIMD) by itself.  Chains from both ends and
+    the middle of the range are the single-chain oracle with the factor fixed (up to the tick at 100) and, carried on with the engine's
+    pooled factor, to the end; the one-wave-per-SIMD instance gives the same 1 048 576 states, ballots and pooled factor bit for bit."""
+    from mcmcf90_amd import engine_from_problem
+    from mcmcf90_amd.workloads import problem
+    n, nsimu, tick = 1048576, 130, 100
+    ckw, pkw, _ = problem("c4", nsimu, adaptint=tick)
+    monkeypatch.delenv("MCMCX_POOLED_WAVES", raising=False)
+    e = engine_from_problem(ckw, pkw, nchains=n, pooled=1, record_accept=1)
+    e.init(); e.run(tick)
+    assert e.last_kernel() == "pooled_mfma_kernel<false, true>", e.last_kernel()
+    plain = oracle.make_cfg(**dict(ckw, doadapt=0, method="dram"))
+    prob = oracle.Problem(**pkw)
+    picks = [0, 63, 524288, 1048575]
+    live = {c: oracle.LiveChain(plain, prob, chain_id=c) for c in picks}
+    th = e.theta()
+    for c in picks:
+        live[c].run(tick)
+        np.testing.assert_array_equal(_bits(th[c]), _bits(live[c].theta))
+    R = e.pooled()[3]
+    assert not np.array_equal(np.triu(R), 0.1 * 2.4 / np.sqrt(50.0) * np.eye(50))     # the tick did refactor
+    e.run()
+    th = e.theta(); masks = e.accept_masks(); tot = e.totals()
+    for c in picks:
+        live[c].set_R(R)
+        live[c].run(nsimu)
+        np.testing.assert_array_equal(_bits(th[c]), _bits(live[c].theta))
+        assert e.rng(c)[0] == live[c].ch.contents.rng.n
+        live[c].close()
+    pop = int(np.unpackbits(masks.view(np.uint8)).sum())
+    assert pop == n * nsimu - tot["stayed"] and tot["proposals"] == n * (nsimu - 1) and tot["status"] == 0
+    e.close()
+    monkeypatch.setenv("MCMCX_POOLED_WAVES", "1")
+    e1 = engine_from_problem(ckw, pkw, nchains=n, pooled=1, record_accept=1)
+    e1.init(); e1.run()
+    assert e1.last_kernel() == "pooled_mfma_kernel<false>", e1.last_kernel()
+    assert np.array_equal(_bits(e1.theta()), _bits(th)) and np.array_equal(e1.accept_masks(), masks)
+    np.testing.assert_array_equal(_bits(e1.pooled()[3]), _bits(R))
+    e1.close()
+
+
 def test_c5_illcond200_scam_pooled_65536_chains(oracle):
     """BASELINE config 5 at full size in the pooled mode (one rotation for all chains, scam_pooled_kernel on the f64
     matrix cores).  (1) up to the first tick every chain is the single-chain oracle with adaptation off; (2) the shared
@@ -132,7 +196,7 @@ def test_c5_illcond200_scam_pooled_65536_chains(oracle):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("lane_svd", [0, 1], ids=["blocked_svd", "lane_svd"])
+@pytest.mark.parametrize("lane_svd", [0, pytest.param(1, marks=pytest.mark.extended)], ids=["blocked_svd", "lane_svd"])   # (the lane form is production below npar 48 only)
 def test_c5_illcond200_scam_replicas_two_ticks(oracle, lane_svd, monkeypatch):
     """BASELINE config 5's target with per-chain rotations (the reference's semantics) THROUGH two adaptations: 70 chains
     (a ragged second tile), adaptint = 10, 25 iterations = 5000 componentwise proposals per chain, the adaptation's pinned

@@ -60,7 +60,7 @@ def _draw(seed):
     return ckw, pkw
 
 
-def _check_against_oracle(oracle, ckw, pkw, seed):
+def _check_against_oracle(oracle, ckw, pkw, seed, want_kernel=None):
     from mcmcf90_amd import engine_from_problem
     cfg = oracle.make_cfg(**ckw)
     prob = oracle.Problem(**pkw)
@@ -74,6 +74,8 @@ def _check_against_oracle(oracle, ckw, pkw, seed):
         e.close()
         return
     e.init(); e.run()
+    if want_kernel:
+        assert e.last_kernel() == want_kernel, e.last_kernel()
     for c in (0, 63, 66):
         o = oracle.run_chain(cfg, prob, chain_id=3 * seed + c, continue_on_downdate_fail=True)
         assert o.rc == 0, (ckw, o.rc)
@@ -97,8 +99,9 @@ def _check_against_oracle(oracle, ckw, pkw, seed):
     e.close()
 
 
-@pytest.mark.parametrize("kernels", ["lane", "auto"])          # the lane-per-chain kernels / whatever the engine picks (tests/conftest.py)
-@pytest.mark.parametrize("seed", range(300))
+# (the lane-per-chain kernels on every seed, the engine's own choice -- the lane-group kernels wherever they cover the draw -- on every other one:
+#  tools/bigfuzz.py runs thousands of seeds on each family once per round)
+@pytest.mark.parametrize("seed,kernels", [(s, "lane") for s in range(300)] + [(s, "auto") for s in range(0, 300, 2)])
 def test_random_configuration(oracle, seed, kernels):
     ckw, pkw = _draw(seed)
     _check_against_oracle(oracle, ckw, pkw, seed)
@@ -125,7 +128,7 @@ def _draw_ram_svd(seed):
 @pytest.mark.parametrize("seed", range(60))
 def test_random_configuration_ram_with_svd_factor(oracle, seed):
     ckw, pkw = _draw_ram_svd(seed)
-    _check_against_oracle(oracle, ckw, pkw, seed)
+    _check_against_oracle(oracle, ckw, pkw, seed, want_kernel="step_kernel_ram_fullr")
 
 
 @pytest.mark.parametrize("kernels", ["lane", "auto"])
@@ -245,11 +248,13 @@ def test_random_configuration_larger_npar(oracle, seed, kernels):
     e.close()
 
 
-@pytest.mark.parametrize("seed", range(30))
-def test_pooled_am_matrix_core_kernel_equals_lane_kernel(seed, monkeypatch):
+@pytest.mark.parametrize("seed,waves", [(s, 1) for s in range(30)] + [(s, 2) for s in (0, 3, 7, 11, 19, 26)])
+def test_pooled_am_matrix_core_kernel_equals_lane_kernel(seed, waves, monkeypatch):
     """pooled_mfma_kernel (products as MFMA tiles) == the lane-per-chain pooled kernel, for random sizes (one to three
-    passes of output blocks, ragged last block and k-block), targets, bounds, priors and the sigma2 update."""
+    passes of output blocks, ragged last block and k-block), targets, bounds, priors and the sigma2 update.  waves = 2: the
+    instance that shares a SIMD between two waves (pooled_mfma_kernel<false, true>; the engine's own choice from 2048 tiles on)."""
     from mcmcf90_amd import engine_from_problem
+    monkeypatch.setenv("MCMCX_POOLED_WAVES", str(waves))
     r = np.random.default_rng(11000 + seed)
     d = int(r.choice([1, 2, 3, 5, 16, 17, 31, 48, 50, 63, 64, 65, 80, 97, 130]))
     kind = str(r.choice(["gauss", "gauss", "banana"])) if d >= 2 else "gauss"
@@ -269,6 +274,7 @@ def test_pooled_am_matrix_core_kernel_equals_lane_kernel(seed, monkeypatch):
         pkw.update(pri_mu=np.zeros(d), pri_sig=np.where(r.random(d) < 0.5, 0.0, 1.0))
     e = engine_from_problem(ckw, pkw, nchains=n, pooled=1, record_accept=1)
     e.init(); e.run()
+    assert e.last_kernel() == ("pooled_mfma_kernel<false, true>" if waves == 2 else "pooled_mfma_kernel<false>"), e.last_kernel()
     monkeypatch.setenv("MCMCX_POOLED_SCALAR", "1")
     e2 = engine_from_problem(ckw, pkw, nchains=n, pooled=1, record_accept=1)
     e2.init(); e2.run()
@@ -389,6 +395,7 @@ def test_random_configuration_response_columns_device_target(oracle, seed):
     prob = oracle.Problem(**pkw)
     e = engine_from_problem(ckw, pkw, nchains=67, record_chain=1, chain_id0=2 * seed)
     e.init(); e.run()
+    assert e.last_kernel() in ("step_kernel_cols", "step_kernel_cols<scam>"), e.last_kernel()      # one launch per segment (round 5), not phase kernels
     for c in (0, 1, 66):
         o = oracle.run_chain(cfg, prob, chain_id=2 * seed + c, continue_on_downdate_fail=True)
         ch, ss, s2 = e.chain(c)

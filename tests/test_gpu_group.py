@@ -32,6 +32,19 @@ def _problem(kind, d, seed, priors=False, bounds=False):
     return pkw
 
 
+def _expected_group_kernel(d, drscale, gw):
+    """The entry of mcx_api.hip's GROUP_TABLE a configuration runs: quads when asked for at npar <= 16; with delayed rejection the
+    instantiation without R2 when drscale is a power of two (npar <= 24), the general one otherwise."""
+    import math
+    quad = gw == 4 and d <= 16
+    if not drscale > 0.0:
+        return "group_step_kernel<quad>" if quad else "group_step_kernel"
+    pow2 = math.frexp(drscale)[0] == 0.5 and d <= 24
+    if quad:
+        return "group_step_kernel<quad, DR2>" if pow2 else "group_step_kernel<quad, DR>"
+    return "group_step_kernel<DR2>" if pow2 else "group_step_kernel<DR>"
+
+
 def _run(ckw, pkw, nchains, group, monkeypatch, chains=(0, 1, 5, 69), gw=16, **ekw):
     from mcmcf90_amd import engine_from_problem
     monkeypatch.setenv("MCMCX_GROUP", "1" if group else "0")
@@ -40,7 +53,8 @@ def _run(ckw, pkw, nchains, group, monkeypatch, chains=(0, 1, 5, 69), gw=16, **e
     e.init(); e.run()
     k = e.last_kernel()
     assert k.startswith("group_step_kernel") == bool(group), k
-    assert ("quad" in k) == (bool(group) and gw == 4 and int(pkw["npar"]) <= 16), k
+    if group:
+        assert k == _expected_group_kernel(int(pkw["npar"]), float(ckw.get("drscale", 0.0)) if ckw.get("method", "dram") != "er" else 0.0, gw), k
     chains = [c for c in chains if c < nchains]
     out = dict(theta=e.theta().copy(), masks=e.accept_masks().copy(), scal=e.scalars().copy(),
                rng=[e.rng(c) for c in chains], ctr=[e.counters(c) for c in chains], R=[e.R(c).copy() for c in chains])

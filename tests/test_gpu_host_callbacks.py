@@ -180,6 +180,50 @@ def test_two_response_columns(oracle, name):
     e.close()
 
 
+@pytest.mark.parametrize("form", ["one_launch", "phase_kernels"])
+@pytest.mark.parametrize("name", ["m1_expdata2_dram_dr_s2", "m2_expdata2_er_s2", "m3_expdata2_scam_s2", "m4_expdata2_ram",
+                                  "m5_expdata2_burnin_greedy_priors"])
+def test_two_response_columns_on_the_device_in_one_launch(oracle, name, form, monkeypatch):
+    """nycol = 2 with the device-resident response-column target WITHOUT the phase kernels: step_kernel_cols runs a whole segment of
+    iterations in one launch (the sums over the columns in MCMC_alpha / MCMC_sscrit / MCMC_DR_alpha13, one gamma draw per column:
+    MCMC_DRAM.F90:100-135,162-206, MCMC_init.F90:119-132).  The reference's two-column fixtures -- run-length column, stream position,
+    rows, ss and sigma2 tails -- and the oracle bit for bit, 130 chains incl. a ragged tile; the phase-kernel form (MCMCX_COLS_PHASED=1)
+    is the same chain."""
+    from mcmcf90_amd import engine_from_problem
+    from golden_util import accepted_from_runlen
+    if form == "phase_kernels":
+        monkeypatch.setenv("MCMCX_COLS_PHASED", "1")
+    z, cfg, prob = load(name, oracle)
+    ckw, pkw = _kw(z)
+    cid = int(z["chain_id"])
+    e = engine_from_problem(ckw, pkw, nchains=130, chain_id0=cid - 1, record_chain=1, record_accept=1)
+    e.init(); e.run(57); e.run()                                      # a launch boundary off the adaptation ticks
+    if form == "one_launch":
+        assert e.last_kernel() == ("step_kernel_cols<scam>" if cfg.doscam else "step_kernel_cols"), e.last_kernel()
+    else:
+        assert e.last_kernel() == ""                                   # no sampling-kernel table entry: the iteration is cut into phase launches
+    np.testing.assert_array_equal(e.accepted(1), accepted_from_runlen(z["runlen"]))
+    ch, ss, s2 = e.chain(1)
+    assert ss.shape[1] == 3 and (not cfg.updatesigma or s2.shape[1] == 2)
+    k = z["rows_head"].shape[0]
+    np.testing.assert_allclose(ch[-k:, :-1], z["rows_tail"], rtol=1e-7)
+    np.testing.assert_allclose(ss[-k:, :-1], z["ss_tail"], rtol=1e-7)
+    if cfg.updatesigma:
+        np.testing.assert_allclose(s2[-k:], z["s2_tail"], rtol=1e-7)
+    assert e.rng(1)[0] == int(z["rng_n"])
+    for c in (0, 1, 64, 129):
+        o = oracle.run_chain(cfg, prob, chain_id=cid - 1 + c, continue_on_downdate_fail=True)
+        chc, ssc, s2c = e.chain(c)
+        np.testing.assert_array_equal(_bits(chc), _bits(o.chain))
+        np.testing.assert_array_equal(_bits(ssc), _bits(o.sschain))
+        if cfg.updatesigma:
+            np.testing.assert_array_equal(_bits(s2c), _bits(o.s2chain))
+        assert e.rng(c)[0] == o.rng_n
+        cnt = e.counters(c)
+        assert (cnt["stayed"], cnt["bndstayed"], cnt["draccepted"], cnt["drtries"], cnt["erstayed"]) == (o.stayed, o.bndstayed, o.draccepted, o.drtries, o.erstayed)
+    e.close()
+
+
 def test_two_columns_need_the_host_target():
     from mcmcf90_amd import Engine, make_config, McmcError
     e = Engine(make_config(2, 1, nsimu=10))

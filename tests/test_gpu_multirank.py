@@ -143,6 +143,63 @@ def test_tree_over_ranks_equals_tree_over_tiles(tmp_path, nranks):
     assert np.array_equal(mN.view(np.uint64), m1.view(np.uint64))
 
 
+@pytest.mark.parametrize("mode", ["pooled_am", "pooled_ram", "replicas_moments"])
+def test_eight_ranks_in_one_process_equal_one_rank_with_eight_times_the_chains(mode):
+    """N = 8 -- the node the scaling bench runs on -- through the engine on the one GPU of the box: eight engines of n chains (chain_id0 = r n),
+    one host thread each, meet in eight communicators of the host transport formed INSIDE this process (the GPU box allows six processes
+    on its card; threads are free), i.e. every tick runs the local tree, the eight-slot gather and moments_tree_kernel with ranks as
+    tiles.  The pooled factor, every chain's state and the all-reduced moment vector must be those of ONE engine of 8 n chains bit for
+    bit: for the moments of the current states (pooled AM; replicas mode: the posterior-moment output) AND for the pooled-RAM statistic
+    (the third kind of exchanged vector).  Eight can tell a pairwise tree from a ring or a linear sum; two cannot."""
+    import threading
+    import uuid
+    from mcmcf90_amd import Comm, engine_from_problem
+    from mcmcf90_amd.workloads import problem
+    world, n = 8, 128                                       # two tiles per rank
+    if mode == "pooled_ram":
+        ckw, pkw, _ = problem("c4", 131, adaptint=20)
+        ekw = dict(pooled=1)
+    elif mode == "pooled_am":
+        ckw, pkw, _ = problem("c4", 231, adaptint=50)
+        ckw = dict(ckw, method="dram")
+        ekw = dict(pooled=1)
+    else:
+        ckw, pkw, _ = problem("c2", 231)
+        ekw = dict()
+    one = engine_from_problem(ckw, pkw, nchains=world * n, record_accept=1, **ekw)
+    one.init(); one.run()
+    ref = dict(theta=one.theta(), mom=one.allreduce_moments(), pooled=one.pooled()[3] if ekw else None, masks=one.accept_masks())
+    one.close()
+    key = "t8" + uuid.uuid4().hex[:12]
+    res, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            c = Comm(key, r, world, 0, backend="host")
+            e = engine_from_problem(ckw, pkw, nchains=n, chain_id0=r * n, record_accept=1, comm=c, **ekw)
+            e.init(); e.run()
+            res[r] = dict(theta=e.theta(), mom=e.allreduce_moments(), pooled=e.pooled()[3] if ekw else None, masks=e.accept_masks())
+            c.barrier()
+            e.close(); c.close()
+        except Exception as ex:                              # a rank that fails must not leave the others in a gather for ever
+            errs.append((r, repr(ex)))
+            raise
+
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs and all(x is not None for x in res), errs
+    bits = lambda a: np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+    assert np.array_equal(bits(np.vstack([x["theta"] for x in res])), bits(ref["theta"]))
+    assert np.array_equal(np.hstack([x["masks"] for x in res]), ref["masks"])
+    for x in res:
+        assert np.array_equal(bits(x["mom"]), bits(ref["mom"])) and x["mom"][0] == world * n
+        if ekw:
+            assert np.array_equal(bits(x["pooled"]), bits(ref["pooled"]))
+
+
 def test_rocm_rccl_without_torch(tmp_path):
     """bench.py's ranks never import torch, so their librccl / libamdhip64 are /opt/rocm's (pytest's own process has
     torch's copies loaded first).  The same transport calls in a torch-free child: unique id through the shm bootstrap,

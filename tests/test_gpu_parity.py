@@ -30,6 +30,19 @@ def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
+# the lane-per-chain kernel each fixture runs at 130 chains (mcx_api.hip's STEP_TABLE / SCAM_TABLE; tests/test_kernel_table.py wants every
+# entry of those tables asserted by some parity test)
+LANE_KERNEL = {
+    "c1_expdata_dram": "step_kernel_dr", "c1_priors_ap": "step_kernel_dr", "c1_shipped_nml": "step_kernel_ldsr",
+    "c2_gauss10_am": "step_kernel_ldsr", "c2_gauss10_am_initcmatn": "step_kernel_ldsr", "c3_banana20_dram": "step_kernel_dr",
+    "c4_gauss50_am": "step_kernel_ldsv", "c4_gauss50_ram": "step_kernel_ram_wide", "e1_expdata_ram_bounds_s2": "step_kernel_ram_ldsr",
+    "e2_gauss1_am": "step_kernel_ldsr", "e3_gauss3_ram_burnin": "step_kernel_ram_ldsr", "e4_banana9_dram_noadapt": "step_kernel_dr",
+    "e5_gauss17_am_short": "step_kernel_ldsv", "e6_expdata_er_priors": "step_kernel_ldsr", "e7_gauss10_er": "step_kernel_ldsr",
+    "e8_nan_target_dr": "step_kernel_dr", "s1_gauss6_scam": "scam_mw_kernel<8>", "s2_gauss6_dram_svd": "step_kernel_ldsv",
+    "s3_gauss6_dram_svd_dr": "step_kernel_dr", "s4_expdata_scam_s2": "scam_mw_kernel<8>", "s5_banana20_scam": "scam_mw_kernel<8>",
+}
+
+
 @pytest.mark.parametrize("kernels", ["lane", "auto"])          # the lane-per-chain kernels / whatever the engine picks (tests/conftest.py)
 @pytest.mark.parametrize("name", SUPPORTED)
 def test_engine_matches_oracle_and_reference(oracle, name, kernels):
@@ -42,6 +55,8 @@ def test_engine_matches_oracle_and_reference(oracle, name, kernels):
     off = 1 if cid > 0 else 0                  # engine chain `off` has the fixture's stream
     e.init(); e.run()
     assert e.simuind == cfg.nsimu
+    if kernels == "lane":
+        assert e.last_kernel() == LANE_KERNEL[name], e.last_kernel()
     # --- against the real reference (fixture)
     acc = e.accepted(off)
     np.testing.assert_array_equal(acc, accepted_from_runlen(z["runlen"]))
@@ -232,6 +247,9 @@ def test_extreme_dimensions(oracle, method, d, extra, monkeypatch):
     pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.05), cmat0=(0.3 / d) * np.eye(d), mu=np.zeros(d), lam=lam)
     e = engine_from_problem(ckw, pkw, nchains=66, record_accept=1)
     e.init(); e.run()
+    want = {("dram", 256, 0): "step_kernel<false, false, false>", ("ram", 256, 0): "step_kernel_ram_wide", ("dram", 1, 1): "step_kernel_dr",
+            ("dram", 150, 1): "step_kernel_dr", ("dram", 160, 1): "step_kernel_dr", ("dram", 161, 1): "step_kernel_dr_big", ("dram", 256, 1): "step_kernel_dr_big"}
+    assert e.last_kernel() == want[(method, d, 1 if extra else 0)], e.last_kernel()
     cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
     th = e.theta()
     for c in (0, 65):
@@ -239,6 +257,48 @@ def test_extreme_dimensions(oracle, method, d, extra, monkeypatch):
         np.testing.assert_array_equal(e.accepted(c), o.accepted)
         np.testing.assert_array_equal(_bits(th[c]), _bits(o.theta))
         np.testing.assert_array_equal(_bits(np.triu(e.R(c))), _bits(np.triu(o.R)))
+    e.close()
+
+
+@pytest.mark.parametrize("method,d,extra", [("dram", 300, {}), ("ram", 300, {}), ("dram", 330, {"drscale": 2.0}), ("ram", 330, {}),
+                                            # (one lane per chain through a 257 x 257 Jacobi SVD: minutes -- run with MCMCX_EXTENDED=1)
+                                            pytest.param("dram", 257, {"condmax": 1e8}, marks=pytest.mark.extended), pytest.param("scam", 257, {}, marks=pytest.mark.extended)])
+def test_npar_above_256(oracle, method, d, extra):
+    """The reference allocates whatever npar the namelist says (MCMC_init.F90:81-102); up to round 4 the engine stopped at 256.  Above it the
+    forms that keep an npar-vector per lane in LDS give way to global scratch -- the adaptation's work vector above npar 320
+    (adapt_post_kernel<.., true>), the pooled-moment kernel above 317 (moments_kernel<true>), the blocked SVD to the lane-per-chain one above 256:
+    slower, bit-equal.  AM, RAM (update and downdate sweeps over 45 150 elements), delayed rejection with its three factors, the SVD
+    factor and SCAM, 70 chains incl. a ragged tile, one adaptation each, against the oracle -- and the pooled moments against numpy."""
+    from mcmcf90_amd import engine_from_problem
+    from mcmcf90_amd import dist as mdist
+    rng = np.random.default_rng(d)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    lam = A @ A.T + np.eye(d)
+    nsimu, adaptint = (12, 5) if method == "scam" else (45, 20)
+    ckw = dict(nsimu=nsimu, adaptint=adaptint, updatesigma=0, method=method, **extra)
+    pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.05), cmat0=(0.3 / d) * np.eye(d), mu=np.zeros(d), lam=lam)
+    e = engine_from_problem(ckw, pkw, nchains=70, record_accept=1)
+    e.init(); e.run()
+    cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
+    th = e.theta()
+    for c in (0, 69):
+        o = oracle.run_chain(cfg, prob, chain_id=c, continue_on_downdate_fail=True)
+        np.testing.assert_array_equal(e.accepted(c), o.accepted)
+        np.testing.assert_array_equal(_bits(th[c]), _bits(o.theta))
+        if cfg.usesvd:
+            np.testing.assert_array_equal(_bits(e.R(c)), _bits(o.R))
+        else:
+            np.testing.assert_array_equal(_bits(np.triu(e.R(c))), _bits(np.triu(o.R)))
+        if method != "ram":
+            cm, mean, wsum = e.chaincov(c)
+            np.testing.assert_array_equal(_bits(np.triu(cm)), _bits(np.triu(o.chaincmat)))
+        if extra.get("drscale"):
+            r2, ic = e.dr_state(c)
+            np.testing.assert_array_equal(_bits(np.triu(ic)), _bits(np.triu(o.iC)))
+        assert e.rng(c)[0] == o.rng_n
+    mean, cov = mdist.finalize_moments(e.pooled_moments(), d, np.asarray(pkw["par0"]))
+    np.testing.assert_allclose(mean, th.mean(axis=0), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(cov, np.cov(th.T), rtol=1e-8, atol=1e-12)
     e.close()
 
 
@@ -252,17 +312,21 @@ def test_delayed_rejection_vectors_in_lds_or_global(oracle, d, monkeypatch):
     ckw = dict(nsimu=130, adaptint=50, updatesigma=0, drscale=2.0)
     pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.05), cmat0=(0.5 / d) * np.eye(d), mu=np.linspace(-1, 1, d), lam=A @ A.T + np.eye(d))
     res = []
-    for big in ("0", "1"):
-        monkeypatch.setenv("MCMCX_DR_BIG", big)
+    for big in ("0", "1", "general"):                     # general: step_body<DR> as it was before step_kernel_dr (MCMCX_DR_GENERAL=1, an A/B form)
+        if big == "general" and d not in (7, 23):
+            continue
+        monkeypatch.setenv("MCMCX_DR_BIG", "0" if big == "general" else big)
+        monkeypatch.setenv("MCMCX_DR_GENERAL", "1" if big == "general" else "0")
         e = engine_from_problem(ckw, pkw, nchains=70, chain_id0=2, record_accept=1)
         e.init(); e.run()
-        assert e.last_kernel() == ("step_kernel_dr_big" if big == "1" else "step_kernel_dr")
+        assert e.last_kernel() == {"0": "step_kernel_dr", "1": "step_kernel_dr_big", "general": "step_kernel<false, true, false>"}[big]
         res.append((e.theta().copy(), e.accept_masks(), [e.R(c).copy() for c in (0, 69)], [e.rng(c)[0] for c in (0, 69)], [e.counters(c)["draccepted"] for c in (0, 69)]))
         e.close()
-    a, b = res
-    assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1]) and a[3] == b[3] and a[4] == b[4]
-    for x, y in zip(a[2], b[2]):
-        np.testing.assert_array_equal(_bits(x), _bits(y))
+    a = res[0]
+    for b in res[1:]:
+        assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1]) and a[3] == b[3] and a[4] == b[4]
+        for x, y in zip(a[2], b[2]):
+            np.testing.assert_array_equal(_bits(x), _bits(y))
     cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
     for i, c in enumerate((0, 69)):
         o = oracle.run_chain(cfg, prob, chain_id=2 + c)
@@ -273,7 +337,7 @@ def test_delayed_rejection_vectors_in_lds_or_global(oracle, d, monkeypatch):
 def test_sizes_beyond_the_limits_fail_loudly():
     from mcmcf90_amd import make_config, Engine, McmcError
     with pytest.raises(McmcError):
-        Engine(make_config(257, 1, nsimu=10))
+        Engine(make_config(8193, 1, nsimu=10))                         # (npar itself is unlimited like the reference's up to int-sized packed indices)
     e = Engine(make_config(200, 4, nsimu=10, drscale=2.0, pooled=1))   # pooled delayed rejection beyond 160 (where its two vectors no longer fit
     e.setpar0(np.zeros(200)); e.set_target("banana", b=0.1)           # the LDS) runs on global scratch since round 3: no limit of its own
     e.init(); e.run()
@@ -325,7 +389,8 @@ def test_engines_release_their_device_memory(oracle):
     dict(burnintime=0, adaptint=100, doburnin=0),                   # aligned (the case every fixture has)
 ], ids=["burn50", "burn130_b40", "hist1", "aligned"])
 @pytest.mark.parametrize("dr", [0.0, 2.0], ids=["am", "dram"])
-def test_history_ring_without_record_chain(oracle, kw, dr):
+@pytest.mark.parametrize("kernels", ["lane", "auto"])          # auto: the lane-group kernels (accept bytes + group_pack_kernel feed the same ring)
+def test_history_ring_without_record_chain(oracle, kw, dr, kernels):
     """record_chain = 0 (what bench.py runs): the history ring only holds the adaptation window.  Its size must cover
     the FIRST window, which is longer than burnintime + adaptint + adapthist whenever that threshold is not a multiple
     of adaptint: final state, factor and covariance bit for bit against the oracle."""
@@ -352,7 +417,8 @@ def test_history_ring_without_record_chain(oracle, kw, dr):
 
 @pytest.mark.parametrize("d,method,extra", [(48, "scam", {}), (49, "scam", {}), (70, "scam", {}), (64, "dram", dict(condmax=1e6)), (65, "dram", dict(condmax=1e6)),
                                             (100, "dram", dict(condmax=50.0, drscale=2.0)), (128, "scam", {}), (129, "scam", {}), (200, "dram", dict(condmax=1e6)),
-                                            (200, "scam", {}), (209, "scam", {}), (255, "scam", {}), (256, "scam", {})])
+                                            (200, "scam", {}), (209, "scam", {}),
+                                            pytest.param(255, "scam", {}, marks=pytest.mark.extended), pytest.param(256, "scam", {}, marks=pytest.mark.extended)])
 def test_blocked_svd_equals_lane_svd_and_oracle(oracle, d, method, extra, monkeypatch):
     """npar >= 48 with an SVD factor: MCMC_adapt's factorisation runs svd_blocked_kernel (a workgroup per chain, block
     pairs of columns in LDS, the pinned routine's pairs in a reordered but equivalent sequence).  Bit for bit the
@@ -437,6 +503,7 @@ def test_scam_waves_per_tile(oracle, nw, kind, d, monkeypatch):
         ckw["nsimu"] = 250
     e = engine_from_problem(ckw, pkw, nchains=70, chain_id0=3, record_accept=1, record_chain=1)
     e.init(); e.run()
+    assert e.last_kernel() == {1: "scam_kernel", 2: "scam_mw_kernel<2>", 4: "scam_mw_kernel<4>", 8: "scam_mw_kernel<8>"}[nw], e.last_kernel()
     cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
     th = e.theta()
     for c in (0, 64, 69):

@@ -235,7 +235,8 @@ def test_pooled_scam_matches_restatement(oracle, kind):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("d,extras", [(40, "s2"), (64, ""), (70, "bounds"), (100, "priors"), (130, ""), (200, "bounds"), (215, ""), (230, "priors"), (200, "sixteen")])
+@pytest.mark.parametrize("d,extras", [(40, "s2"), (64, ""), (70, "bounds"), (100, "priors"), (130, ""), (200, "bounds"), pytest.param(215, "", marks=pytest.mark.extended),
+                                      (230, "priors"), pytest.param(200, "sixteen", marks=pytest.mark.extended)])
 def test_pooled_scam_wave_layouts(oracle, d, extras, monkeypatch):
     """Every split of scam_pooled_kernel's output blocks over its waves: d=40 three leftover blocks and no block wave,
     64 four block waves and nothing left over, 70 / 100 four block waves + one / three leftover blocks, 130 eight + one;
@@ -259,6 +260,7 @@ def test_pooled_scam_wave_layouts(oracle, d, extras, monkeypatch):
         pkw.update(pri_mu=np.zeros(d), pri_sig=np.where(np.arange(d) % 3 == 0, 0.0, 0.5))
     e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
     e.init(); e.run()
+    assert e.last_kernel() == ("scam_pooled12_kernel" if (d >= 193 and extras != "sixteen") else "scam_pooled_kernel"), e.last_kernel()
     cfg = oracle.make_cfg(**dict(ckw, doadapt=0))
     prob = oracle.Problem(**pkw)
     chains = [oracle.LiveChain(cfg, prob, chain_id=c) for c in range(N)]
@@ -286,11 +288,15 @@ def test_pooled_scam_wave_layouts(oracle, d, extras, monkeypatch):
     e.close()
 
 
+@pytest.mark.parametrize("waves", [1, 2], ids=["one_wave_per_simd", "two_waves_per_simd"])
 @pytest.mark.parametrize("d", [50, 70])
-def test_pooled_am_matrix_core_kernel_sizes(oracle, d, monkeypatch):
+def test_pooled_am_matrix_core_kernel_sizes(oracle, d, waves, monkeypatch):
     """pooled_mfma_kernel at d = 50 (one pass of four output blocks, the bench's size) and d = 70 (two passes, products
-    parked in a second LDS buffer): bit for bit the lane-per-chain kernel (MCMCX_POOLED_SCALAR=1) and the restatement."""
+    parked in a second LDS buffer): bit for bit the lane-per-chain kernel (MCMCX_POOLED_SCALAR=1) and the restatement.
+    Both instances: 512 registers at one wave per SIMD, and pooled_mfma_kernel<false, true> -- 256 registers, part of the
+    state spilled around the products -- which the engine takes by itself only from 2048 / 8192 tiles on (MCMCX_POOLED_WAVES)."""
     from mcmcf90_amd import engine_from_problem
+    monkeypatch.setenv("MCMCX_POOLED_WAVES", str(waves))
     N, nsimu, tick = 2 * d + 10, 9, 4           # more chains than parameters, or the pooled covariance is singular
     rng = np.random.default_rng(d)
     A = rng.standard_normal((d, d)) / np.sqrt(d)
@@ -299,9 +305,11 @@ def test_pooled_am_matrix_core_kernel_sizes(oracle, d, monkeypatch):
     pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.1), cmat0=(0.5 / d) * np.eye(d), mu=np.linspace(-0.5, 0.5, d), lam=lam)
     e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
     e.init(); e.run()
+    assert e.last_kernel() == ("pooled_mfma_kernel<false, true>" if waves == 2 else "pooled_mfma_kernel<false>"), e.last_kernel()
     monkeypatch.setenv("MCMCX_POOLED_SCALAR", "1")
     e2 = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
     e2.init(); e2.run()
+    assert e2.last_kernel() == "step_kernel<false, false, true>", e2.last_kernel()
     np.testing.assert_array_equal(_bits(e.theta()), _bits(e2.theta()))
     np.testing.assert_array_equal(e.accept_masks(), e2.accept_masks())
     e2.close()
@@ -472,7 +480,7 @@ def test_pooled_burnin_greedy_ap_match_restatement(oracle, name, extra, c0):
     ("dr_am_130_priors", dict(drscale=2.0), 0.3, "gauss"),               # npar 130: the matrix-core form in two passes, priors and bounds
     ("dr_banana_24", dict(drscale=3.0), 1.0, "banana"),                  # a non-Gaussian target between the products
 ])
-@pytest.mark.parametrize("scalar", [0, 1], ids=["matrix_cores", "lane_kernels"])
+@pytest.mark.parametrize("scalar", [0, 1, 2], ids=["matrix_cores", "lane_kernels", "matrix_cores_two_waves"])
 def test_pooled_delayed_rejection_and_er_match_restatement(oracle, name, extra, c0, kind, scalar, monkeypatch):
     """pooled = 1 with drscale > 0 (one R2 = R / drscale and one iC = dpotri(R) for every chain, recomputed at each pooled
     tick, scaled in place by the burn-in branch as MCMC_adapt.F90:66-78 does) and with method = 'er'.  Delayed rejection on the
@@ -480,6 +488,14 @@ def test_pooled_delayed_rejection_and_er_match_restatement(oracle, name, extra, 
     against the shared tables) and in the lane-per-chain kernels, their quadratic-form vectors in LDS (npar <= 40) or global scratch."""
     from mcmcf90_amd import engine_from_problem
     d, N, nsimu = 5, 130, 420
+    two_waves = scalar == 2                                     # pooled_mfma_kernel<false, true>: the instance without delayed rejection only
+    if two_waves:
+        if "dr" in name:
+            pytest.skip("two waves per SIMD: the instance without delayed rejection")
+        scalar = 0
+        monkeypatch.setenv("MCMCX_POOLED_WAVES", "2")
+    else:
+        monkeypatch.setenv("MCMCX_POOLED_WAVES", "1")
     if scalar:
         monkeypatch.setenv("MCMCX_POOLED_SCALAR", "1")         # the lane-per-chain kernels (shared tables through the scalar cache)
     elif name == "dr_am_global_scratch":
@@ -514,7 +530,7 @@ def test_pooled_delayed_rejection_and_er_match_restatement(oracle, name, extra, 
         assert e.last_kernel() == ("pooled_mfma_kernel<true>" if (not scalar and d <= 140) else        # (its LDS ends at npar ~140)
                                    "step_kernel_pooled_dr" if (d <= 40 and name != "dr_am_global_scratch") else "step_kernel_pooled_dr_big")
     else:
-        assert e.last_kernel() == ("step_kernel<false, false, true>" if scalar else "pooled_mfma_kernel<false>")
+        assert e.last_kernel() == ("step_kernel<false, false, true>" if scalar else "pooled_mfma_kernel<false, true>" if two_waves else "pooled_mfma_kernel<false>")
     chains, st, log = _restate_pooled(oracle, ckw, pkw, N)
     kinds = {k for _, k in log}
     if "scale_down" in name: assert "down" in kinds, log
@@ -541,7 +557,48 @@ def test_pooled_delayed_rejection_and_er_match_restatement(oracle, name, extra, 
     e.close()
 
 
-@pytest.mark.parametrize("d,N,mfma,condmax", [(6, 150, 0, 0.0), (6, 150, 1, 0.0), (50, 200, 1, 0.0), (6, 150, 0, 1e8), (6, 150, 1, 25.0), (20, 130, 1, 1e8)])
+@pytest.mark.parametrize("name,extra", [("am", dict()), ("dr_s2", dict(drscale=2.0, updatesigma=1)), ("er", dict(method="er")),
+                                        ("burnin_dr", dict(drscale=3.0, doburnin=1, burnintime=160, badaptint=50, scalelimit=0.3))])
+def test_pooled_mode_with_response_columns(oracle, name, extra):
+    """pooled = 1 with nycol = 2 (round 5: the response-column target in pooled mode, step_kernel_cols with the shared factor / R2 / iC through
+    the scalar cache): the sums over the columns in MCMC_alpha, MCMC_sscrit and MCMC_DR_alpha13 and one gamma draw per column on every chain,
+    the pooled ticks as for one column -- restated tick by tick with two-column oracle chains."""
+    from mcmcf90_amd import engine_from_problem
+    N, nsimu = 130, 330
+    r = np.random.default_rng(77)
+    x = np.arange(11.0)
+    rates = np.array([0.1, 0.25])
+    Y = np.vstack([9.0 * np.exp(-k * x) + r.standard_normal(11) * 0.3 for k in rates])
+    ckw = dict(dict(nsimu=nsimu, adaptint=100, updatesigma=0, N0=1.0, S02=0.8), **extra)
+    pkw = dict(kind="expdata", npar=3, par0=np.concatenate([[9.0], rates]), cmat0=np.diag([0.02, 0.0002, 0.0002]),
+               sigma2=np.array([0.5, 0.8]), nobs=np.array([11, 11]), xdata=x, ydata=Y, lo=np.zeros(3))
+    e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
+    e.init(); e.run()
+    assert e.last_kernel() == "step_kernel_cols", e.last_kernel()
+    chains, st, log = _restate_pooled(oracle, ckw, pkw, N)
+    assert log, "no pooled tick was taken"
+    theta = np.array([ch.theta for ch in chains])
+    np.testing.assert_array_equal(_bits(e.theta()), _bits(theta), err_msg=str(log))
+    for c in (0, 63, 64, N - 1):
+        np.testing.assert_array_equal(e.accepted(c), chains[c].accepted)
+        assert e.rng(c)[0] == chains[c].ch.contents.rng.n
+    cm, mean, W, R = e.pooled()
+    assert W == st["W"]
+    np.testing.assert_array_equal(_bits(np.triu(R)), _bits(np.triu(st["R"])))
+    tot = e.totals()
+    assert tot["stayed"] == sum(ch.stayed for ch in chains)
+    if "dr" in name:
+        R2, iC = e.dr_state(0)
+        np.testing.assert_array_equal(_bits(np.triu(R2)), _bits(np.triu(st["R2"])))
+        np.testing.assert_array_equal(_bits(np.triu(iC)), _bits(np.triu(st["iC"])))
+        assert tot["drtries"] == sum(ch.drtries for ch in chains) and tot["draccepted"] == sum(ch.draccepted for ch in chains) and tot["drtries"] > 0
+    for ch in chains:
+        ch.close()
+    e.close()
+
+
+@pytest.mark.parametrize("d,N,mfma,condmax", [(6, 150, 0, 0.0), (6, 150, 1, 0.0), (50, 200, 1, 0.0), (6, 150, 0, 1e8), (6, 150, 1, 25.0), (20, 130, 1, 1e8),
+                                              (50, 200, 2, 0.0), (20, 130, 2, 1e8)])          # mfma = 2: pooled_mfma_kernel<false, true> (two waves per SIMD)
 def test_pooled_ram_matches_restatement(oracle, d, N, mfma, condmax, monkeypatch):
     """method = 'ram', pooled = 1: one factor for all chains; every adaptint iterations the chains' rank-one RAM
     statistics sign(a) x x' (MCMC_run_ram.F90:166-172) of that iteration are averaged over all chains and folded into
@@ -551,6 +608,7 @@ def test_pooled_ram_matches_restatement(oracle, d, N, mfma, condmax, monkeypatch
     from mcmcf90_amd import engine_from_problem
     if not mfma:
         monkeypatch.setenv("MCMCX_POOLED_SCALAR", "1")
+    monkeypatch.setenv("MCMCX_POOLED_WAVES", "2" if mfma == 2 else "1")
     nsimu, adaptint, nu, target = 130, 20, 0.7, 0.234
     ckw = dict(nsimu=nsimu, method="ram", adaptint=adaptint, updatesigma=0, nuparam=nu, alphatarget=target, condmax=condmax)
     rng = np.random.default_rng(d)
@@ -559,6 +617,7 @@ def test_pooled_ram_matches_restatement(oracle, d, N, mfma, condmax, monkeypatch
     pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.2), cmat0=cm0, mu=np.zeros(d), lam=A @ A.T + np.eye(d))
     e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
     e.init(); e.run()
+    assert e.last_kernel() == {0: "step_kernel<false, false, true>", 1: "pooled_mfma_kernel<false>", 2: "pooled_mfma_kernel<false, true>"}[mfma], e.last_kernel()
     plain = oracle.make_cfg(**dict(ckw, doadapt=0, method="dram"))
     prob = oracle.Problem(**pkw)
     chains = [oracle.LiveChain(plain, prob, chain_id=c) for c in range(N)]

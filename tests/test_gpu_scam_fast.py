@@ -39,6 +39,7 @@ def test_fast_scam_reproduces_the_reference_fixtures(oracle, name, waves, monkey
     cid = int(z["chain_id"])
     e = engine_from_problem(ckw, pkw, nchains=70, chain_id0=cid - 1, record_accept=1, record_chain=1, scam_fast=1)
     e.init(); e.run()
+    assert e.last_kernel() == ("scam_kernel" if waves == 1 else "scam_mw_kernel<8>" if (waves == 8 or str(pkw["kind"]) != "gauss") else "scam_pooled_kernel<per-chain>"), e.last_kernel()
     np.testing.assert_array_equal(e.accepted(1), accepted_from_runlen(z["runlen"]))
     ch, ss, s2 = e.chain(1)
     np.testing.assert_array_equal(ch[:, -1].astype(np.int32), z["runlen"])
