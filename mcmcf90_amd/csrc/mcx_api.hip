@@ -109,6 +109,7 @@ struct mcmcx_engine {
     double *d_ramscale = nullptr, *d_moments = nullptr;
     double *d_Gc = nullptr, *d_Vc = nullptr, *d_svc = nullptr; uint8_t *d_need = nullptr, *d_state = nullptr; int *d_anyrot = nullptr; int svd_b = 0;    // blocked SVD of the adaptation (large npar)
     int wcap = 0;
+    bool tile_factor = false;           // the adaptation's Cholesky branch through tile_factor_kernel (npar <= 64)
     int group_d4 = 0, group_drm = 0, group_gw = 16; bool group_factor = false; bool group_check_due = true; int *d_gflag = nullptr; uint8_t *d_accb = nullptr;         // lane-group step kernel (mcx_group.hpp): npar rounded up to four when it is the one to launch; accept bytes of a launch
     bool external = false; double *d_r1 = nullptr; std::vector<double> h_r1;      // MCMC_run1: the caller evaluates; exchange vectors of run1_kernel
     // timing of the step kernel
@@ -681,6 +682,20 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
             return;
         }
         if (h->usesvd) hipLaunchKernelGGL(adapt_post_kernel<true>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr, batch_done);
+        else if (h->tile_factor) {
+            // dpotf2 (+ dtrti2 / dlauu2 with delayed rejection) with the packed matrices of 4 NW neighbouring chains in LDS, read and written
+            // once (mcx_group.hpp: tile_factor_kernel); adapt_post_kernel keeps the covariance bookkeeping (phase 3)
+            hipLaunchKernelGGL(adapt_post_kernel<false>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 3, (uint8_t *)nullptr, batch_done);
+            const int nc = (h->d + 15) / 16, nw = nc <= 2 ? 4 : nc == 3 ? 2 : 1, ch = 4 * nw;
+            const size_t tl = (size_t)ch * (h->P | 1) * sizeof(double) + (size_t)ch * sizeof(int);
+            const dim3 tg((unsigned)(8 * ((h->ntiles + 7) / 8) * (64 / ch)));
+            switch (nc) {
+            case 1: hipLaunchKernelGGL((tile_factor_kernel<1, 4>), tg, dim3(256), tl, h->stream, h->E); break;
+            case 2: hipLaunchKernelGGL((tile_factor_kernel<2, 4>), tg, dim3(256), tl, h->stream, h->E); break;
+            case 3: hipLaunchKernelGGL((tile_factor_kernel<3, 2>), tg, dim3(128), tl, h->stream, h->E); break;
+            default: hipLaunchKernelGGL((tile_factor_kernel<4, 1>), tg, dim3(64), tl, h->stream, h->E); break;
+            }
+        }
         else if (h->group_factor) {
             // with the lane-group step kernels: the Cholesky factor, its inverse and R2 in the group layout too (mcx_group.hpp)
             hipLaunchKernelGGL(adapt_post_kernel<false>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 3, (uint8_t *)nullptr, batch_done);
@@ -1732,6 +1747,13 @@ int mcmcx_init(mcmcx_handle h)
             h->group_check_due = true;
             if (h->group_drm == 2 && (rc = dev_alloc(h, &h->d_gflag, 1))) return rc;
         }
+    }
+    // the adaptation's factorisation (Cholesky branch) with the matrices in LDS: any chain count, npar <= 64 (MCMCX_TILE_FACTOR=0: adapt_post_kernel's
+    // own register-block form, A/B and tests; MCMCX_GROUP_FACTOR=1 keeps round 4's group_factor_kernel where it applies)
+    {
+        const char *tf = getenv("MCMCX_TILE_FACTOR");
+        h->tile_factor = am && !h->usesvd && d <= 64 && !(tf && atoi(tf) == 0) && !(h->group_factor && getenv("MCMCX_GROUP_FACTOR"));
+        if (h->tile_factor) h->group_factor = false;
     }
     // 1/simuind**nuparam, computed like the reference: real(simuind) is default REAL (MCMC_run_ram.F90:166)
     {

@@ -831,6 +831,177 @@ __global__ __launch_bounds__(64) void group_factor_kernel(EngineDev E)
     }
 }
 
+// ---------------------------------------------------------------- the same factorisation for any chain count and npar <= 64 (round 5)
+// group_factor_kernel's arithmetic with what kept it from paying once the chip is full taken out: (i) a wave read and wrote its four chains'
+// elements as 32-byte pieces of 512-byte lines (every line of a tile's matrices touched by sixteen waves): here a WORKGROUP of NW waves owns
+// 4 NW neighbouring chains of a tile and moves their matrices between HBM and LDS cooperatively, 32 NW contiguous bytes per element -- whole
+// 128-byte lines at NW = 4 -- and the workgroups of one tile sit on one XCD (blockIdx round-robins over the eight), whose L2 combines what is
+// left; (ii) the LDS copy is the PACKED upper triangle by rows (every operand of dpotf2 / dtrti2 / dlauu2 lies in it), so that npar 50 -- BASELINE
+// config 4's size with method = 'dram' -- holds four chains in 41 kB and three workgroups share a CU; (iii) a lane owns NC = ceil(npar / 16)
+// columns (dpotf2) / rows (dtrti2, dlauu2).  adapt_post_kernel streamed the packed matrices of a tile ~5.6 times through L2 / HBM for its 8 x 8
+// register blocks (33.5 ms per tick of 1 048 576 chains at npar 50, 2.2 ms at config 3's size); this reads and writes each once.
+// Chains of operations: exactly calculate_R / potri_packed (mcx_kernels.hpp) = MCMC_calculate_R's Cholesky branch, MCMC_adapt.F90:211-225.
+// Grid: 8 ceil(ntiles / 8) (64 / (4 NW)) workgroups of 64 NW threads; LDS: 4 NW (P | 1) doubles + 4 NW ints.
+template <int NC, int NW>
+__global__ __launch_bounds__(64 * NW) void tile_factor_kernel(EngineDev E)
+{
+    extern __shared__ double Mf[];
+    constexpr int CH = 4 * NW, WPT = 64 / CH, ES = 64 * NW / CH;          // chains per workgroup, workgroups per tile, elements per cooperative pass
+    const int wg = blockIdx.x, xcd = wg & 7, idx = wg >> 3;
+    const int tile = (idx / WPT) * 8 + xcd, part = idx % WPT;
+    if (tile >= E.ntiles) return;                                          // (uniform over the workgroup)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l16 = lane & 15, row = lane >> 4;
+    const int d = E.d, P = E.P, PS = P | 1;
+    const int cl0 = part * CH, cl = cl0 + 4 * w + row;                      // this lane's chain of the tile
+    double *M = Mf + (size_t)(4 * w + row) * PS;                            // its packed upper triangle: element (i,k), i <= k, at i d - i (i + 1) / 2 + k
+    int *flg = (int *)(Mf + (size_t)CH * PS);
+    const bool act = (TIDX(E.ictr, tile, NICTR, I_ADFLAGS, cl) & ADF_DOCALC) != 0;
+    if (!__syncthreads_or(act ? 1 : 0)) return;
+    const int cc = tid % CH, e0 = tid / CH;                                 // cooperative moves: chain cc of the workgroup, elements e0, e0 + ES, ...
+    {
+        const double *Cg = E.cmat + (size_t)tile * P * 64 + cl0 + cc;
+        double *Mc = Mf + (size_t)cc * PS;
+        for (int e = e0; e < P; e += ES) Mc[e] = Cg[(size_t)e * 64];
+    }
+    __syncthreads();
+    int kk[NC], kc[NC];                                                     // this lane's columns / rows, and clamped for the branch-free loops
+#pragma unroll
+    for (int q = 0; q < NC; ++q) { kk[q] = l16 + 16 * q; kc[q] = kk[q] < d ? kk[q] : d - 1; }
+    // ---- dpotf2('U'): lane = column k; step j adds T(i,j) T(i,k), i < j ascending, to column k's chain; every lane runs the pivot's own chain
+    int info = 0;
+    for (int j = 0; j < d; ++j) {
+        MCX_WAVE_LDS_SYNC();                                                // row j - 1 (other lanes' columns) is written
+        double acc[NC], accj = 0.0;
+#pragma unroll
+        for (int q = 0; q < NC; ++q) acc[q] = 0.0;
+        int rb = 0;                                                         // rowstart(i) - i: element (i,k) at rb + k  (k < i: in bounds, dropped)
+#pragma unroll 4
+        for (int i = 0; i < j; ++i) {
+            const double tij = M[rb + j];
+            double m[NC];
+#pragma unroll
+            for (int q = 0; q < NC; ++q) m[q] = M[rb + kc[q]];
+            accj = dfma(tij, tij, accj);
+#pragma unroll
+            for (int q = 0; q < NC; ++q) acc[q] = dfma(tij, m[q], acc[q]);
+            rb += d - (i + 1);
+        }
+        const double ajj = M[rb + j] - accj;
+        if (act && info == 0 && !(ajj > 0.0)) info = j + 1;
+        const double rjj = sqrt(ajj), rinv = 1.0 / rjj;
+        double nv[NC];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) nv[q] = (M[rb + kc[q]] - acc[q]) * rinv;
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            if (kk[q] == j) M[rb + j] = rjj;
+            if (kk[q] > j && kk[q] < d) M[rb + kk[q]] = nv[q];
+        }
+    }
+    const bool ok = act && info == 0;
+    if (act && l16 == 0) {
+        TIDX(E.ictr, tile, NICTR, I_INFO, cl) = (uint32_t)info;
+        if (info != 0) TIDX(E.ictr, tile, NICTR, I_STATUS, cl) |= ST_CHOL_FAIL;          // warning, old R kept (MCMC_adapt.F90:168-171)
+    }
+    MCX_WAVE_LDS_SYNC();
+    // ---- R = T 2.4 / sqrt(npar) in place (column k of lane k), then out with it -- and R2 = R / drscale -- cooperatively
+    {
+        const double sq = sqrt((double)d);
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            if (kk[q] < d && ok) {
+                int rb = 0;
+                for (int i = 0; i <= kk[q]; ++i) { M[rb + kk[q]] = M[rb + kk[q]] * 2.4 / sq; rb += d - (i + 1); }
+            }
+        }
+    }
+    if (l16 == 0) flg[4 * w + row] = ok ? 1 : 0;
+    __syncthreads();
+    if (flg[cc]) {
+        double *Rg = E.R + (size_t)tile * P * 64 + cl0 + cc;
+        double *R2g = E.dodr ? E.R2 + (size_t)tile * P * 64 + cl0 + cc : nullptr;
+        const double *Mc = Mf + (size_t)cc * PS;
+        for (int e = e0; e < P; e += ES) { const double v = Mc[e]; Rg[(size_t)e * 64] = v; if (R2g) R2g[(size_t)e * 64] = v / E.drscale; }
+    }
+    if (!E.dodr) return;
+    if (!__syncthreads_or(ok ? 1 : 0)) return;                              // (also: the copies above have been read before dpotri overwrites them)
+    // ---- iC = dpotri('U', R): dtrti2 then dlauu2, in place on the scaled factor; lane = ROW r
+    int info2 = 0;
+    { int rb = 0; for (int j = 0; j < d; ++j) { if (ok && info2 == 0 && M[rb + j] == 0.0) info2 = j + 1; rb += d - (j + 1); } }
+    const bool go = ok && info2 == 0;
+    if (ok && info2 != 0 && l16 == 0) TIDX(E.ictr, tile, NICTR, I_STATUS, cl) |= ST_POTRI_FAIL;                   // the reference stops
+    int rbr[NC];                                                            // rowstart(r) - r of this lane's (clamped) rows
+#pragma unroll
+    for (int q = 0; q < NC; ++q) rbr[q] = kc[q] * d - kc[q] * (kc[q] + 1) / 2;
+    if (__any(go)) {
+        int rbj = 0;                                                        // row j
+        for (int j = 0; j < d; ++j) {                        // dtrti2: element (r,j) = -1/A(j,j) x [A(r,j) Ainv(r,r), then + A(jj,j) Ainv(r,jj), jj = r+1..j-1 ascending]
+            MCX_WAVE_LDS_SYNC();                             // column j - 1 (other lanes' rows) is written
+            const double ajj = 1.0 / M[rbj + j];
+            double x[NC];
+#pragma unroll
+            for (int q = 0; q < NC; ++q) x[q] = 0.0;
+            int rb = 0;
+#pragma unroll 4
+            for (int jj = 0; jj < j; ++jj) {
+                const double temp = M[rb + j];               // the original A(jj,j)
+                const bool nz = temp != 0.0;                 // dtrmv skips a zero (the row's own sweep then leaves the zero as it is)
+#pragma unroll
+                for (int q = 0; q < NC; ++q) {
+                    const double m = M[rbr[q] + jj];
+                    const double p = temp * m, f = dfma(temp, m, x[q]);
+                    x[q] = (kk[q] == jj) ? (nz ? p : temp) : ((kk[q] < jj && nz) ? f : x[q]);
+                }
+                rb += d - (jj + 1);
+            }
+            if (go) {
+#pragma unroll
+                for (int q = 0; q < NC; ++q) {
+                    if (kk[q] < j) M[rbr[q] + j] = (-ajj) * x[q];
+                    if (kk[q] == j) M[rbj + j] = ajj;
+                }
+            }
+            rbj += d - (j + 1);
+        }
+        int rbi = 0;                                                        // row i
+        for (int i = 0; i < d; ++i) {                        // dlauu2: A(r,i) = A(i,i) A(r,i) + sum_{k>i} A(i,k) A(r,k) ascending k; the diagonal's sum of squares on every lane
+            MCX_WAVE_LDS_SYNC();
+            const double aii = M[rbi + i];
+            if (i < d - 1) {
+                double dot = 0.0, x[NC];
+#pragma unroll
+                for (int q = 0; q < NC; ++q) x[q] = aii * M[rbr[q] + i];
+                dot = dfma(aii, aii, dot);
+#pragma unroll 4
+                for (int k = i + 1; k < d; ++k) {
+                    const double temp = M[rbi + k];
+                    dot = dfma(temp, temp, dot);
+                    const bool nz = temp != 0.0;
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) { const double f = dfma(temp, M[rbr[q] + k], x[q]); x[q] = nz ? f : x[q]; }
+                }
+                if (go) {
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) {
+                        if (kk[q] < i) M[rbr[q] + i] = x[q];
+                        if (kk[q] == i) M[rbi + i] = dot;
+                    }
+                }
+            } else if (go) {
+#pragma unroll
+                for (int q = 0; q < NC; ++q) if (kk[q] <= i && kk[q] < d) M[rbr[q] + i] = aii * M[rbr[q] + i];
+            }
+            rbi += d - (i + 1);
+        }
+    }
+    __syncthreads();
+    if (flg[cc]) {                                           // (a singular factor leaves the copy of R, as potri_packed does)
+        double *iCg = E.iC + (size_t)tile * P * 64 + cl0 + cc;
+        const double *Mc = Mf + (size_t)cc * PS;
+        for (int e = e0; e < P; e += ES) iCg[(size_t)e * 64] = Mc[e];
+    }
+}
+
 // accept bytes of a launch -> the tile ballots (MCMC_savechain's repeat counts are decoded from them): one thread per
 // (iteration, tile); bit l of a ballot = chain l of the tile accepted
 __global__ void group_pack_kernel(EngineDev E, const uint8_t *accb, int it0, int it1)
