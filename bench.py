@@ -458,6 +458,7 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
         tick_s = max(time.perf_counter() - tt0 - dt / (steps * ips), 0.0)
     eng.close()
     tick_note = None
+    first_tick_s = second_tick_s = None
     if wl == "c5" and replicas and not scam_fast and world == 1 and steps * ips < adaptint_:
         # per-chain rotations at npar = 200: an adaptation is one SVD per chain.  Timed on a second engine of the same chains whose
         # covariance is full rank at the tick (initcmatn = npar: cmat0 carries weight; adaptint 10) -- what every adaptation after the
@@ -472,10 +473,30 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
         tt2 = time.perf_counter()
         e2.close()
         tick_s = max((tt1 - tt0) - (tt2 - tt1), 0.0)
-        tick_note = ("`value` is the rate between two adaptations; an adaptation is one 200 x 200 Jacobi SVD per chain, timed on a second "
-                     "engine of the same %d chains with a full-rank covariance at the tick (initcmatn = npar, adaptint 10: iteration 10 with "
-                     "its adaptation minus iteration 11); sustained_value = proposals of adaptint iterations / (their time + one such "
-                     "adaptation)" % n_local)
+        # ... and the adaptations the configuration REALLY starts with: iteration 100 (100 rows for a 200 x 200 covariance:
+        # rank 99, the pinned Jacobi runs to its 60-sweep cap on the null space's noise -- so does the oracle) and iteration 200 (rank 199).  A third
+        # engine on the configuration's own schedule (adaptint 100, initcmatn 0) gets there with the opt-in fast proposals -- the same accept
+        # decisions, states to 1e-13 of the reference-order ones (tests/test_gpu_scam_fast.py), 2.8 s per hundred iterations instead of 160 --
+        # and runs the same adaptation kernels.
+        ckw3, pkw3, _ = problem(wl, 202, adaptint=adaptint_)
+        e3 = engine_from_problem(ckw3, pkw3, nchains=n_local, chain_id0=rank * n_local, device=dev, pooled=0, comm=None, scam_fast=1)
+        e3.init()
+        early = []
+        for tk in (adaptint_, 2 * adaptint_):
+            e3.run(tk - 1); e3.sync()
+            tt0 = time.perf_counter(); e3.run(tk); e3.sync()
+            tt1 = time.perf_counter(); e3.run(tk + 1); e3.sync()
+            tt2 = time.perf_counter()
+            early.append(max((tt1 - tt0) - (tt2 - tt1), 0.0))
+        e3.close()
+        first_tick_s, second_tick_s = early
+        tick_note = ("`value` is the rate between two adaptations; an adaptation is one 200 x 200 Jacobi SVD per chain.  tick_ms: a full-rank "
+                     "covariance (every adaptation from the third on), timed on a second engine of the same %d chains (initcmatn = npar, adaptint 10: "
+                     "iteration 10 with its adaptation minus iteration 11).  first_tick_ms / second_tick_ms: the configuration's own adaptations at "
+                     "iterations %d and %d (rank-deficient covariances of %d / %d rows: the pinned routine at its sweep cap), timed on a third engine "
+                     "that reached them with scam_fast proposals.  sustained_value = the proposals of the configuration's first %d iterations / "
+                     "(their time at `value` + those two adaptations + %d full-rank ones)"
+                     % (n_local, adaptint_, 2 * adaptint_, adaptint_, 2 * adaptint_, 10 * adaptint_, 8))
     if rank != 0:
         return None, pooled_vec
     its_timed = steps * ips - (1 if warmup == 0 else 0)                         # iteration 1 is the starting point (MCMC_run.F90:35-41)
@@ -551,8 +572,13 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
     adaptation = None
     if tick_s is not None:
         t_it = dt / (steps * ips)
-        adaptation = {"adaptint": adaptint, "tick_ms": tick_s * 1e3,
-                      "sustained_value": float(world) * n_local * per_it * adaptint / (adaptint * t_it + tick_s),
+        sustained = float(world) * n_local * per_it * adaptint / (adaptint * t_it + tick_s)
+        extra_ticks = {}
+        if first_tick_s is not None:                     # the configuration's own schedule over its first ten adaptation periods
+            sustained = float(world) * n_local * per_it * 10 * adaptint / (10 * adaptint * t_it + first_tick_s + second_tick_s + 8 * tick_s)
+            extra_ticks = {"first_tick_ms": first_tick_s * 1e3, "second_tick_ms": second_tick_s * 1e3}
+        adaptation = {"adaptint": adaptint, "tick_ms": tick_s * 1e3, **extra_ticks,
+                      "sustained_value": sustained,
                       "note": tick_note or ("`value` is the rate between two adaptations; sustained_value = proposals of adaptint iterations / (their time + one "
                                             "adaptation), the adaptation timed once after the timed region (iteration %d)" % next_tick)}
     cnt = float(pooled_vec[0])
@@ -715,6 +741,9 @@ def main():
                         others[key]["pooled_check"] = r["pooled_check"]
                     if r.get("adaptation"):
                         others[key].update(tick_ms=r["adaptation"]["tick_ms"], sustained_value=r["adaptation"]["sustained_value"])
+                        for k2 in ("first_tick_ms", "second_tick_ms"):
+                            if k2 in r["adaptation"]:
+                                others[key][k2] = r["adaptation"][k2]
             except Exception as ex:
                 if world > 1:
                     raise

@@ -1748,11 +1748,14 @@ int mcmcx_init(mcmcx_handle h)
             if (h->group_drm == 2 && (rc = dev_alloc(h, &h->d_gflag, 1))) return rc;
         }
     }
-    // the adaptation's factorisation (Cholesky branch) with the matrices in LDS: any chain count, npar <= 64 (MCMCX_TILE_FACTOR=0: adapt_post_kernel's
-    // own register-block form, A/B and tests; MCMCX_GROUP_FACTOR=1 keeps round 4's group_factor_kernel where it applies)
+    // the adaptation's factorisation (Cholesky branch) with the matrices in LDS (tile_factor_kernel): any chain count, npar <= 32 -- config 3's size
+    // (npar 20, delayed rejection, 262144 chains): 2.11 -> 1.44 ms per tick, bound by VALU issue (~25 instructions per inner step of four chains).
+    // Above npar 32 adapt_post_kernel's 8 x 8 register blocks stay: at npar 50 x 1 048 576 chains they stream the matrices ~5.6 times (16.0 ms)
+    // and still beat the LDS form, whose three waves per CU issue ~15 x the instructions per chain (35.2 ms; profiles/r05_a/tick_ab.txt).
+    // MCMCX_TILE_FACTOR = 0 / 1: never / up to npar 64 (A/B, tests); MCMCX_GROUP_FACTOR = 1 keeps round 4's group_factor_kernel where it applies.
     {
         const char *tf = getenv("MCMCX_TILE_FACTOR");
-        h->tile_factor = am && !h->usesvd && d <= 64 && !(tf && atoi(tf) == 0) && !(h->group_factor && getenv("MCMCX_GROUP_FACTOR"));
+        h->tile_factor = am && !h->usesvd && d <= ((tf && atoi(tf) == 1) ? 64 : 32) && !(tf && atoi(tf) == 0) && !(h->group_factor && getenv("MCMCX_GROUP_FACTOR"));
         if (h->tile_factor) h->group_factor = false;
     }
     // 1/simuind**nuparam, computed like the reference: real(simuind) is default REAL (MCMC_run_ram.F90:166)

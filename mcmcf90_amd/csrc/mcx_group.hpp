@@ -858,10 +858,18 @@ __global__ __launch_bounds__(64 * NW) void tile_factor_kernel(EngineDev E)
     const bool act = (TIDX(E.ictr, tile, NICTR, I_ADFLAGS, cl) & ADF_DOCALC) != 0;
     if (!__syncthreads_or(act ? 1 : 0)) return;
     const int cc = tid % CH, e0 = tid / CH;                                 // cooperative moves: chain cc of the workgroup, elements e0, e0 + ES, ...
+    // (sixteen elements' loads before their LDS stores: element by element every load is a round trip of its own -- 80 in a row at npar 50)
+    constexpr int CB = 16;
     {
         const double *Cg = E.cmat + (size_t)tile * P * 64 + cl0 + cc;
         double *Mc = Mf + (size_t)cc * PS;
-        for (int e = e0; e < P; e += ES) Mc[e] = Cg[(size_t)e * 64];
+        for (int e = e0; e < P; e += CB * ES) {
+            double v[CB];
+#pragma unroll
+            for (int u = 0; u < CB; ++u) { const int ee = e + u * ES; v[u] = Cg[(size_t)(ee < P ? ee : P - 1) * 64]; }
+#pragma unroll
+            for (int u = 0; u < CB; ++u) { const int ee = e + u * ES; if (ee < P) Mc[ee] = v[u]; }
+        }
     }
     __syncthreads();
     int kk[NC], kc[NC];                                                     // this lane's columns / rows, and clamped for the branch-free loops
@@ -904,27 +912,27 @@ __global__ __launch_bounds__(64 * NW) void tile_factor_kernel(EngineDev E)
         if (info != 0) TIDX(E.ictr, tile, NICTR, I_STATUS, cl) |= ST_CHOL_FAIL;          // warning, old R kept (MCMC_adapt.F90:168-171)
     }
     MCX_WAVE_LDS_SYNC();
-    // ---- R = T 2.4 / sqrt(npar) in place (column k of lane k), then out with it -- and R2 = R / drscale -- cooperatively
-    {
-        const double sq = sqrt((double)d);
-#pragma unroll
-        for (int q = 0; q < NC; ++q) {
-            if (kk[q] < d && ok) {
-                int rb = 0;
-                for (int i = 0; i <= kk[q]; ++i) { M[rb + kk[q]] = M[rb + kk[q]] * 2.4 / sq; rb += d - (i + 1); }
-            }
-        }
-    }
+    // ---- R = T 2.4 / sqrt(npar), out with it -- and R2 = R / drscale -- cooperatively; the LDS copy takes the scaling too (dpotri works on R)
     if (l16 == 0) flg[4 * w + row] = ok ? 1 : 0;
     __syncthreads();
     if (flg[cc]) {
+        const double sq = sqrt((double)d);
         double *Rg = E.R + (size_t)tile * P * 64 + cl0 + cc;
         double *R2g = E.dodr ? E.R2 + (size_t)tile * P * 64 + cl0 + cc : nullptr;
-        const double *Mc = Mf + (size_t)cc * PS;
-        for (int e = e0; e < P; e += ES) { const double v = Mc[e]; Rg[(size_t)e * 64] = v; if (R2g) R2g[(size_t)e * 64] = v / E.drscale; }
+        double *Mc = Mf + (size_t)cc * PS;
+        for (int e = e0; e < P; e += CB * ES) {
+            double v[CB];
+#pragma unroll
+            for (int u = 0; u < CB; ++u) { const int ee = e + u * ES; v[u] = Mc[ee < P ? ee : P - 1] * 2.4 / sq; }
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                const int ee = e + u * ES;
+                if (ee < P) { Rg[(size_t)ee * 64] = v[u]; if (R2g) { R2g[(size_t)ee * 64] = v[u] / E.drscale; Mc[ee] = v[u]; } }
+            }
+        }
     }
     if (!E.dodr) return;
-    if (!__syncthreads_or(ok ? 1 : 0)) return;                              // (also: the copies above have been read before dpotri overwrites them)
+    if (!__syncthreads_or(ok ? 1 : 0)) return;                              // (also: the scaled copies above are written before dpotri reads them)
     // ---- iC = dpotri('U', R): dtrti2 then dlauu2, in place on the scaled factor; lane = ROW r
     int info2 = 0;
     { int rb = 0; for (int j = 0; j < d; ++j) { if (ok && info2 == 0 && M[rb + j] == 0.0) info2 = j + 1; rb += d - (j + 1); } }
@@ -998,7 +1006,13 @@ __global__ __launch_bounds__(64 * NW) void tile_factor_kernel(EngineDev E)
     if (flg[cc]) {                                           // (a singular factor leaves the copy of R, as potri_packed does)
         double *iCg = E.iC + (size_t)tile * P * 64 + cl0 + cc;
         const double *Mc = Mf + (size_t)cc * PS;
-        for (int e = e0; e < P; e += ES) iCg[(size_t)e * 64] = Mc[e];
+        for (int e = e0; e < P; e += CB * ES) {
+            double v[CB];
+#pragma unroll
+            for (int u = 0; u < CB; ++u) { const int ee = e + u * ES; v[u] = Mc[ee < P ? ee : P - 1]; }
+#pragma unroll
+            for (int u = 0; u < CB; ++u) { const int ee = e + u * ES; if (ee < P) iCg[(size_t)ee * 64] = v[u]; }
+        }
     }
 }
 

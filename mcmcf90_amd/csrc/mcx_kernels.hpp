@@ -2430,19 +2430,31 @@ __global__ __launch_bounds__(64, (!DR && W2) ? 2 : 1) void pooled_mfma_kernel(En
             }
         }
     };
+    // -DMCX_PHASE_PROF (tools/build_variant.sh; profiles/r05_a/c4_pooled_phases.txt): where a wave's iteration goes, by wall_clock64
+#ifdef MCX_PHASE_PROF
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = wall_clock64();
+#define PH(i) { unsigned long long tn = wall_clock64(); ph[i] += tn - tq; tq = tn; }
+#else
+#define PH(i)
+#endif
     for (int it = it0; it <= it1; ++it) {
         // ---- newpar = MCMC_propose(oldpar, R): z straight into the LDS vector, P = R'z on the matrix cores
         gen_normals<MCX_POOLED_NB>(L.g, X, lane, d, true);
+        PH(0)
         if (it == it1) {                                               // the launch's last normals stay readable (pooled RAM statistic)
             double *zk = E.zs + ((size_t)tile * 2 + (it & 1)) * d * 64;
             for (int k = 0; k < d; ++k) GV(zk, k) = XL(k);
         }
         for (int k = d; k < d4; ++k) XL(k) = 0.0;
         product_to_T(g_RT, !E.usesvd);                                 // (condmax > 0: the full SVD factor)
+        PH(1)
         candidate_from_T(cand_t);
+        PH(2)
         bool inb = target_inbounds(E.tgt, d, lane, cand_t);
         double pri2 = target_prior(E.tgt, d, lane, cand_t);
+        PH(3)
         double ss2 = gauss ? gauss_ss() : target_ss<false>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
+        PH(4)
         // ---- alpha, reject (MCMC_run.F90:47-63), as in step_kernel
         bool reject;
         if (!DR && E.method == M_ER) {                    // early rejection, MCMC_run_er.F90:60-89 (no second stage with it)
@@ -2501,6 +2513,7 @@ __global__ __launch_bounds__(64, (!DR && W2) ? 2 : 1) void pooled_mfma_kernel(En
                 }
             }
         }
+        PH(5)
         if (reject) { L.stayed += 1; L.curcount += 1; }
         else { L.ss1 = ss2; L.pri1 = pri2; L.chainind += 1; L.curcount = 1; }
         if (E.updatesigma) {
@@ -2519,9 +2532,16 @@ __global__ __launch_bounds__(64, (!DR && W2) ? 2 : 1) void pooled_mfma_kernel(En
             if (E.record_s2) E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = L.sigma2;
         }
         if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
+        PH(6)
     }
     lane_store(E, tile, lane, L);
     TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane) = erstayed;
+#ifdef MCX_PHASE_PROF
+    if (lane == 0 && (tile == 0 || tile == E.ntiles / 2 || tile == E.ntiles - 1))
+        printf("pooled_mfma tile %d its %d x10ns: normals %llu product %llu candidate %llu bounds+prior %llu target %llu decide %llu accept+history %llu\n",
+               tile, it1 - it0 + 1, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
+#endif
+#undef PH
 }
 
 // ---------------------------------------------------------------- nycol > 1: sums over the response columns
