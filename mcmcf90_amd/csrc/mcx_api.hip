@@ -18,6 +18,7 @@
 #include "../../include/mcmcx_target.h"
 #include "mcx_kernels.hpp"
 #include "mcx_group.hpp"
+#include "mcx_pooled2.hpp"
 
 using namespace mcx;
 static_assert(MCMCX_HE_INB == HE_INB && MCMCX_HE_PRI == HE_PRI && MCMCX_HE_SS == HE_SS && MCMCX_HX_STAGE2 == HX_STAGE2 && MCMCX_HX_CRIT == HX_CRIT,
@@ -478,6 +479,14 @@ static bool pooled_two_waves(const mcmcx_engine *h)
     if (h->sw.pooled_waves >= 0) return h->sw.pooled_waves == 2;                                 // (A/B switch, tests)
     return h->ntiles >= (pooled_mfma_lds(h->d) * 8 <= 160 * 1024 ? 2048 : 8192);
 }
+// pooled_mfma2_kernel (mcx_pooled2.hpp): a tile as a workgroup of two waves sharing the LDS vector -- 17 <= npar <= 64, no delayed rejection.
+// MCMCX_POOLED_WAVES = 3 forces it, 1 / 2 the one-wave instances (A/B, tests)
+static bool pooled_two_per_tile(const mcmcx_engine *h)
+{
+    if (h->dodr || h->d < 17 || h->d > 64) return false;
+    if (h->sw.pooled_waves >= 0) return h->sw.pooled_waves == 3;
+    return false;
+}
 #define STEP_ARGS h->stream, h->E, it0, it1
 #define STEP_RS (h->d_ramscale + it0)
 #define STEP_TGT h->E.tgt.mu, h->E.tgt.lamT
@@ -490,6 +499,8 @@ static const KernelEntry STEP_TABLE[] = {
     // ---- pooled mode (one shared factor)
     {"step", "pooled_mfma_kernel<true>", [](const mcmcx_engine *h) { return pooled_use_mfma(h) && h->dodr != 0; },
      [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(pooled_mfma_kernel<true>, G1, pooled_mfma_lds(h->d), STEP_ARGS, STEP_TGT, h->d_sharedRT, h->d_sharedR2T, h->d_sharediCd); }},
+    {"step", "pooled_mfma2_kernel", [](const mcmcx_engine *h) { return pooled_use_mfma(h) && pooled_two_per_tile(h); },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(pooled_mfma2_kernel, dim3(h->ntiles), dim3(128), pooled_mfma_lds(h->d), STEP_ARGS, STEP_TGT, h->d_sharedRT); }},
     {"step", "pooled_mfma_kernel<false, true>", [](const mcmcx_engine *h) { return pooled_use_mfma(h) && pooled_two_waves(h); },
      [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((pooled_mfma_kernel<false, true>), G1, pooled_mfma_lds(h->d), STEP_ARGS, STEP_TGT, h->d_sharedRT, (const double *)nullptr, (const double *)nullptr); }},
     {"step", "pooled_mfma_kernel<false>", [](const mcmcx_engine *h) { return pooled_use_mfma(h); },

@@ -288,7 +288,7 @@ def test_pooled_scam_wave_layouts(oracle, d, extras, monkeypatch):
     e.close()
 
 
-@pytest.mark.parametrize("waves", [1, 2], ids=["one_wave_per_simd", "two_waves_per_simd"])
+@pytest.mark.parametrize("waves", [1, 2, 3], ids=["one_wave_per_simd", "two_waves_per_simd", "two_waves_per_tile"])
 @pytest.mark.parametrize("d", [50, 70])
 def test_pooled_am_matrix_core_kernel_sizes(oracle, d, waves, monkeypatch):
     """pooled_mfma_kernel at d = 50 (one pass of four output blocks, the bench's size) and d = 70 (two passes, products
@@ -305,7 +305,8 @@ def test_pooled_am_matrix_core_kernel_sizes(oracle, d, waves, monkeypatch):
     pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.1), cmat0=(0.5 / d) * np.eye(d), mu=np.linspace(-0.5, 0.5, d), lam=lam)
     e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
     e.init(); e.run()
-    assert e.last_kernel() == ("pooled_mfma_kernel<false, true>" if waves == 2 else "pooled_mfma_kernel<false>"), e.last_kernel()
+    # (waves = 3: pooled_mfma2_kernel, a tile as a workgroup of two waves -- npar 17..64; at 70 the engine falls back to the one-wave kernel)
+    assert e.last_kernel() == {1: "pooled_mfma_kernel<false>", 2: "pooled_mfma_kernel<false, true>", 3: "pooled_mfma2_kernel" if d <= 64 else "pooled_mfma_kernel<false>"}[waves], e.last_kernel()
     monkeypatch.setenv("MCMCX_POOLED_SCALAR", "1")
     e2 = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
     e2.init(); e2.run()
@@ -557,6 +558,65 @@ def test_pooled_delayed_rejection_and_er_match_restatement(oracle, name, extra, 
     e.close()
 
 
+@pytest.mark.parametrize("name,d,N,extra,kind", [
+    ("am_17", 17, 130, dict(), "gauss"), ("am_50_ragged", 50, 130, dict(), "gauss"), ("am_64", 64, 200, dict(), "gauss"), ("am_33_s2", 33, 140, dict(updatesigma=1), "gauss"),
+    ("er_48", 48, 140, dict(method="er"), "gauss"), ("er_20_s2_priors", 20, 130, dict(method="er", updatesigma=1), "gauss"),
+    ("am_49_bounds_priors", 49, 140, dict(), "gauss"), ("banana_24", 24, 130, dict(), "banana"), ("am_50_record", 50, 130, dict(), "gauss"),
+    ("burnin_up_32", 32, 130, dict(doburnin=1, burnintime=160, badaptint=50, scalelimit=0.3), "gauss"), ("svd_20", 20, 130, dict(condmax=1e8), "gauss"),
+])
+def test_pooled_two_waves_per_tile_matches_restatement(oracle, name, d, N, extra, kind, monkeypatch):
+    """pooled_mfma2_kernel (round 5: a tile of 64 chains as a workgroup of TWO waves sharing the LDS vector -- two lanes per chain for the polar
+    attempts, the output blocks of the two products split between the waves, the chain's scalar work done by both of its lanes): the chain of
+    pooled_mfma_kernel<false> bit for bit and the restatement's -- two to four output blocks, odd and even npar (the cached second deviate changes
+    hands), ragged tiles, the sigma2 update, early rejection, bounds and priors and a non-Gaussian target (the candidate's other half read
+    through global memory), the SVD factor (a full, non-triangular table), burn-in scaling, the history ring and accept masks of a recorded chain."""
+    from mcmcf90_amd import engine_from_problem
+    nsimu = 230
+    ckw = dict(dict(nsimu=nsimu, adaptint=100, updatesigma=0, N0=1.0, S02=0.5), **extra)
+    S = 0.5 ** np.abs(np.subtract.outer(np.arange(d), np.arange(d)))
+    c0 = 1e-6 if "burnin_up" in name else 0.3 / d
+    if kind == "gauss":
+        pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.3), cmat0=c0 * np.eye(d), mu=np.linspace(-1, 1, d), lam=np.linalg.inv(S))
+        if "priors" in name:
+            pkw.update(pri_mu=np.zeros(d), pri_sig=np.where(np.arange(d) % 3 == 0, 0.0, 2.0))
+        if "bounds" in name:
+            pkw.update(lo=np.full(d, -1.5), hi=np.full(d, 1.5))
+        if "s2" in name:
+            pkw.update(sigma2=0.8, nobs=20)
+    else:
+        pkw = dict(kind="banana", npar=d, par0=np.zeros(d), cmat0=(1.0 / d) * np.eye(d), b=0.1)
+    ekw = dict(record_chain=1) if "record" in name else {}
+    res = []
+    for waves in ("3", "1"):
+        monkeypatch.setenv("MCMCX_POOLED_WAVES", waves)
+        e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1, **ekw)
+        e.init(); e.run(57); e.run()
+        assert e.last_kernel() == ("pooled_mfma2_kernel" if waves == "3" else "pooled_mfma_kernel<false>"), e.last_kernel()
+        res.append(dict(theta=e.theta().copy(), masks=e.accept_masks().copy(), scal=e.scalars().copy(), rng=[e.rng(c) for c in (0, 31, 32, 63, 64, N - 1)],
+                        ctr=[e.counters(c) for c in (0, 33, N - 1)], pooled=e.pooled(), tot=e.totals(),
+                        chain=[e.chain(c) for c in (0, 35, N - 1)] if ekw else []))
+        e.close()
+    a, b = res
+    assert np.array_equal(_bits(a["theta"]), _bits(b["theta"])) and np.array_equal(a["masks"], b["masks"]) and np.array_equal(_bits(a["scal"]), _bits(b["scal"]))
+    assert a["rng"] == b["rng"] and a["ctr"] == b["ctr"] and a["tot"] == b["tot"]
+    np.testing.assert_array_equal(_bits(a["pooled"][3]), _bits(b["pooled"][3]))
+    for x, y in zip(a["chain"], b["chain"]):
+        for u, v in zip(x, y):
+            np.testing.assert_array_equal(_bits(u), _bits(v))
+    if "svd" in name:
+        return                                             # (the SVD factor's restatement lives in test_pooled_factor_with_condmax; here: the two kernels)
+    chains, st, log = _restate_pooled(oracle, ckw, pkw, N)
+    assert log
+    theta = np.array([ch.theta for ch in chains])
+    np.testing.assert_array_equal(_bits(a["theta"]), _bits(theta), err_msg=str(log))
+    for i, c in enumerate((0, 31, 32, 63, 64, N - 1)):
+        assert a["rng"][i][0] == chains[c].ch.contents.rng.n
+    np.testing.assert_array_equal(_bits(np.triu(a["pooled"][3])), _bits(np.triu(st["R"])))
+    assert a["tot"]["stayed"] == sum(ch.stayed for ch in chains)
+    for ch in chains:
+        ch.close()
+
+
 @pytest.mark.parametrize("name,extra", [("am", dict()), ("dr_s2", dict(drscale=2.0, updatesigma=1)), ("er", dict(method="er")),
                                         ("burnin_dr", dict(drscale=3.0, doburnin=1, burnintime=160, badaptint=50, scalelimit=0.3))])
 def test_pooled_mode_with_response_columns(oracle, name, extra):
@@ -598,7 +658,8 @@ def test_pooled_mode_with_response_columns(oracle, name, extra):
 
 
 @pytest.mark.parametrize("d,N,mfma,condmax", [(6, 150, 0, 0.0), (6, 150, 1, 0.0), (50, 200, 1, 0.0), (6, 150, 0, 1e8), (6, 150, 1, 25.0), (20, 130, 1, 1e8),
-                                              (50, 200, 2, 0.0), (20, 130, 2, 1e8)])          # mfma = 2: pooled_mfma_kernel<false, true> (two waves per SIMD)
+                                              (50, 200, 2, 0.0), (20, 130, 2, 1e8),           # mfma = 2: pooled_mfma_kernel<false, true> (two waves per SIMD)
+                                              (50, 200, 3, 0.0), (20, 130, 3, 1e8), (33, 140, 3, 0.0)])   # mfma = 3: pooled_mfma2_kernel (two waves per tile)
 def test_pooled_ram_matches_restatement(oracle, d, N, mfma, condmax, monkeypatch):
     """method = 'ram', pooled = 1: one factor for all chains; every adaptint iterations the chains' rank-one RAM
     statistics sign(a) x x' (MCMC_run_ram.F90:166-172) of that iteration are averaged over all chains and folded into
@@ -608,7 +669,7 @@ def test_pooled_ram_matches_restatement(oracle, d, N, mfma, condmax, monkeypatch
     from mcmcf90_amd import engine_from_problem
     if not mfma:
         monkeypatch.setenv("MCMCX_POOLED_SCALAR", "1")
-    monkeypatch.setenv("MCMCX_POOLED_WAVES", "2" if mfma == 2 else "1")
+    monkeypatch.setenv("MCMCX_POOLED_WAVES", str(mfma) if mfma >= 2 else "1")
     nsimu, adaptint, nu, target = 130, 20, 0.7, 0.234
     ckw = dict(nsimu=nsimu, method="ram", adaptint=adaptint, updatesigma=0, nuparam=nu, alphatarget=target, condmax=condmax)
     rng = np.random.default_rng(d)
@@ -617,7 +678,7 @@ def test_pooled_ram_matches_restatement(oracle, d, N, mfma, condmax, monkeypatch
     pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.2), cmat0=cm0, mu=np.zeros(d), lam=A @ A.T + np.eye(d))
     e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
     e.init(); e.run()
-    assert e.last_kernel() == {0: "step_kernel<false, false, true>", 1: "pooled_mfma_kernel<false>", 2: "pooled_mfma_kernel<false, true>"}[mfma], e.last_kernel()
+    assert e.last_kernel() == {0: "step_kernel<false, false, true>", 1: "pooled_mfma_kernel<false>", 2: "pooled_mfma_kernel<false, true>", 3: "pooled_mfma2_kernel"}[mfma], e.last_kernel()
     plain = oracle.make_cfg(**dict(ckw, doadapt=0, method="dram"))
     prob = oracle.Problem(**pkw)
     chains = [oracle.LiveChain(plain, prob, chain_id=c) for c in range(N)]
