@@ -613,6 +613,7 @@ OTHER_CONFIGS = [
     # the few-chains regime (one tile of 64 chains: an iteration is latency, not throughput): us per iteration incl. the adaptation ticks
     ("c2_64_chains", dict(wl="c2", steps=5, warmup=1, chains_per_gpu=64)),
     ("c3_64_chains", dict(wl="c3", steps=5, warmup=1, chains_per_gpu=64)),
+    ("c4_64_chains", dict(wl="c4", steps=5, warmup=1, chains_per_gpu=64)),       # method = 'ram' with one tile: group_ram_kernel (factor in registers)
 ]
 # N > 1: the pooled form of the headline configuration on the same communicator -- its RAM tick (the rank-one statistics of all chains
 # of all ranks gathered and folded into the one shared factor every adaptint iterations) is the collective ON the critical path

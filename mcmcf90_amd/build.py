@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, "csrc", f) for f in ("mcx_api.hip", "mcx_kernels.hpp", "mcx_group.hpp", "mcx_pooled2.hpp", "mcx_device.hpp", "mcx_comm.hpp")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("mcx_api.hip", "mcx_kernels.hpp", "mcx_group.hpp", "mcx_group_ram.hpp", "mcx_pooled2.hpp", "mcx_device.hpp", "mcx_comm.hpp")]
 HDR = os.path.join(os.path.dirname(HERE), "include", "mcmcx.h")
 LIB = os.path.join(HERE, "libmcmcx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

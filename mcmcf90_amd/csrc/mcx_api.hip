@@ -19,6 +19,7 @@
 #include "mcx_kernels.hpp"
 #include "mcx_group.hpp"
 #include "mcx_pooled2.hpp"
+#include "mcx_group_ram.hpp"
 
 using namespace mcx;
 static_assert(MCMCX_HE_INB == HE_INB && MCMCX_HE_PRI == HE_PRI && MCMCX_HE_SS == HE_SS && MCMCX_HX_STAGE2 == HX_STAGE2 && MCMCX_HX_CRIT == HX_CRIT,
@@ -111,6 +112,7 @@ struct mcmcx_engine {
     double *d_Gc = nullptr, *d_Vc = nullptr, *d_svc = nullptr; uint8_t *d_need = nullptr, *d_state = nullptr; int *d_anyrot = nullptr; int svd_b = 0;    // blocked SVD of the adaptation (large npar)
     int wcap = 0;
     bool tile_factor = false;           // the adaptation's Cholesky branch through tile_factor_kernel (npar <= 64)
+    int ram_group_d4 = 0;               // method = 'ram' on group_ram_kernel (mcx_group_ram.hpp): npar rounded up to its instantiation, 0 = not
     int group_d4 = 0, group_drm = 0, group_gw = 16; bool group_factor = false; bool group_check_due = true; int *d_gflag = nullptr; uint8_t *d_accb = nullptr;         // lane-group step kernel (mcx_group.hpp): npar rounded up to four when it is the one to launch; accept bytes of a launch
     bool external = false; double *d_r1 = nullptr; std::vector<double> h_r1;      // MCMC_run1: the caller evaluates; exchange vectors of run1_kernel
     // timing of the step kernel
@@ -491,6 +493,32 @@ static bool pooled_two_per_tile(const mcmcx_engine *h)
 #define STEP_RS (h->d_ramscale + it0)
 #define STEP_TGT h->E.tgt.mu, h->E.tgt.lamT
 #define G1 dim3(h->ntiles), dim3(64)
+// method = 'ram' with few chains: sixteen lanes per chain, the factor in registers, dchud / dchdd on it there (mcx_group_ram.hpp)
+static const int RAM_GROUP_MAX_CHAINS = 4096;           // one wave per SIMD and four chains per wave: the chip holds 4096 at once; beyond, the streaming kernels
+static bool ram_group_covers(const mcmcx_engine *h)
+{
+    return !h->pooled && h->cfg.method == MCMCX_METHOD_RAM && !h->usesvd && !phased(h) && h->ny == 1 && h->d <= 64 &&
+           (h->tkind == TGT_GAUSS || h->tkind == TGT_BANANA || h->tkind == TGT_EXPDATA) && !(h->tkind == TGT_BANANA && h->d < 2);
+}
+template <int D4>
+static void launch_group_ram_d4(mcmcx_engine *h, int it0, int it1)
+{
+    hipLaunchKernelGGL((group_ram_kernel<D4, -1>), dim3(h->ntiles * 16), dim3(64), 0, h->stream, h->E, it0, it1, (const double *)h->d_ramscale, h->E.tgt.lamT, h->d_accb);
+}
+static void launch_group_ram(mcmcx_engine *h, int it0, int it1)
+{
+    switch (h->ram_group_d4) {
+    case 16: launch_group_ram_d4<16>(h, it0, it1); break;
+    case 32: launch_group_ram_d4<32>(h, it0, it1); break;
+    case 56: launch_group_ram_d4<56>(h, it0, it1); break;
+    case 64: launch_group_ram_d4<64>(h, it0, it1); break;
+    default: h->launch_err = "group_ram_kernel: no instantiation for npar " + std::to_string(h->d); return;
+    }
+    if (h->d_accb) {
+        const long long n = (long long)(it1 - it0 + 1) * h->ntiles;
+        hipLaunchKernelGGL(group_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->E, h->d_accb, it0, it1);
+    }
+}
 static const KernelEntry STEP_TABLE[] = {
     // ---- a device target with response columns (nycol >= 1 sums of squares per point): the phases of an iteration in one launch
     {"step", "step_kernel_cols", fused_cols,
@@ -512,6 +540,7 @@ static const KernelEntry STEP_TABLE[] = {
     {"step", "step_kernel<false, false, true>", [](const mcmcx_engine *h) { return h->pooled != 0; },
      [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((step_kernel<false, false, true>), G1, 0, STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
     // ---- method = 'ram', per-chain factors
+    {"step", "group_ram_kernel", [](const mcmcx_engine *h) { return h->ram_group_d4 != 0; }, launch_group_ram},
     {"step", "step_kernel_ram_fullr", [](const mcmcx_engine *h) { return h->E.method == M_RAM && h->usesvd; },
      [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ram_fullr, G1, 0, STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
     {"step", "step_kernel_ram_ldsr", [](const mcmcx_engine *h) { return h->E.method == M_RAM && h->E.lds_scratch == 3; },
@@ -1759,6 +1788,16 @@ int mcmcx_init(mcmcx_handle h)
             if (h->group_drm == 2 && (rc = dev_alloc(h, &h->d_gflag, 1))) return rc;
         }
     }
+    // method = 'ram' with few chains on the lane-group kernel (MCMCX_RAM_GROUP = 1 / 0: always where it covers / never; A/B, tests)
+    h->ram_group_d4 = 0;
+    if (ram_group_covers(h)) {
+        const char *rg = getenv("MCMCX_RAM_GROUP");
+        if (!rg) rg = getenv("MCMCX_GROUP");               // (the kernel-family switch of the tests covers it too)
+        if (rg ? atoi(rg) != 0 : (long long)c.nchains <= RAM_GROUP_MAX_CHAINS) {
+            h->ram_group_d4 = d <= 16 ? 16 : d <= 32 ? 32 : d <= 56 ? 56 : 64;
+            if ((E.hist || E.accmask) && (rc = dev_alloc(h, &h->d_accb, L * (size_t)GROUP_MAXSEG))) return rc;
+        }
+    }
     // the adaptation's factorisation (Cholesky branch) with the matrices in LDS (tile_factor_kernel): any chain count, npar <= 32 -- config 3's size
     // (npar 20, delayed rejection, 262144 chains): 2.11 -> 1.44 ms per tick, bound by VALU issue (~25 instructions per inner step of four chains).
     // Above npar 32 adapt_post_kernel's 8 x 8 register blocks stay: at npar 50 x 1 048 576 chains they stream the matrices ~5.6 times (16.0 ms)
@@ -1874,7 +1913,7 @@ static int run_impl(mcmcx_handle h, int32_t upto)
     HIPCHK(hipSetDevice(h->cfg.device));
     const mcmcx_config &c = h->cfg;
     if (upto > c.nsimu) upto = c.nsimu;
-    const int maxseg = h->group_d4 ? GROUP_MAXSEG : (c.method == MCMCX_METHOD_RAM && !h->pooled) ? 4096 : 1 << 30;
+    const int maxseg = (h->group_d4 || h->ram_group_d4) ? GROUP_MAXSEG : (c.method == MCMCX_METHOD_RAM && !h->pooled) ? 4096 : 1 << 30;
     int it = h->simuind + 1;
     // Several ranks that meet in this engine's ticks (pooled mode with a communicator): a rank that left the loop alone --
     // on a signal it happened to see first, or on an error of its own -- would leave its peers waiting in the next gather.

@@ -269,6 +269,74 @@ def test_tile_factorisation_kernel(oracle, monkeypatch, kind, d, drscale, nch):
             np.testing.assert_array_equal(_bits(np.triu(a[3][2 * i][1])), _bits(np.triu(o.iC)))
 
 
+RAM_CASES = [
+    # kind, npar, start ("default": cmat0 small, RAM adapts by updates; "target": cmat0 = the target's covariance, about half of the iterations downdate), extras
+    ("gauss", 50, "default", {}),                 # BASELINE config 4's shape: four slots, the instantiation for npar <= 56
+    ("gauss", 50, "target", {}),
+    ("gauss", 64, "target", {}),
+    ("gauss", 57, "default", {}),
+    ("gauss", 33, "target", dict(updatesigma=1)),
+    ("gauss", 17, "target", dict(bounds=True)),
+    ("gauss", 16, "default", dict(priors=True)),
+    ("gauss", 7, "target", dict(doburnin=1, burnintime=40)),
+    ("gauss", 1, "target", {}),
+    ("banana", 20, "target", {}),
+    ("expdata", 2, "default", dict(bounds=True, updatesigma=1)),
+    ("gauss", 50, "target", dict(record_chain=1)),
+    ("gauss", 24, "fail", {}),                    # alphatarget near 1 and a large step: choldowndate fails (INFO = -1) on some chains, which go on flagged
+]
+
+
+@pytest.mark.parametrize("kind,d,start,extra", RAM_CASES, ids=["%s%d_%s%s" % (k, d, st, "_" + "_".join(sorted(x)) if x else "") for k, d, st, x in RAM_CASES])
+def test_group_ram_kernel_equals_lane_kernels_and_oracle(oracle, monkeypatch, kind, d, start, extra):
+    """group_ram_kernel (round 5: method = 'ram' with sixteen lanes per chain, the factor in registers for the launch, DCHUD and DCHDD performed on it
+    there -- MCMC_run_ram.F90:45-179, dchud.f:122-139, dchdd.f:141-179) against the lane-per-chain RAM kernels and the oracle: state, factor, ballots,
+    counters incl. the downdate count and the status bit, stream position, bit for bit -- update and downdate chains mixed in one wave, the proposal
+    order after a successful downdate, a failed downdate, bounds (alpha12 left stale), priors, the sigma2 update, burn-in, launches cut at odd places,
+    a recorded chain, a ragged tile and a wave with padding chains."""
+    from mcmcf90_amd import engine_from_problem
+    extra = dict(extra)
+    pkw = _problem(kind, d, 900 + d, extra.pop("priors", False), extra.pop("bounds", False))
+    ekw = dict(record_chain=1) if extra.pop("record_chain", 0) else {}
+    ckw = dict(dict(nsimu=130, method="ram", adaptint=100, updatesigma=0), **extra)
+    if start == "target" and kind == "gauss":
+        pkw["cmat0"] = np.linalg.inv(np.asarray(pkw["lam"]))
+    if start == "fail":
+        ckw.update(alphatarget=0.99, nuparam=0.05)
+        pkw["cmat0"] = 4.0 * np.linalg.inv(np.asarray(pkw["lam"]))
+    if ckw.get("updatesigma"):
+        pkw.update(sigma2=0.8, nobs=15)
+    picks = (0, 1, 63, 69)
+    res = []
+    for group in ("1", "0"):
+        monkeypatch.setenv("MCMCX_RAM_GROUP", group)
+        e = engine_from_problem(ckw, pkw, nchains=70, chain_id0=6, record_accept=1, **ekw)
+        e.init(); e.run(60); e.run(61); e.run()
+        assert (e.last_kernel() == "group_ram_kernel") == (group == "1"), e.last_kernel()
+        res.append(dict(theta=e.theta().copy(), masks=e.accept_masks().copy(), scal=e.scalars().copy(), rng=[e.rng(c) for c in picks], ctr=[e.counters(c) for c in picks],
+                        R=[e.R(c).copy() for c in picks], tot=e.totals(), chain=[e.chain(c) for c in picks[:2]] if ekw else []))
+        e.close()
+    a, b = res
+    assert np.array_equal(_bits(a["theta"]), _bits(b["theta"])) and np.array_equal(a["masks"], b["masks"]) and np.array_equal(_bits(a["scal"]), _bits(b["scal"]))
+    assert a["rng"] == b["rng"] and a["ctr"] == b["ctr"] and a["tot"] == b["tot"], (a["ctr"], b["ctr"], a["tot"], b["tot"])
+    for x, y in zip(a["R"], b["R"]):
+        np.testing.assert_array_equal(_bits(np.triu(x)), _bits(np.triu(y)))
+    for x, y in zip(a["chain"], b["chain"]):
+        for u, v in zip(x, y):
+            np.testing.assert_array_equal(_bits(u), _bits(v))
+    if start == "target" and d > 1:
+        assert a["tot"]["downdates"] > 0
+    if start == "fail":
+        assert a["tot"]["status"] & 1, a["tot"]
+    cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
+    for i, c in enumerate(picks):
+        o = oracle.run_chain(cfg, prob, chain_id=6 + c, continue_on_downdate_fail=True)
+        np.testing.assert_array_equal(_bits(a["theta"][c]), _bits(o.theta))
+        np.testing.assert_array_equal(_bits(np.triu(a["R"][i])), _bits(np.triu(o.R)))
+        assert a["rng"][i][0] == o.rng_n and a["ctr"][i]["stayed"] == o.stayed and a["ctr"][i]["bndstayed"] == o.bndstayed
+        assert bool(a["ctr"][i]["status"] & 1) == (o.ram_downdate_fail != 0)
+
+
 def test_group_kernel_full_chain_and_burnin(oracle, monkeypatch):
     """record_chain (every accepted row through the ring, ballots from the accept bytes), burn-in scaling + greedy restart, launches
     cut at 256 iterations and by mcmcx_run calls of odd lengths."""
