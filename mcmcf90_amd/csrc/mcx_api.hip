@@ -494,7 +494,15 @@ static bool pooled_two_per_tile(const mcmcx_engine *h)
 #define STEP_TGT h->E.tgt.mu, h->E.tgt.lamT
 #define G1 dim3(h->ntiles), dim3(64)
 // method = 'ram' with few chains: sixteen lanes per chain, the factor in registers, dchud / dchdd on it there (mcx_group_ram.hpp)
-static const int RAM_GROUP_MAX_CHAINS = 4096;           // one wave per SIMD and four chains per wave: the chip holds 4096 at once; beyond, the streaming kernels
+// where it is the faster one (tools/ram_group_sweep.py, profiles/r05_b/ram_group_sweep.txt: chain-iterations/s of both families over npar, chain count and
+// regime): one wave per SIMD and four chains per wave, so the chip holds 4096 chains at once and the kernel saturates there (1.68e8 / 4.6e8 / 1.1e9
+// chain-iterations/s at npar 50 / 20 / 10) -- 9x / 6x / 6x the lane kernels up to 4096 chains, still 2.9x / 1.7x / 2.0x at 16384 and 1.6x / 1.1x / 1.2x
+// at 32768; from 65536 chains on the streaming kernels are ahead (0.93 / 0.74 / 0.63)
+static bool ram_group_wins(const mcmcx_engine *h)
+{
+    const long long n = h->cfg.nchains;
+    return n <= 16384 || (n <= 32768 && h->d >= 17);
+}
 static bool ram_group_covers(const mcmcx_engine *h)
 {
     return !h->pooled && h->cfg.method == MCMCX_METHOD_RAM && !h->usesvd && !phased(h) && h->ny == 1 && h->d <= 64 &&
@@ -1793,7 +1801,7 @@ int mcmcx_init(mcmcx_handle h)
     if (ram_group_covers(h)) {
         const char *rg = getenv("MCMCX_RAM_GROUP");
         if (!rg) rg = getenv("MCMCX_GROUP");               // (the kernel-family switch of the tests covers it too)
-        if (rg ? atoi(rg) != 0 : (long long)c.nchains <= RAM_GROUP_MAX_CHAINS) {
+        if (rg ? atoi(rg) != 0 : ram_group_wins(h)) {
             h->ram_group_d4 = d <= 16 ? 16 : d <= 32 ? 32 : d <= 56 ? 56 : 64;
             if ((E.hist || E.accmask) && (rc = dev_alloc(h, &h->d_accb, L * (size_t)GROUP_MAXSEG))) return rc;
         }

@@ -6,7 +6,9 @@
 // dependent row visit after the other: 184 us per iteration at 64 chains and npar 50, against ~8 us for the reference on one host core.  Here the
 // factor never leaves the registers between two launches (npar 50: 152 doubles per lane, one wave per SIMD) and an iteration is ~20-35 us.
 // It is NOT a throughput kernel -- a wave runs DCHUD's fifty serial drotg for four chains where a lane-per-chain wave runs them for 64
-// (profiles/r04_a/ram_group_probe.txt, profiles/r05_a/ram_group8_probe.txt: measured, closed) -- so the engine takes it up to 4096 chains only.
+// (profiles/r04_a/ram_group_probe.txt, profiles/r05_a/ram_group8_probe.txt: measured, closed) -- it saturates at the 4096 chains the chip holds at one
+// wave per SIMD (1.68e8 chain-iterations/s at npar 50, where the streaming kernels reach 2.3e8 with 131072 chains and more), so the engine takes it up
+// to 16384 chains (32768 from npar 17 on: mcx_api.hip, ram_group_wins; profiles/r05_b/ram_group_sweep.txt).
 //
 // Layout as in group_step_kernel: lane l16 of a chain owns the columns l16, l16 + 16, ... of R (rows 0..column in registers, zeros below the
 // diagonal), a vector element k sits in lane k mod 16 (slot k / 16) and reaches the others by row_newbcast.

@@ -63,10 +63,9 @@ def test_c_example_runs():
     assert p.returncode == 0 and "simuind 2000" in out and "pooled mean over 256 chains" in out, out
 
 
-def test_group_kernels_hold_no_v_cmpx(tmp_path):
-    """mcx_group.hpp's DPP sequences are inline asm that opens with `s_nop 1`: enough for a DPP operand written by the preceding VALU
-    instruction, not for a VALU write of EXEC (five wait states), which the hazard recogniser cannot see across an asm statement.  On
-    gfx9 the compiler forms exec masks with v_cmp + s_and_saveexec (SALU), never v_cmpx: the shipped code object is checked for it."""
+@pytest.fixture(scope="module")
+def device_disassembly(tmp_path_factory):
+    """llvm-objdump -d of the shipped gfx950 code object (one run for the tests below)."""
     import shutil
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -74,16 +73,76 @@ def test_group_kernels_hold_no_v_cmpx(tmp_path):
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if not (os.path.exists(lib) and os.path.exists(objdump)):
         pytest.skip("needs the built library and llvm-objdump")
-    shutil.copy(lib, tmp_path / "lib.so")
-    subprocess.run([objdump, "--offloading", "lib.so"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
-    co = [f for f in os.listdir(tmp_path) if "amdgcn" in f]
-    assert co, os.listdir(tmp_path)
-    dis = subprocess.run([objdump, "-d", co[0]], cwd=tmp_path, stdout=subprocess.PIPE, check=True).stdout.decode(errors="replace")
+    tmp = tmp_path_factory.mktemp("dis")
+    shutil.copy(lib, tmp / "lib.so")
+    subprocess.run([objdump, "--offloading", "lib.so"], cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    co = [f for f in os.listdir(tmp) if "amdgcn" in f]
+    assert co, os.listdir(tmp)
+    return subprocess.run([objdump, "-d", co[0]], cwd=tmp, stdout=subprocess.PIPE, check=True).stdout.decode(errors="replace").splitlines()
+
+
+def test_group_kernels_hold_no_v_cmpx(device_disassembly):
+    """mcx_group.hpp's DPP sequences are inline asm that opens with `s_nop 1`: enough for a DPP operand written by the preceding VALU
+    instruction, not for a VALU write of EXEC (five wait states), which the hazard recogniser cannot see across an asm statement.  On
+    gfx9 the compiler forms exec masks with v_cmp + s_and_saveexec (SALU), never v_cmpx: the shipped code object is checked for it."""
     ingroup, seen, bad = False, 0, []
-    for line in dis.splitlines():
+    for line in device_disassembly:
         if line.endswith(">:"):
-            ingroup = "group_step_kernel" in line
+            ingroup = "group_step_kernel" in line or "group_ram_kernel" in line
             seen += ingroup
         elif ingroup and "v_cmpx" in line:
             bad.append(line.strip())
     assert seen >= 10 and not bad, (seen, bad[:3])
+
+
+def _vregs(op):
+    op = op.strip().rstrip(",")
+    m = re.match(r"^v\[(\d+):(\d+)\]$", op)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"^v(\d+)$", op)
+    return {int(m.group(1))} if m else set()
+
+
+def _dpp_hazards(lines):
+    """Every *_dpp instruction of a disassembly: its DPP operand (src0) must not have been written by a VALU instruction within the two
+    wait states before it (an instruction = one wait state, `s_nop N` = N + 1; a label forgets the history: another path may arrive there)."""
+    novdst = ("v_cmp", "v_cmpx", "v_readlane", "v_readfirstlane", "v_nop")
+    bad, ndpp, hist = [], 0, []
+    for ln in lines:
+        t = ln.split("//")[0].strip()
+        if not t or t.endswith(":"):
+            if t.endswith(":"):
+                hist = []
+            continue
+        parts = t.split(None, 1)
+        mn = parts[0]
+        ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+        if mn.endswith("_dpp"):
+            ndpp += 1
+            src0 = _vregs(ops[1].split()[0]) if len(ops) > 1 else set()
+            ws = 0
+            for m2, d2, w2 in reversed(hist):
+                if ws >= 2:
+                    break
+                if m2.startswith("v_") and d2 & src0:
+                    bad.append((t, m2))
+                    break
+                ws += w2
+        w = int(ops[0], 0) + 1 if (mn == "s_nop" and ops) else 1
+        dst = _vregs(ops[0].split()[0]) if (mn.startswith("v_") and not mn.startswith(novdst) and ops) else set()
+        hist.append((mn, dst, w))
+        if len(hist) > 8:
+            hist.pop(0)
+    return ndpp, bad
+
+
+def test_dpp_operands_are_two_wait_states_old(device_disassembly):
+    """the inline-asm DPP chains of the group kernels rely on `s_nop 1` at the head of every statement and on no statement
+    writing a register one of its own DPP operands reads; the compiler's hazard recogniser does not look into them.  Checked on the
+    shipped code object, instruction by instruction, for EVERY DPP instruction (the compiler's own included): the DPP-read operand was
+    not written by a vector instruction within the two wait states before it.  (And the checker sees a hazard when there is one.)"""
+    n, bad = _dpp_hazards(device_disassembly)
+    assert n > 5000 and not bad, (n, bad[:5])
+    fake = ["\tv_add_f64 v[4:5], v[0:1], v[2:3]", "\tv_fmac_f64_dpp v[8:9], v[4:5], v[6:7] row_newbcast:1 row_mask:0xf bank_mask:0xf"]
+    assert _dpp_hazards(fake)[1] and _dpp_hazards([fake[0], "\ts_nop 0", fake[1]])[1] and not _dpp_hazards([fake[0], "\ts_nop 1", fake[1]])[1]
