@@ -29,6 +29,9 @@
 #ifndef MCMCX_TARGET_MAX_NPAR
 #define MCMCX_TARGET_MAX_NPAR 64
 #endif
+#ifndef MCMCX_TARGET_MAX_NY
+#define MCMCX_TARGET_MAX_NY 8                  /* response columns of ssfunction (nycol); define it before the include to change it */
+#endif
 #define MCMCX_TARGET_ABI 1
 #define MCMCX_HE_INB 0        /* result slots of a chain: in bounds (1.0 / 0.0), prior, ss per response column */
 #define MCMCX_HE_PRI 1
@@ -53,11 +56,12 @@ typedef struct mcmcx_target_args {
 #define MCMCX_DEFINE_TARGET(NAME, SSFUN, PRIORFUN, BOUNDSFUN)                                                          \
     extern "C" __device__ const int NAME##_abi = MCMCX_TARGET_ABI;                                                       \
     extern "C" __device__ const int NAME##_max_npar = MCMCX_TARGET_MAX_NPAR;                                             \
+    extern "C" __device__ const int NAME##_max_ny = MCMCX_TARGET_MAX_NY;                                                 \
     extern "C" __global__ void __launch_bounds__(64) NAME(mcmcx_target_args a)                                           \
     {                                                                                                                    \
         const int c = blockIdx.x * 64 + threadIdx.x;                                                                     \
-        double th[MCMCX_TARGET_MAX_NPAR], ss[8];                                                                         \
-        for (int j = 0; j < 8; ++j) ss[j] = 0.0;                                                                         \
+        double th[MCMCX_TARGET_MAX_NPAR], ss[MCMCX_TARGET_MAX_NY];                                                       \
+        for (int j = 0; j < MCMCX_TARGET_MAX_NY; ++j) ss[j] = 0.0;                                                       \
         const bool skip = (c >= a.nchains) || (a.use_stage2 && MCMCX_TI(a.hx, a.nhx, MCMCX_HX_STAGE2, c) == 0.0);        \
         int inb = 1;                                                                                                     \
         double pri = 0.0;                                                                                                \

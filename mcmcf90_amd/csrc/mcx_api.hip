@@ -68,6 +68,7 @@ struct mcmcx_engine {
     bool has_lo = false, has_hi = false, has_pri = false;
     mcmcx_ssfun_t h_ss = nullptr; mcmcx_ssfun_er_t h_ss_er = nullptr; mcmcx_priorfun_t h_pri = nullptr; mcmcx_checkbounds_t h_cb = nullptr; void *h_user = nullptr;
     mcmcx_ssfun_batch_t h_ss_batch = nullptr; int h_threads = 1;      // batched form of the user's ssfunction (opt-in)
+    int mod_max_ny = 8;
     hipModule_t mod = nullptr; hipFunction_t mod_fn = nullptr; void *d_moddata = nullptr;   // user target module (include/mcmcx_target.h)
     std::vector<double> h_bth, h_bss; std::vector<int> h_bidx;
     // host side of the callback path: page-locked, so that the candidates come back and the results go out as asynchronous copies
@@ -157,6 +158,7 @@ static int dev_upload(mcmcx_engine *h, const T **p, const std::vector<T> &v)
 // every kernel family applies; above, the forms that keep an npar-vector per lane in LDS give way to global scratch where the 160 KiB end
 // (delayed rejection > 160, the adaptation's work vector > 320, the pooled-moment kernel > 317), the blocked SVD to the lane-per-chain SVD
 // (> 256), the matrix-core pooled kernels to the lane kernels (their own LDS tests): slower, never refused.
+static const int MCX_MAX_NYCOL = 4096;    // response columns (mcmc.F90:30-33: whatever mcmcnycol.dat says): every per-column array is sized at mcmcx_init
 static const int MCX_MAX_NPAR = 8192;     // P = npar (npar + 1) / 2 and 64 P stay far inside int / size_t arithmetic
 
 // dpotf2('U') + scaling on the host for the shared initial factor: same operation sequence as the
@@ -915,7 +917,8 @@ static int allreduce_moments_enqueue(mcmcx_engine *h, int stage /* 0 all, 1 loca
     if (stage == 0 || stage == 1) {
         int rc = pooled_moments_launch(h, h->d_gather + (size_t)rk * st, kind, it); if (rc) return rc;
         h->h_flag = flag;
-        HIPCHK(hipMemcpyAsync(h->d_gather + (size_t)rk * st + len, &h->h_flag, sizeof(double), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(set_double_kernel, dim3(1), dim3(1), 0, h->stream, h->d_gather + (size_t)rk * st + len, flag);
+        HIPCHK(hipGetLastError());
     }
     if ((stage == 0 || stage == 2) && h->comm) { int rc = comm_allgather(h->comm, h->d_gather, st, h->stream); if (rc) return rc; }
     if (stage == 0 || stage == 3) {
@@ -1473,7 +1476,7 @@ int mcmcx_set_cmat0(mcmcx_handle h, const double *c, int32_t n)
 int mcmcx_set_sigma2nobs(mcmcx_handle h, const double *s2, const int32_t *nobs, int32_t nycol)
 {
     if (!h || !s2 || !nobs) return fail(-1, "null argument");
-    if (nycol < 1 || nycol > 8) return fail(-21, "nycol must be in 1..8");
+    if (nycol < 1 || nycol > MCX_MAX_NYCOL) return fail(-21, "nycol must be in 1.." + std::to_string(MCX_MAX_NYCOL));
     if (h->inited) return fail(-20, "set sigma2 / nobs before mcmcx_init");
     h->ny = nycol; h->sigma2v.assign(s2, s2 + nycol); h->nobsv.assign(nobs, nobs + nycol);
     h->sigma2 = s2[0]; h->nobs = nobs[0]; h->sigma2ok = true;
@@ -1502,7 +1505,7 @@ int mcmcx_set_target_expdata(mcmcx_handle h, int32_t n, const double *x, const d
 int mcmcx_set_target_expdata_cols(mcmcx_handle h, int32_t n, int32_t nycol, const double *x, const double *y)
 {
     if (!h || !x || !y || n < 1) return fail(-1, "bad argument");
-    if (nycol < 1 || nycol > 8) return fail(-21, "nycol must be in 1..8");
+    if (nycol < 1 || nycol > MCX_MAX_NYCOL) return fail(-21, "nycol must be in 1.." + std::to_string(MCX_MAX_NYCOL));
     if (h->d != 1 + nycol) return fail(-22, "response-column target needs npar = 1 + nycol");
     h->tkind = TGT_EXPCOLS; h->tncols = nycol; h->tx.assign(x, x + n); h->ty.assign(y, y + (size_t)n * nycol);
     return 0;
@@ -1548,6 +1551,13 @@ int mcmcx_set_target_module(mcmcx_handle h, const char *code_object_path, const 
         HIPCHK(hipMemcpy(&v, p, sizeof(int), hipMemcpyDeviceToHost));
         if (suffix[1] == 'a' && v != MCMCX_TARGET_ABI) return fail(-37, "target module: built against another mcmcx_target.h (abi " + std::to_string(v) + ")");
         if (suffix[1] == 'm' && h->d > v) return fail(-37, "target module: npar = " + std::to_string(h->d) + " but the module was compiled with MCMCX_TARGET_MAX_NPAR = " + std::to_string(v));
+    }
+    {   // response columns the module's kernel has room for (modules built before round 5 have no such symbol: eight)
+        hipDeviceptr_t p = nullptr; size_t sz = 0; int v = 8;
+        if (hipModuleGetGlobal(&p, &sz, h->mod, (std::string(kernel_name) + "_max_ny").c_str()) == hipSuccess && sz == sizeof(int))
+            HIPCHK(hipMemcpy(&v, p, sizeof(int), hipMemcpyDeviceToHost));
+        else (void)hipGetLastError();
+        h->mod_max_ny = v;
     }
     if (userdata && nbytes > 0) {
         HIPCHK(hipMalloc(&h->d_moddata, (size_t)nbytes));
@@ -1598,6 +1608,8 @@ int mcmcx_init(mcmcx_handle h)
     if (h->ny == 1) { h->sigma2v.assign(1, h->sigma2); h->nobsv.assign(1, h->nobs); }
     const int ny = h->ny;
     if (ny > 1 && !phased(h)) return fail(-36, "nycol > 1 needs the host-callback or the response-column target (the other built-in targets have one column)");
+    if (h->tkind == TGT_MODULE && ny > h->mod_max_ny)
+        return fail(-36, "target module: nycol = " + std::to_string(ny) + " but the module was compiled with MCMCX_TARGET_MAX_NY = " + std::to_string(h->mod_max_ny));
     if (h->tkind == TGT_EXPCOLS && h->tncols != ny) return fail(-36, "response-column target: mcmcx_set_sigma2nobs must give one sigma2 / nobs per column");
     if (ny > 1 && h->pooled && (!fused_cols(h) || c.method == MCMCX_METHOD_SCAM))
         return fail(-36, "nycol > 1 in pooled mode: the device-resident response-column target only, and not with method = 'scam'");

@@ -4915,6 +4915,10 @@ __global__ __launch_bounds__(256) void moments_kernel(EngineDev E, double *out, 
     }
 }
 
+// one double into device memory in stream order (the rank's stop flag behind its moment vector): a pageable hipMemcpyAsync of eight bytes makes the
+// host wait for the stream on this runtime, which put a host round trip between two bench steps
+__global__ void set_double_kernel(double *p, double v) { *p = v; }
+
 // Finish the pooled sum over tiles in the same fixed pairwise tree (adjacent tiles first):
 //     for s = 1, 2, 4, ...: for t = 0, 2s, 4s, ... with t + s < ntiles: v[t] += v[t + s]
 // v[0..len) of tile 0 ends up holding the result.  Deterministic and independent of how tiles are later grouped onto

@@ -49,7 +49,7 @@ typedef struct mcxo_target {
     int ny;                           /* response columns of ssfunction (nycol); 0 or 1 = one; > 1: expdata only, ydata ny x ndata */
 } mcxo_target;
 
-#define MCXO_NYMAX 8
+#define MCXO_NYMAX 32
 double mcxo_ssfun(const mcxo_target *t, const double *theta);               /* column 0 */
 void   mcxo_ssfun_cols(const mcxo_target *t, const double *theta, double *ss); /* all ny columns */
 double mcxo_priorfun(const mcxo_target *t, const double *theta);

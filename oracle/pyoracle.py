@@ -54,7 +54,7 @@ class Chain(C.Structure):
                 ("info_last", C.c_int), ("ram_downdate_fail", C.c_int),
                 ("oldpar", _DP), ("ss1", C.c_double), ("sspri1", C.c_double), ("alpha12", C.c_double),
                 ("continue_on_downdate_fail", C.c_int), ("qcovstd", _DP), ("erstayed", C.c_int),
-                ("ny", C.c_int), ("ss1v", C.c_double * 8), ("sigma2v", C.c_double * 8), ("nobsv", C.c_int * 8),
+                ("ny", C.c_int), ("ss1v", C.c_double * 32), ("sigma2v", C.c_double * 32), ("nobsv", C.c_int * 32),       # MCXO_NYMAX
                 ("trmv_desc", C.c_int), ("last_u", _DP), ("n_calcR", C.c_int), ("svd_floored", C.c_int)]
 
 

@@ -224,6 +224,51 @@ def test_two_response_columns_on_the_device_in_one_launch(oracle, name, form, mo
     e.close()
 
 
+@pytest.mark.parametrize("target", ["device", "host"])
+@pytest.mark.parametrize("method,extra", [("dram", dict(drscale=2.0, updatesigma=1)), ("er", dict()), ("ram", dict())])
+def test_twelve_response_columns(oracle, target, method, extra):
+    """nycol = 12 (round 5: the engine took at most eight; the reference takes whatever mcmcnycol.dat says, MCMC_init.F90:119-132): npar = 13, the
+    response-column model on the device in one launch, and the same model through the host callbacks, against the oracle bit for bit."""
+    import ctypes as C
+    from mcmcf90_amd import Engine, make_config, engine_from_problem
+    ny = 12
+    r = np.random.default_rng(5)
+    x = np.arange(9.0)
+    rates = np.linspace(0.08, 0.3, ny)
+    Y = np.vstack([9.0 * np.exp(-k * x) + r.standard_normal(x.size) * 0.3 for k in rates])
+    ckw = dict(dict(nsimu=160, method=method, adaptint=50, updatesigma=0, N0=1.0, S02=0.6), **extra)
+    pkw = dict(kind="expdata", npar=1 + ny, par0=np.concatenate([[9.0], rates]), cmat0=np.diag([0.01] + [0.0001] * ny) * (10.0 if method == "ram" else 1.0),
+               sigma2=r.uniform(0.4, 1.0, ny), nobs=r.integers(5, 12, ny), xdata=x, ydata=Y, lo=np.zeros(1 + ny))
+    cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
+    if target == "device":
+        e = engine_from_problem(ckw, pkw, nchains=67, chain_id0=3, record_chain=1)
+    else:
+        L = oracle.lib(); tgt = prob.ctarget(); dp = C.POINTER(C.c_double)
+        L.mcxo_priorfun.restype = C.c_double; L.mcxo_checkbounds.restype = C.c_int
+
+        def ssfun(th):
+            out = np.zeros(ny)
+            L.mcxo_ssfun_cols(C.byref(tgt), th.ctypes.data_as(dp), out.ctypes.data_as(dp))
+            return out
+        e = Engine(make_config(1 + ny, 67, record_chain=1, chain_id0=3, **ckw))
+        e.setpar0(prob.par0); e.setcmat0(prob.cmat0); e.setsigma2nobs(prob.sigma2v, prob.nobsv)
+        e.set_target_host(ssfun, lambda th: L.mcxo_priorfun(C.byref(tgt), th.ctypes.data_as(dp)), lambda th: bool(L.mcxo_checkbounds(C.byref(tgt), th.ctypes.data_as(dp))))
+    e.init(); e.run()
+    if target == "device":
+        assert e.last_kernel() == "step_kernel_cols", e.last_kernel()
+    for c in (0, 66):
+        o = oracle.run_chain(cfg, prob, chain_id=3 + c, continue_on_downdate_fail=True)
+        ch, ss, s2 = e.chain(c)
+        assert ss.shape[1] == ny + 1
+        np.testing.assert_array_equal(_bits(ch), _bits(o.chain))
+        np.testing.assert_array_equal(_bits(ss), _bits(o.sschain))
+        if cfg.updatesigma:
+            assert s2.shape[1] == ny
+            np.testing.assert_array_equal(_bits(s2), _bits(o.s2chain))
+        assert e.rng(c)[0] == o.rng_n
+    e.close()
+
+
 def test_two_columns_need_the_host_target():
     from mcmcf90_amd import Engine, make_config, McmcError
     e = Engine(make_config(2, 1, nsimu=10))

@@ -37,6 +37,11 @@ for seed in range(A, B):
                 fn(po, 100000 + seed, "auto") if fn is g.test_random_configuration_in_pieces else fn(po, 100000 + seed); n += 1
             except Exception as e:
                 bad.append((fn.__name__, seed, repr(e)[:200]))
+    if seed % 2 == 0:                                     # npar 13..64: RAM in both regimes (group_ram_kernel / the wide panels), AM / DRAM / ER with the tile factorisation
+        try:
+            g.test_random_configuration_larger_npar(po, 200000 + seed, "auto"); n += 1
+        except Exception as e:
+            bad.append(("larger_npar", seed, repr(e)[:200]))
     if seed % 50 == 0:
         print("seed", seed, "checked", n, "failures", len(bad), "%.0f s" % (time.time() - t0), flush=True)
     if time.time() - t0 > float(os.environ.get("BIGFUZZ_SECONDS", "1500")): 
