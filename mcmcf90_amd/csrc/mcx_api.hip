@@ -491,6 +491,13 @@ static bool pooled_two_per_tile(const mcmcx_engine *h)
     if (h->sw.pooled_waves >= 0) return h->sw.pooled_waves == 3;
     return false;
 }
+// pooled_mfma3_kernel: half a tile (32 chains, two lanes each) per wave, no workgroup; MCMCX_POOLED_WAVES = 4 forces it
+static bool pooled_half_tiles(const mcmcx_engine *h)
+{
+    if (h->dodr || h->d < 17 || h->d > 64) return false;
+    if (h->sw.pooled_waves >= 0) return h->sw.pooled_waves == 4;
+    return false;
+}
 #define STEP_ARGS h->stream, h->E, it0, it1
 #define STEP_RS (h->d_ramscale + it0)
 #define STEP_TGT h->E.tgt.mu, h->E.tgt.lamT
@@ -537,6 +544,8 @@ static const KernelEntry STEP_TABLE[] = {
     // ---- pooled mode (one shared factor)
     {"step", "pooled_mfma_kernel<true>", [](const mcmcx_engine *h) { return pooled_use_mfma(h) && h->dodr != 0; },
      [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(pooled_mfma_kernel<true>, G1, pooled_mfma_lds(h->d), STEP_ARGS, STEP_TGT, h->d_sharedRT, h->d_sharedR2T, h->d_sharediCd); }},
+    {"step", "pooled_mfma3_kernel", [](const mcmcx_engine *h) { return pooled_use_mfma(h) && pooled_half_tiles(h); },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(pooled_mfma3_kernel, dim3(2 * h->ntiles), dim3(64), pooled_mfma_lds(h->d) / 2, STEP_ARGS, STEP_TGT, h->d_sharedRT); }},
     {"step", "pooled_mfma2_kernel", [](const mcmcx_engine *h) { return pooled_use_mfma(h) && pooled_two_per_tile(h); },
      [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(pooled_mfma2_kernel, dim3(h->ntiles), dim3(128), pooled_mfma_lds(h->d), STEP_ARGS, STEP_TGT, h->d_sharedRT); }},
     {"step", "pooled_mfma_kernel<false, true>", [](const mcmcx_engine *h) { return pooled_use_mfma(h) && pooled_two_waves(h); },

@@ -200,6 +200,9 @@ struct GChain {                         // the chain's stream: uniform over its 
     uint64_t cb; uint32_t cw[4];
 };
 
+#ifndef MCX_GROUP_SPLIT
+#define MCX_GROUP_SPLIT 1    // group_normals in two passes: attempts, then the logarithm / root / divisions for the kept pairs only (as gen_normals_split)
+#endif
 // ---------------------------------------------------------------- normals: sixteen polar attempts of a chain at a time
 // z[t] <- the chain's next npar deviates (position 16 t + l16; 0 in the padding), through the chain's LDS row.
 template <int D4, int GW>
@@ -211,6 +214,8 @@ MCX_DEV void group_normals(uint32_t k0, uint32_t k1, GChain &g, double *zrow, in
     if (act && g.saved) { if (l16 == 0) zrow[0] = g.saved_y; g.saved = 0; k = 1; }     // normal_bm's cached second deviate, mcmcrand.F90:172-175
     bool need = act && (k < d);
     bool newsave = false;
+    const int kst = k;                                           // where the drawn pairs start
+    const bool drew = need;
     while (__any(need)) {
         const uint64_t b = (g.n >> 1) + (uint64_t)l16;
         const bool odd = (g.n & 1) != 0;
@@ -226,9 +231,13 @@ MCX_DEV void group_normals(uint32_t k0, uint32_t k1, GChain &g, double *zrow, in
         x1 = 2.0 * x1 - 1.0; x2 = 2.0 * x2 - 1.0;
         const double xx = x1 * x1 + x2 * x2;
         const bool ok = valid && (xx < 1.0) && (xx != 0.0);
+#if MCX_GROUP_SPLIT
+        const double za = x2, zb = x1;                             // parked unscaled where the deviates will stand; scaled below, the kept pairs only
+#else
         const double xs = ok ? xx : 0.5;
         const double zz = sqrt(-2.0 * d_log(xs) / xs);
         const double za = zz * x2, zb = zz * x1;                   // this call's deviate, the next call's (mcmcrand.F90:183-186)
+#endif
         const uint32_t okm = (uint32_t)(__ballot(ok && need) >> (GW * row)) & G::GM;
         const int pre = __popc(okm & ((1u << l16) - 1u));          // accepted attempts before this one
         const int m = (d - k + 1) >> 1;                            // pairs the chain still needs
@@ -251,6 +260,36 @@ MCX_DEV void group_normals(uint32_t k0, uint32_t k1, GChain &g, double *zrow, in
         }
     }
     MCX_WAVE_LDS_SYNC();                                         // (the wave's LDS operations retire in order: its reads below see its writes above)
+#if MCX_GROUP_SPLIT
+    // the second pass: z = sqrt(-2 log(xx) / xx) (mcmcrand.F90:183) for the pairs that were KEPT -- (npar + 1) / 2 of them, where the
+    // attempts above were 16 (4) a round whether accepted, needed or neither -- pair p of the chain on lane p mod 16 (4); xx is formed
+    // again from the same x1, x2 by the same two products and one sum
+    {
+        constexpr int NPB = ((D4 + 1) / 2 + GW - 1) / GW;
+        const int mt = (d - kst + 1) >> 1;
+        double px1[NPB], px2[NPB];
+        sfor<0, NPB>([&](auto U) __attribute__((always_inline)) {
+            constexpr int u = decltype(U)::value;
+            const int pr = GW * u + l16, pos = kst + 2 * pr;
+            const bool live = drew && pr < mt;
+            px2[u] = zrow[live ? pos : 0];
+            px1[u] = zrow[live ? (pos + 1 < d ? pos + 1 : D4) : 0];
+        });
+        sfor<0, NPB>([&](auto U) __attribute__((always_inline)) {
+            constexpr int u = decltype(U)::value;
+            const int pr = GW * u + l16, pos = kst + 2 * pr;
+            const bool live = drew && pr < mt;
+            const double xx0 = px1[u] * px1[u] + px2[u] * px2[u];
+            const double xs = live ? xx0 : 0.5;
+            const double zz = sqrt(-2.0 * d_log(xs) / xs);
+            if (live) {
+                zrow[pos] = zz * px2[u];
+                zrow[pos + 1 < d ? pos + 1 : D4] = zz * px1[u];
+            }
+        });
+        MCX_WAVE_LDS_SYNC();
+    }
+#endif
     sfor<0, G::NS>([&](auto T) __attribute__((always_inline)) {
         constexpr int t = decltype(T)::value;
         const int pos = GW * t + l16;

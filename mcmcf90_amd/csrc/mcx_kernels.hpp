@@ -404,6 +404,17 @@ MCX_DEV bool target_inbounds(const DevTarget &t, int d, int lane, const double *
 #ifndef MCX_POOLED_NB
 #define MCX_POOLED_NB 8      // ... in pooled_mfma_kernel (one wave per SIMD, nothing else to issue while an attempt's chain waits: config 4 pooled 9.25e8 -> 9.65e8 at 8; 1: 9.04, 4: 9.21, 12: 9.55, 16: 8.99)
 #endif
+#ifndef MCX_POOLED_SPLIT
+#define MCX_POOLED_SPLIT 1   // pooled_mfma_kernel draws its vector in two passes (gen_normals_split): attempts first, the logarithm / root / divisions for the kept pairs only
+#endif
+#ifndef MCX_POOLED_NBB
+#define MCX_POOLED_NBB 4
+#endif
+#if MCX_POOLED_SPLIT
+#define MCX_POOLED_GEN gen_normals_split<MCX_POOLED_NB, MCX_POOLED_NBB>
+#else
+#define MCX_POOLED_GEN gen_normals<MCX_POOLED_NB>
+#endif
 #ifndef MCX_RNG_NB
 #define MCX_RNG_NB 2      // polar attempts computed side by side in the kernels that wait for the generator (AM, DRAM, pooled); 4 loses at config 2 (d = 10: a vector is ~11 attempts)
 #endif
@@ -474,6 +485,88 @@ MCX_DEV double gen_normals(Rng &g, double *zs_t, int lane, int d, bool participa
             }
             g.cblk = 0;                                   // the half-used block (n odd) is recomputed by the next single draw
             need = (k < d);
+        }
+    }
+    return su;
+}
+
+// The same vector in TWO passes, for a kernel whose generator is bound by instruction issue (pooled_mfma_kernel: 47 % of an iteration):
+// a wave runs ~40 attempts per lane for the 25 pairs a lane of npar 50 keeps (0.785 a try, the slowest lane sets the trip count), and in
+// the one-pass form every one of them pays for the logarithm, the square root and the two divisions.  Pass A makes the attempts -- the
+// Philox blocks, the two uniforms, the test xx < 1 -- and parks the ACCEPTED pair's (x2, x1) where its deviates will stand; it alone moves
+// the stream.  Pass B visits the parked pairs, exactly as many as the vector holds, and scales them: z = sqrt(-2 log(xx) / xx) with xx formed
+// again from the same two numbers by the same two products and one sum.  Stream position, deviates, the cached second deviate and the order
+// of sum(z**2): those of gen_normals.
+template <int NB, int NBB = 4>
+MCX_DEV double gen_normals_split(Rng &g, double *zs_t, int lane, int d, bool participate)
+{
+    int k = 0;
+    double su = 0.0;
+    if (participate && g.saved && d > 0) { GV(zs_t, 0) = g.saved_y; su = su + g.saved_y * g.saved_y; g.saved = 0; k = 1; }
+    const int k0 = k;
+    bool need = participate && (k < d);
+    double over = 0.0;                                    // x1 of the pair whose second deviate lies past the vector's end
+    while (__any(need)) {
+        const uint64_t b0 = g.n >> 1;
+        const bool odd = (g.n & 1) != 0;
+        uint32_t w[NB + 1][4];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) philox4x32_10((uint32_t)(b0 + j), (uint32_t)((b0 + j) >> 32), g.k0, g.k1, w[j][0], w[j][1], w[j][2], w[j][3]);
+        if (__any(need && odd)) philox4x32_10((uint32_t)(b0 + NB), (uint32_t)((b0 + NB) >> 32), g.k0, g.k1, w[NB][0], w[NB][1], w[NB][2], w[NB][3]);
+        else { w[NB][0] = w[NB][1] = w[NB][2] = w[NB][3] = 0u; }
+        double xa[NB], xb[NB];
+        bool ok[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            double x1 = odd ? bits_to_uniform(w[j][2], w[j][3]) : bits_to_uniform(w[j][0], w[j][1]);
+            double x2 = odd ? bits_to_uniform(w[j + 1][0], w[j + 1][1]) : bits_to_uniform(w[j][2], w[j][3]);
+            x1 = 2.0 * x1 - 1.0; x2 = 2.0 * x2 - 1.0;
+            const double xx = x1 * x1 + x2 * x2;
+            ok[j] = (xx < 1.0) && (xx != 0.0);
+            xa[j] = x2; xb[j] = x1;
+        }
+        if (need) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (k < d) {
+                    g.n += 2;
+                    if (ok[j]) {
+                        GV(zs_t, k) = xa[j]; ++k;
+                        if (k < d) { GV(zs_t, k) = xb[j]; ++k; }
+                        else over = xb[j];
+                    }
+                }
+            }
+            g.cblk = 0;
+            need = (k < d);
+        }
+    }
+    if (participate) {
+        for (int kk = k0; kk < d; kk += 2 * NBB) {
+            double x1[NBB], x2[NBB], za[NBB], zb[NBB];
+#pragma unroll
+            for (int u = 0; u < NBB; ++u) {
+                const int ka = kk + 2 * u;
+                x2[u] = GV(zs_t, ka < d ? ka : d - 1);
+                x1[u] = (ka + 1 < d) ? GV(zs_t, ka + 1) : over;
+            }
+#pragma unroll
+            for (int u = 0; u < NBB; ++u) {
+                const bool live = kk + 2 * u < d;
+                const double xx0 = x1[u] * x1[u] + x2[u] * x2[u];
+                const double xx = live ? xx0 : 0.5;
+                const double z = sqrt(-2.0 * d_log(xx) / xx);
+                zb[u] = z * x1[u]; za[u] = z * x2[u];
+            }
+#pragma unroll
+            for (int u = 0; u < NBB; ++u) {
+                const int ka = kk + 2 * u;
+                if (ka < d) {
+                    GV(zs_t, ka) = za[u]; su = su + za[u] * za[u];
+                    if (ka + 1 < d) { GV(zs_t, ka + 1) = zb[u]; su = su + zb[u] * zb[u]; }
+                    else { g.saved_y = zb[u]; g.saved = 1; }
+                }
+            }
         }
     }
     return su;
@@ -2439,7 +2532,7 @@ __global__ __launch_bounds__(64, (!DR && W2) ? 2 : 1) void pooled_mfma_kernel(En
 #endif
     for (int it = it0; it <= it1; ++it) {
         // ---- newpar = MCMC_propose(oldpar, R): z straight into the LDS vector, P = R'z on the matrix cores
-        gen_normals<MCX_POOLED_NB>(L.g, X, lane, d, true);
+        MCX_POOLED_GEN(L.g, X, lane, d, true);
         PH(0)
         if (it == it1) {                                               // the launch's last normals stay readable (pooled RAM statistic)
             double *zk = E.zs + ((size_t)tile * 2 + (it & 1)) * d * 64;
@@ -2478,7 +2571,7 @@ __global__ __launch_bounds__(64, (!DR && W2) ? 2 : 1) void pooled_mfma_kernel(En
         if (DR && __any(reject)) {
             const bool m = reject;
             if (m) L.drtries += 1;
-            gen_normals<MCX_POOLED_NB>(L.g, X, lane, d, m);            // lanes that did not draw compute on stale values and are not looked at
+            MCX_POOLED_GEN(L.g, X, lane, d, m);            // lanes that did not draw compute on stale values and are not looked at
             for (int k = d; k < d4; ++k) XL(k) = 0.0;
             product_to_T(g_R2T, !E.usesvd);
             candidate_from_T(c2_t);

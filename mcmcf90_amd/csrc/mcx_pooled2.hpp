@@ -27,13 +27,14 @@ namespace mcx {
 #define MCX_POOLED2_NBL 4          // polar attempts per lane and trip (eight per chain and trip, like pooled_mfma_kernel's)
 #endif
 
-// z <- the chain's next d deviates into X[k * 64 + lane] (lane = the chain's index in the tile); h: which of the chain's two lanes this is.
+// z <- the chain's next d deviates into the chain's column of the LDS vector; h: which of the chain's two lanes this is.
 // `participate` and the chain's stream state g are identical in the two lanes on entry, and on exit.
+// (Xc: the chain's column of the LDS vector, xs: its row stride in doubles)
 template <int NBL>
-MCX_DEV void gen_normals2(Rng &g, double *X, int lane, int h, int d, bool participate)
+MCX_DEV void gen_normals2(Rng &g, double *Xc, int xs, int h, int d, bool participate)
 {
     int k = 0;
-    if (participate && g.saved && d > 0) { if (h == 0) XL(0) = g.saved_y; g.saved = 0; k = 1; }     // normal_bm's cached deviate, mcmcrand.F90:172-175
+    if (participate && g.saved && d > 0) { if (h == 0) Xc[0] = g.saved_y; g.saved = 0; k = 1; }     // normal_bm's cached deviate, mcmcrand.F90:172-175
     bool need = participate && (k < d);
     while (__any(need)) {
         const uint64_t b0 = (g.n >> 1) + (uint64_t)(h * NBL);
@@ -71,8 +72,8 @@ MCX_DEV void gen_normals2(Rng &g, double *X, int lane, int h, int d, bool partic
                 const int pre = __popc(all & ((1u << a) - 1u));              // accepted attempts before this one
                 if (((okm >> j) & 1u) && pre < m) {
                     const int pos = k + 2 * pre;
-                    XL(pos) = za[j];
-                    if (pos + 1 < d) XL(pos + 1) = zb[j]; else mysave = zb[j];
+                    Xc[(size_t)pos * xs] = za[j];
+                    if (pos + 1 < d) Xc[(size_t)(pos + 1) * xs] = zb[j]; else mysave = zb[j];
                 }
             }
             if (tot >= m) {
@@ -174,7 +175,7 @@ void pooled_mfma2_kernel(EngineDev E, int it0, int it1, const double *__restrict
     constexpr int CBH = 16;                              // state elements per batch (a lane moves half of the chain's: two batches at npar 50)
     for (int it = it0; it <= it1; ++it) {
         // ---- newpar = MCMC_propose(oldpar, R): z straight into the LDS vector, P = R'z on the matrix cores
-        gen_normals2<MCX_POOLED2_NBL>(L.g, X, lane, h, d, true);
+        gen_normals2<MCX_POOLED2_NBL>(L.g, X + lane, 64, h, d, true);
         if (h == 0) for (int k = d; k < d4; ++k) XL(k) = 0.0;
         PH(0)
         __syncthreads();                                                          // (a) the 64 chains' normals are in X
@@ -314,6 +315,193 @@ void pooled_mfma2_kernel(EngineDev E, int it0, int it1, const double *__restrict
                tile, w, it1 - it0 + 1, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7], ph[8], ph[9]);
 #endif
 #undef PH
+    if (h == 0) {
+        lane_store(E, tile, lane, L);
+        TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane) = erstayed;
+    }
+}
+
+// ---------------------------------------------------------------- ... and with HALF A TILE PER WAVE (no workgroup at all)
+// The two-wave workgroup above spends 47 % of its wave cycles parked at its six barriers.  The same split of the work WITHOUT a partner: one wave
+// = 32 chains of a tile, two lanes per chain exactly as above, all (up to four) output blocks of the products for its own TWO chain groups (eight
+// accumulators), an LDS vector of [d4][32] doubles -- 13.3 kB at npar 50, so twelve waves share a CU (three per SIMD at 168 registers) and no wave
+// ever waits for another.  Per chain the arithmetic of pooled_mfma_kernel; the tile's ballot is written as its two 32-bit halves.
+#ifndef MCX_POOLED3_KU
+#define MCX_POOLED3_KU MCX_POOLED_KU
+#endif
+template <bool TRI>
+MCX_DEV void mfma_product_half(const double *__restrict__ M, const double *X, int pl, int d, int d4, int nt, mcx_d4 (&c)[4][2])
+{
+    const int li = pl & 15, lk = pl >> 4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { c[b][0] = mcx_d4{0.0, 0.0, 0.0, 0.0}; c[b][1] = mcx_d4{0.0, 0.0, 0.0, 0.0}; }
+    int kmax = d4;
+    if (TRI) { const int last = 16 * nt; kmax = last < d4 ? last : d4; }
+    const double *__restrict__ ap = M + (size_t)lk * d + li;
+    const double *xp = X + lk * 32 + li;
+    constexpr int KU = MCX_POOLED3_KU;
+    for (int s0 = 0; s0 < kmax; s0 += 4 * KU) {
+        double a[KU][4];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int s = (s0 + 4 * u < kmax) ? s0 + 4 * u : kmax - 4;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) a[u][b] = ap[(size_t)s * d + 16 * (b < nt ? b : 0)];
+        }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int s = s0 + 4 * u;
+            if (s < kmax) {
+                const double *xq = xp + s * 32;
+                const double b0 = xq[0], b1 = xq[16];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (b < nt && (!TRI || s < 16 * (b + 1))) {
+                        c[b][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][b], b0, c[b][0], 0, 0, 0);
+                        c[b][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][b], b1, c[b][1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+#ifndef MCX_POOLED3_WAVES
+#define MCX_POOLED3_WAVES 3
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MCX_POOLED3_WAVES, MCX_POOLED3_WAVES)))
+void pooled_mfma3_kernel(EngineDev E, int it0, int it1, const double *__restrict__ g_mu, const double *__restrict__ g_lamT, const double *__restrict__ g_RT)
+{
+    extern __shared__ double X[];                        // the half tile's vector [d4][32]
+    const int pl = threadIdx.x, w = blockIdx.x & 1, tile = blockIdx.x >> 1, d = E.d;
+    const int xc = pl & 31, lane = 32 * w + xc, h = pl >> 5;      // xc: the chain's column of X; lane: its index in the tile (GV / TIDX)
+    const int d4 = (d + 3) & ~3, nt = (d + 15) >> 4, li = pl & 15, lk = pl >> 4;
+    const int kh0 = h ? (d + 1) / 2 : 0, kh1 = h ? d : (d + 1) / 2;
+#define XH(k) X[(size_t)(k) * 32 + xc]
+    double *theta_t = E.theta + (size_t)tile * d * 64;
+    double *cand_t = E.cand + (size_t)tile * d * 64;
+    const bool gauss = (E.tgt.kind == TGT_GAUSS);
+    const bool plain = gauss && !E.tgt.lo && !E.tgt.hi && !E.tgt.pmu;
+    LaneState L;
+    lane_load(E, tile, lane, L);
+    uint32_t erstayed = TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane);
+    mcx_d4 c[4][2];
+    constexpr int CBH = 16;
+    for (int it = it0; it <= it1; ++it) {
+        gen_normals2<MCX_POOLED2_NBL>(L.g, X + xc, 32, h, d, true);
+        if (h == 0) for (int k = d; k < d4; ++k) XH(k) = 0.0;
+        MCX_WAVE_LDS_SYNC();
+        if (it == it1) {
+            double *zk = E.zs + ((size_t)tile * 2 + (it & 1)) * d * 64;
+            for (int k = kh0; k < kh1; ++k) GV(zk, k) = XH(k);
+        }
+        if (E.usesvd) mfma_product_half<false>(g_RT, X, pl, d, d4, nt, c);
+        else mfma_product_half<true>(g_RT, X, pl, d, d4, nt, c);
+        MCX_WAVE_LDS_SYNC();
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (b < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * b + lk + 4 * r;
+                    if (row < d4) { double *o = X + (size_t)row * 32 + li; o[0] = c[b][0][r]; o[16] = c[b][1][r]; }
+                }
+            }
+        }
+        MCX_WAVE_LDS_SYNC();
+        for (int k0 = kh0; k0 < kh1; k0 += CBH) {
+            double th[CBH], tv[CBH];
+#pragma unroll
+            for (int u = 0; u < CBH; ++u) { const int k = (k0 + u < kh1) ? k0 + u : kh1 - 1; th[u] = GV(theta_t, k); tv[u] = XH(k); }
+#pragma unroll
+            for (int u = 0; u < CBH; ++u) {
+                if (k0 + u < kh1) {
+                    const double cnd = th[u] + tv[u];
+                    GV(cand_t, k0 + u) = cnd;
+                    if (gauss) XH(k0 + u) = cnd - g_mu[k0 + u];
+                }
+            }
+        }
+        if (!plain) __threadfence_block();                // bounds / prior / a non-Gaussian target read the candidate's other half through global memory
+        const bool inb = target_inbounds(E.tgt, d, lane, cand_t);
+        const double pri2 = target_prior(E.tgt, d, lane, cand_t);
+        double ss2;
+        if (gauss) {
+            if (h == 0) for (int k = d; k < d4; ++k) XH(k) = 0.0;
+            MCX_WAVE_LDS_SYNC();
+            mfma_product_half<false>(g_lamT, X, pl, d, d4, nt, c);      // y = Lam v
+            double q[4][2];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int o0 = 16 * b + lk;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    double qq = c[b][g][0] * X[(size_t)(o0 < d4 ? o0 : 0) * 32 + 16 * g + li];
+#pragma unroll
+                    for (int r = 1; r < 4; ++r) {
+                        const int o = o0 + 4 * r;
+                        const double t = dfma(c[b][g][r], X[(size_t)(o < d4 ? o : 0) * 32 + 16 * g + li], qq);
+                        qq = (o < d) ? t : qq;
+                    }
+                    q[b][g] = qq;
+                }
+            }
+            MCX_WAVE_LDS_SYNC();
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (b < nt && 16 * b + lk < d) { X[(size_t)(4 * b + lk) * 32 + li] = q[b][0]; X[(size_t)(4 * b + lk) * 32 + 16 + li] = q[b][1]; }
+            }
+            MCX_WAVE_LDS_SYNC();
+            ss2 = XH(0);
+#pragma unroll 4
+            for (int e = 1; e < 4 * nt; ++e) if (16 * (e >> 2) + (e & 3) < d) ss2 = ss2 + XH(e);
+            MCX_WAVE_LDS_SYNC();                          // (the next iteration's normals overwrite these rows)
+        } else {
+            ss2 = target_ss<false>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
+        }
+        bool reject;
+        if (E.method == M_ER) {
+            if (!inb) { L.bnd += 1; reject = true; }
+            else {
+                double u = rng_uniform(L.g);
+                double sscrit = -2.0 * d_log(u) + L.ss1 / L.sigma2 + L.pri1;
+                if (pri2 >= sscrit) { reject = true; erstayed += 1; }
+                else { sscrit = L.sigma2 * (sscrit - pri2); reject = (ss2 >= sscrit); }
+            }
+        }
+        else if (!inb) { L.bnd += 1; reject = true; L.alpha12 = 0.0; }
+        else {
+            L.alpha12 = d_alpha(L.ss1, L.pri1, ss2, pri2, L.sigma2);
+            reject = true;
+            if (L.alpha12 >= 1.0) reject = false;
+            else if (L.alpha12 > 0.0) { double u = rng_uniform(L.g); if (u <= L.alpha12) reject = false; }
+        }
+        if (reject) { L.stayed += 1; L.curcount += 1; }
+        else { L.ss1 = ss2; L.pri1 = pri2; L.chainind += 1; L.curcount = 1; }
+        if (E.updatesigma) {
+            double gm = rng_gamma(L.g, E.gam_shape, 2.0 / (E.N0S02 + L.ss1));
+            L.sigma2 = 1.0 / gm;
+        }
+        const unsigned long long ballot = __ballot(!reject);
+        const int slot = it % E.wcap;
+        if (!reject) {
+            double *hrow = E.hist ? E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64 : nullptr;
+            for (int k0 = kh0; k0 < kh1; k0 += CBH) {
+                double v[CBH];
+#pragma unroll
+                for (int u = 0; u < CBH; ++u) v[u] = GV(cand_t, (k0 + u < kh1) ? k0 + u : kh1 - 1);
+#pragma unroll
+                for (int u = 0; u < CBH; ++u) if (k0 + u < kh1) { GV(theta_t, k0 + u) = v[u]; if (hrow) GV(hrow, k0 + u) = v[u]; }
+            }
+            if (hrow && h == 0) GV(hrow, d) = L.ss1;
+        }
+        if (E.hist) {
+            if (pl == 0) ((uint32_t *)&E.wacc[(size_t)tile * E.wcap + slot])[w] = (uint32_t)ballot;     // this half's 32 bits of the tile's ballot
+            if (E.record_s2 && h == 0) E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = L.sigma2;
+        }
+        if (E.accmask && pl == 0) ((uint32_t *)&E.accmask[(size_t)(it - 1) * E.ntiles + tile])[w] = (uint32_t)ballot;
+    }
+#undef XH
     if (h == 0) {
         lane_store(E, tile, lane, L);
         TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane) = erstayed;

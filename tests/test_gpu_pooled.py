@@ -288,7 +288,7 @@ def test_pooled_scam_wave_layouts(oracle, d, extras, monkeypatch):
     e.close()
 
 
-@pytest.mark.parametrize("waves", [1, 2, 3], ids=["one_wave_per_simd", "two_waves_per_simd", "two_waves_per_tile"])
+@pytest.mark.parametrize("waves", [1, 2, 3, 4], ids=["one_wave_per_simd", "two_waves_per_simd", "two_waves_per_tile", "half_tile_per_wave"])
 @pytest.mark.parametrize("d", [50, 70])
 def test_pooled_am_matrix_core_kernel_sizes(oracle, d, waves, monkeypatch):
     """pooled_mfma_kernel at d = 50 (one pass of four output blocks, the bench's size) and d = 70 (two passes, products
@@ -306,7 +306,9 @@ def test_pooled_am_matrix_core_kernel_sizes(oracle, d, waves, monkeypatch):
     e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
     e.init(); e.run()
     # (waves = 3: pooled_mfma2_kernel, a tile as a workgroup of two waves -- npar 17..64; at 70 the engine falls back to the one-wave kernel)
-    assert e.last_kernel() == {1: "pooled_mfma_kernel<false>", 2: "pooled_mfma_kernel<false, true>", 3: "pooled_mfma2_kernel" if d <= 64 else "pooled_mfma_kernel<false>"}[waves], e.last_kernel()
+    # (waves = 4: pooled_mfma3_kernel, half a tile per wave and no workgroup -- the same range)
+    assert e.last_kernel() == {1: "pooled_mfma_kernel<false>", 2: "pooled_mfma_kernel<false, true>", 3: "pooled_mfma2_kernel" if d <= 64 else "pooled_mfma_kernel<false>",
+                               4: "pooled_mfma3_kernel" if 17 <= d <= 64 else "pooled_mfma_kernel<false>"}[waves], e.last_kernel()
     monkeypatch.setenv("MCMCX_POOLED_SCALAR", "1")
     e2 = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
     e2.init(); e2.run()
@@ -587,22 +589,24 @@ def test_pooled_two_waves_per_tile_matches_restatement(oracle, name, d, N, extra
         pkw = dict(kind="banana", npar=d, par0=np.zeros(d), cmat0=(1.0 / d) * np.eye(d), b=0.1)
     ekw = dict(record_chain=1) if "record" in name else {}
     res = []
-    for waves in ("3", "1"):
+    for waves in ("3", "4", "1"):
         monkeypatch.setenv("MCMCX_POOLED_WAVES", waves)
         e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1, **ekw)
         e.init(); e.run(57); e.run()
-        assert e.last_kernel() == ("pooled_mfma2_kernel" if waves == "3" else "pooled_mfma_kernel<false>"), e.last_kernel()
+        assert e.last_kernel() == {"3": "pooled_mfma2_kernel", "4": "pooled_mfma3_kernel", "1": "pooled_mfma_kernel<false>"}[waves], e.last_kernel()
         res.append(dict(theta=e.theta().copy(), masks=e.accept_masks().copy(), scal=e.scalars().copy(), rng=[e.rng(c) for c in (0, 31, 32, 63, 64, N - 1)],
                         ctr=[e.counters(c) for c in (0, 33, N - 1)], pooled=e.pooled(), tot=e.totals(),
                         chain=[e.chain(c) for c in (0, 35, N - 1)] if ekw else []))
         e.close()
-    a, b = res
-    assert np.array_equal(_bits(a["theta"]), _bits(b["theta"])) and np.array_equal(a["masks"], b["masks"]) and np.array_equal(_bits(a["scal"]), _bits(b["scal"]))
-    assert a["rng"] == b["rng"] and a["ctr"] == b["ctr"] and a["tot"] == b["tot"]
-    np.testing.assert_array_equal(_bits(a["pooled"][3]), _bits(b["pooled"][3]))
-    for x, y in zip(a["chain"], b["chain"]):
-        for u, v in zip(x, y):
-            np.testing.assert_array_equal(_bits(u), _bits(v))
+    b = res[-1]
+    for a in res[:-1]:
+        assert np.array_equal(_bits(a["theta"]), _bits(b["theta"])) and np.array_equal(a["masks"], b["masks"]) and np.array_equal(_bits(a["scal"]), _bits(b["scal"]))
+        assert a["rng"] == b["rng"] and a["ctr"] == b["ctr"] and a["tot"] == b["tot"]
+        np.testing.assert_array_equal(_bits(a["pooled"][3]), _bits(b["pooled"][3]))
+        for x, y in zip(a["chain"], b["chain"]):
+            for u, v in zip(x, y):
+                np.testing.assert_array_equal(_bits(u), _bits(v))
+    a = res[0]
     if "svd" in name:
         return                                             # (the SVD factor's restatement lives in test_pooled_factor_with_condmax; here: the two kernels)
     chains, st, log = _restate_pooled(oracle, ckw, pkw, N)
@@ -659,7 +663,8 @@ def test_pooled_mode_with_response_columns(oracle, name, extra):
 
 @pytest.mark.parametrize("d,N,mfma,condmax", [(6, 150, 0, 0.0), (6, 150, 1, 0.0), (50, 200, 1, 0.0), (6, 150, 0, 1e8), (6, 150, 1, 25.0), (20, 130, 1, 1e8),
                                               (50, 200, 2, 0.0), (20, 130, 2, 1e8),           # mfma = 2: pooled_mfma_kernel<false, true> (two waves per SIMD)
-                                              (50, 200, 3, 0.0), (20, 130, 3, 1e8), (33, 140, 3, 0.0)])   # mfma = 3: pooled_mfma2_kernel (two waves per tile)
+                                              (50, 200, 3, 0.0), (20, 130, 3, 1e8), (33, 140, 3, 0.0),    # mfma = 3: pooled_mfma2_kernel (two waves per tile)
+                                              (50, 200, 4, 0.0), (33, 140, 4, 0.0)])                      # mfma = 4: pooled_mfma3_kernel (half a tile per wave)
 def test_pooled_ram_matches_restatement(oracle, d, N, mfma, condmax, monkeypatch):
     """method = 'ram', pooled = 1: one factor for all chains; every adaptint iterations the chains' rank-one RAM
     statistics sign(a) x x' (MCMC_run_ram.F90:166-172) of that iteration are averaged over all chains and folded into
@@ -678,7 +683,7 @@ def test_pooled_ram_matches_restatement(oracle, d, N, mfma, condmax, monkeypatch
     pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.2), cmat0=cm0, mu=np.zeros(d), lam=A @ A.T + np.eye(d))
     e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
     e.init(); e.run()
-    assert e.last_kernel() == {0: "step_kernel<false, false, true>", 1: "pooled_mfma_kernel<false>", 2: "pooled_mfma_kernel<false, true>", 3: "pooled_mfma2_kernel"}[mfma], e.last_kernel()
+    assert e.last_kernel() == {0: "step_kernel<false, false, true>", 1: "pooled_mfma_kernel<false>", 2: "pooled_mfma_kernel<false, true>", 3: "pooled_mfma2_kernel", 4: "pooled_mfma3_kernel"}[mfma], e.last_kernel()
     plain = oracle.make_cfg(**dict(ckw, doadapt=0, method="dram"))
     prob = oracle.Problem(**pkw)
     chains = [oracle.LiveChain(plain, prob, chain_id=c) for c in range(N)]
