@@ -127,6 +127,12 @@ def cases():
     ynan = np.array(YDATA, dtype=float); ynan[4] = np.nan
     c["e8_nan_target_dr"] = (dict(nsimu=300, adaptint=100, drscale=2.0, updatesigma=0),
                              dict(kind="expdata", npar=2, par0=[10, 0.1], cmat0=[[0.2, 0], [0, 0.001]], sigma2=0.5, nobs=11, xdata=XDATA, ydata=ynan, lo=[0, 0]), 61)
+    # --- npar above 256 (round 5 lifted the engine's limit; the reference allocates any npar, MCMC_init.F90:81-102): AM through four adaptations
+    # whose covariance has fewer rows than parameters (qcov_adjust keeps calculate_R's Cholesky alive), RAM with 45 150-element sweeps
+    d = 260
+    g260 = dict(kind="gauss", npar=d, par0=np.full(d, 0.05), cmat0=(0.3 / d) * np.eye(d), mu=np.linspace(-1, 1, d), lam=corr_gauss(d))
+    c["e9_gauss260_am"] = (dict(nsimu=450, adaptint=100, updatesigma=0), g260, 71)
+    c["e10_gauss260_ram"] = (dict(nsimu=400, method="ram", updatesigma=0), g260, 72)
     from mcmcf90_amd.workloads import problem
     ckw, pkw, _ = problem("c5", 250, adaptint=100)
     c["c5_illcond200_scam"] = (ckw, pkw, 51)

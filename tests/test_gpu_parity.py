@@ -40,6 +40,7 @@ LANE_KERNEL = {
     "e5_gauss17_am_short": "step_kernel_ldsv", "e6_expdata_er_priors": "step_kernel_ldsr", "e7_gauss10_er": "step_kernel_ldsr",
     "e8_nan_target_dr": "step_kernel_dr", "s1_gauss6_scam": "scam_mw_kernel<8>", "s2_gauss6_dram_svd": "step_kernel_ldsv",
     "s3_gauss6_dram_svd_dr": "step_kernel_dr", "s4_expdata_scam_s2": "scam_mw_kernel<8>", "s5_banana20_scam": "scam_mw_kernel<8>",
+    "e9_gauss260_am": "step_kernel<false, false, false>", "e10_gauss260_ram": "step_kernel_ram_wide",       # npar above 256 (round 5), from the real reference
 }
 
 
