@@ -96,6 +96,7 @@ struct mcmcx_engine {
     std::vector<double> pool_R2, pool_iC;             // pooled mode with delayed rejection: R / drscale (packed, or full with condmax > 0) and dpotri(R) (packed)
     double *d_sharedR2 = nullptr, *d_sharediC = nullptr;
     double *d_sharedU = nullptr;                      // [U col-major | pad | U row-major | pad | std]
+    bool scam_replicated = false;                     // pooled SCAM above npar 240 (the tile kernels' LDS vector does not fit): the shared rotation copied to every chain, the per-chain kernels run
     double *d_sharedRT = nullptr;                     // pooled AM on the matrix cores: dense R, M[s*d + o] = R(s,o), zero below the diagonal and in the pad rows
     double *d_sharedR2T = nullptr, *d_sharediCd = nullptr;   // ... with delayed rejection: R2 in the same form, iC dense and symmetric
     double *d_sharedR = nullptr; mcmcx_exchange_t xfn = nullptr; void *xuser = nullptr; double *xbuf = nullptr;
@@ -626,6 +627,10 @@ static size_t shared_u_stride(const mcmcx_engine *h) { return (size_t)((h->d + 3
 static size_t scam_pooled_lds(int d) { return ((size_t)((d + 15) / 16) * (16 + 4) * 64 + 128 + (size_t)((d + 15) / 16) * 16) * sizeof(double); }     // X [16 nt][64], Q [4 nt][64], zb, fl, mu [16 nt]
 static int upload_shared_u(mcmcx_engine *h)
 {
+    if (h->scam_replicated) {                           // every chain's own copy of the one rotation and its scales
+        int rc = dev_bcast(h, h->E.Rf, h->pool_U); if (rc) return rc;
+        return dev_bcast(h, h->E.qstd, h->pool_std);
+    }
     const int d = h->d; const size_t st = shared_u_stride(h);
     std::vector<double> b(2 * st + d, 0.0);
     for (int j = 0; j < d; ++j) for (int i = 0; i < d; ++i) { b[(size_t)j * d + i] = h->pool_U[(size_t)j * d + i]; b[st + (size_t)i * d + j] = h->pool_U[(size_t)j * d + i]; }
@@ -655,7 +660,7 @@ static size_t scam_mw_lds(const mcmcx_engine *h) { return (size_t)(4 * ((h->d + 
 static int scam_tile_waves(const mcmcx_engine *h)
 {
     int nw = 1;
-    while (nw < 8 && (long long)h->ntiles * nw * 2 <= 2048) nw *= 2;
+    while (nw < 8 && (long long)h->ntiles * nw * 2 <= 8192) nw *= 2;                       // (1024 tiles x npar 200: 8.4e6 at two waves per tile, 8.9e6 at four, 9.0e6 at eight -- profiles/r05_d/c5rep_waves.txt)
     { const int v = h->sw.scam_waves; if (v == 1 || v == 2 || v == 4 || v == 8) nw = v; }   // A/B switch for tests
     if (scam_mw_lds(h) > 160 * 1024) nw = 1;                                               // (npar > 1200: the one-wave kernel needs no LDS)
     return nw;
@@ -665,10 +670,10 @@ static const KernelEntry SCAM_TABLE[] = {
     {"scam", "step_kernel_cols<scam>", [](const mcmcx_engine *h) { return fused_cols(h) && !h->pooled; },
      [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_cols, G1, 0, STEP_ARGS, (const double *)h->d_ramscale, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr); }},
     // pooled: 16-row output blocks, min(12, 4*(nt/4)) block waves + 4 chain-group waves; twelve waves of 170 registers for 13..15 blocks
-    {"scam", "scam_pooled12_kernel", [](const mcmcx_engine *h) { return h->pooled && scam_use_12(h); },
+    {"scam", "scam_pooled12_kernel", [](const mcmcx_engine *h) { return h->pooled && !h->scam_replicated && scam_use_12(h); },
      [](mcmcx_engine *h, int it0, int it1) { const size_t st = shared_u_stride(h);
         hipLaunchKernelGGL(scam_pooled12_kernel, dim3(h->ntiles), dim3(768), SCAM_POOLED_ARGS, h->d_sharedU, h->d_sharedU + st, h->d_sharedU + 2 * st); }},
-    {"scam", "scam_pooled_kernel", [](const mcmcx_engine *h) { return h->pooled != 0; },
+    {"scam", "scam_pooled_kernel", [](const mcmcx_engine *h) { return h->pooled && !h->scam_replicated; },
      [](mcmcx_engine *h, int it0, int it1) { const size_t st = shared_u_stride(h); const int nw = 4 + std::min(12, ((h->d + 15) / 16) & ~3);
         hipLaunchKernelGGL(scam_pooled_kernel, dim3(h->ntiles), dim3(64 * nw), SCAM_POOLED_ARGS, h->d_sharedU, h->d_sharedU + st, h->d_sharedU + 2 * st); }},
     // (the sixteen-wave layout whatever npar: every lane fetches the column of its own chain's factor per sub-step, and four
@@ -1700,7 +1705,11 @@ int mcmcx_init(mcmcx_handle h)
     if (!h->pooled && (rc = dev_alloc(h, &E.R, L * P, false))) return rc;          // pooled: one shared factor instead
     if ((rc = dev_alloc(h, &E.basetheta, L * d))) return rc;
     if (h->usesvd && h->pooled && c.method == MCMCX_METHOD_SCAM) {     // pooled SCAM: one rotation for every chain
-        if ((rc = dev_alloc(h, &h->d_sharedU, 2 * shared_u_stride(h) + d, false))) return rc;
+        h->scam_replicated = scam_pooled_lds(d) > 160 * 1024;         // npar > 240: slower, not refused -- scam_kernel / scam_mw_kernel on per-chain copies
+        if (h->scam_replicated) {
+            if ((rc = dev_alloc(h, &E.Rf, L * (size_t)d * d, false))) return rc;
+            if ((rc = dev_alloc(h, &E.qstd, L * d))) return rc;
+        } else if ((rc = dev_alloc(h, &h->d_sharedU, 2 * shared_u_stride(h) + d, false))) return rc;
         h->pool_U = Rfull; h->pool_std = qstd0;
         if ((rc = upload_shared_u(h))) return rc;
     } else if (h->usesvd && h->pooled) {                // pooled AM with the SVD factor: one full matrix for every chain (below)
@@ -1766,7 +1775,6 @@ int mcmcx_init(mcmcx_handle h)
         if ((long long)c.nchains * (h->comm ? h->comm->nranks : 1) < 2) return fail(-8, "pooled mode needs at least 2 chains over all ranks");
         if (phase_cut(h) || (fused_cols(h) && c.method == MCMCX_METHOD_SCAM))
             return fail(-8, "pooled mode needs one of the single-launch device targets (gauss, banana, expdata, expcols; scam: not expcols)");
-        if (c.method == MCMCX_METHOD_SCAM && scam_pooled_lds(d) > 160 * 1024) return fail(-8, "pooled scam: npar > 240 does not fit the 160 KiB of LDS");
         if ((rc = dev_alloc(h, &h->d_sharedR, (size_t)P, false))) return rc;
         HIPCHK(hipMemcpy(h->d_sharedR, Rp.data(), (size_t)P * 8, hipMemcpyHostToDevice));
         E.sharedR = h->d_sharedR;

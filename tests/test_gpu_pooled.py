@@ -236,17 +236,18 @@ def test_pooled_scam_matches_restatement(oracle, kind):
 
 @pytest.mark.slow
 @pytest.mark.parametrize("d,extras", [(40, "s2"), (64, ""), (70, "bounds"), (100, "priors"), (130, ""), (200, "bounds"), pytest.param(215, "", marks=pytest.mark.extended),
-                                      (230, "priors"), pytest.param(200, "sixteen", marks=pytest.mark.extended)])
+                                      (230, "priors"), pytest.param(200, "sixteen", marks=pytest.mark.extended), (250, "replicated")])
 def test_pooled_scam_wave_layouts(oracle, d, extras, monkeypatch):
     """Every split of scam_pooled_kernel's output blocks over its waves: d=40 three leftover blocks and no block wave,
     64 four block waves and nothing left over, 70 / 100 four block waves + one / three leftover blocks, 130 eight + one;
     200 / 215 / 230: scam_pooled12_kernel, twelve block waves with four / eight / twelve fifth slots (the last one on the
     scalar wave, ragged last block), and 200 once more in the sixteen-wave layout; with the sigma2 update, box bounds and
-    Gaussian priors (which make theta' round-trip through global memory)."""
+    Gaussian priors (which make theta' round-trip through global memory).  250 (round 5): above npar 240 the tile's LDS vector does not
+    fit; the engine copies the one rotation to every chain and runs the per-chain kernels on it (slower, not refused) -- the same chains."""
     if extras == "sixteen":
         monkeypatch.setenv("MCMCX_SCAM_POOLED_16", "1")
     from mcmcf90_amd import engine_from_problem
-    N, nsimu, tick = 70, 8, 3
+    N, nsimu, tick = (70, 8, 3) if d <= 240 else (66, 5, 3)
     rng = np.random.default_rng(d)
     A = rng.standard_normal((d, d)) / np.sqrt(d)
     lam = A @ A.T + np.diag(np.linspace(0.5, 3.0, d))
@@ -260,13 +261,13 @@ def test_pooled_scam_wave_layouts(oracle, d, extras, monkeypatch):
         pkw.update(pri_mu=np.zeros(d), pri_sig=np.where(np.arange(d) % 3 == 0, 0.0, 0.5))
     e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
     e.init(); e.run()
-    assert e.last_kernel() == ("scam_pooled12_kernel" if (d >= 193 and extras != "sixteen") else "scam_pooled_kernel"), e.last_kernel()
+    assert e.last_kernel() == ("scam_mw_kernel<8>" if d > 240 else "scam_pooled12_kernel" if (d >= 193 and extras != "sixteen") else "scam_pooled_kernel"), e.last_kernel()
     cfg = oracle.make_cfg(**dict(ckw, doadapt=0))
     prob = oracle.Problem(**pkw)
     chains = [oracle.LiveChain(cfg, prob, chain_id=c) for c in range(N)]
     state = {}
     par0, cmat0 = np.asarray(pkw["par0"], float), np.asarray(pkw["cmat0"], float)
-    for t in (3, 6, nsimu):
+    for t in [t for t in (3, 6) if t < nsimu] + [nsimu]:
         for ch in chains:
             ch.run(t)
         if t < nsimu:
@@ -278,7 +279,7 @@ def test_pooled_scam_wave_layouts(oracle, d, extras, monkeypatch):
                 ch.set_R(state["U"]); ch.set_qcovstd(state["std"])
     theta = np.array([ch.theta for ch in chains])
     np.testing.assert_array_equal(_bits(e.theta()), _bits(theta))
-    for c in (0, 63, 64, 69):
+    for c in (0, 63, 64, N - 1):
         np.testing.assert_array_equal(e.accepted(c), chains[c].accepted)
     if extras == "bounds":
         assert sum(e.counters(c)["bndstayed"] for c in range(N)) > 0
