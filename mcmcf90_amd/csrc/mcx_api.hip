@@ -40,7 +40,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 struct mcx_switches {
     int pooled_mfma_dr_min = -1, pooled_scalar = -1, dr_big = -1, dr_general = -1, scam_pooled_16 = -1, scam_fast_lanes = -1, scam_waves = -1,
         svd_lane = -1, cov_td = -1, cov_batch_rows = -1, svd_reg = -1, svd_stream = -1, svd_stream32 = -1, svd_stream_b = -1, ram_wide = -1, pooled_waves = -1,
-        cols_phased = -1;
+        cols_phased = -1, host_mapped = -1, host_fuse = -1, host_spin = -1;
     static int get(const char *name) { const char *e = getenv(name); return e ? atoi(e) : -1; }
     void read()
     {
@@ -48,7 +48,7 @@ struct mcx_switches {
         dr_general = get("MCMCX_DR_GENERAL"); scam_pooled_16 = get("MCMCX_SCAM_POOLED_16"); scam_fast_lanes = get("MCMCX_SCAM_FAST_LANES");
         scam_waves = get("MCMCX_SCAM_WAVES"); svd_lane = get("MCMCX_SVD_LANE"); cov_td = get("MCMCX_COV_TD"); cov_batch_rows = get("MCMCX_COV_BATCH_ROWS");
         svd_reg = get("MCMCX_SVD_REG"); svd_stream = get("MCMCX_SVD_STREAM"); svd_stream32 = get("MCMCX_SVD_STREAM32"); svd_stream_b = get("MCMCX_SVD_STREAM_B"); ram_wide = get("MCMCX_RAM_WIDE"); pooled_waves = get("MCMCX_POOLED_WAVES");
-        cols_phased = get("MCMCX_COLS_PHASED");
+        cols_phased = get("MCMCX_COLS_PHASED"); host_mapped = get("MCMCX_HOST_MAPPED"); host_fuse = get("MCMCX_HOST_FUSE"); host_spin = get("MCMCX_HOST_SPIN");
     }
 };
 struct mcmcx_engine {
@@ -96,6 +96,9 @@ struct mcmcx_engine {
     std::vector<double> pool_R2, pool_iC;             // pooled mode with delayed rejection: R / drscale (packed, or full with condmax > 0) and dpotri(R) (packed)
     double *d_sharedR2 = nullptr, *d_sharediC = nullptr;
     double *d_sharedU = nullptr;                      // [U col-major | pad | U row-major | pad | std]
+    bool p0_done = false;                             // host callbacks: the next iteration's proposal already ran in the previous iteration's last launch
+    bool host_mapped = false, cs_mapped = false;     // host callbacks with few chains: the exchange vectors live in page-locked host memory the device reads and writes directly (no copies between the phases)
+    std::vector<void *> hallocs;
     bool scam_replicated = false;                     // pooled SCAM above npar 240 (the tile kernels' LDS vector does not fit): the shared rotation copied to every chain, the per-chain kernels run
     double *d_sharedRT = nullptr;                     // pooled AM on the matrix cores: dense R, M[s*d + o] = R(s,o), zero below the diagonal and in the pad rows
     double *d_sharedR2T = nullptr, *d_sharediCd = nullptr;   // ... with delayed rejection: R2 in the same form, iC dense and symmetric
@@ -137,6 +140,20 @@ static int dev_alloc(mcmcx_engine *h, T **p, size_t n, bool zero = true)
     if (e != hipSuccess) return fail(-101, "hipMalloc of " + std::to_string(bytes) + " bytes: " + hipGetErrorString(e));
     if (zero) { e = hipMemsetAsync(q, 0, bytes, h->stream); if (e != hipSuccess) return fail(-101, hipGetErrorString(e)); }
     h->allocs.push_back(q);
+    *p = (T *)q;
+    return 0;
+}
+
+// page-locked host memory mapped into the device's address space (the same pointer on both sides)
+template <typename T>
+static int host_alloc(mcmcx_engine *h, T **p, size_t n)
+{
+    void *q = nullptr;
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    hipError_t e = hipHostMalloc(&q, bytes, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e != hipSuccess) return fail(-101, "hipHostMalloc of " + std::to_string(bytes) + " bytes: " + hipGetErrorString(e));
+    memset(q, 0, bytes);
+    h->hallocs.push_back(q);
     *p = (T *)q;
     return 0;
 }
@@ -1202,14 +1219,23 @@ static int host_eval(mcmcx_engine *h, const double *dev_src, int stride_k, bool 
     }
     const size_t L = (size_t)T * 64;
     const int ny = h->ny, nhe = NHE - 1 + ny;
-    if (h->h_cand.resize(L * stride_k) || h->h_ev.resize(L * nhe) || (use_stage2_flag && h->h_hx.resize(L * NHX)))
+    const bool src_mapped = h->host_mapped && (dev_src == h->E.cand || h->cs_mapped);
+    const bool mapped = h->host_mapped;                  // flags and results in place
+    if ((!src_mapped && h->h_cand.resize(L * stride_k)) || (!mapped && (h->h_ev.resize(L * nhe) || (use_stage2_flag && h->h_hx.resize(L * NHX)))))
         return fail(-100, "host callbacks: no page-locked memory for the candidates");
     std::vector<double> ssc(ny, 0.0);
-    HIPCHK(hipMemcpyAsync(h->h_cand.data(), dev_src, h->h_cand.size() * 8, hipMemcpyDeviceToHost, h->stream));
-    if (use_stage2_flag) HIPCHK(hipMemcpyAsync(h->h_hx.data(), h->E.hx, h->h_hx.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    if (!src_mapped) HIPCHK(hipMemcpyAsync(h->h_cand.data(), dev_src, L * stride_k * 8, hipMemcpyDeviceToHost, h->stream));
+    if (use_stage2_flag && !mapped) HIPCHK(hipMemcpyAsync(h->h_hx.data(), h->E.hx, h->h_hx.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    if (h->host_mapped && h->sw.host_spin > 0) {         // MCMCX_HOST_SPIN=1: poll the stream instead of the blocking wait (measured: no difference at one chain, profiles/r05_d/c1_plumbing.txt)
+        hipError_t q;
+        while ((q = hipStreamQuery(h->stream)) == hipErrorNotReady) {}
+        if (q != hipSuccess) return fail(-10, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+    } else
     HIPCHK(hipStreamSynchronize(h->stream));             // (also: the previous stage's results have left h_ev)
-    memset(h->h_ev.data(), 0, h->h_ev.size() * sizeof(double));
-    auto &hx = h->h_hx;
+    const double *h_cand = src_mapped ? dev_src : h->h_cand.data();
+    const double *hx = mapped ? h->E.hx : h->h_hx.data();
+    double *h_ev = mapped ? h->E.hev : h->h_ev.data();
+    memset(h_ev, 0, L * nhe * sizeof(double));
     std::vector<double> th(d);
     if (h->h_ss_batch && !(what == 2 && h->h_ss_er)) {
         // Batched form (opt-in): bounds and prior per chain on this thread, in chain order; then ONE call of the user's
@@ -1218,14 +1244,14 @@ static int host_eval(mcmcx_engine *h, const double *dev_src, int stride_k, bool 
         for (int c = 0; c < h->cfg.nchains; ++c) {
             const int t = c / 64, l = c % 64;
             if (use_stage2_flag && hx[((size_t)t * NHX + HX_STAGE2) * 64 + l] == 0.0) continue;
-            for (int k = 0; k < d; ++k) th[k] = h->h_cand[((size_t)t * stride_k + k) * 64 + l];
+            for (int k = 0; k < d; ++k) th[k] = h_cand[((size_t)t * stride_k + k) * 64 + l];
             int inb = 1; double pri = 0.0;
             if (what != 2) {
                 inb = h->h_cb ? h->h_cb(th.data(), d, h->h_user) : 1;
                 if (inb) pri = h->h_pri ? h->h_pri(th.data(), d, h->h_user) : 0.0;
             }
-            h->h_ev[((size_t)t * nhe + HE_INB) * 64 + l] = inb ? 1.0 : 0.0;
-            h->h_ev[((size_t)t * nhe + HE_PRI) * 64 + l] = pri;
+            h_ev[((size_t)t * nhe + HE_INB) * 64 + l] = inb ? 1.0 : 0.0;
+            h_ev[((size_t)t * nhe + HE_PRI) * 64 + l] = pri;
             if ((what == 0 && inb) || what == 2) { h->h_bidx.push_back(c); h->h_bth.insert(h->h_bth.end(), th.begin(), th.end()); }
         }
         const int n = (int)h->h_bidx.size();
@@ -1244,15 +1270,15 @@ static int host_eval(mcmcx_engine *h, const double *dev_src, int stride_k, bool 
         }
         for (int i = 0; i < n; ++i) {
             const int c = h->h_bidx[i], t = c / 64, l = c % 64;
-            for (int j = 0; j < ny; ++j) h->h_ev[((size_t)t * nhe + HE_SS + j) * 64 + l] = h->h_bss[(size_t)i * ny + j];
+            for (int j = 0; j < ny; ++j) h_ev[((size_t)t * nhe + HE_SS + j) * 64 + l] = h->h_bss[(size_t)i * ny + j];
         }
-        HIPCHK(hipMemcpyAsync(h->E.hev, h->h_ev.data(), h->h_ev.size() * 8, hipMemcpyHostToDevice, h->stream));
+        if (!mapped) HIPCHK(hipMemcpyAsync(h->E.hev, h->h_ev.data(), h->h_ev.size() * 8, hipMemcpyHostToDevice, h->stream));
         return 0;
     }
     for (int c = 0; c < h->cfg.nchains; ++c) {
         const int t = c / 64, l = c % 64;
         if (use_stage2_flag && hx[((size_t)t * NHX + HX_STAGE2) * 64 + l] == 0.0) continue;
-        for (int k = 0; k < d; ++k) th[k] = h->h_cand[((size_t)t * stride_k + k) * 64 + l];
+        for (int k = 0; k < d; ++k) th[k] = h_cand[((size_t)t * stride_k + k) * 64 + l];
         int inb = 1;
         double pri = 0.0;
         std::fill(ssc.begin(), ssc.end(), 0.0);
@@ -1267,48 +1293,57 @@ static int host_eval(mcmcx_engine *h, const double *dev_src, int stride_k, bool 
                 if (what == 0) h->h_ss(th.data(), d, ny, ssc.data(), h->h_user);
             }
         }
-        h->h_ev[((size_t)t * nhe + HE_INB) * 64 + l] = inb ? 1.0 : 0.0;
-        h->h_ev[((size_t)t * nhe + HE_PRI) * 64 + l] = pri;
-        for (int j = 0; j < ny; ++j) h->h_ev[((size_t)t * nhe + HE_SS + j) * 64 + l] = ssc[j];
+        h_ev[((size_t)t * nhe + HE_INB) * 64 + l] = inb ? 1.0 : 0.0;
+        h_ev[((size_t)t * nhe + HE_PRI) * 64 + l] = pri;
+        for (int j = 0; j < ny; ++j) h_ev[((size_t)t * nhe + HE_SS + j) * 64 + l] = ssc[j];
     }
-    HIPCHK(hipMemcpyAsync(h->E.hev, h->h_ev.data(), h->h_ev.size() * 8, hipMemcpyHostToDevice, h->stream));
+    if (!mapped) HIPCHK(hipMemcpyAsync(h->E.hev, h->h_ev.data(), h->h_ev.size() * 8, hipMemcpyHostToDevice, h->stream));
     return 0;
 }
 
-static int host_iteration(mcmcx_engine *h, int it)
+// fuse_next: iteration it + 1 follows without a tick in between -- its proposal (phase 0; SCAM: component 0's phase 5) rides in this iteration's
+// last launch, and h->p0_done tells the next call so (MCMCX_HOST_FUSE=0: one launch per phase, the A/B form the tests compare with)
+static int host_iteration(mcmcx_engine *h, int it, bool fuse_next)
 {
     const dim3 g(h->ntiles), b(64);
-    const double *rs = h->d_ramscale + it;
+    const double *rs = h->d_ramscale + it, *rs0 = h->d_ramscale;
     const size_t lds = lds_step(h);
+    const bool fuse = h->sw.host_fuse != 0;
+    fuse_next = fuse_next && fuse;
+    const bool p0_done = h->p0_done;
+    h->p0_done = false;
     if (h->cfg.method == MCMCX_METHOD_SCAM) {           // MCMC_run_scam: npar componentwise proposals, each evaluated by the host
         for (int j = 0; j < h->d; ++j) {
-            hipLaunchKernelGGL((host_phase_kernel<5>), g, b, 0, h->stream, h->E, it, rs, j);
-            HIPCHK(hipGetLastError());
+            if (!(j == 0 ? p0_done : fuse)) { hipLaunchKernelGGL((host_phase_kernel<5>), g, b, 0, h->stream, h->E, it, rs, j); HIPCHK(hipGetLastError()); }
             int rc = host_eval(h, h->E.cand, h->d, false); if (rc) return rc;
-            hipLaunchKernelGGL((host_phase_kernel<6>), g, b, 0, h->stream, h->E, it, rs, j);
+            if (!fuse) hipLaunchKernelGGL((host_phase_kernel<6>), g, b, 0, h->stream, h->E, it, rs, j);
+            else if (j + 1 < h->d) hipLaunchKernelGGL((host_phase_seq_kernel<6, 5, -1>), g, b, 0, h->stream, h->E, it, j, it, j + 1, 0, 0, rs0);
+            else if (fuse_next) { hipLaunchKernelGGL((host_phase_seq_kernel<6, 7, 5>), g, b, 0, h->stream, h->E, it, j, it, 0, it + 1, 0, rs0); h->p0_done = true; }
+            else hipLaunchKernelGGL((host_phase_seq_kernel<6, 7, -1>), g, b, 0, h->stream, h->E, it, j, it, 0, 0, 0, rs0);
             HIPCHK(hipGetLastError());
         }
-        hipLaunchKernelGGL((host_phase_kernel<7>), g, b, 0, h->stream, h->E, it, rs, 0);
-        HIPCHK(hipGetLastError());
+        if (!fuse) { hipLaunchKernelGGL((host_phase_kernel<7>), g, b, 0, h->stream, h->E, it, rs, 0); HIPCHK(hipGetLastError()); }
         return 0;
     }
-    hipLaunchKernelGGL((host_phase_kernel<0>), g, b, 0, h->stream, h->E, it, rs, 0);
-    HIPCHK(hipGetLastError());
+    if (!p0_done) { hipLaunchKernelGGL((host_phase_kernel<0>), g, b, 0, h->stream, h->E, it, rs, 0); HIPCHK(hipGetLastError()); }
     if (h->cfg.method == MCMCX_METHOD_ER) {             // MCMC_run_er: the threshold is drawn between priorfun and ssfunction_er
         int rc = host_eval(h, h->E.cand, h->d, false, 1); if (rc) return rc;
         hipLaunchKernelGGL((host_phase_kernel<3>), g, b, 0, h->stream, h->E, it, rs, 0);
         HIPCHK(hipGetLastError());
         rc = host_eval(h, h->E.cand, h->d, true, 2); if (rc) return rc;
-        hipLaunchKernelGGL((host_phase_kernel<4>), g, b, 0, h->stream, h->E, it, rs, 0);
+        if (fuse_next) { hipLaunchKernelGGL((host_phase_seq_kernel<4, 0, -1>), g, b, 0, h->stream, h->E, it, 0, it + 1, 0, 0, 0, rs0); h->p0_done = true; }
+        else hipLaunchKernelGGL((host_phase_kernel<4>), g, b, 0, h->stream, h->E, it, rs, 0);
         HIPCHK(hipGetLastError());
         return 0;
     }
     int rc = host_eval(h, h->E.cand, h->d, false); if (rc) return rc;
-    hipLaunchKernelGGL((host_phase_kernel<1>), g, b, 0, h->stream, h->E, it, rs, 0);
+    if (fuse_next && !h->dodr) { hipLaunchKernelGGL((host_phase_seq_kernel<1, 0, -1>), g, b, 0, h->stream, h->E, it, 0, it + 1, 0, 0, 0, rs0); h->p0_done = true; }
+    else hipLaunchKernelGGL((host_phase_kernel<1>), g, b, 0, h->stream, h->E, it, rs, 0);
     HIPCHK(hipGetLastError());
     if (h->dodr) {
         rc = host_eval(h, h->E.cs, 2 * h->d, true); if (rc) return rc;
-        hipLaunchKernelGGL((host_phase_kernel<2>), g, b, lds, h->stream, h->E, it, rs, 0);
+        if (fuse_next) { hipLaunchKernelGGL((host_phase_seq_kernel<2, 0, -1>), g, b, lds, h->stream, h->E, it, 0, it + 1, 0, 0, 0, rs0); h->p0_done = true; }
+        else hipLaunchKernelGGL((host_phase_kernel<2>), g, b, lds, h->stream, h->E, it, rs, 0);
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -1457,6 +1492,7 @@ int mcmcx_destroy(mcmcx_handle h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &p : h->pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (void *p : h->allocs) (void)hipFree(p);
+    for (void *p : h->hallocs) (void)hipHostFree(p);
     h->h_cand.release(); h->h_ev.release(); h->h_hx.release();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     if (h->mod) (void)hipModuleUnload(h->mod);
@@ -1693,9 +1729,13 @@ int mcmcx_init(mcmcx_handle h)
     // state
     const size_t L = (size_t)T * 64;
     if ((rc = dev_alloc(h, &E.theta, L * d))) return rc;
-    if ((rc = dev_alloc(h, &E.cand, L * d))) return rc;
+    // the user's functions on the host and at most sixteen tiles: candidate, results and flags in mapped host memory -- a phase kernel's
+    // stores ARE the hand-over, the host's results are read by the next one in place (MCMCX_HOST_MAPPED=0: device buffers and copies)
+    h->host_mapped = h->tkind == TGT_HOST && T <= 16 && h->sw.host_mapped != 0;
+    h->cs_mapped = h->host_mapped && (c.method == MCMCX_METHOD_DRAM || c.method == MCMCX_METHOD_ER);     // (RAM / SCAM use cs as sweep scratch)
+    if ((rc = h->host_mapped ? host_alloc(h, &E.cand, L * d) : dev_alloc(h, &E.cand, L * d))) return rc;
     if ((rc = dev_alloc(h, &E.zs, L * 2 * d))) return rc;
-    if ((rc = dev_alloc(h, &E.cs, L * 2 * d))) return rc;
+    if ((rc = h->cs_mapped ? host_alloc(h, &E.cs, L * 2 * d) : dev_alloc(h, &E.cs, L * 2 * d))) return rc;
     E.xscr = nullptr;
     if (((h->pooled && h->dodr) || d > 320) && (rc = dev_alloc(h, &E.xscr, L * 2 * d))) return rc;      // step_kernel_pooled_dr_big's quadratic-form vectors; npar > 320: adapt_post_kernel's work vector
     if ((rc = dev_alloc(h, &E.scal, L * NSCAL))) return rc;
@@ -1787,7 +1827,7 @@ int mcmcx_init(mcmcx_handle h)
     }
     E.hev = E.hx = nullptr;
     if (phased(h)) {
-        if ((rc = dev_alloc(h, &E.hev, L * (NHE - 1 + ny)))) return rc;
+        if ((rc = h->host_mapped ? host_alloc(h, &E.hev, L * (NHE - 1 + ny)) : dev_alloc(h, &E.hev, L * (NHE - 1 + ny)))) return rc;
         if (ny > 1) {
             if ((rc = dev_alloc(h, &E.ssv, L * ny))) return rc;
             if ((rc = dev_alloc(h, &E.s2v, L * ny))) return rc;
@@ -1797,7 +1837,7 @@ int mcmcx_init(mcmcx_handle h)
             for (int j = 0; j < ny; ++j) gs[j] = c.N0 / 2.0 + (double)h->nobsv[j] / 2.0;
             if ((rc = dev_upload(h, &E.gshapev, gs))) return rc;
         }
-        if ((rc = dev_alloc(h, &E.hx, L * NHX))) return rc;
+        if ((rc = h->host_mapped ? host_alloc(h, &E.hx, L * NHX) : dev_alloc(h, &E.hx, L * NHX))) return rc;
     }
     E.accmask = nullptr;
     if (c.record_accept && (rc = dev_alloc(h, &E.accmask, (size_t)c.nsimu * T))) return rc;
@@ -1978,7 +2018,7 @@ static int run_impl(mcmcx_handle h, int32_t upto)
             if (mode != 0 || ramtick || end == upto || end - it + 1 >= maxseg) break;
         }
         if (phase_cut(h)) {
-            for (int i2 = it; i2 <= end; ++i2) { int rc = host_iteration(h, i2); if (rc) return rc; }
+            for (int i2 = it; i2 <= end; ++i2) { int rc = host_iteration(h, i2, i2 < end); if (rc) return rc; }
         } else {
             hipEvent_t e0 = nullptr, e1 = nullptr;
             hipError_t er = hipEventCreate(&e0);

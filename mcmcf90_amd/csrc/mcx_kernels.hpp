@@ -2930,6 +2930,19 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
     host_phase_body<PHASE>(E, blockIdx.x, threadIdx.x, it, ramscale, aux, X);
 }
 
+// Two (three) phases that no evaluation separates, in one launch: the last phase of an iteration and the first of the next one (the proposal),
+// a SCAM sub-step's decision and the next component's proposal.  With the user's functions on the host an iteration of few chains is launch and
+// wake-up latency, nothing else -- one launch per evaluation instead of two.  The phases hand over through the chain's own state exactly as
+// separate launches do (every element written and read back by the same lane: see step_kernel_cols).  PB / PC < 0: none.
+template <int PA, int PB, int PC>
+__global__ __launch_bounds__(64) void host_phase_seq_kernel(EngineDev E, int itA, int auxA, int itB, int auxB, int itC, int auxC, const double *__restrict__ ramscale)
+{
+    extern __shared__ double X[];
+    host_phase_body<PA>(E, blockIdx.x, threadIdx.x, itA, ramscale + itA, auxA, X);
+    if constexpr (PB >= 0) host_phase_body<PB>(E, blockIdx.x, threadIdx.x, itB, ramscale + itB, auxB, X);
+    if constexpr (PC >= 0) host_phase_body<PC>(E, blockIdx.x, threadIdx.x, itC, ramscale + itC, auxC, X);
+}
+
 // ---------------------------------------------------------------- nycol > 1 in ONE launch (step_kernel_cols)
 // Iterations it0..it1 of MCMC_run / MCMC_run_ram / MCMC_run_er / MCMC_run_scam for a target the DEVICE evaluates between the phases
 // of an iteration (the response-column target `expcols`: nycol sums of squares per point, one sigma2 per column, sums over the

@@ -27,7 +27,15 @@ def _kw(z):
 
 @pytest.mark.parametrize("name,nsimu", [("c1_shipped_nml", 1000), ("c3_banana20_dram", 700), ("c4_gauss50_ram", 400),
                                         ("c2_gauss10_am", 450)])
-def test_host_callbacks_equal_device_target(oracle, name, nsimu):
+@pytest.mark.parametrize("plumbing", ["fused_mapped", "phase_launches_and_copies"])
+def test_host_callbacks_equal_device_target(oracle, name, nsimu, plumbing, monkeypatch):
+    """The user's ssfunction / priorfun / checkbounds on the host (external_inc.h:4-33): the iteration cut where the reference calls them.
+    plumbing (round 5): with few chains an iteration is launch and wake-up latency, so by default the exchange vectors live in mapped host
+    memory (no copies) and an iteration's last phase shares its launch with the next iteration's proposal; MCMCX_HOST_MAPPED=0 /
+    MCMCX_HOST_FUSE=0 is the form of rounds 1-4 (device buffers, one launch per phase).  Both against the oracle bit for bit, the run cut in
+    two calls (the proposal that rode ahead must not be lost or repeated across mcmcx_run calls)."""
+    if plumbing != "fused_mapped":
+        monkeypatch.setenv("MCMCX_HOST_MAPPED", "0"); monkeypatch.setenv("MCMCX_HOST_FUSE", "0")
     from mcmcf90_amd import Engine, make_config
     z, cfg, prob = load(name, oracle)
     ckw, pkw = _kw(z)
@@ -55,7 +63,7 @@ def test_host_callbacks_equal_device_target(oracle, name, nsimu):
     e.setpar0(pkw["par0"]); e.setcmat0(np.asarray(pkw["cmat0"], dtype=float).reshape(npar, npar))
     e.setsigma2nobs(float(pkw.get("sigma2", 1.0)), int(pkw.get("nobs", 1)))
     e.set_target_host(ssfun, priorfun, checkbounds)
-    e.init(); e.run()
+    e.init(); e.run(137); e.run(138); e.run()
     for c in range(nch):
         o = oracle.run_chain(cfg, prob, chain_id=5 + c)
         ch, ss, s2 = e.chain(c)
