@@ -1068,7 +1068,7 @@ if (MIXED) {
                         d_rotg(GV(seg, 0), xi, rr, c, sn);
                         GV(seg, 0) = rr;
                         if (lc && i < NLC) { lc[(2 * i) * 64 + lane] = c; lc[(2 * i + 1) * 64 + lane] = sn; }
-                        else { GV(cs_t, 2 * i) = c; GV(cs_t, 2 * i + 1) = sn; }
+                        else if (J0 + nw < d) { GV(cs_t, 2 * i) = c; GV(cs_t, 2 * i + 1) = sn; }      // (the last panel's rotations have no later panel to serve)
 #pragma unroll
                         for (int u = 0; u < RWT; ++u) {
                             const bool off = (u > ui) && (u < nw);
