@@ -40,7 +40,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 struct mcx_switches {
     int pooled_mfma_dr_min = -1, pooled_scalar = -1, dr_big = -1, dr_general = -1, scam_pooled_16 = -1, scam_fast_lanes = -1, scam_waves = -1,
         svd_lane = -1, cov_td = -1, cov_batch_rows = -1, svd_reg = -1, svd_stream = -1, svd_stream32 = -1, svd_stream_b = -1, ram_wide = -1, pooled_waves = -1,
-        cols_phased = -1, host_mapped = -1, host_fuse = -1, host_spin = -1;
+        cols_phased = -1, host_mapped = -1, host_fuse = -1, host_spin = -1, svd_shared_rot = -1;
     static int get(const char *name) { const char *e = getenv(name); return e ? atoi(e) : -1; }
     void read()
     {
@@ -48,7 +48,7 @@ struct mcx_switches {
         dr_general = get("MCMCX_DR_GENERAL"); scam_pooled_16 = get("MCMCX_SCAM_POOLED_16"); scam_fast_lanes = get("MCMCX_SCAM_FAST_LANES");
         scam_waves = get("MCMCX_SCAM_WAVES"); svd_lane = get("MCMCX_SVD_LANE"); cov_td = get("MCMCX_COV_TD"); cov_batch_rows = get("MCMCX_COV_BATCH_ROWS");
         svd_reg = get("MCMCX_SVD_REG"); svd_stream = get("MCMCX_SVD_STREAM"); svd_stream32 = get("MCMCX_SVD_STREAM32"); svd_stream_b = get("MCMCX_SVD_STREAM_B"); ram_wide = get("MCMCX_RAM_WIDE"); pooled_waves = get("MCMCX_POOLED_WAVES");
-        cols_phased = get("MCMCX_COLS_PHASED"); host_mapped = get("MCMCX_HOST_MAPPED"); host_fuse = get("MCMCX_HOST_FUSE"); host_spin = get("MCMCX_HOST_SPIN");
+        cols_phased = get("MCMCX_COLS_PHASED"); host_mapped = get("MCMCX_HOST_MAPPED"); host_fuse = get("MCMCX_HOST_FUSE"); host_spin = get("MCMCX_HOST_SPIN"); svd_shared_rot = get("MCMCX_SVD_SHARED_ROT");
     }
 };
 struct mcmcx_engine {
@@ -805,6 +805,11 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
         if (svd_reg && svd_stream && svd_s32) {          // ... all lanes on pairs (npar <= 200), the ring's slots handed over in place
             const int RLs = h->d <= 64 ? 8 : h->d <= 128 ? 16 : 25;
             const size_t lss = (size_t)33 * (8 * RLs + 2) * sizeof(double);
+            if (h->sw.svd_shared_rot > 0) {               // MCMCX_SVD_SHARED_ROT=1: the scalar tail of a pair once per pair -- bit-equal, measured 31 % SLOWER (a step is the latency of that tail, not its issue slots): tests only
+                if (h->d <= 64) hipLaunchKernelGGL(svd_sweep_stream32s_kernel<8>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
+                else if (h->d <= 128) hipLaunchKernelGGL(svd_sweep_stream32s_kernel<16>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
+                else hipLaunchKernelGGL(svd_sweep_stream32s_kernel<25>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
+            } else
             if (h->d <= 64) hipLaunchKernelGGL(svd_sweep_stream32_kernel<8>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
             else if (h->d <= 128) hipLaunchKernelGGL(svd_sweep_stream32_kernel<16>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
             else hipLaunchKernelGGL(svd_sweep_stream32_kernel<25>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
