@@ -436,6 +436,66 @@ def _restate_pooled(oracle, ckw, pkw, N, nranks=1):
     return chains, st, log
 
 
+def _draw_pooled(seed):
+    """A random pooled configuration: AM / delayed rejection / early rejection; burn-in scaling, greedy, AP window, adaptend, initcmatn; sigma2
+    update, bounds, priors; Gaussian and banana targets; npar 2..64; ragged tiles (tools/pooled_restate_fuzz.py runs thousands of these)."""
+    r = np.random.default_rng(91000 + seed)
+    d = int(r.choice([2, 3, 5, 8, 13, 16, 17, 20, 24, 31, 33, 48, 50, 64]))
+    N = int(r.choice([66, 70, 130, 200]))
+    nsimu = int(r.integers(150, 330))
+    ckw = dict(nsimu=nsimu, adaptint=int(r.choice([40, 50, 100])), updatesigma=int(r.random() < 0.3))
+    mode = r.choice(["am", "dr", "er"], p=[0.5, 0.3, 0.2])
+    if mode == "dr": ckw["drscale"] = float(r.choice([1.5, 2.0, 3.0]))
+    if mode == "er": ckw["method"] = "er"
+    if r.random() < 0.4:
+        ckw.update(doburnin=1, burnintime=int(r.integers(60, 200)), badaptint=int(r.choice([25, 50])), scalelimit=float(r.choice([0.05, 0.3, 0.45])), scalefactor=2.5)
+        if r.random() < 0.4: ckw.update(greedy=1, initcmatn=7)
+    if r.random() < 0.2: ckw["adapthist"] = int(r.choice([30, 60]))
+    if r.random() < 0.2: ckw["adaptend"] = int(r.integers(100, nsimu))
+    c0 = float(r.choice([1e-4, 0.05, 0.3, 2.0, 40.0])) / d
+    kind = "banana" if (mode != "er" and r.random() < 0.3) else "gauss"
+    if kind == "gauss":
+        Aa = r.standard_normal((d, d)) / np.sqrt(d)
+        pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.2), cmat0=c0 * np.eye(d), mu=np.linspace(-1, 1, d), lam=Aa @ Aa.T + np.eye(d))
+    else:
+        pkw = dict(kind="banana", npar=d, par0=np.zeros(d), cmat0=c0 * np.eye(d), b=0.1)
+    if r.random() < 0.3: pkw.update(lo=np.full(d, -2.0), hi=np.full(d, 2.0))
+    if r.random() < 0.3: pkw.update(pri_mu=np.zeros(d), pri_sig=np.where(np.arange(d) % 3 == 0, 0.0, 1.5))
+    if ckw["updatesigma"]: pkw.update(sigma2=0.8, nobs=25)
+    return ckw, pkw, N, int(r.integers(20, nsimu))
+
+
+def _check_pooled_against_restatement(oracle, seed):
+    from mcmcf90_amd import engine_from_problem
+    ckw, pkw, N, cut = _draw_pooled(seed)
+    e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
+    e.init(); e.run(cut); e.run()
+    kernel = e.last_kernel()
+    chains, st, log = _restate_pooled(oracle, ckw, pkw, N)
+    try:
+        theta = np.array([ch.theta for ch in chains])
+        np.testing.assert_array_equal(_bits(e.theta()), _bits(theta), err_msg=str((ckw, log)))
+        for c in (0, 63, 64, N - 1):
+            np.testing.assert_array_equal(e.accepted(c), chains[c].accepted, err_msg=str(ckw))
+        cm, mean, W, R = e.pooled()
+        assert W == st["W"], ckw
+        np.testing.assert_array_equal(_bits(np.triu(R)), _bits(np.triu(st["R"])), err_msg=str(ckw))
+        np.testing.assert_array_equal(_bits(mean), _bits(np.array(st["mean"])), err_msg=str(ckw))
+        assert e.totals()["stayed"] == sum(ch.stayed for ch in chains), ckw
+    finally:
+        for ch in chains:
+            ch.close()
+        e.close()
+    return kernel
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_pooled_configuration_matches_restatement(oracle, seed):
+    """Pooled mode has no reference (the reference has one chain): its parity is the tick-by-tick restatement on single-chain oracles.  Beyond
+    the fixed cases of this file: random configurations (round 5; 3400 more through tools/pooled_restate_fuzz.py, profiles/r05_e)."""
+    _check_pooled_against_restatement(oracle, seed)
+
+
 @pytest.mark.parametrize("name,extra,c0", [
     ("scale_up", dict(doburnin=1, burnintime=260, badaptint=50, scalelimit=0.3), 1e-4),       # nearly everything accepted
     ("scale_down", dict(doburnin=1, burnintime=260, badaptint=50, scalelimit=0.3), 40.0),     # nearly everything rejected
