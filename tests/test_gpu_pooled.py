@@ -722,29 +722,10 @@ def test_pooled_mode_with_response_columns(oracle, name, extra):
     e.close()
 
 
-@pytest.mark.parametrize("d,N,mfma,condmax", [(6, 150, 0, 0.0), (6, 150, 1, 0.0), (50, 200, 1, 0.0), (6, 150, 0, 1e8), (6, 150, 1, 25.0), (20, 130, 1, 1e8),
-                                              (50, 200, 2, 0.0), (20, 130, 2, 1e8),           # mfma = 2: pooled_mfma_kernel<false, true> (two waves per SIMD)
-                                              (50, 200, 3, 0.0), (20, 130, 3, 1e8), (33, 140, 3, 0.0),    # mfma = 3: pooled_mfma2_kernel (two waves per tile)
-                                              (50, 200, 4, 0.0), (33, 140, 4, 0.0)])                      # mfma = 4: pooled_mfma3_kernel (half a tile per wave)
-def test_pooled_ram_matches_restatement(oracle, d, N, mfma, condmax, monkeypatch):
-    """method = 'ram', pooled = 1: one factor for all chains; every adaptint iterations the chains' rank-one RAM
-    statistics sign(a) x x' (MCMC_run_ram.F90:166-172) of that iteration are averaged over all chains and folded into
-    the Gram matrix of the shared factor, which is refactored (pooled_ram_tick).  condmax > 0: the shared factor is
-    covtor_svd's full matrix (matutils.F90:378-453), proposals are matmulx(Rf, z), the Gram matrix is Rf Rf' and the
-    refactorisation goes through the pinned SVD with the singular-value floor (condmax = 25 makes it bite)."""
-    from mcmcf90_amd import engine_from_problem
-    if not mfma:
-        monkeypatch.setenv("MCMCX_POOLED_SCALAR", "1")
-    monkeypatch.setenv("MCMCX_POOLED_WAVES", str(mfma) if mfma >= 2 else "1")
-    nsimu, adaptint, nu, target = 130, 20, 0.7, 0.234
-    ckw = dict(nsimu=nsimu, method="ram", adaptint=adaptint, updatesigma=0, nuparam=nu, alphatarget=target, condmax=condmax)
-    rng = np.random.default_rng(d)
-    A = rng.standard_normal((d, d)) / np.sqrt(d)
-    cm0 = (0.5 / d) * (np.diag(10.0 ** np.linspace(-3, 0, d)) if 0.0 < condmax < 100.0 else np.eye(d))     # cond 1000 > condmax: the floor bites
-    pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.2), cmat0=cm0, mu=np.zeros(d), lam=A @ A.T + np.eye(d))
-    e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
-    e.init(); e.run()
-    assert e.last_kernel() == {0: "step_kernel<false, false, true>", 1: "pooled_mfma_kernel<false>", 2: "pooled_mfma_kernel<false, true>", 3: "pooled_mfma2_kernel", 4: "pooled_mfma3_kernel"}[mfma], e.last_kernel()
+def _restate_pooled_ram(oracle, ckw, pkw, N):
+    """pooled_ram_tick, tick by tick, on N single-chain oracles that never adapt on their own: returns (chains, final factor, initial state, floor hits)."""
+    d, condmax = int(pkw["npar"]), float(ckw.get("condmax", 0.0))
+    nsimu, adaptint, nu, target = int(ckw["nsimu"]), int(ckw["adaptint"]), float(ckw["nuparam"]), float(ckw["alphatarget"])
     plain = oracle.make_cfg(**dict(ckw, doadapt=0, method="dram"))
     prob = oracle.Problem(**pkw)
     chains = [oracle.LiveChain(plain, prob, chain_id=c) for c in range(N)]
@@ -811,6 +792,33 @@ def test_pooled_ram_matches_restatement(oracle, d, N, mfma, condmax, monkeypatch
             ch.set_R(R)
     for ch in chains:
         ch.run(nsimu)
+    return chains, R, st, floored
+
+
+@pytest.mark.parametrize("d,N,mfma,condmax", [(6, 150, 0, 0.0), (6, 150, 1, 0.0), (50, 200, 1, 0.0), (6, 150, 0, 1e8), (6, 150, 1, 25.0), (20, 130, 1, 1e8),
+                                              (50, 200, 2, 0.0), (20, 130, 2, 1e8),           # mfma = 2: pooled_mfma_kernel<false, true> (two waves per SIMD)
+                                              (50, 200, 3, 0.0), (20, 130, 3, 1e8), (33, 140, 3, 0.0),    # mfma = 3: pooled_mfma2_kernel (two waves per tile)
+                                              (50, 200, 4, 0.0), (33, 140, 4, 0.0)])                      # mfma = 4: pooled_mfma3_kernel (half a tile per wave)
+def test_pooled_ram_matches_restatement(oracle, d, N, mfma, condmax, monkeypatch):
+    """method = 'ram', pooled = 1: one factor for all chains; every adaptint iterations the chains' rank-one RAM
+    statistics sign(a) x x' (MCMC_run_ram.F90:166-172) of that iteration are averaged over all chains and folded into
+    the Gram matrix of the shared factor, which is refactored (pooled_ram_tick).  condmax > 0: the shared factor is
+    covtor_svd's full matrix (matutils.F90:378-453), proposals are matmulx(Rf, z), the Gram matrix is Rf Rf' and the
+    refactorisation goes through the pinned SVD with the singular-value floor (condmax = 25 makes it bite)."""
+    from mcmcf90_amd import engine_from_problem
+    if not mfma:
+        monkeypatch.setenv("MCMCX_POOLED_SCALAR", "1")
+    monkeypatch.setenv("MCMCX_POOLED_WAVES", str(mfma) if mfma >= 2 else "1")
+    nsimu, adaptint, nu, target = 130, 20, 0.7, 0.234
+    ckw = dict(nsimu=nsimu, method="ram", adaptint=adaptint, updatesigma=0, nuparam=nu, alphatarget=target, condmax=condmax)
+    rng = np.random.default_rng(d)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    cm0 = (0.5 / d) * (np.diag(10.0 ** np.linspace(-3, 0, d)) if 0.0 < condmax < 100.0 else np.eye(d))     # cond 1000 > condmax: the floor bites
+    pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.2), cmat0=cm0, mu=np.zeros(d), lam=A @ A.T + np.eye(d))
+    e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
+    e.init(); e.run()
+    assert e.last_kernel() == {0: "step_kernel<false, false, true>", 1: "pooled_mfma_kernel<false>", 2: "pooled_mfma_kernel<false, true>", 3: "pooled_mfma2_kernel", 4: "pooled_mfma3_kernel"}[mfma], e.last_kernel()
+    chains, R, st, floored = _restate_pooled_ram(oracle, ckw, pkw, N)
     theta = np.array([ch.theta for ch in chains])
     np.testing.assert_array_equal(_bits(e.theta()), _bits(theta))
     for c in (0, 63, 64, N - 1):
@@ -824,6 +832,52 @@ def test_pooled_ram_matches_restatement(oracle, d, N, mfma, condmax, monkeypatch
     for ch in chains:
         ch.close()
     e.close()
+
+
+def _draw_pooled_ram(seed):
+    r = np.random.default_rng(93000 + seed)
+    d = int(r.choice([2, 5, 6, 13, 16, 17, 20, 33, 50, 64]))
+    N = int(r.choice([66, 70, 130, 200]))
+    condmax = float(r.choice([0.0, 0.0, 0.0, 1e8, 25.0]))
+    ckw = dict(nsimu=int(r.integers(60, 160)), method="ram", adaptint=int(r.choice([10, 20, 50])), updatesigma=0, nuparam=float(r.choice([0.6, 0.7, 0.9])),
+               alphatarget=float(r.choice([0.234, 0.4])), condmax=condmax)
+    A = r.standard_normal((d, d)) / np.sqrt(d)
+    scale = float(r.choice([0.02, 0.5, 5.0])) / d
+    cm0 = scale * (np.diag(10.0 ** np.linspace(-3, 0, d)) if 0.0 < condmax < 100.0 else np.eye(d))
+    pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.2), cmat0=cm0, mu=np.linspace(-0.5, 0.5, d), lam=A @ A.T + np.eye(d))
+    if r.random() < 0.3: pkw.update(lo=np.full(d, -2.0), hi=np.full(d, 2.0))
+    if r.random() < 0.3: pkw.update(pri_mu=np.zeros(d), pri_sig=np.where(np.arange(d) % 3 == 0, 0.0, 1.5))
+    return ckw, pkw, N, int(r.integers(5, ckw["nsimu"]))
+
+
+def _check_pooled_ram_against_restatement(oracle, seed):
+    from mcmcf90_amd import engine_from_problem
+    ckw, pkw, N, cut = _draw_pooled_ram(seed)
+    e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
+    e.init(); e.run(cut); e.run()
+    kernel = e.last_kernel()
+    chains, R, st, floored = _restate_pooled_ram(oracle, ckw, pkw, N)
+    try:
+        theta = np.array([ch.theta for ch in chains])
+        np.testing.assert_array_equal(_bits(e.theta()), _bits(theta), err_msg=str(ckw))
+        for c in (0, 63, 64, N - 1):
+            np.testing.assert_array_equal(e.accepted(c), chains[c].accepted, err_msg=str(ckw))
+        if ckw["condmax"] > 0.0:
+            np.testing.assert_array_equal(_bits(e.pooled()[3]), _bits(R), err_msg=str(ckw))
+        else:
+            np.testing.assert_array_equal(_bits(np.triu(e.pooled()[3])), _bits(R), err_msg=str(ckw))
+    finally:
+        for ch in chains:
+            ch.close()
+        e.close()
+    return kernel
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_pooled_ram_configuration_matches_restatement(oracle, seed):
+    """Pooled RAM (the bench's `c4_pooled` mode) on random configurations: npar 2..64, ragged tiles, adaptation every 10 / 20 / 50 iterations,
+    Cholesky and SVD factors (with the floor biting), bounds, priors, the run cut in two calls -- against the tick-by-tick restatement."""
+    _check_pooled_ram_against_restatement(oracle, seed)
 
 
 @pytest.mark.parametrize("mfma,condmax,burn,drscale", [(1, 1e8, 0, 0.0), (0, 1e8, 0, 0.0), (1, 40.0, 0, 0.0), (0, 40.0, 1, 0.0),
