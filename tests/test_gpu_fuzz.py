@@ -118,6 +118,59 @@ def test_random_configuration(oracle, seed, kernels):
     _check_against_oracle(oracle, ckw, pkw, seed)
 
 
+def _check_host_callbacks_against_oracle(oracle, seed, nch=3):
+    """The draw of `seed` with the target on the HOST: ssfunction / priorfun / checkbounds are the oracle's own C target functions behind the
+    engine's callback interface (external_inc.h:4-33), every method incl. SCAM's componentwise loop and early rejection's two evaluations."""
+    import ctypes as C
+    from mcmcf90_amd import Engine, make_config
+    ckw, pkw = _draw(seed)
+    ckw["nsimu"] = min(int(ckw["nsimu"]), 140)
+    if "adaptend" in ckw:
+        ckw["adaptend"] = min(int(ckw["adaptend"]), 100)
+    cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
+    try:
+        oracle.run_chain(oracle.make_cfg(**dict(ckw, nsimu=2)), prob, chain_id=7 * seed)
+    except RuntimeError:
+        return "init stops"
+    L = oracle.lib(); tgt = prob.ctarget()
+    L.mcxo_ssfun.restype = C.c_double; L.mcxo_priorfun.restype = C.c_double; L.mcxo_checkbounds.restype = C.c_int
+    dp = C.POINTER(C.c_double)
+    npar = int(pkw["npar"])
+    e = Engine(make_config(npar, nch, record_chain=1, chain_id0=7 * seed, **ckw))
+    e.setpar0(pkw["par0"]); e.setcmat0(np.asarray(pkw["cmat0"], dtype=float).reshape(npar, npar))
+    e.setsigma2nobs(float(pkw.get("sigma2", 1.0)), int(pkw.get("nobs", 1)))
+    e.set_target_host(lambda th: L.mcxo_ssfun(C.byref(tgt), th.ctypes.data_as(dp)), lambda th: L.mcxo_priorfun(C.byref(tgt), th.ctypes.data_as(dp)),
+                      lambda th: bool(L.mcxo_checkbounds(C.byref(tgt), th.ctypes.data_as(dp))))
+    e.init(); e.run(int(ckw["nsimu"]) // 3); e.run()
+    try:
+        for c in range(nch):
+            o = oracle.run_chain(cfg, prob, chain_id=7 * seed + c, continue_on_downdate_fail=True)
+            if o.rc != 0:
+                assert o.rc <= -2001 and (e.counters(c)["status"] & 4), (ckw, o.rc)
+                continue
+            ch, ss, s2 = e.chain(c)
+            np.testing.assert_array_equal(_bits(ch), _bits(o.chain), err_msg=str(ckw))
+            np.testing.assert_array_equal(_bits(ss), _bits(o.sschain), err_msg=str(ckw))
+            if cfg.updatesigma:
+                np.testing.assert_array_equal(_bits(s2), _bits(o.s2chain), err_msg=str(ckw))
+            cnt = e.counters(c)
+            assert (cnt["stayed"], cnt["bndstayed"], cnt["draccepted"], cnt["drtries"], cnt["erstayed"]) == (o.stayed, o.bndstayed, o.draccepted, o.drtries, o.erstayed), ckw
+            assert e.rng(c)[0] == o.rng_n, ckw
+    finally:
+        e.close()
+    return str(ckw["method"])
+
+
+@pytest.mark.parametrize("plumbing", ["fused_mapped", "phase_launches_and_copies"])
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configuration_host_callbacks(oracle, seed, plumbing, monkeypatch):
+    """Random configurations with the user's functions on the host, in the two plumbing forms (round 5: mapped host memory and fused phases, or
+    device buffers and one launch per phase); tools/bigfuzz.py-style loops: tools/host_fuzz.py."""
+    if plumbing != "fused_mapped":
+        monkeypatch.setenv("MCMCX_HOST_MAPPED", "0"); monkeypatch.setenv("MCMCX_HOST_FUSE", "0")
+    _check_host_callbacks_against_oracle(oracle, seed)
+
+
 @pytest.mark.parametrize("seed", [52160, 61152])
 def test_reference_stops_inside_an_adaptation(oracle, seed):
     """Two draws of tools/bigfuzz.py (round 5, 85 000 configurations) in which the REFERENCE terminates inside MCMC_adapt for one of the checked
