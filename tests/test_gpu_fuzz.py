@@ -294,6 +294,49 @@ def test_random_configuration_npar_65_to_300(oracle, seed):
     _check_larger_npar(oracle, seed, 65, 301)
 
 
+def _check_scam_npar(oracle, seed, dlo=13, dhi=121):
+    """method = 'scam' (MCMC_run_scam.F90:38-138) at npar 13..120: the componentwise loop on the per-chain rotation, adaptations through the
+    lane-per-chain SVD (npar < 48) and the blocked Jacobi (from 48 on), Gaussian and banana targets, bounds, priors, the sigma2 update."""
+    from mcmcf90_amd import engine_from_problem
+    r = np.random.default_rng(8000 + seed)
+    d = int(r.integers(dlo, dhi))
+    ckw = dict(nsimu=int(r.integers(25, 60)), method="scam", adaptint=int(r.choice([10, 20])), updatesigma=int(r.random() < 0.3))
+    if r.random() < 0.3:
+        ckw["condmax"] = float(r.choice([1e6, 50.0, 1e10]))
+    kind = "banana" if r.random() < 0.3 else "gauss"
+    if kind == "gauss":
+        A = r.standard_normal((d, d)) / np.sqrt(d)
+        pkw = dict(kind="gauss", npar=d, par0=r.standard_normal(d) * 0.1, cmat0=np.diag(r.uniform(0.2, 1.0, d)) / d, mu=np.zeros(d), lam=A @ A.T + np.eye(d))
+    else:
+        pkw = dict(kind="banana", npar=d, par0=np.zeros(d), cmat0=(0.5 / d) * np.eye(d), b=0.1)
+    if ckw["updatesigma"]:
+        pkw.update(sigma2=float(r.uniform(0.5, 1.5)), nobs=int(r.integers(5, 40)))
+    if r.random() < 0.25:
+        pkw.update(lo=np.full(d, -2.5), hi=np.full(d, 2.5))
+    if r.random() < 0.25:
+        pkw.update(pri_mu=np.zeros(d), pri_sig=np.where(r.random(d) < 0.5, 0.0, 2.0))
+    cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
+    e = engine_from_problem(ckw, pkw, nchains=66, chain_id0=seed, record_accept=1)
+    e.init(); e.run(int(ckw["nsimu"]) // 2); e.run()
+    th = e.theta()
+    try:
+        for c in (0, 65):
+            o = oracle.run_chain(cfg, prob, chain_id=seed + c)
+            assert o.rc == 0, (ckw, o.rc)
+            np.testing.assert_array_equal(e.accepted(c), o.accepted, err_msg=str(ckw))
+            np.testing.assert_array_equal(_bits(th[c]), _bits(o.theta), err_msg=str(ckw))
+            np.testing.assert_array_equal(_bits(e.R(c)), _bits(o.R), err_msg=str(ckw))
+            np.testing.assert_array_equal(_bits(e.qcovstd(c)), _bits(o.qcovstd), err_msg=str(ckw))
+            assert e.rng(c)[0] == o.rng_n, ckw
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scam_configuration_npar_13_to_120(oracle, seed):
+    _check_scam_npar(oracle, seed)
+
+
 def _check_larger_npar(oracle, seed, dlo=13, dhi=65):
     from mcmcf90_amd import engine_from_problem
     r = np.random.default_rng(7000 + seed)
