@@ -289,6 +289,60 @@ def test_pooled_scam_wave_layouts(oracle, d, extras, monkeypatch):
     e.close()
 
 
+def _check_pooled_scam_against_restatement(oracle, seed):
+    """A random pooled SCAM configuration (one rotation for all chains, adapted from the pooled covariance every adaptint iterations) against the
+    restatement of test_pooled_scam_wave_layouts: npar 2..64, ragged tiles, condmax floors, bounds, priors, the sigma2 update, a cut run."""
+    from mcmcf90_amd import engine_from_problem
+    r = np.random.default_rng(95000 + seed)
+    d = int(r.choice([2, 3, 5, 8, 13, 16, 17, 24, 33, 40, 48, 64]))
+    N = int(r.choice([66, 70, 130]))
+    tick = int(r.choice([3, 4, 5]))
+    nsimu = tick * int(r.integers(2, 4)) + int(r.integers(1, tick))          # never a multiple of the tick
+    ckw = dict(nsimu=nsimu, adaptint=tick, updatesigma=int(r.random() < 0.3), method="scam")
+    if r.random() < 0.3:
+        ckw["condmax"] = float(r.choice([1e6, 50.0]))
+    A = r.standard_normal((d, d)) / np.sqrt(d)
+    pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.1), cmat0=float(r.choice([0.01, 0.3])) * np.eye(d), mu=np.linspace(-0.5, 0.5, d),
+               lam=A @ A.T + np.diag(np.linspace(0.5, 3.0, d)))
+    if ckw["updatesigma"]: pkw.update(sigma2=0.7, nobs=30)
+    if r.random() < 0.3: pkw.update(lo=np.full(d, -0.8), hi=np.full(d, 0.9))
+    if r.random() < 0.3: pkw.update(pri_mu=np.zeros(d), pri_sig=np.where(np.arange(d) % 3 == 0, 0.0, 0.5))
+    e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
+    e.init(); e.run(int(r.integers(1, nsimu))); e.run()
+    kernel = e.last_kernel()
+    cfg = oracle.make_cfg(**dict(ckw, doadapt=0))
+    prob = oracle.Problem(**pkw)
+    chains = [oracle.LiveChain(cfg, prob, chain_id=c) for c in range(N)]
+    try:
+        state = {}
+        par0, cmat0 = np.asarray(pkw["par0"], float), np.asarray(pkw["cmat0"], float)
+        for t in list(range(tick, nsimu, tick)) + [nsimu]:
+            for ch in chains:
+                ch.run(t)
+            if t < nsimu:
+                theta = np.array([ch.theta for ch in chains])
+                cnt, s1, s2 = _pooled_moments(theta, par0, N)
+                state = _merge_and_factor(oracle, state, cnt, s1, s2, par0, d, t == tick, cmat0, 0)
+                state = _scam_factor(oracle, state, d, cfg.condmax)
+                for ch in chains:
+                    ch.set_R(state["U"]); ch.set_qcovstd(state["std"])
+        theta = np.array([ch.theta for ch in chains])
+        np.testing.assert_array_equal(_bits(e.theta()), _bits(theta), err_msg=str(ckw))
+        for c in (0, 63, 64, N - 1):
+            np.testing.assert_array_equal(e.accepted(c), chains[c].accepted, err_msg=str(ckw))
+        np.testing.assert_array_equal(_bits(e.pooled()[3]), _bits(state["U"]), err_msg=str(ckw))
+    finally:
+        for ch in chains:
+            ch.close()
+        e.close()
+    return kernel
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_pooled_scam_configuration_matches_restatement(oracle, seed):
+    _check_pooled_scam_against_restatement(oracle, seed)
+
+
 @pytest.mark.parametrize("waves", [1, 2, 3, 4], ids=["one_wave_per_simd", "two_waves_per_simd", "two_waves_per_tile", "half_tile_per_wave"])
 @pytest.mark.parametrize("d", [50, 70])
 def test_pooled_am_matrix_core_kernel_sizes(oracle, d, waves, monkeypatch):
