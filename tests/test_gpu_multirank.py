@@ -130,6 +130,21 @@ def test_two_ranks_under_torchrun(tmp_path):
     assert np.array_equal(np.fromfile(dump, dtype=np.float64).view(np.uint64), m_own.view(np.uint64))
 
 
+def test_bench_falls_back_to_the_host_transport_when_rccl_does_not_form(tmp_path, monkeypatch):
+    """RCCL has never met N > 1 GPUs in this project's own runs (no node was ever available).  Should its communicator fail to form on the
+    driver's node, bench.py carries the path's latency-sized messages through the shared-memory segment instead and SAYS so in its line
+    (`rccl_error`, `rccl_ranks` 0, the transport named in the workload) rather than producing no scaling point at all.  Simulated here
+    (MCMCX_BENCH_SIMULATE_RCCL_FAILURE): two ranks, the same moments as the plain dry run."""
+    args = ["--gpus", "2", "--one-gpu-dryrun", "--steps", "2", "--warmup", "1", "--chains-per-gpu", "1024", "--no-other-configs"]
+    plain, m_plain = _bench(args, tmp_path, "plain")
+    monkeypatch.setenv("MCMCX_BENCH_SIMULATE_RCCL_FAILURE", "1")
+    fb, m_fb = _bench(args, tmp_path, "fallback")
+    assert "rccl_error" in fb and "simulated" in fb["rccl_error"] and fb["rccl_ranks"] == 0 and "rccl_error" not in plain
+    assert "RCCL did not form" in fb["config"]["workload"] or "RCCL did not form" in json.dumps(fb["config"])
+    assert fb["n_gpus"] == 2 and fb["pooled_check"]["chains"] == 2048
+    assert np.array_equal(m_fb.view(np.uint64), m_plain.view(np.uint64))
+
+
 @pytest.mark.parametrize("nranks", [4])   # the GPU box allows 6 processes on its card: pytest + 4 ranks
 def test_tree_over_ranks_equals_tree_over_tiles(tmp_path, nranks):
     """The claim behind all-gather + tree: for power-of-two shards the pairwise tree over ranks
