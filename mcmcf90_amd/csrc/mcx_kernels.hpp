@@ -506,14 +506,19 @@ MCX_DEV double gen_normals_split(Rng &g, double *zs_t, int lane, int d, bool par
     const int k0 = k;
     bool need = participate && (k < d);
     double over = 0.0;                                    // x1 of the pair whose second deviate lies past the vector's end
+    // block b0 + NB -- the straddling pair's second half when the stream position is odd -- is the NEXT trip's block b0 for every lane that goes on
+    // (it consumed all NB attempts): carried over instead of computed again, NB blocks per trip after the first instead of NB + 1
+    uint32_t cw0 = 0u, cw1 = 0u, cw2 = 0u, cw3 = 0u;
+    uint64_t cblk1 = 0;                                   // the carried block's index + 1 (0: none)
     while (__any(need)) {
         const uint64_t b0 = g.n >> 1;
         const bool odd = (g.n & 1) != 0;
         uint32_t w[NB + 1][4];
+        if (__all(!need || cblk1 == b0 + 1)) { w[0][0] = cw0; w[0][1] = cw1; w[0][2] = cw2; w[0][3] = cw3; }
+        else philox4x32_10((uint32_t)b0, (uint32_t)(b0 >> 32), g.k0, g.k1, w[0][0], w[0][1], w[0][2], w[0][3]);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) philox4x32_10((uint32_t)(b0 + j), (uint32_t)((b0 + j) >> 32), g.k0, g.k1, w[j][0], w[j][1], w[j][2], w[j][3]);
-        if (__any(need && odd)) philox4x32_10((uint32_t)(b0 + NB), (uint32_t)((b0 + NB) >> 32), g.k0, g.k1, w[NB][0], w[NB][1], w[NB][2], w[NB][3]);
-        else { w[NB][0] = w[NB][1] = w[NB][2] = w[NB][3] = 0u; }
+        for (int j = 1; j <= NB; ++j) philox4x32_10((uint32_t)(b0 + j), (uint32_t)((b0 + j) >> 32), g.k0, g.k1, w[j][0], w[j][1], w[j][2], w[j][3]);
+        cw0 = w[NB][0]; cw1 = w[NB][1]; cw2 = w[NB][2]; cw3 = w[NB][3]; cblk1 = b0 + NB + 1;
         double xa[NB], xb[NB];
         bool ok[NB];
 #pragma unroll
