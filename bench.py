@@ -22,7 +22,9 @@ all start.  The ranks meet in libmcmcx.so's communicator (RCCL; the ncclUniqueId
 shm segment), which also carries the barrier and the max-over-ranks of the timing: torch is not imported.
 Every rank prints its device (name, PCI bus id) and its place in the communicator to stderr once, runs RCCL
 with NCCL_DEBUG=WARN, and arms a watchdog around the communicator's formation (--comm-timeout): a rank that
-cannot join ends the run with a non-zero exit code instead of hanging it.
+cannot join ends the run with a non-zero exit code instead of hanging it.  If RCCL itself refuses to form although every rank has its own
+GPU, the same (latency-sized) exchange goes through the shared-memory segment and the line says so: `rccl_error`, `rccl_ranks` 0, the
+transport named in `config.workload`.
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the engine's
 stream around every step-kernel launch of the timed region (mcmcx_kernel_time); `cpu_baseline`
