@@ -565,11 +565,19 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
     bool st2 = false;                                   // ... and whether it is at its second stage
     double c1[NS], ss2s = 0.0, pri2s = 0.0;             // the rejected first-stage candidate with its ss and prior
     sfor<0, NS>([&](auto S) __attribute__((always_inline)) { c1[decltype(S)::value] = 0.0; });
+    // -DMCX_PHASE_PROF (tools/build_variant.sh; profiles/r05_e/c3_phases.txt): where a pass of the loop goes, by wall_clock64
+#ifdef MCX_PHASE_PROF
+    unsigned long long gph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gtq = wall_clock64(), gpasses = 0;
+#define GPH(i) { unsigned long long tn = wall_clock64(); gph[i] += tn - gtq; gtq = tn; }
+#else
+#define GPH(i)
+#endif
     while (__any(it <= it1)) {
         const bool act = it <= it1;
         // ---- newpar = MCMC_propose(oldpar, R) / newpar2 = MCMC_propose(oldpar, R2): the stage's first draws
         double z[NS], cand[NS];
         group_normals<D4, GW>(k0, k1, g, zrow, l16, row, d, act, z);
+        GPH(0)
         const bool any2 = DR && __any(act && st2);
         sfor<0, NS>([&](auto S) __attribute__((always_inline)) {
             constexpr int s = decltype(S)::value;
@@ -600,10 +608,12 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
             }
             cand[s] = th[s] + p;                         // newpar = oldpar + R'z
         });
+        GPH(1)
         // ---- bounds, prior, ss of the candidate
         const bool inb = group_inbounds<D4, GW>(E.tgt, cand, l16, row, d);
         const double pri = group_prior<D4, GW>(E.tgt, cand, l16, d);
         const double ss = group_ss<D4, TK, GW>(E.tgt, cand, l16, d, laml);
+        GPH(2)
         // ---- second stages: MCMC_DR_alpha13's two quadratic forms dx' iC dx, dx_a = newpar2 - newpar, dx_b = oldpar - newpar (MCMC_DRAM.F90:176-182)
         double qa = 0.0, qb = 0.0;
         if constexpr (DR) {
@@ -631,6 +641,7 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
                 sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; gblk_addchain<GW, G::blk(s)>(qa, ta[s]); gblk_addchain<GW, G::blk(s)>(qb, tb_[s]); });
             }
         }
+        GPH(3)
         // ---- MCMC_alpha (MCMC_DRAM.F90:100-118) or MCMC_DR_alpha13 (:162-186), then MCMC_reject (:140-155)
         bool rej = true, take = false, fin = false;
         double alpha = 0.0;
@@ -669,6 +680,7 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
                 }
             }
         }
+        GPH(4)
         if (__any(take)) {
             const double u = group_uniform<GW>(k0, k1, g, take, row);
             if (er) {
@@ -679,6 +691,7 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
                 }
             } else if (take && u <= alpha) rej = false;
         }
+        GPH(5)
         if (act) {
             if (DR && !st2 && rej) {                     // on to the second stage: one delayed-rejection try (MCMC_run.F90:65-91)
                 st2 = true; drtries += 1; ss2s = ss; pri2s = pri;
@@ -717,7 +730,17 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 
             if (E.hist && E.record_s2 && l16 == 0) E.s2hist[((size_t)tile * E.wcap + (it % E.wcap)) * 64 + cl] = sigma2;
             it += 1; st2 = false;
         }
+        GPH(6)
+#ifdef MCX_PHASE_PROF
+        gpasses += 1;
+#endif
     }
+#ifdef MCX_PHASE_PROF
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1))
+        printf("group_step block %d: %llu passes for %d iterations, x10ns: normals %llu proposal %llu bounds+prior+ss %llu DR quadratic forms %llu alpha(exp) %llu uniform+decide %llu bookkeeping+history %llu\n",
+               (int)blockIdx.x, gpasses, it1 - it0 + 1, gph[0], gph[1], gph[2], gph[3], gph[4], gph[5], gph[6]);
+#endif
+#undef GPH
 
     sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = GW * s + l16; if (c < d) TIDX(E.theta, tile, d, c, cl) = th[s]; });
     if (l16 == 0) {
