@@ -38,3 +38,15 @@ def test_every_entry_is_asserted_by_a_gpu_parity_test():
         if not any(re.search(lit, t) for t in src.values()):
             missing.append("%s:%s" % (fam, name))
     assert not missing, "kernel instances no -m gpu test asserts by name: %s" % ", ".join(missing)
+
+
+def test_tools_and_bench_parse():
+    """The measurement scripts under tools/ (and bench.py, __graft_entry__.py) are evidence for DESIGN.md's numbers: they must at least compile."""
+    import ast
+    import glob
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "tools", "*.py"))) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    assert len(files) > 20
+    for f in files:
+        ast.parse(open(f).read(), filename=f)
