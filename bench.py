@@ -22,17 +22,19 @@ all start.  The ranks meet in libmcmcx.so's communicator (RCCL; the ncclUniqueId
 shm segment), which also carries the barrier and the max-over-ranks of the timing: torch is not imported.
 Every rank prints its device (name, PCI bus id) and its place in the communicator to stderr once, runs RCCL
 with NCCL_DEBUG=WARN, and arms a watchdog around the communicator's formation (--comm-timeout): a rank that
-cannot join ends the run with a non-zero exit code instead of hanging it.  If RCCL itself refuses to form although every rank has its own
-GPU, the same (latency-sized) exchange goes through the shared-memory segment and the line says so: `rccl_error`, `rccl_ranks` 0, the
-transport named in `config.workload`.
+cannot join ends the run with a non-zero exit code instead of hanging it.  If RCCL itself refuses to form the run ends non-zero with RCCL's
+own diagnostics and NO line -- unless `--allow-host-transport` was given: then (every rank having its own GPU) the same latency-sized exchange
+goes through the shared-memory segment and the line says so: `transport` "host", `rccl_error`, `rccl_ranks` 0.
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the engine's
 stream around every step-kernel launch of the timed region (mcmcx_kernel_time); `cpu_baseline`
 times the real Fortran reference (oracle/_ref, kind "reference") or the C oracle (kind "port")
-on one host core and on all of them on the same target; `other_configs` holds, at N = 1, a short run of each of the
-other BASELINE configurations in the same process after the headline's timed region and, at N > 1, a short run of c4 in
-POOLED mode on the same communicator -- the one collective that sits on the critical path (the pooled RAM tick every
-adaptint iterations) -- so that one scaling run also measures that; `device` identifies the box (UUID, PCI id, clocks).
+on one host core and on all of them on the same target; `other_configs` (the LAST key, compact entries of <= 160 characters:
+value, frac, bound, issue, kernel, ms, share -- `--verbose` or gpurun_out/bench_other_configs.json for the long form) holds, at N = 1,
+a short run of each of the other BASELINE configurations in the same process after the headline's timed region and, at N > 1, a short
+run of c4 in POOLED mode on the same communicator -- the one collective that sits on the critical path (the pooled RAM tick every
+adaptint iterations) -- so that one scaling run also measures that; `roofline.others` mirrors [value, frac] of every BASELINE
+configuration; `roofline.traffic_source` says where the (stored, not live) PMC figure comes from; `device` identifies the box.
 """
 import argparse
 import json
@@ -56,12 +58,14 @@ FP64_MFMA_PEAK_TF = 78.6       # MI355X FP64 matrix (= FP64 vector) spec peak; t
 VALU_ISSUE_PEAK_GIPS = 256 * 4 * 2.4 / 4.0 * 64 / 64      # 614.4 G wave-instructions/s
 
 WORKLOADS = {   # BASELINE.json configs 2-5; the headline metric is quoted on c4
+    "c1": "C1 at scale: config 1's decay model (npar 2, device-resident), DRAM drscale=2, updatesigma=1",
+    "c1x": "C1 with response columns: nycol=2 (one sigma2 per column), npar 3, DRAM drscale=2, updatesigma=1",
     "c2": "C2: isotropic Gaussian d=10, AM (method=dram, drscale=0)",
     "c3": "C3: banana d=20, DRAM (2-stage delayed rejection, drscale=2)",
     "c4": "C4: correlated Gaussian d=50 (Sigma=0.5^|i-j|)",
     "c5": "C5: ill-conditioned Gaussian d=200 (cond 1e6), SCAM componentwise",
 }
-DEFAULT_CHAINS = {"c2": 65536, "c3": 262144, "c4": 1048576, "c5": 65536}
+DEFAULT_CHAINS = {"c1": 262144, "c1x": 262144, "c2": 65536, "c3": 262144, "c4": 1048576, "c5": 65536}
 # BASELINE.json: c4 and c5 are ONE problem "sharded over 8 x MI355X" -- the whole job's chains are divided among the GPUs of a run
 # (strong scaling); c2 and c3 are quoted "on 1 MI355X" and keep their count per GPU (weak scaling)
 STRONG = ("c4", "c5")
@@ -187,10 +191,8 @@ def reference_all_cores(ckw, pkw, per_it, rate_it, cores):
     return {"value": (p2 - p1) / dt, "unit": "proposals/s", "cores": cores, "kind": "reference",
             "effective_parallelism": r2["cpu_seconds"] / r2["wall"],
             "cgroup_cpu_quota": quota,
-            "sample": "mcmcf90 Fortran reference (flang -O2 + MKL, oracle/_ref/mcxref), %d processes = the CPUs of the affinity mask, "
-                      "one independent chain each, own %s directory: sampling loop only = %d x (proposals(nsimu=%d) - proposals(nsimu=%d)) / "
-                      "(%.2f s - %.2f s wall of the whole batch); CPU seconds used / wall = %.1f"
-                      % (cores, r2["scratch"], cores, n2, n1, r2["wall"], r1["wall"], r2["cpu_seconds"] / r2["wall"])}
+            "sample": "reference (oracle/_ref/mcxref), %d processes x 1 chain on %s: loop only = %d x (prop(nsimu=%d) - prop(nsimu=%d)) / (%.2f - %.2f s); "
+                      "CPU s / wall = %.1f" % (cores, r2["scratch"], cores, n2, n1, r2["wall"], r1["wall"], r2["cpu_seconds"] / r2["wall"])}
 
 
 def port_all_cores(wl, ckw, per_it, port_rate, cores, seconds=0.6):
@@ -212,7 +214,7 @@ def port_all_cores(wl, ckw, per_it, port_rate, cores, seconds=0.6):
         tries += int(out.decode().split()[-1])
     dt = time.perf_counter() - t0
     return {"value": (cores * (n - 1) * per_it + tries) / dt, "unit": "proposals/s", "cores": cores, "kind": "port",
-            "sample": "C oracle, %d independent chains, one process each, nsimu=%d each, %.2f s incl. process start (python + ctypes)" % (cores, n, dt)}
+            "sample": "C oracle, %d processes x 1 chain, nsimu=%d each, %.2f s incl. process start" % (cores, n, dt)}
 
 
 def cpu_baseline(wl, ckw, pkw, per_it, label, target_seconds=12.0, all_cores=True):
@@ -245,9 +247,8 @@ def cpu_baseline(wl, ckw, pkw, per_it, label, target_seconds=12.0, all_cores=Tru
             (p1, t1, _), (p2, t2, scratch) = runs
             value = (p2 - p1) / (t2 - t1)
             out.update(value=value, kind="reference",
-                       sample="mcmcf90 Fortran reference (flang -O2 + MKL, oracle/_ref/mcxref), 1 chain, %s: sampling loop "
-                              "only = (proposals(nsimu=%d) - proposals(nsimu=%d)) / (%.2f s - %.2f s) of the whole program, "
-                              "outputs on %s" % (label, n2, n1, t2, t1, scratch),
+                       sample="mcmcf90 Fortran reference (flang -O2 + MKL, oracle/_ref/mcxref), 1 chain, %s: loop only = "
+                              "(prop(nsimu=%d) - prop(nsimu=%d)) / (%.2f - %.2f s), outputs on %s" % (label, n2, n1, t2, t1, scratch),
                        whole_program_value=p2 / t2, port_value=port_rate)
             if all_cores:
                 try:
@@ -258,6 +259,11 @@ def cpu_baseline(wl, ckw, pkw, per_it, label, target_seconds=12.0, all_cores=Tru
             return out
         except Exception as ex:                      # reference binary present but not runnable here
             out["reference_error"] = str(ex)[:200]
+    if not rr.available():
+        # the evidence pipeline lost its reference (oracle/_ref is a build product: a clean clone on a GPU box has none) -- said in the
+        # line and on stderr, not only through `kind`
+        out["reference_missing"] = True
+        sys.stderr.write("bench.py: oracle/_ref/mcxref (the reference compiled from /root/reference) is ABSENT: cpu_baseline is the C port (kind 'port')\n")
     if all_cores:
         out["all_cores"] = port_all_cores(wl, ckw, per_it, port_rate, cores, seconds=3.0)
     out.update(value=port_rate, kind="port",
@@ -537,8 +543,11 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
             # so an iteration in which a wave holds both kinds moves the factor twice in each direction (2R + 2W)
             tri = d * (d + 1) // 2 * 8
             roof["alg_bytes_2r2w_per_proposal"] = 16 * d + 32 + int(round(tri * (2.0 + 2.0 * (1.0 - (1.0 - down_frac) ** 64))))   # share of waves with a downdate lane
+    # `traffic` is not measured in this run (PMC needs passes of its own): it is the stored figure of profiles/traffic.json, used only while the
+    # engine sources are the ones it was collected with -- the line says where the number comes from, or that there is none for this build
+    roof["traffic_source"] = ("profiles/traffic.json[%s]@%s (%s)" % (ckey, pmc["kernels_sha"], pmc.get("profile"))) if pmc else \
+        ("none: profiles/traffic.json holds no entry for %s at engine sha %s" % (ckey, kernels_sha()))
     if pmc:
-        roof["traffic_measured_at"] = {"kernels_sha": pmc["kernels_sha"], "profile": pmc.get("profile")}
         if "valu_insts_per_proposal" in pmc:      # second roof: vector-instruction issue, from an SQ counter pass
             ips_ach = pmc["valu_insts_per_proposal"] / 64.0 * per_launch_prop / avg_launch_s / 1e9   # wave-instructions/s
             roof["issue"] = {"achieved": ips_ach, "peak": VALU_ISSUE_PEAK_GIPS, "unit": "G wave-instr/s",
@@ -603,20 +612,26 @@ def run_config(wl, steps, warmup, rank, world, dev, comm, chains_per_gpu=0, its_
 
 # the other BASELINE configurations, run briefly after the headline in the same process (N = 1): (key, run_config arguments)
 OTHER_CONFIGS = [
-    ("c2", dict(wl="c2", steps=10, warmup=2)),                      # 1.7 ms per step: ten of them
-    ("c3", dict(wl="c3", steps=3, warmup=1)),
-    ("c4_target", dict(wl="c4", steps=3, warmup=1, start="target", chains_per_gpu=131072)),    # one eighth of the chains: 0.14 s per step
-    ("c4_pooled", dict(wl="c4", steps=6, warmup=1, pooled=True)),
-    ("c5_pooled", dict(wl="c5", steps=2, warmup=1)),
-    ("c5_pooled_scam_fast", dict(wl="c5", steps=2, warmup=1, scam_fast=True)),        # opt-in variants, labelled as such in `workload`
-    ("c5_replicas_scam_fast", dict(wl="c5", steps=2, warmup=1, replicas=True, scam_fast=True)),
-    # MCMC_run_scam.F90:106-115 as written: per-chain rotations, two dgemv per componentwise proposal (no scam_fast); one iteration per step
-    ("c5_replicas", dict(wl="c5", steps=2, warmup=1, replicas=True, its_per_step=1)),
+    # (printed in this order, and the driver keeps the LAST 2000 characters of stdout: the BASELINE configurations come last)
     # the few-chains regime (one tile of 64 chains: an iteration is latency, not throughput): us per iteration incl. the adaptation ticks
     ("c2_64_chains", dict(wl="c2", steps=5, warmup=1, chains_per_gpu=64)),
     ("c3_64_chains", dict(wl="c3", steps=5, warmup=1, chains_per_gpu=64)),
     ("c4_64_chains", dict(wl="c4", steps=5, warmup=1, chains_per_gpu=64)),       # method = 'ram' with one tile: group_ram_kernel (factor in registers)
+    ("c5_pooled_scam_fast", dict(wl="c5", steps=2, warmup=1, scam_fast=True)),        # opt-in variants, labelled as such in `workload`
+    ("c5_replicas_scam_fast", dict(wl="c5", steps=2, warmup=1, replicas=True, scam_fast=True)),
+    # config 1's model at scale: one response column (the lane-group kernels) and two (nycol = 2: step_kernel_cols) -- VERDICT round 5, item 6
+    ("c1", dict(wl="c1", steps=3, warmup=1)),
+    ("c1x", dict(wl="c1x", steps=3, warmup=1)),
+    # MCMC_run_scam.F90:106-115 as written: per-chain rotations, two dgemv per componentwise proposal (no scam_fast); one iteration per step
+    ("c5_replicas", dict(wl="c5", steps=2, warmup=1, replicas=True, its_per_step=1)),
+    ("c5_pooled", dict(wl="c5", steps=2, warmup=1)),
+    ("c4_pooled", dict(wl="c4", steps=6, warmup=1, pooled=True)),
+    ("c4_target", dict(wl="c4", steps=3, warmup=1, start="target", chains_per_gpu=131072)),    # one eighth of the chains: 0.14 s per step
+    ("c3", dict(wl="c3", steps=3, warmup=1)),
+    ("c2", dict(wl="c2", steps=10, warmup=2)),                      # 1.7 ms per step: ten of them
 ]
+# the configurations BASELINE.json names (and c4's two other regimes): mirrored as [value, roofline fraction] into `roofline.others`
+HEADLINE_OTHERS = ("c2", "c3", "c4_target", "c4_pooled", "c5_pooled", "c5_replicas", "c1x")
 # N > 1: the pooled form of the headline configuration on the same communicator -- its RAM tick (the rank-one statistics of all chains
 # of all ranks gathered and folded into the one shared factor every adaptint iterations) is the collective ON the critical path
 OTHER_CONFIGS_MULTI = [
@@ -643,6 +658,11 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the other BASELINE configurations after the headline")
     ap.add_argument("--comm-timeout", type=float, default=float(os.environ.get("MCMCX_COMM_TIMEOUT", "240")),
                     help="seconds the ranks may take to form their communicator before the run is given up")
+    ap.add_argument("--allow-host-transport", action="store_true",
+                    help="N > 1: if RCCL refuses to form although every rank has its own GPU, carry the (latency-sized) exchange through the host "
+                         "segment and say so in the line (`transport`: host, `rccl_ranks` 0).  Off by default: an RCCL failure then ends the run "
+                         "with a non-zero exit code and RCCL's own NCCL_DEBUG=WARN output, so that a scaling record cannot hold a non-RCCL number unasked")
+    ap.add_argument("--verbose", action="store_true", help="`other_configs` entries in their long form (prose workload strings, every field) instead of the compact one")
     ap.add_argument("--one-gpu-dryrun", action="store_true",
                     help="debug: all ranks share GPU 0 and exchange through the host transport (checks the N>1 path on a 1-GPU box)")
     ap.add_argument("--dump-moments", default=None, help="debug: rank 0 writes the final pooled moment vector (float64) to this file")
@@ -687,20 +707,27 @@ def main():
         key = os.environ.get("MCMCX_COMM_KEY") or launcher_key()
         wd = Watchdog(a.comm_timeout, "forming the %d-rank communicator (%s)" % (world, "host transport" if a.one_gpu_dryrun else "ncclCommInitRank"))
         rccl_failed = None
-        simulate = bool(os.environ.get("MCMCX_BENCH_SIMULATE_RCCL_FAILURE"))      # (tests: the fallback below on a one-GPU box)
+        simulate = bool(os.environ.get("MCMCX_BENCH_SIMULATE_RCCL_FAILURE"))      # (tests: what an RCCL failure does, on a one-GPU box)
         try:
             if simulate:
                 raise RuntimeError("simulated: ncclCommInitRank failed")
             comm = Comm(key, rank, world, dev, backend="host" if a.one_gpu_dryrun else "rccl")    # raises unless all ranks arrive
             comm.barrier()
         except Exception as ex:
-            # RCCL would not form (it has never met N > 1 GPUs in this project's own runs): the same exchange staged through the shared-memory
-            # segment by the hosts -- the path's messages are latency-sized (timing scalars, one moment vector per tick), so the numbers stand;
-            # the line says which transport carried them.  Works when every rank fails the same way; a mixed outcome ends at the watchdog.
-            # only RCCL's own refusal, and only with a GPU per rank (ranks that share a device must stay an error: that is what RCCL refuses
-            # first, and a scaling point measured that way would be a lie); a missing or failed peer stays an error too
-            if not simulate and (a.one_gpu_dryrun or ndev < world or "nccl" not in repr(ex)):
-                raise
+            # RCCL would not form (it has never met N > 1 GPUs in this project's own runs).  The path's messages are latency-sized (timing scalars,
+            # one moment vector per tick), so the same exchange staged through the shared-memory segment gives numbers that stand -- but only
+            # with a GPU per rank (ranks sharing a device must stay an error: that is what RCCL refuses first, and a scaling point measured that
+            # way would be a lie) and only when asked for:
+            # Opt-in (--allow-host-transport): by default an RCCL failure is fatal -- rank stderr carries NCCL_DEBUG=WARN's lines, the exit code
+            # is non-zero, no JSON line is printed.  With the flag EVERY rank whose formation raised falls back, whatever its message said (a rank
+            # that only saw a peer's `failed` word or timed out in the bootstrap gets no "nccl" in its text; deciding per message made the ranks
+            # disagree -- ADVICE round 5): a peer that is really gone fails the host communicator's formation the same way.
+            if (not simulate and (a.one_gpu_dryrun or ndev < world)) or not a.allow_host_transport:
+                sys.stderr.write("bench.py rank %d: forming the %d-rank RCCL communicator failed: %r\n"
+                                 "bench.py rank %d: no number is produced (--allow-host-transport would carry the exchange through the host segment)\n"
+                                 % (rank, world, ex, rank))
+                sys.stderr.flush()
+                raise SystemExit(4)
             rccl_failed = repr(ex)[:300]
             sys.stderr.write("bench.py rank %d: RCCL communicator failed (%s); falling back to the host transport\n" % (rank, rccl_failed))
             sys.stderr.flush()
@@ -734,16 +761,18 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": res["config"], "roofline": res["roofline"], "pooled_check": res["pooled_check"],
             **({"adaptation": res["adaptation"]} if res.get("adaptation") else {}),
+            # what carried the N > 1 exchange: "rccl", "host" (opt-in fallback or --one-gpu-dryrun; rccl_ranks 0), "none" (one GPU)
+            "transport": "none" if world == 1 else ("host" if (a.one_gpu_dryrun or rccl_failed) else "rccl"),
             "rccl_ranks": rccl_ranks if (world > 1 and not a.one_gpu_dryrun and not rccl_failed) else (1 if world == 1 else 0),
             **({"rccl_error": rccl_failed} if rccl_failed else {}),
             "engine_sha": kernels_sha(),
             "device": device_ident(L, dev),
         }
+    others, details = {}, {}
     if not a.no_other_configs and plain and (world > 1 or not a.chains_per_gpu):
         # N = 1: the other BASELINE configurations, briefly, in this same process (builder-independent numbers for all of them);
         # N > 1: the pooled form of the headline on the same communicator (every rank runs it: its ticks are collective, so an
         # error there is not swallowed -- a rank that raised alone would leave its peers in the next gather)
-        others = {}
         for key, kw in (OTHER_CONFIGS if world == 1 else OTHER_CONFIGS_MULTI):
             try:
                 t0 = time.perf_counter()
@@ -751,32 +780,55 @@ def main():
                                   **dict(kw, **({"chains_per_gpu": a.chains_per_gpu} if (world > 1 and a.chains_per_gpu) else {})))
                 if rank == 0:
                     rf = r["roofline"]
-                    others[key] = {"value": r["value"], "unit": "proposals/s", "ms_per_step": r["ms_per_step"], "steps": kw["steps"],
-                                   "bound": rf["bound"], "roofline_frac": rf["frac"], "achieved": rf["achieved"], "roofline_unit": rf["unit"],
-                                   "issue_frac": rf.get("issue", {}).get("frac"), "kernel": rf["kernel"],
-                                   "avg_launch_ms": rf["avg_launch_ms"], "kernel_share_of_wall": rf["kernel_share_of_wall"],
-                                   "alg_per_proposal": rf.get("alg_bytes_per_proposal", rf.get("alg_flop_per_proposal")),
-                                   "workload": r["config"]["workload"], "proposals_per_iteration": r["config"]["proposals_per_iteration"],
-                                   "chains_per_gpu": r["config"]["chains_per_gpu"], "n_gpus": world,
-                                   "us_per_iteration": r["ms_per_step"] * 1e3 / r["config"]["its_per_step"],
-                                   "wall_s_incl_init": time.perf_counter() - t0}
+                    details[key] = {"value": r["value"], "unit": "proposals/s", "ms_per_step": r["ms_per_step"], "steps": kw["steps"],
+                                    "bound": rf["bound"], "roofline_frac": rf["frac"], "achieved": rf["achieved"], "roofline_unit": rf["unit"],
+                                    "issue_frac": rf.get("issue", {}).get("frac"), "kernel": rf["kernel"],
+                                    "avg_launch_ms": rf["avg_launch_ms"], "kernel_share_of_wall": rf["kernel_share_of_wall"],
+                                    "alg_per_proposal": rf.get("alg_bytes_per_proposal", rf.get("alg_flop_per_proposal")),
+                                    "traffic_source": rf.get("traffic_source"),
+                                    "workload": r["config"]["workload"], "proposals_per_iteration": r["config"]["proposals_per_iteration"],
+                                    "chains_per_gpu": r["config"]["chains_per_gpu"], "n_gpus": world,
+                                    "us_per_iteration": r["ms_per_step"] * 1e3 / r["config"]["its_per_step"],
+                                    "wall_s_incl_init": time.perf_counter() - t0}
+                    # the compact entry (<= 160 characters): value, fraction of the roof named in `bound`, the vector-issue fraction where an SQ pass
+                    # exists for this build, the kernel as the engine names it, ms per step, the kernel's share of the wall; few chains: us per iteration
+                    c = {"value": float("%.4g" % r["value"]), "frac": round(rf["frac"], 4), "bound": rf["bound"]}
+                    if rf.get("issue"):
+                        c["issue"] = round(rf["issue"]["frac"], 3)
+                    c.update(kernel=rf["kernel"].replace("mcx::", ""), ms=float("%.4g" % r["ms_per_step"]), share=round(rf["kernel_share_of_wall"], 3))
+                    if r["config"]["chains_per_gpu"] <= 64:
+                        c["us_it"] = float("%.3g" % details[key]["us_per_iteration"])
                     if world > 1:
-                        others[key]["rccl_ranks"] = line["rccl_ranks"]
-                        others[key]["pooled_check"] = r["pooled_check"]
+                        details[key]["rccl_ranks"] = line["rccl_ranks"]
+                        details[key]["pooled_check"] = r["pooled_check"]
+                        c["rccl_ranks"] = line["rccl_ranks"]
                     if r.get("adaptation"):
-                        others[key].update(tick_ms=r["adaptation"]["tick_ms"], sustained_value=r["adaptation"]["sustained_value"])
+                        details[key].update(tick_ms=r["adaptation"]["tick_ms"], sustained_value=r["adaptation"]["sustained_value"])
+                        c["tick_ms"] = float("%.4g" % r["adaptation"]["tick_ms"])
                         for k2 in ("first_tick_ms", "second_tick_ms"):
                             if k2 in r["adaptation"]:
-                                others[key][k2] = r["adaptation"][k2]
+                                details[key][k2] = r["adaptation"][k2]
+                                c[k2] = float("%.4g" % r["adaptation"][k2])
+                    others[key] = c
             except Exception as ex:
                 if world > 1:
                     raise
-                others[key] = {"error": str(ex)[:300]}
-        if rank == 0:
-            line["other_configs"] = others
+                others[key] = {"error": str(ex)[:120]}
+                details[key] = {"error": str(ex)[:300]}
     if rank == 0:
+        if others:
+            # the driver stores `roofline` whole: every BASELINE configuration's [proposals/s, fraction of its roof] rides there too
+            line["roofline"]["others"] = {k: [others[k]["value"], others[k]["frac"]] for k in HEADLINE_OTHERS if k in others and "value" in others[k]}
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(*cpu_args)
+        if others:
+            line["other_configs"] = details if a.verbose else others       # LAST key of the line: the tail of stdout holds every configuration
+            try:                                                          # the long form (prose workload strings, every field) beside the line
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, "gpurun_out", "bench_other_configs.json"), "w") as fh:
+                    json.dump(details, fh, indent=1)
+            except OSError:
+                pass
         if a.dump_moments:
             np.asarray(pooled_vec, dtype=np.float64).tofile(a.dump_moments)
         print(json.dumps(line), flush=True)

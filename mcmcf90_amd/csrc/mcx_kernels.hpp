@@ -526,6 +526,9 @@ MCX_DEV double gen_normals_split(Rng &g, double *zs_t, int lane, int d, bool par
             double x1 = odd ? bits_to_uniform(w[j][2], w[j][3]) : bits_to_uniform(w[j][0], w[j][1]);
             double x2 = odd ? bits_to_uniform(w[j + 1][0], w[j + 1][1]) : bits_to_uniform(w[j][2], w[j][3]);
             x1 = 2.0 * x1 - 1.0; x2 = 2.0 * x2 - 1.0;
+#ifdef MCX_PROBE_ALLOK                                             // tools/gen_bound.sh: every attempt accepted (NOT the reference's stream)
+            if (!(x1 * x1 + x2 * x2 < 1.0)) { x1 *= 0.5; x2 *= 0.5; }
+#endif
             const double xx = x1 * x1 + x2 * x2;
             ok[j] = (xx < 1.0) && (xx != 0.0);
             xa[j] = x2; xb[j] = x1;

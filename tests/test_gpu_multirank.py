@@ -130,19 +130,50 @@ def test_two_ranks_under_torchrun(tmp_path):
     assert np.array_equal(np.fromfile(dump, dtype=np.float64).view(np.uint64), m_own.view(np.uint64))
 
 
-def test_bench_falls_back_to_the_host_transport_when_rccl_does_not_form(tmp_path, monkeypatch):
+def test_rccl_failure_is_fatal_unless_the_host_transport_is_allowed(tmp_path, monkeypatch):
     """RCCL has never met N > 1 GPUs in this project's own runs (no node was ever available).  Should its communicator fail to form on the
-    driver's node, bench.py carries the path's latency-sized messages through the shared-memory segment instead and SAYS so in its line
-    (`rccl_error`, `rccl_ranks` 0, the transport named in the workload) rather than producing no scaling point at all.  Simulated here
+    driver's node, bench.py must NOT produce a quiet number: by default the run ends non-zero, prints no JSON line
+    and says why on stderr.  With --allow-host-transport it carries the path's latency-sized messages through the shared-memory segment
+    and SAYS so in its line (`transport` host, `rccl_error`, `rccl_ranks` 0, the transport named in the workload).  Simulated here
     (MCMCX_BENCH_SIMULATE_RCCL_FAILURE): two ranks, the same moments as the plain dry run."""
     args = ["--gpus", "2", "--one-gpu-dryrun", "--steps", "2", "--warmup", "1", "--chains-per-gpu", "1024", "--no-other-configs"]
     plain, m_plain = _bench(args, tmp_path, "plain")
+    assert plain["transport"] == "host" and plain["rccl_ranks"] == 0            # a dry run never claims RCCL either
     monkeypatch.setenv("MCMCX_BENCH_SIMULATE_RCCL_FAILURE", "1")
-    fb, m_fb = _bench(args, tmp_path, "fallback")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MCMCX_COMM_KEY")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=600, env=env)
+    assert p.returncode != 0, "an RCCL failure without --allow-host-transport must end the run non-zero"
+    assert not [l for l in p.stdout.decode().splitlines() if l.startswith("{")], "... and print no JSON line"
+    assert "--allow-host-transport" in p.stderr.decode() and "simulated" in p.stderr.decode()
+    fb, m_fb = _bench(args + ["--allow-host-transport"], tmp_path, "fallback")
     assert "rccl_error" in fb and "simulated" in fb["rccl_error"] and fb["rccl_ranks"] == 0 and "rccl_error" not in plain
+    assert fb["transport"] == "host"
     assert "RCCL did not form" in fb["config"]["workload"] or "RCCL did not form" in json.dumps(fb["config"])
     assert fb["n_gpus"] == 2 and fb["pooled_check"]["chains"] == 2048
     assert np.array_equal(m_fb.view(np.uint64), m_plain.view(np.uint64))
+
+
+def test_the_whole_gpus_n_json_path_with_as_many_ranks_as_the_box_allows(tmp_path):
+    """The complete `bench.py --gpus N` line -- headline configuration AND the N > 1 `other_configs` run (c4 pooled on the same
+    communicator: the collective on the critical path) -- with N = 4 rank processes x 64 chains on the one GPU over the host transport
+    (the GPU box allows six processes on its card: pytest + 4 ranks + the launcher's margin; N = 8 is covered inside one process by
+    test_eight_ranks_in_one_process... and on the host transport without a GPU by tests/test_comm_cpu.py).  The line must say what it is:
+    transport host, rccl_ranks 0, total_chains N x 64, the value of N x 64 chains' proposals -- and the headline's pooled moments must be
+    those of ONE rank with N x 64 chains bit for bit."""
+    world, n = 4, 64
+    common = ["--steps", "2", "--warmup", "1"]
+    many, mN = _bench(common + ["--gpus", str(world), "--one-gpu-dryrun", "--chains-per-gpu", str(n)], tmp_path, "many")
+    one, m1 = _bench(common + ["--gpus", "1", "--chains-per-gpu", str(world * n), "--no-other-configs"], tmp_path, "one")
+    assert many["n_gpus"] == world and many["transport"] == "host" and many["rccl_ranks"] == 0
+    assert many["config"]["total_chains"] == world * n and many["config"]["chains_per_gpu"] == n
+    assert many["pooled_check"]["chains"] == world * n
+    its = 2 * many["config"]["its_per_step"]                       # iteration 1 is the starting point only when warmup = 0
+    assert abs(many["value"] * many["ms_per_step"] * 2e-3 - world * n * its) < 1e-6 * world * n * its, "value x time != the proposals of N x 64 chains"
+    assert np.array_equal(mN.view(np.uint64), m1.view(np.uint64))
+    oc = many["other_configs"]["c4_pooled"]
+    assert oc["rccl_ranks"] == 0 and oc["value"] > 0 and "pooled" in oc["kernel"], oc
+    assert len(json.dumps(oc)) <= 160, "compact entries: the driver keeps the last 2000 characters of stdout"
 
 
 @pytest.mark.parametrize("nranks", [4])   # the GPU box allows 6 processes on its card: pytest + 4 ranks

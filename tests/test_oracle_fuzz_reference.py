@@ -117,32 +117,103 @@ def _svd_dram_against_the_mkl_chain_with_its_logged_factors(oracle, rr, cfg, pro
     return True
 
 
-def _well_posed(oracle, cfg, prob, seed):
-    """Condition number of chaincmat at every iteration where MCMC_adapt may factor it."""
+def _first_ill_posed_tick(oracle, cfg, prob, seed):
+    """The first iteration at which MCMC_adapt may hand LAPACK a covariance it cannot be expected to agree on with itself
+    (None: there is none) -- the condition number of chaincmat at every iteration where MCMC_adapt may factor it."""
     n = prob.npar
     lc = oracle.LiveChain(cfg, prob, chain_id=seed)
-    ok = True
+    bad = None
     step = max(1, min(cfg.adaptint, cfg.badaptint if cfg.badaptint > 0 else cfg.adaptint))
     for it in range(step, cfg.nsimu + 1, step):
         lc.run(it)
         cm = np.ctypeslib.as_array(lc.ch.contents.chaincmat, shape=(n, n)).copy()
         cm = np.triu(cm) + np.triu(cm, 1).T
         if not np.isfinite(cm).all():                          # e.g. a one-row window: covmat divides by wsum - 1 = 0
-            ok = False
+            bad = it
             break
         ev = np.linalg.eigvalsh(cm)
         # Cholesky paths: only what an FP64 dpotrf cannot be expected to agree on with itself (cond > 1e10) is set
         # aside -- cond 1e6 (BASELINE config 5's regime) is well inside what must reproduce.  The SVD paths keep the
         # wider margin: there the singular VECTORS matter, and they turn by O(eps * cond).
         if ev[-1] <= 0 or ev[0] < (1e-6 if cfg.usesvd else 1e-10) * ev[-1]:
-            ok = False
+            bad = it
             break
         # the SVD paths also need distinct singular values: inside a cluster the basis is arbitrary
         if cfg.usesvd and n > 1 and np.min(np.diff(ev)) < 1e-6 * ev[-1]:
-            ok = False
+            bad = it
             break
     lc.close()
-    return ok
+    return bad
+
+
+def _well_posed(oracle, cfg, prob, seed):
+    return _first_ill_posed_tick(oracle, cfg, prob, seed) is None
+
+
+def _agree(r, o, cfg, ckw):
+    """run-length column, stream position, states, sigma2 chain of a reference run and an oracle run"""
+    np.testing.assert_array_equal(r.chain[:, -1].astype(np.int64), o.chain[:, -1].astype(np.int64), err_msg=str(ckw))
+    assert r.rng_n == o.rng_n, ckw
+    scale = np.maximum(np.abs(o.chain[:, :-1]).max(axis=0), 1e-3)
+    assert np.max(np.abs(r.chain[:, :-1] - o.chain[:, :-1]) / scale) < 1e-7, ckw
+    assert r.sschain.shape == o.sschain.shape
+    np.testing.assert_allclose(r.sschain[:, :-1], o.sschain[:, :-1], rtol=1e-7, atol=1e-300)
+    if cfg.updatesigma:
+        assert r.s2chain.shape == o.s2chain.shape
+        np.testing.assert_allclose(r.s2chain, o.s2chain, rtol=1e-7)
+
+
+def _up_to_the_ill_posed_tick(oracle, rr, ckw, cfg, prob, seed, o, bad):
+    """A configuration whose covariance becomes numerically singular (or, on the SVD paths, clustered) at the adaptation of iteration
+    `bad` is not set aside.  What LAPACK makes of that matrix is rounding noise -- but everything UP TO the
+    call is not, and neither is the set of things the reference can do with the answer (MCMC_adapt.F90:167-170, 204-225):
+      (1) the reference's own reaction on the full run is asserted: it completes (dpotrf / dgesvd reported failure -> 'not adapting',
+          old factor kept; or reported success on noise) or it stops in dpotri ('cannot invert cmat') -- nothing else;
+      (2) if it completes and its chain IS the oracle's (both kept the old factor, or the noise did not reach an accept decision), the
+          whole run is compared like a well-posed one;
+      (3) otherwise both sides are cut at nsimu = bad -- the tick is then the run's last act, its factor proposes nothing -- and the
+          run-length column, the stream position, the states AND the covariance handed to the factorisation (mcmccovf.dat against the
+          oracle's chaincmat: same rows, same Welford folds) must agree.
+    Returns 'full' or 'prefix'."""
+    pinned = bool(cfg.usesvd)
+    completed = None
+    try:
+        completed = rr.run_reference(cfg, prob, chain_id=seed, pinned_svd=pinned)
+    except RuntimeError as ex:                                # the program stopped: only dpotri's stop is a legitimate one here
+        assert "cannot invert cmat" in str(ex), "the reference stopped for another reason:\n" + str(ex)[-1500:]
+        assert cfg.dodr, "dpotri is only reached with delayed rejection"
+    if completed is not None:
+        try:
+            _agree(completed, o, cfg, ckw)
+            return "full"
+        except AssertionError:
+            pass
+    ckw2 = dict(ckw, nsimu=int(bad))
+    cfg2 = oracle.make_cfg(**ckw2)
+    o2 = oracle.run_chain(cfg2, prob, chain_id=seed)
+    assert not o2.ram_downdate_fail
+    try:
+        r2 = rr.run_reference(cfg2, prob, chain_id=seed, pinned_svd=pinned)
+    except RuntimeError as ex:
+        # the stop in dpotri comes before the chain files are written: the tick's own iteration cannot be looked at -- one iteration less can
+        assert "cannot invert cmat" in str(ex) and cfg.dodr, str(ex)[-1500:]
+        cfg2 = oracle.make_cfg(**dict(ckw, nsimu=int(bad) - 1))
+        o2 = oracle.run_chain(cfg2, prob, chain_id=seed)
+        r2 = rr.run_reference(cfg2, prob, chain_id=seed, pinned_svd=pinned)
+        _agree(r2, o2, cfg2, ckw)
+        return "prefix"
+    _agree(r2, o2, cfg2, ckw2)
+    # the matrix handed to LAPACK at the tick (upper triangle: covmat fills both, the oracle's record keeps the upper one)
+    cm_o = np.triu(o2.chaincmat) + np.triu(o2.chaincmat, 1).T
+    cm_r = np.triu(r2.chaincmat) + np.triu(r2.chaincmat, 1).T
+    if np.isfinite(cm_o).all():
+        sc = max(np.abs(cm_o).max(), 1e-300)
+        # (with condmax > 0 covtor_svd may have replaced the covariance by U s U' -- the floor bit -- on either side: noise again, not compared)
+        if not cfg.usesvd:
+            assert np.max(np.abs(cm_r - cm_o)) <= 1e-6 * sc, ckw2
+    else:
+        assert not np.isfinite(cm_r).all(), "the oracle's covariance is not finite, the reference's is"
+    return "prefix"
 
 
 @pytest.mark.parametrize("seed", range(400))
@@ -169,9 +240,8 @@ def test_oracle_equals_reference_on_random_configuration(oracle, seed):
         if cfg.usesvd and not cfg.doscam and cfg.method == 0 and os.path.exists(rr.EXE_MKLLOG) and \
                 _svd_dram_against_the_mkl_chain_with_its_logged_factors(oracle, rr, cfg, prob, seed):
             return
-        pytest.skip("a covariance handed to the factorisation is numerically singular (fewer distinct rows than parameters) or, "
-                    "on the SVD paths, has clustered singular values: what LAPACK returns for it is rounding noise, the "
-                    "reference linked to another LAPACK would differ from itself")
+        _up_to_the_ill_posed_tick(oracle, rr, ckw, cfg, prob, seed, o, _first_ill_posed_tick(oracle, cfg, prob, seed))
+        return
     r = rr.run_reference(cfg, prob, chain_id=seed, pinned_svd=bool(cfg.usesvd))
     np.testing.assert_array_equal(r.chain[:, -1].astype(np.int64), o.chain[:, -1].astype(np.int64), err_msg=str(ckw))
     assert r.rng_n == o.rng_n, ckw
@@ -218,10 +288,15 @@ def test_oracle_equals_reference_with_response_columns(oracle, seed):
     cfg = oracle.make_cfg(**ckw)
     prob = oracle.Problem(**pkw)
     o = oracle.run_chain(cfg, prob, chain_id=seed)
-    if o.ram_downdate_fail:
-        pytest.skip("failed RAM downdate: the reference stops there")
-    if cfg.method != 1 and not _well_posed(oracle, cfg, prob, seed):
-        pytest.skip("ill-posed covariance (see above)")
+    if o.ram_downdate_fail:                                   # the reference stops there (matutils.F90:717-722): the run up to the stop is compared
+        cfg, o = _prefix_before_failed_downdate(oracle, rr, ckw, cfg, prob, seed, o)
+        if cfg is None:
+            return
+    if cfg.method != 1:
+        bad = _first_ill_posed_tick(oracle, cfg, prob, seed)
+        if bad is not None:
+            _up_to_the_ill_posed_tick(oracle, rr, ckw, cfg, prob, seed, o, bad)
+            return
     r = rr.run_reference(cfg, prob, chain_id=seed, pinned_svd=bool(cfg.usesvd))
     np.testing.assert_array_equal(r.chain[:, -1].astype(np.int64), o.chain[:, -1].astype(np.int64), err_msg=str(ckw))
     assert r.rng_n == o.rng_n, ckw
