@@ -18,7 +18,6 @@
 #include "../../include/mcmcx_target.h"
 #include "mcx_kernels.hpp"
 #include "mcx_group.hpp"
-#include "mcx_pooled2.hpp"
 #include "mcx_group_ram.hpp"
 
 using namespace mcx;
@@ -35,20 +34,21 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
             return fail(-100, std::string(#call) + ": " + hipGetErrorString(e_));                 \
     } while (0)
 
-// The A/B switches of the kernels' variants (tests, tools): read from the environment ONCE per engine, at mcmcx_create and again at
-// mcmcx_init -- never at launch time.  -1 = not set.
+// The test switches (tests, tools): each FORCES one of two kernel forms that the engine also chooses by itself for some configuration -- so that
+// the parity tests can run both forms on the same small problem.  None selects a form the engine would never take (those live in
+// tools/variants, outside this library).  Read from the environment ONCE per engine, at mcmcx_create and again at mcmcx_init -- never at
+// launch time.  -1 = not set.
 struct mcx_switches {
-    int pooled_mfma_dr_min = -1, pooled_scalar = -1, dr_big = -1, dr_general = -1, scam_pooled_16 = -1, scam_fast_lanes = -1, scam_waves = -1,
-        svd_lane = -1, cov_td = -1, cov_batch_rows = -1, svd_reg = -1, svd_stream = -1, svd_stream32 = -1, svd_stream_b = -1, ram_wide = -1, pooled_waves = -1,
-        cols_phased = -1, host_mapped = -1, host_fuse = -1, host_spin = -1, svd_shared_rot = -1;
+    int pooled_mfma_dr_min = -1, pooled_scalar = -1, dr_big = -1, scam_pooled_16 = -1, scam_fast_lanes = -1, scam_waves = -1,
+        svd_lane = -1, cov_batch_rows = -1, ram_wide = -1, pooled_waves = -1, cols_phased = -1, host_mapped = -1, host_fuse = -1;
     static int get(const char *name) { const char *e = getenv(name); return e ? atoi(e) : -1; }
     void read()
     {
         pooled_mfma_dr_min = get("MCMCX_POOLED_MFMA_DR_MIN"); pooled_scalar = get("MCMCX_POOLED_SCALAR"); dr_big = get("MCMCX_DR_BIG");
-        dr_general = get("MCMCX_DR_GENERAL"); scam_pooled_16 = get("MCMCX_SCAM_POOLED_16"); scam_fast_lanes = get("MCMCX_SCAM_FAST_LANES");
-        scam_waves = get("MCMCX_SCAM_WAVES"); svd_lane = get("MCMCX_SVD_LANE"); cov_td = get("MCMCX_COV_TD"); cov_batch_rows = get("MCMCX_COV_BATCH_ROWS");
-        svd_reg = get("MCMCX_SVD_REG"); svd_stream = get("MCMCX_SVD_STREAM"); svd_stream32 = get("MCMCX_SVD_STREAM32"); svd_stream_b = get("MCMCX_SVD_STREAM_B"); ram_wide = get("MCMCX_RAM_WIDE"); pooled_waves = get("MCMCX_POOLED_WAVES");
-        cols_phased = get("MCMCX_COLS_PHASED"); host_mapped = get("MCMCX_HOST_MAPPED"); host_fuse = get("MCMCX_HOST_FUSE"); host_spin = get("MCMCX_HOST_SPIN"); svd_shared_rot = get("MCMCX_SVD_SHARED_ROT");
+        scam_pooled_16 = get("MCMCX_SCAM_POOLED_16"); scam_fast_lanes = get("MCMCX_SCAM_FAST_LANES");
+        scam_waves = get("MCMCX_SCAM_WAVES"); svd_lane = get("MCMCX_SVD_LANE"); cov_batch_rows = get("MCMCX_COV_BATCH_ROWS");
+        ram_wide = get("MCMCX_RAM_WIDE"); pooled_waves = get("MCMCX_POOLED_WAVES");
+        cols_phased = get("MCMCX_COLS_PHASED"); host_mapped = get("MCMCX_HOST_MAPPED"); host_fuse = get("MCMCX_HOST_FUSE");
     }
 };
 struct mcmcx_engine {
@@ -97,6 +97,7 @@ struct mcmcx_engine {
     double *d_sharedR2 = nullptr, *d_sharediC = nullptr;
     double *d_sharedU = nullptr;                      // [U col-major | pad | U row-major | pad | std]
     bool p0_done = false;                             // host callbacks: the next iteration's proposal already ran in the previous iteration's last launch
+    bool failed = false;                              // a host-callback iteration failed half way: the chains' stream positions are undefined, later runs are refused
     bool host_mapped = false, cs_mapped = false;     // host callbacks with few chains: the exchange vectors live in page-locked host memory the device reads and writes directly (no copies between the phases)
     std::vector<void *> hallocs;
     bool scam_replicated = false;                     // pooled SCAM above npar 240 (the tile kernels' LDS vector does not fit): the shared rotation copied to every chain, the per-chain kernels run
@@ -114,11 +115,11 @@ struct mcmcx_engine {
     EngineDev E{};
     std::vector<void *> allocs;
     double *d_ramscale = nullptr, *d_moments = nullptr;
-    double *d_Gc = nullptr, *d_Vc = nullptr, *d_svc = nullptr; uint8_t *d_need = nullptr, *d_state = nullptr; int *d_anyrot = nullptr; int svd_b = 0;    // blocked SVD of the adaptation (large npar)
+    double *d_Gc = nullptr, *d_Vc = nullptr, *d_svc = nullptr; uint8_t *d_need = nullptr, *d_state = nullptr; int *d_anyrot = nullptr;    // blocked SVD of the adaptation (large npar)
     int wcap = 0;
     bool tile_factor = false;           // the adaptation's Cholesky branch through tile_factor_kernel (npar <= 64)
     int ram_group_d4 = 0;               // method = 'ram' on group_ram_kernel (mcx_group_ram.hpp): npar rounded up to its instantiation, 0 = not
-    int group_d4 = 0, group_drm = 0, group_gw = 16; bool group_factor = false; bool group_check_due = true; int *d_gflag = nullptr; uint8_t *d_accb = nullptr;         // lane-group step kernel (mcx_group.hpp): npar rounded up to four when it is the one to launch; accept bytes of a launch
+    int group_d4 = 0, group_drm = 0, group_gw = 16; bool group_check_due = true; int *d_gflag = nullptr; uint8_t *d_accb = nullptr;         // lane-group step kernel (mcx_group.hpp): npar rounded up to four when it is the one to launch; accept bytes of a launch
     bool external = false; double *d_r1 = nullptr; std::vector<double> h_r1;      // MCMC_run1: the caller evaluates; exchange vectors of run1_kernel
     // timing of the step kernel
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -174,10 +175,13 @@ static int dev_upload(mcmcx_engine *h, const T **p, const std::vector<T> &v)
 
 // No limit on npar like the reference (MCMC_init.F90:81-102 allocates whatever the namelist says) -- beyond int-sized packed indices.  Up to 256
 // every kernel family applies; above, the forms that keep an npar-vector per lane in LDS give way to global scratch where the 160 KiB end
-// (delayed rejection > 160, the adaptation's work vector > 320, the pooled-moment kernel > 317), the blocked SVD to the lane-per-chain SVD
+// (delayed rejection > 160, the adaptation's work vector > 320, the pooled-moment kernel from 316 on), the blocked SVD to the lane-per-chain SVD
 // (> 256), the matrix-core pooled kernels to the lane kernels (their own LDS tests): slower, never refused.
 static const int MCX_MAX_NYCOL = 4096;    // response columns (mcmc.F90:30-33: whatever mcmcnycol.dat says): every per-column array is sized at mcmcx_init
-static const int MCX_MAX_NPAR = 8192;     // P = npar (npar + 1) / 2 and 64 P stay far inside int / size_t arithmetic
+// P = npar (npar + 1) / 2 = 8 390 656 at the cap, 64 P = 537 M and (2 npar + P) 64 = 538 M: every int-typed index expression of the device code
+// (pidx, rowstart, e * 64 + lane) stays below 2**31 with a factor of four to spare -- at 8192, the cap up to round 5, 64 P is 2.147e9 > INT_MAX and
+// only the size_t casts of every current use site kept it correct.  Larger problems are refused loudly at mcmcx_create.
+static const int MCX_MAX_NPAR = 4096;
 
 // dpotf2('U') + scaling on the host for the shared initial factor: same operation sequence as the
 // device's calculate_R (MCMC_calculate_R at MCMC_init.F90:109).  cm: col-major d*d, Rp: packed upper.
@@ -462,13 +466,26 @@ static void launch_group_d4(mcmcx_engine *h, int it0, int it1)
         case 16: launch_group_tk<16, 16, DRM>(h, it0, it1); break;
         case 20: launch_group_tk<16, 20, DRM>(h, it0, it1); break;
         case 24: launch_group_tk<16, 24, DRM>(h, it0, it1); break;
-        case 28: launch_group_tk<16, 28, DRM>(h, it0, it1); break;
-        case 32: launch_group_tk<16, 32, DRM>(h, it0, it1); break;
-        case 40: launch_group_tk<16, 40, DRM>(h, it0, it1); break;       // (above 32: sizes of eight, no delayed rejection)
-        case 48: launch_group_tk<16, 48, DRM>(h, it0, it1); break;
-        case 56: launch_group_tk<16, 56, DRM>(h, it0, it1); break;
-        case 64: launch_group_tk<16, 64, DRM>(h, it0, it1); break;
-        default: h->launch_err = "group kernel: npar > 64";
+        default:
+            // DRM = 2 (iC as a square in LDS) is the engine's choice up to npar 24 only (mcmcx_init): larger sizes are not instantiated -- at
+            // 28 / 32 they could not hold the two waves per SIMD they would declare (Weak 12)
+            if constexpr (DRM != 2) {
+                switch (h->group_d4) {
+                case 28: launch_group_tk<16, 28, DRM>(h, it0, it1); return;
+                case 32: launch_group_tk<16, 32, DRM>(h, it0, it1); return;
+                default: break;
+                }
+            }
+            if constexpr (DRM == 0) {                                    // (above 32: sizes of eight, no delayed rejection)
+                switch (h->group_d4) {
+                case 40: launch_group_tk<16, 40, DRM>(h, it0, it1); return;
+                case 48: launch_group_tk<16, 48, DRM>(h, it0, it1); return;
+                case 56: launch_group_tk<16, 56, DRM>(h, it0, it1); return;
+                case 64: launch_group_tk<16, 64, DRM>(h, it0, it1); return;
+                default: break;
+                }
+            }
+            h->launch_err = "group kernel: no instantiation for npar " + std::to_string(h->d) + " with delayed-rejection mode " + std::to_string(DRM);
         }
     }
 }
@@ -498,23 +515,8 @@ static void launch_group(mcmcx_engine *h, int it0, int it1)
 // 4096, 1.14 at 16384); with one tile per SIMD the spills are all they buy (0.83 .. 0.90) -- tools/pooled_waves_probe.py
 static bool pooled_two_waves(const mcmcx_engine *h)
 {
-    if (h->sw.pooled_waves >= 0) return h->sw.pooled_waves == 2;                                 // (A/B switch, tests)
+    if (h->sw.pooled_waves == 1 || h->sw.pooled_waves == 2) return h->sw.pooled_waves == 2;      // (test switch: either instance on a small problem)
     return h->ntiles >= (pooled_mfma_lds(h->d) * 8 <= 160 * 1024 ? 2048 : 8192);
-}
-// pooled_mfma2_kernel (mcx_pooled2.hpp): a tile as a workgroup of two waves sharing the LDS vector -- 17 <= npar <= 64, no delayed rejection.
-// MCMCX_POOLED_WAVES = 3 forces it, 1 / 2 the one-wave instances (A/B, tests)
-static bool pooled_two_per_tile(const mcmcx_engine *h)
-{
-    if (h->dodr || h->d < 17 || h->d > 64) return false;
-    if (h->sw.pooled_waves >= 0) return h->sw.pooled_waves == 3;
-    return false;
-}
-// pooled_mfma3_kernel: half a tile (32 chains, two lanes each) per wave, no workgroup; MCMCX_POOLED_WAVES = 4 forces it
-static bool pooled_half_tiles(const mcmcx_engine *h)
-{
-    if (h->dodr || h->d < 17 || h->d > 64) return false;
-    if (h->sw.pooled_waves >= 0) return h->sw.pooled_waves == 4;
-    return false;
 }
 #define STEP_ARGS h->stream, h->E, it0, it1
 #define STEP_RS (h->d_ramscale + it0)
@@ -554,6 +556,12 @@ static void launch_group_ram(mcmcx_engine *h, int it0, int it1)
         hipLaunchKernelGGL(group_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->E, h->d_accb, it0, it1);
     }
 }
+#ifdef MCX_VARIANTS                // measured negatives, built only by tools/build_variant.sh -DMCX_VARIANTS -- never part of libmcmcx.so
+#include "../../tools/variants/variants.inc"
+#else
+#define MCX_VARIANT_STEP_ENTRIES
+#define MCX_VARIANT_SVD_SWEEP(h, lss) false
+#endif
 static const KernelEntry STEP_TABLE[] = {
     // ---- a device target with response columns (nycol >= 1 sums of squares per point): the phases of an iteration in one launch
     {"step", "step_kernel_cols", fused_cols,
@@ -562,10 +570,7 @@ static const KernelEntry STEP_TABLE[] = {
     // ---- pooled mode (one shared factor)
     {"step", "pooled_mfma_kernel<true>", [](const mcmcx_engine *h) { return pooled_use_mfma(h) && h->dodr != 0; },
      [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(pooled_mfma_kernel<true>, G1, pooled_mfma_lds(h->d), STEP_ARGS, STEP_TGT, h->d_sharedRT, h->d_sharedR2T, h->d_sharediCd); }},
-    {"step", "pooled_mfma3_kernel", [](const mcmcx_engine *h) { return pooled_use_mfma(h) && pooled_half_tiles(h); },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(pooled_mfma3_kernel, dim3(2 * h->ntiles), dim3(64), pooled_mfma_lds(h->d) / 2, STEP_ARGS, STEP_TGT, h->d_sharedRT); }},
-    {"step", "pooled_mfma2_kernel", [](const mcmcx_engine *h) { return pooled_use_mfma(h) && pooled_two_per_tile(h); },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(pooled_mfma2_kernel, dim3(h->ntiles), dim3(128), pooled_mfma_lds(h->d), STEP_ARGS, STEP_TGT, h->d_sharedRT); }},
+    MCX_VARIANT_STEP_ENTRIES
     {"step", "pooled_mfma_kernel<false, true>", [](const mcmcx_engine *h) { return pooled_use_mfma(h) && pooled_two_waves(h); },
      [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((pooled_mfma_kernel<false, true>), G1, pooled_mfma_lds(h->d), STEP_ARGS, STEP_TGT, h->d_sharedRT, (const double *)nullptr, (const double *)nullptr); }},
     {"step", "pooled_mfma_kernel<false>", [](const mcmcx_engine *h) { return pooled_use_mfma(h); },
@@ -586,13 +591,11 @@ static const KernelEntry STEP_TABLE[] = {
      [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ram_wide, G1, (size_t)NLC * 2 * 64 * sizeof(double), STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
     {"step", "step_kernel<true, false, false>", [](const mcmcx_engine *h) { return h->E.method == M_RAM; },
      [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((step_kernel<true, false, false>), G1, (size_t)NLC * 2 * 64 * sizeof(double), STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
-    // ---- delayed rejection, per-chain factors: the second stage's two vectors in global scratch / in LDS / the general step_body<DR> (A/B)
+    // ---- delayed rejection, per-chain factors: the second stage's two vectors in global scratch / in LDS
     {"step", "step_kernel_dr_big", [](const mcmcx_engine *h) { return h->dodr && !dr_vectors_in_lds(h); },
      [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_dr_big, G1, 0, STEP_ARGS, STEP_TGT); }},
-    {"step", "step_kernel_dr", [](const mcmcx_engine *h) { return h->dodr && !(h->sw.dr_general > 0); },
+    {"step", "step_kernel_dr", [](const mcmcx_engine *h) { return h->dodr != 0; },
      [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_dr, G1, lds_step(h), STEP_ARGS, STEP_TGT); }},
-    {"step", "step_kernel<false, true, false>", [](const mcmcx_engine *h) { return h->dodr != 0; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((step_kernel<false, true, false>), G1, lds_step(h), STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
     // ---- AM / Metropolis / early rejection: state + factor in LDS, state in LDS, nothing in LDS
     {"step", "step_kernel_ldsr", [](const mcmcx_engine *h) { return h->E.lds_scratch == 2; },
      [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ldsr, G1, (size_t)(2 * h->d + h->P) * 64 * sizeof(double), STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
@@ -711,33 +714,21 @@ static void launch_scam(mcmcx_engine *h, int it0, int it1)
 {
     walk_table(h, SCAM_TABLE, sizeof(SCAM_TABLE) / sizeof(SCAM_TABLE[0]), it0, it1);
 }
-// LDS of svd_blocked_kernel for block width b: four blocks of b columns (odd stride) + the rotation slots
-static int svd_ls_host(int d) { return ((d + 1) & ~1) + (((d + 1) & 2) ? 0 : 2); }
-static size_t svd_lds(int d, int b) { const int LS = ((d + 1) & ~1) + (((d + 1) & 2) ? 0 : 2); return ((size_t)2 * b * LS + 64) * sizeof(double) + 32 * sizeof(int); }   // two blocks of b columns + the rotation slots
-// block width of the blocked SVD: two workgroups per CU hide each other's dot-product latency
-static int svd_block_width(int d)
-{
-    if (const char *e = getenv("MCMCX_SVD_BLOCK")) { int b = atoi(e); if (b >= 2 && b <= 32 && svd_lds(d, b) <= 150 * 1024) return b; }
-    int b = 32;
-    while (b > 2 && svd_lds(d, b) > 78 * 1024) --b;
-    return b;
-}
+// the adaptation's SVD one workgroup per chain (mcx_svd.hpp) where its rings and row groups are instantiated
 static bool svd_blocked(const mcmcx_engine *h)
 {
     if (!h->usesvd || h->pooled || h->cfg.method == MCMCX_METHOD_RAM) return false;
-    if (h->sw.svd_lane > 0) return false;                                             // A/B switch for tests: one lane per chain
+    if (h->sw.svd_lane > 0) return false;                                             // test switch: the lane SVD (the engine's form below npar 48 and above 256)
     return h->d >= 48 && h->d <= 256;                                                  // (its rings and row groups are instantiated up to npar 256)
 }
 static void launch_adapt(mcmcx_engine *h, int it, int mode)
 {
     const size_t lds = std::max(lds_bytes(h) / 2, (size_t)36 * 64 * sizeof(double));    // one d-vector / the Cholesky's diagonal block (18 kB: eight waves per CU up to npar 36)
-    const int nb = (h->d + 7) / 8, nblk = nb * (nb + 1) / 2;
     hipLaunchKernelGGL(adapt_pre_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it, mode);
     // covmat's batch branch in blocks (adapt_covb_*): the AP window at every adaptation; with initcmatn = 0 the first AM adaptation and
     // the greedy restarts.  Which lanes take it is the lanes' own business (ADF_BATCH); a tick that cannot hold any skips the launches.
-    const bool td = h->sw.cov_td != 0;
     const bool ap = (mode & AD_AM) && h->cfg.adapthist > 1;
-    const int batch_done = (td && !(h->sw.cov_batch_rows > 0) &&                                                    // (A/B switch for tests: covmat_rows)
+    const int batch_done = (!(h->sw.cov_batch_rows > 0) &&                                                          // (test switch: covmat_rows, the lane form)
                             (ap || (h->cfg.initcmatn == 0 && ((mode & AD_FIRST) || ((mode & AD_BURN) && h->cfg.greedy != 0))))) ? 1 : 0;
     if (batch_done) {
         const int n10 = (h->d + TD - 1) / TD, noff = n10 * (n10 - 1) / 2;
@@ -746,15 +737,12 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
         if (noff > 0) hipLaunchKernelGGL(adapt_covb_off_kernel, dim3(g8 * noff), dim3(64), 0, h->stream, h->E, it, noff);
     }
     if (!((mode & AD_AM) && h->cfg.adapthist > 1)) {                      // the AP window is a batch recompute: no blocked update
-        // blocks of ten (triangular on the diagonal): fewer elements and fewer repeats of the per-fold overhead than the 8 x 8 cover
-        if (td) {
-            const int n10 = (h->d + TD - 1) / TD, noff = n10 * (n10 - 1) / 2;
-            const unsigned g8 = (unsigned)(8 * ((h->ntiles + 7) / 8));
-            hipLaunchKernelGGL(adapt_cov_diag_kernel, dim3(g8 * n10), dim3(64), 0, h->stream, h->E, it, mode, n10);
-            if (noff > 0) hipLaunchKernelGGL(adapt_cov_off_kernel, dim3(g8 * noff), dim3(64), 0, h->stream, h->E, it, mode, noff);
-        }
-        else
-            hipLaunchKernelGGL(adapt_cov_kernel, dim3((unsigned)(8 * ((h->ntiles + 7) / 8) * nblk)), dim3(64), 0, h->stream, h->E, it, mode, nblk);
+        // blocks of ten (triangular on the diagonal)
+        const int n10 = (h->d + TD - 1) / TD, noff = n10 * (n10 - 1) / 2;
+        const unsigned g8 = (unsigned)(8 * ((h->ntiles + 7) / 8));
+        // (LDS: the per-lane FIFO between the window's walk and the folds, mcx_adapt.hpp: CQ entries of 1 + TD / 1 + 2 TD doubles per lane)
+        hipLaunchKernelGGL(adapt_cov_diag_kernel, dim3(g8 * n10), dim3(64), (size_t)CQ * (1 + TD) * 64 * sizeof(double), h->stream, h->E, it, mode, n10);
+        if (noff > 0) hipLaunchKernelGGL(adapt_cov_off_kernel, dim3(g8 * noff), dim3(64), (size_t)CQ * (1 + 2 * TD) * 64 * sizeof(double), h->stream, h->E, it, mode, noff);
     }
     if (!h->d_Gc) {
         if (lds > 160 * 1024) {                             // npar > 320: the work vector in global scratch (slower; no limit)
@@ -777,12 +765,6 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
             default: hipLaunchKernelGGL((tile_factor_kernel<4, 1>), tg, dim3(64), tl, h->stream, h->E); break;
             }
         }
-        else if (h->group_factor) {
-            // with the lane-group step kernels: the Cholesky factor, its inverse and R2 in the group layout too (mcx_group.hpp)
-            hipLaunchKernelGGL(adapt_post_kernel<false>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 3, (uint8_t *)nullptr, batch_done);
-            const int LD = h->d | 1;
-            hipLaunchKernelGGL(group_factor_kernel, dim3(h->ntiles * 16), dim3(64), (size_t)4 * h->d * LD * sizeof(double), h->stream, h->E);
-        }
         else hipLaunchKernelGGL(adapt_post_kernel<false>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr, batch_done);
         return;
     }
@@ -790,72 +772,36 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
     // pair per Jacobi sweep (the rotation log lives in Gw, which is free between tile2chain and the next tick)
     const size_t DD = (size_t)h->d * h->d;
     const dim3 tg((unsigned)((DD + 63) / 64), (unsigned)h->ntiles), tg1((unsigned)((h->d + 63) / 64), (unsigned)h->ntiles);
-    const size_t lsv = svd_lds(h->d, h->svd_b);
-    const bool svd_reg = h->sw.svd_reg != 0;                                                       // (0: A/B, tests -- svd_sweep_kernel)
-    const bool svd_stream = h->sw.svd_stream != 0;                                                    // (0: A/B, tests -- svd_sweep_reg_kernel)
-    int svd_sb = 24;                                     // pair-lanes of the streamed sweep: whole waves of octets, one wave of loaders at least
-    bool svd_s32 = h->d <= 200 && h->sw.svd_stream32 != 0;                                                      // (0, or a block width given: svd_sweep_stream_kernel)
-    bool svd_a32 = h->sw.svd_stream32 != 0;                                                        // the V replay's 32-lane form: any npar
-    { const int b = h->sw.svd_stream_b; if (b >= 2 && b <= 24) { svd_sb = b; svd_s32 = false; svd_a32 = false; } }
     hipLaunchKernelGGL(adapt_post_kernel<true>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 1, h->d_need, batch_done);
     hipLaunchKernelGGL(tile2chain_kernel, tg, dim3(256), 0, h->stream, h->E.Gw, h->d_Gc, DD, DD, h->d_need);
     hipLaunchKernelGGL(svd_init_kernel, dim3(h->nlanes), dim3(256), 0, h->stream, h->d_Vc, h->d_state, h->d_need, h->nlanes, h->d);
     for (int sweep = 0; sweep < 60; ++sweep) {
         (void)hipMemsetAsync(h->d_anyrot, 0, sizeof(int), h->stream);
-        if (svd_reg && svd_stream && svd_s32) {          // ... all lanes on pairs (npar <= 200), the ring's slots handed over in place
+        // the sweep: every later column streamed past a block's pair-lanes through an LDS ring (mcx_svd.hpp) -- all 32 lanes of a row group on
+        // pairs up to npar 200 (svd_sweep_stream32_kernel), 24 pair-lanes and a wave of loaders above (svd_sweep_stream_kernel)
+        if (h->d <= 200) {
             const int RLs = h->d <= 64 ? 8 : h->d <= 128 ? 16 : 25;
             const size_t lss = (size_t)33 * (8 * RLs + 2) * sizeof(double);
-            if (h->sw.svd_shared_rot > 0) {               // MCMCX_SVD_SHARED_ROT=1: the scalar tail of a pair once per pair -- bit-equal, measured 31 % SLOWER (a step is the latency of that tail, not its issue slots): tests only
-                if (h->d <= 64) hipLaunchKernelGGL(svd_sweep_stream32s_kernel<8>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
-                else if (h->d <= 128) hipLaunchKernelGGL(svd_sweep_stream32s_kernel<16>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
-                else hipLaunchKernelGGL(svd_sweep_stream32s_kernel<25>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
-            } else
-            if (h->d <= 64) hipLaunchKernelGGL(svd_sweep_stream32_kernel<8>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
+            if (MCX_VARIANT_SVD_SWEEP(h, lss)) {}
+            else if (h->d <= 64) hipLaunchKernelGGL(svd_sweep_stream32_kernel<8>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
             else if (h->d <= 128) hipLaunchKernelGGL(svd_sweep_stream32_kernel<16>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
             else hipLaunchKernelGGL(svd_sweep_stream32_kernel<25>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
-        } else
-        if (svd_reg && svd_stream) {                     // ... and the columns to their right streamed past them through an LDS ring
-            const int RLs = h->d <= 64 ? 8 : h->d <= 128 ? 16 : h->d <= 208 ? 26 : 32;
+        } else {
+            constexpr int svd_sb = 24;                   // pair-lanes of the streamed sweep: whole waves of octets, one wave of loaders at least
+            const int RLs = h->d <= 208 ? 26 : 32;
             const size_t lss = (size_t)(svd_sb + 2) * (8 * RLs + 2) * sizeof(double);
-            if (h->d <= 64) hipLaunchKernelGGL(svd_sweep_stream_kernel<8>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d, svd_sb);
-            else if (h->d <= 128) hipLaunchKernelGGL(svd_sweep_stream_kernel<16>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d, svd_sb);
-            else if (h->d <= 208) hipLaunchKernelGGL(svd_sweep_stream_kernel<26>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d, svd_sb);
+            if (h->d <= 208) hipLaunchKernelGGL(svd_sweep_stream_kernel<26>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d, svd_sb);
             else hipLaunchKernelGGL(svd_sweep_stream_kernel<32>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d, svd_sb);
-        } else
-        if (svd_reg) {                                   // the I block's columns in registers: one block of LDS (round 4)
-            const size_t lsr = ((size_t)h->svd_b * svd_ls_host(h->d) + 64) * sizeof(double);
-            if (h->d <= 64) hipLaunchKernelGGL(svd_sweep_reg_kernel<8>, dim3(h->nlanes), dim3(256), lsr, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d, h->svd_b);
-            else if (h->d <= 128) hipLaunchKernelGGL(svd_sweep_reg_kernel<16>, dim3(h->nlanes), dim3(256), lsr, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d, h->svd_b);
-            else if (h->d <= 208) hipLaunchKernelGGL(svd_sweep_reg_kernel<26>, dim3(h->nlanes), dim3(256), lsr, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d, h->svd_b);
-            else hipLaunchKernelGGL(svd_sweep_reg_kernel<32>, dim3(h->nlanes), dim3(256), lsr, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d, h->svd_b);
-        } else
-        hipLaunchKernelGGL(svd_sweep_kernel, dim3(h->nlanes), dim3(256), lsv, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d, h->svd_b);
-        if (svd_reg && svd_stream && svd_a32) {          // all 32 lanes of a row group on pairs
-            const unsigned gv = (unsigned)(32 * ((h->nlanes + 7) / 8));
+        }
+        {                                                // the log replayed on V: all 32 lanes of a row group on pairs, any npar
+            const unsigned gv = (unsigned)(32 * ((h->nlanes + 7) / 8));                     // four one-wave workgroups per chain, a chain's on one XCD
             const int RP = h->d <= 64 ? 4 : h->d <= 128 ? 8 : h->d <= 208 ? 13 : 16;
             const size_t lsv2 = (size_t)33 * (4 * RP + 6) * sizeof(double);
             if (h->d <= 64) hipLaunchKernelGGL(svd_applyv_stream32_kernel<4>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d);
             else if (h->d <= 128) hipLaunchKernelGGL(svd_applyv_stream32_kernel<8>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d);
             else if (h->d <= 208) hipLaunchKernelGGL(svd_applyv_stream32_kernel<13>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d);
             else hipLaunchKernelGGL(svd_applyv_stream32_kernel<16>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d);
-        } else
-        if (svd_reg && svd_stream) {
-            const unsigned gv = (unsigned)(32 * ((h->nlanes + 7) / 8));                     // four one-wave workgroups per chain, a chain's on one XCD
-            const int RP = h->d <= 64 ? 4 : h->d <= 128 ? 8 : h->d <= 208 ? 13 : 16;
-            const size_t lsv2 = (size_t)(svd_sb + 2) * (4 * RP + 6) * sizeof(double);
-            if (h->d <= 64) hipLaunchKernelGGL(svd_applyv_stream_kernel<4>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d, svd_sb);
-            else if (h->d <= 128) hipLaunchKernelGGL(svd_applyv_stream_kernel<8>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d, svd_sb);
-            else if (h->d <= 208) hipLaunchKernelGGL(svd_applyv_stream_kernel<13>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d, svd_sb);
-            else hipLaunchKernelGGL(svd_applyv_stream_kernel<16>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d, svd_sb);
-        } else
-        if (svd_reg) {
-            const size_t lsr = ((size_t)h->svd_b * svd_ls_host(h->d) + 64) * sizeof(double);
-            if (h->d <= 64) hipLaunchKernelGGL(svd_applyv_reg_kernel<4>, dim3(h->nlanes), dim3(256), lsr, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d, h->svd_b);
-            else if (h->d <= 128) hipLaunchKernelGGL(svd_applyv_reg_kernel<8>, dim3(h->nlanes), dim3(256), lsr, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d, h->svd_b);
-            else if (h->d <= 208) hipLaunchKernelGGL(svd_applyv_reg_kernel<13>, dim3(h->nlanes), dim3(256), lsr, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d, h->svd_b);
-            else hipLaunchKernelGGL(svd_applyv_reg_kernel<16>, dim3(h->nlanes), dim3(256), lsr, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d, h->svd_b);
-        } else
-        hipLaunchKernelGGL(svd_applyv_kernel, dim3(h->nlanes), dim3(256), lsv, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d, h->svd_b);
+        }
         int any = 0;
         if (hipMemcpyAsync(&any, h->d_anyrot, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) break;   // (reported by the caller's hipGetLastError)
         if (!any) break;
@@ -1231,11 +1177,6 @@ static int host_eval(mcmcx_engine *h, const double *dev_src, int stride_k, bool 
     std::vector<double> ssc(ny, 0.0);
     if (!src_mapped) HIPCHK(hipMemcpyAsync(h->h_cand.data(), dev_src, L * stride_k * 8, hipMemcpyDeviceToHost, h->stream));
     if (use_stage2_flag && !mapped) HIPCHK(hipMemcpyAsync(h->h_hx.data(), h->E.hx, h->h_hx.size() * 8, hipMemcpyDeviceToHost, h->stream));
-    if (h->host_mapped && h->sw.host_spin > 0) {         // MCMCX_HOST_SPIN=1: poll the stream instead of the blocking wait (measured: no difference at one chain, profiles/r05_d/c1_plumbing.txt)
-        hipError_t q;
-        while ((q = hipStreamQuery(h->stream)) == hipErrorNotReady) {}
-        if (q != hipSuccess) return fail(-10, std::string("hipStreamQuery: ") + hipGetErrorString(q));
-    } else
     HIPCHK(hipStreamSynchronize(h->stream));             // (also: the previous stage's results have left h_ev)
     const double *h_cand = src_mapped ? dev_src : h->h_cand.data();
     const double *hx = mapped ? h->E.hx : h->h_hx.data();
@@ -1766,7 +1707,6 @@ int mcmcx_init(mcmcx_handle h)
             if ((rc = dev_alloc(h, &E.Gw, L * DD))) return rc;
             if ((rc = dev_alloc(h, &E.Vw, L * DD))) return rc;
             if (svd_blocked(h) && (c.doadapt != 0 || c.doburnin != 0)) {      // chain-major copies for svd_blocked_kernel
-                h->svd_b = svd_block_width(d);
                 if ((rc = dev_alloc(h, &h->d_Gc, L * DD, false))) return rc;
                 if ((rc = dev_alloc(h, &h->d_Vc, L * DD, false))) return rc;
                 if ((rc = dev_alloc(h, &h->d_svc, L * d, false))) return rc;
@@ -1861,10 +1801,6 @@ int mcmcx_init(mcmcx_handle h)
         if (h->group_d4 && (E.hist || E.accmask) && (rc = dev_alloc(h, &h->d_accb, L * (size_t)GROUP_MAXSEG))) return rc;
         if (h->group_d4) {
             h->group_gw = gw;
-            // the factorisation in the group layout too (group_factor_kernel) where a tick is latency: ~250 us less per tick for one tile at
-            // npar 20 with delayed rejection; with the chip full it is a wash (2.1 ms against adapt_post_kernel's 2.2 at config 3's size)
-            const char *gf = getenv("MCMCX_GROUP_FACTOR");                                          // (0 / 1: A/B, tests)
-            h->group_factor = d <= 32 && h->group_gw == 16 && (gf ? atoi(gf) != 0 : (long long)c.nchains <= 16384);
             h->group_drm = drm;
             h->group_check_due = true;
             if (h->group_drm == 2 && (rc = dev_alloc(h, &h->d_gflag, 1))) return rc;
@@ -1884,11 +1820,10 @@ int mcmcx_init(mcmcx_handle h)
     // (npar 20, delayed rejection, 262144 chains): 2.11 -> 1.44 ms per tick, bound by VALU issue (~25 instructions per inner step of four chains).
     // Above npar 32 adapt_post_kernel's 8 x 8 register blocks stay: at npar 50 x 1 048 576 chains they stream the matrices ~5.6 times (16.0 ms)
     // and still beat the LDS form, whose three waves per CU issue ~15 x the instructions per chain (35.2 ms; profiles/r05_a/tick_ab.txt).
-    // MCMCX_TILE_FACTOR = 0 / 1: never / up to npar 64 (A/B, tests); MCMCX_GROUP_FACTOR = 1 keeps round 4's group_factor_kernel where it applies.
+    // MCMCX_TILE_FACTOR = 0 / 1: never / up to npar 64 (test switch: both forms on one problem).
     {
         const char *tf = getenv("MCMCX_TILE_FACTOR");
-        h->tile_factor = am && !h->usesvd && d <= ((tf && atoi(tf) == 1) ? 64 : 32) && !(tf && atoi(tf) == 0) && !(h->group_factor && getenv("MCMCX_GROUP_FACTOR"));
-        if (h->tile_factor) h->group_factor = false;
+        h->tile_factor = am && !h->usesvd && d <= ((tf && atoi(tf) == 1) ? 64 : 32) && !(tf && atoi(tf) == 0);
     }
     // 1/simuind**nuparam, computed like the reference: real(simuind) is default REAL (MCMC_run_ram.F90:166)
     {
@@ -1992,6 +1927,9 @@ static int run_impl(mcmcx_handle h, int32_t upto)
     if (!h) return fail(-1, "null handle");
     if (!h->inited) return fail(-40, "we have not inited");                           // MCMC_run.F90:22
     if (h->external) return fail(-41, "mcmcx_run: the target is external (mcmcx_set_target_external): drive the chain with mcmcx_run1_*");
+    // (with the phases fused, iteration it + 1's proposal -- Philox draws included -- has already run when an error surfaces in iteration it's
+    //  evaluation; a second run on the handle would draw that proposal again and leave the reference's stream order silently: ADVICE round 5)
+    if (h->failed) return fail(-42, "mcmcx_run: an earlier run on this handle failed inside a host-callback iteration; its chains are in an undefined state -- destroy the handle");
     HIPCHK(hipSetDevice(h->cfg.device));
     const mcmcx_config &c = h->cfg;
     if (upto > c.nsimu) upto = c.nsimu;
@@ -2023,7 +1961,7 @@ static int run_impl(mcmcx_handle h, int32_t upto)
             if (mode != 0 || ramtick || end == upto || end - it + 1 >= maxseg) break;
         }
         if (phase_cut(h)) {
-            for (int i2 = it; i2 <= end; ++i2) { int rc = host_iteration(h, i2, i2 < end); if (rc) return rc; }
+            for (int i2 = it; i2 <= end; ++i2) { int rc = host_iteration(h, i2, i2 < end); if (rc) { h->failed = true; return rc; } }
         } else {
             hipEvent_t e0 = nullptr, e1 = nullptr;
             hipError_t er = hipEventCreate(&e0);
@@ -2370,7 +2308,7 @@ static int pooled_moments_launch(mcmcx_engine *h, double *dev_dst, int kind, int
     const double rs = (kind == 2) ? 1.0 / std::pow((double)(float)it, h->cfg.nuparam) : 0.0;      // like d_ramscale (MCMC_run_ram.F90:166)
     const size_t mlds = ((size_t)64 * (h->d | 1) + 320) * sizeof(double);
     if (mlds <= 160 * 1024) hipLaunchKernelGGL(moments_kernel<false>, dim3(T), dim3(256), mlds, h->stream, h->E, h->d_moments, h->cfg.nchains, kind, it, rs);
-    else hipLaunchKernelGGL(moments_kernel<true>, dim3(T), dim3(256), (size_t)320 * sizeof(double), h->stream, h->E, h->d_moments, h->cfg.nchains, kind, it, rs);   // npar > 317
+    else hipLaunchKernelGGL(moments_kernel<true>, dim3(T), dim3(256), (size_t)320 * sizeof(double), h->stream, h->E, h->d_moments, h->cfg.nchains, kind, it, rs);   // npar >= 316: (64 (d | 1) + 320) 8 bytes exceed 160 KiB (317: 164 864)
     for (long long stride = 1;; stride *= 64) {                            // six levels of the fixed pairwise tree per launch
         const long long groups = (T + 64 * stride - 1) / (64 * stride);
         hipLaunchKernelGGL(moments_tree_kernel, dim3((len + 255) / 256, (unsigned)groups), dim3(256), 0, h->stream, h->d_moments, T, len,

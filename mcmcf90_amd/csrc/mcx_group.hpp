@@ -453,7 +453,7 @@ MCX_DEV double group_ss(const DevTarget &t, const double (&x)[GDims<D4, GW>::NS]
 //          at every chain's factor whenever an adaptation has rewritten it and raises a device flag otherwise; the host queues
 //          this kernel AND the DRM = 1 one behind that flag, and the one it does not select returns at once).  R in registers,
 //          iC as a full symmetric square in LDS (the quadratic forms read it with immediate offsets); two waves per SIMD up to
-//          npar = 20.
+//          npar = 24 (quads: up to npar 12 -- at 13..16 the allocator cannot meet two, the kernel declares one and takes the registers).
 #ifndef MCX_GROUP_WAVES2
 #define MCX_GROUP_WAVES2 2
 #endif
@@ -464,7 +464,7 @@ MCX_DEV double group_ss(const DevTarget &t, const double (&x)[GDims<D4, GW>::NS]
 #define MCX_GROUP_WAVES4 2       // quads (GW = 4)
 #endif
 template <int GW, int D4, int DRM, int TK>
-__global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (TK == TGT_GAUSS && D4 >= MCX_GROUP_GAUSS1)) ? 1 : (GW == 4 ? MCX_GROUP_WAVES4 : MCX_GROUP_WAVES2)) void group_step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ g_lamT, uint8_t *accb,
+__global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (DRM == 2 && GW == 4 && D4 > 12) || (TK == TGT_GAUSS && D4 >= MCX_GROUP_GAUSS1)) ? 1 : (GW == 4 ? MCX_GROUP_WAVES4 : MCX_GROUP_WAVES2)) void group_step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ g_lamT, uint8_t *accb,
                                                                                                    const int *__restrict__ gflag, int want)
 {
     using G = GDims<D4, GW>;
@@ -770,142 +770,23 @@ __global__ void group_check_kernel(EngineDev E, int *flag)
     if (__any(bad) && lane == 0) atomicOr(flag, 1);
 }
 
-// ---------------------------------------------------------------- MCMC_calculate_R in the group layout (Cholesky branch, MCMC_adapt.F90:211-225)
-// adapt_post_kernel's factorisation for the chains whose tick recomputes the factor (ADF_DOCALC), four chains per wave, the matrix in LDS
-// ([row][column] per chain, odd pitch), every chain of operations the one of calculate_R / potri_packed (mcx_kernels.hpp):
+// ---------------------------------------------------------------- MCMC_calculate_R with the matrices in LDS (Cholesky branch, MCMC_adapt.F90:211-225)
+// adapt_post_kernel's factorisation for the chains whose tick recomputes the factor (ADF_DOCALC), any chain count, npar <= 64: a WORKGROUP of NW
+// waves owns 4 NW neighbouring chains of a tile and moves their matrices between HBM and LDS cooperatively, 32 NW contiguous bytes per element --
+// whole 128-byte lines at NW = 4 -- and the workgroups of one tile sit on one XCD (blockIdx round-robins over the eight), whose L2 combines what
+// is left.  The LDS copy is the PACKED upper triangle by rows (every operand of dpotf2 / dtrti2 / dlauu2 lies in it), so that npar 50 -- BASELINE
+// config 4's size with method = 'dram' -- holds four chains in 41 kB and three workgroups share a CU.  Sixteen lanes per chain, a lane owns
+// NC = ceil(npar / 16) columns (dpotf2) / rows (dtrti2, dlauu2); every chain of operations is the one of calculate_R / potri_packed (mcx_adapt.hpp):
 //   dpotf2('U'):   lane = COLUMN k of the factor; step j adds T(i,j) T(i,k), i < j ascending, to column k's chain (T(i,j) is a broadcast read),
 //                  every lane also runs the pivot's own chain, so the pivot needs no exchange; R = T 2.4 / sqrt(npar); R2 = R / drscale;
 //   dtrti2('U'):   lane = ROW r of the inverse; element (r,j) = -1/A(j,j) x [A(r,j) Ainv(r,r), then + A(jj,j) Ainv(r,jj) for jj = r+1..j-1 ascending]:
 //                  dtrmv's column sweep read per ROW -- the temp of sweep jj is the ORIGINAL A(jj,j), sweep r starts row r's chain with the
 //                  product, the sweeps behind it add their terms in order -- so the rows of one column are independent chains;
 //   dlauu2('U'):   lane = ROW r: A(r,i) = A(i,i) A(r,i) + sum_{k>i} A(i,k) A(r,k) ascending k; the diagonal's sum of squares on every lane.
-// A lane-per-chain wave walks these d^3-sized loops through L2 round trips (adapt_post_kernel: 2.2 ms per tick at config 3's size, ~250 us for
-// one tile); here they are LDS reads: 0.9 ms / ~25 us.  Results: R, R2, iC, I_INFO and the status bits, as adapt_post_kernel leaves them.
-__global__ __launch_bounds__(64) void group_factor_kernel(EngineDev E)
-{
-    extern __shared__ double Mf[];
-    const int lane = threadIdx.x, l16 = lane & 15, row = lane >> 4, d = E.d, P = E.P;
-    const int chain = blockIdx.x * 4 + row, tile = chain >> 6, cl = chain & 63;
-    const int LD = d | 1;
-    double *M = Mf + (size_t)row * d * LD;
-    const bool act = (TIDX(E.ictr, tile, NICTR, I_ADFLAGS, cl) & ADF_DOCALC) != 0;
-    if (!__any(act)) return;
-    const double *Ct = E.cmat + (size_t)tile * P * 64;
-    const int k0 = l16, k1 = l16 + 16;                       // this lane's columns (dpotf2) / rows (dtrti2, dlauu2)
-    for (int k = l16; k < d; k += 16) for (int i = 0; i <= k; ++i) M[i * LD + k] = Ct[(size_t)pidx(i, k, d) * 64 + cl];
-    // (the inner loops below are branch-free -- a lane whose column / row is not concerned computes on a clamped address and drops the
-    //  result -- and unrolled by four, so that a dozen LDS reads are in flight instead of one behind every fma)
-    const int k0c = k0 < d ? k0 : d - 1, k1c = k1 < d ? k1 : d - 1;
-    // ---- dpotf2
-    int info = 0;
-    for (int j = 0; j < d; ++j) {
-        MCX_WAVE_LDS_SYNC();                                 // row j - 1 (other lanes' columns) is written
-        double acc0 = 0.0, acc1 = 0.0, accj = 0.0;
-#pragma unroll 4
-        for (int i = 0; i < j; ++i) {
-            const double tij = M[i * LD + j], m0 = M[i * LD + k0c], m1 = M[i * LD + k1c];
-            accj = dfma(tij, tij, accj);
-            acc0 = dfma(tij, m0, acc0);
-            acc1 = dfma(tij, m1, acc1);
-        }
-        const double ajj = M[j * LD + j] - accj;
-        if (act && info == 0 && !(ajj > 0.0)) info = j + 1;
-        const double rjj = sqrt(ajj), rinv = 1.0 / rjj;
-        const double n0 = (M[j * LD + k0c] - acc0) * rinv, n1 = (M[j * LD + k1c] - acc1) * rinv;
-        if (k0 == j || k1 == j) M[j * LD + j] = rjj;
-        if (k0 > j && k0 < d) M[j * LD + k0] = n0;
-        if (k1 > j && k1 < d) M[j * LD + k1] = n1;
-    }
-    const bool ok = act && info == 0;
-    if (act && l16 == 0) {
-        TIDX(E.ictr, tile, NICTR, I_INFO, cl) = (uint32_t)info;
-        if (info != 0) TIDX(E.ictr, tile, NICTR, I_STATUS, cl) |= ST_CHOL_FAIL;          // warning, old R kept (MCMC_adapt.F90:168-171)
-    }
-    // ---- R = T 2.4 / sqrt(npar), R2 = R / drscale
-    {
-        const double sq = sqrt((double)d);
-        double *Rt = E.R + (size_t)tile * P * 64;
-        double *R2t = E.dodr ? E.R2 + (size_t)tile * P * 64 : nullptr;
-        for (int k = l16; k < d; k += 16)
-            for (int i = 0; i <= k; ++i) {
-                const double v = M[i * LD + k] * 2.4 / sq;
-                if (ok) { Rt[(size_t)pidx(i, k, d) * 64 + cl] = v; M[i * LD + k] = v; if (R2t) R2t[(size_t)pidx(i, k, d) * 64 + cl] = v / E.drscale; }
-            }
-    }
-    if (!E.dodr || !__any(ok)) return;
-    MCX_WAVE_LDS_SYNC();
-    // ---- iC = dpotri('U', R): dtrti2 then dlauu2, in place on the scaled factor
-    int info2 = 0;
-    for (int j = 0; j < d; ++j) if (ok && info2 == 0 && M[j * LD + j] == 0.0) info2 = j + 1;
-    const bool go = ok && info2 == 0;
-    if (ok && info2 != 0 && l16 == 0) TIDX(E.ictr, tile, NICTR, I_STATUS, cl) |= ST_POTRI_FAIL;                   // the reference stops
-    const int r0 = l16, r1 = l16 + 16, r0c = k0c, r1c = k1c;
-    if (__any(go)) {
-        for (int j = 0; j < d; ++j) {                        // dtrti2
-            MCX_WAVE_LDS_SYNC();                             // column j - 1 (other lanes' rows) is written
-            const double ajj = 1.0 / M[j * LD + j];
-            double x0 = 0.0, x1 = 0.0;
-#pragma unroll 4
-            for (int jj = 0; jj < j; ++jj) {
-                const double temp = M[jj * LD + j];          // the original A(jj,j)
-                const double m0 = M[r0c * LD + jj], m1 = M[r1c * LD + jj];
-                const bool nz = temp != 0.0;                 // dtrmv skips a zero (the row's own sweep then leaves the zero as it is)
-                const double p0 = temp * m0, f0 = dfma(temp, m0, x0), p1 = temp * m1, f1 = dfma(temp, m1, x1);
-                x0 = (r0 == jj) ? (nz ? p0 : temp) : ((r0 < jj && nz) ? f0 : x0);
-                x1 = (r1 == jj) ? (nz ? p1 : temp) : ((r1 < jj && nz) ? f1 : x1);
-            }
-            if (go) {
-                if (r0 < j) M[r0 * LD + j] = (-ajj) * x0;
-                if (r1 < j) M[r1 * LD + j] = (-ajj) * x1;
-                if (r0 == j || r1 == j) M[j * LD + j] = ajj;
-            }
-        }
-        for (int i = 0; i < d; ++i) {                        // dlauu2
-            MCX_WAVE_LDS_SYNC();
-            const double aii = M[i * LD + i];
-            if (i < d - 1) {
-                double dot = 0.0;
-                double x0 = aii * M[r0c * LD + i], x1 = aii * M[r1c * LD + i];
-                {
-                    const double v = M[i * LD + i];
-                    dot = dfma(v, v, dot);
-                }
-#pragma unroll 4
-                for (int k = i + 1; k < d; ++k) {
-                    const double temp = M[i * LD + k], m0 = M[r0c * LD + k], m1 = M[r1c * LD + k];
-                    dot = dfma(temp, temp, dot);
-                    const bool nz = temp != 0.0;
-                    const double f0 = dfma(temp, m0, x0), f1 = dfma(temp, m1, x1);
-                    x0 = nz ? f0 : x0; x1 = nz ? f1 : x1;
-                }
-                if (go) {
-                    if (r0 < i) M[r0 * LD + i] = x0;
-                    if (r1 < i) M[r1 * LD + i] = x1;
-                    if (r0 == i || r1 == i) M[i * LD + i] = dot;
-                }
-            } else if (go) {
-                if (r0 <= i) M[r0 * LD + i] = aii * M[r0 * LD + i];
-                if (r1 <= i && r1 < d) M[r1 * LD + i] = aii * M[r1 * LD + i];
-            }
-        }
-    }
-    MCX_WAVE_LDS_SYNC();
-    if (ok) {                                                // (a singular factor leaves the copy of R, as potri_packed does)
-        double *iCt = E.iC + (size_t)tile * P * 64;
-        for (int r = l16; r < d; r += 16) for (int k = r; k < d; ++k) iCt[(size_t)pidx(r, k, d) * 64 + cl] = M[r * LD + k];
-    }
-}
-
-// ---------------------------------------------------------------- the same factorisation for any chain count and npar <= 64 (round 5)
-// group_factor_kernel's arithmetic with what kept it from paying once the chip is full taken out: (i) a wave read and wrote its four chains'
-// elements as 32-byte pieces of 512-byte lines (every line of a tile's matrices touched by sixteen waves): here a WORKGROUP of NW waves owns
-// 4 NW neighbouring chains of a tile and moves their matrices between HBM and LDS cooperatively, 32 NW contiguous bytes per element -- whole
-// 128-byte lines at NW = 4 -- and the workgroups of one tile sit on one XCD (blockIdx round-robins over the eight), whose L2 combines what is
-// left; (ii) the LDS copy is the PACKED upper triangle by rows (every operand of dpotf2 / dtrti2 / dlauu2 lies in it), so that npar 50 -- BASELINE
-// config 4's size with method = 'dram' -- holds four chains in 41 kB and three workgroups share a CU; (iii) a lane owns NC = ceil(npar / 16)
-// columns (dpotf2) / rows (dtrti2, dlauu2).  adapt_post_kernel streamed the packed matrices of a tile ~5.6 times through L2 / HBM for its 8 x 8
-// register blocks (33.5 ms per tick of 1 048 576 chains at npar 50, 2.2 ms at config 3's size); this reads and writes each once.
-// Chains of operations: exactly calculate_R / potri_packed (mcx_kernels.hpp) = MCMC_calculate_R's Cholesky branch, MCMC_adapt.F90:211-225.
+// adapt_post_kernel streamed the packed matrices of a tile ~5.6 times through L2 / HBM for its 8 x 8 register blocks (33.5 ms per tick of
+// 1 048 576 chains at npar 50, 2.2 ms at config 3's size); this reads and writes each once.  Results: R, R2, iC, I_INFO and the status bits, as
+// adapt_post_kernel leaves them.  (Round 4's one-wave form with [row][column] squares in LDS, group_factor_kernel, is superseded:
+// tools/variants/README.md.)
 // Grid: 8 ceil(ntiles / 8) (64 / (4 NW)) workgroups of 64 NW threads; LDS: 4 NW (P | 1) doubles + 4 NW ints.
 template <int NC, int NW>
 __global__ __launch_bounds__(64 * NW) void tile_factor_kernel(EngineDev E)

@@ -1,5204 +1,32 @@
-// mcx_kernels.hpp -- HIP kernels of the adaptive-Metropolis engine (gfx950, wave64).
+// mcx_kernels.hpp -- HIP kernels of the adaptive-Metropolis engine (gfx950, wave64): the umbrella over the family headers.
 //
-// Execution model: one lane = one chain, one 64-lane wave (= one workgroup) = one
-// "tile" of 64 chains.  All per-chain arrays in HBM are tile-interleaved,
+// Execution model: one lane = one chain, one 64-lane wave (= one workgroup) = one "tile" of 64 chains.  All per-chain arrays in HBM
+// are tile-interleaved,
 //     element k of chain (tile, lane)  ->  base[(tile*K + k)*64 + lane],
-// i.e. parameter-major inside a tile, so every wave access is one contiguous
-// 512-byte segment and a tile's whole Cholesky factor is one sequential stream.
-// The O(d^2) sweeps over a chain's packed factor are left-looking COLUMN PANELS: PW = 8 columns of
-// per-lane state (rotation work values, proposal accumulators) live in registers with compile-time
-// indices, every row contributes one contiguous PW x 512-byte segment (streamed non-temporally), and
-// the few O(d) vectors (normals, rotations, candidate) sit in per-chain global scratch, with the most
-// re-read rotations cached in LDS.  Nothing is templated on d (d <= 256).
+// i.e. parameter-major inside a tile, so every wave access is one contiguous 512-byte segment and a tile's whole Cholesky factor is
+// one sequential stream.  The O(d^2) sweeps over a chain's packed factor are left-looking COLUMN PANELS: PW = 8 columns of per-lane
+// state (rotation work values, proposal accumulators) live in registers with compile-time indices, every row contributes one
+// contiguous PW x 512-byte segment (streamed non-temporally), and the few O(d) vectors (normals, rotations, candidate) sit in
+// per-chain global scratch, with the most re-read rotations cached in LDS.  Nothing here is templated on npar.
 //
-// Kernels in this file:
-//   step_kernel<RAM,DR,POOLED>   MCMC_run / MCMC_run_ram / MCMC_run_er iterations, lane per chain (the headline kernel)
-//   step_kernel_ram_fullr        method='ram' with condmax > 0: rank-one adaptation of the full SVD factor
-//   scam_kernel                  MCMC_run_scam, lane per chain, per-chain rotation
-//   scam_pooled_kernel           SCAM with one pooled rotation: up to 16 waves per tile, products as f64 MFMA tiles
-//   pooled_mfma_kernel           pooled AM: lane per chain, the two shared-table products as f64 MFMA tiles
-//   host_phase_kernel<0..7>      the iteration cut at the user's host callbacks (DRAM/DR, RAM, ER, SCAM; nycol columns)
-//   dev_eval_kernel              the evaluation between the phases on the device (response-column target)
-//   adapt_kernel                 MCMC_adapt at a tick: covariance update, Cholesky / SVD factor, DR inverse
-//   init_kernel, bcast_kernel, gather_lane_kernel, moments_kernel, moments_tree_kernel, debug kernels
+//   mcx_common.hpp    EngineDev, layout macros, device targets, the normal generator
+//   mcx_products.hpp  R'z on the packed triangle (column panels), full-matrix products, the lane SVD, shared-table forms
+//   mcx_step.hpp      step_kernel<RAM,DR,POOLED> and its forms (the headline kernel: step_kernel_ram_wide), ram_update, dr_body
+//   mcx_scam.hpp      scam_kernel / scam_mw_kernel (per-chain rotation), scam_pooled(12)_kernel (pooled rotation, f64 MFMA)
+//   mcx_pooled.hpp    pooled_mfma_kernel (pooled AM / RAM / ER / DR on the f64 matrix cores)
+//   mcx_phase.hpp     host_phase_kernel<0..7>, dev_eval_kernel, step_kernel_cols (nycol >= 1), run1_kernel
+//   mcx_adapt.hpp     init_kernel, adapt_pre / adapt_cov_diag / adapt_cov_off / adapt_covb_* / adapt_post kernels
+//   mcx_svd.hpp       svd_sweep_stream(32)_kernel, svd_applyv_stream32_kernel, tile <-> chain layout conversion
+//   mcx_moments.hpp   moments_kernel, moments_tree_kernel, debug kernels
+// The lane-GROUP kernels (16 / 4 lanes per chain, factors on chip) are mcx_group.hpp and mcx_group_ram.hpp.
+// Kernel forms that were measured and lost, or that a later form superseded, are not in the product library: tools/variants/README.md.
 #pragma once
-#include "mcx_device.hpp"
-#include <type_traits>
-
-namespace mcx {
-
-enum { TGT_GAUSS = 0, TGT_BANANA = 1, TGT_EXPDATA = 2, TGT_HOST = 3, TGT_EXPCOLS = 4, TGT_MODULE = 5 };   // EXPCOLS / MODULE: host side only (the device sees TGT_HOST + an evaluation kernel between the phases)
-enum { M_DRAM = 0, M_RAM = 1, M_ER = 3 };
-
-// per-chain scalar slots (doubles)
-enum { S_SS1 = 0, S_PRI1, S_SIGMA2, S_ALPHA12, S_SAVEDY, S_WSUM, S_WNEW, NSCAL };   // S_WNEW: chainwsum after the blocked covariance update (adapt_cov_kernel -> adapt_post_kernel)
-// per-chain integer slots (u32)
-enum { I_SAVED = 0, I_STAYED, I_BNDSTAYED, I_DRACC, I_DRTRIES, I_CHAININD, I_CURCOUNT, I_STATUS,
-       I_LASTFREQ, I_BASECNT, I_WINSTART, I_INFO, I_ERSTAYED, I_PDESC, I_DOWNS, I_ADFLAGS, I_NR, I_BSTART, NICTR };   // I_PDESC: 1 after a successful RAM downdate; I_DOWNS: RAM iterations with a < 0 (choldowndate)
-
-// status bits
-enum { ST_RAM_DOWNDATE_FAIL = 1, ST_CHOL_FAIL = 2, ST_POTRI_FAIL = 4 };
-
-struct DevTarget {
-    int kind;
-    const double *mu, *lamT;    // gauss: mean[d] and the precision matrix transposed, lamT[j*d+i] = lam(i,j) (padded)
-    double b;                   // banana
-    int ndata;                  // expdata
-    const double *x, *y;        // y: [ncols][ndata] for the response-column target
-    int ncols;
-    const double *lo, *hi;      // box bounds or nullptr
-    const double *pmu, *psig;   // Gaussian priors or nullptr
-};
-
-struct EngineDev {
-    int d, P, ntiles;
-    int method, dodr, updatesigma, doadapt, doburnin, burnintime, greedy, adapthist;
-    double initcmatn;
-    double gam_shape;           // N0/2 + nobs/2           (MCMC_DRAM.F90:201)
-    double N0S02;               // N0*S02
-    double alphatarget, drscale, scalelimit, scalefactor;
-    DevTarget tgt;
-    // state, tile-interleaved
-    double *theta, *cand, *zs, *cs, *scal, *R, *R2, *iC, *Rtmp;   // cand/zs [d], cs [2d]: per-chain scratch vectors
-    double *xscr;               // [2d] per chain: the two quadratic-form vectors of pooled delayed rejection when LDS would cost waves (step_kernel_pooled_dr_big)
-    double *cmat, *mean, *basetheta;
-    const double *cmat0p, *par0;    // packed upper cmat0 [P], par0 [d] (shared by all chains)
-    uint32_t *ictr;
-    uint64_t *rngn;
-    uint32_t k0, chain_id0;
-    // history ring: slot = it % wcap; hist[(tile*wcap + slot)*(d+1) + k][lane]
-    int wcap, record_s2;
-    double *hist, *s2hist;
-    uint64_t *wacc;             // [tile*wcap + slot]
-    uint64_t *accmask;          // [(it-1)*ntiles + tile] or nullptr
-    uint64_t *rowlist;          // [(tile*(wcap+1) + r)*64 + lane]  (slot | weight<<32)
-    const double *sharedR;      // pooled mode: the one packed factor all chains propose with
-    // SVD paths (condmax > 0 / method='scam'): full column-major d x d factors per chain, element (i,j) at j*d+i
-    int usesvd, doscam; double condmax;
-    int scam_fast;                  // opt-in: componentwise proposals as theta + delta U(:,j) (mcmcx_config::scam_fast)
-    double *Rf, *R2f, *qstd, *Gw, *Vw;
-    // host-callback targets: per-chain evaluation results (inbounds, prior, ss) and state carried between phases
-    double *hev, *hx;
-    // response columns (nycol, mcmc.F90:30-33): ny > 1 only with host callbacks.  hs = d + ny doubles per history row
-    // (theta, then ss per column); hev holds ny ss values per chain; per-chain vectors ssv (current ss), s2v (sigma2),
-    // ss2v (first-stage ss kept for the DR formulas), gshapev[ny] = N0/2 + nobs(j)/2 (shared)
-    int ny, hs;
-    double *ssv, *s2v, *ss2v;
-    const double *gshapev;
-    // small npar, plain AM step kernel: the state vector and the per-chain scratch vectors (theta, candidate, two normal vectors)
-    // live in LDS for the launch -- their store -> load chains are what an iteration waits for when the factor is small
-    int lds_scratch;
-    // delayed rejection: the two npar-vectors of the second stage live in LDS (1) or, where 2 x npar x 512 bytes do not fit a
-    // CU's 160 KiB (npar > 160), in the chain's global scratch (0)
-    int dr_lds;
-};
-
-#define TIDX(base, tile, K, k, lane) ((base)[((size_t)(tile) * (size_t)(K) + (size_t)(k)) * 64 + (lane)])
-
-// Packed upper triangle, ROW-major: element (i,j), i <= j, sits at rowstart(i) + (j - i).
-// Every sweep of the factor (proposal, update, downdate) walks whole rows, forwards or backwards,
-// so a tile's factor is one sequential HBM stream of 512-byte wave segments.
-MCX_DEV int rowstart(int i, int d) { return i * d - (i * (i - 1)) / 2; }
-MCX_DEV int pidx(int i, int j, int d) { return rowstart(i, d) + (j - i); }
-
-constexpr int CH = 8;     // row elements per batch; two batches (2 x 8 x 512 B) are in flight per wave
-
-// The one per-lane d-vector of a wave lives in LDS as X[j*64 + lane] (conflict-free ds_read/write_b64).
-#define XL(j) X[(j) * 64 + lane]
-// element k of a tile-interleaved global vector whose tile base is `p` (uniform pointer)
-#define GV(p, k) (p)[(size_t)(k) * 64 + lane]
-#define GV2(p, k, c) (p)[(size_t)(k) * 64 + (c)]
-// streaming (non-temporal) access for the factor, which is touched once per iteration and should not evict
-// the small per-chain scratch vectors from L2 / Infinity Cache
-#define LDNT(p, k) __builtin_nontemporal_load(&(p)[(size_t)(k) * 64 + lane])
-#define STNT(p, k, v) __builtin_nontemporal_store((v), &(p)[(size_t)(k) * 64 + lane])
-// the downdate's second sweep re-reads what the first one just streamed and writes partial segments (only the downdate
-// lanes): plain accesses, so that L2 can serve the re-read and merge the partial stores (measured: +1..8 %)
-#define LDB(p, k) GV(p, k)
-#define STB(p, k, v) (GV(p, k) = (v))
-
-// Software-pipelined sweep over elements k0..n-1 of one packed row (rowp[k], element stride 64):
-// the next batch of CH elements is requested before the current one is consumed, and the
-// ragged last batch is loaded with clamped addresses, so no load of a row is ever issued alone.
-// f(k, r) is called for k ascending.
-MCX_DEV void load_batch(double (&r)[CH], const double *rowp, int lane, int k, int n)
-{
-#pragma unroll
-    for (int u = 0; u < CH; ++u) { int kk = k + u; kk = kk < n ? kk : n - 1; r[u] = GV(rowp, kk); }
-}
-template <typename F>
-MCX_DEV void sweep(const double *rowp, int lane, int k0, int n, F &&f)
-{
-    double ra[CH], rb[CH];
-    int k = k0;
-    if (k < n) load_batch(ra, rowp, lane, k, n);
-    while (k < n) {
-        int k2 = k + CH;
-        if (k2 < n) load_batch(rb, rowp, lane, k2, n);
-        if (k2 <= n) {
-#pragma unroll
-            for (int u = 0; u < CH; ++u) f(k + u, ra[u]);
-        } else {
-#pragma unroll
-            for (int u = 0; u < CH; ++u) if (k + u < n) f(k + u, ra[u]);
-        }
-        k = k2;
-        if (k >= n) break;
-        int k3 = k + CH;
-        if (k3 < n) load_batch(ra, rowp, lane, k3, n);
-        if (k3 <= n) {
-#pragma unroll
-            for (int u = 0; u < CH; ++u) f(k + u, rb[u]);
-        } else {
-#pragma unroll
-            for (int u = 0; u < CH; ++u) if (k + u < n) f(k + u, rb[u]);
-        }
-        k = k3;
-    }
-}
-
-// dst[k] = src[k] (and h[k] when h is given), k < d, eight elements' loads in flight: written element by element a copy waits
-// for each load before its store and cannot issue the next load before that store (the compiler must assume that the vectors
-// overlap) -- npar cache round trips in a row at every accepted move
-MCX_DEV void copy_vec(double *dst, const double *src, double *h, int lane, int d)
-{
-    int k = 0;
-    for (; k + 8 <= d; k += 8) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = GV(src, k + u);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { GV(dst, k + u) = v[u]; if (h) GV(h, k + u) = v[u]; }
-    }
-    for (; k < d; ++k) { const double v = GV(src, k); GV(dst, k) = v; if (h) GV(h, k) = v; }
-}
-
-// copy_vec with NL loads in flight and no element-by-element tail (the last batch re-reads its last element): for a wave that has its SIMD
-// almost to itself (pooled_mfma_kernel) every batch is a cache round trip nobody else covers
-template <int NL>
-MCX_DEV void copy_vec_wide(double *dst, const double *src, double *h, int lane, int d)
-{
-    for (int k = 0; k < d; k += NL) {
-        double v[NL];
-#pragma unroll
-        for (int u = 0; u < NL; ++u) v[u] = GV(src, (k + u < d) ? k + u : d - 1);
-#pragma unroll
-        for (int u = 0; u < NL; ++u) if (k + u < d) { GV(dst, k + u) = v[u]; if (h) GV(h, k + u) = v[u]; }
-    }
-}
-
-// dst[e] = f(src[e]), e < n, eight loads in flight (dst may be src): the element-by-element loop is a load-op-store round trip per
-// element for the same reason as in copy_vec
-template <typename F>
-MCX_DEV void map_vec(double *dst, const double *src, int lane, int n, F &&f)
-{
-    int e = 0;
-    for (; e + 8 <= n; e += 8) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = GV(src, e + u);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) GV(dst, e + u) = f(v[u]);
-    }
-    for (; e < n; ++e) GV(dst, e) = f(GV(src, e));
-}
-
-// The same sweep handing over a whole batch at a time: f(k, r, m) sees elements k..k+m-1 (m <= CH) in r[0..m-1], k ascending.
-template <typename F>
-MCX_DEV void sweep_batches(const double *rowp, int lane, int k0, int n, F &&f)
-{
-    double ra[CH], rb[CH];
-    int k = k0;
-    if (k < n) load_batch(ra, rowp, lane, k, n);
-    while (k < n) {
-        int k2 = k + CH;
-        if (k2 < n) load_batch(rb, rowp, lane, k2, n);
-        f(k, ra, (k2 <= n) ? CH : n - k);
-        k = k2;
-        if (k >= n) break;
-        int k3 = k + CH;
-        if (k3 < n) load_batch(ra, rowp, lane, k3, n);
-        f(k, rb, (k3 <= n) ? CH : n - k);
-        k = k3;
-    }
-}
-
-// ---------------------------------------------------------------- targets (user ssfunction / priorfun / checkbounds)
-// The candidate is read from a per-chain global scratch vector c_t (element stride 64); the
-// Gaussian target works on 16x16 register panels: y[16] (rows) x v[16] (columns), precision matrix
-// through scalar loads of its transpose (lamT[j*d + i] = lam(i,j), padded by PW doubles).
-constexpr int PW = 8;     // panel width: columns (or rows) of per-lane state held in registers
-#ifndef MCX_RW
-#define MCX_RW 10
-#endif
-#ifndef MCX_TW
-#define MCX_TW 10
-#endif
-constexpr int RW = MCX_RW;  // panel width of the RAM sweep (d = 50: five full panels)
-// step_kernel_ram_wide (npar > RAM_SMALL_MAX, round 4): column panels up to RW_WIDE wide, as few as that allows and as equal as possible
-// (npar 50: 17 + 17 + 16) -- every panel re-reads the rotations and the next normals of the rows above it.  A kernel of its own: the
-// narrow panels in 17-element register rows, or both widths instantiated in one kernel, cost 11-15 % at npar <= 20 (tools/ram_rw_probe.py);
-// 19 columns spill at two waves per SIMD.
-#ifndef MCX_RW_WIDE
-#define MCX_RW_WIDE 17
-#endif
-constexpr int RW_WIDE = MCX_RW_WIDE, RAM_SMALL_MAX = 20;
-MCX_DEV int ram_panel_width(int d, int rwmax) { const int np = (d + rwmax - 1) / rwmax; return (d + np - 1) / np; }
-constexpr int TW = MCX_TW;  // panel width of the per-chain triangular product
-
-// One block of 16 rows of the Gaussian target (mcxt_ss_gauss, oracle/mcx_targets.h): y_i = sum_j lam(i,j) v_j as fma chains
-// ascending in j, and the block's four partial chains q_k over the rows B0 + k + 4r.  ss is the running sum of the q_k over
-// the blocks in order; blocks are independent of one another (a workgroup's waves share them in scam_mw_kernel).
-MCX_DEV void gauss_block_q(int d, int lane, const double *c_t, const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
-                           int B0, double (&q)[4])
-{
-    q[0] = q[1] = q[2] = q[3] = 0.0;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int I0 = B0 + PW * h;
-        if (I0 < d) {
-            const int nr = (d - I0) < PW ? (d - I0) : PW;
-            double y[PW];
-#pragma unroll
-            for (int u = 0; u < PW; ++u) y[u] = 0.0;
-            for (int J0 = 0; J0 < d; J0 += PW) {
-                const int nc = (d - J0) < PW ? (d - J0) : PW;
-                double v[PW];
-#pragma unroll
-                for (int w = 0; w < PW; ++w) { int j = J0 + (w < nc ? w : nc - 1); v[w] = GV(c_t, j) - g_mu[j]; }
-#pragma unroll
-                for (int w = 0; w < PW; ++w) {
-                    if (w < nc) {
-                        const double *__restrict__ lrow = g_lamT + (size_t)(J0 + w) * d + I0;
-#pragma unroll
-                        for (int u = 0; u < PW; ++u) y[u] = dfma(lrow[u], v[w], y[u]);
-                    }
-                }
-            }
-            double vi[PW];
-#pragma unroll
-            for (int u = 0; u < PW; ++u) { int i = I0 + (u < nr ? u : nr - 1); vi[u] = GV(c_t, i) - g_mu[i]; }
-#pragma unroll
-            for (int u = 0; u < PW; ++u) {
-                if (u < nr) { if (h == 0 && u < 4) q[u & 3] = y[u] * vi[u]; else q[u & 3] = dfma(y[u], vi[u], q[u & 3]); }
-            }
-        }
-    }
-}
-
-// WIDE: keep every row accumulator in registers and read the candidate once (pays when the kernel is
-// bandwidth-bound: RAM); otherwise one row panel at a time (fewer registers: pooled / AM / DR kernels).
-template <bool WIDE>
-MCX_DEV double target_ss(const DevTarget &t, int d, int lane, const double *c_t,
-                         const double *__restrict__ g_mu, const double *__restrict__ g_lamT)
-{
-    double ss = 0.0;
-    // Gaussian: ss = v' Lam v in the order of mcxt_ss_gauss (oracle/mcx_targets.h): y_i = fma chain over j from 0; per
-    // block of 16 rows four partial chains q_k over the rows 16t + k + 4r; ss = running sum of the q_k.
-    if (WIDE && t.kind == TGT_GAUSS && d <= 8 * PW) {
-        // Row accumulators of NPM panels of PW (32 rows) stay in registers while the columns stream by, so the candidate
-        // is read once per 32 rows instead of once per row panel (all 64 rows at once spills).
-        constexpr int NPM = 4;
-        const int np = (d + PW - 1) / PW;
-        for (int G0 = 0; G0 < np; G0 += NPM) {
-            double y[NPM][PW];
-#pragma unroll
-            for (int p = 0; p < NPM; ++p)
-#pragma unroll
-                for (int u = 0; u < PW; ++u) y[p][u] = 0.0;
-            for (int J0 = 0; J0 < d; J0 += PW) {
-                const int nc = (d - J0) < PW ? (d - J0) : PW;
-                double v[PW];
-#pragma unroll
-                for (int w = 0; w < PW; ++w) { int j = J0 + (w < nc ? w : nc - 1); v[w] = GV(c_t, j) - g_mu[j]; }
-#pragma unroll
-                for (int w = 0; w < PW; ++w) {
-                    if (w < nc) {
-                        const double *__restrict__ lcol = g_lamT + (size_t)(J0 + w) * d + (size_t)G0 * PW;     // lam(32 G0/4 .., J0+w)
-#pragma unroll
-                        for (int p = 0; p < NPM; ++p) {
-                            if (G0 + p < np) {
-#pragma unroll
-                                for (int u = 0; u < PW; ++u) y[p][u] = dfma(lcol[p * PW + u], v[w], y[p][u]);
-                            }
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int tb = 0; tb < NPM / 2; ++tb) {
-                if (G0 + 2 * tb < np) {
-                    double q[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int p = 2 * tb + h;
-                        if (G0 + p < np) {
-                            const int I0 = (G0 + p) * PW;
-                            const int nr = (d - I0) < PW ? (d - I0) : PW;
-                            double vi[PW];
-#pragma unroll
-                            for (int u = 0; u < PW; ++u) { int i = I0 + (u < nr ? u : nr - 1); vi[u] = GV(c_t, i) - g_mu[i]; }
-#pragma unroll
-                            for (int u = 0; u < PW; ++u) {
-                                if (u < nr) { if (h == 0 && u < 4) q[u & 3] = y[p][u] * vi[u]; else q[u & 3] = dfma(y[p][u], vi[u], q[u & 3]); }
-                            }
-                        }
-                    }
-                    const int B0 = (G0 + 2 * tb) * PW;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) if (B0 + k < d) ss = (B0 == 0 && k == 0) ? q[0] : ss + q[k];
-                }
-            }
-        }
-    } else if (t.kind == TGT_GAUSS) {
-        for (int B0 = 0; B0 < d; B0 += 16) {
-            double q[4];
-            gauss_block_q(d, lane, c_t, g_mu, g_lamT, B0, q);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if (B0 + k < d) ss = (B0 == 0 && k == 0) ? q[0] : ss + q[k];
-        }
-    } else if (t.kind == TGT_BANANA) {
-        double th0 = GV(c_t, 0), th1 = GV(c_t, 1);
-        double t1 = th0 * th0;
-        double q = dfma(t.b, t1, th1) - 100.0 * t.b;
-        ss = dfma(q, q, t1 / 100.0);
-#pragma unroll 4
-        for (int k = 2; k < d; ++k) { double v = GV(c_t, k); ss = dfma(v, v, ss); }
-    } else {
-        double th0 = GV(c_t, 0), th1 = GV(c_t, 1);
-        for (int i = 0; i < t.ndata; ++i) {
-            double r = t.y[i] - th0 * d_exp(-(th1 * t.x[i]));
-            ss = dfma(r, r, ss);
-        }
-    }
-    return ss;
-}
-
-MCX_DEV double target_prior(const DevTarget &t, int d, int lane, const double *c_t)
-{
-    double p = 0.0;
-    if (t.pmu) {
-#pragma unroll 4
-        for (int i = 0; i < d; ++i) {
-            double sg = t.psig[i], th = GV(c_t, i);
-            if (sg > 0.0) { double q = (th - t.pmu[i]) / sg; p = p + q * q; }
-        }
-    }
-    return p;
-}
-
-MCX_DEV bool target_inbounds(const DevTarget &t, int d, int lane, const double *c_t)
-{
-    bool ok = true;
-    if (t.lo || t.hi) {
-#pragma unroll 4
-        for (int i = 0; i < d; ++i) {
-            double th = GV(c_t, i);
-            if (t.lo) ok = ok && (th > t.lo[i]);
-            if (t.hi) ok = ok && (th < t.hi[i]);
-        }
-    }
-    return ok;
-}
-
-#ifndef MCX_POOLED_NB
-#define MCX_POOLED_NB 8      // ... in pooled_mfma_kernel (one wave per SIMD, nothing else to issue while an attempt's chain waits: config 4 pooled 9.25e8 -> 9.65e8 at 8; 1: 9.04, 4: 9.21, 12: 9.55, 16: 8.99)
-#endif
-#ifndef MCX_POOLED_SPLIT
-#define MCX_POOLED_SPLIT 1   // pooled_mfma_kernel draws its vector in two passes (gen_normals_split): attempts first, the logarithm / root / divisions for the kept pairs only
-#endif
-#ifndef MCX_POOLED_NBB
-#define MCX_POOLED_NBB 4
-#endif
-#if MCX_POOLED_SPLIT
-#define MCX_POOLED_GEN gen_normals_split<MCX_POOLED_NB, MCX_POOLED_NBB>
-#else
-#define MCX_POOLED_GEN gen_normals<MCX_POOLED_NB>
-#endif
-#ifndef MCX_RNG_NB
-#define MCX_RNG_NB 2      // polar attempts computed side by side in the kernels that wait for the generator (AM, DRAM, pooled); 4 loses at config 2 (d = 10: a vector is ~11 attempts)
-#endif
-// ---------------------------------------------------------------- normals (mcmcrand.F90:60-83,166-190)
-// Each lane appends accepted polar pairs to its own column of zs (global scratch, element stride 64)
-// until it has d deviates; the wave loops until every participating lane is done.  The cached
-// second deviate of normal_bm is honoured and left behind when d is odd.
-// Returns sum(z**2) accumulated in element order (the `sum(u**2)` of MCMC_run_ram.F90:166), so the RAM
-// update does not have to read the vector again.
-template <int NB = 1>
-MCX_DEV double gen_normals(Rng &g, double *zs_t, int lane, int d, bool participate)
-{
-    int k = 0;
-    double su = 0.0;
-    if (participate && g.saved && d > 0) { GV(zs_t, 0) = g.saved_y; su = su + g.saved_y * g.saved_y; g.saved = 0; k = 1; }
-    bool need = participate && (k < d);
-    if (NB == 1) {
-        while (__any(need)) {
-            if (need) {
-                double a, b;
-                if (polar_try(g, a, b)) {
-                    GV(zs_t, k) = a; su = su + a * a; ++k;
-                    if (k < d) { GV(zs_t, k) = b; su = su + b * b; ++k; }
-                    else { g.saved_y = b; g.saved = 1; }
-                }
-                need = (k < d);
-            }
-        }
-        return su;
-    }
-    // NB attempts per trip, side by side: the Philox blocks, the polar tests and the log / sqrt / division of NB consecutive
-    // attempts of the lane's stream are independent of one another, and a kernel that waits for their dependent chains (one
-    // wave per SIMD at config 2's size) gets NB chains in flight instead of one.  They are CONSUMED in order, and only as
-    // many as the lane needs: an attempt past the one that completes the vector is dropped with its uniforms undrawn, so
-    // the stream position, the deviates and the order of the sum are those of the one-at-a-time loop.
-    while (__any(need)) {
-        const uint64_t b0 = g.n >> 1;
-        const bool odd = (g.n & 1) != 0;
-        uint32_t w[NB + 1][4];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) philox4x32_10((uint32_t)(b0 + j), (uint32_t)((b0 + j) >> 32), g.k0, g.k1, w[j][0], w[j][1], w[j][2], w[j][3]);
-        if (__any(need && odd)) philox4x32_10((uint32_t)(b0 + NB), (uint32_t)((b0 + NB) >> 32), g.k0, g.k1, w[NB][0], w[NB][1], w[NB][2], w[NB][3]);
-        else { w[NB][0] = w[NB][1] = w[NB][2] = w[NB][3] = 0u; }
-        double za[NB], zb[NB];
-        bool ok[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            // uniforms 2 (n/2 + j) and the next one (random_number(x), x(2): mcmcrand.F90:177)
-            double x1 = odd ? bits_to_uniform(w[j][2], w[j][3]) : bits_to_uniform(w[j][0], w[j][1]);
-            double x2 = odd ? bits_to_uniform(w[j + 1][0], w[j + 1][1]) : bits_to_uniform(w[j][2], w[j][3]);
-            x1 = 2.0 * x1 - 1.0; x2 = 2.0 * x2 - 1.0;
-            const double xx = x1 * x1 + x2 * x2;
-            ok[j] = (xx < 1.0) && (xx != 0.0);
-            const double z = sqrt(-2.0 * d_log(ok[j] ? xx : 0.5) / (ok[j] ? xx : 0.5));
-            zb[j] = z * x1; za[j] = z * x2;
-        }
-        if (need) {
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                if (k < d) {
-                    g.n += 2;
-                    if (ok[j]) {
-                        GV(zs_t, k) = za[j]; su = su + za[j] * za[j]; ++k;
-                        if (k < d) { GV(zs_t, k) = zb[j]; su = su + zb[j] * zb[j]; ++k; }
-                        else { g.saved_y = zb[j]; g.saved = 1; }
-                    }
-                }
-            }
-            g.cblk = 0;                                   // the half-used block (n odd) is recomputed by the next single draw
-            need = (k < d);
-        }
-    }
-    return su;
-}
-
-// The same vector in TWO passes, for a kernel whose generator is bound by instruction issue (pooled_mfma_kernel: 47 % of an iteration):
-// a wave runs ~40 attempts per lane for the 25 pairs a lane of npar 50 keeps (0.785 a try, the slowest lane sets the trip count), and in
-// the one-pass form every one of them pays for the logarithm, the square root and the two divisions.  Pass A makes the attempts -- the
-// Philox blocks, the two uniforms, the test xx < 1 -- and parks the ACCEPTED pair's (x2, x1) where its deviates will stand; it alone moves
-// the stream.  Pass B visits the parked pairs, exactly as many as the vector holds, and scales them: z = sqrt(-2 log(xx) / xx) with xx formed
-// again from the same two numbers by the same two products and one sum.  Stream position, deviates, the cached second deviate and the order
-// of sum(z**2): those of gen_normals.
-template <int NB, int NBB = 4>
-MCX_DEV double gen_normals_split(Rng &g, double *zs_t, int lane, int d, bool participate)
-{
-    int k = 0;
-    double su = 0.0;
-    if (participate && g.saved && d > 0) { GV(zs_t, 0) = g.saved_y; su = su + g.saved_y * g.saved_y; g.saved = 0; k = 1; }
-    const int k0 = k;
-    bool need = participate && (k < d);
-    double over = 0.0;                                    // x1 of the pair whose second deviate lies past the vector's end
-    // block b0 + NB -- the straddling pair's second half when the stream position is odd -- is the NEXT trip's block b0 for every lane that goes on
-    // (it consumed all NB attempts): carried over instead of computed again, NB blocks per trip after the first instead of NB + 1
-    uint32_t cw0 = 0u, cw1 = 0u, cw2 = 0u, cw3 = 0u;
-    uint64_t cblk1 = 0;                                   // the carried block's index + 1 (0: none)
-    while (__any(need)) {
-        const uint64_t b0 = g.n >> 1;
-        const bool odd = (g.n & 1) != 0;
-        uint32_t w[NB + 1][4];
-        if (__all(!need || cblk1 == b0 + 1)) { w[0][0] = cw0; w[0][1] = cw1; w[0][2] = cw2; w[0][3] = cw3; }
-        else philox4x32_10((uint32_t)b0, (uint32_t)(b0 >> 32), g.k0, g.k1, w[0][0], w[0][1], w[0][2], w[0][3]);
-#pragma unroll
-        for (int j = 1; j <= NB; ++j) philox4x32_10((uint32_t)(b0 + j), (uint32_t)((b0 + j) >> 32), g.k0, g.k1, w[j][0], w[j][1], w[j][2], w[j][3]);
-        cw0 = w[NB][0]; cw1 = w[NB][1]; cw2 = w[NB][2]; cw3 = w[NB][3]; cblk1 = b0 + NB + 1;
-        double xa[NB], xb[NB];
-        bool ok[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            double x1 = odd ? bits_to_uniform(w[j][2], w[j][3]) : bits_to_uniform(w[j][0], w[j][1]);
-            double x2 = odd ? bits_to_uniform(w[j + 1][0], w[j + 1][1]) : bits_to_uniform(w[j][2], w[j][3]);
-            x1 = 2.0 * x1 - 1.0; x2 = 2.0 * x2 - 1.0;
-#ifdef MCX_PROBE_ALLOK                                             // tools/gen_bound.sh: every attempt accepted (NOT the reference's stream)
-            if (!(x1 * x1 + x2 * x2 < 1.0)) { x1 *= 0.5; x2 *= 0.5; }
-#endif
-            const double xx = x1 * x1 + x2 * x2;
-            ok[j] = (xx < 1.0) && (xx != 0.0);
-            xa[j] = x2; xb[j] = x1;
-        }
-        if (need) {
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                if (k < d) {
-                    g.n += 2;
-                    if (ok[j]) {
-                        GV(zs_t, k) = xa[j]; ++k;
-                        if (k < d) { GV(zs_t, k) = xb[j]; ++k; }
-                        else over = xb[j];
-                    }
-                }
-            }
-            g.cblk = 0;
-            need = (k < d);
-        }
-    }
-    if (participate) {
-        for (int kk = k0; kk < d; kk += 2 * NBB) {
-            double x1[NBB], x2[NBB], za[NBB], zb[NBB];
-#pragma unroll
-            for (int u = 0; u < NBB; ++u) {
-                const int ka = kk + 2 * u;
-                x2[u] = GV(zs_t, ka < d ? ka : d - 1);
-                x1[u] = (ka + 1 < d) ? GV(zs_t, ka + 1) : over;
-            }
-#pragma unroll
-            for (int u = 0; u < NBB; ++u) {
-                const bool live = kk + 2 * u < d;
-                const double xx0 = x1[u] * x1[u] + x2[u] * x2[u];
-                const double xx = live ? xx0 : 0.5;
-                const double z = sqrt(-2.0 * d_log(xx) / xx);
-                zb[u] = z * x1[u]; za[u] = z * x2[u];
-            }
-#pragma unroll
-            for (int u = 0; u < NBB; ++u) {
-                const int ka = kk + 2 * u;
-                if (ka < d) {
-                    GV(zs_t, ka) = za[u]; su = su + za[u] * za[u];
-                    if (ka + 1 < d) { GV(zs_t, ka + 1) = zb[u]; su = su + zb[u] * zb[u]; }
-                    else { g.saved_y = zb[u]; g.saved = 1; }
-                }
-            }
-        }
-    }
-    return su;
-}
-
-// ---------------------------------------------------------------- proposal: P = R'z  (MCMC_DRAM.F90:20-31)
-// dtrmv('U','T','N') (matutils.F90:108-109): p_j = sum_{i<=j} R(i,j) z_i, each dot product ascending in i
-// as one fma chain from 0.  Column panels of PW accumulators in registers; every row contributes one
-// contiguous PW x 512-byte segment, so the factor is read exactly once.
-// PIPE: the AM / DRAM step kernels, where this product is the iteration's only pass over the factor and memory latency is
-// what it waits for: three rows' loads in flight above the diagonal block, two inside it.  The RAM kernel runs it once per
-// launch (later proposals come fused out of the update sweep) and keeps the plain form: its registers are spoken for.
-template <bool PIPE>
-MCX_DEV void trmv_panels(const double *Rt, const double *z_t, double *P_t, const double *theta_t, int lane, int d, bool act,
-                         bool desc = false)
-{
-    const bool asc = act && !desc, dsc = act && desc;
-    if (__any(asc)) {
-        for (int J0 = 0; J0 < d; J0 += TW) {
-            const int nw = (d - J0) < TW ? (d - J0) : TW;
-            double P[TW];
-#pragma unroll
-            for (int u = 0; u < TW; ++u) P[u] = 0.0;
-            if (asc) {
-                // rows above the diagonal block, two rows' loads in flight: left to itself the compiler keeps four loads
-                // outstanding (it sinks each load next to its fma), and a lane-per-chain wave then waits out the HBM
-                // latency once per row; the accumulation order of every P[u] is unchanged (rows ascending)
-                constexpr int NB = PIPE ? 3 : 1;                               // rows in flight
-                double rr[NB][TW], zz[NB];
-#define MCX_TRMV_LD(rv, zv, i_) { zv = GV(z_t, (i_)); const double *seg_ = Rt + (size_t)(rowstart((i_), d) + J0 - (i_)) * 64; \
-                                  _Pragma("unroll") for (int u = 0; u < TW; ++u) rv[u] = LDNT(seg_, u < nw ? u : nw - 1); }
-#define MCX_TRMV_FM(rv, zv) { _Pragma("unroll") for (int u = 0; u < TW; ++u) P[u] = dfma(rv[u], zv, P[u]); }
-#pragma unroll
-                for (int s_ = 0; s_ < NB - 1; ++s_) if (s_ < J0) MCX_TRMV_LD(rr[s_], zz[s_], s_)
-                for (int i = 0; i < J0; i += NB) {
-#pragma unroll
-                    for (int s_ = 0; s_ < NB; ++s_) {
-                        if (i + s_ + NB - 1 < J0) MCX_TRMV_LD(rr[(s_ + NB - 1) % NB], zz[(s_ + NB - 1) % NB], i + s_ + NB - 1)
-                        if (i + s_ < J0) MCX_TRMV_FM(rr[s_], zz[s_])
-                    }
-                }
-#undef MCX_TRMV_LD
-#undef MCX_TRMV_FM
-                {                                                            // diagonal block: elements u >= ui; the next row's loads in flight
-                    double da[TW], db[TW], za = 0.0, zb = 0.0;
-#define MCX_TRMV_LDD(rv, zv, i_) { zv = GV(z_t, (i_)); const double *seg_ = Rt + (size_t)rowstart((i_), d) * 64; const int ui_ = (i_) - J0, m_ = d - 1 - (i_); \
-                                   _Pragma("unroll") for (int u = 0; u < TW; ++u) { int k = u - ui_; k = k < 0 ? 0 : k; k = k > m_ ? m_ : k; rv[u] = LDNT(seg_, k); } }
-#define MCX_TRMV_FMD(rv, zv, i_) { const int ui_ = (i_) - J0; _Pragma("unroll") for (int u = 0; u < TW; ++u) { double nv = dfma(rv[u], zv, P[u]); P[u] = (u >= ui_) ? nv : P[u]; } }
-                    if (PIPE) {
-                        MCX_TRMV_LDD(da, za, J0)
-                        for (int i = J0; i < J0 + nw; i += 2) {
-                            if (i + 1 < J0 + nw) MCX_TRMV_LDD(db, zb, i + 1)
-                            MCX_TRMV_FMD(da, za, i)
-                            if (i + 2 < J0 + nw) MCX_TRMV_LDD(da, za, i + 2)
-                            if (i + 1 < J0 + nw) MCX_TRMV_FMD(db, zb, i + 1)
-                        }
-                    } else {
-                        for (int i = J0; i < J0 + nw; ++i) { MCX_TRMV_LDD(da, za, i) MCX_TRMV_FMD(da, za, i) }
-                    }
-#undef MCX_TRMV_LDD
-#undef MCX_TRMV_FMD
-                }
-                double th[TW];                           // the state's loads before the candidate's stores (see copy_vec)
-#pragma unroll
-                for (int u = 0; u < TW; ++u) th[u] = GV(theta_t, J0 + (u < nw ? u : nw - 1));
-#pragma unroll
-                for (int u = 0; u < TW; ++u) if (u < nw) GV(P_t, J0 + u) = th[u] + P[u];   // newpar = oldpar + R'z
-            }
-        }
-    }
-    // The proposal that follows a successful Cholesky downdate accumulates from the diagonal up (mcxo_trmv_ut_desc): this
-    // standalone form serves the cases where ram_update could not fuse it (first iteration of a launch, host callbacks).
-    if (__any(dsc)) {
-        for (int J0 = 0; J0 < d; J0 += TW) {
-            const int nw = (d - J0) < TW ? (d - J0) : TW;
-            double P[TW];
-#pragma unroll
-            for (int u = 0; u < TW; ++u) P[u] = 0.0;
-            if (dsc) {
-                for (int i = J0 + nw - 1; i >= J0; --i) {                    // diagonal block, rows descending
-                    const double zi = GV(z_t, i);
-                    const double *seg = Rt + (size_t)rowstart(i, d) * 64;
-                    const int ui = i - J0, m = d - 1 - i;
-                    double r[TW];
-#pragma unroll
-                    for (int u = 0; u < TW; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
-#pragma unroll
-                    for (int u = 0; u < TW; ++u) {
-                        const double nv = (u == ui) ? r[u] * zi : dfma(r[u], zi, P[u]);
-                        P[u] = (u >= ui) ? nv : P[u];
-                    }
-                }
-#pragma unroll 2
-                for (int i = J0 - 1; i >= 0; --i) {                          // rows above, descending
-                    const double zi = GV(z_t, i);
-                    const double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
-                    double r[TW];
-#pragma unroll
-                    for (int u = 0; u < TW; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
-#pragma unroll
-                    for (int u = 0; u < TW; ++u) P[u] = dfma(r[u], zi, P[u]);
-                }
-                double th[TW];
-#pragma unroll
-                for (int u = 0; u < TW; ++u) th[u] = GV(theta_t, J0 + (u < nw ? u : nw - 1));
-#pragma unroll
-                for (int u = 0; u < TW; ++u) if (u < nw) GV(P_t, J0 + u) = th[u] + P[u];
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------- full-matrix products for the SVD paths
-// y = M x (dgemv 'N', matutils.F90:161): y = 0, then column by column y_i += x_j M(i,j) -- each y_i is an fma chain
-// ascending in j.  Row panels of PW accumulators in registers; out_t = (add_t ? add_t : 0) + y.
-// PIPE (the per-chain SCAM kernel, which does nothing but stream its rotation): four columns' loads in flight -- left to
-// itself the compiler sinks every load next to its fma and keeps ~4 outstanding.  The step kernels (SVD proposal factor)
-// keep the plain form: their registers are spoken for.
-template <bool PIPE = false, int NBO = 0>       // NBO: rows in flight, when not the default of PIPE
-MCX_DEV void gemvN_panels(const double *Mt, const double *x_t, double *out_t, const double *add_t, int lane, int d, bool act,
-                          int p0 = 0, int pstep = 1)                 // panels p0, p0 + pstep, ...: a workgroup's waves share the rows
-{
-#ifndef MCX_GEMV_NB
-#define MCX_GEMV_NB 4
-#endif
-    constexpr int NB = NBO ? NBO : (PIPE ? MCX_GEMV_NB : 1);
-    for (int I0 = p0 * PW; I0 < d; I0 += pstep * PW) {
-        const int nr = (d - I0) < PW ? (d - I0) : PW;
-        double y[PW];
-#pragma unroll
-        for (int u = 0; u < PW; ++u) y[u] = 0.0;
-        if (act) {
-            double rr[NB][PW], xx[NB];                             // the matrix is streamed (non-temporal), x stays cached
-#define MCX_GEMV_LD(s_, j_) { xx[s_] = GV(x_t, (j_)); const double *seg_ = Mt + ((size_t)(j_) * d + I0) * 64; \
-                              _Pragma("unroll") for (int u = 0; u < PW; ++u) rr[s_][u] = LDNT(seg_, u < nr ? u : nr - 1); }
-#pragma unroll
-            for (int s = 0; s < NB - 1; ++s) if (s < d) MCX_GEMV_LD(s, s)
-#pragma unroll (NB == 1 ? 4 : 1)
-            for (int j = 0; j < d; j += NB) {
-#pragma unroll
-                for (int s = 0; s < NB; ++s) {
-                    if (j + s + NB - 1 < d) MCX_GEMV_LD((s + NB - 1) % NB, j + s + NB - 1)
-                    if (j + s < d) {
-#pragma unroll
-                        for (int u = 0; u < PW; ++u) y[u] = dfma(xx[s], rr[s][u], y[u]);
-                    }
-                }
-            }
-#undef MCX_GEMV_LD
-#pragma unroll
-            for (int u = 0; u < PW; ++u) if (u < nr) GV(out_t, I0 + u) = add_t ? (GV(add_t, I0 + u) + y[u]) : y[u];
-        }
-    }
-}
-// y = M'x (dgemv 'T'): y_k = sum_i M(i,k) x_i, i ascending, one fma chain per column.
-template <bool PIPE = false, int NBO = 0>
-MCX_DEV void gemvT_panels(const double *Mt, const double *x_t, double *out_t, int lane, int d, int p0 = 0, int pstep = 1)
-{
-#ifndef MCX_GEMV_NB
-#define MCX_GEMV_NB 4
-#endif
-    constexpr int NB = NBO ? NBO : (PIPE ? MCX_GEMV_NB : 1);
-    for (int K0 = p0 * PW; K0 < d; K0 += pstep * PW) {
-        const int nc = (d - K0) < PW ? (d - K0) : PW;
-        double t[PW];
-#pragma unroll
-        for (int u = 0; u < PW; ++u) t[u] = 0.0;
-        double rr[NB][PW], xx[NB];
-#define MCX_GEMV_LD(s_, i_) { xx[s_] = GV(x_t, (i_)); _Pragma("unroll") for (int u = 0; u < PW; ++u) rr[s_][u] = LDNT(Mt, (size_t)(K0 + (u < nc ? u : nc - 1)) * d + (i_)); }
-#pragma unroll
-        for (int s = 0; s < NB - 1; ++s) if (s < d) MCX_GEMV_LD(s, s)
-#pragma unroll (NB == 1 ? 4 : 1)
-        for (int i = 0; i < d; i += NB) {
-#pragma unroll
-            for (int s = 0; s < NB; ++s) {
-                if (i + s + NB - 1 < d) MCX_GEMV_LD((s + NB - 1) % NB, i + s + NB - 1)
-                if (i + s < d) {
-#pragma unroll
-                    for (int u = 0; u < PW; ++u) t[u] = dfma(rr[s][u], xx[s], t[u]);
-                }
-            }
-        }
-#undef MCX_GEMV_LD
-#pragma unroll
-        for (int u = 0; u < PW; ++u) if (u < nc) GV(out_t, K0 + u) = t[u];
-    }
-}
-
-// The routine's dot products (oracle/mcx_svd.h): eight partial fma chains over the rows k = j, j + 8, ... and the pairwise tree
-MCX_DEV double svd_tree8(const double (&p)[8]) { return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])); }
-
-// The pinned dgesvd('A','N') of a symmetric PSD matrix: one-sided Jacobi, row-cyclic, operation for operation the
-// routine of oracle/mcx_svd.h (see there).  Gt: in the matrix (column-major d*d per chain), destroyed; Vt: out
-// the singular vectors; sv_t: out singular values, descending.  Lanes converge independently; a converged lane
-// keeps re-deriving "no rotation" from unchanged data, which is the same as having left the loop.
-MCX_DEV void symsvd_dev(double *Gt, double *Vt, double *sv_t, int lane, int d, bool act)
-{
-    for (int j = 0; j < d; ++j) for (int i = 0; i < d; ++i) if (act) GV(Vt, (size_t)j * d + i) = (i == j) ? 1.0 : 0.0;
-    // One pass over k per pair: the rotation of (g_p, g_q) and (v_p, v_q) and, on the fly, the three dot products of
-    // the NEXT pair (p, q+1), which see g_p as this rotation leaves it.  Every chain of operations is the one of
-    // oracle/mcx_svd.h (same operands, same order); only the loops are merged, so that a pair costs one latency-bound
-    // sweep over the columns instead of three.  A pair nobody in the wave rotates leaves g_p alone: alpha carries over
-    // (the same fma chain over the same data), beta and gamma of the next pair take one read of g_p and g_{q+1}.
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        bool rotated = false;
-        for (int p = 0; p < d - 1; ++p) {
-            double *gp = Gt + (size_t)p * d * 64, *vp = Vt + (size_t)p * d * 64;
-            double alpha, beta, gamma;
-            {
-                const double *gq = gp + (size_t)d * 64;
-                double pa[8], pb[8], pg[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { pa[u] = 0.0; pb[u] = 0.0; pg[u] = 0.0; }
-                for (int k0 = 0; k0 < d; k0 += 8) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        if (k0 + u < d) {
-                            double a = GV(gp, k0 + u), b = GV(gq, k0 + u);
-                            pa[u] = dfma(a, a, pa[u]); pb[u] = dfma(b, b, pb[u]); pg[u] = dfma(a, b, pg[u]);
-                        }
-                    }
-                }
-                alpha = svd_tree8(pa); beta = svd_tree8(pb); gamma = svd_tree8(pg);
-            }
-            for (int q = p + 1; q < d; ++q) {
-                double *gq = Gt + (size_t)q * d * 64, *vq = Vt + (size_t)q * d * 64;
-                const bool more = q + 1 < d;
-                const double *gn = more ? gq + (size_t)d * 64 : gq;          // column q+1 (unused when !more)
-                const bool rot = act && (gamma != 0.0) && !(fabs(gamma) <= 1e-15 * sqrt(alpha * beta));
-                double na = 0.0, nb = 0.0, ng = 0.0;
-                double pa[8], pb[8], pg[8];                      // partial chains by row index mod 8 (SB = 8 rows per block below)
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { pa[u] = 0.0; pb[u] = 0.0; pg[u] = 0.0; }
-                if (__any(rot)) {
-                    double c = 1.0, sn = 0.0;
-                    if (rot) {
-                        rotated = true;
-                        double zeta = (beta - alpha) / (2.0 * gamma);
-                        double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                        c = 1.0 / sqrt(1.0 + t * t); sn = c * t;
-                    }
-                    // blocks of SB rows, the next block's fifteen loads issued before this block's stores: the
-                    // columns alias as far as the compiler can tell, so without this every row would wait for its own loads
-                    constexpr int SB = 8;
-                    double A[SB], B[SB], Ee[SB], VA[SB], VB[SB];
-#pragma unroll
-                    for (int u = 0; u < SB; ++u) {
-                        const int k = u < d ? u : d - 1;
-                        A[u] = GV(gp, k); B[u] = GV(gq, k); Ee[u] = GV(gn, k); VA[u] = GV(vp, k); VB[u] = GV(vq, k);
-                    }
-                    for (int k0 = 0; k0 < d; k0 += SB) {
-                        double A2[SB], B2[SB], E2[SB], VA2[SB], VB2[SB];
-#pragma unroll
-                        for (int u = 0; u < SB; ++u) {
-                            int k = k0 + SB + u; k = k < d ? k : d - 1;
-                            A2[u] = GV(gp, k); B2[u] = GV(gq, k); E2[u] = GV(gn, k); VA2[u] = GV(vp, k); VB2[u] = GV(vq, k);
-                        }
-#pragma unroll
-                        for (int u = 0; u < SB; ++u) {
-                            const int k = k0 + u;
-                            if (k < d) {
-                                const double a = A[u], b = B[u], e = Ee[u], va = VA[u], vb = VB[u];
-                                const double ra = c * a - sn * b, rb = sn * a + c * b;
-                                const double aa = rot ? ra : a;
-                                if (rot) { GV(gp, k) = ra; GV(gq, k) = rb; GV(vp, k) = c * va - sn * vb; GV(vq, k) = sn * va + c * vb; }
-                                pa[u] = dfma(aa, aa, pa[u]); pb[u] = dfma(e, e, pb[u]); pg[u] = dfma(aa, e, pg[u]);
-                            }
-                        }
-#pragma unroll
-                        for (int u = 0; u < SB; ++u) { A[u] = A2[u]; B[u] = B2[u]; Ee[u] = E2[u]; VA[u] = VA2[u]; VB[u] = VB2[u]; }
-                    }
-                    na = svd_tree8(pa); nb = svd_tree8(pb); ng = svd_tree8(pg);
-                } else if (more) {
-                    na = alpha;
-                    for (int k0 = 0; k0 < d; k0 += 8) {
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            if (k0 + u < d) {
-                                const double a = GV(gp, k0 + u), e = GV(gn, k0 + u);
-                                pb[u] = dfma(e, e, pb[u]); pg[u] = dfma(a, e, pg[u]);
-                            }
-                        }
-                    }
-                    nb = svd_tree8(pb); ng = svd_tree8(pg);
-                }
-                alpha = na; beta = nb; gamma = ng;
-            }
-        }
-        if (!__any(rotated)) break;
-    }
-    if (act) {
-        for (int j = 0; j < d; ++j) {
-            const double *gj = Gt + (size_t)j * d * 64;
-            double pa[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) pa[u] = 0.0;
-            for (int k0 = 0; k0 < d; k0 += 8) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) if (k0 + u < d) { double g = GV(gj, k0 + u); pa[u] = dfma(g, g, pa[u]); }
-            }
-            GV(sv_t, j) = sqrt(svd_tree8(pa));
-        }
-        for (int i = 0; i < d - 1; ++i) {                     // descending order, first maximum wins
-            int m = i; double sm = GV(sv_t, i);
-            for (int j = i + 1; j < d; ++j) { double sj = GV(sv_t, j); if (sj > sm) { m = j; sm = sj; } }
-            if (m != i) {
-                double ts = GV(sv_t, i); GV(sv_t, i) = GV(sv_t, m); GV(sv_t, m) = ts;
-                for (int k = 0; k < d; ++k) {
-                    double tv = GV(Vt, (size_t)i * d + k); GV(Vt, (size_t)i * d + k) = GV(Vt, (size_t)m * d + k); GV(Vt, (size_t)m * d + k) = tv;
-                }
-            }
-        }
-    }
-}
-
-// Same product with ONE factor shared by every chain (pooled mode): the factor is wave-uniform, so its
-// elements come through the scalar cache (s_load) and the only vector traffic is the chain's own z and P.
-MCX_DEV void trmv_shared(const double *__restrict__ Rs, const double *z_t, double *P_t, const double *theta_t, int lane, int d)
-{
-    for (int J0 = 0; J0 < d; J0 += PW) {
-        const int nw = (d - J0) < PW ? (d - J0) : PW;
-        double P[PW];
-#pragma unroll
-        for (int u = 0; u < PW; ++u) P[u] = 0.0;
-#pragma unroll 2
-        for (int i = 0; i < J0; ++i) {
-            const double zi = GV(z_t, i);
-            const double *__restrict__ seg = Rs + (size_t)(rowstart(i, d) + J0 - i);
-#pragma unroll
-            for (int u = 0; u < PW; ++u) P[u] = dfma(seg[u < nw ? u : nw - 1], zi, P[u]);
-        }
-        for (int i = J0; i < J0 + nw; ++i) {
-            const double zi = GV(z_t, i);
-            const double *__restrict__ seg = Rs + (size_t)rowstart(i, d);
-            const int ui = i - J0, m = d - 1 - i;
-#pragma unroll
-            for (int u = 0; u < PW; ++u) {
-                int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k;
-                double nv = dfma(seg[k], zi, P[u]);
-                P[u] = (u >= ui) ? nv : P[u];
-            }
-        }
-        double th[PW];
-#pragma unroll
-        for (int u = 0; u < PW; ++u) th[u] = GV(theta_t, J0 + (u < nw ? u : nw - 1));
-#pragma unroll
-        for (int u = 0; u < PW; ++u) if (u < nw) GV(P_t, J0 + u) = th[u] + P[u];
-    }
-}
-
-// matmulx(R, z) with ONE full factor shared by every chain (pooled mode with condmax > 0): M[j*d + i] = R(i,j) (column-major,
-// padded by PWS doubles), y_i an fma chain ascending in j like gemvN_panels; the matrix comes through the scalar cache.
-MCX_DEV void gemvN_shared(const double *__restrict__ M, const double *z_t, double *out_t, const double *theta_t, int lane, int d)
-{
-    for (int I0 = 0; I0 < d; I0 += PW) {
-        const int nr = (d - I0) < PW ? (d - I0) : PW;
-        double y[PW];
-#pragma unroll
-        for (int u = 0; u < PW; ++u) y[u] = 0.0;
-#pragma unroll 2
-        for (int j = 0; j < d; ++j) {
-            const double zj = GV(z_t, j);
-            const double *__restrict__ col = M + (size_t)j * d + I0;
-#pragma unroll
-            for (int u = 0; u < PW; ++u) y[u] = dfma(zj, col[u < nr ? u : nr - 1], y[u]);
-        }
-        double th[PW];
-#pragma unroll
-        for (int u = 0; u < PW; ++u) th[u] = GV(theta_t, I0 + (u < nr ? u : nr - 1));
-#pragma unroll
-        for (int u = 0; u < PW; ++u) if (u < nr) GV(out_t, I0 + u) = th[u] + y[u];
-    }
-}
-
-// ---------------------------------------------------------------- RAM rank-1 adaptation (MCMC_run_ram.F90:104-179)
-// a >= 0: cholupdate = DCHUD (dchud.f:122-139); a < 0: choldowndate = DCHDD (dchdd.f:141-179), restated
-// left-looking by column panels: the PW columns' work values sit in registers, the rotations of the
-// rows above come back from a per-chain scratch vector cs_t = (c_0, s_0, c_1, s_1, ...).  Every element
-// sees the same operations in the same order as in LINPACK's column loops.
-// When `fuse` is set the sweeps also accumulate the NEXT proposal P = R_new' z_next into P_t -- update lanes with
-// ascending rows, downdate lanes from the diagonal up (the two pinned dtrmv orders; pdesc says
-// which one a lane's next proposal uses) -- so a wave reads and writes the factor once for its update lanes and once
-// more for its downdate lanes.  Returns true for lanes whose P_t is valid.
-// Rotations (c_i, s_i) of the first NLC rows are kept in LDS (lc), the rest in global scratch: row i's rotation is
-// re-read by every later panel, and the early rows are the ones re-read most often.
-#ifndef MCX_NLC
-#define MCX_NLC 19
-#endif
-#ifndef MCX_MIXED_UNROLL
-#define MCX_MIXED_UNROLL 1
-#endif
-#ifndef MCX_RAM_WAVES
-#define MCX_RAM_WAVES 2
-#endif
-constexpr int NLC = MCX_NLC;     // 19 rows x 2 doubles x 64 lanes = 19 456 B per wave: 8 waves fill the CU's 160 KiB
-// MIXED: the wave holds update AND downdate lanes (RAM near its target acceptance rate).  Stores that cover part of a
-// 512-byte row segment are slow whichever lanes they are (tools/layout_probe2.hip: read all + write 22 % of the lanes
-// takes longer than read all + write all), so in such a wave every lane stores in both sweeps -- the lanes a sweep does
-// not concern store the value they loaded -- and each sweep writes whole segments.  A wave of one kind (the bench's
-// default start: no downdates) takes the other instantiation, whose update sweep stores from inside its own branch.
-template <bool MIXED, int RWT = RW>
-MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, double *cs_t, double *P_t,
-                        const double *theta_t, int lane, int d, double a, double su, bool act, bool fuse, uint32_t &status,
-                        double *lc, bool &pdesc)
-{
-    const bool up = act && (a >= 0.0);
-    const bool down = act && !(a >= 0.0);
-    const int rwe = (RWT == RW) ? RW : ram_panel_width(d, RWT);       // RW: panels of ten (the last one narrower); wide: equal panels
-    // per-chain scratch pair k (rotation c_k, s_k; for a downdate lane first the substitution's a_k): rows < NLC in LDS
-#define CS_(k, w) (*((lc && (k) < NLC) ? &lc[(2 * (k) + (w)) * 64 + lane] : &cs_t[(size_t)(2 * (k) + (w)) * 64 + lane]))
-    // ---- pass A, rows ascending, one read of the factor for both kinds of lanes: update lanes rotate (DCHUD), write and
-    // accumulate the next proposal; downdate lanes run the forward substitution R'a = x of DCHDD (dchdd.f:141-148, x =
-    // -u/sum(u**2)*a), whose solution goes to cs_t[2i+1].  xa = DCHUD's work vector x, or the substitution's partial sums.
-    if (__any(act)) {
-        if (act) {
-            for (int J0 = 0; J0 < d; J0 += rwe) {
-                const int nw = (d - J0) < rwe ? (d - J0) : rwe;
-                double xa[RWT], P[RWT];
-#pragma unroll
-                for (int u = 0; u < RWT; ++u) { xa[u] = up ? GV(zc_t, J0 + (u < nw ? u : nw - 1)) / su * a : 0.0; P[u] = 0.0; }   // x = u/sum(u**2)*a
-if (MIXED) {
-                    // next row's loads before this row's stores (see sweep B)
-                    // (c, s) of an update lane or the substitution's a_i of a downdate lane, and z_next: one row ahead as well
-                    double rn[RWT], cn = 0.0, sn_ = 0.0, zn_ = 0.0;
-                    if (J0 > 0) {
-                        const double *sg = Rt + (size_t)J0 * 64;
-#pragma unroll
-                        for (int u = 0; u < RWT; ++u) rn[u] = LDNT(sg, u < nw ? u : nw - 1);
-                        sn_ = CS_(0, 1);
-                        if (up) { cn = CS_(0, 0); zn_ = fuse ? GV(zn_t, 0) : 0.0; }
-                    }
-#pragma unroll MCX_MIXED_UNROLL
-                    for (int i = 0; i < J0; ++i) {                       // rows above the diagonal block
-                        double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
-                        double r[RWT];
-#pragma unroll
-                        for (int u = 0; u < RWT; ++u) r[u] = rn[u];
-                        const double c = cn, sn = sn_, zi = zn_;
-                        if (i + 1 < J0) {
-                            const double *sg = Rt + (size_t)(rowstart(i + 1, d) + J0 - (i + 1)) * 64;
-#pragma unroll
-                            for (int u = 0; u < RWT; ++u) rn[u] = LDNT(sg, u < nw ? u : nw - 1);
-                            sn_ = CS_(i + 1, 1);
-                            if (up) { cn = CS_(i + 1, 0); zn_ = fuse ? GV(zn_t, i + 1) : 0.0; }
-                        }
-                        if (up) {
-#pragma unroll
-                            for (int u = 0; u < RWT; ++u) {
-                                double t = c * r[u] + sn * xa[u];
-                                xa[u] = c * xa[u] - sn * r[u];
-                                r[u] = t;
-                                P[u] = dfma(t, zi, P[u]);
-                            }
-                        } else {
-#pragma unroll
-                            for (int u = 0; u < RWT; ++u) xa[u] = dfma(r[u], sn, xa[u]);
-                        }
-#pragma unroll
-                        for (int u = 0; u < RWT; ++u) if (u < nw) STNT(seg, u, r[u]);
-                    }
-                } else {
-#pragma unroll 2
-                    for (int i = 0; i < J0; ++i) {                       // rows above the diagonal block
-                        double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
-                        double r[RWT];
-#pragma unroll
-                        for (int u = 0; u < RWT; ++u) r[u] = LDNT(seg, u < nw ? u : nw - 1);
-                        if (up) {
-                            const bool inl = lc && i < NLC;
-                            const double c = inl ? lc[(2 * i) * 64 + lane] : GV(cs_t, 2 * i);
-                            const double sn = inl ? lc[(2 * i + 1) * 64 + lane] : GV(cs_t, 2 * i + 1);
-                            const double zi = fuse ? GV(zn_t, i) : 0.0;
-#pragma unroll
-                            for (int u = 0; u < RWT; ++u) {
-                                double t = c * r[u] + sn * xa[u];
-                                xa[u] = c * xa[u] - sn * r[u];
-                                if (u < nw) STNT(seg, u, t);
-                                P[u] = dfma(t, zi, P[u]);
-                            }
-                        } else {
-                            const double si = CS_(i, 1);
-#pragma unroll
-                            for (int u = 0; u < RWT; ++u) xa[u] = dfma(r[u], si, xa[u]);
-                        }
-                    }
-                }
-                for (int i = J0; i < J0 + nw; ++i) {                     // diagonal block
-                    double *seg = Rt + (size_t)rowstart(i, d) * 64;
-                    const int ui = i - J0, m = d - 1 - i;
-                    double r[RWT];
-#pragma unroll
-                    for (int u = 0; u < RWT; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDNT(seg, k); }
-                    double xi = xa[0];
-#pragma unroll
-                    for (int u = 1; u < RWT; ++u) xi = (u == ui) ? xa[u] : xi;
-                    if (up) {
-                        const double zi = fuse ? GV(zn_t, i) : 0.0;
-                        double rr, c, sn;
-                        d_rotg(GV(seg, 0), xi, rr, c, sn);
-                        GV(seg, 0) = rr;
-                        if (lc && i < NLC) { lc[(2 * i) * 64 + lane] = c; lc[(2 * i + 1) * 64 + lane] = sn; }
-                        else if (J0 + nw < d) { GV(cs_t, 2 * i) = c; GV(cs_t, 2 * i + 1) = sn; }      // (the last panel's rotations have no later panel to serve)
-#pragma unroll
-                        for (int u = 0; u < RWT; ++u) {
-                            const bool off = (u > ui) && (u < nw);
-                            double t = c * r[u] + sn * xa[u];
-                            double nx = c * xa[u] - sn * r[u];
-                            xa[u] = off ? nx : xa[u];
-                            if (!MIXED) { if (off) STNT(seg, u - ui, t); }
-                            else r[u] = off ? t : r[u];
-                            double tp = (u == ui) ? rr : t;
-                            double np = dfma(tp, zi, P[u]);
-                            P[u] = (u >= ui && u < nw) ? np : P[u];
-                        }
-                    } else {
-                        double si = -(GV(zc_t, i) / su * a) - xi;
-                        si = si / GV(seg, 0);
-                        CS_(i, 1) = si;
-#pragma unroll
-                        for (int u = 0; u < RWT; ++u) { double na = dfma(r[u], si, xa[u]); xa[u] = (u > ui) ? na : xa[u]; }
-                    }
-                    if (MIXED) {                                         // the off-diagonal part of the row, every lane
-#pragma unroll
-                        for (int u = 0; u < RWT; ++u) if ((u > ui) && (u < nw)) STNT(seg, u - ui, r[u]);
-                    }
-                }
-                if (up && fuse) {                        // next candidate = theta + R_new' z_next (MCMC_DRAM.F90:29)
-                    double th[RWT];                       // the state's loads before the candidate's stores (see copy_vec)
-#pragma unroll
-                    for (int u = 0; u < RWT; ++u) th[u] = GV(theta_t, J0 + (u < nw ? u : nw - 1));
-#pragma unroll
-                    for (int u = 0; u < RWT; ++u) if (u < nw) GV(P_t, J0 + u) = th[u] + P[u];
-                }
-            }
-        }
-    }
-    if (up) pdesc = false;
-    bool down_ok = false;
-    if (__any(down)) {
-        if (down) {
-            // norm = dnrm2(p, s), classic scale/ssq form (dchdd.f:149)
-            double norm;
-            if (d == 1) norm = fabs(CS_(0, 1));
-            else {
-                double scale = 0.0, ssq = 1.0;
-#pragma unroll 4
-                for (int k = 0; k < d; ++k) {
-                    double xk = CS_(k, 1);
-                    if (xk != 0.0) {
-                        double ax = fabs(xk);
-                        if (scale < ax) { double q = scale / ax; ssq = 1.0 + ssq * (q * q); scale = ax; }
-                        else { double q = ax / scale; ssq = ssq + q * q; }
-                    }
-                }
-                norm = scale * sqrt(ssq);
-            }
-            if (!(norm < 1.0)) {
-                status |= ST_RAM_DOWNDATE_FAIL;      // INFO = -1: R untouched (the reference stops here)
-                pdesc = false;
-            } else {
-                down_ok = true;
-                pdesc = true;
-                double alpha = sqrt(1.0 - norm * norm);
-#pragma unroll 2
-                for (int k = d - 1; k >= 0; --k) {   // dchdd.f:158-167
-                    double sk = CS_(k, 1);
-                    double scale = alpha + fabs(sk);
-                    double aa = alpha / scale, bb = sk / scale;
-                    double nn = sqrt(aa * aa + bb * bb);
-                    CS_(k, 0) = aa / nn;
-                    CS_(k, 1) = bb / nn;
-                    alpha = scale * nn;
-                }
-            }
-        }
-        // ---- pass B (dchdd.f:171-179): each column from its diagonal up; the next proposal accumulates in that
-        // same order (mcxo_trmv_ut_desc), so downdate lanes, too, read and write the factor once more and are done.
-        // MIXED: every lane of the wave loads and stores (whole segments); only the downdate lanes change the values.
-        const bool touch = MIXED ? act : down_ok;
-        if (__any(down_ok)) {
-            if (touch) {
-                for (int J0 = 0; J0 < d; J0 += rwe) {
-                    const int nw = (d - J0) < rwe ? (d - J0) : rwe;
-                    double xx[RWT], P[RWT];
-#pragma unroll
-                    for (int u = 0; u < RWT; ++u) { xx[u] = 0.0; P[u] = 0.0; }
-                    for (int i = J0 + nw - 1; i >= J0; --i) {            // diagonal block, rows descending
-                        double *seg = Rt + (size_t)rowstart(i, d) * 64;
-                        const int ui = i - J0, m = d - 1 - i;
-                        double r[RWT];
-#pragma unroll
-                        for (int u = 0; u < RWT; ++u) { int k = u - ui; k = k < 0 ? 0 : k; k = k > m ? m : k; r[u] = LDB(seg, k); }
-                        if (!MIXED || down_ok) {
-                            const double ci = CS_(i, 0), si = CS_(i, 1);
-                            const double zi = fuse ? GV(zn_t, i) : 0.0;
-#pragma unroll
-                            for (int u = 0; u < RWT; ++u) {
-                                const bool on = (u >= ui) && (u < nw);
-                                double t = ci * xx[u] + si * r[u];
-                                double nr = ci * r[u] - si * xx[u];
-                                if (!MIXED) { if (on) STB(seg, u - ui, nr); }
-                                else r[u] = on ? nr : r[u];
-                                xx[u] = on ? t : xx[u];
-                                const double np = (u == ui) ? nr * zi : dfma(nr, zi, P[u]);
-                                P[u] = on ? np : P[u];
-                            }
-                        }
-                        if (MIXED) {
-#pragma unroll
-                            for (int u = 0; u < RWT; ++u) if ((u >= ui) && (u < nw)) STB(seg, u - ui, r[u]);
-                        }
-                    }
-if (MIXED) {
-                        // The next row's loads go out before this row's stores: vmcnt retires in order, so a load issued
-                        // after a store cannot be waited for without waiting for that store's acknowledgement -- which
-                        // would put the store latency on every row's critical path.
-                        double rn[RWT], cn = 0.0, sn_ = 0.0, zn_ = 0.0;
-                        if (J0 > 0) {
-                            const double *sg = Rt + (size_t)(rowstart(J0 - 1, d) + 1) * 64;
-#pragma unroll
-                            for (int u = 0; u < RWT; ++u) rn[u] = LDB(sg, u < nw ? u : nw - 1);
-                            if (down_ok) { cn = CS_(J0 - 1, 0); sn_ = CS_(J0 - 1, 1); zn_ = fuse ? GV(zn_t, J0 - 1) : 0.0; }
-                        }
-#pragma unroll MCX_MIXED_UNROLL
-                        for (int i = J0 - 1; i >= 0; --i) {              // rows above, descending
-                            double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
-                            double r[RWT];
-#pragma unroll
-                            for (int u = 0; u < RWT; ++u) r[u] = rn[u];
-                            const double ci = cn, si = sn_, zi = zn_;
-                            if (i > 0) {
-                                const double *sg = Rt + (size_t)(rowstart(i - 1, d) + J0 - (i - 1)) * 64;
-#pragma unroll
-                                for (int u = 0; u < RWT; ++u) rn[u] = LDB(sg, u < nw ? u : nw - 1);
-                                if (down_ok) { cn = CS_(i - 1, 0); sn_ = CS_(i - 1, 1); zn_ = fuse ? GV(zn_t, i - 1) : 0.0; }
-                            }
-                            if (down_ok) {
-#pragma unroll
-                                for (int u = 0; u < RWT; ++u) {
-                                    double t = ci * xx[u] + si * r[u];
-                                    const double nr = ci * r[u] - si * xx[u];
-                                    r[u] = nr;
-                                    xx[u] = t;
-                                    P[u] = dfma(nr, zi, P[u]);
-                                }
-                            }
-#pragma unroll
-                            for (int u = 0; u < RWT; ++u) if (u < nw) STB(seg, u, r[u]);
-                        }
-                    } else {
-#pragma unroll 2
-                        for (int i = J0 - 1; i >= 0; --i) {              // rows above, descending
-                            double *seg = Rt + (size_t)(rowstart(i, d) + J0 - i) * 64;
-                            const double ci = CS_(i, 0), si = CS_(i, 1);
-                            const double zi = fuse ? GV(zn_t, i) : 0.0;
-                            double r[RWT];
-#pragma unroll
-                            for (int u = 0; u < RWT; ++u) r[u] = LDB(seg, u < nw ? u : nw - 1);
-#pragma unroll
-                            for (int u = 0; u < RWT; ++u) {
-                                double t = ci * xx[u] + si * r[u];
-                                const double nr = ci * r[u] - si * xx[u];
-                                if (u < nw) STB(seg, u, nr);
-                                xx[u] = t;
-                                P[u] = dfma(nr, zi, P[u]);
-                            }
-                        }
-                    }
-                    if (fuse && down_ok) {
-                        double th[RWT];
-#pragma unroll
-                        for (int u = 0; u < RWT; ++u) th[u] = GV(theta_t, J0 + (u < nw ? u : nw - 1));
-#pragma unroll
-                        for (int u = 0; u < RWT; ++u) if (u < nw) GV(P_t, J0 + u) = th[u] + P[u];
-                    }
-                }
-            }
-        }
-    }
-    return (up || down_ok) && fuse;
-#undef CS_
-}
-
-// The same adaptation on a FULL column-major factor (condmax > 0: R is the d x d SVD factor U sqrt(s) 2.4/sqrt(d) of
-// covtor, and MCMC_adapt_ram hands it to dchud / dchdd as it is, MCMC_run_ram.F90:168-172).  LINPACK only touches
-// R(i,j), i <= j; the proposal matmulx(R,u) (MCMC_run_ram.F90:96-97) goes on using the whole matrix.  Plain column
-// loops, the arithmetic of ram_update element for element; not fused, not tuned (the combination is a curiosity of the
-// reference, kept so that every namelist it accepts runs).
-#define RF(i, j) Rf_t[((size_t)(j) * d + (i)) * 64 + lane]
-MCX_DEV void ram_update_full(double *Rf_t, const double *zc_t, double *cs_t, int lane, int d, double a, double su, bool act,
-                             uint32_t &status)
-{
-    if (!act) return;
-    if (a >= 0.0) {                                              // dchud.f:122-139
-        for (int j = 0; j < d; ++j) {
-            double xj = GV(zc_t, j) / su * a;
-            for (int i = 0; i < j; ++i) {
-                const double c = GV(cs_t, 2 * i), sn = GV(cs_t, 2 * i + 1), r = RF(i, j);
-                double t = c * r + sn * xj;
-                xj = c * xj - sn * r;
-                RF(i, j) = t;
-            }
-            double rr, c, sn;
-            d_rotg(RF(j, j), xj, rr, c, sn);
-            RF(j, j) = rr; GV(cs_t, 2 * j) = c; GV(cs_t, 2 * j + 1) = sn;
-        }
-        return;
-    }
-    for (int j = 0; j < d; ++j) {                                // dchdd.f:141-148: R'a = x, x = -u/sum(u**2)*a
-        double acc = 0.0;
-        for (int i = 0; i < j; ++i) acc = dfma(RF(i, j), GV(cs_t, 2 * i + 1), acc);
-        double xj = -(GV(zc_t, j) / su * a);
-        double sj = xj - acc;
-        GV(cs_t, 2 * j + 1) = sj / RF(j, j);
-    }
-    double norm;                                                 // dnrm2, dchdd.f:149
-    if (d == 1) norm = fabs(GV(cs_t, 1));
-    else {
-        double scale = 0.0, ssq = 1.0;
-        for (int k = 0; k < d; ++k) {
-            double xk = GV(cs_t, 2 * k + 1);
-            if (xk != 0.0) {
-                double ax = fabs(xk);
-                if (scale < ax) { double q = scale / ax; ssq = 1.0 + ssq * (q * q); scale = ax; }
-                else { double q = ax / scale; ssq = ssq + q * q; }
-            }
-        }
-        norm = scale * sqrt(ssq);
-    }
-    if (!(norm < 1.0)) { status |= ST_RAM_DOWNDATE_FAIL; return; }
-    double alpha = sqrt(1.0 - norm * norm);
-    for (int k = d - 1; k >= 0; --k) {                           // dchdd.f:158-167
-        double sk = GV(cs_t, 2 * k + 1);
-        double scale = alpha + fabs(sk);
-        double aa = alpha / scale, bb = sk / scale;
-        double nn = sqrt(aa * aa + bb * bb);
-        GV(cs_t, 2 * k) = aa / nn;
-        GV(cs_t, 2 * k + 1) = bb / nn;
-        alpha = scale * nn;
-    }
-    for (int j = 0; j < d; ++j) {                                // dchdd.f:171-179
-        double xx = 0.0;
-        for (int i = j; i >= 0; --i) {
-            const double ci = GV(cs_t, 2 * i), si = GV(cs_t, 2 * i + 1), r = RF(i, j);
-            double t = ci * xx + si * r;
-            RF(i, j) = ci * r - si * xx;
-            xx = t;
-        }
-    }
-}
-#undef RF
-
-// ---------------------------------------------------------------- delayed rejection (MCMC_run.F90:65-91)
-// q = dx' iC dx with iC symmetric, upper triangle packed by rows (dsymv 'U' + sum, MCMC_DRAM.F90:180-182,
-// matutils.F90:180): y_i = sum_j S(i,j) dx_j ascending j as an fma chain, q = sum_i y_i dx_i.
-// One sweep over the rows: row i finishes y_i and feeds S(i,j) dx_i into y_j for j > i.
-// X holds dx, Y the running y; both per-lane LDS vectors.
-MCX_DEV double quadform_sym(const double *St, int lane, int d, const double *X, double *Y)
-{
-    double q = 0.0;
-    for (int i = 0; i < d; ++i) {
-        const double *rowp = St + (size_t)rowstart(i, d) * 64;
-        const int n = d - i;
-        const double dxi = XL(i);
-        double sii = GV(rowp, 0);
-        double yi = (i == 0) ? sii * dxi : dfma(sii, dxi, Y[i * 64 + lane]);
-        // a batch of row elements at a time: the batch's dx and y values are read together, then the chain of y_i and the
-        // independent updates of y_{i+k} -- element by element every update's LDS store stands between the next element's
-        // loads and the ones before it (the compiler must assume the two vectors overlap), a round trip per element
-        sweep_batches(rowp, lane, 1, n, [&](int k, const double (&sij)[CH], int m) {
-            double xs[CH], ys[CH];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) { const int kk = i + k + (u < m ? u : m - 1); xs[u] = XL(kk); ys[u] = (i == 0) ? 0.0 : Y[kk * 64 + lane]; }
-#pragma unroll
-            for (int u = 0; u < CH; ++u) if (u < m) yi = dfma(sij[u], xs[u], yi);
-#pragma unroll
-            for (int u = 0; u < CH; ++u) if (u < m) Y[(i + k + u) * 64 + lane] = (i == 0) ? sij[u] * dxi : dfma(sij[u], dxi, ys[u]);
-        });
-        q = q + yi * dxi;
-    }
-    return q;
-}
-
-// the same quadratic form with ONE inverse covariance for every chain (pooled mode with delayed rejection): Ss is the
-// packed upper triangle by rows, wave-uniform, read through the scalar cache; per element the operations of quadform_sym
-MCX_DEV double quadform_sym_shared(const double *__restrict__ Ss, int lane, int d, const double *X, double *Y)
-{
-    double q = 0.0;
-    for (int i = 0; i < d; ++i) {
-        const double *__restrict__ rowp = Ss + rowstart(i, d);
-        const int n = d - i;
-        const double dxi = XL(i);
-        const double sii = rowp[0];
-        double yi = (i == 0) ? sii * dxi : dfma(sii, dxi, Y[i * 64 + lane]);
-        for (int k = 1; k < n; ++k) {
-            const double sij = rowp[k];
-            yi = dfma(sij, XL(i + k), yi);
-            Y[(i + k) * 64 + lane] = (i == 0) ? sij * dxi : dfma(sij, dxi, Y[(i + k) * 64 + lane]);
-        }
-        q = q + yi * dxi;
-    }
-    return q;
-}
-
-// ---------------------------------------------------------------- the step kernel
-// Iterations it0..it1 (absolute simuind) of MCMC_run (MCMC_run.F90:41-107) or MCMC_run_ram
-// (MCMC_run_ram.F90:45-81) for one tile of 64 chains.  LDS is used only by the delayed-rejection
-// quadratic forms (2*d*64 doubles when dodr, none otherwise).
-template <bool RAM, bool DR, bool POOLED, bool WIDE_T = (RAM || (!DR && !POOLED)), bool FULLR = false, bool LDSV = false, bool LDSR = false, bool XG = false, int RWT = RW>
-MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__restrict__ ramscale,
-                       const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
-                       const double *__restrict__ g_sharedR, const double *__restrict__ g_sharedR2 = nullptr,
-                       const double *__restrict__ g_sharediC = nullptr)
-{
-    extern __shared__ double Xlds[];
-    const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
-    // the delayed-rejection quadratic forms' two vectors: LDS, or (XG, a compile-time choice: no flat accesses) the chain's global scratch
-    double *X = XG ? E.xscr + (size_t)tile * 2 * d * 64 : Xlds;
-    constexpr bool ldsv = LDSV && !RAM && !DR && !POOLED;                // step_kernel_ldsv: launched with 4 d x 512 bytes of LDS (a compile-time
-                                                                        // choice, so that the vectors' accesses are ds_read / ds_write, not flat)
-    // step_kernel_ldsr (npar <= TW): besides the state, the chain's packed factor stays in LDS for the launch -- AM only reads
-    // it between two ticks -- and ONE vector serves as normals, proposal and candidate (a single column panel: the product
-    // has read every normal before it stores anything)
-    constexpr bool ldsr = ldsv && LDSR;
-    double *theta_g = E.theta + (size_t)tile * d * 64;
-    double *theta_t = ldsv ? X : theta_g;
-    double *cand_t = ldsv ? X + (size_t)d * 64 : E.cand + (size_t)tile * d * 64;           // proposal vector P, then candidate theta + P
-    double *zs_t = ldsr ? cand_t : (ldsv ? X + (size_t)2 * d * 64 : E.zs + (size_t)tile * 2 * d * 64);       // two normal vectors: this iteration's and the next one's
-    double *cs_t = E.cs + (size_t)tile * 2 * d * 64;           // RAM: rotations; DR: second-stage candidate
-    if (ldsv) for (int k = 0; k < d; ++k) GV(theta_t, k) = GV(theta_g, k);
-    // step_kernel_ram_ldsr (npar <= RW: one column panel): the factor that DCHUD / DCHDD rewrite at every iteration stays in LDS for the
-    // launch, behind the 2 npar vectors of rotations -- north_star's "Cholesky factor staged in LDS" for the rank-one update itself
-    constexpr bool ramr = RAM && LDSR && !FULLR;
-    double *Rt = (ldsr || ramr) ? X + (size_t)2 * d * 64 : E.R + (size_t)tile * E.P * 64;
-    if (ldsr || ramr) { const double *Rg = E.R + (size_t)tile * E.P * 64; copy_vec(Rt, Rg, nullptr, lane, E.P); }
-    double *Y = X + (size_t)d * 64;
-    double *c2_t = cs_t;
-
-    Rng g;
-    g.k0 = E.k0; g.k1 = E.chain_id0 + (uint32_t)(tile * 64 + lane);
-    g.n = TIDX(E.rngn, tile, 1, 0, lane); g.cblk = 0; g.c2 = 0; g.c3 = 0;
-    g.saved = (int)TIDX(E.ictr, tile, NICTR, I_SAVED, lane);
-    g.saved_y = TIDX(E.scal, tile, NSCAL, S_SAVEDY, lane);
-    double ss1 = TIDX(E.scal, tile, NSCAL, S_SS1, lane), pri1 = TIDX(E.scal, tile, NSCAL, S_PRI1, lane);
-    double sigma2 = TIDX(E.scal, tile, NSCAL, S_SIGMA2, lane), alpha12 = TIDX(E.scal, tile, NSCAL, S_ALPHA12, lane);
-    uint32_t stayed = TIDX(E.ictr, tile, NICTR, I_STAYED, lane), bnd = TIDX(E.ictr, tile, NICTR, I_BNDSTAYED, lane);
-    uint32_t chainind = TIDX(E.ictr, tile, NICTR, I_CHAININD, lane), curcount = TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane);
-    uint32_t status = TIDX(E.ictr, tile, NICTR, I_STATUS, lane);
-    uint32_t dracc = TIDX(E.ictr, tile, NICTR, I_DRACC, lane), drtries = TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane);
-    uint32_t erstayed = TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane);
-    bool pdesc = RAM && TIDX(E.ictr, tile, NICTR, I_PDESC, lane) != 0u;   // the next proposal's dtrmv order (after a downdate: diagonal first)
-    uint32_t downs = RAM ? TIDX(E.ictr, tile, NICTR, I_DOWNS, lane) : 0u;
-
-    bool have_p = false;                          // lanes whose candidate is already in cand_t
-    double su_c = gen_normals<RAM ? 1 : MCX_RNG_NB>(g, zs_t + (ldsr ? 0 : (size_t)(it0 & 1) * d * 64), lane, d, true), su_n = 0.0;
-
-    for (int it = it0; it <= it1; ++it) {
-        double *zc_t = ldsr ? zs_t : zs_t + (size_t)(it & 1) * d * 64;          // z of this iteration
-        double *zn_t = ldsr ? zs_t : zs_t + (size_t)((it + 1) & 1) * d * 64;    // z of the next one
-        // ---- newpar = MCMC_propose(oldpar, R)
-        if (POOLED) { if (E.usesvd) gemvN_shared(g_sharedR, zc_t, cand_t, theta_t, lane, d); else trmv_shared(g_sharedR, zc_t, cand_t, theta_t, lane, d); }
-        else if (E.usesvd) gemvN_panels(E.Rf + (size_t)tile * d * d * 64, zc_t, cand_t, theta_t, lane, d, true);   // matmulx(R,z)
-        else if (__any(!have_p)) trmv_panels<!RAM>(Rt, zc_t, cand_t, theta_t, lane, d, !have_p, RAM && pdesc);
-        // ---- bounds, prior, ss, alpha, reject
-        bool inb = target_inbounds(E.tgt, d, lane, cand_t);
-        double pri2 = target_prior(E.tgt, d, lane, cand_t);
-        double ss2 = target_ss<WIDE_T>(E.tgt, d, lane, cand_t, g_mu, g_lamT);   // wide (candidate read once) where registers allow
-        bool reject;
-        if (!RAM && !DR && E.method == M_ER) {            // early rejection, MCMC_run_er.F90:60-89
-            if (!inb) { bnd += 1; reject = true; }
-            else {
-                double u = rng_uniform(g);                // MCMC_sscrit, MCMC_DRAM.F90:124-135: always drawn
-                double sscrit = -2.0 * d_log(u) + ss1 / sigma2 + pri1;
-                if (pri2 >= sscrit) { reject = true; erstayed += 1; }
-                else { sscrit = sigma2 * (sscrit - pri2); reject = (ss2 >= sscrit); }
-            }
-        } else if (!inb) {
-            if (!DR) bnd += 1;                            // MCMC_run.F90:49
-            reject = true;
-            if (!RAM) alpha12 = 0.0;                      // RAM leaves alpha12 stale: MCMC_run_ram.F90:52-54
-        } else {
-            alpha12 = d_alpha(ss1, pri1, ss2, pri2, sigma2);
-            reject = true;                                // MCMC_reject, MCMC_DRAM.F90:140-155
-            if (alpha12 >= 1.0) reject = false;
-            else if (alpha12 > 0.0) { double u = rng_uniform(g); if (u <= alpha12) reject = false; }
-        }
-        // ---- second stage: one delayed-rejection try with R2 = R/drscale (MCMC_run.F90:65-91)
-        bool dr_moved = false;
-        if (DR && __any(reject)) {
-            const bool m = reject;
-            if (m) drtries += 1;
-            double *z2_t = zn_t;                          // stage-2 normals: the "next" buffer is still free
-            gen_normals<RAM ? 1 : MCX_RNG_NB>(g, z2_t, lane, d, m);
-            if (POOLED) {                                 // one R2 for every chain; lanes that did not draw compute on stale normals and are not looked at
-                if (E.usesvd) gemvN_shared(g_sharedR2, z2_t, c2_t, theta_t, lane, d); else trmv_shared(g_sharedR2, z2_t, c2_t, theta_t, lane, d);
-            }
-            else if (E.usesvd) gemvN_panels(E.R2f + (size_t)tile * d * d * 64, z2_t, c2_t, theta_t, lane, d, m);
-            else trmv_panels<true>(E.R2 + (size_t)tile * E.P * 64, z2_t, c2_t, theta_t, lane, d, m);
-            if (m) {
-                bool inb2 = target_inbounds(E.tgt, d, lane, c2_t);
-                if (!inb2) bnd += 1;
-                else {
-                    double pri3 = target_prior(E.tgt, d, lane, c2_t);
-                    double ss3 = target_ss<false>(E.tgt, d, lane, c2_t, g_mu, g_lamT);
-                    // MCMC_DR_alpha13, MCMC_DRAM.F90:162-186
-                    double alpha32;
-                    if (alpha12 == 0.0) alpha32 = 0.0;
-                    else alpha32 = min1(d_exp(-0.5 * ((ss2 - ss3) / sigma2 + (pri2 - pri3))));
-                    double l2 = -0.5 * ((ss3 - ss1) / sigma2 + (pri3 - pri1));
-                    const double *iCt = POOLED ? nullptr : E.iC + (size_t)tile * E.P * 64;
-                    for (int k = 0; k < d; ++k) XL(k) = GV(c2_t, k) - GV(cand_t, k);
-                    double qa = POOLED ? quadform_sym_shared(g_sharediC, lane, d, X, Y) : quadform_sym(iCt, lane, d, X, Y);
-                    for (int k = 0; k < d; ++k) XL(k) = GV(theta_t, k) - GV(cand_t, k);
-                    double qb = POOLED ? quadform_sym_shared(g_sharediC, lane, d, X, Y) : quadform_sym(iCt, lane, d, X, Y);
-                    double q1 = -0.5 * (qa - qb);
-                    double alpha13 = min1(d_exp(l2 + q1) * (1.0 - alpha32) / (1.0 - alpha12));
-                    bool rej2 = true;
-                    if (alpha13 >= 1.0) rej2 = false;
-                    else if (alpha13 > 0.0) { double u = rng_uniform(g); if (u <= alpha13) rej2 = false; }
-                    if (!rej2) { dracc += 1; reject = false; dr_moved = true; ss2 = ss3; pri2 = pri3; }
-                }
-            }
-        }
-        if (reject) { stayed += 1; curcount += 1; }
-        else { ss1 = ss2; pri1 = pri2; chainind += 1; curcount = 1; }
-        // ---- MCMC_updatesigma2 (MCMC_DRAM.F90:192-206)
-        if (E.updatesigma) {
-            double gm = rng_gamma(g, E.gam_shape, 2.0 / (E.N0S02 + ss1));
-            sigma2 = 1.0 / gm;
-        }
-        // ---- oldpar = newpar; MCMC_savechain (MCMC_aux.F90:167-185): accept ballot + accepted row into the ring
-        unsigned long long ballot = __ballot(!reject);
-        const int slot = it % E.wcap;
-        if (!reject) {
-            double *h = E.hist ? E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64 : nullptr;
-            const double *src = dr_moved ? c2_t : cand_t;     // newpar = newpar2 when the DR try was accepted
-            copy_vec(theta_t, src, h, lane, d);
-            if (h) GV(h, d) = ss1;
-        }
-        if (E.hist) {
-            if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ballot;
-            if (E.record_s2) E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = sigma2;
-        }
-        if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
-        // ---- the next iteration's normals: nothing else draws between here and its MCMC_propose
-        const bool pre = (it < it1);
-        if (pre) su_n = gen_normals<RAM ? 1 : MCX_RNG_NB>(g, zn_t, lane, d, true);
-        // ---- MCMC_adapt_ram
-        have_p = false;
-        if (RAM && E.doadapt != 0 && !(it < E.burnintime && E.doburnin != 0)) {
-            double a = ramscale[it - it0] * (alpha12 - E.alphatarget);
-            downs += (a >= 0.0) ? 0u : 1u;
-            if (FULLR) ram_update_full(E.Rf + (size_t)tile * d * d * 64, zc_t, cs_t, lane, d, a, su_c, true, status);   // condmax > 0
-            else if (__any(!(a >= 0.0)))                  // a wave with downdate lanes: whole-segment stores in both sweeps
-                have_p = ram_update<true, RWT>(Rt, zc_t, zn_t, cs_t, cand_t, theta_t, lane, d, a, su_c, true, pre, status, RAM ? X : nullptr, pdesc);
-            else have_p = ram_update<false, RWT>(Rt, zc_t, zn_t, cs_t, cand_t, theta_t, lane, d, a, su_c, true, pre, status, RAM ? X : nullptr, pdesc);
-        }
-        su_c = su_n;
-    }
-
-    TIDX(E.rngn, tile, 1, 0, lane) = g.n;
-    TIDX(E.ictr, tile, NICTR, I_SAVED, lane) = (uint32_t)g.saved;
-    TIDX(E.scal, tile, NSCAL, S_SAVEDY, lane) = g.saved_y;
-    TIDX(E.scal, tile, NSCAL, S_SS1, lane) = ss1; TIDX(E.scal, tile, NSCAL, S_PRI1, lane) = pri1;
-    TIDX(E.scal, tile, NSCAL, S_SIGMA2, lane) = sigma2; TIDX(E.scal, tile, NSCAL, S_ALPHA12, lane) = alpha12;
-    TIDX(E.ictr, tile, NICTR, I_STAYED, lane) = stayed; TIDX(E.ictr, tile, NICTR, I_BNDSTAYED, lane) = bnd;
-    TIDX(E.ictr, tile, NICTR, I_CHAININD, lane) = chainind; TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane) = curcount;
-    TIDX(E.ictr, tile, NICTR, I_STATUS, lane) = status;
-    TIDX(E.ictr, tile, NICTR, I_DRACC, lane) = dracc; TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane) = drtries;
-    TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane) = erstayed;
-    if (RAM) { TIDX(E.ictr, tile, NICTR, I_PDESC, lane) = pdesc ? 1u : 0u; TIDX(E.ictr, tile, NICTR, I_DOWNS, lane) = downs; }
-    if (ldsv) for (int k = 0; k < d; ++k) GV(theta_g, k) = GV(theta_t, k);
-    if (ramr) { double *Rg = E.R + (size_t)tile * E.P * 64; copy_vec(Rg, Rt, nullptr, lane, E.P); }
-}
-
-// ---------------------------------------------------------------- delayed rejection with per-chain factors
-// MCMC_run with drscale > 0 (MCMC_run.F90:41-107).  step_body<DR> above moves, per iteration, the factor R, its
-// second-stage copy R2, the inverse covariance iC TWICE (one sweep per quadratic form of MCMC_DR_alpha13) and ~2.5 kB of
-// per-chain scratch vectors that L2 cannot hold between a write and the read that follows it (rocprof,
-// profiles/r02_d_final/c3_dram: 9.4 kB per iteration against 3.7 kB of factors at npar = 20).  Here
-//   * the normals and the first-stage candidate live in the wave's two LDS vectors (the ones step_body<DR> keeps for the
-//     quadratic forms); only the second-stage candidate goes through the chain's global scratch;
-//   * the two quadratic forms dx' iC dx of MCMC_DR_alpha13 (MCMC_DRAM.F90:180-182) share ONE sweep over iC
-//     (quadform2_panels): both dx vectors in the two LDS vectors (normals and first-stage candidate are dead by then).
-// Every chain of operations is the one of step_body<DR> (same operands, same order): the results are its bit for bit.
-
-// qa = xa' S xa and qb = xb' S xb, S symmetric with its upper triangle packed by rows, in one sweep over S.
-// Per form the operations of quadform_sym: y_i = sum_j S(i,j) x_j as ONE fma chain ascending in j -- first the column part
-// S(i',i) x_i' (i' < i), then the diagonal, then the row part -- and q = sum_i y_i x_i ascending in i.  Column panels of TQ:
-// the column parts of the panel's y_j accumulate in registers while the rows stream by (rows ascending); a row's own
-// chain y_i runs along the row, across the panels, and waits between two panels in the chain's global scratch (ysa, ysb:
-// npar doubles each, one store and one load per row and panel boundary -- nothing at npar <= TQ); q takes y_i x_i when
-// the last panel completes it, rows ascending.  xa, xb: per-lane LDS vectors.
-constexpr int TQ = 10;
-MCX_DEV void quadform2_panels(const double *St, int lane, int d, const double *Xa, const double *Xb, double *ysa, double *ysb,
-                              double &qa, double &qb)
-{
-    qa = 0.0; qb = 0.0;
-    for (int J0 = 0; J0 < d; J0 += TQ) {
-        const int nw = (d - J0) < TQ ? (d - J0) : TQ;
-        const bool last = J0 + TQ >= d;
-        double Ya[TQ], Yb[TQ], xja[TQ], xjb[TQ];
-#pragma unroll
-        for (int u = 0; u < TQ; ++u) { const int j = J0 + (u < nw ? u : nw - 1); xja[u] = GV(Xa, j); xjb[u] = GV(Xb, j); Ya[u] = 0.0; Yb[u] = 0.0; }
-        // rows above the panel: the row's chain takes the panel's nw elements, the panel's columns take the row's x_i
-        {
-#ifndef MCX_Q2_NB
-#define MCX_Q2_NB 1
-#endif
-            constexpr int NB = MCX_Q2_NB;                          // rows in flight: more than one spills registers (2: 70, 3: 167), and a spill here costs more than the latency it hides (c3: 20.3 / 17.5 / 14.8 ms per launch at 3 / 2 / 1)
-            double rr[NB][TQ], xa_[NB], xb_[NB], ya_[NB], yb_[NB];
-#define MCX_Q2_LD(s_, i_) { const double *seg_ = St + (size_t)(rowstart((i_), d) + J0 - (i_)) * 64; \
-                            _Pragma("unroll") for (int u = 0; u < TQ; ++u) rr[s_][u] = GV(seg_, u < nw ? u : nw - 1); \
-                            xa_[s_] = GV(Xa, (i_)); xb_[s_] = GV(Xb, (i_)); ya_[s_] = GV(ysa, (i_)); yb_[s_] = GV(ysb, (i_)); }
-#define MCX_Q2_FM(s_, i_) { double ya = ya_[s_], yb = yb_[s_]; const double xia = xa_[s_], xib = xb_[s_]; \
-                            _Pragma("unroll") for (int u = 0; u < TQ; ++u) if (u < nw) { ya = dfma(rr[s_][u], xja[u], ya); yb = dfma(rr[s_][u], xjb[u], yb); } \
-                            _Pragma("unroll") for (int u = 0; u < TQ; ++u) { \
-                                Ya[u] = ((i_) == 0) ? rr[s_][u] * xia : dfma(rr[s_][u], xia, Ya[u]); \
-                                Yb[u] = ((i_) == 0) ? rr[s_][u] * xib : dfma(rr[s_][u], xib, Yb[u]); } \
-                            if (last) { qa = qa + ya * xia; qb = qb + yb * xib; } else { GV(ysa, (i_)) = ya; GV(ysb, (i_)) = yb; } }
-#pragma unroll
-            for (int s = 0; s < NB - 1; ++s) if (s < J0) MCX_Q2_LD(s, s)
-            for (int i = 0; i < J0; i += NB) {
-#pragma unroll
-                for (int s = 0; s < NB; ++s) {
-                    if (i + s + NB - 1 < J0) MCX_Q2_LD((s + NB - 1) % NB, i + s + NB - 1)
-                    if (i + s < J0) MCX_Q2_FM(s, i + s)
-                }
-            }
-#undef MCX_Q2_LD
-#undef MCX_Q2_FM
-        }
-        // diagonal block: row i = J0 + ui takes its diagonal element on top of the finished column part, then the rest of its row
-        {
-            double da[TQ], db[TQ];
-#define MCX_Q2_LDD(rv, i_) { const double *seg_ = St + (size_t)rowstart((i_), d) * 64; const int ui_ = (i_) - J0, m_ = d - 1 - (i_); \
-                             _Pragma("unroll") for (int u = 0; u < TQ; ++u) { int k = u - ui_; k = k < 0 ? 0 : k; k = k > m_ ? m_ : k; rv[u] = GV(seg_, k); } }
-#define MCX_Q2_FMD(rv, i_) { const int ui_ = (i_) - J0; double xia = 0.0, xib = 0.0, ya = 0.0, yb = 0.0; \
-                             _Pragma("unroll") for (int u = 0; u < TQ; ++u) if (u == ui_) { xia = xja[u]; xib = xjb[u]; \
-                                 ya = ((i_) == 0) ? rv[u] * xia : dfma(rv[u], xia, Ya[u]); yb = ((i_) == 0) ? rv[u] * xib : dfma(rv[u], xib, Yb[u]); } \
-                             _Pragma("unroll") for (int u = 0; u < TQ; ++u) if (u > ui_ && u < nw) { \
-                                 ya = dfma(rv[u], xja[u], ya); yb = dfma(rv[u], xjb[u], yb); \
-                                 Ya[u] = ((i_) == 0) ? rv[u] * xia : dfma(rv[u], xia, Ya[u]); \
-                                 Yb[u] = ((i_) == 0) ? rv[u] * xib : dfma(rv[u], xib, Yb[u]); } \
-                             if (last) { qa = qa + ya * xia; qb = qb + yb * xib; } else { GV(ysa, (i_)) = ya; GV(ysb, (i_)) = yb; } }
-            MCX_Q2_LDD(da, J0)
-            for (int i = J0; i < J0 + nw; i += 2) {
-                if (i + 1 < J0 + nw) MCX_Q2_LDD(db, i + 1)
-                MCX_Q2_FMD(da, i)
-                if (i + 2 < J0 + nw) MCX_Q2_LDD(da, i + 2)
-                if (i + 1 < J0 + nw) MCX_Q2_FMD(db, i + 1)
-            }
-#undef MCX_Q2_LDD
-#undef MCX_Q2_FMD
-        }
-    }
-}
-
-template <bool LDSV>      // the two vectors in LDS (a compile-time choice: a pointer that is LDS or global at run time means FLAT accesses)
-MCX_DEV void dr_body(const EngineDev &E, int it0, int it1, const double *__restrict__ g_mu, const double *__restrict__ g_lamT)
-{
-    extern __shared__ double X[];
-    const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
-    double *theta_t = E.theta + (size_t)tile * d * 64;
-    double *c2_t = E.cs + (size_t)tile * 2 * d * 64;           // second-stage candidate (global scratch)
-    // normals of the stage at hand, then dx_a = newpar2 - newpar  |  first-stage candidate, then dx_b = oldpar - newpar
-    double *zb_t = LDSV ? X : c2_t + (size_t)d * 64;
-    double *cand_t = LDSV ? X + (size_t)d * 64 : E.cand + (size_t)tile * d * 64;
-    double *ysa_t = E.zs + (size_t)tile * 2 * d * 64, *ysb_t = ysa_t + (size_t)d * 64;     // row chains between two panels of iC
-    const double *Rt = E.R + (size_t)tile * E.P * 64;
-
-    Rng g;
-    g.k0 = E.k0; g.k1 = E.chain_id0 + (uint32_t)(tile * 64 + lane);
-    g.n = TIDX(E.rngn, tile, 1, 0, lane); g.cblk = 0; g.c2 = 0; g.c3 = 0;
-    g.saved = (int)TIDX(E.ictr, tile, NICTR, I_SAVED, lane);
-    g.saved_y = TIDX(E.scal, tile, NSCAL, S_SAVEDY, lane);
-    double ss1 = TIDX(E.scal, tile, NSCAL, S_SS1, lane), pri1 = TIDX(E.scal, tile, NSCAL, S_PRI1, lane);
-    double sigma2 = TIDX(E.scal, tile, NSCAL, S_SIGMA2, lane), alpha12 = TIDX(E.scal, tile, NSCAL, S_ALPHA12, lane);
-    uint32_t stayed = TIDX(E.ictr, tile, NICTR, I_STAYED, lane), bnd = TIDX(E.ictr, tile, NICTR, I_BNDSTAYED, lane);
-    uint32_t chainind = TIDX(E.ictr, tile, NICTR, I_CHAININD, lane), curcount = TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane);
-    uint32_t dracc = TIDX(E.ictr, tile, NICTR, I_DRACC, lane), drtries = TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane);
-
-    for (int it = it0; it <= it1; ++it) {
-        // ---- newpar = MCMC_propose(oldpar, R)   (the iteration's first draws: nothing else drew since the last one's end)
-        gen_normals<MCX_RNG_NB>(g, zb_t, lane, d, true);
-        if (E.usesvd) gemvN_panels(E.Rf + (size_t)tile * d * d * 64, zb_t, cand_t, theta_t, lane, d, true);   // matmulx(R,z)
-        else trmv_panels<true>(Rt, zb_t, cand_t, theta_t, lane, d, true);
-        // ---- bounds, prior, ss, alpha, reject
-        bool inb = target_inbounds(E.tgt, d, lane, cand_t);
-        double pri2 = target_prior(E.tgt, d, lane, cand_t);
-        double ss2 = target_ss<false>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
-        bool reject;
-        if (!inb) { reject = true; alpha12 = 0.0; }         // (with DR an out-of-bounds first stage is not counted, MCMC_run.F90:49)
-        else {
-            alpha12 = d_alpha(ss1, pri1, ss2, pri2, sigma2);
-            reject = true;                                  // MCMC_reject, MCMC_DRAM.F90:140-155
-            if (alpha12 >= 1.0) reject = false;
-            else if (alpha12 > 0.0) { double u = rng_uniform(g); if (u <= alpha12) reject = false; }
-        }
-        // ---- second stage: one delayed-rejection try with R2 = R/drscale (MCMC_run.F90:65-91)
-        bool dr_moved = false;
-        if (__any(reject)) {
-            const bool m = reject;
-            if (m) drtries += 1;
-            gen_normals<MCX_RNG_NB>(g, zb_t, lane, d, m);
-            if (E.usesvd) gemvN_panels(E.R2f + (size_t)tile * d * d * 64, zb_t, c2_t, theta_t, lane, d, m);
-            else trmv_panels<true>(E.R2 + (size_t)tile * E.P * 64, zb_t, c2_t, theta_t, lane, d, m);
-            if (m) {
-                bool inb2 = target_inbounds(E.tgt, d, lane, c2_t);
-                if (!inb2) bnd += 1;
-                else {
-                    double pri3 = target_prior(E.tgt, d, lane, c2_t);
-                    double ss3 = target_ss<false>(E.tgt, d, lane, c2_t, g_mu, g_lamT);
-                    // MCMC_DR_alpha13, MCMC_DRAM.F90:162-186
-                    double alpha32;
-                    if (alpha12 == 0.0) alpha32 = 0.0;
-                    else alpha32 = min1(d_exp(-0.5 * ((ss2 - ss3) / sigma2 + (pri2 - pri3))));
-                    double l2 = -0.5 * ((ss3 - ss1) / sigma2 + (pri3 - pri1));
-                    // dx_a = newpar2 - newpar, dx_b = oldpar - newpar take this lane's two LDS vectors (its normals and its
-                    // first-stage candidate are dead from here on)
-                    for (int k0 = 0; k0 < d; k0 += 8) {
-                        double c1[8], c2[8], th[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) { const int k = (k0 + u < d) ? k0 + u : d - 1; c1[u] = GV(cand_t, k); c2[u] = GV(c2_t, k); th[u] = GV(theta_t, k); }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) if (k0 + u < d) { GV(zb_t, k0 + u) = c2[u] - c1[u]; GV(cand_t, k0 + u) = th[u] - c1[u]; }
-                    }
-                    double qa, qb;
-                    quadform2_panels(E.iC + (size_t)tile * E.P * 64, lane, d, zb_t, cand_t, ysa_t, ysb_t, qa, qb);
-                    double q1 = -0.5 * (qa - qb);
-                    double alpha13 = min1(d_exp(l2 + q1) * (1.0 - alpha32) / (1.0 - alpha12));
-                    bool rej2 = true;
-                    if (alpha13 >= 1.0) rej2 = false;
-                    else if (alpha13 > 0.0) { double u = rng_uniform(g); if (u <= alpha13) rej2 = false; }
-                    if (!rej2) { dracc += 1; reject = false; dr_moved = true; ss2 = ss3; pri2 = pri3; }
-                }
-            }
-        }
-        if (reject) { stayed += 1; curcount += 1; }
-        else { ss1 = ss2; pri1 = pri2; chainind += 1; curcount = 1; }
-        // ---- MCMC_updatesigma2 (MCMC_DRAM.F90:192-206)
-        if (E.updatesigma) {
-            double gm = rng_gamma(g, E.gam_shape, 2.0 / (E.N0S02 + ss1));
-            sigma2 = 1.0 / gm;
-        }
-        // ---- oldpar = newpar; MCMC_savechain (MCMC_aux.F90:167-185): accept ballot + accepted row into the ring
-        unsigned long long ballot = __ballot(!reject);
-        const int slot = it % E.wcap;
-        if (!reject) {
-            double *h = E.hist ? E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64 : nullptr;
-            if (dr_moved) copy_vec(theta_t, c2_t, h, lane, d);     // newpar = newpar2 when the DR try was accepted (two calls: a source
-            else copy_vec(theta_t, cand_t, h, lane, d);            // that is global or LDS by the lane would mean FLAT accesses)
-            if (h) GV(h, d) = ss1;
-        }
-        if (E.hist) {
-            if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ballot;
-            if (E.record_s2) E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = sigma2;
-        }
-        if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
-    }
-
-    TIDX(E.rngn, tile, 1, 0, lane) = g.n;
-    TIDX(E.ictr, tile, NICTR, I_SAVED, lane) = (uint32_t)g.saved;
-    TIDX(E.scal, tile, NSCAL, S_SAVEDY, lane) = g.saved_y;
-    TIDX(E.scal, tile, NSCAL, S_SS1, lane) = ss1; TIDX(E.scal, tile, NSCAL, S_PRI1, lane) = pri1;
-    TIDX(E.scal, tile, NSCAL, S_SIGMA2, lane) = sigma2; TIDX(E.scal, tile, NSCAL, S_ALPHA12, lane) = alpha12;
-    TIDX(E.ictr, tile, NICTR, I_STAYED, lane) = stayed; TIDX(E.ictr, tile, NICTR, I_BNDSTAYED, lane) = bnd;
-    TIDX(E.ictr, tile, NICTR, I_CHAININD, lane) = chainind; TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane) = curcount;
-    TIDX(E.ictr, tile, NICTR, I_DRACC, lane) = dracc; TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane) = drtries;
-}
-__global__ __launch_bounds__(64, 2) void step_kernel_dr(EngineDev E, int it0, int it1, const double *__restrict__ g_mu, const double *__restrict__ g_lamT)
-{ dr_body<true>(E, it0, it1, g_mu, g_lamT); }
-// npar > 160: the same with the two vectors in global scratch
-__global__ __launch_bounds__(64, 2) void step_kernel_dr_big(EngineDev E, int it0, int it1, const double *__restrict__ g_mu, const double *__restrict__ g_lamT)
-{ dr_body<false>(E, it0, it1, g_mu, g_lamT); }
-
-#ifndef MCX_AM_WAVES
-#define MCX_AM_WAVES 2
-#endif
-#ifndef MCX_AM_WIDE
-#define MCX_AM_WIDE true
-#endif
-template <bool RAM, bool DR, bool POOLED>
-__global__ __launch_bounds__(64, RAM ? MCX_RAM_WAVES : (DR || POOLED) ? 2 : MCX_AM_WAVES) void step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
-                                                     const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
-                                                     const double *__restrict__ g_sharedR)
-{ step_body<RAM, DR, POOLED, (RAM || (!DR && !POOLED && MCX_AM_WIDE))>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
-// the plain AM / Metropolis / ER step with the state vector, the candidate and the two normal vectors in LDS (EngineDev::lds_scratch)
-__global__ __launch_bounds__(64, MCX_AM_WAVES) void step_kernel_ldsv(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
-                                                     const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
-                                                     const double *__restrict__ g_sharedR)
-{ step_body<false, false, false, MCX_AM_WIDE, false, true>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
-// ... and the chain's packed factor too (npar <= TW; EngineDev::lds_scratch == 2): north_star's "Cholesky factor staged in LDS"
-__global__ __launch_bounds__(64, MCX_AM_WAVES) void step_kernel_ldsr(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
-                                                     const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
-                                                     const double *__restrict__ g_sharedR)
-{ step_body<false, false, false, MCX_AM_WIDE, false, true, true>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
-
-// method='ram' at npar <= RW with few enough tiles: the factor in LDS for the launch (EngineDev::lds_scratch == 3)
-__global__ __launch_bounds__(64, 2) void step_kernel_ram_ldsr(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
-                                                     const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
-                                                     const double *__restrict__ g_sharedR)
-{ step_body<true, false, false, true, false, false, true>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
-
-// method='ram' above npar 20: step_kernel<true, false, false> with the wide column panels (RW_WIDE above)
-__global__ __launch_bounds__(64, MCX_RAM_WAVES) void step_kernel_ram_wide(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
-                                                     const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
-                                                     const double *__restrict__ g_sharedR)
-{ step_body<true, false, false, true, false, false, false, false, RW_WIDE>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
-
-// pooled mode with delayed rejection: the shared factor, its second-stage copy R2 = R / drscale and the shared inverse
-// covariance iC = dpotri(R) all come through the scalar cache (the host recomputes the three at every pooled tick)
-__global__ __launch_bounds__(64, 2) void step_kernel_pooled_dr(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
-                                                               const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
-                                                               const double *__restrict__ g_sharedR, const double *__restrict__ g_sharedR2,
-                                                               const double *__restrict__ g_sharediC)
-{ step_body<false, true, true, false>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR, g_sharedR2, g_sharediC); }
-// ... with the two quadratic-form vectors in global scratch (EngineDev::xscr): above npar 20 the LDS form costs waves (51 KiB per wave
-// at npar 50: three waves per CU), and above 160 it does not fit at all
-__global__ __launch_bounds__(64, 2) void step_kernel_pooled_dr_big(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
-                                                                   const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
-                                                                   const double *__restrict__ g_sharedR, const double *__restrict__ g_sharedR2,
-                                                                   const double *__restrict__ g_sharediC)
-{ step_body<false, true, true, false, false, false, false, true>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR, g_sharedR2, g_sharediC); }
-
-// method='ram' with condmax > 0: the factor is the full SVD one (E.Rf), proposals are matmulx(R,u), the rank-one
-// adaptation runs on its upper triangle (ram_update_full)
-__global__ __launch_bounds__(64, 2) void step_kernel_ram_fullr(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
-                                                               const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
-                                                               const double *__restrict__ g_sharedR)
-{ step_body<true, false, false, false, true>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
-
-// ---------------------------------------------------------------- host-callback targets
-// When ssfunction / priorfun / checkbounds are host functions of the user (external_inc.h:4-33) one
-// iteration is cut where the reference calls them (MCMC_run.F90:47,55-56,69,74-75): phase 0 proposes,
-// the host evaluates the candidates of all chains in chain order, phase 1 decides (and proposes the DR
-// try), the host evaluates again, phase 2 decides the DR try and finishes the iteration.  Same device
-// functions as step_kernel; per-lane state round-trips through HBM between phases.
-enum { HX_SS2 = 0, HX_PRI2, HX_REJECT, HX_STAGE2, HX_DRMOVED, HX_SU, HX_CRIT, HX_MOVED, NHX };
-enum { HE_INB = 0, HE_PRI, HE_SS, NHE };
-
-struct LaneState {
-    Rng g;
-    double ss1, pri1, sigma2, alpha12;
-    uint32_t stayed, bnd, chainind, curcount, status, dracc, drtries, pdesc;
-};
-MCX_DEV void lane_load(const EngineDev &E, int tile, int lane, LaneState &L)
-{
-    L.g.k0 = E.k0; L.g.k1 = E.chain_id0 + (uint32_t)(tile * 64 + lane);
-    L.g.n = TIDX(E.rngn, tile, 1, 0, lane); L.g.cblk = 0; L.g.c2 = 0; L.g.c3 = 0;
-    L.g.saved = (int)TIDX(E.ictr, tile, NICTR, I_SAVED, lane);
-    L.g.saved_y = TIDX(E.scal, tile, NSCAL, S_SAVEDY, lane);
-    L.ss1 = TIDX(E.scal, tile, NSCAL, S_SS1, lane); L.pri1 = TIDX(E.scal, tile, NSCAL, S_PRI1, lane);
-    L.sigma2 = TIDX(E.scal, tile, NSCAL, S_SIGMA2, lane); L.alpha12 = TIDX(E.scal, tile, NSCAL, S_ALPHA12, lane);
-    L.stayed = TIDX(E.ictr, tile, NICTR, I_STAYED, lane); L.bnd = TIDX(E.ictr, tile, NICTR, I_BNDSTAYED, lane);
-    L.chainind = TIDX(E.ictr, tile, NICTR, I_CHAININD, lane); L.curcount = TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane);
-    L.status = TIDX(E.ictr, tile, NICTR, I_STATUS, lane);
-    L.dracc = TIDX(E.ictr, tile, NICTR, I_DRACC, lane); L.drtries = TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane);
-    L.pdesc = TIDX(E.ictr, tile, NICTR, I_PDESC, lane);
-}
-MCX_DEV void lane_store(const EngineDev &E, int tile, int lane, const LaneState &L)
-{
-    TIDX(E.rngn, tile, 1, 0, lane) = L.g.n;
-    TIDX(E.ictr, tile, NICTR, I_SAVED, lane) = (uint32_t)L.g.saved;
-    TIDX(E.scal, tile, NSCAL, S_SAVEDY, lane) = L.g.saved_y;
-    TIDX(E.scal, tile, NSCAL, S_SS1, lane) = L.ss1; TIDX(E.scal, tile, NSCAL, S_PRI1, lane) = L.pri1;
-    TIDX(E.scal, tile, NSCAL, S_SIGMA2, lane) = L.sigma2; TIDX(E.scal, tile, NSCAL, S_ALPHA12, lane) = L.alpha12;
-    TIDX(E.ictr, tile, NICTR, I_STAYED, lane) = L.stayed; TIDX(E.ictr, tile, NICTR, I_BNDSTAYED, lane) = L.bnd;
-    TIDX(E.ictr, tile, NICTR, I_CHAININD, lane) = L.chainind; TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane) = L.curcount;
-    TIDX(E.ictr, tile, NICTR, I_STATUS, lane) = L.status;
-    TIDX(E.ictr, tile, NICTR, I_DRACC, lane) = L.dracc; TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane) = L.drtries;
-    TIDX(E.ictr, tile, NICTR, I_PDESC, lane) = L.pdesc;
-}
-
-// scam_fast: newpar_k = oldpar_k + delta U(k,j), elements k0, k0 + kstep, ... (one fma each; U column-major per chain)
-MCX_DEV void scam_fast_propose(const double *Ut, const double *theta_t, double *cand_t, int lane, int d, int j, double delta, int p0 = 0, int pstep = 1)
-{
-    const double *col = Ut + (size_t)j * d * 64;
-    for (int K0 = p0 * PW; K0 < d; K0 += pstep * PW) {
-        double u[PW], th[PW];
-#pragma unroll
-        for (int q = 0; q < PW; ++q) { const int k = K0 + q < d ? K0 + q : d - 1; u[q] = LDNT(col, k); th[q] = GV(theta_t, k); }
-#pragma unroll
-        for (int q = 0; q < PW; ++q) if (K0 + q < d) GV(cand_t, K0 + q) = dfma(delta, u[q], th[q]);
-    }
-}
-
-// ---------------------------------------------------------------- MCMC_run_scam (MCMC_run_scam.F90:38-88)
-// One outer iteration = d componentwise Metropolis sub-steps in the rotated basis: rot = U'theta (dgemv 'T'),
-// rot_j += N(0,1) std_j, theta' = U rot (dgemv 'N'), full ss evaluation, alpha, reject (MCMC_propose_sc :94-117).
-// One chain row per outer iteration.  U (full d x d per chain) is streamed twice per sub-step.
-#ifndef MCX_SCAM_WAVES
-#define MCX_SCAM_WAVES 2
-#endif
-__global__ __launch_bounds__(64, MCX_SCAM_WAVES) void scam_kernel(EngineDev E, int it0, int it1,
-                                                     const double *__restrict__ g_mu, const double *__restrict__ g_lamT)
-{
-    const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
-    double *theta_t = E.theta + (size_t)tile * d * 64;
-    double *cand_t = E.cand + (size_t)tile * d * 64;
-    double *rot_t = E.cs + (size_t)tile * 2 * d * 64;
-    const double *Ut = E.Rf + (size_t)tile * d * d * 64;
-    const double *std_t = E.qstd + (size_t)tile * d * 64;
-    LaneState L;
-    lane_load(E, tile, lane, L);
-    for (int it = it0; it <= it1; ++it) {
-        bool rejall = true;
-        for (int j = 0; j < d; ++j) {
-            if (E.scam_fast) {
-                const double zj = rng_normal(L.g) * GV(std_t, j);
-                scam_fast_propose(Ut, theta_t, cand_t, lane, d, j, zj);
-            } else {
-                gemvT_panels<true>(Ut, theta_t, rot_t, lane, d);
-                const double zj = rng_normal(L.g) * GV(std_t, j);
-                GV(rot_t, j) = GV(rot_t, j) + zj;
-                gemvN_panels<true>(Ut, rot_t, cand_t, nullptr, lane, d, true);
-            }
-            bool inb = target_inbounds(E.tgt, d, lane, cand_t);
-            double pri2 = target_prior(E.tgt, d, lane, cand_t);
-            double ss2 = target_ss<false>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
-            bool reject;
-            if (!inb) { L.bnd += 1; L.alpha12 = 0.0; reject = true; }
-            else {
-                L.alpha12 = d_alpha(L.ss1, L.pri1, ss2, pri2, L.sigma2);
-                reject = true;
-                if (L.alpha12 >= 1.0) reject = false;
-                else if (L.alpha12 > 0.0) { double u = rng_uniform(L.g); if (u <= L.alpha12) reject = false; }
-            }
-            if (!reject) {
-                L.ss1 = ss2; L.pri1 = pri2; rejall = false;
-                copy_vec(theta_t, cand_t, nullptr, lane, d);
-            }
-        }
-        if (rejall) { L.stayed += 1; L.curcount += 1; }
-        else { L.chainind += 1; L.curcount = 1; }
-        if (E.updatesigma) {
-            double gm = rng_gamma(L.g, E.gam_shape, 2.0 / (E.N0S02 + L.ss1));
-            L.sigma2 = 1.0 / gm;
-        }
-        unsigned long long ballot = __ballot(!rejall);
-        const int slot = it % E.wcap;
-        if (E.hist) {
-            if (!rejall) {
-                double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64;
-                for (int k = 0; k < d; ++k) GV(h, k) = GV(theta_t, k);
-                GV(h, d) = L.ss1;
-            }
-            if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ballot;
-            if (E.record_s2) E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = L.sigma2;
-        }
-        if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
-    }
-    lane_store(E, tile, lane, L);
-}
-
-// The same iteration with NW waves per tile (a workgroup of 64 NW threads; lane = chain, wave = a share of the work): for
-// chain counts that leave most of the chip idle at one wave per tile (the reference's own use is ONE chain), where a
-// sub-step is bound by the latency of one wave's loads -- 2 d^2 x 512 bytes streamed with ~16 kB in flight.  Every output
-// element of the two products is its own fma chain (gemvT: one per column, gemvN: one per row), and the Gaussian target's
-// blocks of 16 rows are independent up to the running sum of their q_k, so the waves share panels / blocks without
-// changing one operation; wave 0 owns the per-chain scalar state (stream, ss1, counters), draws, decides, and hands the
-// deviate and the accept flag to the others through LDS.  Vectors stay in the per-chain global scratch (the workgroup's
-// waves run on one CU and meet at workgroup barriers).  lds: [16 nblk][64] partial chains, [64] deviates, [64] flags.
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void scam_mw_kernel(EngineDev E, int it0, int it1,
-                                                          const double *__restrict__ g_mu, const double *__restrict__ g_lamT)
-{
-    extern __shared__ double lds_mw[];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tile = blockIdx.x, d = E.d;
-    const int nblk = (d + 15) / 16;
-    double *Q = lds_mw, *zl = lds_mw + (size_t)4 * nblk * 64, *fl = zl + 64;
-    double *theta_t = E.theta + (size_t)tile * d * 64;
-    double *cand_t = E.cand + (size_t)tile * d * 64;
-    double *rot_t = E.cs + (size_t)tile * 2 * d * 64;
-    const double *Ut = E.Rf + (size_t)tile * d * d * 64;
-    const double *std_t = E.qstd + (size_t)tile * d * 64;
-    const bool gauss = (E.tgt.kind == TGT_GAUSS);
-    LaneState L;
-    if (w == 0) lane_load(E, tile, lane, L);
-    for (int it = it0; it <= it1; ++it) {
-        bool rejall = true;
-        for (int j = 0; j < d; ++j) {
-            if (w == 0) zl[lane] = rng_normal(L.g) * GV(std_t, j);           // the sub-step's first draw (MCMC_run_scam.F90:108)
-            if (E.scam_fast) {
-                __syncthreads();
-                scam_fast_propose(Ut, theta_t, cand_t, lane, d, j, zl[lane], w, NW);
-            } else {
-                gemvT_panels<true, (NW >= 8 ? 2 : 0)>(Ut, theta_t, rot_t, lane, d, w, NW);      // many waves: fewer rows in flight each (registers)
-                __syncthreads();
-                if (w == (j / PW) % NW) GV(rot_t, j) = GV(rot_t, j) + zl[lane];  // by the wave that wrote rot_j
-                __syncthreads();
-                gemvN_panels<true, (NW >= 8 ? 2 : 0)>(Ut, rot_t, cand_t, nullptr, lane, d, true, w, NW);
-            }
-            __syncthreads();
-            if (gauss) {
-                for (int b = w; b < nblk; b += NW) {
-                    double q[4];
-                    gauss_block_q(d, lane, cand_t, g_mu, g_lamT, 16 * b, q);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) Q[(size_t)(4 * b + k) * 64 + lane] = q[k];
-                }
-                __syncthreads();
-            }
-            if (w == 0) {
-                bool inb = target_inbounds(E.tgt, d, lane, cand_t);
-                double pri2 = target_prior(E.tgt, d, lane, cand_t);
-                double ss2 = 0.0;
-                if (gauss) { for (int e = 0; e < 4 * nblk; ++e) if (16 * (e >> 2) + (e & 3) < d) ss2 = (e == 0) ? Q[lane] : ss2 + Q[(size_t)e * 64 + lane]; }
-                else ss2 = target_ss<false>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
-                bool reject;
-                if (!inb) { L.bnd += 1; L.alpha12 = 0.0; reject = true; }
-                else {
-                    L.alpha12 = d_alpha(L.ss1, L.pri1, ss2, pri2, L.sigma2);
-                    reject = true;
-                    if (L.alpha12 >= 1.0) reject = false;
-                    else if (L.alpha12 > 0.0) { double u = rng_uniform(L.g); if (u <= L.alpha12) reject = false; }
-                }
-                if (!reject) { L.ss1 = ss2; L.pri1 = pri2; rejall = false; }
-                fl[lane] = reject ? 0.0 : 1.0;
-            }
-            __syncthreads();
-            if (fl[lane] != 0.0) for (int K0 = w * PW; K0 < d; K0 += NW * PW) {
-                double v[PW];
-#pragma unroll
-                for (int u = 0; u < PW; ++u) v[u] = GV(cand_t, K0 + (K0 + u < d ? u : 0));
-#pragma unroll
-                for (int u = 0; u < PW; ++u) if (K0 + u < d) GV(theta_t, K0 + u) = v[u];
-            }
-            __syncthreads();
-        }
-        if (w == 0) {
-            if (rejall) { L.stayed += 1; L.curcount += 1; }
-            else { L.chainind += 1; L.curcount = 1; }
-            if (E.updatesigma) {
-                double gm = rng_gamma(L.g, E.gam_shape, 2.0 / (E.N0S02 + L.ss1));
-                L.sigma2 = 1.0 / gm;
-            }
-            unsigned long long ballot = __ballot(!rejall);
-            const int slot = it % E.wcap;
-            if (E.hist) {
-                if (!rejall) {
-                    double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64;
-                    copy_vec(h, theta_t, nullptr, lane, d);
-                    GV(h, d) = L.ss1;
-                }
-                if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ballot;
-                if (E.record_s2) E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = L.sigma2;
-            }
-            if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
-        }
-    }
-    if (w == 0) lane_store(E, tile, lane, L);
-}
-
-// ---------------------------------------------------------------- pooled SCAM: one rotation shared by all chains
-// MCMC_run_scam with ONE rotation U (and one qcovstd) for every chain of the node (pooled mode), on the matrix cores.
-//
-// out(o, c) = sum_s M[s*d + o] X(s, c) for every output row o and chain c of a tile, s ascending, one fma chain per
-// (o, c) -- the order of gemvT_panels / gemvN_panels / the Gaussian y rows.  v_mfma_f64_16x16x4_f64 accumulates its
-// four products as an ascending fma chain (checked bit for bit on gfx950, tools/mfma_f64_probe.hip), so D = A B + D
-// repeated over blocks of four s IS that chain.  A = M' (16 outputs x 4 s, from the shared table, L2-resident),
-// B = X (4 s x 16 chains, from the workgroup's LDS vector; d4 = 4*ceil(d/4) rows, the pad rows zero; M has d4 rows,
-// pad rows zero, and PWS doubles of slack).
-//
-// A workgroup is nw waves that share one tile of 64 chains.  Every wave owns four 16x16 (output block x chain group)
-// result tiles -- "slots" -- and keeps them in registers in the MFMA C layout (row = 16*block + (lane>>4) + 4r,
-// chain = 16*group + (lane&15)): a block wave (w < ntw) owns output block w for all four chain groups (one A, four
-// B per k-block), each of the last four waves owns chain group w-ntw of the leftover blocks ntw.. (one B, up to four
-// A) -- so every SIMD (wave mod 4) runs the same number of MFMAs.  The products of a sub-step chain through LDS only:
-// theta -> X -> rot (registers) -> X -> theta' (registers, kept for the accept) -> X = theta'-mu -> y (registers) ->
-// per-lane partial chains q of ss (mcxt_ss_gauss's order is exactly this layout) -> LDS; the last wave carries the
-// per-chain scalar state, sums the q, does prior / bounds / alpha / accept and hands the normal deviate and the accept
-// flag of each chain to the others through LDS.  Arithmetic per chain is operation for operation that of scam_kernel.
-constexpr int PWS = 16;
-typedef double mcx_d4 __attribute__((ext_vector_type(4)));
-typedef double mcx_d2 __attribute__((ext_vector_type(2)));
-
-template <bool BW, int NS, bool XS = false>   // BW: block wave (blk0 = its block, slot = chain group; XS: a fifth slot, group xgrp of block xblk); else group wave (slot s = block blk0+s, s < NS)
-MCX_DEV void mfma_slots(const double *__restrict__ M, const double *X, int lane, int d, int d4, int blk0, int grp, mcx_d4 (&c)[XS ? 5 : 4],
-                        int xblk = 0, int xgrp = 0)
-{
-    const int li = lane & 15, lk = lane >> 4;
-#pragma unroll
-    for (int s = 0; s < (XS ? 5 : 4); ++s) c[s] = mcx_d4{0.0, 0.0, 0.0, 0.0};
-    const double *__restrict__ ap = M + (size_t)lk * d + 16 * blk0 + li;
-    const double *xp = X + lk * 64 + li + (BW ? 0 : 16 * grp);
-    int s0 = 0;
-    if (BW) {
-        const double *__restrict__ axp = M + (size_t)lk * d + 16 * xblk + li;      // XS: the fifth slot's A operand
-        for (; s0 + 16 <= d4; s0 += 16) {               // four k-blocks per trip: the four (eight) A loads go out together
-            double a[4], ax[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { a[u] = ap[(size_t)(s0 + 4 * u) * d]; if (XS) ax[u] = axp[(size_t)(s0 + 4 * u) * d]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double *xq = xp + (s0 + 4 * u) * 64;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) c[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], xq[16 * g], c[g], 0, 0, 0);
-                if (XS) c[XS ? 4 : 0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[u], xq[16 * xgrp], c[XS ? 4 : 0], 0, 0, 0);
-            }
-        }
-        for (; s0 < d4; s0 += 4) {
-            const double a = ap[(size_t)s0 * d];
-            const double *xq = xp + s0 * 64;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) c[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xq[16 * g], c[g], 0, 0, 0);
-            if (XS) c[XS ? 4 : 0] = __builtin_amdgcn_mfma_f64_16x16x4f64(axp[(size_t)s0 * d], xq[16 * xgrp], c[XS ? 4 : 0], 0, 0, 0);
-        }
-    } else {
-        // KU k-blocks per trip, up to four A each: a trip waits for its loads once, and a wave with one or two slots has few
-        // MFMAs to put behind them -- with two k-blocks per trip the four group waves were the last at every barrier
-        // (64 us per sub-step against the block waves' 54 at d = 200); eight A loads in flight per trip whatever NS is
-        constexpr int KU = NS <= 1 ? 8 : (NS == 2 ? 4 : 2);
-        for (; s0 + 4 * KU <= d4; s0 += 4 * KU) {
-            double a[KU][NS > 0 ? NS : 1], bq[KU];
-#pragma unroll
-            for (int u = 0; u < KU; ++u) {
-#pragma unroll
-                for (int s = 0; s < NS; ++s) a[u][s] = ap[(size_t)(s0 + 4 * u) * d + 16 * s];
-                bq[u] = xp[(s0 + 4 * u) * 64];
-            }
-#pragma unroll
-            for (int u = 0; u < KU; ++u)
-#pragma unroll
-                for (int s = 0; s < NS; ++s) c[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][s], bq[u], c[s], 0, 0, 0);
-        }
-        for (; s0 < d4; s0 += 4) {
-            const double bq = xp[s0 * 64];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) c[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[(size_t)s0 * d + 16 * s], bq, c[s], 0, 0, 0);
-        }
-    }
-}
-// Element (slot s, register r) of a lane: output row o = 16*block + (lane>>4) + 4r, chain c = 16*group + (lane&15); its
-// offset o*64 + c in a tile-interleaved vector (and in X) is e0 + (BW ? 16 s : 1024 s) + 256 r.  X has 16*nt rows, so
-// every element has an LDS home; rows >= d are written as zeros (the k loop reads the rows < d4 only).
-template <bool BW, int NS, bool SC, bool XS = false>   // SC: the scalar wave (the last one).  A template parameter, so that the other fifteen waves carry
-                                      // neither the generator nor the per-chain state: at 128 registers a wave they spilled around their MFMAs
-                                      // XS (scam_pooled12_kernel): a block wave with a FIFTH slot, chain group xgrp of block xblk
-MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, int lane, int w, int nw, int blk0, int grp,
-                              const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
-                              const double *__restrict__ g_U, const double *__restrict__ g_UT, const double *__restrict__ g_std,
-                              int xblk = 0, int xgrp = 0)
-{
-    const int tile = blockIdx.x, d = E.d, d4 = (d + 3) & ~3, nt = (d + 15) >> 4, li = lane & 15, lk = lane >> 4;
-    double *Q = X + (size_t)nt * 16 * 64;                                       // [4*nt][64] partial ss chains
-    double *zb = Q + (size_t)nt * 4 * 64, *fl = zb + 64;                      // per chain: the deviate, the accept flag
-    double *mul = fl + 64;                                                      // the target's mean, [16 nt]: read at every third fill
-    constexpr bool sc = SC;                                                     // the scalar wave
-    const bool gauss = (E.tgt.kind == TGT_GAUSS);
-    const bool cand_global = !gauss || E.tgt.pmu || E.tgt.lo || E.tgt.hi;       // prior / bounds / other targets read theta' per chain
-    static_assert(!XS || (BW && NS == 4), "the fifth slot belongs to a block wave");
-    constexpr int nsl = XS ? 5 : NS, NA = XS ? 5 : 4;
-    const int e0 = (16 * blk0 + lk) * 64 + (BW ? 0 : 16 * grp) + li, o0 = 16 * blk0 + lk, c0 = (BW ? 0 : 16 * grp) + li;
-    const int ex = (16 * xblk + lk) * 64 + 16 * xgrp + li, ox = 16 * xblk + lk, cx = 16 * xgrp + li;      // the fifth slot
-#define EOFF(s, r) ((XS && (s) == 4) ? ex + 256 * (r) : e0 + (BW ? 16 : 1024) * (s) + 256 * (r))
-#define EROW(s, r) ((XS && (s) == 4) ? ox + 4 * (r) : o0 + (BW ? 0 : 16) * (s) + 4 * (r))
-#define ECH(s) ((XS && (s) == 4) ? cx : c0 + (BW ? 16 : 0) * (s))
-    double *theta_t = E.theta + (size_t)tile * d * 64;
-    double *cand_t = E.cand + (size_t)tile * d * 64;
-    LaneState L;
-    if (sc) lane_load(E, tile, lane, L);
-    // The group waves own one or two tile sets whose MFMAs form ONE dependent chain per product; at equal priority the (older)
-    // block waves' sixteen independent MFMAs per trip win the matrix pipe and the chain only runs once they are done -- the
-    // whole workgroup then waits ~2 us per product at the barrier.  Raised priority lets the chain interleave.
-    if (!BW) __builtin_amdgcn_s_setprio(2);
-    if (gauss) { for (int o = w * 64 + lane; o < 16 * nt; o += nw * 64) mul[o] = o < d ? g_mu[o] : 0.0; }
-    mcx_d4 cand[NA], cc[NA], th[NA];
-    // The chains' state: every lane keeps the elements of its slots in registers across the sub-steps (they are the ones it
-    // fills into X and the ones it replaces on an accept) and writes them back once per iteration.
-#pragma unroll
-    for (int s = 0; s < NA; ++s)
-        if (s < nsl) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) th[s][r] = theta_t[EROW(s, r) < d ? EOFF(s, r) : e0];
-        }
-#ifdef MCX_PHASE_PROF
-    unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tq = wall_clock64();
-#define PH(i) { unsigned long long tn = wall_clock64(); ph[i] += tn - tq; tq = tn; }
-#else
-#define PH(i)
-#endif
-    for (int it = it0; it <= it1; ++it) {
-        bool rejall = true;
-        for (int j = 0; j < d; ++j) {
-          if (E.scam_fast) {
-            // opt-in (mcmcx_config::scam_fast): theta' = theta + delta U(:,j) from the registers -- no rotation products at all
-            // (g_U == nullptr: per-chain rotations -- the column comes from the chain's own factor, the target still runs on the
-            //  matrix cores: what the lane-per-chain kernels cannot do for it, they re-read the candidate once per 8 rows)
-            const bool pc = (g_U == nullptr);
-            if (sc) zb[lane] = rng_normal(L.g) * (pc ? TIDX(E.qstd, tile, d, j, lane) : g_std[j]);
-            __syncthreads();
-#pragma unroll
-            for (int s = 0; s < NA; ++s) {
-                if (s < nsl) {
-                    const double zj = zb[ECH(s)];
-                    double uc[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int o = EROW(s, r) < d ? EROW(s, r) : 0;
-                        uc[r] = pc ? __builtin_nontemporal_load(&E.Rf[((size_t)tile * d * d + (size_t)j * d + o) * 64 + ECH(s)]) : g_U[(size_t)j * d + o];
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) cand[s][r] = EROW(s, r) < d ? dfma(zj, uc[r], th[s][r]) : 0.0;
-                }
-            }
-          } else {
-#pragma unroll
-            for (int s = 0; s < NA; ++s) {                                       // X = theta
-                if (s < nsl) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) X[EOFF(s, r)] = EROW(s, r) < d ? th[s][r] : 0.0;
-                }
-            }
-            PH(0)
-            __syncthreads();
-            PH(7)
-            // the sub-step's deviate is not needed before the second fill: the scalar wave draws it while the first product runs
-            // (its own share of the product is one tile set) instead of holding everybody at the barrier above
-            if (sc) zb[lane] = rng_normal(L.g) * g_std[j];
-            mfma_slots<BW, NS, XS>(g_UT, X, lane, d, d4, blk0, grp, cc, xblk, xgrp);           // rot = U'theta
-            PH(2)
-            __syncthreads();
-            PH(8)
-#pragma unroll
-            for (int s = 0; s < NA; ++s) {
-                if (s < nsl) {
-                    const double zj = zb[ECH(s)];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int o = EROW(s, r);
-                        double v = cc[s][r];
-                        if (o == j) v = v + zj;
-                        X[EOFF(s, r)] = o < d ? v : 0.0;
-                    }
-                }
-            }
-            PH(3)
-            __syncthreads();
-            PH(9)
-            mfma_slots<BW, NS, XS>(g_U, X, lane, d, d4, blk0, grp, cand, xblk, xgrp);          // theta' = U rot
-            PH(2)
-          }
-            if (cand_global) {
-#pragma unroll
-                for (int s = 0; s < NA; ++s)
-                    if (s < nsl) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) if (EROW(s, r) < d) cand_t[EOFF(s, r)] = cand[s][r];
-                    }
-            }
-            __syncthreads();
-            if (gauss) {
-#pragma unroll
-                for (int s = 0; s < NA; ++s)
-                    if (s < nsl) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { const int o = EROW(s, r); X[EOFF(s, r)] = o < d ? cand[s][r] - mul[o] : 0.0; }
-                    }
-                PH(3)
-                __syncthreads();
-                PH(10)
-                mfma_slots<BW, NS, XS>(g_lamT, X, lane, d, d4, blk0, grp, cc, xblk, xgrp);     // y = Lam v
-                PH(2)
-#pragma unroll
-                for (int s = 0; s < NA; ++s) {                                   // q_(block, lane>>4) = chain over r of y v
-                    if (s < nsl) {
-                        double q = cc[s][0] * X[EOFF(s, 0)];
-#pragma unroll
-                        for (int r = 1; r < 4; ++r) { const double t = dfma(cc[s][r], X[EOFF(s, r)], q); q = EROW(s, r) < d ? t : q; }
-                        if (EROW(s, 0) < d) Q[(size_t)(EROW(s, 0) >> 4) * 256 + (EROW(s, 0) & 3) * 64 + ECH(s)] = q;
-                    }
-                }
-                PH(4)
-                __syncthreads();
-                PH(11)
-            }
-            if (sc) {
-                bool inb = true; double pri2 = 0.0, ss2 = 0.0;
-                if (cand_global) { inb = target_inbounds(E.tgt, d, lane, cand_t); pri2 = target_prior(E.tgt, d, lane, cand_t); }
-                if (gauss) {
-                    ss2 = Q[lane];
-#pragma unroll 4
-                    for (int e = 1; e < 4 * nt; ++e) if (16 * (e >> 2) + (e & 3) < d) ss2 = ss2 + Q[(size_t)e * 64 + lane];
-                } else ss2 = target_ss<false>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
-                bool reject;
-                if (!inb) { L.bnd += 1; L.alpha12 = 0.0; reject = true; }
-                else {
-                    L.alpha12 = d_alpha(L.ss1, L.pri1, ss2, pri2, L.sigma2);
-                    reject = true;
-                    if (L.alpha12 >= 1.0) reject = false;
-                    else if (L.alpha12 > 0.0) { double u = rng_uniform(L.g); if (u <= L.alpha12) reject = false; }
-                }
-                if (!reject) { L.ss1 = ss2; L.pri1 = pri2; rejall = false; }
-                fl[lane] = reject ? 0.0 : 1.0;
-            }
-            PH(5)
-            __syncthreads();
-            PH(12)
-            // accepted chains: theta = theta' (each lane its own elements; the next sub-step reloads exactly those)
-#pragma unroll
-            for (int s = 0; s < NA; ++s)
-                if (s < nsl) {
-                    const bool acc = fl[ECH(s)] != 0.0;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) th[s][r] = acc ? cand[s][r] : th[s][r];
-                }
-        }
-#pragma unroll
-        for (int s = 0; s < NA; ++s)                                             // the iteration's state: for the history row below, the
-            if (s < nsl) {                                                      // pooled moments and the next launch
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (EROW(s, r) < d) theta_t[EOFF(s, r)] = th[s][r];
-            }
-        __syncthreads();
-        if (sc) {
-            if (rejall) { L.stayed += 1; L.curcount += 1; }
-            else { L.chainind += 1; L.curcount = 1; }
-            if (E.updatesigma) {
-                double gm = rng_gamma(L.g, E.gam_shape, 2.0 / (E.N0S02 + L.ss1));
-                L.sigma2 = 1.0 / gm;
-            }
-            unsigned long long ballot = __ballot(!rejall);
-            const int slot = it % E.wcap;
-            if (E.hist) {
-                if (!rejall) {
-                    double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64;
-                    for (int k = 0; k < d; ++k) GV(h, k) = GV(theta_t, k);
-                    GV(h, d) = L.ss1;
-                }
-                if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ballot;
-                if (E.record_s2) E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = L.sigma2;
-            }
-            if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
-        }
-    }
-    if (sc) lane_store(E, tile, lane, L);
-#ifdef MCX_PHASE_PROF
-    PH(6)
-    if (tile == 0 && lane == 0 && (w == 0 || sc)) printf("wave %d x10ns: theta+fill %llu mfma %llu fills %llu q %llu scalar %llu accept %llu | barrier waits after: fill0 %llu P1 %llu fill1 %llu P2 %llu fill2 %llu P3q %llu scalar %llu\n", w, ph[0], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7], ph[8], ph[9], ph[10], ph[11], ph[12], ph[13]);
-#endif
-#undef PH
-#undef EOFF
-#undef EROW
-#undef ECH
-}
-
-__global__ __launch_bounds__(1024, 1) void scam_pooled_kernel(EngineDev E, int it0, int it1,
-                                                             const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
-                                                             const double *__restrict__ g_U, const double *__restrict__ g_UT,
-                                                             const double *__restrict__ g_std)
-{
-    extern __shared__ double X[];
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = (int)(blockDim.x >> 6);
-    const int nt = (E.d + 15) >> 4, ntw = nw - 4;                               // ntw block waves own blocks 0..ntw-1
-    if (w < ntw) scam_pooled_body<true, 4, false>(E, it0, it1, X, lane, w, nw, w, 0, g_mu, g_lamT, g_U, g_UT, g_std);
-    else if (w == nw - 1) switch (nt - ntw) {                                   // the scalar wave
-        case 0: scam_pooled_body<false, 0, true>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
-        case 1: scam_pooled_body<false, 1, true>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
-        case 2: scam_pooled_body<false, 2, true>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
-        case 3: scam_pooled_body<false, 3, true>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
-        default: scam_pooled_body<false, 4, true>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
-    }
-    else switch (nt - ntw) {
-        case 0: scam_pooled_body<false, 0, false>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
-        case 1: scam_pooled_body<false, 1, false>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
-        case 2: scam_pooled_body<false, 2, false>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
-        case 3: scam_pooled_body<false, 3, false>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
-        default: scam_pooled_body<false, 4, false>(E, it0, it1, X, lane, w, nw, ntw, w - ntw, g_mu, g_lamT, g_U, g_UT, g_std); break;
-    }
-}
-
-// The same sub-step with TWELVE waves for 13..15 output blocks (npar 193..240): every wave is a block wave (blocks 0..11, four chain
-// groups each), and the slots of the blocks 12.. -- four per block, one chain group each -- ride as a FIFTH slot on the waves 0, 1, 2, ...
-// (wave w: group w % 4 of block 12 + w / 4), so every SIMD (wave mod 4) still runs nt tile sets per product.  Three waves per SIMD have
-// 170 registers each instead of 128: the three 32-register tile sets of a block wave (state, candidate, product) no longer spill around
-// the products.  The last wave carries the per-chain scalar state on top of its block.
-__global__ __launch_bounds__(768, 1) void scam_pooled12_kernel(EngineDev E, int it0, int it1,
-                                                              const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
-                                                              const double *__restrict__ g_U, const double *__restrict__ g_UT,
-                                                              const double *__restrict__ g_std)
-{
-    extern __shared__ double X[];
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = 12;
-    const int nt = (E.d + 15) >> 4, nx = 4 * (nt - 12);                          // nx extra slots, on the waves 0 .. nx - 1
-    const bool xs = w < nx;
-    const int xblk = 12 + (w >> 2), xgrp = w & 3;
-    if (w == nw - 1) {
-        if (xs) scam_pooled_body<true, 4, true, true>(E, it0, it1, X, lane, w, nw, w, 0, g_mu, g_lamT, g_U, g_UT, g_std, xblk, xgrp);
-        else scam_pooled_body<true, 4, true, false>(E, it0, it1, X, lane, w, nw, w, 0, g_mu, g_lamT, g_U, g_UT, g_std);
-    } else {
-        if (xs) scam_pooled_body<true, 4, false, true>(E, it0, it1, X, lane, w, nw, w, 0, g_mu, g_lamT, g_U, g_UT, g_std, xblk, xgrp);
-        else scam_pooled_body<true, 4, false, false>(E, it0, it1, X, lane, w, nw, w, 0, g_mu, g_lamT, g_U, g_UT, g_std);
-    }
-}
-
-// ---------------------------------------------------------------- pooled AM on the matrix cores
-// One wave = one tile of 64 chains, lane = chain for everything sequential (random numbers, prior, alpha, accept);
-// the two products with tables shared by all chains -- the proposal P = R'z (R the one pooled factor, dense d x d
-// with its lower triangle zero: M[s*d + o] = R(s,o)) and the Gaussian target's y = Lam v -- run as MFMA tiles like in
-// scam_pooled_kernel: B = the wave's own 64 chains' vector in LDS, A from the shared table, NB = 4 output blocks x
-// 4 chain groups = 16 accumulators per pass.  Rows s beyond an output block's last column are zero in R and are
-// skipped (exact: they would add 0*z).  The results come back to lane = chain order through LDS (P) or as the
-// lane-local partial chains of ss (y).  Same arithmetic per chain as step_kernel<false,false,true>.
-#ifndef MCX_POOLED_KU
-#define MCX_POOLED_KU 4
-#endif
-#ifndef MCX_POOLED_CB
-#define MCX_POOLED_CB 16
-#endif
-template <bool TRI>
-MCX_DEV void mfma_wave_product(const double *__restrict__ M, const double *X, int lane, int d, int d4, int ob0, int nb,
-                               mcx_d4 (&c)[4][4])
-{
-    const int li = lane & 15, lk = lane >> 4;
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) c[b][g] = mcx_d4{0.0, 0.0, 0.0, 0.0};
-    int kmax = d4;
-    if (TRI) { const int last = 16 * (ob0 + nb); kmax = last < d4 ? last : d4; }
-    const double *__restrict__ ap = M + (size_t)lk * d + 16 * ob0 + li;
-    const double *xp = X + lk * 64 + li;
-    // KU k-blocks per trip, their 4 KU loads of the shared table first: a trip waits for the L2 once -- one k-block per trip put thirteen
-    // round trips of ~1 us on each product of a wave that has the SIMD almost to itself (round 4: 0.93 -> 0.73 ms per iteration of 1 048 576
-    // chains at npar 50; two k-blocks per trip do almost as well, seven or eight are slower)
-    constexpr int KU = MCX_POOLED_KU;
-    for (int s0 = 0; s0 < kmax; s0 += 4 * KU) {
-        double a[KU][4];
-#pragma unroll
-        for (int u = 0; u < KU; ++u) {
-            const int s = (s0 + 4 * u < kmax) ? s0 + 4 * u : kmax - 4;          // (a k-block past the end: loaded again, not multiplied)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) a[u][b] = ap[(size_t)s * d + 16 * (b < nb ? b : 0)];
-        }
-#pragma unroll
-        for (int u = 0; u < KU; ++u) {
-            const int s = s0 + 4 * u;
-            if (s < kmax) {
-                const double *xq = xp + s * 64;
-                const double b0 = xq[0], b1 = xq[16], b2 = xq[32], b3 = xq[48];
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    if (b < nb && (!TRI || s < 16 * (ob0 + b + 1))) {
-                        c[b][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][b], b0, c[b][0], 0, 0, 0);
-                        c[b][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][b], b1, c[b][1], 0, 0, 0);
-                        c[b][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][b], b2, c[b][2], 0, 0, 0);
-                        c[b][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][b], b3, c[b][3], 0, 0, 0);
-                    }
-                }
-            }
-        }
-    }
-}
-
-// DR: delayed rejection's second stage on the same cores (drscale > 0): the stage-2 proposal with the shared R2 = R / drscale
-// (g_R2T, dense like g_RT), the target once more, and the two quadratic forms dx' iC dx of MCMC_DR_alpha13 as y = iC dx
-// products against the dense symmetric table g_iCd, each followed by the chain q = sum_i y_i dx_i ascending in i (lane = chain:
-// y comes back through the LDS vector, dx waits in the chain's global scratch EngineDev::xscr).  Operation for operation
-// step_body<false, true, true> (the lane-per-chain form with the tables through the scalar cache), whose chains these are.
-// W2 (without delayed rejection): 256 registers, so that two waves share a SIMD (the LDS vector lets six waves on a CU at npar 50: two SIMDs
-// with two).  The compiler spills ~40 doubles of state around the products to fit, and with more tiles than SIMDs it is still faster (round 4;
-// round 2's attempt predates the single-pass LDS layout): 97.1 -> 93.2 ms per 100 iterations of 1 048 576 chains at npar 50.  With one tile
-// per SIMD or fewer there is nobody to share with and the spills are all it buys (npar 20, 65536 chains: 2.1e9 against 2.6e9 proposals/s):
-// the host takes the 512-register instance there.
-template <bool DR, bool W2 = false>
-__global__ __launch_bounds__(64, (!DR && W2) ? 2 : 1) void pooled_mfma_kernel(EngineDev E, int it0, int it1,
-                                                         const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
-                                                         const double *__restrict__ g_RT, const double *__restrict__ g_R2T,
-                                                         const double *__restrict__ g_iCd)
-{
-    extern __shared__ double X[];
-    const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
-    const int d4 = (d + 3) & ~3, nt = (d + 15) >> 4, li = lane & 15, lk = lane >> 4;
-    const bool single = (nt <= 4);                                  // one pass: the outputs may overwrite the input vector
-    // single pass: the products (rows < d4 only) overwrite the vector they came from, and the partial ss chains go over
-    // its first 4 nt rows once y = Lam v is in registers -- 512 d4 bytes of LDS per wave (26 KiB at d = 50: six waves per CU)
-    double *T = single ? X : X + (size_t)d4 * 64;                  // [16 nt][64] products in (row, chain) order
-    double *Q = single ? X : T + (size_t)nt * 16 * 64;             // [4 nt][64] partial ss chains
-    double *theta_t = E.theta + (size_t)tile * d * 64;
-    double *cand_t = E.cand + (size_t)tile * d * 64;
-    double *c2_t = E.cs + (size_t)tile * 2 * d * 64;               // DR: the second-stage candidate
-    double *xs_t = DR ? E.xscr + (size_t)tile * 2 * d * 64 : nullptr;   // DR: dx of the quadratic form in flight
-    const bool gauss = (E.tgt.kind == TGT_GAUSS);
-    LaneState L;
-    lane_load(E, tile, lane, L);
-    uint32_t erstayed = TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane);
-    mcx_d4 c[4][4];
-    // out = M' X on the matrix cores, into T in (row, chain) order; tri: M is upper triangular (rows beyond a block's last column are zero)
-    auto product_to_T = [&](const double *__restrict__ M, bool tri) {
-        for (int ob0 = 0; ob0 < nt; ob0 += 4) {
-            const int nb = (nt - ob0) < 4 ? (nt - ob0) : 4;
-            if (tri) mfma_wave_product<true>(M, X, lane, d, d4, ob0, nb, c);
-            else mfma_wave_product<false>(M, X, lane, d, d4, ob0, nb, c);
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-                if (b < nb) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * (ob0 + b) + lk + 4 * r;
-                        if (row < d4) {                                 // rows >= d are never read
-                            double *o = T + (size_t)row * 64 + li;
-                            o[0] = c[b][0][r]; o[16] = c[b][1][r]; o[32] = c[b][2][r]; o[48] = c[b][3][r];
-                        }
-                    }
-                }
-        }
-    };
-    // ss of the Gaussian target for the vector v = x - mu in X (mcxt_ss_gauss): y = Lam v on the matrix cores, the partial chains
-    // q over r of y v in the lanes that hold them, their sum per chain
-    auto gauss_ss = [&]() -> double {
-        for (int k = d; k < d4; ++k) XL(k) = 0.0;
-        for (int ob0 = 0; ob0 < nt; ob0 += 4) {
-            const int nb = (nt - ob0) < 4 ? (nt - ob0) : 4;
-            mfma_wave_product<false>(g_lamT, X, lane, d, d4, ob0, nb, c);       // y = Lam v
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-                if (b < nb) {
-                    const int o0 = 16 * (ob0 + b) + lk;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {                               // q = chain over r of y v (mcxt_ss_gauss)
-                        double q = c[b][g][0] * X[(size_t)o0 * 64 + 16 * g + li];
-#pragma unroll
-                        for (int r = 1; r < 4; ++r) {
-                            const int o = o0 + 4 * r;
-                            const double t = dfma(c[b][g][r], X[(size_t)(o < d4 ? o : 0) * 64 + 16 * g + li], q);
-                            q = (o < d) ? t : q;
-                        }
-                        if (o0 < d) Q[(size_t)(4 * (ob0 + b) + lk) * 64 + 16 * g + li] = q;
-                    }
-                }
-        }
-        double ss = Q[lane];
-#pragma unroll 4
-        for (int e = 1; e < 4 * nt; ++e) if (16 * (e >> 2) + (e & 3) < d) ss = ss + Q[(size_t)e * 64 + lane];
-        return ss;
-    };
-    // dst = theta + T (lane = chain), and v = dst - mu back into the LDS vector for the Gaussian target
-    auto candidate_from_T = [&](double *dst_t) {
-        constexpr int CB = MCX_POOLED_CB;                // state elements' loads before their stores (see copy_vec): sixteen in flight
-        for (int k0 = 0; k0 < d; k0 += CB) {
-            double th[CB], tv[CB];
-#pragma unroll
-            for (int u = 0; u < CB; ++u) { const int k = (k0 + u < d) ? k0 + u : d - 1; th[u] = GV(theta_t, k); tv[u] = T[(size_t)k * 64 + lane]; }
-#pragma unroll
-            for (int u = 0; u < CB; ++u) {
-                if (k0 + u < d) {
-                    const double cnd = th[u] + tv[u];
-                    GV(dst_t, k0 + u) = cnd;
-                    if (gauss) XL(k0 + u) = cnd - g_mu[k0 + u];
-                }
-            }
-        }
-    };
-    // -DMCX_PHASE_PROF (tools/build_variant.sh; profiles/r05_a/c4_pooled_phases.txt): where a wave's iteration goes, by wall_clock64
-#ifdef MCX_PHASE_PROF
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = wall_clock64();
-#define PH(i) { unsigned long long tn = wall_clock64(); ph[i] += tn - tq; tq = tn; }
-#else
-#define PH(i)
-#endif
-    for (int it = it0; it <= it1; ++it) {
-        // ---- newpar = MCMC_propose(oldpar, R): z straight into the LDS vector, P = R'z on the matrix cores
-        MCX_POOLED_GEN(L.g, X, lane, d, true);
-        PH(0)
-        if (it == it1) {                                               // the launch's last normals stay readable (pooled RAM statistic)
-            double *zk = E.zs + ((size_t)tile * 2 + (it & 1)) * d * 64;
-            for (int k = 0; k < d; ++k) GV(zk, k) = XL(k);
-        }
-        for (int k = d; k < d4; ++k) XL(k) = 0.0;
-        product_to_T(g_RT, !E.usesvd);                                 // (condmax > 0: the full SVD factor)
-        PH(1)
-        candidate_from_T(cand_t);
-        PH(2)
-        bool inb = target_inbounds(E.tgt, d, lane, cand_t);
-        double pri2 = target_prior(E.tgt, d, lane, cand_t);
-        PH(3)
-        double ss2 = gauss ? gauss_ss() : target_ss<false>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
-        PH(4)
-        // ---- alpha, reject (MCMC_run.F90:47-63), as in step_kernel
-        bool reject;
-        if (!DR && E.method == M_ER) {                    // early rejection, MCMC_run_er.F90:60-89 (no second stage with it)
-            if (!inb) { L.bnd += 1; reject = true; }
-            else {
-                double u = rng_uniform(L.g);              // MCMC_sscrit, MCMC_DRAM.F90:124-135: always drawn
-                double sscrit = -2.0 * d_log(u) + L.ss1 / L.sigma2 + L.pri1;
-                if (pri2 >= sscrit) { reject = true; erstayed += 1; }
-                else { sscrit = L.sigma2 * (sscrit - pri2); reject = (ss2 >= sscrit); }
-            }
-        }
-        else if (!inb) { if (!DR) L.bnd += 1; reject = true; L.alpha12 = 0.0; }
-        else {
-            L.alpha12 = d_alpha(L.ss1, L.pri1, ss2, pri2, L.sigma2);
-            reject = true;
-            if (L.alpha12 >= 1.0) reject = false;
-            else if (L.alpha12 > 0.0) { double u = rng_uniform(L.g); if (u <= L.alpha12) reject = false; }
-        }
-        // ---- second stage: one delayed-rejection try with R2 = R/drscale (MCMC_run.F90:65-91)
-        bool dr_moved = false;
-        if (DR && __any(reject)) {
-            const bool m = reject;
-            if (m) L.drtries += 1;
-            MCX_POOLED_GEN(L.g, X, lane, d, m);            // lanes that did not draw compute on stale values and are not looked at
-            for (int k = d; k < d4; ++k) XL(k) = 0.0;
-            product_to_T(g_R2T, !E.usesvd);
-            candidate_from_T(c2_t);
-            const bool inb2 = target_inbounds(E.tgt, d, lane, c2_t);
-            const double pri3 = target_prior(E.tgt, d, lane, c2_t);
-            const double ss3 = gauss ? gauss_ss() : target_ss<false>(E.tgt, d, lane, c2_t, g_mu, g_lamT);
-            double qf[2];
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {                              // qa: dx = newpar2 - newpar, qb: dx = oldpar - newpar (MCMC_DRAM.F90:180-182)
-                const double *a_t = f == 0 ? c2_t : theta_t;
-                for (int k = 0; k < d; ++k) { const double dx = GV(a_t, k) - GV(cand_t, k); XL(k) = dx; GV(xs_t, k) = dx; }
-                for (int k = d; k < d4; ++k) XL(k) = 0.0;
-                product_to_T(g_iCd, false);                            // y = iC dx
-                double q = 0.0;
-                for (int i = 0; i < d; ++i) q = q + T[(size_t)i * 64 + lane] * GV(xs_t, i);
-                qf[f] = q;
-            }
-            if (m) {
-                if (!inb2) L.bnd += 1;
-                else {
-                    // MCMC_DR_alpha13, MCMC_DRAM.F90:162-186
-                    double alpha32;
-                    if (L.alpha12 == 0.0) alpha32 = 0.0;
-                    else alpha32 = min1(d_exp(-0.5 * ((ss2 - ss3) / L.sigma2 + (pri2 - pri3))));
-                    const double l2 = -0.5 * ((ss3 - L.ss1) / L.sigma2 + (pri3 - L.pri1));
-                    const double q1 = -0.5 * (qf[0] - qf[1]);
-                    const double alpha13 = min1(d_exp(l2 + q1) * (1.0 - alpha32) / (1.0 - L.alpha12));
-                    bool rej2 = true;
-                    if (alpha13 >= 1.0) rej2 = false;
-                    else if (alpha13 > 0.0) { double u = rng_uniform(L.g); if (u <= alpha13) rej2 = false; }
-                    if (!rej2) { L.dracc += 1; reject = false; dr_moved = true; ss2 = ss3; pri2 = pri3; }
-                }
-            }
-        }
-        PH(5)
-        if (reject) { L.stayed += 1; L.curcount += 1; }
-        else { L.ss1 = ss2; L.pri1 = pri2; L.chainind += 1; L.curcount = 1; }
-        if (E.updatesigma) {
-            double gm = rng_gamma(L.g, E.gam_shape, 2.0 / (E.N0S02 + L.ss1));
-            L.sigma2 = 1.0 / gm;
-        }
-        unsigned long long ballot = __ballot(!reject);
-        const int slot = it % E.wcap;
-        if (!reject) {
-            double *h = E.hist ? E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64 : nullptr;
-            copy_vec_wide<MCX_POOLED_CB>(theta_t, dr_moved ? c2_t : cand_t, h, lane, d);   // newpar = newpar2 when the DR try was accepted
-            if (h) GV(h, d) = L.ss1;
-        }
-        if (E.hist) {
-            if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ballot;
-            if (E.record_s2) E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = L.sigma2;
-        }
-        if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
-        PH(6)
-    }
-    lane_store(E, tile, lane, L);
-    TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane) = erstayed;
-#ifdef MCX_PHASE_PROF
-    if (lane == 0 && (tile == 0 || tile == E.ntiles / 2 || tile == E.ntiles - 1))
-        printf("pooled_mfma tile %d its %d x10ns: normals %llu product %llu candidate %llu bounds+prior %llu target %llu decide %llu accept+history %llu\n",
-               tile, it1 - it0 + 1, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
-#endif
-#undef PH
-}
-
-// ---------------------------------------------------------------- nycol > 1: sums over the response columns
-// sum((a - b)/sigma2) and friends reduce from 0 in column order, like the reference's array expressions
-// (MCMC_DRAM.F90:111, 129, 176-179); a, b, s2 are per-chain vectors (element j at GV(p, j)).
-MCX_DEV double colsum_diff(const double *a, const double *b, const double *s2, int ny, int lane)
-{
-    double s = 0.0;
-    for (int j = 0; j < ny; ++j) s = s + (GV(a, j) - GV(b, j)) / GV(s2, j);
-    return s;
-}
-MCX_DEV double d_alpha_cols(const double *ss1, double pri1, const double *ss2, double pri2, const double *s2, int ny, int lane)
-{
-    double tst = -0.5 * (colsum_diff(ss2, ss1, s2, ny, lane) + (pri2 - pri1));
-    double a;
-    if (tst >= 0.0) a = 1.0;
-    else if (tst < -708.39641853226408) a = 0.0;
-    else a = d_exp(tst);
-    return a;
-}
-
-// end of an iteration: MCMC_run.F90:93-105 / MCMC_run_ram.F90:66-78
-// ss2cols: with nycol > 1 the accepted point's ss per column (a per-chain vector); nullptr = the scalar ss2
-MCX_DEV void host_finish(const EngineDev &E, int tile, int lane, int it, LaneState &L, bool reject, bool dr_moved,
-                         double ss2, double pri2, const double *ramscale, const double *ss2cols = nullptr)
-{
-    const int d = E.d, ny = E.ny;
-    double *ssv = ny > 1 ? E.ssv + (size_t)tile * ny * 64 : nullptr, *s2v = ny > 1 ? E.s2v + (size_t)tile * ny * 64 : nullptr;
-    double *theta_t = E.theta + (size_t)tile * d * 64;
-    double *cand_t = E.cand + (size_t)tile * d * 64;
-    double *zs_t = E.zs + (size_t)tile * 2 * d * 64;
-    double *cs_t = E.cs + (size_t)tile * 2 * d * 64;
-    if (reject) { L.stayed += 1; L.curcount += 1; }
-    else {
-        if (ny > 1) { for (int j = 0; j < ny; ++j) GV(ssv, j) = GV(ss2cols, j); ss2 = GV(ssv, 0); }
-        L.ss1 = ss2; L.pri1 = pri2; L.chainind += 1; L.curcount = 1;
-    }
-    if (E.updatesigma) {                                // MCMC_updatesigma2: one gamma draw per column, in column order
-        if (ny > 1) {
-            for (int j = 0; j < ny; ++j) {
-                double gm = rng_gamma(L.g, E.gshapev[j], 2.0 / (E.N0S02 + GV(ssv, j)));
-                GV(s2v, j) = 1.0 / gm;
-            }
-            L.sigma2 = GV(s2v, 0);
-        } else {
-            double gm = rng_gamma(L.g, E.gam_shape, 2.0 / (E.N0S02 + L.ss1));
-            L.sigma2 = 1.0 / gm;
-        }
-    }
-    unsigned long long ballot = __ballot(!reject);
-    const int slot = it % E.wcap;
-    if (!reject) {
-        double *h = E.hist ? E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64 : nullptr;
-        const double *src = dr_moved ? cs_t : cand_t;
-        copy_vec(theta_t, src, h, lane, d);
-        if (h) { GV(h, d) = L.ss1; for (int j = 1; j < ny; ++j) GV(h, d + j) = GV(ssv, j); }
-    }
-    if (E.hist) {
-        if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ballot;
-        if (E.record_s2) {
-            if (ny > 1) { for (int j = 0; j < ny; ++j) E.s2hist[(((size_t)tile * E.wcap + slot) * ny + j) * 64 + lane] = GV(s2v, j); }
-            else E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = L.sigma2;
-        }
-    }
-    if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
-    if (E.method == M_RAM && E.doadapt != 0 && !(it < E.burnintime && E.doburnin != 0)) {
-        double a = ramscale[0] * (L.alpha12 - E.alphatarget);
-        if (!(a >= 0.0)) TIDX(E.ictr, tile, NICTR, I_DOWNS, lane) += 1u;
-        const double *hx = E.hx + (size_t)tile * NHX * 64;
-        if (E.usesvd) ram_update_full(E.Rf + (size_t)tile * d * d * 64, zs_t, cs_t, lane, d, a, GV(hx, HX_SU), true, L.status);
-        else { bool pd = L.pdesc != 0u; ram_update<false>(E.R + (size_t)tile * E.P * 64, zs_t, zs_t, cs_t, cand_t, theta_t, lane, d, a, GV(hx, HX_SU), true, false, L.status, nullptr, pd); L.pdesc = pd ? 1u : 0u; }
-    }
-}
-
-// Device-resident evaluation for the phase-cut iteration: fills hev (inbounds, prior, ss per response column) the way
-// host_eval does from the user's host callbacks, for the built-in response-column target
-//   ss_j(theta) = sum_i (y_j(i) - theta_1 exp(-theta_{1+j} x_i))**2,  j = 1..nycol  (oracle/mcx_targets.h: mcxt_ss_expdata_cols)
-// with the library's box bounds and Gaussian priors.  what: 0 = checkbounds, priorfun, ssfunction; 1 = checkbounds and
-// priorfun; 2 = ssfunction alone (ssfunction_er0.f90: the default ssfunction_er is ssfunction).
-MCX_DEV void dev_eval_body(const EngineDev &E, int tile, int lane, const double *src, int stride_k, int use_stage2, int what)
-{
-    const int d = E.d, ny = E.ny;
-    const double *c_t = src + (size_t)tile * stride_k * 64;
-    double *hev = E.hev + (size_t)tile * (NHE - 1 + ny) * 64;
-    const double *hx = E.hx + (size_t)tile * NHX * 64;
-    bool inb = true;
-    double pri = 0.0;
-    const bool skip = use_stage2 && GV(hx, HX_STAGE2) == 0.0;
-    if (!skip && what != 2) {
-        inb = target_inbounds(E.tgt, d, lane, c_t);
-        if (inb) pri = target_prior(E.tgt, d, lane, c_t);          // MCMC_run.F90:54-56: prior first
-    }
-    const bool doss = !skip && ((what == 0 && inb) || what == 2);
-    const double th0 = GV(c_t, 0);
-    for (int j = 0; j < ny; ++j) {
-        double ss = 0.0;
-        if (doss) {
-            const double thj = GV(c_t, 1 + j);
-            const double *yj = E.tgt.y + (size_t)j * E.tgt.ndata;
-            for (int i = 0; i < E.tgt.ndata; ++i) {
-                double r = yj[i] - th0 * d_exp(-(thj * E.tgt.x[i]));
-                ss = dfma(r, r, ss);
-            }
-        }
-        GV(hev, HE_SS + j) = ss;
-    }
-    GV(hev, HE_INB) = (inb && !skip) ? 1.0 : 0.0;
-    GV(hev, HE_PRI) = pri;
-}
-__global__ __launch_bounds__(64) void dev_eval_kernel(EngineDev E, const double *__restrict__ src, int stride_k, int use_stage2, int what)
-{ dev_eval_body(E, blockIdx.x, threadIdx.x, src, stride_k, use_stage2, what); }
-
-// sR / sR2 / siC: pooled mode's shared factor, second-stage factor and inverse covariance (nullptr: the chain's own)
-template <int PHASE>
-MCX_DEV void host_phase_body(const EngineDev &E, int tile, int lane, int it, const double *__restrict__ ramscale, int aux, double *X,
-                             const double *__restrict__ sR = nullptr, const double *__restrict__ sR2 = nullptr, const double *__restrict__ siC = nullptr)
-{
-    const int d = E.d;
-    double *theta_t = E.theta + (size_t)tile * d * 64;
-    double *cand_t = E.cand + (size_t)tile * d * 64;
-    double *zs_t = E.zs + (size_t)tile * 2 * d * 64;           // host mode: first half = stage-1 z, second half = stage-2 z
-    double *c2_t = E.cs + (size_t)tile * 2 * d * 64;
-    const int ny = E.ny;
-    double *hev = E.hev + (size_t)tile * (NHE - 1 + ny) * 64;    // inbounds, prior, ss per column
-    double *hx = E.hx + (size_t)tile * NHX * 64;
-    double *Y = X + (size_t)d * 64;
-    double *ssv = ny > 1 ? E.ssv + (size_t)tile * ny * 64 : nullptr, *s2v = ny > 1 ? E.s2v + (size_t)tile * ny * 64 : nullptr;
-    double *ss2v = ny > 1 ? E.ss2v + (size_t)tile * ny * 64 : nullptr;
-    const double *sshev = hev + (size_t)HE_SS * 64;              // the host's ss columns of the point just evaluated
-    LaneState L;
-    lane_load(E, tile, lane, L);
-    if (PHASE == 0) {                                             // newpar = MCMC_propose(oldpar, R)
-        double su = gen_normals(L.g, zs_t, lane, d, true);
-        GV(hx, HX_SU) = su;
-        if (sR) { if (E.usesvd) gemvN_shared(sR, zs_t, cand_t, theta_t, lane, d); else trmv_shared(sR, zs_t, cand_t, theta_t, lane, d); }
-        else if (E.usesvd) gemvN_panels(E.Rf + (size_t)tile * d * d * 64, zs_t, cand_t, theta_t, lane, d, true);    // matmulx(R,z)
-        else trmv_panels<false>(E.R + (size_t)tile * E.P * 64, zs_t, cand_t, theta_t, lane, d, true, E.method == M_RAM && L.pdesc != 0u);
-    } else if (PHASE == 1) {
-        const bool inb = GV(hev, HE_INB) != 0.0;
-        const double pri2 = GV(hev, HE_PRI), ss2 = GV(hev, HE_SS);
-        bool reject;
-        if (!inb) {
-            if (!E.dodr) L.bnd += 1;
-            reject = true;
-            if (E.method != M_RAM) L.alpha12 = 0.0;
-        } else {
-            L.alpha12 = ny > 1 ? d_alpha_cols(ssv, L.pri1, sshev, pri2, s2v, ny, lane) : d_alpha(L.ss1, L.pri1, ss2, pri2, L.sigma2);
-            reject = true;
-            if (L.alpha12 >= 1.0) reject = false;
-            else if (L.alpha12 > 0.0) { double u = rng_uniform(L.g); if (u <= L.alpha12) reject = false; }
-        }
-        if (E.dodr) {
-            const bool m = reject;
-            if (m) L.drtries += 1;
-            for (int j = 0; j < (ny > 1 ? ny : 0); ++j) GV(ss2v, j) = GV(sshev, j);
-            gen_normals(L.g, zs_t + (size_t)d * 64, lane, d, m);
-            if (sR2) { if (E.usesvd) gemvN_shared(sR2, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d); else trmv_shared(sR2, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d); }
-            else if (E.usesvd) gemvN_panels(E.R2f + (size_t)tile * d * d * 64, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d, m);
-            else trmv_panels<false>(E.R2 + (size_t)tile * E.P * 64, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d, m);
-            GV(hx, HX_SS2) = ss2; GV(hx, HX_PRI2) = pri2;
-            GV(hx, HX_REJECT) = reject ? 1.0 : 0.0; GV(hx, HX_STAGE2) = m ? 1.0 : 0.0;
-        } else {
-            host_finish(E, tile, lane, it, L, reject, false, ss2, pri2, ramscale, sshev);
-        }
-    } else if (PHASE == 5) {                                      // SCAM sub-step aux: propose (MCMC_run_scam.F90:94-117)
-        const int j = aux;
-        double *rot_t = c2_t;
-        const double *Ut = E.Rf + (size_t)tile * d * d * 64;
-        if (j == 0) GV(hx, HX_MOVED) = 0.0;
-        if (E.scam_fast) {
-            const double zj = rng_normal(L.g) * TIDX(E.qstd, tile, d, j, lane);
-            scam_fast_propose(Ut, theta_t, cand_t, lane, d, j, zj);
-        } else {
-            gemvT_panels(Ut, theta_t, rot_t, lane, d);
-            const double zj = rng_normal(L.g) * TIDX(E.qstd, tile, d, j, lane);
-            GV(rot_t, j) = GV(rot_t, j) + zj;
-            gemvN_panels(Ut, rot_t, cand_t, nullptr, lane, d, true);
-        }
-    } else if (PHASE == 6) {                                      // SCAM sub-step: decide with the host's bounds / prior / ss
-        const bool inb = GV(hev, HE_INB) != 0.0;
-        const double pri2 = GV(hev, HE_PRI), ss2 = GV(hev, HE_SS);
-        bool reject;
-        if (!inb) { L.bnd += 1; L.alpha12 = 0.0; reject = true; }
-        else {
-            L.alpha12 = ny > 1 ? d_alpha_cols(ssv, L.pri1, sshev, pri2, s2v, ny, lane) : d_alpha(L.ss1, L.pri1, ss2, pri2, L.sigma2);
-            reject = true;
-            if (L.alpha12 >= 1.0) reject = false;
-            else if (L.alpha12 > 0.0) { double u = rng_uniform(L.g); if (u <= L.alpha12) reject = false; }
-        }
-        if (!reject) {
-            for (int j = 0; j < (ny > 1 ? ny : 0); ++j) GV(ssv, j) = GV(sshev, j);
-            L.ss1 = ss2; L.pri1 = pri2; GV(hx, HX_MOVED) = 1.0;
-            copy_vec(theta_t, cand_t, nullptr, lane, d);
-        }
-    } else if (PHASE == 7) {                                      // SCAM: end of the outer iteration (one chain row)
-        const bool rejall = GV(hx, HX_MOVED) == 0.0;
-        if (rejall) { L.stayed += 1; L.curcount += 1; }
-        else { L.chainind += 1; L.curcount = 1; }
-        if (E.updatesigma) {
-            if (ny > 1) {
-                for (int j = 0; j < ny; ++j) { double gm = rng_gamma(L.g, E.gshapev[j], 2.0 / (E.N0S02 + GV(ssv, j))); GV(s2v, j) = 1.0 / gm; }
-                L.sigma2 = GV(s2v, 0);
-            } else {
-                double gm = rng_gamma(L.g, E.gam_shape, 2.0 / (E.N0S02 + L.ss1));
-                L.sigma2 = 1.0 / gm;
-            }
-        }
-        unsigned long long ballot = __ballot(!rejall);
-        const int slot = it % E.wcap;
-        if (E.hist) {
-            if (!rejall) {
-                double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64;
-                for (int k = 0; k < d; ++k) GV(h, k) = GV(theta_t, k);
-                GV(h, d) = L.ss1;
-                for (int j = 1; j < ny; ++j) GV(h, d + j) = GV(ssv, j);
-            }
-            if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ballot;
-            if (E.record_s2) {
-                if (ny > 1) { for (int j = 0; j < ny; ++j) E.s2hist[(((size_t)tile * E.wcap + slot) * ny + j) * 64 + lane] = GV(s2v, j); }
-                else E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = L.sigma2;
-            }
-        }
-        if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
-    } else if (PHASE == 3) {                                      // early rejection, first half (MCMC_run_er.F90:54-70)
-        // the host has evaluated checkbounds and priorfun; draw the threshold, test the prior, leave sscrit for ssfunction_er
-        const bool inb = GV(hev, HE_INB) != 0.0;
-        const double pri2 = GV(hev, HE_PRI);
-        bool reject = false, need = false;
-        double crit = 0.0;
-        if (!inb) { L.bnd += 1; reject = true; }
-        else {
-            double u = rng_uniform(L.g);                          // MCMC_sscrit, MCMC_DRAM.F90:124-135: always drawn
-            double s1 = L.ss1 / L.sigma2;
-            if (ny > 1) { s1 = 0.0; for (int j = 0; j < ny; ++j) s1 = s1 + GV(ssv, j) / GV(s2v, j); }      // sum(ss1/sigma2)
-            double sscrit = -2.0 * d_log(u) + s1 + L.pri1;
-            if (pri2 >= sscrit) { reject = true; TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane) += 1; }
-            else { crit = L.sigma2 * (sscrit - pri2); need = true; }    // sigma2(1): MCMC_run_er.F90:72
-        }
-        GV(hx, HX_PRI2) = pri2; GV(hx, HX_CRIT) = crit;
-        GV(hx, HX_REJECT) = reject ? 1.0 : 0.0; GV(hx, HX_STAGE2) = need ? 1.0 : 0.0;
-    } else if (PHASE == 4) {                                      // early rejection, second half (:71-101)
-        bool reject = GV(hx, HX_REJECT) != 0.0;
-        const double pri2 = GV(hx, HX_PRI2);
-        double ss2 = 0.0;
-        if (GV(hx, HX_STAGE2) != 0.0) {
-            ss2 = GV(hev, HE_SS);
-            double tot = ss2;
-            if (ny > 1) { tot = 0.0; for (int j = 0; j < ny; ++j) tot = tot + GV(sshev, j); }                 // sum(ss2)
-            reject = (tot >= GV(hx, HX_CRIT));
-        }
-        host_finish(E, tile, lane, it, L, reject, false, ss2, pri2, ramscale, sshev);
-    } else {                                                      // PHASE 2: decide the DR try, finish
-        bool reject = GV(hx, HX_REJECT) != 0.0;
-        double ss2 = GV(hx, HX_SS2), pri2 = GV(hx, HX_PRI2);
-        bool dr_moved = false;
-        if (GV(hx, HX_STAGE2) != 0.0) {
-            const bool inb2 = GV(hev, HE_INB) != 0.0;
-            if (!inb2) L.bnd += 1;
-            else {
-                const double pri3 = GV(hev, HE_PRI), ss3 = GV(hev, HE_SS);
-                double alpha32, l2;
-                if (ny > 1) {
-                    if (L.alpha12 == 0.0) alpha32 = 0.0;
-                    else alpha32 = min1(d_exp(-0.5 * (colsum_diff(ss2v, sshev, s2v, ny, lane) + (pri2 - pri3))));
-                    l2 = -0.5 * (colsum_diff(sshev, ssv, s2v, ny, lane) + (pri3 - L.pri1));
-                } else {
-                    if (L.alpha12 == 0.0) alpha32 = 0.0;
-                    else alpha32 = min1(d_exp(-0.5 * ((ss2 - ss3) / L.sigma2 + (pri2 - pri3))));
-                    l2 = -0.5 * ((ss3 - L.ss1) / L.sigma2 + (pri3 - L.pri1));
-                }
-                const double *iCt = siC ? nullptr : E.iC + (size_t)tile * E.P * 64;
-                double *Xq = E.dr_lds ? X : zs_t, *Yq = E.dr_lds ? Y : zs_t + (size_t)d * 64;   // npar > 160: the (dead) normal vectors
-                for (int k = 0; k < d; ++k) GV(Xq, k) = GV(c2_t, k) - GV(cand_t, k);
-                double qa = siC ? quadform_sym_shared(siC, lane, d, Xq, Yq) : quadform_sym(iCt, lane, d, Xq, Yq);
-                for (int k = 0; k < d; ++k) GV(Xq, k) = GV(theta_t, k) - GV(cand_t, k);
-                double qb = siC ? quadform_sym_shared(siC, lane, d, Xq, Yq) : quadform_sym(iCt, lane, d, Xq, Yq);
-                double q1 = -0.5 * (qa - qb);
-                double alpha13 = min1(d_exp(l2 + q1) * (1.0 - alpha32) / (1.0 - L.alpha12));
-                bool rej2 = true;
-                if (alpha13 >= 1.0) rej2 = false;
-                else if (alpha13 > 0.0) { double u = rng_uniform(L.g); if (u <= alpha13) rej2 = false; }
-                if (!rej2) { L.dracc += 1; reject = false; dr_moved = true; ss2 = ss3; pri2 = pri3; }
-            }
-        }
-        host_finish(E, tile, lane, it, L, reject, dr_moved, ss2, pri2, ramscale, dr_moved ? sshev : ss2v);
-    }
-    lane_store(E, tile, lane, L);
-}
-template <int PHASE>
-__global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, const double *__restrict__ ramscale, int aux)
-{
-    extern __shared__ double X[];
-    host_phase_body<PHASE>(E, blockIdx.x, threadIdx.x, it, ramscale, aux, X);
-}
-
-// Two (three) phases that no evaluation separates, in one launch: the last phase of an iteration and the first of the next one (the proposal),
-// a SCAM sub-step's decision and the next component's proposal.  With the user's functions on the host an iteration of few chains is launch and
-// wake-up latency, nothing else -- one launch per evaluation instead of two.  The phases hand over through the chain's own state exactly as
-// separate launches do (every element written and read back by the same lane: see step_kernel_cols).  PB / PC < 0: none.
-template <int PA, int PB, int PC>
-__global__ __launch_bounds__(64) void host_phase_seq_kernel(EngineDev E, int itA, int auxA, int itB, int auxB, int itC, int auxC, const double *__restrict__ ramscale)
-{
-    extern __shared__ double X[];
-    host_phase_body<PA>(E, blockIdx.x, threadIdx.x, itA, ramscale + itA, auxA, X);
-    if constexpr (PB >= 0) host_phase_body<PB>(E, blockIdx.x, threadIdx.x, itB, ramscale + itB, auxB, X);
-    if constexpr (PC >= 0) host_phase_body<PC>(E, blockIdx.x, threadIdx.x, itC, ramscale + itC, auxC, X);
-}
-
-// ---------------------------------------------------------------- nycol > 1 in ONE launch (step_kernel_cols)
-// Iterations it0..it1 of MCMC_run / MCMC_run_ram / MCMC_run_er / MCMC_run_scam for a target the DEVICE evaluates between the phases
-// of an iteration (the response-column target `expcols`: nycol sums of squares per point, one sigma2 per column, sums over the
-// columns in MCMC_alpha, MCMC_sscrit and MCMC_DR_alpha13, one gamma draw per column -- MCMC_DRAM.F90:100-135,162-206): the phase
-// bodies of the host-callback path and dev_eval_body in the order host_iteration launches them, fused into one kernel.  The phases
-// hand their intermediate results over through the chain's own global scratch (hev, hx, cand, ...) exactly as the separate launches
-// do -- every element is written and read back by the same lane, so program order is all the ordering there is to keep -- which makes
-// the fused form the phase form bit for bit (tests/test_gpu_host_callbacks.py, fixtures m1..m5 both ways).  ramscale: the table's
-// base (1 / it**nuparam at index it).  sR / sR2 / siC: pooled mode's shared tables.
-__global__ __launch_bounds__(64) void step_kernel_cols(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
-                                                       const double *__restrict__ sR, const double *__restrict__ sR2, const double *__restrict__ siC)
-{
-    extern __shared__ double X[];
-    const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
-    for (int it = it0; it <= it1; ++it) {
-        const double *rs = ramscale + it;
-        if (E.doscam) {                                 // MCMC_run_scam.F90:94-138: npar componentwise proposals, each with its own evaluation
-            for (int j = 0; j < d; ++j) {
-                host_phase_body<5>(E, tile, lane, it, rs, j, X);
-                dev_eval_body(E, tile, lane, E.cand, d, 0, 0);
-                host_phase_body<6>(E, tile, lane, it, rs, j, X);
-            }
-            host_phase_body<7>(E, tile, lane, it, rs, 0, X);
-            continue;
-        }
-        host_phase_body<0>(E, tile, lane, it, rs, 0, X, sR, sR2, siC);
-        if (E.method == M_ER) {                         // MCMC_run_er.F90:54-101: the threshold is drawn between priorfun and ssfunction
-            dev_eval_body(E, tile, lane, E.cand, d, 0, 1);
-            host_phase_body<3>(E, tile, lane, it, rs, 0, X, sR, sR2, siC);
-            dev_eval_body(E, tile, lane, E.cand, d, 1, 2);
-            host_phase_body<4>(E, tile, lane, it, rs, 0, X, sR, sR2, siC);
-            continue;
-        }
-        dev_eval_body(E, tile, lane, E.cand, d, 0, 0);
-        host_phase_body<1>(E, tile, lane, it, rs, 0, X, sR, sR2, siC);
-        if (E.dodr) {
-            dev_eval_body(E, tile, lane, E.cs, 2 * d, 1, 0);
-            host_phase_body<2>(E, tile, lane, it, rs, 0, X, sR, sR2, siC);
-        }
-    }
-    // pooled method = 'ram': the tick's statistic reads the last iteration's normals where the single-launch kernels leave them,
-    // in the (it & 1) half of the chain's two normal vectors (moments_kernel kind 2); the phases keep stage-1 normals in the first half
-    if (sR && !E.dodr && (it1 & 1)) {
-        double *zs_t = E.zs + (size_t)tile * 2 * d * 64;
-        for (int k = 0; k < d; ++k) GV(zs_t, d + k) = GV(zs_t, k);
-    }
-}
-
-// ---------------------------------------------------------------- MCMC_run1 / MCMC_run1_er: one evaluation per invocation
-// The reference's file protocol (MCMC_run1.F90:31-256, MCMC_run1_er.F90:28-234) keeps the chain's state in files between
-// program runs; what is arithmetic in it -- the acceptance probability of the point just evaluated, MCMC_reject's draw,
-// the next proposal, early rejection's threshold -- runs here, on the engine's factors (R, R2, iC of mcmcx_init) and
-// the chain's stream.  The caller's vectors travel in r1, tile-interleaved like everything else:
-//   [0,d) the current point (oldpar2; `from` of a proposal)   [d,2d) oldpar1   [2d,3d) newpar (a proposal's result)
-//   then ny each: ssprev2, ssprev1, ss;  then the scalars below.
-enum { R1_PRI2 = 0, R1_PRI1, R1_PRI, R1_A12, R1_ALPHA, R1_REJECT, R1_CRIT, R1_SPARE, NR1 };
-MCX_DEV int r1_len(int d, int ny) { return 3 * d + 3 * ny + NR1; }
-// MODE 0: alpha = MCMC_alpha(oldpar1 -> newpar) (drstage 1, MCMC_run1.F90:141) or MCMC_DR_alpha13(oldpar2, oldpar1,
-//         newpar) (drstage 2, :137-139), then MCMC_reject(alpha) (:143)
-// MODE 1 / 2: newpar = MCMC_propose(from, R) / (from, R2)  (:185-189)
-// MODE 3: sscrit = MCMC_sscrit(ssprev1, sspri1) (MCMC_run1_er.F90:168; MCMC_DRAM.F90:124-135)
-template <int MODE>
-__global__ __launch_bounds__(64) void run1_kernel(EngineDev E, double *r1, int drstage)
-{
-    extern __shared__ double X[];
-    const int lane = threadIdx.x, tile = blockIdx.x, d = E.d, ny = E.ny;
-    double *b = r1 + (size_t)tile * r1_len(d, ny) * 64;
-    double *cur_t = b, *old1_t = b + (size_t)d * 64, *new_t = b + (size_t)2 * d * 64;
-    double *ssp2 = b + (size_t)3 * d * 64, *ssp1 = ssp2 + (size_t)ny * 64, *ssn = ssp1 + (size_t)ny * 64;
-    double *sc = ssn + (size_t)ny * 64;
-    const double *s2v = ny > 1 ? E.s2v + (size_t)tile * ny * 64 : nullptr;
-    double *zs_t = E.zs + (size_t)tile * 2 * d * 64;
-    double *Y = X + (size_t)d * 64;
-    LaneState L;
-    lane_load(E, tile, lane, L);
-    if (MODE == 0) {
-        const double pri1 = GV(sc, R1_PRI1), pri = GV(sc, R1_PRI);
-        double alpha;
-        if (drstage > 1 && E.dodr) {                      // MCMC_DR_alpha13, MCMC_DRAM.F90:162-186: 1 = oldpar2, 2 = oldpar1, 3 = newpar
-            const double pri2c = GV(sc, R1_PRI2), alpha12 = GV(sc, R1_A12);
-            double alpha32, l2;
-            if (ny > 1) {
-                if (alpha12 == 0.0) alpha32 = 0.0;
-                else alpha32 = min1(d_exp(-0.5 * (colsum_diff(ssp1, ssn, s2v, ny, lane) + (pri1 - pri))));
-                l2 = -0.5 * (colsum_diff(ssn, ssp2, s2v, ny, lane) + (pri - pri2c));
-            } else {
-                if (alpha12 == 0.0) alpha32 = 0.0;
-                else alpha32 = min1(d_exp(-0.5 * ((GV(ssp1, 0) - GV(ssn, 0)) / L.sigma2 + (pri1 - pri))));
-                l2 = -0.5 * ((GV(ssn, 0) - GV(ssp2, 0)) / L.sigma2 + (pri - pri2c));
-            }
-            const double *iCt = E.iC + (size_t)tile * E.P * 64;
-            double *Xq = E.dr_lds ? X : zs_t, *Yq = E.dr_lds ? Y : zs_t + (size_t)d * 64;       // npar > 160: the normal vectors' scratch
-            for (int k = 0; k < d; ++k) GV(Xq, k) = GV(new_t, k) - GV(old1_t, k);
-            double qa = quadform_sym(iCt, lane, d, Xq, Yq);
-            for (int k = 0; k < d; ++k) GV(Xq, k) = GV(cur_t, k) - GV(old1_t, k);
-            double qb = quadform_sym(iCt, lane, d, Xq, Yq);
-            double q1 = -0.5 * (qa - qb);
-            alpha = min1(d_exp(l2 + q1) * (1.0 - alpha32) / (1.0 - alpha12));
-        } else {
-            alpha = ny > 1 ? d_alpha_cols(ssp1, pri1, ssn, pri, s2v, ny, lane) : d_alpha(GV(ssp1, 0), pri1, GV(ssn, 0), pri, L.sigma2);
-        }
-        bool reject = true;                               // MCMC_reject, MCMC_DRAM.F90:140-155
-        if (alpha >= 1.0) reject = false;
-        else if (alpha > 0.0) { double u = rng_uniform(L.g); if (u <= alpha) reject = false; }
-        GV(sc, R1_ALPHA) = alpha; GV(sc, R1_REJECT) = reject ? 1.0 : 0.0;
-    } else if (MODE == 1 || MODE == 2) {
-        gen_normals(L.g, zs_t, lane, d, true);
-        if (E.usesvd) gemvN_panels((MODE == 2 ? E.R2f : E.Rf) + (size_t)tile * d * d * 64, zs_t, new_t, cur_t, lane, d, true);   // matmulx(R,z)
-        else trmv_panels<false>((MODE == 2 ? E.R2 : E.R) + (size_t)tile * E.P * 64, zs_t, new_t, cur_t, lane, d, true);
-    } else {
-        double u = rng_uniform(L.g);
-        double s1 = GV(ssp1, 0) / L.sigma2;
-        if (ny > 1) { s1 = 0.0; for (int j = 0; j < ny; ++j) s1 = s1 + GV(ssp1, j) / GV(s2v, j); }           // sum(ss1/sigma2)
-        GV(sc, R1_CRIT) = -2.0 * d_log(u) + s1 + GV(sc, R1_PRI1);
-    }
-    lane_store(E, tile, lane, L);
-}
-
-// ---------------------------------------------------------------- first point (MCMC_run.F90:33-39)
-// dst[(tile*K + e)*64 + lane] = src[e]: every chain starts from the same K-vector (par0, R(cmat0), ...)
-__global__ __launch_bounds__(64) void bcast_kernel(double *dst, const double *__restrict__ src, size_t K)
-{
-    double *o = dst + (size_t)blockIdx.x * K * 64;
-    for (size_t e = blockIdx.y; e < K; e += gridDim.y) o[e * 64 + threadIdx.x] = src[e];
-}
-
-__global__ __launch_bounds__(64) void init_kernel(EngineDev E)
-{
-    const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
-    double *theta_t = E.theta + (size_t)tile * d * 64;
-    double pri1, ss1;
-    const int ny = E.ny;
-    if (E.tgt.kind == TGT_HOST) {
-        const double *hev = E.hev + (size_t)tile * (NHE - 1 + ny) * 64;
-        pri1 = GV(hev, HE_PRI); ss1 = GV(hev, HE_SS);
-        for (int j = 0; j < (ny > 1 ? ny : 0); ++j) TIDX(E.ssv, tile, ny, j, lane) = GV(hev, HE_SS + j);
-    }
-    else { pri1 = target_prior(E.tgt, d, lane, theta_t); ss1 = target_ss<false>(E.tgt, d, lane, theta_t, E.tgt.mu, E.tgt.lamT); }
-    TIDX(E.scal, tile, NSCAL, S_SS1, lane) = ss1; TIDX(E.scal, tile, NSCAL, S_PRI1, lane) = pri1;
-    // row 1 of the chain: iteration 1 counts as accepted
-    const int slot = 1 % E.wcap;
-    if (E.hist) {
-        double *h = E.hist + ((size_t)tile * E.wcap + slot) * (size_t)E.hs * 64;
-        for (int k = 0; k < d; ++k) GV(h, k) = GV(theta_t, k);
-        GV(h, d) = ss1;
-        for (int j = 1; j < ny; ++j) GV(h, d + j) = TIDX(E.ssv, tile, ny, j, lane);
-        if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ~0ull;
-        if (E.record_s2) {
-            if (ny > 1) { for (int j = 0; j < ny; ++j) E.s2hist[(((size_t)tile * E.wcap + slot) * ny + j) * 64 + lane] = TIDX(E.s2v, tile, ny, j, lane); }
-            else E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = TIDX(E.scal, tile, NSCAL, S_SIGMA2, lane);
-        }
-    }
-    if (E.accmask && lane == 0) E.accmask[tile] = ~0ull;
-    for (int k = 0; k < d; ++k) TIDX(E.basetheta, tile, d, k, lane) = GV(theta_t, k);
-}
-
-// ---------------------------------------------------------------- MCMC_adapt (MCMC_adapt.F90:12-174) at a tick
-// mode bits chosen by the host from (simuind, namelist): see mcmcx_run.
-enum { AD_BURN = 1, AD_AM = 2, AD_FIRST = 4 };
-
-// MCMC_calculate_R, Cholesky branch (MCMC_adapt.F90:211-215): R = dpotf2('U', cmat) * 2.4/sqrt(d).
-// dpotf2 computes R(j,k) = (A(j,k) - sum_{i<j} R(i,j) R(i,k)) / R(j,j) with every sum an fma chain ascending in i
-// from 0.  Same chains here, but formed for an 8 x 8 block of (j,k) at a time: the 64 accumulators stay in registers
-// while the finished rows i < J0 stream by once per block (16 loads per 64 fma instead of 1 per fma), then the rows
-// of the block row itself are folded in -- from registers on the diagonal block, whose finished rows and 1/R(j,j) are
-// parked in LDS for the blocks to its right.  At: cmat (read), Tt: the factor (written, and read back as rows i < J0),
-// Rt: scaled copy on success.  X: 36 LDS vectors.  Returns LAPACK's info (0, or j+1 at the first non-positive pivot).
-constexpr int BT = 8;
-#define MCX_DLI(a, b) ((a) * (15 - (a)) / 2 + ((b) - (a) - 1))   // strictly upper part of the 8 x 8 diagonal block, by rows: 28 entries
-MCX_DEV int calculate_R(const double *At, double *Tt, double *Rt, int lane, int d, int P, bool act, double *X)
-{
-    int info = 0;
-    for (int J0 = 0; J0 < d; J0 += BT) {
-        const int nr = (d - J0) < BT ? (d - J0) : BT;
-        for (int K0 = J0; K0 < d; K0 += BT) {
-            const int nc = (d - K0) < BT ? (d - K0) : BT;
-            const bool diag = (K0 == J0);
-            double T[BT][BT];
-#pragma unroll
-            for (int a = 0; a < BT; ++a)
-#pragma unroll
-                for (int b = 0; b < BT; ++b) T[a][b] = 0.0;
-#pragma unroll 2
-            for (int i = 0; i < J0; ++i) {
-                const double *rowi = Tt + (size_t)rowstart(i, d) * 64;             // element (i,k) at rowi[k - i]
-                double rj[BT], rk[BT];
-#pragma unroll
-                for (int a = 0; a < BT; ++a) rj[a] = GV(rowi, J0 - i + (a < nr ? a : nr - 1));
-#pragma unroll
-                for (int b = 0; b < BT; ++b) rk[b] = GV(rowi, K0 - i + (b < nc ? b : nc - 1));
-#pragma unroll
-                for (int a = 0; a < BT; ++a)
-#pragma unroll
-                    for (int b = 0; b < BT; ++b) T[a][b] = dfma(rj[a], rk[b], T[a][b]);
-            }
-#pragma unroll
-            for (int a = 0; a < BT; ++a) {
-                if (a < nr) {
-                    const int j = J0 + a;
-                    const double *arow = At + (size_t)rowstart(j, d) * 64;
-                    double *trow = Tt + (size_t)rowstart(j, d) * 64;
-                    double av[BT];
-#pragma unroll
-                    for (int b = 0; b < BT; ++b) { int k = K0 + (b < nc ? b : nc - 1); av[b] = GV(arow, (k >= j ? k : j) - j); }
-                    if (diag) {
-#pragma unroll
-                        for (int a2 = 0; a2 < a; ++a2)
-#pragma unroll
-                            for (int b = a; b < BT; ++b) T[a][b] = dfma(T[a2][a], T[a2][b], T[a][b]);
-                        const double ajj = av[a] - T[a][a];
-                        if (act && info == 0 && !(ajj > 0.0)) info = j + 1;
-                        const double rjj = sqrt(ajj), rinv = 1.0 / rjj;
-                        T[a][a] = rjj;
-#pragma unroll
-                        for (int b = a + 1; b < BT; ++b) T[a][b] = (av[b] - T[a][b]) * rinv;
-#pragma unroll
-                        for (int b = a; b < BT; ++b) {
-                            if (b < nc) { GV(trow, K0 + b - j) = T[a][b]; if (b > a) X[MCX_DLI(a, b) * 64 + lane] = T[a][b]; }
-                        }
-                        X[(28 + a) * 64 + lane] = rinv;
-                    } else {
-#pragma unroll
-                        for (int a2 = 0; a2 < a; ++a2) {
-                            const double dl = X[MCX_DLI(a2, a) * 64 + lane];
-#pragma unroll
-                            for (int b = 0; b < BT; ++b) T[a][b] = dfma(dl, T[a2][b], T[a][b]);
-                        }
-                        const double rinv = X[(28 + a) * 64 + lane];
-#pragma unroll
-                        for (int b = 0; b < BT; ++b) {
-                            T[a][b] = (av[b] - T[a][b]) * rinv;
-                            if (b < nc) GV(trow, K0 + b - j) = T[a][b];
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (act && info == 0) {
-        double sq = sqrt((double)d);
-        map_vec(Rt, Tt, lane, P, [&](double v) { return v * 2.4 / sq; });
-    }
-    return info;
-}
-#undef MCX_DLI
-
-// dpotri('U') on a packed upper factor, in place: dtrti2('U','N') then dlauu2('U') (MCMC_adapt.F90:217-224).
-// On exit A holds the upper triangle of inv(R'R).  X (LDS) carries one column above the diagonal.
-// X += temp * column(k) over the rows r < n, four rows at a time: the column's loads and X's go out together, then the four
-// independent fmas (each element's own chain is unchanged) -- the plain loop is a load-fma-store round trip per row, because
-// the compiler must assume the vector and the matrix overlap
-MCX_DEV void potri_axpy_col(double *X, const double *At, int lane, int d, int n, int k, double temp)
-{
-    // eight rows per trip, the last trip's spare slots re-read row n - 1 and are dropped: a trip is one cache round trip, and dpotri is
-    // ~1700 of them in a row at npar 20 (round 4; four rows per trip plus an element-by-element tail before)
-    constexpr int NB = 8;
-    for (int r = 0; r < n; r += NB) {
-        double a[NB], x[NB];
-#pragma unroll
-        for (int u = 0; u < NB; ++u) { const int ru = (r + u < n) ? r + u : n - 1; a[u] = GV(At, pidx(ru, k, d)); x[u] = XL(ru); }
-#pragma unroll
-        for (int u = 0; u < NB; ++u) if (r + u < n) XL(r + u) = dfma(temp, a[u], x[u]);
-    }
-}
-MCX_DEV int potri_packed(double *At, int lane, int d, bool act, double *X)
-{
-    int info = 0;
-    for (int j = 0; j < d; ++j) if (act && info == 0 && GV(At, pidx(j, j, d)) == 0.0) info = j + 1;
-    const bool go = act && info == 0;
-    if (__any(go)) {
-        if (go) {
-            for (int j = 0; j < d; ++j) {                    // dtrti2
-                double ajj = 1.0 / GV(At, pidx(j, j, d));
-                GV(At, pidx(j, j, d)) = ajj;
-                ajj = -ajj;
-                for (int i0 = 0; i0 < j; i0 += 8) {             // (eight loads in flight: element by element every one is a cache round trip)
-                    double v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = GV(At, pidx((i0 + u < j) ? i0 + u : j - 1, j, d));
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) if (i0 + u < j) XL(i0 + u) = v[u];
-                }
-                for (int j0 = 0; j0 < j; j0 += 8) {          // dtrmv('U','N','N') with the inverted leading block
-                    double dg[8];                            // (its diagonal: eight loads in flight)
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) dg[u] = GV(At, pidx((j0 + u < j) ? j0 + u : j - 1, (j0 + u < j) ? j0 + u : j - 1, d));
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int jj = j0 + u;
-                        if (jj < j) {
-                            double temp = XL(jj);
-                            if (temp != 0.0) {
-                                potri_axpy_col(X, At, lane, d, jj, jj, temp);
-                                XL(jj) = temp * dg[u];
-                            }
-                        }
-                    }
-                }
-                for (int i = 0; i < j; ++i) GV(At, pidx(i, j, d)) = ajj * XL(i);
-            }
-            for (int i = 0; i < d; ++i) {                    // dlauu2
-                double *rowi = At + (size_t)rowstart(i, d) * 64;
-                double aii = GV(rowi, 0);
-                if (i < d - 1) {
-                    double dot = 0.0;
-                    for (int k0 = 0; k0 < d - i; k0 += 8) {
-                        double v[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) v[u] = GV(rowi, (k0 + u < d - i) ? k0 + u : d - i - 1);
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) if (k0 + u < d - i) dot = dfma(v[u], v[u], dot);
-                    }
-                    GV(rowi, 0) = dot;
-                    for (int r0 = 0; r0 < i; r0 += 8) {
-                        double v[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) v[u] = GV(At, pidx((r0 + u < i) ? r0 + u : i - 1, i, d));
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) if (r0 + u < i) XL(r0 + u) = aii * v[u];
-                    }
-                    for (int k0 = i + 1; k0 < d; k0 += 8) {
-                        double tv[8];                        // (row i's elements: eight loads in flight)
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) tv[u] = GV(rowi, ((k0 + u < d) ? k0 + u : d - 1) - i);
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int k = k0 + u;
-                            if (k < d && tv[u] != 0.0) potri_axpy_col(X, At, lane, d, i, k, tv[u]);
-                        }
-                    }
-                    for (int r = 0; r < i; ++r) GV(At, pidx(r, i, d)) = XL(r);
-                } else {
-                    for (int r = 0; r <= i; ++r) GV(At, pidx(r, i, d)) = aii * GV(At, pidx(r, i, d));
-                }
-            }
-        }
-    }
-    return info;
-}
-
-// covmat (matutils.F90:232-341) over the nr rows listed in `rows` (ring slot | weight << 32; slot 0xffffffff =
-// the window's base row in basetheta) for one chain per lane.  update && wsum > 0: weighted Welford, one row
-// at a time (:283-310); otherwise the two-pass batch branch (:311-338), which overwrites cmat, mean and wsum.
-MCX_DEV void covmat_rows(const EngineDev &E, int tile, int lane, const uint64_t *rows, int nr, bool act, bool update,
-                         double *Ct, double *mean_t, const double *base_t, double *m2_t, double &wsum, double *X)
-{
-    const int d = E.d, P = E.P;
-    int nrmax = act ? nr : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { int other = __shfl_xor(nrmax, o); nrmax = other > nrmax ? other : nrmax; }
-    const double *hist_t = E.hist + (size_t)tile * E.wcap * (size_t)E.hs * 64;
-    const bool upd = act && update && (wsum > 0.0);
-    const bool bat = act && !upd;
-    if (__any(upd)) {
-        for (int r = 0; r < nrmax; ++r) {
-            const bool on = upd && r < nr;
-            uint64_t e = on ? GV(rows, r) : 0ull;
-            uint32_t slot = (uint32_t)e; double w3 = (double)(uint32_t)(e >> 32);
-            if (on) {
-                const bool isbase = (slot == 0xffffffffu);
-                const size_t so = isbase ? 0 : (size_t)slot * (size_t)E.hs * 64;
-                for (int k = 0; k < d; ++k) {
-                    double xv = isbase ? GV(base_t, k) : hist_t[so + (size_t)k * 64 + lane];
-                    XL(k) = xv - GV(mean_t, k);
-                }
-                double f1 = w3 / (wsum + w3 - 1.0);
-                double f2 = wsum / (wsum + w3);
-                for (int a = 0; a < d; ++a) {             // row a of the upper triangle: elements (a, b >= a)
-                    double da = XL(a);
-                    double *rowa = Ct + (size_t)rowstart(a, d) * 64;
-                    const int n = d - a;
-                    for (int k0 = 0; k0 < n; k0 += CH) {  // CH elements per batch: loads first, then the updates
-                        double cab[CH];
-#pragma unroll
-                        for (int u = 0; u < CH; ++u) cab[u] = GV(rowa, (k0 + u < n) ? k0 + u : n - 1);
-#pragma unroll
-                        for (int u = 0; u < CH; ++u) {
-                            if (k0 + u < n) {
-                                double o = da * XL(a + k0 + u);
-                                GV(rowa, k0 + u) = cab[u] + f1 * (f2 * o - cab[u]);
-                            }
-                        }
-                    }
-                }
-                double f3 = w3 / (wsum + w3);
-                for (int k = 0; k < d; ++k) GV(mean_t, k) = GV(mean_t, k) + f3 * XL(k);
-                wsum = w3 + wsum;
-            }
-        }
-    }
-    if (__any(bat)) {
-        double wsum2 = 0.0;
-        if (bat) {
-            for (int r = 0; r < nr; ++r) wsum2 = wsum2 + (double)(uint32_t)(GV(rows, r) >> 32);
-            for (int k = 0; k < d; ++k) GV(m2_t, k) = 0.0;
-        }
-        for (int r = 0; r < nrmax; ++r) {
-            const bool on = bat && r < nr;
-            uint64_t e = on ? GV(rows, r) : 0ull;
-            uint32_t slot = (uint32_t)e; double w = (double)(uint32_t)(e >> 32);
-            if (on) {
-                const bool isbase = (slot == 0xffffffffu);
-                const size_t so = isbase ? 0 : (size_t)slot * (size_t)E.hs * 64;
-                for (int k = 0; k < d; ++k) {
-                    double xv = isbase ? GV(base_t, k) : hist_t[so + (size_t)k * 64 + lane];
-                    GV(m2_t, k) = GV(m2_t, k) + xv * w;
-                }
-            }
-        }
-        if (bat) {
-            for (int k = 0; k < d; ++k) GV(m2_t, k) = GV(m2_t, k) / wsum2;          // xmean2
-            for (int e = 0; e < P; ++e) GV(Ct, e) = 0.0;
-        }
-        for (int r = 0; r < nrmax; ++r) {
-            const bool on = bat && r < nr;
-            uint64_t e = on ? GV(rows, r) : 0ull;
-            uint32_t slot = (uint32_t)e; double w = (double)(uint32_t)(e >> 32);
-            if (on) {
-                const bool isbase = (slot == 0xffffffffu);
-                const size_t so = isbase ? 0 : (size_t)slot * (size_t)E.hs * 64;
-                for (int k = 0; k < d; ++k) {
-                    double xv = isbase ? GV(base_t, k) : hist_t[so + (size_t)k * 64 + lane];
-                    XL(k) = xv - GV(m2_t, k);
-                }
-                // reference: cmat(i,j), j <= i = sum_r (x_ri - m_i) * ((x_rj - m_j) * w_r); kept at packed (j,i)
-                for (int j = 0; j < d; ++j) {
-                    double xb = XL(j) * w;
-                    double *rowj = Ct + (size_t)rowstart(j, d) * 64;
-                    const int n = d - j;
-                    for (int k0 = 0; k0 < n; k0 += CH) {
-                        double cji[CH];
-#pragma unroll
-                        for (int u = 0; u < CH; ++u) cji[u] = GV(rowj, (k0 + u < n) ? k0 + u : n - 1);
-#pragma unroll
-                        for (int u = 0; u < CH; ++u) if (k0 + u < n) GV(rowj, k0 + u) = cji[u] + XL(j + k0 + u) * xb;
-                    }
-                }
-            }
-        }
-        if (bat) {
-            map_vec(Ct, Ct, lane, P, [&](double v) { return v / (wsum2 - 1.0); });
-            copy_vec(mean_t, m2_t, nullptr, lane, d);
-            wsum = wsum2;
-        }
-    }
-}
-
-// The steady-state form of the same Welford update (matutils.F90:283-310), blocked: an 8x8 block of the
-// upper triangle of cmat stays in registers while the window's iterations t0..t1 stream by, so cmat is read
-// and written once per adaptation instead of once per accepted row.  Row r of the reference's
-// chain(lastind:chainind) is "the state between two set ballot bits"; its weight (the repeat count) is known
-// when the next accept arrives, which is when the row is folded in.  Every component's running mean obeys its
-// own recurrence, so recomputing delta = x - mean inside each block repeats the reference's operations exactly.
-//   have_base/count0/adj0 : the window's base row (basetheta), its count at window start, and the amount
-//                           (lastfreq) taken off the first folded weight          (AM: MCMC_adapt.F90:140-147)
-//   unit                  : every row has weight 1 and there is no base row       (greedy: MCMC_adapt.F90:91)
-MCX_DEV void covmat_window_blocked(const EngineDev &E, int tile, int lane, bool act, int t0lane, int t1, bool unit,
-                                   uint32_t count0, uint32_t adj0, double *Ct, const double *mean_t, const double *base_t,
-                                   double *mnew_t, double wsum, int a0, int b0, double &Wend)
-{
-    const int d = E.d;
-    int t0 = act ? t0lane : 0x7fffffff;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { int other = __shfl_xor(t0, o); t0 = other < t0 ? other : t0; }
-    if (t0 == 0x7fffffff) return;
-    const double *hist_t = E.hist + (size_t)tile * E.wcap * (size_t)E.hs * 64;
-    const unsigned long long *wacc_t = (const unsigned long long *)E.wacc + (size_t)tile * E.wcap;
-    Wend = wsum;
-    {
-        {
-            double C[8][8], ma[8], mb[8], xa[8], xb[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int a = (a0 + u < d) ? a0 + u : d - 1;
-                ma[u] = GV(mean_t, a);
-                const int b = (b0 + u < d) ? b0 + u : d - 1;
-                mb[u] = GV(mean_t, b);
-                xa[u] = unit ? 0.0 : GV(base_t, a);
-                xb[u] = unit ? 0.0 : GV(base_t, b);
-#pragma unroll
-                for (int v = 0; v < 8; ++v) {
-                    int bb = (b0 + v < d) ? b0 + v : d - 1;
-                    bb = bb < a ? a : bb;
-                    C[u][v] = GV(Ct, pidx(a, bb, d));
-                }
-            }
-            double W = wsum;
-            bool have = act && !unit;
-            uint32_t cnt = count0, adj = adj0;
-            // One Welford step for the lanes `on` (exec-masked: the other lanes' registers are left alone).  xa / xb turn
-            // into the deltas in place: an `on` lane's row has been consumed and is replaced right after.
-            auto fold = [&](bool on, double w3) {
-                if (on) {
-                    const double f1 = w3 / (W + w3 - 1.0), f2 = W / (W + w3), f3 = w3 / (W + w3);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) { xa[u] = xa[u] - ma[u]; xb[u] = xb[u] - mb[u]; }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-#pragma unroll
-                        for (int v = 0; v < 8; ++v) {
-                            double o = xa[u] * xb[v];
-                            C[u][v] = C[u][v] + f1 * (f2 * o - C[u][v]);
-                        }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) { ma[u] = ma[u] + f3 * xa[u]; mb[u] = mb[u] + f3 * xb[u]; }
-                    W = w3 + W;
-                }
-            };
-            // The accept ballots of 64 iterations at a time sit in one register per lane (one coalesced load) and are
-            // handed out by v_readlane: the loop's control flow never waits on a dependent global load.  The new row's
-            // loads go out BEFORE the fold of the row it replaces, so their latency hides behind that arithmetic.
-            for (int tc = t0; tc <= t1; tc += 64) {
-                const int tl = tc + lane;
-                const unsigned long long mine = (tl <= t1) ? wacc_t[tl % E.wcap] : 0ull;
-                const int nq = (t1 - tc + 1) < 64 ? (t1 - tc + 1) : 64;
-                for (int q = 0; q < nq; ++q) {
-                    const int t = tc + q, slot = t % E.wcap;
-                    const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), q) << 32)
-                                                 | (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mine, q);
-                    const bool inwin = act && (t >= t0lane);
-                    const bool acc = inwin && ((m >> lane) & 1ull);
-                    if (__any(acc)) {
-                        double xan[8], xbn[8];
-                        if (acc) {
-                            const size_t so = (size_t)slot * (size_t)E.hs * 64;
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) {
-                                const int a = (a0 + u < d) ? a0 + u : d - 1, b = (b0 + u < d) ? b0 + u : d - 1;
-                                xan[u] = hist_t[so + (size_t)a * 64 + lane];
-                                xbn[u] = hist_t[so + (size_t)b * 64 + lane];
-                            }
-                        }
-                        const bool fl = acc && have;
-                        if (__any(fl)) fold(fl, unit ? 1.0 : (double)(cnt - adj));
-                        if (acc) {
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) { xa[u] = xan[u]; xb[u] = xbn[u]; }
-                            if (have) adj = 0;
-                            have = true; cnt = 1;
-                        }
-                    }
-                    if (inwin && !acc) cnt += 1;
-                }
-            }
-            if (__any(have)) fold(have, unit ? 1.0 : (double)(cnt - adj));
-            // write the block back (upper triangle only) and, from the diagonal blocks, the means
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int a = a0 + u;
-#pragma unroll
-                for (int v = 0; v < 8; ++v) {
-                    const int b = b0 + v;
-                    if (act && a < d && b < d && b >= a) GV(Ct, pidx(a, b, d)) = C[u][v];
-                }
-                if (act && a0 == b0 && a < d) GV(mnew_t, a) = ma[u];     // the other blocks still need the old means
-            }
-            Wend = W;
-        }
-    }
-}
-
-// One MCMC_adapt tick is three launches.  adapt_pre_kernel (one wave per tile) runs the schedule's branch up to the
-// covariance update: burn-in scaling, the greedy / first-tick restarts, the list of window rows.  adapt_cov_kernel
-// runs the steady-state Welford update with ONE 8 x 8 block of chaincmat per wave: the nb(nb+1)/2 blocks of a tile
-// are separate workgroups that walk the same window of the history ring at about the same time, laid out over the
-// grid so that they land on the same XCD (workgroups go round-robin over the 8 XCDs) -- the window is fetched from HBM
-// once and served to the other blocks by that XCD's L2, where one wave per tile used to stream it from HBM once per
-// block.  adapt_post_kernel (one wave per tile) finishes: the one-off batch branches, the window restart and
-// MCMC_calculate_R.  Every element of chaincmat / chainmean sees the operations of the single-kernel form.
-enum { ADF_DOCALC = 1, ADF_GREEDY = 2, ADF_STEADY = 4,
-       ADF_BATCH = 8,       // the lane takes covmat's two-pass batch branch over the row list (first AM adaptation with initcmatn = 0, AP window,
-                            // greedy restart with initcmatn = 0); I_BSTART = the first iteration whose ballot belongs to the list
-       ADF_BNOINIT = 16 };  // ... and the list's first row is the one accepted AT I_BSTART (greedy: rows 1..it) instead of a row from before it
-
-__global__ __launch_bounds__(64) void adapt_pre_kernel(EngineDev E, int it, int mode)
-{
-    const int lane = threadIdx.x, tile = blockIdx.x, d = E.d, P = E.P;
-    double *Rt = E.R + (size_t)tile * P * 64;
-    double *Ct = E.cmat + (size_t)tile * P * 64;
-    double *mean_t = E.mean + (size_t)tile * d * 64;
-    uint64_t *rows = E.rowlist + (size_t)tile * (E.wcap + 1) * 64;
-    uint32_t stayed = TIDX(E.ictr, tile, NICTR, I_STAYED, lane);
-    uint32_t curcount = TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane);
-    uint32_t lastfreq = TIDX(E.ictr, tile, NICTR, I_LASTFREQ, lane);
-    uint32_t basecnt = TIDX(E.ictr, tile, NICTR, I_BASECNT, lane);
-    uint32_t winstart = TIDX(E.ictr, tile, NICTR, I_WINSTART, lane);
-    double wsum = TIDX(E.scal, tile, NSCAL, S_WSUM, lane);
-    uint32_t flags = 0, bstart = 0;
-    int nr = 0;
-
-    if (mode & AD_BURN) {                                             // MCMC_adapt.F90:60-102
-        double staypc = (double)stayed / (double)it;
-        double sf = E.scalefactor;
-        bool greedy_lane = false;
-        // the factor in use: packed Cholesky factor, or the full d x d SVD factor with condmax > 0
-        double *Ft = E.usesvd ? E.Rf + (size_t)tile * d * d * 64 : Rt;
-        double *F2t = !E.dodr ? nullptr : (E.usesvd ? E.R2f + (size_t)tile * d * d * 64 : E.R2 + (size_t)tile * P * 64);
-        const int nf = E.usesvd ? d * d : P;
-        if (staypc > 1.0 - E.scalelimit) {
-            map_vec(Ft, Ft, lane, nf, [&](double v) { return v / sf; });
-            if (E.dodr) {
-                double *iCt = E.iC + (size_t)tile * P * 64;
-                map_vec(F2t, F2t, lane, nf, [&](double v) { return v / sf; });
-                map_vec(iCt, iCt, lane, P, [&](double v) { return v * sf * sf; });
-            }
-        } else if (staypc < E.scalelimit) {
-            map_vec(Ft, Ft, lane, nf, [&](double v) { return v * sf; });
-            if (E.dodr) {
-                double *iCt = E.iC + (size_t)tile * P * 64;
-                map_vec(F2t, F2t, lane, nf, [&](double v) { return v * sf; });
-                map_vec(iCt, iCt, lane, P, [&](double v) { return v / sf / sf; });
-            }
-        } else {
-            flags |= ADF_DOCALC;
-            greedy_lane = (E.greedy != 0);
-        }
-        if (E.greedy != 0 && greedy_lane) {                           // :83-101 greedy: restart from cmat0 over chain(1:chainind), unit weights
-            flags |= ADF_GREEDY;
-            wsum = E.initcmatn;
-            for (int e = 0; e < P; ++e) GV(Ct, e) = E.cmat0p[e];
-            for (int k = 0; k < d; ++k) GV(mean_t, k) = E.par0[k];
-            if (wsum > 0.0) flags |= ADF_STEADY;
-            else {
-                for (int t = 1; t <= it; ++t) {                       // row list of the one-off batch branch
-                    const int slot = t % E.wcap;
-                    unsigned long long m = E.wacc[(size_t)tile * E.wcap + slot];
-                    if ((m >> lane) & 1ull) { GV(rows, nr) = (uint64_t)(uint32_t)slot | (1ull << 32); ++nr; }
-                }
-                flags |= ADF_BATCH | ADF_BNOINIT; bstart = 1u;
-            }
-        }
-    } else if (mode & AD_AM) {                                        // MCMC_adapt.F90:105-159
-        flags |= ADF_DOCALC;
-        if (mode & AD_FIRST) {
-            wsum = E.initcmatn;
-            for (int e = 0; e < P; ++e) GV(Ct, e) = E.cmat0p[e];
-            for (int k = 0; k < d; ++k) GV(mean_t, k) = E.par0[k];
-        }
-        if (E.adapthist > 1) {
-            // AP (:116-136): rows back from chainind until the repeat counts cover adapthist iterations; the oldest
-            // row's weight is cut so that the weights sum to adapthist; batch recompute (update = .false.)
-            int histsum = (int)curcount;
-            int nback = 0;
-            uint32_t w = curcount;
-            int tt = it - (int)curcount + 1;              // iteration at which the current row was accepted
-            GV(rows, 0) = (uint64_t)(uint32_t)(tt % E.wcap) | ((uint64_t)w << 32);
-            nback = 1;
-            while (histsum < E.adapthist && tt > 1) {
-                int t2 = tt - 1, cnt = 1;                 // previous row: accepted at the last set ballot before tt
-                while (t2 > 1 && !((E.wacc[(size_t)tile * E.wcap + (t2 % E.wcap)] >> lane) & 1ull)) { --t2; ++cnt; }
-                histsum += cnt;
-                GV(rows, nback) = (uint64_t)(uint32_t)(t2 % E.wcap) | ((uint64_t)(uint32_t)cnt << 32);
-                ++nback; tt = t2;
-            }
-            {                                             // oldest row's weight: newfreq - histsum + adapthist
-                uint64_t e = GV(rows, nback - 1);
-                int newfreq = (int)(uint32_t)(e >> 32);
-                int wadj = newfreq - histsum + E.adapthist;
-                GV(rows, nback - 1) = (e & 0xffffffffull) | ((uint64_t)(uint32_t)wadj << 32);
-            }
-            // reverse into chain order (oldest first)
-            for (int a = 0, b2 = nback - 1; a < b2; ++a, --b2) { uint64_t ta = GV(rows, a); GV(rows, a) = GV(rows, b2); GV(rows, b2) = ta; }
-            nr = nback;
-            flags |= ADF_BATCH; bstart = (uint32_t)(tt + 1);          // tt: the iteration at which the oldest listed row was accepted
-        } else if (wsum > 0.0) {
-            flags |= ADF_STEADY;                          // steady state (chainwsum > 0): blocked Welford straight from the ballots
-        } else {
-            // AM (:138-157), one-off batch branch: rows of chain(lastind:chainind) and their weights, from the accept ballots
-            uint32_t w = basecnt;                 // count of the base row when the window started
-            uint32_t slot_prev = 0xffffffffu;     // base row lives in basetheta
-            for (int t = (int)winstart; t <= it; ++t) {
-                const int slot = t % E.wcap;
-                unsigned long long m = E.wacc[(size_t)tile * E.wcap + slot];
-                if ((m >> lane) & 1ull) {
-                    uint32_t wr = (nr == 0) ? (w - lastfreq) : w;
-                    GV(rows, nr) = (uint64_t)slot_prev | ((uint64_t)wr << 32);
-                    ++nr; slot_prev = (uint32_t)slot; w = 1;
-                } else w += 1;
-            }
-            uint32_t wr = (nr == 0) ? (w - lastfreq) : w;
-            GV(rows, nr) = (uint64_t)slot_prev | ((uint64_t)wr << 32);
-            ++nr;
-            flags |= ADF_BATCH; bstart = winstart;                    // the list's first row is the window's base row
-        }
-    }
-    TIDX(E.ictr, tile, NICTR, I_BSTART, lane) = bstart;
-    TIDX(E.ictr, tile, NICTR, I_ADFLAGS, lane) = flags;
-    TIDX(E.ictr, tile, NICTR, I_NR, lane) = (uint32_t)nr;
-    TIDX(E.scal, tile, NSCAL, S_WSUM, lane) = wsum;
-    TIDX(E.scal, tile, NSCAL, S_WNEW, lane) = wsum;
-}
-
-// grid: 8 * ceil(ntiles / 8) * nblk workgroups of one wave; workgroup w runs on XCD w % 8, so
-// tile = (w / 8 / nblk) * 8 + w % 8, block = (w / 8) % nblk keeps a tile's blocks on one XCD and next to each other in time
-__global__ __launch_bounds__(64, 2) void adapt_cov_kernel(EngineDev E, int it, int mode, int nblk)
-{
-    const int lane = threadIdx.x, d = E.d, P = E.P;
-    const int w = blockIdx.x, j = w >> 3;
-    const int tile = (j / nblk) * 8 + (w & 7);
-    int blk = j % nblk;
-    if (tile >= E.ntiles) return;
-    const uint32_t flags = TIDX(E.ictr, tile, NICTR, I_ADFLAGS, lane);
-    const bool steady = (flags & ADF_STEADY) != 0;
-    if (!__any(steady)) return;
-    int a0 = 0, nb = (d + 7) / 8;
-    while (blk >= nb - a0) { blk -= nb - a0; ++a0; }                 // block rows a0 hold nb - a0 blocks
-    const int b0 = (a0 + blk) * 8;
-    a0 *= 8;
-    double *Ct = E.cmat + (size_t)tile * P * 64;
-    const double *mean_t = E.mean + (size_t)tile * d * 64;
-    const double *base_t = E.basetheta + (size_t)tile * d * 64;
-    double *mnew_t = E.cand + (size_t)tile * d * 64;
-    const bool unit = (mode & AD_BURN) != 0;                          // greedy restart: rows 1..it, unit weights, no base row
-    const uint32_t basecnt = TIDX(E.ictr, tile, NICTR, I_BASECNT, lane), lastfreq = TIDX(E.ictr, tile, NICTR, I_LASTFREQ, lane);
-    const int winstart = (int)TIDX(E.ictr, tile, NICTR, I_WINSTART, lane);
-    const double wsum = TIDX(E.scal, tile, NSCAL, S_WSUM, lane);
-    double Wend = wsum;
-    covmat_window_blocked(E, tile, lane, steady, unit ? 1 : winstart, it, unit, unit ? 0u : basecnt, unit ? 0u : lastfreq,
-                          Ct, mean_t, base_t, mnew_t, wsum, a0, b0, Wend);
-    if (a0 == 0 && b0 == 0 && steady) TIDX(E.scal, tile, NSCAL, S_WNEW, lane) = Wend;
-}
-
-// The same update in blocks of TD = 10 (the BASELINE dimensions 10, 20, 50 are whole numbers of them): a DIAGONAL block is
-// its upper triangle, 55 elements, an off-diagonal one 100 -- the 8 x 8 blocks above cover a 10 x 10 matrix with three waves
-// and 192 elements of which 55 are wanted, a 50 x 50 one with 28 waves and 1792 of which 1275 are; and fewer, larger blocks
-// repeat the per-fold overhead (the three divisions, the deltas, the row's loads) less often.  Operation for operation the
-// walk of covmat_window_blocked (deltas, o = delta_u delta_v, C += f1 (f2 o - C), means).  DIAG: launched with two waves per
-// SIMD; the off-diagonal form holds 100 accumulators and runs one wave per SIMD (its hundred independent chains keep the
-// VALU busy without a second wave).  Grid as for adapt_cov_kernel: workgroup w -> XCD w % 8, tile = (w / 8 / nblk) * 8 + w % 8.
-constexpr int TD = 10;
-template <bool DIAG>
-MCX_DEV void covmat_window_td(const EngineDev &E, int it, int mode, int nblk)
-{
-    const int lane = threadIdx.x, d = E.d, P = E.P;
-    const int w = blockIdx.x, j = w >> 3;
-    const int tile = (j / nblk) * 8 + (w & 7);
-    int blk = j % nblk;
-    if (tile >= E.ntiles) return;
-    const uint32_t flags = TIDX(E.ictr, tile, NICTR, I_ADFLAGS, lane);
-    const bool act = (flags & ADF_STEADY) != 0;
-    if (!__any(act)) return;
-    const int nb = (d + TD - 1) / TD;
-    int a0 = 0, b0 = 0;
-    if (DIAG) { a0 = b0 = blk * TD; }
-    else { int ar = 0; while (blk >= nb - 1 - ar) { blk -= nb - 1 - ar; ++ar; } a0 = ar * TD; b0 = (ar + 1 + blk) * TD; }   // block row ar holds nb - 1 - ar off-diagonal blocks
-    double *Ct = E.cmat + (size_t)tile * P * 64;
-    const double *mean_t = E.mean + (size_t)tile * d * 64;
-    const double *base_t = E.basetheta + (size_t)tile * d * 64;
-    double *mnew_t = E.cand + (size_t)tile * d * 64;
-    const bool unit = (mode & AD_BURN) != 0;                          // greedy restart: rows 1..it, unit weights, no base row
-    const uint32_t count0 = unit ? 0u : TIDX(E.ictr, tile, NICTR, I_BASECNT, lane), adj0 = unit ? 0u : TIDX(E.ictr, tile, NICTR, I_LASTFREQ, lane);
-    const int t0lane = unit ? 1 : (int)TIDX(E.ictr, tile, NICTR, I_WINSTART, lane), t1 = it;
-    const double wsum = TIDX(E.scal, tile, NSCAL, S_WSUM, lane);
-    int t0 = act ? t0lane : 0x7fffffff;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { int other = __shfl_xor(t0, o); t0 = other < t0 ? other : t0; }
-    if (t0 == 0x7fffffff) return;
-    const double *hist_t = E.hist + (size_t)tile * E.wcap * (size_t)E.hs * 64;
-    const unsigned long long *wacc_t = (const unsigned long long *)E.wacc + (size_t)tile * E.wcap;
-    constexpr int NBV = DIAG ? 1 : TD;                 // the b-side vectors exist for off-diagonal blocks only
-    double C[TD][TD], ma[TD], xa[TD], mb[NBV], xb[NBV];
-#pragma unroll
-    for (int u = 0; u < TD; ++u) {
-        const int a = (a0 + u < d) ? a0 + u : d - 1;
-        ma[u] = GV(mean_t, a);
-        xa[u] = unit ? 0.0 : GV(base_t, a);
-        if (!DIAG) { const int b = (b0 + u < d) ? b0 + u : d - 1; mb[u] = GV(mean_t, b); xb[u] = unit ? 0.0 : GV(base_t, b); }
-#pragma unroll
-        for (int v = (DIAG ? u : 0); v < TD; ++v) {
-            int bb = (b0 + v < d) ? b0 + v : d - 1;
-            bb = bb < a ? a : bb;
-            C[u][v] = GV(Ct, pidx(a, bb, d));
-        }
-    }
-    double W = wsum;
-    bool have = act && !unit;
-    uint32_t cnt = count0, adj = adj0;
-    auto fold = [&](bool on, double w3) {
-        if (on) {
-            const double f1 = w3 / (W + w3 - 1.0), f2 = W / (W + w3), f3 = w3 / (W + w3);
-#pragma unroll
-            for (int u = 0; u < TD; ++u) { xa[u] = xa[u] - ma[u]; if (!DIAG) xb[u] = xb[u] - mb[u]; }
-#pragma unroll
-            for (int u = 0; u < TD; ++u)
-#pragma unroll
-                for (int v = (DIAG ? u : 0); v < TD; ++v) {
-                    double o = xa[u] * (DIAG ? xa[v] : xb[v]);
-                    C[u][v] = C[u][v] + f1 * (f2 * o - C[u][v]);
-                }
-#pragma unroll
-            for (int u = 0; u < TD; ++u) { ma[u] = ma[u] + f3 * xa[u]; if (!DIAG) mb[u] = mb[u] + f3 * xb[u]; }
-            W = w3 + W;
-        }
-    };
-    for (int tc = t0; tc <= t1; tc += 64) {
-        const int tl = tc + lane;
-        const unsigned long long mine = (tl <= t1) ? wacc_t[tl % E.wcap] : 0ull;
-        const int nq = (t1 - tc + 1) < 64 ? (t1 - tc + 1) : 64;
-        for (int q = 0; q < nq; ++q) {
-            const int t = tc + q, slot = t % E.wcap;
-            const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), q) << 32)
-                                         | (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mine, q);
-            const bool inwin = act && (t >= t0lane);
-            const bool acc = inwin && ((m >> lane) & 1ull);
-            if (__any(acc)) {
-                double xan[TD], xbn[NBV];
-                if (acc) {
-                    const size_t so = (size_t)slot * (size_t)E.hs * 64;
-#pragma unroll
-                    for (int u = 0; u < TD; ++u) {
-                        xan[u] = hist_t[so + (size_t)((a0 + u < d) ? a0 + u : d - 1) * 64 + lane];
-                        if (!DIAG) xbn[u] = hist_t[so + (size_t)((b0 + u < d) ? b0 + u : d - 1) * 64 + lane];
-                    }
-                }
-                const bool fl = acc && have;
-                if (__any(fl)) fold(fl, unit ? 1.0 : (double)(cnt - adj));
-                if (acc) {
-#pragma unroll
-                    for (int u = 0; u < TD; ++u) { xa[u] = xan[u]; if (!DIAG) xb[u] = xbn[u]; }
-                    if (have) adj = 0;
-                    have = true; cnt = 1;
-                }
-            }
-            if (inwin && !acc) cnt += 1;
-        }
-    }
-    if (__any(have)) fold(have, unit ? 1.0 : (double)(cnt - adj));
-#pragma unroll
-    for (int u = 0; u < TD; ++u) {
-        const int a = a0 + u;
-#pragma unroll
-        for (int v = (DIAG ? u : 0); v < TD; ++v) { const int b = b0 + v; if (act && a < d && b < d) GV(Ct, pidx(a, b, d)) = C[u][v]; }
-        if (DIAG && act && a < d) GV(mnew_t, a) = ma[u];     // the other blocks still need the old means
-    }
-    if (DIAG && a0 == 0 && act) TIDX(E.scal, tile, NSCAL, S_WNEW, lane) = W;
-}
-// covmat's batch branch (matutils.F90:311-338: weighted mean first, then sum_r (x_ri - m_i) ((x_rj - m_j) w_r), divided by wsum - 1)
-// in the same blocks: the rows of the lane's list (adapt_pre_kernel: ring slot | weight << 32) are the states between set ballot
-// bits from I_BSTART on, so the block walks the window's iterations in lockstep like the steady form -- a row's loads are whole
-// 512-byte segments whichever lanes want them -- and takes each row's WEIGHT from the list when the next accept closes it.  Two
-// walks (means, then products); element for element the operations of covmat_rows' batch branch, which visits cmat once per ROW
-// (84 ms for the first adaptation of 131072 chains at npar = 50, and every adaptation of an AP run).
-template <bool DIAG>
-MCX_DEV void covmat_batch_td(const EngineDev &E, int it, int nblk)
-{
-    const int lane = threadIdx.x, d = E.d, P = E.P;
-    const int w = blockIdx.x, j = w >> 3;
-    const int tile = (j / nblk) * 8 + (w & 7);
-    int blk = j % nblk;
-    if (tile >= E.ntiles) return;
-    const uint32_t flags = TIDX(E.ictr, tile, NICTR, I_ADFLAGS, lane);
-    const bool act = (flags & ADF_BATCH) != 0, noinit = (flags & ADF_BNOINIT) != 0;
-    if (!__any(act)) return;
-    const int nb = (d + TD - 1) / TD;
-    int a0 = 0, b0 = 0;
-    if (DIAG) { a0 = b0 = blk * TD; }
-    else { int ar = 0; while (blk >= nb - 1 - ar) { blk -= nb - 1 - ar; ++ar; } a0 = ar * TD; b0 = (ar + 1 + blk) * TD; }
-    double *Ct = E.cmat + (size_t)tile * P * 64;
-    const double *base_t = E.basetheta + (size_t)tile * d * 64;
-    double *mnew_t = E.cand + (size_t)tile * d * 64;
-    const uint64_t *rows = E.rowlist + (size_t)tile * (E.wcap + 1) * 64;
-    const int t0lane = (int)TIDX(E.ictr, tile, NICTR, I_BSTART, lane), t1 = it;
-    int t0 = act ? t0lane : 0x7fffffff;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { int other = __shfl_xor(t0, o); t0 = other < t0 ? other : t0; }
-    const double *hist_t = E.hist + (size_t)tile * E.wcap * (size_t)E.hs * 64;
-    const unsigned long long *wacc_t = (const unsigned long long *)E.wacc + (size_t)tile * E.wcap;
-    constexpr int NBV = DIAG ? 1 : TD;
-    double C[TD][TD], ma[TD], xa[TD], mb[NBV], xb[NBV];
-    // one walk over the window: fold(on, weight) closes the row in xa / xb for the lanes `on`
-    auto walk = [&](auto &&fold) {
-        bool have = act && !noinit;
-        int idx = have ? 0 : -1;                          // the list entry of the open row
-        if (have) {                                       // the list's first row dates from before the window: the base row, or a ring slot of the lane's own
-            const uint32_t slot = (uint32_t)GV(rows, 0);
-            const bool isbase = (slot == 0xffffffffu);
-            const size_t so = isbase ? 0 : (size_t)slot * (size_t)E.hs * 64;
-#pragma unroll
-            for (int u = 0; u < TD; ++u) {
-                const int a = (a0 + u < d) ? a0 + u : d - 1;
-                xa[u] = isbase ? GV(base_t, a) : hist_t[so + (size_t)a * 64 + lane];
-                if (!DIAG) { const int b = (b0 + u < d) ? b0 + u : d - 1; xb[u] = isbase ? GV(base_t, b) : hist_t[so + (size_t)b * 64 + lane]; }
-            }
-        }
-        for (int tc = t0; tc <= t1; tc += 64) {
-            const int tl = tc + lane;
-            const unsigned long long mine = (tl <= t1) ? wacc_t[tl % E.wcap] : 0ull;
-            const int nq = (t1 - tc + 1) < 64 ? (t1 - tc + 1) : 64;
-            for (int q = 0; q < nq; ++q) {
-                const int t = tc + q, slot = t % E.wcap;
-                const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), q) << 32)
-                                             | (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mine, q);
-                const bool acc = act && (t >= t0lane) && ((m >> lane) & 1ull);
-                if (__any(acc)) {
-                    double xan[TD], xbn[NBV];
-                    if (acc) {
-                        const size_t so = (size_t)slot * (size_t)E.hs * 64;
-#pragma unroll
-                        for (int u = 0; u < TD; ++u) {
-                            xan[u] = hist_t[so + (size_t)((a0 + u < d) ? a0 + u : d - 1) * 64 + lane];
-                            if (!DIAG) xbn[u] = hist_t[so + (size_t)((b0 + u < d) ? b0 + u : d - 1) * 64 + lane];
-                        }
-                    }
-                    const bool fl = acc && have;
-                    if (__any(fl)) fold(fl, fl ? (double)(uint32_t)(GV(rows, idx) >> 32) : 0.0);
-                    if (acc) {
-#pragma unroll
-                        for (int u = 0; u < TD; ++u) { xa[u] = xan[u]; if (!DIAG) xb[u] = xbn[u]; }
-                        have = true; idx += 1;
-                    }
-                }
-            }
-        }
-        if (__any(have)) fold(have, have ? (double)(uint32_t)(GV(rows, idx) >> 32) : 0.0);
-    };
-    // ---- xmean2 = sum_r x_r w_r / sum_r w_r (rows in list order)
-    double wsum2 = 0.0;
-#pragma unroll
-    for (int u = 0; u < TD; ++u) { ma[u] = 0.0; if (!DIAG) mb[u] = 0.0; }
-    walk([&](bool on, double w3) {
-        if (on) {
-#pragma unroll
-            for (int u = 0; u < TD; ++u) { ma[u] = ma[u] + xa[u] * w3; if (!DIAG) mb[u] = mb[u] + xb[u] * w3; }
-            wsum2 = wsum2 + w3;
-        }
-    });
-#pragma unroll
-    for (int u = 0; u < TD; ++u) { ma[u] = ma[u] / wsum2; if (!DIAG) mb[u] = mb[u] / wsum2; }
-    // ---- cmat(j,k), j <= k: sum_r (x_rk - m_k) ((x_rj - m_j) w_r), then / (wsum - 1)
-#pragma unroll
-    for (int u = 0; u < TD; ++u)
-#pragma unroll
-        for (int v = 0; v < TD; ++v) C[u][v] = 0.0;
-    walk([&](bool on, double w3) {
-        if (on) {
-            double da[TD], db[NBV];
-#pragma unroll
-            for (int u = 0; u < TD; ++u) { da[u] = xa[u] - ma[u]; if (!DIAG) db[u] = xb[u] - mb[u]; }
-#pragma unroll
-            for (int u = 0; u < TD; ++u) {
-                const double xw = da[u] * w3;
-#pragma unroll
-                for (int v = (DIAG ? u : 0); v < TD; ++v) C[u][v] = C[u][v] + (DIAG ? da[v] : db[v]) * xw;
-            }
-        }
-    });
-#pragma unroll
-    for (int u = 0; u < TD; ++u) {
-        const int a = a0 + u;
-#pragma unroll
-        for (int v = (DIAG ? u : 0); v < TD; ++v) { const int b = b0 + v; if (act && a < d && b < d) GV(Ct, pidx(a, b, d)) = C[u][v] / (wsum2 - 1.0); }
-        if (DIAG && act && a < d) GV(mnew_t, a) = ma[u];
-    }
-    if (DIAG && a0 == 0 && act) TIDX(E.scal, tile, NSCAL, S_WNEW, lane) = wsum2;
-}
-__global__ __launch_bounds__(64, 2) void adapt_covb_diag_kernel(EngineDev E, int it, int nblk) { covmat_batch_td<true>(E, it, nblk); }
-__global__ __launch_bounds__(64, 1) void adapt_covb_off_kernel(EngineDev E, int it, int nblk) { covmat_batch_td<false>(E, it, nblk); }
-__global__ __launch_bounds__(64, 2) void adapt_cov_diag_kernel(EngineDev E, int it, int mode, int nblk) { covmat_window_td<true>(E, it, mode, nblk); }
-__global__ __launch_bounds__(64, 1) void adapt_cov_off_kernel(EngineDev E, int it, int mode, int nblk) { covmat_window_td<false>(E, it, mode, nblk); }
-
-// phase 0: the whole tick.  With the blocked SVD (large npar, below) the tick is cut around the factorisation:
-// phase 1 = everything up to and including the symmetric matrix in Gw (and the per-chain `need` flags),
-// phase 2 = everything after the SVD (which has left the singular vectors in Vw and the singular values in cs).
-// SVD: the instance with the SVD branches of MCMC_calculate_R (condmax > 0, scam); the Cholesky instance keeps to 256 registers
-// (two waves per SIMD: its sweeps wait on loads)
-#ifndef MCX_POST_WAVES
-#define MCX_POST_WAVES 2
-#endif
-// XG (npar > 320: one npar-vector per lane no longer fits a CU's LDS): the work vector in the tile's global scratch (EngineDev::xscr) -- a
-// compile-time choice, so that neither form uses flat accesses.  Slower; any npar.
-template <bool SVD, bool XG = false>
-__global__ __launch_bounds__(64, SVD ? 1 : MCX_POST_WAVES) void adapt_post_kernel(EngineDev E, int it, int mode, int phase, uint8_t *need, int batch_done)
-{
-    extern __shared__ double Xlds[];
-    const int lane = threadIdx.x, tile = blockIdx.x, d = E.d, P = E.P;
-    double *X = XG ? E.xscr + (size_t)tile * 2 * d * 64 : Xlds;
-    double *Rt = E.R + (size_t)tile * P * 64;
-    double *Ct = E.cmat + (size_t)tile * P * 64;
-    double *Tt = E.Rtmp + (size_t)tile * P * 64;
-    double *mean_t = E.mean + (size_t)tile * d * 64;
-    double *base_t = E.basetheta + (size_t)tile * d * 64;
-    double *theta_t = E.theta + (size_t)tile * d * 64;
-    double *m2_t = E.cand + (size_t)tile * d * 64;                 // the blocked update's new means; then scratch (xmean2 of the batch branch)
-    uint64_t *rows = E.rowlist + (size_t)tile * (E.wcap + 1) * 64;
-    uint32_t curcount = TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane);
-    uint32_t lastfreq = TIDX(E.ictr, tile, NICTR, I_LASTFREQ, lane);
-    uint32_t basecnt = TIDX(E.ictr, tile, NICTR, I_BASECNT, lane);
-    uint32_t winstart = TIDX(E.ictr, tile, NICTR, I_WINSTART, lane);
-    const uint32_t flags = TIDX(E.ictr, tile, NICTR, I_ADFLAGS, lane);
-    const int nr = (int)TIDX(E.ictr, tile, NICTR, I_NR, lane);
-    const bool docalc = (flags & ADF_DOCALC) != 0, greedy_lane = (flags & ADF_GREEDY) != 0;
-    // lanes whose covariance and mean the blocked kernels have already updated: the steady Welford form, and (batch_done: the
-    // host launched adapt_covb_*) the batch branch over the row list
-    const bool steady = (flags & ADF_STEADY) != 0 || (batch_done != 0 && (flags & ADF_BATCH) != 0);
-    double wsum = TIDX(E.scal, tile, NSCAL, (steady && phase != 2) ? S_WNEW : S_WSUM, lane);
-    if (phase != 2) {
-    if (steady) copy_vec(mean_t, m2_t, nullptr, lane, d);
-
-    if (mode & AD_BURN) {
-        if (E.greedy != 0) {
-            covmat_rows(E, tile, lane, rows, nr, greedy_lane && !steady, true, Ct, mean_t, base_t, m2_t, wsum, X);
-            if (greedy_lane) lastfreq = curcount;
-        }
-        if (docalc) {
-            // lastind = chainind: the covariance window restarts at the current row (lastfreq only touched by greedy)
-            copy_vec(base_t, theta_t, nullptr, lane, d);
-            basecnt = curcount; winstart = (uint32_t)(it + 1);
-        }
-    } else if (mode & AD_AM) {
-        if (E.adapthist > 1) {
-            covmat_rows(E, tile, lane, rows, nr, !steady, false, Ct, mean_t, base_t, m2_t, wsum, X);
-        } else {
-            covmat_rows(E, tile, lane, rows, nr, !steady, true, Ct, mean_t, base_t, m2_t, wsum, X);
-            // lastfreq = count of the current row; lastind = chainind -> window restarts here
-            lastfreq = curcount;
-            copy_vec(base_t, theta_t, nullptr, lane, d);
-            basecnt = curcount; winstart = (uint32_t)(it + 1);
-        }
-    }
-
-    TIDX(E.ictr, tile, NICTR, I_LASTFREQ, lane) = lastfreq;
-    TIDX(E.ictr, tile, NICTR, I_BASECNT, lane) = basecnt;
-    TIDX(E.ictr, tile, NICTR, I_WINSTART, lane) = winstart;
-    TIDX(E.scal, tile, NSCAL, S_WSUM, lane) = wsum;
-    }
-    if (SVD) {
-        // MCMC_calculate_R, SVD branches (MCMC_adapt.F90:189-209): covtor_svd / scam_svd (matutils.F90:378-453, 583-653)
-        double *Gt = E.Gw + (size_t)tile * d * d * 64, *Vt = E.Vw + (size_t)tile * d * d * 64;
-        double *Rft = E.Rf + (size_t)tile * d * d * 64;
-        double *sv_t = E.cs + (size_t)tile * 2 * d * 64;
-        if (phase == 1) need[tile * 64 + lane] = docalc ? 1 : 0;
-        if (__any(docalc)) {
-            if (phase != 2 && docalc) for (int j = 0; j < d; ++j) for (int i = 0; i < d; ++i)
-                GV(Gt, (size_t)j * d + i) = (i <= j) ? GV(Ct, pidx(i, j, d)) : GV(Ct, pidx(j, i, d));
-            if (phase == 1) return;
-            if (phase == 0) symsvd_dev(Gt, Vt, sv_t, lane, d, docalc);
-            if (docalc) {
-                int info = 0;
-                const double s0 = GV(sv_t, 0);
-                if (s0 == 0.0) { info = d; TIDX(E.ictr, tile, NICTR, I_STATUS, lane) |= ST_CHOL_FAIL; }
-                else {
-                    const double tol = s0 / E.condmax;
-                    bool floored = false;
-                    if (GV(sv_t, d - 1) <= tol) {
-                        floored = true;
-                        for (int i = 0; i < d; ++i) if (GV(sv_t, i) < tol) GV(sv_t, i) = tol;
-                    }
-                    if (E.doscam) {                                   // R = U, qcovstd = sqrt(s)
-                        copy_vec(Rft, Vt, nullptr, lane, d * d);
-                        double *std_t = E.qstd + (size_t)tile * d * 64;
-                        for (int i = 0; i < d; ++i) GV(std_t, i) = sqrt(GV(sv_t, i));
-                    } else {                                          // R0 = U diag(sqrt(s)); R = R0*2.4/sqrt(d)
-                        for (int i = 0; i < d; ++i) {
-                            const double sq = sqrt(GV(sv_t, i));
-                            for (int k = 0; k < d; ++k) GV(Vt, (size_t)i * d + k) = sq * GV(Vt, (size_t)i * d + k);
-                        }
-                        if (floored) {                                // cmat = matmul(R0, transpose(R0))
-                            for (int j = 0; j < d; ++j)
-                                for (int i = 0; i <= j; ++i) {
-                                    double acc = 0.0;
-                                    for (int k = 0; k < d; ++k) acc = dfma(GV(Vt, (size_t)k * d + i), GV(Vt, (size_t)k * d + j), acc);
-                                    GV(Ct, pidx(i, j, d)) = acc;
-                                }
-                        }
-                        const double sqd = sqrt((double)d);
-                        map_vec(Rft, Vt, lane, d * d, [&](double v) { return v * 2.4 / sqd; });
-                        if (E.dodr) {                                 // iC = dpotri('u', R): on R's upper triangle; R2 = R/drscale
-                            double *iCt = E.iC + (size_t)tile * P * 64, *R2ft = E.R2f + (size_t)tile * d * d * 64;
-                            for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) GV(iCt, pidx(i, j, d)) = GV(Rft, (size_t)j * d + i);
-                            int info2 = potri_packed(iCt, lane, d, true, X);
-                            if (info2 != 0) TIDX(E.ictr, tile, NICTR, I_STATUS, lane) |= ST_POTRI_FAIL;
-                            map_vec(R2ft, Rft, lane, d * d, [&](double v) { return v / E.drscale; });
-                        }
-                    }
-                }
-                TIDX(E.ictr, tile, NICTR, I_INFO, lane) = (uint32_t)info;
-            }
-        }
-    } else if (phase != 3 && __any(docalc)) {           // (phase 3: group_factor_kernel has the factorisation)
-        int info = calculate_R(Ct, Tt, Rt, lane, d, P, docalc, X);
-        if (docalc) {
-            TIDX(E.ictr, tile, NICTR, I_INFO, lane) = (uint32_t)info;
-            if (info != 0) TIDX(E.ictr, tile, NICTR, I_STATUS, lane) |= ST_CHOL_FAIL;   // warning, old R kept (:168-171)
-        }
-        if (E.dodr) {                                       // iC = dpotri(R), R2 = R/drscale (:216-225)
-            const bool ok = docalc && info == 0;
-            double *R2t = E.R2 + (size_t)tile * P * 64, *iCt = E.iC + (size_t)tile * P * 64;
-            if (ok) copy_vec(iCt, Rt, nullptr, lane, P);
-            int info2 = potri_packed(iCt, lane, d, ok, X);
-            if (ok && info2 != 0) TIDX(E.ictr, tile, NICTR, I_STATUS, lane) |= ST_POTRI_FAIL;  // the reference stops
-            if (ok) map_vec(R2t, Rt, lane, P, [&](double v) { return v / E.drscale; });
-        }
-    }
-}
-
-// ---------------------------------------------------------------- blocked one-sided Jacobi SVD, one workgroup per chain
-// The pinned routine (oracle/mcx_svd.h; symsvd_dev above runs it one lane per chain) streams four columns per pair from
-// HBM: 640 kB of G and V per chain at npar = 200, ~10-26 sweeps x 19900 pairs.  A pair (p,q) only touches columns p
-// and q, so any order of the pairs that keeps "(p,q) after (p,q-1) and after (p-1,q)" (and (p,p+1) after (p-1,p))
-// produces the same bits.  The kernels below use that freedom: column blocks of b, block pairs (I,J) in row-major
-// order with their 2b columns of G in LDS, and inside a block pair the pairs on one anti-diagonal p + q = const at a
-// time -- they are independent.  A step of svd_sweep_kernel: (A) the three dot products of each of the step's pairs
-// (sequential fma chains over the rows, exactly the routine's; one lane per chain, so a quad per pair) and its
-// rotation; (B) all 256 threads apply the step's rotations to the rows of G.  The rows cannot be spread over lanes in
-// (A) -- that would change the summation order -- which is why (A) dominates and why V is kept OUT of the sweep: V
-// never feeds back into the rotations, so the sweep only logs (c, s) per pair and svd_applyv_kernel replays the log
-// on V afterwards, row-parallel and barrier-free (a wave owns its rows).  Half the LDS per block = twice the pairs per
-// step.  One launch of each per sweep; the host stops when no chain rotated (mcx_api.hip: launch_adapt).
-// Storage is chain-major here (a chain's column = 8 d contiguous bytes); tile2chain_kernel / chain2tile_kernel
-// convert from and to the engine's tile-interleaved layout through LDS.
-MCX_DEV int svd_ls(int d) { return ((d + 1) & ~1) + (((d + 1) & 2) ? 0 : 2); }   // LDS column stride: even (16-byte accesses), = 2 mod 4 (16 lanes on 16 columns: 64 banks)
-MCX_DEV size_t svd_pair_index(int p, int q, int d) { return (size_t)p * d - (size_t)p * (p + 1) / 2 + (size_t)(q - p - 1); }
-
-// state[chain]: 0 = not part of this factorisation, 1 = sweeping, 2 = converged (its last sweep rotated nothing)
-__global__ __launch_bounds__(256) void svd_init_kernel(double *Vc, uint8_t *state, const uint8_t *need, int nlanes, int d)
-{
-    const int chain = blockIdx.x, tid = threadIdx.x;
-    if (chain >= nlanes) return;
-    if (tid == 0) state[chain] = need[chain] ? 1 : 0;
-    if (!need[chain]) return;
-    double *V = Vc + (size_t)chain * d * d;
-    for (int e = tid; e < d * d; e += 256) V[e] = (e % (d + 1) == 0) ? 1.0 : 0.0;
-}
-
-__global__ __launch_bounds__(256) void svd_sweep_kernel(double *Gc, mcx_d2 *rot, uint8_t *state, int *any_rotated, int nlanes, int d, int b)
-{
-    extern __shared__ double S[];
-    __shared__ int s_rot;
-    const int chain = blockIdx.x, tid = threadIdx.x;
-    if (chain >= nlanes || state[chain] != 1) return;
-    double *G = Gc + (size_t)chain * d * d;
-    mcx_d2 *log = rot + (size_t)chain * ((size_t)d * (d - 1) / 2);
-    const int LS = svd_ls(d);
-    double *GI = S, *GJ = GI + (size_t)b * LS;
-    double *slot_c = GJ + (size_t)b * LS, *slot_s = slot_c + 32;
-    int *slot_m = (int *)(slot_s + 32);                        // partner column of pair-lane l in this step, or -1
-    const int nb = (d + b - 1) / b;
-    // phase A: EIGHT lanes per pair (b <= 32 pairs: all four waves); lane j of an octet runs the three partial chains of
-    // the routine's dot products over the rows k = j, j + 8, ... -- alpha = sum g_p g_p, beta = sum g_q g_q, gamma = sum g_p g_q --
-    // and an xor-butterfly over the octet adds them in the routine's pairwise order (a + b = b + a bit for bit, so every
-    // lane ends up with the tree's value); the octet's lane 0 derives the rotation.
-    const int ol = tid >> 3, oj = tid & 7;                     // pair-lane of this thread's octet, partial chain
-    const int rl = tid & 31, rk0 = tid >> 5;                   // phase B: pair-lane rl, row pairs 2 rk0, 2 rk0 + 16, ...
-    if (tid == 0) s_rot = 0;
-    __syncthreads();
-    for (int I = 0; I < nb; ++I) {
-        const int I0 = I * b, wI = (d - I0) < b ? (d - I0) : b;
-        for (int e = tid; e < wI * d; e += 256) { const int c = e / d, k = e - c * d; GI[c * LS + k] = G[(size_t)(I0 + c) * d + k]; }
-        for (int J = I; J < nb; ++J) {
-            const int J0 = J * b, wJ = (d - J0) < b ? (d - J0) : b;
-            const bool diag = (J == I);
-            if (!diag)
-                for (int e = tid; e < wJ * d; e += 256) { const int c = e / d, k = e - c * d; GJ[c * LS + k] = G[(size_t)(J0 + c) * d + k]; }
-            __syncthreads();
-            double *Gq = diag ? GI : GJ;
-            const int nsteps = diag ? (2 * wI - 3) : (wI + wJ - 1);            // diag: pairs l < m at step l + m - 1
-            for (int t = 0; t < nsteps; ++t) {
-                // ---- (A) one pair per octet: alpha, beta, gamma and the rotation
-                {
-                    const int l = ol, m = diag ? (t + 1 - l) : (t - l);
-                    const bool valid = (l < wI) && (diag ? (m > l && m < wI) : (m >= 0 && m < wJ));
-                    double alpha = 0.0, beta = 0.0, gamma = 0.0;
-                    if (valid) {
-                        const double *x = GI + (size_t)l * LS, *y = Gq + (size_t)m * LS;
-                        // rows oj, oj + 8, ...: four rows' LDS reads in flight while the chains work through the previous four
-                        int k = oj;
-                        for (; k + 24 < d; k += 32) {
-                            const double x0 = x[k], y0 = y[k], x1 = x[k + 8], y1 = y[k + 8], x2 = x[k + 16], y2 = y[k + 16], x3 = x[k + 24], y3 = y[k + 24];
-                            alpha = dfma(x0, x0, alpha); beta = dfma(y0, y0, beta); gamma = dfma(x0, y0, gamma);
-                            alpha = dfma(x1, x1, alpha); beta = dfma(y1, y1, beta); gamma = dfma(x1, y1, gamma);
-                            alpha = dfma(x2, x2, alpha); beta = dfma(y2, y2, beta); gamma = dfma(x2, y2, gamma);
-                            alpha = dfma(x3, x3, alpha); beta = dfma(y3, y3, beta); gamma = dfma(x3, y3, gamma);
-                        }
-                        for (; k < d; k += 8) {
-                            const double x0 = x[k], y0 = y[k];
-                            alpha = dfma(x0, x0, alpha); beta = dfma(y0, y0, beta); gamma = dfma(x0, y0, gamma);
-                        }
-                    }
-#pragma unroll
-                    for (int o = 1; o < 8; o <<= 1) {
-                        alpha = alpha + __shfl_xor(alpha, o, 64); beta = beta + __shfl_xor(beta, o, 64); gamma = gamma + __shfl_xor(gamma, o, 64);
-                    }
-                    if (oj == 0 && l < b) {
-                        int mm = -1;
-                        if (valid) {
-                            mcx_d2 cs; cs.x = 1.0; cs.y = 0.0;                 // the identity: what svd_applyv_kernel skips
-                            if ((gamma != 0.0) && !(fabs(gamma) <= 1e-15 * sqrt(alpha * beta))) {
-                                const double zeta = (beta - alpha) / (2.0 * gamma);
-                                const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                                const double c = 1.0 / sqrt(1.0 + tt * tt);
-                                cs.x = c; cs.y = c * tt;
-                                slot_c[l] = cs.x; slot_s[l] = cs.y;
-                                mm = m;
-                                s_rot = 1;
-                            }
-                            log[svd_pair_index(I0 + l, (diag ? I0 : J0) + m, d)] = cs;
-                        }
-                        slot_m[l] = mm;
-                    }
-                }
-                __syncthreads();
-                // ---- (B) the step's rotations of G, rows spread over the threads (two adjacent rows per 16-byte access)
-                if (rl < wI) {
-                    const int m = slot_m[rl];
-                    if (m >= 0) {
-                        const double c = slot_c[rl], sn = slot_s[rl];
-                        double *gp = GI + (size_t)rl * LS, *gq = Gq + (size_t)m * LS;
-                        for (int k0 = 2 * rk0; k0 + 1 < d; k0 += 64) {
-                            mcx_d2 a[4], bq[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) { const int k = k0 + 16 * u; if (k + 1 < d) { a[u] = *(mcx_d2 *)(gp + k); bq[u] = *(mcx_d2 *)(gq + k); } }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const int k = k0 + 16 * u;
-                                if (k + 1 < d) {
-                                    mcx_d2 na, nb2;
-                                    na.x = c * a[u].x - sn * bq[u].x; na.y = c * a[u].y - sn * bq[u].y; nb2.x = sn * a[u].x + c * bq[u].x; nb2.y = sn * a[u].y + c * bq[u].y;
-                                    *(mcx_d2 *)(gp + k) = na; *(mcx_d2 *)(gq + k) = nb2;
-                                }
-                            }
-                        }
-                        if ((d & 1) && rk0 == 0) {                              // the odd last row
-                            const int k = d - 1;
-                            const double a0 = gp[k], b0 = gq[k];
-                            gp[k] = c * a0 - sn * b0; gq[k] = sn * a0 + c * b0;
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-            if (!diag)
-                for (int e = tid; e < wJ * d; e += 256) { const int c = e / d, k = e - c * d; G[(size_t)(J0 + c) * d + k] = GJ[c * LS + k]; }
-            __syncthreads();
-        }
-        for (int e = tid; e < wI * d; e += 256) { const int c = e / d, k = e - c * d; G[(size_t)(I0 + c) * d + k] = GI[c * LS + k]; }
-        __syncthreads();
-    }
-    if (tid == 0) { if (s_rot) *any_rotated = 1; else state[chain] = 2; }
-}
-
-// Replays one sweep's rotations on V, same block pairs, same steps.  Thread (rl, rk0) owns rows 2 rk0 + 16 i (+1) of the
-// columns it meets, and the 32 pair-lanes of one row group sit in ONE wave: within a wave the LDS accesses of consecutive
-// steps are ordered, so no barrier is needed between steps.  Chains whose sweep rotated nothing (state 2) are skipped.
-// The same sweep with the I block's columns in REGISTERS (round 4).  svd_sweep_kernel moves 9.6 kB through LDS per pair at npar = 200 --
-// phase A reads both columns for the three dot products, phase B reads and writes both for the rotation -- and that traffic, not the
-// arithmetic, is what a sweep takes (2 workgroups x 230 kB per step against 128 B per clock).  Inside a block pair (I,J) the pair-lane l
-// keeps the SAME column I0 + l for every step -- only its partner changes -- so the octet that owns pair-lane l holds that column in
-// registers (lane j of the octet: rows j, j + 8, ..., the routine's eight partial chains) from the end of the diagonal block to the end
-// of the J loop, and a step is ONE phase: read the partner column from LDS, the three chains, the butterfly, the rotation (all eight lanes
-// derive it: same operands), apply it, write the partner back.  3.2 kB of LDS traffic per pair, one barrier per step, one block of LDS
-// per workgroup instead of two.  In the diagonal block a column is first a partner (in LDS) and then, from the step at which its own
-// pairs start, the octet's own (loaded once).  Same pairs in the same order, same chains, same log: bit for bit svd_sweep_kernel's result.
-template <int RL>
-__global__ __launch_bounds__(256) void svd_sweep_reg_kernel(double *Gc, mcx_d2 *rot, uint8_t *state, int *any_rotated, int nlanes, int d, int b)
-{
-    extern __shared__ double S[];
-    __shared__ int s_rot;
-    const int chain = blockIdx.x, tid = threadIdx.x;
-    if (chain >= nlanes || state[chain] != 1) return;
-    double *G = Gc + (size_t)chain * d * d;
-    mcx_d2 *log = rot + (size_t)chain * ((size_t)d * (d - 1) / 2);
-    const int LS = svd_ls(d);
-    double *GY = S;                                            // the partner block: b columns
-    const int nb = (d + b - 1) / b;
-    const int ol = tid >> 3, oj = tid & 7;                     // pair-lane of this thread's octet, partial chain / row residue
-    if (tid == 0) s_rot = 0;
-    double xr[RL];
-    // one step of pair (l = ol, m): y from LDS column m of GY, x in registers
-    auto pair_step = [&](int m, size_t logidx) {
-        double *ycol = GY + (size_t)m * LS;
-        double yr[RL];
-#pragma unroll
-        for (int u = 0; u < RL; ++u) { const int k = oj + 8 * u; yr[u] = (k < d) ? ycol[k] : 0.0; }
-        double alpha = 0.0, beta = 0.0, gamma = 0.0;
-#pragma unroll
-        for (int u = 0; u < RL; ++u) {
-            if (oj + 8 * u < d) { alpha = dfma(xr[u], xr[u], alpha); beta = dfma(yr[u], yr[u], beta); gamma = dfma(xr[u], yr[u], gamma); }
-        }
-#pragma unroll
-        for (int o = 1; o < 8; o <<= 1) {
-            alpha = alpha + __shfl_xor(alpha, o, 64); beta = beta + __shfl_xor(beta, o, 64); gamma = gamma + __shfl_xor(gamma, o, 64);
-        }
-        mcx_d2 cs; cs.x = 1.0; cs.y = 0.0;                     // the identity: what svd_applyv_kernel skips
-        if ((gamma != 0.0) && !(fabs(gamma) <= 1e-15 * sqrt(alpha * beta))) {
-            const double zeta = (beta - alpha) / (2.0 * gamma);
-            const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-            const double c = 1.0 / sqrt(1.0 + tt * tt);
-            cs.x = c; cs.y = c * tt;
-            const double sn = cs.y;
-#pragma unroll
-            for (int u = 0; u < RL; ++u) {
-                const int k = oj + 8 * u;
-                if (k < d) { const double a0 = xr[u], b0 = yr[u]; xr[u] = c * a0 - sn * b0; ycol[k] = sn * a0 + c * b0; }
-            }
-            if (oj == 0) s_rot = 1;
-        }
-        if (oj == 0) log[logidx] = cs;
-    };
-    __syncthreads();
-    for (int I = 0; I < nb; ++I) {
-        const int I0 = I * b, wI = (d - I0) < b ? (d - I0) : b;
-        for (int e = tid; e < wI * d; e += 256) { const int c = e / d, k = e - c * d; GY[c * LS + k] = G[(size_t)(I0 + c) * d + k]; }
-        __syncthreads();
-        // ---- the diagonal block: pairs l < m at step l + m - 1; column l becomes its octet's own at its first pair (l, l + 1), step 2 l
-        for (int t = 0; t < 2 * wI - 3; ++t) {
-            const int l = ol, m = t + 1 - l;
-            if (l < wI && m > l && m < wI) {
-                if (m == l + 1) {
-#pragma unroll
-                    for (int u = 0; u < RL; ++u) { const int k = oj + 8 * u; xr[u] = (k < d) ? GY[(size_t)l * LS + k] : 0.0; }
-                }
-                pair_step(m, svd_pair_index(I0 + l, I0 + m, d));
-            }
-            __syncthreads();
-        }
-        // the block's last column never had a pair of its own (and with one column there were no steps at all): into registers now
-        if (ol == wI - 1) {
-#pragma unroll
-            for (int u = 0; u < RL; ++u) { const int k = oj + 8 * u; xr[u] = (k < d) ? GY[(size_t)ol * LS + k] : 0.0; }
-        }
-        __syncthreads();
-        // ---- the blocks to the right: pair (l, m) at step l + m
-        for (int J = I + 1; J < nb; ++J) {
-            const int J0 = J * b, wJ = (d - J0) < b ? (d - J0) : b;
-            for (int e = tid; e < wJ * d; e += 256) { const int c = e / d, k = e - c * d; GY[c * LS + k] = G[(size_t)(J0 + c) * d + k]; }
-            __syncthreads();
-            for (int t = 0; t < wI + wJ - 1; ++t) {
-                const int l = ol, m = t - l;
-                if (l < wI && m >= 0 && m < wJ) pair_step(m, svd_pair_index(I0 + l, J0 + m, d));
-                __syncthreads();
-            }
-            for (int e = tid; e < wJ * d; e += 256) { const int c = e / d, k = e - c * d; G[(size_t)(J0 + c) * d + k] = GY[c * LS + k]; }
-            __syncthreads();
-        }
-        if (ol < wI) {
-#pragma unroll
-            for (int u = 0; u < RL; ++u) { const int k = oj + 8 * u; if (k < d) G[(size_t)(I0 + ol) * d + k] = xr[u]; }
-        }
-        __syncthreads();
-    }
-    if (tid == 0) { if (s_rot) *any_rotated = 1; else state[chain] = 2; }
-}
-
-// ... and with every later column STREAMED past the I block (round 4).  In svd_sweep_reg_kernel a block pair (I,J) takes wI + wJ - 1
-// steps for wI wJ pairs: on average half of the pair-lanes have a partner.  The partners of column I0 + l are simply the columns
-// I0 + l + 1 .. npar - 1 in order: pair-lane l meets stream column j (= column I0 + 1 + j) at step l + j, j >= l -- one wavefront over the
-// whole rest of the matrix (the block's own columns are the stream's first wI - 1: pair-lane l takes column I0 + l out of the ring at step
-// 2 l - 1, after its last pair as a partner), every pair-lane busy from its first partner to its last.  Two pairs that share a column keep
-// their order, so do the bits.  A column is needed for wI consecutive steps: it enters a ring of wI + 2 LDS columns one step ahead and
-// leaves it for global memory the step after its last pair.  Each wave holds six octets and sixteen loader lanes: the loaders' global
-// loads (issued one step before they write the ring) and stores run under the wave's own pair arithmetic, and all four SIMDs compute.
-#ifndef MCX_SVDS_WAVES
-#define MCX_SVDS_WAVES 3                                     // waves per SIMD asked for up to npar 208 (RL 26)
-#endif
-#define MCX_SVDS_EPT 4                                       // elements of a column per loader lane: 64 loaders, npar <= 256
-template <int RL>
-__global__ __launch_bounds__(256, (RL <= 26 ? MCX_SVDS_WAVES : 2)) void svd_sweep_stream_kernel(double *Gc, mcx_d2 *rot, uint8_t *state, int *any_rotated, int nlanes, int d, int b)
-{
-    extern __shared__ double S[];
-    __shared__ int s_rot;
-    const int chain = blockIdx.x, tid = threadIdx.x;
-    if (chain >= nlanes || state[chain] != 1) return;
-    double *G = Gc + (size_t)chain * d * d;
-    mcx_d2 *log = rot + (size_t)chain * ((size_t)d * (d - 1) / 2);
-    constexpr int LS = 8 * RL + 2;                             // ring column stride: every octet row 8 u + oj exists (rows >= npar hold zeros: they add
-                                                               // nothing to the three sums and rotate to zero -- no bounds tests in the loop); = 2 mod 4
-    double *GY = S;                                            // the ring: RB columns
-    const int RB = b + 2;
-    const int nb = (d + b - 1) / b;
-    const int wv = tid >> 6, ln = tid & 63;
-    const bool loader = ln >= 48;
-    const int ol = loader ? 64 : wv * 6 + (ln >> 3), oj = ln & 7;   // pair-lane of this thread's octet, partial chain / row residue
-    const int li = wv * 16 + (ln - 48);                        // loader lanes: 0 .. 63
-    if (tid == 0) s_rot = 0;
-    double xr[RL];
-    double stg[MCX_SVDS_EPT];                                  // loaders: the column on its way from global memory to the ring
-    auto pair_step = [&](double *ycol, size_t logidx) __attribute__((always_inline)) {
-        double yr[RL];
-#pragma unroll
-        for (int u = 0; u < RL; ++u) yr[u] = ycol[oj + 8 * u];
-        double alpha = 0.0, beta = 0.0, gamma = 0.0;
-#pragma unroll
-        for (int u = 0; u < RL; ++u) { alpha = dfma(xr[u], xr[u], alpha); beta = dfma(yr[u], yr[u], beta); gamma = dfma(xr[u], yr[u], gamma); }
-#pragma unroll
-        for (int o = 1; o < 8; o <<= 1) {
-            alpha = alpha + __shfl_xor(alpha, o, 64); beta = beta + __shfl_xor(beta, o, 64); gamma = gamma + __shfl_xor(gamma, o, 64);
-        }
-        mcx_d2 cs; cs.x = 1.0; cs.y = 0.0;
-        if ((gamma != 0.0) && !(fabs(gamma) <= 1e-15 * sqrt(alpha * beta))) {
-            const double zeta = (beta - alpha) / (2.0 * gamma);
-            const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-            const double c = 1.0 / sqrt(1.0 + tt * tt);
-            cs.x = c; cs.y = c * tt;
-            const double sn = cs.y;
-#pragma unroll
-            for (int u = 0; u < RL; ++u) {
-                const double a0 = xr[u], b0 = yr[u];
-                xr[u] = c * a0 - sn * b0; ycol[oj + 8 * u] = sn * a0 + c * b0;
-            }
-            if (oj == 0) s_rot = 1;
-        }
-        if (oj == 0) log[logidx] = cs;
-    };
-    for (int e = tid; e < RB * LS; e += 256) GY[e] = 0.0;
-    __syncthreads();
-    for (int I = 0; I < nb; ++I) {
-        const int I0 = I * b, wI = (d - I0) < b ? (d - I0) : b;
-        const int nJ = d - I0 - 1;                             // stream columns: j = 0 .. nJ - 1 is column I0 + 1 + j
-        if (ol == 0) {
-#pragma unroll
-            for (int u = 0; u < RL; ++u) { const int k = oj + 8 * u; xr[u] = (k < d) ? G[(size_t)I0 * d + k] : 0.0; }
-        }
-        for (int e = tid; e < 2 * d; e += 256) {                // the ring's first two columns
-            const int c = e / d, k = e - c * d;
-            if (c < nJ) GY[(size_t)c * LS + k] = G[(size_t)(I0 + 1 + c) * d + k];
-        }
-        __syncthreads();
-        const int nsteps = nJ + wI;                            // (the last one only writes the last column back)
-        for (int t = 0; t < nsteps; ++t) {
-            if (loader) {
-                const int cw = t + 1;                          // ring <- stream column cw (its load was issued in the previous step)
-                if (cw >= 2 && cw < nJ) {
-                    double *dst = GY + (size_t)(cw % RB) * LS;
-#pragma unroll
-                    for (int u = 0; u < MCX_SVDS_EPT; ++u) { const int k = li + 64 * u; if (k < d) dst[k] = stg[u]; }
-                }
-                const int cg = t + 2;                          // issue the load of stream column cg
-                if (cg < nJ) {
-                    const double *src = G + (size_t)(I0 + 1 + cg) * d;
-#pragma unroll
-                    for (int u = 0; u < MCX_SVDS_EPT; ++u) { const int k = li + 64 * u; if (k < d) stg[u] = src[k]; }
-                }
-                const int cs = t - wI;                         // stream column cs had its last pair in the previous step
-                if (cs >= wI - 1 && cs < nJ) {
-                    const double *src = GY + (size_t)(cs % RB) * LS;
-                    double *dst = G + (size_t)(I0 + 1 + cs) * d;
-#pragma unroll
-                    for (int u = 0; u < MCX_SVDS_EPT; ++u) { const int k = li + 64 * u; if (k < d) dst[k] = src[k]; }
-                }
-            } else if (ol < wI) {
-                if (t == 2 * ol - 1) {                         // this pair-lane's own column: its last pair as a partner was in step 2 ol - 2
-                    const double *src = GY + (size_t)((ol - 1) % RB) * LS;
-#pragma unroll
-                    for (int u = 0; u < RL; ++u) xr[u] = src[oj + 8 * u];
-                }
-                const int jj = t - ol;
-                if (jj >= ol && jj < nJ) pair_step(GY + (size_t)(jj % RB) * LS, svd_pair_index(I0 + ol, I0 + 1 + jj, d));
-            }
-            __syncthreads();
-        }
-        if (ol < wI) {
-#pragma unroll
-            for (int u = 0; u < RL; ++u) { const int k = oj + 8 * u; if (k < d) G[(size_t)(I0 + ol) * d + k] = xr[u]; }
-        }
-        __syncthreads();
-    }
-    if (tid == 0) { if (s_rot) *any_rotated = 1; else state[chain] = 2; }
-}
-
-// svd_sweep_stream_kernel with ALL lanes on pairs (npar <= 200): 32 pair-lanes, and every thread carries one element of the column
-// entering the ring and of the one leaving it, so no lane is set aside for loading.  The ring is 33 columns of 8 RL + 2 <= 202 doubles
-// (a leaving column hands its slot to the entering one element by element inside one thread): 53 kB, three workgroups per CU as before.
-// 921 steps per sweep at npar 200 instead of 1134, 64 live lanes per wave instead of 48.
-template <int RL>
-__global__ __launch_bounds__(256, MCX_SVDS_WAVES) void svd_sweep_stream32_kernel(double *Gc, mcx_d2 *rot, uint8_t *state, int *any_rotated, int nlanes, int d)
-{
-    extern __shared__ double S[];
-    __shared__ int s_rot;
-    const int chain = blockIdx.x, tid = threadIdx.x;
-    if (chain >= nlanes || state[chain] != 1) return;
-    double *G = Gc + (size_t)chain * d * d;
-    mcx_d2 *log = rot + (size_t)chain * ((size_t)d * (d - 1) / 2);
-    constexpr int LS = 8 * RL + 2;                             // ring column stride: every octet row 8 u + oj exists (rows >= npar hold zeros: they add
-                                                               // nothing to the three sums and rotate to zero -- no bounds tests in the loop); = 2 mod 4
-    double *GY = S;                                            // the ring: RB columns
-    constexpr int b = 32, RB = b + 1;
-    const int nb = (d + b - 1) / b;
-    const int ol = tid >> 3, oj = tid & 7;                     // pair-lane of this thread's octet, partial chain / row residue
-    const bool ld = tid < d;                                   // ... and every thread moves element `tid` of the columns on their way in and out
-    if (tid == 0) s_rot = 0;
-    double xr[RL];
-    double stg = 0.0;                                          // the element on its way from global memory to the ring
-    auto pair_step = [&](double *ycol, size_t logidx) __attribute__((always_inline)) {
-        double yr[RL];
-#pragma unroll
-        for (int u = 0; u < RL; ++u) yr[u] = ycol[oj + 8 * u];
-        double alpha = 0.0, beta = 0.0, gamma = 0.0;
-#pragma unroll
-        for (int u = 0; u < RL; ++u) { alpha = dfma(xr[u], xr[u], alpha); beta = dfma(yr[u], yr[u], beta); gamma = dfma(xr[u], yr[u], gamma); }
-#pragma unroll
-        for (int o = 1; o < 8; o <<= 1) {
-            alpha = alpha + __shfl_xor(alpha, o, 64); beta = beta + __shfl_xor(beta, o, 64); gamma = gamma + __shfl_xor(gamma, o, 64);
-        }
-        mcx_d2 cs; cs.x = 1.0; cs.y = 0.0;
-        if ((gamma != 0.0) && !(fabs(gamma) <= 1e-15 * sqrt(alpha * beta))) {
-            const double zeta = (beta - alpha) / (2.0 * gamma);
-            const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-            const double c = 1.0 / sqrt(1.0 + tt * tt);
-            cs.x = c; cs.y = c * tt;
-            const double sn = cs.y;
-#pragma unroll
-            for (int u = 0; u < RL; ++u) {
-                const double a0 = xr[u], b0 = yr[u];
-                xr[u] = c * a0 - sn * b0; ycol[oj + 8 * u] = sn * a0 + c * b0;
-            }
-            if (oj == 0) s_rot = 1;
-        }
-        if (oj == 0) log[logidx] = cs;
-    };
-    for (int e = tid; e < RB * LS; e += 256) GY[e] = 0.0;
-    __syncthreads();
-    for (int I = 0; I < nb; ++I) {
-        const int I0 = I * b, wI = (d - I0) < b ? (d - I0) : b;
-        const int nJ = d - I0 - 1;                             // stream columns: j = 0 .. nJ - 1 is column I0 + 1 + j
-        if (ol == 0) {
-#pragma unroll
-            for (int u = 0; u < RL; ++u) { const int k = oj + 8 * u; xr[u] = (k < d) ? G[(size_t)I0 * d + k] : 0.0; }
-        }
-        for (int e = tid; e < 2 * d; e += 256) {                // the ring's first two columns
-            const int c = e / d, k = e - c * d;
-            if (c < nJ) GY[(size_t)c * LS + k] = G[(size_t)(I0 + 1 + c) * d + k];
-        }
-        __syncthreads();
-        const int nsteps = nJ + wI;                            // (the last one only writes the last column back)
-        for (int t = 0; t < nsteps; ++t) {
-            {
-                // ring slot (t + 1) mod RB changes hands: stream column t - wI (its last pair was in the previous step) leaves it for global
-                // memory and column t + 1 (loaded in the previous step) enters -- element by element in the same thread, so RB = wI + 1 will do
-                const int cs = t - wI, cw = t + 1, cg = t + 2;
-                if (ld && cs >= wI - 1 && cs < nJ) G[(size_t)(I0 + 1 + cs) * d + tid] = GY[(size_t)(cs % RB) * LS + tid];
-                if (ld && cw >= 2 && cw < nJ) GY[(size_t)(cw % RB) * LS + tid] = stg;
-                if (ld && cg < nJ) stg = G[(size_t)(I0 + 1 + cg) * d + tid];
-            }
-            if (ol < wI) {
-                if (t == 2 * ol - 1) {                         // this pair-lane's own column: its last pair as a partner was in step 2 ol - 2
-                    const double *src = GY + (size_t)((ol - 1) % RB) * LS;
-#pragma unroll
-                    for (int u = 0; u < RL; ++u) xr[u] = src[oj + 8 * u];
-                }
-                const int jj = t - ol;
-                if (jj >= ol && jj < nJ) pair_step(GY + (size_t)(jj % RB) * LS, svd_pair_index(I0 + ol, I0 + 1 + jj, d));
-            }
-            __syncthreads();
-        }
-        if (ol < wI) {
-#pragma unroll
-            for (int u = 0; u < RL; ++u) { const int k = oj + 8 * u; if (k < d) G[(size_t)(I0 + ol) * d + k] = xr[u]; }
-        }
-        __syncthreads();
-    }
-    if (tid == 0) { if (s_rot) *any_rotated = 1; else state[chain] = 2; }
-}
-
-// svd_sweep_stream32_kernel with the rotations worked out ONCE per pair.  An octet's eight lanes hold eight partial chains of the three sums and, in
-// the kernel above, all eight then run the same scalar tail -- the threshold's square root, zeta's division, the two square roots and the two
-// divisions of t and c: six quarter-rate sequences, about half of a step's instructions -- four waves doing it for eight pairs each.  Here the
-// octets leave (alpha, beta, gamma) in LDS, the first 32 lanes of wave 0 take one pair each, and everybody picks up (c, s) and a flag: the same
-// operations on the same numbers, a quarter of the issue slots for the tail; two more workgroup barriers per step, which three workgroups per CU
-// cover.  MEASURED NEGATIVE (round 5, the verdict's item 7): one adaptation of 16384 chains at npar 200 takes 0.688 s against 0.525 s with the kernel
-// above -- a step is bound by the LATENCY of the tail's five dependent divide / square-root sequences (pinned), which this form lengthens by two
-// barriers, not by its issue slots.  Kept selectable (MCMCX_SVD_SHARED_ROT=1) beside the other forms of the parity test; never the engine's choice.
-template <int RL>
-__global__ __launch_bounds__(256, MCX_SVDS_WAVES) void svd_sweep_stream32s_kernel(double *Gc, mcx_d2 *rot, uint8_t *state, int *any_rotated, int nlanes, int d)
-{
-    extern __shared__ double S[];
-    __shared__ int s_rot;
-    __shared__ double s_abg[3 * 32];
-    __shared__ mcx_d2 s_cs[32];
-    __shared__ int s_on[32];
-    const int chain = blockIdx.x, tid = threadIdx.x;
-    if (chain >= nlanes || state[chain] != 1) return;
-    double *G = Gc + (size_t)chain * d * d;
-    mcx_d2 *log = rot + (size_t)chain * ((size_t)d * (d - 1) / 2);
-    constexpr int LS = 8 * RL + 2;
-    double *GY = S;
-    constexpr int b = 32, RB = b + 1;
-    const int nb = (d + b - 1) / b;
-    const int ol = tid >> 3, oj = tid & 7;
-    const bool ld = tid < d;
-    if (tid == 0) s_rot = 0;
-    double xr[RL], yr[RL];
-    double stg = 0.0;
-    for (int e = tid; e < RB * LS; e += 256) GY[e] = 0.0;
-    __syncthreads();
-    for (int I = 0; I < nb; ++I) {
-        const int I0 = I * b, wI = (d - I0) < b ? (d - I0) : b;
-        const int nJ = d - I0 - 1;
-        if (ol == 0) {
-#pragma unroll
-            for (int u = 0; u < RL; ++u) { const int k = oj + 8 * u; xr[u] = (k < d) ? G[(size_t)I0 * d + k] : 0.0; }
-        }
-        for (int e = tid; e < 2 * d; e += 256) {
-            const int c = e / d, k = e - c * d;
-            if (c < nJ) GY[(size_t)c * LS + k] = G[(size_t)(I0 + 1 + c) * d + k];
-        }
-        __syncthreads();
-        const int nsteps = nJ + wI;
-        for (int t = 0; t < nsteps; ++t) {
-            {
-                const int cs = t - wI, cw = t + 1, cg = t + 2;
-                if (ld && cs >= wI - 1 && cs < nJ) G[(size_t)(I0 + 1 + cs) * d + tid] = GY[(size_t)(cs % RB) * LS + tid];
-                if (ld && cw >= 2 && cw < nJ) GY[(size_t)(cw % RB) * LS + tid] = stg;
-                if (ld && cg < nJ) stg = G[(size_t)(I0 + 1 + cg) * d + tid];
-            }
-            if (ol < wI && t == 2 * ol - 1) {
-                const double *src = GY + (size_t)((ol - 1) % RB) * LS;
-#pragma unroll
-                for (int u = 0; u < RL; ++u) xr[u] = src[oj + 8 * u];
-            }
-            const int jj = t - ol;
-            const bool pa = ol < wI && jj >= ol && jj < nJ;                  // this octet has a pair in this step
-            double *ycol = GY + (size_t)((pa ? jj : 0) % RB) * LS;
-            if (pa) {
-#pragma unroll
-                for (int u = 0; u < RL; ++u) yr[u] = ycol[oj + 8 * u];
-                double alpha = 0.0, beta = 0.0, gamma = 0.0;
-#pragma unroll
-                for (int u = 0; u < RL; ++u) { alpha = dfma(xr[u], xr[u], alpha); beta = dfma(yr[u], yr[u], beta); gamma = dfma(xr[u], yr[u], gamma); }
-#pragma unroll
-                for (int o = 1; o < 8; o <<= 1) {
-                    alpha = alpha + __shfl_xor(alpha, o, 64); beta = beta + __shfl_xor(beta, o, 64); gamma = gamma + __shfl_xor(gamma, o, 64);
-                }
-                if (oj == 0) { s_abg[3 * ol] = alpha; s_abg[3 * ol + 1] = beta; s_abg[3 * ol + 2] = gamma; }
-            }
-            __syncthreads();
-            if (tid < 32) {                                                 // pair-lane tid's rotation (or none)
-                const int jq = t - tid;
-                if (tid < wI && jq >= tid && jq < nJ) {
-                    const double alpha = s_abg[3 * tid], beta = s_abg[3 * tid + 1], gamma = s_abg[3 * tid + 2];
-                    mcx_d2 cs; cs.x = 1.0; cs.y = 0.0;
-                    int on = 0;
-                    if ((gamma != 0.0) && !(fabs(gamma) <= 1e-15 * sqrt(alpha * beta))) {
-                        const double zeta = (beta - alpha) / (2.0 * gamma);
-                        const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                        const double c = 1.0 / sqrt(1.0 + tt * tt);
-                        cs.x = c; cs.y = c * tt;
-                        on = 1; s_rot = 1;
-                    }
-                    s_cs[tid] = cs; s_on[tid] = on;
-                    log[svd_pair_index(I0 + tid, I0 + 1 + jq, d)] = cs;
-                }
-            }
-            __syncthreads();
-            if (pa && s_on[ol]) {
-                const mcx_d2 cs = s_cs[ol];
-                const double c = cs.x, sn = cs.y;
-#pragma unroll
-                for (int u = 0; u < RL; ++u) {
-                    const double a0 = xr[u], b0 = yr[u];
-                    xr[u] = c * a0 - sn * b0; ycol[oj + 8 * u] = sn * a0 + c * b0;
-                }
-            }
-            __syncthreads();
-        }
-        if (ol < wI) {
-#pragma unroll
-            for (int u = 0; u < RL; ++u) { const int k = oj + 8 * u; if (k < d) G[(size_t)(I0 + ol) * d + k] = xr[u]; }
-        }
-        __syncthreads();
-    }
-    if (tid == 0) { if (s_rot) *any_rotated = 1; else state[chain] = 2; }
-}
-
-__global__ __launch_bounds__(256) void svd_applyv_kernel(double *Vc, const mcx_d2 *rot, const uint8_t *state, int nlanes, int d, int b)
-{
-    extern __shared__ double S[];
-    const int chain = blockIdx.x, tid = threadIdx.x;
-    if (chain >= nlanes || state[chain] != 1) return;
-    double *V = Vc + (size_t)chain * d * d;
-    const mcx_d2 *log = rot + (size_t)chain * ((size_t)d * (d - 1) / 2);
-    const int LS = svd_ls(d);
-    double *VI = S, *VJ = VI + (size_t)b * LS;
-    const int nb = (d + b - 1) / b;
-    const int rl = tid & 31, rk0 = tid >> 5;
-    for (int I = 0; I < nb; ++I) {
-        const int I0 = I * b, wI = (d - I0) < b ? (d - I0) : b;
-        for (int e = tid; e < wI * d; e += 256) { const int c = e / d, k = e - c * d; VI[c * LS + k] = V[(size_t)(I0 + c) * d + k]; }
-        for (int J = I; J < nb; ++J) {
-            const int J0 = J * b, wJ = (d - J0) < b ? (d - J0) : b;
-            const bool diag = (J == I);
-            if (!diag)
-                for (int e = tid; e < wJ * d; e += 256) { const int c = e / d, k = e - c * d; VJ[c * LS + k] = V[(size_t)(J0 + c) * d + k]; }
-            __syncthreads();
-            double *Vq = diag ? VI : VJ;
-            const int nsteps = diag ? (2 * wI - 3) : (wI + wJ - 1);
-            if (rl < wI)
-                for (int t = 0; t < nsteps; ++t) {
-                    // step t reads what other lanes of THIS wave wrote in step t - 1: keep the compiler from moving LDS
-                    // accesses across the step boundary (the hardware runs a wave's LDS operations in order)
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    const int m = diag ? (t + 1 - rl) : (t - rl);
-                    const bool valid = diag ? (m > rl && m < wI) : (m >= 0 && m < wJ);
-                    if (!valid) continue;
-                    const mcx_d2 cs = log[svd_pair_index(I0 + rl, (diag ? I0 : J0) + m, d)];
-                    if (cs.x == 1.0 && cs.y == 0.0) continue;
-                    const double c = cs.x, sn = cs.y;
-                    double *vp = VI + (size_t)rl * LS, *vq = Vq + (size_t)m * LS;
-                    for (int k0 = 2 * rk0; k0 + 1 < d; k0 += 64) {
-                        mcx_d2 va[4], vb[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) { const int k = k0 + 16 * u; if (k + 1 < d) { va[u] = *(mcx_d2 *)(vp + k); vb[u] = *(mcx_d2 *)(vq + k); } }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int k = k0 + 16 * u;
-                            if (k + 1 < d) {
-                                mcx_d2 nva, nvb;
-                                nva.x = c * va[u].x - sn * vb[u].x; nva.y = c * va[u].y - sn * vb[u].y; nvb.x = sn * va[u].x + c * vb[u].x; nvb.y = sn * va[u].y + c * vb[u].y;
-                                *(mcx_d2 *)(vp + k) = nva; *(mcx_d2 *)(vq + k) = nvb;
-                            }
-                        }
-                    }
-                    if ((d & 1) && rk0 == 0) {
-                        const int k = d - 1;
-                        const double va0 = vp[k], vb0 = vq[k];
-                        vp[k] = c * va0 - sn * vb0; vq[k] = sn * va0 + c * vb0;
-                    }
-                }
-            __syncthreads();
-            if (!diag)
-                for (int e = tid; e < wJ * d; e += 256) { const int c = e / d, k = e - c * d; V[(size_t)(J0 + c) * d + k] = VJ[c * LS + k]; }
-            __syncthreads();
-        }
-        for (int e = tid; e < wI * d; e += 256) { const int c = e / d, k = e - c * d; V[(size_t)(I0 + c) * d + k] = VI[c * LS + k]; }
-        __syncthreads();
-    }
-}
-
-// svd_applyv_kernel with the I block's columns of V in registers (round 4, like svd_sweep_reg_kernel): thread (rl, rk0) keeps its rows
-// (2 rk0, 2 rk0 + 1) + 16 u of column I0 + rl for the whole row of block pairs; only the partner column goes through LDS.  Same rotations
-// in the same order on the same elements.
-template <int RP>         // row PAIRS per thread: 16 RP >= npar
-__global__ __launch_bounds__(256) void svd_applyv_reg_kernel(double *Vc, const mcx_d2 *rot, const uint8_t *state, int nlanes, int d, int b)
-{
-    extern __shared__ double S[];
-    const int chain = blockIdx.x, tid = threadIdx.x;
-    if (chain >= nlanes || state[chain] != 1) return;
-    double *V = Vc + (size_t)chain * d * d;
-    const mcx_d2 *log = rot + (size_t)chain * ((size_t)d * (d - 1) / 2);
-    const int LS = svd_ls(d);
-    double *VY = S;                                            // the partner block: b columns
-    const int nb = (d + b - 1) / b;
-    const int rl = tid & 31, rk0 = tid >> 5;
-    mcx_d2 vr[RP];                                             // rows k = 2 rk0 + 16 u, k + 1 (the odd last row: .x only, by rk0 = 0's extra slot below)
-    double vlast = 0.0;                                        // row d - 1 when d is odd (thread rk0 = 0)
-    auto load_own = [&](const double *col) {
-#pragma unroll
-        for (int u = 0; u < RP; ++u) { const int k = 2 * rk0 + 16 * u; if (k + 1 < d) vr[u] = *(const mcx_d2 *)(col + k); }
-        if ((d & 1) && rk0 == 0) vlast = col[d - 1];
-    };
-    auto pair_step = [&](int m, size_t logidx) {
-        const mcx_d2 cs = log[logidx];
-        if (cs.x == 1.0 && cs.y == 0.0) return;
-        const double c = cs.x, sn = cs.y;
-        double *vq = VY + (size_t)m * LS;
-        mcx_d2 vb[RP];
-#pragma unroll
-        for (int u = 0; u < RP; ++u) { const int k = 2 * rk0 + 16 * u; if (k + 1 < d) vb[u] = *(mcx_d2 *)(vq + k); }
-#pragma unroll
-        for (int u = 0; u < RP; ++u) {
-            const int k = 2 * rk0 + 16 * u;
-            if (k + 1 < d) {
-                mcx_d2 nva, nvb;
-                nva.x = c * vr[u].x - sn * vb[u].x; nva.y = c * vr[u].y - sn * vb[u].y; nvb.x = sn * vr[u].x + c * vb[u].x; nvb.y = sn * vr[u].y + c * vb[u].y;
-                vr[u] = nva; *(mcx_d2 *)(vq + k) = nvb;
-            }
-        }
-        if ((d & 1) && rk0 == 0) {
-            const int k = d - 1;
-            const double va0 = vlast, vb0 = vq[k];
-            vlast = c * va0 - sn * vb0; vq[k] = sn * va0 + c * vb0;
-        }
-    };
-    for (int I = 0; I < nb; ++I) {
-        const int I0 = I * b, wI = (d - I0) < b ? (d - I0) : b;
-        for (int e = tid; e < wI * d; e += 256) { const int c = e / d, k = e - c * d; VY[c * LS + k] = V[(size_t)(I0 + c) * d + k]; }
-        __syncthreads();
-        // the diagonal block: column rl becomes the thread's own at its first pair (rl, rl + 1), step 2 rl (before that it is a partner, in LDS)
-        if (rl < wI)
-            for (int t = 0; t < 2 * wI - 3; ++t) {
-                // step t reads what other lanes of THIS wave wrote in step t - 1: keep the compiler from moving LDS accesses across the
-                // step boundary (the hardware runs a wave's LDS operations in order; the rows of a thread group never leave its wave)
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const int m = t + 1 - rl;
-                if (!(m > rl && m < wI)) continue;
-                if (m == rl + 1) load_own(VY + (size_t)rl * LS);
-                pair_step(m, svd_pair_index(I0 + rl, I0 + m, d));
-            }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (rl == wI - 1) load_own(VY + (size_t)rl * LS);      // the block's last column never had a pair of its own
-        __syncthreads();
-        for (int J = I + 1; J < nb; ++J) {
-            const int J0 = J * b, wJ = (d - J0) < b ? (d - J0) : b;
-            for (int e = tid; e < wJ * d; e += 256) { const int c = e / d, k = e - c * d; VY[c * LS + k] = V[(size_t)(J0 + c) * d + k]; }
-            __syncthreads();
-            if (rl < wI)
-                for (int t = 0; t < wI + wJ - 1; ++t) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    const int m = t - rl;
-                    if (!(m >= 0 && m < wJ)) continue;
-                    pair_step(m, svd_pair_index(I0 + rl, J0 + m, d));
-                }
-            __syncthreads();
-            for (int e = tid; e < wJ * d; e += 256) { const int c = e / d, k = e - c * d; V[(size_t)(J0 + c) * d + k] = VY[c * LS + k]; }
-            __syncthreads();
-        }
-        if (rl < wI) {
-            double *col = V + (size_t)(I0 + rl) * d;
-#pragma unroll
-            for (int u = 0; u < RP; ++u) { const int k = 2 * rk0 + 16 * u; if (k + 1 < d) *(mcx_d2 *)(col + k) = vr[u]; }
-            if ((d & 1) && rk0 == 0) col[d - 1] = vlast;
-        }
-        __syncthreads();
-    }
-}
-
-// svd_applyv_reg_kernel with V's later columns streamed past the I block like svd_sweep_stream_kernel's: the rotations of a sweep touch
-// the rows of V independently, so each of a chain's four waves (two row groups of 32 lanes: 24 pair-lanes and 8 loader lanes each) is a
-// workgroup of its own, with a ring of b + 2 columns of ITS rows in LDS, and never waits for the others.  A pair-lane reads the next step's
-// (c, s) from the log one step ahead.  blockIdx: the four waves of a chain on one XCD (they read the same log).
-template <int RP>         // row PAIRS per thread: 16 RP >= npar
-__global__ __launch_bounds__(64) void svd_applyv_stream_kernel(double *Vc, const mcx_d2 *rot, const uint8_t *state, int nlanes, int d, int b)
-{
-    extern __shared__ double S[];
-    const int blk = blockIdx.x;
-    const int chain = (blk >> 5) * 8 + (blk & 7), wv = (blk >> 3) & 3;
-    if (chain >= nlanes || state[chain] != 1) return;
-    double *V = Vc + (size_t)chain * d * d;
-    const mcx_d2 *log = rot + (size_t)chain * ((size_t)d * (d - 1) / 2);
-    constexpr int RGS = 2 * RP + 2, SLOT = 4 * RP + 6;          // doubles per row group (its odd last row at 2 RP) and per ring column (SLOT / 2 odd: 16 lanes on 16 columns, 64 banks)
-    const int RB = b + 2;
-    const int nb = (d + b - 1) / b;
-    const int ln = threadIdx.x, rg = ln >> 5, rl = ln & 31, rk0 = 2 * wv + rg;
-    const bool loader = rl >= 24;
-    const int q = rl - 24;
-    const bool oddrow = (d & 1) && rk0 == 0;                    // row d - 1 of an odd npar: row group 0's extra element
-    double *ring = S + rg * RGS;
-    mcx_d2 vr[RP];
-    double vlast = 0.0;
-    double stg[4], stgl = 0.0;                                  // loaders: row pairs u = q, q + 8 of the column on its way to the ring (+ the odd row: lane q = 7)
-    auto g_load = [&](const double *col) __attribute__((always_inline)) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) { const int u = q + 8 * h, k = 2 * rk0 + 16 * u; if (u < RP && k + 1 < d) { stg[2 * h] = col[k]; stg[2 * h + 1] = col[k + 1]; } }
-        if (oddrow && q == 7) stgl = col[d - 1];
-    };
-    auto r_write = [&](double *slot) __attribute__((always_inline)) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) { const int u = q + 8 * h, k = 2 * rk0 + 16 * u; if (u < RP && k + 1 < d) { mcx_d2 v; v.x = stg[2 * h]; v.y = stg[2 * h + 1]; *(mcx_d2 *)(slot + 2 * u) = v; } }
-        if (oddrow && q == 7) slot[2 * RP] = stgl;
-    };
-    auto r_store = [&](const double *slot, double *col) __attribute__((always_inline)) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) { const int u = q + 8 * h, k = 2 * rk0 + 16 * u; if (u < RP && k + 1 < d) { const mcx_d2 v = *(const mcx_d2 *)(slot + 2 * u); col[k] = v.x; col[k + 1] = v.y; } }
-        if (oddrow && q == 7) col[d - 1] = slot[2 * RP];
-    };
-    auto pair_step = [&](double *vq, const mcx_d2 cs) __attribute__((always_inline)) {
-        if (cs.x == 1.0 && cs.y == 0.0) return;
-        const double c = cs.x, sn = cs.y;
-        mcx_d2 vb[RP];
-#pragma unroll
-        for (int u = 0; u < RP; ++u) vb[u] = *(mcx_d2 *)(vq + 2 * u);   // (row pairs beyond npar: zeros in the ring and in vr, they stay zero)
-#pragma unroll
-        for (int u = 0; u < RP; ++u) {
-            mcx_d2 nva, nvb;
-            nva.x = c * vr[u].x - sn * vb[u].x; nva.y = c * vr[u].y - sn * vb[u].y; nvb.x = sn * vr[u].x + c * vb[u].x; nvb.y = sn * vr[u].y + c * vb[u].y;
-            vr[u] = nva; *(mcx_d2 *)(vq + 2 * u) = nvb;
-        }
-        if (oddrow) { const double va0 = vlast, vb0 = vq[2 * RP]; vlast = c * va0 - sn * vb0; vq[2 * RP] = sn * va0 + c * vb0; }
-    };
-    for (int e = ln; e < RB * SLOT; e += 64) S[e] = 0.0;
-    __syncthreads();
-    for (int I = 0; I < nb; ++I) {
-        const int I0 = I * b, wI = (d - I0) < b ? (d - I0) : b;
-        const int nJ = d - I0 - 1;
-        if (rl == 0) {                                          // the block's first column: straight into registers
-            const double *col = V + (size_t)I0 * d;
-#pragma unroll
-            for (int u = 0; u < RP; ++u) { const int k = 2 * rk0 + 16 * u; vr[u].x = 0.0; vr[u].y = 0.0; if (k + 1 < d) { vr[u].x = col[k]; vr[u].y = col[k + 1]; } }
-            if (oddrow) vlast = col[d - 1];
-        }
-        if (loader)
-            for (int c = 0; c < 2 && c < nJ; ++c) { g_load(V + (size_t)(I0 + 1 + c) * d); r_write(ring + (size_t)c * SLOT); }
-        const size_t base = svd_pair_index(I0 + rl, I0 + 1 + rl, d);   // log entry of this pair-lane's first pair (step 2 rl), the next ones follow it
-        mcx_d2 nxt; nxt.x = 1.0; nxt.y = 0.0;
-        if (rl == 0 && nJ > 0) nxt = log[base];
-        const int nsteps = nJ + wI;
-        for (int t = 0; t < nsteps; ++t) {
-            // a step reads what other lanes of THIS wave wrote in the previous one: keep the compiler from moving LDS accesses across the
-            // step boundary (the hardware runs a wave's LDS operations in order)
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (loader) {
-                const int cw = t + 1;
-                if (cw >= 2 && cw < nJ) r_write(ring + (size_t)(cw % RB) * SLOT);
-                const int cg = t + 2;
-                if (cg < nJ) g_load(V + (size_t)(I0 + 1 + cg) * d);
-                const int cs = t - wI;
-                if (cs >= wI - 1 && cs < nJ) r_store(ring + (size_t)(cs % RB) * SLOT, V + (size_t)(I0 + 1 + cs) * d);
-            } else if (rl < wI) {
-                const mcx_d2 cur = nxt;
-                const int jn = t + 1 - rl;                      // the next step's partner
-                if (jn >= rl && jn < nJ) nxt = log[base + (size_t)(jn - rl)];
-                if (t == 2 * rl - 1) {
-                    const double *src = ring + (size_t)((rl - 1) % RB) * SLOT;
-#pragma unroll
-                    for (int u = 0; u < RP; ++u) vr[u] = *(const mcx_d2 *)(src + 2 * u);
-                    if (oddrow) vlast = src[2 * RP];
-                }
-                const int jj = t - rl;
-                if (jj >= rl && jj < nJ) pair_step(ring + (size_t)(jj % RB) * SLOT, cur);
-            }
-        }
-        if (rl < wI) {
-            double *col = V + (size_t)(I0 + rl) * d;
-#pragma unroll
-            for (int u = 0; u < RP; ++u) { const int k = 2 * rk0 + 16 * u; if (k + 1 < d) { col[k] = vr[u].x; col[k + 1] = vr[u].y; } }
-            if (oddrow) col[d - 1] = vlast;
-        }
-        __syncthreads();                                       // (one wave: the next block row's loads follow these stores)
-    }
-}
-
-// svd_applyv_stream_kernel with all 32 lanes of a row group on pairs (like svd_sweep_stream32_kernel; any npar): lane rl < RP also
-// carries row pair rl of the column entering the ring and of the one leaving it; 33 slots.
-template <int RP>         // row PAIRS per thread: 16 RP >= npar
-__global__ __launch_bounds__(64) void svd_applyv_stream32_kernel(double *Vc, const mcx_d2 *rot, const uint8_t *state, int nlanes, int d)
-{
-    extern __shared__ double S[];
-    const int blk = blockIdx.x;
-    const int chain = (blk >> 5) * 8 + (blk & 7), wv = (blk >> 3) & 3;
-    if (chain >= nlanes || state[chain] != 1) return;
-    double *V = Vc + (size_t)chain * d * d;
-    const mcx_d2 *log = rot + (size_t)chain * ((size_t)d * (d - 1) / 2);
-    constexpr int RGS = 2 * RP + 2, SLOT = 4 * RP + 6;          // doubles per row group (its odd last row at 2 RP) and per ring column (SLOT / 2 odd: 16 lanes on 16 columns, 64 banks)
-    constexpr int b = 32, RB = b + 1;
-    const int nb = (d + b - 1) / b;
-    const int ln = threadIdx.x, rg = ln >> 5, rl = ln & 31, rk0 = 2 * wv + rg;
-    const int lu = rl;                                         // ... and row pair `rl` (rl < RP) of the columns on their way in and out
-    const int lk_ = 2 * rk0 + 16 * lu;
-    const bool ld = lu < RP && lk_ + 1 < d;
-    const bool oddrow = (d & 1) && rk0 == 0;                    // row d - 1 of an odd npar: row group 0's extra element
-    double *ring = S + rg * RGS;
-    mcx_d2 vr[RP];
-    double vlast = 0.0;
-    double stg[2] = {0.0, 0.0}, stgl = 0.0;                     // the row pair on its way to the ring (+ the odd row: lane rl = RP)
-    auto g_load = [&](const double *col) __attribute__((always_inline)) {
-        if (ld) { stg[0] = col[lk_]; stg[1] = col[lk_ + 1]; }
-        if (oddrow && lu == RP) stgl = col[d - 1];
-    };
-    auto r_write = [&](double *slot) __attribute__((always_inline)) {
-        if (ld) { mcx_d2 v2; v2.x = stg[0]; v2.y = stg[1]; *(mcx_d2 *)(slot + 2 * lu) = v2; }
-        if (oddrow && lu == RP) slot[2 * RP] = stgl;
-    };
-    auto r_store = [&](const double *slot, double *col) __attribute__((always_inline)) {
-        if (ld) { const mcx_d2 v2 = *(const mcx_d2 *)(slot + 2 * lu); col[lk_] = v2.x; col[lk_ + 1] = v2.y; }
-        if (oddrow && lu == RP) col[d - 1] = slot[2 * RP];
-    };
-    auto pair_step = [&](double *vq, const mcx_d2 cs) __attribute__((always_inline)) {
-        if (cs.x == 1.0 && cs.y == 0.0) return;
-        const double c = cs.x, sn = cs.y;
-        mcx_d2 vb[RP];
-#pragma unroll
-        for (int u = 0; u < RP; ++u) vb[u] = *(mcx_d2 *)(vq + 2 * u);   // (row pairs beyond npar: zeros in the ring and in vr, they stay zero)
-#pragma unroll
-        for (int u = 0; u < RP; ++u) {
-            mcx_d2 nva, nvb;
-            nva.x = c * vr[u].x - sn * vb[u].x; nva.y = c * vr[u].y - sn * vb[u].y; nvb.x = sn * vr[u].x + c * vb[u].x; nvb.y = sn * vr[u].y + c * vb[u].y;
-            vr[u] = nva; *(mcx_d2 *)(vq + 2 * u) = nvb;
-        }
-        if (oddrow) { const double va0 = vlast, vb0 = vq[2 * RP]; vlast = c * va0 - sn * vb0; vq[2 * RP] = sn * va0 + c * vb0; }
-    };
-    for (int e = ln; e < RB * SLOT; e += 64) S[e] = 0.0;
-    __syncthreads();
-    for (int I = 0; I < nb; ++I) {
-        const int I0 = I * b, wI = (d - I0) < b ? (d - I0) : b;
-        const int nJ = d - I0 - 1;
-        if (rl == 0) {                                          // the block's first column: straight into registers
-            const double *col = V + (size_t)I0 * d;
-#pragma unroll
-            for (int u = 0; u < RP; ++u) { const int k = 2 * rk0 + 16 * u; vr[u].x = 0.0; vr[u].y = 0.0; if (k + 1 < d) { vr[u].x = col[k]; vr[u].y = col[k + 1]; } }
-            if (oddrow) vlast = col[d - 1];
-        }
-        for (int c = 0; c < 2 && c < nJ; ++c) { g_load(V + (size_t)(I0 + 1 + c) * d); r_write(ring + (size_t)c * SLOT); }
-        const size_t base = svd_pair_index(I0 + rl, I0 + 1 + rl, d);   // log entry of this pair-lane's first pair (step 2 rl), the next ones follow it
-        mcx_d2 nxt; nxt.x = 1.0; nxt.y = 0.0;
-        if (rl == 0 && nJ > 0) nxt = log[base];
-        const int nsteps = nJ + wI;
-        for (int t = 0; t < nsteps; ++t) {
-            // a step reads what other lanes of THIS wave wrote in the previous one: keep the compiler from moving LDS accesses across the
-            // step boundary (the hardware runs a wave's LDS operations in order)
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            {
-                // slot (t + 1) mod RB changes hands, element by element in the lane that moves it: column t - wI out, column t + 1 in
-                const int cs = t - wI, cw = t + 1, cg = t + 2;
-                if (cs >= wI - 1 && cs < nJ) r_store(ring + (size_t)(cs % RB) * SLOT, V + (size_t)(I0 + 1 + cs) * d);
-                if (cw >= 2 && cw < nJ) r_write(ring + (size_t)(cw % RB) * SLOT);
-                if (cg < nJ) g_load(V + (size_t)(I0 + 1 + cg) * d);
-            }
-            if (rl < wI) {
-                const mcx_d2 cur = nxt;
-                const int jn = t + 1 - rl;                      // the next step's partner
-                if (jn >= rl && jn < nJ) nxt = log[base + (size_t)(jn - rl)];
-                if (t == 2 * rl - 1) {
-                    const double *src = ring + (size_t)((rl - 1) % RB) * SLOT;
-#pragma unroll
-                    for (int u = 0; u < RP; ++u) vr[u] = *(const mcx_d2 *)(src + 2 * u);
-                    if (oddrow) vlast = src[2 * RP];
-                }
-                const int jj = t - rl;
-                if (jj >= rl && jj < nJ) pair_step(ring + (size_t)(jj % RB) * SLOT, cur);
-            }
-        }
-        if (rl < wI) {
-            double *col = V + (size_t)(I0 + rl) * d;
-#pragma unroll
-            for (int u = 0; u < RP; ++u) { const int k = 2 * rk0 + 16 * u; if (k + 1 < d) { col[k] = vr[u].x; col[k + 1] = vr[u].y; } }
-            if (oddrow) col[d - 1] = vlast;
-        }
-        __syncthreads();                                       // (one wave: the next block row's loads follow these stores)
-    }
-}
-
-// singular values = column norms of G (the routine's eight partial chains over the rows), sorted descending (first maximum wins), V's columns
-// with them; the sorted vectors are left in G's place
-__global__ __launch_bounds__(256) void svd_finish_kernel(double *Gc, const double *Vc, double *svc, const uint8_t *state, int nlanes, int d)
-{
-    __shared__ int s_perm[256];
-    __shared__ double s_sv[256];
-    const int chain = blockIdx.x, tid = threadIdx.x;
-    if (chain >= nlanes || state[chain] == 0) return;
-    double *G = Gc + (size_t)chain * d * d;
-    const double *V = Vc + (size_t)chain * d * d;
-    if (tid < d) {
-        const double *gj = G + (size_t)tid * d;
-        double pa[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) pa[u] = 0.0;
-        for (int k0 = 0; k0 < d; k0 += 8) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) if (k0 + u < d) pa[u] = dfma(gj[k0 + u], gj[k0 + u], pa[u]);
-        }
-        s_sv[tid] = sqrt(svd_tree8(pa)); s_perm[tid] = tid;
-    }
-    __syncthreads();
-    if (tid == 0)
-        for (int i = 0; i < d - 1; ++i) {
-            int m = i; double sm = s_sv[i];
-            for (int j = i + 1; j < d; ++j) if (s_sv[j] > sm) { m = j; sm = s_sv[j]; }
-            if (m != i) { double ts = s_sv[i]; s_sv[i] = s_sv[m]; s_sv[m] = ts; int tp = s_perm[i]; s_perm[i] = s_perm[m]; s_perm[m] = tp; }
-        }
-    __syncthreads();
-    if (tid < d) svc[(size_t)chain * d + tid] = s_sv[tid];
-    for (int e = tid; e < d * d; e += 256) { const int j = e / d, k = e - j * d; G[e] = V[(size_t)s_perm[j] * d + k]; }
-}
-
-// tile-interleaved [tile][K][64 lanes]  <->  chain-major [chain][K], 64 x 64 blocks through LDS (both sides coalesced)
-__global__ __launch_bounds__(256) void tile2chain_kernel(const double *__restrict__ src, double *__restrict__ dst, size_t K, size_t Kt, const uint8_t *need)
-{
-    __shared__ double T[64][65];
-    const int tile = blockIdx.y, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const size_t k0 = (size_t)blockIdx.x * 64;
-    bool any = false;
-    for (int l = 0; l < 64; ++l) any = any || need[tile * 64 + l];
-    if (!any) return;
-    for (int r = ty; r < 64; r += 4) if (k0 + r < K) T[r][tx] = src[((size_t)tile * Kt + k0 + r) * 64 + tx];          // element k0+r, lane tx (Kt: elements per tile on the interleaved side)
-    __syncthreads();
-    for (int c = ty; c < 64; c += 4) if (k0 + tx < K && need[tile * 64 + c]) dst[((size_t)tile * 64 + c) * K + k0 + tx] = T[tx][c];
-}
-__global__ __launch_bounds__(256) void chain2tile_kernel(const double *__restrict__ src, double *__restrict__ dst, size_t K, size_t Kt, const uint8_t *need)
-{
-    __shared__ double T[64][65];
-    const int tile = blockIdx.y, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const size_t k0 = (size_t)blockIdx.x * 64;
-    bool any = false;
-    for (int l = 0; l < 64; ++l) any = any || need[tile * 64 + l];
-    if (!any) return;
-    for (int c = ty; c < 64; c += 4) if (k0 + tx < K && need[tile * 64 + c]) T[tx][c] = src[((size_t)tile * 64 + c) * K + k0 + tx];
-    __syncthreads();
-    for (int r = ty; r < 64; r += 4) if (k0 + r < K && need[tile * 64 + tx]) dst[((size_t)tile * Kt + k0 + r) * 64 + tx] = T[r][tx];
-}
-
-// one chain's lane of a tile-interleaved array: out[e] = src[e*64 + lane], e < n (mcmcx_get_chain copies a single
-// chain's history to the host, not the other 63 of its tile)
-__global__ __launch_bounds__(256) void gather_lane_kernel(const double *__restrict__ src, double *out, size_t n, int lane)
-{
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) out[e] = src[e * 64 + lane];
-}
-
-// ---------------------------------------------------------------- pooled moments of the current states
-// out[tile][1 + d + d(d+1)/2]: partial sums over the 64 lanes of a tile by an xor-butterfly (a fixed
-// pairwise tree: adjacent lanes first); the host finishes the tree over tiles, RCCL over GPUs.
-// Second moments are indexed j(j+1)/2 + i for i <= j.
-// kind 0: [count, sum_j x_j, sum x_i x_j (i <= j)], x = theta - par0                       (1 + d + P terms)
-// kind 1: the same followed by sum_c stayed_c (the pooled rejection count of a burn-in tick)  (2 + d + P)
-// kind 2: the pooled RAM statistic of iteration `it` (MCMC_run_ram.F90:166-172 summed over chains): [count, sum alpha,
-//         sum_c sign(a_c) x_c x_c'], x_c = u_c / sum(u_c**2) * a_c, a_c = rs (alpha_c - alphatarget)     (2 + P)
-// BIG (npar > 318: the tile's 64 vectors no longer fit a CU's LDS): the same terms with every x value formed from global memory where it
-// is used -- the same operations on the same operands, so the same bits; only the four 64-vectors (count, alpha or stayed, sign, sum(u**2))
-// and the chains' a = rs (alpha - alphatarget) stay in LDS.  Slower (each term reads its 2 x 64 values through L2); any npar.
-template <bool BIG>
-__global__ __launch_bounds__(256) void moments_kernel(EngineDev E, double *out, int nchains, int kind, int it, double rs)
-{
-    // The tile's 64 vectors x_c go to LDS once (chain-major, odd stride); then each of the 256 threads takes terms m, m + 256, ...:
-    // it forms the term's 64 values (one per chain) and adds them in the butterfly's tree order (lane pairs first) -- the sums
-    // v_l + v_{l^1}, (..) + (..)_{l^2}, ... a xor-butterfly leaves in lane 0 -- in registers.  No barrier after the first, every
-    // lane on a term of its own; the old form (one chain per lane, 64 terms at a time transposed through LDS) spent its time
-    // in the latencies of 1300 global loads and 2 x 20 barriers per tile at four waves per CU.
-    extern __shared__ double XS[];                      // x[64][DP]; then count[64], alpha or stayed [64], sign(a) [64], sum(u**2) [64]
-    const int tid = threadIdx.x, tile = blockIdx.x, d = E.d, P = E.P, DP = BIG ? 0 : (d | 1);
-    double *sp0 = XS + (size_t)64 * DP, *sp1 = sp0 + 64, *sg = sp1 + 64, *ssu = sg + 64, *sa = ssu + 64;
-    const double *theta_t = E.theta + (size_t)tile * d * 64;
-    const double *z_t = E.zs + ((size_t)tile * 2 + (it & 1)) * d * 64;        // kind 2: the normals iteration `it` proposed with
-    const int len = (kind == 2) ? 2 + P : (1 + d + P + (kind == 1 ? 1 : 0));
-    double *o = out + (size_t)tile * len;
-    const int c0 = tid & 63;
-    const bool act = (tile * 64 + c0) < nchains;
-    if (tid < 64) {
-        sp0[c0] = act ? 1.0 : 0.0;
-        double s1 = 0.0, sgn = 1.0, su = 1.0;
-        if (kind == 2) {
-            const double alpha = TIDX(E.scal, tile, NSCAL, S_ALPHA12, c0);
-            const double a = rs * (alpha - E.alphatarget);
-            su = 0.0;
-            for (int k = 0; k < d; ++k) { const double z = GV2(z_t, k, c0); su = su + z * z; }
-            s1 = act ? alpha : 0.0;
-            sgn = (!act || a >= 0.0) ? 1.0 : -1.0;
-        } else if (kind == 1) s1 = act ? (double)TIDX(E.ictr, tile, NICTR, I_STAYED, c0) : 0.0;
-        sp1[c0] = s1; sg[c0] = sgn; ssu[c0] = su;
-        if (BIG) sa[c0] = (kind == 2) ? rs * (TIDX(E.scal, tile, NSCAL, S_ALPHA12, c0) - E.alphatarget) : 0.0;
-    }
-    __syncthreads();
-    if (!BIG) {
-    if (kind == 2) {
-        const double alpha = TIDX(E.scal, tile, NSCAL, S_ALPHA12, c0);
-        const double a = rs * (alpha - E.alphatarget), su = ssu[c0];
-        for (int k = tid >> 6; k < d; k += 4) XS[(size_t)c0 * DP + k] = act ? GV2(z_t, k, c0) / su * a : 0.0;     // x = u / sum(u**2) * a
-    } else {
-        for (int k = tid >> 6; k < d; k += 4) XS[(size_t)c0 * DP + k] = act ? (GV2(theta_t, k, c0) - E.par0[k]) : 0.0;
-    }
-    __syncthreads();
-    }
-    // x value k of chain l of the tile: from the LDS copy, or (BIG) formed here
-    auto xv = [&](int l, int k) -> double {
-        if (!BIG) return XS[(size_t)l * DP + k];
-        if (!(sp0[l] != 0.0)) return 0.0;
-        return (kind == 2) ? GV2(z_t, k, l) / ssu[l] * sa[l] : (GV2(theta_t, k, l) - E.par0[k]);
-    };
-    const int pair0 = (kind == 2) ? 2 : 1 + d;          // first second-moment term
-    for (int m = tid; m < len; m += 256) {
-        double a[64];
-        if (m == 0) {
-#pragma unroll
-            for (int l = 0; l < 64; ++l) a[l] = sp0[l];
-        } else if (m < pair0 && kind == 2) {
-#pragma unroll
-            for (int l = 0; l < 64; ++l) a[l] = sp1[l];
-        } else if (m < pair0) {
-#pragma unroll
-            for (int l = 0; l < 64; ++l) a[l] = xv(l, m - 1);
-        } else if (m >= pair0 + P) {                    // kind 1: the rejection counts
-#pragma unroll
-            for (int l = 0; l < 64; ++l) a[l] = sp1[l];
-        } else {
-            const int q = m - pair0;                    // = j (j + 1) / 2 + i, i <= j
-            int j = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
-            while ((j + 1) * (j + 2) / 2 <= q) ++j;
-            while (j * (j + 1) / 2 > q) --j;
-            const int i2 = q - j * (j + 1) / 2;
-            if (kind == 2) {
-#pragma unroll
-                for (int l = 0; l < 64; ++l) { const double t = xv(l, i2) * xv(l, j); a[l] = (sg[l] >= 0.0) ? t : -t; }
-            } else {
-#pragma unroll
-                for (int l = 0; l < 64; ++l) a[l] = xv(l, i2) * xv(l, j);
-            }
-        }
-#pragma unroll
-        for (int s2 = 1; s2 < 64; s2 <<= 1)
-#pragma unroll
-            for (int l = 0; l + s2 < 64; l += 2 * s2) a[l] = a[l] + a[l + s2];
-        o[m] = a[0];
-    }
-}
-
-// one double into device memory in stream order (the rank's stop flag behind its moment vector): a pageable hipMemcpyAsync of eight bytes makes the
-// host wait for the stream on this runtime, which put a host round trip between two bench steps
-__global__ void set_double_kernel(double *p, double v) { *p = v; }
-
-// Finish the pooled sum over tiles in the same fixed pairwise tree (adjacent tiles first):
-//     for s = 1, 2, 4, ...: for t = 0, 2s, 4s, ... with t + s < ntiles: v[t] += v[t + s]
-// v[0..len) of tile 0 ends up holding the result.  Deterministic and independent of how tiles are later grouped onto
-// GPUs, as long as every GPU owns a power-of-two aligned block.  One launch runs six levels of the tree: thread
-// (group g, moment k) loads the 64 partial sums v[(64 g + i) stride], i < 64, adds them up in registers in tree order
-// and stores the result where the tree leaves it, v[64 g stride]; the host repeats with stride 64, 4096, ... until one
-// group is left.  Loads are coalesced along k and independent of each other.
-__global__ __launch_bounds__(256) void moments_tree_kernel(double *v, int ntiles, int len, int stride, double *dst)
-{
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    const long long t0 = (long long)blockIdx.y * 64 * stride;
-    if (k >= len) return;
-    double a[64];
-#pragma unroll
-    for (int i = 0; i < 64; ++i) {
-        const long long t = t0 + (long long)i * stride;
-        a[i] = (t < ntiles) ? v[(size_t)t * len + k] : 0.0;
-    }
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1)
-#pragma unroll
-        for (int i = 0; i + s < 64; i += 2 * s)
-            if (t0 + (long long)(i + s) * stride < ntiles) a[i] = a[i] + a[i + s];
-    v[(size_t)t0 * len + k] = a[0];
-    if (dst && gridDim.y == 1) dst[k] = a[0];
-}
-
-// ---------------------------------------------------------------- debug probes of the device primitives
-// (tests/test_gpu_primitives.py compares them bit for bit with the oracle)
-__global__ void debug_math_kernel(int op, int n, const double *a, const double *b, double *out)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double x = a[i], y = b ? b[i] : 0.0, r = 0.0;
-    switch (op) {
-    case 0: r = d_log(x); break;
-    case 1: r = d_exp(x); break;
-    case 2: r = sqrt(x); break;
-    case 3: r = x / y; break;
-    case 4: r = dfma(x, y, x); break;
-    case 5: { double c, s, rr; d_rotg(x, y, rr, c, s); r = rr + c * 3.0 + s * 7.0; break; }
-    }
-    out[i] = r;
-}
-
-// stream of one chain: kind 0 uniforms, 1 normals (normal_bm order), 2 gamma(a, b)
-__global__ void debug_rng_kernel(uint32_t k0, uint32_t k1, int kind, int n, double a, double b, double *out, uint64_t *nused)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    Rng g; g.k0 = k0; g.k1 = k1; g.n = 0; g.cblk = 0; g.c2 = g.c3 = 0; g.saved = 0; g.saved_y = 0.0;
-    for (int i = 0; i < n; ++i) {
-        if (kind == 0) out[i] = rng_uniform(g);
-        else if (kind == 1) out[i] = rng_normal(g);
-        else out[i] = rng_gamma(g, a, b);
-    }
-    *nused = g.n;
-}
-
-} // namespace mcx
+#include "mcx_common.hpp"
+#include "mcx_products.hpp"
+#include "mcx_step.hpp"
+#include "mcx_scam.hpp"
+#include "mcx_pooled.hpp"
+#include "mcx_phase.hpp"
+#include "mcx_adapt.hpp"
+#include "mcx_svd.hpp"
+#include "mcx_moments.hpp"

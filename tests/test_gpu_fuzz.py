@@ -394,15 +394,16 @@ def _check_larger_npar(oracle, seed, dlo=13, dhi=65):
     e.close()
 
 
-@pytest.mark.parametrize("seed,waves", [(s, 1) for s in range(30)] + [(s, 2) for s in (0, 3, 7, 11, 19, 26)] + [(s, 3) for s in range(30, 60)] + [(s, 4) for s in range(60, 90)])
+@pytest.mark.parametrize("seed,waves", [(s, 1) for s in range(30)] + [(s, 2) for s in range(30, 90)])
 def test_pooled_am_matrix_core_kernel_equals_lane_kernel(seed, waves, monkeypatch):
     """pooled_mfma_kernel (products as MFMA tiles) == the lane-per-chain pooled kernel, for random sizes (one to three
     passes of output blocks, ragged last block and k-block), targets, bounds, priors and the sigma2 update.  waves = 2: the
-    instance that shares a SIMD between two waves (pooled_mfma_kernel<false, true>; the engine's own choice from 2048 tiles on)."""
+    instance that shares a SIMD between two waves (pooled_mfma_kernel<false, true>; the engine's own choice from 2048 tiles on -- the kernel
+    behind bench.py's c4_pooled: sixty of the ninety draws go to it, the suite time the two-waves-per-tile variants used to take)."""
     from mcmcf90_amd import engine_from_problem
     monkeypatch.setenv("MCMCX_POOLED_WAVES", str(waves))
     r = np.random.default_rng(11000 + seed)
-    d = int(r.choice([1, 2, 3, 5, 16, 17, 31, 48, 50, 63, 64, 65, 80, 97, 130])) if waves < 3 else int(r.choice([17, 18, 25, 31, 32, 33, 47, 48, 49, 50, 63, 64]))
+    d = int(r.choice([1, 2, 3, 5, 16, 17, 31, 48, 50, 63, 64, 65, 80, 97, 130])) if seed < 30 else int(r.choice([17, 18, 25, 31, 32, 33, 47, 48, 49, 50, 63, 64]))
     kind = str(r.choice(["gauss", "gauss", "banana"])) if d >= 2 else "gauss"
     n = int(r.choice([65, 130, 200]))
     ckw = dict(nsimu=int(r.integers(20, 60)), adaptint=int(r.choice([8, 15])), updatesigma=int(r.integers(0, 2)))
@@ -420,7 +421,7 @@ def test_pooled_am_matrix_core_kernel_equals_lane_kernel(seed, waves, monkeypatc
         pkw.update(pri_mu=np.zeros(d), pri_sig=np.where(r.random(d) < 0.5, 0.0, 1.0))
     e = engine_from_problem(ckw, pkw, nchains=n, pooled=1, record_accept=1)
     e.init(); e.run()
-    assert e.last_kernel() == {1: "pooled_mfma_kernel<false>", 2: "pooled_mfma_kernel<false, true>", 3: "pooled_mfma2_kernel", 4: "pooled_mfma3_kernel"}[waves], e.last_kernel()
+    assert e.last_kernel() == {1: "pooled_mfma_kernel<false>", 2: "pooled_mfma_kernel<false, true>"}[waves], e.last_kernel()
     monkeypatch.setenv("MCMCX_POOLED_SCALAR", "1")
     e2 = engine_from_problem(ckw, pkw, nchains=n, pooled=1, record_accept=1)
     e2.init(); e2.run()

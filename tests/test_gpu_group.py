@@ -206,36 +206,10 @@ def test_group_kernel_power_of_two_drscale_and_its_range_check(oracle, monkeypat
         assert sum(c["drtries"] for c in a[3]) > 0
 
 
-@pytest.mark.parametrize("kind,d,drscale", [("gauss", 20, 2.0), ("banana", 31, 3.0), ("gauss", 17, 0.0), ("gauss", 5, 2.0)])
-def test_group_factorisation_kernel(oracle, monkeypatch, kind, d, drscale):
-    """group_factor_kernel (dpotf2 with lanes as columns, dtrti2 / dlauu2 with lanes as rows, the matrix in LDS) against adapt_post_kernel's
-    own factorisation: R, R2, iC and the chain after three adaptations, bit for bit; and against the oracle."""
-    from mcmcf90_amd import engine_from_problem
-    ckw = dict(nsimu=170, adaptint=50, updatesigma=0, drscale=drscale)
-    pkw = _problem(kind, d, 300 + d)
-    res = []
-    for gf in ("1", "0"):                                 # 1: group_factor_kernel; 0: tile_factor_kernel (round 5: the engine's own choice at any chain count)
-        monkeypatch.setenv("MCMCX_GROUP", "1"); monkeypatch.setenv("MCMCX_GROUP_FACTOR", gf)
-        e = engine_from_problem(ckw, pkw, nchains=70, chain_id0=4, record_accept=1)
-        e.init(); e.run()
-        res.append((e.theta().copy(), e.accept_masks().copy(), [e.R(c).copy() for c in (0, 69)], [e.dr_state(c) for c in (0, 69)] if drscale else [], [e.counters(c) for c in (0, 69)]))
-        e.close()
-    a, b = res
-    assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1]) and a[4] == b[4]
-    for x, y in zip(a[2], b[2]):
-        np.testing.assert_array_equal(_bits(np.triu(x)), _bits(np.triu(y)))
-    for x, y in zip(a[3], b[3]):
-        for u, v in zip(x, y):
-            np.testing.assert_array_equal(_bits(np.triu(u)), _bits(np.triu(v)))
-    o = oracle.run_chain(oracle.make_cfg(**ckw), oracle.Problem(**pkw), chain_id=4)
-    np.testing.assert_array_equal(_bits(np.triu(a[2][0])), _bits(np.triu(o.R)))
-    if drscale:
-        np.testing.assert_array_equal(_bits(np.triu(a[3][0][1])), _bits(np.triu(o.iC)))
-
-
 @pytest.mark.parametrize("kind,d,drscale,nch", [("gauss", 50, 0.0, 70), ("gauss", 64, 0.0, 70), ("gauss", 37, 2.0, 70), ("gauss", 33, 0.0, 130), ("gauss", 16, 2.0, 200),
                                                  ("gauss", 1, 0.0, 70), ("gauss", 48, 3.0, 70), ("gauss", 64, 2.0, 66), ("banana", 20, 2.0, 1030), ("gauss", 10, 0.0, 1030),
-                                                 ("gauss", 49, 0.0, 130)])
+                                                 ("gauss", 49, 0.0, 130),
+                                                 ("gauss", 20, 2.0, 70), ("banana", 31, 3.0, 70), ("gauss", 17, 0.0, 70), ("gauss", 5, 2.0, 70)])
 def test_tile_factorisation_kernel(oracle, monkeypatch, kind, d, drscale, nch):
     """tile_factor_kernel (round 5: dpotf2, and dtrti2 / dlauu2 with delayed rejection, on the packed matrices of 4 NW neighbouring chains in LDS -- one to
     four columns / rows per lane, workgroups of 4, 2 or 1 waves, a tile's workgroups on one XCD) against adapt_post_kernel's own factorisation
@@ -247,7 +221,7 @@ def test_tile_factorisation_kernel(oracle, monkeypatch, kind, d, drscale, nch):
     picks = (0, 63, nch - 1)
     res = []
     for tf in ("1", "0"):
-        monkeypatch.delenv("MCMCX_GROUP", raising=False); monkeypatch.delenv("MCMCX_GROUP_FACTOR", raising=False)
+        monkeypatch.delenv("MCMCX_GROUP", raising=False)
         monkeypatch.setenv("MCMCX_TILE_FACTOR", tf)
         e = engine_from_problem(ckw, pkw, nchains=nch, chain_id0=4, record_accept=1)
         e.init(); e.run()

@@ -313,14 +313,11 @@ def test_delayed_rejection_vectors_in_lds_or_global(oracle, d, monkeypatch):
     ckw = dict(nsimu=130, adaptint=50, updatesigma=0, drscale=2.0)
     pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.05), cmat0=(0.5 / d) * np.eye(d), mu=np.linspace(-1, 1, d), lam=A @ A.T + np.eye(d))
     res = []
-    for big in ("0", "1", "general"):                     # general: step_body<DR> as it was before step_kernel_dr (MCMCX_DR_GENERAL=1, an A/B form)
-        if big == "general" and d not in (7, 23):
-            continue
-        monkeypatch.setenv("MCMCX_DR_BIG", "0" if big == "general" else big)
-        monkeypatch.setenv("MCMCX_DR_GENERAL", "1" if big == "general" else "0")
+    for big in ("0", "1"):
+        monkeypatch.setenv("MCMCX_DR_BIG", big)
         e = engine_from_problem(ckw, pkw, nchains=70, chain_id0=2, record_accept=1)
         e.init(); e.run()
-        assert e.last_kernel() == {"0": "step_kernel_dr", "1": "step_kernel_dr_big", "general": "step_kernel<false, true, false>"}[big]
+        assert e.last_kernel() == {"0": "step_kernel_dr", "1": "step_kernel_dr_big"}[big]
         res.append((e.theta().copy(), e.accept_masks(), [e.R(c).copy() for c in (0, 69)], [e.rng(c)[0] for c in (0, 69)], [e.counters(c)["draccepted"] for c in (0, 69)]))
         e.close()
     a = res[0]
@@ -418,14 +415,15 @@ def test_history_ring_without_record_chain(oracle, kw, dr, kernels):
 
 @pytest.mark.parametrize("d,method,extra", [(48, "scam", {}), (49, "scam", {}), (70, "scam", {}), (64, "dram", dict(condmax=1e6)), (65, "dram", dict(condmax=1e6)),
                                             (100, "dram", dict(condmax=50.0, drscale=2.0)), (128, "scam", {}), (129, "scam", {}), (200, "dram", dict(condmax=1e6)),
-                                            (200, "scam", {}), (209, "scam", {}),
+                                            (200, "scam", {}), (209, "scam", {}), (225, "scam", {}),
                                             pytest.param(255, "scam", {}, marks=pytest.mark.extended), pytest.param(256, "scam", {}, marks=pytest.mark.extended)])
 def test_blocked_svd_equals_lane_svd_and_oracle(oracle, d, method, extra, monkeypatch):
-    """npar >= 48 with an SVD factor: MCMC_adapt's factorisation runs svd_blocked_kernel (a workgroup per chain, block
-    pairs of columns in LDS, the pinned routine's pairs in a reordered but equivalent sequence).  Bit for bit the
-    one-lane-per-chain routine (MCMCX_SVD_LANE=1; up to npar = 128) -- factor, singular values, states after several
-    adaptations, a ragged tile -- and the oracle on two chains, up to the engine's largest npar (256: other block counts
-    and partial-chain lengths than 200)."""
+    """npar 48..256 with an SVD factor: MCMC_adapt's factorisation runs one workgroup per chain (mcx_svd.hpp: the pinned routine's pairs in a
+    reordered but equivalent sequence, every later column streamed past a block's pair-lanes -- svd_sweep_stream32_kernel up to npar 200,
+    svd_sweep_stream_kernel<26> up to 208 and <32> up to 256 (209, 225: both instances in the default suite), svd_applyv_stream32_kernel for V).
+    Bit for bit the one-lane-per-chain routine (MCMCX_SVD_LANE=1: the engine's own form below npar 48 and above 256; compared up to npar = 128)
+    -- factor, singular values, states after several adaptations, a ragged tile -- and the oracle on two chains.  (The four superseded
+    generations of these kernels and the shared-rotation negative were compared here up to round 5: tools/variants/README.md.)"""
     from mcmcf90_amd import engine_from_problem
     rng = np.random.default_rng(d)
     A = rng.standard_normal((d, d)) / np.sqrt(d)
@@ -438,33 +436,14 @@ def test_blocked_svd_equals_lane_svd_and_oracle(oracle, d, method, extra, monkey
     ckw = dict(nsimu=nsimu, method=method, adaptint=adaptint, updatesigma=0, **extra)
     pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.05), cmat0=(0.3 / d) * np.eye(d), mu=np.zeros(d), lam=lam)
     res = []
-    # (the lane-per-chain form is the production path below npar = 48 only; at 200 it is compared with the oracle in
-    #  test_gpu_fullsize.py::test_c5_illcond200_scam_replicas_two_ticks, and takes 10-25 s per adaptation up here)
-    # paths: the sweep / V replay with the I block's columns in registers (round 4, the default), with both blocks in LDS
-    # (MCMCX_SVD_REG=0), one lane per chain (MCMCX_SVD_LANE=1)
-    # the columns right of the I block streamed past it through an LDS ring (the default; block width 24 and 16), the I block in
-    # registers and block pairs (MCMCX_SVD_STREAM=0), ...
+    # (the lane-per-chain form takes 10-25 s per adaptation at npar 200: there it is compared with the oracle in
+    #  test_gpu_fullsize.py::test_c5_illcond200_scam_replicas_two_ticks)
     # (odd npar: the V replay's extra row and unaligned columns; 65 / 129 / 209: one row past a register-count instantiation)
-    paths = ("stream", "stream24", "stream16", "reg", "lds", "lane") if d <= 100 else ("stream", "stream24", "lane") if d == 128 else \
-            ("stream", "stream24", "stream16", "reg", "lds") if (d == 129 or (d == 200 and method == "dram")) else \
-            ("stream", "stream24", "reg") if d == 200 else ("stream", "reg")
-    if d in (49, 100):                                    # round 5: a pair's rotation worked out once per pair (svd_sweep_stream32s_kernel: bit-equal, slower, opt-in)
-        paths = paths + ("stream_shared_rot",)
+    paths = ("stream", "lane") if d <= 128 else ("stream",)
     for path in paths:
-        for k in ("MCMCX_SVD_LANE", "MCMCX_SVD_REG", "MCMCX_SVD_STREAM", "MCMCX_SVD_STREAM_B", "MCMCX_SVD_SHARED_ROT"):
-            monkeypatch.delenv(k, raising=False)
-        if path == "stream_shared_rot":
-            monkeypatch.setenv("MCMCX_SVD_SHARED_ROT", "1")
-        if path == "stream16":
-            monkeypatch.setenv("MCMCX_SVD_STREAM_B", "16")
-        if path == "stream24":                            # (npar <= 200: "stream" is the 32-pair-lane form)
-            monkeypatch.setenv("MCMCX_SVD_STREAM32", "0")
-        if path in ("reg", "lds"):
-            monkeypatch.setenv("MCMCX_SVD_STREAM", "0")
+        monkeypatch.delenv("MCMCX_SVD_LANE", raising=False)
         if path == "lane":
             monkeypatch.setenv("MCMCX_SVD_LANE", "1")
-        if path == "lds":
-            monkeypatch.setenv("MCMCX_SVD_REG", "0")
         e = engine_from_problem(ckw, pkw, nchains=70, chain_id0=5, record_accept=1)
         e.init(); e.run()
         res.append((e.theta(), e.accept_masks(), [e.R(c) for c in (0, 63, 64, 69)],

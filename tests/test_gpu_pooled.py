@@ -343,7 +343,7 @@ def test_random_pooled_scam_configuration_matches_restatement(oracle, seed):
     _check_pooled_scam_against_restatement(oracle, seed)
 
 
-@pytest.mark.parametrize("waves", [1, 2, 3, 4], ids=["one_wave_per_simd", "two_waves_per_simd", "two_waves_per_tile", "half_tile_per_wave"])
+@pytest.mark.parametrize("waves", [1, 2], ids=["one_wave_per_simd", "two_waves_per_simd"])
 @pytest.mark.parametrize("d", [50, 70])
 def test_pooled_am_matrix_core_kernel_sizes(oracle, d, waves, monkeypatch):
     """pooled_mfma_kernel at d = 50 (one pass of four output blocks, the bench's size) and d = 70 (two passes, products
@@ -360,10 +360,7 @@ def test_pooled_am_matrix_core_kernel_sizes(oracle, d, waves, monkeypatch):
     pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.1), cmat0=(0.5 / d) * np.eye(d), mu=np.linspace(-0.5, 0.5, d), lam=lam)
     e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
     e.init(); e.run()
-    # (waves = 3: pooled_mfma2_kernel, a tile as a workgroup of two waves -- npar 17..64; at 70 the engine falls back to the one-wave kernel)
-    # (waves = 4: pooled_mfma3_kernel, half a tile per wave and no workgroup -- the same range)
-    assert e.last_kernel() == {1: "pooled_mfma_kernel<false>", 2: "pooled_mfma_kernel<false, true>", 3: "pooled_mfma2_kernel" if d <= 64 else "pooled_mfma_kernel<false>",
-                               4: "pooled_mfma3_kernel" if 17 <= d <= 64 else "pooled_mfma_kernel<false>"}[waves], e.last_kernel()
+    assert e.last_kernel() == {1: "pooled_mfma_kernel<false>", 2: "pooled_mfma_kernel<false, true>"}[waves], e.last_kernel()
     monkeypatch.setenv("MCMCX_POOLED_SCALAR", "1")
     e2 = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
     e2.init(); e2.run()
@@ -681,12 +678,13 @@ def test_pooled_delayed_rejection_and_er_match_restatement(oracle, name, extra, 
     ("am_49_bounds_priors", 49, 140, dict(), "gauss"), ("banana_24", 24, 130, dict(), "banana"), ("am_50_record", 50, 130, dict(), "gauss"),
     ("burnin_up_32", 32, 130, dict(doburnin=1, burnintime=160, badaptint=50, scalelimit=0.3), "gauss"), ("svd_20", 20, 130, dict(condmax=1e8), "gauss"),
 ])
-def test_pooled_two_waves_per_tile_matches_restatement(oracle, name, d, N, extra, kind, monkeypatch):
-    """pooled_mfma2_kernel (round 5: a tile of 64 chains as a workgroup of TWO waves sharing the LDS vector -- two lanes per chain for the polar
-    attempts, the output blocks of the two products split between the waves, the chain's scalar work done by both of its lanes): the chain of
-    pooled_mfma_kernel<false> bit for bit and the restatement's -- two to four output blocks, odd and even npar (the cached second deviate changes
-    hands), ragged tiles, the sigma2 update, early rejection, bounds and priors and a non-Gaussian target (the candidate's other half read
-    through global memory), the SVD factor (a full, non-triangular table), burn-in scaling, the history ring and accept masks of a recorded chain."""
+def test_pooled_two_waves_per_simd_matches_restatement(oracle, name, d, N, extra, kind, monkeypatch):
+    """pooled_mfma_kernel<false, true> -- the instance behind bench.py's c4_pooled: 256 registers, two waves per SIMD, part of the state spilled
+    around the products; the engine's own choice from 2048 / 8192 tiles on, forced here on a small problem (MCMCX_POOLED_WAVES=2) -- gives the
+    chain of pooled_mfma_kernel<false> bit for bit and the restatement's: two to four output blocks, odd and even npar (the cached second deviate),
+    ragged tiles, the sigma2 update, early rejection, bounds and priors and a non-Gaussian target, the SVD factor (a full, non-triangular table),
+    burn-in scaling, the history ring and accept masks of a recorded chain.  (Up to round 5 these cases ran the two-waves-per-tile and
+    half-tile variants, which are no longer in the library: tools/variants/README.md.)"""
     from mcmcf90_amd import engine_from_problem
     nsimu = 230
     ckw = dict(dict(nsimu=nsimu, adaptint=100, updatesigma=0, N0=1.0, S02=0.5), **extra)
@@ -704,11 +702,11 @@ def test_pooled_two_waves_per_tile_matches_restatement(oracle, name, d, N, extra
         pkw = dict(kind="banana", npar=d, par0=np.zeros(d), cmat0=(1.0 / d) * np.eye(d), b=0.1)
     ekw = dict(record_chain=1) if "record" in name else {}
     res = []
-    for waves in ("3", "4", "1"):
+    for waves in ("2", "1"):
         monkeypatch.setenv("MCMCX_POOLED_WAVES", waves)
         e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1, **ekw)
         e.init(); e.run(57); e.run()
-        assert e.last_kernel() == {"3": "pooled_mfma2_kernel", "4": "pooled_mfma3_kernel", "1": "pooled_mfma_kernel<false>"}[waves], e.last_kernel()
+        assert e.last_kernel() == {"2": "pooled_mfma_kernel<false, true>", "1": "pooled_mfma_kernel<false>"}[waves], e.last_kernel()
         res.append(dict(theta=e.theta().copy(), masks=e.accept_masks().copy(), scal=e.scalars().copy(), rng=[e.rng(c) for c in (0, 31, 32, 63, 64, N - 1)],
                         ctr=[e.counters(c) for c in (0, 33, N - 1)], pooled=e.pooled(), tot=e.totals(),
                         chain=[e.chain(c) for c in (0, 35, N - 1)] if ekw else []))
@@ -851,8 +849,7 @@ def _restate_pooled_ram(oracle, ckw, pkw, N):
 
 @pytest.mark.parametrize("d,N,mfma,condmax", [(6, 150, 0, 0.0), (6, 150, 1, 0.0), (50, 200, 1, 0.0), (6, 150, 0, 1e8), (6, 150, 1, 25.0), (20, 130, 1, 1e8),
                                               (50, 200, 2, 0.0), (20, 130, 2, 1e8),           # mfma = 2: pooled_mfma_kernel<false, true> (two waves per SIMD)
-                                              (50, 200, 3, 0.0), (20, 130, 3, 1e8), (33, 140, 3, 0.0),    # mfma = 3: pooled_mfma2_kernel (two waves per tile)
-                                              (50, 200, 4, 0.0), (33, 140, 4, 0.0)])                      # mfma = 4: pooled_mfma3_kernel (half a tile per wave)
+                                              (33, 140, 2, 0.0), (64, 200, 2, 0.0), (17, 130, 2, 25.0)])
 def test_pooled_ram_matches_restatement(oracle, d, N, mfma, condmax, monkeypatch):
     """method = 'ram', pooled = 1: one factor for all chains; every adaptint iterations the chains' rank-one RAM
     statistics sign(a) x x' (MCMC_run_ram.F90:166-172) of that iteration are averaged over all chains and folded into
@@ -871,7 +868,7 @@ def test_pooled_ram_matches_restatement(oracle, d, N, mfma, condmax, monkeypatch
     pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.2), cmat0=cm0, mu=np.zeros(d), lam=A @ A.T + np.eye(d))
     e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
     e.init(); e.run()
-    assert e.last_kernel() == {0: "step_kernel<false, false, true>", 1: "pooled_mfma_kernel<false>", 2: "pooled_mfma_kernel<false, true>", 3: "pooled_mfma2_kernel", 4: "pooled_mfma3_kernel"}[mfma], e.last_kernel()
+    assert e.last_kernel() == {0: "step_kernel<false, false, true>", 1: "pooled_mfma_kernel<false>", 2: "pooled_mfma_kernel<false, true>"}[mfma], e.last_kernel()
     chains, R, st, floored = _restate_pooled_ram(oracle, ckw, pkw, N)
     theta = np.array([ch.theta for ch in chains])
     np.testing.assert_array_equal(_bits(e.theta()), _bits(theta))
