@@ -1,5 +1,7 @@
-// mcx_adapt.hpp -- the first point (init_kernel) and MCMC_adapt at a tick (MCMC_adapt.F90:12-230): schedule, covmat in 10 x 10 blocks, MCMC_calculate_R
-// (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled, mcx_phase, mcx_adapt, mcx_svd, mcx_moments)
+// mcx_adapt.hpp -- the first point (init_kernel) and MCMC_adapt at a tick (MCMC_adapt.F90:12-230): schedule, covmat in 10 x 10 blocks,
+// MCMC_calculate_R
+// (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled, mcx_phase,
+// mcx_adapt, mcx_svd, mcx_moments)
 #pragma once
 #include "mcx_phase.hpp"
 
@@ -35,7 +37,8 @@ __global__ __launch_bounds__(64) void init_kernel(EngineDev E)
         for (int j = 1; j < ny; ++j) GV(h, d + j) = TIDX(E.ssv, tile, ny, j, lane);
         if (lane == 0) E.wacc[(size_t)tile * E.wcap + slot] = ~0ull;
         if (E.record_s2) {
-            if (ny > 1) { for (int j = 0; j < ny; ++j) E.s2hist[(((size_t)tile * E.wcap + slot) * ny + j) * 64 + lane] = TIDX(E.s2v, tile, ny, j, lane); }
+            if (ny > 1) { for (int j = 0; j < ny; ++j) E.s2hist[(((size_t)tile * E.wcap + slot) * ny + j) * 64 + lane] = TIDX(E.s2v, tile,
+                ny, j, lane); }
             else E.s2hist[((size_t)tile * E.wcap + slot) * 64 + lane] = TIDX(E.scal, tile, NSCAL, S_SIGMA2, lane);
         }
     }
@@ -162,7 +165,8 @@ MCX_DEV int potri_packed(double *At, int lane, int d, bool act, double *X)
                 double ajj = 1.0 / GV(At, pidx(j, j, d));
                 GV(At, pidx(j, j, d)) = ajj;
                 ajj = -ajj;
-                for (int i0 = 0; i0 < j; i0 += 8) {             // (eight loads in flight: element by element every one is a cache round trip)
+                // (eight loads in flight: element by element every one is a cache round trip)
+                for (int i0 = 0; i0 < j; i0 += 8) {
                     double v[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) v[u] = GV(At, pidx((i0 + u < j) ? i0 + u : j - 1, j, d));
@@ -344,9 +348,11 @@ MCX_DEV void covmat_rows(const EngineDev &E, int tile, int lane, const uint64_t 
 // lane by lane (covmat_rows), the window restart and MCMC_calculate_R -- or hands the factorisation to tile_factor_kernel (mcx_group.hpp)
 // or to the blocked SVD (mcx_svd.hpp).  Every element of chaincmat / chainmean sees the operations of the reference's covmat.
 enum { ADF_DOCALC = 1, ADF_GREEDY = 2, ADF_STEADY = 4,
-       ADF_BATCH = 8,       // the lane takes covmat's two-pass batch branch over the row list (first AM adaptation with initcmatn = 0, AP window,
-                            // greedy restart with initcmatn = 0); I_BSTART = the first iteration whose ballot belongs to the list
-       ADF_BNOINIT = 16 };  // ... and the list's first row is the one accepted AT I_BSTART (greedy: rows 1..it) instead of a row from before it
+       // the lane takes covmat's two-pass batch branch over the row list (first AM adaptation with initcmatn = 0, AP window, greedy restart
+       // with initcmatn = 0); I_BSTART = the first iteration whose ballot belongs to the list
+       ADF_BATCH = 8,
+       // ... and the list's first row is the one accepted AT I_BSTART (greedy: rows 1..it) instead of a row from before it
+       ADF_BNOINIT = 16 };
 
 __global__ __launch_bounds__(64) void adapt_pre_kernel(EngineDev E, int it, int mode)
 {
@@ -390,7 +396,8 @@ __global__ __launch_bounds__(64) void adapt_pre_kernel(EngineDev E, int it, int 
             flags |= ADF_DOCALC;
             greedy_lane = (E.greedy != 0);
         }
-        if (E.greedy != 0 && greedy_lane) {                           // :83-101 greedy: restart from cmat0 over chain(1:chainind), unit weights
+        // :83-101 greedy: restart from cmat0 over chain(1:chainind), unit weights
+        if (E.greedy != 0 && greedy_lane) {
             flags |= ADF_GREEDY;
             wsum = E.initcmatn;
             for (int e = 0; e < P; ++e) GV(Ct, e) = E.cmat0p[e];
@@ -478,10 +485,13 @@ __global__ __launch_bounds__(64) void adapt_pre_kernel(EngineDev E, int it, int 
 // an off-diagonal one 100 -- fewer, larger blocks repeat the per-fold overhead (the three divisions, the deltas, the row's loads) less
 // often than the 8 x 8 cover of round 3 did (tools/variants/README.md).  DIAG: launched with two waves per SIMD; the off-diagonal form
 // holds 100 accumulators and runs one wave per SIMD (its hundred independent chains keep the VALU busy without a second wave).
+// The walk is in lockstep and a fold runs under the exec mask of whoever accepted at that iteration; decoupling walk and folds by a
+// per-lane
+// FIFO in LDS (fewer, fuller rounds) was built in round 6, is bit-equal, and LOSES at the bench's acceptance rates:
+// tools/variants/mcx_cov_fifo.hpp.
 // Grid: 8 * ceil(ntiles / 8) * nblk workgroups of one wave; workgroup w runs on XCD w % 8, so tile = (w / 8 / nblk) * 8 + w % 8,
 // block = (w / 8) % nblk keeps a tile's blocks on one XCD and next to each other in time.
 constexpr int TD = 10;
-constexpr int CQ = 3;            // rows a lane can have waiting between the window's walk and its folds (LDS: CQ x (1 + TD | 2 TD) x 512 bytes per wave)
 template <bool DIAG>
 MCX_DEV void covmat_window_td(const EngineDev &E, int it, int mode, int nblk)
 {
@@ -496,13 +506,15 @@ MCX_DEV void covmat_window_td(const EngineDev &E, int it, int mode, int nblk)
     const int nb = (d + TD - 1) / TD;
     int a0 = 0, b0 = 0;
     if (DIAG) { a0 = b0 = blk * TD; }
-    else { int ar = 0; while (blk >= nb - 1 - ar) { blk -= nb - 1 - ar; ++ar; } a0 = ar * TD; b0 = (ar + 1 + blk) * TD; }   // block row ar holds nb - 1 - ar off-diagonal blocks
+    // block row ar holds nb - 1 - ar off-diagonal blocks
+    else { int ar = 0; while (blk >= nb - 1 - ar) { blk -= nb - 1 - ar; ++ar; } a0 = ar * TD; b0 = (ar + 1 + blk) * TD; }
     double *Ct = E.cmat + (size_t)tile * P * 64;
     const double *mean_t = E.mean + (size_t)tile * d * 64;
     const double *base_t = E.basetheta + (size_t)tile * d * 64;
     double *mnew_t = E.cand + (size_t)tile * d * 64;
     const bool unit = (mode & AD_BURN) != 0;                          // greedy restart: rows 1..it, unit weights, no base row
-    const uint32_t count0 = unit ? 0u : TIDX(E.ictr, tile, NICTR, I_BASECNT, lane), adj0 = unit ? 0u : TIDX(E.ictr, tile, NICTR, I_LASTFREQ, lane);
+    const uint32_t count0 = unit ? 0u : TIDX(E.ictr, tile, NICTR, I_BASECNT, lane), adj0 = unit ? 0u : TIDX(E.ictr, tile, NICTR,
+        I_LASTFREQ, lane);
     const int t0lane = unit ? 1 : (int)TIDX(E.ictr, tile, NICTR, I_WINSTART, lane), t1 = it;
     const double wsum = TIDX(E.scal, tile, NSCAL, S_WSUM, lane);
     int t0 = act ? t0lane : 0x7fffffff;
@@ -527,6 +539,8 @@ MCX_DEV void covmat_window_td(const EngineDev &E, int it, int mode, int nblk)
         }
     }
     double W = wsum;
+    bool have = act && !unit;
+    uint32_t cnt = count0, adj = adj0;
     auto fold = [&](bool on, double w3) {
         if (on) {
             const double f1 = w3 / (W + w3 - 1.0), f2 = W / (W + w3), f3 = w3 / (W + w3);
@@ -544,41 +558,6 @@ MCX_DEV void covmat_window_td(const EngineDev &E, int it, int mode, int nblk)
             W = w3 + W;
         }
     };
-    // The window is walked in lockstep (a row's loads are whole 512-byte segments whichever lanes want them), but a lane FOLDS only where its
-    // own chain accepted -- a quarter to a half of the iterations -- and a fold is five hundred operations under the exec mask of whoever
-    // accepted at that iteration: up to round 5 a wave ran ~one fold per iteration of the window for the 25-45 each lane needs.  Round 6:
-    // the walk (producer) and the folds (consumer) are decoupled by a per-lane FIFO of CQ rows in LDS.  The producer closes the lane's
-    // previous row -- its weight is known now -- and appends (that weight, the new row); the consumer pops one entry PER LANE per round,
-    // whatever iteration it came from, so nearly every lane works in every round and a window takes about as many rounds as its busiest
-    // lane has rows (tools: 100 -> ~40 at 20 % accepted, ~54 at 30 %, ~70 at 45 %).  A lane's folds keep their order and their operands:
-    // the same bits.  A round is forced when an accepting lane finds its FIFO full; the rest drains at the end.
-    extern __shared__ double cq[];                       // [CQ][NQ][64]: entry = (weight of the row it closes | -1: none), the new row's NQ - 1 values
-    constexpr int NQ = 1 + (DIAG ? TD : 2 * TD);
-    int qn = 0, qhead = 0, qtail = 0;                    // entries waiting, next to pop, next to fill (slots modulo CQ)
-    bool have = act && !unit, term = false;              // producer: the lane has an open row; its last entry closes the window (no new row)
-    uint32_t cnt = count0, adj = adj0;
-    auto round = [&]() {                                 // every lane with an entry takes its oldest one
-        const bool on = qn > 0;
-        double w3 = -1.0, xan[TD], xbn[NBV];
-        const bool last = on && term && qn == 1;         // the closing entry: a weight, no row
-        if (on) {
-            const double *e = cq + ((size_t)(qhead % CQ) * NQ) * 64 + lane;
-            w3 = e[0];
-            if (!last) {
-#pragma unroll
-                for (int u = 0; u < TD; ++u) { xan[u] = e[(size_t)(1 + u) * 64]; if (!DIAG) xbn[u] = e[(size_t)(1 + TD + u) * 64]; }
-            }
-        }
-        const bool fl = on && w3 >= 0.0;
-        if (__any(fl)) fold(fl, w3);
-        if (on) {
-            if (!last) {
-#pragma unroll
-                for (int u = 0; u < TD; ++u) { xa[u] = xan[u]; if (!DIAG) xb[u] = xbn[u]; }
-            }
-            ++qhead; --qn;
-        }
-    };
     for (int tc = t0; tc <= t1; tc += 64) {
         const int tl = tc + lane;
         const unsigned long long mine = (tl <= t1) ? wacc_t[tl % E.wcap] : 0ull;
@@ -590,17 +569,20 @@ MCX_DEV void covmat_window_td(const EngineDev &E, int it, int mode, int nblk)
             const bool inwin = act && (t >= t0lane);
             const bool acc = inwin && ((m >> lane) & 1ull);
             if (__any(acc)) {
-                while (__any(acc && qn == CQ)) round();
+                double xan[TD], xbn[NBV];
                 if (acc) {
                     const size_t so = (size_t)slot * (size_t)E.hs * 64;
-                    double *e = cq + ((size_t)(qtail % CQ) * NQ) * 64 + lane;
-                    e[0] = have ? (unit ? 1.0 : (double)(cnt - adj)) : -1.0;
 #pragma unroll
                     for (int u = 0; u < TD; ++u) {
-                        e[(size_t)(1 + u) * 64] = hist_t[so + (size_t)((a0 + u < d) ? a0 + u : d - 1) * 64 + lane];
-                        if (!DIAG) e[(size_t)(1 + TD + u) * 64] = hist_t[so + (size_t)((b0 + u < d) ? b0 + u : d - 1) * 64 + lane];
+                        xan[u] = hist_t[so + (size_t)((a0 + u < d) ? a0 + u : d - 1) * 64 + lane];
+                        if (!DIAG) xbn[u] = hist_t[so + (size_t)((b0 + u < d) ? b0 + u : d - 1) * 64 + lane];
                     }
-                    ++qtail; ++qn;
+                }
+                const bool fl = acc && have;
+                if (__any(fl)) fold(fl, unit ? 1.0 : (double)(cnt - adj));
+                if (acc) {
+#pragma unroll
+                    for (int u = 0; u < TD; ++u) { xa[u] = xan[u]; if (!DIAG) xb[u] = xbn[u]; }
                     if (have) adj = 0;
                     have = true; cnt = 1;
                 }
@@ -608,13 +590,7 @@ MCX_DEV void covmat_window_td(const EngineDev &E, int it, int mode, int nblk)
             if (inwin && !acc) cnt += 1;
         }
     }
-    // the open row of every lane is closed by the window's end
-    while (__any(have && qn == CQ)) round();
-    if (have) {
-        cq[((size_t)(qtail % CQ) * NQ) * 64 + lane] = unit ? 1.0 : (double)(cnt - adj);
-        ++qtail; ++qn; term = true;
-    }
-    while (__any(qn > 0)) round();
+    if (__any(have)) fold(have, unit ? 1.0 : (double)(cnt - adj));
 #pragma unroll
     for (int u = 0; u < TD; ++u) {
         const int a = a0 + u;
@@ -661,7 +637,8 @@ MCX_DEV void covmat_batch_td(const EngineDev &E, int it, int nblk)
     auto walk = [&](auto &&fold) {
         bool have = act && !noinit;
         int idx = have ? 0 : -1;                          // the list entry of the open row
-        if (have) {                                       // the list's first row dates from before the window: the base row, or a ring slot of the lane's own
+        // the list's first row dates from before the window: the base row, or a ring slot of the lane's own
+        if (have) {
             const uint32_t slot = (uint32_t)GV(rows, 0);
             const bool isbase = (slot == 0xffffffffu);
             const size_t so = isbase ? 0 : (size_t)slot * (size_t)E.hs * 64;
@@ -669,7 +646,8 @@ MCX_DEV void covmat_batch_td(const EngineDev &E, int it, int nblk)
             for (int u = 0; u < TD; ++u) {
                 const int a = (a0 + u < d) ? a0 + u : d - 1;
                 xa[u] = isbase ? GV(base_t, a) : hist_t[so + (size_t)a * 64 + lane];
-                if (!DIAG) { const int b = (b0 + u < d) ? b0 + u : d - 1; xb[u] = isbase ? GV(base_t, b) : hist_t[so + (size_t)b * 64 + lane]; }
+                if (!DIAG) { const int b = (b0 + u < d) ? b0 + u : d - 1; xb[u] = isbase ? GV(base_t,
+                    b) : hist_t[so + (size_t)b * 64 + lane]; }
             }
         }
         for (int tc = t0; tc <= t1; tc += 64) {
@@ -738,15 +716,18 @@ MCX_DEV void covmat_batch_td(const EngineDev &E, int it, int nblk)
     for (int u = 0; u < TD; ++u) {
         const int a = a0 + u;
 #pragma unroll
-        for (int v = (DIAG ? u : 0); v < TD; ++v) { const int b = b0 + v; if (act && a < d && b < d) GV(Ct, pidx(a, b, d)) = C[u][v] / (wsum2 - 1.0); }
+        for (int v = (DIAG ? u : 0); v < TD; ++v) { const int b = b0 + v; if (act && a < d && b < d) GV(Ct, pidx(a, b,
+            d)) = C[u][v] / (wsum2 - 1.0); }
         if (DIAG && act && a < d) GV(mnew_t, a) = ma[u];
     }
     if (DIAG && a0 == 0 && act) TIDX(E.scal, tile, NSCAL, S_WNEW, lane) = wsum2;
 }
 __global__ __launch_bounds__(64, 2) void adapt_covb_diag_kernel(EngineDev E, int it, int nblk) { covmat_batch_td<true>(E, it, nblk); }
 __global__ __launch_bounds__(64, 1) void adapt_covb_off_kernel(EngineDev E, int it, int nblk) { covmat_batch_td<false>(E, it, nblk); }
-__global__ __launch_bounds__(64, 2) void adapt_cov_diag_kernel(EngineDev E, int it, int mode, int nblk) { covmat_window_td<true>(E, it, mode, nblk); }
-__global__ __launch_bounds__(64, 1) void adapt_cov_off_kernel(EngineDev E, int it, int mode, int nblk) { covmat_window_td<false>(E, it, mode, nblk); }
+__global__ __launch_bounds__(64, 2) void adapt_cov_diag_kernel(EngineDev E, int it, int mode, int nblk) { covmat_window_td<true>(E, it,
+    mode, nblk); }
+__global__ __launch_bounds__(64, 1) void adapt_cov_off_kernel(EngineDev E, int it, int mode, int nblk) { covmat_window_td<false>(E, it,
+    mode, nblk); }
 
 // phase 0: the whole tick.  With the blocked SVD (large npar, below) the tick is cut around the factorisation:
 // phase 1 = everything up to and including the symmetric matrix in Gw (and the per-chain `need` flags),
@@ -759,7 +740,8 @@ __global__ __launch_bounds__(64, 1) void adapt_cov_off_kernel(EngineDev E, int i
 // XG (npar > 320: one npar-vector per lane no longer fits a CU's LDS): the work vector in the tile's global scratch (EngineDev::xscr) -- a
 // compile-time choice, so that neither form uses flat accesses.  Slower; any npar.
 template <bool SVD, bool XG = false>
-__global__ __launch_bounds__(64, SVD ? 1 : MCX_POST_WAVES) void adapt_post_kernel(EngineDev E, int it, int mode, int phase, uint8_t *need, int batch_done)
+__global__ __launch_bounds__(64, SVD ? 1 : MCX_POST_WAVES) void adapt_post_kernel(EngineDev E, int it, int mode, int phase, uint8_t *need,
+    int batch_done)
 {
     extern __shared__ double Xlds[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d, P = E.P;
@@ -770,7 +752,8 @@ __global__ __launch_bounds__(64, SVD ? 1 : MCX_POST_WAVES) void adapt_post_kerne
     double *mean_t = E.mean + (size_t)tile * d * 64;
     double *base_t = E.basetheta + (size_t)tile * d * 64;
     double *theta_t = E.theta + (size_t)tile * d * 64;
-    double *m2_t = E.cand + (size_t)tile * d * 64;                 // the blocked update's new means; then scratch (xmean2 of the batch branch)
+    // the blocked update's new means; then scratch (xmean2 of the batch branch)
+    double *m2_t = E.cand + (size_t)tile * d * 64;
     uint64_t *rows = E.rowlist + (size_t)tile * (E.wcap + 1) * 64;
     uint32_t curcount = TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane);
     uint32_t lastfreq = TIDX(E.ictr, tile, NICTR, I_LASTFREQ, lane);

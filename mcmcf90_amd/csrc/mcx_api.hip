@@ -21,7 +21,8 @@
 #include "mcx_group_ram.hpp"
 
 using namespace mcx;
-static_assert(MCMCX_HE_INB == HE_INB && MCMCX_HE_PRI == HE_PRI && MCMCX_HE_SS == HE_SS && MCMCX_HX_STAGE2 == HX_STAGE2 && MCMCX_HX_CRIT == HX_CRIT,
+static_assert(MCMCX_HE_INB == HE_INB && MCMCX_HE_PRI == HE_PRI && MCMCX_HE_SS == HE_SS && MCMCX_HX_STAGE2 == HX_STAGE2
+    && MCMCX_HX_CRIT == HX_CRIT,
               "include/mcmcx_target.h and mcx_kernels.hpp disagree about the phase-state slots");
 
 static thread_local std::string g_err;
@@ -34,7 +35,8 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
             return fail(-100, std::string(#call) + ": " + hipGetErrorString(e_));                 \
     } while (0)
 
-// The test switches (tests, tools): each FORCES one of two kernel forms that the engine also chooses by itself for some configuration -- so that
+// The test switches (tests, tools): each FORCES one of two kernel forms that the engine also chooses by itself for some configuration -- so
+// that
 // the parity tests can run both forms on the same small problem.  None selects a form the engine would never take (those live in
 // tools/variants, outside this library).  Read from the environment ONCE per engine, at mcmcx_create and again at mcmcx_init -- never at
 // launch time.  -1 = not set.
@@ -66,7 +68,8 @@ struct mcmcx_engine {
     int ny = 1; std::vector<double> sigma2v; std::vector<int> nobsv;      // nycol columns (host callbacks only when > 1)
     int tkind = -1, tncols = 1; std::vector<double> tmu, tlam, tx, ty, tlo, thi, tpmu, tpsig; double tb = 0.1;
     bool has_lo = false, has_hi = false, has_pri = false;
-    mcmcx_ssfun_t h_ss = nullptr; mcmcx_ssfun_er_t h_ss_er = nullptr; mcmcx_priorfun_t h_pri = nullptr; mcmcx_checkbounds_t h_cb = nullptr; void *h_user = nullptr;
+    mcmcx_ssfun_t h_ss = nullptr; mcmcx_ssfun_er_t h_ss_er = nullptr; mcmcx_priorfun_t h_pri = nullptr; mcmcx_checkbounds_t h_cb = nullptr;
+        void *h_user = nullptr;
     mcmcx_ssfun_batch_t h_ss_batch = nullptr; int h_threads = 1;      // batched form of the user's ssfunction (opt-in)
     int mod_max_ny = 8;
     hipModule_t mod = nullptr; hipFunction_t mod_fn = nullptr; void *d_moddata = nullptr;   // user target module (include/mcmcx_target.h)
@@ -92,35 +95,50 @@ struct mcmcx_engine {
     int pool_status = 0; double pool_alpha = 0.0;       // pooled RAM: skipped ticks, mean acceptance of the last tick
     int pooled = 0; double pool_W = 0.0; std::vector<double> pool_mean, pool_C, pool_R;   // packed upper, row-major
     std::vector<double> pool_U, pool_std;             // pooled SCAM: the shared rotation (column-major) and qcovstd
-    std::vector<double> pool_Rf;                      // pooled AM with condmax > 0: covtor_svd's full factor U sqrt(s) 2.4/sqrt(d), column-major
-    std::vector<double> pool_R2, pool_iC;             // pooled mode with delayed rejection: R / drscale (packed, or full with condmax > 0) and dpotri(R) (packed)
+    // pooled AM with condmax > 0: covtor_svd's full factor U sqrt(s) 2.4/sqrt(d), column-major
+    std::vector<double> pool_Rf;
+    // pooled mode with delayed rejection: R / drscale (packed, or full with condmax > 0) and dpotri(R) (packed)
+    std::vector<double> pool_R2, pool_iC;
     double *d_sharedR2 = nullptr, *d_sharediC = nullptr;
     double *d_sharedU = nullptr;                      // [U col-major | pad | U row-major | pad | std]
-    bool p0_done = false;                             // host callbacks: the next iteration's proposal already ran in the previous iteration's last launch
-    bool failed = false;                              // a host-callback iteration failed half way: the chains' stream positions are undefined, later runs are refused
-    bool host_mapped = false, cs_mapped = false;     // host callbacks with few chains: the exchange vectors live in page-locked host memory the device reads and writes directly (no copies between the phases)
+    // host callbacks: the next iteration's proposal already ran in the previous iteration's last launch
+    bool p0_done = false;
+    // a host-callback iteration failed half way: the chains' stream positions are undefined, later runs are refused
+    bool failed = false;
+    // host callbacks with few chains: the exchange vectors live in page-locked host memory the device reads and writes directly (no copies
+    // between the phases)
+    bool host_mapped = false, cs_mapped = false;
     std::vector<void *> hallocs;
-    bool scam_replicated = false;                     // pooled SCAM above npar 240 (the tile kernels' LDS vector does not fit): the shared rotation copied to every chain, the per-chain kernels run
-    double *d_sharedRT = nullptr;                     // pooled AM on the matrix cores: dense R, M[s*d + o] = R(s,o), zero below the diagonal and in the pad rows
+    // pooled SCAM above npar 240 (the tile kernels' LDS vector does not fit): the shared rotation copied to every chain, the per-chain
+    // kernels run
+    bool scam_replicated = false;
+    // pooled AM on the matrix cores: dense R, M[s*d + o] = R(s,o), zero below the diagonal and in the pad rows
+    double *d_sharedRT = nullptr;
     double *d_sharedR2T = nullptr, *d_sharediCd = nullptr;   // ... with delayed rejection: R2 in the same form, iC dense and symmetric
     double *d_sharedR = nullptr; mcmcx_exchange_t xfn = nullptr; void *xuser = nullptr; double *xbuf = nullptr;
     struct mcmcx_comm *comm = nullptr;                // the node's communicator (mcx_comm.hpp); nullptr = this GPU alone
-    double *d_gather = nullptr, *d_pooled = nullptr;  // [nranks][len + 1] per-rank moment vectors (+ the rank's stop flag), [len + 1] their tree sum
+    // [nranks][len + 1] per-rank moment vectors (+ the rank's stop flag), [len + 1] their tree sum
+    double *d_gather = nullptr, *d_pooled = nullptr;
     double h_flag = 0.0;                              // this rank's stop flag of the exchange being enqueued (1 = a caught signal)
     bool run_entered = false;                         // mcmcx_run is past its argument checks (a failure from here on may strand peers)
-    bool stop_seen = false;                           // the summed stop flag of the tick just applied was non-zero: every rank leaves after this tick
+    // the summed stop flag of the tick just applied was non-zero: every rank leaves after this tick
+    bool stop_seen = false;
     double S02eff = 0.0;
     // device
     hipStream_t stream = nullptr; bool own_stream = false;
     EngineDev E{};
     std::vector<void *> allocs;
     double *d_ramscale = nullptr, *d_moments = nullptr;
-    double *d_Gc = nullptr, *d_Vc = nullptr, *d_svc = nullptr; uint8_t *d_need = nullptr, *d_state = nullptr; int *d_anyrot = nullptr;    // blocked SVD of the adaptation (large npar)
+    // blocked SVD of the adaptation (large npar)
+    double *d_Gc = nullptr, *d_Vc = nullptr, *d_svc = nullptr; uint8_t *d_need = nullptr, *d_state = nullptr; int *d_anyrot = nullptr;
     int wcap = 0;
     bool tile_factor = false;           // the adaptation's Cholesky branch through tile_factor_kernel (npar <= 64)
-    int ram_group_d4 = 0;               // method = 'ram' on group_ram_kernel (mcx_group_ram.hpp): npar rounded up to its instantiation, 0 = not
-    int group_d4 = 0, group_drm = 0, group_gw = 16; bool group_check_due = true; int *d_gflag = nullptr; uint8_t *d_accb = nullptr;         // lane-group step kernel (mcx_group.hpp): npar rounded up to four when it is the one to launch; accept bytes of a launch
-    bool external = false; double *d_r1 = nullptr; std::vector<double> h_r1;      // MCMC_run1: the caller evaluates; exchange vectors of run1_kernel
+    // method = 'ram' on group_ram_kernel (mcx_group_ram.hpp): npar rounded up to its instantiation, 0 = not
+    int ram_group_d4 = 0;
+    // lane-group step kernel (mcx_group.hpp): npar rounded up to four when it is the one to launch; accept bytes of a launch
+    int group_d4 = 0, group_drm = 0, group_gw = 16; bool group_check_due = true; int *d_gflag = nullptr; uint8_t *d_accb = nullptr;
+    // MCMC_run1: the caller evaluates; exchange vectors of run1_kernel
+    bool external = false; double *d_r1 = nullptr; std::vector<double> h_r1;
     // timing of the step kernel
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double ms_total = 0.0; long long launches = 0, steps = 0;
@@ -128,7 +146,8 @@ struct mcmcx_engine {
 
 struct DevBufs {                                       // hipFree on every exit path
     std::vector<void *> p;
-    template <typename T> hipError_t alloc(T **q, size_t bytes) { void *v = nullptr; hipError_t e = hipMalloc(&v, bytes); if (e == hipSuccess) p.push_back(v); *q = (T *)v; return e; }
+    template <typename T> hipError_t alloc(T **q, size_t bytes) { void *v = nullptr; hipError_t e = hipMalloc(&v, bytes);
+        if (e == hipSuccess) p.push_back(v); *q = (T *)v; return e; }
     ~DevBufs() { for (void *v : p) (void)hipFree(v); }
 };
 
@@ -173,13 +192,18 @@ static int dev_upload(mcmcx_engine *h, const T **p, const std::vector<T> &v)
     return 0;
 }
 
-// No limit on npar like the reference (MCMC_init.F90:81-102 allocates whatever the namelist says) -- beyond int-sized packed indices.  Up to 256
+// No limit on npar like the reference (MCMC_init.F90:81-102 allocates whatever the namelist says) -- beyond int-sized packed indices.  Up
+// to 256
 // every kernel family applies; above, the forms that keep an npar-vector per lane in LDS give way to global scratch where the 160 KiB end
-// (delayed rejection > 160, the adaptation's work vector > 320, the pooled-moment kernel from 316 on), the blocked SVD to the lane-per-chain SVD
+// (delayed rejection > 160, the adaptation's work vector > 320, the pooled-moment kernel from 316 on), the blocked SVD to the
+// lane-per-chain SVD
 // (> 256), the matrix-core pooled kernels to the lane kernels (their own LDS tests): slower, never refused.
-static const int MCX_MAX_NYCOL = 4096;    // response columns (mcmc.F90:30-33: whatever mcmcnycol.dat says): every per-column array is sized at mcmcx_init
-// P = npar (npar + 1) / 2 = 8 390 656 at the cap, 64 P = 537 M and (2 npar + P) 64 = 538 M: every int-typed index expression of the device code
-// (pidx, rowstart, e * 64 + lane) stays below 2**31 with a factor of four to spare -- at 8192, the cap up to round 5, 64 P is 2.147e9 > INT_MAX and
+// response columns (mcmc.F90:30-33: whatever mcmcnycol.dat says): every per-column array is sized at mcmcx_init
+static const int MCX_MAX_NYCOL = 4096;
+// P = npar (npar + 1) / 2 = 8 390 656 at the cap, 64 P = 537 M and (2 npar + P) 64 = 538 M: every int-typed index expression of the device
+// code
+// (pidx, rowstart, e * 64 + lane) stays below 2**31 with a factor of four to spare -- at 8192, the cap up to round 5, 64 P is 2.147e9 >
+// INT_MAX and
 // only the size_t casts of every current use site kept it correct.  Larger problems are refused loudly at mcmcx_create.
 static const int MCX_MAX_NPAR = 4096;
 
@@ -228,7 +252,8 @@ static void host_symsvd(int n, std::vector<double> &G, std::vector<double> &V, s
                 double *gp = &G[(size_t)p * n], *gq = &G[(size_t)q * n];
                 // the routine's dot products: eight partial fma chains by row index mod 8, added pairwise (oracle/mcx_svd.h)
                 double pa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int k = 0; k < n; ++k) { const int j = k & 7; pa[j] = std::fma(gp[k], gp[k], pa[j]); pb[j] = std::fma(gq[k], gq[k], pb[j]); pg[j] = std::fma(gp[k], gq[k], pg[j]); }
+                for (int k = 0; k < n; ++k) { const int j = k & 7; pa[j] = std::fma(gp[k], gp[k], pa[j]); pb[j] = std::fma(gq[k], gq[k],
+                    pb[j]); pg[j] = std::fma(gp[k], gq[k], pg[j]); }
                 const double alpha = h_tree8(pa), beta = h_tree8(pb), gamma = h_tree8(pg);
                 if (gamma == 0.0) continue;
                 if (std::fabs(gamma) <= 1e-15 * std::sqrt(alpha * beta)) continue;
@@ -257,10 +282,12 @@ static void host_symsvd(int n, std::vector<double> &G, std::vector<double> &V, s
 // MCMC_calculate_R, SVD branches, for the shared initial covariance (MCMC_init.F90:109): returns 0 or an error code.
 // Rfull: column-major d*d factor (U for scam, U sqrt(s) 2.4/sqrt(d) otherwise); std: sqrt(s) (scam)
 static int host_initial_svd(int d, const std::vector<double> &cm, double condmax, bool scam,
-                            std::vector<double> &Rfull, std::vector<double> &std, std::vector<double> *floored_cm = nullptr, bool scaled = true)
+                            std::vector<double> &Rfull, std::vector<double> &std, std::vector<double> *floored_cm = nullptr,
+                                bool scaled = true)
 {
     std::vector<double> G((size_t)d * d), V, sv;
-    for (int j = 0; j < d; ++j) for (int i = 0; i < d; ++i) G[(size_t)j * d + i] = (i <= j) ? cm[(size_t)i + (size_t)j * d] : cm[(size_t)j + (size_t)i * d];
+    for (int j = 0; j < d; ++j) for (int i = 0; i < d;
+        ++i) G[(size_t)j * d + i] = (i <= j) ? cm[(size_t)i + (size_t)j * d] : cm[(size_t)j + (size_t)i * d];
     host_symsvd(d, G, V, sv);
     if (sv[0] == 0.0) return d;
     const double tol = sv[0] / condmax;
@@ -272,7 +299,9 @@ static int host_initial_svd(int d, const std::vector<double> &cm, double condmax
         for (int i = 0; i < d; ++i) std[i] = std::sqrt(sv[i]);
     } else {
         const double sqd = std::sqrt((double)d);
-        for (int i = 0; i < d; ++i) { double sq = std::sqrt(sv[i]); for (int k = 0; k < d; ++k) V[(size_t)i * d + k] = sq * V[(size_t)i * d + k]; }   // R0 = U diag(sqrt(s))
+        // R0 = U diag(sqrt(s))
+        for (int i = 0; i < d; ++i) { double sq = std::sqrt(sv[i]); for (int k = 0; k < d;
+            ++k) V[(size_t)i * d + k] = sq * V[(size_t)i * d + k]; }
         if (floored && floored_cm) {                    // covtor_svd info = -1: cmat = matmul(R0, transpose(R0)), matutils.F90:441-446
             floored_cm->assign((size_t)d * d, 0.0);
             for (int j = 0; j < d; ++j)
@@ -329,22 +358,30 @@ static int host_potri(int d, std::vector<double> &A)
 static size_t pooled_mfma_lds(int d)
 {
     const size_t d4 = (size_t)((d + 3) & ~3), nt = (size_t)((d + 15) / 16);
-    const size_t rows = (nt <= 4) ? std::max(d4, 4 * nt) : d4 + 16 * nt + 4 * nt;   // single pass: products and ss chains reuse the vector's rows
+    // single pass: products and ss chains reuse the vector's rows
+    const size_t rows = (nt <= 4) ? std::max(d4, 4 * nt) : d4 + 16 * nt + 4 * nt;
     return rows * 64 * sizeof(double);
 }
 static bool pooled_use_mfma(const mcmcx_engine *h)
 {
-    if (!h->pooled || (h->cfg.method != MCMCX_METHOD_DRAM && h->cfg.method != MCMCX_METHOD_RAM && h->cfg.method != MCMCX_METHOD_ER)) return false;   // (SCAM has its own)
-    if (h->dodr) {                                                                                                   // DR: with its dense tables, and above
-        if (h->cfg.method != MCMCX_METHOD_DRAM || !h->d_sharedR2T) return false;                                     // npar 20 (8.3e8 against 8.9e8 iterations/s
-        int dmin = 21;                                                                                               // for the lane kernel with its LDS vectors at 20;
-        if (h->sw.pooled_mfma_dr_min >= 0) dmin = h->sw.pooled_mfma_dr_min;                                         // 32: 5.6e8 / 2.5e8, 50: 3.2e8 / 0.8e8)
+    // (SCAM has its own)
+    if (!h->pooled || (h->cfg.method != MCMCX_METHOD_DRAM && h->cfg.method != MCMCX_METHOD_RAM
+        && h->cfg.method != MCMCX_METHOD_ER)) return false;
+    // DR: with its dense tables, and above
+    if (h->dodr) {
+        // npar 20 (8.3e8 against 8.9e8 iterations/s
+        if (h->cfg.method != MCMCX_METHOD_DRAM || !h->d_sharedR2T) return false;
+        // for the lane kernel with its LDS vectors at 20;
+        int dmin = 21;
+        // 32: 5.6e8 / 2.5e8, 50: 3.2e8 / 0.8e8)
+        if (h->sw.pooled_mfma_dr_min >= 0) dmin = h->sw.pooled_mfma_dr_min;
         if (h->d < dmin) return false;
     }
     if (h->sw.pooled_scalar > 0) return false;                                         // A/B switch for tests: the lane-per-chain kernel
     return pooled_mfma_lds(h->d) <= 160 * 1024;
 }
-static bool phased(const mcmcx_engine *h) { return h->tkind == TGT_HOST || h->tkind == TGT_EXPCOLS || h->tkind == TGT_MODULE; }   // iteration cut at the evaluations
+// iteration cut at the evaluations
+static bool phased(const mcmcx_engine *h) { return h->tkind == TGT_HOST || h->tkind == TGT_EXPCOLS || h->tkind == TGT_MODULE; }
 // ... except where the DEVICE evaluates between the phases (the response-column target): the phases fused into one launch per segment
 // (step_kernel_cols); MCMCX_COLS_PHASED=1 keeps the separate launches (A/B, tests)
 static bool fused_cols(const mcmcx_engine *h) { return h->tkind == TGT_EXPCOLS && !(h->sw.cols_phased > 0); }
@@ -389,8 +426,10 @@ static const int GROUP_MAX_NPAR = 64, GROUP_MAX_NPAR_DR = 32;      // (with dela
 static bool group_covers(const mcmcx_engine *h)
 {
     const mcmcx_config &c = h->cfg;
-    return !h->pooled && (c.method == MCMCX_METHOD_DRAM || (c.method == MCMCX_METHOD_ER && !h->dodr)) && !h->usesvd && !phased(h) && h->ny == 1 &&
-           (h->tkind == TGT_GAUSS || h->tkind == TGT_BANANA || h->tkind == TGT_EXPDATA) && h->d <= (h->dodr ? GROUP_MAX_NPAR_DR : GROUP_MAX_NPAR) &&
+    return !h->pooled && (c.method == MCMCX_METHOD_DRAM || (c.method == MCMCX_METHOD_ER && !h->dodr)) && !h->usesvd && !phased(h)
+        && h->ny == 1 &&
+           (h->tkind == TGT_GAUSS || h->tkind == TGT_BANANA || h->tkind == TGT_EXPDATA) && h->d <= (h->dodr ? GROUP_MAX_NPAR_DR
+               : GROUP_MAX_NPAR) &&
            !(h->tkind == TGT_BANANA && h->d < 2) && !(h->tkind == TGT_EXPDATA && h->d < 2);
 }
 // ... and where it is the faster one (tools/group_sweep.py, profiles/r04_a/group_sweep.txt: proposals/s of both kernel families over npar,
@@ -423,7 +462,8 @@ static bool group_wins(const mcmcx_engine *h, int drm, int gw)
     if (gw == 4) return h->dodr ? (drm == 2 || n <= 131072) : (d >= 11 || n <= 131072);
     return d >= 11 || (h->dodr && d >= 9 && n <= 131072);
 }
-// one instantiation per (group width, npar rounded up, delayed-rejection form, target kind); DRM 0 = none, 1 = the general form (R, R2, iC in
+// one instantiation per (group width, npar rounded up, delayed-rejection form, target kind); DRM 0 = none, 1 = the general form (R, R2, iC
+// in
 // registers), 2 = drscale a power of two (no R2; iC in LDS): the instantiation without R2 runs unless the device flag says that some factor
 // leaves the range in which R'z / drscale is R2'z bit for bit; the general one is queued behind the same flag and returns at once otherwise
 template <int GW, int D4, int DRM, int TK>
@@ -431,13 +471,18 @@ static void launch_group_inst(mcmcx_engine *h, int it0, int it1)
 {
     const dim3 g(h->ntiles * (GW == 16 ? 16 : 4)), b(64);           // 64 / GW chains per wave
     const double *lam = h->E.tgt.lamT;
-    if constexpr (DRM != 0 && D4 > GROUP_MAX_NPAR_DR) h->launch_err = "group kernel: no delayed-rejection instantiation above npar " + std::to_string(GROUP_MAX_NPAR_DR);
+    if constexpr (DRM != 0 && D4 > GROUP_MAX_NPAR_DR) h->launch_err = "group kernel: no delayed-rejection instantiation above npar " +
+        std::to_string(GROUP_MAX_NPAR_DR);
     else if constexpr (TK == TGT_EXPDATA && D4 != 4) h->launch_err = "group kernel: the expdata target has two parameters";
-    else if constexpr (DRM == 0) hipLaunchKernelGGL((group_step_kernel<GW, D4, 0, TK>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)nullptr, 0);
-    else if constexpr (DRM == 1) hipLaunchKernelGGL((group_step_kernel<GW, D4, 1, -1>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)nullptr, 0);
+    else if constexpr (DRM == 0) hipLaunchKernelGGL((group_step_kernel<GW, D4, 0, TK>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb,
+        (const int *)nullptr, 0);
+    else if constexpr (DRM == 1) hipLaunchKernelGGL((group_step_kernel<GW, D4, 1, -1>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb,
+        (const int *)nullptr, 0);
     else {
-        hipLaunchKernelGGL((group_step_kernel<GW, D4, 2, TK>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)h->d_gflag, 0);
-        hipLaunchKernelGGL((group_step_kernel<GW, D4, 1, -1>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)h->d_gflag, 1);
+        hipLaunchKernelGGL((group_step_kernel<GW, D4, 2, TK>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)h->d_gflag,
+            0);
+        hipLaunchKernelGGL((group_step_kernel<GW, D4, 1, -1>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)h->d_gflag,
+            1);
     }
 }
 template <int GW, int D4, int DRM>
@@ -467,7 +512,8 @@ static void launch_group_d4(mcmcx_engine *h, int it0, int it1)
         case 20: launch_group_tk<16, 20, DRM>(h, it0, it1); break;
         case 24: launch_group_tk<16, 24, DRM>(h, it0, it1); break;
         default:
-            // DRM = 2 (iC as a square in LDS) is the engine's choice up to npar 24 only (mcmcx_init): larger sizes are not instantiated -- at
+            // DRM = 2 (iC as a square in LDS) is the engine's choice up to npar 24 only (mcmcx_init): larger sizes are not instantiated --
+            // at
             // 28 / 32 they could not hold the two waves per SIMD they would declare (Weak 12)
             if constexpr (DRM != 2) {
                 switch (h->group_d4) {
@@ -485,17 +531,24 @@ static void launch_group_d4(mcmcx_engine *h, int it0, int it1)
                 default: break;
                 }
             }
-            h->launch_err = "group kernel: no instantiation for npar " + std::to_string(h->d) + " with delayed-rejection mode " + std::to_string(DRM);
+            h->launch_err = "group kernel: no instantiation for npar " + std::to_string(h->d) + " with delayed-rejection mode " +
+                std::to_string(DRM);
         }
     }
 }
 static const KernelEntry GROUP_TABLE[] = {
-    {"group", "group_step_kernel",            [](const mcmcx_engine *h) { return h->group_gw == 16 && h->group_drm == 0; }, launch_group_d4<16, 0>},
-    {"group", "group_step_kernel<DR>",        [](const mcmcx_engine *h) { return h->group_gw == 16 && h->group_drm == 1; }, launch_group_d4<16, 1>},
-    {"group", "group_step_kernel<DR2>",       [](const mcmcx_engine *h) { return h->group_gw == 16 && h->group_drm == 2; }, launch_group_d4<16, 2>},
-    {"group", "group_step_kernel<quad>",      [](const mcmcx_engine *h) { return h->group_gw == 4 && h->group_drm == 0; }, launch_group_d4<4, 0>},
-    {"group", "group_step_kernel<quad, DR>",  [](const mcmcx_engine *h) { return h->group_gw == 4 && h->group_drm == 1; }, launch_group_d4<4, 1>},
-    {"group", "group_step_kernel<quad, DR2>", [](const mcmcx_engine *h) { return h->group_gw == 4 && h->group_drm == 2; }, launch_group_d4<4, 2>},
+    {"group", "group_step_kernel",            [](const mcmcx_engine *h) { return h->group_gw == 16 && h->group_drm == 0; },
+        launch_group_d4<16, 0>},
+    {"group", "group_step_kernel<DR>",        [](const mcmcx_engine *h) { return h->group_gw == 16 && h->group_drm == 1; },
+        launch_group_d4<16, 1>},
+    {"group", "group_step_kernel<DR2>",       [](const mcmcx_engine *h) { return h->group_gw == 16 && h->group_drm == 2; },
+        launch_group_d4<16, 2>},
+    {"group", "group_step_kernel<quad>",      [](const mcmcx_engine *h) { return h->group_gw == 4 && h->group_drm == 0; },
+        launch_group_d4<4, 0>},
+    {"group", "group_step_kernel<quad, DR>",  [](const mcmcx_engine *h) { return h->group_gw == 4 && h->group_drm == 1; },
+        launch_group_d4<4, 1>},
+    {"group", "group_step_kernel<quad, DR2>", [](const mcmcx_engine *h) { return h->group_gw == 4 && h->group_drm == 2; },
+        launch_group_d4<4, 2>},
 };
 static void launch_group(mcmcx_engine *h, int it0, int it1)
 {
@@ -511,11 +564,13 @@ static void launch_group(mcmcx_engine *h, int it0, int it1)
     }
 }
 // pooled_mfma_kernel<false, true>: two waves per SIMD (256 registers, some state spilled) pay with more tiles than SIMDs: from two per SIMD
-// where the LDS vector lets eight waves on a CU (npar <= 39: +25 .. +55 %), from eight where it lets six (npar 50: 0.80 at 2048 tiles, 0.99 at
+// where the LDS vector lets eight waves on a CU (npar <= 39: +25 .. +55 %), from eight where it lets six (npar 50: 0.80 at 2048 tiles, 0.99
+// at
 // 4096, 1.14 at 16384); with one tile per SIMD the spills are all they buy (0.83 .. 0.90) -- tools/pooled_waves_probe.py
 static bool pooled_two_waves(const mcmcx_engine *h)
 {
-    if (h->sw.pooled_waves == 1 || h->sw.pooled_waves == 2) return h->sw.pooled_waves == 2;      // (test switch: either instance on a small problem)
+    // (test switch: either instance on a small problem)
+    if (h->sw.pooled_waves == 1 || h->sw.pooled_waves == 2) return h->sw.pooled_waves == 2;
     return h->ntiles >= (pooled_mfma_lds(h->d) * 8 <= 160 * 1024 ? 2048 : 8192);
 }
 #define STEP_ARGS h->stream, h->E, it0, it1
@@ -523,9 +578,12 @@ static bool pooled_two_waves(const mcmcx_engine *h)
 #define STEP_TGT h->E.tgt.mu, h->E.tgt.lamT
 #define G1 dim3(h->ntiles), dim3(64)
 // method = 'ram' with few chains: sixteen lanes per chain, the factor in registers, dchud / dchdd on it there (mcx_group_ram.hpp)
-// where it is the faster one (tools/ram_group_sweep.py, profiles/r05_b/ram_group_sweep.txt: chain-iterations/s of both families over npar, chain count and
-// regime): one wave per SIMD and four chains per wave, so the chip holds 4096 chains at once and the kernel saturates there (1.68e8 / 4.6e8 / 1.1e9
-// chain-iterations/s at npar 50 / 20 / 10) -- 9x / 6x / 6x the lane kernels up to 4096 chains, still 2.9x / 1.7x / 2.0x at 16384 and 1.6x / 1.1x / 1.2x
+// where it is the faster one (tools/ram_group_sweep.py, profiles/r05_b/ram_group_sweep.txt: chain-iterations/s of both families over npar,
+// chain count and
+// regime): one wave per SIMD and four chains per wave, so the chip holds 4096 chains at once and the kernel saturates there (1.68e8 / 4.6e8
+// / 1.1e9
+// chain-iterations/s at npar 50 / 20 / 10) -- 9x / 6x / 6x the lane kernels up to 4096 chains, still 2.9x / 1.7x / 2.0x at 16384 and 1.6x /
+// 1.1x / 1.2x
 // at 32768; from 65536 chains on the streaming kernels are ahead (0.93 / 0.74 / 0.63)
 static bool ram_group_wins(const mcmcx_engine *h)
 {
@@ -540,7 +598,8 @@ static bool ram_group_covers(const mcmcx_engine *h)
 template <int D4>
 static void launch_group_ram_d4(mcmcx_engine *h, int it0, int it1)
 {
-    hipLaunchKernelGGL((group_ram_kernel<D4, -1>), dim3(h->ntiles * 16), dim3(64), 0, h->stream, h->E, it0, it1, (const double *)h->d_ramscale, h->E.tgt.lamT, h->d_accb);
+    hipLaunchKernelGGL((group_ram_kernel<D4, -1>), dim3(h->ntiles * 16), dim3(64), 0, h->stream, h->E, it0, it1,
+        (const double *)h->d_ramscale, h->E.tgt.lamT, h->d_accb);
 }
 static void launch_group_ram(mcmcx_engine *h, int it0, int it1)
 {
@@ -561,36 +620,49 @@ static void launch_group_ram(mcmcx_engine *h, int it0, int it1)
 #else
 #define MCX_VARIANT_STEP_ENTRIES
 #define MCX_VARIANT_SVD_SWEEP(h, lss) false
+#define MCX_VARIANT_COV(h, g8, n10, noff, it, mode) false
 #endif
 static const KernelEntry STEP_TABLE[] = {
     // ---- a device target with response columns (nycol >= 1 sums of squares per point): the phases of an iteration in one launch
     {"step", "step_kernel_cols", fused_cols,
      [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_cols, G1, lds_step(h), STEP_ARGS, (const double *)h->d_ramscale,
-                                                                (const double *)(h->pooled ? h->E.sharedR : nullptr), (const double *)h->d_sharedR2, (const double *)h->d_sharediC); }},
+                                                                (const double *)(h->pooled ? h->E.sharedR : nullptr),
+                                                                    (const double *)h->d_sharedR2, (const double *)h->d_sharediC); }},
     // ---- pooled mode (one shared factor)
     {"step", "pooled_mfma_kernel<true>", [](const mcmcx_engine *h) { return pooled_use_mfma(h) && h->dodr != 0; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(pooled_mfma_kernel<true>, G1, pooled_mfma_lds(h->d), STEP_ARGS, STEP_TGT, h->d_sharedRT, h->d_sharedR2T, h->d_sharediCd); }},
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(pooled_mfma_kernel<true>, G1, pooled_mfma_lds(h->d), STEP_ARGS, STEP_TGT,
+         h->d_sharedRT, h->d_sharedR2T, h->d_sharediCd); }},
     MCX_VARIANT_STEP_ENTRIES
     {"step", "pooled_mfma_kernel<false, true>", [](const mcmcx_engine *h) { return pooled_use_mfma(h) && pooled_two_waves(h); },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((pooled_mfma_kernel<false, true>), G1, pooled_mfma_lds(h->d), STEP_ARGS, STEP_TGT, h->d_sharedRT, (const double *)nullptr, (const double *)nullptr); }},
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((pooled_mfma_kernel<false, true>), G1, pooled_mfma_lds(h->d), STEP_ARGS,
+         STEP_TGT, h->d_sharedRT, (const double *)nullptr, (const double *)nullptr); }},
     {"step", "pooled_mfma_kernel<false>", [](const mcmcx_engine *h) { return pooled_use_mfma(h); },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(pooled_mfma_kernel<false>, G1, pooled_mfma_lds(h->d), STEP_ARGS, STEP_TGT, h->d_sharedRT, (const double *)nullptr, (const double *)nullptr); }},
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(pooled_mfma_kernel<false>, G1, pooled_mfma_lds(h->d), STEP_ARGS, STEP_TGT,
+         h->d_sharedRT, (const double *)nullptr, (const double *)nullptr); }},
     {"step", "step_kernel_pooled_dr_big", [](const mcmcx_engine *h) { return h->pooled && h->dodr && !dr_vectors_in_lds(h, 4); },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_pooled_dr_big, G1, 0, STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR, h->d_sharedR2, h->d_sharediC); }},
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_pooled_dr_big, G1, 0, STEP_ARGS, STEP_RS, STEP_TGT,
+         h->E.sharedR, h->d_sharedR2, h->d_sharediC); }},
     {"step", "step_kernel_pooled_dr", [](const mcmcx_engine *h) { return h->pooled && h->dodr; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_pooled_dr, G1, lds_step(h), STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR, h->d_sharedR2, h->d_sharediC); }},
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_pooled_dr, G1, lds_step(h), STEP_ARGS, STEP_RS, STEP_TGT,
+         h->E.sharedR, h->d_sharedR2, h->d_sharediC); }},
     {"step", "step_kernel<false, false, true>", [](const mcmcx_engine *h) { return h->pooled != 0; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((step_kernel<false, false, true>), G1, 0, STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((step_kernel<false, false, true>), G1, 0, STEP_ARGS, STEP_RS, STEP_TGT,
+         h->E.sharedR); }},
     // ---- method = 'ram', per-chain factors
     {"step", "group_ram_kernel", [](const mcmcx_engine *h) { return h->ram_group_d4 != 0; }, launch_group_ram},
     {"step", "step_kernel_ram_fullr", [](const mcmcx_engine *h) { return h->E.method == M_RAM && h->usesvd; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ram_fullr, G1, 0, STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ram_fullr, G1, 0, STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR);
+         }},
     {"step", "step_kernel_ram_ldsr", [](const mcmcx_engine *h) { return h->E.method == M_RAM && h->E.lds_scratch == 3; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ram_ldsr, G1, (size_t)(2 * h->d + h->P) * 64 * sizeof(double), STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
-    {"step", "step_kernel_ram_wide", [](const mcmcx_engine *h) { return h->E.method == M_RAM && h->d > RAM_SMALL_MAX && h->sw.ram_wide != 0; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ram_wide, G1, (size_t)NLC * 2 * 64 * sizeof(double), STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ram_ldsr, G1, (size_t)(2 * h->d + h->P) * 64 * sizeof(double),
+         STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
+    {"step", "step_kernel_ram_wide", [](const mcmcx_engine *h) {
+        return h->E.method == M_RAM && h->d > RAM_SMALL_MAX && h->sw.ram_wide != 0; },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ram_wide, G1, (size_t)NLC * 2 * 64 * sizeof(double), STEP_ARGS,
+         STEP_RS, STEP_TGT, h->E.sharedR); }},
     {"step", "step_kernel<true, false, false>", [](const mcmcx_engine *h) { return h->E.method == M_RAM; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((step_kernel<true, false, false>), G1, (size_t)NLC * 2 * 64 * sizeof(double), STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((step_kernel<true, false, false>), G1,
+         (size_t)NLC * 2 * 64 * sizeof(double), STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
     // ---- delayed rejection, per-chain factors: the second stage's two vectors in global scratch / in LDS
     {"step", "step_kernel_dr_big", [](const mcmcx_engine *h) { return h->dodr && !dr_vectors_in_lds(h); },
      [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_dr_big, G1, 0, STEP_ARGS, STEP_TGT); }},
@@ -598,11 +670,14 @@ static const KernelEntry STEP_TABLE[] = {
      [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_dr, G1, lds_step(h), STEP_ARGS, STEP_TGT); }},
     // ---- AM / Metropolis / early rejection: state + factor in LDS, state in LDS, nothing in LDS
     {"step", "step_kernel_ldsr", [](const mcmcx_engine *h) { return h->E.lds_scratch == 2; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ldsr, G1, (size_t)(2 * h->d + h->P) * 64 * sizeof(double), STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ldsr, G1, (size_t)(2 * h->d + h->P) * 64 * sizeof(double),
+         STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
     {"step", "step_kernel_ldsv", [](const mcmcx_engine *h) { return h->E.lds_scratch != 0; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ldsv, G1, (size_t)4 * h->d * 64 * sizeof(double), STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ldsv, G1, (size_t)4 * h->d * 64 * sizeof(double), STEP_ARGS,
+         STEP_RS, STEP_TGT, h->E.sharedR); }},
     {"step", "step_kernel<false, false, false>", [](const mcmcx_engine *) { return true; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((step_kernel<false, false, false>), G1, 0, STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((step_kernel<false, false, false>), G1, 0, STEP_ARGS, STEP_RS, STEP_TGT,
+         h->E.sharedR); }},
 };
 static void launch_step(mcmcx_engine *h, int it0, int it1)
 {
@@ -643,8 +718,11 @@ static int upload_shared_rf(mcmcx_engine *h)            // dense M[s*d + o] = Rf
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
-static size_t shared_u_stride(const mcmcx_engine *h) { return (size_t)((h->d + 3) & ~3) * h->d + PWS; }     // d4 rows (pad rows zero) + slack
-static size_t scam_pooled_lds(int d) { return ((size_t)((d + 15) / 16) * (16 + 4) * 64 + 128 + (size_t)((d + 15) / 16) * 16) * sizeof(double); }     // X [16 nt][64], Q [4 nt][64], zb, fl, mu [16 nt]
+// d4 rows (pad rows zero) + slack
+static size_t shared_u_stride(const mcmcx_engine *h) { return (size_t)((h->d + 3) & ~3) * h->d + PWS; }
+// X [16 nt][64], Q [4 nt][64], zb, fl, mu [16 nt]
+static size_t scam_pooled_lds(int d) {
+    return ((size_t)((d + 15) / 16) * (16 + 4) * 64 + 128 + (size_t)((d + 15) / 16) * 16) * sizeof(double); }
 static int upload_shared_u(mcmcx_engine *h)
 {
     if (h->scam_replicated) {                           // every chain's own copy of the one rotation and its scales
@@ -653,7 +731,8 @@ static int upload_shared_u(mcmcx_engine *h)
     }
     const int d = h->d; const size_t st = shared_u_stride(h);
     std::vector<double> b(2 * st + d, 0.0);
-    for (int j = 0; j < d; ++j) for (int i = 0; i < d; ++i) { b[(size_t)j * d + i] = h->pool_U[(size_t)j * d + i]; b[st + (size_t)i * d + j] = h->pool_U[(size_t)j * d + i]; }
+    for (int j = 0; j < d; ++j) for (int i = 0; i < d; ++i) { b[(size_t)j * d + i] = h->pool_U[(size_t)j * d + i];
+        b[st + (size_t)i * d + j] = h->pool_U[(size_t)j * d + i]; }
     for (int i = 0; i < d; ++i) b[2 * st + i] = h->pool_std[i];
     HIPCHK(hipMemcpyAsync(h->d_sharedU, b.data(), b.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -680,33 +759,42 @@ static size_t scam_mw_lds(const mcmcx_engine *h) { return (size_t)(4 * ((h->d + 
 static int scam_tile_waves(const mcmcx_engine *h)
 {
     int nw = 1;
-    while (nw < 8 && (long long)h->ntiles * nw * 2 <= 8192) nw *= 2;                       // (1024 tiles x npar 200: 8.4e6 at two waves per tile, 8.9e6 at four, 9.0e6 at eight -- profiles/r05_d/c5rep_waves.txt)
+    // (1024 tiles x npar 200: 8.4e6 at two waves per tile, 8.9e6 at four, 9.0e6 at eight -- profiles/r05_d/c5rep_waves.txt)
+    while (nw < 8 && (long long)h->ntiles * nw * 2 <= 8192) nw *= 2;
     { const int v = h->sw.scam_waves; if (v == 1 || v == 2 || v == 4 || v == 8) nw = v; }   // A/B switch for tests
-    if (scam_mw_lds(h) > 160 * 1024) nw = 1;                                               // (npar > 1200: the one-wave kernel needs no LDS)
+    // (npar > 1200: the one-wave kernel needs no LDS)
+    if (scam_mw_lds(h) > 160 * 1024) nw = 1;
     return nw;
 }
 #define SCAM_POOLED_ARGS scam_pooled_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT
 static const KernelEntry SCAM_TABLE[] = {
     {"scam", "step_kernel_cols<scam>", [](const mcmcx_engine *h) { return fused_cols(h) && !h->pooled; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_cols, G1, 0, STEP_ARGS, (const double *)h->d_ramscale, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr); }},
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_cols, G1, 0, STEP_ARGS, (const double *)h->d_ramscale,
+         (const double *)nullptr, (const double *)nullptr, (const double *)nullptr); }},
     // pooled: 16-row output blocks, min(12, 4*(nt/4)) block waves + 4 chain-group waves; twelve waves of 170 registers for 13..15 blocks
     {"scam", "scam_pooled12_kernel", [](const mcmcx_engine *h) { return h->pooled && !h->scam_replicated && scam_use_12(h); },
      [](mcmcx_engine *h, int it0, int it1) { const size_t st = shared_u_stride(h);
-        hipLaunchKernelGGL(scam_pooled12_kernel, dim3(h->ntiles), dim3(768), SCAM_POOLED_ARGS, h->d_sharedU, h->d_sharedU + st, h->d_sharedU + 2 * st); }},
+        hipLaunchKernelGGL(scam_pooled12_kernel, dim3(h->ntiles), dim3(768), SCAM_POOLED_ARGS, h->d_sharedU, h->d_sharedU + st,
+            h->d_sharedU + 2 * st); }},
     {"scam", "scam_pooled_kernel", [](const mcmcx_engine *h) { return h->pooled && !h->scam_replicated; },
      [](mcmcx_engine *h, int it0, int it1) { const size_t st = shared_u_stride(h); const int nw = 4 + std::min(12, ((h->d + 15) / 16) & ~3);
-        hipLaunchKernelGGL(scam_pooled_kernel, dim3(h->ntiles), dim3(64 * nw), SCAM_POOLED_ARGS, h->d_sharedU, h->d_sharedU + st, h->d_sharedU + 2 * st); }},
+        hipLaunchKernelGGL(scam_pooled_kernel, dim3(h->ntiles), dim3(64 * nw), SCAM_POOLED_ARGS, h->d_sharedU, h->d_sharedU + st,
+            h->d_sharedU + 2 * st); }},
     // (the sixteen-wave layout whatever npar: every lane fetches the column of its own chain's factor per sub-step, and four
     //  waves per SIMD cover that better than three -- 4.62e8 against 4.45e8 proposals/s at npar 200)
     {"scam", "scam_pooled_kernel<per-chain>", scam_fast_tile_kernel,
      [](mcmcx_engine *h, int it0, int it1) { const int nw = 4 + std::min(12, ((h->d + 15) / 16) & ~3);
-        hipLaunchKernelGGL(scam_pooled_kernel, dim3(h->ntiles), dim3(64 * nw), SCAM_POOLED_ARGS, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr); }},
+        hipLaunchKernelGGL(scam_pooled_kernel, dim3(h->ntiles), dim3(64 * nw), SCAM_POOLED_ARGS, (const double *)nullptr,
+            (const double *)nullptr, (const double *)nullptr); }},
     {"scam", "scam_mw_kernel<8>", [](const mcmcx_engine *h) { return scam_tile_waves(h) == 8; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(scam_mw_kernel<8>, dim3(h->ntiles), dim3(512), scam_mw_lds(h), STEP_ARGS, STEP_TGT); }},
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(scam_mw_kernel<8>, dim3(h->ntiles), dim3(512), scam_mw_lds(h), STEP_ARGS,
+         STEP_TGT); }},
     {"scam", "scam_mw_kernel<4>", [](const mcmcx_engine *h) { return scam_tile_waves(h) == 4; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(scam_mw_kernel<4>, dim3(h->ntiles), dim3(256), scam_mw_lds(h), STEP_ARGS, STEP_TGT); }},
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(scam_mw_kernel<4>, dim3(h->ntiles), dim3(256), scam_mw_lds(h), STEP_ARGS,
+         STEP_TGT); }},
     {"scam", "scam_mw_kernel<2>", [](const mcmcx_engine *h) { return scam_tile_waves(h) == 2; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(scam_mw_kernel<2>, dim3(h->ntiles), dim3(128), scam_mw_lds(h), STEP_ARGS, STEP_TGT); }},
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(scam_mw_kernel<2>, dim3(h->ntiles), dim3(128), scam_mw_lds(h), STEP_ARGS,
+         STEP_TGT); }},
     {"scam", "scam_kernel", [](const mcmcx_engine *) { return true; },
      [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(scam_kernel, G1, 0, STEP_ARGS, STEP_TGT); }},
 };
@@ -718,17 +806,21 @@ static void launch_scam(mcmcx_engine *h, int it0, int it1)
 static bool svd_blocked(const mcmcx_engine *h)
 {
     if (!h->usesvd || h->pooled || h->cfg.method == MCMCX_METHOD_RAM) return false;
-    if (h->sw.svd_lane > 0) return false;                                             // test switch: the lane SVD (the engine's form below npar 48 and above 256)
-    return h->d >= 48 && h->d <= 256;                                                  // (its rings and row groups are instantiated up to npar 256)
+    // test switch: the lane SVD (the engine's form below npar 48 and above 256)
+    if (h->sw.svd_lane > 0) return false;
+    // (its rings and row groups are instantiated up to npar 256)
+    return h->d >= 48 && h->d <= 256;
 }
 static void launch_adapt(mcmcx_engine *h, int it, int mode)
 {
-    const size_t lds = std::max(lds_bytes(h) / 2, (size_t)36 * 64 * sizeof(double));    // one d-vector / the Cholesky's diagonal block (18 kB: eight waves per CU up to npar 36)
+    // one d-vector / the Cholesky's diagonal block (18 kB: eight waves per CU up to npar 36)
+    const size_t lds = std::max(lds_bytes(h) / 2, (size_t)36 * 64 * sizeof(double));
     hipLaunchKernelGGL(adapt_pre_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it, mode);
     // covmat's batch branch in blocks (adapt_covb_*): the AP window at every adaptation; with initcmatn = 0 the first AM adaptation and
     // the greedy restarts.  Which lanes take it is the lanes' own business (ADF_BATCH); a tick that cannot hold any skips the launches.
     const bool ap = (mode & AD_AM) && h->cfg.adapthist > 1;
-    const int batch_done = (!(h->sw.cov_batch_rows > 0) &&                                                          // (test switch: covmat_rows, the lane form)
+    // (test switch: covmat_rows, the lane form)
+    const int batch_done = (!(h->sw.cov_batch_rows > 0) &&
                             (ap || (h->cfg.initcmatn == 0 && ((mode & AD_FIRST) || ((mode & AD_BURN) && h->cfg.greedy != 0))))) ? 1 : 0;
     if (batch_done) {
         const int n10 = (h->d + TD - 1) / TD, noff = n10 * (n10 - 1) / 2;
@@ -740,21 +832,28 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
         // blocks of ten (triangular on the diagonal)
         const int n10 = (h->d + TD - 1) / TD, noff = n10 * (n10 - 1) / 2;
         const unsigned g8 = (unsigned)(8 * ((h->ntiles + 7) / 8));
-        // (LDS: the per-lane FIFO between the window's walk and the folds, mcx_adapt.hpp: CQ entries of 1 + TD / 1 + 2 TD doubles per lane)
-        hipLaunchKernelGGL(adapt_cov_diag_kernel, dim3(g8 * n10), dim3(64), (size_t)CQ * (1 + TD) * 64 * sizeof(double), h->stream, h->E, it, mode, n10);
-        if (noff > 0) hipLaunchKernelGGL(adapt_cov_off_kernel, dim3(g8 * noff), dim3(64), (size_t)CQ * (1 + 2 * TD) * 64 * sizeof(double), h->stream, h->E, it, mode, noff);
+        if (MCX_VARIANT_COV(h, g8, n10, noff, it, mode)) {}
+        else {
+            hipLaunchKernelGGL(adapt_cov_diag_kernel, dim3(g8 * n10), dim3(64), 0, h->stream, h->E, it, mode, n10);
+            if (noff > 0) hipLaunchKernelGGL(adapt_cov_off_kernel, dim3(g8 * noff), dim3(64), 0, h->stream, h->E, it, mode, noff);
+        }
     }
     if (!h->d_Gc) {
         if (lds > 160 * 1024) {                             // npar > 320: the work vector in global scratch (slower; no limit)
-            if (h->usesvd) hipLaunchKernelGGL((adapt_post_kernel<true, true>), dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr, batch_done);
-            else hipLaunchKernelGGL((adapt_post_kernel<false, true>), dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr, batch_done);
+            if (h->usesvd) hipLaunchKernelGGL((adapt_post_kernel<true, true>), dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it, mode, 0,
+                (uint8_t *)nullptr, batch_done);
+            else hipLaunchKernelGGL((adapt_post_kernel<false, true>), dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it, mode, 0,
+                (uint8_t *)nullptr, batch_done);
             return;
         }
-        if (h->usesvd) hipLaunchKernelGGL(adapt_post_kernel<true>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr, batch_done);
+        if (h->usesvd) hipLaunchKernelGGL(adapt_post_kernel<true>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 0,
+            (uint8_t *)nullptr, batch_done);
         else if (h->tile_factor) {
-            // dpotf2 (+ dtrti2 / dlauu2 with delayed rejection) with the packed matrices of 4 NW neighbouring chains in LDS, read and written
+            // dpotf2 (+ dtrti2 / dlauu2 with delayed rejection) with the packed matrices of 4 NW neighbouring chains in LDS, read and
+            // written
             // once (mcx_group.hpp: tile_factor_kernel); adapt_post_kernel keeps the covariance bookkeeping (phase 3)
-            hipLaunchKernelGGL(adapt_post_kernel<false>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 3, (uint8_t *)nullptr, batch_done);
+            hipLaunchKernelGGL(adapt_post_kernel<false>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 3, (uint8_t *)nullptr,
+                batch_done);
             const int nc = (h->d + 15) / 16, nw = nc <= 2 ? 4 : nc == 3 ? 2 : 1, ch = 4 * nw;
             const size_t tl = (size_t)ch * (h->P | 1) * sizeof(double) + (size_t)ch * sizeof(int);
             const dim3 tg((unsigned)(8 * ((h->ntiles + 7) / 8) * (64 / ch)));
@@ -765,7 +864,8 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
             default: hipLaunchKernelGGL((tile_factor_kernel<4, 1>), tg, dim3(64), tl, h->stream, h->E); break;
             }
         }
-        else hipLaunchKernelGGL(adapt_post_kernel<false>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr, batch_done);
+        else hipLaunchKernelGGL(adapt_post_kernel<false>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr,
+            batch_done);
         return;
     }
     // large npar with an SVD factor: the factorisation runs one workgroup per chain on chain-major copies, one launch
@@ -777,36 +877,51 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
     hipLaunchKernelGGL(svd_init_kernel, dim3(h->nlanes), dim3(256), 0, h->stream, h->d_Vc, h->d_state, h->d_need, h->nlanes, h->d);
     for (int sweep = 0; sweep < 60; ++sweep) {
         (void)hipMemsetAsync(h->d_anyrot, 0, sizeof(int), h->stream);
-        // the sweep: every later column streamed past a block's pair-lanes through an LDS ring (mcx_svd.hpp) -- all 32 lanes of a row group on
+        // the sweep: every later column streamed past a block's pair-lanes through an LDS ring (mcx_svd.hpp) -- all 32 lanes of a row group
+        // on
         // pairs up to npar 200 (svd_sweep_stream32_kernel), 24 pair-lanes and a wave of loaders above (svd_sweep_stream_kernel)
         if (h->d <= 200) {
             const int RLs = h->d <= 64 ? 8 : h->d <= 128 ? 16 : 25;
             const size_t lss = (size_t)33 * (8 * RLs + 2) * sizeof(double);
             if (MCX_VARIANT_SVD_SWEEP(h, lss)) {}
-            else if (h->d <= 64) hipLaunchKernelGGL(svd_sweep_stream32_kernel<8>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
-            else if (h->d <= 128) hipLaunchKernelGGL(svd_sweep_stream32_kernel<16>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
-            else hipLaunchKernelGGL(svd_sweep_stream32_kernel<25>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
+            else if (h->d <= 64) hipLaunchKernelGGL(svd_sweep_stream32_kernel<8>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc,
+                (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
+            else if (h->d <= 128) hipLaunchKernelGGL(svd_sweep_stream32_kernel<16>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc,
+                (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
+            else hipLaunchKernelGGL(svd_sweep_stream32_kernel<25>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw,
+                h->d_state, h->d_anyrot, h->nlanes, h->d);
         } else {
-            constexpr int svd_sb = 24;                   // pair-lanes of the streamed sweep: whole waves of octets, one wave of loaders at least
+            // pair-lanes of the streamed sweep: whole waves of octets, one wave of loaders at least
+            constexpr int svd_sb = 24;
             const int RLs = h->d <= 208 ? 26 : 32;
             const size_t lss = (size_t)(svd_sb + 2) * (8 * RLs + 2) * sizeof(double);
-            if (h->d <= 208) hipLaunchKernelGGL(svd_sweep_stream_kernel<26>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d, svd_sb);
-            else hipLaunchKernelGGL(svd_sweep_stream_kernel<32>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d, svd_sb);
+            if (h->d <= 208) hipLaunchKernelGGL(svd_sweep_stream_kernel<26>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc,
+                (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d, svd_sb);
+            else hipLaunchKernelGGL(svd_sweep_stream_kernel<32>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw,
+                h->d_state, h->d_anyrot, h->nlanes, h->d, svd_sb);
         }
         {                                                // the log replayed on V: all 32 lanes of a row group on pairs, any npar
-            const unsigned gv = (unsigned)(32 * ((h->nlanes + 7) / 8));                     // four one-wave workgroups per chain, a chain's on one XCD
+            // four one-wave workgroups per chain, a chain's on one XCD
+            const unsigned gv = (unsigned)(32 * ((h->nlanes + 7) / 8));
             const int RP = h->d <= 64 ? 4 : h->d <= 128 ? 8 : h->d <= 208 ? 13 : 16;
             const size_t lsv2 = (size_t)33 * (4 * RP + 6) * sizeof(double);
-            if (h->d <= 64) hipLaunchKernelGGL(svd_applyv_stream32_kernel<4>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d);
-            else if (h->d <= 128) hipLaunchKernelGGL(svd_applyv_stream32_kernel<8>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d);
-            else if (h->d <= 208) hipLaunchKernelGGL(svd_applyv_stream32_kernel<13>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d);
-            else hipLaunchKernelGGL(svd_applyv_stream32_kernel<16>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d);
+            if (h->d <= 64) hipLaunchKernelGGL(svd_applyv_stream32_kernel<4>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc,
+                (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d);
+            else if (h->d <= 128) hipLaunchKernelGGL(svd_applyv_stream32_kernel<8>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc,
+                (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d);
+            else if (h->d <= 208) hipLaunchKernelGGL(svd_applyv_stream32_kernel<13>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc,
+                (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d);
+            else hipLaunchKernelGGL(svd_applyv_stream32_kernel<16>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw,
+                h->d_state, h->nlanes, h->d);
         }
         int any = 0;
-        if (hipMemcpyAsync(&any, h->d_anyrot, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) break;   // (reported by the caller's hipGetLastError)
+        // (reported by the caller's hipGetLastError)
+        if (hipMemcpyAsync(&any, h->d_anyrot, sizeof(int), hipMemcpyDeviceToHost,
+            h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) break;
         if (!any) break;
     }
-    hipLaunchKernelGGL(svd_finish_kernel, dim3(h->nlanes), dim3(256), 0, h->stream, h->d_Gc, h->d_Vc, h->d_svc, h->d_state, h->nlanes, h->d);
+    hipLaunchKernelGGL(svd_finish_kernel, dim3(h->nlanes), dim3(256), 0, h->stream, h->d_Gc, h->d_Vc, h->d_svc, h->d_state, h->nlanes,
+        h->d);
     hipLaunchKernelGGL(chain2tile_kernel, tg, dim3(256), 0, h->stream, h->d_Gc, h->E.Vw, DD, DD, h->d_need);
     hipLaunchKernelGGL(chain2tile_kernel, tg1, dim3(256), 0, h->stream, h->d_svc, h->E.cs, (size_t)h->d, (size_t)2 * h->d, h->d_need);
     hipLaunchKernelGGL(adapt_post_kernel<true>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 2, h->d_need, batch_done);
@@ -891,7 +1006,8 @@ static int pooled_vec_len(const mcmcx_engine *h, int kind);
 // slot carries one more element behind the vector, the rank's STOP FLAG (1 = a signal was caught here): its sum over the
 // ranks comes back with the moments, so the decision to leave a run that has collectives ahead is taken by all ranks at
 // the same tick (a rank that returned alone would leave its peers waiting in the next gather).
-static int allreduce_moments_enqueue(mcmcx_engine *h, int stage /* 0 all, 1 local part, 2 gather, 3 tree */, int kind = 0, int it = 0, double flag = 0.0)
+static int allreduce_moments_enqueue(mcmcx_engine *h, int stage /* 0 all, 1 local part, 2 gather, 3 tree */, int kind = 0, int it = 0,
+    double flag = 0.0)
 {
     const int len = pooled_vec_len(h, kind), st = len + 1;
     const int nr = h->comm ? h->comm->nranks : 1, rk = h->comm ? h->comm->rank : 0;
@@ -922,7 +1038,8 @@ static int pooled_reduce(mcmcx_engine *h, int kind, int it, std::vector<double> 
 {
     const int len = pooled_vec_len(h, kind);
     v.assign(len + 1, 0.0);
-    if (h->xfn && kind != 0) return fail(-8, "pooled burn-in scaling and the pooled RAM variant exchange through a communicator (mcmcx_set_comm), not through the mcmcx_set_exchange hook");
+    if (h->xfn && kind != 0) return
+        fail(-8, "pooled burn-in scaling and the pooled RAM variant exchange through a communicator (mcmcx_set_comm), not through the mcmcx_set_exchange hook");
     if (!h->xfn) {
         int rc = allreduce_moments_enqueue(h, 0, kind, it, (collective_run(h) && g_interrupt) ? 1.0 : 0.0); if (rc) return rc;
         if ((rc = comm_wait_stream(h->comm, h->stream))) return rc;
@@ -938,8 +1055,11 @@ static int pooled_reduce(mcmcx_engine *h, int kind, int it, std::vector<double> 
     v.resize(len);
     if (collective_run(h) && stop != 0.0) h->stop_seen = true;
     // the vector has been through an exchange: refuse to merge garbage (it would poison the pooled state for the rest of the run)
-    if (!(v[0] >= 2.0) || !std::isfinite(v[0])) return fail(-46, "pooled adaptation needs at least 2 chains over all ranks (count = " + std::to_string(v[0]) + ")");
-    for (int k = 1; k < len; ++k) if (!std::isfinite(v[k])) return fail(-46, "pooled adaptation: non-finite pooled statistic at iteration " + std::to_string(it));
+    if (!(v[0] >= 2.0) || !std::isfinite(v[0])) return fail(-46, "pooled adaptation needs at least 2 chains over all ranks (count = " +
+        std::to_string(v[0]) + ")");
+    for (int k = 1; k < len;
+        ++k) if (!std::isfinite(v[k])) return fail(-46, "pooled adaptation: non-finite pooled statistic at iteration " +
+        std::to_string(it));
     return 0;
 }
 
@@ -957,7 +1077,8 @@ static int pooled_upload_dr(mcmcx_engine *h, bool fresh)
             for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) iC[h_pidx(i, j, d)] = h->pool_Rf[(size_t)j * d + i];
         } else { h->pool_R2 = h->pool_R; iC = h->pool_R; }
         for (auto &v : h->pool_R2) v = v / h->cfg.drscale;
-        if (host_potri(d, iC) != 0) h->pool_status |= ST_POTRI_FAIL;          // the reference stops ("cannot invert cmat"); the old iC stays
+        // the reference stops ("cannot invert cmat"); the old iC stays
+        if (host_potri(d, iC) != 0) h->pool_status |= ST_POTRI_FAIL;
         else h->pool_iC = iC;
     }
     std::vector<double> r2 = h->pool_R2;
@@ -965,12 +1086,15 @@ static int pooled_upload_dr(mcmcx_engine *h, bool fresh)
     HIPCHK(hipMemcpyAsync(h->d_sharedR2, r2.data(), r2.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_sharediC, h->pool_iC.data(), (size_t)P * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (h->d_sharedR2T) {                                  // pooled_mfma_kernel<true>: R2 like d_sharedRT (M[s*d + o] = R2(s,o)), iC dense symmetric
+    // pooled_mfma_kernel<true>: R2 like d_sharedRT (M[s*d + o] = R2(s,o)), iC dense symmetric
+    if (h->d_sharedR2T) {
         const int d4 = (d + 3) & ~3;
         std::vector<double> m((size_t)d4 * d + PWS, 0.0), q((size_t)d4 * d + PWS, 0.0);
-        if (h->usesvd) memcpy(m.data(), h->pool_R2.data(), (size_t)d * d * 8);          // the full factor as it stands: M[s*d + o] = R2f(o, s)
+        // the full factor as it stands: M[s*d + o] = R2f(o, s)
+        if (h->usesvd) memcpy(m.data(), h->pool_R2.data(), (size_t)d * d * 8);
         else for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) m[(size_t)i * d + j] = h->pool_R2[h_pidx(i, j, d)];
-        for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) { const double v = h->pool_iC[h_pidx(i, j, d)]; q[(size_t)i * d + j] = v; q[(size_t)j * d + i] = v; }
+        for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) { const double v = h->pool_iC[h_pidx(i, j, d)]; q[(size_t)i * d + j] = v;
+            q[(size_t)j * d + i] = v; }
         HIPCHK(hipMemcpyAsync(h->d_sharedR2T, m.data(), m.size() * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d_sharediCd, q.data(), q.size() * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -1004,7 +1128,8 @@ static int pooled_factor(mcmcx_engine *h)
         std::vector<double> Rf, sd, fc;
         if (host_initial_svd(d, cm, c.condmax, false, Rf, sd, &fc) == 0) {
             h->pool_Rf = Rf;
-            if (!fc.empty()) for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) h->pool_C[h_pidx(i, j, d)] = fc[(size_t)i + (size_t)j * d];
+            if (!fc.empty()) for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) h->pool_C[h_pidx(i, j,
+                d)] = fc[(size_t)i + (size_t)j * d];
             int rc = pooled_upload_R(h);
             return rc ? rc : pooled_upload_dr(h, true);
         }
@@ -1172,7 +1297,8 @@ static int host_eval(mcmcx_engine *h, const double *dev_src, int stride_k, bool 
     const int ny = h->ny, nhe = NHE - 1 + ny;
     const bool src_mapped = h->host_mapped && (dev_src == h->E.cand || h->cs_mapped);
     const bool mapped = h->host_mapped;                  // flags and results in place
-    if ((!src_mapped && h->h_cand.resize(L * stride_k)) || (!mapped && (h->h_ev.resize(L * nhe) || (use_stage2_flag && h->h_hx.resize(L * NHX)))))
+    if ((!src_mapped && h->h_cand.resize(L * stride_k)) || (!mapped && (h->h_ev.resize(L * nhe) || (use_stage2_flag
+        && h->h_hx.resize(L * NHX)))))
         return fail(-100, "host callbacks: no page-locked memory for the candidates");
     std::vector<double> ssc(ny, 0.0);
     if (!src_mapped) HIPCHK(hipMemcpyAsync(h->h_cand.data(), dev_src, L * stride_k * 8, hipMemcpyDeviceToHost, h->stream));
@@ -1210,7 +1336,8 @@ static int host_eval(mcmcx_engine *h, const double *dev_src, int stride_k, bool 
             std::vector<std::thread> pool;
             for (int w = 0; w < nt; ++w) {
                 const int lo = (int)((long long)n * w / nt), hi = (int)((long long)n * (w + 1) / nt);
-                if (hi > lo) pool.emplace_back([=]() { h->h_ss_batch(h->h_bth.data() + (size_t)lo * d, d, hi - lo, ny, h->h_bss.data() + (size_t)lo * ny, h->h_user); });
+                if (hi > lo) pool.emplace_back([=]() { h->h_ss_batch(h->h_bth.data() + (size_t)lo * d, d, hi - lo, ny,
+                    h->h_bss.data() + (size_t)lo * ny, h->h_user); });
             }
             for (auto &t : pool) t.join();
         }
@@ -1247,7 +1374,8 @@ static int host_eval(mcmcx_engine *h, const double *dev_src, int stride_k, bool 
     return 0;
 }
 
-// fuse_next: iteration it + 1 follows without a tick in between -- its proposal (phase 0; SCAM: component 0's phase 5) rides in this iteration's
+// fuse_next: iteration it + 1 follows without a tick in between -- its proposal (phase 0; SCAM: component 0's phase 5) rides in this
+// iteration's
 // last launch, and h->p0_done tells the next call so (MCMCX_HOST_FUSE=0: one launch per phase, the A/B form the tests compare with)
 static int host_iteration(mcmcx_engine *h, int it, bool fuse_next)
 {
@@ -1260,11 +1388,14 @@ static int host_iteration(mcmcx_engine *h, int it, bool fuse_next)
     h->p0_done = false;
     if (h->cfg.method == MCMCX_METHOD_SCAM) {           // MCMC_run_scam: npar componentwise proposals, each evaluated by the host
         for (int j = 0; j < h->d; ++j) {
-            if (!(j == 0 ? p0_done : fuse)) { hipLaunchKernelGGL((host_phase_kernel<5>), g, b, 0, h->stream, h->E, it, rs, j); HIPCHK(hipGetLastError()); }
+            if (!(j == 0 ? p0_done : fuse)) { hipLaunchKernelGGL((host_phase_kernel<5>), g, b, 0, h->stream, h->E, it, rs, j);
+                HIPCHK(hipGetLastError()); }
             int rc = host_eval(h, h->E.cand, h->d, false); if (rc) return rc;
             if (!fuse) hipLaunchKernelGGL((host_phase_kernel<6>), g, b, 0, h->stream, h->E, it, rs, j);
-            else if (j + 1 < h->d) hipLaunchKernelGGL((host_phase_seq_kernel<6, 5, -1>), g, b, 0, h->stream, h->E, it, j, it, j + 1, 0, 0, rs0);
-            else if (fuse_next) { hipLaunchKernelGGL((host_phase_seq_kernel<6, 7, 5>), g, b, 0, h->stream, h->E, it, j, it, 0, it + 1, 0, rs0); h->p0_done = true; }
+            else if (j + 1 < h->d) hipLaunchKernelGGL((host_phase_seq_kernel<6, 5, -1>), g, b, 0, h->stream, h->E, it, j, it, j + 1, 0, 0,
+                rs0);
+            else if (fuse_next) { hipLaunchKernelGGL((host_phase_seq_kernel<6, 7, 5>), g, b, 0, h->stream, h->E, it, j, it, 0, it + 1, 0,
+                rs0); h->p0_done = true; }
             else hipLaunchKernelGGL((host_phase_seq_kernel<6, 7, -1>), g, b, 0, h->stream, h->E, it, j, it, 0, 0, 0, rs0);
             HIPCHK(hipGetLastError());
         }
@@ -1277,18 +1408,21 @@ static int host_iteration(mcmcx_engine *h, int it, bool fuse_next)
         hipLaunchKernelGGL((host_phase_kernel<3>), g, b, 0, h->stream, h->E, it, rs, 0);
         HIPCHK(hipGetLastError());
         rc = host_eval(h, h->E.cand, h->d, true, 2); if (rc) return rc;
-        if (fuse_next) { hipLaunchKernelGGL((host_phase_seq_kernel<4, 0, -1>), g, b, 0, h->stream, h->E, it, 0, it + 1, 0, 0, 0, rs0); h->p0_done = true; }
+        if (fuse_next) { hipLaunchKernelGGL((host_phase_seq_kernel<4, 0, -1>), g, b, 0, h->stream, h->E, it, 0, it + 1, 0, 0, 0, rs0);
+            h->p0_done = true; }
         else hipLaunchKernelGGL((host_phase_kernel<4>), g, b, 0, h->stream, h->E, it, rs, 0);
         HIPCHK(hipGetLastError());
         return 0;
     }
     int rc = host_eval(h, h->E.cand, h->d, false); if (rc) return rc;
-    if (fuse_next && !h->dodr) { hipLaunchKernelGGL((host_phase_seq_kernel<1, 0, -1>), g, b, 0, h->stream, h->E, it, 0, it + 1, 0, 0, 0, rs0); h->p0_done = true; }
+    if (fuse_next && !h->dodr) { hipLaunchKernelGGL((host_phase_seq_kernel<1, 0, -1>), g, b, 0, h->stream, h->E, it, 0, it + 1, 0, 0, 0,
+        rs0); h->p0_done = true; }
     else hipLaunchKernelGGL((host_phase_kernel<1>), g, b, 0, h->stream, h->E, it, rs, 0);
     HIPCHK(hipGetLastError());
     if (h->dodr) {
         rc = host_eval(h, h->E.cs, 2 * h->d, true); if (rc) return rc;
-        if (fuse_next) { hipLaunchKernelGGL((host_phase_seq_kernel<2, 0, -1>), g, b, lds, h->stream, h->E, it, 0, it + 1, 0, 0, 0, rs0); h->p0_done = true; }
+        if (fuse_next) { hipLaunchKernelGGL((host_phase_seq_kernel<2, 0, -1>), g, b, lds, h->stream, h->E, it, 0, it + 1, 0, 0, 0, rs0);
+            h->p0_done = true; }
         else hipLaunchKernelGGL((host_phase_kernel<2>), g, b, lds, h->stream, h->E, it, rs, 0);
         HIPCHK(hipGetLastError());
     }
@@ -1300,7 +1434,8 @@ static int run1_check(mcmcx_engine *h)
 {
     if (!h) return fail(-1, "null handle");
     if (!h->inited) return fail(-40, "we have not inited");                           // MCMC_run1.F90:55
-    if (!h->external) return fail(-42, "mcmcx_run1_*: needs mcmcx_set_target_external (the caller evaluates ssfunction / priorfun / checkbounds)");
+    if (!h->external) return
+        fail(-42, "mcmcx_run1_*: needs mcmcx_set_target_external (the caller evaluates ssfunction / priorfun / checkbounds)");
     return 0;
 }
 static void run1_put(mcmcx_engine *h, int slot0, int K, const double *src /* [nchains][K] or nullptr */)
@@ -1345,7 +1480,8 @@ int mcmcx_device_info(int32_t device, char *buf, int32_t len)
     hipError_t e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) { snprintf(buf, (size_t)len, "device %d: %s", device, hipGetErrorString(e)); return fail(-10, buf); }
     (void)hipDeviceGetPCIBusId(bus, (int)sizeof bus, device);
-    snprintf(buf, (size_t)len, "%s %s, pci %s, %d CUs, %.0f GiB", prop.name, prop.gcnArchName, bus, prop.multiProcessorCount, (double)prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
+    snprintf(buf, (size_t)len, "%s %s, pci %s, %d CUs, %.0f GiB", prop.name, prop.gcnArchName, bus, prop.multiProcessorCount,
+        (double)prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
     return 0;
 }
 
@@ -1369,7 +1505,8 @@ const char *mcmcx_last_kernel(mcmcx_handle h)
 {
     static thread_local std::string name;
     name = h ? h->last_kernel : "";
-    if (name.size() >= 2 && name.front() == '(' && name.back() == ')') name = name.substr(1, name.size() - 2);   // template instances are launched as (k<...>)
+    // template instances are launched as (k<...>)
+    if (name.size() >= 2 && name.front() == '(' && name.back() == ')') name = name.substr(1, name.size() - 2);
     return name.c_str();
 }
 
@@ -1513,7 +1650,8 @@ int mcmcx_set_target_host(mcmcx_handle h, mcmcx_ssfun_t ss, mcmcx_priorfun_t pri
     return 0;
 }
 
-int mcmcx_set_target_host_batch(mcmcx_handle h, mcmcx_ssfun_batch_t ss_batch, mcmcx_priorfun_t pri, mcmcx_checkbounds_t cb, void *user, int32_t nthreads)
+int mcmcx_set_target_host_batch(mcmcx_handle h, mcmcx_ssfun_batch_t ss_batch, mcmcx_priorfun_t pri, mcmcx_checkbounds_t cb, void *user,
+    int32_t nthreads)
 {
     if (!h || !ss_batch) return fail(-1, "mcmcx_set_target_host_batch: ssfunction_batch is required");
     if (h->inited) return fail(-20, "set the target before mcmcx_init");
@@ -1539,14 +1677,18 @@ int mcmcx_set_target_module(mcmcx_handle h, const char *code_object_path, const 
     hipError_t e = hipModuleLoad(&h->mod, code_object_path);
     if (e != hipSuccess) return fail(-37, std::string("cannot load the target module ") + code_object_path + ": " + hipGetErrorString(e));
     e = hipModuleGetFunction(&h->mod_fn, h->mod, kernel_name);
-    if (e != hipSuccess) return fail(-37, std::string("target module: no kernel named ") + kernel_name + " (define it with MCMCX_DEFINE_TARGET, include/mcmcx_target.h)");
+    if (e != hipSuccess) return fail(-37,
+        std::string("target module: no kernel named ") + kernel_name + " (define it with MCMCX_DEFINE_TARGET, include/mcmcx_target.h)");
     for (const char *suffix : {"_abi", "_max_npar"}) {
         hipDeviceptr_t p = nullptr; size_t sz = 0; int v = 0;
         e = hipModuleGetGlobal(&p, &sz, h->mod, (std::string(kernel_name) + suffix).c_str());
-        if (e != hipSuccess || sz != sizeof(int)) return fail(-37, std::string("target module: ") + kernel_name + suffix + " is missing (not built with MCMCX_DEFINE_TARGET?)");
+        if (e != hipSuccess || sz != sizeof(int)) return fail(-37,
+            std::string("target module: ") + kernel_name + suffix + " is missing (not built with MCMCX_DEFINE_TARGET?)");
         HIPCHK(hipMemcpy(&v, p, sizeof(int), hipMemcpyDeviceToHost));
-        if (suffix[1] == 'a' && v != MCMCX_TARGET_ABI) return fail(-37, "target module: built against another mcmcx_target.h (abi " + std::to_string(v) + ")");
-        if (suffix[1] == 'm' && h->d > v) return fail(-37, "target module: npar = " + std::to_string(h->d) + " but the module was compiled with MCMCX_TARGET_MAX_NPAR = " + std::to_string(v));
+        if (suffix[1] == 'a' && v != MCMCX_TARGET_ABI) return fail(-37, "target module: built against another mcmcx_target.h (abi " +
+            std::to_string(v) + ")");
+        if (suffix[1] == 'm' && h->d > v) return fail(-37, "target module: npar = " + std::to_string(h->d)
+            + " but the module was compiled with MCMCX_TARGET_MAX_NPAR = " + std::to_string(v));
     }
     {   // response columns the module's kernel has room for (modules built before round 5 have no such symbol: eight)
         hipDeviceptr_t p = nullptr; size_t sz = 0; int v = 8;
@@ -1603,10 +1745,13 @@ int mcmcx_init(mcmcx_handle h)
     if (!h->sigma2ok) { h->sigma2 = 1.0; h->nobs = 1; h->ny = 1; }                    // MCMC_init.F90:52-59
     if (h->ny == 1) { h->sigma2v.assign(1, h->sigma2); h->nobsv.assign(1, h->nobs); }
     const int ny = h->ny;
-    if (ny > 1 && !phased(h)) return fail(-36, "nycol > 1 needs the host-callback or the response-column target (the other built-in targets have one column)");
+    if (ny > 1 && !phased(h)) return
+        fail(-36, "nycol > 1 needs the host-callback or the response-column target (the other built-in targets have one column)");
     if (h->tkind == TGT_MODULE && ny > h->mod_max_ny)
-        return fail(-36, "target module: nycol = " + std::to_string(ny) + " but the module was compiled with MCMCX_TARGET_MAX_NY = " + std::to_string(h->mod_max_ny));
-    if (h->tkind == TGT_EXPCOLS && h->tncols != ny) return fail(-36, "response-column target: mcmcx_set_sigma2nobs must give one sigma2 / nobs per column");
+        return fail(-36, "target module: nycol = " + std::to_string(ny) + " but the module was compiled with MCMCX_TARGET_MAX_NY = " +
+            std::to_string(h->mod_max_ny));
+    if (h->tkind == TGT_EXPCOLS
+        && h->tncols != ny) return fail(-36, "response-column target: mcmcx_set_sigma2nobs must give one sigma2 / nobs per column");
     if (ny > 1 && h->pooled && (!fused_cols(h) || c.method == MCMCX_METHOD_SCAM))
         return fail(-36, "nycol > 1 in pooled mode: the device-resident response-column target only, and not with method = 'scam'");
     if (h->tkind < 0) return fail(-31, "no target: the device engine needs mcmcx_set_target_*");
@@ -1622,7 +1767,8 @@ int mcmcx_init(mcmcx_handle h)
 
     EngineDev &E = h->E;
     E.d = d; E.P = P; E.ntiles = T;
-    E.method = (c.method == MCMCX_METHOD_RAM && !h->pooled) ? M_RAM : (c.method == MCMCX_METHOD_ER ? M_ER : M_DRAM);   // pooled RAM adapts on the host side: the kernels see a plain Metropolis step
+    // pooled RAM adapts on the host side: the kernels see a plain Metropolis step
+    E.method = (c.method == MCMCX_METHOD_RAM && !h->pooled) ? M_RAM : (c.method == MCMCX_METHOD_ER ? M_ER : M_DRAM);
     E.usesvd = h->usesvd; E.doscam = (c.method == MCMCX_METHOD_SCAM) ? 1 : 0; E.condmax = c.condmax;
     E.scam_fast = c.scam_fast ? 1 : 0;
     E.Rf = E.R2f = E.qstd = E.Gw = E.Vw = nullptr;
@@ -1642,13 +1788,15 @@ int mcmcx_init(mcmcx_handle h)
         int cus = 256;
         if (hipGetDeviceProperties(&prop, c.device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
         const bool fits = per_cu >= 8 || (per_cu >= 1 && (long long)T <= (long long)per_cu * cus);
-        E.lds_scratch = (!h->pooled && !h->dodr && c.method != MCMCX_METHOD_RAM && c.method != MCMCX_METHOD_SCAM && fits && !(ev && atoi(ev) == 0)) ? 1 : 0;
+        E.lds_scratch = (!h->pooled && !h->dodr && c.method != MCMCX_METHOD_RAM && c.method != MCMCX_METHOD_SCAM && fits && !(ev
+            && atoi(ev) == 0)) ? 1 : 0;
         // ... and the packed factor with it (step_kernel_ldsr) where one column panel covers npar and state + factor of all tiles
         // are resident at once: (2 npar + npar (npar + 1) / 2) x 512 bytes per wave, 38 KiB at npar = 10 = four waves per CU
         const size_t per_wave_r = (size_t)(2 * d + P) * 64 * sizeof(double);
         const int per_cu_r = (int)((size_t)160 * 1024 / per_wave_r);
         const bool fits_r = per_cu_r >= 8 || (per_cu_r >= 1 && (long long)T <= (long long)per_cu_r * cus);
-        if (E.lds_scratch && !h->usesvd && d <= TW && fits_r && !(ev && atoi(ev) == 1)) E.lds_scratch = 2;     // MCMCX_LDS_SCRATCH=1: the state only (A/B)
+        // MCMCX_LDS_SCRATCH=1: the state only (A/B)
+        if (E.lds_scratch && !h->usesvd && d <= TW && fits_r && !(ev && atoi(ev) == 1)) E.lds_scratch = 2;
         // method='ram' (per-chain factor, Cholesky form): the factor DCHUD / DCHDD rewrite every iteration, and their rotations, in LDS for
         // the launch where one column panel covers npar and all tiles are resident at once (step_kernel_ram_ldsr)
         if (!h->pooled && c.method == MCMCX_METHOD_RAM && !h->usesvd && d <= RW && fits_r && !(ev && atoi(ev) == 0)) E.lds_scratch = 3;
@@ -1665,10 +1813,12 @@ int mcmcx_init(mcmcx_handle h)
         for (int i = 0; i < d; ++i) for (int j = 0; j < d; ++j) lt[(size_t)j * d + i] = h->tlam[(size_t)i * d + j];
         if ((rc = dev_upload(h, &E.tgt.lamT, lt))) return rc;
     }
-    if (h->tkind == TGT_EXPDATA || h->tkind == TGT_EXPCOLS) { if ((rc = dev_upload(h, &E.tgt.x, h->tx))) return rc; if ((rc = dev_upload(h, &E.tgt.y, h->ty))) return rc; }
+    if (h->tkind == TGT_EXPDATA || h->tkind == TGT_EXPCOLS) { if ((rc = dev_upload(h, &E.tgt.x, h->tx))) return rc; if ((rc = dev_upload(h,
+        &E.tgt.y, h->ty))) return rc; }
     if (h->has_lo && (rc = dev_upload(h, &E.tgt.lo, h->tlo))) return rc;
     if (h->has_hi && (rc = dev_upload(h, &E.tgt.hi, h->thi))) return rc;
-    if (h->has_pri) { if ((rc = dev_upload(h, &E.tgt.pmu, h->tpmu))) return rc; if ((rc = dev_upload(h, &E.tgt.psig, h->tpsig))) return rc; }
+    if (h->has_pri) { if ((rc = dev_upload(h, &E.tgt.pmu, h->tpmu))) return rc; if ((rc = dev_upload(h, &E.tgt.psig, h->tpsig))) return rc;
+        }
     if ((rc = dev_upload(h, &E.par0, h->par0))) return rc;
     if ((rc = dev_upload(h, &E.cmat0p, Cp))) return rc;
 
@@ -1678,12 +1828,14 @@ int mcmcx_init(mcmcx_handle h)
     // the user's functions on the host and at most sixteen tiles: candidate, results and flags in mapped host memory -- a phase kernel's
     // stores ARE the hand-over, the host's results are read by the next one in place (MCMCX_HOST_MAPPED=0: device buffers and copies)
     h->host_mapped = h->tkind == TGT_HOST && T <= 16 && h->sw.host_mapped != 0;
-    h->cs_mapped = h->host_mapped && (c.method == MCMCX_METHOD_DRAM || c.method == MCMCX_METHOD_ER);     // (RAM / SCAM use cs as sweep scratch)
+    // (RAM / SCAM use cs as sweep scratch)
+    h->cs_mapped = h->host_mapped && (c.method == MCMCX_METHOD_DRAM || c.method == MCMCX_METHOD_ER);
     if ((rc = h->host_mapped ? host_alloc(h, &E.cand, L * d) : dev_alloc(h, &E.cand, L * d))) return rc;
     if ((rc = dev_alloc(h, &E.zs, L * 2 * d))) return rc;
     if ((rc = h->cs_mapped ? host_alloc(h, &E.cs, L * 2 * d) : dev_alloc(h, &E.cs, L * 2 * d))) return rc;
     E.xscr = nullptr;
-    if (((h->pooled && h->dodr) || d > 320) && (rc = dev_alloc(h, &E.xscr, L * 2 * d))) return rc;      // step_kernel_pooled_dr_big's quadratic-form vectors; npar > 320: adapt_post_kernel's work vector
+    // step_kernel_pooled_dr_big's quadratic-form vectors; npar > 320: adapt_post_kernel's work vector
+    if (((h->pooled && h->dodr) || d > 320) && (rc = dev_alloc(h, &E.xscr, L * 2 * d))) return rc;
     if ((rc = dev_alloc(h, &E.scal, L * NSCAL))) return rc;
     if ((rc = dev_alloc(h, &E.ictr, L * NICTR))) return rc;
     if ((rc = dev_alloc(h, &E.rngn, L))) return rc;
@@ -1691,7 +1843,8 @@ int mcmcx_init(mcmcx_handle h)
     if (!h->pooled && (rc = dev_alloc(h, &E.R, L * P, false))) return rc;          // pooled: one shared factor instead
     if ((rc = dev_alloc(h, &E.basetheta, L * d))) return rc;
     if (h->usesvd && h->pooled && c.method == MCMCX_METHOD_SCAM) {     // pooled SCAM: one rotation for every chain
-        h->scam_replicated = scam_pooled_lds(d) > 160 * 1024;         // npar > 240: slower, not refused -- scam_kernel / scam_mw_kernel on per-chain copies
+        // npar > 240: slower, not refused -- scam_kernel / scam_mw_kernel on per-chain copies
+        h->scam_replicated = scam_pooled_lds(d) > 160 * 1024;
         if (h->scam_replicated) {
             if ((rc = dev_alloc(h, &E.Rf, L * (size_t)d * d, false))) return rc;
             if ((rc = dev_alloc(h, &E.qstd, L * d))) return rc;
@@ -1757,7 +1910,8 @@ int mcmcx_init(mcmcx_handle h)
     }
     E.sharedR = nullptr;
     if (h->pooled) {
-        if ((long long)c.nchains * (h->comm ? h->comm->nranks : 1) < 2) return fail(-8, "pooled mode needs at least 2 chains over all ranks");
+        if ((long long)c.nchains * (h->comm ? h->comm->nranks
+            : 1) < 2) return fail(-8, "pooled mode needs at least 2 chains over all ranks");
         if (phase_cut(h) || (fused_cols(h) && c.method == MCMCX_METHOD_SCAM))
             return fail(-8, "pooled mode needs one of the single-launch device targets (gauss, banana, expdata, expcols; scam: not expcols)");
         if ((rc = dev_alloc(h, &h->d_sharedR, (size_t)P, false))) return rc;
@@ -1816,9 +1970,12 @@ int mcmcx_init(mcmcx_handle h)
             if ((E.hist || E.accmask) && (rc = dev_alloc(h, &h->d_accb, L * (size_t)GROUP_MAXSEG))) return rc;
         }
     }
-    // the adaptation's factorisation (Cholesky branch) with the matrices in LDS (tile_factor_kernel): any chain count, npar <= 32 -- config 3's size
-    // (npar 20, delayed rejection, 262144 chains): 2.11 -> 1.44 ms per tick, bound by VALU issue (~25 instructions per inner step of four chains).
-    // Above npar 32 adapt_post_kernel's 8 x 8 register blocks stay: at npar 50 x 1 048 576 chains they stream the matrices ~5.6 times (16.0 ms)
+    // the adaptation's factorisation (Cholesky branch) with the matrices in LDS (tile_factor_kernel): any chain count, npar <= 32 -- config
+    // 3's size
+    // (npar 20, delayed rejection, 262144 chains): 2.11 -> 1.44 ms per tick, bound by VALU issue (~25 instructions per inner step of four
+    // chains).
+    // Above npar 32 adapt_post_kernel's 8 x 8 register blocks stay: at npar 50 x 1 048 576 chains they stream the matrices ~5.6 times (16.0
+    // ms)
     // and still beat the LDS form, whose three waves per CU issue ~15 x the instructions per chain (35.2 ms; profiles/r05_a/tick_ab.txt).
     // MCMCX_TILE_FACTOR = 0 / 1: never / up to npar 64 (test switch: both forms on one problem).
     {
@@ -1833,8 +1990,10 @@ int mcmcx_init(mcmcx_handle h)
         if ((rc = dev_upload(h, &p, rs))) return rc;
         h->d_ramscale = const_cast<double *>(p);
     }
-    if ((rc = dev_alloc(h, &h->d_moments, (size_t)(T + 1) * (2 + d + P)))) return rc;                         // longest pooled vector: 2 + d + P
-    if ((rc = dev_alloc(h, &h->d_gather, (size_t)(h->comm ? h->comm->nranks : 1) * (3 + d + P)))) return rc;   // longest vector + the stop flag
+    // longest pooled vector: 2 + d + P
+    if ((rc = dev_alloc(h, &h->d_moments, (size_t)(T + 1) * (2 + d + P)))) return rc;
+    // longest vector + the stop flag
+    if ((rc = dev_alloc(h, &h->d_gather, (size_t)(h->comm ? h->comm->nranks : 1) * (3 + d + P)))) return rc;
     if ((rc = dev_alloc(h, &h->d_pooled, (size_t)(3 + d + P)))) return rc;
 
     // fill theta = par0, R = R(cmat0), chaincmat = cmat0, chainmean = par0, scalars
@@ -1927,8 +2086,10 @@ static int run_impl(mcmcx_handle h, int32_t upto)
     if (!h) return fail(-1, "null handle");
     if (!h->inited) return fail(-40, "we have not inited");                           // MCMC_run.F90:22
     if (h->external) return fail(-41, "mcmcx_run: the target is external (mcmcx_set_target_external): drive the chain with mcmcx_run1_*");
-    // (with the phases fused, iteration it + 1's proposal -- Philox draws included -- has already run when an error surfaces in iteration it's
-    //  evaluation; a second run on the handle would draw that proposal again and leave the reference's stream order silently: ADVICE round 5)
+    // (with the phases fused, iteration it + 1's proposal -- Philox draws included -- has already run when an error surfaces in iteration
+    // it's
+    // evaluation; a second run on the handle would draw that proposal again and leave the reference's stream order silently: ADVICE round
+    // 5)
     if (h->failed) return fail(-42, "mcmcx_run: an earlier run on this handle failed inside a host-callback iteration; its chains are in an undefined state -- destroy the handle");
     HIPCHK(hipSetDevice(h->cfg.device));
     const mcmcx_config &c = h->cfg;
@@ -1972,7 +2133,8 @@ static int run_impl(mcmcx_handle h, int32_t upto)
                 if (h->cfg.method == MCMCX_METHOD_SCAM) launch_scam(h, it, end); else launch_step(h, it, end);
                 er = hipGetLastError();
             }
-            if (er == hipSuccess && !h->launch_err.empty()) {      // a cover predicate and the dispatch disagree: fail, never skip iterations silently
+            // a cover predicate and the dispatch disagree: fail, never skip iterations silently
+            if (er == hipSuccess && !h->launch_err.empty()) {
                 if (e0) (void)hipEventDestroy(e0);
                 if (e1) (void)hipEventDestroy(e1);
                 return fail(-103, "step launch: " + h->launch_err);
@@ -2012,9 +2174,11 @@ int mcmcx_run1_decide(mcmcx_handle h, int32_t drstage, const double *oldpar2, co
                       const double *newpar, const double *ss, const double *sspri, double *alpha_out, int32_t *reject_out)
 {
     int rc = run1_check(h); if (rc) return rc;
-    if (!oldpar1 || !ssprev1 || !sspri1 || !newpar || !ss || !sspri || !alpha_out || !reject_out) return fail(-1, "mcmcx_run1_decide: null argument");
+    if (!oldpar1 || !ssprev1 || !sspri1 || !newpar || !ss || !sspri || !alpha_out
+        || !reject_out) return fail(-1, "mcmcx_run1_decide: null argument");
     const bool dr2 = drstage > 1 && h->dodr;
-    if (dr2 && (!oldpar2 || !ssprev2 || !sspri2 || !alpha12)) return fail(-1, "mcmcx_run1_decide: the second stage needs oldpar2, ssprev2, sspri2, alpha12");
+    if (dr2 && (!oldpar2 || !ssprev2 || !sspri2
+        || !alpha12)) return fail(-1, "mcmcx_run1_decide: the second stage needs oldpar2, ssprev2, sspri2, alpha12");
     const int d = h->d, ny = h->ny, n = h->cfg.nchains, s0 = 3 * d + 3 * ny;
     h->h_r1.assign((size_t)h->ntiles * 64 * (s0 + NR1), 0.0);
     run1_put(h, 0, d, dr2 ? oldpar2 : nullptr); run1_put(h, d, d, oldpar1); run1_put(h, 2 * d, d, newpar);
@@ -2159,7 +2323,8 @@ int mcmcx_get_R(mcmcx_handle h, int32_t chain, double *R)
 {
     int rc = check_chain(h, chain); if (rc) return rc;
     std::vector<double> p;
-    if (h->pooled && h->usesvd) { const auto &M = h->cfg.method == MCMCX_METHOD_SCAM ? h->pool_U : h->pool_Rf; memcpy(R, M.data(), sizeof(double) * M.size()); return 0; }
+    if (h->pooled && h->usesvd) { const auto &M = h->cfg.method == MCMCX_METHOD_SCAM ? h->pool_U : h->pool_Rf; memcpy(R, M.data(),
+        sizeof(double) * M.size()); return 0; }
     if (h->pooled) { unpack_upper(h->d, h->pool_R, R, false); return 0; }
     if (h->usesvd) {                                     // full column-major factor
         if ((rc = fetch_chain_vec(h, h->E.Rf, h->d * h->d, chain, p))) return rc;
@@ -2174,7 +2339,8 @@ int mcmcx_get_R(mcmcx_handle h, int32_t chain, double *R)
 int mcmcx_get_qcovstd(mcmcx_handle h, int32_t chain, double *std)
 {
     int rc = check_chain(h, chain); if (rc) return rc;
-    if (h->pooled && h->usesvd && h->cfg.method == MCMCX_METHOD_SCAM) { memcpy(std, h->pool_std.data(), sizeof(double) * h->pool_std.size()); return 0; }
+    if (h->pooled && h->usesvd && h->cfg.method == MCMCX_METHOD_SCAM) { memcpy(std, h->pool_std.data(),
+        sizeof(double) * h->pool_std.size()); return 0; }
     if (!h->E.qstd) return fail(-45, "no SVD state (condmax = 0)");
     std::vector<double> p;
     if ((rc = fetch_chain_vec(h, h->E.qstd, h->d, chain, p))) return rc;
@@ -2193,7 +2359,8 @@ int mcmcx_get_dr(mcmcx_handle h, int32_t chain, double *R2, double *iC)
         if (iC) unpack_upper(h->d, h->pool_iC, iC, false);
         return 0;
     }
-    if (R2 && h->usesvd) { if ((rc = fetch_chain_vec(h, h->E.R2f, h->d * h->d, chain, p))) return rc; memcpy(R2, p.data(), sizeof(double) * p.size()); }
+    if (R2 && h->usesvd) { if ((rc = fetch_chain_vec(h, h->E.R2f, h->d * h->d, chain, p))) return rc; memcpy(R2, p.data(),
+        sizeof(double) * p.size()); }
     else if (R2) { if ((rc = fetch_chain_vec(h, h->E.R2, h->P, chain, p))) return rc; unpack_upper(h->d, p, R2, false); }
     if (iC) { if ((rc = fetch_chain_vec(h, h->E.iC, h->P, chain, p))) return rc; unpack_upper(h->d, p, iC, false); }
     return 0;
@@ -2260,7 +2427,8 @@ int mcmcx_get_chain(mcmcx_handle h, int32_t chain, double *chain_out, double *ss
     auto gather = [&](const double *src, size_t n, std::vector<double> &dst) -> int {
         double *tmp = nullptr;
         HIPCHK(hipMalloc(&tmp, n * sizeof(double)));       // (freed on every path below)
-        hipLaunchKernelGGL(gather_lane_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, h->stream, src, tmp, n, lane);
+        hipLaunchKernelGGL(gather_lane_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, h->stream, src, tmp,
+            n, lane);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         dst.resize(n);
@@ -2281,7 +2449,8 @@ int mcmcx_get_chain(mcmcx_handle h, int32_t chain, double *chain_out, double *ss
                 for (int k = 0; k < d; ++k) chain_out[(size_t)row * (d + 1) + k] = hv[so + k];
                 chain_out[(size_t)row * (d + 1) + d] = 1.0;
             }
-            if (ss_out) { for (int j = 0; j < ny; ++j) ss_out[(size_t)row * (ny + 1) + j] = hv[so + d + j]; ss_out[(size_t)row * (ny + 1) + ny] = 1.0; }
+            if (ss_out) { for (int j = 0; j < ny; ++j) ss_out[(size_t)row * (ny + 1) + j] = hv[so + d + j];
+                ss_out[(size_t)row * (ny + 1) + ny] = 1.0; }
         } else {
             if (chain_out) chain_out[(size_t)row * (d + 1) + d] += 1.0;
             if (ss_out) ss_out[(size_t)row * (ny + 1) + ny] += 1.0;
@@ -2291,7 +2460,8 @@ int mcmcx_get_chain(mcmcx_handle h, int32_t chain, double *chain_out, double *ss
     if (s2_out && h->E.s2hist) {
         std::vector<double> sv;
         if ((rc = gather(h->E.s2hist + (size_t)tile * W * ny * 64, (size_t)W * ny, sv))) return rc;
-        for (int it = 1; it <= h->simuind; ++it) for (int j = 0; j < ny; ++j) s2_out[(size_t)(it - 1) * ny + j] = sv[(size_t)(it % W) * ny + j];
+        for (int it = 1; it <= h->simuind; ++it) for (int j = 0; j < ny;
+            ++j) s2_out[(size_t)(it - 1) * ny + j] = sv[(size_t)(it % W) * ny + j];
     }
     return 0;
 }
@@ -2307,8 +2477,11 @@ static int pooled_moments_launch(mcmcx_engine *h, double *dev_dst, int kind, int
     const int len = pooled_vec_len(h, kind), T = h->ntiles;
     const double rs = (kind == 2) ? 1.0 / std::pow((double)(float)it, h->cfg.nuparam) : 0.0;      // like d_ramscale (MCMC_run_ram.F90:166)
     const size_t mlds = ((size_t)64 * (h->d | 1) + 320) * sizeof(double);
-    if (mlds <= 160 * 1024) hipLaunchKernelGGL(moments_kernel<false>, dim3(T), dim3(256), mlds, h->stream, h->E, h->d_moments, h->cfg.nchains, kind, it, rs);
-    else hipLaunchKernelGGL(moments_kernel<true>, dim3(T), dim3(256), (size_t)320 * sizeof(double), h->stream, h->E, h->d_moments, h->cfg.nchains, kind, it, rs);   // npar >= 316: (64 (d | 1) + 320) 8 bytes exceed 160 KiB (317: 164 864)
+    if (mlds <= 160 * 1024) hipLaunchKernelGGL(moments_kernel<false>, dim3(T), dim3(256), mlds, h->stream, h->E, h->d_moments,
+        h->cfg.nchains, kind, it, rs);
+    // npar >= 316: (64 (d | 1) + 320) 8 bytes exceed 160 KiB (317: 164 864)
+    else hipLaunchKernelGGL(moments_kernel<true>, dim3(T), dim3(256), (size_t)320 * sizeof(double), h->stream, h->E, h->d_moments,
+        h->cfg.nchains, kind, it, rs);
     for (long long stride = 1;; stride *= 64) {                            // six levels of the fixed pairwise tree per launch
         const long long groups = (T + 64 * stride - 1) / (64 * stride);
         hipLaunchKernelGGL(moments_tree_kernel, dim3((len + 255) / 256, (unsigned)groups), dim3(256), 0, h->stream, h->d_moments, T, len,
@@ -2343,7 +2516,9 @@ int mcmcx_get_pooled(mcmcx_handle h, double *cmat, double *mean, double *wsum, d
     if (cmat) unpack_upper(h->d, h->pool_C, cmat, true);
     if (mean) memcpy(mean, h->pool_mean.data(), sizeof(double) * (size_t)h->d);
     if (wsum) *wsum = h->pool_W;
-    if (R && h->usesvd) { const auto &M = h->cfg.method == MCMCX_METHOD_SCAM ? h->pool_U : h->pool_Rf; memcpy(R, M.data(), sizeof(double) * M.size()); }   // scam: the rotation U; condmax > 0: the full SVD factor; column-major
+    // scam: the rotation U; condmax > 0: the full SVD factor; column-major
+    if (R && h->usesvd) { const auto &M = h->cfg.method == MCMCX_METHOD_SCAM ? h->pool_U : h->pool_Rf; memcpy(R, M.data(),
+        sizeof(double) * M.size()); }
     else if (R) unpack_upper(h->d, h->pool_R, R, false);
     return 0;
 }
@@ -2361,7 +2536,8 @@ int mcmcx_set_comm(mcmcx_handle h, mcmcx_comm_t c)
 {
     if (!h) return fail(-1, "null handle");
     if (h->inited) return fail(-1, "mcmcx_set_comm after mcmcx_init");
-    if (c && c->device != h->cfg.device) return fail(-1, "mcmcx_set_comm: the communicator lives on device " + std::to_string(c->device) + ", the engine on " + std::to_string(h->cfg.device));
+    if (c && c->device != h->cfg.device) return fail(-1, "mcmcx_set_comm: the communicator lives on device " + std::to_string(c->device)
+        + ", the engine on " + std::to_string(h->cfg.device));
     h->comm = c;
     return 0;
 }
@@ -2404,7 +2580,8 @@ int mcmcx_run_all(mcmcx_handle *hs, int32_t n, int32_t upto)
 {
     if (!hs || n < 1) return fail(-1, "bad argument");
     bool serial = (n == 1);
-    for (int i = 0; i < n; ++i) { if (!hs[i]) return fail(-1, "null handle"); if (phased(hs[i]) && hs[i]->tkind == TGT_HOST) serial = true; }
+    for (int i = 0; i < n; ++i) { if (!hs[i]) return fail(-1, "null handle"); if (phased(hs[i]) && hs[i]->tkind == TGT_HOST) serial = true;
+        }
     if (serial) {
         int worst = 0;
         for (int i = 0; i < n; ++i) { int rc = mcmcx_run(hs[i], upto); if (rc < 0) return rc; worst = std::max(worst, rc); }
@@ -2416,7 +2593,8 @@ int mcmcx_run_all(mcmcx_handle *hs, int32_t n, int32_t upto)
     rcs[0] = mcmcx_run(hs[0], upto); if (rcs[0] < 0) errs[0] = g_err;
     for (auto &t : th) t.join();
     int worst = 0;
-    for (int i = 0; i < n; ++i) { if (rcs[i] < 0) return fail(rcs[i], "engine " + std::to_string(i) + ": " + errs[i]); worst = std::max(worst, rcs[i]); }
+    for (int i = 0; i < n; ++i) { if (rcs[i] < 0) return fail(rcs[i], "engine " + std::to_string(i) + ": " + errs[i]);
+        worst = std::max(worst, rcs[i]); }
     return worst;
 }
 
@@ -2429,10 +2607,12 @@ extern "C" {
 int mcmcx_debug_kernel_table(int32_t index, char *buf, int32_t len)
 {
     const KernelEntry *tabs[] = {STEP_TABLE, GROUP_TABLE, SCAM_TABLE};
-    const size_t ns[] = {sizeof(STEP_TABLE) / sizeof(STEP_TABLE[0]), sizeof(GROUP_TABLE) / sizeof(GROUP_TABLE[0]), sizeof(SCAM_TABLE) / sizeof(SCAM_TABLE[0])};
+    const size_t ns[] = {sizeof(STEP_TABLE) / sizeof(STEP_TABLE[0]), sizeof(GROUP_TABLE) / sizeof(GROUP_TABLE[0]),
+        sizeof(SCAM_TABLE) / sizeof(SCAM_TABLE[0])};
     int total = 0, k = index;
     for (int t = 0; t < 3; ++t) {
-        if (k >= 0 && k < (int)ns[t] && buf && len > 0) { snprintf(buf, (size_t)len, "%s:%s", tabs[t][k].family, tabs[t][k].name); k = -1 - total - (int)ns[t]; }
+        if (k >= 0 && k < (int)ns[t] && buf && len > 0) { snprintf(buf, (size_t)len, "%s:%s", tabs[t][k].family, tabs[t][k].name);
+            k = -1 - total - (int)ns[t]; }
         else if (k >= 0) k -= (int)ns[t];
         total += (int)ns[t];
     }
@@ -2461,7 +2641,8 @@ int mcmcx_debug_math(int32_t op, int32_t n, const double *a, const double *b, do
 int mcmcx_debug_set_factor(mcmcx_handle h, const double *R_colmajor, const double *qcovstd)
 {
     if (!h || !h->inited || !R_colmajor) return fail(-1, "mcmcx_debug_set_factor: bad argument");
-    if (!h->usesvd || h->pooled || !h->E.Rf) return fail(-45, "mcmcx_debug_set_factor: per-chain SVD factor only (condmax > 0, not pooled)");
+    if (!h->usesvd || h->pooled
+        || !h->E.Rf) return fail(-45, "mcmcx_debug_set_factor: per-chain SVD factor only (condmax > 0, not pooled)");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipStreamSynchronize(h->stream));
     std::vector<double> r(R_colmajor, R_colmajor + (size_t)h->d * h->d);

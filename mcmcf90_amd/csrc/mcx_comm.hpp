@@ -34,7 +34,8 @@
             return fail(-110, std::string(#call) + ": " + ncclGetErrorString(r_));                \
     } while (0)
 
-static const int MCX_SHM_SLOT = 131072;         // doubles per rank in the host segment (1 MiB): >= 3 + d + d(d+1)/2 up to d = 510; longer messages fail loudly (RCCL has no such limit)
+// doubles per rank in the host segment (1 MiB): >= 3 + d + d(d+1)/2 up to d = 510; longer messages fail loudly (RCCL has no such limit)
+static const int MCX_SHM_SLOT = 131072;
 static const int MCX_COMM_MAXRANKS = 64;        // one level of moments_tree_kernel
 
 struct mcx_shm_header {
@@ -78,7 +79,8 @@ static int comm_wait_stream(mcmcx_comm *c, hipStream_t stream)
         const hipError_t e = hipStreamQuery(stream);
         if (e == hipSuccess) return 0;
         if (e != hipErrorNotReady) return fail(-100, std::string("hipStreamQuery: ") + hipGetErrorString(e));
-        if ((c->group_failed && c->group_failed->load(std::memory_order_relaxed)) || (c->hdr && c->hdr->failed.load(std::memory_order_relaxed))) {
+        if ((c->group_failed && c->group_failed->load(std::memory_order_relaxed)) || (c->hdr
+            && c->hdr->failed.load(std::memory_order_relaxed))) {
             if (c->nccl) { (void)ncclCommAbort(c->nccl); c->nccl = nullptr; }     // frees this rank's pending collective
             return fail(-111, "mcmcx_comm: another rank failed; this rank's collective was aborted (rank " + std::to_string(c->rank) + ")");
         }
@@ -190,7 +192,8 @@ static int comm_allgather(mcmcx_comm *c, double *dev_all, int len, hipStream_t s
         return 0;
     }
     if (len > MCX_SHM_SLOT) return fail(-113, "mcmcx_comm: message too long for the host segment");
-    HIPCHK(hipMemcpyAsync(c->slots + (size_t)c->rank * MCX_SHM_SLOT, dev_all + (size_t)c->rank * len, (size_t)len * 8, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(c->slots + (size_t)c->rank * MCX_SHM_SLOT, dev_all + (size_t)c->rank * len, (size_t)len * 8,
+        hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     int rc = shm_barrier(c); if (rc) return rc;
     c->hbuf.resize((size_t)c->nranks * len);
@@ -214,7 +217,8 @@ int mcmcx_comm_create(const char *key, int32_t rank, int32_t nranks, int32_t dev
     if (!nogpu) {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(-10, "no HIP device: the mcmcx engine has no CPU fallback");
-        if (device < 0 || device >= ndev) return fail(-10, "mcmcx_comm_create: bad device ordinal " + std::to_string(device) + " (" + std::to_string(ndev) + " visible)");
+        if (device < 0 || device >= ndev) return fail(-10, "mcmcx_comm_create: bad device ordinal " + std::to_string(device) + " (" +
+            std::to_string(ndev) + " visible)");
         HIPCHK(hipSetDevice(device));
     }
     mcmcx_comm *c = new mcmcx_comm();
@@ -230,16 +234,19 @@ int mcmcx_comm_create(const char *key, int32_t rank, int32_t nranks, int32_t dev
         ncclUniqueId id;
         if (rank == 0) {
             ncclResult_t r = ncclGetUniqueId(&id);
-            if (r != ncclSuccess) { c->hdr->failed.store(1); comm_free(c); return fail(-110, std::string("ncclGetUniqueId: ") + ncclGetErrorString(r)); }
+            if (r != ncclSuccess) { c->hdr->failed.store(1); comm_free(c); return fail(-110,
+                std::string("ncclGetUniqueId: ") + ncclGetErrorString(r)); }
             memcpy(c->hdr->uid, id.internal, NCCL_UNIQUE_ID_BYTES);
         }
         if ((rc = shm_barrier(c))) { comm_free(c); return rc; }
         memcpy(id.internal, c->hdr->uid, NCCL_UNIQUE_ID_BYTES);
         ncclResult_t r = ncclCommInitRank(&c->nccl, nranks, id, rank);
-        if (r != ncclSuccess) { c->hdr->failed.store(1); c->nccl = nullptr; comm_free(c); return fail(-110, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
+        if (r != ncclSuccess) { c->hdr->failed.store(1); c->nccl = nullptr; comm_free(c); return fail(-110,
+            std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
     }
     if ((rc = shm_barrier(c))) { comm_free(c); return rc; }
-    if (rank == 0) c->hdr->magic.store(0, std::memory_order_release);      // formed: nobody attaches to this segment any more (see shm_attach)
+    // formed: nobody attaches to this segment any more (see shm_attach)
+    if (rank == 0) c->hdr->magic.store(0, std::memory_order_release);
     *out = c;
     return 0;
 }
@@ -252,7 +259,8 @@ int mcmcx_comm_create_all(int32_t ndev_want, const int32_t *devices, mcmcx_comm_
     std::vector<int> dl(ndev_want);
     for (int i = 0; i < ndev_want; ++i) {
         dl[i] = devices ? devices[i] : i;
-        if (dl[i] < 0 || dl[i] >= ndev) return fail(-10, "ngpus = " + std::to_string(ndev_want) + " but only " + std::to_string(ndev) + " HIP device(s) are visible");
+        if (dl[i] < 0 || dl[i] >= ndev) return fail(-10, "ngpus = " + std::to_string(ndev_want) + " but only " + std::to_string(ndev)
+            + " HIP device(s) are visible");
         for (int k = 0; k < i; ++k) if (dl[k] == dl[i]) return fail(-10, "mcmcx_comm_create_all: duplicate device");
     }
     std::vector<ncclComm_t> comms(ndev_want);
@@ -261,11 +269,13 @@ int mcmcx_comm_create_all(int32_t ndev_want, const int32_t *devices, mcmcx_comm_
     NCCLCHK(ncclCommInitAll(comms.data(), ndev_want, dl.data()));
     for (int i = 0; i < ndev_want; ++i) {
         mcmcx_comm *c = new mcmcx_comm();
-        c->rank = i; c->nranks = ndev_want; c->device = dl[i]; c->backend = MCMCX_COMM_RCCL; c->single_process = true; c->nccl = comms[i]; c->group_failed = group_failed;
+        c->rank = i; c->nranks = ndev_want; c->device = dl[i]; c->backend = MCMCX_COMM_RCCL; c->single_process = true; c->nccl = comms[i];
+            c->group_failed = group_failed;
         hipError_t e = hipSetDevice(dl[i]);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipMalloc((void **)&c->d_scratch, 512 * sizeof(double));
-        if (e != hipSuccess) {                                              // nothing half-made is handed back: every rank so far, this one,
+        // nothing half-made is handed back: every rank so far, this one,
+        if (e != hipSuccess) {
             const std::string msg = hipGetErrorString(e);                   // and the raw communicators of the ranks not reached yet
             comm_free(c);
             for (int k = 0; k < i; ++k) { comm_free(out[k]); out[k] = nullptr; }
@@ -285,7 +295,8 @@ int32_t mcmcx_comm_size(mcmcx_comm_t c) { return c ? c->nranks : -1; }
 int mcmcx_comm_allreduce_host(mcmcx_comm_t c, double *v, int32_t n, int32_t op)
 {
     if (!c || !v || n < 1 || n > 512) return fail(-1, "mcmcx_comm_allreduce_host: bad argument");
-    if (c->single_process) return fail(-1, "mcmcx_comm_allreduce_host: one process per rank only (reduce over the engines on the host instead)");
+    if (c->single_process) return
+        fail(-1, "mcmcx_comm_allreduce_host: one process per rank only (reduce over the engines on the host instead)");
     if (c->nranks == 1) return 0;
     if (c->backend == MCMCX_COMM_RCCL) {
         HIPCHK(hipSetDevice(c->device));
@@ -300,7 +311,8 @@ int mcmcx_comm_allreduce_host(mcmcx_comm_t c, double *v, int32_t n, int32_t op)
     std::vector<double> acc(n);
     for (int k = 0; k < n; ++k) {
         double a = c->slots[k];
-        for (int r = 1; r < c->nranks; ++r) { const double b = c->slots[(size_t)r * MCX_SHM_SLOT + k]; a = (op == 1) ? (b > a ? b : a) : a + b; }
+        for (int r = 1; r < c->nranks; ++r) { const double b = c->slots[(size_t)r * MCX_SHM_SLOT + k];
+            a = (op == 1) ? (b > a ? b : a) : a + b; }
         acc[k] = a;
     }
     rc = shm_barrier(c); if (rc) return rc;
@@ -312,7 +324,8 @@ int mcmcx_comm_barrier(mcmcx_comm_t c)
 {
     if (!c) return fail(-1, "null communicator");
     if (c->single_process || c->nranks == 1) return 0;
-    if (c->backend == MCMCX_COMM_RCCL) { double one = 1.0; return mcmcx_comm_allreduce_host(c, &one, 1, 0); }   // through the GPUs, like the data
+    // through the GPUs, like the data
+    if (c->backend == MCMCX_COMM_RCCL) { double one = 1.0; return mcmcx_comm_allreduce_host(c, &one, 1, 0); }
     return shm_barrier(c);
 }
 

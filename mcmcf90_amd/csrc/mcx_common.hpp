@@ -1,6 +1,7 @@
 // mcx_common.hpp -- what every kernel family shares: the engine's device view (EngineDev), the tile-interleaved layout (TIDX, GV ...),
 // the device-resident targets (ssfunction / priorfun / checkbounds), the normal generator (normal_bm, mcmcrand.F90:166-190)
-// (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled, mcx_phase, mcx_adapt, mcx_svd, mcx_moments)
+// (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled, mcx_phase,
+// mcx_adapt, mcx_svd, mcx_moments)
 #pragma once
 #include "mcx_device.hpp"
 #include <type_traits>
@@ -8,14 +9,17 @@
 namespace mcx {
 
 
-enum { TGT_GAUSS = 0, TGT_BANANA = 1, TGT_EXPDATA = 2, TGT_HOST = 3, TGT_EXPCOLS = 4, TGT_MODULE = 5 };   // EXPCOLS / MODULE: host side only (the device sees TGT_HOST + an evaluation kernel between the phases)
+// EXPCOLS / MODULE: host side only (the device sees TGT_HOST + an evaluation kernel between the phases)
+enum { TGT_GAUSS = 0, TGT_BANANA = 1, TGT_EXPDATA = 2, TGT_HOST = 3, TGT_EXPCOLS = 4, TGT_MODULE = 5 };
 enum { M_DRAM = 0, M_RAM = 1, M_ER = 3 };
 
 // per-chain scalar slots (doubles)
-enum { S_SS1 = 0, S_PRI1, S_SIGMA2, S_ALPHA12, S_SAVEDY, S_WSUM, S_WNEW, NSCAL };   // S_WNEW: chainwsum after the blocked covariance update (adapt_cov_diag_kernel -> adapt_post_kernel)
+// S_WNEW: chainwsum after the blocked covariance update (adapt_cov_diag_kernel -> adapt_post_kernel)
+enum { S_SS1 = 0, S_PRI1, S_SIGMA2, S_ALPHA12, S_SAVEDY, S_WSUM, S_WNEW, NSCAL };
 // per-chain integer slots (u32)
 enum { I_SAVED = 0, I_STAYED, I_BNDSTAYED, I_DRACC, I_DRTRIES, I_CHAININD, I_CURCOUNT, I_STATUS,
-       I_LASTFREQ, I_BASECNT, I_WINSTART, I_INFO, I_ERSTAYED, I_PDESC, I_DOWNS, I_ADFLAGS, I_NR, I_BSTART, NICTR };   // I_PDESC: 1 after a successful RAM downdate; I_DOWNS: RAM iterations with a < 0 (choldowndate)
+       // I_PDESC: 1 after a successful RAM downdate; I_DOWNS: RAM iterations with a < 0 (choldowndate)
+       I_LASTFREQ, I_BASECNT, I_WINSTART, I_INFO, I_ERSTAYED, I_PDESC, I_DOWNS, I_ADFLAGS, I_NR, I_BSTART, NICTR };
 
 // status bits
 enum { ST_RAM_DOWNDATE_FAIL = 1, ST_CHOL_FAIL = 2, ST_POTRI_FAIL = 4 };
@@ -41,7 +45,8 @@ struct EngineDev {
     DevTarget tgt;
     // state, tile-interleaved
     double *theta, *cand, *zs, *cs, *scal, *R, *R2, *iC, *Rtmp;   // cand/zs [d], cs [2d]: per-chain scratch vectors
-    double *xscr;               // [2d] per chain: the two quadratic-form vectors of pooled delayed rejection when LDS would cost waves (step_kernel_pooled_dr_big)
+    // [2d] per chain: the two quadratic-form vectors of pooled delayed rejection when LDS would cost waves (step_kernel_pooled_dr_big)
+    double *xscr;
     double *cmat, *mean, *basetheta;
     const double *cmat0p, *par0;    // packed upper cmat0 [P], par0 [d] (shared by all chains)
     uint32_t *ictr;
@@ -321,7 +326,8 @@ MCX_DEV double target_ss(const DevTarget &t, int d, int lane, const double *c_t,
                             for (int u = 0; u < PW; ++u) { int i = I0 + (u < nr ? u : nr - 1); vi[u] = GV(c_t, i) - g_mu[i]; }
 #pragma unroll
                             for (int u = 0; u < PW; ++u) {
-                                if (u < nr) { if (h == 0 && u < 4) q[u & 3] = y[p][u] * vi[u]; else q[u & 3] = dfma(y[p][u], vi[u], q[u & 3]); }
+                                if (u < nr) { if (h == 0 && u < 4) q[u & 3] = y[p][u] * vi[u]; else q[u & 3] = dfma(y[p][u], vi[u],
+                                    q[u & 3]); }
                             }
                         }
                     }
@@ -383,10 +389,14 @@ MCX_DEV bool target_inbounds(const DevTarget &t, int d, int lane, const double *
 }
 
 #ifndef MCX_POOLED_NB
-#define MCX_POOLED_NB 8      // ... in pooled_mfma_kernel (one wave per SIMD, nothing else to issue while an attempt's chain waits: config 4 pooled 9.25e8 -> 9.65e8 at 8; 1: 9.04, 4: 9.21, 12: 9.55, 16: 8.99)
+// ... in pooled_mfma_kernel (one wave per SIMD, nothing else to issue while an attempt's chain waits: config 4 pooled 9.25e8 -> 9.65e8 at
+// 8; 1: 9.04, 4: 9.21, 12: 9.55, 16: 8.99)
+#define MCX_POOLED_NB 8
 #endif
 #ifndef MCX_POOLED_SPLIT
-#define MCX_POOLED_SPLIT 1   // pooled_mfma_kernel draws its vector in two passes (gen_normals_split): attempts first, the logarithm / root / divisions for the kept pairs only
+// pooled_mfma_kernel draws its vector in two passes (gen_normals_split): attempts first, the logarithm / root / divisions for the kept
+// pairs only
+#define MCX_POOLED_SPLIT 1
 #endif
 #ifndef MCX_POOLED_NBB
 #define MCX_POOLED_NBB 4
@@ -397,7 +407,9 @@ MCX_DEV bool target_inbounds(const DevTarget &t, int d, int lane, const double *
 #define MCX_POOLED_GEN gen_normals<MCX_POOLED_NB>
 #endif
 #ifndef MCX_RNG_NB
-#define MCX_RNG_NB 2      // polar attempts computed side by side in the kernels that wait for the generator (AM, DRAM, pooled); 4 loses at config 2 (d = 10: a vector is ~11 attempts)
+// polar attempts computed side by side in the kernels that wait for the generator (AM, DRAM, pooled); 4 loses at config 2 (d = 10: a vector
+// is ~11 attempts)
+#define MCX_RNG_NB 2
 #endif
 // ---------------------------------------------------------------- normals (mcmcrand.F90:60-83,166-190)
 // Each lane appends accepted polar pairs to its own column of zs (global scratch, element stride 64)
@@ -436,8 +448,10 @@ MCX_DEV double gen_normals(Rng &g, double *zs_t, int lane, int d, bool participa
         const bool odd = (g.n & 1) != 0;
         uint32_t w[NB + 1][4];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) philox4x32_10((uint32_t)(b0 + j), (uint32_t)((b0 + j) >> 32), g.k0, g.k1, w[j][0], w[j][1], w[j][2], w[j][3]);
-        if (__any(need && odd)) philox4x32_10((uint32_t)(b0 + NB), (uint32_t)((b0 + NB) >> 32), g.k0, g.k1, w[NB][0], w[NB][1], w[NB][2], w[NB][3]);
+        for (int j = 0; j < NB; ++j) philox4x32_10((uint32_t)(b0 + j), (uint32_t)((b0 + j) >> 32), g.k0, g.k1, w[j][0], w[j][1], w[j][2],
+            w[j][3]);
+        if (__any(need && odd)) philox4x32_10((uint32_t)(b0 + NB), (uint32_t)((b0 + NB) >> 32), g.k0, g.k1, w[NB][0], w[NB][1], w[NB][2],
+            w[NB][3]);
         else { w[NB][0] = w[NB][1] = w[NB][2] = w[NB][3] = 0u; }
         double za[NB], zb[NB];
         bool ok[NB];
@@ -475,7 +489,8 @@ MCX_DEV double gen_normals(Rng &g, double *zs_t, int lane, int d, bool participa
 // a wave runs ~40 attempts per lane for the 25 pairs a lane of npar 50 keeps (0.785 a try, the slowest lane sets the trip count), and in
 // the one-pass form every one of them pays for the logarithm, the square root and the two divisions.  Pass A makes the attempts -- the
 // Philox blocks, the two uniforms, the test xx < 1 -- and parks the ACCEPTED pair's (x2, x1) where its deviates will stand; it alone moves
-// the stream.  Pass B visits the parked pairs, exactly as many as the vector holds, and scales them: z = sqrt(-2 log(xx) / xx) with xx formed
+// the stream.  Pass B visits the parked pairs, exactly as many as the vector holds, and scales them: z = sqrt(-2 log(xx) / xx) with xx
+// formed
 // again from the same two numbers by the same two products and one sum.  Stream position, deviates, the cached second deviate and the order
 // of sum(z**2): those of gen_normals.
 template <int NB, int NBB = 4>
@@ -487,7 +502,8 @@ MCX_DEV double gen_normals_split(Rng &g, double *zs_t, int lane, int d, bool par
     const int k0 = k;
     bool need = participate && (k < d);
     double over = 0.0;                                    // x1 of the pair whose second deviate lies past the vector's end
-    // block b0 + NB -- the straddling pair's second half when the stream position is odd -- is the NEXT trip's block b0 for every lane that goes on
+    // block b0 + NB -- the straddling pair's second half when the stream position is odd -- is the NEXT trip's block b0 for every lane that
+    // goes on
     // (it consumed all NB attempts): carried over instead of computed again, NB blocks per trip after the first instead of NB + 1
     uint32_t cw0 = 0u, cw1 = 0u, cw2 = 0u, cw3 = 0u;
     uint64_t cblk1 = 0;                                   // the carried block's index + 1 (0: none)
@@ -498,7 +514,8 @@ MCX_DEV double gen_normals_split(Rng &g, double *zs_t, int lane, int d, bool par
         if (__all(!need || cblk1 == b0 + 1)) { w[0][0] = cw0; w[0][1] = cw1; w[0][2] = cw2; w[0][3] = cw3; }
         else philox4x32_10((uint32_t)b0, (uint32_t)(b0 >> 32), g.k0, g.k1, w[0][0], w[0][1], w[0][2], w[0][3]);
 #pragma unroll
-        for (int j = 1; j <= NB; ++j) philox4x32_10((uint32_t)(b0 + j), (uint32_t)((b0 + j) >> 32), g.k0, g.k1, w[j][0], w[j][1], w[j][2], w[j][3]);
+        for (int j = 1; j <= NB; ++j) philox4x32_10((uint32_t)(b0 + j), (uint32_t)((b0 + j) >> 32), g.k0, g.k1, w[j][0], w[j][1], w[j][2],
+            w[j][3]);
         cw0 = w[NB][0]; cw1 = w[NB][1]; cw2 = w[NB][2]; cw3 = w[NB][3]; cblk1 = b0 + NB + 1;
         double xa[NB], xb[NB];
         bool ok[NB];
@@ -507,7 +524,8 @@ MCX_DEV double gen_normals_split(Rng &g, double *zs_t, int lane, int d, bool par
             double x1 = odd ? bits_to_uniform(w[j][2], w[j][3]) : bits_to_uniform(w[j][0], w[j][1]);
             double x2 = odd ? bits_to_uniform(w[j + 1][0], w[j + 1][1]) : bits_to_uniform(w[j][2], w[j][3]);
             x1 = 2.0 * x1 - 1.0; x2 = 2.0 * x2 - 1.0;
-#ifdef MCX_PROBE_ALLOK                                             // tools/gen_bound.sh: every attempt accepted (NOT the reference's stream)
+// tools/gen_bound.sh: every attempt accepted (NOT the reference's stream)
+#ifdef MCX_PROBE_ALLOK
             if (!(x1 * x1 + x2 * x2 < 1.0)) { x1 *= 0.5; x2 *= 0.5; }
 #endif
             const double xx = x1 * x1 + x2 * x2;

@@ -185,7 +185,8 @@ MCX_DEV double d_exp(double x)
     const bool neg = (hx >> 31) != 0u;
     hx &= 0x7fffffff;
     if (hx >= 0x40862E42) return d_exp_ref(x);                           // |x| >= 709.78, infinite, NaN
-    // |x| > 0.5 ln 2: k = +-1 below 1.5 ln 2 (hi = x -+ ln2HI, lo = +-ln2LO), else k = int(x / ln 2 +- 0.5), hi = x - k ln2HI, lo = k ln2LO --
+    // |x| > 0.5 ln 2: k = +-1 below 1.5 ln 2 (hi = x -+ ln2HI, lo = +-ln2LO), else k = int(x / ln 2 +- 0.5), hi = x - k ln2HI, lo = k ln2LO
+    // --
     // the first form is the second with k forced (fma(-(+-1), ln2HI, x) rounds x -+ ln2HI once, (+-1) ln2LO is exact); k = 0 otherwise,
     // for which hi = x, lo = 0 and hi - lo = x
     const bool big = hx > 0x3fd62e42, mid = hx < 0x3FF0A2B2;

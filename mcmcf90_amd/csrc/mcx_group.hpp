@@ -149,7 +149,8 @@ template <int GW, int N>
 MCX_DEV void gblk_fmac(double &p, double z, const double *r)
 {
     if constexpr (GW == 16) blk_fmac<N>(p, z, r);
-    else { static_assert(N == 4, "a quad"); p = dfma(r[0], grp_bcast<4, 0>(z), p); p = dfma(r[1], grp_bcast<4, 1>(z), p); p = dfma(r[2], grp_bcast<4, 2>(z), p); p = dfma(r[3], grp_bcast<4, 3>(z), p); }
+    else { static_assert(N == 4, "a quad"); p = dfma(r[0], grp_bcast<4, 0>(z), p); p = dfma(r[1], grp_bcast<4, 1>(z), p); p = dfma(r[2],
+        grp_bcast<4, 2>(z), p); p = dfma(r[3], grp_bcast<4, 3>(z), p); }
 }
 template <int GW, int N>
 MCX_DEV void gblk_fmac2(double &pa, double &pb, double za, double zb, const double *r)
@@ -167,7 +168,8 @@ template <int GW, int N>
 MCX_DEV void gblk_addchain(double &q, double t)
 {
     if constexpr (GW == 16) blk_addchain<N>(q, t);
-    else { static_assert(N == 4, "a quad"); q = q + grp_bcast<4, 0>(t); q = q + grp_bcast<4, 1>(t); q = q + grp_bcast<4, 2>(t); q = q + grp_bcast<4, 3>(t); }
+    else { static_assert(N == 4, "a quad"); q = q + grp_bcast<4, 0>(t); q = q + grp_bcast<4, 1>(t); q = q + grp_bcast<4, 2>(t);
+        q = q + grp_bcast<4, 3>(t); }
 }
 template <int GW, int N>
 MCX_DEV void gblk_sqchain(double &ss, double v)
@@ -201,17 +203,20 @@ struct GChain {                         // the chain's stream: uniform over its 
 };
 
 #ifndef MCX_GROUP_SPLIT
-#define MCX_GROUP_SPLIT 1    // group_normals in two passes: attempts, then the logarithm / root / divisions for the kept pairs only (as gen_normals_split)
+// group_normals in two passes: attempts, then the logarithm / root / divisions for the kept pairs only (as gen_normals_split)
+#define MCX_GROUP_SPLIT 1
 #endif
 // ---------------------------------------------------------------- normals: sixteen polar attempts of a chain at a time
 // z[t] <- the chain's next npar deviates (position 16 t + l16; 0 in the padding), through the chain's LDS row.
 template <int D4, int GW>
-MCX_DEV void group_normals(uint32_t k0, uint32_t k1, GChain &g, double *zrow, int l16, int row, int d, bool act, double (&z)[GDims<D4, GW>::NS])
+MCX_DEV void group_normals(uint32_t k0, uint32_t k1, GChain &g, double *zrow, int l16, int row, int d, bool act, double (&z)[GDims<D4,
+    GW>::NS])
 {
     using G = GDims<D4, GW>;
     int k = 0;
     MCX_WAVE_LDS_SYNC();                                         // the previous round's reads of the row are done
-    if (act && g.saved) { if (l16 == 0) zrow[0] = g.saved_y; g.saved = 0; k = 1; }     // normal_bm's cached second deviate, mcmcrand.F90:172-175
+    // normal_bm's cached second deviate, mcmcrand.F90:172-175
+    if (act && g.saved) { if (l16 == 0) zrow[0] = g.saved_y; g.saved = 0; k = 1; }
     bool need = act && (k < d);
     bool newsave = false;
     const int kst = k;                                           // where the drawn pairs start
@@ -229,13 +234,15 @@ MCX_DEV void group_normals(uint32_t k0, uint32_t k1, GChain &g, double *zrow, in
         double x2 = odd ? bits_to_uniform(nw0, nw1) : bits_to_uniform(w2, w3);
         const bool valid = !(odd && l16 == GW - 1);
         x1 = 2.0 * x1 - 1.0; x2 = 2.0 * x2 - 1.0;
-#ifdef MCX_PROBE_ALLOK                                             // tools/gen_bound.sh: every attempt accepted (NOT the reference's stream) -- the round count no pooling of attempts can beat
+// tools/gen_bound.sh: every attempt accepted (NOT the reference's stream) -- the round count no pooling of attempts can beat
+#ifdef MCX_PROBE_ALLOK
         if (!(x1 * x1 + x2 * x2 < 1.0)) { x1 *= 0.5; x2 *= 0.5; }
 #endif
         const double xx = x1 * x1 + x2 * x2;
         const bool ok = valid && (xx < 1.0) && (xx != 0.0);
 #if MCX_GROUP_SPLIT
-        const double za = x2, zb = x1;                             // parked unscaled where the deviates will stand; scaled below, the kept pairs only
+        // parked unscaled where the deviates will stand; scaled below, the kept pairs only
+        const double za = x2, zb = x1;
 #else
         const double xs = ok ? xx : 0.5;
         const double zz = sqrt(-2.0 * d_log(xs) / xs);
@@ -262,7 +269,8 @@ MCX_DEV void group_normals(uint32_t k0, uint32_t k1, GChain &g, double *zrow, in
             }
         }
     }
-    MCX_WAVE_LDS_SYNC();                                         // (the wave's LDS operations retire in order: its reads below see its writes above)
+    // (the wave's LDS operations retire in order: its reads below see its writes above)
+    MCX_WAVE_LDS_SYNC();
 #if MCX_GROUP_SPLIT
     // the second pass: z = sqrt(-2 log(xx) / xx) (mcmcrand.F90:183) for the pairs that were KEPT -- (npar + 1) / 2 of them, where the
     // attempts above were 16 (4) a round whether accepted, needed or neither -- pair p of the chain on lane p mod 16 (4); xx is formed
@@ -368,7 +376,8 @@ MCX_DEV double group_ss(const DevTarget &t, const double (&x)[GDims<D4, GW>::NS]
 {
     using G = GDims<D4, GW>;
     double ss = 0.0;
-    if (TK == TGT_BANANA || (TK < 0 && t.kind == TGT_BANANA)) {                       // target_ss: ss = fma chain over theta_k**2, k ascending from 2
+    // target_ss: ss = fma chain over theta_k**2, k ascending from 2
+    if (TK == TGT_BANANA || (TK < 0 && t.kind == TGT_BANANA)) {
         const double th0 = grp_bcast<GW, 0>(x[0]), th1 = grp_bcast<GW, 1>(x[0]);
         const double t1 = th0 * th0;
         const double q = dfma(t.b, t1, th1) - 100.0 * t.b;
@@ -378,7 +387,8 @@ MCX_DEV double group_ss(const DevTarget &t, const double (&x)[GDims<D4, GW>::NS]
             const double w = (s == 0 && l16 < 2) ? 0.0 : x[s];        // fma(0, 0, ss) = ss: positions 0, 1 and the padding drop out
             gblk_sqchain<GW, G::blk(s)>(ss, w);
         });
-    } else if (TK == TGT_EXPDATA || (TK < 0 && t.kind == TGT_EXPDATA)) {               // ss = fma chain over the residuals, data index ascending
+    // ss = fma chain over the residuals, data index ascending
+    } else if (TK == TGT_EXPDATA || (TK < 0 && t.kind == TGT_EXPDATA)) {
         const double th0 = grp_bcast<GW, 0>(x[0]), th1 = grp_bcast<GW, 1>(x[0]);
         for (int base = 0; base < t.ndata; base += GW) {
             const int i = base + l16;
@@ -388,7 +398,8 @@ MCX_DEV double group_ss(const DevTarget &t, const double (&x)[GDims<D4, GW>::NS]
         }
     } else {                                          // Gaussian: mcxt_ss_gauss (oracle/mcx_targets.h), lane = row of Lam
         double v[G::NS], y[G::NS];
-        sfor<0, G::NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = GW * s + l16; v[s] = (c < d) ? x[s] - t.mu[c] : 0.0; });
+        sfor<0, G::NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = GW * s + l16;
+            v[s] = (c < d) ? x[s] - t.mu[c] : 0.0; });
         sfor<0, G::NS>([&](auto S) __attribute__((always_inline)) {
             constexpr int s = decltype(S)::value;
             const int c = GW * s + l16;
@@ -396,7 +407,8 @@ MCX_DEV double group_ss(const DevTarget &t, const double (&x)[GDims<D4, GW>::NS]
             sfor<0, G::NS>([&](auto TT) __attribute__((always_inline)) {
                 constexpr int tb = decltype(TT)::value;
                 constexpr int n = G::blk(tb);
-                double lam[n];                         // row c of the precision matrix from the wave's LDS copy [j][c] (pitch D4, zero padding)
+                // row c of the precision matrix from the wave's LDS copy [j][c] (pitch D4, zero padding)
+                double lam[n];
 #pragma unroll
                 for (int u = 0; u < n; ++u) lam[u] = laml[(GW * tb + u) * D4 + ((c < D4) ? c : D4 - 1)];
                 gblk_fmac<GW, n>(ys, v[tb], lam);
@@ -411,7 +423,8 @@ MCX_DEV double group_ss(const DevTarget &t, const double (&x)[GDims<D4, GW>::NS]
                 const int c = 16 * s + l16;
                 // lane k < 4 collects lanes k + 4, k + 8, k + 12
                 double q = y[s] * v[s];
-                const double y4 = row_down<4>(y[s]), v4 = row_down<4>(v[s]), y8 = row_down<8>(y[s]), v8 = row_down<8>(v[s]), y12 = row_down<12>(y[s]), v12 = row_down<12>(v[s]);
+                const double y4 = row_down<4>(y[s]), v4 = row_down<4>(v[s]), y8 = row_down<8>(y[s]), v8 = row_down<8>(v[s]),
+                    y12 = row_down<12>(y[s]), v12 = row_down<12>(v[s]);
                 if (c + 4 < d) q = dfma(y4, v4, q);
                 if (c + 8 < d) q = dfma(y8, v8, q);
                 if (c + 12 < d) q = dfma(y12, v12, q);
@@ -458,19 +471,24 @@ MCX_DEV double group_ss(const DevTarget &t, const double (&x)[GDims<D4, GW>::NS]
 #define MCX_GROUP_WAVES2 2
 #endif
 #ifndef MCX_GROUP_GAUSS1
-#define MCX_GROUP_GAUSS1 99      // the Gaussian target from this D4 on: one wave per SIMD (its matrix-vector product spills at 256 registers)
+// the Gaussian target from this D4 on: one wave per SIMD (its matrix-vector product spills at 256 registers)
+#define MCX_GROUP_GAUSS1 99
 #endif
 #ifndef MCX_GROUP_WAVES4
 #define MCX_GROUP_WAVES4 2       // quads (GW = 4)
 #endif
 template <int GW, int D4, int DRM, int TK>
-__global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (DRM == 2 && GW == 4 && D4 > 12) || (TK == TGT_GAUSS && D4 >= MCX_GROUP_GAUSS1)) ? 1 : (GW == 4 ? MCX_GROUP_WAVES4 : MCX_GROUP_WAVES2)) void group_step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ g_lamT, uint8_t *accb,
+__global__ __launch_bounds__(64,
+    (DRM == 1 || D4 > 32 || (DRM == 2 && GW == 4 && D4 > 12) || (TK == TGT_GAUSS && D4 >= MCX_GROUP_GAUSS1)) ? 1 : (GW == 4
+    ? MCX_GROUP_WAVES4 : MCX_GROUP_WAVES2)) void group_step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ g_lamT,
+    uint8_t *accb,
                                                                                                    const int *__restrict__ gflag, int want)
 {
     using G = GDims<D4, GW>;
     constexpr int NS = G::NS, CPW = G::CPW;
     constexpr bool DR = DRM != 0;
-    if (gflag && ((*gflag != 0) != (want != 0))) return;          // the other instantiation has this launch (wave-uniform: every wave reads the same word)
+    // the other instantiation has this launch (wave-uniform: every wave reads the same word)
+    if (gflag && ((*gflag != 0) != (want != 0))) return;
     // LDS: [iC squares of the four chains (DRM = 2)] [the chains' normal rows]: a padding lane's read past its chain's square lands in the
     // next square or in the normal rows (finite or not, its result is discarded)
     constexpr int SQ = (DRM == 2) ? D4 * D4 : 0;
@@ -480,9 +498,11 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (DRM == 2 && GW == 4 &&
     constexpr int LC = (LS >= 0) ? D4 - GW * LS : 0;                              // its columns
     constexpr int RL = LC * D4;                                                   // doubles per chain
     constexpr int NRR = (LS >= 0) ? G::off(LS) : G::NR;                           // doubles of R per lane that stay in registers
-    constexpr int LQ = (TK == TGT_GAUSS || TK < 0) ? D4 * D4 : 0;                   // the Gaussian target's precision matrix, [j][i] with pitch D4
+    // the Gaussian target's precision matrix, [j][i] with pitch D4
+    constexpr int LQ = (TK == TGT_GAUSS || TK < 0) ? D4 * D4 : 0;
     __shared__ double lds[CPW * SQ + CPW * RL + CPW * G::ZS + LQ];
-    const int lane = threadIdx.x, l16 = lane & (GW - 1), row = lane / GW, d = E.d;          // (l16: the lane's place in its group, row: the group = chain of the wave)
+    // (l16: the lane's place in its group, row: the group = chain of the wave)
+    const int lane = threadIdx.x, l16 = lane & (GW - 1), row = lane / GW, d = E.d;
     const int chain = blockIdx.x * CPW + row, tile = chain >> 6, cl = chain & 63;
     const size_t nslots = (size_t)E.ntiles * 64;
     double *zrow = lds + CPW * SQ + CPW * RL + row * G::ZS;
@@ -490,10 +510,12 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (DRM == 2 && GW == 4 &&
     const double *laml = lds + CPW * SQ + CPW * RL + CPW * G::ZS;
     if constexpr (LQ > 0) {
         if (E.tgt.kind == TGT_GAUSS) {
-            for (int e = lane; e < D4 * D4; e += 64) { const int j = e / D4, i = e % D4; lds[CPW * SQ + CPW * RL + CPW * G::ZS + e] = (i < d && j < d) ? g_lamT[(size_t)j * d + i] : 0.0; }
+            for (int e = lane; e < D4 * D4; e += 64) { const int j = e / D4, i = e % D4;
+                lds[CPW * SQ + CPW * RL + CPW * G::ZS + e] = (i < d && j < d) ? g_lamT[(size_t)j * d + i] : 0.0; }
         }
     }
-    const double *rll = lds + CPW * SQ + row * RL + ((l16 < LC) ? l16 : (LC > 0 ? LC - 1 : 0));     // (lanes past the slot's columns read its last one: finite, discarded)
+    // (lanes past the slot's columns read its last one: finite, discarded)
+    const double *rll = lds + CPW * SQ + row * RL + ((l16 < LC) ? l16 : (LC > 0 ? LC - 1 : 0));
 
     // ---- factors into registers / LDS (once per launch)
     double Rr[NRR > 0 ? NRR : 1], R2r[DRM == 1 ? G::NR : 1], Sr[DRM == 1 ? NS * D4 : 1];
@@ -535,7 +557,8 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (DRM == 2 && GW == 4 &&
             }
         });
     }
-    MCX_WAVE_LDS_SYNC();                                       // the fills above (Lam, R's last slot, iC) before any lane reads another lane's part
+    // the fills above (Lam, R's last slot, iC) before any lane reads another lane's part
+    MCX_WAVE_LDS_SYNC();
     const double inv2 = (DRM == 2) ? 1.0 / E.drscale : 1.0;   // exact: drscale is a power of two in this instantiation
     double th[NS];
     sfor<0, NS>([&](auto S) __attribute__((always_inline)) {
@@ -617,12 +640,14 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (DRM == 2 && GW == 4 &&
         const double pri = group_prior<D4, GW>(E.tgt, cand, l16, d);
         const double ss = group_ss<D4, TK, GW>(E.tgt, cand, l16, d, laml);
         GPH(2)
-        // ---- second stages: MCMC_DR_alpha13's two quadratic forms dx' iC dx, dx_a = newpar2 - newpar, dx_b = oldpar - newpar (MCMC_DRAM.F90:176-182)
+        // ---- second stages: MCMC_DR_alpha13's two quadratic forms dx' iC dx, dx_a = newpar2 - newpar, dx_b = oldpar - newpar
+        // (MCMC_DRAM.F90:176-182)
         double qa = 0.0, qb = 0.0;
         if constexpr (DR) {
             if (any2) {
                 double xa[NS], xb[NS], ta[NS], tb_[NS];
-                sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; xa[s] = cand[s] - c1[s]; xb[s] = th[s] - c1[s]; });
+                sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; xa[s] = cand[s] - c1[s];
+                    xb[s] = th[s] - c1[s]; });
                 sfor<0, NS>([&](auto S) __attribute__((always_inline)) {
                     constexpr int s = decltype(S)::value;
                     double ya = -0.0, yb = -0.0;                      // first term a plain product (see blk_fmac2)
@@ -641,7 +666,8 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (DRM == 2 && GW == 4 &&
                     const bool in = GW * s + l16 < d;
                     ta[s] = in ? ya * xa[s] : 0.0; tb_[s] = in ? yb * xb[s] : 0.0;
                 });
-                sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; gblk_addchain<GW, G::blk(s)>(qa, ta[s]); gblk_addchain<GW, G::blk(s)>(qb, tb_[s]); });
+                sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; gblk_addchain<GW,
+                    G::blk(s)>(qa, ta[s]); gblk_addchain<GW, G::blk(s)>(qb, tb_[s]); });
             }
         }
         GPH(3)
@@ -650,7 +676,8 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (DRM == 2 && GW == 4 &&
         double alpha = 0.0;
         {
             // tst of MCMC_alpha for a first stage, l2 of MCMC_DR_alpha13 for a second: the same expression of the same operands
-            // (x / 1.0 is x: with sigma2 = 1 on every chain of the wave -- no sigma2 update, the reference's default -- the divisions are skipped)
+            // (x / 1.0 is x: with sigma2 = 1 on every chain of the wave -- no sigma2 update, the reference's default -- the divisions are
+            // skipped)
             const bool s2one = __all(sigma2 == 1.0);
             double dss = ss - ss1, dss2 = ss2s - ss;
             if (!s2one) { dss = dss / sigma2; dss2 = dss2 / sigma2; }
@@ -660,11 +687,13 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (DRM == 2 && GW == 4 &&
             const double a32 = -0.5 * (dss2 + (pri2s - pri));
             const double e1 = d_exp((DR && st2) ? a32 : tstl);
             if (act) {
-                if (er) {                                                   // early rejection, MCMC_run_er.F90:60-89: u is always drawn (MCMC_sscrit)
+                // early rejection, MCMC_run_er.F90:60-89: u is always drawn (MCMC_sscrit)
+                if (er) {
                     if (!inb) bnd += 1;
                     else take = true;
                 } else if (!(DR && st2)) {
-                    if (!inb) { alpha12 = 0.0; if (!DR) bnd += 1; }          // MCMC_run.F90:49 (with DR an out-of-bounds first stage is not counted)
+                    // MCMC_run.F90:49 (with DR an out-of-bounds first stage is not counted)
+                    if (!inb) { alpha12 = 0.0; if (!DR) bnd += 1; }
                     else {
                         alpha12 = (tstl >= 0.0) ? 1.0 : ((tstl < -708.39641853226408) ? 0.0 : e1);      // d_alpha
                         if (alpha12 >= 1.0) rej = false;
@@ -687,7 +716,8 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (DRM == 2 && GW == 4 &&
         if (__any(take)) {
             const double u = group_uniform<GW>(k0, k1, g, take, row);
             if (er) {
-                if (take) {                                                  // sscrit = -2 log u + ss1 / sigma2 + pri1 (MCMC_DRAM.F90:124-135)
+                // sscrit = -2 log u + ss1 / sigma2 + pri1 (MCMC_DRAM.F90:124-135)
+                if (take) {
                     double sscrit = -2.0 * d_log(u) + ss1 / sigma2 + pri1;
                     if (pri >= sscrit) erstayed += 1;                        // rejected on the prior alone
                     else { sscrit = sigma2 * (sscrit - pri); rej = (ss >= sscrit); }
@@ -708,11 +738,13 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (DRM == 2 && GW == 4 &&
                     sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; th[s] = cand[s]; });
                     if (E.hist) {
                         double *h = E.hist + ((size_t)tile * E.wcap + (it % E.wcap)) * (size_t)E.hs * 64;
-                        sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = GW * s + l16; if (c < d) h[(size_t)c * 64 + cl] = th[s]; });
+                        sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value;
+                            const int c = GW * s + l16; if (c < d) h[(size_t)c * 64 + cl] = th[s]; });
                         if (l16 == 0) h[(size_t)d * 64 + cl] = ss1;
                     }
                 }
-                if (accb && l16 == 0) accb[(size_t)(it - it0) * nslots + chain] = rej ? (uint8_t)0 : (uint8_t)1;   // the accept byte for the ballots
+                // the accept byte for the ballots
+                if (accb && l16 == 0) accb[(size_t)(it - it0) * nslots + chain] = rej ? (uint8_t)0 : (uint8_t)1;
                 fin = true;
             }
         }
@@ -745,7 +777,8 @@ __global__ __launch_bounds__(64, (DRM == 1 || D4 > 32 || (DRM == 2 && GW == 4 &&
 #endif
 #undef GPH
 
-    sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = GW * s + l16; if (c < d) TIDX(E.theta, tile, d, c, cl) = th[s]; });
+    sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = GW * s + l16;
+        if (c < d) TIDX(E.theta, tile, d, c, cl) = th[s]; });
     if (l16 == 0) {
         TIDX(E.scal, tile, NSCAL, S_SIGMA2, cl) = sigma2;
         TIDX(E.rngn, tile, 1, 0, cl) = g.n;
@@ -766,25 +799,35 @@ __global__ void group_check_kernel(EngineDev E, int *flag)
     const int lane = threadIdx.x, tile = blockIdx.x;
     const double *Rt = E.R + (size_t)tile * E.P * 64;
     bool bad = false;
-    for (int e = 0; e < E.P; ++e) { const double r = GV(Rt, e); const double ar = fabs(r); bad = bad || (r != 0.0 && !(ar >= 0x1.0p-500 && ar <= 0x1.0p500)); }
+    for (int e = 0; e < E.P; ++e) { const double r = GV(Rt, e); const double ar = fabs(r);
+        bad = bad || (r != 0.0 && !(ar >= 0x1.0p-500 && ar <= 0x1.0p500)); }
     if (__any(bad) && lane == 0) atomicOr(flag, 1);
 }
 
-// ---------------------------------------------------------------- MCMC_calculate_R with the matrices in LDS (Cholesky branch, MCMC_adapt.F90:211-225)
-// adapt_post_kernel's factorisation for the chains whose tick recomputes the factor (ADF_DOCALC), any chain count, npar <= 64: a WORKGROUP of NW
-// waves owns 4 NW neighbouring chains of a tile and moves their matrices between HBM and LDS cooperatively, 32 NW contiguous bytes per element --
-// whole 128-byte lines at NW = 4 -- and the workgroups of one tile sit on one XCD (blockIdx round-robins over the eight), whose L2 combines what
-// is left.  The LDS copy is the PACKED upper triangle by rows (every operand of dpotf2 / dtrti2 / dlauu2 lies in it), so that npar 50 -- BASELINE
+// ---------------------------------------------------------------- MCMC_calculate_R with the matrices in LDS (Cholesky branch,
+// MCMC_adapt.F90:211-225)
+// adapt_post_kernel's factorisation for the chains whose tick recomputes the factor (ADF_DOCALC), any chain count, npar <= 64: a WORKGROUP
+// of NW
+// waves owns 4 NW neighbouring chains of a tile and moves their matrices between HBM and LDS cooperatively, 32 NW contiguous bytes per
+// element --
+// whole 128-byte lines at NW = 4 -- and the workgroups of one tile sit on one XCD (blockIdx round-robins over the eight), whose L2 combines
+// what
+// is left.  The LDS copy is the PACKED upper triangle by rows (every operand of dpotf2 / dtrti2 / dlauu2 lies in it), so that npar 50 --
+// BASELINE
 // config 4's size with method = 'dram' -- holds four chains in 41 kB and three workgroups share a CU.  Sixteen lanes per chain, a lane owns
-// NC = ceil(npar / 16) columns (dpotf2) / rows (dtrti2, dlauu2); every chain of operations is the one of calculate_R / potri_packed (mcx_adapt.hpp):
-//   dpotf2('U'):   lane = COLUMN k of the factor; step j adds T(i,j) T(i,k), i < j ascending, to column k's chain (T(i,j) is a broadcast read),
+// NC = ceil(npar / 16) columns (dpotf2) / rows (dtrti2, dlauu2); every chain of operations is the one of calculate_R / potri_packed
+// (mcx_adapt.hpp):
+// dpotf2('U'):   lane = COLUMN k of the factor; step j adds T(i,j) T(i,k), i < j ascending, to column k's chain (T(i,j) is a broadcast
+// read),
 //                  every lane also runs the pivot's own chain, so the pivot needs no exchange; R = T 2.4 / sqrt(npar); R2 = R / drscale;
-//   dtrti2('U'):   lane = ROW r of the inverse; element (r,j) = -1/A(j,j) x [A(r,j) Ainv(r,r), then + A(jj,j) Ainv(r,jj) for jj = r+1..j-1 ascending]:
+// dtrti2('U'):   lane = ROW r of the inverse; element (r,j) = -1/A(j,j) x [A(r,j) Ainv(r,r), then + A(jj,j) Ainv(r,jj) for jj = r+1..j-1
+// ascending]:
 //                  dtrmv's column sweep read per ROW -- the temp of sweep jj is the ORIGINAL A(jj,j), sweep r starts row r's chain with the
 //                  product, the sweeps behind it add their terms in order -- so the rows of one column are independent chains;
 //   dlauu2('U'):   lane = ROW r: A(r,i) = A(i,i) A(r,i) + sum_{k>i} A(i,k) A(r,k) ascending k; the diagonal's sum of squares on every lane.
 // adapt_post_kernel streamed the packed matrices of a tile ~5.6 times through L2 / HBM for its 8 x 8 register blocks (33.5 ms per tick of
-// 1 048 576 chains at npar 50, 2.2 ms at config 3's size); this reads and writes each once.  Results: R, R2, iC, I_INFO and the status bits, as
+// 1 048 576 chains at npar 50, 2.2 ms at config 3's size); this reads and writes each once.  Results: R, R2, iC, I_INFO and the status
+// bits, as
 // adapt_post_kernel leaves them.  (Round 4's one-wave form with [row][column] squares in LDS, group_factor_kernel, is superseded:
 // tools/variants/README.md.)
 // Grid: 8 ceil(ntiles / 8) (64 / (4 NW)) workgroups of 64 NW threads; LDS: 4 NW (P | 1) doubles + 4 NW ints.
@@ -792,18 +835,21 @@ template <int NC, int NW>
 __global__ __launch_bounds__(64 * NW) void tile_factor_kernel(EngineDev E)
 {
     extern __shared__ double Mf[];
-    constexpr int CH = 4 * NW, WPT = 64 / CH, ES = 64 * NW / CH;          // chains per workgroup, workgroups per tile, elements per cooperative pass
+    // chains per workgroup, workgroups per tile, elements per cooperative pass
+    constexpr int CH = 4 * NW, WPT = 64 / CH, ES = 64 * NW / CH;
     const int wg = blockIdx.x, xcd = wg & 7, idx = wg >> 3;
     const int tile = (idx / WPT) * 8 + xcd, part = idx % WPT;
     if (tile >= E.ntiles) return;                                          // (uniform over the workgroup)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l16 = lane & 15, row = lane >> 4;
     const int d = E.d, P = E.P, PS = P | 1;
     const int cl0 = part * CH, cl = cl0 + 4 * w + row;                      // this lane's chain of the tile
-    double *M = Mf + (size_t)(4 * w + row) * PS;                            // its packed upper triangle: element (i,k), i <= k, at i d - i (i + 1) / 2 + k
+    // its packed upper triangle: element (i,k), i <= k, at i d - i (i + 1) / 2 + k
+    double *M = Mf + (size_t)(4 * w + row) * PS;
     int *flg = (int *)(Mf + (size_t)CH * PS);
     const bool act = (TIDX(E.ictr, tile, NICTR, I_ADFLAGS, cl) & ADF_DOCALC) != 0;
     if (!__syncthreads_or(act ? 1 : 0)) return;
-    const int cc = tid % CH, e0 = tid / CH;                                 // cooperative moves: chain cc of the workgroup, elements e0, e0 + ES, ...
+    // cooperative moves: chain cc of the workgroup, elements e0, e0 + ES, ...
+    const int cc = tid % CH, e0 = tid / CH;
     // (sixteen elements' loads before their LDS stores: element by element every load is a round trip of its own -- 80 in a row at npar 50)
     constexpr int CB = 16;
     {
@@ -818,17 +864,20 @@ __global__ __launch_bounds__(64 * NW) void tile_factor_kernel(EngineDev E)
         }
     }
     __syncthreads();
-    int kk[NC], kc[NC];                                                     // this lane's columns / rows, and clamped for the branch-free loops
+    // this lane's columns / rows, and clamped for the branch-free loops
+    int kk[NC], kc[NC];
 #pragma unroll
     for (int q = 0; q < NC; ++q) { kk[q] = l16 + 16 * q; kc[q] = kk[q] < d ? kk[q] : d - 1; }
-    // ---- dpotf2('U'): lane = column k; step j adds T(i,j) T(i,k), i < j ascending, to column k's chain; every lane runs the pivot's own chain
+    // ---- dpotf2('U'): lane = column k; step j adds T(i,j) T(i,k), i < j ascending, to column k's chain; every lane runs the pivot's own
+    // chain
     int info = 0;
     for (int j = 0; j < d; ++j) {
         MCX_WAVE_LDS_SYNC();                                                // row j - 1 (other lanes' columns) is written
         double acc[NC], accj = 0.0;
 #pragma unroll
         for (int q = 0; q < NC; ++q) acc[q] = 0.0;
-        int rb = 0;                                                         // rowstart(i) - i: element (i,k) at rb + k  (k < i: in bounds, dropped)
+        // rowstart(i) - i: element (i,k) at rb + k  (k < i: in bounds, dropped)
+        int rb = 0;
 #pragma unroll 4
         for (int i = 0; i < j; ++i) {
             const double tij = M[rb + j];
@@ -858,7 +907,8 @@ __global__ __launch_bounds__(64 * NW) void tile_factor_kernel(EngineDev E)
         if (info != 0) TIDX(E.ictr, tile, NICTR, I_STATUS, cl) |= ST_CHOL_FAIL;          // warning, old R kept (MCMC_adapt.F90:168-171)
     }
     MCX_WAVE_LDS_SYNC();
-    // ---- R = T 2.4 / sqrt(npar), out with it -- and R2 = R / drscale -- cooperatively; the LDS copy takes the scaling too (dpotri works on R)
+    // ---- R = T 2.4 / sqrt(npar), out with it -- and R2 = R / drscale -- cooperatively; the LDS copy takes the scaling too (dpotri works
+    // on R)
     if (l16 == 0) flg[4 * w + row] = ok ? 1 : 0;
     __syncthreads();
     if (flg[cc]) {
@@ -878,7 +928,8 @@ __global__ __launch_bounds__(64 * NW) void tile_factor_kernel(EngineDev E)
         }
     }
     if (!E.dodr) return;
-    if (!__syncthreads_or(ok ? 1 : 0)) return;                              // (also: the scaled copies above are written before dpotri reads them)
+    // (also: the scaled copies above are written before dpotri reads them)
+    if (!__syncthreads_or(ok ? 1 : 0)) return;
     // ---- iC = dpotri('U', R): dtrti2 then dlauu2, in place on the scaled factor; lane = ROW r
     int info2 = 0;
     { int rb = 0; for (int j = 0; j < d; ++j) { if (ok && info2 == 0 && M[rb + j] == 0.0) info2 = j + 1; rb += d - (j + 1); } }
@@ -889,7 +940,8 @@ __global__ __launch_bounds__(64 * NW) void tile_factor_kernel(EngineDev E)
     for (int q = 0; q < NC; ++q) rbr[q] = kc[q] * d - kc[q] * (kc[q] + 1) / 2;
     if (__any(go)) {
         int rbj = 0;                                                        // row j
-        for (int j = 0; j < d; ++j) {                        // dtrti2: element (r,j) = -1/A(j,j) x [A(r,j) Ainv(r,r), then + A(jj,j) Ainv(r,jj), jj = r+1..j-1 ascending]
+        // dtrti2: element (r,j) = -1/A(j,j) x [A(r,j) Ainv(r,r), then + A(jj,j) Ainv(r,jj), jj = r+1..j-1 ascending]
+        for (int j = 0; j < d; ++j) {
             MCX_WAVE_LDS_SYNC();                             // column j - 1 (other lanes' rows) is written
             const double ajj = 1.0 / M[rbj + j];
             double x[NC];
@@ -918,7 +970,8 @@ __global__ __launch_bounds__(64 * NW) void tile_factor_kernel(EngineDev E)
             rbj += d - (j + 1);
         }
         int rbi = 0;                                                        // row i
-        for (int i = 0; i < d; ++i) {                        // dlauu2: A(r,i) = A(i,i) A(r,i) + sum_{k>i} A(i,k) A(r,k) ascending k; the diagonal's sum of squares on every lane
+        // dlauu2: A(r,i) = A(i,i) A(r,i) + sum_{k>i} A(i,k) A(r,k) ascending k; the diagonal's sum of squares on every lane
+        for (int i = 0; i < d; ++i) {
             MCX_WAVE_LDS_SYNC();
             const double aii = M[rbi + i];
             if (i < d - 1) {

@@ -1,25 +1,32 @@
 // mcx_group_ram.hpp -- MCMC_run_ram (MCMC_run_ram.F90:45-179) in the lane-group layout: sixteen lanes per chain, four chains per wave, the
-// factor R in REGISTERS for the whole launch and MCMC_adapt_ram's rank-one update / downdate (dchud.f:122-139, dchdd.f:141-179) performed on it
+// factor R in REGISTERS for the whole launch and MCMC_adapt_ram's rank-one update / downdate (dchud.f:122-139, dchdd.f:141-179) performed
+// on it
 // there.  Included by mcx_api.hip after mcx_group.hpp (round 5; VERDICT round 4, "a few-chains RAM path").
 //
-// Why: with few chains an iteration is latency.  The lane-per-chain RAM kernels stream the packed factor through L2 twice per iteration, one
-// dependent row visit after the other: 184 us per iteration at 64 chains and npar 50, against ~8 us for the reference on one host core.  Here the
+// Why: with few chains an iteration is latency.  The lane-per-chain RAM kernels stream the packed factor through L2 twice per iteration,
+// one
+// dependent row visit after the other: 184 us per iteration at 64 chains and npar 50, against ~8 us for the reference on one host core.
+// Here the
 // factor never leaves the registers between two launches (npar 50: 152 doubles per lane, one wave per SIMD) and an iteration is ~20-35 us.
 // It is NOT a throughput kernel -- a wave runs DCHUD's fifty serial drotg for four chains where a lane-per-chain wave runs them for 64
-// (profiles/r04_a/ram_group_probe.txt, profiles/r05_a/ram_group8_probe.txt: measured, closed) -- it saturates at the 4096 chains the chip holds at one
-// wave per SIMD (1.68e8 chain-iterations/s at npar 50, where the streaming kernels reach 2.3e8 with 131072 chains and more), so the engine takes it up
+// (profiles/r04_a/ram_group_probe.txt, profiles/r05_a/ram_group8_probe.txt: measured, closed) -- it saturates at the 4096 chains the chip
+// holds at one
+// wave per SIMD (1.68e8 chain-iterations/s at npar 50, where the streaming kernels reach 2.3e8 with 131072 chains and more), so the engine
+// takes it up
 // to 16384 chains (32768 from npar 17 on: mcx_api.hip, ram_group_wins; profiles/r05_b/ram_group_sweep.txt).
 //
-// Layout as in group_step_kernel: lane l16 of a chain owns the columns l16, l16 + 16, ... of R (rows 0..column in registers, zeros below the
+// Layout as in group_step_kernel: lane l16 of a chain owns the columns l16, l16 + 16, ... of R (rows 0..column in registers, zeros below
+// the
 // diagonal), a vector element k sits in lane k mod 16 (slot k / 16) and reaches the others by row_newbcast.
 //   proposal   p_c = sum_{i <= c} R(i,c) z_i ascending in i (v_fmac_f64_dpp chains); after a successful downdate the reference order is the
-//              diagonal term as a plain product first, then rows c - 1 .. 0 (mcxo_trmv_ut_desc) -- the same uniform walk
+// diagonal term as a plain product first, then rows c - 1 .. 0 (mcxo_trmv_ut_desc) -- the same uniform walk
 //              from the last row down with the lane's own diagonal row selected as the chain's start.
-//   DCHUD      step i: (R(i,i), x_i) -> drotg on every lane of the chain (broadcast inputs, so c and s are uniform); row i of every later column
+// DCHUD      step i: (R(i,i), x_i) -> drotg on every lane of the chain (broadcast inputs, so c and s are uniform); row i of every later
+// column
 //              and the work vector rotate -- tools/ram_group_probe.hip's loop, masked per chain.
-//   DCHDD      forward substitution RIGHT-looking: s_j = (x_j - acc_j) / R(j,j) on the owner lane, broadcast, acc_k = fma(R(j,k), s_j, acc_k)
-//              for the columns k > j -- every column's ddot receives its terms in ascending row order, as dchdd.f:145 takes them; the classic
-//              dnrm2 recurrence runs along on the broadcast values; then rotations are generated from the LAST element backwards (dchdd.f:158-167,
+// DCHDD      forward substitution RIGHT-looking: s_j = (x_j - acc_j) / R(j,j) on the owner lane, broadcast, acc_k = fma(R(j,k), s_j, acc_k)
+// for the columns k > j -- every column's ddot receives its terms in ascending row order, as dchdd.f:145 takes them; the classic
+// dnrm2 recurrence runs along on the broadcast values; then rotations are generated from the LAST element backwards (dchdd.f:158-167,
 //              uniform over the chain) and each is applied at once to row k of the columns >= k (column j's own recurrence xx_j starts at
 //              its diagonal, dchdd.f:171-179) -- no rotation is ever stored.
 // Every operation on every element is the one ram_update / ram_update_full (mcx_kernels.hpp) perform: bit-equal to the lane kernels and the
@@ -29,7 +36,8 @@
 namespace mcx {
 
 // p = fma(r_i, z_i, p) over the rows i = N-1 .. 0 of a block, lane-uniform walk, with the chain's START at the lane's own diagonal row
-// (i == dg: p = r_i * z_i, a plain product; rows above it: untouched).  dg: the lane's diagonal row inside this block, or -1 (the whole block
+// (i == dg: p = r_i * z_i, a plain product; rows above it: untouched).  dg: the lane's diagonal row inside this block, or -1 (the whole
+// block
 // lies above / below the lane's column start: `live` says whether the chain has started).
 template <int N>
 MCX_DEV void blk_fmac_desc(double &p, bool &live, double z, const double *r, int dg)
@@ -49,7 +57,8 @@ __global__ __launch_bounds__(64, 1) void group_ram_kernel(EngineDev E, int it0, 
 {
     using G = GDims<D4, 16>;
     constexpr int NS = G::NS, CPW = 4, GW = 16;
-    constexpr int LQ = (TK == TGT_GAUSS || TK < 0) ? D4 * D4 : 0;                   // the Gaussian target's precision matrix, [j][i] with pitch D4
+    // the Gaussian target's precision matrix, [j][i] with pitch D4
+    constexpr int LQ = (TK == TGT_GAUSS || TK < 0) ? D4 * D4 : 0;
     __shared__ double lds[CPW * G::ZS + LQ];
     const int lane = threadIdx.x, l16 = lane & 15, row = lane >> 4, d = E.d;
     const int chain = blockIdx.x * CPW + row, tile = chain >> 6, cl = chain & 63;
@@ -58,7 +67,8 @@ __global__ __launch_bounds__(64, 1) void group_ram_kernel(EngineDev E, int it0, 
     const double *laml = lds + CPW * G::ZS;
     if constexpr (LQ > 0) {
         if (E.tgt.kind == TGT_GAUSS)
-            for (int e = lane; e < D4 * D4; e += 64) { const int j = e / D4, i = e % D4; lds[CPW * G::ZS + e] = (i < d && j < d) ? g_lamT[(size_t)j * d + i] : 0.0; }
+            for (int e = lane; e < D4 * D4; e += 64) { const int j = e / D4, i = e % D4;
+                lds[CPW * G::ZS + e] = (i < d && j < d) ? g_lamT[(size_t)j * d + i] : 0.0; }
     }
     // ---- the factor into registers (once per launch; written back at its end)
     double Rr[G::NR];
@@ -101,7 +111,8 @@ __global__ __launch_bounds__(64, 1) void group_ram_kernel(EngineDev E, int it0, 
         double z[NS], cand[NS];
         group_normals<D4, GW>(k0, k1, g, zrow, l16, row, d, true, z);
         double su = 0.0;
-        sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; gblk_addchain<GW, G::blk(s)>(su, z[s] * z[s]); });
+        sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; gblk_addchain<GW, G::blk(s)>(su,
+            z[s] * z[s]); });
         const bool anydesc = __any(pdesc);
         sfor<0, NS>([&](auto S) __attribute__((always_inline)) {
             constexpr int s = decltype(S)::value;
@@ -145,12 +156,14 @@ __global__ __launch_bounds__(64, 1) void group_ram_kernel(EngineDev E, int it0, 
             sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; th[s] = cand[s]; });
             if (E.hist) {
                 double *h = E.hist + ((size_t)tile * E.wcap + (it % E.wcap)) * (size_t)E.hs * 64;
-                sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = GW * s + l16; if (c < d) h[(size_t)c * 64 + cl] = th[s]; });
+                sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = GW * s + l16;
+                    if (c < d) h[(size_t)c * 64 + cl] = th[s]; });
                 if (l16 == 0) h[(size_t)d * 64 + cl] = ss1;
             }
         }
         if (accb && l16 == 0) accb[(size_t)(it - it0) * nslots + chain] = rej ? (uint8_t)0 : (uint8_t)1;
-        if (E.updatesigma) {                                // MCMC_updatesigma2: the chain's own sampler on the chain's stream, sixteen identical copies
+        // MCMC_updatesigma2: the chain's own sampler on the chain's stream, sixteen identical copies
+        if (E.updatesigma) {
             Rng q;
             q.k0 = k0; q.k1 = k1; q.n = g.n; q.cblk = 0; q.c2 = 0; q.c3 = 0; q.saved = g.saved; q.saved_y = g.saved_y;
             const double gm = rng_gamma(q, E.gam_shape, 2.0 / (E.N0S02 + ss1));
@@ -210,7 +223,8 @@ __global__ __launch_bounds__(64, 1) void group_ram_kernel(EngineDev E, int it0, 
                             const double f = dfma(Rr[G::off(sj) + j], s_j, acc[sj]);
                             acc[sj] = (l16 > lj) ? f : acc[sj];
                         }
-                        sfor<sj + 1, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s2 = decltype(S)::value; acc[s2] = dfma(Rr[G::off(s2) + j], s_j, acc[s2]); });
+                        sfor<sj + 1, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s2 = decltype(S)::value;
+                            acc[s2] = dfma(Rr[G::off(s2) + j], s_j, acc[s2]); });
                         // dnrm2, classic scale / ssq form (dchdd.f:149)
                         if (j == 0) s0abs = fabs(s_j);
                         if (s_j != 0.0) {
@@ -226,7 +240,8 @@ __global__ __launch_bounds__(64, 1) void group_ram_kernel(EngineDev E, int it0, 
                 const bool go = dn && !fail;
                 if (dn) pdesc = go;
                 if (__any(go)) {
-                    // rotations from the last element backwards (dchdd.f:158-167), each applied at once to row k of the columns >= k (:171-179)
+                    // rotations from the last element backwards (dchdd.f:158-167), each applied at once to row k of the columns >= k
+                    // (:171-179)
                     double alpha = sqrt(1.0 - norm * norm);
                     double xx[NS];
                     sfor<0, NS>([&](auto S) __attribute__((always_inline)) { xx[decltype(S)::value] = 0.0; });
@@ -270,7 +285,8 @@ __global__ __launch_bounds__(64, 1) void group_ram_kernel(EngineDev E, int it0, 
             for (int i = 0; i < G::rows(s); ++i) if (c < d && i <= c) Rt[(size_t)pidx(i, c, d) * 64 + cl] = Rr[G::off(s) + i];
         });
     }
-    sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = GW * s + l16; if (c < d) TIDX(E.theta, tile, d, c, cl) = th[s]; });
+    sfor<0, NS>([&](auto S) __attribute__((always_inline)) { constexpr int s = decltype(S)::value; const int c = GW * s + l16;
+        if (c < d) TIDX(E.theta, tile, d, c, cl) = th[s]; });
     if (l16 == 0) {
         TIDX(E.scal, tile, NSCAL, S_SIGMA2, cl) = sigma2;
         TIDX(E.rngn, tile, 1, 0, cl) = g.n;

@@ -1,6 +1,8 @@
-// mcx_phase.hpp -- the iteration cut at the user's evaluations: host_phase_kernel (host callbacks), dev_eval_kernel + step_kernel_cols (device
+// mcx_phase.hpp -- the iteration cut at the user's evaluations: host_phase_kernel (host callbacks), dev_eval_kernel + step_kernel_cols
+// (device
 // target with response columns, nycol >= 1, in one launch), run1_kernel (MCMC_run1 / MCMC_run1_er)
-// (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled, mcx_phase, mcx_adapt, mcx_svd, mcx_moments)
+// (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled, mcx_phase,
+// mcx_adapt, mcx_svd, mcx_moments)
 #pragma once
 #include "mcx_pooled.hpp"
 
@@ -74,7 +76,8 @@ MCX_DEV void host_finish(const EngineDev &E, int tile, int lane, int it, LaneSta
         if (!(a >= 0.0)) TIDX(E.ictr, tile, NICTR, I_DOWNS, lane) += 1u;
         const double *hx = E.hx + (size_t)tile * NHX * 64;
         if (E.usesvd) ram_update_full(E.Rf + (size_t)tile * d * d * 64, zs_t, cs_t, lane, d, a, GV(hx, HX_SU), true, L.status);
-        else { bool pd = L.pdesc != 0u; ram_update<false>(E.R + (size_t)tile * E.P * 64, zs_t, zs_t, cs_t, cand_t, theta_t, lane, d, a, GV(hx, HX_SU), true, false, L.status, nullptr, pd); L.pdesc = pd ? 1u : 0u; }
+        else { bool pd = L.pdesc != 0u; ram_update<false>(E.R + (size_t)tile * E.P * 64, zs_t, zs_t, cs_t, cand_t, theta_t, lane, d, a,
+            GV(hx, HX_SU), true, false, L.status, nullptr, pd); L.pdesc = pd ? 1u : 0u; }
     }
 }
 
@@ -119,7 +122,8 @@ __global__ __launch_bounds__(64) void dev_eval_kernel(EngineDev E, const double 
 // sR / sR2 / siC: pooled mode's shared factor, second-stage factor and inverse covariance (nullptr: the chain's own)
 template <int PHASE>
 MCX_DEV void host_phase_body(const EngineDev &E, int tile, int lane, int it, const double *__restrict__ ramscale, int aux, double *X,
-                             const double *__restrict__ sR = nullptr, const double *__restrict__ sR2 = nullptr, const double *__restrict__ siC = nullptr)
+                             const double *__restrict__ sR = nullptr, const double *__restrict__ sR2 = nullptr,
+                                 const double *__restrict__ siC = nullptr)
 {
     const int d = E.d;
     double *theta_t = E.theta + (size_t)tile * d * 64;
@@ -160,7 +164,8 @@ MCX_DEV void host_phase_body(const EngineDev &E, int tile, int lane, int it, con
             if (m) L.drtries += 1;
             for (int j = 0; j < (ny > 1 ? ny : 0); ++j) GV(ss2v, j) = GV(sshev, j);
             gen_normals(L.g, zs_t + (size_t)d * 64, lane, d, m);
-            if (sR2) { if (E.usesvd) gemvN_shared(sR2, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d); else trmv_shared(sR2, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d); }
+            if (sR2) { if (E.usesvd) gemvN_shared(sR2, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d); else trmv_shared(sR2,
+                zs_t + (size_t)d * 64, c2_t, theta_t, lane, d); }
             else if (E.usesvd) gemvN_panels(E.R2f + (size_t)tile * d * d * 64, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d, m);
             else trmv_panels<false>(E.R2 + (size_t)tile * E.P * 64, zs_t + (size_t)d * 64, c2_t, theta_t, lane, d, m);
             GV(hx, HX_SS2) = ss2; GV(hx, HX_PRI2) = pri2;
@@ -204,7 +209,8 @@ MCX_DEV void host_phase_body(const EngineDev &E, int tile, int lane, int it, con
         else { L.chainind += 1; L.curcount = 1; }
         if (E.updatesigma) {
             if (ny > 1) {
-                for (int j = 0; j < ny; ++j) { double gm = rng_gamma(L.g, E.gshapev[j], 2.0 / (E.N0S02 + GV(ssv, j))); GV(s2v, j) = 1.0 / gm; }
+                for (int j = 0; j < ny; ++j) { double gm = rng_gamma(L.g, E.gshapev[j], 2.0 / (E.N0S02 + GV(ssv, j))); GV(s2v,
+                    j) = 1.0 / gm; }
                 L.sigma2 = GV(s2v, 0);
             } else {
                 double gm = rng_gamma(L.g, E.gam_shape, 2.0 / (E.N0S02 + L.ss1));
@@ -299,12 +305,15 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
     host_phase_body<PHASE>(E, blockIdx.x, threadIdx.x, it, ramscale, aux, X);
 }
 
-// Two (three) phases that no evaluation separates, in one launch: the last phase of an iteration and the first of the next one (the proposal),
-// a SCAM sub-step's decision and the next component's proposal.  With the user's functions on the host an iteration of few chains is launch and
+// Two (three) phases that no evaluation separates, in one launch: the last phase of an iteration and the first of the next one (the
+// proposal),
+// a SCAM sub-step's decision and the next component's proposal.  With the user's functions on the host an iteration of few chains is launch
+// and
 // wake-up latency, nothing else -- one launch per evaluation instead of two.  The phases hand over through the chain's own state exactly as
 // separate launches do (every element written and read back by the same lane: see step_kernel_cols).  PB / PC < 0: none.
 template <int PA, int PB, int PC>
-__global__ __launch_bounds__(64) void host_phase_seq_kernel(EngineDev E, int itA, int auxA, int itB, int auxB, int itC, int auxC, const double *__restrict__ ramscale)
+__global__ __launch_bounds__(64) void host_phase_seq_kernel(EngineDev E, int itA, int auxA, int itB, int auxB, int itC, int auxC,
+    const double *__restrict__ ramscale)
 {
     extern __shared__ double X[];
     host_phase_body<PA>(E, blockIdx.x, threadIdx.x, itA, ramscale + itA, auxA, X);
@@ -325,13 +334,15 @@ __global__ __launch_bounds__(64) void host_phase_seq_kernel(EngineDev E, int itA
 #define MCX_COLS_WAVES 1
 #endif
 __global__ __launch_bounds__(64, MCX_COLS_WAVES) void step_kernel_cols(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
-                                                       const double *__restrict__ sR, const double *__restrict__ sR2, const double *__restrict__ siC)
+                                                       const double *__restrict__ sR, const double *__restrict__ sR2,
+                                                           const double *__restrict__ siC)
 {
     extern __shared__ double X[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
     for (int it = it0; it <= it1; ++it) {
         const double *rs = ramscale + it;
-        if (E.doscam) {                                 // MCMC_run_scam.F90:94-138: npar componentwise proposals, each with its own evaluation
+        // MCMC_run_scam.F90:94-138: npar componentwise proposals, each with its own evaluation
+        if (E.doscam) {
             for (int j = 0; j < d; ++j) {
                 host_phase_body<5>(E, tile, lane, it, rs, j, X);
                 dev_eval_body(E, tile, lane, E.cand, d, 0, 0);
@@ -422,7 +433,8 @@ __global__ __launch_bounds__(64) void run1_kernel(EngineDev E, double *r1, int d
         GV(sc, R1_ALPHA) = alpha; GV(sc, R1_REJECT) = reject ? 1.0 : 0.0;
     } else if (MODE == 1 || MODE == 2) {
         gen_normals(L.g, zs_t, lane, d, true);
-        if (E.usesvd) gemvN_panels((MODE == 2 ? E.R2f : E.Rf) + (size_t)tile * d * d * 64, zs_t, new_t, cur_t, lane, d, true);   // matmulx(R,z)
+        // matmulx(R,z)
+        if (E.usesvd) gemvN_panels((MODE == 2 ? E.R2f : E.Rf) + (size_t)tile * d * d * 64, zs_t, new_t, cur_t, lane, d, true);
         else trmv_panels<false>((MODE == 2 ? E.R2 : E.R) + (size_t)tile * E.P * 64, zs_t, new_t, cur_t, lane, d, true);
     } else {
         double u = rng_uniform(L.g);

@@ -1,6 +1,8 @@
-// mcx_pooled.hpp -- pooled AM / RAM / ER / DR on the f64 matrix cores (pooled_mfma_kernel): one wave per tile, the shared tables' products as
+// mcx_pooled.hpp -- pooled AM / RAM / ER / DR on the f64 matrix cores (pooled_mfma_kernel): one wave per tile, the shared tables' products
+// as
 // v_mfma_f64_16x16x4_f64 tiles
-// (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled, mcx_phase, mcx_adapt, mcx_svd, mcx_moments)
+// (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled, mcx_phase,
+// mcx_adapt, mcx_svd, mcx_moments)
 #pragma once
 #include "mcx_scam.hpp"
 
@@ -34,7 +36,8 @@ MCX_DEV void mfma_wave_product(const double *__restrict__ M, const double *X, in
     const double *__restrict__ ap = M + (size_t)lk * d + 16 * ob0 + li;
     const double *xp = X + lk * 64 + li;
     // KU k-blocks per trip, their 4 KU loads of the shared table first: a trip waits for the L2 once -- one k-block per trip put thirteen
-    // round trips of ~1 us on each product of a wave that has the SIMD almost to itself (round 4: 0.93 -> 0.73 ms per iteration of 1 048 576
+    // round trips of ~1 us on each product of a wave that has the SIMD almost to itself (round 4: 0.93 -> 0.73 ms per iteration of 1 048
+    // 576
     // chains at npar 50; two k-blocks per trip do almost as well, seven or eight are slower)
     constexpr int KU = MCX_POOLED_KU;
     for (int s0 = 0; s0 < kmax; s0 += 4 * KU) {
@@ -70,8 +73,10 @@ MCX_DEV void mfma_wave_product(const double *__restrict__ M, const double *X, in
 // products against the dense symmetric table g_iCd, each followed by the chain q = sum_i y_i dx_i ascending in i (lane = chain:
 // y comes back through the LDS vector, dx waits in the chain's global scratch EngineDev::xscr).  Operation for operation
 // step_body<false, true, true> (the lane-per-chain form with the tables through the scalar cache), whose chains these are.
-// W2 (without delayed rejection): 256 registers, so that two waves share a SIMD (the LDS vector lets six waves on a CU at npar 50: two SIMDs
-// with two).  The compiler spills ~40 doubles of state around the products to fit, and with more tiles than SIMDs it is still faster (round 4;
+// W2 (without delayed rejection): 256 registers, so that two waves share a SIMD (the LDS vector lets six waves on a CU at npar 50: two
+// SIMDs
+// with two).  The compiler spills ~40 doubles of state around the products to fit, and with more tiles than SIMDs it is still faster (round
+// 4;
 // round 2's attempt predates the single-pass LDS layout): 97.1 -> 93.2 ms per 100 iterations of 1 048 576 chains at npar 50.  With one tile
 // per SIMD or fewer there is nobody to share with and the spills are all it buys (npar 20, 65536 chains: 2.1e9 against 2.6e9 proposals/s):
 // the host takes the 512-register instance there.
@@ -153,7 +158,8 @@ __global__ __launch_bounds__(64, (!DR && W2) ? 2 : 1) void pooled_mfma_kernel(En
         for (int k0 = 0; k0 < d; k0 += CB) {
             double th[CB], tv[CB];
 #pragma unroll
-            for (int u = 0; u < CB; ++u) { const int k = (k0 + u < d) ? k0 + u : d - 1; th[u] = GV(theta_t, k); tv[u] = T[(size_t)k * 64 + lane]; }
+            for (int u = 0; u < CB; ++u) { const int k = (k0 + u < d) ? k0 + u : d - 1; th[u] = GV(theta_t, k);
+                tv[u] = T[(size_t)k * 64 + lane]; }
 #pragma unroll
             for (int u = 0; u < CB; ++u) {
                 if (k0 + u < d) {
@@ -221,7 +227,8 @@ __global__ __launch_bounds__(64, (!DR && W2) ? 2 : 1) void pooled_mfma_kernel(En
             const double ss3 = gauss ? gauss_ss() : target_ss<false>(E.tgt, d, lane, c2_t, g_mu, g_lamT);
             double qf[2];
 #pragma unroll
-            for (int f = 0; f < 2; ++f) {                              // qa: dx = newpar2 - newpar, qb: dx = oldpar - newpar (MCMC_DRAM.F90:180-182)
+            // qa: dx = newpar2 - newpar, qb: dx = oldpar - newpar (MCMC_DRAM.F90:180-182)
+            for (int f = 0; f < 2; ++f) {
                 const double *a_t = f == 0 ? c2_t : theta_t;
                 for (int k = 0; k < d; ++k) { const double dx = GV(a_t, k) - GV(cand_t, k); XL(k) = dx; GV(xs_t, k) = dx; }
                 for (int k = d; k < d4; ++k) XL(k) = 0.0;

@@ -1,6 +1,7 @@
 // mcx_products.hpp -- the matrix-vector products of MCMC_propose (MCMC_DRAM.F90:20-31) on a lane's own factor: dtrmv('U','T') on the packed
 // triangle in column panels, the full-matrix forms of the SVD paths, the lane-per-chain Jacobi SVD, the shared-table (pooled) forms
-// (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled, mcx_phase, mcx_adapt, mcx_svd, mcx_moments)
+// (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled, mcx_phase,
+// mcx_adapt, mcx_svd, mcx_moments)
 #pragma once
 #include "mcx_common.hpp"
 
@@ -44,9 +45,11 @@ MCX_DEV void trmv_panels(const double *Rt, const double *z_t, double *P_t, const
                 }
 #undef MCX_TRMV_LD
 #undef MCX_TRMV_FM
-                {                                                            // diagonal block: elements u >= ui; the next row's loads in flight
+                // diagonal block: elements u >= ui; the next row's loads in flight
+                {
                     double da[TW], db[TW], za = 0.0, zb = 0.0;
-#define MCX_TRMV_LDD(rv, zv, i_) { zv = GV(z_t, (i_)); const double *seg_ = Rt + (size_t)rowstart((i_), d) * 64; const int ui_ = (i_) - J0, m_ = d - 1 - (i_); \
+#define MCX_TRMV_LDD(rv, zv, i_) { zv = GV(z_t, (i_)); const double *seg_ = Rt + (size_t)rowstart((i_), d) * 64; \
+    const int ui_ = (i_) - J0, m_ = d - 1 - (i_); \
                                    _Pragma("unroll") for (int u = 0; u < TW; ++u) { int k = u - ui_; k = k < 0 ? 0 : k; k = k > m_ ? m_ : k; rv[u] = LDNT(seg_, k); } }
 #define MCX_TRMV_FMD(rv, zv, i_) { const int ui_ = (i_) - J0; _Pragma("unroll") for (int u = 0; u < TW; ++u) { double nv = dfma(rv[u], zv, P[u]); P[u] = (u >= ui_) ? nv : P[u]; } }
                     if (PIPE) {
@@ -309,7 +312,8 @@ MCX_DEV void symsvd_dev(double *Gt, double *Vt, double *sv_t, int lane, int d, b
             if (m != i) {
                 double ts = GV(sv_t, i); GV(sv_t, i) = GV(sv_t, m); GV(sv_t, m) = ts;
                 for (int k = 0; k < d; ++k) {
-                    double tv = GV(Vt, (size_t)i * d + k); GV(Vt, (size_t)i * d + k) = GV(Vt, (size_t)m * d + k); GV(Vt, (size_t)m * d + k) = tv;
+                    double tv = GV(Vt, (size_t)i * d + k); GV(Vt, (size_t)i * d + k) = GV(Vt, (size_t)m * d + k); GV(Vt,
+                        (size_t)m * d + k) = tv;
                 }
             }
         }

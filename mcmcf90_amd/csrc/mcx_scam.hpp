@@ -1,6 +1,8 @@
-// mcx_scam.hpp -- MCMC_run_scam (MCMC_run_scam.F90:38-138): per-chain rotations (scam_kernel, scam_mw_kernel) and the pooled rotation on the
+// mcx_scam.hpp -- MCMC_run_scam (MCMC_run_scam.F90:38-138): per-chain rotations (scam_kernel, scam_mw_kernel) and the pooled rotation on
+// the
 // f64 matrix cores (scam_pooled_kernel, scam_pooled12_kernel); the lane state the phase kernels share (LaneState)
-// (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled, mcx_phase, mcx_adapt, mcx_svd, mcx_moments)
+// (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled, mcx_phase,
+// mcx_adapt, mcx_svd, mcx_moments)
 #pragma once
 #include "mcx_step.hpp"
 
@@ -49,7 +51,8 @@ MCX_DEV void lane_store(const EngineDev &E, int tile, int lane, const LaneState 
 }
 
 // scam_fast: newpar_k = oldpar_k + delta U(k,j), elements k0, k0 + kstep, ... (one fma each; U column-major per chain)
-MCX_DEV void scam_fast_propose(const double *Ut, const double *theta_t, double *cand_t, int lane, int d, int j, double delta, int p0 = 0, int pstep = 1)
+MCX_DEV void scam_fast_propose(const double *Ut, const double *theta_t, double *cand_t, int lane, int d, int j, double delta, int p0 = 0,
+    int pstep = 1)
 {
     const double *col = Ut + (size_t)j * d * 64;
     for (int K0 = p0 * PW; K0 < d; K0 += pstep * PW) {
@@ -161,7 +164,8 @@ __global__ __launch_bounds__(64 * NW) void scam_mw_kernel(EngineDev E, int it0, 
                 __syncthreads();
                 scam_fast_propose(Ut, theta_t, cand_t, lane, d, j, zl[lane], w, NW);
             } else {
-                gemvT_panels<true, (NW >= 8 ? 2 : 0)>(Ut, theta_t, rot_t, lane, d, w, NW);      // many waves: fewer rows in flight each (registers)
+                // many waves: fewer rows in flight each (registers)
+                gemvT_panels<true, (NW >= 8 ? 2 : 0)>(Ut, theta_t, rot_t, lane, d, w, NW);
                 __syncthreads();
                 if (w == (j / PW) % NW) GV(rot_t, j) = GV(rot_t, j) + zl[lane];  // by the wave that wrote rot_j
                 __syncthreads();
@@ -181,7 +185,8 @@ __global__ __launch_bounds__(64 * NW) void scam_mw_kernel(EngineDev E, int it0, 
                 bool inb = target_inbounds(E.tgt, d, lane, cand_t);
                 double pri2 = target_prior(E.tgt, d, lane, cand_t);
                 double ss2 = 0.0;
-                if (gauss) { for (int e = 0; e < 4 * nblk; ++e) if (16 * (e >> 2) + (e & 3) < d) ss2 = (e == 0) ? Q[lane] : ss2 + Q[(size_t)e * 64 + lane]; }
+                if (gauss) { for (int e = 0; e < 4 * nblk;
+                    ++e) if (16 * (e >> 2) + (e & 3) < d) ss2 = (e == 0) ? Q[lane] : ss2 + Q[(size_t)e * 64 + lane]; }
                 else ss2 = target_ss<false>(E.tgt, d, lane, cand_t, g_mu, g_lamT);
                 bool reject;
                 if (!inb) { L.bnd += 1; L.alpha12 = 0.0; reject = true; }
@@ -251,7 +256,9 @@ constexpr int PWS = 16;
 typedef double mcx_d4 __attribute__((ext_vector_type(4)));
 typedef double mcx_d2 __attribute__((ext_vector_type(2)));
 
-template <bool BW, int NS, bool XS = false>   // BW: block wave (blk0 = its block, slot = chain group; XS: a fifth slot, group xgrp of block xblk); else group wave (slot s = block blk0+s, s < NS)
+// BW: block wave (blk0 = its block, slot = chain group; XS: a fifth slot, group xgrp of block xblk); else group wave (slot s = block
+// blk0+s, s < NS)
+template <bool BW, int NS, bool XS = false>
 MCX_DEV void mfma_slots(const double *__restrict__ M, const double *X, int lane, int d, int d4, int blk0, int grp, mcx_d4 (&c)[XS ? 5 : 4],
                         int xblk = 0, int xgrp = 0)
 {
@@ -310,8 +317,10 @@ MCX_DEV void mfma_slots(const double *__restrict__ M, const double *X, int lane,
 // Element (slot s, register r) of a lane: output row o = 16*block + (lane>>4) + 4r, chain c = 16*group + (lane&15); its
 // offset o*64 + c in a tile-interleaved vector (and in X) is e0 + (BW ? 16 s : 1024 s) + 256 r.  X has 16*nt rows, so
 // every element has an LDS home; rows >= d are written as zeros (the k loop reads the rows < d4 only).
-template <bool BW, int NS, bool SC, bool XS = false>   // SC: the scalar wave (the last one).  A template parameter, so that the other fifteen waves carry
-                                      // neither the generator nor the per-chain state: at 128 registers a wave they spilled around their MFMAs
+// SC: the scalar wave (the last one).  A template parameter, so that the other fifteen waves carry
+template <bool BW, int NS, bool SC, bool XS = false>
+                                      // neither the generator nor the per-chain state: at 128 registers a wave they spilled around their
+                                      // MFMAs
                                       // XS (scam_pooled12_kernel): a block wave with a FIFTH slot, chain group xgrp of block xblk
 MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, int lane, int w, int nw, int blk0, int grp,
                               const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
@@ -374,7 +383,8 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int o = EROW(s, r) < d ? EROW(s, r) : 0;
-                        uc[r] = pc ? __builtin_nontemporal_load(&E.Rf[((size_t)tile * d * d + (size_t)j * d + o) * 64 + ECH(s)]) : g_U[(size_t)j * d + o];
+                        uc[r] = pc ? __builtin_nontemporal_load(&E.Rf[((size_t)tile * d * d + (size_t)j * d + o) * 64 + ECH(s)])
+                            : g_U[(size_t)j * d + o];
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) cand[s][r] = EROW(s, r) < d ? dfma(zj, uc[r], th[s][r]) : 0.0;
@@ -513,7 +523,8 @@ MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, i
     if (sc) lane_store(E, tile, lane, L);
 #ifdef MCX_PHASE_PROF
     PH(6)
-    if (tile == 0 && lane == 0 && (w == 0 || sc)) printf("wave %d x10ns: theta+fill %llu mfma %llu fills %llu q %llu scalar %llu accept %llu | barrier waits after: fill0 %llu P1 %llu fill1 %llu P2 %llu fill2 %llu P3q %llu scalar %llu\n", w, ph[0], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7], ph[8], ph[9], ph[10], ph[11], ph[12], ph[13]);
+    if (tile == 0 && lane == 0 && (w == 0
+        || sc)) printf("wave %d x10ns: theta+fill %llu mfma %llu fills %llu q %llu scalar %llu accept %llu | barrier waits after: fill0 %llu P1 %llu fill1 %llu P2 %llu fill2 %llu P3q %llu scalar %llu\n", w, ph[0], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7], ph[8], ph[9], ph[10], ph[11], ph[12], ph[13]);
 #endif
 #undef PH
 #undef EOFF

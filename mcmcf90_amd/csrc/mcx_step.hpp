@@ -1,6 +1,7 @@
 // mcx_step.hpp -- the lane-per-chain sampling kernels: MCMC_run / MCMC_run_ram / MCMC_run_er iterations (step_body), MCMC_adapt_ram with
 // DCHUD / DCHDD in two sweeps over column panels (ram_update), delayed rejection (dr_body), and their __global__ entry points
-// (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled, mcx_phase, mcx_adapt, mcx_svd, mcx_moments)
+// (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled, mcx_phase,
+// mcx_adapt, mcx_svd, mcx_moments)
 #pragma once
 #include "mcx_products.hpp"
 
@@ -51,7 +52,8 @@ MCX_DEV bool ram_update(double *Rt, const double *zc_t, const double *zn_t, doub
                 const int nw = (d - J0) < rwe ? (d - J0) : rwe;
                 double xa[RWT], P[RWT];
 #pragma unroll
-                for (int u = 0; u < RWT; ++u) { xa[u] = up ? GV(zc_t, J0 + (u < nw ? u : nw - 1)) / su * a : 0.0; P[u] = 0.0; }   // x = u/sum(u**2)*a
+                // x = u/sum(u**2)*a
+                for (int u = 0; u < RWT; ++u) { xa[u] = up ? GV(zc_t, J0 + (u < nw ? u : nw - 1)) / su * a : 0.0; P[u] = 0.0; }
 if (MIXED) {
                     // next row's loads before this row's stores (see sweep B)
                     // (c, s) of an update lane or the substitution's a_i of a downdate lane, and z_next: one row ahead as well
@@ -133,7 +135,8 @@ if (MIXED) {
                         d_rotg(GV(seg, 0), xi, rr, c, sn);
                         GV(seg, 0) = rr;
                         if (lc && i < NLC) { lc[(2 * i) * 64 + lane] = c; lc[(2 * i + 1) * 64 + lane] = sn; }
-                        else if (J0 + nw < d) { GV(cs_t, 2 * i) = c; GV(cs_t, 2 * i + 1) = sn; }      // (the last panel's rotations have no later panel to serve)
+                        // (the last panel's rotations have no later panel to serve)
+                        else if (J0 + nw < d) { GV(cs_t, 2 * i) = c; GV(cs_t, 2 * i + 1) = sn; }
 #pragma unroll
                         for (int u = 0; u < RWT; ++u) {
                             const bool off = (u > ui) && (u < nw);
@@ -404,7 +407,8 @@ MCX_DEV double quadform_sym(const double *St, int lane, int d, const double *X, 
         sweep_batches(rowp, lane, 1, n, [&](int k, const double (&sij)[CH], int m) {
             double xs[CH], ys[CH];
 #pragma unroll
-            for (int u = 0; u < CH; ++u) { const int kk = i + k + (u < m ? u : m - 1); xs[u] = XL(kk); ys[u] = (i == 0) ? 0.0 : Y[kk * 64 + lane]; }
+            for (int u = 0; u < CH; ++u) { const int kk = i + k + (u < m ? u : m - 1); xs[u] = XL(kk);
+                ys[u] = (i == 0) ? 0.0 : Y[kk * 64 + lane]; }
 #pragma unroll
             for (int u = 0; u < CH; ++u) if (u < m) yi = dfma(sij[u], xs[u], yi);
 #pragma unroll
@@ -440,7 +444,8 @@ MCX_DEV double quadform_sym_shared(const double *__restrict__ Ss, int lane, int 
 // Iterations it0..it1 (absolute simuind) of MCMC_run (MCMC_run.F90:41-107) or MCMC_run_ram
 // (MCMC_run_ram.F90:45-81) for one tile of 64 chains.  LDS is used only by the delayed-rejection
 // quadratic forms (2*d*64 doubles when dodr, none otherwise).
-template <bool RAM, bool DR, bool POOLED, bool WIDE_T = (RAM || (!DR && !POOLED)), bool FULLR = false, bool LDSV = false, bool LDSR = false, bool XG = false, int RWT = RW>
+template <bool RAM, bool DR, bool POOLED, bool WIDE_T = (RAM || (!DR && !POOLED)), bool FULLR = false, bool LDSV = false,
+    bool LDSR = false, bool XG = false, int RWT = RW>
 MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__restrict__ ramscale,
                        const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
                        const double *__restrict__ g_sharedR, const double *__restrict__ g_sharedR2 = nullptr,
@@ -450,8 +455,9 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
     // the delayed-rejection quadratic forms' two vectors: LDS, or (XG, a compile-time choice: no flat accesses) the chain's global scratch
     double *X = XG ? E.xscr + (size_t)tile * 2 * d * 64 : Xlds;
-    constexpr bool ldsv = LDSV && !RAM && !DR && !POOLED;                // step_kernel_ldsv: launched with 4 d x 512 bytes of LDS (a compile-time
-                                                                        // choice, so that the vectors' accesses are ds_read / ds_write, not flat)
+    // step_kernel_ldsv: launched with 4 d x 512 bytes of LDS (a compile-time choice, so that the vectors' accesses are ds_read / ds_write,
+    // not flat)
+    constexpr bool ldsv = LDSV && !RAM && !DR && !POOLED;
     // step_kernel_ldsr (npar <= TW): besides the state, the chain's packed factor stays in LDS for the launch -- AM only reads
     // it between two ticks -- and ONE vector serves as normals, proposal and candidate (a single column panel: the product
     // has read every normal before it stores anything)
@@ -459,7 +465,8 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
     double *theta_g = E.theta + (size_t)tile * d * 64;
     double *theta_t = ldsv ? X : theta_g;
     double *cand_t = ldsv ? X + (size_t)d * 64 : E.cand + (size_t)tile * d * 64;           // proposal vector P, then candidate theta + P
-    double *zs_t = ldsr ? cand_t : (ldsv ? X + (size_t)2 * d * 64 : E.zs + (size_t)tile * 2 * d * 64);       // two normal vectors: this iteration's and the next one's
+    // two normal vectors: this iteration's and the next one's
+    double *zs_t = ldsr ? cand_t : (ldsv ? X + (size_t)2 * d * 64 : E.zs + (size_t)tile * 2 * d * 64);
     double *cs_t = E.cs + (size_t)tile * 2 * d * 64;           // RAM: rotations; DR: second-stage candidate
     if (ldsv) for (int k = 0; k < d; ++k) GV(theta_t, k) = GV(theta_g, k);
     // step_kernel_ram_ldsr (npar <= RW: one column panel): the factor that DCHUD / DCHDD rewrite at every iteration stays in LDS for the
@@ -482,7 +489,8 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
     uint32_t status = TIDX(E.ictr, tile, NICTR, I_STATUS, lane);
     uint32_t dracc = TIDX(E.ictr, tile, NICTR, I_DRACC, lane), drtries = TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane);
     uint32_t erstayed = TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane);
-    bool pdesc = RAM && TIDX(E.ictr, tile, NICTR, I_PDESC, lane) != 0u;   // the next proposal's dtrmv order (after a downdate: diagonal first)
+    // the next proposal's dtrmv order (after a downdate: diagonal first)
+    bool pdesc = RAM && TIDX(E.ictr, tile, NICTR, I_PDESC, lane) != 0u;
     uint32_t downs = RAM ? TIDX(E.ictr, tile, NICTR, I_DOWNS, lane) : 0u;
 
     bool have_p = false;                          // lanes whose candidate is already in cand_t
@@ -492,7 +500,8 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
         double *zc_t = ldsr ? zs_t : zs_t + (size_t)(it & 1) * d * 64;          // z of this iteration
         double *zn_t = ldsr ? zs_t : zs_t + (size_t)((it + 1) & 1) * d * 64;    // z of the next one
         // ---- newpar = MCMC_propose(oldpar, R)
-        if (POOLED) { if (E.usesvd) gemvN_shared(g_sharedR, zc_t, cand_t, theta_t, lane, d); else trmv_shared(g_sharedR, zc_t, cand_t, theta_t, lane, d); }
+        if (POOLED) { if (E.usesvd) gemvN_shared(g_sharedR, zc_t, cand_t, theta_t, lane, d); else trmv_shared(g_sharedR, zc_t, cand_t,
+            theta_t, lane, d); }
         else if (E.usesvd) gemvN_panels(E.Rf + (size_t)tile * d * d * 64, zc_t, cand_t, theta_t, lane, d, true);   // matmulx(R,z)
         else if (__any(!have_p)) trmv_panels<!RAM>(Rt, zc_t, cand_t, theta_t, lane, d, !have_p, RAM && pdesc);
         // ---- bounds, prior, ss, alpha, reject
@@ -525,8 +534,10 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
             if (m) drtries += 1;
             double *z2_t = zn_t;                          // stage-2 normals: the "next" buffer is still free
             gen_normals<RAM ? 1 : MCX_RNG_NB>(g, z2_t, lane, d, m);
-            if (POOLED) {                                 // one R2 for every chain; lanes that did not draw compute on stale normals and are not looked at
-                if (E.usesvd) gemvN_shared(g_sharedR2, z2_t, c2_t, theta_t, lane, d); else trmv_shared(g_sharedR2, z2_t, c2_t, theta_t, lane, d);
+            // one R2 for every chain; lanes that did not draw compute on stale normals and are not looked at
+            if (POOLED) {
+                if (E.usesvd) gemvN_shared(g_sharedR2, z2_t, c2_t, theta_t, lane, d); else trmv_shared(g_sharedR2, z2_t, c2_t, theta_t,
+                    lane, d);
             }
             else if (E.usesvd) gemvN_panels(E.R2f + (size_t)tile * d * d * 64, z2_t, c2_t, theta_t, lane, d, m);
             else trmv_panels<true>(E.R2 + (size_t)tile * E.P * 64, z2_t, c2_t, theta_t, lane, d, m);
@@ -586,8 +597,10 @@ MCX_DEV void step_body(const EngineDev &E, int it0, int it1, const double *__res
             downs += (a >= 0.0) ? 0u : 1u;
             if (FULLR) ram_update_full(E.Rf + (size_t)tile * d * d * 64, zc_t, cs_t, lane, d, a, su_c, true, status);   // condmax > 0
             else if (__any(!(a >= 0.0)))                  // a wave with downdate lanes: whole-segment stores in both sweeps
-                have_p = ram_update<true, RWT>(Rt, zc_t, zn_t, cs_t, cand_t, theta_t, lane, d, a, su_c, true, pre, status, RAM ? X : nullptr, pdesc);
-            else have_p = ram_update<false, RWT>(Rt, zc_t, zn_t, cs_t, cand_t, theta_t, lane, d, a, su_c, true, pre, status, RAM ? X : nullptr, pdesc);
+                have_p = ram_update<true, RWT>(Rt, zc_t, zn_t, cs_t, cand_t, theta_t, lane, d, a, su_c, true, pre, status,
+                    RAM ? X : nullptr, pdesc);
+            else have_p = ram_update<false, RWT>(Rt, zc_t, zn_t, cs_t, cand_t, theta_t, lane, d, a, su_c, true, pre, status,
+                RAM ? X : nullptr, pdesc);
         }
         su_c = su_n;
     }
@@ -635,13 +648,16 @@ MCX_DEV void quadform2_panels(const double *St, int lane, int d, const double *X
         const bool last = J0 + TQ >= d;
         double Ya[TQ], Yb[TQ], xja[TQ], xjb[TQ];
 #pragma unroll
-        for (int u = 0; u < TQ; ++u) { const int j = J0 + (u < nw ? u : nw - 1); xja[u] = GV(Xa, j); xjb[u] = GV(Xb, j); Ya[u] = 0.0; Yb[u] = 0.0; }
+        for (int u = 0; u < TQ; ++u) { const int j = J0 + (u < nw ? u : nw - 1); xja[u] = GV(Xa, j); xjb[u] = GV(Xb, j); Ya[u] = 0.0;
+            Yb[u] = 0.0; }
         // rows above the panel: the row's chain takes the panel's nw elements, the panel's columns take the row's x_i
         {
 #ifndef MCX_Q2_NB
 #define MCX_Q2_NB 1
 #endif
-            constexpr int NB = MCX_Q2_NB;                          // rows in flight: more than one spills registers (2: 70, 3: 167), and a spill here costs more than the latency it hides (c3: 20.3 / 17.5 / 14.8 ms per launch at 3 / 2 / 1)
+            // rows in flight: more than one spills registers (2: 70, 3: 167), and a spill here costs more than the latency it hides (c3:
+            // 20.3 / 17.5 / 14.8 ms per launch at 3 / 2 / 1)
+            constexpr int NB = MCX_Q2_NB;
             double rr[NB][TQ], xa_[NB], xb_[NB], ya_[NB], yb_[NB];
 #define MCX_Q2_LD(s_, i_) { const double *seg_ = St + (size_t)(rowstart((i_), d) + J0 - (i_)) * 64; \
                             _Pragma("unroll") for (int u = 0; u < TQ; ++u) rr[s_][u] = GV(seg_, u < nw ? u : nw - 1); \
@@ -671,7 +687,8 @@ MCX_DEV void quadform2_panels(const double *St, int lane, int d, const double *X
                              _Pragma("unroll") for (int u = 0; u < TQ; ++u) { int k = u - ui_; k = k < 0 ? 0 : k; k = k > m_ ? m_ : k; rv[u] = GV(seg_, k); } }
 #define MCX_Q2_FMD(rv, i_) { const int ui_ = (i_) - J0; double xia = 0.0, xib = 0.0, ya = 0.0, yb = 0.0; \
                              _Pragma("unroll") for (int u = 0; u < TQ; ++u) if (u == ui_) { xia = xja[u]; xib = xjb[u]; \
-                                 ya = ((i_) == 0) ? rv[u] * xia : dfma(rv[u], xia, Ya[u]); yb = ((i_) == 0) ? rv[u] * xib : dfma(rv[u], xib, Yb[u]); } \
+                                 ya = ((i_) == 0) ? rv[u] * xia : dfma(rv[u], xia, Ya[u]); yb = ((i_) == 0) ? rv[u] * xib : dfma(rv[u], \
+                                     xib, Yb[u]); } \
                              _Pragma("unroll") for (int u = 0; u < TQ; ++u) if (u > ui_ && u < nw) { \
                                  ya = dfma(rv[u], xja[u], ya); yb = dfma(rv[u], xjb[u], yb); \
                                  Ya[u] = ((i_) == 0) ? rv[u] * xia : dfma(rv[u], xia, Ya[u]); \
@@ -755,9 +772,11 @@ MCX_DEV void dr_body(const EngineDev &E, int it0, int it1, const double *__restr
                     for (int k0 = 0; k0 < d; k0 += 8) {
                         double c1[8], c2[8], th[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) { const int k = (k0 + u < d) ? k0 + u : d - 1; c1[u] = GV(cand_t, k); c2[u] = GV(c2_t, k); th[u] = GV(theta_t, k); }
+                        for (int u = 0; u < 8; ++u) { const int k = (k0 + u < d) ? k0 + u : d - 1; c1[u] = GV(cand_t, k); c2[u] = GV(c2_t,
+                            k); th[u] = GV(theta_t, k); }
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) if (k0 + u < d) { GV(zb_t, k0 + u) = c2[u] - c1[u]; GV(cand_t, k0 + u) = th[u] - c1[u]; }
+                        for (int u = 0; u < 8; ++u) if (k0 + u < d) { GV(zb_t, k0 + u) = c2[u] - c1[u]; GV(cand_t, k0 + u) = th[u] - c1[u];
+                            }
                     }
                     double qa, qb;
                     quadform2_panels(E.iC + (size_t)tile * E.P * 64, lane, d, zb_t, cand_t, ysa_t, ysb_t, qa, qb);
@@ -802,10 +821,12 @@ MCX_DEV void dr_body(const EngineDev &E, int it0, int it1, const double *__restr
     TIDX(E.ictr, tile, NICTR, I_CHAININD, lane) = chainind; TIDX(E.ictr, tile, NICTR, I_CURCOUNT, lane) = curcount;
     TIDX(E.ictr, tile, NICTR, I_DRACC, lane) = dracc; TIDX(E.ictr, tile, NICTR, I_DRTRIES, lane) = drtries;
 }
-__global__ __launch_bounds__(64, 2) void step_kernel_dr(EngineDev E, int it0, int it1, const double *__restrict__ g_mu, const double *__restrict__ g_lamT)
+__global__ __launch_bounds__(64, 2) void step_kernel_dr(EngineDev E, int it0, int it1, const double *__restrict__ g_mu,
+    const double *__restrict__ g_lamT)
 { dr_body<true>(E, it0, it1, g_mu, g_lamT); }
 // npar > 160: the same with the two vectors in global scratch
-__global__ __launch_bounds__(64, 2) void step_kernel_dr_big(EngineDev E, int it0, int it1, const double *__restrict__ g_mu, const double *__restrict__ g_lamT)
+__global__ __launch_bounds__(64, 2) void step_kernel_dr_big(EngineDev E, int it0, int it1, const double *__restrict__ g_mu,
+    const double *__restrict__ g_lamT)
 { dr_body<false>(E, it0, it1, g_mu, g_lamT); }
 
 #ifndef MCX_AM_WAVES
@@ -815,7 +836,8 @@ __global__ __launch_bounds__(64, 2) void step_kernel_dr_big(EngineDev E, int it0
 #define MCX_AM_WIDE true
 #endif
 template <bool RAM, bool DR, bool POOLED>
-__global__ __launch_bounds__(64, RAM ? MCX_RAM_WAVES : (DR || POOLED) ? 2 : MCX_AM_WAVES) void step_kernel(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
+__global__ __launch_bounds__(64, RAM ? MCX_RAM_WAVES : (DR || POOLED) ? 2 : MCX_AM_WAVES) void step_kernel(EngineDev E, int it0, int it1,
+    const double *__restrict__ ramscale,
                                                      const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
                                                      const double *__restrict__ g_sharedR)
 { step_body<RAM, DR, POOLED, (RAM || (!DR && !POOLED && MCX_AM_WIDE))>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
@@ -837,7 +859,8 @@ __global__ __launch_bounds__(64, 2) void step_kernel_ram_ldsr(EngineDev E, int i
 { step_body<true, false, false, true, false, false, true>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
 
 // method='ram' above npar 20: step_kernel<true, false, false> with the wide column panels (RW_WIDE above)
-__global__ __launch_bounds__(64, MCX_RAM_WAVES) void step_kernel_ram_wide(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
+__global__ __launch_bounds__(64, MCX_RAM_WAVES) void step_kernel_ram_wide(EngineDev E, int it0, int it1,
+    const double *__restrict__ ramscale,
                                                      const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
                                                      const double *__restrict__ g_sharedR)
 { step_body<true, false, false, true, false, false, false, false, RW_WIDE>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR); }
@@ -853,7 +876,8 @@ __global__ __launch_bounds__(64, 2) void step_kernel_pooled_dr(EngineDev E, int 
 // at npar 50: three waves per CU), and above 160 it does not fit at all
 __global__ __launch_bounds__(64, 2) void step_kernel_pooled_dr_big(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
                                                                    const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
-                                                                   const double *__restrict__ g_sharedR, const double *__restrict__ g_sharedR2,
+                                                                   const double *__restrict__ g_sharedR,
+                                                                       const double *__restrict__ g_sharedR2,
                                                                    const double *__restrict__ g_sharediC)
 { step_body<false, true, true, false, false, false, false, true>(E, it0, it1, ramscale, g_mu, g_lamT, g_sharedR, g_sharedR2, g_sharediC); }
 

@@ -1,5 +1,7 @@
-// mcx_svd.hpp -- the adaptation's SVD at large npar: blocked one-sided Jacobi (the pinned routine, oracle/mcx_svd.h), one workgroup per chain
-// (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled, mcx_phase, mcx_adapt, mcx_svd, mcx_moments)
+// mcx_svd.hpp -- the adaptation's SVD at large npar: blocked one-sided Jacobi (the pinned routine, oracle/mcx_svd.h), one workgroup per
+// chain
+// (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled, mcx_phase,
+// mcx_adapt, mcx_svd, mcx_moments)
 #pragma once
 #include "mcx_adapt.hpp"
 
@@ -23,7 +25,8 @@ namespace mcx {
 // column = 8 d contiguous bytes); tile2chain_kernel / chain2tile_kernel convert from and to the engine's tile-interleaved layout.
 // Earlier generations of these kernels (block pairs in LDS; the I block in registers without the stream; a shared scalar tail per pair)
 // are bit-equal, slower, and no longer in the library: tools/variants/README.md.
-MCX_DEV int svd_ls(int d) { return ((d + 1) & ~1) + (((d + 1) & 2) ? 0 : 2); }   // LDS column stride: even (16-byte accesses), = 2 mod 4 (16 lanes on 16 columns: 64 banks)
+// LDS column stride: even (16-byte accesses), = 2 mod 4 (16 lanes on 16 columns: 64 banks)
+MCX_DEV int svd_ls(int d) { return ((d + 1) & ~1) + (((d + 1) & 2) ? 0 : 2); }
 MCX_DEV size_t svd_pair_index(int p, int q, int d) { return (size_t)p * d - (size_t)p * (p + 1) / 2 + (size_t)(q - p - 1); }
 
 // state[chain]: 0 = not part of this factorisation, 1 = sweeping, 2 = converged (its last sweep rotated nothing)
@@ -50,7 +53,8 @@ __global__ __launch_bounds__(256) void svd_init_kernel(double *Vc, uint8_t *stat
 #endif
 #define MCX_SVDS_EPT 4                                       // elements of a column per loader lane: 64 loaders, npar <= 256
 template <int RL>
-__global__ __launch_bounds__(256, (RL <= 26 ? MCX_SVDS_WAVES : 2)) void svd_sweep_stream_kernel(double *Gc, mcx_d2 *rot, uint8_t *state, int *any_rotated, int nlanes, int d, int b)
+__global__ __launch_bounds__(256, (RL <= 26 ? MCX_SVDS_WAVES : 2)) void svd_sweep_stream_kernel(double *Gc, mcx_d2 *rot, uint8_t *state,
+    int *any_rotated, int nlanes, int d, int b)
 {
     extern __shared__ double S[];
     __shared__ int s_rot;
@@ -58,8 +62,9 @@ __global__ __launch_bounds__(256, (RL <= 26 ? MCX_SVDS_WAVES : 2)) void svd_swee
     if (chain >= nlanes || state[chain] != 1) return;
     double *G = Gc + (size_t)chain * d * d;
     mcx_d2 *log = rot + (size_t)chain * ((size_t)d * (d - 1) / 2);
-    constexpr int LS = 8 * RL + 2;                             // ring column stride: every octet row 8 u + oj exists (rows >= npar hold zeros: they add
-                                                               // nothing to the three sums and rotate to zero -- no bounds tests in the loop); = 2 mod 4
+    // ring column stride: every octet row 8 u + oj exists (rows >= npar hold zeros: they add nothing to the three sums and rotate to zero
+    // -- no bounds tests in the loop); = 2 mod 4
+    constexpr int LS = 8 * RL + 2;
     double *GY = S;                                            // the ring: RB columns
     const int RB = b + 2;
     const int nb = (d + b - 1) / b;
@@ -76,7 +81,8 @@ __global__ __launch_bounds__(256, (RL <= 26 ? MCX_SVDS_WAVES : 2)) void svd_swee
         for (int u = 0; u < RL; ++u) yr[u] = ycol[oj + 8 * u];
         double alpha = 0.0, beta = 0.0, gamma = 0.0;
 #pragma unroll
-        for (int u = 0; u < RL; ++u) { alpha = dfma(xr[u], xr[u], alpha); beta = dfma(yr[u], yr[u], beta); gamma = dfma(xr[u], yr[u], gamma); }
+        for (int u = 0; u < RL; ++u) { alpha = dfma(xr[u], xr[u], alpha); beta = dfma(yr[u], yr[u], beta); gamma = dfma(xr[u], yr[u],
+            gamma); }
 #pragma unroll
         for (int o = 1; o < 8; o <<= 1) {
             alpha = alpha + __shfl_xor(alpha, o, 64); beta = beta + __shfl_xor(beta, o, 64); gamma = gamma + __shfl_xor(gamma, o, 64);
@@ -134,7 +140,8 @@ __global__ __launch_bounds__(256, (RL <= 26 ? MCX_SVDS_WAVES : 2)) void svd_swee
                     for (int u = 0; u < MCX_SVDS_EPT; ++u) { const int k = li + 64 * u; if (k < d) dst[k] = src[k]; }
                 }
             } else if (ol < wI) {
-                if (t == 2 * ol - 1) {                         // this pair-lane's own column: its last pair as a partner was in step 2 ol - 2
+                // this pair-lane's own column: its last pair as a partner was in step 2 ol - 2
+                if (t == 2 * ol - 1) {
                     const double *src = GY + (size_t)((ol - 1) % RB) * LS;
 #pragma unroll
                     for (int u = 0; u < RL; ++u) xr[u] = src[oj + 8 * u];
@@ -158,7 +165,8 @@ __global__ __launch_bounds__(256, (RL <= 26 ? MCX_SVDS_WAVES : 2)) void svd_swee
 // (a leaving column hands its slot to the entering one element by element inside one thread): 53 kB, three workgroups per CU as before.
 // 921 steps per sweep at npar 200 instead of 1134, 64 live lanes per wave instead of 48.
 template <int RL>
-__global__ __launch_bounds__(256, MCX_SVDS_WAVES) void svd_sweep_stream32_kernel(double *Gc, mcx_d2 *rot, uint8_t *state, int *any_rotated, int nlanes, int d)
+__global__ __launch_bounds__(256, MCX_SVDS_WAVES) void svd_sweep_stream32_kernel(double *Gc, mcx_d2 *rot, uint8_t *state, int *any_rotated,
+    int nlanes, int d)
 {
     extern __shared__ double S[];
     __shared__ int s_rot;
@@ -166,13 +174,15 @@ __global__ __launch_bounds__(256, MCX_SVDS_WAVES) void svd_sweep_stream32_kernel
     if (chain >= nlanes || state[chain] != 1) return;
     double *G = Gc + (size_t)chain * d * d;
     mcx_d2 *log = rot + (size_t)chain * ((size_t)d * (d - 1) / 2);
-    constexpr int LS = 8 * RL + 2;                             // ring column stride: every octet row 8 u + oj exists (rows >= npar hold zeros: they add
-                                                               // nothing to the three sums and rotate to zero -- no bounds tests in the loop); = 2 mod 4
+    // ring column stride: every octet row 8 u + oj exists (rows >= npar hold zeros: they add nothing to the three sums and rotate to zero
+    // -- no bounds tests in the loop); = 2 mod 4
+    constexpr int LS = 8 * RL + 2;
     double *GY = S;                                            // the ring: RB columns
     constexpr int b = 32, RB = b + 1;
     const int nb = (d + b - 1) / b;
     const int ol = tid >> 3, oj = tid & 7;                     // pair-lane of this thread's octet, partial chain / row residue
-    const bool ld = tid < d;                                   // ... and every thread moves element `tid` of the columns on their way in and out
+    // ... and every thread moves element `tid` of the columns on their way in and out
+    const bool ld = tid < d;
     if (tid == 0) s_rot = 0;
     double xr[RL];
     double stg = 0.0;                                          // the element on its way from global memory to the ring
@@ -182,7 +192,8 @@ __global__ __launch_bounds__(256, MCX_SVDS_WAVES) void svd_sweep_stream32_kernel
         for (int u = 0; u < RL; ++u) yr[u] = ycol[oj + 8 * u];
         double alpha = 0.0, beta = 0.0, gamma = 0.0;
 #pragma unroll
-        for (int u = 0; u < RL; ++u) { alpha = dfma(xr[u], xr[u], alpha); beta = dfma(yr[u], yr[u], beta); gamma = dfma(xr[u], yr[u], gamma); }
+        for (int u = 0; u < RL; ++u) { alpha = dfma(xr[u], xr[u], alpha); beta = dfma(yr[u], yr[u], beta); gamma = dfma(xr[u], yr[u],
+            gamma); }
 #pragma unroll
         for (int o = 1; o < 8; o <<= 1) {
             alpha = alpha + __shfl_xor(alpha, o, 64); beta = beta + __shfl_xor(beta, o, 64); gamma = gamma + __shfl_xor(gamma, o, 64);
@@ -220,15 +231,18 @@ __global__ __launch_bounds__(256, MCX_SVDS_WAVES) void svd_sweep_stream32_kernel
         const int nsteps = nJ + wI;                            // (the last one only writes the last column back)
         for (int t = 0; t < nsteps; ++t) {
             {
-                // ring slot (t + 1) mod RB changes hands: stream column t - wI (its last pair was in the previous step) leaves it for global
-                // memory and column t + 1 (loaded in the previous step) enters -- element by element in the same thread, so RB = wI + 1 will do
+                // ring slot (t + 1) mod RB changes hands: stream column t - wI (its last pair was in the previous step) leaves it for
+                // global
+                // memory and column t + 1 (loaded in the previous step) enters -- element by element in the same thread, so RB = wI + 1
+                // will do
                 const int cs = t - wI, cw = t + 1, cg = t + 2;
                 if (ld && cs >= wI - 1 && cs < nJ) G[(size_t)(I0 + 1 + cs) * d + tid] = GY[(size_t)(cs % RB) * LS + tid];
                 if (ld && cw >= 2 && cw < nJ) GY[(size_t)(cw % RB) * LS + tid] = stg;
                 if (ld && cg < nJ) stg = G[(size_t)(I0 + 1 + cg) * d + tid];
             }
             if (ol < wI) {
-                if (t == 2 * ol - 1) {                         // this pair-lane's own column: its last pair as a partner was in step 2 ol - 2
+                // this pair-lane's own column: its last pair as a partner was in step 2 ol - 2
+                if (t == 2 * ol - 1) {
                     const double *src = GY + (size_t)((ol - 1) % RB) * LS;
 #pragma unroll
                     for (int u = 0; u < RL; ++u) xr[u] = src[oj + 8 * u];
@@ -263,7 +277,8 @@ __global__ __launch_bounds__(64) void svd_applyv_stream32_kernel(double *Vc, con
     if (chain >= nlanes || state[chain] != 1) return;
     double *V = Vc + (size_t)chain * d * d;
     const mcx_d2 *log = rot + (size_t)chain * ((size_t)d * (d - 1) / 2);
-    constexpr int RGS = 2 * RP + 2, SLOT = 4 * RP + 6;          // doubles per row group (its odd last row at 2 RP) and per ring column (SLOT / 2 odd: 16 lanes on 16 columns, 64 banks)
+    // doubles per row group (its odd last row at 2 RP) and per ring column (SLOT / 2 odd: 16 lanes on 16 columns, 64 banks)
+    constexpr int RGS = 2 * RP + 2, SLOT = 4 * RP + 6;
     constexpr int b = 32, RB = b + 1;
     const int nb = (d + b - 1) / b;
     const int ln = threadIdx.x, rg = ln >> 5, rl = ln & 31, rk0 = 2 * wv + rg;
@@ -292,11 +307,13 @@ __global__ __launch_bounds__(64) void svd_applyv_stream32_kernel(double *Vc, con
         const double c = cs.x, sn = cs.y;
         mcx_d2 vb[RP];
 #pragma unroll
-        for (int u = 0; u < RP; ++u) vb[u] = *(mcx_d2 *)(vq + 2 * u);   // (row pairs beyond npar: zeros in the ring and in vr, they stay zero)
+        // (row pairs beyond npar: zeros in the ring and in vr, they stay zero)
+        for (int u = 0; u < RP; ++u) vb[u] = *(mcx_d2 *)(vq + 2 * u);
 #pragma unroll
         for (int u = 0; u < RP; ++u) {
             mcx_d2 nva, nvb;
-            nva.x = c * vr[u].x - sn * vb[u].x; nva.y = c * vr[u].y - sn * vb[u].y; nvb.x = sn * vr[u].x + c * vb[u].x; nvb.y = sn * vr[u].y + c * vb[u].y;
+            nva.x = c * vr[u].x - sn * vb[u].x; nva.y = c * vr[u].y - sn * vb[u].y; nvb.x = sn * vr[u].x + c * vb[u].x;
+                nvb.y = sn * vr[u].y + c * vb[u].y;
             vr[u] = nva; *(mcx_d2 *)(vq + 2 * u) = nvb;
         }
         if (oddrow) { const double va0 = vlast, vb0 = vq[2 * RP]; vlast = c * va0 - sn * vb0; vq[2 * RP] = sn * va0 + c * vb0; }
@@ -309,11 +326,13 @@ __global__ __launch_bounds__(64) void svd_applyv_stream32_kernel(double *Vc, con
         if (rl == 0) {                                          // the block's first column: straight into registers
             const double *col = V + (size_t)I0 * d;
 #pragma unroll
-            for (int u = 0; u < RP; ++u) { const int k = 2 * rk0 + 16 * u; vr[u].x = 0.0; vr[u].y = 0.0; if (k + 1 < d) { vr[u].x = col[k]; vr[u].y = col[k + 1]; } }
+            for (int u = 0; u < RP; ++u) { const int k = 2 * rk0 + 16 * u; vr[u].x = 0.0; vr[u].y = 0.0; if (k + 1 < d) { vr[u].x = col[k];
+                vr[u].y = col[k + 1]; } }
             if (oddrow) vlast = col[d - 1];
         }
         for (int c = 0; c < 2 && c < nJ; ++c) { g_load(V + (size_t)(I0 + 1 + c) * d); r_write(ring + (size_t)c * SLOT); }
-        const size_t base = svd_pair_index(I0 + rl, I0 + 1 + rl, d);   // log entry of this pair-lane's first pair (step 2 rl), the next ones follow it
+        // log entry of this pair-lane's first pair (step 2 rl), the next ones follow it
+        const size_t base = svd_pair_index(I0 + rl, I0 + 1 + rl, d);
         mcx_d2 nxt; nxt.x = 1.0; nxt.y = 0.0;
         if (rl == 0 && nJ > 0) nxt = log[base];
         const int nsteps = nJ + wI;
@@ -353,7 +372,8 @@ __global__ __launch_bounds__(64) void svd_applyv_stream32_kernel(double *Vc, con
     }
 }
 
-// singular values = column norms of G (the routine's eight partial chains over the rows), sorted descending (first maximum wins), V's columns
+// singular values = column norms of G (the routine's eight partial chains over the rows), sorted descending (first maximum wins), V's
+// columns
 // with them; the sorted vectors are left in G's place
 __global__ __launch_bounds__(256) void svd_finish_kernel(double *Gc, const double *Vc, double *svc, const uint8_t *state, int nlanes, int d)
 {
@@ -387,7 +407,8 @@ __global__ __launch_bounds__(256) void svd_finish_kernel(double *Gc, const doubl
 }
 
 // tile-interleaved [tile][K][64 lanes]  <->  chain-major [chain][K], 64 x 64 blocks through LDS (both sides coalesced)
-__global__ __launch_bounds__(256) void tile2chain_kernel(const double *__restrict__ src, double *__restrict__ dst, size_t K, size_t Kt, const uint8_t *need)
+__global__ __launch_bounds__(256) void tile2chain_kernel(const double *__restrict__ src, double *__restrict__ dst, size_t K, size_t Kt,
+    const uint8_t *need)
 {
     __shared__ double T[64][65];
     const int tile = blockIdx.y, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -395,11 +416,13 @@ __global__ __launch_bounds__(256) void tile2chain_kernel(const double *__restric
     bool any = false;
     for (int l = 0; l < 64; ++l) any = any || need[tile * 64 + l];
     if (!any) return;
-    for (int r = ty; r < 64; r += 4) if (k0 + r < K) T[r][tx] = src[((size_t)tile * Kt + k0 + r) * 64 + tx];          // element k0+r, lane tx (Kt: elements per tile on the interleaved side)
+    // element k0+r, lane tx (Kt: elements per tile on the interleaved side)
+    for (int r = ty; r < 64; r += 4) if (k0 + r < K) T[r][tx] = src[((size_t)tile * Kt + k0 + r) * 64 + tx];
     __syncthreads();
     for (int c = ty; c < 64; c += 4) if (k0 + tx < K && need[tile * 64 + c]) dst[((size_t)tile * 64 + c) * K + k0 + tx] = T[tx][c];
 }
-__global__ __launch_bounds__(256) void chain2tile_kernel(const double *__restrict__ src, double *__restrict__ dst, size_t K, size_t Kt, const uint8_t *need)
+__global__ __launch_bounds__(256) void chain2tile_kernel(const double *__restrict__ src, double *__restrict__ dst, size_t K, size_t Kt,
+    const uint8_t *need)
 {
     __shared__ double T[64][65];
     const int tile = blockIdx.y, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;

@@ -20,7 +20,7 @@ def _bits(a):
 
 def run(ckw, pkw, n, env, want, **ekw):
     from mcmcf90_amd import engine_from_problem
-    for k in ("MCMCX_POOLED_WAVES", "MCMCX_DR_GENERAL", "MCMCX_SVD_SHARED_ROT", "MCMCX_GROUP"):
+    for k in ("MCMCX_POOLED_WAVES", "MCMCX_DR_GENERAL", "MCMCX_SVD_SHARED_ROT", "MCMCX_GROUP", "MCMCX_DR_BIG"):
         os.environ.pop(k, None)
     os.environ.update(env)
     e = engine_from_problem(ckw, pkw, nchains=n, record_accept=1, **ekw)
@@ -54,8 +54,8 @@ def main():
         A = rng.standard_normal((d, d)) / np.sqrt(d)
         ckw = dict(nsimu=130, adaptint=50, updatesigma=0, drscale=2.0)
         pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.05), cmat0=(0.5 / d) * np.eye(d), mu=np.linspace(-1, 1, d), lam=A @ A.T + np.eye(d))
-        base = run(ckw, pkw, 70, {"MCMCX_GROUP": "0"}, "step_kernel_dr")
-        ok &= same(run(ckw, pkw, 70, {"MCMCX_GROUP": "0", "MCMCX_DR_GENERAL": "1"}, "step_kernel<false, true, false>"), base, "step_kernel<false, true, false> npar %d" % d)
+        base = run(ckw, pkw, 70, {"MCMCX_GROUP": "0", "MCMCX_DR_BIG": "0"}, "step_kernel_dr")
+        ok &= same(run(ckw, pkw, 70, {"MCMCX_GROUP": "0", "MCMCX_DR_BIG": "0", "MCMCX_DR_GENERAL": "1"}, "step_kernel<false, true, false>"), base, "step_kernel<false, true, false> npar %d" % d)
     for d in (49, 100):                                         # the blocked SVD's rotations once per pair
         A = rng.standard_normal((d, d)) / np.sqrt(d)
         ckw = dict(nsimu=45, method="scam", adaptint=14, updatesigma=0)
