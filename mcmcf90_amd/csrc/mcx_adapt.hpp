@@ -1,7 +1,6 @@
 // mcx_adapt.hpp -- the first point (init_kernel) and MCMC_adapt at a tick (MCMC_adapt.F90:12-230): schedule, covmat in 10 x 10 blocks,
-// MCMC_calculate_R
-// (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled, mcx_phase,
-// mcx_adapt, mcx_svd, mcx_moments)
+// MCMC_calculate_R (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam,
+// mcx_pooled, mcx_phase, mcx_adapt, mcx_svd, mcx_moments)
 #pragma once
 #include "mcx_phase.hpp"
 
@@ -476,21 +475,19 @@ __global__ __launch_bounds__(64) void adapt_pre_kernel(EngineDev E, int it, int 
 
 // The steady-state form of covmat's Welford update (matutils.F90:283-310), blocked: one block of the upper triangle of cmat stays in
 // registers while the window's iterations t0..t1 stream by, so cmat is read and written once per adaptation instead of once per accepted
-// row.  Row r of the reference's chain(lastind:chainind) is "the state between two set ballot bits"; its weight (the repeat count) is
-// known when the next accept arrives, which is when the row is folded in.  Every component's running mean obeys its own recurrence, so
-// recomputing delta = x - mean inside each block repeats the reference's operations exactly (deltas, o = delta_u delta_v,
-// C += f1 (f2 o - C), means).  The window's base row (basetheta), its count at window start and the amount (lastfreq) taken off the first
-// folded weight are the AM branch's (MCMC_adapt.F90:140-147); the greedy restart (:91) has unit weights and no base row.
-// Blocks of TD = 10 (the BASELINE dimensions 10, 20, 50 are whole numbers of them): a DIAGONAL block is its upper triangle, 55 elements,
-// an off-diagonal one 100 -- fewer, larger blocks repeat the per-fold overhead (the three divisions, the deltas, the row's loads) less
-// often than the 8 x 8 cover of round 3 did (tools/variants/README.md).  DIAG: launched with two waves per SIMD; the off-diagonal form
-// holds 100 accumulators and runs one wave per SIMD (its hundred independent chains keep the VALU busy without a second wave).
-// The walk is in lockstep and a fold runs under the exec mask of whoever accepted at that iteration; decoupling walk and folds by a
-// per-lane
-// FIFO in LDS (fewer, fuller rounds) was built in round 6, is bit-equal, and LOSES at the bench's acceptance rates:
-// tools/variants/mcx_cov_fifo.hpp.
-// Grid: 8 * ceil(ntiles / 8) * nblk workgroups of one wave; workgroup w runs on XCD w % 8, so tile = (w / 8 / nblk) * 8 + w % 8,
-// block = (w / 8) % nblk keeps a tile's blocks on one XCD and next to each other in time.
+// row.  Row r of the reference's chain(lastind:chainind) is "the state between two set ballot bits"; its weight (the repeat count) is known
+// when the next accept arrives, which is when the row is folded in.  Every component's running mean obeys its own recurrence, so
+// recomputing delta = x - mean inside each block repeats the reference's operations exactly (deltas, o = delta_u delta_v, C += f1 (f2 o -
+// C), means).  The window's base row (basetheta), its count at window start and the amount (lastfreq) taken off the first folded weight are
+// the AM branch's (MCMC_adapt.F90:140-147); the greedy restart (:91) has unit weights and no base row. Blocks of TD = 10 (the BASELINE
+// dimensions 10, 20, 50 are whole numbers of them): a DIAGONAL block is its upper triangle, 55 elements, an off-diagonal one 100 -- fewer,
+// larger blocks repeat the per-fold overhead (the three divisions, the deltas, the row's loads) less often than the 8 x 8 cover of round 3
+// did (tools/variants/README.md).  DIAG: launched with two waves per SIMD; the off-diagonal form holds 100 accumulators and runs one wave
+// per SIMD (its hundred independent chains keep the VALU busy without a second wave). The walk is in lockstep and a fold runs under the
+// exec mask of whoever accepted at that iteration; decoupling walk and folds by a per-lane FIFO in LDS (fewer, fuller rounds) was built in
+// round 6, is bit-equal, and LOSES at the bench's acceptance rates: tools/variants/mcx_cov_fifo.hpp. Grid: 8 * ceil(ntiles / 8) * nblk
+// workgroups of one wave; workgroup w runs on XCD w % 8, so tile = (w / 8 / nblk) * 8 + w % 8, block = (w / 8) % nblk keeps a tile's blocks
+// on one XCD and next to each other in time.
 constexpr int TD = 10;
 template <bool DIAG>
 MCX_DEV void covmat_window_td(const EngineDev &E, int it, int mode, int nblk)

@@ -36,8 +36,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
     } while (0)
 
 // The test switches (tests, tools): each FORCES one of two kernel forms that the engine also chooses by itself for some configuration -- so
-// that
-// the parity tests can run both forms on the same small problem.  None selects a form the engine would never take (those live in
+// that the parity tests can run both forms on the same small problem.  None selects a form the engine would never take (those live in
 // tools/variants, outside this library).  Read from the environment ONCE per engine, at mcmcx_create and again at mcmcx_init -- never at
 // launch time.  -1 = not set.
 struct mcx_switches {
@@ -193,18 +192,15 @@ static int dev_upload(mcmcx_engine *h, const T **p, const std::vector<T> &v)
 }
 
 // No limit on npar like the reference (MCMC_init.F90:81-102 allocates whatever the namelist says) -- beyond int-sized packed indices.  Up
-// to 256
-// every kernel family applies; above, the forms that keep an npar-vector per lane in LDS give way to global scratch where the 160 KiB end
-// (delayed rejection > 160, the adaptation's work vector > 320, the pooled-moment kernel from 316 on), the blocked SVD to the
-// lane-per-chain SVD
-// (> 256), the matrix-core pooled kernels to the lane kernels (their own LDS tests): slower, never refused.
-// response columns (mcmc.F90:30-33: whatever mcmcnycol.dat says): every per-column array is sized at mcmcx_init
+// to 256 every kernel family applies; above, the forms that keep an npar-vector per lane in LDS give way to global scratch where the 160
+// KiB end (delayed rejection > 160, the adaptation's work vector > 320, the pooled-moment kernel from 316 on), the blocked SVD to the
+// lane-per-chain SVD (> 256), the matrix-core pooled kernels to the lane kernels (their own LDS tests): slower, never refused. response
+// columns (mcmc.F90:30-33: whatever mcmcnycol.dat says): every per-column array is sized at mcmcx_init
 static const int MCX_MAX_NYCOL = 4096;
 // P = npar (npar + 1) / 2 = 8 390 656 at the cap, 64 P = 537 M and (2 npar + P) 64 = 538 M: every int-typed index expression of the device
-// code
-// (pidx, rowstart, e * 64 + lane) stays below 2**31 with a factor of four to spare -- at 8192, the cap up to round 5, 64 P is 2.147e9 >
-// INT_MAX and
-// only the size_t casts of every current use site kept it correct.  Larger problems are refused loudly at mcmcx_create.
+// code (pidx, rowstart, e * 64 + lane) stays below 2**31 with a factor of four to spare -- at 8192, the cap up to round 5, 64 P is 2.147e9
+// > INT_MAX and only the size_t casts of every current use site kept it correct.  Larger problems are refused loudly at
+// mcmcx_create.
 static const int MCX_MAX_NPAR = 4096;
 
 // dpotf2('U') + scaling on the host for the shared initial factor: same operation sequence as the
@@ -463,9 +459,9 @@ static bool group_wins(const mcmcx_engine *h, int drm, int gw)
     return d >= 11 || (h->dodr && d >= 9 && n <= 131072);
 }
 // one instantiation per (group width, npar rounded up, delayed-rejection form, target kind); DRM 0 = none, 1 = the general form (R, R2, iC
-// in
-// registers), 2 = drscale a power of two (no R2; iC in LDS): the instantiation without R2 runs unless the device flag says that some factor
-// leaves the range in which R'z / drscale is R2'z bit for bit; the general one is queued behind the same flag and returns at once otherwise
+// in registers), 2 = drscale a power of two (no R2; iC in LDS): the instantiation without R2 runs unless the device flag says that some
+// factor leaves the range in which R'z / drscale is R2'z bit for bit; the general one is queued behind the same flag and returns at once
+// otherwise
 template <int GW, int D4, int DRM, int TK>
 static void launch_group_inst(mcmcx_engine *h, int it0, int it1)
 {
@@ -513,8 +509,7 @@ static void launch_group_d4(mcmcx_engine *h, int it0, int it1)
         case 24: launch_group_tk<16, 24, DRM>(h, it0, it1); break;
         default:
             // DRM = 2 (iC as a square in LDS) is the engine's choice up to npar 24 only (mcmcx_init): larger sizes are not instantiated --
-            // at
-            // 28 / 32 they could not hold the two waves per SIMD they would declare (Weak 12)
+            // at 28 / 32 they could not hold the two waves per SIMD they would declare (Weak 12)
             if constexpr (DRM != 2) {
                 switch (h->group_d4) {
                 case 28: launch_group_tk<16, 28, DRM>(h, it0, it1); return;
@@ -565,8 +560,7 @@ static void launch_group(mcmcx_engine *h, int it0, int it1)
 }
 // pooled_mfma_kernel<false, true>: two waves per SIMD (256 registers, some state spilled) pay with more tiles than SIMDs: from two per SIMD
 // where the LDS vector lets eight waves on a CU (npar <= 39: +25 .. +55 %), from eight where it lets six (npar 50: 0.80 at 2048 tiles, 0.99
-// at
-// 4096, 1.14 at 16384); with one tile per SIMD the spills are all they buy (0.83 .. 0.90) -- tools/pooled_waves_probe.py
+// at 4096, 1.14 at 16384); with one tile per SIMD the spills are all they buy (0.83 .. 0.90) -- tools/pooled_waves_probe.py
 static bool pooled_two_waves(const mcmcx_engine *h)
 {
     // (test switch: either instance on a small problem)
@@ -577,14 +571,11 @@ static bool pooled_two_waves(const mcmcx_engine *h)
 #define STEP_RS (h->d_ramscale + it0)
 #define STEP_TGT h->E.tgt.mu, h->E.tgt.lamT
 #define G1 dim3(h->ntiles), dim3(64)
-// method = 'ram' with few chains: sixteen lanes per chain, the factor in registers, dchud / dchdd on it there (mcx_group_ram.hpp)
-// where it is the faster one (tools/ram_group_sweep.py, profiles/r05_b/ram_group_sweep.txt: chain-iterations/s of both families over npar,
-// chain count and
-// regime): one wave per SIMD and four chains per wave, so the chip holds 4096 chains at once and the kernel saturates there (1.68e8 / 4.6e8
-// / 1.1e9
-// chain-iterations/s at npar 50 / 20 / 10) -- 9x / 6x / 6x the lane kernels up to 4096 chains, still 2.9x / 1.7x / 2.0x at 16384 and 1.6x /
-// 1.1x / 1.2x
-// at 32768; from 65536 chains on the streaming kernels are ahead (0.93 / 0.74 / 0.63)
+// method = 'ram' with few chains: sixteen lanes per chain, the factor in registers, dchud / dchdd on it there (mcx_group_ram.hpp) where it
+// is the faster one (tools/ram_group_sweep.py, profiles/r05_b/ram_group_sweep.txt: chain-iterations/s of both families over npar, chain
+// count and regime): one wave per SIMD and four chains per wave, so the chip holds 4096 chains at once and the kernel saturates there
+// (1.68e8 / 4.6e8 / 1.1e9 chain-iterations/s at npar 50 / 20 / 10) -- 9x / 6x / 6x the lane kernels up to 4096 chains, still 2.9x / 1.7x /
+// 2.0x at 16384 and 1.6x / 1.1x / 1.2x at 32768; from 65536 chains on the streaming kernels are ahead (0.93 / 0.74 / 0.63)
 static bool ram_group_wins(const mcmcx_engine *h)
 {
     const long long n = h->cfg.nchains;
@@ -624,10 +615,14 @@ static void launch_group_ram(mcmcx_engine *h, int it0, int it1)
 #endif
 static const KernelEntry STEP_TABLE[] = {
     // ---- a device target with response columns (nycol >= 1 sums of squares per point): the phases of an iteration in one launch
+    // (one instantiation per method class: MCMC_run_ram's carries the rank-one update's panels, the others do not)
+    {"step", "step_kernel_cols<ram>", [](const mcmcx_engine *h) { return fused_cols(h) && h->E.method == M_RAM; },
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_cols<1>, G1, lds_step(h), STEP_ARGS, (const double *)h->d_ramscale,
+                                                                (const double *)nullptr, (const double *)nullptr, (const double *)nullptr); }},
     {"step", "step_kernel_cols", fused_cols,
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_cols, G1, lds_step(h), STEP_ARGS, (const double *)h->d_ramscale,
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_cols<0>, G1, lds_step(h), STEP_ARGS, (const double *)h->d_ramscale,
                                                                 (const double *)(h->pooled ? h->E.sharedR : nullptr),
-                                                                    (const double *)h->d_sharedR2, (const double *)h->d_sharediC); }},
+                                                                (const double *)h->d_sharedR2, (const double *)h->d_sharediC); }},
     // ---- pooled mode (one shared factor)
     {"step", "pooled_mfma_kernel<true>", [](const mcmcx_engine *h) { return pooled_use_mfma(h) && h->dodr != 0; },
      [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(pooled_mfma_kernel<true>, G1, pooled_mfma_lds(h->d), STEP_ARGS, STEP_TGT,
@@ -769,7 +764,7 @@ static int scam_tile_waves(const mcmcx_engine *h)
 #define SCAM_POOLED_ARGS scam_pooled_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT
 static const KernelEntry SCAM_TABLE[] = {
     {"scam", "step_kernel_cols<scam>", [](const mcmcx_engine *h) { return fused_cols(h) && !h->pooled; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_cols, G1, 0, STEP_ARGS, (const double *)h->d_ramscale,
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_cols<2>, G1, 0, STEP_ARGS, (const double *)h->d_ramscale,
          (const double *)nullptr, (const double *)nullptr, (const double *)nullptr); }},
     // pooled: 16-row output blocks, min(12, 4*(nt/4)) block waves + 4 chain-group waves; twelve waves of 170 registers for 13..15 blocks
     {"scam", "scam_pooled12_kernel", [](const mcmcx_engine *h) { return h->pooled && !h->scam_replicated && scam_use_12(h); },
@@ -850,8 +845,7 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
             (uint8_t *)nullptr, batch_done);
         else if (h->tile_factor) {
             // dpotf2 (+ dtrti2 / dlauu2 with delayed rejection) with the packed matrices of 4 NW neighbouring chains in LDS, read and
-            // written
-            // once (mcx_group.hpp: tile_factor_kernel); adapt_post_kernel keeps the covariance bookkeeping (phase 3)
+            // written once (mcx_group.hpp: tile_factor_kernel); adapt_post_kernel keeps the covariance bookkeeping (phase 3)
             hipLaunchKernelGGL(adapt_post_kernel<false>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 3, (uint8_t *)nullptr,
                 batch_done);
             const int nc = (h->d + 15) / 16, nw = nc <= 2 ? 4 : nc == 3 ? 2 : 1, ch = 4 * nw;
@@ -878,8 +872,7 @@ static void launch_adapt(mcmcx_engine *h, int it, int mode)
     for (int sweep = 0; sweep < 60; ++sweep) {
         (void)hipMemsetAsync(h->d_anyrot, 0, sizeof(int), h->stream);
         // the sweep: every later column streamed past a block's pair-lanes through an LDS ring (mcx_svd.hpp) -- all 32 lanes of a row group
-        // on
-        // pairs up to npar 200 (svd_sweep_stream32_kernel), 24 pair-lanes and a wave of loaders above (svd_sweep_stream_kernel)
+        // on pairs up to npar 200 (svd_sweep_stream32_kernel), 24 pair-lanes and a wave of loaders above (svd_sweep_stream_kernel)
         if (h->d <= 200) {
             const int RLs = h->d <= 64 ? 8 : h->d <= 128 ? 16 : 25;
             const size_t lss = (size_t)33 * (8 * RLs + 2) * sizeof(double);
@@ -1375,8 +1368,8 @@ static int host_eval(mcmcx_engine *h, const double *dev_src, int stride_k, bool 
 }
 
 // fuse_next: iteration it + 1 follows without a tick in between -- its proposal (phase 0; SCAM: component 0's phase 5) rides in this
-// iteration's
-// last launch, and h->p0_done tells the next call so (MCMCX_HOST_FUSE=0: one launch per phase, the A/B form the tests compare with)
+// iteration's last launch, and h->p0_done tells the next call so (MCMCX_HOST_FUSE=0: one launch per phase, the A/B form the tests compare
+// with)
 static int host_iteration(mcmcx_engine *h, int it, bool fuse_next)
 {
     const dim3 g(h->ntiles), b(64);
@@ -1971,13 +1964,10 @@ int mcmcx_init(mcmcx_handle h)
         }
     }
     // the adaptation's factorisation (Cholesky branch) with the matrices in LDS (tile_factor_kernel): any chain count, npar <= 32 -- config
-    // 3's size
-    // (npar 20, delayed rejection, 262144 chains): 2.11 -> 1.44 ms per tick, bound by VALU issue (~25 instructions per inner step of four
-    // chains).
-    // Above npar 32 adapt_post_kernel's 8 x 8 register blocks stay: at npar 50 x 1 048 576 chains they stream the matrices ~5.6 times (16.0
-    // ms)
-    // and still beat the LDS form, whose three waves per CU issue ~15 x the instructions per chain (35.2 ms; profiles/r05_a/tick_ab.txt).
-    // MCMCX_TILE_FACTOR = 0 / 1: never / up to npar 64 (test switch: both forms on one problem).
+    // 3's size (npar 20, delayed rejection, 262144 chains): 2.11 -> 1.44 ms per tick, bound by VALU issue (~25 instructions per inner step
+    // of four chains). Above npar 32 adapt_post_kernel's 8 x 8 register blocks stay: at npar 50 x 1 048 576 chains they stream the matrices
+    // ~5.6 times (16.0 ms) and still beat the LDS form, whose three waves per CU issue ~15 x the instructions per chain (35.2 ms;
+    // profiles/r05_a/tick_ab.txt). MCMCX_TILE_FACTOR = 0 / 1: never / up to npar 64 (test switch: both forms on one problem).
     {
         const char *tf = getenv("MCMCX_TILE_FACTOR");
         h->tile_factor = am && !h->usesvd && d <= ((tf && atoi(tf) == 1) ? 64 : 32) && !(tf && atoi(tf) == 0);
@@ -2087,9 +2077,8 @@ static int run_impl(mcmcx_handle h, int32_t upto)
     if (!h->inited) return fail(-40, "we have not inited");                           // MCMC_run.F90:22
     if (h->external) return fail(-41, "mcmcx_run: the target is external (mcmcx_set_target_external): drive the chain with mcmcx_run1_*");
     // (with the phases fused, iteration it + 1's proposal -- Philox draws included -- has already run when an error surfaces in iteration
-    // it's
-    // evaluation; a second run on the handle would draw that proposal again and leave the reference's stream order silently: ADVICE round
-    // 5)
+    // it's evaluation; a second run on the handle would draw that proposal again and leave the reference's stream order silently: ADVICE
+    // round 5)
     if (h->failed) return fail(-42, "mcmcx_run: an earlier run on this handle failed inside a host-callback iteration; its chains are in an undefined state -- destroy the handle");
     HIPCHK(hipSetDevice(h->cfg.device));
     const mcmcx_config &c = h->cfg;

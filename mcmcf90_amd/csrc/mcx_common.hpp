@@ -485,12 +485,11 @@ MCX_DEV double gen_normals(Rng &g, double *zs_t, int lane, int d, bool participa
     return su;
 }
 
-// The same vector in TWO passes, for a kernel whose generator is bound by instruction issue (pooled_mfma_kernel: 47 % of an iteration):
-// a wave runs ~40 attempts per lane for the 25 pairs a lane of npar 50 keeps (0.785 a try, the slowest lane sets the trip count), and in
-// the one-pass form every one of them pays for the logarithm, the square root and the two divisions.  Pass A makes the attempts -- the
-// Philox blocks, the two uniforms, the test xx < 1 -- and parks the ACCEPTED pair's (x2, x1) where its deviates will stand; it alone moves
-// the stream.  Pass B visits the parked pairs, exactly as many as the vector holds, and scales them: z = sqrt(-2 log(xx) / xx) with xx
-// formed
+// The same vector in TWO passes, for a kernel whose generator is bound by instruction issue (pooled_mfma_kernel: 47 % of an iteration): a
+// wave runs ~40 attempts per lane for the 25 pairs a lane of npar 50 keeps (0.785 a try, the slowest lane sets the trip count), and in the
+// one-pass form every one of them pays for the logarithm, the square root and the two divisions.  Pass A makes the attempts -- the Philox
+// blocks, the two uniforms, the test xx < 1 -- and parks the ACCEPTED pair's (x2, x1) where its deviates will stand; it alone moves the
+// stream.  Pass B visits the parked pairs, exactly as many as the vector holds, and scales them: z = sqrt(-2 log(xx) / xx) with xx formed
 // again from the same two numbers by the same two products and one sum.  Stream position, deviates, the cached second deviate and the order
 // of sum(z**2): those of gen_normals.
 template <int NB, int NBB = 4>
@@ -503,8 +502,7 @@ MCX_DEV double gen_normals_split(Rng &g, double *zs_t, int lane, int d, bool par
     bool need = participate && (k < d);
     double over = 0.0;                                    // x1 of the pair whose second deviate lies past the vector's end
     // block b0 + NB -- the straddling pair's second half when the stream position is odd -- is the NEXT trip's block b0 for every lane that
-    // goes on
-    // (it consumed all NB attempts): carried over instead of computed again, NB blocks per trip after the first instead of NB + 1
+    // goes on (it consumed all NB attempts): carried over instead of computed again, NB blocks per trip after the first instead of NB + 1
     uint32_t cw0 = 0u, cw1 = 0u, cw2 = 0u, cw3 = 0u;
     uint64_t cblk1 = 0;                                   // the carried block's index + 1 (0: none)
     while (__any(need)) {

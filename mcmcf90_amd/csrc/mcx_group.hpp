@@ -827,10 +827,8 @@ __global__ void group_check_kernel(EngineDev E, int *flag)
 //   dlauu2('U'):   lane = ROW r: A(r,i) = A(i,i) A(r,i) + sum_{k>i} A(i,k) A(r,k) ascending k; the diagonal's sum of squares on every lane.
 // adapt_post_kernel streamed the packed matrices of a tile ~5.6 times through L2 / HBM for its 8 x 8 register blocks (33.5 ms per tick of
 // 1 048 576 chains at npar 50, 2.2 ms at config 3's size); this reads and writes each once.  Results: R, R2, iC, I_INFO and the status
-// bits, as
-// adapt_post_kernel leaves them.  (Round 4's one-wave form with [row][column] squares in LDS, group_factor_kernel, is superseded:
-// tools/variants/README.md.)
-// Grid: 8 ceil(ntiles / 8) (64 / (4 NW)) workgroups of 64 NW threads; LDS: 4 NW (P | 1) doubles + 4 NW ints.
+// bits, as adapt_post_kernel leaves them.  (Round 4's one-wave form with [row][column] squares in LDS, group_factor_kernel, is superseded:
+// tools/variants/README.md.) Grid: 8 ceil(ntiles / 8) (64 / (4 NW)) workgroups of 64 NW threads; LDS: 4 NW (P | 1) doubles + 4 NW ints.
 template <int NC, int NW>
 __global__ __launch_bounds__(64 * NW) void tile_factor_kernel(EngineDev E)
 {

@@ -1,23 +1,18 @@
 // mcx_group_ram.hpp -- MCMC_run_ram (MCMC_run_ram.F90:45-179) in the lane-group layout: sixteen lanes per chain, four chains per wave, the
 // factor R in REGISTERS for the whole launch and MCMC_adapt_ram's rank-one update / downdate (dchud.f:122-139, dchdd.f:141-179) performed
-// on it
-// there.  Included by mcx_api.hip after mcx_group.hpp (round 5; VERDICT round 4, "a few-chains RAM path").
+// on it there.  Included by mcx_api.hip after mcx_group.hpp (round 5; VERDICT round 4, "a few-chains RAM path").
 //
 // Why: with few chains an iteration is latency.  The lane-per-chain RAM kernels stream the packed factor through L2 twice per iteration,
-// one
-// dependent row visit after the other: 184 us per iteration at 64 chains and npar 50, against ~8 us for the reference on one host core.
-// Here the
-// factor never leaves the registers between two launches (npar 50: 152 doubles per lane, one wave per SIMD) and an iteration is ~20-35 us.
-// It is NOT a throughput kernel -- a wave runs DCHUD's fifty serial drotg for four chains where a lane-per-chain wave runs them for 64
-// (profiles/r04_a/ram_group_probe.txt, profiles/r05_a/ram_group8_probe.txt: measured, closed) -- it saturates at the 4096 chains the chip
-// holds at one
-// wave per SIMD (1.68e8 chain-iterations/s at npar 50, where the streaming kernels reach 2.3e8 with 131072 chains and more), so the engine
-// takes it up
-// to 16384 chains (32768 from npar 17 on: mcx_api.hip, ram_group_wins; profiles/r05_b/ram_group_sweep.txt).
+// one dependent row visit after the other: 184 us per iteration at 64 chains and npar 50, against ~8 us for the reference on one host core.
+// Here the factor never leaves the registers between two launches (npar 50: 152 doubles per lane, one wave per SIMD) and an iteration is
+// ~20-35 us. It is NOT a throughput kernel -- a wave runs DCHUD's fifty serial drotg for four chains where a lane-per-chain wave runs them
+// for 64 (profiles/r04_a/ram_group_probe.txt, profiles/r05_a/ram_group8_probe.txt: measured, closed) -- it saturates at the 4096 chains the
+// chip holds at one wave per SIMD (1.68e8 chain-iterations/s at npar 50, where the streaming kernels reach 2.3e8 with 131072 chains and
+// more), so the engine takes it up to 16384 chains (32768 from npar 17 on: mcx_api.hip, ram_group_wins;
+// profiles/r05_b/ram_group_sweep.txt).
 //
 // Layout as in group_step_kernel: lane l16 of a chain owns the columns l16, l16 + 16, ... of R (rows 0..column in registers, zeros below
-// the
-// diagonal), a vector element k sits in lane k mod 16 (slot k / 16) and reaches the others by row_newbcast.
+// the diagonal), a vector element k sits in lane k mod 16 (slot k / 16) and reaches the others by row_newbcast.
 //   proposal   p_c = sum_{i <= c} R(i,c) z_i ascending in i (v_fmac_f64_dpp chains); after a successful downdate the reference order is the
 // diagonal term as a plain product first, then rows c - 1 .. 0 (mcxo_trmv_ut_desc) -- the same uniform walk
 //              from the last row down with the lane's own diagonal row selected as the chain's start.
@@ -37,8 +32,7 @@ namespace mcx {
 
 // p = fma(r_i, z_i, p) over the rows i = N-1 .. 0 of a block, lane-uniform walk, with the chain's START at the lane's own diagonal row
 // (i == dg: p = r_i * z_i, a plain product; rows above it: untouched).  dg: the lane's diagonal row inside this block, or -1 (the whole
-// block
-// lies above / below the lane's column start: `live` says whether the chain has started).
+// block lies above / below the lane's column start: `live` says whether the chain has started).
 template <int N>
 MCX_DEV void blk_fmac_desc(double &p, bool &live, double z, const double *r, int dg)
 {

@@ -1,7 +1,6 @@
 // mcx_moments.hpp -- pooled moments of the current states (the one exchanged vector of the multi-GPU path), the fixed pairwise tree, debug
-// probes
-// (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled, mcx_phase,
-// mcx_adapt, mcx_svd, mcx_moments)
+// probes (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled,
+// mcx_phase, mcx_adapt, mcx_svd, mcx_moments)
 #pragma once
 #include "mcx_svd.hpp"
 
@@ -16,9 +15,9 @@ namespace mcx {
 // kind 2: the pooled RAM statistic of iteration `it` (MCMC_run_ram.F90:166-172 summed over chains): [count, sum alpha,
 //         sum_c sign(a_c) x_c x_c'], x_c = u_c / sum(u_c**2) * a_c, a_c = rs (alpha_c - alphatarget)     (2 + P)
 // BIG (npar >= 316: (64 (d | 1) + 320) doubles exceed 160 KiB -- the tile's 64 vectors no longer fit a CU's LDS): the same terms with every
-// x value formed from global memory where it
-// is used -- the same operations on the same operands, so the same bits; only the four 64-vectors (count, alpha or stayed, sign, sum(u**2))
-// and the chains' a = rs (alpha - alphatarget) stay in LDS.  Slower (each term reads its 2 x 64 values through L2); any npar.
+// x value formed from global memory where it is used -- the same operations on the same operands, so the same bits; only the four
+// 64-vectors (count, alpha or stayed, sign, sum(u**2)) and the chains' a = rs (alpha - alphatarget) stay in LDS.  Slower (each term reads
+// its 2 x 64 values through L2); any npar.
 template <bool BIG>
 __global__ __launch_bounds__(256) void moments_kernel(EngineDev E, double *out, int nchains, int kind, int it, double rs)
 {
@@ -105,8 +104,7 @@ __global__ __launch_bounds__(256) void moments_kernel(EngineDev E, double *out, 
 }
 
 // one double into device memory in stream order (the rank's stop flag behind its moment vector): a pageable hipMemcpyAsync of eight bytes
-// makes the
-// host wait for the stream on this runtime, which put a host round trip between two bench steps
+// makes the host wait for the stream on this runtime, which put a host round trip between two bench steps
 __global__ void set_double_kernel(double *p, double v) { *p = v; }
 
 // Finish the pooled sum over tiles in the same fixed pairwise tree (adjacent tiles first):

@@ -1,6 +1,5 @@
 // mcx_phase.hpp -- the iteration cut at the user's evaluations: host_phase_kernel (host callbacks), dev_eval_kernel + step_kernel_cols
-// (device
-// target with response columns, nycol >= 1, in one launch), run1_kernel (MCMC_run1 / MCMC_run1_er)
+// (device target with response columns, nycol >= 1, in one launch), run1_kernel (MCMC_run1 / MCMC_run1_er)
 // (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled, mcx_phase,
 // mcx_adapt, mcx_svd, mcx_moments)
 #pragma once
@@ -29,6 +28,9 @@ MCX_DEV double d_alpha_cols(const double *ss1, double pri1, const double *ss2, d
 
 // end of an iteration: MCMC_run.F90:93-105 / MCMC_run_ram.F90:66-78
 // ss2cols: with nycol > 1 the accepted point's ss per column (a per-chain vector); nullptr = the scalar ss2
+// MSEL: the method class at compile time -- -1: whatever the engine holds (the host-callback phase kernels), 0: not RAM, 1: RAM, 2: SCAM
+// (step_kernel_cols: an instantiation without the RAM update's panels needs a third fewer registers)
+template <int MSEL = -1>
 MCX_DEV void host_finish(const EngineDev &E, int tile, int lane, int it, LaneState &L, bool reject, bool dr_moved,
                          double ss2, double pri2, const double *ramscale, const double *ss2cols = nullptr)
 {
@@ -71,7 +73,7 @@ MCX_DEV void host_finish(const EngineDev &E, int tile, int lane, int it, LaneSta
         }
     }
     if (E.accmask && lane == 0) E.accmask[(size_t)(it - 1) * E.ntiles + tile] = ballot;
-    if (E.method == M_RAM && E.doadapt != 0 && !(it < E.burnintime && E.doburnin != 0)) {
+    if ((MSEL < 0 ? E.method == M_RAM : MSEL == 1) && E.doadapt != 0 && !(it < E.burnintime && E.doburnin != 0)) {
         double a = ramscale[0] * (L.alpha12 - E.alphatarget);
         if (!(a >= 0.0)) TIDX(E.ictr, tile, NICTR, I_DOWNS, lane) += 1u;
         const double *hx = E.hx + (size_t)tile * NHX * 64;
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(64) void dev_eval_kernel(EngineDev E, const double 
 { dev_eval_body(E, blockIdx.x, threadIdx.x, src, stride_k, use_stage2, what); }
 
 // sR / sR2 / siC: pooled mode's shared factor, second-stage factor and inverse covariance (nullptr: the chain's own)
-template <int PHASE>
+template <int PHASE, int MSEL = -1>
 MCX_DEV void host_phase_body(const EngineDev &E, int tile, int lane, int it, const double *__restrict__ ramscale, int aux, double *X,
                              const double *__restrict__ sR = nullptr, const double *__restrict__ sR2 = nullptr,
                                  const double *__restrict__ siC = nullptr)
@@ -171,7 +173,7 @@ MCX_DEV void host_phase_body(const EngineDev &E, int tile, int lane, int it, con
             GV(hx, HX_SS2) = ss2; GV(hx, HX_PRI2) = pri2;
             GV(hx, HX_REJECT) = reject ? 1.0 : 0.0; GV(hx, HX_STAGE2) = m ? 1.0 : 0.0;
         } else {
-            host_finish(E, tile, lane, it, L, reject, false, ss2, pri2, ramscale, sshev);
+            host_finish<MSEL>(E, tile, lane, it, L, reject, false, ss2, pri2, ramscale, sshev);
         }
     } else if (PHASE == 5) {                                      // SCAM sub-step aux: propose (MCMC_run_scam.F90:94-117)
         const int j = aux;
@@ -260,7 +262,7 @@ MCX_DEV void host_phase_body(const EngineDev &E, int tile, int lane, int it, con
             if (ny > 1) { tot = 0.0; for (int j = 0; j < ny; ++j) tot = tot + GV(sshev, j); }                 // sum(ss2)
             reject = (tot >= GV(hx, HX_CRIT));
         }
-        host_finish(E, tile, lane, it, L, reject, false, ss2, pri2, ramscale, sshev);
+        host_finish<MSEL>(E, tile, lane, it, L, reject, false, ss2, pri2, ramscale, sshev);
     } else {                                                      // PHASE 2: decide the DR try, finish
         bool reject = GV(hx, HX_REJECT) != 0.0;
         double ss2 = GV(hx, HX_SS2), pri2 = GV(hx, HX_PRI2);
@@ -294,7 +296,7 @@ MCX_DEV void host_phase_body(const EngineDev &E, int tile, int lane, int it, con
                 if (!rej2) { L.dracc += 1; reject = false; dr_moved = true; ss2 = ss3; pri2 = pri3; }
             }
         }
-        host_finish(E, tile, lane, it, L, reject, dr_moved, ss2, pri2, ramscale, dr_moved ? sshev : ss2v);
+        host_finish<MSEL>(E, tile, lane, it, L, reject, dr_moved, ss2, pri2, ramscale, dr_moved ? sshev : ss2v);
     }
     lane_store(E, tile, lane, L);
 }
@@ -306,11 +308,10 @@ __global__ __launch_bounds__(64) void host_phase_kernel(EngineDev E, int it, con
 }
 
 // Two (three) phases that no evaluation separates, in one launch: the last phase of an iteration and the first of the next one (the
-// proposal),
-// a SCAM sub-step's decision and the next component's proposal.  With the user's functions on the host an iteration of few chains is launch
-// and
-// wake-up latency, nothing else -- one launch per evaluation instead of two.  The phases hand over through the chain's own state exactly as
-// separate launches do (every element written and read back by the same lane: see step_kernel_cols).  PB / PC < 0: none.
+// proposal), a SCAM sub-step's decision and the next component's proposal.  With the user's functions on the host an iteration of few
+// chains is launch and wake-up latency, nothing else -- one launch per evaluation instead of two.  The phases hand over through the chain's
+// own state exactly as separate launches do (every element written and read back by the same lane: see step_kernel_cols).  PB / PC < 0:
+// none.
 template <int PA, int PB, int PC>
 __global__ __launch_bounds__(64) void host_phase_seq_kernel(EngineDev E, int itA, int auxA, int itB, int auxB, int itC, int auxC,
     const double *__restrict__ ramscale)
@@ -330,45 +331,48 @@ __global__ __launch_bounds__(64) void host_phase_seq_kernel(EngineDev E, int itA
 // do -- every element is written and read back by the same lane, so program order is all the ordering there is to keep -- which makes
 // the fused form the phase form bit for bit (tests/test_gpu_host_callbacks.py, fixtures m1..m5 both ways).  ramscale: the table's
 // base (1 / it**nuparam at index it).  sR / sR2 / siC: pooled mode's shared tables.
+// MSEL: 0 = MCMC_run / MCMC_run_er (with or without delayed rejection), 1 = MCMC_run_ram, 2 = MCMC_run_scam -- one instantiation each, so that
+// none carries the others' code (the one general kernel of round 5 held 294 registers and 506 spilled SGPRs and ran one wave per SIMD; two
+// waves: config 1's model with two response columns 2.26 -> 3.09e9 proposals/s even with that kernel, profiles/r06_e/cols_waves.txt)
 #ifndef MCX_COLS_WAVES
-#define MCX_COLS_WAVES 1
+#define MCX_COLS_WAVES 2
 #endif
+template <int MSEL>
 __global__ __launch_bounds__(64, MCX_COLS_WAVES) void step_kernel_cols(EngineDev E, int it0, int it1, const double *__restrict__ ramscale,
-                                                       const double *__restrict__ sR, const double *__restrict__ sR2,
-                                                           const double *__restrict__ siC)
+                                                                       const double *__restrict__ sR, const double *__restrict__ sR2,
+                                                                       const double *__restrict__ siC)
 {
     extern __shared__ double X[];
     const int lane = threadIdx.x, tile = blockIdx.x, d = E.d;
     for (int it = it0; it <= it1; ++it) {
         const double *rs = ramscale + it;
-        // MCMC_run_scam.F90:94-138: npar componentwise proposals, each with its own evaluation
-        if (E.doscam) {
+        if constexpr (MSEL == 2) {                      // MCMC_run_scam.F90:94-138: npar componentwise proposals, each with its own evaluation
             for (int j = 0; j < d; ++j) {
-                host_phase_body<5>(E, tile, lane, it, rs, j, X);
+                host_phase_body<5, MSEL>(E, tile, lane, it, rs, j, X);
                 dev_eval_body(E, tile, lane, E.cand, d, 0, 0);
-                host_phase_body<6>(E, tile, lane, it, rs, j, X);
+                host_phase_body<6, MSEL>(E, tile, lane, it, rs, j, X);
             }
-            host_phase_body<7>(E, tile, lane, it, rs, 0, X);
-            continue;
-        }
-        host_phase_body<0>(E, tile, lane, it, rs, 0, X, sR, sR2, siC);
-        if (E.method == M_ER) {                         // MCMC_run_er.F90:54-101: the threshold is drawn between priorfun and ssfunction
-            dev_eval_body(E, tile, lane, E.cand, d, 0, 1);
-            host_phase_body<3>(E, tile, lane, it, rs, 0, X, sR, sR2, siC);
-            dev_eval_body(E, tile, lane, E.cand, d, 1, 2);
-            host_phase_body<4>(E, tile, lane, it, rs, 0, X, sR, sR2, siC);
-            continue;
-        }
-        dev_eval_body(E, tile, lane, E.cand, d, 0, 0);
-        host_phase_body<1>(E, tile, lane, it, rs, 0, X, sR, sR2, siC);
-        if (E.dodr) {
-            dev_eval_body(E, tile, lane, E.cs, 2 * d, 1, 0);
-            host_phase_body<2>(E, tile, lane, it, rs, 0, X, sR, sR2, siC);
+            host_phase_body<7, MSEL>(E, tile, lane, it, rs, 0, X);
+        } else {
+            host_phase_body<0, MSEL>(E, tile, lane, it, rs, 0, X, sR, sR2, siC);
+            if (MSEL == 0 && E.method == M_ER) {        // MCMC_run_er.F90:54-101: the threshold is drawn between priorfun and ssfunction
+                dev_eval_body(E, tile, lane, E.cand, d, 0, 1);
+                host_phase_body<3, MSEL>(E, tile, lane, it, rs, 0, X, sR, sR2, siC);
+                dev_eval_body(E, tile, lane, E.cand, d, 1, 2);
+                host_phase_body<4, MSEL>(E, tile, lane, it, rs, 0, X, sR, sR2, siC);
+                continue;
+            }
+            dev_eval_body(E, tile, lane, E.cand, d, 0, 0);
+            host_phase_body<1, MSEL>(E, tile, lane, it, rs, 0, X, sR, sR2, siC);
+            if (MSEL == 0 && E.dodr) {
+                dev_eval_body(E, tile, lane, E.cs, 2 * d, 1, 0);
+                host_phase_body<2, MSEL>(E, tile, lane, it, rs, 0, X, sR, sR2, siC);
+            }
         }
     }
     // pooled method = 'ram': the tick's statistic reads the last iteration's normals where the single-launch kernels leave them,
     // in the (it & 1) half of the chain's two normal vectors (moments_kernel kind 2); the phases keep stage-1 normals in the first half
-    if (sR && !E.dodr && (it1 & 1)) {
+    if (MSEL != 2 && sR && !E.dodr && (it1 & 1)) {
         double *zs_t = E.zs + (size_t)tile * 2 * d * 64;
         for (int k = 0; k < d; ++k) GV(zs_t, d + k) = GV(zs_t, k);
     }

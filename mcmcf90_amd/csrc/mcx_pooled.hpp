@@ -1,8 +1,6 @@
 // mcx_pooled.hpp -- pooled AM / RAM / ER / DR on the f64 matrix cores (pooled_mfma_kernel): one wave per tile, the shared tables' products
-// as
-// v_mfma_f64_16x16x4_f64 tiles
-// (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled, mcx_phase,
-// mcx_adapt, mcx_svd, mcx_moments)
+// as v_mfma_f64_16x16x4_f64 tiles (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step,
+// mcx_scam, mcx_pooled, mcx_phase, mcx_adapt, mcx_svd, mcx_moments)
 #pragma once
 #include "mcx_scam.hpp"
 
@@ -37,8 +35,7 @@ MCX_DEV void mfma_wave_product(const double *__restrict__ M, const double *X, in
     const double *xp = X + lk * 64 + li;
     // KU k-blocks per trip, their 4 KU loads of the shared table first: a trip waits for the L2 once -- one k-block per trip put thirteen
     // round trips of ~1 us on each product of a wave that has the SIMD almost to itself (round 4: 0.93 -> 0.73 ms per iteration of 1 048
-    // 576
-    // chains at npar 50; two k-blocks per trip do almost as well, seven or eight are slower)
+    // 576 chains at npar 50; two k-blocks per trip do almost as well, seven or eight are slower)
     constexpr int KU = MCX_POOLED_KU;
     for (int s0 = 0; s0 < kmax; s0 += 4 * KU) {
         double a[KU][4];
@@ -68,18 +65,15 @@ MCX_DEV void mfma_wave_product(const double *__restrict__ M, const double *X, in
     }
 }
 
-// DR: delayed rejection's second stage on the same cores (drscale > 0): the stage-2 proposal with the shared R2 = R / drscale
-// (g_R2T, dense like g_RT), the target once more, and the two quadratic forms dx' iC dx of MCMC_DR_alpha13 as y = iC dx
-// products against the dense symmetric table g_iCd, each followed by the chain q = sum_i y_i dx_i ascending in i (lane = chain:
-// y comes back through the LDS vector, dx waits in the chain's global scratch EngineDev::xscr).  Operation for operation
-// step_body<false, true, true> (the lane-per-chain form with the tables through the scalar cache), whose chains these are.
-// W2 (without delayed rejection): 256 registers, so that two waves share a SIMD (the LDS vector lets six waves on a CU at npar 50: two
-// SIMDs
-// with two).  The compiler spills ~40 doubles of state around the products to fit, and with more tiles than SIMDs it is still faster (round
-// 4;
-// round 2's attempt predates the single-pass LDS layout): 97.1 -> 93.2 ms per 100 iterations of 1 048 576 chains at npar 50.  With one tile
-// per SIMD or fewer there is nobody to share with and the spills are all it buys (npar 20, 65536 chains: 2.1e9 against 2.6e9 proposals/s):
-// the host takes the 512-register instance there.
+// DR: delayed rejection's second stage on the same cores (drscale > 0): the stage-2 proposal with the shared R2 = R / drscale (g_R2T, dense
+// like g_RT), the target once more, and the two quadratic forms dx' iC dx of MCMC_DR_alpha13 as y = iC dx products against the dense
+// symmetric table g_iCd, each followed by the chain q = sum_i y_i dx_i ascending in i (lane = chain: y comes back through the LDS vector,
+// dx waits in the chain's global scratch EngineDev::xscr).  Operation for operation step_body<false, true, true> (the lane-per-chain form
+// with the tables through the scalar cache), whose chains these are. W2 (without delayed rejection): 256 registers, so that two waves share
+// a SIMD (the LDS vector lets six waves on a CU at npar 50: two SIMDs with two).  The compiler spills ~40 doubles of state around the
+// products to fit, and with more tiles than SIMDs it is still faster (round 4; round 2's attempt predates the single-pass LDS layout): 97.1
+// -> 93.2 ms per 100 iterations of 1 048 576 chains at npar 50.  With one tile per SIMD or fewer there is nobody to share with and the
+// spills are all it buys (npar 20, 65536 chains: 2.1e9 against 2.6e9 proposals/s): the host takes the 512-register instance there.
 template <bool DR, bool W2 = false>
 __global__ __launch_bounds__(64, (!DR && W2) ? 2 : 1) void pooled_mfma_kernel(EngineDev E, int it0, int it1,
                                                          const double *__restrict__ g_mu, const double *__restrict__ g_lamT,

@@ -1,6 +1,5 @@
 // mcx_scam.hpp -- MCMC_run_scam (MCMC_run_scam.F90:38-138): per-chain rotations (scam_kernel, scam_mw_kernel) and the pooled rotation on
-// the
-// f64 matrix cores (scam_pooled_kernel, scam_pooled12_kernel); the lane state the phase kernels share (LaneState)
+// the f64 matrix cores (scam_pooled_kernel, scam_pooled12_kernel); the lane state the phase kernels share (LaneState)
 // (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled, mcx_phase,
 // mcx_adapt, mcx_svd, mcx_moments)
 #pragma once
@@ -320,8 +319,7 @@ MCX_DEV void mfma_slots(const double *__restrict__ M, const double *X, int lane,
 // SC: the scalar wave (the last one).  A template parameter, so that the other fifteen waves carry
 template <bool BW, int NS, bool SC, bool XS = false>
                                       // neither the generator nor the per-chain state: at 128 registers a wave they spilled around their
-                                      // MFMAs
-                                      // XS (scam_pooled12_kernel): a block wave with a FIFTH slot, chain group xgrp of block xblk
+                                      // MFMAs XS (scam_pooled12_kernel): a block wave with a FIFTH slot, chain group xgrp of block xblk
 MCX_DEV void scam_pooled_body(const EngineDev &E, int it0, int it1, double *X, int lane, int w, int nw, int blk0, int grp,
                               const double *__restrict__ g_mu, const double *__restrict__ g_lamT,
                               const double *__restrict__ g_U, const double *__restrict__ g_UT, const double *__restrict__ g_std,

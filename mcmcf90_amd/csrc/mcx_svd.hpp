@@ -1,7 +1,6 @@
 // mcx_svd.hpp -- the adaptation's SVD at large npar: blocked one-sided Jacobi (the pinned routine, oracle/mcx_svd.h), one workgroup per
-// chain
-// (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled, mcx_phase,
-// mcx_adapt, mcx_svd, mcx_moments)
+// chain (one of the family headers mcx_kernels.hpp includes, in this order: mcx_common, mcx_products, mcx_step, mcx_scam, mcx_pooled,
+// mcx_phase, mcx_adapt, mcx_svd, mcx_moments)
 #pragma once
 #include "mcx_adapt.hpp"
 
@@ -232,9 +231,8 @@ __global__ __launch_bounds__(256, MCX_SVDS_WAVES) void svd_sweep_stream32_kernel
         for (int t = 0; t < nsteps; ++t) {
             {
                 // ring slot (t + 1) mod RB changes hands: stream column t - wI (its last pair was in the previous step) leaves it for
-                // global
-                // memory and column t + 1 (loaded in the previous step) enters -- element by element in the same thread, so RB = wI + 1
-                // will do
+                // global memory and column t + 1 (loaded in the previous step) enters -- element by element in the same thread, so RB = wI
+                // + 1 will do
                 const int cs = t - wI, cw = t + 1, cg = t + 2;
                 if (ld && cs >= wI - 1 && cs < nJ) G[(size_t)(I0 + 1 + cs) * d + tid] = GY[(size_t)(cs % RB) * LS + tid];
                 if (ld && cw >= 2 && cw < nJ) GY[(size_t)(cw % RB) * LS + tid] = stg;
@@ -373,8 +371,7 @@ __global__ __launch_bounds__(64) void svd_applyv_stream32_kernel(double *Vc, con
 }
 
 // singular values = column norms of G (the routine's eight partial chains over the rows), sorted descending (first maximum wins), V's
-// columns
-// with them; the sorted vectors are left in G's place
+// columns with them; the sorted vectors are left in G's place
 __global__ __launch_bounds__(256) void svd_finish_kernel(double *Gc, const double *Vc, double *svc, const uint8_t *state, int nlanes, int d)
 {
     __shared__ int s_perm[256];

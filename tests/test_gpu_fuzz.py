@@ -542,7 +542,8 @@ def test_random_configuration_response_columns_device_target(oracle, seed):
     prob = oracle.Problem(**pkw)
     e = engine_from_problem(ckw, pkw, nchains=67, record_chain=1, chain_id0=2 * seed)
     e.init(); e.run()
-    assert e.last_kernel() in ("step_kernel_cols", "step_kernel_cols<scam>"), e.last_kernel()      # one launch per segment (round 5), not phase kernels
+    # one launch per segment (round 5), not phase kernels; one instantiation per method class (round 6)
+    assert e.last_kernel() == ("step_kernel_cols<scam>" if cfg.doscam else "step_kernel_cols<ram>" if cfg.method == 1 else "step_kernel_cols"), e.last_kernel()
     for c in (0, 1, 66):
         o = oracle.run_chain(cfg, prob, chain_id=2 * seed + c, continue_on_downdate_fail=True)
         ch, ss, s2 = e.chain(c)

@@ -207,7 +207,7 @@ def test_two_response_columns_on_the_device_in_one_launch(oracle, name, form, mo
     e = engine_from_problem(ckw, pkw, nchains=130, chain_id0=cid - 1, record_chain=1, record_accept=1)
     e.init(); e.run(57); e.run()                                      # a launch boundary off the adaptation ticks
     if form == "one_launch":
-        assert e.last_kernel() == ("step_kernel_cols<scam>" if cfg.doscam else "step_kernel_cols"), e.last_kernel()
+        assert e.last_kernel() == ("step_kernel_cols<scam>" if cfg.doscam else "step_kernel_cols<ram>" if cfg.method == 1 else "step_kernel_cols"), e.last_kernel()
     else:
         assert e.last_kernel() == ""                                   # no sampling-kernel table entry: the iteration is cut into phase launches
     np.testing.assert_array_equal(e.accepted(1), accepted_from_runlen(z["runlen"]))
@@ -263,7 +263,7 @@ def test_twelve_response_columns(oracle, target, method, extra):
         e.set_target_host(ssfun, lambda th: L.mcxo_priorfun(C.byref(tgt), th.ctypes.data_as(dp)), lambda th: bool(L.mcxo_checkbounds(C.byref(tgt), th.ctypes.data_as(dp))))
     e.init(); e.run()
     if target == "device":
-        assert e.last_kernel() == "step_kernel_cols", e.last_kernel()
+        assert e.last_kernel() == ("step_kernel_cols<ram>" if method == "ram" else "step_kernel_cols"), e.last_kernel()
     for c in (0, 66):
         o = oracle.run_chain(cfg, prob, chain_id=3 + c, continue_on_downdate_fail=True)
         ch, ss, s2 = e.chain(c)

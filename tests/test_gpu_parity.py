@@ -262,7 +262,10 @@ def test_extreme_dimensions(oracle, method, d, extra, monkeypatch):
 
 
 @pytest.mark.parametrize("method,d,extra", [("dram", 300, {}), ("ram", 300, {}), ("dram", 330, {"drscale": 2.0}), ("ram", 330, {}),
-                                            # (one lane per chain through a 257 x 257 Jacobi SVD: minutes -- run with MCMCX_EXTENDED=1)
+                                            # one step past the blocked SVD's last instantiation (npar 256): the lane-per-chain SVD, in the DEFAULT suite
+                                            # -- initcmatn = npar gives the one adaptation a full-rank covariance, which the Jacobi finishes in a few sweeps
+                                            ("dram", 257, {"condmax": 1e8, "initcmatn": 257}),
+                                            # (... and with the rank-deficient covariance of 20 rows, the routine at its 60-sweep cap: minutes -- MCMCX_EXTENDED=1)
                                             pytest.param("dram", 257, {"condmax": 1e8}, marks=pytest.mark.extended), pytest.param("scam", 257, {}, marks=pytest.mark.extended)])
 def test_npar_above_256(oracle, method, d, extra):
     """The reference allocates whatever npar the namelist says (MCMC_init.F90:81-102); up to round 4 the engine stopped at 256.  Above it the
@@ -276,6 +279,8 @@ def test_npar_above_256(oracle, method, d, extra):
     A = rng.standard_normal((d, d)) / np.sqrt(d)
     lam = A @ A.T + np.eye(d)
     nsimu, adaptint = (12, 5) if method == "scam" else (45, 20)
+    if extra.get("initcmatn"):                          # the default-suite lane-SVD case: one adaptation (a 257 x 257 Jacobi SVD on one lane is ~20 s)
+        nsimu = 25
     ckw = dict(nsimu=nsimu, adaptint=adaptint, updatesigma=0, method=method, **extra)
     pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.05), cmat0=(0.3 / d) * np.eye(d), mu=np.zeros(d), lam=lam)
     e = engine_from_problem(ckw, pkw, nchains=70, record_accept=1)

@@ -13,3 +13,5 @@ print({k: (round(v["value"] / 1e6, 1), v["kernel"]) for k, v in j["other_configs
 print(json.dumps(j["cpu_baseline"])[:700])
 PY
 python -c "import __graft_entry__ as g; g.smoke()"
+# the `extended` set (non-production duplicates and the slow lane-SVD cases above npar 256: ADVICE round 5 -- a release always has them)
+MCMCX_EXTENDED=1 timeout -k 10 700 python -m pytest tests -m "gpu and extended" -x -q > gpurun_out/gpu_extended.log 2>&1; echo extended rc $?; tail -3 gpurun_out/gpu_extended.log

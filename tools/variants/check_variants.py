@@ -20,7 +20,7 @@ def _bits(a):
 
 def run(ckw, pkw, n, env, want, **ekw):
     from mcmcf90_amd import engine_from_problem
-    for k in ("MCMCX_POOLED_WAVES", "MCMCX_DR_GENERAL", "MCMCX_SVD_SHARED_ROT", "MCMCX_GROUP", "MCMCX_DR_BIG"):
+    for k in ("MCMCX_POOLED_WAVES", "MCMCX_DR_GENERAL", "MCMCX_SVD_SHARED_ROT", "MCMCX_GROUP", "MCMCX_DR_BIG", "MCMCX_COV_FIFO"):
         os.environ.pop(k, None)
     os.environ.update(env)
     e = engine_from_problem(ckw, pkw, nchains=n, record_accept=1, **ekw)
@@ -62,6 +62,12 @@ def main():
         pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.05), cmat0=(0.3 / d) * np.eye(d), mu=np.zeros(d), lam=A @ A.T + np.diag(10.0 ** np.linspace(-1, 2, d)))
         base = run(ckw, pkw, 70, {}, None)
         ok &= same(run(ckw, pkw, 70, {"MCMCX_SVD_SHARED_ROT": "1"}, None), base, "svd_sweep_stream32s_kernel npar %d" % d)
+    for d, dr in ((10, 0.0), (23, 2.0), (50, 0.0)):             # the covariance update's folds behind a per-lane FIFO (round 6)
+        A = rng.standard_normal((d, d)) / np.sqrt(d)
+        ckw = dict(nsimu=330, adaptint=100, updatesigma=0, drscale=dr)
+        pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.05), cmat0=(0.5 / d) * np.eye(d), mu=np.linspace(-1, 1, d), lam=A @ A.T + np.eye(d))
+        base = run(ckw, pkw, 200, {}, None)
+        ok &= same(run(ckw, pkw, 200, {"MCMCX_COV_FIFO": "1"}, None), base, "adapt_cov_{diag,off}_fifo_kernel npar %d" % d)
     print("all bit-equal" if ok else "DIFFERENCES FOUND")
     sys.exit(0 if ok else 1)
 
