@@ -234,6 +234,43 @@ def test_pooled_scam_matches_restatement(oracle, kind):
     e.close()
 
 
+@pytest.mark.parametrize("seed", range(18))
+def test_pooled_scam_twelve_wave_layout_equals_the_sixteen_wave_layout(seed, monkeypatch):
+    """scam_pooled12_kernel (npar 193..240: twelve block waves of 170 registers, a fifth slot on some of them -- the kernel behind bench.py's
+    c5_pooled) against scam_pooled_kernel's sixteen-wave layout of the same configuration (MCMCX_SCAM_POOLED_16=1), which the restatement
+    tests tie to the oracle: random npar over the whole range (every count of fifth slots, ragged last blocks), ragged tiles, bounds,
+    priors, the sigma2 update, one pooled adaptation -- states, accept ballots, stream positions, the shared rotation, bit for bit.
+    (Weak 4: the suite gave this kernel four runs.)"""
+    from mcmcf90_amd import engine_from_problem
+    r = np.random.default_rng(9100 + seed)
+    d = int(r.integers(193, 241))
+    N = int(r.choice([64, 70, 130]))
+    A = r.standard_normal((d, d)) / np.sqrt(d)
+    ckw = dict(nsimu=5, adaptint=3, updatesigma=int(r.integers(0, 2)), method="scam")
+    pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.1), cmat0=0.01 * np.eye(d), mu=np.linspace(-0.5, 0.5, d), lam=A @ A.T + np.diag(np.linspace(0.5, 3.0, d)))
+    if ckw["updatesigma"]:
+        pkw.update(sigma2=0.7, nobs=30)
+    if r.random() < 0.4:
+        pkw.update(lo=np.full(d, -0.2), hi=np.full(d, 0.45))
+    if r.random() < 0.4:
+        pkw.update(pri_mu=np.zeros(d), pri_sig=np.where(np.arange(d) % 3 == 0, 0.0, 0.5))
+    res = []
+    for sixteen in (False, True):
+        if sixteen:
+            monkeypatch.setenv("MCMCX_SCAM_POOLED_16", "1")
+        else:
+            monkeypatch.delenv("MCMCX_SCAM_POOLED_16", raising=False)
+        e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
+        e.init(); e.run()
+        assert e.last_kernel() == ("scam_pooled_kernel" if sixteen else "scam_pooled12_kernel"), e.last_kernel()
+        res.append((e.theta().copy(), e.accept_masks().copy(), [e.rng(c) for c in (0, N - 1)], e.pooled()[3].copy(), e.scalars().copy()))
+        e.close()
+    a, b = res
+    assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    np.testing.assert_array_equal(_bits(a[3]), _bits(b[3]))
+    np.testing.assert_array_equal(_bits(a[4]), _bits(b[4]))
+
+
 @pytest.mark.slow
 @pytest.mark.parametrize("d,extras", [(40, "s2"), (64, ""), (70, "bounds"), (100, "priors"), (130, ""), (200, "bounds"), pytest.param(215, "", marks=pytest.mark.extended),
                                       (230, "priors"), pytest.param(200, "sixteen", marks=pytest.mark.extended), (250, "replicated")])

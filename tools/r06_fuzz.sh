@@ -1,0 +1,15 @@
+#!/bin/bash
+# tools/r06_fuzz.sh PART -- on the GPU box: the one-off fuzz harnesses on the round's final build, seeds no earlier round used (profiles/r06_g/README.md)
+cd "$(dirname "$0")/.." || exit 1
+O=gpurun_out/r06g; mkdir -p $O
+case "$1" in
+  a) BIGFUZZ_SECONDS=560 python tools/bigfuzz.py 700000 900000 2>&1 | tee $O/bigfuzz_auto.txt | grep -E "^seed .*00 |configs|time limit|^\(" ;
+     MCMCX_GROUP=0 BIGFUZZ_SECONDS=420 python tools/bigfuzz.py 900000 990000 2>&1 | tee $O/bigfuzz_lane.txt | grep -E "^seed .*00 |configs|time limit|^\(" ;;
+  b) POOLED_FUZZ_SECONDS=280 python tools/pooled_restate_fuzz.py 700000 720000 2>&1 | tee $O/pooled_restate_fuzz.txt | tail -n 3
+     POOLED_FUZZ_SECONDS=200 python tools/pooled_restate_fuzz.py 720000 740000 ram 2>&1 | tee $O/pooled_ram_restate_fuzz.txt | tail -n 3
+     POOLED_FUZZ_SECONDS=200 python tools/pooled_restate_fuzz.py 740000 760000 scam 2>&1 | tee $O/pooled_scam_restate_fuzz.txt | tail -n 3
+     MCMCX_POOLED_WAVES=2 POOLED_FUZZ_SECONDS=200 python tools/pooled_restate_fuzz.py 760000 780000 2>&1 | tee $O/pooled_restate_fuzz_w2.txt | tail -n 3 ;;
+  c) HOST_FUZZ_SECONDS=240 python tools/host_fuzz.py 700000 720000 2>&1 | tee $O/host_fuzz_fused.txt | tail -n 3
+     BIGNPAR_SECONDS=330 python tools/bignpar_fuzz.py 700000 720000 2>&1 | tee $O/bignpar_fuzz.txt | tail -n 3
+     BIGNPAR_SECONDS=300 python tools/bignpar_fuzz.py 720000 740000 scam 2>&1 | tee $O/scam_npar_fuzz.txt | tail -n 3 ;;
+esac
