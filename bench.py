@@ -290,6 +290,10 @@ def device_ident(L, dev):
     except Exception as ex:
         out["error"] = str(ex)[:120]
     try:
+        # (under rocprofv3 the profiler's preloaded library has initialised the GPU in every child too, and rocm-smi is a `#!/usr/bin/env python3`
+        #  script: an exec after GPU initialisation, which the GPU boxes refuse -- skip it there)
+        if "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD") or os.environ.get("ROCPROF_OUTPUT_PATH"):
+            raise RuntimeError("profiler run: rocm-smi skipped")
         p = subprocess.run(["/opt/rocm/bin/rocm-smi", "-d", str(dev), "--showclocks", "--showmaxpower", "--showserial", "--json"],
                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=20)
         j = json.loads(p.stdout.decode())
