@@ -134,7 +134,11 @@ int mcmcx_init(mcmcx_handle h);
  * is left waiting in a collective: that tick's adaptation IS applied before the ranks return, so mcmcx_clear_interrupt +
  * mcmcx_run resumes into the trajectory of an uninterrupted run.  Where no tick lies ahead of the call's `upto`
  * (doadapt = 0, past adaptend, the tail of a run) nothing collective remains and the rank that caught the signal returns
- * at its next launch boundary by itself.  A rank that fails marks the communicator and its peers' waits give up (< 0). */
+ * at its next launch boundary by itself.  A rank that fails marks the communicator and its peers' waits give up (< 0).
+ * A run that failed inside a host-callback iteration (a HIP error around the user's ssfunction / priorfun / checkbounds) leaves
+ * the handle unusable: with the phases fused, the next iteration's proposal -- its random draws included -- has already run, and a
+ * second mcmcx_run would draw it again and leave the reference's stream order.  Later calls return -42; destroy the handle.
+ * (mcmcx_create refuses npar > 4096 with -5: the packed triangle's int-typed indices, 64 npar (npar + 1) / 2 < 2**31.) */
 int mcmcx_run(mcmcx_handle h, int32_t upto);
 int mcmcx_sync(mcmcx_handle h);
 

@@ -38,6 +38,26 @@ def test_no_gpu_means_loud_failure_not_fallback():
     assert rc < 0 and b"no HIP device" in L.mcmcx_last_error()
 
 
+def test_npar_cap_is_checked_before_anything_is_sized():
+    """npar <= 4096 (at the old cap of 8192, 64 P = 2.147e9 exceeded INT_MAX and only the size_t casts of the use sites kept the
+    packed indices correct).  One past the cap is refused with the cap in the message -- before any device is looked for, so the check runs
+    here without a GPU; AT the cap the configuration passes that check (and then fails for want of a device, or is created on a GPU box:
+    the P-sized arrays are allocated at mcmcx_init, not here).  64 P and (2 npar + P) 64 at the cap stay below 2**31."""
+    import ctypes as C
+    from mcmcf90_amd import _lib, make_config
+    L = _lib.load()
+    h = C.c_void_p()
+    rc = L.mcmcx_create(C.byref(make_config(4097, 1, nsimu=10)), C.byref(h))
+    assert rc == -5 and b"1..4096" in L.mcmcx_last_error(), (rc, L.mcmcx_last_error())
+    rc = L.mcmcx_create(C.byref(make_config(4096, 1, nsimu=10)), C.byref(h))
+    if rc == 0:
+        L.mcmcx_destroy(h)
+    else:
+        assert rc == -10 and b"no HIP device" in L.mcmcx_last_error(), (rc, L.mcmcx_last_error())
+    P = 4096 * 4097 // 2
+    assert 64 * P < 2 ** 31 and (2 * 4096 + P) * 64 < 2 ** 31
+
+
 def test_header_is_plain_c_and_the_c_example_links():
     """include/mcmcx.h must be usable from C (the reference's host language side binds a C ABI): compile the example
     driver as pedantic C99 against it and link it with libmcmcx.so."""

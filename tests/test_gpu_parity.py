@@ -308,6 +308,32 @@ def test_npar_above_256(oracle, method, d, extra):
     e.close()
 
 
+@pytest.mark.parametrize("d", [315, 316])
+def test_pooled_moments_at_the_lds_switch(oracle, d):
+    """moments_kernel keeps a tile's 64 state vectors in LDS while (64 (npar | 1) + 320) doubles fit 160 KiB -- up to npar 315 -- and forms every
+    value from global memory from 316 on (moments_kernel<true>; ADVICE round 5: the comments said 317 / 318).  Both sides of the switch: the
+    pooled moment vector of 70 chains after a few Metropolis iterations against numpy, and chain 0 / 69 against the oracle."""
+    from mcmcf90_amd import engine_from_problem
+    from mcmcf90_amd import dist as mdist
+    assert (64 * (315 | 1) + 320) * 8 <= 160 * 1024 < (64 * (316 | 1) + 320) * 8
+    rng = np.random.default_rng(d)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    ckw = dict(nsimu=8, doadapt=0, updatesigma=0)
+    pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.05), cmat0=(0.3 / d) * np.eye(d), mu=np.zeros(d), lam=A @ A.T + np.eye(d))
+    e = engine_from_problem(ckw, pkw, nchains=70, record_accept=1)
+    e.init(); e.run()
+    th = e.theta()
+    mean, cov = mdist.finalize_moments(e.pooled_moments(), d, np.asarray(pkw["par0"]))
+    np.testing.assert_allclose(mean, th.mean(axis=0), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(cov, np.cov(th.T), rtol=1e-8, atol=1e-12)
+    cfg = oracle.make_cfg(**ckw); prob = oracle.Problem(**pkw)
+    for c in (0, 69):
+        o = oracle.run_chain(cfg, prob, chain_id=c)
+        np.testing.assert_array_equal(e.accepted(c), o.accepted)
+        np.testing.assert_array_equal(_bits(th[c]), _bits(o.theta))
+    e.close()
+
+
 @pytest.mark.parametrize("d", [7, 20, 23, 37, 64])
 def test_delayed_rejection_vectors_in_lds_or_global(oracle, d, monkeypatch):
     """step_kernel_dr (second-stage vectors in LDS: the engine's choice up to npar 20) and step_kernel_dr_big (in global scratch:
