@@ -5,6 +5,8 @@
 // and decodes the device history back into the reference's chain/sschain/s2chain
 // form.  No CPU fallback: every numerical step of the sampler runs in the HIP kernels
 // of mcx_kernels.hpp; without a GPU every entry point that needs one fails.
+// ONE translation unit: the host parts below are included in order (engine object, initial factor, kernel selection and
+// launchers, adaptation tick, pooled mode and communicator, host callbacks); this file holds the extern "C" entry points.
 #include <hip/hip_runtime.h>
 #include <csignal>
 #include <cmath>
@@ -20,1444 +22,12 @@
 #include "mcx_group.hpp"
 #include "mcx_group_ram.hpp"
 
-using namespace mcx;
-static_assert(MCMCX_HE_INB == HE_INB && MCMCX_HE_PRI == HE_PRI && MCMCX_HE_SS == HE_SS && MCMCX_HX_STAGE2 == HX_STAGE2
-    && MCMCX_HX_CRIT == HX_CRIT,
-              "include/mcmcx_target.h and mcx_kernels.hpp disagree about the phase-state slots");
-
-static thread_local std::string g_err;
-static int fail(int code, const std::string &msg) { g_err = msg; return code; }
-
-#define HIPCHK(call)                                                                              \
-    do {                                                                                          \
-        hipError_t e_ = (call);                                                                   \
-        if (e_ != hipSuccess)                                                                     \
-            return fail(-100, std::string(#call) + ": " + hipGetErrorString(e_));                 \
-    } while (0)
-
-// The test switches (tests, tools): each FORCES one of two kernel forms that the engine also chooses by itself for some configuration -- so
-// that the parity tests can run both forms on the same small problem.  None selects a form the engine would never take (those live in
-// tools/variants, outside this library).  Read from the environment ONCE per engine, at mcmcx_create and again at mcmcx_init -- never at
-// launch time.  -1 = not set.
-struct mcx_switches {
-    int pooled_mfma_dr_min = -1, pooled_scalar = -1, dr_big = -1, scam_pooled_16 = -1, scam_fast_lanes = -1, scam_waves = -1,
-        svd_lane = -1, cov_batch_rows = -1, ram_wide = -1, pooled_waves = -1, cols_phased = -1, host_mapped = -1, host_fuse = -1;
-    static int get(const char *name) { const char *e = getenv(name); return e ? atoi(e) : -1; }
-    void read()
-    {
-        pooled_mfma_dr_min = get("MCMCX_POOLED_MFMA_DR_MIN"); pooled_scalar = get("MCMCX_POOLED_SCALAR"); dr_big = get("MCMCX_DR_BIG");
-        scam_pooled_16 = get("MCMCX_SCAM_POOLED_16"); scam_fast_lanes = get("MCMCX_SCAM_FAST_LANES");
-        scam_waves = get("MCMCX_SCAM_WAVES"); svd_lane = get("MCMCX_SVD_LANE"); cov_batch_rows = get("MCMCX_COV_BATCH_ROWS");
-        ram_wide = get("MCMCX_RAM_WIDE"); pooled_waves = get("MCMCX_POOLED_WAVES");
-        cols_phased = get("MCMCX_COLS_PHASED"); host_mapped = get("MCMCX_HOST_MAPPED"); host_fuse = get("MCMCX_HOST_FUSE");
-    }
-};
-struct mcmcx_engine {
-    mcmcx_config cfg;
-    mcx_switches sw;
-    int d = 0, P = 0, ntiles = 0, nlanes = 0;
-    int dodr = 0, usesvd = 0;
-    bool inited = false;
-    int simuind = 0;
-    const char *last_kernel = "";       // name of the sampling kernel launch_step / launch_scam chose last (mcmcx_last_kernel)
-    std::string launch_err;             // set by a launcher that found no kernel for the configuration: the run fails with it
-    // host copies of the problem
-    std::vector<double> par0, cmat0;                 // cmat0 col-major d*d
-    double sigma2 = 1.0; int nobs = 1; bool sigma2ok = false;
-    int ny = 1; std::vector<double> sigma2v; std::vector<int> nobsv;      // nycol columns (host callbacks only when > 1)
-    int tkind = -1, tncols = 1; std::vector<double> tmu, tlam, tx, ty, tlo, thi, tpmu, tpsig; double tb = 0.1;
-    bool has_lo = false, has_hi = false, has_pri = false;
-    mcmcx_ssfun_t h_ss = nullptr; mcmcx_ssfun_er_t h_ss_er = nullptr; mcmcx_priorfun_t h_pri = nullptr; mcmcx_checkbounds_t h_cb = nullptr;
-        void *h_user = nullptr;
-    mcmcx_ssfun_batch_t h_ss_batch = nullptr; int h_threads = 1;      // batched form of the user's ssfunction (opt-in)
-    int mod_max_ny = 8;
-    hipModule_t mod = nullptr; hipFunction_t mod_fn = nullptr; void *d_moddata = nullptr;   // user target module (include/mcmcx_target.h)
-    std::vector<double> h_bth, h_bss; std::vector<int> h_bidx;
-    // host side of the callback path: page-locked, so that the candidates come back and the results go out as asynchronous copies
-    // on the engine's stream with ONE synchronisation per stage (pageable buffers cost a staged, blocking copy each way)
-    struct Pinned {
-        double *p = nullptr; size_t cap = 0, n = 0;
-        int resize(size_t m) {
-            n = m;
-            if (m <= cap) return 0;
-            if (p) (void)hipHostFree(p);
-            p = nullptr; cap = 0;
-            if (hipHostMalloc((void **)&p, m * sizeof(double), hipHostMallocDefault) != hipSuccess) return -1;
-            cap = m; return 0;
-        }
-        double &operator[](size_t i) { return p[i]; }
-        double *data() { return p; }
-        size_t size() const { return n; }
-        void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = n = 0; }
-    } h_cand, h_ev, h_hx;
-    // pooled mode
-    int pool_status = 0; double pool_alpha = 0.0;       // pooled RAM: skipped ticks, mean acceptance of the last tick
-    int pooled = 0; double pool_W = 0.0; std::vector<double> pool_mean, pool_C, pool_R;   // packed upper, row-major
-    std::vector<double> pool_U, pool_std;             // pooled SCAM: the shared rotation (column-major) and qcovstd
-    // pooled AM with condmax > 0: covtor_svd's full factor U sqrt(s) 2.4/sqrt(d), column-major
-    std::vector<double> pool_Rf;
-    // pooled mode with delayed rejection: R / drscale (packed, or full with condmax > 0) and dpotri(R) (packed)
-    std::vector<double> pool_R2, pool_iC;
-    double *d_sharedR2 = nullptr, *d_sharediC = nullptr;
-    double *d_sharedU = nullptr;                      // [U col-major | pad | U row-major | pad | std]
-    // host callbacks: the next iteration's proposal already ran in the previous iteration's last launch
-    bool p0_done = false;
-    // a host-callback iteration failed half way: the chains' stream positions are undefined, later runs are refused
-    bool failed = false;
-    // host callbacks with few chains: the exchange vectors live in page-locked host memory the device reads and writes directly (no copies
-    // between the phases)
-    bool host_mapped = false, cs_mapped = false;
-    std::vector<void *> hallocs;
-    // pooled SCAM above npar 240 (the tile kernels' LDS vector does not fit): the shared rotation copied to every chain, the per-chain
-    // kernels run
-    bool scam_replicated = false;
-    // pooled AM on the matrix cores: dense R, M[s*d + o] = R(s,o), zero below the diagonal and in the pad rows
-    double *d_sharedRT = nullptr;
-    double *d_sharedR2T = nullptr, *d_sharediCd = nullptr;   // ... with delayed rejection: R2 in the same form, iC dense and symmetric
-    double *d_sharedR = nullptr; mcmcx_exchange_t xfn = nullptr; void *xuser = nullptr; double *xbuf = nullptr;
-    struct mcmcx_comm *comm = nullptr;                // the node's communicator (mcx_comm.hpp); nullptr = this GPU alone
-    // [nranks][len + 1] per-rank moment vectors (+ the rank's stop flag), [len + 1] their tree sum
-    double *d_gather = nullptr, *d_pooled = nullptr;
-    double h_flag = 0.0;                              // this rank's stop flag of the exchange being enqueued (1 = a caught signal)
-    bool run_entered = false;                         // mcmcx_run is past its argument checks (a failure from here on may strand peers)
-    // the summed stop flag of the tick just applied was non-zero: every rank leaves after this tick
-    bool stop_seen = false;
-    double S02eff = 0.0;
-    // device
-    hipStream_t stream = nullptr; bool own_stream = false;
-    EngineDev E{};
-    std::vector<void *> allocs;
-    double *d_ramscale = nullptr, *d_moments = nullptr;
-    // blocked SVD of the adaptation (large npar)
-    double *d_Gc = nullptr, *d_Vc = nullptr, *d_svc = nullptr; uint8_t *d_need = nullptr, *d_state = nullptr; int *d_anyrot = nullptr;
-    int wcap = 0;
-    bool tile_factor = false;           // the adaptation's Cholesky branch through tile_factor_kernel (npar <= 64)
-    // method = 'ram' on group_ram_kernel (mcx_group_ram.hpp): npar rounded up to its instantiation, 0 = not
-    int ram_group_d4 = 0;
-    // lane-group step kernel (mcx_group.hpp): npar rounded up to four when it is the one to launch; accept bytes of a launch
-    int group_d4 = 0, group_drm = 0, group_gw = 16; bool group_check_due = true; int *d_gflag = nullptr; uint8_t *d_accb = nullptr;
-    // MCMC_run1: the caller evaluates; exchange vectors of run1_kernel
-    bool external = false; double *d_r1 = nullptr; std::vector<double> h_r1;
-    // timing of the step kernel
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
-    double ms_total = 0.0; long long launches = 0, steps = 0;
-};
-
-struct DevBufs {                                       // hipFree on every exit path
-    std::vector<void *> p;
-    template <typename T> hipError_t alloc(T **q, size_t bytes) { void *v = nullptr; hipError_t e = hipMalloc(&v, bytes);
-        if (e == hipSuccess) p.push_back(v); *q = (T *)v; return e; }
-    ~DevBufs() { for (void *v : p) (void)hipFree(v); }
-};
-
-template <typename T>
-static int dev_alloc(mcmcx_engine *h, T **p, size_t n, bool zero = true)
-{
-    void *q = nullptr;
-    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
-    hipError_t e = hipMalloc(&q, bytes);
-    if (e != hipSuccess) return fail(-101, "hipMalloc of " + std::to_string(bytes) + " bytes: " + hipGetErrorString(e));
-    if (zero) { e = hipMemsetAsync(q, 0, bytes, h->stream); if (e != hipSuccess) return fail(-101, hipGetErrorString(e)); }
-    h->allocs.push_back(q);
-    *p = (T *)q;
-    return 0;
-}
-
-// page-locked host memory mapped into the device's address space (the same pointer on both sides)
-template <typename T>
-static int host_alloc(mcmcx_engine *h, T **p, size_t n)
-{
-    void *q = nullptr;
-    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
-    hipError_t e = hipHostMalloc(&q, bytes, hipHostMallocMapped | hipHostMallocCoherent);
-    if (e != hipSuccess) return fail(-101, "hipHostMalloc of " + std::to_string(bytes) + " bytes: " + hipGetErrorString(e));
-    memset(q, 0, bytes);
-    h->hallocs.push_back(q);
-    *p = (T *)q;
-    return 0;
-}
-
-template <typename T>
-static int dev_upload(mcmcx_engine *h, const T **p, const std::vector<T> &v)
-{
-    T *q = nullptr;
-    int rc = dev_alloc(h, &q, v.size(), false);
-    if (rc) return rc;
-    if (!v.empty()) {
-        hipError_t e = hipMemcpy(q, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
-        if (e != hipSuccess) return fail(-102, hipGetErrorString(e));
-    }
-    *p = q;
-    return 0;
-}
-
-// No limit on npar like the reference (MCMC_init.F90:81-102 allocates whatever the namelist says) -- beyond int-sized packed indices.  Up
-// to 256 every kernel family applies; above, the forms that keep an npar-vector per lane in LDS give way to global scratch where the 160
-// KiB end (delayed rejection > 160, the adaptation's work vector > 320, the pooled-moment kernel from 316 on), the blocked SVD to the
-// lane-per-chain SVD (> 256), the matrix-core pooled kernels to the lane kernels (their own LDS tests): slower, never refused. response
-// columns (mcmc.F90:30-33: whatever mcmcnycol.dat says): every per-column array is sized at mcmcx_init
-static const int MCX_MAX_NYCOL = 4096;
-// P = npar (npar + 1) / 2 = 8 390 656 at the cap, 64 P = 537 M and (2 npar + P) 64 = 538 M: every int-typed index expression of the device
-// code (pidx, rowstart, e * 64 + lane) stays below 2**31 with a factor of four to spare -- at 8192, the cap up to round 5, 64 P is 2.147e9
-// > INT_MAX and only the size_t casts of every current use site kept it correct.  Larger problems are refused loudly at
-// mcmcx_create.
-static const int MCX_MAX_NPAR = 4096;
-
-// dpotf2('U') + scaling on the host for the shared initial factor: same operation sequence as the
-// device's calculate_R (MCMC_calculate_R at MCMC_init.F90:109).  cm: col-major d*d, Rp: packed upper.
-static inline int h_rowstart(int i, int d) { return i * d - (i * (i - 1)) / 2; }
-static inline int h_pidx(int i, int j, int d) { return h_rowstart(i, d) + (j - i); }
-
-static int host_initial_R(int d, const std::vector<double> &cm, std::vector<double> &Rp, std::vector<double> &Cp)
-{
-    int P = d * (d + 1) / 2;
-    std::vector<double> A(P);
-    for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) A[h_pidx(i, j, d)] = cm[(size_t)i + (size_t)j * d];
-    Cp = A;
-    for (int j = 0; j < d; ++j) {
-        double dot = 0.0;
-        for (int i = 0; i < j; ++i) dot = std::fma(A[h_pidx(i, j, d)], A[h_pidx(i, j, d)], dot);
-        double ajj = A[h_pidx(j, j, d)] - dot;
-        if (!(ajj > 0.0)) return j + 1;
-        double rj = std::sqrt(ajj);
-        A[h_pidx(j, j, d)] = rj;
-        double rinv = 1.0 / rj;
-        for (int k = j + 1; k < d; ++k) {
-            double t = 0.0;
-            for (int i = 0; i < j; ++i) t = std::fma(A[h_pidx(i, k, d)], A[h_pidx(i, j, d)], t);
-            A[h_pidx(j, k, d)] = (A[h_pidx(j, k, d)] - t) * rinv;
-        }
-    }
-    double sq = std::sqrt((double)d);
-    Rp.resize(P);
-    for (int e = 0; e < P; ++e) Rp[e] = A[e] * 2.4 / sq;
-    return 0;
-}
-
-// The pinned dgesvd('A','N') of a symmetric PSD matrix (one-sided Jacobi), same operation sequence as the device's
-// symsvd_dev; used for the shared initial factor.  G, V column-major n*n.
-static inline double h_tree8(const double *p) { return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])); }
-static void host_symsvd(int n, std::vector<double> &G, std::vector<double> &V, std::vector<double> &sv)
-{
-    V.assign((size_t)n * n, 0.0); sv.assign(n, 0.0);
-    for (int j = 0; j < n; ++j) V[(size_t)j * n + j] = 1.0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        bool rotated = false;
-        for (int p = 0; p < n - 1; ++p)
-            for (int q = p + 1; q < n; ++q) {
-                double *gp = &G[(size_t)p * n], *gq = &G[(size_t)q * n];
-                // the routine's dot products: eight partial fma chains by row index mod 8, added pairwise (oracle/mcx_svd.h)
-                double pa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int k = 0; k < n; ++k) { const int j = k & 7; pa[j] = std::fma(gp[k], gp[k], pa[j]); pb[j] = std::fma(gq[k], gq[k],
-                    pb[j]); pg[j] = std::fma(gp[k], gq[k], pg[j]); }
-                const double alpha = h_tree8(pa), beta = h_tree8(pb), gamma = h_tree8(pg);
-                if (gamma == 0.0) continue;
-                if (std::fabs(gamma) <= 1e-15 * std::sqrt(alpha * beta)) continue;
-                rotated = true;
-                double zeta = (beta - alpha) / (2.0 * gamma);
-                double t = std::copysign(1.0, zeta) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
-                double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
-                for (int k = 0; k < n; ++k) { double a = gp[k], b = gq[k]; gp[k] = c * a - sn * b; gq[k] = sn * a + c * b; }
-                double *vp = &V[(size_t)p * n], *vq = &V[(size_t)q * n];
-                for (int k = 0; k < n; ++k) { double a = vp[k], b = vq[k]; vp[k] = c * a - sn * b; vq[k] = sn * a + c * b; }
-            }
-        if (!rotated) break;
-    }
-    for (int j = 0; j < n; ++j) {
-        double pa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int k = 0; k < n; ++k) pa[k & 7] = std::fma(G[(size_t)j * n + k], G[(size_t)j * n + k], pa[k & 7]);
-        sv[j] = std::sqrt(h_tree8(pa));
-    }
-    for (int i = 0; i < n - 1; ++i) {
-        int m = i;
-        for (int j = i + 1; j < n; ++j) if (sv[j] > sv[m]) m = j;
-        if (m != i) { std::swap(sv[i], sv[m]); for (int k = 0; k < n; ++k) std::swap(V[(size_t)i * n + k], V[(size_t)m * n + k]); }
-    }
-}
-
-// MCMC_calculate_R, SVD branches, for the shared initial covariance (MCMC_init.F90:109): returns 0 or an error code.
-// Rfull: column-major d*d factor (U for scam, U sqrt(s) 2.4/sqrt(d) otherwise); std: sqrt(s) (scam)
-static int host_initial_svd(int d, const std::vector<double> &cm, double condmax, bool scam,
-                            std::vector<double> &Rfull, std::vector<double> &std, std::vector<double> *floored_cm = nullptr,
-                                bool scaled = true)
-{
-    std::vector<double> G((size_t)d * d), V, sv;
-    for (int j = 0; j < d; ++j) for (int i = 0; i < d;
-        ++i) G[(size_t)j * d + i] = (i <= j) ? cm[(size_t)i + (size_t)j * d] : cm[(size_t)j + (size_t)i * d];
-    host_symsvd(d, G, V, sv);
-    if (sv[0] == 0.0) return d;
-    const double tol = sv[0] / condmax;
-    bool floored = false;
-    if (sv[d - 1] <= tol) { floored = true; for (int i = 0; i < d; ++i) if (sv[i] < tol) sv[i] = tol; }
-    Rfull.resize((size_t)d * d); std.assign(d, 0.0);
-    if (scam) {
-        Rfull = V;
-        for (int i = 0; i < d; ++i) std[i] = std::sqrt(sv[i]);
-    } else {
-        const double sqd = std::sqrt((double)d);
-        // R0 = U diag(sqrt(s))
-        for (int i = 0; i < d; ++i) { double sq = std::sqrt(sv[i]); for (int k = 0; k < d;
-            ++k) V[(size_t)i * d + k] = sq * V[(size_t)i * d + k]; }
-        if (floored && floored_cm) {                    // covtor_svd info = -1: cmat = matmul(R0, transpose(R0)), matutils.F90:441-446
-            floored_cm->assign((size_t)d * d, 0.0);
-            for (int j = 0; j < d; ++j)
-                for (int i = 0; i <= j; ++i) {
-                    double acc = 0.0;
-                    for (int k = 0; k < d; ++k) acc = std::fma(V[(size_t)k * d + i], V[(size_t)k * d + j], acc);
-                    (*floored_cm)[(size_t)i + (size_t)j * d] = acc;
-                }
-        }
-        for (size_t e = 0; e < (size_t)d * d; ++e) Rfull[e] = scaled ? V[e] * 2.4 / sqd : V[e];
-    }
-    return 0;
-}
-
-// dpotri('U') on the packed factor (dtrti2 + dlauu2), same operation sequence as the device's potri_packed
-static int host_potri(int d, std::vector<double> &A)
-{
-    for (int j = 0; j < d; ++j) if (A[h_pidx(j, j, d)] == 0.0) return j + 1;
-    std::vector<double> x(d);
-    for (int j = 0; j < d; ++j) {
-        double ajj = 1.0 / A[h_pidx(j, j, d)];
-        A[h_pidx(j, j, d)] = ajj; ajj = -ajj;
-        for (int i = 0; i < j; ++i) x[i] = A[h_pidx(i, j, d)];
-        for (int jj = 0; jj < j; ++jj) {
-            double temp = x[jj];
-            if (temp != 0.0) {
-                for (int i = 0; i < jj; ++i) x[i] = std::fma(temp, A[h_pidx(i, jj, d)], x[i]);
-                x[jj] = temp * A[h_pidx(jj, jj, d)];
-            }
-        }
-        for (int i = 0; i < j; ++i) A[h_pidx(i, j, d)] = ajj * x[i];
-    }
-    for (int i = 0; i < d; ++i) {
-        double aii = A[h_pidx(i, i, d)];
-        if (i < d - 1) {
-            double dot = 0.0;
-            for (int k = i; k < d; ++k) dot = std::fma(A[h_pidx(i, k, d)], A[h_pidx(i, k, d)], dot);
-            A[h_pidx(i, i, d)] = dot;
-            for (int r = 0; r < i; ++r) x[r] = aii * A[h_pidx(r, i, d)];
-            for (int k = i + 1; k < d; ++k) {
-                double temp = A[h_pidx(i, k, d)];
-                if (temp != 0.0) for (int r = 0; r < i; ++r) x[r] = std::fma(temp, A[h_pidx(r, k, d)], x[r]);
-            }
-            for (int r = 0; r < i; ++r) A[h_pidx(r, i, d)] = x[r];
-        } else {
-            for (int r = 0; r <= i; ++r) A[h_pidx(r, i, d)] = aii * A[h_pidx(r, i, d)];
-        }
-    }
-    return 0;
-}
-
-// LDS of pooled_mfma_kernel: the tile's vector [d4][64] (+ the products [16 nt][64] when they need more than one pass)
-// and the partial ss chains [4 nt][64]
-static size_t pooled_mfma_lds(int d)
-{
-    const size_t d4 = (size_t)((d + 3) & ~3), nt = (size_t)((d + 15) / 16);
-    // single pass: products and ss chains reuse the vector's rows
-    const size_t rows = (nt <= 4) ? std::max(d4, 4 * nt) : d4 + 16 * nt + 4 * nt;
-    return rows * 64 * sizeof(double);
-}
-static bool pooled_use_mfma(const mcmcx_engine *h)
-{
-    // (SCAM has its own)
-    if (!h->pooled || (h->cfg.method != MCMCX_METHOD_DRAM && h->cfg.method != MCMCX_METHOD_RAM
-        && h->cfg.method != MCMCX_METHOD_ER)) return false;
-    // DR: with its dense tables, and above
-    if (h->dodr) {
-        // npar 20 (8.3e8 against 8.9e8 iterations/s
-        if (h->cfg.method != MCMCX_METHOD_DRAM || !h->d_sharedR2T) return false;
-        // for the lane kernel with its LDS vectors at 20;
-        int dmin = 21;
-        // 32: 5.6e8 / 2.5e8, 50: 3.2e8 / 0.8e8)
-        if (h->sw.pooled_mfma_dr_min >= 0) dmin = h->sw.pooled_mfma_dr_min;
-        if (h->d < dmin) return false;
-    }
-    if (h->sw.pooled_scalar > 0) return false;                                         // A/B switch for tests: the lane-per-chain kernel
-    return pooled_mfma_lds(h->d) <= 160 * 1024;
-}
-// iteration cut at the evaluations
-static bool phased(const mcmcx_engine *h) { return h->tkind == TGT_HOST || h->tkind == TGT_EXPCOLS || h->tkind == TGT_MODULE; }
-// ... except where the DEVICE evaluates between the phases (the response-column target): the phases fused into one launch per segment
-// (step_kernel_cols); MCMCX_COLS_PHASED=1 keeps the separate launches (A/B, tests)
-static bool fused_cols(const mcmcx_engine *h) { return h->tkind == TGT_EXPCOLS && !(h->sw.cols_phased > 0); }
-static bool phase_cut(const mcmcx_engine *h) { return phased(h) && !fused_cols(h); }
-static size_t lds_bytes(const mcmcx_engine *h) { return (size_t)h->d * 64 * sizeof(double) * 2; }   // adapt / DR work vectors
-static bool dr_fits_lds(const mcmcx_engine *h) { return lds_bytes(h) <= 160 * 1024; }          // npar <= 160
-static size_t lds_step(const mcmcx_engine *h) { return (h->dodr && dr_fits_lds(h)) ? lds_bytes(h) : 0; }
-// step_kernel_dr keeps the second stage's two vectors in LDS, step_kernel_dr_big in global scratch.  LDS pays while eight waves
-// still fit a CU (npar <= 20: 6.9e8 against 6.0e8 iterations/s at 20); beyond, the waves it costs are worth more than the bytes
-// it saves (npar 24: 3.1e8 against 4.1e8, 64: 3.2e7 / 4.6e7, 100: 0.8e7 / 1.7e7 -- tools/dr_sweep.py)
-// (the pooled form, whose factors come through the scalar cache, is bound by that latency rather than by waves: LDS down to four
-//  waves per CU -- npar 32: 2.5e8 against 2.2e8, 50: 7.4e7 / 8.1e7, 100: 0.8e7 / 1.3e7 -- tools/pooled_dr_probe.py)
-static bool dr_vectors_in_lds(const mcmcx_engine *h, int min_waves = 8)
-{
-    if (!dr_fits_lds(h)) return false;
-    if (h->sw.dr_big >= 0) return h->sw.dr_big == 0;                                  // A/B switch for tests: 1 = global scratch, 0 = LDS
-    return lds_bytes(h) * (size_t)min_waves <= 160 * 1024;
-}
-static void launch_init(mcmcx_engine *h)
-{ hipLaunchKernelGGL(init_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E); }
-// ---- which sampling kernel runs: ONE table per launcher, walked in order -- the first entry whose predicate holds is launched and
-// its name noted for mcmcx_last_kernel (bench.py labels its roofline with it).  The tables are exported through
-// mcmcx_debug_kernel_table, so that tests/test_kernel_table.py can list every selectable instance and require a parity test that
-// asserted each of them.  A configuration no entry accepts is an error of the run (launch_err), never a silent no-launch.
-struct KernelEntry {
-    const char *family;                                   // "step" (launch_step), "group" (launch_group), "scam" (launch_scam)
-    const char *name;
-    bool (*when)(const mcmcx_engine *);
-    void (*launch)(mcmcx_engine *, int it0, int it1);
-};
-static void walk_table(mcmcx_engine *h, const KernelEntry *tab, size_t n, int it0, int it1)
-{
-    for (size_t i = 0; i < n; ++i)
-        if (tab[i].when(h)) { h->last_kernel = tab[i].name; tab[i].launch(h, it0, it1); return; }
-    h->launch_err = std::string("no ") + (n ? tab[0].family : "?") + " kernel covers this configuration";
-}
-// ---- the lane-group step kernel (mcx_group.hpp): four chains per wave, factors in registers
-static const int GROUP_MAXSEG = 256;                  // iterations per launch (one accept byte per chain and iteration in d_accb)
-static const int GROUP_MAX_NPAR = 64, GROUP_MAX_NPAR_DR = 32;      // (with delayed rejection three tables must fit a lane's registers)
-// what the kernel covers: MCMC_run with per-chain Cholesky factors (method 'dram', with or without delayed rejection), one of
-// the single-launch device targets, one response column
-static bool group_covers(const mcmcx_engine *h)
-{
-    const mcmcx_config &c = h->cfg;
-    return !h->pooled && (c.method == MCMCX_METHOD_DRAM || (c.method == MCMCX_METHOD_ER && !h->dodr)) && !h->usesvd && !phased(h)
-        && h->ny == 1 &&
-           (h->tkind == TGT_GAUSS || h->tkind == TGT_BANANA || h->tkind == TGT_EXPDATA) && h->d <= (h->dodr ? GROUP_MAX_NPAR_DR
-               : GROUP_MAX_NPAR) &&
-           !(h->tkind == TGT_BANANA && h->d < 2) && !(h->tkind == TGT_EXPDATA && h->d < 2);
-}
-// ... and where it is the faster one (tools/group_sweep.py, profiles/r04_a/group_sweep.txt: proposals/s of both kernel families over npar,
-// target, delayed rejection and chain count).  Up to 16384 chains always: the chip is not full, a chain's iteration is latency, and
-// sixteen lanes per chain with the factors on chip take 2-5 us where a lane takes 7-160 (4x-33x).  With the chip full, from npar 11
-// on: 1.04-1.3x without delayed rejection up to npar 20 and 1.7-3x above, 1.1-3.7x with it; at npar <= 10 the lane kernels, which keep
-// the factor in LDS there, stay ahead (group: 0.35-0.9x).
-// ... and with which group width: four lanes per chain (sixteen chains per wave) for small npar with the chip full, where sixteen lanes
-// would mostly idle (tools/quad_sweep.py, profiles/r04_b/quad_sweep.txt: without delayed rejection 1.3-3.6x the sixteen-lane form at npar
-// <= 16 and 1.1-3.2x the lane kernels up to 131072 chains -- 1.5-1.7x at any count from npar 11 on; with it at npar <= 8)
-static int group_width(const mcmcx_engine *h)
-{
-    if ((long long)h->cfg.nchains <= 16384 || h->d > 16 || h->cfg.updatesigma) return 16;
-    if (!h->dodr) return 4;
-    return h->d <= 8 ? 4 : 16;
-}
-static bool group_wins(const mcmcx_engine *h, int drm, int gw)
-{
-    const long long n = h->cfg.nchains;
-    const int d = h->d;
-    if (h->cfg.updatesigma) {
-        // MCMC_updatesigma2's gamma sampler is a serial, data-dependent sequence of draws per chain: a group wave runs it for four chains,
-        // a lane wave for 64 (tools/group_probe2.py: 2.3-12x up to 1024 chains, 0.9-5x at 16384, 0.45-0.8x beyond without delayed
-        // rejection, 1.3-1.6x with it at npar 20)
-        if (n <= 8192) return true;
-        if (n <= 16384) return d >= 4;
-        return h->dodr && d >= 11;
-    }
-    if (n <= 16384) return true;
-    if (gw == 4) return h->dodr ? (drm == 2 || n <= 131072) : (d >= 11 || n <= 131072);
-    return d >= 11 || (h->dodr && d >= 9 && n <= 131072);
-}
-// one instantiation per (group width, npar rounded up, delayed-rejection form, target kind); DRM 0 = none, 1 = the general form (R, R2, iC
-// in registers), 2 = drscale a power of two (no R2; iC in LDS): the instantiation without R2 runs unless the device flag says that some
-// factor leaves the range in which R'z / drscale is R2'z bit for bit; the general one is queued behind the same flag and returns at once
-// otherwise
-template <int GW, int D4, int DRM, int TK>
-static void launch_group_inst(mcmcx_engine *h, int it0, int it1)
-{
-    const dim3 g(h->ntiles * (GW == 16 ? 16 : 4)), b(64);           // 64 / GW chains per wave
-    const double *lam = h->E.tgt.lamT;
-    if constexpr (DRM != 0 && D4 > GROUP_MAX_NPAR_DR) h->launch_err = "group kernel: no delayed-rejection instantiation above npar " +
-        std::to_string(GROUP_MAX_NPAR_DR);
-    else if constexpr (TK == TGT_EXPDATA && D4 != 4) h->launch_err = "group kernel: the expdata target has two parameters";
-    else if constexpr (DRM == 0) hipLaunchKernelGGL((group_step_kernel<GW, D4, 0, TK>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb,
-        (const int *)nullptr, 0);
-    else if constexpr (DRM == 1) hipLaunchKernelGGL((group_step_kernel<GW, D4, 1, -1>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb,
-        (const int *)nullptr, 0);
-    else {
-        hipLaunchKernelGGL((group_step_kernel<GW, D4, 2, TK>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)h->d_gflag,
-            0);
-        hipLaunchKernelGGL((group_step_kernel<GW, D4, 1, -1>), g, b, 0, h->stream, h->E, it0, it1, lam, h->d_accb, (const int *)h->d_gflag,
-            1);
-    }
-}
-template <int GW, int D4, int DRM>
-static void launch_group_tk(mcmcx_engine *h, int it0, int it1)
-{
-    if (h->tkind == TGT_BANANA) launch_group_inst<GW, D4, DRM, TGT_BANANA>(h, it0, it1);
-    else if (h->tkind == TGT_EXPDATA) launch_group_inst<GW, D4, DRM, TGT_EXPDATA>(h, it0, it1);
-    else launch_group_inst<GW, D4, DRM, TGT_GAUSS>(h, it0, it1);
-}
-template <int GW, int DRM>
-static void launch_group_d4(mcmcx_engine *h, int it0, int it1)
-{
-    if constexpr (GW == 4) {                              // quads: npar <= 16
-        switch (h->group_d4) {
-        case 4: launch_group_tk<4, 4, DRM>(h, it0, it1); break;
-        case 8: launch_group_tk<4, 8, DRM>(h, it0, it1); break;
-        case 12: launch_group_tk<4, 12, DRM>(h, it0, it1); break;
-        case 16: launch_group_tk<4, 16, DRM>(h, it0, it1); break;
-        default: h->launch_err = "group kernel (quads): npar > 16";
-        }
-    } else {
-        switch (h->group_d4) {
-        case 4: launch_group_tk<16, 4, DRM>(h, it0, it1); break;
-        case 8: launch_group_tk<16, 8, DRM>(h, it0, it1); break;
-        case 12: launch_group_tk<16, 12, DRM>(h, it0, it1); break;
-        case 16: launch_group_tk<16, 16, DRM>(h, it0, it1); break;
-        case 20: launch_group_tk<16, 20, DRM>(h, it0, it1); break;
-        case 24: launch_group_tk<16, 24, DRM>(h, it0, it1); break;
-        default:
-            // DRM = 2 (iC as a square in LDS) is the engine's choice up to npar 24 only (mcmcx_init): larger sizes are not instantiated --
-            // at 28 / 32 they could not hold the two waves per SIMD they would declare (Weak 12)
-            if constexpr (DRM != 2) {
-                switch (h->group_d4) {
-                case 28: launch_group_tk<16, 28, DRM>(h, it0, it1); return;
-                case 32: launch_group_tk<16, 32, DRM>(h, it0, it1); return;
-                default: break;
-                }
-            }
-            if constexpr (DRM == 0) {                                    // (above 32: sizes of eight, no delayed rejection)
-                switch (h->group_d4) {
-                case 40: launch_group_tk<16, 40, DRM>(h, it0, it1); return;
-                case 48: launch_group_tk<16, 48, DRM>(h, it0, it1); return;
-                case 56: launch_group_tk<16, 56, DRM>(h, it0, it1); return;
-                case 64: launch_group_tk<16, 64, DRM>(h, it0, it1); return;
-                default: break;
-                }
-            }
-            h->launch_err = "group kernel: no instantiation for npar " + std::to_string(h->d) + " with delayed-rejection mode " +
-                std::to_string(DRM);
-        }
-    }
-}
-static const KernelEntry GROUP_TABLE[] = {
-    {"group", "group_step_kernel",            [](const mcmcx_engine *h) { return h->group_gw == 16 && h->group_drm == 0; },
-        launch_group_d4<16, 0>},
-    {"group", "group_step_kernel<DR>",        [](const mcmcx_engine *h) { return h->group_gw == 16 && h->group_drm == 1; },
-        launch_group_d4<16, 1>},
-    {"group", "group_step_kernel<DR2>",       [](const mcmcx_engine *h) { return h->group_gw == 16 && h->group_drm == 2; },
-        launch_group_d4<16, 2>},
-    {"group", "group_step_kernel<quad>",      [](const mcmcx_engine *h) { return h->group_gw == 4 && h->group_drm == 0; },
-        launch_group_d4<4, 0>},
-    {"group", "group_step_kernel<quad, DR>",  [](const mcmcx_engine *h) { return h->group_gw == 4 && h->group_drm == 1; },
-        launch_group_d4<4, 1>},
-    {"group", "group_step_kernel<quad, DR2>", [](const mcmcx_engine *h) { return h->group_gw == 4 && h->group_drm == 2; },
-        launch_group_d4<4, 2>},
-};
-static void launch_group(mcmcx_engine *h, int it0, int it1)
-{
-    if (h->group_drm == 2 && h->group_check_due) {       // the factors have been rewritten since the last look
-        (void)hipMemsetAsync(h->d_gflag, 0, sizeof(int), h->stream);
-        hipLaunchKernelGGL(group_check_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, h->d_gflag);
-        h->group_check_due = false;
-    }
-    walk_table(h, GROUP_TABLE, sizeof(GROUP_TABLE) / sizeof(GROUP_TABLE[0]), it0, it1);
-    if (h->d_accb && h->launch_err.empty()) {
-        const long long n = (long long)(it1 - it0 + 1) * h->ntiles;
-        hipLaunchKernelGGL(group_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->E, h->d_accb, it0, it1);
-    }
-}
-// pooled_mfma_kernel<false, true>: two waves per SIMD (256 registers, some state spilled) pay with more tiles than SIMDs: from two per SIMD
-// where the LDS vector lets eight waves on a CU (npar <= 39: +25 .. +55 %), from eight where it lets six (npar 50: 0.80 at 2048 tiles, 0.99
-// at 4096, 1.14 at 16384); with one tile per SIMD the spills are all they buy (0.83 .. 0.90) -- tools/pooled_waves_probe.py
-static bool pooled_two_waves(const mcmcx_engine *h)
-{
-    // (test switch: either instance on a small problem)
-    if (h->sw.pooled_waves == 1 || h->sw.pooled_waves == 2) return h->sw.pooled_waves == 2;
-    return h->ntiles >= (pooled_mfma_lds(h->d) * 8 <= 160 * 1024 ? 2048 : 8192);
-}
-#define STEP_ARGS h->stream, h->E, it0, it1
-#define STEP_RS (h->d_ramscale + it0)
-#define STEP_TGT h->E.tgt.mu, h->E.tgt.lamT
-#define G1 dim3(h->ntiles), dim3(64)
-// method = 'ram' with few chains: sixteen lanes per chain, the factor in registers, dchud / dchdd on it there (mcx_group_ram.hpp) where it
-// is the faster one (tools/ram_group_sweep.py, profiles/r05_b/ram_group_sweep.txt: chain-iterations/s of both families over npar, chain
-// count and regime): one wave per SIMD and four chains per wave, so the chip holds 4096 chains at once and the kernel saturates there
-// (1.68e8 / 4.6e8 / 1.1e9 chain-iterations/s at npar 50 / 20 / 10) -- 9x / 6x / 6x the lane kernels up to 4096 chains, still 2.9x / 1.7x /
-// 2.0x at 16384 and 1.6x / 1.1x / 1.2x at 32768; from 65536 chains on the streaming kernels are ahead (0.93 / 0.74 / 0.63)
-static bool ram_group_wins(const mcmcx_engine *h)
-{
-    const long long n = h->cfg.nchains;
-    return n <= 16384 || (n <= 32768 && h->d >= 17);
-}
-static bool ram_group_covers(const mcmcx_engine *h)
-{
-    return !h->pooled && h->cfg.method == MCMCX_METHOD_RAM && !h->usesvd && !phased(h) && h->ny == 1 && h->d <= 64 &&
-           (h->tkind == TGT_GAUSS || h->tkind == TGT_BANANA || h->tkind == TGT_EXPDATA) && !(h->tkind == TGT_BANANA && h->d < 2);
-}
-template <int D4>
-static void launch_group_ram_d4(mcmcx_engine *h, int it0, int it1)
-{
-    hipLaunchKernelGGL((group_ram_kernel<D4, -1>), dim3(h->ntiles * 16), dim3(64), 0, h->stream, h->E, it0, it1,
-        (const double *)h->d_ramscale, h->E.tgt.lamT, h->d_accb);
-}
-static void launch_group_ram(mcmcx_engine *h, int it0, int it1)
-{
-    switch (h->ram_group_d4) {
-    case 16: launch_group_ram_d4<16>(h, it0, it1); break;
-    case 32: launch_group_ram_d4<32>(h, it0, it1); break;
-    case 56: launch_group_ram_d4<56>(h, it0, it1); break;
-    case 64: launch_group_ram_d4<64>(h, it0, it1); break;
-    default: h->launch_err = "group_ram_kernel: no instantiation for npar " + std::to_string(h->d); return;
-    }
-    if (h->d_accb) {
-        const long long n = (long long)(it1 - it0 + 1) * h->ntiles;
-        hipLaunchKernelGGL(group_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->E, h->d_accb, it0, it1);
-    }
-}
-#ifdef MCX_VARIANTS                // measured negatives, built only by tools/build_variant.sh -DMCX_VARIANTS -- never part of libmcmcx.so
-#include "../../tools/variants/variants.inc"
-#else
-#define MCX_VARIANT_STEP_ENTRIES
-#define MCX_VARIANT_SVD_SWEEP(h, lss) false
-#define MCX_VARIANT_COV(h, g8, n10, noff, it, mode) false
-#endif
-static const KernelEntry STEP_TABLE[] = {
-    // ---- a device target with response columns (nycol >= 1 sums of squares per point): the phases of an iteration in one launch
-    // (one instantiation per method class: MCMC_run_ram's carries the rank-one update's panels, the others do not)
-    {"step", "step_kernel_cols<ram>", [](const mcmcx_engine *h) { return fused_cols(h) && h->E.method == M_RAM; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_cols<1>, G1, lds_step(h), STEP_ARGS, (const double *)h->d_ramscale,
-                                                                (const double *)nullptr, (const double *)nullptr, (const double *)nullptr); }},
-    {"step", "step_kernel_cols", fused_cols,
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_cols<0>, G1, lds_step(h), STEP_ARGS, (const double *)h->d_ramscale,
-                                                                (const double *)(h->pooled ? h->E.sharedR : nullptr),
-                                                                (const double *)h->d_sharedR2, (const double *)h->d_sharediC); }},
-    // ---- pooled mode (one shared factor)
-    {"step", "pooled_mfma_kernel<true>", [](const mcmcx_engine *h) { return pooled_use_mfma(h) && h->dodr != 0; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(pooled_mfma_kernel<true>, G1, pooled_mfma_lds(h->d), STEP_ARGS, STEP_TGT,
-         h->d_sharedRT, h->d_sharedR2T, h->d_sharediCd); }},
-    MCX_VARIANT_STEP_ENTRIES
-    {"step", "pooled_mfma_kernel<false, true>", [](const mcmcx_engine *h) { return pooled_use_mfma(h) && pooled_two_waves(h); },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((pooled_mfma_kernel<false, true>), G1, pooled_mfma_lds(h->d), STEP_ARGS,
-         STEP_TGT, h->d_sharedRT, (const double *)nullptr, (const double *)nullptr); }},
-    {"step", "pooled_mfma_kernel<false>", [](const mcmcx_engine *h) { return pooled_use_mfma(h); },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(pooled_mfma_kernel<false>, G1, pooled_mfma_lds(h->d), STEP_ARGS, STEP_TGT,
-         h->d_sharedRT, (const double *)nullptr, (const double *)nullptr); }},
-    {"step", "step_kernel_pooled_dr_big", [](const mcmcx_engine *h) { return h->pooled && h->dodr && !dr_vectors_in_lds(h, 4); },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_pooled_dr_big, G1, 0, STEP_ARGS, STEP_RS, STEP_TGT,
-         h->E.sharedR, h->d_sharedR2, h->d_sharediC); }},
-    {"step", "step_kernel_pooled_dr", [](const mcmcx_engine *h) { return h->pooled && h->dodr; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_pooled_dr, G1, lds_step(h), STEP_ARGS, STEP_RS, STEP_TGT,
-         h->E.sharedR, h->d_sharedR2, h->d_sharediC); }},
-    {"step", "step_kernel<false, false, true>", [](const mcmcx_engine *h) { return h->pooled != 0; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((step_kernel<false, false, true>), G1, 0, STEP_ARGS, STEP_RS, STEP_TGT,
-         h->E.sharedR); }},
-    // ---- method = 'ram', per-chain factors
-    {"step", "group_ram_kernel", [](const mcmcx_engine *h) { return h->ram_group_d4 != 0; }, launch_group_ram},
-    {"step", "step_kernel_ram_fullr", [](const mcmcx_engine *h) { return h->E.method == M_RAM && h->usesvd; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ram_fullr, G1, 0, STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR);
-         }},
-    {"step", "step_kernel_ram_ldsr", [](const mcmcx_engine *h) { return h->E.method == M_RAM && h->E.lds_scratch == 3; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ram_ldsr, G1, (size_t)(2 * h->d + h->P) * 64 * sizeof(double),
-         STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
-    {"step", "step_kernel_ram_wide", [](const mcmcx_engine *h) {
-        return h->E.method == M_RAM && h->d > RAM_SMALL_MAX && h->sw.ram_wide != 0; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ram_wide, G1, (size_t)NLC * 2 * 64 * sizeof(double), STEP_ARGS,
-         STEP_RS, STEP_TGT, h->E.sharedR); }},
-    {"step", "step_kernel<true, false, false>", [](const mcmcx_engine *h) { return h->E.method == M_RAM; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((step_kernel<true, false, false>), G1,
-         (size_t)NLC * 2 * 64 * sizeof(double), STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
-    // ---- delayed rejection, per-chain factors: the second stage's two vectors in global scratch / in LDS
-    {"step", "step_kernel_dr_big", [](const mcmcx_engine *h) { return h->dodr && !dr_vectors_in_lds(h); },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_dr_big, G1, 0, STEP_ARGS, STEP_TGT); }},
-    {"step", "step_kernel_dr", [](const mcmcx_engine *h) { return h->dodr != 0; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_dr, G1, lds_step(h), STEP_ARGS, STEP_TGT); }},
-    // ---- AM / Metropolis / early rejection: state + factor in LDS, state in LDS, nothing in LDS
-    {"step", "step_kernel_ldsr", [](const mcmcx_engine *h) { return h->E.lds_scratch == 2; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ldsr, G1, (size_t)(2 * h->d + h->P) * 64 * sizeof(double),
-         STEP_ARGS, STEP_RS, STEP_TGT, h->E.sharedR); }},
-    {"step", "step_kernel_ldsv", [](const mcmcx_engine *h) { return h->E.lds_scratch != 0; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_ldsv, G1, (size_t)4 * h->d * 64 * sizeof(double), STEP_ARGS,
-         STEP_RS, STEP_TGT, h->E.sharedR); }},
-    {"step", "step_kernel<false, false, false>", [](const mcmcx_engine *) { return true; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((step_kernel<false, false, false>), G1, 0, STEP_ARGS, STEP_RS, STEP_TGT,
-         h->E.sharedR); }},
-};
-static void launch_step(mcmcx_engine *h, int it0, int it1)
-{
-    if (h->group_d4) { launch_group(h, it0, it1); return; }
-    walk_table(h, STEP_TABLE, sizeof(STEP_TABLE) / sizeof(STEP_TABLE[0]), it0, it1);
-}
-// every chain's copy of a K-vector, filled on the device
-static int dev_bcast(mcmcx_engine *h, double *dst, const std::vector<double> &v)
-{
-    double *tmp = nullptr;
-    HIPCHK(hipMalloc(&tmp, v.size() * sizeof(double)));
-    hipError_t e = hipMemcpy(tmp, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        const unsigned gy = (unsigned)std::min<size_t>(v.size(), 64);
-        hipLaunchKernelGGL(bcast_kernel, dim3(h->ntiles, gy), dim3(64), 0, h->stream, dst, tmp, v.size());
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    }
-    (void)hipFree(tmp);
-    if (e != hipSuccess) return fail(-100, hipGetErrorString(e));
-    return 0;
-}
-static int upload_shared_rt(mcmcx_engine *h)
-{
-    const int d = h->d, d4 = (d + 3) & ~3;
-    std::vector<double> m((size_t)d4 * d + PWS, 0.0);
-    for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) m[(size_t)i * d + j] = h->pool_R[h_pidx(i, j, d)];
-    HIPCHK(hipMemcpyAsync(h->d_sharedRT, m.data(), m.size() * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return 0;
-}
-static int upload_shared_rf(mcmcx_engine *h)            // dense M[s*d + o] = Rf(o, s): the column-major factor as it stands, pad rows zero
-{
-    const int d = h->d, d4 = (d + 3) & ~3;
-    std::vector<double> m((size_t)d4 * d + PWS, 0.0);
-    memcpy(m.data(), h->pool_Rf.data(), (size_t)d * d * 8);
-    HIPCHK(hipMemcpyAsync(h->d_sharedRT, m.data(), m.size() * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return 0;
-}
-// d4 rows (pad rows zero) + slack
-static size_t shared_u_stride(const mcmcx_engine *h) { return (size_t)((h->d + 3) & ~3) * h->d + PWS; }
-// X [16 nt][64], Q [4 nt][64], zb, fl, mu [16 nt]
-static size_t scam_pooled_lds(int d) {
-    return ((size_t)((d + 15) / 16) * (16 + 4) * 64 + 128 + (size_t)((d + 15) / 16) * 16) * sizeof(double); }
-static int upload_shared_u(mcmcx_engine *h)
-{
-    if (h->scam_replicated) {                           // every chain's own copy of the one rotation and its scales
-        int rc = dev_bcast(h, h->E.Rf, h->pool_U); if (rc) return rc;
-        return dev_bcast(h, h->E.qstd, h->pool_std);
-    }
-    const int d = h->d; const size_t st = shared_u_stride(h);
-    std::vector<double> b(2 * st + d, 0.0);
-    for (int j = 0; j < d; ++j) for (int i = 0; i < d; ++i) { b[(size_t)j * d + i] = h->pool_U[(size_t)j * d + i];
-        b[st + (size_t)i * d + j] = h->pool_U[(size_t)j * d + i]; }
-    for (int i = 0; i < d; ++i) b[2 * st + i] = h->pool_std[i];
-    HIPCHK(hipMemcpyAsync(h->d_sharedU, b.data(), b.size() * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return 0;
-}
-// 13..15 output blocks (npar 193..240): twelve waves of 170 registers (scam_pooled12_kernel) instead of sixteen of 128
-static bool scam_use_12(const mcmcx_engine *h)
-{
-    const int nt = (h->d + 15) / 16;
-    if (h->sw.scam_pooled_16 > 0) return false;                                       // A/B switch for tests: the sixteen-wave layout
-    return nt >= 13 && nt <= 15;
-}
-// opt-in fast proposals with the Gaussian target: the workgroup-per-tile kernel of the pooled mode with each chain's own
-// rotation column (g_U = nullptr) -- the target's d x d product on the matrix cores instead of lane by lane
-static bool scam_fast_tile_kernel(const mcmcx_engine *h)
-{
-    return h->cfg.scam_fast && h->tkind == TGT_GAUSS && !h->has_lo && !h->has_hi && !h->has_pri && scam_pooled_lds(h->d) <= 160 * 1024 &&
-           !(h->sw.scam_fast_lanes > 0);
-}
-// few tiles: several waves per tile (scam_mw_kernel), so that a sub-step is not bound by the latency of one wave's loads
-// while most of the chip idles -- as many waves as keep the chip's ~2048 resident-wave slots busy, at most 8 (sixteen
-// waves of 128 registers spill the products' panels)
-static size_t scam_mw_lds(const mcmcx_engine *h) { return (size_t)(4 * ((h->d + 15) / 16) + 2) * 64 * sizeof(double); }
-static int scam_tile_waves(const mcmcx_engine *h)
-{
-    int nw = 1;
-    // (1024 tiles x npar 200: 8.4e6 at two waves per tile, 8.9e6 at four, 9.0e6 at eight -- profiles/r05_d/c5rep_waves.txt)
-    while (nw < 8 && (long long)h->ntiles * nw * 2 <= 8192) nw *= 2;
-    { const int v = h->sw.scam_waves; if (v == 1 || v == 2 || v == 4 || v == 8) nw = v; }   // A/B switch for tests
-    // (npar > 1200: the one-wave kernel needs no LDS)
-    if (scam_mw_lds(h) > 160 * 1024) nw = 1;
-    return nw;
-}
-#define SCAM_POOLED_ARGS scam_pooled_lds(h->d), h->stream, h->E, it0, it1, h->E.tgt.mu, h->E.tgt.lamT
-static const KernelEntry SCAM_TABLE[] = {
-    {"scam", "step_kernel_cols<scam>", [](const mcmcx_engine *h) { return fused_cols(h) && !h->pooled; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_cols<2>, G1, 0, STEP_ARGS, (const double *)h->d_ramscale,
-         (const double *)nullptr, (const double *)nullptr, (const double *)nullptr); }},
-    // pooled: 16-row output blocks, min(12, 4*(nt/4)) block waves + 4 chain-group waves; twelve waves of 170 registers for 13..15 blocks
-    {"scam", "scam_pooled12_kernel", [](const mcmcx_engine *h) { return h->pooled && !h->scam_replicated && scam_use_12(h); },
-     [](mcmcx_engine *h, int it0, int it1) { const size_t st = shared_u_stride(h);
-        hipLaunchKernelGGL(scam_pooled12_kernel, dim3(h->ntiles), dim3(768), SCAM_POOLED_ARGS, h->d_sharedU, h->d_sharedU + st,
-            h->d_sharedU + 2 * st); }},
-    {"scam", "scam_pooled_kernel", [](const mcmcx_engine *h) { return h->pooled && !h->scam_replicated; },
-     [](mcmcx_engine *h, int it0, int it1) { const size_t st = shared_u_stride(h); const int nw = 4 + std::min(12, ((h->d + 15) / 16) & ~3);
-        hipLaunchKernelGGL(scam_pooled_kernel, dim3(h->ntiles), dim3(64 * nw), SCAM_POOLED_ARGS, h->d_sharedU, h->d_sharedU + st,
-            h->d_sharedU + 2 * st); }},
-    // (the sixteen-wave layout whatever npar: every lane fetches the column of its own chain's factor per sub-step, and four
-    //  waves per SIMD cover that better than three -- 4.62e8 against 4.45e8 proposals/s at npar 200)
-    {"scam", "scam_pooled_kernel<per-chain>", scam_fast_tile_kernel,
-     [](mcmcx_engine *h, int it0, int it1) { const int nw = 4 + std::min(12, ((h->d + 15) / 16) & ~3);
-        hipLaunchKernelGGL(scam_pooled_kernel, dim3(h->ntiles), dim3(64 * nw), SCAM_POOLED_ARGS, (const double *)nullptr,
-            (const double *)nullptr, (const double *)nullptr); }},
-    {"scam", "scam_mw_kernel<8>", [](const mcmcx_engine *h) { return scam_tile_waves(h) == 8; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(scam_mw_kernel<8>, dim3(h->ntiles), dim3(512), scam_mw_lds(h), STEP_ARGS,
-         STEP_TGT); }},
-    {"scam", "scam_mw_kernel<4>", [](const mcmcx_engine *h) { return scam_tile_waves(h) == 4; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(scam_mw_kernel<4>, dim3(h->ntiles), dim3(256), scam_mw_lds(h), STEP_ARGS,
-         STEP_TGT); }},
-    {"scam", "scam_mw_kernel<2>", [](const mcmcx_engine *h) { return scam_tile_waves(h) == 2; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(scam_mw_kernel<2>, dim3(h->ntiles), dim3(128), scam_mw_lds(h), STEP_ARGS,
-         STEP_TGT); }},
-    {"scam", "scam_kernel", [](const mcmcx_engine *) { return true; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(scam_kernel, G1, 0, STEP_ARGS, STEP_TGT); }},
-};
-static void launch_scam(mcmcx_engine *h, int it0, int it1)
-{
-    walk_table(h, SCAM_TABLE, sizeof(SCAM_TABLE) / sizeof(SCAM_TABLE[0]), it0, it1);
-}
-// the adaptation's SVD one workgroup per chain (mcx_svd.hpp) where its rings and row groups are instantiated
-static bool svd_blocked(const mcmcx_engine *h)
-{
-    if (!h->usesvd || h->pooled || h->cfg.method == MCMCX_METHOD_RAM) return false;
-    // test switch: the lane SVD (the engine's form below npar 48 and above 256)
-    if (h->sw.svd_lane > 0) return false;
-    // (its rings and row groups are instantiated up to npar 256)
-    return h->d >= 48 && h->d <= 256;
-}
-static void launch_adapt(mcmcx_engine *h, int it, int mode)
-{
-    // one d-vector / the Cholesky's diagonal block (18 kB: eight waves per CU up to npar 36)
-    const size_t lds = std::max(lds_bytes(h) / 2, (size_t)36 * 64 * sizeof(double));
-    hipLaunchKernelGGL(adapt_pre_kernel, dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it, mode);
-    // covmat's batch branch in blocks (adapt_covb_*): the AP window at every adaptation; with initcmatn = 0 the first AM adaptation and
-    // the greedy restarts.  Which lanes take it is the lanes' own business (ADF_BATCH); a tick that cannot hold any skips the launches.
-    const bool ap = (mode & AD_AM) && h->cfg.adapthist > 1;
-    // (test switch: covmat_rows, the lane form)
-    const int batch_done = (!(h->sw.cov_batch_rows > 0) &&
-                            (ap || (h->cfg.initcmatn == 0 && ((mode & AD_FIRST) || ((mode & AD_BURN) && h->cfg.greedy != 0))))) ? 1 : 0;
-    if (batch_done) {
-        const int n10 = (h->d + TD - 1) / TD, noff = n10 * (n10 - 1) / 2;
-        const unsigned g8 = (unsigned)(8 * ((h->ntiles + 7) / 8));
-        hipLaunchKernelGGL(adapt_covb_diag_kernel, dim3(g8 * n10), dim3(64), 0, h->stream, h->E, it, n10);
-        if (noff > 0) hipLaunchKernelGGL(adapt_covb_off_kernel, dim3(g8 * noff), dim3(64), 0, h->stream, h->E, it, noff);
-    }
-    if (!((mode & AD_AM) && h->cfg.adapthist > 1)) {                      // the AP window is a batch recompute: no blocked update
-        // blocks of ten (triangular on the diagonal)
-        const int n10 = (h->d + TD - 1) / TD, noff = n10 * (n10 - 1) / 2;
-        const unsigned g8 = (unsigned)(8 * ((h->ntiles + 7) / 8));
-        if (MCX_VARIANT_COV(h, g8, n10, noff, it, mode)) {}
-        else {
-            hipLaunchKernelGGL(adapt_cov_diag_kernel, dim3(g8 * n10), dim3(64), 0, h->stream, h->E, it, mode, n10);
-            if (noff > 0) hipLaunchKernelGGL(adapt_cov_off_kernel, dim3(g8 * noff), dim3(64), 0, h->stream, h->E, it, mode, noff);
-        }
-    }
-    if (!h->d_Gc) {
-        if (lds > 160 * 1024) {                             // npar > 320: the work vector in global scratch (slower; no limit)
-            if (h->usesvd) hipLaunchKernelGGL((adapt_post_kernel<true, true>), dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it, mode, 0,
-                (uint8_t *)nullptr, batch_done);
-            else hipLaunchKernelGGL((adapt_post_kernel<false, true>), dim3(h->ntiles), dim3(64), 0, h->stream, h->E, it, mode, 0,
-                (uint8_t *)nullptr, batch_done);
-            return;
-        }
-        if (h->usesvd) hipLaunchKernelGGL(adapt_post_kernel<true>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 0,
-            (uint8_t *)nullptr, batch_done);
-        else if (h->tile_factor) {
-            // dpotf2 (+ dtrti2 / dlauu2 with delayed rejection) with the packed matrices of 4 NW neighbouring chains in LDS, read and
-            // written once (mcx_group.hpp: tile_factor_kernel); adapt_post_kernel keeps the covariance bookkeeping (phase 3)
-            hipLaunchKernelGGL(adapt_post_kernel<false>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 3, (uint8_t *)nullptr,
-                batch_done);
-            const int nc = (h->d + 15) / 16, nw = nc <= 2 ? 4 : nc == 3 ? 2 : 1, ch = 4 * nw;
-            const size_t tl = (size_t)ch * (h->P | 1) * sizeof(double) + (size_t)ch * sizeof(int);
-            const dim3 tg((unsigned)(8 * ((h->ntiles + 7) / 8) * (64 / ch)));
-            switch (nc) {
-            case 1: hipLaunchKernelGGL((tile_factor_kernel<1, 4>), tg, dim3(256), tl, h->stream, h->E); break;
-            case 2: hipLaunchKernelGGL((tile_factor_kernel<2, 4>), tg, dim3(256), tl, h->stream, h->E); break;
-            case 3: hipLaunchKernelGGL((tile_factor_kernel<3, 2>), tg, dim3(128), tl, h->stream, h->E); break;
-            default: hipLaunchKernelGGL((tile_factor_kernel<4, 1>), tg, dim3(64), tl, h->stream, h->E); break;
-            }
-        }
-        else hipLaunchKernelGGL(adapt_post_kernel<false>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 0, (uint8_t *)nullptr,
-            batch_done);
-        return;
-    }
-    // large npar with an SVD factor: the factorisation runs one workgroup per chain on chain-major copies, one launch
-    // pair per Jacobi sweep (the rotation log lives in Gw, which is free between tile2chain and the next tick)
-    const size_t DD = (size_t)h->d * h->d;
-    const dim3 tg((unsigned)((DD + 63) / 64), (unsigned)h->ntiles), tg1((unsigned)((h->d + 63) / 64), (unsigned)h->ntiles);
-    hipLaunchKernelGGL(adapt_post_kernel<true>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 1, h->d_need, batch_done);
-    hipLaunchKernelGGL(tile2chain_kernel, tg, dim3(256), 0, h->stream, h->E.Gw, h->d_Gc, DD, DD, h->d_need);
-    hipLaunchKernelGGL(svd_init_kernel, dim3(h->nlanes), dim3(256), 0, h->stream, h->d_Vc, h->d_state, h->d_need, h->nlanes, h->d);
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        (void)hipMemsetAsync(h->d_anyrot, 0, sizeof(int), h->stream);
-        // the sweep: every later column streamed past a block's pair-lanes through an LDS ring (mcx_svd.hpp) -- all 32 lanes of a row group
-        // on pairs up to npar 200 (svd_sweep_stream32_kernel), 24 pair-lanes and a wave of loaders above (svd_sweep_stream_kernel)
-        if (h->d <= 200) {
-            const int RLs = h->d <= 64 ? 8 : h->d <= 128 ? 16 : 25;
-            const size_t lss = (size_t)33 * (8 * RLs + 2) * sizeof(double);
-            if (MCX_VARIANT_SVD_SWEEP(h, lss)) {}
-            else if (h->d <= 64) hipLaunchKernelGGL(svd_sweep_stream32_kernel<8>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc,
-                (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
-            else if (h->d <= 128) hipLaunchKernelGGL(svd_sweep_stream32_kernel<16>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc,
-                (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d);
-            else hipLaunchKernelGGL(svd_sweep_stream32_kernel<25>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw,
-                h->d_state, h->d_anyrot, h->nlanes, h->d);
-        } else {
-            // pair-lanes of the streamed sweep: whole waves of octets, one wave of loaders at least
-            constexpr int svd_sb = 24;
-            const int RLs = h->d <= 208 ? 26 : 32;
-            const size_t lss = (size_t)(svd_sb + 2) * (8 * RLs + 2) * sizeof(double);
-            if (h->d <= 208) hipLaunchKernelGGL(svd_sweep_stream_kernel<26>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc,
-                (mcx_d2 *)h->E.Gw, h->d_state, h->d_anyrot, h->nlanes, h->d, svd_sb);
-            else hipLaunchKernelGGL(svd_sweep_stream_kernel<32>, dim3(h->nlanes), dim3(256), lss, h->stream, h->d_Gc, (mcx_d2 *)h->E.Gw,
-                h->d_state, h->d_anyrot, h->nlanes, h->d, svd_sb);
-        }
-        {                                                // the log replayed on V: all 32 lanes of a row group on pairs, any npar
-            // four one-wave workgroups per chain, a chain's on one XCD
-            const unsigned gv = (unsigned)(32 * ((h->nlanes + 7) / 8));
-            const int RP = h->d <= 64 ? 4 : h->d <= 128 ? 8 : h->d <= 208 ? 13 : 16;
-            const size_t lsv2 = (size_t)33 * (4 * RP + 6) * sizeof(double);
-            if (h->d <= 64) hipLaunchKernelGGL(svd_applyv_stream32_kernel<4>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc,
-                (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d);
-            else if (h->d <= 128) hipLaunchKernelGGL(svd_applyv_stream32_kernel<8>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc,
-                (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d);
-            else if (h->d <= 208) hipLaunchKernelGGL(svd_applyv_stream32_kernel<13>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc,
-                (const mcx_d2 *)h->E.Gw, h->d_state, h->nlanes, h->d);
-            else hipLaunchKernelGGL(svd_applyv_stream32_kernel<16>, dim3(gv), dim3(64), lsv2, h->stream, h->d_Vc, (const mcx_d2 *)h->E.Gw,
-                h->d_state, h->nlanes, h->d);
-        }
-        int any = 0;
-        // (reported by the caller's hipGetLastError)
-        if (hipMemcpyAsync(&any, h->d_anyrot, sizeof(int), hipMemcpyDeviceToHost,
-            h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) break;
-        if (!any) break;
-    }
-    hipLaunchKernelGGL(svd_finish_kernel, dim3(h->nlanes), dim3(256), 0, h->stream, h->d_Gc, h->d_Vc, h->d_svc, h->d_state, h->nlanes,
-        h->d);
-    hipLaunchKernelGGL(chain2tile_kernel, tg, dim3(256), 0, h->stream, h->d_Gc, h->E.Vw, DD, DD, h->d_need);
-    hipLaunchKernelGGL(chain2tile_kernel, tg1, dim3(256), 0, h->stream, h->d_svc, h->E.cs, (size_t)h->d, (size_t)2 * h->d, h->d_need);
-    hipLaunchKernelGGL(adapt_post_kernel<true>, dim3(h->ntiles), dim3(64), lds, h->stream, h->E, it, mode, 2, h->d_need, batch_done);
-}
-
-// Which branch of MCMC_adapt fires at iteration `it` (0 = none).  MCMC_adapt.F90:42-46, 60-61, 105.
-static int adapt_mode(const mcmcx_config &c, int it)
-{
-    if (c.method == MCMCX_METHOD_RAM) return 0;
-    if (c.doadapt == 0 && c.doburnin == 0) return 0;
-    if (c.adaptend > 0 && it > c.adaptend) return 0;
-    bool m1 = (c.adaptint != 0) && (it % c.adaptint == 0);
-    bool m2 = (c.badaptint != 0) && (it % c.badaptint == 0);
-    if (!m1 && !m2) return 0;
-    if (it < c.burnintime && c.doburnin != 0 && m2) return AD_BURN;
-    if (it >= c.burnintime + c.adaptint + c.adapthist && c.doadapt != 0)
-        return AD_AM | ((it == c.burnintime + c.adaptint + c.adapthist) ? AD_FIRST : 0);
-    return 0;
-}
-
-// pooled RAM: every adaptint iterations once the burn-in is over (MCMC_run_ram.F90:123-131), up to adaptend
-static bool pooled_ram_due(const mcmcx_engine *h, int it)
-{
-    const mcmcx_config &c = h->cfg;
-    if (!h->pooled || c.method != MCMCX_METHOD_RAM || c.doadapt == 0 || c.adaptint <= 0) return false;
-    if (it < c.burnintime && c.doburnin != 0) return false;
-    if (c.adaptend > 0 && it > c.adaptend) return false;
-    return it % c.adaptint == 0;
-}
-
-// ------------------------------------------------------------------ getters
-template <typename T>
-static int fetch(mcmcx_engine *h, const T *dev, size_t n, std::vector<T> &out)
-{
-    out.resize(n);
-    HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(out.data(), dev, n * sizeof(T), hipMemcpyDeviceToHost));
-    return 0;
-}
-// gather element k of one chain from a tile-interleaved array
-template <typename T>
-static int fetch_chain_vec(mcmcx_engine *h, const T *dev, int K, int chain, std::vector<T> &out)
-{
-    int tile = chain / 64, lane = chain % 64;
-    std::vector<T> tmp;
-    int rc = fetch(h, dev + (size_t)tile * K * 64, (size_t)K * 64, tmp);
-    if (rc) return rc;
-    out.resize(K);
-    for (int k = 0; k < K; ++k) out[k] = tmp[(size_t)k * 64 + lane];
-    return 0;
-}
-static int check_chain(mcmcx_engine *h, int chain)
-{
-    if (!h) return fail(-1, "null handle");
-    if (!h->inited) return fail(-40, "we have not inited");
-    if (chain < 0 || chain >= h->cfg.nchains) return fail(-41, "chain index out of range");
-    return 0;
-}
-
-static void unpack_upper(int d, const std::vector<double> &p, double *colmajor, bool symmetric)
-{
-    for (int j = 0; j < d; ++j)
-        for (int i = 0; i < d; ++i) {
-            double v = 0.0;
-            if (i <= j) v = p[h_pidx(i, j, d)];
-            else if (symmetric) v = p[h_pidx(j, i, d)];
-            colmajor[(size_t)i + (size_t)j * d] = v;
-        }
-}
-
-static volatile sig_atomic_t g_interrupt = 0;
-static bool g_sig_installed = false;       // then mcmcx_run waits for each launch, so that a signal is seen at the next boundary
-static void on_signal(int) { g_interrupt = 1; }
-
-static int pooled_moments_launch(mcmcx_engine *h, double *dev_dst, int kind = 0, int it = 0);
-static int pooled_vec_len(const mcmcx_engine *h, int kind);
-#include "mcx_comm.hpp"
-
-// Pooled moments of the chains of ALL ranks, left in h->d_pooled (asynchronous on the engine's stream): local tree ->
-// slot `rank` of d_gather -> all-gather over the communicator -> the same pairwise tree over the ranks.  Every rank's
-// slot carries one more element behind the vector, the rank's STOP FLAG (1 = a signal was caught here): its sum over the
-// ranks comes back with the moments, so the decision to leave a run that has collectives ahead is taken by all ranks at
-// the same tick (a rank that returned alone would leave its peers waiting in the next gather).
-static int allreduce_moments_enqueue(mcmcx_engine *h, int stage /* 0 all, 1 local part, 2 gather, 3 tree */, int kind = 0, int it = 0,
-    double flag = 0.0)
-{
-    const int len = pooled_vec_len(h, kind), st = len + 1;
-    const int nr = h->comm ? h->comm->nranks : 1, rk = h->comm ? h->comm->rank : 0;
-    HIPCHK(hipSetDevice(h->cfg.device));
-    if (stage == 0 || stage == 1) {
-        int rc = pooled_moments_launch(h, h->d_gather + (size_t)rk * st, kind, it); if (rc) return rc;
-        h->h_flag = flag;
-        hipLaunchKernelGGL(set_double_kernel, dim3(1), dim3(1), 0, h->stream, h->d_gather + (size_t)rk * st + len, flag);
-        HIPCHK(hipGetLastError());
-    }
-    if ((stage == 0 || stage == 2) && h->comm) { int rc = comm_allgather(h->comm, h->d_gather, st, h->stream); if (rc) return rc; }
-    if (stage == 0 || stage == 3) {
-        hipLaunchKernelGGL(moments_tree_kernel, dim3((st + 255) / 256, 1), dim3(256), 0, h->stream, h->d_gather, nr, st, 1, h->d_pooled);
-        HIPCHK(hipGetLastError());
-    }
-    return 0;
-}
-
-// several ranks meet in this engine's ticks: its run may only be left at a tick, by agreement (the stop flag above)
-static bool collective_run(const mcmcx_engine *h) { return h->pooled && h->comm && h->comm->nranks > 1 && !h->xfn; }
-
-// The pooled statistic vector of `kind` over the chains of ALL ranks, on the host.  With a communicator: local tree ->
-// all-gather -> tree over ranks; with the caller's exchange hook (kind 0 only): the hook sums the device buffer.
-// When some rank raised its stop flag, h->stop_seen is set: every rank reads the same sum at the same tick, APPLIES that tick
-// like any other (all of them hold the same pooled vector) and leaves mcmcx_run behind it -- so a run resumed after
-// mcmcx_clear_interrupt continues exactly like one that was never interrupted.
-static int pooled_reduce(mcmcx_engine *h, int kind, int it, std::vector<double> &v)
-{
-    const int len = pooled_vec_len(h, kind);
-    v.assign(len + 1, 0.0);
-    if (h->xfn && kind != 0) return
-        fail(-8, "pooled burn-in scaling and the pooled RAM variant exchange through a communicator (mcmcx_set_comm), not through the mcmcx_set_exchange hook");
-    if (!h->xfn) {
-        int rc = allreduce_moments_enqueue(h, 0, kind, it, (collective_run(h) && g_interrupt) ? 1.0 : 0.0); if (rc) return rc;
-        if ((rc = comm_wait_stream(h->comm, h->stream))) return rc;
-        HIPCHK(hipMemcpy(v.data(), h->d_pooled, (size_t)(len + 1) * 8, hipMemcpyDeviceToHost));
-    } else {
-        double *dst = h->xbuf ? h->xbuf : h->d_moments + (size_t)h->ntiles * len;  // tail of the moments workspace
-        int rc = pooled_moments_launch(h, dst, kind, it); if (rc) return rc;
-        HIPCHK(hipStreamSynchronize(h->stream));
-        h->xfn(h->xuser);                                                            // the caller's own exchange
-        HIPCHK(hipMemcpy(v.data(), dst, (size_t)len * 8, hipMemcpyDeviceToHost));
-    }
-    const double stop = v[len];
-    v.resize(len);
-    if (collective_run(h) && stop != 0.0) h->stop_seen = true;
-    // the vector has been through an exchange: refuse to merge garbage (it would poison the pooled state for the rest of the run)
-    if (!(v[0] >= 2.0) || !std::isfinite(v[0])) return fail(-46, "pooled adaptation needs at least 2 chains over all ranks (count = " +
-        std::to_string(v[0]) + ")");
-    for (int k = 1; k < len;
-        ++k) if (!std::isfinite(v[k])) return fail(-46, "pooled adaptation: non-finite pooled statistic at iteration " +
-        std::to_string(it));
-    return 0;
-}
-
-// Delayed rejection in pooled mode (MCMC_adapt.F90:216-225 once for all chains): R2 = R / drscale, iC = dpotri('U', R) on
-// the upper triangle of the factor as it stands.  fresh: a new factor (recompute both); otherwise the burn-in scaling
-// has already been applied to the tables themselves, as MCMC_adapt.F90:66-78 does.
-static int pooled_upload_dr(mcmcx_engine *h, bool fresh)
-{
-    if (!h->dodr) return 0;
-    const int d = h->d, P = h->P;
-    if (fresh) {
-        std::vector<double> iC(P);
-        if (h->usesvd) {
-            h->pool_R2 = h->pool_Rf;
-            for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) iC[h_pidx(i, j, d)] = h->pool_Rf[(size_t)j * d + i];
-        } else { h->pool_R2 = h->pool_R; iC = h->pool_R; }
-        for (auto &v : h->pool_R2) v = v / h->cfg.drscale;
-        // the reference stops ("cannot invert cmat"); the old iC stays
-        if (host_potri(d, iC) != 0) h->pool_status |= ST_POTRI_FAIL;
-        else h->pool_iC = iC;
-    }
-    std::vector<double> r2 = h->pool_R2;
-    if (h->usesvd) r2.resize((size_t)((d + 3) & ~3) * d + PWS, 0.0);
-    HIPCHK(hipMemcpyAsync(h->d_sharedR2, r2.data(), r2.size() * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_sharediC, h->pool_iC.data(), (size_t)P * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    // pooled_mfma_kernel<true>: R2 like d_sharedRT (M[s*d + o] = R2(s,o)), iC dense symmetric
-    if (h->d_sharedR2T) {
-        const int d4 = (d + 3) & ~3;
-        std::vector<double> m((size_t)d4 * d + PWS, 0.0), q((size_t)d4 * d + PWS, 0.0);
-        // the full factor as it stands: M[s*d + o] = R2f(o, s)
-        if (h->usesvd) memcpy(m.data(), h->pool_R2.data(), (size_t)d * d * 8);
-        else for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) m[(size_t)i * d + j] = h->pool_R2[h_pidx(i, j, d)];
-        for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) { const double v = h->pool_iC[h_pidx(i, j, d)]; q[(size_t)i * d + j] = v;
-            q[(size_t)j * d + i] = v; }
-        HIPCHK(hipMemcpyAsync(h->d_sharedR2T, m.data(), m.size() * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->d_sharediCd, q.data(), q.size() * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-    }
-    return 0;
-}
-
-static int pooled_upload_R(mcmcx_engine *h)
-{
-    if (h->usesvd) return upload_shared_rf(h);
-    HIPCHK(hipMemcpyAsync(h->d_sharedR, h->pool_R.data(), (size_t)h->P * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    if (h->d_sharedRT) return upload_shared_rt(h);
-    return 0;
-}
-
-// chaincmat -> the shared proposal factor (MCMC_calculate_R): dpotf2 + 2.4/sqrt(d), or the pinned SVD for scam; on
-// failure the old factor stays (MCMC_adapt.F90:168-171)
-static int pooled_factor(mcmcx_engine *h)
-{
-    const mcmcx_config &c = h->cfg;
-    const int d = h->d;
-    std::vector<double> cm((size_t)d * d, 0.0), Rp, Cp;
-    for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) cm[(size_t)i + (size_t)j * d] = h->pool_C[h_pidx(i, j, d)];
-    if (c.method == MCMCX_METHOD_SCAM) {                // scam_svd of the pooled covariance, MCMC_adapt.F90:189-200
-        std::vector<double> U, sd;
-        if (host_initial_svd(d, cm, c.condmax, true, U, sd) == 0) { h->pool_U = U; h->pool_std = sd; return upload_shared_u(h); }
-        return 0;
-    }
-    if (h->usesvd) {                                    // covtor_svd of the pooled covariance, MCMC_adapt.F90:203-209
-        std::vector<double> Rf, sd, fc;
-        if (host_initial_svd(d, cm, c.condmax, false, Rf, sd, &fc) == 0) {
-            h->pool_Rf = Rf;
-            if (!fc.empty()) for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) h->pool_C[h_pidx(i, j,
-                d)] = fc[(size_t)i + (size_t)j * d];
-            int rc = pooled_upload_R(h);
-            return rc ? rc : pooled_upload_dr(h, true);
-        }
-        return 0;
-    }
-    if (host_initial_R(d, cm, Rp, Cp) == 0) { h->pool_R = Rp; int rc = pooled_upload_R(h); return rc ? rc : pooled_upload_dr(h, true); }
-    return 0;
-}
-
-// merge the batch of n unit-weight rows (moments v about par0) into (chaincmat, chainmean, chainwsum): covmat's
-// weighted update for a whole batch at once, or its batch branch when there is nothing to update (wsum = 0) or when
-// `replace` (the AP window: covmat(..., update = .false.), MCMC_adapt.F90:131-133)
-static void pooled_merge(mcmcx_engine *h, const std::vector<double> &v, bool replace)
-{
-    const int d = h->d, P = h->P;
-    const double n = v[0];
-    std::vector<double> m1(d), mb(d), Cb(P);
-    for (int j = 0; j < d; ++j) { m1[j] = v[1 + j] / n; mb[j] = h->par0[j] + m1[j]; }
-    for (int j = 0; j < d; ++j)
-        for (int i = 0; i <= j; ++i) {
-            double s2 = v[1 + d + j * (j + 1) / 2 + i];
-            Cb[h_pidx(i, j, d)] = (s2 - n * m1[i] * m1[j]) / (n - 1.0);
-        }
-    if (replace || !(h->pool_W > 0.0)) {
-        h->pool_C = Cb; h->pool_mean = mb; h->pool_W = n;
-    } else {
-        const double W = h->pool_W, Wn = W + n;
-        std::vector<double> dl(d);
-        for (int j = 0; j < d; ++j) dl[j] = mb[j] - h->pool_mean[j];
-        const double f = W * n / Wn;
-        for (int j = 0; j < d; ++j)
-            for (int i = 0; i <= j; ++i) {
-                const int e = h_pidx(i, j, d);
-                h->pool_C[e] = ((W - 1.0) * h->pool_C[e] + (n - 1.0) * Cb[e] + f * dl[i] * dl[j]) / (Wn - 1.0);
-            }
-        const double g = n / Wn;
-        for (int j = 0; j < d; ++j) h->pool_mean[j] = h->pool_mean[j] + g * dl[j];
-        h->pool_W = Wn;
-    }
-}
-
-static void pooled_restart(mcmcx_engine *h)             // chainwsum = initcmatn, chaincmat = cmat0, chainmean = par0
-{
-    const int d = h->d;
-    h->pool_W = (double)h->cfg.initcmatn;
-    for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) h->pool_C[h_pidx(i, j, d)] = h->cmat0[(size_t)i + (size_t)j * d];
-    h->pool_mean = h->par0;
-}
-
-// Pooled tick: the multi-chain form of MCMC_adapt (MCMC_adapt.F90:60-170).  The N current states of all ranks are a
-// batch of N unit-weight rows; `stayed` is summed over the chains.  Every operation below is restated in
-// tests/test_gpu_pooled.py.
-//   burn-in tick (:60-102): pooled rejection rate sum(stayed) / (N it) against scalelimit -> the shared factor is scaled
-//       down / up; in between, greedy restarts from cmat0 and merges the batch, otherwise chaincmat stays, and the
-//       factor is recomputed from chaincmat either way (which is what undoes earlier scalings in the reference too)
-//   AM tick (:105-159): first time restart from cmat0; merge the batch; AP (adapthist > 1): the batch replaces the
-//       covariance instead (the window of the single chain becomes the snapshot of the population)
-static int pooled_tick(mcmcx_engine *h, int it, int mode)
-{
-    const mcmcx_config &c = h->cfg;
-    std::vector<double> v;
-    if (mode & AD_BURN) {
-        int rc = pooled_reduce(h, 1, it, v); if (rc) return rc;
-        const double staypc = v[pooled_vec_len(h, 1) - 1] / (v[0] * (double)it);
-        const double sf = c.scalefactor;
-        if (staypc > 1.0 - c.scalelimit || staypc < c.scalelimit) {
-            const bool down = staypc > 1.0 - c.scalelimit;
-            for (auto &r : (h->usesvd ? h->pool_Rf : h->pool_R)) r = down ? r / sf : r * sf;
-            if (h->dodr) {                                  // R2 and iC are scaled themselves (MCMC_adapt.F90:66-78), not recomputed
-                for (auto &r : h->pool_R2) r = down ? r / sf : r * sf;
-                for (auto &r : h->pool_iC) r = down ? r * sf * sf : r / sf / sf;
-            }
-            int rc2 = pooled_upload_R(h);
-            return rc2 ? rc2 : pooled_upload_dr(h, false);
-        }
-        if (c.greedy != 0) { pooled_restart(h); pooled_merge(h, v, false); }
-        return pooled_factor(h);
-    }
-    int rc = pooled_reduce(h, 0, it, v); if (rc) return rc;
-    if (it == c.burnintime + c.adaptint + c.adapthist) pooled_restart(h);           // first time: MCMC_adapt.F90:108-114
-    pooled_merge(h, v, c.adapthist > 1);
-    return pooled_factor(h);
-}
-
-// Pooled RAM tick (the multi-chain form of MCMC_adapt_ram, MCMC_run_ram.F90:104-179): every adaptint iterations the
-// rank-one statistics of that iteration, one per chain, are averaged over all chains of all ranks and applied to the
-// Gram matrix of the shared factor at once:   R'R  <-  R'R + (1/N) sum_c sign(a_c) x_c x_c',
-// x_c = u_c / sum(u_c**2) * a_c,  a_c = (alpha_c - alphatarget) / it**nuparam  -- N Cholesky up/downdates of weight 1/N
-// folded into one refactorisation.  A Gram matrix that stops being positive definite keeps the old factor (the
-// single-chain code stops on a failed downdate; here one bad tick is skipped and flagged).
-static int pooled_ram_tick(mcmcx_engine *h, int it)
-{
-    const int d = h->d, P = h->P;
-    std::vector<double> v;
-    int rc = pooled_reduce(h, 2, it, v); if (rc) return rc;
-    const double n = v[0];
-    if (h->usesvd) {
-        // condmax > 0: the shared factor is the full matrix Rf of covtor_svd (matutils.F90:378-453), proposals are
-        // matmulx(Rf, z) with covariance Rf Rf'.  The same fold on that Gram matrix, refactored the way this factor is made:
-        // Rf <- U sqrt(s) of Rf Rf' + (1/N) sum_c sign(a_c) x_c x_c', singular values floored at s_1 / condmax (no 2.4/sqrt(d):
-        // the Gram matrix carries the scale already, like the Cholesky form below)
-        std::vector<double> S((size_t)d * d, 0.0), Rf, sd;
-        for (int j = 0; j < d; ++j)
-            for (int i = 0; i <= j; ++i) {
-                double acc = 0.0;
-                for (int k = 0; k < d; ++k) acc = std::fma(h->pool_Rf[(size_t)k * d + i], h->pool_Rf[(size_t)k * d + j], acc);
-                S[(size_t)i + (size_t)j * d] = acc + v[2 + j * (j + 1) / 2 + i] / n;
-            }
-        if (host_initial_svd(d, S, h->cfg.condmax, false, Rf, sd, nullptr, false) != 0) { h->pool_status |= ST_CHOL_FAIL; return 0; }
-        h->pool_Rf = Rf;
-        h->pool_alpha = v[1] / n;
-        return pooled_upload_R(h);
-    }
-    std::vector<double> S(P), A;
-    for (int j = 0; j < d; ++j)
-        for (int i = 0; i <= j; ++i) {
-            double acc = 0.0;
-            for (int k = 0; k <= i; ++k) acc = std::fma(h->pool_R[h_pidx(k, i, d)], h->pool_R[h_pidx(k, j, d)], acc);
-            S[h_pidx(i, j, d)] = acc + v[2 + j * (j + 1) / 2 + i] / n;
-        }
-    A = S;
-    for (int j = 0; j < d; ++j) {                       // dpotf2('U'), the order of host_initial_R
-        double dot = 0.0;
-        for (int i = 0; i < j; ++i) dot = std::fma(A[h_pidx(i, j, d)], A[h_pidx(i, j, d)], dot);
-        double ajj = A[h_pidx(j, j, d)] - dot;
-        if (!(ajj > 0.0)) { h->pool_status |= ST_CHOL_FAIL; return 0; }
-        double rj = std::sqrt(ajj);
-        A[h_pidx(j, j, d)] = rj;
-        double rinv = 1.0 / rj;
-        for (int k = j + 1; k < d; ++k) {
-            double t = 0.0;
-            for (int i = 0; i < j; ++i) t = std::fma(A[h_pidx(i, k, d)], A[h_pidx(i, j, d)], t);
-            A[h_pidx(j, k, d)] = (A[h_pidx(j, k, d)] - t) * rinv;
-        }
-    }
-    h->pool_R = A;
-    h->pool_alpha = v[1] / n;
-    return pooled_upload_R(h);
-}
-
-// Host-callback evaluation of one candidate vector per chain, in chain order, from the calling thread
-// (the reference's callbacks keep SAVEd state and are not thread-safe: testcases/mcmcrun.F90:69-70).
-// src: tile-interleaved device vector [T][stride][64]; only chains with want != 0 (hx slot) are evaluated.
-// what: 0 = checkbounds, priorfun, ssfunction (MCMC_run.F90:47-56); 1 = checkbounds and priorfun only, 2 = ssfunction_er
-// with each chain's threshold (the two halves of an early-rejection iteration, MCMC_run_er.F90:54-76)
-static int host_eval(mcmcx_engine *h, const double *dev_src, int stride_k, bool use_stage2_flag, int what = 0)
-{
-    const int d = h->d, T = h->ntiles;
-    if (h->tkind == TGT_EXPCOLS) {                      // device-resident response-column target: no host round trip
-        hipLaunchKernelGGL(dev_eval_kernel, dim3(T), dim3(64), 0, h->stream, h->E, dev_src, stride_k, use_stage2_flag ? 1 : 0, what);
-        HIPCHK(hipGetLastError());
-        return 0;
-    }
-    if (h->tkind == TGT_MODULE) {                       // the user's own device code, loaded from a code object
-        mcmcx_target_args a;
-        a.src = dev_src; a.hev = h->E.hev; a.hx = h->E.hx; a.userdata = h->d_moddata;
-        a.stride_k = stride_k; a.npar = d; a.ny = h->ny; a.nhe = NHE - 1 + h->ny; a.nhx = NHX; a.nchains = h->cfg.nchains;
-        a.use_stage2 = use_stage2_flag ? 1 : 0; a.what = what;
-        size_t asz = sizeof(a);
-        void *cfgv[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
-        HIPCHK(hipModuleLaunchKernel(h->mod_fn, (unsigned)T, 1, 1, 64, 1, 1, 0, h->stream, nullptr, cfgv));
-        return 0;
-    }
-    const size_t L = (size_t)T * 64;
-    const int ny = h->ny, nhe = NHE - 1 + ny;
-    const bool src_mapped = h->host_mapped && (dev_src == h->E.cand || h->cs_mapped);
-    const bool mapped = h->host_mapped;                  // flags and results in place
-    if ((!src_mapped && h->h_cand.resize(L * stride_k)) || (!mapped && (h->h_ev.resize(L * nhe) || (use_stage2_flag
-        && h->h_hx.resize(L * NHX)))))
-        return fail(-100, "host callbacks: no page-locked memory for the candidates");
-    std::vector<double> ssc(ny, 0.0);
-    if (!src_mapped) HIPCHK(hipMemcpyAsync(h->h_cand.data(), dev_src, L * stride_k * 8, hipMemcpyDeviceToHost, h->stream));
-    if (use_stage2_flag && !mapped) HIPCHK(hipMemcpyAsync(h->h_hx.data(), h->E.hx, h->h_hx.size() * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));             // (also: the previous stage's results have left h_ev)
-    const double *h_cand = src_mapped ? dev_src : h->h_cand.data();
-    const double *hx = mapped ? h->E.hx : h->h_hx.data();
-    double *h_ev = mapped ? h->E.hev : h->h_ev.data();
-    memset(h_ev, 0, L * nhe * sizeof(double));
-    std::vector<double> th(d);
-    if (h->h_ss_batch && !(what == 2 && h->h_ss_er)) {
-        // Batched form (opt-in): bounds and prior per chain on this thread, in chain order; then ONE call of the user's
-        // ssfunction_batch per worker thread over the chains that need the sum of squares.
-        h->h_bidx.clear(); h->h_bth.clear();
-        for (int c = 0; c < h->cfg.nchains; ++c) {
-            const int t = c / 64, l = c % 64;
-            if (use_stage2_flag && hx[((size_t)t * NHX + HX_STAGE2) * 64 + l] == 0.0) continue;
-            for (int k = 0; k < d; ++k) th[k] = h_cand[((size_t)t * stride_k + k) * 64 + l];
-            int inb = 1; double pri = 0.0;
-            if (what != 2) {
-                inb = h->h_cb ? h->h_cb(th.data(), d, h->h_user) : 1;
-                if (inb) pri = h->h_pri ? h->h_pri(th.data(), d, h->h_user) : 0.0;
-            }
-            h_ev[((size_t)t * nhe + HE_INB) * 64 + l] = inb ? 1.0 : 0.0;
-            h_ev[((size_t)t * nhe + HE_PRI) * 64 + l] = pri;
-            if ((what == 0 && inb) || what == 2) { h->h_bidx.push_back(c); h->h_bth.insert(h->h_bth.end(), th.begin(), th.end()); }
-        }
-        const int n = (int)h->h_bidx.size();
-        h->h_bss.assign((size_t)n * ny, 0.0);
-        // the first evaluation (MCMC_init's starting point) stays on the calling thread: user code commonly loads its
-        // data on first call (testcases/mcmcrun.F90:69-70) -- after that concurrent calls only read it
-        const int nt = h->inited ? std::max(1, std::min(h->h_threads, n)) : 1;
-        if (nt <= 1) { if (n > 0) h->h_ss_batch(h->h_bth.data(), d, n, ny, h->h_bss.data(), h->h_user); }
-        else {
-            std::vector<std::thread> pool;
-            for (int w = 0; w < nt; ++w) {
-                const int lo = (int)((long long)n * w / nt), hi = (int)((long long)n * (w + 1) / nt);
-                if (hi > lo) pool.emplace_back([=]() { h->h_ss_batch(h->h_bth.data() + (size_t)lo * d, d, hi - lo, ny,
-                    h->h_bss.data() + (size_t)lo * ny, h->h_user); });
-            }
-            for (auto &t : pool) t.join();
-        }
-        for (int i = 0; i < n; ++i) {
-            const int c = h->h_bidx[i], t = c / 64, l = c % 64;
-            for (int j = 0; j < ny; ++j) h_ev[((size_t)t * nhe + HE_SS + j) * 64 + l] = h->h_bss[(size_t)i * ny + j];
-        }
-        if (!mapped) HIPCHK(hipMemcpyAsync(h->E.hev, h->h_ev.data(), h->h_ev.size() * 8, hipMemcpyHostToDevice, h->stream));
-        return 0;
-    }
-    for (int c = 0; c < h->cfg.nchains; ++c) {
-        const int t = c / 64, l = c % 64;
-        if (use_stage2_flag && hx[((size_t)t * NHX + HX_STAGE2) * 64 + l] == 0.0) continue;
-        for (int k = 0; k < d; ++k) th[k] = h_cand[((size_t)t * stride_k + k) * 64 + l];
-        int inb = 1;
-        double pri = 0.0;
-        std::fill(ssc.begin(), ssc.end(), 0.0);
-        if (what == 2) {                                                             // MCMC_ssfunction_er(newpar, sscrit)
-            const double crit = hx[((size_t)t * NHX + HX_CRIT) * 64 + l];
-            if (h->h_ss_er) h->h_ss_er(th.data(), d, ny, crit, ssc.data(), h->h_user);
-            else h->h_ss(th.data(), d, ny, ssc.data(), h->h_user);                   // ssfunction_er0.f90: no er for ss
-        } else {
-            inb = h->h_cb ? h->h_cb(th.data(), d, h->h_user) : 1;                    // checkbounds0.f90: .true.
-            if (inb) {                                                               // MCMC_run.F90:54-56: prior first
-                pri = h->h_pri ? h->h_pri(th.data(), d, h->h_user) : 0.0;
-                if (what == 0) h->h_ss(th.data(), d, ny, ssc.data(), h->h_user);
-            }
-        }
-        h_ev[((size_t)t * nhe + HE_INB) * 64 + l] = inb ? 1.0 : 0.0;
-        h_ev[((size_t)t * nhe + HE_PRI) * 64 + l] = pri;
-        for (int j = 0; j < ny; ++j) h_ev[((size_t)t * nhe + HE_SS + j) * 64 + l] = ssc[j];
-    }
-    if (!mapped) HIPCHK(hipMemcpyAsync(h->E.hev, h->h_ev.data(), h->h_ev.size() * 8, hipMemcpyHostToDevice, h->stream));
-    return 0;
-}
-
-// fuse_next: iteration it + 1 follows without a tick in between -- its proposal (phase 0; SCAM: component 0's phase 5) rides in this
-// iteration's last launch, and h->p0_done tells the next call so (MCMCX_HOST_FUSE=0: one launch per phase, the A/B form the tests compare
-// with)
-static int host_iteration(mcmcx_engine *h, int it, bool fuse_next)
-{
-    const dim3 g(h->ntiles), b(64);
-    const double *rs = h->d_ramscale + it, *rs0 = h->d_ramscale;
-    const size_t lds = lds_step(h);
-    const bool fuse = h->sw.host_fuse != 0;
-    fuse_next = fuse_next && fuse;
-    const bool p0_done = h->p0_done;
-    h->p0_done = false;
-    if (h->cfg.method == MCMCX_METHOD_SCAM) {           // MCMC_run_scam: npar componentwise proposals, each evaluated by the host
-        for (int j = 0; j < h->d; ++j) {
-            if (!(j == 0 ? p0_done : fuse)) { hipLaunchKernelGGL((host_phase_kernel<5>), g, b, 0, h->stream, h->E, it, rs, j);
-                HIPCHK(hipGetLastError()); }
-            int rc = host_eval(h, h->E.cand, h->d, false); if (rc) return rc;
-            if (!fuse) hipLaunchKernelGGL((host_phase_kernel<6>), g, b, 0, h->stream, h->E, it, rs, j);
-            else if (j + 1 < h->d) hipLaunchKernelGGL((host_phase_seq_kernel<6, 5, -1>), g, b, 0, h->stream, h->E, it, j, it, j + 1, 0, 0,
-                rs0);
-            else if (fuse_next) { hipLaunchKernelGGL((host_phase_seq_kernel<6, 7, 5>), g, b, 0, h->stream, h->E, it, j, it, 0, it + 1, 0,
-                rs0); h->p0_done = true; }
-            else hipLaunchKernelGGL((host_phase_seq_kernel<6, 7, -1>), g, b, 0, h->stream, h->E, it, j, it, 0, 0, 0, rs0);
-            HIPCHK(hipGetLastError());
-        }
-        if (!fuse) { hipLaunchKernelGGL((host_phase_kernel<7>), g, b, 0, h->stream, h->E, it, rs, 0); HIPCHK(hipGetLastError()); }
-        return 0;
-    }
-    if (!p0_done) { hipLaunchKernelGGL((host_phase_kernel<0>), g, b, 0, h->stream, h->E, it, rs, 0); HIPCHK(hipGetLastError()); }
-    if (h->cfg.method == MCMCX_METHOD_ER) {             // MCMC_run_er: the threshold is drawn between priorfun and ssfunction_er
-        int rc = host_eval(h, h->E.cand, h->d, false, 1); if (rc) return rc;
-        hipLaunchKernelGGL((host_phase_kernel<3>), g, b, 0, h->stream, h->E, it, rs, 0);
-        HIPCHK(hipGetLastError());
-        rc = host_eval(h, h->E.cand, h->d, true, 2); if (rc) return rc;
-        if (fuse_next) { hipLaunchKernelGGL((host_phase_seq_kernel<4, 0, -1>), g, b, 0, h->stream, h->E, it, 0, it + 1, 0, 0, 0, rs0);
-            h->p0_done = true; }
-        else hipLaunchKernelGGL((host_phase_kernel<4>), g, b, 0, h->stream, h->E, it, rs, 0);
-        HIPCHK(hipGetLastError());
-        return 0;
-    }
-    int rc = host_eval(h, h->E.cand, h->d, false); if (rc) return rc;
-    if (fuse_next && !h->dodr) { hipLaunchKernelGGL((host_phase_seq_kernel<1, 0, -1>), g, b, 0, h->stream, h->E, it, 0, it + 1, 0, 0, 0,
-        rs0); h->p0_done = true; }
-    else hipLaunchKernelGGL((host_phase_kernel<1>), g, b, 0, h->stream, h->E, it, rs, 0);
-    HIPCHK(hipGetLastError());
-    if (h->dodr) {
-        rc = host_eval(h, h->E.cs, 2 * h->d, true); if (rc) return rc;
-        if (fuse_next) { hipLaunchKernelGGL((host_phase_seq_kernel<2, 0, -1>), g, b, lds, h->stream, h->E, it, 0, it + 1, 0, 0, 0, rs0);
-            h->p0_done = true; }
-        else hipLaunchKernelGGL((host_phase_kernel<2>), g, b, lds, h->stream, h->E, it, rs, 0);
-        HIPCHK(hipGetLastError());
-    }
-    return 0;
-}
-
-// ---- MCMC_run1 / MCMC_run1_er: the arithmetic of one invocation (run1_kernel), all chains at once, vectors row-major per chain
-static int run1_check(mcmcx_engine *h)
-{
-    if (!h) return fail(-1, "null handle");
-    if (!h->inited) return fail(-40, "we have not inited");                           // MCMC_run1.F90:55
-    if (!h->external) return
-        fail(-42, "mcmcx_run1_*: needs mcmcx_set_target_external (the caller evaluates ssfunction / priorfun / checkbounds)");
-    return 0;
-}
-static void run1_put(mcmcx_engine *h, int slot0, int K, const double *src /* [nchains][K] or nullptr */)
-{
-    const int n1 = 3 * h->d + 3 * h->ny + NR1;
-    for (int c = 0; c < h->cfg.nchains; ++c) {
-        const int t = c / 64, l = c % 64;
-        for (int k = 0; k < K; ++k) h->h_r1[((size_t)t * n1 + slot0 + k) * 64 + l] = src ? src[(size_t)c * K + k] : 0.0;
-    }
-}
-static void run1_get(mcmcx_engine *h, int slot0, int K, double *dst)
-{
-    const int n1 = 3 * h->d + 3 * h->ny + NR1;
-    for (int c = 0; c < h->cfg.nchains; ++c) {
-        const int t = c / 64, l = c % 64;
-        for (int k = 0; k < K; ++k) dst[(size_t)c * K + k] = h->h_r1[((size_t)t * n1 + slot0 + k) * 64 + l];
-    }
-}
-template <int MODE>
-static int run1_launch(mcmcx_engine *h, int drstage)
-{
-    HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(hipMemcpyAsync(h->d_r1, h->h_r1.data(), h->h_r1.size() * 8, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL((run1_kernel<MODE>), dim3(h->ntiles), dim3(64), MODE == 0 ? lds_step(h) : 0, h->stream, h->E, h->d_r1, drstage);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(h->h_r1.data(), h->d_r1, h->h_r1.size() * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return 0;
-}
+#include "mcx_host_engine.hpp"
+#include "mcx_host_linalg.hpp"
+#include "mcx_host_launch.hpp"
+#include "mcx_host_adapt.hpp"
+#include "mcx_host_pooled.hpp"
+#include "mcx_host_callbacks.hpp"
 
 // ------------------------------------------------------------------ C ABI
 extern "C" {
