@@ -12,4 +12,8 @@ case "$1" in
   c) HOST_FUZZ_SECONDS=240 python tools/host_fuzz.py 700000 720000 2>&1 | tee $O/host_fuzz_fused.txt | tail -n 3
      BIGNPAR_SECONDS=330 python tools/bignpar_fuzz.py 700000 720000 2>&1 | tee $O/bignpar_fuzz.txt | tail -n 3
      BIGNPAR_SECONDS=300 python tools/bignpar_fuzz.py 720000 740000 scam 2>&1 | tee $O/scam_npar_fuzz.txt | tail -n 3 ;;
+  d) BIGFUZZ_SECONDS=1000 python tools/bigfuzz.py 1000000 1300000 2>&1 | tee $O/bigfuzz_auto_2.txt | grep -E "^seed .*000 |configs|time limit|^\(" ;;
+  e) POOLED_FUZZ_SECONDS=330 python tools/pooled_restate_fuzz.py 800000 830000 2>&1 | tee $O/pooled_restate_fuzz_2.txt | tail -n 3
+     MCMCX_POOLED_WAVES=2 POOLED_FUZZ_SECONDS=330 python tools/pooled_restate_fuzz.py 830000 860000 ram 2>&1 | tee $O/pooled_ram_restate_fuzz_w2.txt | tail -n 3
+     BIGNPAR_SECONDS=330 python tools/bignpar_fuzz.py 800000 830000 2>&1 | tee $O/bignpar_fuzz_2.txt | tail -n 3 ;;
 esac

@@ -1,4 +1,5 @@
-// mcx_pooled2.hpp -- pooled AM / RAM / early rejection on the matrix cores with TWO WAVES PER TILE (round 5).  Included by mcx_api.hip.
+// tools/variants/mcx_pooled2.hpp -- a MEASURED NEGATIVE, not part of libmcmcx.so (tools/variants/README.md; included by variants.inc under -DMCX_VARIANTS).
+// Pooled AM / RAM / early rejection on the matrix cores with TWO WAVES PER TILE (round 5).
 //
 // pooled_mfma_kernel (mcx_kernels.hpp) runs one wave per tile of 64 chains.  Its iteration is half random numbers (VALU issue) and half
 // latency -- operand trips of the two products, the state's round trips, LDS transposes (profiles/r05_a/c4_pooled_phases.txt) -- and the one
