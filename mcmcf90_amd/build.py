@@ -17,7 +17,7 @@ import tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = ("mcx_api.hip", "mcx_host_engine.hpp", "mcx_host_linalg.hpp", "mcx_host_launch.hpp", "mcx_host_adapt.hpp", "mcx_host_pooled.hpp",
         "mcx_host_callbacks.hpp", "mcx_kernels.hpp", "mcx_common.hpp", "mcx_products.hpp", "mcx_step.hpp", "mcx_scam.hpp", "mcx_pooled.hpp",
-        "mcx_phase.hpp", "mcx_adapt.hpp", "mcx_svd.hpp", "mcx_moments.hpp", "mcx_group.hpp", "mcx_group_ram.hpp", "mcx_device.hpp", "mcx_comm.hpp")
+        "mcx_pooled_ks.hpp",        "mcx_phase.hpp", "mcx_adapt.hpp", "mcx_svd.hpp", "mcx_moments.hpp", "mcx_group.hpp", "mcx_group_ram.hpp", "mcx_device.hpp", "mcx_comm.hpp")
 SRC = [os.path.join(HERE, "csrc", f) for f in CSRC]
 HDR = os.path.join(os.path.dirname(HERE), "include", "mcmcx.h")
 LIB = os.path.join(HERE, "libmcmcx.so")

@@ -1,5 +1,7 @@
-// mcx_host_engine.hpp -- the engine object behind a mcmcx_handle: error reporting, the test switches, the host and device state of N chains, allocation helpers.
-// Part of the ONE translation unit mcx_api.hip (included there, in this order: mcx_host_engine, mcx_host_linalg, mcx_host_launch, mcx_host_adapt, mcx_host_pooled, mcx_host_callbacks); not a stand-alone header.
+// mcx_host_engine.hpp -- the engine object behind a mcmcx_handle: error reporting, the test switches, the host and device state of N
+// chains, allocation helpers.
+// Part of the ONE translation unit mcx_api.hip (included there, in this order: mcx_host_engine, mcx_host_linalg, mcx_host_launch,
+// mcx_host_adapt, mcx_host_pooled, mcx_host_callbacks); not a stand-alone header.
 
 using namespace mcx;
 static_assert(MCMCX_HE_INB == HE_INB && MCMCX_HE_PRI == HE_PRI && MCMCX_HE_SS == HE_SS && MCMCX_HX_STAGE2 == HX_STAGE2
@@ -22,14 +24,15 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // launch time.  -1 = not set.
 struct mcx_switches {
     int pooled_mfma_dr_min = -1, pooled_scalar = -1, dr_big = -1, scam_pooled_16 = -1, scam_fast_lanes = -1, scam_waves = -1,
-        svd_lane = -1, cov_batch_rows = -1, ram_wide = -1, pooled_waves = -1, cols_phased = -1, host_mapped = -1, host_fuse = -1;
+        svd_lane = -1, cov_batch_rows = -1, ram_wide = -1, pooled_waves = -1, pooled_ks = -1, cols_phased = -1, host_mapped = -1,
+            host_fuse = -1;
     static int get(const char *name) { const char *e = getenv(name); return e ? atoi(e) : -1; }
     void read()
     {
         pooled_mfma_dr_min = get("MCMCX_POOLED_MFMA_DR_MIN"); pooled_scalar = get("MCMCX_POOLED_SCALAR"); dr_big = get("MCMCX_DR_BIG");
         scam_pooled_16 = get("MCMCX_SCAM_POOLED_16"); scam_fast_lanes = get("MCMCX_SCAM_FAST_LANES");
         scam_waves = get("MCMCX_SCAM_WAVES"); svd_lane = get("MCMCX_SVD_LANE"); cov_batch_rows = get("MCMCX_COV_BATCH_ROWS");
-        ram_wide = get("MCMCX_RAM_WIDE"); pooled_waves = get("MCMCX_POOLED_WAVES");
+        ram_wide = get("MCMCX_RAM_WIDE"); pooled_waves = get("MCMCX_POOLED_WAVES"); pooled_ks = get("MCMCX_POOLED_KS");
         cols_phased = get("MCMCX_COLS_PHASED"); host_mapped = get("MCMCX_HOST_MAPPED"); host_fuse = get("MCMCX_HOST_FUSE");
     }
 };

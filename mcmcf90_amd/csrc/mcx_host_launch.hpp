@@ -1,5 +1,7 @@
-// mcx_host_launch.hpp -- which sampling kernel runs: cover predicates, the three selection tables (step / group / scam) and their launchers, the shared tables' uploads.
-// Part of the ONE translation unit mcx_api.hip (included there, in this order: mcx_host_engine, mcx_host_linalg, mcx_host_launch, mcx_host_adapt, mcx_host_pooled, mcx_host_callbacks); not a stand-alone header.
+// mcx_host_launch.hpp -- which sampling kernel runs: cover predicates, the three selection tables (step / group / scam) and their
+// launchers, the shared tables' uploads.
+// Part of the ONE translation unit mcx_api.hip (included there, in this order: mcx_host_engine, mcx_host_linalg, mcx_host_launch,
+// mcx_host_adapt, mcx_host_pooled, mcx_host_callbacks); not a stand-alone header.
 
 // LDS of pooled_mfma_kernel: the tile's vector [d4][64] (+ the products [16 nt][64] when they need more than one pass)
 // and the partial ss chains [4 nt][64]
@@ -219,6 +221,20 @@ static bool pooled_two_waves(const mcmcx_engine *h)
     if (h->sw.pooled_waves == 1 || h->sw.pooled_waves == 2) return h->sw.pooled_waves == 2;
     return h->ntiles >= (pooled_mfma_lds(h->d) * 8 <= 160 * 1024 ? 2048 : 8192);
 }
+// pooled_mfma_ks_kernel: the forty-row LDS vector (eight tiles on a CU whatever npar is) where the whole vector leaves fewer, for the
+// problems that fill those CUs: npar 41..64, no delayed rejection, and two tiles per SIMD or more.  Against pooled_mfma_kernel<false, true>
+// at 16384 tiles (tools/pooled_ks_sweep.py, profiles/r06_j): 1.00 at npar 41 / 44 (seven tiles there), 1.06 .. 1.10 at 45..52 (six),
+// 1.12 .. 1.25 at 53..64 (five); with a non-Gaussian target 1.05 .. 1.42.  Against what the engine took before at fewer tiles
+// (tools/pooled_ks_tiles.py; pooled_mfma_kernel<false> below 8192): 1.15 .. 1.22 at 2048 / 4096 tiles for npar 45 / 50, 0.98 / 1.02 at 64;
+// 0.63 .. 0.69 at 1024 tiles (one per SIMD: the spills are all two waves buy there).
+static bool pooled_forty_rows(const mcmcx_engine *h)
+{
+    const int d4 = (h->d + 3) & ~3;
+    if (!pooled_use_mfma(h) || h->dodr || d4 <= PKS || d4 > 64) return false;
+    // (test switch: either form on a small problem)
+    if (h->sw.pooled_ks == 0 || h->sw.pooled_ks == 1) return h->sw.pooled_ks == 1;
+    return h->sw.pooled_waves != 1 && h->ntiles >= 2048;
+}
 #define STEP_ARGS h->stream, h->E, it0, it1
 #define STEP_RS (h->d_ramscale + it0)
 #define STEP_TGT h->E.tgt.mu, h->E.tgt.lamT
@@ -269,17 +285,20 @@ static const KernelEntry STEP_TABLE[] = {
     // ---- a device target with response columns (nycol >= 1 sums of squares per point): the phases of an iteration in one launch
     // (one instantiation per method class: MCMC_run_ram's carries the rank-one update's panels, the others do not)
     {"step", "step_kernel_cols<ram>", [](const mcmcx_engine *h) { return fused_cols(h) && h->E.method == M_RAM; },
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_cols<1>, G1, lds_step(h), STEP_ARGS, (const double *)h->d_ramscale,
-                                                                (const double *)nullptr, (const double *)nullptr, (const double *)nullptr); }},
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_cols<1>, G1, lds_step(h), STEP_ARGS,
+         (const double *)h->d_ramscale, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr); }},
     {"step", "step_kernel_cols", fused_cols,
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_cols<0>, G1, lds_step(h), STEP_ARGS, (const double *)h->d_ramscale,
-                                                                (const double *)(h->pooled ? h->E.sharedR : nullptr),
-                                                                (const double *)h->d_sharedR2, (const double *)h->d_sharediC); }},
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(step_kernel_cols<0>, G1, lds_step(h), STEP_ARGS,
+         (const double *)h->d_ramscale, (const double *)(h->pooled ? h->E.sharedR : nullptr), (const double *)h->d_sharedR2,
+         (const double *)h->d_sharediC); }},
     // ---- pooled mode (one shared factor)
     {"step", "pooled_mfma_kernel<true>", [](const mcmcx_engine *h) { return pooled_use_mfma(h) && h->dodr != 0; },
      [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(pooled_mfma_kernel<true>, G1, pooled_mfma_lds(h->d), STEP_ARGS, STEP_TGT,
          h->d_sharedRT, h->d_sharedR2T, h->d_sharediCd); }},
     MCX_VARIANT_STEP_ENTRIES
+    {"step", "pooled_mfma_ks_kernel", pooled_forty_rows,
+     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(pooled_mfma_ks_kernel, G1, (size_t)PKS * 64 * sizeof(double), STEP_ARGS,
+         STEP_TGT, h->d_sharedRT); }},
     {"step", "pooled_mfma_kernel<false, true>", [](const mcmcx_engine *h) { return pooled_use_mfma(h) && pooled_two_waves(h); },
      [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((pooled_mfma_kernel<false, true>), G1, pooled_mfma_lds(h->d), STEP_ARGS,
          STEP_TGT, h->d_sharedRT, (const double *)nullptr, (const double *)nullptr); }},

@@ -14,6 +14,7 @@
 //   mcx_step.hpp      step_kernel<RAM,DR,POOLED> and its forms (the headline kernel: step_kernel_ram_wide), ram_update, dr_body
 //   mcx_scam.hpp      scam_kernel / scam_mw_kernel (per-chain rotation), scam_pooled(12)_kernel (pooled rotation, f64 MFMA)
 //   mcx_pooled.hpp    pooled_mfma_kernel (pooled AM / RAM / ER / DR on the f64 matrix cores)
+//   mcx_pooled_ks.hpp pooled_mfma_ks_kernel (the same with a forty-row LDS vector in two pieces: eight tiles per CU at npar 41..64)
 //   mcx_phase.hpp     host_phase_kernel<0..7>, dev_eval_kernel, step_kernel_cols (nycol >= 1), run1_kernel
 //   mcx_adapt.hpp     init_kernel, adapt_pre / adapt_cov_diag / adapt_cov_off / adapt_covb_* / adapt_post kernels
 //   mcx_svd.hpp       svd_sweep_stream(32)_kernel, svd_applyv_stream32_kernel, tile <-> chain layout conversion
@@ -26,6 +27,7 @@
 #include "mcx_step.hpp"
 #include "mcx_scam.hpp"
 #include "mcx_pooled.hpp"
+#include "mcx_pooled_ks.hpp"
 #include "mcx_phase.hpp"
 #include "mcx_adapt.hpp"
 #include "mcx_svd.hpp"

@@ -103,17 +103,20 @@ def test_c4_gauss50_ram_1048576_chains(oracle):
 
 def test_c4_gauss50_pooled_ram_1048576_chains(oracle, monkeypatch):
     """... and its pooled twin (bench.py's `c4_pooled`: one shared factor, the RAM statistic of all chains folded in every adaptint
-    iterations): at 16384 tiles the engine takes pooled_mfma_kernel<false, true> (two waves per SIMD) by itself.  Chains from both ends and
+    iterations): at 16384 tiles the engine takes pooled_mfma_ks_kernel (two waves per SIMD, the LDS vector in two pieces of forty rows: eight
+    tiles per CU) by itself, and pooled_mfma_kernel<false, true> when that form is switched off.  Chains from both ends and
     the middle of the range are the single-chain oracle with the factor fixed (up to the tick at 100) and, carried on with the engine's
-    pooled factor, to the end; the one-wave-per-SIMD instance gives the same 1 048 576 states, ballots and pooled factor bit for bit."""
+    pooled factor, to the end; the whole-vector and the one-wave-per-SIMD instances give the same 1 048 576 states, ballots and pooled factor
+    bit for bit."""
     from mcmcf90_amd import engine_from_problem
     from mcmcf90_amd.workloads import problem
     n, nsimu, tick = 1048576, 130, 100
     ckw, pkw, _ = problem("c4", nsimu, adaptint=tick)
     monkeypatch.delenv("MCMCX_POOLED_WAVES", raising=False)
+    monkeypatch.delenv("MCMCX_POOLED_KS", raising=False)
     e = engine_from_problem(ckw, pkw, nchains=n, pooled=1, record_accept=1)
     e.init(); e.run(tick)
-    assert e.last_kernel() == "pooled_mfma_kernel<false, true>", e.last_kernel()
+    assert e.last_kernel() == "pooled_mfma_ks_kernel", e.last_kernel()
     plain = oracle.make_cfg(**dict(ckw, doadapt=0, method="dram"))
     prob = oracle.Problem(**pkw)
     picks = [0, 63, 524288, 1048575]
@@ -135,13 +138,14 @@ def test_c4_gauss50_pooled_ram_1048576_chains(oracle, monkeypatch):
     pop = int(np.unpackbits(masks.view(np.uint8)).sum())
     assert pop == n * nsimu - tot["stayed"] and tot["proposals"] == n * (nsimu - 1) and tot["status"] == 0
     e.close()
-    monkeypatch.setenv("MCMCX_POOLED_WAVES", "1")
-    e1 = engine_from_problem(ckw, pkw, nchains=n, pooled=1, record_accept=1)
-    e1.init(); e1.run()
-    assert e1.last_kernel() == "pooled_mfma_kernel<false>", e1.last_kernel()
-    assert np.array_equal(_bits(e1.theta()), _bits(th)) and np.array_equal(e1.accept_masks(), masks)
-    np.testing.assert_array_equal(_bits(e1.pooled()[3]), _bits(R))
-    e1.close()
+    for switch, value, kernel in (("MCMCX_POOLED_KS", "0", "pooled_mfma_kernel<false, true>"), ("MCMCX_POOLED_WAVES", "1", "pooled_mfma_kernel<false>")):
+        monkeypatch.setenv(switch, value)
+        e1 = engine_from_problem(ckw, pkw, nchains=n, pooled=1, record_accept=1)
+        e1.init(); e1.run()
+        assert e1.last_kernel() == kernel, e1.last_kernel()
+        assert np.array_equal(_bits(e1.theta()), _bits(th)) and np.array_equal(e1.accept_masks(), masks)
+        np.testing.assert_array_equal(_bits(e1.pooled()[3]), _bits(R))
+        e1.close()
 
 
 def test_c5_illcond200_scam_pooled_65536_chains(oracle):

@@ -399,7 +399,8 @@ def test_pooled_am_matrix_core_kernel_equals_lane_kernel(seed, waves, monkeypatc
     """pooled_mfma_kernel (products as MFMA tiles) == the lane-per-chain pooled kernel, for random sizes (one to three
     passes of output blocks, ragged last block and k-block), targets, bounds, priors and the sigma2 update.  waves = 2: the
     instance that shares a SIMD between two waves (pooled_mfma_kernel<false, true>; the engine's own choice from 2048 tiles on -- the kernel
-    behind bench.py's c4_pooled: sixty of the ninety draws go to it, the suite time the two-waves-per-tile variants used to take)."""
+    behind bench.py's c4_pooled: sixty of the ninety draws go to it, the suite time the two-waves-per-tile variants used to take); the last
+    thirty of them run pooled_mfma_ks_kernel (the LDS vector in two pieces of forty rows) where npar is 41..64."""
     from mcmcf90_amd import engine_from_problem
     monkeypatch.setenv("MCMCX_POOLED_WAVES", str(waves))
     r = np.random.default_rng(11000 + seed)
@@ -419,9 +420,11 @@ def test_pooled_am_matrix_core_kernel_equals_lane_kernel(seed, waves, monkeypatc
         pkw.update(lo=np.full(d, -1.0), hi=np.full(d, 1.2))
     if r.random() < 0.4:
         pkw.update(pri_mu=np.zeros(d), pri_sig=np.where(r.random(d) < 0.5, 0.0, 1.0))
+    ks = waves == 2 and seed >= 60 and 40 < d <= 64
+    monkeypatch.setenv("MCMCX_POOLED_KS", "1" if ks else "0")
     e = engine_from_problem(ckw, pkw, nchains=n, pooled=1, record_accept=1)
     e.init(); e.run()
-    assert e.last_kernel() == {1: "pooled_mfma_kernel<false>", 2: "pooled_mfma_kernel<false, true>"}[waves], e.last_kernel()
+    assert e.last_kernel() == ("pooled_mfma_ks_kernel" if ks else {1: "pooled_mfma_kernel<false>", 2: "pooled_mfma_kernel<false, true>"}[waves]), e.last_kernel()
     monkeypatch.setenv("MCMCX_POOLED_SCALAR", "1")
     e2 = engine_from_problem(ckw, pkw, nchains=n, pooled=1, record_accept=1)
     e2.init(); e2.run()

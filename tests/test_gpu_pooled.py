@@ -716,6 +716,10 @@ def test_pooled_delayed_rejection_and_er_match_restatement(oracle, name, extra, 
     ("er_48", 48, 140, dict(method="er"), "gauss"), ("er_20_s2_priors", 20, 130, dict(method="er", updatesigma=1), "gauss"),
     ("am_49_bounds_priors", 49, 140, dict(), "gauss"), ("banana_24", 24, 130, dict(), "banana"), ("am_50_record", 50, 130, dict(), "gauss"),
     ("burnin_up_32", 32, 130, dict(doburnin=1, burnintime=160, badaptint=50, scalelimit=0.3), "gauss"), ("svd_20", 20, 130, dict(condmax=1e8), "gauss"),
+    # npar 41..64: the forty-row form too (every class of npar rounded up to four, odd and even counts of deviates beyond the cut)
+    ("am_41", 41, 130, dict(), "gauss"), ("am_45_s2", 45, 140, dict(updatesigma=1), "gauss"), ("banana_53", 53, 130, dict(), "banana"),
+    ("svd_57", 57, 130, dict(condmax=1e8), "gauss"), ("burnin_up_60", 60, 130, dict(doburnin=1, burnintime=160, badaptint=50, scalelimit=0.3), "gauss"),
+    ("er_63_s2_priors", 63, 130, dict(method="er", updatesigma=1), "gauss"), ("am_52_bounds_record", 52, 200, dict(), "gauss"),
 ])
 def test_pooled_two_waves_per_simd_matches_restatement(oracle, name, d, N, extra, kind, monkeypatch):
     """pooled_mfma_kernel<false, true> -- the instance behind bench.py's c4_pooled: 256 registers, two waves per SIMD, part of the state spilled
@@ -723,7 +727,9 @@ def test_pooled_two_waves_per_simd_matches_restatement(oracle, name, d, N, extra
     chain of pooled_mfma_kernel<false> bit for bit and the restatement's: two to four output blocks, odd and even npar (the cached second deviate),
     ragged tiles, the sigma2 update, early rejection, bounds and priors and a non-Gaussian target, the SVD factor (a full, non-triangular table),
     burn-in scaling, the history ring and accept masks of a recorded chain.  (Up to round 5 these cases ran the two-waves-per-tile and
-    half-tile variants, which are no longer in the library: tools/variants/README.md.)"""
+    half-tile variants, which are no longer in the library: tools/variants/README.md.)
+    At npar 41..64 a third run: pooled_mfma_ks_kernel (the LDS vector in two pieces of forty rows, eight tiles per CU; the engine's own choice
+    from 2048 tiles on, MCMCX_POOLED_KS=1 here) -- the same chain again, bit for bit."""
     from mcmcf90_amd import engine_from_problem
     nsimu = 230
     ckw = dict(dict(nsimu=nsimu, adaptint=100, updatesigma=0, N0=1.0, S02=0.5), **extra)
@@ -741,11 +747,12 @@ def test_pooled_two_waves_per_simd_matches_restatement(oracle, name, d, N, extra
         pkw = dict(kind="banana", npar=d, par0=np.zeros(d), cmat0=(1.0 / d) * np.eye(d), b=0.1)
     ekw = dict(record_chain=1) if "record" in name else {}
     res = []
-    for waves in ("2", "1"):
-        monkeypatch.setenv("MCMCX_POOLED_WAVES", waves)
+    for waves in (("ks",) if 40 < d <= 64 else ()) + ("2", "1"):
+        monkeypatch.setenv("MCMCX_POOLED_WAVES", "2" if waves == "ks" else waves)
+        monkeypatch.setenv("MCMCX_POOLED_KS", "1" if waves == "ks" else "0")
         e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1, **ekw)
         e.init(); e.run(57); e.run()
-        assert e.last_kernel() == {"2": "pooled_mfma_kernel<false, true>", "1": "pooled_mfma_kernel<false>"}[waves], e.last_kernel()
+        assert e.last_kernel() == {"ks": "pooled_mfma_ks_kernel", "2": "pooled_mfma_kernel<false, true>", "1": "pooled_mfma_kernel<false>"}[waves], e.last_kernel()
         res.append(dict(theta=e.theta().copy(), masks=e.accept_masks().copy(), scal=e.scalars().copy(), rng=[e.rng(c) for c in (0, 31, 32, 63, 64, N - 1)],
                         ctr=[e.counters(c) for c in (0, 33, N - 1)], pooled=e.pooled(), tot=e.totals(),
                         chain=[e.chain(c) for c in (0, 35, N - 1)] if ekw else []))
@@ -888,7 +895,8 @@ def _restate_pooled_ram(oracle, ckw, pkw, N):
 
 @pytest.mark.parametrize("d,N,mfma,condmax", [(6, 150, 0, 0.0), (6, 150, 1, 0.0), (50, 200, 1, 0.0), (6, 150, 0, 1e8), (6, 150, 1, 25.0), (20, 130, 1, 1e8),
                                               (50, 200, 2, 0.0), (20, 130, 2, 1e8),           # mfma = 2: pooled_mfma_kernel<false, true> (two waves per SIMD)
-                                              (33, 140, 2, 0.0), (64, 200, 2, 0.0), (17, 130, 2, 25.0)])
+                                              (33, 140, 2, 0.0), (64, 200, 2, 0.0), (17, 130, 2, 25.0),
+                                              (50, 200, 3, 0.0), (64, 200, 3, 0.0), (45, 130, 3, 1e8), (57, 140, 3, 25.0)])    # 3: pooled_mfma_ks_kernel
 def test_pooled_ram_matches_restatement(oracle, d, N, mfma, condmax, monkeypatch):
     """method = 'ram', pooled = 1: one factor for all chains; every adaptint iterations the chains' rank-one RAM
     statistics sign(a) x x' (MCMC_run_ram.F90:166-172) of that iteration are averaged over all chains and folded into
@@ -898,7 +906,8 @@ def test_pooled_ram_matches_restatement(oracle, d, N, mfma, condmax, monkeypatch
     from mcmcf90_amd import engine_from_problem
     if not mfma:
         monkeypatch.setenv("MCMCX_POOLED_SCALAR", "1")
-    monkeypatch.setenv("MCMCX_POOLED_WAVES", str(mfma) if mfma >= 2 else "1")
+    monkeypatch.setenv("MCMCX_POOLED_WAVES", "2" if mfma >= 2 else "1")
+    monkeypatch.setenv("MCMCX_POOLED_KS", "1" if mfma == 3 else "0")
     nsimu, adaptint, nu, target = 130, 20, 0.7, 0.234
     ckw = dict(nsimu=nsimu, method="ram", adaptint=adaptint, updatesigma=0, nuparam=nu, alphatarget=target, condmax=condmax)
     rng = np.random.default_rng(d)
@@ -907,7 +916,8 @@ def test_pooled_ram_matches_restatement(oracle, d, N, mfma, condmax, monkeypatch
     pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.2), cmat0=cm0, mu=np.zeros(d), lam=A @ A.T + np.eye(d))
     e = engine_from_problem(ckw, pkw, nchains=N, pooled=1, record_accept=1)
     e.init(); e.run()
-    assert e.last_kernel() == {0: "step_kernel<false, false, true>", 1: "pooled_mfma_kernel<false>", 2: "pooled_mfma_kernel<false, true>"}[mfma], e.last_kernel()
+    assert e.last_kernel() == {0: "step_kernel<false, false, true>", 1: "pooled_mfma_kernel<false>", 2: "pooled_mfma_kernel<false, true>",
+                               3: "pooled_mfma_ks_kernel"}[mfma], e.last_kernel()
     chains, R, st, floored = _restate_pooled_ram(oracle, ckw, pkw, N)
     theta = np.array([ch.theta for ch in chains])
     np.testing.assert_array_equal(_bits(e.theta()), _bits(theta))

@@ -1,8 +1,7 @@
-"""tools/pooled_ks_check.py -- pooled_mfma_ks_kernel (the tile's LDS vector in two pieces of 40 rows: eight tiles per CU at npar 41..64) against
-pooled_mfma_kernel<false, true> (MCMCX_POOLED_KS=0) on the same configurations, bit for bit -- states, accept ballots, stream positions, scalars, the
-pooled factor -- and both timed at BASELINE config 4's size.  A measured negative (tools/variants/mcx_pooled_ks.hpp): needs a variant build,
-    tools/build_variant.sh neg -DMCX_VARIANTS; MCMCX_LIBRARY=$PWD/variants_build/libmcmcx_neg.so python tools/pooled_ks_check.py
-GPU box."""
+"""tools/pooled_ks_check.py -- pooled_mfma_ks_kernel (the tile's LDS vector in two pieces of forty rows: eight tiles per CU at npar 41..64,
+MCMCX_POOLED_KS=1) against pooled_mfma_kernel<false, true> (MCMCX_POOLED_KS=0) on the same 77 configurations, bit for bit -- states, accept
+ballots, stream positions, scalars, the pooled factor -- and both timed at BASELINE config 4's size.  The kernel's development harness (it was a
+tools/variants form until it won: docs/history/r06.md section 8c); the suite's own cases are tests/test_gpu_pooled.py.  GPU box."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -20,7 +20,7 @@ def _bits(a):
 
 def run(ckw, pkw, n, env, want, **ekw):
     from mcmcf90_amd import engine_from_problem
-    for k in ("MCMCX_POOLED_WAVES", "MCMCX_DR_GENERAL", "MCMCX_SVD_SHARED_ROT", "MCMCX_GROUP", "MCMCX_DR_BIG", "MCMCX_COV_FIFO", "MCMCX_POOLED_KS"):
+    for k in ("MCMCX_POOLED_WAVES", "MCMCX_DR_GENERAL", "MCMCX_SVD_SHARED_ROT", "MCMCX_GROUP", "MCMCX_DR_BIG", "MCMCX_COV_FIFO"):
         os.environ.pop(k, None)
     os.environ.update(env)
     e = engine_from_problem(ckw, pkw, nchains=n, record_accept=1, **ekw)
@@ -68,12 +68,6 @@ def main():
         pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.05), cmat0=(0.5 / d) * np.eye(d), mu=np.linspace(-1, 1, d), lam=A @ A.T + np.eye(d))
         base = run(ckw, pkw, 200, {}, None)
         ok &= same(run(ckw, pkw, 200, {"MCMCX_COV_FIFO": "1"}, None), base, "adapt_cov_{diag,off}_fifo_kernel npar %d" % d)
-    for d in (41, 50, 64):                                      # the pooled kernel's LDS vector in two pieces (round 6); 77 more cases: tools/pooled_ks_check.py
-        A = rng.standard_normal((d, d)) / np.sqrt(d)
-        ckw = dict(nsimu=230, adaptint=100, updatesigma=0)
-        pkw = dict(kind="gauss", npar=d, par0=np.full(d, 0.3), cmat0=(0.3 / d) * np.eye(d), mu=np.linspace(-1, 1, d), lam=A @ A.T + np.eye(d))
-        base = run(ckw, pkw, 140, {"MCMCX_POOLED_WAVES": "2"}, "pooled_mfma_kernel<false, true>", pooled=1)
-        ok &= same(run(ckw, pkw, 140, {"MCMCX_POOLED_WAVES": "2", "MCMCX_POOLED_KS": "1"}, "pooled_mfma_ks_kernel", pooled=1), base, "pooled_mfma_ks_kernel npar %d" % d)
     print("all bit-equal" if ok else "DIFFERENCES FOUND")
     sys.exit(0 if ok else 1)
 
