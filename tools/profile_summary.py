@@ -9,7 +9,7 @@ import csv, glob, hashlib, json, os, statistics, sys
 
 out = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ("step_kernel", "scam_pooled_kernel", "scam_pooled12_kernel", "scam_kernel", "pooled_mfma_kernel")
+KERNELS = ("step_kernel", "scam_pooled_kernel", "scam_pooled12_kernel", "scam_kernel", "pooled_mfma_kernel", "pooled_mfma_ks_kernel")
 
 
 sys.path.insert(0, ROOT)
