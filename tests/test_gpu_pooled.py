@@ -5,6 +5,7 @@ moment tree / merge / Cholesky written out in Python floats in the engine's oper
 accept masks and the shared factor must agree bit for bit.  A second test splits the chains over two engines
 that exchange their moment vectors through the exchange hook (the RCCL all-reduce of the multi-GPU run)."""
 import ctypes as C
+import os
 import math
 import threading
 import numpy as np
@@ -526,11 +527,17 @@ def _restate_pooled(oracle, ckw, pkw, N, nranks=1):
     return chains, st, log
 
 
+def _fuzz_npar(default):
+    """the sizes a random pooled configuration draws from; POOLED_FUZZ_NPAR=41,45,... narrows tools/pooled_restate_fuzz.py to one kernel's range"""
+    e = os.environ.get("POOLED_FUZZ_NPAR")
+    return [int(x) for x in e.split(",")] if e else default
+
+
 def _draw_pooled(seed):
     """A random pooled configuration: AM / delayed rejection / early rejection; burn-in scaling, greedy, AP window, adaptend, initcmatn; sigma2
     update, bounds, priors; Gaussian and banana targets; npar 2..64; ragged tiles (tools/pooled_restate_fuzz.py runs thousands of these)."""
     r = np.random.default_rng(91000 + seed)
-    d = int(r.choice([2, 3, 5, 8, 13, 16, 17, 20, 24, 31, 33, 48, 50, 64]))
+    d = int(r.choice(_fuzz_npar([2, 3, 5, 8, 13, 16, 17, 20, 24, 31, 33, 48, 50, 64])))
     N = int(r.choice([66, 70, 130, 200]))
     nsimu = int(r.integers(150, 330))
     ckw = dict(nsimu=nsimu, adaptint=int(r.choice([40, 50, 100])), updatesigma=int(r.random() < 0.3))
@@ -936,7 +943,7 @@ def test_pooled_ram_matches_restatement(oracle, d, N, mfma, condmax, monkeypatch
 
 def _draw_pooled_ram(seed):
     r = np.random.default_rng(93000 + seed)
-    d = int(r.choice([2, 5, 6, 13, 16, 17, 20, 33, 50, 64]))
+    d = int(r.choice(_fuzz_npar([2, 5, 6, 13, 16, 17, 20, 33, 50, 64])))
     N = int(r.choice([66, 70, 130, 200]))
     condmax = float(r.choice([0.0, 0.0, 0.0, 1e8, 25.0]))
     ckw = dict(nsimu=int(r.integers(60, 160)), method="ram", adaptint=int(r.choice([10, 20, 50])), updatesigma=0, nuparam=float(r.choice([0.6, 0.7, 0.9])),

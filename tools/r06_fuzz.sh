@@ -16,4 +16,8 @@ case "$1" in
   e) POOLED_FUZZ_SECONDS=330 python tools/pooled_restate_fuzz.py 800000 830000 2>&1 | tee $O/pooled_restate_fuzz_2.txt | tail -n 3
      MCMCX_POOLED_WAVES=2 POOLED_FUZZ_SECONDS=330 python tools/pooled_restate_fuzz.py 830000 860000 ram 2>&1 | tee $O/pooled_ram_restate_fuzz_w2.txt | tail -n 3
      BIGNPAR_SECONDS=330 python tools/bignpar_fuzz.py 800000 830000 2>&1 | tee $O/bignpar_fuzz_2.txt | tail -n 3 ;;
+  f) export MCMCX_POOLED_WAVES=2 MCMCX_POOLED_KS=1 POOLED_FUZZ_NPAR=41,42,43,44,45,47,48,49,50,51,52,53,55,56,57,59,60,61,63,64    # pooled_mfma_ks_kernel
+     O=gpurun_out/r06k; mkdir -p $O
+     POOLED_FUZZ_SECONDS=400 python tools/pooled_restate_fuzz.py 900000 930000 2>&1 | tee $O/pooled_restate_fuzz_ks.txt | tail -n 3
+     POOLED_FUZZ_SECONDS=400 python tools/pooled_restate_fuzz.py 930000 960000 ram 2>&1 | tee $O/pooled_ram_restate_fuzz_ks.txt | tail -n 3 ;;
 esac
