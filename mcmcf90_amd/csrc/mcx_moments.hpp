@@ -6,6 +6,31 @@
 
 namespace mcx {
 
+// The xor-butterfly's tree over 64 values (adjacent lanes first: v_l + v_{l^1}, (..) + (..)_{l^2}, ...; the sum it leaves in lane 0)
+// for values that are PRODUCED as they are needed: eight at a time summed in their tree, the eight group sums through a binary counter
+// of three partial sums -- the same additions with the same operands on the same sides as the array form, so the same bits.  The loop
+// over the groups is a real loop: unrolled, the scheduler asks for all 128 LDS values first (the array form cost moments_kernel 260
+// registers and all but one block per CU; a fully unrolled counter under __launch_bounds__(256, 4) spilled 20 of them).  Round 6.
+template <class F>
+MCX_DEV double tree64(F &&val)
+{
+    double s3 = 0.0, s4 = 0.0, s5 = 0.0, res = 0.0;      // sums of 8, 16, 32 values waiting for their partner
+#pragma clang loop unroll(disable)
+    for (int g = 0; g < 8; ++g) {
+        const int l = 8 * g;
+        const double v0 = val(l), v1 = val(l + 1), v2 = val(l + 2), v3 = val(l + 3);
+        const double v4 = val(l + 4), v5 = val(l + 5), v6 = val(l + 6), v7 = val(l + 7);
+        double v = ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
+        if (!(g & 1)) { s3 = v; continue; }
+        v = s3 + v;
+        if (!(g & 2)) { s4 = v; continue; }
+        v = s4 + v;
+        if (!(g & 4)) { s5 = v; continue; }
+        res = s5 + v;
+    }
+    return res;
+}
+
 // ---------------------------------------------------------------- pooled moments of the current states
 // out[tile][1 + d + d(d+1)/2]: partial sums over the 64 lanes of a tile by an xor-butterfly (a fixed
 // pairwise tree: adjacent lanes first); the host finishes the tree over tiles, RCCL over GPUs.
@@ -23,7 +48,7 @@ __global__ __launch_bounds__(256) void moments_kernel(EngineDev E, double *out, 
 {
     // The tile's 64 vectors x_c go to LDS once (chain-major, odd stride); then each of the 256 threads takes terms m, m + 256, ...:
     // it forms the term's 64 values (one per chain) and adds them in the butterfly's tree order (lane pairs first) -- the sums
-    // v_l + v_{l^1}, (..) + (..)_{l^2}, ... a xor-butterfly leaves in lane 0 -- in registers.  No barrier after the first, every
+    // v_l + v_{l^1}, (..) + (..)_{l^2}, ... a xor-butterfly leaves in lane 0 -- as they come (tree64).  No barrier after the first, every
     // lane on a term of its own; the old form (one chain per lane, 64 terms at a time transposed through LDS) spent its time
     // in the latencies of 1300 global loads and 2 x 20 barriers per tile at four waves per CU.
     extern __shared__ double XS[];                      // x[64][DP]; then count[64], alpha or stayed [64], sign(a) [64], sum(u**2) [64]
@@ -68,38 +93,21 @@ __global__ __launch_bounds__(256) void moments_kernel(EngineDev E, double *out, 
     };
     const int pair0 = (kind == 2) ? 2 : 1 + d;          // first second-moment term
     for (int m = tid; m < len; m += 256) {
-        double a[64];
-        if (m == 0) {
-#pragma unroll
-            for (int l = 0; l < 64; ++l) a[l] = sp0[l];
-        } else if (m < pair0 && kind == 2) {
-#pragma unroll
-            for (int l = 0; l < 64; ++l) a[l] = sp1[l];
-        } else if (m < pair0) {
-#pragma unroll
-            for (int l = 0; l < 64; ++l) a[l] = xv(l, m - 1);
-        } else if (m >= pair0 + P) {                    // kind 1: the rejection counts
-#pragma unroll
-            for (int l = 0; l < 64; ++l) a[l] = sp1[l];
-        } else {
+        double r;
+        if (m == 0) r = tree64([&](int l) { return sp0[l]; });
+        else if (m < pair0 && kind == 2) r = tree64([&](int l) { return sp1[l]; });
+        else if (m < pair0) r = tree64([&](int l) { return xv(l, m - 1); });
+        else if (m >= pair0 + P) r = tree64([&](int l) { return sp1[l]; });          // kind 1: the rejection counts
+        else {
             const int q = m - pair0;                    // = j (j + 1) / 2 + i, i <= j
             int j = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
             while ((j + 1) * (j + 2) / 2 <= q) ++j;
             while (j * (j + 1) / 2 > q) --j;
             const int i2 = q - j * (j + 1) / 2;
-            if (kind == 2) {
-#pragma unroll
-                for (int l = 0; l < 64; ++l) { const double t = xv(l, i2) * xv(l, j); a[l] = (sg[l] >= 0.0) ? t : -t; }
-            } else {
-#pragma unroll
-                for (int l = 0; l < 64; ++l) a[l] = xv(l, i2) * xv(l, j);
-            }
+            if (kind == 2) r = tree64([&](int l) { const double t = xv(l, i2) * xv(l, j); return (sg[l] >= 0.0) ? t : -t; });
+            else r = tree64([&](int l) { return xv(l, i2) * xv(l, j); });
         }
-#pragma unroll
-        for (int s2 = 1; s2 < 64; s2 <<= 1)
-#pragma unroll
-            for (int l = 0; l + s2 < 64; l += 2 * s2) a[l] = a[l] + a[l + s2];
-        o[m] = a[0];
+        o[m] = r;
     }
 }
 
