@@ -297,8 +297,11 @@ static const KernelEntry STEP_TABLE[] = {
          h->d_sharedRT, h->d_sharedR2T, h->d_sharediCd); }},
     MCX_VARIANT_STEP_ENTRIES
     {"step", "pooled_mfma_ks_kernel", pooled_forty_rows,
-     [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL(pooled_mfma_ks_kernel, G1, (size_t)PKS * 64 * sizeof(double), STEP_ARGS,
-         STEP_TGT, h->d_sharedRT); }},
+     [](mcmcx_engine *h, int it0, int it1) {
+         // (npar 49..52: the fourth output block has four rows and goes through the 4 x 4 x 4 instruction)
+         const size_t lds = (size_t)PKS * 64 * sizeof(double);
+         if (((h->d + 3) & ~3) == 52) hipLaunchKernelGGL(pooled_mfma_ks_kernel<true>, G1, lds, STEP_ARGS, STEP_TGT, h->d_sharedRT);
+         else hipLaunchKernelGGL(pooled_mfma_ks_kernel<false>, G1, lds, STEP_ARGS, STEP_TGT, h->d_sharedRT); }},
     {"step", "pooled_mfma_kernel<false, true>", [](const mcmcx_engine *h) { return pooled_use_mfma(h) && pooled_two_waves(h); },
      [](mcmcx_engine *h, int it0, int it1) { hipLaunchKernelGGL((pooled_mfma_kernel<false, true>), G1, pooled_mfma_lds(h->d), STEP_ARGS,
          STEP_TGT, h->d_sharedRT, (const double *)nullptr, (const double *)nullptr); }},

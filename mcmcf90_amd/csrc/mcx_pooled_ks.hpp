@@ -26,6 +26,7 @@
 //    67.3  the second piece's reloads in batches of twelve (an `unroll(disable)` loop had serialised twelve dependent round trips)
 //    65.3  all sixteen accumulators out at once (LDS + the other global half), ONE candidate pass
 //    59.2  that pass as two loops, one per address space (`k < 40 ? LDS : global` per access had compiled to sixteen flat loads)
+//    54.5  npar 49..52: the fourth output block's four rows through v_mfma_f64_4x4x4_4b_f64 (mfma_wave_part<S3>)
 // Measured and not kept: one generator call with per-access destinations (81.1), the second piece prefetched into registers before pass 1
 // (105 .. 118: no room beside sixteen accumulators), the second piece and v's restore by global_load_lds from rows parked in global
 // (60.5: the extra stores cost more than the two hidden round trips).
@@ -40,10 +41,18 @@ constexpr int PKS = 40;
 #define MCX_KS_CL 20          // the candidate pass' batch over the LDS rows (divides PKS) and over the global rows
 #define MCX_KS_CG 12
 #endif
+// S3 (npar 49..52: the fourth output block has FOUR rows): that block through v_mfma_f64_4x4x4_4b_f64 -- a quarter of the passes of a
+// 16 x 16 x 4.  Its operands sit where the large instruction's do (k = lane / 16 in A and B; tools/mfma4_probe.hip, profiles/r06_m): B
+// is the SAME register (chains 16 g + lane % 16), A the element of row 48 + lane % 4 instead of 48 + lane % 16, and D lane (lane / 16,
+// lane % 16) holds row 48 + lane / 16 of chain 16 g + lane % 16 -- component 0 of the large instruction's accumulator, which is all of
+// it that rows < 52 ever used.  The four products are added to C in ascending k, one fma each, like the large instruction's: the same
+// bits (77 configurations; 57.7 -> 54.5 ms per 100 iterations at config 4's size).
+template <bool S3>
 MCX_DEV void mfma_wave_part(const double *__restrict__ M, const double *X, int xoff, int lane, int d, int nb, int s_lo, int s_hi,
-                            mcx_d4 (&c)[4][4], bool TRI)
+                            mcx_d4 (&c)[4][4], double (&c3)[4], bool TRI)
 {
     const int li = lane & 15, lk = lane >> 4;
+    const double *__restrict__ ap4 = M + (size_t)lk * d + 48 + (li & 3);
     int kmax = s_hi;
     if (TRI) { const int last = 16 * nb; kmax = last < kmax ? last : kmax; }
     const double *__restrict__ ap = M + (size_t)lk * d + li;
@@ -55,7 +64,7 @@ MCX_DEV void mfma_wave_part(const double *__restrict__ M, const double *X, int x
         for (int u = 0; u < KU; ++u) {
             const int s = (s0 + 4 * u < kmax) ? s0 + 4 * u : kmax - 4;          // (a k-block past the end: loaded again, not multiplied)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) a[u][b] = ap[(size_t)s * d + 16 * (b < nb ? b : 0)];
+            for (int b = 0; b < 4; ++b) a[u][b] = (S3 && b == 3) ? ap4[(size_t)s * d] : ap[(size_t)s * d + 16 * (b < nb ? b : 0)];
         }
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
@@ -65,7 +74,12 @@ MCX_DEV void mfma_wave_part(const double *__restrict__ M, const double *X, int x
                 const double b0 = xq[0], b1 = xq[16], b2 = xq[32], b3 = xq[48];
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    if (b < nb && (!TRI || s < 16 * (b + 1))) {
+                    if (S3 && b == 3) {
+                        c3[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[u][3], b0, c3[0], 0, 0, 0);
+                        c3[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[u][3], b1, c3[1], 0, 0, 0);
+                        c3[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[u][3], b2, c3[2], 0, 0, 0);
+                        c3[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[u][3], b3, c3[3], 0, 0, 0);
+                    } else if (b < nb && (!TRI || s < 16 * (b + 1))) {
                         c[b][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][b], b0, c[b][0], 0, 0, 0);
                         c[b][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][b], b1, c[b][1], 0, 0, 0);
                         c[b][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][b], b2, c[b][2], 0, 0, 0);
@@ -77,6 +91,7 @@ MCX_DEV void mfma_wave_part(const double *__restrict__ M, const double *X, int x
     }
 }
 
+template <bool S3>
 __global__ __launch_bounds__(64, 2) void pooled_mfma_ks_kernel(EngineDev E, int it0, int it1, const double *__restrict__ g_mu,
                                                                 const double *__restrict__ g_lamT, const double *__restrict__ g_RT)
 {
@@ -91,11 +106,14 @@ __global__ __launch_bounds__(64, 2) void pooled_mfma_ks_kernel(EngineDev E, int 
     lane_load(E, tile, lane, L);
     uint32_t erstayed = TIDX(E.ictr, tile, NICTR, I_ERSTAYED, lane);
     mcx_d4 c[4][4];
+    double c3[4];                                                   // S3: the fourth block's accumulators (c[3] is never touched then)
     auto zero_c = [&]() {
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < (S3 ? 3 : 4); ++b)
 #pragma unroll
             for (int g = 0; g < 4; ++g) c[b][g] = mcx_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) c3[g] = 0.0;
     };
     // the sixteen accumulators leave at once, in (row, chain) order: rows < PKS into the LDS rows, rows PKS.. into the iteration's global
     // scratch
@@ -105,12 +123,13 @@ __global__ __launch_bounds__(64, 2) void pooled_mfma_ks_kernel(EngineDev E, int 
         for (int b = 0; b < 4; ++b)
             if (b < nt) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < ((S3 && b == 3) ? 1 : 4); ++r) {
                     const int row = 16 * b + lk + 4 * r;
                     // (rows d..d4-1 do not exist in the global vector; LDS rows are all < PKS < d)
                     if (row < d) {
                         double *o = ((16 * b + 4 * r < PKS) ? X : zg) + (size_t)row * 64 + li;
-                        o[0] = c[b][0][r]; o[16] = c[b][1][r]; o[32] = c[b][2][r]; o[48] = c[b][3][r];
+                        if (S3 && b == 3) { o[0] = c3[0]; o[16] = c3[1]; o[32] = c3[2]; o[48] = c3[3]; }
+                        else { o[0] = c[b][0][r]; o[16] = c[b][1][r]; o[32] = c[b][2][r]; o[48] = c[b][3][r]; }
                     }
                 }
             }
@@ -164,7 +183,7 @@ __global__ __launch_bounds__(64, 2) void pooled_mfma_ks_kernel(EngineDev E, int 
                     }
                 }
             }
-            mfma_wave_part(M, X, piece * PKS, lane, d, nt, piece * PKS, piece ? d4 : PKS, c, tr);
+            mfma_wave_part<S3>(M, X, piece * PKS, lane, d, nt, piece * PKS, piece ? d4 : PKS, c, c3, tr);
         }
     };
 #ifdef MCX_PHASE_PROF
@@ -199,8 +218,8 @@ __global__ __launch_bounds__(64, 2) void pooled_mfma_ks_kernel(EngineDev E, int 
             PHK(7)
             const int nlost = d4 - PKS;                                // rows 0..nlost-1 of v were overwritten by the second piece
             double qv[4][4];
-            // the chains of blocks 3, 2 first (their rows 40.. stand in LDS rows 0.., 32..39 in place); then v[0..nlost) comes back from the
-            // chain's global candidate into its rows, and blocks 1, 0 read theirs
+            // the chains of blocks 3, 2 first (their rows 40.. stand in LDS rows 0.., 32..39 in place); then v[0..nlost) comes back from
+            // the chain's global candidate into its rows, and blocks 1, 0 read theirs
             auto block_q = [&](int b) {
                 const int o0 = 16 * b + lk;
 #pragma unroll
@@ -210,9 +229,9 @@ __global__ __launch_bounds__(64, 2) void pooled_mfma_ks_kernel(EngineDev E, int 
                         const int oc = o < d4 ? o : 0;
                         return X[(size_t)((b >= 2 && oc >= PKS) ? oc - PKS : oc) * 64 + ch];
                     };
-                    double q = c[b][g][0] * vrow(o0);
+                    double q = ((S3 && b == 3) ? c3[g] : c[b][g][0]) * vrow(o0);
 #pragma unroll
-                    for (int r = 1; r < 4; ++r) {
+                    for (int r = 1; r < ((S3 && b == 3) ? 1 : 4); ++r) {
                         const int o = o0 + 4 * r;
                         const double t = dfma(c[b][g][r], vrow(o), q);
                         q = (o < d) ? t : q;

@@ -727,6 +727,7 @@ def test_pooled_delayed_rejection_and_er_match_restatement(oracle, name, extra, 
     ("am_41", 41, 130, dict(), "gauss"), ("am_45_s2", 45, 140, dict(updatesigma=1), "gauss"), ("banana_53", 53, 130, dict(), "banana"),
     ("svd_57", 57, 130, dict(condmax=1e8), "gauss"), ("burnin_up_60", 60, 130, dict(doburnin=1, burnintime=160, badaptint=50, scalelimit=0.3), "gauss"),
     ("er_63_s2_priors", 63, 130, dict(method="er", updatesigma=1), "gauss"), ("am_52_bounds_record", 52, 200, dict(), "gauss"),
+    ("am_51_s2_priors", 51, 130, dict(updatesigma=1), "gauss"),      # (49..52: the instantiation whose fourth output block is a 4 x 4 x 4 product)
 ])
 def test_pooled_two_waves_per_simd_matches_restatement(oracle, name, d, N, extra, kind, monkeypatch):
     """pooled_mfma_kernel<false, true> -- the instance behind bench.py's c4_pooled: 256 registers, two waves per SIMD, part of the state spilled

@@ -20,4 +20,8 @@ case "$1" in
      O=gpurun_out/r06k; mkdir -p $O
      POOLED_FUZZ_SECONDS=400 python tools/pooled_restate_fuzz.py 900000 930000 2>&1 | tee $O/pooled_restate_fuzz_ks.txt | tail -n 3
      POOLED_FUZZ_SECONDS=400 python tools/pooled_restate_fuzz.py 930000 960000 ram 2>&1 | tee $O/pooled_ram_restate_fuzz_ks.txt | tail -n 3 ;;
+  g) export MCMCX_POOLED_WAVES=2 MCMCX_POOLED_KS=1 POOLED_FUZZ_NPAR=49,50,51,52    # pooled_mfma_ks_kernel<true>: the fourth block through the 4 x 4 x 4 instruction
+     O=gpurun_out/r06m; mkdir -p $O
+     POOLED_FUZZ_SECONDS=200 python tools/pooled_restate_fuzz.py 960000 980000 2>&1 | tee $O/pooled_restate_fuzz_s3.txt | tail -n 3
+     POOLED_FUZZ_SECONDS=200 python tools/pooled_restate_fuzz.py 980000 999000 ram 2>&1 | tee $O/pooled_ram_restate_fuzz_s3.txt | tail -n 3 ;;
 esac
