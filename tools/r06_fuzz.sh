@@ -24,4 +24,8 @@ case "$1" in
      O=gpurun_out/r06m; mkdir -p $O
      POOLED_FUZZ_SECONDS=200 python tools/pooled_restate_fuzz.py 960000 980000 2>&1 | tee $O/pooled_restate_fuzz_s3.txt | tail -n 3
      POOLED_FUZZ_SECONDS=200 python tools/pooled_restate_fuzz.py 980000 999000 ram 2>&1 | tee $O/pooled_ram_restate_fuzz_s3.txt | tail -n 3 ;;
+  h) O=gpurun_out/r06n; mkdir -p $O                # the final build (tree64 in moments_kernel: every pooled tick), the engine's own kernel choices
+     POOLED_FUZZ_SECONDS=200 python tools/pooled_restate_fuzz.py 1100000 1120000 2>&1 | tee $O/pooled_restate_fuzz.txt | tail -n 3
+     POOLED_FUZZ_SECONDS=150 python tools/pooled_restate_fuzz.py 1120000 1140000 ram 2>&1 | tee $O/pooled_ram_restate_fuzz.txt | tail -n 3
+     POOLED_FUZZ_SECONDS=200 python tools/pooled_restate_fuzz.py 1140000 1160000 scam 2>&1 | tee $O/pooled_scam_restate_fuzz.txt | tail -n 3 ;;
 esac
