@@ -36,3 +36,15 @@ def test_stored_pmc_traffic_is_of_these_sources():
         assert e["kernels_sha"] == _sha(), "profiles/traffic.json[%s] was measured on other kernel sources: tools/profile_all.sh + tools/install_profiles.py" % key
         assert os.path.exists(os.path.join(ROOT, e["profile"])), e["profile"]
         assert e["hbm_bytes_per_proposal"] > 0 and e["valu_insts_per_proposal"] > 0, key
+
+
+def test_kernel_sources_stay_within_140_columns():
+    """tools/rewrap.py brought mcmcf90_amd/csrc to at most 140 columns (round 6); what is left are printf formats, inline asm / _Pragma lines and the
+    two-line banners of the host parts.  No new long lines."""
+    import glob
+    long_lines = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "mcmcf90_amd", "csrc", "*.h*"))):
+        for n, line in enumerate(open(f).read().split("\n"), 1):
+            if len(line) > 140:
+                long_lines.append("%s:%d (%d)" % (os.path.basename(f), n, len(line)))
+    assert len(long_lines) <= 21, long_lines
